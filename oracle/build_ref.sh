@@ -1,0 +1,73 @@
+#!/usr/bin/env bash
+# Build the REFERENCE's own CPU programs (compute-fbank-feats, compute-mfcc-feats, apply-cmvn,
+# compute-cmvn-stats, nnet3-init, nnet3-info, nnet3-compute, nnet3-copy) straight from the sources
+# where they lie under /root/reference/src, into oracle/_ref/ (git-ignored, travels to the GPU box).
+#
+# TEST INFRASTRUCTURE ONLY: these binaries pin the restated oracle (oracle/*.c, oracle/*.py) and
+# may serve as the "reference" CPU baseline in bench.py.  Nothing in kaldi_amd/ may call them.
+#
+# No reference source is copied: we compile in place with g++ (the reference's own build system --
+# configure + per-dir Makefiles + OpenFst -- is not run).  Two generated headers stand in for
+# pieces the reference's build would generate/download:
+#   base/version.h   (normally written by base/get_version.sh)
+#   fst/fst-decl.h   (OpenFst forward declarations only; hmm/transition-model.h:26 includes it)
+# The decoder (src/decoder, src/lat, src/fstext) needs real OpenFst 1.8.4 which is absent
+# => unbuildable here; see oracle/lattice_faster_oracle.cc for the restatement.
+set -euo pipefail
+REF=${KALDI_REFERENCE:-/root/reference}
+R=$REF/src
+HERE=$(cd "$(dirname "$0")" && pwd)
+W=$HERE/_ref
+if [ ! -d "$R" ]; then echo "build_ref: $R absent (GPU box?) - using prebuilt files in $W"; exit 0; fi
+mkdir -p $W/inc/base $W/stub/fst $W/obj $W/mkl $W/bin
+printf '#define KALDI_VERSION "5.5-oracle"\n#define KALDI_GIT_HEAD "oracle"\n' > $W/inc/base/version.h
+cat > $W/stub/fst/fst-decl.h <<'EOS'
+#ifndef ORACLE_FST_DECL_STUB_H_
+#define ORACLE_FST_DECL_STUB_H_
+namespace fst {
+template <class A> class Fst; template <class A> class VectorFst;
+template <class W> class ArcTpl; template <class T> class TropicalWeightTpl;
+using StdArc = ArcTpl<TropicalWeightTpl<float>>;
+using StdFst = Fst<StdArc>; using StdVectorFst = VectorFst<StdArc>;
+}
+#endif
+EOS
+MKL=/opt/conda/lib/libmkl_rt.so
+FLAGS="-std=c++17 -O2 -DNDEBUG -w -I $W/inc -I $W/stub -I $R -I $REF/tools/CLAPACK -DHAVE_CLAPACK -DOPENFST_VER=10804 -DHAVE_EXECINFO_H=1 -DHAVE_CXXABI_H -DHAVE_CUDA=0 -pthread"
+
+list_sources() {
+  for d in base matrix util feat cudamatrix tree itf; do
+    ls $R/$d/*.cc 2>/dev/null | grep -v -e '-test\.cc$' -e 'tree/tree-renderer\.cc' || true
+  done
+  echo $R/transform/cmvn.cc
+  echo $R/hmm/transition-model.cc; echo $R/hmm/hmm-topology.cc
+  ls $R/nnet3/*.cc | grep -v -e '-test\.cc$' -e 'nnet-example' -e 'nnet-chain-' -e 'nnet-discriminative-' \
+      -e 'discriminative-' -e 'nnet-batch-compute\.cc'
+}
+compile_one() {
+  src=$1; o=$W/obj/$(basename $(dirname $src))_$(basename ${src%.cc}).o
+  if [ ! -f $o ] || [ $src -nt $o ]; then g++ $FLAGS -c $src -o $o || { echo "FAILED $src"; exit 1; }; fi
+}
+export -f compile_one; export W FLAGS
+list_sources | xargs -P ${JOBS:-8} -I{} bash -c 'compile_one {}'
+rm -f $W/libref.a; ar rcs $W/libref.a $W/obj/*.o
+link() { # name src
+  g++ $FLAGS $2 $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/$1
+}
+link compute-fbank-feats $R/featbin/compute-fbank-feats.cc
+link compute-mfcc-feats  $R/featbin/compute-mfcc-feats.cc
+link apply-cmvn          $R/featbin/apply-cmvn.cc
+link compute-cmvn-stats  $R/featbin/compute-cmvn-stats.cc
+link copy-feats          $R/featbin/copy-feats.cc
+link nnet3-init          $R/nnet3bin/nnet3-init.cc
+link nnet3-info          $R/nnet3bin/nnet3-info.cc
+link nnet3-compute       $R/nnet3bin/nnet3-compute.cc
+link nnet3-copy          $R/nnet3bin/nnet3-copy.cc
+for f in /opt/conda/lib/libmkl_{rt,core,intel_lp64,sequential,gnu_thread,intel_thread,avx2,avx512,def,mc3,vml_avx2,vml_avx512,vml_def}.so.1; do
+  [ -e $f ] && ln -sf $f $W/mkl/ || true; done
+cat > $W/env.sh <<EOS
+export LD_LIBRARY_PATH=$W/mkl\${LD_LIBRARY_PATH:+:\$LD_LIBRARY_PATH}
+export MKL_THREADING_LAYER=SEQUENTIAL
+export PATH=$W/bin:\$PATH
+EOS
+echo "build_ref: ok -> $W/bin"

@@ -1,0 +1,296 @@
+/*
+ * oracle/feat_oracle.c  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, float32 arithmetic like the reference's BaseFloat) of the Kaldi
+ * fbank / MFCC / CMVN feature path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this file's shared object; kaldi_amd/ never does.
+ *
+ * Pinned against (tests/test_oracle_feat.py):
+ *   - the reference's own HTK golden vectors src/feat/test_data/test.wav.fbank_htk.{1..4} and
+ *     test.wav.fea_htk.{1..6} with the tolerances of feat/feature-fbank-test.cc / feature-mfcc-test.cc
+ *   - outputs of the reference binaries compute-fbank-feats / compute-mfcc-feats / apply-cmvn built
+ *     from /root/reference by oracle/build_ref.sh (fixtures in tests/golden/, generator committed).
+ *
+ * Each function cites the reference file:line it restates (paths relative to /root/reference/src).
+ * The one deliberate deviation: the complex FFT of length N/2 is an iterative radix-2 Cooley-Tukey
+ * in float32 instead of the reference's split-radix butterflies (matrix/srfft.cc:211-352); both are
+ * exact DFTs up to float32 round-off (measured max |delta log-mel| vs the reference binary ~2e-6).
+ * The real-FFT unpacking step and the packed output layout follow srfft.cc:356-432 literally.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#ifndef M_PI
+#define M_PI 3.1415926535897932384626433832795
+#endif
+#define M_2PI 6.283185307179586476925286766559005
+
+typedef struct {
+  /* FrameExtractionOptions, feat/feature-window.h:35-67 */
+  float samp_freq, frame_shift_ms, frame_length_ms, dither, preemph_coeff, blackman_coeff;
+  int32_t remove_dc_offset, round_to_power_of_two, snip_edges;
+  int32_t window_type; /* 0 hanning 1 sine 2 hamming 3 povey 4 rectangular 5 blackman */
+  /* MelBanksOptions, feat/mel-computations.h:43-60 */
+  int32_t num_bins;
+  float low_freq, high_freq, vtln_low, vtln_high;
+  int32_t htk_mode;
+  /* FbankOptions feat/feature-fbank.h:44-61 / MfccOptions feat/feature-mfcc.h:40-60 */
+  int32_t use_energy;
+  float energy_floor;
+  int32_t raw_energy, htk_compat, use_log_fbank, use_power;
+  int32_t num_ceps;
+  float cepstral_lifter;
+  int32_t feature_type; /* 0 fbank, 1 mfcc */
+  float vtln_warp;      /* argument of Compute(wave, vtln_warp, ...); 1.0 = none */
+} k3o_feat_opts;
+
+/* feat/feature-window.h:106-115 */
+static int32_t window_shift(const k3o_feat_opts *o) { return (int32_t)(o->samp_freq * 0.001 * o->frame_shift_ms); }
+static int32_t window_size(const k3o_feat_opts *o) { return (int32_t)(o->samp_freq * 0.001 * o->frame_length_ms); }
+static int32_t padded_window_size(const k3o_feat_opts *o) {
+  int32_t w = window_size(o);
+  if (!o->round_to_power_of_two) return w;
+  int32_t n = 1; while (n < w) n <<= 1; return n;
+}
+
+/* feat/feature-window.cc:28-38 */
+static int64_t first_sample_of_frame(int32_t frame, const k3o_feat_opts *o) {
+  int64_t shift = window_shift(o);
+  if (o->snip_edges) return frame * shift;
+  int64_t mid = shift * frame + shift / 2;
+  return mid - window_size(o) / 2;
+}
+
+/* feat/feature-window.cc:40-87 (flush = true, the offline case) */
+int32_t k3o_num_frames(int64_t num_samples, const k3o_feat_opts *o) {
+  int64_t shift = window_shift(o), len = window_size(o);
+  if (o->snip_edges) {
+    if (num_samples < len) return 0;
+    return (int32_t)(1 + ((num_samples - len) / shift));
+  }
+  return (int32_t)((num_samples + (shift / 2)) / shift);
+}
+
+int32_t k3o_feat_dim(const k3o_feat_opts *o) {
+  if (o->feature_type == 1) return o->num_ceps;                 /* feature-mfcc.h Dim() */
+  return o->num_bins + (o->use_energy ? 1 : 0);                  /* feature-fbank.h Dim() */
+}
+
+/* feat/feature-window.cc:109-135 */
+static void make_window(const k3o_feat_opts *o, float *w) {
+  int32_t L = window_size(o);
+  double a = M_2PI / (L - 1);
+  for (int32_t i = 0; i < L; i++) {
+    double x = (double)i;
+    switch (o->window_type) {
+      case 0: w[i] = (float)(0.5 - 0.5 * cos(a * x)); break;
+      case 1: w[i] = (float)(sin(0.5 * a * x)); break;
+      case 2: w[i] = (float)(0.54 - 0.46 * cos(a * x)); break;
+      case 3: w[i] = (float)(pow(0.5 - 0.5 * cos(a * x), 0.85)); break;
+      case 4: w[i] = 1.0f; break;
+      default: w[i] = (float)(o->blackman_coeff - 0.5 * cos(a * x) + (0.5 - o->blackman_coeff) * cos(2 * a * x));
+    }
+  }
+}
+
+/* feat/mel-computations.h:81-87 */
+static float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
+
+static float inv_mel_scale(float m) { return 700.0f * (expf(m / 1127.0f) - 1.0f); }
+
+/* feat/mel-computations.cc:150-210 VtlnWarpFreq, :212-222 VtlnWarpMelFreq */
+static float vtln_warp_freq(float vlow, float vhigh, float low, float high, float warp, float freq) {
+  if (freq < low || freq > high) return freq;
+  float one = 1.0f;
+  float l = vlow * (one > warp ? one : warp), h = vhigh * (one < warp ? one : warp);
+  float scale = 1.0f / warp, Fl = scale * l, Fh = scale * h;
+  float scale_left = (Fl - low) / (l - low), scale_right = (high - Fh) / (high - h);
+  if (freq < l) return low + scale_left * (freq - low);
+  else if (freq < h) return scale * freq;
+  else return high + scale_right * (freq - high);
+}
+static float vtln_warp_mel(float vlow, float vhigh, float low, float high, float warp, float mel) {
+  return mel_scale(vtln_warp_freq(vlow, vhigh, low, high, warp, inv_mel_scale(mel)));
+}
+
+typedef struct { int32_t offset, len; float *w; } melbin;
+
+/* feat/mel-computations.cc:33-142 */
+static melbin *make_mel_banks(const k3o_feat_opts *o) {
+  int32_t nb = o->num_bins, npad = padded_window_size(o), nfft = npad / 2;
+  float nyq = 0.5f * o->samp_freq, low = o->low_freq;
+  float high = (o->high_freq > 0.0f) ? o->high_freq : nyq + o->high_freq;
+  float bin_w = o->samp_freq / npad;
+  float mlow = mel_scale(low), mhigh = mel_scale(high);
+  float delta = (mhigh - mlow) / (nb + 1);
+  float vlow = o->vtln_low, vhigh = o->vtln_high; if (vhigh < 0.0f) vhigh += nyq;
+  melbin *b = (melbin *)calloc(nb, sizeof(melbin));
+  float *tmp = (float *)malloc(sizeof(float) * nfft);
+  for (int32_t bin = 0; bin < nb; bin++) {
+    float left = mlow + bin * delta, center = mlow + (bin + 1) * delta, right = mlow + (bin + 2) * delta;
+    if (o->vtln_warp != 1.0f) {
+      left = vtln_warp_mel(vlow, vhigh, low, high, o->vtln_warp, left);
+      center = vtln_warp_mel(vlow, vhigh, low, high, o->vtln_warp, center);
+      right = vtln_warp_mel(vlow, vhigh, low, high, o->vtln_warp, right);
+    }
+    int32_t first = -1, last = -1;
+    memset(tmp, 0, sizeof(float) * nfft);
+    for (int32_t i = 0; i < nfft; i++) {
+      float freq = bin_w * i, mel = mel_scale(freq);
+      if (mel > left && mel < right) {
+        float wt = (mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center);
+        tmp[i] = wt;
+        if (first == -1) first = i;
+        last = i;
+      }
+    }
+    b[bin].offset = first; b[bin].len = last + 1 - first;
+    b[bin].w = (float *)malloc(sizeof(float) * b[bin].len);
+    memcpy(b[bin].w, tmp + first, sizeof(float) * b[bin].len);
+    if (o->htk_mode && bin == 0 && mlow != 0.0f) b[bin].w[0] = 0.0f;
+  }
+  free(tmp);
+  return b;
+}
+
+/* complex FFT of length n (power of two), interleaved re/im, forward (exp(-i...)).  See header. */
+static void complex_fft(float *d, int32_t n, const float *tw /* n/2 (cos,-sin) pairs */) {
+  for (int32_t i = 1, j = 0; i < n; i++) {
+    int32_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { float tr = d[2*i], ti = d[2*i+1]; d[2*i] = d[2*j]; d[2*i+1] = d[2*j+1]; d[2*j] = tr; d[2*j+1] = ti; }
+  }
+  for (int32_t len = 2; len <= n; len <<= 1) {
+    int32_t half = len >> 1, step = n / len;
+    for (int32_t i = 0; i < n; i += len)
+      for (int32_t k = 0; k < half; k++) {
+        float wr = tw[2*(k*step)], wi = tw[2*(k*step)+1];
+        float *a = d + 2*(i+k), *b = d + 2*(i+k+half);
+        float xr = b[0]*wr - b[1]*wi, xi = b[0]*wi + b[1]*wr;
+        b[0] = a[0] - xr; b[1] = a[1] - xi; a[0] += xr; a[1] += xi;
+      }
+  }
+}
+
+/* matrix/srfft.cc:356-432, forward branch: in-place real FFT of N floats; output packed
+ * [re0, re(N/2), re1, im1, re2, im2, ...]. */
+static void real_fft(float *data, int32_t N, const float *tw) {
+  int32_t N2 = N / 2;
+  complex_fft(data, N2, tw);
+  float rootN_re = (float)cos(-M_2PI / N), rootN_im = (float)sin(-M_2PI / N);
+  /* ComplexImExp(static_cast<Real>(M_2PI/N * forward_sign)) evaluates cos/sin of a float arg */
+  { float ang = (float)(M_2PI / N * -1); rootN_re = cosf(ang); rootN_im = sinf(ang); }
+  float kN_re = 1.0f, kN_im = 0.0f;
+  for (int32_t k = 1; 2 * k <= N2; k++) {
+    { float t = kN_re * rootN_re - kN_im * rootN_im; kN_im = kN_re * rootN_im + kN_im * rootN_re; kN_re = t; }
+    float Ck_re = 0.5f * (data[2*k] + data[N - 2*k]);
+    float Ck_im = 0.5f * (data[2*k+1] - data[N - 2*k + 1]);
+    float Dk_re = 0.5f * (data[2*k+1] + data[N - 2*k + 1]);
+    float Dk_im = -0.5f * (data[2*k] - data[N - 2*k]);
+    data[2*k] = Ck_re + (Dk_re * kN_re - Dk_im * kN_im);
+    data[2*k+1] = Ck_im + (Dk_re * kN_im + Dk_im * kN_re);
+    int32_t kd = N2 - k;
+    if (kd != k) {
+      /* D_k' = conj(D_k), twiddle = (-kN_re, kN_im) */
+      data[2*kd] = Ck_re + (Dk_re * -kN_re - (-Dk_im) * kN_im);
+      data[2*kd+1] = -Ck_im + (Dk_re * kN_im + (-Dk_im) * -kN_re);
+    }
+  }
+  float z = data[0] + data[1], n2 = data[0] - data[1];
+  data[0] = z; data[1] = n2;
+}
+
+static float dotf(const float *a, const float *b, int32_t n) { float s = 0.0f; for (int32_t i = 0; i < n; i++) s += a[i] * b[i]; return s; }
+
+/*
+ * Whole-utterance feature extraction: feat/feature-common-inl.h:59-83 (frame loop) calling
+ * ExtractWindow (feature-window.cc:166-224), ProcessWindow (:137-160) and FbankComputer::Compute
+ * (feature-fbank.cc:72-123) / MfccComputer::Compute (feature-mfcc.cc:28-80).  dither must be 0
+ * (RandGauss is unreproducible).  out: [num_frames x dim] row-major.  Returns frames.
+ */
+int32_t k3o_compute_features(const k3o_feat_opts *o, const float *wave, int64_t nsamp, float *out) {
+  int32_t L = window_size(o), N = padded_window_size(o), T = k3o_num_frames(nsamp, o);
+  int32_t nb = o->num_bins, dim = k3o_feat_dim(o);
+  if (T <= 0) return 0;
+  if (N & (N - 1)) return -1; /* oracle covers the srfft (power of two) branch only */
+  float *win = (float *)malloc(sizeof(float) * L); make_window(o, win);
+  melbin *banks = make_mel_banks(o);
+  float *tw = (float *)malloc(sizeof(float) * N);
+  for (int32_t k = 0; k < N / 4; k++) { double a = -M_2PI * k / (N / 2); tw[2*k] = (float)cos(a); tw[2*k+1] = (float)sin(a); }
+  float *frame = (float *)malloc(sizeof(float) * N);
+  float *mel = (float *)malloc(sizeof(float) * nb);
+  /* MFCC tables: matrix/matrix-functions.cc:592-608, mel-computations.cc:253-259 */
+  float *dct = NULL, *lifter = NULL;
+  if (o->feature_type == 1) {
+    dct = (float *)malloc(sizeof(float) * o->num_ceps * nb);
+    float norm0 = sqrtf(1.0f / (float)nb), norm = sqrtf(2.0f / (float)nb);
+    for (int32_t j = 0; j < nb; j++) dct[j] = norm0;
+    for (int32_t k = 1; k < o->num_ceps; k++)
+      for (int32_t n = 0; n < nb; n++) dct[k * nb + n] = (float)(norm * cos((double)M_PI / nb * (n + 0.5) * k));
+    lifter = (float *)malloc(sizeof(float) * o->num_ceps);
+    for (int32_t i = 0; i < o->num_ceps; i++) lifter[i] = (float)(1.0 + 0.5 * o->cepstral_lifter * sin(M_PI * i / o->cepstral_lifter));
+  }
+  float log_energy_floor = (o->energy_floor > 0.0f) ? logf(o->energy_floor) : 0.0f;
+  for (int32_t f = 0; f < T; f++) {
+    int64_t start = first_sample_of_frame(f, o);
+    /* ExtractWindow: copy or reflect (feature-window.cc:195-214) */
+    for (int32_t s = 0; s < L; s++) {
+      int64_t si = s + start;
+      while (si < 0 || si >= nsamp) { if (si < 0) si = -si - 1; else si = 2 * nsamp - 1 - si; }
+      frame[s] = wave[si];
+    }
+    for (int32_t s = L; s < N; s++) frame[s] = 0.0f;
+    /* ProcessWindow */
+    if (o->remove_dc_offset) { float sum = 0.0f; for (int32_t s = 0; s < L; s++) sum += frame[s]; float m = -sum / L; for (int32_t s = 0; s < L; s++) frame[s] += m; }
+    float raw_log_energy = 0.0f;
+    if (o->use_energy && o->raw_energy) { float e = dotf(frame, frame, L); if (e < FLT_EPSILON) e = FLT_EPSILON; raw_log_energy = logf(e); }
+    if (o->preemph_coeff != 0.0f) { for (int32_t i = L - 1; i > 0; i--) frame[i] -= o->preemph_coeff * frame[i-1]; frame[0] -= o->preemph_coeff * frame[0]; }
+    for (int32_t s = 0; s < L; s++) frame[s] *= win[s];
+    if (o->use_energy && !o->raw_energy) { float e = dotf(frame, frame, N); if (e < FLT_EPSILON) e = FLT_EPSILON; raw_log_energy = logf(e); }
+    real_fft(frame, N, tw);
+    /* ComputePowerSpectrum feat/feature-functions.cc:30-52 */
+    { int32_t h = N / 2; float fe = frame[0] * frame[0], le = frame[1] * frame[1];
+      for (int32_t i = 1; i < h; i++) { float re = frame[2*i], im = frame[2*i+1]; frame[i] = re*re + im*im; }
+      frame[0] = fe; frame[h] = le; }
+    if (o->feature_type == 0 && !o->use_power) for (int32_t i = 0; i <= N / 2; i++) frame[i] = powf(frame[i], 0.5f);
+    /* MelBanks::Compute mel-computations.cc:226-251 */
+    for (int32_t b = 0; b < nb; b++) { float e = dotf(banks[b].w, frame + banks[b].offset, banks[b].len); if (o->htk_mode && e < 1.0f) e = 1.0f; mel[b] = e; }
+    float *row = out + (int64_t)f * dim;
+    if (o->feature_type == 0) {
+      int32_t off = (o->use_energy && !o->htk_compat) ? 1 : 0;
+      for (int32_t b = 0; b < nb; b++) { float e = mel[b]; if (o->use_log_fbank) { if (e < FLT_EPSILON) e = FLT_EPSILON; e = logf(e); } row[off + b] = e; }
+      if (o->use_energy) { if (o->energy_floor > 0.0f && raw_log_energy < log_energy_floor) raw_log_energy = log_energy_floor; row[o->htk_compat ? nb : 0] = raw_log_energy; }
+    } else {
+      for (int32_t b = 0; b < nb; b++) { float e = mel[b]; if (e < FLT_EPSILON) e = FLT_EPSILON; mel[b] = logf(e); }
+      for (int32_t c = 0; c < o->num_ceps; c++) row[c] = dotf(dct + c * nb, mel, nb);
+      if (o->cepstral_lifter != 0.0f) for (int32_t c = 0; c < o->num_ceps; c++) row[c] *= lifter[c];
+      if (o->use_energy) { if (o->energy_floor > 0.0f && raw_log_energy < log_energy_floor) raw_log_energy = log_energy_floor; row[0] = raw_log_energy; }
+      if (o->htk_compat) { float e = row[0]; for (int32_t i = 0; i < o->num_ceps - 1; i++) row[i] = row[i+1]; if (!o->use_energy) e *= (float)M_SQRT2; row[o->num_ceps - 1] = e; }
+    }
+  }
+  for (int32_t b = 0; b < nb; b++) free(banks[b].w);
+  free(banks); free(win); free(tw); free(frame); free(mel); free(dct); free(lifter);
+  return T;
+}
+
+/* transform/cmvn.cc:30-62 AccCmvnStats (double accumulators) then :64-115 ApplyCmvn, per utterance
+ * (what `compute-cmvn-stats | apply-cmvn` do for a one-utterance speaker).  In place. */
+int32_t k3o_cmvn_offline(float *feats, int32_t T, int32_t dim, int32_t norm_vars) {
+  if (T < 1) return -1;
+  double *mean = (double *)calloc(dim, sizeof(double)), *var = (double *)calloc(dim, sizeof(double));
+  for (int32_t t = 0; t < T; t++) for (int32_t d = 0; d < dim; d++) { float x = feats[(int64_t)t*dim+d]; mean[d] += x * 1.0f; var[d] += x * x * 1.0f; }
+  double count = T;
+  for (int32_t d = 0; d < dim; d++) {
+    if (!norm_vars) { /* Vector<float>::AddVec(float alpha, Vector<double>) kaldi-vector.cc:1044-1052 */
+      float alpha = (float)(-1.0 / count); float off = (float)(0.0f + alpha * mean[d]);
+      for (int32_t t = 0; t < T; t++) feats[(int64_t)t*dim+d] += off; }
+    else { double m = mean[d] / count, v = var[d] / count - m * m; if (v < 1.0e-20) v = 1.0e-20; double sc = 1.0 / sqrt(v); float fo = (float)(-(m * sc)), fs = (float)sc;
+      for (int32_t t = 0; t < T; t++) { float x = feats[(int64_t)t*dim+d]; x *= fs; x += fo; feats[(int64_t)t*dim+d] = x; } }
+  }
+  free(mean); free(var);
+  return 0;
+}

@@ -1,0 +1,61 @@
+"""ctypes front-end of oracle/feat_oracle.c (TEST INFRASTRUCTURE; see that file's header)."""
+import ctypes, os, numpy as np
+from . import build as _build
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+WINDOW_TYPES = {"hanning": 0, "sine": 1, "hamming": 2, "povey": 3, "rectangular": 4, "blackman": 5}
+
+class FeatOpts(ctypes.Structure):
+    """Field order == k3o_feat_opts == k3_feat_opts (include/k3hip.h)."""
+    _fields_ = [("samp_freq", ctypes.c_float), ("frame_shift_ms", ctypes.c_float), ("frame_length_ms", ctypes.c_float),
+                ("dither", ctypes.c_float), ("preemph_coeff", ctypes.c_float), ("blackman_coeff", ctypes.c_float),
+                ("remove_dc_offset", ctypes.c_int32), ("round_to_power_of_two", ctypes.c_int32), ("snip_edges", ctypes.c_int32),
+                ("window_type", ctypes.c_int32), ("num_bins", ctypes.c_int32),
+                ("low_freq", ctypes.c_float), ("high_freq", ctypes.c_float), ("vtln_low", ctypes.c_float), ("vtln_high", ctypes.c_float),
+                ("htk_mode", ctypes.c_int32), ("use_energy", ctypes.c_int32), ("energy_floor", ctypes.c_float),
+                ("raw_energy", ctypes.c_int32), ("htk_compat", ctypes.c_int32), ("use_log_fbank", ctypes.c_int32), ("use_power", ctypes.c_int32),
+                ("num_ceps", ctypes.c_int32), ("cepstral_lifter", ctypes.c_float), ("feature_type", ctypes.c_int32), ("vtln_warp", ctypes.c_float)]
+
+def fbank_opts(**kw):
+    """FbankOptions defaults: feat/feature-fbank.h:44-61, feature-window.h:53-66, mel-computations.h:56-58."""
+    o = FeatOpts(16000.0, 10.0, 25.0, 1.0, 0.97, 0.42, 1, 1, 1, 3, 23, 20.0, 0.0, 100.0, -500.0, 0, 0, 0.0, 1, 0, 1, 1, 13, 22.0, 0, 1.0)
+    for k, v in kw.items():
+        setattr(o, k, WINDOW_TYPES[v] if k == "window_type" and isinstance(v, str) else v)
+    return o
+
+def mfcc_opts(**kw):
+    """MfccOptions defaults: feat/feature-mfcc.h:40-60."""
+    o = fbank_opts(use_energy=1, feature_type=1)
+    for k, v in kw.items():
+        setattr(o, k, WINDOW_TYPES[v] if k == "window_type" and isinstance(v, str) else v)
+    return o
+
+_lib = None
+def lib():
+    global _lib
+    if _lib is None:
+        _build.build(with_ref=False)
+        _lib = ctypes.CDLL(os.path.join(HERE, "libk3oracle_feat.so"))
+        _lib.k3o_num_frames.restype = ctypes.c_int32
+        _lib.k3o_num_frames.argtypes = [ctypes.c_int64, ctypes.POINTER(FeatOpts)]
+        _lib.k3o_feat_dim.argtypes = [ctypes.POINTER(FeatOpts)]
+        _lib.k3o_compute_features.argtypes = [ctypes.POINTER(FeatOpts), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        _lib.k3o_cmvn_offline.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    return _lib
+
+def num_frames(nsamp, opts):
+    return lib().k3o_num_frames(int(nsamp), ctypes.byref(opts))
+
+def compute_features(wave, opts):
+    wave = np.ascontiguousarray(wave, dtype=np.float32)
+    T = num_frames(len(wave), opts); dim = lib().k3o_feat_dim(ctypes.byref(opts))
+    out = np.zeros((max(T, 0), dim), dtype=np.float32)
+    if T > 0:
+        r = lib().k3o_compute_features(ctypes.byref(opts), wave.ctypes.data, len(wave), out.ctypes.data)
+        assert r == T, r
+    return out
+
+def cmvn_offline(feats, norm_vars=False):
+    f = np.array(feats, dtype=np.float32, order='C', copy=True)
+    r = lib().k3o_cmvn_offline(f.ctypes.data, f.shape[0], f.shape[1], int(norm_vars)); assert r == 0
+    return f
