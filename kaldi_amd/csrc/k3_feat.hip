@@ -1,0 +1,571 @@
+// k3_feat.hip -- batched fbank / MFCC / CMVN for gfx950 (MI355X), hand-written HIP.
+//
+// One fused kernel per batch: window extraction (copy/reflect, zero-pad) -> DC removal ->
+// raw log-energy -> pre-emphasis -> window multiply -> 512-point real FFT -> power spectrum ->
+// mel filterbank -> floor/log [-> DCT -> lifter] -> store.  Nothing but the waveform is read from
+// HBM and nothing but the feature rows is written: algorithmic traffic = 160 new samples * 4 B in
+// + dim * 4 B out per frame (HBM-bound stage, intensity ~20-30 flop/B).
+//
+// CDNA4 mapping (wave64): a wavefront processes 4 frames at once, 16 lanes per frame.  The 512-point
+// real FFT is a 256-point complex FFT of z[n] = x[2n] + i x[2n+1] (the packing the reference's
+// SplitRadixRealFft uses, matrix/srfft.cc:356-432) factored 16 x 16: each lane does a radix-16 FFT in
+// registers, the 16x16 transpose between the two passes goes through a padded (stride 17) LDS tile
+// (conflict-free ds_write_b64 / ds_read_b64), then the real-FFT unpacking + |.|^2 produce the 257
+// power bins in LDS and the sparse mel dot-products run 16 bins at a time.  All tables (window, twiddles,
+// mel weights, DCT) are staged in LDS once per workgroup, which then loops over 64 frames.
+//
+// Reference semantics restated (paths relative to the reference's src/):
+//   ExtractWindow feat/feature-window.cc:166-224, ProcessWindow :137-160, Preemphasize :101-107,
+//   FeatureWindowFunction :109-135, ComputePowerSpectrum feat/feature-functions.cc:30-52,
+//   MelBanks feat/mel-computations.cc:33-142,226-251, FbankComputer::Compute feat/feature-fbank.cc:72-123,
+//   MfccComputer::Compute feat/feature-mfcc.cc:28-80, ComputeDctMatrix matrix/matrix-functions.cc:592-608,
+//   ComputeLifterCoeffs feat/mel-computations.cc:253-259, AccCmvnStats/ApplyCmvn transform/cmvn.cc:30-115.
+// The FFT butterfly order differs from split-radix (round-off level only; parity bound 1e-4 on log-mel).
+#include "k3_common.h"
+#include <cmath>
+#include <cfloat>
+#include <vector>
+#include <cstring>
+
+namespace {
+
+constexpr int kNfft = 512;            // padded window size supported by this kernel
+constexpr int kNc = 256;              // complex FFT length
+constexpr int kFramesPerIter = 16;    // 4 waves x 4 frames
+constexpr int kThreads = 256;
+constexpr int kTpad = 17;             // transpose tile row stride (float2 units)
+constexpr int kFrameBufBytes = 16 * kTpad * 8;  // 2176 B per frame: transpose tile / X / (P | logmel)
+constexpr int kLogMelOff = 1040;      // byte offset of the log-mel vector inside the frame buffer
+
+struct FeatParams {
+  int win_len, win_shift, snip_edges, remove_dc, use_energy, raw_energy, htk_compat, use_log, use_power,
+      htk_mode, feature_type, num_bins, num_ceps, dim, has_energy_floor, has_lifter, total_w;
+  float preemph, log_energy_floor;
+  const float *window;      // [win_len]
+  const float2 *tw256;      // [256] exp(-2 pi i m / 256)
+  const float2 *tw512;      // [129] exp(-2 pi i k / 512), k = 0..128, built by the reference's recurrence
+  const int *bin_meta;      // [3 * num_bins]: first fft bin, length, offset into bin_w
+  const float *bin_w;       // [total_w]
+  const float *dct;         // [num_ceps x num_bins] (mfcc)
+  const float *lifter;      // [num_ceps] (mfcc)
+};
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// forward 4-point DFT in place: (a,b,c,d) -> (X0,X1,X2,X3)
+__device__ __forceinline__ void fft4(float2 &a, float2 &b, float2 &c, float2 &d) {
+  float2 s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+  a = cadd(s0, s2);
+  c = csub(s0, s2);
+  b = make_float2(s1.x + s3.y, s1.y - s3.x);   // s1 - i s3
+  d = make_float2(s1.x - s3.y, s1.y + s3.x);   // s1 + i s3
+}
+
+// forward 16-point DFT in registers; on return X[k] sits at v[4*(k&3) + (k>>2)]
+__device__ __forceinline__ void fft16(float2 (&v)[16]) {
+  constexpr float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f, r2 = 0.70710678118654752440f;
+#pragma unroll
+  for (int n2 = 0; n2 < 4; n2++) fft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+  // v[4*k1 + n2] *= exp(-2 pi i n2 k1 / 16)
+  v[5] = cmul(v[5], make_float2(c1, -s1));      // m = 1
+  v[6] = cmul(v[6], make_float2(r2, -r2));      // m = 2
+  v[7] = cmul(v[7], make_float2(s1, -c1));      // m = 3
+  v[9] = cmul(v[9], make_float2(r2, -r2));      // m = 2
+  v[10] = make_float2(v[10].y, -v[10].x);       // m = 4: * (-i)
+  v[11] = cmul(v[11], make_float2(-r2, -r2));   // m = 6
+  v[13] = cmul(v[13], make_float2(s1, -c1));    // m = 3
+  v[14] = cmul(v[14], make_float2(-r2, -r2));   // m = 6
+  v[15] = cmul(v[15], make_float2(-c1, s1));    // m = 9
+#pragma unroll
+  for (int k1 = 0; k1 < 4; k1++) fft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+__host__ __device__ constexpr int fft16_slot(int k) { return 4 * (k & 3) + (k >> 2); }
+
+__device__ __forceinline__ float group_sum16(float x) {
+  x += __shfl_xor(x, 8, 16); x += __shfl_xor(x, 4, 16); x += __shfl_xor(x, 2, 16); x += __shfl_xor(x, 1, 16);
+  return x;
+}
+
+__global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const float *__restrict__ waves,
+                                                          const int64_t *__restrict__ wave_off,
+                                                          const int64_t *__restrict__ frame_off, int num_utts,
+                                                          int64_t total_frames, float *__restrict__ feats, int64_t ld,
+                                                          int frames_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS carve (all offsets multiples of 16)
+  float2 *s_tw256 = reinterpret_cast<float2 *>(smem);                 // 2048 B
+  float2 *s_tw512 = reinterpret_cast<float2 *>(smem + 2048);          // 129*8 = 1032 -> 1040 B
+  float *s_window = reinterpret_cast<float *>(smem + 2048 + 1040);    // 512*4 = 2048 B
+  int *s_meta = reinterpret_cast<int *>(smem + 2048 + 1040 + 2048);   // 3*num_bins ints, padded to 16
+  const int meta_bytes = ((3 * p.num_bins * 4 + 15) / 16) * 16;
+  float *s_binw = reinterpret_cast<float *>(smem + 5136 + meta_bytes);
+  const int binw_bytes = ((p.total_w * 4 + 15) / 16) * 16;
+  char *s_frames = smem + 5136 + meta_bytes + binw_bytes;             // 16 frame buffers
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 256; i += kThreads) s_tw256[i] = p.tw256[i];
+  for (int i = tid; i < 129; i += kThreads) s_tw512[i] = p.tw512[i];
+  for (int i = tid; i < kNfft; i += kThreads) s_window[i] = (i < p.win_len) ? p.window[i] : 0.0f;
+  for (int i = tid; i < 3 * p.num_bins; i += kThreads) s_meta[i] = p.bin_meta[i];
+  for (int i = tid; i < p.total_w; i += kThreads) s_binw[i] = p.bin_w[i];
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l = lane & 15;
+  const int fslot = wave * 4 + grp;
+  char *fb = s_frames + fslot * kFrameBufBytes;
+  float2 *T = reinterpret_cast<float2 *>(fb);
+  float *P = reinterpret_cast<float *>(fb);
+  float *M = reinterpret_cast<float *>(fb + kLogMelOff);
+  const int L = p.win_len;
+  const float eps = FLT_EPSILON;
+
+  const int64_t block_first = (int64_t)blockIdx.x * frames_per_block;
+  for (int it = 0; it < frames_per_block; it += kFramesPerIter) {
+    const int64_t g = block_first + it + fslot;
+    const bool valid = g < total_frames;
+    float x0[16], x1[16];
+    int64_t n = 0, start = 0;
+    const float *base = waves;
+    if (valid) {
+      // utterance lookup: largest u with frame_off[u] <= g
+      int lo = 0, hi = num_utts;   // invariant frame_off[lo] <= g < frame_off[hi]
+      while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (frame_off[mid] <= g) lo = mid; else hi = mid; }
+      const int64_t f = g - frame_off[lo];
+      const int64_t w0 = wave_off[lo];
+      n = wave_off[lo + 1] - w0;
+      base = waves + w0;
+      start = p.snip_edges ? f * p.win_shift : f * p.win_shift + p.win_shift / 2 - L / 2;   // FirstSampleOfFrame
+    }
+    const bool interior = valid && start >= 0 && start + L <= n;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int s = 2 * (l + 16 * j);
+      float a = 0.0f, b = 0.0f;
+      if (interior) {
+        if (s < L) a = base[start + s];
+        if (s + 1 < L) b = base[start + s + 1];
+      } else if (valid) {
+        if (s < L) { int64_t si = start + s; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; a = base[si]; }
+        if (s + 1 < L) { int64_t si = start + s + 1; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; b = base[si]; }
+      }
+      x0[j] = a; x1[j] = b;
+    }
+    // ---- ProcessWindow ----
+    if (p.remove_dc) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; j++) sum += x0[j] + x1[j];
+      sum = group_sum16(sum);
+      const float m = -sum / (float)L;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int s = 2 * (l + 16 * j);
+        if (s < L) x0[j] += m;
+        if (s + 1 < L) x1[j] += m;
+      }
+    }
+    float log_energy = 0.0f;
+    if (p.use_energy && p.raw_energy) {
+      float e = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; j++) e += x0[j] * x0[j] + x1[j] * x1[j];
+      e = group_sum16(e);
+      log_energy = logf(fmaxf(e, eps));
+    }
+    float2 v[16];
+    {
+      const float c = p.preemph;
+      float prev_hi = 0.0f;  // lane 15's x1[j-1]
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int s = 2 * (l + 16 * j);
+        float up = __shfl_up(x1[j], 1, 16);
+        float prev0 = (l > 0) ? up : ((j > 0) ? prev_hi : x0[0]);
+        prev_hi = __shfl(x1[j], 15, 16);
+        float y0 = x0[j], y1 = x1[j];
+        if (c != 0.0f) {
+          // __fmul_rn/__fsub_rn keep the reference's two roundings (no fma contraction)
+          if (s < L) y0 = __fsub_rn(x0[j], __fmul_rn(c, prev0));
+          if (s + 1 < L) y1 = __fsub_rn(x1[j], __fmul_rn(c, x0[j]));
+        }
+        const float2 w = *reinterpret_cast<const float2 *>(&s_window[s]);
+        v[j] = make_float2(y0 * w.x, y1 * w.y);
+      }
+    }
+    if (p.use_energy && !p.raw_energy) {
+      float e = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; j++) e += v[j].x * v[j].x + v[j].y * v[j].y;
+      e = group_sum16(e);
+      log_energy = logf(fmaxf(e, eps));
+    }
+    // ---- 256-point complex FFT, pass 1 (over j), twiddle, transpose ----
+    fft16(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) {
+      float2 y = v[fft16_slot(k2)];
+      if (k2 > 0) y = cmul(y, s_tw256[(l * k2) & 255]);
+      T[k2 * kTpad + l] = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = T[l * kTpad + i];
+    fft16(v);   // now X[l + 16*k1] = v[slot(k1)]
+    __syncthreads();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) T[l + 16 * k1] = v[fft16_slot(k1)];
+    __syncthreads();
+    // ---- real-FFT unpacking (srfft.cc:372-405) + power spectrum ----
+    float2 Bk[8], Bm[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int k = l + 16 * i;
+      Bk[i] = T[k];
+      Bm[i] = T[(kNc - k) & 255];
+    }
+    const float2 B128 = T[128];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int k = l + 16 * i;
+      if (k == 0) {
+        const float a0 = Bk[0].x + Bk[0].y, an = Bk[0].x - Bk[0].y;
+        float p0 = a0 * a0, pn = an * an;
+        if (!p.use_power) { p0 = sqrtf(p0); pn = sqrtf(pn); }
+        P[0] = p0; P[kNc] = pn;
+      } else {
+        const float2 w = s_tw512[k];
+        const float Cr = 0.5f * (Bk[i].x + Bm[i].x), Ci = 0.5f * (Bk[i].y - Bm[i].y);
+        const float Dr = 0.5f * (Bk[i].y + Bm[i].y), Di = -0.5f * (Bk[i].x - Bm[i].x);
+        const float Ar = Cr + (Dr * w.x - Di * w.y), Ai = Ci + (Dr * w.y + Di * w.x);
+        const float Er = Cr + (Dr * (-w.x) + Di * w.y), Ei = -Ci + (Dr * w.y + Di * w.x);
+        float pk = Ar * Ar + Ai * Ai, pm = Er * Er + Ei * Ei;
+        if (!p.use_power) { pk = sqrtf(pk); pm = sqrtf(pm); }
+        P[k] = pk; P[kNc - k] = pm;
+      }
+    }
+    if (l == 0) {  // k = N/4 = 128 (kdash == k)
+      const float2 w = s_tw512[128];
+      const float Cr = B128.x, Ci = 0.0f, Dr = B128.y, Di = 0.0f;
+      const float Ar = Cr + (Dr * w.x - Di * w.y), Ai = Ci + (Dr * w.y + Di * w.x);
+      float pk = Ar * Ar + Ai * Ai;
+      if (!p.use_power) pk = sqrtf(pk);
+      P[128] = pk;
+    }
+    __syncthreads();
+    // ---- mel filterbank: MelBanks::Compute ----
+    float *row = feats + g * ld;
+    const int mel_off = (p.feature_type == 0 && p.use_energy && !p.htk_compat) ? 1 : 0;
+    float logmel[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int b = l + 16 * r;
+      float e = 0.0f;
+      if (r * 16 < p.num_bins && b < p.num_bins) {
+        const int first = s_meta[3 * b], len = s_meta[3 * b + 1], wo = s_meta[3 * b + 2];
+        for (int i = 0; i < len; i++) e += s_binw[wo + i] * P[first + i];
+        if (p.htk_mode && e < 1.0f) e = 1.0f;
+        if (p.feature_type == 1 || p.use_log) e = logf(fmaxf(e, eps));
+      }
+      logmel[r] = e;
+    }
+    if (p.feature_type == 0) {
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const int b = l + 16 * r; if (b < p.num_bins) row[mel_off + b] = logmel[r]; }
+        if (p.use_energy && l == 0) {
+          float e = log_energy;
+          if (p.has_energy_floor && e < p.log_energy_floor) e = p.log_energy_floor;
+          row[p.htk_compat ? p.num_bins : 0] = e;
+        }
+      }
+      __syncthreads();   // P is overwritten by the next iteration's transpose tile
+    } else {
+      __syncthreads();   // all P reads done before M (aliases the tile tail) is written
+#pragma unroll
+      for (int r = 0; r < 8; r++) { const int b = l + 16 * r; if (b < p.num_bins) M[b] = logmel[r]; }
+      __syncthreads();
+      for (int r = 0; r * 16 < p.num_ceps; r++) {
+        const int c = l + 16 * r;
+        if (c < p.num_ceps && valid) {
+          const float *drow = p.dct + c * p.num_bins;
+          float acc = 0.0f;
+          for (int b = 0; b < p.num_bins; b++) acc += drow[b] * M[b];
+          if (p.has_lifter) acc *= p.lifter[c];
+          if (c == 0 && p.use_energy) {
+            float e = log_energy;
+            if (p.has_energy_floor && e < p.log_energy_floor) e = p.log_energy_floor;
+            acc = e;
+          }
+          int oc = c;
+          if (p.htk_compat) {
+            if (c == 0) { oc = p.num_ceps - 1; if (!p.use_energy) acc *= 1.41421356237309504880f; }
+            else oc = c - 1;
+          }
+          row[oc] = acc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------ CMVN ----------------------
+// One workgroup per (utterance, 8-column group): fp64 sums of x and x^2 over time (AccCmvnStats),
+// then x*scale+offset in place (ApplyCmvn).  Rows of an utterance are contiguous, so a wave reads
+// full rows (coalesced) and each lane owns column (lane % dim_tile).
+__global__ __launch_bounds__(256) void k3_cmvn_kernel(float *__restrict__ feats, int64_t ld, int dim,
+                                                      const int64_t *__restrict__ frame_off, int norm_vars,
+                                                      double *__restrict__ stats) {
+  __shared__ double s_sum[256], s_sq[256];
+  __shared__ float s_scale[64], s_offset[64];
+  const int u = blockIdx.x;
+  const int col0 = blockIdx.y * 64;
+  const int64_t r0 = frame_off[u], r1 = frame_off[u + 1];
+  const int64_t T = r1 - r0;
+  const int c = threadIdx.x & 63, rlane = threadIdx.x >> 6;   // 4 row-lanes x 64 columns
+  const int col = col0 + c;
+  double sum = 0.0, sq = 0.0;
+  if (col < dim)
+    for (int64_t t = r0 + rlane; t < r1; t += 4) {
+      const float x = feats[t * ld + col];
+      sum += (double)x; sq += (double)(x * x);   // reference: float product, double accumulate (cmvn.cc:46-47)
+    }
+  s_sum[threadIdx.x] = sum; s_sq[threadIdx.x] = sq;
+  __syncthreads();
+  if (rlane == 0 && col < dim) {
+    const double m = s_sum[c] + s_sum[64 + c] + s_sum[128 + c] + s_sum[192 + c];
+    const double v = s_sq[c] + s_sq[64 + c] + s_sq[128 + c] + s_sq[192 + c];
+    const double count = (double)T;
+    if (stats) {
+      double *st = stats + (int64_t)u * 2 * (dim + 1);
+      st[col] = m; st[dim + 1 + col] = v;
+      if (col == 0) { st[dim] = count; st[2 * dim + 1] = 0.0; }
+    }
+    if (!norm_vars) {
+      const float alpha = (float)(-1.0 / count);            // Vector<float>::AddVec(float, Vector<double>)
+      s_scale[c] = 1.0f; s_offset[c] = (float)(0.0f + alpha * m);
+    } else {
+      const double mean = m / count;
+      double var = v / count - mean * mean;
+      if (var < 1.0e-20) var = 1.0e-20;
+      const double scale = 1.0 / sqrt(var);
+      s_scale[c] = (float)scale; s_offset[c] = (float)(-(mean * scale));
+    }
+  }
+  __syncthreads();
+  if (col < dim && T > 0) {
+    const float sc = s_scale[c], of = s_offset[c];
+    for (int64_t t = r0 + rlane; t < r1; t += 4) {
+      float x = feats[t * ld + col];
+      if (norm_vars) x = __fmul_rn(x, sc);       // MulColsVec then AddVecToRows: two roundings
+      feats[t * ld + col] = __fadd_rn(x, of);
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side ------------------
+struct k3_feat_plan {
+  k3_feat_opts opts;
+  FeatParams prm;
+  int dim, win_len, win_shift, padded;
+  size_t lds_bytes;
+  void *d_blob;
+};
+
+static int32_t window_shift(const k3_feat_opts &o) { return (int32_t)(o.samp_freq * 0.001 * o.frame_shift_ms); }
+static int32_t window_size(const k3_feat_opts &o) { return (int32_t)(o.samp_freq * 0.001 * o.frame_length_ms); }
+static float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
+static float inv_mel_scale(float m) { return 700.0f * (expf(m / 1127.0f) - 1.0f); }
+static float vtln_warp_freq(float vlo, float vhi, float lo, float hi, float warp, float freq) {
+  if (freq < lo || freq > hi) return freq;
+  const float l = vlo * std::max(1.0f, warp), h = vhi * std::min(1.0f, warp), scale = 1.0f / warp;
+  const float Fl = scale * l, Fh = scale * h;
+  const float sl = (Fl - lo) / (l - lo), sr = (hi - Fh) / (hi - h);
+  if (freq < l) return lo + sl * (freq - lo);
+  if (freq < h) return scale * freq;
+  return hi + sr * (freq - hi);
+}
+
+extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out) {
+  K3_REQUIRE(opts && out, "k3_feat_plan_create: null argument");
+  const k3_feat_opts &o = *opts;
+  const int L = window_size(o), shift = window_shift(o);
+  int padded = L;
+  if (o.round_to_power_of_two) { padded = 1; while (padded < L) padded <<= 1; }
+  K3_REQUIRE(L > 1 && shift > 0, "k3_feat_plan_create: bad frame length/shift");
+  if (padded != kNfft) {
+    k3::set_error("k3_feat_plan_create: padded window size %d unsupported (this build handles %d, i.e. "
+                  "frame lengths of 257..512 samples with --round-to-power-of-two=true)", padded, kNfft);
+    return K3_ERR_UNSUPPORTED;
+  }
+  if (o.dither != 0.0f) {
+    k3::set_error("k3_feat_plan_create: dither != 0 unsupported (parity runs use --dither=0)");
+    return K3_ERR_UNSUPPORTED;
+  }
+  K3_REQUIRE(o.num_bins >= 3 && o.num_bins <= 128, "k3_feat_plan_create: need 3 <= num_bins <= 128");
+  K3_REQUIRE(o.preemph_coeff >= 0.0f && o.preemph_coeff <= 1.0f, "k3_feat_plan_create: preemph_coeff out of [0,1]");
+  if (o.feature_type == 1) K3_REQUIRE(o.num_ceps >= 1 && o.num_ceps <= o.num_bins, "num-ceps cannot be larger than num-mel-bins");
+
+  // window: FeatureWindowFunction, feature-window.cc:109-135
+  std::vector<float> window(L);
+  const double a = 6.283185307179586476925286766559005 / (L - 1);
+  for (int i = 0; i < L; i++) {
+    const double x = i;
+    switch (o.window_type) {
+      case 0: window[i] = 0.5 - 0.5 * cos(a * x); break;
+      case 1: window[i] = sin(0.5 * a * x); break;
+      case 2: window[i] = 0.54 - 0.46 * cos(a * x); break;
+      case 3: window[i] = pow(0.5 - 0.5 * cos(a * x), 0.85); break;
+      case 4: window[i] = 1.0; break;
+      case 5: window[i] = o.blackman_coeff - 0.5 * cos(a * x) + (0.5 - o.blackman_coeff) * cos(2 * a * x); break;
+      default: return k3::fail(K3_ERR_ARG, "Invalid window type", __FILE__, __LINE__);
+    }
+  }
+  // mel banks: MelBanks::MelBanks, mel-computations.cc:33-142
+  const int nb = o.num_bins, nfft_bins = padded / 2;
+  const float nyq = 0.5f * o.samp_freq, low = o.low_freq;
+  const float high = (o.high_freq > 0.0f) ? o.high_freq : nyq + o.high_freq;
+  if (low < 0.0f || low >= nyq || high <= 0.0f || high > nyq || high <= low) {
+    k3::set_error("Bad values in options: low-freq %g and high-freq %g vs. nyquist %g", low, high, nyq);
+    return K3_ERR_ARG;
+  }
+  const float bin_width = o.samp_freq / padded;
+  const float mlow = mel_scale(low), mhigh = mel_scale(high), delta = (mhigh - mlow) / (nb + 1);
+  float vlo = o.vtln_low, vhi = o.vtln_high;
+  if (vhi < 0.0f) vhi += nyq;
+  if (o.vtln_warp != 1.0f && (vlo < 0.0f || vlo <= low || vlo >= high || vhi <= 0.0f || vhi >= high || vhi <= vlo)) {
+    k3::set_error("Bad values in options: vtln-low %g and vtln-high %g, versus low-freq %g and high-freq %g", vlo, vhi, low, high);
+    return K3_ERR_ARG;
+  }
+  std::vector<int> meta(3 * nb);
+  std::vector<float> binw;
+  for (int bin = 0; bin < nb; bin++) {
+    float left = mlow + bin * delta, center = mlow + (bin + 1) * delta, right = mlow + (bin + 2) * delta;
+    if (o.vtln_warp != 1.0f) {
+      left = mel_scale(vtln_warp_freq(vlo, vhi, low, high, o.vtln_warp, inv_mel_scale(left)));
+      center = mel_scale(vtln_warp_freq(vlo, vhi, low, high, o.vtln_warp, inv_mel_scale(center)));
+      right = mel_scale(vtln_warp_freq(vlo, vhi, low, high, o.vtln_warp, inv_mel_scale(right)));
+    }
+    int first = -1, last = -1;
+    std::vector<float> w(nfft_bins, 0.0f);
+    for (int i = 0; i < nfft_bins; i++) {
+      const float mel = mel_scale(bin_width * i);
+      if (mel > left && mel < right) {
+        w[i] = (mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center);
+        if (first == -1) first = i;
+        last = i;
+      }
+    }
+    if (first == -1) return k3::fail(K3_ERR_ARG, "You may have set --num-mel-bins too large.", __FILE__, __LINE__);
+    meta[3 * bin] = first; meta[3 * bin + 1] = last + 1 - first; meta[3 * bin + 2] = (int)binw.size();
+    for (int i = first; i <= last; i++) binw.push_back(w[i]);
+    if (o.htk_mode && bin == 0 && mlow != 0.0f) binw[meta[2]] = 0.0f;
+  }
+  // twiddles
+  std::vector<float> tw256(512), tw512(2 * 129);
+  for (int m = 0; m < 256; m++) { const double ang = -6.283185307179586476925286766559005 * m / 256.0; tw256[2 * m] = cos(ang); tw256[2 * m + 1] = sin(ang); }
+  {  // srfft.cc:370-376: kN built by repeated float complex multiplication by exp(-2 pi i / N)
+    const float ang = (float)(6.283185307179586476925286766559005 / padded * -1);
+    const float rr = cosf(ang), ri = sinf(ang);
+    float kr = 1.0f, ki = 0.0f;
+    tw512[0] = 1.0f; tw512[1] = 0.0f;
+    for (int k = 1; k <= 128; k++) { const float t = kr * rr - ki * ri; ki = kr * ri + ki * rr; kr = t; tw512[2 * k] = kr; tw512[2 * k + 1] = ki; }
+  }
+  // MFCC tables
+  std::vector<float> dct, lifter;
+  if (o.feature_type == 1) {
+    dct.resize((size_t)o.num_ceps * nb);
+    const float n0 = std::sqrt(1.0f / (float)nb), n1 = std::sqrt(2.0f / (float)nb);
+    for (int j = 0; j < nb; j++) dct[j] = n0;
+    for (int k = 1; k < o.num_ceps; k++)
+      for (int n = 0; n < nb; n++) dct[(size_t)k * nb + n] = n1 * std::cos((double)M_PI / nb * (n + 0.5) * k);
+    lifter.resize(o.num_ceps);
+    for (int i = 0; i < o.num_ceps; i++) lifter[i] = 1.0 + 0.5 * o.cepstral_lifter * sin(M_PI * i / o.cepstral_lifter);
+  }
+  // one device blob
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  size_t off_win = 0, off_tw256 = al(off_win + window.size() * 4), off_tw512 = al(off_tw256 + tw256.size() * 4),
+         off_meta = al(off_tw512 + tw512.size() * 4), off_binw = al(off_meta + meta.size() * 4),
+         off_dct = al(off_binw + binw.size() * 4), off_lift = al(off_dct + dct.size() * 4), total = al(off_lift + lifter.size() * 4 + 4);
+  std::vector<char> host(total, 0);
+  memcpy(&host[off_win], window.data(), window.size() * 4);
+  memcpy(&host[off_tw256], tw256.data(), tw256.size() * 4);
+  memcpy(&host[off_tw512], tw512.data(), tw512.size() * 4);
+  memcpy(&host[off_meta], meta.data(), meta.size() * 4);
+  memcpy(&host[off_binw], binw.data(), binw.size() * 4);
+  if (!dct.empty()) { memcpy(&host[off_dct], dct.data(), dct.size() * 4); memcpy(&host[off_lift], lifter.data(), lifter.size() * 4); }
+  void *blob = nullptr;
+  K3_HIP_CHECK(hipMalloc(&blob, total));
+  K3_HIP_CHECK(hipMemcpy(blob, host.data(), total, hipMemcpyHostToDevice));
+
+  k3_feat_plan *pl = new k3_feat_plan();
+  pl->opts = o; pl->win_len = L; pl->win_shift = shift; pl->padded = padded; pl->d_blob = blob;
+  pl->dim = (o.feature_type == 1) ? o.num_ceps : nb + (o.use_energy ? 1 : 0);
+  FeatParams &p = pl->prm;
+  p.win_len = L; p.win_shift = shift; p.snip_edges = o.snip_edges; p.remove_dc = o.remove_dc_offset;
+  p.use_energy = o.use_energy; p.raw_energy = o.raw_energy; p.htk_compat = o.htk_compat; p.use_log = o.use_log_fbank;
+  p.use_power = (o.feature_type == 1) ? 1 : o.use_power; p.htk_mode = o.htk_mode; p.feature_type = o.feature_type;
+  p.num_bins = nb; p.num_ceps = o.num_ceps; p.dim = pl->dim;
+  p.has_energy_floor = o.energy_floor > 0.0f; p.log_energy_floor = p.has_energy_floor ? logf(o.energy_floor) : 0.0f;
+  p.has_lifter = (o.feature_type == 1 && o.cepstral_lifter != 0.0f);
+  p.total_w = (int)binw.size(); p.preemph = o.preemph_coeff;
+  char *b = (char *)blob;
+  p.window = (const float *)(b + off_win); p.tw256 = (const float2 *)(b + off_tw256); p.tw512 = (const float2 *)(b + off_tw512);
+  p.bin_meta = (const int *)(b + off_meta); p.bin_w = (const float *)(b + off_binw);
+  p.dct = (const float *)(b + off_dct); p.lifter = (const float *)(b + off_lift);
+  const size_t meta_bytes = ((3 * nb * 4 + 15) / 16) * 16, binw_bytes = ((binw.size() * 4 + 15) / 16) * 16;
+  pl->lds_bytes = 5136 + meta_bytes + binw_bytes + (size_t)kFramesPerIter * kFrameBufBytes;
+  if ((size_t)kLogMelOff + nb * 4 > (size_t)kFrameBufBytes) { delete pl; hipFree(blob); return k3::fail(K3_ERR_UNSUPPORTED, "num_bins too large for the LDS frame buffer", __FILE__, __LINE__); }
+  *out = pl;
+  return K3_OK;
+}
+
+extern "C" void k3_feat_plan_destroy(k3_feat_plan *plan) {
+  if (!plan) return;
+  if (plan->d_blob) (void)hipFree(plan->d_blob);
+  delete plan;
+}
+
+extern "C" int32_t k3_feat_dim(const k3_feat_plan *plan) { return plan ? plan->dim : -1; }
+
+extern "C" int32_t k3_feat_num_frames(const k3_feat_plan *plan, int64_t nsamp) {
+  if (!plan) return -1;
+  const int64_t shift = plan->win_shift, len = plan->win_len;
+  if (plan->opts.snip_edges) return nsamp < len ? 0 : (int32_t)(1 + (nsamp - len) / shift);
+  return (int32_t)((nsamp + shift / 2) / shift);
+}
+
+extern "C" int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_t *d_wave_offsets,
+                                     const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
+                                     float *d_feats, int64_t ld, void *stream) {
+  K3_REQUIRE(plan && d_waves && d_wave_offsets && d_frame_offsets && d_feats, "k3_feat_compute_batch: null argument");
+  K3_REQUIRE(num_utts >= 0 && total_frames >= 0 && ld >= plan->dim, "k3_feat_compute_batch: bad sizes");
+  if (total_frames == 0 || num_utts == 0) return K3_OK;
+  const int frames_per_block = 64;
+  const int64_t blocks = (total_frames + frames_per_block - 1) / frames_per_block;
+  K3_REQUIRE(blocks < (1ll << 31), "k3_feat_compute_batch: too many frames for one launch");
+  static bool attr_set = false;
+  if (!attr_set) {
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_feat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k3_feat_kernel, dim3((unsigned)blocks), dim3(kThreads), plan->lds_bytes, (hipStream_t)stream, plan->prm,
+                     d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+
+extern "C" int k3_cmvn_offline_batch(float *d_feats, int64_t ld, int32_t dim, const int64_t *d_frame_offsets,
+                                     int32_t num_utts, int32_t norm_vars, double *d_stats, void *stream) {
+  K3_REQUIRE(d_feats && d_frame_offsets && dim > 0 && ld >= dim && num_utts >= 0, "k3_cmvn_offline_batch: bad argument");
+  if (num_utts == 0) return K3_OK;
+  hipLaunchKernelGGL(k3_cmvn_kernel, dim3((unsigned)num_utts, (unsigned)((dim + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                     d_feats, ld, (int)dim, d_frame_offsets, (int)norm_vars, d_stats);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}

@@ -1,0 +1,66 @@
+"""Python plumbing over the feature C ABI (k3_feat_*): what the C++ adapter
+kaldi::CudaSpectralFeatures / OnlineCudaFeaturePipeline (kaldi_amd/host) calls, exposed to tests and
+bench.py.  torch is used for device buffers and the current stream only."""
+import ctypes, torch
+from . import lib as _l
+
+def fbank_options(**kw):
+    """FbankOptions defaults (feat/feature-fbank.h:44-61, feature-window.h:53-66, mel-computations.h:56-58)."""
+    o = _l.FeatOpts(16000.0, 10.0, 25.0, 1.0, 0.97, 0.42, 1, 1, 1, 3, 23, 20.0, 0.0, 100.0, -500.0, 0, 0, 0.0, 1, 0, 1, 1, 13, 22.0, 0, 1.0)
+    for k, v in kw.items():
+        setattr(o, k, _l.WINDOW_TYPES[v] if k == "window_type" and isinstance(v, str) else v)
+    return o
+
+def mfcc_options(**kw):
+    """MfccOptions defaults (feat/feature-mfcc.h:40-60): 23 bins, 13 ceps, use_energy, lifter 22."""
+    o = fbank_options(use_energy=1, feature_type=1)
+    for k, v in kw.items():
+        setattr(o, k, _l.WINDOW_TYPES[v] if k == "window_type" and isinstance(v, str) else v)
+    return o
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+class SpectralFeatures:
+    """Batched equivalent of CudaSpectralFeatures(opts) (cudafeat/feature-spectral-cuda.h): ComputeFeatures over
+    a ragged batch of utterances held in one device buffer."""
+    def __init__(self, opts):
+        self._L = _l.load()
+        self._h = ctypes.c_void_p()
+        self.opts = opts
+        _l.check(self._L.k3_feat_plan_create(ctypes.byref(opts), ctypes.byref(self._h)))
+        self.dim = self._L.k3_feat_dim(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.k3_feat_plan_destroy(self._h); self._h = ctypes.c_void_p()
+
+    def Dim(self):
+        return self.dim
+
+    def NumFrames(self, nsamp):
+        return self._L.k3_feat_num_frames(self._h, int(nsamp))
+
+    def offsets(self, lengths, device):
+        """host-side bookkeeping: (wave_offsets, frame_offsets) int64 device tensors + total_frames."""
+        wo = [0]; fo = [0]
+        for n in lengths:
+            wo.append(wo[-1] + int(n)); fo.append(fo[-1] + self.NumFrames(n))
+        return (torch.tensor(wo, dtype=torch.int64, device=device), torch.tensor(fo, dtype=torch.int64, device=device), fo[-1], fo)
+
+    def ComputeFeatures(self, waves, wave_offsets, frame_offsets, total_frames, out=None):
+        """waves: float32 [sum nsamp] on the GPU; returns float32 [total_frames, dim]."""
+        assert waves.is_cuda and waves.dtype == torch.float32 and waves.is_contiguous()
+        if out is None:
+            out = torch.empty((total_frames, self.dim), dtype=torch.float32, device=waves.device)
+        _l.check(self._L.k3_feat_compute_batch(self._h, waves.data_ptr(), wave_offsets.data_ptr(), frame_offsets.data_ptr(),
+                                               wave_offsets.numel() - 1, int(total_frames), out.data_ptr(), out.stride(0), _stream()))
+        return out
+
+def ApplyCmvnOffline(feats, frame_offsets, norm_vars=False, stats=None):
+    """compute-cmvn-stats | apply-cmvn per utterance, in place (transform/cmvn.cc:30-115)."""
+    assert feats.is_cuda and feats.dtype == torch.float32
+    L = _l.load()
+    _l.check(L.k3_cmvn_offline_batch(feats.data_ptr(), feats.stride(0), feats.shape[1], frame_offsets.data_ptr(),
+                                     frame_offsets.numel() - 1, int(norm_vars), stats.data_ptr() if stats is not None else None, _stream()))
+    return feats

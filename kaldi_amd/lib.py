@@ -1,0 +1,46 @@
+"""ctypes binding of libk3hip.so (include/k3hip.h).  Fails loudly when the library is missing."""
+import ctypes, os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libk3hip.so")
+
+class K3Error(RuntimeError):
+    """Raised for any non-zero k3_status (the C++ adapters raise KaldiFatalError instead)."""
+
+class FeatOpts(ctypes.Structure):
+    """k3_feat_opts (include/k3hip.h); defaults = FbankOptions (feat/feature-fbank.h:44-61)."""
+    _fields_ = [("samp_freq", ctypes.c_float), ("frame_shift_ms", ctypes.c_float), ("frame_length_ms", ctypes.c_float),
+                ("dither", ctypes.c_float), ("preemph_coeff", ctypes.c_float), ("blackman_coeff", ctypes.c_float),
+                ("remove_dc_offset", ctypes.c_int32), ("round_to_power_of_two", ctypes.c_int32), ("snip_edges", ctypes.c_int32),
+                ("window_type", ctypes.c_int32), ("num_bins", ctypes.c_int32),
+                ("low_freq", ctypes.c_float), ("high_freq", ctypes.c_float), ("vtln_low", ctypes.c_float), ("vtln_high", ctypes.c_float),
+                ("htk_mode", ctypes.c_int32), ("use_energy", ctypes.c_int32), ("energy_floor", ctypes.c_float),
+                ("raw_energy", ctypes.c_int32), ("htk_compat", ctypes.c_int32), ("use_log_fbank", ctypes.c_int32), ("use_power", ctypes.c_int32),
+                ("num_ceps", ctypes.c_int32), ("cepstral_lifter", ctypes.c_float), ("feature_type", ctypes.c_int32), ("vtln_warp", ctypes.c_float)]
+
+WINDOW_TYPES = {"hanning": 0, "sine": 1, "hamming": 2, "povey": 3, "rectangular": 4, "blackman": 5}
+
+_lib = None
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise K3Error(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950).  kaldi_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.k3_last_error.restype = ctypes.c_char_p
+    L.k3_feat_plan_create.argtypes = [ctypes.POINTER(FeatOpts), ctypes.POINTER(vp)]
+    L.k3_feat_plan_destroy.argtypes = [vp]; L.k3_feat_plan_destroy.restype = None
+    L.k3_feat_dim.argtypes = [vp]; L.k3_feat_dim.restype = i32
+    L.k3_feat_num_frames.argtypes = [vp, i64]; L.k3_feat_num_frames.restype = i32
+    L.k3_feat_compute_batch.argtypes = [vp, vp, vp, vp, i32, i64, vp, i64, vp]
+    L.k3_cmvn_offline_batch.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp]
+    _lib = L
+    return L
+
+def check(status):
+    if status != 0:
+        raise K3Error(f"k3 status {status}: {load().k3_last_error().decode()}")

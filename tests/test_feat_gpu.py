@@ -1,0 +1,100 @@
+"""GPU parity: HIP fbank/MFCC/CMVN (through the C ABI) vs the oracle, the reference-binary fixtures
+and the HTK golden vectors.  Tolerances: |delta| <= 1e-4 on log-mel (north_star / SURVEY 8d parity
+gate), 3e-4 on MFCC (values up to ~150, float32 ulp 1.5e-5, 40-term sums), HTK goldens at the
+reference tests' own tolerances."""
+import numpy as np, pytest, torch
+from tests import feat_cases as fc
+
+pytestmark = pytest.mark.gpu
+
+def _gpu_feats(waves, opts):
+    from kaldi_amd import feat
+    sf = feat.SpectralFeatures(opts)
+    dev = torch.device("cuda:0")
+    cat = torch.from_numpy(np.concatenate([np.asarray(w, np.float32) for w in waves]) if waves else np.zeros(0, np.float32)).to(dev)
+    wo, fo, total, fo_h = sf.offsets([len(w) for w in waves], dev)
+    out = sf.ComputeFeatures(cat, wo, fo, total)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    return [out[fo_h[i]:fo_h[i + 1]] for i in range(len(waves))]
+
+def _opts(kind, kw):
+    from kaldi_amd import feat
+    return feat.mfcc_options(**kw) if kind == "mfcc" else feat.fbank_options(**kw)
+
+@pytest.mark.parametrize("name", sorted(fc.REF_CASES))
+def test_hip_vs_reference_binary(feat_golden, name):
+    kind, kw, wkey = fc.REF_CASES[name]
+    got = _gpu_feats([feat_golden[wkey].astype(np.float32)], _opts(kind, kw))[0]
+    ref = feat_golden["ref_" + name]
+    assert got.shape == ref.shape
+    tol = 1e-4 if kind == "fbank" else 3e-4
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+
+@pytest.mark.parametrize("idx", [1, 2, 3, 4])
+def test_hip_fbank_vs_htk(feat_golden, idx):
+    kw, tol = fc.HTK_FBANK[idx]
+    got = _gpu_feats([feat_golden["wav"].astype(np.float32)], _opts("fbank", kw))[0]
+    d = np.abs(got[10:-10] - feat_golden[f"htk_fbank_{idx}"][10:-10])
+    if idx == 3: d = d[:, :20]
+    assert d.max() <= tol
+
+@pytest.mark.parametrize("idx", [1, 2, 3, 4, 5, 6])
+def test_hip_mfcc_vs_htk(feat_golden, idx):
+    got = _gpu_feats([feat_golden["wav"].astype(np.float32)], _opts("mfcc", fc.HTK_MFCC[idx]))[0]
+    assert np.abs(got[10:-10] - feat_golden[f"htk_mfcc_{idx}"][10:-10, :13]).max() <= 1e-3
+
+def test_hip_ragged_batch_vs_oracle():
+    """ragged batch incl. an utterance too short for one frame and exact-fit lengths."""
+    from oracle import feat_oracle as fo
+    rng = np.random.default_rng(1235)
+    lens = [400, 399, 160000, 559, 560, 32000 + 7, 48123, 1, 16000]
+    waves = [np.clip(np.rint(rng.normal(0, 3000, n)), -32768, 32767).astype(np.float32) for n in lens]
+    for kind, kw in (("fbank", dict(dither=0.0, num_bins=40)), ("mfcc", dict(dither=0.0, num_bins=40, num_ceps=40, low_freq=20.0, high_freq=-400.0, use_energy=0)),
+                     ("fbank", dict(dither=0.0, num_bins=40, snip_edges=0, use_energy=1))):
+        got = _gpu_feats(waves, _opts(kind, kw))
+        oo = fo.mfcc_opts(**kw) if kind == "mfcc" else fo.fbank_opts(**kw)
+        for w, g in zip(waves, got):
+            ref = fo.compute_features(w, oo)
+            assert g.shape == ref.shape
+            if ref.size:
+                assert np.abs(g - ref).max() <= (1e-4 if kind == "fbank" else 3e-4)
+
+def test_hip_cmvn(feat_golden):
+    from kaldi_amd import feat
+    from oracle import feat_oracle as fo
+    dev = torch.device("cuda:0")
+    base = feat_golden["ref_fbank_default40"]
+    for nv in (0, 1):
+        x = torch.from_numpy(np.concatenate([base, base[:57] * 0.5 + 1.0])).to(dev)
+        fo_t = torch.tensor([0, base.shape[0], base.shape[0] + 57], dtype=torch.int64, device=dev)
+        stats = torch.zeros((2, 2, 41), dtype=torch.float64, device=dev)
+        feat.ApplyCmvnOffline(x, fo_t, norm_vars=bool(nv), stats=stats)
+        torch.cuda.synchronize()
+        got = x.cpu().numpy()
+        assert np.abs(got[:base.shape[0]] - feat_golden[f"ref_cmvn_normvars{nv}"]).max() <= 2e-6
+        ref2 = fo.cmvn_offline(base[:57] * 0.5 + 1.0, norm_vars=bool(nv))
+        assert np.abs(got[base.shape[0]:] - ref2).max() <= 2e-6
+        assert stats[0, 0, 40].item() == base.shape[0]
+
+def test_hip_full_size_properties():
+    """BASELINE config sizes (512 x 10 s): determinism + shift-consistency (frame f of an utterance equals frame 0 of
+    the same utterance advanced by f*160 samples) instead of a CPU oracle pass."""
+    from kaldi_amd import feat
+    dev = torch.device("cuda:0")
+    U, n = 512, 160000
+    g = torch.Generator(device="cpu"); g.manual_seed(1234)
+    w = (torch.randn(U * n, generator=g) * 3000).round().clamp(-32768, 32767).to(dev)
+    sf = feat.SpectralFeatures(feat.fbank_options(dither=0.0, num_bins=40))
+    wo, fo, total, _ = sf.offsets([n] * U, dev)
+    assert total == U * 998
+    a = sf.ComputeFeatures(w, wo, fo, total); b = sf.ComputeFeatures(w, wo, fo, total)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    # shift consistency on utterance 3: treat samples [160*k, ...) as a new utterance
+    k = 37
+    sub = w[3 * n + 160 * k: 4 * n].contiguous()
+    wo2, fo2, total2, _ = sf.offsets([sub.numel()], dev)
+    c = sf.ComputeFeatures(sub, wo2, fo2, total2)
+    torch.cuda.synchronize()
+    assert torch.equal(c, a[3 * 998 + k: 4 * 998])
