@@ -29,6 +29,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise K3Error(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950).  kaldi_amd has no CPU fallback.")
+    # torch ships its own libamdhip64; load it FIRST so libk3hip.so binds to the same HIP runtime
+    # (two runtimes in one process => "No HIP GPUs are available" in whichever initialises second).
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     L.k3_last_error.restype = ctypes.c_char_p
