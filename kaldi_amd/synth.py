@@ -1,0 +1,181 @@
+"""Synthetic workload generators: 16 kHz Gaussian PCM16 waveforms and random-init,
+BatchNorm-calibrated TDNN / TDNN-F chain models written in Kaldi's own nnet3 BINARY model format
+(Nnet::Write, nnet3/nnet-nnet.cc:630-662; component Write()s cited per writer below), so the same
+file feeds the reference's nnet3-compute, the oracle and k3_nnet_load().
+
+There is no network for real checkpoints; weights are seeded random with BatchNorm statistics set to
+the empirical statistics of a calibration batch, which keeps activations O(1) like a trained model
+(a fresh BatchNormComponent has count 0 and the reference would fabricate random stats,
+nnet-normalize-component.cc:216-225)."""
+import io, struct
+import numpy as np
+
+# ----------------------------------------------------------------------------- waves ----
+def gaussian_pcm16(num_samples, seed, sigma=3000.0):
+    rng = np.random.default_rng(seed)
+    return np.clip(np.rint(rng.normal(0.0, sigma, num_samples)), -32768, 32767).astype(np.int16)
+
+# ----------------------------------------------------------------------------- binary writers ----
+def _tok(f, s): f.write(s.encode() + b" ")
+def _i32(f, v): f.write(b"\x04" + struct.pack("<i", int(v)))
+def _f32(f, v): f.write(b"\x04" + struct.pack("<f", float(v)))
+def _f64(f, v): f.write(b"\x08" + struct.pack("<d", float(v)))
+def _bool(f, v): f.write(b"T" if v else b"F")
+def _vec(f, v):
+    v = np.ascontiguousarray(v, dtype="<f4"); f.write(b"FV \x04" + struct.pack("<i", v.size)); f.write(v.tobytes())
+def _mat(f, m):
+    m = np.ascontiguousarray(m, dtype="<f4"); f.write(b"FM \x04" + struct.pack("<i", m.shape[0]) + b"\x04" + struct.pack("<i", m.shape[1])); f.write(m.tobytes())
+def _ivec(f, v):
+    v = np.asarray(v, dtype="<i4"); f.write(b"\x04" + struct.pack("<i", v.size) + v.tobytes())
+
+def _w_affine(f, c):   # NaturalGradientAffineComponent::Write nnet-simple-component.cc:2948-2970
+    _tok(f, "<NaturalGradientAffineComponent>"); _tok(f, "<MaxChange>"); _f32(f, 0.75); _tok(f, "<LearningRate>"); _f32(f, 0.001)
+    _tok(f, "<LinearParams>"); _mat(f, c["W"]); _tok(f, "<BiasParams>"); _vec(f, c["b"])
+    _tok(f, "<RankIn>"); _i32(f, 20); _tok(f, "<RankOut>"); _i32(f, 80); _tok(f, "<UpdatePeriod>"); _i32(f, 4)
+    _tok(f, "<NumSamplesHistory>"); _f32(f, 2000.0); _tok(f, "<Alpha>"); _f32(f, 4.0); _tok(f, "</NaturalGradientAffineComponent>")
+
+def _w_tdnn(f, c):     # TdnnComponent::Write nnet-tdnn-component.cc:382-408
+    _tok(f, "<TdnnComponent>"); _tok(f, "<MaxChange>"); _f32(f, 0.75); _tok(f, "<LearningRate>"); _f32(f, 0.001)
+    _tok(f, "<TimeOffsets>"); _ivec(f, c["offsets"]); _tok(f, "<LinearParams>"); _mat(f, c["W"]); _tok(f, "<BiasParams>"); _vec(f, c["b"])
+    _tok(f, "<OrthonormalConstraint>"); _f32(f, 0.0); _tok(f, "<UseNaturalGradient>"); _bool(f, True)
+    _tok(f, "<NumSamplesHistory>"); _f32(f, 2000.0); _tok(f, "<AlphaInOut>"); _f32(f, 4.0); _f32(f, 4.0)
+    _tok(f, "<RankInOut>"); _i32(f, 20); _i32(f, 80); _tok(f, "</TdnnComponent>")
+
+def _w_linear(f, c):   # LinearComponent::Write nnet-simple-component.cc:3174-3201
+    _tok(f, "<LinearComponent>"); _tok(f, "<MaxChange>"); _f32(f, 0.75); _tok(f, "<LearningRate>"); _f32(f, 0.001)
+    _tok(f, "<Params>"); _mat(f, c["W"]); _tok(f, "<UseNaturalGradient>"); _bool(f, True)
+    _tok(f, "<RankInOut>"); _i32(f, 20); _i32(f, 80); _tok(f, "<Alpha>"); _f32(f, 4.0)
+    _tok(f, "<NumSamplesHistory>"); _f32(f, 2000.0); _tok(f, "<UpdatePeriod>"); _i32(f, 4); _tok(f, "</LinearComponent>")
+
+def _w_relu(f, c):     # NonlinearComponent::Write nnet-component-itf.cc:546-603
+    d = c["dim"]; z = np.zeros(d, np.float32)
+    _tok(f, "<RectifiedLinearComponent>"); _tok(f, "<Dim>"); _i32(f, d); _tok(f, "<ValueAvg>"); _vec(f, z); _tok(f, "<DerivAvg>"); _vec(f, z)
+    _tok(f, "<Count>"); _f64(f, 0.0); _tok(f, "<OderivRms>"); _vec(f, z); _tok(f, "<OderivCount>"); _f64(f, 0.0)
+    _tok(f, "<NumDimsSelfRepaired>"); _f64(f, 0.0); _tok(f, "<NumDimsProcessed>"); _f64(f, 0.0)
+    _tok(f, "<SelfRepairScale>"); _f32(f, 1e-05); _tok(f, "</RectifiedLinearComponent>")
+
+def _w_bn(f, c):       # BatchNormComponent::Write nnet-normalize-component.cc:616-645
+    d = c["dim"]
+    _tok(f, "<BatchNormComponent>"); _tok(f, "<Dim>"); _i32(f, d); _tok(f, "<BlockDim>"); _i32(f, d); _tok(f, "<Epsilon>"); _f32(f, 0.001)
+    _tok(f, "<TargetRms>"); _f32(f, c.get("target_rms", 1.0)); _tok(f, "<TestMode>"); _bool(f, False); _tok(f, "<Count>"); _f64(f, c["count"])
+    _tok(f, "<StatsMean>"); _vec(f, c["mean"]); _tok(f, "<StatsVar>"); _vec(f, c["var"]); _tok(f, "</BatchNormComponent>")
+
+def _w_noop(f, c):     # NoOpComponent::Write nnet-simple-component.cc:480-487
+    _tok(f, "<NoOpComponent>"); _tok(f, "<Dim>"); _i32(f, c["dim"]); _tok(f, "<BackpropScale>"); _f32(f, 1.0); _tok(f, "</NoOpComponent>")
+
+_WRITERS = {"affine": _w_affine, "tdnn": _w_tdnn, "linear": _w_linear, "relu": _w_relu, "batchnorm": _w_bn, "noop": _w_noop}
+
+class SynthNnet:
+    """config_lines (exactly what xconfig_to_configs.py emits into final.config, minus 'component' lines)
+    + components [(name, kind, params)]."""
+    def __init__(self): self.config_lines, self.components = [], []
+
+    def write(self, path, binary=True):
+        assert binary
+        with open(path, "wb") as f:
+            f.write(b"\0B"); _tok(f, "<Nnet3>"); f.write(b"\n")
+            for l in self.config_lines: f.write(l.encode() + b"\n")
+            f.write(b"\n"); _tok(f, "<NumComponents>"); _i32(f, len(self.components))
+            for name, kind, prm in self.components:
+                _tok(f, "<ComponentName>"); _tok(f, name); _WRITERS[kind](f, prm)
+            _tok(f, "</Nnet3>")
+
+    def num_params(self):
+        n = 0
+        for _, kind, p in self.components:
+            if kind in ("affine", "tdnn", "linear"): n += p["W"].size + (p["b"].size if "b" in p else 0)
+        return n
+
+# ----------------------------------------------------------------------------- model builders ----
+def _calib_feats(rng, frames, dim):
+    return (rng.standard_normal((frames, dim)) * 1.2 + 16.5).astype(np.float32)
+
+def _splice(x, offsets):
+    """x: [T x D] valid for t = 0..T-1 -> rows for t = -min..T-1-max, columns appended in offset order."""
+    lo, hi = -min(offsets), x.shape[0] - 1 - max(offsets)
+    return np.concatenate([x[lo + o: hi + o + 1] for o in offsets], axis=1)
+
+def _bn_from(x):
+    return dict(dim=x.shape[1], count=float(x.shape[0]), mean=x.mean(0).astype(np.float32), var=x.var(0).astype(np.float32))
+
+def _bn_apply(x, p, eps=1e-3):
+    scale = (p["var"] + eps) ** -0.5 * p.get("target_rms", 1.0)
+    return ((x - p["mean"]) * scale).astype(np.float32)
+
+def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0) + (3,) * 12, prefinal_small=192,
+               num_pdfs=6024, bypass_scale=0.75, calib_frames=600, out_std=2.5):
+    """The 17-layer LibriSpeech TDNN-F layout (egs/librispeech/s5/local/chain/tuning/run_tdnn_1d.sh:220-249 minus
+    ivector/LDA/xent/dropout) at mini_librispeech widths (run_tdnn_1k.sh:185-202): '17L-768/96-6024', ~6.28 M params.
+    Node/component names follow steps/libs/nnet3/xconfig (composite_layers.py:68-227)."""
+    rng = np.random.default_rng(seed)
+    net = SynthNnet(); L = net.config_lines; C = net.components
+    x = _calib_feats(rng, calib_frames, input_dim)     # calibration activations, shrinking as context is consumed
+    def randn(r, c, std): return (rng.standard_normal((r, c)) * std).astype(np.float32)
+    L.append(f"input-node name=input dim={input_dim}")
+    # tdnn1: relu-batchnorm-layer input=Append(-1,0,1)
+    W = randn(dim, 3 * input_dim, 1.0 / np.sqrt(3 * input_dim)); b = (rng.standard_normal(dim) * 0.1).astype(np.float32)
+    C.append(("tdnn1.affine", "affine", dict(W=W, b=b)))
+    L.append("component-node name=tdnn1.affine component=tdnn1.affine input=Append(Offset(input, -1), input, Offset(input, 1))")
+    # centre the affine on the calibration input so the random first layer is not saturated by the fbank offset
+    h = _splice(x, (-1, 0, 1)) @ W.T + b
+    b -= h.mean(0).astype(np.float32); h = _splice(x, (-1, 0, 1)) @ W.T + b
+    h = np.maximum(h, 0); C.append(("tdnn1.relu", "relu", dict(dim=dim))); L.append("component-node name=tdnn1.relu component=tdnn1.relu input=tdnn1.affine")
+    bn = _bn_from(h); C.append(("tdnn1.batchnorm", "batchnorm", bn)); L.append("component-node name=tdnn1.batchnorm component=tdnn1.batchnorm input=tdnn1.relu")
+    h = _bn_apply(h, bn); prev = "tdnn1.batchnorm"
+    for li, s in enumerate(strides):
+        n = f"tdnnf{li + 2}"
+        o1 = (-s, 0) if s else (0,); o2 = (0, s) if s else (0,)
+        W1 = randn(bottleneck, len(o1) * dim, 1.0 / np.sqrt(len(o1) * dim))
+        W2 = randn(dim, len(o2) * bottleneck, 1.0 / np.sqrt(len(o2) * bottleneck)); b2 = (rng.standard_normal(dim) * 0.1).astype(np.float32)
+        C.append((f"{n}.linear", "tdnn", dict(offsets=o1, W=W1, b=np.zeros(0, np.float32))))
+        L.append(f"component-node name={n}.linear component={n}.linear input={prev}")
+        C.append((f"{n}.affine", "tdnn", dict(offsets=o2, W=W2, b=b2)))
+        L.append(f"component-node name={n}.affine component={n}.affine input={n}.linear")
+        z = _splice(h, o1) @ W1.T                         # valid for t = s .. T-1
+        y = np.maximum(_splice(z, o2) @ W2.T + b2, 0)     # valid for t = s .. T-1-s  (relative to h's origin)
+        C.append((f"{n}.relu", "relu", dict(dim=dim))); L.append(f"component-node name={n}.relu component={n}.relu input={n}.affine")
+        bn = _bn_from(y); C.append((f"{n}.batchnorm", "batchnorm", bn)); L.append(f"component-node name={n}.batchnorm component={n}.batchnorm input={n}.relu")
+        C.append((f"{n}.noop", "noop", dict(dim=dim)))
+        L.append(f"component-node name={n}.noop component={n}.noop input=Sum(Scale({bypass_scale}, {prev}), {n}.batchnorm)")
+        h = (np.float32(bypass_scale) * h[s: h.shape[0] - s] + _bn_apply(y, bn)).astype(np.float32)
+        prev = f"{n}.noop"
+    # prefinal-l (linear-component), prefinal-chain (prefinal-layer), output (output-layer include-log-softmax=false)
+    Wl = randn(prefinal_small, dim, 1.0 / np.sqrt(dim)); C.append(("prefinal-l", "linear", dict(W=Wl)))
+    L.append(f"component-node name=prefinal-l component=prefinal-l input={prev}")
+    h = h @ Wl.T
+    Wa = randn(dim, prefinal_small, 1.0 / np.sqrt(prefinal_small)); ba = (rng.standard_normal(dim) * 0.1).astype(np.float32)
+    C.append(("prefinal-chain.affine", "affine", dict(W=Wa, b=ba))); L.append("component-node name=prefinal-chain.affine component=prefinal-chain.affine input=prefinal-l")
+    h = np.maximum(h @ Wa.T + ba, 0)
+    C.append(("prefinal-chain.relu", "relu", dict(dim=dim))); L.append("component-node name=prefinal-chain.relu component=prefinal-chain.relu input=prefinal-chain.affine")
+    bn = _bn_from(h); C.append(("prefinal-chain.batchnorm1", "batchnorm", bn)); L.append("component-node name=prefinal-chain.batchnorm1 component=prefinal-chain.batchnorm1 input=prefinal-chain.relu")
+    h = _bn_apply(h, bn)
+    Wp = randn(prefinal_small, dim, 1.0 / np.sqrt(dim)); C.append(("prefinal-chain.linear", "linear", dict(W=Wp)))
+    L.append("component-node name=prefinal-chain.linear component=prefinal-chain.linear input=prefinal-chain.batchnorm1")
+    h = h @ Wp.T
+    bn = _bn_from(h); C.append(("prefinal-chain.batchnorm2", "batchnorm", bn)); L.append("component-node name=prefinal-chain.batchnorm2 component=prefinal-chain.batchnorm2 input=prefinal-chain.linear")
+    h = _bn_apply(h, bn)
+    Wo = randn(num_pdfs, prefinal_small, out_std / np.sqrt(prefinal_small)); bo = (rng.standard_normal(num_pdfs) * 0.5).astype(np.float32)
+    C.append(("output.affine", "affine", dict(W=Wo, b=bo))); L.append("component-node name=output.affine component=output.affine input=prefinal-chain.batchnorm2")
+    L.append("output-node name=output input=output.affine objective=linear")
+    return net
+
+def make_tdnn(seed=1, input_dim=40, dim=512, offsets=((-1, 0, 1), (-1, 0, 1), (-3, 0, 3)), num_pdfs=2000, calib_frames=400, out_std=2.5):
+    """BASELINE config 1 '3x512' TDNN: 3 x [TdnnComponent -> ReLU -> BatchNorm] + AffineComponent."""
+    rng = np.random.default_rng(seed)
+    net = SynthNnet(); L = net.config_lines; C = net.components
+    h = _calib_feats(rng, calib_frames, input_dim); L.append(f"input-node name=input dim={input_dim}")
+    prev, d_in = "input", input_dim
+    for i, offs in enumerate(offsets):
+        n = f"tdnn{i + 1}"
+        W = (rng.standard_normal((dim, len(offs) * d_in)) / np.sqrt(len(offs) * d_in)).astype(np.float32); b = (rng.standard_normal(dim) * 0.1).astype(np.float32)
+        y = _splice(h, offs) @ W.T + b
+        if i == 0: b -= y.mean(0).astype(np.float32); y = _splice(h, offs) @ W.T + b
+        y = np.maximum(y, 0)
+        C.append((f"{n}.affine", "tdnn", dict(offsets=offs, W=W, b=b))); L.append(f"component-node name={n}.affine component={n}.affine input={prev}")
+        C.append((f"{n}.relu", "relu", dict(dim=dim))); L.append(f"component-node name={n}.relu component={n}.relu input={n}.affine")
+        bn = _bn_from(y); C.append((f"{n}.batchnorm", "batchnorm", bn)); L.append(f"component-node name={n}.batchnorm component={n}.batchnorm input={n}.relu")
+        h = _bn_apply(y, bn); prev, d_in = f"{n}.batchnorm", dim
+    Wo = (rng.standard_normal((num_pdfs, dim)) * out_std / np.sqrt(dim)).astype(np.float32); bo = (rng.standard_normal(num_pdfs) * 0.5).astype(np.float32)
+    C.append(("output.affine", "affine", dict(W=Wo, b=bo))); L.append(f"component-node name=output.affine component=output.affine input={prev}")
+    L.append("output-node name=output input=output.affine objective=linear")
+    return net
