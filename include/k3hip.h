@@ -65,6 +65,38 @@ int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_
 int k3_cmvn_offline_batch(float *d_feats, int64_t ld, int32_t dim, const int64_t *d_frame_offsets,
                           int32_t num_utts, int32_t norm_vars, double *d_stats, void *stream);
 
+/* ---------------------------------------------------------------- nnet3 forward -------------
+ * Replaces, for "simple" feed-forward TDNN / TDNN-F models: nnet3::NnetComputer::Run over the compiled
+ * program of DecodableNnetSimple (nnet3/nnet-am-decodable-simple.cc:93-276; nnet3/nnet-compute.cc:236-459)
+ * and the GPU reference BatchedStaticNnet3::RunBatch (cudadecoder/batched-static-nnet3.cc:293-365).
+ * Results equal nnet3-compute's: rows t = 0, s, 2s, .. (ceil(T/s) per utterance), edge frames replicated. */
+typedef struct k3_nnet k3_nnet;
+typedef struct k3_nnet_batch k3_nnet_batch;
+typedef struct k3_nnet_info {
+  int32_t input_dim, output_dim, left_context, right_context;
+  int32_t num_components, num_fused_nodes, has_priors;
+  int64_t num_params;
+} k3_nnet_info;
+/* Nnet::Read (nnet3/nnet-nnet.cc:586-628) / AmNnetSimple::Read (nnet3/am-nnet-simple.cc:47-57): text or binary,
+ * raw nnet or final.mdl (TransitionModel + AmNnetSimple).  BatchNorm/dropout are put in test mode
+ * (SetBatchnormTestMode/SetDropoutTestMode, nnet3/nnet-utils.h:188,258) and layers are fused (cf. CollapseModel).
+ * K3_ERR_UNSUPPORTED for component/descriptor types outside the TDNN/TDNN-F family. */
+int k3_nnet_load(const char *model_path, k3_nnet **nnet);
+void k3_nnet_destroy(k3_nnet *nnet);
+int k3_nnet_get_info(const k3_nnet *nnet, k3_nnet_info *info);
+int k3_nnet_get_priors(const k3_nnet *nnet, float *h_priors /* [output_dim] */);
+/* Plans one ragged batch: h_num_frames[u] input frames per utterance, stored back to back (utterance u starts at
+ * row sum_{v<u} h_num_frames[v] of the feature matrix -- the layout k3_feat_compute_batch writes).
+ * h_log_priors (nullable) and acoustic_scale fold DecodableNnetSimple's "-log prior, * acwt" (:268-271) into the
+ * last layer's epilogue.  Owns the activation workspace in HBM. */
+int k3_nnet_batch_create(k3_nnet *nnet, int32_t num_utts, const int32_t *h_num_frames, int32_t frame_subsampling_factor,
+                         const float *h_log_priors, float acoustic_scale, k3_nnet_batch **batch);
+void k3_nnet_batch_destroy(k3_nnet_batch *batch);
+/* total output rows; h_out_offsets (nullable) receives the U+1 row offsets of the utterances in d_out */
+int64_t k3_nnet_batch_output_rows(const k3_nnet_batch *batch, int64_t *h_out_offsets);
+double k3_nnet_batch_flops(const k3_nnet_batch *batch);   /* exact sum of 2*M*N*K over the launched GEMMs */
+int k3_nnet_forward(k3_nnet_batch *batch, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

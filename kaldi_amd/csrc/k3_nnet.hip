@@ -1,0 +1,499 @@
+// k3_nnet.hip -- nnet3 TDNN / TDNN-F forward for gfx950: one fused MFMA kernel per affine layer.
+//
+//   out[r, :] = epilogue( sum_{o in offsets} in[row(r) + shift_o, :] * W_o^T )
+//
+// * The time-stride splice of TdnnComponent (nnet3/nnet-tdnn-component.cc:181-211: one GEMM per offset on a
+//   strided sub-matrix view) is never materialised: the A-tile loader walks K over (offset, column) pairs and
+//   applies the row shift on the fly, so a 2-offset TDNN-F half-layer is ONE GEMM with K = 2*D.
+// * GEMMs run on the FP32 matrix core (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bitwise an fmaf chain)
+//   -- the only MFMA class that meets the 1e-4 log-likelihood parity bound; 157.3 TFLOP/s peak.
+// * Bias, ReLU, test-mode BatchNorm (y = x*scale + offset, nnet-normalize-component.cc:460-462) and the
+//   0.75-scaled bypass Sum(Scale(0.75, x), y) are executed in the GEMM epilogue on the accumulators.
+// * Whole utterances are evaluated at once (no chunking): edge frames are replicated by CLAMPING the row
+//   index of the first layer's loads (DecodableNnetSimple, nnet-am-decodable-simple.cc:154-163), every
+//   layer computes exactly the arithmetic progression of time steps its consumers need (the compiler's
+//   time-step pruning), rows are utterance-major so ragged batches need no padding.
+// * Tiling: 256 threads = 4 wavefronts; block tile 128 x {128|96} x 32, LDS rows padded to 36 floats so
+//   ds_read_b128 fragment loads and ds_write_b128 stages are bank-conflict free; K is permuted inside each
+//   8-wide group so one b128 read feeds 4 consecutive MFMAs; global->register->LDS double buffering;
+//   blockIdx is remapped so that the N-tiles sharing an A panel run on the same XCD (shared L2).
+#include "k3_common.h"
+#include "k3_nnet_model.h"
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 128, kBK = 32, kLdsLd = 36, kThreads = 256;
+constexpr int kMaxOffsets = 8, kMaxOps = 6;
+
+struct TileDesc {      // one per (utterance, 128-row slab) of a node's output
+  int out_row0, nrows; // rows [out_row0, out_row0 + nrows) of the output buffer
+  int in_base;         // input row of local index 0 with shift 0
+  int in_lo, in_hi;    // clamp bounds (absolute input rows) -- edge-frame replication for the first layer
+  int res_base;        // residual row of local index 0
+  int pad0, pad1;
+};
+
+struct GemmParams {
+  const float *A; long long lda; int in_dim, noff, row_stride; int shifts[kMaxOffsets];
+  const float *W; int ldw, Ktot;
+  float *C; long long ldc; int N;
+  const float *bias;
+  int nops; int op_kind[kMaxOps]; const float *op_scale[kMaxOps]; const float *op_offset[kMaxOps];
+  const float *R; long long ldr; int res_row_stride; float res_scale;
+  const TileDesc *tiles; int num_m_tiles, num_n_tiles;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
+  constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
+  constexpr int A_LOADS = kBM * kBK / 4 / kThreads;   // float4 loads per thread per k-tile (4)
+  constexpr int B_LOADS = BN * kBK / 4 / kThreads;    // 4 or 3
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *As = reinterpret_cast<float *>(smem);                         // [2][kBM][kLdsLd]
+  float *Bs = As + 2 * kBM * kLdsLd;                                   // [2][BN][kLdsLd]
+
+  // XCD-aware remap (T1): the dispatcher places block b on XCD b % 8; give each XCD a contiguous logical range
+  const int nblocks = p.num_m_tiles * p.num_n_tiles;
+  int bid = blockIdx.x;
+  { const int per = nblocks / 8; if (bid < per * 8) bid = (bid % 8) * per + bid / 8; }
+  const int m_tile = bid / p.num_n_tiles, n_tile = bid % p.num_n_tiles;
+  const TileDesc td = p.tiles[m_tile];
+  const int n0 = n_tile * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int ld_row = tid >> 3, ld_kv = (tid & 7) * 4;
+
+  // per-thread row bookkeeping for the A loader (rows beyond nrows re-read the last valid row; never stored)
+  int a_row_local[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; i++) a_row_local[i] = min(i * 32 + ld_row, td.nrows - 1) * p.row_stride + td.in_base;
+
+  f32x4 ra[A_LOADS], rb[B_LOADS];
+  auto load_tiles = [&](int kt) {
+    const int kglob = kt * kBK + ld_kv;
+    const int oi = kglob / p.in_dim, col = kglob - oi * p.in_dim;
+    const bool kvalid = kglob < p.Ktot;
+    const int shift = kvalid ? p.shifts[oi] : 0;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; i++) {
+      if (kvalid) {
+        const int row = clampi(a_row_local[i] + shift, td.in_lo, td.in_hi);
+        ra[i] = *reinterpret_cast<const f32x4 *>(p.A + (long long)row * p.lda + col);
+      } else {
+        ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; i++)   // W is zero-padded to [Npad x Kpad]: no bounds checks
+      rb[i] = *reinterpret_cast<const f32x4 *>(p.W + (long long)(n0 + i * 32 + ld_row) * p.ldw + kglob);
+  };
+  auto store_tiles = [&](int buf) {
+    float *a = As + buf * kBM * kLdsLd, *b = Bs + buf * BN * kLdsLd;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; i++) *reinterpret_cast<f32x4 *>(a + (i * 32 + ld_row) * kLdsLd + ld_kv) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; i++) *reinterpret_cast<f32x4 *>(b + (i * 32 + ld_row) * kLdsLd + ld_kv) = rb[i];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.0f;
+
+  const int nk = (p.Ktot + kBK - 1) / kBK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float *a = As + buf * kBM * kLdsLd + (wm * WM + frag_row) * kLdsLd + frag_k;
+    const float *b = Bs + buf * BN * kLdsLd + (wn * WN + frag_row) * kLdsLd + frag_k;
+#pragma unroll
+    for (int kk = 0; kk < kBK / 8; kk++) {
+      f32x4 fa[MI], fb[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++) fa[mi] = *reinterpret_cast<const f32x4 *>(a + mi * 32 * kLdsLd + kk * 8);
+#pragma unroll
+      for (int ni = 0; ni < NI; ni++) fb[ni] = *reinterpret_cast<const f32x4 *>(b + ni * 32 * kLdsLd + kk * 8);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+    const int col = n0 + wn * WN + ni * 32 + (lane & 31);
+    if (col >= p.N) continue;
+    const float bias = p.bias ? p.bias[col] : 0.0f;
+    float sc[kMaxOps], of[kMaxOps];
+#pragma unroll
+    for (int o = 0; o < kMaxOps; o++) {
+      sc[o] = 1.0f; of[o] = 0.0f;
+      if (o < p.nops && p.op_kind[o] == k3::kEpiScaleOffset) { sc[o] = p.op_scale[o][col]; of[o] = p.op_offset[o][col]; }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int lrow = wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (lrow >= td.nrows) continue;
+        float v = acc[mi][ni][r] + bias;
+#pragma unroll
+        for (int o = 0; o < kMaxOps; o++) {
+          if (o < p.nops) {
+            const int kind = p.op_kind[o];
+            if (kind == k3::kEpiRelu) v = fmaxf(v, 0.0f);
+            else if (kind == k3::kEpiScaleOffset) v = v * sc[o] + of[o];
+            else v = p.res_scale * p.R[(long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + col] + v;
+          }
+        }
+        p.C[(long long)(td.out_row0 + lrow) * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+// element-wise fused node without a GEMM (rare: a ReLU/BatchNorm/NoOp whose input has several consumers)
+__global__ __launch_bounds__(256) void k3_elementwise_kernel(GemmParams p) {
+  const TileDesc td = p.tiles[blockIdx.x];
+  for (int idx = threadIdx.x; idx < td.nrows * p.N; idx += 256) {
+    const int lrow = idx / p.N, col = idx - lrow * p.N;
+    const int row = clampi(td.in_base + lrow * p.row_stride + p.shifts[0], td.in_lo, td.in_hi);
+    float v = p.A[(long long)row * p.lda + col];
+    for (int o = 0; o < p.nops; o++) {
+      const int kind = p.op_kind[o];
+      if (kind == k3::kEpiRelu) v = fmaxf(v, 0.0f);
+      else if (kind == k3::kEpiScaleOffset) v = v * p.op_scale[o][col] + p.op_offset[o][col];
+      else v = p.res_scale * p.R[(long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + col] + v;
+    }
+    p.C[(long long)(td.out_row0 + lrow) * p.ldc + col] = v;
+  }
+}
+
+int gcd_i(int a, int b) { a = abs(a); b = abs(b); while (b) { int t = a % b; a = b; b = t; } return a; }
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct DeviceNode {     // model-level (batch independent) device data of one fused node
+  float *W = nullptr; int ldw = 0, npad = 0, bn = 128;
+  float *bias = nullptr;
+  std::vector<float *> op_scale, op_offset;   // per op (null when not scale/offset)
+};
+
+}  // namespace
+
+struct k3_nnet {
+  k3::FusedModel fm;
+  std::vector<DeviceNode> dev;
+  std::vector<void *> allocs;
+  bool uploaded = false;
+  ~k3_nnet() { for (void *p : allocs) (void)hipFree(p); }
+};
+
+struct k3_nnet_batch {
+  k3_nnet *net = nullptr;
+  int num_utts = 0, subsampling = 1;
+  std::vector<int> num_frames;
+  std::vector<long long> out_offsets;           // [U+1] rows of the output matrix
+  long long total_in_rows = 0, total_out_rows = 0;
+  double flops = 0.0;
+  // per node
+  std::vector<GemmParams> params;
+  std::vector<int> node_a, node_r, node_g;      // first time, right extension, step
+  std::vector<void *> allocs;
+  float *out_scale = nullptr, *out_offset = nullptr;
+  ~k3_nnet_batch() { for (void *p : allocs) (void)hipFree(p); }
+};
+
+namespace {
+
+template <typename T>
+int upload(std::vector<void *> *allocs, const std::vector<T> &h, T **d) {
+  *d = nullptr;
+  if (h.empty()) return K3_OK;
+  K3_HIP_CHECK(hipMalloc((void **)d, h.size() * sizeof(T)));
+  allocs->push_back(*d);
+  K3_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return K3_OK;
+}
+
+void free_all(std::vector<void *> *allocs) {
+  for (void *p : *allocs) (void)hipFree(p);
+  allocs->clear();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C ABI ----
+// weights are uploaded lazily (first batch) so that k3_nnet_load / k3_nnet_get_info work without a GPU
+static int ensure_uploaded(k3_nnet *net) {
+  k3::FusedModel &fm = net->fm;
+  if (net->uploaded) return K3_OK;
+  net->dev.resize(fm.nodes.size());
+  for (size_t i = 0; i < fm.nodes.size(); i++) {
+    const k3::FusedNode &f = fm.nodes[i];
+    DeviceNode &d = net->dev[i];
+    if (f.has_gemm) {
+      const int K = (int)f.offsets.size() * f.in_dim, N = f.out_dim;
+      d.bn = (N % 96 == 0 && N % 128 != 0) ? 96 : 128;
+      d.npad = (int)align_up(N, d.bn); d.ldw = (int)align_up(K, kBK);
+      std::vector<float> wp((size_t)d.npad * d.ldw, 0.0f);
+      for (int n = 0; n < N; n++) memcpy(&wp[(size_t)n * d.ldw], &f.W[(size_t)n * K], sizeof(float) * K);
+      int rc = upload(&net->allocs, wp, &d.W); if (rc) { return rc; }
+      rc = upload(&net->allocs, f.bias, &d.bias); if (rc) { return rc; }
+    }
+    d.op_scale.assign(f.ops.size(), nullptr); d.op_offset.assign(f.ops.size(), nullptr);
+    for (size_t o = 0; o < f.ops.size(); o++)
+      if (f.ops[o].kind == k3::kEpiScaleOffset) {
+        int rc = upload(&net->allocs, f.ops[o].scale, &d.op_scale[o]); if (rc) { return rc; }
+        rc = upload(&net->allocs, f.ops[o].offset, &d.op_offset[o]); if (rc) { return rc; }
+      }
+  }
+  net->uploaded = true;
+  return K3_OK;
+}
+
+extern "C" int k3_nnet_load(const char *path, k3_nnet **out) {
+  K3_REQUIRE(path && out, "k3_nnet_load: null argument");
+  k3::RawModel raw; std::string err;
+  if (!k3::ReadModelFile(path, &raw, &err)) { k3::set_error("k3_nnet_load: %s", err.c_str()); return K3_ERR_ARG; }
+  std::unique_ptr<k3_nnet> net(new k3_nnet());
+  if (!k3::FuseModel(raw, &net->fm, &err)) { k3::set_error("k3_nnet_load: %s: %s", path, err.c_str()); return K3_ERR_UNSUPPORTED; }
+  for (const k3::FusedNode &f : net->fm.nodes) {
+    if ((int)f.offsets.size() > kMaxOffsets || (int)f.ops.size() > kMaxOps) {
+      k3::set_error("k3_nnet_load: node %s has %zu offsets / %zu epilogue ops (limits %d / %d)", f.name.c_str(), f.offsets.size(), f.ops.size(), kMaxOffsets, kMaxOps);
+      return K3_ERR_UNSUPPORTED;
+    }
+    if (f.in_dim % 4 != 0 && f.has_gemm) {
+      k3::set_error("k3_nnet_load: node %s input dim %d is not a multiple of 4 (vector loads)", f.name.c_str(), f.in_dim);
+      return K3_ERR_UNSUPPORTED;
+    }
+  }
+  *out = net.release();
+  return K3_OK;
+}
+
+extern "C" void k3_nnet_destroy(k3_nnet *net) { delete net; }
+
+extern "C" int k3_nnet_get_info(const k3_nnet *net, k3_nnet_info *info) {
+  K3_REQUIRE(net && info, "k3_nnet_get_info: null argument");
+  info->input_dim = net->fm.input_dim; info->output_dim = net->fm.output_dim;
+  info->left_context = net->fm.left_context; info->right_context = net->fm.right_context;
+  info->num_components = net->fm.num_components; info->num_fused_nodes = (int)net->fm.nodes.size();
+  info->has_priors = net->fm.priors.empty() ? 0 : 1; info->num_params = net->fm.num_params;
+  return K3_OK;
+}
+
+extern "C" int k3_nnet_get_priors(const k3_nnet *net, float *h_priors) {
+  K3_REQUIRE(net && h_priors, "k3_nnet_get_priors: null argument");
+  K3_REQUIRE(!net->fm.priors.empty(), "k3_nnet_get_priors: model has no priors");
+  memcpy(h_priors, net->fm.priors.data(), sizeof(float) * net->fm.priors.size());
+  return K3_OK;
+}
+
+extern "C" void k3_nnet_batch_destroy(k3_nnet_batch *b) { delete b; }
+
+extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_t *h_num_frames, int32_t subsampling,
+                                    const float *h_log_priors, float acoustic_scale, k3_nnet_batch **out) {
+  K3_REQUIRE(net && h_num_frames && out && num_utts > 0 && subsampling >= 1, "k3_nnet_batch_create: bad argument");
+  { const int rc = ensure_uploaded(net); if (rc) return rc; }
+  const k3::FusedModel &fm = net->fm;
+  const int nn = (int)fm.nodes.size();
+  std::unique_ptr<k3_nnet_batch> b(new k3_nnet_batch());
+  b->net = net; b->num_utts = num_utts; b->subsampling = subsampling;
+  b->num_frames.assign(h_num_frames, h_num_frames + num_utts);
+  for (int u = 0; u < num_utts; u++) K3_REQUIRE(h_num_frames[u] > 0, "k3_nnet_batch_create: utterance with no frames");
+
+  // ---- which time steps must each node produce?  t = a + k*g, k >= 0, up to t_last_out(u) + r
+  std::vector<int> A(nn, 0), R(nn, 0), G(nn, 0); std::vector<char> used(nn, 0);
+  A[fm.output_node] = 0; R[fm.output_node] = 0; G[fm.output_node] = subsampling; used[fm.output_node] = 1;
+  {
+    // consumers are always later nodes, so one backward sweep suffices; a node may have several consumers
+    std::vector<std::vector<std::pair<int, int>>> anchors(nn);   // (anchor time, step) contributed by consumers
+    std::vector<int> rmax(nn, -(1 << 30));
+    for (int i = nn - 1; i >= 0; i--) {
+      if (i != fm.output_node) {
+        if (anchors[i].empty()) continue;          // unused node (e.g. feeds only an unused output)
+        int a = 1 << 30, g = 0;
+        for (auto &an : anchors[i]) a = std::min(a, an.first);
+        for (auto &an : anchors[i]) { g = gcd_i(g, an.second); g = gcd_i(g, an.first - a); }
+        A[i] = a; G[i] = g; R[i] = rmax[i]; used[i] = 1;
+      }
+      const k3::FusedNode &f = fm.nodes[i];
+      auto contribute = [&](int src, int off) {
+        if (src < 0) return;
+        anchors[src].push_back({A[i] + off, G[i]});
+        rmax[src] = std::max(rmax[src], R[i] + off);
+      };
+      for (int o : f.offsets) contribute(f.input, o);
+      for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual) contribute(op.res_node, 0);
+    }
+  }
+  b->node_a = A; b->node_r = R; b->node_g = G;
+
+  // ---- row bookkeeping
+  auto n_out = [&](int u) { return (b->num_frames[u] + subsampling - 1) / subsampling; };
+  auto rows_of = [&](int i, int u) { const int tlast = (n_out(u) - 1) * subsampling; return (tlast + R[i] - A[i]) / G[i] + 1; };
+  std::vector<std::vector<long long>> rowoff(nn, std::vector<long long>(num_utts + 1, 0));
+  for (int i = 0; i < nn; i++) if (used[i]) for (int u = 0; u < num_utts; u++) rowoff[i][u + 1] = rowoff[i][u] + rows_of(i, u);
+  std::vector<long long> featoff(num_utts + 1, 0);
+  for (int u = 0; u < num_utts; u++) featoff[u + 1] = featoff[u] + b->num_frames[u];
+  b->total_in_rows = featoff[num_utts];
+  b->out_offsets = rowoff[fm.output_node]; b->total_out_rows = b->out_offsets[num_utts];
+  for (int i = 0; i < nn; i++) K3_REQUIRE(rowoff[i][num_utts] < (1ll << 31), "k3_nnet_batch_create: more than 2^31 rows in one batch");
+
+  // ---- activation buffers with liveness-based reuse
+  std::vector<int> last_use(nn, -1);
+  for (int i = 0; i < nn; i++) {
+    if (!used[i]) continue;
+    if (fm.nodes[i].input >= 0) last_use[fm.nodes[i].input] = i;
+    for (const k3::EpiOp &op : fm.nodes[i].ops) if (op.kind == k3::kEpiResidual && op.res_node >= 0) last_use[op.res_node] = i;
+  }
+  struct Slot { size_t bytes; int busy_until; float *ptr; };
+  std::vector<Slot> slots; std::vector<int> slot_of(nn, -1); std::vector<int> ld(nn, 0);
+  for (int i = 0; i < nn; i++) {
+    if (!used[i] || i == fm.output_node) continue;
+    ld[i] = (int)align_up(fm.nodes[i].out_dim, 4);
+    const size_t need = (size_t)rowoff[i][num_utts] * ld[i] * sizeof(float);
+    int best = -1;
+    for (size_t s = 0; s < slots.size(); s++) if (slots[s].busy_until < i && (best < 0 || slots[s].bytes > slots[best].bytes)) best = (int)s;
+    if (best < 0) { slots.push_back({need, last_use[i], nullptr}); best = (int)slots.size() - 1; }
+    else { slots[best].bytes = std::max(slots[best].bytes, need); slots[best].busy_until = last_use[i]; }
+    slot_of[i] = best;
+  }
+  for (Slot &s : slots) { K3_HIP_CHECK(hipMalloc((void **)&s.ptr, std::max<size_t>(s.bytes, 256))); b->allocs.push_back(s.ptr); }
+
+  // ---- output transform: (x - log_prior) * acwt as one more scale/offset op (nnet-am-decodable-simple.cc:268-271)
+  const bool out_xform = (h_log_priors != nullptr) || acoustic_scale != 1.0f;
+  if (out_xform) {
+    std::vector<float> sc(fm.output_dim, acoustic_scale), of(fm.output_dim, 0.0f);
+    if (h_log_priors) for (int i = 0; i < fm.output_dim; i++) of[i] = -h_log_priors[i] * acoustic_scale;
+    int rc = upload(&b->allocs, sc, &b->out_scale); if (rc) { return rc; }
+    rc = upload(&b->allocs, of, &b->out_offset); if (rc) { return rc; }
+  }
+
+  // ---- per-node launch parameters + tile tables
+  b->params.resize(nn);
+  for (int i = 0; i < nn; i++) {
+    GemmParams &p = b->params[i]; memset(&p, 0, sizeof(p));
+    if (!used[i]) { p.num_m_tiles = 0; continue; }
+    const k3::FusedNode &f = fm.nodes[i]; const DeviceNode &d = net->dev[i];
+    const int src = f.input;
+    const int g_in = src < 0 ? 1 : G[src], a_in = src < 0 ? 0 : A[src];
+    p.in_dim = f.in_dim; p.noff = (int)f.offsets.size(); p.row_stride = G[i] / g_in;
+    for (int o = 0; o < p.noff; o++) {
+      const int num = A[i] + f.offsets[o] - a_in;
+      if (num % g_in != 0 || G[i] % g_in != 0) { k3::set_error("k3_nnet_batch_create: internal time-grid error at node %s", f.name.c_str()); return K3_ERR_ARG; }
+      p.shifts[o] = num / g_in;
+    }
+    p.A = src < 0 ? nullptr : slots[slot_of[src]].ptr;       // network input pointer is patched in k3_nnet_forward
+    p.lda = src < 0 ? 0 : ld[src];
+    p.W = d.W; p.ldw = d.ldw; p.Ktot = p.noff * f.in_dim; p.N = f.out_dim; p.bias = d.bias;
+    p.C = (i == fm.output_node) ? nullptr : slots[slot_of[i]].ptr; p.ldc = ld[i];
+    p.nops = (int)f.ops.size();
+    int res = -2;
+    for (int o = 0; o < p.nops; o++) {
+      p.op_kind[o] = f.ops[o].kind; p.op_scale[o] = d.op_scale[o]; p.op_offset[o] = d.op_offset[o];
+      if (f.ops[o].kind == k3::kEpiResidual) { res = f.ops[o].res_node; p.res_scale = f.ops[o].res_scale; }
+    }
+    if (i == fm.output_node && out_xform) {
+      if (p.nops >= kMaxOps) { k3::set_error("k3_nnet_batch_create: too many epilogue ops on the output node"); return K3_ERR_UNSUPPORTED; }
+      p.op_kind[p.nops] = k3::kEpiScaleOffset; p.op_scale[p.nops] = b->out_scale; p.op_offset[p.nops] = b->out_offset; p.nops++;
+    }
+    int g_res = 1, a_res = 0;
+    if (res >= -1) {
+      g_res = res < 0 ? 1 : G[res]; a_res = res < 0 ? 0 : A[res];
+      p.R = res < 0 ? nullptr : slots[slot_of[res]].ptr; p.ldr = res < 0 ? 0 : ld[res];
+      p.res_row_stride = G[i] / g_res;
+    }
+    std::vector<TileDesc> tiles;
+    for (int u = 0; u < num_utts; u++) {
+      const int rows = rows_of(i, u);
+      for (int r0 = 0; r0 < rows; r0 += kBM) {
+        TileDesc t; memset(&t, 0, sizeof t);
+        t.out_row0 = (int)rowoff[i][u] + r0; t.nrows = std::min(kBM, rows - r0);
+        if (src < 0) { t.in_base = (int)featoff[u] + r0 * p.row_stride; t.in_lo = (int)featoff[u]; t.in_hi = (int)featoff[u + 1] - 1; }
+        else { t.in_base = (int)rowoff[src][u] + r0 * p.row_stride; t.in_lo = (int)rowoff[src][u]; t.in_hi = (int)rowoff[src][u + 1] - 1; }
+        if (res >= -1) {
+          const int base = (A[i] - a_res) / g_res;
+          t.res_base = (int)(res < 0 ? featoff[u] : rowoff[res][u]) + base + r0 * p.res_row_stride;
+        }
+        tiles.push_back(t);
+      }
+      if (f.has_gemm) b->flops += 2.0 * rows * (double)p.Ktot * f.out_dim;
+    }
+    TileDesc *dt = nullptr; int rc = upload(&b->allocs, tiles, &dt); if (rc) { return rc; }
+    p.tiles = dt; p.num_m_tiles = (int)tiles.size();
+    p.num_n_tiles = f.has_gemm ? d.npad / d.bn : 1;
+  }
+  *out = b.release();
+  return K3_OK;
+}
+
+extern "C" int64_t k3_nnet_batch_output_rows(const k3_nnet_batch *b, int64_t *h_out_offsets) {
+  if (!b) return -1;
+  if (h_out_offsets) for (size_t i = 0; i < b->out_offsets.size(); i++) h_out_offsets[i] = b->out_offsets[i];
+  return b->total_out_rows;
+}
+
+extern "C" double k3_nnet_batch_flops(const k3_nnet_batch *b) { return b ? b->flops : -1.0; }
+
+extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream) {
+  K3_REQUIRE(b && d_feats && d_out, "k3_nnet_forward: null argument");
+  const k3::FusedModel &fm = b->net->fm;
+  K3_REQUIRE(ld_feats >= fm.input_dim && ld_feats % 4 == 0 && ((uintptr_t)d_feats & 15) == 0, "k3_nnet_forward: features must be 16-byte aligned with ld % 4 == 0");
+  K3_REQUIRE(ld_out >= fm.output_dim, "k3_nnet_forward: ld_out < output dim");
+  static bool attr_set = false;
+  if (!attr_set) {
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<128, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<96, 32, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (size_t i = 0; i < fm.nodes.size(); i++) {
+    GemmParams p = b->params[i];
+    if (p.num_m_tiles == 0) continue;
+    const k3::FusedNode &f = fm.nodes[i];
+    if (f.input < 0) { p.A = d_feats; p.lda = ld_feats; }
+    for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual && op.res_node < 0) { p.R = d_feats; p.ldr = ld_feats; }
+    if ((int)i == fm.output_node) { p.C = d_out; p.ldc = ld_out; }
+    if (!f.has_gemm) {
+      hipLaunchKernelGGL(k3_elementwise_kernel, dim3(p.num_m_tiles), dim3(256), 0, st, p);
+    } else {
+      const int blocks = p.num_m_tiles * p.num_n_tiles;
+      if (b->net->dev[i].bn == 96) {
+        const size_t lds = 2 * (kBM + 96) * kLdsLd * sizeof(float);
+        hipLaunchKernelGGL((k3_tdnn_gemm_kernel<96, 32, 96>), dim3(blocks), dim3(kThreads), lds, st, p);
+      } else {
+        const size_t lds = 2 * (kBM + 128) * kLdsLd * sizeof(float);
+        hipLaunchKernelGGL((k3_tdnn_gemm_kernel<128, 64, 64>), dim3(blocks), dim3(kThreads), lds, st, p);
+      }
+    }
+    K3_HIP_CHECK(hipGetLastError());
+  }
+  return K3_OK;
+}

@@ -18,6 +18,11 @@ class FeatOpts(ctypes.Structure):
                 ("raw_energy", ctypes.c_int32), ("htk_compat", ctypes.c_int32), ("use_log_fbank", ctypes.c_int32), ("use_power", ctypes.c_int32),
                 ("num_ceps", ctypes.c_int32), ("cepstral_lifter", ctypes.c_float), ("feature_type", ctypes.c_int32), ("vtln_warp", ctypes.c_float)]
 
+class NnetInfo(ctypes.Structure):
+    """k3_nnet_info (include/k3hip.h)"""
+    _fields_ = [("input_dim", ctypes.c_int32), ("output_dim", ctypes.c_int32), ("left_context", ctypes.c_int32), ("right_context", ctypes.c_int32),
+                ("num_components", ctypes.c_int32), ("num_fused_nodes", ctypes.c_int32), ("has_priors", ctypes.c_int32), ("num_params", ctypes.c_int64)]
+
 WINDOW_TYPES = {"hanning": 0, "sine": 1, "hamming": 2, "povey": 3, "rectangular": 4, "blackman": 5}
 
 _lib = None
@@ -41,6 +46,15 @@ def load():
     L.k3_feat_num_frames.argtypes = [vp, i64]; L.k3_feat_num_frames.restype = i32
     L.k3_feat_compute_batch.argtypes = [vp, vp, vp, vp, i32, i64, vp, i64, vp]
     L.k3_cmvn_offline_batch.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp]
+    L.k3_nnet_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.k3_nnet_destroy.argtypes = [vp]; L.k3_nnet_destroy.restype = None
+    L.k3_nnet_get_info.argtypes = [vp, ctypes.POINTER(NnetInfo)]
+    L.k3_nnet_get_priors.argtypes = [vp, vp]
+    L.k3_nnet_batch_create.argtypes = [vp, i32, vp, i32, vp, ctypes.c_float, ctypes.POINTER(vp)]
+    L.k3_nnet_batch_destroy.argtypes = [vp]; L.k3_nnet_batch_destroy.restype = None
+    L.k3_nnet_batch_output_rows.argtypes = [vp, vp]; L.k3_nnet_batch_output_rows.restype = i64
+    L.k3_nnet_batch_flops.argtypes = [vp]; L.k3_nnet_batch_flops.restype = ctypes.c_double
+    L.k3_nnet_forward.argtypes = [vp, vp, i64, vp, i64, vp]
     _lib = L
     return L
 

@@ -103,13 +103,14 @@ def _bn_apply(x, p, eps=1e-3):
     return ((x - p["mean"]) * scale).astype(np.float32)
 
 def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0) + (3,) * 12, prefinal_small=192,
-               num_pdfs=6024, bypass_scale=0.75, calib_frames=600, out_std=2.5):
+               num_pdfs=6024, bypass_scale=0.75, calib_frames=600, out_std=2.5, calib_feats=None):
     """The 17-layer LibriSpeech TDNN-F layout (egs/librispeech/s5/local/chain/tuning/run_tdnn_1d.sh:220-249 minus
     ivector/LDA/xent/dropout) at mini_librispeech widths (run_tdnn_1k.sh:185-202): '17L-768/96-6024', ~6.28 M params.
     Node/component names follow steps/libs/nnet3/xconfig (composite_layers.py:68-227)."""
     rng = np.random.default_rng(seed)
     net = SynthNnet(); L = net.config_lines; C = net.components
-    x = _calib_feats(rng, calib_frames, input_dim)     # calibration activations, shrinking as context is consumed
+    # calibration activations (shrinking as context is consumed); pass real features of the workload when available
+    x = np.asarray(calib_feats, np.float32) if calib_feats is not None else _calib_feats(rng, calib_frames, input_dim)
     def randn(r, c, std): return (rng.standard_normal((r, c)) * std).astype(np.float32)
     L.append(f"input-node name=input dim={input_dim}")
     # tdnn1: relu-batchnorm-layer input=Append(-1,0,1)

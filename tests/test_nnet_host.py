@@ -1,0 +1,48 @@
+"""CPU: the product's model reader + layer fuser (host logic of k3_nnet_load) and the oracle reading the
+same Kaldi-format files; the oracle is pinned to the reference's nnet3-compute by the committed fixture."""
+import os, numpy as np, pytest
+from kaldi_amd import synth
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+def test_reader_and_fuser_on_synth_tdnnf(tmp_path):
+    import __graft_entry__ as ge; ge.build()
+    from kaldi_amd import nnet3
+    net = synth.make_tdnnf(seed=3, dim=64, bottleneck=16, strides=(1, 0, 3, 3), prefinal_small=32, num_pdfs=120, calib_frames=300)
+    p = tmp_path / "m.raw"; net.write(str(p))
+    n = nnet3.Nnet(p)
+    i = n.info
+    assert (i.input_dim, i.output_dim) == (40, 120)
+    assert (i.left_context, i.right_context) == (1 + 1 + 0 + 3 + 3, 1 + 1 + 0 + 3 + 3)
+    assert i.num_params == net.num_params()
+    # tdnn1 + 4 x (linear, affine) + prefinal-l + prefinal affine + prefinal linear + output = 13 fused GEMM nodes
+    assert i.num_fused_nodes == 13 and i.num_components == len(net.components)
+
+def test_reader_accepts_reference_written_files():
+    """text and binary files written by the REFERENCE's nnet3-copy (fixture) parse to the same model."""
+    import __graft_entry__ as ge; ge.build()
+    from kaldi_amd import nnet3
+    a = nnet3.Nnet(os.path.join(GOLD, "nnet_small.txt")).info
+    b = nnet3.Nnet(os.path.join(GOLD, "nnet_small.raw")).info
+    for f, _ in a._fields_:
+        assert getattr(a, f) == getattr(b, f), f
+    assert a.num_fused_nodes == 11 and a.output_dim == 96   # tdnn1 + 3 x (linear, affine) + prefinal-l + 2 prefinal + output
+
+def test_oracle_vs_reference_nnet3_compute():
+    from oracle import nnet3_oracle as no
+    g = np.load(os.path.join(GOLD, "nnet_small_io.npz"))
+    for fmt in ("txt", "raw"):
+        net = no.read_nnet(os.path.join(GOLD, "nnet_small." + fmt))
+        for s in (1, 3):
+            got = no.compute(net, g["feats"], s)
+            ref = g[f"ref_out_{fmt}_s{s}"]
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() <= 1e-4, np.abs(got - ref).max()
+
+def test_unsupported_model_fails_loudly(tmp_path):
+    import __graft_entry__ as ge; ge.build()
+    from kaldi_amd import nnet3, lib
+    txt = open(os.path.join(GOLD, "nnet_small.txt")).read().replace("<RectifiedLinearComponent>", "<SigmoidComponent>").replace("</RectifiedLinearComponent>", "</SigmoidComponent>")
+    p = tmp_path / "bad.txt"; p.write_text(txt)
+    with pytest.raises(lib.K3Error, match="SigmoidComponent"):
+        nnet3.Nnet(p)
