@@ -238,6 +238,8 @@ def _cfg(line):
     return kind, d
 
 # ----------------------------------------------------------------------------- evaluation ----
+_DTYPE = np.float32
+def _F(): return _DTYPE
 class _Seq:
     """values of one node for integer times t0 .. t0+len-1 (dense, step 1)."""
     def __init__(self, t0, x): self.t0, self.x = t0, x
@@ -265,28 +267,28 @@ def _apply_component(c, seq):
     """seq -> seq for components without time context; TdnnComponent handled here too."""
     x, f, t = seq.x, c.fields, c.type
     if t in ("NaturalGradientAffineComponent", "AffineComponent", "FixedAffineComponent"):
-        return _Seq(seq.t0, (x @ f["<LinearParams>"].T + f["<BiasParams>"]).astype(np.float32))
+        return _Seq(seq.t0, (x @ f["<LinearParams>"].T + f["<BiasParams>"]).astype(_F()))
     if t == "LinearComponent":
-        return _Seq(seq.t0, (x @ f["<Params>"].T).astype(np.float32))
+        return _Seq(seq.t0, (x @ f["<Params>"].T).astype(_F()))
     if t == "TdnnComponent":
         offs = [int(v) for v in np.atleast_1d(f["<TimeOffsets>"])]
         W = f["<LinearParams>"]; D = W.shape[1] // len(offs)
         lo, hi = seq.t0 - min(offs), seq.t1 - max(offs)
         n = hi - lo + 1
-        y = np.zeros((n, W.shape[0]), np.float32)
+        y = np.zeros((n, W.shape[0]), _F())
         if f["<BiasParams>"].size: y += f["<BiasParams>"]
         for i, o in enumerate(offs):
             s = lo + o - seq.t0
             y += x[s:s + n] @ W[:, i * D:(i + 1) * D].T
-        return _Seq(lo, y.astype(np.float32))
-    if t == "RectifiedLinearComponent": return _Seq(seq.t0, np.maximum(x, np.float32(0)))
+        return _Seq(lo, y.astype(_F()))
+    if t == "RectifiedLinearComponent": return _Seq(seq.t0, np.maximum(x, _F()(0)))
     if t in ("NoOpComponent", "DropoutComponent", "GeneralDropoutComponent"): return seq
     if t == "BatchNormComponent":
         sc, of = _bn_scale_offset(c)
-        return _Seq(seq.t0, (x * sc + of).astype(np.float32))
+        return _Seq(seq.t0, (x * sc + of).astype(_F()))
     if t == "LogSoftmaxComponent":
         m = x.max(axis=1, keepdims=True)
-        return _Seq(seq.t0, (x - m - np.log(np.exp(x - m).sum(axis=1, keepdims=True))).astype(np.float32))
+        return _Seq(seq.t0, (x - m - np.log(np.exp(x - m).sum(axis=1, keepdims=True))).astype(_F()))
     raise ValueError("oracle: unsupported component type " + t)
 
 def _eval_desc(d, vals):
@@ -295,7 +297,7 @@ def _eval_desc(d, vals):
     if k == "offset":
         s = _eval_desc(d[1], vals); return _Seq(s.t0 - d[2], s.x)      # value at t is src at t+off
     if k == "scale":
-        s = _eval_desc(d[2], vals); return _Seq(s.t0, (np.float32(d[1]) * s.x).astype(np.float32))
+        s = _eval_desc(d[2], vals); return _Seq(s.t0, (_F()(d[1]) * s.x).astype(_F()))
     parts = [_eval_desc(p, vals) for p in d[1]]
     lo, hi = max(p.t0 for p in parts), min(p.t1 for p in parts)
     cut = [p.x[lo - p.t0: hi - p.t0 + 1] for p in parts]
@@ -303,7 +305,7 @@ def _eval_desc(d, vals):
     if k == "sum":
         y = cut[0].copy()
         for c in cut[1:]: y = y + c
-        return _Seq(lo, y.astype(np.float32))
+        return _Seq(lo, y.astype(_F()))
     raise ValueError(k)
 
 def context(net):
@@ -328,9 +330,19 @@ def context(net):
             return dctx(parse_descriptor(a["input"]))
     raise ValueError("no output node")
 
-def compute(net, feats, frame_subsampling_factor=1, log_priors=None, acoustic_scale=1.0):
-    """nnet3-compute semantics for one utterance: feats [T x input_dim] -> [ceil(T/s) x output_dim]."""
-    feats = np.asarray(feats, np.float32); T = feats.shape[0]; s = frame_subsampling_factor
+def compute(net, feats, frame_subsampling_factor=1, log_priors=None, acoustic_scale=1.0, dtype=np.float32):
+    """nnet3-compute semantics for one utterance: feats [T x input_dim] -> [ceil(T/s) x output_dim].
+    dtype=np.float64 evaluates the same graph in double precision (the value both float32 implementations --
+    the reference's MKL sgemm path and the MFMA kernel -- are roundings of); default float32 like BaseFloat."""
+    global _DTYPE
+    _DTYPE = dtype
+    try:
+        return _compute(net, feats, frame_subsampling_factor, log_priors, acoustic_scale)
+    finally:
+        _DTYPE = np.float32
+
+def _compute(net, feats, frame_subsampling_factor, log_priors, acoustic_scale):
+    feats = np.asarray(feats, np.float32).astype(_F()); T = feats.shape[0]; s = frame_subsampling_factor
     L, R = context(net)
     n_out = (T + s - 1) // s
     t_last = (n_out - 1) * s
@@ -347,6 +359,6 @@ def compute(net, feats, frame_subsampling_factor=1, log_priors=None, acoustic_sc
             o = _eval_desc(parse_descriptor(a["input"]), vals)
             assert o.t0 <= 0 and o.t1 >= t_last, (o.t0, o.t1, t_last)
             out = o.x[(-o.t0):(t_last - o.t0 + 1):s].copy()
-    if log_priors is not None: out = out - np.asarray(log_priors, np.float32)      # :268-269
-    if acoustic_scale != 1.0: out = out * np.float32(acoustic_scale)               # :271
-    return out.astype(np.float32)
+    if log_priors is not None: out = out - np.asarray(log_priors, np.float32).astype(_F())      # :268-269
+    if acoustic_scale != 1.0: out = out * _F()(acoustic_scale)               # :271
+    return out.astype(_F())

@@ -1,6 +1,16 @@
 """GPU parity: k3_nnet_forward (fused FP32-MFMA TDNN/TDNN-F forward through the C ABI) vs
 (a) the reference's nnet3-compute outputs committed as fixtures and (b) the numpy oracle on seeded models.
-Tolerance: |delta| <= 1e-4 on the output (pseudo log-likelihoods), the north_star bound."""
+Tolerance: |delta| <= 1e-4 on the output (pseudo log-likelihoods), the north_star bound: against the reference's
+own nnet3-compute outputs directly, and against the oracle evaluated in float64 (the value that both float32
+implementations round); vs the float32 numpy oracle, which carries its own ~5e-5 rounding noise at |x| ~ 20,
+the bound is 2e-4 (two independent float32 roundings)."""
+TOL, TOL_F32 = 1e-4, 2e-4
+def _check(no, onet, f, g, s, lp=None, acwt=1.0):
+    ref64 = no.compute(onet, f, s, lp, acwt, dtype=np.float64)
+    ref32 = no.compute(onet, f, s, lp, acwt)
+    assert g.shape == ref32.shape
+    assert np.abs(g - ref64).max() <= TOL, (f.shape, np.abs(g - ref64).max())
+    assert np.abs(g - ref32).max() <= TOL_F32, (f.shape, np.abs(g - ref32).max())
 import os, numpy as np, pytest, torch
 from kaldi_amd import synth
 pytestmark = pytest.mark.gpu
@@ -42,9 +52,7 @@ def test_hip_vs_oracle_ragged_tdnnf(tmp_path):
         got, b = _forward(p, feats, s)
         assert b.flops > 0
         for f, g in zip(feats, got):
-            ref = no.compute(onet, f, s)
-            assert g.shape == ref.shape
-            assert np.abs(g - ref).max() <= 1e-4, (f.shape, np.abs(g - ref).max())
+            _check(no, onet, f, g, s)
 
 def test_hip_vs_oracle_tdnn_config1_priors_acwt(tmp_path):
     """BASELINE config 1 model (3x512 TDNN, 2000 outputs) incl. the -log(prior) * acwt epilogue."""
@@ -57,8 +65,7 @@ def test_hip_vs_oracle_tdnn_config1_priors_acwt(tmp_path):
     got, _ = _forward(p, feats, 1, lp, 0.1)
     onet = no.read_nnet(p)
     for f, g in zip(feats, got):
-        ref = no.compute(onet, f, 1, lp, 0.1)
-        assert np.abs(g - ref).max() <= 1e-4
+        _check(no, onet, f, g, 1, lp, 0.1)
 
 def test_hip_full_model_spot_check(tmp_path):
     """The benchmark model (17L-768/96-6024) on a 64-utterance batch: every utterance is the same signal, so all
@@ -72,5 +79,4 @@ def test_hip_full_model_spot_check(tmp_path):
     got, _ = _forward(p, [f] * 64, 3)
     for g in got[1:]:
         assert np.array_equal(g, got[0])
-    ref = no.compute(no.read_nnet(p), f, 3)
-    assert np.abs(got[0] - ref).max() <= 1e-4, np.abs(got[0] - ref).max()
+    _check(no, no.read_nnet(p), f, got[0], 3)
