@@ -4,18 +4,19 @@ Tolerance: |delta| <= 1e-4 on the output (pseudo log-likelihoods), the north_sta
 own nnet3-compute outputs directly, and against the oracle evaluated in float64 (the value that both float32
 implementations round); vs the float32 numpy oracle, which carries its own ~5e-5 rounding noise at |x| ~ 20,
 the bound is 2e-4 (two independent float32 roundings)."""
+import os, numpy as np, pytest, torch
+from kaldi_amd import synth
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
 TOL, TOL_F32 = 1e-4, 2e-4
+
 def _check(no, onet, f, g, s, lp=None, acwt=1.0):
     ref64 = no.compute(onet, f, s, lp, acwt, dtype=np.float64)
     ref32 = no.compute(onet, f, s, lp, acwt)
     assert g.shape == ref32.shape
     assert np.abs(g - ref64).max() <= TOL, (f.shape, np.abs(g - ref64).max())
     assert np.abs(g - ref32).max() <= TOL_F32, (f.shape, np.abs(g - ref32).max())
-import os, numpy as np, pytest, torch
-from kaldi_amd import synth
-pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLD = os.path.join(ROOT, "tests", "golden")
 
 def _forward(model_path, feats_list, s, log_priors=None, acwt=1.0):
     from kaldi_amd import nnet3
