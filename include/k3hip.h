@@ -97,6 +97,78 @@ int64_t k3_nnet_batch_output_rows(const k3_nnet_batch *batch, int64_t *h_out_off
 double k3_nnet_batch_flops(const k3_nnet_batch *batch);   /* exact sum of 2*M*N*K over the launched GEMMs */
 int k3_nnet_forward(k3_nnet_batch *batch, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream);
 
+/* ---------------------------------------------------------------- decoding graph -------------
+ * Replaces: cuda_decoder::CudaFst(const fst::StdFst &fst, const TransitionInformation *trans_model)
+ * (cudadecoder/cuda-fst.h:62-149, cuda-fst.cc:38-197): the HCLG as a CSR resident in HBM, emitting arcs of a state
+ * stored before its non-emitting (ilabel 0) arcs, transition-id -> pdf-id applied on the ilabels
+ * (cuda-fst.cc:166-175).  Input is a generic host CSR in FST arc order (what an OpenFst reader or a graph
+ * builder hands over): arcs of state s are [h_arc_offsets[s], h_arc_offsets[s+1]); h_final[s] is the final cost
+ * (+inf = not final); h_tid2pdf[t] maps ilabel t in [1, num_tids) to a column of the log-likelihood matrix
+ * (NULL = identity minus one is NOT assumed: pass the map).  The device copy is 16 B per arc + 8 B per state. */
+typedef struct k3_fst k3_fst;
+int k3_fst_create(int32_t num_states, int32_t start, const int32_t *h_arc_offsets, const int32_t *h_ilabel,
+                  const int32_t *h_olabel, const float *h_weight, const int32_t *h_nextstate, const float *h_final,
+                  const int32_t *h_tid2pdf, int32_t num_tids, k3_fst **fst);
+void k3_fst_destroy(k3_fst *fst);
+int64_t k3_fst_num_arcs(const k3_fst *fst);
+int32_t k3_fst_num_states(const k3_fst *fst);
+/* Size in bytes and device address of the packed read-only graph image (one contiguous allocation), so that a
+ * multi-GPU launcher can broadcast it once over RCCL (ncclBroadcast of `bytes` uint8 from the loading rank) and
+ * attach it on the other ranks with k3_fst_attach() -- SURVEY 8e: "HCLG broadcast once over RCCL/xGMI". */
+int k3_fst_image(const k3_fst *fst, void **d_image, int64_t *bytes);
+int k3_fst_create_empty(int32_t num_states, int64_t num_arcs, int32_t start, k3_fst **fst); /* allocate an image of that shape (receiver side) */
+
+/* ---------------------------------------------------------------- lattice decoder ------------
+ * Replaces: LatticeFasterDecoder::Decode = InitDecoding + AdvanceDecoding + FinalizeDecoding + GetRawLattice
+ * (decoder/lattice-faster-decoder.cc:63-197,588-649; the CPU parity oracle) behind the batched lane model of
+ * cuda_decoder::CudaDecoder (cudadecoder/cuda-decoder.h:224-345: ctor(fst, config, nlanes, nchannels),
+ * InitDecoding, AdvanceDecoding, GetRawLattice).  One workgroup per lane runs the whole frame recurrence.
+ * Semantics = the reference CPU decoder's token passing with the beam applied against the FINAL per-frame
+ * cutoff (order-independent; see DESIGN.md "decoder parity"), float32 costs formed in the reference's
+ * evaluation order; lattice-beam pruning (PruneForwardLinks / PruneForwardLinksFinal / PruneTokensForFrame,
+ * :308-507) runs on the GPU after the last frame.  Field names/defaults = LatticeFasterDecoderConfig
+ * (decoder/lattice-faster-decoder.h:37-107) / CudaDecoderConfig (cuda-decoder.h:58-163). */
+typedef struct k3_decoder_config {
+  float beam;              /* 16.0 (recipes: 15.0) */
+  int32_t max_active;      /* INT32_MAX  (CudaDecoderConfig: 10000) */
+  int32_t min_active;      /* 200 */
+  float lattice_beam;      /* 10.0 (recipes: 8.0) */
+  float beam_delta;        /* 0.5 */
+  /* capacities (tokens/links are kept for every frame until FinalizeDecoding; exceeding one is K3_ERR_OVERFLOW,
+   * never a silent beam change -- contrast cuda-decoder.cc:944-976) */
+  int32_t frame_tokens_cap;   /* max tokens alive on one frame of one lane (hash table = 2x next pow2) */
+  int32_t frame_cands_cap;    /* max emitting arcs that pass the pre-pass bound on one frame */
+  int64_t lane_tokens_cap;    /* tokens of all frames of one lane */
+  int64_t lane_links_cap;     /* forward links of all frames of one lane */
+} k3_decoder_config;
+void k3_decoder_config_default(k3_decoder_config *cfg);
+typedef struct k3_decoder k3_decoder;
+/* nlanes = max utterances decoded by one k3_decoder_decode_batch call; the fst must outlive the decoder
+ * (cuda-decoder.h:220). num_pdfs = columns of the log-likelihood matrix. */
+int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg, int32_t nlanes, int32_t num_pdfs, k3_decoder **dec);
+void k3_decoder_destroy(k3_decoder *dec);
+/* Decode num_utts utterances: utterance u owns rows h_row_offsets[u] .. h_row_offsets[u+1] of d_loglikes
+ * (row-major, leading dimension ld; already scaled by the acoustic scale, as DecodableAmNnetSimple hands them
+ * over).  Asynchronous on `stream`; results are fetched with the calls below (which synchronise). */
+int k3_decoder_decode_batch(k3_decoder *dec, int32_t num_utts, const float *d_loglikes, int64_t ld,
+                            const int64_t *h_row_offsets, void *stream);
+/* Per utterance: [0] lattice states, [1] lattice arcs, [2] status (0 ok, 1 no surviving tokens, <0 k3_status),
+ * [3] reached_final (a final-state token was active on the last frame), [4] tokens created, [5] links created,
+ * [6] max tokens on one frame, [7] emitting arcs traversed (candidates examined).  h_info: [num_utts x 8] int64. */
+int k3_decoder_lattice_info(k3_decoder *dec, int64_t *h_info);
+/* GetRawLattice for every utterance of the last batch, concatenated in utterance order (utterance u owns
+ * states h_state_offsets[u]..[u+1] and arcs h_arc_offsets[u]..[u+1]; arc endpoints are indices local to the
+ * utterance).  All output pointers are HOST buffers sized from k3_decoder_lattice_info.
+ * arc weight = LatticeWeight(graph_cost, acoustic_cost - cost_offset) (lattice-faster-decoder.cc:174-181);
+ * final_cost = +inf for non-final lattice states. */
+int k3_decoder_get_raw_lattices(k3_decoder *dec, int32_t *h_st_frame, int32_t *h_st_state, float *h_st_cost,
+                                float *h_st_final, int32_t *h_arc_src, int32_t *h_arc_dst, int32_t *h_arc_ilabel,
+                                int32_t *h_arc_olabel, float *h_arc_graph, float *h_arc_ac);
+/* per-frame diagnostics of one utterance of the last batch (host arrays of length num_frames, any may be NULL):
+ * tokens seen by GetCutoff, cur_cutoff, adaptive_beam, next_cutoff, cost_offset */
+int k3_decoder_frame_stats(k3_decoder *dec, int32_t utt, int32_t *h_ntoks, float *h_cur_cutoff, float *h_adaptive_beam,
+                           float *h_next_cutoff, float *h_cost_offset);
+
 #ifdef __cplusplus
 }
 #endif

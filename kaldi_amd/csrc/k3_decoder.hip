@@ -1,0 +1,934 @@
+// k3_decoder.hip -- batched HCLG lattice decoder for gfx950 (MI355X): wavefront-scan + LDS-atomic token passing
+// over a CSR graph resident in HBM, one persistent workgroup per lane (utterance).
+//
+// What it computes (paths relative to the reference's src/): LatticeFasterDecoder::Decode + GetRawLattice
+// (decoder/lattice-faster-decoder.cc:63-197,588-649), i.e. per frame GetCutoff (:653-720), ProcessEmitting (:723-814),
+// ProcessNonemitting (:830-897), then FinalizeDecoding = PruneForwardLinksFinal (:385-467) + per-frame
+// PruneForwardLinks (:308-379) / PruneTokensForFrame (:488-507), with float32 costs formed in the reference's
+// evaluation order ((cur + (cost_offset - loglike)) + graph; eps arcs cur + graph; link_extra = next.extra +
+// ((tot + ac + graph) - next.tot)).  The beam is applied against the FINAL next_cutoff of the frame (the serial code
+// tightens it while it walks its hash list, which makes its exact arc set depend on hash order; DESIGN.md
+// "decoder parity") and ties for the best token go to the smaller state id.
+//
+// Design (not the CUDA reference's: that one launches ~22 kernels per frame over arc-level tokens, prunes with a
+// histogram and builds the lattice on the host):
+//  * one workgroup per lane keeps the whole 333-step frame recurrence inside ONE kernel launch: no host sync, no
+//    inter-workgroup communication; 2 x 256 CUs' worth of lanes fill the chip, lanes of different length just retire
+//    at different times.  Counters, cutoffs, radix-select histograms and the frame's log-likelihood row live in LDS.
+//  * tokens are (frame, state) with the minimum cost kept by atomicMin on an order-preserving integer image of
+//    the float in a per-lane open-addressing table {state, cost, token, stamp} (16 B slots, one cache line per probe);
+//  * arcs are expanded wave-cooperatively: 64 tokens per wavefront, a wave scan of their out-degrees, then every
+//    lane takes one arc per step (binary search over the scan through ds_bpermute), so a 4000-arc loop state and a
+//    1-arc chain state cost the same per arc; queue appends are ballot/popcount aggregated (one LDS atomic per wave);
+//  * max_active / min_active use an exact radix select (std::nth_element's k-th value), not a histogram estimate;
+//  * every accepted arc leaves a 16 B forward link {src, dst, arc, acoustic}; lattice-beam pruning runs on the GPU
+//    after the last frame (one workgroup per lane, frames in reverse, epsilon links iterated to the exact fixpoint)
+//    and only the surviving lattice is compacted and copied to the host.
+// HBM layout: graph = {int2 offsets[S+1] (first arc, first eps arc), 16 B arcs {next, weight, pdf, olabel} with the
+// emitting arcs of a state before its eps arcs, finals[S], arc ilabels[A]} in ONE allocation (broadcastable);
+// per lane: token pool (state, cost, extra) for all frames, link pool, per-frame offsets and cutoffs.
+#include "k3_common.h"
+#pragma clang fp contract(off)   // costs must be formed add-by-add like the reference (no FMA contraction)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <vector>
+
+namespace {
+
+constexpr int kBlock = 512;                 // threads per lane-workgroup (8 wavefronts)
+constexpr int kWaves = kBlock / 64;
+constexpr unsigned kEncInf = 0xFF800000u;   // enc(+inf)
+constexpr unsigned kEncMax = 0xFFFFFFFFu;
+constexpr int kEmpty = -1;
+
+struct Slot { int key; unsigned cost; int tok; int stamp; };          // 16 B hash slot
+struct ArcRec { int next; float w; int pdf; int olabel; };            // 16 B graph arc
+struct Link { unsigned src, dst; int arc; float ac; };                // 16 B forward link (token indices are lane-pool indices)
+
+enum { kStOk = 0, kStNoTokens = 1 };
+
+struct LaneInfo {            // per lane, written by the kernels, read by the host
+  long long n_tokens, n_links, n_cands;   // created
+  int status, reached_final, max_frame_tokens, num_frames;
+  int out_states, out_arcs;               // after pruning
+  float final_best_cost; int final_empty;
+};
+
+struct DecParams {
+  // graph
+  const int2 *offs; const ArcRec *arcs; const float *final_cost; const int *arc_ilabel; int start;
+  // config
+  float beam, lattice_beam, beam_delta; int max_active, min_active;
+  int frame_tokens_cap, frame_cands_cap, hash_mask; long long lane_tokens_cap, lane_links_cap;
+  // input
+  const float *loglikes; long long ld; const long long *row_off; int num_pdfs; int use_lds_row;
+  // per-lane pools (lane l at base + l * stride)
+  int *tok_state; unsigned *tok_cost; float *tok_extra; Link *links;
+  Slot *hash; int *tok_slot; int *wl;            // wl: 2 x frame_tokens_cap
+  float *c_tot, *c_ac; int *c_dst, *c_arc, *c_src;
+  // per-lane per-frame arrays, stride fstride = max_frames + 2
+  long long fstride; long long *tok_off; long long *link_off_e, *link_off_n;
+  int *st_ntoks; float *st_cur, *st_ab, *st_next, *st_co;
+  LaneInfo *info;
+};
+
+__device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ float dec(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+#define K3_ALD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define K3_AST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+__device__ __forceinline__ unsigned hash_state(int s) { unsigned x = (unsigned)s * 2654435761u; return x ^ (x >> 15); }
+
+struct Shared {
+  unsigned long long red64[kWaves];
+  int redi[kWaves];
+  int hist[256];
+  int n_next, n_cand, n_wl[2], err, sel_digit, sel_k, flag;
+  unsigned min_tot;
+  long long n_link;
+  unsigned long long bcast64;
+};
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { unsigned t = __shfl_xor(v, o); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ unsigned long long block_min_u64(unsigned long long v, Shared &sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_min_u64(v);
+  __syncthreads();
+  if (lane == 0) sh.red64[wave] = v;
+  __syncthreads();
+  unsigned long long r = sh.red64[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; w++) r = sh.red64[w] < r ? sh.red64[w] : r;
+  return r;
+}
+__device__ int block_sum_i32(int v, Shared &sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum_i32(v);
+  __syncthreads();
+  if (lane == 0) sh.redi[wave] = v;
+  __syncthreads();
+  int r = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) r += sh.redi[w];
+  return r;
+}
+
+// uniform snapshot of the lane's error flag (read between two barriers so that no wavefront can race ahead and set it)
+__device__ __forceinline__ int block_err(Shared &sh) { __syncthreads(); const int e = sh.err; __syncthreads(); return e; }
+
+// ballot/popcount aggregated append: returns the slot index for lanes with pred (one LDS atomic per wavefront)
+__device__ __forceinline__ int wave_append(bool pred, int *counter) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = __ballot(pred);
+  if (m == 0) return 0;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader);
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ long long wave_append64(bool pred, long long *counter) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = __ballot(pred);
+  if (m == 0) return 0;
+  const int leader = __ffsll((long long)m) - 1;
+  long long base = 0;
+  if (lane == leader) base = (long long)atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
+  base = __shfl(base, leader);
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// 64 (begin, degree) pairs, one per lane -> f(valid, arc, owner_lane) once per arc, one arc per lane per step.
+// Every lane of the wavefront must call this (uniform control flow); f must keep the wavefront converged.
+template <typename F>
+__device__ __forceinline__ void wave_expand(int beg, int deg, F &&f) {
+  const int lane = threadIdx.x & 63;
+  int incl = deg;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int total = __shfl(incl, 63);
+  const int excl = incl - deg;
+  for (int j0 = 0; j0 < total; j0 += 64) {
+    const int j = j0 + lane;
+    int lo = 0, hi = 63;
+#pragma unroll
+    for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; const int v = __shfl(incl, mid); if (v > j) hi = mid; else lo = mid + 1; }
+    lo = lo > 63 ? 63 : lo;
+    const int obeg = __shfl(beg, lo), oexcl = __shfl(excl, lo);
+    f(j < total, obeg + (j - oexcl), lo);
+  }
+}
+
+// find the slot of `state` or claim an empty one.  All key accesses are atomics (performed at L2).
+__device__ __forceinline__ int slot_find_or_claim(Slot *tab, unsigned mask, int state, bool *claimed) {
+  unsigned h = hash_state(state) & mask;
+  for (unsigned probe = 0; probe <= mask; probe++) {
+    const int old = atomicCAS(&tab[h].key, kEmpty, state);
+    if (old == kEmpty) { *claimed = true; return (int)h; }
+    if (old == state) { *claimed = false; return (int)h; }
+    h = (h + 1) & mask;
+  }
+  *claimed = false; return -1;
+}
+__device__ __forceinline__ int slot_find(Slot *tab, unsigned mask, int state) {
+  unsigned h = hash_state(state) & mask;
+  for (unsigned probe = 0; probe <= mask; probe++) {
+    const int k = K3_ALD(&tab[h].key);
+    if (k == state) return (int)h;
+    if (k == kEmpty) return -1;
+    h = (h + 1) & mask;
+  }
+  return -1;
+}
+
+// exact k-th smallest (0-based) of keys[0..n) -- the value std::nth_element leaves at position k
+__device__ unsigned block_select_kth(const unsigned *keys, int n, int k, Shared &sh) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned prefix = 0, mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    __syncthreads();
+    for (int i = tid; i < 256; i += kBlock) sh.hist[i] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+      const int i = i0 + tid;
+      bool v = i < n; unsigned key = 0;
+      if (v) { key = keys[i]; v = (key & mask) == prefix; }
+      const int d = (key >> shift) & 255;
+      const unsigned long long mv = __ballot(v);
+      const int d0 = __shfl(d, mv ? __ffsll((long long)mv) - 1 : 0);
+      const unsigned long long diff = __ballot(v && d != d0);
+      if (mv != 0) {
+        if (diff == 0) { if (lane == __ffsll((long long)mv) - 1) atomicAdd(&sh.hist[d0], __popcll(mv)); }
+        else if (v) atomicAdd(&sh.hist[d], 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, d = 0;
+      for (; d < 255; d++) { const int c = sh.hist[d]; if (k < cum + c) break; cum += c; }
+      sh.sel_digit = d; sh.sel_k = k - cum;
+    }
+    __syncthreads();
+    prefix |= (unsigned)sh.sel_digit << shift; mask |= 0xFFu << shift; k = sh.sel_k;
+  }
+  return prefix;
+}
+
+// ---- epsilon closure + eps links + frame finalisation for the frame being built (tokens [nb, nb + n_next)) ----
+// ProcessNonemitting (lattice-faster-decoder.cc:830-897): relax eps arcs until no cost changes, with tot < cutoff;
+// the links a token ends up with are exactly its eps arcs with cur + graph < cutoff at its final cost.
+__device__ void finish_frame(const DecParams &p, Shared &sh, float cutoff, long long nb, int *tok_state, unsigned *tok_cost, Link *links,
+                             Slot *hash, int *tok_slot, int *wl) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned mask = (unsigned)p.hash_mask;
+  // round-0 worklist: every token of the frame (those without eps arcs or above the cutoff expand to nothing)
+  __syncthreads();
+  if (tid == 0) { sh.n_wl[0] = 0; sh.n_wl[1] = 0; }
+  __syncthreads();
+  {
+    const int n = sh.n_next;
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+      const int i = i0 + tid; bool v = i < n; int slot = 0;
+      if (v) {
+        slot = tok_slot[i];
+        const int2 a = p.offs[tok_state[nb + i]], b = p.offs[tok_state[nb + i] + 1];
+        v = (b.x - a.y) > 0 && dec(K3_ALD(&hash[slot].cost)) < cutoff;
+      }
+      const int pos = wave_append(v, &sh.n_wl[0]);
+      if (v) { wl[pos] = slot; K3_AST(&hash[slot].stamp, 1); }
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int round = 1;; round++) {
+    const int n = sh.n_wl[cur];
+    if (block_err(sh) || n == 0) break;
+    int *wl_cur = wl + (long long)cur * p.frame_tokens_cap, *wl_nxt = wl + (long long)(cur ^ 1) * p.frame_tokens_cap;
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+      const int i = i0 + tid; const bool v = i < n;
+      int beg = 0, deg = 0; float c = 0.0f;
+      if (v) {
+        const int slot = wl_cur[i];
+        const int st = K3_ALD(&hash[slot].key);
+        c = dec(K3_ALD(&hash[slot].cost));
+        if (c < cutoff) { const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
+      }
+      wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
+        const float oc = __shfl(c, owner);
+        bool claimed = false, push = false; int slot2 = -1, nxt = 0;
+        if (valid) {
+          const ArcRec r = p.arcs[arc];
+          const float tot = oc + r.w; nxt = r.next;
+          if (tot < cutoff) {
+            slot2 = slot_find_or_claim(hash, mask, r.next, &claimed);
+            if (slot2 < 0) { sh.err = K3_ERR_OVERFLOW; }
+            else {
+              const unsigned e = enc(tot);
+              const unsigned old = atomicMin(&hash[slot2].cost, e);
+              if (e < old) push = atomicExch(&hash[slot2].stamp, round + 1) != round + 1;
+            }
+          }
+        }
+        const int idx = wave_append(claimed, &sh.n_next);
+        if (claimed) {
+          if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { K3_AST(&hash[slot2].tok, idx); tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; }
+          else sh.err = K3_ERR_OVERFLOW;
+        }
+        const int pos = wave_append(push, &sh.n_wl[cur ^ 1]);
+        if (push) { if (pos < p.frame_tokens_cap) wl_nxt[pos] = slot2; else sh.err = K3_ERR_OVERFLOW; }
+      });
+    }
+    __syncthreads();
+    if (tid == 0) sh.n_wl[cur] = 0;
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (block_err(sh)) return;
+  // eps links at the final costs
+  {
+    const int n = sh.n_next;
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+      const int i = i0 + tid; const bool v = i < n;
+      int beg = 0, deg = 0; float c = 0.0f;
+      if (v) {
+        const int st = tok_state[nb + i];
+        c = dec(K3_ALD(&hash[tok_slot[i]].cost));
+        if (c < cutoff) { const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
+      }
+      wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
+        const float oc = __shfl(c, owner); const int oi = __shfl(i, owner);
+        bool mk = false; int dtok = 0;
+        if (valid) {
+          const ArcRec r = p.arcs[arc];
+          if (oc + r.w < cutoff) {
+            const int s2 = slot_find(hash, mask, r.next);
+            if (s2 >= 0) { mk = true; dtok = K3_ALD(&hash[s2].tok); } else sh.err = K3_ERR_HIP;   // cannot happen at the fixpoint
+          }
+        }
+        const long long pos = wave_append64(mk, &sh.n_link);
+        if (mk) { if (pos < p.lane_links_cap) links[pos] = Link{(unsigned)(nb + oi), (unsigned)(nb + dtok), arc, 0.0f}; else sh.err = K3_ERR_OVERFLOW; }
+      });
+    }
+  }
+  if (block_err(sh)) return;
+  // final costs into the pool, clear the table
+  {
+    const int n = sh.n_next;
+    for (int i = tid; i < n; i += kBlock) {
+      const int slot = tok_slot[i];
+      tok_cost[nb + i] = K3_ALD(&hash[slot].cost);
+      K3_AST(&hash[slot].cost, kEncMax); K3_AST(&hash[slot].stamp, 0); K3_AST(&hash[slot].tok, -1); K3_AST(&hash[slot].key, kEmpty);
+    }
+  }
+  (void)lane;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ Shared sh;
+  float *s_ll = reinterpret_cast<float *>(smem_raw);
+  const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
+  int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
+  Link *links = p.links + (long long)L * p.lane_links_cap;
+  Slot *hash = p.hash + (long long)L * (p.hash_mask + 1);
+  int *tok_slot = p.tok_slot + (long long)L * p.frame_tokens_cap, *wl = p.wl + 2ll * L * p.frame_tokens_cap;
+  float *c_tot = p.c_tot + (long long)L * p.frame_cands_cap, *c_ac = p.c_ac + (long long)L * p.frame_cands_cap;
+  int *c_dst = p.c_dst + (long long)L * p.frame_cands_cap, *c_arc = p.c_arc + (long long)L * p.frame_cands_cap, *c_src = p.c_src + (long long)L * p.frame_cands_cap;
+  long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
+  int *st_ntoks = p.st_ntoks + L * p.fstride; float *st_cur = p.st_cur + L * p.fstride, *st_ab = p.st_ab + L * p.fstride,
+        *st_next = p.st_next + L * p.fstride, *st_co = p.st_co + L * p.fstride;
+  const unsigned mask = (unsigned)p.hash_mask;
+  const float kInf = __builtin_inff();
+
+  if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; }
+  __syncthreads();
+  // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
+  if (tid == 0) {
+    bool cl; const int slot = slot_find_or_claim(hash, mask, p.start, &cl);
+    atomicMin(&hash[slot].cost, enc(0.0f)); K3_AST(&hash[slot].tok, 0); tok_slot[0] = slot; tok_state[0] = p.start; sh.n_next = 1;
+    tok_off[0] = 0; loff_n[0] = 0;
+  }
+  __syncthreads();
+  finish_frame(p, sh, p.beam, 0, tok_state, tok_cost, links, hash, tok_slot, wl);
+  long long cur_base = 0; int n_cur = sh.n_next; long long n_cands_total = 0; int max_frame = n_cur;
+  __syncthreads();
+  if (tid == 0) { tok_off[1] = n_cur; loff_e[0] = sh.n_link; }
+  int status = kStOk;
+
+  for (int f = 0; f < T; f++) {
+    if (block_err(sh)) break;
+    // stage the log-likelihood row of this frame in LDS (coalesced), overlapped with the cutoff passes
+    const float *row = p.loglikes + (r0 + f) * p.ld;
+    if (p.use_lds_row) for (int i = tid; i < p.num_pdfs; i += kBlock) s_ll[i] = row[i];
+    const float *ll = p.use_lds_row ? s_ll : row;
+    const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
+    if (n_cur == 0) { status = kStNoTokens; break; }
+    // ---- GetCutoff (:653-720)
+    unsigned long long bm = ~0ull;
+    for (int i = tid; i < n_cur; i += kBlock) { const unsigned long long v = ((unsigned long long)ccs[i] << 32) | (unsigned)cst[i]; bm = v < bm ? v : bm; }
+    bm = block_min_u64(bm, sh);
+    const float best = dec((unsigned)(bm >> 32)); const int best_state = (int)(unsigned)(bm & 0xFFFFFFFFull);
+    float cur_cutoff, ab;
+    const float beam_cutoff = best + p.beam;
+    if (p.max_active == 0x7FFFFFFF && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }
+    else {
+      const unsigned ebc = enc(beam_cutoff);
+      int c_lt = 0, c_le = 0;
+      for (int i = tid; i < n_cur; i += kBlock) { const unsigned k = ccs[i]; c_lt += k < ebc; c_le += k <= ebc; }
+      c_lt = block_sum_i32(c_lt, sh); c_le = block_sum_i32(c_le, sh);
+      // tmp[max_active] < beam_cutoff  <=>  more than max_active elements are < beam_cutoff
+      if (n_cur > p.max_active && c_lt > p.max_active) {
+        const float mac = dec(block_select_kth(ccs, n_cur, p.max_active, sh));
+        ab = mac - best + p.beam_delta; cur_cutoff = mac;
+      } else if (n_cur > p.min_active && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }   // min_active_cutoff = best <= beam_cutoff
+      else if (n_cur > p.min_active && c_le > p.min_active) { ab = p.beam; cur_cutoff = beam_cutoff; }      // tmp[min_active] <= beam_cutoff
+      else if (n_cur > p.min_active) {
+        const float mic = dec(block_select_kth(ccs, n_cur, p.min_active, sh));
+        ab = mic - best + p.beam_delta; cur_cutoff = mic;
+      } else { ab = kInf - best + p.beam_delta; cur_cutoff = kInf; }                                          // min_active_cutoff = +inf
+    }
+    const float co = -best;
+    // ---- pre-pass over the best token's emitting arcs (:753-768; note its own evaluation order)
+    __syncthreads();
+    unsigned n0 = kEncMax;
+    {
+      const int2 a = p.offs[best_state];
+      for (int arc = a.x + tid; arc < a.y; arc += kBlock) {
+        const ArcRec r = p.arcs[arc];
+        const float nw = r.w + co - ll[r.pdf] + best;
+        const unsigned e = enc(nw + ab); n0 = e < n0 ? e : n0;
+      }
+    }
+    n0 = (unsigned)(block_min_u64((unsigned long long)n0, sh) & 0xFFFFFFFFull);
+    const float next0 = n0 == kEncMax ? kInf : dec(n0);
+    if (tid == 0) { sh.n_cand = 0; sh.min_tot = kEncMax; sh.n_next = 0; }
+    __syncthreads();
+    // ---- ProcessEmitting pass 1 (:779-797): every emitting arc of every token <= cur_cutoff; keep tot < pre-pass bound
+    for (int t0 = 0; t0 < n_cur; t0 += kBlock) {
+      const int t = t0 + tid; const bool v = t < n_cur;
+      int beg = 0, deg = 0; float c = 0.0f;
+      if (v) { c = dec(ccs[t]); if (c <= cur_cutoff) { const int2 a = p.offs[cst[t]]; beg = a.x; deg = a.y - a.x; } }
+      wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
+        const float oc = __shfl(c, owner); const int ot = __shfl(t, owner);
+        bool pass = false; float tot = 0.0f, ac = 0.0f; int nxt = 0;
+        if (valid) {
+          const ArcRec r = p.arcs[arc];
+          ac = co - ll[r.pdf]; tot = oc + ac + r.w; nxt = r.next;
+          pass = tot < next0;
+        }
+        const unsigned wm = wave_min_u32(pass ? enc(tot) : kEncMax);
+        if (lane == 0 && wm != kEncMax) atomicMin(&sh.min_tot, wm);
+        const int pos = wave_append(pass, &sh.n_cand);
+        if (pass) {
+          if (pos < p.frame_cands_cap) { c_tot[pos] = tot; c_ac[pos] = ac; c_dst[pos] = nxt; c_arc[pos] = arc; c_src[pos] = ot; }
+          else sh.err = K3_ERR_OVERFLOW;
+        }
+      });
+    }
+    if (block_err(sh)) break;
+    // ---- final bound of the frame, pass 2: tokens (min cost per state) for the accepted arcs
+    float accept = next0;
+    { const unsigned mt = sh.min_tot; if (mt != kEncMax) { const float t = dec(mt) + ab; if (t < accept) accept = t; } }
+    const int n_cand = sh.n_cand;
+    const long long nb = cur_base + n_cur;
+    for (int j0 = 0; j0 < n_cand; j0 += kBlock) {
+      const int j = j0 + tid; bool claimed = false; int slot = -1, nxt = 0;
+      if (j < n_cand) {
+        const float tot = c_tot[j];
+        if (tot < accept) {
+          nxt = c_dst[j];
+          slot = slot_find_or_claim(hash, mask, nxt, &claimed);
+          if (slot < 0) sh.err = K3_ERR_OVERFLOW; else atomicMin(&hash[slot].cost, enc(tot));
+          c_dst[j] = slot;
+        } else c_arc[j] = -1;
+      }
+      const int idx = wave_append(claimed, &sh.n_next);
+      if (claimed) {
+        if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { K3_AST(&hash[slot].tok, idx); tok_slot[idx] = slot; tok_state[nb + idx] = nxt; }
+        else sh.err = K3_ERR_OVERFLOW;
+      }
+    }
+    if (block_err(sh)) break;
+    // ---- forward links of the accepted arcs (:803-806)
+    if (tid == 0) loff_e[f] = sh.n_link;
+    __syncthreads();
+    for (int j0 = 0; j0 < n_cand; j0 += kBlock) {
+      const int j = j0 + tid; bool mk = false; int arc = -1;
+      if (j < n_cand) { arc = c_arc[j]; mk = arc >= 0 && c_dst[j] >= 0; }
+      const long long pos = wave_append64(mk, &sh.n_link);
+      if (mk) {
+        if (pos < p.lane_links_cap) links[pos] = Link{(unsigned)(cur_base + c_src[j]), (unsigned)(nb + K3_ALD(&hash[c_dst[j]].tok)), arc, c_ac[j]};
+        else sh.err = K3_ERR_OVERFLOW;
+      }
+    }
+    if (block_err(sh)) break;
+    if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
+    n_cands_total += n_cand;
+    // ---- ProcessNonemitting(next_cutoff) + eps links + publish the frame
+    finish_frame(p, sh, accept, nb, tok_state, tok_cost, links, hash, tok_slot, wl);
+    if (block_err(sh)) break;
+    cur_base = nb; n_cur = sh.n_next; max_frame = n_cur > max_frame ? n_cur : max_frame;
+    __syncthreads();
+    if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    LaneInfo &li = p.info[L];
+    li.n_tokens = cur_base + n_cur; li.n_links = sh.n_link; li.n_cands = n_cands_total; li.max_frame_tokens = max_frame;
+    li.status = sh.err ? sh.err : status; li.num_frames = T; li.reached_final = 0; li.out_states = 0; li.out_arcs = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FinalizeDecoding (:634-649) on the GPU: one workgroup per lane, frames in reverse.  tok_extra holds extra_cost.
+// Inside a frame the eps links make the extra costs depend on each other; the dependency graph is acyclic, so the
+// fixpoint is unique and reached by iterating x <- min(base, min_links f(x)) until nothing changes.
+__device__ __forceinline__ float link_extra_cost(float next_extra, float tot, float ac, float graph, float next_tot) {
+  return next_extra + ((tot + ac + graph) - next_tot);
+}
+
+__global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
+  __shared__ Shared sh;
+  __shared__ int s_changed, s_has_final;
+  __shared__ unsigned s_best, s_best_final;
+  const int L = blockIdx.x, tid = threadIdx.x;
+  LaneInfo &li = p.info[L];
+  if (li.status != kStOk) return;
+  const int T = li.num_frames;
+  const int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; const unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
+  float *extra = p.tok_extra + (long long)L * p.lane_tokens_cap;
+  const Link *links = p.links + (long long)L * p.lane_links_cap;
+  const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
+  const float kInf = __builtin_inff(); const float lb = p.lattice_beam;
+  unsigned *xenc = reinterpret_cast<unsigned *>(extra);   // extra costs are >= 0 or +inf: their float bits order like unsigned ints
+
+  // ---- last frame: ComputeFinalCosts (:545-586) + PruneForwardLinksFinal (:385-467)
+  const long long tb = tok_off[T], te = tok_off[T + 1];
+  if (tid == 0) { s_best = kEncMax; s_best_final = kEncMax; s_has_final = 0; }
+  __syncthreads();
+  for (long long t = tb + tid; t < te; t += kBlock) {
+    const float c = dec(tok_cost[t]), fc = p.final_cost[tok_state[t]];
+    atomicMin(&s_best, enc(c)); atomicMin(&s_best_final, enc(c + fc));
+    if (fc != kInf) s_has_final = 1;
+  }
+  __syncthreads();
+  const float best = dec(s_best), best_final = dec(s_best_final);
+  const float final_best = (best_final != kInf) ? best_final : best;
+  const bool final_empty = !s_has_final;
+  if (tid == 0) { li.reached_final = s_has_final; li.final_best_cost = final_best; li.final_empty = final_empty; }
+  // base term per token; eps links of the last frame are [loff_n[T], loff_e[T])
+  for (long long t = tb + tid; t < te; t += kBlock) extra[t] = 0.0f;        // tokens on the last frame start with extra_cost 0
+  __syncthreads();
+  {
+    const long long l0 = loff_n[T], l1 = loff_e[T];
+    // Jacobi sweeps: xn <- base, atomicMin over the surviving eps links evaluated at the previous sweep's extras (xn lives in
+    // this lane's candidate scratch), until no extra cost changes.
+    unsigned *xn = reinterpret_cast<unsigned *>(p.c_tot + (long long)L * p.frame_cands_cap);   // frame_cands_cap >= frame_tokens_cap (checked on the host)
+    for (;;) {
+      __syncthreads();
+      if (tid == 0) s_changed = 0;
+      for (long long t = tb + tid; t < te; t += kBlock) {
+        const float fc = final_empty ? 0.0f : p.final_cost[tok_state[t]];
+        xn[t - tb] = enc(dec(tok_cost[t]) + fc - final_best);
+      }
+      __syncthreads();
+      for (long long l = l0 + tid; l < l1; l += kBlock) {
+        const Link k = links[l];
+        float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
+        if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - tb], enc(le)); }
+      }
+      __syncthreads();
+      for (long long t = tb + tid; t < te; t += kBlock) {
+        float v = dec(xn[t - tb]);
+        if (v > lb) v = kInf;
+        if (__float_as_uint(v) != __float_as_uint(extra[t])) s_changed = 1;
+        extra[t] = v;
+      }
+      __syncthreads();
+      if (!s_changed) break;
+    }
+  }
+  __syncthreads();
+  // ---- frames T-1 .. 0: PruneForwardLinks(f, delta = 0) then PruneTokensForFrame(f+1) (tokens with extra = inf vanish)
+  for (int f = T - 1; f >= 0; f--) {
+    const long long b0 = tok_off[f], b1 = tok_off[f + 1];
+    const long long e0 = loff_e[f], e1 = loff_n[f + 1];     // emitting links f -> f+1
+    const long long n0 = loff_n[f], n1 = loff_e[f];         // eps links inside frame f
+    unsigned *xb = reinterpret_cast<unsigned *>(p.c_tot + (long long)L * p.frame_cands_cap);   // base (emitting part), enc
+    unsigned *xn = reinterpret_cast<unsigned *>(p.c_ac + (long long)L * p.frame_cands_cap);
+    for (long long t = b0 + tid; t < b1; t += kBlock) { xb[t - b0] = kEncInf; extra[t] = 0.0f; }
+    __syncthreads();
+    for (long long l = e0 + tid; l < e1; l += kBlock) {
+      const Link k = links[l];
+      float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
+      if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xb[k.src - b0], enc(le)); }
+    }
+    __syncthreads();
+    if (n1 == n0) {
+      for (long long t = b0 + tid; t < b1; t += kBlock) extra[t] = dec(xb[t - b0]);
+    } else {
+      for (;;) {
+        __syncthreads();
+        if (tid == 0) s_changed = 0;
+        for (long long t = b0 + tid; t < b1; t += kBlock) xn[t - b0] = xb[t - b0];
+        __syncthreads();
+        for (long long l = n0 + tid; l < n1; l += kBlock) {
+          const Link k = links[l];
+          float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
+          if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - b0], enc(le)); }
+        }
+        __syncthreads();
+        for (long long t = b0 + tid; t < b1; t += kBlock) {
+          const float v = dec(xn[t - b0]);
+          if (__float_as_uint(v) != __float_as_uint(extra[t])) s_changed = 1;
+          extra[t] = v;
+        }
+        __syncthreads();
+        if (!s_changed) break;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- count survivors: tokens with extra != inf; links with link_extra <= lattice_beam (final extras)
+  int ns = 0, na = 0;
+  for (long long t = tid; t < tok_off[T + 1]; t += kBlock) ns += extra[t] != kInf;
+  for (long long l = tid; l < li.n_links; l += kBlock) {
+    const Link k = links[l];
+    const float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
+    na += !(le > lb) && extra[k.src] != kInf;
+  }
+  ns = block_sum_i32(ns, sh); na = block_sum_i32(na, sh);
+  if (tid == 0) { li.out_states = ns; li.out_arcs = na; }
+  (void)xenc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GetRawLattice (:114-197): compact the surviving tokens / links of every lane into the output arrays.
+struct OutParams {
+  const long long *st_off, *arc_off;     // [U+1] prefix sums of out_states / out_arcs (device)
+  int *st_frame, *st_state; float *st_cost, *st_final; int *arc_src, *arc_dst, *arc_il, *arc_ol; float *arc_g, *arc_ac;
+  int *newidx;                            // per-lane scratch [lane_tokens_cap]: pool index -> lattice state index
+};
+
+__global__ __launch_bounds__(kBlock) void k3_decode_output_kernel(DecParams p, OutParams o) {
+  __shared__ int s_n;
+  const int L = blockIdx.x, tid = threadIdx.x;
+  const LaneInfo &li = p.info[L];
+  if (li.status != kStOk) return;
+  const int T = li.num_frames;
+  const int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; const unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
+  const float *extra = p.tok_extra + (long long)L * p.lane_tokens_cap;
+  const Link *links = p.links + (long long)L * p.lane_links_cap;
+  const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
+  const float *st_co = p.st_co + L * p.fstride;
+  int *newidx = o.newidx + (long long)L * p.lane_tokens_cap;
+  const float kInf = __builtin_inff(); const float lb = p.lattice_beam;
+  const long long so = o.st_off[L], ao = o.arc_off[L];
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int f = 0; f <= T; f++) {          // frame-major numbering (any per-frame order is a valid GetRawLattice numbering)
+    const long long b0 = tok_off[f], b1 = tok_off[f + 1];
+    for (long long t0 = b0; t0 < b1; t0 += kBlock) {
+      const long long t = t0 + tid; const bool v = t < b1 && extra[t] != kInf;
+      const int pos = wave_append(v, &s_n);
+      if (v) {
+        newidx[t] = pos;
+        o.st_frame[so + pos] = f; o.st_state[so + pos] = tok_state[t]; o.st_cost[so + pos] = dec(tok_cost[t]);
+        float fin = kInf;
+        if (f == T) { if (li.final_empty) fin = 0.0f; else fin = p.final_cost[tok_state[t]]; }
+        o.st_final[so + pos] = fin;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  // links in pool order; frame of a link: emitting links of frame f lie in [loff_e[f], loff_n[f+1])
+  for (int f = 0; f <= T; f++) {
+    const long long n0 = loff_n[f], n1 = loff_e[f];
+    const long long e0 = loff_e[f], e1 = (f < T) ? loff_n[f + 1] : loff_e[f];
+    for (int part = 0; part < 2; part++) {
+      const long long l0 = part ? e0 : n0, l1 = part ? e1 : n1;
+      for (long long x0 = l0; x0 < l1; x0 += kBlock) {
+        const long long l = x0 + tid; bool v = l < l1; Link k{}; float g = 0.0f;
+        if (v) {
+          k = links[l]; g = p.arcs[k.arc].w;
+          const float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, g, dec(tok_cost[k.dst]));
+          v = !(le > lb) && extra[k.src] != kInf;
+        }
+        const int pos = wave_append(v, &s_n);
+        if (v) {
+          const int il = p.arc_ilabel[k.arc];
+          o.arc_src[ao + pos] = newidx[k.src]; o.arc_dst[ao + pos] = newidx[k.dst]; o.arc_il[ao + pos] = il; o.arc_ol[ao + pos] = p.arcs[k.arc].olabel;
+          o.arc_g[ao + pos] = g; o.arc_ac[ao + pos] = part ? (k.ac - st_co[f]) : (k.ac - 0.0f);
+        }
+      }
+    }
+  }
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ graph ----
+struct k3_fst {
+  int32_t num_states = 0, start = 0; int64_t num_arcs = 0;
+  void *image = nullptr; size_t bytes = 0;
+  int2 *offs = nullptr; ArcRec *arcs = nullptr; float *final_cost = nullptr; int *arc_ilabel = nullptr;
+  ~k3_fst() { if (image) (void)hipFree(image); }
+};
+
+static int fst_alloc(k3_fst *f) {
+  const size_t o0 = 0, o1 = align_up(o0 + sizeof(int2) * (size_t)(f->num_states + 1), 256), o2 = align_up(o1 + sizeof(ArcRec) * (size_t)f->num_arcs, 256),
+               o3 = align_up(o2 + sizeof(float) * (size_t)f->num_states, 256), o4 = align_up(o3 + sizeof(int) * (size_t)f->num_arcs, 256);
+  f->bytes = o4;
+  K3_HIP_CHECK(hipMalloc(&f->image, f->bytes));
+  char *b = (char *)f->image;
+  f->offs = (int2 *)(b + o0); f->arcs = (ArcRec *)(b + o1); f->final_cost = (float *)(b + o2); f->arc_ilabel = (int *)(b + o3);
+  return K3_OK;
+}
+
+extern "C" int k3_fst_create(int32_t num_states, int32_t start, const int32_t *h_off, const int32_t *h_il, const int32_t *h_ol, const float *h_w,
+                             const int32_t *h_next, const float *h_final, const int32_t *h_tid2pdf, int32_t num_tids, k3_fst **out) {
+  K3_REQUIRE(num_states > 0 && start >= 0 && start < num_states && h_off && h_il && h_ol && h_w && h_next && h_final && h_tid2pdf && out, "k3_fst_create: bad argument");
+  std::unique_ptr<k3_fst> f(new k3_fst());
+  f->num_states = num_states; f->start = start; f->num_arcs = h_off[num_states];
+  { const int rc = fst_alloc(f.get()); if (rc) return rc; }
+  std::vector<char> host(f->bytes, 0);
+  int2 *offs = (int2 *)(host.data() + ((char *)f->offs - (char *)f->image));
+  ArcRec *arcs = (ArcRec *)(host.data() + ((char *)f->arcs - (char *)f->image));
+  float *fin = (float *)(host.data() + ((char *)f->final_cost - (char *)f->image));
+  int *ail = (int *)(host.data() + ((char *)f->arc_ilabel - (char *)f->image));
+  int64_t pos = 0;
+  for (int32_t s = 0; s < num_states; s++) {       // emitting arcs of a state first, then its eps arcs, FST order kept inside each group
+    offs[s].x = (int)pos;
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 1) offs[s].y = (int)pos;
+      for (int32_t a = h_off[s]; a < h_off[s + 1]; a++) {
+        const bool emit = h_il[a] != 0;
+        if (emit != (pass == 0)) continue;
+        if (h_next[a] < 0 || h_next[a] >= num_states) { k3::set_error("k3_fst_create: arc %d has next state %d out of range", a, h_next[a]); return K3_ERR_ARG; }
+        int pdf = 0;
+        if (emit) {
+          if (h_il[a] < 0 || h_il[a] >= num_tids) { k3::set_error("k3_fst_create: ilabel %d outside the transition-id map [1, %d)", h_il[a], num_tids); return K3_ERR_ARG; }
+          pdf = h_tid2pdf[h_il[a]];
+        }
+        arcs[pos] = ArcRec{h_next[a], h_w[a], pdf, h_ol[a]}; ail[pos] = h_il[a]; pos++;
+      }
+    }
+    fin[s] = h_final[s];
+  }
+  offs[num_states].x = (int)pos; offs[num_states].y = (int)pos;
+  K3_HIP_CHECK(hipMemcpy(f->image, host.data(), f->bytes, hipMemcpyHostToDevice));
+  *out = f.release();
+  return K3_OK;
+}
+
+extern "C" int k3_fst_create_empty(int32_t num_states, int64_t num_arcs, int32_t start, k3_fst **out) {
+  K3_REQUIRE(num_states > 0 && num_arcs >= 0 && out, "k3_fst_create_empty: bad argument");
+  std::unique_ptr<k3_fst> f(new k3_fst());
+  f->num_states = num_states; f->start = start; f->num_arcs = num_arcs;
+  { const int rc = fst_alloc(f.get()); if (rc) return rc; }
+  *out = f.release();
+  return K3_OK;
+}
+extern "C" void k3_fst_destroy(k3_fst *f) { delete f; }
+extern "C" int64_t k3_fst_num_arcs(const k3_fst *f) { return f ? f->num_arcs : -1; }
+extern "C" int32_t k3_fst_num_states(const k3_fst *f) { return f ? f->num_states : -1; }
+extern "C" int k3_fst_image(const k3_fst *f, void **d_image, int64_t *bytes) {
+  K3_REQUIRE(f && d_image && bytes, "k3_fst_image: null argument");
+  *d_image = f->image; *bytes = (int64_t)f->bytes; return K3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder ----
+struct k3_decoder {
+  const k3_fst *fst = nullptr; k3_decoder_config cfg{}; int nlanes = 0, num_pdfs = 0;
+  DecParams p{};
+  std::vector<void *> allocs;
+  long long fstride = 0; std::vector<void *> frame_allocs;
+  long long *d_row_off = nullptr;
+  int last_utts = 0; std::vector<int> last_frames;
+  hipStream_t last_stream = nullptr;
+  std::vector<LaneInfo> h_info; bool info_valid = false;
+  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); }
+};
+
+extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
+  if (!c) return;
+  c->beam = 16.0f; c->max_active = std::numeric_limits<int32_t>::max(); c->min_active = 200; c->lattice_beam = 10.0f; c->beam_delta = 0.5f;
+  c->frame_tokens_cap = 32768; c->frame_cands_cap = 65536; c->lane_tokens_cap = 2000000; c->lane_links_cap = 4000000;
+}
+
+template <typename T> static int dmalloc(std::vector<void *> *allocs, T **ptr, size_t n) {
+  *ptr = nullptr;
+  K3_HIP_CHECK(hipMalloc((void **)ptr, std::max<size_t>(n, 1) * sizeof(T)));
+  allocs->push_back(*ptr);
+  return K3_OK;
+}
+
+extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg, int32_t nlanes, int32_t num_pdfs, k3_decoder **out) {
+  K3_REQUIRE(fst && cfg && out && nlanes > 0 && num_pdfs > 0, "k3_decoder_create: bad argument");
+  K3_REQUIRE(cfg->beam > 0 && cfg->lattice_beam > 0 && cfg->max_active > 1 && cfg->min_active >= 0 && cfg->min_active < cfg->max_active, "k3_decoder_create: bad beam / active limits");
+  K3_REQUIRE(cfg->frame_tokens_cap >= 64 && cfg->frame_cands_cap >= cfg->frame_tokens_cap && cfg->lane_tokens_cap >= cfg->frame_tokens_cap && cfg->lane_links_cap > 0 &&
+             cfg->lane_tokens_cap < (1ll << 31) && cfg->lane_links_cap < (1ll << 40), "k3_decoder_create: bad capacities (need frame_cands_cap >= frame_tokens_cap, lane_tokens_cap < 2^31)");
+  std::unique_ptr<k3_decoder> d(new k3_decoder());
+  d->fst = fst; d->cfg = *cfg; d->nlanes = nlanes; d->num_pdfs = num_pdfs;
+  DecParams &p = d->p;
+  p.offs = fst->offs; p.arcs = fst->arcs; p.final_cost = fst->final_cost; p.arc_ilabel = fst->arc_ilabel; p.start = fst->start;
+  p.beam = cfg->beam; p.lattice_beam = cfg->lattice_beam; p.beam_delta = cfg->beam_delta; p.max_active = cfg->max_active; p.min_active = cfg->min_active;
+  p.frame_tokens_cap = cfg->frame_tokens_cap; p.frame_cands_cap = cfg->frame_cands_cap; p.lane_tokens_cap = cfg->lane_tokens_cap; p.lane_links_cap = cfg->lane_links_cap;
+  int hs = 1; while (hs < 2 * cfg->frame_tokens_cap) hs <<= 1;
+  p.hash_mask = hs - 1; p.num_pdfs = num_pdfs;
+  p.use_lds_row = ((size_t)num_pdfs * sizeof(float) <= 96 * 1024) ? 1 : 0;
+  const size_t nl = (size_t)nlanes;
+  int rc;
+  if ((rc = dmalloc(&d->allocs, &p.tok_state, nl * cfg->lane_tokens_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.tok_cost, nl * cfg->lane_tokens_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.tok_extra, nl * cfg->lane_tokens_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.links, nl * cfg->lane_links_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.hash, nl * hs))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.tok_slot, nl * cfg->frame_tokens_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.wl, 2 * nl * cfg->frame_tokens_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.c_tot, nl * cfg->frame_cands_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.c_ac, nl * cfg->frame_cands_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.c_dst, nl * cfg->frame_cands_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.c_arc, nl * cfg->frame_cands_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.c_src, nl * cfg->frame_cands_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.info, nl))) return rc;
+  if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
+  // empty table: key = -1, cost = max, tok = -1, stamp = 0
+  std::vector<Slot> init((size_t)hs, Slot{kEmpty, kEncMax, -1, 0});
+  for (int l = 0; l < nlanes; l++) K3_HIP_CHECK(hipMemcpy(p.hash + (size_t)l * hs, init.data(), sizeof(Slot) * hs, hipMemcpyHostToDevice));
+  K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_decode_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  *out = d.release();
+  return K3_OK;
+}
+
+extern "C" void k3_decoder_destroy(k3_decoder *d) { delete d; }
+
+extern "C" int k3_decoder_decode_batch(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream) {
+  K3_REQUIRE(d && d_loglikes && h_row_off && num_utts > 0 && num_utts <= d->nlanes && ld >= d->num_pdfs, "k3_decoder_decode_batch: bad argument");
+  int maxT = 0; d->last_frames.resize(num_utts);
+  for (int u = 0; u < num_utts; u++) {
+    const long long T = h_row_off[u + 1] - h_row_off[u];
+    K3_REQUIRE(T > 0 && T < (1 << 30), "k3_decoder_decode_batch: utterance with no frames");
+    d->last_frames[u] = (int)T; maxT = std::max(maxT, (int)T);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  DecParams &p = d->p;
+  if (maxT + 2 > d->fstride) {      // (re)allocate the per-frame arrays
+    K3_HIP_CHECK(hipStreamSynchronize(st));
+    for (void *q : d->frame_allocs) (void)hipFree(q);
+    d->frame_allocs.clear();
+    d->fstride = maxT + 2; const size_t n = (size_t)d->nlanes * d->fstride; int rc;
+    if ((rc = dmalloc(&d->frame_allocs, &p.tok_off, n))) return rc;
+    if ((rc = dmalloc(&d->frame_allocs, &p.link_off_e, n))) return rc;
+    if ((rc = dmalloc(&d->frame_allocs, &p.link_off_n, n))) return rc;
+    if ((rc = dmalloc(&d->frame_allocs, &p.st_ntoks, n))) return rc;
+    if ((rc = dmalloc(&d->frame_allocs, &p.st_cur, n))) return rc;
+    if ((rc = dmalloc(&d->frame_allocs, &p.st_ab, n))) return rc;
+    if ((rc = dmalloc(&d->frame_allocs, &p.st_next, n))) return rc;
+    if ((rc = dmalloc(&d->frame_allocs, &p.st_co, n))) return rc;
+    p.fstride = d->fstride;
+  }
+  std::vector<long long> ro(h_row_off, h_row_off + num_utts + 1);
+  K3_HIP_CHECK(hipMemcpyAsync(d->d_row_off, ro.data(), sizeof(long long) * (num_utts + 1), hipMemcpyHostToDevice, st));
+  K3_HIP_CHECK(hipStreamSynchronize(st));    // ro is a stack-scoped staging buffer
+  p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off;
+  const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
+  hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k3_decode_prune_kernel, dim3(num_utts), dim3(kBlock), 0, st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  d->last_utts = num_utts; d->last_stream = st; d->info_valid = false;
+  return K3_OK;
+}
+
+static int fetch_info(k3_decoder *d) {
+  if (d->info_valid) return K3_OK;
+  K3_REQUIRE(d->last_utts > 0, "k3_decoder: no batch has been decoded");
+  K3_HIP_CHECK(hipStreamSynchronize(d->last_stream));
+  d->h_info.resize(d->last_utts);
+  K3_HIP_CHECK(hipMemcpy(d->h_info.data(), d->p.info, sizeof(LaneInfo) * d->last_utts, hipMemcpyDeviceToHost));
+  d->info_valid = true;
+  return K3_OK;
+}
+
+extern "C" int k3_decoder_lattice_info(k3_decoder *d, int64_t *h_info) {
+  K3_REQUIRE(d && h_info, "k3_decoder_lattice_info: null argument");
+  { const int rc = fetch_info(d); if (rc) return rc; }
+  int worst = K3_OK;
+  for (int u = 0; u < d->last_utts; u++) {
+    const LaneInfo &li = d->h_info[u]; int64_t *o = h_info + 8 * u;
+    o[0] = li.status == kStOk ? li.out_states : 0; o[1] = li.status == kStOk ? li.out_arcs : 0; o[2] = li.status; o[3] = li.reached_final;
+    o[4] = li.n_tokens; o[5] = li.n_links; o[6] = li.max_frame_tokens; o[7] = li.n_cands;
+    if (li.status < 0) { worst = li.status; k3::set_error("k3_decoder: utterance %d failed with status %d (%s); tokens %lld links %lld max tokens/frame %d -- raise the k3_decoder_config capacities",
+                                                          u, li.status, li.status == K3_ERR_OVERFLOW ? "capacity overflow" : "internal error", li.n_tokens, li.n_links, li.max_frame_tokens); }
+  }
+  return worst;
+}
+
+extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int32_t *st_state, float *st_cost, float *st_final, int32_t *arc_src, int32_t *arc_dst,
+                                           int32_t *arc_il, int32_t *arc_ol, float *arc_g, float *arc_ac) {
+  K3_REQUIRE(d && st_frame && st_state && st_cost && st_final && arc_src && arc_dst && arc_il && arc_ol && arc_g && arc_ac, "k3_decoder_get_raw_lattices: null argument");
+  { const int rc = fetch_info(d); if (rc) return rc; }
+  const int U = d->last_utts;
+  std::vector<long long> so(U + 1, 0), ao(U + 1, 0);
+  for (int u = 0; u < U; u++) { const LaneInfo &li = d->h_info[u]; const bool ok = li.status == kStOk; so[u + 1] = so[u] + (ok ? li.out_states : 0); ao[u + 1] = ao[u] + (ok ? li.out_arcs : 0); }
+  const size_t NS = (size_t)so[U], NA = (size_t)ao[U];
+  std::vector<void *> tmp; OutParams o{};
+  long long *d_so, *d_ao; int rc;
+  auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
+  if ((rc = dmalloc(&tmp, &d_so, U + 1)) || (rc = dmalloc(&tmp, &d_ao, U + 1)) || (rc = dmalloc(&tmp, &o.st_frame, NS)) || (rc = dmalloc(&tmp, &o.st_state, NS)) ||
+      (rc = dmalloc(&tmp, &o.st_cost, NS)) || (rc = dmalloc(&tmp, &o.st_final, NS)) || (rc = dmalloc(&tmp, &o.arc_src, NA)) || (rc = dmalloc(&tmp, &o.arc_dst, NA)) ||
+      (rc = dmalloc(&tmp, &o.arc_il, NA)) || (rc = dmalloc(&tmp, &o.arc_ol, NA)) || (rc = dmalloc(&tmp, &o.arc_g, NA)) || (rc = dmalloc(&tmp, &o.arc_ac, NA)) ||
+      (rc = dmalloc(&tmp, &o.newidx, (size_t)U * d->cfg.lane_tokens_cap))) { cleanup(); return rc; }
+  o.st_off = d_so; o.arc_off = d_ao;
+  hipStream_t st = d->last_stream;
+#define K3_TRY(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { cleanup(); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
+  K3_TRY(hipMemcpy(d_so, so.data(), sizeof(long long) * (U + 1), hipMemcpyHostToDevice));
+  K3_TRY(hipMemcpy(d_ao, ao.data(), sizeof(long long) * (U + 1), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k3_decode_output_kernel, dim3(U), dim3(kBlock), 0, st, d->p, o);
+  K3_TRY(hipGetLastError());
+  K3_TRY(hipStreamSynchronize(st));
+  K3_TRY(hipMemcpy(st_frame, o.st_frame, 4 * NS, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(st_state, o.st_state, 4 * NS, hipMemcpyDeviceToHost));
+  K3_TRY(hipMemcpy(st_cost, o.st_cost, 4 * NS, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(st_final, o.st_final, 4 * NS, hipMemcpyDeviceToHost));
+  K3_TRY(hipMemcpy(arc_src, o.arc_src, 4 * NA, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(arc_dst, o.arc_dst, 4 * NA, hipMemcpyDeviceToHost));
+  K3_TRY(hipMemcpy(arc_il, o.arc_il, 4 * NA, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(arc_ol, o.arc_ol, 4 * NA, hipMemcpyDeviceToHost));
+  K3_TRY(hipMemcpy(arc_g, o.arc_g, 4 * NA, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(arc_ac, o.arc_ac, 4 * NA, hipMemcpyDeviceToHost));
+#undef K3_TRY
+  cleanup();
+  return K3_OK;
+}
+
+extern "C" int k3_decoder_frame_stats(k3_decoder *d, int32_t utt, int32_t *ntoks, float *cur, float *ab, float *next, float *co) {
+  K3_REQUIRE(d && utt >= 0 && utt < d->last_utts, "k3_decoder_frame_stats: bad utterance index");
+  { const int rc = fetch_info(d); if (rc) return rc; }
+  const int T = d->last_frames[utt]; const size_t off = (size_t)utt * d->fstride;
+  if (ntoks) K3_HIP_CHECK(hipMemcpy(ntoks, d->p.st_ntoks + off, 4 * T, hipMemcpyDeviceToHost));
+  if (cur) K3_HIP_CHECK(hipMemcpy(cur, d->p.st_cur + off, 4 * T, hipMemcpyDeviceToHost));
+  if (ab) K3_HIP_CHECK(hipMemcpy(ab, d->p.st_ab + off, 4 * T, hipMemcpyDeviceToHost));
+  if (next) K3_HIP_CHECK(hipMemcpy(next, d->p.st_next + off, 4 * T, hipMemcpyDeviceToHost));
+  if (co) K3_HIP_CHECK(hipMemcpy(co, d->p.st_co + off, 4 * T, hipMemcpyDeviceToHost));
+  return K3_OK;
+}

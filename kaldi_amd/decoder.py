@@ -1,0 +1,89 @@
+"""Python plumbing over the decoder C ABI (k3_fst_*, k3_decoder_*): what the C++ adapters CudaFst / CudaDecoder
+(kaldi_amd/host) call, exposed to tests and bench.py.  torch = device buffers + stream only."""
+import ctypes, numpy as np, torch
+from . import lib as _l
+from .lattice import RawLattice
+
+def decoder_config(**kw):
+    """k3_decoder_config with LatticeFasterDecoderConfig defaults; override by keyword (beam=15.0, max_active=10000, ...)."""
+    c = _l.DecoderConfig(); _l.load().k3_decoder_config_default(ctypes.byref(c))
+    for k, v in kw.items():
+        assert hasattr(c, k), k
+        setattr(c, k, v)
+    return c
+
+class CudaFst:
+    """The decoding graph resident in HBM (cf. cuda_decoder::CudaFst, cudadecoder/cuda-fst.h:62-149).
+    fst: kaldi_amd.fst.Fst; tid2pdf: int32 map transition-id -> pdf-id (ApplyTransitionModelOnIlabels, cuda-fst.cc:166-175)."""
+    def __init__(self, fst, tid2pdf):
+        self._L = _l.load(); self._h = ctypes.c_void_p()
+        t2p = np.ascontiguousarray(tid2pdf, np.int32)
+        self.start = fst.start; self.num_states = fst.num_states; self.num_arcs = fst.num_arcs
+        _l.check(self._L.k3_fst_create(fst.num_states, fst.start, fst.arc_offsets.ctypes.data, fst.ilabel.ctypes.data, fst.olabel.ctypes.data,
+                                       fst.weight.ctypes.data, fst.nextstate.ctypes.data, fst.final.ctypes.data, t2p.ctypes.data, t2p.size, ctypes.byref(self._h)))
+
+    @classmethod
+    def empty(cls, num_states, num_arcs, start):
+        """receiver side of the graph broadcast: an image of the right shape, filled by a collective"""
+        self = cls.__new__(cls); self._L = _l.load(); self._h = ctypes.c_void_p()
+        self.start = start; self.num_states = num_states; self.num_arcs = num_arcs
+        _l.check(self._L.k3_fst_create_empty(num_states, num_arcs, start, ctypes.byref(self._h)))
+        return self
+
+    def image(self):
+        """(device pointer, bytes) of the packed read-only graph image"""
+        ptr, n = ctypes.c_void_p(), ctypes.c_int64()
+        _l.check(self._L.k3_fst_image(self._h, ctypes.byref(ptr), ctypes.byref(n)))
+        return ptr.value, n.value
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.k3_fst_destroy(self._h); self._h = ctypes.c_void_p()
+
+class CudaDecoder:
+    """Batched lattice decoder (cf. cuda_decoder::CudaDecoder, cudadecoder/cuda-decoder.h:224-345): nlanes utterances per call."""
+    INFO = ("lat_states", "lat_arcs", "status", "reached_final", "tokens", "links", "max_frame_tokens", "arcs_examined")
+    def __init__(self, fst, config, nlanes, num_pdfs):
+        self._L = _l.load(); self._h = ctypes.c_void_p(); self.fst = fst; self.config = config; self.nlanes = nlanes
+        _l.check(self._L.k3_decoder_create(fst._h, ctypes.byref(config), nlanes, num_pdfs, ctypes.byref(self._h)))
+        self._n = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.k3_decoder_destroy(self._h); self._h = ctypes.c_void_p()
+
+    def DecodeBatch(self, loglikes, row_offsets):
+        """loglikes: float32 [rows x >= num_pdfs] on the GPU; utterance u = rows row_offsets[u]..row_offsets[u+1] (host ints).
+        Asynchronous on the current stream."""
+        assert loglikes.is_cuda and loglikes.dtype == torch.float32 and loglikes.stride(1) == 1
+        ro = np.ascontiguousarray(row_offsets, np.int64); self._n = ro.size - 1
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _l.check(self._L.k3_decoder_decode_batch(self._h, self._n, loglikes.data_ptr(), loglikes.stride(0), ro.ctypes.data, st))
+
+    def LatticeInfo(self, check=True):
+        """int64 [num_utts x 8], columns = CudaDecoder.INFO (synchronises)"""
+        info = np.zeros((self._n, 8), np.int64)
+        rc = self._L.k3_decoder_lattice_info(self._h, info.ctypes.data)
+        if check: _l.check(rc)
+        return info
+
+    def GetRawLattices(self):
+        """list of RawLattice, one per utterance of the last batch (GetRawLattice, not yet Connect()-ed)"""
+        info = self.LatticeInfo()
+        so = np.concatenate([[0], np.cumsum(info[:, 0])]); ao = np.concatenate([[0], np.cumsum(info[:, 1])])
+        NS, NA = int(so[-1]), int(ao[-1])
+        si = [np.zeros(max(NS, 1), np.int32) for _ in range(2)]; sf = [np.zeros(max(NS, 1), np.float32) for _ in range(2)]
+        ai = [np.zeros(max(NA, 1), np.int32) for _ in range(4)]; af = [np.zeros(max(NA, 1), np.float32) for _ in range(2)]
+        _l.check(self._L.k3_decoder_get_raw_lattices(self._h, si[0].ctypes.data, si[1].ctypes.data, sf[0].ctypes.data, sf[1].ctypes.data,
+                                                     ai[0].ctypes.data, ai[1].ctypes.data, ai[2].ctypes.data, ai[3].ctypes.data, af[0].ctypes.data, af[1].ctypes.data))
+        out = []
+        for u in range(self._n):
+            s0, s1, a0, a1 = so[u], so[u + 1], ao[u], ao[u + 1]
+            out.append(RawLattice(si[0][s0:s1], si[1][s0:s1], sf[1][s0:s1], ai[0][a0:a1], ai[1][a0:a1], ai[2][a0:a1], ai[3][a0:a1], af[0][a0:a1], af[1][a0:a1],
+                                  self.fst.start, st_cost=sf[0][s0:s1]))
+        return out
+
+    def FrameStats(self, utt, num_frames):
+        nt = np.zeros(num_frames, np.int32); f = [np.zeros(num_frames, np.float32) for _ in range(4)]
+        _l.check(self._L.k3_decoder_frame_stats(self._h, utt, nt.ctypes.data, f[0].ctypes.data, f[1].ctypes.data, f[2].ctypes.data, f[3].ctypes.data))
+        return dict(ntoks=nt, cur_cutoff=f[0], adaptive_beam=f[1], next_cutoff=f[2], cost_offset=f[3])

@@ -23,6 +23,12 @@ class NnetInfo(ctypes.Structure):
     _fields_ = [("input_dim", ctypes.c_int32), ("output_dim", ctypes.c_int32), ("left_context", ctypes.c_int32), ("right_context", ctypes.c_int32),
                 ("num_components", ctypes.c_int32), ("num_fused_nodes", ctypes.c_int32), ("has_priors", ctypes.c_int32), ("num_params", ctypes.c_int64)]
 
+class DecoderConfig(ctypes.Structure):
+    """k3_decoder_config (include/k3hip.h); decoding fields = LatticeFasterDecoderConfig (decoder/lattice-faster-decoder.h:37-107)."""
+    _fields_ = [("beam", ctypes.c_float), ("max_active", ctypes.c_int32), ("min_active", ctypes.c_int32), ("lattice_beam", ctypes.c_float),
+                ("beam_delta", ctypes.c_float), ("frame_tokens_cap", ctypes.c_int32), ("frame_cands_cap", ctypes.c_int32),
+                ("lane_tokens_cap", ctypes.c_int64), ("lane_links_cap", ctypes.c_int64)]
+
 WINDOW_TYPES = {"hanning": 0, "sine": 1, "hamming": 2, "povey": 3, "rectangular": 4, "blackman": 5}
 
 _lib = None
@@ -55,6 +61,19 @@ def load():
     L.k3_nnet_batch_output_rows.argtypes = [vp, vp]; L.k3_nnet_batch_output_rows.restype = i64
     L.k3_nnet_batch_flops.argtypes = [vp]; L.k3_nnet_batch_flops.restype = ctypes.c_double
     L.k3_nnet_forward.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.k3_fst_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, ctypes.POINTER(vp)]
+    L.k3_fst_create_empty.argtypes = [i32, i64, i32, ctypes.POINTER(vp)]
+    L.k3_fst_destroy.argtypes = [vp]; L.k3_fst_destroy.restype = None
+    L.k3_fst_num_arcs.argtypes = [vp]; L.k3_fst_num_arcs.restype = i64
+    L.k3_fst_num_states.argtypes = [vp]; L.k3_fst_num_states.restype = i32
+    L.k3_fst_image.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    L.k3_decoder_config_default.argtypes = [ctypes.POINTER(DecoderConfig)]; L.k3_decoder_config_default.restype = None
+    L.k3_decoder_create.argtypes = [vp, ctypes.POINTER(DecoderConfig), i32, i32, ctypes.POINTER(vp)]
+    L.k3_decoder_destroy.argtypes = [vp]; L.k3_decoder_destroy.restype = None
+    L.k3_decoder_decode_batch.argtypes = [vp, i32, vp, i64, vp, vp]
+    L.k3_decoder_lattice_info.argtypes = [vp, vp]
+    L.k3_decoder_get_raw_lattices.argtypes = [vp] + [vp] * 10
+    L.k3_decoder_frame_stats.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

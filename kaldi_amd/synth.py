@@ -180,3 +180,63 @@ def make_tdnn(seed=1, input_dim=40, dim=512, offsets=((-1, 0, 1), (-1, 0, 1), (-
     C.append(("output.affine", "affine", dict(W=Wo, b=bo))); L.append(f"component-node name=output.affine component=output.affine input={prev}")
     L.append("output-node name=output input=output.affine objective=linear")
     return net
+
+# ----------------------------------------------------------------------------- synthetic HCLG ----
+def make_hclg(num_states=2_000_000, num_arcs=5_000_000, num_pdfs=6024, seed=4321, eps_frac=0.25, selfloop_frac=0.6,
+              olabel_frac=0.08, final_frac=0.03, start_degree=4000, num_words=200_000):
+    """A decodable graph with HCLG-like statistics: mean out-degree num_arcs/num_states with a heavy
+    start/loop state, ~(1-eps_frac) emitting arcs with ilabel = transition-id in [1, 2*num_pdfs] (tid -> pdf is
+    (tid-1) mod num_pdfs, see tid2pdf()), self-loops on selfloop_frac of the states, epsilon arcs only from lower to
+    higher state ids (=> no epsilon cycles, which TopSortTokens asserts: lattice-faster-decoder.cc:995), olabels on
+    olabel_frac of the arcs, final_frac final states; every state is accessible and co-accessible.
+    Returns a kaldi_amd.fst.Fst."""
+    from .fst import Fst
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import breadth_first_order
+    rng = np.random.default_rng(seed)
+    S = int(num_states); assert S >= 4
+    src, dst, eps = [], [], []
+    # (b) self-loops (emitting)
+    loops = np.nonzero(rng.random(S) < selfloop_frac)[0].astype(np.int64)
+    src.append(loops); dst.append(loops); eps.append(np.zeros(loops.size, bool))
+    # (c) the heavy start/loop state
+    sd = int(min(start_degree, max(1, S // 2)))
+    src.append(np.zeros(sd, np.int64)); dst.append(rng.integers(1, S, sd)); eps.append(np.zeros(sd, bool))
+    # (a) accessibility: every state s >= 1 gets an in-arc from a random earlier state
+    s_all = np.arange(1, S, dtype=np.int64)
+    par = (rng.random(S - 1) * s_all).astype(np.int64)
+    # (e) every state without a child in (a) gets one emitting arc to a random state (keeps it co-accessible w.h.p.)
+    has_child = np.zeros(S, bool); has_child[par] = True; has_child[0] = True
+    lack = np.nonzero(~has_child)[0].astype(np.int64)
+    n_rest = max(0, int(num_arcs) - (S - 1) - loops.size - sd - lack.size)
+    p_eps = min(0.9, eps_frac * float(num_arcs) / max(1, S - 1 + n_rest))   # epsilon arcs only occur in (a) and (d)
+    src.append(par); dst.append(s_all); eps.append(rng.random(S - 1) < p_eps)
+    src.append(lack); dst.append(rng.integers(0, S, lack.size)); eps.append(np.zeros(lack.size, bool))
+    # (d) the rest: random sources; emitting arcs go anywhere, epsilon arcs go to a higher state id
+    rs = rng.integers(0, S - 1, n_rest); re_ = rng.random(n_rest) < p_eps
+    rd = np.where(re_, rs + 1 + (rng.random(n_rest) * (S - 1 - rs)).astype(np.int64), rng.integers(0, S, n_rest))
+    src.append(rs); dst.append(rd); eps.append(re_)
+    src, dst, eps = np.concatenate(src), np.concatenate(dst), np.concatenate(eps)
+    final = np.full(S, np.inf, np.float32)
+    fin = np.nonzero(rng.random(S) < final_frac)[0]
+    if fin.size == 0: fin = np.array([S - 1])
+    final[fin] = rng.uniform(0.0, 5.0, fin.size).astype(np.float32)
+    # co-accessibility: reverse BFS from a super-final node; patch the states it misses with an arc to a final state
+    rev = csr_matrix((np.ones(src.size + fin.size, np.int8), (np.concatenate([dst, np.full(fin.size, S)]), np.concatenate([src, fin]))), shape=(S + 1, S + 1))
+    seen = np.zeros(S + 1, bool); seen[breadth_first_order(rev, S, directed=True, return_predecessors=False)] = True
+    miss = np.nonzero(~seen[:S])[0]
+    if miss.size:
+        src = np.concatenate([src, miss]); dst = np.concatenate([dst, fin[rng.integers(0, fin.size, miss.size)]]); eps = np.concatenate([eps, np.zeros(miss.size, bool)])
+    A = src.size
+    ilabel = np.where(eps, 0, rng.integers(1, 2 * num_pdfs + 1, A)).astype(np.int32)
+    has_word = rng.random(A) < olabel_frac
+    olabel = np.where(has_word, rng.integers(1, num_words, A), 0).astype(np.int32)
+    weight = np.where(has_word, rng.uniform(2.0, 12.0, A), rng.uniform(0.05, 2.5, A)).astype(np.float32)
+    perm = rng.permutation(A)       # arcs of a state in random (but seeded) order, emitting and epsilon interleaved
+    return Fst.from_arcs(S, 0, src[perm], ilabel[perm], olabel[perm], weight[perm], dst[perm], final)
+
+def tid2pdf(num_pdfs):
+    """the synthetic TransitionInformation: transition-id t in [1, 2*num_pdfs] -> pdf (t-1) mod num_pdfs; index 0 unused."""
+    t = np.arange(2 * num_pdfs + 1, dtype=np.int64)
+    m = ((t - 1) % num_pdfs).astype(np.int32); m[0] = 0
+    return m

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 TARGETS = [
     ("libk3oracle_feat.so", ["feat_oracle.c"], "gcc", ["-O2", "-std=gnu11"]),
     ("libk3oracle_nnet.so", ["nnet_oracle.c"], "gcc", ["-O3", "-std=gnu11", "-march=native"]),
-    ("libk3oracle_dec.so", ["lattice_faster_oracle.cc"], "g++", ["-O2", "-std=c++17"]),
+    ("libk3oracle_dec.so", ["lattice_faster_oracle.cc"], "g++", ["-O2", "-std=c++17", "-ffp-contract=off", "-Wall"]),
 ]
 
 def _stale(out, srcs):

@@ -1,0 +1,508 @@
+/*
+ * oracle/lattice_faster_oracle.cc  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of Kaldi's LatticeFasterDecoder (the parity oracle north_star names:
+ * "lattice-faster-decoder") over a plain CSR WFST.  The reference's decoder cannot be compiled in this
+ * container (src/decoder, src/lat and src/fstext need OpenFst 1.8.4, which is neither installed nor vendored:
+ * tools/Makefile:10), and the reference holds NO golden vectors or tests for its decoders
+ * (decoder/Makefile:6 and cudadecoder/Makefile:16 have empty TESTFILES)  =>  PARITY UNPINNED for this file:
+ * it is checked only against hand-computed tiny cases and its own two evaluation modes (tests/test_oracle_decoder.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the shared object built from
+ * this file; kaldi_amd/ never does.
+ *
+ * What is restated (paths relative to /root/reference/src):
+ *   decoder/lattice-faster-decoder.h:37-107   LatticeFasterDecoderConfig (beam, max_active, min_active, lattice_beam,
+ *                                             prune_interval, beam_delta, hash_ratio, prune_scale)
+ *   decoder/lattice-faster-decoder.cc:63-81   InitDecoding            -> Decoder::Init
+ *                                   :227-233  PossiblyResizeHash      -> Decoder::MaybeGrowHash
+ *                                   :259-302  FindOrAddToken          -> Decoder::FindOrAdd
+ *                                   :308-379  PruneForwardLinks       -> Decoder::PruneLinks
+ *                                   :385-467  PruneForwardLinksFinal  -> Decoder::PruneLinksFinal
+ *                                   :488-507  PruneTokensForFrame     -> Decoder::PruneTokens
+ *                                   :515-542  PruneActiveTokens       -> Decoder::PruneActive
+ *                                   :545-586  ComputeFinalCosts       -> Decoder::FinalCosts
+ *                                   :588-632  AdvanceDecoding         -> Decoder::Advance
+ *                                   :634-649  FinalizeDecoding        -> Decoder::Finalize
+ *                                   :653-720  GetCutoff               -> Decoder::Cutoff
+ *                                   :723-814  ProcessEmitting         -> Decoder::Emitting
+ *                                   :830-897  ProcessNonemitting      -> Decoder::Nonemitting
+ *                                   :114-197  GetRawLattice           -> Decoder::RawLattice (states keyed by token,
+ *                                             the per-frame numbering of TopSortTokens :927-1002 is not reproduced:
+ *                                             parity is defined on the lattice canonicalised by (frame, fst state))
+ *   util/hash-list-inl.h:37-165               HashList (bucket-chain list whose iteration order decides the token
+ *                                             visit order of ProcessEmitting)            -> struct StateList
+ *   decoder/decodable-matrix.h / nnet3/nnet-am-decodable-simple.h  LogLikelihood(frame, tid) = M(frame, tid2pdf[tid])
+ *
+ * Two evaluation modes:
+ *   mode 0 "literal":   exactly the serial algorithm, next_cutoff tightened while the token list is traversed in
+ *                       HashList order (so a few tokens/links exist only because the bound was still loose).
+ *   mode 1 "two-pass":  the order-independent definition the GPU decoder implements: an arc is accepted iff
+ *                       tot < min(prepass bound, min_tot + adaptive_beam), i.e. against the FINAL next_cutoff.
+ * SURVEY.md 9.1 argues that both give the same lattice after FinalizeDecoding except at exact float ties and in
+ * the min_active corner; tests assert equality on the test sets and the GPU path is compared with both.
+ * All arithmetic is float32 in the reference's evaluation order; compile WITHOUT -ffast-math / FMA contraction.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+const float kInf = std::numeric_limits<float>::infinity();
+
+struct Fst {              // generic CSR acceptor/transducer: arcs of state s are [off[s], off[s+1]) in FST order
+  int32_t num_states, start;
+  const int32_t *off, *ilabel, *olabel, *next;
+  const float *weight, *final_cost;   // final_cost[s] = +inf for non-final states
+  std::vector<int32_t> num_ieps;      // NumInputEpsilons(s)
+};
+
+struct Config {           // LatticeFasterDecoderConfig, lattice-faster-decoder.h:37-107
+  float beam; int32_t max_active, min_active; float lattice_beam; int32_t prune_interval;
+  float beam_delta, hash_ratio, prune_scale;
+};
+
+struct Link { int32_t dst, ilabel, olabel; float graph, ac; int32_t next; };
+struct Tok  { float tot, extra; int32_t links, next, state, frame; };
+struct FrameList { int32_t head = -1; bool must_prune_links = true, must_prune_toks = true; };
+
+// util/hash-list-inl.h: elements form ONE singly linked list; a bucket remembers its last element and the bucket
+// that was occupied before it, so a bucket's elements are the run between the previous bucket's last element
+// and its own.  New buckets go to the list tail; new elements of an occupied bucket go right after its last one.
+struct StateList {
+  struct Elem { int32_t key, val, tail; };
+  struct Bucket { int64_t prev_bucket; int32_t last; };
+  std::vector<Elem> elems; std::vector<int32_t> free_;
+  std::vector<Bucket> buckets; size_t hash_size = 0;
+  int32_t head = -1; int64_t tail_bucket = -1;
+  size_t Size() const { return hash_size; }
+  void SetSize(size_t n) { hash_size = n; if (n > buckets.size()) buckets.resize(n, Bucket{0, -1}); }
+  int32_t NewElem() {
+    if (!free_.empty()) { int32_t e = free_.back(); free_.pop_back(); return e; }
+    elems.push_back(Elem{0, -1, -1}); return (int32_t)elems.size() - 1;
+  }
+  void Delete(int32_t e) { free_.push_back(e); }
+  int32_t Clear() {   // hands the list to the caller, empties the index
+    for (int64_t b = tail_bucket; b != -1; b = buckets[b].prev_bucket) buckets[b].last = -1;
+    tail_bucket = -1; int32_t h = head; head = -1; return h;
+  }
+  int32_t BucketBegin(const Bucket &b) const { return b.prev_bucket == -1 ? head : elems[buckets[b.prev_bucket].last].tail; }
+  int32_t Insert(int32_t key, int32_t val) {      // returns the element (existing or new)
+    const size_t idx = (size_t)key % hash_size; Bucket &b = buckets[idx];
+    if (b.last != -1) {
+      const int32_t stop = elems[b.last].tail;
+      for (int32_t e = BucketBegin(b); e != stop; e = elems[e].tail) if (elems[e].key == key) return e;
+    }
+    const int32_t e = NewElem(); elems[e].key = key; elems[e].val = val;
+    Bucket &bb = buckets[idx];
+    if (bb.last == -1) {
+      if (tail_bucket == -1) head = e; else elems[buckets[tail_bucket].last].tail = e;
+      elems[e].tail = -1; bb.last = e; bb.prev_bucket = tail_bucket; tail_bucket = (int64_t)idx;
+    } else {
+      elems[e].tail = elems[bb.last].tail; elems[bb.last].tail = e; bb.last = e;
+    }
+    return e;
+  }
+};
+
+struct FrameStat { int32_t ntoks; float cur_cutoff, adaptive_beam, next_cutoff, cost_offset; };
+
+struct Decoder {
+  const Fst &fst; Config cfg; int mode;
+  const float *loglikes; int64_t ld; const int32_t *tid2pdf; int32_t num_frames_ready;
+  std::vector<Tok> toks; std::vector<int32_t> free_toks;
+  std::vector<Link> links; std::vector<int32_t> free_links;
+  std::vector<FrameList> active;      // active[f]: tokens after consuming f frames
+  StateList cur;                      // state -> token of the newest frame
+  std::vector<float> cost_offsets; std::vector<int32_t> queue; std::vector<float> tmp;
+  int64_t num_toks = 0;
+  bool finalized = false; float final_relative_cost = kInf, final_best_cost = kInf;
+  std::vector<std::pair<int32_t, float>> final_costs;   // (token, final cost) for final-state tokens of the last frame
+  std::vector<char> tok_is_final;                       // indexed by token when finalized
+  // diagnostics
+  std::vector<FrameStat> stats; int64_t n_extra_links = 0, n_extra_toks = 0, n_best_ties = 0, n_links_created = 0;
+
+  Decoder(const Fst &f, const Config &c, int m) : fst(f), cfg(c), mode(m) { cur.SetSize(1000); }  // lattice-faster-decoder.cc:37-43
+
+  float LogLike(int32_t frame, int32_t tid) const { return loglikes[(int64_t)frame * ld + tid2pdf[tid]]; }
+  int32_t NumFramesDecoded() const { return (int32_t)active.size() - 1; }
+
+  int32_t NewTok(float tot, float extra, int32_t next, int32_t state, int32_t frame) {
+    int32_t t;
+    if (!free_toks.empty()) { t = free_toks.back(); free_toks.pop_back(); } else { toks.push_back(Tok()); t = (int32_t)toks.size() - 1; }
+    toks[t] = Tok{tot, extra, -1, next, state, frame}; return t;
+  }
+  int32_t NewLink(int32_t dst, int32_t il, int32_t ol, float g, float a, int32_t next) {
+    int32_t l;
+    if (!free_links.empty()) { l = free_links.back(); free_links.pop_back(); } else { links.push_back(Link()); l = (int32_t)links.size() - 1; }
+    links[l] = Link{dst, il, ol, g, a, next}; n_links_created++; return l;
+  }
+  void DeleteLinks(int32_t t) { for (int32_t l = toks[t].links; l != -1;) { int32_t n = links[l].next; free_links.push_back(l); l = n; } toks[t].links = -1; }
+
+  void MaybeGrowHash(size_t n) {   // :227-233
+    const size_t want = (size_t)((float)n * cfg.hash_ratio);
+    if (want > cur.Size()) cur.SetSize(want);
+  }
+
+  // :259-302.  Returns the list element; *changed = new token or cost lowered.
+  int32_t FindOrAdd(int32_t state, int32_t frame_plus_one, float tot, bool *changed) {
+    int32_t &head = active[frame_plus_one].head;
+    const int32_t e = cur.Insert(state, -1);
+    if (cur.elems[e].val == -1) {
+      const int32_t t = NewTok(tot, 0.0f, head, state, frame_plus_one);
+      head = t; num_toks++; cur.elems[e].val = t;
+      if (changed) *changed = true;
+    } else {
+      Tok &t = toks[cur.elems[e].val];
+      if (t.tot > tot) { t.tot = tot; if (changed) *changed = true; }
+      else if (changed) *changed = false;
+    }
+    return e;
+  }
+
+  void Init() {   // :63-81
+    active.assign(1, FrameList());
+    const int32_t t = NewTok(0.0f, 0.0f, -1, fst.start, 0);
+    active[0].head = t; const int32_t e = cur.Insert(fst.start, t); (void)e; num_toks++;
+    Nonemitting(cfg.beam);
+  }
+
+  // :653-720.  list = element list handed over by cur.Clear()
+  float Cutoff(int32_t list, size_t *count, float *adaptive_beam, int32_t *best_elem) {
+    float best = kInf; size_t n = 0; *best_elem = -1;
+    const bool plain = (cfg.max_active == std::numeric_limits<int32_t>::max() && cfg.min_active == 0);
+    tmp.clear();
+    for (int32_t e = list; e != -1; e = cur.elems[e].tail, n++) {
+      const float w = toks[cur.elems[e].val].tot;
+      if (!plain) tmp.push_back(w);
+      if (w < best) { best = w; *best_elem = e; }
+      else if (w == best && *best_elem != -1) {
+        n_best_ties++;
+        // mode 1 breaks ties by the smaller FST state (what the GPU decoder does); mode 0 keeps the first in list order
+        if (mode == 1 && cur.elems[e].key < cur.elems[*best_elem].key) *best_elem = e;
+      }
+    }
+    *count = n;
+    if (plain) { *adaptive_beam = cfg.beam; return best + cfg.beam; }
+    const float beam_cutoff = best + cfg.beam; float min_active_cutoff = kInf, max_active_cutoff = kInf;
+    if (tmp.size() > (size_t)cfg.max_active) {
+      std::nth_element(tmp.begin(), tmp.begin() + cfg.max_active, tmp.end());
+      max_active_cutoff = tmp[cfg.max_active];
+    }
+    if (max_active_cutoff < beam_cutoff) { *adaptive_beam = max_active_cutoff - best + cfg.beam_delta; return max_active_cutoff; }
+    if (tmp.size() > (size_t)cfg.min_active) {
+      if (cfg.min_active == 0) min_active_cutoff = best;
+      else {
+        std::nth_element(tmp.begin(), tmp.begin() + cfg.min_active,
+                         tmp.size() > (size_t)cfg.max_active ? tmp.begin() + cfg.max_active : tmp.end());
+        min_active_cutoff = tmp[cfg.min_active];
+      }
+    }
+    if (min_active_cutoff > beam_cutoff) { *adaptive_beam = min_active_cutoff - best + cfg.beam_delta; return min_active_cutoff; }
+    *adaptive_beam = cfg.beam; return beam_cutoff;
+  }
+
+  // :723-814
+  float Emitting() {
+    const int32_t frame = (int32_t)active.size() - 1;
+    active.resize(active.size() + 1);
+    const int32_t list = cur.Clear();
+    int32_t best_elem; float adaptive_beam; size_t cnt;
+    const float cur_cutoff = Cutoff(list, &cnt, &adaptive_beam, &best_elem);
+    MaybeGrowHash(cnt);
+    float next_cutoff = kInf, cost_offset = 0.0f;
+    if (best_elem != -1) {   // pre-pass over the best token's arcs (:753-768); note the different evaluation order
+      const int32_t s = cur.elems[best_elem].key; const float tot = toks[cur.elems[best_elem].val].tot;
+      cost_offset = -tot;
+      for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++)
+        if (fst.ilabel[a] != 0) {
+          const float nw = fst.weight[a] + cost_offset - LogLike(frame, fst.ilabel[a]) + tot;
+          if (nw + adaptive_beam < next_cutoff) next_cutoff = nw + adaptive_beam;
+        }
+    }
+    cost_offsets.resize(frame + 1, 0.0f); cost_offsets[frame] = cost_offset;
+    float accept_cutoff = kInf;     // mode 1: the final bound, computed by a first pass over all arcs
+    if (mode == 1) {
+      float min_tot = kInf;
+      for (int32_t e = list; e != -1; e = cur.elems[e].tail) {
+        const int32_t s = cur.elems[e].key; const float c = toks[cur.elems[e].val].tot;
+        if (c <= cur_cutoff)
+          for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++)
+            if (fst.ilabel[a] != 0) {
+              const float ac = cost_offset - LogLike(frame, fst.ilabel[a]);
+              const float t = c + ac + fst.weight[a];
+              if (t < min_tot) min_tot = t;
+            }
+      }
+      accept_cutoff = next_cutoff;
+      if (min_tot + adaptive_beam < accept_cutoff) accept_cutoff = min_tot + adaptive_beam;
+    }
+    std::vector<std::pair<int32_t, float>> made;   // (link, tot) for the extras diagnostic (mode 0)
+    for (int32_t e = list, e_tail; e != -1; e = e_tail) {
+      const int32_t s = cur.elems[e].key, t = cur.elems[e].val;
+      if (toks[t].tot <= cur_cutoff) {
+        for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++) {
+          if (fst.ilabel[a] == 0) continue;
+          const float ac_cost = cost_offset - LogLike(frame, fst.ilabel[a]), graph_cost = fst.weight[a], cur_cost = toks[t].tot;
+          const float tot_cost = cur_cost + ac_cost + graph_cost;
+          if (mode == 1) { if (tot_cost >= accept_cutoff) continue; }
+          else {
+            if (tot_cost >= next_cutoff) continue;
+            else if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
+          }
+          const int32_t en = FindOrAdd(fst.next[a], frame + 1, tot_cost, nullptr);
+          toks[t].links = NewLink(cur.elems[en].val, fst.ilabel[a], fst.olabel[a], graph_cost, ac_cost, toks[t].links);
+          if (mode == 0) made.push_back({toks[t].links, tot_cost});
+        }
+      }
+      e_tail = cur.elems[e].tail; cur.Delete(e);
+    }
+    if (mode == 1) next_cutoff = accept_cutoff;
+    else {
+      for (auto &m : made) if (m.second >= next_cutoff) n_extra_links++;
+      for (int32_t t = active[frame + 1].head; t != -1; t = toks[t].next) if (toks[t].tot >= next_cutoff) n_extra_toks++;
+    }
+    stats.push_back(FrameStat{(int32_t)cnt, cur_cutoff, adaptive_beam, next_cutoff, cost_offset});
+    return next_cutoff;
+  }
+
+  // :830-897
+  void Nonemitting(float cutoff) {
+    const int32_t frame = (int32_t)active.size() - 2;
+    queue.clear();
+    for (int32_t e = cur.head; e != -1; e = cur.elems[e].tail) if (fst.num_ieps[cur.elems[e].key] != 0) queue.push_back(e);
+    while (!queue.empty()) {
+      const int32_t e = queue.back(); queue.pop_back();
+      const int32_t s = cur.elems[e].key, t = cur.elems[e].val;
+      const float cur_cost = toks[t].tot;
+      if (cur_cost >= cutoff) continue;
+      DeleteLinks(t);
+      for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++) {
+        if (fst.ilabel[a] != 0) continue;
+        const float graph_cost = fst.weight[a], tot_cost = cur_cost + graph_cost;
+        if (tot_cost < cutoff) {
+          bool changed;
+          const int32_t en = FindOrAdd(fst.next[a], frame + 1, tot_cost, &changed);
+          toks[t].links = NewLink(cur.elems[en].val, 0, fst.olabel[a], graph_cost, 0.0f, toks[t].links);
+          if (changed && fst.num_ieps[fst.next[a]] != 0) queue.push_back(en);
+        }
+      }
+    }
+  }
+
+  // :308-379
+  void PruneLinks(int32_t f, bool *extra_changed, bool *links_pruned, float delta) {
+    *extra_changed = false; *links_pruned = false;
+    bool changed = true;
+    while (changed) {
+      changed = false;
+      for (int32_t t = active[f].head; t != -1; t = toks[t].next) {
+        float tok_extra = kInf; int32_t prev = -1;
+        for (int32_t l = toks[t].links; l != -1;) {
+          const Tok &nt = toks[links[l].dst];
+          float link_extra = nt.extra + ((toks[t].tot + links[l].ac + links[l].graph) - nt.tot);
+          if (link_extra != link_extra) abort();
+          if (link_extra > cfg.lattice_beam) {
+            const int32_t nl = links[l].next;
+            if (prev != -1) links[prev].next = nl; else toks[t].links = nl;
+            free_links.push_back(l); l = nl; *links_pruned = true;
+          } else {
+            if (link_extra < 0.0f) link_extra = 0.0f;
+            if (link_extra < tok_extra) tok_extra = link_extra;
+            prev = l; l = links[l].next;
+          }
+        }
+        if (std::fabs(tok_extra - toks[t].extra) > delta) changed = true;
+        toks[t].extra = tok_extra;
+      }
+      if (changed) *extra_changed = true;
+    }
+  }
+
+  // :545-586 (final_costs keyed by token)
+  void FinalCosts(float *rel, float *best_out) {
+    final_costs.clear();
+    float best = kInf, best_final = kInf;
+    for (int32_t e = cur.head; e != -1; e = cur.elems[e].tail) {
+      const int32_t s = cur.elems[e].key, t = cur.elems[e].val;
+      const float fc = fst.final_cost[s], cost = toks[t].tot, with_final = cost + fc;
+      best = std::min(cost, best); best_final = std::min(with_final, best_final);
+      if (fc != kInf) final_costs.push_back({t, fc});
+    }
+    *rel = (best == kInf && best_final == kInf) ? kInf : best_final - best;
+    *best_out = (best_final != kInf) ? best_final : best;
+  }
+
+  static bool ApproxEqual(float a, float b, float tol) {   // base/kaldi-math.h:265-275
+    if (a == b) return true;
+    const float diff = std::fabs(a - b);
+    if (diff == kInf || diff != diff) return false;
+    return diff <= tol * (std::fabs(a) + std::fabs(b));
+  }
+
+  // :385-467
+  void PruneLinksFinal() {
+    const int32_t f = (int32_t)active.size() - 1;
+    FinalCosts(&final_relative_cost, &final_best_cost);
+    finalized = true;
+    std::vector<float> fc(toks.size(), final_costs.empty() ? 0.0f : kInf);
+    for (auto &p : final_costs) fc[p.first] = p.second;
+    for (int32_t e = cur.Clear(), n; e != -1; e = n) { n = cur.elems[e].tail; cur.Delete(e); }
+    bool changed = true; const float delta = 1.0e-05f;
+    while (changed) {
+      changed = false;
+      for (int32_t t = active[f].head; t != -1; t = toks[t].next) {
+        float tok_extra = toks[t].tot + fc[t] - final_best_cost; int32_t prev = -1;
+        for (int32_t l = toks[t].links; l != -1;) {
+          const Tok &nt = toks[links[l].dst];
+          float link_extra = nt.extra + ((toks[t].tot + links[l].ac + links[l].graph) - nt.tot);
+          if (link_extra > cfg.lattice_beam) {
+            const int32_t nl = links[l].next;
+            if (prev != -1) links[prev].next = nl; else toks[t].links = nl;
+            free_links.push_back(l); l = nl;
+          } else {
+            if (link_extra < 0.0f) link_extra = 0.0f;
+            if (link_extra < tok_extra) tok_extra = link_extra;
+            prev = l; l = links[l].next;
+          }
+        }
+        if (tok_extra > cfg.lattice_beam) tok_extra = kInf;
+        if (!ApproxEqual(toks[t].extra, tok_extra, delta)) changed = true;
+        toks[t].extra = tok_extra;
+      }
+    }
+  }
+
+  // :488-507
+  void PruneTokens(int32_t f) {
+    int32_t prev = -1;
+    for (int32_t t = active[f].head, n; t != -1; t = n) {
+      n = toks[t].next;
+      if (toks[t].extra == kInf) {
+        if (prev != -1) toks[prev].next = n; else active[f].head = n;
+        DeleteLinks(t); free_toks.push_back(t); toks[t].frame = -1; num_toks--;
+      } else prev = t;
+    }
+  }
+
+  // :515-542
+  void PruneActive(float delta) {
+    const int32_t cur_f = NumFramesDecoded();
+    for (int32_t f = cur_f - 1; f >= 0; f--) {
+      if (active[f].must_prune_links) {
+        bool ec = false, lp = false;
+        PruneLinks(f, &ec, &lp, delta);
+        if (ec && f > 0) active[f - 1].must_prune_links = true;
+        if (lp) active[f].must_prune_toks = true;
+        active[f].must_prune_links = false;
+      }
+      if (f + 1 < cur_f && active[f + 1].must_prune_toks) { PruneTokens(f + 1); active[f + 1].must_prune_toks = false; }
+    }
+  }
+
+  void Advance() {   // :588-632
+    while (NumFramesDecoded() < num_frames_ready) {
+      if (NumFramesDecoded() % cfg.prune_interval == 0) PruneActive(cfg.lattice_beam * cfg.prune_scale);
+      const float cutoff = Emitting();
+      Nonemitting(cutoff);
+    }
+  }
+
+  void Finalize() {  // :634-649
+    const int32_t last = NumFramesDecoded();
+    PruneLinksFinal();
+    for (int32_t f = last - 1; f >= 0; f--) { bool b1, b2; PruneLinks(f, &b1, &b2, 0.0f); PruneTokens(f + 1); }
+    PruneTokens(0);
+  }
+};
+
+struct Lattice {   // GetRawLattice (:114-197) output with states identified by (frame, fst state)
+  std::vector<int32_t> st_frame, st_state; std::vector<float> st_cost, st_final;   // st_final = +inf when not final
+  std::vector<int32_t> arc_src, arc_dst, arc_ilabel, arc_olabel; std::vector<float> arc_graph, arc_ac;
+  std::vector<FrameStat> stats; std::vector<float> cost_offsets;
+  int64_t n_extra_links, n_extra_toks, n_best_ties, n_links_created; int32_t reached_final; float final_relative_cost;
+};
+
+}  // namespace
+
+extern "C" {
+
+struct k3o_fst { int32_t num_states, start; const int32_t *arc_offsets, *ilabel, *olabel, *nextstate; const float *weight, *final_cost; };
+struct k3o_lfd_config { float beam; int32_t max_active, min_active; float lattice_beam; int32_t prune_interval; float beam_delta, hash_ratio, prune_scale; };
+
+// Decode one utterance: loglikes [num_frames x ld] (already scaled, as DecodableAmNnetSimple hands them over),
+// tid2pdf maps a transition-id (arc ilabel) to a column.  mode 0 = literal, 1 = two-pass.  Returns a lattice handle
+// (never NULL); an empty lattice (0 states) means "no tokens survived".
+void *k3o_lfd_decode(const k3o_fst *f, const float *loglikes, int32_t num_frames, int64_t ld, const int32_t *tid2pdf,
+                     const k3o_lfd_config *c, int32_t mode) {
+  Fst fst{f->num_states, f->start, f->arc_offsets, f->ilabel, f->olabel, f->nextstate, f->weight, f->final_cost, {}};
+  fst.num_ieps.assign(fst.num_states, 0);
+  for (int32_t s = 0; s < fst.num_states; s++) for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++) if (fst.ilabel[a] == 0) fst.num_ieps[s]++;
+  Config cfg{c->beam, c->max_active, c->min_active, c->lattice_beam, c->prune_interval, c->beam_delta, c->hash_ratio, c->prune_scale};
+  Decoder d(fst, cfg, mode);
+  d.loglikes = loglikes; d.ld = ld; d.tid2pdf = tid2pdf; d.num_frames_ready = num_frames;
+  d.Init(); d.Advance(); d.Finalize();
+  Lattice *L = new Lattice();
+  L->stats = d.stats; L->cost_offsets = d.cost_offsets;
+  L->n_extra_links = d.n_extra_links; L->n_extra_toks = d.n_extra_toks; L->n_best_ties = d.n_best_ties; L->n_links_created = d.n_links_created;
+  L->reached_final = (d.final_relative_cost != kInf) ? 1 : 0;   // ReachedFinal(): FinalRelativeCost() != inf
+  L->final_relative_cost = d.final_relative_cost;
+  const int32_t T = d.NumFramesDecoded();
+  std::vector<int32_t> id(d.toks.size(), -1);
+  for (int32_t fr = 0; fr <= T; fr++) {
+    if (d.active[fr].head == -1) { L->st_frame.clear(); L->st_state.clear(); L->st_cost.clear(); L->st_final.clear(); return L; }  // GetRawLattice returns false
+    for (int32_t t = d.active[fr].head; t != -1; t = d.toks[t].next) {
+      id[t] = (int32_t)L->st_frame.size();
+      L->st_frame.push_back(fr); L->st_state.push_back(d.toks[t].state); L->st_cost.push_back(d.toks[t].tot); L->st_final.push_back(kInf);
+    }
+  }
+  std::vector<float> fc(d.toks.size(), kInf);
+  for (auto &p : d.final_costs) fc[p.first] = p.second;
+  for (int32_t fr = 0; fr <= T; fr++)
+    for (int32_t t = d.active[fr].head; t != -1; t = d.toks[t].next) {
+      for (int32_t l = d.toks[t].links; l != -1; l = d.links[l].next) {
+        const Link &k = d.links[l];
+        float off = 0.0f;
+        if (k.ilabel != 0) off = d.cost_offsets[fr];
+        L->arc_src.push_back(id[t]); L->arc_dst.push_back(id[k.dst]); L->arc_ilabel.push_back(k.ilabel); L->arc_olabel.push_back(k.olabel);
+        L->arc_graph.push_back(k.graph); L->arc_ac.push_back(k.ac - off);
+      }
+      if (fr == T) {
+        if (!d.final_costs.empty()) { if (fc[t] != kInf) L->st_final[id[t]] = fc[t]; }
+        else L->st_final[id[t]] = 0.0f;       // LatticeWeight::One()
+      }
+    }
+  return L;
+}
+
+void k3o_lfd_sizes(const void *h, int64_t *out /* [8] */) {
+  const Lattice *L = (const Lattice *)h;
+  out[0] = (int64_t)L->st_frame.size(); out[1] = (int64_t)L->arc_src.size(); out[2] = (int64_t)L->stats.size();
+  out[3] = L->n_extra_links; out[4] = L->n_extra_toks; out[5] = L->n_best_ties; out[6] = L->reached_final; out[7] = L->n_links_created;
+}
+void k3o_lfd_states(const void *h, int32_t *frame, int32_t *state, float *cost, float *final_cost) {
+  const Lattice *L = (const Lattice *)h; const size_t n = L->st_frame.size();
+  memcpy(frame, L->st_frame.data(), 4 * n); memcpy(state, L->st_state.data(), 4 * n);
+  memcpy(cost, L->st_cost.data(), 4 * n); memcpy(final_cost, L->st_final.data(), 4 * n);
+}
+void k3o_lfd_arcs(const void *h, int32_t *src, int32_t *dst, int32_t *ilabel, int32_t *olabel, float *graph, float *ac) {
+  const Lattice *L = (const Lattice *)h; const size_t n = L->arc_src.size();
+  memcpy(src, L->arc_src.data(), 4 * n); memcpy(dst, L->arc_dst.data(), 4 * n); memcpy(ilabel, L->arc_ilabel.data(), 4 * n);
+  memcpy(olabel, L->arc_olabel.data(), 4 * n); memcpy(graph, L->arc_graph.data(), 4 * n); memcpy(ac, L->arc_ac.data(), 4 * n);
+}
+// per decoded frame: ntoks (size of the token list GetCutoff saw), cur_cutoff, adaptive_beam, next_cutoff, cost_offset
+void k3o_lfd_frame_stats(const void *h, int32_t *ntoks, float *cur_cutoff, float *adaptive_beam, float *next_cutoff, float *cost_offset) {
+  const Lattice *L = (const Lattice *)h;
+  for (size_t i = 0; i < L->stats.size(); i++) {
+    ntoks[i] = L->stats[i].ntoks; cur_cutoff[i] = L->stats[i].cur_cutoff; adaptive_beam[i] = L->stats[i].adaptive_beam;
+    next_cutoff[i] = L->stats[i].next_cutoff; cost_offset[i] = L->stats[i].cost_offset;
+  }
+}
+void k3o_lfd_free(void *h) { delete (Lattice *)h; }
+
+}  // extern "C"

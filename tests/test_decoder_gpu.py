@@ -1,0 +1,80 @@
+"""GPU parity: the HIP lattice decoder (k3_decoder_* through the C ABI) vs the restated LatticeFasterDecoder oracle on the
+SAME log-likelihood matrix.  Bar: the raw lattice after FinalizeDecoding is identical in canonical form -- same (frame, HCLG
+state) tokens, same arcs with labels, graph and acoustic costs BIT-identical -- against the oracle's order-independent mode
+(mode 1); against the literal serial mode (mode 0) the GPU lattice must be a sub-lattice with identical costs and the same
+best path (the serial code additionally keeps a few hash-order dependent arcs beyond the final beam)."""
+import numpy as np, pytest, torch
+from kaldi_amd import synth
+pytestmark = pytest.mark.gpu
+
+def _setup(S, A, N, seed, start_degree):
+    from kaldi_amd import decoder
+    f = synth.make_hclg(S, A, N, seed=seed, start_degree=start_degree)
+    t2p = synth.tid2pdf(N)
+    return f, t2p, decoder.CudaFst(f, t2p)
+
+def _gpu_decode(cf, N, lls, nlanes=None, **cfg):
+    from kaldi_amd import decoder
+    c = decoder.decoder_config(**cfg)
+    dec = decoder.CudaDecoder(cf, c, nlanes or len(lls), N)
+    ro = np.concatenate([[0], np.cumsum([l.shape[0] for l in lls])])
+    x = torch.from_numpy(np.concatenate(lls)).cuda()
+    dec.DecodeBatch(x, ro)
+    info = dec.LatticeInfo()
+    return dec.GetRawLattices(), info, dec
+
+def _ocfg(lo, **kw):
+    return lo.Config(**{k: v for k, v in kw.items() if k in ("beam", "max_active", "min_active", "lattice_beam", "beam_delta")})
+
+def _sub_lattice(small, big):
+    ss, sa = small.canonical(); bs, ba = big.canonical()
+    S = set(map(tuple, bs[:, :1].tolist())); A = set(map(tuple, ba.tolist()))
+    return all(tuple(r) in S for r in ss[:, :1].tolist()) and all(tuple(r) in A for r in sa.tolist())
+
+@pytest.mark.parametrize("case", [
+    dict(S=2000, A=5000, N=50, T=[60, 1, 7, 33], seed=1, cfg=dict(beam=15.0, lattice_beam=8.0, max_active=10000)),
+    dict(S=2000, A=5000, N=50, T=[50, 20], seed=2, cfg=dict(beam=12.0, lattice_beam=6.0, max_active=300, min_active=20)),          # max_active bites: radix select
+    dict(S=300, A=700, N=20, T=[40, 40, 3], seed=3, cfg=dict(beam=6.0, lattice_beam=4.0, max_active=10000, min_active=200)),     # min_active loosens the beam
+    dict(S=5000, A=14000, N=200, T=[120], seed=4, cfg=dict(beam=16.0, lattice_beam=10.0, max_active=2**31 - 1, min_active=0)),  # plain beam branch
+    dict(S=20000, A=50000, N=500, T=[80, 64], seed=5, cfg=dict(beam=15.0, lattice_beam=8.0, max_active=7000)),
+])
+def test_raw_lattice_matches_oracle(case):
+    from oracle import lattice_oracle as lo
+    N = case["N"]
+    f, t2p, cf = _setup(case["S"], case["A"], N, case["seed"], start_degree=max(8, case["S"] // 50))
+    rng = np.random.default_rng(case["seed"] + 100)
+    lls = [(rng.standard_normal((T, N)) * 2.5).astype(np.float32) for T in case["T"]]
+    lats, info, dec = _gpu_decode(cf, N, lls, **case["cfg"])
+    for u, ll in enumerate(lls):
+        ref, oi = lo.decode(f, ll, t2p, _ocfg(lo, **case["cfg"]), mode=1)
+        st = dec.FrameStats(u, ll.shape[0])
+        assert np.array_equal(st["ntoks"], oi["ntoks"]), (u, st["ntoks"][:10], oi["ntoks"][:10])
+        for k in ("cur_cutoff", "adaptive_beam", "next_cutoff", "cost_offset"):
+            assert np.array_equal(st[k].view(np.int32), oi[k].view(np.int32)), (u, k)
+        assert info[u, 2] == 0 and bool(info[u, 3]) == oi["reached_final"]
+        d = lats[u].diff(ref)
+        assert d == "", (u, d)
+        assert lats[u].connect().diff(ref.connect()) == ""
+        lit, _ = lo.decode(f, ll, t2p, _ocfg(lo, **case["cfg"]), mode=0)
+        bp_g, bp_l = lats[u].connect().best_path(), lit.connect().best_path()
+        assert (bp_g is None) == (bp_l is None)
+        if bp_g is not None:
+            assert bp_g[0] == bp_l[0] and bp_g[1] == bp_l[1]
+
+def test_capacity_overflow_is_an_error_not_a_beam_change():
+    from kaldi_amd import lib
+    f, t2p, cf = _setup(2000, 5000, 50, 1, 40)
+    rng = np.random.default_rng(0)
+    ll = (rng.standard_normal((30, 50)) * 2.5).astype(np.float32)
+    with pytest.raises(lib.K3Error):
+        _gpu_decode(cf, 50, [ll], beam=15.0, lattice_beam=8.0, frame_tokens_cap=64, frame_cands_cap=64, lane_tokens_cap=4096, lane_links_cap=4096)
+
+def test_lanes_are_independent_and_deterministic():
+    """the same utterance in every lane of a 96-lane batch gives 96 identical lattices, equal to a 1-lane run"""
+    f, t2p, cf = _setup(3000, 8000, 80, 7, 60)
+    rng = np.random.default_rng(3)
+    ll = (rng.standard_normal((45, 80)) * 2.5).astype(np.float32)
+    one, _, _ = _gpu_decode(cf, 80, [ll], beam=14.0, lattice_beam=7.0, max_active=5000)
+    many, _, _ = _gpu_decode(cf, 80, [ll] * 96, beam=14.0, lattice_beam=7.0, max_active=5000)
+    for m in many:
+        assert m.diff(one[0]) == ""
