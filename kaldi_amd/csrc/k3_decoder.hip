@@ -260,6 +260,7 @@ __device__ void finish_frame(const DecParams &p, Shared &sh, float cutoff, long 
   for (int round = 1;; round++) {
     const int n = sh.n_wl[cur];
     if (block_err(sh) || n == 0) break;
+    if (round > 100000) { sh.err = K3_ERR_HIP; break; }        // an epsilon cycle with negative weight: cannot converge
     int *wl_cur = wl + (long long)cur * p.frame_tokens_cap, *wl_nxt = wl + (long long)(cur ^ 1) * p.frame_tokens_cap;
     for (int i0 = 0; i0 < n; i0 += kBlock) {
       const int i = i0 + tid; const bool v = i < n;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
     // Jacobi sweeps: xn <- base, atomicMin over the surviving eps links evaluated at the previous sweep's extras (xn lives in
     // this lane's candidate scratch), until no extra cost changes.
     unsigned *xn = reinterpret_cast<unsigned *>(p.c_tot + (long long)L * p.frame_cands_cap);   // frame_cands_cap >= frame_tokens_cap (checked on the host)
-    for (;;) {
+    for (int sweep = 0; sweep < 100000; sweep++) {
       __syncthreads();
       if (tid == 0) s_changed = 0;
       for (long long t = tb + tid; t < te; t += kBlock) {
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
     if (n1 == n0) {
       for (long long t = b0 + tid; t < b1; t += kBlock) extra[t] = dec(xb[t - b0]);
     } else {
-      for (;;) {
+      for (int sweep = 0; sweep < 100000; sweep++) {
         __syncthreads();
         if (tid == 0) s_changed = 0;
         for (long long t = b0 + tid; t < b1; t += kBlock) xn[t - b0] = xb[t - b0];
