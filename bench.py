@@ -2,29 +2,36 @@
 """bench.py -- RTFx of the batched acoustic pipeline on MI355X (driver contract in the task statement).
 
 A "step" = one pass of the hot path over one batch of synthetic 16 kHz audio already resident in HBM:
-  fbank (k3_feat_compute_batch) -> 17-layer TDNN-F forward (k3_nnet_forward) [-> HCLG lattice decode once the
-  decoder lands].  value = audio seconds processed by ALL ranks / wall seconds (max over ranks).
-Weak scaling: every rank processes its own --utts utterances; no data-path collective.
-Extra objects in the JSON line: "roofline" (dominant kernel vs its CDNA4 peak, timed with HIP events on the
-launch stream) and "cpu_baseline" (the reference's own compute-fbank-feats + nnet3-compute binaries from
-oracle/_ref when present, else the oracle port; rank 0, N=1 only, bounded sample)."""
+  fbank (k3_feat_compute_batch) -> 17-layer TDNN-F forward (k3_nnet_forward) -> HCLG lattice decode
+  (k3_decoder_decode_batch: token passing + lattice-beam pruning on the GPU) -> raw lattices compacted and copied to
+  host buffers (k3_decoder_get_raw_lattices).  Lattice determinisation is host work outside the path.
+value = audio seconds processed by ALL ranks / wall seconds (max over ranks).
+Weak scaling: every rank decodes its own --utts utterances; the decoding graph is built on rank 0 and broadcast ONCE
+over RCCL (before the timed region); no data-path collective.
+Extra objects in the JSON line: "roofline" (the dominant kernel vs its CDNA4 bound, timed with HIP events on the
+launch stream), "roofline_gemm" (the TDNN-F affine GEMMs vs the FP32 MFMA peak), "stage_ms", "decode_stats" and
+"cpu_baseline" (the reference's own compute-fbank-feats + nnet3-compute binaries from oracle/_ref and the restated
+LatticeFasterDecoder oracle on ONE host core; rank 0, N=1 only, bounded sample)."""
 import argparse, json, os, subprocess, sys, tempfile, time
 import numpy as np, torch
 import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-def cpu_baseline(model_path, utt_seconds, budget_s=20.0):
-    """Reference binaries (kind=reference) on ONE host core, bounded sample of the same workload."""
-    from oracle import kaldi_io as kio
+BEAM, LATTICE_BEAM, MAX_ACTIVE = 15.0, 8.0, 10000      # BASELINE.json configs[2]: beam 15; recipes' lattice-beam 8; CudaDecoderConfig max-active
+
+def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, n_utts=3):
+    """Same workload on ONE host core, bounded sample: reference binaries for fbank + nnet3 (when oracle/_ref was
+    built; the GPU box gets the prebuilt files), restated LatticeFasterDecoder (oracle) for the decode leg."""
+    from oracle import kaldi_io as kio, lattice_oracle as lo
     from kaldi_amd import synth
     bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
-    n_utts = 4
     with tempfile.TemporaryDirectory() as td:
         scp = []
         for i in range(n_utts):
             kio.write_wav(f"{td}/u{i}.wav", synth.gaussian_pcm16(int(16000 * utt_seconds), 1234 + i)); scp.append(f"u{i} {td}/u{i}.wav")
         open(f"{td}/wav.scp", "w").write("\n".join(scp) + "\n")
+        audio = n_utts * utt_seconds
         if os.path.exists(os.path.join(bindir, "nnet3-compute")):
             env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
             t0 = time.time()
@@ -32,23 +39,28 @@ def cpu_baseline(model_path, utt_seconds, budget_s=20.0):
             t1 = time.time()
             subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], env=env, stderr=subprocess.DEVNULL)
             t2 = time.time()
-            audio = n_utts * utt_seconds
-            return {"value": audio / (t2 - t0), "unit": "RTFx (audio-s/wall-s)", "cores": 1, "kind": "reference",
-                    "sample": f"{n_utts} x {utt_seconds:g} s utts through the reference's compute-fbank-feats ({audio/(t1-t0):.0f}x RT) + nnet3-compute ({audio/(t2-t1):.0f}x RT), 1 core, MKL sequential"}
-        from oracle import feat_oracle as fo, nnet3_oracle as no
-        net = no.read_nnet(model_path); t0 = time.time()
-        for i in range(n_utts):
-            w, _ = kio.read_wav(f"{td}/u{i}.wav")
-            no.compute(net, fo.compute_features(w.astype(np.float32), fo.fbank_opts(dither=0.0, num_bins=40)), 3)
-        dt = time.time() - t0
-        return {"value": n_utts * utt_seconds / dt, "unit": "RTFx (audio-s/wall-s)", "cores": 1, "kind": "port",
-                "sample": f"{n_utts} x {utt_seconds:g} s utts through oracle/feat_oracle.c + oracle/nnet3_oracle.py (numpy BLAS)"}
+            lls = kio.read_ark(f"{td}/o.ark"); front = "reference compute-fbank-feats (%.0fx RT) + reference nnet3-compute (%.0fx RT)" % (audio / (t1 - t0), audio / (t2 - t1))
+        else:
+            from oracle import feat_oracle as fo, nnet3_oracle as no
+            net = no.read_nnet(model_path); t0 = time.time(); lls = {}
+            for i in range(n_utts):
+                w, _ = kio.read_wav(f"{td}/u{i}.wav")
+                lls[f"u{i}"] = no.compute(net, fo.compute_features(w.astype(np.float32), fo.fbank_opts(dither=0.0, num_bins=40)), 3)
+            t2 = time.time(); front = "oracle fbank (C) + oracle nnet3 (numpy)"
+        cfg = lo.Config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE); t2p = synth.tid2pdf(num_pdfs)
+        t3 = time.time()
+        for k in sorted(lls): lo.decode(graph, lls[k], t2p, cfg, mode=0)
+        t4 = time.time()
+        return {"value": audio / ((t2 - t0) + (t4 - t3)), "unit": "RTFx (audio-s/wall-s)", "cores": 1, "kind": "port",
+                "sample": f"{n_utts} x {utt_seconds:g} s utts, 1 core: {front} + restated LatticeFasterDecoder oracle ({audio / (t4 - t3):.0f}x RT; "
+                          "the reference's nnet3-latgen-faster needs OpenFst and cannot be built here)"}
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=512); ap.add_argument("--utt-seconds", type=float, default=10.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-states", type=int, default=2_000_000); ap.add_argument("--graph-arcs", type=int, default=5_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local); dev = torch.device("cuda", local)
@@ -58,7 +70,7 @@ def main():
     import __graft_entry__ as ge
     if rank == 0: ge.build()
     if world > 1: dist.barrier()
-    from kaldi_amd import feat, nnet3, synth
+    from kaldi_amd import feat, nnet3, synth, decoder, parallel
 
     U, nsamp = args.utts, int(16000 * args.utt_seconds)
     # synthetic workload: Gaussian PCM16 sigma 3000, per-rank seed; 17L-768/96-6024 TDNN-F, seed 1
@@ -67,30 +79,53 @@ def main():
     sf = feat.SpectralFeatures(feat.fbank_options(dither=0.0, num_bins=40))
     wo, fo, total_frames, fo_h = sf.offsets([nsamp] * U, dev)
     model_path = os.path.join(tempfile.gettempdir(), f"k3_bench_tdnnf_{rank}.raw")
-    # BatchNorm calibration on real fbank features of this workload (first utterance)
-    calib = sf.ComputeFeatures(waves[:nsamp].contiguous(), *sf.offsets([nsamp], dev)[:3]).cpu().numpy()[:600]
+    # BatchNorm calibration on real fbank features of rank 0's first utterance (same model on every rank)
+    g0 = torch.Generator(device="cpu"); g0.manual_seed(1234)
+    w0 = (torch.randn(nsamp, generator=g0) * 3000).round().clamp(-32768, 32767).to(dev)
+    calib = sf.ComputeFeatures(w0, *sf.offsets([nsamp], dev)[:3]).cpu().numpy()[:600]
     net_spec = synth.make_tdnnf(seed=1, calib_feats=calib); net_spec.write(model_path)
-    net = nnet3.Nnet(model_path)
+    net = nnet3.Nnet(model_path); num_pdfs = net.info.output_dim
     nb = nnet3.NnetBatch(net, [fo_h[i + 1] - fo_h[i] for i in range(U)], 3)
     feats = torch.empty((total_frames, sf.dim), dtype=torch.float32, device=dev)
-    loglikes = torch.empty((nb.total_out_rows, net.info.output_dim), dtype=torch.float32, device=dev)
+    loglikes = torch.empty((nb.total_out_rows, num_pdfs), dtype=torch.float32, device=dev)
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    def step(timed=None):
-        if timed is not None: ev[0].record()
+    # decoding graph: built and uploaded on rank 0, broadcast once over RCCL/xGMI to the other ranks
+    graph = dec = None
+    if not args.no_decode:
+        graph = synth.make_hclg(args.graph_states, args.graph_arcs, num_pdfs) if rank == 0 else None
+        t0 = time.perf_counter()
+        cfst = parallel.broadcast_graph(graph, synth.tid2pdf(num_pdfs), rank, world, dev)
+        t_bcast = time.perf_counter() - t0
+        cfg = decoder.decoder_config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE, frame_tokens_cap=65536, frame_cands_cap=131072,
+                                     lane_tokens_cap=int(4500 * args.utt_seconds * 33.4) + 65536, lane_links_cap=int(6000 * args.utt_seconds * 33.4) + 131072)
+        dec = decoder.CudaDecoder(cfst, cfg, U, num_pdfs); dec.SetProfiling(True)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    lat_sizes = [0, 0]
+    def step(timed=False):
+        if timed: ev[0].record()
         sf.ComputeFeatures(waves, wo, fo, total_frames, out=feats)
-        if timed is not None: ev[1].record()
+        if timed: ev[1].record()
         nb.forward(feats, out=loglikes)
-        if timed is not None: ev[2].record()
+        if timed: ev[2].record()
+        if dec is not None:
+            dec.DecodeBatch(loglikes, nb.out_offsets)
+            if timed: ev[3].record()
+            lats = dec.GetRawLattices()          # synchronises: compaction kernel + D2H of the pruned lattices
+            lat_sizes[0] = sum(l.num_states for l in lats); lat_sizes[1] = sum(l.num_arcs for l in lats)
+            if timed: ev[4].record()
     for _ in range(args.warmup): step()
     torch.cuda.synchronize()
     if world > 1: dist.barrier()
-    t_feat = t_nnet = 0.0
+    acc = np.zeros(6)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timed=True)
-        # events are read after the loop's final sync; accumulate lazily
-        torch.cuda.current_stream().synchronize(); t_feat += ev[0].elapsed_time(ev[1]); t_nnet += ev[1].elapsed_time(ev[2])
+        torch.cuda.current_stream().synchronize()
+        acc[0] += ev[0].elapsed_time(ev[1]); acc[1] += ev[1].elapsed_time(ev[2])
+        if dec is not None:
+            acc[2] += ev[2].elapsed_time(ev[3]); acc[3] += ev[3].elapsed_time(ev[4])
+            k = dec.KernelTimes(); acc[4] += k[0]; acc[5] += k[1]
     torch.cuda.synchronize()
     if world > 1: dist.barrier()
     dt = time.perf_counter() - t0
@@ -98,19 +133,33 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = t.item()
     audio_s = U * args.utt_seconds * world * args.steps
     if rank == 0:
-        nnet_ms = t_nnet / args.steps
-        line = {"metric": "RTFx (audio-s/wall-s) batched fbank + TDNN-F forward (HCLG decode: not yet in the timed path)",
+        acc /= args.steps
+        gemm_tf = nb.flops / (acc[1] * 1e-3) / 1e12
+        line = {"metric": "RTFx (audio-s/wall-s) batched fbank -> TDNN-F -> HCLG lattice decode" if dec is not None else "RTFx (audio-s/wall-s) batched fbank + TDNN-F forward (decode disabled by --no-decode)",
                 "value": audio_s / dt, "unit": "RTFx (audio-s/wall-s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic (Gaussian PCM16 sigma=3000 seed 1234+rank; random-init BN-calibrated 17L-768/96-6024 TDNN-F seed 1)",
-                "config": {"workload": f"configs[1]: fbank(40) + 17-layer TDNN-F forward, {U} x {args.utt_seconds:g} s utts per GPU, frame-subsampling 3",
+                "dtype": "f32", "data": "synthetic (Gaussian PCM16 sigma=3000 seed 1234+rank; random-init BN-calibrated 17L-768/96-6024 TDNN-F seed 1; synthetic HCLG seed 4321)",
+                "config": {"workload": (f"configs[2]: fbank(40) -> 17-layer TDNN-F (frame-subsampling 3) -> HCLG lattice decode (beam {BEAM:g}, lattice-beam {LATTICE_BEAM:g}, max-active {MAX_ACTIVE}, "
+                                        f"{args.graph_states} states / {args.graph_arcs} arcs), {U} x {args.utt_seconds:g} s utts per GPU") if dec is not None else
+                                       f"configs[1]: fbank(40) + 17-layer TDNN-F forward, {U} x {args.utt_seconds:g} s utts per GPU",
                            "utts_per_gpu": U, "frames_per_utt": fo_h[1], "output_rows": int(nb.total_out_rows), "params": int(net.info.num_params), "parallelism": f"utterance-shard x{world}"},
-                "stage_ms": {"fbank": t_feat / args.steps, "nnet3": nnet_ms},
-                "roofline": {"bound": "mfma", "kernel": "k3_tdnn_gemm_kernel (all 35 launches of one forward)", "achieved": nb.flops / (nnet_ms * 1e-3) / 1e12,
-                             "peak": 157.3, "unit": "TFLOP/s", "frac": nb.flops / (nnet_ms * 1e-3) / 1e12 / 157.3, "traffic": None,
-                             "note": "achieved = exact sum(2MNK) of the launched GEMMs / HIP-event time of the forward on the launch stream; FP32 MFMA peak"}}
+                "stage_ms": {"fbank": acc[0], "nnet3": acc[1], "decode": acc[2], "decode.token_passing_kernel": acc[4], "decode.lattice_prune_kernel": acc[5], "lattice_compact_and_d2h": acc[3]},
+                "roofline_gemm": {"bound": "mfma", "kernel": "k3_tdnn_gemm_kernel (all 35 launches of one forward)", "achieved": gemm_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": gemm_tf / 157.3,
+                                  "note": "exact sum(2MNK) of the launched GEMMs / HIP-event time of the forward on the launch stream; FP32 MFMA peak (the only MFMA class inside the 1e-4 bound)"}}
+        if dec is not None:
+            info = dec.LatticeInfo(); ab = dec.algorithmic_bytes(info); gbs = ab / (acc[4] * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+                                "note": "algorithmic bytes (SURVEY 8d: 32 B/emitting arc traversed + 28 B/eps arc traversed + 16 B/token) from device counters / HIP-event time of the kernel on its launch stream; "
+                                        "the kernel is bound by the 333-step frame recurrence (dependent-latency chain per lane), not by bandwidth"}
+            line["decode_stats"] = {"graph_broadcast_s": t_bcast if world > 1 else 0.0, "emitting_arcs_traversed": int(info[:, 7].sum()), "eps_arcs_traversed": int(info[:, 8].sum()), "tokens": int(info[:, 4].sum()),
+                                    "links": int(info[:, 5].sum()), "max_tokens_on_a_frame": int(info[:, 6].max()), "lattice_states": lat_sizes[0], "lattice_arcs": lat_sizes[1],
+                                    "reached_final_frac": float(info[:, 3].mean()), "algorithmic_bytes": ab}
+        else:
+            line["roofline"] = dict(line["roofline_gemm"], traffic=None)
         if world == 1 and not args.no_cpu_baseline:
-            try: line["cpu_baseline"] = cpu_baseline(model_path, args.utt_seconds)
+            try:
+                if graph is None: graph = synth.make_hclg(args.graph_states, args.graph_arcs, num_pdfs)
+                line["cpu_baseline"] = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds)
             except Exception as e: line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line))
     if world > 1: dist.destroy_process_group()

@@ -117,6 +117,8 @@ int32_t k3_fst_num_states(const k3_fst *fst);
  * attach it on the other ranks with k3_fst_attach() -- SURVEY 8e: "HCLG broadcast once over RCCL/xGMI". */
 int k3_fst_image(const k3_fst *fst, void **d_image, int64_t *bytes);
 int k3_fst_create_empty(int32_t num_states, int64_t num_arcs, int32_t start, k3_fst **fst); /* allocate an image of that shape (receiver side) */
+int k3_fst_export_image(const k3_fst *fst, void *d_dst);   /* device-to-device copy of the image into a caller buffer (e.g. the collective's send buffer) */
+int k3_fst_import_image(k3_fst *fst, const void *d_src);   /* the reverse, after the collective */
 
 /* ---------------------------------------------------------------- lattice decoder ------------
  * Replaces: LatticeFasterDecoder::Decode = InitDecoding + AdvanceDecoding + FinalizeDecoding + GetRawLattice
@@ -154,7 +156,8 @@ int k3_decoder_decode_batch(k3_decoder *dec, int32_t num_utts, const float *d_lo
                             const int64_t *h_row_offsets, void *stream);
 /* Per utterance: [0] lattice states, [1] lattice arcs, [2] status (0 ok, 1 no surviving tokens, <0 k3_status),
  * [3] reached_final (a final-state token was active on the last frame), [4] tokens created, [5] links created,
- * [6] max tokens on one frame, [7] emitting arcs traversed (candidates examined).  h_info: [num_utts x 8] int64. */
+ * [6] max tokens on one frame, [7] emitting arcs traversed, [8] epsilon arcs traversed, [9] frames.
+ * h_info: [num_utts x 10] int64. */
 int k3_decoder_lattice_info(k3_decoder *dec, int64_t *h_info);
 /* GetRawLattice for every utterance of the last batch, concatenated in utterance order (utterance u owns
  * states h_state_offsets[u]..[u+1] and arcs h_arc_offsets[u]..[u+1]; arc endpoints are indices local to the
@@ -164,6 +167,10 @@ int k3_decoder_lattice_info(k3_decoder *dec, int64_t *h_info);
 int k3_decoder_get_raw_lattices(k3_decoder *dec, int32_t *h_st_frame, int32_t *h_st_state, float *h_st_cost,
                                 float *h_st_final, int32_t *h_arc_src, int32_t *h_arc_dst, int32_t *h_arc_ilabel,
                                 int32_t *h_arc_olabel, float *h_arc_graph, float *h_arc_ac);
+/* HIP-event timing of the two decode kernels of the last batch on their launch stream: h_ms[0] = token passing
+ * (k3_decode_forward_kernel), h_ms[1] = lattice-beam pruning (k3_decode_prune_kernel). */
+int k3_decoder_set_profiling(k3_decoder *dec, int32_t on);
+int k3_decoder_kernel_times(k3_decoder *dec, float *h_ms);
 /* per-frame diagnostics of one utterance of the last batch (host arrays of length num_frames, any may be NULL):
  * tokens seen by GetCutoff, cur_cutoff, adaptive_beam, next_cutoff, cost_offset */
 int k3_decoder_frame_stats(k3_decoder *dec, int32_t utt, int32_t *h_ntoks, float *h_cur_cutoff, float *h_adaptive_beam,

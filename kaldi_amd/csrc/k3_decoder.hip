@@ -51,7 +51,7 @@ struct Link { unsigned src, dst; int arc; float ac; };                // 16 B fo
 enum { kStOk = 0, kStNoTokens = 1 };
 
 struct LaneInfo {            // per lane, written by the kernels, read by the host
-  long long n_tokens, n_links, n_cands;   // created
+  long long n_tokens, n_links, n_cands, n_eps;   // created / emitting arcs examined / eps arcs examined
   int status, reached_final, max_frame_tokens, num_frames;
   int out_states, out_arcs;               // after pruning
   float final_best_cost; int final_empty;
@@ -87,6 +87,7 @@ struct Shared {
   int redi[kWaves];
   int hist[256];
   int n_next, n_cand, n_wl[2], err, sel_digit, sel_k, flag;
+  unsigned long long n_eps, n_emit;
   unsigned min_tot;
   long long n_link;
   unsigned long long bcast64;
@@ -274,6 +275,7 @@ __device__ void finish_frame(const DecParams &p, Shared &sh, float cutoff, long 
       wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
         const float oc = __shfl(c, owner);
         bool claimed = false, push = false; int slot2 = -1, nxt = 0;
+        { const unsigned long long mv = __ballot(valid); if (lane == 0 && mv) atomicAdd(&sh.n_eps, (unsigned long long)__popcll(mv)); }
         if (valid) {
           const ArcRec r = p.arcs[arc];
           const float tot = oc + r.w; nxt = r.next;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
   const unsigned mask = (unsigned)p.hash_mask;
   const float kInf = __builtin_inff();
 
-  if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; }
+  if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; }
   __syncthreads();
   // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
   if (tid == 0) {
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
   }
   __syncthreads();
   finish_frame(p, sh, p.beam, 0, tok_state, tok_cost, links, hash, tok_slot, wl);
-  long long cur_base = 0; int n_cur = sh.n_next; long long n_cands_total = 0; int max_frame = n_cur;
+  long long cur_base = 0; int n_cur = sh.n_next; int max_frame = n_cur;
   __syncthreads();
   if (tid == 0) { tok_off[1] = n_cur; loff_e[0] = sh.n_link; }
   int status = kStOk;
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
       wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
         const float oc = __shfl(c, owner); const int ot = __shfl(t, owner);
         bool pass = false; float tot = 0.0f, ac = 0.0f; int nxt = 0;
+        { const unsigned long long mv = __ballot(valid); if (lane == 0 && mv) atomicAdd(&sh.n_emit, (unsigned long long)__popcll(mv)); }
         if (valid) {
           const ArcRec r = p.arcs[arc];
           ac = co - ll[r.pdf]; tot = oc + ac + r.w; nxt = r.next;
@@ -483,7 +486,6 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
     }
     if (block_err(sh)) break;
     if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
-    n_cands_total += n_cand;
     // ---- ProcessNonemitting(next_cutoff) + eps links + publish the frame
     finish_frame(p, sh, accept, nb, tok_state, tok_cost, links, hash, tok_slot, wl);
     if (block_err(sh)) break;
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
   __syncthreads();
   if (tid == 0) {
     LaneInfo &li = p.info[L];
-    li.n_tokens = cur_base + n_cur; li.n_links = sh.n_link; li.n_cands = n_cands_total; li.max_frame_tokens = max_frame;
+    li.n_tokens = cur_base + n_cur; li.n_links = sh.n_link; li.n_cands = (long long)sh.n_emit; li.n_eps = (long long)sh.n_eps; li.max_frame_tokens = max_frame;
     li.status = sh.err ? sh.err : status; li.num_frames = T; li.reached_final = 0; li.out_states = 0; li.out_arcs = 0;
   }
 }
@@ -753,6 +755,16 @@ extern "C" int k3_fst_create_empty(int32_t num_states, int64_t num_arcs, int32_t
   *out = f.release();
   return K3_OK;
 }
+extern "C" int k3_fst_export_image(const k3_fst *f, void *d_dst) {
+  K3_REQUIRE(f && d_dst, "k3_fst_export_image: null argument");
+  K3_HIP_CHECK(hipMemcpy(d_dst, f->image, f->bytes, hipMemcpyDeviceToDevice));
+  return K3_OK;
+}
+extern "C" int k3_fst_import_image(k3_fst *f, const void *d_src) {
+  K3_REQUIRE(f && d_src, "k3_fst_import_image: null argument");
+  K3_HIP_CHECK(hipMemcpy(f->image, d_src, f->bytes, hipMemcpyDeviceToDevice));
+  return K3_OK;
+}
 extern "C" void k3_fst_destroy(k3_fst *f) { delete f; }
 extern "C" int64_t k3_fst_num_arcs(const k3_fst *f) { return f ? f->num_arcs : -1; }
 extern "C" int32_t k3_fst_num_states(const k3_fst *f) { return f ? f->num_states : -1; }
@@ -771,7 +783,9 @@ struct k3_decoder {
   int last_utts = 0; std::vector<int> last_frames;
   hipStream_t last_stream = nullptr;
   std::vector<LaneInfo> h_info; bool info_valid = false;
-  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); }
+  bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int *d_newidx = nullptr;
+  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
 };
 
 extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
@@ -817,6 +831,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &p.c_src, nl * cfg->frame_cands_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.info, nl))) return rc;
   if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
+  if ((rc = dmalloc(&d->allocs, &d->d_newidx, nl * cfg->lane_tokens_cap))) return rc;
   // empty table: key = -1, cost = max, tok = -1, stamp = 0
   std::vector<Slot> init((size_t)hs, Slot{kEmpty, kEncMax, -1, 0});
   for (int l = 0; l < nlanes; l++) K3_HIP_CHECK(hipMemcpy(p.hash + (size_t)l * hs, init.data(), sizeof(Slot) * hs, hipMemcpyHostToDevice));
@@ -826,6 +841,20 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
 }
 
 extern "C" void k3_decoder_destroy(k3_decoder *d) { delete d; }
+
+extern "C" int k3_decoder_set_profiling(k3_decoder *d, int32_t on) {
+  K3_REQUIRE(d, "k3_decoder_set_profiling: null argument");
+  if (on) for (hipEvent_t &e : d->ev) if (!e) K3_HIP_CHECK(hipEventCreate(&e));
+  d->profiling = on != 0;
+  return K3_OK;
+}
+extern "C" int k3_decoder_kernel_times(k3_decoder *d, float *h_ms) {
+  K3_REQUIRE(d && h_ms && d->profiling && d->last_utts > 0, "k3_decoder_kernel_times: profiling is off or nothing was decoded");
+  K3_HIP_CHECK(hipEventSynchronize(d->ev[2]));
+  K3_HIP_CHECK(hipEventElapsedTime(&h_ms[0], d->ev[0], d->ev[1]));
+  K3_HIP_CHECK(hipEventElapsedTime(&h_ms[1], d->ev[1], d->ev[2]));
+  return K3_OK;
+}
 
 extern "C" int k3_decoder_decode_batch(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream) {
   K3_REQUIRE(d && d_loglikes && h_row_off && num_utts > 0 && num_utts <= d->nlanes && ld >= d->num_pdfs, "k3_decoder_decode_batch: bad argument");
@@ -857,10 +886,13 @@ extern "C" int k3_decoder_decode_batch(k3_decoder *d, int32_t num_utts, const fl
   K3_HIP_CHECK(hipStreamSynchronize(st));    // ro is a stack-scoped staging buffer
   p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
+  if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
+  if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
   hipLaunchKernelGGL(k3_decode_prune_kernel, dim3(num_utts), dim3(kBlock), 0, st, p);
   K3_HIP_CHECK(hipGetLastError());
+  if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[2], st));
   d->last_utts = num_utts; d->last_stream = st; d->info_valid = false;
   return K3_OK;
 }
@@ -880,9 +912,9 @@ extern "C" int k3_decoder_lattice_info(k3_decoder *d, int64_t *h_info) {
   { const int rc = fetch_info(d); if (rc) return rc; }
   int worst = K3_OK;
   for (int u = 0; u < d->last_utts; u++) {
-    const LaneInfo &li = d->h_info[u]; int64_t *o = h_info + 8 * u;
+    const LaneInfo &li = d->h_info[u]; int64_t *o = h_info + 10 * u;
     o[0] = li.status == kStOk ? li.out_states : 0; o[1] = li.status == kStOk ? li.out_arcs : 0; o[2] = li.status; o[3] = li.reached_final;
-    o[4] = li.n_tokens; o[5] = li.n_links; o[6] = li.max_frame_tokens; o[7] = li.n_cands;
+    o[4] = li.n_tokens; o[5] = li.n_links; o[6] = li.max_frame_tokens; o[7] = li.n_cands; o[8] = li.n_eps; o[9] = li.num_frames;
     if (li.status < 0) { worst = li.status; k3::set_error("k3_decoder: utterance %d failed with status %d (%s); tokens %lld links %lld max tokens/frame %d -- raise the k3_decoder_config capacities",
                                                           u, li.status, li.status == K3_ERR_OVERFLOW ? "capacity overflow" : "internal error", li.n_tokens, li.n_links, li.max_frame_tokens); }
   }
@@ -902,8 +934,8 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
   auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
   if ((rc = dmalloc(&tmp, &d_so, U + 1)) || (rc = dmalloc(&tmp, &d_ao, U + 1)) || (rc = dmalloc(&tmp, &o.st_frame, NS)) || (rc = dmalloc(&tmp, &o.st_state, NS)) ||
       (rc = dmalloc(&tmp, &o.st_cost, NS)) || (rc = dmalloc(&tmp, &o.st_final, NS)) || (rc = dmalloc(&tmp, &o.arc_src, NA)) || (rc = dmalloc(&tmp, &o.arc_dst, NA)) ||
-      (rc = dmalloc(&tmp, &o.arc_il, NA)) || (rc = dmalloc(&tmp, &o.arc_ol, NA)) || (rc = dmalloc(&tmp, &o.arc_g, NA)) || (rc = dmalloc(&tmp, &o.arc_ac, NA)) ||
-      (rc = dmalloc(&tmp, &o.newidx, (size_t)U * d->cfg.lane_tokens_cap))) { cleanup(); return rc; }
+      (rc = dmalloc(&tmp, &o.arc_il, NA)) || (rc = dmalloc(&tmp, &o.arc_ol, NA)) || (rc = dmalloc(&tmp, &o.arc_g, NA)) || (rc = dmalloc(&tmp, &o.arc_ac, NA))) { cleanup(); return rc; }
+  o.newidx = d->d_newidx;
   o.st_off = d_so; o.arc_off = d_ao;
   hipStream_t st = d->last_stream;
 #define K3_TRY(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { cleanup(); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)

@@ -30,6 +30,15 @@ class CudaFst:
         _l.check(self._L.k3_fst_create_empty(num_states, num_arcs, start, ctypes.byref(self._h)))
         return self
 
+    def export_image(self, tensor):
+        """copy the graph image into a uint8 CUDA tensor (the collective's buffer)"""
+        assert tensor.is_cuda and tensor.dtype == torch.uint8 and tensor.numel() >= self.image()[1]
+        _l.check(self._L.k3_fst_export_image(self._h, tensor.data_ptr()))
+
+    def import_image(self, tensor):
+        assert tensor.is_cuda and tensor.dtype == torch.uint8 and tensor.numel() >= self.image()[1]
+        _l.check(self._L.k3_fst_import_image(self._h, tensor.data_ptr()))
+
     def image(self):
         """(device pointer, bytes) of the packed read-only graph image"""
         ptr, n = ctypes.c_void_p(), ctypes.c_int64()
@@ -37,20 +46,26 @@ class CudaFst:
         return ptr.value, n.value
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._L.k3_fst_destroy(self._h); self._h = ctypes.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._L.k3_fst_destroy(self._h); self._h.value = None
+        except Exception:      # interpreter shutdown
+            pass
 
 class CudaDecoder:
     """Batched lattice decoder (cf. cuda_decoder::CudaDecoder, cudadecoder/cuda-decoder.h:224-345): nlanes utterances per call."""
-    INFO = ("lat_states", "lat_arcs", "status", "reached_final", "tokens", "links", "max_frame_tokens", "arcs_examined")
+    INFO = ("lat_states", "lat_arcs", "status", "reached_final", "tokens", "links", "max_frame_tokens", "emitting_arcs", "eps_arcs", "frames")
     def __init__(self, fst, config, nlanes, num_pdfs):
         self._L = _l.load(); self._h = ctypes.c_void_p(); self.fst = fst; self.config = config; self.nlanes = nlanes
         _l.check(self._L.k3_decoder_create(fst._h, ctypes.byref(config), nlanes, num_pdfs, ctypes.byref(self._h)))
         self._n = 0
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._L.k3_decoder_destroy(self._h); self._h = ctypes.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._L.k3_decoder_destroy(self._h); self._h.value = None
+        except Exception:      # interpreter shutdown
+            pass
 
     def DecodeBatch(self, loglikes, row_offsets):
         """loglikes: float32 [rows x >= num_pdfs] on the GPU; utterance u = rows row_offsets[u]..row_offsets[u+1] (host ints).
@@ -61,8 +76,8 @@ class CudaDecoder:
         _l.check(self._L.k3_decoder_decode_batch(self._h, self._n, loglikes.data_ptr(), loglikes.stride(0), ro.ctypes.data, st))
 
     def LatticeInfo(self, check=True):
-        """int64 [num_utts x 8], columns = CudaDecoder.INFO (synchronises)"""
-        info = np.zeros((self._n, 8), np.int64)
+        """int64 [num_utts x 10], columns = CudaDecoder.INFO (synchronises)"""
+        info = np.zeros((self._n, 10), np.int64)
         rc = self._L.k3_decoder_lattice_info(self._h, info.ctypes.data)
         if check: _l.check(rc)
         return info
@@ -82,6 +97,18 @@ class CudaDecoder:
             out.append(RawLattice(si[0][s0:s1], si[1][s0:s1], sf[1][s0:s1], ai[0][a0:a1], ai[1][a0:a1], ai[2][a0:a1], ai[3][a0:a1], af[0][a0:a1], af[1][a0:a1],
                                   self.fst.start, st_cost=sf[0][s0:s1]))
         return out
+
+    def SetProfiling(self, on=True):
+        _l.check(self._L.k3_decoder_set_profiling(self._h, int(on)))
+
+    def KernelTimes(self):
+        """(token-passing kernel ms, lattice-pruning kernel ms) of the last batch, HIP events on the launch stream"""
+        ms = np.zeros(2, np.float32); _l.check(self._L.k3_decoder_kernel_times(self._h, ms.ctypes.data)); return float(ms[0]), float(ms[1])
+
+    def algorithmic_bytes(self, info=None):
+        """32 B per emitting arc traversed + 28 B per epsilon arc traversed + 16 B per token per frame"""
+        info = self.LatticeInfo() if info is None else info
+        return 32.0 * info[:, 7].sum() + 28.0 * info[:, 8].sum() + 16.0 * info[:, 4].sum()
 
     def FrameStats(self, utt, num_frames):
         nt = np.zeros(num_frames, np.int32); f = [np.zeros(num_frames, np.float32) for _ in range(4)]

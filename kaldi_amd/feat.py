@@ -32,8 +32,11 @@ class SpectralFeatures:
         self.dim = self._L.k3_feat_dim(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._L.k3_feat_plan_destroy(self._h); self._h = ctypes.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._L.k3_feat_plan_destroy(self._h); self._h.value = None
+        except Exception:      # interpreter shutdown
+            pass
 
     def Dim(self):
         return self.dim

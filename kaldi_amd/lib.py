@@ -73,6 +73,8 @@ def load():
     L.k3_decoder_decode_batch.argtypes = [vp, i32, vp, i64, vp, vp]
     L.k3_decoder_lattice_info.argtypes = [vp, vp]
     L.k3_decoder_get_raw_lattices.argtypes = [vp] + [vp] * 10
+    L.k3_fst_export_image.argtypes = [vp, vp]; L.k3_fst_import_image.argtypes = [vp, vp]
+    L.k3_decoder_set_profiling.argtypes = [vp, i32]; L.k3_decoder_kernel_times.argtypes = [vp, vp]
     L.k3_decoder_frame_stats.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     _lib = L
     return L

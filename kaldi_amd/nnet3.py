@@ -11,8 +11,11 @@ class Nnet:
         self.info = _l.NnetInfo(); _l.check(self._L.k3_nnet_get_info(self._h, ctypes.byref(self.info)))
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._L.k3_nnet_destroy(self._h); self._h = ctypes.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._L.k3_nnet_destroy(self._h); self._h.value = None
+        except Exception:      # interpreter shutdown
+            pass
 
     def priors(self):
         p = np.zeros(self.info.output_dim, np.float32)
@@ -32,8 +35,11 @@ class NnetBatch:
         self.flops = self._L.k3_nnet_batch_flops(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._L.k3_nnet_batch_destroy(self._h); self._h = ctypes.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._L.k3_nnet_batch_destroy(self._h); self._h.value = None
+        except Exception:      # interpreter shutdown
+            pass
 
     def forward(self, feats, out=None):
         """feats: float32 [sum T_u, >= input_dim] on the GPU -> float32 [total_out_rows, output_dim]."""

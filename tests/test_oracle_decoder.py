@@ -1,0 +1,130 @@
+"""CPU tests of the restated LatticeFasterDecoder oracle (oracle/lattice_faster_oracle.cc).  The reference holds no decoder
+tests or fixtures (decoder/Makefile:6), so the oracle is checked against hand-computed cases that restate the reference's
+float32 arithmetic (lattice-faster-decoder.cc:789-793, 174-181, 339-341) and against invariants of the algorithm."""
+import numpy as np, pytest
+from kaldi_amd.fst import Fst
+from kaldi_amd import synth
+from oracle import lattice_oracle as lo
+F = np.float32
+INF = np.inf
+
+def _fst(n, start, arcs, finals):
+    """arcs: (src, ilabel, olabel, weight, dst)"""
+    final = np.full(n, np.inf, np.float32)
+    for s, c in finals.items(): final[s] = c
+    a = np.array(arcs, dtype=object).reshape(-1, 5)
+    return Fst.from_arcs(n, start, a[:, 0].astype(np.int64), a[:, 1].astype(np.int32), a[:, 2].astype(np.int32), a[:, 3].astype(np.float32), a[:, 4].astype(np.int32), final)
+
+def _arcs(lat):
+    k = lat.keys()
+    return sorted((int(lat.st_frame[s]), int(lat.st_state[s]), int(lat.st_frame[d]), int(lat.st_state[d]), int(i), int(o), float(g), float(a))
+                  for s, d, i, o, g, a in zip(lat.arc_src, lat.arc_dst, lat.arc_ilabel, lat.arc_olabel, lat.arc_graph, lat.arc_ac))
+
+T2P = np.array([0, 0, 1, 2], np.int32)      # tid 1,2,3 -> pdf 0,1,2
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_linear_chain_costs_follow_the_reference_arithmetic(mode):
+    f = _fst(3, 0, [(0, 1, 7, 0.5, 1), (1, 2, 0, 0.25, 2)], {2: 0.125})
+    ll = np.array([[-1.5, -9.0, 0.0], [-7.0, -2.25, 0.0]], np.float32)
+    lat, info = lo.decode(f, ll, T2P, lo.Config(beam=10.0, lattice_beam=5.0), mode)
+    # frame 0: best token cost 0 -> cost_offset = -0; ac = cost_offset - loglike; tot = cur + ac + graph
+    co0 = F(-0.0); ac0 = F(co0 - F(-1.5)); c1 = F(F(F(0) + ac0) + F(0.5))
+    co1 = F(-c1); ac1 = F(co1 - F(-2.25)); c2 = F(F(c1 + ac1) + F(0.25))
+    assert info["reached_final"] and lat.num_states == 3
+    assert _arcs(lat) == [(0, 0, 1, 1, 1, 7, 0.5, float(F(ac0 - co0))), (1, 1, 2, 2, 2, 0, 0.25, float(F(ac1 - co1)))]
+    assert np.array_equal(np.sort(lat.st_cost), np.sort(np.array([0.0, c1, c2], np.float32)))
+    fin = lat.st_final[np.isfinite(lat.st_final)]
+    assert fin.tolist() == [0.125]
+    il, ol, g, ac = lat.best_path()
+    assert il == [1, 2] and ol == [7] and abs(g - 0.875) < 1e-6 and abs(ac - 3.75) < 1e-5
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_epsilon_closure_min_cost_and_both_links_kept(mode):
+    # 0 -eps(0.5)-> 1, 0 -eps(0.25)-> 2 -eps(0.125)-> 1 : token at state 1 gets cost 0.375, BOTH links into it stay (:886-887)
+    # 1 -tid1(1.0)-> 3 final
+    f = _fst(4, 0, [(0, 0, 0, 0.5, 1), (0, 0, 5, 0.25, 2), (2, 0, 0, 0.125, 1), (1, 1, 0, 1.0, 3)], {3: 0.0})
+    ll = np.zeros((1, 3), np.float32)
+    lat, _ = lo.decode(f, ll, T2P, lo.Config(beam=10.0, lattice_beam=5.0), mode)
+    a = _arcs(lat)
+    assert (0, 0, 0, 1, 0, 0, 0.5, 0.0) in a and (0, 0, 0, 2, 0, 5, 0.25, 0.0) in a and (0, 2, 0, 1, 0, 0, 0.125, 0.0) in a
+    k = {(int(fr), int(st)): float(c) for fr, st, c in zip(lat.st_frame, lat.st_state, lat.st_cost)}
+    assert k[(0, 1)] == 0.375 and k[(1, 3)] == 1.375
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_lattice_beam_prunes_the_worse_branch_only_beyond_the_beam(mode):
+    # two parallel 2-frame paths 0->1->3 and 0->2->3; the second is worse by `gap` on graph cost
+    for gap, kept in ((1.0, True), (3.0, False)):
+        f = _fst(4, 0, [(0, 1, 0, 0.5, 1), (0, 1, 0, 0.5 + gap, 2), (1, 1, 0, 0.5, 3), (2, 1, 0, 0.5, 3)], {3: 0.0})
+        lat, _ = lo.decode(f, np.zeros((2, 3), np.float32), T2P, lo.Config(beam=10.0, lattice_beam=2.0), mode)
+        states = {(int(a), int(b)) for a, b in zip(lat.st_frame, lat.st_state)}
+        assert ((1, 2) in states) == kept, (gap, states)
+        assert (1, 1) in states and (2, 3) in states
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_no_final_state_reached_all_last_tokens_final_with_weight_one(mode):
+    f = _fst(3, 0, [(0, 1, 0, 0.5, 1), (1, 1, 0, 0.5, 1)], {2: 0.0})          # state 2 is never reached
+    lat, info = lo.decode(f, np.zeros((3, 3), np.float32), T2P, lo.Config(beam=10.0, lattice_beam=5.0), mode)
+    assert not info["reached_final"]
+    last = lat.st_frame == 3
+    assert last.sum() == 1 and lat.st_final[last].tolist() == [0.0]            # LatticeWeight::One()
+
+def test_beam_prunes_against_the_frame_best():
+    # from the start state: arcs with cost 0 and cost 9; beam 5 -> the second token must not exist on frame 1
+    f = _fst(3, 0, [(0, 1, 0, 0.0, 1), (0, 2, 0, 9.0, 2), (1, 1, 0, 0.0, 1), (2, 1, 0, 0.0, 2)], {1: 0.0, 2: 0.0})
+    cfg = lo.Config(beam=5.0, lattice_beam=20.0, min_active=0)
+    for mode in (0, 1):
+        lat, _ = lo.decode(f, np.zeros((2, 3), np.float32), T2P, cfg, mode)
+        assert {(int(a), int(b)) for a, b in zip(lat.st_frame, lat.st_state)} == {(0, 0), (1, 1), (2, 1)}
+
+def _rand_case(seed, S=1500, A=4000, N=40, T=50):
+    f = synth.make_hclg(S, A, N, seed=seed, start_degree=30)
+    rng = np.random.default_rng(seed + 1)
+    return f, synth.tid2pdf(N), (rng.standard_normal((T, N)) * 2.5).astype(np.float32)
+
+def _is_sub(small, big):
+    ss, sa = small.canonical(); bs, ba = big.canonical()
+    S = set(map(tuple, bs.tolist())); A = set(map(tuple, ba.tolist()))
+    return all(tuple(r) in S for r in ss.tolist()) and all(tuple(r) in A for r in sa.tolist())
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_two_pass_mode_is_the_order_independent_core_of_the_literal_mode(seed):
+    """mode 1 (beam applied against the FINAL next_cutoff) gives a sub-lattice of mode 0 (serial tightening) with bit-identical
+    costs and the same best path; mode 0's surplus arcs exist only because next_cutoff was still loose when they were visited."""
+    f, t2p, ll = _rand_case(seed)
+    cfg = lo.Config(beam=15.0, lattice_beam=8.0, max_active=10000)
+    l0, i0 = lo.decode(f, ll, t2p, cfg, 0); l1, i1 = lo.decode(f, ll, t2p, cfg, 1)
+    assert i1["extra_links"] == 0 and i0["extra_links"] > 0
+    assert _is_sub(l1.connect(), l0.connect())
+    b0, b1 = l0.connect().best_path(), l1.connect().best_path()
+    assert b0[0] == b1[0] and b0[1] == b1[1] and abs(b0[2] - b1[2]) < 1e-3 and abs(b0[3] - b1[3]) < 1e-3
+
+def test_literal_mode_depends_on_the_hash_size_two_pass_mode_does_not():
+    """hash_ratio is a pure memory/speed knob of the reference (lattice-faster-decoder.h:56,90), yet it changes the HashList
+    iteration order and with it the literal algorithm's arc set; the two-pass definition is invariant."""
+    differs = 0
+    for seed in (1, 2, 3, 4):
+        f, t2p, ll = _rand_case(seed, S=40000, A=100000, N=60, T=40)      # states >> hash size, so state % hash_size matters
+        a = [lo.decode(f, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0, hash_ratio=hr), 0)[0] for hr in (2.0, 3.7)]
+        b = [lo.decode(f, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0, hash_ratio=hr), 1)[0] for hr in (2.0, 3.7)]
+        differs += a[0].diff(a[1]) != ""
+        assert b[0].diff(b[1]) == ""
+    assert differs > 0
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_periodic_pruning_does_not_change_the_final_lattice(mode):
+    """PruneActiveTokens every prune_interval frames only frees memory: same lattice with it disabled --
+    the GPU decoder prunes once, after the last frame."""
+    f, t2p, ll = _rand_case(5, T=70)
+    a = lo.decode(f, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0, prune_interval=25), mode)[0]
+    b = lo.decode(f, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0, prune_interval=10**9), mode)[0]
+    c = lo.decode(f, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0, prune_interval=3), mode)[0]
+    assert a.diff(b) == "" and a.diff(c) == ""
+
+def test_max_active_and_min_active_cutoffs():
+    f, t2p, ll = _rand_case(6, T=30)
+    _, wide = lo.decode(f, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0), 1)
+    _, capped = lo.decode(f, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0, max_active=100, min_active=10), 1)
+    assert wide["ntoks"].max() > 300
+    assert (capped["adaptive_beam"][5:] < 15.0).any()              # max_active tighter than the beam on some frame
+    _, loose = lo.decode(f, ll, t2p, lo.Config(beam=1.0, lattice_beam=0.5, min_active=200), 1)
+    assert (loose["adaptive_beam"] > 1.0).any()                    # min_active looser than the beam
