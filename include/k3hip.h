@@ -171,6 +171,8 @@ int k3_decoder_get_raw_lattices(k3_decoder *dec, int32_t *h_st_frame, int32_t *h
  * (k3_decode_forward_kernel), h_ms[1] = lattice-beam pruning (k3_decode_prune_kernel). */
 int k3_decoder_set_profiling(k3_decoder *dec, int32_t on);
 int k3_decoder_kernel_times(k3_decoder *dec, float *h_ms);
+/* developer aid: per-phase shader-clock totals of the token-passing kernel (all zero unless the library was built with -DK3_DEC_PROF) */
+int k3_decoder_phase_cycles(k3_decoder *dec, int64_t *h_cycles /* [16] */);
 /* per-frame diagnostics of one utterance of the last batch (host arrays of length num_frames, any may be NULL):
  * tokens seen by GetCutoff, cur_cutoff, adaptive_beam, next_cutoff, cost_offset */
 int k3_decoder_frame_stats(k3_decoder *dec, int32_t utt, int32_t *h_ntoks, float *h_cur_cutoff, float *h_adaptive_beam,

@@ -38,8 +38,12 @@
 
 namespace {
 
-constexpr int kBlock = 512;                 // threads per lane-workgroup (8 wavefronts)
-constexpr int kWaves = kBlock / 64;
+#ifndef K3_DEC_BLOCK
+#define K3_DEC_BLOCK 512
+#endif
+constexpr int kBlock = K3_DEC_BLOCK;      // threads per lane-workgroup
+constexpr int kPBlock = 512;                 // threads per lane-workgroup of the prune / output kernels
+constexpr int kWaves = (kBlock > kPBlock ? kBlock : kPBlock) / 64;
 constexpr unsigned kEncInf = 0xFF800000u;   // enc(+inf)
 constexpr unsigned kEncMax = 0xFFFFFFFFu;
 constexpr int kEmpty = -1;
@@ -57,7 +61,13 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
   float final_best_cost; int final_empty;
 };
 
+#ifdef K3_DEC_PROF
+#define K3_T(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); p.prof[blockIdx.x * 16 + (i)] += now__ - t_last__; t_last__ = now__; } } while (0)
+#else
+#define K3_T(i) do { } while (0)
+#endif
 struct DecParams {
+  long long *prof;   // [nlanes x 16] cycle counters per phase (only with -DK3_DEC_PROF)
   // graph
   const int2 *offs; const ArcRec *arcs; const float *final_cost; const int *arc_ilabel; int start;
   // config
@@ -115,8 +125,8 @@ __device__ unsigned long long block_min_u64(unsigned long long v, Shared &sh) {
   if (lane == 0) sh.red64[wave] = v;
   __syncthreads();
   unsigned long long r = sh.red64[0];
-#pragma unroll
-  for (int w = 1; w < kWaves; w++) r = sh.red64[w] < r ? sh.red64[w] : r;
+  const int nw = (int)blockDim.x >> 6;
+  for (int w = 1; w < nw; w++) r = sh.red64[w] < r ? sh.red64[w] : r;
   return r;
 }
 __device__ int block_sum_i32(int v, Shared &sh) {
@@ -126,8 +136,8 @@ __device__ int block_sum_i32(int v, Shared &sh) {
   if (lane == 0) sh.redi[wave] = v;
   __syncthreads();
   int r = 0;
-#pragma unroll
-  for (int w = 0; w < kWaves; w++) r += sh.redi[w];
+  const int nw = (int)blockDim.x >> 6;
+  for (int w = 0; w < nw; w++) r += sh.redi[w];
   return r;
 }
 
@@ -199,6 +209,53 @@ __device__ __forceinline__ int slot_find(Slot *tab, unsigned mask, int state) {
   return -1;
 }
 
+// Two-level state -> token table of the frame being built.  Level 1 lives in LDS (kHL slots, SoA key/cost/token): a state
+// is looked up in a kProbe-slot window; slots are never freed inside a frame, so once a window is full it stays full and
+// every thread agrees that such a state belongs to level 2, the per-lane open-addressing table in HBM.  Slot ids < kHL are
+// LDS slots, ids >= kHL are kHL + index of the HBM slot.  Typical frames (~1-3 k tokens) never leave LDS.
+constexpr int kHL = 4096, kProbe = 48;
+#define K3_LLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+struct Table {
+  int *lkey; unsigned *lcost; int *ltok; unsigned *lmark;     // LDS: [kHL], [kHL], [kHL], [kHL / 32]
+  Slot *g; unsigned gmask;                                     // HBM level
+  __device__ __forceinline__ int claim(int state, bool *claimed) const {
+    unsigned h = hash_state(state) & (kHL - 1);
+    for (int probe = 0; probe < kProbe; probe++) {
+      int k = K3_LLD(&lkey[h]); bool cl = false;
+      if (k == kEmpty) { const int old = atomicCAS(&lkey[h], kEmpty, state); if (old == kEmpty) { cl = true; k = state; } else k = old; }
+      if (k == state) { *claimed = cl; return (int)h; }
+      h = (h + 1) & (kHL - 1);
+    }
+    const int gs = slot_find_or_claim(g, gmask, state, claimed);
+    return gs < 0 ? -1 : kHL + gs;
+  }
+  __device__ __forceinline__ int find(int state) const {
+    unsigned h = hash_state(state) & (kHL - 1);
+    for (int probe = 0; probe < kProbe; probe++) {
+      const int k = K3_LLD(&lkey[h]);
+      if (k == state) return (int)h;
+      if (k == kEmpty) return -1;           // a window with a hole was never full: the state cannot be in level 2
+      h = (h + 1) & (kHL - 1);
+    }
+    const int gs = slot_find(g, gmask, state);
+    return gs < 0 ? -1 : kHL + gs;
+  }
+  __device__ __forceinline__ unsigned cost_min(int id, unsigned e) const { return id < kHL ? atomicMin(&lcost[id], e) : atomicMin(&g[id - kHL].cost, e); }
+  __device__ __forceinline__ unsigned cost(int id) const { return id < kHL ? K3_LLD(&lcost[id]) : K3_ALD(&g[id - kHL].cost); }
+  __device__ __forceinline__ int key(int id) const { return id < kHL ? K3_LLD(&lkey[id]) : K3_ALD(&g[id - kHL].key); }
+  __device__ __forceinline__ int tok(int id) const { return id < kHL ? K3_LLD(&ltok[id]) : K3_ALD(&g[id - kHL].tok); }
+  __device__ __forceinline__ void set_tok(int id, int t) const { if (id < kHL) __hip_atomic_store(&ltok[id], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else K3_AST(&g[id - kHL].tok, t); }
+  // true if the slot was not yet queued for round `stamp` (LDS slots: one bit per slot, cleared at the start of every round)
+  __device__ __forceinline__ bool mark(int id, int stamp) const {
+    if (id < kHL) { const unsigned bit = 1u << (id & 31); return (atomicOr(&lmark[id >> 5], bit) & bit) == 0; }
+    return atomicExch(&g[id - kHL].stamp, stamp) != stamp;
+  }
+  __device__ __forceinline__ void clear(int id) const {
+    if (id < kHL) { lkey[id] = kEmpty; lcost[id] = kEncMax; }
+    else { Slot *q = &g[id - kHL]; K3_AST(&q->cost, kEncMax); K3_AST(&q->stamp, 0); K3_AST(&q->tok, -1); K3_AST(&q->key, kEmpty); }
+  }
+};
+
 // exact k-th smallest (0-based) of keys[0..n) -- the value std::nth_element leaves at position k
 __device__ unsigned block_select_kth(const unsigned *keys, int n, int k, Shared &sh) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -235,42 +292,31 @@ __device__ unsigned block_select_kth(const unsigned *keys, int n, int k, Shared 
 // ---- epsilon closure + eps links + frame finalisation for the frame being built (tokens [nb, nb + n_next)) ----
 // ProcessNonemitting (lattice-faster-decoder.cc:830-897): relax eps arcs until no cost changes, with tot < cutoff;
 // the links a token ends up with are exactly its eps arcs with cur + graph < cutoff at its final cost.
-__device__ void finish_frame(const DecParams &p, Shared &sh, float cutoff, long long nb, int *tok_state, unsigned *tok_cost, Link *links,
-                             Slot *hash, int *tok_slot, int *wl) {
+__device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, const Table &tb, float cutoff, long long nb, int *tok_state, unsigned *tok_cost,
+                                             Link *links, int *tok_slot, int *wl, long long &t_last__) {
   const int tid = threadIdx.x, lane = tid & 63;
-  const unsigned mask = (unsigned)p.hash_mask;
-  // round-0 worklist: every token of the frame (those without eps arcs or above the cutoff expand to nothing)
   __syncthreads();
   if (tid == 0) { sh.n_wl[0] = 0; sh.n_wl[1] = 0; }
   __syncthreads();
-  {
-    const int n = sh.n_next;
-    for (int i0 = 0; i0 < n; i0 += kBlock) {
-      const int i = i0 + tid; bool v = i < n; int slot = 0;
-      if (v) {
-        slot = tok_slot[i];
-        const int2 a = p.offs[tok_state[nb + i]], b = p.offs[tok_state[nb + i] + 1];
-        v = (b.x - a.y) > 0 && dec(K3_ALD(&hash[slot].cost)) < cutoff;
-      }
-      const int pos = wave_append(v, &sh.n_wl[0]);
-      if (v) { wl[pos] = slot; K3_AST(&hash[slot].stamp, 1); }
-    }
-  }
-  __syncthreads();
+  K3_T(7);
+  // round 1 work-list = every token of the frame = tok_slot[0 .. n_next) itself (tokens without eps arcs expand to nothing)
   int cur = 0;
   for (int round = 1;; round++) {
-    const int n = sh.n_wl[cur];
+    const int n = round == 1 ? sh.n_next : sh.n_wl[cur];
     if (block_err(sh) || n == 0) break;
     if (round > 100000) { sh.err = K3_ERR_HIP; break; }        // an epsilon cycle with negative weight: cannot converge
-    int *wl_cur = wl + (long long)cur * p.frame_tokens_cap, *wl_nxt = wl + (long long)(cur ^ 1) * p.frame_tokens_cap;
+    const int *wl_cur = round == 1 ? tok_slot : wl + (long long)cur * p.frame_tokens_cap;
+    int *wl_nxt = wl + (long long)(round == 1 ? 0 : (cur ^ 1)) * p.frame_tokens_cap;
+    int *n_nxt = &sh.n_wl[round == 1 ? 0 : (cur ^ 1)];
+    for (int i = tid; i < kHL / 32; i += kBlock) tb.lmark[i] = 0;
+    __syncthreads();
     for (int i0 = 0; i0 < n; i0 += kBlock) {
       const int i = i0 + tid; const bool v = i < n;
       int beg = 0, deg = 0; float c = 0.0f;
       if (v) {
         const int slot = wl_cur[i];
-        const int st = K3_ALD(&hash[slot].key);
-        c = dec(K3_ALD(&hash[slot].cost));
-        if (c < cutoff) { const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
+        c = dec(tb.cost(slot));
+        if (c < cutoff) { const int st = tb.key(slot); const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
       }
       wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
         const float oc = __shfl(c, owner);
@@ -280,30 +326,31 @@ __device__ void finish_frame(const DecParams &p, Shared &sh, float cutoff, long 
           const ArcRec r = p.arcs[arc];
           const float tot = oc + r.w; nxt = r.next;
           if (tot < cutoff) {
-            slot2 = slot_find_or_claim(hash, mask, r.next, &claimed);
-            if (slot2 < 0) { sh.err = K3_ERR_OVERFLOW; }
+            slot2 = tb.claim(r.next, &claimed);
+            if (slot2 < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; }
             else {
               const unsigned e = enc(tot);
-              const unsigned old = atomicMin(&hash[slot2].cost, e);
-              if (e < old) push = atomicExch(&hash[slot2].stamp, round + 1) != round + 1;
+              const unsigned old = tb.cost_min(slot2, e);
+              if (e < old) push = tb.mark(slot2, round + 1);
             }
           }
         }
         const int idx = wave_append(claimed, &sh.n_next);
         if (claimed) {
-          if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { K3_AST(&hash[slot2].tok, idx); tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; }
+          if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tb.set_tok(slot2, idx); tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; }
           else sh.err = K3_ERR_OVERFLOW;
         }
-        const int pos = wave_append(push, &sh.n_wl[cur ^ 1]);
+        const int pos = wave_append(push, n_nxt);
         if (push) { if (pos < p.frame_tokens_cap) wl_nxt[pos] = slot2; else sh.err = K3_ERR_OVERFLOW; }
       });
     }
     __syncthreads();
-    if (tid == 0) sh.n_wl[cur] = 0;
-    cur ^= 1;
+    if (round == 1) cur = 0;
+    else { if (tid == 0) sh.n_wl[cur] = 0; cur ^= 1; }
     __syncthreads();
   }
   if (block_err(sh)) return;
+  K3_T(8);
   // eps links at the final costs
   {
     const int n = sh.n_next;
@@ -311,9 +358,9 @@ __device__ void finish_frame(const DecParams &p, Shared &sh, float cutoff, long 
       const int i = i0 + tid; const bool v = i < n;
       int beg = 0, deg = 0; float c = 0.0f;
       if (v) {
-        const int st = tok_state[nb + i];
-        c = dec(K3_ALD(&hash[tok_slot[i]].cost));
-        if (c < cutoff) { const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
+        const int slot = tok_slot[i];
+        c = dec(tb.cost(slot));
+        if (c < cutoff) { const int st = tb.key(slot); const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
       }
       wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
         const float oc = __shfl(c, owner); const int oi = __shfl(i, owner);
@@ -321,8 +368,8 @@ __device__ void finish_frame(const DecParams &p, Shared &sh, float cutoff, long 
         if (valid) {
           const ArcRec r = p.arcs[arc];
           if (oc + r.w < cutoff) {
-            const int s2 = slot_find(hash, mask, r.next);
-            if (s2 >= 0) { mk = true; dtok = K3_ALD(&hash[s2].tok); } else sh.err = K3_ERR_HIP;   // cannot happen at the fixpoint
+            const int s2 = tb.find(r.next);
+            if (s2 >= 0) { mk = true; dtok = tb.tok(s2); } else sh.err = K3_ERR_HIP;   // cannot happen at the fixpoint
           }
         }
         const long long pos = wave_append64(mk, &sh.n_link);
@@ -331,22 +378,30 @@ __device__ void finish_frame(const DecParams &p, Shared &sh, float cutoff, long 
     }
   }
   if (block_err(sh)) return;
+  K3_T(9);
   // final costs into the pool, clear the table
   {
     const int n = sh.n_next;
     for (int i = tid; i < n; i += kBlock) {
       const int slot = tok_slot[i];
-      tok_cost[nb + i] = K3_ALD(&hash[slot].cost);
-      K3_AST(&hash[slot].cost, kEncMax); K3_AST(&hash[slot].stamp, 0); K3_AST(&hash[slot].tok, -1); K3_AST(&hash[slot].key, kEmpty);
+      tok_cost[nb + i] = tb.cost(slot);
+      if (slot >= kHL) tb.clear(slot);
     }
+    __syncthreads();
+    for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; }
   }
   (void)lane;
   __syncthreads();
+  K3_T(10);
 }
 
-__global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) {
+#ifndef K3_DEC_WPE
+#define K3_DEC_WPE 4
+#endif
+__global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(DecParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ Shared sh;
+  __shared__ int s_lkey[kHL]; __shared__ unsigned s_lcost[kHL]; __shared__ int s_ltok[kHL]; __shared__ unsigned s_lmark[kHL / 32];
   float *s_ll = reinterpret_cast<float *>(smem_raw);
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
@@ -363,15 +418,18 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
   const float kInf = __builtin_inff();
 
   if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; }
+  for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; }
+  const Table tb{s_lkey, s_lcost, s_ltok, s_lmark, hash, mask};
   __syncthreads();
   // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
   if (tid == 0) {
-    bool cl; const int slot = slot_find_or_claim(hash, mask, p.start, &cl);
-    atomicMin(&hash[slot].cost, enc(0.0f)); K3_AST(&hash[slot].tok, 0); tok_slot[0] = slot; tok_state[0] = p.start; sh.n_next = 1;
+    bool cl; const int slot = tb.claim(p.start, &cl);
+    tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; sh.n_next = 1;
     tok_off[0] = 0; loff_n[0] = 0;
   }
   __syncthreads();
-  finish_frame(p, sh, p.beam, 0, tok_state, tok_cost, links, hash, tok_slot, wl);
+  long long t_last__ = (long long)__builtin_readcyclecounter();
+  finish_frame(p, sh, tb, p.beam, 0, tok_state, tok_cost, links, tok_slot, wl, t_last__);
   long long cur_base = 0; int n_cur = sh.n_next; int max_frame = n_cur;
   __syncthreads();
   if (tid == 0) { tok_off[1] = n_cur; loff_e[0] = sh.n_link; }
@@ -380,6 +438,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
   for (int f = 0; f < T; f++) {
     if (block_err(sh)) break;
     // stage the log-likelihood row of this frame in LDS (coalesced), overlapped with the cutoff passes
+    K3_T(0);
     const float *row = p.loglikes + (r0 + f) * p.ld;
     if (p.use_lds_row) for (int i = tid; i < p.num_pdfs; i += kBlock) s_ll[i] = row[i];
     const float *ll = p.use_lds_row ? s_ll : row;
@@ -409,6 +468,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
         ab = mic - best + p.beam_delta; cur_cutoff = mic;
       } else { ab = kInf - best + p.beam_delta; cur_cutoff = kInf; }                                          // min_active_cutoff = +inf
     }
+    K3_T(1);
     const float co = -best;
     // ---- pre-pass over the best token's emitting arcs (:753-768; note its own evaluation order)
     __syncthreads();
@@ -423,6 +483,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
     }
     n0 = (unsigned)(block_min_u64((unsigned long long)n0, sh) & 0xFFFFFFFFull);
     const float next0 = n0 == kEncMax ? kInf : dec(n0);
+    K3_T(2);
     if (tid == 0) { sh.n_cand = 0; sh.min_tot = kEncMax; sh.n_next = 0; }
     __syncthreads();
     // ---- ProcessEmitting pass 1 (:779-797): every emitting arc of every token <= cur_cutoff; keep tot < pre-pass bound
@@ -449,6 +510,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
       });
     }
     if (block_err(sh)) break;
+    K3_T(3);
     // ---- final bound of the frame, pass 2: tokens (min cost per state) for the accepted arcs
     float accept = next0;
     { const unsigned mt = sh.min_tot; if (mt != kEncMax) { const float t = dec(mt) + ab; if (t < accept) accept = t; } }
@@ -460,18 +522,19 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
         const float tot = c_tot[j];
         if (tot < accept) {
           nxt = c_dst[j];
-          slot = slot_find_or_claim(hash, mask, nxt, &claimed);
-          if (slot < 0) sh.err = K3_ERR_OVERFLOW; else atomicMin(&hash[slot].cost, enc(tot));
+          slot = tb.claim(nxt, &claimed);
+          if (slot < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; } else tb.cost_min(slot, enc(tot));
           c_dst[j] = slot;
         } else c_arc[j] = -1;
       }
       const int idx = wave_append(claimed, &sh.n_next);
       if (claimed) {
-        if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { K3_AST(&hash[slot].tok, idx); tok_slot[idx] = slot; tok_state[nb + idx] = nxt; }
+        if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tb.set_tok(slot, idx); tok_slot[idx] = slot; tok_state[nb + idx] = nxt; }
         else sh.err = K3_ERR_OVERFLOW;
       }
     }
     if (block_err(sh)) break;
+    K3_T(4);
     // ---- forward links of the accepted arcs (:803-806)
     if (tid == 0) loff_e[f] = sh.n_link;
     __syncthreads();
@@ -480,14 +543,15 @@ __global__ __launch_bounds__(kBlock) void k3_decode_forward_kernel(DecParams p) 
       if (j < n_cand) { arc = c_arc[j]; mk = arc >= 0 && c_dst[j] >= 0; }
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
-        if (pos < p.lane_links_cap) links[pos] = Link{(unsigned)(cur_base + c_src[j]), (unsigned)(nb + K3_ALD(&hash[c_dst[j]].tok)), arc, c_ac[j]};
+        if (pos < p.lane_links_cap) links[pos] = Link{(unsigned)(cur_base + c_src[j]), (unsigned)(nb + tb.tok(c_dst[j])), arc, c_ac[j]};
         else sh.err = K3_ERR_OVERFLOW;
       }
     }
     if (block_err(sh)) break;
+    K3_T(5);
     if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
     // ---- ProcessNonemitting(next_cutoff) + eps links + publish the frame
-    finish_frame(p, sh, accept, nb, tok_state, tok_cost, links, hash, tok_slot, wl);
+    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, tok_slot, wl, t_last__);
     if (block_err(sh)) break;
     cur_base = nb; n_cur = sh.n_next; max_frame = n_cur > max_frame ? n_cur : max_frame;
     __syncthreads();
@@ -509,7 +573,7 @@ __device__ __forceinline__ float link_extra_cost(float next_extra, float tot, fl
   return next_extra + ((tot + ac + graph) - next_tot);
 }
 
-__global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
+__global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
   __shared__ Shared sh;
   __shared__ int s_changed, s_has_final;
   __shared__ unsigned s_best, s_best_final;
@@ -528,7 +592,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
   const long long tb = tok_off[T], te = tok_off[T + 1];
   if (tid == 0) { s_best = kEncMax; s_best_final = kEncMax; s_has_final = 0; }
   __syncthreads();
-  for (long long t = tb + tid; t < te; t += kBlock) {
+  for (long long t = tb + tid; t < te; t += kPBlock) {
     const float c = dec(tok_cost[t]), fc = p.final_cost[tok_state[t]];
     atomicMin(&s_best, enc(c)); atomicMin(&s_best_final, enc(c + fc));
     if (fc != kInf) s_has_final = 1;
@@ -539,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
   const bool final_empty = !s_has_final;
   if (tid == 0) { li.reached_final = s_has_final; li.final_best_cost = final_best; li.final_empty = final_empty; }
   // base term per token; eps links of the last frame are [loff_n[T], loff_e[T])
-  for (long long t = tb + tid; t < te; t += kBlock) extra[t] = 0.0f;        // tokens on the last frame start with extra_cost 0
+  for (long long t = tb + tid; t < te; t += kPBlock) extra[t] = 0.0f;        // tokens on the last frame start with extra_cost 0
   __syncthreads();
   {
     const long long l0 = loff_n[T], l1 = loff_e[T];
@@ -549,18 +613,18 @@ __global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
     for (int sweep = 0; sweep < 100000; sweep++) {
       __syncthreads();
       if (tid == 0) s_changed = 0;
-      for (long long t = tb + tid; t < te; t += kBlock) {
+      for (long long t = tb + tid; t < te; t += kPBlock) {
         const float fc = final_empty ? 0.0f : p.final_cost[tok_state[t]];
         xn[t - tb] = enc(dec(tok_cost[t]) + fc - final_best);
       }
       __syncthreads();
-      for (long long l = l0 + tid; l < l1; l += kBlock) {
+      for (long long l = l0 + tid; l < l1; l += kPBlock) {
         const Link k = links[l];
         float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
         if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - tb], enc(le)); }
       }
       __syncthreads();
-      for (long long t = tb + tid; t < te; t += kBlock) {
+      for (long long t = tb + tid; t < te; t += kPBlock) {
         float v = dec(xn[t - tb]);
         if (v > lb) v = kInf;
         if (__float_as_uint(v) != __float_as_uint(extra[t])) s_changed = 1;
@@ -578,29 +642,29 @@ __global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
     const long long n0 = loff_n[f], n1 = loff_e[f];         // eps links inside frame f
     unsigned *xb = reinterpret_cast<unsigned *>(p.c_tot + (long long)L * p.frame_cands_cap);   // base (emitting part), enc
     unsigned *xn = reinterpret_cast<unsigned *>(p.c_ac + (long long)L * p.frame_cands_cap);
-    for (long long t = b0 + tid; t < b1; t += kBlock) { xb[t - b0] = kEncInf; extra[t] = 0.0f; }
+    for (long long t = b0 + tid; t < b1; t += kPBlock) { xb[t - b0] = kEncInf; extra[t] = 0.0f; }
     __syncthreads();
-    for (long long l = e0 + tid; l < e1; l += kBlock) {
+    for (long long l = e0 + tid; l < e1; l += kPBlock) {
       const Link k = links[l];
       float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
       if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xb[k.src - b0], enc(le)); }
     }
     __syncthreads();
     if (n1 == n0) {
-      for (long long t = b0 + tid; t < b1; t += kBlock) extra[t] = dec(xb[t - b0]);
+      for (long long t = b0 + tid; t < b1; t += kPBlock) extra[t] = dec(xb[t - b0]);
     } else {
       for (int sweep = 0; sweep < 100000; sweep++) {
         __syncthreads();
         if (tid == 0) s_changed = 0;
-        for (long long t = b0 + tid; t < b1; t += kBlock) xn[t - b0] = xb[t - b0];
+        for (long long t = b0 + tid; t < b1; t += kPBlock) xn[t - b0] = xb[t - b0];
         __syncthreads();
-        for (long long l = n0 + tid; l < n1; l += kBlock) {
+        for (long long l = n0 + tid; l < n1; l += kPBlock) {
           const Link k = links[l];
           float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
           if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - b0], enc(le)); }
         }
         __syncthreads();
-        for (long long t = b0 + tid; t < b1; t += kBlock) {
+        for (long long t = b0 + tid; t < b1; t += kPBlock) {
           const float v = dec(xn[t - b0]);
           if (__float_as_uint(v) != __float_as_uint(extra[t])) s_changed = 1;
           extra[t] = v;
@@ -613,8 +677,8 @@ __global__ __launch_bounds__(kBlock) void k3_decode_prune_kernel(DecParams p) {
   }
   // ---- count survivors: tokens with extra != inf; links with link_extra <= lattice_beam (final extras)
   int ns = 0, na = 0;
-  for (long long t = tid; t < tok_off[T + 1]; t += kBlock) ns += extra[t] != kInf;
-  for (long long l = tid; l < li.n_links; l += kBlock) {
+  for (long long t = tid; t < tok_off[T + 1]; t += kPBlock) ns += extra[t] != kInf;
+  for (long long l = tid; l < li.n_links; l += kPBlock) {
     const Link k = links[l];
     const float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
     na += !(le > lb) && extra[k.src] != kInf;
@@ -632,7 +696,7 @@ struct OutParams {
   int *newidx;                            // per-lane scratch [lane_tokens_cap]: pool index -> lattice state index
 };
 
-__global__ __launch_bounds__(kBlock) void k3_decode_output_kernel(DecParams p, OutParams o) {
+__global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, OutParams o) {
   __shared__ int s_n;
   const int L = blockIdx.x, tid = threadIdx.x;
   const LaneInfo &li = p.info[L];
@@ -650,7 +714,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_output_kernel(DecParams p, O
   __syncthreads();
   for (int f = 0; f <= T; f++) {          // frame-major numbering (any per-frame order is a valid GetRawLattice numbering)
     const long long b0 = tok_off[f], b1 = tok_off[f + 1];
-    for (long long t0 = b0; t0 < b1; t0 += kBlock) {
+    for (long long t0 = b0; t0 < b1; t0 += kPBlock) {
       const long long t = t0 + tid; const bool v = t < b1 && extra[t] != kInf;
       const int pos = wave_append(v, &s_n);
       if (v) {
@@ -671,7 +735,7 @@ __global__ __launch_bounds__(kBlock) void k3_decode_output_kernel(DecParams p, O
     const long long e0 = loff_e[f], e1 = (f < T) ? loff_n[f + 1] : loff_e[f];
     for (int part = 0; part < 2; part++) {
       const long long l0 = part ? e0 : n0, l1 = part ? e1 : n1;
-      for (long long x0 = l0; x0 < l1; x0 += kBlock) {
+      for (long long x0 = l0; x0 < l1; x0 += kPBlock) {
         const long long l = x0 + tid; bool v = l < l1; Link k{}; float g = 0.0f;
         if (v) {
           k = links[l]; g = p.arcs[k.arc].w;
@@ -814,7 +878,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   p.frame_tokens_cap = cfg->frame_tokens_cap; p.frame_cands_cap = cfg->frame_cands_cap; p.lane_tokens_cap = cfg->lane_tokens_cap; p.lane_links_cap = cfg->lane_links_cap;
   int hs = 1; while (hs < 2 * cfg->frame_tokens_cap) hs <<= 1;
   p.hash_mask = hs - 1; p.num_pdfs = num_pdfs;
-  p.use_lds_row = ((size_t)num_pdfs * sizeof(float) <= 96 * 1024) ? 1 : 0;
+  p.use_lds_row = ((size_t)num_pdfs * sizeof(float) <= 28 * 1024) ? 1 : 0;   // keeps a lane under 80 KB of LDS: two lanes per CU
   const size_t nl = (size_t)nlanes;
   int rc;
   if ((rc = dmalloc(&d->allocs, &p.tok_state, nl * cfg->lane_tokens_cap))) return rc;
@@ -830,12 +894,14 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &p.c_arc, nl * cfg->frame_cands_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.c_src, nl * cfg->frame_cands_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.info, nl))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.prof, nl * 16))) return rc;
+  K3_HIP_CHECK(hipMemset(p.prof, 0, nl * 16 * sizeof(long long)));
   if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
   if ((rc = dmalloc(&d->allocs, &d->d_newidx, nl * cfg->lane_tokens_cap))) return rc;
   // empty table: key = -1, cost = max, tok = -1, stamp = 0
   std::vector<Slot> init((size_t)hs, Slot{kEmpty, kEncMax, -1, 0});
   for (int l = 0; l < nlanes; l++) K3_HIP_CHECK(hipMemcpy(p.hash + (size_t)l * hs, init.data(), sizeof(Slot) * hs, hipMemcpyHostToDevice));
-  K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_decode_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_decode_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   *out = d.release();
   return K3_OK;
 }
@@ -890,7 +956,7 @@ extern "C" int k3_decoder_decode_batch(k3_decoder *d, int32_t num_utts, const fl
   hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
-  hipLaunchKernelGGL(k3_decode_prune_kernel, dim3(num_utts), dim3(kBlock), 0, st, p);
+  hipLaunchKernelGGL(k3_decode_prune_kernel, dim3(num_utts), dim3(kPBlock), 0, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[2], st));
   d->last_utts = num_utts; d->last_stream = st; d->info_valid = false;
@@ -941,7 +1007,7 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
 #define K3_TRY(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { cleanup(); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
   K3_TRY(hipMemcpy(d_so, so.data(), sizeof(long long) * (U + 1), hipMemcpyHostToDevice));
   K3_TRY(hipMemcpy(d_ao, ao.data(), sizeof(long long) * (U + 1), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k3_decode_output_kernel, dim3(U), dim3(kBlock), 0, st, d->p, o);
+  hipLaunchKernelGGL(k3_decode_output_kernel, dim3(U), dim3(kPBlock), 0, st, d->p, o);
   K3_TRY(hipGetLastError());
   K3_TRY(hipStreamSynchronize(st));
   K3_TRY(hipMemcpy(st_frame, o.st_frame, 4 * NS, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(st_state, o.st_state, 4 * NS, hipMemcpyDeviceToHost));
@@ -951,6 +1017,15 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
   K3_TRY(hipMemcpy(arc_g, o.arc_g, 4 * NA, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(arc_ac, o.arc_ac, 4 * NA, hipMemcpyDeviceToHost));
 #undef K3_TRY
   cleanup();
+  return K3_OK;
+}
+
+extern "C" int k3_decoder_phase_cycles(k3_decoder *d, int64_t *h_cycles /* [16] summed over lanes, reset */) {
+  K3_REQUIRE(d && h_cycles, "k3_decoder_phase_cycles: null argument");
+  std::vector<long long> h((size_t)d->nlanes * 16);
+  K3_HIP_CHECK(hipMemcpy(h.data(), d->p.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; i++) { h_cycles[i] = 0; for (int l = 0; l < d->nlanes; l++) h_cycles[i] += h[(size_t)l * 16 + i]; }
+  K3_HIP_CHECK(hipMemset(d->p.prof, 0, h.size() * sizeof(long long)));
   return K3_OK;
 }
 

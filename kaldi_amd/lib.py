@@ -2,7 +2,7 @@
 import ctypes, os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libk3hip.so")
+LIB_PATH = os.environ.get("K3HIP_LIB", os.path.join(HERE, "lib", "libk3hip.so"))   # K3HIP_LIB: developer override (kernel variants)
 
 class K3Error(RuntimeError):
     """Raised for any non-zero k3_status (the C++ adapters raise KaldiFatalError instead)."""
@@ -75,6 +75,7 @@ def load():
     L.k3_decoder_get_raw_lattices.argtypes = [vp] + [vp] * 10
     L.k3_fst_export_image.argtypes = [vp, vp]; L.k3_fst_import_image.argtypes = [vp, vp]
     L.k3_decoder_set_profiling.argtypes = [vp, i32]; L.k3_decoder_kernel_times.argtypes = [vp, vp]
+    L.k3_decoder_phase_cycles.argtypes = [vp, vp]
     L.k3_decoder_frame_stats.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     _lib = L
     return L

@@ -183,18 +183,21 @@ def make_tdnn(seed=1, input_dim=40, dim=512, offsets=((-1, 0, 1), (-1, 0, 1), (-
 
 # ----------------------------------------------------------------------------- synthetic HCLG ----
 def make_hclg(num_states=2_000_000, num_arcs=5_000_000, num_pdfs=6024, seed=4321, eps_frac=0.25, selfloop_frac=0.6,
-              olabel_frac=0.08, final_frac=0.03, start_degree=4000, num_words=200_000):
+              olabel_frac=0.08, final_frac=0.03, start_degree=4000, num_words=200_000, max_eps_depth=4):
     """A decodable graph with HCLG-like statistics: mean out-degree num_arcs/num_states with a heavy
     start/loop state, ~(1-eps_frac) emitting arcs with ilabel = transition-id in [1, 2*num_pdfs] (tid -> pdf is
-    (tid-1) mod num_pdfs, see tid2pdf()), self-loops on selfloop_frac of the states, epsilon arcs only from lower to
-    higher state ids (=> no epsilon cycles, which TopSortTokens asserts: lattice-faster-decoder.cc:995), olabels on
-    olabel_frac of the arcs, final_frac final states; every state is accessible and co-accessible.
+    (tid-1) mod num_pdfs, see tid2pdf()), self-loops on selfloop_frac of the states, olabels on olabel_frac of the arcs,
+    final_frac final states; every state is accessible and co-accessible.
+    Input-epsilon arcs: only from a state of epsilon-level l to a state of level l+1 with a higher id, level(s) = s mod
+    (max_eps_depth+1)  =>  no epsilon cycles (TopSortTokens asserts that: lattice-faster-decoder.cc:995) and epsilon chains of
+    at most max_eps_depth arcs, like a real HCLG where they come from n-gram back-off and lexicon optional-silence arcs.
     Returns a kaldi_amd.fst.Fst."""
     from .fst import Fst
     from scipy.sparse import csr_matrix
     from scipy.sparse.csgraph import breadth_first_order
     rng = np.random.default_rng(seed)
-    S = int(num_states); assert S >= 4
+    S = int(num_states); assert S >= 4 * (max_eps_depth + 1)
+    P = max_eps_depth + 1
     src, dst, eps = [], [], []
     # (b) self-loops (emitting)
     loops = np.nonzero(rng.random(S) < selfloop_frac)[0].astype(np.int64)
@@ -202,20 +205,30 @@ def make_hclg(num_states=2_000_000, num_arcs=5_000_000, num_pdfs=6024, seed=4321
     # (c) the heavy start/loop state
     sd = int(min(start_degree, max(1, S // 2)))
     src.append(np.zeros(sd, np.int64)); dst.append(rng.integers(1, S, sd)); eps.append(np.zeros(sd, bool))
-    # (a) accessibility: every state s >= 1 gets an in-arc from a random earlier state
+    # (a) accessibility: every state s >= 1 gets an in-arc from a random earlier state; for ~45 % of the states of level >= 1
+    #     the parent is taken from the previous level and the arc is an epsilon arc
     s_all = np.arange(1, S, dtype=np.int64)
     par = (rng.random(S - 1) * s_all).astype(np.int64)
+    sp_eps = (s_all % P != 0) & (rng.random(S - 1) < 0.45)
+    cnt_b = (s_all - 1) // P + 1                                                     # earlier states of the previous level: s-1, s-1-P, ...
+    par = np.where(sp_eps, s_all - 1 - P * (rng.random(S - 1) * cnt_b).astype(np.int64), par)
+    sp_eps &= (par >= 0) & (par % P == (s_all % P) - 1)
+    par = np.maximum(par, 0)
+    src.append(par); dst.append(s_all); eps.append(sp_eps)
     # (e) every state without a child in (a) gets one emitting arc to a random state (keeps it co-accessible w.h.p.)
     has_child = np.zeros(S, bool); has_child[par] = True; has_child[0] = True
     lack = np.nonzero(~has_child)[0].astype(np.int64)
-    n_rest = max(0, int(num_arcs) - (S - 1) - loops.size - sd - lack.size)
-    p_eps = min(0.9, eps_frac * float(num_arcs) / max(1, S - 1 + n_rest))   # epsilon arcs only occur in (a) and (d)
-    src.append(par); dst.append(s_all); eps.append(rng.random(S - 1) < p_eps)
     src.append(lack); dst.append(rng.integers(0, S, lack.size)); eps.append(np.zeros(lack.size, bool))
-    # (d) the rest: random sources; emitting arcs go anywhere, epsilon arcs go to a higher state id
-    rs = rng.integers(0, S - 1, n_rest); re_ = rng.random(n_rest) < p_eps
-    rd = np.where(re_, rs + 1 + (rng.random(n_rest) * (S - 1 - rs)).astype(np.int64), rng.integers(0, S, n_rest))
-    src.append(rs); dst.append(rd); eps.append(re_)
+    # (d) the rest: epsilon arcs level l -> level l+1 (higher id), then emitting arcs between random states
+    n_rest = max(0, int(num_arcs) - (S - 1) - loops.size - sd - lack.size)
+    n_eps = max(0, min(n_rest, int(round(eps_frac * num_arcs)) - int(sp_eps.sum())))
+    es = rng.integers(0, S - 2 * P, n_eps); es -= (es % P == P - 1)                 # sources of level < max_eps_depth
+    cnt = (S - 2 - es) // P + 1                                                      # states of the next level above es
+    ed = es + 1 + P * (rng.random(n_eps) * cnt).astype(np.int64)
+    ok = (ed > es) & (ed < S) & (ed % P == (es % P) + 1)
+    src.append(es[ok]); dst.append(ed[ok]); eps.append(np.ones(int(ok.sum()), bool))
+    n_emit = n_rest - int(ok.sum())
+    src.append(rng.integers(0, S - 1, n_emit)); dst.append(rng.integers(0, S, n_emit)); eps.append(np.zeros(n_emit, bool))
     src, dst, eps = np.concatenate(src), np.concatenate(dst), np.concatenate(eps)
     final = np.full(S, np.inf, np.float32)
     fin = np.nonzero(rng.random(S) < final_frac)[0]

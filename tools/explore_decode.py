@@ -3,7 +3,7 @@
 import os, sys, time, tempfile, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
-ge.build()
+if not os.environ.get("K3HIP_LIB"): ge.build()
 from kaldi_amd import feat, nnet3, synth, decoder
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
@@ -32,3 +32,9 @@ for k, name in enumerate(decoder.CudaDecoder.INFO): print(name, "min/mean/max", 
 t = time.time(); lats = dec.GetRawLattices(); print("GetRawLattices %.3fs" % (time.time() - t))
 st = dec.FrameStats(0, int(nb.out_offsets[1])); print("ntoks[:30]", st["ntoks"][:30], "mean", st["ntoks"].mean(), "ab", st["adaptive_beam"][:10])
 audio = U * secs; print("audio-s", audio)
+import ctypes
+from kaldi_amd import lib as _l
+cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
+names = ["(loop top/err)", "cutoff", "prepass", "expand", "pass2 insert", "links", "-", "eps worklist build", "eps rounds", "eps links", "finalize+clear"]
+tot = cyc.sum()
+if tot: print("phase share:", {n: round(100.0 * c / tot, 1) for n, c in zip(names, cyc) if n != "-"}, "cycles/lane/frame", tot / U / 333 / 2)
