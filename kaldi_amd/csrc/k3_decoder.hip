@@ -50,7 +50,10 @@ constexpr int kEmpty = -1;
 
 struct Slot { int key; unsigned cost; int tok; int stamp; };          // 16 B hash slot
 struct ArcRec { int next; float w; int pdf; int olabel; };            // 16 B graph arc
-struct Link { unsigned src, dst; int arc; float ac; };                // 16 B forward link (token indices are lane-pool indices)
+// 16 B forward link (token indices are lane-pool indices): `tot` = (src cost + acoustic) + graph exactly as the forward pass formed
+// it, which is the term PruneForwardLinks needs (:339-341), so pruning never touches the graph; the arc id (labels, graph cost for
+// the lattice writer) lives in a parallel 4 B array that only the output kernel reads
+struct Link { unsigned src, dst; float tot; float ac; };
 
 enum { kStOk = 0, kStNoTokens = 1 };
 
@@ -76,7 +79,7 @@ struct DecParams {
   // input
   const float *loglikes; long long ld; const long long *row_off; int num_pdfs; int use_lds_row;
   // per-lane pools (lane l at base + l * stride)
-  int *tok_state; unsigned *tok_cost; float *tok_extra; Link *links;
+  int *tok_state; unsigned *tok_cost; float *tok_extra; Link *links; int *link_arc;
   Slot *hash; int *tok_slot; int *wl;            // wl: 2 x frame_tokens_cap
   float *c_tot, *c_ac; int *c_dst, *c_arc, *c_src;
   // per-lane per-frame arrays, stride fstride = max_frames + 2
@@ -293,7 +296,7 @@ __device__ unsigned block_select_kth(const unsigned *keys, int n, int k, Shared 
 // ProcessNonemitting (lattice-faster-decoder.cc:830-897): relax eps arcs until no cost changes, with tot < cutoff;
 // the links a token ends up with are exactly its eps arcs with cur + graph < cutoff at its final cost.
 __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, const Table &tb, float cutoff, long long nb, int *tok_state, unsigned *tok_cost,
-                                             Link *links, int *tok_slot, int *wl, long long &t_last__) {
+                                             Link *links, int *link_arc, int *tok_slot, int *wl, long long &t_last__) {
   const int tid = threadIdx.x, lane = tid & 63;
   __syncthreads();
   if (tid == 0) { sh.n_wl[0] = 0; sh.n_wl[1] = 0; }
@@ -364,16 +367,17 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
       }
       wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
         const float oc = __shfl(c, owner); const int oi = __shfl(i, owner);
-        bool mk = false; int dtok = 0;
+        bool mk = false; int dtok = 0; float tot = 0.0f;
         if (valid) {
           const ArcRec r = p.arcs[arc];
-          if (oc + r.w < cutoff) {
+          tot = oc + r.w;
+          if (tot < cutoff) {
             const int s2 = tb.find(r.next);
             if (s2 >= 0) { mk = true; dtok = tb.tok(s2); } else sh.err = K3_ERR_HIP;   // cannot happen at the fixpoint
           }
         }
         const long long pos = wave_append64(mk, &sh.n_link);
-        if (mk) { if (pos < p.lane_links_cap) links[pos] = Link{(unsigned)(nb + oi), (unsigned)(nb + dtok), arc, 0.0f}; else sh.err = K3_ERR_OVERFLOW; }
+        if (mk) { if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(nb + oi), (unsigned)(nb + dtok), tot, 0.0f}; link_arc[pos] = arc; } else sh.err = K3_ERR_OVERFLOW; }
       });
     }
   }
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
   int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
-  Link *links = p.links + (long long)L * p.lane_links_cap;
+  Link *links = p.links + (long long)L * p.lane_links_cap; int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
   Slot *hash = p.hash + (long long)L * (p.hash_mask + 1);
   int *tok_slot = p.tok_slot + (long long)L * p.frame_tokens_cap, *wl = p.wl + 2ll * L * p.frame_tokens_cap;
   float *c_tot = p.c_tot + (long long)L * p.frame_cands_cap, *c_ac = p.c_ac + (long long)L * p.frame_cands_cap;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   }
   __syncthreads();
   long long t_last__ = (long long)__builtin_readcyclecounter();
-  finish_frame(p, sh, tb, p.beam, 0, tok_state, tok_cost, links, tok_slot, wl, t_last__);
+  finish_frame(p, sh, tb, p.beam, 0, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__);
   long long cur_base = 0; int n_cur = sh.n_next; int max_frame = n_cur;
   __syncthreads();
   if (tid == 0) { tok_off[1] = n_cur; loff_e[0] = sh.n_link; }
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       if (j < n_cand) { arc = c_arc[j]; mk = arc >= 0 && c_dst[j] >= 0; }
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
-        if (pos < p.lane_links_cap) links[pos] = Link{(unsigned)(cur_base + c_src[j]), (unsigned)(nb + tb.tok(c_dst[j])), arc, c_ac[j]};
+        if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + c_src[j]), (unsigned)(nb + tb.tok(c_dst[j])), c_tot[j], c_ac[j]}; link_arc[pos] = arc; }
         else sh.err = K3_ERR_OVERFLOW;
       }
     }
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     K3_T(5);
     if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
     // ---- ProcessNonemitting(next_cutoff) + eps links + publish the frame
-    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, tok_slot, wl, t_last__);
+    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__);
     if (block_err(sh)) break;
     cur_base = nb; n_cur = sh.n_next; max_frame = n_cur > max_frame ? n_cur : max_frame;
     __syncthreads();
@@ -569,14 +573,18 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
 // FinalizeDecoding (:634-649) on the GPU: one workgroup per lane, frames in reverse.  tok_extra holds extra_cost.
 // Inside a frame the eps links make the extra costs depend on each other; the dependency graph is acyclic, so the
 // fixpoint is unique and reached by iterating x <- min(base, min_links f(x)) until nothing changes.
-__device__ __forceinline__ float link_extra_cost(float next_extra, float tot, float ac, float graph, float next_tot) {
-  return next_extra + ((tot + ac + graph) - next_tot);
+__device__ __forceinline__ float link_extra_cost(float next_extra, float via_link_tot, float next_tot) {
+  return next_extra + (via_link_tot - next_tot);      // next_tok->extra_cost + ((tok->tot_cost + ac + graph) - next_tok->tot_cost), :339-341
 }
+
+constexpr int kPCap = 2048;      // frames with at most this many tokens are pruned entirely inside LDS
 
 __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
   __shared__ Shared sh;
   __shared__ int s_changed, s_has_final;
   __shared__ unsigned s_best, s_best_final;
+  __shared__ float s_cost[2][kPCap], s_extra[2][kPCap];   // token costs / extra costs of frames f+1 (buffer nb) and f (buffer nb ^ 1)
+  __shared__ unsigned s_xb[kPCap], s_xn[kPCap];
   const int L = blockIdx.x, tid = threadIdx.x;
   LaneInfo &li = p.info[L];
   if (li.status != kStOk) return;
@@ -586,9 +594,8 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
   const Link *links = p.links + (long long)L * p.lane_links_cap;
   const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
   const float kInf = __builtin_inff(); const float lb = p.lattice_beam;
-  unsigned *xenc = reinterpret_cast<unsigned *>(extra);   // extra costs are >= 0 or +inf: their float bits order like unsigned ints
 
-  // ---- last frame: ComputeFinalCosts (:545-586) + PruneForwardLinksFinal (:385-467)
+  // ---- last frame: ComputeFinalCosts (:545-586) + PruneForwardLinksFinal (:385-467), in HBM (one frame only)
   const long long tb = tok_off[T], te = tok_off[T + 1];
   if (tid == 0) { s_best = kEncMax; s_best_final = kEncMax; s_has_final = 0; }
   __syncthreads();
@@ -602,7 +609,6 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
   const float final_best = (best_final != kInf) ? best_final : best;
   const bool final_empty = !s_has_final;
   if (tid == 0) { li.reached_final = s_has_final; li.final_best_cost = final_best; li.final_empty = final_empty; }
-  // base term per token; eps links of the last frame are [loff_n[T], loff_e[T])
   for (long long t = tb + tid; t < te; t += kPBlock) extra[t] = 0.0f;        // tokens on the last frame start with extra_cost 0
   __syncthreads();
   {
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
       __syncthreads();
       for (long long l = l0 + tid; l < l1; l += kPBlock) {
         const Link k = links[l];
-        float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
+        float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
         if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - tb], enc(le)); }
       }
       __syncthreads();
@@ -635,18 +641,74 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
     }
   }
   __syncthreads();
-  // ---- frames T-1 .. 0: PruneForwardLinks(f, delta = 0) then PruneTokensForFrame(f+1) (tokens with extra = inf vanish)
+  // ---- frames T-1 .. 0: PruneForwardLinks(f, delta = 0) then PruneTokensForFrame(f+1) (tokens with extra = inf vanish).
+  // Fast path: both frames fit in LDS -> per frame one round trip to HBM (its links + its token costs), everything else in LDS.
+  int nbuf = 0; bool next_in_lds = false;
   for (int f = T - 1; f >= 0; f--) {
-    const long long b0 = tok_off[f], b1 = tok_off[f + 1];
+    const long long b0 = tok_off[f], b1 = tok_off[f + 1], b2 = tok_off[f + 2];
     const long long e0 = loff_e[f], e1 = loff_n[f + 1];     // emitting links f -> f+1
     const long long n0 = loff_n[f], n1 = loff_e[f];         // eps links inside frame f
+    const int nf = (int)(b1 - b0), nn = (int)(b2 - b1);
+    if (nf <= kPCap && nn <= kPCap) {
+      float *ncost = s_cost[nbuf], *nextra = s_extra[nbuf], *ccost = s_cost[nbuf ^ 1], *cextra = s_extra[nbuf ^ 1];
+      if (!next_in_lds) { for (int i = tid; i < nn; i += kPBlock) { ncost[i] = dec(tok_cost[b1 + i]); nextra[i] = extra[b1 + i]; } }
+      for (int i = tid; i < nf; i += kPBlock) { ccost[i] = dec(tok_cost[b0 + i]); s_xb[i] = kEncInf; cextra[i] = 0.0f; }
+      // this thread's eps links stay in registers over the sweeps (a frame has a few hundred of them)
+      constexpr int kEpsRegs = 4;
+      Link er[kEpsRegs]; const int neps = (int)(n1 - n0);
+#pragma unroll
+      for (int k = 0; k < kEpsRegs; k++) { const int i = tid + k * kPBlock; if (i < neps) er[k] = links[n0 + i]; }
+      __syncthreads();
+      for (long long l = e0 + tid; l < e1; l += kPBlock) {
+        const Link k = links[l];
+        float le = link_extra_cost(nextra[k.dst - b1], k.tot, ncost[k.dst - b1]);
+        if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&s_xb[k.src - b0], enc(le)); }
+      }
+      __syncthreads();
+      if (neps == 0) {
+        for (int i = tid; i < nf; i += kPBlock) { const float v = dec(s_xb[i]); cextra[i] = v; extra[b0 + i] = v; }
+      } else {
+        for (int sweep = 0; sweep < 100000; sweep++) {
+          __syncthreads();
+          if (tid == 0) s_changed = 0;
+          for (int i = tid; i < nf; i += kPBlock) s_xn[i] = s_xb[i];
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < kEpsRegs; k++) {
+            const int i = tid + k * kPBlock;
+            if (i < neps) {
+              float le = link_extra_cost(cextra[er[k].dst - b0], er[k].tot, ccost[er[k].dst - b0]);
+              if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&s_xn[er[k].src - b0], enc(le)); }
+            }
+          }
+          for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) {       // (rare) more eps links than fit in registers
+            const Link k = links[l];
+            float le = link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]);
+            if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&s_xn[k.src - b0], enc(le)); }
+          }
+          __syncthreads();
+          for (int i = tid; i < nf; i += kPBlock) {
+            const float v = dec(s_xn[i]);
+            if (__float_as_uint(v) != __float_as_uint(cextra[i])) s_changed = 1;
+            cextra[i] = v;
+          }
+          __syncthreads();
+          if (!s_changed) break;
+        }
+        for (int i = tid; i < nf; i += kPBlock) extra[b0 + i] = cextra[i];
+      }
+      nbuf ^= 1; next_in_lds = true;
+      __syncthreads();
+      continue;
+    }
+    next_in_lds = false;
     unsigned *xb = reinterpret_cast<unsigned *>(p.c_tot + (long long)L * p.frame_cands_cap);   // base (emitting part), enc
     unsigned *xn = reinterpret_cast<unsigned *>(p.c_ac + (long long)L * p.frame_cands_cap);
     for (long long t = b0 + tid; t < b1; t += kPBlock) { xb[t - b0] = kEncInf; extra[t] = 0.0f; }
     __syncthreads();
     for (long long l = e0 + tid; l < e1; l += kPBlock) {
       const Link k = links[l];
-      float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
+      float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
       if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xb[k.src - b0], enc(le)); }
     }
     __syncthreads();
@@ -660,7 +722,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
         __syncthreads();
         for (long long l = n0 + tid; l < n1; l += kPBlock) {
           const Link k = links[l];
-          float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
+          float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
           if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - b0], enc(le)); }
         }
         __syncthreads();
@@ -675,17 +737,19 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
     }
     __syncthreads();
   }
+  __syncthreads();
   // ---- count survivors: tokens with extra != inf; links with link_extra <= lattice_beam (final extras)
   int ns = 0, na = 0;
   for (long long t = tid; t < tok_off[T + 1]; t += kPBlock) ns += extra[t] != kInf;
   for (long long l = tid; l < li.n_links; l += kPBlock) {
     const Link k = links[l];
-    const float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, p.arcs[k.arc].w, dec(tok_cost[k.dst]));
-    na += !(le > lb) && extra[k.src] != kInf;
+    const float xs = extra[k.src];
+    if (xs == kInf) continue;                      // dead source: all its links were excised
+    const float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
+    na += !(le > lb);
   }
   ns = block_sum_i32(ns, sh); na = block_sum_i32(na, sh);
   if (tid == 0) { li.out_states = ns; li.out_arcs = na; }
-  (void)xenc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -704,7 +768,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, 
   const int T = li.num_frames;
   const int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; const unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
   const float *extra = p.tok_extra + (long long)L * p.lane_tokens_cap;
-  const Link *links = p.links + (long long)L * p.lane_links_cap;
+  const Link *links = p.links + (long long)L * p.lane_links_cap; const int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
   const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
   const float *st_co = p.st_co + L * p.fstride;
   int *newidx = o.newidx + (long long)L * p.lane_tokens_cap;
@@ -736,17 +800,17 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, 
     for (int part = 0; part < 2; part++) {
       const long long l0 = part ? e0 : n0, l1 = part ? e1 : n1;
       for (long long x0 = l0; x0 < l1; x0 += kPBlock) {
-        const long long l = x0 + tid; bool v = l < l1; Link k{}; float g = 0.0f;
+        const long long l = x0 + tid; bool v = l < l1; Link k{};
         if (v) {
-          k = links[l]; g = p.arcs[k.arc].w;
-          const float le = link_extra_cost(extra[k.dst], dec(tok_cost[k.src]), k.ac, g, dec(tok_cost[k.dst]));
-          v = !(le > lb) && extra[k.src] != kInf;
+          k = links[l];
+          v = extra[k.src] != kInf;
+          if (v) { const float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])); v = !(le > lb); }
         }
         const int pos = wave_append(v, &s_n);
         if (v) {
-          const int il = p.arc_ilabel[k.arc];
-          o.arc_src[ao + pos] = newidx[k.src]; o.arc_dst[ao + pos] = newidx[k.dst]; o.arc_il[ao + pos] = il; o.arc_ol[ao + pos] = p.arcs[k.arc].olabel;
-          o.arc_g[ao + pos] = g; o.arc_ac[ao + pos] = part ? (k.ac - st_co[f]) : (k.ac - 0.0f);
+          const int arc = link_arc[l]; const ArcRec r = p.arcs[arc];
+          o.arc_src[ao + pos] = newidx[k.src]; o.arc_dst[ao + pos] = newidx[k.dst]; o.arc_il[ao + pos] = p.arc_ilabel[arc]; o.arc_ol[ao + pos] = r.olabel;
+          o.arc_g[ao + pos] = r.w; o.arc_ac[ao + pos] = part ? (k.ac - st_co[f]) : (k.ac - 0.0f);
         }
       }
     }
@@ -885,6 +949,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &p.tok_cost, nl * cfg->lane_tokens_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.tok_extra, nl * cfg->lane_tokens_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.links, nl * cfg->lane_links_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.link_arc, nl * cfg->lane_links_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.hash, nl * hs))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.tok_slot, nl * cfg->frame_tokens_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.wl, 2 * nl * cfg->frame_tokens_cap))) return rc;

@@ -21,11 +21,11 @@ t = time.time(); f = synth.make_hclg(); print("graph", f.stats(), "gen %.1fs" % 
 t = time.time(); cf = decoder.CudaFst(f, synth.tid2pdf(net.info.output_dim)); print("upload %.2fs" % (time.time() - t))
 cfg = decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, frame_tokens_cap=65536, frame_cands_cap=131072,
                              lane_tokens_cap=int(os.environ.get("TOKCAP", 6_000_000)), lane_links_cap=int(os.environ.get("LINKCAP", 12_000_000)))
-dec = decoder.CudaDecoder(cf, cfg, U, net.info.output_dim)
+dec = decoder.CudaDecoder(cf, cfg, U, net.info.output_dim); dec.SetProfiling(True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 for it in range(2):
     ev[0].record(); dec.DecodeBatch(ll, nb.out_offsets); ev[1].record(); torch.cuda.synchronize()
-    print("decode (forward+prune) ms:", ev[0].elapsed_time(ev[1]))
+    print("decode (forward+prune) ms:", ev[0].elapsed_time(ev[1]), "kernels (token passing, prune):", dec.KernelTimes())
 info = dec.LatticeInfo(check=False)
 print("status", np.unique(info[:, 2], return_counts=True), "reached_final", info[:, 3].mean())
 for k, name in enumerate(decoder.CudaDecoder.INFO): print(name, "min/mean/max", info[:, k].min(), info[:, k].mean(), info[:, k].max())
