@@ -61,6 +61,7 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
   long long n_tokens, n_links, n_cands, n_eps;   // created / emitting arcs examined / eps arcs examined
   int status, reached_final, max_frame_tokens, num_frames;
   int out_states, out_arcs;               // after pruning
+  int live_overflow;                      // the survivor lists were too small: the output kernel rescans the pools
   float final_best_cost; int final_empty;
 };
 
@@ -80,6 +81,7 @@ struct DecParams {
   const float *loglikes; long long ld; const long long *row_off; int num_pdfs; int use_lds_row;
   // per-lane pools (lane l at base + l * stride)
   int *tok_state; unsigned *tok_cost; float *tok_extra; Link *links; int *link_arc;
+  int *live_tok; long long *live_link; int *newidx; int live_cap;   // survivors of the pruning pass (pool indices), per lane
   Slot *hash; int *tok_slot; int *wl;            // wl: 2 x frame_tokens_cap
   float *c_tot, *c_ac; int *c_dst, *c_arc, *c_src;
   // per-lane per-frame arrays, stride fstride = max_frames + 2
@@ -580,7 +582,6 @@ __device__ __forceinline__ float link_extra_cost(float next_extra, float via_lin
 constexpr int kPCap = 2048;      // frames with at most this many tokens are pruned entirely inside LDS
 
 __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
-  __shared__ Shared sh;
   __shared__ int s_changed, s_has_final;
   __shared__ unsigned s_best, s_best_final;
   __shared__ float s_cost[2][kPCap], s_extra[2][kPCap];   // token costs / extra costs of frames f+1 (buffer nb) and f (buffer nb ^ 1)
@@ -595,6 +596,13 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
   const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
   const float kInf = __builtin_inff(); const float lb = p.lattice_beam;
 
+  // survivors (tokens with extra != inf, links with link_extra <= lattice_beam) are recorded frame by frame
+  __shared__ int s_nt, s_nl;
+  if (tid == 0) { s_nt = 0; s_nl = 0; }
+  int *live_tok = p.live_tok + (long long)L * p.live_cap; long long *live_link = p.live_link + (long long)L * p.live_cap;
+  int *newidx = p.newidx + (long long)L * p.lane_tokens_cap;
+  auto keep_tok = [&](long long t) { const int pos = atomicAdd(&s_nt, 1); if (pos < p.live_cap) live_tok[pos] = (int)t; newidx[t] = pos; };
+  auto keep_link = [&](long long l) { const int pos = atomicAdd(&s_nl, 1); if (pos < p.live_cap) live_link[pos] = l; };
   // ---- last frame: ComputeFinalCosts (:545-586) + PruneForwardLinksFinal (:385-467), in HBM (one frame only)
   const long long tb = tok_off[T], te = tok_off[T + 1];
   if (tid == 0) { s_best = kEncMax; s_best_final = kEncMax; s_has_final = 0; }
@@ -639,6 +647,11 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
       __syncthreads();
       if (!s_changed) break;
     }
+    for (long long t = tb + tid; t < te; t += kPBlock) if (extra[t] != kInf) keep_tok(t);
+    for (long long l = l0 + tid; l < l1; l += kPBlock) {
+      const Link k = links[l];
+      if (extra[k.src] != kInf && !(link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])) > lb)) keep_link(l);
+    }
   }
   __syncthreads();
   // ---- frames T-1 .. 0: PruneForwardLinks(f, delta = 0) then PruneTokensForFrame(f+1) (tokens with extra = inf vanish).
@@ -662,11 +675,11 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
       for (long long l = e0 + tid; l < e1; l += kPBlock) {
         const Link k = links[l];
         float le = link_extra_cost(nextra[k.dst - b1], k.tot, ncost[k.dst - b1]);
-        if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&s_xb[k.src - b0], enc(le)); }
+        if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; atomicMin(&s_xb[k.src - b0], enc(le)); }     // a surviving emitting link keeps its source alive
       }
       __syncthreads();
       if (neps == 0) {
-        for (int i = tid; i < nf; i += kPBlock) { const float v = dec(s_xb[i]); cextra[i] = v; extra[b0 + i] = v; }
+        for (int i = tid; i < nf; i += kPBlock) { const float v = dec(s_xb[i]); cextra[i] = v; extra[b0 + i] = v; if (v != kInf) keep_tok(b0 + i); }
       } else {
         for (int sweep = 0; sweep < 100000; sweep++) {
           __syncthreads();
@@ -695,7 +708,13 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
           __syncthreads();
           if (!s_changed) break;
         }
-        for (int i = tid; i < nf; i += kPBlock) extra[b0 + i] = cextra[i];
+        for (int i = tid; i < nf; i += kPBlock) { extra[b0 + i] = cextra[i]; if (cextra[i] != kInf) keep_tok(b0 + i); }
+#pragma unroll
+        for (int k = 0; k < kEpsRegs; k++) {
+          const int i = tid + k * kPBlock;
+          if (i < neps && !(link_extra_cost(cextra[er[k].dst - b0], er[k].tot, ccost[er[k].dst - b0]) > lb)) keep_link(n0 + i);
+        }
+        for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (!(link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]) > lb)) keep_link(l); }
       }
       nbuf ^= 1; next_in_lds = true;
       __syncthreads();
@@ -709,11 +728,11 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
     for (long long l = e0 + tid; l < e1; l += kPBlock) {
       const Link k = links[l];
       float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
-      if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xb[k.src - b0], enc(le)); }
+      if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; atomicMin(&xb[k.src - b0], enc(le)); }
     }
     __syncthreads();
     if (n1 == n0) {
-      for (long long t = b0 + tid; t < b1; t += kPBlock) extra[t] = dec(xb[t - b0]);
+      for (long long t = b0 + tid; t < b1; t += kPBlock) { const float v = dec(xb[t - b0]); extra[t] = v; if (v != kInf) keep_tok(t); }
     } else {
       for (int sweep = 0; sweep < 100000; sweep++) {
         __syncthreads();
@@ -734,22 +753,13 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
         __syncthreads();
         if (!s_changed) break;
       }
+      for (long long t = b0 + tid; t < b1; t += kPBlock) if (extra[t] != kInf) keep_tok(t);
+      for (long long l = n0 + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (!(link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])) > lb)) keep_link(l); }
     }
     __syncthreads();
   }
   __syncthreads();
-  // ---- count survivors: tokens with extra != inf; links with link_extra <= lattice_beam (final extras)
-  int ns = 0, na = 0;
-  for (long long t = tid; t < tok_off[T + 1]; t += kPBlock) ns += extra[t] != kInf;
-  for (long long l = tid; l < li.n_links; l += kPBlock) {
-    const Link k = links[l];
-    const float xs = extra[k.src];
-    if (xs == kInf) continue;                      // dead source: all its links were excised
-    const float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
-    na += !(le > lb);
-  }
-  ns = block_sum_i32(ns, sh); na = block_sum_i32(na, sh);
-  if (tid == 0) { li.out_states = ns; li.out_arcs = na; }
+  if (tid == 0) { li.out_states = s_nt; li.out_arcs = s_nl; li.live_overflow = (s_nt > p.live_cap || s_nl > p.live_cap) ? 1 : 0; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -757,7 +767,6 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
 struct OutParams {
   const long long *st_off, *arc_off;     // [U+1] prefix sums of out_states / out_arcs (device)
   int *st_frame, *st_state; float *st_cost, *st_final; int *arc_src, *arc_dst, *arc_il, *arc_ol; float *arc_g, *arc_ac;
-  int *newidx;                            // per-lane scratch [lane_tokens_cap]: pool index -> lattice state index
 };
 
 __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, OutParams o) {
@@ -771,9 +780,31 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, 
   const Link *links = p.links + (long long)L * p.lane_links_cap; const int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
   const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
   const float *st_co = p.st_co + L * p.fstride;
-  int *newidx = o.newidx + (long long)L * p.lane_tokens_cap;
+  int *newidx = p.newidx + (long long)L * p.lane_tokens_cap;
   const float kInf = __builtin_inff(); const float lb = p.lattice_beam;
   const long long so = o.st_off[L], ao = o.arc_off[L];
+  if (!li.live_overflow) {       // survivors were listed by the pruning pass: touch only them
+    const int *live_tok = p.live_tok + (long long)L * p.live_cap; const long long *live_link = p.live_link + (long long)L * p.live_cap;
+    for (int i = tid; i < li.out_states; i += kPBlock) {
+      const long long t = live_tok[i];
+      int lo = 0, hi = T;                                  // frame f with tok_off[f] <= t < tok_off[f+1]
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tok_off[mid] <= t) lo = mid; else hi = mid - 1; }
+      o.st_frame[so + i] = lo; o.st_state[so + i] = tok_state[t]; o.st_cost[so + i] = dec(tok_cost[t]);
+      float fin = kInf;
+      if (lo == T) { if (li.final_empty) fin = 0.0f; else fin = p.final_cost[tok_state[t]]; }
+      o.st_final[so + i] = fin;
+    }
+    for (int i = tid; i < li.out_arcs; i += kPBlock) {
+      const long long l = live_link[i]; const Link k = links[l];
+      int lo = 0, hi = T;                                  // frame f with loff_n[f] <= l < loff_n[f+1]
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (loff_n[mid] <= l) lo = mid; else hi = mid - 1; }
+      const bool emitting = l >= loff_e[lo];
+      const int arc = link_arc[l]; const ArcRec r = p.arcs[arc];
+      o.arc_src[ao + i] = newidx[k.src]; o.arc_dst[ao + i] = newidx[k.dst]; o.arc_il[ao + i] = p.arc_ilabel[arc]; o.arc_ol[ao + i] = r.olabel;
+      o.arc_g[ao + i] = r.w; o.arc_ac[ao + i] = emitting ? (k.ac - st_co[lo]) : (k.ac - 0.0f);
+    }
+    return;
+  }
   if (tid == 0) s_n = 0;
   __syncthreads();
   for (int f = 0; f <= T; f++) {          // frame-major numbering (any per-frame order is a valid GetRawLattice numbering)
@@ -911,9 +942,10 @@ struct k3_decoder {
   int last_utts = 0; std::vector<int> last_frames;
   hipStream_t last_stream = nullptr;
   std::vector<LaneInfo> h_info; bool info_valid = false;
+  void *out_buf = nullptr; size_t out_bytes = 0;
   bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int *d_newidx = nullptr;
-  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+
+  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); if (out_buf) (void)hipFree(out_buf); }
 };
 
 extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
@@ -962,7 +994,10 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &p.prof, nl * 16))) return rc;
   K3_HIP_CHECK(hipMemset(p.prof, 0, nl * 16 * sizeof(long long)));
   if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
-  if ((rc = dmalloc(&d->allocs, &d->d_newidx, nl * cfg->lane_tokens_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.newidx, nl * cfg->lane_tokens_cap))) return rc;
+  p.live_cap = (int)std::min<long long>(cfg->lane_tokens_cap, 1 << 18);
+  if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
+  if ((rc = dmalloc(&d->allocs, &p.live_link, nl * p.live_cap))) return rc;
   // empty table: key = -1, cost = max, tok = -1, stamp = 0
   std::vector<Slot> init((size_t)hs, Slot{kEmpty, kEncMax, -1, 0});
   for (int l = 0; l < nlanes; l++) K3_HIP_CHECK(hipMemcpy(p.hash + (size_t)l * hs, init.data(), sizeof(Slot) * hs, hipMemcpyHostToDevice));
@@ -1060,13 +1095,22 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
   std::vector<long long> so(U + 1, 0), ao(U + 1, 0);
   for (int u = 0; u < U; u++) { const LaneInfo &li = d->h_info[u]; const bool ok = li.status == kStOk; so[u + 1] = so[u] + (ok ? li.out_states : 0); ao[u + 1] = ao[u] + (ok ? li.out_arcs : 0); }
   const size_t NS = (size_t)so[U], NA = (size_t)ao[U];
-  std::vector<void *> tmp; OutParams o{};
-  long long *d_so, *d_ao; int rc;
-  auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
-  if ((rc = dmalloc(&tmp, &d_so, U + 1)) || (rc = dmalloc(&tmp, &d_ao, U + 1)) || (rc = dmalloc(&tmp, &o.st_frame, NS)) || (rc = dmalloc(&tmp, &o.st_state, NS)) ||
-      (rc = dmalloc(&tmp, &o.st_cost, NS)) || (rc = dmalloc(&tmp, &o.st_final, NS)) || (rc = dmalloc(&tmp, &o.arc_src, NA)) || (rc = dmalloc(&tmp, &o.arc_dst, NA)) ||
-      (rc = dmalloc(&tmp, &o.arc_il, NA)) || (rc = dmalloc(&tmp, &o.arc_ol, NA)) || (rc = dmalloc(&tmp, &o.arc_g, NA)) || (rc = dmalloc(&tmp, &o.arc_ac, NA))) { cleanup(); return rc; }
-  o.newidx = d->d_newidx;
+  // one grow-only device staging area: [offsets | 4 state arrays | 6 arc arrays]
+  const size_t need = sizeof(long long) * 2 * (U + 1) + 4 * (4 * NS + 6 * NA) + 256;
+  if (need > d->out_bytes) {
+    if (d->out_buf) (void)hipFree(d->out_buf);
+    d->out_buf = nullptr; d->out_bytes = 0;
+    K3_HIP_CHECK(hipMalloc(&d->out_buf, need + need / 4));
+    d->out_bytes = need + need / 4;
+  }
+  OutParams o{};
+  char *base = (char *)d->out_buf;
+  long long *d_so = (long long *)base, *d_ao = d_so + (U + 1);
+  char *q = (char *)(d_ao + (U + 1));
+  o.st_frame = (int *)q; q += 4 * NS; o.st_state = (int *)q; q += 4 * NS; o.st_cost = (float *)q; q += 4 * NS; o.st_final = (float *)q; q += 4 * NS;
+  o.arc_src = (int *)q; q += 4 * NA; o.arc_dst = (int *)q; q += 4 * NA; o.arc_il = (int *)q; q += 4 * NA; o.arc_ol = (int *)q; q += 4 * NA;
+  o.arc_g = (float *)q; q += 4 * NA; o.arc_ac = (float *)q; q += 4 * NA;
+  auto cleanup = [&]() {};
   o.st_off = d_so; o.arc_off = d_ao;
   hipStream_t st = d->last_stream;
 #define K3_TRY(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { cleanup(); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
