@@ -21,6 +21,7 @@
 #include "k3_nnet_model.h"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -49,7 +50,7 @@ struct GemmParams {
   const float *bias;
   int nops; int op_kind[kMaxOps]; const float *op_scale[kMaxOps]; const float *op_offset[kMaxOps];
   const float *R; long long ldr; int res_row_stride; float res_scale;
-  const TileDesc *tiles; int num_m_tiles, num_n_tiles;
+  const TileDesc *tiles; int num_m_tiles, num_n_tiles; int dbg; long long *dbg_buf;
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
     for (int i = 0; i < B_LOADS; i++) *reinterpret_cast<f32x4 *>(b + (i * 32 + ld_row) * kLdsLd + ld_kv) = rb[i];
   };
 
+  // one k-ordered fma chain per output element over all time offsets (the reference's MKL sgemm also sums k sequentially
+  // inside its K blocks), bias added in the epilogue
   f32x16 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; mi++)
@@ -116,11 +119,14 @@ __global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
       for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.0f;
 
   const int nk = (p.Ktot + kBK - 1) / kBK;
+  long long t0 = 0, t1 = 0, t2 = 0;
+  if (p.dbg & 8) t0 = (long long)__builtin_readcyclecounter();
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
+  if (p.dbg & 8) t1 = (long long)__builtin_readcyclecounter();
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
-  for (int kt = 0; kt < nk; kt++) {
+  for (int kt = 0; kt < ((p.dbg & 4) ? 1 : nk); kt++) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
     const float *a = As + buf * kBM * kLdsLd + (wm * WM + frag_row) * kLdsLd + frag_k;
@@ -144,37 +150,75 @@ __global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if (p.dbg & 8) t2 = (long long)__builtin_readcyclecounter();
+  // ---- epilogue.  The MFMA C/D layout gives a lane 4 consecutive ROWS of one column (col = lane & 31,
+  // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)), i.e. dword stores of 128-byte row pieces: 64 store and 64 residual-load
+  // instructions per lane, which is what the affine layers (K = 192 only) spent 60 % of their time on.  Instead each wavefront
+  // transposes its WM x WN accumulator tile through LDS (the tile buffers are dead by now) and then works on float4 row
+  // pieces: 4x fewer, 4x wider memory instructions, 256-byte runs per row.
+  constexpr int kStLd = WN + 4, C4 = WN / 4, ITERS = WM * C4 / 64;
+  float *stage = reinterpret_cast<float *>(smem) + wave * (WM * kStLd);
 #pragma unroll
-  for (int ni = 0; ni < NI; ni++) {
-    const int col = n0 + wn * WN + ni * 32 + (lane & 31);
-    if (col >= p.N) continue;
-    const float bias = p.bias ? p.bias[col] : 0.0f;
-    float sc[kMaxOps], of[kMaxOps];
+  for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-    for (int o = 0; o < kMaxOps; o++) {
-      sc[o] = 1.0f; of[o] = 0.0f;
-      if (o < p.nops && p.op_kind[o] == k3::kEpiScaleOffset) { sc[o] = p.op_scale[o][col]; of[o] = p.op_offset[o][col]; }
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        stage[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * kStLd + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+  int res_kind = -1;
+#pragma unroll
+  for (int o = 0; o < kMaxOps; o++) if (o < p.nops && p.op_kind[o] == k3::kEpiResidual) res_kind = o;
+  const float *__restrict__ R = p.R; float *__restrict__ C = p.C;
+  const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                      (res_kind < 0 || ((p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0)));
+  f32x4 res[ITERS];
+  if (res_kind >= 0 && vec_ok && !(p.dbg & 1)) {       // all residual row pieces of the tile in flight before the first use
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+      const int idx = it * 64 + lane, row = idx / C4, c4 = idx - row * C4;
+      const int lrow = min(wm * WM + row, td.nrows - 1), col = min(n0 + wn * WN + c4 * 4, p.N - 4);
+      res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + col);
     }
+  }
+  __syncthreads();
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++) {
+  for (int it = 0; it < ITERS; it++) {
+    const int idx = it * 64 + lane, row = idx / C4, c4 = idx - row * C4;
+    const int lrow = wm * WM + row, col = n0 + wn * WN + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * kStLd + c4 * 4);
+    if (col >= p.N || lrow >= td.nrows) continue;
+    if (vec_ok) {
+      if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + col);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int lrow = wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (lrow >= td.nrows) continue;
-        float v = acc[mi][ni][r] + bias;
-#pragma unroll
-        for (int o = 0; o < kMaxOps; o++) {
-          if (o < p.nops) {
-            const int kind = p.op_kind[o];
-            if (kind == k3::kEpiRelu) v = fmaxf(v, 0.0f);
-            else if (kind == k3::kEpiScaleOffset) v = v * sc[o] + of[o];
-            else v = p.res_scale * p.R[(long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + col] + v;
-          }
+      for (int o = 0; o < kMaxOps; o++) {
+        if (o < p.nops) {
+          const int kind = p.op_kind[o];
+          if (kind == k3::kEpiRelu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
+          else if (kind == k3::kEpiScaleOffset) v = v * *reinterpret_cast<const f32x4 *>(p.op_scale[o] + col) + *reinterpret_cast<const f32x4 *>(p.op_offset[o] + col);
+          else v = p.res_scale * res[it] + v;
         }
-        p.C[(long long)(td.out_row0 + lrow) * p.ldc + col] = v;
+      }
+      if (!(p.dbg & 2) || v[0] == 12345.678f) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v;
+    } else {                                           // unaligned / odd-width output: element-wise tail path
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int c = col + e;
+        if (c >= p.N) break;
+        float x = v[e] + (p.bias ? p.bias[c] : 0.0f);
+        for (int o = 0; o < p.nops; o++) {
+          const int kind = p.op_kind[o];
+          if (kind == k3::kEpiRelu) x = fmaxf(x, 0.0f);
+          else if (kind == k3::kEpiScaleOffset) x = x * p.op_scale[o][c] + p.op_offset[o][c];
+          else x = p.res_scale * R[(long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + c] + x;
+        }
+        C[(long long)(td.out_row0 + lrow) * p.ldc + c] = x;
       }
     }
+  }
+  if ((p.dbg & 8) && tid == 0) {
+    const long long t3 = (long long)__builtin_readcyclecounter();
+    atomicAdd((unsigned long long *)&p.dbg_buf[0], (unsigned long long)(t1 - t0)); atomicAdd((unsigned long long *)&p.dbg_buf[1], (unsigned long long)(t2 - t1));
+    atomicAdd((unsigned long long *)&p.dbg_buf[2], (unsigned long long)(t3 - t2)); atomicAdd((unsigned long long *)&p.dbg_buf[3], 1ull);
   }
 }
 
@@ -477,6 +521,19 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
   for (size_t i = 0; i < fm.nodes.size(); i++) {
     GemmParams p = b->params[i];
     if (p.num_m_tiles == 0) continue;
+    { static const int dbg = getenv("K3_GEMM_DBG") ? atoi(getenv("K3_GEMM_DBG")) : 0; p.dbg = dbg;
+      static long long *dbuf = nullptr;
+      if (dbg & 8) {
+        if (!dbuf) { (void)hipMalloc((void **)&dbuf, 64 * 4 * sizeof(long long)); (void)hipMemset(dbuf, 0, 64 * 4 * sizeof(long long)); }
+        p.dbg_buf = dbuf + 4 * (i % 64);
+        if (i + 1 == fm.nodes.size()) {    // dump after the last node was launched (previous forward's numbers + this one's so far)
+          long long h[64 * 4]; (void)hipDeviceSynchronize(); (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+          for (size_t n = 0; n < fm.nodes.size() && n < 64; n++) if (h[4 * n + 3]) fprintf(stderr, "node %zu %-24s blocks %lld  prologue %.0f  mainloop %.0f  epilogue %.0f cycles/block\n", n, fm.nodes[n].name.c_str(), h[4 * n + 3],
+                  (double)h[4 * n] / h[4 * n + 3], (double)h[4 * n + 1] / h[4 * n + 3], (double)h[4 * n + 2] / h[4 * n + 3]);
+          (void)hipMemset(dbuf, 0, sizeof(h));
+        }
+      }
+    }
     const k3::FusedNode &f = fm.nodes[i];
     if (f.input < 0) { p.A = d_feats; p.lda = ld_feats; }
     for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual && op.res_node < 0) { p.R = d_feats; p.ldr = ld_feats; }
