@@ -95,12 +95,15 @@ def _splice(x, offsets):
     lo, hi = -min(offsets), x.shape[0] - 1 - max(offsets)
     return np.concatenate([x[lo + o: hi + o + 1] for o in offsets], axis=1)
 
+# calibration activations are evaluated in float64 and only the statistics are rounded to float32, so that the generated model
+# is bit-identical on every machine (float32 BLAS summation order differs between CPUs; the fixtures depend on the exact model)
 def _bn_from(x):
+    x = np.asarray(x, np.float64)
     return dict(dim=x.shape[1], count=float(x.shape[0]), mean=x.mean(0).astype(np.float32), var=x.var(0).astype(np.float32))
 
 def _bn_apply(x, p, eps=1e-3):
-    scale = (p["var"] + eps) ** -0.5 * p.get("target_rms", 1.0)
-    return ((x - p["mean"]) * scale).astype(np.float32)
+    scale = (p["var"].astype(np.float64) + eps) ** -0.5 * p.get("target_rms", 1.0)
+    return (np.asarray(x, np.float64) - p["mean"].astype(np.float64)) * scale
 
 def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0) + (3,) * 12, prefinal_small=192,
                num_pdfs=6024, bypass_scale=0.75, calib_frames=600, out_std=2.5, calib_feats=None):
@@ -110,7 +113,7 @@ def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0
     rng = np.random.default_rng(seed)
     net = SynthNnet(); L = net.config_lines; C = net.components
     # calibration activations (shrinking as context is consumed); pass real features of the workload when available
-    x = np.asarray(calib_feats, np.float32) if calib_feats is not None else _calib_feats(rng, calib_frames, input_dim)
+    x = np.asarray(calib_feats if calib_feats is not None else _calib_feats(rng, calib_frames, input_dim), np.float64)
     def randn(r, c, std): return (rng.standard_normal((r, c)) * std).astype(np.float32)
     L.append(f"input-node name=input dim={input_dim}")
     # tdnn1: relu-batchnorm-layer input=Append(-1,0,1)
@@ -118,8 +121,8 @@ def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0
     C.append(("tdnn1.affine", "affine", dict(W=W, b=b)))
     L.append("component-node name=tdnn1.affine component=tdnn1.affine input=Append(Offset(input, -1), input, Offset(input, 1))")
     # centre the affine on the calibration input so the random first layer is not saturated by the fbank offset
-    h = _splice(x, (-1, 0, 1)) @ W.T + b
-    b -= h.mean(0).astype(np.float32); h = _splice(x, (-1, 0, 1)) @ W.T + b
+    h = _splice(x, (-1, 0, 1)) @ W.T.astype(np.float64) + b
+    b -= h.mean(0).astype(np.float32); h = _splice(x, (-1, 0, 1)) @ W.T.astype(np.float64) + b
     h = np.maximum(h, 0); C.append(("tdnn1.relu", "relu", dict(dim=dim))); L.append("component-node name=tdnn1.relu component=tdnn1.relu input=tdnn1.affine")
     bn = _bn_from(h); C.append(("tdnn1.batchnorm", "batchnorm", bn)); L.append("component-node name=tdnn1.batchnorm component=tdnn1.batchnorm input=tdnn1.relu")
     h = _bn_apply(h, bn); prev = "tdnn1.batchnorm"
@@ -132,27 +135,27 @@ def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0
         L.append(f"component-node name={n}.linear component={n}.linear input={prev}")
         C.append((f"{n}.affine", "tdnn", dict(offsets=o2, W=W2, b=b2)))
         L.append(f"component-node name={n}.affine component={n}.affine input={n}.linear")
-        z = _splice(h, o1) @ W1.T                         # valid for t = s .. T-1
-        y = np.maximum(_splice(z, o2) @ W2.T + b2, 0)     # valid for t = s .. T-1-s  (relative to h's origin)
+        z = _splice(h, o1) @ W1.T.astype(np.float64)                         # valid for t = s .. T-1
+        y = np.maximum(_splice(z, o2) @ W2.T.astype(np.float64) + b2, 0)     # valid for t = s .. T-1-s  (relative to h's origin)
         C.append((f"{n}.relu", "relu", dict(dim=dim))); L.append(f"component-node name={n}.relu component={n}.relu input={n}.affine")
         bn = _bn_from(y); C.append((f"{n}.batchnorm", "batchnorm", bn)); L.append(f"component-node name={n}.batchnorm component={n}.batchnorm input={n}.relu")
         C.append((f"{n}.noop", "noop", dict(dim=dim)))
         L.append(f"component-node name={n}.noop component={n}.noop input=Sum(Scale({bypass_scale}, {prev}), {n}.batchnorm)")
-        h = (np.float32(bypass_scale) * h[s: h.shape[0] - s] + _bn_apply(y, bn)).astype(np.float32)
+        h = bypass_scale * h[s: h.shape[0] - s] + _bn_apply(y, bn)
         prev = f"{n}.noop"
     # prefinal-l (linear-component), prefinal-chain (prefinal-layer), output (output-layer include-log-softmax=false)
     Wl = randn(prefinal_small, dim, 1.0 / np.sqrt(dim)); C.append(("prefinal-l", "linear", dict(W=Wl)))
     L.append(f"component-node name=prefinal-l component=prefinal-l input={prev}")
-    h = h @ Wl.T
+    h = h @ Wl.T.astype(np.float64)
     Wa = randn(dim, prefinal_small, 1.0 / np.sqrt(prefinal_small)); ba = (rng.standard_normal(dim) * 0.1).astype(np.float32)
     C.append(("prefinal-chain.affine", "affine", dict(W=Wa, b=ba))); L.append("component-node name=prefinal-chain.affine component=prefinal-chain.affine input=prefinal-l")
-    h = np.maximum(h @ Wa.T + ba, 0)
+    h = np.maximum(h @ Wa.T.astype(np.float64) + ba, 0)
     C.append(("prefinal-chain.relu", "relu", dict(dim=dim))); L.append("component-node name=prefinal-chain.relu component=prefinal-chain.relu input=prefinal-chain.affine")
     bn = _bn_from(h); C.append(("prefinal-chain.batchnorm1", "batchnorm", bn)); L.append("component-node name=prefinal-chain.batchnorm1 component=prefinal-chain.batchnorm1 input=prefinal-chain.relu")
     h = _bn_apply(h, bn)
     Wp = randn(prefinal_small, dim, 1.0 / np.sqrt(dim)); C.append(("prefinal-chain.linear", "linear", dict(W=Wp)))
     L.append("component-node name=prefinal-chain.linear component=prefinal-chain.linear input=prefinal-chain.batchnorm1")
-    h = h @ Wp.T
+    h = h @ Wp.T.astype(np.float64)
     bn = _bn_from(h); C.append(("prefinal-chain.batchnorm2", "batchnorm", bn)); L.append("component-node name=prefinal-chain.batchnorm2 component=prefinal-chain.batchnorm2 input=prefinal-chain.linear")
     h = _bn_apply(h, bn)
     Wo = randn(num_pdfs, prefinal_small, out_std / np.sqrt(prefinal_small)); bo = (rng.standard_normal(num_pdfs) * 0.5).astype(np.float32)
@@ -169,8 +172,8 @@ def make_tdnn(seed=1, input_dim=40, dim=512, offsets=((-1, 0, 1), (-1, 0, 1), (-
     for i, offs in enumerate(offsets):
         n = f"tdnn{i + 1}"
         W = (rng.standard_normal((dim, len(offs) * d_in)) / np.sqrt(len(offs) * d_in)).astype(np.float32); b = (rng.standard_normal(dim) * 0.1).astype(np.float32)
-        y = _splice(h, offs) @ W.T + b
-        if i == 0: b -= y.mean(0).astype(np.float32); y = _splice(h, offs) @ W.T + b
+        y = _splice(np.asarray(h, np.float64), offs) @ W.T.astype(np.float64) + b
+        if i == 0: b -= y.mean(0).astype(np.float32); y = _splice(np.asarray(h, np.float64), offs) @ W.T.astype(np.float64) + b
         y = np.maximum(y, 0)
         C.append((f"{n}.affine", "tdnn", dict(offsets=offs, W=W, b=b))); L.append(f"component-node name={n}.affine component={n}.affine input={prev}")
         C.append((f"{n}.relu", "relu", dict(dim=dim))); L.append(f"component-node name={n}.relu component={n}.relu input={n}.affine")
