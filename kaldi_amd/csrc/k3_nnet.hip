@@ -45,6 +45,7 @@ struct TileDesc {      // one per (utterance, 128-row slab) of a node's output
 
 struct GemmParams {
   const float *A; long long lda; int in_dim, noff, row_stride; int shifts[kMaxOffsets];
+  int tiles_per_off, tiles_per_seg;   // k-tiles per time offset (0: offsets are not tile aligned) / per accumulation segment
   const float *W; int ldw, Ktot;
   float *C; long long ldc; int N;
   const float *bias;
@@ -56,7 +57,7 @@ struct GemmParams {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 template <int BN, int WM, int WN>
-__global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p) {
   constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
   constexpr int A_LOADS = kBM * kBK / 4 / kThreads;   // float4 loads per thread per k-tile (4)
   constexpr int B_LOADS = BN * kBK / 4 / kThreads;    // 4 or 3
@@ -100,23 +101,40 @@ __global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
     for (int i = 0; i < B_LOADS; i++)   // W is zero-padded to [Npad x Kpad]: no bounds checks
       rb[i] = *reinterpret_cast<const f32x4 *>(p.W + (long long)(n0 + i * 32 + ld_row) * p.ldw + kglob);
   };
+  // LDS K layout: inside every group of 8 k-values position p holds k = 2 * (p & 3) + (p >> 2), so that the b128 fragment a
+  // lane of half h = lane >> 5 reads (positions 4h .. 4h+3) is k = h, 2+h, 4+h, 6+h and MFMA j (A column k = lane >> 5)
+  // consumes k = 2j, 2j+1: the accumulation runs over k in ASCENDING order, the order a CPU sgemm kernel sums in -- with a
+  // different order every partial sum rounds differently and the result drifts ~5x further from the reference.
+  // A thread holding k..k+3 therefore writes (k, k+2) and (k+1, k+3) as two 8-byte pieces.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int st_col = (ld_kv & ~7) + ((ld_kv >> 2) & 1) * 2;
   auto store_tiles = [&](int buf) {
     float *a = As + buf * kBM * kLdsLd, *b = Bs + buf * BN * kLdsLd;
 #pragma unroll
-    for (int i = 0; i < A_LOADS; i++) *reinterpret_cast<f32x4 *>(a + (i * 32 + ld_row) * kLdsLd + ld_kv) = ra[i];
+    for (int i = 0; i < A_LOADS; i++) {
+      float *q = a + (i * 32 + ld_row) * kLdsLd + st_col;
+      *reinterpret_cast<f32x2 *>(q) = f32x2{ra[i][0], ra[i][2]}; *reinterpret_cast<f32x2 *>(q + 4) = f32x2{ra[i][1], ra[i][3]};
+    }
 #pragma unroll
-    for (int i = 0; i < B_LOADS; i++) *reinterpret_cast<f32x4 *>(b + (i * 32 + ld_row) * kLdsLd + ld_kv) = rb[i];
+    for (int i = 0; i < B_LOADS; i++) {
+      float *q = b + (i * 32 + ld_row) * kLdsLd + st_col;
+      *reinterpret_cast<f32x2 *>(q) = f32x2{rb[i][0], rb[i][2]}; *reinterpret_cast<f32x2 *>(q + 4) = f32x2{rb[i][1], rb[i][3]};
+    }
   };
 
-  // one k-ordered fma chain per output element over all time offsets (the reference's MKL sgemm also sums k sequentially
-  // inside its K blocks), bias added in the epilogue
-  f32x16 acc[MI][NI];
+  // Association mirrors the reference (out = bias; out += in_o . W_o^T per time offset, nnet-tdnn-component.cc:199-207, each
+  // an sgemm that sums k in ascending order inside blocks of K and adds the block into C): `tot` starts at the bias, `acc` is
+  // an ascending-k fma chain over one segment (a time offset, cut every tiles_per_seg k-tiles) added into `tot` at its end.
+  f32x16 acc[MI][NI], tot[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; mi++)
+  for (int ni = 0; ni < NI; ni++) {
+    const int col = n0 + wn * WN + ni * 32 + (lane & 31);
+    const float b0 = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++)
+    for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.0f;
+      for (int r = 0; r < 16; r++) { acc[mi][ni][r] = 0.0f; tot[mi][ni][r] = b0; }
+  }
 
   const int nk = (p.Ktot + kBK - 1) / kBK;
   long long t0 = 0, t1 = 0, t2 = 0;
@@ -146,6 +164,18 @@ __global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
           for (int ni = 0; ni < NI; ni++)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
     }
+    {   // end of an accumulation segment?
+      bool flush = kt + 1 == nk;
+      if (p.tiles_per_off > 0) { const int w = kt % p.tiles_per_off + 1; flush = flush || w == p.tiles_per_off || w % p.tiles_per_seg == 0; }
+      if (flush) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { tot[mi][ni][r] += acc[mi][ni][r]; acc[mi][ni][r] = 0.0f; }
+      }
+    }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
   }
@@ -164,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
       for (int r = 0; r < 16; r++)
-        stage[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * kStLd + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+        stage[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * kStLd + ni * 32 + (lane & 31)] = tot[mi][ni][r];
   int res_kind = -1;
 #pragma unroll
   for (int o = 0; o < kMaxOps; o++) if (o < p.nops && p.op_kind[o] == k3::kEpiResidual) res_kind = o;
@@ -188,7 +218,6 @@ __global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
     f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * kStLd + c4 * 4);
     if (col >= p.N || lrow >= td.nrows) continue;
     if (vec_ok) {
-      if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + col);
 #pragma unroll
       for (int o = 0; o < kMaxOps; o++) {
         if (o < p.nops) {
@@ -204,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void k3_tdnn_gemm_kernel(GemmParams p) {
       for (int e = 0; e < 4; e++) {
         const int c = col + e;
         if (c >= p.N) break;
-        float x = v[e] + (p.bias ? p.bias[c] : 0.0f);
+        float x = v[e];
         for (int o = 0; o < p.nops; o++) {
           const int kind = p.op_kind[o];
           if (kind == k3::kEpiRelu) x = fmaxf(x, 0.0f);
@@ -454,6 +483,7 @@ extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_
       if (num % g_in != 0 || G[i] % g_in != 0) { k3::set_error("k3_nnet_batch_create: internal time-grid error at node %s", f.name.c_str()); return K3_ERR_ARG; }
       p.shifts[o] = num / g_in;
     }
+    p.tiles_per_off = (f.in_dim % kBK == 0) ? f.in_dim / kBK : 0; p.tiles_per_seg = 384 / kBK;
     p.A = src < 0 ? nullptr : slots[slot_of[src]].ptr;       // network input pointer is patched in k3_nnet_forward
     p.lda = src < 0 ? 0 : ld[src];
     p.W = d.W; p.ldw = d.ldw; p.Ktot = p.noff * f.in_dim; p.N = f.out_dim; p.bias = d.bias;
