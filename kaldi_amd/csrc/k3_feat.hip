@@ -41,6 +41,7 @@ struct FeatParams {
   int win_len, win_shift, snip_edges, remove_dc, use_energy, raw_energy, htk_compat, use_log, use_power,
       htk_mode, feature_type, num_bins, num_ceps, dim, has_energy_floor, has_lifter, total_w;
   float preemph, log_energy_floor;
+  float dither; unsigned dither_seed;   // Dither (feat/feature-window.cc:90-98): x[i] += RandGauss() * dither, independently per frame
   const float *window;      // [win_len]
   const float2 *tw256;      // [256] exp(-2 pi i m / 256)
   const float2 *tw512;      // [129] exp(-2 pi i k / 512), k = 0..128, built by the reference's recurrence
@@ -153,6 +154,18 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const f
       x0[j] = a; x1[j] = b;
     }
     // ---- ProcessWindow ----
+    if (p.dither != 0.0f && valid) {     // counter-based generator (frame, sample pair, seed) -> Box-Muller pair; not the reference's rand() stream
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int s = 2 * (l + 16 * j);
+        unsigned long long z = ((unsigned long long)g * 1024ull + (unsigned)(s >> 1)) * 0x9E3779B97F4A7C15ull + ((unsigned long long)p.dither_seed << 32 | 0x7F4A7C15u);
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;          // splitmix64 finaliser
+        const float u1 = ((unsigned)(z >> 40) + 1.0f) * (1.0f / 16777217.0f), u2 = (unsigned)((z >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1)), th = 6.283185307179586f * u2;
+        if (s < L) x0[j] += p.dither * r * cosf(th);
+        if (s + 1 < L) x1[j] += p.dither * r * sinf(th);
+      }
+    }
     if (p.remove_dc) {
       float sum = 0.0f;
 #pragma unroll
@@ -403,10 +416,8 @@ extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out)
                   "frame lengths of 257..512 samples with --round-to-power-of-two=true)", padded, kNfft);
     return K3_ERR_UNSUPPORTED;
   }
-  if (o.dither != 0.0f) {
-    k3::set_error("k3_feat_plan_create: dither != 0 unsupported (parity runs use --dither=0)");
-    return K3_ERR_UNSUPPORTED;
-  }
+  // dither != 0 is supported with a counter-based generator (statistically like the reference's RandGauss, not the same stream:
+  // parity runs use --dither=0)
   K3_REQUIRE(o.num_bins >= 3 && o.num_bins <= 128, "k3_feat_plan_create: need 3 <= num_bins <= 128");
   K3_REQUIRE(o.preemph_coeff >= 0.0f && o.preemph_coeff <= 1.0f, "k3_feat_plan_create: preemph_coeff out of [0,1]");
   if (o.feature_type == 1) K3_REQUIRE(o.num_ceps >= 1 && o.num_ceps <= o.num_bins, "num-ceps cannot be larger than num-mel-bins");
@@ -508,6 +519,7 @@ extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out)
   pl->dim = (o.feature_type == 1) ? o.num_ceps : nb + (o.use_energy ? 1 : 0);
   FeatParams &p = pl->prm;
   p.win_len = L; p.win_shift = shift; p.snip_edges = o.snip_edges; p.remove_dc = o.remove_dc_offset;
+  p.dither = o.dither; p.dither_seed = 0x1234567u;
   p.use_energy = o.use_energy; p.raw_energy = o.raw_energy; p.htk_compat = o.htk_compat; p.use_log = o.use_log_fbank;
   p.use_power = (o.feature_type == 1) ? 1 : o.use_power; p.htk_mode = o.htk_mode; p.feature_type = o.feature_type;
   p.num_bins = nb; p.num_ceps = o.num_ceps; p.dim = pl->dim;

@@ -1,0 +1,158 @@
+// batched-wav-nnet3-cuda2 -- drop-in for cudadecoderbin/batched-wav-nnet3-cuda2.cc:51-260 on MI355X:
+//   batched-wav-nnet3-cuda2 [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>
+// Same positional arguments, same option names (BatchedThreadedNnet3CudaPipeline2Config and its nested configs), same exit codes
+// (1 usage, -1 exception) and the same closing log line "Overall:  Aggregate Total Time: .. Total Audio: .. RealTimeX: ..".
+// The pipeline behind it is the whole-utterance batch path of libk3hip.so: waveforms -> k3_feat_compute_batch -> k3_nnet_forward ->
+// k3_decoder_decode_batch -> raw lattices (fst::Connect'ed, acoustic scores un-scaled, decoder-wrappers.cc:350-373).
+// Lattice determinisation is host work outside this library: --determinize-lattice=true is rejected, not silently ignored.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include "k3_feat_options.h"
+using namespace k3host;
+#define HIPCHK(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) K3H_ERR << "HIP error " << hipGetErrorName(e__) << " in " << #e; } while (0)
+
+int main(int argc, char **argv) {
+  try {
+    const char *usage =
+        "Reads in wav file(s) and decodes them with neural nets\n(nnet3 setup).  Note: some configuration values and inputs are\n"
+        "set via config files whose filenames are passed as options\nOutput is a lattice wspecifier\n"
+        "Usage: batched-wav-nnet3-cuda2 [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
+    ParseOptions po(usage);
+    bool write_lattice = true, segmentation = false, determinize = false, gpu_feat = true, use_online = false, reset_on_endpoint = false, tensor_cores = false, tf32 = false, add_pitch = false, debug_comp = false, cache_mem = true;
+    int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, worker_threads = -1, copy_threads = 2, frames_per_chunk = 50, subsampling = 1;
+    int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, elc = 0, erc = 0, elci = -1, ercf = -1;
+    float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f; double mem_prop = 0.5;
+    std::string word_syms, postproc, feature_type = "mfcc", mfcc_config, fbank_config, plp_config, pitch_config, cmvn_config, global_cmvn, ivector_config, use_gpu = "yes";
+    po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
+    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
+    po.Register("file-limit", &num_todo, "Limits the number of files that are processed by this driver.");
+    po.Register("iterations", &iterations, "Number of times to decode the corpus. Output will be written only once.");
+    po.Register("segmentation", &segmentation, "Split audio files into segments (not supported)");
+    po.Register("lattice-postprocessor-rxfilename", &postproc, "(optional) Config file for lattice postprocessor (not supported)");
+    po.Register("max-batch-size", &max_batch, "The maximum execution batch size (utterances decoded together)");
+    po.Register("num-channels", &num_channels, "(accepted; whole-utterance batching needs no separate channel pool)");
+    po.Register("cuda-worker-threads", &worker_threads, "(accepted; lattice pruning runs on the GPU, no CPU worker pool)");
+    po.Register("cuda-decoder-copy-threads", &copy_threads, "(accepted, unused)");
+    po.Register("determinize-lattice", &determinize, "Determinize the lattice before output (only false is supported: determinization is host work outside this library)");
+    po.Register("gpu-feature-extract", &gpu_feat, "Use GPU feature extraction (always true)"); po.Register("use-online-features", &use_online, "(only false is supported)");
+    po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused: offline decoding)");
+    po.Register("beam", &beam, "Decoding beam. Larger->slower, more accurate."); po.Register("lattice-beam", &lattice_beam, "The width of the lattice beam");
+    po.Register("max-active", &max_active, "Decoder max active states. Larger->slower; more accurate"); po.Register("min-active", &min_active, "Decoder min active states (LatticeFasterDecoderConfig)");
+    po.Register("beam-delta", &beam_delta, "Increment used when the active-state limits move the beam (LatticeFasterDecoderConfig)");
+    po.Register("main-q-capacity", &main_q, "Max tokens alive on one frame of one utterance (-1 = 4 * max-active, capped)"); po.Register("aux-q-capacity", &aux_q, "Max arcs considered on one frame (-1 = 3 * main-q-capacity)");
+    po.Register("ntokens-pre-allocated", &ntok_pre, "Tokens kept per utterance for all frames"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
+    po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
+    po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole, chunking does not change the outputs of a feed-forward model)");
+    po.Register("extra-left-context", &elc, "(accepted; only 0 is supported)"); po.Register("extra-right-context", &erc, "(accepted; only 0 is supported)");
+    po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)"); po.Register("debug-computation", &debug_comp, "(accepted, unused)");
+    po.Register("feature-type", &feature_type, "Base feature type [mfcc, fbank]"); po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc.conf)");
+    po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)"); po.Register("plp-config", &plp_config, "(PLP features are not supported)");
+    po.Register("add-pitch", &add_pitch, "(pitch features are not supported)"); po.Register("online-pitch-config", &pitch_config, "(not supported)");
+    po.Register("cmvn-config", &cmvn_config, "(online CMVN is not supported; chain recipes use --norm-means=false)"); po.Register("global-cmvn-stats", &global_cmvn, "(not supported)");
+    po.Register("ivector-extraction-config", &ivector_config, "(i-vector extraction is not supported)");
+    po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)"); po.Register("cuda-use-tensor-cores", &tensor_cores, "(accepted, unused: FP32 matrix cores are always used)");
+    po.Register("cuda-use-tf32-compute", &tf32, "(accepted, unused: gfx950 has no tf32/xf32)"); po.Register("cuda-cache-memory", &cache_mem, "(accepted, unused)"); po.Register("cuda-memory-proportion", &mem_prop, "(accepted, unused)");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
+    if (determinize) K3H_ERR << "--determinize-lattice=true is not supported: this program writes the raw (state-level) lattice; run lattice-determinize-pruned on its output";
+    if (segmentation || use_online || add_pitch || !ivector_config.empty() || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
+      K3H_ERR << "an option that needs a component outside the accelerated path was given (segmentation / online features / pitch / ivectors / PLP / CMVN / extra context)";
+    const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);
+
+    // feature options come from the config file named for the selected feature type, like OnlineNnet2FeaturePipelineInfo
+    const bool mfcc = feature_type == "mfcc";
+    if (!mfcc && feature_type != "fbank") K3H_ERR << "Invalid feature type: " << feature_type << " (supported: mfcc, fbank)";
+    FeatOptions fo(mfcc);
+    { ParseOptions fpo(""); fo.Register(&fpo); const std::string &cfg = mfcc ? mfcc_config : fbank_config; if (!cfg.empty()) fpo.ReadConfigFile(cfg); }
+    const k3_feat_opts &fopts = fo.Finish();
+    k3_feat_plan *plan = nullptr; K3H_CHECK_K3(k3_feat_plan_create(&fopts, &plan));
+    const int fdim = k3_feat_dim(plan);
+
+    // model: TransitionModel (tid -> pdf) + AmNnetSimple
+    TransitionInfo ti = ReadTransitionModel(nnet3_rx);
+    k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(nnet3_rx.c_str(), &nnet));
+    k3_nnet_info ninfo; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ninfo));
+    if (ninfo.input_dim != fdim) K3H_ERR << "Feature dimension " << fdim << " does not match the model's input dimension " << ninfo.input_dim;
+    if (ninfo.output_dim != ti.num_pdfs) K3H_ERR << "Model output dimension " << ninfo.output_dim << " != number of pdfs in the transition model " << ti.num_pdfs;
+    std::vector<float> log_priors;
+    if (ninfo.has_priors) { log_priors.resize(ninfo.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet, log_priors.data())); for (float &p : log_priors) p = logf(p); }
+
+    // decoding graph
+    HostFst hfst = ReadFstKaldiGeneric(fst_rx);
+    k3_fst *fst = nullptr;
+    K3H_CHECK_K3(k3_fst_create(hfst.NumStates(), hfst.start, hfst.arc_offsets.data(), hfst.ilabel.data(), hfst.olabel.data(), hfst.weight.data(), hfst.nextstate.data(),
+                               hfst.final_cost.data(), ti.id2pdf.data(), (int32_t)ti.id2pdf.size(), &fst));
+    k3_decoder_config dc; k3_decoder_config_default(&dc);
+    dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(min_active, max_active - 1); dc.beam_delta = beam_delta;
+    dc.frame_tokens_cap = main_q > 0 ? main_q : std::min(65536, std::max(4 * max_active, 4096)); dc.frame_cands_cap = aux_q > 0 ? std::max(aux_q, dc.frame_tokens_cap) : 3 * dc.frame_tokens_cap;
+    dc.lane_tokens_cap = std::max<int64_t>(ntok_pre, dc.frame_tokens_cap); dc.lane_links_cap = 2 * dc.lane_tokens_cap;
+    k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, max_batch, ninfo.output_dim, &dec));
+
+    auto scp = ReadScp(wav_rspec);
+    if (num_todo >= 0 && (size_t)num_todo < scp.size()) scp.resize(num_todo);
+    std::unique_ptr<TableWriter> writer; if (write_lattice) writer.reset(new TableWriter(out_wspec));
+    int num_task = 0, num_err = 0; double total_audio = 0.0;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (int iter = 0; iter < iterations; iter++) {
+      for (size_t b0 = 0; b0 < scp.size(); b0 += max_batch) {
+        const size_t b1 = std::min(scp.size(), b0 + (size_t)max_batch);
+        std::vector<std::string> keys; std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int32_t> nframes;
+        for (size_t i = b0; i < b1; i++) {
+          Wave w;
+          try { w = ReadWave(scp[i].second); } catch (const FatalError &) { num_err++; continue; }
+          if (w.samp_freq != fopts.samp_freq) { K3H_WARN << "Sample frequency mismatch for " << scp[i].first; num_err++; continue; }
+          const int nf = k3_feat_num_frames(plan, (int64_t)w.samples.size());
+          if (nf == 0) { K3H_WARN << "Utterance " << scp[i].first << " is too short to decode"; num_err++; continue; }
+          keys.push_back(scp[i].first); all.insert(all.end(), w.samples.begin(), w.samples.end()); woff.push_back((int64_t)all.size()); foff.push_back(foff.back() + nf); nframes.push_back(nf);
+          total_audio += w.samples.size() / (double)w.samp_freq; num_task++;
+        }
+        if (keys.empty()) continue;
+        const int U = (int)keys.size(); const int64_t tot = foff.back();
+        float *d_w, *d_f, *d_ll; int64_t *d_wo, *d_fo;
+        HIPCHK(hipMalloc((void **)&d_w, all.size() * 4)); HIPCHK(hipMalloc((void **)&d_f, (size_t)tot * fdim * 4));
+        HIPCHK(hipMalloc((void **)&d_wo, woff.size() * 8)); HIPCHK(hipMalloc((void **)&d_fo, foff.size() * 8));
+        HIPCHK(hipMemcpy(d_w, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_wo, woff.data(), woff.size() * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_fo, foff.data(), foff.size() * 8, hipMemcpyHostToDevice));
+        K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w, d_wo, d_fo, U, tot, d_f, fdim, nullptr));
+        k3_nnet_batch *nb = nullptr;
+        K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
+        std::vector<int64_t> ro(U + 1); const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
+        HIPCHK(hipMalloc((void **)&d_ll, (size_t)rows * ninfo.output_dim * 4));
+        K3H_CHECK_K3(k3_nnet_forward(nb, d_f, fdim, d_ll, ninfo.output_dim, nullptr));
+        K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_ll, ninfo.output_dim, ro.data(), nullptr));
+        std::vector<int64_t> info(10 * (size_t)U); K3H_CHECK_K3(k3_decoder_lattice_info(dec, info.data()));
+        if (iter == 0 && writer) {
+          int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
+          std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
+          K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));
+          int64_t s0 = 0, a0 = 0;
+          for (int u = 0; u < U; u++) {
+            const int64_t ns = info[10 * u], na = info[10 * u + 1];
+            if (info[10 * u + 2] != 0 || ns == 0) { K3H_WARN << "Failed to decode utterance with id " << keys[u]; num_err++; s0 += ns; a0 += na; continue; }
+            if (!info[10 * u + 3]) K3H_WARN << "Outputting partial output for utterance " << keys[u] << " since no final-state reached";
+            Lattice lat; lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns); lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
+            lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na); lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na); lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
+            lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
+            for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
+            Connect(&lat);
+            if (acoustic_scale != 0.0f) ScaleAcoustic(&lat, 1.0 / acoustic_scale);      // "We'll write the lattice without acoustic scaling"
+            writer->WriteLattice(keys[u], lat);
+            s0 += ns; a0 += na;
+          }
+        }
+        k3_nnet_batch_destroy(nb);
+        HIPCHK(hipFree(d_w)); HIPCHK(hipFree(d_f)); HIPCHK(hipFree(d_wo)); HIPCHK(hipFree(d_fo)); HIPCHK(hipFree(d_ll));
+      }
+    }
+    HIPCHK(hipDeviceSynchronize());
+    if (writer) writer->Flush();
+    const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
+    K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio << " RealTimeX: " << total_audio / total_time;
+    k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan);
+    return 0;
+  } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
+}

@@ -1,0 +1,28 @@
+// k3-host-tool -- developer/test aid for the host-side format readers (no GPU needed):
+//   k3-host-tool tid2pdf <model.mdl>          NumPdfs, NumTransitionIds, then TransitionIdToPdf(1..N)  (same output as oracle's dump-tid2pdf)
+//   k3-host-tool fstinfo <fst>                states arcs start, FNV-1a checksum of the CSR
+//   k3-host-tool copy-fst <fst-in> <fst-out>  read (vector|const) and write as vector
+#include <iostream>
+#include "k3_host.h"
+using namespace k3host;
+int main(int argc, char **argv) {
+  try {
+    g_program = "k3-host-tool";
+    const std::string cmd = argc > 1 ? argv[1] : "";
+    if (cmd == "tid2pdf" && argc == 3) {
+      TransitionInfo ti = ReadTransitionModel(argv[2]);
+      std::cout << ti.num_pdfs << " " << ti.id2pdf.size() - 1 << "\n";
+      for (size_t t = 1; t < ti.id2pdf.size(); t++) std::cout << ti.id2pdf[t] << (t % 32 ? " " : "\n");
+      std::cout << "\n"; return 0;
+    }
+    if (cmd == "fstinfo" && argc == 3) {
+      HostFst f = ReadFstKaldiGeneric(argv[2]);
+      uint64_t h = 1469598103934665603ull; auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+      mix(f.arc_offsets.data(), 4 * f.arc_offsets.size()); mix(f.ilabel.data(), 4 * f.ilabel.size()); mix(f.olabel.data(), 4 * f.olabel.size());
+      mix(f.weight.data(), 4 * f.weight.size()); mix(f.nextstate.data(), 4 * f.nextstate.size()); mix(f.final_cost.data(), 4 * f.final_cost.size());
+      std::cout << f.NumStates() << " " << f.ilabel.size() << " " << f.start << " " << h << "\n"; return 0;
+    }
+    if (cmd == "copy-fst" && argc == 4) { WriteFstVector(ReadFstKaldiGeneric(argv[2]), argv[3]); return 0; }
+    std::cerr << "usage: k3-host-tool tid2pdf <mdl> | fstinfo <fst> | copy-fst <in> <out>\n"; return 1;
+  } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
+}

@@ -1,0 +1,453 @@
+// k3_host.cc -- see k3_host.h.  Formats are restated from the reference's readers/writers (cited per function); OpenFst's
+// binary container is restated from its documented layout (FstHeader + vector/const bodies) and is exercised against
+// kaldi_amd/fst.py's writer only, because OpenFst itself is not available here.
+#include "k3_host.h"
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <limits>
+
+namespace k3host {
+
+std::string g_program = "k3";
+int g_verbose = 0;
+
+LogLine::LogLine(const char *severity, const char *func, const char *file, int line, bool is_fatal) : sev(severity), fatal(is_fatal) {
+  const char *base = strrchr(file, '/');
+  ss << severity << " (" << g_program << "[k3hip]:" << func << "():" << (base ? base + 1 : file) << ":" << line << ") ";
+}
+LogLine::~LogLine() noexcept(false) {
+  std::cerr << ss.str() << "\n";
+  if (fatal) throw FatalError(ss.str());
+}
+
+// ------------------------------------------------------------------------------------------------ ParseOptions ----
+ParseOptions::ParseOptions(const char *usage) : usage_(usage) {}
+std::string ParseOptions::Normalize(const std::string &n) { std::string r = n; for (char &c : r) { if (c == '_') c = '-'; c = (char)tolower(c); } return r; }
+void ParseOptions::RegisterImpl(const std::string &name, Kind k, void *p, const std::string &doc, const std::string &def) {
+  opts_[Normalize(name)] = Opt{k, p, doc, def};
+}
+void ParseOptions::Register(const std::string &n, bool *p, const std::string &d) { RegisterImpl(n, kBool, p, d, *p ? "true" : "false"); }
+void ParseOptions::Register(const std::string &n, int32_t *p, const std::string &d) { RegisterImpl(n, kInt, p, d, std::to_string(*p)); }
+void ParseOptions::Register(const std::string &n, float *p, const std::string &d) { std::ostringstream o; o << *p; RegisterImpl(n, kFloat, p, d, o.str()); }
+void ParseOptions::Register(const std::string &n, double *p, const std::string &d) { std::ostringstream o; o << *p; RegisterImpl(n, kDouble, p, d, o.str()); }
+void ParseOptions::Register(const std::string &n, std::string *p, const std::string &d) { RegisterImpl(n, kString, p, d, *p); }
+
+bool ParseOptions::SetOption(const std::string &key_in, const std::string &value, bool has_value) {
+  const std::string key = Normalize(key_in);
+  auto it = opts_.find(key);
+  if (it == opts_.end()) return false;
+  Opt &o = it->second; char *end = nullptr; errno = 0;
+  switch (o.kind) {
+    case kBool: {
+      std::string v = value; for (char &c : v) c = (char)tolower(c);
+      if (!has_value || v == "true" || v == "t" || v == "1" || v.empty()) *(bool *)o.ptr = true;
+      else if (v == "false" || v == "f" || v == "0") *(bool *)o.ptr = false;
+      else K3H_ERR << "Invalid format for boolean argument [expected true or false]: --" << key << "=" << value;
+      break;
+    }
+    case kInt: { long v = strtol(value.c_str(), &end, 10); if (!has_value || value.empty() || *end || errno) K3H_ERR << "Invalid integer option \"" << value << "\" for --" << key; *(int32_t *)o.ptr = (int32_t)v; break; }
+    case kFloat: { double v = strtod(value.c_str(), &end); if (!has_value || value.empty() || *end) K3H_ERR << "Invalid floating-point option \"" << value << "\" for --" << key; *(float *)o.ptr = (float)v; break; }
+    case kDouble: { double v = strtod(value.c_str(), &end); if (!has_value || value.empty() || *end) K3H_ERR << "Invalid floating-point option \"" << value << "\" for --" << key; *(double *)o.ptr = v; break; }
+    case kString: *(std::string *)o.ptr = value; break;
+  }
+  set_[key] = 1;
+  return true;
+}
+
+void ParseOptions::ReadConfigFile(const std::string &path) {          // util/parse-options.cc:434-490: one --opt=value per line, # comments
+  const std::string txt = ReadWholeInput(path);
+  std::istringstream is(txt); std::string line; int ln = 0;
+  while (std::getline(is, line)) {
+    ln++;
+    const size_t h = line.find('#'); if (h != std::string::npos) line.erase(h);
+    const size_t b = line.find_first_not_of(" \t\r"); if (b == std::string::npos) continue;
+    line = line.substr(b, line.find_last_not_of(" \t\r") - b + 1);
+    if (line.compare(0, 2, "--") != 0) K3H_ERR << "Reading config file " << path << ": line " << ln << " does not look like a line from a Kaldi command-line program's config file: should be of the form --x=y.";
+    const size_t eq = line.find('=');
+    const std::string key = line.substr(2, eq == std::string::npos ? std::string::npos : eq - 2), val = eq == std::string::npos ? "" : line.substr(eq + 1);
+    if (!SetOption(key, val, eq != std::string::npos)) K3H_ERR << "Invalid option " << line << " in config file " << path;
+  }
+}
+
+int ParseOptions::Read(int argc, const char *const *argv) {
+  argv_.assign(argv, argv + argc);
+  if (argc > 0) { const char *b = strrchr(argv[0], '/'); g_program = b ? b + 1 : argv[0]; }
+  std::string config; Register("config", &config, "Configuration file to read (this option may be repeated)");
+  bool help = false, print_args = true; Register("help", &help, "Print out usage message"); Register("print-args", &print_args, "Print the command line arguments (to stderr)");
+  Register("verbose", &g_verbose, "Verbose level (higher->more logging)");
+  int i = 1;
+  for (; i < argc; i++) {
+    const std::string a = argv[i];
+    if (a == "--") { i++; break; }
+    if (a.compare(0, 2, "--") != 0) break;
+    const size_t eq = a.find('=');
+    const std::string key = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2), val = eq == std::string::npos ? "" : a.substr(eq + 1);
+    if (!SetOption(key, val, eq != std::string::npos)) { PrintUsage(true); K3H_ERR << "Invalid option " << a; }
+    if (Normalize(key) == "config") ReadConfigFile(config);
+    if (help) { PrintUsage(); exit(0); }
+  }
+  for (; i < argc; i++) args_.push_back(argv[i]);
+  if (print_args) { std::ostringstream o; for (int k = 0; k < argc; k++) o << argv[k] << " "; std::cerr << o.str() << "\n"; }
+  return i;
+}
+const std::string &ParseOptions::GetArg(int i) const {
+  if (i < 1 || i > (int)args_.size()) K3H_ERR << "ParseOptions::GetArg, invalid index " << i;
+  return args_[i - 1];
+}
+void ParseOptions::PrintUsage(bool print_command_line) const {
+  std::cerr << "\n" << usage_ << "\nOptions:\n";
+  for (auto &kv : opts_) std::cerr << "  --" << kv.first << " : " << kv.second.doc << " (default = " << kv.second.default_str << ")\n";
+  if (print_command_line) { std::cerr << "Command line was: "; for (auto &a : argv_) std::cerr << a << " "; std::cerr << "\n"; }
+}
+
+// ------------------------------------------------------------------------------------------------ streams ----
+static std::string Trim(const std::string &s) { const size_t b = s.find_first_not_of(" \t\r\n"); if (b == std::string::npos) return ""; return s.substr(b, s.find_last_not_of(" \t\r\n") - b + 1); }
+std::shared_ptr<FILE> OpenInput(const std::string &rx_in) {
+  const std::string rx = Trim(rx_in);
+  if (rx.empty()) K3H_ERR << "empty rxfilename";
+  if (rx == "-") return std::shared_ptr<FILE>(stdin, [](FILE *) {});
+  if (rx.back() == '|') {
+    FILE *f = popen(rx.substr(0, rx.size() - 1).c_str(), "r");
+    if (!f) K3H_ERR << "Failed opening pipe for reading, command is: " << rx;
+    return std::shared_ptr<FILE>(f, [](FILE *p) { pclose(p); });
+  }
+  FILE *f = fopen(rx.c_str(), "rb");
+  if (!f) K3H_ERR << "Failed to open input file " << rx << ": " << strerror(errno);
+  return std::shared_ptr<FILE>(f, [](FILE *p) { fclose(p); });
+}
+std::shared_ptr<FILE> OpenOutput(const std::string &wx_in) {
+  const std::string wx = Trim(wx_in);
+  if (wx.empty() || wx == "-") return std::shared_ptr<FILE>(stdout, [](FILE *p) { fflush(p); });
+  if (wx[0] == '|') {
+    FILE *f = popen(wx.substr(1).c_str(), "w");
+    if (!f) K3H_ERR << "Failed opening pipe for writing, command is: " << wx;
+    return std::shared_ptr<FILE>(f, [](FILE *p) { pclose(p); });
+  }
+  FILE *f = fopen(wx.c_str(), "wb");
+  if (!f) K3H_ERR << "Failed to open output file " << wx << ": " << strerror(errno);
+  return std::shared_ptr<FILE>(f, [](FILE *p) { fclose(p); });
+}
+std::string ReadWholeInput(const std::string &rx) {
+  auto f = OpenInput(rx); std::string out; char buf[1 << 16]; size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f.get())) > 0) out.append(buf, n);
+  return out;
+}
+
+std::vector<std::pair<std::string, std::string>> ReadScp(const std::string &rspecifier) {
+  const size_t colon = rspecifier.find(':');
+  if (colon == std::string::npos || rspecifier.compare(0, 3, "scp") != 0)
+    K3H_ERR << "Invalid rspecifier " << rspecifier << " (this program reads script files: scp:<file>)";
+  const std::string txt = ReadWholeInput(rspecifier.substr(colon + 1));
+  std::vector<std::pair<std::string, std::string>> out; std::istringstream is(txt); std::string line;
+  while (std::getline(is, line)) {
+    line = Trim(line); if (line.empty()) continue;
+    const size_t sp = line.find_first_of(" \t");
+    if (sp == std::string::npos) K3H_ERR << "Invalid line in script file: " << line;
+    out.push_back({line.substr(0, sp), Trim(line.substr(sp + 1))});
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------ wave ----
+Wave ReadWave(const std::string &rxfilename) {      // feat/wave-reader.cc:113-330 (PCM, 16 bit; channel 0 is returned)
+  const std::string b = ReadWholeInput(rxfilename);
+  auto u32 = [&](size_t p) { uint32_t v; memcpy(&v, b.data() + p, 4); return v; };
+  auto u16 = [&](size_t p) { uint16_t v; memcpy(&v, b.data() + p, 2); return v; };
+  if (b.size() < 44 || b.compare(0, 4, "RIFF") != 0 || b.compare(8, 4, "WAVE") != 0) K3H_ERR << "WaveData: expected RIFF/WAVE header in " << rxfilename;
+  size_t pos = 12; int channels = 0, bits = 0; Wave w;
+  while (pos + 8 <= b.size()) {
+    const std::string id = b.substr(pos, 4); const uint32_t sz = u32(pos + 4);
+    if (id == "fmt ") {
+      if (u16(pos + 8) != 1) K3H_ERR << "WaveData: can read only PCM data, audio_format is not 1 in " << rxfilename;
+      channels = u16(pos + 10); w.samp_freq = (float)u32(pos + 12); bits = u16(pos + 22);
+      if (bits != 16 || channels < 1) K3H_ERR << "WaveData: unsupported bits_per_sample / channels = " << bits << " / " << channels;
+    } else if (id == "data") {
+      if (!channels) K3H_ERR << "WaveData: data chunk before fmt chunk in " << rxfilename;
+      size_t n = std::min<size_t>(sz == 0xFFFFFFFFu || sz == 0 ? b.size() - pos - 8 : sz, b.size() - pos - 8) / (2 * channels);
+      w.samples.resize(n);
+      const int16_t *s = reinterpret_cast<const int16_t *>(b.data() + pos + 8);
+      for (size_t i = 0; i < n; i++) { int16_t v; memcpy(&v, s + i * channels, 2); w.samples[i] = (float)v; }
+      return w;
+    }
+    pos += 8 + sz + (sz & 1);
+  }
+  K3H_ERR << "WaveData: no data chunk in " << rxfilename;
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------------ Kaldi basic IO ----
+namespace {
+struct In {          // in-memory reader for Kaldi's text/binary object format (base/io-funcs-inl.h)
+  const std::string &b; size_t p = 0; bool binary = false;
+  explicit In(const std::string &buf) : b(buf) { if (b.size() >= 2 && b[0] == '\0' && b[1] == 'B') { binary = true; p = 2; } }
+  void SkipWs() { while (p < b.size() && isspace((unsigned char)b[p])) p++; }
+  std::string Token() {
+    SkipWs(); const size_t s = p;
+    while (p < b.size() && !isspace((unsigned char)b[p])) p++;
+    if (p == s) K3H_ERR << "unexpected end of file while reading a token";
+    std::string t = b.substr(s, p - s);
+    if (binary && p < b.size()) p++;          // the single space after a token
+    return t;
+  }
+  void Expect(const char *tok) { const std::string t = Token(); if (t != tok) K3H_ERR << "Expected token " << tok << ", got " << t; }
+  template <class T> T Basic() {
+    if (binary) {
+      if (p + 1 + sizeof(T) > b.size()) K3H_ERR << "unexpected end of file";
+      const int sz = (signed char)b[p];
+      if (sz != (int)sizeof(T)) K3H_ERR << "ReadBasicType: did not get expected integer type, " << sz << " vs. " << sizeof(T);
+      T v; memcpy(&v, b.data() + p + 1, sizeof(T)); p += 1 + sizeof(T); return v;
+    }
+    const std::string t = Token(); char *e = nullptr;
+    const double d = strtod(t.c_str(), &e);
+    if (*e) K3H_ERR << "ReadBasicType: could not parse \"" << t << "\"";
+    return (T)d;
+  }
+  std::vector<int32_t> IntVector() {
+    std::vector<int32_t> v;
+    if (binary) {
+      const int sz = (signed char)b[p]; if (sz != 4) K3H_ERR << "ReadIntegerVector: expected 4-byte integers, got " << sz;
+      int32_t n; memcpy(&n, b.data() + p + 1, 4); p += 5;
+      v.resize(n); if (n) memcpy(v.data(), b.data() + p, 4 * (size_t)n); p += 4 * (size_t)n;
+    } else {
+      Expect("["); for (std::string t = Token(); t != "]"; t = Token()) v.push_back(atoi(t.c_str()));
+    }
+    return v;
+  }
+  std::vector<float> FloatVector() {
+    std::vector<float> v;
+    if (binary) {
+      const std::string t = Token();
+      if (t != "FV" && t != "DV") K3H_ERR << "expected a vector (FV/DV), got " << t;
+      const int32_t n = Basic<int32_t>(); v.resize(n);
+      if (t == "FV") { if (n) memcpy(v.data(), b.data() + p, 4 * (size_t)n); p += 4 * (size_t)n; }
+      else { for (int32_t i = 0; i < n; i++) { double d; memcpy(&d, b.data() + p + 8 * (size_t)i, 8); v[i] = (float)d; } p += 8 * (size_t)n; }
+    } else {
+      Expect("["); for (std::string t = Token(); t != "]"; t = Token()) v.push_back((float)atof(t.c_str()));
+    }
+    return v;
+  }
+};
+struct HmmState { int32_t fwd_pdf_class = -1, self_pdf_class = -1; std::vector<std::pair<int32_t, float>> trans; };
+}  // namespace
+
+TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename) {
+  const std::string buf = ReadWholeInput(mdl_rxfilename);
+  In in(buf);
+  in.Expect("<TransitionModel>"); in.Expect("<Topology>");
+  std::vector<int32_t> phone2idx; std::vector<std::vector<HmmState>> entries;
+  if (!in.binary) {                                                       // hmm-topology.cc:33-118
+    for (std::string t = in.Token(); t != "</Topology>"; t = in.Token()) {
+      if (t != "<TopologyEntry>") K3H_ERR << "Reading HmmTopology object, expected </Topology> or <TopologyEntry>, got " << t;
+      in.Expect("<ForPhones>"); std::vector<int32_t> phones;
+      for (std::string s = in.Token(); s != "</ForPhones>"; s = in.Token()) phones.push_back(atoi(s.c_str()));
+      std::vector<HmmState> entry;
+      std::string tok = in.Token();
+      while (tok != "</TopologyEntry>") {
+        if (tok != "<State>") K3H_ERR << "Expected </TopologyEntry> or <State>, got instead " << tok;
+        const int32_t st = in.Basic<int32_t>();
+        if (st != (int32_t)entry.size()) K3H_ERR << "States are expected to be in order from zero";
+        HmmState hs; tok = in.Token();
+        if (tok == "<PdfClass>") { hs.fwd_pdf_class = hs.self_pdf_class = in.Basic<int32_t>(); tok = in.Token(); }
+        else if (tok == "<ForwardPdfClass>") { hs.fwd_pdf_class = in.Basic<int32_t>(); in.Expect("<SelfLoopPdfClass>"); hs.self_pdf_class = in.Basic<int32_t>(); tok = in.Token(); }
+        while (tok == "<Transition>") { const int32_t d = in.Basic<int32_t>(); const float pr = in.Basic<float>(); hs.trans.push_back({d, pr}); tok = in.Token(); }
+        if (tok != "</State>") K3H_ERR << "Expected </State>, got instead " << tok;
+        entry.push_back(hs); tok = in.Token();
+      }
+      for (int32_t ph : phones) { if ((int32_t)phone2idx.size() <= ph) phone2idx.resize(ph + 1, -1); phone2idx[ph] = (int32_t)entries.size(); }
+      entries.push_back(entry);
+    }
+  } else {                                                                // hmm-topology.cc:119-152
+    (void)in.IntVector(); phone2idx = in.IntVector();
+    int32_t sz = in.Basic<int32_t>(); bool is_hmm = true;
+    if (sz == -1) { is_hmm = false; sz = in.Basic<int32_t>(); }
+    entries.resize(sz);
+    for (auto &e : entries) {
+      e.resize(in.Basic<int32_t>());
+      for (auto &hs : e) {
+        hs.fwd_pdf_class = in.Basic<int32_t>(); hs.self_pdf_class = is_hmm ? hs.fwd_pdf_class : in.Basic<int32_t>();
+        hs.trans.resize(in.Basic<int32_t>());
+        for (auto &tr : hs.trans) { tr.first = in.Basic<int32_t>(); tr.second = in.Basic<float>(); }
+      }
+    }
+    in.Expect("</Topology>");
+  }
+  const std::string tok = in.Token();                                    // transition-model.cc:229-243
+  if (tok != "<Triples>" && tok != "<Tuples>") K3H_ERR << "TransitionModel: expected <Triples> or <Tuples>, got " << tok;
+  const int32_t n = in.Basic<int32_t>();
+  TransitionInfo ti; ti.id2pdf.assign(1, 0);
+  for (int32_t i = 0; i < n; i++) {                                       // ComputeDerived (:90-124): transition-ids in tuple order
+    const int32_t phone = in.Basic<int32_t>(), hs = in.Basic<int32_t>(), fpdf = in.Basic<int32_t>();
+    const int32_t spdf = tok == "<Tuples>" ? in.Basic<int32_t>() : fpdf;
+    if (phone <= 0 || phone >= (int32_t)phone2idx.size() || phone2idx[phone] < 0) K3H_ERR << "TransitionModel: phone " << phone << " has no topology entry";
+    const auto &entry = entries[phone2idx[phone]];
+    if (hs < 0 || hs >= (int32_t)entry.size()) K3H_ERR << "TransitionModel: bad hmm-state " << hs;
+    for (const auto &tr : entry[hs].trans) ti.id2pdf.push_back(tr.first == hs ? spdf : fpdf);     // IsSelfLoop
+    ti.num_pdfs = std::max(ti.num_pdfs, 1 + std::max(fpdf, spdf));
+  }
+  const std::string endtok = in.Token();
+  if (endtok != "</Triples>" && endtok != "</Tuples>") K3H_ERR << "TransitionModel: expected </Triples> or </Tuples>, got " << endtok;
+  in.Expect("<LogProbs>");
+  const std::vector<float> lp = in.FloatVector();
+  if (lp.size() != ti.id2pdf.size()) K3H_ERR << "TransitionModel: " << lp.size() - 1 << " log-probs for " << ti.id2pdf.size() - 1 << " transition-ids";
+  in.Expect("</LogProbs>"); in.Expect("</TransitionModel>");
+  return ti;
+}
+
+// ------------------------------------------------------------------------------------------------ OpenFst binary ----
+namespace {
+const int32_t kFstMagic = 2125659606;
+struct Bin {
+  const std::string &b; size_t p = 0;
+  explicit Bin(const std::string &buf) : b(buf) {}
+  template <class T> T Get() { if (p + sizeof(T) > b.size()) K3H_ERR << "unexpected end of FST file"; T v; memcpy(&v, b.data() + p, sizeof(T)); p += sizeof(T); return v; }
+  std::string Str() { const int32_t n = Get<int32_t>(); if (n < 0 || p + n > b.size()) K3H_ERR << "corrupt FST header"; std::string s = b.substr(p, n); p += n; return s; }
+  void Align(size_t a) { p = (p + a - 1) / a * a; }
+};
+void PutStr(std::string *o, const std::string &s) { const int32_t n = (int32_t)s.size(); o->append((const char *)&n, 4); o->append(s); }
+template <class T> void Put(std::string *o, T v) { o->append((const char *)&v, sizeof(T)); }
+}  // namespace
+
+HostFst ReadFstKaldiGeneric(const std::string &rxfilename) {
+  const std::string buf = ReadWholeInput(rxfilename);
+  Bin in(buf);
+  if (in.Get<int32_t>() != kFstMagic) K3H_ERR << "Reading FST: error reading FST header from " << rxfilename << " (text FSTs are not supported: compile it with fstcompile)";
+  const std::string ftype = in.Str(), atype = in.Str();
+  const int32_t version = in.Get<int32_t>(), flags = in.Get<int32_t>(); (void)in.Get<uint64_t>();
+  const int64_t start = in.Get<int64_t>(), ns = in.Get<int64_t>(), na = in.Get<int64_t>();
+  if (atype != "standard") K3H_ERR << "FST with arc type " << atype << " is not supported.";
+  if (flags & 3) K3H_ERR << "FST files with embedded symbol tables are not supported (write it with --keep_isymbols=false --keep_osymbols=false)";
+  HostFst f; f.start = (int32_t)start;
+  if (ftype == "vector") {
+    f.arc_offsets.push_back(0);
+    for (int64_t s = 0; s < ns; s++) {
+      f.final_cost.push_back(in.Get<float>());
+      const int64_t n = in.Get<int64_t>();
+      for (int64_t a = 0; a < n; a++) { f.ilabel.push_back(in.Get<int32_t>()); f.olabel.push_back(in.Get<int32_t>()); f.weight.push_back(in.Get<float>()); f.nextstate.push_back(in.Get<int32_t>()); }
+      f.arc_offsets.push_back((int32_t)f.ilabel.size());
+    }
+  } else if (ftype == "const") {                     // ConstFst<StdArc, uint32>: states {final, pos, narcs, niepsilons, noepsilons} then arcs
+    const bool aligned = (flags & 4) != 0 || version == 1;
+    if (aligned) in.Align(16);
+    std::vector<uint32_t> pos(ns), cnt(ns);
+    for (int64_t s = 0; s < ns; s++) { f.final_cost.push_back(in.Get<float>()); pos[s] = in.Get<uint32_t>(); cnt[s] = in.Get<uint32_t>(); (void)in.Get<uint32_t>(); (void)in.Get<uint32_t>(); }
+    if (aligned) in.Align(16);
+    const size_t arcs0 = in.p;
+    f.arc_offsets.push_back(0);
+    for (int64_t s = 0; s < ns; s++) {
+      in.p = arcs0 + 16 * (size_t)pos[s];
+      for (uint32_t a = 0; a < cnt[s]; a++) { f.ilabel.push_back(in.Get<int32_t>()); f.olabel.push_back(in.Get<int32_t>()); f.weight.push_back(in.Get<float>()); f.nextstate.push_back(in.Get<int32_t>()); }
+      f.arc_offsets.push_back((int32_t)f.ilabel.size());
+    }
+  } else K3H_ERR << "Reading FST: unsupported FST type: " << ftype;
+  if ((int64_t)f.ilabel.size() != na && ftype == "const") K3H_ERR << "FST arc count mismatch";
+  if (f.start < 0 || f.start >= f.NumStates()) K3H_ERR << "FST has no start state";
+  return f;
+}
+
+void WriteFstVector(const HostFst &f, const std::string &wxfilename) {
+  std::string o; Put(&o, kFstMagic); PutStr(&o, "vector"); PutStr(&o, "standard");
+  Put<int32_t>(&o, 2); Put<int32_t>(&o, 0); Put<uint64_t>(&o, 3); Put<int64_t>(&o, f.start); Put<int64_t>(&o, f.NumStates()); Put<int64_t>(&o, (int64_t)f.ilabel.size());
+  for (int32_t s = 0; s < f.NumStates(); s++) {
+    Put(&o, f.final_cost[s]); Put<int64_t>(&o, f.arc_offsets[s + 1] - f.arc_offsets[s]);
+    for (int32_t a = f.arc_offsets[s]; a < f.arc_offsets[s + 1]; a++) { Put(&o, f.ilabel[a]); Put(&o, f.olabel[a]); Put(&o, f.weight[a]); Put(&o, f.nextstate[a]); }
+  }
+  auto out = OpenOutput(wxfilename); fwrite(o.data(), 1, o.size(), out.get());
+}
+
+// ------------------------------------------------------------------------------------------------ lattices ----
+void Connect(Lattice *lat) {
+  const int32_t n = lat->NumStates(); const size_t na = lat->arc_src.size();
+  if (n == 0) return;
+  std::vector<int32_t> foff(n + 1, 0), roff(n + 1, 0);
+  for (size_t a = 0; a < na; a++) { foff[lat->arc_src[a] + 1]++; roff[lat->arc_dst[a] + 1]++; }
+  for (int32_t s = 0; s < n; s++) { foff[s + 1] += foff[s]; roff[s + 1] += roff[s]; }
+  std::vector<int32_t> fadj(na), radj(na), fp(foff.begin(), foff.end() - 1), rp(roff.begin(), roff.end() - 1);
+  for (size_t a = 0; a < na; a++) { fadj[fp[lat->arc_src[a]]++] = lat->arc_dst[a]; radj[rp[lat->arc_dst[a]]++] = lat->arc_src[a]; }
+  std::vector<char> acc(n, 0), co(n, 0); std::vector<int32_t> st;
+  if (lat->start >= 0) { acc[lat->start] = 1; st.push_back(lat->start); }
+  while (!st.empty()) { const int32_t s = st.back(); st.pop_back(); for (int32_t k = foff[s]; k < foff[s + 1]; k++) if (!acc[fadj[k]]) { acc[fadj[k]] = 1; st.push_back(fadj[k]); } }
+  for (int32_t s = 0; s < n; s++) if (std::isfinite(lat->st_final[s])) { co[s] = 1; st.push_back(s); }
+  while (!st.empty()) { const int32_t s = st.back(); st.pop_back(); for (int32_t k = roff[s]; k < roff[s + 1]; k++) if (!co[radj[k]]) { co[radj[k]] = 1; st.push_back(radj[k]); } }
+  std::vector<int32_t> newid(n, -1); int32_t m = 0;
+  if (lat->start >= 0 && acc[lat->start] && co[lat->start]) newid[lat->start] = m++;     // start state first (state 0), like GetRawLattice
+  for (int32_t s = 0; s < n; s++) if (newid[s] < 0 && acc[s] && co[s]) newid[s] = m++;
+  Lattice o; o.st_frame.resize(m); o.st_state.resize(m); o.st_final.resize(m); o.start = m ? 0 : -1;
+  for (int32_t s = 0; s < n; s++) if (newid[s] >= 0) { o.st_frame[newid[s]] = lat->st_frame[s]; o.st_state[newid[s]] = lat->st_state[s]; o.st_final[newid[s]] = lat->st_final[s]; }
+  for (size_t a = 0; a < na; a++) {
+    const int32_t s = newid[lat->arc_src[a]], d = newid[lat->arc_dst[a]];
+    if (s < 0 || d < 0) continue;
+    o.arc_src.push_back(s); o.arc_dst.push_back(d); o.arc_ilabel.push_back(lat->arc_ilabel[a]); o.arc_olabel.push_back(lat->arc_olabel[a]);
+    o.arc_graph.push_back(lat->arc_graph[a]); o.arc_ac.push_back(lat->arc_ac[a]);
+  }
+  *lat = std::move(o);
+}
+void ScaleAcoustic(Lattice *lat, double scale) { for (float &a : lat->arc_ac) a = (float)(a * scale); }
+
+TableWriter::TableWriter(const std::string &wspecifier) {
+  const size_t colon = wspecifier.find(':');
+  if (colon == std::string::npos || wspecifier.compare(0, 3, "ark") != 0) K3H_ERR << "Invalid wspecifier " << wspecifier << " (supported: ark:<wxfilename>, ark,t:<wxfilename>)";
+  const std::string opts = wspecifier.substr(0, colon);
+  if (opts.find("scp") != std::string::npos) K3H_ERR << "wspecifier " << wspecifier << ": ark,scp output is not supported by this program";
+  binary_ = opts.find(",t") == std::string::npos;
+  f_ = OpenOutput(wspecifier.substr(colon + 1));
+}
+void TableWriter::Flush() { fflush(f_.get()); }
+
+static void PrintWeight(std::string *o, float g, float a) {     // operator<< of LatticeWeightTpl: "graph,acoustic"
+  char buf[64]; auto num = [&](float v) { if (std::isinf(v)) return std::string(v > 0 ? "Infinity" : "-Infinity"); snprintf(buf, sizeof buf, "%g", (double)v); return std::string(buf); };
+  *o += num(g); *o += ","; *o += num(a);
+}
+void TableWriter::WriteLattice(const std::string &key, const Lattice &lat) {
+  // arcs grouped by source state in state order (a VectorFst stores them per state)
+  const int32_t n = lat.NumStates(); const size_t na = lat.arc_src.size();
+  std::vector<int32_t> off(n + 1, 0), order(na);
+  for (size_t a = 0; a < na; a++) off[lat.arc_src[a] + 1]++;
+  for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
+  { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < na; a++) order[p[lat.arc_src[a]]++] = (int32_t)a; }
+  std::string o = key + " ";
+  if (!binary_) {          // lat/kaldi-lattice.cc:401-417: newline, fst::FstPrinter (start state first, tab separated, weight omitted when One), newline
+    o += "\n";
+    auto print_state = [&](int32_t s) {
+      for (int32_t k = off[s]; k < off[s + 1]; k++) {
+        const int32_t a = order[k];
+        o += std::to_string(s) + "\t" + std::to_string(lat.arc_dst[a]) + "\t" + std::to_string(lat.arc_ilabel[a]) + "\t" + std::to_string(lat.arc_olabel[a]);
+        if (!(lat.arc_graph[a] == 0.0f && lat.arc_ac[a] == 0.0f)) { o += "\t"; PrintWeight(&o, lat.arc_graph[a], lat.arc_ac[a]); }
+        o += "\n";
+      }
+      if (std::isfinite(lat.st_final[s])) { o += std::to_string(s); if (lat.st_final[s] != 0.0f) { o += "\t"; PrintWeight(&o, lat.st_final[s], 0.0f); } o += "\n"; }
+    };
+    if (lat.start >= 0) print_state(lat.start);
+    for (int32_t s = 0; s < n; s++) if (s != lat.start) print_state(s);
+    o += "\n";
+  } else {                  // VectorFst<LatticeArc>::Write: FstHeader (arc type "lattice4") + per state {final (2 floats), narcs, arcs of 20 B}
+    Put(&o, kFstMagic); PutStr(&o, "vector"); PutStr(&o, "lattice4");
+    Put<int32_t>(&o, 2); Put<int32_t>(&o, 0); Put<uint64_t>(&o, 3); Put<int64_t>(&o, lat.start); Put<int64_t>(&o, n); Put<int64_t>(&o, (int64_t)na);
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int32_t s = 0; s < n; s++) {
+      const bool fin = std::isfinite(lat.st_final[s]);
+      Put<float>(&o, fin ? lat.st_final[s] : inf); Put<float>(&o, fin ? 0.0f : inf); Put<int64_t>(&o, off[s + 1] - off[s]);
+      for (int32_t k = off[s]; k < off[s + 1]; k++) { const int32_t a = order[k]; Put(&o, lat.arc_ilabel[a]); Put(&o, lat.arc_olabel[a]); Put(&o, lat.arc_graph[a]); Put(&o, lat.arc_ac[a]); Put(&o, lat.arc_dst[a]); }
+    }
+  }
+  if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on lattice " << key;
+}
+
+void TableWriter::WriteMatrix(const std::string &key, const float *data, int32_t rows, int32_t cols, int64_t stride) {
+  std::string o = key + " ";
+  if (binary_) {          // "\0B" "FM " \4 rows \4 cols data   (matrix/kaldi-matrix.cc:1382-1400)
+    o.append("\0B", 2); o += "FM "; o.push_back(4); Put(&o, rows); o.push_back(4); Put(&o, cols);
+    for (int32_t r = 0; r < rows; r++) o.append((const char *)(data + (int64_t)r * stride), 4 * (size_t)cols);
+  } else {
+    o += " [";
+    char buf[32];
+    for (int32_t r = 0; r < rows; r++) { o += "\n  "; for (int32_t c = 0; c < cols; c++) { snprintf(buf, sizeof buf, "%g ", (double)data[(int64_t)r * stride + c]); o += buf; } }
+    o += "]\n";
+  }
+  if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on matrix " << key;
+}
+
+}  // namespace k3host

@@ -1,0 +1,109 @@
+// k3_host.h -- host-side C++ glue above the C ABI of libk3hip.so: the pieces of Kaldi's CLI contract that the drop-in
+// binaries need (SURVEY.md 8b "CLI" and "File formats" rows), restated, not linked -- OpenFst and Kaldi's table code are not
+// available to link against.  Nothing here touches the GPU except through include/k3hip.h and hipMalloc/hipMemcpy.
+//
+//   ParseOptions            util/parse-options.{h,cc}: --name=value, --config=file, --help, typed Register(), exit codes
+//   ReadScp / OpenInput     util/kaldi-table (scp: rspecifiers; rxfilenames "file", "-", "cmd |")
+//   ReadWave                feat/wave-reader.{h,cc}: RIFF/WAVE PCM16
+//   ReadTransitionModel     hmm/transition-model.cc:225-251 + hmm/hmm-topology.cc:31-158 (text and binary) -> tid -> pdf map
+//   ReadFstKaldiGeneric     fstext/kaldi-fst-io.cc:51-107: OpenFst binary "vector"/"const" StdArc FST -> CSR
+//   LatticeWriter           lat/kaldi-lattice.cc:392-420 + util/kaldi-holder: "ark:" / "ark,t:" Lattice (text = FstPrinter format)
+//   MatrixWriter            matrix/kaldi-matrix.cc:1382-1400 ("FM" binary) / text
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace k3host {
+
+extern std::string g_program;      // basename(argv[0]), used in the log prefix
+extern int g_verbose;
+
+struct LogLine {                   // KALDI_LOG / KALDI_WARN / KALDI_ERR look-alike: "LOG (prog:func():file:line) msg"
+  std::ostringstream ss; const char *sev; bool fatal;
+  LogLine(const char *severity, const char *func, const char *file, int line, bool is_fatal);
+  ~LogLine() noexcept(false);
+  template <class T> LogLine &operator<<(const T &v) { ss << v; return *this; }
+};
+struct FatalError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define K3H_LOG ::k3host::LogLine("LOG", __func__, __FILE__, __LINE__, false)
+#define K3H_WARN ::k3host::LogLine("WARNING", __func__, __FILE__, __LINE__, false)
+#define K3H_ERR ::k3host::LogLine("ERROR", __func__, __FILE__, __LINE__, true)
+#define K3H_VLOG(n) if ((n) <= ::k3host::g_verbose) ::k3host::LogLine("VLOG", __func__, __FILE__, __LINE__, false)
+#define K3H_CHECK_K3(expr) do { if ((expr) != 0) K3H_ERR << #expr << ": " << k3_last_error(); } while (0)
+
+class ParseOptions {
+ public:
+  explicit ParseOptions(const char *usage);
+  void Register(const std::string &name, bool *p, const std::string &doc);
+  void Register(const std::string &name, int32_t *p, const std::string &doc);
+  void Register(const std::string &name, float *p, const std::string &doc);
+  void Register(const std::string &name, double *p, const std::string &doc);
+  void Register(const std::string &name, std::string *p, const std::string &doc);
+  // returns the index of the first positional argument; exits(0) on --help; throws FatalError on an invalid option
+  int Read(int argc, const char *const *argv);
+  void ReadConfigFile(const std::string &path);
+  int NumArgs() const { return (int)args_.size(); }
+  const std::string &GetArg(int i) const;          // 1-based like Kaldi
+  void PrintUsage(bool print_command_line = false) const;
+  bool IsSet(const std::string &name) const { return set_.count(Normalize(name)) != 0; }
+ private:
+  enum Kind { kBool, kInt, kFloat, kDouble, kString };
+  struct Opt { Kind kind; void *ptr; std::string doc, default_str; };
+  static std::string Normalize(const std::string &n);
+  void RegisterImpl(const std::string &name, Kind k, void *p, const std::string &doc, const std::string &def);
+  bool SetOption(const std::string &key, const std::string &value, bool has_value);
+  std::string usage_; std::map<std::string, Opt> opts_; std::map<std::string, int> set_; std::vector<std::string> args_, argv_;
+};
+
+// rxfilename: "path", "-" (stdin) or "command |"; the returned FILE is closed (fclose / pclose) by the deleter
+std::shared_ptr<FILE> OpenInput(const std::string &rxfilename);
+std::shared_ptr<FILE> OpenOutput(const std::string &wxfilename);    // "path", "-" or "| command"
+std::string ReadWholeInput(const std::string &rxfilename);
+
+// "scp:wav.scp" (options before the colon are ignored) -> (key, rxfilename) pairs in file order
+std::vector<std::pair<std::string, std::string>> ReadScp(const std::string &rspecifier);
+
+struct Wave { float samp_freq = 0; std::vector<float> samples; };   // channel 0, values in int16 range like WaveData
+Wave ReadWave(const std::string &rxfilename);
+
+// .mdl (text or binary): parses the TransitionModel in front of the nnet; id2pdf[0] is unused
+struct TransitionInfo { int32_t num_pdfs = 0; std::vector<int32_t> id2pdf; };
+TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename);
+
+struct HostFst {          // generic CSR in FST arc order (input of k3_fst_create)
+  int32_t start = -1; std::vector<int32_t> arc_offsets, ilabel, olabel, nextstate; std::vector<float> weight, final_cost;
+  int32_t NumStates() const { return (int32_t)final_cost.size(); }
+};
+HostFst ReadFstKaldiGeneric(const std::string &rxfilename);
+void WriteFstVector(const HostFst &fst, const std::string &wxfilename);
+
+struct Lattice {          // one utterance of k3_decoder_get_raw_lattices, already trimmed by Connect()
+  std::vector<int32_t> st_frame, st_state; std::vector<float> st_final;
+  std::vector<int32_t> arc_src, arc_dst, arc_ilabel, arc_olabel; std::vector<float> arc_graph, arc_ac;
+  int32_t start = -1;
+  int32_t NumStates() const { return (int32_t)st_final.size(); }
+};
+// fst::Connect (decoder/decoder-wrappers.cc:353): drop states that are not accessible from `start` or not co-accessible to a
+// final state, renumber with the start state first
+void Connect(Lattice *lat);
+// scales acoustic costs by 1/acoustic_scale (ScaleLattice(AcousticLatticeScale(1/acwt)), decoder-wrappers.cc:366-370)
+void ScaleAcoustic(Lattice *lat, double scale);
+
+class TableWriter {        // "ark:wxfilename" | "ark,t:wxfilename" (other options ignored); one stream
+ public:
+  explicit TableWriter(const std::string &wspecifier);
+  bool Binary() const { return binary_; }
+  void WriteLattice(const std::string &key, const Lattice &lat);
+  void WriteMatrix(const std::string &key, const float *data, int32_t rows, int32_t cols, int64_t stride);
+  void Flush();
+ private:
+  std::shared_ptr<FILE> f_; bool binary_ = true;
+};
+
+}  // namespace k3host

@@ -70,15 +70,21 @@ class SynthNnet:
     + components [(name, kind, params)]."""
     def __init__(self): self.config_lines, self.components = [], []
 
-    def write(self, path, binary=True):
+    def write(self, path, binary=True, as_mdl=False, num_pdfs=None, priors=None, left_context=0, right_context=0):
+        """raw nnet3 (Nnet::Write) or, with as_mdl, final.mdl = TransitionModel + AmNnetSimple (am-nnet-simple.cc:34-45)"""
         assert binary
         with open(path, "wb") as f:
-            f.write(b"\0B"); _tok(f, "<Nnet3>"); f.write(b"\n")
+            f.write(b"\0B")
+            if as_mdl: write_transition_model(f, num_pdfs)
+            _tok(f, "<Nnet3>"); f.write(b"\n")
             for l in self.config_lines: f.write(l.encode() + b"\n")
             f.write(b"\n"); _tok(f, "<NumComponents>"); _i32(f, len(self.components))
             for name, kind, prm in self.components:
                 _tok(f, "<ComponentName>"); _tok(f, name); _WRITERS[kind](f, prm)
             _tok(f, "</Nnet3>")
+            if as_mdl:
+                _tok(f, "<LeftContext>"); _i32(f, left_context); _tok(f, "<RightContext>"); _i32(f, right_context)
+                _tok(f, "<Priors>"); _vec(f, np.zeros(0, np.float32) if priors is None else priors)
 
     def num_params(self):
         n = 0
@@ -252,7 +258,24 @@ def make_hclg(num_states=2_000_000, num_arcs=5_000_000, num_pdfs=6024, seed=4321
     return Fst.from_arcs(S, 0, src[perm], ilabel[perm], olabel[perm], weight[perm], dst[perm], final)
 
 def tid2pdf(num_pdfs):
-    """the synthetic TransitionInformation: transition-id t in [1, 2*num_pdfs] -> pdf (t-1) mod num_pdfs; index 0 unused."""
+    """the synthetic TransitionModel (write_transition_model): num_pdfs one-state phones, each with a self-loop and a forward
+    transition sharing one pdf => transition-ids 2p-1, 2p -> pdf p-1, i.e. pdf = (tid - 1) // 2; index 0 unused."""
     t = np.arange(2 * num_pdfs + 1, dtype=np.int64)
-    m = ((t - 1) % num_pdfs).astype(np.int32); m[0] = 0
+    m = ((t - 1) // 2).astype(np.int32); m[0] = 0
     return m
+
+def write_transition_model(f, num_pdfs):
+    """TransitionModel::Write, binary (hmm/transition-model.cc:252-283; HmmTopology::Write hmm/hmm-topology.cc:160-215):
+    one topology entry for phones 1..num_pdfs: state 0 <PdfClass 0> with transitions (0, 0.5) (1, 0.5), state 1 final;
+    triples (phone p, hmm-state 0, pdf p-1); log-probs log(0.5)."""
+    _tok(f, "<TransitionModel>"); _tok(f, "<Topology>")
+    phones = np.arange(1, num_pdfs + 1, dtype="<i4"); phone2idx = np.zeros(num_pdfs + 1, "<i4"); phone2idx[0] = -1
+    for v in (phones, phone2idx): f.write(b"\x04" + struct.pack("<i", v.size) + v.tobytes())
+    _i32(f, 1)                       # one entry (HMM format: no -1 marker)
+    _i32(f, 2)                       # two states
+    _i32(f, 0); _i32(f, 2); _i32(f, 0); _f32(f, 0.5); _i32(f, 1); _f32(f, 0.5)     # state 0: pdf class 0, 2 transitions
+    _i32(f, -1); _i32(f, 0)          # state 1: no pdf, no transitions
+    _tok(f, "</Topology>"); _tok(f, "<Triples>"); _i32(f, num_pdfs)
+    for p in range(1, num_pdfs + 1): _i32(f, p); _i32(f, 0); _i32(f, p - 1)
+    _tok(f, "</Triples>"); _tok(f, "<LogProbs>"); _vec(f, np.concatenate([[0.0], np.full(2 * num_pdfs, np.log(0.5))]).astype(np.float32)); _tok(f, "</LogProbs>")
+    _tok(f, "</TransitionModel>")

@@ -1,0 +1,90 @@
+"""GPU tests of the drop-in command-line programs (kaldi_amd/bin, built from kaldi_amd/host):
+compute-fbank-feats-cuda / compute-mfcc-feats-cuda against the reference's own compute-fbank-feats / compute-mfcc-feats
+binaries (oracle/_ref) on the same wav.scp, and batched-wav-nnet3-cuda2 end to end (final.mdl + OpenFst HCLG + wav.scp ->
+lattice archive) against the Python-API pipeline over the same C ABI and against the oracle chain."""
+import os, subprocess, numpy as np, pytest, torch
+from kaldi_amd import synth
+from kaldi_amd.lattice import RawLattice
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "kaldi_amd", "bin"); REF = os.path.join(ROOT, "oracle", "_ref", "bin")
+ENV = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
+
+def _wavs(td, lens, seed=50):
+    from oracle import kaldi_io as kio
+    lines = []
+    for i, n in enumerate(lens):
+        kio.write_wav(f"{td}/u{i}.wav", synth.gaussian_pcm16(n, seed + i)); lines.append(f"utt{i} {td}/u{i}.wav")
+    open(f"{td}/wav.scp", "w").write("\n".join(lines) + "\n")
+
+@pytest.mark.parametrize("kind,flags", [("fbank", ["--dither=0", "--num-mel-bins=40"]), ("mfcc", ["--dither=0", "--num-mel-bins=40", "--num-ceps=40", "--low-freq=20", "--high-freq=-400"]),
+                                        ("fbank", ["--dither=0", "--snip-edges=false", "--use-energy=true", "--window-type=hamming"])])
+def test_feature_programs_match_the_reference_binaries(tmp_path, kind, flags):
+    from oracle import kaldi_io as kio
+    if not os.path.exists(os.path.join(REF, f"compute-{kind}-feats")): pytest.skip("oracle/_ref not present")
+    td = str(tmp_path); _wavs(td, [16000, 4001, 23001, 399 + 160 * 3])
+    r = subprocess.run([os.path.join(REF, f"compute-{kind}-feats")] + flags + [f"scp:{td}/wav.scp", f"ark:{td}/ref.ark"], env=ENV, capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    g = subprocess.run([os.path.join(BIN, f"compute-{kind}-feats-cuda")] + flags + [f"scp:{td}/wav.scp", f"ark:{td}/gpu.ark"], capture_output=True, text=True); assert g.returncode == 0, g.stderr
+    a, b = kio.read_ark(f"{td}/ref.ark"), kio.read_ark(f"{td}/gpu.ark")
+    assert list(a) == list(b)
+    for k in a:
+        assert a[k].shape == b[k].shape and np.abs(a[k] - b[k]).max() <= 1e-4, (k, np.abs(a[k] - b[k]).max())
+    assert "Done 4 out of 4 utterances" in g.stderr
+
+def _parse_text_lattices(path, start_state_of=None):
+    lats, key, arcs, fins = {}, None, [], {}
+    for line in open(path):
+        line = line.rstrip("\n")
+        if key is None:
+            if line.strip(): key = line.strip(); arcs, fins = [], {}
+            continue
+        if line == "":
+            lats[key] = (arcs, fins); key = None; continue
+        f = line.split("\t")
+        if len(f) >= 4:
+            g, a = (0.0, 0.0) if len(f) == 4 else map(float, f[4].split(","))
+            arcs.append((int(f[0]), int(f[1]), int(f[2]), int(f[3]), np.float32(g), np.float32(a)))
+        else:
+            fins[int(f[0])] = np.float32(0.0) if len(f) == 1 else np.float32(float(f[1].split(",")[0]))
+    return lats
+
+def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
+    from kaldi_amd import feat, nnet3, decoder
+    from oracle import kaldi_io as kio
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001]
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5)
+    net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40   # comment\n--dither=0\n")
+    cmd = [os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0",
+           "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--max-batch-size=2", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/lat.txt"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Decoded 3 utterances, 0 with errors." in r.stderr and "RealTimeX:" in r.stderr
+    got = _parse_text_lattices(f"{td}/lat.txt")
+    assert list(got) == ["utt0", "utt1", "utt2"]
+    # the same path through the Python API
+    dev = torch.device("cuda:0"); t2p = synth.tid2pdf(N)
+    sf = feat.SpectralFeatures(feat.fbank_options(dither=0.0, num_bins=40))
+    waves = [kio.read_wav(f"{td}/u{i}.wav")[0].astype(np.float32) for i in range(3)]
+    wo, fo, total, fo_h = sf.offsets([len(w) for w in waves], dev)
+    feats = sf.ComputeFeatures(torch.from_numpy(np.concatenate(waves)).to(dev), wo, fo, total)
+    nn = nnet3.Nnet(f"{td}/final.mdl"); nb = nnet3.NnetBatch(nn, [fo_h[i + 1] - fo_h[i] for i in range(3)], 3)
+    ll = nb.forward(feats)
+    dec = decoder.CudaDecoder(decoder.CudaFst(graph, t2p), decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000), 3, N)
+    dec.DecodeBatch(ll, nb.out_offsets); lats = dec.GetRawLattices()
+    for u, key in enumerate(got):
+        ref = lats[u].connect()
+        arcs, fins = got[key]
+        assert len(arcs) == ref.num_arcs and len(arcs) > 0, (key, len(arcs), ref.num_arcs)
+        # the text format prints 6 significant digits: compare label multisets exactly and costs loosely
+        assert sorted((a[2], a[3]) for a in arcs) == sorted(zip(ref.arc_ilabel.tolist(), ref.arc_olabel.tolist()))
+        assert abs(sum(float(a[4]) for a in arcs) - float(ref.arc_graph.astype(np.float64).sum())) < 1e-3 * len(arcs)
+        assert abs(sum(float(a[5]) for a in arcs) - float(ref.arc_ac.astype(np.float64).sum())) < 1e-3 * len(arcs)
+        assert len(fins) == int(np.isfinite(ref.st_final).sum())
+    # binary archive: same lattices, exact float bits
+    cmd[-1] = f"ark:{td}/lat.ark"
+    assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
+    assert os.path.getsize(f"{td}/lat.ark") > 1000 and open(f"{td}/lat.ark", "rb").read(9) == b"utt0 \xd6\xfd\xb2\x7e"

@@ -1,0 +1,47 @@
+"""CPU tests of the host-side C++ glue (kaldi_amd/host): Kaldi file formats and CLI contract, no GPU involved.
+The TransitionModel parser is pinned against the REFERENCE's own class (oracle/_ref/bin/dump-tid2pdf links
+hmm/transition-model.cc) on binary and text .mdl files (the text one written by the reference's nnet3-am-copy)."""
+import os, subprocess, numpy as np, pytest
+from kaldi_amd import synth
+from kaldi_amd.fst import Fst
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "kaldi_amd", "bin"); REF = os.path.join(ROOT, "oracle", "_ref", "bin")
+ENV = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"))
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as ge
+    ge.build()
+
+def _run(*a, env=None): return subprocess.run(list(a), capture_output=True, text=True, env=env)
+
+def test_transition_model_parser_matches_the_reference_class(tmp_path):
+    if not os.path.exists(os.path.join(REF, "dump-tid2pdf")): pytest.skip("oracle/_ref not built (needs /root/reference)")
+    N = 30; mdl = str(tmp_path / "m.mdl")
+    synth.make_tdnn(seed=1, dim=64, num_pdfs=N).write(mdl, as_mdl=True, num_pdfs=N, left_context=5, right_context=5)
+    ref = _run(os.path.join(REF, "dump-tid2pdf"), mdl, env=ENV).stdout
+    assert ref.split()[:2] == [str(N), str(2 * N)]
+    assert _run(os.path.join(BIN, "k3-host-tool"), "tid2pdf", mdl).stdout == ref
+    txt = str(tmp_path / "m.txt.mdl")
+    assert _run(os.path.join(REF, "nnet3-am-copy"), "--binary=false", mdl, txt, env=ENV).returncode == 0
+    assert _run(os.path.join(BIN, "k3-host-tool"), "tid2pdf", txt).stdout == ref
+    assert np.array_equal(np.array(ref.split()[2:], int), synth.tid2pdf(N)[1:])
+
+def test_openfst_binary_reader_and_writer_round_trip(tmp_path):
+    f = synth.make_hclg(300, 700, 20, seed=3, start_degree=8)
+    a, b = str(tmp_path / "g.fst"), str(tmp_path / "g2.fst")
+    f.write_openfst(a)
+    r = _run(os.path.join(BIN, "k3-host-tool"), "fstinfo", a)
+    assert r.stdout.split()[:3] == [str(f.num_states), str(f.num_arcs), str(f.start)], r.stderr
+    assert _run(os.path.join(BIN, "k3-host-tool"), "copy-fst", a, b).returncode == 0
+    g = Fst.read_openfst(b)
+    assert all(np.array_equal(getattr(f, k), getattr(g, k)) for k in ("arc_offsets", "ilabel", "olabel", "weight", "nextstate", "final")) and g.start == f.start
+
+def test_cli_exit_codes_follow_the_reference():
+    """usage -> 1 (batched-wav-nnet3-cuda2.cc:110-113), exception -> -1 with the message on stderr (:256-259)"""
+    exe = os.path.join(BIN, "batched-wav-nnet3-cuda2")
+    r = _run(exe); assert r.returncode == 1 and "Usage: batched-wav-nnet3-cuda2" in r.stderr
+    r = _run(exe, "--no-such-option=1", "a", "b", "c", "d"); assert r.returncode == 255 and "Invalid option" in r.stderr
+    r = _run(exe, "--determinize-lattice=true", "a", "b", "c", "d"); assert r.returncode == 255 and "determinize" in r.stderr
+    r = _run(os.path.join(BIN, "compute-fbank-feats-cuda"), "only-one-arg"); assert r.returncode == 1
+    r = _run(exe, "--help"); assert r.returncode == 0 and "--lattice-beam" in r.stderr and "--max-batch-size" in r.stderr
