@@ -450,4 +450,120 @@ void TableWriter::WriteMatrix(const std::string &key, const float *data, int32_t
   if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on matrix " << key;
 }
 
+
+// ------------------------------------------------------------------------------------------------ matrices ----
+namespace {
+size_t ReadOneMatrix(const std::string &b, size_t p, Matrix *m, const std::string &what) {
+  auto need = [&](size_t n) { if (p + n > b.size()) K3H_ERR << "unexpected end of data reading matrix " << what; };
+  auto i32 = [&]() { need(5); if (b[p] != 4) K3H_ERR << "bad integer marker in matrix " << what; int32_t v; memcpy(&v, b.data() + p + 1, 4); p += 5; return v; };
+  if (p + 2 <= b.size() && b[p] == '\0' && b[p + 1] == 'B') {
+    p += 2; const size_t t0 = p; while (p < b.size() && b[p] != ' ') p++;
+    const std::string tok = b.substr(t0, p - t0); p++;
+    if (tok == "FM" || tok == "DM") {
+      m->rows = i32(); m->cols = i32(); const size_t n = (size_t)m->rows * m->cols; m->data.resize(n);
+      if (tok == "FM") { need(4 * n); memcpy(m->data.data(), b.data() + p, 4 * n); p += 4 * n; }
+      else { need(8 * n); for (size_t i = 0; i < n; i++) { double d; memcpy(&d, b.data() + p + 8 * i, 8); m->data[i] = (float)d; } p += 8 * n; }
+    } else if (tok == "CM" || tok == "CM2" || tok == "CM3") {
+      need(16); float mn, range; int32_t nr, nc; memcpy(&mn, b.data() + p, 4); memcpy(&range, b.data() + p + 4, 4); memcpy(&nr, b.data() + p + 8, 4); memcpy(&nc, b.data() + p + 12, 4); p += 16;
+      m->rows = nr; m->cols = nc; m->data.resize((size_t)nr * nc);
+      if (tok == "CM") {                 // per-column percentile headers + column-major bytes (compressed-matrix.cc:626-648)
+        need((size_t)nc * 8 + (size_t)nc * nr);
+        const uint16_t *ch = reinterpret_cast<const uint16_t *>(b.data() + p); const uint8_t *bytes = reinterpret_cast<const uint8_t *>(b.data() + p + (size_t)nc * 8);
+        for (int32_t c = 0; c < nc; c++) {
+          uint16_t h[4]; memcpy(h, ch + 4 * c, 8);
+          const float p0 = mn + range * 1.52590218966964e-05F * h[0], p25 = mn + range * 1.52590218966964e-05F * h[1], p75 = mn + range * 1.52590218966964e-05F * h[2], p100 = mn + range * 1.52590218966964e-05F * h[3];
+          for (int32_t r = 0; r < nr; r++) {
+            const uint8_t v = bytes[(size_t)c * nr + r]; float f;
+            if (v <= 64) f = p0 + (p25 - p0) * v * (1 / 64.0); else if (v <= 192) f = p25 + (p75 - p25) * (v - 64) * (1 / 128.0); else f = p75 + (p100 - p75) * (v - 192) * (1 / 63.0);
+            m->data[(size_t)r * nc + c] = f;
+          }
+        }
+        p += (size_t)nc * 8 + (size_t)nc * nr;
+      } else if (tok == "CM2") {
+        need(2 * (size_t)nr * nc); const float inc = range * (1.0f / 65535.0f);
+        for (size_t i = 0; i < (size_t)nr * nc; i++) { uint16_t v; memcpy(&v, b.data() + p + 2 * i, 2); m->data[i] = mn + v * inc; }
+        p += 2 * (size_t)nr * nc;
+      } else {
+        need((size_t)nr * nc); const float inc = range * (1.0f / 255.0f);
+        for (size_t i = 0; i < (size_t)nr * nc; i++) m->data[i] = mn + (uint8_t)b[p + i] * inc;
+        p += (size_t)nr * nc;
+      }
+    } else K3H_ERR << "Expected a matrix (FM, DM, CM, CM2, CM3), got token " << tok << " reading " << what;
+    return p;
+  }
+  // text: " [\n a b c\n d e f ]"
+  while (p < b.size() && isspace((unsigned char)b[p])) p++;
+  if (p >= b.size() || b[p] != '[') K3H_ERR << "Expected \"[\" reading text matrix " << what;
+  p++; std::vector<float> row; m->rows = 0; m->cols = 0; m->data.clear();
+  while (p < b.size()) {
+    while (p < b.size() && (b[p] == ' ' || b[p] == '\t' || b[p] == '\r')) p++;
+    if (p >= b.size()) break;
+    if (b[p] == '\n' || b[p] == ']') {
+      if (!row.empty()) { if (m->cols && (int32_t)row.size() != m->cols) K3H_ERR << "Inconsistent row lengths in text matrix " << what; m->cols = (int32_t)row.size(); m->data.insert(m->data.end(), row.begin(), row.end()); m->rows++; row.clear(); }
+      if (b[p++] == ']') { while (p < b.size() && b[p] != '\n') p++; if (p < b.size()) p++; return p; }
+      continue;
+    }
+    char *e = nullptr; const float v = strtof(b.c_str() + p, &e);
+    if (e == b.c_str() + p) K3H_ERR << "Bad number in text matrix " << what;
+    row.push_back(v); p = e - b.c_str();
+  }
+  K3H_ERR << "Unterminated text matrix " << what;
+  return p;
+}
+}  // namespace
+
+std::vector<std::pair<std::string, Matrix>> ReadMatrixTable(const std::string &rspecifier) {
+  const size_t colon = rspecifier.find(':');
+  if (colon == std::string::npos) K3H_ERR << "Invalid rspecifier " << rspecifier;
+  const std::string kind = rspecifier.substr(0, 3), rest = rspecifier.substr(colon + 1);
+  std::vector<std::pair<std::string, Matrix>> out;
+  if (kind == "ark") {
+    const std::string b = ReadWholeInput(rest); size_t p = 0;
+    while (true) {
+      while (p < b.size() && isspace((unsigned char)b[p])) p++;
+      if (p >= b.size()) break;
+      const size_t k0 = p; while (p < b.size() && !isspace((unsigned char)b[p])) p++;
+      const std::string key = b.substr(k0, p - k0); p++;
+      Matrix m; p = ReadOneMatrix(b, p, &m, key); out.push_back({key, std::move(m)});
+    }
+  } else if (kind == "scp") {
+    std::map<std::string, std::string> cache;
+    for (auto &kv : ReadScp(rspecifier)) {
+      std::string path = kv.second; size_t off = 0;
+      const size_t c = path.rfind(':');
+      if (c != std::string::npos && c + 1 < path.size() && path.find_first_not_of("0123456789", c + 1) == std::string::npos) { off = strtoull(path.c_str() + c + 1, nullptr, 10); path = path.substr(0, c); }
+      if (!cache.count(path)) { if (cache.size() > 4) cache.clear(); cache[path] = ReadWholeInput(path); }
+      Matrix m; ReadOneMatrix(cache[path], off, &m, kv.first); out.push_back({kv.first, std::move(m)});
+    }
+  } else K3H_ERR << "Invalid rspecifier " << rspecifier << " (supported: ark:, scp:)";
+  return out;
+}
+
+bool BestPath(const Lattice &lat, std::vector<int32_t> *ali, std::vector<int32_t> *words, double *gcost, double *acost) {
+  const int32_t n = lat.NumStates(); const size_t na = lat.arc_src.size();
+  if (n == 0 || lat.start < 0) return false;
+  std::vector<double> best(n, std::numeric_limits<double>::infinity()); std::vector<int64_t> back(n, -1);
+  best[lat.start] = 0.0;
+  std::vector<int32_t> order(na); for (size_t a = 0; a < na; a++) order[a] = (int32_t)a;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return lat.st_frame[lat.arc_src[x]] < lat.st_frame[lat.arc_src[y]]; });
+  for (bool changed = true; changed;) {       // arcs in frame order; epsilon chains inside a frame may need another sweep
+    changed = false;
+    for (int32_t a : order) { const double c = best[lat.arc_src[a]] + (double)lat.arc_graph[a] + (double)lat.arc_ac[a]; if (c < best[lat.arc_dst[a]]) { best[lat.arc_dst[a]] = c; back[lat.arc_dst[a]] = a; changed = true; } }
+  }
+  int32_t end = -1; double bc = std::numeric_limits<double>::infinity();
+  for (int32_t s = 0; s < n; s++) if (std::isfinite(lat.st_final[s]) && best[s] + lat.st_final[s] < bc) { bc = best[s] + lat.st_final[s]; end = s; }
+  if (end < 0) return false;
+  ali->clear(); words->clear(); *gcost = lat.st_final[end]; *acost = 0.0;
+  for (int32_t s = end; s != lat.start;) { const int64_t a = back[s]; if (lat.arc_ilabel[a]) ali->push_back(lat.arc_ilabel[a]); if (lat.arc_olabel[a]) words->push_back(lat.arc_olabel[a]); *gcost += lat.arc_graph[a]; *acost += lat.arc_ac[a]; s = lat.arc_src[a]; }
+  std::reverse(ali->begin(), ali->end()); std::reverse(words->begin(), words->end());
+  return true;
+}
+
+void TableWriter::WriteInt32Vector(const std::string &key, const std::vector<int32_t> &v) {
+  std::string o = key + " ";
+  if (binary_) { o.append("\0B", 2); o.push_back(4); Put<int32_t>(&o, (int32_t)v.size()); for (int32_t x : v) { o.push_back(4); Put(&o, x); } }     // BasicVectorHolder::Write
+  else { for (int32_t x : v) o += std::to_string(x) + " "; o += "\n"; }
+  if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on vector " << key;
+}
+
 }  // namespace k3host

@@ -95,12 +95,22 @@ void Connect(Lattice *lat);
 // scales acoustic costs by 1/acoustic_scale (ScaleLattice(AcousticLatticeScale(1/acwt)), decoder-wrappers.cc:366-370)
 void ScaleAcoustic(Lattice *lat, double scale);
 
+// Kaldi float matrices from an archive or script file: "ark:rxfilename", "scp:rxfilename" (entries "key file" or
+// "key file:offset"); binary FM / DM / CM / CM2 / CM3 (matrix/kaldi-matrix.cc:1402-1520, compressed-matrix.cc:560-660) and text
+struct Matrix { int32_t rows = 0, cols = 0; std::vector<float> data; };
+std::vector<std::pair<std::string, Matrix>> ReadMatrixTable(const std::string &rspecifier);
+
+// best path through a raw lattice (LatticeFasterDecoder::GetBestPath = ShortestPath over the raw lattice, :103-111):
+// transition-ids (alignment) and output labels (words) along it, total graph and acoustic cost.  false if no final state is reachable.
+bool BestPath(const Lattice &lat, std::vector<int32_t> *alignment, std::vector<int32_t> *words, double *graph_cost, double *acoustic_cost);
+
 class TableWriter {        // "ark:wxfilename" | "ark,t:wxfilename" (other options ignored); one stream
  public:
   explicit TableWriter(const std::string &wspecifier);
   bool Binary() const { return binary_; }
   void WriteLattice(const std::string &key, const Lattice &lat);
   void WriteMatrix(const std::string &key, const float *data, int32_t rows, int32_t cols, int64_t stride);
+  void WriteInt32Vector(const std::string &key, const std::vector<int32_t> &v);      // Int32VectorWriter (util/kaldi-holder-inl.h BasicVectorHolder)
   void Flush();
  private:
   std::shared_ptr<FILE> f_; bool binary_ = true;

@@ -1,0 +1,119 @@
+// nnet3-latgen-faster -- drop-in for nnet3bin/nnet3-latgen-faster.cc:33-260 with the forward pass and the decoder on MI355X:
+//   nnet3-latgen-faster [options] <nnet-in> <fst-in> <features-rspecifier> <lattice-wspecifier> [ <words-wspecifier> [<alignments-wspecifier>] ]
+// = DecodableAmNnetSimple + LatticeFasterDecoder + DecodeUtteranceLatticeFaster (decoder/decoder-wrappers.cc:287-382) per utterance in
+// the reference; here all utterances of a batch run through k3_nnet_forward and k3_decoder_decode_batch.  The reference determinizes
+// by default (CompactLattice output); determinization is host OpenFst code outside this library, so --determinize-lattice=false is
+// REQUIRED and the raw state-level lattice is written (what the reference writes with that flag).
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <iostream>
+#include "k3_host.h"
+#include "../../include/k3hip.h"
+using namespace k3host;
+#define HIPCHK(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) K3H_ERR << "HIP error " << hipGetErrorName(e__) << " in " << #e; } while (0)
+int main(int argc, char **argv) {
+  try {
+    const char *usage = "Generate lattices using nnet3 neural net model.\n"
+                        "Usage: nnet3-latgen-faster [options] <nnet-in> <fst-in> <features-rspecifier> <lattice-wspecifier> [ <words-wspecifier> [<alignments-wspecifier>] ]\n"
+                        "See also: nnet3-latgen-faster-parallel, nnet3-latgen-faster-batch\n";
+    ParseOptions po(usage);
+    bool allow_partial = false, determinize = true, debug_comp = false, phone_det = true, word_det = true, minimize = false; std::string word_syms, use_gpu = "yes", ivector_rspecifier, online_ivector_rspecifier, utt2spk;
+    int32_t subsampling = 1, frames_per_chunk = 50, elc = 0, erc = 0, elci = -1, ercf = -1, online_ivector_period = 0, max_batch = 256, max_active = 2147483647, min_active = 200, prune_interval = 25, max_mem = 50000000;
+    float beam = 16.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, hash_ratio = 2.0f, prune_scale = 0.1f, delta = 0.000976562f;
+    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)"); po.Register("allow-partial", &allow_partial, "If true, produce output even if end state was not reached.");
+    po.Register("beam", &beam, "Decoding beam.  Larger->slower, more accurate."); po.Register("max-active", &max_active, "Decoder max active states.  Larger->slower; more accurate");
+    po.Register("min-active", &min_active, "Decoder minimum #active states."); po.Register("lattice-beam", &lattice_beam, "Lattice generation beam.  Larger->slower, and deeper lattices");
+    po.Register("prune-interval", &prune_interval, "(accepted; pruning runs once after the last frame and gives the same lattice)"); po.Register("determinize-lattice", &determinize, "If true, determinize the lattice (only false is supported by this build)");
+    po.Register("beam-delta", &beam_delta, "Increment used in decoding-- this parameter is obscure and relates to a speedup in the way the max-active constraint is applied.");
+    po.Register("hash-ratio", &hash_ratio, "(accepted, unused: no hash-order dependence)"); po.Register("prune-scale", &prune_scale, "(accepted, unused)");
+    po.Register("max-mem", &max_mem, "(determinization option, unused)"); po.Register("phone-determinize", &phone_det, "(determinization option, unused)"); po.Register("word-determinize", &word_det, "(determinization option, unused)");
+    po.Register("minimize", &minimize, "(determinization option, unused)"); po.Register("delta", &delta, "(determinization option, unused)");
+    po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods"); po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
+    po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole)"); po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)");
+    po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)"); po.Register("debug-computation", &debug_comp, "(accepted, unused)");
+    po.Register("ivectors", &ivector_rspecifier, "(not supported)"); po.Register("online-ivectors", &online_ivector_rspecifier, "(not supported)"); po.Register("online-ivector-period", &online_ivector_period, "(not supported)"); po.Register("utt2spk", &utt2spk, "(not supported)");
+    po.Register("use-gpu", &use_gpu, "(this build always uses the GPU)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
+    po.Read(argc, argv);
+    if (po.NumArgs() < 4 || po.NumArgs() > 6) { po.PrintUsage(); return 1; }
+    if (determinize) K3H_ERR << "--determinize-lattice=true (the default) is not supported: pass --determinize-lattice=false and run lattice-determinize-pruned on the output";
+    if (!ivector_rspecifier.empty() || !online_ivector_rspecifier.empty() || elc || erc) K3H_ERR << "i-vectors / extra context are not supported by this program";
+    const std::string model_rx = po.GetArg(1), fst_rx = po.GetArg(2);
+    if (fst_rx.find(':') != std::string::npos && fst_rx.compare(0, 3, "ark") == 0) K3H_ERR << "a table of per-utterance FSTs is not supported; give one HCLG";
+    TransitionInfo ti = ReadTransitionModel(model_rx);
+    k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(model_rx.c_str(), &nnet));
+    k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
+    if (ni.output_dim != ti.num_pdfs) K3H_ERR << "Model output dimension " << ni.output_dim << " != number of pdfs in the transition model " << ti.num_pdfs;
+    std::vector<float> log_priors;
+    if (ni.has_priors) { log_priors.resize(ni.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet, log_priors.data())); for (float &p : log_priors) p = logf(p); }
+    HostFst hfst = ReadFstKaldiGeneric(fst_rx);
+    k3_fst *fst = nullptr;
+    K3H_CHECK_K3(k3_fst_create(hfst.NumStates(), hfst.start, hfst.arc_offsets.data(), hfst.ilabel.data(), hfst.olabel.data(), hfst.weight.data(), hfst.nextstate.data(), hfst.final_cost.data(),
+                               ti.id2pdf.data(), (int32_t)ti.id2pdf.size(), &fst));
+    k3_decoder_config dc; k3_decoder_config_default(&dc);
+    dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(min_active, max_active - 1); dc.beam_delta = beam_delta;
+    dc.frame_tokens_cap = 65536; dc.frame_cands_cap = 4 * 65536; dc.lane_tokens_cap = 4000000; dc.lane_links_cap = 8000000;
+    k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, max_batch, ni.output_dim, &dec));
+    auto feats = ReadMatrixTable(po.GetArg(3)); TableWriter lat_writer(po.GetArg(4));
+    std::unique_ptr<TableWriter> words_writer, ali_writer;
+    if (po.NumArgs() >= 5 && !po.GetArg(5).empty()) words_writer.reset(new TableWriter(po.GetArg(5)));
+    if (po.NumArgs() >= 6 && !po.GetArg(6).empty()) ali_writer.reset(new TableWriter(po.GetArg(6)));
+    int num_success = 0, num_fail = 0; int64_t frame_count = 0; double tot_like = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t b0 = 0; b0 < feats.size(); b0 += max_batch) {
+      const size_t b1 = std::min(feats.size(), b0 + (size_t)max_batch);
+      std::vector<size_t> idx; std::vector<int32_t> nf; std::vector<float> all;
+      for (size_t i = b0; i < b1; i++) {
+        const Matrix &m = feats[i].second;
+        if (m.rows == 0) { K3H_WARN << "Zero-length utterance: " << feats[i].first; num_fail++; continue; }
+        if (m.cols != ni.input_dim) K3H_ERR << "Neural net expects 'input' features with dimension " << ni.input_dim << " but you provided " << m.cols;
+        idx.push_back(i); nf.push_back(m.rows); all.insert(all.end(), m.data.begin(), m.data.end());
+      }
+      if (idx.empty()) continue;
+      const int U = (int)idx.size();
+      k3_nnet_batch *nb = nullptr; K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, nf.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
+      std::vector<int64_t> ro(U + 1); const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
+      float *d_f, *d_o; HIPCHK(hipMalloc((void **)&d_f, all.size() * 4)); HIPCHK(hipMalloc((void **)&d_o, (size_t)rows * ni.output_dim * 4));
+      HIPCHK(hipMemcpy(d_f, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+      K3H_CHECK_K3(k3_nnet_forward(nb, d_f, ni.input_dim, d_o, ni.output_dim, nullptr));
+      K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_o, ni.output_dim, ro.data(), nullptr));
+      std::vector<int64_t> info(10 * (size_t)U); K3H_CHECK_K3(k3_decoder_lattice_info(dec, info.data()));
+      int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
+      std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
+      K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));
+      int64_t s0 = 0, a0 = 0;
+      for (int u = 0; u < U; u++) {
+        const std::string &utt = feats[idx[u]].first; const int64_t ns = info[10 * u], na = info[10 * u + 1];
+        const bool ok = info[10 * u + 2] == 0 && ns > 0, reached_final = info[10 * u + 3] != 0;
+        if (!ok) { K3H_WARN << "Failed to decode utterance with id " << utt; num_fail++; s0 += ns; a0 += na; continue; }
+        if (!reached_final) {
+          if (allow_partial) K3H_WARN << "Outputting partial output for utterance " << utt << " since no final-state reached";
+          else { K3H_WARN << "Not producing output for utterance " << utt << " since no final-state reached and --allow-partial=false."; num_fail++; s0 += ns; a0 += na; continue; }
+        }
+        Lattice lat; lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns); lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
+        lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na); lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na); lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
+        lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
+        for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
+        s0 += ns; a0 += na;
+        std::vector<int32_t> ali, words; double gc = 0, ac = 0;
+        if (!BestPath(lat, &ali, &words, &gc, &ac)) { K3H_WARN << "Failed to get traceback for utterance " << utt; num_fail++; continue; }
+        if (words_writer) words_writer->WriteInt32Vector(utt, words);
+        if (ali_writer) ali_writer->WriteInt32Vector(utt, ali);
+        Connect(&lat);
+        if (acoustic_scale != 0.0f) ScaleAcoustic(&lat, 1.0 / acoustic_scale);
+        lat_writer.WriteLattice(utt, lat);
+        const double like = -(gc + ac); const size_t nfr = ali.size();
+        K3H_LOG << "Log-like per frame for utterance " << utt << " is " << (like / std::max<size_t>(nfr, 1)) << " over " << nfr << " frames.";
+        tot_like += like; frame_count += (int64_t)nfr; num_success++;
+      }
+      k3_nnet_batch_destroy(nb); HIPCHK(hipFree(d_f)); HIPCHK(hipFree(d_o));
+    }
+    lat_writer.Flush(); if (words_writer) words_writer->Flush(); if (ali_writer) ali_writer->Flush();
+    const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    K3H_LOG << "Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is " << (elapsed * 100.0 / std::max<int64_t>(frame_count, 1));
+    K3H_LOG << "Done " << num_success << " utterances, failed for " << num_fail;
+    K3H_LOG << "Overall log-likelihood per frame is " << (tot_like / std::max<int64_t>(frame_count, 1)) << " over " << frame_count << " frames.";
+    k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet);
+    return num_success != 0 ? 0 : 1;
+  } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
+}

@@ -91,3 +91,55 @@ def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
     cmd[-1] = f"ark:{td}/lat.ark"
     assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
     assert os.path.getsize(f"{td}/lat.ark") > 1000 and open(f"{td}/lat.ark", "rb").read(9) == b"utt0 \xd6\xfd\xb2\x7e"
+
+def test_nnet3_compute_matches_the_reference_binary_incl_compressed_archives(tmp_path):
+    """same model file, same feature archive (also as a COMPRESSED archive and an scp with byte offsets written by the
+    reference's copy-feats) -> our nnet3-compute vs the reference's nnet3-compute"""
+    from oracle import kaldi_io as kio
+    if not os.path.exists(os.path.join(REF, "nnet3-compute")): pytest.skip("oracle/_ref not present")
+    td = str(tmp_path); rng = np.random.default_rng(3)
+    feats = {f"utt{i}": (rng.standard_normal((T, 40)) * 1.2 + 16.5).astype(np.float32) for i, T in enumerate([83, 7, 250])}
+    kio.write_ark(f"{td}/f.ark", feats)
+    mdl = os.path.join(ROOT, "tests", "golden", "nnet_small.raw")
+    for s in (1, 3):
+        assert subprocess.run([os.path.join(REF, "nnet3-compute"), "--use-gpu=no", f"--frame-subsampling-factor={s}", mdl, f"ark:{td}/f.ark", f"ark:{td}/ref{s}.ark"], env=ENV, capture_output=True).returncode == 0
+        g = subprocess.run([os.path.join(BIN, "nnet3-compute"), f"--frame-subsampling-factor={s}", mdl, f"ark:{td}/f.ark", f"ark:{td}/gpu{s}.ark"], capture_output=True, text=True); assert g.returncode == 0, g.stderr
+        a, b = kio.read_ark(f"{td}/ref{s}.ark"), kio.read_ark(f"{td}/gpu{s}.ark")
+        assert list(a) == list(b)
+        for k in a: assert a[k].shape == b[k].shape and np.abs(a[k] - b[k]).max() <= 1e-4, (s, k, np.abs(a[k] - b[k]).max())
+    # compressed archive + scp with offsets, produced by the reference's copy-feats: both programs see the same (lossy) features
+    assert subprocess.run([os.path.join(REF, "copy-feats"), "--compress=true", f"ark:{td}/f.ark", f"ark,scp:{td}/c.ark,{td}/c.scp"], env=ENV, capture_output=True).returncode == 0
+    assert subprocess.run([os.path.join(REF, "nnet3-compute"), "--use-gpu=no", mdl, f"scp:{td}/c.scp", f"ark:{td}/refc.ark"], env=ENV, capture_output=True).returncode == 0
+    g = subprocess.run([os.path.join(BIN, "nnet3-compute"), mdl, f"scp:{td}/c.scp", f"ark,t:{td}/gpuc.txt"], capture_output=True, text=True); assert g.returncode == 0, g.stderr
+    a = kio.read_ark(f"{td}/refc.ark")
+    txt = open(f"{td}/gpuc.txt").read().replace("[", " ").replace("]", " ").split()
+    vals = [t for t in txt if not t.startswith("utt")]; got = np.array(vals, np.float32)
+    ref = np.concatenate([a[k].ravel() for k in a])
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-4      # text output keeps 6 significant digits
+
+def test_nnet3_latgen_faster_end_to_end(tmp_path):
+    """features archive -> lattices, words, alignments; the best path must equal the oracle chain's (oracle nnet3 + oracle decoder)"""
+    from oracle import kaldi_io as kio, nnet3_oracle as no, lattice_oracle as lo
+    td = str(tmp_path); N = 120; rng = np.random.default_rng(4)
+    feats = {f"utt{i}": (rng.standard_normal((T, 40)) * 1.2 + 16.5).astype(np.float32) for i, T in enumerate([120, 45])}
+    kio.write_ark(f"{td}/f.ark", feats)
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=feats["utt0"], out_std=1.5)
+    net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N); net.write(f"{td}/final.raw")
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
+    cmd = [os.path.join(BIN, "nnet3-latgen-faster"), "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=7000",
+           "--determinize-lattice=false", "--allow-partial=true", f"{td}/final.mdl", f"{td}/HCLG.fst", f"ark:{td}/f.ark", f"ark,t:{td}/lat.txt", f"ark,t:{td}/words.txt", f"ark,t:{td}/ali.txt"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Done 2 utterances, failed for 0" in r.stderr and "Overall log-likelihood per frame is" in r.stderr
+    words = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(f"{td}/words.txt")}
+    ali = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(f"{td}/ali.txt")}
+    onet = no.read_nnet(f"{td}/final.raw"); t2p = synth.tid2pdf(N)
+    for k, f in feats.items():
+        ll = no.compute(onet, f, 3)
+        ref, _ = lo.decode(graph, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0, max_active=7000), mode=0)
+        bp = ref.connect().best_path()
+        assert len(ali[k]) == ll.shape[0]
+        assert words[k] == bp[1] and ali[k] == bp[0], k
+    # default --determinize-lattice=true is refused loudly
+    r = subprocess.run([c for c in cmd if not c.startswith("--determinize")], capture_output=True, text=True)
+    assert r.returncode == 255 and "determinize-lattice" in r.stderr
