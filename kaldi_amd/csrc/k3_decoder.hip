@@ -219,6 +219,7 @@ __device__ __forceinline__ int slot_find(Slot *tab, unsigned mask, int state) {
 // every thread agrees that such a state belongs to level 2, the per-lane open-addressing table in HBM.  Slot ids < kHL are
 // LDS slots, ids >= kHL are kHL + index of the HBM slot.  Typical frames (~1-3 k tokens) never leave LDS.
 constexpr int kHL = 4096, kProbe = 48;
+constexpr int kRowRegs = (7168 + kBlock - 1) / kBlock;   // registers that carry the next frame's log-likelihood row (LDS rows are <= 28 KB)
 #define K3_LLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 struct Table {
   int *lkey; unsigned *lcost; int *ltok; unsigned *lmark;     // LDS: [kHL], [kHL], [kHL], [kHL / 32]
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     // stage the log-likelihood row of this frame in LDS (coalesced), overlapped with the cutoff passes
     K3_T(0);
     const float *row = p.loglikes + (r0 + f) * p.ld;
-    if (p.use_lds_row) for (int i = tid; i < p.num_pdfs; i += kBlock) s_ll[i] = row[i];
+    if (p.use_lds_row && f == 0) for (int i = tid; i < p.num_pdfs; i += kBlock) s_ll[i] = row[i];   // later rows are prefetched one frame ahead
     const float *ll = p.use_lds_row ? s_ll : row;
     const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
     if (n_cur == 0) { status = kStNoTokens; break; }
@@ -517,6 +518,14 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     }
     if (block_err(sh)) break;
     K3_T(3);
+    // the LDS row is dead from here on: fetch the next frame's row into registers now (the loads fly during the rest of the frame),
+    // park it in LDS at the end of the frame
+    float rowreg[kRowRegs];
+    const bool prefetch = p.use_lds_row && f + 1 < T;
+    if (prefetch) {
+#pragma unroll
+      for (int k = 0; k < kRowRegs; k++) { const int i = tid + k * kBlock; rowreg[k] = i < p.num_pdfs ? row[p.ld + i] : 0.0f; }
+    }
     // ---- final bound of the frame, pass 2: tokens (min cost per state) for the accepted arcs
     float accept = next0;
     { const unsigned mt = sh.min_tot; if (mt != kEncMax) { const float t = dec(mt) + ab; if (t < accept) accept = t; } }
@@ -560,6 +569,10 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__);
     if (block_err(sh)) break;
     cur_base = nb; n_cur = sh.n_next; max_frame = n_cur > max_frame ? n_cur : max_frame;
+    if (prefetch) {
+#pragma unroll
+      for (int k = 0; k < kRowRegs; k++) { const int i = tid + k * kBlock; if (i < p.num_pdfs) s_ll[i] = rowreg[k]; }
+    }
     __syncthreads();
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
   }

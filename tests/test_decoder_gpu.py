@@ -78,3 +78,16 @@ def test_lanes_are_independent_and_deterministic():
     many, _, _ = _gpu_decode(cf, 80, [ll] * 96, beam=14.0, lattice_beam=7.0, max_active=5000)
     for m in many:
         assert m.diff(one[0]) == ""
+
+def test_graph_image_export_import_is_the_broadcast_path():
+    """what kaldi_amd.parallel.broadcast_graph does on ranks != 0: an empty graph of the right shape + the image bytes of rank 0"""
+    from kaldi_amd import decoder
+    f, t2p, cf = _setup(2000, 5000, 50, 1, 40)
+    ptr, nbytes = cf.image()
+    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda"); cf.export_image(buf)
+    cf2 = decoder.CudaFst.empty(f.num_states, f.num_arcs, f.start); cf2.import_image(buf.clone())
+    rng = np.random.default_rng(0)
+    ll = (rng.standard_normal((40, 50)) * 2.5).astype(np.float32)
+    a, _, _ = _gpu_decode(cf, 50, [ll], beam=15.0, lattice_beam=8.0)
+    b, _, _ = _gpu_decode(cf2, 50, [ll], beam=15.0, lattice_beam=8.0)
+    assert a[0].num_arcs > 0 and a[0].diff(b[0]) == ""
