@@ -178,6 +178,28 @@ int k3_decoder_phase_cycles(k3_decoder *dec, int64_t *h_cycles /* [16] */);
 int k3_decoder_frame_stats(k3_decoder *dec, int32_t utt, int32_t *h_ntoks, float *h_cur_cutoff, float *h_adaptive_beam,
                            float *h_next_cutoff, float *h_cost_offset);
 
+/* ---------------------------------------------------------------- CuMatrix operations --------
+ * The CuMatrixBase<BaseFloat> methods the nnet3 forward pass of a TDNN / TDNN-F model executes through Kaldi's generic
+ * NnetComputer, so that a Kaldi build can keep its graph compiler/executor and swap only the device kernels:
+ * each entry point is the body of the CuMatrixBase method of the same name (cudamatrix/cu-matrix.h:79-791; kernels
+ * cudamatrix/cu-kernels.cu).  Row-major float32, leading dimension = CuMatrixBase::Stride(), device pointers. */
+int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta,
+                       float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream);      /* AddMatMat: C = alpha op(A) op(B) + beta C, FP32 MFMA */
+int k3_mat_set(float *d_C, int64_t ldc, int32_t rows, int32_t cols, float value, void *stream);                 /* Set / SetZero */
+int k3_mat_scale(float *d_C, int64_t ldc, int32_t rows, int32_t cols, float value, void *stream);               /* Scale */
+int k3_mat_add(float *d_C, int64_t ldc, int32_t rows, int32_t cols, float value, void *stream);                 /* Add */
+int k3_mat_apply_floor(float *d_C, int64_t ldc, int32_t rows, int32_t cols, float floor_val, void *stream);     /* ApplyFloor (ReLU = floor 0) */
+int k3_mat_apply_ceiling(float *d_C, int64_t ldc, int32_t rows, int32_t cols, float ceiling_val, void *stream); /* ApplyCeiling */
+int k3_mat_copy_rows_from_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_v, void *stream);    /* CopyRowsFromVec (bias broadcast) */
+int k3_mat_mul_cols_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_scale, void *stream);      /* MulColsVec (BatchNorm scale) */
+int k3_mat_mul_rows_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_scale, void *stream);      /* MulRowsVec */
+int k3_mat_add_vec_to_rows(float alpha, const float *d_row, float beta, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream);  /* AddVecToRows (BatchNorm offset) */
+int k3_mat_add_vec_to_cols(float alpha, const float *d_col, float beta, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream);  /* AddVecToCols */
+int k3_mat_copy_from_mat(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, int32_t trans, void *stream);  /* CopyFromMat */
+int k3_mat_add_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream); /* AddMat */
+int k3_mat_copy_rows(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *stream); /* CopyRows, index -1 = zero row */
+int k3_mat_add_rows(float alpha, const float *d_src, int64_t lds, const int32_t *d_indexes, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream); /* AddRows, index -1 = skip */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,115 @@
+// k3_matrix.hip -- the CuMatrixBase<float> operations the nnet3 forward pass of a TDNN / TDNN-F model executes when it runs
+// through Kaldi's generic NnetComputer (AddMatMat, CopyRowsFromVec, CopyFromMat, ApplyFloor, MulColsVec,
+// AddVecToRows, Scale, AddMat, CopyRows, AddRows, SetZero/Set), as gfx950 kernels behind a C ABI.  They let a Kaldi build keep its
+// own graph compiler and executor (nnet3/nnet-compute.cc:236-459) and only swap the device kernels under CuMatrix
+// (cudamatrix/cu-matrix.cc, cu-kernels.cu); the fused path in k3_nnet.hip is the fast path for the same models.
+// All matrices are row-major float32 with a leading dimension (CuMatrixBase::Stride()), device pointers.
+#include "k3_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// C = alpha * op(A) * op(B) + beta * C   (CuMatrixBase::AddMatMat, cu-matrix.cc:1329-1375 -> cublas_gemm).
+// 64 x 64 x 16 tiles, 4 wavefronts of one 32x32 FP32-MFMA tile each; operands go through LDS element-wise so that any
+// transpose / stride / ragged edge is handled by the index function.  k is consumed in ascending order.
+__global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int K, float alpha, const float *A, long long lda, int ta,
+                                                              const float *B, long long ldb, int tb, float beta, float *C, long long ldc) {
+  __shared__ float As[64][17], Bs[16][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int e = tid; e < 64 * 16; e += 256) {
+      const int r = e >> 4, k = e & 15, gm = m0 + r, gk = k0 + k;
+      As[r][k] = (gm < M && gk < K) ? (ta ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk]) : 0.0f;
+      const int kb = e >> 6, c = e & 63, gn = n0 + c, gk2 = k0 + kb;
+      Bs[kb][c] = (gn < N && gk2 < K) ? (tb ? B[(long long)gn * ldb + gk2] : B[(long long)gk2 * ldb + gn]) : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      const int k = 2 * kk + (lane >> 5);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[wm * 32 + (lane & 31)][k], Bs[k][wn * 32 + (lane & 31)], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col < N) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < M) { float *c = C + (long long)row * ldc + col; *c = (beta == 0.0f) ? alpha * acc[r] : alpha * acc[r] + beta * *c; }
+    }
+  }
+}
+
+enum { kOpSet, kOpScale, kOpFloor, kOpCeil, kOpAddConst, kOpCopyRowsFromVec, kOpMulColsVec, kOpMulRowsVec, kOpAddVecToRows, kOpAddVecToCols, kOpCopy, kOpCopyT, kOpAddMat, kOpAddMatT,
+       kOpCopyRows, kOpAddRows };
+struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; };
+
+__global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c >= p.cols) return;
+  for (int r = blockIdx.y * 4 + (threadIdx.x >> 6); r < p.rows; r += gridDim.y * 4) {
+    float *d = p.C + (long long)r * p.ldc + c; float x = 0.0f;
+    switch (p.op) {
+      case kOpSet: x = p.a; break;
+      case kOpScale: x = *d * p.a; break;
+      case kOpFloor: x = fmaxf(*d, p.a); break;
+      case kOpCeil: x = fminf(*d, p.a); break;
+      case kOpAddConst: x = *d + p.a; break;
+      case kOpCopyRowsFromVec: x = p.v[c]; break;
+      case kOpMulColsVec: x = *d * p.v[c]; break;
+      case kOpMulRowsVec: x = *d * p.v[r]; break;
+      case kOpAddVecToRows: x = p.a * p.v[c] + p.b * *d; break;                   // cu-matrix.cc AddVecToRows: beta * this + alpha * row
+      case kOpAddVecToCols: x = p.a * p.v[r] + p.b * *d; break;
+      case kOpCopy: x = p.S[(long long)r * p.lds + c]; break;
+      case kOpCopyT: x = p.S[(long long)c * p.lds + r]; break;
+      case kOpAddMat: x = *d + p.a * p.S[(long long)r * p.lds + c]; break;
+      case kOpAddMatT: x = *d + p.a * p.S[(long long)c * p.lds + r]; break;
+      case kOpCopyRows: { const int s = p.idx[r]; x = s < 0 ? 0.0f : p.S[(long long)s * p.lds + c]; break; }          // index -1 = zero row
+      case kOpAddRows: { const int s = p.idx[r]; x = s < 0 ? *d : *d + p.a * p.S[(long long)s * p.lds + c]; break; }
+    }
+    *d = x;
+  }
+}
+
+int launch_ew(const EwParams &p, void *stream) {
+  if (p.rows <= 0 || p.cols <= 0) return K3_OK;
+  dim3 grid((p.cols + 63) / 64, (unsigned)std::min(65535, (p.rows + 3) / 4));
+  hipLaunchKernelGGL(k3_ew_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+EwParams mk(int op, float *C, long long ldc, int rows, int cols) { EwParams p{}; p.op = op; p.C = C; p.ldc = ldc; p.rows = rows; p.cols = cols; return p; }
+
+}  // namespace
+
+#define K3_MAT_REQUIRE(C, ldc, rows, cols) K3_REQUIRE((C) && (rows) >= 0 && (cols) >= 0 && (ldc) >= (cols), "k3_mat: bad matrix argument")
+
+extern "C" int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta,
+                                  float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream) {
+  K3_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && ldc >= N, "k3_mat_add_mat_mat: bad argument");
+  K3_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N), "k3_mat_add_mat_mat: leading dimension smaller than the row length");
+  if (M == 0 || N == 0) return K3_OK;
+  hipLaunchKernelGGL(k3_gemm_generic_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, N, K, alpha, d_A, lda, trans_a, d_B, ldb, trans_b, beta, d_C, ldc);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+extern "C" int k3_mat_set(float *C, int64_t ldc, int32_t rows, int32_t cols, float value, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); EwParams p = mk(kOpSet, C, ldc, rows, cols); p.a = value; return launch_ew(p, st); }
+extern "C" int k3_mat_scale(float *C, int64_t ldc, int32_t rows, int32_t cols, float value, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); EwParams p = mk(kOpScale, C, ldc, rows, cols); p.a = value; return launch_ew(p, st); }
+extern "C" int k3_mat_add(float *C, int64_t ldc, int32_t rows, int32_t cols, float value, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); EwParams p = mk(kOpAddConst, C, ldc, rows, cols); p.a = value; return launch_ew(p, st); }
+extern "C" int k3_mat_apply_floor(float *C, int64_t ldc, int32_t rows, int32_t cols, float floor_val, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); EwParams p = mk(kOpFloor, C, ldc, rows, cols); p.a = floor_val; return launch_ew(p, st); }
+extern "C" int k3_mat_apply_ceiling(float *C, int64_t ldc, int32_t rows, int32_t cols, float ceil_val, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); EwParams p = mk(kOpCeil, C, ldc, rows, cols); p.a = ceil_val; return launch_ew(p, st); }
+extern "C" int k3_mat_copy_rows_from_vec(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_v, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_v, "k3_mat_copy_rows_from_vec: null vector"); EwParams p = mk(kOpCopyRowsFromVec, C, ldc, rows, cols); p.v = d_v; return launch_ew(p, st); }
+extern "C" int k3_mat_mul_cols_vec(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_scale, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_scale, "k3_mat_mul_cols_vec: null vector"); EwParams p = mk(kOpMulColsVec, C, ldc, rows, cols); p.v = d_scale; return launch_ew(p, st); }
+extern "C" int k3_mat_mul_rows_vec(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_scale, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_scale, "k3_mat_mul_rows_vec: null vector"); EwParams p = mk(kOpMulRowsVec, C, ldc, rows, cols); p.v = d_scale; return launch_ew(p, st); }
+extern "C" int k3_mat_add_vec_to_rows(float alpha, const float *d_row, float beta, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_row, "k3_mat_add_vec_to_rows: null vector"); EwParams p = mk(kOpAddVecToRows, C, ldc, rows, cols); p.v = d_row; p.a = alpha; p.b = beta; return launch_ew(p, st); }
+extern "C" int k3_mat_add_vec_to_cols(float alpha, const float *d_col, float beta, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_col, "k3_mat_add_vec_to_cols: null vector"); EwParams p = mk(kOpAddVecToCols, C, ldc, rows, cols); p.v = d_col; p.a = alpha; p.b = beta; return launch_ew(p, st); }
+extern "C" int k3_mat_copy_from_mat(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, int32_t trans, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && lds >= (trans ? rows : cols), "k3_mat_copy_from_mat: bad source"); EwParams p = mk(trans ? kOpCopyT : kOpCopy, C, ldc, rows, cols); p.S = d_src; p.lds = lds; return launch_ew(p, st); }
+extern "C" int k3_mat_add_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_A && lda >= (trans_a ? rows : cols), "k3_mat_add_mat: bad source"); EwParams p = mk(trans_a ? kOpAddMatT : kOpAddMat, C, ldc, rows, cols); p.S = d_A; p.lds = lda; p.a = alpha; return launch_ew(p, st); }
+extern "C" int k3_mat_copy_rows(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_indexes && lds >= cols, "k3_mat_copy_rows: bad source"); EwParams p = mk(kOpCopyRows, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_indexes; return launch_ew(p, st); }
+extern "C" int k3_mat_add_rows(float alpha, const float *d_src, int64_t lds, const int32_t *d_indexes, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_indexes && lds >= cols, "k3_mat_add_rows: bad source"); EwParams p = mk(kOpAddRows, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_indexes; p.a = alpha; return launch_ew(p, st); }

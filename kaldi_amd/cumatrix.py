@@ -1,0 +1,35 @@
+"""CuMatrix-style view over a torch CUDA tensor whose methods call the k3_mat_* C ABI (include/k3hip.h): the Python mirror of
+the adapter a Kaldi build would put under cudamatrix/cu-matrix.cc.  Method names and argument order follow CuMatrixBase
+(cudamatrix/cu-matrix.h:79-791); kTrans/kNoTrans as booleans."""
+import ctypes, torch
+from . import lib as _l
+
+def _st(): return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+class CuMatrix:
+    def __init__(self, t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+        self.t = t; self._L = _l.load()
+    def NumRows(self): return self.t.shape[0]
+    def NumCols(self): return self.t.shape[1]
+    def Stride(self): return self.t.stride(0)
+    def _a(self): return (self.t.data_ptr(), self.Stride(), self.NumRows(), self.NumCols())
+    def AddMatMat(self, alpha, A, transA, B, transB, beta):
+        M, N = self.NumRows(), self.NumCols(); K = A.NumRows() if transA else A.NumCols()
+        assert (A.NumCols() if transA else A.NumRows()) == M and (B.NumRows() if transB else B.NumCols()) == N and (B.NumCols() if transB else B.NumRows()) == K
+        _l.check(self._L.k3_mat_add_mat_mat(alpha, A.t.data_ptr(), A.Stride(), int(transA), B.t.data_ptr(), B.Stride(), int(transB), beta, self.t.data_ptr(), self.Stride(), M, N, K, _st()))
+    def SetZero(self): self.Set(0.0)
+    def Set(self, v): _l.check(self._L.k3_mat_set(*self._a(), v, _st()))
+    def Scale(self, v): _l.check(self._L.k3_mat_scale(*self._a(), v, _st()))
+    def Add(self, v): _l.check(self._L.k3_mat_add(*self._a(), v, _st()))
+    def ApplyFloor(self, v): _l.check(self._L.k3_mat_apply_floor(*self._a(), v, _st()))
+    def ApplyCeiling(self, v): _l.check(self._L.k3_mat_apply_ceiling(*self._a(), v, _st()))
+    def CopyRowsFromVec(self, v): _l.check(self._L.k3_mat_copy_rows_from_vec(*self._a(), v.data_ptr(), _st()))
+    def MulColsVec(self, v): _l.check(self._L.k3_mat_mul_cols_vec(*self._a(), v.data_ptr(), _st()))
+    def MulRowsVec(self, v): _l.check(self._L.k3_mat_mul_rows_vec(*self._a(), v.data_ptr(), _st()))
+    def AddVecToRows(self, alpha, row, beta=1.0): _l.check(self._L.k3_mat_add_vec_to_rows(alpha, row.data_ptr(), beta, *self._a(), _st()))
+    def AddVecToCols(self, alpha, col, beta=1.0): _l.check(self._L.k3_mat_add_vec_to_cols(alpha, col.data_ptr(), beta, *self._a(), _st()))
+    def CopyFromMat(self, M, trans=False): _l.check(self._L.k3_mat_copy_from_mat(*self._a(), M.t.data_ptr(), M.Stride(), int(trans), _st()))
+    def AddMat(self, alpha, A, transA=False): _l.check(self._L.k3_mat_add_mat(alpha, A.t.data_ptr(), A.Stride(), int(transA), *self._a(), _st()))
+    def CopyRows(self, src, indexes): _l.check(self._L.k3_mat_copy_rows(*self._a(), src.t.data_ptr(), src.Stride(), indexes.data_ptr(), _st()))
+    def AddRows(self, alpha, src, indexes): _l.check(self._L.k3_mat_add_rows(alpha, src.t.data_ptr(), src.Stride(), indexes.data_ptr(), *self._a(), _st()))

@@ -77,6 +77,15 @@ def load():
     L.k3_decoder_set_profiling.argtypes = [vp, i32]; L.k3_decoder_kernel_times.argtypes = [vp, vp]
     L.k3_decoder_phase_cycles.argtypes = [vp, vp]
     L.k3_decoder_frame_stats.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    f32 = ctypes.c_float
+    L.k3_mat_add_mat_mat.argtypes = [f32, vp, i64, i32, vp, i64, i32, f32, vp, i64, i32, i32, i32, vp]
+    for n in ("set", "scale", "add", "apply_floor", "apply_ceiling"): getattr(L, "k3_mat_" + n).argtypes = [vp, i64, i32, i32, f32, vp]
+    for n in ("copy_rows_from_vec", "mul_cols_vec", "mul_rows_vec"): getattr(L, "k3_mat_" + n).argtypes = [vp, i64, i32, i32, vp, vp]
+    for n in ("add_vec_to_rows", "add_vec_to_cols"): getattr(L, "k3_mat_" + n).argtypes = [f32, vp, f32, vp, i64, i32, i32, vp]
+    L.k3_mat_copy_from_mat.argtypes = [vp, i64, i32, i32, vp, i64, i32, vp]
+    L.k3_mat_add_mat.argtypes = [f32, vp, i64, i32, vp, i64, i32, i32, vp]
+    L.k3_mat_copy_rows.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp]
+    L.k3_mat_add_rows.argtypes = [f32, vp, i64, vp, vp, i64, i32, i32, vp]
     _lib = L
     return L
 
