@@ -152,9 +152,13 @@ def main():
                                   "note": "exact sum(2MNK) of the launched GEMMs / HIP-event time of the forward on the launch stream; FP32 MFMA peak (the only MFMA class inside the 1e-4 bound)"}}
         if dec is not None:
             info = dec.LatticeInfo(); ab = dec.algorithmic_bytes(info); gbs = ab / (acc[4] * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+            line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": ab,
                                 "note": "algorithmic bytes (SURVEY 8d: 32 B/emitting arc traversed + 28 B/eps arc traversed + 16 B/token) from device counters / HIP-event time of the kernel on its launch stream; "
                                         "the kernel is bound by the 333-step frame recurrence (dependent-latency chain per lane), not by bandwidth"}
+            try:      # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot collect counters itself)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+                if U == 512 and args.utt_seconds == 10.0: line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]; line["roofline"]["traffic_source"] = tj["source"]
+            except Exception: pass
             line["decode_stats"] = {"graph_broadcast_s": t_bcast if world > 1 else 0.0, "emitting_arcs_traversed": int(info[:, 7].sum()), "eps_arcs_traversed": int(info[:, 8].sum()), "tokens": int(info[:, 4].sum()),
                                     "links": int(info[:, 5].sum()), "max_tokens_on_a_frame": int(info[:, 6].max()), "lattice_states": lat_sizes[0], "lattice_arcs": lat_sizes[1],
                                     "reached_final_frac": float(info[:, 3].mean()), "algorithmic_bytes": ab}
