@@ -67,10 +67,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    local %= max(1, torch.cuda.device_count())       # (a 1-GPU box can rehearse the N > 1 path with K3_DIST_BACKEND=gloo: all ranks share the device)
     torch.cuda.set_device(local); dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("K3_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI
+        if backend == "nccl": dist.init_process_group("nccl", device_id=dev)
+        else: dist.init_process_group(backend)
     import __graft_entry__ as ge
     if rank == 0: ge.build()
     if world > 1: dist.barrier()
