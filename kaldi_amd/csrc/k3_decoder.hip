@@ -67,8 +67,10 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
 
 #ifdef K3_DEC_PROF
 #define K3_T(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); p.prof[blockIdx.x * 16 + (i)] += now__ - t_last__; t_last__ = now__; } } while (0)
+#define K3_TW(i) do { __builtin_amdgcn_s_waitcnt(0); K3_T(i); } while (0)      /* drain this wave's memory ops first: attributes load latency to the segment */
 #else
 #define K3_T(i) do { } while (0)
+#define K3_TW(i) do { } while (0)
 #endif
 struct DecParams {
   long long *prof;   // [nlanes x 16] cycle counters per phase (only with -DK3_DEC_PROF)
@@ -119,6 +121,11 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return v;
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
@@ -299,7 +306,7 @@ __device__ unsigned block_select_kth(const unsigned *keys, int n, int k, Shared 
 // ProcessNonemitting (lattice-faster-decoder.cc:830-897): relax eps arcs until no cost changes, with tot < cutoff;
 // the links a token ends up with are exactly its eps arcs with cur + graph < cutoff at its final cost.
 __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, const Table &tb, float cutoff, long long nb, int *tok_state, unsigned *tok_cost,
-                                             Link *links, int *link_arc, int *tok_slot, int *wl, long long &t_last__) {
+                                             Link *links, int *link_arc, int *tok_slot, int *wl, long long &t_last__, unsigned &cnt_eps) {
   const int tid = threadIdx.x, lane = tid & 63;
   __syncthreads();
   if (tid == 0) { sh.n_wl[0] = 0; sh.n_wl[1] = 0; }
@@ -314,20 +321,25 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
     const int *wl_cur = round == 1 ? tok_slot : wl + (long long)cur * p.frame_tokens_cap;
     int *wl_nxt = wl + (long long)(round == 1 ? 0 : (cur ^ 1)) * p.frame_tokens_cap;
     int *n_nxt = &sh.n_wl[round == 1 ? 0 : (cur ^ 1)];
+    K3_T(8);
     for (int i = tid; i < kHL / 32; i += kBlock) tb.lmark[i] = 0;
     __syncthreads();
+    K3_T(11);
     for (int i0 = 0; i0 < n; i0 += kBlock) {
       const int i = i0 + tid; const bool v = i < n;
-      int beg = 0, deg = 0; float c = 0.0f;
+      int beg = 0, deg = 0; float c = 0.0f; int slot_ = 0;
+      if (v) slot_ = wl_cur[i];
+      K3_TW(12);
       if (v) {
-        const int slot = wl_cur[i];
+        const int slot = slot_;
         c = dec(tb.cost(slot));
         if (c < cutoff) { const int st = tb.key(slot); const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
       }
+      K3_TW(13);
       wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
         const float oc = __shfl(c, owner);
         bool claimed = false, push = false; int slot2 = -1, nxt = 0;
-        { const unsigned long long mv = __ballot(valid); if (lane == 0 && mv) atomicAdd(&sh.n_eps, (unsigned long long)__popcll(mv)); }
+        cnt_eps += valid;
         if (valid) {
           const ArcRec r = p.arcs[arc];
           const float tot = oc + r.w; nxt = r.next;
@@ -349,8 +361,10 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         const int pos = wave_append(push, n_nxt);
         if (push) { if (pos < p.frame_tokens_cap) wl_nxt[pos] = slot2; else sh.err = K3_ERR_OVERFLOW; }
       });
+      K3_TW(14);
     }
     __syncthreads();
+    K3_T(15);
     if (round == 1) cur = 0;
     else { if (tid == 0) sh.n_wl[cur] = 0; cur ^= 1; }
     __syncthreads();
@@ -436,7 +450,8 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   }
   __syncthreads();
   long long t_last__ = (long long)__builtin_readcyclecounter();
-  finish_frame(p, sh, tb, p.beam, 0, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__);
+  unsigned cnt_eps = 0, cnt_emit = 0;      // per-thread arc counters (reduced once at the end of the kernel)
+  finish_frame(p, sh, tb, p.beam, 0, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__, cnt_eps);
   long long cur_base = 0; int n_cur = sh.n_next; int max_frame = n_cur;
   __syncthreads();
   if (tid == 0) { tok_off[1] = n_cur; loff_e[0] = sh.n_link; }
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
         const float oc = __shfl(c, owner); const int ot = __shfl(t, owner);
         bool pass = false; float tot = 0.0f, ac = 0.0f; int nxt = 0;
-        { const unsigned long long mv = __ballot(valid); if (lane == 0 && mv) atomicAdd(&sh.n_emit, (unsigned long long)__popcll(mv)); }
+        cnt_emit += valid;
         if (valid) {
           const ArcRec r = p.arcs[arc];
           ac = co - ll[r.pdf]; tot = oc + ac + r.w; nxt = r.next;
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     K3_T(5);
     if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
     // ---- ProcessNonemitting(next_cutoff) + eps links + publish the frame
-    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__);
+    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__, cnt_eps);
     if (block_err(sh)) break;
     cur_base = nb; n_cur = sh.n_next; max_frame = n_cur > max_frame ? n_cur : max_frame;
     if (prefetch) {
@@ -576,6 +591,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     __syncthreads();
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
   }
+  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit); if (lane == 0) { atomicAdd(&sh.n_eps, a); atomicAdd(&sh.n_emit, b); } }
   __syncthreads();
   if (tid == 0) {
     LaneInfo &li = p.info[L];

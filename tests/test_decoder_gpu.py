@@ -37,6 +37,7 @@ def _sub_lattice(small, big):
     dict(S=300, A=700, N=20, T=[40, 40, 3], seed=3, cfg=dict(beam=6.0, lattice_beam=4.0, max_active=10000, min_active=200)),     # min_active loosens the beam
     dict(S=5000, A=14000, N=200, T=[120], seed=4, cfg=dict(beam=16.0, lattice_beam=10.0, max_active=2**31 - 1, min_active=0)),  # plain beam branch
     dict(S=20000, A=50000, N=500, T=[80, 64], seed=5, cfg=dict(beam=15.0, lattice_beam=8.0, max_active=7000)),
+    dict(S=6000, A=15000, N=8000, T=[30, 12], seed=6, cfg=dict(beam=15.0, lattice_beam=8.0, max_active=10000)),                 # > 7168 pdfs: the log-likelihood row is read from HBM, not staged in LDS
 ])
 def test_raw_lattice_matches_oracle(case):
     from oracle import lattice_oracle as lo

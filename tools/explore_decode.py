@@ -35,6 +35,6 @@ audio = U * secs; print("audio-s", audio)
 import ctypes
 from kaldi_amd import lib as _l
 cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
-names = ["(loop top/err)", "cutoff", "prepass", "expand", "pass2 insert", "links", "-", "eps worklist build", "eps rounds", "eps links", "finalize+clear"]
+names = ["(loop top/err)", "cutoff", "prepass", "expand", "pass2 insert", "links", "-", "eps worklist build", "round:err-barriers", "eps links", "finalize+clear", "round:mark-clear+barrier", "round:wl read", "round:cost+offs", "round:expand(arcs,claims,stores)", "round:end barrier"]
 tot = cyc.sum()
 if tot: print("phase share:", {n: round(100.0 * c / tot, 1) for n, c in zip(names, cyc) if n != "-"}, "cycles/lane/frame", tot / U / 333 / 2)
