@@ -154,6 +154,14 @@ void k3_decoder_destroy(k3_decoder *dec);
  * over).  Asynchronous on `stream`; results are fetched with the calls below (which synchronise). */
 int k3_decoder_decode_batch(k3_decoder *dec, int32_t num_utts, const float *d_loglikes, int64_t ld,
                             const int64_t *h_row_offsets, void *stream);
+/* The same in the pieces of CudaDecoder's online interface (cuda-decoder.h:248-262, lanes == channels here): InitDecoding for num_utts
+ * lanes, AdvanceDecoding chunk by chunk (lane u consumes rows h_row_offsets[u]..[u+1] of this call's d_loglikes as its next frames; an
+ * empty range idles the lane), FinalizeDecoding = lattice-beam pruning with final-probs.  Chunked calls give results bit-identical to
+ * k3_decoder_decode_batch.  max_total_frames bounds the frames a lane receives between init and finalize. */
+int k3_decoder_init_decoding(k3_decoder *dec, int32_t num_utts, int32_t max_total_frames, void *stream);
+int k3_decoder_advance_decoding(k3_decoder *dec, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_offsets, void *stream);
+int k3_decoder_finalize_decoding(k3_decoder *dec, void *stream);
+int32_t k3_decoder_num_frames_decoded(const k3_decoder *dec, int32_t utt);     /* NumFramesDecoded(channel) */
 /* Per utterance: [0] lattice states, [1] lattice arcs, [2] status (0 ok, 1 no surviving tokens, <0 k3_status),
  * [3] reached_final (a final-state token was active on the last frame), [4] tokens created, [5] links created,
  * [6] max tokens on one frame, [7] emitting arcs traversed, [8] epsilon arcs traversed, [9] frames.

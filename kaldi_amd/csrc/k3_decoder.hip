@@ -62,6 +62,7 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
   int status, reached_final, max_frame_tokens, num_frames;
   int out_states, out_arcs;               // after pruning
   int live_overflow;                      // the survivor lists were too small: the output kernel rescans the pools
+  long long cur_base; int n_cur;          // resume point of AdvanceDecoding: first token / token count of the newest frame
   float final_best_cost; int final_empty;
 };
 
@@ -81,6 +82,7 @@ struct DecParams {
   int frame_tokens_cap, frame_cands_cap, hash_mask; long long lane_tokens_cap, lane_links_cap;
   // input
   const float *loglikes; long long ld; const long long *row_off; int num_pdfs; int use_lds_row;
+  int resume;                             // 0: InitDecoding first, frames are 0..T-1; 1: continue after LaneInfo::num_frames frames (AdvanceDecoding)
   // per-lane pools (lane l at base + l * stride)
   int *tok_state; unsigned *tok_cost; float *tok_extra; Link *links; int *link_arc;
   int *live_tok; long long *live_link; int *newidx; int live_cap;   // survivors of the pruning pass (pool indices), per lane
@@ -442,27 +444,36 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; }
   const Table tb{s_lkey, s_lcost, s_ltok, s_lmark, hash, mask};
   __syncthreads();
-  // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
-  if (tid == 0) {
-    bool cl; const int slot = tb.claim(p.start, &cl);
-    tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; sh.n_next = 1;
-    tok_off[0] = 0; loff_n[0] = 0;
-  }
-  __syncthreads();
   long long t_last__ = (long long)__builtin_readcyclecounter();
   unsigned cnt_eps = 0, cnt_emit = 0;      // per-thread arc counters (reduced once at the end of the kernel)
-  finish_frame(p, sh, tb, p.beam, 0, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__, cnt_eps);
-  long long cur_base = 0; int n_cur = sh.n_next; int max_frame = n_cur;
-  __syncthreads();
-  if (tid == 0) { tok_off[1] = n_cur; loff_e[0] = sh.n_link; }
-  int status = kStOk;
+  long long cur_base = 0; int n_cur = 0, max_frame = 0, f0 = 0, status = kStOk;
+  if (!p.resume) {
+    // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
+    if (tid == 0) {
+      bool cl; const int slot = tb.claim(p.start, &cl);
+      tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; sh.n_next = 1;
+      tok_off[0] = 0; loff_n[0] = 0;
+    }
+    __syncthreads();
+    finish_frame(p, sh, tb, p.beam, 0, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__, cnt_eps);
+    n_cur = sh.n_next; max_frame = n_cur;
+    __syncthreads();
+    if (tid == 0) { tok_off[1] = n_cur; loff_e[0] = sh.n_link; }
+  } else {
+    // ---- AdvanceDecoding on a later chunk: pick the lane up where the previous launch left it
+    const LaneInfo &li = p.info[L];
+    if (li.status != kStOk) return;
+    f0 = li.num_frames; cur_base = li.cur_base; n_cur = li.n_cur; max_frame = li.max_frame_tokens;
+    if (tid == 0) { sh.n_link = li.n_links; sh.n_eps = (unsigned long long)li.n_eps; sh.n_emit = (unsigned long long)li.n_cands; }
+    __syncthreads();
+  }
 
-  for (int f = 0; f < T; f++) {
+  for (int f = f0; f < f0 + T; f++) {
     if (block_err(sh)) break;
     // stage the log-likelihood row of this frame in LDS (coalesced), overlapped with the cutoff passes
     K3_T(0);
-    const float *row = p.loglikes + (r0 + f) * p.ld;
-    if (p.use_lds_row && f == 0) for (int i = tid; i < p.num_pdfs; i += kBlock) s_ll[i] = row[i];   // later rows are prefetched one frame ahead
+    const float *row = p.loglikes + (r0 + (f - f0)) * p.ld;
+    if (p.use_lds_row && f == f0) for (int i = tid; i < p.num_pdfs; i += kBlock) s_ll[i] = row[i];   // later rows are prefetched one frame ahead
     const float *ll = p.use_lds_row ? s_ll : row;
     const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
     if (n_cur == 0) { status = kStNoTokens; break; }
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     // the LDS row is dead from here on: fetch the next frame's row into registers now (the loads fly during the rest of the frame),
     // park it in LDS at the end of the frame
     float rowreg[kRowRegs];
-    const bool prefetch = p.use_lds_row && f + 1 < T;
+    const bool prefetch = p.use_lds_row && f + 1 < f0 + T;
     if (prefetch) {
 #pragma unroll
       for (int k = 0; k < kRowRegs; k++) { const int i = tid + k * kBlock; rowreg[k] = i < p.num_pdfs ? row[p.ld + i] : 0.0f; }
@@ -596,7 +607,8 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   if (tid == 0) {
     LaneInfo &li = p.info[L];
     li.n_tokens = cur_base + n_cur; li.n_links = sh.n_link; li.n_cands = (long long)sh.n_emit; li.n_eps = (long long)sh.n_eps; li.max_frame_tokens = max_frame;
-    li.status = sh.err ? sh.err : status; li.num_frames = T; li.reached_final = 0; li.out_states = 0; li.out_arcs = 0;
+    li.status = sh.err ? sh.err : status; li.num_frames = f0 + T; li.reached_final = 0; li.out_states = 0; li.out_arcs = 0;
+    li.cur_base = cur_base; li.n_cur = n_cur;
   }
 }
 
@@ -972,6 +984,7 @@ struct k3_decoder {
   hipStream_t last_stream = nullptr;
   std::vector<LaneInfo> h_info; bool info_valid = false;
   void *out_buf = nullptr; size_t out_bytes = 0;
+  bool started = false, finalized = false;
   bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
   ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); if (out_buf) (void)hipFree(out_buf); }
@@ -1051,45 +1064,82 @@ extern "C" int k3_decoder_kernel_times(k3_decoder *d, float *h_ms) {
   return K3_OK;
 }
 
-extern "C" int k3_decoder_decode_batch(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream) {
-  K3_REQUIRE(d && d_loglikes && h_row_off && num_utts > 0 && num_utts <= d->nlanes && ld >= d->num_pdfs, "k3_decoder_decode_batch: bad argument");
-  int maxT = 0; d->last_frames.resize(num_utts);
+static int ensure_frame_capacity(k3_decoder *d, int max_frames, hipStream_t st) {
+  DecParams &p = d->p;
+  if (max_frames + 2 <= d->fstride) return K3_OK;
+  K3_HIP_CHECK(hipStreamSynchronize(st));
+  for (void *q : d->frame_allocs) (void)hipFree(q);
+  d->frame_allocs.clear();
+  d->fstride = max_frames + 2; const size_t n = (size_t)d->nlanes * d->fstride; int rc;
+  if ((rc = dmalloc(&d->frame_allocs, &p.tok_off, n))) return rc;
+  if ((rc = dmalloc(&d->frame_allocs, &p.link_off_e, n))) return rc;
+  if ((rc = dmalloc(&d->frame_allocs, &p.link_off_n, n))) return rc;
+  if ((rc = dmalloc(&d->frame_allocs, &p.st_ntoks, n))) return rc;
+  if ((rc = dmalloc(&d->frame_allocs, &p.st_cur, n))) return rc;
+  if ((rc = dmalloc(&d->frame_allocs, &p.st_ab, n))) return rc;
+  if ((rc = dmalloc(&d->frame_allocs, &p.st_next, n))) return rc;
+  if ((rc = dmalloc(&d->frame_allocs, &p.st_co, n))) return rc;
+  p.fstride = d->fstride;
+  return K3_OK;
+}
+
+// InitDecoding for `num_utts` lanes (cuda-decoder.h:248 InitDecoding(channels)): the next k3_decoder_advance_decoding starts new utterances.
+// max_total_frames bounds the frames any lane will be advanced by before k3_decoder_finalize_decoding.
+extern "C" int k3_decoder_init_decoding(k3_decoder *d, int32_t num_utts, int32_t max_total_frames, void *stream) {
+  K3_REQUIRE(d && num_utts > 0 && num_utts <= d->nlanes && max_total_frames > 0, "k3_decoder_init_decoding: bad argument");
+  { const int rc = ensure_frame_capacity(d, max_total_frames, (hipStream_t)stream); if (rc) return rc; }
+  d->last_utts = num_utts; d->last_frames.assign(num_utts, 0); d->started = false; d->finalized = false; d->info_valid = false; d->last_stream = (hipStream_t)stream;
+  return K3_OK;
+}
+
+// AdvanceDecoding (cuda-decoder.h:262: AdvanceDecoding(lanes, loglikes)): lane u consumes rows h_row_offsets[u] .. [u+1] of d_loglikes as
+// its NEXT frames (zero rows = the lane idles in this call).  Chunked calls give bit-identical results to one call with all frames.
+extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream) {
+  K3_REQUIRE(d && d_loglikes && h_row_off && num_utts == d->last_utts && ld >= d->num_pdfs, "k3_decoder_advance_decoding: bad argument (call k3_decoder_init_decoding for this many lanes first)");
+  K3_REQUIRE(!d->finalized, "k3_decoder_advance_decoding: FinalizeDecoding was already called");
+  hipStream_t st = (hipStream_t)stream; DecParams &p = d->p;
   for (int u = 0; u < num_utts; u++) {
     const long long T = h_row_off[u + 1] - h_row_off[u];
-    K3_REQUIRE(T > 0 && T < (1 << 30), "k3_decoder_decode_batch: utterance with no frames");
-    d->last_frames[u] = (int)T; maxT = std::max(maxT, (int)T);
+    K3_REQUIRE(T >= 0 && d->last_frames[u] + T + 2 <= d->fstride, "k3_decoder_advance_decoding: more frames than max_total_frames of k3_decoder_init_decoding");
+    d->last_frames[u] += (int)T;
   }
-  hipStream_t st = (hipStream_t)stream;
-  DecParams &p = d->p;
-  if (maxT + 2 > d->fstride) {      // (re)allocate the per-frame arrays
-    K3_HIP_CHECK(hipStreamSynchronize(st));
-    for (void *q : d->frame_allocs) (void)hipFree(q);
-    d->frame_allocs.clear();
-    d->fstride = maxT + 2; const size_t n = (size_t)d->nlanes * d->fstride; int rc;
-    if ((rc = dmalloc(&d->frame_allocs, &p.tok_off, n))) return rc;
-    if ((rc = dmalloc(&d->frame_allocs, &p.link_off_e, n))) return rc;
-    if ((rc = dmalloc(&d->frame_allocs, &p.link_off_n, n))) return rc;
-    if ((rc = dmalloc(&d->frame_allocs, &p.st_ntoks, n))) return rc;
-    if ((rc = dmalloc(&d->frame_allocs, &p.st_cur, n))) return rc;
-    if ((rc = dmalloc(&d->frame_allocs, &p.st_ab, n))) return rc;
-    if ((rc = dmalloc(&d->frame_allocs, &p.st_next, n))) return rc;
-    if ((rc = dmalloc(&d->frame_allocs, &p.st_co, n))) return rc;
-    p.fstride = d->fstride;
-  }
-  std::vector<long long> ro(h_row_off, h_row_off + num_utts + 1);
-  K3_HIP_CHECK(hipMemcpyAsync(d->d_row_off, ro.data(), sizeof(long long) * (num_utts + 1), hipMemcpyHostToDevice, st));
-  K3_HIP_CHECK(hipStreamSynchronize(st));    // ro is a stack-scoped staging buffer
-  p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off;
+  K3_HIP_CHECK(hipStreamSynchronize(st));            // d_row_off may still be read by the previous chunk's kernel
+  K3_HIP_CHECK(hipMemcpy(d->d_row_off, h_row_off, sizeof(long long) * (num_utts + 1), hipMemcpyHostToDevice));
+  p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off; p.resume = d->started ? 1 : 0;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
-  hipLaunchKernelGGL(k3_decode_prune_kernel, dim3(num_utts), dim3(kPBlock), 0, st, p);
+  d->started = true; d->last_stream = st; d->info_valid = false;
+  return K3_OK;
+}
+
+// FinalizeDecoding (lattice-faster-decoder.cc:634-649) on the GPU: lattice-beam pruning with final-probs; lattices can be fetched afterwards.
+extern "C" int k3_decoder_finalize_decoding(k3_decoder *d, void *stream) {
+  K3_REQUIRE(d && d->started && !d->finalized, "k3_decoder_finalize_decoding: nothing to finalize");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k3_decode_prune_kernel, dim3(d->last_utts), dim3(kPBlock), 0, st, d->p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[2], st));
-  d->last_utts = num_utts; d->last_stream = st; d->info_valid = false;
+  d->finalized = true; d->last_stream = st; d->info_valid = false;
   return K3_OK;
+}
+
+extern "C" int32_t k3_decoder_num_frames_decoded(const k3_decoder *d, int32_t utt) { return (d && utt >= 0 && utt < d->last_utts) ? d->last_frames[utt] : -1; }
+
+extern "C" int k3_decoder_decode_batch(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream) {
+  K3_REQUIRE(d && d_loglikes && h_row_off && num_utts > 0 && num_utts <= d->nlanes && ld >= d->num_pdfs, "k3_decoder_decode_batch: bad argument");
+  int maxT = 0;
+  for (int u = 0; u < num_utts; u++) {
+    const long long T = h_row_off[u + 1] - h_row_off[u];
+    K3_REQUIRE(T > 0 && T < (1 << 30), "k3_decoder_decode_batch: utterance with no frames");
+    maxT = std::max(maxT, (int)T);
+  }
+  int rc;
+  if ((rc = k3_decoder_init_decoding(d, num_utts, maxT, stream))) return rc;
+  if ((rc = k3_decoder_advance_decoding(d, num_utts, d_loglikes, ld, h_row_off, stream))) return rc;
+  return k3_decoder_finalize_decoding(d, stream);
 }
 
 static int fetch_info(k3_decoder *d) {

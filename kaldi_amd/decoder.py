@@ -75,6 +75,21 @@ class CudaDecoder:
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _l.check(self._L.k3_decoder_decode_batch(self._h, self._n, loglikes.data_ptr(), loglikes.stride(0), ro.ctypes.data, st))
 
+    def InitDecoding(self, num_utts, max_total_frames):
+        self._n = num_utts
+        _l.check(self._L.k3_decoder_init_decoding(self._h, num_utts, int(max_total_frames), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def AdvanceDecoding(self, loglikes, row_offsets):
+        """the next chunk of frames for every lane: lane u gets rows row_offsets[u]..row_offsets[u+1] of `loglikes` (may be empty)"""
+        assert loglikes.is_cuda and loglikes.dtype == torch.float32 and loglikes.stride(1) == 1
+        ro = np.ascontiguousarray(row_offsets, np.int64); assert ro.size - 1 == self._n
+        _l.check(self._L.k3_decoder_advance_decoding(self._h, self._n, loglikes.data_ptr(), loglikes.stride(0), ro.ctypes.data, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def FinalizeDecoding(self):
+        _l.check(self._L.k3_decoder_finalize_decoding(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def NumFramesDecoded(self, utt): return self._L.k3_decoder_num_frames_decoded(self._h, utt)
+
     def LatticeInfo(self, check=True):
         """int64 [num_utts x 10], columns = CudaDecoder.INFO (synchronises)"""
         info = np.zeros((self._n, 10), np.int64)

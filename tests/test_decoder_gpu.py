@@ -92,3 +92,25 @@ def test_graph_image_export_import_is_the_broadcast_path():
     a, _, _ = _gpu_decode(cf, 50, [ll], beam=15.0, lattice_beam=8.0)
     b, _, _ = _gpu_decode(cf2, 50, [ll], beam=15.0, lattice_beam=8.0)
     assert a[0].num_arcs > 0 and a[0].diff(b[0]) == ""
+
+def test_chunked_advance_decoding_is_bit_identical_to_whole_utterance_decoding():
+    """InitDecoding / AdvanceDecoding (ragged chunks, incl. lanes that idle in a call) / FinalizeDecoding == DecodeBatch"""
+    from kaldi_amd import decoder
+    f, t2p, cf = _setup(3000, 8000, 80, 9, 60)
+    rng = np.random.default_rng(5); N = 80
+    lls = [(rng.standard_normal((T, N)) * 2.5).astype(np.float32) for T in (120, 45, 77)]
+    cfg = dict(beam=14.0, lattice_beam=7.0, max_active=3000)
+    whole, _, _ = _gpu_decode(cf, N, lls, **cfg)
+    dec = decoder.CudaDecoder(cf, decoder.decoder_config(**cfg), 3, N)
+    dec.InitDecoding(3, 130)
+    done = [0, 0, 0]
+    for chunk in ([50, 45, 0], [17, 0, 30], [53, 0, 47]):
+        parts = [lls[u][done[u]:done[u] + c] for u, c in enumerate(chunk)]
+        x = torch.from_numpy(np.concatenate(parts)).cuda()
+        dec.AdvanceDecoding(x, np.concatenate([[0], np.cumsum(chunk)]))
+        done = [d + c for d, c in zip(done, chunk)]
+        assert [dec.NumFramesDecoded(u) for u in range(3)] == done
+    dec.FinalizeDecoding()
+    lats = dec.GetRawLattices()
+    for u in range(3):
+        assert lats[u].num_arcs > 0 and lats[u].diff(whole[u]) == "", u
