@@ -260,13 +260,23 @@ struct Table {
   __device__ __forceinline__ int key(int id) const { return id < kHL ? K3_LLD(&lkey[id]) : K3_ALD(&g[id - kHL].key); }
   __device__ __forceinline__ int tok(int id) const { return id < kHL ? K3_LLD(&ltok[id]) : K3_ALD(&g[id - kHL].tok); }
   __device__ __forceinline__ void set_tok(int id, int t) const { if (id < kHL) __hip_atomic_store(&ltok[id], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else K3_AST(&g[id - kHL].tok, t); }
+  // token index of a slot some other thread claimed a moment ago: the claimer publishes it right after its claim (same
+  // program point for every lane of a wave, so lanes of one wave never wait on each other); bounded in case of a bug
+  __device__ __forceinline__ int wait_tok(int id, int *err) const {
+    for (int spin = 0; spin < (1 << 22); spin++) {
+      const int t = tok(id);
+      if (t >= 0) return t;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *err = K3_ERR_HIP; return 0;
+  }
   // true if the slot was not yet queued for round `stamp` (LDS slots: one bit per slot, cleared at the start of every round)
   __device__ __forceinline__ bool mark(int id, int stamp) const {
     if (id < kHL) { const unsigned bit = 1u << (id & 31); return (atomicOr(&lmark[id >> 5], bit) & bit) == 0; }
     return atomicExch(&g[id - kHL].stamp, stamp) != stamp;
   }
   __device__ __forceinline__ void clear(int id) const {
-    if (id < kHL) { lkey[id] = kEmpty; lcost[id] = kEncMax; }
+    if (id < kHL) { lkey[id] = kEmpty; lcost[id] = kEncMax; ltok[id] = -1; }
     else { Slot *q = &g[id - kHL]; K3_AST(&q->cost, kEncMax); K3_AST(&q->stamp, 0); K3_AST(&q->tok, -1); K3_AST(&q->key, kEmpty); }
   }
 };
@@ -329,39 +339,53 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
     K3_T(11);
     for (int i0 = 0; i0 < n; i0 += kBlock) {
       const int i = i0 + tid; const bool v = i < n;
-      int beg = 0, deg = 0; float c = 0.0f; int slot_ = 0;
+      int beg = 0, deg = 0, ti = 0; unsigned cb = 0; int slot_ = 0;
       if (v) slot_ = wl_cur[i];
       K3_TW(12);
       if (v) {
         const int slot = slot_;
-        c = dec(tb.cost(slot));
-        if (c < cutoff) { const int st = tb.key(slot); const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
+        cb = tb.cost(slot);
+        if (dec(cb) < cutoff) {
+          const int st = tb.key(slot); ti = tb.tok(slot);
+          const int2 a = p.offs[st], b = p.offs[st + 1];
+          // a token is expanded once per cost value: tok_cost holds the cost of its latest expansion until the frame is published
+          const unsigned prev = atomicExch(&tok_cost[nb + ti], cb);
+          if (prev != cb) { beg = a.y; deg = b.x - a.y; }
+        }
       }
       K3_TW(13);
       wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
-        const float oc = __shfl(c, owner);
-        bool claimed = false, push = false; int slot2 = -1, nxt = 0;
+        const unsigned ocb = __shfl(cb, owner); const int oti = __shfl(ti, owner);
+        const float oc = dec(ocb);
+        bool claimed = false, push = false, mk = false; int slot2 = -1, nxt = 0; float tot = 0.0f;
         cnt_eps += valid;
         if (valid) {
           const ArcRec r = p.arcs[arc];
-          const float tot = oc + r.w; nxt = r.next;
+          tot = oc + r.w; nxt = r.next;
           if (tot < cutoff) {
             slot2 = tb.claim(r.next, &claimed);
             if (slot2 < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; }
             else {
+              mk = true;
               const unsigned e = enc(tot);
               const unsigned old = tb.cost_min(slot2, e);
               if (e < old) push = tb.mark(slot2, round + 1);
             }
           }
         }
-        const int idx = wave_append(claimed, &sh.n_next);
+        int idx = wave_append(claimed, &sh.n_next);
         if (claimed) {
-          if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tb.set_tok(slot2, idx); tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; }
-          else sh.err = K3_ERR_OVERFLOW;
+          if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; tok_cost[nb + idx] = kEncMax; }
+          else { sh.err = K3_ERR_OVERFLOW; idx = 0; }
+          tb.set_tok(slot2, idx);
         }
         const int pos = wave_append(push, n_nxt);
         if (push) { if (pos < p.frame_tokens_cap) wl_nxt[pos] = slot2; else sh.err = K3_ERR_OVERFLOW; }
+        // the eps link of this arc at the source's present cost; links written at a cost the source later improves on
+        // are recognised as stale by their stamp (Link::ac of an eps link = the source cost it was created at)
+        if (mk && !claimed) idx = tb.wait_tok(slot2, &sh.err);
+        const long long lp = wave_append64(mk, &sh.n_link);
+        if (mk) { if (lp < p.lane_links_cap) { links[lp] = Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}; link_arc[lp] = arc; } else sh.err = K3_ERR_OVERFLOW; }
       });
       K3_TW(14);
     }
@@ -370,35 +394,6 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
     if (round == 1) cur = 0;
     else { if (tid == 0) sh.n_wl[cur] = 0; cur ^= 1; }
     __syncthreads();
-  }
-  if (block_err(sh)) return;
-  K3_T(8);
-  // eps links at the final costs
-  {
-    const int n = sh.n_next;
-    for (int i0 = 0; i0 < n; i0 += kBlock) {
-      const int i = i0 + tid; const bool v = i < n;
-      int beg = 0, deg = 0; float c = 0.0f;
-      if (v) {
-        const int slot = tok_slot[i];
-        c = dec(tb.cost(slot));
-        if (c < cutoff) { const int st = tb.key(slot); const int2 a = p.offs[st], b = p.offs[st + 1]; beg = a.y; deg = b.x - a.y; }
-      }
-      wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
-        const float oc = __shfl(c, owner); const int oi = __shfl(i, owner);
-        bool mk = false; int dtok = 0; float tot = 0.0f;
-        if (valid) {
-          const ArcRec r = p.arcs[arc];
-          tot = oc + r.w;
-          if (tot < cutoff) {
-            const int s2 = tb.find(r.next);
-            if (s2 >= 0) { mk = true; dtok = tb.tok(s2); } else sh.err = K3_ERR_HIP;   // cannot happen at the fixpoint
-          }
-        }
-        const long long pos = wave_append64(mk, &sh.n_link);
-        if (mk) { if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(nb + oi), (unsigned)(nb + dtok), tot, 0.0f}; link_arc[pos] = arc; } else sh.err = K3_ERR_OVERFLOW; }
-      });
-    }
   }
   if (block_err(sh)) return;
   K3_T(9);
@@ -411,7 +406,7 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
       if (slot >= kHL) tb.clear(slot);
     }
     __syncthreads();
-    for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; }
+    for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }
   }
   (void)lane;
   __syncthreads();
@@ -441,7 +436,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   const float kInf = __builtin_inff();
 
   if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; }
-  for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; }
+  for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; s_ltok[i] = -1; }
   const Table tb{s_lkey, s_lcost, s_ltok, s_lmark, hash, mask};
   __syncthreads();
   long long t_last__ = (long long)__builtin_readcyclecounter();
@@ -451,7 +446,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
     if (tid == 0) {
       bool cl; const int slot = tb.claim(p.start, &cl);
-      tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; sh.n_next = 1;
+      tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; tok_cost[0] = kEncMax; sh.n_next = 1;
       tok_off[0] = 0; loff_n[0] = 0;
     }
     __syncthreads();
@@ -557,34 +552,29 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     { const unsigned mt = sh.min_tot; if (mt != kEncMax) { const float t = dec(mt) + ab; if (t < accept) accept = t; } }
     const int n_cand = sh.n_cand;
     const long long nb = cur_base + n_cur;
-    for (int j0 = 0; j0 < n_cand; j0 += kBlock) {
-      const int j = j0 + tid; bool claimed = false; int slot = -1, nxt = 0;
-      if (j < n_cand) {
-        const float tot = c_tot[j];
-        if (tot < accept) {
-          nxt = c_dst[j];
-          slot = tb.claim(nxt, &claimed);
-          if (slot < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; } else tb.cost_min(slot, enc(tot));
-          c_dst[j] = slot;
-        } else c_arc[j] = -1;
-      }
-      const int idx = wave_append(claimed, &sh.n_next);
-      if (claimed) {
-        if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tb.set_tok(slot, idx); tok_slot[idx] = slot; tok_state[nb + idx] = nxt; }
-        else sh.err = K3_ERR_OVERFLOW;
-      }
-    }
-    if (block_err(sh)) break;
-    K3_T(4);
-    // ---- forward links of the accepted arcs (:803-806)
     if (tid == 0) loff_e[f] = sh.n_link;
     __syncthreads();
     for (int j0 = 0; j0 < n_cand; j0 += kBlock) {
-      const int j = j0 + tid; bool mk = false; int arc = -1;
-      if (j < n_cand) { arc = c_arc[j]; mk = arc >= 0 && c_dst[j] >= 0; }
+      const int j = j0 + tid; bool claimed = false, mk = false; int slot = -1, nxt = 0; float tot = 0.0f;
+      if (j < n_cand) {
+        tot = c_tot[j];
+        if (tot < accept) {
+          nxt = c_dst[j];
+          slot = tb.claim(nxt, &claimed);
+          if (slot < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; } else { tb.cost_min(slot, enc(tot)); mk = true; }
+        }
+      }
+      int idx = wave_append(claimed, &sh.n_next);
+      if (claimed) {
+        if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot; tok_state[nb + idx] = nxt; tok_cost[nb + idx] = kEncMax; }
+        else { sh.err = K3_ERR_OVERFLOW; idx = 0; }
+        tb.set_tok(slot, idx);
+      }
+      // ---- forward link of the accepted arc (:803-806)
+      if (mk && !claimed) idx = tb.wait_tok(slot, &sh.err);
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
-        if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + c_src[j]), (unsigned)(nb + tb.tok(c_dst[j])), c_tot[j], c_ac[j]}; link_arc[pos] = arc; }
+        if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + c_src[j]), (unsigned)(nb + idx), tot, c_ac[j]}; link_arc[pos] = c_arc[j]; }
         else sh.err = K3_ERR_OVERFLOW;
       }
     }
@@ -619,6 +609,10 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
 __device__ __forceinline__ float link_extra_cost(float next_extra, float via_link_tot, float next_tot) {
   return next_extra + (via_link_tot - next_tot);      // next_tok->extra_cost + ((tok->tot_cost + ac + graph) - next_tok->tot_cost), :339-341
 }
+
+// eps links are written while the closure is still running; one whose source token was improved afterwards is stale:
+// its stamp (Link::ac) is not the final cost of its source (k3_decode_forward_kernel, finish_frame)
+__device__ __forceinline__ bool eps_link_live(const Link &k, unsigned src_cost_enc) { return __float_as_uint(k.ac) == src_cost_enc; }
 
 constexpr int kPCap = 2048;      // frames with at most this many tokens are pruned entirely inside LDS
 
@@ -675,6 +669,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
       __syncthreads();
       for (long long l = l0 + tid; l < l1; l += kPBlock) {
         const Link k = links[l];
+        if (!eps_link_live(k, tok_cost[k.src])) continue;
         float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
         if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - tb], enc(le)); }
       }
@@ -691,7 +686,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
     for (long long t = tb + tid; t < te; t += kPBlock) if (extra[t] != kInf) keep_tok(t);
     for (long long l = l0 + tid; l < l1; l += kPBlock) {
       const Link k = links[l];
-      if (extra[k.src] != kInf && !(link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])) > lb)) keep_link(l);
+      if (eps_link_live(k, tok_cost[k.src]) && extra[k.src] != kInf && !(link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])) > lb)) keep_link(l);
     }
   }
   __syncthreads();
@@ -713,6 +708,9 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
 #pragma unroll
       for (int k = 0; k < kEpsRegs; k++) { const int i = tid + k * kPBlock; if (i < neps) er[k] = links[n0 + i]; }
       __syncthreads();
+      unsigned elive = 0;
+#pragma unroll
+      for (int k = 0; k < kEpsRegs; k++) { const int i = tid + k * kPBlock; if (i < neps && eps_link_live(er[k], enc(ccost[er[k].src - b0]))) elive |= 1u << k; }
       for (long long l = e0 + tid; l < e1; l += kPBlock) {
         const Link k = links[l];
         float le = link_extra_cost(nextra[k.dst - b1], k.tot, ncost[k.dst - b1]);
@@ -729,14 +727,14 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
           __syncthreads();
 #pragma unroll
           for (int k = 0; k < kEpsRegs; k++) {
-            const int i = tid + k * kPBlock;
-            if (i < neps) {
+            if (elive >> k & 1) {
               float le = link_extra_cost(cextra[er[k].dst - b0], er[k].tot, ccost[er[k].dst - b0]);
               if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&s_xn[er[k].src - b0], enc(le)); }
             }
           }
           for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) {       // (rare) more eps links than fit in registers
             const Link k = links[l];
+            if (!eps_link_live(k, enc(ccost[k.src - b0]))) continue;
             float le = link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]);
             if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&s_xn[k.src - b0], enc(le)); }
           }
@@ -753,9 +751,9 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
 #pragma unroll
         for (int k = 0; k < kEpsRegs; k++) {
           const int i = tid + k * kPBlock;
-          if (i < neps && !(link_extra_cost(cextra[er[k].dst - b0], er[k].tot, ccost[er[k].dst - b0]) > lb)) keep_link(n0 + i);
+          if ((elive >> k & 1) && !(link_extra_cost(cextra[er[k].dst - b0], er[k].tot, ccost[er[k].dst - b0]) > lb)) keep_link(n0 + i);
         }
-        for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (!(link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]) > lb)) keep_link(l); }
+        for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (eps_link_live(k, enc(ccost[k.src - b0])) && !(link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]) > lb)) keep_link(l); }
       }
       nbuf ^= 1; next_in_lds = true;
       __syncthreads();
@@ -782,6 +780,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
         __syncthreads();
         for (long long l = n0 + tid; l < n1; l += kPBlock) {
           const Link k = links[l];
+          if (!eps_link_live(k, tok_cost[k.src])) continue;
           float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
           if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - b0], enc(le)); }
         }
@@ -795,7 +794,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
         if (!s_changed) break;
       }
       for (long long t = b0 + tid; t < b1; t += kPBlock) if (extra[t] != kInf) keep_tok(t);
-      for (long long l = n0 + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (!(link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])) > lb)) keep_link(l); }
+      for (long long l = n0 + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (eps_link_live(k, tok_cost[k.src]) && !(link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])) > lb)) keep_link(l); }
     }
     __syncthreads();
   }
@@ -842,7 +841,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, 
       const bool emitting = l >= loff_e[lo];
       const int arc = link_arc[l]; const ArcRec r = p.arcs[arc];
       o.arc_src[ao + i] = newidx[k.src]; o.arc_dst[ao + i] = newidx[k.dst]; o.arc_il[ao + i] = p.arc_ilabel[arc]; o.arc_ol[ao + i] = r.olabel;
-      o.arc_g[ao + i] = r.w; o.arc_ac[ao + i] = emitting ? (k.ac - st_co[lo]) : (k.ac - 0.0f);
+      o.arc_g[ao + i] = r.w; o.arc_ac[ao + i] = emitting ? (k.ac - st_co[lo]) : 0.0f;
     }
     return;
   }
@@ -875,14 +874,14 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, 
         const long long l = x0 + tid; bool v = l < l1; Link k{};
         if (v) {
           k = links[l];
-          v = extra[k.src] != kInf;
+          v = extra[k.src] != kInf && (part == 1 || eps_link_live(k, tok_cost[k.src]));
           if (v) { const float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])); v = !(le > lb); }
         }
         const int pos = wave_append(v, &s_n);
         if (v) {
           const int arc = link_arc[l]; const ArcRec r = p.arcs[arc];
           o.arc_src[ao + pos] = newidx[k.src]; o.arc_dst[ao + pos] = newidx[k.dst]; o.arc_il[ao + pos] = p.arc_ilabel[arc]; o.arc_ol[ao + pos] = r.olabel;
-          o.arc_g[ao + pos] = r.w; o.arc_ac[ao + pos] = part ? (k.ac - st_co[f]) : (k.ac - 0.0f);
+          o.arc_g[ao + pos] = r.w; o.arc_ac[ao + pos] = part ? (k.ac - st_co[f]) : 0.0f;
         }
       }
     }

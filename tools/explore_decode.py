@@ -38,3 +38,5 @@ cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctyp
 names = ["(loop top/err)", "cutoff", "prepass", "expand", "pass2 insert", "links", "-", "eps worklist build", "round:err-barriers", "eps links", "finalize+clear", "round:mark-clear+barrier", "round:wl read", "round:cost+offs", "round:expand(arcs,claims,stores)", "round:end barrier"]
 tot = cyc.sum()
 if tot: print("phase share:", {n: round(100.0 * c / tot, 1) for n, c in zip(names, cyc) if n != "-"}, "cycles/lane/frame", tot / U / 333 / 2)
+allnt = np.concatenate([dec.FrameStats(u, int(nb.out_offsets[u + 1] - nb.out_offsets[u]))["ntoks"] for u in range(0, U, max(1, U // 32))])
+print("ntoks percentiles 10/50/75/90/95/99/max:", [int(np.percentile(allnt, q)) for q in (10, 50, 75, 90, 95, 99, 100)], "frac <= 1024:", float((allnt <= 1024).mean()), "<= 2048:", float((allnt <= 2048).mean()), "<= 3072:", float((allnt <= 3072).mean()))
