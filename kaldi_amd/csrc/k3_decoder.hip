@@ -67,7 +67,10 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
 };
 
 #ifdef K3_DEC_PROF
-#define K3_T(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); p.prof[blockIdx.x * 16 + (i)] += now__ - t_last__; t_last__ = now__; } } while (0)
+#ifndef K3_DEC_PROF_MAXTOK
+#define K3_DEC_PROF_MAXTOK 0x7FFFFFFF      /* count only frames built from at most this many tokens */
+#endif
+#define K3_T(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); if (sh.prof_n <= K3_DEC_PROF_MAXTOK) sh.prof[i] += now__ - t_last__; t_last__ = now__; } } while (0)
 #define K3_TW(i) do { __builtin_amdgcn_s_waitcnt(0); K3_T(i); } while (0)      /* drain this wave's memory ops first: attributes load latency to the segment */
 #else
 #define K3_T(i) do { } while (0)
@@ -110,6 +113,7 @@ struct Shared {
   unsigned min_tot;
   long long n_link;
   unsigned long long bcast64;
+  int prof_n; long long prof[16];
 };
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
@@ -183,21 +187,26 @@ __device__ __forceinline__ long long wave_append64(bool pred, long long *counter
 // 64 (begin, degree) pairs, one per lane -> f(valid, arc, owner_lane) once per arc, one arc per lane per step.
 // Every lane of the wavefront must call this (uniform control flow); f must keep the wavefront converged.
 template <typename F>
-__device__ __forceinline__ void wave_expand(int beg, int deg, F &&f) {
+__device__ __forceinline__ void wave_expand(const ArcRec *arcs, int beg, int deg, F &&f) {
   const int lane = threadIdx.x & 63;
   int incl = deg;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
   const int total = __shfl(incl, 63);
   const int excl = incl - deg;
-  for (int j0 = 0; j0 < total; j0 += 64) {
-    const int j = j0 + lane;
+  auto locate = [&](int j, int &arc, int &owner) {
     int lo = 0, hi = 63;
 #pragma unroll
     for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; const int v = __shfl(incl, mid); if (v > j) hi = mid; else lo = mid + 1; }
     lo = lo > 63 ? 63 : lo;
     const int obeg = __shfl(beg, lo), oexcl = __shfl(excl, lo);
-    f(j < total, obeg + (j - oexcl), lo);
+    arc = obeg + (j - oexcl); owner = lo;
+  };
+  for (int j0 = 0; j0 < total; j0 += 64) {
+    int a, o; ArcRec r{};
+    locate(j0 + lane, a, o);
+    if (j0 + lane < total) r = arcs[a];
+    f(j0 + lane < total, a, o, r);
   }
 }
 
@@ -227,8 +236,16 @@ __device__ __forceinline__ int slot_find(Slot *tab, unsigned mask, int state) {
 // is looked up in a kProbe-slot window; slots are never freed inside a frame, so once a window is full it stays full and
 // every thread agrees that such a state belongs to level 2, the per-lane open-addressing table in HBM.  Slot ids < kHL are
 // LDS slots, ids >= kHL are kHL + index of the HBM slot.  Typical frames (~1-3 k tokens) never leave LDS.
-constexpr int kHL = 4096, kProbe = 48;
-constexpr int kRowRegs = (7168 + kBlock - 1) / kBlock;   // registers that carry the next frame's log-likelihood row (LDS rows are <= 28 KB)
+#ifndef K3_DEC_HL
+#define K3_DEC_HL 4096
+#endif
+#ifndef K3_DEC_LDSROW
+#define K3_DEC_LDSROW 1
+#endif
+constexpr int kHL = K3_DEC_HL, kProbe = 48;
+constexpr int kRowRegs = K3_DEC_LDSROW ? (6400 + kBlock - 1) / kBlock : 1;   // registers that carry the next frame's log-likelihood row (LDS rows are <= 25 KB)
+constexpr int kCurRegs = 4;       // frames of <= kCurRegs * kBlock tokens hand their (cost, state) pairs to the next frame in registers
+constexpr int kWlLds = 1024;      // the first kWlLds work-list entries of an eps round live in LDS (16-bit LDS slot ids)
 #define K3_LLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 struct Table {
   int *lkey; unsigned *lcost; int *ltok; unsigned *lmark;     // LDS: [kHL], [kHL], [kHL], [kHL / 32]
@@ -281,18 +298,19 @@ struct Table {
   }
 };
 
-// exact k-th smallest (0-based) of keys[0..n) -- the value std::nth_element leaves at position k
-__device__ unsigned block_select_kth(const unsigned *keys, int n, int k, Shared &sh) {
+// exact k-th smallest (0-based) of the block's keys -- the value std::nth_element leaves at position k.  for_keys(fn) calls
+// fn(valid, key) the same number of times in every thread of a wavefront (valid = false pads the tail); MSB-first radix
+// select, 8 bits per pass; the digit is located by a 64-lane scan of the 256-bin histogram (4 bins per lane).
+template <typename ForKeys>
+__device__ __forceinline__ unsigned block_select_kth(ForKeys &&for_keys, int k, Shared &sh) {
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     __syncthreads();
     for (int i = tid; i < 256; i += kBlock) sh.hist[i] = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += kBlock) {
-      const int i = i0 + tid;
-      bool v = i < n; unsigned key = 0;
-      if (v) { key = keys[i]; v = (key & mask) == prefix; }
+    for_keys([&](bool v, unsigned key) {
+      v = v && (key & mask) == prefix;
       const int d = (key >> shift) & 255;
       const unsigned long long mv = __ballot(v);
       const int d0 = __shfl(d, mv ? __ffsll((long long)mv) - 1 : 0);
@@ -301,12 +319,23 @@ __device__ unsigned block_select_kth(const unsigned *keys, int n, int k, Shared 
         if (diff == 0) { if (lane == __ffsll((long long)mv) - 1) atomicAdd(&sh.hist[d0], __popcll(mv)); }
         else if (v) atomicAdd(&sh.hist[d], 1);
       }
-    }
+    });
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0, d = 0;
-      for (; d < 255; d++) { const int c = sh.hist[d]; if (k < cum + c) break; cum += c; }
-      sh.sel_digit = d; sh.sel_k = k - cum;
+    if (tid < 64) {
+      const int c0 = sh.hist[4 * lane], c1 = sh.hist[4 * lane + 1], c2 = sh.hist[4 * lane + 2], c3 = sh.hist[4 * lane + 3];
+      int incl = c0 + c1 + c2 + c3;
+      const int own = incl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      const int excl = incl - own;
+      const unsigned long long hit = __ballot(k >= excl && k < incl);
+      const int owner = hit ? __ffsll((long long)hit) - 1 : 63;        // k beyond the total (cannot happen for k < n): last bin, like a serial scan would
+      if (lane == owner) {
+        int d = 4 * lane, cum = excl;
+        if (hit) { if (k >= cum + c0) { cum += c0; d++; if (k >= cum + c1) { cum += c1; d++; if (k >= cum + c2) { cum += c2; d++; } } } }
+        else { d = 255; cum = incl - c3; }
+        sh.sel_digit = d; sh.sel_k = k - cum;
+      }
     }
     __syncthreads();
     prefix |= (unsigned)sh.sel_digit << shift; mask |= 0xFFu << shift; k = sh.sel_k;
@@ -318,7 +347,8 @@ __device__ unsigned block_select_kth(const unsigned *keys, int n, int k, Shared 
 // ProcessNonemitting (lattice-faster-decoder.cc:830-897): relax eps arcs until no cost changes, with tot < cutoff;
 // the links a token ends up with are exactly its eps arcs with cur + graph < cutoff at its final cost.
 __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, const Table &tb, float cutoff, long long nb, int *tok_state, unsigned *tok_cost,
-                                             Link *links, int *link_arc, int *tok_slot, int *wl, long long &t_last__, unsigned &cnt_eps) {
+                                             Link *links, int *link_arc, int *tok_slot, int *wl, unsigned short (*lwl)[kWlLds], unsigned (&creg)[kCurRegs], int (&sreg)[kCurRegs],
+                                             long long &t_last__, unsigned &cnt_eps) {
   const int tid = threadIdx.x, lane = tid & 63;
   __syncthreads();
   if (tid == 0) { sh.n_wl[0] = 0; sh.n_wl[1] = 0; }
@@ -332,7 +362,8 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
     if (round > 100000) { sh.err = K3_ERR_HIP; break; }        // an epsilon cycle with negative weight: cannot converge
     const int *wl_cur = round == 1 ? tok_slot : wl + (long long)cur * p.frame_tokens_cap;
     int *wl_nxt = wl + (long long)(round == 1 ? 0 : (cur ^ 1)) * p.frame_tokens_cap;
-    int *n_nxt = &sh.n_wl[round == 1 ? 0 : (cur ^ 1)];
+    const int nxt_buf = round == 1 ? 0 : (cur ^ 1);
+    int *n_nxt = &sh.n_wl[nxt_buf];
     K3_T(8);
     for (int i = tid; i < kHL / 32; i += kBlock) tb.lmark[i] = 0;
     __syncthreads();
@@ -340,7 +371,10 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
     for (int i0 = 0; i0 < n; i0 += kBlock) {
       const int i = i0 + tid; const bool v = i < n;
       int beg = 0, deg = 0, ti = 0; unsigned cb = 0; int slot_ = 0;
-      if (v) slot_ = wl_cur[i];
+      if (v) {
+        if (round == 1) slot_ = wl_cur[i];
+        else { slot_ = i < kWlLds ? (int)lwl[cur][i] : 0xFFFF; if (slot_ == 0xFFFF) slot_ = wl_cur[i]; }
+      }
       K3_TW(12);
       if (v) {
         const int slot = slot_;
@@ -354,13 +388,12 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         }
       }
       K3_TW(13);
-      wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
+      wave_expand(p.arcs, beg, deg, [&](bool valid, int arc, int owner, const ArcRec &r) {
         const unsigned ocb = __shfl(cb, owner); const int oti = __shfl(ti, owner);
         const float oc = dec(ocb);
         bool claimed = false, push = false, mk = false; int slot2 = -1, nxt = 0; float tot = 0.0f;
         cnt_eps += valid;
         if (valid) {
-          const ArcRec r = p.arcs[arc];
           tot = oc + r.w; nxt = r.next;
           if (tot < cutoff) {
             slot2 = tb.claim(r.next, &claimed);
@@ -380,7 +413,10 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
           tb.set_tok(slot2, idx);
         }
         const int pos = wave_append(push, n_nxt);
-        if (push) { if (pos < p.frame_tokens_cap) wl_nxt[pos] = slot2; else sh.err = K3_ERR_OVERFLOW; }
+        if (push) {
+          if (pos < kWlLds) lwl[nxt_buf][pos] = slot2 < kHL ? (unsigned short)slot2 : (unsigned short)0xFFFF;
+          if (pos >= kWlLds || slot2 >= kHL) { if (pos < p.frame_tokens_cap) wl_nxt[pos] = slot2; else sh.err = K3_ERR_OVERFLOW; }
+        }
         // the eps link of this arc at the source's present cost; links written at a cost the source later improves on
         // are recognised as stale by their stamp (Link::ac of an eps link = the source cost it was created at)
         if (mk && !claimed) idx = tb.wait_tok(slot2, &sh.err);
@@ -400,10 +436,18 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
   // final costs into the pool, clear the table
   {
     const int n = sh.n_next;
-    for (int i = tid; i < n; i += kBlock) {
-      const int slot = tok_slot[i];
-      tok_cost[nb + i] = tb.cost(slot);
-      if (slot >= kHL) tb.clear(slot);
+    if (n <= kCurRegs * kBlock) {       // the next frame starts from these registers instead of re-reading the pool
+#pragma unroll
+      for (int k = 0; k < kCurRegs; k++) {
+        const int i = tid + k * kBlock;
+        if (i < n) { const int slot = tok_slot[i]; const unsigned c = tb.cost(slot); creg[k] = c; sreg[k] = tb.key(slot); tok_cost[nb + i] = c; if (slot >= kHL) tb.clear(slot); }
+      }
+    } else {
+      for (int i = tid; i < n; i += kBlock) {
+        const int slot = tok_slot[i];
+        tok_cost[nb + i] = tb.cost(slot);
+        if (slot >= kHL) tb.clear(slot);
+      }
     }
     __syncthreads();
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }
@@ -420,6 +464,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ Shared sh;
   __shared__ int s_lkey[kHL]; __shared__ unsigned s_lcost[kHL]; __shared__ int s_ltok[kHL]; __shared__ unsigned s_lmark[kHL / 32];
+  __shared__ unsigned short s_lwl[2][kWlLds];
   float *s_ll = reinterpret_cast<float *>(smem_raw);
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
@@ -435,6 +480,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   const unsigned mask = (unsigned)p.hash_mask;
   const float kInf = __builtin_inff();
 
+  if (tid < 16) sh.prof[tid] = 0;
   if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; }
   for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; s_ltok[i] = -1; }
   const Table tb{s_lkey, s_lcost, s_ltok, s_lmark, hash, mask};
@@ -442,6 +488,9 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   long long t_last__ = (long long)__builtin_readcyclecounter();
   unsigned cnt_eps = 0, cnt_emit = 0;      // per-thread arc counters (reduced once at the end of the kernel)
   long long cur_base = 0; int n_cur = 0, max_frame = 0, f0 = 0, status = kStOk;
+  unsigned creg[kCurRegs]; int sreg[kCurRegs]; bool in_regs = false;      // (cost, state) of current-frame token tid + k * kBlock
+#pragma unroll
+  for (int k = 0; k < kCurRegs; k++) { creg[k] = kEncMax; sreg[k] = 0; }
   if (!p.resume) {
     // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
     if (tid == 0) {
@@ -450,10 +499,6 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       tok_off[0] = 0; loff_n[0] = 0;
     }
     __syncthreads();
-    finish_frame(p, sh, tb, p.beam, 0, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__, cnt_eps);
-    n_cur = sh.n_next; max_frame = n_cur;
-    __syncthreads();
-    if (tid == 0) { tok_off[1] = n_cur; loff_e[0] = sh.n_link; }
   } else {
     // ---- AdvanceDecoding on a later chunk: pick the lane up where the previous launch left it
     const LaneInfo &li = p.info[L];
@@ -463,8 +508,18 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     __syncthreads();
   }
 
-  for (int f = f0; f < f0 + T; f++) {
+#ifdef K3_DEC_PROF
+  long long t_frame__ = (long long)__builtin_readcyclecounter();
+#endif
+  // frame -1 (only on a fresh start) is InitDecoding's eps closure of the start token with cutoff = beam: it shares the
+  // ProcessNonemitting code of the real frames (one copy of it in the instruction stream)
+  for (int f = p.resume ? f0 : -1; f < f0 + T; f++) {
     if (block_err(sh)) break;
+#ifdef K3_DEC_PROF
+    if (tid == 0) sh.prof_n = n_cur;
+#endif
+    float accept = p.beam; long long nb = 0;
+    if (f >= 0) {
     // stage the log-likelihood row of this frame in LDS (coalesced), overlapped with the cutoff passes
     K3_T(0);
     const float *row = p.loglikes + (r0 + (f - f0)) * p.ld;
@@ -473,9 +528,24 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
     if (n_cur == 0) { status = kStNoTokens; break; }
     // ---- GetCutoff (:653-720)
+    // fn(i, cost, state) over this thread's share of the current frame: from registers when the previous frame left them there
+    auto for_cur = [&](auto fn) {
+      if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kCurRegs; k++) { const int i = tid + k * kBlock; if (i < n_cur) fn(i, creg[k], sreg[k]); }
+      } else for (int i = tid; i < n_cur; i += kBlock) fn(i, ccs[i], cst[i]);
+    };
+    auto for_keys = [&](auto fn) {       // wave-uniform trip count (block_select_kth)
+      if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kCurRegs; k++) { if (k * kBlock < n_cur) fn(tid + k * kBlock < n_cur, creg[k]); }
+      } else for (int i0 = 0; i0 < n_cur; i0 += kBlock) { const int i = i0 + tid; fn(i < n_cur, i < n_cur ? ccs[i] : 0u); }
+    };
     unsigned long long bm = ~0ull;
-    for (int i = tid; i < n_cur; i += kBlock) { const unsigned long long v = ((unsigned long long)ccs[i] << 32) | (unsigned)cst[i]; bm = v < bm ? v : bm; }
+    for_cur([&](int, unsigned c, int st) { const unsigned long long v = ((unsigned long long)c << 32) | (unsigned)st; bm = v < bm ? v : bm; });
+    K3_T(1);
     bm = block_min_u64(bm, sh);
+    K3_T(1);
     const float best = dec((unsigned)(bm >> 32)); const int best_state = (int)(unsigned)(bm & 0xFFFFFFFFull);
     float cur_cutoff, ab;
     const float beam_cutoff = best + p.beam;
@@ -483,18 +553,18 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     else {
       const unsigned ebc = enc(beam_cutoff);
       int c_lt = 0, c_le = 0;
-      for (int i = tid; i < n_cur; i += kBlock) { const unsigned k = ccs[i]; c_lt += k < ebc; c_le += k <= ebc; }
+      for_cur([&](int, unsigned k, int) { c_lt += k < ebc; c_le += k <= ebc; });
+      K3_T(1);
       c_lt = block_sum_i32(c_lt, sh); c_le = block_sum_i32(c_le, sh);
+      K3_T(1);
       // tmp[max_active] < beam_cutoff  <=>  more than max_active elements are < beam_cutoff
-      if (n_cur > p.max_active && c_lt > p.max_active) {
-        const float mac = dec(block_select_kth(ccs, n_cur, p.max_active, sh));
-        ab = mac - best + p.beam_delta; cur_cutoff = mac;
-      } else if (n_cur > p.min_active && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }   // min_active_cutoff = best <= beam_cutoff
+      int kth = -1;
+      if (n_cur > p.max_active && c_lt > p.max_active) kth = p.max_active;                                   // max_active_cutoff = tmp[max_active] < beam_cutoff
+      else if (n_cur > p.min_active && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }         // min_active_cutoff = best <= beam_cutoff
       else if (n_cur > p.min_active && c_le > p.min_active) { ab = p.beam; cur_cutoff = beam_cutoff; }      // tmp[min_active] <= beam_cutoff
-      else if (n_cur > p.min_active) {
-        const float mic = dec(block_select_kth(ccs, n_cur, p.min_active, sh));
-        ab = mic - best + p.beam_delta; cur_cutoff = mic;
-      } else { ab = kInf - best + p.beam_delta; cur_cutoff = kInf; }                                          // min_active_cutoff = +inf
+      else if (n_cur > p.min_active) kth = p.min_active;                                                     // min_active_cutoff = tmp[min_active] > beam_cutoff
+      else { ab = kInf - best + p.beam_delta; cur_cutoff = kInf; }                                           // min_active_cutoff = +inf
+      if (kth >= 0) { const float sel = dec(block_select_kth(for_keys, kth, sh)); ab = sel - best + p.beam_delta; cur_cutoff = sel; }
     }
     K3_T(1);
     const float co = -best;
@@ -515,16 +585,12 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     if (tid == 0) { sh.n_cand = 0; sh.min_tot = kEncMax; sh.n_next = 0; }
     __syncthreads();
     // ---- ProcessEmitting pass 1 (:779-797): every emitting arc of every token <= cur_cutoff; keep tot < pre-pass bound
-    for (int t0 = 0; t0 < n_cur; t0 += kBlock) {
-      const int t = t0 + tid; const bool v = t < n_cur;
-      int beg = 0, deg = 0; float c = 0.0f;
-      if (v) { c = dec(ccs[t]); if (c <= cur_cutoff) { const int2 a = p.offs[cst[t]]; beg = a.x; deg = a.y - a.x; } }
-      wave_expand(beg, deg, [&](bool valid, int arc, int owner) {
+    auto expand_tok = [&](int t, float c, int beg, int deg) {
+      wave_expand(p.arcs, beg, deg, [&](bool valid, int arc, int owner, const ArcRec &r) {
         const float oc = __shfl(c, owner); const int ot = __shfl(t, owner);
         bool pass = false; float tot = 0.0f, ac = 0.0f; int nxt = 0;
         cnt_emit += valid;
         if (valid) {
-          const ArcRec r = p.arcs[arc];
           ac = co - ll[r.pdf]; tot = oc + ac + r.w; nxt = r.next;
           pass = tot < next0;
         }
@@ -536,30 +602,41 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
           else sh.err = K3_ERR_OVERFLOW;
         }
       });
+    };
+    for (int t0 = 0, k = 0; t0 < n_cur; t0 += kBlock, k++) {
+      const int t = t0 + tid; const bool v = t < n_cur;
+      unsigned cb = kEncMax; int st = 0;
+      if (in_regs) { cb = k == 0 ? creg[0] : k == 1 ? creg[1] : k == 2 ? creg[2] : creg[3]; st = k == 0 ? sreg[0] : k == 1 ? sreg[1] : k == 2 ? sreg[2] : sreg[3]; }
+      else if (v) { cb = ccs[t]; st = cst[t]; }
+      int beg = 0, deg = 0; const float c = dec(cb);
+      if (v && c <= cur_cutoff) { const int2 a = p.offs[st]; beg = a.x; deg = a.y - a.x; }
+      expand_tok(t, c, beg, deg);
     }
+    if (tid == 0) loff_e[f] = sh.n_link;
     if (block_err(sh)) break;
     K3_T(3);
-    // the LDS row is dead from here on: fetch the next frame's row into registers now (the loads fly during the rest of the frame),
-    // park it in LDS at the end of the frame
+    // the LDS row is dead from here on: fetch the next frame's row into registers now (the loads fly during pass 2),
+    // park it in LDS after pass 2
     float rowreg[kRowRegs];
-    const bool prefetch = p.use_lds_row && f + 1 < f0 + T;
-    if (prefetch) {
+    const bool prefetch = K3_DEC_LDSROW && p.use_lds_row && f + 1 < f0 + T;
+    auto fetch_row = [&]() {
 #pragma unroll
       for (int k = 0; k < kRowRegs; k++) { const int i = tid + k * kBlock; rowreg[k] = i < p.num_pdfs ? row[p.ld + i] : 0.0f; }
-    }
+    };
+    bool row_pending = prefetch;      // issued behind the first candidate loads: vector loads return in order, the candidates must not queue behind the row
     // ---- final bound of the frame, pass 2: tokens (min cost per state) for the accepted arcs
-    float accept = next0;
+    accept = next0;
     { const unsigned mt = sh.min_tot; if (mt != kEncMax) { const float t = dec(mt) + ab; if (t < accept) accept = t; } }
     const int n_cand = sh.n_cand;
-    const long long nb = cur_base + n_cur;
-    if (tid == 0) loff_e[f] = sh.n_link;
-    __syncthreads();
+    nb = cur_base + n_cur;
     for (int j0 = 0; j0 < n_cand; j0 += kBlock) {
-      const int j = j0 + tid; bool claimed = false, mk = false; int slot = -1, nxt = 0; float tot = 0.0f;
+      const int j = j0 + tid; bool claimed = false, mk = false; int slot = -1, nxt = 0, c_a = 0, c_s = 0; float tot = 0.0f, c_c = 0.0f;
       if (j < n_cand) {
-        tot = c_tot[j];
+        tot = c_tot[j]; nxt = c_dst[j]; c_a = c_arc[j]; c_s = c_src[j]; c_c = c_ac[j];      // one round trip for the whole record
+      }
+      if (row_pending) { fetch_row(); row_pending = false; }
+      if (j < n_cand) {
         if (tot < accept) {
-          nxt = c_dst[j];
           slot = tb.claim(nxt, &claimed);
           if (slot < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; } else { tb.cost_min(slot, enc(tot)); mk = true; }
         }
@@ -574,26 +651,35 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       if (mk && !claimed) idx = tb.wait_tok(slot, &sh.err);
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
-        if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + c_src[j]), (unsigned)(nb + idx), tot, c_ac[j]}; link_arc[pos] = c_arc[j]; }
+        if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + c_s), (unsigned)(nb + idx), tot, c_c}; link_arc[pos] = c_a; }
         else sh.err = K3_ERR_OVERFLOW;
       }
     }
+    if (row_pending) fetch_row();
     if (block_err(sh)) break;
     K3_T(5);
-    if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
-    // ---- ProcessNonemitting(next_cutoff) + eps links + publish the frame
-    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, t_last__, cnt_eps);
-    if (block_err(sh)) break;
-    cur_base = nb; n_cur = sh.n_next; max_frame = n_cur > max_frame ? n_cur : max_frame;
+    // park the prefetched row (nobody reads the LDS row between here and the next frame's pre-pass)
     if (prefetch) {
 #pragma unroll
       for (int k = 0; k < kRowRegs; k++) { const int i = tid + k * kBlock; if (i < p.num_pdfs) s_ll[i] = rowreg[k]; }
     }
+    if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
+    }   // f >= 0
+    // ---- ProcessNonemitting(next_cutoff) + eps links + publish the frame
+    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
+    if (block_err(sh)) break;
+    cur_base = nb; n_cur = sh.n_next; max_frame = n_cur > max_frame ? n_cur : max_frame; in_regs = n_cur <= kCurRegs * kBlock;
     __syncthreads();
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
+#ifdef K3_DEC_PROF
+    if (tid == 0 && f >= 0) { const long long now__ = (long long)__builtin_readcyclecounter(); st_ab[f] = (float)(now__ - t_frame__); t_frame__ = now__; }   // profiling builds only: FrameStats' adaptive_beam column = cycles of the frame
+#endif
   }
   { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit); if (lane == 0) { atomicAdd(&sh.n_eps, a); atomicAdd(&sh.n_emit, b); } }
   __syncthreads();
+#ifdef K3_DEC_PROF
+  if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
+#endif
   if (tid == 0) {
     LaneInfo &li = p.info[L];
     li.n_tokens = cur_base + n_cur; li.n_links = sh.n_link; li.n_cands = (long long)sh.n_emit; li.n_eps = (long long)sh.n_eps; li.max_frame_tokens = max_frame;
@@ -1015,7 +1101,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   p.frame_tokens_cap = cfg->frame_tokens_cap; p.frame_cands_cap = cfg->frame_cands_cap; p.lane_tokens_cap = cfg->lane_tokens_cap; p.lane_links_cap = cfg->lane_links_cap;
   int hs = 1; while (hs < 2 * cfg->frame_tokens_cap) hs <<= 1;
   p.hash_mask = hs - 1; p.num_pdfs = num_pdfs;
-  p.use_lds_row = ((size_t)num_pdfs * sizeof(float) <= 28 * 1024) ? 1 : 0;   // keeps a lane under 80 KB of LDS: two lanes per CU
+  p.use_lds_row = (K3_DEC_LDSROW && (size_t)num_pdfs * sizeof(float) <= 25 * 1024) ? 1 : 0;   // keeps a lane under 80 KB of LDS: two lanes per CU
   const size_t nl = (size_t)nlanes;
   int rc;
   if ((rc = dmalloc(&d->allocs, &p.tok_state, nl * cfg->lane_tokens_cap))) return rc;

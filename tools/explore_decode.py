@@ -19,7 +19,7 @@ feats = sf.ComputeFeatures(waves, wo, fo, total_frames); ll = nb.forward(feats);
 print("loglikes", tuple(ll.shape), "mean", ll.mean().item(), "std", ll.std().item(), "max", ll.max().item(), "row-max mean", ll.max(dim=1).values.mean().item())
 t = time.time(); f = synth.make_hclg(); print("graph", f.stats(), "gen %.1fs" % (time.time() - t))
 t = time.time(); cf = decoder.CudaFst(f, synth.tid2pdf(net.info.output_dim)); print("upload %.2fs" % (time.time() - t))
-cfg = decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, frame_tokens_cap=65536, frame_cands_cap=131072,
+cfg = decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, min_active=int(os.environ.get("MINACT", 200)), frame_tokens_cap=65536, frame_cands_cap=131072,
                              lane_tokens_cap=int(os.environ.get("TOKCAP", 6_000_000)), lane_links_cap=int(os.environ.get("LINKCAP", 12_000_000)))
 dec = decoder.CudaDecoder(cf, cfg, U, net.info.output_dim); dec.SetProfiling(True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -35,8 +35,18 @@ audio = U * secs; print("audio-s", audio)
 import ctypes
 from kaldi_amd import lib as _l
 cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
-names = ["(loop top/err)", "cutoff", "prepass", "expand", "pass2 insert", "links", "-", "eps worklist build", "round:err-barriers", "eps links", "finalize+clear", "round:mark-clear+barrier", "round:wl read", "round:cost+offs", "round:expand(arcs,claims,stores)", "round:end barrier"]
+names = ["(loop top/err)", "cutoff", "prepass", "expand", "p2:cand read", "p2:link store+barrier", "p2:claim+publish", "eps worklist build", "round:err-barriers", "p2:wait_tok", "finalize+clear", "round:mark-clear+barrier", "round:wl read", "round:cost+offs", "round:expand(arcs,claims,stores)", "round:end barrier"]
 tot = cyc.sum()
 if tot: print("phase share:", {n: round(100.0 * c / tot, 1) for n, c in zip(names, cyc) if n != "-"}, "cycles/lane/frame", tot / U / 333 / 2)
 allnt = np.concatenate([dec.FrameStats(u, int(nb.out_offsets[u + 1] - nb.out_offsets[u]))["ntoks"] for u in range(0, U, max(1, U // 32))])
 print("ntoks percentiles 10/50/75/90/95/99/max:", [int(np.percentile(allnt, q)) for q in (10, 50, 75, 90, 95, 99, 100)], "frac <= 1024:", float((allnt <= 1024).mean()), "<= 2048:", float((allnt <= 2048).mean()), "<= 3072:", float((allnt <= 3072).mean()))
+if os.environ.get("K3HIP_LIB", "").endswith("_prof.so"):
+    xs, ys = [], []
+    for u in range(0, U, max(1, U // 64)):
+        st = dec.FrameStats(u, int(nb.out_offsets[u + 1] - nb.out_offsets[u])); xs.append(st["ntoks"][1:]); ys.append(st["adaptive_beam"][1:])
+    x = np.concatenate(xs).astype(np.float64); y = np.concatenate(ys).astype(np.float64)
+    A = np.stack([np.ones_like(x), x], 1); coef = np.linalg.lstsq(A, y, rcond=None)[0]
+    print("frame cycles ~ %.0f + %.2f * ntoks; mean cycles %.0f, mean ntoks %.0f; fixed share %.2f" % (coef[0], coef[1], y.mean(), x.mean(), coef[0] / y.mean()))
+    for lo, hi in ((0, 256), (256, 512), (512, 1024), (1024, 2048), (2048, 4096), (4096, 8192), (8192, 1 << 30)):
+        m = (x >= lo) & (x < hi)
+        if m.any(): print("  ntoks [%d,%d): frames %.3f, time share %.3f, mean cycles %.0f" % (lo, hi, m.mean(), y[m].sum() / y.sum(), y[m].mean()))
