@@ -65,6 +65,22 @@ int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_
 int k3_cmvn_offline_batch(float *d_feats, int64_t ld, int32_t dim, const int64_t *d_frame_offsets,
                           int32_t num_utts, int32_t norm_vars, double *d_stats, void *stream);
 
+/* Online (sliding-window) CMVN of whole utterances: OnlineCmvn::GetFrame for every frame (feat/online-feature.cc:361-468), what
+ * online2bin/apply-cmvn-online.cc:92-129 and the GPU reference CudaOnlineCmvn::ComputeFeatures
+ * (cudafeat/feature-online-cmvn-cuda.cu:174-215) do.  Options = OnlineCmvnOptions (feat/online-feature.h:201-240); fp64 window
+ * statistics with the reference's add-new / subtract-oldest recursion.  d_global_stats [2 x (dim+1)] doubles (sums + count,
+ * sums of squares) as read from a <global-cmvn-stats> file; d_speaker_stats (may be NULL) [U x 2 x (dim+1)]: per utterance, the
+ * stats of the speaker's earlier utterances (OnlineCmvnState::speaker_cmvn_stats; count 0 = none).  skip_dims: host array
+ * (--skip-dims).  d_out must not alias d_in.  Synchronises the stream (error flag); K3_ERR_ARG where the reference raises. */
+typedef struct k3_online_cmvn_opts {
+  int32_t cmn_window, speaker_frames, global_frames;   /* 600, 600, 200 */
+  int32_t normalize_mean, normalize_variance;           /* 1, 0 */
+} k3_online_cmvn_opts;
+void k3_online_cmvn_opts_default(k3_online_cmvn_opts *opts);
+int k3_cmvn_online_batch(const float *d_in, int64_t ld_in, float *d_out, int64_t ld_out, int32_t dim, const int64_t *d_frame_offsets,
+                         int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
+                         const int32_t *skip_dims, int32_t num_skip_dims, void *stream);
+
 /* ---------------------------------------------------------------- nnet3 forward -------------
  * Replaces, for "simple" feed-forward TDNN / TDNN-F models: nnet3::NnetComputer::Run over the compiled
  * program of DecodableNnetSimple (nnet3/nnet-am-decodable-simple.cc:93-276; nnet3/nnet-compute.cc:236-459)

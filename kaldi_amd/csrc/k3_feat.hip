@@ -326,12 +326,17 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const f
 }
 
 // ------------------------------------------------------------------ CMVN ----------------------
+// The reference rounds every product before it is added (it is compiled without FMA).  __fmul_rn / __dmul_rn are plain
+// operators in this HIP and get contracted with a following add; an empty asm makes the rounded product opaque to the optimiser.
+__device__ __forceinline__ float rounded(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double rounded(double x) { asm volatile("" : "+v"(x)); return x; }
 // One workgroup per (utterance, 8-column group): fp64 sums of x and x^2 over time (AccCmvnStats),
 // then x*scale+offset in place (ApplyCmvn).  Rows of an utterance are contiguous, so a wave reads
 // full rows (coalesced) and each lane owns column (lane % dim_tile).
 __global__ __launch_bounds__(256) void k3_cmvn_kernel(float *__restrict__ feats, int64_t ld, int dim,
                                                       const int64_t *__restrict__ frame_off, int norm_vars,
                                                       double *__restrict__ stats) {
+#pragma clang fp contract(off)      // the reference rounds the product and the sum separately (MulColsVec, then AddVecToRows)
   __shared__ double s_sum[256], s_sq[256];
   __shared__ float s_scale[64], s_offset[64];
   const int u = blockIdx.x;
@@ -373,8 +378,87 @@ __global__ __launch_bounds__(256) void k3_cmvn_kernel(float *__restrict__ feats,
     const float sc = s_scale[c], of = s_offset[c];
     for (int64_t t = r0 + rlane; t < r1; t += 4) {
       float x = feats[t * ld + col];
-      if (norm_vars) x = __fmul_rn(x, sc);       // MulColsVec then AddVecToRows: two roundings
-      feats[t * ld + col] = __fadd_rn(x, of);
+      if (norm_vars) x = rounded(x * sc);        // MulColsVec then AddVecToRows: two roundings
+      feats[t * ld + col] = x + of;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------ online CMVN ---------------
+// OnlineCmvn::GetFrame for every frame (feat/online-feature.cc:361-468): one lane per (utterance, column) walks the frames in
+// order, carrying the window sums in fp64 exactly as ComputeStatsForFrame does (add the new frame, then subtract the one that
+// leaves the window), smooths them with the speaker / global stats (SmoothOnlineCmvnStats) and applies ApplyCmvn to the row.
+// The recursion is sequential in t by definition (its rounding depends on the order); rows are read coalesced across the
+// columns of a wave, 8 frames ahead.  No fp contraction anywhere: the reference is compiled without FMA.
+struct OnlineCmvnParams {
+  const float *in; float *out; long long ld_in, ld_out; int dim; const long long *frame_off;
+  int cmn_window, speaker_frames, global_frames, norm_means, norm_vars;
+  const double *global_stats, *speaker_stats;      // [2 x (dim+1)], [U x 2 x (dim+1)] or null
+  unsigned long long skip[4];                      // bit d set: FakeStatsForSomeDims for column d
+  int *err;                                        // set to 1 where the reference raises (count < 1, global count <= 0)
+};
+
+__global__ __launch_bounds__(64) void k3_cmvn_online_kernel(OnlineCmvnParams p) {
+#pragma clang fp contract(off)      // __fmul_rn & co are plain operators in this HIP: keep the compiler from fusing them into fma
+  const int u = blockIdx.x, d = blockIdx.y * 64 + threadIdx.x;
+  if (d >= p.dim) return;
+  const long long r0 = p.frame_off[u], T = p.frame_off[u + 1] - r0;
+  const int C = p.dim + 1, W = p.cmn_window;
+  const float *x = p.in + r0 * p.ld_in + d; float *y = p.out + r0 * p.ld_out + d;
+  const double g_m = p.global_stats[d], g_v = p.global_stats[C + d], g_n = p.global_stats[p.dim];
+  const double *sp = p.speaker_stats ? p.speaker_stats + (long long)u * 2 * C : nullptr;
+  const double s_m = sp ? sp[d] : 0.0, s_v = sp ? sp[C + d] : 0.0, s_n = sp ? sp[p.dim] : 0.0;
+  const bool skip = d < 256 && ((p.skip[d >> 6] >> (d & 63)) & 1ull);
+  double sum = 0.0, sq = 0.0, n = 0.0;
+  constexpr int kAhead = 8;
+  for (long long t0 = 0; t0 < T; t0 += kAhead) {
+    float xn[kAhead], xo[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) {
+      const long long t = t0 + k;
+      xn[k] = t < T ? x[t * p.ld_in] : 0.0f;
+      xo[k] = (t < T && t - W >= 0) ? x[(t - W) * p.ld_in] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) {
+      const long long t = t0 + k;
+      if (t >= T) break;
+      const double xd = (double)xn[k];
+      sum = __dadd_rn(sum, xd); if (p.norm_vars) sq = __dadd_rn(sq, rounded(xd * xd)); n = __dadd_rn(n, 1.0);
+      if (t - W >= 0) { const double od = (double)xo[k]; sum = __dadd_rn(sum, -od); if (p.norm_vars) sq = __dadd_rn(sq, -rounded(od * od)); n = __dadd_rn(n, -1.0); }
+      double m = sum, v = sq, cnt = n;
+      if (cnt < (double)W) {
+        if (sp) {
+          double from_spk = (double)W - cnt;
+          if (from_spk > (double)p.speaker_frames) from_spk = (double)p.speaker_frames;
+          if (from_spk > s_n) from_spk = s_n;
+          if (from_spk > 0.0) { const double a = __ddiv_rn(from_spk, s_n); m = __dadd_rn(m, rounded(a * s_m)); v = __dadd_rn(v, rounded(a * s_v)); cnt = __dadd_rn(cnt, rounded(a * s_n)); }
+        }
+        if (cnt < (double)W) {
+          double from_glob = (double)W - cnt;
+          if (!(g_n > 0.0)) { *p.err = 1; return; }
+          if (from_glob > (double)p.global_frames) from_glob = (double)p.global_frames;
+          if (from_glob > 0.0) { const double a = __ddiv_rn(from_glob, g_n); m = __dadd_rn(m, rounded(a * g_m)); v = __dadd_rn(v, rounded(a * g_v)); cnt = __dadd_rn(cnt, rounded(a * g_n)); }
+        }
+      }
+      if (skip) { m = 0.0; v = cnt; }
+      float z = xn[k];
+      if (p.norm_means) {
+        if (cnt < 1.0) { *p.err = 1; return; }
+        if (!p.norm_vars) {
+          const float alpha = (float)__ddiv_rn(-1.0, cnt);
+          const float off = (float)__dadd_rn(0.0, rounded((double)alpha * m));
+          z = __fadd_rn(z, off);
+        } else {
+          const double mean = __ddiv_rn(m, cnt);
+          double var = __dadd_rn(__ddiv_rn(v, cnt), -rounded(mean * mean));
+          if (var < 1.0e-20) var = 1.0e-20;
+          const double scale = __ddiv_rn(1.0, __dsqrt_rn(var));
+          z = rounded(z * (float)scale); z = __fadd_rn(z, (float)(-rounded(mean * scale)));
+        }
+      }
+      y[t * p.ld_out] = z;
     }
   }
 }
@@ -580,4 +664,41 @@ extern "C" int k3_cmvn_offline_batch(float *d_feats, int64_t ld, int32_t dim, co
                      d_feats, ld, (int)dim, d_frame_offsets, (int)norm_vars, d_stats);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
+}
+
+extern "C" int k3_cmvn_online_batch(const float *d_in, int64_t ld_in, float *d_out, int64_t ld_out, int32_t dim, const int64_t *d_frame_offsets,
+                                    int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
+                                    const int32_t *skip_dims, int32_t num_skip_dims, void *stream) {
+  K3_REQUIRE(d_in && d_out && d_in != d_out && d_frame_offsets && opts && d_global_stats && dim > 0 && ld_in >= dim && ld_out >= dim && num_utts >= 0,
+             "k3_cmvn_online_batch: bad argument (in-place operation is not possible: the window needs the raw frames)");
+  // OnlineCmvnOptions::Check (feat/online-feature.h:226-229) and the assertion in OnlineCmvn::GetFrame (:465)
+  K3_REQUIRE(opts->speaker_frames <= opts->cmn_window && opts->global_frames <= opts->speaker_frames && opts->cmn_window > 0 && opts->global_frames >= 0,
+             "k3_cmvn_online_batch: need global_frames <= speaker_frames <= cmn_window");
+  K3_REQUIRE(opts->normalize_mean || !opts->normalize_variance, "k3_cmvn_online_batch: cannot normalize the variance but not the mean");
+  K3_REQUIRE(num_skip_dims == 0 || skip_dims, "k3_cmvn_online_batch: skip_dims missing");
+  if (num_utts == 0) return K3_OK;
+  OnlineCmvnParams p{};
+  p.in = d_in; p.out = d_out; p.ld_in = ld_in; p.ld_out = ld_out; p.dim = dim; p.frame_off = (const long long *)d_frame_offsets;
+  p.cmn_window = opts->cmn_window; p.speaker_frames = opts->speaker_frames; p.global_frames = opts->global_frames;
+  p.norm_means = opts->normalize_mean; p.norm_vars = opts->normalize_variance;
+  p.global_stats = d_global_stats; p.speaker_stats = d_speaker_stats;
+  for (int32_t i = 0; i < num_skip_dims; i++) {
+    K3_REQUIRE(skip_dims[i] >= 0 && skip_dims[i] < dim && skip_dims[i] < 256, "k3_cmvn_online_batch: skip dimension out of range (0 <= d < min(dim, 256))");
+    p.skip[skip_dims[i] >> 6] |= 1ull << (skip_dims[i] & 63);
+  }
+  static int *d_err = nullptr;
+  if (!d_err) { K3_HIP_CHECK(hipMalloc(&d_err, sizeof(int))); K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); }
+  p.err = d_err;
+  hipLaunchKernelGGL(k3_cmvn_online_kernel, dim3((unsigned)num_utts, (unsigned)((dim + 63) / 64)), dim3(64), 0, (hipStream_t)stream, p);
+  K3_HIP_CHECK(hipGetLastError());
+  int h_err = 0;
+  K3_HIP_CHECK(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  K3_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (h_err) { K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); K3_REQUIRE(false, "k3_cmvn_online_batch: insufficient stats (count < 1 or empty global stats), the reference raises an error here"); }
+  return K3_OK;
+}
+
+extern "C" void k3_online_cmvn_opts_default(k3_online_cmvn_opts *o) {
+  if (!o) return;
+  o->cmn_window = 600; o->speaker_frames = 600; o->global_frames = 200; o->normalize_mean = 1; o->normalize_variance = 0;
 }

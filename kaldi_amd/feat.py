@@ -67,3 +67,23 @@ def ApplyCmvnOffline(feats, frame_offsets, norm_vars=False, stats=None):
     _l.check(L.k3_cmvn_offline_batch(feats.data_ptr(), feats.stride(0), feats.shape[1], frame_offsets.data_ptr(),
                                      frame_offsets.numel() - 1, int(norm_vars), stats.data_ptr() if stats is not None else None, _stream()))
     return feats
+
+
+def ApplyCmvnOnline(feats, frame_offsets, global_stats, speaker_stats=None, cmn_window=600, speaker_frames=600, global_frames=200,
+                    norm_means=True, norm_vars=False, skip_dims=(), out=None):
+    """apply-cmvn-online on a batch of whole utterances (OnlineCmvn::GetFrame per frame, feat/online-feature.cc:361-468; GPU reference
+    CudaOnlineCmvn::ComputeFeatures).  feats float32 [rows, dim] on the GPU; global_stats float64 [2, dim+1]; speaker_stats (optional)
+    float64 [U, 2, dim+1].  Returns a new matrix (the window needs the raw frames, so not in place)."""
+    assert feats.is_cuda and feats.dtype == torch.float32
+    dim = feats.shape[1]; U = frame_offsets.numel() - 1
+    g = torch.as_tensor(global_stats, dtype=torch.float64).to(feats.device).contiguous(); assert tuple(g.shape) == (2, dim + 1)
+    sp = None
+    if speaker_stats is not None:
+        sp = torch.as_tensor(speaker_stats, dtype=torch.float64).to(feats.device).contiguous(); assert tuple(sp.shape) == (U, 2, dim + 1)
+    if out is None: out = torch.empty_like(feats)
+    o = _l.OnlineCmvnOpts(int(cmn_window), int(speaker_frames), int(global_frames), int(bool(norm_means)), int(bool(norm_vars)))
+    import ctypes as _ct
+    sk = (_ct.c_int32 * max(1, len(skip_dims)))(*[int(d) for d in skip_dims])
+    _l.check(_l.load().k3_cmvn_online_batch(feats.data_ptr(), feats.stride(0), out.data_ptr(), out.stride(0), dim, frame_offsets.data_ptr(), U, _ct.byref(o),
+                                            g.data_ptr(), sp.data_ptr() if sp is not None else None, _ct.cast(sk, _ct.c_void_p) if len(skip_dims) else None, len(skip_dims), _stream()))
+    return out

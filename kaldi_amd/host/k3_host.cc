@@ -512,6 +512,51 @@ size_t ReadOneMatrix(const std::string &b, size_t p, Matrix *m, const std::strin
 }
 }  // namespace
 
+MatrixD ReadDoubleMatrix(const std::string &rxfilename) {
+  const std::string b = ReadWholeInput(rxfilename); MatrixD m; size_t p = 0;
+  auto need = [&](size_t n) { if (p + n > b.size()) K3H_ERR << "unexpected end of data reading matrix from " << rxfilename; };
+  if (b.size() >= 2 && b[0] == '\0' && b[1] == 'B') {
+    p = 2; const size_t t0 = p; while (p < b.size() && b[p] != ' ') p++;
+    const std::string tok = b.substr(t0, p - t0); p++;
+    if (tok != "DM" && tok != "FM") K3H_ERR << "Expected a matrix (DM or FM) in " << rxfilename << ", got token " << tok;
+    auto i32 = [&]() { need(5); if (b[p] != 4) K3H_ERR << "bad integer marker in " << rxfilename; int32_t v; memcpy(&v, b.data() + p + 1, 4); p += 5; return v; };
+    m.rows = i32(); m.cols = i32(); const size_t n = (size_t)m.rows * m.cols; m.data.resize(n);
+    if (tok == "DM") { need(8 * n); memcpy(m.data.data(), b.data() + p, 8 * n); }
+    else { need(4 * n); for (size_t i = 0; i < n; i++) { float f; memcpy(&f, b.data() + p + 4 * i, 4); m.data[i] = f; } }
+    return m;
+  }
+  while (p < b.size() && isspace((unsigned char)b[p])) p++;
+  if (p >= b.size() || b[p] != '[') K3H_ERR << "Expected \"[\" reading text matrix from " << rxfilename;
+  p++; std::vector<double> row;
+  while (p < b.size()) {
+    while (p < b.size() && (b[p] == ' ' || b[p] == '\t' || b[p] == '\r')) p++;
+    if (p >= b.size()) break;
+    if (b[p] == '\n' || b[p] == ']') {
+      if (!row.empty()) { if (m.cols && (int32_t)row.size() != m.cols) K3H_ERR << "Inconsistent row lengths in text matrix " << rxfilename; m.cols = (int32_t)row.size(); m.data.insert(m.data.end(), row.begin(), row.end()); m.rows++; row.clear(); }
+      if (b[p++] == ']') return m;
+      continue;
+    }
+    char *e = nullptr; const double v = strtod(b.c_str() + p, &e);
+    if (e == b.c_str() + p) K3H_ERR << "Bad number in text matrix " << rxfilename;
+    row.push_back(v); p = e - b.c_str();
+  }
+  K3H_ERR << "Unterminated text matrix " << rxfilename;
+  return m;
+}
+
+std::vector<std::pair<std::string, std::vector<std::string>>> ReadTokenVectorTable(const std::string &rspecifier) {
+  const size_t colon = rspecifier.find(':');
+  if (colon == std::string::npos || rspecifier.compare(0, 3, "ark") != 0) K3H_ERR << "Expected an ark: rspecifier for a token-vector table, got " << rspecifier;
+  std::istringstream in(ReadWholeInput(rspecifier.substr(colon + 1))); std::string line;
+  std::vector<std::pair<std::string, std::vector<std::string>>> out;
+  while (std::getline(in, line)) {
+    std::istringstream ls(line); std::string key, tok; if (!(ls >> key)) continue;
+    std::vector<std::string> v; while (ls >> tok) v.push_back(tok);
+    out.push_back({key, std::move(v)});
+  }
+  return out;
+}
+
 std::vector<std::pair<std::string, Matrix>> ReadMatrixTable(const std::string &rspecifier) {
   const size_t colon = rspecifier.find(':');
   if (colon == std::string::npos) K3H_ERR << "Invalid rspecifier " << rspecifier;

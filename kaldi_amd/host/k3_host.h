@@ -99,6 +99,11 @@ void ScaleAcoustic(Lattice *lat, double scale);
 // "key file:offset"); binary FM / DM / CM / CM2 / CM3 (matrix/kaldi-matrix.cc:1402-1520, compressed-matrix.cc:560-660) and text
 struct Matrix { int32_t rows = 0, cols = 0; std::vector<float> data; };
 std::vector<std::pair<std::string, Matrix>> ReadMatrixTable(const std::string &rspecifier);
+// one Matrix<double> object from an rxfilename (ReadKaldiObject: binary "DM"/"FM" after the \0B header, or text) -- CMVN stats files
+struct MatrixD { int32_t rows = 0, cols = 0; std::vector<double> data; };
+MatrixD ReadDoubleMatrix(const std::string &rxfilename);
+// Kaldi token-vector table (util/kaldi-holder-inl.h TokenVectorHolder): "ark:file" with lines "key tok1 tok2 ..." (spk2utt)
+std::vector<std::pair<std::string, std::vector<std::string>>> ReadTokenVectorTable(const std::string &rspecifier);
 
 // best path through a raw lattice (LatticeFasterDecoder::GetBestPath = ShortestPath over the raw lattice, :103-111):
 // transition-ids (alignment) and output labels (words) along it, total graph and acoustic cost.  false if no final state is reachable.

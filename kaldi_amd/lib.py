@@ -18,6 +18,10 @@ class FeatOpts(ctypes.Structure):
                 ("raw_energy", ctypes.c_int32), ("htk_compat", ctypes.c_int32), ("use_log_fbank", ctypes.c_int32), ("use_power", ctypes.c_int32),
                 ("num_ceps", ctypes.c_int32), ("cepstral_lifter", ctypes.c_float), ("feature_type", ctypes.c_int32), ("vtln_warp", ctypes.c_float)]
 
+class OnlineCmvnOpts(ctypes.Structure):      # k3_online_cmvn_opts
+    _fields_ = [("cmn_window", ctypes.c_int32), ("speaker_frames", ctypes.c_int32), ("global_frames", ctypes.c_int32),
+                ("normalize_mean", ctypes.c_int32), ("normalize_variance", ctypes.c_int32)]
+
 class NnetInfo(ctypes.Structure):
     """k3_nnet_info (include/k3hip.h)"""
     _fields_ = [("input_dim", ctypes.c_int32), ("output_dim", ctypes.c_int32), ("left_context", ctypes.c_int32), ("right_context", ctypes.c_int32),
@@ -52,6 +56,8 @@ def load():
     L.k3_feat_num_frames.argtypes = [vp, i64]; L.k3_feat_num_frames.restype = i32
     L.k3_feat_compute_batch.argtypes = [vp, vp, vp, vp, i32, i64, vp, i64, vp]
     L.k3_cmvn_offline_batch.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp]
+    L.k3_online_cmvn_opts_default.argtypes = [ctypes.POINTER(OnlineCmvnOpts)]; L.k3_online_cmvn_opts_default.restype = None
+    L.k3_cmvn_online_batch.argtypes = [vp, i64, vp, i64, i32, vp, i32, ctypes.POINTER(OnlineCmvnOpts), vp, vp, vp, i32, vp]
     L.k3_nnet_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.k3_nnet_destroy.argtypes = [vp]; L.k3_nnet_destroy.restype = None
     L.k3_nnet_get_info.argtypes = [vp, ctypes.POINTER(NnetInfo)]

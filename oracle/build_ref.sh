@@ -59,6 +59,7 @@ link compute-mfcc-feats  $R/featbin/compute-mfcc-feats.cc
 link apply-cmvn          $R/featbin/apply-cmvn.cc
 link compute-cmvn-stats  $R/featbin/compute-cmvn-stats.cc
 link copy-feats          $R/featbin/copy-feats.cc
+link apply-cmvn-online  $R/online2bin/apply-cmvn-online.cc
 link nnet3-init          $R/nnet3bin/nnet3-init.cc
 link nnet3-info          $R/nnet3bin/nnet3-info.cc
 link nnet3-compute       $R/nnet3bin/nnet3-compute.cc

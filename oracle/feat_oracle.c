@@ -294,3 +294,61 @@ int32_t k3o_cmvn_offline(float *feats, int32_t T, int32_t dim, int32_t norm_vars
   free(mean); free(var);
   return 0;
 }
+
+/* feat/online-feature.cc OnlineCmvn::GetFrame (:441-468) for every frame of one utterance (what online2bin/apply-cmvn-online.cc
+ * does per utterance): sliding-window stats in double built by the add-new / subtract-oldest recursion of ComputeStatsForFrame
+ * (:361-393; the caching at :272-338 only copies stats), SmoothOnlineCmvnStats (:397-439) with the speaker stats (may be NULL)
+ * and the global stats, FakeStatsForSomeDims (transform/cmvn.cc:168-179) for skip_dims, then ApplyCmvn (transform/cmvn.cc:64-115)
+ * on the single row.  Stats layout [2 x (dim+1)] doubles: row 0 = sums and count, row 1 = sums of squares.  Returns 0, or -1 on the
+ * conditions the reference raises errors for (no global stats, count < 1). */
+int32_t k3o_cmvn_online(const float *in, float *out, int32_t T, int32_t dim, int32_t cmn_window, int32_t speaker_frames, int32_t global_frames,
+                        int32_t norm_means, int32_t norm_vars, const double *global_stats, const double *speaker_stats,
+                        const int32_t *skip_dims, int32_t n_skip) {
+  if (!global_stats || dim < 1 || speaker_frames > cmn_window || global_frames > speaker_frames) return -1;
+  if (norm_vars && !norm_means) return -1;
+  const int32_t C = dim + 1;
+  double *st = (double *)calloc(2 * C, sizeof(double)), *sm = (double *)calloc(2 * C, sizeof(double));
+  int32_t rc = 0;
+  for (int32_t t = 0; t < T && rc == 0; t++) {
+    for (int32_t d = 0; d < dim; d++) { double x = in[(int64_t)t * dim + d]; st[d] += 1.0 * x; if (norm_vars) st[C + d] += 1.0 * x * x; }
+    st[dim] += 1.0;
+    if (t - cmn_window >= 0) {
+      const float *old = in + (int64_t)(t - cmn_window) * dim;
+      for (int32_t d = 0; d < dim; d++) { double x = old[d]; st[d] += -1.0 * x; if (norm_vars) st[C + d] += -1.0 * x * x; }
+      st[dim] -= 1.0;
+    }
+    for (int32_t i = 0; i < 2 * C; i++) sm[i] = st[i];
+    const int32_t rows = norm_vars ? 2 : 1;          /* the one-row shortcut of SmoothOnlineCmvnStats when variance is not needed */
+    double cur = sm[dim];
+    if (cur < cmn_window) {
+      if (speaker_stats) {
+        double from_spk = cmn_window - cur, spk_count = speaker_stats[dim];
+        if (from_spk > speaker_frames) from_spk = speaker_frames;
+        if (from_spk > spk_count) from_spk = spk_count;
+        if (from_spk > 0.0) { double a = from_spk / spk_count; for (int32_t r = 0; r < rows; r++) for (int32_t i = 0; i < C; i++) sm[r * C + i] += a * speaker_stats[r * C + i]; }
+        cur = sm[dim];
+      }
+      if (cur < cmn_window) {
+        double from_glob = cmn_window - cur, glob_count = global_stats[dim];
+        if (!(glob_count > 0.0)) { rc = -1; break; }
+        if (from_glob > global_frames) from_glob = global_frames;
+        if (from_glob > 0.0) { double a = from_glob / glob_count; for (int32_t r = 0; r < rows; r++) for (int32_t i = 0; i < C; i++) sm[r * C + i] += a * global_stats[r * C + i]; }
+      }
+    }
+    for (int32_t k = 0; k < n_skip; k++) { sm[skip_dims[k]] = 0.0; sm[C + skip_dims[k]] = sm[dim]; }
+    const float *x = in + (int64_t)t * dim; float *y = out + (int64_t)t * dim;
+    if (!norm_means) { for (int32_t d = 0; d < dim; d++) y[d] = x[d]; continue; }
+    const double count = sm[dim];
+    if (count < 1.0) { rc = -1; break; }
+    for (int32_t d = 0; d < dim; d++) {
+      if (!norm_vars) { float alpha = (float)(-1.0 / count); float off = (float)(0.0f + alpha * sm[d]); y[d] = x[d] + 1.0f * off; }
+      else {
+        double m = sm[d] / count, v = sm[C + d] / count - m * m; if (v < 1.0e-20) v = 1.0e-20;
+        double sc = 1.0 / sqrt(v); float fo = (float)(-(m * sc)), fs = (float)sc;
+        float z = x[d]; z *= fs; z += 1.0f * fo; y[d] = z;
+      }
+    }
+  }
+  free(st); free(sm);
+  return rc;
+}

@@ -41,6 +41,7 @@ def lib():
         _lib.k3o_feat_dim.argtypes = [ctypes.POINTER(FeatOpts)]
         _lib.k3o_compute_features.argtypes = [ctypes.POINTER(FeatOpts), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         _lib.k3o_cmvn_offline.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        _lib.k3o_cmvn_online.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int32] * 7 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
     return _lib
 
 def num_frames(nsamp, opts):
@@ -59,3 +60,14 @@ def cmvn_offline(feats, norm_vars=False):
     f = np.array(feats, dtype=np.float32, order='C', copy=True)
     r = lib().k3o_cmvn_offline(f.ctypes.data, f.shape[0], f.shape[1], int(norm_vars)); assert r == 0
     return f
+
+def cmvn_online(feats, global_stats, speaker_stats=None, cmn_window=600, speaker_frames=600, global_frames=200, norm_means=True, norm_vars=False, skip_dims=()):
+    """apply-cmvn-online on one utterance (feat/online-feature.cc:361-468).  Stats are [2 x (dim+1)] float64."""
+    f = np.ascontiguousarray(feats, dtype=np.float32); out = np.empty_like(f)
+    g = np.ascontiguousarray(global_stats, dtype=np.float64); assert g.shape == (2, f.shape[1] + 1)
+    sp = None if speaker_stats is None else np.ascontiguousarray(speaker_stats, dtype=np.float64)
+    sk = np.ascontiguousarray(list(skip_dims), dtype=np.int32)
+    r = lib().k3o_cmvn_online(f.ctypes.data, out.ctypes.data, f.shape[0], f.shape[1], cmn_window, speaker_frames, global_frames, int(norm_means), int(norm_vars),
+                              g.ctypes.data, None if sp is None else sp.ctypes.data, sk.ctypes.data if len(sk) else None, len(sk))
+    if r != 0: raise ValueError("online CMVN: the reference raises an error for these stats/options")
+    return out

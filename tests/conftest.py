@@ -11,3 +11,8 @@ def pytest_configure(config):
 def feat_golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "feat_golden.npz"))
+
+@pytest.fixture(scope="session")
+def cmvn_online_golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "cmvn_online_golden.npz"))

@@ -143,3 +143,35 @@ def test_nnet3_latgen_faster_end_to_end(tmp_path):
     # default --determinize-lattice=true is refused loudly
     r = subprocess.run([c for c in cmd if not c.startswith("--determinize")], capture_output=True, text=True)
     assert r.returncode == 255 and "determinize-lattice" in r.stderr
+
+
+@pytest.mark.parametrize("flags,spk", [([], False), (["--cmn-window=100", "--speaker-frames=100", "--global-frames=10", "--norm-vars=true", "--skip-dims=0:5"], True),
+                                       (["--cmn-window=100", "--speaker-frames=60", "--global-frames=25"], True)])
+def test_apply_cmvn_online_cuda_matches_the_reference_binary(tmp_path, cmvn_online_golden, flags, spk):
+    """apply-cmvn-online-cuda (and its --spk2utt extension) vs the reference's online2bin/apply-cmvn-online run here on the same archive
+    (oracle/_ref), and vs the committed fixtures where the option set is one of theirs."""
+    from oracle import kaldi_io as kio
+    g = cmvn_online_golden; td = str(tmp_path)
+    kio.write_ark(f"{td}/ab.ark", {"utt_a": g["feats_a"], "utt_b": g["feats_b"]})
+    with open(f"{td}/g.txt", "w") as f:
+        f.write(" [\n" + "\n".join("  " + " ".join(repr(float(x)) for x in row) for row in g["global"]) + " ]\n")
+    open(f"{td}/spk2utt", "w").write("spk1 utt_a utt_b\n")
+    extra = [f"--spk2utt=ark:{td}/spk2utt"] if spk else []
+    r = subprocess.run([os.path.join(BIN, "apply-cmvn-online-cuda")] + flags + extra + [f"{td}/g.txt", f"ark:{td}/ab.ark", f"ark:{td}/gpu.ark"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Applied online CMVN to 2 files, or 1141 frames." in r.stderr
+    got = kio.read_ark(f"{td}/gpu.ark")
+    if os.path.exists(os.path.join(REF, "apply-cmvn-online")):
+        q = subprocess.run([os.path.join(REF, "apply-cmvn-online")] + flags + extra + [f"{td}/g.txt", f"ark:{td}/ab.ark", f"ark:{td}/ref.ark"], env=ENV, capture_output=True, text=True)
+        assert q.returncode == 0, q.stderr
+        ref = kio.read_ark(f"{td}/ref.ark")
+        assert list(ref) == list(got)
+        for k in ref: assert np.array_equal(ref[k], got[k]), (k, np.abs(ref[k] - got[k]).max())
+    name = {(): "default", ("--cmn-window=100", "--speaker-frames=100", "--global-frames=10", "--norm-vars=true", "--skip-dims=0:5"): "w100_spk_vars_skip",
+            ("--cmn-window=100", "--speaker-frames=60", "--global-frames=25"): "w100_spk"}[tuple(flags)]
+    for k in got: assert np.array_equal(got[k], g[f"ref_{name}_{k}"])
+    # usage / error behaviour of the reference program: wrong argument count -> usage + exit 1; bad stats -> message + exit 255 (-1)
+    assert subprocess.run([os.path.join(BIN, "apply-cmvn-online-cuda"), f"{td}/g.txt"], capture_output=True).returncode == 1
+    open(f"{td}/bad.txt", "w").write(" [\n 1 2 3 ]\n")
+    b = subprocess.run([os.path.join(BIN, "apply-cmvn-online-cuda"), f"{td}/bad.txt", f"ark:{td}/ab.ark", f"ark:{td}/o.ark"], capture_output=True, text=True)
+    assert b.returncode == 255 and "stats" in b.stderr

@@ -98,3 +98,46 @@ def test_hip_full_size_properties():
     c = sf.ComputeFeatures(sub, wo2, fo2, total2)
     torch.cuda.synchronize()
     assert torch.equal(c, a[3 * 998 + k: 4 * 998])
+
+
+# ---- online CMVN: HIP vs the reference's apply-cmvn-online fixtures and vs the oracle
+from tests import cmvn_cases as cc
+
+@pytest.mark.parametrize("name", sorted(cc.CASES))
+def test_hip_cmvn_online_vs_reference_binary(cmvn_online_golden, name):
+    from kaldi_amd import feat
+    from oracle import feat_oracle as fo
+    g = cmvn_online_golden; dev = torch.device("cuda:0")
+    runs = list(cc.runs(g, name)); kw = runs[0][4]
+    dim = runs[0][1].shape[1]
+    feats = torch.from_numpy(np.concatenate([r[1] for r in runs], 0)).to(dev)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum([r[1].shape[0] for r in runs])]), dtype=torch.int64, device=dev)
+    spk = None
+    if any(r[3] is not None for r in runs):
+        spk = np.stack([r[3] if r[3] is not None else np.zeros((2, dim + 1)) for r in runs], 0)
+    got = feat.ApplyCmvnOnline(feats, offs, runs[0][2], speaker_stats=spk, **kw).cpu().numpy()
+    o = 0
+    for utt, f, gs, sp, _ in runs:
+        ref = g[f"ref_{name}_{utt}"]; mine = got[o:o + f.shape[0]]; o += f.shape[0]
+        assert np.abs(mine - ref).max() <= 2e-6, (name, utt, np.abs(mine - ref).max())
+        orc = fo.cmvn_online(f, gs, speaker_stats=sp, **kw)
+        assert np.array_equal(mine, orc), (name, utt, np.abs(mine - orc).max())     # same fp64 recursion, no contraction: bit-equal to the restatement
+
+def test_hip_cmvn_online_batch_ragged_and_errors(cmvn_online_golden):
+    from kaldi_amd import feat
+    from oracle import feat_oracle as fo
+    g = cmvn_online_golden; dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5); lens = [0, 1, 37, 650, 1203, 5]
+    mats = [(rng.normal(0, 3, (n, 13)) + rng.normal(0, 2, (1, 13))).astype(np.float32) for n in lens]
+    feats = torch.from_numpy(np.concatenate(mats, 0)).to(dev)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=dev)
+    padded = torch.zeros((feats.shape[0], 16), device=dev); padded[:, :13] = feats        # leading dimension > dim
+    got = feat.ApplyCmvnOnline(padded[:, :13], offs, g["global"], norm_vars=True).cpu().numpy()
+    o = 0
+    for m in mats:
+        if m.shape[0]: assert np.array_equal(got[o:o + m.shape[0]], fo.cmvn_online(m, g["global"], norm_vars=True))
+        o += m.shape[0]
+    bad = g["global"].copy(); bad[0, -1] = 0.0
+    with pytest.raises(RuntimeError): feat.ApplyCmvnOnline(feats, offs, bad)
+    with pytest.raises(RuntimeError): feat.ApplyCmvnOnline(feats, offs, g["global"], cmn_window=10, speaker_frames=20, global_frames=5)
+    with pytest.raises(RuntimeError): feat.ApplyCmvnOnline(feats, offs, g["global"], norm_means=False, norm_vars=True)

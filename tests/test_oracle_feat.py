@@ -46,3 +46,23 @@ def test_oracle_num_frames_edges():
     o2 = fo.fbank_opts(snip_edges=0)
     assert fo.num_frames(160000, o2) == 1000 and fo.num_frames(79, o2) == 0 and fo.num_frames(80, o2) == 1
     assert fo.compute_features(np.zeros(100, np.float32), o).shape == (0, 23)
+
+# ---- online CMVN (feat/online-feature.cc OnlineCmvn) vs the reference's apply-cmvn-online (tests/golden/cmvn_online_golden.npz)
+from tests import cmvn_cases as cc
+
+@pytest.mark.parametrize("name", sorted(cc.CASES))
+def test_oracle_cmvn_online_vs_reference_binary(cmvn_online_golden, name):
+    g = cmvn_online_golden
+    for utt, feats, gstats, spk, kw in cc.runs(g, name):
+        got = fo.cmvn_online(feats, gstats, speaker_stats=spk, **kw)
+        ref = g[f"ref_{name}_{utt}"]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-6, (name, utt, np.abs(got - ref).max())
+        if not kw.get("norm_vars"): assert np.array_equal(got, ref)          # mean-only: the double-precision recursion is reproduced exactly
+
+def test_oracle_cmvn_online_rejects_what_the_reference_rejects(cmvn_online_golden):
+    g = cmvn_online_golden
+    with pytest.raises(ValueError): fo.cmvn_online(g["feats_a"], g["global"], norm_means=False, norm_vars=True)
+    bad = g["global"].copy(); bad[0, -1] = 0.0
+    with pytest.raises(ValueError): fo.cmvn_online(g["feats_a"], bad)
+    with pytest.raises(ValueError): fo.cmvn_online(g["feats_a"], g["global"], cmn_window=10, speaker_frames=20, global_frames=5)
