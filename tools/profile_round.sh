@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): collects the rocprofv3 evidence for bench.py's numbers into gpurun_out/prof_<tag>/.
+#   tools/profile_round.sh <tag>
+# 1. kernel trace + stats (csv) of `bench.py --steps 3 --warmup 1`; 2./3. PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace
+# domains) of one step.  tools/profile_summary.py turns the raw output into the files committed under profiles/.
+set -u
+TAG=${1:-rXX}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
+export TMPDIR=/tmp; cd /tmp
+B="python $ROOT/bench.py --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $B --steps 3 --warmup 1 > $OUT/bench_trace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $B --steps 1 --warmup 0 > $OUT/bench_pmc_$c.log 2>&1
+done
+cd $ROOT
+timeout 600 python bench.py --steps 5 --warmup 2 > $OUT/bench_line.json 2> $OUT/bench_line.err
+python tools/profile_summary.py $TAG $OUT
+ls -la $OUT

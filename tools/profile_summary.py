@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Reduce the raw rocprofv3 output of tools/profile_round.sh to the small summaries committed under profiles/:
+  <tag>_bench_full_pipeline_kernel_stats.csv   the --stats kernel table of the traced bench run
+  <tag>_bench_full_pipeline_pmc_hbm.csv        FETCH_SIZE / WRITE_SIZE summed per kernel (KB, as rocprof reports them)
+  <tag>_bench_line.json                        the bench.py line of the same build
+  hbm_traffic.json                             per-launch HBM traffic of the dominant kernel (read by bench.py's roofline.traffic)
+usage: profile_summary.py <tag> <dir with trace/ pmc_FETCH_SIZE/ pmc_WRITE_SIZE/ bench_line.json>"""
+import csv, glob, json, os, re, sys
+tag, src = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); dst = os.path.join(ROOT, "gpurun_out", "profiles_" + tag); os.makedirs(dst, exist_ok=True)
+def find(sub, pat):
+    f = sorted(glob.glob(os.path.join(src, sub, "**", pat), recursive=True)); return f[0] if f else None
+st = find("trace", "*kernel_stats.csv")
+if st: open(os.path.join(dst, f"{tag}_bench_full_pipeline_kernel_stats.csv"), "w").write(open(st).read())
+rows = []
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name); name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_:]+(?:<[^>]*>)?)", name); return m.group(1) if m else name
+traffic = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = find("pmc_" + c, "*counter_collection.csv")
+    if not f: continue
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") != c: continue
+        k = short(r["Kernel_Name"]); a = acc.setdefault(k, [set(), 0.0]); a[0].add(r["Dispatch_Id"]); a[1] += float(r["Counter_Value"])
+    for k, (d, v) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        rows.append((k, c, len(d), v, v / max(1, len(d))))
+        if k.startswith("k3_decode_forward_kernel"): traffic[c] = v / max(1, len(d)) * 1024.0
+with open(os.path.join(dst, f"{tag}_bench_full_pipeline_pmc_hbm.csv"), "w") as f:
+    f.write(f"# rocprofv3 --pmc <counter> (separate passes, no trace domains) over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline` (512 x 10 s utts), {tag}\n"
+            "# Counter_Value summed over the dispatches of each kernel; FETCH_SIZE / WRITE_SIZE are in KB (rocprof definition).\n"
+            "# gfx950 caveat (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced loads (x2 correction); narrow random\n"
+            "# 4-16 B accesses (the decoder's pattern) and WRITE_SIZE are uncalibrated -> read these as relative over-fetch indicators, not absolute HBM bytes.\n"
+            "kernel,counter,dispatches,sum_KB,per_dispatch_KB\n")
+    for r in rows: f.write("%s,%s,%d,%.1f,%.1f\n" % r)
+bl = os.path.join(src, "bench_line.json")
+if os.path.exists(bl):
+    lines = [l for l in open(bl).read().splitlines() if l.startswith("{")]
+    if lines: open(os.path.join(dst, f"{tag}_bench_line.json"), "w").write(lines[-1] + "\n")
+if len(traffic) == 2:
+    json.dump({"kernel": "k3_decode_forward_kernel", "source": f"profiles/{tag}_bench_full_pipeline_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 512 x 10 s utts)",
+               "fetch_bytes_per_launch": traffic["FETCH_SIZE"], "write_bytes_per_launch": traffic["WRITE_SIZE"], "traffic_bytes_per_launch": traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"],
+               "note": "FETCH_SIZE/WRITE_SIZE as reported (KB x 1024); the gfx950 x2 correction for wide coalesced loads does not apply to the decoder's narrow random accesses; uncalibrated for this pattern"},
+              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+print("summaries in", dst, os.listdir(dst))
