@@ -56,7 +56,9 @@ struct GemmParams {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <int BN, int WM, int WN>
+// kAligned: every k-tile lies inside one time offset and inside K (tiles_per_off > 0) -- a separate instantiation, because a
+// runtime choice between the two loaders makes the compiler merge their registers with moves that wait for the loads at once.
+template <int BN, int WM, int WN, bool kAligned>
 __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p) {
   constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
   constexpr int A_LOADS = kBM * kBK / 4 / kThreads;   // float4 loads per thread per k-tile (4)
@@ -83,18 +85,33 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
   for (int i = 0; i < A_LOADS; i++) a_row_local[i] = min(i * 32 + ld_row, td.nrows - 1) * p.row_stride + td.in_base;
 
   f32x4 ra[A_LOADS], rb[B_LOADS];
-  auto load_tiles = [&](int kt) {
+  // `oi_u` = time offset the k-tile lies in when offsets are tile aligned (tiles_per_off > 0): uniform over the block, so the
+  // row shift is picked with scalar selects.  (Indexing the kernel-argument array with a per-lane value costs a dependent
+  // global load at the top of every k-tile, and the waits the compiler puts around it serialise the whole tile prefetch.)
+  auto load_tiles = [&](int kt, int oi_u) {
     const int kglob = kt * kBK + ld_kv;
-    const int oi = kglob / p.in_dim, col = kglob - oi * p.in_dim;
-    const bool kvalid = kglob < p.Ktot;
-    const int shift = kvalid ? p.shifts[oi] : 0;
+    if constexpr (kAligned) {        // straight-line loads, nothing to wait for in between
+      int sh = p.shifts[0];
 #pragma unroll
-    for (int i = 0; i < A_LOADS; i++) {
-      if (kvalid) {
-        const int row = clampi(a_row_local[i] + shift, td.in_lo, td.in_hi);
+      for (int o = 1; o < kMaxOffsets; o++) sh = oi_u == o ? p.shifts[o] : sh;
+      const int col = kglob - oi_u * p.in_dim;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; i++) {
+        const int row = clampi(a_row_local[i] + sh, td.in_lo, td.in_hi);
         ra[i] = *reinterpret_cast<const f32x4 *>(p.A + (long long)row * p.lda + col);
-      } else {
-        ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      const bool kvalid = kglob < p.Ktot;
+      const int oi = kglob / p.in_dim, col = kglob - oi * p.in_dim;
+      const int shift = kvalid ? p.shifts[oi] : 0;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; i++) {
+        if (kvalid) {
+          const int row = clampi(a_row_local[i] + shift, td.in_lo, td.in_hi);
+          ra[i] = *reinterpret_cast<const f32x4 *>(p.A + (long long)row * p.lda + col);
+        } else {
+          ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
 #pragma unroll
@@ -139,14 +156,21 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
   const int nk = (p.Ktot + kBK - 1) / kBK;
   long long t0 = 0, t1 = 0, t2 = 0;
   if (p.dbg & 8) t0 = (long long)__builtin_readcyclecounter();
-  load_tiles(0);
+  int oi_next = 0, w_next = 0;       // time offset of tile kt + 1 and its index inside the offset (tiles_per_off > 0)
+  load_tiles(0, 0);
   store_tiles(0);
   __syncthreads();
   if (p.dbg & 8) t1 = (long long)__builtin_readcyclecounter();
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
   for (int kt = 0; kt < ((p.dbg & 4) ? 1 : nk); kt++) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
+    // prefetch tile kt + 1 (the last iteration fetches its own tile again: no branch in the loop body, so the compiler's
+    // s_waitcnt placement stays exact -- with conditional prefetches it put vmcnt(0) between the loads of one tile)
+    const int w_cur = w_next, oi_cur = oi_next;        // index of tile kt inside its offset
+    const bool more = kt + 1 < nk;
+    if (++w_next == p.tiles_per_off) { w_next = 0; oi_next++; }
+    load_tiles(more ? kt + 1 : kt, more ? oi_next : oi_cur);
+    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMAs: the scheduler otherwise sinks the loads to the end of the tile, right in front of their use
     const float *a = As + buf * kBM * kLdsLd + (wm * WM + frag_row) * kLdsLd + frag_k;
     const float *b = Bs + buf * BN * kLdsLd + (wn * WN + frag_row) * kLdsLd + frag_k;
 #pragma unroll
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
     }
     {   // end of an accumulation segment?
       bool flush = kt + 1 == nk;
-      if (p.tiles_per_off > 0) { const int w = kt % p.tiles_per_off + 1; flush = flush || w == p.tiles_per_off || w % p.tiles_per_seg == 0; }
+      if (p.tiles_per_off > 0) { const int w = w_cur + 1; flush = flush || w == p.tiles_per_off || w % p.tiles_per_seg == 0; }
       if (flush) {
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
@@ -176,7 +200,7 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
             for (int r = 0; r < 16; r++) { tot[mi][ni][r] += acc[mi][ni][r]; acc[mi][ni][r] = 0.0f; }
       }
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    store_tiles(buf ^ 1);
     __syncthreads();
   }
 
@@ -543,8 +567,10 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
   K3_REQUIRE(ld_out >= fm.output_dim, "k3_nnet_forward: ld_out < output dim");
   static bool attr_set = false;
   if (!attr_set) {
-    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<128, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<96, 32, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<128, 64, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<128, 64, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<96, 32, 96, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<96, 32, 96, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -574,10 +600,12 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
       const int blocks = p.num_m_tiles * p.num_n_tiles;
       if (b->net->dev[i].bn == 96) {
         const size_t lds = 2 * (kBM + 96) * kLdsLd * sizeof(float);
-        hipLaunchKernelGGL((k3_tdnn_gemm_kernel<96, 32, 96>), dim3(blocks), dim3(kThreads), lds, st, p);
+        if (p.tiles_per_off > 0) hipLaunchKernelGGL((k3_tdnn_gemm_kernel<96, 32, 96, true>), dim3(blocks), dim3(kThreads), lds, st, p);
+        else hipLaunchKernelGGL((k3_tdnn_gemm_kernel<96, 32, 96, false>), dim3(blocks), dim3(kThreads), lds, st, p);
       } else {
         const size_t lds = 2 * (kBM + 128) * kLdsLd * sizeof(float);
-        hipLaunchKernelGGL((k3_tdnn_gemm_kernel<128, 64, 64>), dim3(blocks), dim3(kThreads), lds, st, p);
+        if (p.tiles_per_off > 0) hipLaunchKernelGGL((k3_tdnn_gemm_kernel<128, 64, 64, true>), dim3(blocks), dim3(kThreads), lds, st, p);
+        else hipLaunchKernelGGL((k3_tdnn_gemm_kernel<128, 64, 64, false>), dim3(blocks), dim3(kThreads), lds, st, p);
       }
     }
     K3_HIP_CHECK(hipGetLastError());
