@@ -88,18 +88,19 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
   // `oi_u` = time offset the k-tile lies in when offsets are tile aligned (tiles_per_off > 0): uniform over the block, so the
   // row shift is picked with scalar selects.  (Indexing the kernel-argument array with a per-lane value costs a dependent
   // global load at the top of every k-tile, and the waits the compiler puts around it serialise the whole tile prefetch.)
-  auto load_tiles = [&](int kt, int oi_u) {
+  const float *a_ptr[A_LOADS];      // kAligned: this thread's A addresses for the next tile; recomputed when the time offset changes
+  auto load_tiles = [&](int kt, int oi_u, int w_u) {
     const int kglob = kt * kBK + ld_kv;
     if constexpr (kAligned) {        // straight-line loads, nothing to wait for in between
-      int sh = p.shifts[0];
+      if (w_u == 0) {                // first tile of a time offset (block-uniform): row shift and clamped rows change
+        int sh = p.shifts[0];
 #pragma unroll
-      for (int o = 1; o < kMaxOffsets; o++) sh = oi_u == o ? p.shifts[o] : sh;
-      const int col = kglob - oi_u * p.in_dim;
+        for (int o = 1; o < kMaxOffsets; o++) sh = oi_u == o ? p.shifts[o] : sh;
 #pragma unroll
-      for (int i = 0; i < A_LOADS; i++) {
-        const int row = clampi(a_row_local[i] + sh, td.in_lo, td.in_hi);
-        ra[i] = *reinterpret_cast<const f32x4 *>(p.A + (long long)row * p.lda + col);
+        for (int i = 0; i < A_LOADS; i++) a_ptr[i] = p.A + (long long)clampi(a_row_local[i] + sh, td.in_lo, td.in_hi) * p.lda + ld_kv;
       }
+#pragma unroll
+      for (int i = 0; i < A_LOADS; i++) { ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i]); a_ptr[i] += kBK; }
     } else {
       const bool kvalid = kglob < p.Ktot;
       const int oi = kglob / p.in_dim, col = kglob - oi * p.in_dim;
@@ -130,12 +131,12 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
 #pragma unroll
     for (int i = 0; i < A_LOADS; i++) {
       float *q = a + (i * 32 + ld_row) * kLdsLd + st_col;
-      *reinterpret_cast<f32x2 *>(q) = f32x2{ra[i][0], ra[i][2]}; *reinterpret_cast<f32x2 *>(q + 4) = f32x2{ra[i][1], ra[i][3]};
+      q[0] = ra[i][0]; q[4] = ra[i][1]; q[1] = ra[i][2]; q[5] = ra[i][3];       // two ds_write2_b32 straight from the load registers
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; i++) {
       float *q = b + (i * 32 + ld_row) * kLdsLd + st_col;
-      *reinterpret_cast<f32x2 *>(q) = f32x2{rb[i][0], rb[i][2]}; *reinterpret_cast<f32x2 *>(q + 4) = f32x2{rb[i][1], rb[i][3]};
+      q[0] = rb[i][0]; q[4] = rb[i][1]; q[1] = rb[i][2]; q[5] = rb[i][3];
     }
   };
 
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
   long long t0 = 0, t1 = 0, t2 = 0;
   if (p.dbg & 8) t0 = (long long)__builtin_readcyclecounter();
   int oi_next = 0, w_next = 0;       // time offset of tile kt + 1 and its index inside the offset (tiles_per_off > 0)
-  load_tiles(0, 0);
+  load_tiles(0, 0, 0);
   store_tiles(0);
   __syncthreads();
   if (p.dbg & 8) t1 = (long long)__builtin_readcyclecounter();
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
     const int w_cur = w_next, oi_cur = oi_next;        // index of tile kt inside its offset
     const bool more = kt + 1 < nk;
     if (++w_next == p.tiles_per_off) { w_next = 0; oi_next++; }
-    load_tiles(more ? kt + 1 : kt, more ? oi_next : oi_cur);
+    load_tiles(more ? kt + 1 : kt, more ? oi_next : oi_cur, more ? w_next : 1);
     __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMAs: the scheduler otherwise sinks the loads to the end of the tile, right in front of their use
     const float *a = As + buf * kBM * kLdsLd + (wm * WM + frag_row) * kLdsLd + frag_k;
     const float *b = Bs + buf * BN * kLdsLd + (wn * WN + frag_row) * kLdsLd + frag_k;
