@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
   // instructions per lane, which is what the affine layers (K = 192 only) spent 60 % of their time on.  Instead each wavefront
   // transposes its WM x WN accumulator tile through LDS (the tile buffers are dead by now) and then works on float4 row
   // pieces: 4x fewer, 4x wider memory instructions, 256-byte runs per row.
-  constexpr int kStLd = WN + 4, C4 = WN / 4, ITERS = WM * C4 / 64;
+  constexpr int kStLd = WN + 4, C4 = WN / 4, RPI = 64 / C4, ITERS = WM / RPI;      // RPI rows per iteration; lanes >= RPI * C4 idle (WN = 96: 48 of 64 busy)
   float *stage = reinterpret_cast<float *>(smem) + wave * (WM * kStLd);
 #pragma unroll
   for (int mi = 0; mi < MI; mi++)
@@ -226,35 +226,64 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
   const float *__restrict__ R = p.R; float *__restrict__ C = p.C;
   const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                       (res_kind < 0 || ((p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0)));
-  f32x4 res[ITERS];
-  if (res_kind >= 0 && vec_ok && !(p.dbg & 1)) {       // all residual row pieces of the tile in flight before the first use
+  // Everything the per-element program needs is fetched up front, all loads in flight together: the residual row pieces of the
+  // tile and, per epilogue op, this lane's four columns of its scale / offset vectors (a lane keeps the same columns over all
+  // its rows).  The op program is then applied op by op over the whole register tile: six block-uniform dispatches per tile
+  // instead of per row piece, and no scalar / vector loads between the arithmetic.  (Fetching kinds, pointers and vectors
+  // inside the row loop cost 42 k of the 48 k epilogue cycles of a K = 192 layer.)
+  const int c4 = lane % C4, row0 = lane / C4;                 // row = it * RPI + row0, column group c4
+  static_assert(WM % RPI == 0, "rows per iteration must divide the wave tile");
+  const bool lane_on = lane < RPI * C4;
+  const int col = lane_on ? n0 + wn * WN + c4 * 4 : p.N;      // idle lanes look like out-of-range columns
+  if (vec_ok) {
+    f32x4 res[ITERS], opS[kMaxOps], opO[kMaxOps], v[ITERS];
+    const bool col_ok = col < p.N;
+    const int colc = min(col, p.N - 4);
+    const int row0c = lane_on ? row0 : 0;
+    if (res_kind >= 0 && !(p.dbg & 1)) {
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-      const int idx = it * 64 + lane, row = idx / C4, c4 = idx - row * C4;
-      const int lrow = min(wm * WM + row, td.nrows - 1), col = min(n0 + wn * WN + c4 * 4, p.N - 4);
-      res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + col);
+      for (int it = 0; it < ITERS; it++) {
+        const int lrow = min(wm * WM + it * RPI + row0, td.nrows - 1);
+        res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + colc);
+      }
     }
-  }
-  __syncthreads();
 #pragma unroll
-  for (int it = 0; it < ITERS; it++) {
-    const int idx = it * 64 + lane, row = idx / C4, c4 = idx - row * C4;
-    const int lrow = wm * WM + row, col = n0 + wn * WN + c4 * 4;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * kStLd + c4 * 4);
-    if (col >= p.N || lrow >= td.nrows) continue;
-    if (vec_ok) {
+    for (int o = 0; o < kMaxOps; o++) {
+      if (o < p.nops && p.op_kind[o] == k3::kEpiScaleOffset) {
+        opS[o] = *reinterpret_cast<const f32x4 *>(p.op_scale[o] + colc); opO[o] = *reinterpret_cast<const f32x4 *>(p.op_offset[o] + colc);
+      }
+    }
+    __syncthreads();
 #pragma unroll
-      for (int o = 0; o < kMaxOps; o++) {
-        if (o < p.nops) {
-          const int kind = p.op_kind[o];
-          if (kind == k3::kEpiRelu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
-          else if (kind == k3::kEpiScaleOffset) v = v * *reinterpret_cast<const f32x4 *>(p.op_scale[o] + col) + *reinterpret_cast<const f32x4 *>(p.op_offset[o] + col);
-          else v = p.res_scale * res[it] + v;
+    for (int it = 0; it < ITERS; it++) v[it] = *reinterpret_cast<const f32x4 *>(stage + (it * RPI + row0c) * kStLd + c4 * 4);
+#pragma unroll
+    for (int o = 0; o < kMaxOps; o++) {
+      if (o < p.nops) {
+        const int kind = p.op_kind[o];
+        if (kind == k3::kEpiRelu) {
+#pragma unroll
+          for (int it = 0; it < ITERS; it++) { v[it][0] = fmaxf(v[it][0], 0.0f); v[it][1] = fmaxf(v[it][1], 0.0f); v[it][2] = fmaxf(v[it][2], 0.0f); v[it][3] = fmaxf(v[it][3], 0.0f); }
+        } else if (kind == k3::kEpiScaleOffset) {
+#pragma unroll
+          for (int it = 0; it < ITERS; it++) v[it] = v[it] * opS[o] + opO[o];
+        } else {
+#pragma unroll
+          for (int it = 0; it < ITERS; it++) v[it] = p.res_scale * res[it] + v[it];
         }
       }
-      if (!(p.dbg & 2) || v[0] == 12345.678f) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v;
-    } else {                                           // unaligned / odd-width output: element-wise tail path
+    }
 #pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+      const int lrow = wm * WM + it * RPI + row0;
+      if (col_ok && lrow < td.nrows && (!(p.dbg & 2) || v[it][0] == 12345.678f)) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v[it];
+    }
+  } else {                                             // unaligned / odd-width output: element-wise tail path
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) {
+      const int row = it * RPI + row0, lrow = wm * WM + row;
+      if (col >= p.N || lrow >= td.nrows) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * kStLd + c4 * 4);
       for (int e = 0; e < 4; e++) {
         const int c = col + e;
         if (c >= p.N) break;
