@@ -58,7 +58,11 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 // kAligned: every k-tile lies inside one time offset and inside K (tiles_per_off > 0) -- a separate instantiation, because a
 // runtime choice between the two loaders makes the compiler merge their registers with moves that wait for the loads at once.
-template <int BN, int WM, int WN, bool kAligned>
+// EPI: the epilogue program known at compile time -- 0: any (run-time dispatch per op), 1: ReLU, scale/offset, residual (a TDNN-F
+// affine + ReLU + BatchNorm + bypass), 2: none (linear bottleneck), 3: ReLU, scale/offset.  The fixed programs are straight-line
+// code; the run-time dispatch costs a register shuffle per op when it merges the branches.
+enum { kEpiAny = 0, kEpiReluScaleRes = 1, kEpiNone = 2, kEpiReluScale = 3 };
+template <int BN, int WM, int WN, bool kAligned, int EPI>
 __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p) {
   constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
   constexpr int A_LOADS = kBM * kBK / 4 / kThreads;   // float4 loads per thread per k-tile (4)
@@ -240,36 +244,49 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
     const bool col_ok = col < p.N;
     const int colc = min(col, p.N - 4);
     const int row0c = lane_on ? row0 : 0;
-    if (res_kind >= 0 && !(p.dbg & 1)) {
+    if ((EPI == kEpiAny || EPI == kEpiReluScaleRes) && res_kind >= 0 && !(p.dbg & 1)) {
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
         const int lrow = min(wm * WM + it * RPI + row0, td.nrows - 1);
         res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + colc);
       }
     }
+    if (EPI == kEpiAny) {
 #pragma unroll
-    for (int o = 0; o < kMaxOps; o++) {
-      if (o < p.nops && p.op_kind[o] == k3::kEpiScaleOffset) {
-        opS[o] = *reinterpret_cast<const f32x4 *>(p.op_scale[o] + colc); opO[o] = *reinterpret_cast<const f32x4 *>(p.op_offset[o] + colc);
+      for (int o = 0; o < kMaxOps; o++) {
+        if (o < p.nops && p.op_kind[o] == k3::kEpiScaleOffset) {
+          opS[o] = *reinterpret_cast<const f32x4 *>(p.op_scale[o] + colc); opO[o] = *reinterpret_cast<const f32x4 *>(p.op_offset[o] + colc);
+        }
       }
+    } else if (EPI == kEpiReluScaleRes || EPI == kEpiReluScale) {
+      opS[1] = *reinterpret_cast<const f32x4 *>(p.op_scale[1] + colc); opO[1] = *reinterpret_cast<const f32x4 *>(p.op_offset[1] + colc);
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) v[it] = *reinterpret_cast<const f32x4 *>(stage + (it * RPI + row0c) * kStLd + c4 * 4);
+    if (EPI == kEpiAny) {
 #pragma unroll
-    for (int o = 0; o < kMaxOps; o++) {
-      if (o < p.nops) {
-        const int kind = p.op_kind[o];
-        if (kind == k3::kEpiRelu) {
+      for (int o = 0; o < kMaxOps; o++) {
+        if (o < p.nops) {
+          const int kind = p.op_kind[o];
+          if (kind == k3::kEpiRelu) {
 #pragma unroll
-          for (int it = 0; it < ITERS; it++) { v[it][0] = fmaxf(v[it][0], 0.0f); v[it][1] = fmaxf(v[it][1], 0.0f); v[it][2] = fmaxf(v[it][2], 0.0f); v[it][3] = fmaxf(v[it][3], 0.0f); }
-        } else if (kind == k3::kEpiScaleOffset) {
+            for (int it = 0; it < ITERS; it++) { v[it][0] = fmaxf(v[it][0], 0.0f); v[it][1] = fmaxf(v[it][1], 0.0f); v[it][2] = fmaxf(v[it][2], 0.0f); v[it][3] = fmaxf(v[it][3], 0.0f); }
+          } else if (kind == k3::kEpiScaleOffset) {
 #pragma unroll
-          for (int it = 0; it < ITERS; it++) v[it] = v[it] * opS[o] + opO[o];
-        } else {
+            for (int it = 0; it < ITERS; it++) v[it] = v[it] * opS[o] + opO[o];
+          } else {
 #pragma unroll
-          for (int it = 0; it < ITERS; it++) v[it] = p.res_scale * res[it] + v[it];
+            for (int it = 0; it < ITERS; it++) v[it] = p.res_scale * res[it] + v[it];
+          }
         }
+      }
+    } else if (EPI == kEpiReluScaleRes || EPI == kEpiReluScale) {
+#pragma unroll
+      for (int it = 0; it < ITERS; it++) {
+        v[it][0] = fmaxf(v[it][0], 0.0f); v[it][1] = fmaxf(v[it][1], 0.0f); v[it][2] = fmaxf(v[it][2], 0.0f); v[it][3] = fmaxf(v[it][3], 0.0f);
+        v[it] = v[it] * opS[1] + opO[1];
+        if (EPI == kEpiReluScaleRes) v[it] = p.res_scale * res[it] + v[it];
       }
     }
 #pragma unroll
@@ -597,10 +614,11 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
   K3_REQUIRE(ld_out >= fm.output_dim, "k3_nnet_forward: ld_out < output dim");
   static bool attr_set = false;
   if (!attr_set) {
-    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<128, 64, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<128, 64, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<96, 32, 96, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<96, 32, 96, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define K3_GEMM_VARIANTS(X) X(128, 64, 64, true, kEpiAny) X(128, 64, 64, false, kEpiAny) X(128, 64, 64, true, kEpiReluScaleRes) X(128, 64, 64, false, kEpiReluScale) \
+                            X(128, 64, 64, true, kEpiReluScale) X(96, 32, 96, true, kEpiAny) X(96, 32, 96, false, kEpiAny) X(96, 32, 96, true, kEpiNone)
+#define K3_SET_ATTR(bn, wm, wn, al, ep) K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<bn, wm, wn, al, ep>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_GEMM_VARIANTS(K3_SET_ATTR)
+#undef K3_SET_ATTR
     attr_set = true;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -628,15 +646,18 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
       hipLaunchKernelGGL(k3_elementwise_kernel, dim3(p.num_m_tiles), dim3(256), 0, st, p);
     } else {
       const int blocks = p.num_m_tiles * p.num_n_tiles;
-      if (b->net->dev[i].bn == 96) {
-        const size_t lds = 2 * (kBM + 96) * kLdsLd * sizeof(float);
-        if (p.tiles_per_off > 0) hipLaunchKernelGGL((k3_tdnn_gemm_kernel<96, 32, 96, true>), dim3(blocks), dim3(kThreads), lds, st, p);
-        else hipLaunchKernelGGL((k3_tdnn_gemm_kernel<96, 32, 96, false>), dim3(blocks), dim3(kThreads), lds, st, p);
-      } else {
-        const size_t lds = 2 * (kBM + 128) * kLdsLd * sizeof(float);
-        if (p.tiles_per_off > 0) hipLaunchKernelGGL((k3_tdnn_gemm_kernel<128, 64, 64, true>), dim3(blocks), dim3(kThreads), lds, st, p);
-        else hipLaunchKernelGGL((k3_tdnn_gemm_kernel<128, 64, 64, false>), dim3(blocks), dim3(kThreads), lds, st, p);
-      }
+      // the epilogue program, matched against the fixed ones
+      int epi = kEpiAny;
+      if (p.nops == 0) epi = kEpiNone;
+      else if (p.nops == 3 && p.op_kind[0] == k3::kEpiRelu && p.op_kind[1] == k3::kEpiScaleOffset && p.op_kind[2] == k3::kEpiResidual) epi = kEpiReluScaleRes;
+      else if (p.nops == 2 && p.op_kind[0] == k3::kEpiRelu && p.op_kind[1] == k3::kEpiScaleOffset) epi = kEpiReluScale;
+      const bool al = p.tiles_per_off > 0, bn96 = b->net->dev[i].bn == 96;
+      const size_t lds = 2 * (kBM + (bn96 ? 96 : 128)) * kLdsLd * sizeof(float);
+      bool launched = false;
+#define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3(kThreads), lds, st, p); launched = true; }
+      K3_GEMM_VARIANTS(K3_LAUNCH)
+      if (!launched) { epi = kEpiAny; K3_GEMM_VARIANTS(K3_LAUNCH) }      // no fixed-program instantiation for this shape: run-time dispatch
+#undef K3_LAUNCH
     }
     K3_HIP_CHECK(hipGetLastError());
   }
