@@ -108,7 +108,7 @@ struct Shared {
   unsigned long long red64[kWaves];
   int redi[kWaves];
   int hist[256];
-  int n_next, n_cand, n_wl[2], err, sel_digit, sel_k, flag;
+  int n_next, n_cand, n_wl[3], err_r[4], err, sel_digit, sel_k, flag;      // n_wl / err_r rotate over the eps rounds (one barrier per round)
   unsigned long long n_eps, n_emit;
   unsigned min_tot;
   long long n_link;
@@ -248,7 +248,7 @@ constexpr int kCurRegs = 4;       // frames of <= kCurRegs * kBlock tokens hand 
 constexpr int kWlLds = 1024;      // the first kWlLds work-list entries of an eps round live in LDS (16-bit LDS slot ids)
 #define K3_LLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 struct Table {
-  int *lkey; unsigned *lcost; int *ltok; unsigned *lmark;     // LDS: [kHL], [kHL], [kHL], [kHL / 32]
+  int *lkey; unsigned *lcost; int *ltok; unsigned *lmark;     // LDS: [kHL], [kHL], [kHL], [3][kHL / 32] (mark bits of three consecutive eps rounds)
   Slot *g; unsigned gmask;                                     // HBM level
   __device__ __forceinline__ int claim(int state, bool *claimed) const {
     unsigned h = hash_state(state) & (kHL - 1);
@@ -285,11 +285,11 @@ struct Table {
       if (t >= 0) return t;
       __builtin_amdgcn_s_sleep(1);
     }
-    *err = K3_ERR_HIP; return 0;
+    *err = K3_ERR_HIP; return -1;
   }
   // true if the slot was not yet queued for round `stamp` (LDS slots: one bit per slot, cleared at the start of every round)
   __device__ __forceinline__ bool mark(int id, int stamp) const {
-    if (id < kHL) { const unsigned bit = 1u << (id & 31); return (atomicOr(&lmark[id >> 5], bit) & bit) == 0; }
+    if (id < kHL) { const unsigned bit = 1u << (id & 31); return (atomicOr(&lmark[(stamp % 3) * (kHL / 32) + (id >> 5)], bit) & bit) == 0; }
     return atomicExch(&g[id - kHL].stamp, stamp) != stamp;
   }
   __device__ __forceinline__ void clear(int id) const {
@@ -350,23 +350,24 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
                                              Link *links, int *link_arc, int *tok_slot, int *wl, unsigned short (*lwl)[kWlLds], unsigned (&creg)[kCurRegs], int (&sreg)[kCurRegs],
                                              long long &t_last__, unsigned &cnt_eps) {
   const int tid = threadIdx.x, lane = tid & 63;
-  __syncthreads();
-  if (tid == 0) { sh.n_wl[0] = 0; sh.n_wl[1] = 0; }
+  // One barrier per round.  Work-list counters n_wl[3], error flags err_r[4] and LDS mark bits [3] rotate: round r reads list r,
+  // appends to list r + 1 (count n_wl[(r+1) % 3], marks (r+1) % 3, data buffer (r+1) & 1) and recycles the slots of round r + 2,
+  // which nobody touches any more; what is read after a round's barrier (its error flag, the next count) is not written again
+  // before the following barrier, so every wavefront takes the same decision.
+  if (tid < 3) sh.n_wl[tid] = 0;
+  if (tid < 4) sh.err_r[tid] = 0;
+  for (int i = tid; i < 3 * (kHL / 32); i += kBlock) tb.lmark[i] = 0;
   __syncthreads();
   K3_T(7);
   // round 1 work-list = every token of the frame = tok_slot[0 .. n_next) itself (tokens without eps arcs expand to nothing)
-  int cur = 0;
-  for (int round = 1;; round++) {
-    const int n = round == 1 ? sh.n_next : sh.n_wl[cur];
-    if (block_err(sh) || n == 0) break;
+  int n = sh.n_next;
+  for (int round = 1; n > 0; round++) {
     if (round > 100000) { sh.err = K3_ERR_HIP; break; }        // an epsilon cycle with negative weight: cannot converge
+    const int cur = round & 1, nxt_buf = cur ^ 1;
     const int *wl_cur = round == 1 ? tok_slot : wl + (long long)cur * p.frame_tokens_cap;
-    int *wl_nxt = wl + (long long)(round == 1 ? 0 : (cur ^ 1)) * p.frame_tokens_cap;
-    const int nxt_buf = round == 1 ? 0 : (cur ^ 1);
-    int *n_nxt = &sh.n_wl[nxt_buf];
-    K3_T(8);
-    for (int i = tid; i < kHL / 32; i += kBlock) tb.lmark[i] = 0;
-    __syncthreads();
+    int *wl_nxt = wl + (long long)nxt_buf * p.frame_tokens_cap;
+    int *n_nxt = &sh.n_wl[(round + 1) % 3];
+    auto fail = [&](int code) { sh.err = code; sh.err_r[round & 3] = 1; };
     K3_T(11);
     for (int i0 = 0; i0 < n; i0 += kBlock) {
       const int i = i0 + tid; const bool v = i < n;
@@ -397,7 +398,7 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
           tot = oc + r.w; nxt = r.next;
           if (tot < cutoff) {
             slot2 = tb.claim(r.next, &claimed);
-            if (slot2 < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; }
+            if (slot2 < 0) { fail(K3_ERR_OVERFLOW); claimed = false; }
             else {
               mk = true;
               const unsigned e = enc(tot);
@@ -409,27 +410,29 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         int idx = wave_append(claimed, &sh.n_next);
         if (claimed) {
           if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; tok_cost[nb + idx] = kEncMax; }
-          else { sh.err = K3_ERR_OVERFLOW; idx = 0; }
+          else { fail(K3_ERR_OVERFLOW); idx = 0; }
           tb.set_tok(slot2, idx);
         }
         const int pos = wave_append(push, n_nxt);
         if (push) {
           if (pos < kWlLds) lwl[nxt_buf][pos] = slot2 < kHL ? (unsigned short)slot2 : (unsigned short)0xFFFF;
-          if (pos >= kWlLds || slot2 >= kHL) { if (pos < p.frame_tokens_cap) wl_nxt[pos] = slot2; else sh.err = K3_ERR_OVERFLOW; }
+          if (pos >= kWlLds || slot2 >= kHL) { if (pos < p.frame_tokens_cap) wl_nxt[pos] = slot2; else fail(K3_ERR_OVERFLOW); }
         }
         // the eps link of this arc at the source's present cost; links written at a cost the source later improves on
         // are recognised as stale by their stamp (Link::ac of an eps link = the source cost it was created at)
-        if (mk && !claimed) idx = tb.wait_tok(slot2, &sh.err);
+        if (mk && !claimed) { idx = tb.wait_tok(slot2, &sh.err); if (idx < 0) { fail(K3_ERR_HIP); idx = 0; } }
         const long long lp = wave_append64(mk, &sh.n_link);
-        if (mk) { if (lp < p.lane_links_cap) { links[lp] = Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}; link_arc[lp] = arc; } else sh.err = K3_ERR_OVERFLOW; }
+        if (mk) { if (lp < p.lane_links_cap) { links[lp] = Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}; link_arc[lp] = arc; } else fail(K3_ERR_OVERFLOW); }
       });
       K3_TW(14);
     }
+    // recycle the slots round + 2 will append to / flag / mark
+    if (tid == 0) { sh.n_wl[(round + 2) % 3] = 0; sh.err_r[(round + 2) & 3] = 0; }
+    for (int i = tid; i < kHL / 32; i += kBlock) tb.lmark[((round + 2) % 3) * (kHL / 32) + i] = 0;
     __syncthreads();
     K3_T(15);
-    if (round == 1) cur = 0;
-    else { if (tid == 0) sh.n_wl[cur] = 0; cur ^= 1; }
-    __syncthreads();
+    if (sh.err_r[round & 3]) break;
+    n = sh.n_wl[(round + 1) % 3];
   }
   if (block_err(sh)) return;
   K3_T(9);
@@ -463,7 +466,7 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
 __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(DecParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ Shared sh;
-  __shared__ int s_lkey[kHL]; __shared__ unsigned s_lcost[kHL]; __shared__ int s_ltok[kHL]; __shared__ unsigned s_lmark[kHL / 32];
+  __shared__ int s_lkey[kHL]; __shared__ unsigned s_lcost[kHL]; __shared__ int s_ltok[kHL]; __shared__ unsigned s_lmark[3 * (kHL / 32)];
   __shared__ unsigned short s_lwl[2][kWlLds];
   float *s_ll = reinterpret_cast<float *>(smem_raw);
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
         tb.set_tok(slot, idx);
       }
       // ---- forward link of the accepted arc (:803-806)
-      if (mk && !claimed) idx = tb.wait_tok(slot, &sh.err);
+      if (mk && !claimed) { idx = tb.wait_tok(slot, &sh.err); if (idx < 0) idx = 0; }
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
         if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + c_s), (unsigned)(nb + idx), tot, c_c}; link_arc[pos] = c_a; }
