@@ -76,6 +76,11 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
 #define K3_T(i) do { } while (0)
 #define K3_TW(i) do { } while (0)
 #endif
+#ifdef K3_PRUNE_PROF
+#define K3_PT(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); s_pprof[i] += now__ - pt_last__; pt_last__ = now__; } } while (0)
+#else
+#define K3_PT(i) do { } while (0)
+#endif
 struct DecParams {
   long long *prof;   // [nlanes x 16] cycle counters per phase (only with -DK3_DEC_PROF)
   // graph
@@ -703,13 +708,16 @@ __device__ __forceinline__ float link_extra_cost(float next_extra, float via_lin
 // its stamp (Link::ac) is not the final cost of its source (k3_decode_forward_kernel, finish_frame)
 __device__ __forceinline__ bool eps_link_live(const Link &k, unsigned src_cost_enc) { return __float_as_uint(k.ac) == src_cost_enc; }
 
-constexpr int kPCap = 2048;      // frames with at most this many tokens are pruned entirely inside LDS
+#ifndef K3_PCAP
+#define K3_PCAP 3072
+#endif
+constexpr int kPCap = K3_PCAP;      // frames with at most this many tokens are pruned entirely inside LDS
 
-__global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
-  __shared__ int s_changed, s_has_final;
+__global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p) {
+  __shared__ int s_changed, s_has_final, s_chg[4];
   __shared__ unsigned s_best, s_best_final;
   __shared__ float s_cost[2][kPCap], s_extra[2][kPCap];   // token costs / extra costs of frames f+1 (buffer nb) and f (buffer nb ^ 1)
-  __shared__ unsigned s_xb[kPCap], s_xn[kPCap];
+  __shared__ unsigned s_xb[kPCap];
   const int L = blockIdx.x, tid = threadIdx.x;
   LaneInfo &li = p.info[L];
   if (li.status != kStOk) return;
@@ -723,6 +731,11 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
   // survivors (tokens with extra != inf, links with link_extra <= lattice_beam) are recorded frame by frame
   __shared__ int s_nt, s_nl;
   if (tid == 0) { s_nt = 0; s_nl = 0; }
+#ifdef K3_PRUNE_PROF
+  __shared__ long long s_pprof[16];
+  if (tid < 16) s_pprof[tid] = 0;
+  long long pt_last__ = (long long)__builtin_readcyclecounter();
+#endif
   int *live_tok = p.live_tok + (long long)L * p.live_cap; long long *live_link = p.live_link + (long long)L * p.live_cap;
   int *newidx = p.newidx + (long long)L * p.lane_tokens_cap;
   auto keep_tok = [&](long long t) { const int pos = atomicAdd(&s_nt, 1); if (pos < p.live_cap) live_tok[pos] = (int)t; newidx[t] = pos; };
@@ -781,62 +794,105 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
   __syncthreads();
   // ---- frames T-1 .. 0: PruneForwardLinks(f, delta = 0) then PruneTokensForFrame(f+1) (tokens with extra = inf vanish).
   // Fast path: both frames fit in LDS -> per frame one round trip to HBM (its links + its token costs), everything else in LDS.
+  // The data a frame needs from HBM (its emitting links, its eps links, its token costs) does not depend on the sweep itself:
+  // it is requested into registers while the frame above is still being processed, so that the LDS path never waits for HBM.
+  // Inside that path the barriers order LDS traffic only (no vmcnt wait: the prefetch stays in flight, and nothing written to
+  // HBM there is read back before a full __syncthreads()).
+  struct FrameOff { long long b0, b1, b2, e0, e1, n0, n1; };
+  auto uni = [](long long v) {       // block-uniform value -> scalar registers
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  auto load_off = [&](int f) {
+    FrameOff o{0, 0, 0, 0, 0, 0, 0};
+    if (f >= 0) { o.b0 = uni(tok_off[f]); o.b1 = uni(tok_off[f + 1]); o.b2 = uni(tok_off[f + 2]); o.e0 = uni(loff_e[f]); o.e1 = uni(loff_n[f + 1]); o.n0 = uni(loff_n[f]); o.n1 = o.e0; }
+    return o;
+  };
+  // frame f - 1's offsets share all but three values with frame f's: those are fetched a frame early and made scalar late
+  long long raw_b0 = 0, raw_e0 = 0, raw_n0 = 0;
+  auto request_off = [&](int f) { if (f >= 0) { raw_b0 = tok_off[f]; raw_e0 = loff_e[f]; raw_n0 = loff_n[f]; } };
+  auto finish_off = [&](int f, const FrameOff &above) {      // `above` = offsets of frame f + 1
+    FrameOff o{0, 0, 0, 0, 0, 0, 0};
+    if (f >= 0) { o.b0 = uni(raw_b0); o.b1 = above.b0; o.b2 = above.b1; o.e0 = uni(raw_e0); o.e1 = above.n0; o.n0 = uni(raw_n0); o.n1 = o.e0; }
+    return o;
+  };
+  auto fits = [&](const FrameOff &o) { return o.b1 - o.b0 <= kPCap && o.b2 - o.b1 <= kPCap; };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  constexpr int kPre = 3, kEpsRegs = 3, kCostRegs = kPCap / kPBlock;      // what a thread holds of the next frame (the kernel has 128 registers per thread)
+  Link pl[kPre], er[kEpsRegs]; unsigned pc[kCostRegs]; bool pre_valid = false;
+  auto prefetch_main = [&](const FrameOff &o) {      // emitting links + token costs of a frame
+#pragma unroll
+    for (int k = 0; k < kPre; k++) { const long long l = o.e0 + tid + k * kPBlock; if (l < o.e1) pl[k] = links[l]; }
+#pragma unroll
+    for (int k = 0; k < kCostRegs; k++) { const long long i = tid + k * kPBlock; if (i < o.b1 - o.b0) pc[k] = tok_cost[o.b0 + i]; }
+  };
+  auto prefetch_eps = [&](const FrameOff &o) {
+#pragma unroll
+    for (int k = 0; k < kEpsRegs; k++) { const long long i = tid + k * kPBlock; if (i < o.n1 - o.n0) er[k] = links[o.n0 + i]; }
+  };
+  K3_PT(0);      // last frame
   int nbuf = 0; bool next_in_lds = false;
+  FrameOff o_cur = load_off(T - 1), o_nxt = load_off(T - 2);
+  if (T >= 1 && fits(o_cur)) { prefetch_main(o_cur); pre_valid = true; }
   for (int f = T - 1; f >= 0; f--) {
-    const long long b0 = tok_off[f], b1 = tok_off[f + 1], b2 = tok_off[f + 2];
-    const long long e0 = loff_e[f], e1 = loff_n[f + 1];     // emitting links f -> f+1
-    const long long n0 = loff_n[f], n1 = loff_e[f];         // eps links inside frame f
+    const FrameOff o = o_cur; o_cur = o_nxt;
+    request_off(f - 2);
+    const long long b0 = o.b0, b1 = o.b1, b2 = o.b2, e0 = o.e0, e1 = o.e1, n0 = o.n0, n1 = o.n1;
     const int nf = (int)(b1 - b0), nn = (int)(b2 - b1);
     if (nf <= kPCap && nn <= kPCap) {
       float *ncost = s_cost[nbuf], *nextra = s_extra[nbuf], *ccost = s_cost[nbuf ^ 1], *cextra = s_extra[nbuf ^ 1];
+      if (!pre_valid) prefetch_main(o);                                  // the frame above took the HBM path
       if (!next_in_lds) { for (int i = tid; i < nn; i += kPBlock) { ncost[i] = dec(tok_cost[b1 + i]); nextra[i] = extra[b1 + i]; } }
-      for (int i = tid; i < nf; i += kPBlock) { ccost[i] = dec(tok_cost[b0 + i]); s_xb[i] = kEncInf; cextra[i] = 0.0f; }
-      // this thread's eps links stay in registers over the sweeps (a frame has a few hundred of them)
-      constexpr int kEpsRegs = 4;
-      Link er[kEpsRegs]; const int neps = (int)(n1 - n0);
 #pragma unroll
-      for (int k = 0; k < kEpsRegs; k++) { const int i = tid + k * kPBlock; if (i < neps) er[k] = links[n0 + i]; }
-      __syncthreads();
+      for (int k = 0; k < kCostRegs; k++) { const int i = tid + k * kPBlock; if (i < nf) { ccost[i] = dec(pc[k]); s_xb[i] = kEncInf; cextra[i] = 0.0f; } }
+      const int neps = (int)(n1 - n0);
+      prefetch_eps(o);          // this frame's eps links: needed after the emitting links, their latency hides behind those
+      lds_barrier();
+      K3_PT(1);    // staging
+      auto emit_link = [&](const Link &k, long long l) {
+        float le = link_extra_cost(nextra[k.dst - b1], k.tot, ncost[k.dst - b1]);
+        if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; atomicMin(&s_xb[k.src - b0], enc(le)); }     // a surviving emitting link keeps its source alive
+      };
+#pragma unroll
+      for (int k = 0; k < kPre; k++) { const long long l = e0 + tid + k * kPBlock; if (l < e1) emit_link(pl[k], l); }
+      for (long long l = e0 + kPre * kPBlock + tid; l < e1; l += kPBlock) emit_link(links[l], l);                  // (rare) more than fit in registers
+      // the frame below: its emitting links and costs are requested now
+      const bool pre_next = f >= 1 && fits(o_cur);
+      if (pre_next) prefetch_main(o_cur);
       unsigned elive = 0;
 #pragma unroll
       for (int k = 0; k < kEpsRegs; k++) { const int i = tid + k * kPBlock; if (i < neps && eps_link_live(er[k], enc(ccost[er[k].src - b0]))) elive |= 1u << k; }
-      for (long long l = e0 + tid; l < e1; l += kPBlock) {
-        const Link k = links[l];
-        float le = link_extra_cost(nextra[k.dst - b1], k.tot, ncost[k.dst - b1]);
-        if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; atomicMin(&s_xb[k.src - b0], enc(le)); }     // a surviving emitting link keeps its source alive
-      }
-      __syncthreads();
-      if (neps == 0) {
-        for (int i = tid; i < nf; i += kPBlock) { const float v = dec(s_xb[i]); cextra[i] = v; extra[b0 + i] = v; if (v != kInf) keep_tok(b0 + i); }
-      } else {
+      lds_barrier();
+      K3_PT(2);    // emitting links
+      if (neps != 0) {
+        // eps links relax s_xb downwards in place until nothing moves (acyclic dependencies: the unique fixpoint, reached link by
+        // link).  The "changed" flags rotate over four slots so that one barrier per sweep is enough.
+        if (tid < 4) s_chg[tid] = 0;
+        lds_barrier();
         for (int sweep = 0; sweep < 100000; sweep++) {
-          __syncthreads();
-          if (tid == 0) s_changed = 0;
-          for (int i = tid; i < nf; i += kPBlock) s_xn[i] = s_xb[i];
-          __syncthreads();
+          bool moved = false;
 #pragma unroll
           for (int k = 0; k < kEpsRegs; k++) {
             if (elive >> k & 1) {
-              float le = link_extra_cost(cextra[er[k].dst - b0], er[k].tot, ccost[er[k].dst - b0]);
-              if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&s_xn[er[k].src - b0], enc(le)); }
+              float le = link_extra_cost(dec(K3_LLD(&s_xb[er[k].dst - b0])), er[k].tot, ccost[er[k].dst - b0]);
+              if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < atomicMin(&s_xb[er[k].src - b0], e)) moved = true; }
             }
           }
           for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) {       // (rare) more eps links than fit in registers
             const Link k = links[l];
             if (!eps_link_live(k, enc(ccost[k.src - b0]))) continue;
-            float le = link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]);
-            if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&s_xn[k.src - b0], enc(le)); }
+            float le = link_extra_cost(dec(K3_LLD(&s_xb[k.dst - b0])), k.tot, ccost[k.dst - b0]);
+            if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < atomicMin(&s_xb[k.src - b0], e)) moved = true; }
           }
-          __syncthreads();
-          for (int i = tid; i < nf; i += kPBlock) {
-            const float v = dec(s_xn[i]);
-            if (__float_as_uint(v) != __float_as_uint(cextra[i])) s_changed = 1;
-            cextra[i] = v;
-          }
-          __syncthreads();
-          if (!s_changed) break;
+          if (moved) s_chg[sweep & 3] = 1;
+          if (tid == 0) s_chg[(sweep + 2) & 3] = 0;      // read last after the barrier of sweep - 2: every wavefront is past it
+          lds_barrier();
+          if (!s_chg[sweep & 3]) break;
         }
-        for (int i = tid; i < nf; i += kPBlock) { extra[b0 + i] = cextra[i]; if (cextra[i] != kInf) keep_tok(b0 + i); }
+      }
+      for (int i = tid; i < nf; i += kPBlock) { const float v = dec(s_xb[i]); cextra[i] = v; extra[b0 + i] = v; if (v != kInf) keep_tok(b0 + i); }
+      if (neps != 0) {
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < kEpsRegs; k++) {
           const int i = tid + k * kPBlock;
@@ -844,50 +900,90 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_prune_kernel(DecParams p) {
         }
         for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (eps_link_live(k, enc(ccost[k.src - b0])) && !(link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]) > lb)) keep_link(l); }
       }
+      K3_PT(3);    // eps fixpoint + write-back
+      pre_valid = pre_next;
       nbuf ^= 1; next_in_lds = true;
-      __syncthreads();
+      o_nxt = finish_off(f - 2, o_cur);
+      lds_barrier();
+      K3_PT(4);    // offsets + end barrier
       continue;
     }
+    __syncthreads();                   // leaving the LDS path: what it wrote to HBM (extra costs) is read below
+    pre_valid = false;
     next_in_lds = false;
-    unsigned *xb = reinterpret_cast<unsigned *>(p.c_tot + (long long)L * p.frame_cands_cap);   // base (emitting part), enc
-    unsigned *xn = reinterpret_cast<unsigned *>(p.c_ac + (long long)L * p.frame_cands_cap);
-    for (long long t = b0 + tid; t < b1; t += kPBlock) { xb[t - b0] = kEncInf; extra[t] = 0.0f; }
+    // HBM path (a frame above kPCap tokens).  x[] = order-preserving image of the extra costs of the frame's tokens, in this
+    // lane's candidate scratch.  Emitting links first, then the eps links relax x downwards in place (atomicMin) until nothing
+    // moves: the eps dependency graph is acyclic, so this reaches the same unique fixpoint as the reference's sweeps, link by
+    // link instead of token by token.  Loads are issued kB links at a time: a frame of 25 k tokens would otherwise pay one
+    // memory round trip per 512 links.
+    unsigned *x = reinterpret_cast<unsigned *>(p.c_tot + (long long)L * p.frame_cands_cap);
+    constexpr int kB = 4, kE = 2;      // links in flight per thread: emitting / eps passes (register budget of the kernel: 128)
+    for (long long t = b0 + tid; t < b1; t += kPBlock) x[t - b0] = kEncInf;
     __syncthreads();
-    for (long long l = e0 + tid; l < e1; l += kPBlock) {
-      const Link k = links[l];
-      float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
-      if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; atomicMin(&xb[k.src - b0], enc(le)); }
+    for (long long l0 = e0 + tid; l0 < e1; l0 += kB * kPBlock) {
+      Link k[kB]; float xe[kB], xc[kB];
+#pragma unroll
+      for (int j = 0; j < kB; j++) { const long long l = l0 + j * kPBlock; if (l < e1) k[j] = links[l]; }
+#pragma unroll
+      for (int j = 0; j < kB; j++) { const long long l = l0 + j * kPBlock; if (l < e1) { xe[j] = extra[k[j].dst]; xc[j] = dec(tok_cost[k[j].dst]); } }
+#pragma unroll
+      for (int j = 0; j < kB; j++) {
+        const long long l = l0 + j * kPBlock;
+        if (l < e1) { float le = link_extra_cost(xe[j], k[j].tot, xc[j]); if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; atomicMin(&x[k[j].src - b0], enc(le)); } }
+      }
     }
     __syncthreads();
-    if (n1 == n0) {
-      for (long long t = b0 + tid; t < b1; t += kPBlock) { const float v = dec(xb[t - b0]); extra[t] = v; if (v != kInf) keep_tok(t); }
-    } else {
+    if (n1 != n0) {
       for (int sweep = 0; sweep < 100000; sweep++) {
         __syncthreads();
         if (tid == 0) s_changed = 0;
-        for (long long t = b0 + tid; t < b1; t += kPBlock) xn[t - b0] = xb[t - b0];
         __syncthreads();
-        for (long long l = n0 + tid; l < n1; l += kPBlock) {
-          const Link k = links[l];
-          if (!eps_link_live(k, tok_cost[k.src])) continue;
-          float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
-          if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - b0], enc(le)); }
-        }
-        __syncthreads();
-        for (long long t = b0 + tid; t < b1; t += kPBlock) {
-          const float v = dec(xn[t - b0]);
-          if (__float_as_uint(v) != __float_as_uint(extra[t])) s_changed = 1;
-          extra[t] = v;
+        for (long long l0 = n0 + tid; l0 < n1; l0 += kE * kPBlock) {
+          Link k[kE]; unsigned sc[kE], xd[kE]; float dc[kE];
+#pragma unroll
+          for (int j = 0; j < kE; j++) { const long long l = l0 + j * kPBlock; if (l < n1) k[j] = links[l]; }
+#pragma unroll
+          for (int j = 0; j < kE; j++) { const long long l = l0 + j * kPBlock; if (l < n1) { sc[j] = tok_cost[k[j].src]; xd[j] = K3_ALD(&x[k[j].dst - b0]); dc[j] = dec(tok_cost[k[j].dst]); } }
+#pragma unroll
+          for (int j = 0; j < kE; j++) {
+            const long long l = l0 + j * kPBlock;
+            if (l < n1 && eps_link_live(k[j], sc[j])) {
+              float le = link_extra_cost(dec(xd[j]), k[j].tot, dc[j]);
+              if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < atomicMin(&x[k[j].src - b0], e)) s_changed = 1; }
+            }
+          }
         }
         __syncthreads();
         if (!s_changed) break;
       }
-      for (long long t = b0 + tid; t < b1; t += kPBlock) if (extra[t] != kInf) keep_tok(t);
-      for (long long l = n0 + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (eps_link_live(k, tok_cost[k.src]) && !(link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst])) > lb)) keep_link(l); }
     }
+    for (long long t0 = b0 + tid; t0 < b1; t0 += kB * kPBlock) {
+      unsigned v[kB];
+#pragma unroll
+      for (int j = 0; j < kB; j++) { const long long t = t0 + j * kPBlock; if (t < b1) v[j] = x[t - b0]; }
+#pragma unroll
+      for (int j = 0; j < kB; j++) { const long long t = t0 + j * kPBlock; if (t < b1) { const float e = dec(v[j]); extra[t] = e; if (e != kInf) keep_tok(t); } }
+    }
+    for (long long l0 = n0 + tid; l0 < n1; l0 += kE * kPBlock) {
+      Link k[kE]; unsigned sc[kE], xd[kE], xs[kE]; float dc[kE];
+#pragma unroll
+      for (int j = 0; j < kE; j++) { const long long l = l0 + j * kPBlock; if (l < n1) k[j] = links[l]; }
+#pragma unroll
+      for (int j = 0; j < kE; j++) { const long long l = l0 + j * kPBlock; if (l < n1) { sc[j] = tok_cost[k[j].src]; xd[j] = x[k[j].dst - b0]; xs[j] = x[k[j].src - b0]; dc[j] = dec(tok_cost[k[j].dst]); } }
+#pragma unroll
+      for (int j = 0; j < kE; j++) {
+        const long long l = l0 + j * kPBlock;
+        if (l < n1 && eps_link_live(k[j], sc[j]) && xs[j] != kEncInf && !(link_extra_cost(dec(xd[j]), k[j].tot, dc[j]) > lb)) keep_link(l);
+      }
+    }
+    o_nxt = finish_off(f - 2, o_cur);
     __syncthreads();
+    K3_PT(5);      // HBM-path frame
   }
   __syncthreads();
+#ifdef K3_PRUNE_PROF
+  if (tid < 16) p.prof[blockIdx.x * 16 + tid] = s_pprof[tid];
+#endif
   if (tid == 0) { li.out_states = s_nt; li.out_arcs = s_nl; li.live_overflow = (s_nt > p.live_cap || s_nl > p.live_cap) ? 1 : 0; }
 }
 
