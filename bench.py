@@ -119,7 +119,7 @@ def main():
             dec.DecodeBatch(loglikes, nb.out_offsets)
             if timed: ev[3].record()
             lats = dec.GetRawLattices()          # synchronises: compaction kernel + D2H of the pruned lattices
-            lat_sizes[0] = sum(l.num_states for l in lats); lat_sizes[1] = sum(l.num_arcs for l in lats)
+            lat_sizes[0] = int(lats.state_offsets[-1]); lat_sizes[1] = int(lats.arc_offsets[-1])      # all lattices are on the host now (flat arrays + offsets)
             if timed: ev[4].record()
     for _ in range(args.warmup): step()
     torch.cuda.synchronize()

@@ -1377,10 +1377,20 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
   o.st_off = d_so; o.arc_off = d_ao;
   hipStream_t st = d->last_stream;
 #define K3_TRY(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { cleanup(); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
-  K3_TRY(hipMemcpy(d_so, so.data(), sizeof(long long) * (U + 1), hipMemcpyHostToDevice));
-  K3_TRY(hipMemcpy(d_ao, ao.data(), sizeof(long long) * (U + 1), hipMemcpyHostToDevice));
+  so.insert(so.end(), ao.begin(), ao.end());        // d_so and d_ao are adjacent: one upload
+  K3_TRY(hipMemcpyAsync(d_so, so.data(), sizeof(long long) * 2 * (U + 1), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k3_decode_output_kernel, dim3(U), dim3(kPBlock), 0, st, d->p, o);
   K3_TRY(hipGetLastError());
+  // the caller's ten arrays laid out back to back in this order (kaldi_amd/decoder.py carves them out of one pinned buffer):
+  // a single device-to-host copy
+  const bool contiguous = (char *)st_state == (char *)st_frame + 4 * NS && (char *)st_cost == (char *)st_state + 4 * NS && (char *)st_final == (char *)st_cost + 4 * NS &&
+                          (char *)arc_src == (char *)st_final + 4 * NS && (char *)arc_dst == (char *)arc_src + 4 * NA && (char *)arc_il == (char *)arc_dst + 4 * NA &&
+                          (char *)arc_ol == (char *)arc_il + 4 * NA && (char *)arc_g == (char *)arc_ol + 4 * NA && (char *)arc_ac == (char *)arc_g + 4 * NA;
+  if (contiguous) {
+    K3_TRY(hipMemcpyAsync(st_frame, o.st_frame, 4 * (4 * NS + 6 * NA), hipMemcpyDeviceToHost, st));
+    K3_TRY(hipStreamSynchronize(st));
+    return K3_OK;
+  }
   K3_TRY(hipStreamSynchronize(st));
   K3_TRY(hipMemcpy(st_frame, o.st_frame, 4 * NS, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(st_state, o.st_state, 4 * NS, hipMemcpyDeviceToHost));
   K3_TRY(hipMemcpy(st_cost, o.st_cost, 4 * NS, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(st_final, o.st_final, 4 * NS, hipMemcpyDeviceToHost));

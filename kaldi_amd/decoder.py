@@ -52,6 +52,23 @@ class CudaFst:
         except Exception:      # interpreter shutdown
             pass
 
+class RawLatticeBatch:
+    """The lattices of one batch as handed over by k3_decoder_get_raw_lattices: flat arrays + per-utterance offsets.  Behaves like a
+    list of RawLattice (len, indexing, iteration); the objects are numpy views created on access."""
+    def __init__(self, so, ao, si, sf, ai, af, start):
+        self.state_offsets, self.arc_offsets, self._si, self._sf, self._ai, self._af, self._start = so, ao, si, sf, ai, af, start
+    def __len__(self): return len(self.state_offsets) - 1
+    def __getitem__(self, u):
+        if isinstance(u, slice): return [self[i] for i in range(*u.indices(len(self)))]
+        if u < 0: u += len(self)
+        if not 0 <= u < len(self): raise IndexError(u)
+        s0, s1, a0, a1 = self.state_offsets[u], self.state_offsets[u + 1], self.arc_offsets[u], self.arc_offsets[u + 1]
+        si, sf, ai, af = self._si, self._sf, self._ai, self._af
+        return RawLattice(si[0][s0:s1], si[1][s0:s1], sf[1][s0:s1], ai[0][a0:a1], ai[1][a0:a1], ai[2][a0:a1], ai[3][a0:a1], af[0][a0:a1], af[1][a0:a1],
+                          self._start, st_cost=sf[0][s0:s1])
+    def __iter__(self): return (self[u] for u in range(len(self)))
+
+
 class CudaDecoder:
     """Batched lattice decoder (cf. cuda_decoder::CudaDecoder, cudadecoder/cuda-decoder.h:224-345): nlanes utterances per call."""
     INFO = ("lat_states", "lat_arcs", "status", "reached_final", "tokens", "links", "max_frame_tokens", "emitting_arcs", "eps_arcs", "frames")
@@ -97,21 +114,28 @@ class CudaDecoder:
         if check: _l.check(rc)
         return info
 
-    def GetRawLattices(self):
-        """list of RawLattice, one per utterance of the last batch (GetRawLattice, not yet Connect()-ed)"""
+    def GetRawLattices(self, copy=False):
+        """sequence of RawLattice, one per utterance of the last batch (GetRawLattice, not yet Connect()-ed).  All lattices arrive in
+        ten flat host arrays (one D2H copy each); the per-utterance RawLattice objects are views made on access."""
         info = self.LatticeInfo()
         so = np.concatenate([[0], np.cumsum(info[:, 0])]); ao = np.concatenate([[0], np.cumsum(info[:, 1])])
         NS, NA = int(so[-1]), int(ao[-1])
-        si = [np.zeros(max(NS, 1), np.int32) for _ in range(2)]; sf = [np.zeros(max(NS, 1), np.float32) for _ in range(2)]
-        ai = [np.zeros(max(NA, 1), np.int32) for _ in range(4)]; af = [np.zeros(max(NA, 1), np.float32) for _ in range(2)]
+        # ten arrays back to back in one page-locked host buffer: k3_decoder_get_raw_lattices then needs a single D2H copy.  Two
+        # buffers alternate, so the lattices of a batch stay valid until the call after the next one (copy=True detaches them).
+        n32 = 4 * NS + 6 * NA
+        slot = self._lat_slot = 1 - getattr(self, "_lat_slot", 1)
+        bufs = self.__dict__.setdefault("_lat_bufs", [None, None])
+        if bufs[slot] is None or bufs[slot].numel() < max(n32, 1):
+            bufs[slot] = torch.empty(max(n32 + n32 // 4, 1024), dtype=torch.int32, pin_memory=True)
+        flat = bufs[slot].numpy()[:max(n32, 1)]
+        if copy: flat = np.empty(max(n32, 1), np.int32)
+        cuts = np.cumsum([0] + [NS] * 4 + [NA] * 6)
+        parts = [flat[cuts[i]:cuts[i + 1]] for i in range(10)]
+        si = [parts[0], parts[1]]; sf = [parts[2].view(np.float32), parts[3].view(np.float32)]
+        ai = [parts[4], parts[5], parts[6], parts[7]]; af = [parts[8].view(np.float32), parts[9].view(np.float32)]
         _l.check(self._L.k3_decoder_get_raw_lattices(self._h, si[0].ctypes.data, si[1].ctypes.data, sf[0].ctypes.data, sf[1].ctypes.data,
                                                      ai[0].ctypes.data, ai[1].ctypes.data, ai[2].ctypes.data, ai[3].ctypes.data, af[0].ctypes.data, af[1].ctypes.data))
-        out = []
-        for u in range(self._n):
-            s0, s1, a0, a1 = so[u], so[u + 1], ao[u], ao[u + 1]
-            out.append(RawLattice(si[0][s0:s1], si[1][s0:s1], sf[1][s0:s1], ai[0][a0:a1], ai[1][a0:a1], ai[2][a0:a1], ai[3][a0:a1], af[0][a0:a1], af[1][a0:a1],
-                                  self.fst.start, st_cost=sf[0][s0:s1]))
-        return out
+        return RawLatticeBatch(so, ao, si, sf, ai, af, self.fst.start)
 
     def SetProfiling(self, on=True):
         _l.check(self._L.k3_decoder_set_profiling(self._h, int(on)))
