@@ -374,26 +374,41 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
     int *n_nxt = &sh.n_wl[(round + 1) % 3];
     auto fail = [&](int code) { sh.err = code; sh.err_r[round & 3] = 1; };
     K3_T(11);
-    for (int i0 = 0; i0 < n; i0 += kBlock) {
-      const int i = i0 + tid; const bool v = i < n;
-      int beg = 0, deg = 0, ti = 0; unsigned cb = 0; int slot_ = 0;
-      if (v) {
-        if (round == 1) slot_ = wl_cur[i];
-        else { slot_ = i < kWlLds ? (int)lwl[cur][i] : 0xFFFF; if (slot_ == 0xFFFF) slot_ = wl_cur[i]; }
+    // Software pipeline over the work-list (it matters for frames with thousands of tokens): while item i is expanded, the
+    // arc range of item i + kBlock is already on its way and the slot of item i + 2 kBlock is being read, so an iteration
+    // exposes one memory round trip (the arcs) instead of three.
+    auto fetch_slot = [&](int i) {
+      int s_ = -1;
+      if (i < n) {
+        if (round == 1) s_ = wl_cur[i];
+        else { s_ = i < kWlLds ? (int)lwl[cur][i] : 0xFFFF; if (s_ == 0xFFFF) s_ = wl_cur[i]; }
       }
-      K3_TW(12);
-      if (v) {
-        const int slot = slot_;
-        cb = tb.cost(slot);
-        if (dec(cb) < cutoff) {
-          const int st = tb.key(slot); ti = tb.tok(slot);
-          const int2 a = p.offs[st], b = p.offs[st + 1];
+      return s_;
+    };
+    struct Pending { int ay, bx, ti; unsigned cb, prev; };      // what stage B requested; beg / deg follow once it has arrived
+    auto request = [&](int slot) {
+      Pending q{0, 0, 0, 0u, 0u};
+      if (slot >= 0) {
+        q.cb = tb.cost(slot); q.prev = q.cb;
+        if (dec(q.cb) < cutoff) {
+          const int st = tb.key(slot); q.ti = tb.tok(slot);
+          const int2 a = p.offs[st], b = p.offs[st + 1]; q.ay = a.y; q.bx = b.x;
           // a token is expanded once per cost value: tok_cost holds the cost of its latest expansion until the frame is published
-          const unsigned prev = atomicExch(&tok_cost[nb + ti], cb);
-          if (prev != cb) { beg = a.y; deg = b.x - a.y; }
+          q.prev = atomicExch(&tok_cost[nb + q.ti], q.cb);
         }
       }
+      return q;
+    };
+    Pending pend = request(fetch_slot(tid));
+    int slot_next = fetch_slot(tid + kBlock);
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+      const Pending pn = request(slot_next);
+      slot_next = fetch_slot(i0 + 2 * kBlock + tid);
       K3_TW(13);
+      const unsigned cb = pend.cb; const int ti = pend.ti;
+      int beg = 0, deg = 0;
+      if (pend.prev != cb) { beg = pend.ay; deg = pend.bx - pend.ay; }
+      pend = pn;
       wave_expand(p.arcs, beg, deg, [&](bool valid, int arc, int owner, const ArcRec &r) {
         const unsigned ocb = __shfl(cb, owner); const int oti = __shfl(ti, owner);
         const float oc = dec(ocb);

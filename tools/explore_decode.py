@@ -35,7 +35,7 @@ audio = U * secs; print("audio-s", audio)
 import ctypes
 from kaldi_amd import lib as _l
 cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
-names = ["(loop top/err)", "cutoff", "prepass", "expand", "p2:cand read", "p2:link store+barrier", "p2:claim+publish", "eps worklist build", "round:err-barriers", "p2:wait_tok", "finalize+clear", "round:mark-clear+barrier", "round:wl read", "round:cost+offs", "round:expand(arcs,claims,stores)", "round:end barrier"]
+names = ["(loop top/err)", "cutoff", "prepass", "pass1 expand", "-", "pass2 claim+links", "-", "closure init", "-", "closure exit check", "finalize+clear", "round: top", "round: wl read", "round: cost+offs+exch", "round: expand(arcs,claims,links)", "round: recycle+barrier"]
 tot = cyc.sum()
 if tot: print("phase share:", {n: round(100.0 * c / tot, 1) for n, c in zip(names, cyc) if n != "-"}, "cycles/lane/frame", tot / U / 333 / 2)
 allnt = np.concatenate([dec.FrameStats(u, int(nb.out_offsets[u + 1] - nb.out_offsets[u]))["ntoks"] for u in range(0, U, max(1, U // 32))])
