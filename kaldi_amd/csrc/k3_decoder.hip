@@ -652,11 +652,13 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     { const unsigned mt = sh.min_tot; if (mt != kEncMax) { const float t = dec(mt) + ab; if (t < accept) accept = t; } }
     const int n_cand = sh.n_cand;
     nb = cur_base + n_cur;
+    // candidate records are read one block ahead of their use
+    float q_tot = 0.0f, q_c = 0.0f; int q_nxt = 0, q_a = 0, q_s = 0;
+    if (tid < n_cand) { q_tot = c_tot[tid]; q_nxt = c_dst[tid]; q_a = c_arc[tid]; q_s = c_src[tid]; q_c = c_ac[tid]; }
     for (int j0 = 0; j0 < n_cand; j0 += kBlock) {
-      const int j = j0 + tid; bool claimed = false, mk = false; int slot = -1, nxt = 0, c_a = 0, c_s = 0; float tot = 0.0f, c_c = 0.0f;
-      if (j < n_cand) {
-        tot = c_tot[j]; nxt = c_dst[j]; c_a = c_arc[j]; c_s = c_src[j]; c_c = c_ac[j];      // one round trip for the whole record
-      }
+      const int j = j0 + tid; bool claimed = false, mk = false; int slot = -1;
+      const float tot = q_tot, c_c = q_c; const int nxt = q_nxt, c_a = q_a, c_s = q_s;
+      { const int jn = j + kBlock; if (jn < n_cand) { q_tot = c_tot[jn]; q_nxt = c_dst[jn]; q_a = c_arc[jn]; q_s = c_src[jn]; q_c = c_ac[jn]; } }
       if (row_pending) { fetch_row(); row_pending = false; }
       if (j < n_cand) {
         if (tot < accept) {
