@@ -49,3 +49,94 @@ class NnetBatch:
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _l.check(self._L.k3_nnet_forward(self._h, feats.data_ptr(), feats.stride(0), out.data_ptr(), out.stride(0), st))
         return out
+
+
+class BatchedStaticNnet3:
+    """Streaming driver of the nnet3 forward, the role of cudadecoder/batched-static-nnet3.{h,cc} (BatchedStaticNnet3::RunBatch
+    :293-365): the network is planned ONCE for `max_batch_size` slots of `frames_per_chunk` input frames plus the model's left and
+    right input context; between calls the last context frames of every channel are stashed on the GPU; the first chunk of a channel
+    sees frame 0 replicated to the left, the last chunk flushes the frames still waiting for right context with the last frame
+    replicated (DecodableNnetSimple's edge handling, nnet3/nnet-am-decodable-simple.cc:154-163).  Like the reference it recomputes
+    the context frames of every chunk instead of keeping per-layer state, so every output row is the same arithmetic on the same
+    inputs as in a whole-utterance forward: the chunked log-likelihoods are bit-identical to NnetBatch.forward's.
+
+    RunBatch(channels, chunks, is_first_chunk, is_last_chunk) -> list of [n_out_i, output_dim] GPU tensors (views into an internal
+    buffer, valid until the next call): the output frames of each slot's channel that became computable, in time order."""
+    def __init__(self, nnet, max_batch_size, nchannels=None, frames_per_chunk=150, frame_subsampling_factor=3, log_priors=None, acoustic_scale=1.0,
+                 device="cuda:0"):
+        from .cumatrix import CuMatrix
+        self._CuMatrix = CuMatrix
+        s = self.s = int(frame_subsampling_factor); C = self.C = int(frames_per_chunk)
+        if C <= 0 or C % s: raise ValueError("frames_per_chunk must be a positive multiple of the frame-subsampling factor")
+        self.nnet, self.B = nnet, int(max_batch_size); self.nch = int(nchannels or max_batch_size)
+        if self.nch < self.B: raise ValueError("nchannels must be >= max_batch_size")
+        self.Lc = -(-nnet.info.left_context // s) * s; self.Rc = int(nnet.info.right_context)
+        self.P = self.Lc + C + self.Rc; self.rows_per_slot = -(-self.P // s)
+        self.dim = nnet.info.input_dim; self.dev = torch.device(device)
+        self.batch = NnetBatch(nnet, [self.P] * self.B, s, log_priors, acoustic_scale)
+        self.S = self.Lc + self.Rc + C + 2 * s             # frames a channel can have waiting between calls (generous)
+        self.stash = [torch.zeros((self.nch * self.S, self.dim), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.cur = 0
+        self.inp = torch.zeros((self.B * self.P, self.dim), dtype=torch.float32, device=self.dev)
+        self.out = torch.empty((self.batch.total_out_rows, nnet.info.output_dim), dtype=torch.float32, device=self.dev)
+        self.t_next = np.zeros(self.nch, np.int64); self.n_seen = np.zeros(self.nch, np.int64); self.stash_lo = np.zeros(self.nch, np.int64)
+
+    def GetNOutputFramesPerChunk(self): return self.C // self.s
+    def GetTotalNnet3RightContext(self): return self.Rc
+
+    def _pass(self, channels, new, n_new, last):
+        """one planned forward over the slots: returns per-slot (row0, count) in self.out"""
+        B, P, S, s = len(channels), self.P, self.S, self.s
+        idx_st = np.full(self.B * P, -1, np.int32); idx_nw = np.full(self.B * P, -1, np.int32)
+        upd_st = np.full(self.nch * S, -1, np.int32); upd_nw = np.full(self.nch * S, -1, np.int32)
+        keep = np.ones(self.nch, bool); keep[list(channels)] = False
+        for ch in np.nonzero(keep)[0]:                    # untouched channels keep their stash
+            n = int(self.n_seen[ch] - self.stash_lo[ch]); upd_st[ch * S: ch * S + n] = np.arange(ch * S, ch * S + n, dtype=np.int32)
+        res = []; new_off = np.concatenate([[0], np.cumsum(n_new)])
+        for i, ch in enumerate(channels):
+            avail = int(self.n_seen[ch] + n_new[i]); tn = int(self.t_next[ch])
+            if last[i]: count = max(0, -(-(avail - tn) // s))
+            else: count = max(0, (avail - 1 - self.Rc - tn) // s + 1) if avail - 1 - self.Rc - tn >= 0 else 0
+            count = min(count, self.C // s)
+            if avail > 0:
+                tau = np.clip(np.arange(tn - self.Lc, tn - self.Lc + P), 0, avail - 1)
+                from_new = tau >= self.n_seen[ch]
+                idx_nw[i * P:(i + 1) * P][from_new] = (new_off[i] + tau[from_new] - self.n_seen[ch]).astype(np.int32)
+                idx_st[i * P:(i + 1) * P][~from_new] = (ch * S + tau[~from_new] - self.stash_lo[ch]).astype(np.int32)
+            res.append((i * self.rows_per_slot + self.Lc // s, count))
+            tn2 = tn + count * s; lo2 = max(0, tn2 - self.Lc)
+            tau = np.arange(lo2, avail); assert len(tau) <= S, "internal: stash capacity"
+            from_new = tau >= self.n_seen[ch]
+            upd_nw[ch * S: ch * S + len(tau)][from_new] = (new_off[i] + tau[from_new] - self.n_seen[ch]).astype(np.int32)
+            upd_st[ch * S: ch * S + len(tau)][~from_new] = (ch * S + tau[~from_new] - self.stash_lo[ch]).astype(np.int32)
+            self.t_next[ch], self.n_seen[ch], self.stash_lo[ch] = tn2, avail, lo2
+        A, Bn = self.stash[self.cur], self.stash[self.cur ^ 1]
+        d = lambda a: torch.from_numpy(a).to(self.dev)
+        M = self._CuMatrix
+        M(self.inp).CopyRows(M(A), d(idx_st))
+        if new is not None and new.shape[0] > 0: M(self.inp).AddRows(1.0, M(new), d(idx_nw))
+        M(Bn).CopyRows(M(A), d(upd_st))
+        if new is not None and new.shape[0] > 0: M(Bn).AddRows(1.0, M(new), d(upd_nw))
+        self.cur ^= 1
+        self.batch.forward(self.inp, out=self.out)
+        return res
+
+    def RunBatch(self, channels, chunks, is_first_chunk, is_last_chunk):
+        if len(channels) > self.B or len(set(channels)) != len(channels): raise ValueError("at most one chunk per channel and max_batch_size slots")
+        n_new = [int(c.shape[0]) for c in chunks]
+        if any(n > self.C for n in n_new): raise ValueError("a chunk has more than frames_per_chunk frames")
+        for ch, first in zip(channels, is_first_chunk):
+            if first: self.t_next[ch] = self.n_seen[ch] = self.stash_lo[ch] = 0
+        new = torch.cat([c.to(self.dev, torch.float32) for c in chunks], 0) if chunks else None
+        res = self._pass(list(channels), new, n_new, list(is_last_chunk))
+        outs = [[self.out[r0:r0 + n].clone()] if n else [] for r0, n in res]
+        # end of stream: the frames that were waiting for right context may need more passes than one chunk's worth of output rows
+        pending = [i for i, ch in enumerate(channels) if is_last_chunk[i] and self.t_next[ch] < self.n_seen[ch]]
+        while pending:
+            chs = [channels[i] for i in pending]
+            res2 = self._pass(chs, None, [0] * len(chs), [True] * len(chs))
+            for i, (r0, n) in zip(pending, res2):
+                if n: outs[i].append(self.out[r0:r0 + n].clone())
+            pending = [i for i in pending if self.t_next[channels[i]] < self.n_seen[channels[i]]]
+        od = self.nnet.info.output_dim
+        return [torch.cat(o, 0) if o else torch.empty((0, od), dtype=torch.float32, device=self.dev) for o in outs]

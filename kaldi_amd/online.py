@@ -1,0 +1,89 @@
+"""Streaming (chunked) use of the three stages, the role of the reference's online pipeline
+(cudadecoder/batched-threaded-nnet3-cuda-online-pipeline.{h,cc}: DecodeBatch(channels, wave chunks, is_first_chunk, is_last_chunk);
+cudafeat/online-batched-feature-pipeline-cuda.h:83-92 ComputeFeaturesBatched; cudadecoder/batched-static-nnet3.cc RunBatch;
+CudaDecoder::InitDecoding / AdvanceDecoding).  Every stage recomputes nothing it has already emitted and keeps only input-level state
+per channel (trailing samples, context frames, the decoder lane), so the chunked results are bit-identical to the offline batch path
+(tests/test_online_gpu.py).  Host-side orchestration only: all arithmetic runs in the same HIP kernels through the C ABI."""
+import numpy as np, torch
+from . import feat as _feat, nnet3 as _nnet3, decoder as _decoder
+
+
+class OnlineBatchedFeaturePipeline:
+    """ComputeFeaturesBatched over channels: a channel's samples that do not yet complete a frame (and the overlap the next frames
+    reach back into) are kept on the GPU between calls.  snip_edges=true framing (feat/feature-window.cc:30-87): frame f covers
+    samples [f * shift, f * shift + window), so the frames of a chunked stream are exactly those of the whole waveform."""
+    def __init__(self, opts, num_channels, device="cuda:0"):
+        if not opts.snip_edges: raise ValueError("streaming features need snip_edges=true (edge reflection depends on the end of the stream)")
+        self.sf = _feat.SpectralFeatures(opts); self.dev = torch.device(device)
+        self.shift = int(opts.samp_freq * 0.001 * opts.frame_shift_ms); self.win = int(opts.samp_freq * 0.001 * opts.frame_length_ms)
+        self.stash = [torch.zeros(0, dtype=torch.float32, device=self.dev) for _ in range(num_channels)]
+        self.frames_done = np.zeros(num_channels, np.int64)
+
+    def Dim(self): return self.sf.dim
+
+    def ComputeFeaturesBatched(self, channels, wave_chunks, is_first_chunk, is_last_chunk=None):
+        """wave_chunks[i]: float32 samples (int16 range) of channels[i]; returns a list of [n_new_frames_i, dim] feature tensors"""
+        waves = []
+        for ch, w, first in zip(channels, wave_chunks, is_first_chunk):
+            if first: self.stash[ch] = torch.zeros(0, dtype=torch.float32, device=self.dev); self.frames_done[ch] = 0
+            waves.append(torch.cat([self.stash[ch], w.to(self.dev, torch.float32)]))
+        lens = [int(w.numel()) for w in waves]
+        wo, fo, total, fo_h = self.sf.offsets(lens, self.dev)
+        out = self.sf.ComputeFeatures(torch.cat(waves) if waves else torch.zeros(0, device=self.dev), wo, fo, total) if total > 0 else \
+            torch.zeros((0, self.sf.dim), dtype=torch.float32, device=self.dev)
+        res = []
+        for i, ch in enumerate(channels):
+            n = fo_h[i + 1] - fo_h[i]
+            res.append(out[fo_h[i]:fo_h[i + 1]])
+            self.stash[ch] = waves[i][n * self.shift:]            # the next frame starts n * shift samples further
+            self.frames_done[ch] += n
+        return res
+
+
+class BatchedOnlinePipeline:
+    """A group of `num_channels` utterances decoded chunk by chunk: DecodeBatch(channels, wave_chunks, is_first_chunk, is_last_chunk)
+    pushes the new audio through features -> nnet3 (BatchedStaticNnet3) -> CudaDecoder.AdvanceDecoding; GetRawLattices() finalises the
+    group.  (One lane per channel; the lanes of a group are initialised and finalised together -- k3_decoder_init_decoding /
+    k3_decoder_finalize_decoding work on the whole lane set.)"""
+    def __init__(self, feat_opts, nnet, cuda_fst, decoder_config, num_channels, max_frames_per_channel, frames_per_chunk=150,
+                 frame_subsampling_factor=3, log_priors=None, acoustic_scale=1.0, device="cuda:0"):
+        self.nch = num_channels; self.dev = torch.device(device)
+        self.features = OnlineBatchedFeaturePipeline(feat_opts, num_channels, device)
+        self.nnet = _nnet3.BatchedStaticNnet3(nnet, num_channels, num_channels, frames_per_chunk, frame_subsampling_factor, log_priors, acoustic_scale, device)
+        self.C = frames_per_chunk
+        self.decoder = _decoder.CudaDecoder(cuda_fst, decoder_config, num_channels, nnet.info.output_dim)
+        self.decoder.InitDecoding(num_channels, int(max_frames_per_channel) * num_channels)
+        self.pending = [torch.zeros((0, self.features.Dim()), dtype=torch.float32, device=self.dev) for _ in range(num_channels)]
+        self.started = np.zeros(num_channels, bool); self.num_pdfs = nnet.info.output_dim
+
+    def DecodeBatch(self, channels, wave_chunks, is_first_chunk, is_last_chunk):
+        feats = self.features.ComputeFeaturesBatched(channels, wave_chunks, is_first_chunk, is_last_chunk)
+        lls = {ch: [] for ch in channels}
+        # feature frames go to the network at most frames_per_chunk at a time; what does not fill a chunk waits (unless the stream ends)
+        todo = {ch: torch.cat([self.pending[ch], f]) for ch, f in zip(channels, feats)}
+        last = dict(zip(channels, is_last_chunk))
+        while True:
+            # a channel runs when it has a full chunk, or when its stream ends (then whatever is left, possibly nothing, closes it)
+            chs = [ch for ch in channels if todo[ch] is not None and (todo[ch].shape[0] >= self.C or last[ch])]
+            if not chs: break
+            chunks, firsts, lasts = [], [], []
+            for ch in chs:
+                n = min(self.C, todo[ch].shape[0]); chunks.append(todo[ch][:n]); rest = todo[ch][n:]
+                firsts.append(not self.started[ch]); self.started[ch] = True
+                is_end = bool(last[ch]) and rest.shape[0] == 0
+                lasts.append(is_end); todo[ch] = None if is_end else rest
+            outs = self.nnet.RunBatch(chs, chunks, firsts, lasts)
+            for ch, o in zip(chs, outs): lls[ch].append(o)
+        for ch in channels: self.pending[ch] = todo[ch] if todo[ch] is not None else torch.zeros((0, self.features.Dim()), dtype=torch.float32, device=self.dev)
+        # one AdvanceDecoding call for all lanes: lanes without new frames get an empty row range
+        per_lane = [torch.cat(lls[ch]) if ch in lls and lls[ch] else None for ch in range(self.nch)]
+        ro = np.zeros(self.nch + 1, np.int64)
+        for ch in range(self.nch): ro[ch + 1] = ro[ch] + (per_lane[ch].shape[0] if per_lane[ch] is not None else 0)
+        if ro[-1] > 0:
+            mat = torch.cat([x for x in per_lane if x is not None])
+            self.decoder.AdvanceDecoding(mat, ro)
+        return [int(ro[ch + 1] - ro[ch]) for ch in channels]
+
+    def GetRawLattices(self):
+        self.decoder.FinalizeDecoding()
+        return self.decoder.GetRawLattices()

@@ -99,3 +99,40 @@ def test_hip_full_model_spot_check(tmp_path):
     for g in got[1:]:
         assert np.array_equal(g, got[0])
     _check(no, no.read_nnet(p), f, got[0], 3)
+
+
+def test_batched_static_nnet3_streaming_equals_whole_utterance(tmp_path):
+    """Chunked streaming forward (BatchedStaticNnet3.RunBatch: per-channel input context stashed between calls, first/last chunk edge
+    replication, right-context latency, end-of-stream flush) vs the whole-utterance forward: the same rows, bit for bit."""
+    import torch
+    from kaldi_amd import nnet3, synth
+    rng = np.random.default_rng(11); dev = torch.device("cuda:0")
+    calib = (rng.standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net_w = synth.make_tdnnf(seed=5, dim=96, bottleneck=24, strides=(1, 1, 0, 3, 3), prefinal_small=48, num_pdfs=120, calib_feats=calib, out_std=1.5)
+    mp = str(tmp_path / "m.raw"); net_w.write(mp)
+    net = nnet3.Nnet(mp); s = 3
+    lens = [1, 2, 47, 150, 151, 333, 610, 29]
+    utts = [torch.from_numpy((rng.standard_normal((T, 40)) * 1.2 + 16.5).astype(np.float32)).to(dev) for T in lens]
+    whole = nnet3.NnetBatch(net, lens, s); ref = whole.forward(torch.cat(utts, 0)); torch.cuda.synchronize()
+    ref_u = [ref[whole.out_offsets[u]:whole.out_offsets[u + 1]] for u in range(len(lens))]
+    for C, B in ((150, 4), (30, 3)):
+        drv = nnet3.BatchedStaticNnet3(net, max_batch_size=B, nchannels=B + 2, frames_per_chunk=C, frame_subsampling_factor=s)
+        assert drv.GetNOutputFramesPerChunk() == C // s
+        got = [[] for _ in lens]; pos = [0] * len(lens); todo = list(range(len(lens))); chan_of = {}; free = list(range(B + 2))
+        while todo or chan_of:
+            # admit utterances to free channels, then run one batch of up to B slots with random chunk sizes
+            while todo and free and len(chan_of) < B + 2: chan_of[todo.pop(0)] = free.pop(0)
+            slots = list(chan_of.items())[:B]
+            chans, chunks, first, last = [], [], [], []
+            for u, ch in slots:
+                n = int(rng.integers(0, C + 1)) if lens[u] - pos[u] > 3 else lens[u] - pos[u]
+                n = min(n, lens[u] - pos[u])
+                chans.append(ch); chunks.append(utts[u][pos[u]:pos[u] + n]); first.append(pos[u] == 0); pos[u] += n; last.append(pos[u] == lens[u])
+            outs = drv.RunBatch(chans, chunks, first, last)
+            for (u, ch), o, l in zip(slots, outs, last):
+                got[u].append(o)
+                if l: free.append(chan_of.pop(u))
+        for u in range(len(lens)):
+            g = torch.cat(got[u], 0)
+            assert g.shape == ref_u[u].shape, (C, u, g.shape, ref_u[u].shape)
+            assert torch.equal(g, ref_u[u]), (C, u, (g - ref_u[u]).abs().max().item())
