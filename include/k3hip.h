@@ -177,6 +177,13 @@ int k3_decoder_decode_batch(k3_decoder *dec, int32_t num_utts, const float *d_lo
 int k3_decoder_init_decoding(k3_decoder *dec, int32_t num_utts, int32_t max_total_frames, void *stream);
 int k3_decoder_advance_decoding(k3_decoder *dec, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_offsets, void *stream);
 int k3_decoder_finalize_decoding(k3_decoder *dec, void *stream);
+/* Channels with independent lifetimes inside one lane group (CudaDecoder::InitDecoding(channels) cuda-decoder.h:248 / the per-channel
+ * end of an utterance in the online pipeline): k3_decoder_init_channels restarts the listed lanes (start token + eps closure at their
+ * next k3_decoder_advance_decoding), k3_decoder_finalize_channels runs FinalizeDecoding on the listed lanes only; afterwards
+ * k3_decoder_lattice_info / k3_decoder_get_raw_lattices return exactly those lanes, in the order given, while the other lanes of the
+ * group keep their state and go on decoding.  A lane is a channel here: its tokens and links live in its own HBM pools. */
+int k3_decoder_init_channels(k3_decoder *dec, const int32_t *channels, int32_t num_channels, void *stream);
+int k3_decoder_finalize_channels(k3_decoder *dec, const int32_t *channels, int32_t num_channels, void *stream);
 int32_t k3_decoder_num_frames_decoded(const k3_decoder *dec, int32_t utt);     /* NumFramesDecoded(channel) */
 /* Per utterance: [0] lattice states, [1] lattice arcs, [2] status (0 ok, 1 no surviving tokens, <0 k3_status),
  * [3] reached_final (a final-state token was active on the last frame), [4] tokens created, [5] links created,

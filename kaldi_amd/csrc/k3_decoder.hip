@@ -90,7 +90,8 @@ struct DecParams {
   int frame_tokens_cap, frame_cands_cap, hash_mask; long long lane_tokens_cap, lane_links_cap;
   // input
   const float *loglikes; long long ld; const long long *row_off; int num_pdfs; int use_lds_row;
-  int resume;                             // 0: InitDecoding first, frames are 0..T-1; 1: continue after LaneInfo::num_frames frames (AdvanceDecoding)
+  const int *fresh;                       // [nlanes] 1: InitDecoding first (start token + eps closure), frames start at 0; 0: continue after LaneInfo::num_frames frames (AdvanceDecoding)
+  const int *lane_ids;                    // prune / output kernels: the lanes being finalised (workgroup b works on lane lane_ids[b]); null = lane b
   // per-lane pools (lane l at base + l * stride)
   int *tok_state; unsigned *tok_cost; float *tok_extra; Link *links; int *link_arc;
   int *live_tok; long long *live_link; int *newidx; int live_cap;   // survivors of the pruning pass (pool indices), per lane
@@ -514,7 +515,9 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   unsigned creg[kCurRegs]; int sreg[kCurRegs]; bool in_regs = false;      // (cost, state) of current-frame token tid + k * kBlock
 #pragma unroll
   for (int k = 0; k < kCurRegs; k++) { creg[k] = kEncMax; sreg[k] = 0; }
-  if (!p.resume) {
+  const bool fresh = p.fresh[L] != 0;
+  if (!fresh && T == 0) return;        // the lane idles in this call (it may already be finalised: its LaneInfo must stay as it is)
+  if (fresh) {
     // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
     if (tid == 0) {
       bool cl; const int slot = tb.claim(p.start, &cl);
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
 #endif
   // frame -1 (only on a fresh start) is InitDecoding's eps closure of the start token with cutoff = beam: it shares the
   // ProcessNonemitting code of the real frames (one copy of it in the instruction stream)
-  for (int f = p.resume ? f0 : -1; f < f0 + T; f++) {
+  for (int f = fresh ? -1 : f0; f < f0 + T; f++) {
     if (block_err(sh)) break;
 #ifdef K3_DEC_PROF
     if (tid == 0) sh.prof_n = n_cur;
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
   __shared__ unsigned s_best, s_best_final;
   __shared__ float s_cost[2][kPCap], s_extra[2][kPCap];   // token costs / extra costs of frames f+1 (buffer nb) and f (buffer nb ^ 1)
   __shared__ unsigned s_xb[kPCap];
-  const int L = blockIdx.x, tid = threadIdx.x;
+  const int L = p.lane_ids ? p.lane_ids[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
   LaneInfo &li = p.info[L];
   if (li.status != kStOk) return;
   const int T = li.num_frames;
@@ -1013,7 +1016,7 @@ struct OutParams {
 
 __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, OutParams o) {
   __shared__ int s_n;
-  const int L = blockIdx.x, tid = threadIdx.x;
+  const int L = p.lane_ids ? p.lane_ids[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
   const LaneInfo &li = p.info[L];
   if (li.status != kStOk) return;
   const int T = li.num_frames;
@@ -1024,7 +1027,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, 
   const float *st_co = p.st_co + L * p.fstride;
   int *newidx = p.newidx + (long long)L * p.lane_tokens_cap;
   const float kInf = __builtin_inff(); const float lb = p.lattice_beam;
-  const long long so = o.st_off[L], ao = o.arc_off[L];
+  const long long so = o.st_off[blockIdx.x], ao = o.arc_off[blockIdx.x];      // offsets are per finalised lane, in launch order
   if (!li.live_overflow) {       // survivors were listed by the pruning pass: touch only them
     const int *live_tok = p.live_tok + (long long)L * p.live_cap; const long long *live_link = p.live_link + (long long)L * p.live_cap;
     for (int i = tid; i < li.out_states; i += kPBlock) {
@@ -1180,8 +1183,9 @@ struct k3_decoder {
   DecParams p{};
   std::vector<void *> allocs;
   long long fstride = 0; std::vector<void *> frame_allocs;
-  long long *d_row_off = nullptr;
-  int last_utts = 0; std::vector<int> last_frames;
+  long long *d_row_off = nullptr; int *d_fresh = nullptr, *d_lane_ids = nullptr;
+  int last_utts = 0; std::vector<int> last_frames, fresh, lane_final;   // per lane: frames consumed, InitDecoding pending, FinalizeDecoding done
+  std::vector<int> sel;                                                   // lanes of the latest finalize call (what the lattice getters return)
   hipStream_t last_stream = nullptr;
   std::vector<LaneInfo> h_info; bool info_valid = false;
   void *out_buf = nullptr; size_t out_bytes = 0;
@@ -1237,6 +1241,8 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &p.prof, nl * 16))) return rc;
   K3_HIP_CHECK(hipMemset(p.prof, 0, nl * 16 * sizeof(long long)));
   if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
+  if ((rc = dmalloc(&d->allocs, &d->d_fresh, nl))) return rc;
+  if ((rc = dmalloc(&d->allocs, &d->d_lane_ids, nl))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.newidx, nl * cfg->lane_tokens_cap))) return rc;
   p.live_cap = (int)std::min<long long>(cfg->lane_tokens_cap, 1 << 18);
   if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
@@ -1289,7 +1295,17 @@ static int ensure_frame_capacity(k3_decoder *d, int max_frames, hipStream_t st) 
 extern "C" int k3_decoder_init_decoding(k3_decoder *d, int32_t num_utts, int32_t max_total_frames, void *stream) {
   K3_REQUIRE(d && num_utts > 0 && num_utts <= d->nlanes && max_total_frames > 0, "k3_decoder_init_decoding: bad argument");
   { const int rc = ensure_frame_capacity(d, max_total_frames, (hipStream_t)stream); if (rc) return rc; }
-  d->last_utts = num_utts; d->last_frames.assign(num_utts, 0); d->started = false; d->finalized = false; d->info_valid = false; d->last_stream = (hipStream_t)stream;
+  d->last_utts = num_utts; d->last_frames.assign(num_utts, 0); d->fresh.assign(num_utts, 1); d->lane_final.assign(num_utts, 0); d->sel.clear();
+  d->started = false; d->finalized = false; d->info_valid = false; d->last_stream = (hipStream_t)stream;
+  return K3_OK;
+}
+
+// CudaDecoder::InitDecoding(channels) (cuda-decoder.h:248): restart the listed lanes of the current group; the other lanes keep decoding.
+extern "C" int k3_decoder_init_channels(k3_decoder *d, const int32_t *channels, int32_t n, void *stream) {
+  K3_REQUIRE(d && channels && n >= 0 && d->last_utts > 0, "k3_decoder_init_channels: call k3_decoder_init_decoding for the lane group first");
+  for (int i = 0; i < n; i++) K3_REQUIRE(channels[i] >= 0 && channels[i] < d->last_utts, "k3_decoder_init_channels: channel out of range");
+  for (int i = 0; i < n; i++) { d->last_frames[channels[i]] = 0; d->fresh[channels[i]] = 1; d->lane_final[channels[i]] = 0; }
+  d->finalized = false; d->info_valid = false; (void)stream;
   return K3_OK;
 }
 
@@ -1297,16 +1313,18 @@ extern "C" int k3_decoder_init_decoding(k3_decoder *d, int32_t num_utts, int32_t
 // its NEXT frames (zero rows = the lane idles in this call).  Chunked calls give bit-identical results to one call with all frames.
 extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream) {
   K3_REQUIRE(d && d_loglikes && h_row_off && num_utts == d->last_utts && ld >= d->num_pdfs, "k3_decoder_advance_decoding: bad argument (call k3_decoder_init_decoding for this many lanes first)");
-  K3_REQUIRE(!d->finalized, "k3_decoder_advance_decoding: FinalizeDecoding was already called");
   hipStream_t st = (hipStream_t)stream; DecParams &p = d->p;
   for (int u = 0; u < num_utts; u++) {
     const long long T = h_row_off[u + 1] - h_row_off[u];
     K3_REQUIRE(T >= 0 && d->last_frames[u] + T + 2 <= d->fstride, "k3_decoder_advance_decoding: more frames than max_total_frames of k3_decoder_init_decoding");
+    K3_REQUIRE(T == 0 || !d->lane_final[u], "k3_decoder_advance_decoding: frames for a finalised lane (k3_decoder_init_channels restarts it)");
     d->last_frames[u] += (int)T;
   }
   K3_HIP_CHECK(hipStreamSynchronize(st));            // d_row_off may still be read by the previous chunk's kernel
   K3_HIP_CHECK(hipMemcpy(d->d_row_off, h_row_off, sizeof(long long) * (num_utts + 1), hipMemcpyHostToDevice));
-  p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off; p.resume = d->started ? 1 : 0;
+  K3_HIP_CHECK(hipMemcpy(d->d_fresh, d->fresh.data(), sizeof(int) * num_utts, hipMemcpyHostToDevice));
+  std::fill(d->fresh.begin(), d->fresh.end(), 0);
+  p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off; p.fresh = d->d_fresh; p.lane_ids = nullptr;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
@@ -1317,14 +1335,34 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
 }
 
 // FinalizeDecoding (lattice-faster-decoder.cc:634-649) on the GPU: lattice-beam pruning with final-probs; lattices can be fetched afterwards.
-extern "C" int k3_decoder_finalize_decoding(k3_decoder *d, void *stream) {
-  K3_REQUIRE(d && d->started && !d->finalized, "k3_decoder_finalize_decoding: nothing to finalize");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k3_decode_prune_kernel, dim3(d->last_utts), dim3(kPBlock), 0, st, d->p);
+static int finalize_lanes(k3_decoder *d, const std::vector<int> &lanes, hipStream_t st) {
+  K3_REQUIRE(d->started, "k3_decoder_finalize_decoding: nothing to finalize");
+  for (int l : lanes) K3_REQUIRE(l >= 0 && l < d->last_utts && !d->fresh[l], "k3_decoder_finalize: lane out of range or never advanced");
+  if (lanes.empty()) { d->sel.clear(); return K3_OK; }
+  K3_HIP_CHECK(hipStreamSynchronize(st));            // d_lane_ids may still be read by an earlier finalize
+  K3_HIP_CHECK(hipMemcpy(d->d_lane_ids, lanes.data(), sizeof(int) * lanes.size(), hipMemcpyHostToDevice));
+  d->p.lane_ids = d->d_lane_ids;
+  hipLaunchKernelGGL(k3_decode_prune_kernel, dim3((unsigned)lanes.size()), dim3(kPBlock), 0, st, d->p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[2], st));
-  d->finalized = true; d->last_stream = st; d->info_valid = false;
+  for (int l : lanes) d->lane_final[l] = 1;
+  d->sel = lanes; d->last_stream = st; d->info_valid = false;
   return K3_OK;
+}
+
+extern "C" int k3_decoder_finalize_decoding(k3_decoder *d, void *stream) {
+  K3_REQUIRE(d && d->started && !d->finalized, "k3_decoder_finalize_decoding: nothing to finalize");
+  std::vector<int> all(d->last_utts); for (int u = 0; u < d->last_utts; u++) all[u] = u;
+  const int rc = finalize_lanes(d, all, (hipStream_t)stream);
+  if (rc == K3_OK) d->finalized = true;
+  return rc;
+}
+
+// FinalizeDecoding of some lanes only (an utterance ended on those channels); k3_decoder_lattice_info / k3_decoder_get_raw_lattices
+// then return these lanes, in the order given.  The other lanes of the group go on decoding.
+extern "C" int k3_decoder_finalize_channels(k3_decoder *d, const int32_t *channels, int32_t n, void *stream) {
+  K3_REQUIRE(d && channels && n >= 0, "k3_decoder_finalize_channels: bad argument");
+  return finalize_lanes(d, std::vector<int>(channels, channels + n), (hipStream_t)stream);
 }
 
 extern "C" int32_t k3_decoder_num_frames_decoded(const k3_decoder *d, int32_t utt) { return (d && utt >= 0 && utt < d->last_utts) ? d->last_frames[utt] : -1; }
@@ -1357,8 +1395,9 @@ extern "C" int k3_decoder_lattice_info(k3_decoder *d, int64_t *h_info) {
   K3_REQUIRE(d && h_info, "k3_decoder_lattice_info: null argument");
   { const int rc = fetch_info(d); if (rc) return rc; }
   int worst = K3_OK;
-  for (int u = 0; u < d->last_utts; u++) {
-    const LaneInfo &li = d->h_info[u]; int64_t *o = h_info + 10 * u;
+  for (size_t k = 0; k < d->sel.size(); k++) {
+    const int u = d->sel[k];
+    const LaneInfo &li = d->h_info[u]; int64_t *o = h_info + 10 * k;
     o[0] = li.status == kStOk ? li.out_states : 0; o[1] = li.status == kStOk ? li.out_arcs : 0; o[2] = li.status; o[3] = li.reached_final;
     o[4] = li.n_tokens; o[5] = li.n_links; o[6] = li.max_frame_tokens; o[7] = li.n_cands; o[8] = li.n_eps; o[9] = li.num_frames;
     if (li.status < 0) { worst = li.status; k3::set_error("k3_decoder: utterance %d failed with status %d (%s); tokens %lld links %lld max tokens/frame %d -- raise the k3_decoder_config capacities",
@@ -1371,9 +1410,10 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
                                            int32_t *arc_il, int32_t *arc_ol, float *arc_g, float *arc_ac) {
   K3_REQUIRE(d && st_frame && st_state && st_cost && st_final && arc_src && arc_dst && arc_il && arc_ol && arc_g && arc_ac, "k3_decoder_get_raw_lattices: null argument");
   { const int rc = fetch_info(d); if (rc) return rc; }
-  const int U = d->last_utts;
+  const int U = (int)d->sel.size();
+  K3_REQUIRE(U > 0, "k3_decoder_get_raw_lattices: no finalised lanes");
   std::vector<long long> so(U + 1, 0), ao(U + 1, 0);
-  for (int u = 0; u < U; u++) { const LaneInfo &li = d->h_info[u]; const bool ok = li.status == kStOk; so[u + 1] = so[u] + (ok ? li.out_states : 0); ao[u + 1] = ao[u] + (ok ? li.out_arcs : 0); }
+  for (int u = 0; u < U; u++) { const LaneInfo &li = d->h_info[d->sel[u]]; const bool ok = li.status == kStOk; so[u + 1] = so[u] + (ok ? li.out_states : 0); ao[u + 1] = ao[u] + (ok ? li.out_arcs : 0); }
   const size_t NS = (size_t)so[U], NA = (size_t)ao[U];
   // one grow-only device staging area: [offsets | 4 state arrays | 6 arc arrays]
   const size_t need = sizeof(long long) * 2 * (U + 1) + 4 * (4 * NS + 6 * NA) + 256;
@@ -1396,6 +1436,7 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
 #define K3_TRY(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { cleanup(); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
   so.insert(so.end(), ao.begin(), ao.end());        // d_so and d_ao are adjacent: one upload
   K3_TRY(hipMemcpyAsync(d_so, so.data(), sizeof(long long) * 2 * (U + 1), hipMemcpyHostToDevice, st));
+  d->p.lane_ids = d->d_lane_ids;                     // still holds d->sel (only a finalize call rewrites it)
   hipLaunchKernelGGL(k3_decode_output_kernel, dim3(U), dim3(kPBlock), 0, st, d->p, o);
   K3_TRY(hipGetLastError());
   // the caller's ten arrays laid out back to back in this order (kaldi_amd/decoder.py carves them out of one pinned buffer):

@@ -88,7 +88,7 @@ class CudaDecoder:
         """loglikes: float32 [rows x >= num_pdfs] on the GPU; utterance u = rows row_offsets[u]..row_offsets[u+1] (host ints).
         Asynchronous on the current stream."""
         assert loglikes.is_cuda and loglikes.dtype == torch.float32 and loglikes.stride(1) == 1
-        ro = np.ascontiguousarray(row_offsets, np.int64); self._n = ro.size - 1
+        ro = np.ascontiguousarray(row_offsets, np.int64); self._n = ro.size - 1; self._n_sel = None
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _l.check(self._L.k3_decoder_decode_batch(self._h, self._n, loglikes.data_ptr(), loglikes.stride(0), ro.ctypes.data, st))
 
@@ -103,13 +103,24 @@ class CudaDecoder:
         _l.check(self._L.k3_decoder_advance_decoding(self._h, self._n, loglikes.data_ptr(), loglikes.stride(0), ro.ctypes.data, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def FinalizeDecoding(self):
+        self._n_sel = None
         _l.check(self._L.k3_decoder_finalize_decoding(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def InitChannels(self, channels):
+        """restart the listed lanes of the current group (CudaDecoder::InitDecoding(channels)); the others keep decoding"""
+        ch = np.ascontiguousarray(channels, np.int32)
+        _l.check(self._L.k3_decoder_init_channels(self._h, ch.ctypes.data, ch.size, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def FinalizeChannels(self, channels):
+        """FinalizeDecoding on the listed lanes only; LatticeInfo / GetRawLattices then return these lanes, in this order"""
+        ch = np.ascontiguousarray(channels, np.int32); self._n_sel = int(ch.size)
+        _l.check(self._L.k3_decoder_finalize_channels(self._h, ch.ctypes.data, ch.size, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def NumFramesDecoded(self, utt): return self._L.k3_decoder_num_frames_decoded(self._h, utt)
 
     def LatticeInfo(self, check=True):
         """int64 [num_utts x 10], columns = CudaDecoder.INFO (synchronises)"""
-        info = np.zeros((self._n, 10), np.int64)
+        info = np.zeros((getattr(self, "_n_sel", None) or self._n, 10), np.int64)
         rc = self._L.k3_decoder_lattice_info(self._h, info.ctypes.data)
         if check: _l.check(rc)
         return info

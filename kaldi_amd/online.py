@@ -41,10 +41,11 @@ class OnlineBatchedFeaturePipeline:
 
 
 class BatchedOnlinePipeline:
-    """A group of `num_channels` utterances decoded chunk by chunk: DecodeBatch(channels, wave_chunks, is_first_chunk, is_last_chunk)
-    pushes the new audio through features -> nnet3 (BatchedStaticNnet3) -> CudaDecoder.AdvanceDecoding; GetRawLattices() finalises the
-    group.  (One lane per channel; the lanes of a group are initialised and finalised together -- k3_decoder_init_decoding /
-    k3_decoder_finalize_decoding work on the whole lane set.)"""
+    """`num_channels` concurrent audio streams decoded chunk by chunk, the channel model of BatchedThreadedNnet3CudaOnlinePipeline:
+    DecodeBatch(channels, wave_chunks, is_first_chunk, is_last_chunk) pushes the new audio of the listed channels through
+    features -> nnet3 (BatchedStaticNnet3) -> CudaDecoder.AdvanceDecoding; a channel whose stream ended is finalised on the spot
+    (lattice-beam pruning on the GPU) and its raw lattice is returned, the channel is free for the next utterance.  One decoder lane
+    per channel (k3_decoder_init_channels / k3_decoder_finalize_channels); `max_frames_per_channel` bounds an utterance's length."""
     def __init__(self, feat_opts, nnet, cuda_fst, decoder_config, num_channels, max_frames_per_channel, frames_per_chunk=150,
                  frame_subsampling_factor=3, log_priors=None, acoustic_scale=1.0, device="cuda:0"):
         self.nch = num_channels; self.dev = torch.device(device)
@@ -52,11 +53,18 @@ class BatchedOnlinePipeline:
         self.nnet = _nnet3.BatchedStaticNnet3(nnet, num_channels, num_channels, frames_per_chunk, frame_subsampling_factor, log_priors, acoustic_scale, device)
         self.C = frames_per_chunk
         self.decoder = _decoder.CudaDecoder(cuda_fst, decoder_config, num_channels, nnet.info.output_dim)
-        self.decoder.InitDecoding(num_channels, int(max_frames_per_channel) * num_channels)
-        self.pending = [torch.zeros((0, self.features.Dim()), dtype=torch.float32, device=self.dev) for _ in range(num_channels)]
-        self.started = np.zeros(num_channels, bool); self.num_pdfs = nnet.info.output_dim
+        self.decoder.InitDecoding(num_channels, int(max_frames_per_channel))
+        self.num_pdfs = nnet.info.output_dim
+        self._empty_feats = torch.zeros((0, self.features.Dim()), dtype=torch.float32, device=self.dev)
+        self.pending = [self._empty_feats for _ in range(num_channels)]
+        self.started = np.zeros(num_channels, bool); self.frames_decoded = np.zeros(num_channels, np.int64)
 
     def DecodeBatch(self, channels, wave_chunks, is_first_chunk, is_last_chunk):
+        """returns {channel: RawLattice} for the channels whose stream ended with this call"""
+        fresh = [ch for ch, first in zip(channels, is_first_chunk) if first]
+        if fresh:
+            self.decoder.InitChannels(fresh)
+            for ch in fresh: self.pending[ch] = self._empty_feats; self.started[ch] = False; self.frames_decoded[ch] = 0
         feats = self.features.ComputeFeaturesBatched(channels, wave_chunks, is_first_chunk, is_last_chunk)
         lls = {ch: [] for ch in channels}
         # feature frames go to the network at most frames_per_chunk at a time; what does not fill a chunk waits (unless the stream ends)
@@ -74,16 +82,17 @@ class BatchedOnlinePipeline:
                 lasts.append(is_end); todo[ch] = None if is_end else rest
             outs = self.nnet.RunBatch(chs, chunks, firsts, lasts)
             for ch, o in zip(chs, outs): lls[ch].append(o)
-        for ch in channels: self.pending[ch] = todo[ch] if todo[ch] is not None else torch.zeros((0, self.features.Dim()), dtype=torch.float32, device=self.dev)
+        for ch in channels: self.pending[ch] = todo[ch] if todo[ch] is not None else self._empty_feats
         # one AdvanceDecoding call for all lanes: lanes without new frames get an empty row range
         per_lane = [torch.cat(lls[ch]) if ch in lls and lls[ch] else None for ch in range(self.nch)]
         ro = np.zeros(self.nch + 1, np.int64)
         for ch in range(self.nch): ro[ch + 1] = ro[ch] + (per_lane[ch].shape[0] if per_lane[ch] is not None else 0)
-        if ro[-1] > 0:
-            mat = torch.cat([x for x in per_lane if x is not None])
+        if ro[-1] > 0 or fresh:
+            mat = torch.cat([x for x in per_lane if x is not None]) if ro[-1] > 0 else torch.zeros((1, self.num_pdfs), dtype=torch.float32, device=self.dev)
             self.decoder.AdvanceDecoding(mat, ro)
-        return [int(ro[ch + 1] - ro[ch]) for ch in channels]
-
-    def GetRawLattices(self):
-        self.decoder.FinalizeDecoding()
-        return self.decoder.GetRawLattices()
+        for ch in channels: self.frames_decoded[ch] += ro[ch + 1] - ro[ch]
+        ended = [ch for ch in channels if last[ch]]
+        if not ended: return {}
+        self.decoder.FinalizeChannels(ended)
+        lats = self.decoder.GetRawLattices(copy=True)
+        return {ch: lats[k] for k, ch in enumerate(ended)}

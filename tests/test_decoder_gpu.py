@@ -115,3 +115,44 @@ def test_chunked_advance_decoding_is_bit_identical_to_whole_utterance_decoding()
     lats = dec.GetRawLattices()
     for u in range(3):
         assert lats[u].num_arcs > 0 and lats[u].diff(whole[u]) == "", u
+
+
+def test_channels_with_independent_lifetimes():
+    """InitChannels / FinalizeChannels: utterances start and end at different times on the lanes of one group (the online pipeline's
+    channel model); every utterance's lattice equals the one from decoding it alone in one piece."""
+    from kaldi_amd import decoder
+    N = 60; f, t2p, cf = _setup(2500, 6500, N, seed=21, start_degree=40)
+    cfg = dict(beam=14.0, lattice_beam=7.0, max_active=10000)
+    rng = np.random.default_rng(77)
+    lens = [37, 80, 5, 64, 120, 18, 51]
+    lls = [(rng.standard_normal((T, N)) * 2.5).astype(np.float32) for T in lens]
+    ref, _, _ = _gpu_decode(cf, N, lls, **cfg); ref = [ref[u] for u in range(len(lens))]
+    nl = 3; dec = decoder.CudaDecoder(cf, decoder.decoder_config(**cfg), nl, N)
+    dec.InitDecoding(nl, 200 * nl)
+    queue = list(range(len(lens))); on = {}      # lane -> [utt, frames fed]
+    done = {}
+    while queue or on:
+        for lane in range(nl):
+            if lane not in on and queue:
+                on[lane] = [queue.pop(0), 0]
+                if dec.NumFramesDecoded(lane) != 0 or len(done) > 0 or True: dec.InitChannels([lane])
+        rows, ro = [], [0]
+        for lane in range(nl):
+            n = 0
+            if lane in on:
+                u, p = on[lane]; n = min(int(rng.integers(0, 30)), lens[u] - p)
+                rows.append(lls[u][p:p + n]); on[lane][1] += n
+            ro.append(ro[-1] + n)
+        if ro[-1] == 0: continue
+        dec.AdvanceDecoding(torch.from_numpy(np.concatenate(rows)).cuda(), np.array(ro))
+        ended = [lane for lane in on if on[lane][1] == lens[on[lane][0]]]
+        if ended:
+            dec.FinalizeChannels(ended)
+            info = dec.LatticeInfo(); lats = dec.GetRawLattices(copy=True)
+            assert info.shape[0] == len(ended) and len(lats) == len(ended)
+            for k, lane in enumerate(ended):
+                u = on[lane][0]; assert info[k, 9] == lens[u] and info[k, 2] == 0
+                done[u] = lats[k]; del on[lane]
+    assert sorted(done) == list(range(len(lens)))
+    for u in range(len(lens)):
+        d = done[u].diff(ref[u]); assert d == "", (u, d)

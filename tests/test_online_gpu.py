@@ -42,20 +42,24 @@ def test_online_pipeline_lattices_equal_offline(tmp_path):
     feats = sf.ComputeFeatures(torch.cat(waves), wo, fo, total)
     nb = nnet3.NnetBatch(nn, [fo_h[i + 1] - fo_h[i] for i in range(len(lens))], 3); ll = nb.forward(feats)
     dec = decoder.CudaDecoder(cf, cfg, len(lens), N); dec.DecodeBatch(ll, nb.out_offsets); ref = dec.GetRawLattices(copy=True)
-    # streaming, two chunk regimes
+    # streaming: 3 channels serve the 4 utterances (a channel is reused as soon as its utterance ended), two chunk regimes
     for C, max_samples in ((150, 30000), (30, 5000)):
-        pipe = online.BatchedOnlinePipeline(opts, nn, cf, cfg, num_channels=len(lens), max_frames_per_channel=400, frames_per_chunk=C, frame_subsampling_factor=3)
-        pos = [0] * len(lens); fed = np.zeros(len(lens), np.int64)
-        while any(p < n for p, n in zip(pos, lens)):
-            chans = [u for u in range(len(lens)) if pos[u] < lens[u] and rng.random() < 0.8]
+        nch = 3
+        pipe = online.BatchedOnlinePipeline(opts, nn, cf, cfg, num_channels=nch, max_frames_per_channel=400, frames_per_chunk=C, frame_subsampling_factor=3)
+        pos = [0] * len(lens); queue = list(range(len(lens))); on = {}; got = {}
+        while queue or on:
+            for ch in range(nch):
+                if ch not in on and queue: on[ch] = queue.pop(0)
+            chans = [ch for ch in on if rng.random() < 0.8]
             if not chans: continue
             chunks, first, last = [], [], []
-            for u in chans:
-                n = min(int(rng.integers(1, max_samples)), lens[u] - pos[u]); chunks.append(waves[u][pos[u]:pos[u] + n]); first.append(pos[u] == 0); pos[u] += n; last.append(pos[u] == lens[u])
-            for u, k in zip(chans, pipe.DecodeBatch(chans, chunks, first, last)): fed[u] += k
-        assert fed.tolist() == [int(nb.out_offsets[u + 1] - nb.out_offsets[u]) for u in range(len(lens))]
-        lats = pipe.GetRawLattices()
+            for ch in chans:
+                u = on[ch]; n = min(int(rng.integers(1, max_samples)), lens[u] - pos[u])
+                chunks.append(waves[u][pos[u]:pos[u] + n]); first.append(pos[u] == 0); pos[u] += n; last.append(pos[u] == lens[u])
+            for ch, lat in pipe.DecodeBatch(chans, chunks, first, last).items():
+                u = on.pop(ch); got[u] = lat
+                assert pipe.frames_decoded[ch] == int(nb.out_offsets[u + 1] - nb.out_offsets[u])
+        assert sorted(got) == list(range(len(lens)))
         for u in range(len(lens)):
-            assert pipe.decoder.NumFramesDecoded(u) == fed[u]
-            d = lats[u].diff(ref[u]); assert d == "", (C, u, d)
-            assert lats[u].num_arcs > 0
+            d = got[u].diff(ref[u]); assert d == "", (C, u, d)
+            assert got[u].num_arcs > 0
