@@ -244,11 +244,21 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
     const bool col_ok = col < p.N;
     const int colc = min(col, p.N - 4);
     const int row0c = lane_on ? row0 : 0;
+    // a full tile (all of the 128 rows and BN columns exist: every tile but the last of an utterance / of N) needs no per-row
+    // bounds logic and walks its rows with one pointer increment per row piece
+    const bool full = td.nrows == kBM && n0 + BN <= p.N;
     if ((EPI == kEpiAny || EPI == kEpiReluScaleRes) && res_kind >= 0 && !(p.dbg & 1)) {
+      if (full) {
+        const float *rp = R + (long long)(td.res_base + (wm * WM + row0c) * p.res_row_stride) * p.ldr + colc;
+        const long long rstep = (long long)RPI * p.res_row_stride * p.ldr;
 #pragma unroll
-      for (int it = 0; it < ITERS; it++) {
-        const int lrow = min(wm * WM + it * RPI + row0, td.nrows - 1);
-        res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + colc);
+        for (int it = 0; it < ITERS; it++) res[it] = *reinterpret_cast<const f32x4 *>(rp + it * rstep);
+      } else {
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+          const int lrow = min(wm * WM + it * RPI + row0, td.nrows - 1);
+          res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + colc);
+        }
       }
     }
     if (EPI == kEpiAny) {
@@ -289,10 +299,19 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
         if (EPI == kEpiReluScaleRes) v[it] = p.res_scale * res[it] + v[it];
       }
     }
+    if (full && !(p.dbg & 2)) {
+      if (lane_on) {
+        float *cp = C + (long long)(td.out_row0 + wm * WM + row0) * p.ldc + col;
+        const long long cstep = (long long)RPI * p.ldc;
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-      const int lrow = wm * WM + it * RPI + row0;
-      if (col_ok && lrow < td.nrows && (!(p.dbg & 2) || v[it][0] == 12345.678f)) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v[it];
+        for (int it = 0; it < ITERS; it++) *reinterpret_cast<f32x4 *>(cp + it * cstep) = v[it];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < ITERS; it++) {
+        const int lrow = wm * WM + it * RPI + row0;
+        if (col_ok && lrow < td.nrows && (!(p.dbg & 2) || v[it][0] == 12345.678f)) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v[it];
+      }
     }
   } else {                                             // unaligned / odd-width output: element-wise tail path
     __syncthreads();
