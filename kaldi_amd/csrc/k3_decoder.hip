@@ -70,7 +70,10 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
 #ifndef K3_DEC_PROF_MAXTOK
 #define K3_DEC_PROF_MAXTOK 0x7FFFFFFF      /* count only frames built from at most this many tokens */
 #endif
-#define K3_T(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); if (sh.prof_n <= K3_DEC_PROF_MAXTOK) sh.prof[i] += now__ - t_last__; t_last__ = now__; } } while (0)
+#ifndef K3_DEC_PROF_MINTOK
+#define K3_DEC_PROF_MINTOK 0
+#endif
+#define K3_T(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); if (sh.prof_n <= K3_DEC_PROF_MAXTOK && sh.prof_n >= K3_DEC_PROF_MINTOK) sh.prof[i] += now__ - t_last__; t_last__ = now__; } } while (0)
 #define K3_TW(i) do { __builtin_amdgcn_s_waitcnt(0); K3_T(i); } while (0)      /* drain this wave's memory ops first: attributes load latency to the segment */
 #else
 #define K3_T(i) do { } while (0)
@@ -467,10 +470,14 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         if (i < n) { const int slot = tok_slot[i]; const unsigned c = tb.cost(slot); creg[k] = c; sreg[k] = tb.key(slot); tok_cost[nb + i] = c; if (slot >= kHL) tb.clear(slot); }
       }
     } else {
-      for (int i = tid; i < n; i += kBlock) {
-        const int slot = tok_slot[i];
-        tok_cost[nb + i] = tb.cost(slot);
-        if (slot >= kHL) tb.clear(slot);
+      for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {      // four slot reads in flight per thread (frames of this size pay a round trip per iteration)
+        int sl[4]; unsigned c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int i = i0 + j * kBlock; sl[j] = i < n ? tok_slot[i] : -1; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = sl[j] >= 0 ? tb.cost(sl[j]) : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int i = i0 + j * kBlock; if (sl[j] >= 0) { tok_cost[nb + i] = c[j]; if (sl[j] >= kHL) tb.clear(sl[j]); } }
       }
     }
     __syncthreads();
@@ -559,7 +566,15 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       if (in_regs) {
 #pragma unroll
         for (int k = 0; k < kCurRegs; k++) { const int i = tid + k * kBlock; if (i < n_cur) fn(i, creg[k], sreg[k]); }
-      } else for (int i = tid; i < n_cur; i += kBlock) fn(i, ccs[i], cst[i]);
+      } else {
+        for (int i0 = tid; i0 < n_cur; i0 += 4 * kBlock) {
+          unsigned c[4]; int st[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { const int i = i0 + j * kBlock; c[j] = i < n_cur ? ccs[i] : 0u; st[j] = i < n_cur ? cst[i] : 0; }
+#pragma unroll
+          for (int j = 0; j < 4; j++) { const int i = i0 + j * kBlock; if (i < n_cur) fn(i, c[j], st[j]); }
+        }
+      }
     };
     auto for_keys = [&](auto fn) {       // wave-uniform trip count (block_select_kth)
       if (in_regs) {
