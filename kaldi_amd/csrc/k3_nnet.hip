@@ -63,10 +63,12 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // code; the run-time dispatch costs a register shuffle per op when it merges the branches.
 enum { kEpiAny = 0, kEpiReluScaleRes = 1, kEpiNone = 2, kEpiReluScale = 3 };
 template <int BN, int WM, int WN, bool kAligned, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN) == 8 ? 4 : 2) void k3_tdnn_gemm_kernel(GemmParams p) {
+  constexpr int NT = (kBM / WM) * (BN / WN) * 64, LR = NT / 8;      // threads per workgroup (4 or 8 wavefronts); rows the loader covers per pass
   constexpr int MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN;
-  constexpr int A_LOADS = kBM * kBK / 4 / kThreads;   // float4 loads per thread per k-tile (4)
-  constexpr int B_LOADS = BN * kBK / 4 / kThreads;    // 4 or 3
+  constexpr int A_LOADS = kBM * kBK / 4 / NT;   // float4 loads per thread per k-tile
+  constexpr int B_LOADS = BN * kBK / 4 / NT;
+  static_assert(kBM % LR == 0 && BN % LR == 0, "loader passes must tile the block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *As = reinterpret_cast<float *>(smem);                         // [2][kBM][kLdsLd]
   float *Bs = As + 2 * kBM * kLdsLd;                                   // [2][BN][kLdsLd]
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
   // per-thread row bookkeeping for the A loader (rows beyond nrows re-read the last valid row; never stored)
   int a_row_local[A_LOADS];
 #pragma unroll
-  for (int i = 0; i < A_LOADS; i++) a_row_local[i] = min(i * 32 + ld_row, td.nrows - 1) * p.row_stride + td.in_base;
+  for (int i = 0; i < A_LOADS; i++) a_row_local[i] = min(i * LR + ld_row, td.nrows - 1) * p.row_stride + td.in_base;
 
   f32x4 ra[A_LOADS], rb[B_LOADS];
   // `oi_u` = time offset the k-tile lies in when offsets are tile aligned (tiles_per_off > 0): uniform over the block, so the
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; i++)   // W is zero-padded to [Npad x Kpad]: no bounds checks
-      rb[i] = *reinterpret_cast<const f32x4 *>(p.W + (long long)(n0 + i * 32 + ld_row) * p.ldw + kglob);
+      rb[i] = *reinterpret_cast<const f32x4 *>(p.W + (long long)(n0 + i * LR + ld_row) * p.ldw + kglob);
   };
   // LDS K layout: inside every group of 8 k-values position p holds k = 2 * (p & 3) + (p >> 2), so that the b128 fragment a
   // lane of half h = lane >> 5 reads (positions 4h .. 4h+3) is k = h, 2+h, 4+h, 6+h and MFMA j (A column k = lane >> 5)
@@ -134,12 +136,12 @@ __global__ __launch_bounds__(kThreads, 2) void k3_tdnn_gemm_kernel(GemmParams p)
     float *a = As + buf * kBM * kLdsLd, *b = Bs + buf * BN * kLdsLd;
 #pragma unroll
     for (int i = 0; i < A_LOADS; i++) {
-      float *q = a + (i * 32 + ld_row) * kLdsLd + st_col;
+      float *q = a + (i * LR + ld_row) * kLdsLd + st_col;
       q[0] = ra[i][0]; q[4] = ra[i][1]; q[1] = ra[i][2]; q[5] = ra[i][3];       // two ds_write2_b32 straight from the load registers
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; i++) {
-      float *q = b + (i * 32 + ld_row) * kLdsLd + st_col;
+      float *q = b + (i * LR + ld_row) * kLdsLd + st_col;
       q[0] = rb[i][0]; q[4] = rb[i][1]; q[1] = rb[i][2]; q[5] = rb[i][3];
     }
   };
@@ -673,7 +675,7 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
       const bool al = p.tiles_per_off > 0, bn96 = b->net->dev[i].bn == 96;
       const size_t lds = 2 * (kBM + (bn96 ? 96 : 128)) * kLdsLd * sizeof(float);
       bool launched = false;
-#define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3(kThreads), lds, st, p); launched = true; }
+#define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3((kBM / wm) * (bn / wn) * 64), lds, st, p); launched = true; }
       K3_GEMM_VARIANTS(K3_LAUNCH)
       if (!launched) { epi = kEpiAny; K3_GEMM_VARIANTS(K3_LAUNCH) }      // no fixed-program instantiation for this shape: run-time dispatch
 #undef K3_LAUNCH
