@@ -49,6 +49,7 @@ constexpr unsigned kEncMax = 0xFFFFFFFFu;
 constexpr int kEmpty = -1;
 
 struct Slot { int key; unsigned cost; int tok; int stamp; };          // 16 B hash slot
+constexpr unsigned kEpsFlag = 0x80000000u;     // ArcRec::next bit 31: the destination state has epsilon arcs (set by k3_fst_create)
 struct ArcRec { int next; float w; int pdf; int olabel; };            // 16 B graph arc
 // 16 B forward link (token indices are lane-pool indices): `tot` = (src cost + acoustic) + graph exactly as the forward pass formed
 // it, which is the term PruneForwardLinks needs (:339-341), so pruning never touches the graph; the arc id (labels, graph cost for
@@ -363,17 +364,13 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
   // appends to list r + 1 (count n_wl[(r+1) % 3], marks (r+1) % 3, data buffer (r+1) & 1) and recycles the slots of round r + 2,
   // which nobody touches any more; what is read after a round's barrier (its error flag, the next count) is not written again
   // before the following barrier, so every wavefront takes the same decision.
-  if (tid < 3) sh.n_wl[tid] = 0;
-  if (tid < 4) sh.err_r[tid] = 0;
-  for (int i = tid; i < 3 * (kHL / 32); i += kBlock) tb.lmark[i] = 0;
-  __syncthreads();
+  // (the counters, flags and marks were reset before pass 2, which fills list 1 = the frame's tokens whose state has eps arcs)
   K3_T(7);
-  // round 1 work-list = every token of the frame = tok_slot[0 .. n_next) itself (tokens without eps arcs expand to nothing)
-  int n = sh.n_next;
+  int n = sh.n_wl[1];
   for (int round = 1; n > 0; round++) {
     if (round > 100000) { sh.err = K3_ERR_HIP; break; }        // an epsilon cycle with negative weight: cannot converge
     const int cur = round & 1, nxt_buf = cur ^ 1;
-    const int *wl_cur = round == 1 ? tok_slot : wl + (long long)cur * p.frame_tokens_cap;
+    const int *wl_cur = wl + (long long)cur * p.frame_tokens_cap;
     int *wl_nxt = wl + (long long)nxt_buf * p.frame_tokens_cap;
     int *n_nxt = &sh.n_wl[(round + 1) % 3];
     auto fail = [&](int code) { sh.err = code; sh.err_r[round & 3] = 1; };
@@ -384,8 +381,7 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
     auto fetch_slot = [&](int i) {
       int s_ = -1;
       if (i < n) {
-        if (round == 1) s_ = wl_cur[i];
-        else { s_ = i < kWlLds ? (int)lwl[cur][i] : 0xFFFF; if (s_ == 0xFFFF) s_ = wl_cur[i]; }
+        s_ = i < kWlLds ? (int)lwl[cur][i] : 0xFFFF; if (s_ == 0xFFFF) s_ = wl_cur[i];
       }
       return s_;
     };
@@ -419,21 +415,21 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         bool claimed = false, push = false, mk = false; int slot2 = -1, nxt = 0; float tot = 0.0f;
         cnt_eps += valid;
         if (valid) {
-          tot = oc + r.w; nxt = r.next;
+          tot = oc + r.w; nxt = (int)((unsigned)r.next & ~kEpsFlag);
           if (tot < cutoff) {
-            slot2 = tb.claim(r.next, &claimed);
+            slot2 = tb.claim(nxt, &claimed);
             if (slot2 < 0) { fail(K3_ERR_OVERFLOW); claimed = false; }
             else {
               mk = true;
               const unsigned e = enc(tot);
               const unsigned old = tb.cost_min(slot2, e);
-              if (e < old) push = tb.mark(slot2, round + 1);
+              if (e < old && r.next < 0) push = tb.mark(slot2, round + 1);      // only tokens whose state has eps arcs are queued
             }
           }
         }
         int idx = wave_append(claimed, &sh.n_next);
         if (claimed) {
-          if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; tok_cost[nb + idx] = kEncMax; }
+          if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; K3_AST(&tok_cost[nb + idx], kEncMax); }
           else { fail(K3_ERR_OVERFLOW); idx = 0; }
           tb.set_tok(slot2, idx);
         }
@@ -514,6 +510,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   if (tid < 16) sh.prof[tid] = 0;
   if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; }
   for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; s_ltok[i] = -1; }
+  for (int i = tid; i < 3 * (kHL / 32); i += kBlock) s_lmark[i] = 0;
   const Table tb{s_lkey, s_lcost, s_ltok, s_lmark, hash, mask};
   __syncthreads();
   long long t_last__ = (long long)__builtin_readcyclecounter();
@@ -528,7 +525,9 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
     if (tid == 0) {
       bool cl; const int slot = tb.claim(p.start, &cl);
-      tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; tok_cost[0] = kEncMax; sh.n_next = 1;
+      tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; K3_AST(&tok_cost[0], kEncMax); sh.n_next = 1;      // marker stores are agent-scope atomics: the expander's atomicExch (at L2) must not overtake them
+      sh.n_wl[0] = 0; sh.n_wl[2] = 0; sh.n_wl[1] = 1; for (int i = 0; i < 4; i++) sh.err_r[i] = 0;      // round-1 list = the start token
+      if (slot < kHL) s_lwl[1][0] = (unsigned short)slot; else { s_lwl[1][0] = 0xFFFF; wl[p.frame_tokens_cap] = slot; }
       tok_off[0] = 0; loff_n[0] = 0;
     }
     __syncthreads();
@@ -624,6 +623,9 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     const float next0 = n0 == kEncMax ? kInf : dec(n0);
     K3_T(2);
     if (tid == 0) { sh.n_cand = 0; sh.min_tot = kEncMax; sh.n_next = 0; }
+    if (tid < 3) sh.n_wl[tid] = 0;
+    if (tid < 4) sh.err_r[tid] = 0;
+    for (int i = tid; i < 3 * (kHL / 32); i += kBlock) s_lmark[i] = 0;
     __syncthreads();
     // ---- ProcessEmitting pass 1 (:779-797): every emitting arc of every token <= cur_cutoff; keep tot < pre-pass bound
     auto expand_tok = [&](int t, float c, int beg, int deg) {
@@ -676,19 +678,28 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     for (int j0 = 0; j0 < n_cand; j0 += kBlock) {
       const int j = j0 + tid; bool claimed = false, mk = false; int slot = -1;
       const float tot = q_tot, c_c = q_c; const int nxt = q_nxt, c_a = q_a, c_s = q_s;
+      const int state = (int)((unsigned)nxt & ~kEpsFlag);
       { const int jn = j + kBlock; if (jn < n_cand) { q_tot = c_tot[jn]; q_nxt = c_dst[jn]; q_a = c_arc[jn]; q_s = c_src[jn]; q_c = c_ac[jn]; } }
       if (row_pending) { fetch_row(); row_pending = false; }
       if (j < n_cand) {
         if (tot < accept) {
-          slot = tb.claim(nxt, &claimed);
+          slot = tb.claim(state, &claimed);
           if (slot < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; } else { tb.cost_min(slot, enc(tot)); mk = true; }
         }
       }
       int idx = wave_append(claimed, &sh.n_next);
       if (claimed) {
-        if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot; tok_state[nb + idx] = nxt; tok_cost[nb + idx] = kEncMax; }
+        if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot; tok_state[nb + idx] = state; K3_AST(&tok_cost[nb + idx], kEncMax); }
         else { sh.err = K3_ERR_OVERFLOW; idx = 0; }
         tb.set_tok(slot, idx);
+      }
+      {   // round 1 of the eps closure works on the new tokens whose state has eps arcs
+        const bool q1 = claimed && nxt < 0;
+        const int pos1 = wave_append(q1, &sh.n_wl[1]);
+        if (q1) {
+          if (pos1 < kWlLds) s_lwl[1][pos1] = slot < kHL ? (unsigned short)slot : (unsigned short)0xFFFF;
+          if (pos1 >= kWlLds || slot >= kHL) { if (pos1 < p.frame_tokens_cap) wl[p.frame_tokens_cap + pos1] = slot; else sh.err = K3_ERR_OVERFLOW; }
+        }
       }
       // ---- forward link of the accepted arc (:803-806)
       if (mk && !claimed) { idx = tb.wait_tok(slot, &sh.err); if (idx < 0) idx = 0; }
@@ -1141,6 +1152,9 @@ extern "C" int k3_fst_create(int32_t num_states, int32_t start, const int32_t *h
   ArcRec *arcs = (ArcRec *)(host.data() + ((char *)f->arcs - (char *)f->image));
   float *fin = (float *)(host.data() + ((char *)f->final_cost - (char *)f->image));
   int *ail = (int *)(host.data() + ((char *)f->arc_ilabel - (char *)f->image));
+  // bit 31 of ArcRec::next = "the destination has epsilon arcs": the eps closure then never queues tokens that cannot expand
+  std::vector<char> has_eps(num_states, 0);
+  for (int32_t s = 0; s < num_states; s++) for (int32_t a = h_off[s]; a < h_off[s + 1]; a++) if (h_il[a] == 0) { has_eps[s] = 1; break; }
   int64_t pos = 0;
   for (int32_t s = 0; s < num_states; s++) {       // emitting arcs of a state first, then its eps arcs, FST order kept inside each group
     offs[s].x = (int)pos;
@@ -1155,7 +1169,7 @@ extern "C" int k3_fst_create(int32_t num_states, int32_t start, const int32_t *h
           if (h_il[a] < 0 || h_il[a] >= num_tids) { k3::set_error("k3_fst_create: ilabel %d outside the transition-id map [1, %d)", h_il[a], num_tids); return K3_ERR_ARG; }
           pdf = h_tid2pdf[h_il[a]];
         }
-        arcs[pos] = ArcRec{h_next[a], h_w[a], pdf, h_ol[a]}; ail[pos] = h_il[a]; pos++;
+        arcs[pos] = ArcRec{(int)((unsigned)h_next[a] | (has_eps[h_next[a]] ? kEpsFlag : 0u)), h_w[a], pdf, h_ol[a]}; ail[pos] = h_il[a]; pos++;
       }
     }
     fin[s] = h_final[s];

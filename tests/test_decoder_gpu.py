@@ -156,3 +156,22 @@ def test_channels_with_independent_lifetimes():
     assert sorted(done) == list(range(len(lens)))
     for u in range(len(lens)):
         d = done[u].diff(ref[u]); assert d == "", (u, d)
+
+
+def test_repeated_decodes_are_identical_to_the_oracle():
+    """The same batch decoded again and again on fresh and on reused decoders: every run must give the oracle's token counts.  (A
+    plain store of the 'not yet expanded' marker could be overtaken by the expander's L2 atomic: runs differed once in ~10.)"""
+    from kaldi_amd import decoder
+    from oracle import lattice_oracle as lo
+    N = 50; f, t2p, _ = _setup(2000, 5000, N, seed=2, start_degree=40)
+    cfg = dict(beam=12.0, lattice_beam=6.0, max_active=300, min_active=20)
+    rng = np.random.default_rng(102)
+    base = [(rng.standard_normal((T, N)) * 2.5).astype(np.float32) for T in (50, 20)]
+    ref = [lo.decode(f, ll, t2p, _ocfg(lo, **cfg), mode=1)[1]["ntoks"] for ll in base]
+    lls = base * 8; ro = np.concatenate([[0], np.cumsum([l.shape[0] for l in lls])]); x = torch.from_numpy(np.concatenate(lls)).cuda()
+    for rep in range(6):
+        cf = decoder.CudaFst(f, t2p); dec = decoder.CudaDecoder(cf, decoder.decoder_config(**cfg), len(lls), N)
+        for k in range(3):
+            dec.DecodeBatch(x, ro); dec.LatticeInfo()
+            for u in range(len(lls)):
+                assert np.array_equal(dec.FrameStats(u, lls[u].shape[0])["ntoks"], ref[u % 2]), (rep, k, u)
