@@ -1,0 +1,203 @@
+// batched-wav-nnet3-cuda-online -- the streaming counterpart of batched-wav-nnet3-cuda2 (cudadecoderbin/batched-wav-nnet3-cuda-online.cc):
+//   batched-wav-nnet3-cuda-online [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>
+// The wav files are played as --num-channels concurrent audio streams: every round each busy channel submits its next chunk of
+// --frames-per-chunk frames' worth of samples; the chunks go through the streaming drivers of k3_online.h (sample stash ->
+// k3_feat_compute_batch, input-context stash -> k3_nnet_forward planned once, k3_decoder_advance_decoding); a channel whose stream
+// ended is finalised (k3_decoder_finalize_channels), its lattice written and the channel given to the next file.  Lattices are
+// bit-identical to batched-wav-nnet3-cuda2's.  Not implemented from the reference program: the dynamic batcher's wall-clock pacing
+// (--simulate-realtime-writing), latency statistics, partial hypotheses / endpointing, CTM output, lattice determinisation.
+#include <chrono>
+#include <cstring>
+#include <cmath>
+#include <deque>
+#include <iostream>
+#include "k3_feat_options.h"
+#include "k3_online.h"
+using namespace k3host;
+
+int main(int argc, char **argv) {
+  try {
+    const char *usage =
+        "Reads in wav file(s) and simulates online decoding with neural nets (nnet3 setup), the audio of several files being fed chunk by chunk.\n"
+        "Usage: batched-wav-nnet3-cuda-online [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
+    ParseOptions po(usage);
+    bool write_lattice = true, determinize = false, print_partial = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
+    int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, frames_per_chunk = 51, subsampling = 1, num_streaming = 2000;
+    int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, max_frames = 6000;
+    float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f;
+    std::string feature_type = "mfcc", mfcc_config, fbank_config, word_syms, use_gpu = "yes";
+    po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
+    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
+    po.Register("file-limit", &num_todo, "Limits the number of files that are processed by this driver.");
+    po.Register("iterations", &iterations, "Number of times to decode the corpus. Output will be written only once.");
+    po.Register("max-batch-size", &max_batch, "The maximum execution batch size (chunks evaluated together)");
+    po.Register("num-channels", &num_channels, "The number of parallel audio channels (-1 = max-batch-size)");
+    po.Register("num-parallel-streaming-channels", &num_streaming, "(accepted; the streams are fed round-robin over --num-channels)");
+    po.Register("determinize-lattice", &determinize, "Determinize the lattice before output (only false is supported)");
+    po.Register("print-partial-hypotheses", &print_partial, "(not supported)"); po.Register("print-endpoints", &print_endpoints, "(not supported)");
+    po.Register("simulate-realtime-writing", &simulate_rt, "(accepted, unused: chunks are submitted as fast as the GPU takes them)");
+    po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused)");
+    po.Register("beam", &beam, "Decoding beam. Larger->slower, more accurate."); po.Register("lattice-beam", &lattice_beam, "The width of the lattice beam");
+    po.Register("max-active", &max_active, "Decoder max active states. Larger->slower; more accurate"); po.Register("min-active", &min_active, "Decoder min active states");
+    po.Register("beam-delta", &beam_delta, "Increment used when the active-state limits move the beam");
+    po.Register("main-q-capacity", &main_q, "Max tokens alive on one frame of one utterance (-1 = 4 * max-active, capped)"); po.Register("aux-q-capacity", &aux_q, "Max arcs considered on one frame (-1 = 3 * main-q-capacity)");
+    po.Register("ntokens-pre-allocated", &ntok_pre, "Tokens kept per utterance for all frames"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
+    po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
+    po.Register("frames-per-chunk", &frames_per_chunk, "Number of feature frames evaluated per chunk and channel (a multiple of --frame-subsampling-factor)");
+    po.Register("max-utterance-frames", &max_frames, "Upper bound on the decoded (subsampled) frames of one utterance: sizes the per-channel frame tables");
+    po.Register("feature-type", &feature_type, "Base feature type [mfcc, fbank]"); po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc.conf)");
+    po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)"); po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
+    if (determinize || print_partial || print_endpoints) K3H_ERR << "--determinize-lattice / --print-partial-hypotheses / --print-endpoints are not supported";
+    if (num_channels < 0) num_channels = max_batch;
+    if (num_channels > max_batch) max_batch = num_channels;      // one slot per channel and round
+    const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);
+
+    const bool mfcc = feature_type == "mfcc";
+    if (!mfcc && feature_type != "fbank") K3H_ERR << "Invalid feature type: " << feature_type << " (supported: mfcc, fbank)";
+    FeatOptions fo(mfcc);
+    { ParseOptions fpo(""); fo.Register(&fpo); const std::string &cfg = mfcc ? mfcc_config : fbank_config; if (!cfg.empty()) fpo.ReadConfigFile(cfg); }
+    const k3_feat_opts &fopts = fo.Finish();
+    k3_feat_plan *plan = nullptr; K3H_CHECK_K3(k3_feat_plan_create(&fopts, &plan));
+    const int fdim = k3_feat_dim(plan);
+    TransitionInfo ti = ReadTransitionModel(nnet3_rx);
+    k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(nnet3_rx.c_str(), &nnet));
+    k3_nnet_info ninfo; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ninfo));
+    if (ninfo.input_dim != fdim) K3H_ERR << "Feature dimension " << fdim << " does not match the model's input dimension " << ninfo.input_dim;
+    if (ninfo.output_dim != ti.num_pdfs) K3H_ERR << "Model output dimension " << ninfo.output_dim << " != number of pdfs in the transition model " << ti.num_pdfs;
+    std::vector<float> log_priors;
+    if (ninfo.has_priors) { log_priors.resize(ninfo.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet, log_priors.data())); for (float &p : log_priors) p = logf(p); }
+    HostFst hfst = ReadFstKaldiGeneric(fst_rx);
+    k3_fst *fst = nullptr;
+    K3H_CHECK_K3(k3_fst_create(hfst.NumStates(), hfst.start, hfst.arc_offsets.data(), hfst.ilabel.data(), hfst.olabel.data(), hfst.weight.data(), hfst.nextstate.data(),
+                               hfst.final_cost.data(), ti.id2pdf.data(), (int32_t)ti.id2pdf.size(), &fst));
+    k3_decoder_config dc; k3_decoder_config_default(&dc);
+    dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(min_active, max_active - 1); dc.beam_delta = beam_delta;
+    dc.frame_tokens_cap = main_q > 0 ? main_q : std::min(65536, std::max(4 * max_active, 4096)); dc.frame_cands_cap = aux_q > 0 ? std::max(aux_q, dc.frame_tokens_cap) : 3 * dc.frame_tokens_cap;
+    dc.lane_tokens_cap = std::max<int64_t>(ntok_pre, dc.frame_tokens_cap); dc.lane_links_cap = 2 * dc.lane_tokens_cap;
+    const int nch = num_channels, N = ninfo.output_dim, C = frames_per_chunk / subsampling * subsampling > 0 ? frames_per_chunk / subsampling * subsampling : subsampling;
+    k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, nch, N, &dec));
+    K3H_CHECK_K3(k3_decoder_init_decoding(dec, nch, max_frames, nullptr));
+    OnlineFeatures features(plan, fopts, nch);
+    StaticNnet3 net(nnet, nch, nch, C, subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale);
+    const int shift = (int)(fopts.samp_freq * 0.001 * fopts.frame_shift_ms), chunk_samples = C * shift;
+
+    auto scp = ReadScp(wav_rspec);
+    if (num_todo >= 0 && (size_t)num_todo < scp.size()) scp.resize(num_todo);
+    std::unique_ptr<TableWriter> writer; if (write_lattice) writer.reset(new TableWriter(out_wspec));
+    int num_task = 0, num_err = 0; double total_audio = 0.0;
+    // per-channel state of the simulation
+    struct Chan { int utt = -1; Wave wav; size_t pos = 0; int pend = 0; bool started = false; };
+    std::vector<Chan> chan(nch);
+    std::vector<DevBuf<float>> pend(nch), pend_tmp(1); DevBuf<float> newbuf, ll; DevBuf<int32_t> llidx;
+    const size_t pend_cap = (size_t)(2 * C + 8);
+    for (auto &p : pend) p.need(pend_cap * fdim);
+    pend_tmp[0].need(pend_cap * fdim);
+    const auto t_start = std::chrono::steady_clock::now();
+    for (int iter = 0; iter < iterations; iter++) {
+      std::deque<int> queue; for (size_t i = 0; i < scp.size(); i++) queue.push_back((int)i);
+      int busy = 0;
+      while (!queue.empty() || busy > 0) {
+        // admit files to free channels
+        for (int ch = 0; ch < nch && !queue.empty(); ch++) {
+          if (chan[ch].utt >= 0) continue;
+          const int u = queue.front(); queue.pop_front();
+          Wave w;
+          try { w = ReadWave(scp[u].second); } catch (const FatalError &) { num_err++; ch--; continue; }
+          if (w.samp_freq != fopts.samp_freq) { K3H_WARN << "Sample frequency mismatch for " << scp[u].first; num_err++; ch--; continue; }
+          if (k3_feat_num_frames(plan, (int64_t)w.samples.size()) == 0) { K3H_WARN << "Utterance " << scp[u].first << " is too short to decode"; num_err++; ch--; continue; }
+          total_audio += w.samples.size() / (double)w.samp_freq; num_task++;
+          chan[ch] = Chan(); chan[ch].utt = u; chan[ch].wav = std::move(w); busy++;
+        }
+        if (busy == 0) break;
+        // one chunk of audio per busy channel
+        std::vector<int> chs; std::vector<std::vector<float>> chunks; std::vector<char> first, last;
+        for (int ch = 0; ch < nch; ch++) {
+          Chan &c = chan[ch]; if (c.utt < 0) continue;
+          const size_t n = std::min<size_t>(chunk_samples, c.wav.samples.size() - c.pos);
+          chs.push_back(ch); chunks.emplace_back(c.wav.samples.begin() + c.pos, c.wav.samples.begin() + c.pos + n);
+          first.push_back(c.pos == 0); c.pos += n; last.push_back(c.pos == c.wav.samples.size());
+        }
+        std::vector<int32_t> fresh; for (size_t i = 0; i < chs.size(); i++) if (first[i]) { fresh.push_back(chs[i]); net.Reset(chs[i]); }
+        if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec, fresh.data(), (int32_t)fresh.size(), nullptr));
+        float *d_feats = nullptr;
+        const std::vector<int> nf = features.ComputeFeaturesBatched(chs, chunks, first, &d_feats);
+        { int64_t off = 0;
+          for (size_t i = 0; i < chs.size(); i++) {
+            Chan &c = chan[chs[i]];
+            if ((size_t)(c.pend + nf[i]) > pend_cap) K3H_ERR << "internal: pending-frame buffer";
+            if (nf[i] > 0) K3O_HIP(hipMemcpy(pend[chs[i]].p + (size_t)c.pend * fdim, d_feats + off * fdim, (size_t)nf[i] * fdim * 4, hipMemcpyDeviceToDevice));
+            c.pend += nf[i]; off += nf[i];
+          } }
+        std::vector<char> is_last(nch, 0), closed(nch, 0); for (size_t i = 0; i < chs.size(); i++) is_last[chs[i]] = last[i];
+        bool need_advance = !fresh.empty();
+        while (true) {
+          std::vector<int> run; std::vector<int> n_new; std::vector<char> lasts;
+          for (int ch : chs) if (!closed[ch] && (chan[ch].pend >= C || is_last[ch])) run.push_back(ch);
+          if (run.empty() && !need_advance) break;
+          int64_t tot_new = 0;
+          for (int ch : run) { const int n = std::min(C, chan[ch].pend); n_new.push_back(n); tot_new += n; }
+          newbuf.need((size_t)std::max<int64_t>(tot_new, 1) * fdim);
+          { int64_t off = 0;
+            for (size_t i = 0; i < run.size(); i++) {
+              Chan &c = chan[run[i]]; const int n = n_new[i], rest = c.pend - n;
+              if (n > 0) K3O_HIP(hipMemcpy(newbuf.p + off * fdim, pend[run[i]].p, (size_t)n * fdim * 4, hipMemcpyDeviceToDevice));
+              if (rest > 0) { K3O_HIP(hipMemcpy(pend_tmp[0].p, pend[run[i]].p + (size_t)n * fdim, (size_t)rest * fdim * 4, hipMemcpyDeviceToDevice));
+                              K3O_HIP(hipMemcpy(pend[run[i]].p, pend_tmp[0].p, (size_t)rest * fdim * 4, hipMemcpyDeviceToDevice)); }
+              c.pend = rest; off += n;
+              const bool end = is_last[run[i]] && rest == 0; lasts.push_back(end); if (end) closed[run[i]] = 1;
+              c.started = true;
+            } }
+          std::vector<int64_t> ro(nch + 1, 0); std::vector<int32_t> idx;
+          if (!run.empty()) {
+            auto res = net.Pass(run, newbuf.p, n_new, lasts);
+            // end of stream: frames still waiting for right context may take more passes
+            std::vector<std::vector<std::pair<int, int>>> per(nch); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
+            for (int ch = 0; ch < nch; ch++) { int64_t n = 0; for (auto &r : per[ch]) { for (int k = 0; k < r.second; k++) idx.push_back(r.first + k); n += r.second; } ro[ch + 1] = ro[ch] + n; }
+          }
+          ll.need((size_t)std::max<size_t>(idx.size(), 1) * N);
+          if (!idx.empty()) { llidx.upload(idx); K3H_CHECK_K3(k3_mat_copy_rows(ll.p, N, (int32_t)idx.size(), N, net.Out(), N, llidx.p, nullptr)); }
+          K3H_CHECK_K3(k3_decoder_advance_decoding(dec, nch, ll.p, N, ro.data(), nullptr));
+          need_advance = false;
+          // flush passes for closed channels whose last outputs did not fit one pass
+          for (int ch : run) if (closed[ch] && net.Pending(ch)) { closed[ch] = 0; }      // stays in `run` candidates: is_last and pend == 0 -> another (empty-input) pass
+        }
+        // finalise the channels whose stream ended, write their lattices, free the channels
+        std::vector<int32_t> ended; for (size_t i = 0; i < chs.size(); i++) if (last[i]) ended.push_back(chs[i]);
+        if (!ended.empty()) {
+          K3H_CHECK_K3(k3_decoder_finalize_channels(dec, ended.data(), (int32_t)ended.size(), nullptr));
+          const int U = (int)ended.size();
+          std::vector<int64_t> info(10 * (size_t)U); K3H_CHECK_K3(k3_decoder_lattice_info(dec, info.data()));
+          int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
+          std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
+          if (NS > 0) K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));
+          int64_t s0 = 0, a0 = 0;
+          for (int u = 0; u < U; u++) {
+            const int64_t ns = info[10 * u], na = info[10 * u + 1]; const std::string &key = scp[chan[ended[u]].utt].first;
+            if (info[10 * u + 2] != 0 || ns == 0) { K3H_WARN << "Failed to decode utterance with id " << key; num_err++; }
+            else if (iter == 0 && writer) {
+              if (!info[10 * u + 3]) K3H_WARN << "Outputting partial output for utterance " << key << " since no final-state reached";
+              Lattice lat; lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns); lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
+              lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na); lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na); lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
+              lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
+              for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
+              Connect(&lat);
+              if (acoustic_scale != 0.0f) ScaleAcoustic(&lat, 1.0 / acoustic_scale);
+              writer->WriteLattice(key, lat);
+            }
+            s0 += ns; a0 += na;
+            chan[ended[u]] = Chan(); busy--;
+          }
+        }
+      }
+    }
+    K3O_HIP(hipDeviceSynchronize());
+    if (writer) writer->Flush();
+    const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
+    K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio << " RealTimeX: " << total_audio / total_time;
+    k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan);
+    return 0;
+  } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
+}

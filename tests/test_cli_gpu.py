@@ -175,3 +175,33 @@ def test_apply_cmvn_online_cuda_matches_the_reference_binary(tmp_path, cmvn_onli
     open(f"{td}/bad.txt", "w").write(" [\n 1 2 3 ]\n")
     b = subprocess.run([os.path.join(BIN, "apply-cmvn-online-cuda"), f"{td}/bad.txt", f"ark:{td}/ab.ark", f"ark:{td}/o.ark"], capture_output=True, text=True)
     assert b.returncode == 255 and "stats" in b.stderr
+
+
+def test_batched_wav_nnet3_cuda_online_equals_offline_program(tmp_path):
+    """the streaming program (chunks of audio over a few channels, channels reused as files end) writes the same lattices as
+    batched-wav-nnet3-cuda2: same keys, identical text records"""
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001, 31000, 4100]
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5)
+    net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000"]
+    a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=5", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/off.txt"], capture_output=True, text=True)
+    assert a.returncode == 0, a.stderr
+    off = _parse_text_lattices(f"{td}/off.txt")
+    for fpc, nch in ((150, 2), (30, 3)):
+        import time; t0 = time.time()
+        b = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + [f"--num-channels={nch}", f"--frames-per-chunk={fpc}", "--max-utterance-frames=400",
+                                                                                            f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/on.txt"], capture_output=True, text=True)
+        assert b.returncode == 0, b.stderr
+        print("online program", fpc, nch, "%.1f s" % (time.time() - t0), b.stderr.strip().splitlines()[-1])
+        assert "Decoded 5 utterances, 0 with errors." in b.stderr and "RealTimeX:" in b.stderr
+        on = _parse_text_lattices(f"{td}/on.txt")
+        assert sorted(on) == sorted(off) == [f"utt{i}" for i in range(5)]
+        for k in off:
+            # state numbers depend on the order the GPU happened to emit the arcs in: compare the arcs without them
+            canon = lambda lat: (sorted((a[2], a[3], float(a[4]), float(a[5])) for a in lat[0]), sorted(float(v) for v in lat[1].values()))
+            assert canon(on[k]) == canon(off[k]), (fpc, k)
+    assert subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online"), "x"], capture_output=True).returncode == 1
