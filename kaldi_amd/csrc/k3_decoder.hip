@@ -180,7 +180,7 @@ __device__ __forceinline__ int wave_append(bool pred, int *counter) {
   const int leader = __ffsll((long long)m) - 1;
   int base = 0;
   if (lane == leader) base = atomicAdd(counter, __popcll(m));
-  base = __shfl(base, leader);
+  base = __builtin_amdgcn_readlane(base, leader);          // leader is wave-uniform: a v_readlane, not an LDS-crossbar shuffle
   return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 __device__ __forceinline__ long long wave_append64(bool pred, long long *counter) {
@@ -190,7 +190,8 @@ __device__ __forceinline__ long long wave_append64(bool pred, long long *counter
   const int leader = __ffsll((long long)m) - 1;
   long long base = 0;
   if (lane == leader) base = (long long)atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
-  base = __shfl(base, leader);
+  base = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)base >> 32), leader) << 32) |
+                     (unsigned)__builtin_amdgcn_readlane((int)(unsigned)base, leader));
   return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
@@ -199,10 +200,16 @@ __device__ __forceinline__ long long wave_append64(bool pred, long long *counter
 template <typename F>
 __device__ __forceinline__ void wave_expand(const ArcRec *arcs, int beg, int deg, F &&f) {
   const int lane = threadIdx.x & 63;
+  // inclusive scan of the degrees with DPP row shifts / row broadcasts (a few cycles each; the ds_bpermute shuffle chain they replace
+  // is six dependent LDS-crossbar round trips)
   int incl = deg;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-  const int total = __shfl(incl, 63);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);      // row_shr:1
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);      // row_shr:2
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);      // row_shr:4
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);      // row_shr:8
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+  const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - deg;
   auto locate = [&](int j, int &arc, int &owner) {
     int lo = 0, hi = 63;
