@@ -3,9 +3,10 @@
 // The wav files are played as --num-channels concurrent audio streams: every round each busy channel submits its next chunk of
 // --frames-per-chunk frames' worth of samples; the chunks go through the streaming drivers of k3_online.h (sample stash ->
 // k3_feat_compute_batch, input-context stash -> k3_nnet_forward planned once, k3_decoder_advance_decoding); a channel whose stream
-// ended is finalised (k3_decoder_finalize_channels), its lattice written and the channel given to the next file.  Lattices are
-// bit-identical to batched-wav-nnet3-cuda2's.  Not implemented from the reference program: the dynamic batcher's wall-clock pacing
-// (--simulate-realtime-writing), latency statistics, partial hypotheses / endpointing, CTM output, lattice determinisation.
+// ended is finalised (k3_decoder_finalize_channels), its lattice determinized on the host (default; see batched-wav-nnet3-cuda2.cc) and
+// written, and the channel given to the next file.  Lattices are bit-identical to batched-wav-nnet3-cuda2's.  Not implemented from the
+// reference program: the dynamic batcher's wall-clock pacing (--simulate-realtime-writing), latency statistics, partial hypotheses /
+// endpointing, CTM output.
 #include <chrono>
 #include <cstring>
 #include <cmath>
@@ -21,10 +22,10 @@ int main(int argc, char **argv) {
         "Reads in wav file(s) and simulates online decoding with neural nets (nnet3 setup), the audio of several files being fed chunk by chunk.\n"
         "Usage: batched-wav-nnet3-cuda-online [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
     ParseOptions po(usage);
-    bool write_lattice = true, determinize = false, print_partial = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
+    bool write_lattice = true, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, frames_per_chunk = 51, subsampling = 1, num_streaming = 2000;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, max_frames = 6000;
-    float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f;
+    float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; int32_t det_max_mem = 50000000;
     std::string feature_type = "mfcc", mfcc_config, fbank_config, word_syms, use_gpu = "yes";
     po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
@@ -33,7 +34,10 @@ int main(int argc, char **argv) {
     po.Register("max-batch-size", &max_batch, "The maximum execution batch size (chunks evaluated together)");
     po.Register("num-channels", &num_channels, "The number of parallel audio channels (-1 = max-batch-size)");
     po.Register("num-parallel-streaming-channels", &num_streaming, "(accepted; the streams are fed round-robin over --num-channels)");
-    po.Register("determinize-lattice", &determinize, "Determinize the lattice before output (only false is supported)");
+    po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
+    po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
+    po.Register("phone-determinize", &phone_det, "(accepted: the word-level pass alone gives the same best path per word sequence)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
+    po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)");
     po.Register("print-partial-hypotheses", &print_partial, "(not supported)"); po.Register("print-endpoints", &print_endpoints, "(not supported)");
     po.Register("simulate-realtime-writing", &simulate_rt, "(accepted, unused: chunks are submitted as fast as the GPU takes them)");
     po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused)");
@@ -49,7 +53,9 @@ int main(int argc, char **argv) {
     po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)"); po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)");
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
-    if (determinize || print_partial || print_endpoints) K3H_ERR << "--determinize-lattice / --print-partial-hypotheses / --print-endpoints are not supported";
+    if (print_partial || print_endpoints) K3H_ERR << "--print-partial-hypotheses / --print-endpoints are not supported";
+    if (determinize && (!word_det || minimize)) K3H_ERR << "--word-determinize=false and --minimize=true are not supported";
+    DeterminizeLatticePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem;
     if (num_channels < 0) num_channels = max_batch;
     if (num_channels > max_batch) max_batch = num_channels;      // one slot per channel and round
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);
@@ -183,8 +189,11 @@ int main(int argc, char **argv) {
               lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
               for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
               Connect(&lat);
-              if (acoustic_scale != 0.0f) ScaleAcoustic(&lat, 1.0 / acoustic_scale);
-              writer->WriteLattice(key, lat);
+              if (determinize) {
+                CompactLattice clat;
+                if (!DeterminizeLatticePruned(lat, lattice_beam, &clat, det_opts)) K3H_WARN << "Determinization finished earlier than the beam for utterance " << key;
+                writer->WriteCompactLattice(key, clat);
+              } else writer->WriteLattice(key, lat);
             }
             s0 += ns; a0 += na;
             chan[ended[u]] = Chan(); busy--;

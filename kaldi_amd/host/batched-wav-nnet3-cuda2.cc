@@ -3,8 +3,11 @@
 // Same positional arguments, same option names (BatchedThreadedNnet3CudaPipeline2Config and its nested configs), same exit codes
 // (1 usage, -1 exception) and the same closing log line "Overall:  Aggregate Total Time: .. Total Audio: .. RealTimeX: ..".
 // The pipeline behind it is the whole-utterance batch path of libk3hip.so: waveforms -> k3_feat_compute_batch -> k3_nnet_forward ->
-// k3_decoder_decode_batch -> raw lattices (fst::Connect'ed, acoustic scores un-scaled, decoder-wrappers.cc:350-373).
-// Lattice determinisation is host work outside this library: --determinize-lattice=true is rejected, not silently ignored.
+// k3_decoder_decode_batch -> raw lattices -> (default, like BatchedThreadedNnet3CudaOnlinePipelineConfig::determinize_lattice) word-level
+// pruned determinization on the host (k3_lattice.cc; beam = --lattice-beam, batched-threaded-nnet3-cuda-online-pipeline.cc:759-765) ->
+// CompactLattice table.  Like the reference's CUDA pipeline the lattice keeps the acoustic scale it was decoded with (only the CPU
+// decoders' wrappers undo it).  --determinize-lattice=false writes the trimmed state-level lattice as a Lattice table; the reference
+// writes that same lattice re-packed by ConvertLattice as a CompactLattice -- Kaldi's lattice readers accept either form.
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -21,10 +24,10 @@ int main(int argc, char **argv) {
         "set via config files whose filenames are passed as options\nOutput is a lattice wspecifier\n"
         "Usage: batched-wav-nnet3-cuda2 [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
     ParseOptions po(usage);
-    bool write_lattice = true, segmentation = false, determinize = false, gpu_feat = true, use_online = false, reset_on_endpoint = false, tensor_cores = false, tf32 = false, add_pitch = false, debug_comp = false, cache_mem = true;
+    bool write_lattice = true, segmentation = false, determinize = true, minimize = false, phone_det = true, word_det = true, gpu_feat = true, use_online = false, reset_on_endpoint = false, tensor_cores = false, tf32 = false, add_pitch = false, debug_comp = false, cache_mem = true;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, worker_threads = -1, copy_threads = 2, frames_per_chunk = 50, subsampling = 1;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, elc = 0, erc = 0, elci = -1, ercf = -1;
-    float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f; double mem_prop = 0.5;
+    float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; double mem_prop = 0.5; int32_t det_max_mem = 50000000;
     std::string word_syms, postproc, feature_type = "mfcc", mfcc_config, fbank_config, plp_config, pitch_config, cmvn_config, global_cmvn, ivector_config, use_gpu = "yes";
     po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
@@ -36,7 +39,10 @@ int main(int argc, char **argv) {
     po.Register("num-channels", &num_channels, "(accepted; whole-utterance batching needs no separate channel pool)");
     po.Register("cuda-worker-threads", &worker_threads, "(accepted; lattice pruning runs on the GPU, no CPU worker pool)");
     po.Register("cuda-decoder-copy-threads", &copy_threads, "(accepted, unused)");
-    po.Register("determinize-lattice", &determinize, "Determinize the lattice before output (only false is supported: determinization is host work outside this library)");
+    po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
+    po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
+    po.Register("phone-determinize", &phone_det, "(accepted: the word-level pass alone gives the same best path per word sequence)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
+    po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)");
     po.Register("gpu-feature-extract", &gpu_feat, "Use GPU feature extraction (always true)"); po.Register("use-online-features", &use_online, "(only false is supported)");
     po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused: offline decoding)");
     po.Register("beam", &beam, "Decoding beam. Larger->slower, more accurate."); po.Register("lattice-beam", &lattice_beam, "The width of the lattice beam");
@@ -57,7 +63,8 @@ int main(int argc, char **argv) {
     po.Register("cuda-use-tf32-compute", &tf32, "(accepted, unused: gfx950 has no tf32/xf32)"); po.Register("cuda-cache-memory", &cache_mem, "(accepted, unused)"); po.Register("cuda-memory-proportion", &mem_prop, "(accepted, unused)");
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
-    if (determinize) K3H_ERR << "--determinize-lattice=true is not supported: this program writes the raw (state-level) lattice; run lattice-determinize-pruned on its output";
+    if (determinize && (!word_det || minimize)) K3H_ERR << "--word-determinize=false and --minimize=true are not supported";
+    DeterminizeLatticePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem;
     if (segmentation || use_online || add_pitch || !ivector_config.empty() || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
       K3H_ERR << "an option that needs a component outside the accelerated path was given (segmentation / online features / pitch / ivectors / PLP / CMVN / extra context)";
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);
@@ -138,8 +145,11 @@ int main(int argc, char **argv) {
             lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
             for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
             Connect(&lat);
-            if (acoustic_scale != 0.0f) ScaleAcoustic(&lat, 1.0 / acoustic_scale);      // "We'll write the lattice without acoustic scaling"
-            writer->WriteLattice(keys[u], lat);
+            if (determinize) {
+              CompactLattice clat;
+              if (!DeterminizeLatticePruned(lat, lattice_beam, &clat, det_opts)) K3H_WARN << "Determinization finished earlier than the beam for utterance " << keys[u];
+              writer->WriteCompactLattice(keys[u], clat);
+            } else writer->WriteLattice(keys[u], lat);
             s0 += ns; a0 += na;
           }
         }

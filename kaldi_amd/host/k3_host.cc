@@ -376,7 +376,11 @@ void Connect(Lattice *lat) {
   if (lat->start >= 0 && acc[lat->start] && co[lat->start]) newid[lat->start] = m++;     // start state first (state 0), like GetRawLattice
   for (int32_t s = 0; s < n; s++) if (newid[s] < 0 && acc[s] && co[s]) newid[s] = m++;
   Lattice o; o.st_frame.resize(m); o.st_state.resize(m); o.st_final.resize(m); o.start = m ? 0 : -1;
-  for (int32_t s = 0; s < n; s++) if (newid[s] >= 0) { o.st_frame[newid[s]] = lat->st_frame[s]; o.st_state[newid[s]] = lat->st_state[s]; o.st_final[newid[s]] = lat->st_final[s]; }
+  if (!lat->st_final_ac.empty()) o.st_final_ac.resize(m);
+  for (int32_t s = 0; s < n; s++) if (newid[s] >= 0) {
+    o.st_frame[newid[s]] = lat->st_frame[s]; o.st_state[newid[s]] = lat->st_state[s]; o.st_final[newid[s]] = lat->st_final[s];
+    if (!lat->st_final_ac.empty()) o.st_final_ac[newid[s]] = lat->st_final_ac[s];
+  }
   for (size_t a = 0; a < na; a++) {
     const int32_t s = newid[lat->arc_src[a]], d = newid[lat->arc_dst[a]];
     if (s < 0 || d < 0) continue;
@@ -385,7 +389,7 @@ void Connect(Lattice *lat) {
   }
   *lat = std::move(o);
 }
-void ScaleAcoustic(Lattice *lat, double scale) { for (float &a : lat->arc_ac) a = (float)(a * scale); }
+void ScaleAcoustic(Lattice *lat, double scale) { for (float &a : lat->arc_ac) a = (float)(a * scale); for (float &a : lat->st_final_ac) a = (float)(a * scale); }
 
 TableWriter::TableWriter(const std::string &wspecifier) {
   const size_t colon = wspecifier.find(':');
@@ -418,7 +422,7 @@ void TableWriter::WriteLattice(const std::string &key, const Lattice &lat) {
         if (!(lat.arc_graph[a] == 0.0f && lat.arc_ac[a] == 0.0f)) { o += "\t"; PrintWeight(&o, lat.arc_graph[a], lat.arc_ac[a]); }
         o += "\n";
       }
-      if (std::isfinite(lat.st_final[s])) { o += std::to_string(s); if (lat.st_final[s] != 0.0f) { o += "\t"; PrintWeight(&o, lat.st_final[s], 0.0f); } o += "\n"; }
+      if (std::isfinite(lat.st_final[s])) { const float fa = lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]; o += std::to_string(s); if (lat.st_final[s] != 0.0f || fa != 0.0f) { o += "\t"; PrintWeight(&o, lat.st_final[s], fa); } o += "\n"; }
     };
     if (lat.start >= 0) print_state(lat.start);
     for (int32_t s = 0; s < n; s++) if (s != lat.start) print_state(s);
@@ -429,7 +433,7 @@ void TableWriter::WriteLattice(const std::string &key, const Lattice &lat) {
     const float inf = std::numeric_limits<float>::infinity();
     for (int32_t s = 0; s < n; s++) {
       const bool fin = std::isfinite(lat.st_final[s]);
-      Put<float>(&o, fin ? lat.st_final[s] : inf); Put<float>(&o, fin ? 0.0f : inf); Put<int64_t>(&o, off[s + 1] - off[s]);
+      Put<float>(&o, fin ? lat.st_final[s] : inf); Put<float>(&o, fin ? (lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]) : inf); Put<int64_t>(&o, off[s + 1] - off[s]);
       for (int32_t k = off[s]; k < off[s + 1]; k++) { const int32_t a = order[k]; Put(&o, lat.arc_ilabel[a]); Put(&o, lat.arc_olabel[a]); Put(&o, lat.arc_graph[a]); Put(&o, lat.arc_ac[a]); Put(&o, lat.arc_dst[a]); }
     }
   }

@@ -85,6 +85,7 @@ void WriteFstVector(const HostFst &fst, const std::string &wxfilename);
 
 struct Lattice {          // one utterance of k3_decoder_get_raw_lattices, already trimmed by Connect()
   std::vector<int32_t> st_frame, st_state; std::vector<float> st_final;
+  std::vector<float> st_final_ac;          // acoustic part of the final weights; empty = all zero (what the decoder produces)
   std::vector<int32_t> arc_src, arc_dst, arc_ilabel, arc_olabel; std::vector<float> arc_graph, arc_ac;
   int32_t start = -1;
   int32_t NumStates() const { return (int32_t)st_final.size(); }
@@ -94,6 +95,35 @@ struct Lattice {          // one utterance of k3_decoder_get_raw_lattices, alrea
 void Connect(Lattice *lat);
 // scales acoustic costs by 1/acoustic_scale (ScaleLattice(AcousticLatticeScale(1/acwt)), decoder-wrappers.cc:366-370)
 void ScaleAcoustic(Lattice *lat, double scale);
+
+// ---- word-level lattice determinization (k3_lattice.cc) ----------------------------------------------------------------------
+// CompactLattice (lat/kaldi-lattice.h:46): acceptor over word labels whose weights carry (graph, acoustic) costs and the
+// transition-id string of the best alignment for that stretch of words.
+struct CompactLattice {
+  int32_t start = -1;
+  std::vector<char> is_final; std::vector<float> fin_graph, fin_ac; std::vector<std::vector<int32_t>> fin_str;
+  std::vector<int32_t> arc_src, arc_dst, arc_label; std::vector<float> arc_graph, arc_ac; std::vector<std::vector<int32_t>> arc_str;
+  int32_t NumStates() const { return (int32_t)is_final.size(); }
+  int32_t AddState() { is_final.push_back(0); fin_graph.push_back(0); fin_ac.push_back(0); fin_str.emplace_back(); return NumStates() - 1; }
+};
+struct DeterminizeLatticePrunedOptions {     // lat/determinize-lattice-pruned.h:113-148, same defaults
+  float delta = 1.0f / 1024.0f; int32_t max_mem = -1, max_loop = -1, max_states = -1, max_arcs = -1; float retry_cutoff = 0.5f;
+};
+// DeterminizeLatticePruned (lat/determinize-lattice-pruned.cc:1190-1236) behind the preparation its callers do
+// (Invert, TopSort, ArcSort on the word label: lattice-determinize-pruned.cc:104-112, determinize-lattice-pruned.cc:1479-1496)
+// and followed by fst::Connect.  Keeps, for every word sequence whose best path is within `beam` of the best path, that best
+// path only (costs and transition-id string).  Returns false when a limit of `opts` stopped it early (output pruned tighter).
+// Throws FatalError when the lattice has a cycle.
+bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *clat, const DeterminizeLatticePrunedOptions &opts = DeterminizeLatticePrunedOptions());
+void Connect(CompactLattice *clat);                        // fst::Connect; keeps the relative order of the surviving states
+void ScaleAcoustic(CompactLattice *clat, double scale);
+bool TopSortIfNeeded(CompactLattice *clat);                // TopSortCompactLatticeIfNeeded (lat/lattice-functions.cc); false on a cycle
+// kaldi::PruneLattice (lat/lattice-functions.cc:233-318) on a raw lattice (any state order; acyclic): drops arcs and final
+// weights that are on no path within `beam` of the best path, then trims.
+bool PruneLattice(double beam, Lattice *lat);
+// "ark:rxfilename" / "ark,t:rxfilename" table of state-level lattices (LatticeHolder::Read, lat/kaldi-lattice.cc:422-459: the
+// first byte after the key tells text from OpenFst binary).
+std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string &rspecifier);
 
 // Kaldi float matrices from an archive or script file: "ark:rxfilename", "scp:rxfilename" (entries "key file" or
 // "key file:offset"); binary FM / DM / CM / CM2 / CM3 (matrix/kaldi-matrix.cc:1402-1520, compressed-matrix.cc:560-660) and text
@@ -114,6 +144,7 @@ class TableWriter {        // "ark:wxfilename" | "ark,t:wxfilename" (other optio
   explicit TableWriter(const std::string &wspecifier);
   bool Binary() const { return binary_; }
   void WriteLattice(const std::string &key, const Lattice &lat);
+  void WriteCompactLattice(const std::string &key, const CompactLattice &clat);
   void WriteMatrix(const std::string &key, const float *data, int32_t rows, int32_t cols, int64_t stride);
   void WriteInt32Vector(const std::string &key, const std::vector<int32_t> &v);      // Int32VectorWriter (util/kaldi-holder-inl.h BasicVectorHolder)
   void Flush();

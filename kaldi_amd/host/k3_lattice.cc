@@ -1,0 +1,647 @@
+// k3_lattice.cc -- host-side lattice post-processing above the decoder's raw lattices: word-level pruned determinization to a
+// CompactLattice, PruneLattice, topological sorting, the CompactLattice writers and a reader for state-level lattice tables.
+//
+// This restates the algorithm of the reference's lat/determinize-lattice-pruned.cc (LatticeDeterminizerPruned, cited per function)
+// in this library's own data structures: a CSR input automaton, a string trie addressed by int32 ids instead of Entry pointers,
+// std containers for the subset hashes.  PARITY UNPINNED: OpenFst is not vendored in /root/reference, so neither the reference's
+// determinizer nor its tests can be built here; tests/test_lattice_det.py checks the defining properties instead (deterministic on
+// word labels, per word sequence the cost and alignment of the best raw path, every word sequence within the beam kept), which is
+// what the reference's own determinize-lattice-pruned-test.cc does with RandEquivalent.
+//
+// What is deliberately not restated: the phone-level first pass of DeterminizeLatticePhonePruned (:1388-1407).  It is an efficiency
+// device (it bounds the subset sizes of the word pass); it yields the same best path per word sequence, but can pick a different one of
+// several equal-cost alignments and, when --max-mem stops it early, a different effective beam.  --minimize is not implemented.
+#include "k3_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <queue>
+#include <unordered_map>
+
+namespace k3host {
+namespace {
+const float kInfF = std::numeric_limits<float>::infinity();
+const double kInfD = std::numeric_limits<double>::infinity();
+
+// ---- LatticeWeightTpl<float> (fstext/lattice-weight.h): value1 = graph cost, value2 = acoustic cost -----------------------------
+struct LatW { float g, a; };
+inline LatW One() { return {0.0f, 0.0f}; }
+inline LatW Zero() { return {kInfF, kInfF}; }
+inline bool operator==(LatW x, LatW y) { return x.g == y.g && x.a == y.a; }
+inline bool operator!=(LatW x, LatW y) { return !(x == y); }
+inline LatW Times(LatW x, LatW y) { return {x.g + y.g, x.a + y.a}; }
+inline int Compare(LatW x, LatW y) {           // :295-308: +1 when x is the better (cheaper) one; ties broken on the graph part
+  const float fx = x.g + x.a, fy = y.g + y.a;
+  if (fx < fy) return 1;
+  if (fx > fy) return -1;
+  if (x.g < y.g) return 1;
+  if (x.g > y.g) return -1;
+  return 0;
+}
+inline LatW Plus(LatW x, LatW y) { return Compare(x, y) >= 0 ? x : y; }      // :312-315
+inline LatW Divide(LatW x, LatW y) {           // :371-386
+  const float g = x.g - y.g, a = x.a - y.a;
+  if (g != g || a != a || g == -kInfF || a == -kInfF) { K3H_WARN << "LatticeWeight Divide: NaN or invalid number produced, returning zero"; return Zero(); }
+  if (g == kInfF || a == kInfF) return Zero();
+  return {g, a};
+}
+inline bool ApproxEqual(LatW x, LatW y, float delta) {    // :390-395
+  if (x.g == y.g && x.a == y.a) return true;
+  return std::fabs((x.g + x.a) - (y.g + y.a)) <= delta;
+}
+inline double Cost(LatW w) { return (double)w.g + (double)w.a; }   // ConvertToCost :846
+
+// ---- the determinizer's input: topologically sorted, arcs sorted on the word label, word = input side ----------------------------
+struct InputFst {
+  int32_t start = -1;
+  std::vector<int32_t> off, word, tid, next; std::vector<LatW> w, fin;
+  int32_t NumStates() const { return (int32_t)fin.size(); }
+};
+
+// depth-first topological order like fst::TopSort (reverse finishing order, arcs visited in stored order); false on a cycle.
+// Only states reachable from `start` are ordered (the callers trim first); order[i] = old state id of new state i.
+bool TopOrder(int32_t n, int32_t start, const std::vector<int32_t> &off, const std::vector<int32_t> &next, std::vector<int32_t> *order) {
+  order->clear();
+  if (start < 0) return true;
+  std::vector<char> color(n, 0); std::vector<int32_t> stack, pos(n, 0), finish;
+  stack.push_back(start); color[start] = 1; pos[start] = off[start];
+  while (!stack.empty()) {
+    const int32_t s = stack.back();
+    if (pos[s] < off[s + 1]) {
+      const int32_t d = next[pos[s]++];
+      if (color[d] == 1) return false;
+      if (color[d] == 0) { color[d] = 1; pos[d] = off[d]; stack.push_back(d); }
+    } else { color[s] = 2; finish.push_back(s); stack.pop_back(); }
+  }
+  order->assign(finish.rbegin(), finish.rend());
+  return true;
+}
+
+// Invert + TopSort + ArcSort(ILabelCompare) of the callers (lattice-determinize-pruned.cc:104-112)
+InputFst PrepareInput(const Lattice &lat_in) {
+  Lattice lat = lat_in; Connect(&lat);
+  InputFst f; const int32_t n = lat.NumStates(); const size_t na = lat.arc_src.size();
+  if (n == 0 || lat.start < 0) return f;
+  std::vector<int32_t> off(n + 1, 0), idx(na), nx(na);
+  for (size_t a = 0; a < na; a++) off[lat.arc_src[a] + 1]++;
+  for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
+  { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < na; a++) { const int32_t k = p[lat.arc_src[a]]++; idx[k] = (int32_t)a; nx[k] = lat.arc_dst[a]; } }
+  std::vector<int32_t> order;
+  if (!TopOrder(n, lat.start, off, nx, &order)) K3H_ERR << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles).";
+  std::vector<int32_t> newid(n, -1); for (size_t i = 0; i < order.size(); i++) newid[order[i]] = (int32_t)i;
+  const int32_t m = (int32_t)order.size();
+  f.start = newid[lat.start]; f.fin.resize(m); f.off.assign(m + 1, 0);
+  for (int32_t i = 0; i < m; i++) {
+    const int32_t s = order[i];
+    f.fin[i] = std::isfinite(lat.st_final[s]) ? LatW{lat.st_final[s], lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]} : Zero();
+    std::vector<int32_t> arcs(idx.begin() + off[s], idx.begin() + off[s + 1]);
+    std::stable_sort(arcs.begin(), arcs.end(), [&](int32_t x, int32_t y) { return lat.arc_olabel[x] < lat.arc_olabel[y]; });
+    for (int32_t a : arcs) { f.word.push_back(lat.arc_olabel[a]); f.tid.push_back(lat.arc_ilabel[a]); f.next.push_back(newid[lat.arc_dst[a]]); f.w.push_back({lat.arc_graph[a], lat.arc_ac[a]}); }
+    f.off[i + 1] = (int32_t)f.word.size();
+  }
+  return f;
+}
+
+// kaldi::PruneLattice (lat/lattice-functions.cc:233-318) on the prepared automaton; state order (hence sortedness) is kept
+bool PruneInput(double beam, InputFst *f) {
+  const int32_t n = f->NumStates();
+  if (n == 0) return false;
+  std::vector<double> fwd(n, kInfD); fwd[f->start] = 0.0; double best_final = kInfD;
+  for (int32_t s = 0; s < n; s++) {
+    for (int32_t k = f->off[s]; k < f->off[s + 1]; k++) { const double c = fwd[s] + Cost(f->w[k]); if (fwd[f->next[k]] > c) fwd[f->next[k]] = c; }
+    const double fc = fwd[s] + Cost(f->fin[s]); if (fc < best_final) best_final = fc;
+  }
+  const double cutoff = best_final + beam;
+  std::vector<double> bwd(n, kInfD); std::vector<char> keep_arc(f->word.size(), 0);
+  for (int32_t s = n - 1; s >= 0; s--) {
+    double b = Cost(f->fin[s]);
+    if (b + fwd[s] > cutoff && b != kInfD) f->fin[s] = Zero();
+    for (int32_t k = f->off[s]; k < f->off[s + 1]; k++) {
+      const double ab = Cost(f->w[k]) + bwd[f->next[k]];
+      if (ab < b) b = ab;
+      keep_arc[k] = !(fwd[s] + ab > cutoff);
+    }
+    bwd[s] = b;
+  }
+  // trim: accessible through kept arcs and co-accessible to a final weight that is still there
+  std::vector<char> acc(n, 0), co(n, 0); acc[f->start] = 1;
+  for (int32_t s = 0; s < n; s++) if (acc[s]) for (int32_t k = f->off[s]; k < f->off[s + 1]; k++) if (keep_arc[k]) acc[f->next[k]] = 1;
+  for (int32_t s = n - 1; s >= 0; s--) { if (f->fin[s] != Zero()) co[s] = 1; for (int32_t k = f->off[s]; k < f->off[s + 1] && !co[s]; k++) if (keep_arc[k] && co[f->next[k]]) co[s] = 1; }
+  std::vector<int32_t> newid(n, -1); int32_t m = 0; for (int32_t s = 0; s < n; s++) if (acc[s] && co[s]) newid[s] = m++;
+  InputFst o; o.start = newid[f->start]; o.fin.resize(m); o.off.assign(m + 1, 0);
+  for (int32_t s = 0; s < n; s++) {
+    if (newid[s] < 0) continue;
+    o.fin[newid[s]] = f->fin[s];
+    for (int32_t k = f->off[s]; k < f->off[s + 1]; k++) if (keep_arc[k] && newid[f->next[k]] >= 0) { o.word.push_back(f->word[k]); o.tid.push_back(f->tid[k]); o.next.push_back(newid[f->next[k]]); o.w.push_back(f->w[k]); }
+    o.off[newid[s] + 1] = (int32_t)o.word.size();
+  }
+  if (o.start < 0) o = InputFst();
+  *f = std::move(o);
+  return true;
+}
+
+// ---- LatticeStringRepository (fstext/determinize-lattice.h): strings of transition-ids as nodes of a trie; id 0 is the empty string.
+// Equal sequences always get the same id, which is what lets subsets be hashed and compared on (state, string id).
+class StringTrie {
+ public:
+  StringTrie() : parent_(1, -1), label_(1, 0), depth_(1, 0) {}
+  int32_t Successor(int32_t s, int32_t label) {
+    const uint64_t key = ((uint64_t)(uint32_t)s << 32) | (uint32_t)label;
+    auto it = succ_.find(key);
+    if (it != succ_.end()) return it->second;
+    const int32_t id = (int32_t)parent_.size();
+    parent_.push_back(s); label_.push_back(label); depth_.push_back(depth_[s] + 1); succ_.emplace(key, id);
+    return id;
+  }
+  void ToVector(int32_t s, std::vector<int32_t> *v) const { v->resize(depth_[s]); for (int32_t i = depth_[s] - 1; i >= 0; i--, s = parent_[s]) (*v)[i] = label_[s]; }
+  int32_t FromVector(const std::vector<int32_t> &v, size_t from = 0) { int32_t s = 0; for (size_t i = from; i < v.size(); i++) s = Successor(s, v[i]); return s; }
+  int32_t Concatenate(int32_t a, int32_t b) { if (b == 0) return a; if (a == 0) return b; std::vector<int32_t> v; ToVector(b, &v); for (int32_t l : v) a = Successor(a, l); return a; }
+  void ReduceToCommonPrefix(int32_t s, std::vector<int32_t> *prefix) const {
+    while (depth_[s] > (int32_t)prefix->size()) s = parent_[s];
+    prefix->resize(depth_[s]);
+    for (int32_t i = depth_[s] - 1; i >= 0; i--, s = parent_[s]) if (label_[s] != (*prefix)[i]) prefix->resize(i);
+  }
+  int32_t RemovePrefix(int32_t s, size_t n) { if (n == 0) return s; std::vector<int32_t> v; ToVector(s, &v); return FromVector(v, n); }
+  int32_t Depth(int32_t s) const { return depth_[s]; }
+  int32_t Parent(int32_t s) const { return parent_[s]; }
+  size_t NumEntries() const { return parent_.size() - 1; }
+ private:
+  std::vector<int32_t> parent_, label_, depth_;
+  std::unordered_map<uint64_t, int32_t> succ_;
+};
+
+// ---- LatticeDeterminizerPruned (lat/determinize-lattice-pruned.cc:47-1190) -------------------------------------------------------
+class Determinizer {
+ public:
+  Determinizer(const InputFst &f, double beam, const DeterminizeLatticePrunedOptions &opts) : f_(f), beam_(beam), opts_(opts), minimal_hash_(16, SubsetHash(), SubsetEqual{opts.delta}), initial_hash_(16, SubsetHash(), SubsetEqual{opts.delta}) {}
+
+  bool Determinize(double *effective_beam) {                 // :329-375
+    Initialize();
+    while (!queue_.empty()) {
+      const size_t num_states = out_.size();
+      if ((opts_.max_states > 0 && (int64_t)num_states > opts_.max_states) || (opts_.max_arcs > 0 && num_arcs_ > opts_.max_arcs) || (num_states % 10 == 0 && !CheckMemoryUsage())) break;
+      Task *task = queue_.top(); queue_.pop();
+      ProcessTransition(task->state, task->label, &task->subset);
+      delete task;
+    }
+    *effective_beam = queue_.empty() ? beam_ : queue_.top()->priority_cost - backward_[f_.start];
+    const bool done = queue_.empty();
+    while (!queue_.empty()) { delete queue_.top(); queue_.pop(); }
+    return done;
+  }
+
+  void Output(CompactLattice *o) const {                     // :61-107: one output state per determinized state, final weights from the kNoState arcs
+    *o = CompactLattice();
+    if (out_.empty()) return;
+    for (size_t s = 0; s < out_.size(); s++) o->AddState();
+    o->start = 0;
+    std::vector<int32_t> str;
+    for (size_t s = 0; s < out_.size(); s++)
+      for (const TempArc &t : out_[s].arcs) {
+        trie_.ToVector(t.string, &str);
+        if (t.next < 0) { o->is_final[s] = 1; o->fin_graph[s] = t.w.g; o->fin_ac[s] = t.w.a; o->fin_str[s] = str; }
+        else { o->arc_src.push_back((int32_t)s); o->arc_dst.push_back(t.next); o->arc_label.push_back(t.label); o->arc_graph.push_back(t.w.g); o->arc_ac.push_back(t.w.a); o->arc_str.push_back(str); }
+      }
+  }
+
+ private:
+  struct Element {                                           // :390-409; `state` is an input state except inside initial_hash_ values
+    int32_t state, string; LatW w;
+    bool operator!=(const Element &o) const { return state != o.state || string != o.string || w != o.w; }
+  };
+  struct TempArc { int32_t label, string, next; LatW w; };    // :413-418; next < 0: really a final weight
+  struct OutputState { std::vector<Element> minimal_subset; std::vector<TempArc> arcs; double forward_cost; };
+  struct Task { int32_t state, label; std::vector<Element> subset; double priority_cost; };
+  struct TaskCompare { bool operator()(const Task *a, const Task *b) const { return a->priority_cost > b->priority_cost; } };     // :1156-1162: cheapest first
+  struct SubsetHash {                                        // :432-443: state and string only, not the weight
+    size_t operator()(const std::vector<Element> *v) const { size_t h = 0, factor = 1; for (const Element &e : *v) { h *= factor; h += (size_t)e.state + 103333u * (size_t)e.string; factor *= 23531; } return h; }
+  };
+  struct SubsetEqual {                                       // :447-463: exact on state and string, within delta on the weight
+    float delta;
+    bool operator()(const std::vector<Element> *a, const std::vector<Element> *b) const {
+      if (a->size() != b->size()) return false;
+      for (size_t i = 0; i < a->size(); i++) if ((*a)[i].state != (*b)[i].state || (*a)[i].string != (*b)[i].string || !ApproxEqual((*a)[i].w, (*b)[i].w, delta)) return false;
+      return true;
+    }
+  };
+
+  // order on (weight, string) pairs of CompactLatticeWeight (:601-625): the better weight wins; on a tie the SHORTER string is the
+  // greater one (opposite order on lengths), then the lexicographically larger
+  int Compare(LatW aw, int32_t as, LatW bw, int32_t bs) const {
+    const int wc = k3host::Compare(aw, bw);
+    if (wc != 0) return wc;
+    if (as == bs) return 0;
+    const int32_t al = trie_.Depth(as), bl = trie_.Depth(bs);
+    if (al > bl) return -1;
+    if (al < bl) return 1;
+    std::vector<int32_t> av, bv; trie_.ToVector(as, &av); trie_.ToVector(bs, &bv);
+    for (int32_t i = 0; i < al; i++) { if (av[i] < bv[i]) return -1; if (av[i] > bv[i]) return 1; }
+    return 0;
+  }
+
+  bool IsIsymbolOrFinal(int32_t s) const {                   // :1018-1042 (no cache: the arcs are sorted, one look at the last arc decides)
+    if (f_.fin[s] != Zero()) return true;
+    for (int32_t k = f_.off[s + 1] - 1; k >= f_.off[s] && f_.word[k] != 0; k--) if (f_.w[k] != Zero()) return true;
+    return false;
+  }
+  void ConvertToMinimal(std::vector<Element> *subset) const {  // :501-513
+    size_t o = 0; for (const Element &e : *subset) if (IsIsymbolOrFinal(e.state)) (*subset)[o++] = e;
+    subset->resize(o);
+  }
+
+  void EpsilonClosure(std::vector<Element> *subset) {        // :632-724: best (weight, string) per state reachable over word-epsilon arcs
+    struct ByState { bool operator()(const Element &a, const Element &b) const { return a.state > b.state; } };
+    std::priority_queue<Element, std::vector<Element>, ByState> queue;
+    std::unordered_map<int32_t, Element> cur;
+    for (const Element &e : *subset) { queue.push(e); cur[e.state] = e; }
+    bool replaced = false; int32_t counter = 0;
+    while (!queue.empty()) {
+      const Element elem = queue.top(); queue.pop();
+      if (replaced && cur[elem.state] != elem) continue;     // a stale copy of an element that was improved later
+      if (opts_.max_loop > 0 && counter++ > opts_.max_loop) K3H_ERR << "Lattice determinization aborted since looped more than " << opts_.max_loop << " times during epsilon closure.";
+      for (int32_t k = f_.off[elem.state]; k < f_.off[elem.state + 1] && f_.word[k] == 0; k++) {
+        if (f_.w[k] == Zero()) continue;
+        Element nx; nx.state = f_.next[k]; nx.w = Times(elem.w, f_.w[k]); nx.string = -1;
+        auto string_of = [&]() { return f_.tid[k] == 0 ? elem.string : trie_.Successor(elem.string, f_.tid[k]); };
+        auto it = cur.find(nx.state);
+        if (it == cur.end()) { nx.string = string_of(); cur[nx.state] = nx; queue.push(nx); continue; }
+        int comp = k3host::Compare(nx.w, it->second.w);
+        if (comp == 0) { nx.string = string_of(); comp = Compare(nx.w, nx.string, it->second.w, it->second.string); }
+        if (comp == 1) { if (nx.string < 0) nx.string = string_of(); it->second.string = nx.string; it->second.w = nx.w; queue.push(nx); replaced = true; }
+      }
+    }
+    subset->clear(); subset->reserve(cur.size());
+    for (const auto &kv : cur) subset->push_back(kv.second);
+    std::sort(subset->begin(), subset->end(), [](const Element &a, const Element &b) { return a.state < b.state; });
+  }
+
+  void ProcessFinal(int32_t id) {                            // :731-769
+    OutputState &st = out_[id];
+    int32_t fstr = 0; LatW fw = Zero(); bool is_final = false;
+    for (const Element &e : st.minimal_subset) {
+      const LatW w = Times(e.w, f_.fin[e.state]);
+      if (w != Zero() && (!is_final || Compare(w, e.string, fw, fstr) == 1)) { is_final = true; fw = w; fstr = e.string; }
+    }
+    if (is_final && Cost(fw) + st.forward_cost <= cutoff_) { st.arcs.push_back({0, fstr, -1, fw}); num_arcs_++; }
+  }
+
+  void NormalizeSubset(std::vector<Element> *elems, LatW *tot, int32_t *common) {    // :774-803
+    if (elems->empty()) { K3H_WARN << "empty subset"; *common = 0; *tot = Zero(); return; }
+    std::vector<int32_t> prefix; trie_.ToVector((*elems)[0].string, &prefix);
+    LatW w = (*elems)[0].w;
+    for (size_t i = 1; i < elems->size(); i++) { w = Plus(w, (*elems)[i].w); trie_.ReduceToCommonPrefix((*elems)[i].string, &prefix); }
+    for (Element &e : *elems) { e.w = Divide(e.w, w); e.string = trie_.RemovePrefix(e.string, prefix.size()); }
+    *common = trie_.FromVector(prefix); *tot = w;
+  }
+
+  void MakeSubsetUnique(std::vector<Element> *subset) const {  // :808-835: sorted on state; keep the best element per state
+    size_t o = 0;
+    for (size_t i = 0; i < subset->size();) {
+      Element best = (*subset)[i++];
+      for (; i < subset->size() && (*subset)[i].state == best.state; i++)
+        if (Compare((*subset)[i].w, (*subset)[i].string, best.w, best.string) == 1) { best.string = (*subset)[i].string; best.w = (*subset)[i].w; }
+      (*subset)[o++] = best;
+    }
+    subset->resize(o);
+  }
+
+  int32_t MinimalToStateId(const std::vector<Element> &subset, double forward_cost) {   // :520-547
+    auto it = minimal_hash_.find(&subset);
+    if (it != minimal_hash_.end()) {
+      if (forward_cost < out_[it->second].forward_cost - 0.1) K3H_WARN << "New cost is less (check the difference is small) " << forward_cost << ", " << out_[it->second].forward_cost;
+      return it->second;
+    }
+    const int32_t id = (int32_t)out_.size();
+    out_.push_back(OutputState{subset, {}, forward_cost});
+    minimal_hash_[&out_.back().minimal_subset] = id;
+    num_elems_ += (int64_t)subset.size();
+    ProcessFinal(id);
+    ProcessTransitions(id);
+    return id;
+  }
+
+  // a normalized subset before epsilon closure -> its determinized state plus what normalisation after the closure took out (:552-593)
+  int32_t InitialToStateId(const std::vector<Element> &subset_in, double forward_cost, LatW *remaining, int32_t *common) {
+    auto it = initial_hash_.find(&subset_in);
+    if (it != initial_hash_.end()) { *remaining = it->second.w; *common = it->second.string; return it->second.state; }
+    std::vector<Element> subset(subset_in);
+    EpsilonClosure(&subset);
+    ConvertToMinimal(&subset);
+    Element elem;
+    NormalizeSubset(&subset, &elem.w, &elem.string);
+    forward_cost += Cost(elem.w);
+    elem.state = MinimalToStateId(subset, forward_cost);
+    *remaining = elem.w; *common = elem.string;
+    if (elem.w == Zero()) K3H_WARN << "Zero weight!";
+    initial_keys_.push_back(subset_in);
+    initial_hash_[&initial_keys_.back()] = elem;
+    num_elems_ += (int64_t)subset_in.size();
+    return elem.state;
+  }
+
+  void ProcessTransition(int32_t ostate, int32_t label, std::vector<Element> *subset) {   // :845-874
+    double forward_cost = out_[ostate].forward_cost;
+    int32_t common; LatW tot;
+    NormalizeSubset(subset, &tot, &common);
+    forward_cost += Cost(tot);
+    LatW next_tot; int32_t next_common;
+    const int32_t next = InitialToStateId(*subset, forward_cost, &next_tot, &next_common);
+    out_[ostate].arcs.push_back({label, trie_.Concatenate(common, next_common), next, Times(tot, next_tot)});
+    num_arcs_++;
+  }
+
+  void ProcessTransitions(int32_t id) {                      // :903-1014: one queued task per word label leaving the subset
+    std::vector<std::pair<int32_t, Element>> all;
+    for (const Element &e : out_[id].minimal_subset)
+      for (int32_t k = f_.off[e.state]; k < f_.off[e.state + 1]; k++) {
+        if (f_.word[k] == 0 || f_.w[k] == Zero()) continue;
+        all.push_back({f_.word[k], Element{f_.next[k], f_.tid[k] == 0 ? e.string : trie_.Successor(e.string, f_.tid[k]), Times(e.w, f_.w[k])}});
+      }
+    std::sort(all.begin(), all.end(), [](const std::pair<int32_t, Element> &a, const std::pair<int32_t, Element> &b) { return a.first != b.first ? a.first < b.first : a.second.state < b.second.state; });
+    const double forward_cost = out_[id].forward_cost;
+    for (size_t i = 0; i < all.size();) {
+      Task *task = new Task; task->state = id; task->label = all[i].first; task->priority_cost = kInfD;
+      for (; i < all.size() && all[i].first == task->label; i++) {
+        task->subset.push_back(all[i].second);
+        task->priority_cost = std::min(task->priority_cost, Cost(all[i].second.w) + backward_[all[i].second.state]);
+      }
+      task->priority_cost += forward_cost;
+      if (task->priority_cost > cutoff_) { delete task; continue; }
+      MakeSubsetUnique(&task->subset);
+      queue_.push(task);
+      const double best = backward_[f_.start];
+      if (task->priority_cost < best - (0.01 + 1.0e-04 * std::fabs(best))) K3H_WARN << "Cost below best cost was encountered:" << task->priority_cost << " < " << best;
+    }
+  }
+
+  void Initialize() {                                        // ComputeBackwardWeight :1044-1068 + InitializeDeterminization :1070-1118
+    const int32_t n = f_.NumStates();
+    backward_.assign(n, kInfD);
+    for (int32_t s = n - 1; s >= 0; s--) {
+      double c = Cost(f_.fin[s]);
+      for (int32_t k = f_.off[s]; k < f_.off[s + 1]; k++) c = std::min(c, Cost(f_.w[k]) + backward_[f_.next[k]]);
+      backward_[s] = c;
+    }
+    if (f_.start < 0) return;
+    if (backward_[f_.start] == kInfD) K3H_WARN << "Total weight of input lattice is zero.";
+    cutoff_ = backward_[f_.start] + beam_;
+    // the start state's subset is not normalized: there is nowhere to put a common weight / string in front of it
+    std::vector<Element> subset(1, Element{f_.start, 0, One()});
+    EpsilonClosure(&subset);
+    ConvertToMinimal(&subset);
+    out_.push_back(OutputState{subset, {}, 0.0});
+    num_elems_ += (int64_t)subset.size();
+    minimal_hash_[&out_.back().minimal_subset] = 0;
+    ProcessFinal(0);
+    ProcessTransitions(0);
+  }
+
+  // :286-327.  The reference measures (2 x 16 B per trie entry) + 24 B per arc + 24 B per subset element and, above --max-mem,
+  // rebuilds the trie from the strings still referenced.  Here nothing needs freeing (ids stay valid), so the "rebuild" only counts
+  // what a rebuild would keep; entries created later are added to that count.
+  bool CheckMemoryUsage() {
+    if (opts_.max_mem <= 0) return true;
+    const int64_t arcs = num_arcs_ * 24, elems = num_elems_ * 24;
+    int64_t repo = ((int64_t)trie_.NumEntries() - trie_dropped_) * 32;
+    if (repo + arcs + elems <= opts_.max_mem) return true;
+    std::vector<char> live(trie_.NumEntries() + 1, 0);
+    auto mark = [&](int32_t s) { for (; s > 0 && !live[s]; s = trie_.Parent(s)) live[s] = 1; };
+    for (const OutputState &st : out_) { for (const Element &e : st.minimal_subset) mark(e.string); for (const TempArc &t : st.arcs) mark(t.string); }
+    for (const auto &kv : initial_hash_) { for (const Element &e : *kv.first) mark(e.string); mark(kv.second.string); }
+    { std::vector<Task *> tasks; while (!queue_.empty()) { tasks.push_back(queue_.top()); queue_.pop(); } for (Task *t : tasks) { for (const Element &e : t->subset) mark(e.string); queue_.push(t); } }
+    int64_t kept = 0; for (char c : live) kept += c;
+    trie_dropped_ = (int64_t)trie_.NumEntries() - kept;
+    const int64_t new_repo = kept * 32;
+    if (new_repo + arcs + elems > (int64_t)(opts_.max_mem * 0.8)) {
+      double eff = beam_; if (!queue_.empty()) eff = queue_.top()->priority_cost - backward_[f_.start];
+      K3H_WARN << "Did not reach requested beam in determinize-lattice: size exceeds maximum " << opts_.max_mem << " bytes; (repo,arcs,elems) = (" << repo << "," << arcs << "," << elems
+               << "), after rebuilding, repo size was " << new_repo << ", effective beam was " << eff << " vs. requested beam " << beam_;
+      return false;
+    }
+    return true;
+  }
+
+  const InputFst &f_; double beam_; DeterminizeLatticePrunedOptions opts_;
+  double cutoff_ = kInfD; std::vector<double> backward_;
+  StringTrie trie_; int64_t trie_dropped_ = 0, num_arcs_ = 0, num_elems_ = 0;
+  std::deque<OutputState> out_;                              // deque: the hashes keep pointers to the subsets
+  std::deque<std::vector<Element>> initial_keys_;
+  std::unordered_map<const std::vector<Element> *, int32_t, SubsetHash, SubsetEqual> minimal_hash_;
+  std::unordered_map<const std::vector<Element> *, Element, SubsetHash, SubsetEqual> initial_hash_;
+  std::priority_queue<Task *, std::vector<Task *>, TaskCompare> queue_;
+};
+}  // namespace
+
+// lat/determinize-lattice-pruned.cc:1190-1236: determinize; when a limit cut it short at less than retry_cutoff x beam, prune the
+// raw lattice to a narrower beam and start over (at most 10 times)
+bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *clat, const DeterminizeLatticePrunedOptions &opts) {
+  if (!(beam > 0.0)) K3H_ERR << "DeterminizeLatticePruned: beam must be positive, got " << beam;
+  if (!(opts.retry_cutoff >= 0.0f && opts.retry_cutoff < 1.0f)) K3H_ERR << "DeterminizeLatticePruned: retry-cutoff must be in [0, 1)";
+  InputFst f = PrepareInput(lat);
+  *clat = CompactLattice();
+  if (f.NumStates() == 0) return true;
+  for (int iter = 0;; iter++) {
+    Determinizer det(f, beam, opts);
+    double effective_beam;
+    const bool ans = det.Determinize(&effective_beam);
+    if (effective_beam >= beam * opts.retry_cutoff || beam == kInfD || iter + 1 == 10) { det.Output(clat); Connect(clat); return ans; }
+    if (effective_beam < 0.0) effective_beam = 0.0;
+    double new_beam = beam * std::sqrt(effective_beam / beam);
+    if (new_beam < 0.5 * beam) new_beam = 0.5 * beam;
+    beam = new_beam;
+    PruneInput(beam, &f);
+    K3H_LOG << "Pruned state-level lattice with beam " << beam << " and retrying determinization with that beam.";
+    if (f.NumStates() == 0) return false;
+  }
+}
+
+bool PruneLattice(double beam, Lattice *lat) {
+  if (!(beam > 0.0)) K3H_ERR << "PruneLattice: beam must be positive";
+  Connect(lat);
+  const int32_t n = lat->NumStates(); const size_t na = lat->arc_src.size();
+  if (n == 0) return false;
+  std::vector<int32_t> off(n + 1, 0), idx(na), nx(na);
+  for (size_t a = 0; a < na; a++) off[lat->arc_src[a] + 1]++;
+  for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
+  { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < na; a++) { const int32_t k = p[lat->arc_src[a]]++; idx[k] = (int32_t)a; nx[k] = lat->arc_dst[a]; } }
+  std::vector<int32_t> order;
+  if (!TopOrder(n, lat->start, off, nx, &order)) { K3H_WARN << "Cycles detected in lattice"; return false; }
+  auto fin = [&](int32_t s) { return std::isfinite(lat->st_final[s]) ? (double)lat->st_final[s] + (lat->st_final_ac.empty() ? 0.0 : (double)lat->st_final_ac[s]) : kInfD; };
+  auto cost = [&](int32_t a) { return (double)lat->arc_graph[a] + (double)lat->arc_ac[a]; };
+  std::vector<double> fwd(n, kInfD), bwd(n, kInfD); fwd[lat->start] = 0.0; double best = kInfD;
+  for (int32_t s : order) { for (int32_t k = off[s]; k < off[s + 1]; k++) { const double c = fwd[s] + cost(idx[k]); if (c < fwd[nx[k]]) fwd[nx[k]] = c; } best = std::min(best, fwd[s] + fin(s)); }
+  const double cutoff = best + beam;
+  std::vector<char> drop(na, 0);
+  for (auto it = order.rbegin(); it != order.rend(); ++it) {
+    const int32_t s = *it; double b = fin(s);
+    if (b + fwd[s] > cutoff && b != kInfD) lat->st_final[s] = kInfF;
+    for (int32_t k = off[s]; k < off[s + 1]; k++) { const double ab = cost(idx[k]) + bwd[nx[k]]; if (ab < b) b = ab; if (fwd[s] + ab > cutoff) drop[idx[k]] = 1; }
+    bwd[s] = b;
+  }
+  size_t o = 0;
+  for (size_t a = 0; a < na; a++) if (!drop[a]) {
+    lat->arc_src[o] = lat->arc_src[a]; lat->arc_dst[o] = lat->arc_dst[a]; lat->arc_ilabel[o] = lat->arc_ilabel[a]; lat->arc_olabel[o] = lat->arc_olabel[a]; lat->arc_graph[o] = lat->arc_graph[a]; lat->arc_ac[o] = lat->arc_ac[a]; o++;
+  }
+  for (auto *v : {&lat->arc_src, &lat->arc_dst, &lat->arc_ilabel, &lat->arc_olabel}) v->resize(o);
+  lat->arc_graph.resize(o); lat->arc_ac.resize(o);
+  Connect(lat);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------ CompactLattice ----
+namespace {
+void Renumber(CompactLattice *c, const std::vector<int32_t> &newid, int32_t m) {     // newid[s] < 0: state removed
+  CompactLattice o; for (int32_t i = 0; i < m; i++) o.AddState();
+  o.start = c->start >= 0 ? newid[c->start] : -1;
+  for (int32_t s = 0; s < c->NumStates(); s++) if (newid[s] >= 0) { const int32_t t = newid[s]; o.is_final[t] = c->is_final[s]; o.fin_graph[t] = c->fin_graph[s]; o.fin_ac[t] = c->fin_ac[s]; o.fin_str[t] = std::move(c->fin_str[s]); }
+  // arcs stay grouped by (new) source state, in their old relative order
+  std::vector<int32_t> keep; for (size_t a = 0; a < c->arc_src.size(); a++) if (newid[c->arc_src[a]] >= 0 && newid[c->arc_dst[a]] >= 0) keep.push_back((int32_t)a);
+  std::stable_sort(keep.begin(), keep.end(), [&](int32_t x, int32_t y) { return newid[c->arc_src[x]] < newid[c->arc_src[y]]; });
+  for (int32_t a : keep) { o.arc_src.push_back(newid[c->arc_src[a]]); o.arc_dst.push_back(newid[c->arc_dst[a]]); o.arc_label.push_back(c->arc_label[a]); o.arc_graph.push_back(c->arc_graph[a]); o.arc_ac.push_back(c->arc_ac[a]); o.arc_str.push_back(std::move(c->arc_str[a])); }
+  if (o.start < 0) o = CompactLattice();
+  *c = std::move(o);
+}
+void Csr(const CompactLattice &c, std::vector<int32_t> *off, std::vector<int32_t> *nx) {
+  const int32_t n = c.NumStates(); off->assign(n + 1, 0); nx->resize(c.arc_src.size());
+  for (int32_t s : c.arc_src) (*off)[s + 1]++;
+  for (int32_t s = 0; s < n; s++) (*off)[s + 1] += (*off)[s];
+  std::vector<int32_t> p(off->begin(), off->end() - 1); for (size_t a = 0; a < c.arc_src.size(); a++) (*nx)[p[c.arc_src[a]]++] = c.arc_dst[a];
+}
+}  // namespace
+
+void Connect(CompactLattice *c) {
+  const int32_t n = c->NumStates();
+  if (n == 0) return;
+  std::vector<int32_t> off, nx; Csr(*c, &off, &nx);
+  std::vector<int32_t> roff(n + 1, 0), radj(c->arc_src.size());
+  for (int32_t d : c->arc_dst) roff[d + 1]++;
+  for (int32_t s = 0; s < n; s++) roff[s + 1] += roff[s];
+  { std::vector<int32_t> p(roff.begin(), roff.end() - 1); for (size_t a = 0; a < c->arc_src.size(); a++) radj[p[c->arc_dst[a]]++] = c->arc_src[a]; }
+  std::vector<char> acc(n, 0), co(n, 0); std::vector<int32_t> st;
+  if (c->start >= 0) { acc[c->start] = 1; st.push_back(c->start); }
+  while (!st.empty()) { const int32_t s = st.back(); st.pop_back(); for (int32_t k = off[s]; k < off[s + 1]; k++) if (!acc[nx[k]]) { acc[nx[k]] = 1; st.push_back(nx[k]); } }
+  for (int32_t s = 0; s < n; s++) if (c->is_final[s]) { co[s] = 1; st.push_back(s); }
+  while (!st.empty()) { const int32_t s = st.back(); st.pop_back(); for (int32_t k = roff[s]; k < roff[s + 1]; k++) if (!co[radj[k]]) { co[radj[k]] = 1; st.push_back(radj[k]); } }
+  std::vector<int32_t> newid(n, -1); int32_t m = 0; for (int32_t s = 0; s < n; s++) if (acc[s] && co[s]) newid[s] = m++;
+  if (m == n) return;
+  Renumber(c, newid, m);
+}
+
+void ScaleAcoustic(CompactLattice *c, double scale) { for (float &a : c->arc_ac) a = (float)(a * scale); for (int32_t s = 0; s < c->NumStates(); s++) if (c->is_final[s]) c->fin_ac[s] = (float)(c->fin_ac[s] * scale); }
+
+bool TopSortIfNeeded(CompactLattice *c) {
+  bool sorted = true;
+  for (size_t a = 0; a < c->arc_src.size() && sorted; a++) sorted = c->arc_dst[a] > c->arc_src[a];
+  if (sorted) return true;
+  std::vector<int32_t> off, nx, order; Csr(*c, &off, &nx);
+  if (!TopOrder(c->NumStates(), c->start, off, nx, &order)) return false;
+  std::vector<int32_t> newid(c->NumStates(), -1); for (size_t i = 0; i < order.size(); i++) newid[order[i]] = (int32_t)i;
+  int32_t m = (int32_t)order.size(); for (int32_t s = 0; s < c->NumStates(); s++) if (newid[s] < 0) newid[s] = m++;     // unreachable states go last
+  Renumber(c, newid, m);
+  return true;
+}
+
+namespace {
+template <class T> void Put(std::string *o, T v) { o->append((const char *)&v, sizeof(T)); }
+void PutStr(std::string *o, const std::string &s) { Put<int32_t>(o, (int32_t)s.size()); o->append(s); }
+std::string Num(float v) { if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity"; char buf[64]; snprintf(buf, sizeof buf, "%g", (double)v); return buf; }
+void PrintCompactWeight(std::string *o, float g, float a, const std::vector<int32_t> &str) {     // operator<< of CompactLatticeWeightTpl (fstext/lattice-weight.h:728-738)
+  *o += Num(g); *o += ","; *o += Num(a); *o += ",";
+  for (size_t i = 0; i < str.size(); i++) { if (i) *o += "_"; *o += std::to_string(str[i]); }
+}
+}  // namespace
+
+void TableWriter::WriteCompactLattice(const std::string &key, const CompactLattice &c) {      // WriteCompactLattice (lat/kaldi-lattice.cc:65-94)
+  const int32_t n = c.NumStates(); const size_t na = c.arc_src.size();
+  std::vector<int32_t> off(n + 1, 0), order(na);
+  for (size_t a = 0; a < na; a++) off[c.arc_src[a] + 1]++;
+  for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
+  { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < na; a++) order[p[c.arc_src[a]]++] = (int32_t)a; }
+  std::string o = key + " ";
+  if (!binary_) {          // FstPrinter in acceptor mode: "src dst label weight", weight left out when it is One (0,0,empty string)
+    o += "\n";
+    auto print_state = [&](int32_t s) {
+      for (int32_t k = off[s]; k < off[s + 1]; k++) {
+        const int32_t a = order[k];
+        o += std::to_string(s) + "\t" + std::to_string(c.arc_dst[a]) + "\t" + std::to_string(c.arc_label[a]);
+        if (!(c.arc_graph[a] == 0.0f && c.arc_ac[a] == 0.0f && c.arc_str[a].empty())) { o += "\t"; PrintCompactWeight(&o, c.arc_graph[a], c.arc_ac[a], c.arc_str[a]); }
+        o += "\n";
+      }
+      if (c.is_final[s]) { o += std::to_string(s); if (!(c.fin_graph[s] == 0.0f && c.fin_ac[s] == 0.0f && c.fin_str[s].empty())) { o += "\t"; PrintCompactWeight(&o, c.fin_graph[s], c.fin_ac[s], c.fin_str[s]); } o += "\n"; }
+    };
+    if (c.start >= 0) print_state(c.start);
+    for (int32_t s = 0; s < n; s++) if (s != c.start) print_state(s);
+    o += "\n";
+  } else {                  // VectorFst<CompactLatticeArc>::Write; the weight is {2 floats, int32 length, int32 labels} (lattice-weight.h:529-539)
+    Put<int32_t>(&o, 2125659606); PutStr(&o, "vector"); PutStr(&o, "compactlattice44");
+    Put<int32_t>(&o, 2); Put<int32_t>(&o, 0); Put<uint64_t>(&o, 3); Put<int64_t>(&o, c.start); Put<int64_t>(&o, n); Put<int64_t>(&o, (int64_t)na);
+    auto put_w = [&](float g, float a, const std::vector<int32_t> &str) { Put(&o, g); Put(&o, a); Put<int32_t>(&o, (int32_t)str.size()); for (int32_t t : str) Put(&o, t); };
+    static const std::vector<int32_t> kEmpty;
+    for (int32_t s = 0; s < n; s++) {
+      if (c.is_final[s]) put_w(c.fin_graph[s], c.fin_ac[s], c.fin_str[s]); else put_w(kInfF, kInfF, kEmpty);
+      Put<int64_t>(&o, off[s + 1] - off[s]);
+      for (int32_t k = off[s]; k < off[s + 1]; k++) { const int32_t a = order[k]; Put(&o, c.arc_label[a]); Put(&o, c.arc_label[a]); put_w(c.arc_graph[a], c.arc_ac[a], c.arc_str[a]); Put(&o, c.arc_dst[a]); }
+    }
+  }
+  if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on compact lattice " << key;
+}
+
+// ------------------------------------------------------------------------------------------------ lattice table reader ----
+std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string &rspecifier) {
+  const size_t colon = rspecifier.find(':');
+  if (colon == std::string::npos || rspecifier.compare(0, 3, "ark") != 0) K3H_ERR << "Invalid lattice rspecifier " << rspecifier << " (supported: ark:<rxfilename>, ark,t:<rxfilename>)";
+  const std::string b = ReadWholeInput(rspecifier.substr(colon + 1));
+  std::vector<std::pair<std::string, Lattice>> out;
+  size_t p = 0;
+  auto parse_float = [&](const std::string &t) { if (t == "Infinity") return kInfF; if (t == "-Infinity") return -kInfF; char *e; const float v = strtof(t.c_str(), &e); if (*e || t.empty()) K3H_ERR << "Bad number \"" << t << "\" in lattice"; return v; };
+  while (true) {
+    while (p < b.size() && (b[p] == '\n' || b[p] == ' ' || b[p] == '\t' || b[p] == '\r')) p++;
+    if (p >= b.size()) break;
+    const size_t k0 = p; while (p < b.size() && !isspace((unsigned char)b[p])) p++;
+    const std::string key = b.substr(k0, p - k0);
+    if (p >= b.size() || b[p] != ' ') K3H_ERR << "Lattice table: expected a space after key " << key;
+    p++;
+    Lattice lat;
+    auto add_state = [&](int64_t s) { while ((int64_t)lat.st_final.size() <= s) { lat.st_final.push_back(kInfF); lat.st_final_ac.push_back(kInfF); lat.st_frame.push_back(0); lat.st_state.push_back(0); } };
+    if (p < b.size() && (unsigned char)b[p] == 214) {       // first byte of the FST magic number: binary
+      auto get = [&](auto *v) { if (p + sizeof(*v) > b.size()) K3H_ERR << "unexpected end of lattice " << key; memcpy(v, b.data() + p, sizeof(*v)); p += sizeof(*v); };
+      auto str = [&]() { int32_t n; get(&n); if (n < 0 || p + n > b.size()) K3H_ERR << "corrupt FST header in lattice " << key; std::string s = b.substr(p, n); p += n; return s; };
+      int32_t magic, version, flags; uint64_t props; int64_t start, ns, na; get(&magic);
+      const std::string ftype = str(), atype = str(); get(&version); get(&flags); get(&props); get(&start); get(&ns); get(&na);
+      if (ftype != "vector" || atype != "lattice4") K3H_ERR << "Lattice " << key << ": expected a vector FST with arc type lattice4, got " << ftype << " / " << atype << " (compact lattices are not read by this program)";
+      if (flags & 3) K3H_ERR << "Lattice " << key << " has embedded symbol tables";
+      lat.start = (int32_t)start; if (ns > 0) add_state(ns - 1);
+      for (int64_t s = 0; s < ns; s++) {
+        float g, a; int64_t n; get(&g); get(&a); get(&n);
+        lat.st_final[s] = (std::isfinite(g) && std::isfinite(a)) ? g : kInfF; lat.st_final_ac[s] = a;
+        for (int64_t i = 0; i < n; i++) { int32_t il, ol, nx; get(&il); get(&ol); get(&g); get(&a); get(&nx); lat.arc_src.push_back((int32_t)s); lat.arc_dst.push_back(nx); lat.arc_ilabel.push_back(il); lat.arc_olabel.push_back(ol); lat.arc_graph.push_back(g); lat.arc_ac.push_back(a); }
+      }
+    } else {                                                  // text: lines until an empty line (lat/kaldi-lattice.cc:204-300 reads the FstPrinter format)
+      while (p < b.size() && b[p] != '\n') p++;
+      p++;
+      bool first = true;
+      while (p < b.size()) {
+        const size_t l0 = p; while (p < b.size() && b[p] != '\n') p++;
+        std::string line = b.substr(l0, p - l0); p++;
+        std::vector<std::string> col; { std::istringstream ss(line); std::string t; while (ss >> t) col.push_back(t); }
+        if (col.empty()) break;
+        auto weight = [&](const std::string &t, float *g, float *a) { const size_t c = t.find(','); if (c == std::string::npos || t.find(',', c + 1) != std::string::npos) K3H_ERR << "Lattice " << key << ": bad weight \"" << t << "\" (compact lattices are not read by this program)"; *g = parse_float(t.substr(0, c)); *a = parse_float(t.substr(c + 1)); };
+        const int64_t s = strtoll(col[0].c_str(), nullptr, 10); add_state(s);
+        if (first) { lat.start = (int32_t)s; first = false; }
+        if (col.size() <= 2) { float g = 0, a = 0; if (col.size() == 2) weight(col[1], &g, &a); lat.st_final[s] = g; lat.st_final_ac[s] = a; }
+        else if (col.size() == 4 || col.size() == 5) {
+          float g = 0, a = 0; if (col.size() == 5) weight(col[4], &g, &a);
+          const int64_t d = strtoll(col[1].c_str(), nullptr, 10); add_state(d);
+          lat.arc_src.push_back((int32_t)s); lat.arc_dst.push_back((int32_t)d); lat.arc_ilabel.push_back((int32_t)strtol(col[2].c_str(), nullptr, 10)); lat.arc_olabel.push_back((int32_t)strtol(col[3].c_str(), nullptr, 10)); lat.arc_graph.push_back(g); lat.arc_ac.push_back(a);
+        } else K3H_ERR << "Lattice " << key << ": bad line \"" << line << "\"";
+      }
+    }
+    for (size_t s = 0; s < lat.st_final.size(); s++) if (!std::isfinite(lat.st_final[s])) lat.st_final_ac[s] = 0.0f;
+    out.emplace_back(key, std::move(lat));
+  }
+  return out;
+}
+
+}  // namespace k3host

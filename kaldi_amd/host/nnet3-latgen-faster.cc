@@ -1,9 +1,11 @@
 // nnet3-latgen-faster -- drop-in for nnet3bin/nnet3-latgen-faster.cc:33-260 with the forward pass and the decoder on MI355X:
 //   nnet3-latgen-faster [options] <nnet-in> <fst-in> <features-rspecifier> <lattice-wspecifier> [ <words-wspecifier> [<alignments-wspecifier>] ]
 // = DecodableAmNnetSimple + LatticeFasterDecoder + DecodeUtteranceLatticeFaster (decoder/decoder-wrappers.cc:287-382) per utterance in
-// the reference; here all utterances of a batch run through k3_nnet_forward and k3_decoder_decode_batch.  The reference determinizes
-// by default (CompactLattice output); determinization is host OpenFst code outside this library, so --determinize-lattice=false is
-// REQUIRED and the raw state-level lattice is written (what the reference writes with that flag).
+// the reference; here all utterances of a batch run through k3_nnet_forward and k3_decoder_decode_batch.  Like the reference it
+// determinizes by default and writes CompactLattices (decoder-wrappers.cc:354-368); the determinizer is the host-side word-level
+// restatement in k3_lattice.cc (no phone-level first pass: --phone-determinize is accepted and has no effect on the result beyond the
+// choice among equal-cost alignments; --word-determinize=false and --minimize=true are rejected).  --determinize-lattice=false writes
+// the raw state-level lattice.
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -24,11 +26,12 @@ int main(int argc, char **argv) {
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)"); po.Register("allow-partial", &allow_partial, "If true, produce output even if end state was not reached.");
     po.Register("beam", &beam, "Decoding beam.  Larger->slower, more accurate."); po.Register("max-active", &max_active, "Decoder max active states.  Larger->slower; more accurate");
     po.Register("min-active", &min_active, "Decoder minimum #active states."); po.Register("lattice-beam", &lattice_beam, "Lattice generation beam.  Larger->slower, and deeper lattices");
-    po.Register("prune-interval", &prune_interval, "(accepted; pruning runs once after the last frame and gives the same lattice)"); po.Register("determinize-lattice", &determinize, "If true, determinize the lattice (only false is supported by this build)");
+    po.Register("prune-interval", &prune_interval, "(accepted; pruning runs once after the last frame and gives the same lattice)"); po.Register("determinize-lattice", &determinize, "If true, determinize the lattice (lattice-determinization, keeping only best pdf-sequence for each word-sequence).");
     po.Register("beam-delta", &beam_delta, "Increment used in decoding-- this parameter is obscure and relates to a speedup in the way the max-active constraint is applied.");
     po.Register("hash-ratio", &hash_ratio, "(accepted, unused: no hash-order dependence)"); po.Register("prune-scale", &prune_scale, "(accepted, unused)");
-    po.Register("max-mem", &max_mem, "(determinization option, unused)"); po.Register("phone-determinize", &phone_det, "(determinization option, unused)"); po.Register("word-determinize", &word_det, "(determinization option, unused)");
-    po.Register("minimize", &minimize, "(determinization option, unused)"); po.Register("delta", &delta, "(determinization option, unused)");
+    po.Register("max-mem", &max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this)."); po.Register("phone-determinize", &phone_det, "(accepted: the word-level pass alone gives the same best path per word sequence)");
+    po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
+    po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)"); po.Register("delta", &delta, "Tolerance used in determinization");
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods"); po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
     po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole)"); po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)");
     po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)"); po.Register("debug-computation", &debug_comp, "(accepted, unused)");
@@ -36,7 +39,8 @@ int main(int argc, char **argv) {
     po.Register("use-gpu", &use_gpu, "(this build always uses the GPU)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
     po.Read(argc, argv);
     if (po.NumArgs() < 4 || po.NumArgs() > 6) { po.PrintUsage(); return 1; }
-    if (determinize) K3H_ERR << "--determinize-lattice=true (the default) is not supported: pass --determinize-lattice=false and run lattice-determinize-pruned on the output";
+    if (determinize && (!word_det || minimize)) K3H_ERR << "--word-determinize=false and --minimize=true are not supported";
+    DeterminizeLatticePrunedOptions det_opts; det_opts.delta = delta; det_opts.max_mem = max_mem;
     if (!ivector_rspecifier.empty() || !online_ivector_rspecifier.empty() || elc || erc) K3H_ERR << "i-vectors / extra context are not supported by this program";
     const std::string model_rx = po.GetArg(1), fst_rx = po.GetArg(2);
     if (fst_rx.find(':') != std::string::npos && fst_rx.compare(0, 3, "ark") == 0) K3H_ERR << "a table of per-utterance FSTs is not supported; give one HCLG";
@@ -100,8 +104,15 @@ int main(int argc, char **argv) {
         if (words_writer) words_writer->WriteInt32Vector(utt, words);
         if (ali_writer) ali_writer->WriteInt32Vector(utt, ali);
         Connect(&lat);
-        if (acoustic_scale != 0.0f) ScaleAcoustic(&lat, 1.0 / acoustic_scale);
-        lat_writer.WriteLattice(utt, lat);
+        if (determinize) {
+          CompactLattice clat;
+          if (!DeterminizeLatticePruned(lat, lattice_beam, &clat, det_opts)) K3H_WARN << "Determinization finished earlier than the beam for utterance " << utt;
+          if (acoustic_scale != 0.0f) ScaleAcoustic(&clat, 1.0 / acoustic_scale);
+          lat_writer.WriteCompactLattice(utt, clat);
+        } else {
+          if (acoustic_scale != 0.0f) ScaleAcoustic(&lat, 1.0 / acoustic_scale);
+          lat_writer.WriteLattice(utt, lat);
+        }
         const double like = -(gc + ac); const size_t nfr = ali.size();
         K3H_LOG << "Log-like per frame for utterance " << utt << " is " << (like / std::max<size_t>(nfr, 1)) << " over " << nfr << " frames.";
         tot_like += like; frame_count += (int64_t)nfr; num_success++;

@@ -51,6 +51,22 @@ def _parse_text_lattices(path, start_state_of=None):
             fins[int(f[0])] = np.float32(0.0) if len(f) == 1 else np.float32(float(f[1].split(",")[0]))
     return lats
 
+def _compact_best_words(c, want="words"):
+    """cheapest path of a parsed CompactLattice (tests/lattice_cases.parse_compact_text): its word labels or its transition-ids"""
+    by_src = {}
+    for a in c["arcs"]: by_src.setdefault(a[0], []).append(a)
+    memo = {}
+    def best(s):
+        if s not in memo:
+            cand = [(c["finals"][s][0] + c["finals"][s][1], (), tuple(c["finals"][s][2]))] if s in c["finals"] else []
+            for a in by_src.get(s, []):
+                bc, bw, bt = best(a[1]); cand.append((a[3] + a[4] + bc, (a[2],) + bw, tuple(a[5]) + bt))
+            memo[s] = min(cand) if cand else (float("inf"), (), ())
+        return memo[s]
+    import sys; sys.setrecursionlimit(20000)
+    r = best(c["start"])
+    return list(r[1] if want == "words" else r[2])
+
 def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
     from kaldi_amd import feat, nnet3, decoder
     from oracle import kaldi_io as kio
@@ -62,7 +78,7 @@ def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
     graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
     open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40   # comment\n--dither=0\n")
     cmd = [os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0",
-           "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--max-batch-size=2", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/lat.txt"]
+           "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--max-batch-size=2", "--determinize-lattice=false", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/lat.txt"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Decoded 3 utterances, 0 with errors." in r.stderr and "RealTimeX:" in r.stderr
@@ -91,6 +107,25 @@ def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
     cmd[-1] = f"ark:{td}/lat.ark"
     assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
     assert os.path.getsize(f"{td}/lat.ark") > 1000 and open(f"{td}/lat.ark", "rb").read(9) == b"utt0 \xd6\xfd\xb2\x7e"
+    # default: determinized CompactLattices.  Must equal what lattice-determinize-pruned (same host code, CPU program) makes of the
+    # raw binary archive above, and its best path must spell the raw lattice's best word sequence.
+    from tests import lattice_cases as lc
+    cmd_det = [c for c in cmd if not c.startswith("--determinize")]; cmd_det[-1] = f"ark,t:{td}/det.txt"
+    r = subprocess.run(cmd_det, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r2 = subprocess.run([os.path.join(BIN, "lattice-determinize-pruned"), "--beam=8.0", "--acoustic-scale=1.0", f"ark:{td}/lat.ark", f"ark,t:{td}/det2.txt"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    det, det2 = lc.parse_compact_text(open(f"{td}/det.txt").read()), lc.parse_compact_text(open(f"{td}/det2.txt").read())
+    assert list(det) == list(det2) == ["utt0", "utt1", "utt2"]
+    for u, key in enumerate(det):
+        # state numbers differ (the CPU program sorts topologically); the arcs without them must agree
+        canon = lambda c: sorted((a[2], a[5], round(a[3], 2), round(a[4], 2)) for a in c["arcs"])
+        assert canon(det[key]) == canon(det2[key]) and len(det[key]["arcs"]) > 0, key
+        by_src = {}
+        for a_ in det[key]["arcs"]:
+            assert (a_[0], a_[2]) not in by_src and a_[2] != 0          # deterministic on words, no epsilons
+            by_src[(a_[0], a_[2])] = a_
+        assert _compact_best_words(det[key]) == lats[u].connect().best_path()[1], key
 
 def test_nnet3_compute_matches_the_reference_binary_incl_compressed_archives(tmp_path):
     """same model file, same feature archive (also as a COMPRESSED archive and an scp with byte offsets written by the
@@ -140,9 +175,16 @@ def test_nnet3_latgen_faster_end_to_end(tmp_path):
         bp = ref.connect().best_path()
         assert len(ali[k]) == ll.shape[0]
         assert words[k] == bp[1] and ali[k] == bp[0], k
-    # default --determinize-lattice=true is refused loudly
-    r = subprocess.run([c for c in cmd if not c.startswith("--determinize")], capture_output=True, text=True)
-    assert r.returncode == 255 and "determinize-lattice" in r.stderr
+    # default --determinize-lattice=true: CompactLattices whose best path is the same word sequence and alignment
+    from tests import lattice_cases as lc
+    cmd_det = [c for c in cmd if not c.startswith("--determinize")]; cmd_det[-3] = f"ark,t:{td}/clat.txt"
+    r = subprocess.run(cmd_det, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    clats = lc.parse_compact_text(open(f"{td}/clat.txt").read())
+    assert sorted(clats) == sorted(feats)
+    for k in feats:
+        assert _compact_best_words(clats[k]) == words[k], k
+        assert _compact_best_words(clats[k], want="tids") == ali[k], k
 
 
 @pytest.mark.parametrize("flags,spk", [([], False), (["--cmn-window=100", "--speaker-frames=100", "--global-frames=10", "--norm-vars=true", "--skip-dims=0:5"], True),
@@ -187,7 +229,7 @@ def test_batched_wav_nnet3_cuda_online_equals_offline_program(tmp_path):
     net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
     graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
     open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
-    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000"]
+    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--determinize-lattice=false"]
     a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=5", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/off.txt"], capture_output=True, text=True)
     assert a.returncode == 0, a.stderr
     off = _parse_text_lattices(f"{td}/off.txt")

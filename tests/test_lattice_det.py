@@ -1,0 +1,246 @@
+"""Host-side word-level lattice determinization (kaldi_amd/host/k3_lattice.cc, the lattice-determinize-pruned program): CPU only.
+OpenFst is not available, so the reference's determinizer cannot be run here (parity unpinned); these are the defining properties
+the reference's own determinize-lattice-pruned-test.cc checks through RandEquivalent, verified by exhaustive path enumeration on
+small random lattices:
+  * the output is deterministic on word labels and has no epsilon arcs,
+  * every word sequence whose best raw path is within the beam is present,
+  * each word sequence present appears once, with the (graph, acoustic) cost and the transition-id string of its best raw path.
+Tolerance: 2e-3 on path costs (float32 sums of up to ~30 arc costs below 10 accumulated in a different association order)."""
+import os, subprocess, numpy as np, pytest
+from tests import lattice_cases as lc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROG = os.path.join(ROOT, "kaldi_amd", "bin", "lattice-determinize-pruned")
+TOL = 2e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as ge
+    ge.build()
+    assert os.path.exists(PROG)
+
+
+def _run(args, inp, binary_out=False):
+    r = subprocess.run([PROG] + args + ["ark:-", "ark:-" if binary_out else "ark,t:-"], input=inp, capture_output=True, timeout=120)
+    return r
+
+
+def _check(lat, out, beam, acoustic_scale=1.0, expect_complete=True):
+    raw = lc.enumerate_raw(lat, acoustic_scale)
+    best_raw = {w: min(v) for w, v in raw.items()}
+    best = min(c[0] for c in best_raw.values())
+    # deterministic, epsilon-free
+    seen = set()
+    for (s, d, w, g, a, t) in out["arcs"]:
+        assert w != 0
+        assert (s, w) not in seen, "two arcs with the same word leave state %d" % s
+        seen.add((s, w))
+    det = lc.enumerate_compact(out, acoustic_scale)
+    for w, paths in det.items():
+        assert len(paths) == 1
+        assert w in best_raw, "word sequence %r is not in the raw lattice" % (w,)
+        cost, g, a, tids = paths[0]; rc, rg, ra, rt = best_raw[w]
+        assert abs(cost - rc) <= TOL and abs(g - rg) <= TOL and abs(a - ra) <= TOL, (w, paths[0], best_raw[w])
+        runner_up = sorted(v[0] for v in raw[w])[1] if len(raw[w]) > 1 else np.inf
+        if runner_up - rc > 2 * TOL: assert tids == rt, (w, tids, rt)
+        else: assert any(tids == v[3] and abs(v[0] - rc) <= 2 * TOL for v in raw[w])
+    if expect_complete:
+        for w, (rc, _, _, _) in best_raw.items():
+            if rc <= best + beam - TOL: assert w in det, "word sequence %r (cost %.4f, best %.4f, beam %g) was lost" % (w, rc, best, beam)
+        assert any(abs(best_raw[w][0] - best) <= TOL for w in det)        # the best path survives
+    return raw, det
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("beam", [0.5, 3.0, 1000.0])
+def test_determinize_properties(seed, beam):
+    lat = lc.random_lattice(seed, frames=5 + seed % 3, width=3 + seed % 2, words=2 + seed % 3)
+    r = _run(["--beam=%g" % beam], lc.lattice_text("utt%d" % seed, lat).encode())
+    assert r.returncode == 0, r.stderr.decode()
+    out = lc.parse_compact_text(r.stdout.decode())["utt%d" % seed]
+    raw, det = _check(lat, out, beam)
+    if beam >= 1000.0: assert set(det) == set(raw)
+
+
+def test_exact_ties_pick_one_alignment():
+    """costs on a 1/4 grid: many exactly equal path costs; the result must still be deterministic and optimal, and the alignment
+    chosen must be one of the cheapest (ties broken on graph cost, then the string order of CompactLatticeWeight)."""
+    for seed in range(6):
+        lat = lc.random_lattice(100 + seed, frames=6, width=3, words=2, tids=4, quant=4)
+        r = _run(["--beam=50"], lc.lattice_text("u", lat).encode())
+        assert r.returncode == 0, r.stderr.decode()
+        _check(lat, lc.parse_compact_text(r.stdout.decode())["u"], 50.0)
+
+
+def test_acoustic_scale_changes_ranking_and_is_undone_on_output():
+    lat = lc.random_lattice(7, frames=6, width=4, words=3)
+    outs = {}
+    for sc in (1.0, 0.1):
+        r = _run(["--beam=2.0", "--acoustic-scale=%g" % sc], lc.lattice_text("u", lat).encode())
+        assert r.returncode == 0, r.stderr.decode()
+        outs[sc] = lc.parse_compact_text(r.stdout.decode())["u"]
+        _check(lat, outs[sc], 2.0, acoustic_scale=sc)
+    assert outs[1.0] != outs[0.1]
+
+
+def test_binary_io_matches_text_io():
+    lats = [lc.random_lattice(40 + i, frames=5, width=3) for i in range(4)]
+    text_in = "".join(lc.lattice_text("k%d" % i, l) for i, l in enumerate(lats)).encode()
+    bin_in = b"".join(lc.lattice_binary("k%d" % i, l) for i, l in enumerate(lats))
+    a = _run(["--beam=4"], text_in); b = _run(["--beam=4"], bin_in); c = _run(["--beam=4"], bin_in, binary_out=True)
+    assert a.returncode == 0 and b.returncode == 0 and c.returncode == 0, (a.stderr, b.stderr, c.stderr)
+    assert a.stdout == b.stdout
+    ta = lc.parse_compact_text(a.stdout.decode()); tc = lc.parse_compact_binary(c.stdout)
+    assert list(ta) == list(tc) == ["k0", "k1", "k2", "k3"]
+    for k in ta:
+        assert ta[k]["start"] == tc[k]["start"] and len(ta[k]["arcs"]) == len(tc[k]["arcs"])
+        for x, y in zip(ta[k]["arcs"], tc[k]["arcs"]):
+            assert x[:3] == y[:3] and x[5] == y[5] and np.allclose(x[3:5], y[3:5], rtol=1e-5, atol=1e-6)      # %g text keeps 6 digits
+        assert set(ta[k]["finals"]) == set(tc[k]["finals"])
+
+
+def test_output_is_topologically_sorted_with_start_zero():
+    for seed in range(5):
+        lat = lc.random_lattice(60 + seed, frames=7, width=4, words=3)
+        out = lc.parse_compact_text(_run(["--beam=6"], lc.lattice_text("u", lat).encode()).stdout.decode())["u"]
+        assert out["start"] == 0
+        assert all(d > s for (s, d, *_) in out["arcs"])
+
+
+def test_limits_stop_early_but_keep_a_valid_lattice():
+    lat = lc.random_lattice(3, frames=8, width=4, words=4, p_word=0.6)
+    full = lc.parse_compact_text(_run(["--beam=1000"], lc.lattice_text("u", lat).encode()).stdout.decode())["u"]
+    r = _run(["--beam=1000", "--max-states=5", "--retry-cutoff=0"], lc.lattice_text("u", lat).encode())
+    assert r.returncode == 0 and b"did not succeed" in r.stderr
+    part = lc.parse_compact_text(r.stdout.decode())["u"]
+    assert 0 < len(part["arcs"]) < len(full["arcs"])
+    _check(lat, part, 1000.0, expect_complete=False)
+    # --max-mem: tiny budget; with retries the raw lattice is pruned to a narrower beam and determinized again
+    r = _run(["--beam=1000", "--max-mem=300"], lc.lattice_text("u", lat).encode())
+    assert r.returncode == 0 and b"Did not reach requested beam" in r.stderr and b"retrying determinization" in r.stderr
+    _check(lat, lc.parse_compact_text(r.stdout.decode())["u"], 1000.0, expect_complete=False)
+
+
+def test_degenerate_inputs():
+    # no final state reachable -> empty output lattice, warning, still "done"
+    lat = dict(start=0, n=3, finals={}, arcs=[(0, 1, 1, 1, 1.0, 1.0), (1, 2, 2, 0, 1.0, 1.0)])
+    r = _run([], lc.lattice_text("e", lat).encode())
+    assert r.returncode == 0 and b"was empty" in r.stderr and r.stdout.decode().strip() == "e"
+    # a single final start state
+    lat = dict(start=0, n=1, finals={0: (0.5, 0.0)}, arcs=[])
+    out = lc.parse_compact_text(_run([], lc.lattice_text("s", lat).encode()).stdout.decode())["s"]
+    assert out["arcs"] == [] and list(out["finals"]) == [0] and abs(out["finals"][0][0] - 0.5) < 1e-6
+    # words only on non-emitting arcs and a final weight with alignment left over after the last word
+    lat = dict(start=0, n=4, finals={3: (0.25, 0.0)}, arcs=[(0, 1, 5, 0, 1.0, 2.0), (1, 2, 0, 7, 0.5, 0.0), (2, 3, 6, 0, 1.0, 1.0), (0, 2, 4, 7, 3.0, 3.0)])
+    out = lc.parse_compact_text(_run([], lc.lattice_text("w", lat).encode()).stdout.decode())["w"]
+    det = lc.enumerate_compact(out)
+    assert list(det) == [(7,)] and det[(7,)][0][3] == (5, 6) and abs(det[(7,)][0][0] - 5.75) < 1e-5
+    # a cycle cannot be sorted: error exit like the reference's KALDI_ERR in the wrapper
+    lat = dict(start=0, n=2, finals={1: (0.0, 0.0)}, arcs=[(0, 1, 1, 1, 1.0, 1.0), (1, 0, 0, 0, 1.0, 0.0)])
+    r = _run([], lc.lattice_text("c", lat).encode())
+    assert r.returncode != 0 and b"Topological sorting" in r.stderr
+    # command-line contract
+    assert subprocess.run([PROG], capture_output=True).returncode == 1
+    assert subprocess.run([PROG, "--acoustic-scale=0", "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
+    assert subprocess.run([PROG, "--minimize=true", "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
+
+
+def _best_cost_for_words(lat, words):
+    """cheapest raw path spelling exactly `words`: DP over (state, number of words consumed) in a topological order."""
+    by_src = {}
+    for a in lat["arcs"]: by_src.setdefault(a[0], []).append(a)
+    indeg = {}
+    for a in lat["arcs"]: indeg[a[1]] = indeg.get(a[1], 0) + 1
+    order = []; ready = [s for s in range(lat["n"]) if indeg.get(s, 0) == 0]
+    while ready:
+        s = ready.pop(); order.append(s)
+        for a in by_src.get(s, []):
+            indeg[a[1]] -= 1
+            if indeg[a[1]] == 0: ready.append(a[1])
+    inf = float("inf"); best = {(lat["start"], 0): 0.0}; ans = inf
+    for s in order:
+        for k in range(len(words) + 1):
+            c = best.get((s, k), inf)
+            if c == inf: continue
+            if k == len(words) and s in lat["finals"]: ans = min(ans, c + sum(lat["finals"][s]))
+            for (_, d, tid, w, g, a) in by_src.get(s, []):
+                if w == 0: key = (d, k)
+                elif k < len(words) and words[k] == w: key = (d, k + 1)
+                else: continue
+                if c + g + a < best.get(key, inf): best[key] = c + g + a
+    return ans
+
+
+def _check_sampled(lat, out, nframes, samples=40, tol=0.02):
+    """for lattices with too many paths to enumerate: determinism, one transition-id per frame on every path, sampled word sequences
+    against a dynamic program over the raw lattice, and the overall best cost."""
+    by_src = {}
+    for a in out["arcs"]: by_src.setdefault(a[0], []).append(a)
+    assert all(len({a[2] for a in v}) == len(v) and all(a[2] != 0 for a in v) for v in by_src.values())
+    rng = np.random.default_rng(0)
+    for _ in range(samples):
+        s = out["start"]; words = []; cost = 0.0; ntid = 0
+        while True:
+            choices = by_src.get(s, [])
+            if s in out["finals"] and (not choices or rng.random() < 0.3):
+                cost += out["finals"][s][0] + out["finals"][s][1]; ntid += len(out["finals"][s][2]); break
+            assert choices, "dead end at state %d" % s             # Connect ran: every state reaches a final state
+            a = choices[int(rng.integers(len(choices)))]; words.append(a[2]); cost += a[3] + a[4]; ntid += len(a[5]); s = a[1]
+        assert ntid == nframes
+        assert abs(_best_cost_for_words(lat, words) - cost) <= tol, (words, cost)
+    import sys; sys.setrecursionlimit(20000)
+    by = {}
+    for a in lat["arcs"]: by.setdefault(a[0], []).append(a)
+    m1, m2 = {}, {}
+    def bw(s):
+        if s not in m1:
+            m1[s] = min([sum(lat["finals"][s]) if s in lat["finals"] else np.inf] + [a[4] + a[5] + bw(a[1]) for a in by.get(s, [])])
+        return m1[s]
+    def bw_out(s):
+        if s not in m2:
+            m2[s] = min([out["finals"][s][0] + out["finals"][s][1] if s in out["finals"] else np.inf] + [a[3] + a[4] + bw_out(a[1]) for a in by_src.get(s, [])])
+        return m2[s]
+    assert abs(bw(lat["start"]) - bw_out(out["start"])) <= tol
+
+
+def test_decoder_sized_lattice_sampled_paths():
+    """a lattice of the size one utterance produces (200 frames, ~1000 states, several thousand arcs)"""
+    lat = lc.random_lattice(11, frames=200, width=6, words=5, p_word=0.08)
+    r = _run(["--beam=4"], lc.lattice_text("big", lat).encode())
+    assert r.returncode == 0, r.stderr.decode()
+    _check_sampled(lat, lc.parse_compact_text(r.stdout.decode())["big"], 200)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_lattices_of_the_decoder_oracle(seed):
+    """raw lattices exactly as the decoder emits them (states = tokens, epsilon-input arcs inside a frame, words on few arcs):
+    the CPU restatement of LatticeFasterDecoder on a synthetic HCLG supplies them, binary table in, --beam = the lattice beam."""
+    from kaldi_amd import synth
+    from oracle import lattice_oracle as lo
+    T = 60; N = 40
+    f = synth.make_hclg(1500, 4000, N, seed=seed, start_degree=30)
+    ll = (np.random.default_rng(seed + 1).standard_normal((T, N)) * 2.5).astype(np.float32)
+    raw = lo.decode(f, ll, synth.tid2pdf(N), lo.Config(beam=15.0, lattice_beam=6.0, max_active=10000), 1)[0].connect()
+    assert raw.num_arcs > 500 and (raw.arc_ilabel == 0).any() and (raw.arc_olabel != 0).any()
+    lat = dict(start=raw.start_index(), n=raw.num_states, finals={int(s): (float(raw.st_final[s]), 0.0) for s in np.nonzero(np.isfinite(raw.st_final))[0]},
+               arcs=[(int(s), int(d), int(i), int(o), float(g), float(a)) for s, d, i, o, g, a in zip(raw.arc_src, raw.arc_dst, raw.arc_ilabel, raw.arc_olabel, raw.arc_graph, raw.arc_ac)])
+    r = _run(["--beam=6"], lc.lattice_binary("utt", lat))
+    assert r.returncode == 0 and b"did not succeed" not in r.stderr, r.stderr.decode()
+    out = lc.parse_compact_text(r.stdout.decode())["utt"]
+    assert 0 < len(out["arcs"]) < raw.num_arcs
+    _check_sampled(lat, out, T, samples=25, tol=0.01)
+    # the best path of the determinized lattice is the decoder's best path
+    bp = raw.best_path()
+    by_src = {}
+    for a in out["arcs"]: by_src.setdefault(a[0], []).append(a)
+    memo = {}
+    def best(s):
+        if s not in memo:
+            c = [(out["finals"][s][0] + out["finals"][s][1], (), out["finals"][s][2])] if s in out["finals"] else []
+            for a in by_src.get(s, []):
+                bc, bw_, bt = best(a[1]); c.append((a[3] + a[4] + bc, (a[2],) + bw_, a[5] + bt))
+            memo[s] = min(c) if c else (np.inf, (), ())
+        return memo[s]
+    cost, words, tids = best(out["start"])
+    assert list(words) == bp[1] and list(tids) == bp[0] and abs(cost - (bp[2] + bp[3])) < 1e-2
