@@ -12,6 +12,7 @@
 #include <cmath>
 #include <deque>
 #include <iostream>
+#include <thread>
 #include "k3_feat_options.h"
 #include "k3_online.h"
 using namespace k3host;
@@ -23,6 +24,7 @@ int main(int argc, char **argv) {
         "Usage: batched-wav-nnet3-cuda-online [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
     ParseOptions po(usage);
     bool write_lattice = true, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
+    int32_t worker_threads = -1;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, frames_per_chunk = 51, subsampling = 1, num_streaming = 2000;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, max_frames = 6000;
     float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; int32_t det_max_mem = 50000000;
@@ -35,6 +37,7 @@ int main(int argc, char **argv) {
     po.Register("num-channels", &num_channels, "The number of parallel audio channels (-1 = max-batch-size)");
     po.Register("num-parallel-streaming-channels", &num_streaming, "(accepted; the streams are fed round-robin over --num-channels)");
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
+    po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
     po.Register("phone-determinize", &phone_det, "(accepted: the word-level pass alone gives the same best path per word sequence)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)");
@@ -92,6 +95,11 @@ int main(int argc, char **argv) {
     auto scp = ReadScp(wav_rspec);
     if (num_todo >= 0 && (size_t)num_todo < scp.size()) scp.resize(num_todo);
     std::unique_ptr<TableWriter> writer; if (write_lattice) writer.reset(new TableWriter(out_wspec));
+    std::unique_ptr<DeterminizeSequencer> det_pool;          // lattices are determinized on worker threads while the streams go on
+    if (writer && determinize) {
+      DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
+      pc.beam = lattice_beam; pc.det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
+    }
     int num_task = 0, num_err = 0; double total_audio = 0.0;
     // per-channel state of the simulation
     struct Chan { int utt = -1; Wave wav; size_t pos = 0; int pend = 0; bool started = false; };
@@ -189,11 +197,7 @@ int main(int argc, char **argv) {
               lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
               for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
               Connect(&lat);
-              if (determinize) {
-                CompactLattice clat;
-                if (!DeterminizeLatticePruned(lat, lattice_beam, &clat, det_opts)) K3H_WARN << "Determinization finished earlier than the beam for utterance " << key;
-                writer->WriteCompactLattice(key, clat);
-              } else writer->WriteLattice(key, lat);
+              if (det_pool) det_pool->Run(key, std::move(lat)); else writer->WriteLattice(key, lat);
             }
             s0 += ns; a0 += na;
             chan[ended[u]] = Chan(); busy--;
@@ -202,6 +206,7 @@ int main(int argc, char **argv) {
       }
     }
     K3O_HIP(hipDeviceSynchronize());
+    if (det_pool) { det_pool->Wait(); det_pool.reset(); }
     if (writer) writer->Flush();
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <thread>
 #include "k3_feat_options.h"
 using namespace k3host;
 #define HIPCHK(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) K3H_ERR << "HIP error " << hipGetErrorName(e__) << " in " << #e; } while (0)
@@ -37,7 +38,7 @@ int main(int argc, char **argv) {
     po.Register("lattice-postprocessor-rxfilename", &postproc, "(optional) Config file for lattice postprocessor (not supported)");
     po.Register("max-batch-size", &max_batch, "The maximum execution batch size (utterances decoded together)");
     po.Register("num-channels", &num_channels, "(accepted; whole-utterance batching needs no separate channel pool)");
-    po.Register("cuda-worker-threads", &worker_threads, "(accepted; lattice pruning runs on the GPU, no CPU worker pool)");
+    po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
     po.Register("cuda-decoder-copy-threads", &copy_threads, "(accepted, unused)");
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
@@ -101,6 +102,12 @@ int main(int argc, char **argv) {
     auto scp = ReadScp(wav_rspec);
     if (num_todo >= 0 && (size_t)num_todo < scp.size()) scp.resize(num_todo);
     std::unique_ptr<TableWriter> writer; if (write_lattice) writer.reset(new TableWriter(out_wspec));
+    // determinization runs on worker threads while the GPU works on the next batch; records come out in submission order
+    std::unique_ptr<DeterminizeSequencer> det_pool;
+    if (writer && determinize) {
+      DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
+      pc.beam = lattice_beam; pc.det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
+    }
     int num_task = 0, num_err = 0; double total_audio = 0.0;
     const auto t_start = std::chrono::steady_clock::now();
     for (int iter = 0; iter < iterations; iter++) {
@@ -145,11 +152,7 @@ int main(int argc, char **argv) {
             lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
             for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
             Connect(&lat);
-            if (determinize) {
-              CompactLattice clat;
-              if (!DeterminizeLatticePruned(lat, lattice_beam, &clat, det_opts)) K3H_WARN << "Determinization finished earlier than the beam for utterance " << keys[u];
-              writer->WriteCompactLattice(keys[u], clat);
-            } else writer->WriteLattice(keys[u], lat);
+            if (det_pool) det_pool->Run(keys[u], std::move(lat)); else writer->WriteLattice(keys[u], lat);
             s0 += ns; a0 += na;
           }
         }
@@ -158,6 +161,7 @@ int main(int argc, char **argv) {
       }
     }
     HIPCHK(hipDeviceSynchronize());
+    if (det_pool) { det_pool->Wait(); det_pool.reset(); }
     if (writer) writer->Flush();
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";

@@ -152,4 +152,22 @@ class TableWriter {        // "ark:wxfilename" | "ark,t:wxfilename" (other optio
   std::shared_ptr<FILE> f_; bool binary_ = true;
 };
 
+// Determinization on worker threads with the output order of the submissions -- util/kaldi-thread.h:171-260 TaskSequencer as
+// lattice-determinize-pruned-parallel.cc:30-100 uses it, and the job the reference's CUDA pipeline gives its --cuda-worker-threads
+// pool (batched-threaded-nnet3-cuda-online-pipeline.cc:735-810): per lattice  scale acoustic costs by pre_scale -> DeterminizeLatticePruned
+// -> (optional TopSortIfNeeded) -> scale by post_scale -> WriteCompactLattice.  Run() blocks while num_threads + 20 lattices are
+// in flight (bounds memory).  An error inside a worker is re-thrown from the next Run() / Wait().
+class DeterminizeSequencer {
+ public:
+  struct Config { int32_t num_threads = 1; double beam = 10.0, pre_scale = 1.0, post_scale = 1.0; bool topsort = false; DeterminizeLatticePrunedOptions det; };
+  DeterminizeSequencer(const Config &config, TableWriter *writer);
+  ~DeterminizeSequencer();
+  void Run(std::string key, Lattice &&lat);
+  void Wait();                              // returns when everything submitted so far has been written
+  int32_t NumDone() const;
+  int32_t NumWarn() const;                  // determinization stopped early, or empty output
+ private:
+  struct Impl; std::unique_ptr<Impl> impl_;
+};
+
 }  // namespace k3host

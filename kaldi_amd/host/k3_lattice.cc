@@ -19,6 +19,9 @@
 #include <limits>
 #include <queue>
 #include <unordered_map>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 namespace k3host {
 namespace {
@@ -587,6 +590,69 @@ void TableWriter::WriteCompactLattice(const std::string &key, const CompactLatti
   }
   if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on compact lattice " << key;
 }
+
+// ------------------------------------------------------------------------------------------------ DeterminizeSequencer ----
+struct DeterminizeSequencer::Impl {
+  Config cfg; TableWriter *writer;
+  std::mutex m; std::condition_variable cv_work, cv_done;
+  struct Job { int64_t seq; std::string key; Lattice lat; };
+  std::deque<Job> queue;                                                   // submitted, not yet picked up
+  std::map<int64_t, std::pair<std::string, CompactLattice>> finished;      // determinized, waiting for their turn to be written
+  int64_t submitted = 0, written = 0; int32_t num_warn = 0; bool stop = false; std::string error;
+  std::vector<std::thread> threads;
+
+  void Work() {
+    for (;;) {
+      Job job;
+      { std::unique_lock<std::mutex> lk(m); cv_work.wait(lk, [&] { return stop || !queue.empty(); }); if (queue.empty()) return; job = std::move(queue.front()); queue.pop_front(); }
+      CompactLattice clat; bool warn = false; std::string err;
+      try {
+        if (cfg.pre_scale != 1.0) ScaleAcoustic(&job.lat, cfg.pre_scale);
+        if (!DeterminizeLatticePruned(job.lat, cfg.beam, &clat, cfg.det)) { K3H_WARN << "For key " << job.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; warn = true; }
+        if (clat.NumStates() == 0) { K3H_WARN << "For key " << job.key << ", determinized and trimmed lattice was empty."; warn = true; }
+        if (cfg.topsort && !TopSortIfNeeded(&clat)) K3H_WARN << "Topological sorting of the determinized lattice failed for key " << job.key;
+        if (cfg.post_scale != 1.0) ScaleAcoustic(&clat, cfg.post_scale);
+      } catch (const std::exception &e) { err = e.what(); }
+      job.lat = Lattice();
+      std::unique_lock<std::mutex> lk(m);
+      if (!err.empty() && error.empty()) error = err;
+      num_warn += warn;
+      finished.emplace(job.seq, std::make_pair(std::move(job.key), std::move(clat)));
+      // whoever completes the next lattice in line writes it and everything behind it that is already there
+      for (auto it = finished.find(written); it != finished.end(); it = finished.find(written)) {
+        if (error.empty()) { try { writer->WriteCompactLattice(it->second.first, it->second.second); } catch (const std::exception &e) { error = e.what(); } }
+        finished.erase(it); written++;
+      }
+      cv_done.notify_all();
+    }
+  }
+};
+
+DeterminizeSequencer::DeterminizeSequencer(const Config &config, TableWriter *writer) : impl_(new Impl) {
+  impl_->cfg = config; impl_->writer = writer;
+  const int32_t n = std::max<int32_t>(1, config.num_threads);
+  for (int32_t i = 0; i < n; i++) impl_->threads.emplace_back([this] { impl_->Work(); });
+}
+DeterminizeSequencer::~DeterminizeSequencer() {
+  { std::unique_lock<std::mutex> lk(impl_->m); impl_->stop = true; }
+  impl_->cv_work.notify_all();
+  for (std::thread &t : impl_->threads) t.join();      // workers drain the queue before they leave
+}
+void DeterminizeSequencer::Run(std::string key, Lattice &&lat) {
+  std::unique_lock<std::mutex> lk(impl_->m);
+  const int64_t max_in_flight = (int64_t)impl_->threads.size() + 20;
+  impl_->cv_done.wait(lk, [&] { return impl_->submitted - impl_->written < max_in_flight; });
+  if (!impl_->error.empty()) { const std::string e = impl_->error; lk.unlock(); throw FatalError(e); }
+  impl_->queue.push_back(Impl::Job{impl_->submitted++, std::move(key), std::move(lat)});
+  lk.unlock(); impl_->cv_work.notify_one();
+}
+void DeterminizeSequencer::Wait() {
+  std::unique_lock<std::mutex> lk(impl_->m);
+  impl_->cv_done.wait(lk, [&] { return impl_->written == impl_->submitted; });
+  if (!impl_->error.empty()) { const std::string e = impl_->error; lk.unlock(); throw FatalError(e); }
+}
+int32_t DeterminizeSequencer::NumDone() const { std::unique_lock<std::mutex> lk(impl_->m); return (int32_t)impl_->written; }
+int32_t DeterminizeSequencer::NumWarn() const { std::unique_lock<std::mutex> lk(impl_->m); return impl_->num_warn; }
 
 // ------------------------------------------------------------------------------------------------ lattice table reader ----
 std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string &rspecifier) {

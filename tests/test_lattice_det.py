@@ -244,3 +244,30 @@ def test_lattices_of_the_decoder_oracle(seed):
         return memo[s]
     cost, words, tids = best(out["start"])
     assert list(words) == bp[1] and list(tids) == bp[0] and abs(cost - (bp[2] + bp[3])) < 1e-2
+
+
+def test_parallel_program_writes_in_input_order_and_matches_the_serial_one():
+    """lattice-determinize-pruned-parallel (worker threads behind a sequencer, = the pool the decoding programs hand their lattices
+    to): same records for any thread count, input order kept, same lattices as the serial program up to state numbering."""
+    par = PROG + "-parallel"
+    lats = [lc.random_lattice(200 + i, frames=4 + i % 5, width=3 + i % 2, words=3) for i in range(40)]
+    inp = b"".join(lc.lattice_binary("k%02d" % i, l) for i, l in enumerate(lats))
+    outs = [subprocess.run([par, "--beam=5", "--acoustic-scale=0.5", "--num-threads=%d" % n, "ark:-", "ark,t:-"], input=inp, capture_output=True, timeout=120) for n in (1, 7)]
+    assert all(o.returncode == 0 for o in outs), outs[1].stderr.decode()
+    assert outs[0].stdout == outs[1].stdout
+    par_l = lc.parse_compact_text(outs[0].stdout.decode())
+    assert list(par_l) == ["k%02d" % i for i in range(40)]
+    ser = _run(["--beam=5", "--acoustic-scale=0.5"], inp); assert ser.returncode == 0
+    ser_l = lc.parse_compact_text(ser.stdout.decode())
+    nonempty = 0
+    for k in par_l:
+        a, b = lc.enumerate_compact(par_l[k], 0.5), lc.enumerate_compact(ser_l[k], 0.5)
+        assert a == b
+        nonempty += len(a) > 0
+    assert nonempty >= 30          # a few random lattices have no reachable final state: empty in both
+    # a lattice that cannot be determinized (cycle) in the middle of the table: error exit, message on stderr
+    bad = dict(start=0, n=2, finals={1: (0.0, 0.0)}, arcs=[(0, 1, 1, 1, 1.0, 1.0), (1, 0, 0, 0, 1.0, 0.0)])
+    inp2 = b"".join(lc.lattice_binary("k%02d" % i, l) for i, l in enumerate(lats[:10])) + lc.lattice_binary("bad", bad) + lc.lattice_binary("after", lats[11])
+    r = subprocess.run([par, "--num-threads=3", "ark:-", "ark,t:-"], input=inp2, capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"Topological sorting" in r.stderr
+    assert subprocess.run([par], capture_output=True).returncode == 1
