@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
     po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
-    po.Register("phone-determinize", &phone_det, "(accepted: the word-level pass alone gives the same best path per word sequence)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
+    po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)");
     po.Register("print-partial-hypotheses", &print_partial, "(not supported)"); po.Register("print-endpoints", &print_endpoints, "(not supported)");
     po.Register("simulate-realtime-writing", &simulate_rt, "(accepted, unused: chunks are submitted as fast as the GPU takes them)");
@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     if (print_partial || print_endpoints) K3H_ERR << "--print-partial-hypotheses / --print-endpoints are not supported";
     if (determinize && (!word_det || minimize)) K3H_ERR << "--word-determinize=false and --minimize=true are not supported";
-    DeterminizeLatticePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem;
+    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det;
     if (num_channels < 0) num_channels = max_batch;
     if (num_channels > max_batch) max_batch = num_channels;      // one slot per channel and round
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);
@@ -98,7 +98,7 @@ int main(int argc, char **argv) {
     std::unique_ptr<DeterminizeSequencer> det_pool;          // lattices are determinized on worker threads while the streams go on
     if (writer && determinize) {
       DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
-      pc.beam = lattice_beam; pc.det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
+      pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
     }
     int num_task = 0, num_err = 0; double total_audio = 0.0;
     // per-channel state of the simulation

@@ -3,7 +3,7 @@
 // Same positional arguments, same option names (BatchedThreadedNnet3CudaPipeline2Config and its nested configs), same exit codes
 // (1 usage, -1 exception) and the same closing log line "Overall:  Aggregate Total Time: .. Total Audio: .. RealTimeX: ..".
 // The pipeline behind it is the whole-utterance batch path of libk3hip.so: waveforms -> k3_feat_compute_batch -> k3_nnet_forward ->
-// k3_decoder_decode_batch -> raw lattices -> (default, like BatchedThreadedNnet3CudaOnlinePipelineConfig::determinize_lattice) word-level
+// k3_decoder_decode_batch -> raw lattices -> (default, like BatchedThreadedNnet3CudaOnlinePipelineConfig::determinize_lattice) phone- then word-level
 // pruned determinization on the host (k3_lattice.cc; beam = --lattice-beam, batched-threaded-nnet3-cuda-online-pipeline.cc:759-765) ->
 // CompactLattice table.  Like the reference's CUDA pipeline the lattice keeps the acoustic scale it was decoded with (only the CPU
 // decoders' wrappers undo it).  --determinize-lattice=false writes the trimmed state-level lattice as a Lattice table; the reference
@@ -42,7 +42,7 @@ int main(int argc, char **argv) {
     po.Register("cuda-decoder-copy-threads", &copy_threads, "(accepted, unused)");
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
-    po.Register("phone-determinize", &phone_det, "(accepted: the word-level pass alone gives the same best path per word sequence)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
+    po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)");
     po.Register("gpu-feature-extract", &gpu_feat, "Use GPU feature extraction (always true)"); po.Register("use-online-features", &use_online, "(only false is supported)");
     po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused: offline decoding)");
@@ -65,7 +65,7 @@ int main(int argc, char **argv) {
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     if (determinize && (!word_det || minimize)) K3H_ERR << "--word-determinize=false and --minimize=true are not supported";
-    DeterminizeLatticePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem;
+    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det;
     if (segmentation || use_online || add_pitch || !ivector_config.empty() || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
       K3H_ERR << "an option that needs a component outside the accelerated path was given (segmentation / online features / pitch / ivectors / PLP / CMVN / extra context)";
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);
@@ -106,7 +106,7 @@ int main(int argc, char **argv) {
     std::unique_ptr<DeterminizeSequencer> det_pool;
     if (writer && determinize) {
       DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
-      pc.beam = lattice_beam; pc.det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
+      pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
     }
     int num_task = 0, num_err = 0; double total_audio = 0.0;
     const auto t_start = std::chrono::steady_clock::now();

@@ -1,5 +1,6 @@
 // k3-host-tool -- developer/test aid for the host-side format readers (no GPU needed):
 //   k3-host-tool tid2pdf <model.mdl>          NumPdfs, NumTransitionIds, then TransitionIdToPdf(1..N)  (same output as oracle's dump-tid2pdf)
+//   k3-host-tool tidinfo <model.mdl>          per transition-id: phone, self-loop flag, start-of-phone flag
 //   k3-host-tool fstinfo <fst>                states arcs start, FNV-1a checksum of the CSR
 //   k3-host-tool copy-fst <fst-in> <fst-out>  read (vector|const) and write as vector
 #include <iostream>
@@ -15,6 +16,11 @@ int main(int argc, char **argv) {
       for (size_t t = 1; t < ti.id2pdf.size(); t++) std::cout << ti.id2pdf[t] << (t % 32 ? " " : "\n");
       std::cout << "\n"; return 0;
     }
+    if (cmd == "tidinfo" && argc == 3) {       // per transition-id: phone, IsSelfLoop, TransitionIdIsStartOfPhone (same output as oracle's dump-tidinfo)
+      TransitionInfo ti = ReadTransitionModel(argv[2]);
+      for (size_t t = 1; t < ti.id2pdf.size(); t++) std::cout << t << " " << ti.id2phone[t] << " " << (int)ti.self_loop[t] << " " << (int)ti.phone_start[t] << "\n";
+      return 0;
+    }
     if (cmd == "fstinfo" && argc == 3) {
       HostFst f = ReadFstKaldiGeneric(argv[2]);
       uint64_t h = 1469598103934665603ull; auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
@@ -23,6 +29,6 @@ int main(int argc, char **argv) {
       std::cout << f.NumStates() << " " << f.ilabel.size() << " " << f.start << " " << h << "\n"; return 0;
     }
     if (cmd == "copy-fst" && argc == 4) { WriteFstVector(ReadFstKaldiGeneric(argv[2]), argv[3]); return 0; }
-    std::cerr << "usage: k3-host-tool tid2pdf <mdl> | fstinfo <fst> | copy-fst <in> <out>\n"; return 1;
+    std::cerr << "usage: k3-host-tool tid2pdf <mdl> | tidinfo <mdl> | fstinfo <fst> | copy-fst <in> <out>\n"; return 1;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
 }

@@ -73,7 +73,8 @@ struct Wave { float samp_freq = 0; std::vector<float> samples; };   // channel 0
 Wave ReadWave(const std::string &rxfilename);
 
 // .mdl (text or binary): parses the TransitionModel in front of the nnet; id2pdf[0] is unused
-struct TransitionInfo { int32_t num_pdfs = 0; std::vector<int32_t> id2pdf; };
+// id2phone / self_loop / phone_start = TransitionIdToPhone, IsSelfLoop, TransitionIdIsStartOfPhone (hmm/transition-model.cc:790,925)
+struct TransitionInfo { int32_t num_pdfs = 0; std::vector<int32_t> id2pdf, id2phone; std::vector<char> self_loop, phone_start; };
 TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename);
 
 struct HostFst {          // generic CSR in FST arc order (input of k3_fst_create)
@@ -115,6 +116,12 @@ struct DeterminizeLatticePrunedOptions {     // lat/determinize-lattice-pruned.h
 // path only (costs and transition-id string).  Returns false when a limit of `opts` stopped it early (output pruned tighter).
 // Throws FatalError when the lattice has a cycle.
 bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *clat, const DeterminizeLatticePrunedOptions &opts = DeterminizeLatticePrunedOptions());
+// DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1410-1499): what the decoders call.  With phone_determinize a
+// first pass runs over the lattice with phone labels inserted at the phone boundaries (keeps the word pass's subsets small), then the
+// word-level pass.  word_determinize=false and minimize=true are not implemented (FatalError).
+struct DeterminizeLatticePhonePrunedOptions { float delta = 1.0f / 1024.0f; int32_t max_mem = 50000000; bool phone_determinize = true, word_determinize = true, minimize = false; };
+bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &trans, double beam, CompactLattice *clat,
+                                   const DeterminizeLatticePhonePrunedOptions &opts = DeterminizeLatticePhonePrunedOptions());
 void Connect(CompactLattice *clat);                        // fst::Connect; keeps the relative order of the surviving states
 void ScaleAcoustic(CompactLattice *clat, double scale);
 bool TopSortIfNeeded(CompactLattice *clat);                // TopSortCompactLatticeIfNeeded (lat/lattice-functions.cc); false on a cycle
@@ -159,7 +166,10 @@ class TableWriter {        // "ark:wxfilename" | "ark,t:wxfilename" (other optio
 // in flight (bounds memory).  An error inside a worker is re-thrown from the next Run() / Wait().
 class DeterminizeSequencer {
  public:
-  struct Config { int32_t num_threads = 1; double beam = 10.0, pre_scale = 1.0, post_scale = 1.0; bool topsort = false; DeterminizeLatticePrunedOptions det; };
+  struct Config {
+    int32_t num_threads = 1; double beam = 10.0, pre_scale = 1.0, post_scale = 1.0; bool topsort = false; DeterminizeLatticePrunedOptions det;
+    const TransitionInfo *trans = nullptr; DeterminizeLatticePhonePrunedOptions phone_det;       // trans != nullptr: DeterminizeLatticePhonePruned with phone_det
+  };
   DeterminizeSequencer(const Config &config, TableWriter *writer);
   ~DeterminizeSequencer();
   void Run(std::string key, Lattice &&lat);

@@ -8,9 +8,10 @@
 // word labels, per word sequence the cost and alignment of the best raw path, every word sequence within the beam kept), which is
 // what the reference's own determinize-lattice-pruned-test.cc does with RandEquivalent.
 //
-// What is deliberately not restated: the phone-level first pass of DeterminizeLatticePhonePruned (:1388-1407).  It is an efficiency
-// device (it bounds the subset sizes of the word pass); it yields the same best path per word sequence, but can pick a different one of
-// several equal-cost alignments and, when --max-mem stops it early, a different effective beam.  --minimize is not implemented.
+// Both entry points of the reference are here: DeterminizeLatticePruned (one word-level pass; lattice-determinize-pruned) and
+// DeterminizeLatticePhonePruned (phone-level pass first, then the word-level pass; what the decoders and
+// lattice-determinize-phone-pruned call).  Not implemented: --minimize (PushCompactLatticeStrings / Weights + MinimizeCompactLattice)
+// and --word-determinize=false (needs ConvertLattice's Factor).
 #include "k3_host.h"
 #include <algorithm>
 #include <cmath>
@@ -82,26 +83,42 @@ bool TopOrder(int32_t n, int32_t start, const std::vector<int32_t> &off, const s
   return true;
 }
 
-// Invert + TopSort + ArcSort(ILabelCompare) of the callers (lattice-determinize-pruned.cc:104-112)
-InputFst PrepareInput(const Lattice &lat_in) {
+// mutable edge-list form of the same automaton (word = input side, transition-id = output side), for the steps that add states
+struct EdgeFst {
+  int32_t start = -1; std::vector<LatW> fin; std::vector<int32_t> src, dst, word, tid; std::vector<LatW> w;
+  int32_t AddState() { fin.push_back(Zero()); return (int32_t)fin.size() - 1; }
+  void AddArc(int32_t s, int32_t d, int32_t wd, int32_t t, LatW wt) { src.push_back(s); dst.push_back(d); word.push_back(wd); tid.push_back(t); w.push_back(wt); }
+};
+
+// Invert (lattice-determinize-pruned.cc:104) after fst::Connect
+EdgeFst InvertedEdges(const Lattice &lat_in) {
   Lattice lat = lat_in; Connect(&lat);
-  InputFst f; const int32_t n = lat.NumStates(); const size_t na = lat.arc_src.size();
-  if (n == 0 || lat.start < 0) return f;
+  EdgeFst e; e.start = lat.NumStates() ? lat.start : -1;
+  for (int32_t s = 0; s < lat.NumStates(); s++) e.fin.push_back(std::isfinite(lat.st_final[s]) ? LatW{lat.st_final[s], lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]} : Zero());
+  for (size_t a = 0; a < lat.arc_src.size(); a++) e.AddArc(lat.arc_src[a], lat.arc_dst[a], lat.arc_olabel[a], lat.arc_ilabel[a], {lat.arc_graph[a], lat.arc_ac[a]});
+  return e;
+}
+
+// TopSort + ArcSort(ILabelCompare) (lattice-determinize-pruned.cc:106-112): states reachable from the start state in depth-first
+// topological order, the arcs of a state stably sorted on the word label
+InputFst SortedInput(const EdgeFst &e) {
+  InputFst f; const int32_t n = (int32_t)e.fin.size(); const size_t na = e.src.size();
+  if (n == 0 || e.start < 0) return f;
   std::vector<int32_t> off(n + 1, 0), idx(na), nx(na);
-  for (size_t a = 0; a < na; a++) off[lat.arc_src[a] + 1]++;
+  for (size_t a = 0; a < na; a++) off[e.src[a] + 1]++;
   for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
-  { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < na; a++) { const int32_t k = p[lat.arc_src[a]]++; idx[k] = (int32_t)a; nx[k] = lat.arc_dst[a]; } }
+  { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < na; a++) { const int32_t k = p[e.src[a]]++; idx[k] = (int32_t)a; nx[k] = e.dst[a]; } }
   std::vector<int32_t> order;
-  if (!TopOrder(n, lat.start, off, nx, &order)) K3H_ERR << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles).";
+  if (!TopOrder(n, e.start, off, nx, &order)) K3H_ERR << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles).";
   std::vector<int32_t> newid(n, -1); for (size_t i = 0; i < order.size(); i++) newid[order[i]] = (int32_t)i;
   const int32_t m = (int32_t)order.size();
-  f.start = newid[lat.start]; f.fin.resize(m); f.off.assign(m + 1, 0);
+  f.start = newid[e.start]; f.fin.resize(m); f.off.assign(m + 1, 0);
   for (int32_t i = 0; i < m; i++) {
     const int32_t s = order[i];
-    f.fin[i] = std::isfinite(lat.st_final[s]) ? LatW{lat.st_final[s], lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]} : Zero();
+    f.fin[i] = e.fin[s];
     std::vector<int32_t> arcs(idx.begin() + off[s], idx.begin() + off[s + 1]);
-    std::stable_sort(arcs.begin(), arcs.end(), [&](int32_t x, int32_t y) { return lat.arc_olabel[x] < lat.arc_olabel[y]; });
-    for (int32_t a : arcs) { f.word.push_back(lat.arc_olabel[a]); f.tid.push_back(lat.arc_ilabel[a]); f.next.push_back(newid[lat.arc_dst[a]]); f.w.push_back({lat.arc_graph[a], lat.arc_ac[a]}); }
+    std::stable_sort(arcs.begin(), arcs.end(), [&](int32_t x, int32_t y) { return e.word[x] < e.word[y]; });
+    for (int32_t a : arcs) { f.word.push_back(e.word[a]); f.tid.push_back(e.tid[a]); f.next.push_back(newid[e.dst[a]]); f.w.push_back(e.w[a]); }
     f.off[i + 1] = (int32_t)f.word.size();
   }
   return f;
@@ -193,6 +210,28 @@ class Determinizer {
     const bool done = queue_.empty();
     while (!queue_.empty()) { delete queue_.top(); queue_.pop(); }
     return done;
+  }
+
+  // :112-186: the same automaton as an ordinary FST; a string of k transition-ids becomes a chain of k arcs (weight and word on the
+  // first), a final weight with a string a chain into a new final state
+  void Output(EdgeFst *o) const {
+    *o = EdgeFst();
+    if (out_.empty()) return;
+    for (size_t s = 0; s < out_.size(); s++) o->AddState();
+    o->start = 0;
+    std::vector<int32_t> seq;
+    for (size_t s = 0; s < out_.size(); s++)
+      for (const TempArc &t : out_[s].arcs) {
+        trie_.ToVector(t.string, &seq);
+        int32_t cur = (int32_t)s;
+        if (t.next < 0) {
+          for (size_t i = 0; i < seq.size(); i++) { const int32_t nx = o->AddState(); o->AddArc(cur, nx, 0, seq[i], i == 0 ? t.w : One()); cur = nx; }
+          o->fin[cur] = seq.empty() ? t.w : One();
+        } else {
+          for (size_t i = 0; i + 1 < seq.size(); i++) { const int32_t nx = o->AddState(); o->AddArc(cur, nx, i == 0 ? t.label : 0, seq[i], i == 0 ? t.w : One()); cur = nx; }
+          o->AddArc(cur, t.next, seq.size() <= 1 ? t.label : 0, seq.empty() ? 0 : seq.back(), seq.size() <= 1 ? t.w : One());
+        }
+      }
   }
 
   void Output(CompactLattice *o) const {                     // :61-107: one output state per determinized state, final weights from the kNoState arcs
@@ -437,19 +476,17 @@ class Determinizer {
 };
 }  // namespace
 
-// lat/determinize-lattice-pruned.cc:1190-1236: determinize; when a limit cut it short at less than retry_cutoff x beam, prune the
-// raw lattice to a narrower beam and start over (at most 10 times)
-bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *clat, const DeterminizeLatticePrunedOptions &opts) {
+namespace {
+// lat/determinize-lattice-pruned.cc:1190-1236 / :1243-1287: determinize; when a limit cut it short at less than retry_cutoff x beam,
+// prune the raw lattice to a narrower beam and start over (at most 10 times).  `emit` receives the determinizer that is kept.
+template <class Emit> bool DeterminizeWithRetries(InputFst f, double beam, const DeterminizeLatticePrunedOptions &opts, Emit emit) {
   if (!(beam > 0.0)) K3H_ERR << "DeterminizeLatticePruned: beam must be positive, got " << beam;
   if (!(opts.retry_cutoff >= 0.0f && opts.retry_cutoff < 1.0f)) K3H_ERR << "DeterminizeLatticePruned: retry-cutoff must be in [0, 1)";
-  InputFst f = PrepareInput(lat);
-  *clat = CompactLattice();
-  if (f.NumStates() == 0) return true;
   for (int iter = 0;; iter++) {
     Determinizer det(f, beam, opts);
     double effective_beam;
     const bool ans = det.Determinize(&effective_beam);
-    if (effective_beam >= beam * opts.retry_cutoff || beam == kInfD || iter + 1 == 10) { det.Output(clat); Connect(clat); return ans; }
+    if (effective_beam >= beam * opts.retry_cutoff || beam == kInfD || iter + 1 == 10) { emit(det); return ans; }
     if (effective_beam < 0.0) effective_beam = 0.0;
     double new_beam = beam * std::sqrt(effective_beam / beam);
     if (new_beam < 0.5 * beam) new_beam = 0.5 * beam;
@@ -458,6 +495,53 @@ bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *c
     K3H_LOG << "Pruned state-level lattice with beam " << beam << " and retrying determinization with that beam.";
     if (f.NumStates() == 0) return false;
   }
+}
+
+// DeterminizeLatticeInsertPhones (:1291-1343): a phone label on the word side of every arc that starts a phone (a non-self-loop
+// transition out of HMM state 0), on an extra arc when the arc already carries a word; arcs leaving the start state are left alone.
+// Returns the first label used for phones.
+int32_t InsertPhones(const TransitionInfo &ti, EdgeFst *e) {
+  int32_t first = 1; for (int32_t wd : e->word) first = std::max(first, wd + 1);
+  const size_t na = e->src.size();
+  for (size_t a = 0; a < na; a++) {
+    const int32_t t = e->tid[a];
+    if (e->src[a] == e->start || t == 0) continue;
+    if (t < 0 || t >= (int32_t)ti.id2phone.size()) K3H_ERR << "Lattice has transition-id " << t << " but the model has " << ti.id2phone.size() - 1;
+    if (!ti.phone_start[t] || ti.self_loop[t]) continue;
+    const int32_t label = first + ti.id2phone[t];
+    if (e->word[a] == 0) e->word[a] = label;
+    else { const int32_t x = e->AddState(); e->AddArc(x, e->dst[a], label, 0, One()); e->dst[a] = x; }
+  }
+  return first;
+}
+}  // namespace
+
+bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *clat, const DeterminizeLatticePrunedOptions &opts) {
+  *clat = CompactLattice();
+  InputFst f = SortedInput(InvertedEdges(lat));
+  if (f.NumStates() == 0) return true;
+  return DeterminizeWithRetries(std::move(f), beam, opts, [&](const Determinizer &det) { det.Output(clat); Connect(clat); });
+}
+
+// DeterminizeLatticePhonePrunedWrapper (:1479-1499) -> DeterminizeLatticePhonePruned (:1410-1462): first a pass over the lattice with
+// phone labels inserted at the phone boundaries (DeterminizeLatticePhonePrunedFirstPass :1388-1407; its output is an ordinary FST,
+// no longer deterministic once the phone labels are deleted again), then the word-level pass.
+bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &trans, double beam, CompactLattice *clat, const DeterminizeLatticePhonePrunedOptions &opts) {
+  if (opts.minimize) K3H_ERR << "DeterminizeLatticePhonePruned: --minimize=true is not supported";
+  if (!opts.word_determinize) K3H_ERR << "DeterminizeLatticePhonePruned: --word-determinize=false is not supported";
+  DeterminizeLatticePrunedOptions det_opts; det_opts.delta = opts.delta; det_opts.max_mem = opts.max_mem;
+  if (!opts.phone_determinize) return DeterminizeLatticePruned(lat, beam, clat, det_opts);
+  *clat = CompactLattice();
+  EdgeFst e = InvertedEdges(lat);
+  if (e.fin.empty()) return true;
+  const int32_t first_phone_label = InsertPhones(trans, &e);
+  InputFst f = SortedInput(e);
+  EdgeFst pass1;
+  bool ans = DeterminizeWithRetries(std::move(f), beam, det_opts, [&](const Determinizer &det) { det.Output(&pass1); });
+  for (int32_t &wd : pass1.word) if (wd >= first_phone_label) wd = 0;          // DeterminizeLatticeDeletePhones :1346-1368
+  InputFst g = SortedInput(pass1);
+  if (g.NumStates() == 0) return ans;
+  return DeterminizeWithRetries(std::move(g), beam, det_opts, [&](const Determinizer &det) { det.Output(clat); Connect(clat); }) && ans;
 }
 
 bool PruneLattice(double beam, Lattice *lat) {
@@ -608,7 +692,8 @@ struct DeterminizeSequencer::Impl {
       CompactLattice clat; bool warn = false; std::string err;
       try {
         if (cfg.pre_scale != 1.0) ScaleAcoustic(&job.lat, cfg.pre_scale);
-        if (!DeterminizeLatticePruned(job.lat, cfg.beam, &clat, cfg.det)) { K3H_WARN << "For key " << job.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; warn = true; }
+        const bool ok = cfg.trans ? DeterminizeLatticePhonePruned(job.lat, *cfg.trans, cfg.beam, &clat, cfg.phone_det) : DeterminizeLatticePruned(job.lat, cfg.beam, &clat, cfg.det);
+        if (!ok) { K3H_WARN << "For key " << job.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; warn = true; }
         if (clat.NumStates() == 0) { K3H_WARN << "For key " << job.key << ", determinized and trimmed lattice was empty."; warn = true; }
         if (cfg.topsort && !TopSortIfNeeded(&clat)) K3H_WARN << "Topological sorting of the determinized lattice failed for key " << job.key;
         if (cfg.post_scale != 1.0) ScaleAcoustic(&clat, cfg.post_scale);

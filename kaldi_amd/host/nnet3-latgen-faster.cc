@@ -2,10 +2,9 @@
 //   nnet3-latgen-faster [options] <nnet-in> <fst-in> <features-rspecifier> <lattice-wspecifier> [ <words-wspecifier> [<alignments-wspecifier>] ]
 // = DecodableAmNnetSimple + LatticeFasterDecoder + DecodeUtteranceLatticeFaster (decoder/decoder-wrappers.cc:287-382) per utterance in
 // the reference; here all utterances of a batch run through k3_nnet_forward and k3_decoder_decode_batch.  Like the reference it
-// determinizes by default and writes CompactLattices (decoder-wrappers.cc:354-368); the determinizer is the host-side word-level
-// restatement in k3_lattice.cc (no phone-level first pass: --phone-determinize is accepted and has no effect on the result beyond the
-// choice among equal-cost alignments; --word-determinize=false and --minimize=true are rejected).  --determinize-lattice=false writes
-// the raw state-level lattice.
+// determinizes by default and writes CompactLattices (decoder-wrappers.cc:354-368); the determinizer is the host-side restatement
+// of DeterminizeLatticePhonePrunedWrapper in k3_lattice.cc (--word-determinize=false and --minimize=true are rejected).
+// --determinize-lattice=false writes the raw state-level lattice.
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -29,7 +28,7 @@ int main(int argc, char **argv) {
     po.Register("prune-interval", &prune_interval, "(accepted; pruning runs once after the last frame and gives the same lattice)"); po.Register("determinize-lattice", &determinize, "If true, determinize the lattice (lattice-determinization, keeping only best pdf-sequence for each word-sequence).");
     po.Register("beam-delta", &beam_delta, "Increment used in decoding-- this parameter is obscure and relates to a speedup in the way the max-active constraint is applied.");
     po.Register("hash-ratio", &hash_ratio, "(accepted, unused: no hash-order dependence)"); po.Register("prune-scale", &prune_scale, "(accepted, unused)");
-    po.Register("max-mem", &max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this)."); po.Register("phone-determinize", &phone_det, "(accepted: the word-level pass alone gives the same best path per word sequence)");
+    po.Register("max-mem", &max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this)."); po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)");
     po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)"); po.Register("delta", &delta, "Tolerance used in determinization");
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods"); po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
@@ -40,7 +39,7 @@ int main(int argc, char **argv) {
     po.Read(argc, argv);
     if (po.NumArgs() < 4 || po.NumArgs() > 6) { po.PrintUsage(); return 1; }
     if (determinize && (!word_det || minimize)) K3H_ERR << "--word-determinize=false and --minimize=true are not supported";
-    DeterminizeLatticePrunedOptions det_opts; det_opts.delta = delta; det_opts.max_mem = max_mem;
+    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = delta; det_opts.max_mem = max_mem; det_opts.phone_determinize = phone_det;
     if (!ivector_rspecifier.empty() || !online_ivector_rspecifier.empty() || elc || erc) K3H_ERR << "i-vectors / extra context are not supported by this program";
     const std::string model_rx = po.GetArg(1), fst_rx = po.GetArg(2);
     if (fst_rx.find(':') != std::string::npos && fst_rx.compare(0, 3, "ark") == 0) K3H_ERR << "a table of per-utterance FSTs is not supported; give one HCLG";
@@ -106,7 +105,7 @@ int main(int argc, char **argv) {
         Connect(&lat);
         if (determinize) {
           CompactLattice clat;
-          if (!DeterminizeLatticePruned(lat, lattice_beam, &clat, det_opts)) K3H_WARN << "Determinization finished earlier than the beam for utterance " << utt;
+          if (!DeterminizeLatticePhonePruned(lat, ti, lattice_beam, &clat, det_opts)) K3H_WARN << "Determinization finished earlier than the beam for utterance " << utt;
           if (acoustic_scale != 0.0f) ScaleAcoustic(&clat, 1.0 / acoustic_scale);
           lat_writer.WriteCompactLattice(utt, clat);
         } else {

@@ -67,6 +67,7 @@ link nnet3-copy          $R/nnet3bin/nnet3-copy.cc
 link nnet3-am-info       $R/nnet3bin/nnet3-am-info.cc
 link nnet3-am-copy       $R/nnet3bin/nnet3-am-copy.cc
 link dump-tid2pdf        $HERE/ref_tools/dump_tid2pdf.cc
+link dump-tidinfo        $HERE/ref_tools/dump_tidinfo.cc
 for f in /opt/conda/lib/libmkl_{rt,core,intel_lp64,sequential,gnu_thread,intel_thread,avx2,avx512,def,mc3,vml_avx2,vml_avx512,vml_def}.so.1; do
   [ -e $f ] && ln -sf $f $W/mkl/ || true; done
 cat > $W/env.sh <<EOS

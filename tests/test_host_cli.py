@@ -27,6 +27,19 @@ def test_transition_model_parser_matches_the_reference_class(tmp_path):
     assert _run(os.path.join(BIN, "k3-host-tool"), "tid2pdf", txt).stdout == ref
     assert np.array_equal(np.array(ref.split()[2:], int), synth.tid2pdf(N)[1:])
 
+def test_transition_id_phone_info_matches_the_reference_class(tmp_path):
+    """TransitionIdToPhone / IsSelfLoop / TransitionIdIsStartOfPhone for every transition-id (what the phone-level determinization
+    pass asks of the model) against the reference's TransitionModel, binary and text .mdl"""
+    if not os.path.exists(os.path.join(REF, "dump-tidinfo")): pytest.skip("oracle/_ref not built (needs /root/reference)")
+    N = 30; mdl = str(tmp_path / "m.mdl")
+    synth.make_tdnn(seed=1, dim=64, num_pdfs=N).write(mdl, as_mdl=True, num_pdfs=N, left_context=5, right_context=5)
+    ref = _run(os.path.join(REF, "dump-tidinfo"), mdl, env=ENV).stdout
+    assert len(ref.splitlines()) > N
+    assert _run(os.path.join(BIN, "k3-host-tool"), "tidinfo", mdl).stdout == ref
+    txt = str(tmp_path / "m.txt")
+    assert _run(os.path.join(REF, "nnet3-am-copy"), "--binary=false", mdl, txt, env=ENV).returncode == 0
+    assert _run(os.path.join(BIN, "k3-host-tool"), "tidinfo", txt).stdout == ref
+
 def test_openfst_binary_reader_and_writer_round_trip(tmp_path):
     f = synth.make_hclg(300, 700, 20, seed=3, start_degree=8)
     a, b = str(tmp_path / "g.fst"), str(tmp_path / "g2.fst")

@@ -271,3 +271,58 @@ def test_parallel_program_writes_in_input_order_and_matches_the_serial_one():
     r = subprocess.run([par, "--num-threads=3", "ark:-", "ark,t:-"], input=inp2, capture_output=True, timeout=120)
     assert r.returncode != 0 and b"Topological sorting" in r.stderr
     assert subprocess.run([par], capture_output=True).returncode == 1
+
+
+# ---- the two-pass (phone, then word) determinization the decoders apply: lattice-determinize-phone-pruned
+PHONE_PROG = PROG.replace("lattice-determinize-pruned", "lattice-determinize-phone-pruned")
+
+@pytest.fixture(scope="module")
+def mdl(tmp_path_factory):
+    """a transition model with 20 one-state phones: transition-ids 2p-1 (self-loop) and 2p (forward = start of the phone)"""
+    from kaldi_amd import synth
+    path = str(tmp_path_factory.mktemp("mdl") / "final.mdl")
+    synth.make_tdnn(seed=1, dim=32, num_pdfs=20).write(path, as_mdl=True, num_pdfs=20, left_context=2, right_context=2)
+    return path
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("beam", [1.0, 1000.0])
+def test_phone_pruned_two_pass_properties(mdl, seed, beam):
+    lat = lc.random_lattice(500 + seed, frames=5 + seed % 3, width=3 + seed % 2, words=2 + seed % 3, tids=40)
+    inp = lc.lattice_text("u", lat).encode()
+    r = subprocess.run([PHONE_PROG, "--beam=%g" % beam, mdl, "ark:-", "ark,t:-"], input=inp, capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    out = lc.parse_compact_text(r.stdout.decode())["u"]
+    raw, det = _check(lat, out, beam)
+    # same word sequences and costs as the single word-level pass wherever the beam guarantees them
+    one = lc.enumerate_compact(lc.parse_compact_text(_run(["--beam=%g" % beam], inp).stdout.decode())["u"])
+    best = min(v[0][0] for v in det.values())
+    for w, v in one.items():
+        if v[0][0] <= best + beam - TOL:
+            assert w in det and abs(det[w][0][0] - v[0][0]) <= TOL
+    if beam >= 1000.0: assert set(det) == set(one) == set(raw)
+    # --phone-determinize=false is the single pass
+    r2 = subprocess.run([PHONE_PROG, "--beam=%g" % beam, "--phone-determinize=false", mdl, "ark:-", "ark,t:-"], input=inp, capture_output=True, timeout=120)
+    assert r2.returncode == 0 and lc.enumerate_compact(lc.parse_compact_text(r2.stdout.decode())["u"]) == one
+
+
+def test_phone_pruned_on_decoder_oracle_lattices_and_errors(mdl):
+    from kaldi_amd import synth
+    from oracle import lattice_oracle as lo
+    T = 50; N = 20
+    f = synth.make_hclg(1500, 4000, N, seed=5, start_degree=30)
+    ll = (np.random.default_rng(9).standard_normal((T, N)) * 2.5).astype(np.float32)
+    raw = lo.decode(f, ll, synth.tid2pdf(N), lo.Config(beam=15.0, lattice_beam=6.0, max_active=10000), 1)[0].connect()
+    lat = dict(start=raw.start_index(), n=raw.num_states, finals={int(s): (float(raw.st_final[s]), 0.0) for s in np.nonzero(np.isfinite(raw.st_final))[0]},
+               arcs=[(int(s), int(d), int(i), int(o), float(g), float(a)) for s, d, i, o, g, a in zip(raw.arc_src, raw.arc_dst, raw.arc_ilabel, raw.arc_olabel, raw.arc_graph, raw.arc_ac)])
+    r = subprocess.run([PHONE_PROG, "--beam=6", mdl, "ark:-", "ark,t:-"], input=lc.lattice_binary("utt", lat), capture_output=True, timeout=120)
+    assert r.returncode == 0 and b"did not succeed" not in r.stderr, r.stderr.decode()
+    out = lc.parse_compact_text(r.stdout.decode())["utt"]
+    assert 0 < len(out["arcs"]) < raw.num_arcs
+    _check_sampled(lat, out, T, samples=25, tol=0.01)
+    # a transition-id the model does not have, unsupported variants, usage
+    bad = dict(start=0, n=3, finals={2: (0.0, 0.0)}, arcs=[(0, 1, 3, 1, 1.0, 1.0), (1, 2, 4000, 2, 1.0, 1.0)])
+    r = subprocess.run([PHONE_PROG, mdl, "ark:-", "ark,t:-"], input=lc.lattice_text("b", bad).encode(), capture_output=True)
+    assert r.returncode != 0 and b"transition-id 4000" in r.stderr
+    assert subprocess.run([PHONE_PROG, "--minimize=true", mdl, "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
+    assert subprocess.run([PHONE_PROG, mdl], capture_output=True).returncode == 1
