@@ -107,13 +107,13 @@ def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
     cmd[-1] = f"ark:{td}/lat.ark"
     assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
     assert os.path.getsize(f"{td}/lat.ark") > 1000 and open(f"{td}/lat.ark", "rb").read(9) == b"utt0 \xd6\xfd\xb2\x7e"
-    # default: determinized CompactLattices.  Must equal what lattice-determinize-pruned (same host code, CPU program) makes of the
+    # default: determinized CompactLattices.  Must equal what lattice-determinize-phone-pruned (same host code, CPU program) makes of the
     # raw binary archive above, and its best path must spell the raw lattice's best word sequence.
     from tests import lattice_cases as lc
     cmd_det = [c for c in cmd if not c.startswith("--determinize")]; cmd_det[-1] = f"ark,t:{td}/det.txt"
     r = subprocess.run(cmd_det, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    r2 = subprocess.run([os.path.join(BIN, "lattice-determinize-pruned"), "--beam=8.0", "--acoustic-scale=1.0", f"ark:{td}/lat.ark", f"ark,t:{td}/det2.txt"], capture_output=True, text=True)
+    r2 = subprocess.run([os.path.join(BIN, "lattice-determinize-phone-pruned"), "--beam=8.0", "--acoustic-scale=1.0", f"{td}/final.mdl", f"ark:{td}/lat.ark", f"ark,t:{td}/det2.txt"], capture_output=True, text=True)
     assert r2.returncode == 0, r2.stderr
     det, det2 = lc.parse_compact_text(open(f"{td}/det.txt").read()), lc.parse_compact_text(open(f"{td}/det2.txt").read())
     assert list(det) == list(det2) == ["utt0", "utt1", "utt2"]
