@@ -12,9 +12,13 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <array>
+#include <functional>
+#include <future>
 #include <iostream>
 #include <thread>
 #include "k3_feat_options.h"
+#include "k3_online.h"
 using namespace k3host;
 #define HIPCHK(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) K3H_ERR << "HIP error " << hipGetErrorName(e__) << " in " << #e; } while (0)
 
@@ -39,7 +43,7 @@ int main(int argc, char **argv) {
     po.Register("max-batch-size", &max_batch, "The maximum execution batch size (utterances decoded together)");
     po.Register("num-channels", &num_channels, "(accepted; whole-utterance batching needs no separate channel pool)");
     po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
-    po.Register("cuda-decoder-copy-threads", &copy_threads, "(accepted, unused)");
+    po.Register("cuda-decoder-copy-threads", &copy_threads, "Number of worker threads that read the wave files and fill the pinned staging buffers.");
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
     po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
@@ -109,63 +113,107 @@ int main(int argc, char **argv) {
       pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
     }
     int num_task = 0, num_err = 0; double total_audio = 0.0;
-    const auto t_start = std::chrono::steady_clock::now();
-    for (int iter = 0; iter < iterations; iter++) {
-      for (size_t b0 = 0; b0 < scp.size(); b0 += max_batch) {
-        const size_t b1 = std::min(scp.size(), b0 + (size_t)max_batch);
-        std::vector<std::string> keys; std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int32_t> nframes;
-        for (size_t i = b0; i < b1; i++) {
-          Wave w;
-          try { w = ReadWave(scp[i].second); } catch (const FatalError &) { num_err++; continue; }
-          if (w.samp_freq != fopts.samp_freq) { K3H_WARN << "Sample frequency mismatch for " << scp[i].first; num_err++; continue; }
-          const int nf = k3_feat_num_frames(plan, (int64_t)w.samples.size());
-          if (nf == 0) { K3H_WARN << "Utterance " << scp[i].first << " is too short to decode"; num_err++; continue; }
-          keys.push_back(scp[i].first); all.insert(all.end(), w.samples.begin(), w.samples.end()); woff.push_back((int64_t)all.size()); foff.push_back(foff.back() + nf); nframes.push_back(nf);
-          total_audio += w.samples.size() / (double)w.samp_freq; num_task++;
-        }
-        if (keys.empty()) continue;
-        const int U = (int)keys.size(); const int64_t tot = foff.back();
-        float *d_w, *d_f, *d_ll; int64_t *d_wo, *d_fo;
-        HIPCHK(hipMalloc((void **)&d_w, all.size() * 4)); HIPCHK(hipMalloc((void **)&d_f, (size_t)tot * fdim * 4));
-        HIPCHK(hipMalloc((void **)&d_wo, woff.size() * 8)); HIPCHK(hipMalloc((void **)&d_fo, foff.size() * 8));
-        HIPCHK(hipMemcpy(d_w, all.data(), all.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_wo, woff.data(), woff.size() * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_fo, foff.data(), foff.size() * 8, hipMemcpyHostToDevice));
-        K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w, d_wo, d_fo, U, tot, d_f, fdim, nullptr));
-        k3_nnet_batch *nb = nullptr;
-        K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
-        std::vector<int64_t> ro(U + 1); const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
-        HIPCHK(hipMalloc((void **)&d_ll, (size_t)rows * ninfo.output_dim * 4));
-        K3H_CHECK_K3(k3_nnet_forward(nb, d_f, fdim, d_ll, ninfo.output_dim, nullptr));
-        K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_ll, ninfo.output_dim, ro.data(), nullptr));
-        std::vector<int64_t> info(10 * (size_t)U); K3H_CHECK_K3(k3_decoder_lattice_info(dec, info.data()));
-        if (iter == 0 && writer) {
-          int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
-          std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
-          K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));
-          int64_t s0 = 0, a0 = 0;
-          for (int u = 0; u < U; u++) {
-            const int64_t ns = info[10 * u], na = info[10 * u + 1];
-            if (info[10 * u + 2] != 0 || ns == 0) { K3H_WARN << "Failed to decode utterance with id " << keys[u]; num_err++; s0 += ns; a0 += na; continue; }
-            if (!info[10 * u + 3]) K3H_WARN << "Outputting partial output for utterance " << keys[u] << " since no final-state reached";
-            Lattice lat; lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns); lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
-            lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na); lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na); lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
-            lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
-            for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
-            Connect(&lat);
-            if (det_pool) det_pool->Run(keys[u], std::move(lat)); else writer->WriteLattice(keys[u], lat);
-            s0 += ns; a0 += na;
-          }
-        }
-        k3_nnet_batch_destroy(nb);
-        HIPCHK(hipFree(d_w)); HIPCHK(hipFree(d_f)); HIPCHK(hipFree(d_wo)); HIPCHK(hipFree(d_fo)); HIPCHK(hipFree(d_ll));
+
+    // Three overlapped stages, one batch apart (the reference overlaps the same work with its thread pool and copy threads):
+    //   reader  (background): ReadWave on --cuda-decoder-copy-threads threads into one of two pinned staging buffers
+    //   GPU     (this thread): async H2D from the pinned buffer, features, network, decoder, raw lattices back to the host
+    //   post    (background): per-utterance Lattice objects, fst::Connect, then the determinization pool or the raw writer
+    struct Batch { std::vector<std::string> keys; std::vector<int64_t> woff, foff; std::vector<int32_t> nframes; int slot = 0, iter = 0, num_err = 0; double audio = 0.0; };
+    struct Pinned { float *p = nullptr; size_t cap = 0; };
+    Pinned pinned[2];
+    const int n_read_threads = std::max(1, copy_threads);
+    auto load_batch = [&](size_t b0, size_t b1, int slot, int iter) {
+      Batch b; b.slot = slot; b.iter = iter; b.woff.assign(1, 0); b.foff.assign(1, 0);
+      std::vector<Wave> waves(b1 - b0); std::vector<char> bad(b1 - b0, 0);
+      auto parallel = [&](const std::function<void(size_t)> &fn) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_read_threads; t++) th.emplace_back([&, t] { for (size_t i = t; i < waves.size(); i += n_read_threads) fn(i); });
+        for (auto &x : th) x.join();
+      };
+      parallel([&](size_t i) { try { waves[i] = ReadWave(scp[b0 + i].second); } catch (const std::exception &) { bad[i] = 1; } });
+      std::vector<size_t> src;
+      for (size_t i = 0; i < waves.size(); i++) {
+        const Wave &w = waves[i];
+        if (bad[i]) { b.num_err++; continue; }
+        if (w.samp_freq != fopts.samp_freq) { K3H_WARN << "Sample frequency mismatch for " << scp[b0 + i].first; b.num_err++; continue; }
+        const int nf = k3_feat_num_frames(plan, (int64_t)w.samples.size());
+        if (nf == 0) { K3H_WARN << "Utterance " << scp[b0 + i].first << " is too short to decode"; b.num_err++; continue; }
+        b.keys.push_back(scp[b0 + i].first); src.push_back(i); b.woff.push_back(b.woff.back() + (int64_t)w.samples.size()); b.foff.push_back(b.foff.back() + nf); b.nframes.push_back(nf);
+        b.audio += w.samples.size() / (double)w.samp_freq;
       }
+      Pinned &pb = pinned[slot]; const size_t need = (size_t)b.woff.back();
+      if (need > pb.cap) { if (pb.p) HIPCHK(hipHostFree(pb.p)); pb.cap = need + need / 4 + 1024; HIPCHK(hipHostMalloc((void **)&pb.p, pb.cap * sizeof(float), hipHostMallocDefault)); }
+      std::vector<std::thread> th;
+      for (int t = 0; t < n_read_threads; t++) th.emplace_back([&, t] { for (size_t k = t; k < src.size(); k += n_read_threads) memcpy(pb.p + b.woff[k], waves[src[k]].samples.data(), waves[src[k]].samples.size() * sizeof(float)); });
+      for (auto &x : th) x.join();
+      return b;
+    };
+    struct Raw { std::vector<std::string> keys; std::vector<int64_t> info; std::vector<int32_t> sf, ss, as, ad, ai, ao; std::vector<float> sc, sfin, ag, aa; };
+    int post_err = 0;
+    auto post_process = [&](std::shared_ptr<Raw> r) {
+      int64_t s0 = 0, a0 = 0; const int U = (int)r->keys.size();
+      for (int u = 0; u < U; u++) {
+        const int64_t ns = r->info[10 * u], na = r->info[10 * u + 1]; const std::string &key = r->keys[u];
+        if (r->info[10 * u + 2] != 0 || ns == 0) { K3H_WARN << "Failed to decode utterance with id " << key; post_err++; s0 += ns; a0 += na; continue; }
+        if (!r->info[10 * u + 3]) K3H_WARN << "Outputting partial output for utterance " << key << " since no final-state reached";
+        Lattice lat; lat.st_frame.assign(r->sf.begin() + s0, r->sf.begin() + s0 + ns); lat.st_state.assign(r->ss.begin() + s0, r->ss.begin() + s0 + ns); lat.st_final.assign(r->sfin.begin() + s0, r->sfin.begin() + s0 + ns);
+        lat.arc_src.assign(r->as.begin() + a0, r->as.begin() + a0 + na); lat.arc_dst.assign(r->ad.begin() + a0, r->ad.begin() + a0 + na); lat.arc_ilabel.assign(r->ai.begin() + a0, r->ai.begin() + a0 + na);
+        lat.arc_olabel.assign(r->ao.begin() + a0, r->ao.begin() + a0 + na); lat.arc_graph.assign(r->ag.begin() + a0, r->ag.begin() + a0 + na); lat.arc_ac.assign(r->aa.begin() + a0, r->aa.begin() + a0 + na);
+        for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
+        Connect(&lat);
+        if (det_pool) det_pool->Run(key, std::move(lat)); else writer->WriteLattice(key, lat);
+        s0 += ns; a0 += na;
+      }
+    };
+    // the list of (iteration, first file, last file) batches
+    std::vector<std::array<size_t, 3>> plan_batches;
+    for (int iter = 0; iter < iterations; iter++) for (size_t b0 = 0; b0 < scp.size(); b0 += max_batch) plan_batches.push_back({(size_t)iter, b0, std::min(scp.size(), b0 + (size_t)max_batch)});
+    DevBuf<float> d_w, d_f, d_ll; DevBuf<int64_t> d_wo, d_fo;
+    std::future<Batch> next; std::future<void> post;
+    const auto t_start = std::chrono::steady_clock::now();
+    if (!plan_batches.empty()) next = std::async(std::launch::async, load_batch, plan_batches[0][1], plan_batches[0][2], 0, (int)plan_batches[0][0]);
+    for (size_t k = 0; k < plan_batches.size(); k++) {
+      auto tick = [] { return std::chrono::steady_clock::now(); }; auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      const auto t_a = tick();
+      Batch b = next.get();
+      const auto t_b = tick();
+      if (k + 1 < plan_batches.size()) next = std::async(std::launch::async, load_batch, plan_batches[k + 1][1], plan_batches[k + 1][2], (int)((k + 1) & 1), (int)plan_batches[k + 1][0]);
+      num_err += b.num_err; if (b.iter == 0) { total_audio += b.audio; num_task += (int)b.keys.size(); }      // per iteration, like the reference's counters
+      if (b.keys.empty()) continue;
+      const int U = (int)b.keys.size(); const int64_t tot = b.foff.back(), nsamp = b.woff.back();
+      HIPCHK(hipMemcpyAsync(d_w.need((size_t)nsamp), pinned[b.slot].p, (size_t)nsamp * sizeof(float), hipMemcpyHostToDevice, nullptr));
+      d_wo.upload(b.woff); d_fo.upload(b.foff);
+      K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w.p, d_wo.p, d_fo.p, U, tot, d_f.need((size_t)tot * fdim), fdim, nullptr));
+      k3_nnet_batch *nb = nullptr;
+      K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
+      std::vector<int64_t> ro(U + 1); const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
+      K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
+      K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_ll.p, ninfo.output_dim, ro.data(), nullptr));
+      auto r = std::make_shared<Raw>(); r->info.resize(10 * (size_t)U);
+      K3H_CHECK_K3(k3_decoder_lattice_info(dec, r->info.data()));
+      const auto t_c = tick();
+      if (b.iter == 0 && writer) {
+        int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += r->info[10 * u]; NA += r->info[10 * u + 1]; }
+        r->sf.resize(NS + 1); r->ss.resize(NS + 1); r->sc.resize(NS + 1); r->sfin.resize(NS + 1);
+        r->as.resize(NA + 1); r->ad.resize(NA + 1); r->ai.resize(NA + 1); r->ao.resize(NA + 1); r->ag.resize(NA + 1); r->aa.resize(NA + 1);
+        K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, r->sf.data(), r->ss.data(), r->sc.data(), r->sfin.data(), r->as.data(), r->ad.data(), r->ai.data(), r->ao.data(), r->ag.data(), r->aa.data()));
+        r->keys = std::move(b.keys);
+        if (post.valid()) post.get();          // keeps the records in order; an error in the previous batch's post stage surfaces here
+        post = std::async(std::launch::async, post_process, r);
+      } else {
+        for (int u = 0; u < U; u++) if (r->info[10 * u + 2] != 0 || r->info[10 * u] == 0) { K3H_WARN << "Failed to decode utterance with id " << b.keys[u]; num_err++; }
+      }
+      k3_nnet_batch_destroy(nb);
+      K3H_VLOG(1) << "batch " << k << ": waited " << ms(t_a, t_b) << " ms for the reader, " << ms(t_b, t_c) << " ms upload + features + network + decoder, " << ms(t_c, tick()) << " ms lattices to the host + hand-over";
     }
+    if (post.valid()) post.get();
+    num_err += post_err;
     HIPCHK(hipDeviceSynchronize());
     if (det_pool) { det_pool->Wait(); det_pool.reset(); }
     if (writer) writer->Flush();
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
-    K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio << " RealTimeX: " << total_audio / total_time;
+    K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio * iterations << " RealTimeX: " << total_audio * iterations / total_time;
     k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan);
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
