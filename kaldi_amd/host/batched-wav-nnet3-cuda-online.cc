@@ -23,7 +23,7 @@ int main(int argc, char **argv) {
         "Reads in wav file(s) and simulates online decoding with neural nets (nnet3 setup), the audio of several files being fed chunk by chunk.\n"
         "Usage: batched-wav-nnet3-cuda-online [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
     ParseOptions po(usage);
-    bool write_lattice = true, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
+    bool write_compact = true, write_lattice = true, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
     int32_t worker_threads = -1;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, frames_per_chunk = 51, subsampling = 1, num_streaming = 2000;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, max_frames = 6000;
@@ -37,6 +37,7 @@ int main(int argc, char **argv) {
     po.Register("num-channels", &num_channels, "The number of parallel audio channels (-1 = max-batch-size)");
     po.Register("num-parallel-streaming-channels", &num_streaming, "(accepted; the streams are fed round-robin over --num-channels)");
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
+    po.Register("write-compact", &write_compact, "(not in the reference) with --determinize-lattice=false: true = the state-level lattice re-packed as a CompactLattice like the reference (ConvertLattice), false = written as a Lattice table");
     po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
     po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
@@ -197,7 +198,9 @@ int main(int argc, char **argv) {
               lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
               for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
               Connect(&lat);
-              if (det_pool) det_pool->Run(key, std::move(lat)); else writer->WriteLattice(key, lat);
+              if (det_pool) det_pool->Run(key, std::move(lat));
+        else if (write_compact) { CompactLattice clat; ConvertLattice(lat, &clat); writer->WriteCompactLattice(key, clat); }
+        else writer->WriteLattice(key, lat);
             }
             s0 += ns; a0 += na;
             chan[ended[u]] = Chan(); busy--;

@@ -6,8 +6,8 @@
 // k3_decoder_decode_batch -> raw lattices -> (default, like BatchedThreadedNnet3CudaOnlinePipelineConfig::determinize_lattice) phone- then word-level
 // pruned determinization on the host (k3_lattice.cc; beam = --lattice-beam, batched-threaded-nnet3-cuda-online-pipeline.cc:759-765) ->
 // CompactLattice table.  Like the reference's CUDA pipeline the lattice keeps the acoustic scale it was decoded with (only the CPU
-// decoders' wrappers undo it).  --determinize-lattice=false writes the trimmed state-level lattice as a Lattice table; the reference
-// writes that same lattice re-packed by ConvertLattice as a CompactLattice -- Kaldi's lattice readers accept either form.
+// decoders' wrappers undo it).  --determinize-lattice=false writes the trimmed state-level lattice re-packed by ConvertLattice as a
+// CompactLattice, as the reference does; with --write-compact=false (an addition) it is written as a Lattice table, arc for arc.
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
@@ -29,7 +29,7 @@ int main(int argc, char **argv) {
         "set via config files whose filenames are passed as options\nOutput is a lattice wspecifier\n"
         "Usage: batched-wav-nnet3-cuda2 [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
     ParseOptions po(usage);
-    bool write_lattice = true, segmentation = false, determinize = true, minimize = false, phone_det = true, word_det = true, gpu_feat = true, use_online = false, reset_on_endpoint = false, tensor_cores = false, tf32 = false, add_pitch = false, debug_comp = false, cache_mem = true;
+    bool write_compact = true, write_lattice = true, segmentation = false, determinize = true, minimize = false, phone_det = true, word_det = true, gpu_feat = true, use_online = false, reset_on_endpoint = false, tensor_cores = false, tf32 = false, add_pitch = false, debug_comp = false, cache_mem = true;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, worker_threads = -1, copy_threads = 2, frames_per_chunk = 50, subsampling = 1;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, elc = 0, erc = 0, elci = -1, ercf = -1;
     float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; double mem_prop = 0.5; int32_t det_max_mem = 50000000;
@@ -45,6 +45,7 @@ int main(int argc, char **argv) {
     po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
     po.Register("cuda-decoder-copy-threads", &copy_threads, "Number of worker threads that read the wave files and fill the pinned staging buffers.");
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
+    po.Register("write-compact", &write_compact, "(not in the reference) with --determinize-lattice=false: true = the state-level lattice re-packed as a CompactLattice like the reference (ConvertLattice), false = written as a Lattice table");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
     po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)");
@@ -161,7 +162,9 @@ int main(int argc, char **argv) {
         lat.arc_olabel.assign(r->ao.begin() + a0, r->ao.begin() + a0 + na); lat.arc_graph.assign(r->ag.begin() + a0, r->ag.begin() + a0 + na); lat.arc_ac.assign(r->aa.begin() + a0, r->aa.begin() + a0 + na);
         for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
         Connect(&lat);
-        if (det_pool) det_pool->Run(key, std::move(lat)); else writer->WriteLattice(key, lat);
+        if (det_pool) det_pool->Run(key, std::move(lat));
+        else if (write_compact) { CompactLattice clat; ConvertLattice(lat, &clat); writer->WriteCompactLattice(key, clat); }
+        else writer->WriteLattice(key, lat);
         s0 += ns; a0 += na;
       }
     };

@@ -3,6 +3,7 @@
 //   k3-host-tool tidinfo <model.mdl>          per transition-id: phone, self-loop flag, start-of-phone flag
 //   k3-host-tool fstinfo <fst>                states arcs start, FNV-1a checksum of the CSR
 //   k3-host-tool copy-fst <fst-in> <fst-out>  read (vector|const) and write as vector
+//   k3-host-tool convert-lattice <lattice-rspecifier> <lattice-wspecifier>   state-level lattices re-packed as CompactLattices
 #include <iostream>
 #include "k3_host.h"
 using namespace k3host;
@@ -28,7 +29,12 @@ int main(int argc, char **argv) {
       mix(f.weight.data(), 4 * f.weight.size()); mix(f.nextstate.data(), 4 * f.nextstate.size()); mix(f.final_cost.data(), 4 * f.final_cost.size());
       std::cout << f.NumStates() << " " << f.ilabel.size() << " " << f.start << " " << h << "\n"; return 0;
     }
+    if (cmd == "convert-lattice" && argc == 4) {       // Lattice table -> CompactLattice table without determinization (ConvertLattice)
+      TableWriter w(argv[3]);
+      for (auto &kv : ReadLatticeTable(argv[2])) { Connect(&kv.second); CompactLattice c; ConvertLattice(kv.second, &c); w.WriteCompactLattice(kv.first, c); }
+      w.Flush(); return 0;
+    }
     if (cmd == "copy-fst" && argc == 4) { WriteFstVector(ReadFstKaldiGeneric(argv[2]), argv[3]); return 0; }
-    std::cerr << "usage: k3-host-tool tid2pdf <mdl> | tidinfo <mdl> | fstinfo <fst> | copy-fst <in> <out>\n"; return 1;
+    std::cerr << "usage: k3-host-tool tid2pdf <mdl> | tidinfo <mdl> | fstinfo <fst> | copy-fst <in> <out> | convert-lattice <rspecifier> <wspecifier>\n"; return 1;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
 }

@@ -122,6 +122,11 @@ bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *c
 struct DeterminizeLatticePhonePrunedOptions { float delta = 1.0f / 1024.0f; int32_t max_mem = 50000000; bool phone_determinize = true, word_determinize = true, minimize = false; };
 bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &trans, double beam, CompactLattice *clat,
                                    const DeterminizeLatticePhonePrunedOptions &opts = DeterminizeLatticePhonePrunedOptions());
+// ConvertLattice(Lattice -> CompactLattice) (fstext/lattice-utils-inl.h:33-86): no determinization; Factor (fstext/factor-inl.h:70-150)
+// folds linear chains of states (one arc in, one arc out, not final, no word on the arc out) into single arcs that carry the chain's
+// transition-ids as their string, then the states are sorted topologically.  What the reference's CUDA pipeline writes with
+// --determinize-lattice=false.
+void ConvertLattice(const Lattice &lat, CompactLattice *clat);
 void Connect(CompactLattice *clat);                        // fst::Connect; keeps the relative order of the surviving states
 void ScaleAcoustic(CompactLattice *clat, double scale);
 bool TopSortIfNeeded(CompactLattice *clat);                // TopSortCompactLatticeIfNeeded (lat/lattice-functions.cc); false on a cycle

@@ -616,6 +616,65 @@ void Connect(CompactLattice *c) {
   Renumber(c, newid, m);
 }
 
+void ConvertLattice(const Lattice &lat, CompactLattice *out) {
+  *out = CompactLattice();
+  const int32_t n = lat.NumStates(); const size_t na = lat.arc_src.size();
+  if (n == 0 || lat.start < 0) return;
+  std::vector<int32_t> off(n + 1, 0), idx(na);
+  for (size_t a = 0; a < na; a++) off[lat.arc_src[a] + 1]++;
+  for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
+  { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < na; a++) idx[p[lat.arc_src[a]]++] = (int32_t)a; }
+  // depth-first discovery order (DfsOrderVisitor), arcs in stored order
+  std::vector<int32_t> order, stack, pos(n); std::vector<char> seen(n, 0);
+  stack.push_back(lat.start); seen[lat.start] = 1; pos[lat.start] = off[lat.start]; order.push_back(lat.start);
+  while (!stack.empty()) {
+    const int32_t s = stack.back();
+    if (pos[s] < off[s + 1]) { const int32_t d = lat.arc_dst[idx[pos[s]++]]; if (!seen[d]) { seen[d] = 1; pos[d] = off[d]; order.push_back(d); stack.push_back(d); } }
+    else stack.pop_back();
+  }
+  // GetStateProperties: a state is the middle of a chain when it has exactly one arc in and one out, is not final, not the start
+  // state, and its arc out carries no word
+  std::vector<int32_t> nin(n, 0); for (size_t a = 0; a < na; a++) nin[lat.arc_dst[a]]++;
+  std::vector<char> remove(n, 0);
+  for (int32_t s = 0; s < n; s++)
+    remove[s] = s != lat.start && nin[s] == 1 && off[s + 1] - off[s] == 1 && !std::isfinite(lat.st_final[s]) && lat.arc_olabel[idx[off[s]]] == 0;
+  EdgeFst f; std::vector<int32_t> map(n, -1); std::vector<std::vector<int32_t>> strings;
+  auto state_of = [&](int32_t s) { if (map[s] < 0) map[s] = f.AddState(); return map[s]; };
+  for (int32_t s : order) {
+    if (remove[s]) continue;
+    const int32_t ns = state_of(s);
+    for (int32_t k = off[s]; k < off[s + 1]; k++) {
+      int32_t a = idx[k]; LatW w{lat.arc_graph[a], lat.arc_ac[a]}; const int32_t word = lat.arc_olabel[a];
+      std::vector<int32_t> str; if (lat.arc_ilabel[a] != 0) str.push_back(lat.arc_ilabel[a]);
+      int32_t d = lat.arc_dst[a];
+      while (remove[d]) { a = idx[off[d]]; w = Times(w, LatW{lat.arc_graph[a], lat.arc_ac[a]}); if (lat.arc_ilabel[a] != 0) str.push_back(lat.arc_ilabel[a]); d = lat.arc_dst[a]; }
+      f.AddArc(ns, state_of(d), word, (int32_t)strings.size(), w); strings.push_back(std::move(str));       // the tid slot holds the index of the arc's string
+    }
+    if (std::isfinite(lat.st_final[s])) f.fin[ns] = LatW{lat.st_final[s], lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]};
+  }
+  f.start = map[lat.start];
+  // TopSort(&ffst), then one compact arc per factored arc
+  const int32_t m = (int32_t)f.fin.size();
+  std::vector<int32_t> foff(m + 1, 0), fnx(f.src.size()), fidx(f.src.size());
+  for (int32_t x : f.src) foff[x + 1]++;
+  for (int32_t x = 0; x < m; x++) foff[x + 1] += foff[x];
+  { std::vector<int32_t> p(foff.begin(), foff.end() - 1); for (size_t a = 0; a < f.src.size(); a++) { const int32_t k = p[f.src[a]]++; fidx[k] = (int32_t)a; fnx[k] = f.dst[a]; } }
+  std::vector<int32_t> torder;
+  if (!TopOrder(m, f.start, foff, fnx, &torder)) K3H_ERR << "ConvertLattice: the lattice has a cycle";
+  std::vector<int32_t> newid(m, -1); for (size_t i = 0; i < torder.size(); i++) newid[torder[i]] = (int32_t)i;
+  for (size_t i = 0; i < torder.size(); i++) out->AddState();
+  out->start = newid[f.start];
+  for (int32_t x : torder) {
+    const int32_t t = newid[x];
+    if (f.fin[x] != Zero()) { out->is_final[t] = 1; out->fin_graph[t] = f.fin[x].g; out->fin_ac[t] = f.fin[x].a; }
+    for (int32_t k = foff[x]; k < foff[x + 1]; k++) {
+      const int32_t a = fidx[k];
+      if (newid[f.dst[a]] < 0) continue;
+      out->arc_src.push_back(t); out->arc_dst.push_back(newid[f.dst[a]]); out->arc_label.push_back(f.word[a]); out->arc_graph.push_back(f.w[a].g); out->arc_ac.push_back(f.w[a].a); out->arc_str.push_back(std::move(strings[f.tid[a]]));
+    }
+  }
+}
+
 void ScaleAcoustic(CompactLattice *c, double scale) { for (float &a : c->arc_ac) a = (float)(a * scale); for (int32_t s = 0; s < c->NumStates(); s++) if (c->is_final[s]) c->fin_ac[s] = (float)(c->fin_ac[s] * scale); }
 
 bool TopSortIfNeeded(CompactLattice *c) {

@@ -135,6 +135,6 @@ def enumerate_compact(c, acoustic_scale=1.0, limit=200000):
             fg, fa, ft = c["finals"][s]
             out.setdefault(words, []).append((g + fg + (ac + fa * acoustic_scale), g + fg, ac + fa * acoustic_scale, tids + ft)); n[0] += 1
             assert n[0] < limit
-        for (_, d, w, ag, aa, at) in by_src.get(s, []): rec(d, words + (w,), tids + at, g + ag, ac + aa * acoustic_scale)
+        for (_, d, w, ag, aa, at) in by_src.get(s, []): rec(d, words + ((w,) if w else ()), tids + at, g + ag, ac + aa * acoustic_scale)
     if c["start"] >= 0: rec(c["start"], (), (), 0.0, 0.0)
     return out

@@ -78,7 +78,7 @@ def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
     graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
     open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40   # comment\n--dither=0\n")
     cmd = [os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0",
-           "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--max-batch-size=2", "--determinize-lattice=false", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/lat.txt"]
+           "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--max-batch-size=2", "--determinize-lattice=false", "--write-compact=false", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/lat.txt"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Decoded 3 utterances, 0 with errors." in r.stderr and "RealTimeX:" in r.stderr
@@ -110,7 +110,7 @@ def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
     # default: determinized CompactLattices.  Must equal what lattice-determinize-phone-pruned (same host code, CPU program) makes of the
     # raw binary archive above, and its best path must spell the raw lattice's best word sequence.
     from tests import lattice_cases as lc
-    cmd_det = [c for c in cmd if not c.startswith("--determinize")]; cmd_det[-1] = f"ark,t:{td}/det.txt"
+    cmd_det = [c for c in cmd if not c.startswith("--determinize") and not c.startswith("--write-compact")]; cmd_det[-1] = f"ark,t:{td}/det.txt"
     r = subprocess.run(cmd_det, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r2 = subprocess.run([os.path.join(BIN, "lattice-determinize-phone-pruned"), "--beam=8.0", "--acoustic-scale=1.0", f"{td}/final.mdl", f"ark:{td}/lat.ark", f"ark,t:{td}/det2.txt"], capture_output=True, text=True)
@@ -126,6 +126,15 @@ def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
             assert (a_[0], a_[2]) not in by_src and a_[2] != 0          # deterministic on words, no epsilons
             by_src[(a_[0], a_[2])] = a_
         assert _compact_best_words(det[key]) == lats[u].connect().best_path()[1], key
+    # --determinize-lattice=false alone: the raw lattice re-packed as a CompactLattice (ConvertLattice), = k3-host-tool convert-lattice
+    cmd_cv = [c for c in cmd if not c.startswith("--write-compact")]; cmd_cv[-1] = f"ark,t:{td}/conv.txt"
+    assert subprocess.run(cmd_cv, capture_output=True, text=True).returncode == 0
+    assert subprocess.run([os.path.join(BIN, "k3-host-tool"), "convert-lattice", f"ark:{td}/lat.ark", f"ark,t:{td}/conv2.txt"], capture_output=True).returncode == 0
+    cv, cv2 = lc.parse_compact_text(open(f"{td}/conv.txt").read()), lc.parse_compact_text(open(f"{td}/conv2.txt").read())
+    for u, key in enumerate(cv):
+        canon = lambda c: sorted((a[2], a[5], round(a[3], 2), round(a[4], 2)) for a in c["arcs"])
+        assert canon(cv[key]) == canon(cv2[key]) and 0 < len(cv[key]["arcs"]) <= lats[u].connect().num_arcs, key
+        assert sum(len(a[5]) for a in cv[key]["arcs"]) == int((lats[u].connect().arc_ilabel != 0).sum())          # every transition-id is on exactly one arc
 
 def test_nnet3_compute_matches_the_reference_binary_incl_compressed_archives(tmp_path):
     """same model file, same feature archive (also as a COMPRESSED archive and an scp with byte offsets written by the
@@ -229,7 +238,7 @@ def test_batched_wav_nnet3_cuda_online_equals_offline_program(tmp_path):
     net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
     graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
     open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
-    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--determinize-lattice=false"]
+    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--determinize-lattice=false", "--write-compact=false"]
     a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=5", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/off.txt"], capture_output=True, text=True)
     assert a.returncode == 0, a.stderr
     off = _parse_text_lattices(f"{td}/off.txt")

@@ -326,3 +326,26 @@ def test_phone_pruned_on_decoder_oracle_lattices_and_errors(mdl):
     assert r.returncode != 0 and b"transition-id 4000" in r.stderr
     assert subprocess.run([PHONE_PROG, "--minimize=true", mdl, "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
     assert subprocess.run([PHONE_PROG, mdl], capture_output=True).returncode == 1
+
+
+def test_convert_lattice_folds_chains_and_keeps_every_path():
+    """ConvertLattice (what --determinize-lattice=false writes in the reference's CUDA programs): no path is added, lost or re-costed;
+    linear chains become single arcs carrying the chain's transition-ids; states come out topologically sorted."""
+    tool = os.path.join(ROOT, "kaldi_amd", "bin", "k3-host-tool")
+    for seed in range(6):
+        lat = lc.random_lattice(700 + seed, frames=7, width=2 + seed % 3, words=3, p_word=0.2)
+        r = subprocess.run([tool, "convert-lattice", "ark:-", "ark,t:-"], input=lc.lattice_binary("u", lat), capture_output=True, timeout=60)
+        assert r.returncode == 0, r.stderr.decode()
+        out = lc.parse_compact_text(r.stdout.decode())["u"]
+        raw = lc.enumerate_raw(lat); conv = lc.enumerate_compact(out)
+        assert set(raw) == set(conv)
+        for w in raw:
+            a = sorted((t, c) for c, _, _, t in raw[w]); b = sorted((t, c) for c, _, _, t in conv[w])
+            assert [x[0] for x in a] == [x[0] for x in b] and np.allclose([x[1] for x in a], [x[1] for x in b], atol=2e-3), w      # text output: 6 significant digits
+        assert all(d > s for (s, d, *_) in out["arcs"])
+    # a pure chain with one word collapses into one arc (the final weight stays on the last state)
+    chain = dict(start=0, n=5, finals={4: (0.5, 0.0)}, arcs=[(0, 1, 3, 9, 1.0, 2.0), (1, 2, 4, 0, 0.0, 1.0), (2, 3, 0, 0, 0.25, 0.0), (3, 4, 5, 0, 0.0, 1.5)])
+    r = subprocess.run([tool, "convert-lattice", "ark:-", "ark,t:-"], input=lc.lattice_text("c", chain).encode(), capture_output=True)
+    out = lc.parse_compact_text(r.stdout.decode())["c"]
+    assert len(out["arcs"]) == 1 and out["arcs"][0][2] == 9 and out["arcs"][0][5] == (3, 4, 5) and abs(out["arcs"][0][3] - 1.25) < 1e-6 and abs(out["arcs"][0][4] - 4.5) < 1e-6
+    assert list(out["finals"].values()) == [(0.5, 0.0, ())]
