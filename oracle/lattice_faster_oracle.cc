@@ -2,11 +2,16 @@
  * oracle/lattice_faster_oracle.cc  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * CPU restatement of Kaldi's LatticeFasterDecoder (the parity oracle north_star names:
- * "lattice-faster-decoder") over a plain CSR WFST.  The reference's decoder cannot be compiled in this
- * container (src/decoder, src/lat and src/fstext need OpenFst 1.8.4, which is neither installed nor vendored:
- * tools/Makefile:10), and the reference holds NO golden vectors or tests for its decoders
- * (decoder/Makefile:6 and cudadecoder/Makefile:16 have empty TESTFILES)  =>  PARITY UNPINNED for this file:
- * it is checked only against hand-computed tiny cases and its own two evaluation modes (tests/test_oracle_decoder.py).
+ * "lattice-faster-decoder") over a plain CSR WFST.
+ *
+ * PINNED against the reference's own source: the reference holds no golden vectors or tests for its decoders
+ * (decoder/Makefile:6 and cudadecoder/Makefile:16 have empty TESTFILES) and OpenFst 1.8.4 is neither installed nor
+ * vendored (tools/Makefile:10), but decoder/lattice-faster-decoder.{h,cc} compile UNMODIFIED against a stand-in for the
+ * small part of OpenFst they touch (oracle/ref_tools/minifst, recipe in oracle/build_ref.sh -> oracle/_ref/bin/
+ * ref-lattice-decoder).  Mode 0 of this file reproduces that binary's GetRawLattice output exactly -- states per
+ * frame, arcs, labels, float bits, sharing of states, up to state renaming -- on every case of tests/decoder_cases.py
+ * (active-state limits, beams, prune intervals, hash sizes; tests/test_oracle_decoder.py, live where oracle/_ref is
+ * present and through the digests recorded in tests/golden/decoder_ref_golden.json elsewhere).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the shared object built from
  * this file; kaldi_amd/ never does.

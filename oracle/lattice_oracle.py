@@ -1,5 +1,5 @@
 """oracle/lattice_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
-ctypes front-end of oracle/lattice_faster_oracle.cc (the restated LatticeFasterDecoder; PARITY UNPINNED, see its
+ctypes front-end of oracle/lattice_faster_oracle.cc (the restated LatticeFasterDecoder; pinned to the reference's own decoder source, see its
 header).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
 import ctypes, os
 import numpy as np

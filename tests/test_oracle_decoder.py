@@ -128,3 +128,38 @@ def test_max_active_and_min_active_cutoffs():
     assert (capped["adaptive_beam"][5:] < 15.0).any()              # max_active tighter than the beam on some frame
     _, loose = lo.decode(f, ll, t2p, lo.Config(beam=1.0, lattice_beam=0.5, min_active=200), 1)
     assert (loose["adaptive_beam"] > 1.0).any()                    # min_active looser than the beam
+
+
+# ---- the restated decoder against the REFERENCE's own decoder source ------------------------------------------------------------
+# oracle/_ref/bin/ref-lattice-decoder is /root/reference/src/decoder/lattice-faster-decoder.cc compiled unmodified against a stand-in
+# for the part of OpenFst it touches (oracle/ref_tools/minifst, oracle/build_ref.sh).  The oracle's literal mode (mode 0) must
+# reproduce its GetRawLattice output exactly: same states per frame, same arcs, same labels, same float bits, same sharing of states
+# -- compared up to state renaming (tests/lattice_sig.py), for all limits / beams / prune intervals / hash sizes of decoder_cases.
+import json, os
+from tests import decoder_cases as dcases, lattice_sig as lsig
+_GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decoder_ref_golden.json")))
+
+@pytest.mark.parametrize("name", sorted(dcases.CASES))
+def test_literal_mode_equals_the_reference_decoder(name):
+    f, t2p, ll, kw = dcases.make(name)
+    lat, info = lo.decode(f, ll, t2p, lo.Config(**kw), 0)
+    g = _GOLD[name]
+    assert (lat.num_states, lat.num_arcs, info["reached_final"]) == (g["states"], g["arcs"], g["reached_final"])
+    canon = lsig.canonical_of_raw(lat)
+    assert lsig.digest(canon) == g["digest"]                 # recorded from the reference binary (tests/golden/make_golden_decoder.py)
+    from oracle import ref_decoder as rd
+    if rd.available():                                       # and live, where oracle/_ref is present
+        ref = rd.decode(f, ll, t2p, lo.Config(**kw))
+        assert lsig.canonical_of_reference(ref) == canon
+        assert ref["num_frames"] == ll.shape[0]
+
+def test_reference_decoder_edge_cases_match_too():
+    """no token survives / final state not reached / a single frame: whatever the reference does, the oracle does"""
+    from oracle import ref_decoder as rd
+    if not rd.available(): pytest.skip("oracle/_ref not built (needs /root/reference)")
+    f = _fst(4, 0, [(0, 1, 7, 0.5, 1), (1, 2, 0, 0.25, 2), (1, 3, 9, 4.0, 3), (2, 0, 0, 0.0, 3)], {3: 0.125})
+    for T, cfg in ((1, lo.Config(beam=10.0, lattice_beam=5.0)), (2, lo.Config(beam=10.0, lattice_beam=5.0)), (2, lo.Config(beam=10.0, lattice_beam=0.5)), (3, lo.Config(beam=1.0, lattice_beam=1.0))):
+        ll = (np.random.default_rng(T).standard_normal((T, 3)) * 2).astype(np.float32)
+        ref = rd.decode(f, ll, T2P, cfg); lat, info = lo.decode(f, ll, T2P, cfg, 0)
+        assert ref["reached_final"] == info["reached_final"]
+        assert lsig.canonical_of_reference(ref) == lsig.canonical_of_raw(lat), (T, ref["frame"].size, lat.num_states)
