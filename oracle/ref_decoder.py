@@ -28,4 +28,5 @@ def decode(fst, loglikes, tid2pdf, cfg):
             ns, na, start, reached, nframes = np.fromfile(f, np.int64, 5)
             frame = np.fromfile(f, np.int32, ns); fg = np.fromfile(f, np.float32, ns); fa = np.fromfile(f, np.float32, ns)
             src, dst, il, ol = (np.fromfile(f, np.int32, na) for _ in range(4)); g = np.fromfile(f, np.float32, na); ac = np.fromfile(f, np.float32, na)
-    return dict(frame=frame, final_graph=fg, final_ac=fa, src=src, dst=dst, ilabel=il, olabel=ol, graph=g, ac=ac, start=int(start), reached_final=bool(reached), num_frames=int(nframes), log=r.stderr)
+            secs = float(np.fromfile(f, np.float64, 1)[0])
+    return dict(frame=frame, final_graph=fg, final_ac=fa, src=src, dst=dst, ilabel=il, olabel=ol, graph=g, ac=ac, start=int(start), reached_final=bool(reached), num_frames=int(nframes), decode_seconds=secs, log=r.stderr)

@@ -9,7 +9,8 @@
 //          int32 arc_offsets[num_states+1], ilabel[A], olabel[A], nextstate[A]; float weight[A], final[num_states];
 //          int32 tid2pdf[num_tids_plus_1]; float loglikes[T*num_pdfs]
 // out.bin: int64 {num_states, num_arcs, start, reached_final, num_frames_decoded}; int32 frame[S]; float final_graph[S], final_ac[S];
-//          int32 src[A], dst[A], ilabel[A], olabel[A]; float graph[A], acoustic[A]
+//          int32 src[A], dst[A], ilabel[A], olabel[A]; float graph[A], acoustic[A]; double seconds spent in Decode()
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -68,7 +69,9 @@ int main(int argc, char **argv) {
     cfg.max_active = h[7]; cfg.min_active = h[8]; cfg.prune_interval = h[9];
     Decoder dec(graph, cfg);
     MatrixDecodable decodable(ll, T, P, t2p);
+    const auto t0 = std::chrono::steady_clock::now();
     dec.Decode(&decodable);
+    const double decode_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     kaldi::Lattice lat;
     dec.GetRawLattice(&lat, true);
     const int64_t ns = lat.NumStates(); int64_t na = 0; for (int64_t s = 0; s < ns; s++) na += (int64_t)lat.NumArcs((int)s);
@@ -87,6 +90,7 @@ int main(int argc, char **argv) {
     const int64_t hdr[5] = {ns, na, lat.Start(), dec.ReachedFinal() ? 1 : 0, dec.NumFramesDecoded()};
     fwrite(hdr, 8, 5, o); fwrite(frame.data(), 4, ns, o); fwrite(fg.data(), 4, ns, o); fwrite(fa.data(), 4, ns, o);
     fwrite(src.data(), 4, na, o); fwrite(dst.data(), 4, na, o); fwrite(oi.data(), 4, na, o); fwrite(oo.data(), 4, na, o); fwrite(g.data(), 4, na, o); fwrite(ac.data(), 4, na, o);
+    fwrite(&decode_seconds, 8, 1, o);
     fclose(o);
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
