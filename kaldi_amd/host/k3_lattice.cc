@@ -3,10 +3,13 @@
 //
 // This restates the algorithm of the reference's lat/determinize-lattice-pruned.cc (LatticeDeterminizerPruned, cited per function)
 // in this library's own data structures: a CSR input automaton, a string trie addressed by int32 ids instead of Entry pointers,
-// std containers for the subset hashes.  PARITY UNPINNED: OpenFst is not vendored in /root/reference, so neither the reference's
-// determinizer nor its tests can be built here; tests/test_lattice_det.py checks the defining properties instead (deterministic on
-// word labels, per word sequence the cost and alignment of the best raw path, every word sequence within the beam kept), which is
-// what the reference's own determinize-lattice-pruned-test.cc does with RandEquivalent.
+// std containers for the subset hashes.  PINNED to the reference's own source: OpenFst is not vendored in /root/reference, but
+// lat/determinize-lattice-pruned.cc compiles unmodified against a stand-in for the part of OpenFst it touches (oracle/ref_tools/minifst
+// -> oracle/_ref/bin/ref-lattice-determinize), and the programs built on this file print the same CompactLattices as that binary,
+// character for character, on random lattices, exact cost ties, decoder lattices and the --max-mem prune-and-retry path, for the
+// word-level and the phone+word entry points (tests/test_lattice_det.py; digests of the reference output in tests/golden/).
+// The property tests of the same file (deterministic on word labels, per word sequence the cost and alignment of the best raw path,
+// every word sequence within the beam kept) stay: they are what the reference's determinize-lattice-pruned-test.cc checks.
 //
 // Both entry points of the reference are here: DeterminizeLatticePruned (one word-level pass; lattice-determinize-pruned) and
 // DeterminizeLatticePhonePruned (phone-level pass first, then the word-level pass; what the decoders and
@@ -90,9 +93,10 @@ struct EdgeFst {
   void AddArc(int32_t s, int32_t d, int32_t wd, int32_t t, LatW wt) { src.push_back(s); dst.push_back(d); word.push_back(wd); tid.push_back(t); w.push_back(wt); }
 };
 
-// Invert (lattice-determinize-pruned.cc:104) after fst::Connect
-EdgeFst InvertedEdges(const Lattice &lat_in) {
-  Lattice lat = lat_in; Connect(&lat);
+// Invert (lattice-determinize-pruned.cc:104).  The lattice is NOT trimmed first: states that lead nowhere still count as members of
+// the subsets (they change which weight / string is common to a subset), exactly as in the reference.  The decoders trim before
+// they determinize (decoder-wrappers.cc:353), and so do the programs here.
+EdgeFst InvertedEdges(const Lattice &lat) {
   EdgeFst e; e.start = lat.NumStates() ? lat.start : -1;
   for (int32_t s = 0; s < lat.NumStates(); s++) e.fin.push_back(std::isfinite(lat.st_final[s]) ? LatW{lat.st_final[s], lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]} : Zero());
   for (size_t a = 0; a < lat.arc_src.size(); a++) e.AddArc(lat.arc_src[a], lat.arc_dst[a], lat.arc_olabel[a], lat.arc_ilabel[a], {lat.arc_graph[a], lat.arc_ac[a]});
@@ -166,15 +170,19 @@ bool PruneInput(double beam, InputFst *f) {
 // Equal sequences always get the same id, which is what lets subsets be hashed and compared on (state, string id).
 class StringTrie {
  public:
-  StringTrie() : parent_(1, -1), label_(1, 0), depth_(1, 0) {}
+  StringTrie() : parent_(1, -1), label_(1, 0), depth_(1, 0), held_(1, 1) {}
   int32_t Successor(int32_t s, int32_t label) {
     const uint64_t key = ((uint64_t)(uint32_t)s << 32) | (uint32_t)label;
     auto it = succ_.find(key);
-    if (it != succ_.end()) return it->second;
+    if (it != succ_.end()) { if (!held_[it->second]) { held_[it->second] = 1; num_held_++; } return it->second; }
     const int32_t id = (int32_t)parent_.size();
-    parent_.push_back(s); label_.push_back(label); depth_.push_back(depth_[s] + 1); succ_.emplace(key, id);
+    parent_.push_back(s); label_.push_back(label); depth_.push_back(depth_[s] + 1); held_.push_back(1); num_held_++; succ_.emplace(key, id);
     return id;
   }
+  // The reference frees the entries nobody refers to when memory runs short (LatticeStringRepository::Rebuild) and creates them
+  // again on demand; ids here stay valid for ever, so only the book-keeping is mirrored: which entries the reference would hold now.
+  size_t NumHeld() const { return num_held_; }
+  void KeepOnly(const std::vector<char> &needed) { num_held_ = 0; for (size_t i = 1; i < held_.size(); i++) { held_[i] = needed[i]; num_held_ += needed[i]; } }
   void ToVector(int32_t s, std::vector<int32_t> *v) const { v->resize(depth_[s]); for (int32_t i = depth_[s] - 1; i >= 0; i--, s = parent_[s]) (*v)[i] = label_[s]; }
   int32_t FromVector(const std::vector<int32_t> &v, size_t from = 0) { int32_t s = 0; for (size_t i = from; i < v.size(); i++) s = Successor(s, v[i]); return s; }
   int32_t Concatenate(int32_t a, int32_t b) { if (b == 0) return a; if (a == 0) return b; std::vector<int32_t> v; ToVector(b, &v); for (int32_t l : v) a = Successor(a, l); return a; }
@@ -188,7 +196,7 @@ class StringTrie {
   int32_t Parent(int32_t s) const { return parent_[s]; }
   size_t NumEntries() const { return parent_.size() - 1; }
  private:
-  std::vector<int32_t> parent_, label_, depth_;
+  std::vector<int32_t> parent_, label_, depth_; std::vector<char> held_; size_t num_held_ = 0;
   std::unordered_map<uint64_t, int32_t> succ_;
 };
 
@@ -440,22 +448,21 @@ class Determinizer {
     ProcessTransitions(0);
   }
 
-  // :286-327.  The reference measures (2 x 16 B per trie entry) + 24 B per arc + 24 B per subset element and, above --max-mem,
-  // rebuilds the trie from the strings still referenced.  Here nothing needs freeing (ids stay valid), so the "rebuild" only counts
-  // what a rebuild would keep; entries created later are added to that count.
+  // :286-327.  The reference measures (2 x 16 B per trie entry) + 32 B per arc + 24 B per subset element and, above --max-mem,
+  // rebuilds the trie from the strings still referenced (:218-264).  Here nothing needs freeing; the trie only notes which entries
+  // the reference would be holding, so that the early exit happens at the same point.
   bool CheckMemoryUsage() {
     if (opts_.max_mem <= 0) return true;
-    const int64_t arcs = num_arcs_ * 24, elems = num_elems_ * 24;
-    int64_t repo = ((int64_t)trie_.NumEntries() - trie_dropped_) * 32;
+    const int64_t arcs = num_arcs_ * 32, elems = num_elems_ * 24;        // sizeof(TempArc) = 32 (4 + pad + 8 + 4 + 8, 8-aligned), sizeof(Element) = 24
+    const int64_t repo = (int64_t)trie_.NumHeld() * 32;
     if (repo + arcs + elems <= opts_.max_mem) return true;
     std::vector<char> live(trie_.NumEntries() + 1, 0);
     auto mark = [&](int32_t s) { for (; s > 0 && !live[s]; s = trie_.Parent(s)) live[s] = 1; };
     for (const OutputState &st : out_) { for (const Element &e : st.minimal_subset) mark(e.string); for (const TempArc &t : st.arcs) mark(t.string); }
     for (const auto &kv : initial_hash_) { for (const Element &e : *kv.first) mark(e.string); mark(kv.second.string); }
     { std::vector<Task *> tasks; while (!queue_.empty()) { tasks.push_back(queue_.top()); queue_.pop(); } for (Task *t : tasks) { for (const Element &e : t->subset) mark(e.string); queue_.push(t); } }
-    int64_t kept = 0; for (char c : live) kept += c;
-    trie_dropped_ = (int64_t)trie_.NumEntries() - kept;
-    const int64_t new_repo = kept * 32;
+    trie_.KeepOnly(live);
+    const int64_t new_repo = (int64_t)trie_.NumHeld() * 32;
     if (new_repo + arcs + elems > (int64_t)(opts_.max_mem * 0.8)) {
       double eff = beam_; if (!queue_.empty()) eff = queue_.top()->priority_cost - backward_[f_.start];
       K3H_WARN << "Did not reach requested beam in determinize-lattice: size exceeds maximum " << opts_.max_mem << " bytes; (repo,arcs,elems) = (" << repo << "," << arcs << "," << elems
@@ -467,7 +474,7 @@ class Determinizer {
 
   const InputFst &f_; double beam_; DeterminizeLatticePrunedOptions opts_;
   double cutoff_ = kInfD; std::vector<double> backward_;
-  StringTrie trie_; int64_t trie_dropped_ = 0, num_arcs_ = 0, num_elems_ = 0;
+  StringTrie trie_; int64_t num_arcs_ = 0, num_elems_ = 0;
   std::deque<OutputState> out_;                              // deque: the hashes keep pointers to the subsets
   std::deque<std::vector<Element>> initial_keys_;
   std::unordered_map<const std::vector<Element> *, int32_t, SubsetHash, SubsetEqual> minimal_hash_;

@@ -15,7 +15,9 @@
 # decoder/lattice-faster-decoder.{h,cc} only touch a small part of OpenFst's public interface (a graph's read interface, a vector
 # FST to fill, arc iterators, a memory pool): oracle/ref_tools/minifst/ is a stand-in for exactly that part, and with it the
 # reference's decoder source compiles UNMODIFIED into oracle/_ref/bin/ref-lattice-decoder (driver: ref_tools/ref_lattice_decoder.cc).
-# That binary pins the restated decoder oracle (oracle/lattice_faster_oracle.cc, tests/test_oracle_decoder.py).
+# That binary pins the restated decoder oracle (oracle/lattice_faster_oracle.cc, tests/test_oracle_decoder.py).  With TopSort / ArcSort /
+# Invert / Connect added to the stand-in, lat/determinize-lattice-pruned.cc compiles unmodified too: oracle/_ref/bin/
+# ref-lattice-determinize pins the host-side determinizer of the drop-in programs (kaldi_amd/host/k3_lattice.cc, tests/test_lattice_det.py).
 set -euo pipefail
 REF=${KALDI_REFERENCE:-/root/reference}
 R=$REF/src
@@ -77,6 +79,9 @@ MF="-std=c++17 -O2 -DNDEBUG -w -I $HERE/ref_tools/minifst -I $W/inc -I $R -I $RE
 mkdir -p $W/obj_minifst
 g++ $MF -c $R/decoder/lattice-faster-decoder.cc -o $W/obj_minifst/lattice-faster-decoder.o
 g++ $MF $HERE/ref_tools/ref_lattice_decoder.cc $W/obj_minifst/lattice-faster-decoder.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-lattice-decoder
+# the reference's lattice determinization (lat/determinize-lattice-pruned.cc, unmodified) over the same stand-in: pins kaldi_amd/host/k3_lattice.cc
+g++ $MF -c $R/lat/determinize-lattice-pruned.cc -o $W/obj_minifst/determinize-lattice-pruned.o
+g++ $MF $HERE/ref_tools/ref_lattice_determinize.cc $W/obj_minifst/determinize-lattice-pruned.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-lattice-determinize
 for f in /opt/conda/lib/libmkl_{rt,core,intel_lp64,sequential,gnu_thread,intel_thread,avx2,avx512,def,mc3,vml_avx2,vml_avx512,vml_def}.so.1; do
   [ -e $f ] && ln -sf $f $W/mkl/ || true; done
 cat > $W/env.sh <<EOS

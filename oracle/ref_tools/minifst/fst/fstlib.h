@@ -1,11 +1,24 @@
 // oracle/ref_tools/minifst/fst/fstlib.h -- TEST INFRASTRUCTURE.  A stand-in for the part of OpenFst's public interface that the
 // reference's decoder/lattice-faster-decoder.{h,cc} and fstext/lattice-weight.h touch, so that those reference sources can be
-// compiled UNMODIFIED into oracle/_ref without OpenFst (which /root/reference does not vendor).  Written from OpenFst's documented
-// API (names, signatures, semantics); containers are plain std::vector.  Only what the decoder needs is real; the FST algorithms its
-// other member functions mention (ShortestPath, Invert, ArcSort, Connect) are declared and abort when called.
+// compiled UNMODIFIED into oracle/_ref without OpenFst (which /root/reference does not vendor); lat/determinize-lattice-pruned.cc
+// compiles against it as well.  Written from OpenFst's documented API (names, signatures, semantics); containers are plain
+// std::vector.  TopSort, ArcSort, Invert and Connect are implemented (depth-first topological order / std::sort / label swap / trim,
+// as documented); ShortestPath is declared and aborts when called.
 #ifndef K3_MINIFST_FSTLIB_H_
 #define K3_MINIFST_FSTLIB_H_
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <deque>
+#include <functional>
+#include <list>
+#include <map>
+#include <queue>
+#include <set>
+#include <sstream>
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
 #include <cstdlib>
 #include <iostream>
 #include <limits>
@@ -65,6 +78,7 @@ template <class W> struct ArcTpl {
 using StdArc = ArcTpl<TropicalWeight>;
 
 // read interface: what the decoder asks of a decoding graph
+class SymbolTable;
 template <class A> class Fst {
  public:
   using Arc = A; using StateId = typename A::StateId; using Weight = typename A::Weight;
@@ -75,9 +89,16 @@ template <class A> class Fst {
   virtual size_t NumInputEpsilons(StateId s) const = 0;
   virtual const std::string &Type() const = 0;
   virtual uint64 Properties(uint64 mask, bool /*test*/) const { return mask & kExpanded; }
+  virtual const SymbolTable *InputSymbols() const { return nullptr; }
+  virtual const SymbolTable *OutputSymbols() const { return nullptr; }
   virtual const A *ArcsOf(StateId s) const = 0;          // (not OpenFst API: what this stand-in's ArcIterator reads)
+  virtual Fst *Copy(bool safe = false) const = 0;
 };
-template <class A> class ExpandedFst : public Fst<A> { public: virtual typename A::StateId NumStates() const = 0; };
+template <class A> class ExpandedFst : public Fst<A> {
+ public:
+  virtual typename A::StateId NumStates() const = 0;
+  ExpandedFst *Copy(bool safe = false) const override = 0;
+};
 template <class A> class MutableFst : public ExpandedFst<A> {
  public:
   virtual typename A::StateId AddState() = 0;
@@ -85,6 +106,12 @@ template <class A> class MutableFst : public ExpandedFst<A> {
   virtual void SetStart(typename A::StateId s) = 0;
   virtual void SetFinal(typename A::StateId s, typename A::Weight w) = 0;
   virtual void DeleteStates() = 0;
+  virtual void SetInputSymbols(const SymbolTable *) {}
+  virtual void SetOutputSymbols(const SymbolTable *) {}
+  virtual A *MutableArcsOf(typename A::StateId s) = 0;   // (not OpenFst API: behind MutableArcIterator and the algorithms below)
+  virtual void ArcsChanged(typename A::StateId s, bool sorted_on_ilabel) = 0;
+  virtual void ReplaceStates(const std::vector<typename A::StateId> &order) = 0;      // new state i = old state order[i]; states not listed are deleted
+  MutableFst *Copy(bool safe = false) const override = 0;
 };
 
 template <class A> class VectorFst : public MutableFst<A> {
@@ -92,6 +119,8 @@ template <class A> class VectorFst : public MutableFst<A> {
   using Arc = A; using StateId = typename A::StateId; using Weight = typename A::Weight;
   VectorFst() {}
   explicit VectorFst(const Fst<A> &f) { CopyFrom(f); }
+  VectorFst &operator=(const Fst<A> &f) { if (&f != this) { states_.clear(); start_ = kNoStateId; ilabel_sorted_ = false; CopyFrom(f); } return *this; }
+  VectorFst *Copy(bool = false) const override { return new VectorFst(*this); }
   StateId Start() const override { return start_; }
   Weight Final(StateId s) const override { return states_[s].final; }
   size_t NumArcs(StateId s) const override { return states_[s].arcs.size(); }
@@ -100,7 +129,39 @@ template <class A> class VectorFst : public MutableFst<A> {
   const A *ArcsOf(StateId s) const override { return states_[s].arcs.data(); }
   StateId NumStates() const override { return (StateId)states_.size(); }
   StateId AddState() override { states_.emplace_back(); return (StateId)states_.size() - 1; }
-  void AddArc(StateId s, const A &arc) override { states_[s].arcs.push_back(arc); if (arc.ilabel == 0) states_[s].niepsilons++; }
+  void AddArc(StateId s, const A &arc) override { states_[s].arcs.push_back(arc); if (arc.ilabel == 0) states_[s].niepsilons++; ilabel_sorted_ = false; }
+  A *MutableArcsOf(StateId s) override { return states_[s].arcs.data(); }
+  void ArcsChanged(StateId s, bool sorted_on_ilabel) override {
+    states_[s].niepsilons = 0; for (const A &a : states_[s].arcs) if (a.ilabel == 0) states_[s].niepsilons++;
+    if (!sorted_on_ilabel) ilabel_sorted_ = false;
+  }
+  void MarkILabelSorted() { ilabel_sorted_ = true; }
+  void ReplaceStates(const std::vector<StateId> &order) override {
+    std::vector<StateId> newid(states_.size(), kNoStateId);
+    for (size_t i = 0; i < order.size(); i++) newid[order[i]] = (StateId)i;
+    std::vector<State> ns(order.size());
+    for (size_t i = 0; i < order.size(); i++) {
+      State &o = states_[order[i]]; ns[i].final = o.final;
+      for (A &a : o.arcs) if (newid[a.nextstate] != kNoStateId) { a.nextstate = newid[a.nextstate]; ns[i].arcs.push_back(a); if (a.ilabel == 0) ns[i].niepsilons++; }
+    }
+    start_ = start_ == kNoStateId ? kNoStateId : newid[start_];
+    states_.swap(ns);
+  }
+  // kExpanded / kMutable always; kILabelSorted as last established by ArcSort (or computed when `test`); kTopSorted only computed
+  uint64 Properties(uint64 mask, bool test) const override {
+    uint64 p = kExpanded | kMutable;
+    bool ils = ilabel_sorted_;
+    if (test) {
+      bool top = true; ils = true;
+      for (size_t s = 0; s < states_.size(); s++) for (size_t k = 0; k < states_[s].arcs.size(); k++) {
+        if (states_[s].arcs[k].nextstate <= (StateId)s) top = false;
+        if (k && states_[s].arcs[k].ilabel < states_[s].arcs[k - 1].ilabel) ils = false;
+      }
+      if (top) p |= kTopSorted;
+    }
+    if (ils) p |= kILabelSorted;
+    return p & mask;
+  }
   void SetStart(StateId s) override { start_ = s; }
   void SetFinal(StateId s, Weight w) override { states_[s].final = w; }
   void DeleteStates() override { states_.clear(); start_ = kNoStateId; }
@@ -109,11 +170,17 @@ template <class A> class VectorFst : public MutableFst<A> {
  protected:
   void CopyFrom(const Fst<A> &f);
   struct State { Weight final = Weight::Zero(); std::vector<A> arcs; size_t niepsilons = 0; };
-  std::vector<State> states_; StateId start_ = kNoStateId;
+  std::vector<State> states_; StateId start_ = kNoStateId; bool ilabel_sorted_ = false;
 };
+template <class A> void VectorFst<A>::CopyFrom(const Fst<A> &f) {
+  const auto *e = dynamic_cast<const ExpandedFst<A> *>(&f); CHECK(e != nullptr);
+  for (StateId s = 0; s < e->NumStates(); s++) { AddState(); SetFinal(s, e->Final(s)); const A *a = e->ArcsOf(s); for (size_t k = 0; k < e->NumArcs(s); k++) AddArc(s, a[k]); }
+  start_ = e->Start();
+}
 template <class A> class ConstFst : public VectorFst<A> {
  public:
   ConstFst() {}
+  ConstFst *Copy(bool = false) const override { return new ConstFst(*this); }
   const std::string &Type() const override { static const std::string t = "const"; return t; }
 };
 using StdFst = Fst<StdArc>; using StdVectorFst = VectorFst<StdArc>; using StdConstFst = ConstFst<StdArc>;
@@ -131,6 +198,29 @@ template <class F> class ArcIterator {
  private:
   const Arc *arcs_; size_t n_, i_;
 };
+
+template <class F> class StateIterator {
+ public:
+  using StateId = typename F::Arc::StateId;
+  explicit StateIterator(const F &fst) : n_(fst.NumStates()), s_(0) {}
+  bool Done() const { return s_ >= n_; }
+  StateId Value() const { return s_; }
+  void Next() { ++s_; }
+ private:
+  StateId n_, s_;
+};
+template <class F> class MutableArcIterator {
+ public:
+  using Arc = typename F::Arc; using StateId = typename Arc::StateId;
+  MutableArcIterator(F *fst, StateId s) : fst_(fst), s_(s), n_(fst->NumArcs(s)), i_(0) {}
+  bool Done() const { return i_ >= n_; }
+  const Arc &Value() const { return fst_->ArcsOf(s_)[i_]; }
+  void Next() { ++i_; }
+  void SetValue(const Arc &a) { fst_->MutableArcsOf(s_)[i_] = a; fst_->ArcsChanged(s_, false); }
+ private:
+  F *fst_; StateId s_; size_t n_, i_;
+};
+template <class To, class From> To down_cast(From *f) { return static_cast<To>(f); }
 
 template <class T> class MemoryPool {          // fst/memory.h: fixed-size object pool; here straight to the heap
  public:
@@ -155,8 +245,53 @@ template <class W1, class W2> class PairWeight {
 template <class A> struct ILabelCompare { bool operator()(const A &a, const A &b) const { return a.ilabel < b.ilabel; } };
 [[noreturn]] inline void NotInStandIn(const char *what) { std::cerr << what << " is not part of the OpenFst stand-in (oracle/ref_tools/minifst)\n"; std::abort(); }
 template <class A> void ShortestPath(const Fst<A> &, MutableFst<A> *) { NotInStandIn("ShortestPath"); }
-template <class A> void Invert(MutableFst<A> *) { NotInStandIn("Invert"); }
-template <class A, class C> void ArcSort(MutableFst<A> *, C) { NotInStandIn("ArcSort"); }
-template <class A> void Connect(MutableFst<A> *) { NotInStandIn("Connect"); }
+template <class A> void Invert(MutableFst<A> *f) {
+  for (typename A::StateId s = 0; s < f->NumStates(); s++) { A *a = f->MutableArcsOf(s); for (size_t k = 0; k < f->NumArcs(s); k++) std::swap(a[k].ilabel, a[k].olabel); f->ArcsChanged(s, false); }
+}
+template <class A, class C> void ArcSort(MutableFst<A> *f, C comp) {
+  for (typename A::StateId s = 0; s < f->NumStates(); s++) { A *a = f->MutableArcsOf(s); std::sort(a, a + f->NumArcs(s), comp); f->ArcsChanged(s, true); }
+  if (auto *v = dynamic_cast<VectorFst<A> *>(f)) v->MarkILabelSorted();
+}
+// depth-first search from the start state, then from every state not reached yet in numeric order; new numbering = reverse finishing
+// order (fst/topsort.h).  false (and the FST untouched) when there is a cycle.
+template <class A> bool TopSort(MutableFst<A> *f) {
+  using StateId = typename A::StateId;
+  const StateId n = f->NumStates();
+  if (n == 0) return true;
+  std::vector<char> color(n, 0); std::vector<size_t> pos(n, 0); std::vector<StateId> stack, finish;
+  auto visit = [&](StateId root) {
+    stack.push_back(root); color[root] = 1;
+    while (!stack.empty()) {
+      const StateId s = stack.back();
+      if (pos[s] < f->NumArcs(s)) {
+        const StateId d = f->ArcsOf(s)[pos[s]++].nextstate;
+        if (color[d] == 1) return false;
+        if (color[d] == 0) { color[d] = 1; stack.push_back(d); }
+      } else { color[s] = 2; finish.push_back(s); stack.pop_back(); }
+    }
+    return true;
+  };
+  if (f->Start() != kNoStateId && !visit(f->Start())) return false;
+  for (StateId s = 0; s < n; s++) if (color[s] == 0 && !visit(s)) return false;
+  std::vector<StateId> order(finish.rbegin(), finish.rend());
+  f->ReplaceStates(order);
+  return true;
+}
+// keeps the states that are reachable from the start state and from which a final state is reachable, in their old relative order
+template <class A> void Connect(MutableFst<A> *f) {
+  using StateId = typename A::StateId; using Weight = typename A::Weight;
+  const StateId n = f->NumStates();
+  if (n == 0) return;
+  std::vector<char> acc(n, 0), co(n, 0); std::vector<StateId> st; std::vector<std::vector<StateId>> rev(n);
+  for (StateId s = 0; s < n; s++) for (size_t k = 0; k < f->NumArcs(s); k++) rev[f->ArcsOf(s)[k].nextstate].push_back(s);
+  if (f->Start() != kNoStateId) { acc[f->Start()] = 1; st.push_back(f->Start()); }
+  while (!st.empty()) { const StateId s = st.back(); st.pop_back(); for (size_t k = 0; k < f->NumArcs(s); k++) { const StateId d = f->ArcsOf(s)[k].nextstate; if (!acc[d]) { acc[d] = 1; st.push_back(d); } } }
+  for (StateId s = 0; s < n; s++) if (f->Final(s) != Weight::Zero()) { co[s] = 1; st.push_back(s); }
+  while (!st.empty()) { const StateId s = st.back(); st.pop_back(); for (StateId p : rev[s]) if (!co[p]) { co[p] = 1; st.push_back(p); } }
+  std::vector<StateId> order; for (StateId s = 0; s < n; s++) if (acc[s] && co[s]) order.push_back(s);
+  if ((StateId)order.size() == n) return;
+  if (order.empty() || !(acc[f->Start()] && co[f->Start()])) { f->DeleteStates(); return; }
+  f->ReplaceStates(order);
+}
 }  // namespace fst
 #endif

@@ -1,7 +1,7 @@
 """Host-side word-level lattice determinization (kaldi_amd/host/k3_lattice.cc, the lattice-determinize-pruned program): CPU only.
-OpenFst is not available, so the reference's determinizer cannot be run here (parity unpinned); these are the defining properties
-the reference's own determinize-lattice-pruned-test.cc checks through RandEquivalent, verified by exhaustive path enumeration on
-small random lattices:
+Two kinds of checks: (1) at the end of the file, character-for-character equality with the REFERENCE's own determinizer source
+(compiled unmodified against the OpenFst stand-in of oracle/ref_tools/minifst); (2) the defining properties the reference's own
+determinize-lattice-pruned-test.cc checks through RandEquivalent, verified by exhaustive path enumeration on small random lattices:
   * the output is deterministic on word labels and has no epsilon arcs,
   * every word sequence whose best raw path is within the beam is present,
   * each word sequence present appears once, with the (graph, acoustic) cost and the transition-id string of its best raw path.
@@ -349,3 +349,61 @@ def test_convert_lattice_folds_chains_and_keeps_every_path():
     out = lc.parse_compact_text(r.stdout.decode())["c"]
     assert len(out["arcs"]) == 1 and out["arcs"][0][2] == 9 and out["arcs"][0][5] == (3, 4, 5) and abs(out["arcs"][0][3] - 1.25) < 1e-6 and abs(out["arcs"][0][4] - 4.5) < 1e-6
     assert list(out["finals"].values()) == [(0.5, 0.0, ())]
+
+
+# ---- the restated determinizer against the REFERENCE's own source ----------------------------------------------------------------
+# oracle/_ref/bin/ref-lattice-determinize is /root/reference/src/lat/determinize-lattice-pruned.cc compiled unmodified against a
+# stand-in for the part of OpenFst it touches (oracle/ref_tools/minifst, oracle/build_ref.sh), driven like the reference's
+# lattice-determinize-pruned / lattice-determinize-phone-pruned.  The programs here must print the same CompactLattices character for
+# character: same states in the same order, same arcs, same weights to the 6 digits of the text format, same transition-id strings.
+REF_EXE = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-lattice-determinize")
+
+def _ref_lattices(kind):
+    if kind == "random": return [("k%02d" % s, lc.random_lattice(s, frames=5 + s % 4, width=3 + s % 3, words=2 + s % 3, tids=40)) for s in range(12)]
+    if kind == "ties": return [("t%02d" % s, lc.random_lattice(100 + s, frames=6, width=3, words=2, tids=40, quant=4)) for s in range(8)]
+    if kind == "wide": return [("b%d" % s, lc.random_lattice(900 + s, frames=12, width=4, words=4, tids=40, p_word=0.5)) for s in range(4)]
+    raise KeyError(kind)
+
+REF_CASES = {   # name: (lattices, mode, beam, acoustic scale, extra options)
+    "word_beam3": ("random", "word", 3.0, 1.0, ()), "word_wide_scaled": ("random", "word", 1000.0, 0.5, ()),
+    "phone_beam3": ("random", "phone", 3.0, 1.0, ()), "phone_wide_scaled": ("random", "phone", 1000.0, 0.3, ()),
+    "word_ties": ("ties", "word", 50.0, 1.0, ()), "phone_ties": ("ties", "phone", 50.0, 1.0, ()),
+    "word_max_mem_retry": ("wide", "word", 8.0, 1.0, ("--max-mem=20000",)), "phone_max_mem_retry": ("wide", "phone", 1000.0, 1.0, ("--max-mem=2000",)),
+}
+
+def write_model(td):
+    from kaldi_amd import synth
+    path = os.path.join(td, "final.mdl")
+    synth.make_tdnn(seed=1, dim=32, num_pdfs=20).write(path, as_mdl=True, num_pdfs=20, left_context=2, right_context=2)
+    return path
+
+def _case_input(name, td):
+    kind, mode, beam, scale, extra = REF_CASES[name]
+    path = os.path.join(td, name + ".in.txt")
+    open(path, "w").write("".join(lc.lattice_text(k, l) for k, l in _ref_lattices(kind)))
+    return path, mode, beam, scale, list(extra)
+
+def run_reference(name, td, mdl):
+    path, mode, beam, scale, extra = _case_input(name, td)
+    out = os.path.join(td, name + ".ref.txt")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([REF_EXE, mode, repr(beam), repr(scale), path, out] + ([mdl] if mode == "phone" else []) + extra, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    return open(out).read()
+
+def run_ours(name, td, mdl):
+    path, mode, beam, scale, extra = _case_input(name, td)
+    exe = PROG if mode == "word" else PHONE_PROG
+    r = subprocess.run([exe, "--beam=%r" % beam, "--acoustic-scale=%r" % scale] + extra + ([mdl] if mode == "phone" else []) + ["ark,t:" + path, "ark,t:-"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+@pytest.mark.parametrize("name", sorted(REF_CASES))
+def test_output_equals_the_reference_determinizer_character_for_character(name, tmp_path):
+    import json
+    td = str(tmp_path); model = write_model(td)
+    ours = run_ours(name, td, model)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "det_ref_golden.json")))
+    assert ours == gold[name]                                # recorded from the reference binary (tests/golden/make_golden_det.py)
+    if os.path.exists(REF_EXE): assert ours == run_reference(name, td, model)      # and live, where oracle/_ref is present
+    assert len(lc.parse_compact_text(ours)) == len(_ref_lattices(REF_CASES[name][0]))
