@@ -35,7 +35,7 @@ constexpr int kNoLabel = -1;
 constexpr float kDelta = 1.0F / 1024.0F;
 constexpr char kStringSeparator = '_';
 constexpr uint64 kLeftSemiring = 0x1, kRightSemiring = 0x2, kSemiring = 0x3, kCommutative = 0x4, kIdempotent = 0x8, kPath = 0x10;
-constexpr uint64 kExpanded = 0x1, kMutable = 0x2, kILabelSorted = 0x10000000ULL, kTopSorted = 0x4000000000ULL;
+constexpr uint64 kExpanded = 0x1, kMutable = 0x2, kILabelSorted = 0x10000000ULL, kOLabelSorted = 0x40000000ULL, kTopSorted = 0x4000000000ULL;
 inline std::string FST_FLAGS_fst_weight_separator = ",";
 enum DivideType { DIVIDE_LEFT, DIVIDE_RIGHT, DIVIDE_ANY };
 
@@ -108,6 +108,7 @@ template <class A> class MutableFst : public ExpandedFst<A> {
   virtual void DeleteStates() = 0;
   virtual void SetInputSymbols(const SymbolTable *) {}
   virtual void SetOutputSymbols(const SymbolTable *) {}
+  virtual void SetProperties(uint64 /*props*/, uint64 /*mask*/) {}
   virtual A *MutableArcsOf(typename A::StateId s) = 0;   // (not OpenFst API: behind MutableArcIterator and the algorithms below)
   virtual void ArcsChanged(typename A::StateId s, bool sorted_on_ilabel) = 0;
   virtual void ReplaceStates(const std::vector<typename A::StateId> &order) = 0;      // new state i = old state order[i]; states not listed are deleted
@@ -230,7 +231,10 @@ template <class T> class MemoryPool {          // fst/memory.h: fixed-size objec
 };
 
 // names the reference's fstext/openfst_compat.h and lattice-weight.h mention in declarations that the decoder never uses
-struct ArcMapFstOptions {};
+enum MapFinalAction { MAP_NO_SUPERFINAL, MAP_ALLOW_SUPERFINAL, MAP_REQUIRE_SUPERFINAL };
+enum MapSymbolsAction { MAP_CLEAR_SYMBOLS, MAP_COPY_SYMBOLS, MAP_NOOP_SYMBOLS };
+struct CacheOptions { CacheOptions(bool = false, size_t = 0) {} };
+struct ArcMapFstOptions { ArcMapFstOptions() {} explicit ArcMapFstOptions(const CacheOptions &) {} };
 template <class A, class B, class C> class ArcMapFst;
 template <class W1, class W2> class PairWeight {
  public:
@@ -251,6 +255,36 @@ template <class A> void Invert(MutableFst<A> *f) {
 template <class A, class C> void ArcSort(MutableFst<A> *f, C comp) {
   for (typename A::StateId s = 0; s < f->NumStates(); s++) { A *a = f->MutableArcsOf(s); std::sort(a, a + f->NumArcs(s), comp); f->ArcsChanged(s, true); }
   if (auto *v = dynamic_cast<VectorFst<A> *>(f)) v->MarkILabelSorted();
+}
+// fst/dfs-visit.h: depth-first traversal driven by a visitor (InitVisit, InitState(s, root), TreeArc / BackArc / ForwardOrCrossArc(s, arc),
+// FinishState(s, parent, parent_arc), FinishVisit); roots are the start state, then every state not reached yet in numeric order.
+template <class F, class Visitor> void DfsVisit(const F &fst, Visitor *visitor) {
+  using Arc = typename F::Arc; using StateId = typename Arc::StateId;
+  visitor->InitVisit(fst);
+  const auto *e = dynamic_cast<const ExpandedFst<Arc> *>(&fst); CHECK(e != nullptr);
+  const StateId n = e->NumStates();
+  if (fst.Start() == kNoStateId) { visitor->FinishVisit(); return; }
+  std::vector<char> color(n, 0); std::vector<size_t> pos(n, 0); std::vector<StateId> stack;
+  bool go = true;
+  auto run = [&](StateId root) {
+    color[root] = 1; stack.push_back(root); go = visitor->InitState(root, root);
+    while (!stack.empty()) {
+      const StateId s = stack.back();
+      if (!go || pos[s] >= fst.NumArcs(s)) {
+        color[s] = 2; stack.pop_back();
+        if (!stack.empty()) { const StateId p = stack.back(); visitor->FinishState(s, p, &fst.ArcsOf(p)[pos[p] - 1]); } else visitor->FinishState(s, kNoStateId, nullptr);
+        continue;
+      }
+      const Arc &arc = fst.ArcsOf(s)[pos[s]++];
+      const StateId d = arc.nextstate;
+      if (color[d] == 0) { go = visitor->TreeArc(s, arc); if (!go) continue; color[d] = 1; stack.push_back(d); go = visitor->InitState(d, root); }
+      else if (color[d] == 1) go = visitor->BackArc(s, arc);
+      else go = visitor->ForwardOrCrossArc(s, arc);
+    }
+  };
+  run(fst.Start());
+  for (StateId s = 0; s < n && go; s++) if (color[s] == 0) run(s);
+  visitor->FinishVisit();
 }
 // depth-first search from the start state, then from every state not reached yet in numeric order; new numbering = reverse finishing
 // order (fst/topsort.h).  false (and the FST untouched) when there is a cycle.

@@ -12,4 +12,5 @@ with tempfile.TemporaryDirectory() as td:
     for name in t.REF_CASES:
         out[name] = t.run_reference(name, td, mdl)
         print(name, len(out[name]), "bytes")
+    out["convert_lattice"] = t.run_reference_convert(td)
 json.dump(out, open(os.path.join(ROOT, "tests", "golden", "det_ref_golden.json"), "w"), indent=0, sort_keys=True)

@@ -407,3 +407,26 @@ def test_output_equals_the_reference_determinizer_character_for_character(name, 
     assert ours == gold[name]                                # recorded from the reference binary (tests/golden/make_golden_det.py)
     if os.path.exists(REF_EXE): assert ours == run_reference(name, td, model)      # and live, where oracle/_ref is present
     assert len(lc.parse_compact_text(ours)) == len(_ref_lattices(REF_CASES[name][0]))
+
+
+def _convert_input(td):
+    path = os.path.join(td, "conv.in.txt")
+    open(path, "w").write("".join(lc.lattice_text("k%02d" % s, lc.random_lattice(700 + s, frames=7, width=2 + s % 3, words=3, p_word=0.2)) for s in range(16)))
+    return path
+
+def run_reference_convert(td):
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = os.path.join(td, "conv.ref.txt")
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "bin", "ref-convert-lattice"), _convert_input(td), out], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    return open(out).read()
+
+def test_convert_lattice_equals_the_reference_character_for_character(tmp_path):
+    """ConvertLattice + Factor of the reference (fstext/lattice-utils-inl.h, fstext/factor-inl.h, compiled unmodified against the
+    OpenFst stand-in): same folded chains, same state order, same text"""
+    import json
+    td = str(tmp_path)
+    r = subprocess.run([os.path.join(ROOT, "kaldi_amd", "bin", "k3-host-tool"), "convert-lattice", "ark,t:" + _convert_input(td), "ark,t:-"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == json.load(open(os.path.join(ROOT, "tests", "golden", "det_ref_golden.json")))["convert_lattice"]
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bin", "ref-convert-lattice")): assert r.stdout == run_reference_convert(td)
