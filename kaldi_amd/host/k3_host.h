@@ -118,7 +118,7 @@ struct DeterminizeLatticePrunedOptions {     // lat/determinize-lattice-pruned.h
 bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *clat, const DeterminizeLatticePrunedOptions &opts = DeterminizeLatticePrunedOptions());
 // DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1410-1499): what the decoders call.  With phone_determinize a
 // first pass runs over the lattice with phone labels inserted at the phone boundaries (keeps the word pass's subsets small), then the
-// word-level pass.  word_determinize=false and minimize=true are not implemented (FatalError).
+// word-level pass, then (minimize) push + minimize.  word_determinize=false is not implemented (FatalError).
 struct DeterminizeLatticePhonePrunedOptions { float delta = 1.0f / 1024.0f; int32_t max_mem = 50000000; bool phone_determinize = true, word_determinize = true, minimize = false; };
 bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &trans, double beam, CompactLattice *clat,
                                    const DeterminizeLatticePhonePrunedOptions &opts = DeterminizeLatticePhonePrunedOptions());
@@ -130,6 +130,13 @@ void ConvertLattice(const Lattice &lat, CompactLattice *clat);
 void Connect(CompactLattice *clat);                        // fst::Connect; keeps the relative order of the surviving states
 void ScaleAcoustic(CompactLattice *clat, double scale);
 bool TopSortIfNeeded(CompactLattice *clat);                // TopSortCompactLatticeIfNeeded (lat/lattice-functions.cc); false on a cycle
+// --minimize of the determinization programs (determinize-lattice-pruned.cc:1455-1460, lattice-determinize-pruned.cc:122-126):
+// PushCompactLatticeStrings / PushCompactLatticeWeights (lat/push-lattice.cc: transition-ids and weights moved as far towards the start
+// state as all paths allow) then MinimizeCompactLattice (lat/minimize-lattice.cc: states with the same future merged; delta = tolerance on
+// weights).  All three sort the lattice topologically first and return false when that fails.
+bool PushCompactLatticeStrings(CompactLattice *clat);
+bool PushCompactLatticeWeights(CompactLattice *clat);
+bool MinimizeCompactLattice(CompactLattice *clat, float delta = 1.0f / 1024.0f);
 // kaldi::PruneLattice (lat/lattice-functions.cc:233-318) on a raw lattice (any state order; acyclic): drops arcs and final
 // weights that are on no path within `beam` of the best path, then trims.
 bool PruneLattice(double beam, Lattice *lat);
@@ -172,7 +179,7 @@ class TableWriter {        // "ark:wxfilename" | "ark,t:wxfilename" (other optio
 class DeterminizeSequencer {
  public:
   struct Config {
-    int32_t num_threads = 1; double beam = 10.0, pre_scale = 1.0, post_scale = 1.0; bool topsort = false; DeterminizeLatticePrunedOptions det;
+    int32_t num_threads = 1; double beam = 10.0, pre_scale = 1.0, post_scale = 1.0; bool topsort = false, minimize = false; DeterminizeLatticePrunedOptions det;
     const TransitionInfo *trans = nullptr; DeterminizeLatticePhonePrunedOptions phone_det;       // trans != nullptr: DeterminizeLatticePhonePruned with phone_det
   };
   DeterminizeSequencer(const Config &config, TableWriter *writer);

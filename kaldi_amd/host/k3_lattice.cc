@@ -13,8 +13,8 @@
 //
 // Both entry points of the reference are here: DeterminizeLatticePruned (one word-level pass; lattice-determinize-pruned) and
 // DeterminizeLatticePhonePruned (phone-level pass first, then the word-level pass; what the decoders and
-// lattice-determinize-phone-pruned call).  Not implemented: --minimize (PushCompactLatticeStrings / Weights + MinimizeCompactLattice)
-// and --word-determinize=false (needs ConvertLattice's Factor).
+// lattice-determinize-phone-pruned call), with --minimize (PushCompactLatticeStrings / Weights + MinimizeCompactLattice).
+// Not implemented: --word-determinize=false.
 #include "k3_host.h"
 #include <algorithm>
 #include <cmath>
@@ -534,10 +534,13 @@ bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *c
 // phone labels inserted at the phone boundaries (DeterminizeLatticePhonePrunedFirstPass :1388-1407; its output is an ordinary FST,
 // no longer deterministic once the phone labels are deleted again), then the word-level pass.
 bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &trans, double beam, CompactLattice *clat, const DeterminizeLatticePhonePrunedOptions &opts) {
-  if (opts.minimize) K3H_ERR << "DeterminizeLatticePhonePruned: --minimize=true is not supported";
   if (!opts.word_determinize) K3H_ERR << "DeterminizeLatticePhonePruned: --word-determinize=false is not supported";
   DeterminizeLatticePrunedOptions det_opts; det_opts.delta = opts.delta; det_opts.max_mem = opts.max_mem;
-  if (!opts.phone_determinize) return DeterminizeLatticePruned(lat, beam, clat, det_opts);
+  auto finish = [&](bool ans) {                  // :1455-1460
+    if (opts.minimize) { ans = PushCompactLatticeStrings(clat) && ans; ans = PushCompactLatticeWeights(clat) && ans; ans = MinimizeCompactLattice(clat) && ans; }
+    return ans;
+  };
+  if (!opts.phone_determinize) return finish(DeterminizeLatticePruned(lat, beam, clat, det_opts));
   *clat = CompactLattice();
   EdgeFst e = InvertedEdges(lat);
   if (e.fin.empty()) return true;
@@ -548,7 +551,7 @@ bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &tra
   for (int32_t &wd : pass1.word) if (wd >= first_phone_label) wd = 0;          // DeterminizeLatticeDeletePhones :1346-1368
   InputFst g = SortedInput(pass1);
   if (g.NumStates() == 0) return ans;
-  return DeterminizeWithRetries(std::move(g), beam, det_opts, [&](const Determinizer &det) { det.Output(clat); Connect(clat); }) && ans;
+  return finish(DeterminizeWithRetries(std::move(g), beam, det_opts, [&](const Determinizer &det) { det.Output(clat); Connect(clat); }) && ans);
 }
 
 bool PruneLattice(double beam, Lattice *lat) {
@@ -696,6 +699,135 @@ bool TopSortIfNeeded(CompactLattice *c) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------ push + minimize ----
+namespace {
+struct ArcsByState {                 // arc indices grouped by source state, in stored order
+  std::vector<int32_t> off, idx;
+  explicit ArcsByState(const CompactLattice &c) : off(c.NumStates() + 1, 0), idx(c.arc_src.size()) {
+    for (int32_t s : c.arc_src) off[s + 1]++;
+    for (int32_t s = 0; s < c.NumStates(); s++) off[s + 1] += off[s];
+    std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < c.arc_src.size(); a++) idx[p[c.arc_src[a]]++] = (int32_t)a;
+  }
+  int32_t Num(int32_t s) const { return off[s + 1] - off[s]; }
+  int32_t Arc(int32_t s, int32_t k) const { return idx[off[s] + k]; }
+};
+// CompactLatticePusher::GetString (push-lattice.cc:53-84): the first `len` transition-ids met from `state`, through arc `arc_k`
+// (-1: any path -- the final string if the state is final, else the first arc)
+void GetString(const CompactLattice &c, const ArcsByState &by, int32_t state, int32_t arc_k, int32_t *out, size_t len) {
+  if (len == 0) return;
+  if (arc_k < 0 && c.is_final[state]) {
+    if (c.fin_str[state].size() < len) K3H_ERR << "PushCompactLatticeStrings: paths in lattice have inconsistent lengths";
+    std::copy(c.fin_str[state].begin(), c.fin_str[state].begin() + len, out); return;
+  }
+  if (by.Num(state) == 0 || arc_k >= by.Num(state)) K3H_ERR << "PushCompactLatticeStrings: paths in lattice are inconsistent in length";
+  const int32_t a = by.Arc(state, arc_k < 0 ? 0 : arc_k); const std::vector<int32_t> &str = c.arc_str[a];
+  if (str.size() >= len) std::copy(str.begin(), str.begin() + len, out);
+  else { std::copy(str.begin(), str.end(), out); GetString(c, by, c.arc_dst[a], -1, out + str.size(), len - str.size()); }
+}
+}  // namespace
+
+bool PushCompactLatticeStrings(CompactLattice *c) {      // push-lattice.cc:30-227
+  if (!TopSortIfNeeded(c)) { K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)"; return false; }
+  const int32_t n = c->NumStates(); const ArcsByState by(*c);
+  std::vector<int32_t> shift(n, 0);
+  for (int32_t s = n - 1; s > c->start; s--) {           // ComputeShifts :134-164; the start state keeps shift 0
+    const int32_t narcs = by.Num(s);
+    if (narcs == 0) { shift[s] = c->is_final[s] ? (int32_t)c->fin_str[s].size() : 0; continue; }
+    int32_t sh = std::numeric_limits<int32_t>::max();
+    if (c->is_final[s]) sh = std::min(sh, (int32_t)c->fin_str[s].size());
+    for (int32_t k = 0; k < narcs; k++) { const int32_t a = by.Arc(s, k); sh = std::min(sh, shift[c->arc_dst[a]] + (int32_t)c->arc_str[a].size()); }
+    if (narcs + (c->is_final[s] ? 1 : 0) > 1 && sh > 0) {     // CheckForConflict :86-131: the strings moved back must agree on every way out
+      std::vector<int32_t> str(sh), cmp(sh); int32_t k;
+      if (c->is_final[s]) { std::copy(c->fin_str[s].begin(), c->fin_str[s].begin() + sh, str.begin()); k = 0; }
+      else { GetString(*c, by, s, 0, str.data(), str.size()); k = 1; }
+      for (; k < narcs; k++) {
+        GetString(*c, by, s, k, cmp.data(), cmp.size());
+        const auto pr = std::mismatch(str.begin(), str.end(), cmp.begin());
+        if (pr.first != str.end()) { sh = (int32_t)(pr.first - str.begin()); str.resize(sh); cmp.resize(sh); }
+      }
+    }
+    shift[s] = sh;
+  }
+  // ApplyShifts :166-200 (in state order; GetString reads strings of later states, which are still unmodified)
+  CompactLattice o = *c;
+  for (int32_t s = 0; s < n; s++) {
+    for (int32_t k = 0; k < by.Num(s); k++) {
+      const int32_t a = by.Arc(s, k); std::vector<int32_t> str = c->arc_str[a]; const size_t orig = str.size(), next_shift = (size_t)shift[c->arc_dst[a]];
+      str.resize(orig + next_shift);
+      GetString(o, by, c->arc_dst[a], -1, str.data() + orig, next_shift);
+      o.arc_str[a].assign(str.begin() + shift[s], str.end());
+    }
+    if (c->is_final[s]) o.fin_str[s].assign(c->fin_str[s].begin() + shift[s], c->fin_str[s].end());
+  }
+  *c = std::move(o);
+  return true;
+}
+
+bool PushCompactLatticeWeights(CompactLattice *c) {      // push-lattice.cc:236-289
+  if (!TopSortIfNeeded(c)) { K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)"; return false; }
+  const int32_t n = c->NumStates();
+  if (n == 0) { K3H_WARN << "Pushing weights of empty compact lattice"; return true; }
+  const ArcsByState by(*c);
+  std::vector<LatW> to_end(n);
+  for (int32_t s = n - 1; s >= 0; s--) {
+    LatW w = c->is_final[s] ? LatW{c->fin_graph[s], c->fin_ac[s]} : Zero();
+    for (int32_t k = 0; k < by.Num(s); k++) { const int32_t a = by.Arc(s, k); w = Plus(w, Times(LatW{c->arc_graph[a], c->arc_ac[a]}, to_end[c->arc_dst[a]])); }
+    if (w == Zero()) K3H_WARN << "Lattice has non-coaccessible states.";
+    to_end[s] = w;
+  }
+  to_end[0] = One();                 // the leftover weight stays on the start state
+  for (int32_t s = 0; s < n; s++) {
+    const LatW here = to_end[s];
+    if (here == Zero()) continue;
+    for (int32_t k = 0; k < by.Num(s); k++) {
+      const int32_t a = by.Arc(s, k); const LatW next = to_end[c->arc_dst[a]];
+      if (next != Zero()) { const LatW w = Times(LatW{c->arc_graph[a], c->arc_ac[a]}, Divide(next, here)); c->arc_graph[a] = w.g; c->arc_ac[a] = w.a; }
+    }
+    if (c->is_final[s]) { const LatW w = Divide(LatW{c->fin_graph[s], c->fin_ac[s]}, here); c->fin_graph[s] = w.g; c->fin_ac[s] = w.a; }
+  }
+  return true;
+}
+
+bool MinimizeCompactLattice(CompactLattice *c, float delta) {      // minimize-lattice.cc:37-275
+  if (!TopSortIfNeeded(c)) { K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)"; return false; }
+  const int32_t n = c->NumStates(); const ArcsByState by(*c);
+  auto string_hash = [](const std::vector<int32_t> &v) { size_t h = 0; for (int32_t x : v) { h *= 7853; h += (size_t)x; } return h == 0 ? (size_t)53281 : h; };    // VectorHasher, never 0
+  std::vector<size_t> hash(n);
+  for (int32_t s = n - 1; s >= 0; s--) {                 // ComputeStateHashValues :98-123: order-insensitive over the arcs
+    size_t h = c->is_final[s] ? (size_t)607 * string_hash(c->fin_str[s]) : (size_t)33317;
+    for (int32_t k = 0; k < by.Num(s); k++) {
+      const int32_t a = by.Arc(s, k); size_t label = (size_t)c->arc_label[a]; if (label == 0) label = 51907;
+      h += (size_t)1447 * label * (1 + string_hash(c->arc_str[a]) * hash[c->arc_dst[a]]);
+    }
+    hash[s] = h;
+  }
+  std::unordered_map<size_t, std::vector<int32_t>> groups;
+  for (int32_t s = 0; s < n; s++) groups[hash[s]].push_back(s);
+  std::vector<int32_t> map(n); for (int32_t s = 0; s < n; s++) map[s] = s;
+  struct A { int32_t label, next; LatW w; const std::vector<int32_t> *str; };
+  auto arcs_of = [&](int32_t s) {
+    std::vector<A> v; for (int32_t k = 0; k < by.Num(s); k++) { const int32_t a = by.Arc(s, k); v.push_back({c->arc_label[a], map[c->arc_dst[a]], LatW{c->arc_graph[a], c->arc_ac[a]}, &c->arc_str[a]}); }
+    std::sort(v.begin(), v.end(), [](const A &x, const A &y) { return x.label != y.label ? x.label < y.label : x.next < y.next; });
+    return v;
+  };
+  auto equivalent = [&](int32_t s, int32_t t) {          // :143-186
+    if (c->is_final[s] != c->is_final[t]) return false;
+    if (c->is_final[s] && !(ApproxEqual(LatW{c->fin_graph[s], c->fin_ac[s]}, LatW{c->fin_graph[t], c->fin_ac[t]}, delta) && c->fin_str[s] == c->fin_str[t])) return false;
+    if (by.Num(s) != by.Num(t)) return false;
+    const std::vector<A> x = arcs_of(s), y = arcs_of(t);
+    for (size_t i = 0; i < x.size(); i++) if (x[i].next != y[i].next || x[i].label != y[i].label || !(ApproxEqual(x[i].w, y[i].w, 1.0f / 1024.0f) && *x[i].str == *y[i].str)) return false;
+    return true;
+  };
+  for (int32_t s = n - 1; s >= 0; s--)                   // ComputeStateMap :188-229
+    for (int32_t t : groups[hash[s]]) if (t > s && map[t] == t && equivalent(s, t)) { map[s] = t; break; }
+  bool any = false; for (int32_t s = 0; s < n; s++) any |= map[s] != s;
+  if (!any) return true;
+  c->start = map[c->start];                              // ModifyModel :231-262
+  for (size_t a = 0; a < c->arc_src.size(); a++) if (map[c->arc_src[a]] == c->arc_src[a]) c->arc_dst[a] = map[c->arc_dst[a]];
+  Connect(c);
+  return true;
+}
+
 namespace {
 template <class T> void Put(std::string *o, T v) { o->append((const char *)&v, sizeof(T)); }
 void PutStr(std::string *o, const std::string &s) { Put<int32_t>(o, (int32_t)s.size()); o->append(s); }
@@ -761,6 +893,7 @@ struct DeterminizeSequencer::Impl {
         const bool ok = cfg.trans ? DeterminizeLatticePhonePruned(job.lat, *cfg.trans, cfg.beam, &clat, cfg.phone_det) : DeterminizeLatticePruned(job.lat, cfg.beam, &clat, cfg.det);
         if (!ok) { K3H_WARN << "For key " << job.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; warn = true; }
         if (clat.NumStates() == 0) { K3H_WARN << "For key " << job.key << ", determinized and trimmed lattice was empty."; warn = true; }
+        if (cfg.minimize && !cfg.trans) { PushCompactLatticeStrings(&clat); PushCompactLatticeWeights(&clat); MinimizeCompactLattice(&clat); }      // with cfg.trans: phone_det.minimize, inside
         if (cfg.topsort && !TopSortIfNeeded(&clat)) K3H_WARN << "Topological sorting of the determinized lattice failed for key " << job.key;
         if (cfg.post_scale != 1.0) ScaleAcoustic(&clat, cfg.post_scale);
       } catch (const std::exception &e) { err = e.what(); }

@@ -1,6 +1,6 @@
 // lattice-determinize-pruned-parallel -- same command line as the reference's latbin/lattice-determinize-pruned-parallel.cc:104-190:
 // lattice-determinize-pruned with --num-threads; lattices are determinized on worker threads and written in input order
-// (DeterminizeSequencer = the reference's TaskSequencer).  Host-only.  --minimize=true is rejected.
+// (DeterminizeSequencer = the reference's TaskSequencer).  Host-only.
 #include <iostream>
 #include "k3_host.h"
 using namespace k3host;
@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
     DeterminizeLatticePrunedOptions opts; opts.max_mem = 50000000; opts.max_loop = 0;
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic likelihoods");
     po.Register("beam", &beam, "Pruning beam [applied after acoustic scaling].");
-    po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported by this build)");
+    po.Register("minimize", &minimize, "If true, push and minimize after determinization");
     po.Register("delta", &opts.delta, "Tolerance used in determinization");
     po.Register("max-mem", &opts.max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this)");
     po.Register("max-arcs", &opts.max_arcs, "Maximum number of arcs in output FST (total, not per state");
@@ -31,14 +31,13 @@ int main(int argc, char **argv) {
     po.Register("num-threads-total", &num_threads_total, "(accepted; the number of lattices in flight is num-threads + 20)");
     po.Read(argc, argv);
     if (po.NumArgs() != 2) { po.PrintUsage(); return 1; }
-    if (minimize) K3H_ERR << "--minimize=true is not supported";
     if (acoustic_scale == 0.0f) K3H_ERR << "Do not use a zero acoustic scale (cannot be inverted)";
     if (num_threads < 1) K3H_ERR << "--num-threads must be at least 1";
     auto lats = ReadLatticeTable(po.GetArg(1));
     TableWriter writer(po.GetArg(2));
     int32_t n_done = 0, n_warn = 0;
     {
-      DeterminizeSequencer::Config cfg; cfg.num_threads = num_threads; cfg.beam = beam; cfg.pre_scale = acoustic_scale; cfg.post_scale = 1.0 / acoustic_scale; cfg.det = opts;
+      DeterminizeSequencer::Config cfg; cfg.num_threads = num_threads; cfg.beam = beam; cfg.pre_scale = acoustic_scale; cfg.post_scale = 1.0 / acoustic_scale; cfg.det = opts; cfg.minimize = minimize;
       DeterminizeSequencer seq(cfg, &writer);
       for (auto &kv : lats) seq.Run(kv.first, std::move(kv.second));
       seq.Wait(); n_done = seq.NumDone(); n_warn = seq.NumWarn();

@@ -1,7 +1,7 @@
 // lattice-determinize-pruned -- same command line as the reference's latbin/lattice-determinize-pruned.cc:28-170: reads state-level
 // lattices (what the decoders here write with --determinize-lattice=false), scales the acoustic costs, determinizes on the word
 // labels with pruning, writes CompactLattices with the acoustic scale undone.  Host-only (no GPU work on this path).
-// Not implemented: --write-compact=false and --minimize=true (rejected, not ignored).
+// Not implemented: --write-compact=false (rejected, not ignored).
 #include <iostream>
 #include "k3_host.h"
 using namespace k3host;
@@ -21,7 +21,7 @@ int main(int argc, char **argv) {
     po.Register("write-compact", &write_compact, "If true, write in normal (compact) form (only true is supported by this build)");
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic likelihoods");
     po.Register("beam", &beam, "Pruning beam [applied after acoustic scaling].");
-    po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported by this build)");
+    po.Register("minimize", &minimize, "If true, push and minimize after determinization");
     po.Register("delta", &opts.delta, "Tolerance used in determinization");
     po.Register("max-mem", &opts.max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this)");
     po.Register("max-arcs", &opts.max_arcs, "Maximum number of arcs in output FST (total, not per state");
@@ -31,7 +31,6 @@ int main(int argc, char **argv) {
     po.Read(argc, argv);
     if (po.NumArgs() != 2) { po.PrintUsage(); return 1; }
     if (!write_compact) K3H_ERR << "--write-compact=false is not supported";
-    if (minimize) K3H_ERR << "--minimize=true is not supported";
     if (acoustic_scale == 0.0f) K3H_ERR << "Do not use a zero acoustic scale (cannot be inverted)";
     auto lats = ReadLatticeTable(po.GetArg(1));
     TableWriter writer(po.GetArg(2));
@@ -42,6 +41,7 @@ int main(int argc, char **argv) {
       CompactLattice clat;
       if (!DeterminizeLatticePruned(lat, beam, &clat, opts)) { K3H_WARN << "For key " << kv.first << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; n_warn++; }
       if (clat.NumStates() == 0) { K3H_WARN << "For key " << kv.first << ", determinized and trimmed lattice was empty."; n_warn++; }
+      if (minimize) { PushCompactLatticeStrings(&clat); PushCompactLatticeWeights(&clat); MinimizeCompactLattice(&clat); }
       if (!TopSortIfNeeded(&clat)) K3H_WARN << "Topological sorting of the determinized lattice failed for key " << kv.first;
       states_in += lat.NumStates(); arcs_out += (double)clat.arc_src.size();
       ScaleAcoustic(&clat, 1.0 / acoustic_scale);

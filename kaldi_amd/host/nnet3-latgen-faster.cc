@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
     po.Register("hash-ratio", &hash_ratio, "(accepted, unused: no hash-order dependence)"); po.Register("prune-scale", &prune_scale, "(accepted, unused)");
     po.Register("max-mem", &max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this)."); po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)");
     po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
-    po.Register("minimize", &minimize, "If true, push and minimize after determinization (only false is supported)"); po.Register("delta", &delta, "Tolerance used in determinization");
+    po.Register("minimize", &minimize, "If true, push and minimize after determinization."); po.Register("delta", &delta, "Tolerance used in determinization");
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods"); po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
     po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole)"); po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)");
     po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)"); po.Register("debug-computation", &debug_comp, "(accepted, unused)");
@@ -38,8 +38,8 @@ int main(int argc, char **argv) {
     po.Register("use-gpu", &use_gpu, "(this build always uses the GPU)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
     po.Read(argc, argv);
     if (po.NumArgs() < 4 || po.NumArgs() > 6) { po.PrintUsage(); return 1; }
-    if (determinize && (!word_det || minimize)) K3H_ERR << "--word-determinize=false and --minimize=true are not supported";
-    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = delta; det_opts.max_mem = max_mem; det_opts.phone_determinize = phone_det;
+    if (determinize && !word_det) K3H_ERR << "--word-determinize=false is not supported";
+    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = delta; det_opts.max_mem = max_mem; det_opts.phone_determinize = phone_det; det_opts.minimize = minimize;
     if (!ivector_rspecifier.empty() || !online_ivector_rspecifier.empty() || elc || erc) K3H_ERR << "i-vectors / extra context are not supported by this program";
     const std::string model_rx = po.GetArg(1), fst_rx = po.GetArg(2);
     if (fst_rx.find(':') != std::string::npos && fst_rx.compare(0, 3, "ark") == 0) K3H_ERR << "a table of per-utterance FSTs is not supported; give one HCLG";

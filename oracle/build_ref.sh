@@ -80,8 +80,8 @@ mkdir -p $W/obj_minifst
 g++ $MF -c $R/decoder/lattice-faster-decoder.cc -o $W/obj_minifst/lattice-faster-decoder.o
 g++ $MF $HERE/ref_tools/ref_lattice_decoder.cc $W/obj_minifst/lattice-faster-decoder.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-lattice-decoder
 # the reference's lattice determinization (lat/determinize-lattice-pruned.cc, unmodified) over the same stand-in: pins kaldi_amd/host/k3_lattice.cc
-g++ $MF -c $R/lat/determinize-lattice-pruned.cc -o $W/obj_minifst/determinize-lattice-pruned.o
-g++ $MF $HERE/ref_tools/ref_lattice_determinize.cc $W/obj_minifst/determinize-lattice-pruned.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-lattice-determinize
+for f in determinize-lattice-pruned push-lattice minimize-lattice; do g++ $MF -c $R/lat/$f.cc -o $W/obj_minifst/$f.o; done
+g++ $MF $HERE/ref_tools/ref_lattice_determinize.cc $W/obj_minifst/determinize-lattice-pruned.o $W/obj_minifst/push-lattice.o $W/obj_minifst/minimize-lattice.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-lattice-determinize
 # ConvertLattice + Factor (fstext/lattice-utils-inl.h, fstext/factor-inl.h: header-only templates of the reference) over the stand-in
 g++ $MF $HERE/ref_tools/ref_convert_lattice.cc $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-convert-lattice
 for f in /opt/conda/lib/libmkl_{rt,core,intel_lp64,sequential,gnu_thread,intel_thread,avx2,avx512,def,mc3,vml_avx2,vml_avx512,vml_def}.so.1; do

@@ -5,7 +5,8 @@
 //   ref-lattice-determinize word  <beam> <acoustic-scale> <lattices.txt> <out.txt>            = latbin/lattice-determinize-pruned.cc:96-140
 //   ref-lattice-determinize phone <beam> <acoustic-scale> <lattices.txt> <out.txt> <model>    = latbin/lattice-determinize-phone-pruned.cc:100-140
 // lattices.txt: Kaldi text archive of state-level lattices ("key", then "src dst ilabel olabel [graph,acoustic]" / "state [graph,acoustic]"
-// lines, blank line after each lattice).  Extra arguments after these: --max-mem=N --delta=X (defaults of the programs).
+// lines, blank line after each lattice).  Extra arguments after these: --max-mem=N --delta=X --minimize=true (defaults of the programs).
+// --minimize runs the reference's lat/push-lattice.cc and lat/minimize-lattice.cc (compiled unmodified as well).
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -13,6 +14,8 @@
 #include <string>
 #include "hmm/transition-model.h"
 #include "lat/determinize-lattice-pruned.h"
+#include "lat/minimize-lattice.h"
+#include "lat/push-lattice.h"
 #include "util/common-utils.h"
 
 namespace {
@@ -52,8 +55,12 @@ int main(int argc, char **argv) {
   try {
     if (argc < 6) { std::cerr << "usage: ref-lattice-determinize word|phone <beam> <acoustic-scale> <lattices.txt> <out.txt> [<model>] [--max-mem=N] [--delta=X]\n"; return 1; }
     const std::string mode = argv[1]; const double beam = (float)atof(argv[2]), acoustic_scale = (float)atof(argv[3]);     // BaseFloat options in the reference programs
-    int max_mem = 50000000; float delta = fst::kDelta; std::string model;
-    for (int i = 6; i < argc; i++) { const std::string a = argv[i]; if (a.compare(0, 10, "--max-mem=") == 0) max_mem = atoi(a.c_str() + 10); else if (a.compare(0, 8, "--delta=") == 0) delta = (float)atof(a.c_str() + 8); else model = a; }
+    int max_mem = 50000000; float delta = fst::kDelta; std::string model; bool minimize = false;
+    for (int i = 6; i < argc; i++) {
+      const std::string a = argv[i];
+      if (a.compare(0, 10, "--max-mem=") == 0) max_mem = atoi(a.c_str() + 10); else if (a.compare(0, 8, "--delta=") == 0) delta = (float)atof(a.c_str() + 8);
+      else if (a == "--minimize=true") minimize = true; else model = a;
+    }
     kaldi::TransitionModel trans;
     if (mode == "phone") { bool binary; kaldi::Input ki(model, &binary); trans.Read(ki.Stream(), binary); }
     std::ifstream in(argv[4]); std::ofstream out(argv[5]);
@@ -79,8 +86,9 @@ int main(int argc, char **argv) {
         fst::ArcSort(&lat, fst::ILabelCompare<LatticeArc>());
         ok = fst::DeterminizeLatticePruned(lat, beam, &clat, opts);
         fst::Connect(&clat);
+        if (minimize) { fst::PushCompactLatticeStrings(&clat); fst::PushCompactLatticeWeights(&clat); fst::MinimizeCompactLattice(&clat); }      // lattice-determinize-pruned.cc:122-126
       } else {                                                // lattice-determinize-phone-pruned.cc:117-123
-        fst::DeterminizeLatticePhonePrunedOptions opts; opts.max_mem = max_mem; opts.delta = delta;
+        fst::DeterminizeLatticePhonePrunedOptions opts; opts.max_mem = max_mem; opts.delta = delta; opts.minimize = minimize;
         ScaleAcoustic(&lat, acoustic_scale);
         ok = fst::DeterminizeLatticePhonePrunedWrapper(trans, &lat, beam, &clat, opts);
       }

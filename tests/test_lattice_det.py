@@ -143,7 +143,7 @@ def test_degenerate_inputs():
     # command-line contract
     assert subprocess.run([PROG], capture_output=True).returncode == 1
     assert subprocess.run([PROG, "--acoustic-scale=0", "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
-    assert subprocess.run([PROG, "--minimize=true", "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
+    assert subprocess.run([PROG, "--write-compact=false", "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
 
 
 def _best_cost_for_words(lat, words):
@@ -324,7 +324,7 @@ def test_phone_pruned_on_decoder_oracle_lattices_and_errors(mdl):
     bad = dict(start=0, n=3, finals={2: (0.0, 0.0)}, arcs=[(0, 1, 3, 1, 1.0, 1.0), (1, 2, 4000, 2, 1.0, 1.0)])
     r = subprocess.run([PHONE_PROG, mdl, "ark:-", "ark,t:-"], input=lc.lattice_text("b", bad).encode(), capture_output=True)
     assert r.returncode != 0 and b"transition-id 4000" in r.stderr
-    assert subprocess.run([PHONE_PROG, "--minimize=true", mdl, "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
+    assert subprocess.run([PHONE_PROG, "--word-determinize=false", mdl, "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
     assert subprocess.run([PHONE_PROG, mdl], capture_output=True).returncode == 1
 
 
@@ -369,6 +369,8 @@ REF_CASES = {   # name: (lattices, mode, beam, acoustic scale, extra options)
     "phone_beam3": ("random", "phone", 3.0, 1.0, ()), "phone_wide_scaled": ("random", "phone", 1000.0, 0.3, ()),
     "word_ties": ("ties", "word", 50.0, 1.0, ()), "phone_ties": ("ties", "phone", 50.0, 1.0, ()),
     "word_max_mem_retry": ("wide", "word", 8.0, 1.0, ("--max-mem=20000",)), "phone_max_mem_retry": ("wide", "phone", 1000.0, 1.0, ("--max-mem=2000",)),
+    "word_minimize": ("random", "word", 1000.0, 1.0, ("--minimize=true",)), "phone_minimize": ("random", "phone", 3.0, 0.5, ("--minimize=true",)),
+    "ties_minimize": ("ties", "phone", 50.0, 1.0, ("--minimize=true",)),
 }
 
 def write_model(td):
@@ -430,3 +432,20 @@ def test_convert_lattice_equals_the_reference_character_for_character(tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout == json.load(open(os.path.join(ROOT, "tests", "golden", "det_ref_golden.json")))["convert_lattice"]
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bin", "ref-convert-lattice")): assert r.stdout == run_reference_convert(td)
+
+
+def test_minimize_merges_states_and_keeps_the_language():
+    """--minimize (push strings, push weights, merge equivalent states): fewer or equal arcs, the same word sequences with the same
+    costs and alignments, still deterministic"""
+    shrunk = 0
+    for seed in range(10):
+        lat = lc.random_lattice(seed, frames=5 + seed % 4, width=3 + seed % 3, words=2 + seed % 3, tids=40)
+        inp = lc.lattice_text("u", lat).encode()
+        a = lc.parse_compact_text(_run(["--beam=1000"], inp).stdout.decode())["u"]
+        b = lc.parse_compact_text(_run(["--beam=1000", "--minimize=true"], inp).stdout.decode())["u"]
+        assert len(b["arcs"]) <= len(a["arcs"]); shrunk += len(b["arcs"]) < len(a["arcs"])
+        ea, eb = lc.enumerate_compact(a), lc.enumerate_compact(b)
+        assert set(ea) == set(eb)
+        for w in ea: assert ea[w][0][3] == eb[w][0][3] and np.allclose(ea[w][0][:3], eb[w][0][:3], atol=2e-3)
+        assert len({(x[0], x[2]) for x in b["arcs"]}) == len(b["arcs"])
+    assert shrunk >= 1
