@@ -40,7 +40,7 @@ int main(int argc, char **argv) {
     po.Register("write-compact", &write_compact, "(not in the reference) with --determinize-lattice=false: true = the state-level lattice re-packed as a CompactLattice like the reference (ConvertLattice), false = written as a Lattice table");
     po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
-    po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
+    po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization.");
     po.Register("print-partial-hypotheses", &print_partial, "(not supported)"); po.Register("print-endpoints", &print_endpoints, "(not supported)");
     po.Register("simulate-realtime-writing", &simulate_rt, "(accepted, unused: chunks are submitted as fast as the GPU takes them)");
@@ -58,8 +58,7 @@ int main(int argc, char **argv) {
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     if (print_partial || print_endpoints) K3H_ERR << "--print-partial-hypotheses / --print-endpoints are not supported";
-    if (determinize && !word_det) K3H_ERR << "--word-determinize=false is not supported";
-    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.minimize = minimize;
+    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
     if (num_channels < 0) num_channels = max_batch;
     if (num_channels > max_batch) max_batch = num_channels;      // one slot per channel and round
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);

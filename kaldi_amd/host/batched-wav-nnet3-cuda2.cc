@@ -47,7 +47,7 @@ int main(int argc, char **argv) {
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
     po.Register("write-compact", &write_compact, "(not in the reference) with --determinize-lattice=false: true = the state-level lattice re-packed as a CompactLattice like the reference (ConvertLattice), false = written as a Lattice table");
     po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
-    po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
+    po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization.");
     po.Register("gpu-feature-extract", &gpu_feat, "Use GPU feature extraction (always true)"); po.Register("use-online-features", &use_online, "(only false is supported)");
     po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused: offline decoding)");
@@ -69,8 +69,7 @@ int main(int argc, char **argv) {
     po.Register("cuda-use-tf32-compute", &tf32, "(accepted, unused: gfx950 has no tf32/xf32)"); po.Register("cuda-cache-memory", &cache_mem, "(accepted, unused)"); po.Register("cuda-memory-proportion", &mem_prop, "(accepted, unused)");
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
-    if (determinize && !word_det) K3H_ERR << "--word-determinize=false is not supported";
-    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.minimize = minimize;
+    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
     if (segmentation || use_online || add_pitch || !ivector_config.empty() || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
       K3H_ERR << "an option that needs a component outside the accelerated path was given (segmentation / online features / pitch / ivectors / PLP / CMVN / extra context)";
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);

@@ -118,7 +118,7 @@ struct DeterminizeLatticePrunedOptions {     // lat/determinize-lattice-pruned.h
 bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *clat, const DeterminizeLatticePrunedOptions &opts = DeterminizeLatticePrunedOptions());
 // DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1410-1499): what the decoders call.  With phone_determinize a
 // first pass runs over the lattice with phone labels inserted at the phone boundaries (keeps the word pass's subsets small), then the
-// word-level pass, then (minimize) push + minimize.  word_determinize=false is not implemented (FatalError).
+// word-level pass, then (minimize) push + minimize; with word_determinize=false the first pass's result re-packed by ConvertLattice.
 struct DeterminizeLatticePhonePrunedOptions { float delta = 1.0f / 1024.0f; int32_t max_mem = 50000000; bool phone_determinize = true, word_determinize = true, minimize = false; };
 bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &trans, double beam, CompactLattice *clat,
                                    const DeterminizeLatticePhonePrunedOptions &opts = DeterminizeLatticePhonePrunedOptions());

@@ -14,7 +14,7 @@
 // Both entry points of the reference are here: DeterminizeLatticePruned (one word-level pass; lattice-determinize-pruned) and
 // DeterminizeLatticePhonePruned (phone-level pass first, then the word-level pass; what the decoders and
 // lattice-determinize-phone-pruned call), with --minimize (PushCompactLatticeStrings / Weights + MinimizeCompactLattice).
-// Not implemented: --word-determinize=false.
+// --word-determinize=false gives the first pass's result (or, with both passes off, the lattice itself) re-packed by ConvertLattice.
 #include "k3_host.h"
 #include <algorithm>
 #include <cmath>
@@ -67,21 +67,27 @@ struct InputFst {
   int32_t NumStates() const { return (int32_t)fin.size(); }
 };
 
-// depth-first topological order like fst::TopSort (reverse finishing order, arcs visited in stored order); false on a cycle.
-// Only states reachable from `start` are ordered (the callers trim first); order[i] = old state id of new state i.
+// depth-first topological order like fst::TopSort: the search starts at the start state, then at every state not reached yet in
+// numeric order (states that cannot be reached from the start state stay in the automaton, as in the reference); arcs are visited in
+// stored order; new numbering = reverse finishing order.  false on a cycle.  order[i] = old state id of new state i.
 bool TopOrder(int32_t n, int32_t start, const std::vector<int32_t> &off, const std::vector<int32_t> &next, std::vector<int32_t> *order) {
   order->clear();
   if (start < 0) return true;
   std::vector<char> color(n, 0); std::vector<int32_t> stack, pos(n, 0), finish;
-  stack.push_back(start); color[start] = 1; pos[start] = off[start];
-  while (!stack.empty()) {
-    const int32_t s = stack.back();
-    if (pos[s] < off[s + 1]) {
-      const int32_t d = next[pos[s]++];
-      if (color[d] == 1) return false;
-      if (color[d] == 0) { color[d] = 1; pos[d] = off[d]; stack.push_back(d); }
-    } else { color[s] = 2; finish.push_back(s); stack.pop_back(); }
-  }
+  auto visit = [&](int32_t root) {
+    stack.push_back(root); color[root] = 1; pos[root] = off[root];
+    while (!stack.empty()) {
+      const int32_t s = stack.back();
+      if (pos[s] < off[s + 1]) {
+        const int32_t d = next[pos[s]++];
+        if (color[d] == 1) return false;
+        if (color[d] == 0) { color[d] = 1; pos[d] = off[d]; stack.push_back(d); }
+      } else { color[s] = 2; finish.push_back(s); stack.pop_back(); }
+    }
+    return true;
+  };
+  if (!visit(start)) return false;
+  for (int32_t s = 0; s < n; s++) if (color[s] == 0 && !visit(s)) return false;
   order->assign(finish.rbegin(), finish.rend());
   return true;
 }
@@ -104,8 +110,8 @@ EdgeFst InvertedEdges(const Lattice &lat) {
 }
 
 // TopSort + ArcSort(ILabelCompare) (lattice-determinize-pruned.cc:106-112): states reachable from the start state in depth-first
-// topological order, the arcs of a state stably sorted on the word label
-InputFst SortedInput(const EdgeFst &e) {
+// topological order, the arcs of a state sorted on the word label (std::sort like OpenFst's ArcSort; sort_arcs = false: TopSort only)
+InputFst SortedInput(const EdgeFst &e, bool sort_arcs = true) {
   InputFst f; const int32_t n = (int32_t)e.fin.size(); const size_t na = e.src.size();
   if (n == 0 || e.start < 0) return f;
   std::vector<int32_t> off(n + 1, 0), idx(na), nx(na);
@@ -121,7 +127,7 @@ InputFst SortedInput(const EdgeFst &e) {
     const int32_t s = order[i];
     f.fin[i] = e.fin[s];
     std::vector<int32_t> arcs(idx.begin() + off[s], idx.begin() + off[s + 1]);
-    std::stable_sort(arcs.begin(), arcs.end(), [&](int32_t x, int32_t y) { return e.word[x] < e.word[y]; });
+    if (sort_arcs) std::sort(arcs.begin(), arcs.end(), [&](int32_t x, int32_t y) { return e.word[x] < e.word[y]; });
     for (int32_t a : arcs) { f.word.push_back(e.word[a]); f.tid.push_back(e.tid[a]); f.next.push_back(newid[e.dst[a]]); f.w.push_back(e.w[a]); }
     f.off[i + 1] = (int32_t)f.word.size();
   }
@@ -534,7 +540,24 @@ bool DeterminizeLatticePruned(const Lattice &lat, double beam, CompactLattice *c
 // phone labels inserted at the phone boundaries (DeterminizeLatticePhonePrunedFirstPass :1388-1407; its output is an ordinary FST,
 // no longer deterministic once the phone labels are deleted again), then the word-level pass.
 bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &trans, double beam, CompactLattice *clat, const DeterminizeLatticePhonePrunedOptions &opts) {
-  if (!opts.word_determinize) K3H_ERR << "DeterminizeLatticePhonePruned: --word-determinize=false is not supported";
+  // ConvertLattice(..., invert = false) of an automaton that has the words on its input side (:1422-1425, :1443-1446)
+  auto convert = [&](const EdgeFst &e) {
+    Lattice l; l.start = e.start; const size_t ns = e.fin.size();
+    l.st_frame.assign(ns, 0); l.st_state.assign(ns, 0); l.st_final.resize(ns); l.st_final_ac.resize(ns);
+    for (size_t s = 0; s < ns; s++) { const bool f = e.fin[s] != Zero(); l.st_final[s] = f ? e.fin[s].g : kInfF; l.st_final_ac[s] = f ? e.fin[s].a : 0.0f; }
+    l.arc_src = e.src; l.arc_dst = e.dst; l.arc_ilabel = e.tid; l.arc_olabel = e.word;
+    for (const LatW &w : e.w) { l.arc_graph.push_back(w.g); l.arc_ac.push_back(w.a); }
+    ConvertLattice(l, clat); Connect(clat);          // the wrapper's Connect (:1497)
+  };
+  auto sorted_edges = [&](const InputFst &f) {           // back to an edge list, in the order the determinizer's input had (TopSort + ArcSort)
+    EdgeFst e; e.start = f.start; e.fin = f.fin;
+    for (int32_t s = 0; s < f.NumStates(); s++) for (int32_t k = f.off[s]; k < f.off[s + 1]; k++) e.AddArc(s, f.next[k], f.word[k], f.tid[k], f.w[k]);
+    return e;
+  };
+  if (!opts.phone_determinize && !opts.word_determinize) {
+    K3H_WARN << "Both --phone-determinize and --word-determinize are set to false, copying lattice without determinization.";
+    convert(sorted_edges(SortedInput(InvertedEdges(lat)))); return true;
+  }
   DeterminizeLatticePrunedOptions det_opts; det_opts.delta = opts.delta; det_opts.max_mem = opts.max_mem;
   auto finish = [&](bool ans) {                  // :1455-1460
     if (opts.minimize) { ans = PushCompactLatticeStrings(clat) && ans; ans = PushCompactLatticeWeights(clat) && ans; ans = MinimizeCompactLattice(clat) && ans; }
@@ -549,6 +572,7 @@ bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &tra
   EdgeFst pass1;
   bool ans = DeterminizeWithRetries(std::move(f), beam, det_opts, [&](const Determinizer &det) { det.Output(&pass1); });
   for (int32_t &wd : pass1.word) if (wd >= first_phone_label) wd = 0;          // DeterminizeLatticeDeletePhones :1346-1368
+  if (!opts.word_determinize) { convert(sorted_edges(SortedInput(pass1, false))); return ans; }      // TopSort :1405, then ConvertLattice :1443-1446
   InputFst g = SortedInput(pass1);
   if (g.NumStates() == 0) return ans;
   return finish(DeterminizeWithRetries(std::move(g), beam, det_opts, [&](const Determinizer &det) { det.Output(clat); Connect(clat); }) && ans);
@@ -636,12 +660,16 @@ void ConvertLattice(const Lattice &lat, CompactLattice *out) {
   { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < na; a++) idx[p[lat.arc_src[a]]++] = (int32_t)a; }
   // depth-first discovery order (DfsOrderVisitor), arcs in stored order
   std::vector<int32_t> order, stack, pos(n); std::vector<char> seen(n, 0);
-  stack.push_back(lat.start); seen[lat.start] = 1; pos[lat.start] = off[lat.start]; order.push_back(lat.start);
-  while (!stack.empty()) {
-    const int32_t s = stack.back();
-    if (pos[s] < off[s + 1]) { const int32_t d = lat.arc_dst[idx[pos[s]++]]; if (!seen[d]) { seen[d] = 1; pos[d] = off[d]; order.push_back(d); stack.push_back(d); } }
-    else stack.pop_back();
-  }
+  auto visit = [&](int32_t root) {
+    stack.push_back(root); seen[root] = 1; pos[root] = off[root]; order.push_back(root);
+    while (!stack.empty()) {
+      const int32_t s = stack.back();
+      if (pos[s] < off[s + 1]) { const int32_t d = lat.arc_dst[idx[pos[s]++]]; if (!seen[d]) { seen[d] = 1; pos[d] = off[d]; order.push_back(d); stack.push_back(d); } }
+      else stack.pop_back();
+    }
+  };
+  visit(lat.start);
+  for (int32_t s = 0; s < n; s++) if (!seen[s]) visit(s);           // DfsVisit goes on with the states the start state does not reach
   // GetStateProperties: a state is the middle of a chain when it has exactly one arc in and one out, is not final, not the start
   // state, and its arc out carries no word
   std::vector<int32_t> nin(n, 0); for (size_t a = 0; a < na; a++) nin[lat.arc_dst[a]]++;

@@ -2,7 +2,7 @@
 //   lattice-determinize-phone-pruned [options] <model> <lattice-rspecifier> <lattice-wspecifier>
 // The determinization the decoders apply (DeterminizeLatticePhonePrunedWrapper): a first pass with phone labels inserted at the phone
 // boundaries, found with the model's transition-id -> phone map, then the word-level pass.  Host-only.
-// Not implemented: --write-compact=false, --word-determinize=false (rejected, not ignored).
+// Not implemented: --write-compact=false (rejected, not ignored).
 #include <iostream>
 #include "k3_host.h"
 using namespace k3host;
@@ -30,12 +30,11 @@ int main(int argc, char **argv) {
     po.Register("delta", &opts.delta, "Tolerance used in determinization");
     po.Register("max-mem", &opts.max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
     po.Register("phone-determinize", &opts.phone_determinize, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)");
-    po.Register("word-determinize", &opts.word_determinize, "If true, do a second pass of determinization on words only (only true is supported by this build)");
+    po.Register("word-determinize", &opts.word_determinize, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
     po.Register("minimize", &opts.minimize, "If true, push and minimize after determinization.");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) { po.PrintUsage(); return 1; }
     if (!write_compact) K3H_ERR << "--write-compact=false is not supported";
-    if (!opts.word_determinize) K3H_ERR << "--word-determinize=false is not supported";
     if (acoustic_scale == 0.0f) K3H_ERR << "Do not use a zero acoustic scale (cannot be inverted)";
     const TransitionInfo trans = ReadTransitionModel(po.GetArg(1));
     auto lats = ReadLatticeTable(po.GetArg(2));

@@ -3,7 +3,7 @@
 // = DecodableAmNnetSimple + LatticeFasterDecoder + DecodeUtteranceLatticeFaster (decoder/decoder-wrappers.cc:287-382) per utterance in
 // the reference; here all utterances of a batch run through k3_nnet_forward and k3_decoder_decode_batch.  Like the reference it
 // determinizes by default and writes CompactLattices (decoder-wrappers.cc:354-368); the determinizer is the host-side restatement
-// of DeterminizeLatticePhonePrunedWrapper in k3_lattice.cc (--word-determinize=false and --minimize=true are rejected).
+// of DeterminizeLatticePhonePrunedWrapper in k3_lattice.cc.
 // --determinize-lattice=false writes the raw state-level lattice.
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -29,7 +29,7 @@ int main(int argc, char **argv) {
     po.Register("beam-delta", &beam_delta, "Increment used in decoding-- this parameter is obscure and relates to a speedup in the way the max-active constraint is applied.");
     po.Register("hash-ratio", &hash_ratio, "(accepted, unused: no hash-order dependence)"); po.Register("prune-scale", &prune_scale, "(accepted, unused)");
     po.Register("max-mem", &max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this)."); po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)");
-    po.Register("word-determinize", &word_det, "If true, do a pass of determinization on words only (only true is supported)");
+    po.Register("word-determinize", &word_det, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization."); po.Register("delta", &delta, "Tolerance used in determinization");
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods"); po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
     po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole)"); po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)");
@@ -38,8 +38,7 @@ int main(int argc, char **argv) {
     po.Register("use-gpu", &use_gpu, "(this build always uses the GPU)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
     po.Read(argc, argv);
     if (po.NumArgs() < 4 || po.NumArgs() > 6) { po.PrintUsage(); return 1; }
-    if (determinize && !word_det) K3H_ERR << "--word-determinize=false is not supported";
-    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = delta; det_opts.max_mem = max_mem; det_opts.phone_determinize = phone_det; det_opts.minimize = minimize;
+    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = delta; det_opts.max_mem = max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
     if (!ivector_rspecifier.empty() || !online_ivector_rspecifier.empty() || elc || erc) K3H_ERR << "i-vectors / extra context are not supported by this program";
     const std::string model_rx = po.GetArg(1), fst_rx = po.GetArg(2);
     if (fst_rx.find(':') != std::string::npos && fst_rx.compare(0, 3, "ark") == 0) K3H_ERR << "a table of per-utterance FSTs is not supported; give one HCLG";

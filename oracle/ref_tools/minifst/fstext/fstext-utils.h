@@ -1,6 +1,5 @@
 // TEST INFRASTRUCTURE: stands in for the reference's fstext/fstext-utils.h (a large collection of OpenFst extensions) with the one
-// function lat/determinize-lattice-pruned.cc takes from it, and the declaration of ConvertLattice (fstext/lattice-utils.h) that the
-// same file mentions on a path the oracle driver never takes.
+// function lat/determinize-lattice-pruned.cc takes from it; ConvertLattice comes from the reference's own fstext/lattice-utils.h.
 #ifndef K3_MINIFST_FSTEXT_UTILS_H_
 #define K3_MINIFST_FSTEXT_UTILS_H_
 #include "fst/fstlib.h"
@@ -13,6 +12,6 @@ template <class Arc> typename Arc::Label HighestNumberedInputSymbol(const Fst<Ar
   for (typename Arc::StateId s = 0; s < e->NumStates(); s++) for (size_t k = 0; k < e->NumArcs(s); k++) ans = std::max(ans, e->ArcsOf(s)[k].ilabel);
   return ans;
 }
-template <class Weight, class Int> void ConvertLattice(const ExpandedFst<ArcTpl<Weight>> &, MutableFst<ArcTpl<CompactLatticeWeightTpl<Weight, Int>>> *, bool = true) { NotInStandIn("ConvertLattice"); }
 }  // namespace fst
+#include "fstext/lattice-utils.h"     // the reference's: ConvertLattice (+ Factor), used by DeterminizeLatticePhonePruned when --word-determinize=false
 #endif

@@ -55,11 +55,11 @@ int main(int argc, char **argv) {
   try {
     if (argc < 6) { std::cerr << "usage: ref-lattice-determinize word|phone <beam> <acoustic-scale> <lattices.txt> <out.txt> [<model>] [--max-mem=N] [--delta=X]\n"; return 1; }
     const std::string mode = argv[1]; const double beam = (float)atof(argv[2]), acoustic_scale = (float)atof(argv[3]);     // BaseFloat options in the reference programs
-    int max_mem = 50000000; float delta = fst::kDelta; std::string model; bool minimize = false;
+    int max_mem = 50000000; float delta = fst::kDelta; std::string model; bool minimize = false, word_det = true, phone_det = true;
     for (int i = 6; i < argc; i++) {
       const std::string a = argv[i];
       if (a.compare(0, 10, "--max-mem=") == 0) max_mem = atoi(a.c_str() + 10); else if (a.compare(0, 8, "--delta=") == 0) delta = (float)atof(a.c_str() + 8);
-      else if (a == "--minimize=true") minimize = true; else model = a;
+      else if (a == "--minimize=true") minimize = true; else if (a == "--word-determinize=false") word_det = false; else if (a == "--phone-determinize=false") phone_det = false; else model = a;
     }
     kaldi::TransitionModel trans;
     if (mode == "phone") { bool binary; kaldi::Input ki(model, &binary); trans.Read(ki.Stream(), binary); }
@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
         fst::Connect(&clat);
         if (minimize) { fst::PushCompactLatticeStrings(&clat); fst::PushCompactLatticeWeights(&clat); fst::MinimizeCompactLattice(&clat); }      // lattice-determinize-pruned.cc:122-126
       } else {                                                // lattice-determinize-phone-pruned.cc:117-123
-        fst::DeterminizeLatticePhonePrunedOptions opts; opts.max_mem = max_mem; opts.delta = delta; opts.minimize = minimize;
+        fst::DeterminizeLatticePhonePrunedOptions opts; opts.max_mem = max_mem; opts.delta = delta; opts.minimize = minimize; opts.word_determinize = word_det; opts.phone_determinize = phone_det;
         ScaleAcoustic(&lat, acoustic_scale);
         ok = fst::DeterminizeLatticePhonePrunedWrapper(trans, &lat, beam, &clat, opts);
       }

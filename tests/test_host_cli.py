@@ -55,7 +55,7 @@ def test_cli_exit_codes_follow_the_reference():
     exe = os.path.join(BIN, "batched-wav-nnet3-cuda2")
     r = _run(exe); assert r.returncode == 1 and "Usage: batched-wav-nnet3-cuda2" in r.stderr
     r = _run(exe, "--no-such-option=1", "a", "b", "c", "d"); assert r.returncode == 255 and "Invalid option" in r.stderr
-    r = _run(exe, "--word-determinize=false", "a", "b", "c", "d"); assert r.returncode == 255 and "word-determinize" in r.stderr
+    r = _run(exe, "--segmentation=true", "a", "b", "c", "d"); assert r.returncode == 255 and "outside the accelerated path" in r.stderr
     r = _run(os.path.join(BIN, "compute-fbank-feats-cuda"), "only-one-arg"); assert r.returncode == 1
     r = _run(exe, "--help"); assert r.returncode == 0 and "--lattice-beam" in r.stderr and "--max-batch-size" in r.stderr
 
@@ -64,7 +64,6 @@ def test_streaming_and_cmvn_programs_usage_and_option_errors():
     on = os.path.join(BIN, "batched-wav-nnet3-cuda-online")
     r = _run(on); assert r.returncode == 1 and "Usage: batched-wav-nnet3-cuda-online" in r.stderr
     r = _run(on, "--print-endpoints=true", "a", "b", "c", "d"); assert r.returncode == 255 and "not supported" in r.stderr
-    r = _run(on, "--word-determinize=false", "a", "b", "c", "d"); assert r.returncode == 255 and "not supported" in r.stderr
     r = _run(on, "--help"); assert r.returncode == 0 and "--frames-per-chunk" in r.stderr and "--num-channels" in r.stderr
     cm = os.path.join(BIN, "apply-cmvn-online-cuda")
     r = _run(cm, "a"); assert r.returncode == 1 and "Usage: apply-cmvn-online-cuda" in r.stderr

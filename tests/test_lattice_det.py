@@ -324,7 +324,7 @@ def test_phone_pruned_on_decoder_oracle_lattices_and_errors(mdl):
     bad = dict(start=0, n=3, finals={2: (0.0, 0.0)}, arcs=[(0, 1, 3, 1, 1.0, 1.0), (1, 2, 4000, 2, 1.0, 1.0)])
     r = subprocess.run([PHONE_PROG, mdl, "ark:-", "ark,t:-"], input=lc.lattice_text("b", bad).encode(), capture_output=True)
     assert r.returncode != 0 and b"transition-id 4000" in r.stderr
-    assert subprocess.run([PHONE_PROG, "--word-determinize=false", mdl, "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
+    assert subprocess.run([PHONE_PROG, "--write-compact=false", mdl, "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
     assert subprocess.run([PHONE_PROG, mdl], capture_output=True).returncode == 1
 
 
@@ -371,6 +371,7 @@ REF_CASES = {   # name: (lattices, mode, beam, acoustic scale, extra options)
     "word_max_mem_retry": ("wide", "word", 8.0, 1.0, ("--max-mem=20000",)), "phone_max_mem_retry": ("wide", "phone", 1000.0, 1.0, ("--max-mem=2000",)),
     "word_minimize": ("random", "word", 1000.0, 1.0, ("--minimize=true",)), "phone_minimize": ("random", "phone", 3.0, 0.5, ("--minimize=true",)),
     "ties_minimize": ("ties", "phone", 50.0, 1.0, ("--minimize=true",)),
+    "phone_pass_only": ("random", "phone", 3.0, 1.0, ("--word-determinize=false",)), "no_pass": ("random", "phone", 3.0, 1.0, ("--word-determinize=false", "--phone-determinize=false")),
 }
 
 def write_model(td):
