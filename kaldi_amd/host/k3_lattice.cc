@@ -174,21 +174,40 @@ bool PruneInput(double beam, InputFst *f) {
 
 // ---- LatticeStringRepository (fstext/determinize-lattice.h): strings of transition-ids as nodes of a trie; id 0 is the empty string.
 // Equal sequences always get the same id, which is what lets subsets be hashed and compared on (state, string id).
+// uint64 -> int32 hash table with linear probing (the trie's child index and its memo of prefix removals: millions of look-ups per lattice)
+class FlatMap64 {
+ public:
+  FlatMap64() : keys_(1024), vals_(1024, -1), mask_(1023) {}
+  int32_t *Find(uint64_t key) { for (size_t i = Hash(key) & mask_;; i = (i + 1) & mask_) { if (vals_[i] < 0) return nullptr; if (keys_[i] == key) return &vals_[i]; } }
+  void Insert(uint64_t key, int32_t val) {           // key must not be present; val >= 0
+    if (2 * (count_ + 1) > keys_.size()) Grow();
+    for (size_t i = Hash(key) & mask_;; i = (i + 1) & mask_) if (vals_[i] < 0) { keys_[i] = key; vals_[i] = val; count_++; return; }
+  }
+  void Clear() { std::fill(vals_.begin(), vals_.end(), -1); count_ = 0; }
+ private:
+  static size_t Hash(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; return (size_t)k; }
+  void Grow() {
+    std::vector<uint64_t> ok; std::vector<int32_t> ov; ok.swap(keys_); ov.swap(vals_);
+    keys_.assign(2 * ok.size(), 0); vals_.assign(2 * ov.size(), -1); mask_ = keys_.size() - 1; count_ = 0;
+    for (size_t i = 0; i < ok.size(); i++) if (ov[i] >= 0) Insert(ok[i], ov[i]);
+  }
+  std::vector<uint64_t> keys_; std::vector<int32_t> vals_; size_t mask_, count_ = 0;
+};
+
 class StringTrie {
  public:
   StringTrie() : parent_(1, -1), label_(1, 0), depth_(1, 0), held_(1, 1) {}
   int32_t Successor(int32_t s, int32_t label) {
     const uint64_t key = ((uint64_t)(uint32_t)s << 32) | (uint32_t)label;
-    auto it = succ_.find(key);
-    if (it != succ_.end()) { if (!held_[it->second]) { held_[it->second] = 1; num_held_++; } return it->second; }
+    if (int32_t *hit = succ_.Find(key)) { if (!held_[*hit]) { held_[*hit] = 1; num_held_++; } return *hit; }
     const int32_t id = (int32_t)parent_.size();
-    parent_.push_back(s); label_.push_back(label); depth_.push_back(depth_[s] + 1); held_.push_back(1); num_held_++; succ_.emplace(key, id);
+    parent_.push_back(s); label_.push_back(label); depth_.push_back(depth_[s] + 1); held_.push_back(1); num_held_++; succ_.Insert(key, id);
     return id;
   }
   // The reference frees the entries nobody refers to when memory runs short (LatticeStringRepository::Rebuild) and creates them
   // again on demand; ids here stay valid for ever, so only the book-keeping is mirrored: which entries the reference would hold now.
   size_t NumHeld() const { return num_held_; }
-  void KeepOnly(const std::vector<char> &needed) { num_held_ = 0; for (size_t i = 1; i < held_.size(); i++) { held_[i] = needed[i]; num_held_ += needed[i]; } }
+  void KeepOnly(const std::vector<char> &needed) { num_held_ = 0; for (size_t i = 1; i < held_.size(); i++) { held_[i] = needed[i]; num_held_ += needed[i]; } removed_.Clear(); }
   void ToVector(int32_t s, std::vector<int32_t> *v) const { v->resize(depth_[s]); for (int32_t i = depth_[s] - 1; i >= 0; i--, s = parent_[s]) (*v)[i] = label_[s]; }
   int32_t FromVector(const std::vector<int32_t> &v, size_t from = 0) { int32_t s = 0; for (size_t i = from; i < v.size(); i++) s = Successor(s, v[i]); return s; }
   int32_t Concatenate(int32_t a, int32_t b) { if (b == 0) return a; if (a == 0) return b; std::vector<int32_t> v; ToVector(b, &v); for (int32_t l : v) a = Successor(a, l); return a; }
@@ -197,13 +216,31 @@ class StringTrie {
     prefix->resize(depth_[s]);
     for (int32_t i = depth_[s] - 1; i >= 0; i--, s = parent_[s]) if (label_[s] != (*prefix)[i]) prefix->resize(i);
   }
-  int32_t RemovePrefix(int32_t s, size_t n) { if (n == 0) return s; std::vector<int32_t> v; ToVector(s, &v); return FromVector(v, n); }
+  // the string without its first n labels.  RemovePrefix(s, n) = Successor(RemovePrefix(parent(s), n), label(s)): results are remembered
+  // per (node, n), so strings that share an ancestor share the work.  (The memo is dropped whenever KeepOnly changes what is held: a
+  // remembered answer skips the Successor calls that would mark its entries as held again.)
+  int32_t RemovePrefix(int32_t s, size_t n) {
+    if (n == 0) return s;
+    chain_.clear(); int32_t base = 0;
+    for (int32_t cur = s; depth_[cur] > (int32_t)n; cur = parent_[cur]) {
+      if (int32_t *hit = removed_.Find(((uint64_t)(uint32_t)cur << 32) | (uint32_t)n)) { base = *hit; break; }
+      chain_.push_back(cur);
+    }
+    for (size_t i = chain_.size(); i-- > 0;) { base = Successor(base, label_[chain_[i]]); removed_.Insert(((uint64_t)(uint32_t)chain_[i] << 32) | (uint32_t)n, base); }
+    return base;
+  }
+  int32_t CommonPrefix(int32_t a, int32_t b) const {
+    while (depth_[a] > depth_[b]) a = parent_[a];
+    while (depth_[b] > depth_[a]) b = parent_[b];
+    while (a != b) { a = parent_[a]; b = parent_[b]; }
+    return a;
+  }
   int32_t Depth(int32_t s) const { return depth_[s]; }
   int32_t Parent(int32_t s) const { return parent_[s]; }
   size_t NumEntries() const { return parent_.size() - 1; }
  private:
-  std::vector<int32_t> parent_, label_, depth_; std::vector<char> held_; size_t num_held_ = 0;
-  std::unordered_map<uint64_t, int32_t> succ_;
+  std::vector<int32_t> parent_, label_, depth_, chain_; std::vector<char> held_; size_t num_held_ = 0;
+  FlatMap64 succ_, removed_;
 };
 
 // ---- LatticeDeterminizerPruned (lat/determinize-lattice-pruned.cc:47-1190) -------------------------------------------------------
@@ -310,26 +347,30 @@ class Determinizer {
   void EpsilonClosure(std::vector<Element> *subset) {        // :632-724: best (weight, string) per state reachable over word-epsilon arcs
     struct ByState { bool operator()(const Element &a, const Element &b) const { return a.state > b.state; } };
     std::priority_queue<Element, std::vector<Element>, ByState> queue;
-    std::unordered_map<int32_t, Element> cur;
-    for (const Element &e : *subset) { queue.push(e); cur[e.state] = e; }
+    // the reference's map state -> Element, as a slot table over the input states (slots are handed back at the end)
+    if (slot_.size() != (size_t)f_.NumStates()) slot_.assign(f_.NumStates(), -1);
+    std::vector<Element> &cur = closure_; cur.clear();
+    auto find = [&](int32_t state) -> Element * { return slot_[state] < 0 ? nullptr : &cur[slot_[state]]; };
+    auto insert = [&](const Element &e) { slot_[e.state] = (int32_t)cur.size(); cur.push_back(e); };
+    for (const Element &e : *subset) { queue.push(e); if (Element *p = find(e.state)) *p = e; else insert(e); }
     bool replaced = false; int32_t counter = 0;
     while (!queue.empty()) {
       const Element elem = queue.top(); queue.pop();
-      if (replaced && cur[elem.state] != elem) continue;     // a stale copy of an element that was improved later
+      if (replaced && *find(elem.state) != elem) continue;     // a stale copy of an element that was improved later
       if (opts_.max_loop > 0 && counter++ > opts_.max_loop) K3H_ERR << "Lattice determinization aborted since looped more than " << opts_.max_loop << " times during epsilon closure.";
       for (int32_t k = f_.off[elem.state]; k < f_.off[elem.state + 1] && f_.word[k] == 0; k++) {
         if (f_.w[k] == Zero()) continue;
         Element nx; nx.state = f_.next[k]; nx.w = Times(elem.w, f_.w[k]); nx.string = -1;
         auto string_of = [&]() { return f_.tid[k] == 0 ? elem.string : trie_.Successor(elem.string, f_.tid[k]); };
-        auto it = cur.find(nx.state);
-        if (it == cur.end()) { nx.string = string_of(); cur[nx.state] = nx; queue.push(nx); continue; }
-        int comp = k3host::Compare(nx.w, it->second.w);
-        if (comp == 0) { nx.string = string_of(); comp = Compare(nx.w, nx.string, it->second.w, it->second.string); }
-        if (comp == 1) { if (nx.string < 0) nx.string = string_of(); it->second.string = nx.string; it->second.w = nx.w; queue.push(nx); replaced = true; }
+        Element *old = find(nx.state);
+        if (old == nullptr) { nx.string = string_of(); insert(nx); queue.push(nx); continue; }
+        int comp = k3host::Compare(nx.w, old->w);
+        if (comp == 0) { nx.string = string_of(); comp = Compare(nx.w, nx.string, old->w, old->string); }
+        if (comp == 1) { if (nx.string < 0) nx.string = string_of(); old->string = nx.string; old->w = nx.w; queue.push(nx); replaced = true; }
       }
     }
-    subset->clear(); subset->reserve(cur.size());
-    for (const auto &kv : cur) subset->push_back(kv.second);
+    for (const Element &e : cur) slot_[e.state] = -1;
+    subset->assign(cur.begin(), cur.end());
     std::sort(subset->begin(), subset->end(), [](const Element &a, const Element &b) { return a.state < b.state; });
   }
 
@@ -345,11 +386,14 @@ class Determinizer {
 
   void NormalizeSubset(std::vector<Element> *elems, LatW *tot, int32_t *common) {    // :774-803
     if (elems->empty()) { K3H_WARN << "empty subset"; *common = 0; *tot = Zero(); return; }
-    std::vector<int32_t> prefix; trie_.ToVector((*elems)[0].string, &prefix);
+    // the longest common prefix of the strings is their lowest common ancestor in the trie (a node, no vectors needed; it and its
+    // ancestors are prefixes of strings in use, so the reference's ConvertFromVector would find them all in place)
+    int32_t prefix = (*elems)[0].string;
     LatW w = (*elems)[0].w;
-    for (size_t i = 1; i < elems->size(); i++) { w = Plus(w, (*elems)[i].w); trie_.ReduceToCommonPrefix((*elems)[i].string, &prefix); }
-    for (Element &e : *elems) { e.w = Divide(e.w, w); e.string = trie_.RemovePrefix(e.string, prefix.size()); }
-    *common = trie_.FromVector(prefix); *tot = w;
+    for (size_t i = 1; i < elems->size(); i++) { w = Plus(w, (*elems)[i].w); prefix = trie_.CommonPrefix(prefix, (*elems)[i].string); }
+    const size_t prefix_len = (size_t)trie_.Depth(prefix);
+    for (Element &e : *elems) { e.w = Divide(e.w, w); e.string = trie_.RemovePrefix(e.string, prefix_len); }
+    *common = prefix; *tot = w;
   }
 
   void MakeSubsetUnique(std::vector<Element> *subset) const {  // :808-835: sorted on state; keep the best element per state
@@ -481,6 +525,7 @@ class Determinizer {
   const InputFst &f_; double beam_; DeterminizeLatticePrunedOptions opts_;
   double cutoff_ = kInfD; std::vector<double> backward_;
   StringTrie trie_; int64_t num_arcs_ = 0, num_elems_ = 0;
+  std::vector<int32_t> slot_; std::vector<Element> closure_;       // scratch of EpsilonClosure
   std::deque<OutputState> out_;                              // deque: the hashes keep pointers to the subsets
   std::deque<std::vector<Element>> initial_keys_;
   std::unordered_map<const std::vector<Element> *, int32_t, SubsetHash, SubsetEqual> minimal_hash_;
