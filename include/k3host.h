@@ -1,0 +1,55 @@
+/* k3host.h -- C ABI of the HOST tail of the path (no GPU work): what happens to a raw lattice after k3_decoder_get_raw_lattices.
+ * Built into kaldi_amd/lib/libk3host.so from kaldi_amd/host/k3_lattice.cc (plain C++, no HIP).  Plain pointers and sizes; 0 = success,
+ * negative = error with the message in k3h_last_error() (thread-local).
+ *
+ * Reference interfaces replaced (paths relative to the reference's src/):
+ *   k3h_determinize_lattice   fst::DeterminizeLatticePhonePrunedWrapper   lat/determinize-lattice-pruned.h:284-289 (.cc:1479-1499)   [trans != NULL]
+ *                             fst::DeterminizeLatticePruned               lat/determinize-lattice-pruned.h:209-214 (.cc:1190-1236)   [trans == NULL]
+ *                             as called by DecodeUtteranceLatticeFaster (decoder/decoder-wrappers.cc:354-362) and by the CUDA pipeline
+ *                             (cudadecoder/batched-threaded-nnet3-cuda-online-pipeline.cc:759-765)
+ *   k3h_convert_lattice       fst::ConvertLattice(Lattice -> CompactLattice) fstext/lattice-utils.h:49-53 (the pipeline's --determinize-lattice=false)
+ *   k3h_transitions_read      ReadKaldiObject(model, &trans_model): the transition-id -> phone / self-loop / phone-start map that
+ *                             DeterminizeLatticeInsertPhones asks of TransitionInformation (lat/determinize-lattice-pruned.cc:1291-1343)
+ *   k3h_clat_write            CompactLatticeWriter::Write (lat/kaldi-lattice.cc:65-94; "ark:" binary compactlattice44 / "ark,t:" text)
+ * The lattice arrays are exactly what k3_decoder_get_raw_lattices returns for one utterance (include/k3hip.h), already trimmed or not.
+ */
+#ifndef K3HOST_H_
+#define K3HOST_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct k3h_transitions k3h_transitions;
+typedef struct k3h_clat k3h_clat;
+
+/* fst::DeterminizeLatticePhonePrunedOptions (lat/determinize-lattice-pruned.h:145-180), same defaults */
+typedef struct k3h_det_opts { float delta; int32_t max_mem; int32_t phone_determinize; int32_t word_determinize; int32_t minimize; } k3h_det_opts;
+void k3h_det_opts_default(k3h_det_opts *opts);
+
+const char *k3h_last_error(void);
+
+int k3h_transitions_read(const char *model_rxfilename, k3h_transitions **out);
+int32_t k3h_transitions_num_ids(const k3h_transitions *t);
+void k3h_transitions_free(k3h_transitions *t);
+
+/* *complete = 0 when a limit (max_mem) stopped the determinization before the beam was reached (output pruned tighter), else 1 */
+int k3h_determinize_lattice(const k3h_transitions *trans, int32_t num_states, int32_t start, const float *st_final,
+                            int64_t num_arcs, const int32_t *arc_src, const int32_t *arc_dst, const int32_t *arc_ilabel, const int32_t *arc_olabel,
+                            const float *arc_graph, const float *arc_ac, double beam, const k3h_det_opts *opts, k3h_clat **out, int32_t *complete);
+int k3h_convert_lattice(int32_t num_states, int32_t start, const float *st_final, int64_t num_arcs, const int32_t *arc_src, const int32_t *arc_dst,
+                        const int32_t *arc_ilabel, const int32_t *arc_olabel, const float *arc_graph, const float *arc_ac, k3h_clat **out);
+
+/* sizes, then the arrays: transition-id strings are concatenated in `strings` (all final strings in state order, then all arc strings in
+ * arc order); final_str_off has num_states + 1 entries, arc_str_off num_arcs + 1 entries, both index into `strings` */
+int k3h_clat_sizes(const k3h_clat *c, int32_t *num_states, int64_t *num_arcs, int64_t *num_string_labels);
+int k3h_clat_get(const k3h_clat *c, int32_t *start, uint8_t *is_final, float *final_graph, float *final_ac, int64_t *final_str_off,
+                 int32_t *arc_src, int32_t *arc_dst, int32_t *arc_label, float *arc_graph, float *arc_ac, int64_t *arc_str_off, int32_t *strings);
+int k3h_clat_scale_acoustic(k3h_clat *c, double scale);                 /* fst::ScaleLattice(fst::AcousticLatticeScale(scale), &clat) */
+int k3h_clat_write(const k3h_clat *c, const char *key, const char *wspecifier);   /* one record; "ark:file" or "ark,t:file" */
+void k3h_clat_free(k3h_clat *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+// k3_host_abi.cc -- the C ABI of include/k3host.h over k3_lattice.cc / k3_host.cc (-> kaldi_amd/lib/libk3host.so).  No GPU code.
+#include <cmath>
+#include <cstring>
+#include "../../include/k3host.h"
+#include "k3_host.h"
+using namespace k3host;
+
+struct k3h_transitions { TransitionInfo info; };
+struct k3h_clat { CompactLattice c; };
+namespace {
+thread_local std::string g_err;
+template <class F> int Guard(F f) { try { f(); return 0; } catch (const std::exception &e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown error"; return -2; } }
+Lattice FromArrays(int32_t ns, int32_t start, const float *fin, int64_t na, const int32_t *src, const int32_t *dst, const int32_t *il, const int32_t *ol, const float *g, const float *ac) {
+  if (ns < 0 || na < 0 || (ns > 0 && (start < 0 || start >= ns))) K3H_ERR << "bad lattice: " << ns << " states, start " << start << ", " << na << " arcs";
+  Lattice l; l.start = ns ? start : -1; l.st_frame.assign(ns, 0); l.st_state.assign(ns, 0); l.st_final.assign(fin, fin + ns);
+  for (float &f : l.st_final) if (!std::isfinite(f)) f = std::numeric_limits<float>::infinity();
+  l.arc_src.assign(src, src + na); l.arc_dst.assign(dst, dst + na); l.arc_ilabel.assign(il, il + na); l.arc_olabel.assign(ol, ol + na); l.arc_graph.assign(g, g + na); l.arc_ac.assign(ac, ac + na);
+  for (int64_t a = 0; a < na; a++) if (src[a] < 0 || src[a] >= ns || dst[a] < 0 || dst[a] >= ns) K3H_ERR << "bad lattice: arc " << a << " goes " << src[a] << " -> " << dst[a];
+  return l;
+}
+}  // namespace
+
+extern "C" {
+const char *k3h_last_error(void) { return g_err.c_str(); }
+void k3h_det_opts_default(k3h_det_opts *o) { const DeterminizeLatticePhonePrunedOptions d; o->delta = d.delta; o->max_mem = d.max_mem; o->phone_determinize = d.phone_determinize; o->word_determinize = d.word_determinize; o->minimize = d.minimize; }
+
+int k3h_transitions_read(const char *rx, k3h_transitions **out) { return Guard([&] { auto *t = new k3h_transitions; try { t->info = ReadTransitionModel(rx); } catch (...) { delete t; throw; } *out = t; }); }
+int32_t k3h_transitions_num_ids(const k3h_transitions *t) { return (int32_t)t->info.id2pdf.size() - 1; }
+void k3h_transitions_free(k3h_transitions *t) { delete t; }
+
+int k3h_determinize_lattice(const k3h_transitions *trans, int32_t ns, int32_t start, const float *fin, int64_t na, const int32_t *src, const int32_t *dst, const int32_t *il,
+                            const int32_t *ol, const float *g, const float *ac, double beam, const k3h_det_opts *o, k3h_clat **out, int32_t *complete) {
+  return Guard([&] {
+    const Lattice lat = FromArrays(ns, start, fin, na, src, dst, il, ol, g, ac);
+    DeterminizeLatticePhonePrunedOptions po;
+    if (o) { po.delta = o->delta; po.max_mem = o->max_mem; po.phone_determinize = o->phone_determinize != 0; po.word_determinize = o->word_determinize != 0; po.minimize = o->minimize != 0; }
+    auto *c = new k3h_clat; bool ok;
+    try {
+      if (trans) ok = DeterminizeLatticePhonePruned(lat, trans->info, beam, &c->c, po);
+      else {
+        DeterminizeLatticePrunedOptions d; d.delta = po.delta; d.max_mem = po.max_mem;
+        ok = DeterminizeLatticePruned(lat, beam, &c->c, d);
+        if (po.minimize) { PushCompactLatticeStrings(&c->c); PushCompactLatticeWeights(&c->c); MinimizeCompactLattice(&c->c); }
+      }
+    } catch (...) { delete c; throw; }
+    *out = c; if (complete) *complete = ok ? 1 : 0;
+  });
+}
+int k3h_convert_lattice(int32_t ns, int32_t start, const float *fin, int64_t na, const int32_t *src, const int32_t *dst, const int32_t *il, const int32_t *ol, const float *g, const float *ac, k3h_clat **out) {
+  return Guard([&] { const Lattice lat = FromArrays(ns, start, fin, na, src, dst, il, ol, g, ac); auto *c = new k3h_clat; try { ConvertLattice(lat, &c->c); } catch (...) { delete c; throw; } *out = c; });
+}
+int k3h_clat_sizes(const k3h_clat *c, int32_t *ns, int64_t *na, int64_t *nl) {
+  return Guard([&] { int64_t n = 0; for (const auto &s : c->c.fin_str) n += (int64_t)s.size(); for (const auto &s : c->c.arc_str) n += (int64_t)s.size(); *ns = c->c.NumStates(); *na = (int64_t)c->c.arc_src.size(); *nl = n; });
+}
+int k3h_clat_get(const k3h_clat *h, int32_t *start, uint8_t *is_final, float *fg, float *fa, int64_t *foff, int32_t *src, int32_t *dst, int32_t *label, float *g, float *a, int64_t *aoff, int32_t *strings) {
+  return Guard([&] {
+    const CompactLattice &c = h->c; const int32_t ns = c.NumStates(); const size_t na = c.arc_src.size(); int64_t p = 0;
+    *start = c.start;
+    for (int32_t s = 0; s < ns; s++) { is_final[s] = (uint8_t)c.is_final[s]; fg[s] = c.fin_graph[s]; fa[s] = c.fin_ac[s]; foff[s] = p; for (int32_t t : c.fin_str[s]) strings[p++] = t; }
+    foff[ns] = p;
+    for (size_t k = 0; k < na; k++) { src[k] = c.arc_src[k]; dst[k] = c.arc_dst[k]; label[k] = c.arc_label[k]; g[k] = c.arc_graph[k]; a[k] = c.arc_ac[k]; aoff[k] = p; for (int32_t t : c.arc_str[k]) strings[p++] = t; }
+    aoff[na] = p;
+  });
+}
+int k3h_clat_scale_acoustic(k3h_clat *c, double scale) { return Guard([&] { ScaleAcoustic(&c->c, scale); }); }
+int k3h_clat_write(const k3h_clat *c, const char *key, const char *wspecifier) { return Guard([&] { TableWriter w(wspecifier); w.WriteCompactLattice(key, c->c); w.Flush(); }); }
+void k3h_clat_free(k3h_clat *c) { delete c; }
+}

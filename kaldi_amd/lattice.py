@@ -96,3 +96,104 @@ class RawLattice:
         while s != s0:
             a = back[s]; il.append(int(self.arc_ilabel[a])); ol.append(int(self.arc_olabel[a])); g += float(self.arc_graph[a]); ac += float(self.arc_ac[a]); s = self.arc_src[a]
         return [i for i in il[::-1] if i], [o for o in ol[::-1] if o], g, ac
+
+
+# ---- the host tail: determinization to a CompactLattice (include/k3host.h, kaldi_amd/host/k3_lattice.cc) -------------------------------
+class TransitionInformation:
+    """the transition-id -> phone / self-loop / phone-start map of a model file, which the phone-level determinization pass needs
+    (kaldi::TransitionInformation as DeterminizeLatticeInsertPhones uses it)"""
+    def __init__(self, model_rxfilename):
+        import ctypes
+        from . import hostlib as hl
+        self._L = hl.load(); self._h = ctypes.c_void_p()
+        hl.check(self._L.k3h_transitions_read(str(model_rxfilename).encode(), ctypes.byref(self._h)))
+    def NumTransitionIds(self): return int(self._L.k3h_transitions_num_ids(self._h))
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value: self._L.k3h_transitions_free(self._h); self._h.value = None
+
+
+class CompactLattice:
+    """kaldi::CompactLattice (lat/kaldi-lattice.h:46) as flat arrays: an acceptor over word labels; every arc and every final weight
+    carries (graph cost, acoustic cost) and the transition-ids of the best alignment for that stretch (strings[off[k]:off[k+1]])."""
+    def __init__(self, handle, lib):
+        import ctypes
+        self._L, self._h = lib, handle
+        ns, na, nl = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        from . import hostlib as hl
+        hl.check(lib.k3h_clat_sizes(handle, ctypes.byref(ns), ctypes.byref(na), ctypes.byref(nl)))
+        ns, na, nl = ns.value, na.value, nl.value
+        self.is_final = np.zeros(ns, np.uint8); self.final_graph = np.zeros(ns, np.float32); self.final_ac = np.zeros(ns, np.float32); self.final_str_off = np.zeros(ns + 1, np.int64)
+        self.arc_src, self.arc_dst, self.arc_label = (np.zeros(na, np.int32) for _ in range(3)); self.arc_graph = np.zeros(na, np.float32); self.arc_ac = np.zeros(na, np.float32)
+        self.arc_str_off = np.zeros(na + 1, np.int64); self.strings = np.zeros(max(nl, 1), np.int32)
+        start = ctypes.c_int32()
+        hl.check(lib.k3h_clat_get(handle, ctypes.byref(start), *[x.ctypes.data for x in (self.is_final, self.final_graph, self.final_ac, self.final_str_off, self.arc_src, self.arc_dst,
+                                                                                            self.arc_label, self.arc_graph, self.arc_ac, self.arc_str_off, self.strings)]))
+        self.start = start.value; self.strings = self.strings[:nl]
+    @property
+    def num_states(self): return self.is_final.size
+    @property
+    def num_arcs(self): return self.arc_src.size
+    def arc_string(self, k): return self.strings[self.arc_str_off[k]:self.arc_str_off[k + 1]]
+    def final_string(self, s): return self.strings[self.final_str_off[s]:self.final_str_off[s + 1]]
+    def Write(self, key, wspecifier):
+        """one record of a CompactLattice table: "ark:file" (binary) or "ark,t:file" (text)"""
+        from . import hostlib as hl
+        hl.check(self._L.k3h_clat_write(self._h, str(key).encode(), str(wspecifier).encode()))
+    def ScaleAcoustic(self, scale):
+        from . import hostlib as hl
+        hl.check(self._L.k3h_clat_scale_acoustic(self._h, float(scale)))
+        return CompactLattice._refresh(self)
+    def _refresh(self):
+        new = CompactLattice(self._h, self._L); self.__dict__.update({k: v for k, v in new.__dict__.items() if k not in ("_h", "_L")}); new._h = None
+        return self
+    def best_path(self):
+        """(transition-ids, words, graph cost, acoustic cost) of the cheapest path"""
+        n = self.num_states
+        if n == 0 or self.start < 0: return None
+        order = np.argsort(self.arc_src, kind="stable")
+        best = np.full(n, np.inf); back = np.full(n, -1, np.int64); best[self.start] = 0.0
+        for _ in range(2 if np.all(self.arc_dst > self.arc_src) else n):
+            for a in order:
+                c = best[self.arc_src[a]] + float(self.arc_graph[a]) + float(self.arc_ac[a])
+                if c < best[self.arc_dst[a]]: best[self.arc_dst[a]] = c; back[self.arc_dst[a]] = a
+        fin = np.nonzero(self.is_final)[0]
+        if fin.size == 0 or not np.isfinite(best[fin]).any(): return None
+        tot = best[fin] + self.final_graph[fin] + self.final_ac[fin]; s = int(fin[int(np.argmin(tot))])
+        tids = list(self.final_string(s)); words = []; g = float(self.final_graph[s]); ac = float(self.final_ac[s])
+        while s != self.start:
+            a = int(back[s]); tids = list(self.arc_string(a)) + tids; words.insert(0, int(self.arc_label[a])); g += float(self.arc_graph[a]); ac += float(self.arc_ac[a]); s = int(self.arc_src[a])
+        return [int(t) for t in tids], [w for w in words if w], g, ac
+    def __del__(self):
+        if getattr(self, "_h", None): self._L.k3h_clat_free(self._h); self._h = None
+
+
+def _lattice_args(raw):
+    import ctypes
+    arrs = [np.ascontiguousarray(raw.st_final, np.float32), np.ascontiguousarray(raw.arc_src, np.int32), np.ascontiguousarray(raw.arc_dst, np.int32), np.ascontiguousarray(raw.arc_ilabel, np.int32),
+            np.ascontiguousarray(raw.arc_olabel, np.int32), np.ascontiguousarray(raw.arc_graph, np.float32), np.ascontiguousarray(raw.arc_ac, np.float32)]
+    start = raw.start_index()
+    return arrs, [raw.num_states, max(start, 0), arrs[0].ctypes.data, raw.num_arcs] + [a.ctypes.data for a in arrs[1:]]
+
+
+def DeterminizeLatticePhonePruned(raw, beam, trans=None, delta=None, max_mem=None, phone_determinize=True, word_determinize=True, minimize=False):
+    """fst::DeterminizeLatticePhonePrunedWrapper on a RawLattice (trim it first, like the decoders: raw.connect()); with trans=None the
+    word-level pass alone (fst::DeterminizeLatticePruned).  Returns (CompactLattice, reached_the_beam)."""
+    import ctypes
+    from . import hostlib as hl
+    L = hl.load(); o = hl.DetOpts(); L.k3h_det_opts_default(ctypes.byref(o))
+    if delta is not None: o.delta = delta
+    if max_mem is not None: o.max_mem = max_mem
+    o.phone_determinize, o.word_determinize, o.minimize = int(phone_determinize), int(word_determinize), int(minimize)
+    keep, args = _lattice_args(raw); h = ctypes.c_void_p(); ok = ctypes.c_int32()
+    if raw.num_states and raw.start_index() < 0: raise hl.K3HostError("the lattice has no start state (frame 0, graph start state)")
+    hl.check(L.k3h_determinize_lattice(trans._h if trans is not None else None, *args, float(beam), ctypes.byref(o), ctypes.byref(h), ctypes.byref(ok)))
+    return CompactLattice(h, L), bool(ok.value)
+
+
+def ConvertLattice(raw):
+    """fst::ConvertLattice(Lattice -> CompactLattice): no determinization, linear chains folded into single arcs"""
+    import ctypes
+    from . import hostlib as hl
+    L = hl.load(); keep, args = _lattice_args(raw); h = ctypes.c_void_p()
+    hl.check(L.k3h_convert_lattice(*args, ctypes.byref(h)))
+    return CompactLattice(h, L)
