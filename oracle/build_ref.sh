@@ -84,6 +84,22 @@ for f in determinize-lattice-pruned push-lattice minimize-lattice; do g++ $MF -c
 g++ $MF $HERE/ref_tools/ref_lattice_determinize.cc $W/obj_minifst/determinize-lattice-pruned.o $W/obj_minifst/push-lattice.o $W/obj_minifst/minimize-lattice.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-lattice-determinize
 # ConvertLattice + Factor (fstext/lattice-utils-inl.h, fstext/factor-inl.h: header-only templates of the reference) over the stand-in
 g++ $MF $HERE/ref_tools/ref_convert_lattice.cc $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-convert-lattice
+# i-vector extraction (the next row to build): the reference's gmm/, ivector/ and online2/online-ivector-feature.cc with
+# the programs that create a small extractor from features (gmm-global-init-from-feats -> gmm-global-to-fgmm -> ivector-extractor-init)
+# and the one that is the oracle for the GPU path to come (ivector-extract-online2 = OnlineIvectorFeature, what
+# cudafeat/online-ivector-feature-cuda.cc re-implements); *-copy dump the models as text for the host readers' tests.
+mkdir -p $W/obj_iv
+compile_iv() { src=$1; o=$W/obj_iv/$(basename $(dirname $src))_$(basename ${src%.cc}).o; if [ ! -f $o ] || [ $src -nt $o ]; then g++ $MF -c $src -o $o || { echo "FAILED $src"; exit 1; }; fi; }
+export -f compile_iv; export MF
+{ ls $R/gmm/*.cc | grep -v -e '-test\.cc$'; echo $R/ivector/ivector-extractor.cc; echo $R/online2/online-ivector-feature.cc; echo $R/hmm/posterior.cc; } | xargs -P ${JOBS:-8} -I{} bash -c 'compile_iv {}'
+rm -f $W/libref_iv.a; ar rcs $W/libref_iv.a $W/obj_iv/*.o
+link_iv() { g++ $MF $2 $W/libref_iv.a $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/$1; }
+link_iv ivector-extract-online2     $R/online2bin/ivector-extract-online2.cc
+link_iv gmm-global-init-from-feats  $R/gmmbin/gmm-global-init-from-feats.cc
+link_iv gmm-global-to-fgmm          $R/gmmbin/gmm-global-to-fgmm.cc
+link_iv gmm-global-copy             $R/gmmbin/gmm-global-copy.cc
+link_iv ivector-extractor-init      $R/ivectorbin/ivector-extractor-init.cc
+link_iv ivector-extractor-copy      $R/ivectorbin/ivector-extractor-copy.cc
 for f in /opt/conda/lib/libmkl_{rt,core,intel_lp64,sequential,gnu_thread,intel_thread,avx2,avx512,def,mc3,vml_avx2,vml_avx512,vml_def}.so.1; do
   [ -e $f ] && ln -sf $f $W/mkl/ || true; done
 cat > $W/env.sh <<EOS
