@@ -1,6 +1,7 @@
 // k3-host-tool -- developer/test aid for the host-side format readers (no GPU needed):
 //   k3-host-tool tid2pdf <model.mdl>          NumPdfs, NumTransitionIds, then TransitionIdToPdf(1..N)  (same output as oracle's dump-tid2pdf)
 //   k3-host-tool tidinfo <model.mdl>          per transition-id: phone, self-loop flag, start-of-phone flag
+//   k3-host-tool gmm-dump <diag-gmm> | ie-dump <ivector-extractor>      the numbers of an i-vector extractor's model files
 //   k3-host-tool fstinfo <fst>                states arcs start, FNV-1a checksum of the CSR
 //   k3-host-tool copy-fst <fst-in> <fst-out>  read (vector|const) and write as vector
 //   k3-host-tool convert-lattice <lattice-rspecifier> <lattice-wspecifier>   state-level lattices re-packed as CompactLattices
@@ -21,6 +22,18 @@ int main(int argc, char **argv) {
       TransitionInfo ti = ReadTransitionModel(argv[2]);
       for (size_t t = 1; t < ti.id2pdf.size(); t++) std::cout << t << " " << ti.id2phone[t] << " " << (int)ti.self_loop[t] << " " << (int)ti.phone_start[t] << "\n";
       return 0;
+    }
+    if (cmd == "gmm-dump" && argc == 3) {               // every number of a DiagGmm file, one block per member (compared with the reference's text dump)
+      const DiagGmmModel g = ReadDiagGmm(argv[2]); std::cout.precision(9);
+      std::cout << "num_gauss " << g.num_gauss << " dim " << g.dim << "\n";
+      auto dump = [&](const char *name, const std::vector<double> &v) { std::cout << name; for (double x : v) std::cout << " " << x; std::cout << "\n"; };
+      dump("gconsts", g.gconsts); dump("weights", g.weights); dump("means_invvars", g.means_invvars); dump("inv_vars", g.inv_vars); return 0;
+    }
+    if (cmd == "ie-dump" && argc == 3) {
+      const IvectorExtractorModel m = ReadIvectorExtractor(argv[2]); std::cout.precision(12);
+      std::cout << "num_gauss " << m.num_gauss << " feat_dim " << m.feat_dim << " ivector_dim " << m.ivector_dim << " w " << m.w_rows << "x" << m.w_cols << " prior_offset " << m.prior_offset << "\n";
+      auto dump = [&](const char *name, const std::vector<double> &v) { std::cout << name; for (double x : v) std::cout << " " << x; std::cout << "\n"; };
+      dump("w", m.w); dump("w_vec", m.w_vec); dump("M", m.M); dump("sigma_inv", m.sigma_inv); return 0;
     }
     if (cmd == "fstinfo" && argc == 3) {
       HostFst f = ReadFstKaldiGeneric(argv[2]);

@@ -230,6 +230,20 @@ struct In {          // in-memory reader for Kaldi's text/binary object format (
     }
     return v;
   }
+  // binary Kaldi containers as doubles: "FV"/"DV" n, "FM"/"DM" rows cols, "FP"/"DP" n (packed lower triangle, n(n+1)/2 values)
+  std::vector<double> BinaryDoubles(const char *what, const char *f_tok, const char *d_tok, int ndims, int32_t *dims) {
+    if (!binary) K3H_ERR << "reading " << what << ": text-format models are not supported, copy the model with --binary=true";
+    const std::string t = Token();
+    if (t != f_tok && t != d_tok) K3H_ERR << "reading " << what << ": expected " << f_tok << " or " << d_tok << ", got " << t;
+    size_t n = 1;
+    for (int i = 0; i < ndims; i++) { dims[i] = Basic<int32_t>(); if (dims[i] < 0) K3H_ERR << "reading " << what << ": negative dimension"; n *= (size_t)dims[i]; }
+    if (ndims == 1 && t[1] == 'P') n = (size_t)dims[0] * ((size_t)dims[0] + 1) / 2;
+    std::vector<double> v(n); const size_t w = t[0] == 'F' ? 4 : 8;
+    if (p + w * n > b.size()) K3H_ERR << "reading " << what << ": unexpected end of file";
+    for (size_t i = 0; i < n; i++) { if (w == 4) { float f; memcpy(&f, b.data() + p + 4 * i, 4); v[i] = f; } else memcpy(&v[i], b.data() + p + 8 * i, 8); }
+    p += w * n;
+    return v;
+  }
 };
 struct HmmState { int32_t fwd_pdf_class = -1, self_pdf_class = -1; std::vector<std::pair<int32_t, float>> trans; };
 }  // namespace
@@ -298,6 +312,47 @@ TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename) {
   if (lp.size() != ti.id2pdf.size()) K3H_ERR << "TransitionModel: " << lp.size() - 1 << " log-probs for " << ti.id2pdf.size() - 1 << " transition-ids";
   in.Expect("</LogProbs>"); in.Expect("</TransitionModel>");
   return ti;
+}
+
+// ------------------------------------------------------------------------------------------------ i-vector extractor models ----
+DiagGmmModel ReadDiagGmm(const std::string &rxfilename) {               // DiagGmm::Read (gmm/diag-gmm.cc:728-756)
+  const std::string buf = ReadWholeInput(rxfilename); In in(buf); DiagGmmModel g; int32_t d[2];
+  std::string tok = in.Token();
+  if (tok != "<DiagGMM>" && tok != "<DiagGMMBegin>") K3H_ERR << "Expected <DiagGMM>, got " << tok;
+  tok = in.Token();
+  if (tok == "<GCONSTS>") { g.gconsts = in.BinaryDoubles("DiagGmm gconsts", "FV", "DV", 1, d); in.Expect("<WEIGHTS>"); }
+  else if (tok != "<WEIGHTS>") K3H_ERR << "DiagGmm::Read, expected <WEIGHTS> or <GCONSTS>, got " << tok;
+  g.weights = in.BinaryDoubles("DiagGmm weights", "FV", "DV", 1, d); g.num_gauss = d[0];
+  in.Expect("<MEANS_INVVARS>"); g.means_invvars = in.BinaryDoubles("DiagGmm means_invvars", "FM", "DM", 2, d);
+  if (d[0] != g.num_gauss) K3H_ERR << "DiagGmm: " << d[0] << " mean rows for " << g.num_gauss << " weights";
+  g.dim = d[1];
+  in.Expect("<INV_VARS>"); g.inv_vars = in.BinaryDoubles("DiagGmm inv_vars", "FM", "DM", 2, d);
+  if (d[0] != g.num_gauss || d[1] != g.dim) K3H_ERR << "DiagGmm: inv_vars is " << d[0] << " x " << d[1] << ", expected " << g.num_gauss << " x " << g.dim;
+  tok = in.Token();
+  if (tok != "</DiagGMM>" && tok != "<DiagGMMEnd>") K3H_ERR << "Expected </DiagGMM>, got " << tok;
+  return g;
+}
+IvectorExtractorModel ReadIvectorExtractor(const std::string &rxfilename) {     // IvectorExtractor::Read (ivector/ivector-extractor.cc:828-849)
+  const std::string buf = ReadWholeInput(rxfilename); In in(buf); IvectorExtractorModel m; int32_t d[2];
+  in.Expect("<IvectorExtractor>"); in.Expect("<w>");
+  m.w = in.BinaryDoubles("IvectorExtractor w", "FM", "DM", 2, d); m.w_rows = d[0]; m.w_cols = d[1];
+  in.Expect("<w_vec>"); m.w_vec = in.BinaryDoubles("IvectorExtractor w_vec", "FV", "DV", 1, d);
+  in.Expect("<M>"); m.num_gauss = in.Basic<int32_t>();
+  if (m.num_gauss <= 0) K3H_ERR << "IvectorExtractor: bad number of Gaussians " << m.num_gauss;
+  for (int32_t i = 0; i < m.num_gauss; i++) {
+    std::vector<double> mi = in.BinaryDoubles("IvectorExtractor M", "FM", "DM", 2, d);
+    if (i == 0) { m.feat_dim = d[0]; m.ivector_dim = d[1]; } else if (d[0] != m.feat_dim || d[1] != m.ivector_dim) K3H_ERR << "IvectorExtractor: M matrices of different sizes";
+    m.M.insert(m.M.end(), mi.begin(), mi.end());
+  }
+  in.Expect("<SigmaInv>");
+  for (int32_t i = 0; i < m.num_gauss; i++) {
+    std::vector<double> si = in.BinaryDoubles("IvectorExtractor SigmaInv", "FP", "DP", 1, d);
+    if (d[0] != m.feat_dim) K3H_ERR << "IvectorExtractor: SigmaInv of dimension " << d[0] << ", expected " << m.feat_dim;
+    m.sigma_inv.insert(m.sigma_inv.end(), si.begin(), si.end());
+  }
+  in.Expect("<IvectorOffset>"); m.prior_offset = in.Basic<double>();
+  in.Expect("</IvectorExtractor>");
+  return m;
 }
 
 // ------------------------------------------------------------------------------------------------ OpenFst binary ----

@@ -77,6 +77,15 @@ Wave ReadWave(const std::string &rxfilename);
 struct TransitionInfo { int32_t num_pdfs = 0; std::vector<int32_t> id2pdf, id2phone; std::vector<char> self_loop, phone_start; };
 TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename);
 
+// model files of the online i-vector extractor (binary files only), values widened to double, matrices row-major:
+// DiagGmm (gmm/diag-gmm.h: the UBM that selects Gaussians and gives posteriors) and IvectorExtractor (ivector/ivector-extractor.h:
+// per Gaussian i the projection M_i [feat_dim x ivector_dim] and the packed lower triangle of Sigma_i^-1, the weight projection w,
+// the prior offset).  Readers only, for the GPU path to come.
+struct DiagGmmModel { int32_t num_gauss = 0, dim = 0; std::vector<double> gconsts, weights, means_invvars, inv_vars; };
+DiagGmmModel ReadDiagGmm(const std::string &rxfilename);
+struct IvectorExtractorModel { int32_t num_gauss = 0, feat_dim = 0, ivector_dim = 0, w_rows = 0, w_cols = 0; double prior_offset = 0; std::vector<double> w, w_vec, M, sigma_inv; };
+IvectorExtractorModel ReadIvectorExtractor(const std::string &rxfilename);
+
 struct HostFst {          // generic CSR in FST arc order (input of k3_fst_create)
   int32_t start = -1; std::vector<int32_t> arc_offsets, ilabel, olabel, nextstate; std::vector<float> weight, final_cost;
   int32_t NumStates() const { return (int32_t)final_cost.size(); }

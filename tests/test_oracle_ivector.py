@@ -27,3 +27,33 @@ def test_reference_binary_reproduces_the_golden_ivectors(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     iv = kio.read_ark(f"{td}/iv.ark")
     for u in feats: assert np.array_equal(iv[u], g["iv_default_" + u]), u
+
+
+def _numbers(text):
+    import re
+    return np.array([float(x) for x in re.findall(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?", text)])
+
+def test_host_readers_of_the_model_files_match_the_reference_dumps():
+    """kaldi_amd/host's readers of the binary DiagGmm / IvectorExtractor files against the text dumps the REFERENCE's gmm-global-copy and
+    ivector-extractor-copy made of the same models (final.*.txt in the fixture; text prints ~7 significant digits)"""
+    import __graft_entry__ as ge
+    ge.build()
+    tool = os.path.join(ROOT, "kaldi_amd", "bin", "k3-host-tool")
+    r = subprocess.run([tool, "gmm-dump", os.path.join(DIR, "final.dubm")], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    mine = {l.split()[0]: _numbers(l.split(" ", 1)[1]) if " " in l else np.zeros(0) for l in r.stdout.splitlines()[1:]}
+    ref = open(os.path.join(DIR, "final.dubm.txt")).read()
+    sect = lambda a, b: _numbers(ref.split(a, 1)[1].split(b, 1)[0])
+    for name, a, b in (("gconsts", "<GCONSTS>", "<WEIGHTS>"), ("weights", "<WEIGHTS>", "<MEANS_INVVARS>"), ("means_invvars", "<MEANS_INVVARS>", "<INV_VARS>"), ("inv_vars", "<INV_VARS>", "</DiagGMM>")):
+        assert mine[name].shape == sect(a, b).shape and np.allclose(mine[name], sect(a, b), rtol=2e-6, atol=1e-9), name
+    assert r.stdout.splitlines()[0] == "num_gauss 32 dim 20"
+    r = subprocess.run([tool, "ie-dump", os.path.join(DIR, "final.ie")], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines()[0].startswith("num_gauss 32 feat_dim 20 ivector_dim 16 w 0x0 prior_offset 100")
+    mine = {l.split()[0]: _numbers(l.split(" ", 1)[1]) if " " in l else np.zeros(0) for l in r.stdout.splitlines()[1:]}
+    ref = open(os.path.join(DIR, "final.ie.txt")).read()
+    assert np.allclose(mine["w_vec"], _numbers(ref.split("<w_vec>", 1)[1].split("<M>", 1)[0]), rtol=2e-6)
+    M = _numbers(ref.split("<M>", 1)[1].split("<SigmaInv>", 1)[0])[1:]                     # the first number is the count of matrices
+    assert mine["M"].shape == M.shape == (32 * 20 * 16,) and np.allclose(mine["M"], M, rtol=2e-6, atol=1e-9)
+    S = _numbers(ref.split("<SigmaInv>", 1)[1].split("<IvectorOffset>", 1)[0])
+    assert mine["sigma_inv"].shape == S.shape == (32 * 20 * 21 // 2,) and np.allclose(mine["sigma_inv"], S, rtol=2e-6, atol=1e-9)
+    # error behaviour: a text-format model is refused with a message, a truncated file too
+    assert subprocess.run([tool, "gmm-dump", os.path.join(DIR, "final.dubm.txt")], capture_output=True).returncode != 0
