@@ -57,3 +57,21 @@ def test_host_readers_of_the_model_files_match_the_reference_dumps():
     assert mine["sigma_inv"].shape == S.shape == (32 * 20 * 21 // 2,) and np.allclose(mine["sigma_inv"], S, rtol=2e-6, atol=1e-9)
     # error behaviour: a text-format model is refused with a message, a truncated file too
     assert subprocess.run([tool, "gmm-dump", os.path.join(DIR, "final.dubm.txt")], capture_output=True).returncode != 0
+
+
+def test_numpy_restatement_matches_the_reference_ivectors():
+    """oracle/ivector_oracle.py (the algorithm written out: posteriors, statistics, conjugate-gradient solution, schedule) against the
+    reference binary's output.  Tolerance 2e-4 absolute on i-vector entries of magnitude ~1: the reference sums float32 feature
+    statistics through BLAS in a different order, and 15 CG iterations amplify the last bits."""
+    from oracle import ivector_oracle as io
+    g = np.load(os.path.join(DIR, "ivector_golden.npz"))
+    ubm, ie = io.read_models(os.path.join(DIR, "final.dubm.txt"), os.path.join(DIR, "final.ie.txt"))
+    lda = io.re.sub(r"[\[\]]", " ", open(os.path.join(DIR, "final.mat")).read()); lda = np.array(lda.split(), np.float64).reshape(20, -1).astype(np.float32)
+    st = np.array(io.re.sub(r"[\[\]]", " ", open(os.path.join(DIR, "global_cmvn.stats")).read()).split(), np.float64).reshape(2, -1)
+    for u in ("utt0", "utt1", "utt2", "utt3"):
+        mine = io.extract_online(g["feat_" + u], ubm, ie, lda, st, max_count=100.0)
+        ref = g["iv_default_" + u]
+        assert mine.shape == ref.shape
+        assert np.abs(mine - ref).max() <= 2e-4, (u, np.abs(mine - ref).max())
+    rep = io.extract_online(g["feat_utt3"], ubm, ie, lda, st, max_count=100.0, repeat=True)
+    assert np.abs(rep - g["iv_repeat_utt3"]).max() <= 2e-4
