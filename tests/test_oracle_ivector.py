@@ -61,7 +61,7 @@ def test_host_readers_of_the_model_files_match_the_reference_dumps():
 
 def test_numpy_restatement_matches_the_reference_ivectors():
     """oracle/ivector_oracle.py (the algorithm written out: posteriors, statistics, conjugate-gradient solution, schedule) against the
-    reference binary's output.  Tolerance 2e-4 absolute on i-vector entries of magnitude ~1: the reference sums float32 feature
+    reference binary's output.  Tolerance 5e-5 absolute (measured 8e-6) on i-vector entries of magnitude ~0.2: the reference sums float32 feature
     statistics through BLAS in a different order, and 15 CG iterations amplify the last bits."""
     from oracle import ivector_oracle as io
     g = np.load(os.path.join(DIR, "ivector_golden.npz"))
@@ -72,6 +72,6 @@ def test_numpy_restatement_matches_the_reference_ivectors():
         mine = io.extract_online(g["feat_" + u], ubm, ie, lda, st, max_count=100.0)
         ref = g["iv_default_" + u]
         assert mine.shape == ref.shape
-        assert np.abs(mine - ref).max() <= 2e-4, (u, np.abs(mine - ref).max())
+        assert np.abs(mine - ref).max() <= 5e-5, (u, np.abs(mine - ref).max())          # measured: <= 8e-6
     rep = io.extract_online(g["feat_utt3"], ubm, ie, lda, st, max_count=100.0, repeat=True)
-    assert np.abs(rep - g["iv_repeat_utt3"]).max() <= 2e-4
+    assert np.abs(rep - g["iv_repeat_utt3"]).max() <= 5e-5
