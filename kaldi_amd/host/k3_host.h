@@ -136,6 +136,9 @@ bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &tra
 // transition-ids as their string, then the states are sorted topologically.  What the reference's CUDA pipeline writes with
 // --determinize-lattice=false.
 void ConvertLattice(const Lattice &lat, CompactLattice *clat);
+// the other direction (fstext/lattice-utils-inl.h:88-152): every arc / final weight with a string of k transition-ids becomes a chain of
+// k arcs through new states (word and weight on the first); what Kaldi's lattice readers do when a CompactLattice table is read as Lattice
+void ConvertLattice(const CompactLattice &clat, Lattice *lat);
 void Connect(CompactLattice *clat);                        // fst::Connect; keeps the relative order of the surviving states
 void ScaleAcoustic(CompactLattice *clat, double scale);
 bool TopSortIfNeeded(CompactLattice *clat);                // TopSortCompactLatticeIfNeeded (lat/lattice-functions.cc); false on a cycle
@@ -150,7 +153,8 @@ bool MinimizeCompactLattice(CompactLattice *clat, float delta = 1.0f / 1024.0f);
 // weights that are on no path within `beam` of the best path, then trims.
 bool PruneLattice(double beam, Lattice *lat);
 // "ark:rxfilename" / "ark,t:rxfilename" table of state-level lattices (LatticeHolder::Read, lat/kaldi-lattice.cc:422-459: the
-// first byte after the key tells text from OpenFst binary).
+// first byte after the key tells text from OpenFst binary).  CompactLattice records (arc type compactlattice44, or text weights with a
+// transition-id string) are accepted too and expanded with ConvertLattice, like the reference's SequentialLatticeReader.
 std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string &rspecifier);
 
 // Kaldi float matrices from an archive or script file: "ark:rxfilename", "scp:rxfilename" (entries "key file" or

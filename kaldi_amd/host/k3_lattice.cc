@@ -758,6 +758,32 @@ void ConvertLattice(const Lattice &lat, CompactLattice *out) {
   }
 }
 
+void ConvertLattice(const CompactLattice &c, Lattice *out) {
+  Lattice l; const int32_t n = c.NumStates();
+  l.start = c.start; l.st_final.assign(n, kInfF); l.st_final_ac.assign(n, 0.0f);
+  auto add_state = [&]() { l.st_final.push_back(kInfF); l.st_final_ac.push_back(0.0f); return (int32_t)l.st_final.size() - 1; };
+  auto add_arc = [&](int32_t s, int32_t d, int32_t tid, int32_t word, float g, float a) { l.arc_src.push_back(s); l.arc_dst.push_back(d); l.arc_ilabel.push_back(tid); l.arc_olabel.push_back(word); l.arc_graph.push_back(g); l.arc_ac.push_back(a); };
+  std::vector<int32_t> off(n + 1, 0), idx(c.arc_src.size());
+  for (int32_t s : c.arc_src) off[s + 1]++;
+  for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
+  { std::vector<int32_t> p(off.begin(), off.end() - 1); for (size_t a = 0; a < c.arc_src.size(); a++) idx[p[c.arc_src[a]]++] = (int32_t)a; }
+  for (int32_t s = 0; s < n; s++) {
+    if (c.is_final[s]) {
+      int32_t cur = s; const std::vector<int32_t> &str = c.fin_str[s];
+      for (size_t k = 0; k < str.size(); k++) { const int32_t nx = add_state(); add_arc(cur, nx, str[k], 0, k == 0 ? c.fin_graph[s] : 0.0f, k == 0 ? c.fin_ac[s] : 0.0f); cur = nx; }
+      l.st_final[cur] = str.empty() ? c.fin_graph[s] : 0.0f; l.st_final_ac[cur] = str.empty() ? c.fin_ac[s] : 0.0f;
+    }
+    for (int32_t k = off[s]; k < off[s + 1]; k++) {
+      const int32_t a = idx[k]; const std::vector<int32_t> &str = c.arc_str[a]; int32_t cur = s;
+      for (size_t i = 0; i + 1 < str.size(); i++) { const int32_t nx = add_state(); add_arc(cur, nx, str[i], i == 0 ? c.arc_label[a] : 0, i == 0 ? c.arc_graph[a] : 0.0f, i == 0 ? c.arc_ac[a] : 0.0f); cur = nx; }
+      const bool single = str.size() <= 1;
+      add_arc(cur, c.arc_dst[a], str.empty() ? 0 : str.back(), single ? c.arc_label[a] : 0, single ? c.arc_graph[a] : 0.0f, single ? c.arc_ac[a] : 0.0f);
+    }
+  }
+  l.st_frame.assign(l.st_final.size(), 0); l.st_state.assign(l.st_final.size(), 0);
+  *out = std::move(l);
+}
+
 void ScaleAcoustic(CompactLattice *c, double scale) { for (float &a : c->arc_ac) a = (float)(a * scale); for (int32_t s = 0; s < c->NumStates(); s++) if (c->is_final[s]) c->fin_ac[s] = (float)(c->fin_ac[s] * scale); }
 
 bool TopSortIfNeeded(CompactLattice *c) {
@@ -1033,8 +1059,19 @@ std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string 
       auto str = [&]() { int32_t n; get(&n); if (n < 0 || p + n > b.size()) K3H_ERR << "corrupt FST header in lattice " << key; std::string s = b.substr(p, n); p += n; return s; };
       int32_t magic, version, flags; uint64_t props; int64_t start, ns, na; get(&magic);
       const std::string ftype = str(), atype = str(); get(&version); get(&flags); get(&props); get(&start); get(&ns); get(&na);
-      if (ftype != "vector" || atype != "lattice4") K3H_ERR << "Lattice " << key << ": expected a vector FST with arc type lattice4, got " << ftype << " / " << atype << " (compact lattices are not read by this program)";
+      if (ftype != "vector" || (atype != "lattice4" && atype != "compactlattice44")) K3H_ERR << "Lattice " << key << ": expected a vector FST with arc type lattice4 or compactlattice44, got " << ftype << " / " << atype;
       if (flags & 3) K3H_ERR << "Lattice " << key << " has embedded symbol tables";
+      if (atype == "compactlattice44") {
+        CompactLattice c; c.start = (int32_t)start; for (int64_t s = 0; s < ns; s++) c.AddState();
+        auto weight = [&](float *g, float *a, std::vector<int32_t> *str) { int32_t n; get(g); get(a); get(&n); if (n < 0) K3H_ERR << "corrupt compact lattice " << key; str->resize(n); for (int32_t &t : *str) get(&t); };
+        for (int64_t s = 0; s < ns; s++) {
+          float g, a; std::vector<int32_t> str; int64_t n; weight(&g, &a, &str); get(&n);
+          if (std::isfinite(g) && std::isfinite(a)) { c.is_final[s] = 1; c.fin_graph[s] = g; c.fin_ac[s] = a; c.fin_str[s] = str; }
+          for (int64_t i = 0; i < n; i++) { int32_t il, ol, nx; get(&il); get(&ol); weight(&g, &a, &str); get(&nx); c.arc_src.push_back((int32_t)s); c.arc_dst.push_back(nx); c.arc_label.push_back(il); c.arc_graph.push_back(g); c.arc_ac.push_back(a); c.arc_str.push_back(str); }
+        }
+        ConvertLattice(c, &lat);
+        out.emplace_back(key, std::move(lat)); continue;
+      }
       lat.start = (int32_t)start; if (ns > 0) add_state(ns - 1);
       for (int64_t s = 0; s < ns; s++) {
         float g, a; int64_t n; get(&g); get(&a); get(&n);
@@ -1044,13 +1081,30 @@ std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string 
     } else {                                                  // text: lines until an empty line (lat/kaldi-lattice.cc:204-300 reads the FstPrinter format)
       while (p < b.size() && b[p] != '\n') p++;
       p++;
-      bool first = true;
+      bool first = true, compact = false; CompactLattice c;
+      auto cadd = [&](int64_t s) { while (c.NumStates() <= s) c.AddState(); };
+      auto cweight = [&](const std::string &t, float *g, float *a, std::vector<int32_t> *str) {      // "graph,acoustic,t1_t2_..."
+        const size_t c1 = t.find(','), c2 = t.find(',', c1 + 1); *g = parse_float(t.substr(0, c1)); *a = parse_float(t.substr(c1 + 1, c2 - c1 - 1)); str->clear();
+        for (size_t q = c2 + 1; q < t.size();) { size_t e = t.find('_', q); if (e == std::string::npos) e = t.size(); str->push_back((int32_t)strtol(t.substr(q, e - q).c_str(), nullptr, 10)); q = e + 1; }
+      };
       while (p < b.size()) {
         const size_t l0 = p; while (p < b.size() && b[p] != '\n') p++;
         std::string line = b.substr(l0, p - l0); p++;
         std::vector<std::string> col; { std::istringstream ss(line); std::string t; while (ss >> t) col.push_back(t); }
         if (col.empty()) break;
-        auto weight = [&](const std::string &t, float *g, float *a) { const size_t c = t.find(','); if (c == std::string::npos || t.find(',', c + 1) != std::string::npos) K3H_ERR << "Lattice " << key << ": bad weight \"" << t << "\" (compact lattices are not read by this program)"; *g = parse_float(t.substr(0, c)); *a = parse_float(t.substr(c + 1)); };
+        // a CompactLattice record is an acceptor (3 or 4 columns per arc) whose weights have three comma-separated fields
+        if (first && ((col.size() == 3) || (col.size() == 4 && std::count(col[3].begin(), col[3].end(), ',') == 2) || (col.size() == 2 && std::count(col[1].begin(), col[1].end(), ',') == 2))) compact = true;
+        if (compact) {
+          const int64_t s = strtoll(col[0].c_str(), nullptr, 10); cadd(s);
+          if (first) { c.start = (int32_t)s; first = false; }
+          float g = 0, a = 0; std::vector<int32_t> str;
+          if (col.size() <= 2) { if (col.size() == 2) cweight(col[1], &g, &a, &str); c.is_final[s] = 1; c.fin_graph[s] = g; c.fin_ac[s] = a; c.fin_str[s] = str; }
+          else if (col.size() <= 4) { if (col.size() == 4) cweight(col[3], &g, &a, &str); const int64_t d = strtoll(col[1].c_str(), nullptr, 10); cadd(d);
+            c.arc_src.push_back((int32_t)s); c.arc_dst.push_back((int32_t)d); c.arc_label.push_back((int32_t)strtol(col[2].c_str(), nullptr, 10)); c.arc_graph.push_back(g); c.arc_ac.push_back(a); c.arc_str.push_back(str); }
+          else K3H_ERR << "Lattice " << key << ": bad line \"" << line << "\"";
+          continue;
+        }
+        auto weight = [&](const std::string &t, float *g, float *a) { const size_t c = t.find(','); if (c == std::string::npos || t.find(',', c + 1) != std::string::npos) K3H_ERR << "Lattice " << key << ": bad weight \"" << t << "\""; *g = parse_float(t.substr(0, c)); *a = parse_float(t.substr(c + 1)); };
         const int64_t s = strtoll(col[0].c_str(), nullptr, 10); add_state(s);
         if (first) { lat.start = (int32_t)s; first = false; }
         if (col.size() <= 2) { float g = 0, a = 0; if (col.size() == 2) weight(col[1], &g, &a); lat.st_final[s] = g; lat.st_final_ac[s] = a; }
@@ -1060,6 +1114,7 @@ std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string 
           lat.arc_src.push_back((int32_t)s); lat.arc_dst.push_back((int32_t)d); lat.arc_ilabel.push_back((int32_t)strtol(col[2].c_str(), nullptr, 10)); lat.arc_olabel.push_back((int32_t)strtol(col[3].c_str(), nullptr, 10)); lat.arc_graph.push_back(g); lat.arc_ac.push_back(a);
         } else K3H_ERR << "Lattice " << key << ": bad line \"" << line << "\"";
       }
+      if (compact) ConvertLattice(c, &lat);
     }
     for (size_t s = 0; s < lat.st_final.size(); s++) if (!std::isfinite(lat.st_final[s])) lat.st_final_ac[s] = 0.0f;
     out.emplace_back(key, std::move(lat));

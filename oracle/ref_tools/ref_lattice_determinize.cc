@@ -7,11 +7,13 @@
 // lattices.txt: Kaldi text archive of state-level lattices ("key", then "src dst ilabel olabel [graph,acoustic]" / "state [graph,acoustic]"
 // lines, blank line after each lattice).  Extra arguments after these: --max-mem=N --delta=X --minimize=true (defaults of the programs).
 // --minimize runs the reference's lat/push-lattice.cc and lat/minimize-lattice.cc (compiled unmodified as well).
+#include <algorithm>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
+#include "fstext/lattice-utils.h"
 #include "hmm/transition-model.h"
 #include "lat/determinize-lattice-pruned.h"
 #include "lat/minimize-lattice.h"
@@ -67,16 +69,32 @@ int main(int argc, char **argv) {
     std::string line; int n_done = 0, n_fail = 0;
     while (std::getline(in, line)) {
       std::istringstream ks(line); std::string key; if (!(ks >> key)) continue;
-      Lattice lat; bool first = true;
+      Lattice lat; bool first = true, compact = false; CompactLattice cin;
       auto need = [&](int s) { while (lat.NumStates() <= s) lat.AddState(); };
+      auto cneed = [&](int s) { while (cin.NumStates() <= s) cin.AddState(); };
+      auto cweight = [&](const std::string &t) {       // "graph,acoustic,t1_t2_..." -> CompactLatticeWeight
+        const size_t c1 = t.find(','), c2 = t.find(',', c1 + 1); std::vector<kaldi::int32> str;
+        for (size_t q = c2 + 1; q < t.size();) { size_t e = t.find('_', q); if (e == std::string::npos) e = t.size(); str.push_back(atoi(t.substr(q, e - q).c_str())); q = e + 1; }
+        return kaldi::CompactLatticeWeight(LatticeWeight(Num(t.substr(0, c1)), Num(t.substr(c1 + 1, c2 - c1 - 1))), str);
+      };
       while (std::getline(in, line)) {
         std::vector<std::string> col; { std::istringstream ss(line); std::string t; while (ss >> t) col.push_back(t); }
         if (col.empty()) break;
+        auto commas = [](const std::string &t) { return std::count(t.begin(), t.end(), ','); };
+        if (first && (col.size() == 3 || (col.size() == 4 && commas(col[3]) == 2) || (col.size() == 2 && commas(col[1]) == 2))) compact = true;
+        if (compact) {       // a CompactLattice record: read it as one and let the REFERENCE's ConvertLattice (fstext/lattice-utils-inl.h:88-152) expand it below
+          const int s = atoi(col[0].c_str()); cneed(s);
+          if (first) { cin.SetStart(s); first = false; }
+          if (col.size() <= 2) cin.SetFinal(s, col.size() == 2 ? cweight(col[1]) : kaldi::CompactLatticeWeight::One());
+          else { const int d = atoi(col[1].c_str()); cneed(d); const int l = atoi(col[2].c_str()); cin.AddArc(s, kaldi::CompactLatticeArc(l, l, col.size() == 4 ? cweight(col[3]) : kaldi::CompactLatticeWeight::One(), d)); }
+          continue;
+        }
         const int s = atoi(col[0].c_str()); need(s);
         if (first) { lat.SetStart(s); first = false; }
         if (col.size() <= 2) lat.SetFinal(s, col.size() == 2 ? ParseWeight(col[1]) : LatticeWeight::One());
         else { const int d = atoi(col[1].c_str()); need(d); lat.AddArc(s, LatticeArc(atoi(col[2].c_str()), atoi(col[3].c_str()), col.size() == 5 ? ParseWeight(col[4]) : LatticeWeight::One(), d)); }
       }
+      if (compact) fst::ConvertLattice(cin, &lat);
       CompactLattice clat; bool ok;
       if (mode == "word") {                                   // lattice-determinize-pruned.cc:104-131
         fst::DeterminizeLatticePrunedOptions opts; opts.max_mem = max_mem; opts.max_loop = 0; opts.delta = delta;

@@ -359,6 +359,9 @@ def test_convert_lattice_folds_chains_and_keeps_every_path():
 REF_EXE = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-lattice-determinize")
 
 def _ref_lattices(kind):
+    if kind == "compact":       # CompactLattice records as input (the usual case in recipes: re-determinizing determinized lattices): made by our own program
+        out = lc.parse_compact_text(_run(["--beam=1000"], "".join(lc.lattice_text(k, l) for k, l in _ref_lattices("random")).encode()).stdout.decode())
+        return [(k, ("compact", v)) for k, v in out.items()]
     if kind == "random": return [("k%02d" % s, lc.random_lattice(s, frames=5 + s % 4, width=3 + s % 3, words=2 + s % 3, tids=40)) for s in range(12)]
     if kind == "ties": return [("t%02d" % s, lc.random_lattice(100 + s, frames=6, width=3, words=2, tids=40, quant=4)) for s in range(8)]
     if kind == "wide": return [("b%d" % s, lc.random_lattice(900 + s, frames=12, width=4, words=4, tids=40, p_word=0.5)) for s in range(4)]
@@ -371,6 +374,7 @@ REF_CASES = {   # name: (lattices, mode, beam, acoustic scale, extra options)
     "word_max_mem_retry": ("wide", "word", 8.0, 1.0, ("--max-mem=20000",)), "phone_max_mem_retry": ("wide", "phone", 1000.0, 1.0, ("--max-mem=2000",)),
     "word_minimize": ("random", "word", 1000.0, 1.0, ("--minimize=true",)), "phone_minimize": ("random", "phone", 3.0, 0.5, ("--minimize=true",)),
     "ties_minimize": ("ties", "phone", 50.0, 1.0, ("--minimize=true",)),
+    "compact_input": ("compact", "word", 2.0, 1.0, ()),
     "phone_pass_only": ("random", "phone", 3.0, 1.0, ("--word-determinize=false",)), "no_pass": ("random", "phone", 3.0, 1.0, ("--word-determinize=false", "--phone-determinize=false")),
 }
 
@@ -383,7 +387,16 @@ def write_model(td):
 def _case_input(name, td):
     kind, mode, beam, scale, extra = REF_CASES[name]
     path = os.path.join(td, name + ".in.txt")
-    open(path, "w").write("".join(lc.lattice_text(k, l) for k, l in _ref_lattices(kind)))
+    def text(k, l):
+        if not (isinstance(l, tuple) and l[0] == "compact"): return lc.lattice_text(k, l)
+        c = l[1]; w = lambda g, a, t: "%r,%r,%s" % (g, a, "_".join(map(str, t))); by = {}
+        for a in c["arcs"]: by.setdefault(a[0], []).append(a)
+        lines = [k + " "]
+        for s in [c["start"]] + sorted(set(list(by) + list(c["finals"])) - {c["start"]}):
+            lines += ["%d\t%d\t%d\t%s" % (s, a[1], a[2], w(a[3], a[4], a[5])) for a in by.get(s, [])]
+            if s in c["finals"]: lines.append("%d\t%s" % (s, w(*c["finals"][s])))
+        return "\n".join(lines) + "\n\n" if c["start"] >= 0 else k + " \n\n"
+    open(path, "w").write("".join(text(k, l) for k, l in _ref_lattices(kind)))
     return path, mode, beam, scale, list(extra)
 
 def run_reference(name, td, mdl):
