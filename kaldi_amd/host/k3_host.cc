@@ -658,9 +658,10 @@ bool BestPath(const Lattice &lat, std::vector<int32_t> *ali, std::vector<int32_t
     for (int32_t a : order) { const double c = best[lat.arc_src[a]] + (double)lat.arc_graph[a] + (double)lat.arc_ac[a]; if (c < best[lat.arc_dst[a]]) { best[lat.arc_dst[a]] = c; back[lat.arc_dst[a]] = a; changed = true; } }
   }
   int32_t end = -1; double bc = std::numeric_limits<double>::infinity();
-  for (int32_t s = 0; s < n; s++) if (std::isfinite(lat.st_final[s]) && best[s] + lat.st_final[s] < bc) { bc = best[s] + lat.st_final[s]; end = s; }
+  auto final_ac = [&](int32_t s) { return lat.st_final_ac.empty() ? 0.0 : (double)lat.st_final_ac[s]; };      // zero for the decoder's lattices
+  for (int32_t s = 0; s < n; s++) if (std::isfinite(lat.st_final[s]) && best[s] + lat.st_final[s] + final_ac(s) < bc) { bc = best[s] + lat.st_final[s] + final_ac(s); end = s; }
   if (end < 0) return false;
-  ali->clear(); words->clear(); *gcost = lat.st_final[end]; *acost = 0.0;
+  ali->clear(); words->clear(); *gcost = lat.st_final[end]; *acost = final_ac(end);
   for (int32_t s = end; s != lat.start;) { const int64_t a = back[s]; if (lat.arc_ilabel[a]) ali->push_back(lat.arc_ilabel[a]); if (lat.arc_olabel[a]) words->push_back(lat.arc_olabel[a]); *gcost += lat.arc_graph[a]; *acost += lat.arc_ac[a]; s = lat.arc_src[a]; }
   std::reverse(ali->begin(), ali->end()); std::reverse(words->begin(), words->end());
   return true;

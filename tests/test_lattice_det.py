@@ -463,3 +463,26 @@ def test_minimize_merges_states_and_keeps_the_language():
         for w in ea: assert ea[w][0][3] == eb[w][0][3] and np.allclose(ea[w][0][:3], eb[w][0][:3], atol=2e-3)
         assert len({(x[0], x[2]) for x in b["arcs"]}) == len(b["arcs"])
     assert shrunk >= 1
+
+
+def test_lattice_best_path_program():
+    """lattice-best-path on raw and on determinized (compact, binary) tables: the cheapest path by exhaustive enumeration, with the scales"""
+    exe = PROG.replace("lattice-determinize-pruned", "lattice-best-path")
+    lats = [("k%d" % s, lc.random_lattice(s, frames=5 + s % 4, width=3 + s % 3, words=2 + s % 3, tids=40)) for s in range(1, 9)]
+    raw_txt = "".join(lc.lattice_text(k, l) for k, l in lats).encode()
+    det_bin = _run(["--beam=1000"], raw_txt, binary_out=True).stdout
+    det = lc.parse_compact_binary(det_bin)          # (a determinized lattice keeps one alignment per word sequence: its own paths are the truth for it)
+    for inp, spec, truth in ((raw_txt, "ark,t:-", {k: lc.enumerate_raw(l) for k, l in lats}), (det_bin, "ark:-", {k: lc.enumerate_compact(det[k]) for k, _ in lats})):
+        for lm, ac in ((1.0, 1.0), (1.0, 0.2), (0.5, 1.0)):
+            r = subprocess.run([exe, "--lm-scale=%g" % lm, "--acoustic-scale=%g" % ac, spec, "ark,t:-", "ark,t:/dev/null"], input=inp, capture_output=True, timeout=60)
+            assert r.returncode == 0, r.stderr.decode()
+            got = {l.split()[0]: tuple(int(x) for x in l.split()[1:]) for l in r.stdout.decode().splitlines()}
+            for k, l in lats:
+                paths = truth[k]
+                if not paths: assert k not in got; continue
+                cost = lambda v: lm * v[1] + ac * v[2]
+                best = min(((cost(v), w) for w, vs in paths.items() for v in vs))
+                ties = [w for w, vs in paths.items() for v in vs if abs(cost(v) - best[0]) < 1e-4]
+                assert got[k] in ties, (k, lm, ac, got[k], best)
+    assert b"Overall cost per frame is" in r.stderr and b"Done" in r.stderr
+    assert subprocess.run([exe], capture_output=True).returncode == 1
