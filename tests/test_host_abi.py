@@ -72,3 +72,24 @@ def test_convert_lattice_and_errors(tmp_path):
     bad = _raw(dict(start=0, n=2, finals={1: (0.0, 0.0)}, arcs=[(0, 1, 1, 1, 1.0, 1.0), (1, 0, 0, 0, 1.0, 0.0)]))
     with pytest.raises(hostlib.K3HostError, match="Topological sorting"): kl.DeterminizeLatticePhonePruned(bad, 5.0)
     with pytest.raises(hostlib.K3HostError): kl.DeterminizeLatticePhonePruned(_raw(lat), -1.0)
+
+
+def test_determinization_is_thread_safe(tmp_path):
+    """the reference calls its determinizer from pool threads (one lattice each); the C ABI must allow the same: 8 Python threads (ctypes
+    releases the GIL) determinize different lattices concurrently with one shared transition map, results equal the serial ones"""
+    import threading
+    from kaldi_amd import lattice as kl, synth
+    mdl = str(tmp_path / "final.mdl"); synth.make_tdnn(seed=1, dim=32, num_pdfs=20).write(mdl, as_mdl=True, num_pdfs=20, left_context=2, right_context=2)
+    trans = kl.TransitionInformation(mdl)
+    raws = [_raw(lc.random_lattice(300 + s, frames=20, width=4, words=3, tids=40)) for s in range(16)]
+    def sig(c): return (c.num_states, c.num_arcs, c.arc_label.tolist(), c.arc_graph.tolist(), c.strings.tolist())
+    serial = [sig(kl.DeterminizeLatticePhonePruned(r, 5.0, trans)[0]) for r in raws]
+    out = [None] * len(raws); errs = []
+    def work(i):
+        try:
+            for _ in range(3): out[i] = sig(kl.DeterminizeLatticePhonePruned(raws[i], 5.0, trans)[0])
+        except Exception as e: errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(raws))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs and out == serial
