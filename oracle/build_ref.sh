@@ -107,4 +107,5 @@ export LD_LIBRARY_PATH=$W/mkl\${LD_LIBRARY_PATH:+:\$LD_LIBRARY_PATH}
 export MKL_THREADING_LAYER=SEQUENTIAL
 export PATH=$W/bin:\$PATH
 EOS
+strip $W/bin/* 2>/dev/null || true      # the binaries travel to the GPU box with every gpurun call: keep them small
 echo "build_ref: ok -> $W/bin"
