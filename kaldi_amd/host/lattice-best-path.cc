@@ -1,7 +1,6 @@
 // lattice-best-path -- same command line as the reference's latbin/lattice-best-path.cc:30-140: the 1-best word sequence and alignment of
 // every lattice of a table (Lattice or CompactLattice records, text or binary), after scaling graph costs by --lm-scale and acoustic
 // costs by --acoustic-scale.  Host-only; with it the output of the decoding programs here can be scored without a Kaldi build.
-// --word-symbol-table (debug printing of the words) needs a symbol table reader and is not implemented.
 #include <cmath>
 #include <iostream>
 #include "k3_host.h"
@@ -17,10 +16,15 @@ int main(int argc, char **argv) {
     float acoustic_scale = 1.0f, lm_scale = 1.0f; std::string word_syms;
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic likelihoods");
     po.Register("lm-scale", &lm_scale, "Scaling factor for LM probabilities. Note: the ratio acoustic-scale/lm-scale is all that matters.");
-    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (not supported)");
+    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output]");
     po.Read(argc, argv);
     if (po.NumArgs() < 1 || po.NumArgs() > 3) { po.PrintUsage(); return 1; }
-    if (!word_syms.empty()) K3H_ERR << "--word-symbol-table is not supported";
+    std::map<int32_t, std::string> syms;                  // fst::SymbolTable::ReadText: lines "symbol id"
+    if (!word_syms.empty()) {
+      std::istringstream in(ReadWholeInput(word_syms)); std::string sym; long id;
+      while (in >> sym >> id) syms[(int32_t)id] = sym;
+      if (syms.empty()) K3H_ERR << "Could not read symbol table from file " << word_syms;
+    }
     std::unique_ptr<TableWriter> words_writer, ali_writer;
     if (po.NumArgs() >= 2 && !po.GetArg(2).empty()) words_writer.reset(new TableWriter(po.GetArg(2)));
     if (po.NumArgs() >= 3 && !po.GetArg(3).empty()) ali_writer.reset(new TableWriter(po.GetArg(3)));
@@ -35,6 +39,11 @@ int main(int argc, char **argv) {
       K3H_LOG << "For utterance " << kv.first << ", best cost " << g << " + " << a << " = " << (g + a) << " over " << ali.size() << " frames.";
       if (words_writer) words_writer->WriteInt32Vector(kv.first, words);
       if (ali_writer) ali_writer->WriteInt32Vector(kv.first, ali);
+      if (!syms.empty()) {
+        std::string line = kv.first + " ";
+        for (int32_t w : words) { auto it = syms.find(w); if (it == syms.end()) K3H_ERR << "Word-id " << w << " not in symbol table."; line += it->second + " "; }
+        std::cerr << line << "\n";
+      }
       n_done++; n_frame += (int64_t)ali.size(); tot_graph += g; tot_ac += a;
     }
     if (words_writer) words_writer->Flush();

@@ -486,3 +486,10 @@ def test_lattice_best_path_program():
                 assert got[k] in ties, (k, lm, ac, got[k], best)
     assert b"Overall cost per frame is" in r.stderr and b"Done" in r.stderr
     assert subprocess.run([exe], capture_output=True).returncode == 1
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt") as f:                    # --word-symbol-table: the words of every utterance on stderr, like the reference
+        f.write("<eps> 0\nalpha 1\nbeta 2\ngamma 3\ndelta 4\n"); f.flush()
+        r = subprocess.run([exe, "--word-symbol-table=" + f.name, "ark,t:-", "ark,t:-"], input=raw_txt, capture_output=True, timeout=60)
+        assert r.returncode == 0
+        words = {l.split()[0]: l.split()[1:] for l in r.stdout.decode().splitlines()}; names = {"1": "alpha", "2": "beta", "3": "gamma", "4": "delta"}
+        for k, w in words.items(): assert (k + " " + " ".join(names[x] for x in w)).strip() in [l.strip() for l in r.stderr.decode().splitlines()]
