@@ -604,11 +604,18 @@ bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &tra
     convert(sorted_edges(SortedInput(InvertedEdges(lat)))); return true;
   }
   DeterminizeLatticePrunedOptions det_opts; det_opts.delta = opts.delta; det_opts.max_mem = opts.max_mem;
-  auto finish = [&](bool ans) {                  // :1455-1460
+  // :1455-1460, then the wrapper's Connect (:1497): pushing and minimizing see the determinizer's output before it is trimmed
+  auto finish = [&](bool ans) {
     if (opts.minimize) { ans = PushCompactLatticeStrings(clat) && ans; ans = PushCompactLatticeWeights(clat) && ans; ans = MinimizeCompactLattice(clat) && ans; }
+    Connect(clat);
     return ans;
   };
-  if (!opts.phone_determinize) return finish(DeterminizeLatticePruned(lat, beam, clat, det_opts));
+  if (!opts.phone_determinize) {
+    *clat = CompactLattice();
+    InputFst f = SortedInput(InvertedEdges(lat));
+    if (f.NumStates() == 0) return true;
+    return finish(DeterminizeWithRetries(std::move(f), beam, det_opts, [&](const Determinizer &det) { det.Output(clat); }));
+  }
   *clat = CompactLattice();
   EdgeFst e = InvertedEdges(lat);
   if (e.fin.empty()) return true;
@@ -620,7 +627,7 @@ bool DeterminizeLatticePhonePruned(const Lattice &lat, const TransitionInfo &tra
   if (!opts.word_determinize) { convert(sorted_edges(SortedInput(pass1, false))); return ans; }      // TopSort :1405, then ConvertLattice :1443-1446
   InputFst g = SortedInput(pass1);
   if (g.NumStates() == 0) return ans;
-  return finish(DeterminizeWithRetries(std::move(g), beam, det_opts, [&](const Determinizer &det) { det.Output(clat); Connect(clat); }) && ans);
+  return finish(DeterminizeWithRetries(std::move(g), beam, det_opts, [&](const Determinizer &det) { det.Output(clat); }) && ans);
 }
 
 bool PruneLattice(double beam, Lattice *lat) {

@@ -493,3 +493,23 @@ def test_lattice_best_path_program():
         assert r.returncode == 0
         words = {l.split()[0]: l.split()[1:] for l in r.stdout.decode().splitlines()}; names = {"1": "alpha", "2": "beta", "3": "gamma", "4": "delta"}
         for k, w in words.items(): assert (k + " " + " ".join(names[x] for x in w)).strip() in [l.strip() for l in r.stderr.decode().splitlines()]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_EXE), reason="oracle/_ref not built (needs /root/reference)")
+def test_random_configurations_against_the_reference_binary(tmp_path):
+    """fuzz: random lattice shapes (incl. cost grids that force exact ties), both entry points, random beam / acoustic scale / --minimize /
+    --max-mem / --delta: every output identical to the reference determinizer's, character for character (a 600-lattice run of this loop
+    found the one ordering detail the fixed cases had missed: --minimize runs before the wrapper's Connect)"""
+    td = str(tmp_path); model = write_model(td); rng = np.random.default_rng(4321)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for rnd in range(8):
+        kw = dict(frames=int(rng.integers(3, 12)), width=int(rng.integers(1, 5)), words=int(rng.integers(1, 5)), tids=40, p_word=float(rng.uniform(0.05, 0.9)), eps_arcs=bool(rng.integers(0, 2)),
+                  quant=(None, 2, 4, 16)[int(rng.integers(0, 4))])
+        open(f"{td}/in.txt", "w").write("".join(lc.lattice_text("r%d_%d" % (rnd, i), lc.random_lattice(int(rng.integers(0, 1 << 30)), **kw)) for i in range(10)))
+        mode = ("word", "phone")[rnd % 2]; beam = float(rng.choice([0.5, 2.0, 5.0, 1000.0])); sc = float(rng.choice([1.0, 0.1, 0.5, 2.0]))
+        extra = [[], ["--minimize=true"], ["--max-mem=%d" % int(rng.integers(500, 40000))], ["--minimize=true", "--delta=0.01"]][int(rng.integers(0, 4))]
+        r = subprocess.run([REF_EXE, mode, repr(beam), repr(sc), f"{td}/in.txt", f"{td}/ref.txt"] + ([model] if mode == "phone" else []) + extra, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        m = subprocess.run([PROG if mode == "word" else PHONE_PROG, "--beam=%r" % beam, "--acoustic-scale=%r" % sc] + extra + ([model] if mode == "phone" else []) + [f"ark,t:{td}/in.txt", "ark,t:-"], capture_output=True, text=True)
+        assert m.returncode == 0, m.stderr
+        assert m.stdout == open(f"{td}/ref.txt").read(), (rnd, mode, beam, sc, extra, kw)
