@@ -163,3 +163,22 @@ def test_reference_decoder_edge_cases_match_too():
         ref = rd.decode(f, ll, T2P, cfg); lat, info = lo.decode(f, ll, T2P, cfg, 0)
         assert ref["reached_final"] == info["reached_final"]
         assert lsig.canonical_of_reference(ref) == lsig.canonical_of_raw(lat), (T, ref["frame"].size, lat.num_states)
+
+def test_random_configurations_against_the_reference_decoder():
+    """fuzz (live only): random graph sizes, utterance lengths, score spreads and every LatticeFasterDecoderConfig field; the literal mode
+    equals the reference decoder's raw lattice each time (a 40-configuration run of this loop: 40 identical)"""
+    from oracle import ref_decoder as rd
+    if not rd.available(): pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(778)
+    for it in range(8):
+        N = int(rng.choice([20, 40, 80])); S = int(rng.choice([300, 1500, 6000])); A = int(S * rng.uniform(2.0, 3.5)); T = int(rng.integers(1, 70))
+        f = synth.make_hclg(S, A, N, seed=int(rng.integers(0, 1 << 30)), start_degree=int(rng.choice([5, 30, 200])))
+        ll = (rng.standard_normal((T, N)) * float(rng.choice([1.0, 2.5, 5.0]))).astype(np.float32)
+        kw = dict(beam=float(rng.choice([4.0, 8.0, 15.0, 20.0])), lattice_beam=float(rng.choice([1.0, 4.0, 8.0, 12.0])), beam_delta=float(rng.choice([0.5, 0.1, 2.0])),
+                  hash_ratio=float(rng.choice([2.0, 1.0, 3.7])), prune_interval=int(rng.choice([25, 1, 7, 1000])), prune_scale=float(rng.choice([0.1, 0.5])))
+        if rng.random() < 0.4: kw["max_active"] = int(rng.choice([50, 200, 1000]))
+        if rng.random() < 0.4: kw["min_active"] = int(rng.choice([0, 20, 500]))
+        if "max_active" in kw and kw.get("min_active", 200) >= kw["max_active"]: kw["min_active"] = max(0, kw["max_active"] - 1)
+        cfg = lo.Config(**kw)
+        ref = rd.decode(f, ll, synth.tid2pdf(N), cfg); lat, info = lo.decode(f, ll, synth.tid2pdf(N), cfg, 0)
+        assert ref["reached_final"] == info["reached_final"] and lsig.canonical_of_reference(ref) == lsig.canonical_of_raw(lat), (it, kw, ref["frame"].size, lat.num_states)
