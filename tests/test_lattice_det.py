@@ -513,3 +513,50 @@ def test_random_configurations_against_the_reference_binary(tmp_path):
         m = subprocess.run([PROG if mode == "word" else PHONE_PROG, "--beam=%r" % beam, "--acoustic-scale=%r" % sc] + extra + ([model] if mode == "phone" else []) + [f"ark,t:{td}/in.txt", "ark,t:-"], capture_output=True, text=True)
         assert m.returncode == 0, m.stderr
         assert m.stdout == open(f"{td}/ref.txt").read(), (rnd, mode, beam, sc, extra, kw)
+
+
+def test_scoring_filters_scale_penalty_prune():
+    """lattice-scale | lattice-add-penalty | lattice-best-path as local/score.sh chains them, and lattice-prune: against exhaustive enumeration"""
+    bindir = os.path.dirname(PROG); T = lambda n: os.path.join(bindir, n)
+    lats = [("k%d" % s, lc.random_lattice(40 + s, frames=5 + s % 4, width=3 + s % 3, words=2 + s % 3, tids=40)) for s in range(8)]
+    raw_txt = "".join(lc.lattice_text(k, l) for k, l in lats).encode()
+    a = subprocess.run([T("lattice-scale"), "--inv-acoustic-scale=10", "ark,t:-", "ark:-"], input=raw_txt, capture_output=True); assert a.returncode == 0, a.stderr.decode()
+    b = subprocess.run([T("lattice-add-penalty"), "--word-ins-penalty=0.5", "ark:-", "ark:-"], input=a.stdout, capture_output=True); assert b.returncode == 0, b.stderr.decode()
+    c = subprocess.run([T("lattice-best-path"), "ark:-", "ark,t:-"], input=b.stdout, capture_output=True); assert c.returncode == 0, c.stderr.decode()
+    got = {l.split()[0]: tuple(int(x) for x in l.split()[1:]) for l in c.stdout.decode().splitlines()}
+    for k, l in lats:
+        paths = lc.enumerate_raw(l)
+        if not paths: assert k not in got; continue
+        cost = lambda w, v: v[1] + v[2] / 10.0 + 0.5 * len(w)
+        best = min(cost(w, v) for w, vs in paths.items() for v in vs)
+        assert got[k] in [w for w, vs in paths.items() for v in vs if abs(cost(w, v) - best) < 1e-4], k
+    # the penalty lands on every arc that carries a word, nowhere else: total path cost grows by 0.5 per word
+    pen = lc.parse_compact_binary(b.stdout); sc = lc.parse_compact_binary(a.stdout)
+    for k, _ in lats:
+        ea, eb = lc.enumerate_compact(sc[k]), lc.enumerate_compact(pen[k])
+        assert set(ea) == set(eb)
+        for w in ea: assert abs(min(v[0] for v in eb[w]) - min(v[0] for v in ea[w]) - 0.5 * len(w)) < 1e-3
+    # lattice-prune: nothing within the beam is lost, nothing is invented, costs unchanged (acoustic scale applied for the beam only)
+    p = subprocess.run([T("lattice-prune"), "--beam=3", "--acoustic-scale=0.5", "--write-compact=false", "ark,t:-", "ark,t:-"], input=raw_txt, capture_output=True); assert p.returncode == 0, p.stderr.decode()
+    assert b"pruned from on average" in p.stderr
+    out = {}
+    for rec in p.stdout.decode().split("\n\n"):
+        ls_ = [x for x in rec.split("\n") if x.strip()]
+        if not ls_: continue
+        key = ls_[0].strip(); arcs = []; fin = {}; start = None
+        for x in ls_[1:]:
+            f = x.split("\t"); s = int(f[0]); start = s if start is None else start
+            if len(f) <= 2: fin[s] = tuple(float(v) for v in f[1].split(",")) if len(f) == 2 else (0.0, 0.0)
+            else: g, a_ = (float(v) for v in f[4].split(",")) if len(f) == 5 else (0.0, 0.0); arcs.append((s, int(f[1]), int(f[2]), int(f[3]), g, a_))
+        out[key] = dict(start=start, n=1 + max([a_[1] for a_ in arcs] + [a_[0] for a_ in arcs] + list(fin) + [0]), finals=fin, arcs=arcs)
+    for k, l in lats:
+        raw = lc.enumerate_raw(l, 0.5)
+        if not raw: continue
+        best = min(v[0] for vs in raw.values() for v in vs)
+        kept = lc.enumerate_raw(out[k], 0.5); kept_set = {(w, v[3]) for w, vs in kept.items() for v in vs}
+        for w, vs in raw.items():
+            for v in vs:
+                if v[0] <= best + 3.0 - 1e-3: assert (w, v[3]) in kept_set, (k, w)
+        assert kept_set <= {(w, v[3]) for w, vs in raw.items() for v in vs}
+    assert subprocess.run([T("lattice-scale")], capture_output=True).returncode == 1
+    assert subprocess.run([T("lattice-scale"), "--acoustic-scale=2", "--inv-acoustic-scale=3", "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
