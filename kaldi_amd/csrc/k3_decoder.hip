@@ -529,6 +529,12 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   const bool fresh = p.fresh[L] != 0;
   if (!fresh && T == 0) return;        // the lane idles in this call (it may already be finalised: its LaneInfo must stay as it is)
   if (fresh) {
+    // The frame loop leaves through `break` on an error (capacity overflow, spin limit) without running the end of finish_frame, which is
+    // what empties the level-2 (HBM) slots of the frame: a lane restarted after a failed utterance wipes its table first.
+    if (p.info[L].status < 0) {
+      for (unsigned i = tid; i <= mask; i += kBlock) { Slot *q = &hash[i]; K3_AST(&q->cost, kEncMax); K3_AST(&q->stamp, 0); K3_AST(&q->tok, -1); K3_AST(&q->key, kEmpty); }
+      __threadfence(); __syncthreads();
+    }
     // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
     if (tid == 0) {
       bool cl; const int slot = tb.claim(p.start, &cl);
@@ -1132,7 +1138,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------ graph ----
 struct k3_fst {
-  int32_t num_states = 0, start = 0; int64_t num_arcs = 0;
+  int32_t num_states = 0, start = 0; int64_t num_arcs = 0; int32_t max_pdf = -1;      // max_pdf: largest column of the log-likelihood matrix an arc reads (-1: unknown, image imported)
   void *image = nullptr; size_t bytes = 0;
   int2 *offs = nullptr; ArcRec *arcs = nullptr; float *final_cost = nullptr; int *arc_ilabel = nullptr;
   ~k3_fst() { if (image) (void)hipFree(image); }
@@ -1175,6 +1181,8 @@ extern "C" int k3_fst_create(int32_t num_states, int32_t start, const int32_t *h
         if (emit) {
           if (h_il[a] < 0 || h_il[a] >= num_tids) { k3::set_error("k3_fst_create: ilabel %d outside the transition-id map [1, %d)", h_il[a], num_tids); return K3_ERR_ARG; }
           pdf = h_tid2pdf[h_il[a]];
+          if (pdf < 0) { k3::set_error("k3_fst_create: transition-id %d maps to pdf %d", h_il[a], pdf); return K3_ERR_ARG; }
+          f->max_pdf = std::max(f->max_pdf, pdf);
         }
         arcs[pos] = ArcRec{(int)((unsigned)h_next[a] | (has_eps[h_next[a]] ? kEpsFlag : 0u)), h_w[a], pdf, h_ol[a]}; ail[pos] = h_il[a]; pos++;
       }
@@ -1246,6 +1254,7 @@ template <typename T> static int dmalloc(std::vector<void *> *allocs, T **ptr, s
 
 extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg, int32_t nlanes, int32_t num_pdfs, k3_decoder **out) {
   K3_REQUIRE(fst && cfg && out && nlanes > 0 && num_pdfs > 0, "k3_decoder_create: bad argument");
+  if (fst->max_pdf >= num_pdfs) { k3::set_error("k3_decoder_create: the graph reads pdf %d but the log-likelihood matrix has %d columns (graph / model mismatch)", fst->max_pdf, num_pdfs); return K3_ERR_ARG; }
   K3_REQUIRE(cfg->beam > 0 && cfg->lattice_beam > 0 && cfg->max_active > 1 && cfg->min_active >= 0 && cfg->min_active < cfg->max_active, "k3_decoder_create: bad beam / active limits");
   K3_REQUIRE(cfg->frame_tokens_cap >= 64 && cfg->frame_cands_cap >= cfg->frame_tokens_cap && cfg->lane_tokens_cap >= cfg->frame_tokens_cap && cfg->lane_links_cap > 0 &&
              cfg->lane_tokens_cap < (1ll << 31) && cfg->lane_links_cap < (1ll << 40), "k3_decoder_create: bad capacities (need frame_cands_cap >= frame_tokens_cap, lane_tokens_cap < 2^31)");
@@ -1274,6 +1283,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &p.c_arc, nl * cfg->frame_cands_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.c_src, nl * cfg->frame_cands_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.info, nl))) return rc;
+  K3_HIP_CHECK(hipMemset(p.info, 0, nl * sizeof(LaneInfo)));      // status 0: the kernel's fresh path reads the lane's previous status
   if ((rc = dmalloc(&d->allocs, &p.prof, nl * 16))) return rc;
   K3_HIP_CHECK(hipMemset(p.prof, 0, nl * 16 * sizeof(long long)));
   if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
@@ -1354,8 +1364,8 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
     const long long T = h_row_off[u + 1] - h_row_off[u];
     K3_REQUIRE(T >= 0 && d->last_frames[u] + T + 2 <= d->fstride, "k3_decoder_advance_decoding: more frames than max_total_frames of k3_decoder_init_decoding");
     K3_REQUIRE(T == 0 || !d->lane_final[u], "k3_decoder_advance_decoding: frames for a finalised lane (k3_decoder_init_channels restarts it)");
-    d->last_frames[u] += (int)T;
   }
+  for (int u = 0; u < num_utts; u++) d->last_frames[u] += (int)(h_row_off[u + 1] - h_row_off[u]);      // state changes only after every check passed
   K3_HIP_CHECK(hipStreamSynchronize(st));            // d_row_off may still be read by the previous chunk's kernel
   K3_HIP_CHECK(hipMemcpy(d->d_row_off, h_row_off, sizeof(long long) * (num_utts + 1), hipMemcpyHostToDevice));
   K3_HIP_CHECK(hipMemcpy(d->d_fresh, d->fresh.data(), sizeof(int) * num_utts, hipMemcpyHostToDevice));

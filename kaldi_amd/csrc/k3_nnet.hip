@@ -18,6 +18,7 @@
 //   8-wide group so one b128 read feeds 4 consecutive MFMAs; global->register->LDS double buffering;
 //   blockIdx is remapped so that the N-tiles sharing an A panel run on the same XCD (shared L2).
 #include "k3_common.h"
+#include <mutex>
 #include "k3_nnet_model.h"
 #include <algorithm>
 #include <cstring>
@@ -27,6 +28,12 @@
 #include <string>
 #include <vector>
 
+// developer-only timing / short-circuit switches of the GEMM kernel: compiled in only with -DK3_GEMM_PROF (never in the shipped library)
+#ifdef K3_GEMM_PROF
+#define K3_GDBG (p.dbg)
+#else
+#define K3_GDBG 0
+#endif
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -162,14 +169,14 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
 
   const int nk = (p.Ktot + kBK - 1) / kBK;
   long long t0 = 0, t1 = 0, t2 = 0;
-  if (p.dbg & 8) t0 = (long long)__builtin_readcyclecounter();
+  if (K3_GDBG & 8) t0 = (long long)__builtin_readcyclecounter();
   int oi_next = 0, w_next = 0;       // time offset of tile kt + 1 and its index inside the offset (tiles_per_off > 0)
   load_tiles(0, 0, 0);
   store_tiles(0);
   __syncthreads();
-  if (p.dbg & 8) t1 = (long long)__builtin_readcyclecounter();
+  if (K3_GDBG & 8) t1 = (long long)__builtin_readcyclecounter();
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
-  for (int kt = 0; kt < ((p.dbg & 4) ? 1 : nk); kt++) {
+  for (int kt = 0; kt < ((K3_GDBG & 4) ? 1 : nk); kt++) {
     const int buf = kt & 1;
     // prefetch tile kt + 1 (the last iteration fetches its own tile again: no branch in the loop body, so the compiler's
     // s_waitcnt placement stays exact -- with conditional prefetches it put vmcnt(0) between the loads of one tile)
@@ -211,7 +218,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
     __syncthreads();
   }
 
-  if (p.dbg & 8) t2 = (long long)__builtin_readcyclecounter();
+  if (K3_GDBG & 8) t2 = (long long)__builtin_readcyclecounter();
   // ---- epilogue.  The MFMA C/D layout gives a lane 4 consecutive ROWS of one column (col = lane & 31,
   // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)), i.e. dword stores of 128-byte row pieces: 64 store and 64 residual-load
   // instructions per lane, which is what the affine layers (K = 192 only) spent 60 % of their time on.  Instead each wavefront
@@ -249,7 +256,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
     // a full tile (all of the 128 rows and BN columns exist: every tile but the last of an utterance / of N) needs no per-row
     // bounds logic and walks its rows with one pointer increment per row piece
     const bool full = td.nrows == kBM && n0 + BN <= p.N;
-    if ((EPI == kEpiAny || EPI == kEpiReluScaleRes) && res_kind >= 0 && !(p.dbg & 1)) {
+    if ((EPI == kEpiAny || EPI == kEpiReluScaleRes) && res_kind >= 0 && !(K3_GDBG & 1)) {
       if (full) {
         const float *rp = R + (long long)(td.res_base + (wm * WM + row0c) * p.res_row_stride) * p.ldr + colc;
         const long long rstep = (long long)RPI * p.res_row_stride * p.ldr;
@@ -301,7 +308,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
         if (EPI == kEpiReluScaleRes) v[it] = p.res_scale * res[it] + v[it];
       }
     }
-    if (full && !(p.dbg & 2)) {
+    if (full && !(K3_GDBG & 2)) {
       if (lane_on) {
         float *cp = C + (long long)(td.out_row0 + wm * WM + row0) * p.ldc + col;
         const long long cstep = (long long)RPI * p.ldc;
@@ -312,7 +319,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
         const int lrow = wm * WM + it * RPI + row0;
-        if (col_ok && lrow < td.nrows && (!(p.dbg & 2) || v[it][0] == 12345.678f)) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v[it];
+        if (col_ok && lrow < td.nrows && (!(K3_GDBG & 2) || v[it][0] == 12345.678f)) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v[it];
       }
     }
   } else {                                             // unaligned / odd-width output: element-wise tail path
@@ -336,7 +343,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
       }
     }
   }
-  if ((p.dbg & 8) && tid == 0) {
+  if ((K3_GDBG & 8) && tid == 0) {
     const long long t3 = (long long)__builtin_readcyclecounter();
     atomicAdd((unsigned long long *)&p.dbg_buf[0], (unsigned long long)(t1 - t0)); atomicAdd((unsigned long long *)&p.dbg_buf[1], (unsigned long long)(t2 - t1));
     atomicAdd((unsigned long long *)&p.dbg_buf[2], (unsigned long long)(t3 - t2)); atomicAdd((unsigned long long *)&p.dbg_buf[3], 1ull);
@@ -633,19 +640,20 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
   const k3::FusedModel &fm = b->net->fm;
   K3_REQUIRE(ld_feats >= fm.input_dim && ld_feats % 4 == 0 && ((uintptr_t)d_feats & 15) == 0, "k3_nnet_forward: features must be 16-byte aligned with ld % 4 == 0");
   K3_REQUIRE(ld_out >= fm.output_dim, "k3_nnet_forward: ld_out < output dim");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once; int attr_rc = K3_OK;      // per-thread streams may call this concurrently (SURVEY 8b "Threading")
+  std::call_once(attr_once, [&]() { attr_rc = [&]() -> int {
 #define K3_GEMM_VARIANTS(X) X(128, 64, 64, true, kEpiAny) X(128, 64, 64, false, kEpiAny) X(128, 64, 64, true, kEpiReluScaleRes) X(128, 64, 64, false, kEpiReluScale) \
                             X(128, 64, 64, true, kEpiReluScale) X(96, 32, 96, true, kEpiAny) X(96, 32, 96, false, kEpiAny) X(96, 32, 96, true, kEpiNone)
 #define K3_SET_ATTR(bn, wm, wn, al, ep) K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<bn, wm, wn, al, ep>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     K3_GEMM_VARIANTS(K3_SET_ATTR)
 #undef K3_SET_ATTR
-    attr_set = true;
-  }
+    return K3_OK; }(); });
+  if (attr_rc) return attr_rc;
   hipStream_t st = (hipStream_t)stream;
   for (size_t i = 0; i < fm.nodes.size(); i++) {
     GemmParams p = b->params[i];
     if (p.num_m_tiles == 0) continue;
+#ifdef K3_GEMM_PROF
     { static const int dbg = getenv("K3_GEMM_DBG") ? atoi(getenv("K3_GEMM_DBG")) : 0; p.dbg = dbg;
       static long long *dbuf = nullptr;
       if (dbg & 8) {
@@ -659,6 +667,7 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
         }
       }
     }
+#endif
     const k3::FusedNode &f = fm.nodes[i];
     if (f.input < 0) { p.A = d_feats; p.lda = ld_feats; }
     for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual && op.res_node < 0) { p.R = d_feats; p.ldr = ld_feats; }

@@ -160,7 +160,10 @@ class CudaDecoder:
         info = self.LatticeInfo() if info is None else info
         return 32.0 * info[:, 7].sum() + 28.0 * info[:, 8].sum() + 16.0 * info[:, 4].sum()
 
-    def FrameStats(self, utt, num_frames):
+    def FrameStats(self, utt, num_frames=None):
+        nd = self.NumFramesDecoded(utt)
+        assert num_frames is None or num_frames == nd, (num_frames, nd)      # the C side writes NumFramesDecoded(utt) elements
+        num_frames = nd
         nt = np.zeros(num_frames, np.int32); f = [np.zeros(num_frames, np.float32) for _ in range(4)]
         _l.check(self._L.k3_decoder_frame_stats(self._h, utt, nt.ctypes.data, f[0].ctypes.data, f[1].ctypes.data, f[2].ctypes.data, f[3].ctypes.data))
         return dict(ntoks=nt, cur_cutoff=f[0], adaptive_beam=f[1], next_cutoff=f[2], cost_offset=f[3])

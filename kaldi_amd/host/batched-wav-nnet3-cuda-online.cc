@@ -182,7 +182,7 @@ int main(int argc, char **argv) {
         if (!ended.empty()) {
           K3H_CHECK_K3(k3_decoder_finalize_channels(dec, ended.data(), (int32_t)ended.size(), nullptr));
           const int U = (int)ended.size();
-          std::vector<int64_t> info(10 * (size_t)U); K3H_CHECK_K3(k3_decoder_lattice_info(dec, info.data()));
+          std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec, info.data());
           int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
           std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
           if (NS > 0) K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));

@@ -192,7 +192,7 @@ int main(int argc, char **argv) {
       K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
       K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_ll.p, ninfo.output_dim, ro.data(), nullptr));
       auto r = std::make_shared<Raw>(); r->info.resize(10 * (size_t)U);
-      K3H_CHECK_K3(k3_decoder_lattice_info(dec, r->info.data()));
+      K3H_LATTICE_INFO(dec, r->info.data());
       const auto t_c = tick();
       if (b.iter == 0 && writer) {
         int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += r->info[10 * u]; NA += r->info[10 * u + 1]; }

@@ -4,6 +4,7 @@
 //   k3-host-tool gmm-dump <diag-gmm> | ie-dump <ivector-extractor>      the numbers of an i-vector extractor's model files
 //   k3-host-tool fstinfo <fst>                states arcs start, FNV-1a checksum of the CSR
 //   k3-host-tool copy-fst <fst-in> <fst-out>  read (vector|const) and write as vector
+//   k3-host-tool parse-options [options] [args]   the option values ParseOptions::Read ends up with (config files vs command line)
 //   k3-host-tool convert-lattice <lattice-rspecifier> <lattice-wspecifier>   state-level lattices re-packed as CompactLattices
 #include <iostream>
 #include "k3_host.h"
@@ -46,6 +47,12 @@ int main(int argc, char **argv) {
       TableWriter w(argv[3]);
       for (auto &kv : ReadLatticeTable(argv[2])) { Connect(&kv.second); CompactLattice c; ConvertLattice(kv.second, &c); w.WriteCompactLattice(kv.first, c); }
       w.Flush(); return 0;
+    }
+    if (cmd == "parse-options") {                      // what an option ends up as after ParseOptions::Read (util/parse-options.cc:329-371: config files first, command line wins)
+      ParseOptions po("test"); float beam = 16.0f; int32_t max_active = 7; bool flag = false; std::string name = "dflt";
+      po.Register("beam", &beam, "beam"); po.Register("max-active", &max_active, "max active"); po.Register("flag", &flag, "flag"); po.Register("name", &name, "name");
+      po.Read(argc - 1, argv + 1);
+      std::cout << "beam=" << beam << " max-active=" << max_active << " flag=" << (flag ? "true" : "false") << " name=" << name << " nargs=" << po.NumArgs() << "\n"; return 0;
     }
     if (cmd == "copy-fst" && argc == 4) { WriteFstVector(ReadFstKaldiGeneric(argv[2]), argv[3]); return 0; }
     std::cerr << "usage: k3-host-tool tid2pdf <mdl> | tidinfo <mdl> | fstinfo <fst> | copy-fst <in> <out> | convert-lattice <rspecifier> <wspecifier>\n"; return 1;

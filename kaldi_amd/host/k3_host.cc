@@ -79,17 +79,29 @@ int ParseOptions::Read(int argc, const char *const *argv) {
   std::string config; Register("config", &config, "Configuration file to read (this option may be repeated)");
   bool help = false, print_args = true; Register("help", &help, "Print out usage message"); Register("print-args", &print_args, "Print the command line arguments (to stderr)");
   Register("verbose", &g_verbose, "Verbose level (higher->more logging)");
+  // util/parse-options.cc:329-371: a first pass reads every --config file (and answers --help), the second pass applies the
+  // command-line options, so the command line always wins whatever the order of the arguments
+  auto split = [](const std::string &a, std::string *key, std::string *val) {
+    const size_t eq = a.find('=');
+    *key = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2); *val = eq == std::string::npos ? "" : a.substr(eq + 1);
+    return eq != std::string::npos;
+  };
+  for (int k = 1; k < argc; k++) {
+    const std::string a = argv[k];
+    if (a == "--" || a.compare(0, 2, "--") != 0) break;
+    std::string key, val; const bool has = split(a, &key, &val);
+    if (Normalize(key) == "config") { if (!has || val.empty()) K3H_ERR << "Invalid option " << a; ReadConfigFile(val); }
+    if (Normalize(key) == "help") { PrintUsage(); exit(0); }
+  }
   int i = 1;
   for (; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "--") { i++; break; }
     if (a.compare(0, 2, "--") != 0) break;
-    const size_t eq = a.find('=');
-    const std::string key = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2), val = eq == std::string::npos ? "" : a.substr(eq + 1);
-    if (!SetOption(key, val, eq != std::string::npos)) { PrintUsage(true); K3H_ERR << "Invalid option " << a; }
-    if (Normalize(key) == "config") ReadConfigFile(config);
-    if (help) { PrintUsage(); exit(0); }
+    std::string key, val; const bool has = split(a, &key, &val);
+    if (!SetOption(key, val, has)) { PrintUsage(true); K3H_ERR << "Invalid option " << a; }
   }
+  (void)help;
   for (; i < argc; i++) args_.push_back(argv[i]);
   if (print_args) { std::ostringstream o; for (int k = 0; k < argc; k++) o << argv[k] << " "; std::cerr << o.str() << "\n"; }
   return i;

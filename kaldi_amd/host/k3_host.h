@@ -36,6 +36,12 @@ struct FatalError : std::runtime_error { using std::runtime_error::runtime_error
 #define K3H_ERR ::k3host::LogLine("ERROR", __func__, __FILE__, __LINE__, true)
 #define K3H_VLOG(n) if ((n) <= ::k3host::g_verbose) ::k3host::LogLine("VLOG", __func__, __FILE__, __LINE__, false)
 #define K3H_CHECK_K3(expr) do { if ((expr) != 0) K3H_ERR << #expr << ": " << k3_last_error(); } while (0)
+// k3_decoder_lattice_info for a batch in which single lanes may have failed: a lane that ran out of token / link capacity has its
+// status in info[10 u + 2] (and 0 states / arcs); the other lanes of the batch are good and the job goes on (the reference decoder
+// never fails a whole job for one utterance).  Only errors that are not per-lane (HIP failure, bad argument) are fatal.
+#define K3H_LATTICE_INFO(dec, info_ptr) do { const int rc__ = k3_decoder_lattice_info((dec), (info_ptr)); \
+    if (rc__ == K3_ERR_OVERFLOW) K3H_WARN << "some utterances of this batch exceeded the decoder capacities and will be reported as failed: " << k3_last_error(); \
+    else if (rc__ != 0) K3H_ERR << "k3_decoder_lattice_info: " << k3_last_error(); } while (0)
 
 class ParseOptions {
  public:

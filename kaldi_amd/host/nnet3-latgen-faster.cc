@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
                         "See also: nnet3-latgen-faster-parallel, nnet3-latgen-faster-batch\n";
     ParseOptions po(usage);
     bool allow_partial = false, determinize = true, debug_comp = false, phone_det = true, word_det = true, minimize = false; std::string word_syms, use_gpu = "yes", ivector_rspecifier, online_ivector_rspecifier, utt2spk;
-    int32_t subsampling = 1, frames_per_chunk = 50, elc = 0, erc = 0, elci = -1, ercf = -1, online_ivector_period = 0, max_batch = 256, max_active = 2147483647, min_active = 200, prune_interval = 25, max_mem = 50000000;
+    int32_t subsampling = 1, frames_per_chunk = 50, elc = 0, erc = 0, elci = -1, ercf = -1, online_ivector_period = 0, max_batch = 256, max_active = 2147483647, min_active = 200, prune_interval = 25, max_mem = 50000000, frame_tokens_cap = 65536, lane_tokens_cap = 4000000, lane_links_cap = 8000000;
     float beam = 16.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, hash_ratio = 2.0f, prune_scale = 0.1f, delta = 0.000976562f;
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)"); po.Register("allow-partial", &allow_partial, "If true, produce output even if end state was not reached.");
     po.Register("beam", &beam, "Decoding beam.  Larger->slower, more accurate."); po.Register("max-active", &max_active, "Decoder max active states.  Larger->slower; more accurate");
@@ -35,6 +35,8 @@ int main(int argc, char **argv) {
     po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole)"); po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)");
     po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)"); po.Register("debug-computation", &debug_comp, "(accepted, unused)");
     po.Register("ivectors", &ivector_rspecifier, "(not supported)"); po.Register("online-ivectors", &online_ivector_rspecifier, "(not supported)"); po.Register("online-ivector-period", &online_ivector_period, "(not supported)"); po.Register("utt2spk", &utt2spk, "(not supported)");
+    po.Register("frame-tokens-cap", &frame_tokens_cap, "Decoder capacity: tokens alive on one frame of one utterance"); po.Register("lane-tokens-cap", &lane_tokens_cap, "Decoder capacity: tokens of all frames of one utterance (an utterance that exceeds it is reported as failed)");
+    po.Register("lane-links-cap", &lane_links_cap, "Decoder capacity: forward links of all frames of one utterance");
     po.Register("use-gpu", &use_gpu, "(this build always uses the GPU)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
     po.Read(argc, argv);
     if (po.NumArgs() < 4 || po.NumArgs() > 6) { po.PrintUsage(); return 1; }
@@ -54,7 +56,7 @@ int main(int argc, char **argv) {
                                ti.id2pdf.data(), (int32_t)ti.id2pdf.size(), &fst));
     k3_decoder_config dc; k3_decoder_config_default(&dc);
     dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(min_active, max_active - 1); dc.beam_delta = beam_delta;
-    dc.frame_tokens_cap = 65536; dc.frame_cands_cap = 4 * 65536; dc.lane_tokens_cap = 4000000; dc.lane_links_cap = 8000000;
+    dc.frame_tokens_cap = frame_tokens_cap; dc.frame_cands_cap = 4 * frame_tokens_cap; dc.lane_tokens_cap = lane_tokens_cap; dc.lane_links_cap = lane_links_cap;
     k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, max_batch, ni.output_dim, &dec));
     auto feats = ReadMatrixTable(po.GetArg(3)); TableWriter lat_writer(po.GetArg(4));
     std::unique_ptr<TableWriter> words_writer, ali_writer;
@@ -79,7 +81,7 @@ int main(int argc, char **argv) {
       HIPCHK(hipMemcpy(d_f, all.data(), all.size() * 4, hipMemcpyHostToDevice));
       K3H_CHECK_K3(k3_nnet_forward(nb, d_f, ni.input_dim, d_o, ni.output_dim, nullptr));
       K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_o, ni.output_dim, ro.data(), nullptr));
-      std::vector<int64_t> info(10 * (size_t)U); K3H_CHECK_K3(k3_decoder_lattice_info(dec, info.data()));
+      std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec, info.data());
       int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
       std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
       K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));

@@ -44,6 +44,14 @@
  *                       HashList order (so a few tokens/links exist only because the bound was still loose).
  *   mode 1 "two-pass":  the order-independent definition the GPU decoder implements: an arc is accepted iff
  *                       tot < min(prepass bound, min_tot + adaptive_beam), i.e. against the FINAL next_cutoff.
+ *   mode 2 "literal, phase-parallel": the SAME results as mode 0, bit for bit, but computed the way the GPU kernel
+ *                       (k3_decoder_config.literal_order) computes them: no serial walk over a hash list.  The token
+ *                       visit order is derived from (first-occupation time of the bucket, insertion time) keys, arc
+ *                       acceptance from an exclusive prefix-min over the arc sequence, token creation times from a
+ *                       min over accepted arc sequence numbers, the eps closure from an order-free fixpoint followed
+ *                       by a replay of the LIFO queue on the closure sub-graph that only recovers creation ORDER.
+ *   mode 3              mode 2 with the work inside every parallel phase visited in a shuffled order (what a GPU does):
+ *                       tests assert mode 0 == mode 2 == mode 3, i.e. the phase decomposition is order-free.
  * SURVEY.md 9.1 argues that both give the same lattice after FinalizeDecoding except at exact float ties and in
  * the min_active corner; tests assert equality on the test sets and the GPU path is compared with both.
  * All arithmetic is float32 in the reference's evaluation order; compile WITHOUT -ffast-math / FMA contraction.
@@ -300,6 +308,223 @@ struct Decoder {
     }
   }
 
+
+  // =====================================================================================================================
+  // modes 2 / 3: the literal algorithm in the phase structure of the GPU kernel.  Every loop marked PAR is a data-parallel
+  // phase on the GPU (any visiting order must give the same result: mode 3 shuffles it); loops marked SER are the replay.
+  struct Frame2 {                       // tokens of the newest frame, local index i
+    std::vector<int32_t> state, tok, order;       // tok = pool index; order[r] = local index of the r-th element of the HashList
+    std::vector<float> cost;
+  };
+  Frame2 cf; size_t hash_size2 = 1000;  // lattice-faster-decoder.cc:41 toks_.SetSize(1000)
+  uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+  int64_t n_replay_pops = 0, n_replay_pushes = 0;
+  uint32_t Rand() { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng_state >> 33); }
+  template <class T> void MaybeShuffle(std::vector<T> &v) { if (mode != 3) return; for (size_t i = v.size(); i > 1; i--) std::swap(v[i - 1], v[Rand() % i]); }
+  std::vector<int32_t> Iota(size_t n) { std::vector<int32_t> v(n); for (size_t i = 0; i < n; i++) v[i] = (int32_t)i; MaybeShuffle(v); return v; }
+
+  // HashList order (util/hash-list-inl.h:125-165) of tokens with unique creation labels: buckets in order of first occupation,
+  // insertion order inside a bucket == sort by (label of the bucket's first occupant, own label).  Computed without a sort of
+  // keys: dense creation rank d (a bitmap prefix count on the GPU), per-bucket first rank / count, prefix sum over the leaders.
+  void HashOrder(const std::vector<int32_t> &state, const std::vector<uint32_t> &label, std::vector<int32_t> *order, std::vector<int32_t> *by_ins) {
+    const size_t n = state.size();
+    uint32_t M = 0; for (uint32_t l : label) M = std::max(M, l + 1);
+    std::vector<uint32_t> bm((M + 31) / 32 + 1, 0), wpre((M + 31) / 32 + 1, 0);
+    for (int32_t i : Iota(n)) { if (bm[label[i] >> 5] >> (label[i] & 31) & 1) abort(); bm[label[i] >> 5] |= 1u << (label[i] & 31); }       // PAR (atomicOr)
+    for (size_t w = 1; w < bm.size(); w++) wpre[w] = wpre[w - 1] + (uint32_t)__builtin_popcount(bm[w - 1]);                                  // scan
+    std::vector<int32_t> d(n); by_ins->assign(n, -1);
+    std::vector<uint32_t> bfirst(hash_size2, 0xFFFFFFFFu), bcnt(hash_size2, 0), bfill(hash_size2, 0);
+    for (int32_t i : Iota(n)) {                                                                                                                // PAR
+      const uint32_t l = label[i]; d[i] = (int32_t)(wpre[l >> 5] + (uint32_t)__builtin_popcount(bm[l >> 5] & ((1u << (l & 31)) - 1u)));
+      (*by_ins)[d[i]] = i;
+      const size_t b = (size_t)state[i] % hash_size2; bfirst[b] = std::min(bfirst[b], (uint32_t)d[i]); bcnt[b]++;
+    }
+    std::vector<uint32_t> lead(n + 1, 0);
+    for (int32_t dd : Iota(n)) { const int32_t i = (*by_ins)[dd]; const size_t b = (size_t)state[i] % hash_size2; lead[dd] = bfirst[b] == (uint32_t)dd ? bcnt[b] : 0; }   // PAR
+    { uint32_t run = 0; for (size_t k = 0; k <= n; k++) { const uint32_t v = k < n ? lead[k] : 0; lead[k] = run; run += v; } }                 // exclusive scan
+    std::vector<int32_t> grp(n, -1);
+    for (int32_t i : Iota(n)) { const size_t b = (size_t)state[i] % hash_size2; if (bcnt[b] > 1) grp[lead[bfirst[b]] + bfill[b]++] = d[i]; }   // PAR (atomicAdd)
+    order->assign(n, -1);
+    for (int32_t i : Iota(n)) {                                                                                                                // PAR
+      const size_t b = (size_t)state[i] % hash_size2; const uint32_t L = lead[bfirst[b]]; uint32_t rank = 0;
+      if (bcnt[b] > 1) for (uint32_t k = 0; k < bcnt[b]; k++) rank += grp[L + k] < d[i];
+      (*order)[L + rank] = i;
+    }
+  }
+
+  struct PendingLink { int32_t src_tok, dst_local, ilabel, olabel; float graph, ac; };
+
+  // ProcessNonemitting (:830-897) for the frame being built + publication of the frame.  state/cost/label: the tokens the
+  // emitting pass created (label = creation time, unique); n_labels = number of labels handed out so far.
+  void Nonemitting2(float cutoff, std::vector<int32_t> state, std::vector<float> cost, std::vector<uint32_t> label, uint32_t n_labels,
+                    std::vector<PendingLink> links_in) {
+    const int32_t frame_plus_one = (int32_t)active.size() - 1;
+    const size_t n_e = state.size();
+    std::vector<int32_t> order1, by_ins;
+    HashOrder(state, label, &order1, &by_ins);          // the list ProcessNonemitting walks to fill its queue (:845-850)
+    // ---- order-free fixpoint: final costs, the tokens the closure creates (no creation time yet)
+    static thread_local std::vector<int32_t> index_of_state;      // state -> local index (a hash table on the GPU); all -1 between calls
+    if ((int32_t)index_of_state.size() < fst.num_states) index_of_state.assign(fst.num_states, -1);
+    for (size_t i = 0; i < n_e; i++) index_of_state[state[i]] = (int32_t)i;
+    const std::vector<float> c0 = cost;                  // costs right after ProcessEmitting
+    std::vector<int32_t> wl;
+    for (int32_t i : Iota(n_e)) if (fst.num_ieps[state[i]] != 0) wl.push_back(i);
+    while (!wl.empty()) {                                // rounds; PAR inside a round (atomicMin on the costs)
+      std::vector<int32_t> nxt; MaybeShuffle(wl);
+      for (int32_t i : wl) {
+        const float c = cost[i]; if (c >= cutoff) continue;
+        const int32_t s = state[i];
+        for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++) {
+          if (fst.ilabel[a] != 0) continue;
+          const float tot = c + fst.weight[a];
+          if (!(tot < cutoff)) continue;
+          int32_t d = index_of_state[fst.next[a]];
+          if (d < 0) { d = (int32_t)state.size(); index_of_state[fst.next[a]] = d; state.push_back(fst.next[a]); cost.push_back(kInf); label.push_back(0xFFFFFFFFu); }
+          if (tot < cost[d]) { cost[d] = tot; if (fst.num_ieps[state[d]] != 0) nxt.push_back(d); }
+        }
+      }
+      wl.swap(nxt);
+    }
+    const size_t n = state.size();
+    // ---- closure sub-graph in token space: per source token its eps arcs, in arc order, that pass at the FINAL costs
+    // (an arc that fails at the final cost of its source fails at every earlier, higher cost of it too)
+    std::vector<int32_t> cbeg(n + 1, 0), cdst; std::vector<float> cw; std::vector<int32_t> carc;
+    for (size_t i = 0; i < n; i++) {
+      cbeg[i] = (int32_t)cdst.size();
+      if (fst.num_ieps[state[i]] == 0 || !(cost[i] < cutoff)) continue;
+      for (int32_t a = fst.off[state[i]]; a < fst.off[state[i] + 1]; a++)
+        if (fst.ilabel[a] == 0) { const bool pass = cost[i] + fst.weight[a] < cutoff; cdst.push_back(pass ? index_of_state[fst.next[a]] : -1); cw.push_back(fst.weight[a]); carc.push_back(a); }
+    }
+    cbeg[n] = (int32_t)cdst.size();
+    // ---- SER replay of the LIFO queue (:851-896) on the sub-graph: recovers only the ORDER in which the closure creates tokens
+    {
+      std::vector<float> rc(n, kInf); std::vector<char> ex(n, 0);
+      for (size_t i = 0; i < n_e; i++) { rc[i] = c0[i]; ex[i] = 1; }
+      std::vector<int32_t> stack; size_t p = n_e;         // the initial queue = order1 filtered by "has eps arcs", consumed from its back
+      for (;;) {
+        int32_t e = -1;
+        if (!stack.empty()) { e = stack.back(); stack.pop_back(); }
+        else { while (p > 0) { const int32_t i = order1[--p]; if (fst.num_ieps[state[i]] != 0) { e = i; break; } } if (e < 0) break; }
+        n_replay_pops++;
+        const float c = rc[e];
+        if (c >= cutoff) continue;
+        for (int32_t k = cbeg[e]; k < cbeg[e + 1]; k++) {
+          const int32_t d = cdst[k]; if (d < 0) continue;
+          const float tot = c + cw[k];
+          if (!(tot < cutoff)) continue;
+          bool changed = false;
+          if (!ex[d]) { ex[d] = 1; rc[d] = tot; label[d] = n_labels++; changed = true; }
+          else if (rc[d] > tot) { rc[d] = tot; changed = true; }
+          if (changed && fst.num_ieps[state[d]] != 0) { stack.push_back(d); n_replay_pushes++; }
+        }
+      }
+      for (size_t i = 0; i < n; i++) if (!ex[i] || rc[i] != cost[i]) abort();      // the replay must land on the fixpoint
+    }
+    for (size_t i = 0; i < n; i++) index_of_state[state[i]] = -1;
+    // ---- publish: final HashList order, tokens materialised in creation order (active_toks_ list = reverse creation order)
+    std::vector<int32_t> order;
+    HashOrder(state, label, &order, &by_ins);
+    std::vector<int32_t> tok(n, -1);
+    for (size_t dd = 0; dd < n; dd++) {
+      const int32_t i = by_ins[dd];
+      int32_t &head = active[frame_plus_one].head;
+      const int32_t t = NewTok(cost[i], 0.0f, head, state[i], frame_plus_one); head = t; num_toks++; tok[i] = t;
+    }
+    for (const PendingLink &k : links_in) toks[k.src_tok].links = NewLink(tok[k.dst_local], k.ilabel, k.olabel, k.graph, k.ac, toks[k.src_tok].links);
+    for (size_t i = 0; i < n; i++)
+      for (int32_t k = cbeg[i]; k < cbeg[i + 1]; k++)
+        if (cdst[k] >= 0) toks[tok[i]].links = NewLink(tok[cdst[k]], 0, fst.olabel[carc[k]], cw[k], 0.0f, toks[tok[i]].links);
+    cf.state = state; cf.cost = cost; cf.tok = tok; cf.order = order;
+  }
+
+  void Init2() {
+    active.assign(1, FrameList());
+    Nonemitting2(cfg.beam, {fst.start}, {0.0f}, {0u}, 1u, {});
+  }
+
+  float CutoffFromCosts(float best, size_t n, float *adaptive_beam) {     // the part of GetCutoff (:666-719) after the list walk; tmp = all costs
+    const bool plain = (cfg.max_active == std::numeric_limits<int32_t>::max() && cfg.min_active == 0);
+    (void)n;
+    if (plain) { *adaptive_beam = cfg.beam; return best + cfg.beam; }
+    const float beam_cutoff = best + cfg.beam; float min_active_cutoff = kInf, max_active_cutoff = kInf;
+    if (tmp.size() > (size_t)cfg.max_active) { std::nth_element(tmp.begin(), tmp.begin() + cfg.max_active, tmp.end()); max_active_cutoff = tmp[cfg.max_active]; }
+    if (max_active_cutoff < beam_cutoff) { *adaptive_beam = max_active_cutoff - best + cfg.beam_delta; return max_active_cutoff; }
+    if (tmp.size() > (size_t)cfg.min_active) {
+      if (cfg.min_active == 0) min_active_cutoff = best;
+      else {
+        std::nth_element(tmp.begin(), tmp.begin() + cfg.min_active, tmp.size() > (size_t)cfg.max_active ? tmp.begin() + cfg.max_active : tmp.end());
+        min_active_cutoff = tmp[cfg.min_active];
+      }
+    }
+    if (min_active_cutoff > beam_cutoff) { *adaptive_beam = min_active_cutoff - best + cfg.beam_delta; return min_active_cutoff; }
+    *adaptive_beam = cfg.beam; return beam_cutoff;
+  }
+
+  float Emitting2() {
+    const int32_t frame = (int32_t)active.size() - 1;
+    active.resize(active.size() + 1);
+    const size_t n = cf.state.size();
+    // GetCutoff: best token = minimum cost, the FIRST such token in list order (:661-663 strict <)
+    std::vector<int32_t> pos(n); for (size_t r = 0; r < n; r++) pos[cf.order[r]] = (int32_t)r;
+    float best = kInf; int32_t best_i = -1; tmp.clear();
+    for (int32_t i : Iota(n)) {                                                                       // PAR (min over (cost, position))
+      tmp.push_back(cf.cost[i]);
+      if (cf.cost[i] < best || (cf.cost[i] == best && best_i >= 0 && pos[i] < pos[best_i])) { if (cf.cost[i] == best) n_best_ties++; best = cf.cost[i]; best_i = i; }
+    }
+    float adaptive_beam; const float cur_cutoff = CutoffFromCosts(best, n, &adaptive_beam);
+    { const size_t want = (size_t)((float)n * cfg.hash_ratio); if (want > hash_size2) hash_size2 = want; }     // PossiblyResizeHash :227-233
+    float next0 = kInf, cost_offset = 0.0f;
+    if (best_i != -1) {
+      const int32_t s = cf.state[best_i]; const float tot = cf.cost[best_i]; cost_offset = -tot;
+      for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++)
+        if (fst.ilabel[a] != 0) { const float nw = fst.weight[a] + cost_offset - LogLike(frame, fst.ilabel[a]) + tot; if (nw + adaptive_beam < next0) next0 = nw + adaptive_beam; }
+    }
+    cost_offsets.resize(frame + 1, 0.0f); cost_offsets[frame] = cost_offset;
+    // arc sequence: tokens in list order, arcs in FST order; seq_base[r] = exclusive prefix sum of the emitting out-degrees
+    std::vector<uint32_t> seq_base(n + 1, 0);
+    for (size_t r = 0; r < n; r++) {
+      const int32_t i = cf.order[r]; uint32_t deg = 0;
+      if (cf.cost[i] <= cur_cutoff) for (int32_t a = fst.off[cf.state[i]]; a < fst.off[cf.state[i] + 1]; a++) deg += fst.ilabel[a] != 0;
+      seq_base[r + 1] = seq_base[r] + deg;
+    }
+    const uint32_t M = seq_base[n];
+    // pass A (PAR): v[j] = tot_j + adaptive_beam for every arc; the cutoff in force when arc j is examined is
+    // min(next0, min_{j' < j} v[j']) -- a rejected arc never lowers it (tot >= cutoff  =>  tot + beam >= cutoff)
+    std::vector<float> v(M), before(M);
+    auto for_arcs = [&](auto fn) {
+      for (int32_t r : Iota(n)) {
+        const int32_t i = cf.order[r]; if (!(cf.cost[i] <= cur_cutoff)) continue;
+        uint32_t j = seq_base[r];
+        for (int32_t a = fst.off[cf.state[i]]; a < fst.off[cf.state[i] + 1]; a++) if (fst.ilabel[a] != 0) fn(i, a, j++);
+      }
+    };
+    for_arcs([&](int32_t i, int32_t a, uint32_t j) {
+      const float ac = cost_offset - LogLike(frame, fst.ilabel[a]); const float tot = cf.cost[i] + ac + fst.weight[a];
+      v[j] = tot + adaptive_beam;
+    });
+    float run = next0;
+    for (uint32_t j = 0; j < M; j++) { before[j] = run; if (v[j] < run) run = v[j]; }                 // exclusive prefix-min (scan)
+    const float next_cutoff = run;
+    // pass B (PAR): accepted arcs claim their destination token: cost = min, creation label = min sequence number
+    std::vector<int32_t> nstate; std::vector<float> ncost; std::vector<uint32_t> nlabel; std::vector<PendingLink> plinks;
+    static thread_local std::vector<int32_t> index_of_state; if ((int32_t)index_of_state.size() < fst.num_states) index_of_state.assign(fst.num_states, -1);
+    for_arcs([&](int32_t i, int32_t a, uint32_t j) {
+      const float ac = cost_offset - LogLike(frame, fst.ilabel[a]), graph = fst.weight[a]; const float tot = cf.cost[i] + ac + graph;
+      if (tot >= before[j]) return;
+      if (tot >= next_cutoff) n_extra_links++;                                                        // order-sensitive event: exists only because the bound was still loose
+      int32_t d = index_of_state[fst.next[a]];
+      if (d < 0) { d = (int32_t)nstate.size(); index_of_state[fst.next[a]] = d; nstate.push_back(fst.next[a]); ncost.push_back(kInf); nlabel.push_back(0xFFFFFFFFu); }
+      if (tot < ncost[d]) ncost[d] = tot;
+      if (j < nlabel[d]) nlabel[d] = j;
+      plinks.push_back(PendingLink{cf.tok[i], d, fst.ilabel[a], fst.olabel[a], graph, ac});
+    });
+    for (int32_t s : nstate) index_of_state[s] = -1;
+    for (float c : ncost) if (c >= next_cutoff) n_extra_toks++;
+    stats.push_back(FrameStat{(int32_t)n, cur_cutoff, adaptive_beam, next_cutoff, cost_offset});
+    Nonemitting2(next_cutoff, nstate, ncost, nlabel, M, plinks);
+    return next_cutoff;
+  }
+
   // :308-379
   void PruneLinks(int32_t f, bool *extra_changed, bool *links_pruned, float delta) {
     *extra_changed = false; *links_pruned = false;
@@ -333,12 +558,13 @@ struct Decoder {
   void FinalCosts(float *rel, float *best_out) {
     final_costs.clear();
     float best = kInf, best_final = kInf;
-    for (int32_t e = cur.head; e != -1; e = cur.elems[e].tail) {
-      const int32_t s = cur.elems[e].key, t = cur.elems[e].val;
+    auto one = [&](int32_t s, int32_t t) {
       const float fc = fst.final_cost[s], cost = toks[t].tot, with_final = cost + fc;
       best = std::min(cost, best); best_final = std::min(with_final, best_final);
       if (fc != kInf) final_costs.push_back({t, fc});
-    }
+    };
+    if (mode >= 2) for (size_t i = 0; i < cf.state.size(); i++) one(cf.state[i], cf.tok[i]);
+    else for (int32_t e = cur.head; e != -1; e = cur.elems[e].tail) one(cur.elems[e].key, cur.elems[e].val);
     *rel = (best == kInf && best_final == kInf) ? kInf : best_final - best;
     *best_out = (best_final != kInf) ? best_final : best;
   }
@@ -413,6 +639,7 @@ struct Decoder {
   void Advance() {   // :588-632
     while (NumFramesDecoded() < num_frames_ready) {
       if (NumFramesDecoded() % cfg.prune_interval == 0) PruneActive(cfg.lattice_beam * cfg.prune_scale);
+      if (mode >= 2) { Emitting2(); continue; }
       const float cutoff = Emitting();
       Nonemitting(cutoff);
     }
@@ -430,7 +657,7 @@ struct Lattice {   // GetRawLattice (:114-197) output with states identified by 
   std::vector<int32_t> st_frame, st_state; std::vector<float> st_cost, st_final;   // st_final = +inf when not final
   std::vector<int32_t> arc_src, arc_dst, arc_ilabel, arc_olabel; std::vector<float> arc_graph, arc_ac;
   std::vector<FrameStat> stats; std::vector<float> cost_offsets;
-  int64_t n_extra_links, n_extra_toks, n_best_ties, n_links_created; int32_t reached_final; float final_relative_cost;
+  int64_t n_extra_links, n_extra_toks, n_best_ties, n_links_created, n_replay_pops, n_replay_pushes; int32_t reached_final; float final_relative_cost;
 };
 
 }  // namespace
@@ -451,10 +678,11 @@ void *k3o_lfd_decode(const k3o_fst *f, const float *loglikes, int32_t num_frames
   Config cfg{c->beam, c->max_active, c->min_active, c->lattice_beam, c->prune_interval, c->beam_delta, c->hash_ratio, c->prune_scale};
   Decoder d(fst, cfg, mode);
   d.loglikes = loglikes; d.ld = ld; d.tid2pdf = tid2pdf; d.num_frames_ready = num_frames;
-  d.Init(); d.Advance(); d.Finalize();
+  if (mode >= 2) d.Init2(); else d.Init();
+  d.Advance(); d.Finalize();
   Lattice *L = new Lattice();
   L->stats = d.stats; L->cost_offsets = d.cost_offsets;
-  L->n_extra_links = d.n_extra_links; L->n_extra_toks = d.n_extra_toks; L->n_best_ties = d.n_best_ties; L->n_links_created = d.n_links_created;
+  L->n_extra_links = d.n_extra_links; L->n_extra_toks = d.n_extra_toks; L->n_best_ties = d.n_best_ties; L->n_links_created = d.n_links_created; L->n_replay_pops = d.n_replay_pops; L->n_replay_pushes = d.n_replay_pushes;
   L->reached_final = (d.final_relative_cost != kInf) ? 1 : 0;   // ReachedFinal(): FinalRelativeCost() != inf
   L->final_relative_cost = d.final_relative_cost;
   const int32_t T = d.NumFramesDecoded();
@@ -485,10 +713,10 @@ void *k3o_lfd_decode(const k3o_fst *f, const float *loglikes, int32_t num_frames
   return L;
 }
 
-void k3o_lfd_sizes(const void *h, int64_t *out /* [8] */) {
+void k3o_lfd_sizes(const void *h, int64_t *out /* [10] */) {
   const Lattice *L = (const Lattice *)h;
   out[0] = (int64_t)L->st_frame.size(); out[1] = (int64_t)L->arc_src.size(); out[2] = (int64_t)L->stats.size();
-  out[3] = L->n_extra_links; out[4] = L->n_extra_toks; out[5] = L->n_best_ties; out[6] = L->reached_final; out[7] = L->n_links_created;
+  out[3] = L->n_extra_links; out[4] = L->n_extra_toks; out[5] = L->n_best_ties; out[6] = L->reached_final; out[7] = L->n_links_created; out[8] = L->n_replay_pops; out[9] = L->n_replay_pushes;
 }
 void k3o_lfd_states(const void *h, int32_t *frame, int32_t *state, float *cost, float *final_cost) {
   const Lattice *L = (const Lattice *)h; const size_t n = L->st_frame.size();

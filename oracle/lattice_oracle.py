@@ -41,7 +41,7 @@ def decode(fst, loglikes, tid2pdf, cfg=None, mode=0):
              fst.weight.ctypes.data, fst.final.ctypes.data)
     h = ctypes.c_void_p(L.k3o_lfd_decode(ctypes.byref(f), ll.ctypes.data, ll.shape[0], ll.shape[1], t2p.ctypes.data, ctypes.byref(cfg), mode))
     try:
-        sz = np.zeros(8, np.int64); L.k3o_lfd_sizes(h, sz.ctypes.data_as(ctypes.c_void_p))
+        sz = np.zeros(10, np.int64); L.k3o_lfd_sizes(h, sz.ctypes.data_as(ctypes.c_void_p))
         ns, na, nf = int(sz[0]), int(sz[1]), int(sz[2])
         fr, st = np.zeros(ns, np.int32), np.zeros(ns, np.int32); co, fc = np.zeros(ns, np.float32), np.zeros(ns, np.float32)
         L.k3o_lfd_states(h, fr.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p), co.ctypes.data_as(ctypes.c_void_p), fc.ctypes.data_as(ctypes.c_void_p))
@@ -52,6 +52,8 @@ def decode(fst, loglikes, tid2pdf, cfg=None, mode=0):
     finally:
         L.k3o_lfd_free(h)
     lat = RawLattice(fr, st, fc, a[0], a[1], a[2], a[3], a[4], a[5], fst.start, st_cost=co)
-    info = dict(extra_links=int(sz[3]), extra_toks=int(sz[4]), best_ties=int(sz[5]), reached_final=bool(sz[6]), links_created=int(sz[7]),
+    # order_sensitive_events: forward links (extra_links) / tokens (extra_toks) the literal algorithm created only because
+    # next_cutoff was still loose when their arc was examined (tot >= the frame's final next_cutoff); 0 by construction in mode 1
+    info = dict(order_sensitive_events=int(sz[3]) + int(sz[4]), replay_pops=int(sz[8]), replay_pushes=int(sz[9]), extra_links=int(sz[3]), extra_toks=int(sz[4]), best_ties=int(sz[5]), reached_final=bool(sz[6]), links_created=int(sz[7]),
                 ntoks=nt, cur_cutoff=fs[0], adaptive_beam=fs[1], next_cutoff=fs[2], cost_offset=fs[3])
     return lat, info

@@ -69,3 +69,17 @@ def test_streaming_and_cmvn_programs_usage_and_option_errors():
     r = _run(cm, "a"); assert r.returncode == 1 and "Usage: apply-cmvn-online-cuda" in r.stderr
     r = _run(cm, "--skip-dims=1:x", "a", "b", "c"); assert r.returncode == 255 and "skip-dims" in r.stderr
     r = _run(cm, "--help"); assert r.returncode == 0 and "--cmn-window" in r.stderr and "--spk2utt" in r.stderr
+
+
+def test_command_line_options_win_over_config_files_whatever_their_order(tmp_path):
+    """util/parse-options.cc:329-371: every --config file is read in a first pass, the command line is applied afterwards"""
+    tool = os.path.join(BIN, "k3-host-tool"); c1 = str(tmp_path / "a.conf"); c2 = str(tmp_path / "b.conf")
+    open(c1, "w").write("# recipe defaults\n--beam=3.0\n--max-active=100 # trailing comment\n--flag=true\n")
+    open(c2, "w").write("--name=from_b\n--beam=4.5\n")
+    out = lambda *a: _run(tool, "parse-options", "--print-args=false", *a).stdout.strip()
+    assert out("--beam=100", "--config=" + c1) == "beam=100 max-active=100 flag=true name=dflt nargs=0"
+    assert out("--config=" + c1, "--beam=100") == "beam=100 max-active=100 flag=true name=dflt nargs=0"
+    assert out("--config=" + c1, "--config=" + c2, "--flag=false", "x", "y") == "beam=4.5 max-active=100 flag=false name=from_b nargs=2"
+    assert out("--name=cli", "--config=" + c2, "--", "--beam=1") == "beam=4.5 max-active=7 flag=false name=cli nargs=1"
+    bad = str(tmp_path / "bad.conf"); open(bad, "w").write("--no-such-option=1\n")
+    assert _run(tool, "parse-options", "--config=" + bad).returncode != 0

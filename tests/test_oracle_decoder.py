@@ -182,3 +182,38 @@ def test_random_configurations_against_the_reference_decoder():
         cfg = lo.Config(**kw)
         ref = rd.decode(f, ll, synth.tid2pdf(N), cfg); lat, info = lo.decode(f, ll, synth.tid2pdf(N), cfg, 0)
         assert ref["reached_final"] == info["reached_final"] and lsig.canonical_of_reference(ref) == lsig.canonical_of_raw(lat), (it, kw, ref["frame"].size, lat.num_states)
+
+
+# ---- the literal algorithm in the phase structure of the GPU kernel (mode 2) and with every parallel phase shuffled (mode 3) --------
+def _same_run(f, ll, t2p, cfg, modes=(2, 3)):
+    l0, i0 = lo.decode(f, ll, t2p, cfg, 0)
+    for m in modes:
+        l, i = lo.decode(f, ll, t2p, cfg, m)
+        for k in ("ntoks", "cur_cutoff", "adaptive_beam", "next_cutoff", "cost_offset"):
+            assert np.array_equal(np.asarray(i0[k]).view(np.int32), np.asarray(i[k]).view(np.int32)), (m, k)
+        assert l.diff(l0) == "" and i["order_sensitive_events"] == i0["order_sensitive_events"] and i["reached_final"] == i0["reached_final"], m
+    return i0
+
+@pytest.mark.parametrize("name", sorted(n for n in dcases.CASES if n != "bench_config"))
+def test_phase_parallel_literal_mode_equals_the_serial_literal_mode(name):
+    """HashList visit order from (bucket first-occupation, insertion) ranks, acceptance by exclusive prefix-min over the arc sequence,
+    creation times by min over accepted arc numbers, eps closure = order-free fixpoint + replay of the LIFO queue for the creation
+    ORDER only: bit-identical lattices, per-frame cutoffs and order-sensitive-event counts to the serial algorithm (which the
+    reference-decoder tests above pin to the reference's own source).  This is the algorithm k3_decoder_config.literal_order runs."""
+    f, t2p, ll, kw = dcases.make(name)
+    i0 = _same_run(f, ll, t2p, lo.Config(**kw))
+    if name != "min_active_loosens": assert i0["order_sensitive_events"] > 0
+
+def test_phase_parallel_literal_mode_random_configurations():
+    """fuzz incl. cost grids that force exact ties (best-token ties, equal-cost arcs): 10 here, an 80-configuration run found none"""
+    rng = np.random.default_rng(5)
+    for it in range(10):
+        N = int(rng.choice([20, 40, 80])); S = int(rng.choice([300, 1500, 6000])); A = int(S * rng.uniform(2.0, 3.5)); T = int(rng.integers(1, 50))
+        f = synth.make_hclg(S, A, N, seed=int(rng.integers(0, 1 << 30)), start_degree=int(rng.choice([5, 30, 200])))
+        ll = (rng.standard_normal((T, N)) * float(rng.choice([1.0, 2.5, 5.0]))).astype(np.float32)
+        if it % 3 == 0: ll = np.round(ll * 2) / 2; f.weight[:] = np.round(f.weight * 4) / 4
+        kw = dict(beam=float(rng.choice([4.0, 8.0, 15.0])), lattice_beam=float(rng.choice([1.0, 4.0, 8.0])), beam_delta=float(rng.choice([0.5, 0.1])), hash_ratio=float(rng.choice([2.0, 1.0, 3.7])))
+        if rng.random() < 0.5: kw["max_active"] = int(rng.choice([50, 200, 1000]))
+        if rng.random() < 0.5: kw["min_active"] = int(rng.choice([0, 20]))
+        if "max_active" in kw and kw.get("min_active", 200) >= kw["max_active"]: kw["min_active"] = max(0, kw["max_active"] - 1)      # LatticeFasterDecoderConfig::Check(): min_active <= max_active
+        _same_run(f, ll, synth.tid2pdf(N), lo.Config(**kw))
