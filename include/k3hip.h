@@ -158,6 +158,15 @@ typedef struct k3_decoder_config {
   int32_t frame_cands_cap;    /* max emitting arcs that pass the pre-pass bound on one frame */
   int64_t lane_tokens_cap;    /* tokens of all frames of one lane */
   int64_t lane_links_cap;     /* forward links of all frames of one lane */
+  /* literal_order = 1: reproduce the reference's SERIAL algorithm bit for bit -- next_cutoff tightened while the previous frame's tokens are
+   * visited in HashList order (lattice-faster-decoder.cc:779-797, util/hash-list-inl.h:125-165), the first minimum-cost token of that list as
+   * the best token, PruneForwardLinksFinal's in-place sweeps with its 1e-5 stop rule (:385-467).  The raw lattice then equals
+   * LatticeFasterDecoder::GetRawLattice exactly (states, arcs, labels, cost bits); token passing costs about 2-3x the default mode, which
+   * applies the frame's FINAL bound to every arc (order-independent, a sub-lattice with the same best path).  hash_ratio =
+   * LatticeFasterDecoderConfig::hash_ratio (2.0): it decides the bucket count and with it the reference's visit order.
+   * Needs frame_tokens_cap <= 65536 < frame_cands_cap. */
+  int32_t literal_order;      /* 0 */
+  float hash_ratio;           /* 2.0 */
 } k3_decoder_config;
 void k3_decoder_config_default(k3_decoder_config *cfg);
 typedef struct k3_decoder k3_decoder;
@@ -190,6 +199,10 @@ int32_t k3_decoder_num_frames_decoded(const k3_decoder *dec, int32_t utt);     /
  * [6] max tokens on one frame, [7] emitting arcs traversed, [8] epsilon arcs traversed, [9] frames.
  * h_info: [num_utts x 10] int64. */
 int k3_decoder_lattice_info(k3_decoder *dec, int64_t *h_info);
+/* SURVEY 9.1 "order-sensitive events", per finalised utterance (same order as k3_decoder_lattice_info).  literal_order: forward links that exist
+ * only because next_cutoff was still loose when their arc was examined (tot >= the frame's final next_cutoff); default mode: emitting arcs below
+ * the pre-pass bound but not below the final bound (an upper bound on the arcs the serial and the two-pass rule can disagree on). */
+int k3_decoder_order_sensitive_events(k3_decoder *dec, int64_t *h_events);
 /* GetRawLattice for every utterance of the last batch, concatenated in utterance order (utterance u owns
  * states h_state_offsets[u]..[u+1] and arcs h_arc_offsets[u]..[u+1]; arc endpoints are indices local to the
  * utterance).  All output pointers are HOST buffers sized from k3_decoder_lattice_info.

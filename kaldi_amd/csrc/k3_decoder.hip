@@ -65,6 +65,11 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
   int live_overflow;                      // the survivor lists were too small: the output kernel rescans the pools
   long long cur_base; int n_cur;          // resume point of AdvanceDecoding: first token / token count of the newest frame
   float final_best_cost; int final_empty;
+  // SURVEY 9.1 "order-sensitive events".  literal_order: forward links the serial algorithm creates only because next_cutoff was still loose when
+  // their arc was examined (tot >= the frame's final next_cutoff) -- the oracle's extra_links.  Default (two-pass) mode: emitting arcs below the
+  // pre-pass bound but not below the final bound, an upper bound on the arcs the two rules can disagree on.
+  long long n_order_sensitive;
+  int hash_size, order_sel;               // literal_order: HashList bucket count (PossiblyResizeHash) and which half of lt_order holds the newest frame, carried across AdvanceDecoding calls
 };
 
 #ifdef K3_DEC_PROF
@@ -105,6 +110,18 @@ struct DecParams {
   long long fstride; long long *tok_off; long long *link_off_e, *link_off_n;
   int *st_ntoks; float *st_cur, *st_ab, *st_next, *st_co;
   LaneInfo *info;
+  // literal_order scratch (k3_decoder_literal.h), per lane
+  int literal; float hash_ratio; int hash_cap, seq_words_cap, eps_cap, stack_cap;
+  int *lt_order;          // [2 x frame_tokens_cap] HashList order of the current / the next frame (local token indices)
+  int *lt_by_ins;         // [frame_tokens_cap] tokens of the newest frame in creation order (the final-frame sweeps walk it backwards)
+  unsigned *lt_label;     // [frame_tokens_cap] creation label of a token being built (all 0xFFFFFFFF between frames)
+  int *lt_dense, *lt_grp; unsigned *lt_lead;            // [frame_tokens_cap (+1)]
+  unsigned *lt_bm, *lt_wpre;                             // [seq_words_cap] label bitmap (all 0 between uses) / word prefix counts
+  unsigned *lt_bfirst, *lt_bcnt, *lt_bfill;              // [hash_cap] per bucket: first dense rank (0xFFFFFFFF), members, fill cursor (0)
+  unsigned *lt_cmin; int *lt_ccnt;                       // [frame_tokens_cap / 64 + 2] per 64-token chunk: min (tot + adaptive_beam), emitting arcs
+  float *lt_c0;                                          // [frame_tokens_cap] token costs right after ProcessEmitting
+  int2 *lt_crng; int *lt_cdst; float *lt_cw;             // closure sub-graph in token space: per token (first, count), per eps arc (dst token | -1, weight)
+  float *lt_rcost; int *lt_rflag, *lt_rown, *lt_stack;   // replay state (global copies; small frames use LDS)
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -119,7 +136,7 @@ struct Shared {
   int redi[kWaves];
   int hist[256];
   int n_next, n_cand, n_wl[3], err_r[4], err, sel_digit, sel_k, flag;      // n_wl / err_r rotate over the eps rounds (one barrier per round)
-  unsigned long long n_eps, n_emit;
+  unsigned long long n_eps, n_emit, n_os;
   unsigned min_tot;
   long long n_link;
   unsigned long long bcast64;
@@ -363,6 +380,7 @@ __device__ __forceinline__ unsigned block_select_kth(ForKeys &&for_keys, int k, 
 // ---- epsilon closure + eps links + frame finalisation for the frame being built (tokens [nb, nb + n_next)) ----
 // ProcessNonemitting (lattice-faster-decoder.cc:830-897): relax eps arcs until no cost changes, with tot < cutoff;
 // the links a token ends up with are exactly its eps arcs with cur + graph < cutoff at its final cost.
+template <bool kPublish = true>
 __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, const Table &tb, float cutoff, long long nb, int *tok_state, unsigned *tok_cost,
                                              Link *links, int *link_arc, int *tok_slot, int *wl, unsigned short (*lwl)[kWlLds], unsigned (&creg)[kCurRegs], int (&sreg)[kCurRegs],
                                              long long &t_last__, unsigned &cnt_eps) {
@@ -463,6 +481,7 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
   }
   if (block_err(sh)) return;
   K3_T(9);
+  if (!kPublish) return;      // literal_order publishes the frame itself (it still needs the table)
   // final costs into the pool, clear the table
   {
     const int n = sh.n_next;
@@ -515,13 +534,13 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   const float kInf = __builtin_inff();
 
   if (tid < 16) sh.prof[tid] = 0;
-  if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; }
+  if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; sh.n_os = 0; }
   for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; s_ltok[i] = -1; }
   for (int i = tid; i < 3 * (kHL / 32); i += kBlock) s_lmark[i] = 0;
   const Table tb{s_lkey, s_lcost, s_ltok, s_lmark, hash, mask};
   __syncthreads();
   long long t_last__ = (long long)__builtin_readcyclecounter();
-  unsigned cnt_eps = 0, cnt_emit = 0;      // per-thread arc counters (reduced once at the end of the kernel)
+  unsigned cnt_eps = 0, cnt_emit = 0, cnt_os = 0;      // per-thread arc counters (reduced once at the end of the kernel)
   long long cur_base = 0; int n_cur = 0, max_frame = 0, f0 = 0, status = kStOk;
   unsigned creg[kCurRegs]; int sreg[kCurRegs]; bool in_regs = false;      // (cost, state) of current-frame token tid + k * kBlock
 #pragma unroll
@@ -549,7 +568,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     const LaneInfo &li = p.info[L];
     if (li.status != kStOk) return;
     f0 = li.num_frames; cur_base = li.cur_base; n_cur = li.n_cur; max_frame = li.max_frame_tokens;
-    if (tid == 0) { sh.n_link = li.n_links; sh.n_eps = (unsigned long long)li.n_eps; sh.n_emit = (unsigned long long)li.n_cands; }
+    if (tid == 0) { sh.n_link = li.n_links; sh.n_eps = (unsigned long long)li.n_eps; sh.n_emit = (unsigned long long)li.n_cands; sh.n_os = (unsigned long long)li.n_order_sensitive; }
     __syncthreads();
   }
 
@@ -695,6 +714,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       { const int jn = j + kBlock; if (jn < n_cand) { q_tot = c_tot[jn]; q_nxt = c_dst[jn]; q_a = c_arc[jn]; q_s = c_src[jn]; q_c = c_ac[jn]; } }
       if (row_pending) { fetch_row(); row_pending = false; }
       if (j < n_cand) {
+        cnt_os += !(tot < accept);
         if (tot < accept) {
           slot = tb.claim(state, &claimed);
           if (slot < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; } else { tb.cost_min(slot, enc(tot)); mk = true; }
@@ -742,7 +762,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     if (tid == 0 && f >= 0) { const long long now__ = (long long)__builtin_readcyclecounter(); st_ab[f] = (float)(now__ - t_frame__); t_frame__ = now__; }   // profiling builds only: FrameStats' adaptive_beam column = cycles of the frame
 #endif
   }
-  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit); if (lane == 0) { atomicAdd(&sh.n_eps, a); atomicAdd(&sh.n_emit, b); } }
+  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { atomicAdd(&sh.n_eps, a); atomicAdd(&sh.n_emit, b); atomicAdd(&sh.n_os, c); } }
   __syncthreads();
 #ifdef K3_DEC_PROF
   if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
@@ -751,7 +771,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     LaneInfo &li = p.info[L];
     li.n_tokens = cur_base + n_cur; li.n_links = sh.n_link; li.n_cands = (long long)sh.n_emit; li.n_eps = (long long)sh.n_eps; li.max_frame_tokens = max_frame;
     li.status = sh.err ? sh.err : status; li.num_frames = f0 + T; li.reached_final = 0; li.out_states = 0; li.out_arcs = 0;
-    li.cur_base = cur_base; li.n_cur = n_cur;
+    li.cur_base = cur_base; li.n_cur = n_cur; li.n_order_sensitive = (long long)sh.n_os;
   }
 }
 
@@ -771,6 +791,8 @@ __device__ __forceinline__ bool eps_link_live(const Link &k, unsigned src_cost_e
 #define K3_PCAP 3072
 #endif
 constexpr int kPCap = K3_PCAP;      // frames with at most this many tokens are pruned entirely inside LDS
+
+#include "k3_decoder_literal.h"
 
 __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p) {
   __shared__ int s_changed, s_has_final, s_chg[4];
@@ -815,6 +837,25 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
   if (tid == 0) { li.reached_final = s_has_final; li.final_best_cost = final_best; li.final_empty = final_empty; }
   for (long long t = tb + tid; t < te; t += kPBlock) extra[t] = 0.0f;        // tokens on the last frame start with extra_cost 0
   __syncthreads();
+  if (p.literal) {
+    // literal_order: the reference's in-place sweeps in token-list order with its 1e-5 stop rule (k3_decoder_literal.h)
+    const long long l0 = loff_n[T], l1 = loff_e[T];
+    __shared__ int s_lit_err, s_lit_m, s_lit_redi[kPBlock / 64];
+    if (tid == 0) s_lit_err = 0;
+    __syncthreads();
+    lit_final_frame(p, L, tb, te, l0, l1, final_best, final_empty, tok_state, tok_cost, extra, links, &s_lit_err,
+                    s_cost[0], s_extra[0], s_xb, reinterpret_cast<int *>(s_cost[1]), s_extra[1], s_lit_redi, &s_lit_m);
+    __syncthreads();
+    if (s_lit_err) { if (tid == 0) li.status = s_lit_err; return; }
+    const int m = s_lit_m; const long long fc = p.frame_cands_cap;
+    const unsigned *g_off = reinterpret_cast<const unsigned *>(p.c_dst + L * fc); const int *lid = p.c_arc + L * fc; const int *g_ldst = p.wl + 2ll * L * p.frame_tokens_cap;
+    for (long long t = tb + tid; t < te; t += kPBlock) if (extra[t] != kInf) keep_tok(t);
+    for (long long t = tb + tid; t < te; t += kPBlock) {
+      if (extra[t] == kInf) continue;
+      for (unsigned j = g_off[t - tb]; j < g_off[t - tb + 1]; j++) if (g_ldst[j] < 0) keep_link(l0 + lid[j]);
+    }
+    (void)m;
+  } else
   {
     const long long l0 = loff_n[T], l1 = loff_e[T];
     // Jacobi sweeps: xn <- base, atomicMin over the surviving eps links evaluated at the previous sweep's extras (xn lives in
@@ -1243,6 +1284,7 @@ extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
   if (!c) return;
   c->beam = 16.0f; c->max_active = std::numeric_limits<int32_t>::max(); c->min_active = 200; c->lattice_beam = 10.0f; c->beam_delta = 0.5f;
   c->frame_tokens_cap = 32768; c->frame_cands_cap = 65536; c->lane_tokens_cap = 2000000; c->lane_links_cap = 4000000;
+  c->literal_order = 0; c->hash_ratio = 2.0f;
 }
 
 template <typename T> static int dmalloc(std::vector<void *> *allocs, T **ptr, size_t n) {
@@ -1293,6 +1335,43 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   p.live_cap = (int)std::min<long long>(cfg->lane_tokens_cap, 1 << 18);
   if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.live_link, nl * p.live_cap))) return rc;
+  p.literal = cfg->literal_order ? 1 : 0; p.hash_ratio = cfg->hash_ratio;
+  if (p.literal) {
+    K3_REQUIRE(cfg->hash_ratio > 0.0f && cfg->hash_ratio <= 64.0f, "k3_decoder_create: literal_order needs 0 < hash_ratio <= 64 (LatticeFasterDecoderConfig::hash_ratio)");
+    K3_REQUIRE(cfg->frame_tokens_cap <= 65536 && cfg->frame_cands_cap > cfg->frame_tokens_cap, "k3_decoder_create: literal_order needs frame_tokens_cap <= 65536 < frame_cands_cap");
+    const size_t cap = (size_t)cfg->frame_tokens_cap, nch = cap / 64 + 2;
+    p.hash_cap = (int)std::max<double>(1000.0, std::ceil((double)cap * cfg->hash_ratio) + 1.0);
+    p.seq_words_cap = (int)((8 * (size_t)cfg->frame_cands_cap + cap) / 32 + 64);      // labels: emitting arcs expanded on a frame + tokens its closure creates
+    p.eps_cap = cfg->frame_cands_cap; p.stack_cap = 4 * cfg->frame_tokens_cap;
+    if ((rc = dmalloc(&d->allocs, &p.lt_order, 2 * nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_by_ins, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_label, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_dense, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_grp, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_lead, nl * (cap + 1)))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_bm, nl * p.seq_words_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_wpre, nl * p.seq_words_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_bfirst, nl * p.hash_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_bcnt, nl * p.hash_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_bfill, nl * p.hash_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_cmin, 2 * nl * nch))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_ccnt, 2 * nl * nch))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_c0, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_crng, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_cdst, nl * p.eps_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_cw, nl * p.eps_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_rcost, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_rflag, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_rown, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_stack, nl * p.stack_cap))) return rc;
+    // idle patterns of the scratch: labels / bucket firsts all ones, bitmap / bucket counters zero
+    K3_HIP_CHECK(hipMemset(p.lt_label, 0xFF, nl * cap * sizeof(unsigned)));
+    K3_HIP_CHECK(hipMemset(p.lt_bm, 0, nl * p.seq_words_cap * sizeof(unsigned)));
+    K3_HIP_CHECK(hipMemset(p.lt_bfirst, 0xFF, nl * p.hash_cap * sizeof(unsigned)));
+    K3_HIP_CHECK(hipMemset(p.lt_bcnt, 0, nl * p.hash_cap * sizeof(unsigned)));
+    K3_HIP_CHECK(hipMemset(p.lt_bfill, 0, nl * p.hash_cap * sizeof(unsigned)));
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitDynLds));
+  }
   // empty table: key = -1, cost = max, tok = -1, stamp = 0
   std::vector<Slot> init((size_t)hs, Slot{kEmpty, kEncMax, -1, 0});
   for (int l = 0; l < nlanes; l++) K3_HIP_CHECK(hipMemcpy(p.hash + (size_t)l * hs, init.data(), sizeof(Slot) * hs, hipMemcpyHostToDevice));
@@ -1373,7 +1452,8 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off; p.fresh = d->d_fresh; p.lane_ids = nullptr;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
-  hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
+  if (p.literal) hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(num_utts), dim3(kBlock), kLitDynLds, st, p);
+  else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
   d->started = true; d->last_stream = st; d->info_valid = false;
@@ -1450,6 +1530,13 @@ extern "C" int k3_decoder_lattice_info(k3_decoder *d, int64_t *h_info) {
                                                           u, li.status, li.status == K3_ERR_OVERFLOW ? "capacity overflow" : "internal error", li.n_tokens, li.n_links, li.max_frame_tokens); }
   }
   return worst;
+}
+
+extern "C" int k3_decoder_order_sensitive_events(k3_decoder *d, int64_t *h_events) {
+  K3_REQUIRE(d && h_events, "k3_decoder_order_sensitive_events: null argument");
+  { const int rc = fetch_info(d); if (rc) return rc; }
+  for (size_t k = 0; k < d->sel.size(); k++) h_events[k] = d->h_info[d->sel[k]].n_order_sensitive;
+  return K3_OK;
 }
 
 extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int32_t *st_state, float *st_cost, float *st_final, int32_t *arc_src, int32_t *arc_dst,

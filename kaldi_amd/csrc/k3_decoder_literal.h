@@ -1,0 +1,518 @@
+// k3_decoder_literal.h -- token passing that reproduces LatticeFasterDecoder's SERIAL algorithm bit for bit (k3_decoder_config.literal_order).
+// Included by k3_decoder.hip inside its anonymous namespace (shares DecParams, Table, Shared, the wave helpers and finish_frame).
+//
+// The reference walks the previous frame's tokens in HashList order and tightens next_cutoff while it goes
+// (decoder/lattice-faster-decoder.cc:779-797), so which arcs it accepts depends on that order, and the order depends on the order in which
+// tokens were inserted into the hash (util/hash-list-inl.h:125-165), including the LIFO order of ProcessNonemitting's queue (:845-896).
+// The default kernel applies the frame's FINAL bound instead (order-free, a sub-lattice).  This kernel computes the serial result without a
+// serial walk; the phase structure is the one oracle/lattice_faster_oracle.cc proves equal to the serial code (its modes 2 / 3):
+//   * visit order      = tokens sorted by (creation rank of their bucket's first occupant, own creation rank), bucket = state % hash_size
+//                        (PossiblyResizeHash :227-233 tracked per lane): dense creation ranks by a bitmap prefix count, per-bucket first /
+//                        count by atomics, a prefix sum over the bucket leaders -- no key sort;
+//   * acceptance       = tot < min(pre-pass bound, min over EARLIER arcs of (tot + adaptive_beam)): a rejected arc never lowers the bound
+//                        (tot >= bound => tot + beam >= bound), so the bound in force at arc j is an exclusive prefix-min over the arc sequence
+//                        (tokens in visit order, arcs in FST order): per 64-token chunk minima, a scan over the chunks, a wave scan inside;
+//   * creation time    = min sequence number over the accepted arcs into a state (atomicMin);
+//   * eps closure      = the order-free fixpoint of the default kernel (costs, tokens, links), then a REPLAY of the LIFO queue by one
+//                        wavefront on the closure sub-graph in token space, which only recovers the order in which tokens are created;
+//   * final frame      = PruneForwardLinksFinal's in-place sweeps in token-list order with its 1e-5 ApproxEqual stop rule (:385-467), emulated
+//                        token by token (k3_decode_prune_kernel, literal branch).
+// Capacities: frame_tokens_cap <= 65536; arcs expanded + tokens created on one frame <= 32 * seq_words_cap.
+
+constexpr int kRN = 2048, kRA = 2048, kRS = 4096;
+constexpr size_t kLitDynLds = (size_t)kRN * 16 + (size_t)kRA * 8 + (size_t)kRS * 4;      // replay in LDS: tokens / closure arcs / stack entries of a frame (larger frames: HBM scratch)
+constexpr unsigned kLabelNone = 0xFFFFFFFFu;
+enum { kRfHasEps = 1, kRfExists = 2 };
+
+// exclusive prefix sum over n values produced by in(i), written to out[i]; returns the total.  All threads of the block call it.
+template <typename In>
+__device__ __forceinline__ int block_excl_scan(In &&in, unsigned *out, int n, int *redi) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)blockDim.x >> 6;
+  int carry = 0;
+  for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
+    const int i = i0 + tid; const int x = i < n ? (int)in(i) : 0;
+    int incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) redi[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < nw; w++) { const int s = redi[w]; if (w < wave) woff += s; tot += s; }
+    if (i < n) out[i] = (unsigned)(carry + woff + incl - x);
+    carry += tot;
+  }
+  __syncthreads();
+  return carry;
+}
+
+// wave_expand with the arc's position j in the wave's arc sequence (owner lanes in order, arcs of an owner in FST order); returns the number of arcs
+template <typename F>
+__device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int deg, F &&f) {
+  const int lane = threadIdx.x & 63;
+  int incl = deg;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int total = __shfl(incl, 63);
+  const int excl = incl - deg;
+  for (int j0 = 0; j0 < total; j0 += 64) {
+    const int j = j0 + lane;
+    int lo = 0, hi = 63;
+#pragma unroll
+    for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; const int v = __shfl(incl, mid); if (v > j) hi = mid; else lo = mid + 1; }
+    lo = lo > 63 ? 63 : lo;
+    const int obeg = __shfl(beg, lo), oexcl = __shfl(excl, lo);
+    const int a = obeg + (j - oexcl); ArcRec r{};
+    if (j < total) r = arcs[a];
+    f(j < total, j, a, lo, r);
+  }
+  return total;
+}
+
+struct LitLane {      // this lane's slices of the literal_order scratch
+  int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *bfirst, *bcnt, *bfill, *cmin; float *c0, *cw, *rcost; int2 *crng;
+  __device__ LitLane(const DecParams &p, int L) {
+    const long long cap = p.frame_tokens_cap, nch = cap / 64 + 2;
+    order[0] = p.lt_order + 2ll * L * cap; order[1] = order[0] + cap; by_ins = p.lt_by_ins + L * cap; dense = p.lt_dense + L * cap; grp = p.lt_grp + L * cap;
+    label = p.lt_label + L * cap; lead = p.lt_lead + L * (cap + 1); bm = p.lt_bm + (long long)L * p.seq_words_cap; wpre = p.lt_wpre + (long long)L * p.seq_words_cap;
+    bfirst = p.lt_bfirst + (long long)L * p.hash_cap; bcnt = p.lt_bcnt + (long long)L * p.hash_cap; bfill = p.lt_bfill + (long long)L * p.hash_cap;
+    cmin = p.lt_cmin + 2ll * L * nch; ccnt = p.lt_ccnt + 2ll * L * nch; c0 = p.lt_c0 + L * cap; crng = p.lt_crng + L * cap;
+    cdst = p.lt_cdst + (long long)L * p.eps_cap; cw = p.lt_cw + (long long)L * p.eps_cap; rcost = p.lt_rcost + L * cap; rflag = p.lt_rflag + L * cap; rown = p.lt_rown + L * cap;
+    stack = p.lt_stack + (long long)L * p.stack_cap;
+  }
+};
+
+// HashList order of n tokens with unique creation labels < M: order_out[position] = token.  by_ins[d] = token with creation rank d.
+__device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out) {
+  const int tid = threadIdx.x;
+  const int W = (int)((M + 31u) >> 5);
+  for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); atomicOr(&q.bm[l >> 5], 1u << (l & 31)); }
+  __syncthreads();
+  block_excl_scan([&](int w) { return __popc(K3_ALD(&q.bm[w])); }, q.wpre, W, sh.redi);
+  for (int i = tid; i < n; i += kBlock) {
+    const unsigned l = K3_ALD(&q.label[i]); const unsigned wd = K3_ALD(&q.bm[l >> 5]);
+    const int d = (int)(q.wpre[l >> 5] + (unsigned)__popc(wd & ((1u << (l & 31)) - 1u)));
+    q.dense[i] = d; q.by_ins[d] = i;
+    const unsigned b = (unsigned)st[i] % hash_size; atomicMin(&q.bfirst[b], (unsigned)d); atomicAdd(&q.bcnt[b], 1u);
+  }
+  __syncthreads();
+  block_excl_scan([&](int d) { const unsigned b = (unsigned)st[q.by_ins[d]] % hash_size; return K3_ALD(&q.bfirst[b]) == (unsigned)d ? K3_ALD(&q.bcnt[b]) : 0u; }, q.lead, n, sh.redi);
+  for (int i = tid; i < n; i += kBlock) {
+    const unsigned b = (unsigned)st[i] % hash_size;
+    if (K3_ALD(&q.bcnt[b]) > 1u) { const unsigned lp = q.lead[K3_ALD(&q.bfirst[b])]; const unsigned s = atomicAdd(&q.bfill[b], 1u); q.grp[lp + s] = q.dense[i]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kBlock) {
+    const unsigned b = (unsigned)st[i] % hash_size; const unsigned cnt = K3_ALD(&q.bcnt[b]), lp = q.lead[K3_ALD(&q.bfirst[b])];
+    unsigned rank = 0;
+    if (cnt > 1u) { const int d = q.dense[i]; for (unsigned k = 0; k < cnt; k++) rank += q.grp[lp + k] < d; }
+    order_out[lp + rank] = i;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kBlock) {      // scratch back to its idle pattern
+    const unsigned l = K3_ALD(&q.label[i]); const unsigned b = (unsigned)st[i] % hash_size;
+    K3_AST(&q.bm[l >> 5], 0u); K3_AST(&q.bfirst[b], kLabelNone); K3_AST(&q.bcnt[b], 0u); K3_AST(&q.bfill[b], 0u);
+  }
+  __syncthreads();
+}
+
+struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
+
+__global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(DecParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];       // replay arrays of a small frame
+  __shared__ Shared sh; __shared__ LitShared ls;
+  __shared__ int s_lkey[kHL]; __shared__ unsigned s_lcost[kHL]; __shared__ int s_ltok[kHL]; __shared__ unsigned s_lmark[3 * (kHL / 32)];
+  __shared__ unsigned short s_lwl[2][kWlLds];
+  __shared__ int s_own[1024];      // replay: which lane of the batch targets a token (binned; a false clash only takes the one-by-one path)
+  const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
+  const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
+  int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
+  Link *links = p.links + (long long)L * p.lane_links_cap; int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
+  Slot *hash = p.hash + (long long)L * (p.hash_mask + 1);
+  int *tok_slot = p.tok_slot + (long long)L * p.frame_tokens_cap, *wl = p.wl + 2ll * L * p.frame_tokens_cap;
+  long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
+  int *st_ntoks = p.st_ntoks + L * p.fstride; float *st_cur = p.st_cur + L * p.fstride, *st_ab = p.st_ab + L * p.fstride, *st_next = p.st_next + L * p.fstride, *st_co = p.st_co + L * p.fstride;
+  const unsigned mask = (unsigned)p.hash_mask; const float kInf = __builtin_inff(); const int cap = p.frame_tokens_cap;
+  const LitLane q(p, L);
+  // replay arrays in LDS
+  float *l_rcost = reinterpret_cast<float *>(smem_raw); int *l_rflag = reinterpret_cast<int *>(l_rcost + kRN); int2 *l_crng = reinterpret_cast<int2 *>(l_rflag + kRN);
+  int *l_cdst = reinterpret_cast<int *>(l_crng + kRN); float *l_cw = reinterpret_cast<float *>(l_cdst + kRA); int *l_stack = reinterpret_cast<int *>(l_cw + kRA);
+
+  if (tid < 16) sh.prof[tid] = 0;
+  if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; sh.n_os = 0; }
+  for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; s_ltok[i] = -1; }
+  for (int i = tid; i < 3 * (kHL / 32); i += kBlock) s_lmark[i] = 0;
+  const Table tb{s_lkey, s_lcost, s_ltok, s_lmark, hash, mask};
+  __syncthreads();
+  long long t_last__ = 0; (void)t_last__;
+  unsigned cnt_eps = 0, cnt_emit = 0, cnt_os = 0;
+  long long cur_base = 0; int n_cur = 0, max_frame = 0, f0 = 0, status = kStOk, sel = 0; unsigned hash_size = 1000;      // :41 toks_.SetSize(1000)
+  unsigned creg[kCurRegs]; int sreg[kCurRegs];
+#pragma unroll
+  for (int k = 0; k < kCurRegs; k++) { creg[k] = kEncMax; sreg[k] = 0; }
+  const bool fresh = p.fresh[L] != 0;
+  if (!fresh && T == 0) return;
+  if (fresh) {
+    if (p.info[L].status < 0) {      // a failed utterance left the scratch in an unknown state: back to the idle patterns
+      for (unsigned i = tid; i <= mask; i += kBlock) { Slot *s_ = &hash[i]; K3_AST(&s_->cost, kEncMax); K3_AST(&s_->stamp, 0); K3_AST(&s_->tok, -1); K3_AST(&s_->key, kEmpty); }
+      for (int i = tid; i < cap; i += kBlock) K3_AST(&q.label[i], kLabelNone);
+      for (int i = tid; i < p.seq_words_cap; i += kBlock) K3_AST(&q.bm[i], 0u);
+      for (int i = tid; i < p.hash_cap; i += kBlock) { K3_AST(&q.bfirst[i], kLabelNone); K3_AST(&q.bcnt[i], 0u); K3_AST(&q.bfill[i], 0u); }
+      __threadfence(); __syncthreads();
+    }
+    if (tid == 0) {
+      bool cl; const int slot = tb.claim(p.start, &cl);
+      tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; K3_AST(&tok_cost[0], kEncMax); sh.n_next = 1;
+      sh.n_wl[0] = 0; sh.n_wl[2] = 0; sh.n_wl[1] = 1; for (int i = 0; i < 4; i++) sh.err_r[i] = 0;
+      if (slot < kHL) s_lwl[1][0] = (unsigned short)slot; else { s_lwl[1][0] = 0xFFFF; wl[p.frame_tokens_cap] = slot; }
+      tok_off[0] = 0; loff_n[0] = 0;
+      K3_AST(&q.label[0], 0u); q.c0[0] = 0.0f;
+    }
+    __syncthreads();
+  } else {
+    const LaneInfo &li = p.info[L];
+    if (li.status != kStOk) return;
+    f0 = li.num_frames; cur_base = li.cur_base; n_cur = li.n_cur; max_frame = li.max_frame_tokens; sel = li.order_sel; hash_size = (unsigned)li.hash_size;
+    if (tid == 0) { sh.n_link = li.n_links; sh.n_eps = (unsigned long long)li.n_eps; sh.n_emit = (unsigned long long)li.n_cands; sh.n_os = (unsigned long long)li.n_order_sensitive; }
+    __syncthreads();
+  }
+
+  for (int f = fresh ? -1 : f0; f < f0 + T; f++) {
+    if (block_err(sh)) break;
+    float accept = p.beam; long long nb = 0; unsigned m_e = 1; int n_e = 1;
+    const int *ord_cur = q.order[sel]; int *ord_nxt = q.order[sel ^ 1];
+    if (f >= 0) {
+      const float *ll = p.loglikes + (r0 + (f - f0)) * p.ld;
+      const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
+      if (n_cur == 0) { status = kStNoTokens; break; }
+      // ---- GetCutoff (:653-720): the best token is the FIRST minimum-cost token of the list (strict <, :661-663)
+      unsigned long long bm = ~0ull;
+      for (int r = tid; r < n_cur; r += kBlock) { const unsigned long long v = ((unsigned long long)ccs[ord_cur[r]] << 32) | (unsigned)r; bm = v < bm ? v : bm; }
+      bm = block_min_u64(bm, sh);
+      const float best = dec((unsigned)(bm >> 32)); const int best_state = cst[ord_cur[(int)(unsigned)(bm & 0xFFFFFFFFull)]];
+      auto for_keys = [&](auto fn) { for (int i0 = 0; i0 < n_cur; i0 += kBlock) { const int i = i0 + tid; fn(i < n_cur, i < n_cur ? ccs[i] : 0u); } };
+      float cur_cutoff, ab;
+      const float beam_cutoff = best + p.beam;
+      if (p.max_active == 0x7FFFFFFF && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }
+      else {
+        const unsigned ebc = enc(beam_cutoff);
+        int c_lt = 0, c_le = 0;
+        for (int i = tid; i < n_cur; i += kBlock) { const unsigned k = ccs[i]; c_lt += k < ebc; c_le += k <= ebc; }
+        c_lt = block_sum_i32(c_lt, sh); c_le = block_sum_i32(c_le, sh);
+        int kth = -1;
+        if (n_cur > p.max_active && c_lt > p.max_active) kth = p.max_active;
+        else if (n_cur > p.min_active && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }
+        else if (n_cur > p.min_active && c_le > p.min_active) { ab = p.beam; cur_cutoff = beam_cutoff; }
+        else if (n_cur > p.min_active) kth = p.min_active;
+        else { ab = kInf - best + p.beam_delta; cur_cutoff = kInf; }
+        if (kth >= 0) { const float sel_ = dec(block_select_kth(for_keys, kth, sh)); ab = sel_ - best + p.beam_delta; cur_cutoff = sel_; }
+      }
+      { const unsigned want = (unsigned)((float)n_cur * p.hash_ratio); if (want > hash_size) hash_size = want; }      // PossiblyResizeHash (:227-233)
+      if (hash_size > (unsigned)p.hash_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
+      const float co = -best;
+      // ---- pre-pass over the best token's emitting arcs (:753-768)
+      __syncthreads();
+      unsigned n0 = kEncMax;
+      {
+        const int2 a = p.offs[best_state];
+        for (int arc = a.x + tid; arc < a.y; arc += kBlock) { const ArcRec r = p.arcs[arc]; const float nw_ = r.w + co - ll[r.pdf] + best; const unsigned e = enc(nw_ + ab); n0 = e < n0 ? e : n0; }
+      }
+      n0 = (unsigned)(block_min_u64((unsigned long long)n0, sh) & 0xFFFFFFFFull);
+      const float next0 = n0 == kEncMax ? kInf : dec(n0);
+      if (tid == 0) { sh.n_cand = 0; sh.n_next = 0; }
+      if (tid < 3) sh.n_wl[tid] = 0;
+      if (tid < 4) sh.err_r[tid] = 0;
+      for (int i = tid; i < 3 * (kHL / 32); i += kBlock) s_lmark[i] = 0;
+      __syncthreads();
+      if (block_err(sh)) break;
+      // ---- pass A: per 64-token chunk of the visit order, the number of emitting arcs and min (tot + adaptive_beam)
+      const int nchunks = (n_cur + 63) >> 6;
+      auto chunk_tokens = [&](int c, int &i, float &cost, int &beg, int &deg) {
+        const int r = 64 * c + lane; const bool v = r < n_cur;
+        i = v ? ord_cur[r] : 0; const unsigned cb = v ? ccs[i] : kEncMax; const int st = v ? cst[i] : 0; cost = dec(cb); beg = 0; deg = 0;
+        if (v && cost <= cur_cutoff) { const int2 a = p.offs[st]; beg = a.x; deg = a.y - a.x; }
+      };
+      for (int c = wave; c < nchunks; c += nw) {
+        int i, beg, deg; float cost; chunk_tokens(c, i, cost, beg, deg);
+        unsigned cm = kEncMax;
+        const int total = wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int, int, int owner, const ArcRec &r) {
+          const float oc = __shfl(cost, owner);
+          if (valid) { const float ac = co - ll[r.pdf]; const float tot = oc + ac + r.w; const unsigned e = enc(tot + ab); cm = e < cm ? e : cm; }
+          cnt_emit += valid;
+        });
+        cm = wave_min_u32(cm);
+        if (lane == 0) { q.cmin[c] = cm; q.ccnt[c] = total; }
+      }
+      __syncthreads();
+      // exclusive scans over the chunks: bound in force at a chunk's first arc, sequence number of its first arc
+      if (wave == 0) {
+        unsigned run = enc(next0); int base = 0;
+        unsigned *cpre = q.cmin + (cap / 64 + 2); int *cbase = q.ccnt + (cap / 64 + 2);
+        for (int c0 = 0; c0 < nchunks; c0 += 64) {
+          const int c = c0 + lane; const unsigned m = c < nchunks ? q.cmin[c] : kEncMax; const int k = c < nchunks ? q.ccnt[c] : 0;
+          unsigned em = m; int ik = k;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(em, o); const int tk = __shfl_up(ik, o); if (lane >= o) { em = t < em ? t : em; ik += tk; } }
+          unsigned exm = __shfl_up(em, 1); if (lane == 0) exm = kEncMax; exm = run < exm ? run : exm;
+          if (c < nchunks) { cpre[c] = exm; cbase[c] = base + ik - k; }
+          const unsigned wm = __shfl(em, 63); run = wm < run ? wm : run; base += __shfl(ik, 63);
+        }
+        if (lane == 0) { ls.final_cut = run; ls.m_e = base; }
+      }
+      if (tid == 0) loff_e[f] = sh.n_link;
+      __syncthreads();
+      accept = dec(ls.final_cut); m_e = (unsigned)ls.m_e;      // the frame's final next_cutoff; labels 0 .. m_e-1 belong to the emitting arcs
+      if ((long long)m_e + cap > 32ll * p.seq_words_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
+      if (block_err(sh)) break;
+      nb = cur_base + n_cur;
+      // ---- pass B: accept against the bound in force at each arc; min cost / min sequence number per destination state; forward links
+      {
+        const unsigned *cpre = q.cmin + (cap / 64 + 2); const int *cbase = q.ccnt + (cap / 64 + 2);
+        for (int c = wave; c < nchunks; c += nw) {
+          int i, beg, deg; float cost; chunk_tokens(c, i, cost, beg, deg);
+          unsigned run = cpre[c]; const int jbase = cbase[c];
+          wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int j, int arc, int owner, const ArcRec &r) {
+            const float oc = __shfl(cost, owner); const int oi = __shfl(i, owner);
+            float ac = 0.0f, tot = 0.0f; unsigned e = kEncMax;
+            if (valid) { ac = co - ll[r.pdf]; tot = oc + ac + r.w; e = enc(tot + ab); }
+            unsigned em = e;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(em, o); if (lane >= o) em = t < em ? t : em; }
+            unsigned exm = __shfl_up(em, 1); if (lane == 0) exm = kEncMax; exm = run < exm ? run : exm;
+            { const unsigned wm = __shfl(em, 63); run = wm < run ? wm : run; }
+            const bool acc = valid && tot < dec(exm);
+            cnt_os += acc && !(tot < accept);
+            const int state = (int)((unsigned)r.next & ~kEpsFlag);
+            bool claimed = false, mk = false; int slot = -1;
+            if (acc) {
+              slot = tb.claim(state, &claimed);
+              if (slot < 0) { sh.err = K3_ERR_OVERFLOW; claimed = false; } else { tb.cost_min(slot, enc(tot)); mk = true; }
+            }
+            int idx = wave_append(claimed, &sh.n_next);
+            if (claimed) {
+              if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot; tok_state[nb + idx] = state; K3_AST(&tok_cost[nb + idx], kEncMax); }
+              else { sh.err = K3_ERR_OVERFLOW; idx = 0; }
+              tb.set_tok(slot, idx);
+            }
+            {
+              const bool q1 = claimed && r.next < 0;
+              const int pos1 = wave_append(q1, &sh.n_wl[1]);
+              if (q1) {
+                if (pos1 < kWlLds) s_lwl[1][pos1] = slot < kHL ? (unsigned short)slot : (unsigned short)0xFFFF;
+                if (pos1 >= kWlLds || slot >= kHL) { if (pos1 < p.frame_tokens_cap) wl[p.frame_tokens_cap + pos1] = slot; else sh.err = K3_ERR_OVERFLOW; }
+              }
+            }
+            if (mk && !claimed) { idx = tb.wait_tok(slot, &sh.err); if (idx < 0) idx = 0; }
+            if (mk) atomicMin(&q.label[idx], (unsigned)(jbase + j));
+            const long long pos = wave_append64(mk, &sh.n_link);
+            if (mk) {
+              if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}; link_arc[pos] = arc; }
+              else sh.err = K3_ERR_OVERFLOW;
+            }
+          });
+        }
+      }
+      if (block_err(sh)) break;
+      n_e = sh.n_next;
+      if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
+      for (int i = tid; i < n_e; i += kBlock) q.c0[i] = dec(tb.cost(tok_slot[i]));      // costs right after ProcessEmitting (the replay starts from them)
+      __syncthreads();
+    }   // f >= 0
+    // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens made so far
+    lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt);
+    // ---- ProcessNonemitting: order-free fixpoint (costs, new tokens, eps links)
+    finish_frame<false>(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
+    if (block_err(sh)) break;
+    const int n = sh.n_next;
+    // ---- closure sub-graph in token space: per token its eps arcs in FST order, destination = token index, or -1 for an arc that fails at
+    // the token's FINAL cost (it then fails at every earlier, higher cost too)
+    if (tid == 0) { ls.n_csr = 0; ls.n_created = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+      const int i = i0 + tid; int deg = 0, ebeg = 0; bool has_eps = false;
+      if (i < n) {
+        const float c = dec(tb.cost(tok_slot[i])); const int st = tok_state[nb + i];
+        const int2 a = p.offs[st], b = p.offs[st + 1];
+        ebeg = a.y; has_eps = b.x > a.y; deg = (has_eps && c < accept) ? b.x - a.y : 0;
+      }
+      int incl = deg;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      int wbase = 0;
+      if (lane == 63) wbase = atomicAdd(&ls.n_csr, incl);
+      wbase = __shfl(wbase, 63);
+      if (i < n) { q.crng[i] = make_int2(wbase + incl - deg, deg); q.rflag[i] = (has_eps ? kRfHasEps : 0) | (i < n_e ? kRfExists : 0); q.rown[i] = ebeg; }
+    }
+    __syncthreads();
+    const int n_csr = ls.n_csr;
+    if (n_csr > p.eps_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
+    if (block_err(sh)) break;
+    const bool use_lds = n <= kRN && n_csr <= kRA;
+    float *rcost = use_lds ? l_rcost : q.rcost; int *rflag = use_lds ? l_rflag : q.rflag; int2 *crng = use_lds ? l_crng : q.crng;
+    int *cdst = use_lds ? l_cdst : q.cdst; float *cw = use_lds ? l_cw : q.cw; int *stack = use_lds ? l_stack : q.stack; const int stack_cap = use_lds ? kRS : p.stack_cap;
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+      const int i = i0 + tid; int beg = 0, deg = 0, base = 0; float c = 0.0f;
+      if (i < n) {
+        const int2 rg = q.crng[i]; base = rg.x; deg = rg.y; beg = q.rown[i]; c = dec(tb.cost(tok_slot[i]));
+        crng[i] = rg; rflag[i] = q.rflag[i]; rcost[i] = i < n_e ? q.c0[i] : kInf;
+      }
+      wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int, int arc, int owner, const ArcRec &r) {
+        const float oc = __shfl(c, owner); const int obase = __shfl(base, owner), obeg = __shfl(beg, owner);
+        if (valid) {
+          int d = -1;
+          if (oc + r.w < accept) { const int s2 = tb.find((int)((unsigned)r.next & ~kEpsFlag)); if (s2 >= 0) d = tb.tok(s2); else sh.err = K3_ERR_HIP; }
+          cdst[obase + (arc - obeg)] = d; cw[obase + (arc - obeg)] = r.w;
+        }
+      });
+    }
+    __syncthreads();
+    if (block_err(sh)) break;
+    // ---- replay of the LIFO queue (:851-896) by one wavefront: only the ORDER in which the closure creates tokens comes out of it
+    if (wave == 0) {
+      int sp = 0, pcur = n_e, created = 0, err = 0;
+      for (int iters = 0;; iters++) {
+        if (iters > (1 << 24)) { err = 2; break; }      // cannot happen (every pop follows a cost decrease); keeps a bug from hanging the GPU
+        int e = -1;
+        if (sp > 0) { e = stack[--sp]; }
+        else {
+          while (pcur > 0 && e < 0) {      // the initial queue = order1 filtered by "state has eps arcs", consumed from its back
+            const int r = pcur - 1 - lane; const int i = r >= 0 ? ord_nxt[r] : -1;
+            const bool he = i >= 0 && (rflag[i] & kRfHasEps);
+            const unsigned long long mk = __ballot(he);
+            if (mk) { const int first = __ffsll((long long)mk) - 1; e = __shfl(i, first); pcur = pcur - 1 - first; }
+            else pcur = pcur > 64 ? pcur - 64 : 0;
+          }
+          if (e < 0) break;
+        }
+        const float c = rcost[e]; const int2 rg = crng[e];
+        if (!(c < accept)) continue;
+        for (int k0 = 0; k0 < rg.y; k0 += 64) {
+          const int k = k0 + lane; const bool v = k < rg.y;
+          const int d = v ? cdst[rg.x + k] : -1; const float w = v ? cw[rg.x + k] : 0.0f;
+          const float tot = c + w; const bool ok = d >= 0 && tot < accept;
+          // two arcs of this batch into the same token must be applied one after the other
+          if (ok) s_own[d & 1023] = lane;
+          __threadfence_block();
+          const bool clash = ok && s_own[d & 1023] != lane;
+          const unsigned long long okm = __ballot(ok);
+          if (__ballot(clash) == 0ull) {
+            const int fl = ok ? rflag[d] : 0; const float old = ok ? rcost[d] : 0.0f;
+            const bool isnew = ok && !(fl & kRfExists), better = ok && (fl & kRfExists) && old > tot, changed = isnew || better;
+            const unsigned long long nm = __ballot(isnew);
+            if (isnew) { rflag[d] = fl | kRfExists; q.label[d] = m_e + (unsigned)(created + __popcll(nm & ((1ull << lane) - 1ull))); }
+            created += __popcll(nm);
+            if (changed) rcost[d] = tot;
+            const bool push = changed && (fl & kRfHasEps);
+            const unsigned long long pm = __ballot(push);
+            if (sp + __popcll(pm) > stack_cap) { err = 1; break; }
+            if (push) stack[sp + __popcll(pm & ((1ull << lane) - 1ull))] = d;
+            sp += __popcll(pm);
+          } else {
+            for (unsigned long long rest = okm; rest; rest &= rest - 1) {
+              const int jl = __ffsll((long long)rest) - 1; const int dj = __shfl(d, jl); const float tj = __shfl(tot, jl);
+              const int fl = rflag[dj]; const float old = rcost[dj];
+              const bool isnew = !(fl & kRfExists), changed = isnew || old > tj;
+              if (isnew) { if (lane == 0) { rflag[dj] = fl | kRfExists; q.label[dj] = m_e + (unsigned)created; } created++; }
+              if (changed && lane == 0) rcost[dj] = tj;
+              if (changed && (fl & kRfHasEps)) { if (sp + 1 > stack_cap) { err = 1; break; } if (lane == 0) stack[sp] = dj; sp++; }
+              __threadfence_block();
+            }
+            if (err) break;
+          }
+          __threadfence_block();
+        }
+        if (err) break;
+      }
+      if (lane == 0) { ls.n_created = created; if (err) sh.err = err == 2 ? K3_ERR_HIP : K3_ERR_OVERFLOW; }
+    }
+    __syncthreads();
+    if (block_err(sh)) break;
+    if (n_e + ls.n_created != n) { if (tid == 0) sh.err = K3_ERR_HIP; }      // every token of the fixpoint must have been created by the replay
+    if (block_err(sh)) break;
+    // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
+    lit_hash_order(q, sh, n, m_e + (unsigned)ls.n_created, tok_state + nb, hash_size, ord_nxt);
+    // ---- publish the frame: final costs into the pool, empty table, idle labels
+    for (int i = tid; i < n; i += kBlock) { const int slot = tok_slot[i]; tok_cost[nb + i] = tb.cost(slot); if (slot >= kHL) tb.clear(slot); K3_AST(&q.label[i], kLabelNone); }
+    __syncthreads();
+    for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }
+    __syncthreads();
+    cur_base = nb; n_cur = n; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1;
+    if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
+  }
+  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { atomicAdd(&sh.n_eps, a); atomicAdd(&sh.n_emit, b); atomicAdd(&sh.n_os, c); } }
+  __syncthreads();
+  if (tid == 0) {
+    LaneInfo &li = p.info[L];
+    li.n_tokens = cur_base + n_cur; li.n_links = sh.n_link; li.n_cands = (long long)sh.n_emit; li.n_eps = (long long)sh.n_eps; li.max_frame_tokens = max_frame;
+    li.status = sh.err ? sh.err : status; li.num_frames = f0 + T; li.reached_final = 0; li.out_states = 0; li.out_arcs = 0;
+    li.cur_base = cur_base; li.n_cur = n_cur; li.n_order_sensitive = (long long)sh.n_os; li.hash_size = (int)hash_size; li.order_sel = sel;
+  }
+}
+
+// PruneForwardLinksFinal (:385-467) exactly: in-place sweeps over the last frame's tokens in list order (newest token first) until no extra
+// cost moves by more than 1e-5 relative (ApproxEqual, base/kaldi-math.h:265-275); a link is excised when it is found above the lattice beam.
+// n tokens tb.., eps links [l0, l1).  base / extra: per token; off: first link of a token (n + 1); ldst (bit 31 = keep), ldelta: per live link.
+__device__ __forceinline__ bool lit_approx_equal(float a, float b, float tol) {
+  if (a == b) return true;
+  const float diff = fabsf(a - b);
+  if (diff == __builtin_inff() || diff != diff) return false;
+  return diff <= tol * (fabsf(a) + fabsf(b));
+}
+
+// The literal branch of k3_decode_prune_kernel's last-frame stage.  LDS arrays (each kPCap entries) are used when the frame fits.
+__device__ __forceinline__ void lit_final_frame(const DecParams &p, int L, long long tb, long long te, long long l0, long long l1, float final_best, bool final_empty,
+                                               const int *tok_state, const unsigned *tok_cost, float *extra, const Link *links, int *err,
+                                               float *l_base, float *l_extra, unsigned *l_off, int *l_ldst, float *l_ldelta, int *redi, int *s_m) {
+  const int tid = threadIdx.x; const int n = (int)(te - tb); const float kInf = __builtin_inff(), lb = p.lattice_beam;
+  const long long fc = p.frame_cands_cap;
+  unsigned *g_off = reinterpret_cast<unsigned *>(p.c_dst + L * fc); unsigned *cursor = reinterpret_cast<unsigned *>(p.c_src + L * fc); int *lid = p.c_arc + L * fc;
+  float *g_base = p.c_tot + L * fc, *g_delta = p.c_ac + L * fc; int *g_ldst = p.wl + 2ll * L * p.frame_tokens_cap;
+  const int *by_ins = p.lt_by_ins + (long long)L * p.frame_tokens_cap;
+  for (int t = tid; t < n; t += kPBlock) K3_AST(&cursor[t], 0u);
+  __syncthreads();
+  for (long long l = l0 + tid; l < l1; l += kPBlock) { const Link k = links[l]; if (eps_link_live(k, tok_cost[k.src])) atomicAdd(&cursor[k.src - tb], 1u); }
+  __syncthreads();
+  const int m = block_excl_scan([&](int t) { return K3_ALD(&cursor[t]); }, g_off, n, redi);
+  if (tid == 0) { g_off[n] = (unsigned)m; *s_m = m; }
+  if (m > fc || m > 2ll * p.frame_tokens_cap || n + 1 > fc) { if (tid == 0) *err = K3_ERR_OVERFLOW; return; }
+  for (int t = tid; t < n; t += kPBlock) K3_AST(&cursor[t], 0u);
+  __syncthreads();
+  for (long long l = l0 + tid; l < l1; l += kPBlock) {
+    const Link k = links[l];
+    if (!eps_link_live(k, tok_cost[k.src])) continue;
+    const unsigned pos = g_off[k.src - tb] + atomicAdd(&cursor[k.src - tb], 1u);
+    lid[pos] = (int)(l - l0); g_ldst[pos] = (int)(k.dst - tb); g_delta[pos] = k.tot - dec(tok_cost[k.dst]);      // (tot + ac + graph) - next_tok->tot_cost
+  }
+  for (int t = tid; t < n; t += kPBlock) { const float fcost = final_empty ? 0.0f : p.final_cost[tok_state[tb + t]]; g_base[t] = dec(tok_cost[tb + t]) + fcost - final_best; }
+  __syncthreads();
+  const bool use_lds = n + 1 <= kPCap && m <= kPCap;
+  float *base = use_lds ? l_base : g_base, *ex = use_lds ? l_extra : extra + tb, *ldelta = use_lds ? l_ldelta : g_delta; unsigned *off = use_lds ? l_off : g_off; int *ldst = use_lds ? l_ldst : g_ldst;
+  if (use_lds) {
+    for (int t = tid; t <= n; t += kPBlock) { off[t] = g_off[t]; if (t < n) base[t] = g_base[t]; }
+    for (int j = tid; j < m; j += kPBlock) { ldst[j] = g_ldst[j]; ldelta[j] = g_delta[j]; }
+  }
+  for (int t = tid; t < n; t += kPBlock) ex[t] = 0.0f;      // a new token's extra_cost (:271)
+  __syncthreads();
+  if (tid == 0) {
+    bool changed = true;
+    for (int sweep = 0; changed && sweep < 100000; sweep++) {
+      changed = false;
+      for (int d = n - 1; d >= 0; d--) {      // active_toks_[frame].toks: newest token first
+        const int t = by_ins[d];
+        float te_ = base[t];
+        for (unsigned j = off[t]; j < off[t + 1]; j++) {
+          const int dst = ldst[j] & 0x7FFFFFFF;
+          float le = ex[dst] + ldelta[j];
+          if (le > lb) ldst[j] = dst;
+          else { ldst[j] = dst | (int)0x80000000; if (le < 0.0f) le = 0.0f; if (le < te_) te_ = le; }
+        }
+        if (te_ > lb) te_ = kInf;
+        if (!lit_approx_equal(ex[t], te_, 1.0e-05f)) changed = true;
+        ex[t] = te_;
+      }
+    }
+  }
+  __syncthreads();
+  if (use_lds) { for (int t = tid; t < n; t += kPBlock) extra[tb + t] = ex[t]; for (int j = tid; j < m; j += kPBlock) g_ldst[j] = ldst[j]; }
+  __syncthreads();
+}

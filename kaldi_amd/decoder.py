@@ -125,6 +125,12 @@ class CudaDecoder:
         if check: _l.check(rc)
         return info
 
+    def OrderSensitiveEvents(self):
+        """int64 per finalised utterance: literal_order -> forward links that exist only because next_cutoff was still loose when
+        their arc was examined; default mode -> emitting arcs below the pre-pass bound but not below the final bound (an upper bound)"""
+        ev = np.zeros(getattr(self, "_n_sel", None) or self._n, np.int64)
+        _l.check(self._L.k3_decoder_order_sensitive_events(self._h, ev.ctypes.data)); return ev
+
     def GetRawLattices(self, copy=False):
         """sequence of RawLattice, one per utterance of the last batch (GetRawLattice, not yet Connect()-ed).  All lattices arrive in
         ten flat host arrays (one D2H copy each); the per-utterance RawLattice objects are views made on access."""

@@ -31,7 +31,7 @@ class DecoderConfig(ctypes.Structure):
     """k3_decoder_config (include/k3hip.h); decoding fields = LatticeFasterDecoderConfig (decoder/lattice-faster-decoder.h:37-107)."""
     _fields_ = [("beam", ctypes.c_float), ("max_active", ctypes.c_int32), ("min_active", ctypes.c_int32), ("lattice_beam", ctypes.c_float),
                 ("beam_delta", ctypes.c_float), ("frame_tokens_cap", ctypes.c_int32), ("frame_cands_cap", ctypes.c_int32),
-                ("lane_tokens_cap", ctypes.c_int64), ("lane_links_cap", ctypes.c_int64)]
+                ("lane_tokens_cap", ctypes.c_int64), ("lane_links_cap", ctypes.c_int64), ("literal_order", ctypes.c_int32), ("hash_ratio", ctypes.c_float)]
 
 WINDOW_TYPES = {"hanning": 0, "sine": 1, "hamming": 2, "povey": 3, "rectangular": 4, "blackman": 5}
 
@@ -80,7 +80,7 @@ def load():
     L.k3_decoder_init_decoding.argtypes = [vp, i32, i32, vp]; L.k3_decoder_advance_decoding.argtypes = [vp, i32, vp, i64, vp, vp]
     L.k3_decoder_init_channels.argtypes = [vp, vp, i32, vp]; L.k3_decoder_finalize_channels.argtypes = [vp, vp, i32, vp]
     L.k3_decoder_finalize_decoding.argtypes = [vp, vp]; L.k3_decoder_num_frames_decoded.argtypes = [vp, i32]; L.k3_decoder_num_frames_decoded.restype = i32
-    L.k3_decoder_lattice_info.argtypes = [vp, vp]
+    L.k3_decoder_lattice_info.argtypes = [vp, vp]; L.k3_decoder_order_sensitive_events.argtypes = [vp, vp]
     L.k3_decoder_get_raw_lattices.argtypes = [vp] + [vp] * 10
     L.k3_fst_export_image.argtypes = [vp, vp]; L.k3_fst_import_image.argtypes = [vp, vp]
     L.k3_decoder_set_profiling.argtypes = [vp, i32]; L.k3_decoder_kernel_times.argtypes = [vp, vp]

@@ -60,3 +60,20 @@ def test_ctypes_declarations_agree_with_the_headers():
                     elif re.search(r"\bfloat\b", p): assert t is C.c_float, (name, p, t)
             checked += 1
         assert checked >= 8, (header, checked)
+
+
+def test_struct_layouts_agree_with_the_header():
+    """the ctypes mirrors of the POD structs have the fields of include/k3hip.h in the same order with the same C types"""
+    from kaldi_amd import lib
+    import ctypes as C
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "k3hip.h")).read(), flags=re.S)
+    ctype = {"float": C.c_float, "int32_t": C.c_int32, "int64_t": C.c_int64, "double": C.c_double}
+    for cname, mirror in (("k3_feat_opts", lib.FeatOpts), ("k3_online_cmvn_opts", lib.OnlineCmvnOpts), ("k3_nnet_info", lib.NnetInfo), ("k3_decoder_config", lib.DecoderConfig)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl: continue
+            t, names = decl.split(None, 1)
+            fields += [(n.strip(), ctype[t]) for n in names.split(",")]
+        assert [(n, t) for n, t in mirror._fields_] == fields, cname
