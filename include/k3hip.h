@@ -244,6 +244,12 @@ int k3_mat_add_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, 
 int k3_mat_copy_rows(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *stream); /* CopyRows, index -1 = zero row */
 int k3_mat_add_rows(float alpha, const float *d_src, int64_t lds, const int32_t *d_indexes, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream); /* AddRows, index -1 = skip */
 
+/* CuVectorBase: a vector is a [1 x dim] matrix for Set / Add / Scale / ApplyFloor / AddVec (k3_mat_add_vec_to_rows) / MulElements
+ * (k3_mat_mul_cols_vec); the three operations below have no matrix counterpart (cudamatrix/cu-vector.h:79-103,147-160). */
+int k3_vec_convert(const void *d_src, int32_t src_is_f64, void *d_dst, int32_t dst_is_f64, int32_t n, void *stream);   /* CopyFromVec(const CuVectorBase<OtherReal>&) */
+int k3_vec_pow(const float *d_src, float *d_dst, int32_t n, float power, void *stream);                                /* Pow / ApplyPow */
+int k3_vec_add_vec_vec(float alpha, const float *d_a, const float *d_b, float beta, float *d_v, int32_t n, void *stream);  /* AddVecVec: v = alpha a .* b + beta v */
+
 #ifdef __cplusplus
 }
 #endif

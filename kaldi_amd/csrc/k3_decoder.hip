@@ -121,7 +121,7 @@ struct DecParams {
   unsigned *lt_cmin; int *lt_ccnt;                       // [frame_tokens_cap / 64 + 2] per 64-token chunk: min (tot + adaptive_beam), emitting arcs
   float *lt_c0;                                          // [frame_tokens_cap] token costs right after ProcessEmitting
   int2 *lt_crng; int *lt_cdst; float *lt_cw;             // closure sub-graph in token space: per token (first, count), per eps arc (dst token | -1, weight)
-  float *lt_rcost; int *lt_rflag, *lt_rown, *lt_stack;   // replay state (global copies; small frames use LDS)
+  float *lt_rcost; int *lt_rflag, *lt_rown, *lt_stack, *lt_iq, *lt_c2t; int2 *lt_arcs2; int4 *lt_meta;   // replay state (global copies; small frames use LDS)
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -1364,6 +1364,10 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     if ((rc = dmalloc(&d->allocs, &p.lt_rflag, nl * cap))) return rc;
     if ((rc = dmalloc(&d->allocs, &p.lt_rown, nl * cap))) return rc;
     if ((rc = dmalloc(&d->allocs, &p.lt_stack, nl * p.stack_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_iq, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_arcs2, nl * p.eps_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_meta, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_c2t, nl * cap))) return rc;
     // idle patterns of the scratch: labels / bucket firsts all ones, bitmap / bucket counters zero
     K3_HIP_CHECK(hipMemset(p.lt_label, 0xFF, nl * cap * sizeof(unsigned)));
     K3_HIP_CHECK(hipMemset(p.lt_bm, 0, nl * p.seq_words_cap * sizeof(unsigned)));

@@ -19,8 +19,8 @@
 //                        token by token (k3_decode_prune_kernel, literal branch).
 // Capacities: frame_tokens_cap <= 65536; arcs expanded + tokens created on one frame <= 32 * seq_words_cap.
 
-constexpr int kRN = 2048, kRA = 2048, kRS = 4096;
-constexpr size_t kLitDynLds = (size_t)kRN * 16 + (size_t)kRA * 8 + (size_t)kRS * 4;      // replay in LDS: tokens / closure arcs / stack entries of a frame (larger frames: HBM scratch)
+constexpr int kRN = kHL / 2, kRA = 2048, kRS = 1024;      // replay fully in LDS: closure ids (cost + meta alias the level-1 table: kHL x 12 B) / passing arcs / stack entries
+constexpr size_t kLitDynLds = (size_t)kRA * 8 + (size_t)kRS * 4;      // replay in LDS: tokens / closure arcs / stack entries of a frame (larger frames: HBM scratch)
 constexpr unsigned kLabelNone = 0xFFFFFFFFu;
 enum { kRfHasEps = 1, kRfExists = 2 };
 
@@ -70,7 +70,7 @@ __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int 
 }
 
 struct LitLane {      // this lane's slices of the literal_order scratch
-  int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *bfirst, *bcnt, *bfill, *cmin; float *c0, *cw, *rcost; int2 *crng;
+  int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *bfirst, *bcnt, *bfill, *cmin; float *c0, *cw, *rcost; int2 *crng, *arcs2; int4 *meta; int *iq, *c2t;
   __device__ LitLane(const DecParams &p, int L) {
     const long long cap = p.frame_tokens_cap, nch = cap / 64 + 2;
     order[0] = p.lt_order + 2ll * L * cap; order[1] = order[0] + cap; by_ins = p.lt_by_ins + L * cap; dense = p.lt_dense + L * cap; grp = p.lt_grp + L * cap;
@@ -78,7 +78,7 @@ struct LitLane {      // this lane's slices of the literal_order scratch
     bfirst = p.lt_bfirst + (long long)L * p.hash_cap; bcnt = p.lt_bcnt + (long long)L * p.hash_cap; bfill = p.lt_bfill + (long long)L * p.hash_cap;
     cmin = p.lt_cmin + 2ll * L * nch; ccnt = p.lt_ccnt + 2ll * L * nch; c0 = p.lt_c0 + L * cap; crng = p.lt_crng + L * cap;
     cdst = p.lt_cdst + (long long)L * p.eps_cap; cw = p.lt_cw + (long long)L * p.eps_cap; rcost = p.lt_rcost + L * cap; rflag = p.lt_rflag + L * cap; rown = p.lt_rown + L * cap;
-    stack = p.lt_stack + (long long)L * p.stack_cap;
+    stack = p.lt_stack + (long long)L * p.stack_cap; arcs2 = p.lt_arcs2 + (long long)L * p.eps_cap; iq = p.lt_iq + L * cap; meta = p.lt_meta + L * cap; c2t = p.lt_c2t + L * cap;
   }
 };
 
@@ -118,10 +118,86 @@ __device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int
 
 struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 
-__global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(DecParams p) {
+// The replay loop.  MODE 0: costs, meta, arcs, stack and the creation list in LDS; MODE 1: costs, stack and list in LDS, meta / arcs read-only
+// in HBM; MODE 2: everything in HBM.  rcost[id] = the cost the serial code has seen for the token so far (+inf: not created yet);
+// meta[id] = {first passing arc, passing arcs, destination and weight of the first one}; clist[k] = id of the k-th token the closure creates.
+template <int MODE>
+__device__ __forceinline__ void lit_replay(float *rcost, const int4 *meta, const int2 *AR, int *stack, int stack_cap, unsigned *clist, const int *iq, int n_iq, float accept,
+                                           int *s_own, int *out_created, int *out_err, int *out_pops) {
+  const int lane = threadIdx.x & 63; const float kInf = __builtin_inff();
+  int sp = 0, kpos = n_iq, created = 0, err = 0, e_fwd = -1, cbase = -64, cache = 0, iters = 0;
+  for (;; iters++) {
+    if (iters > (1 << 24)) { err = 2; break; }      // cannot happen (every pop follows a cost decrease); keeps a bug from hanging the GPU
+    int e;
+    if (e_fwd >= 0) { e = e_fwd; e_fwd = -1; }
+    else if (sp > 0) e = stack[--sp];
+    else if (kpos > 0) {
+      kpos--;
+      if ((kpos & ~63) != cbase) { cbase = kpos & ~63; cache = cbase + lane < n_iq ? iq[cbase + lane] : 0; }
+      e = __builtin_amdgcn_readlane(cache, __builtin_amdgcn_readfirstlane(kpos & 63));
+    } else break;
+    const float c = rcost[e]; const int4 mt = meta[e];
+    if (!(c < accept)) continue;
+    for (int k0 = 0; k0 < mt.y; k0 += 64) {
+      if (e_fwd >= 0) { if (sp + 1 > stack_cap) { err = 1; break; } stack[sp++] = e_fwd; e_fwd = -1; if (MODE == 2) __threadfence_block(); }
+      const int k = k0 + lane; const bool v = k < mt.y;
+      int2 ar = make_int2(mt.z, mt.w);
+      if (mt.y > 1 || k0 > 0) ar = v ? AR[mt.x + k] : make_int2(0, 0);
+      const int d = ar.x; const float tot = c + __int_as_float(ar.y); const bool ok = v && tot < accept;
+      const unsigned long long okm = __ballot(ok);
+      bool clash = false;
+      if (__popcll(okm) >= 2) {      // two arcs of this batch into the same token must be applied one after the other
+        if (ok) s_own[d & 1023] = lane;
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes above are in place (LDS executes a wavefront's accesses in order)
+        clash = __ballot(ok && s_own[d & 1023] != lane) != 0ull;
+      }
+      if (!clash) {
+        const float old = ok ? rcost[d] : 0.0f; const int dpc = ok ? meta[d].y : 0;
+        const bool isnew = ok && old == kInf, changed = ok && old > tot;      // a token's cost is < cutoff < inf once it exists
+        const unsigned long long nm = __ballot(isnew);
+        if (isnew) clist[created + __popcll(nm & ((1ull << lane) - 1ull))] = (unsigned)d;
+        created += __popcll(nm);
+        if (changed) rcost[d] = tot;
+        const unsigned long long pm = __ballot(changed && dpc > 0);      // only tokens that can expand are queued
+        if (pm) {
+          const int np = __popcll(pm), top = 63 - __clzll((long long)pm);
+          if (sp + np > stack_cap) { err = 1; break; }
+          const int rank = __popcll(pm & ((1ull << lane) - 1ull));
+          if ((pm >> lane & 1ull) && lane != top) stack[sp + rank] = d;
+          sp += np - 1; e_fwd = __builtin_amdgcn_readlane(d, __builtin_amdgcn_readfirstlane(top));
+        }
+      } else {
+        for (unsigned long long rest = okm; rest; rest &= rest - 1) {
+          const int jl = __ffsll((long long)rest) - 1; const int dj = __shfl(d, jl); const float tj = __shfl(tot, jl);
+          const float old = rcost[dj];
+          const bool isnew = old == kInf, changed = old > tj;
+          if (isnew) { if (lane == 0) clist[created] = (unsigned)dj; created++; }
+          if (changed && lane == 0) rcost[dj] = tj;
+          if (changed && meta[dj].y > 0) { if (sp + 1 > stack_cap) { err = 1; break; } if (lane == 0) stack[sp] = dj; sp++; }
+          if (MODE == 2) __threadfence_block();
+        }
+        if (err) break;
+      }
+      if (MODE == 2) __threadfence_block();
+    }
+    if (err) break;
+  }
+  *out_created = created; *out_err = err; *out_pops = iters;
+}
+
+
+#ifdef K3_LIT_PROF
+#define K3_LT(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); sh.prof[i] += now__ - lt_last__; lt_last__ = now__; } } while (0)
+#else
+#define K3_LT(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(DecParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];       // replay arrays of a small frame
   __shared__ Shared sh; __shared__ LitShared ls;
-  __shared__ int s_lkey[kHL]; __shared__ unsigned s_lcost[kHL]; __shared__ int s_ltok[kHL]; __shared__ unsigned s_lmark[3 * (kHL / 32)];
+  __shared__ __attribute__((aligned(16))) int s_tab[3 * kHL];      // level-1 table {key, cost, token}; between the closure and the end of a frame: the replay's records
+  int *const s_lkey = s_tab; unsigned *const s_lcost = reinterpret_cast<unsigned *>(s_tab + kHL); int *const s_ltok = s_tab + 2 * kHL;
+  __shared__ unsigned s_lmark[3 * (kHL / 32)];
   __shared__ unsigned short s_lwl[2][kWlLds];
   __shared__ int s_own[1024];      // replay: which lane of the batch targets a token (binned; a false clash only takes the one-by-one path)
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
@@ -134,10 +210,6 @@ __global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(De
   int *st_ntoks = p.st_ntoks + L * p.fstride; float *st_cur = p.st_cur + L * p.fstride, *st_ab = p.st_ab + L * p.fstride, *st_next = p.st_next + L * p.fstride, *st_co = p.st_co + L * p.fstride;
   const unsigned mask = (unsigned)p.hash_mask; const float kInf = __builtin_inff(); const int cap = p.frame_tokens_cap;
   const LitLane q(p, L);
-  // replay arrays in LDS
-  float *l_rcost = reinterpret_cast<float *>(smem_raw); int *l_rflag = reinterpret_cast<int *>(l_rcost + kRN); int2 *l_crng = reinterpret_cast<int2 *>(l_rflag + kRN);
-  int *l_cdst = reinterpret_cast<int *>(l_crng + kRN); float *l_cw = reinterpret_cast<float *>(l_cdst + kRA); int *l_stack = reinterpret_cast<int *>(l_cw + kRA);
-
   if (tid < 16) sh.prof[tid] = 0;
   if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; sh.n_os = 0; }
   for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; s_ltok[i] = -1; }
@@ -145,6 +217,7 @@ __global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(De
   const Table tb{s_lkey, s_lcost, s_ltok, s_lmark, hash, mask};
   __syncthreads();
   long long t_last__ = 0; (void)t_last__;
+  long long lt_last__ = (long long)__builtin_readcyclecounter(); (void)lt_last__;
   unsigned cnt_eps = 0, cnt_emit = 0, cnt_os = 0;
   long long cur_base = 0; int n_cur = 0, max_frame = 0, f0 = 0, status = kStOk, sel = 0; unsigned hash_size = 1000;      // :41 toks_.SetSize(1000)
   unsigned creg[kCurRegs]; int sreg[kCurRegs];
@@ -207,6 +280,7 @@ __global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(De
         else { ab = kInf - best + p.beam_delta; cur_cutoff = kInf; }
         if (kth >= 0) { const float sel_ = dec(block_select_kth(for_keys, kth, sh)); ab = sel_ - best + p.beam_delta; cur_cutoff = sel_; }
       }
+      K3_LT(0);
       { const unsigned want = (unsigned)((float)n_cur * p.hash_ratio); if (want > hash_size) hash_size = want; }      // PossiblyResizeHash (:227-233)
       if (hash_size > (unsigned)p.hash_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
       const float co = -best;
@@ -225,6 +299,7 @@ __global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(De
       for (int i = tid; i < 3 * (kHL / 32); i += kBlock) s_lmark[i] = 0;
       __syncthreads();
       if (block_err(sh)) break;
+      K3_LT(1);
       // ---- pass A: per 64-token chunk of the visit order, the number of emitting arcs and min (tot + adaptive_beam)
       const int nchunks = (n_cur + 63) >> 6;
       auto chunk_tokens = [&](int c, int &i, float &cost, int &beg, int &deg) {
@@ -244,6 +319,7 @@ __global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(De
         if (lane == 0) { q.cmin[c] = cm; q.ccnt[c] = total; }
       }
       __syncthreads();
+      K3_LT(2);
       // exclusive scans over the chunks: bound in force at a chunk's first arc, sequence number of its first arc
       if (wave == 0) {
         unsigned run = enc(next0); int base = 0;
@@ -265,6 +341,7 @@ __global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(De
       if ((long long)m_e + cap > 32ll * p.seq_words_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
       if (block_err(sh)) break;
       nb = cur_base + n_cur;
+      K3_LT(2);
       // ---- pass B: accept against the bound in force at each arc; min cost / min sequence number per destination state; forward links
       {
         const unsigned *cpre = q.cmin + (cap / 64 + 2); const int *cbase = q.ccnt + (cap / 64 + 2);
@@ -313,27 +390,37 @@ __global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(De
         }
       }
       if (block_err(sh)) break;
+      K3_LT(4);
       n_e = sh.n_next;
       if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
       for (int i = tid; i < n_e; i += kBlock) q.c0[i] = dec(tb.cost(tok_slot[i]));      // costs right after ProcessEmitting (the replay starts from them)
       __syncthreads();
     }   // f >= 0
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens made so far
+    K3_LT(4);
     lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt);
+    K3_LT(6);
     // ---- ProcessNonemitting: order-free fixpoint (costs, new tokens, eps links)
     finish_frame<false>(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
     if (block_err(sh)) break;
     const int n = sh.n_next;
-    // ---- closure sub-graph in token space: per token its eps arcs in FST order, destination = token index, or -1 for an arc that fails at
-    // the token's FINAL cost (it then fails at every earlier, higher cost too)
-    if (tid == 0) { ls.n_csr = 0; ls.n_created = 0; }
+    K3_LT(7);
+    // ---- closure sub-graph in "closure id" space.  Only tokens that take part in it get an id: sources (>= 1 eps arc that passes at the
+    // token's FINAL cost -- an arc that fails there fails at every earlier, higher cost too) and their destinations.  Per id: the cost the
+    // replay has seen so far (+inf = not created yet), meta = {first passing arc, number of passing arcs}; per passing arc, in FST order:
+    // {destination id, weight}.
+    if (tid == 0) { ls.n_created = 0; ls.n_csr = 0; }
+    for (int i = tid; i < n; i += kBlock) { K3_AST(&q.rflag[i], 0); K3_AST(&q.rown[i], 0); }
     __syncthreads();
+    // step 1 (wave-cooperative): every eps arc of every token below the cutoff -> slot {destination token | -1, weight} of an uncompacted
+    // CSR, passing arcs counted per source, destinations flagged
     for (int i0 = 0; i0 < n; i0 += kBlock) {
-      const int i = i0 + tid; int deg = 0, ebeg = 0; bool has_eps = false;
+      const int i = i0 + tid; int deg = 0, ebeg = 0; float c = 0.0f;
       if (i < n) {
-        const float c = dec(tb.cost(tok_slot[i])); const int st = tok_state[nb + i];
+        const unsigned cb = tb.cost(tok_slot[i]); c = dec(cb); const int st = tok_state[nb + i];
+        tok_cost[nb + i] = cb;                                 // the frame's final cost (the closure's "expanded at" marker is no longer needed)
         const int2 a = p.offs[st], b = p.offs[st + 1];
-        ebeg = a.y; has_eps = b.x > a.y; deg = (has_eps && c < accept) ? b.x - a.y : 0;
+        ebeg = a.y; deg = (b.x > a.y && c < accept) ? b.x - a.y : 0;
       }
       int incl = deg;
 #pragma unroll
@@ -341,106 +428,97 @@ __global__ __launch_bounds__(kBlock, 1) void k3_decode_forward_literal_kernel(De
       int wbase = 0;
       if (lane == 63) wbase = atomicAdd(&ls.n_csr, incl);
       wbase = __shfl(wbase, 63);
-      if (i < n) { q.crng[i] = make_int2(wbase + incl - deg, deg); q.rflag[i] = (has_eps ? kRfHasEps : 0) | (i < n_e ? kRfExists : 0); q.rown[i] = ebeg; }
-    }
-    __syncthreads();
-    const int n_csr = ls.n_csr;
-    if (n_csr > p.eps_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
-    if (block_err(sh)) break;
-    const bool use_lds = n <= kRN && n_csr <= kRA;
-    float *rcost = use_lds ? l_rcost : q.rcost; int *rflag = use_lds ? l_rflag : q.rflag; int2 *crng = use_lds ? l_crng : q.crng;
-    int *cdst = use_lds ? l_cdst : q.cdst; float *cw = use_lds ? l_cw : q.cw; int *stack = use_lds ? l_stack : q.stack; const int stack_cap = use_lds ? kRS : p.stack_cap;
-    for (int i0 = 0; i0 < n; i0 += kBlock) {
-      const int i = i0 + tid; int beg = 0, deg = 0, base = 0; float c = 0.0f;
-      if (i < n) {
-        const int2 rg = q.crng[i]; base = rg.x; deg = rg.y; beg = q.rown[i]; c = dec(tb.cost(tok_slot[i]));
-        crng[i] = rg; rflag[i] = q.rflag[i]; rcost[i] = i < n_e ? q.c0[i] : kInf;
-      }
-      wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int, int arc, int owner, const ArcRec &r) {
-        const float oc = __shfl(c, owner); const int obase = __shfl(base, owner), obeg = __shfl(beg, owner);
+      const int base = wbase + incl - deg;
+      if (i < n) q.crng[i] = make_int2(base, deg);
+      if (wbase + __shfl(incl, 63) > p.eps_cap) { sh.err = K3_ERR_OVERFLOW; deg = 0; }
+      wave_expand_seq(p.arcs, ebeg, deg, [&](bool valid, int, int arc, int owner, const ArcRec &r) {
+        const float oc = __shfl(c, owner); const int obase = __shfl(base, owner), obeg = __shfl(ebeg, owner), oi = i0 + (tid & ~63) + owner;
         if (valid) {
           int d = -1;
-          if (oc + r.w < accept) { const int s2 = tb.find((int)((unsigned)r.next & ~kEpsFlag)); if (s2 >= 0) d = tb.tok(s2); else sh.err = K3_ERR_HIP; }
-          cdst[obase + (arc - obeg)] = d; cw[obase + (arc - obeg)] = r.w;
+          if (oc + r.w < accept) {
+            const int s2 = tb.find((int)((unsigned)r.next & ~kEpsFlag));
+            if (s2 >= 0) { d = tb.tok(s2); atomicOr(&q.rflag[d], 1); atomicAdd(&q.rown[oi], 1); } else sh.err = K3_ERR_HIP;
+          }
+          q.cdst[obase + (arc - obeg)] = d; q.cw[obase + (arc - obeg)] = r.w;
         }
       });
     }
     __syncthreads();
     if (block_err(sh)) break;
+    for (int i = tid; i < n; i += kBlock) { const int slot = tok_slot[i]; if (slot >= kHL) tb.clear(slot); }      // last use of the table in this frame
+    const int n_cid = block_excl_scan([&](int i) { return (K3_ALD(&q.rown[i]) > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1u : 0u; }, reinterpret_cast<unsigned *>(q.grp), n, sh.redi);
+    const int n_arc = block_excl_scan([&](int i) { return (unsigned)K3_ALD(&q.rown[i]); }, q.lead, n, sh.redi);
+    // mode 0: costs, meta and arcs in LDS; mode 1: costs in LDS, meta / arcs (read-only during the replay) in HBM; mode 2: all in HBM
+    // (mode 0: kRN x (16 B meta + 4 B cost + 4 B creation list) = the table's 12 B x kHL; mode 1: 3 kHL costs in the table, the list where mode 0 keeps its arcs)
+    const int rmode = (n_cid <= kRN && n_arc <= kRA) ? 0 : ((n_cid <= 3 * kHL && n - n_e <= kRA * 2) ? 1 : 2);
+    // LDS arena of the replay: the level-1 table's memory (dead from here until the end of the frame) + the dynamic segment
+    float *rcost = rmode == 2 ? q.rcost : reinterpret_cast<float *>(s_tab) + (rmode == 0 ? 2 * kHL : 0);
+    int4 *meta = rmode == 0 ? reinterpret_cast<int4 *>(s_tab) : q.meta;
+    int2 *AR = rmode == 0 ? reinterpret_cast<int2 *>(smem_raw) : q.arcs2;
+    const unsigned *clist = rmode == 0 ? reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN : rmode == 1 ? reinterpret_cast<unsigned *>(smem_raw) : reinterpret_cast<unsigned *>(q.rflag);
+    // step 2: per involved token its record, per source its passing arcs compacted in FST order
+    for (int i = tid; i < n; i += kBlock) {
+      const int pc = K3_ALD(&q.rown[i]);
+      if (pc > 0 || K3_ALD(&q.rflag[i]) != 0) {
+        const int cid = q.grp[i]; const int abeg = (int)q.lead[i];
+        q.c2t[cid] = i;
+        rcost[cid] = i < n_e ? q.c0[i] : kInf; int d0 = 0, w0 = 0;
+        if (pc > 0) {
+          const int2 rg = q.crng[i]; int k = abeg;
+          for (int a = rg.x; a < rg.x + rg.y; a++) { const int d = q.cdst[a]; if (d >= 0) { const int2 ar = make_int2(q.grp[d], __float_as_int(q.cw[a])); if (k == abeg) { d0 = ar.x; w0 = ar.y; } AR[k++] = ar; } }
+        }
+        meta[cid] = make_int4(abeg, pc, d0, w0);      // the first passing arc rides along: most sources have exactly one
+      }
+    }
+    // the initial queue (:845-850): the tokens ProcessEmitting made, in HashList order, that can expand (a token without a passing arc at its
+    // final cost pops as a no-op); it is consumed from its back
+    const int n_iq = block_excl_scan([&](int r) { return K3_ALD(&q.rown[ord_nxt[r]]) > 0 ? 1u : 0u; }, reinterpret_cast<unsigned *>(q.dense), n_e, sh.redi);
+    for (int r = tid; r < n_e; r += kBlock) { const int i = ord_nxt[r]; if (K3_ALD(&q.rown[i]) > 0) q.iq[q.dense[r]] = q.grp[i]; }
+    __syncthreads();
+    K3_LT(8);
+#ifdef K3_LIT_PROF
+    if (tid == 0) { sh.prof[13] += n; sh.prof[14] += rmode == 0 ? 1 : 0; sh.prof[15] += 1; }
+    const long long rp_t0 = (long long)__builtin_readcyclecounter();
+#endif
     // ---- replay of the LIFO queue (:851-896) by one wavefront: only the ORDER in which the closure creates tokens comes out of it
     if (wave == 0) {
-      int sp = 0, pcur = n_e, created = 0, err = 0;
-      for (int iters = 0;; iters++) {
-        if (iters > (1 << 24)) { err = 2; break; }      // cannot happen (every pop follows a cost decrease); keeps a bug from hanging the GPU
-        int e = -1;
-        if (sp > 0) { e = stack[--sp]; }
-        else {
-          while (pcur > 0 && e < 0) {      // the initial queue = order1 filtered by "state has eps arcs", consumed from its back
-            const int r = pcur - 1 - lane; const int i = r >= 0 ? ord_nxt[r] : -1;
-            const bool he = i >= 0 && (rflag[i] & kRfHasEps);
-            const unsigned long long mk = __ballot(he);
-            if (mk) { const int first = __ffsll((long long)mk) - 1; e = __shfl(i, first); pcur = pcur - 1 - first; }
-            else pcur = pcur > 64 ? pcur - 64 : 0;
-          }
-          if (e < 0) break;
-        }
-        const float c = rcost[e]; const int2 rg = crng[e];
-        if (!(c < accept)) continue;
-        for (int k0 = 0; k0 < rg.y; k0 += 64) {
-          const int k = k0 + lane; const bool v = k < rg.y;
-          const int d = v ? cdst[rg.x + k] : -1; const float w = v ? cw[rg.x + k] : 0.0f;
-          const float tot = c + w; const bool ok = d >= 0 && tot < accept;
-          // two arcs of this batch into the same token must be applied one after the other
-          if (ok) s_own[d & 1023] = lane;
-          __threadfence_block();
-          const bool clash = ok && s_own[d & 1023] != lane;
-          const unsigned long long okm = __ballot(ok);
-          if (__ballot(clash) == 0ull) {
-            const int fl = ok ? rflag[d] : 0; const float old = ok ? rcost[d] : 0.0f;
-            const bool isnew = ok && !(fl & kRfExists), better = ok && (fl & kRfExists) && old > tot, changed = isnew || better;
-            const unsigned long long nm = __ballot(isnew);
-            if (isnew) { rflag[d] = fl | kRfExists; q.label[d] = m_e + (unsigned)(created + __popcll(nm & ((1ull << lane) - 1ull))); }
-            created += __popcll(nm);
-            if (changed) rcost[d] = tot;
-            const bool push = changed && (fl & kRfHasEps);
-            const unsigned long long pm = __ballot(push);
-            if (sp + __popcll(pm) > stack_cap) { err = 1; break; }
-            if (push) stack[sp + __popcll(pm & ((1ull << lane) - 1ull))] = d;
-            sp += __popcll(pm);
-          } else {
-            for (unsigned long long rest = okm; rest; rest &= rest - 1) {
-              const int jl = __ffsll((long long)rest) - 1; const int dj = __shfl(d, jl); const float tj = __shfl(tot, jl);
-              const int fl = rflag[dj]; const float old = rcost[dj];
-              const bool isnew = !(fl & kRfExists), changed = isnew || old > tj;
-              if (isnew) { if (lane == 0) { rflag[dj] = fl | kRfExists; q.label[dj] = m_e + (unsigned)created; } created++; }
-              if (changed && lane == 0) rcost[dj] = tj;
-              if (changed && (fl & kRfHasEps)) { if (sp + 1 > stack_cap) { err = 1; break; } if (lane == 0) stack[sp] = dj; sp++; }
-              __threadfence_block();
-            }
-            if (err) break;
-          }
-          __threadfence_block();
-        }
-        if (err) break;
-      }
+      __builtin_amdgcn_s_setprio(3);      // one wavefront on a dependent chain: let it issue ahead of the other workgroup's parallel phases
+      int created = 0, err = 0, pops = 0;
+      // (separate instantiations so that mode 0 compiles to LDS instructions only: a flat access would wait for every outstanding global access)
+      if (rmode == 0) lit_replay<0>(reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw), reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
+                                    reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, q.iq, n_iq, accept, s_own, &created, &err, &pops);
+      else if (rmode == 1) lit_replay<1>(reinterpret_cast<float *>(s_tab), q.meta, q.arcs2, reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
+                                         reinterpret_cast<unsigned *>(smem_raw), q.iq, n_iq, accept, s_own, &created, &err, &pops);
+      else lit_replay<2>(q.rcost, q.meta, q.arcs2, q.stack, p.stack_cap, reinterpret_cast<unsigned *>(q.rflag), q.iq, n_iq, accept, s_own, &created, &err, &pops);
+      __builtin_amdgcn_s_setprio(0);
+#ifdef K3_LIT_PROF
+      if (lane == 0) { sh.prof[12] += pops; if (rmode != 0) { sh.prof[5] += pops; sh.prof[3] += (long long)__builtin_readcyclecounter() - rp_t0; } }
+#endif
       if (lane == 0) { ls.n_created = created; if (err) sh.err = err == 2 ? K3_ERR_HIP : K3_ERR_OVERFLOW; }
     }
     __syncthreads();
+    K3_LT(9);
     if (block_err(sh)) break;
     if (n_e + ls.n_created != n) { if (tid == 0) sh.err = K3_ERR_HIP; }      // every token of the fixpoint must have been created by the replay
     if (block_err(sh)) break;
+    for (int k = tid; k < ls.n_created; k += kBlock) K3_AST(&q.label[q.c2t[clist[k]]], m_e + (unsigned)k);      // creation labels of the closure's tokens      // creation labels of the closure's tokens
+    for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
+    __syncthreads();
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
     lit_hash_order(q, sh, n, m_e + (unsigned)ls.n_created, tok_state + nb, hash_size, ord_nxt);
+    K3_LT(10);
     // ---- publish the frame: final costs into the pool, empty table, idle labels
-    for (int i = tid; i < n; i += kBlock) { const int slot = tok_slot[i]; tok_cost[nb + i] = tb.cost(slot); if (slot >= kHL) tb.clear(slot); K3_AST(&q.label[i], kLabelNone); }
+    for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], kLabelNone);
     __syncthreads();
-    for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }
-    __syncthreads();
+    K3_LT(11);
     cur_base = nb; n_cur = n; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1;
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
   }
   { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { atomicAdd(&sh.n_eps, a); atomicAdd(&sh.n_emit, b); atomicAdd(&sh.n_os, c); } }
   __syncthreads();
+#ifdef K3_LIT_PROF
+  if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
+#endif
   if (tid == 0) {
     LaneInfo &li = p.info[L];
     li.n_tokens = cur_base + n_cur; li.n_links = sh.n_link; li.n_cands = (long long)sh.n_emit; li.n_eps = (long long)sh.n_eps; li.max_frame_tokens = max_frame;

@@ -18,10 +18,21 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
   __shared__ float As[64][17], Bs[16][65];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  f32x16 acc;
+  // The accumulation order is the contract: like the blocked CPU sgemm the reference calls, k runs in ascending order
+  // inside blocks of 384 and every block's sum is added to the running result, which starts from beta * C.
+  f32x16 acc, total;
+  const int col = n0 + wn * 32 + (lane & 31);
 #pragma unroll
-  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+  for (int r = 0; r < 16; r++) {
+    acc[r] = 0.0f; total[r] = 0.0f;
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (beta != 0.0f && row < M && col < N) total[r] = beta * C[(long long)row * ldc + col];
+  }
   for (int k0 = 0; k0 < K; k0 += 16) {
+    if (k0 != 0 && k0 % 384 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) { total[r] += alpha * acc[r]; acc[r] = 0.0f; }
+    }
     for (int e = tid; e < 64 * 16; e += 256) {
       const int r = e >> 4, k = e & 15, gm = m0 + r, gk = k0 + k;
       As[r][k] = (gm < M && gk < K) ? (ta ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk]) : 0.0f;
@@ -36,12 +47,11 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
     }
     __syncthreads();
   }
-  const int col = n0 + wn * 32 + (lane & 31);
   if (col < N) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < M) { float *c = C + (long long)row * ldc + col; *c = (beta == 0.0f) ? alpha * acc[r] : alpha * acc[r] + beta * *c; }
+      if (row < M) C[(long long)row * ldc + col] = total[r] + alpha * acc[r];
     }
   }
 }
@@ -76,6 +86,11 @@ __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {
     *d = x;
   }
 }
+
+// element-wise vector kernels the CuVector side of the adapter needs (model preparation: BatchNormComponent::ComputeDerived, nnet-normalize-component.cc:205-247)
+template <typename TS, typename TD> __global__ void k3_vec_convert_kernel(const TS *s, TD *d, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) d[i] = (TD)s[i]; }
+__global__ void k3_vec_pow_kernel(const float *s, float *d, int n, float power) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) d[i] = powf(s[i], power); }
+__global__ void k3_vec_add_vec_vec_kernel(float alpha, const float *a, const float *b, float beta, float *d, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) d[i] = alpha * a[i] * b[i] + beta * d[i]; }
 
 int launch_ew(const EwParams &p, void *stream) {
   if (p.rows <= 0 || p.cols <= 0) return K3_OK;
@@ -113,3 +128,30 @@ extern "C" int k3_mat_copy_from_mat(float *C, int64_t ldc, int32_t rows, int32_t
 extern "C" int k3_mat_add_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_A && lda >= (trans_a ? rows : cols), "k3_mat_add_mat: bad source"); EwParams p = mk(trans_a ? kOpAddMatT : kOpAddMat, C, ldc, rows, cols); p.S = d_A; p.lds = lda; p.a = alpha; return launch_ew(p, st); }
 extern "C" int k3_mat_copy_rows(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_indexes && lds >= cols, "k3_mat_copy_rows: bad source"); EwParams p = mk(kOpCopyRows, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_indexes; return launch_ew(p, st); }
 extern "C" int k3_mat_add_rows(float alpha, const float *d_src, int64_t lds, const int32_t *d_indexes, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_indexes && lds >= cols, "k3_mat_add_rows: bad source"); EwParams p = mk(kOpAddRows, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_indexes; p.a = alpha; return launch_ew(p, st); }
+
+// ---- vectors (CuVectorBase): everything else a vector needs is the matrix entry points on a [1 x dim] matrix
+extern "C" int k3_vec_convert(const void *d_src, int32_t src_is_f64, void *d_dst, int32_t dst_is_f64, int32_t n, void *st) {      // CuVectorBase<Real>::CopyFromVec(const CuVectorBase<OtherReal>&)
+  K3_REQUIRE(d_src && d_dst && n >= 0, "k3_vec_convert: bad argument");
+  if (n == 0) return K3_OK;
+  const dim3 g((n + 255) / 256), b(256);
+  if (src_is_f64 && !dst_is_f64) hipLaunchKernelGGL((k3_vec_convert_kernel<double, float>), g, b, 0, (hipStream_t)st, (const double *)d_src, (float *)d_dst, n);
+  else if (!src_is_f64 && dst_is_f64) hipLaunchKernelGGL((k3_vec_convert_kernel<float, double>), g, b, 0, (hipStream_t)st, (const float *)d_src, (double *)d_dst, n);
+  else if (src_is_f64) hipLaunchKernelGGL((k3_vec_convert_kernel<double, double>), g, b, 0, (hipStream_t)st, (const double *)d_src, (double *)d_dst, n);
+  else hipLaunchKernelGGL((k3_vec_convert_kernel<float, float>), g, b, 0, (hipStream_t)st, (const float *)d_src, (float *)d_dst, n);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+extern "C" int k3_vec_pow(const float *d_src, float *d_dst, int32_t n, float power, void *st) {                                         // CuVectorBase::Pow / ApplyPow
+  K3_REQUIRE(d_src && d_dst && n >= 0, "k3_vec_pow: bad argument");
+  if (n == 0) return K3_OK;
+  hipLaunchKernelGGL(k3_vec_pow_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, d_src, d_dst, n, power);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+extern "C" int k3_vec_add_vec_vec(float alpha, const float *d_a, const float *d_b, float beta, float *d_v, int32_t n, void *st) {        // CuVectorBase::AddVecVec: v = alpha a .* b + beta v
+  K3_REQUIRE(d_a && d_b && d_v && n >= 0, "k3_vec_add_vec_vec: bad argument");
+  if (n == 0) return K3_OK;
+  hipLaunchKernelGGL(k3_vec_add_vec_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, alpha, d_a, d_b, beta, d_v, n);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
