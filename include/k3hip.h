@@ -59,6 +59,12 @@ int32_t k3_feat_num_frames(const k3_feat_plan *plan, int64_t nsamp); /* NumFrame
 int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_t *d_wave_offsets,
                           const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
                           float *d_feats, int64_t ld, void *stream);
+/* The same with the samples as 16-bit PCM, the way WaveData reads them from a RIFF file (feat/wave-reader.cc:187-244) before it converts
+ * them to float: the values are identical, the kernel reads 2 instead of 4 bytes per sample (480 B per frame) and the host
+ * ships half the bytes over PCIe. */
+int k3_feat_compute_batch_pcm16(k3_feat_plan *plan, const int16_t *d_waves, const int64_t *d_wave_offsets,
+                                const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
+                                float *d_feats, int64_t ld, void *stream);
 /* Per-utterance CMVN in place: AccCmvnStats + ApplyCmvn (transform/cmvn.cc:30-115), what
  * `compute-cmvn-stats | apply-cmvn [--norm-vars]` do with one utterance per speaker.
  * fp64 accumulators like the reference.  d_stats (optional, may be NULL): [U x 2 x (dim+1)] doubles. */
@@ -249,6 +255,9 @@ int k3_mat_add_rows(float alpha, const float *d_src, int64_t lds, const int32_t 
 int k3_vec_convert(const void *d_src, int32_t src_is_f64, void *d_dst, int32_t dst_is_f64, int32_t n, void *stream);   /* CopyFromVec(const CuVectorBase<OtherReal>&) */
 int k3_vec_pow(const float *d_src, float *d_dst, int32_t n, float power, void *stream);                                /* Pow / ApplyPow */
 int k3_vec_add_vec_vec(float alpha, const float *d_a, const float *d_b, float beta, float *d_v, int32_t n, void *stream);  /* AddVecVec: v = alpha a .* b + beta v */
+int k3_vec_unary(int32_t op, float *d_v, int32_t n, void *stream);   /* op 0 ApplyLog, 1 ApplyExp, 2 InvertElements */
+/* CuVectorBase<double> (a model's accumulated statistics): op 0 Scale(alpha); 1 Pow: v = a ^ alpha; 2 AddVec: v = alpha a + beta v; 3 AddVecVec: v = alpha a .* b + beta v */
+int k3_vec_f64(int32_t op, double alpha, const double *d_a, const double *d_b, double beta, double *d_v, int32_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@
 //   ComputeLifterCoeffs feat/mel-computations.cc:253-259, AccCmvnStats/ApplyCmvn transform/cmvn.cc:30-115.
 // The FFT butterfly order differs from split-radix (round-off level only; parity bound 1e-4 on log-mel).
 #include "k3_common.h"
+#include <mutex>
 #include <cmath>
 #include <cfloat>
 #include <vector>
@@ -89,7 +90,9 @@ __device__ __forceinline__ float group_sum16(float x) {
   return x;
 }
 
-__global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const float *__restrict__ waves,
+// TS = float (CuVector<BaseFloat> waves, the reference's interface) or int16_t (PCM16 as it sits in a wav file: 2 of the 480 B / frame of SURVEY 8d)
+template <typename TS>
+__global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const TS *__restrict__ waves,
                                                           const int64_t *__restrict__ wave_off,
                                                           const int64_t *__restrict__ frame_off, int num_utts,
                                                           int64_t total_frames, float *__restrict__ feats, int64_t ld,
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const f
     const bool valid = g < total_frames;
     float x0[16], x1[16];
     int64_t n = 0, start = 0;
-    const float *base = waves;
+    const TS *base = waves;
     if (valid) {
       // utterance lookup: largest u with frame_off[u] <= g
       int lo = 0, hi = num_utts;   // invariant frame_off[lo] <= g < frame_off[hi]
@@ -145,11 +148,11 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const f
       const int s = 2 * (l + 16 * j);
       float a = 0.0f, b = 0.0f;
       if (interior) {
-        if (s < L) a = base[start + s];
-        if (s + 1 < L) b = base[start + s + 1];
+        if (s < L) a = (float)base[start + s];
+        if (s + 1 < L) b = (float)base[start + s + 1];
       } else if (valid) {
-        if (s < L) { int64_t si = start + s; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; a = base[si]; }
-        if (s + 1 < L) { int64_t si = start + s + 1; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; b = base[si]; }
+        if (s < L) { int64_t si = start + s; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; a = (float)base[si]; }
+        if (s + 1 < L) { int64_t si = start + s + 1; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; b = (float)base[si]; }
       }
       x0[j] = a; x1[j] = b;
     }
@@ -636,24 +639,30 @@ extern "C" int32_t k3_feat_num_frames(const k3_feat_plan *plan, int64_t nsamp) {
   return (int32_t)((nsamp + shift / 2) / shift);
 }
 
-extern "C" int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_t *d_wave_offsets,
-                                     const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
-                                     float *d_feats, int64_t ld, void *stream) {
+template <typename TS>
+static int feat_launch(k3_feat_plan *plan, const TS *d_waves, const int64_t *d_wave_offsets, const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
+                       float *d_feats, int64_t ld, void *stream) {
   K3_REQUIRE(plan && d_waves && d_wave_offsets && d_frame_offsets && d_feats, "k3_feat_compute_batch: null argument");
   K3_REQUIRE(num_utts >= 0 && total_frames >= 0 && ld >= plan->dim, "k3_feat_compute_batch: bad sizes");
   if (total_frames == 0 || num_utts == 0) return K3_OK;
   const int frames_per_block = 64;
   const int64_t blocks = (total_frames + frames_per_block - 1) / frames_per_block;
   K3_REQUIRE(blocks < (1ll << 31), "k3_feat_compute_batch: too many frames for one launch");
-  static bool attr_set = false;
-  if (!attr_set) {
-    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_feat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k3_feat_kernel, dim3((unsigned)blocks), dim3(kThreads), plan->lds_bytes, (hipStream_t)stream, plan->prm,
+  static std::once_flag once; int rc = K3_OK;
+  std::call_once(once, [&]() { rc = [&]() -> int { K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_feat_kernel<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return K3_OK; }(); });
+  if (rc) return rc;
+  hipLaunchKernelGGL(k3_feat_kernel<TS>, dim3((unsigned)blocks), dim3(kThreads), plan->lds_bytes, (hipStream_t)stream, plan->prm,
                      d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
+}
+extern "C" int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_t *d_wave_offsets, const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
+                                     float *d_feats, int64_t ld, void *stream) {
+  return feat_launch(plan, d_waves, d_wave_offsets, d_frame_offsets, num_utts, total_frames, d_feats, ld, stream);
+}
+extern "C" int k3_feat_compute_batch_pcm16(k3_feat_plan *plan, const int16_t *d_waves, const int64_t *d_wave_offsets, const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
+                                           float *d_feats, int64_t ld, void *stream) {
+  return feat_launch(plan, d_waves, d_wave_offsets, d_frame_offsets, num_utts, total_frames, d_feats, ld, stream);
 }
 
 extern "C" int k3_cmvn_offline_batch(float *d_feats, int64_t ld, int32_t dim, const int64_t *d_frame_offsets,

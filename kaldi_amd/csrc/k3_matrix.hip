@@ -89,8 +89,20 @@ __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {
 
 // element-wise vector kernels the CuVector side of the adapter needs (model preparation: BatchNormComponent::ComputeDerived, nnet-normalize-component.cc:205-247)
 template <typename TS, typename TD> __global__ void k3_vec_convert_kernel(const TS *s, TD *d, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) d[i] = (TD)s[i]; }
+__global__ void k3_vec_unary_kernel(int op, float *d, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) { const float x = d[i]; d[i] = op == 0 ? logf(x) : op == 1 ? expf(x) : 1.0f / x; } }
 __global__ void k3_vec_pow_kernel(const float *s, float *d, int n, float power) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) d[i] = powf(s[i], power); }
 __global__ void k3_vec_add_vec_vec_kernel(float alpha, const float *a, const float *b, float beta, float *d, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) d[i] = alpha * a[i] * b[i] + beta * d[i]; }
+
+// float64 vectors: accumulated statistics of a model (BatchNorm sums, NonlinearComponent value / derivative sums) are CuVector<double>
+__global__ void k3_vec64_kernel(int op, double alpha, const double *a, const double *b, double beta, double *d, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  switch (op) {
+    case 0: d[i] = d[i] * alpha; break;                                  // Scale
+    case 1: d[i] = pow(a[i], alpha); break;                              // Pow
+    case 2: d[i] = alpha * a[i] + beta * d[i]; break;                    // AddVec
+    case 3: d[i] = alpha * a[i] * b[i] + beta * d[i]; break;             // AddVecVec
+  }
+}
 
 int launch_ew(const EwParams &p, void *stream) {
   if (p.rows <= 0 || p.cols <= 0) return K3_OK;
@@ -131,8 +143,8 @@ extern "C" int k3_mat_add_rows(float alpha, const float *d_src, int64_t lds, con
 
 // ---- vectors (CuVectorBase): everything else a vector needs is the matrix entry points on a [1 x dim] matrix
 extern "C" int k3_vec_convert(const void *d_src, int32_t src_is_f64, void *d_dst, int32_t dst_is_f64, int32_t n, void *st) {      // CuVectorBase<Real>::CopyFromVec(const CuVectorBase<OtherReal>&)
-  K3_REQUIRE(d_src && d_dst && n >= 0, "k3_vec_convert: bad argument");
   if (n == 0) return K3_OK;
+  K3_REQUIRE(d_src && d_dst && n > 0, "k3_vec_convert: bad argument");
   const dim3 g((n + 255) / 256), b(256);
   if (src_is_f64 && !dst_is_f64) hipLaunchKernelGGL((k3_vec_convert_kernel<double, float>), g, b, 0, (hipStream_t)st, (const double *)d_src, (float *)d_dst, n);
   else if (!src_is_f64 && dst_is_f64) hipLaunchKernelGGL((k3_vec_convert_kernel<float, double>), g, b, 0, (hipStream_t)st, (const float *)d_src, (double *)d_dst, n);
@@ -142,16 +154,33 @@ extern "C" int k3_vec_convert(const void *d_src, int32_t src_is_f64, void *d_dst
   return K3_OK;
 }
 extern "C" int k3_vec_pow(const float *d_src, float *d_dst, int32_t n, float power, void *st) {                                         // CuVectorBase::Pow / ApplyPow
-  K3_REQUIRE(d_src && d_dst && n >= 0, "k3_vec_pow: bad argument");
   if (n == 0) return K3_OK;
+  K3_REQUIRE(d_src && d_dst && n > 0, "k3_vec_pow: bad argument");
   hipLaunchKernelGGL(k3_vec_pow_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, d_src, d_dst, n, power);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }
 extern "C" int k3_vec_add_vec_vec(float alpha, const float *d_a, const float *d_b, float beta, float *d_v, int32_t n, void *st) {        // CuVectorBase::AddVecVec: v = alpha a .* b + beta v
-  K3_REQUIRE(d_a && d_b && d_v && n >= 0, "k3_vec_add_vec_vec: bad argument");
   if (n == 0) return K3_OK;
+  K3_REQUIRE(d_a && d_b && d_v && n > 0, "k3_vec_add_vec_vec: bad argument");
   hipLaunchKernelGGL(k3_vec_add_vec_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, alpha, d_a, d_b, beta, d_v, n);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+
+// float64 vectors (cudamatrix/cu-vector.h): op 0 Scale(alpha), 1 Pow(a, alpha) -> v, 2 AddVec: v = alpha a + beta v, 3 AddVecVec: v = alpha a .* b + beta v
+extern "C" int k3_vec_f64(int32_t op, double alpha, const double *d_a, const double *d_b, double beta, double *d_v, int32_t n, void *st) {
+  if (n == 0) return K3_OK;
+  K3_REQUIRE(d_v && n > 0 && op >= 0 && op <= 3 && (op == 0 || d_a) && (op != 3 || d_b), "k3_vec_f64: bad argument");
+  hipLaunchKernelGGL(k3_vec64_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, op, alpha, d_a, d_b, beta, d_v, n);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+
+extern "C" int k3_vec_unary(int32_t op, float *d_v, int32_t n, void *st) {      // op 0 ApplyLog, 1 ApplyExp, 2 InvertElements
+  if (n == 0) return K3_OK;
+  K3_REQUIRE(d_v && n > 0 && op >= 0 && op <= 2, "k3_vec_unary: bad argument");
+  hipLaunchKernelGGL(k3_vec_unary_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, op, d_v, n);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }

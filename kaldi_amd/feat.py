@@ -52,11 +52,13 @@ class SpectralFeatures:
         return (torch.tensor(wo, dtype=torch.int64, device=device), torch.tensor(fo, dtype=torch.int64, device=device), fo[-1], fo)
 
     def ComputeFeatures(self, waves, wave_offsets, frame_offsets, total_frames, out=None):
-        """waves: float32 [sum nsamp] on the GPU; returns float32 [total_frames, dim]."""
-        assert waves.is_cuda and waves.dtype == torch.float32 and waves.is_contiguous()
+        """waves: float32 (CuVector<BaseFloat>, the reference's interface) or int16 (PCM16 as read from a wav file: same values, half the
+        bytes) [sum nsamp] on the GPU; returns float32 [total_frames, dim]."""
+        assert waves.is_cuda and waves.dtype in (torch.float32, torch.int16) and waves.is_contiguous()
         if out is None:
             out = torch.empty((total_frames, self.dim), dtype=torch.float32, device=waves.device)
-        _l.check(self._L.k3_feat_compute_batch(self._h, waves.data_ptr(), wave_offsets.data_ptr(), frame_offsets.data_ptr(),
+        fn = self._L.k3_feat_compute_batch if waves.dtype == torch.float32 else self._L.k3_feat_compute_batch_pcm16
+        _l.check(fn(self._h, waves.data_ptr(), wave_offsets.data_ptr(), frame_offsets.data_ptr(),
                                                wave_offsets.numel() - 1, int(total_frames), out.data_ptr(), out.stride(0), _stream()))
         return out
 

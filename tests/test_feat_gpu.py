@@ -141,3 +141,18 @@ def test_hip_cmvn_online_batch_ragged_and_errors(cmvn_online_golden):
     with pytest.raises(RuntimeError): feat.ApplyCmvnOnline(feats, offs, bad)
     with pytest.raises(RuntimeError): feat.ApplyCmvnOnline(feats, offs, g["global"], cmn_window=10, speaker_frames=20, global_frames=5)
     with pytest.raises(RuntimeError): feat.ApplyCmvnOnline(feats, offs, g["global"], norm_means=False, norm_vars=True)
+
+
+def test_pcm16_input_gives_the_same_bits_as_float_input():
+    """k3_feat_compute_batch_pcm16: the samples as 16-bit PCM (what WaveData holds before its conversion to float) -> identical features"""
+    import torch
+    from kaldi_amd import feat
+    rng = np.random.default_rng(3); dev = torch.device("cuda:0")
+    lens = [16000, 401, 23001, 7777]
+    pcm = [np.clip(np.rint(rng.normal(0, 3000, n)), -32768, 32767).astype(np.int16) for n in lens]
+    for opts in (feat.fbank_options(dither=0.0, num_bins=40), feat.mfcc_options(dither=0.0) if hasattr(feat, "mfcc_options") else feat.fbank_options(dither=0.0, num_bins=23, snip_edges=False)):
+        sf = feat.SpectralFeatures(opts)
+        wo, fo, total, _ = sf.offsets(lens, dev)
+        a = sf.ComputeFeatures(torch.from_numpy(np.concatenate(pcm).astype(np.float32)).to(dev), wo, fo, total)
+        b = sf.ComputeFeatures(torch.from_numpy(np.concatenate(pcm)).to(dev), wo, fo, total)
+        assert torch.equal(a, b)
