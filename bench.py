@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- RTFx of the batched acoustic pipeline on MI355X (driver contract in the task statement).
+"""bench.py -- RTFx of the batched acoustic pipeline on MI355X (driver contract in the task statement; metric definition SURVEY 8d).
 
-A "step" = one pass of the hot path over one batch of synthetic 16 kHz audio already resident in HBM:
-  fbank (k3_feat_compute_batch) -> 17-layer TDNN-F forward (k3_nnet_forward) -> HCLG lattice decode
-  (k3_decoder_decode_batch: token passing + lattice-beam pruning on the GPU) -> raw lattices compacted and copied to
-  host buffers (k3_decoder_get_raw_lattices).  Lattice determinisation is host work outside the path.
-value = audio seconds processed by ALL ranks / wall seconds (max over ranks).
-Weak scaling: every rank decodes its own --utts utterances; the decoding graph is built on rank 0 and broadcast ONCE
-over RCCL (before the timed region); no data-path collective.
-Extra objects in the JSON line: "roofline" (the dominant kernel vs its CDNA4 bound, timed with HIP events on the
-launch stream), "roofline_gemm" (the TDNN-F affine GEMMs vs the FP32 MFMA peak), "stage_ms", "decode_stats" and
-"cpu_baseline" (the reference's own compute-fbank-feats + nnet3-compute binaries from oracle/_ref and the restated
-LatticeFasterDecoder oracle on ONE host core; rank 0, N=1 only, bounded sample)."""
-import argparse, json, os, subprocess, sys, tempfile, time
+A "step" = one pass of the hot path over one batch of synthetic 16 kHz audio, from the first waveform byte in (page-locked) HOST memory to the
+last lattice handed to the writer:
+  PCM16 H2D -> fbank (k3_feat_compute_batch_pcm16) -> 17-layer TDNN-F forward (k3_nnet_forward) -> HCLG lattice decode (k3_decoder_decode_batch:
+  token passing + lattice-beam pruning on the GPU) -> raw lattices compacted and copied to host buffers (k3_decoder_get_raw_lattices)
+  -> per utterance Connect + lattice determinization on a pool of host threads (k3h_postprocess_batch), one batch behind the GPU.
+value = audio seconds processed by ALL ranks / wall seconds (max over ranks), everything above inside the timed region (the determinization
+of the last batch included).
+
+Decoder mode.  `value` is measured with k3_decoder_config.literal_order = 1: the raw lattices are then IDENTICAL to the reference's CPU
+LatticeFasterDecoder (states, arcs, labels, cost bits; tests/test_decoder_literal_gpu.py checks 32 of this workload's utterances against the
+reference's own decoder source).  `value_two_pass` is the same pipeline with the order-independent fast decoder (default mode), whose lattices
+are a close but NOT identical relative of the reference's at this configuration (profiles/r02_decoder_parity_bench_config.json).
+
+Weak scaling: every rank decodes its own --utts utterances; the decoding graph is built on rank 0 and broadcast ONCE over RCCL (before the
+timed region); no data-path collective.
+Extra objects in the JSON line: "roofline" (the dominant kernel vs its CDNA4 bound, timed with HIP events on the launch stream),
+"roofline_gemm" (the TDNN-F affine GEMMs vs the FP32 MFMA peak), "stage_ms", "decode_stats", "value_kernels" and "cpu_baseline" (the reference's
+own compute-fbank-feats + nnet3-compute + LatticeFasterDecoder binaries from oracle/_ref on the host cores; rank 0, N=1 only, bounded sample)."""
+import argparse, ctypes, json, os, subprocess, sys, tempfile, time
+from concurrent.futures import ThreadPoolExecutor
 import numpy as np, torch
 import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -20,56 +28,46 @@ sys.path.insert(0, ROOT)
 
 BEAM, LATTICE_BEAM, MAX_ACTIVE = 15.0, 8.0, 10000      # BASELINE.json configs[2]: beam 15; recipes' lattice-beam 8; CudaDecoderConfig max-active
 
-def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, n_utts=6):
-    """Same workload on ONE host core, bounded sample: reference binaries for fbank + nnet3 (when oracle/_ref was
-    built; the GPU box gets the prebuilt files), restated LatticeFasterDecoder (oracle) for the decode leg."""
-    from oracle import kaldi_io as kio, lattice_oracle as lo
+def _cpu_worker(job):
+    """one host core: reference compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder::Decode on its utterances; returns (audio_s, wall_s, stage seconds)"""
+    from oracle import kaldi_io as kio, lattice_oracle as lo, ref_decoder as rd
     from kaldi_amd import synth
+    wid, seeds, utt_seconds, model_path, graph, num_pdfs = job
     bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
     with tempfile.TemporaryDirectory() as td:
         scp = []
-        for i in range(n_utts):
-            kio.write_wav(f"{td}/u{i}.wav", synth.gaussian_pcm16(int(16000 * utt_seconds), 1234 + i)); scp.append(f"u{i} {td}/u{i}.wav")
+        for s in seeds:
+            kio.write_wav(f"{td}/u{s}.wav", synth.gaussian_pcm16(int(16000 * utt_seconds), s)); scp.append(f"u{s} {td}/u{s}.wav")
         open(f"{td}/wav.scp", "w").write("\n".join(scp) + "\n")
-        audio = n_utts * utt_seconds
-        if os.path.exists(os.path.join(bindir, "nnet3-compute")):
-            env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
-            # untimed warm-up on a 1 s utterance: pages the binaries and MKL in (a cold first exec costs ~10 s on a fresh box)
-            kio.write_wav(f"{td}/w.wav", synth.gaussian_pcm16(16000, 99)); open(f"{td}/w.scp", "w").write(f"w {td}/w.wav\n")
-            subprocess.check_call([f"{bindir}/compute-fbank-feats", "--dither=0", "--num-mel-bins=40", f"scp:{td}/w.scp", f"ark:{td}/wf.ark"], env=env, stderr=subprocess.DEVNULL)
-            subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/wf.ark", f"ark:{td}/wo.ark"], env=env, stderr=subprocess.DEVNULL)
-            t0 = time.time()
-            subprocess.check_call([f"{bindir}/compute-fbank-feats", "--dither=0", "--num-mel-bins=40", f"scp:{td}/wav.scp", f"ark:{td}/f.ark"], env=env, stderr=subprocess.DEVNULL)
-            t1 = time.time()
-            subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], env=env, stderr=subprocess.DEVNULL)
-            t2 = time.time()
-            lls = kio.read_ark(f"{td}/o.ark"); front = "reference compute-fbank-feats (%.0fx RT) + reference nnet3-compute (%.0fx RT)" % (audio / (t1 - t0), audio / (t2 - t1))
-        else:
-            from oracle import feat_oracle as fo, nnet3_oracle as no
-            net = no.read_nnet(model_path); t0 = time.time(); lls = {}
-            for i in range(n_utts):
-                w, _ = kio.read_wav(f"{td}/u{i}.wav")
-                lls[f"u{i}"] = no.compute(net, fo.compute_features(w.astype(np.float32), fo.fbank_opts(dither=0.0, num_bins=40)), 3)
-            t2 = time.time(); front = "oracle fbank (C) + oracle nnet3 (numpy)"
-        cfg = lo.Config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE); t2p = synth.tid2pdf(num_pdfs)
-        dec_s = None
-        if front.startswith("reference"):
-            # decode leg: the reference's own decoder/lattice-faster-decoder.cc (compiled unmodified against the OpenFst stand-in of
-            # oracle/ref_tools/minifst); the time spent inside LatticeFasterDecoder::Decode() is reported by the binary itself
-            try:
-                from oracle import ref_decoder as rd
-                if rd.available(): dec_s = sum(rd.decode(graph, lls[k], t2p, cfg)["decode_seconds"] for k in sorted(lls))
-            except Exception as e:
-                print("cpu_baseline: reference decoder binary failed (%s); timing the restated decoder instead" % e, file=sys.stderr); dec_s = None
-        if dec_s is not None:
-            return {"value": audio / ((t2 - t0) + dec_s), "unit": "RTFx (audio-s/wall-s)", "cores": 1, "kind": "reference",
-                    "sample": f"{n_utts} x {utt_seconds:g} s utts, 1 core: {front} + reference LatticeFasterDecoder::Decode ({audio / dec_s:.0f}x RT; "
-                              "decoder/lattice-faster-decoder.cc compiled unmodified, FST containers from oracle/ref_tools/minifst because OpenFst is not vendored)"}
-        t3 = time.time()
-        for k in sorted(lls): lo.decode(graph, lls[k], t2p, cfg, mode=0)
-        t4 = time.time()
-        return {"value": audio / ((t2 - t0) + (t4 - t3)), "unit": "RTFx (audio-s/wall-s)", "cores": 1, "kind": "port",
-                "sample": f"{n_utts} x {utt_seconds:g} s utts, 1 core: {front} + restated LatticeFasterDecoder oracle ({audio / (t4 - t3):.0f}x RT)"}
+        t0 = time.time()
+        subprocess.check_call([f"{bindir}/compute-fbank-feats", "--dither=0", "--num-mel-bins=40", f"scp:{td}/wav.scp", f"ark:{td}/f.ark"], env=env, stderr=subprocess.DEVNULL)
+        t1 = time.time()
+        subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], env=env, stderr=subprocess.DEVNULL)
+        t2 = time.time()
+        lls = kio.read_ark(f"{td}/o.ark"); cfg = lo.Config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE); t2p = synth.tid2pdf(num_pdfs)
+        dec_s = sum(rd.decode(graph, lls[k], t2p, cfg)["decode_seconds"] for k in sorted(lls))      # time inside LatticeFasterDecoder::Decode, reported by the binary
+    return len(seeds) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s)
+
+def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, utts_per_core=2, max_procs=16):
+    """The same workload on the host cores, bounded sample, the way decode.sh --nj splits it: P independent single-threaded workers, each running
+    the REFERENCE's own binaries (oracle/_ref, built from /root/reference by oracle/build_ref.sh) on its utterances."""
+    from oracle import ref_decoder as rd
+    bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
+    if not (os.path.exists(os.path.join(bindir, "nnet3-compute")) and rd.available()):
+        return {"error": "oracle/_ref is not built (needs /root/reference once; it travels to the GPU box)"}
+    ncores = os.cpu_count() or 1; P = max(1, min(ncores, max_procs))
+    _cpu_worker((99, [99], 1.0, model_path, graph, num_pdfs))            # untimed warm-up: pages the binaries and MKL in
+    jobs = [(w, [1234 + w * utts_per_core + k for k in range(utts_per_core)], utt_seconds, model_path, graph, num_pdfs) for w in range(P)]
+    t0 = time.time()
+    with ThreadPoolExecutor(P) as ex: res = list(ex.map(_cpu_worker, jobs))      # threads only launch and wait for the single-threaded reference processes
+    wall = time.time() - t0
+    audio = sum(r[0] for r in res); per_core = [r[0] / r[1] for r in res]; st = np.sum([r[2] for r in res], axis=0)
+    return {"value": audio / max(r[1] for r in res), "unit": "RTFx (audio-s/wall-s)", "cores": P, "kind": "reference", "host_cores_available": ncores,
+            "per_core_rtfx_mean": float(np.mean(per_core)), "wall_s_including_process_startup": wall,
+            "sample": f"{P} single-threaded workers x {utts_per_core} x {utt_seconds:g} s utts (like decode.sh --nj {P}); aggregate = audio / slowest worker; per stage over all workers: "
+                      f"reference compute-fbank-feats {audio / st[0]:.0f}x RT, reference nnet3-compute {audio / st[1]:.0f}x RT, reference LatticeFasterDecoder::Decode {audio / st[2]:.0f}x RT "
+                      "(decoder/lattice-faster-decoder.cc compiled unmodified; FST containers from oracle/ref_tools/minifst because OpenFst is not vendored)"}
 
 def main():
     ap = argparse.ArgumentParser()
@@ -77,6 +75,8 @@ def main():
     ap.add_argument("--utts", type=int, default=512); ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--graph-states", type=int, default=2_000_000); ap.add_argument("--graph-arcs", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-two-pass", action="store_true", help="skip the second (order-independent decoder) measurement")
+    ap.add_argument("--det-threads", type=int, default=0, help="host threads of the determinization pool (0 = all cores / ranks)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     local %= max(1, torch.cuda.device_count())       # (a 1-GPU box can rehearse the N > 1 path with K3_DIST_BACKEND=gloo: all ranks share the device)
@@ -89,12 +89,14 @@ def main():
     import __graft_entry__ as ge
     if rank == 0: ge.build()
     if world > 1: dist.barrier()
-    from kaldi_amd import feat, nnet3, synth, decoder, parallel
+    from kaldi_amd import feat, nnet3, synth, decoder, parallel, hostlib
 
     U, nsamp = args.utts, int(16000 * args.utt_seconds)
-    # synthetic workload: Gaussian PCM16 sigma 3000, per-rank seed; 17L-768/96-6024 TDNN-F, seed 1
+    det_threads = args.det_threads or max(1, (os.cpu_count() or 1) // world)
+    # synthetic workload: Gaussian PCM16 sigma 3000, per-rank seed, in page-locked host memory; 17L-768/96-6024 TDNN-F, seed 1
     g = torch.Generator(device="cpu"); g.manual_seed(1234 + rank)
-    waves = (torch.randn(U * nsamp, generator=g) * 3000).round().clamp(-32768, 32767).to(dev)
+    pcm_host = (torch.randn(U * nsamp, generator=g) * 3000).round().clamp(-32768, 32767).to(torch.int16).pin_memory()
+    pcm_dev = torch.empty(U * nsamp, dtype=torch.int16, device=dev)
     sf = feat.SpectralFeatures(feat.fbank_options(dither=0.0, num_bins=40))
     wo, fo, total_frames, fo_h = sf.offsets([nsamp] * U, dev)
     model_path = os.path.join(tempfile.gettempdir(), f"k3_bench_tdnnf_{rank}.raw")
@@ -109,74 +111,112 @@ def main():
     loglikes = torch.empty((nb.total_out_rows, num_pdfs), dtype=torch.float32, device=dev)
 
     # decoding graph: built and uploaded on rank 0, broadcast once over RCCL/xGMI to the other ranks
-    graph = dec = None
+    graph = None; decs = {}
     if not args.no_decode:
         graph = synth.make_hclg(args.graph_states, args.graph_arcs, num_pdfs) if rank == 0 else None
         t0 = time.perf_counter()
         cfst = parallel.broadcast_graph(graph, synth.tid2pdf(num_pdfs), rank, world, dev)
         t_bcast = time.perf_counter() - t0
-        cfg = decoder.decoder_config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE, frame_tokens_cap=65536, frame_cands_cap=131072,
-                                     lane_tokens_cap=int(4500 * args.utt_seconds * 33.4) + 65536, lane_links_cap=int(6000 * args.utt_seconds * 33.4) + 131072)
-        dec = decoder.CudaDecoder(cfst, cfg, U, num_pdfs); dec.SetProfiling(True)
+        caps = dict(frame_tokens_cap=65536, frame_cands_cap=131072, lane_tokens_cap=int(4500 * args.utt_seconds * 33.4) + 65536, lane_links_cap=int(6000 * args.utt_seconds * 33.4) + 131072)
+        for mode in (["literal"] if args.no_two_pass else ["literal", "two_pass"]):
+            d = decoder.CudaDecoder(cfst, decoder.decoder_config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE, literal_order=1 if mode == "literal" else 0, **caps), U, num_pdfs)
+            d.SetProfiling(True); decs[mode] = d
+    hl = hostlib.load(); det_opts = hostlib.DetOpts(); hl.k3h_det_opts_default(ctypes.byref(det_opts))
+    pool = ThreadPoolExecutor(1)                      # hands a batch of lattices to the native worker pool (k3h_postprocess_batch runs det_threads threads itself)
+    def postprocess(lats):
+        """Connect + DeterminizeLatticePruned (word level, beam = lattice-beam: what the CUDA pipeline does with --determinize-lattice=true and no
+        phone pass) of every lattice of the batch; returns (determinized states, arcs)"""
+        n = len(lats); cs = np.zeros(n, np.int32); ca = np.zeros(n, np.int64); ok = np.zeros(n, np.int32)
+        so = np.ascontiguousarray(lats.state_offsets, np.int64); ao = np.ascontiguousarray(lats.arc_offsets, np.int64)
+        si, sf_, ai, af = lats._si, lats._sf, lats._ai, lats._af
+        hostlib.check(hl.k3h_postprocess_batch(None, n, so.ctypes.data, ao.ctypes.data, int(cfst.start), si[0].ctypes.data, si[1].ctypes.data, sf_[1].ctypes.data, ai[0].ctypes.data, ai[1].ctypes.data,
+                                               ai[2].ctypes.data, ai[3].ctypes.data, af[0].ctypes.data, af[1].ctypes.data, float(LATTICE_BEAM), ctypes.byref(det_opts), det_threads, None,
+                                               cs.ctypes.data, ca.ctypes.data, ok.ctypes.data))
+        return int(cs.sum()), int(ca.sum())
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-    lat_sizes = [0, 0]
-    def step(timed=False):
-        if timed: ev[0].record()
-        sf.ComputeFeatures(waves, wo, fo, total_frames, out=feats)
-        if timed: ev[1].record()
-        nb.forward(feats, out=loglikes)
-        if timed: ev[2].record()
-        if dec is not None:
-            dec.DecodeBatch(loglikes, nb.out_offsets)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    def run(mode, steps, warmup):
+        """W untimed + K timed steps of the whole path in one decoder mode; returns (wall seconds of the K steps, per-stage ms, last lattice sizes, determinized sizes)"""
+        dec = decs.get(mode); lat_sizes = [0, 0]; det_sizes = [0, 0]; pending = []
+        def step(timed):
+            if timed: ev[0].record()
+            pcm_dev.copy_(pcm_host, non_blocking=True)                     # first waveform byte leaves host memory
+            if timed: ev[1].record()
+            sf.ComputeFeatures(pcm_dev, wo, fo, total_frames, out=feats)
+            if timed: ev[2].record()
+            nb.forward(feats, out=loglikes)
             if timed: ev[3].record()
-            lats = dec.GetRawLattices()          # synchronises: compaction kernel + D2H of the pruned lattices
-            lat_sizes[0] = int(lats.state_offsets[-1]); lat_sizes[1] = int(lats.arc_offsets[-1])      # all lattices are on the host now (flat arrays + offsets)
-            if timed: ev[4].record()
-    for _ in range(args.warmup): step()
-    torch.cuda.synchronize()
-    if world > 1: dist.barrier()
-    acc = np.zeros(6)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timed=True)
-        torch.cuda.current_stream().synchronize()
-        acc[0] += ev[0].elapsed_time(ev[1]); acc[1] += ev[1].elapsed_time(ev[2])
-        if dec is not None:
-            acc[2] += ev[2].elapsed_time(ev[3]); acc[3] += ev[3].elapsed_time(ev[4])
-            k = dec.KernelTimes(); acc[4] += k[0]; acc[5] += k[1]
-    torch.cuda.synchronize()
-    if world > 1: dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = t.item()
+            if dec is not None:
+                dec.DecodeBatch(loglikes, nb.out_offsets)
+                if timed: ev[4].record()
+                while len(pending) >= 2: r = pending.pop(0).result(); det_sizes[0], det_sizes[1] = r      # the host buffers of batch k-2 are about to be reused
+                lats = dec.GetRawLattices()          # synchronises: compaction kernel + D2H of the pruned lattices
+                lat_sizes[0] = int(lats.state_offsets[-1]); lat_sizes[1] = int(lats.arc_offsets[-1])
+                if timed: ev[5].record()
+                pending.append(pool.submit(postprocess, lats))
+        for _ in range(warmup): step(False)
+        while pending: pending.pop(0).result()
+        torch.cuda.synchronize()
+        if world > 1: dist.barrier()
+        acc = np.zeros(8)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+            torch.cuda.current_stream().synchronize()
+            acc[0] += ev[0].elapsed_time(ev[1]); acc[1] += ev[1].elapsed_time(ev[2]); acc[2] += ev[2].elapsed_time(ev[3])
+            if dec is not None:
+                acc[3] += ev[3].elapsed_time(ev[4]); acc[4] += ev[4].elapsed_time(ev[5])
+                k = dec.KernelTimes(); acc[5] += k[0]; acc[6] += k[1]
+        while pending: r = pending.pop(0).result(); det_sizes[0], det_sizes[1] = r      # last lattice handed to the writer
+        torch.cuda.synchronize()
+        if world > 1: dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = t.item()
+        return dt, acc / steps, lat_sizes, det_sizes
+
+    mode0 = "literal" if decs else None
+    dt, acc, lat_sizes, det_sizes = run(mode0, args.steps, args.warmup)
     audio_s = U * args.utt_seconds * world * args.steps
+    two = run("two_pass", args.steps, args.warmup) if "two_pass" in decs else None
     if rank == 0:
-        acc /= args.steps
-        gemm_tf = nb.flops / (acc[1] * 1e-3) / 1e12
-        line = {"metric": "RTFx (audio-s/wall-s) batched fbank -> TDNN-F -> HCLG lattice decode" if dec is not None else "RTFx (audio-s/wall-s) batched fbank + TDNN-F forward (decode disabled by --no-decode)",
+        gemm_tf = nb.flops / (acc[2] * 1e-3) / 1e12
+        kernels_ms = acc[1] + acc[2] + acc[3]
+        line = {"metric": "RTFx (audio-s/wall-s) batched fbank -> TDNN-F -> HCLG lattice decode" if decs else "RTFx (audio-s/wall-s) batched fbank + TDNN-F forward (decode disabled by --no-decode)",
                 "value": audio_s / dt, "unit": "RTFx (audio-s/wall-s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic (Gaussian PCM16 sigma=3000 seed 1234+rank; random-init BN-calibrated 17L-768/96-6024 TDNN-F seed 1; synthetic HCLG seed 4321)",
-                "config": {"workload": (f"configs[2]: fbank(40) -> 17-layer TDNN-F (frame-subsampling 3) -> HCLG lattice decode (beam {BEAM:g}, lattice-beam {LATTICE_BEAM:g}, max-active {MAX_ACTIVE}, "
-                                        f"{args.graph_states} states / {args.graph_arcs} arcs), {U} x {args.utt_seconds:g} s utts per GPU") if dec is not None else
-                                       f"configs[1]: fbank(40) + 17-layer TDNN-F forward, {U} x {args.utt_seconds:g} s utts per GPU",
+                "dtype": "f32", "data": "synthetic (Gaussian PCM16 sigma=3000 seed 1234+rank in page-locked host memory; random-init BN-calibrated 17L-768/96-6024 TDNN-F seed 1; synthetic HCLG seed 4321)",
+                "config": {"workload": (f"configs[2]: PCM16 H2D -> fbank(40) -> 17-layer TDNN-F (frame-subsampling 3) -> HCLG lattice decode (beam {BEAM:g}, lattice-beam {LATTICE_BEAM:g}, max-active {MAX_ACTIVE}, "
+                                        f"{args.graph_states} states / {args.graph_arcs} arcs) -> raw lattices to the host -> Connect + determinization on {det_threads} host threads, {U} x {args.utt_seconds:g} s utts per GPU") if decs else
+                                       f"configs[1]: PCM16 H2D -> fbank(40) + 17-layer TDNN-F forward, {U} x {args.utt_seconds:g} s utts per GPU",
+                           "decoder_mode": "literal_order=1: raw lattices identical to the reference's LatticeFasterDecoder" if decs else None,
                            "utts_per_gpu": U, "frames_per_utt": fo_h[1], "output_rows": int(nb.total_out_rows), "params": int(net.info.num_params), "parallelism": f"utterance-shard x{world}"},
-                "stage_ms": {"fbank": acc[0], "nnet3": acc[1], "decode": acc[2], "decode.token_passing_kernel": acc[4], "decode.lattice_prune_kernel": acc[5], "lattice_compact_and_d2h": acc[3]},
-                "roofline_gemm": {"bound": "mfma", "kernel": "k3_tdnn_gemm_kernel (all 35 launches of one forward)", "achieved": gemm_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": gemm_tf / 157.3,
+                "value_kernels": U * args.utt_seconds * world / (kernels_ms * 1e-3),
+                "value_kernels_note": "audio / (fbank + TDNN-F + decode kernel time of a step): what the GPU stages alone sustain, H2D / D2H / host tail excluded",
+                "stage_ms": {"pcm16_h2d": acc[0], "fbank": acc[1], "nnet3": acc[2], "decode": acc[3], "decode.token_passing_kernel": acc[5], "decode.lattice_prune_kernel": acc[6], "lattice_compact_and_d2h": acc[4]},
+                "roofline_gemm": {"bound": "mfma", "kernel": "k3_tdnn_gemm_kernel (all launches of one forward)", "achieved": gemm_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": gemm_tf / 157.3,
                                   "note": "exact sum(2MNK) of the launched GEMMs / HIP-event time of the forward on the launch stream; FP32 MFMA peak (the only MFMA class inside the 1e-4 bound)"}}
-        if dec is not None:
-            info = dec.LatticeInfo(); ab = dec.algorithmic_bytes(info); gbs = ab / (acc[4] * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": ab,
+        if decs:
+            dec = decs["literal"]; info = dec.LatticeInfo(); ab = dec.algorithmic_bytes(info); gbs = ab / (acc[5] * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_literal_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                "traffic": None, "traffic_measured_in_run": False, "algorithmic_bytes_per_launch": ab,
                                 "note": "algorithmic bytes (SURVEY 8d: 32 B/emitting arc traversed + 28 B/eps arc traversed + 16 B/token) from device counters / HIP-event time of the kernel on its launch stream; "
-                                        "the kernel is bound by the 333-step frame recurrence (dependent-latency chain per lane), not by bandwidth"}
-            try:      # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot collect counters itself)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+                                        "the kernel is bound by the per-frame dependent-latency chain (33 barriers + the serial replay of the eps queue per frame and lane), not by bandwidth"}
+            try:      # HBM traffic of the same kernel from the committed rocprofv3 PMC passes of this round (bench.py cannot collect counters itself)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_r02.json")))
                 if U == 512 and args.utt_seconds == 10.0: line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]; line["roofline"]["traffic_source"] = tj["source"]
             except Exception: pass
             line["decode_stats"] = {"graph_broadcast_s": t_bcast if world > 1 else 0.0, "emitting_arcs_traversed": int(info[:, 7].sum()), "eps_arcs_traversed": int(info[:, 8].sum()), "tokens": int(info[:, 4].sum()),
                                     "links": int(info[:, 5].sum()), "max_tokens_on_a_frame": int(info[:, 6].max()), "lattice_states": lat_sizes[0], "lattice_arcs": lat_sizes[1],
-                                    "reached_final_frac": float(info[:, 3].mean()), "algorithmic_bytes": ab}
+                                    "determinized_states": det_sizes[0], "determinized_arcs": det_sizes[1], "reached_final_frac": float(info[:, 3].mean()), "algorithmic_bytes": ab,
+                                    "order_sensitive_events": int(dec.OrderSensitiveEvents().sum())}
+            if two is not None:
+                dt2, acc2, ls2, ds2 = two; d2 = decs["two_pass"]; info2 = d2.LatticeInfo(); ab2 = d2.algorithmic_bytes(info2)
+                line["value_two_pass"] = audio_s / dt2
+                line["two_pass"] = {"note": "same pipeline with the order-independent decoder (literal_order = 0): faster, lattices close to but NOT identical with the reference's at this configuration",
+                                    "ms_per_step": 1000.0 * dt2 / args.steps, "stage_ms": {"pcm16_h2d": acc2[0], "fbank": acc2[1], "nnet3": acc2[2], "decode": acc2[3], "decode.token_passing_kernel": acc2[5], "decode.lattice_prune_kernel": acc2[6], "lattice_compact_and_d2h": acc2[4]},
+                                    "roofline": {"bound": "hbm", "kernel": "k3_decode_forward_kernel", "achieved": ab2 / (acc2[5] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ab2 / (acc2[5] * 1e-3) / 1e9 / 8000.0},
+                                    "lattice_states": ls2[0], "lattice_arcs": ls2[1], "order_sensitive_upper_bound": int(d2.OrderSensitiveEvents().sum())}
         else:
             line["roofline"] = dict(line["roofline_gemm"], traffic=None)
         if world == 1 and not args.no_cpu_baseline:
@@ -185,6 +225,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds)
             except Exception as e: line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line))
+    pool.shutdown()
     if world > 1: dist.destroy_process_group()
 
 if __name__ == "__main__":

@@ -40,6 +40,17 @@ int k3h_determinize_lattice(const k3h_transitions *trans, int32_t num_states, in
 int k3h_convert_lattice(int32_t num_states, int32_t start, const float *st_final, int64_t num_arcs, const int32_t *arc_src, const int32_t *arc_dst,
                         const int32_t *arc_ilabel, const int32_t *arc_olabel, const float *arc_graph, const float *arc_ac, k3h_clat **out);
 
+/* The host tail for a whole batch in the layout k3_decoder_get_raw_lattices returns (concatenated arrays; utterance u owns states
+ * state_offsets[u]..[u+1] and arcs arc_offsets[u]..[u+1], arc end points local to the utterance): per utterance fst::Connect
+ * (decoder/decoder-wrappers.cc:353) + the determinization above, on num_threads worker threads -- the CPU worker pool of the reference's
+ * pipeline (cudadecoder/batched-threaded-nnet3-cuda-pipeline2.h:170-177).  graph_start = the decoding graph's start state (a lattice starts at
+ * the state of frame 0 with that graph state).  h_out (nullable): a handle per utterance (NULL where no path survived), freed by the caller with
+ * k3h_clat_free; the three count arrays (nullable) receive the size of each determinized lattice and whether the beam was reached. */
+int k3h_postprocess_batch(const k3h_transitions *trans, int32_t num_utts, const int64_t *state_offsets, const int64_t *arc_offsets, int32_t graph_start,
+                          const int32_t *st_frame, const int32_t *st_state, const float *st_final, const int32_t *arc_src, const int32_t *arc_dst, const int32_t *arc_ilabel,
+                          const int32_t *arc_olabel, const float *arc_graph, const float *arc_ac, double beam, const k3h_det_opts *opts, int32_t num_threads,
+                          k3h_clat **h_out, int32_t *h_clat_states, int64_t *h_clat_arcs, int32_t *h_complete);
+
 /* sizes, then the arrays: transition-id strings are concatenated in `strings` (all final strings in state order, then all arc strings in
  * arc order); final_str_off has num_states + 1 entries, arc_str_off num_arcs + 1 entries, both index into `strings` */
 int k3h_clat_sizes(const k3h_clat *c, int32_t *num_states, int64_t *num_arcs, int64_t *num_string_labels);

@@ -1,6 +1,10 @@
 // k3_host_abi.cc -- the C ABI of include/k3host.h over k3_lattice.cc / k3_host.cc (-> kaldi_amd/lib/libk3host.so).  No GPU code.
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <mutex>
+#include <memory>
+#include <thread>
 #include "../../include/k3host.h"
 #include "k3_host.h"
 using namespace k3host;
@@ -60,6 +64,49 @@ int k3h_clat_get(const k3h_clat *h, int32_t *start, uint8_t *is_final, float *fg
     foff[ns] = p;
     for (size_t k = 0; k < na; k++) { src[k] = c.arc_src[k]; dst[k] = c.arc_dst[k]; label[k] = c.arc_label[k]; g[k] = c.arc_graph[k]; a[k] = c.arc_ac[k]; aoff[k] = p; for (int32_t t : c.arc_str[k]) strings[p++] = t; }
     aoff[na] = p;
+  });
+}
+// The host tail for a whole batch as k3_decoder_get_raw_lattices hands it over (concatenated arrays + per-utterance offsets): per utterance
+// Connect (decoder-wrappers.cc:353) + DeterminizeLatticePhonePrunedWrapper / DeterminizeLatticePruned, on `num_threads` worker threads
+// (cf. the CPU worker pool of the reference pipeline, batched-threaded-nnet3-cuda-pipeline2.h:170-177).  h_out (nullable): one handle per
+// utterance (NULL for an utterance without a surviving path), to be freed by the caller; without it the lattices are dropped after counting.
+int k3h_postprocess_batch(const k3h_transitions *trans, int32_t num_utts, const int64_t *state_offsets, const int64_t *arc_offsets, int32_t graph_start,
+                          const int32_t *st_frame, const int32_t *st_state, const float *st_final, const int32_t *arc_src, const int32_t *arc_dst, const int32_t *arc_ilabel,
+                          const int32_t *arc_olabel, const float *arc_graph, const float *arc_ac, double beam, const k3h_det_opts *o, int32_t num_threads,
+                          k3h_clat **h_out, int32_t *h_clat_states, int64_t *h_clat_arcs, int32_t *h_complete) {
+  return Guard([&] {
+    if (num_utts < 0 || !state_offsets || !arc_offsets) K3H_ERR << "k3h_postprocess_batch: bad argument";
+    DeterminizeLatticePhonePrunedOptions po;
+    if (o) { po.delta = o->delta; po.max_mem = o->max_mem; po.phone_determinize = o->phone_determinize != 0; po.word_determinize = o->word_determinize != 0; po.minimize = o->minimize != 0; }
+    std::atomic<int32_t> next(0); std::atomic<int> failed(0); std::string first_err; std::mutex mu;
+    auto work = [&]() {
+      for (;;) {
+        const int32_t u = next.fetch_add(1); if (u >= num_utts) return;
+        try {
+          const int64_t s0 = state_offsets[u], ns = state_offsets[u + 1] - s0, a0 = arc_offsets[u], na = arc_offsets[u + 1] - a0;
+          if (h_out) h_out[u] = nullptr;
+          if (h_clat_states) h_clat_states[u] = 0; if (h_clat_arcs) h_clat_arcs[u] = 0; if (h_complete) h_complete[u] = 0;
+          if (ns == 0) continue;
+          Lattice lat; lat.st_frame.assign(st_frame + s0, st_frame + s0 + ns); lat.st_state.assign(st_state + s0, st_state + s0 + ns); lat.st_final.assign(st_final + s0, st_final + s0 + ns);
+          lat.arc_src.assign(arc_src + a0, arc_src + a0 + na); lat.arc_dst.assign(arc_dst + a0, arc_dst + a0 + na); lat.arc_ilabel.assign(arc_ilabel + a0, arc_ilabel + a0 + na);
+          lat.arc_olabel.assign(arc_olabel + a0, arc_olabel + a0 + na); lat.arc_graph.assign(arc_graph + a0, arc_graph + a0 + na); lat.arc_ac.assign(arc_ac + a0, arc_ac + a0 + na);
+          lat.start = -1; for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == graph_start) lat.start = (int32_t)s;
+          if (lat.start < 0) continue;
+          Connect(&lat);
+          if (lat.NumStates() == 0) continue;
+          std::unique_ptr<k3h_clat> c(new k3h_clat); bool ok;
+          if (trans) ok = DeterminizeLatticePhonePruned(lat, trans->info, beam, &c->c, po);
+          else { DeterminizeLatticePrunedOptions d; d.delta = po.delta; d.max_mem = po.max_mem; ok = DeterminizeLatticePruned(lat, beam, &c->c, d); }
+          if (h_clat_states) h_clat_states[u] = c->c.NumStates(); if (h_clat_arcs) h_clat_arcs[u] = (int64_t)c->c.arc_src.size(); if (h_complete) h_complete[u] = ok ? 1 : 0;
+          if (h_out) h_out[u] = c.release();
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> g(mu); if (!failed.fetch_add(1)) first_err = e.what(); }
+      }
+    };
+    std::vector<std::thread> th; const int nt = std::max(1, std::min<int>(num_threads, num_utts));
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (failed.load()) K3H_ERR << "k3h_postprocess_batch: " << failed.load() << " utterances failed, first: " << first_err;
   });
 }
 int k3h_clat_scale_acoustic(k3h_clat *c, double scale) { return Guard([&] { ScaleAcoustic(&c->c, scale); }); }

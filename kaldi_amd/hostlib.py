@@ -26,6 +26,7 @@ def load():
         lat = [ctypes.c_int32, ctypes.c_int32, P, ctypes.c_int64, P, P, P, P, P, P]
         L.k3h_determinize_lattice.argtypes = [P] + lat + [ctypes.c_double, ctypes.POINTER(DetOpts), ctypes.POINTER(P), ctypes.POINTER(ctypes.c_int32)]
         L.k3h_convert_lattice.argtypes = lat + [ctypes.POINTER(P)]
+        L.k3h_postprocess_batch.argtypes = [P, ctypes.c_int32, P, P, ctypes.c_int32] + [P] * 9 + [ctypes.c_double, ctypes.POINTER(DetOpts), ctypes.c_int32, P, P, P, P]
         L.k3h_clat_sizes.argtypes = [P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.k3h_clat_get.argtypes = [P, ctypes.POINTER(ctypes.c_int32)] + [P] * 11
         L.k3h_clat_scale_acoustic.argtypes = [P, ctypes.c_double]

@@ -16,7 +16,7 @@ rows = []
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name); name = re.sub(r"^void ", "", name)
     m = re.match(r"([A-Za-z0-9_:]+(?:<[^>]*>)?)", name); return m.group(1) if m else name
-traffic = {}
+traffic = {}; traffic2 = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = find("pmc_" + c, "*counter_collection.csv")
     if not f: continue
@@ -26,7 +26,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = short(r["Kernel_Name"]); a = acc.setdefault(k, [set(), 0.0]); a[0].add(r["Dispatch_Id"]); a[1] += float(r["Counter_Value"])
     for k, (d, v) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         rows.append((k, c, len(d), v, v / max(1, len(d))))
-        if k.startswith("k3_decode_forward_kernel"): traffic[c] = v / max(1, len(d)) * 1024.0
+        if k.startswith("k3_decode_forward_literal_kernel"): traffic[c] = v / max(1, len(d)) * 1024.0
+        if k.startswith("k3_decode_forward_kernel"): traffic2[c] = v / max(1, len(d)) * 1024.0
 with open(os.path.join(dst, f"{tag}_bench_full_pipeline_pmc_hbm.csv"), "w") as f:
     f.write(f"# rocprofv3 --pmc <counter> (separate passes, no trace domains) over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline` (512 x 10 s utts), {tag}\n"
             "# Counter_Value summed over the dispatches of each kernel; FETCH_SIZE / WRITE_SIZE are in KB (rocprof definition).\n"
@@ -39,8 +40,8 @@ if os.path.exists(bl):
     lines = [l for l in open(bl).read().splitlines() if l.startswith("{")]
     if lines: open(os.path.join(dst, f"{tag}_bench_line.json"), "w").write(lines[-1] + "\n")
 if len(traffic) == 2:
-    json.dump({"kernel": "k3_decode_forward_kernel", "source": f"profiles/{tag}_bench_full_pipeline_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 512 x 10 s utts)",
+    json.dump({"kernel": "k3_decode_forward_literal_kernel", "two_pass_kernel_traffic_bytes_per_launch": (traffic2.get("FETCH_SIZE", 0) + traffic2.get("WRITE_SIZE", 0)) or None, "source": f"profiles/{tag}_bench_full_pipeline_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 512 x 10 s utts)",
                "fetch_bytes_per_launch": traffic["FETCH_SIZE"], "write_bytes_per_launch": traffic["WRITE_SIZE"], "traffic_bytes_per_launch": traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"],
                "note": "FETCH_SIZE/WRITE_SIZE as reported (KB x 1024); the gfx950 x2 correction for wide coalesced loads does not apply to the decoder's narrow random accesses; uncalibrated for this pattern"},
-              open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+              open(os.path.join(dst, "hbm_traffic_r02.json"), "w"), indent=1)
 print("summaries in", dst, os.listdir(dst))
