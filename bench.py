@@ -49,7 +49,7 @@ def _cpu_worker(job):
         dec_s = sum(rd.decode(graph, lls[k], t2p, cfg)["decode_seconds"] for k in sorted(lls))      # time inside LatticeFasterDecoder::Decode, reported by the binary
     return len(seeds) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s)
 
-def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, utts_per_core=2, max_procs=16):
+def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, utts_per_core=6, max_procs=32):
     """The same workload on the host cores, bounded sample, the way decode.sh --nj splits it: P independent single-threaded workers, each running
     the REFERENCE's own binaries (oracle/_ref, built from /root/reference by oracle/build_ref.sh) on its utterances."""
     from oracle import ref_decoder as rd
