@@ -121,59 +121,78 @@ struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 // The replay loop.  MODE 0: costs, meta, arcs, stack and the creation list in LDS; MODE 1: costs, stack and list in LDS, meta / arcs read-only
 // in HBM; MODE 2: everything in HBM.  rcost[id] = the cost the serial code has seen for the token so far (+inf: not created yet);
 // meta[id] = {first passing arc, passing arcs, destination and weight of the first one}; clist[k] = id of the k-th token the closure creates.
+#define K3_U(x) __builtin_amdgcn_readfirstlane(x)      /* a wave-uniform int: pin it to a scalar register so that its arithmetic and the branches on it run on the scalar unit */
+__device__ __forceinline__ float k3_uf(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 template <int MODE>
 __device__ __forceinline__ void lit_replay(float *rcost, const int4 *meta, const int2 *AR, int *stack, int stack_cap, unsigned *clist, const int *iq, int n_iq, float accept,
                                            int *s_own, int *out_created, int *out_err, int *out_pops) {
   const int lane = threadIdx.x & 63; const float kInf = __builtin_inff();
-  int sp = 0, kpos = n_iq, created = 0, err = 0, e_fwd = -1, cbase = -64, cache = 0, iters = 0;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int sp = 0, kpos = K3_U(n_iq), created = 0, err = 0, e_fwd = -1, cbase = -64, cache = 0, iters = 0;      // all wave-uniform except `cache`
+  accept = k3_uf(accept);
   for (;; iters++) {
     if (iters > (1 << 24)) { err = 2; break; }      // cannot happen (every pop follows a cost decrease); keeps a bug from hanging the GPU
     int e;
     if (e_fwd >= 0) { e = e_fwd; e_fwd = -1; }
-    else if (sp > 0) e = stack[--sp];
+    else if (sp > 0) { sp = sp - 1; e = K3_U(stack[sp]); }
     else if (kpos > 0) {
-      kpos--;
+      kpos = kpos - 1;
       if ((kpos & ~63) != cbase) { cbase = kpos & ~63; cache = cbase + lane < n_iq ? iq[cbase + lane] : 0; }
-      e = __builtin_amdgcn_readlane(cache, __builtin_amdgcn_readfirstlane(kpos & 63));
+      e = __builtin_amdgcn_readlane(cache, kpos & 63);
     } else break;
-    const float c = rcost[e]; const int4 mt = meta[e];
-    if (!(c < accept)) continue;
-    for (int k0 = 0; k0 < mt.y; k0 += 64) {
-      if (e_fwd >= 0) { if (sp + 1 > stack_cap) { err = 1; break; } stack[sp++] = e_fwd; e_fwd = -1; if (MODE == 2) __threadfence_block(); }
-      const int k = k0 + lane; const bool v = k < mt.y;
-      int2 ar = make_int2(mt.z, mt.w);
-      if (mt.y > 1 || k0 > 0) ar = v ? AR[mt.x + k] : make_int2(0, 0);
+    const float c = k3_uf(rcost[e]); const int4 mt4 = meta[e];
+    const int pc = K3_U(mt4.y), abeg = K3_U(mt4.x);
+    if (!(c < accept) || pc == 0) continue;
+    if (pc == 1) {
+      // ---- one passing arc (the common case): the whole pop is scalar work; every lane computes the same values, lane 0 stores
+      const int d = K3_U(mt4.z); const float tot = c + k3_uf(__int_as_float(mt4.w));
+      if (tot < accept) {
+        const float old = k3_uf(rcost[d]);
+        if (old > tot) {
+          if (old == kInf) { if (lane == 0) clist[created] = (unsigned)d; created++; }
+          if (lane == 0) rcost[d] = tot;
+          if (K3_U(meta[d].y) > 0) e_fwd = d;      // pushed and popped again at once
+          if (MODE == 2) __threadfence_block();
+        }
+      }
+      continue;
+    }
+    for (int k0 = 0; k0 < pc; k0 += 64) {
+      if (e_fwd >= 0) { if (sp + 1 > stack_cap) { err = 1; break; } if (lane == 0) stack[sp] = e_fwd; sp++; e_fwd = -1; if (MODE == 2) __threadfence_block(); }
+      const int k = k0 + lane; const bool v = k < pc;
+      const int2 ar = v ? AR[abeg + k] : make_int2(0, 0);
       const int d = ar.x; const float tot = c + __int_as_float(ar.y); const bool ok = v && tot < accept;
       const unsigned long long okm = __ballot(ok);
+      if (okm == 0ull) continue;
       bool clash = false;
       if (__popcll(okm) >= 2) {      // two arcs of this batch into the same token must be applied one after the other
-        if (ok) s_own[d & 1023] = lane;
-        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes above are in place (LDS executes a wavefront's accesses in order)
-        clash = __ballot(ok && s_own[d & 1023] != lane) != 0ull;
+        volatile int *own = s_own;      // volatile: the compiler must not forward a lane's own store to its load (another lane's store may have landed in between)
+        if (ok) own[d & 1023] = lane;
+        __builtin_amdgcn_wave_barrier();
+        clash = __ballot(ok && own[d & 1023] != lane) != 0ull;      // (LDS executes a wavefront's accesses in order)
       }
       if (!clash) {
         const float old = ok ? rcost[d] : 0.0f; const int dpc = ok ? meta[d].y : 0;
         const bool isnew = ok && old == kInf, changed = ok && old > tot;      // a token's cost is < cutoff < inf once it exists
         const unsigned long long nm = __ballot(isnew);
-        if (isnew) clist[created + __popcll(nm & ((1ull << lane) - 1ull))] = (unsigned)d;
+        if (isnew) clist[created + __popcll(nm & lt_mask)] = (unsigned)d;
         created += __popcll(nm);
         if (changed) rcost[d] = tot;
         const unsigned long long pm = __ballot(changed && dpc > 0);      // only tokens that can expand are queued
         if (pm) {
           const int np = __popcll(pm), top = 63 - __clzll((long long)pm);
           if (sp + np > stack_cap) { err = 1; break; }
-          const int rank = __popcll(pm & ((1ull << lane) - 1ull));
-          if ((pm >> lane & 1ull) && lane != top) stack[sp + rank] = d;
-          sp += np - 1; e_fwd = __builtin_amdgcn_readlane(d, __builtin_amdgcn_readfirstlane(top));
+          if ((pm >> lane & 1ull) && lane != top) stack[sp + __popcll(pm & lt_mask)] = d;
+          sp += np - 1; e_fwd = __builtin_amdgcn_readlane(d, top);
         }
       } else {
         for (unsigned long long rest = okm; rest; rest &= rest - 1) {
-          const int jl = __ffsll((long long)rest) - 1; const int dj = __shfl(d, jl); const float tj = __shfl(tot, jl);
-          const float old = rcost[dj];
+          const int jl = __ffsll((long long)rest) - 1; const int dj = __builtin_amdgcn_readlane(d, jl); const float tj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), jl));
+          const float old = k3_uf(rcost[dj]);
           const bool isnew = old == kInf, changed = old > tj;
           if (isnew) { if (lane == 0) clist[created] = (unsigned)dj; created++; }
           if (changed && lane == 0) rcost[dj] = tj;
-          if (changed && meta[dj].y > 0) { if (sp + 1 > stack_cap) { err = 1; break; } if (lane == 0) stack[sp] = dj; sp++; }
+          if (changed && K3_U(meta[dj].y) > 0) { if (sp + 1 > stack_cap) { err = 1; break; } if (lane == 0) stack[sp] = dj; sp++; }
           if (MODE == 2) __threadfence_block();
         }
         if (err) break;
@@ -184,7 +203,6 @@ __device__ __forceinline__ void lit_replay(float *rcost, const int4 *meta, const
   }
   *out_created = created; *out_err = err; *out_pops = iters;
 }
-
 
 #ifdef K3_LIT_PROF
 #define K3_LT(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); sh.prof[i] += now__ - lt_last__; lt_last__ = now__; } } while (0)
@@ -494,11 +512,17 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
 #ifdef K3_LIT_PROF
       if (lane == 0) { sh.prof[12] += pops; if (rmode != 0) { sh.prof[5] += pops; sh.prof[3] += (long long)__builtin_readcyclecounter() - rp_t0; } }
 #endif
+#ifdef K3_LIT_DEBUG
+      if (lane == 0 && err) printf("lane %d frame %d: replay err %d pops %d created %d\n", L, f, err, pops, created);
+#endif
       if (lane == 0) { ls.n_created = created; if (err) sh.err = err == 2 ? K3_ERR_HIP : K3_ERR_OVERFLOW; }
     }
     __syncthreads();
     K3_LT(9);
     if (block_err(sh)) break;
+#ifdef K3_LIT_DEBUG
+    if (n_e + ls.n_created != n && tid == 0) printf("lane %d frame %d: n_e %d created %d n %d n_cid %d n_arc %d n_iq %d rmode %d\n", L, f, n_e, ls.n_created, n, n_cid, n_arc, n_iq, rmode);
+#endif
     if (n_e + ls.n_created != n) { if (tid == 0) sh.err = K3_ERR_HIP; }      // every token of the fixpoint must have been created by the replay
     if (block_err(sh)) break;
     for (int k = tid; k < ls.n_created; k += kBlock) K3_AST(&q.label[q.c2t[clist[k]]], m_e + (unsigned)k);      // creation labels of the closure's tokens      // creation labels of the closure's tokens
