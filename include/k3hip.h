@@ -205,6 +205,14 @@ int32_t k3_decoder_num_frames_decoded(const k3_decoder *dec, int32_t utt);     /
  * [6] max tokens on one frame, [7] emitting arcs traversed, [8] epsilon arcs traversed, [9] frames.
  * h_info: [num_utts x 10] int64. */
 int k3_decoder_lattice_info(k3_decoder *dec, int64_t *h_info);
+/* GetBestPath (cuda-decoder.h:306) and the traceback behind GetPartialHypothesis / EndpointDetected (:286-295, cuda-decoder.cc:1864-1960): the
+ * one-best path of each listed lane from the tokens it holds NOW -- after k3_decoder_advance_decoding (a partial result: use_final_probs = 0)
+ * or after finalisation.  Path u owns entries h_offsets[u] .. h_offsets[u+1] (n + 1 offsets) of the four arc arrays, first arc first; arc weight =
+ * LatticeWeight(graph, acoustic) as in GetRawLattice.  h_final_cost[u] = the final cost that was added (0 when none); h_relative_cost[u] =
+ * FinalRelativeCost() = min(cost + final) - min(cost) over the newest frame (+inf: no final state active), the quantity kaldi::EndpointDetected
+ * takes; h_reached_final[u]; the three may be NULL.  cap_arcs = capacity of the arc arrays (K3_ERR_OVERFLOW when too small). */
+int k3_decoder_get_best_path(k3_decoder *dec, const int32_t *channels, int32_t num_channels, int32_t use_final_probs, int64_t *h_offsets, int64_t cap_arcs,
+                             int32_t *h_ilabel, int32_t *h_olabel, float *h_graph, float *h_ac, float *h_final_cost, float *h_relative_cost, int32_t *h_reached_final);
 /* SURVEY 9.1 "order-sensitive events", per finalised utterance (same order as k3_decoder_lattice_info).  literal_order: forward links that exist
  * only because next_cutoff was still loose when their arc was examined (tot >= the frame's final next_cutoff); default mode: emitting arcs below
  * the pre-pass bound but not below the final bound (an upper bound on the arcs the serial and the two-pass rule can disagree on). */

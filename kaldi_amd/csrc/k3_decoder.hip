@@ -1173,6 +1173,73 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Best-path traceback on the token / link pools of a lane, finalised or not (CudaDecoder::GetBestPath cuda-decoder.cc:1072-1179, and the
+// traceback behind GetPartialHypothesis / EndpointDetected :1864-1960).  A token's cost is the minimum over its incoming links of the
+// link's `tot`, so the best predecessor of a token is an incoming link whose `tot` equals the token's cost bit for bit (ties: the link
+// created first).  One workgroup per requested lane walks back from the best token of the newest frame: per step one scan over the eps
+// links of the frame, then over the emitting links into it.  Output per lane: the arcs of the path, last arc first.
+struct BestPathParams { int *path_il, *path_ol; float *path_g, *path_ac; int *path_len; float *final_cost, *relative_cost; int *reached_final; int cap; int use_final; };
+
+__global__ __launch_bounds__(kPBlock) void k3_decode_best_path_kernel(DecParams p, BestPathParams o) {
+  __shared__ unsigned long long s_best; __shared__ unsigned s_min, s_minf; __shared__ long long s_link;
+  const int L = p.lane_ids[blockIdx.x], tid = threadIdx.x;
+  const LaneInfo &li = p.info[L];
+  const long long po = (long long)blockIdx.x * o.cap;
+  if (tid == 0) { o.path_len[blockIdx.x] = 0; o.final_cost[blockIdx.x] = 0.0f; o.relative_cost[blockIdx.x] = __builtin_inff(); o.reached_final[blockIdx.x] = 0; }
+  if (li.status != kStOk) return;
+  const int T = li.num_frames;
+  const int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; const unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
+  const Link *links = p.links + (long long)L * p.lane_links_cap; const int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
+  const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
+  const float *st_co = p.st_co + L * p.fstride; const float kInf = __builtin_inff();
+  // best token of the newest frame: min (cost + final) if a final state was reached and final-probs are asked for, else min cost
+  const long long tb = tok_off[T], te = tok_off[T + 1];
+  if (tid == 0) { s_min = kEncMax; s_minf = kEncMax; s_best = ~0ull; }
+  __syncthreads();
+  for (long long t = tb + tid; t < te; t += kPBlock) { const float c = dec(tok_cost[t]); atomicMin(&s_min, enc(c)); atomicMin(&s_minf, enc(c + p.final_cost[tok_state[t]])); }
+  __syncthreads();
+  const bool any_final = s_minf != kEncMax && dec(s_minf) != kInf; const bool with_final = o.use_final && any_final;
+  for (long long t = tb + tid; t < te; t += kPBlock) {
+    const float c = dec(tok_cost[t]); const float v = with_final ? c + p.final_cost[tok_state[t]] : c;
+    atomicMin(&s_best, ((unsigned long long)enc(v) << 32) | (unsigned)(t - tb));
+  }
+  __syncthreads();
+  if (te == tb) return;
+  long long cur = tb + (long long)(s_best & 0xFFFFFFFFull);
+  if (tid == 0) { o.reached_final[blockIdx.x] = any_final; o.final_cost[blockIdx.x] = with_final ? p.final_cost[tok_state[cur]] : 0.0f; o.relative_cost[blockIdx.x] = any_final ? dec(s_minf) - dec(s_min) : kInf; }
+  int len = 0, f = T;
+  for (int guard = 0; guard < 4 * (T + 1) + 64; guard++) {
+    const unsigned cc = tok_cost[cur];
+    __syncthreads();
+    if (tid == 0) s_link = 0x7FFFFFFFFFFFFFFFll;
+    __syncthreads();
+    // an eps link of frame f into cur (source in the same frame), stamped with its source's final cost (live), whose tot is cur's cost
+    for (long long l = loff_n[f] + tid; l < loff_e[f]; l += kPBlock) {
+      const Link k = links[l];
+      if (k.dst == (unsigned)cur && __float_as_uint(k.tot) == __float_as_uint(dec(cc)) && eps_link_live(k, tok_cost[k.src])) atomicMin((unsigned long long *)&s_link, (unsigned long long)l);
+    }
+    __syncthreads();
+    long long best = s_link; bool emitting = false;
+    if (best == 0x7FFFFFFFFFFFFFFFll && f > 0) {
+      __syncthreads();
+      for (long long l = loff_e[f - 1] + tid; l < loff_n[f]; l += kPBlock) {
+        const Link k = links[l];
+        if (k.dst == (unsigned)cur && __float_as_uint(k.tot) == __float_as_uint(dec(cc))) atomicMin((unsigned long long *)&s_link, (unsigned long long)l);
+      }
+      __syncthreads();
+      best = s_link; emitting = true;
+    }
+    if (best == 0x7FFFFFFFFFFFFFFFll) break;      // the start token (or a token nothing points to: cannot happen for a token with finite cost)
+    const Link k = links[best];
+    if (len >= o.cap) { if (tid == 0) o.path_len[blockIdx.x] = -1; return; }
+    if (tid == 0) { const int a = link_arc[best]; const ArcRec r = p.arcs[a]; o.path_il[po + len] = p.arc_ilabel[a]; o.path_ol[po + len] = r.olabel; o.path_g[po + len] = r.w; o.path_ac[po + len] = emitting ? k.ac - st_co[f - 1] : 0.0f; }
+    len++; cur = k.src; if (emitting) f--;
+  }
+  if (tid == 0) o.path_len[blockIdx.x] = len;
+}
+
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
@@ -1593,6 +1660,50 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
   K3_TRY(hipMemcpy(arc_il, o.arc_il, 4 * NA, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(arc_ol, o.arc_ol, 4 * NA, hipMemcpyDeviceToHost));
   K3_TRY(hipMemcpy(arc_g, o.arc_g, 4 * NA, hipMemcpyDeviceToHost)); K3_TRY(hipMemcpy(arc_ac, o.arc_ac, 4 * NA, hipMemcpyDeviceToHost));
 #undef K3_TRY
+  cleanup();
+  return K3_OK;
+}
+
+
+// GetBestPath (cuda-decoder.h:306) / the traceback of GetPartialHypothesis (:286): one-best path of each listed lane from the tokens it holds
+// NOW -- after k3_decoder_advance_decoding (partial result: call it with use_final_probs = 0) or after finalisation.  Path u owns entries
+// h_offsets[u] .. h_offsets[u+1] of the four arc arrays, in path order (first arc first); arc weight = LatticeWeight(graph, acoustic) as in
+// GetRawLattice.  h_final_cost[u]: the final cost that was added (0 when none); h_relative_cost[u] = FinalRelativeCost() = min(cost + final)
+// - min(cost) over the newest frame (+inf: no final state active) -- what kaldi::EndpointDetected takes; cap_arcs = capacity of the arc arrays.
+extern "C" int k3_decoder_get_best_path(k3_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs, int64_t *h_offsets, int64_t cap_arcs,
+                                        int32_t *h_ilabel, int32_t *h_olabel, float *h_graph, float *h_ac, float *h_final_cost, float *h_relative_cost, int32_t *h_reached_final) {
+  K3_REQUIRE(d && channels && n > 0 && n <= d->nlanes && h_offsets && h_ilabel && h_olabel && h_graph && h_ac && d->started, "k3_decoder_get_best_path: bad argument or nothing decoded");
+  for (int i = 0; i < n; i++) K3_REQUIRE(channels[i] >= 0 && channels[i] < d->last_utts && !d->fresh[channels[i]], "k3_decoder_get_best_path: channel out of range or never advanced");
+  hipStream_t st = d->last_stream; K3_HIP_CHECK(hipStreamSynchronize(st));
+  int maxT = 0; for (int i = 0; i < n; i++) maxT = std::max(maxT, d->last_frames[channels[i]]);
+  const int cap = 4 * maxT + 64;
+  int *d_ids = nullptr, *d_il = nullptr, *d_ol = nullptr, *d_len = nullptr, *d_rf = nullptr; float *d_g = nullptr, *d_ac = nullptr, *d_fc = nullptr, *d_rc = nullptr;
+  std::vector<void *> tmp; auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
+  int rc; const size_t nc = (size_t)n * cap;
+  if ((rc = dmalloc(&tmp, &d_ids, (size_t)n)) || (rc = dmalloc(&tmp, &d_il, nc)) || (rc = dmalloc(&tmp, &d_ol, nc)) || (rc = dmalloc(&tmp, &d_g, nc)) || (rc = dmalloc(&tmp, &d_ac, nc)) ||
+      (rc = dmalloc(&tmp, &d_len, (size_t)n)) || (rc = dmalloc(&tmp, &d_fc, (size_t)n)) || (rc = dmalloc(&tmp, &d_rc, (size_t)n)) || (rc = dmalloc(&tmp, &d_rf, (size_t)n))) { cleanup(); return rc; }
+#define K3_TRY(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { cleanup(); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
+  K3_TRY(hipMemcpy(d_ids, channels, sizeof(int) * n, hipMemcpyHostToDevice));
+  DecParams p = d->p; p.lane_ids = d_ids;
+  BestPathParams o{d_il, d_ol, d_g, d_ac, d_len, d_fc, d_rc, d_rf, cap, use_final_probs ? 1 : 0};
+  hipLaunchKernelGGL(k3_decode_best_path_kernel, dim3(n), dim3(kPBlock), 0, st, p, o);
+  K3_TRY(hipGetLastError());
+  std::vector<int> len(n), rf(n), il(nc), ol(nc); std::vector<float> g(nc), ac(nc), fc(n), rcst(n);
+  K3_TRY(hipMemcpyAsync(len.data(), d_len, sizeof(int) * n, hipMemcpyDeviceToHost, st)); K3_TRY(hipMemcpyAsync(rf.data(), d_rf, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+  K3_TRY(hipMemcpyAsync(il.data(), d_il, sizeof(int) * nc, hipMemcpyDeviceToHost, st)); K3_TRY(hipMemcpyAsync(ol.data(), d_ol, sizeof(int) * nc, hipMemcpyDeviceToHost, st));
+  K3_TRY(hipMemcpyAsync(g.data(), d_g, sizeof(float) * nc, hipMemcpyDeviceToHost, st)); K3_TRY(hipMemcpyAsync(ac.data(), d_ac, sizeof(float) * nc, hipMemcpyDeviceToHost, st));
+  K3_TRY(hipMemcpyAsync(fc.data(), d_fc, sizeof(float) * n, hipMemcpyDeviceToHost, st)); K3_TRY(hipMemcpyAsync(rcst.data(), d_rc, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+  K3_TRY(hipStreamSynchronize(st));
+#undef K3_TRY
+  int64_t total = 0; h_offsets[0] = 0;
+  for (int u = 0; u < n; u++) { if (len[u] < 0) { cleanup(); k3::set_error("k3_decoder_get_best_path: path of channel %d longer than %d arcs", channels[u], cap); return K3_ERR_OVERFLOW; } total += len[u]; h_offsets[u + 1] = total; }
+  if (total > cap_arcs) { cleanup(); k3::set_error("k3_decoder_get_best_path: %lld arcs but room for %lld", (long long)total, (long long)cap_arcs); return K3_ERR_OVERFLOW; }
+  for (int u = 0; u < n; u++)
+    for (int k = 0; k < len[u]; k++) {      // the kernel wrote the last arc first
+      const size_t src = (size_t)u * cap + (size_t)(len[u] - 1 - k); const int64_t q = h_offsets[u] + k;
+      h_ilabel[q] = il[src]; h_olabel[q] = ol[src]; h_graph[q] = g[src]; h_ac[q] = ac[src];
+    }
+  for (int u = 0; u < n; u++) { if (h_final_cost) h_final_cost[u] = fc[u]; if (h_relative_cost) h_relative_cost[u] = rcst[u]; if (h_reached_final) h_reached_final[u] = rf[u]; }
   cleanup();
   return K3_OK;
 }

@@ -125,6 +125,23 @@ class CudaDecoder:
         if check: _l.check(rc)
         return info
 
+    def GetBestPath(self, channels=None, use_final_probs=True):
+        """one-best path per channel from the tokens the lanes hold now (CudaDecoder::GetBestPath; with use_final_probs=False in the middle of an
+        utterance: the traceback of GetPartialHypothesis).  Returns a list of dicts: ilabels (transition-ids, eps arcs included as 0), olabels
+        (words, eps removed), graph, acoustic (sums), final_cost, relative_cost (FinalRelativeCost), reached_final."""
+        ch = np.ascontiguousarray(range(self._n) if channels is None else channels, np.int32); n = ch.size
+        cap = int(sum(4 * max(1, self.NumFramesDecoded(int(c))) + 64 for c in ch))
+        off = np.zeros(n + 1, np.int64); il = np.zeros(cap, np.int32); ol = np.zeros(cap, np.int32); g = np.zeros(cap, np.float32); ac = np.zeros(cap, np.float32)
+        fc = np.zeros(n, np.float32); rc = np.zeros(n, np.float32); rf = np.zeros(n, np.int32)
+        _l.check(self._L.k3_decoder_get_best_path(self._h, ch.ctypes.data, n, int(bool(use_final_probs)), off.ctypes.data, cap, il.ctypes.data, ol.ctypes.data, g.ctypes.data, ac.ctypes.data,
+                                                  fc.ctypes.data, rc.ctypes.data, rf.ctypes.data))
+        out = []
+        for u in range(n):
+            a, b = off[u], off[u + 1]
+            out.append(dict(ilabels=[int(x) for x in il[a:b] if x], olabels=[int(x) for x in ol[a:b] if x], graph=float(g[a:b].astype(np.float64).sum()) + float(fc[u]), acoustic=float(ac[a:b].astype(np.float64).sum()),
+                            final_cost=float(fc[u]), relative_cost=float(rc[u]), reached_final=bool(rf[u]), num_arcs=int(b - a)))
+        return out
+
     def OrderSensitiveEvents(self):
         """int64 per finalised utterance: literal_order -> forward links that exist only because next_cutoff was still loose when
         their arc was examined; default mode -> emitting arcs below the pre-pass bound but not below the final bound (an upper bound)"""

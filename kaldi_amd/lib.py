@@ -82,6 +82,7 @@ def load():
     L.k3_decoder_finalize_decoding.argtypes = [vp, vp]; L.k3_decoder_num_frames_decoded.argtypes = [vp, i32]; L.k3_decoder_num_frames_decoded.restype = i32
     L.k3_decoder_lattice_info.argtypes = [vp, vp]; L.k3_decoder_order_sensitive_events.argtypes = [vp, vp]
     L.k3_decoder_get_raw_lattices.argtypes = [vp] + [vp] * 10
+    L.k3_decoder_get_best_path.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]
     L.k3_fst_export_image.argtypes = [vp, vp]; L.k3_fst_import_image.argtypes = [vp, vp]
     L.k3_decoder_set_profiling.argtypes = [vp, i32]; L.k3_decoder_kernel_times.argtypes = [vp, vp]
     L.k3_decoder_phase_cycles.argtypes = [vp, vp]

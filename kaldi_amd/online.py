@@ -40,6 +40,30 @@ class OnlineBatchedFeaturePipeline:
         return res
 
 
+class OnlineEndpointRule:
+    """online2/online-endpoint.h:84-97"""
+    def __init__(self, must_contain_nonsilence=True, min_trailing_silence=1.0, max_relative_cost=float("inf"), min_utterance_length=0.0):
+        self.must_contain_nonsilence, self.min_trailing_silence, self.max_relative_cost, self.min_utterance_length = must_contain_nonsilence, min_trailing_silence, max_relative_cost, min_utterance_length
+
+class OnlineEndpointConfig:
+    """online2/online-endpoint.h:134-153: the five rules with the reference's defaults; silence_phones = set of phone ids"""
+    def __init__(self, silence_phones=()):
+        inf = float("inf"); self.silence_phones = set(int(x) for x in silence_phones)
+        self.rules = [OnlineEndpointRule(False, 5.0, inf, 0.0), OnlineEndpointRule(True, 0.5, 2.0, 0.0), OnlineEndpointRule(True, 1.0, 8.0, 0.0),
+                      OnlineEndpointRule(True, 2.0, inf, 0.0), OnlineEndpointRule(False, 0.0, inf, 20.0)]
+
+def EndpointDetected(config, num_frames_decoded, trailing_silence_frames, frame_shift_in_seconds, final_relative_cost):
+    """kaldi::EndpointDetected (online2/online-endpoint.cc:26-72), in float32 like the reference"""
+    f = np.float32
+    assert num_frames_decoded >= trailing_silence_frames
+    utt_len = f(num_frames_decoded) * f(frame_shift_in_seconds); sil = f(trailing_silence_frames) * f(frame_shift_in_seconds)
+    for r in config.rules:
+        contains_nonsilence = utt_len > sil
+        if (contains_nonsilence or not r.must_contain_nonsilence) and sil >= f(r.min_trailing_silence) and f(final_relative_cost) <= f(r.max_relative_cost) and utt_len >= f(r.min_utterance_length):
+            return True
+    return False
+
+
 class BatchedOnlinePipeline:
     """`num_channels` concurrent audio streams decoded chunk by chunk, the channel model of BatchedThreadedNnet3CudaOnlinePipeline:
     DecodeBatch(channels, wave_chunks, is_first_chunk, is_last_chunk) pushes the new audio of the listed channels through
@@ -58,6 +82,23 @@ class BatchedOnlinePipeline:
         self._empty_feats = torch.zeros((0, self.features.Dim()), dtype=torch.float32, device=self.dev)
         self.pending = [self._empty_feats for _ in range(num_channels)]
         self.started = np.zeros(num_channels, bool); self.frames_decoded = np.zeros(num_channels, np.int64)
+        self.frame_shift_seconds = 0.001 * feat_opts.frame_shift_ms * frame_subsampling_factor      # SetOutputFrameShiftInSeconds
+
+    def GetPartialHypothesis(self, channels):
+        """CudaDecoder::GetPartialHypothesis (cuda-decoder.h:286): the words of the best path to the tokens each channel holds now (no final-probs)"""
+        return [bp["olabels"] for bp in self.decoder.GetBestPath(channels, use_final_probs=False)]
+
+    def EndpointDetected(self, channels, config, tid2phone):
+        """CudaDecoder::EndpointDetected (cuda-decoder.h:293, cuda-decoder.cc:1921-1950): kaldi::EndpointDetected on the best-path traceback of each
+        channel -- trailing frames whose transition-id belongs to a silence phone, frames decoded, FinalRelativeCost.  tid2phone: phone of a transition-id."""
+        out = []
+        for ch, bp in zip(channels, self.decoder.GetBestPath(channels, use_final_probs=False)):
+            sil = 0
+            for t in reversed(bp["ilabels"]):
+                if int(tid2phone[t]) not in config.silence_phones: break
+                sil += 1
+            out.append(EndpointDetected(config, int(self.decoder.NumFramesDecoded(int(ch))), sil, self.frame_shift_seconds, bp["relative_cost"]))
+        return out
 
     def DecodeBatch(self, channels, wave_chunks, is_first_chunk, is_last_chunk):
         """returns {channel: RawLattice} for the channels whose stream ended with this call"""

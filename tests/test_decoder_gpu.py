@@ -175,3 +175,55 @@ def test_repeated_decodes_are_identical_to_the_oracle():
             dec.DecodeBatch(x, ro); dec.LatticeInfo()
             for u in range(len(lls)):
                 assert np.array_equal(dec.FrameStats(u, lls[u].shape[0])["ntoks"], ref[u % 2]), (rep, k, u)
+
+
+@pytest.mark.parametrize("literal", [0, 1])
+def test_best_path_traceback_on_the_gpu_pools(literal):
+    """k3_decoder_get_best_path (CudaDecoder::GetBestPath / the traceback of GetPartialHypothesis): after finalisation the traceback equals the best
+    path through the raw lattice (labels, costs); in the middle of an utterance (no final-probs) it equals the best path of the utterance cut there,
+    and FinalRelativeCost is the oracle's."""
+    from kaldi_amd import decoder
+    from oracle import lattice_oracle as lo
+    N = 60; f, t2p, cf = _setup(2500, 6500, N, seed=31, start_degree=40)
+    cfg = dict(beam=14.0, lattice_beam=7.0, max_active=3000)
+    rng = np.random.default_rng(8); lls = [(rng.standard_normal((T, N)) * 2.5).astype(np.float32) for T in (70, 33, 51)]
+    caps = dict(frame_tokens_cap=32768, frame_cands_cap=65536)
+    dec = decoder.CudaDecoder(cf, decoder.decoder_config(literal_order=literal, **dict(caps, **cfg)), 3, N)
+    # partial: feed the first k frames, trace back without final-probs
+    cut = [40, 33, 20]
+    dec.InitDecoding(3, 100)
+    dec.AdvanceDecoding(torch.from_numpy(np.concatenate([l[:c] for l, c in zip(lls, cut)])).cuda(), np.concatenate([[0], np.cumsum(cut)]))
+    part = dec.GetBestPath([0, 1, 2], use_final_probs=False)
+    for u in range(3):
+        import copy
+        f_nofinal = copy.copy(f); f_nofinal.final = np.full_like(f.final, np.inf)      # no final states: FinalizeDecoding then keeps the paths to ANY token of the newest frame
+        ref, oi = lo.decode(f_nofinal, lls[u][:cut[u]], t2p, _ocfg(lo, **cfg), mode=0 if literal else 1)
+        bp = ref.connect().best_path()
+        assert part[u]["ilabels"] == bp[0] and part[u]["olabels"] == bp[1], u
+        assert abs(part[u]["graph"] - bp[2]) < 1e-3 and abs(part[u]["acoustic"] - bp[3]) < 1e-3
+        assert len(part[u]["ilabels"]) == cut[u]
+    # the rest of the frames, finalise, trace back with final-probs
+    rest = [l[c:] for l, c in zip(lls, cut)]
+    dec.AdvanceDecoding(torch.from_numpy(np.concatenate(rest)).cuda(), np.concatenate([[0], np.cumsum([r.shape[0] for r in rest])]))
+    full_partial = dec.GetBestPath(None, use_final_probs=True)
+    dec.FinalizeDecoding(); lats = dec.GetRawLattices(); fin = dec.GetBestPath(None, use_final_probs=True)
+    for u in range(3):
+        bp = lats[u].connect().best_path()
+        for got in (fin[u], full_partial[u]):
+            assert got["ilabels"] == bp[0] and got["olabels"] == bp[1], u
+            assert abs(got["graph"] - bp[2]) < 1e-3 and abs(got["acoustic"] - bp[3]) < 1e-3
+        if fin[u]["reached_final"]: assert np.isfinite(fin[u]["relative_cost"]) and fin[u]["relative_cost"] >= 0.0
+
+
+def test_endpoint_rules_follow_the_reference():
+    """kaldi::EndpointDetected (online2/online-endpoint.cc:26-72) with the default rules: hand-checked cases"""
+    from kaldi_amd import online
+    c = online.OnlineEndpointConfig(silence_phones=[1])
+    E = lambda n, sil, rc: online.EndpointDetected(c, n, sil, 0.03, rc)
+    assert not E(100, 10, np.inf)                  # 0.3 s of silence, no final state: nothing fires
+    assert E(200, 170, np.inf)                     # rule 1: 5.1 s of trailing silence, anything
+    assert not E(165, 165, 1.0)                    # only silence so far (4.95 s): rules 2-4 need non-silence, rule 1 needs 5 s
+    assert E(100, 17, 1.5)                         # rule 2: >= 0.5 s silence, relative cost <= 2
+    assert not E(100, 17, 3.0) and E(100, 34, 3.0) # rule 3: >= 1 s, relative cost <= 8
+    assert E(100, 67, np.inf)                      # rule 4: >= 2 s
+    assert E(700, 0, np.inf)                       # rule 5: utterance >= 20 s
