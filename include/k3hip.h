@@ -191,6 +191,9 @@ int k3_decoder_decode_batch(k3_decoder *dec, int32_t num_utts, const float *d_lo
  * k3_decoder_decode_batch.  max_total_frames bounds the frames a lane receives between init and finalize. */
 int k3_decoder_init_decoding(k3_decoder *dec, int32_t num_utts, int32_t max_total_frames, void *stream);
 int k3_decoder_advance_decoding(k3_decoder *dec, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_offsets, void *stream);
+/* The reference's own form of the call, CudaDecoder::AdvanceDecoding(lanes_assignements) (cuda-decoder.h:262): each listed channel gets a DEVICE
+ * pointer to the log-likelihoods of its next num_frames frames (rows ld floats apart), wherever they live; the other channels of the group idle. */
+int k3_decoder_advance_decoding_lanes(k3_decoder *dec, int32_t num_channels, const int32_t *channels, const float *const *h_lane_frames, int32_t num_frames, int64_t ld, void *stream);
 int k3_decoder_finalize_decoding(k3_decoder *dec, void *stream);
 /* Channels with independent lifetimes inside one lane group (CudaDecoder::InitDecoding(channels) cuda-decoder.h:248 / the per-channel
  * end of an utterance in the online pipeline): k3_decoder_init_channels restarts the listed lanes (start token + eps closure at their

@@ -99,6 +99,7 @@ struct DecParams {
   int frame_tokens_cap, frame_cands_cap, hash_mask; long long lane_tokens_cap, lane_links_cap;
   // input
   const float *loglikes; long long ld; const long long *row_off; int num_pdfs; int use_lds_row;
+  const float *const *lane_rows;          // non-null: lane l's next frames start at lane_rows[l] (rows ld apart) instead of row row_off[l] of `loglikes`
   const int *fresh;                       // [nlanes] 1: InitDecoding first (start token + eps closure), frames start at 0; 0: continue after LaneInfo::num_frames frames (AdvanceDecoding)
   const int *lane_ids;                    // prune / output kernels: the lanes being finalised (workgroup b works on lane lane_ids[b]); null = lane b
   // per-lane pools (lane l at base + l * stride)
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     if (f >= 0) {
     // stage the log-likelihood row of this frame in LDS (coalesced), overlapped with the cutoff passes
     K3_T(0);
-    const float *row = p.loglikes + (r0 + (f - f0)) * p.ld;
+    const float *row = p.lane_rows ? p.lane_rows[L] + (long long)(f - f0) * p.ld : p.loglikes + (r0 + (f - f0)) * p.ld;
     if (p.use_lds_row && f == f0) for (int i = tid; i < p.num_pdfs; i += kBlock) s_ll[i] = row[i];   // later rows are prefetched one frame ahead
     const float *ll = p.use_lds_row ? s_ll : row;
     const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
@@ -1335,7 +1336,7 @@ struct k3_decoder {
   DecParams p{};
   std::vector<void *> allocs;
   long long fstride = 0; std::vector<void *> frame_allocs;
-  long long *d_row_off = nullptr; int *d_fresh = nullptr, *d_lane_ids = nullptr;
+  long long *d_row_off = nullptr; int *d_fresh = nullptr, *d_lane_ids = nullptr; const float **d_lane_rows = nullptr;
   int last_utts = 0; std::vector<int> last_frames, fresh, lane_final;   // per lane: frames consumed, InitDecoding pending, FinalizeDecoding done
   std::vector<int> sel;                                                   // lanes of the latest finalize call (what the lattice getters return)
   hipStream_t last_stream = nullptr;
@@ -1520,11 +1521,41 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   K3_HIP_CHECK(hipMemcpy(d->d_row_off, h_row_off, sizeof(long long) * (num_utts + 1), hipMemcpyHostToDevice));
   K3_HIP_CHECK(hipMemcpy(d->d_fresh, d->fresh.data(), sizeof(int) * num_utts, hipMemcpyHostToDevice));
   std::fill(d->fresh.begin(), d->fresh.end(), 0);
-  p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off; p.fresh = d->d_fresh; p.lane_ids = nullptr;
+  p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off; p.fresh = d->d_fresh; p.lane_ids = nullptr; p.lane_rows = nullptr;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   if (p.literal) hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(num_utts), dim3(kBlock), kLitDynLds, st, p);
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
+  d->started = true; d->last_stream = st; d->info_valid = false;
+  return K3_OK;
+}
+
+// AdvanceDecoding(lanes_assignements) of the reference (cuda-decoder.h:262): every listed channel gets a device pointer to the log-likelihoods of
+// its next frame(s) -- num_frames rows, ld floats apart -- wherever they live; the other channels of the group idle.
+extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const int32_t *channels, const float *const *h_lane_frames, int32_t num_frames, int64_t ld, void *stream) {
+  K3_REQUIRE(d && channels && h_lane_frames && n >= 0 && num_frames > 0 && ld >= d->num_pdfs && d->last_utts > 0, "k3_decoder_advance_decoding_lanes: bad argument (call k3_decoder_init_decoding first)");
+  hipStream_t st = (hipStream_t)stream; DecParams &p = d->p; const int U = d->last_utts;
+  std::vector<long long> ro(U + 1, 0); std::vector<const float *> rows(U, nullptr); std::vector<int> T(U, 0);
+  for (int i = 0; i < n; i++) {
+    const int c = channels[i];
+    K3_REQUIRE(c >= 0 && c < U && h_lane_frames[i] && T[c] == 0, "k3_decoder_advance_decoding_lanes: channel out of range / listed twice / null frame pointer");
+    K3_REQUIRE(d->last_frames[c] + num_frames + 2 <= d->fstride && !d->lane_final[c], "k3_decoder_advance_decoding_lanes: more frames than max_total_frames, or a finalised channel");
+    T[c] = num_frames; rows[c] = h_lane_frames[i];
+  }
+  for (int u = 0; u < U; u++) { ro[u + 1] = ro[u] + T[u]; d->last_frames[u] += T[u]; }
+  K3_HIP_CHECK(hipStreamSynchronize(st));
+  if (!d->d_lane_rows) { int rc = dmalloc(&d->allocs, &d->d_lane_rows, (size_t)d->nlanes); if (rc) return rc; }
+  K3_HIP_CHECK(hipMemcpy(d->d_row_off, ro.data(), sizeof(long long) * (U + 1), hipMemcpyHostToDevice));
+  K3_HIP_CHECK(hipMemcpy(d->d_lane_rows, rows.data(), sizeof(float *) * U, hipMemcpyHostToDevice));
+  K3_HIP_CHECK(hipMemcpy(d->d_fresh, d->fresh.data(), sizeof(int) * U, hipMemcpyHostToDevice));
+  std::fill(d->fresh.begin(), d->fresh.end(), 0);
+  p.loglikes = nullptr; p.ld = ld; p.row_off = d->d_row_off; p.fresh = d->d_fresh; p.lane_ids = nullptr; p.lane_rows = d->d_lane_rows;
+  const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
+  if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
+  if (p.literal) hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(U), dim3(kBlock), kLitDynLds, st, p);
+  else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
   d->started = true; d->last_stream = st; d->info_valid = false;

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     float accept = p.beam; long long nb = 0; unsigned m_e = 1; int n_e = 1;
     const int *ord_cur = q.order[sel]; int *ord_nxt = q.order[sel ^ 1];
     if (f >= 0) {
-      const float *ll = p.loglikes + (r0 + (f - f0)) * p.ld;
+      const float *ll = p.lane_rows ? p.lane_rows[L] + (long long)(f - f0) * p.ld : p.loglikes + (r0 + (f - f0)) * p.ld;
       const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
       if (n_cur == 0) { status = kStNoTokens; break; }
       // ---- GetCutoff (:653-720): the best token is the FIRST minimum-cost token of the list (strict <, :661-663)

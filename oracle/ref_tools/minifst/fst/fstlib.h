@@ -200,10 +200,13 @@ template <class F> class ArcIterator {
   const Arc *arcs_; size_t n_, i_;
 };
 
+template <class A> typename A::StateId CountStates(const Fst<A> &fst) {      // (OpenFst's StateIterator works on the base class too)
+  const ExpandedFst<A> *e = dynamic_cast<const ExpandedFst<A> *>(&fst); CHECK(e != nullptr); return e->NumStates();
+}
 template <class F> class StateIterator {
  public:
   using StateId = typename F::Arc::StateId;
-  explicit StateIterator(const F &fst) : n_(fst.NumStates()), s_(0) {}
+  explicit StateIterator(const F &fst) : n_(CountStates<typename F::Arc>(fst)), s_(0) {}
   bool Done() const { return s_ >= n_; }
   StateId Value() const { return s_; }
   void Next() { ++s_; }

@@ -1,0 +1,75 @@
+// tests/adapter/cuda_decoder_example.cc -- a caller of kaldi::cuda_decoder::CudaFst / CudaDecoder written against the REFERENCE's signatures
+// (cudadecoder/cuda-fst.h:62-149, cuda-decoder.h:224-345) and compiled against include/k3_cuda_decoder.h + the reference's lattice types.
+// Same file protocol as oracle/ref_tools/ref_lattice_decoder.cc (the reference's CPU LatticeFasterDecoder), so that the test can compare the
+// two outputs directly:   cuda-decoder-example <in.bin> <out.bin> [frames-per-call]
+#include <hip/hip_runtime_api.h>
+#include <cstdio>
+#include <iostream>
+#include <vector>
+#include "k3_cuda_decoder.h"
+using namespace kaldi; using namespace kaldi::cuda_decoder;
+namespace {
+struct Reader { FILE *f; template <class T> void get(T *p, size_t n) { if (n && fread(p, sizeof(T), n, f) != n) { std::cerr << "short read\n"; exit(2); } } };
+struct IdentityTransitions : public TransitionInformation {      // the test graphs carry their own transition-id -> pdf-id table
+  explicit IdentityTransitions(const std::vector<int32> &t2p) : t2p_(t2p) {}
+  bool TransitionIdsEquivalent(int32 a, int32 b) const override { return a == b; }
+  bool TransitionIdIsStartOfPhone(int32) const override { return true; }
+  int32 TransitionIdToPhone(int32) const override { return 1; }
+  bool IsFinal(int32) const override { return true; }
+  bool IsSelfLoop(int32) const override { return false; }
+  const std::vector<int32> &TransitionIdToPdfArray() const override { return t2p_; }
+  int32 NumPdfs() const override { int32 m = 0; for (int32 p : t2p_) m = std::max(m, p + 1); return m; }
+  std::vector<int32> t2p_;
+};
+}
+int main(int argc, char **argv) {
+  if (argc < 3) { std::cerr << "usage: cuda-decoder-example <in.bin> <out.bin> [frames-per-call]\n"; return 1; }
+  try {
+    Reader in{fopen(argv[1], "rb")}; if (!in.f) return 2;
+    int32_t h[10]; float c[5]; in.get(h, 10); in.get(c, 5);
+    const int32_t S = h[1], start = h[2], A = h[3], T = h[4], P = h[5], NT = h[6];
+    std::vector<int32_t> off(S + 1), il(A), ol(A), nx(A), t2p(NT); std::vector<float> w(A), fin(S), ll((size_t)T * P);
+    in.get(off.data(), S + 1); in.get(il.data(), A); in.get(ol.data(), A); in.get(nx.data(), A); in.get(w.data(), A); in.get(fin.data(), S); in.get(t2p.data(), NT); in.get(ll.data(), ll.size());
+    fclose(in.f);
+    fst::VectorFst<fst::StdArc> graph;
+    for (int32_t s = 0; s < S; s++) graph.AddState();
+    graph.SetStart(start);
+    for (int32_t s = 0; s < S; s++) { graph.SetFinal(s, fst::TropicalWeight(fin[s])); for (int32_t a = off[s]; a < off[s + 1]; a++) graph.AddArc(s, fst::StdArc(il[a], ol[a], fst::TropicalWeight(w[a]), nx[a])); }
+    IdentityTransitions trans(t2p);
+    CudaFst cuda_fst(graph, &trans);
+    CudaDecoderConfig cfg; cfg.default_beam = c[0]; cfg.lattice_beam = c[1]; cfg.beam_delta = c[2]; cfg.hash_ratio = c[3]; cfg.max_active = h[7]; cfg.min_active = h[8];
+    cfg.main_q_capacity = 65536; cfg.aux_q_capacity = 262144; cfg.ntokens_pre_allocated = 2500000;
+    const int32 nchannels = 2;
+    CudaDecoder decoder(cuda_fst, cfg, nchannels, nchannels, P, T + 8);
+    decoder.AllowPartialHypotheses();
+    float *d_ll = NULL;
+    if (hipMalloc((void **)&d_ll, sizeof(float) * ll.size()) != hipSuccess || hipMemcpy(d_ll, ll.data(), sizeof(float) * ll.size(), hipMemcpyHostToDevice) != hipSuccess) { std::cerr << "hip alloc/copy failed\n"; return 3; }
+    const int32 step = argc > 3 ? atoi(argv[3]) : 1;
+    std::vector<ChannelId> channels = {1};                               // decode on channel 1; channel 0 stays idle
+    decoder.InitDecoding(channels);
+    for (int32 t = 0; t < T; t += step) {
+      const int32 n = std::min(step, T - t);
+      std::vector<std::pair<ChannelId, const BaseFloat *>> lanes = {{1, d_ll + (size_t)t * P}};
+      if (n == 1) decoder.AdvanceDecoding(lanes); else decoder.AdvanceDecoding(lanes, n, P);
+    }
+    PartialHypothesis *ph; decoder.GetPartialHypothesis(1, &ph);
+    Lattice best, lat; std::vector<Lattice *> outs = {&best};
+    decoder.GetBestPath(channels, outs, true);
+    outs[0] = &lat; decoder.GetRawLattice(channels, outs, true);
+    std::cerr << "frames decoded " << decoder.NumFramesDecoded(1) << ", partial hypothesis: " << ph->out_str << ", best path arcs " << best.NumStates() - 1 << "\n";
+    const int64_t ns = lat.NumStates(); int64_t na = 0; for (int64_t s = 0; s < ns; s++) na += (int64_t)lat.NumArcs((int)s);
+    // (states of the raw lattice are numbered frame by frame by the C ABI: recover the frames from the arcs)
+    std::vector<int32_t> frame(ns, 0); std::vector<float> fg(ns), fa(ns), g, ac; std::vector<int32_t> src, dst, oi, oo;
+    for (int64_t s = 0; s < ns; s++) {
+      const LatticeWeight f = lat.Final((int)s); fg[s] = f.Value1(); fa[s] = f.Value2();
+      for (fst::ArcIterator<Lattice> it(lat, (int)s); !it.Done(); it.Next()) { const LatticeArc &arc = it.Value(); src.push_back((int32_t)s); dst.push_back(arc.nextstate); oi.push_back(arc.ilabel); oo.push_back(arc.olabel); g.push_back(arc.weight.Value1()); ac.push_back(arc.weight.Value2()); }
+    }
+    for (bool changed = true; changed;) { changed = false; for (size_t a = 0; a < src.size(); a++) { const int32_t fr = frame[src[a]] + (oi[a] != 0 ? 1 : 0); if (fr > frame[dst[a]]) { frame[dst[a]] = fr; changed = true; } } }
+    FILE *o = fopen(argv[2], "wb"); if (!o) return 2;
+    const int64_t hdr[5] = {ns, na, lat.Start(), 1, decoder.NumFramesDecoded(1)}; const double secs = 0.0;
+    fwrite(hdr, 8, 5, o); fwrite(frame.data(), 4, ns, o); fwrite(fg.data(), 4, ns, o); fwrite(fa.data(), 4, ns, o);
+    fwrite(src.data(), 4, na, o); fwrite(dst.data(), 4, na, o); fwrite(oi.data(), 4, na, o); fwrite(oo.data(), 4, na, o); fwrite(g.data(), 4, na, o); fwrite(ac.data(), 4, na, o); fwrite(&secs, 8, 1, o);
+    fclose(o); (void)hipFree(d_ll);
+    return 0;
+  } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
+}
