@@ -134,6 +134,7 @@ int k3_fst_create(int32_t num_states, int32_t start, const int32_t *h_arc_offset
 void k3_fst_destroy(k3_fst *fst);
 int64_t k3_fst_num_arcs(const k3_fst *fst);
 int32_t k3_fst_num_states(const k3_fst *fst);
+int32_t k3_fst_start(const k3_fst *fst);
 /* Size in bytes and device address of the packed read-only graph image (one contiguous allocation), so that a
  * multi-GPU launcher can broadcast it once over RCCL (ncclBroadcast of `bytes` uint8 from the loading rank) and
  * attach it on the other ranks with k3_fst_attach() -- SURVEY 8e: "HCLG broadcast once over RCCL/xGMI". */
@@ -141,6 +142,15 @@ int k3_fst_image(const k3_fst *fst, void **d_image, int64_t *bytes);
 int k3_fst_create_empty(int32_t num_states, int64_t num_arcs, int32_t start, k3_fst **fst); /* allocate an image of that shape (receiver side) */
 int k3_fst_export_image(const k3_fst *fst, void *d_dst);   /* device-to-device copy of the image into a caller buffer (e.g. the collective's send buffer) */
 int k3_fst_import_image(k3_fst *fst, const void *d_src);   /* the reverse, after the collective */
+
+/* Multi-GPU: one process per GPU; the graph is read and converted on ONE rank and broadcast over RCCL (xGMI inside a node) into the
+ * other ranks' HBM, once; nothing else is shared (utterances are independent, every rank writes its own lattices: lat.JOB of decode.sh:123).
+ * k3_fst_bcast: on `root` *fst is the graph; on the other ranks *fst is NULL on entry and owns a graph with root's image on return.  `comm` is an
+ * ncclComm_t -- the application's own, or k3_comm_create's: the 128-byte ncclUniqueId travels through a file every rank can see (rank 0 writes
+ * id_file, the others wait up to timeout_seconds for it).  RCCL is bound at run time (dlopen): single-GPU users never load it. */
+int k3_comm_create(const char *id_file, int32_t rank, int32_t world_size, int32_t timeout_seconds, void **comm);
+void k3_comm_destroy(void *comm);
+int k3_fst_bcast(k3_fst **fst, void *comm /* ncclComm_t */, int32_t root, int32_t rank, void *stream);
 
 /* ---------------------------------------------------------------- lattice decoder ------------
  * Replaces: LatticeFasterDecoder::Decode = InitDecoding + AdvanceDecoding + FinalizeDecoding + GetRawLattice

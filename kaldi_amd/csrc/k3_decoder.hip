@@ -1322,9 +1322,19 @@ extern "C" int k3_fst_import_image(k3_fst *f, const void *d_src) {
   K3_HIP_CHECK(hipMemcpy(f->image, d_src, f->bytes, hipMemcpyDeviceToDevice));
   return K3_OK;
 }
+extern "C" int k3_fst_shape_and_image(const k3_fst *f, int64_t *shape, void **d_image) {      // (k3_comm.hip)
+  K3_REQUIRE(f && shape && d_image, "k3_fst_shape_and_image: null argument");
+  shape[0] = f->num_states; shape[1] = f->num_arcs; shape[2] = f->start; shape[3] = (int64_t)f->bytes; shape[4] = f->max_pdf; *d_image = f->image; return K3_OK;
+}
+extern "C" int k3_fst_create_shaped(const int64_t *shape, k3_fst **out) {
+  k3_fst *f = nullptr; const int rc = k3_fst_create_empty((int32_t)shape[0], shape[1], (int32_t)shape[2], &f); if (rc) return rc;
+  if ((int64_t)f->bytes != shape[3]) { delete f; k3::set_error("k3_fst_bcast: image size mismatch between ranks (different library builds?)"); return K3_ERR_ARG; }
+  f->max_pdf = (int32_t)shape[4]; *out = f; return K3_OK;
+}
 extern "C" void k3_fst_destroy(k3_fst *f) { delete f; }
 extern "C" int64_t k3_fst_num_arcs(const k3_fst *f) { return f ? f->num_arcs : -1; }
 extern "C" int32_t k3_fst_num_states(const k3_fst *f) { return f ? f->num_states : -1; }
+extern "C" int32_t k3_fst_start(const k3_fst *f) { return f ? f->start : -1; }
 extern "C" int k3_fst_image(const k3_fst *f, void **d_image, int64_t *bytes) {
   K3_REQUIRE(f && d_image && bytes, "k3_fst_image: null argument");
   *d_image = f->image; *bytes = (int64_t)f->bytes; return K3_OK;

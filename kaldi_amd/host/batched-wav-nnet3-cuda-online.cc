@@ -23,6 +23,7 @@ int main(int argc, char **argv) {
         "Reads in wav file(s) and simulates online decoding with neural nets (nnet3 setup), the audio of several files being fed chunk by chunk.\n"
         "Usage: batched-wav-nnet3-cuda-online [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
     ParseOptions po(usage);
+    bool literal_order = true; float hash_ratio = 2.0f;
     bool write_compact = true, write_lattice = true, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
     int32_t worker_threads = -1;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, frames_per_chunk = 51, subsampling = 1, num_streaming = 2000;
@@ -45,6 +46,7 @@ int main(int argc, char **argv) {
     po.Register("print-partial-hypotheses", &print_partial, "(not supported)"); po.Register("print-endpoints", &print_endpoints, "(not supported)");
     po.Register("simulate-realtime-writing", &simulate_rt, "(accepted, unused: chunks are submitted as fast as the GPU takes them)");
     po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused)");
+    po.Register("literal-order", &literal_order, "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's; false = the order-independent fast decoder"); po.Register("hash-ratio", &hash_ratio, "LatticeFasterDecoderConfig::hash_ratio (used with --literal-order)");
     po.Register("beam", &beam, "Decoding beam. Larger->slower, more accurate."); po.Register("lattice-beam", &lattice_beam, "The width of the lattice beam");
     po.Register("max-active", &max_active, "Decoder max active states. Larger->slower; more accurate"); po.Register("min-active", &min_active, "Decoder min active states");
     po.Register("beam-delta", &beam_delta, "Increment used when the active-state limits move the beam");
@@ -85,6 +87,7 @@ int main(int argc, char **argv) {
     dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(min_active, max_active - 1); dc.beam_delta = beam_delta;
     dc.frame_tokens_cap = main_q > 0 ? main_q : std::min(65536, std::max(4 * max_active, 4096)); dc.frame_cands_cap = aux_q > 0 ? std::max(aux_q, dc.frame_tokens_cap) : 3 * dc.frame_tokens_cap;
     dc.lane_tokens_cap = std::max<int64_t>(ntok_pre, dc.frame_tokens_cap); dc.lane_links_cap = 2 * dc.lane_tokens_cap;
+    dc.literal_order = literal_order ? 1 : 0; dc.hash_ratio = hash_ratio; if (literal_order) { dc.frame_tokens_cap = std::min(dc.frame_tokens_cap, 65536); dc.frame_cands_cap = std::max(dc.frame_cands_cap, dc.frame_tokens_cap + 1); }
     const int nch = num_channels, N = ninfo.output_dim, C = frames_per_chunk / subsampling * subsampling > 0 ? frames_per_chunk / subsampling * subsampling : subsampling;
     k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, nch, N, &dec));
     K3H_CHECK_K3(k3_decoder_init_decoding(dec, nch, max_frames, nullptr));

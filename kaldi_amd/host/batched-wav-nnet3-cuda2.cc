@@ -33,6 +33,7 @@ int main(int argc, char **argv) {
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, worker_threads = -1, copy_threads = 2, frames_per_chunk = 50, subsampling = 1;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, elc = 0, erc = 0, elci = -1, ercf = -1;
     float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; double mem_prop = 0.5; int32_t det_max_mem = 50000000;
+    bool literal_order = true; float hash_ratio = 2.0f; int32_t rank = getenv("RANK") ? atoi(getenv("RANK")) : 0, world_size = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1, device = -1; std::string nccl_id_file;
     std::string word_syms, postproc, feature_type = "mfcc", mfcc_config, fbank_config, plp_config, pitch_config, cmvn_config, global_cmvn, ivector_config, use_gpu = "yes";
     po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
@@ -65,6 +66,12 @@ int main(int argc, char **argv) {
     po.Register("add-pitch", &add_pitch, "(pitch features are not supported)"); po.Register("online-pitch-config", &pitch_config, "(not supported)");
     po.Register("cmvn-config", &cmvn_config, "(online CMVN is not supported; chain recipes use --norm-means=false)"); po.Register("global-cmvn-stats", &global_cmvn, "(not supported)");
     po.Register("ivector-extraction-config", &ivector_config, "(i-vector extraction is not supported)");
+    po.Register("literal-order", &literal_order, "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's, bit for bit (serial cutoff tightening in hash-list order reproduced on the GPU); false = the order-independent fast decoder");
+    po.Register("hash-ratio", &hash_ratio, "LatticeFasterDecoderConfig::hash_ratio (it decides the reference's token visit order; used with --literal-order)");
+    po.Register("rank", &rank, "(not in the reference) this process's rank in a multi-GPU job: it takes the utterances i with i % world-size == rank, uses GPU <rank> of the node unless LOCAL_RANK / --device says otherwise, and writes the lattice wspecifier with JOB replaced by rank + 1 (lat.JOB.gz of decode.sh).  Default: $RANK or 0");
+    po.Register("world-size", &world_size, "(not in the reference) number of ranks (one process per GPU).  Default: $WORLD_SIZE or 1");
+    po.Register("device", &device, "(not in the reference) HIP device of this process (-1: $LOCAL_RANK, else rank modulo the number of devices)");
+    po.Register("nccl-id-file", &nccl_id_file, "(not in the reference) with world-size > 1: rank 0 reads the graph and broadcasts it once over RCCL/xGMI to the other ranks; the communicator's id travels through this file (shared directory).  Empty: every rank reads the graph itself");
     po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)"); po.Register("cuda-use-tensor-cores", &tensor_cores, "(accepted, unused: FP32 matrix cores are always used)");
     po.Register("cuda-use-tf32-compute", &tf32, "(accepted, unused: gfx950 has no tf32/xf32)"); po.Register("cuda-cache-memory", &cache_mem, "(accepted, unused)"); po.Register("cuda-memory-proportion", &mem_prop, "(accepted, unused)");
     po.Read(argc, argv);
@@ -72,7 +79,13 @@ int main(int argc, char **argv) {
     DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
     if (segmentation || use_online || add_pitch || !ivector_config.empty() || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
       K3H_ERR << "an option that needs a component outside the accelerated path was given (segmentation / online features / pitch / ivectors / PLP / CMVN / extra context)";
-    const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);
+    const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3); std::string out_wspec = po.GetArg(4);
+    if (world_size < 1 || rank < 0 || rank >= world_size) K3H_ERR << "--rank=" << rank << " is not in [0, --world-size=" << world_size << ")";
+    { int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev)); if (ndev < 1) K3H_ERR << "no HIP device";
+      if (device < 0) device = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) % ndev : rank % ndev;
+      if (device >= ndev) K3H_ERR << "--device=" << device << " but the node has " << ndev << " devices";
+      HIPCHK(hipSetDevice(device)); }
+    for (size_t q; (q = out_wspec.find("JOB")) != std::string::npos;) out_wspec.replace(q, 3, std::to_string(rank + 1));      // utils/run.pl convention
 
     // feature options come from the config file named for the selected feature type, like OnlineNnet2FeaturePipelineInfo
     const bool mfcc = feature_type == "mfcc";
@@ -93,18 +106,29 @@ int main(int argc, char **argv) {
     if (ninfo.has_priors) { log_priors.resize(ninfo.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet, log_priors.data())); for (float &p : log_priors) p = logf(p); }
 
     // decoding graph
-    HostFst hfst = ReadFstKaldiGeneric(fst_rx);
-    k3_fst *fst = nullptr;
-    K3H_CHECK_K3(k3_fst_create(hfst.NumStates(), hfst.start, hfst.arc_offsets.data(), hfst.ilabel.data(), hfst.olabel.data(), hfst.weight.data(), hfst.nextstate.data(),
-                               hfst.final_cost.data(), ti.id2pdf.data(), (int32_t)ti.id2pdf.size(), &fst));
+    // (multi-GPU: read and converted once, on rank 0, then one RCCL broadcast of the device image; the start state travels with it)
+    HostFst hfst; k3_fst *fst = nullptr; const bool bcast = world_size > 1 && !nccl_id_file.empty();
+    if (!bcast || rank == 0) {
+      hfst = ReadFstKaldiGeneric(fst_rx);
+      K3H_CHECK_K3(k3_fst_create(hfst.NumStates(), hfst.start, hfst.arc_offsets.data(), hfst.ilabel.data(), hfst.olabel.data(), hfst.weight.data(), hfst.nextstate.data(),
+                                 hfst.final_cost.data(), ti.id2pdf.data(), (int32_t)ti.id2pdf.size(), &fst));
+    }
+    if (bcast) {
+      void *comm = nullptr; K3H_CHECK_K3(k3_comm_create(nccl_id_file.c_str(), rank, world_size, 600, &comm));
+      K3H_CHECK_K3(k3_fst_bcast(&fst, comm, 0, rank, nullptr)); k3_comm_destroy(comm);
+      K3H_LOG << "rank " << rank << ": decoding graph " << (rank == 0 ? "sent" : "received") << " over RCCL (" << k3_fst_num_states(fst) << " states, " << k3_fst_num_arcs(fst) << " arcs)";
+    }
+    const int32_t graph_start = k3_fst_start(fst);
     k3_decoder_config dc; k3_decoder_config_default(&dc);
     dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(min_active, max_active - 1); dc.beam_delta = beam_delta;
     dc.frame_tokens_cap = main_q > 0 ? main_q : std::min(65536, std::max(4 * max_active, 4096)); dc.frame_cands_cap = aux_q > 0 ? std::max(aux_q, dc.frame_tokens_cap) : 3 * dc.frame_tokens_cap;
     dc.lane_tokens_cap = std::max<int64_t>(ntok_pre, dc.frame_tokens_cap); dc.lane_links_cap = 2 * dc.lane_tokens_cap;
+    dc.literal_order = literal_order ? 1 : 0; dc.hash_ratio = hash_ratio; if (literal_order) { dc.frame_tokens_cap = std::min(dc.frame_tokens_cap, 65536); dc.frame_cands_cap = std::max(dc.frame_cands_cap, dc.frame_tokens_cap + 1); }
     k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, max_batch, ninfo.output_dim, &dec));
 
     auto scp = ReadScp(wav_rspec);
     if (num_todo >= 0 && (size_t)num_todo < scp.size()) scp.resize(num_todo);
+    if (world_size > 1) { decltype(scp) mine; for (size_t i = 0; i < scp.size(); i++) if ((int32_t)(i % (size_t)world_size) == rank) mine.push_back(scp[i]); scp.swap(mine); }      // static round-robin shard
     std::unique_ptr<TableWriter> writer; if (write_lattice) writer.reset(new TableWriter(out_wspec));
     // determinization runs on worker threads while the GPU works on the next batch; records come out in submission order
     std::unique_ptr<DeterminizeSequencer> det_pool;
@@ -159,7 +183,7 @@ int main(int argc, char **argv) {
         Lattice lat; lat.st_frame.assign(r->sf.begin() + s0, r->sf.begin() + s0 + ns); lat.st_state.assign(r->ss.begin() + s0, r->ss.begin() + s0 + ns); lat.st_final.assign(r->sfin.begin() + s0, r->sfin.begin() + s0 + ns);
         lat.arc_src.assign(r->as.begin() + a0, r->as.begin() + a0 + na); lat.arc_dst.assign(r->ad.begin() + a0, r->ad.begin() + a0 + na); lat.arc_ilabel.assign(r->ai.begin() + a0, r->ai.begin() + a0 + na);
         lat.arc_olabel.assign(r->ao.begin() + a0, r->ao.begin() + a0 + na); lat.arc_graph.assign(r->ag.begin() + a0, r->ag.begin() + a0 + na); lat.arc_ac.assign(r->aa.begin() + a0, r->aa.begin() + a0 + na);
-        for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
+        for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == graph_start) lat.start = (int32_t)s;
         Connect(&lat);
         if (det_pool) det_pool->Run(key, std::move(lat));
         else if (write_compact) { CompactLattice clat; ConvertLattice(lat, &clat); writer->WriteCompactLattice(key, clat); }

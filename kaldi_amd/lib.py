@@ -73,6 +73,8 @@ def load():
     L.k3_fst_num_arcs.argtypes = [vp]; L.k3_fst_num_arcs.restype = i64
     L.k3_fst_num_states.argtypes = [vp]; L.k3_fst_num_states.restype = i32
     L.k3_fst_image.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    L.k3_comm_create.argtypes = [ctypes.c_char_p, i32, i32, i32, ctypes.POINTER(vp)]; L.k3_comm_destroy.argtypes = [vp]; L.k3_comm_destroy.restype = None
+    L.k3_fst_bcast.argtypes = [ctypes.POINTER(vp), vp, i32, i32, vp]
     L.k3_decoder_config_default.argtypes = [ctypes.POINTER(DecoderConfig)]; L.k3_decoder_config_default.restype = None
     L.k3_decoder_create.argtypes = [vp, ctypes.POINTER(DecoderConfig), i32, i32, ctypes.POINTER(vp)]
     L.k3_decoder_destroy.argtypes = [vp]; L.k3_decoder_destroy.restype = None

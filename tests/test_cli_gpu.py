@@ -92,7 +92,7 @@ def test_batched_wav_nnet3_cuda2_end_to_end(tmp_path):
     feats = sf.ComputeFeatures(torch.from_numpy(np.concatenate(waves)).to(dev), wo, fo, total)
     nn = nnet3.Nnet(f"{td}/final.mdl"); nb = nnet3.NnetBatch(nn, [fo_h[i + 1] - fo_h[i] for i in range(3)], 3)
     ll = nb.forward(feats)
-    dec = decoder.CudaDecoder(decoder.CudaFst(graph, t2p), decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000), 3, N)
+    dec = decoder.CudaDecoder(decoder.CudaFst(graph, t2p), decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, literal_order=1), 3, N)      # the program's default: --literal-order=true
     dec.DecodeBatch(ll, nb.out_offsets); lats = dec.GetRawLattices()
     for u, key in enumerate(got):
         ref = lats[u].connect()
@@ -256,3 +256,27 @@ def test_batched_wav_nnet3_cuda_online_equals_offline_program(tmp_path):
             canon = lambda lat: (sorted((a[2], a[3], float(a[4]), float(a[5])) for a in lat[0]), sorted(float(v) for v in lat[1].values()))
             assert canon(on[k]) == canon(off[k]), (fpc, k)
     assert subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online"), "x"], capture_output=True).returncode == 1
+
+
+def test_batched_wav_nnet3_cuda2_rank_sharding_and_job_naming(tmp_path):
+    """--rank / --world-size: rank r decodes the utterances i with i % world == r and writes lat.<r+1> (the lat.JOB convention of
+    decode.sh); the union of the ranks' archives is the single-process archive, record for record.  (The ranks run one after the other here: the
+    test box has one GPU; with --nccl-id-file they would also share one RCCL broadcast of the graph, tests/test_parallel_gpu.py.)"""
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001, 12000, 8000]
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    synth.make_hclg(3000, 8000, N, seed=11, start_degree=50).write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    base = [os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0",
+            "--max-batch-size=4", "--determinize-lattice=false", "--write-compact=false"]
+    tail = [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp"]
+    r = subprocess.run(base + tail + [f"ark,t:{td}/all.txt"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    for rank in (0, 1):
+        r = subprocess.run(base + [f"--rank={rank}", "--world-size=2", "--device=0"] + tail + [f"ark,t:{td}/lat.JOB.txt"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+        assert f"Decoded {3 - rank} utterances, 0 with errors." in r.stderr
+    whole, r1, r2 = _parse_text_lattices(f"{td}/all.txt"), _parse_text_lattices(f"{td}/lat.1.txt"), _parse_text_lattices(f"{td}/lat.2.txt")
+    assert list(r1) == ["utt0", "utt2", "utt4"] and list(r2) == ["utt1", "utt3"] and sorted(whole) == sorted(list(r1) + list(r2))
+    canon = lambda lat: (sorted((a[2], a[3], float(a[4]), float(a[5])) for a in lat[0]), sorted(float(v) for v in lat[1].values()))      # state numbers depend on the batch a lattice was decoded in
+    for part in (r1, r2):
+        for k, lat in part.items(): assert canon(lat) == canon(whole[k]) and len(lat[0]) > 0, k

@@ -1,0 +1,41 @@
+"""GPU: the multi-GPU entry points of the C ABI on the one GPU the test box has.  k3_comm_create + k3_fst_bcast with a one-rank RCCL communicator
+(rank 0 writes the ncclUniqueId file, creates the communicator, broadcasts shape and image in place): the RCCL binding (dlopen librccl.so.1, call
+sequence, data types) is exercised end to end; a graph attached from an image (the receiving side's code path: k3_fst_create_empty + image bytes)
+decodes identically.  N > 1 ranks need N GPUs: the driver's scaling run covers that; tests/test_parallel_cpu.py covers the sharding logic."""
+import ctypes, os, numpy as np, pytest, torch
+from kaldi_amd import synth
+pytestmark = pytest.mark.gpu
+
+def test_graph_broadcast_through_the_c_abi_single_rank(tmp_path):
+    from kaldi_amd import decoder, lib
+    L = lib.load(); N = 50
+    f = synth.make_hclg(2000, 5000, N, seed=1, start_degree=40); t2p = synth.tid2pdf(N); cf = decoder.CudaFst(f, t2p)
+    comm = ctypes.c_void_p()
+    lib.check(L.k3_comm_create(str(tmp_path / "nccl.id").encode(), 0, 1, 10, ctypes.byref(comm)))
+    assert os.path.getsize(tmp_path / "nccl.id") == 128
+    h = ctypes.c_void_p(cf._h.value)
+    lib.check(L.k3_fst_bcast(ctypes.byref(h), comm, 0, 0, None))
+    assert h.value == cf._h.value                       # the root keeps its graph
+    L.k3_comm_destroy(comm)
+    rng = np.random.default_rng(0); ll = (rng.standard_normal((40, N)) * 2.5).astype(np.float32)
+    dec = decoder.CudaDecoder(cf, decoder.decoder_config(beam=15.0, lattice_beam=8.0, literal_order=1), 1, N)
+    dec.DecodeBatch(torch.from_numpy(ll).cuda(), np.array([0, 40])); a = dec.GetRawLattices(copy=True)[0]
+    # receiving side: an empty graph of the broadcast shape + the image bytes
+    ptr, nbytes = cf.image(); buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda"); cf.export_image(buf)
+    cf2 = decoder.CudaFst.empty(f.num_states, f.num_arcs, f.start); cf2.import_image(buf)
+    dec2 = decoder.CudaDecoder(cf2, decoder.decoder_config(beam=15.0, lattice_beam=8.0, literal_order=1), 1, N)
+    dec2.DecodeBatch(torch.from_numpy(ll).cuda(), np.array([0, 40])); b = dec2.GetRawLattices(copy=True)[0]
+    assert a.num_arcs > 0 and a.diff(b) == ""
+
+def test_bench_two_ranks_on_one_device_with_gloo(tmp_path):
+    """bench.py's N > 1 path rehearsed on one GPU (K3_DIST_BACKEND=gloo: both ranks share the device): graph built on rank 0, broadcast_graph to
+    rank 1, per-rank decode, max-over-ranks timing, one JSON line with n_gpus = 2"""
+    import json, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, K3_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr=127.0.0.1", "--master-port=29731", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "1", "--warmup", "1", "--utts", "8", "--utt-seconds", "2", "--graph-states", "20000", "--graph-arcs", "50000", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["decode_stats"]["graph_broadcast_s"] > 0 and line["decode_stats"]["lattice_arcs"] > 0
