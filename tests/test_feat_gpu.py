@@ -2,7 +2,7 @@
 and the HTK golden vectors.  Tolerances: |delta| <= 1e-4 on log-mel (north_star / SURVEY 8d parity
 gate), 3e-4 on MFCC (values up to ~150, float32 ulp 1.5e-5, 40-term sums), HTK goldens at the
 reference tests' own tolerances."""
-import numpy as np, pytest, torch
+import os, numpy as np, pytest, torch
 from tests import feat_cases as fc
 
 pytestmark = pytest.mark.gpu
@@ -28,8 +28,15 @@ def test_hip_vs_reference_binary(feat_golden, name):
     got = _gpu_feats([feat_golden[wkey].astype(np.float32)], _opts(kind, kw))[0]
     ref = feat_golden["ref_" + name]
     assert got.shape == ref.shape
+    # log-mel: the 1e-4 of SURVEY 8d.  Lifted cepstra (values up to 150, cepstral lifter x12 on top of a 40-term DCT): the REFERENCE's own float32
+    # binary is 1.2e-4 .. 3.7e-4 away from the float64 evaluation of its own formulas (tests/golden/feat_truth64.npz, generator committed), so two
+    # float32 implementations cannot be asked to agree to 1e-4 there.  What is asserted instead: within 3e-4 of the reference binary AND no further
+    # from the float64 truth than the reference itself is (+ 5e-5): the difference to the reference is the reference's float32 rounding, not ours.
     tol = 1e-4 if kind == "fbank" else 3e-4
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+    truth = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feat_truth64.npz"))["truth64_" + name]
+    err_ref, err_gpu = np.abs(ref - truth).max(), np.abs(got - truth).max()
+    assert err_gpu <= err_ref + 5e-5, (name, err_gpu, err_ref)
 
 @pytest.mark.parametrize("idx", [1, 2, 3, 4])
 def test_hip_fbank_vs_htk(feat_golden, idx):
