@@ -87,6 +87,50 @@ int k3_cmvn_online_batch(const float *d_in, int64_t ld_in, float *d_out, int64_t
                          int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
                          const int32_t *skip_dims, int32_t num_skip_dims, void *stream);
 
+/* ---------------------------------------------------------------- online i-vectors -----------
+ * Replaces, for whole utterances: OnlineIvectorFeature (online2/online-ivector-feature.h:278-420) as ivector-extract-online2 drives it
+ * (online2bin/ivector-extract-online2.cc:120-175: every frame weighted 1, fresh adaptation state, use_most_recent_ivector=false) and the GPU
+ * reference BatchedIvectorExtractorCuda::GetIvectors (cudafeat/feature-online-batched-ivector-cuda.h:30-61).  One i-vector per
+ * ivector_period frames: row k of an utterance is the estimate from the statistics of frames 0..k*period (UpdateStatsUntilFrame :248-277),
+ * with the prior offset subtracted from its first element like GetFrame (:327-355).  The arithmetic follows the CPU reference (fp64 statistics,
+ * 15 warm-started conjugate-gradient iterations); exact_solve = 1 replaces the conjugate gradient by a Cholesky solve, the method of the GPU
+ * reference (and LinearCgd's own fall-back).
+ * The model is handed over as host arrays, the way the reference's readers hold them (libk3host's k3h_ivector_config_* reads the files of an
+ * --ivector-extraction-config): lda [lda_rows x lda_cols] with lda_cols = feat_dim*(left+right+1) or one more (an offset column,
+ * OnlineTransform); global_cmvn_stats [2 x (feat_dim+1)]; the diagonal UBM (DiagGmm gconsts / means_invvars / inv_vars, [G] / [G x D] / [G x D],
+ * D = lda_rows); the extractor's M [G x D x R] and Sigma^-1 [G x D(D+1)/2] packed lower triangles (IvectorExtractor M_, Sigma_inv_), prior_offset. */
+typedef struct k3_ivector k3_ivector;
+typedef struct k3_ivector_model {
+  int32_t feat_dim, lda_rows, lda_cols, num_gauss, ivector_dim;
+  const float *lda;
+  const double *global_cmvn_stats;
+  const double *gconsts, *means_invvars, *inv_vars;
+  const double *M, *sigma_inv;
+  double prior_offset;
+} k3_ivector_model;
+typedef struct k3_ivector_opts {       /* OnlineIvectorExtractionConfig (online2/online-ivector-feature.h:60-150) + its splice / cmvn configs */
+  int32_t left_context, right_context; /* --splice-config */
+  int32_t num_gselect;                 /* 5 */
+  float min_post, posterior_scale;     /* 0.025, 0.1 */
+  float max_count;                     /* 0 = off */
+  int32_t ivector_period;              /* 10 */
+  int32_t num_cg_iters;                /* 15 */
+  int32_t exact_solve;                 /* 0 */
+  int32_t online_cmvn_iextractor;      /* 0: the statistics see the features without CMVN (--online-cmvn-iextractor) */
+  k3_online_cmvn_opts cmvn;            /* --cmvn-config */
+} k3_ivector_opts;
+typedef struct k3_ivector_info { int32_t feat_dim, lda_dim, num_gauss, ivector_dim, ivector_period; } k3_ivector_info;
+void k3_ivector_opts_default(k3_ivector_opts *opts);
+int k3_ivector_create(const k3_ivector_model *model, const k3_ivector_opts *opts, k3_ivector **iv);
+void k3_ivector_destroy(k3_ivector *iv);
+int k3_ivector_get_info(const k3_ivector *iv, k3_ivector_info *info);
+/* rows of the output: sum over utterances of ceil(frames / period); h_row_offsets (nullable) gets the U+1 row offsets */
+int64_t k3_ivector_num_rows(const k3_ivector *iv, int32_t num_utts, const int64_t *h_frame_offsets, int64_t *h_row_offsets);
+/* d_feats: the utterances' base features back to back (h_frame_offsets[u]..[u+1], host array of U+1, first 0), as k3_feat_compute_batch writes
+ * them; d_ivectors [num_rows x ld_ivectors].  Asynchronous on `stream` after a short synchronisation for the offsets. */
+int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
+                             float *d_ivectors, int64_t ld_ivectors, void *stream);
+
 /* ---------------------------------------------------------------- nnet3 forward -------------
  * Replaces, for "simple" feed-forward TDNN / TDNN-F models: nnet3::NnetComputer::Run over the compiled
  * program of DecodableNnetSimple (nnet3/nnet-am-decodable-simple.cc:93-276; nnet3/nnet-compute.cc:236-459)

@@ -11,6 +11,7 @@
  *   k3h_transitions_read      ReadKaldiObject(model, &trans_model): the transition-id -> phone / self-loop / phone-start map that
  *                             DeterminizeLatticeInsertPhones asks of TransitionInformation (lat/determinize-lattice-pruned.cc:1291-1343)
  *   k3h_clat_write            CompactLatticeWriter::Write (lat/kaldi-lattice.cc:65-94; "ark:" binary compactlattice44 / "ark,t:" text)
+ *   k3h_ivector_config_read   OnlineIvectorExtractionInfo::Init                     online2/online-ivector-feature.cc:29-68
  * The lattice arrays are exactly what k3_decoder_get_raw_lattices returns for one utterance (include/k3hip.h), already trimmed or not.
  */
 #ifndef K3HOST_H_
@@ -59,6 +60,18 @@ int k3h_clat_get(const k3h_clat *c, int32_t *start, uint8_t *is_final, float *fi
 int k3h_clat_scale_acoustic(k3h_clat *c, double scale);                 /* fst::ScaleLattice(fst::AcousticLatticeScale(scale), &clat) */
 int k3h_clat_write(const k3h_clat *c, const char *key, const char *wspecifier);   /* one record; "ark:file" or "ark,t:file" */
 void k3h_clat_free(k3h_clat *c);
+
+/* OnlineIvectorExtractionInfo(config) (online2/online-ivector-feature.cc:29-98): parse an --ivector-extraction-config file and read every file it
+ * names (LDA matrix, global CMVN stats, cmvn / splice configs, diagonal UBM, i-vector extractor), with the reference's checks and messages.
+ * k3h_ivector_config_get hands out what include/k3hip.h's k3_ivector_create takes; the pointers stay valid until k3h_ivector_config_free.
+ *   ints[16]  = feat_dim, lda_rows, lda_cols, num_gauss, ivector_dim, left_context, right_context, ivector_period, num_gselect, num_cg_iters,
+ *               cmn_window, speaker_frames, global_frames, normalize_mean, normalize_variance, online_cmvn_iextractor
+ *   reals[5]  = min_post, posterior_scale, max_count, prior_offset, max_remembered_frames */
+typedef struct k3h_ivector_config k3h_ivector_config;
+int k3h_ivector_config_read(const char *config_rxfilename, k3h_ivector_config **out);
+int k3h_ivector_config_get(const k3h_ivector_config *c, int32_t *ints, double *reals, const float **lda, const double **global_cmvn_stats, const double **gconsts,
+                           const double **means_invvars, const double **inv_vars, const double **M, const double **sigma_inv);
+void k3h_ivector_config_free(k3h_ivector_config *c);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,367 @@
+// k3_ivector.hip -- online i-vector extraction of whole utterances on gfx950.  Paths relative to the reference's src/.
+//
+// What is computed, per utterance, is what OnlineIvectorFeature computes when ivector-extract-online2 drives it with every frame weighted 1 and a
+// fresh adaptation state (online2/online-ivector-feature.cc): an i-vector after every frame t with t % ivector_period == 0, from statistics of
+// frames 0..t, solved by a warm-started conjugate-gradient descent.  The GPU reference BatchedIvectorExtractorCuda::GetIvectors
+// (cudafeat/feature-online-batched-ivector-cuda.h:30-61) has the same stages (splice, LDA, posteriors, statistics, solution) in float and with a
+// direct solve; opts.exact_solve = 1 gives that solution method, the default follows the CPU reference because that is what the golden vectors of
+// tests/golden/ivector pin.
+//
+//   stage                        kernel                          reference
+//   online CMVN (posterior side) k3_cmvn_online_batch            OnlineCmvn, online-ivector-feature.cc:144-163
+//   splice(+-c) + LDA            ivec_splice_lda_kernel          OnlineSpliceFrames + OnlineTransform, :144-163 / :239-243 (no CMVN on the statistics side)
+//   UBM log-likes + pruning      ivec_posterior_kernel           DiagGmm::LogLikelihoods gmm/diag-gmm.cc:557-586; VectorToPosteriorEntry hmm/posterior.cc:440-510
+//   derived model terms          ivec_sigma_inv_m / ivec_u       IvectorExtractor::ComputeDerivedVars ivector/ivector-extractor.cc:208-218 (once, at create)
+//   statistics + solution        ivec_estimate_kernel            OnlineIvectorEstimationStats::AccStats :611-670, GetIvector :732-756, LinearCgd matrix/optimization.cc:453-560
+//
+// Layout in HBM: model terms in fp64 (U_g [G][R][R] symmetric, Sigma_g^-1 M_g [G][D][R]) like the reference's Matrix<double>; the UBM in fp32,
+// stored [D][G] so that a wave reading one feature dimension of 64 Gaussians reads 256 contiguous bytes.  One workgroup per utterance walks the
+// periods in order (the statistics are cumulative and the solver is warm-started, so periods of one utterance are serial; utterances are not).
+// The quadratic term lives in LDS when it fits (R <= 128: R*R*8 B <= 128 KB of the CU's 160 KB), else in a per-utterance global scratch.
+#include "k3_common.h"
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+struct DevBuf {
+  void *p = nullptr; size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return K3_OK;
+    if (p) { hipFree(p); p = nullptr; cap = 0; }
+    K3_HIP_CHECK(hipMalloc(&p, bytes)); cap = bytes; return K3_OK;
+  }
+  ~DevBuf() { if (p) hipFree(p); }
+};
+}  // namespace
+
+struct k3_ivector {
+  k3_ivector_opts o;
+  int32_t F = 0, D = 0, G = 0, R = 0, splice = 0, has_offset = 0;
+  double prior_offset = 0;
+  float *lda = nullptr;              // [D][lda_cols]
+  double *global_stats = nullptr;    // [2][F+1]
+  float *gconsts = nullptr, *miv_t = nullptr, *iv_t = nullptr;   // [G], [D][G], [D][G]
+  double *U = nullptr, *SM = nullptr;                            // [G][R][R], [G][D][R]
+  bool quad_in_lds = true;
+  DevBuf frame_off, cmvn, xpost, xstats, post_g, post_w, post_n, quad, state;
+  ~k3_ivector() { for (void *p : {(void *)lda, (void *)global_stats, (void *)gconsts, (void *)miv_t, (void *)iv_t, (void *)U, (void *)SM}) if (p) hipFree(p); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------- derived model terms
+// SM[g][d][r] = sum_e SigmaInv_g[d][e] M_g[e][r]   (SigmaInv packed lower triangle, row-major: (i, j<=i) at i(i+1)/2 + j)
+__global__ void ivec_sigma_inv_m(const double *__restrict__ M, const double *__restrict__ Sp, double *__restrict__ SM, int G, int D, int R) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)G * D * R) return;
+  const int r = (int)(i % R), d = (int)((i / R) % D), g = (int)(i / ((long)R * D));
+  const double *S = Sp + (size_t)g * (D * (D + 1) / 2), *Mg = M + (size_t)g * D * R; double a = 0;
+  for (int e = 0; e < D; e++) { const double s = e <= d ? S[d * (d + 1) / 2 + e] : S[e * (e + 1) / 2 + d]; a += s * Mg[(size_t)e * R + r]; }
+  SM[i] = a;
+}
+// U[g][r][s] = sum_d M_g[d][r] SM[g][d][s], computed for s <= r and mirrored (the reference keeps U_g as a packed symmetric row)
+__global__ void ivec_u(const double *__restrict__ M, const double *__restrict__ SM, double *__restrict__ U, int G, int D, int R) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long)G * R * R) return;
+  const int s = (int)(i % R), r = (int)((i / R) % R), g = (int)(i / ((long)R * R));
+  if (s > r) return;
+  const double *Mg = M + (size_t)g * D * R, *SMg = SM + (size_t)g * D * R; double a = 0;
+  for (int d = 0; d < D; d++) a += Mg[(size_t)d * R + r] * SMg[(size_t)d * R + s];
+  U[((size_t)g * R + r) * R + s] = a; U[((size_t)g * R + s) * R + r] = a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- splice + LDA
+// out[t][d] = offset[d] + sum_{o=-lc..rc} sum_f lda[d][(o+lc) F + f] in[clamp(t+o)][f]; one thread per (frame, output dim); rows of one utterance only
+__global__ void ivec_splice_lda_kernel(const float *__restrict__ in, int64_t ld_in, const int64_t *__restrict__ frame_off, int num_utts, const float *__restrict__ lda,
+                                       int lda_cols, int has_offset, int F, int D, int lc, int rc, float *__restrict__ out, int64_t total_frames) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= total_frames * D) return;
+  const int64_t row = i / D; const int d = (int)(i % D);
+  int lo = 0, hi = num_utts;                                  // utterance of this row: last u with frame_off[u] <= row
+  while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (frame_off[m] <= row) lo = m; else hi = m; }
+  const int64_t b = frame_off[lo], e = frame_off[lo + 1];
+  const float *w = lda + (size_t)d * lda_cols; float a = 0.f;
+  for (int o = -lc; o <= rc; o++) {
+    int64_t t = row + o; t = t < b ? b : (t >= e ? e - 1 : t);
+    const float *x = in + t * ld_in, *wo = w + (size_t)(o + lc) * F;
+    for (int f = 0; f < F; f++) a = fmaf(wo[f], x[f], a);
+  }
+  out[i] = has_offset ? w[lda_cols - 1] + a : a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- posteriors
+// One wave per frame.  The log-likelihoods of the G Gaussians go to LDS; the num_gselect best that pass the min-post cut are taken one at a time
+// (a wave arg-max each), then pruned and renormalised by lane 0 exactly as VectorToPosteriorEntry does (float arithmetic, same order).
+__global__ void __launch_bounds__(kBlock) ivec_posterior_kernel(const float *__restrict__ x, int D, int G, const float *__restrict__ gconsts, const float *__restrict__ miv_t,
+                                                                const float *__restrict__ iv_t, int num_gselect, float min_post, float post_scale, int64_t total_frames,
+                                                                int32_t *__restrict__ post_g, float *__restrict__ post_w, int32_t *__restrict__ post_n) {
+  extern __shared__ float s_ll[];                             // [waves per block][G] log-likes, then [waves][2 * num_gselect] selections
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, nw = blockDim.x / kWave;
+  const int64_t t = (int64_t)blockIdx.x * nw + wave;
+  float *ll = s_ll + (size_t)wave * G; float *sel_p = s_ll + (size_t)nw * G + (size_t)wave * 2 * num_gselect; int *sel_g = (int *)(sel_p + num_gselect);
+  if (t >= total_frames) return;                              // whole waves leave together; no block barrier below
+  const float *xt = x + t * D;
+  float mx = -INFINITY;
+  for (int g = lane; g < G; g += kWave) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int d = 0; d < D; d++) { const float v = xt[d]; a1 = fmaf(miv_t[(size_t)d * G + g], v, a1); a2 = fmaf(iv_t[(size_t)d * G + g], v * v, a2); }
+    const float l = gconsts[g] + a1 - 0.5f * a2; ll[g] = l; mx = fmaxf(mx, l);
+  }
+  for (int o = kWave / 2; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float cut = min_post != 0.f ? mx + logf(min_post) : -INFINITY;
+  int n = 0;
+  for (int k = 0; k < num_gselect; k++) {
+    float bl = -INFINITY; int bg = 0x7fffffff;
+    for (int g = lane; g < G; g += kWave) { const float l = ll[g]; if (l > cut && (l > bl)) { bl = l; bg = g; } }      // lowest g among equal values of a lane
+    for (int o = kWave / 2; o; o >>= 1) {
+      const float ol = __shfl_xor(bl, o); const int og = __shfl_xor(bg, o);
+      if (ol > bl || (ol == bl && og < bg)) { bl = ol; bg = og; }
+    }
+    if (bg == 0x7fffffff) break;
+    if (lane == 0) { sel_p[n] = expf(bl - mx); sel_g[n] = bg; }
+    if (bg % kWave == lane) ll[bg] = -INFINITY;             // its owner lane retires it
+    n++; __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    float tot = 0.f; for (int k = 0; k < n; k++) tot += sel_p[k];
+    const float cutoff = min_post * tot;
+    while (n > 1 && sel_p[n - 1] < cutoff) { tot -= sel_p[n - 1]; n--; }
+    const float inv = 1.0f / tot;
+    for (int k = 0; k < n; k++) { post_g[t * num_gselect + k] = sel_g[k]; post_w[t * num_gselect + k] = (sel_p[k] * inv) * post_scale; }
+    post_n[t] = n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- statistics + solution
+__device__ __forceinline__ double block_sum(double v, double *s_red) {          // all threads get the sum; fixed order, so every run gives the same bits
+  for (int o = kWave / 2; o; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if (threadIdx.x % kWave == 0) s_red[threadIdx.x / kWave] = v;
+  __syncthreads();
+  double s = 0; for (int w = 0; w < kBlock / kWave; w++) s += s_red[w];
+  return s;
+}
+
+// y = A x for symmetric A [R][R]: thread i reads column i (= row i), consecutive threads consecutive addresses
+__device__ __forceinline__ double sym_row_dot(const double *A, const double *x, int R, int i) {
+  double a = 0; for (int j = 0; j < R; j++) a += A[(size_t)j * R + i] * x[j]; return a;
+}
+
+// In-place Cholesky solve of A x = b on a scratch copy C of A (lower triangle used); "the exact optimisation" of LinearCgd's fall-back
+// (matrix/optimization.cc:545-556) and the solution method of the GPU reference.  C may be any memory the whole block sees.
+__device__ void chol_solve(double *C, const double *b, double *x, double *y, int R) {
+  for (int k = 0; k < R; k++) {
+    __syncthreads();
+    if (threadIdx.x == 0) C[(size_t)k * R + k] = sqrt(C[(size_t)k * R + k]);
+    __syncthreads();
+    const double dkk = C[(size_t)k * R + k];
+    for (int i = k + 1 + threadIdx.x; i < R; i += kBlock) C[(size_t)i * R + k] /= dkk;
+    __syncthreads();
+    const int m = R - k - 1;                                    // trailing update of the lower triangle
+    for (int e = threadIdx.x; e < m * m; e += kBlock) { const int i = k + 1 + e / m, j = k + 1 + e % m; if (j <= i) C[(size_t)i * R + j] -= C[(size_t)i * R + k] * C[(size_t)j * R + k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                                       // R <= a few hundred: two serial triangular solves
+    for (int i = 0; i < R; i++) { double a = b[i]; for (int j = 0; j < i; j++) a -= C[(size_t)i * R + j] * y[j]; y[i] = a / C[(size_t)i * R + i]; }
+    for (int i = R - 1; i >= 0; i--) { double a = y[i]; for (int j = i + 1; j < R; j++) a -= C[(size_t)j * R + i] * x[j]; x[i] = a / C[(size_t)i * R + i]; }
+  }
+  __syncthreads();
+}
+
+struct EstParams {
+  const float *xstats; const int64_t *frame_off; const int32_t *post_g; const float *post_w; const int32_t *post_n;
+  const double *U, *SM; double *quad_g, *chol_g;              // per utterance [R][R] scratch (quad_g NULL = LDS)
+  float *out; int64_t ld_out; const int64_t *out_off;
+  int D, R, S, period, num_cg_iters, exact_solve; double prior, max_count;
+};
+
+__global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
+  extern __shared__ double s_dyn[];
+  const int R = p.R, D = p.D, S = p.S, P = p.period, tid = threadIdx.x, u = blockIdx.x;
+  double *s_x = s_dyn, *s_r = s_x + R, *s_p = s_r + R, *s_ap = s_p + R, *s_lin = s_ap + R, *s_xo = s_lin + R, *s_red = s_xo + R;    // 6R + 4 doubles
+  const int max_ent = P * S;
+  int *e_g = (int *)(s_red + kBlock / kWave); int *e_t = e_g + max_ent; float *e_w = (float *)(e_t + max_ent); float *e_gw = e_w + max_ent;   // gw > 0 marks a leader
+  double *A = p.quad_g ? p.quad_g + (size_t)u * R * R : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7);
+  double *C = p.chol_g + (size_t)u * R * R;
+  __shared__ int s_n; __shared__ double s_tot;
+  const int64_t fb = p.frame_off[u]; const int T = (int)(p.frame_off[u + 1] - fb);
+  for (int i = tid; i < R * R; i += kBlock) A[i] = (i / R == i % R) ? 1.0 : 0.0;      // quadratic term of the prior: I; linear term: prior_offset e_0
+  if (tid < R) { s_lin[tid] = tid == 0 ? p.prior : 0.0; s_x[tid] = tid == 0 ? p.prior : 0.0; }
+  double nframes = 0.0;
+  __syncthreads();
+  for (int k = 0; (int64_t)k * P < T; k++) {
+    const int t_lo = k == 0 ? 0 : (k - 1) * P + 1, t_hi = k * P;                     // frames not yet in the statistics, up to and including frame k*P
+    if (tid == 0) {                                                                   // entries in frame order, then in the order VectorToPosteriorEntry left them
+      int n = 0;
+      for (int t = t_lo; t <= t_hi; t++) { const int c = p.post_n[fb + t]; for (int j = 0; j < c; j++) { e_g[n] = p.post_g[(fb + t) * S + j]; e_w[n] = p.post_w[(fb + t) * S + j]; e_t[n] = t; n++; } }
+      s_n = n;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int e = tid; e < n; e += kBlock) {                                           // total weight of a Gaussian: a float sum in frame order, like AccStats' Vector<BaseFloat>
+      bool leader = true; for (int f = 0; f < e; f++) if (e_g[f] == e_g[e]) { leader = false; break; }
+      float gw = 0.f; if (leader) for (int f = e; f < n; f++) if (e_g[f] == e_g[e]) gw += e_w[f];
+      e_gw[e] = leader ? gw : 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) { double tot = 0; for (int e = 0; e < n; e++) tot += (double)e_gw[e]; s_tot = tot; }
+    if (tid < R) {                                                                    // linear += sum_e w_e SM[g_e]^T x_stats[t_e]
+      double a = 0;
+      for (int e = 0; e < n; e++) {
+        const double *sm = p.SM + (size_t)e_g[e] * D * R + tid; const float *x = p.xstats + (fb + e_t[e]) * D; double b = 0;
+        for (int d = 0; d < D; d++) b += sm[(size_t)d * R] * (double)x[d];
+        a += (double)e_w[e] * b;
+      }
+      s_lin[tid] += a;
+    }
+    for (int i = tid; i < R * R; i += kBlock) {                                       // quad += sum_g gw_g U_g
+      double a = 0; for (int e = 0; e < n; e++) if (e_gw[e] > 0.f) a += (double)e_gw[e] * p.U[(size_t)e_g[e] * R * R + i];
+      A[i] += a;
+    }
+    __syncthreads();
+    const double tot = s_tot;
+    if (p.max_count > 0.0) {                                                          // --max-count: the prior grows with the count beyond max_count (AccStats :650-668)
+      const double change = fmax(nframes + tot, p.max_count) / p.max_count - fmax(nframes, p.max_count) / p.max_count;
+      if (change != 0.0) { if (tid == 0) s_lin[0] += p.prior * change; if (tid < R) A[(size_t)tid * R + tid] += change; }
+    }
+    nframes += tot;
+    __syncthreads();
+    if (nframes > 0.0) {
+      if (tid == 0 && s_x[0] == 0.0) s_x[0] = p.prior;
+      __syncthreads();
+      if (p.exact_solve) {
+        for (int i = tid; i < R * R; i += kBlock) C[i] = A[i];
+        chol_solve(C, s_lin, s_x, s_ap, R);
+      } else {                                                                        // LinearCgd<double>, defaults of LinearCgdOptions, warm start s_x
+        double v = tid < R ? s_lin[tid] - sym_row_dot(A, s_x, R, tid) : 0.0;
+        if (tid < R) { s_p[tid] = v; s_r[tid] = -v; s_xo[tid] = s_x[tid]; }
+        double r_cur = block_sum(v * v, s_red); const double r_init = r_cur; double r_rec = r_cur; const double rf = 0.01 * 0.01;
+        const int max_it = p.num_cg_iters;
+        for (int it = 0; it < R + 5 && it != max_it; it++) {
+          const double ap = tid < R ? sym_row_dot(A, s_p, R, tid) : 0.0;
+          if (tid < R) s_ap[tid] = ap;
+          const double pr = block_sum(tid < R ? s_p[tid] * s_r[tid] : 0.0, s_red), pap = block_sum(tid < R ? s_p[tid] * ap : 0.0, s_red);
+          const double alpha = -pr / pap;
+          double rn = 0;
+          if (tid < R) { s_x[tid] += alpha * s_p[tid]; rn = s_r[tid] + alpha * ap; s_r[tid] = rn; }
+          double r_next = block_sum(rn * rn, s_red);
+          if (r_next < rf * r_rec || r_next > r_rec / rf) {                           // recompute the residual from scratch
+            rn = tid < R ? sym_row_dot(A, s_x, R, tid) - s_lin[tid] : 0.0;
+            __syncthreads(); if (tid < R) s_r[tid] = rn;
+            r_next = block_sum(rn * rn, s_red); r_rec = r_next;
+          }
+          if (r_next <= 2.2250738585072014e-308) break;
+          const double beta = r_next / r_cur;
+          __syncthreads(); if (tid < R) s_p[tid] = beta * s_p[tid] - s_r[tid];
+          __syncthreads();
+          r_cur = r_next;
+        }
+        const double bb = block_sum(tid < R ? s_lin[tid] * s_lin[tid] : 0.0, s_red);
+        if (r_cur > r_init && r_cur > r_init + 1.0e-10 * bb) {                        // the squared residual got worse: exact optimisation
+          for (int i = tid; i < R * R; i += kBlock) C[i] = A[i];
+          chol_solve(C, s_lin, s_x, s_ap, R);
+        }
+      }
+    } else if (tid < R) s_x[tid] = tid == 0 ? p.prior : 0.0;
+    __syncthreads();
+    if (tid < R) p.out[(p.out_off[u] + k) * p.ld_out + tid] = tid == 0 ? (float)s_x[0] - (float)p.prior : (float)s_x[tid];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- C ABI
+extern "C" void k3_ivector_opts_default(k3_ivector_opts *o) {
+  if (!o) return;
+  o->left_context = 0; o->right_context = 0; o->num_gselect = 5; o->min_post = 0.025f; o->posterior_scale = 0.1f; o->max_count = 0.f;
+  o->ivector_period = 10; o->num_cg_iters = 15; o->exact_solve = 0; o->online_cmvn_iextractor = 0; k3_online_cmvn_opts_default(&o->cmvn);
+}
+
+template <typename T> static int upload(T **dst, const std::vector<T> &h) { K3_HIP_CHECK(hipMalloc((void **)dst, h.size() * sizeof(T))); K3_HIP_CHECK(hipMemcpy(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return K3_OK; }
+
+extern "C" int k3_ivector_create(const k3_ivector_model *m, const k3_ivector_opts *opts, k3_ivector **out) {
+  K3_REQUIRE(m && opts && out, "k3_ivector_create: null argument");
+  K3_REQUIRE(m->feat_dim > 0 && m->lda && m->lda_rows > 0 && m->global_cmvn_stats && m->num_gauss > 0 && m->gconsts && m->means_invvars && m->inv_vars && m->ivector_dim > 0 && m->M && m->sigma_inv,
+             "k3_ivector_create: incomplete model");
+  K3_REQUIRE(m->ivector_dim <= kBlock, "k3_ivector_create: i-vector dimension above 256");
+  const int spl = opts->left_context + opts->right_context + 1;
+  K3_REQUIRE(opts->left_context >= 0 && opts->right_context >= 0, "k3_ivector_create: negative splice context");
+  K3_REQUIRE(m->lda_cols == m->feat_dim * spl || m->lda_cols == m->feat_dim * spl + 1, "k3_ivector_create: the LDA matrix does not match the spliced feature dimension");   // OnlineTransform, feat/online-feature.cc:520-535
+  K3_REQUIRE(opts->num_gselect > 0 && opts->ivector_period > 0 && opts->min_post >= 0.f && opts->min_post < 1.f, "k3_ivector_create: bad option value");                    // OnlineIvectorExtractionInfo::Check :100-121
+  K3_REQUIRE(opts->posterior_scale > 0.f && opts->posterior_scale <= 1.f && opts->max_count >= 0.f, "k3_ivector_create: bad posterior-scale / max-count");
+  std::unique_ptr<k3_ivector> iv(new k3_ivector);
+  iv->o = *opts; iv->F = m->feat_dim; iv->D = m->lda_rows; iv->G = m->num_gauss; iv->R = m->ivector_dim; iv->splice = spl; iv->has_offset = m->lda_cols == m->feat_dim * spl + 1;
+  iv->prior_offset = m->prior_offset;
+  const int F = iv->F, D = iv->D, G = iv->G, R = iv->R;
+  { std::vector<float> h(m->lda, m->lda + (size_t)D * m->lda_cols); const int rc = upload(&iv->lda, h); if (rc) return rc; }
+  { std::vector<double> h(m->global_cmvn_stats, m->global_cmvn_stats + 2 * (size_t)(F + 1)); const int rc = upload(&iv->global_stats, h); if (rc) return rc; }
+  { std::vector<float> gc(G), a((size_t)D * G), b((size_t)D * G);
+    for (int g = 0; g < G; g++) { gc[g] = (float)m->gconsts[g]; for (int d = 0; d < D; d++) { a[(size_t)d * G + g] = (float)m->means_invvars[(size_t)g * D + d]; b[(size_t)d * G + g] = (float)m->inv_vars[(size_t)g * D + d]; } }
+    int rc = upload(&iv->gconsts, gc); if (!rc) rc = upload(&iv->miv_t, a); if (!rc) rc = upload(&iv->iv_t, b); if (rc) return rc; }
+  { double *dM = nullptr, *dS = nullptr;
+    std::vector<double> hM(m->M, m->M + (size_t)G * D * R), hS(m->sigma_inv, m->sigma_inv + (size_t)G * (D * (D + 1) / 2));
+    int rc = upload(&dM, hM); if (!rc) rc = upload(&dS, hS);
+    if (!rc && hipMalloc((void **)&iv->SM, (size_t)G * D * R * 8) != hipSuccess) rc = K3_ERR_HIP;
+    if (!rc && hipMalloc((void **)&iv->U, (size_t)G * R * R * 8) != hipSuccess) rc = K3_ERR_HIP;
+    if (!rc) {
+      const long n1 = (long)G * D * R, n2 = (long)G * R * R;
+      hipLaunchKernelGGL(ivec_sigma_inv_m, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, 0, dM, dS, iv->SM, G, D, R);
+      hipLaunchKernelGGL(ivec_u, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, 0, dM, iv->SM, iv->U, G, D, R);
+      if (hipDeviceSynchronize() != hipSuccess) rc = K3_ERR_HIP;
+    }
+    if (dM) hipFree(dM); if (dS) hipFree(dS);
+    if (rc) { k3::set_error("k3_ivector_create: device allocation or the derived-variable kernels failed"); return rc; } }
+  iv->quad_in_lds = (size_t)R * R * 8 <= 128 * 1024 && !getenv("K3_IVECTOR_QUAD_IN_HBM");
+  *out = iv.release(); return K3_OK;
+}
+extern "C" void k3_ivector_destroy(k3_ivector *iv) { delete iv; }
+extern "C" int k3_ivector_get_info(const k3_ivector *iv, k3_ivector_info *info) {
+  K3_REQUIRE(iv && info, "k3_ivector_get_info: null argument");
+  info->feat_dim = iv->F; info->lda_dim = iv->D; info->num_gauss = iv->G; info->ivector_dim = iv->R; info->ivector_period = iv->o.ivector_period; return K3_OK;
+}
+extern "C" int64_t k3_ivector_num_rows(const k3_ivector *iv, int32_t num_utts, const int64_t *h_frame_offsets, int64_t *h_row_offsets) {
+  if (!iv || !h_frame_offsets || num_utts < 0) return -1;
+  int64_t n = 0; const int P = iv->o.ivector_period;
+  for (int u = 0; u < num_utts; u++) { if (h_row_offsets) h_row_offsets[u] = n; n += (h_frame_offsets[u + 1] - h_frame_offsets[u] + P - 1) / P; }
+  if (h_row_offsets) h_row_offsets[num_utts] = n;
+  return n;
+}
+
+extern "C" int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
+                                        void *stream_) {
+  K3_REQUIRE(iv && d_feats && h_frame_offsets && d_ivectors && num_utts > 0, "k3_ivector_extract_batch: null or empty argument");
+  K3_REQUIRE(ld_feats >= iv->F && ld_ivectors >= iv->R, "k3_ivector_extract_batch: leading dimension smaller than the row length");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period; const int64_t N = h_frame_offsets[num_utts] - h_frame_offsets[0];
+  K3_REQUIRE(h_frame_offsets[0] == 0, "k3_ivector_extract_batch: frame offsets must start at 0");
+  for (int u = 0; u < num_utts; u++) K3_REQUIRE(h_frame_offsets[u + 1] > h_frame_offsets[u], "k3_ivector_extract_batch: an utterance without frames");   // the reference writes no i-vector for an empty utterance
+  std::vector<int64_t> offs(2 * (size_t)(num_utts + 1));
+  for (int u = 0; u <= num_utts; u++) offs[u] = h_frame_offsets[u];
+  k3_ivector_num_rows(iv, num_utts, h_frame_offsets, offs.data() + num_utts + 1);
+  int rc = iv->frame_off.reserve(offs.size() * 8); if (rc) return rc;
+  if ((rc = iv->cmvn.reserve((size_t)N * F * 4)) || (rc = iv->xpost.reserve((size_t)N * D * 4)) || (rc = iv->xstats.reserve((size_t)N * D * 4)) || (rc = iv->post_g.reserve((size_t)N * S * 4)) ||
+      (rc = iv->post_w.reserve((size_t)N * S * 4)) || (rc = iv->post_n.reserve((size_t)N * 4)) || (rc = iv->state.reserve((size_t)num_utts * R * R * 8)))
+    return rc;
+  if (!iv->quad_in_lds && (rc = iv->quad.reserve((size_t)num_utts * R * R * 8))) return rc;
+  K3_HIP_CHECK(hipMemcpyAsync(iv->frame_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, stream));
+  K3_HIP_CHECK(hipStreamSynchronize(stream));                   // offs is a local
+  const int64_t *d_off = (const int64_t *)iv->frame_off.p, *d_row_off = d_off + num_utts + 1;
+  rc = k3_cmvn_online_batch(d_feats, ld_feats, (float *)iv->cmvn.p, F, F, d_off, num_utts, &iv->o.cmvn, iv->global_stats, nullptr, nullptr, 0, stream_); if (rc) return rc;
+  const unsigned nb = (unsigned)((N * D + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)iv->cmvn.p, (int64_t)F, d_off, num_utts, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D,
+                     iv->o.left_context, iv->o.right_context, (float *)iv->xpost.p, N);
+  hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, iv->o.online_cmvn_iextractor ? (const float *)iv->cmvn.p : d_feats, iv->o.online_cmvn_iextractor ? (int64_t)F : ld_feats, d_off, num_utts, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D,
+                     iv->o.left_context, iv->o.right_context, (float *)iv->xstats.p, N);
+  const int nw = kBlock / kWave; const size_t lds_post = ((size_t)nw * G + (size_t)nw * 2 * S) * 4;
+  K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_extract_batch: too many Gaussians for the posterior kernel's LDS tile");
+  const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;       // GetMinPost caps it, online-ivector-feature.cc:188-199
+  hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((N + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)iv->xpost.p, D, G, iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
+                     iv->o.posterior_scale, N, (int32_t *)iv->post_g.p, (float *)iv->post_w.p, (int32_t *)iv->post_n.p);
+  EstParams p; p.xstats = (const float *)iv->xstats.p; p.frame_off = d_off; p.post_g = (const int32_t *)iv->post_g.p; p.post_w = (const float *)iv->post_w.p; p.post_n = (const int32_t *)iv->post_n.p;
+  p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)iv->quad.p; p.chol_g = (double *)iv->state.p; p.out = d_ivectors; p.ld_out = ld_ivectors; p.out_off = d_row_off;
+  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count;
+  size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
+  K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_extract_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
+  K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
+  hipLaunchKernelGGL(ivec_estimate_kernel, dim3((unsigned)num_utts), dim3(kBlock), lds_est, stream, p);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}

@@ -686,4 +686,54 @@ void TableWriter::WriteInt32Vector(const std::string &key, const std::vector<int
   if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on vector " << key;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- i-vector extraction config
+void IvectorExtractionInfo::Register(ParseOptions *po) {       // option names and meanings of OnlineIvectorExtractionConfig::Register (online2/online-ivector-feature.h:113-160)
+  po->Register("lda-matrix", &lda_mat_rxfilename, "Filename of LDA matrix, e.g. final.mat; used for iVector extraction.");
+  po->Register("global-cmvn-stats", &global_cmvn_stats_rxfilename, "(Extended) filename for global CMVN stats, used in iVector extraction, obtained for example from 'matrix-sum scp:data/train/cmvn.scp -'");
+  po->Register("cmvn-config", &cmvn_config_rxfilename, "Configuration file for online CMVN features (e.g. conf/online_cmvn.conf), only used for iVector extraction.");
+  po->Register("online-cmvn-iextractor", &online_cmvn_iextractor, "add online-cmvn to feature pipeline of ivector extractor (the statistics side).");
+  po->Register("splice-config", &splice_config_rxfilename, "Configuration file for frame splicing (--left-context and --right-context options); used for iVector extraction.");
+  po->Register("diag-ubm", &diag_ubm_rxfilename, "Filename of diagonal UBM used to obtain posteriors for iVector extraction, e.g. final.dubm");
+  po->Register("ivector-extractor", &ivector_extractor_rxfilename, "Filename of iVector extractor, e.g. final.ie");
+  po->Register("ivector-period", &ivector_period, "Frequency with which we extract iVectors for neural network adaptation");
+  po->Register("num-gselect", &num_gselect, "Number of Gaussians to select for iVector extraction");
+  po->Register("min-post", &min_post, "Threshold for posterior pruning in iVector extraction");
+  po->Register("posterior-scale", &posterior_scale, "Scale for posteriors in iVector extraction (may be viewed as inverse of prior scale)");
+  po->Register("max-count", &max_count, "Maximum data count we allow before we start scaling the prior term up (0 = off)");
+  po->Register("num-cg-iters", &num_cg_iters, "Number of iterations of conjugate gradient descent to perform each time we re-estimate the iVector.");
+  po->Register("use-most-recent-ivector", &use_most_recent_ivector, "If true, always use most recent available iVector, rather than the one for the designated frame.");
+  po->Register("greedy-ivector-extractor", &greedy_ivector_extractor, "If true, 'read ahead' as many frames as we currently have available when extracting the iVector.");
+  po->Register("max-remembered-frames", &max_remembered_frames, "The maximum number of frames of adaptation history that we carry through to later utterances of the same speaker");
+}
+void IvectorExtractionInfo::Init() {
+  const char *note = "(note: this may be needed in the file supplied to --ivector-extractor-config)";
+  if (lda_mat_rxfilename.empty()) K3H_ERR << "--lda-matrix option must be set " << note;
+  { const MatrixD m = ReadDoubleMatrix(lda_mat_rxfilename); lda_rows = m.rows; lda_cols = m.cols; lda.assign(m.data.begin(), m.data.end()); }
+  if (global_cmvn_stats_rxfilename.empty()) K3H_ERR << "--global-cmvn-stats option must be set " << note;
+  global_cmvn_stats = ReadDoubleMatrix(global_cmvn_stats_rxfilename);
+  if (cmvn_config_rxfilename.empty()) K3H_ERR << "--cmvn-config option must be set " << note;
+  { ParseOptions po(""); po.Register("cmn-window", &cmn_window, ""); po.Register("global-frames", &global_frames, ""); po.Register("speaker-frames", &speaker_frames, "");
+    po.Register("norm-vars", &normalize_variance, ""); po.Register("norm-means", &normalize_mean, ""); std::string skip; po.Register("skip-dims", &skip, "");
+    po.ReadConfigFile(cmvn_config_rxfilename);
+    if (!skip.empty()) K3H_ERR << "--skip-dims in the i-vector extractor's cmvn config is not supported"; }
+  if (splice_config_rxfilename.empty()) K3H_ERR << "--splice-config option must be set " << note;
+  { ParseOptions po(""); po.Register("left-context", &left_context, ""); po.Register("right-context", &right_context, ""); po.ReadConfigFile(splice_config_rxfilename); }
+  if (diag_ubm_rxfilename.empty()) K3H_ERR << "--diag-ubm option must be set " << note;
+  ubm = ReadDiagGmm(diag_ubm_rxfilename);
+  if (ivector_extractor_rxfilename.empty()) K3H_ERR << "--ivector-extractor option must be set " << note;
+  ie = ReadIvectorExtractor(ivector_extractor_rxfilename);
+  // Check()
+  if (global_cmvn_stats.rows != 2) K3H_ERR << "global CMVN stats must have two rows, got " << global_cmvn_stats.rows;
+  const int32_t base = global_cmvn_stats.cols - 1, spliced = base * (left_context + 1 + right_context);
+  if (lda_cols != spliced && lda_cols != spliced + 1) K3H_ERR << "LDA matrix has " << lda_cols << " columns, the spliced features have dimension " << spliced;
+  if (lda_rows != ubm.dim) K3H_ERR << "LDA matrix has " << lda_rows << " rows, the diagonal UBM has dimension " << ubm.dim;
+  if (ubm.dim != ie.feat_dim) K3H_ERR << "the diagonal UBM has dimension " << ubm.dim << ", the iVector extractor " << ie.feat_dim;
+  if (ubm.num_gauss != ie.num_gauss) K3H_ERR << "the diagonal UBM has " << ubm.num_gauss << " Gaussians, the iVector extractor " << ie.num_gauss;
+  if (ivector_period <= 0 || num_gselect <= 0 || !(min_post < 0.5f) || !(posterior_scale > 0.0f && posterior_scale <= 1.0f) || max_remembered_frames < 0.0f)
+    K3H_ERR << "invalid value among --ivector-period, --num-gselect, --min-post, --posterior-scale, --max-remembered-frames";
+}
+IvectorExtractionInfo ReadIvectorExtractionConfig(const std::string &config_rxfilename) {
+  IvectorExtractionInfo info; ParseOptions po(""); info.Register(&po); po.ReadConfigFile(config_rxfilename); info.Init(); return info;
+}
+
 }  // namespace k3host

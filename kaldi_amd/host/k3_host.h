@@ -170,6 +170,20 @@ std::vector<std::pair<std::string, Matrix>> ReadMatrixTable(const std::string &r
 // one Matrix<double> object from an rxfilename (ReadKaldiObject: binary "DM"/"FM" after the \0B header, or text) -- CMVN stats files
 struct MatrixD { int32_t rows = 0, cols = 0; std::vector<double> data; };
 MatrixD ReadDoubleMatrix(const std::string &rxfilename);
+// OnlineIvectorExtractionConfig (online2/online-ivector-feature.h:60-150) with the files it names read in, i.e. OnlineIvectorExtractionInfo::Init
+// (online-ivector-feature.cc:29-68) + Check (:80-98).  Paths inside the config are used as written, like the reference.
+struct IvectorExtractionInfo {
+  std::string lda_mat_rxfilename, global_cmvn_stats_rxfilename, cmvn_config_rxfilename, splice_config_rxfilename, diag_ubm_rxfilename, ivector_extractor_rxfilename;
+  bool online_cmvn_iextractor = false, use_most_recent_ivector = true, greedy_ivector_extractor = false;
+  int32_t ivector_period = 10, num_gselect = 5, num_cg_iters = 15; float min_post = 0.025f, posterior_scale = 0.1f, max_count = 0.0f, max_remembered_frames = 1000.0f;
+  int32_t left_context = 4, right_context = 4;                                                        // OnlineSpliceOptions (feat/online-feature.h:478-487)
+  int32_t cmn_window = 600, speaker_frames = 600, global_frames = 200; bool normalize_mean = true, normalize_variance = false;   // OnlineCmvnOptions
+  std::vector<float> lda; int32_t lda_rows = 0, lda_cols = 0; MatrixD global_cmvn_stats; DiagGmmModel ubm; IvectorExtractorModel ie;
+  void Register(ParseOptions *po);
+  void Init();                                                                                        // reads the files, checks the dimensions
+};
+IvectorExtractionInfo ReadIvectorExtractionConfig(const std::string &config_rxfilename);
+
 // Kaldi token-vector table (util/kaldi-holder-inl.h TokenVectorHolder): "ark:file" with lines "key tok1 tok2 ..." (spk2utt)
 std::vector<std::pair<std::string, std::vector<std::string>>> ReadTokenVectorTable(const std::string &rspecifier);
 

@@ -11,6 +11,7 @@ using namespace k3host;
 
 struct k3h_transitions { TransitionInfo info; };
 struct k3h_clat { CompactLattice c; };
+struct k3h_ivector_config { IvectorExtractionInfo info; };
 namespace {
 thread_local std::string g_err;
 template <class F> int Guard(F f) { try { f(); return 0; } catch (const std::exception &e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown error"; return -2; } }
@@ -112,4 +113,18 @@ int k3h_postprocess_batch(const k3h_transitions *trans, int32_t num_utts, const 
 int k3h_clat_scale_acoustic(k3h_clat *c, double scale) { return Guard([&] { ScaleAcoustic(&c->c, scale); }); }
 int k3h_clat_write(const k3h_clat *c, const char *key, const char *wspecifier) { return Guard([&] { TableWriter w(wspecifier); w.WriteCompactLattice(key, c->c); w.Flush(); }); }
 void k3h_clat_free(k3h_clat *c) { delete c; }
+int k3h_ivector_config_read(const char *rx, k3h_ivector_config **out) { return Guard([&] { auto *c = new k3h_ivector_config; try { c->info = ReadIvectorExtractionConfig(rx); } catch (...) { delete c; throw; } *out = c; }); }
+int k3h_ivector_config_get(const k3h_ivector_config *c, int32_t *ints, double *reals, const float **lda, const double **gstats, const double **gconsts, const double **miv, const double **iv,
+                           const double **M, const double **sigma_inv) {
+  return Guard([&] {
+    const IvectorExtractionInfo &i = c->info;
+    const int32_t v[16] = {i.global_cmvn_stats.cols - 1, i.lda_rows, i.lda_cols, i.ubm.num_gauss, i.ie.ivector_dim, i.left_context, i.right_context, i.ivector_period, i.num_gselect, i.num_cg_iters,
+                           i.cmn_window, i.speaker_frames, i.global_frames, i.normalize_mean, i.normalize_variance, i.online_cmvn_iextractor};
+    if (ints) memcpy(ints, v, sizeof v);
+    if (reals) { reals[0] = i.min_post; reals[1] = i.posterior_scale; reals[2] = i.max_count; reals[3] = i.ie.prior_offset; reals[4] = i.max_remembered_frames; }
+    if (lda) *lda = i.lda.data(); if (gstats) *gstats = i.global_cmvn_stats.data.data(); if (gconsts) *gconsts = i.ubm.gconsts.data(); if (miv) *miv = i.ubm.means_invvars.data();
+    if (iv) *iv = i.ubm.inv_vars.data(); if (M) *M = i.ie.M.data(); if (sigma_inv) *sigma_inv = i.ie.sigma_inv.data();
+  });
+}
+void k3h_ivector_config_free(k3h_ivector_config *c) { delete c; }
 }

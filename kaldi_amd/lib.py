@@ -22,6 +22,19 @@ class OnlineCmvnOpts(ctypes.Structure):      # k3_online_cmvn_opts
     _fields_ = [("cmn_window", ctypes.c_int32), ("speaker_frames", ctypes.c_int32), ("global_frames", ctypes.c_int32),
                 ("normalize_mean", ctypes.c_int32), ("normalize_variance", ctypes.c_int32)]
 
+class IvectorModel(ctypes.Structure):       # k3_ivector_model: host arrays
+    _fields_ = [("feat_dim", ctypes.c_int32), ("lda_rows", ctypes.c_int32), ("lda_cols", ctypes.c_int32), ("num_gauss", ctypes.c_int32), ("ivector_dim", ctypes.c_int32),
+                ("lda", ctypes.c_void_p), ("global_cmvn_stats", ctypes.c_void_p), ("gconsts", ctypes.c_void_p), ("means_invvars", ctypes.c_void_p), ("inv_vars", ctypes.c_void_p),
+                ("M", ctypes.c_void_p), ("sigma_inv", ctypes.c_void_p), ("prior_offset", ctypes.c_double)]
+
+class IvectorOpts(ctypes.Structure):        # k3_ivector_opts
+    _fields_ = [("left_context", ctypes.c_int32), ("right_context", ctypes.c_int32), ("num_gselect", ctypes.c_int32), ("min_post", ctypes.c_float), ("posterior_scale", ctypes.c_float),
+                ("max_count", ctypes.c_float), ("ivector_period", ctypes.c_int32), ("num_cg_iters", ctypes.c_int32), ("exact_solve", ctypes.c_int32),
+                ("online_cmvn_iextractor", ctypes.c_int32), ("cmvn", OnlineCmvnOpts)]
+
+class IvectorInfo(ctypes.Structure):        # k3_ivector_info
+    _fields_ = [("feat_dim", ctypes.c_int32), ("lda_dim", ctypes.c_int32), ("num_gauss", ctypes.c_int32), ("ivector_dim", ctypes.c_int32), ("ivector_period", ctypes.c_int32)]
+
 class NnetInfo(ctypes.Structure):
     """k3_nnet_info (include/k3hip.h)"""
     _fields_ = [("input_dim", ctypes.c_int32), ("output_dim", ctypes.c_int32), ("left_context", ctypes.c_int32), ("right_context", ctypes.c_int32),
@@ -58,6 +71,12 @@ def load():
     L.k3_cmvn_offline_batch.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp]
     L.k3_online_cmvn_opts_default.argtypes = [ctypes.POINTER(OnlineCmvnOpts)]; L.k3_online_cmvn_opts_default.restype = None
     L.k3_cmvn_online_batch.argtypes = [vp, i64, vp, i64, i32, vp, i32, ctypes.POINTER(OnlineCmvnOpts), vp, vp, vp, i32, vp]
+    L.k3_ivector_opts_default.argtypes = [ctypes.POINTER(IvectorOpts)]; L.k3_ivector_opts_default.restype = None
+    L.k3_ivector_create.argtypes = [ctypes.POINTER(IvectorModel), ctypes.POINTER(IvectorOpts), ctypes.POINTER(vp)]
+    L.k3_ivector_destroy.argtypes = [vp]; L.k3_ivector_destroy.restype = None
+    L.k3_ivector_get_info.argtypes = [vp, ctypes.POINTER(IvectorInfo)]
+    L.k3_ivector_num_rows.argtypes = [vp, i32, vp, vp]; L.k3_ivector_num_rows.restype = i64
+    L.k3_ivector_extract_batch.argtypes = [vp, vp, i64, vp, i32, vp, i64, vp]
     L.k3_nnet_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.k3_nnet_destroy.argtypes = [vp]; L.k3_nnet_destroy.restype = None
     L.k3_nnet_get_info.argtypes = [vp, ctypes.POINTER(NnetInfo)]

@@ -1,0 +1,106 @@
+"""GPU parity of the online i-vector extraction (k3_ivector_* through the C ABI) against
+  - the REFERENCE binary's output (ivector-extract-online2, tests/golden/ivector/ivector_golden.npz), model files read by libk3host, and
+  - oracle/ivector_oracle.py (itself pinned to that binary in tests/test_oracle_ivector.py) on seeded random models and options.
+Tolerance: 2e-5 absolute on i-vector entries of magnitude ~0.2 .. 3 (the oracle itself is 8e-6 from the binary: float32 feature statistics summed
+in a different order, amplified by 15 conjugate-gradient iterations); measured values are printed by the tests."""
+import os, numpy as np, pytest, torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); DIR = os.path.join(ROOT, "tests", "golden", "ivector")
+TOL = 2e-5
+
+
+def _run(ex, feats_list):
+    dev = torch.device("cuda:0"); fo = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats_list])])
+    x = torch.from_numpy(np.concatenate(feats_list).astype(np.float32)).to(dev)
+    out, ro = ex.GetIvectors(x, fo); torch.cuda.synchronize(); out = out.cpu().numpy()
+    return [out[ro[u]:ro[u + 1]] for u in range(len(feats_list))]
+
+
+@pytest.fixture
+def golden(monkeypatch):
+    monkeypatch.chdir(DIR)                      # the config names its files relative to the working directory, like the reference
+    return np.load(os.path.join(DIR, "ivector_golden.npz"))
+
+
+def test_reference_binary_ivectors_batch_of_four(golden):
+    from kaldi_amd.ivector import OnlineIvectorExtractionInfo, BatchedIvectorExtractor
+    info = OnlineIvectorExtractionInfo("ivector_extractor.conf"); ex = BatchedIvectorExtractor(info)
+    assert (ex.FeatDim(), ex.LdaDim(), ex.IvectorDim(), ex.NumGauss()) == (13, 20, 16, 32)
+    utts = ["utt0", "utt1", "utt2", "utt3"]
+    got = _run(ex, [golden["feat_" + u] for u in utts]); worst = 0.0
+    for u, g in zip(utts, got):
+        ref = golden["iv_default_" + u]; assert g.shape == ref.shape
+        worst = max(worst, np.abs(g - ref).max())
+    print("max |gpu - reference binary| =", worst)
+    assert worst <= TOL, worst
+    # one utterance alone and in a different batch position gives the same bits (no cross-utterance state)
+    alone = _run(ex, [golden["feat_utt2"]])[0]; assert np.array_equal(alone, got[2])
+    rev = _run(ex, [golden["feat_" + u] for u in utts[::-1]]); assert all(np.array_equal(a, b) for a, b in zip(rev[::-1], got))
+
+
+def test_quadratic_term_in_hbm_gives_the_same_bits(golden, monkeypatch):
+    from kaldi_amd.ivector import OnlineIvectorExtractionInfo, BatchedIvectorExtractor
+    info = OnlineIvectorExtractionInfo("ivector_extractor.conf")
+    a = _run(BatchedIvectorExtractor(info), [golden["feat_utt0"], golden["feat_utt3"]])
+    monkeypatch.setenv("K3_IVECTOR_QUAD_IN_HBM", "1")
+    b = _run(BatchedIvectorExtractor(info), [golden["feat_utt0"], golden["feat_utt3"]])
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def _random_model(rng, F, lc, rc, D, G, R, offset_col):
+    lda = rng.standard_normal((D, F * (lc + rc + 1) + (1 if offset_col else 0))).astype(np.float32) * 0.3
+    n = 1000.0; mean = rng.standard_normal(F); var = 0.5 + rng.random(F)
+    st = np.zeros((2, F + 1)); st[0, :F] = n * mean; st[0, F] = n; st[1, :F] = n * (var + mean * mean)
+    means = rng.standard_normal((G, D)) * 1.5; var_g = 0.5 + rng.random((G, D)); w = rng.random(G) + 0.2; w /= w.sum()
+    inv = 1.0 / var_g; miv = means * inv
+    gc = np.log(w) - 0.5 * (D * np.log(2 * np.pi) + np.log(var_g).sum(1) + (means * means * inv).sum(1))
+    ubm = dict(gconsts=gc.astype(np.float32), means_invvars=miv.astype(np.float32), inv_vars=inv.astype(np.float32))
+    M = rng.standard_normal((G, D, R)) * 0.3; S = np.zeros((G, D, D))
+    for g in range(G): a = rng.standard_normal((D, D)) * 0.2; S[g] = a @ a.T + np.diag(0.5 + rng.random(D))
+    ie = dict(M=M, sigma_inv=S, prior_offset=float(rng.choice([0.0, 10.0, 100.0])), ivector_dim=R)
+    return lda, st, ubm, ie
+
+
+CASES = [  # F, lc, rc, D, G, R, offset column, options, frames per utterance
+    (13, 3, 3, 20, 32, 16, False, dict(), [57, 140]),
+    (10, 2, 1, 12, 70, 24, True, dict(num_gselect=3, min_post=0.0, posterior_scale=1.0, max_count=0.0, ivector_period=7, num_cg_iters=5), [1, 8, 64]),
+    (16, 1, 1, 24, 130, 40, False, dict(num_gselect=8, min_post=0.1, posterior_scale=0.3, max_count=20.0, ivector_period=4, num_cg_iters=15), [33, 90]),
+    (8, 0, 0, 8, 5, 3, True, dict(num_gselect=5, min_post=0.3, posterior_scale=0.5, max_count=3.0, ivector_period=1, num_cg_iters=2), [12]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("exact", [0, 1])
+def test_against_the_oracle_on_random_models(case, exact, monkeypatch):
+    from kaldi_amd.ivector import BatchedIvectorExtractor
+    from oracle import ivector_oracle as io
+    F, lc, rc, D, G, R, off, o, lens = CASES[case]; rng = np.random.default_rng(100 + case)
+    lda, st, ubm, ie = _random_model(rng, F, lc, rc, D, G, R, off)
+    opts = dict(num_gselect=5, min_post=0.025, posterior_scale=0.1, max_count=0.0, ivector_period=10, num_cg_iters=15); opts.update(o)
+    feats = [(rng.standard_normal((T, F)) * 2.0 + rng.standard_normal(F)).astype(np.float32) for T in lens]
+    il = np.tril_indices(D); packed = np.stack([ie["sigma_inv"][g][il] for g in range(G)])
+    ex = BatchedIvectorExtractor.FromArrays(lda, st, ubm["gconsts"], ubm["means_invvars"], ubm["inv_vars"], ie["M"], packed, ie["prior_offset"], left_context=lc, right_context=rc,
+                                            exact_solve=exact, **opts)
+    got = _run(ex, feats)
+    if exact: monkeypatch.setattr(io, "_linear_cgd", lambda A, b, x, max_iters: np.linalg.solve(A, b))       # the fall-back branch of LinearCgd, taken always
+    worst = 0.0
+    for f, g in zip(feats, got):
+        want = io.extract_online(f, ubm, ie, lda, st, left_context=lc, right_context=rc, **opts)
+        assert g.shape == want.shape; scale = max(1.0, np.abs(want).max())
+        worst = max(worst, np.abs(g - want).max() / scale)
+    print("case", case, "exact", exact, "max scaled |gpu - oracle| =", worst)
+    assert worst <= TOL, worst
+
+
+def test_argument_errors():
+    from kaldi_amd.ivector import BatchedIvectorExtractor
+    from kaldi_amd.lib import K3Error
+    rng = np.random.default_rng(1); lda, st, ubm, ie = _random_model(rng, 8, 1, 1, 8, 4, 3, False)
+    il = np.tril_indices(8); packed = np.stack([ie["sigma_inv"][g][il] for g in range(4)])
+    mk = lambda **kw: BatchedIvectorExtractor.FromArrays(lda, st, ubm["gconsts"], ubm["means_invvars"], ubm["inv_vars"], ie["M"], packed, 0.0, **kw)
+    with pytest.raises(K3Error): mk(left_context=2, right_context=2)                       # LDA columns do not match the splice width
+    with pytest.raises(K3Error): mk(left_context=1, right_context=1, ivector_period=0)
+    ex = mk(left_context=1, right_context=1)
+    x = torch.zeros((10, 8), device="cuda:0")
+    with pytest.raises(K3Error): ex.GetIvectors(x, [0, 10, 10])                             # an utterance without frames
