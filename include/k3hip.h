@@ -142,6 +142,7 @@ typedef struct k3_nnet_info {
   int32_t input_dim, output_dim, left_context, right_context;
   int32_t num_components, num_fused_nodes, has_priors;
   int64_t num_params;
+  int32_t ivector_dim;                 /* dim of input-node name=ivector, 0 = none */
 } k3_nnet_info;
 /* Nnet::Read (nnet3/nnet-nnet.cc:586-628) / AmNnetSimple::Read (nnet3/am-nnet-simple.cc:47-57): text or binary,
  * raw nnet or final.mdl (TransitionModel + AmNnetSimple).  BatchNorm/dropout are put in test mode
@@ -162,6 +163,18 @@ void k3_nnet_batch_destroy(k3_nnet_batch *batch);
 int64_t k3_nnet_batch_output_rows(const k3_nnet_batch *batch, int64_t *h_out_offsets);
 double k3_nnet_batch_flops(const k3_nnet_batch *batch);   /* exact sum of 2*M*N*K over the launched GEMMs */
 int k3_nnet_forward(k3_nnet_batch *batch, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream);
+/* Models with the recipes' i-vector input ("input-node name=ivector", tdnn1 fed by Append(.., ReplaceIndex(ivector, t, 0)); k3_nnet_info.ivector_dim > 0).
+ * online_ivector_period > 0: nnet3-compute / nnet3-latgen-faster --online-ivectors=.. --online-ivector-period=P --frames-per-chunk=C: the network is
+ * evaluated chunk by chunk (chunks of C frames rounded up to a multiple of the subsampling factor), chunk c with the row GetCurrentIvector picks for it
+ * (frame in the middle of the chunk / P, the last row when the matrix is a little short; nnet-am-decodable-simple.cc:93-213), h_num_ivector_rows[u] rows
+ * per utterance.  online_ivector_period = 0: --ivectors, one i-vector per utterance (row u), whole utterances at once.
+ * d_ivectors: the utterances' rows back to back ([sum rows x ld_ivectors], k3_nnet_batch_ivector_rows in total) -- the layout k3_ivector_extract_batch writes. */
+int k3_nnet_batch_create_ivector(k3_nnet *nnet, int32_t num_utts, const int32_t *h_num_frames, int32_t frame_subsampling_factor,
+                                 const float *h_log_priors, float acoustic_scale, int32_t frames_per_chunk, int32_t online_ivector_period,
+                                 const int32_t *h_num_ivector_rows, k3_nnet_batch **batch);
+int64_t k3_nnet_batch_ivector_rows(const k3_nnet_batch *batch);
+int k3_nnet_forward_ivector(k3_nnet_batch *batch, const float *d_feats, int64_t ld_feats, const float *d_ivectors, int64_t ld_ivectors,
+                            float *d_out, int64_t ld_out, void *stream);
 
 /* ---------------------------------------------------------------- decoding graph -------------
  * Replaces: cuda_decoder::CudaFst(const fst::StdFst &fst, const TransitionInformation *trans_model)

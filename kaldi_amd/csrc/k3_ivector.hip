@@ -32,10 +32,10 @@ struct DevBuf {
   void *p = nullptr; size_t cap = 0;
   int reserve(size_t bytes) {
     if (bytes <= cap) return K3_OK;
-    if (p) { hipFree(p); p = nullptr; cap = 0; }
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     K3_HIP_CHECK(hipMalloc(&p, bytes)); cap = bytes; return K3_OK;
   }
-  ~DevBuf() { if (p) hipFree(p); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
 };
 }  // namespace
 
@@ -49,7 +49,7 @@ struct k3_ivector {
   double *U = nullptr, *SM = nullptr;                            // [G][R][R], [G][D][R]
   bool quad_in_lds = true;
   DevBuf frame_off, cmvn, xpost, xstats, post_g, post_w, post_n, quad, state;
-  ~k3_ivector() { for (void *p : {(void *)lda, (void *)global_stats, (void *)gconsts, (void *)miv_t, (void *)iv_t, (void *)U, (void *)SM}) if (p) hipFree(p); }
+  ~k3_ivector() { for (void *p : {(void *)lda, (void *)global_stats, (void *)gconsts, (void *)miv_t, (void *)iv_t, (void *)U, (void *)SM}) if (p) (void)hipFree(p); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------- derived model terms
@@ -307,7 +307,8 @@ extern "C" int k3_ivector_create(const k3_ivector_model *m, const k3_ivector_opt
       hipLaunchKernelGGL(ivec_u, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, 0, dM, iv->SM, iv->U, G, D, R);
       if (hipDeviceSynchronize() != hipSuccess) rc = K3_ERR_HIP;
     }
-    if (dM) hipFree(dM); if (dS) hipFree(dS);
+    if (dM) (void)hipFree(dM);
+    if (dS) (void)hipFree(dS);
     if (rc) { k3::set_error("k3_ivector_create: device allocation or the derived-variable kernels failed"); return rc; } }
   iv->quad_in_lds = (size_t)R * R * 8 <= 128 * 1024 && !getenv("K3_IVECTOR_QUAD_IN_HBM");
   *out = iv.release(); return K3_OK;

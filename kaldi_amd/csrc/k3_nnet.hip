@@ -47,7 +47,8 @@ struct TileDesc {      // one per (utterance, 128-row slab) of a node's output
   int in_base;         // input row of local index 0 with shift 0
   int in_lo, in_hi;    // clamp bounds (absolute input rows) -- edge-frame replication for the first layer
   int res_base;        // residual row of local index 0
-  int pad0, pad1;
+  int bias_row;        // row of GemmParams::seq_bias this slab starts from instead of the bias (a node fed by the chunk's i-vector)
+  int pad1;
 };
 
 struct GemmParams {
@@ -56,6 +57,7 @@ struct GemmParams {
   const float *W; int ldw, Ktot;
   float *C; long long ldc; int N;
   const float *bias;
+  const float *seq_bias; long long ld_seq_bias;      // non-null: per-sequence rows "bias + W_iv . ivector" (k3_seq_bias_kernel), picked by TileDesc::bias_row
   int nops; int op_kind[kMaxOps]; const float *op_scale[kMaxOps]; const float *op_offset[kMaxOps];
   const float *R; long long ldr; int res_row_stride; float res_scale;
   const TileDesc *tiles; int num_m_tiles, num_n_tiles; int dbg; long long *dbg_buf;
@@ -160,7 +162,8 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
 #pragma unroll
   for (int ni = 0; ni < NI; ni++) {
     const int col = n0 + wn * WN + ni * 32 + (lane & 31);
-    const float b0 = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+    const float *bias = p.seq_bias ? p.seq_bias + (long long)td.bias_row * p.ld_seq_bias : p.bias;
+    const float b0 = (bias && col < p.N) ? bias[col] : 0.0f;
 #pragma unroll
     for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -373,8 +376,20 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct DeviceNode {     // model-level (batch independent) device data of one fused node
   float *W = nullptr; int ldw = 0, npad = 0, bn = 128;
   float *bias = nullptr;
+  float *W_iv = nullptr;                      // [N x ivector_dim] (nodes fed by ReplaceIndex(ivector, t, 0))
   std::vector<float *> op_scale, op_offset;   // per op (null when not scale/offset)
 };
+
+// seq_bias[s][n] = bias[n] + sum_k W_iv[n][k] * ivector[iv_row[s]][k]: what the i-vector columns of the first affine add to every row of
+// sequence (chunk) s.  One thread per (s, n), ascending k like the reference's sgemm; tiny (sequences x N x ivector_dim).
+__global__ void k3_seq_bias_kernel(const float *__restrict__ iv, long long ld_iv, const int *__restrict__ iv_row, int num_seqs, const float *__restrict__ W_iv, int iv_dim,
+                                   const float *__restrict__ bias, int N, float *__restrict__ out, long long ld_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long long)num_seqs * N) return;
+  const int s = (int)(i / N), n = (int)(i % N);
+  const float *x = iv + (long long)iv_row[s] * ld_iv, *w = W_iv + (long long)n * iv_dim; float a = 0.f;
+  for (int k = 0; k < iv_dim; k++) a = fmaf(w[k], x[k], a);
+  out[(long long)s * ld_out + n] = (bias ? bias[n] : 0.f) + a;
+}
 
 }  // namespace
 
@@ -398,6 +413,10 @@ struct k3_nnet_batch {
   std::vector<int> node_a, node_r, node_g;      // first time, right extension, step
   std::vector<void *> allocs;
   float *out_scale = nullptr, *out_offset = nullptr;
+  // i-vector input: sequences (chunks) and the i-vector row each one takes
+  int num_seqs = 0; int *d_seq_iv_row = nullptr; long long total_iv_rows = 0;
+  std::vector<float *> seq_bias;                // per node (null = none) [num_seqs x ld]
+  std::vector<int> seq_bias_ld;
   ~k3_nnet_batch() { for (void *p : allocs) (void)hipFree(p); }
 };
 
@@ -437,6 +456,7 @@ static int ensure_uploaded(k3_nnet *net) {
       for (int n = 0; n < N; n++) memcpy(&wp[(size_t)n * d.ldw], &f.W[(size_t)n * K], sizeof(float) * K);
       int rc = upload(&net->allocs, wp, &d.W); if (rc) { return rc; }
       rc = upload(&net->allocs, f.bias, &d.bias); if (rc) { return rc; }
+      rc = upload(&net->allocs, f.W_iv, &d.W_iv); if (rc) { return rc; }
     }
     d.op_scale.assign(f.ops.size(), nullptr); d.op_offset.assign(f.ops.size(), nullptr);
     for (size_t o = 0; o < f.ops.size(); o++)
@@ -476,7 +496,7 @@ extern "C" int k3_nnet_get_info(const k3_nnet *net, k3_nnet_info *info) {
   info->input_dim = net->fm.input_dim; info->output_dim = net->fm.output_dim;
   info->left_context = net->fm.left_context; info->right_context = net->fm.right_context;
   info->num_components = net->fm.num_components; info->num_fused_nodes = (int)net->fm.nodes.size();
-  info->has_priors = net->fm.priors.empty() ? 0 : 1; info->num_params = net->fm.num_params;
+  info->has_priors = net->fm.priors.empty() ? 0 : 1; info->num_params = net->fm.num_params; info->ivector_dim = net->fm.ivector_dim;
   return K3_OK;
 }
 
@@ -489,8 +509,14 @@ extern "C" int k3_nnet_get_priors(const k3_nnet *net, float *h_priors) {
 
 extern "C" void k3_nnet_batch_destroy(k3_nnet_batch *b) { delete b; }
 
-extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_t *h_num_frames, int32_t subsampling,
-                                    const float *h_log_priors, float acoustic_scale, k3_nnet_batch **out) {
+// One planner for both entry points.  A SEQUENCE is what the network is evaluated over as one piece: a whole utterance (no i-vector, or one
+// i-vector per utterance: the result does not depend on how the reference chunks it) or one chunk of frames_per_chunk frames of an utterance
+// (--online-ivectors: every chunk gets its own i-vector, so the activations near a chunk boundary differ between the two chunks that need them,
+// exactly as in DecodableNnetSimple::EnsureFrameIsComputed, nnet-am-decodable-simple.cc:93-168).  Input rows outside the UTTERANCE are clamped
+// (edge-frame replication, :154-163) whatever the sequence.
+namespace { struct Seq { int u, t0, n_out, iv_row; }; }
+static int batch_create_impl(k3_nnet *net, int32_t num_utts, const int32_t *h_num_frames, int32_t subsampling, const float *h_log_priors, float acoustic_scale,
+                             bool with_ivector, int32_t frames_per_chunk, int32_t online_ivector_period, const int32_t *h_num_ivector_rows, k3_nnet_batch **out) {
   K3_REQUIRE(net && h_num_frames && out && num_utts > 0 && subsampling >= 1, "k3_nnet_batch_create: bad argument");
   { const int rc = ensure_uploaded(net); if (rc) return rc; }
   const k3::FusedModel &fm = net->fm;
@@ -499,6 +525,28 @@ extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_
   b->net = net; b->num_utts = num_utts; b->subsampling = subsampling;
   b->num_frames.assign(h_num_frames, h_num_frames + num_utts);
   for (int u = 0; u < num_utts; u++) K3_REQUIRE(h_num_frames[u] > 0, "k3_nnet_batch_create: utterance with no frames");
+  std::vector<Seq> seqs;
+  {
+    long long iv_base = 0;
+    for (int u = 0; u < num_utts; u++) {
+      const int n_sub = (h_num_frames[u] + subsampling - 1) / subsampling;
+      if (!with_ivector || online_ivector_period <= 0) { seqs.push_back({u, 0, n_sub, with_ivector ? (int)iv_base : -1}); if (with_ivector) iv_base += 1; continue; }
+      const int per = (frames_per_chunk + subsampling - 1) / subsampling, rows = h_num_ivector_rows[u];      // the chunk rounded up to a multiple of s (CheckAndFixConfigs, nnet-am-decodable-simple.h:120-134)
+      K3_REQUIRE(rows > 0, "k3_nnet_batch_create_ivector: utterance without i-vector rows");
+      for (int c0 = 0; c0 < n_sub; c0 += per) {
+        const int n = std::min(per, n_sub - c0), first = c0 * subsampling, last = (c0 + n - 1) * subsampling;
+        int f = (first + (last - first) / 2) / online_ivector_period;                                        // GetCurrentIvector :178-213
+        if (f >= rows) {
+          if ((long long)(f - (rows - 1)) * online_ivector_period > 50) { k3::set_error("Could not get iVector for frame %d, only available till frame %d * ivector-period=%d (mismatched --online-ivector-period?)", first + (last - first) / 2, rows, online_ivector_period); return K3_ERR_ARG; }
+          f = rows - 1;
+        }
+        seqs.push_back({u, first, n, (int)(iv_base + f)});
+      }
+      iv_base += rows;
+    }
+    b->total_iv_rows = iv_base;
+  }
+  const int num_seqs = (int)seqs.size(); b->num_seqs = num_seqs;
 
   // ---- which time steps must each node produce?  t = a + k*g, k >= 0, up to t_last_out(u) + r
   std::vector<int> A(nn, 0), R(nn, 0), G(nn, 0); std::vector<char> used(nn, 0);
@@ -528,15 +576,17 @@ extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_
   b->node_a = A; b->node_r = R; b->node_g = G;
 
   // ---- row bookkeeping
-  auto n_out = [&](int u) { return (b->num_frames[u] + subsampling - 1) / subsampling; };
-  auto rows_of = [&](int i, int u) { const int tlast = (n_out(u) - 1) * subsampling; return (tlast + R[i] - A[i]) / G[i] + 1; };
-  std::vector<std::vector<long long>> rowoff(nn, std::vector<long long>(num_utts + 1, 0));
-  for (int i = 0; i < nn; i++) if (used[i]) for (int u = 0; u < num_utts; u++) rowoff[i][u + 1] = rowoff[i][u] + rows_of(i, u);
+  auto rows_of = [&](int i, int q) { const int tlast = (seqs[q].n_out - 1) * subsampling; return (tlast + R[i] - A[i]) / G[i] + 1; };      // rows of node i in sequence q
+  std::vector<std::vector<long long>> rowoff(nn, std::vector<long long>(num_seqs + 1, 0));
+  for (int i = 0; i < nn; i++) if (used[i]) for (int q = 0; q < num_seqs; q++) rowoff[i][q + 1] = rowoff[i][q] + rows_of(i, q);
   std::vector<long long> featoff(num_utts + 1, 0);
   for (int u = 0; u < num_utts; u++) featoff[u + 1] = featoff[u] + b->num_frames[u];
   b->total_in_rows = featoff[num_utts];
-  b->out_offsets = rowoff[fm.output_node]; b->total_out_rows = b->out_offsets[num_utts];
-  for (int i = 0; i < nn; i++) K3_REQUIRE(rowoff[i][num_utts] < (1ll << 31), "k3_nnet_batch_create: more than 2^31 rows in one batch");
+  b->out_offsets.assign(num_utts + 1, 0);                      // the chunks of an utterance are consecutive sequences, so its output rows are contiguous
+  for (int q = 0; q < num_seqs; q++) b->out_offsets[seqs[q].u + 1] += seqs[q].n_out;
+  for (int u = 0; u < num_utts; u++) b->out_offsets[u + 1] += b->out_offsets[u];
+  b->total_out_rows = b->out_offsets[num_utts];
+  for (int i = 0; i < nn; i++) K3_REQUIRE(rowoff[i][num_seqs] < (1ll << 31), "k3_nnet_batch_create: more than 2^31 rows in one batch");
 
   // ---- activation buffers with liveness-based reuse
   std::vector<int> last_use(nn, -1);
@@ -550,7 +600,7 @@ extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_
   for (int i = 0; i < nn; i++) {
     if (!used[i] || i == fm.output_node) continue;
     ld[i] = (int)align_up(fm.nodes[i].out_dim, 4);
-    const size_t need = (size_t)rowoff[i][num_utts] * ld[i] * sizeof(float);
+    const size_t need = (size_t)rowoff[i][num_seqs] * ld[i] * sizeof(float);
     int best = -1;
     for (size_t s = 0; s < slots.size(); s++) if (slots[s].busy_until < i && (best < 0 || slots[s].bytes > slots[best].bytes)) best = (int)s;
     if (best < 0) { slots.push_back({need, last_use[i], nullptr}); best = (int)slots.size() - 1; }
@@ -569,7 +619,7 @@ extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_
   }
 
   // ---- per-node launch parameters + tile tables
-  b->params.resize(nn);
+  b->params.resize(nn); b->seq_bias.assign(nn, nullptr); b->seq_bias_ld.assign(nn, 0);
   for (int i = 0; i < nn; i++) {
     GemmParams &p = b->params[i]; memset(&p, 0, sizeof(p));
     if (!used[i]) { p.num_m_tiles = 0; continue; }
@@ -604,28 +654,57 @@ extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_
       p.res_row_stride = G[i] / g_res;
     }
     std::vector<TileDesc> tiles;
-    for (int u = 0; u < num_utts; u++) {
-      const int rows = rows_of(i, u);
+    for (int q = 0; q < num_seqs; q++) {
+      const int rows = rows_of(i, q), u = seqs[q].u, t0 = seqs[q].t0;
       for (int r0 = 0; r0 < rows; r0 += kBM) {
         TileDesc t; memset(&t, 0, sizeof t);
-        t.out_row0 = (int)rowoff[i][u] + r0; t.nrows = std::min(kBM, rows - r0);
-        if (src < 0) { t.in_base = (int)featoff[u] + r0 * p.row_stride; t.in_lo = (int)featoff[u]; t.in_hi = (int)featoff[u + 1] - 1; }
-        else { t.in_base = (int)rowoff[src][u] + r0 * p.row_stride; t.in_lo = (int)rowoff[src][u]; t.in_hi = (int)rowoff[src][u + 1] - 1; }
+        t.out_row0 = (int)rowoff[i][q] + r0; t.nrows = std::min(kBM, rows - r0); t.bias_row = q;
+        if (src < 0) { t.in_base = (int)featoff[u] + t0 + r0 * p.row_stride; t.in_lo = (int)featoff[u]; t.in_hi = (int)featoff[u + 1] - 1; }
+        else { t.in_base = (int)rowoff[src][q] + r0 * p.row_stride; t.in_lo = (int)rowoff[src][q]; t.in_hi = (int)rowoff[src][q + 1] - 1; }
         if (res >= -1) {
           const int base = (A[i] - a_res) / g_res;
-          t.res_base = (int)(res < 0 ? featoff[u] : rowoff[res][u]) + base + r0 * p.res_row_stride;
+          t.res_base = (int)(res < 0 ? featoff[u] + t0 : rowoff[res][q]) + base + r0 * p.res_row_stride;
         }
         tiles.push_back(t);
       }
       if (f.has_gemm) b->flops += 2.0 * rows * (double)p.Ktot * f.out_dim;
     }
+    if (!f.W_iv.empty()) {                                       // this node starts from "bias + W_iv . ivector(sequence)" (k3_seq_bias_kernel, run by k3_nnet_forward_ivector)
+      K3_REQUIRE(with_ivector, "k3_nnet_batch_create: the model has an i-vector input: use k3_nnet_batch_create_ivector");
+      float *sb = nullptr; const int ldsb = (int)align_up(f.out_dim, 4);
+      K3_HIP_CHECK(hipMalloc((void **)&sb, (size_t)num_seqs * ldsb * sizeof(float))); b->allocs.push_back(sb);
+      b->seq_bias[i] = sb; b->seq_bias_ld[i] = ldsb; p.seq_bias = sb; p.ld_seq_bias = ldsb;
+      b->flops += 2.0 * num_seqs * (double)fm.ivector_dim * f.out_dim;
+    }
     TileDesc *dt = nullptr; int rc = upload(&b->allocs, tiles, &dt); if (rc) { return rc; }
     p.tiles = dt; p.num_m_tiles = (int)tiles.size();
     p.num_n_tiles = f.has_gemm ? d.npad / d.bn : 1;
   }
+  if (with_ivector) {
+    std::vector<int> rows(num_seqs); for (int q = 0; q < num_seqs; q++) rows[q] = seqs[q].iv_row;
+    int *d = nullptr; const int rc = upload(&b->allocs, rows, &d); if (rc) return rc;
+    b->d_seq_iv_row = d;
+  }
   *out = b.release();
   return K3_OK;
 }
+
+extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_t *h_num_frames, int32_t subsampling,
+                                    const float *h_log_priors, float acoustic_scale, k3_nnet_batch **out) {
+  K3_REQUIRE(net, "k3_nnet_batch_create: bad argument");
+  K3_REQUIRE(net->fm.ivector_dim == 0, "k3_nnet_batch_create: the model has an i-vector input (input-node name=ivector): use k3_nnet_batch_create_ivector");
+  return batch_create_impl(net, num_utts, h_num_frames, subsampling, h_log_priors, acoustic_scale, false, 0, 0, nullptr, out);
+}
+
+extern "C" int k3_nnet_batch_create_ivector(k3_nnet *net, int32_t num_utts, const int32_t *h_num_frames, int32_t subsampling, const float *h_log_priors, float acoustic_scale,
+                                            int32_t frames_per_chunk, int32_t online_ivector_period, const int32_t *h_num_ivector_rows, k3_nnet_batch **out) {
+  K3_REQUIRE(net, "k3_nnet_batch_create_ivector: bad argument");
+  K3_REQUIRE(net->fm.ivector_dim > 0, "k3_nnet_batch_create_ivector: the model has no i-vector input");      // "Neural net expects 'ivector' features with dimension 0 but you provided N" (:105-107)
+  K3_REQUIRE(online_ivector_period == 0 || (online_ivector_period > 0 && frames_per_chunk > 0 && h_num_ivector_rows), "k3_nnet_batch_create_ivector: online i-vectors need a period, a chunk size and the row counts");
+  return batch_create_impl(net, num_utts, h_num_frames, subsampling, h_log_priors, acoustic_scale, true, frames_per_chunk, online_ivector_period, h_num_ivector_rows, out);
+}
+
+extern "C" int64_t k3_nnet_batch_ivector_rows(const k3_nnet_batch *b) { return b ? b->total_iv_rows : -1; }
 
 extern "C" int64_t k3_nnet_batch_output_rows(const k3_nnet_batch *b, int64_t *h_out_offsets) {
   if (!b) return -1;
@@ -635,7 +714,24 @@ extern "C" int64_t k3_nnet_batch_output_rows(const k3_nnet_batch *b, int64_t *h_
 
 extern "C" double k3_nnet_batch_flops(const k3_nnet_batch *b) { return b ? b->flops : -1.0; }
 
+static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream);
 extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream) {
+  K3_REQUIRE(b && b->net->fm.ivector_dim == 0, "k3_nnet_forward: null batch, or the model has an i-vector input (use k3_nnet_forward_ivector)");
+  return forward_impl(b, d_feats, ld_feats, d_out, ld_out, stream);
+}
+extern "C" int k3_nnet_forward_ivector(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, const float *d_ivectors, int64_t ld_ivectors, float *d_out, int64_t ld_out, void *stream) {
+  K3_REQUIRE(b && d_ivectors && b->d_seq_iv_row, "k3_nnet_forward_ivector: null argument, or the batch was not made by k3_nnet_batch_create_ivector");
+  const k3::FusedModel &fm = b->net->fm;
+  K3_REQUIRE(ld_ivectors >= fm.ivector_dim, "k3_nnet_forward_ivector: ld_ivectors < i-vector dim");
+  for (size_t i = 0; i < fm.nodes.size(); i++) {
+    if (!b->seq_bias[i]) continue;
+    const long long n = (long long)b->num_seqs * fm.nodes[i].out_dim;
+    hipLaunchKernelGGL(k3_seq_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_ivectors, (long long)ld_ivectors, b->d_seq_iv_row, b->num_seqs, b->net->dev[i].W_iv,
+                       fm.ivector_dim, b->net->dev[i].bias, fm.nodes[i].out_dim, b->seq_bias[i], (long long)b->seq_bias_ld[i]);
+  }
+  return forward_impl(b, d_feats, ld_feats, d_out, ld_out, stream);
+}
+static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream) {
   K3_REQUIRE(b && d_feats && d_out, "k3_nnet_forward: null argument");
   const k3::FusedModel &fm = b->net->fm;
   K3_REQUIRE(ld_feats >= fm.input_dim && ld_feats % 4 == 0 && ((uintptr_t)d_feats & 15) == 0, "k3_nnet_forward: features must be 16-byte aligned with ld % 4 == 0");

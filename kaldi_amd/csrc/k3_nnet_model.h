@@ -56,10 +56,12 @@ struct FusedNode {
   std::vector<int> offsets;    // one per K block (time offsets in frames); {0} for elementwise nodes
   std::vector<float> W;        // [out_dim x (offsets.size() * in_dim)] row-major (Kaldi linear_params_ layout)
   std::vector<float> bias;     // empty = none
+  std::vector<float> W_iv;     // [out_dim x ivector_dim]: the columns that multiply ReplaceIndex(ivector, t, 0), the last part of the Append(); empty = none
   std::vector<EpiOp> ops;
 };
 struct FusedModel {
   int input_dim = 0, output_dim = 0, output_node = -1;
+  int ivector_dim = 0;                          // input-node name=ivector (0 = the model has none)
   int left_context = 0, right_context = 0;      // of 'output' w.r.t. 'input'
   std::vector<FusedNode> nodes;
   std::vector<float> priors;                    // AmNnetSimple priors (may be empty)

@@ -210,7 +210,7 @@ bool ReadModelFile(const std::string &path, RawModel *out, std::string *err) {
 namespace {
 
 struct Desc {   // nnet-descriptor.h subset
-  enum Kind { kNode, kOffset, kAppend, kSum, kScale } kind = kNode;
+  enum Kind { kNode, kOffset, kAppend, kSum, kScale, kIvector } kind = kNode;      // kIvector = ReplaceIndex(ivector, t, 0)
   std::string node;
   int offset = 0;
   float scale = 1.0f;
@@ -250,8 +250,14 @@ struct DescParser {
         if (i < s.size() && s[i] == ',') { i++; continue; }
         break;
       }
+    } else if (word == "ReplaceIndex") {      // only the recipes' ReplaceIndex(ivector, t, 0): "the i-vector of this chunk, whatever t" (nnet-descriptor.h:246-268)
+      d->kind = Desc::kIvector; Desc inner; int zero = -1;
+      if (!parse(&inner) || !expect(',')) return false;
+      ws(); const bool is_t = i < s.size() && s[i] == 't'; if (is_t) i++;
+      if (!is_t || !expect(',') || !integer(&zero) || zero != 0 || inner.kind != Desc::kNode || inner.node != "ivector") { err = "only ReplaceIndex(ivector, t, 0) is supported, got '" + s + "'"; return false; }
+      d->node = "ivector";
     } else {
-      err = "descriptor function " + word + "() is unsupported (IfDefined/Failover/Round/ReplaceIndex/Const need recurrent or multi-input models)";
+      err = "descriptor function " + word + "() is unsupported (IfDefined/Failover/Round/Const need recurrent or multi-input models)";
       return false;
     }
     return expect(')');
@@ -343,7 +349,8 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
   for (const std::string &line : raw.config_lines) {
     std::string first; auto kv = ParseKeyValues(line, &first);
     if (first == "input-node") {
-      if (kv["name"] != "input") { *err = "input-node '" + kv["name"] + "': only a single 'input' (no ivector) is supported"; return false; }
+      if (kv["name"] == "ivector") { fm->ivector_dim = atoi(kv["dim"].c_str()); if (fm->ivector_dim <= 0) { *err = "input-node ivector with a bad dim"; return false; } continue; }
+      if (kv["name"] != "input") { *err = "input-node '" + kv["name"] + "': only 'input' and 'ivector' are supported"; return false; }
       fm->input_dim = atoi(kv["dim"].c_str());
     } else if (first == "component-node" || first == "output-node") {
       CfgNode n; n.kind = first; n.name = kv["name"]; n.component = kv["component"];
@@ -368,13 +375,17 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
     *idx = it->second; return true;
   };
   // input descriptor of a GEMM node -> (source, offsets)
-  auto splice_of = [&](const Desc &d, std::string *src, std::vector<int> *offs) -> bool {
-    std::vector<const Desc *> parts;
+  auto splice_of = [&](const Desc &d, std::string *src, std::vector<int> *offs, bool *with_ivector) -> bool {
+    std::vector<const Desc *> parts; *with_ivector = false;
     if (d.kind == Desc::kAppend) for (const Desc &a : d.args) parts.push_back(&a); else parts.push_back(&d);
+    if (parts.size() > 1 && parts.back()->kind == Desc::kIvector) {
+      if (fm->ivector_dim <= 0) { *err = "ReplaceIndex(ivector, t, 0) in a model without input-node name=ivector"; return false; }
+      *with_ivector = true; parts.pop_back();
+    }
     for (const Desc *p : parts) {
       int o = 0; const Desc *q = p;
       while (q->kind == Desc::kOffset) { o += q->offset; q = &q->args[0]; }
-      if (q->kind != Desc::kNode) { *err = "unsupported input descriptor for an affine component (need Append(Offset(x,t)...) of one node)"; return false; }
+      if (q->kind != Desc::kNode) { *err = "unsupported input descriptor for an affine component (need Append(Offset(x,t)..., [ReplaceIndex(ivector, t, 0)]) of one node, the i-vector last)"; return false; }
       if (!src->empty() && *src != q->node) { *err = "Append() of different nodes (" + *src + ", " + q->node + ") is unsupported (no ivector/multi-stream models)"; return false; }
       *src = q->node; offs->push_back(o);
     }
@@ -393,8 +404,8 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
     if (ci == comps.end()) { *err = "component-node " + n.name + ": unknown component " + n.component; return false; }
     const RawComponent &c = *ci->second;
     if (IsAffineLike(c.type)) {
-      std::string src; std::vector<int> desc_offs;
-      if (!splice_of(n.desc, &src, &desc_offs)) return false;
+      std::string src; std::vector<int> desc_offs; bool with_iv = false;
+      if (!splice_of(n.desc, &src, &desc_offs, &with_iv)) return false;
       FusedNode f; f.has_gemm = true; f.name = n.name;
       if (!lookup(src, &f.input)) return false;
       f.in_dim = dims[src];
@@ -410,11 +421,17 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
       // K blocks: component offset major, descriptor part minor (the component sees the appended vector)
       for (int co : comp_offs) for (int dofs : desc_offs) f.offsets.push_back(co + dofs);
       f.out_dim = w->rows;
-      if ((int64_t)w->cols != (int64_t)f.offsets.size() * f.in_dim) {
-        char m[256]; snprintf(m, sizeof m, "%s %s: weight is %d x %d but input is %zu x %d", c.type.c_str(), c.name.c_str(), w->rows, w->cols, f.offsets.size(), f.in_dim);
+      const int iv_cols = with_iv ? fm->ivector_dim : 0;
+      if (with_iv && comp_offs.size() != 1) { *err = "TdnnComponent " + c.name + " with several time offsets over an Append() that holds the i-vector is unsupported"; return false; }
+      if ((int64_t)w->cols != (int64_t)f.offsets.size() * f.in_dim + iv_cols) {
+        char m[256]; snprintf(m, sizeof m, "%s %s: weight is %d x %d but input is %zu x %d + %d", c.type.c_str(), c.name.c_str(), w->rows, w->cols, f.offsets.size(), f.in_dim, iv_cols);
         *err = m; return false;
       }
-      f.W = w->data;
+      if (!with_iv) f.W = w->data;
+      else {                                              // split the columns: [ spliced | i-vector ]
+        const int ks = w->cols - iv_cols; f.W.resize((size_t)w->rows * ks); f.W_iv.resize((size_t)w->rows * iv_cols);
+        for (int r = 0; r < w->rows; r++) { memcpy(&f.W[(size_t)r * ks], &w->data[(size_t)r * w->cols], sizeof(float) * ks); memcpy(&f.W_iv[(size_t)r * iv_cols], &w->data[(size_t)r * w->cols + ks], sizeof(float) * iv_cols); }
+      }
       if (b && !b->data.empty()) { if ((int)b->data.size() != f.out_dim) { *err = c.name + ": bias dim mismatch"; return false; } f.bias = b->data; }
       fm->nodes.push_back(std::move(f));
       producer[n.name] = (int)fm->nodes.size() - 1; dims[n.name] = fm->nodes.back().out_dim;

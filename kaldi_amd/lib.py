@@ -38,7 +38,8 @@ class IvectorInfo(ctypes.Structure):        # k3_ivector_info
 class NnetInfo(ctypes.Structure):
     """k3_nnet_info (include/k3hip.h)"""
     _fields_ = [("input_dim", ctypes.c_int32), ("output_dim", ctypes.c_int32), ("left_context", ctypes.c_int32), ("right_context", ctypes.c_int32),
-                ("num_components", ctypes.c_int32), ("num_fused_nodes", ctypes.c_int32), ("has_priors", ctypes.c_int32), ("num_params", ctypes.c_int64)]
+                ("num_components", ctypes.c_int32), ("num_fused_nodes", ctypes.c_int32), ("has_priors", ctypes.c_int32), ("num_params", ctypes.c_int64),
+                ("ivector_dim", ctypes.c_int32)]
 
 class DecoderConfig(ctypes.Structure):
     """k3_decoder_config (include/k3hip.h); decoding fields = LatticeFasterDecoderConfig (decoder/lattice-faster-decoder.h:37-107)."""
@@ -86,6 +87,9 @@ def load():
     L.k3_nnet_batch_output_rows.argtypes = [vp, vp]; L.k3_nnet_batch_output_rows.restype = i64
     L.k3_nnet_batch_flops.argtypes = [vp]; L.k3_nnet_batch_flops.restype = ctypes.c_double
     L.k3_nnet_forward.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.k3_nnet_batch_create_ivector.argtypes = [vp, i32, vp, i32, vp, ctypes.c_float, i32, i32, vp, ctypes.POINTER(vp)]
+    L.k3_nnet_batch_ivector_rows.argtypes = [vp]; L.k3_nnet_batch_ivector_rows.restype = i64
+    L.k3_nnet_forward_ivector.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp]
     L.k3_fst_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, ctypes.POINTER(vp)]
     L.k3_fst_create_empty.argtypes = [i32, i64, i32, ctypes.POINTER(vp)]
     L.k3_fst_destroy.argtypes = [vp]; L.k3_fst_destroy.restype = None

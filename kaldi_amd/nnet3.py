@@ -23,12 +23,20 @@ class Nnet:
 
 class NnetBatch:
     """One planned ragged batch (cf. BatchedStaticNnet3::RunBatch, cudadecoder/batched-static-nnet3.cc:293-365)."""
-    def __init__(self, nnet, num_frames, frame_subsampling_factor=1, log_priors=None, acoustic_scale=1.0):
+    def __init__(self, nnet, num_frames, frame_subsampling_factor=1, log_priors=None, acoustic_scale=1.0, ivector_rows=None, online_ivector_period=0, frames_per_chunk=50):
+        """ivector_rows (models with an i-vector input): None = one i-vector per utterance (--ivectors); else the number of --online-ivectors rows of
+        every utterance, with online_ivector_period and frames_per_chunk as nnet3-compute / nnet3-latgen-faster take them"""
         self.nnet = nnet; self._L = nnet._L; self._h = ctypes.c_void_p()
         nf = np.ascontiguousarray(num_frames, dtype=np.int32)
         lp = None if log_priors is None else np.ascontiguousarray(log_priors, dtype=np.float32)
-        _l.check(self._L.k3_nnet_batch_create(nnet._h, len(nf), nf.ctypes.data, int(frame_subsampling_factor),
-                                              None if lp is None else lp.ctypes.data, float(acoustic_scale), ctypes.byref(self._h)))
+        if nnet.info.ivector_dim > 0:
+            rows = None if ivector_rows is None else np.ascontiguousarray(ivector_rows, dtype=np.int32)
+            _l.check(self._L.k3_nnet_batch_create_ivector(nnet._h, len(nf), nf.ctypes.data, int(frame_subsampling_factor), None if lp is None else lp.ctypes.data, float(acoustic_scale),
+                                                          int(frames_per_chunk), 0 if rows is None else int(online_ivector_period), None if rows is None else rows.ctypes.data, ctypes.byref(self._h)))
+            self.total_ivector_rows = self._L.k3_nnet_batch_ivector_rows(self._h)
+        else:
+            _l.check(self._L.k3_nnet_batch_create(nnet._h, len(nf), nf.ctypes.data, int(frame_subsampling_factor),
+                                                  None if lp is None else lp.ctypes.data, float(acoustic_scale), ctypes.byref(self._h)))
         off = np.zeros(len(nf) + 1, np.int64)
         self.total_out_rows = self._L.k3_nnet_batch_output_rows(self._h, off.ctypes.data)
         self.out_offsets = off
@@ -41,13 +49,18 @@ class NnetBatch:
         except Exception:      # interpreter shutdown
             pass
 
-    def forward(self, feats, out=None):
-        """feats: float32 [sum T_u, >= input_dim] on the GPU -> float32 [total_out_rows, output_dim]."""
+    def forward(self, feats, out=None, ivectors=None):
+        """feats: float32 [sum T_u, >= input_dim] on the GPU -> float32 [total_out_rows, output_dim]; ivectors (models with an i-vector input):
+        float32 [total_ivector_rows, ivector_dim] on the GPU, the utterances' rows back to back."""
         assert feats.is_cuda and feats.dtype == torch.float32 and feats.stride(1) == 1
         if out is None:
             out = torch.empty((self.total_out_rows, self.nnet.info.output_dim), dtype=torch.float32, device=feats.device)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _l.check(self._L.k3_nnet_forward(self._h, feats.data_ptr(), feats.stride(0), out.data_ptr(), out.stride(0), st))
+        if ivectors is None:
+            _l.check(self._L.k3_nnet_forward(self._h, feats.data_ptr(), feats.stride(0), out.data_ptr(), out.stride(0), st))
+        else:
+            assert ivectors.is_cuda and ivectors.dtype == torch.float32 and ivectors.stride(1) == 1 and ivectors.shape[0] == self.total_ivector_rows
+            _l.check(self._L.k3_nnet_forward_ivector(self._h, feats.data_ptr(), feats.stride(0), ivectors.data_ptr(), ivectors.stride(0), out.data_ptr(), out.stride(0), st))
         return out
 
 

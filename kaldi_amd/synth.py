@@ -112,7 +112,7 @@ def _bn_apply(x, p, eps=1e-3):
     return (np.asarray(x, np.float64) - p["mean"].astype(np.float64)) * scale
 
 def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0) + (3,) * 12, prefinal_small=192,
-               num_pdfs=6024, bypass_scale=0.75, calib_frames=600, out_std=2.5, calib_feats=None):
+               num_pdfs=6024, bypass_scale=0.75, calib_frames=600, out_std=2.5, calib_feats=None, ivector_dim=0):
     """The 17-layer LibriSpeech TDNN-F layout (egs/librispeech/s5/local/chain/tuning/run_tdnn_1d.sh:220-249 minus
     ivector/LDA/xent/dropout) at mini_librispeech widths (run_tdnn_1k.sh:185-202): '17L-768/96-6024', ~6.28 M params.
     Node/component names follow steps/libs/nnet3/xconfig (composite_layers.py:68-227)."""
@@ -121,11 +121,17 @@ def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0
     # calibration activations (shrinking as context is consumed); pass real features of the workload when available
     x = np.asarray(calib_feats if calib_feats is not None else _calib_feats(rng, calib_frames, input_dim), np.float64)
     def randn(r, c, std): return (rng.standard_normal((r, c)) * std).astype(np.float32)
+    if ivector_dim: L.append(f"input-node name=ivector dim={ivector_dim}")      # ivector_dim > 0: the recipe's "input dim=100 name=ivector" and Append(-1,0,1,ReplaceIndex(ivector, t, 0)) (run_tdnn_1d.sh:222-228)
     L.append(f"input-node name=input dim={input_dim}")
     # tdnn1: relu-batchnorm-layer input=Append(-1,0,1)
     W = randn(dim, 3 * input_dim, 1.0 / np.sqrt(3 * input_dim)); b = (rng.standard_normal(dim) * 0.1).astype(np.float32)
-    C.append(("tdnn1.affine", "affine", dict(W=W, b=b)))
-    L.append("component-node name=tdnn1.affine component=tdnn1.affine input=Append(Offset(input, -1), input, Offset(input, 1))")
+    if ivector_dim:      # the i-vector columns come last, like the Append() order; drawn after W so that ivector_dim = 0 models keep their weights
+        Wfull = np.concatenate([W, randn(dim, ivector_dim, 0.5 / np.sqrt(ivector_dim))], axis=1)
+        C.append(("tdnn1.affine", "affine", dict(W=Wfull, b=b)))
+        L.append("component-node name=tdnn1.affine component=tdnn1.affine input=Append(Offset(input, -1), input, Offset(input, 1), ReplaceIndex(ivector, t, 0))")
+    else:
+        C.append(("tdnn1.affine", "affine", dict(W=W, b=b)))
+        L.append("component-node name=tdnn1.affine component=tdnn1.affine input=Append(Offset(input, -1), input, Offset(input, 1))")
     # centre the affine on the calibration input so the random first layer is not saturated by the fbank offset
     h = _splice(x, (-1, 0, 1)) @ W.T.astype(np.float64) + b
     b -= h.mean(0).astype(np.float32); h = _splice(x, (-1, 0, 1)) @ W.T.astype(np.float64) + b

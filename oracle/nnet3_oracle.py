@@ -228,6 +228,9 @@ def parse_descriptor(s):
     if fn == "Append": return ("append", [parse_descriptor(a) for a in args])
     if fn == "Sum": return ("sum", [parse_descriptor(a) for a in args])
     if fn == "Scale": return ("scale", float(args[0]), parse_descriptor(args[1]))
+    if fn == "ReplaceIndex":       # ReplaceIndex(ivector, t, 0): the value of `ivector` at t = 0 for every t (nnet-descriptor.h:246-268)
+        assert args[1] == "t" and int(args[2]) == 0, s
+        return ("const", parse_descriptor(args[0]))
     raise ValueError("unsupported descriptor " + s)
 
 def _cfg(line):
@@ -298,9 +301,11 @@ def _eval_desc(d, vals):
         s = _eval_desc(d[1], vals); return _Seq(s.t0 - d[2], s.x)      # value at t is src at t+off
     if k == "scale":
         s = _eval_desc(d[2], vals); return _Seq(s.t0, (_F()(d[1]) * s.x).astype(_F()))
+    if k == "const": return ("const", _eval_desc(d[1], vals).x[0])
     parts = [_eval_desc(p, vals) for p in d[1]]
-    lo, hi = max(p.t0 for p in parts), min(p.t1 for p in parts)
-    cut = [p.x[lo - p.t0: hi - p.t0 + 1] for p in parts]
+    timed = [p for p in parts if not isinstance(p, tuple)]
+    lo, hi = max(p.t0 for p in timed), min(p.t1 for p in timed)
+    cut = [np.tile(p[1][None, :], (hi - lo + 1, 1)) if isinstance(p, tuple) else p.x[lo - p.t0: hi - p.t0 + 1] for p in parts]
     if k == "append": return _Seq(lo, np.concatenate(cut, axis=1))
     if k == "sum":
         y = cut[0].copy()
@@ -313,6 +318,7 @@ def context(net):
     ctx = {"input": (0, 0)}
     def dctx(d):
         k = d[0]
+        if k == "const": return (0, 0)
         if k == "node": return ctx[d[1]]
         if k == "offset": l, r = dctx(d[1]); return (l - d[2], r + d[2])
         if k == "scale": return dctx(d[2])
@@ -330,35 +336,55 @@ def context(net):
             return dctx(parse_descriptor(a["input"]))
     raise ValueError("no output node")
 
-def compute(net, feats, frame_subsampling_factor=1, log_priors=None, acoustic_scale=1.0, dtype=np.float32):
+def compute(net, feats, frame_subsampling_factor=1, log_priors=None, acoustic_scale=1.0, dtype=np.float32, ivector=None, online_ivectors=None,
+            online_ivector_period=10, frames_per_chunk=50):
     """nnet3-compute semantics for one utterance: feats [T x input_dim] -> [ceil(T/s) x output_dim].
     dtype=np.float64 evaluates the same graph in double precision (the value both float32 implementations --
-    the reference's MKL sgemm path and the MFMA kernel -- are roundings of); default float32 like BaseFloat."""
+    the reference's MKL sgemm path and the MFMA kernel -- are roundings of); default float32 like BaseFloat.
+    ivector [N] (--ivectors: one per utterance) or online_ivectors [rows x N] (--online-ivectors, one row per online_ivector_period frames):
+    the network is then evaluated chunk by chunk like DecodableNnetSimple (nnet-am-decodable-simple.cc:93-168), every chunk of
+    frames_per_chunk frames with the i-vector GetCurrentIvector picks for it (:178-213)."""
     global _DTYPE
     _DTYPE = dtype
     try:
-        return _compute(net, feats, frame_subsampling_factor, log_priors, acoustic_scale)
+        if ivector is None and online_ivectors is None: return _compute(net, feats, frame_subsampling_factor, log_priors, acoustic_scale)
+        s = frame_subsampling_factor; T = np.asarray(feats).shape[0]; n_sub = (T + s - 1) // s; per = (frames_per_chunk + s - 1) // s       # CheckAndFixConfigs rounds the chunk up to a multiple of s (nnet-am-decodable-simple.h:120-134)
+        rows = []
+        for c0 in range(0, n_sub, per):
+            n = min(n_sub - c0, per); first, last = c0 * s, (c0 + n - 1) * s
+            if ivector is not None: iv = np.asarray(ivector, np.float32)
+            else:
+                oi = np.asarray(online_ivectors, np.float32); f = (first + (last - first) // 2) // online_ivector_period
+                if f >= oi.shape[0]:
+                    if (f - (oi.shape[0] - 1)) * online_ivector_period > 50: raise ValueError("Could not get iVector for frame (mismatched --online-ivector-period?)")
+                    f = oi.shape[0] - 1
+                iv = oi[f]
+            rows.append(_compute(net, feats, s, log_priors, acoustic_scale, first_out=first, num_out=n, ivector=iv))
+        return np.concatenate(rows, axis=0)
     finally:
         _DTYPE = np.float32
 
-def _compute(net, feats, frame_subsampling_factor, log_priors, acoustic_scale):
+def _compute(net, feats, frame_subsampling_factor, log_priors, acoustic_scale, first_out=0, num_out=None, ivector=None):
+    """outputs for t = first_out + k*s, k < num_out (default: the whole utterance)"""
     feats = np.asarray(feats, np.float32).astype(_F()); T = feats.shape[0]; s = frame_subsampling_factor
     L, R = context(net)
-    n_out = (T + s - 1) // s
-    t_last = (n_out - 1) * s
-    idx = np.clip(np.arange(-L, t_last + R + 1), 0, T - 1)          # edge replication (:154-163)
-    vals = {"input": _Seq(-L, feats[idx])}
+    n_out = (T + s - 1) // s if num_out is None else num_out
+    t_first = first_out; t_last = first_out + (n_out - 1) * s
+    idx = np.clip(np.arange(t_first - L, t_last + R + 1), 0, T - 1)          # edge replication (:154-163)
+    vals = {"input": _Seq(t_first - L, feats[idx])}
+    if ivector is not None: vals["ivector"] = _Seq(0, np.asarray(ivector, np.float32).astype(_F())[None, :])
     out = None
     for line in net.config_lines:
         kind, a = _cfg(line)
         if kind == "input-node":
-            assert a["name"] == "input", "oracle handles a single input (no ivector)"
+            assert a["name"] in ("input", "ivector"), a["name"]
+            if a["name"] == "ivector": assert ivector is not None and np.asarray(ivector).size == int(a["dim"]), "the model expects an i-vector input"
         elif kind == "component-node":
             vals[a["name"]] = _apply_component(net.components[a["component"]], _eval_desc(parse_descriptor(a["input"]), vals))
         elif kind == "output-node" and a["name"] == "output":
             o = _eval_desc(parse_descriptor(a["input"]), vals)
-            assert o.t0 <= 0 and o.t1 >= t_last, (o.t0, o.t1, t_last)
-            out = o.x[(-o.t0):(t_last - o.t0 + 1):s].copy()
+            assert o.t0 <= t_first and o.t1 >= t_last, (o.t0, o.t1, t_first, t_last)
+            out = o.x[(t_first - o.t0):(t_last - o.t0 + 1):s].copy()
     if log_priors is not None: out = out - np.asarray(log_priors, np.float32).astype(_F())      # :268-269
     if acoustic_scale != 1.0: out = out * _F()(acoustic_scale)               # :271
     return out.astype(_F())

@@ -136,3 +136,54 @@ def test_batched_static_nnet3_streaming_equals_whole_utterance(tmp_path):
             g = torch.cat(got[u], 0)
             assert g.shape == ref_u[u].shape, (C, u, g.shape, ref_u[u].shape)
             assert torch.equal(g, ref_u[u]), (C, u, (g - ref_u[u]).abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------- models with an i-vector input
+IV_CASES = {"s1_c50_p10": (1, 50, 10, False), "s3_c50_p10": (3, 50, 10, False), "s3_c21_p7": (3, 21, 7, False), "s1_c20_p10_short": (1, 20, 10, False), "s3_utt": (3, 50, 0, True), "s1_utt": (1, 50, 0, True)}
+
+def _forward_iv(n, feats_list, s, iv_list, period, chunk, utt_level):
+    from kaldi_amd import nnet3
+    dev = torch.device("cuda:0")
+    b = nnet3.NnetBatch(n, [f.shape[0] for f in feats_list], s, ivector_rows=None if utt_level else [iv.shape[0] for iv in iv_list], online_ivector_period=period, frames_per_chunk=chunk)
+    x = torch.from_numpy(np.concatenate(feats_list)).to(dev); v = torch.from_numpy(np.concatenate([np.atleast_2d(iv) for iv in iv_list]).astype(np.float32)).to(dev)
+    y = b.forward(x, ivectors=v); torch.cuda.synchronize(); y = y.cpu().numpy()
+    return [y[b.out_offsets[i]:b.out_offsets[i + 1]] for i in range(len(feats_list))]
+
+@pytest.mark.parametrize("name", sorted(IV_CASES))
+def test_ivector_input_vs_reference_nnet3_compute(name):
+    """tests/golden/nnet_ivector*: the REFERENCE's nnet3-compute --online-ivectors / --ivectors on a model with the recipe's i-vector input"""
+    from kaldi_amd import nnet3
+    g = np.load(os.path.join(GOLD, "nnet_ivector_io.npz")); n = nnet3.Nnet(os.path.join(GOLD, "nnet_ivector.raw")); assert n.info.ivector_dim == 12
+    s, chunk, period, utt = IV_CASES[name]
+    got = _forward_iv(n, [g["feats"]], s, [g["iv_" + name]], period, chunk, utt)[0]; ref = g["ref_" + name]
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= TOL, np.abs(got - ref).max()
+
+def test_ivector_input_ragged_batch_vs_oracle(tmp_path):
+    """several utterances of different lengths (one shorter than a chunk, one a single frame), each with its own online i-vectors, in one batch"""
+    from kaldi_amd import nnet3
+    from oracle import nnet3_oracle as no
+    net = synth.make_tdnnf(seed=21, dim=64, bottleneck=16, strides=(1, 3, 0, 3), prefinal_small=32, num_pdfs=120, calib_frames=300, ivector_dim=20)
+    p = str(tmp_path / "m.raw"); net.write(p); onet = no.read_nnet(p); n = nnet3.Nnet(p); rng = np.random.default_rng(3)
+    for s, chunk, period in ((3, 50, 10), (1, 30, 10), (3, 150, 5)):
+        lens = [260, 17, 1, 149, 75]
+        feats = [_feats(rng, T) for T in lens]; ivs = [(rng.standard_normal(((T + period - 1) // period, 20)) * 0.7).astype(np.float32) for T in lens]
+        got = _forward_iv(n, feats, s, ivs, period, chunk, False)
+        for f, iv, g in zip(feats, ivs, got):
+            want = no.compute(onet, f, s, online_ivectors=iv, online_ivector_period=period, frames_per_chunk=chunk)
+            assert g.shape == want.shape and (np.abs(g - want) - 1e-5 * np.abs(want)).max() <= TOL, (s, chunk, f.shape[0], np.abs(g - want).max())
+    # one i-vector per utterance
+    feats = [_feats(rng, T) for T in (90, 33)]; ivs = [rng.standard_normal(20).astype(np.float32) for _ in range(2)]
+    got = _forward_iv(n, feats, 3, ivs, 0, 50, True)
+    for f, iv, g in zip(feats, ivs, got):
+        want = no.compute(onet, f, 3, ivector=iv); assert g.shape == want.shape and (np.abs(g - want) - 1e-5 * np.abs(want)).max() <= TOL
+
+def test_ivector_input_errors(tmp_path):
+    from kaldi_amd import nnet3, lib
+    g = np.load(os.path.join(GOLD, "nnet_ivector_io.npz")); n = nnet3.Nnet(os.path.join(GOLD, "nnet_ivector.raw")); dev = torch.device("cuda:0")
+    b = nnet3.NnetBatch(n, [131], 1, ivector_rows=[14], online_ivector_period=10)
+    with pytest.raises(lib.K3Error, match="i-vector"): b.forward(torch.from_numpy(g["feats"]).to(dev))            # the i-vectors are not optional for this model
+    with pytest.raises(lib.K3Error, match="Could not get iVector"): nnet3.NnetBatch(n, [131], 1, ivector_rows=[3], online_ivector_period=10)   # far too few rows: the reference's error
+    plain = nnet3.Nnet(os.path.join(GOLD, "nnet_small.raw"))
+    with pytest.raises(lib.K3Error, match="no i-vector input"):
+        h = __import__("ctypes").c_void_p(); nf = np.array([50], np.int32); rows = np.array([5], np.int32)
+        lib.check(lib.load().k3_nnet_batch_create_ivector(plain._h, 1, nf.ctypes.data, 1, None, 1.0, 50, 10, rows.ctypes.data, __import__("ctypes").byref(h)))

@@ -73,3 +73,19 @@ def test_random_architectures_against_the_reference_nnet3_compute(tmp_path):
         assert r.returncode == 0, r.stderr[-1500:]
         ref = kio.read_ark(f"{td}/o.ark")["u"]; mine = no.compute(no.read_nnet(f"{td}/m.raw"), feats, s)
         assert mine.shape == ref.shape and np.abs(mine - ref).max() <= 1e-4, (it, mine.shape, ref.shape)
+
+
+IV_CASES = {"s1_c50_p10": (1, 50, 10, False), "s3_c50_p10": (3, 50, 10, False), "s3_c21_p7": (3, 21, 7, False), "s1_c20_p10_short": (1, 20, 10, False), "s3_utt": (3, 50, 0, True), "s1_utt": (1, 50, 0, True)}
+
+def test_oracle_with_ivector_input_vs_reference_nnet3_compute():
+    """the recipe's i-vector input (Append(-1,0,1,ReplaceIndex(ivector, t, 0))): the oracle's chunk-by-chunk evaluation against the REFERENCE's
+    nnet3-compute --online-ivectors / --ivectors (tests/golden/make_golden_nnet_ivector.py), 1e-4 like the rest of the nnet path"""
+    from oracle import nnet3_oracle as no
+    g = np.load(os.path.join(GOLD, "nnet_ivector_io.npz")); net = no.read_nnet(os.path.join(GOLD, "nnet_ivector.raw"))
+    for name, (s, chunk, period, utt) in IV_CASES.items():
+        kw = dict(ivector=g["iv_" + name]) if utt else dict(online_ivectors=g["iv_" + name], online_ivector_period=period)
+        got = no.compute(net, g["feats"], s, frames_per_chunk=chunk, **kw); ref = g["ref_" + name]
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-4, (name, np.abs(got - ref).max())
+    # the chunking matters: the whole-utterance evaluation with one of the rows is NOT what the reference computes
+    other = no.compute(net, g["feats"], 1, ivector=g["iv_s1_c50_p10"][0])
+    assert np.abs(other - g["ref_s1_c50_p10"]).max() > 1e-2
