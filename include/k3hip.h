@@ -130,6 +130,15 @@ int64_t k3_ivector_num_rows(const k3_ivector *iv, int32_t num_utts, const int64_
  * them; d_ivectors [num_rows x ld_ivectors].  Asynchronous on `stream` after a short synchronisation for the offsets. */
 int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
                              float *d_ivectors, int64_t ld_ivectors, void *stream);
+/* The same with the speaker's adaptation state (OnlineIvectorExtractorAdaptationState, online-ivector-feature.h:185-230: what
+ * ivector-extract-online2 carries from one utterance of a speaker to the next, :100-178): per utterance, the CMVN statistics of the speaker's earlier
+ * utterances (d_cmvn_speaker_stats [U x 2 x (feat_dim+1)], count 0 = none; nullable) and the i-vector statistics so far (d_stats_in, nullable = fresh);
+ * d_stats_out (nullable) receives the statistics after the utterance's last estimate (GetAdaptationState).  One record is k3_ivector_stats_size()
+ * doubles: num_frames, the linear term [R], the quadratic term [R x R].  Utterances of one speaker go in consecutive calls. */
+int64_t k3_ivector_stats_size(const k3_ivector *iv);
+int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
+                                   float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in,
+                                   double *d_stats_out, void *stream);
 
 /* ---------------------------------------------------------------- nnet3 forward -------------
  * Replaces, for "simple" feed-forward TDNN / TDNN-F models: nnet3::NnetComputer::Run over the compiled

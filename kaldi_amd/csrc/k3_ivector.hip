@@ -173,6 +173,7 @@ struct EstParams {
   const double *U, *SM; double *quad_g, *chol_g;              // per utterance [R][R] scratch (quad_g NULL = LDS)
   float *out; int64_t ld_out; const int64_t *out_off;
   int D, R, S, period, num_cg_iters, exact_solve; double prior, max_count;
+  const double *state_in; double *state_out;      // per utterance [1 + R + R*R]: num_frames, linear, quadratic (OnlineIvectorEstimationStats), nullable
 };
 
 __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
@@ -185,9 +186,10 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
   double *C = p.chol_g + (size_t)u * R * R;
   __shared__ int s_n; __shared__ double s_tot;
   const int64_t fb = p.frame_off[u]; const int T = (int)(p.frame_off[u + 1] - fb);
-  for (int i = tid; i < R * R; i += kBlock) A[i] = (i / R == i % R) ? 1.0 : 0.0;      // quadratic term of the prior: I; linear term: prior_offset e_0
-  if (tid < R) { s_lin[tid] = tid == 0 ? p.prior : 0.0; s_x[tid] = tid == 0 ? p.prior : 0.0; }
-  double nframes = 0.0;
+  const double *st_in = p.state_in ? p.state_in + (size_t)u * (1 + R + (size_t)R * R) : nullptr;      // the speaker's statistics so far (SetAdaptationState)
+  for (int i = tid; i < R * R; i += kBlock) A[i] = st_in ? st_in[1 + R + i] : ((i / R == i % R) ? 1.0 : 0.0);      // fresh: quadratic term of the prior I, linear term prior_offset e_0
+  if (tid < R) { s_lin[tid] = st_in ? st_in[1 + tid] : (tid == 0 ? p.prior : 0.0); s_x[tid] = tid == 0 ? p.prior : 0.0; }
+  double nframes = st_in ? st_in[0] : 0.0;
   __syncthreads();
   for (int k = 0; (int64_t)k * P < T; k++) {
     const int t_lo = k == 0 ? 0 : (k - 1) * P + 1, t_hi = k * P;                     // frames not yet in the statistics, up to and including frame k*P
@@ -266,6 +268,13 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
     __syncthreads();
     if (tid < R) p.out[(p.out_off[u] + k) * p.ld_out + tid] = tid == 0 ? (float)s_x[0] - (float)p.prior : (float)s_x[tid];
   }
+  if (p.state_out) {                                                                  // GetAdaptationState: the statistics as they stand after the last estimate
+    double *so = p.state_out + (size_t)u * (1 + R + (size_t)R * R);
+    __syncthreads();
+    if (tid == 0) so[0] = nframes;
+    if (tid < R) so[1 + tid] = s_lin[tid];
+    for (int i = tid; i < R * R; i += kBlock) so[1 + R + i] = A[i];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- C ABI
@@ -326,8 +335,15 @@ extern "C" int64_t k3_ivector_num_rows(const k3_ivector *iv, int32_t num_utts, c
   return n;
 }
 
+extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
+                                              const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream_);
 extern "C" int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
                                         void *stream_) {
+  return k3_ivector_extract_batch_adapt(iv, d_feats, ld_feats, h_frame_offsets, num_utts, d_ivectors, ld_ivectors, nullptr, nullptr, nullptr, stream_);
+}
+extern "C" int64_t k3_ivector_stats_size(const k3_ivector *iv) { return iv ? 1 + iv->R + (int64_t)iv->R * iv->R : -1; }
+extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
+                                              const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream_) {
   K3_REQUIRE(iv && d_feats && h_frame_offsets && d_ivectors && num_utts > 0, "k3_ivector_extract_batch: null or empty argument");
   K3_REQUIRE(ld_feats >= iv->F && ld_ivectors >= iv->R, "k3_ivector_extract_batch: leading dimension smaller than the row length");
   hipStream_t stream = (hipStream_t)stream_;
@@ -345,7 +361,7 @@ extern "C" int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, in
   K3_HIP_CHECK(hipMemcpyAsync(iv->frame_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, stream));
   K3_HIP_CHECK(hipStreamSynchronize(stream));                   // offs is a local
   const int64_t *d_off = (const int64_t *)iv->frame_off.p, *d_row_off = d_off + num_utts + 1;
-  rc = k3_cmvn_online_batch(d_feats, ld_feats, (float *)iv->cmvn.p, F, F, d_off, num_utts, &iv->o.cmvn, iv->global_stats, nullptr, nullptr, 0, stream_); if (rc) return rc;
+  rc = k3_cmvn_online_batch(d_feats, ld_feats, (float *)iv->cmvn.p, F, F, d_off, num_utts, &iv->o.cmvn, iv->global_stats, d_cmvn_speaker_stats, nullptr, 0, stream_); if (rc) return rc;
   const unsigned nb = (unsigned)((N * D + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)iv->cmvn.p, (int64_t)F, d_off, num_utts, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D,
                      iv->o.left_context, iv->o.right_context, (float *)iv->xpost.p, N);
@@ -358,7 +374,7 @@ extern "C" int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, in
                      iv->o.posterior_scale, N, (int32_t *)iv->post_g.p, (float *)iv->post_w.p, (int32_t *)iv->post_n.p);
   EstParams p; p.xstats = (const float *)iv->xstats.p; p.frame_off = d_off; p.post_g = (const int32_t *)iv->post_g.p; p.post_w = (const float *)iv->post_w.p; p.post_n = (const int32_t *)iv->post_n.p;
   p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)iv->quad.p; p.chol_g = (double *)iv->state.p; p.out = d_ivectors; p.ld_out = ld_ivectors; p.out_off = d_row_off;
-  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count;
+  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out;
   size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
   K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_extract_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));

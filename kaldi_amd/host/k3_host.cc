@@ -537,6 +537,10 @@ size_t ReadOneMatrix(const std::string &b, size_t p, Matrix *m, const std::strin
       m->rows = i32(); m->cols = i32(); const size_t n = (size_t)m->rows * m->cols; m->data.resize(n);
       if (tok == "FM") { need(4 * n); memcpy(m->data.data(), b.data() + p, 4 * n); p += 4 * n; }
       else { need(8 * n); for (size_t i = 0; i < n; i++) { double d; memcpy(&d, b.data() + p + 8 * i, 8); m->data[i] = (float)d; } p += 8 * n; }
+    } else if (tok == "FV" || tok == "DV") {      // a vector table read as one-row matrices (--ivectors)
+      m->rows = 1; m->cols = i32(); const size_t n = (size_t)m->cols; m->data.resize(n);
+      if (tok == "FV") { need(4 * n); memcpy(m->data.data(), b.data() + p, 4 * n); p += 4 * n; }
+      else { need(8 * n); for (size_t i = 0; i < n; i++) { double d; memcpy(&d, b.data() + p + 8 * i, 8); m->data[i] = (float)d; } p += 8 * n; }
     } else if (tok == "CM" || tok == "CM2" || tok == "CM3") {
       need(16); float mn, range; int32_t nr, nc; memcpy(&mn, b.data() + p, 4); memcpy(&range, b.data() + p + 4, 4); memcpy(&nr, b.data() + p + 8, 4); memcpy(&nc, b.data() + p + 12, 4); p += 16;
       m->rows = nr; m->cols = nc; m->data.resize((size_t)nr * nc);

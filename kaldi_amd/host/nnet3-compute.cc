@@ -7,6 +7,7 @@
 #include <cmath>
 #include <iostream>
 #include "k3_host.h"
+#include "k3_nnet_ivector_cli.h"
 #include "../../include/k3hip.h"
 using namespace k3host;
 #define HIPCHK(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) K3H_ERR << "HIP error " << hipGetErrorName(e__) << " in " << #e; } while (0)
@@ -19,13 +20,16 @@ int main(int argc, char **argv) {
     int32_t subsampling = 1, frames_per_chunk = 50, elc = 0, erc = 0, elci = -1, ercf = -1, online_ivector_period = 0, max_batch = 512; float acoustic_scale = 1.0f;
     po.Register("apply-exp", &apply_exp, "If true, apply exp function to output"); po.Register("use-priors", &use_priors, "If true, subtract the logs of the priors stored with the model (in this case, a .mdl file is expected as input).");
     po.Register("use-gpu", &use_gpu, "yes|no|optional|wait (this build always uses the GPU)"); po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output is less than the frame-rate of the input");
-    po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole)"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
+    po.Register("frames-per-chunk", &frames_per_chunk, "Number of frames in each chunk that is separately evaluated by the neural net (matters with --online-ivectors: one i-vector per chunk; without i-vectors the result does not depend on it and utterances are evaluated whole)"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
     po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)"); po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)");
-    po.Register("ivectors", &ivector_rspecifier, "(not supported)"); po.Register("online-ivectors", &online_ivector_rspecifier, "(not supported)"); po.Register("online-ivector-period", &online_ivector_period, "(not supported)");
-    po.Register("utt2spk", &utt2spk, "(not supported)"); po.Register("debug-computation", &debug_comp, "(accepted, unused)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
+    po.Register("ivectors", &ivector_rspecifier, "Rspecifier for iVectors as vectors (i.e. not estimated online); per utterance by default, or per speaker if you provide the --utt2spk option.");
+    po.Register("online-ivectors", &online_ivector_rspecifier, "Rspecifier for iVectors estimated online, as matrices.  If you supply this, you must set the --online-ivector-period option.");
+    po.Register("online-ivector-period", &online_ivector_period, "Number of frames between iVectors in matrices supplied to the --online-ivectors option");
+    po.Register("utt2spk", &utt2spk, "Rspecifier for utt2spk option used to get ivectors per speaker"); po.Register("debug-computation", &debug_comp, "(accepted, unused)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) { po.PrintUsage(); return 1; }
-    if (!ivector_rspecifier.empty() || !online_ivector_rspecifier.empty() || elc || erc) K3H_ERR << "i-vectors / extra context are not supported by this program";
+    if (elc || erc) K3H_ERR << "extra context is not supported by this program (feed-forward TDNN / TDNN-F models do not use it)";
+    IvectorInputs iv; iv.Open(ivector_rspecifier, online_ivector_rspecifier, utt2spk, online_ivector_period);
     k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(po.GetArg(1).c_str(), &nnet));
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
     std::vector<float> log_priors;
@@ -35,23 +39,23 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t b0 = 0; b0 < feats.size(); b0 += max_batch) {
       const size_t b1 = std::min(feats.size(), b0 + (size_t)max_batch);
-      std::vector<size_t> idx; std::vector<int32_t> nf; std::vector<float> all;
+      std::vector<size_t> idx; std::vector<int32_t> nf; std::vector<float> all; std::vector<const Matrix *> utt_iv;
       for (size_t i = b0; i < b1; i++) {
         const Matrix &m = feats[i].second;
         if (m.rows == 0) { K3H_WARN << "Zero-length utterance: " << feats[i].first; num_fail++; continue; }
         if (m.cols != ni.input_dim) K3H_ERR << "Neural net expects 'input' features with dimension " << ni.input_dim << " but you provided " << m.cols;
-        idx.push_back(i); nf.push_back(m.rows); all.insert(all.end(), m.data.begin(), m.data.end());
+        const Matrix *v = iv.Any() ? iv.Get(feats[i].first) : nullptr;
+        if (iv.Any() && !v) { K3H_WARN << "No iVector available for utterance " << feats[i].first; num_fail++; continue; }
+        idx.push_back(i); nf.push_back(m.rows); all.insert(all.end(), m.data.begin(), m.data.end()); utt_iv.push_back(v);
       }
       if (idx.empty()) continue;
-      k3_nnet_batch *nb = nullptr; K3H_CHECK_K3(k3_nnet_batch_create(nnet, (int32_t)idx.size(), nf.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
-      std::vector<int64_t> ro(idx.size() + 1); const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
-      float *d_f, *d_o; HIPCHK(hipMalloc((void **)&d_f, all.size() * 4)); HIPCHK(hipMalloc((void **)&d_o, (size_t)rows * ni.output_dim * 4));
-      HIPCHK(hipMemcpy(d_f, all.data(), all.size() * 4, hipMemcpyHostToDevice));
-      K3H_CHECK_K3(k3_nnet_forward(nb, d_f, ni.input_dim, d_o, ni.output_dim, nullptr));
+      k3_nnet_batch *nb = nullptr; std::vector<int64_t> ro; float *d_o = nullptr;
+      RunNnetBatch(nnet, ni, nf, all, iv, utt_iv, subsampling, frames_per_chunk, log_priors, acoustic_scale, &nb, &ro, &d_o);
+      const int64_t rows = ro.back();
       std::vector<float> h((size_t)rows * ni.output_dim); HIPCHK(hipMemcpy(h.data(), d_o, h.size() * 4, hipMemcpyDeviceToHost));
       if (apply_exp) for (float &v : h) v = expf(v);
       for (size_t u = 0; u < idx.size(); u++) { writer.WriteMatrix(feats[idx[u]].first, h.data() + ro[u] * ni.output_dim, (int32_t)(ro[u + 1] - ro[u]), ni.output_dim, ni.output_dim); frame_count += nf[u]; num_success++; }
-      k3_nnet_batch_destroy(nb); HIPCHK(hipFree(d_f)); HIPCHK(hipFree(d_o));
+      k3_nnet_batch_destroy(nb); HIPCHK(hipFree(d_o));
     }
     writer.Flush();
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

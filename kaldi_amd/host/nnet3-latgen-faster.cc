@@ -10,6 +10,7 @@
 #include <cmath>
 #include <iostream>
 #include "k3_host.h"
+#include "k3_nnet_ivector_cli.h"
 #include "../../include/k3hip.h"
 using namespace k3host;
 #define HIPCHK(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) K3H_ERR << "HIP error " << hipGetErrorName(e__) << " in " << #e; } while (0)
@@ -32,16 +33,19 @@ int main(int argc, char **argv) {
     po.Register("word-determinize", &word_det, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization."); po.Register("delta", &delta, "Tolerance used in determinization");
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods"); po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
-    po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole)"); po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)");
+    po.Register("frames-per-chunk", &frames_per_chunk, "Number of frames in each chunk that is separately evaluated by the neural net (matters with --online-ivectors: one i-vector per chunk)"); po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)");
     po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)"); po.Register("debug-computation", &debug_comp, "(accepted, unused)");
-    po.Register("ivectors", &ivector_rspecifier, "(not supported)"); po.Register("online-ivectors", &online_ivector_rspecifier, "(not supported)"); po.Register("online-ivector-period", &online_ivector_period, "(not supported)"); po.Register("utt2spk", &utt2spk, "(not supported)");
+    po.Register("ivectors", &ivector_rspecifier, "Rspecifier for iVectors as vectors (i.e. not estimated online); per utterance by default, or per speaker if you provide the --utt2spk option.");
+    po.Register("online-ivectors", &online_ivector_rspecifier, "Rspecifier for iVectors estimated online, as matrices.  If you supply this, you must set the --online-ivector-period option.");
+    po.Register("online-ivector-period", &online_ivector_period, "Number of frames between iVectors in matrices supplied to the --online-ivectors option"); po.Register("utt2spk", &utt2spk, "Rspecifier for utt2spk option used to get ivectors per speaker");
     po.Register("frame-tokens-cap", &frame_tokens_cap, "Decoder capacity: tokens alive on one frame of one utterance"); po.Register("lane-tokens-cap", &lane_tokens_cap, "Decoder capacity: tokens of all frames of one utterance (an utterance that exceeds it is reported as failed)");
     po.Register("lane-links-cap", &lane_links_cap, "Decoder capacity: forward links of all frames of one utterance");
     po.Register("use-gpu", &use_gpu, "(this build always uses the GPU)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
     po.Read(argc, argv);
     if (po.NumArgs() < 4 || po.NumArgs() > 6) { po.PrintUsage(); return 1; }
     DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = delta; det_opts.max_mem = max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
-    if (!ivector_rspecifier.empty() || !online_ivector_rspecifier.empty() || elc || erc) K3H_ERR << "i-vectors / extra context are not supported by this program";
+    if (elc || erc) K3H_ERR << "extra context is not supported by this program (feed-forward TDNN / TDNN-F models do not use it)";
+    IvectorInputs iv; iv.Open(ivector_rspecifier, online_ivector_rspecifier, utt2spk, online_ivector_period);
     const std::string model_rx = po.GetArg(1), fst_rx = po.GetArg(2);
     if (fst_rx.find(':') != std::string::npos && fst_rx.compare(0, 3, "ark") == 0) K3H_ERR << "a table of per-utterance FSTs is not supported; give one HCLG";
     TransitionInfo ti = ReadTransitionModel(model_rx);
@@ -66,20 +70,19 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t b0 = 0; b0 < feats.size(); b0 += max_batch) {
       const size_t b1 = std::min(feats.size(), b0 + (size_t)max_batch);
-      std::vector<size_t> idx; std::vector<int32_t> nf; std::vector<float> all;
+      std::vector<size_t> idx; std::vector<int32_t> nf; std::vector<float> all; std::vector<const Matrix *> utt_iv;
       for (size_t i = b0; i < b1; i++) {
         const Matrix &m = feats[i].second;
         if (m.rows == 0) { K3H_WARN << "Zero-length utterance: " << feats[i].first; num_fail++; continue; }
         if (m.cols != ni.input_dim) K3H_ERR << "Neural net expects 'input' features with dimension " << ni.input_dim << " but you provided " << m.cols;
-        idx.push_back(i); nf.push_back(m.rows); all.insert(all.end(), m.data.begin(), m.data.end());
+        const Matrix *v = iv.Any() ? iv.Get(feats[i].first) : nullptr;
+        if (iv.Any() && !v) { K3H_WARN << "No iVector available for utterance " << feats[i].first; num_fail++; continue; }
+        idx.push_back(i); nf.push_back(m.rows); all.insert(all.end(), m.data.begin(), m.data.end()); utt_iv.push_back(v);
       }
       if (idx.empty()) continue;
       const int U = (int)idx.size();
-      k3_nnet_batch *nb = nullptr; K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, nf.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
-      std::vector<int64_t> ro(U + 1); const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
-      float *d_f, *d_o; HIPCHK(hipMalloc((void **)&d_f, all.size() * 4)); HIPCHK(hipMalloc((void **)&d_o, (size_t)rows * ni.output_dim * 4));
-      HIPCHK(hipMemcpy(d_f, all.data(), all.size() * 4, hipMemcpyHostToDevice));
-      K3H_CHECK_K3(k3_nnet_forward(nb, d_f, ni.input_dim, d_o, ni.output_dim, nullptr));
+      k3_nnet_batch *nb = nullptr; std::vector<int64_t> ro; float *d_o = nullptr;
+      RunNnetBatch(nnet, ni, nf, all, iv, utt_iv, subsampling, frames_per_chunk, log_priors, acoustic_scale, &nb, &ro, &d_o);
       K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_o, ni.output_dim, ro.data(), nullptr));
       std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec, info.data());
       int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
@@ -117,7 +120,7 @@ int main(int argc, char **argv) {
         K3H_LOG << "Log-like per frame for utterance " << utt << " is " << (like / std::max<size_t>(nfr, 1)) << " over " << nfr << " frames.";
         tot_like += like; frame_count += (int64_t)nfr; num_success++;
       }
-      k3_nnet_batch_destroy(nb); HIPCHK(hipFree(d_f)); HIPCHK(hipFree(d_o));
+      k3_nnet_batch_destroy(nb); HIPCHK(hipFree(d_o));
     }
     lat_writer.Flush(); if (words_writer) words_writer->Flush(); if (ali_writer) ali_writer->Flush();
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -79,13 +79,21 @@ class BatchedIvectorExtractor:
     def IvectorDim(self): return self.ivector_dim
     def NumGauss(self): return self.num_gauss
 
-    def GetIvectors(self, feats, frame_offsets):
+    def GetIvectors(self, feats, frame_offsets, cmvn_speaker_stats=None, stats_in=None, return_stats=False):
+        """-> (ivectors, row_offsets[, stats]).  cmvn_speaker_stats [U, 2, feat_dim+1] / stats_in [U, StatsSize()] (float64, host or GPU): the adaptation state
+        the speaker's earlier utterances left (OnlineIvectorExtractorAdaptationState); return_stats: also the i-vector statistics after each utterance."""
         assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and feats.stride(1) == 1
         fo = np.ascontiguousarray(np.asarray(frame_offsets, dtype=np.int64)); U = fo.size - 1
         ro = np.zeros(U + 1, np.int64)
         n = self._L.k3_ivector_num_rows(self._h, U, fo.ctypes.data, ro.ctypes.data)
         if n < 0: raise _l.K3Error("k3_ivector_num_rows: bad argument")
         out = torch.empty((n, self.ivector_dim), dtype=torch.float32, device=feats.device)
-        _l.check(self._L.k3_ivector_extract_batch(self._h, feats.data_ptr(), feats.stride(0), fo.ctypes.data, U, out.data_ptr(), out.stride(0),
-                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        return out, ro
+        dev = lambda a: None if a is None else torch.as_tensor(np.asarray(a, np.float64) if not torch.is_tensor(a) else a, dtype=torch.float64).to(feats.device).contiguous()
+        cm, si = dev(cmvn_speaker_stats), dev(stats_in)
+        so = torch.empty((U, self.StatsSize()), dtype=torch.float64, device=feats.device) if return_stats else None
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _l.check(self._L.k3_ivector_extract_batch_adapt(self._h, feats.data_ptr(), feats.stride(0), fo.ctypes.data, U, out.data_ptr(), out.stride(0), ptr(cm), ptr(si), ptr(so),
+                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return (out, ro, so) if return_stats else (out, ro)
+
+    def StatsSize(self): return int(self._L.k3_ivector_stats_size(self._h))

@@ -78,6 +78,7 @@ def load():
     L.k3_ivector_get_info.argtypes = [vp, ctypes.POINTER(IvectorInfo)]
     L.k3_ivector_num_rows.argtypes = [vp, i32, vp, vp]; L.k3_ivector_num_rows.restype = i64
     L.k3_ivector_extract_batch.argtypes = [vp, vp, i64, vp, i32, vp, i64, vp]
+    L.k3_ivector_extract_batch_adapt.argtypes = [vp, vp, i64, vp, i32, vp, i64, vp, vp, vp, vp]; L.k3_ivector_stats_size.argtypes = [vp]; L.k3_ivector_stats_size.restype = i64
     L.k3_nnet_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.k3_nnet_destroy.argtypes = [vp]; L.k3_nnet_destroy.restype = None
     L.k3_nnet_get_info.argtypes = [vp, ctypes.POINTER(NnetInfo)]

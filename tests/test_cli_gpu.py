@@ -280,3 +280,39 @@ def test_batched_wav_nnet3_cuda2_rank_sharding_and_job_naming(tmp_path):
     canon = lambda lat: (sorted((a[2], a[3], float(a[4]), float(a[5])) for a in lat[0]), sorted(float(v) for v in lat[1].values()))      # state numbers depend on the batch a lattice was decoded in
     for part in (r1, r2):
         for k, lat in part.items(): assert canon(lat) == canon(whole[k]) and len(lat[0]) > 0, k
+
+
+def test_ivector_extract_online2_and_nnet3_compute_with_ivectors(tmp_path):
+    """the recipe's i-vector chain on the command line: ivector-extract-online2 (two utterances per speaker: the adaptation state is carried) against the
+    REFERENCE binary's output (tests/golden/ivector), --repeat, then nnet3-compute --online-ivectors / --ivectors against the reference's nnet3-compute"""
+    from oracle import kaldi_io as kio
+    td = str(tmp_path); IV = os.path.join(ROOT, "tests", "golden", "ivector")
+    g = np.load(os.path.join(IV, "ivector_golden.npz")); ref = np.load(os.path.join(IV, "ivector_adapt_golden.npz")); utts = ["utt0", "utt1", "utt2", "utt3"]
+    kio.write_ark(f"{td}/feats.ark", {u: g["feat_" + u] for u in utts}); open(f"{td}/spk2utt", "w").write("spkA utt0 utt1\nspkB utt2 utt3 utt_missing\n")
+    exe = os.path.join(BIN, "ivector-extract-online2")
+    r = subprocess.run([exe, "--config=ivector_extractor.conf", f"ark:{td}/spk2utt", f"ark:{td}/feats.ark", f"ark:{td}/iv.ark"], capture_output=True, text=True, cwd=IV); assert r.returncode == 0, r.stderr
+    assert "Did not find audio for utterance utt_missing" in r.stderr and "Estimated iVectors for 4 files, 1 with errors." in r.stderr
+    iv = kio.read_ark(f"{td}/iv.ark")
+    for u in utts: assert iv[u].shape == ref["iv_" + u].shape and np.abs(iv[u] - ref["iv_" + u]).max() <= 2e-5, (u, np.abs(iv[u] - ref["iv_" + u]).max())
+    open(f"{td}/spk2utt1", "w").write("".join(f"{u} {u}\n" for u in utts))
+    r = subprocess.run([exe, "--config=ivector_extractor.conf", "--repeat=true", "--max-batch-size=3", f"ark:{td}/spk2utt1", f"ark:{td}/feats.ark", f"ark:{td}/ivr.ark"], capture_output=True, text=True, cwd=IV); assert r.returncode == 0, r.stderr
+    ivr = kio.read_ark(f"{td}/ivr.ark")
+    for u in utts: assert ivr[u].shape == g["iv_repeat_" + u].shape and np.abs(ivr[u] - g["iv_repeat_" + u]).max() <= 2e-5
+    bad = subprocess.run([exe, "--config=ivector_extractor.conf", "--diag-ubm=nonexistent.dubm", f"ark:{td}/spk2utt1", f"ark:{td}/feats.ark", f"ark:{td}/x.ark"], capture_output=True, text=True, cwd=IV)
+    assert bad.returncode != 0 and "nonexistent.dubm" in bad.stderr
+    # ---- the network side
+    GOLD = os.path.join(ROOT, "tests", "golden"); n = np.load(os.path.join(GOLD, "nnet_ivector_io.npz")); mdl = os.path.join(GOLD, "nnet_ivector.raw")
+    kio.write_ark(f"{td}/f.ark", {"u": n["feats"]}); nc = os.path.join(BIN, "nnet3-compute")
+    for name, (s, chunk, period) in {"s3_c21_p7": (3, 21, 7), "s1_c20_p10_short": (1, 20, 10)}.items():
+        kio.write_ark(f"{td}/oiv.ark", {"u": n["iv_" + name]})
+        r = subprocess.run([nc, f"--frame-subsampling-factor={s}", f"--frames-per-chunk={chunk}", f"--online-ivectors=ark:{td}/oiv.ark", f"--online-ivector-period={period}", mdl, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = kio.read_ark(f"{td}/o.ark")["u"]; assert got.shape == n["ref_" + name].shape and np.abs(got - n["ref_" + name]).max() <= 1e-4
+    open(f"{td}/iv.txt", "w").write("spk  [ " + " ".join(repr(float(x)) for x in n["iv_s3_utt"]) + " ]\n"); open(f"{td}/utt2spk", "w").write("u spk\n")
+    r = subprocess.run([nc, "--frame-subsampling-factor=3", f"--ivectors=ark,t:{td}/iv.txt", f"--utt2spk=ark:{td}/utt2spk", mdl, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    got = kio.read_ark(f"{td}/o.ark")["u"]; assert np.abs(got - n["ref_s3_utt"]).max() <= 1e-4
+    r = subprocess.run([nc, mdl, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], capture_output=True, text=True)            # the model needs i-vectors: the reference's message
+    assert r.returncode != 0 and "Neural net expects 'ivector' features with dimension 12 but you provided 0" in r.stderr
+    kio.write_ark(f"{td}/oiv.ark", {"other": n["iv_s3_c21_p7"]})
+    r = subprocess.run([nc, f"--online-ivectors=ark:{td}/oiv.ark", "--online-ivector-period=7", mdl, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], capture_output=True, text=True)
+    assert r.returncode != 0 and "No iVector available for utterance u" in r.stderr

@@ -104,3 +104,23 @@ def test_argument_errors():
     ex = mk(left_context=1, right_context=1)
     x = torch.zeros((10, 8), device="cuda:0")
     with pytest.raises(K3Error): ex.GetIvectors(x, [0, 10, 10])                             # an utterance without frames
+
+
+def test_adaptation_state_carried_to_the_speakers_next_utterance(golden):
+    """spkA = utt0 utt1, spkB = utt2 utt3 (tests/golden/make_golden_ivector_adapt.py): the second utterance of a speaker starts from the CMVN and
+    i-vector statistics of the first, and its i-vectors are far (0.6) from the fresh-state ones"""
+    from kaldi_amd.ivector import OnlineIvectorExtractionInfo, BatchedIvectorExtractor
+    ref = np.load(os.path.join(DIR, "ivector_adapt_golden.npz"))
+    ex = BatchedIvectorExtractor(OnlineIvectorExtractionInfo("ivector_extractor.conf")); dev = torch.device("cuda:0")
+    first = [golden["feat_utt0"], golden["feat_utt2"]]; second = [golden["feat_utt1"], golden["feat_utt3"]]
+    x = torch.from_numpy(np.concatenate(first)).to(dev); fo = np.concatenate([[0], np.cumsum([f.shape[0] for f in first])])
+    iv1, ro1, stats = ex.GetIvectors(x, fo, return_stats=True)
+    cm = np.zeros((2, 2, 14))
+    for k, f in enumerate(first): cm[k, 0, :13] = f.astype(np.float64).sum(0); cm[k, 0, 13] = f.shape[0]; cm[k, 1, :13] = (f.astype(np.float64) ** 2).sum(0)
+    x2 = torch.from_numpy(np.concatenate(second)).to(dev); fo2 = np.concatenate([[0], np.cumsum([f.shape[0] for f in second])])
+    iv2, ro2 = ex.GetIvectors(x2, fo2, cmvn_speaker_stats=cm, stats_in=stats); torch.cuda.synchronize()
+    iv1, iv2 = iv1.cpu().numpy(), iv2.cpu().numpy(); worst = 0.0
+    for k, u in enumerate(("utt0", "utt2")): worst = max(worst, np.abs(iv1[ro1[k]:ro1[k + 1]] - ref["iv_" + u]).max())
+    for k, u in enumerate(("utt1", "utt3")): worst = max(worst, np.abs(iv2[ro2[k]:ro2[k + 1]] - ref["iv_" + u]).max())
+    print("max |gpu - reference binary| with adaptation state =", worst)
+    assert worst <= TOL, worst
