@@ -58,14 +58,15 @@ int main(int argc, char **argv) {
     po.Register("main-q-capacity", &main_q, "Max tokens alive on one frame of one utterance (-1 = 4 * max-active, capped)"); po.Register("aux-q-capacity", &aux_q, "Max arcs considered on one frame (-1 = 3 * main-q-capacity)");
     po.Register("ntokens-pre-allocated", &ntok_pre, "Tokens kept per utterance for all frames"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
     po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
-    po.Register("frames-per-chunk", &frames_per_chunk, "(accepted; utterances are evaluated whole, chunking does not change the outputs of a feed-forward model)");
+    po.Register("frames-per-chunk", &frames_per_chunk, "Number of frames in each chunk that is separately evaluated by the neural net (matters with i-vectors: one i-vector per chunk; without them chunking does not change the outputs of a feed-forward model and utterances are evaluated whole)");
     po.Register("extra-left-context", &elc, "(accepted; only 0 is supported)"); po.Register("extra-right-context", &erc, "(accepted; only 0 is supported)");
     po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)"); po.Register("debug-computation", &debug_comp, "(accepted, unused)");
     po.Register("feature-type", &feature_type, "Base feature type [mfcc, fbank]"); po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc.conf)");
     po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)"); po.Register("plp-config", &plp_config, "(PLP features are not supported)");
     po.Register("add-pitch", &add_pitch, "(pitch features are not supported)"); po.Register("online-pitch-config", &pitch_config, "(not supported)");
     po.Register("cmvn-config", &cmvn_config, "(online CMVN is not supported; chain recipes use --norm-means=false)"); po.Register("global-cmvn-stats", &global_cmvn, "(not supported)");
-    po.Register("ivector-extraction-config", &ivector_config, "(i-vector extraction is not supported)");
+    po.Register("ivector-extraction-config", &ivector_config, "Configuration file for online iVector extraction, see class OnlineIvectorExtractionConfig in the code.  The i-vectors are extracted on the GPU, one per --ivector-period frames, and every "
+                "--frames-per-chunk chunk of the network sees the one at its middle frame: the results of ivector-extract-online2 | nnet3-latgen-faster --online-ivectors (steps/online/nnet2/extract_ivectors_online.sh + steps/nnet3/decode.sh)");
     po.Register("literal-order", &literal_order, "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's, bit for bit (serial cutoff tightening in hash-list order reproduced on the GPU); false = the order-independent fast decoder");
     po.Register("hash-ratio", &hash_ratio, "LatticeFasterDecoderConfig::hash_ratio (it decides the reference's token visit order; used with --literal-order)");
     po.Register("rank", &rank, "(not in the reference) this process's rank in a multi-GPU job: it takes the utterances i with i % world-size == rank, uses GPU <rank> of the node unless LOCAL_RANK / --device says otherwise, and writes the lattice wspecifier with JOB replaced by rank + 1 (lat.JOB.gz of decode.sh).  Default: $RANK or 0");
@@ -77,8 +78,8 @@ int main(int argc, char **argv) {
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
-    if (segmentation || use_online || add_pitch || !ivector_config.empty() || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
-      K3H_ERR << "an option that needs a component outside the accelerated path was given (segmentation / online features / pitch / ivectors / PLP / CMVN / extra context)";
+    if (segmentation || use_online || add_pitch || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
+      K3H_ERR << "an option that needs a component outside the accelerated path was given (segmentation / online features / pitch / PLP / CMVN / extra context)";
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3); std::string out_wspec = po.GetArg(4);
     if (world_size < 1 || rank < 0 || rank >= world_size) K3H_ERR << "--rank=" << rank << " is not in [0, --world-size=" << world_size << ")";
     { int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev)); if (ndev < 1) K3H_ERR << "no HIP device";
@@ -101,6 +102,23 @@ int main(int argc, char **argv) {
     k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(nnet3_rx.c_str(), &nnet));
     k3_nnet_info ninfo; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ninfo));
     if (ninfo.input_dim != fdim) K3H_ERR << "Feature dimension " << fdim << " does not match the model's input dimension " << ninfo.input_dim;
+    // i-vector extractor (optional): OnlineNnet2FeaturePipelineInfo's ivector_extractor_info (online2/online-nnet2-feature-pipeline.cc:70-80)
+    k3_ivector *ivx = nullptr; IvectorExtractionInfo iv_info; int32_t iv_period = 0;
+    if (!ivector_config.empty()) {
+      iv_info = ReadIvectorExtractionConfig(ivector_config);
+      k3_ivector_model m; memset(&m, 0, sizeof m);
+      m.feat_dim = iv_info.global_cmvn_stats.cols - 1; m.lda_rows = iv_info.lda_rows; m.lda_cols = iv_info.lda_cols; m.num_gauss = iv_info.ubm.num_gauss; m.ivector_dim = iv_info.ie.ivector_dim;
+      m.lda = iv_info.lda.data(); m.global_cmvn_stats = iv_info.global_cmvn_stats.data.data(); m.gconsts = iv_info.ubm.gconsts.data(); m.means_invvars = iv_info.ubm.means_invvars.data(); m.inv_vars = iv_info.ubm.inv_vars.data();
+      m.M = iv_info.ie.M.data(); m.sigma_inv = iv_info.ie.sigma_inv.data(); m.prior_offset = iv_info.ie.prior_offset;
+      k3_ivector_opts o; k3_ivector_opts_default(&o);
+      o.left_context = iv_info.left_context; o.right_context = iv_info.right_context; o.num_gselect = iv_info.num_gselect; o.min_post = iv_info.min_post; o.posterior_scale = iv_info.posterior_scale; o.max_count = iv_info.max_count;
+      o.ivector_period = iv_info.ivector_period; o.num_cg_iters = iv_info.num_cg_iters; o.online_cmvn_iextractor = iv_info.online_cmvn_iextractor;
+      o.cmvn.cmn_window = iv_info.cmn_window; o.cmvn.speaker_frames = iv_info.speaker_frames; o.cmvn.global_frames = iv_info.global_frames; o.cmvn.normalize_mean = iv_info.normalize_mean; o.cmvn.normalize_variance = iv_info.normalize_variance;
+      if (m.feat_dim != fdim) K3H_ERR << "The i-vector extractor expects features of dimension " << m.feat_dim << " but the feature config gives " << fdim;
+      K3H_CHECK_K3(k3_ivector_create(&m, &o, &ivx)); iv_period = iv_info.ivector_period;
+    }
+    if ((ninfo.ivector_dim > 0) != (ivx != nullptr) || (ivx && ninfo.ivector_dim != iv_info.ie.ivector_dim))
+      K3H_ERR << "Neural net expects 'ivector' features with dimension " << ninfo.ivector_dim << " but you provided " << (ivx ? iv_info.ie.ivector_dim : 0);
     if (ninfo.output_dim != ti.num_pdfs) K3H_ERR << "Model output dimension " << ninfo.output_dim << " != number of pdfs in the transition model " << ti.num_pdfs;
     std::vector<float> log_priors;
     if (ninfo.has_priors) { log_priors.resize(ninfo.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet, log_priors.data())); for (float &p : log_priors) p = logf(p); }
@@ -194,7 +212,7 @@ int main(int argc, char **argv) {
     // the list of (iteration, first file, last file) batches
     std::vector<std::array<size_t, 3>> plan_batches;
     for (int iter = 0; iter < iterations; iter++) for (size_t b0 = 0; b0 < scp.size(); b0 += max_batch) plan_batches.push_back({(size_t)iter, b0, std::min(scp.size(), b0 + (size_t)max_batch)});
-    DevBuf<float> d_w, d_f, d_ll; DevBuf<int64_t> d_wo, d_fo;
+    DevBuf<float> d_w, d_f, d_ll, d_iv; DevBuf<int64_t> d_wo, d_fo;
     std::future<Batch> next; std::future<void> post;
     const auto t_start = std::chrono::steady_clock::now();
     if (!plan_batches.empty()) next = std::async(std::launch::async, load_batch, plan_batches[0][1], plan_batches[0][2], 0, (int)plan_batches[0][0]);
@@ -210,10 +228,19 @@ int main(int argc, char **argv) {
       HIPCHK(hipMemcpyAsync(d_w.need((size_t)nsamp), pinned[b.slot].p, (size_t)nsamp * sizeof(float), hipMemcpyHostToDevice, nullptr));
       d_wo.upload(b.woff); d_fo.upload(b.foff);
       K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w.p, d_wo.p, d_fo.p, U, tot, d_f.need((size_t)tot * fdim), fdim, nullptr));
-      k3_nnet_batch *nb = nullptr;
-      K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
-      std::vector<int64_t> ro(U + 1); const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
-      K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
+      k3_nnet_batch *nb = nullptr; std::vector<int64_t> ro(U + 1);
+      if (!ivx) {
+        K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
+        const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
+        K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
+      } else {
+        std::vector<int32_t> iv_rows(U); for (int u = 0; u < U; u++) iv_rows[u] = (b.nframes[u] + iv_period - 1) / iv_period;
+        const int64_t n_iv = k3_ivector_num_rows(ivx, U, b.foff.data(), nullptr);
+        K3H_CHECK_K3(k3_ivector_extract_batch(ivx, d_f.p, fdim, b.foff.data(), U, d_iv.need((size_t)n_iv * ninfo.ivector_dim), ninfo.ivector_dim, nullptr));
+        K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, frames_per_chunk, iv_period, iv_rows.data(), &nb));
+        const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
+        K3H_CHECK_K3(k3_nnet_forward_ivector(nb, d_f.p, fdim, d_iv.p, ninfo.ivector_dim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
+      }
       K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_ll.p, ninfo.output_dim, ro.data(), nullptr));
       auto r = std::make_shared<Raw>(); r->info.resize(10 * (size_t)U);
       K3H_LATTICE_INFO(dec, r->info.data());
@@ -240,7 +267,7 @@ int main(int argc, char **argv) {
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
     K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio * iterations << " RealTimeX: " << total_audio * iterations / total_time;
-    k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan);
+    k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan); if (ivx) k3_ivector_destroy(ivx);
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
 }

@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
                         "Usage: nnet3-latgen-faster [options] <nnet-in> <fst-in> <features-rspecifier> <lattice-wspecifier> [ <words-wspecifier> [<alignments-wspecifier>] ]\n"
                         "See also: nnet3-latgen-faster-parallel, nnet3-latgen-faster-batch\n";
     ParseOptions po(usage);
-    bool allow_partial = false, determinize = true, debug_comp = false, phone_det = true, word_det = true, minimize = false; std::string word_syms, use_gpu = "yes", ivector_rspecifier, online_ivector_rspecifier, utt2spk;
+    bool allow_partial = false, determinize = true, debug_comp = false, literal_order = true, phone_det = true, word_det = true, minimize = false; std::string word_syms, use_gpu = "yes", ivector_rspecifier, online_ivector_rspecifier, utt2spk;
     int32_t subsampling = 1, frames_per_chunk = 50, elc = 0, erc = 0, elci = -1, ercf = -1, online_ivector_period = 0, max_batch = 256, max_active = 2147483647, min_active = 200, prune_interval = 25, max_mem = 50000000, frame_tokens_cap = 65536, lane_tokens_cap = 4000000, lane_links_cap = 8000000;
     float beam = 16.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, hash_ratio = 2.0f, prune_scale = 0.1f, delta = 0.000976562f;
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)"); po.Register("allow-partial", &allow_partial, "If true, produce output even if end state was not reached.");
@@ -28,7 +28,8 @@ int main(int argc, char **argv) {
     po.Register("min-active", &min_active, "Decoder minimum #active states."); po.Register("lattice-beam", &lattice_beam, "Lattice generation beam.  Larger->slower, and deeper lattices");
     po.Register("prune-interval", &prune_interval, "(accepted; pruning runs once after the last frame and gives the same lattice)"); po.Register("determinize-lattice", &determinize, "If true, determinize the lattice (lattice-determinization, keeping only best pdf-sequence for each word-sequence).");
     po.Register("beam-delta", &beam_delta, "Increment used in decoding-- this parameter is obscure and relates to a speedup in the way the max-active constraint is applied.");
-    po.Register("hash-ratio", &hash_ratio, "(accepted, unused: no hash-order dependence)"); po.Register("prune-scale", &prune_scale, "(accepted, unused)");
+    po.Register("hash-ratio", &hash_ratio, "Setting used in decoder to control hash behavior (it decides the token visit order, hence which tokens the running cutoff keeps; honoured with --literal-order)");
+    po.Register("literal-order", &literal_order, "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's, bit for bit; false = the order-independent fast decoder"); po.Register("prune-scale", &prune_scale, "(accepted, unused)");
     po.Register("max-mem", &max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this)."); po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)");
     po.Register("word-determinize", &word_det, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization."); po.Register("delta", &delta, "Tolerance used in determinization");
@@ -61,6 +62,7 @@ int main(int argc, char **argv) {
     k3_decoder_config dc; k3_decoder_config_default(&dc);
     dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(min_active, max_active - 1); dc.beam_delta = beam_delta;
     dc.frame_tokens_cap = frame_tokens_cap; dc.frame_cands_cap = 4 * frame_tokens_cap; dc.lane_tokens_cap = lane_tokens_cap; dc.lane_links_cap = lane_links_cap;
+    dc.literal_order = literal_order ? 1 : 0; dc.hash_ratio = hash_ratio; if (literal_order) dc.frame_tokens_cap = std::min(dc.frame_tokens_cap, 65536);
     k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, max_batch, ni.output_dim, &dec));
     auto feats = ReadMatrixTable(po.GetArg(3)); TableWriter lat_writer(po.GetArg(4));
     std::unique_ptr<TableWriter> words_writer, ali_writer;

@@ -316,3 +316,43 @@ def test_ivector_extract_online2_and_nnet3_compute_with_ivectors(tmp_path):
     kio.write_ark(f"{td}/oiv.ark", {"other": n["iv_s3_c21_p7"]})
     r = subprocess.run([nc, f"--online-ivectors=ark:{td}/oiv.ark", "--online-ivector-period=7", mdl, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], capture_output=True, text=True)
     assert r.returncode != 0 and "No iVector available for utterance u" in r.stderr
+
+
+def test_batched_wav_nnet3_cuda2_with_ivector_extraction(tmp_path):
+    """wav -> fbank -> i-vectors (GPU, one per 10 frames) -> TDNN-F with the i-vector input, chunk by chunk -> lattices, in ONE program, against the chain of
+    separate programs the recipes run: compute-fbank-feats | ivector-extract-online2 | nnet3-latgen-faster --online-ivectors (same best path, same lattice)"""
+    from oracle import kaldi_io as kio
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001, 4000]; IV = os.path.join(ROOT, "tests", "golden", "ivector")
+    _wavs(td, lens); open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    r = subprocess.run([os.path.join(BIN, "compute-fbank-feats-cuda"), f"--config={td}/fbank.conf", f"scp:{td}/wav.scp", f"ark:{td}/f.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    feats = kio.read_ark(f"{td}/f.ark"); allf = np.concatenate(list(feats.values())).astype(np.float64); rng = np.random.default_rng(8)
+    # the fixture's UBM and extractor live in the 20-dim LDA space; only the LDA matrix and the CMVN statistics see the 40-dim features
+    tm = lambda path, m: open(path, "w").write(" [\n" + "\n".join("  " + " ".join(repr(float(x)) for x in row) for row in m) + " ]\n")
+    st = np.zeros((2, 41)); st[0, :40] = allf.sum(0); st[1, :40] = (allf ** 2).sum(0); st[0, 40] = allf.shape[0]; tm(f"{td}/global_cmvn.stats", st)
+    tm(f"{td}/final.mat", (rng.standard_normal((20, 7 * 40)) * 1.5 / np.sqrt(7 * 40)).astype(np.float32))
+    open(f"{td}/splice.conf", "w").write("--left-context=3\n--right-context=3\n"); open(f"{td}/cmvn.conf", "w").write("\n")
+    open(f"{td}/ivector.conf", "w").write(f"--lda-matrix={td}/final.mat\n--global-cmvn-stats={td}/global_cmvn.stats\n--cmvn-config={td}/cmvn.conf\n--splice-config={td}/splice.conf\n--diag-ubm={IV}/final.dubm\n"
+                                          f"--ivector-extractor={IV}/final.ie\n--num-gselect=5\n--min-post=0.025\n--posterior-scale=0.1\n--max-count=100\n--ivector-period=10\n")
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=feats["utt0"], out_std=1.5, ivector_dim=16)
+    net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
+    common = ["--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--frames-per-chunk=51", "--determinize-lattice=false"]
+    r = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", f"--ivector-extraction-config={td}/ivector.conf", "--max-batch-size=3", "--write-compact=false"] + common +
+                       [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/lat.txt"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Decoded 4 utterances, 0 with errors." in r.stderr
+    # the chain of separate programs
+    open(f"{td}/spk2utt", "w").write("".join(f"{k} {k}\n" for k in feats))
+    r = subprocess.run([os.path.join(BIN, "ivector-extract-online2"), f"--config={td}/ivector.conf", f"ark:{td}/spk2utt", f"ark:{td}/f.ark", f"ark:{td}/iv.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    iv = kio.read_ark(f"{td}/iv.ark"); assert all(iv[k].shape == ((feats[k].shape[0] + 9) // 10, 16) for k in feats) and max(np.abs(v).max() for v in iv.values()) > 0.05
+    r = subprocess.run([os.path.join(BIN, "nnet3-latgen-faster")] + common + [f"--online-ivectors=ark:{td}/iv.ark", "--online-ivector-period=10", f"{td}/final.mdl", f"{td}/HCLG.fst", f"ark:{td}/f.ark", f"ark,t:{td}/lat2.txt",
+                        f"ark,t:{td}/words2.txt", f"ark,t:{td}/ali2.txt"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    a, b = _parse_text_lattices(f"{td}/lat.txt"), _parse_text_lattices(f"{td}/lat2.txt"); assert list(a) == list(b) == list(feats)
+    for k in a:      # the same raw lattices (state numbers depend on the order the GPU appended the arcs in: compare the arcs as (labels, costs) multisets)
+        assert sorted(x[2:] for x in a[k][0]) == sorted(x[2:] for x in b[k][0]) and len(a[k][0]) > 10 and sorted(a[k][1].values()) == sorted(b[k][1].values()), k
+    r = subprocess.run([os.path.join(BIN, "lattice-best-path"), "--acoustic-scale=1.0", f"ark,t:{td}/lat.txt", f"ark,t:{td}/words.txt", f"ark,t:{td}/ali.txt"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    assert open(f"{td}/words.txt").read() == open(f"{td}/words2.txt").read() and open(f"{td}/ali.txt").read() == open(f"{td}/ali2.txt").read()
+    # without the extractor the model cannot run: the reference's message
+    r = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf"] + common + [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/x.ark"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Neural net expects 'ivector' features with dimension 16 but you provided 0" in r.stderr
