@@ -30,13 +30,14 @@
 
 namespace {
 
-constexpr int kNfft = 512;            // padded window size supported by this kernel
-constexpr int kNc = 256;              // complex FFT length
+// The kernel is instantiated for padded window sizes N = 32 R, R = 8 / 16 / 32 (256, 512, 1024 samples: 8 kHz, 16 kHz and 32..44.1 kHz speech at
+// 25 ms): the complex FFT of length NC = 16 R is a Cooley-Tukey R x 16 (a lane holds R points, 16 lanes hold a frame).
 constexpr int kFramesPerIter = 16;    // 4 waves x 4 frames
 constexpr int kThreads = 256;
 constexpr int kTpad = 17;             // transpose tile row stride (float2 units)
-constexpr int kFrameBufBytes = 16 * kTpad * 8;  // 2176 B per frame: transpose tile / X / (P | logmel)
-constexpr int kLogMelOff = 1040;      // byte offset of the log-mel vector inside the frame buffer
+__host__ __device__ constexpr int frame_buf_bytes(int R) { return R * kTpad * 8; }                       // R = 16: 2176 B per frame: transpose tile / X / (P | logmel)
+__host__ __device__ constexpr int logmel_off(int R) { return ((16 * R + 1) * 4 + 15) / 16 * 16; }        // byte offset of the log-mel vector inside the frame buffer (R = 16: 1040)
+__host__ __device__ constexpr int lds_fixed_bytes(int R) { return 16 * R * 8 + ((8 * R + 1) * 8 + 15) / 16 * 16 + 32 * R * 4; }   // twiddles NC, twiddles N (N/4 + 1), window (R = 16: 5136)
 
 struct FeatParams {
   int win_len, win_shift, snip_edges, remove_dc, use_energy, raw_energy, htk_compat, use_log, use_power,
@@ -44,8 +45,8 @@ struct FeatParams {
   float preemph, log_energy_floor;
   float dither; unsigned dither_seed;   // Dither (feat/feature-window.cc:90-98): x[i] += RandGauss() * dither, independently per frame
   const float *window;      // [win_len]
-  const float2 *tw256;      // [256] exp(-2 pi i m / 256)
-  const float2 *tw512;      // [129] exp(-2 pi i k / 512), k = 0..128, built by the reference's recurrence
+  const float2 *tw256;      // [NC] exp(-2 pi i m / NC)
+  const float2 *tw512;      // [N/4 + 1] exp(-2 pi i k / N), k = 0..N/4, built by the reference's recurrence
   const int *bin_meta;      // [3 * num_bins]: first fft bin, length, offset into bin_w
   const float *bin_w;       // [total_w]
   const float *dct;         // [num_ceps x num_bins] (mfcc)
@@ -85,32 +86,70 @@ __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 }
 __host__ __device__ constexpr int fft16_slot(int k) { return 4 * (k & 3) + (k >> 2); }
 
+// forward R-point DFT in registers, R = 8 / 16 / 32; X[k] sits at v[FftR<R>::slot(k)]
+template <int R> struct FftR;
+template <> struct FftR<16> {
+  static __device__ __forceinline__ void run(float2 (&v)[16]) { fft16(v); }
+  static __host__ __device__ constexpr int slot(int k) { return fft16_slot(k); }
+};
+template <> struct FftR<8> {      // two 4-point DFTs (even / odd samples) + one radix-2 stage
+  static __device__ __forceinline__ void run(float2 (&v)[8]) {
+    constexpr float r2 = 0.70710678118654752440f;
+    fft4(v[0], v[2], v[4], v[6]); fft4(v[1], v[3], v[5], v[7]);
+    const float2 o1 = cmul(v[3], make_float2(r2, -r2)), o2 = make_float2(v[5].y, -v[5].x), o3 = cmul(v[7], make_float2(-r2, -r2)), o0 = v[1];
+    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0); v[1] = cadd(e1, o1); v[5] = csub(e1, o1); v[2] = cadd(e2, o2); v[6] = csub(e2, o2); v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+  }
+  static __host__ __device__ constexpr int slot(int k) { return k; }
+};
+template <> struct FftR<32> {     // two 16-point DFTs (even / odd samples) + one radix-2 stage
+  static __device__ __forceinline__ void run(float2 (&v)[32]) {
+    constexpr float c[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128673848f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508978178f,
+                             0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508978178f, -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                             -0.92387953251128673848f, -0.98078528040323044913f};
+    constexpr float sn[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508978178f, 0.55557023301960222474f, 0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128673848f,
+                              0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128673848f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                              0.38268343236508978178f, 0.19509032201612826785f};
+    float2 e[16], o[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    fft16(e); fft16(o);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const float2 ek = e[fft16_slot(k)], ok = k == 0 ? o[fft16_slot(0)] : cmul(o[fft16_slot(k)], make_float2(c[k], -sn[k]));
+      v[k] = cadd(ek, ok); v[k + 16] = csub(ek, ok);
+    }
+  }
+  static __host__ __device__ constexpr int slot(int k) { return k; }
+};
+
 __device__ __forceinline__ float group_sum16(float x) {
   x += __shfl_xor(x, 8, 16); x += __shfl_xor(x, 4, 16); x += __shfl_xor(x, 2, 16); x += __shfl_xor(x, 1, 16);
   return x;
 }
 
 // TS = float (CuVector<BaseFloat> waves, the reference's interface) or int16_t (PCM16 as it sits in a wav file: 2 of the 480 B / frame of SURVEY 8d)
-template <typename TS>
+template <typename TS, int R>
 __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const TS *__restrict__ waves,
                                                           const int64_t *__restrict__ wave_off,
                                                           const int64_t *__restrict__ frame_off, int num_utts,
                                                           int64_t total_frames, float *__restrict__ feats, int64_t ld,
                                                           int frames_per_block) {
+  constexpr int kNc = 16 * R, kNfft = 32 * R, kFrameBufBytes = frame_buf_bytes(R), kLogMelOff = logmel_off(R), kTwN = ((8 * R + 1) * 8 + 15) / 16 * 16, kFixed = lds_fixed_bytes(R);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS carve (all offsets multiples of 16)
-  float2 *s_tw256 = reinterpret_cast<float2 *>(smem);                 // 2048 B
-  float2 *s_tw512 = reinterpret_cast<float2 *>(smem + 2048);          // 129*8 = 1032 -> 1040 B
-  float *s_window = reinterpret_cast<float *>(smem + 2048 + 1040);    // 512*4 = 2048 B
-  int *s_meta = reinterpret_cast<int *>(smem + 2048 + 1040 + 2048);   // 3*num_bins ints, padded to 16
+  float2 *s_tw256 = reinterpret_cast<float2 *>(smem);                 // NC * 8 B (R = 16: 2048)
+  float2 *s_tw512 = reinterpret_cast<float2 *>(smem + kNc * 8);       // (N/4 + 1) * 8 -> 16-aligned (1040)
+  float *s_window = reinterpret_cast<float *>(smem + kNc * 8 + kTwN); // N * 4 B (2048)
+  int *s_meta = reinterpret_cast<int *>(smem + kFixed);               // 3*num_bins ints, padded to 16
   const int meta_bytes = ((3 * p.num_bins * 4 + 15) / 16) * 16;
-  float *s_binw = reinterpret_cast<float *>(smem + 5136 + meta_bytes);
+  float *s_binw = reinterpret_cast<float *>(smem + kFixed + meta_bytes);
   const int binw_bytes = ((p.total_w * 4 + 15) / 16) * 16;
-  char *s_frames = smem + 5136 + meta_bytes + binw_bytes;             // 16 frame buffers
+  char *s_frames = smem + kFixed + meta_bytes + binw_bytes;           // 16 frame buffers
 
   const int tid = threadIdx.x;
-  for (int i = tid; i < 256; i += kThreads) s_tw256[i] = p.tw256[i];
-  for (int i = tid; i < 129; i += kThreads) s_tw512[i] = p.tw512[i];
+  for (int i = tid; i < kNc; i += kThreads) s_tw256[i] = p.tw256[i];
+  for (int i = tid; i < kNc / 2 + 1; i += kThreads) s_tw512[i] = p.tw512[i];
   for (int i = tid; i < kNfft; i += kThreads) s_window[i] = (i < p.win_len) ? p.window[i] : 0.0f;
   for (int i = tid; i < 3 * p.num_bins; i += kThreads) s_meta[i] = p.bin_meta[i];
   for (int i = tid; i < p.total_w; i += kThreads) s_binw[i] = p.bin_w[i];
@@ -129,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
   for (int it = 0; it < frames_per_block; it += kFramesPerIter) {
     const int64_t g = block_first + it + fslot;
     const bool valid = g < total_frames;
-    float x0[16], x1[16];
+    float x0[R], x1[R];
     int64_t n = 0, start = 0;
     const TS *base = waves;
     if (valid) {
@@ -144,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
     }
     const bool interior = valid && start >= 0 && start + L <= n;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < R; j++) {
       const int s = 2 * (l + 16 * j);
       float a = 0.0f, b = 0.0f;
       if (interior) {
@@ -159,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
     // ---- ProcessWindow ----
     if (p.dither != 0.0f && valid) {     // counter-based generator (frame, sample pair, seed) -> Box-Muller pair; not the reference's rand() stream
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < R; j++) {
         const int s = 2 * (l + 16 * j);
         unsigned long long z = ((unsigned long long)g * 1024ull + (unsigned)(s >> 1)) * 0x9E3779B97F4A7C15ull + ((unsigned long long)p.dither_seed << 32 | 0x7F4A7C15u);
         z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;          // splitmix64 finaliser
@@ -172,11 +211,11 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
     if (p.remove_dc) {
       float sum = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 16; j++) sum += x0[j] + x1[j];
+      for (int j = 0; j < R; j++) sum += x0[j] + x1[j];
       sum = group_sum16(sum);
       const float m = -sum / (float)L;
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < R; j++) {
         const int s = 2 * (l + 16 * j);
         if (s < L) x0[j] += m;
         if (s + 1 < L) x1[j] += m;
@@ -186,16 +225,16 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
     if (p.use_energy && p.raw_energy) {
       float e = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 16; j++) e += x0[j] * x0[j] + x1[j] * x1[j];
+      for (int j = 0; j < R; j++) e += x0[j] * x0[j] + x1[j] * x1[j];
       e = group_sum16(e);
       log_energy = logf(fmaxf(e, eps));
     }
-    float2 v[16];
+    float2 v[R];
     {
       const float c = p.preemph;
       float prev_hi = 0.0f;  // lane 15's x1[j-1]
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
+      for (int j = 0; j < R; j++) {
         const int s = 2 * (l + 16 * j);
         float up = __shfl_up(x1[j], 1, 16);
         float prev0 = (l > 0) ? up : ((j > 0) ? prev_hi : x0[0]);
@@ -213,38 +252,53 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
     if (p.use_energy && !p.raw_energy) {
       float e = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 16; j++) e += v[j].x * v[j].x + v[j].y * v[j].y;
+      for (int j = 0; j < R; j++) e += v[j].x * v[j].x + v[j].y * v[j].y;
       e = group_sum16(e);
       log_energy = logf(fmaxf(e, eps));
     }
-    // ---- 256-point complex FFT, pass 1 (over j), twiddle, transpose ----
-    fft16(v);
+    // ---- NC-point complex FFT, NC = R x 16.  Pass 1: a lane's R points (n = l + 16 j) -> Y[l][k2]; twiddle W_NC^(l k2); transpose;
+    //      pass 2: for every k2 a 16-point DFT over l -> X[k2 + R k1] ----
+    FftR<R>::run(v);
 #pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) {
-      float2 y = v[fft16_slot(k2)];
-      if (k2 > 0) y = cmul(y, s_tw256[(l * k2) & 255]);
+    for (int k2 = 0; k2 < R; k2++) {
+      float2 y = v[FftR<R>::slot(k2)];
+      if (k2 > 0) y = cmul(y, s_tw256[(l * k2) & (kNc - 1)]);
       T[k2 * kTpad + l] = y;
     }
     __syncthreads();
+    constexpr int kPer = (R + 15) / 16;          // k2 values a lane transforms in pass 2 (R = 8: lanes 8..15 idle)
+    float2 u[kPer][16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = T[l * kTpad + i];
-    fft16(v);   // now X[l + 16*k1] = v[slot(k1)]
+    for (int q = 0; q < kPer; q++) {
+      const int k2 = l + 16 * q;
+      if (k2 < R) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) u[q][i] = T[k2 * kTpad + i];
+        fft16(u[q]);   // now X[k2 + R*k1] = u[q][slot(k1)]
+      }
+    }
     __syncthreads();
 #pragma unroll
-    for (int k1 = 0; k1 < 16; k1++) T[l + 16 * k1] = v[fft16_slot(k1)];
+    for (int q = 0; q < kPer; q++) {
+      const int k2 = l + 16 * q;
+      if (k2 < R) {
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) T[k2 + R * k1] = u[q][fft16_slot(k1)];
+      }
+    }
     __syncthreads();
     // ---- real-FFT unpacking (srfft.cc:372-405) + power spectrum ----
-    float2 Bk[8], Bm[8];
+    float2 Bk[R / 2], Bm[R / 2];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < R / 2; i++) {
       const int k = l + 16 * i;
       Bk[i] = T[k];
-      Bm[i] = T[(kNc - k) & 255];
+      Bm[i] = T[(kNc - k) & (kNc - 1)];
     }
-    const float2 B128 = T[128];
+    const float2 B128 = T[kNc / 2];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < R / 2; i++) {
       const int k = l + 16 * i;
       if (k == 0) {
         const float a0 = Bk[0].x + Bk[0].y, an = Bk[0].x - Bk[0].y;
@@ -262,13 +316,13 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
         P[k] = pk; P[kNc - k] = pm;
       }
     }
-    if (l == 0) {  // k = N/4 = 128 (kdash == k)
-      const float2 w = s_tw512[128];
+    if (l == 0) {  // k = N/4 (kdash == k)
+      const float2 w = s_tw512[kNc / 2];
       const float Cr = B128.x, Ci = 0.0f, Dr = B128.y, Di = 0.0f;
       const float Ar = Cr + (Dr * w.x - Di * w.y), Ai = Ci + (Dr * w.y + Di * w.x);
       float pk = Ar * Ar + Ai * Ai;
       if (!p.use_power) pk = sqrtf(pk);
-      P[128] = pk;
+      P[kNc / 2] = pk;
     }
     __syncthreads();
     // ---- mel filterbank: MelBanks::Compute ----
@@ -498,11 +552,12 @@ extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out)
   int padded = L;
   if (o.round_to_power_of_two) { padded = 1; while (padded < L) padded <<= 1; }
   K3_REQUIRE(L > 1 && shift > 0, "k3_feat_plan_create: bad frame length/shift");
-  if (padded != kNfft) {
-    k3::set_error("k3_feat_plan_create: padded window size %d unsupported (this build handles %d, i.e. "
-                  "frame lengths of 257..512 samples with --round-to-power-of-two=true)", padded, kNfft);
+  if (padded != 256 && padded != 512 && padded != 1024) {
+    k3::set_error("k3_feat_plan_create: padded window size %d unsupported (this build handles 256, 512 and 1024, i.e. "
+                  "frame lengths of 129..1024 samples with --round-to-power-of-two=true)", padded);
     return K3_ERR_UNSUPPORTED;
   }
+  const int R = padded / 32, NC = padded / 2;
   // dither != 0 is supported with a counter-based generator (statistically like the reference's RandGauss, not the same stream:
   // parity runs use --dither=0)
   K3_REQUIRE(o.num_bins >= 3 && o.num_bins <= 128, "k3_feat_plan_create: need 3 <= num_bins <= 128");
@@ -565,14 +620,14 @@ extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out)
     if (o.htk_mode && bin == 0 && mlow != 0.0f) binw[meta[2]] = 0.0f;
   }
   // twiddles
-  std::vector<float> tw256(512), tw512(2 * 129);
-  for (int m = 0; m < 256; m++) { const double ang = -6.283185307179586476925286766559005 * m / 256.0; tw256[2 * m] = cos(ang); tw256[2 * m + 1] = sin(ang); }
+  std::vector<float> tw256(2 * (size_t)NC), tw512(2 * ((size_t)NC / 2 + 1));
+  for (int m = 0; m < NC; m++) { const double ang = -6.283185307179586476925286766559005 * m / (double)NC; tw256[2 * m] = cos(ang); tw256[2 * m + 1] = sin(ang); }
   {  // srfft.cc:370-376: kN built by repeated float complex multiplication by exp(-2 pi i / N)
     const float ang = (float)(6.283185307179586476925286766559005 / padded * -1);
     const float rr = cosf(ang), ri = sinf(ang);
     float kr = 1.0f, ki = 0.0f;
     tw512[0] = 1.0f; tw512[1] = 0.0f;
-    for (int k = 1; k <= 128; k++) { const float t = kr * rr - ki * ri; ki = kr * ri + ki * rr; kr = t; tw512[2 * k] = kr; tw512[2 * k + 1] = ki; }
+    for (int k = 1; k <= NC / 2; k++) { const float t = kr * rr - ki * ri; ki = kr * ri + ki * rr; kr = t; tw512[2 * k] = kr; tw512[2 * k + 1] = ki; }
   }
   // MFCC tables
   std::vector<float> dct, lifter;
@@ -618,8 +673,8 @@ extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out)
   p.bin_meta = (const int *)(b + off_meta); p.bin_w = (const float *)(b + off_binw);
   p.dct = (const float *)(b + off_dct); p.lifter = (const float *)(b + off_lift);
   const size_t meta_bytes = ((3 * nb * 4 + 15) / 16) * 16, binw_bytes = ((binw.size() * 4 + 15) / 16) * 16;
-  pl->lds_bytes = 5136 + meta_bytes + binw_bytes + (size_t)kFramesPerIter * kFrameBufBytes;
-  if ((size_t)kLogMelOff + nb * 4 > (size_t)kFrameBufBytes) { delete pl; hipFree(blob); return k3::fail(K3_ERR_UNSUPPORTED, "num_bins too large for the LDS frame buffer", __FILE__, __LINE__); }
+  pl->lds_bytes = lds_fixed_bytes(R) + meta_bytes + binw_bytes + (size_t)kFramesPerIter * frame_buf_bytes(R);
+  if ((size_t)logmel_off(R) + nb * 4 > (size_t)frame_buf_bytes(R)) { delete pl; hipFree(blob); return k3::fail(K3_ERR_UNSUPPORTED, "num_bins too large for the LDS frame buffer", __FILE__, __LINE__); }
   *out = pl;
   return K3_OK;
 }
@@ -649,10 +704,17 @@ static int feat_launch(k3_feat_plan *plan, const TS *d_waves, const int64_t *d_w
   const int64_t blocks = (total_frames + frames_per_block - 1) / frames_per_block;
   K3_REQUIRE(blocks < (1ll << 31), "k3_feat_compute_batch: too many frames for one launch");
   static std::once_flag once; int rc = K3_OK;
-  std::call_once(once, [&]() { rc = [&]() -> int { K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_feat_kernel<TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return K3_OK; }(); });
+  std::call_once(once, [&]() { rc = [&]() -> int {
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_feat_kernel<TS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_feat_kernel<TS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_feat_kernel<TS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return K3_OK; }(); });
   if (rc) return rc;
-  hipLaunchKernelGGL(k3_feat_kernel<TS>, dim3((unsigned)blocks), dim3(kThreads), plan->lds_bytes, (hipStream_t)stream, plan->prm,
-                     d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block);
+  const dim3 grid((unsigned)blocks), block(kThreads); hipStream_t st = (hipStream_t)stream;
+  switch (plan->padded) {      // one instantiation per padded window size
+    case 256: hipLaunchKernelGGL((k3_feat_kernel<TS, 8>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block); break;
+    case 512: hipLaunchKernelGGL((k3_feat_kernel<TS, 16>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block); break;
+    default: hipLaunchKernelGGL((k3_feat_kernel<TS, 32>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block); break;
+  }
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }

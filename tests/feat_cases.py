@@ -32,3 +32,12 @@ REF_CASES = {
     "fbank_syn40": ("fbank", dict(dither=0.0, num_bins=40), "syn_wav"),
     "mfcc_syn_hires": ("mfcc", dict(dither=0.0, num_bins=40, num_ceps=40, low_freq=20.0, high_freq=-400.0, use_energy=0), "syn_wav"),
 }
+# windows that pad to 256 / 1024 samples (tests/golden/make_golden_feat_fftsizes.py): name -> (kind, opts, sample rate, samples, seed)
+FFTSIZE_CASES = {
+    "fbank_8k": ("fbank", dict(dither=0.0, samp_freq=8000.0, num_bins=23), 8000, 11000, 41),
+    "mfcc_8k": ("mfcc", dict(dither=0.0, samp_freq=8000.0), 8000, 9001, 42),
+    "mfcc_8k_nosnip": ("mfcc", dict(dither=0.0, samp_freq=8000.0, snip_edges=0, use_energy=0, low_freq=40.0, high_freq=-200.0), 8000, 7333, 43),
+    "fbank_32k": ("fbank", dict(dither=0.0, samp_freq=32000.0, num_bins=40), 32000, 40000, 44),
+    "fbank_16k_50ms": ("fbank", dict(dither=0.0, frame_length_ms=50.0, num_bins=40, use_energy=1), 16000, 20000, 45),
+    "mfcc_16k_40ms_hires": ("mfcc", dict(dither=0.0, frame_length_ms=40.0, frame_shift_ms=15.0, num_bins=40, num_ceps=40, low_freq=20.0, high_freq=-400.0, use_energy=0), 16000, 24000, 46),
+}

@@ -163,3 +163,25 @@ def test_pcm16_input_gives_the_same_bits_as_float_input():
         a = sf.ComputeFeatures(torch.from_numpy(np.concatenate(pcm).astype(np.float32)).to(dev), wo, fo, total)
         b = sf.ComputeFeatures(torch.from_numpy(np.concatenate(pcm)).to(dev), wo, fo, total)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", sorted(fc.FFTSIZE_CASES))
+def test_hip_on_256_and_1024_point_windows_vs_reference_binary(name):
+    """the FFT sizes next to 16 kHz / 25 ms's 512: 8 kHz telephone speech (256) and 32 kHz or long windows (1024), against the REFERENCE binaries' output"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feat_fftsizes_golden.npz"))
+    kind, kw, rate, nsamp, seed = fc.FFTSIZE_CASES[name]
+    wav = g["wav_" + name].astype(np.float32)
+    got = _gpu_feats([wav, wav[: len(wav) // 2]], _opts(kind, kw)); ref = g["ref_" + name]
+    assert got[0].shape == ref.shape
+    tol = 1e-4 if kind == "fbank" else 3e-4
+    assert np.abs(got[0] - ref).max() <= tol, np.abs(got[0] - ref).max()
+    # against the oracle on the second, shorter utterance of the batch
+    from oracle import feat_oracle as fo
+    want = fo.compute_features(wav[: len(wav) // 2], fo.mfcc_opts(**kw) if kind == "mfcc" else fo.fbank_opts(**kw))
+    assert got[1].shape == want.shape and np.abs(got[1] - want).max() <= tol
+
+
+def test_unsupported_window_size_is_refused():
+    from kaldi_amd import feat, lib
+    with pytest.raises(lib.K3Error, match="padded window size 2048"): feat.SpectralFeatures(feat.fbank_options(samp_freq=44100.0))      # 1102 samples -> 2048
+    with pytest.raises(lib.K3Error, match="padded window size 400"): feat.SpectralFeatures(feat.fbank_options(round_to_power_of_two=0))

@@ -105,3 +105,15 @@ def test_random_option_sets_against_the_reference_binaries(tmp_path):
         assert np.abs(mine[fin] - ref[fin]).max() <= 3e-5 * max(1.0, np.abs(ref[fin]).max()), (kind, kw, np.abs(mine[fin] - ref[fin]).max())
         checked += 1
     assert checked >= 10
+
+
+@pytest.mark.parametrize("name", sorted(fc.FFTSIZE_CASES))
+def test_oracle_vs_reference_binary_on_256_and_1024_point_windows(name):
+    """8 kHz / 25 ms (256-sample padded window), 32 kHz / 25 ms and 16 kHz / 40-50 ms (1024): tests/golden/make_golden_feat_fftsizes.py"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feat_fftsizes_golden.npz"))
+    kind, kw, rate, nsamp, seed = fc.FFTSIZE_CASES[name]
+    got = fo.compute_features(g["wav_" + name].astype(np.float32), _mk(kind, kw)); ref = g["ref_" + name]
+    assert got.shape == ref.shape
+    tol = 5e-5 if kind == "fbank" else 2e-4
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
