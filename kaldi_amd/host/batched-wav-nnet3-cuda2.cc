@@ -213,6 +213,7 @@ int main(int argc, char **argv) {
     std::vector<std::array<size_t, 3>> plan_batches;
     for (int iter = 0; iter < iterations; iter++) for (size_t b0 = 0; b0 < scp.size(); b0 += max_batch) plan_batches.push_back({(size_t)iter, b0, std::min(scp.size(), b0 + (size_t)max_batch)});
     DevBuf<float> d_w, d_f, d_ll, d_iv; DevBuf<int64_t> d_wo, d_fo;
+    std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache;
     std::future<Batch> next; std::future<void> post;
     const auto t_start = std::chrono::steady_clock::now();
     if (!plan_batches.empty()) next = std::async(std::launch::async, load_batch, plan_batches[0][1], plan_batches[0][2], 0, (int)plan_batches[0][0]);
@@ -228,16 +229,20 @@ int main(int argc, char **argv) {
       HIPCHK(hipMemcpyAsync(d_w.need((size_t)nsamp), pinned[b.slot].p, (size_t)nsamp * sizeof(float), hipMemcpyHostToDevice, nullptr));
       d_wo.upload(b.woff); d_fo.upload(b.foff);
       K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w.p, d_wo.p, d_fo.p, U, tot, d_f.need((size_t)tot * fdim), fdim, nullptr));
+      // the network plan of a batch (row bookkeeping, tile tables, activation workspace in HBM) depends only on the utterances' frame counts: kept for
+      // the batches that come back (--iterations, equal-length test sets) instead of being rebuilt per batch
       k3_nnet_batch *nb = nullptr; std::vector<int64_t> ro(U + 1);
+      for (auto &c : plan_cache) if (c.first == b.nframes) { nb = c.second; break; }
+      const bool cached = nb != nullptr;
       if (!ivx) {
-        K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
+        if (!cached) K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
         const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
         K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
       } else {
         std::vector<int32_t> iv_rows(U); for (int u = 0; u < U; u++) iv_rows[u] = (b.nframes[u] + iv_period - 1) / iv_period;
         const int64_t n_iv = k3_ivector_num_rows(ivx, U, b.foff.data(), nullptr);
         K3H_CHECK_K3(k3_ivector_extract_batch(ivx, d_f.p, fdim, b.foff.data(), U, d_iv.need((size_t)n_iv * ninfo.ivector_dim), ninfo.ivector_dim, nullptr));
-        K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, frames_per_chunk, iv_period, iv_rows.data(), &nb));
+        if (!cached) K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, frames_per_chunk, iv_period, iv_rows.data(), &nb));
         const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
         K3H_CHECK_K3(k3_nnet_forward_ivector(nb, d_f.p, fdim, d_iv.p, ninfo.ivector_dim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
       }
@@ -256,12 +261,13 @@ int main(int argc, char **argv) {
       } else {
         for (int u = 0; u < U; u++) if (r->info[10 * u + 2] != 0 || r->info[10 * u] == 0) { K3H_WARN << "Failed to decode utterance with id " << b.keys[u]; num_err++; }
       }
-      k3_nnet_batch_destroy(nb);
+      if (!cached) { plan_cache.push_back({b.nframes, nb}); if (plan_cache.size() > 4) { k3_nnet_batch_destroy(plan_cache.front().second); plan_cache.erase(plan_cache.begin()); } }
       K3H_VLOG(1) << "batch " << k << ": waited " << ms(t_a, t_b) << " ms for the reader, " << ms(t_b, t_c) << " ms upload + features + network + decoder, " << ms(t_c, tick()) << " ms lattices to the host + hand-over";
     }
     if (post.valid()) post.get();
     num_err += post_err;
     HIPCHK(hipDeviceSynchronize());
+    for (auto &c : plan_cache) k3_nnet_batch_destroy(c.second);
     if (det_pool) { det_pool->Wait(); det_pool.reset(); }
     if (writer) writer->Flush();
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

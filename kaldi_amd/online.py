@@ -137,3 +137,80 @@ class BatchedOnlinePipeline:
         self.decoder.FinalizeChannels(ended)
         lats = self.decoder.GetRawLattices(copy=True)
         return {ch: lats[k] for k, ch in enumerate(ended)}
+
+
+class CudaOnlinePipelineDynamicBatcher:
+    """cudadecoder/cuda-online-pipeline-dynamic-batcher.{h,cc}: client threads Push() audio chunks of many streams (correlation ids); a batcher thread
+    forms batches -- as soon as max_batch_size chunks wait, or every `dynamic_batcher_timeout` seconds -- and runs them through the pipeline's
+    DecodeBatch.  Same rules as the reference: a batch holds at most one chunk per stream; chunks that do not fit (batch full, stream already in the
+    batch, no free channel for a new stream: "All decoding channels are in use") wait in a FIFO backlog, which is drained first into the next batch
+    (:73-124); Push deep-copies the samples.  A stream's channel is claimed at its first chunk (TryInitCorrID) and released when its last chunk was
+    decoded; `lattice_callback(corr_id, RawLattice)` delivers the lattice then (the pipeline's SetLatticeCallback role)."""
+    LOOP_TICK = 100e-6      # kDynamicBatcherLoopTick
+
+    def __init__(self, pipeline, max_batch_size=None, dynamic_batcher_timeout=2e-3, lattice_callback=None):
+        import threading, collections
+        self.pipe = pipeline; self.max_batch = int(max_batch_size or pipeline.nch); self.timeout = float(dynamic_batcher_timeout); self.cb = lattice_callback
+        self._lock = threading.Lock(); self._backlog = collections.deque(); self._next = []; self._next_ids = set()
+        self._chan = {}; self._free = list(range(pipeline.nch)); self._pending = collections.Counter(); self._not_done = 0
+        self._run = True; self._error = None; self.batch_sizes = []
+        self._thread = threading.Thread(target=self._loop, daemon=True); self._thread.start()
+
+    def _try_add(self, chunk):                       # TryAddChunkToNextBatchDeepCopy; the caller holds the lock
+        corr_id, first, last, samples = chunk
+        if len(self._next) >= self.max_batch or corr_id in self._next_ids: return False
+        if first:
+            if not self._free: return False          # all decoding channels are in use
+            self._chan[corr_id] = self._free.pop(0)
+        elif corr_id not in self._chan: raise KeyError(f"chunk of stream {corr_id} before its first chunk")
+        self._next.append(chunk); self._next_ids.add(corr_id); return True
+
+    def Push(self, corr_id, is_first_chunk, is_last_chunk, wave_samples):
+        if self._error: raise self._error
+        chunk = (corr_id, bool(is_first_chunk), bool(is_last_chunk), wave_samples.clone() if torch.is_tensor(wave_samples) else torch.from_numpy(np.array(wave_samples, np.float32)))
+        with self._lock:
+            # FIFO per stream: a chunk may not overtake an earlier chunk of its stream that is still in the backlog
+            if any(c[0] == corr_id for c in self._backlog) or not self._try_add(chunk): self._backlog.append(chunk)
+            self._pending[corr_id] += 1; self._not_done += 1
+
+    def GetNumPendingChunks(self, corr_id):
+        with self._lock: return self._pending.get(corr_id, 0)
+
+    def WaitForCompletion(self):
+        import time
+        while True:
+            if self._error: raise self._error
+            with self._lock:
+                if self._not_done == 0: return
+            time.sleep(self.LOOP_TICK)
+
+    def Close(self):
+        self._run = False; self._thread.join()
+
+    def _loop(self):
+        import time
+        next_timeout = time.monotonic() + self.timeout
+        try:
+            while self._run:
+                if self._not_done >= self.max_batch or time.monotonic() >= next_timeout:
+                    with self._lock:
+                        cur, self._next, self._next_ids = self._next, [], set()
+                        kept = type(self._backlog)(); blocked = set()      # FillNextBatchWithBacklog, FIFO; a stream's later chunks stay behind its first waiting one
+                        for c in self._backlog:
+                            if c[0] in blocked or not self._try_add(c): kept.append(c); blocked.add(c[0])
+                        self._backlog = kept
+                    if cur:
+                        chans = [self._chan[c[0]] for c in cur]
+                        lats = self.pipe.DecodeBatch(chans, [c[3].to(self.pipe.dev) for c in cur], [c[1] for c in cur], [c[2] for c in cur])
+                        self.batch_sizes.append(len(cur))
+                        done = []
+                        with self._lock:
+                            for c in cur:
+                                self._pending[c[0]] -= 1; self._not_done -= 1
+                                if c[2]: ch = self._chan.pop(c[0]); self._free.append(ch); done.append((c[0], lats[ch]))
+                        if self.cb:
+                            for corr_id, lat in done: self.cb(corr_id, lat)
+                    next_timeout = time.monotonic() + self.timeout
+                else: time.sleep(self.LOOP_TICK)
+        except Exception as e:      # surfaces in Push / WaitForCompletion
+            self._error = e
