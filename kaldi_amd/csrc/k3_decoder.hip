@@ -123,6 +123,7 @@ struct DecParams {
   float *lt_c0;                                          // [frame_tokens_cap] token costs right after ProcessEmitting
   int2 *lt_crng; int *lt_cdst; float *lt_cw;             // closure sub-graph in token space: per token (first, count), per eps arc (dst token | -1, weight)
   float *lt_rcost; int *lt_rflag, *lt_rown, *lt_stack, *lt_iq, *lt_c2t; int2 *lt_arcs2; int4 *lt_meta;   // replay state (global copies; small frames use LDS)
+  int *lt_par, *lt_rtmp, *lt_rlist, *lt_wcomp; int4 *lt_cinfo, *lt_coffs; int2 *lt_rinfo;      // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of the tokens it created
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -1413,7 +1414,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   p.live_cap = (int)std::min<long long>(cfg->lane_tokens_cap, 1 << 18);
   if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.live_link, nl * p.live_cap))) return rc;
-  p.literal = cfg->literal_order ? 1 : 0; p.hash_ratio = cfg->hash_ratio;
+  p.literal = cfg->literal_order == 2 ? 2 : (cfg->literal_order ? 1 : 0); p.hash_ratio = cfg->hash_ratio;      // 2: the closure's creation order by the one-wavefront replay (the fall-back of 1)
   if (p.literal) {
     K3_REQUIRE(cfg->hash_ratio > 0.0f && cfg->hash_ratio <= 64.0f, "k3_decoder_create: literal_order needs 0 < hash_ratio <= 64 (LatticeFasterDecoderConfig::hash_ratio)");
     K3_REQUIRE(cfg->frame_tokens_cap <= 65536 && cfg->frame_cands_cap > cfg->frame_tokens_cap, "k3_decoder_create: literal_order needs frame_tokens_cap <= 65536 < frame_cands_cap");
@@ -1446,6 +1447,13 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     if ((rc = dmalloc(&d->allocs, &p.lt_arcs2, nl * p.eps_cap))) return rc;
     if ((rc = dmalloc(&d->allocs, &p.lt_meta, nl * cap))) return rc;
     if ((rc = dmalloc(&d->allocs, &p.lt_c2t, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_par, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_rtmp, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_rlist, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_wcomp, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_cinfo, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_coffs, nl * cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.lt_rinfo, nl * cap))) return rc;
     // idle patterns of the scratch: labels / bucket firsts all ones, bitmap / bucket counters zero
     K3_HIP_CHECK(hipMemset(p.lt_label, 0xFF, nl * cap * sizeof(unsigned)));
     K3_HIP_CHECK(hipMemset(p.lt_bm, 0, nl * p.seq_words_cap * sizeof(unsigned)));

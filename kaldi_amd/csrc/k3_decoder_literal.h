@@ -24,6 +24,17 @@ constexpr size_t kLitDynLds = (size_t)kRA * 8 + (size_t)kRS * 4;      // replay 
 constexpr unsigned kLabelNone = 0xFFFFFFFFu;
 enum { kRfHasEps = 1, kRfExists = 2 };
 
+// inclusive prefix sum over the wavefront with DPP row shifts / row broadcasts (no LDS-crossbar round trips)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // exclusive prefix sum over n values produced by in(i), written to out[i]; returns the total.  All threads of the block call it.
 template <typename In>
 __device__ __forceinline__ int block_excl_scan(In &&in, unsigned *out, int n, int *redi) {
@@ -31,9 +42,7 @@ __device__ __forceinline__ int block_excl_scan(In &&in, unsigned *out, int n, in
   int carry = 0;
   for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
     const int i = i0 + tid; const int x = i < n ? (int)in(i) : 0;
-    int incl = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int incl = wave_incl_scan(x);
     __syncthreads();
     if (lane == 63) redi[wave] = incl;
     __syncthreads();
@@ -41,6 +50,26 @@ __device__ __forceinline__ int block_excl_scan(In &&in, unsigned *out, int n, in
     for (int w = 0; w < nw; w++) { const int s = redi[w]; if (w < wave) woff += s; tot += s; }
     if (i < n) out[i] = (unsigned)(carry + woff + incl - x);
     carry += tot;
+  }
+  __syncthreads();
+  return carry;
+}
+
+// the same over four counters at once: in(i) -> int4, out(i, exclusive sums); returns the totals.  red4: LDS, one int4 per wavefront.
+template <typename In, typename Out>
+__device__ __forceinline__ int4 block_excl_scan4(In &&in, Out &&out, int n, int4 *red4) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)blockDim.x >> 6;
+  int4 carry = make_int4(0, 0, 0, 0);
+  for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
+    const int i = i0 + tid; const int4 x = i < n ? in(i) : make_int4(0, 0, 0, 0);
+    const int4 incl = make_int4(wave_incl_scan(x.x), wave_incl_scan(x.y), wave_incl_scan(x.z), wave_incl_scan(x.w));
+    __syncthreads();
+    if (lane == 63) red4[wave] = incl;
+    __syncthreads();
+    int4 woff = make_int4(0, 0, 0, 0), tot = make_int4(0, 0, 0, 0);
+    for (int w = 0; w < nw; w++) { const int4 s = red4[w]; if (w < wave) { woff.x += s.x; woff.y += s.y; woff.z += s.z; woff.w += s.w; } tot.x += s.x; tot.y += s.y; tot.z += s.z; tot.w += s.w; }
+    if (i < n) out(i, make_int4(carry.x + woff.x + incl.x - x.x, carry.y + woff.y + incl.y - x.y, carry.z + woff.z + incl.z - x.z, carry.w + woff.w + incl.w - x.w));
+    carry.x += tot.x; carry.y += tot.y; carry.z += tot.z; carry.w += tot.w;
   }
   __syncthreads();
   return carry;
@@ -71,6 +100,7 @@ __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int 
 
 struct LitLane {      // this lane's slices of the literal_order scratch
   int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *bfirst, *bcnt, *bfill, *cmin; float *c0, *cw, *rcost; int2 *crng, *arcs2; int4 *meta; int *iq, *c2t;
+  int *par, *rtmp, *rlist, *wcomp; int4 *cinfo, *coffs; int2 *rinfo;      // component replay (below)
   __device__ LitLane(const DecParams &p, int L) {
     const long long cap = p.frame_tokens_cap, nch = cap / 64 + 2;
     order[0] = p.lt_order + 2ll * L * cap; order[1] = order[0] + cap; by_ins = p.lt_by_ins + L * cap; dense = p.lt_dense + L * cap; grp = p.lt_grp + L * cap;
@@ -79,6 +109,7 @@ struct LitLane {      // this lane's slices of the literal_order scratch
     cmin = p.lt_cmin + 2ll * L * nch; ccnt = p.lt_ccnt + 2ll * L * nch; c0 = p.lt_c0 + L * cap; crng = p.lt_crng + L * cap;
     cdst = p.lt_cdst + (long long)L * p.eps_cap; cw = p.lt_cw + (long long)L * p.eps_cap; rcost = p.lt_rcost + L * cap; rflag = p.lt_rflag + L * cap; rown = p.lt_rown + L * cap;
     stack = p.lt_stack + (long long)L * p.stack_cap; arcs2 = p.lt_arcs2 + (long long)L * p.eps_cap; iq = p.lt_iq + L * cap; meta = p.lt_meta + L * cap; c2t = p.lt_c2t + L * cap;
+    par = p.lt_par + L * cap; rtmp = p.lt_rtmp + L * cap; rlist = p.lt_rlist + L * cap; wcomp = p.lt_wcomp + L * cap; cinfo = p.lt_cinfo + L * cap; coffs = p.lt_coffs + L * cap; rinfo = p.lt_rinfo + L * cap;
   }
 };
 
@@ -204,6 +235,111 @@ __device__ __forceinline__ void lit_replay(float *rcost, const int4 *meta, const
   *out_created = created; *out_err = err; *out_pops = iters;
 }
 
+// ---- The replay split by weakly connected COMPONENTS of the closure sub-graph (oracle mode 4).  The serial code consumes its queue root by
+// root (a root = an entry of the initial queue; the stack is back at its initial level before the next root is taken) and a root's cascade
+// reads and writes only the costs of tokens it can reach, so cascades in different components commute.  Every component replays its own
+// roots in queue order on ONE THREAD with a stack of its own (hundreds of components per frame, the longest chain a dozen pops), and the
+// creation labels are handed out afterwards root by root in queue order by a prefix sum over the roots' creation counts.
+template <typename P> __device__ __forceinline__ int uf_find(P par, int x) { for (;;) { const int q_ = K3_ALD(&par[x]); if (q_ == x) return x; x = q_; } }
+// lock-free union: the larger root hooks under the smaller one (parents only ever decrease: no cycles)
+template <typename P> __device__ __forceinline__ void uf_union(P par, int a, int b) {
+  for (;;) {
+    a = uf_find(par, a); b = uf_find(par, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }
+    if (atomicCAS(&par[a], a, b) == a) return;
+  }
+}
+
+// One worker = one component, on one thread.  rcost / meta / AR / clist as in lit_replay (LDS or HBM by instantiation); stk: this component's
+// slice of the stack pool.  Returns false when the stack slice overflows (the frame then takes the serial replay).
+template <typename RC, typename MT, typename AT, typename CL>
+__device__ __forceinline__ bool lit_replay_component(RC rcost, MT meta, AT AR, CL clist, const int *iq, const int *rlist, int2 *rinfo, int *stk, int scap,
+                                                     int r0, int rcnt, int cpos, float accept) {
+  const float kInf = __builtin_inff();
+  for (int j = 0; j < rcnt; j++) {
+    const int k = rlist[r0 + j]; int cur = iq[k]; const int seg0 = cpos; int sp = 0;
+    for (;;) {
+      const float cc = rcost[cur]; const int4 mt = meta[cur];
+      int nxt = -1;      // the newest push stays in a register: it is the next pop
+      if (cc < accept) {
+        for (int a = 0; a < mt.y; a++) {
+          int d = mt.z, wb = mt.w;
+          if (a > 0) { const int2 ar = AR[mt.x + a]; d = ar.x; wb = ar.y; }
+          const float tot = cc + __int_as_float(wb);
+          if (tot < accept) {
+            const float old = rcost[d];
+            if (old > tot) {
+              if (old == kInf) clist[cpos++] = (unsigned)d;
+              rcost[d] = tot;
+              if (meta[d].y > 0) { if (nxt >= 0) { if (sp >= scap) return false; stk[sp++] = nxt; } nxt = d; }
+            }
+          }
+        }
+      }
+      if (nxt >= 0) cur = nxt; else if (sp > 0) cur = stk[--sp]; else break;
+    }
+    rinfo[k] = make_int2(seg0, cpos - seg0);
+  }
+  return true;
+}
+
+// All phases of the component replay; every thread of the block calls it.  par: n_cid ints (LDS for small frames).  Returns the number of tokens
+// created, or -1 when the frame has to take the serial replay (rcost / clist are then in an undefined state).
+template <typename RC, typename MT, typename AT, typename CL, typename P>
+__device__ __forceinline__ int lit_replay_components(const DecParams &p, const LitLane &q, Shared &sh, int *s_flag, RC rcost, MT meta, AT AR, CL clist, P par,
+                                                     int n_cid, int n_arc, int n_iq, unsigned m_e, float accept) {
+  const int tid = threadIdx.x; const float kInf = __builtin_inff();
+  int4 *red4 = reinterpret_cast<int4 *>(sh.hist);
+  if (n_arc > p.stack_cap) return -1;
+  for (int c = tid; c < n_cid; c += kBlock) { K3_AST(&par[c], c); int *ci = reinterpret_cast<int *>(&q.cinfo[c]); K3_AST(&ci[0], 0); K3_AST(&ci[1], 0); K3_AST(&ci[2], 0); K3_AST(&ci[3], 0); }
+  if (tid == 0) *s_flag = 0;
+  __syncthreads();
+  for (int c = tid; c < n_cid; c += kBlock) {
+    const int4 mt = meta[c];
+    for (int a = 0; a < mt.y; a++) uf_union(par, c, a == 0 ? mt.z : AR[mt.x + a].x);
+  }
+  __syncthreads();
+  // per component (indexed by its root id): roots of the initial queue, tokens the closure creates, passing arcs
+  for (int c = tid; c < n_cid; c += kBlock) {
+    const int r = uf_find(par, c); if (r != c) K3_AST(&par[c], r);
+    int *ci = reinterpret_cast<int *>(&q.cinfo[r]);
+    if (rcost[c] == kInf) atomicAdd(&ci[1], 1);
+    const int pc = meta[c].y; if (pc > 0) atomicAdd(&ci[2], pc);
+  }
+  for (int k = tid; k < n_iq; k += kBlock) { const int r = uf_find(par, q.iq[k]); atomicAdd(reinterpret_cast<int *>(&q.cinfo[r]), 1); }
+  __syncthreads();
+  const int4 tot = block_excl_scan4([&](int c) { const int *ci = reinterpret_cast<const int *>(&q.cinfo[c]); const int rc_ = K3_ALD(&ci[0]); return make_int4(rc_, K3_ALD(&ci[1]), K3_ALD(&ci[2]), rc_ > 0 ? 1 : 0); },
+                                    [&](int c, int4 ex) { q.coffs[c] = ex; if (K3_ALD(reinterpret_cast<const int *>(&q.cinfo[c])) > 0) q.wcomp[ex.w] = c; }, n_cid, red4);
+  const int n_workers = tot.w;
+  // a component's roots in queue order (the queue is consumed from its back: descending k)
+  for (int k = tid; k < n_iq; k += kBlock) {
+    const int r = uf_find(par, q.iq[k]); int *ci = reinterpret_cast<int *>(&q.cinfo[r]);
+    const int pos = atomicAdd(&ci[3], 1); q.rtmp[q.coffs[r].x + pos] = k;
+  }
+  __syncthreads();
+  for (int k = tid; k < n_iq; k += kBlock) {
+    const int r = uf_find(par, q.iq[k]); const int cnt = K3_ALD(reinterpret_cast<const int *>(&q.cinfo[r])), off = q.coffs[r].x;
+    int rank = 0;
+    if (cnt > 1) for (int t = 0; t < cnt; t++) rank += q.rtmp[off + t] > k;
+    q.rlist[off + rank] = k;
+  }
+  __syncthreads();
+  for (int w = tid; w < n_workers; w += kBlock) {
+    const int c = q.wcomp[w]; const int4 co = q.coffs[c]; const int *ci = reinterpret_cast<const int *>(&q.cinfo[c]);
+    if (!lit_replay_component(rcost, meta, AR, clist, q.iq, q.rlist, q.rinfo, q.stack + co.z, K3_ALD(&ci[2]), co.x, K3_ALD(&ci[0]), co.y, accept)) *s_flag = 1;
+  }
+  __syncthreads();
+  if (*s_flag) return -1;
+  // creation labels: roots in queue order (j-th root processed = position n_iq - 1 - j), tokens of a root in the order it created them
+  const int created = block_excl_scan([&](int j) { return (unsigned)q.rinfo[n_iq - 1 - j].y; }, reinterpret_cast<unsigned *>(q.dense), n_iq, sh.redi);
+  for (int j = tid; j < n_iq; j += kBlock) {
+    const int2 ri = q.rinfo[n_iq - 1 - j]; const unsigned base = m_e + (unsigned)q.dense[j];
+    for (int t = 0; t < ri.y; t++) K3_AST(&q.label[q.c2t[clist[ri.x + t]]], base + (unsigned)t);
+  }
+  return created;
+}
+
 #ifdef K3_LIT_PROF
 #define K3_LT(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); sh.prof[i] += now__ - lt_last__; lt_last__ = now__; } } while (0)
 #else
@@ -216,8 +352,11 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
   __shared__ __attribute__((aligned(16))) int s_tab[3 * kHL];      // level-1 table {key, cost, token}; between the closure and the end of a frame: the replay's records
   int *const s_lkey = s_tab; unsigned *const s_lcost = reinterpret_cast<unsigned *>(s_tab + kHL); int *const s_ltok = s_tab + 2 * kHL;
   __shared__ unsigned s_lmark[3 * (kHL / 32)];
-  __shared__ unsigned short s_lwl[2][kWlLds];
-  __shared__ int s_own[1024];      // replay: which lane of the batch targets a token (binned; a false clash only takes the one-by-one path)
+  // 8 KB shared by three users with disjoint lifetimes: the eps rounds' work-lists (first half), the serial replay's clash bins (second half:
+  // which lane of a batch targets a token; a false clash only takes the one-by-one path), the component replay's union-find parents (all of it)
+  __shared__ __attribute__((aligned(16))) int s_aux[2 * 1024];
+  static_assert(2 * kWlLds * sizeof(unsigned short) <= 1024 * sizeof(int) && kHL / 2 <= 2 * 1024, "s_aux layout");
+  unsigned short (*const s_lwl)[kWlLds] = reinterpret_cast<unsigned short (*)[kWlLds]>(s_aux); int *const s_own = s_aux + 1024;
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
   const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
   int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
@@ -498,38 +637,57 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     if (tid == 0) { sh.prof[13] += n; sh.prof[14] += rmode == 0 ? 1 : 0; sh.prof[15] += 1; }
     const long long rp_t0 = (long long)__builtin_readcyclecounter();
 #endif
-    // ---- replay of the LIFO queue (:851-896) by one wavefront: only the ORDER in which the closure creates tokens comes out of it
-    if (wave == 0) {
-      __builtin_amdgcn_s_setprio(3);      // one wavefront on a dependent chain: let it issue ahead of the other workgroup's parallel phases
-      int created = 0, err = 0, pops = 0;
-      // (separate instantiations so that mode 0 compiles to LDS instructions only: a flat access would wait for every outstanding global access)
-      if (rmode == 0) lit_replay<0>(reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw), reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
-                                    reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, q.iq, n_iq, accept, s_own, &created, &err, &pops);
-      else if (rmode == 1) lit_replay<1>(reinterpret_cast<float *>(s_tab), q.meta, q.arcs2, reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
-                                         reinterpret_cast<unsigned *>(smem_raw), q.iq, n_iq, accept, s_own, &created, &err, &pops);
-      else lit_replay<2>(q.rcost, q.meta, q.arcs2, q.stack, p.stack_cap, reinterpret_cast<unsigned *>(q.rflag), q.iq, n_iq, accept, s_own, &created, &err, &pops);
-      __builtin_amdgcn_s_setprio(0);
+    // ---- replay of the LIFO queue (:851-896): only the ORDER in which the closure creates tokens comes out of it.  literal_order = 1: split by
+    // connected components of the closure sub-graph, one thread per component; literal_order = 2 (and frames whose component stacks overflow):
+    // the whole queue by one wavefront.
+    // (separate instantiations so that mode 0 compiles to LDS instructions only: a flat access would wait for every outstanding global access)
+    int created_total = -1;
+    if (p.literal == 1) {
+      if (rmode == 0) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw),
+                                                            reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, s_aux, n_cid, n_arc, n_iq, m_e, accept);
+      else if (rmode == 1) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab), (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(smem_raw), q.par, n_cid, n_arc, n_iq, m_e, accept);
+      else created_total = lit_replay_components(p, q, sh, &ls.use_lds, q.rcost, (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(q.rflag), q.par, n_cid, n_arc, n_iq, m_e, accept);
 #ifdef K3_LIT_PROF
-      if (lane == 0) { sh.prof[12] += pops; if (rmode != 0) { sh.prof[5] += pops; sh.prof[3] += (long long)__builtin_readcyclecounter() - rp_t0; } }
+      if (tid == 0 && created_total < 0) sh.prof[5] += 1;
 #endif
-#ifdef K3_LIT_DEBUG
-      if (lane == 0 && err) printf("lane %d frame %d: replay err %d pops %d created %d\n", L, f, err, pops, created);
-#endif
-      if (lane == 0) { ls.n_created = created; if (err) sh.err = err == 2 ? K3_ERR_HIP : K3_ERR_OVERFLOW; }
+      if (created_total < 0) {      // back to the state step 2 left
+        for (int c = tid; c < n_cid; c += kBlock) { const int i = q.c2t[c]; rcost[c] = i < n_e ? q.c0[i] : kInf; }
+        __syncthreads();
+      }
     }
-    __syncthreads();
-    K3_LT(9);
-    if (block_err(sh)) break;
-#ifdef K3_LIT_DEBUG
-    if (n_e + ls.n_created != n && tid == 0) printf("lane %d frame %d: n_e %d created %d n %d n_cid %d n_arc %d n_iq %d rmode %d\n", L, f, n_e, ls.n_created, n, n_cid, n_arc, n_iq, rmode);
+    if (created_total < 0) {
+      if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);      // one wavefront on a dependent chain: let it issue ahead of the other workgroup's parallel phases
+        int created = 0, err = 0, pops = 0;
+        if (rmode == 0) lit_replay<0>(reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw), reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
+                                      reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, q.iq, n_iq, accept, s_own, &created, &err, &pops);
+        else if (rmode == 1) lit_replay<1>(reinterpret_cast<float *>(s_tab), q.meta, q.arcs2, reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
+                                           reinterpret_cast<unsigned *>(smem_raw), q.iq, n_iq, accept, s_own, &created, &err, &pops);
+        else lit_replay<2>(q.rcost, q.meta, q.arcs2, q.stack, p.stack_cap, reinterpret_cast<unsigned *>(q.rflag), q.iq, n_iq, accept, s_own, &created, &err, &pops);
+        __builtin_amdgcn_s_setprio(0);
+#ifdef K3_LIT_PROF
+        if (lane == 0) { sh.prof[12] += pops; if (rmode != 0) sh.prof[3] += (long long)__builtin_readcyclecounter() - rp_t0; }
 #endif
-    if (n_e + ls.n_created != n) { if (tid == 0) sh.err = K3_ERR_HIP; }      // every token of the fixpoint must have been created by the replay
+#ifdef K3_LIT_DEBUG
+        if (lane == 0 && err) printf("lane %d frame %d: replay err %d pops %d created %d\n", L, f, err, pops, created);
+#endif
+        if (lane == 0) { ls.n_created = created; if (err) sh.err = err == 2 ? K3_ERR_HIP : K3_ERR_OVERFLOW; }
+      }
+      __syncthreads();
+      if (block_err(sh)) break;
+      created_total = ls.n_created;
+      for (int k = tid; k < created_total; k += kBlock) K3_AST(&q.label[q.c2t[clist[k]]], m_e + (unsigned)k);      // creation labels of the closure's tokens
+    }
+    K3_LT(9);
+#ifdef K3_LIT_DEBUG
+    if (n_e + created_total != n && tid == 0) printf("lane %d frame %d: n_e %d created %d n %d n_cid %d n_arc %d n_iq %d rmode %d\n", L, f, n_e, created_total, n, n_cid, n_arc, n_iq, rmode);
+#endif
+    if (n_e + created_total != n) { if (tid == 0) sh.err = K3_ERR_HIP; }      // every token of the fixpoint must have been created by the replay
     if (block_err(sh)) break;
-    for (int k = tid; k < ls.n_created; k += kBlock) K3_AST(&q.label[q.c2t[clist[k]]], m_e + (unsigned)k);      // creation labels of the closure's tokens      // creation labels of the closure's tokens
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     __syncthreads();
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
-    lit_hash_order(q, sh, n, m_e + (unsigned)ls.n_created, tok_state + nb, hash_size, ord_nxt);
+    lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt);
     K3_LT(10);
     // ---- publish the frame: final costs into the pool, empty table, idle labels
     for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], kLabelNone);

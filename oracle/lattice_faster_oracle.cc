@@ -52,6 +52,7 @@
  *                       by a replay of the LIFO queue on the closure sub-graph that only recovers creation ORDER.
  *   mode 3              mode 2 with the work inside every parallel phase visited in a shuffled order (what a GPU does):
  *                       tests assert mode 0 == mode 2 == mode 3, i.e. the phase decomposition is order-free.
+ *   mode 4              mode 3 with the replay split by connected components of the closure sub-graph (what the GPU kernel does).
  * SURVEY.md 9.1 argues that both give the same lattice after FinalizeDecoding except at exact float ties and in
  * the min_active corner; tests assert equality on the test sets and the GPU path is compared with both.
  * All arithmetic is float32 in the reference's evaluation order; compile WITHOUT -ffast-math / FMA contraction.
@@ -61,6 +62,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <limits>
 #include <vector>
 
@@ -318,9 +320,9 @@ struct Decoder {
   };
   Frame2 cf; size_t hash_size2 = 1000;  // lattice-faster-decoder.cc:41 toks_.SetSize(1000)
   uint64_t rng_state = 0x9E3779B97F4A7C15ull;
-  int64_t n_replay_pops = 0, n_replay_pushes = 0;
+  int64_t n_replay_pops = 0, n_replay_pushes = 0, n_replay_crit = 0, n_replay_comps = 0, n_replay_frames = 0;
   uint32_t Rand() { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng_state >> 33); }
-  template <class T> void MaybeShuffle(std::vector<T> &v) { if (mode != 3) return; for (size_t i = v.size(); i > 1; i--) std::swap(v[i - 1], v[Rand() % i]); }
+  template <class T> void MaybeShuffle(std::vector<T> &v) { if (mode < 3) return; for (size_t i = v.size(); i > 1; i--) std::swap(v[i - 1], v[Rand() % i]); }
   std::vector<int32_t> Iota(size_t n) { std::vector<int32_t> v(n); for (size_t i = 0; i < n; i++) v[i] = (int32_t)i; MaybeShuffle(v); return v; }
 
   // HashList order (util/hash-list-inl.h:125-165) of tokens with unique creation labels: buckets in order of first occupation,
@@ -396,6 +398,51 @@ struct Decoder {
         if (fst.ilabel[a] == 0) { const bool pass = cost[i] + fst.weight[a] < cutoff; cdst.push_back(pass ? index_of_state[fst.next[a]] : -1); cw.push_back(fst.weight[a]); carc.push_back(a); }
     }
     cbeg[n] = (int32_t)cdst.size();
+    // ---- mode 4: the replay split by weakly connected COMPONENTS of the closure sub-graph.  The queue is consumed root by root (a root = an entry
+    // of the initial queue; the stack is back at its initial level before the next root is taken), and a root's cascade only reads and writes the
+    // costs of tokens it can reach, so cascades in different components commute: every component replays its own roots in queue order with a
+    // stack of its own (PAR over components, SER inside one), and the creation labels are handed out afterwards root by root in queue order.
+    if (mode == 4) {
+      std::vector<int32_t> par(n); for (size_t i = 0; i < n; i++) par[i] = (int32_t)i;
+      auto find = [&](int32_t x) { while (par[x] != x) x = par[x]; return x; };
+      { std::vector<std::pair<int32_t, int32_t>> edges;
+        for (size_t i = 0; i < n; i++) for (int32_t k = cbeg[i]; k < cbeg[i + 1]; k++) if (cdst[k] >= 0) edges.push_back({(int32_t)i, cdst[k]});
+        MaybeShuffle(edges);
+        for (auto &e : edges) { int32_t a = find(e.first), b = find(e.second); if (a == b) continue; if (a < b) std::swap(a, b); par[a] = b; } }      // PAR (lock-free union: the larger root hooks under the smaller)
+      std::vector<int32_t> roots;                         // processing order = the initial queue from its back
+      for (size_t p = n_e; p > 0; p--) { const int32_t i = order1[p - 1]; if (fst.num_ieps[state[i]] != 0) roots.push_back(i); }
+      std::vector<std::vector<int32_t>> comp_roots(n); std::vector<int32_t> comps;
+      for (size_t r = 0; r < roots.size(); r++) { const int32_t c = find(roots[r]); if (comp_roots[c].empty()) comps.push_back(c); comp_roots[c].push_back((int32_t)r); }
+      MaybeShuffle(comps);
+      std::vector<float> rc(n, kInf); std::vector<char> ex(n, 0);
+      for (size_t i = 0; i < n_e; i++) { rc[i] = c0[i]; ex[i] = 1; }
+      std::vector<std::vector<int32_t>> created(roots.size());
+      int64_t crit = 0;
+      for (int32_t c : comps) {                           // PAR over components
+        std::vector<int32_t> stack; const int64_t pops0 = n_replay_pops;
+        for (int32_t r : comp_roots[c]) {                 // SER: this component's roots in queue order
+          stack.push_back(roots[r]);
+          while (!stack.empty()) {
+            const int32_t e = stack.back(); stack.pop_back(); n_replay_pops++;
+            const float cc = rc[e];
+            if (cc >= cutoff) continue;
+            for (int32_t k = cbeg[e]; k < cbeg[e + 1]; k++) {
+              const int32_t d = cdst[k]; if (d < 0) continue;
+              const float tot = cc + cw[k];
+              if (!(tot < cutoff)) continue;
+              bool changed = false;
+              if (!ex[d]) { ex[d] = 1; rc[d] = tot; created[r].push_back(d); changed = true; }
+              else if (rc[d] > tot) { rc[d] = tot; changed = true; }
+              if (changed && fst.num_ieps[state[d]] != 0) { stack.push_back(d); n_replay_pushes++; }
+            }
+          }
+        }
+        crit = std::max(crit, n_replay_pops - pops0);
+      }
+      n_replay_crit += crit; n_replay_comps += (int64_t)comps.size(); n_replay_frames++;
+      for (size_t r = 0; r < roots.size(); r++) for (int32_t d : created[r]) label[d] = n_labels++;      // exclusive scan over the roots' counts on the GPU
+      for (size_t i = 0; i < n; i++) if (!ex[i] || rc[i] != cost[i]) abort();
+    } else
     // ---- SER replay of the LIFO queue (:851-896) on the sub-graph: recovers only the ORDER in which the closure creates tokens
     {
       std::vector<float> rc(n, kInf); std::vector<char> ex(n, 0);
@@ -677,6 +724,7 @@ void *k3o_lfd_decode(const k3o_fst *f, const float *loglikes, int32_t num_frames
   for (int32_t s = 0; s < fst.num_states; s++) for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++) if (fst.ilabel[a] == 0) fst.num_ieps[s]++;
   Config cfg{c->beam, c->max_active, c->min_active, c->lattice_beam, c->prune_interval, c->beam_delta, c->hash_ratio, c->prune_scale};
   Decoder d(fst, cfg, mode);
+  struct StatPrinter { Decoder &d; ~StatPrinter() { if (getenv("K3O_COMP_STATS") && d.n_replay_frames) fprintf(stderr, "replay: frames %lld pops/frame %.1f comps/frame %.1f critical-path pops/frame %.1f\n", (long long)d.n_replay_frames, (double)d.n_replay_pops / d.n_replay_frames, (double)d.n_replay_comps / d.n_replay_frames, (double)d.n_replay_crit / d.n_replay_frames); } } stat_printer{d};
   d.loglikes = loglikes; d.ld = ld; d.tid2pdf = tid2pdf; d.num_frames_ready = num_frames;
   if (mode >= 2) d.Init2(); else d.Init();
   d.Advance(); d.Finalize();

@@ -17,7 +17,7 @@ _CAPS = dict(frame_tokens_cap=65536, frame_cands_cap=262144, lane_tokens_cap=2_5
 def _decode(cf, N, lls, literal=True, **cfg):
     from kaldi_amd import decoder
     kw = {k: v for k, v in cfg.items() if k in ("beam", "max_active", "min_active", "lattice_beam", "beam_delta", "hash_ratio")}
-    c = decoder.decoder_config(literal_order=1 if literal else 0, **dict(_CAPS, **kw))
+    c = decoder.decoder_config(literal_order=int(literal), **dict(_CAPS, **kw))      # 1: component replay, 2: one-wavefront replay (the fall-back of 1)
     dec = decoder.CudaDecoder(cf, c, len(lls), N)
     ro = np.concatenate([[0], np.cumsum([l.shape[0] for l in lls])])
     dec.DecodeBatch(torch.from_numpy(np.concatenate(lls)).cuda(), ro)
@@ -35,13 +35,14 @@ def _check_against_oracle(dec, u, lat, f, ll, t2p, kw):
     assert d == "", (u, d)
     return oi
 
+@pytest.mark.parametrize("replay", [1, 2])
 @pytest.mark.parametrize("name", sorted(dcases.CASES))
-def test_literal_order_equals_the_reference_decoder(name):
+def test_literal_order_equals_the_reference_decoder(name, replay):
     from kaldi_amd import decoder
     from oracle import ref_decoder as rd, lattice_oracle as lo
     f, t2p, ll, kw = dcases.make(name); N = ll.shape[1]
     cf = decoder.CudaFst(f, t2p)
-    lats, info, dec = _decode(cf, N, [ll, ll[: max(1, ll.shape[0] // 2)]], **kw)
+    lats, info, dec = _decode(cf, N, [ll, ll[: max(1, ll.shape[0] // 2)]], literal=replay, **kw)
     assert (info[:, 2] == 0).all(), info[:, 2]
     oi = _check_against_oracle(dec, 0, lats[0], f, ll, t2p, kw)
     _check_against_oracle(dec, 1, lats[1], f, ll[: max(1, ll.shape[0] // 2)], t2p, kw)
@@ -52,7 +53,8 @@ def test_literal_order_equals_the_reference_decoder(name):
     if rd.available():                                             # and live
         assert lsig.canonical_of_reference(rd.decode(f, ll, t2p, lo.Config(**kw))) == canon
 
-def test_literal_order_random_configurations_and_lane_reuse():
+@pytest.mark.parametrize("replay", [1, 2])
+def test_literal_order_random_configurations_and_lane_reuse(replay):
     """random graphs / lengths / spreads / every LatticeFasterDecoderConfig field incl. cost grids with exact ties; the same decoder object
     decodes every batch (scratch must return to its idle state), lanes hold different utterances"""
     from kaldi_amd import decoder
@@ -67,7 +69,7 @@ def test_literal_order_random_configurations_and_lane_reuse():
         if rng.random() < 0.5: kw["min_active"] = int(rng.choice([0, 20, 500]))
         if "max_active" in kw and kw.get("min_active", 200) >= kw["max_active"]: kw["min_active"] = max(0, kw["max_active"] - 1)
         cf = decoder.CudaFst(f, t2p)
-        lats, info, dec = _decode(cf, N, lls, **kw)
+        lats, info, dec = _decode(cf, N, lls, literal=replay, **kw)
         for u, ll in enumerate(lls):
             assert info[u, 2] in (0, 1), (it, u, info[u])
             if info[u, 2] == 0: _check_against_oracle(dec, u, lats[u], f, ll, t2p, kw)

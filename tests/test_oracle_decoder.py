@@ -185,7 +185,7 @@ def test_random_configurations_against_the_reference_decoder():
 
 
 # ---- the literal algorithm in the phase structure of the GPU kernel (mode 2) and with every parallel phase shuffled (mode 3) --------
-def _same_run(f, ll, t2p, cfg, modes=(2, 3)):
+def _same_run(f, ll, t2p, cfg, modes=(2, 3, 4)):
     l0, i0 = lo.decode(f, ll, t2p, cfg, 0)
     for m in modes:
         l, i = lo.decode(f, ll, t2p, cfg, m)
