@@ -112,7 +112,7 @@ struct DecParams {
   int *st_ntoks; float *st_cur, *st_ab, *st_next, *st_co;
   LaneInfo *info;
   // literal_order scratch (k3_decoder_literal.h), per lane
-  int literal; float hash_ratio; int hash_cap, seq_words_cap, eps_cap, stack_cap;
+  int literal; float hash_ratio; int hash_cap, seq_words_cap, eps_cap, stack_cap; long long lt_lane_bytes;      // the lt_* pointers below are lane 0's; lane l's arrays start lt_lane_bytes * l further on
   int *lt_order;          // [2 x frame_tokens_cap] HashList order of the current / the next frame (local token indices)
   int *lt_by_ins;         // [frame_tokens_cap] tokens of the newest frame in creation order (the final-frame sweeps walk it backwards)
   unsigned *lt_label;     // [frame_tokens_cap] creation label of a token being built (all 0xFFFFFFFF between frames)
@@ -128,8 +128,20 @@ struct DecParams {
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
 __device__ __forceinline__ float dec(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
-#define K3_ALD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define K3_AST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// Every atomic below works on the state of ONE lane, and a lane is owned by one workgroup in every kernel: workgroup scope is enough.  (Agent
+// scope makes gfx950 resolve the operation beyond the XCD's L2 -- the coherence point of the eight XCDs -- at several times the latency.)
+#ifndef K3_DEC_SCOPE
+#define K3_DEC_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+#define K3_ALD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, K3_DEC_SCOPE)
+#define K3_AST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, K3_DEC_SCOPE)
+template <typename T, typename V> __device__ __forceinline__ T k3a_add(T *p, V v) { return __hip_atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED, K3_DEC_SCOPE); }
+template <typename T, typename V> __device__ __forceinline__ T k3a_min(T *p, V v) { return __hip_atomic_fetch_min(p, (T)v, __ATOMIC_RELAXED, K3_DEC_SCOPE); }
+template <typename T, typename V> __device__ __forceinline__ T k3a_or(T *p, V v) { return __hip_atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED, K3_DEC_SCOPE); }
+template <typename T, typename V> __device__ __forceinline__ T k3a_exch(T *p, V v) { return __hip_atomic_exchange(p, (T)v, __ATOMIC_RELAXED, K3_DEC_SCOPE); }
+template <typename T, typename V, typename W> __device__ __forceinline__ T k3a_cas(T *p, V expected, W desired) {
+  T e = (T)expected; __hip_atomic_compare_exchange_strong(p, &e, (T)desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, K3_DEC_SCOPE); return e;
+}
 
 __device__ __forceinline__ unsigned hash_state(int s) { unsigned x = (unsigned)s * 2654435761u; return x ^ (x >> 15); }
 
@@ -198,7 +210,7 @@ __device__ __forceinline__ int wave_append(bool pred, int *counter) {
   if (m == 0) return 0;
   const int leader = __ffsll((long long)m) - 1;
   int base = 0;
-  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  if (lane == leader) base = k3a_add(counter, __popcll(m));
   base = __builtin_amdgcn_readlane(base, leader);          // leader is wave-uniform: a v_readlane, not an LDS-crossbar shuffle
   return base + __popcll(m & ((1ull << lane) - 1ull));
 }
@@ -208,7 +220,7 @@ __device__ __forceinline__ long long wave_append64(bool pred, long long *counter
   if (m == 0) return 0;
   const int leader = __ffsll((long long)m) - 1;
   long long base = 0;
-  if (lane == leader) base = (long long)atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
+  if (lane == leader) base = (long long)k3a_add((unsigned long long *)counter, (unsigned long long)__popcll(m));
   base = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)base >> 32), leader) << 32) |
                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)base, leader));
   return base + __popcll(m & ((1ull << lane) - 1ull));
@@ -250,7 +262,7 @@ __device__ __forceinline__ void wave_expand(const ArcRec *arcs, int beg, int deg
 __device__ __forceinline__ int slot_find_or_claim(Slot *tab, unsigned mask, int state, bool *claimed) {
   unsigned h = hash_state(state) & mask;
   for (unsigned probe = 0; probe <= mask; probe++) {
-    const int old = atomicCAS(&tab[h].key, kEmpty, state);
+    const int old = k3a_cas(&tab[h].key, kEmpty, state);
     if (old == kEmpty) { *claimed = true; return (int)h; }
     if (old == state) { *claimed = false; return (int)h; }
     h = (h + 1) & mask;
@@ -290,7 +302,7 @@ struct Table {
     unsigned h = hash_state(state) & (kHL - 1);
     for (int probe = 0; probe < kProbe; probe++) {
       int k = K3_LLD(&lkey[h]); bool cl = false;
-      if (k == kEmpty) { const int old = atomicCAS(&lkey[h], kEmpty, state); if (old == kEmpty) { cl = true; k = state; } else k = old; }
+      if (k == kEmpty) { const int old = k3a_cas(&lkey[h], kEmpty, state); if (old == kEmpty) { cl = true; k = state; } else k = old; }
       if (k == state) { *claimed = cl; return (int)h; }
       h = (h + 1) & (kHL - 1);
     }
@@ -308,7 +320,7 @@ struct Table {
     const int gs = slot_find(g, gmask, state);
     return gs < 0 ? -1 : kHL + gs;
   }
-  __device__ __forceinline__ unsigned cost_min(int id, unsigned e) const { return id < kHL ? atomicMin(&lcost[id], e) : atomicMin(&g[id - kHL].cost, e); }
+  __device__ __forceinline__ unsigned cost_min(int id, unsigned e) const { return id < kHL ? k3a_min(&lcost[id], e) : k3a_min(&g[id - kHL].cost, e); }
   __device__ __forceinline__ unsigned cost(int id) const { return id < kHL ? K3_LLD(&lcost[id]) : K3_ALD(&g[id - kHL].cost); }
   __device__ __forceinline__ int key(int id) const { return id < kHL ? K3_LLD(&lkey[id]) : K3_ALD(&g[id - kHL].key); }
   __device__ __forceinline__ int tok(int id) const { return id < kHL ? K3_LLD(&ltok[id]) : K3_ALD(&g[id - kHL].tok); }
@@ -325,8 +337,8 @@ struct Table {
   }
   // true if the slot was not yet queued for round `stamp` (LDS slots: one bit per slot, cleared at the start of every round)
   __device__ __forceinline__ bool mark(int id, int stamp) const {
-    if (id < kHL) { const unsigned bit = 1u << (id & 31); return (atomicOr(&lmark[(stamp % 3) * (kHL / 32) + (id >> 5)], bit) & bit) == 0; }
-    return atomicExch(&g[id - kHL].stamp, stamp) != stamp;
+    if (id < kHL) { const unsigned bit = 1u << (id & 31); return (k3a_or(&lmark[(stamp % 3) * (kHL / 32) + (id >> 5)], bit) & bit) == 0; }
+    return k3a_exch(&g[id - kHL].stamp, stamp) != stamp;
   }
   __device__ __forceinline__ void clear(int id) const {
     if (id < kHL) { lkey[id] = kEmpty; lcost[id] = kEncMax; ltok[id] = -1; }
@@ -352,8 +364,8 @@ __device__ __forceinline__ unsigned block_select_kth(ForKeys &&for_keys, int k, 
       const int d0 = __shfl(d, mv ? __ffsll((long long)mv) - 1 : 0);
       const unsigned long long diff = __ballot(v && d != d0);
       if (mv != 0) {
-        if (diff == 0) { if (lane == __ffsll((long long)mv) - 1) atomicAdd(&sh.hist[d0], __popcll(mv)); }
-        else if (v) atomicAdd(&sh.hist[d], 1);
+        if (diff == 0) { if (lane == __ffsll((long long)mv) - 1) k3a_add(&sh.hist[d0], __popcll(mv)); }
+        else if (v) k3a_add(&sh.hist[d], 1);
       }
     });
     __syncthreads();
@@ -421,7 +433,7 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
           const int st = tb.key(slot); q.ti = tb.tok(slot);
           const int2 a = p.offs[st], b = p.offs[st + 1]; q.ay = a.y; q.bx = b.x;
           // a token is expanded once per cost value: tok_cost holds the cost of its latest expansion until the frame is published
-          q.prev = atomicExch(&tok_cost[nb + q.ti], q.cb);
+          q.prev = k3a_exch(&tok_cost[nb + q.ti], q.cb);
         }
       }
       return q;
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
           pass = tot < next0;
         }
         const unsigned wm = wave_min_u32(pass ? enc(tot) : kEncMax);
-        if (lane == 0 && wm != kEncMax) atomicMin(&sh.min_tot, wm);
+        if (lane == 0 && wm != kEncMax) k3a_min(&sh.min_tot, wm);
         const int pos = wave_append(pass, &sh.n_cand);
         if (pass) {
           if (pos < p.frame_cands_cap) { c_tot[pos] = tot; c_ac[pos] = ac; c_dst[pos] = nxt; c_arc[pos] = arc; c_src[pos] = ot; }
@@ -764,7 +776,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     if (tid == 0 && f >= 0) { const long long now__ = (long long)__builtin_readcyclecounter(); st_ab[f] = (float)(now__ - t_frame__); t_frame__ = now__; }   // profiling builds only: FrameStats' adaptive_beam column = cycles of the frame
 #endif
   }
-  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { atomicAdd(&sh.n_eps, a); atomicAdd(&sh.n_emit, b); atomicAdd(&sh.n_os, c); } }
+  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { k3a_add(&sh.n_eps, a); k3a_add(&sh.n_emit, b); k3a_add(&sh.n_os, c); } }
   __syncthreads();
 #ifdef K3_DEC_PROF
   if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
@@ -821,15 +833,15 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
 #endif
   int *live_tok = p.live_tok + (long long)L * p.live_cap; long long *live_link = p.live_link + (long long)L * p.live_cap;
   int *newidx = p.newidx + (long long)L * p.lane_tokens_cap;
-  auto keep_tok = [&](long long t) { const int pos = atomicAdd(&s_nt, 1); if (pos < p.live_cap) live_tok[pos] = (int)t; newidx[t] = pos; };
-  auto keep_link = [&](long long l) { const int pos = atomicAdd(&s_nl, 1); if (pos < p.live_cap) live_link[pos] = l; };
+  auto keep_tok = [&](long long t) { const int pos = k3a_add(&s_nt, 1); if (pos < p.live_cap) live_tok[pos] = (int)t; newidx[t] = pos; };
+  auto keep_link = [&](long long l) { const int pos = k3a_add(&s_nl, 1); if (pos < p.live_cap) live_link[pos] = l; };
   // ---- last frame: ComputeFinalCosts (:545-586) + PruneForwardLinksFinal (:385-467), in HBM (one frame only)
   const long long tb = tok_off[T], te = tok_off[T + 1];
   if (tid == 0) { s_best = kEncMax; s_best_final = kEncMax; s_has_final = 0; }
   __syncthreads();
   for (long long t = tb + tid; t < te; t += kPBlock) {
     const float c = dec(tok_cost[t]), fc = p.final_cost[tok_state[t]];
-    atomicMin(&s_best, enc(c)); atomicMin(&s_best_final, enc(c + fc));
+    k3a_min(&s_best, enc(c)); k3a_min(&s_best_final, enc(c + fc));
     if (fc != kInf) s_has_final = 1;
   }
   __syncthreads();
@@ -875,7 +887,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
         const Link k = links[l];
         if (!eps_link_live(k, tok_cost[k.src])) continue;
         float le = link_extra_cost(extra[k.dst], k.tot, dec(tok_cost[k.dst]));
-        if (!(le > lb)) { if (le < 0.0f) le = 0.0f; atomicMin(&xn[k.src - tb], enc(le)); }
+        if (!(le > lb)) { if (le < 0.0f) le = 0.0f; k3a_min(&xn[k.src - tb], enc(le)); }
       }
       __syncthreads();
       for (long long t = tb + tid; t < te; t += kPBlock) {
@@ -953,7 +965,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
       K3_PT(1);    // staging
       auto emit_link = [&](const Link &k, long long l) {
         float le = link_extra_cost(nextra[k.dst - b1], k.tot, ncost[k.dst - b1]);
-        if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; atomicMin(&s_xb[k.src - b0], enc(le)); }     // a surviving emitting link keeps its source alive
+        if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; k3a_min(&s_xb[k.src - b0], enc(le)); }     // a surviving emitting link keeps its source alive
       };
 #pragma unroll
       for (int k = 0; k < kPre; k++) { const long long l = e0 + tid + k * kPBlock; if (l < e1) emit_link(pl[k], l); }
@@ -977,14 +989,14 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
           for (int k = 0; k < kEpsRegs; k++) {
             if (elive >> k & 1) {
               float le = link_extra_cost(dec(K3_LLD(&s_xb[er[k].dst - b0])), er[k].tot, ccost[er[k].dst - b0]);
-              if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < atomicMin(&s_xb[er[k].src - b0], e)) moved = true; }
+              if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < k3a_min(&s_xb[er[k].src - b0], e)) moved = true; }
             }
           }
           for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) {       // (rare) more eps links than fit in registers
             const Link k = links[l];
             if (!eps_link_live(k, enc(ccost[k.src - b0]))) continue;
             float le = link_extra_cost(dec(K3_LLD(&s_xb[k.dst - b0])), k.tot, ccost[k.dst - b0]);
-            if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < atomicMin(&s_xb[k.src - b0], e)) moved = true; }
+            if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < k3a_min(&s_xb[k.src - b0], e)) moved = true; }
           }
           if (moved) s_chg[sweep & 3] = 1;
           if (tid == 0) s_chg[(sweep + 2) & 3] = 0;      // read last after the barrier of sweep - 2: every wavefront is past it
@@ -1031,7 +1043,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
 #pragma unroll
       for (int j = 0; j < kB; j++) {
         const long long l = l0 + j * kPBlock;
-        if (l < e1) { float le = link_extra_cost(xe[j], k[j].tot, xc[j]); if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; atomicMin(&x[k[j].src - b0], enc(le)); } }
+        if (l < e1) { float le = link_extra_cost(xe[j], k[j].tot, xc[j]); if (!(le > lb)) { keep_link(l); if (le < 0.0f) le = 0.0f; k3a_min(&x[k[j].src - b0], enc(le)); } }
       }
     }
     __syncthreads();
@@ -1051,7 +1063,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
             const long long l = l0 + j * kPBlock;
             if (l < n1 && eps_link_live(k[j], sc[j])) {
               float le = link_extra_cost(dec(xd[j]), k[j].tot, dc[j]);
-              if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < atomicMin(&x[k[j].src - b0], e)) s_changed = 1; }
+              if (!(le > lb)) { if (le < 0.0f) le = 0.0f; const unsigned e = enc(le); if (e < k3a_min(&x[k[j].src - b0], e)) s_changed = 1; }
             }
           }
         }
@@ -1200,12 +1212,12 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_best_path_kernel(DecParams 
   const long long tb = tok_off[T], te = tok_off[T + 1];
   if (tid == 0) { s_min = kEncMax; s_minf = kEncMax; s_best = ~0ull; }
   __syncthreads();
-  for (long long t = tb + tid; t < te; t += kPBlock) { const float c = dec(tok_cost[t]); atomicMin(&s_min, enc(c)); atomicMin(&s_minf, enc(c + p.final_cost[tok_state[t]])); }
+  for (long long t = tb + tid; t < te; t += kPBlock) { const float c = dec(tok_cost[t]); k3a_min(&s_min, enc(c)); k3a_min(&s_minf, enc(c + p.final_cost[tok_state[t]])); }
   __syncthreads();
   const bool any_final = s_minf != kEncMax && dec(s_minf) != kInf; const bool with_final = o.use_final && any_final;
   for (long long t = tb + tid; t < te; t += kPBlock) {
     const float c = dec(tok_cost[t]); const float v = with_final ? c + p.final_cost[tok_state[t]] : c;
-    atomicMin(&s_best, ((unsigned long long)enc(v) << 32) | (unsigned)(t - tb));
+    k3a_min(&s_best, ((unsigned long long)enc(v) << 32) | (unsigned)(t - tb));
   }
   __syncthreads();
   if (te == tb) return;
@@ -1220,7 +1232,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_best_path_kernel(DecParams 
     // an eps link of frame f into cur (source in the same frame), stamped with its source's final cost (live), whose tot is cur's cost
     for (long long l = loff_n[f] + tid; l < loff_e[f]; l += kPBlock) {
       const Link k = links[l];
-      if (k.dst == (unsigned)cur && __float_as_uint(k.tot) == __float_as_uint(dec(cc)) && eps_link_live(k, tok_cost[k.src])) atomicMin((unsigned long long *)&s_link, (unsigned long long)l);
+      if (k.dst == (unsigned)cur && __float_as_uint(k.tot) == __float_as_uint(dec(cc)) && eps_link_live(k, tok_cost[k.src])) k3a_min((unsigned long long *)&s_link, (unsigned long long)l);
     }
     __syncthreads();
     long long best = s_link; bool emitting = false;
@@ -1228,7 +1240,7 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_best_path_kernel(DecParams 
       __syncthreads();
       for (long long l = loff_e[f - 1] + tid; l < loff_n[f]; l += kPBlock) {
         const Link k = links[l];
-        if (k.dst == (unsigned)cur && __float_as_uint(k.tot) == __float_as_uint(dec(cc))) atomicMin((unsigned long long *)&s_link, (unsigned long long)l);
+        if (k.dst == (unsigned)cur && __float_as_uint(k.tot) == __float_as_uint(dec(cc))) k3a_min((unsigned long long *)&s_link, (unsigned long long)l);
       }
       __syncthreads();
       best = s_link; emitting = true;
@@ -1422,44 +1434,30 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     p.hash_cap = (int)std::max<double>(1000.0, std::ceil((double)cap * cfg->hash_ratio) + 1.0);
     p.seq_words_cap = (int)((8 * (size_t)cfg->frame_cands_cap + cap) / 32 + 64);      // labels: emitting arcs expanded on a frame + tokens its closure creates
     p.eps_cap = cfg->frame_cands_cap; p.stack_cap = 4 * cfg->frame_tokens_cap;
-    if ((rc = dmalloc(&d->allocs, &p.lt_order, 2 * nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_by_ins, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_label, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_dense, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_grp, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_lead, nl * (cap + 1)))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_bm, nl * p.seq_words_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_wpre, nl * p.seq_words_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_bfirst, nl * p.hash_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_bcnt, nl * p.hash_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_bfill, nl * p.hash_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_cmin, 2 * nl * nch))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_ccnt, 2 * nl * nch))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_c0, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_crng, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_cdst, nl * p.eps_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_cw, nl * p.eps_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_rcost, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_rflag, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_rown, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_stack, nl * p.stack_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_iq, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_arcs2, nl * p.eps_cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_meta, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_c2t, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_par, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_rtmp, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_rlist, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_wcomp, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_cinfo, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_coffs, nl * cap))) return rc;
-    if ((rc = dmalloc(&d->allocs, &p.lt_rinfo, nl * cap))) return rc;
+    // one arena, LANE-major: a lane's scratch arrays are neighbours in memory (a workgroup touches the first few KB of every one of them on
+    // every frame; as separate allocations that was ~45 distant pages per lane, and the address translation dominated the memory latency)
+    size_t off = 0;
+    auto place = [&](auto **ptr, size_t count) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(off); off += (count * sizeof(T) + 255) & ~(size_t)255; };
+    place(&p.lt_order, 2 * cap); place(&p.lt_label, cap); place(&p.lt_c0, cap); place(&p.lt_rflag, cap); place(&p.lt_rown, cap); place(&p.lt_grp, cap); place(&p.lt_lead, cap + 1);
+    place(&p.lt_crng, cap); place(&p.lt_c2t, cap); place(&p.lt_iq, cap); place(&p.lt_dense, cap); place(&p.lt_by_ins, cap); place(&p.lt_meta, cap); place(&p.lt_rcost, cap);
+    place(&p.lt_par, cap); place(&p.lt_rtmp, cap); place(&p.lt_rlist, cap); place(&p.lt_wcomp, cap); place(&p.lt_cinfo, cap); place(&p.lt_coffs, cap); place(&p.lt_rinfo, cap);
+    place(&p.lt_cmin, 2 * nch); place(&p.lt_ccnt, 2 * nch); place(&p.lt_cdst, (size_t)p.eps_cap); place(&p.lt_cw, (size_t)p.eps_cap); place(&p.lt_arcs2, (size_t)p.eps_cap);
+    place(&p.lt_stack, (size_t)p.stack_cap); place(&p.lt_bm, (size_t)p.seq_words_cap); place(&p.lt_wpre, (size_t)p.seq_words_cap);
+    place(&p.lt_bfirst, (size_t)p.hash_cap); place(&p.lt_bcnt, (size_t)p.hash_cap); place(&p.lt_bfill, (size_t)p.hash_cap);
+    p.lt_lane_bytes = (long long)((off + 4095) & ~(size_t)4095);
+    char *arena = nullptr;
+    if ((rc = dmalloc(&d->allocs, &arena, nl * (size_t)p.lt_lane_bytes))) return rc;
+    auto rebase = [&](auto **ptr) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(arena + reinterpret_cast<size_t>(*ptr)); };
+    rebase(&p.lt_order); rebase(&p.lt_label); rebase(&p.lt_c0); rebase(&p.lt_rflag); rebase(&p.lt_rown); rebase(&p.lt_grp); rebase(&p.lt_lead); rebase(&p.lt_crng); rebase(&p.lt_c2t); rebase(&p.lt_iq);
+    rebase(&p.lt_dense); rebase(&p.lt_by_ins); rebase(&p.lt_meta); rebase(&p.lt_rcost); rebase(&p.lt_par); rebase(&p.lt_rtmp); rebase(&p.lt_rlist); rebase(&p.lt_wcomp); rebase(&p.lt_cinfo); rebase(&p.lt_coffs);
+    rebase(&p.lt_rinfo); rebase(&p.lt_cmin); rebase(&p.lt_ccnt); rebase(&p.lt_cdst); rebase(&p.lt_cw); rebase(&p.lt_arcs2); rebase(&p.lt_stack); rebase(&p.lt_bm); rebase(&p.lt_wpre); rebase(&p.lt_bfirst);
+    rebase(&p.lt_bcnt); rebase(&p.lt_bfill);
     // idle patterns of the scratch: labels / bucket firsts all ones, bitmap / bucket counters zero
-    K3_HIP_CHECK(hipMemset(p.lt_label, 0xFF, nl * cap * sizeof(unsigned)));
-    K3_HIP_CHECK(hipMemset(p.lt_bm, 0, nl * p.seq_words_cap * sizeof(unsigned)));
-    K3_HIP_CHECK(hipMemset(p.lt_bfirst, 0xFF, nl * p.hash_cap * sizeof(unsigned)));
-    K3_HIP_CHECK(hipMemset(p.lt_bcnt, 0, nl * p.hash_cap * sizeof(unsigned)));
-    K3_HIP_CHECK(hipMemset(p.lt_bfill, 0, nl * p.hash_cap * sizeof(unsigned)));
+    K3_HIP_CHECK(hipMemset2D(p.lt_label, (size_t)p.lt_lane_bytes, 0xFF, cap * sizeof(unsigned), nl));
+    K3_HIP_CHECK(hipMemset2D(p.lt_bm, (size_t)p.lt_lane_bytes, 0, (size_t)p.seq_words_cap * sizeof(unsigned), nl));
+    K3_HIP_CHECK(hipMemset2D(p.lt_bfirst, (size_t)p.lt_lane_bytes, 0xFF, (size_t)p.hash_cap * sizeof(unsigned), nl));
+    K3_HIP_CHECK(hipMemset2D(p.lt_bcnt, (size_t)p.lt_lane_bytes, 0, (size_t)p.hash_cap * sizeof(unsigned), nl));
+    K3_HIP_CHECK(hipMemset2D(p.lt_bfill, (size_t)p.lt_lane_bytes, 0, (size_t)p.hash_cap * sizeof(unsigned), nl));
     K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitDynLds));
   }
   // empty table: key = -1, cost = max, tok = -1, stamp = 0
@@ -1761,7 +1759,8 @@ extern "C" int k3_decoder_phase_cycles(k3_decoder *d, int64_t *h_cycles /* [16] 
   K3_REQUIRE(d && h_cycles, "k3_decoder_phase_cycles: null argument");
   std::vector<long long> h((size_t)d->nlanes * 16);
   K3_HIP_CHECK(hipMemcpy(h.data(), d->p.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  for (int i = 0; i < 16; i++) { h_cycles[i] = 0; for (int l = 0; l < d->nlanes; l++) h_cycles[i] += h[(size_t)l * 16 + i]; }
+  const bool mx = getenv("K3_PROF_MAX") != nullptr;      // profiling builds: the slowest lane instead of the sum
+  for (int i = 0; i < 16; i++) { h_cycles[i] = 0; for (int l = 0; l < d->nlanes; l++) h_cycles[i] = mx ? std::max<int64_t>(h_cycles[i], h[(size_t)l * 16 + i]) : h_cycles[i] + h[(size_t)l * 16 + i]; }
   K3_HIP_CHECK(hipMemset(d->p.prof, 0, h.size() * sizeof(long long)));
   return K3_OK;
 }

@@ -20,9 +20,29 @@
 // Capacities: frame_tokens_cap <= 65536; arcs expanded + tokens created on one frame <= 32 * seq_words_cap.
 
 constexpr int kRN = kHL / 2, kRA = 2048, kRS = 1024;      // replay fully in LDS: closure ids (cost + meta alias the level-1 table: kHL x 12 B) / passing arcs / stack entries
-constexpr size_t kLitDynLds = (size_t)kRA * 8 + (size_t)kRS * 4;      // replay in LDS: tokens / closure arcs / stack entries of a frame (larger frames: HBM scratch)
+constexpr size_t kLitDynLds = (size_t)kRA * 8 + (size_t)kRS * 4;      // (the hash-order passes use the same segment between replays: kHoLds below)      // replay in LDS: tokens / closure arcs / stack entries of a frame (larger frames: HBM scratch)
 constexpr unsigned kLabelNone = 0xFFFFFFFFu;
 enum { kRfHasEps = 1, kRfExists = 2 };
+
+// -DK3_LIT_PROF=1: cycles per phase of a frame (K3_LT);  =2: cycles per sub-phase of the two hash-order passes and the component replay (K3_LS)
+// -DK3_LIT_PROF_MINTOK=a -DK3_LIT_PROF_MAXTOK=b: only frames built from a..b tokens are counted (sh.prof_n = the frame's n_cur)
+#ifndef K3_LIT_PROF_MINTOK
+#define K3_LIT_PROF_MINTOK 0
+#endif
+#ifndef K3_LIT_PROF_MAXTOK
+#define K3_LIT_PROF_MAXTOK 0x7FFFFFFF
+#endif
+#define K3_LP_ON (sh.prof_n >= K3_LIT_PROF_MINTOK && sh.prof_n <= K3_LIT_PROF_MAXTOK)
+#if defined(K3_LIT_PROF) && K3_LIT_PROF == 2
+#define K3_LT(i) do { if (threadIdx.x == 0) lt_last__ = (long long)__builtin_readcyclecounter(); } while (0)
+#define K3_LS(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); if (K3_LP_ON) sh.prof[i] += now__ - lt_last__; lt_last__ = now__; } } while (0)
+#elif defined(K3_LIT_PROF)
+#define K3_LT(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); if (K3_LP_ON) sh.prof[i] += now__ - lt_last__; lt_last__ = now__; } } while (0)
+#define K3_LS(i) do { } while (0)
+#else
+#define K3_LT(i) do { } while (0)
+#define K3_LS(i) do { } while (0)
+#endif
 
 // inclusive prefix sum over the wavefront with DPP row shifts / row broadcasts (no LDS-crossbar round trips)
 __device__ __forceinline__ int wave_incl_scan(int v) {
@@ -39,6 +59,23 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 template <typename In>
 __device__ __forceinline__ int block_excl_scan(In &&in, unsigned *out, int n, int *redi) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)blockDim.x >> 6;
+  const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+  if (per <= 4) {      // the usual frame: every thread takes `per` consecutive items (their loads are in flight together), one pass, two barriers
+    const int b = tid * per; int x[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[k] = (k < per && b + k < n) ? (int)in(b + k) : 0; sum += x[k]; }
+    const int incl = wave_incl_scan(sum);
+    __syncthreads();
+    if (lane == 63) redi[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < nw; w++) { const int s = redi[w]; if (w < wave) woff += s; tot += s; }
+    int run = woff + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (k < per && b + k < n) { out[b + k] = (unsigned)run; run += x[k]; }
+    __syncthreads();
+    return tot;
+  }
   int carry = 0;
   for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
     const int i = i0 + tid; const int x = i < n ? (int)in(i) : 0;
@@ -59,17 +96,38 @@ __device__ __forceinline__ int block_excl_scan(In &&in, unsigned *out, int n, in
 template <typename In, typename Out>
 __device__ __forceinline__ int4 block_excl_scan4(In &&in, Out &&out, int n, int4 *red4) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)blockDim.x >> 6;
-  int4 carry = make_int4(0, 0, 0, 0);
-  for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
-    const int i = i0 + tid; const int4 x = i < n ? in(i) : make_int4(0, 0, 0, 0);
-    const int4 incl = make_int4(wave_incl_scan(x.x), wave_incl_scan(x.y), wave_incl_scan(x.z), wave_incl_scan(x.w));
+  const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+  auto add = [](int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+  auto sub = [](int4 a, int4 b) { return make_int4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+  auto wscan = [](int4 a) { return make_int4(wave_incl_scan(a.x), wave_incl_scan(a.y), wave_incl_scan(a.z), wave_incl_scan(a.w)); };
+  const int4 zero = make_int4(0, 0, 0, 0);
+  if (per <= 4) {
+    const int b = tid * per; int4 x[4], sum = zero;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[k] = (k < per && b + k < n) ? in(b + k) : zero; sum = add(sum, x[k]); }
+    const int4 incl = wscan(sum);
     __syncthreads();
     if (lane == 63) red4[wave] = incl;
     __syncthreads();
-    int4 woff = make_int4(0, 0, 0, 0), tot = make_int4(0, 0, 0, 0);
-    for (int w = 0; w < nw; w++) { const int4 s = red4[w]; if (w < wave) { woff.x += s.x; woff.y += s.y; woff.z += s.z; woff.w += s.w; } tot.x += s.x; tot.y += s.y; tot.z += s.z; tot.w += s.w; }
-    if (i < n) out(i, make_int4(carry.x + woff.x + incl.x - x.x, carry.y + woff.y + incl.y - x.y, carry.z + woff.z + incl.z - x.z, carry.w + woff.w + incl.w - x.w));
-    carry.x += tot.x; carry.y += tot.y; carry.z += tot.z; carry.w += tot.w;
+    int4 woff = zero, tot = zero;
+    for (int w = 0; w < nw; w++) { const int4 s = red4[w]; if (w < wave) woff = add(woff, s); tot = add(tot, s); }
+    int4 run = sub(add(woff, incl), sum);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (k < per && b + k < n) { out(b + k, run); run = add(run, x[k]); }
+    __syncthreads();
+    return tot;
+  }
+  int4 carry = zero;
+  for (int i0 = 0; i0 < n; i0 += (int)blockDim.x) {
+    const int i = i0 + tid; const int4 x = i < n ? in(i) : zero;
+    const int4 incl = wscan(x);
+    __syncthreads();
+    if (lane == 63) red4[wave] = incl;
+    __syncthreads();
+    int4 woff = zero, tot = zero;
+    for (int w = 0; w < nw; w++) { const int4 s = red4[w]; if (w < wave) woff = add(woff, s); tot = add(tot, s); }
+    if (i < n) out(i, sub(add(add(carry, woff), incl), x));
+    carry = add(carry, tot);
   }
   __syncthreads();
   return carry;
@@ -102,37 +160,43 @@ struct LitLane {      // this lane's slices of the literal_order scratch
   int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *bfirst, *bcnt, *bfill, *cmin; float *c0, *cw, *rcost; int2 *crng, *arcs2; int4 *meta; int *iq, *c2t;
   int *par, *rtmp, *rlist, *wcomp; int4 *cinfo, *coffs; int2 *rinfo;      // component replay (below)
   __device__ LitLane(const DecParams &p, int L) {
-    const long long cap = p.frame_tokens_cap, nch = cap / 64 + 2;
-    order[0] = p.lt_order + 2ll * L * cap; order[1] = order[0] + cap; by_ins = p.lt_by_ins + L * cap; dense = p.lt_dense + L * cap; grp = p.lt_grp + L * cap;
-    label = p.lt_label + L * cap; lead = p.lt_lead + L * (cap + 1); bm = p.lt_bm + (long long)L * p.seq_words_cap; wpre = p.lt_wpre + (long long)L * p.seq_words_cap;
-    bfirst = p.lt_bfirst + (long long)L * p.hash_cap; bcnt = p.lt_bcnt + (long long)L * p.hash_cap; bfill = p.lt_bfill + (long long)L * p.hash_cap;
-    cmin = p.lt_cmin + 2ll * L * nch; ccnt = p.lt_ccnt + 2ll * L * nch; c0 = p.lt_c0 + L * cap; crng = p.lt_crng + L * cap;
-    cdst = p.lt_cdst + (long long)L * p.eps_cap; cw = p.lt_cw + (long long)L * p.eps_cap; rcost = p.lt_rcost + L * cap; rflag = p.lt_rflag + L * cap; rown = p.lt_rown + L * cap;
-    stack = p.lt_stack + (long long)L * p.stack_cap; arcs2 = p.lt_arcs2 + (long long)L * p.eps_cap; iq = p.lt_iq + L * cap; meta = p.lt_meta + L * cap; c2t = p.lt_c2t + L * cap;
-    par = p.lt_par + L * cap; rtmp = p.lt_rtmp + L * cap; rlist = p.lt_rlist + L * cap; wcomp = p.lt_wcomp + L * cap; cinfo = p.lt_cinfo + L * cap; coffs = p.lt_coffs + L * cap; rinfo = p.lt_rinfo + L * cap;
+    const long long cap = p.frame_tokens_cap, nch = cap / 64 + 2; const long long lb = p.lt_lane_bytes * L;
+    auto at = [lb](auto *base) { return reinterpret_cast<decltype(base)>(reinterpret_cast<char *>(base) + lb); };
+    order[0] = at(p.lt_order); order[1] = order[0] + cap; by_ins = at(p.lt_by_ins); dense = at(p.lt_dense); grp = at(p.lt_grp);
+    label = at(p.lt_label); lead = at(p.lt_lead); bm = at(p.lt_bm); wpre = at(p.lt_wpre);
+    bfirst = at(p.lt_bfirst); bcnt = at(p.lt_bcnt); bfill = at(p.lt_bfill);
+    cmin = at(p.lt_cmin); ccnt = at(p.lt_ccnt); c0 = at(p.lt_c0); crng = at(p.lt_crng); (void)nch;
+    cdst = at(p.lt_cdst); cw = at(p.lt_cw); rcost = at(p.lt_rcost); rflag = at(p.lt_rflag); rown = at(p.lt_rown);
+    stack = at(p.lt_stack); arcs2 = at(p.lt_arcs2); iq = at(p.lt_iq); meta = at(p.lt_meta); c2t = at(p.lt_c2t);
+    par = at(p.lt_par); rtmp = at(p.lt_rtmp); rlist = at(p.lt_rlist); wcomp = at(p.lt_wcomp); cinfo = at(p.lt_cinfo); coffs = at(p.lt_coffs); rinfo = at(p.lt_rinfo);
   }
 };
 
 // HashList order of n tokens with unique creation labels < M: order_out[position] = token.  by_ins[d] = token with creation rank d.
-__device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out) {
+__device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, long long &lt_last__) {
   const int tid = threadIdx.x;
   const int W = (int)((M + 31u) >> 5);
-  for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); atomicOr(&q.bm[l >> 5], 1u << (l & 31)); }
+  for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); k3a_or(&q.bm[l >> 5], 1u << (l & 31)); }
   __syncthreads();
+  K3_LS(0);
   block_excl_scan([&](int w) { return __popc(K3_ALD(&q.bm[w])); }, q.wpre, W, sh.redi);
+  K3_LS(1);
   for (int i = tid; i < n; i += kBlock) {
     const unsigned l = K3_ALD(&q.label[i]); const unsigned wd = K3_ALD(&q.bm[l >> 5]);
     const int d = (int)(q.wpre[l >> 5] + (unsigned)__popc(wd & ((1u << (l & 31)) - 1u)));
     q.dense[i] = d; q.by_ins[d] = i;
-    const unsigned b = (unsigned)st[i] % hash_size; atomicMin(&q.bfirst[b], (unsigned)d); atomicAdd(&q.bcnt[b], 1u);
+    const unsigned b = (unsigned)st[i] % hash_size; k3a_min(&q.bfirst[b], (unsigned)d); k3a_add(&q.bcnt[b], 1u);
   }
   __syncthreads();
+  K3_LS(2);
   block_excl_scan([&](int d) { const unsigned b = (unsigned)st[q.by_ins[d]] % hash_size; return K3_ALD(&q.bfirst[b]) == (unsigned)d ? K3_ALD(&q.bcnt[b]) : 0u; }, q.lead, n, sh.redi);
+  K3_LS(3);
   for (int i = tid; i < n; i += kBlock) {
     const unsigned b = (unsigned)st[i] % hash_size;
-    if (K3_ALD(&q.bcnt[b]) > 1u) { const unsigned lp = q.lead[K3_ALD(&q.bfirst[b])]; const unsigned s = atomicAdd(&q.bfill[b], 1u); q.grp[lp + s] = q.dense[i]; }
+    if (K3_ALD(&q.bcnt[b]) > 1u) { const unsigned lp = q.lead[K3_ALD(&q.bfirst[b])]; const unsigned s = k3a_add(&q.bfill[b], 1u); q.grp[lp + s] = q.dense[i]; }
   }
   __syncthreads();
+  K3_LS(4);
   for (int i = tid; i < n; i += kBlock) {
     const unsigned b = (unsigned)st[i] % hash_size; const unsigned cnt = K3_ALD(&q.bcnt[b]), lp = q.lead[K3_ALD(&q.bfirst[b])];
     unsigned rank = 0;
@@ -140,13 +204,97 @@ __device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int
     order_out[lp + rank] = i;
   }
   __syncthreads();
+  K3_LS(5);
   for (int i = tid; i < n; i += kBlock) {      // scratch back to its idle pattern
     const unsigned l = K3_ALD(&q.label[i]); const unsigned b = (unsigned)st[i] % hash_size;
     K3_AST(&q.bm[l >> 5], 0u); K3_AST(&q.bfirst[b], kLabelNone); K3_AST(&q.bcnt[b], 0u); K3_AST(&q.bfill[b], 0u);
   }
   __syncthreads();
+  K3_LS(6);
 }
 
+// The same for the usual frame (n <= kHoN tokens, labels < kHoM): label bitmap, leader offsets and bucket groups live in LDS (`arena`, kHoLds
+// bytes), a thread keeps its <= 4 tokens in registers across the phases, and global memory is touched three times -- the labels (one
+// stream), the bucket heads (hash_size is unbounded: min rank / count by atomics, then read back) and the result.
+constexpr int kHoN = 2048, kHoM = 16384;
+constexpr size_t kHoLds = (size_t)(kHoM / 32) * 4 + (size_t)(kHoM / 32) * 2 + 2 * (size_t)kHoN * 2;
+__device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins,
+                                                   char *arena, long long &lt_last__) {
+  static_assert(kHoN <= 4 * kBlock && kHoM / 32 <= kBlock, "one pass per phase");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
+  const int W = (int)((M + 31u) >> 5);
+  unsigned *s_bm = reinterpret_cast<unsigned *>(arena); unsigned short *s_wpre = reinterpret_cast<unsigned short *>(s_bm + kHoM / 32), *s_lead = s_wpre + kHoM / 32, *s_grp = s_lead + kHoN;
+  unsigned lab[4], bkt[4], lf[4], cnt[4]; int d[4];
+  if (tid < W) s_bm[tid] = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { lab[k] = K3_ALD(&q.label[i]); bkt[k] = (unsigned)st[i] % hash_size; } }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) atomicOr(&s_bm[lab[k] >> 5], 1u << (lab[k] & 31)); }
+  __syncthreads();
+  K3_LS(0);
+  {      // exclusive prefix count over the bitmap words (W <= kBlock: one word per thread)
+    const int x = tid < W ? __popc(s_bm[tid]) : 0; const int incl = wave_incl_scan(x);
+    if (lane == 63) sh.redi[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < nw; w++) if (w < wave) woff += sh.redi[w];
+    if (tid < W) s_wpre[tid] = (unsigned short)(woff + incl - x);
+    __syncthreads();
+  }
+  K3_LS(1);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = tid + k * kBlock;
+    if (i < n) {
+      const unsigned l = lab[k]; d[k] = (int)s_wpre[l >> 5] + __popc(s_bm[l >> 5] & ((1u << (l & 31)) - 1u));
+      k3a_min(&q.bfirst[bkt[k]], (unsigned)d[k]); k3a_add(&q.bcnt[bkt[k]], 1u);
+      if (write_by_ins) q.by_ins[d[k]] = i;
+    }
+  }
+  __syncthreads();
+  K3_LS(2);
+  bool multi = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { lf[k] = K3_ALD(&q.bfirst[bkt[k]]); cnt[k] = K3_ALD(&q.bcnt[bkt[k]]); } }
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { s_lead[d[k]] = lf[k] == (unsigned)d[k] ? (unsigned short)cnt[k] : (unsigned short)0; multi |= cnt[k] > 1u; } }
+  multi = __syncthreads_or(multi);
+  {      // exclusive scan of the leaders' bucket sizes in creation order, in place (4 consecutive ranks per thread)
+    const int b0 = tid * 4; int x[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[k] = b0 + k < n ? (int)s_lead[b0 + k] : 0; sum += x[k]; }
+    const int incl = wave_incl_scan(sum);
+    if (lane == 63) sh.redi[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < nw; w++) if (w < wave) run += sh.redi[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (b0 + k < n) { s_lead[b0 + k] = (unsigned short)run; run += x[k]; }
+    __syncthreads();
+  }
+  K3_LS(3);
+  if (multi) {      // buckets with several tokens: their members' ranks, grouped behind the leader's offset
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n && cnt[k] > 1u) { const unsigned s_ = k3a_add(&q.bfill[bkt[k]], 1u); s_grp[s_lead[lf[k]] + s_] = (unsigned short)d[k]; } }
+    __syncthreads();
+  }
+  K3_LS(4);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = tid + k * kBlock;
+    if (i < n) {
+      const unsigned lp = s_lead[lf[k]]; unsigned rank = 0;
+      if (cnt[k] > 1u) for (unsigned t = 0; t < cnt[k]; t++) rank += (int)s_grp[lp + t] < d[k];
+      order_out[lp + rank] = i;
+      K3_AST(&q.bfirst[bkt[k]], kLabelNone); K3_AST(&q.bcnt[bkt[k]], 0u); if (cnt[k] > 1u) K3_AST(&q.bfill[bkt[k]], 0u);      // scratch back to its idle pattern
+    }
+  }
+  __syncthreads();
+  K3_LS(5);
+}
+
+static_assert(kHoLds <= kLitDynLds, "the hash-order arena lives in the replay's dynamic segment");
 struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 
 // The replay loop.  MODE 0: costs, meta, arcs, stack and the creation list in LDS; MODE 1: costs, stack and list in LDS, meta / arcs read-only
@@ -247,7 +395,7 @@ template <typename P> __device__ __forceinline__ void uf_union(P par, int a, int
     a = uf_find(par, a); b = uf_find(par, b);
     if (a == b) return;
     if (a < b) { const int t = a; a = b; b = t; }
-    if (atomicCAS(&par[a], a, b) == a) return;
+    if (k3a_cas(&par[a], a, b) == a) return;
   }
 }
 
@@ -288,34 +436,38 @@ __device__ __forceinline__ bool lit_replay_component(RC rcost, MT meta, AT AR, C
 // created, or -1 when the frame has to take the serial replay (rcost / clist are then in an undefined state).
 template <typename RC, typename MT, typename AT, typename CL, typename P>
 __device__ __forceinline__ int lit_replay_components(const DecParams &p, const LitLane &q, Shared &sh, int *s_flag, RC rcost, MT meta, AT AR, CL clist, P par,
-                                                     int n_cid, int n_arc, int n_iq, unsigned m_e, float accept) {
+                                                     int n_cid, int n_arc, int n_iq, unsigned m_e, float accept, long long &lt_last__) {
   const int tid = threadIdx.x; const float kInf = __builtin_inff();
   int4 *red4 = reinterpret_cast<int4 *>(sh.hist);
   if (n_arc > p.stack_cap) return -1;
   for (int c = tid; c < n_cid; c += kBlock) { K3_AST(&par[c], c); int *ci = reinterpret_cast<int *>(&q.cinfo[c]); K3_AST(&ci[0], 0); K3_AST(&ci[1], 0); K3_AST(&ci[2], 0); K3_AST(&ci[3], 0); }
   if (tid == 0) *s_flag = 0;
   __syncthreads();
+  K3_LS(7);
   for (int c = tid; c < n_cid; c += kBlock) {
     const int4 mt = meta[c];
     for (int a = 0; a < mt.y; a++) uf_union(par, c, a == 0 ? mt.z : AR[mt.x + a].x);
   }
   __syncthreads();
+  K3_LS(8);
   // per component (indexed by its root id): roots of the initial queue, tokens the closure creates, passing arcs
   for (int c = tid; c < n_cid; c += kBlock) {
     const int r = uf_find(par, c); if (r != c) K3_AST(&par[c], r);
     int *ci = reinterpret_cast<int *>(&q.cinfo[r]);
-    if (rcost[c] == kInf) atomicAdd(&ci[1], 1);
-    const int pc = meta[c].y; if (pc > 0) atomicAdd(&ci[2], pc);
+    if (rcost[c] == kInf) k3a_add(&ci[1], 1);
+    const int pc = meta[c].y; if (pc > 0) k3a_add(&ci[2], pc);
   }
-  for (int k = tid; k < n_iq; k += kBlock) { const int r = uf_find(par, q.iq[k]); atomicAdd(reinterpret_cast<int *>(&q.cinfo[r]), 1); }
+  for (int k = tid; k < n_iq; k += kBlock) { const int r = uf_find(par, q.iq[k]); k3a_add(reinterpret_cast<int *>(&q.cinfo[r]), 1); }
   __syncthreads();
+  K3_LS(9);
   const int4 tot = block_excl_scan4([&](int c) { const int *ci = reinterpret_cast<const int *>(&q.cinfo[c]); const int rc_ = K3_ALD(&ci[0]); return make_int4(rc_, K3_ALD(&ci[1]), K3_ALD(&ci[2]), rc_ > 0 ? 1 : 0); },
                                     [&](int c, int4 ex) { q.coffs[c] = ex; if (K3_ALD(reinterpret_cast<const int *>(&q.cinfo[c])) > 0) q.wcomp[ex.w] = c; }, n_cid, red4);
   const int n_workers = tot.w;
+  K3_LS(10);
   // a component's roots in queue order (the queue is consumed from its back: descending k)
   for (int k = tid; k < n_iq; k += kBlock) {
     const int r = uf_find(par, q.iq[k]); int *ci = reinterpret_cast<int *>(&q.cinfo[r]);
-    const int pos = atomicAdd(&ci[3], 1); q.rtmp[q.coffs[r].x + pos] = k;
+    const int pos = k3a_add(&ci[3], 1); q.rtmp[q.coffs[r].x + pos] = k;
   }
   __syncthreads();
   for (int k = tid; k < n_iq; k += kBlock) {
@@ -325,11 +477,13 @@ __device__ __forceinline__ int lit_replay_components(const DecParams &p, const L
     q.rlist[off + rank] = k;
   }
   __syncthreads();
+  K3_LS(11);
   for (int w = tid; w < n_workers; w += kBlock) {
     const int c = q.wcomp[w]; const int4 co = q.coffs[c]; const int *ci = reinterpret_cast<const int *>(&q.cinfo[c]);
     if (!lit_replay_component(rcost, meta, AR, clist, q.iq, q.rlist, q.rinfo, q.stack + co.z, K3_ALD(&ci[2]), co.x, K3_ALD(&ci[0]), co.y, accept)) *s_flag = 1;
   }
   __syncthreads();
+  K3_LS(12);
   if (*s_flag) return -1;
   // creation labels: roots in queue order (j-th root processed = position n_iq - 1 - j), tokens of a root in the order it created them
   const int created = block_excl_scan([&](int j) { return (unsigned)q.rinfo[n_iq - 1 - j].y; }, reinterpret_cast<unsigned *>(q.dense), n_iq, sh.redi);
@@ -337,14 +491,9 @@ __device__ __forceinline__ int lit_replay_components(const DecParams &p, const L
     const int2 ri = q.rinfo[n_iq - 1 - j]; const unsigned base = m_e + (unsigned)q.dense[j];
     for (int t = 0; t < ri.y; t++) K3_AST(&q.label[q.c2t[clist[ri.x + t]]], base + (unsigned)t);
   }
+  K3_LS(13);
   return created;
 }
-
-#ifdef K3_LIT_PROF
-#define K3_LT(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); sh.prof[i] += now__ - lt_last__; lt_last__ = now__; } } while (0)
-#else
-#define K3_LT(i) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(DecParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];       // replay arrays of a small frame
@@ -410,6 +559,9 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
   for (int f = fresh ? -1 : f0; f < f0 + T; f++) {
     if (block_err(sh)) break;
     float accept = p.beam; long long nb = 0; unsigned m_e = 1; int n_e = 1;
+#ifdef K3_LIT_PROF
+    if (tid == 0) sh.prof_n = n_cur;
+#endif
     const int *ord_cur = q.order[sel]; int *ord_nxt = q.order[sel ^ 1];
     if (f >= 0) {
       const float *ll = p.lane_rows ? p.lane_rows[L] + (long long)(f - f0) * p.ld : p.loglikes + (r0 + (f - f0)) * p.ld;
@@ -537,7 +689,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
               }
             }
             if (mk && !claimed) { idx = tb.wait_tok(slot, &sh.err); if (idx < 0) idx = 0; }
-            if (mk) atomicMin(&q.label[idx], (unsigned)(jbase + j));
+            if (mk) k3a_min(&q.label[idx], (unsigned)(jbase + j));
             const long long pos = wave_append64(mk, &sh.n_link);
             if (mk) {
               if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}; link_arc[pos] = arc; }
@@ -555,7 +707,8 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     }   // f >= 0
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens made so far
     K3_LT(4);
-    lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt);
+    if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, lt_last__);
+    else lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
     K3_LT(6);
     // ---- ProcessNonemitting: order-free fixpoint (costs, new tokens, eps links)
     finish_frame<false>(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
@@ -583,7 +736,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
       int wbase = 0;
-      if (lane == 63) wbase = atomicAdd(&ls.n_csr, incl);
+      if (lane == 63) wbase = k3a_add(&ls.n_csr, incl);
       wbase = __shfl(wbase, 63);
       const int base = wbase + incl - deg;
       if (i < n) q.crng[i] = make_int2(base, deg);
@@ -594,7 +747,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
           int d = -1;
           if (oc + r.w < accept) {
             const int s2 = tb.find((int)((unsigned)r.next & ~kEpsFlag));
-            if (s2 >= 0) { d = tb.tok(s2); atomicOr(&q.rflag[d], 1); atomicAdd(&q.rown[oi], 1); } else sh.err = K3_ERR_HIP;
+            if (s2 >= 0) { d = tb.tok(s2); k3a_or(&q.rflag[d], 1); k3a_add(&q.rown[oi], 1); } else sh.err = K3_ERR_HIP;
           }
           q.cdst[obase + (arc - obeg)] = d; q.cw[obase + (arc - obeg)] = r.w;
         }
@@ -634,8 +787,8 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     __syncthreads();
     K3_LT(8);
 #ifdef K3_LIT_PROF
-    if (tid == 0) { sh.prof[13] += n; sh.prof[14] += rmode == 0 ? 1 : 0; sh.prof[15] += 1; }
-    const long long rp_t0 = (long long)__builtin_readcyclecounter();
+    if (tid == 0 && K3_LP_ON) { if (K3_LIT_PROF == 1) { sh.prof[13] += n; sh.prof[14] += rmode == 0 ? 1 : 0; } sh.prof[15] += 1; }
+    const long long rp_t0 = (long long)__builtin_readcyclecounter(); (void)rp_t0;
 #endif
     // ---- replay of the LIFO queue (:851-896): only the ORDER in which the closure creates tokens comes out of it.  literal_order = 1: split by
     // connected components of the closure sub-graph, one thread per component; literal_order = 2 (and frames whose component stacks overflow):
@@ -644,10 +797,10 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     int created_total = -1;
     if (p.literal == 1) {
       if (rmode == 0) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw),
-                                                            reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, s_aux, n_cid, n_arc, n_iq, m_e, accept);
-      else if (rmode == 1) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab), (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(smem_raw), q.par, n_cid, n_arc, n_iq, m_e, accept);
-      else created_total = lit_replay_components(p, q, sh, &ls.use_lds, q.rcost, (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(q.rflag), q.par, n_cid, n_arc, n_iq, m_e, accept);
-#ifdef K3_LIT_PROF
+                                                            reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, s_aux, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
+      else if (rmode == 1) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab), (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(smem_raw), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
+      else created_total = lit_replay_components(p, q, sh, &ls.use_lds, q.rcost, (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(q.rflag), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
+#if defined(K3_LIT_PROF) && K3_LIT_PROF == 1
       if (tid == 0 && created_total < 0) sh.prof[5] += 1;
 #endif
       if (created_total < 0) {      // back to the state step 2 left
@@ -665,7 +818,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
                                            reinterpret_cast<unsigned *>(smem_raw), q.iq, n_iq, accept, s_own, &created, &err, &pops);
         else lit_replay<2>(q.rcost, q.meta, q.arcs2, q.stack, p.stack_cap, reinterpret_cast<unsigned *>(q.rflag), q.iq, n_iq, accept, s_own, &created, &err, &pops);
         __builtin_amdgcn_s_setprio(0);
-#ifdef K3_LIT_PROF
+#if defined(K3_LIT_PROF) && K3_LIT_PROF == 1
         if (lane == 0) { sh.prof[12] += pops; if (rmode != 0) sh.prof[3] += (long long)__builtin_readcyclecounter() - rp_t0; }
 #endif
 #ifdef K3_LIT_DEBUG
@@ -687,7 +840,8 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     __syncthreads();
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
-    lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt);
+    if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, smem_raw, lt_last__);
+    else lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
     K3_LT(10);
     // ---- publish the frame: final costs into the pool, empty table, idle labels
     for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], kLabelNone);
@@ -696,7 +850,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     cur_base = nb; n_cur = n; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1;
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
   }
-  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { atomicAdd(&sh.n_eps, a); atomicAdd(&sh.n_emit, b); atomicAdd(&sh.n_os, c); } }
+  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { k3a_add(&sh.n_eps, a); k3a_add(&sh.n_emit, b); k3a_add(&sh.n_os, c); } }
   __syncthreads();
 #ifdef K3_LIT_PROF
   if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
@@ -719,6 +873,93 @@ __device__ __forceinline__ bool lit_approx_equal(float a, float b, float tol) {
   return diff <= tol * (fabsf(a) + fabsf(b));
 }
 
+template <bool PACKED>
+__device__ __forceinline__ void lit_final_sweeps(const float *base, float *ex, const unsigned *off, int *ldst, const float *ldelta, const int *by_ins, int n, float lb) {
+  const float kInf = __builtin_inff(); const unsigned omask = PACKED ? 0xFFFFu : 0xFFFFFFFFu;
+  bool changed = true;
+  for (int sweep = 0; changed && sweep < 100000; sweep++) {
+    changed = false;
+    for (int d = n - 1; d >= 0; d--) {      // active_toks_[frame].toks: newest token first
+      const int t = PACKED ? (int)(off[d] >> 16) : by_ins[d];
+      float te_ = base[t];
+      for (unsigned j = off[t] & omask, je = off[t + 1] & omask; j < je; j++) {
+        const int dst = ldst[j] & 0x7FFFFFFF;
+        float le = ex[dst] + ldelta[j];
+        if (le > lb) ldst[j] = dst;
+        else { ldst[j] = dst | (int)0x80000000; if (le < 0.0f) le = 0.0f; if (le < te_) te_ = le; }
+      }
+      if (te_ > lb) te_ = kInf;
+      if (!lit_approx_equal(ex[t], te_, 1.0e-05f)) changed = true;
+      ex[t] = te_;
+    }
+  }
+}
+
+// The same sweeps WITHOUT the serial walk, for frames too large for LDS (where every step of the walk is a global round trip).  A token's
+// new extra cost depends on the new values of the link destinations visited before it in the sweep (created later) and on the old values of the
+// others: level(t) = 1 + max level over its earlier-visited destinations; the tokens of one level are independent, a sweep is one parallel
+// pass per level with old / new values double-buffered.  Same arithmetic on the same operands as the walk, hence the same bits.  Returns false
+// (nothing changed) when the dependency chains are deeper than kLvMax: the caller then walks.
+constexpr int kLvMax = 62;
+__device__ __forceinline__ bool lit_final_sweeps_parallel(const float *base, float *ex, const unsigned *off, int *ldst, const float *ldelta, const int *by_ins, int n, float lb,
+                                                          int *dn, int *level, float *exn, int *blist) {
+  __shared__ int s_lv[kLvMax + 2], s_cur[kLvMax + 2], s_flag;
+  const int tid = threadIdx.x; const float kInf = __builtin_inff();
+  for (int d = tid; d < n; d += kPBlock) { dn[by_ins[d]] = d; level[d] = 0; }
+  if (tid == 0) s_flag = 0;
+  __syncthreads();
+  for (int round = 0;; round++) {
+    for (int t = tid; t < n; t += kPBlock) {
+      const int my = dn[t]; int lv = 0;
+      for (unsigned j = off[t]; j < off[t + 1]; j++) { const int dst = ldst[j] & 0x7FFFFFFF; if (dn[dst] > my) { const int l_ = level[dst] + 1; lv = l_ > lv ? l_ : lv; } }
+      if (lv != level[t]) { level[t] = lv; s_flag = 1; }
+    }
+    __syncthreads();
+    const int f = s_flag;
+    __syncthreads();
+    if (!f) break;
+    if (round > kLvMax) return false;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+  }
+  if (tid < kLvMax + 2) { s_lv[tid] = 0; s_cur[tid] = 0; }
+  __syncthreads();
+  for (int t = tid; t < n; t += kPBlock) { const int lv = level[t]; if (lv > kLvMax) s_flag = 1; else atomicAdd(&s_lv[lv + 1], 1); }
+  __syncthreads();
+  if (s_flag) return false;
+  if (tid == 0) { for (int l = 0; l <= kLvMax; l++) s_lv[l + 1] += s_lv[l]; }      // s_lv[l] = first position of level l
+  __syncthreads();
+  for (int t = tid; t < n; t += kPBlock) { const int lv = level[t]; blist[s_lv[lv] + atomicAdd(&s_cur[lv], 1)] = t; }
+  __syncthreads();
+  for (int sweep = 0; sweep < 100000; sweep++) {
+    for (int lv = 0; lv <= kLvMax; lv++) {
+      const int b0 = s_lv[lv], b1 = s_lv[lv + 1];
+      if (b0 == n) break;      // (uniform: no tokens at this level or above)
+      for (int x = b0 + tid; x < b1; x += kPBlock) {
+        const int t = blist[x], my = dn[t];
+        float te_ = base[t];
+        for (unsigned j = off[t]; j < off[t + 1]; j++) {
+          const int dst = ldst[j] & 0x7FFFFFFF;
+          float le = (dn[dst] > my ? exn[dst] : ex[dst]) + ldelta[j];
+          if (le > lb) ldst[j] = dst;
+          else { ldst[j] = dst | (int)0x80000000; if (le < 0.0f) le = 0.0f; if (le < te_) te_ = le; }
+        }
+        if (te_ > lb) te_ = kInf;
+        if (!lit_approx_equal(ex[t], te_, 1.0e-05f)) s_flag = 1;
+        exn[t] = te_;
+      }
+      __syncthreads();
+    }
+    const int f = s_flag;
+    for (int t = tid; t < n; t += kPBlock) ex[t] = exn[t];
+    __syncthreads();
+    if (!f) break;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+  }
+  return true;
+}
+
 // The literal branch of k3_decode_prune_kernel's last-frame stage.  LDS arrays (each kPCap entries) are used when the frame fits.
 __device__ __forceinline__ void lit_final_frame(const DecParams &p, int L, long long tb, long long te, long long l0, long long l1, float final_best, bool final_empty,
                                                const int *tok_state, const unsigned *tok_cost, float *extra, const Link *links, int *err,
@@ -727,10 +968,10 @@ __device__ __forceinline__ void lit_final_frame(const DecParams &p, int L, long 
   const long long fc = p.frame_cands_cap;
   unsigned *g_off = reinterpret_cast<unsigned *>(p.c_dst + L * fc); unsigned *cursor = reinterpret_cast<unsigned *>(p.c_src + L * fc); int *lid = p.c_arc + L * fc;
   float *g_base = p.c_tot + L * fc, *g_delta = p.c_ac + L * fc; int *g_ldst = p.wl + 2ll * L * p.frame_tokens_cap;
-  const int *by_ins = p.lt_by_ins + (long long)L * p.frame_tokens_cap;
+  const int *by_ins = reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.lt_by_ins) + p.lt_lane_bytes * L);
   for (int t = tid; t < n; t += kPBlock) K3_AST(&cursor[t], 0u);
   __syncthreads();
-  for (long long l = l0 + tid; l < l1; l += kPBlock) { const Link k = links[l]; if (eps_link_live(k, tok_cost[k.src])) atomicAdd(&cursor[k.src - tb], 1u); }
+  for (long long l = l0 + tid; l < l1; l += kPBlock) { const Link k = links[l]; if (eps_link_live(k, tok_cost[k.src])) k3a_add(&cursor[k.src - tb], 1u); }
   __syncthreads();
   const int m = block_excl_scan([&](int t) { return K3_ALD(&cursor[t]); }, g_off, n, redi);
   if (tid == 0) { g_off[n] = (unsigned)m; *s_m = m; }
@@ -740,36 +981,26 @@ __device__ __forceinline__ void lit_final_frame(const DecParams &p, int L, long 
   for (long long l = l0 + tid; l < l1; l += kPBlock) {
     const Link k = links[l];
     if (!eps_link_live(k, tok_cost[k.src])) continue;
-    const unsigned pos = g_off[k.src - tb] + atomicAdd(&cursor[k.src - tb], 1u);
+    const unsigned pos = g_off[k.src - tb] + k3a_add(&cursor[k.src - tb], 1u);
     lid[pos] = (int)(l - l0); g_ldst[pos] = (int)(k.dst - tb); g_delta[pos] = k.tot - dec(tok_cost[k.dst]);      // (tot + ac + graph) - next_tok->tot_cost
   }
   for (int t = tid; t < n; t += kPBlock) { const float fcost = final_empty ? 0.0f : p.final_cost[tok_state[tb + t]]; g_base[t] = dec(tok_cost[tb + t]) + fcost - final_best; }
   __syncthreads();
   const bool use_lds = n + 1 <= kPCap && m <= kPCap;
   float *base = use_lds ? l_base : g_base, *ex = use_lds ? l_extra : extra + tb, *ldelta = use_lds ? l_ldelta : g_delta; unsigned *off = use_lds ? l_off : g_off; int *ldst = use_lds ? l_ldst : g_ldst;
-  if (use_lds) {
-    for (int t = tid; t <= n; t += kPBlock) { off[t] = g_off[t]; if (t < n) base[t] = g_base[t]; }
+  if (use_lds) {      // (offsets < 65536 here: the creation list rides in the upper halves, off[d] >> 16 = the token with creation rank d)
+    for (int t = tid; t <= n; t += kPBlock) { off[t] = g_off[t] | (t < n ? (unsigned)by_ins[t] << 16 : 0u); if (t < n) base[t] = g_base[t]; }
     for (int j = tid; j < m; j += kPBlock) { ldst[j] = g_ldst[j]; ldelta[j] = g_delta[j]; }
   }
   for (int t = tid; t < n; t += kPBlock) ex[t] = 0.0f;      // a new token's extra_cost (:271)
   __syncthreads();
-  if (tid == 0) {
-    bool changed = true;
-    for (int sweep = 0; changed && sweep < 100000; sweep++) {
-      changed = false;
-      for (int d = n - 1; d >= 0; d--) {      // active_toks_[frame].toks: newest token first
-        const int t = by_ins[d];
-        float te_ = base[t];
-        for (unsigned j = off[t]; j < off[t + 1]; j++) {
-          const int dst = ldst[j] & 0x7FFFFFFF;
-          float le = ex[dst] + ldelta[j];
-          if (le > lb) ldst[j] = dst;
-          else { ldst[j] = dst | (int)0x80000000; if (le < 0.0f) le = 0.0f; if (le < te_) te_ = le; }
-        }
-        if (te_ > lb) te_ = kInf;
-        if (!lit_approx_equal(ex[t], te_, 1.0e-05f)) changed = true;
-        ex[t] = te_;
-      }
+  // (two call sites so that the LDS case compiles to ds_ instructions: through a pointer chosen at run time every access of the serial walk
+  // would be a flat access with the latency of a global one)
+  if (use_lds) { if (tid == 0) lit_final_sweeps<true>(l_base, l_extra, l_off, l_ldst, l_ldelta, by_ins, n, lb); }
+  else {
+    const LitLane q(p, L);      // (forward-pass scratch, idle here)
+    if (!lit_final_sweeps_parallel(g_base, extra + tb, g_off, g_ldst, g_delta, by_ins, n, lb, p.tok_slot + (long long)L * p.frame_tokens_cap, reinterpret_cast<int *>(cursor), q.c0, q.dense)) {
+      if (tid == 0) lit_final_sweeps<false>(g_base, extra + tb, g_off, g_ldst, g_delta, by_ins, n, lb);
     }
   }
   __syncthreads();
