@@ -123,7 +123,7 @@ struct DecParams {
   float *lt_c0;                                          // [frame_tokens_cap] token costs right after ProcessEmitting
   int2 *lt_crng; int *lt_cdst; float *lt_cw;             // closure sub-graph in token space: per token (first, count), per eps arc (dst token | -1, weight)
   float *lt_rcost; int *lt_rflag, *lt_rown, *lt_stack, *lt_iq, *lt_c2t; int2 *lt_arcs2; int4 *lt_meta;   // replay state (global copies; small frames use LDS)
-  int *lt_par, *lt_rtmp, *lt_rlist, *lt_wcomp; int4 *lt_cinfo, *lt_coffs; int2 *lt_rinfo;      // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of the tokens it created
+  int *lt_par, *lt_rtmp; int2 *lt_rlist, *lt_rinfo; int4 *lt_cinfo, *lt_coffs, *lt_wrec;      // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of the tokens it created
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -1440,7 +1440,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     auto place = [&](auto **ptr, size_t count) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(off); off += (count * sizeof(T) + 255) & ~(size_t)255; };
     place(&p.lt_order, 2 * cap); place(&p.lt_label, cap); place(&p.lt_c0, cap); place(&p.lt_rflag, cap); place(&p.lt_rown, cap); place(&p.lt_grp, cap); place(&p.lt_lead, cap + 1);
     place(&p.lt_crng, cap); place(&p.lt_c2t, cap); place(&p.lt_iq, cap); place(&p.lt_dense, cap); place(&p.lt_by_ins, cap); place(&p.lt_meta, cap); place(&p.lt_rcost, cap);
-    place(&p.lt_par, cap); place(&p.lt_rtmp, cap); place(&p.lt_rlist, cap); place(&p.lt_wcomp, cap); place(&p.lt_cinfo, cap); place(&p.lt_coffs, cap); place(&p.lt_rinfo, cap);
+    place(&p.lt_par, cap); place(&p.lt_rtmp, cap); place(&p.lt_rlist, cap); place(&p.lt_wrec, 2 * cap); place(&p.lt_cinfo, cap); place(&p.lt_coffs, cap); place(&p.lt_rinfo, cap);
     place(&p.lt_cmin, 2 * nch); place(&p.lt_ccnt, 2 * nch); place(&p.lt_cdst, (size_t)p.eps_cap); place(&p.lt_cw, (size_t)p.eps_cap); place(&p.lt_arcs2, (size_t)p.eps_cap);
     place(&p.lt_stack, (size_t)p.stack_cap); place(&p.lt_bm, (size_t)p.seq_words_cap); place(&p.lt_wpre, (size_t)p.seq_words_cap);
     place(&p.lt_bfirst, (size_t)p.hash_cap); place(&p.lt_bcnt, (size_t)p.hash_cap); place(&p.lt_bfill, (size_t)p.hash_cap);
@@ -1449,7 +1449,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     if ((rc = dmalloc(&d->allocs, &arena, nl * (size_t)p.lt_lane_bytes))) return rc;
     auto rebase = [&](auto **ptr) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(arena + reinterpret_cast<size_t>(*ptr)); };
     rebase(&p.lt_order); rebase(&p.lt_label); rebase(&p.lt_c0); rebase(&p.lt_rflag); rebase(&p.lt_rown); rebase(&p.lt_grp); rebase(&p.lt_lead); rebase(&p.lt_crng); rebase(&p.lt_c2t); rebase(&p.lt_iq);
-    rebase(&p.lt_dense); rebase(&p.lt_by_ins); rebase(&p.lt_meta); rebase(&p.lt_rcost); rebase(&p.lt_par); rebase(&p.lt_rtmp); rebase(&p.lt_rlist); rebase(&p.lt_wcomp); rebase(&p.lt_cinfo); rebase(&p.lt_coffs);
+    rebase(&p.lt_dense); rebase(&p.lt_by_ins); rebase(&p.lt_meta); rebase(&p.lt_rcost); rebase(&p.lt_par); rebase(&p.lt_rtmp); rebase(&p.lt_rlist); rebase(&p.lt_wrec); rebase(&p.lt_cinfo); rebase(&p.lt_coffs);
     rebase(&p.lt_rinfo); rebase(&p.lt_cmin); rebase(&p.lt_ccnt); rebase(&p.lt_cdst); rebase(&p.lt_cw); rebase(&p.lt_arcs2); rebase(&p.lt_stack); rebase(&p.lt_bm); rebase(&p.lt_wpre); rebase(&p.lt_bfirst);
     rebase(&p.lt_bcnt); rebase(&p.lt_bfill);
     // idle patterns of the scratch: labels / bucket firsts all ones, bitmap / bucket counters zero

@@ -158,7 +158,7 @@ __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int 
 
 struct LitLane {      // this lane's slices of the literal_order scratch
   int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *bfirst, *bcnt, *bfill, *cmin; float *c0, *cw, *rcost; int2 *crng, *arcs2; int4 *meta; int *iq, *c2t;
-  int *par, *rtmp, *rlist, *wcomp; int4 *cinfo, *coffs; int2 *rinfo;      // component replay (below)
+  int *par, *rtmp; int2 *rlist, *rinfo; int4 *cinfo, *coffs, *wrec;      // component replay (below)
   __device__ LitLane(const DecParams &p, int L) {
     const long long cap = p.frame_tokens_cap, nch = cap / 64 + 2; const long long lb = p.lt_lane_bytes * L;
     auto at = [lb](auto *base) { return reinterpret_cast<decltype(base)>(reinterpret_cast<char *>(base) + lb); };
@@ -168,7 +168,7 @@ struct LitLane {      // this lane's slices of the literal_order scratch
     cmin = at(p.lt_cmin); ccnt = at(p.lt_ccnt); c0 = at(p.lt_c0); crng = at(p.lt_crng); (void)nch;
     cdst = at(p.lt_cdst); cw = at(p.lt_cw); rcost = at(p.lt_rcost); rflag = at(p.lt_rflag); rown = at(p.lt_rown);
     stack = at(p.lt_stack); arcs2 = at(p.lt_arcs2); iq = at(p.lt_iq); meta = at(p.lt_meta); c2t = at(p.lt_c2t);
-    par = at(p.lt_par); rtmp = at(p.lt_rtmp); rlist = at(p.lt_rlist); wcomp = at(p.lt_wcomp); cinfo = at(p.lt_cinfo); coffs = at(p.lt_coffs); rinfo = at(p.lt_rinfo);
+    par = at(p.lt_par); rtmp = at(p.lt_rtmp); rlist = at(p.lt_rlist); wrec = at(p.lt_wrec); cinfo = at(p.lt_cinfo); coffs = at(p.lt_coffs); rinfo = at(p.lt_rinfo);
   }
 };
 
@@ -388,6 +388,7 @@ __device__ __forceinline__ void lit_replay(float *rcost, const int4 *meta, const
 // reads and writes only the costs of tokens it can reach, so cascades in different components commute.  Every component replays its own
 // roots in queue order on ONE THREAD with a stack of its own (hundreds of components per frame, the longest chain a dozen pops), and the
 // creation labels are handed out afterwards root by root in queue order by a prefix sum over the roots' creation counts.
+__device__ __forceinline__ int4 k3_ald4(const int4 *p_) { const int *w = reinterpret_cast<const int *>(p_); return make_int4(K3_ALD(&w[0]), K3_ALD(&w[1]), K3_ALD(&w[2]), K3_ALD(&w[3])); }      // words updated by atomics (at L2): not through the L1
 template <typename P> __device__ __forceinline__ int uf_find(P par, int x) { for (;;) { const int q_ = K3_ALD(&par[x]); if (q_ == x) return x; x = q_; } }
 // lock-free union: the larger root hooks under the smaller one (parents only ever decrease: no cycles)
 template <typename P> __device__ __forceinline__ void uf_union(P par, int a, int b) {
@@ -402,11 +403,13 @@ template <typename P> __device__ __forceinline__ void uf_union(P par, int a, int
 // One worker = one component, on one thread.  rcost / meta / AR / clist as in lit_replay (LDS or HBM by instantiation); stk: this component's
 // slice of the stack pool.  Returns false when the stack slice overflows (the frame then takes the serial replay).
 template <typename RC, typename MT, typename AT, typename CL>
-__device__ __forceinline__ bool lit_replay_component(RC rcost, MT meta, AT AR, CL clist, const int *iq, const int *rlist, int2 *rinfo, int *stk, int scap,
+__device__ __forceinline__ bool lit_replay_component(RC rcost, MT meta, AT AR, CL clist, const int2 *rlist, int2 *rinfo, int *stk, int scap,
                                                      int r0, int rcnt, int cpos, float accept) {
   const float kInf = __builtin_inff();
+  int2 root = rlist[r0];      // {position in the initial queue, closure id}
   for (int j = 0; j < rcnt; j++) {
-    const int k = rlist[r0 + j]; int cur = iq[k]; const int seg0 = cpos; int sp = 0;
+    const int k = root.x; int cur = root.y; const int seg0 = cpos; int sp = 0;
+    if (j + 1 < rcnt) root = rlist[r0 + j + 1];      // (in flight while this root's cascade runs)
     for (;;) {
       const float cc = rcost[cur]; const int4 mt = meta[cur];
       int nxt = -1;      // the newest push stays in a register: it is the next pop
@@ -432,18 +435,16 @@ __device__ __forceinline__ bool lit_replay_component(RC rcost, MT meta, AT AR, C
   return true;
 }
 
-// All phases of the component replay; every thread of the block calls it.  par: n_cid ints (LDS for small frames).  Returns the number of tokens
-// created, or -1 when the frame has to take the serial replay (rcost / clist are then in an undefined state).
+// All phases of the component replay; every thread of the block calls it.  par: n_cid ints (LDS for small frames), par[c] = c and cinfo[c] = 0
+// on entry (the caller's step 2 sets them).  Returns the number of tokens created, or -1 when the frame has to take the serial replay (rcost /
+// clist are then in an undefined state).  Loops over roots / components keep up to four items per thread in flight (a phase costs its chain of
+// dependent round trips once, not once per item).
 template <typename RC, typename MT, typename AT, typename CL, typename P>
 __device__ __forceinline__ int lit_replay_components(const DecParams &p, const LitLane &q, Shared &sh, int *s_flag, RC rcost, MT meta, AT AR, CL clist, P par,
                                                      int n_cid, int n_arc, int n_iq, unsigned m_e, float accept, long long &lt_last__) {
   const int tid = threadIdx.x; const float kInf = __builtin_inff();
   int4 *red4 = reinterpret_cast<int4 *>(sh.hist);
   if (n_arc > p.stack_cap) return -1;
-  for (int c = tid; c < n_cid; c += kBlock) { K3_AST(&par[c], c); int *ci = reinterpret_cast<int *>(&q.cinfo[c]); K3_AST(&ci[0], 0); K3_AST(&ci[1], 0); K3_AST(&ci[2], 0); K3_AST(&ci[3], 0); }
-  if (tid == 0) *s_flag = 0;
-  __syncthreads();
-  K3_LS(7);
   for (int c = tid; c < n_cid; c += kBlock) {
     const int4 mt = meta[c];
     for (int a = 0; a < mt.y; a++) uf_union(par, c, a == 0 ? mt.z : AR[mt.x + a].x);
@@ -457,39 +458,74 @@ __device__ __forceinline__ int lit_replay_components(const DecParams &p, const L
     if (rcost[c] == kInf) k3a_add(&ci[1], 1);
     const int pc = meta[c].y; if (pc > 0) k3a_add(&ci[2], pc);
   }
-  for (int k = tid; k < n_iq; k += kBlock) { const int r = uf_find(par, q.iq[k]); k3a_add(reinterpret_cast<int *>(&q.cinfo[r]), 1); }
+  for (int k0 = tid; k0 < n_iq; k0 += 4 * kBlock) {
+    int e[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int k = k0 + u * kBlock; if (k < n_iq) e[u] = q.iq[k]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int k = k0 + u * kBlock; if (k < n_iq) k3a_add(reinterpret_cast<int *>(&q.cinfo[uf_find(par, e[u])]), 1); }
+  }
   __syncthreads();
   K3_LS(9);
-  const int4 tot = block_excl_scan4([&](int c) { const int *ci = reinterpret_cast<const int *>(&q.cinfo[c]); const int rc_ = K3_ALD(&ci[0]); return make_int4(rc_, K3_ALD(&ci[1]), K3_ALD(&ci[2]), rc_ > 0 ? 1 : 0); },
-                                    [&](int c, int4 ex) { q.coffs[c] = ex; if (K3_ALD(reinterpret_cast<const int *>(&q.cinfo[c])) > 0) q.wcomp[ex.w] = c; }, n_cid, red4);
+  // offsets per component; a component with roots is a worker: its record {first root slot, roots, first creation slot, first stack slot | stack slots}
+  const int4 tot = block_excl_scan4([&](int c) { const int4 ci = k3_ald4(&q.cinfo[c]); return make_int4(ci.x, ci.y, ci.z, ci.x > 0 ? 1 : 0); },
+                                    [&](int c, int4 ex) { q.coffs[c] = ex; }, n_cid, red4);
   const int n_workers = tot.w;
   K3_LS(10);
-  // a component's roots in queue order (the queue is consumed from its back: descending k)
-  for (int k = tid; k < n_iq; k += kBlock) {
-    const int r = uf_find(par, q.iq[k]); int *ci = reinterpret_cast<int *>(&q.cinfo[r]);
-    const int pos = k3a_add(&ci[3], 1); q.rtmp[q.coffs[r].x + pos] = k;
+  // a component's roots in queue order (the queue is consumed from its back: descending k).  A component with one root (the usual case) is done
+  // in one step; the others collect their roots, then rank them.
+  bool multi = false;
+  for (int k0 = tid; k0 < n_iq; k0 += 2 * kBlock) {
+    int e[2], r[2]; int4 ci[2], co[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) { const int k = k0 + u * kBlock; if (k < n_iq) e[u] = q.iq[k]; }
+#pragma unroll
+    for (int u = 0; u < 2; u++) { const int k = k0 + u * kBlock; if (k < n_iq) { r[u] = uf_find(par, e[u]); ci[u] = k3_ald4(&q.cinfo[r[u]]); co[u] = q.coffs[r[u]]; } }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int k = k0 + u * kBlock;
+      if (k < n_iq) {
+        if (ci[u].x == 1) q.rlist[co[u].x] = make_int2(k, e[u]);
+        else { multi = true; const int pos = k3a_add(reinterpret_cast<int *>(&q.cinfo[r[u]]) + 3, 1); q.rtmp[co[u].x + pos] = k; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {      // the worker's record (a 1-root component: by its root; the others: by their first root in queue order, below)
+      const int k = k0 + u * kBlock;
+      if (k < n_iq && ci[u].x == 1) { q.wrec[2 * co[u].w] = make_int4(co[u].x, 1, co[u].y, co[u].z); q.wrec[2 * co[u].w + 1] = make_int4(ci[u].z, 0, 0, 0); }
+    }
   }
-  __syncthreads();
-  for (int k = tid; k < n_iq; k += kBlock) {
-    const int r = uf_find(par, q.iq[k]); const int cnt = K3_ALD(reinterpret_cast<const int *>(&q.cinfo[r])), off = q.coffs[r].x;
-    int rank = 0;
-    if (cnt > 1) for (int t = 0; t < cnt; t++) rank += q.rtmp[off + t] > k;
-    q.rlist[off + rank] = k;
+  multi = __syncthreads_or(multi);
+  if (multi) {
+    for (int k = tid; k < n_iq; k += kBlock) {
+      const int e = q.iq[k]; const int r = uf_find(par, e); const int4 ci = k3_ald4(&q.cinfo[r]), co = q.coffs[r];
+      if (ci.x > 1) {
+        int rank = 0;
+        for (int t = 0; t < ci.x; t++) rank += q.rtmp[co.x + t] > k;
+        q.rlist[co.x + rank] = make_int2(k, e);
+        if (rank == 0) { q.wrec[2 * co.w] = make_int4(co.x, ci.x, co.y, co.z); q.wrec[2 * co.w + 1] = make_int4(ci.z, 0, 0, 0); }
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   K3_LS(11);
   for (int w = tid; w < n_workers; w += kBlock) {
-    const int c = q.wcomp[w]; const int4 co = q.coffs[c]; const int *ci = reinterpret_cast<const int *>(&q.cinfo[c]);
-    if (!lit_replay_component(rcost, meta, AR, clist, q.iq, q.rlist, q.rinfo, q.stack + co.z, K3_ALD(&ci[2]), co.x, K3_ALD(&ci[0]), co.y, accept)) *s_flag = 1;
+    const int4 w0 = q.wrec[2 * w], w1 = q.wrec[2 * w + 1];
+    if (!lit_replay_component(rcost, meta, AR, clist, q.rlist, q.rinfo, q.stack + w0.w, w1.x, w0.x, w0.y, w0.z, accept)) *s_flag = 1;
   }
   __syncthreads();
   K3_LS(12);
   if (*s_flag) return -1;
   // creation labels: roots in queue order (j-th root processed = position n_iq - 1 - j), tokens of a root in the order it created them
   const int created = block_excl_scan([&](int j) { return (unsigned)q.rinfo[n_iq - 1 - j].y; }, reinterpret_cast<unsigned *>(q.dense), n_iq, sh.redi);
-  for (int j = tid; j < n_iq; j += kBlock) {
-    const int2 ri = q.rinfo[n_iq - 1 - j]; const unsigned base = m_e + (unsigned)q.dense[j];
-    for (int t = 0; t < ri.y; t++) K3_AST(&q.label[q.c2t[clist[ri.x + t]]], base + (unsigned)t);
+  for (int j0 = tid; j0 < n_iq; j0 += 4 * kBlock) {
+    int2 ri[4]; unsigned base[4]; int t0[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int j = j0 + u * kBlock; ri[u] = make_int2(0, 0); if (j < n_iq) { ri[u] = q.rinfo[n_iq - 1 - j]; base[u] = m_e + (unsigned)q.dense[j]; } }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (ri[u].y > 0) t0[u] = q.c2t[clist[ri[u].x]];      // (most roots create one token)
+#pragma unroll
+    for (int u = 0; u < 4; u++) for (int t = 0; t < ri[u].y; t++) K3_AST(&q.label[t == 0 ? t0[u] : q.c2t[clist[ri[u].x + t]]], base[u] + (unsigned)t);
   }
   K3_LS(13);
   return created;
@@ -723,41 +759,51 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     for (int i = tid; i < n; i += kBlock) { K3_AST(&q.rflag[i], 0); K3_AST(&q.rown[i], 0); }
     __syncthreads();
     // step 1 (wave-cooperative): every eps arc of every token below the cutoff -> slot {destination token | -1, weight} of an uncompacted
-    // CSR, passing arcs counted per source, destinations flagged
-    for (int i0 = 0; i0 < n; i0 += kBlock) {
-      const int i = i0 + tid; int deg = 0, ebeg = 0; float c = 0.0f;
-      if (i < n) {
-        const unsigned cb = tb.cost(tok_slot[i]); c = dec(cb); const int st = tok_state[nb + i];
-        tok_cost[nb + i] = cb;                                 // the frame's final cost (the closure's "expanded at" marker is no longer needed)
-        const int2 a = p.offs[st], b = p.offs[st + 1];
-        ebeg = a.y; deg = (b.x > a.y && c < accept) ? b.x - a.y : 0;
-      }
-      int incl = deg;
+    // CSR, passing arcs counted per source, destinations flagged.  (A thread's tokens of two 512-token blocks are fetched together.)
+    for (int ib = 0; ib < n; ib += 2 * kBlock) {
+      int slot4[2], st4[2]; unsigned cb4[2]; int2 oa4[2], ob4[2];
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-      int wbase = 0;
-      if (lane == 63) wbase = k3a_add(&ls.n_csr, incl);
-      wbase = __shfl(wbase, 63);
-      const int base = wbase + incl - deg;
-      if (i < n) q.crng[i] = make_int2(base, deg);
-      if (wbase + __shfl(incl, 63) > p.eps_cap) { sh.err = K3_ERR_OVERFLOW; deg = 0; }
-      wave_expand_seq(p.arcs, ebeg, deg, [&](bool valid, int, int arc, int owner, const ArcRec &r) {
-        const float oc = __shfl(c, owner); const int obase = __shfl(base, owner), obeg = __shfl(ebeg, owner), oi = i0 + (tid & ~63) + owner;
-        if (valid) {
-          int d = -1;
-          if (oc + r.w < accept) {
-            const int s2 = tb.find((int)((unsigned)r.next & ~kEpsFlag));
-            if (s2 >= 0) { d = tb.tok(s2); k3a_or(&q.rflag[d], 1); k3a_add(&q.rown[oi], 1); } else sh.err = K3_ERR_HIP;
+      for (int u = 0; u < 2; u++) { const int i = ib + u * kBlock + tid; if (i < n) { slot4[u] = tok_slot[i]; st4[u] = tok_state[nb + i]; } }
+#pragma unroll
+      for (int u = 0; u < 2; u++) { const int i = ib + u * kBlock + tid; if (i < n) { cb4[u] = tb.cost(slot4[u]); oa4[u] = p.offs[st4[u]]; ob4[u] = p.offs[st4[u] + 1]; } }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i0 = ib + u * kBlock;
+        if (i0 < n) {      // (block-uniform)
+          const int i = i0 + tid; int deg = 0, ebeg = 0; float c = 0.0f;
+          if (i < n) {
+            c = dec(cb4[u]);
+            tok_cost[nb + i] = cb4[u];                                 // the frame's final cost (the closure's "expanded at" marker is no longer needed)
+            ebeg = oa4[u].y; deg = (ob4[u].x > oa4[u].y && c < accept) ? ob4[u].x - oa4[u].y : 0;
           }
-          q.cdst[obase + (arc - obeg)] = d; q.cw[obase + (arc - obeg)] = r.w;
+          const int incl = wave_incl_scan(deg);
+          int wbase = 0;
+          if (lane == 63) wbase = k3a_add(&ls.n_csr, incl);
+          wbase = __builtin_amdgcn_readlane(wbase, 63);
+          const int base = wbase + incl - deg;
+          if (i < n) q.crng[i] = make_int2(base, deg);
+          if (wbase + __builtin_amdgcn_readlane(incl, 63) > p.eps_cap) { sh.err = K3_ERR_OVERFLOW; deg = 0; }
+          wave_expand_seq(p.arcs, ebeg, deg, [&](bool valid, int, int arc, int owner, const ArcRec &r) {
+            const float oc = __shfl(c, owner); const int obase = __shfl(base, owner), obeg = __shfl(ebeg, owner), oi = i0 + (tid & ~63) + owner;
+            if (valid) {
+              int d = -1;
+              if (oc + r.w < accept) {
+                const int s2 = tb.find((int)((unsigned)r.next & ~kEpsFlag));
+                if (s2 >= 0) { d = tb.tok(s2); k3a_or(&q.rflag[d], 1); k3a_add(&q.rown[oi], 1); } else sh.err = K3_ERR_HIP;
+              }
+              q.cdst[obase + (arc - obeg)] = d; q.cw[obase + (arc - obeg)] = r.w;
+            }
+          });
         }
-      });
+      }
     }
     __syncthreads();
     if (block_err(sh)) break;
     for (int i = tid; i < n; i += kBlock) { const int slot = tok_slot[i]; if (slot >= kHL) tb.clear(slot); }      // last use of the table in this frame
-    const int n_cid = block_excl_scan([&](int i) { return (K3_ALD(&q.rown[i]) > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1u : 0u; }, reinterpret_cast<unsigned *>(q.grp), n, sh.redi);
-    const int n_arc = block_excl_scan([&](int i) { return (unsigned)K3_ALD(&q.rown[i]); }, q.lead, n, sh.redi);
+    // closure ids of the involved tokens and first arc slots of the sources: one pass
+    const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
+                                       [&](int i, int4 ex) { q.grp[i] = ex.x; q.lead[i] = (unsigned)ex.y; }, n, reinterpret_cast<int4 *>(sh.hist));
+    const int n_cid = tot2.x, n_arc = tot2.y;
     // mode 0: costs, meta and arcs in LDS; mode 1: costs in LDS, meta / arcs (read-only during the replay) in HBM; mode 2: all in HBM
     // (mode 0: kRN x (16 B meta + 4 B cost + 4 B creation list) = the table's 12 B x kHL; mode 1: 3 kHL costs in the table, the list where mode 0 keeps its arcs)
     const int rmode = (n_cid <= kRN && n_arc <= kRA) ? 0 : ((n_cid <= 3 * kHL && n - n_e <= kRA * 2) ? 1 : 2);
@@ -765,19 +811,38 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     float *rcost = rmode == 2 ? q.rcost : reinterpret_cast<float *>(s_tab) + (rmode == 0 ? 2 * kHL : 0);
     int4 *meta = rmode == 0 ? reinterpret_cast<int4 *>(s_tab) : q.meta;
     int2 *AR = rmode == 0 ? reinterpret_cast<int2 *>(smem_raw) : q.arcs2;
+    int *par = rmode == 0 ? s_aux : q.par;
     const unsigned *clist = rmode == 0 ? reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN : rmode == 1 ? reinterpret_cast<unsigned *>(smem_raw) : reinterpret_cast<unsigned *>(q.rflag);
-    // step 2: per involved token its record, per source its passing arcs compacted in FST order
-    for (int i = tid; i < n; i += kBlock) {
-      const int pc = K3_ALD(&q.rown[i]);
-      if (pc > 0 || K3_ALD(&q.rflag[i]) != 0) {
-        const int cid = q.grp[i]; const int abeg = (int)q.lead[i];
-        q.c2t[cid] = i;
-        rcost[cid] = i < n_e ? q.c0[i] : kInf; int d0 = 0, w0 = 0;
-        if (pc > 0) {
-          const int2 rg = q.crng[i]; int k = abeg;
-          for (int a = rg.x; a < rg.x + rg.y; a++) { const int d = q.cdst[a]; if (d >= 0) { const int2 ar = make_int2(q.grp[d], __float_as_int(q.cw[a])); if (k == abeg) { d0 = ar.x; w0 = ar.y; } AR[k++] = ar; } }
+    if (tid == 0) ls.use_lds = 0;      // (the component replay's "take the serial replay" flag)
+    // step 2: per involved token its record (and its component-replay cells: own parent, zero counters), per source its passing arcs compacted in
+    // FST order.  kSB tokens per thread in flight (the kernel has 128 registers per thread: more would spill).
+    constexpr int kSB = 2;
+    for (int ib = tid; ib < n; ib += kSB * kBlock) {
+      int pc4[kSB], fl4[kSB], cid4[kSB], abeg4[kSB], d1[kSB], g1[kSB]; int2 rg4[kSB]; float c04[kSB], w1[kSB]; bool inv[kSB];
+#pragma unroll
+      for (int u = 0; u < kSB; u++) { const int i = ib + u * kBlock; pc4[u] = 0; fl4[u] = 0; if (i < n) { pc4[u] = K3_ALD(&q.rown[i]); fl4[u] = K3_ALD(&q.rflag[i]); } inv[u] = pc4[u] > 0 || fl4[u] != 0; }
+#pragma unroll
+      for (int u = 0; u < kSB; u++) { const int i = ib + u * kBlock; if (inv[u]) { cid4[u] = q.grp[i]; abeg4[u] = (int)q.lead[i]; c04[u] = i < n_e ? q.c0[i] : kInf; if (pc4[u] > 0) rg4[u] = q.crng[i]; } }
+#pragma unroll
+      for (int u = 0; u < kSB; u++) { d1[u] = -1; if (inv[u] && pc4[u] > 0) { d1[u] = q.cdst[rg4[u].x]; w1[u] = q.cw[rg4[u].x]; } }
+#pragma unroll
+      for (int u = 0; u < kSB; u++) if (d1[u] >= 0) g1[u] = q.grp[d1[u]];
+#pragma unroll
+      for (int u = 0; u < kSB; u++) {
+        const int i = ib + u * kBlock;
+        if (inv[u]) {
+          const int cid = cid4[u], abeg = abeg4[u];
+          q.c2t[cid] = i; rcost[cid] = c04[u]; int d0 = 0, w0 = 0;
+          if (p.literal == 1) { K3_AST(&par[cid], cid); int *ci = reinterpret_cast<int *>(&q.cinfo[cid]); K3_AST(&ci[0], 0); K3_AST(&ci[1], 0); K3_AST(&ci[2], 0); K3_AST(&ci[3], 0); }
+          if (pc4[u] > 0) {
+            int k = abeg;
+            for (int a = rg4[u].x; a < rg4[u].x + rg4[u].y; a++) {
+              const int d = a == rg4[u].x ? d1[u] : q.cdst[a];
+              if (d >= 0) { const int2 ar = make_int2(a == rg4[u].x ? g1[u] : q.grp[d], __float_as_int(a == rg4[u].x ? w1[u] : q.cw[a])); if (k == abeg) { d0 = ar.x; w0 = ar.y; } AR[k++] = ar; }
+            }
+          }
+          meta[cid] = make_int4(abeg, pc4[u], d0, w0);      // the first passing arc rides along: most sources have exactly one
         }
-        meta[cid] = make_int4(abeg, pc, d0, w0);      // the first passing arc rides along: most sources have exactly one
       }
     }
     // the initial queue (:845-850): the tokens ProcessEmitting made, in HashList order, that can expand (a token without a passing arc at its
