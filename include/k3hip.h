@@ -346,6 +346,28 @@ int k3_vec_unary(int32_t op, float *d_v, int32_t n, void *stream);   /* op 0 App
 /* CuVectorBase<double> (a model's accumulated statistics): op 0 Scale(alpha); 1 Pow: v = a ^ alpha; 2 AddVec: v = alpha a + beta v; 3 AddVecVec: v = alpha a .* b + beta v */
 int k3_vec_f64(int32_t op, double alpha, const double *d_a, const double *d_b, double beta, double *d_v, int32_t n, void *stream);
 
+/* ---- chain training, first slice: the LF-MMI denominator.  Stands behind chain::DenominatorGraph's constructor
+ * (chain/chain-den-graph.cc:29-143) and chain::DenominatorComputation::Forward / Backward (chain/chain-denominator.h:203-318,
+ * chain-denominator.cc:106-440; GPU reference chain/chain-kernels.cu:108-296).
+ * k3_chain_den_create: the denominator FST as host CSR arrays -- arcs of state s are arc_offsets[s] .. arc_offsets[s+1], ilabel = pdf-id + 1
+ * (what CreateDenominatorFst writes), weight = -log transition probability, final_cost[s] = -log final probability (+inf: not final; only
+ * the initial probabilities' normalisation uses it).  Transitions by source and by destination and the initial probabilities are built as
+ * the reference's constructor builds them.
+ * k3_chain_den_forward_backward: d_nnet_output is the network's output for num_sequences sequences of frames_per_sequence frames, row
+ * t * num_sequences + s = frame t of sequence s (the layout of a chain minibatch), ld floats apart.  *h_objf = the total log-probability of the
+ * minibatch (Forward()'s return value).  d_nnet_output_deriv (may be NULL: forward only) += deriv_weight * posterior of each pdf on each
+ * frame (Backward()'s contract; chain training passes -supervision.weight); *h_ok (may be NULL) = Backward()'s return value: 0 when the
+ * alpha-beta check of chain-denominator.cc:404-440 fails and the minibatch should be abandoned.  Synchronises the stream.
+ * One launch for the whole minibatch, one workgroup per sequence; K3_ERR_UNSUPPORTED when 16 states + 8 pdfs bytes exceed 150 KB of LDS. */
+typedef struct k3_chain_den k3_chain_den;
+int k3_chain_den_create(int32_t num_states, int32_t start, int32_t num_pdfs, const int64_t *arc_offsets, const int32_t *ilabel, const int32_t *nextstate,
+                        const float *weight, const float *final_cost, k3_chain_den **den);
+void k3_chain_den_destroy(k3_chain_den *den);
+int k3_chain_den_num_states(const k3_chain_den *den);
+int k3_chain_den_initial_probs(const k3_chain_den *den, float *h_probs /* [num_states] */);   /* DenominatorGraph::InitialProbs() */
+int k3_chain_den_forward_backward(k3_chain_den *den, const float *d_nnet_output, int64_t ld, int32_t num_sequences, int32_t frames_per_sequence,
+                                  float leaky_hmm_coefficient, float deriv_weight, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_objf, int32_t *h_ok, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,51 @@
+"""kaldi_amd.chain -- host-side mirror of the reference's chain-training classes for the part that is built: the LF-MMI denominator.
+`DenominatorGraph(fst, num_pdfs)` = chain::DenominatorGraph (chain/chain-den-graph.h:60-143), `DenominatorComputation(opts, den_graph,
+num_sequences, nnet_output)` with `Forward()` / `Backward(deriv_weight, nnet_output_deriv)` = chain::DenominatorComputation
+(chain/chain-denominator.h:203-318).  ctypes plumbing over libk3hip.so (include/k3hip.h: k3_chain_den_*); torch only owns the device memory."""
+import ctypes
+import numpy as np
+import torch
+from . import lib as _l
+
+class ChainTrainingOptions:
+    """the fields of chain::ChainTrainingOptions (chain/chain-training.h:45-104) the denominator reads"""
+    def __init__(self, leaky_hmm_coefficient=1.0e-05):
+        self.leaky_hmm_coefficient = float(leaky_hmm_coefficient)
+
+class DenominatorGraph:
+    def __init__(self, fst, num_pdfs):
+        """fst: kaldi_amd.fst.Fst whose ilabels are pdf-id + 1 (the output of the reference's chain-make-den-fst)"""
+        L = _l.load()
+        off = np.ascontiguousarray(fst.arc_offsets, np.int64); il = np.ascontiguousarray(fst.ilabel, np.int32); nx = np.ascontiguousarray(fst.nextstate, np.int32)
+        w = np.ascontiguousarray(fst.weight, np.float32); fin = np.ascontiguousarray(fst.final, np.float32)
+        h = ctypes.c_void_p()
+        _l.check(L.k3_chain_den_create(int(fst.num_states), int(fst.start), int(num_pdfs), off.ctypes.data, il.ctypes.data, nx.ctypes.data, w.ctypes.data, fin.ctypes.data, ctypes.byref(h)))
+        self._h = h; self.num_states = int(fst.num_states); self.num_pdfs = int(num_pdfs)
+    def NumStates(self): return self.num_states
+    def NumPdfs(self): return self.num_pdfs
+    def InitialProbs(self):
+        p = np.zeros(self.num_states, np.float32); _l.check(_l.load().k3_chain_den_initial_probs(self._h, p.ctypes.data)); return p
+    def __del__(self):
+        if getattr(self, "_h", None): _l.load().k3_chain_den_destroy(self._h); self._h = None
+
+class DenominatorComputation:
+    """nnet_output: [frames_per_sequence * num_sequences, num_pdfs] float32 on the GPU, row t * num_sequences + s."""
+    def __init__(self, opts, den_graph, num_sequences, nnet_output):
+        assert nnet_output.dtype == torch.float32 and nnet_output.is_cuda and nnet_output.shape[1] == den_graph.num_pdfs and nnet_output.stride(1) == 1
+        assert nnet_output.shape[0] % num_sequences == 0
+        self.opts, self.g, self.B, self.out = opts, den_graph, int(num_sequences), nnet_output
+        self.T = nnet_output.shape[0] // self.B; self._objf = None; self._ok = True
+    def _run(self, deriv_weight, deriv):
+        objf = ctypes.c_float(0.0); ok = ctypes.c_int32(1)
+        _l.check(_l.load().k3_chain_den_forward_backward(self.g._h, self.out.data_ptr(), self.out.stride(0), self.B, self.T, self.opts.leaky_hmm_coefficient, float(deriv_weight),
+                                                         deriv.data_ptr() if deriv is not None else None, deriv.stride(0) if deriv is not None else 0, ctypes.byref(objf), ctypes.byref(ok),
+                                                         torch.cuda.current_stream().cuda_stream))
+        return objf.value, bool(ok.value)
+    def Forward(self):
+        """total log-probability of the minibatch over the denominator graph"""
+        self._objf, _ = self._run(0.0, None); return self._objf
+    def Backward(self, deriv_weight, nnet_output_deriv):
+        """nnet_output_deriv += deriv_weight * occupation probabilities; returns False when the minibatch should be abandoned (alpha-beta check).
+        (The forward pass is repeated inside the same launch: the kernel keeps no state between calls.)"""
+        assert nnet_output_deriv.shape == self.out.shape and nnet_output_deriv.stride(1) == 1 and nnet_output_deriv.is_cuda
+        self._objf, ok = self._run(deriv_weight, nnet_output_deriv); return ok

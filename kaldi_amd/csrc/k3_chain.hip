@@ -1,0 +1,252 @@
+// k3_chain.hip -- LF-MMI denominator forward-backward on gfx950 (first slice of the chain-training row).  Paths relative to
+// the reference's src/.
+//
+// Replaces chain::DenominatorComputation::Forward / Backward (chain/chain-denominator.cc:106-440; GPU reference: chain/chain-kernels.cu:108-296,
+// one launch per frame and direction with grid = HMM states x sequence blocks, plus three cudamatrix calls per frame for the leaky-HMM terms:
+// ~8 launches per frame, ~800 per minibatch of 50-frame sequences, each a few microseconds of work) and DenominatorGraph's constructor
+// (chain/chain-den-graph.cc:29-143: transitions by source and by destination, initial probabilities by 100 steps of HMM propagation).
+//
+// MI355X design, not a port: the sequences of a minibatch are independent (they only share the graph), and one sequence's alpha / beta vector
+// (one float per HMM state: 16 KB at 4 k states) fits the LDS of a CU with room to spare.  So ONE launch does the whole minibatch, one workgroup
+// per sequence walking all frames forward and then backward:
+//   * alpha-dash of the previous frame, the alpha being built, the frame's exp(nnet output) row (read where it lies: a sequence's frame is one
+//     contiguous row of the [frames x sequences, pdfs] output matrix -- the reference transposes the whole matrix first) and, going backward,
+//     beta / beta-dash and the frame's derivative row all live in LDS; the graph (12 B per transition) streams from L2, shared by every CU;
+//   * HBM traffic is the alpha-dash rows (written once going forward, read once going backward), the output rows (read twice) and the
+//     derivative rows (one read-modify-write each): the kernel is bound by the LDS gathers per transition, not by HBM;
+//   * the work is spread over TRANSITIONS, not states (in- and out-degrees of a denominator graph are very uneven): a wavefront reads 64 consecutive
+//     transitions (structure of arrays, coalesced), gathers the two LDS operands and adds the product into its state's accumulator with an LDS
+//     atomic on a double -- the reference accumulates each state in double too, so the order of the additions is invisible after the final
+//     rounding to float; the list is ordered by the state at the OTHER end, which scatters the 64 atomics of a wavefront.
+// Arithmetic follows the CPU reference: per-state sums in double over float products, 'arbitrary scale' = 1 / (alpha-sum of the previous
+// frame) folded into every transition, leaky-HMM terms as in AlphaDash / Beta (:200-248), exp limited to [-30, 30] (:91), the betas carrying
+// 1 / total-prob (:320-336).  Summation ORDER differs (atomics; the derivative rows are float), so
+// results agree with the reference to float rounding, not bit for bit: tests hold |objf difference| <= 1e-4 relative and derivatives <= 1e-5 absolute.
+#include "k3_common.h"
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+constexpr int kBlock = 1024, kWaves = kBlock / 64;
+struct Tr { float p; int pdf; int st; };      // DenominatorGraphTransition (chain/chain-datastruct.h:41-46), host side only
+
+// One transition list in two orders, structure of arrays (a wavefront reads 64 consecutive transitions: four coalesced loads).  Forward pass: ordered by
+// SOURCE state, so that the 64 atomic adds of a wavefront go to scattered destinations; backward pass: ordered by DESTINATION state for the same reason.
+struct Edges { const float *p; const int *pdf, *src, *dst; };
+struct DenParams {
+  Edges by_src, by_dst; int E; const float *init;
+  int S, P, B, T; float leaky, deriv_weight;
+  const float *out; long long ld; float *deriv; long long ld_deriv;
+  float *alpha;            // [B][T + 1][S + 1] alpha-dash per frame, the alpha-sum in column S
+  double *logprob;         // [B] log total prob + correction for the arbitrary scales
+  float *check;            // [B][2] at t = 0: sum_h alpha-dash * beta-dash, sum of the derivative row (both 1 when all is well)
+  int do_backward;
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ double block_sum_f64(double v, double *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int w = 0; w < kWaves; w++) r += red[w];
+  return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k3_chain_den_kernel(DenParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[kWaves];
+  const int S = p.S, P = p.P, E = p.E, s = blockIdx.x, tid = threadIdx.x;
+  double *acc = reinterpret_cast<double *>(smem);                 // [S] per-state sums of the frame being built (double, like the reference's accumulators)
+  float *a_prev = reinterpret_cast<float *>(acc + S);             // [S + 1] alpha-dash of the previous frame (backward: beta of the next frame)
+  float *probs = a_prev + (S + 1);                                // [P] exp of the frame's output row
+  float *drow = probs + P;                                        // [P] backward: the frame's derivative row
+  float *occ = drow + P;                                          // [S + 1] backward: alpha-dash of this frame / its alpha-sum
+  float *alpha = p.alpha + (long long)s * (p.T + 1) * (S + 1);
+  const float leaky = p.leaky;
+  auto load_probs = [&](int t) {
+    const float *row = p.out + ((long long)t * p.B + s) * p.ld;
+    for (int k = tid; k < P; k += kBlock) { float x = row[k]; x = x < -30.0f ? -30.0f : (x > 30.0f ? 30.0f : x); probs[k] = expf(x); }      // ApplyExpLimited(-30, 30), :91
+  };
+  // ---- forward (:106-260)
+  for (int h = tid; h < S; h += kBlock) acc[h] = (double)p.init[h];      // AlphaFirstFrame (scale 1 below)
+  double corr = 0.0;      // sum over t < T of log(alpha-sum_t): ComputeTotLogLike's correction term
+  for (int t = 0; t <= p.T; t++) {
+    double scale = 1.0;
+    if (t > 0) {
+      load_probs(t - 1);
+      for (int h = tid; h < S; h += kBlock) acc[h] = 0.0;
+      __syncthreads();
+      scale = (double)(float)(1.0 / (double)a_prev[S]);      // 'arbitrary scale' (:186-196)
+      const Edges e = p.by_src;
+#pragma unroll 8
+      for (int k = tid; k < E; k += kBlock) atomicAdd(&acc[e.dst[k]], (double)(a_prev[e.src[k]] * e.p[k] * probs[e.pdf[k]]));
+    }
+    __syncthreads();
+    // AlphaDash (:200-220): alpha-sum, then alpha += leaky * init * alpha-sum
+    double part = 0.0;
+    for (int h = tid; h < S; h += kBlock) { const float v = (float)(acc[h] * scale); occ[h] = v; part += (double)v; }
+    const float asum = (float)block_sum_f64(part, red);
+    for (int h = tid; h < S; h += kBlock) { const float v = occ[h] + leaky * p.init[h] * asum; a_prev[h] = v; alpha[(long long)t * (S + 1) + h] = v; }
+    if (tid == 0) { a_prev[S] = asum; alpha[(long long)t * (S + 1) + S] = asum; }
+    if (t < p.T) corr += log((double)asum);
+    __syncthreads();
+  }
+  // ComputeTotLogLike (:262-300): the last alpha-dash summed over the states
+  double part = 0.0;
+  for (int h = tid; h < S; h += kBlock) part += (double)a_prev[h];
+  const float tot_prob = (float)block_sum_f64(part, red);
+  if (tid == 0) p.logprob[s] = log((double)tot_prob) + corr;
+  if (!p.do_backward) return;
+  // ---- backward (:304-440).  a_prev <- beta of frame t + 1; acc -> beta-dash of frame t.
+  float *bdash = occ;      // beta-dash is only needed until the beta is made from it (occ is rebuilt every frame)
+  auto beta_from_dash = [&]() {      // Beta(t) (:222-248): beta = beta-dash + leaky * sum_h beta-dash_h * init_h
+    double pp = 0.0;
+    for (int h = tid; h < S; h += kBlock) pp += (double)(bdash[h] * p.init[h]);
+    const float bsum = leaky * (float)block_sum_f64(pp, red);
+    for (int h = tid; h < S; h += kBlock) a_prev[h] = bdash[h] + bsum;
+    __syncthreads();
+  };
+  const float inv_tot = 1.0f / tot_prob;
+  __syncthreads();
+  for (int h = tid; h < S; h += kBlock) bdash[h] = inv_tot;      // BetaDashLastFrame
+  __syncthreads();
+  beta_from_dash();
+  for (int t = p.T - 1; t >= 0; t--) {
+    load_probs(t);
+    for (int k = tid; k < P; k += kBlock) drow[k] = 0.0f;
+    const float inv_scale = alpha[(long long)t * (S + 1) + S];
+    for (int h = tid; h < S; h += kBlock) { acc[h] = 0.0; occ[h] = alpha[(long long)t * (S + 1) + h] / inv_scale; }      // occupation factor (:372)
+    __syncthreads();
+    {
+      const Edges e = p.by_dst;
+#pragma unroll 4
+      for (int k = tid; k < E; k += kBlock) {
+        const int sr = e.src[k], pd = e.pdf[k];
+        const float vf = e.p[k] * a_prev[e.dst[k]] * probs[pd];
+        atomicAdd(&acc[sr], (double)vf); atomicAdd(&drow[pd], vf * occ[sr]);
+      }
+    }
+    __syncthreads();
+    double ab = 0.0;
+    for (int h = tid; h < S; h += kBlock) { const float bd = (float)(acc[h] / (double)inv_scale); if (t == 0) ab += (double)(occ[h] * inv_scale * bd); bdash[h] = bd; }      // (occ is dead: each thread overwrites only the cells it read)
+    if (t == 0) {      // BetaGeneralFrameDebug (:404-440): both sums are 1 per sequence when the computation is healthy
+      double ds = 0.0;
+      for (int k = tid; k < P; k += kBlock) ds += (double)drow[k];
+      ab = block_sum_f64(ab, red); ds = block_sum_f64(ds, red);
+      if (tid == 0) { p.check[2 * s] = (float)ab; p.check[2 * s + 1] = (float)ds; }
+    }
+    float *drv = p.deriv + ((long long)t * p.B + s) * p.ld_deriv;
+    for (int k = tid; k < P; k += kBlock) drv[k] += p.deriv_weight * drow[k];      // nnet_output_deriv += deriv_weight * deriv (:318-330)
+    beta_from_dash();
+  }
+}
+}  // namespace
+
+struct k3_chain_den {
+  int S = 0, P = 0; int E = 0;
+  float *ep = nullptr; int *ei = nullptr; float *init = nullptr;      // ep: [2][E] probabilities, ei: [2][3][E] pdf / src / dst, first half ordered by source, second by destination
+  std::vector<float> h_init;
+  float *alpha = nullptr; size_t alpha_cap = 0; double *logprob = nullptr; float *check = nullptr; int b_cap = 0;
+};
+
+extern "C" void k3_chain_den_destroy(k3_chain_den *d) {
+  if (!d) return;
+  for (void *q : {(void *)d->ep, (void *)d->ei, (void *)d->init, (void *)d->alpha, (void *)d->logprob, (void *)d->check}) if (q) (void)hipFree(q);
+  delete d;
+}
+
+extern "C" int k3_chain_den_create(int32_t num_states, int32_t start, int32_t num_pdfs, const int64_t *arc_offsets, const int32_t *ilabel, const int32_t *nextstate,
+                                   const float *weight, const float *final_cost, k3_chain_den **out) {
+  K3_REQUIRE(out && arc_offsets && ilabel && nextstate && weight && final_cost && num_states > 0 && num_pdfs > 0 && start >= 0 && start < num_states, "k3_chain_den_create: bad argument");
+  const int S = num_states; const long long A = arc_offsets[S];
+  K3_REQUIRE(A >= 0 && A < (1ll << 30), "k3_chain_den_create: bad arc count");
+  // SetTransitions (chain-den-graph.cc:52-95): a transition = (probability exp(-weight), pdf-id = label - 1, the state at its other end); the reference keeps
+  // them per source state and per destination state -- here the same two orders as flat lists
+  std::vector<std::vector<Tr>> ins(S);
+  std::vector<float> ep(2 * (size_t)A); std::vector<int> ei(6 * (size_t)A);
+  int *pdf0 = ei.data(), *src0 = pdf0 + A, *dst0 = src0 + A, *pdf1 = dst0 + A, *src1 = pdf1 + A, *dst1 = src1 + A;
+  for (int st = 0; st < S; st++)
+    for (long long a = arc_offsets[st]; a < arc_offsets[st + 1]; a++) {
+      K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= num_pdfs && nextstate[a] >= 0 && nextstate[a] < S, "k3_chain_den_create: arc label must be pdf-id + 1 in [1, num_pdfs], next state in range");
+      const float pr = expf(-weight[a]);
+      ep[a] = pr; pdf0[a] = ilabel[a] - 1; src0[a] = st; dst0[a] = nextstate[a];
+      ins[nextstate[a]].push_back(Tr{pr, ilabel[a] - 1, st});
+    }
+  { long long k = 0; for (int st = 0; st < S; st++) for (const Tr &t : ins[st]) { ep[A + k] = t.p; pdf1[k] = t.pdf; src1[k] = t.st; dst1[k] = st; k++; } }
+  // SetInitialProbs (:97-143): mass on the start state, 100 steps of propagation through the per-state normalised HMM, averaged
+  std::vector<double> norm(S), cur(S, 0.0), nxt(S, 0.0), avg(S, 0.0);
+  for (int st = 0; st < S; st++) {
+    double tot = std::exp(-(double)final_cost[st]);
+    for (long long a = arc_offsets[st]; a < arc_offsets[st + 1]; a++) tot += std::exp(-(double)weight[a]);
+    K3_REQUIRE(tot > 0.0 && tot < 100.0, "k3_chain_den_create: a state's outgoing probability mass must be in (0, 100)");
+    norm[st] = 1.0 / tot;
+  }
+  cur[start] = 1.0;
+  for (int it = 0; it < 100; it++) {
+    for (int st = 0; st < S; st++) avg[st] += (1.0 / 100) * cur[st];
+    for (int st = 0; st < S; st++) { const double pr = cur[st] * norm[st]; for (long long a = arc_offsets[st]; a < arc_offsets[st + 1]; a++) nxt[nextstate[a]] += pr * std::exp(-(double)weight[a]); }
+    cur.swap(nxt); std::fill(nxt.begin(), nxt.end(), 0.0);
+    double sum = 0.0; for (double v : cur) sum += v;
+    for (double &v : cur) v *= 1.0 / sum;
+  }
+  auto d = new k3_chain_den; d->S = S; d->P = num_pdfs; d->E = (int)A;
+  d->h_init.resize(S); for (int st = 0; st < S; st++) d->h_init[st] = (float)avg[st];
+#define K3_TRYC(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { k3_chain_den_destroy(d); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
+  K3_TRYC(hipMalloc(&d->ep, sizeof(float) * std::max<size_t>(1, ep.size()))); K3_TRYC(hipMalloc(&d->ei, sizeof(int) * std::max<size_t>(1, ei.size()))); K3_TRYC(hipMalloc(&d->init, sizeof(float) * S));
+  K3_TRYC(hipMemcpy(d->ep, ep.data(), sizeof(float) * ep.size(), hipMemcpyHostToDevice)); K3_TRYC(hipMemcpy(d->ei, ei.data(), sizeof(int) * ei.size(), hipMemcpyHostToDevice));
+  K3_TRYC(hipMemcpy(d->init, d->h_init.data(), sizeof(float) * S, hipMemcpyHostToDevice));
+#undef K3_TRYC
+  *out = d;
+  return K3_OK;
+}
+
+extern "C" int k3_chain_den_num_states(const k3_chain_den *d) { return d ? d->S : 0; }
+extern "C" int k3_chain_den_initial_probs(const k3_chain_den *d, float *h_probs) {
+  K3_REQUIRE(d && h_probs, "k3_chain_den_initial_probs: null argument");
+  std::copy(d->h_init.begin(), d->h_init.end(), h_probs);
+  return K3_OK;
+}
+
+extern "C" int k3_chain_den_forward_backward(k3_chain_den *d, const float *d_nnet_output, int64_t ld, int32_t num_sequences, int32_t frames_per_sequence, float leaky_hmm_coefficient,
+                                             float deriv_weight, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_objf, int32_t *h_ok, void *stream) {
+  K3_REQUIRE(d && d_nnet_output && h_objf && num_sequences > 0 && frames_per_sequence > 0 && ld >= d->P, "k3_chain_den_forward_backward: bad argument");
+  K3_REQUIRE(leaky_hmm_coefficient > 0.0f && leaky_hmm_coefficient < 1.0f, "k3_chain_den_forward_backward: leaky-hmm-coefficient must be in (0, 1) (chain-denominator.cc:58)");
+  K3_REQUIRE(!d_nnet_output_deriv || ld_deriv >= d->P, "k3_chain_den_forward_backward: bad derivative stride");
+  const size_t lds = sizeof(double) * (size_t)d->S + sizeof(float) * (2 * (size_t)(d->S + 1) + 2 * (size_t)d->P);
+  if (lds > 150 * 1024) { k3::set_error("k3_chain_den_forward_backward: %d states x %d pdfs need %zu B of LDS per sequence (limit 150 KB)", d->S, d->P, lds); return K3_ERR_UNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t need = (size_t)num_sequences * (frames_per_sequence + 1) * (d->S + 1);
+  if (need > d->alpha_cap) { if (d->alpha) (void)hipFree(d->alpha); d->alpha = nullptr; d->alpha_cap = 0; K3_HIP_CHECK(hipMalloc(&d->alpha, need * sizeof(float))); d->alpha_cap = need; }
+  if (num_sequences > d->b_cap) {
+    if (d->logprob) (void)hipFree(d->logprob); if (d->check) (void)hipFree(d->check); d->logprob = nullptr; d->check = nullptr; d->b_cap = 0;
+    K3_HIP_CHECK(hipMalloc(&d->logprob, sizeof(double) * num_sequences)); K3_HIP_CHECK(hipMalloc(&d->check, sizeof(float) * 2 * num_sequences)); d->b_cap = num_sequences;
+  }
+  DenParams p{};
+  const size_t E = (size_t)d->E;
+  p.by_src = Edges{d->ep, d->ei, d->ei + E, d->ei + 2 * E}; p.by_dst = Edges{d->ep + E, d->ei + 3 * E, d->ei + 4 * E, d->ei + 5 * E}; p.E = d->E; p.init = d->init;
+  p.S = d->S; p.P = d->P; p.B = num_sequences; p.T = frames_per_sequence; p.leaky = leaky_hmm_coefficient; p.deriv_weight = deriv_weight;
+  p.out = d_nnet_output; p.ld = ld; p.deriv = d_nnet_output_deriv; p.ld_deriv = ld_deriv; p.alpha = d->alpha; p.logprob = d->logprob; p.check = d->check;
+  p.do_backward = d_nnet_output_deriv ? 1 : 0;
+  K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_chain_den_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k3_chain_den_kernel, dim3(num_sequences), dim3(kBlock), lds, st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  std::vector<double> lp(num_sequences); std::vector<float> chk(2 * (size_t)num_sequences, 1.0f);
+  K3_HIP_CHECK(hipMemcpyAsync(lp.data(), d->logprob, sizeof(double) * num_sequences, hipMemcpyDeviceToHost, st));
+  if (p.do_backward) K3_HIP_CHECK(hipMemcpyAsync(chk.data(), d->check, sizeof(float) * 2 * num_sequences, hipMemcpyDeviceToHost, st));
+  K3_HIP_CHECK(hipStreamSynchronize(st));
+  double tot = 0.0; for (double v : lp) tot += v;
+  *h_objf = (float)tot;
+  if (h_ok) {      // BetaGeneralFrameDebug's verdict (:419-438): abandon the minibatch when either total is off by more than 2
+    double ab = 0.0, ds = 0.0; for (int s = 0; s < num_sequences; s++) { ab += chk[2 * s]; ds += chk[2 * s + 1]; }
+    *h_ok = (std::isfinite(tot) && std::fabs(ab - num_sequences) <= 2.0 && std::fabs(ds - num_sequences) <= 2.0) ? 1 : 0;
+  }
+  return K3_OK;
+}

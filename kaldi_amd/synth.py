@@ -285,3 +285,26 @@ def write_transition_model(f, num_pdfs):
     for p in range(1, num_pdfs + 1): _i32(f, p); _i32(f, 0); _i32(f, p - 1)
     _tok(f, "</Triples>"); _tok(f, "<LogProbs>"); _vec(f, np.concatenate([[0.0], np.full(2 * num_pdfs, np.log(0.5))]).astype(np.float32)); _tok(f, "</LogProbs>")
     _tok(f, "</TransitionModel>")
+
+
+def make_den_fst(num_states=3000, num_pdfs=4000, seed=77, mean_degree=12.0, hub_frac=0.01, hub_degree=400):
+    """A denominator graph with the shape chain-make-den-fst gives a phone language model compiled down to pdf-ids: an
+    epsilon-free, recurrent acceptor whose labels are pdf-id + 1; out-degrees geometric around mean_degree with a few hub states (the states
+    after silence / frequent phones) of ~hub_degree arcs, so in-degrees are skewed too; each state's outgoing probabilities sum to (1 - final
+    probability) like a normalised LM.  Every state is reachable (state s > 0 has an in-arc from an earlier state)."""
+    from .fst import Fst
+    rng = np.random.default_rng(seed); S = int(num_states)
+    deg = np.minimum(rng.geometric(1.0 / mean_degree, S), 8 * int(mean_degree)).astype(np.int64)
+    hubs = rng.choice(S, max(1, int(hub_frac * S)), replace=False); deg[hubs] = np.minimum(hub_degree, S)
+    src = np.repeat(np.arange(S), deg); A = src.size
+    pop = rng.lognormal(0.0, 1.5, S); pop /= pop.sum()                          # popular destinations: skewed in-degree
+    dst = rng.choice(S, A, p=pop)
+    extra_src = (rng.random(S - 1) * np.arange(1, S)).astype(np.int64); extra_dst = np.arange(1, S)      # reachability
+    src = np.concatenate([src, extra_src]); dst = np.concatenate([dst, extra_dst])
+    order = np.argsort(src, kind="stable"); src, dst = src[order], dst[order]; A = src.size
+    pdf = rng.integers(0, num_pdfs, A)
+    raw = rng.gamma(0.7, 1.0, A) + 1e-3; tot = np.zeros(S); np.add.at(tot, src, raw)
+    final_p = rng.uniform(0.01, 0.1, S)
+    prob = raw / tot[src] * (1.0 - final_p[src])
+    off = np.zeros(S + 1, np.int64); np.add.at(off, src + 1, 1); off = np.cumsum(off)
+    return Fst(0, off, (pdf + 1).astype(np.int32), (pdf + 1).astype(np.int32), (-np.log(prob)).astype(np.float32), dst.astype(np.int32), (-np.log(final_p)).astype(np.float32))

@@ -1,0 +1,42 @@
+"""The LF-MMI denominator oracle (oracle/chain_oracle.py: numpy restatement of chain/chain-den-graph.cc:52-143 and chain/chain-denominator.cc:106-440)
+against the REFERENCE's own code: committed outputs of oracle/_ref/bin/ref-chain-den (tests/golden/chain_den_golden.npz, generator
+tests/golden/make_chain_golden.py) and, where oracle/_ref exists, the binary itself on fresh random cases."""
+import importlib.util, os, numpy as np, pytest
+from kaldi_amd import synth
+from oracle import chain_oracle as co
+HERE = os.path.dirname(os.path.abspath(__file__))
+_spec = importlib.util.spec_from_file_location("make_chain_golden", os.path.join(HERE, "golden", "make_chain_golden.py")); mg = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(mg)
+GOLD = np.load(os.path.join(HERE, "golden", "chain_den_golden.npz"))
+
+@pytest.mark.parametrize("name", sorted(mg.CASES))
+def test_oracle_equals_the_reference_fixture(name):
+    f, P, out, B, leaky, dw = mg.make(name); o = co.den_oracle(f, P, out, B, leaky, dw)
+    assert abs(o["objf"] - float(GOLD[name + ".objf"])) <= 2e-6 * abs(float(GOLD[name + ".objf"])) + 1e-5
+    assert o["ok"] == bool(GOLD[name + ".ok"])
+    assert np.abs(o["initial_probs"] - GOLD[name + ".initial_probs"]).max() <= 1e-7
+    assert np.abs(o["deriv"] - GOLD[name + ".deriv"]).max() <= 2e-6
+
+def test_derivative_is_the_gradient_of_the_objective():
+    """Backward's occupation probabilities are d objf / d nnet_output (inside the [-30, 30] range): central differences on a few entries"""
+    f, P, out, B, leaky, dw = mg.make("small"); o = co.den_oracle(f, P, out.astype(np.float64), B, leaky, 1.0)
+    rng = np.random.default_rng(0)
+    for _ in range(6):
+        i, j = int(rng.integers(0, out.shape[0])), int(rng.integers(0, P)); e = 1e-2
+        a = out.copy(); a[i, j] += e; b = out.copy(); b[i, j] -= e
+        g = (co.den_oracle(f, P, a, B, leaky, 1.0)["objf"] - co.den_oracle(f, P, b, B, leaky, 1.0)["objf"]) / (2 * e)
+        assert abs(g - o["deriv"][i, j]) <= 2e-3 * max(1.0, abs(g)), (i, j, g, o["deriv"][i, j])
+
+def test_posteriors_sum_to_one_per_frame_and_sequence():
+    f, P, out, B, leaky, dw = mg.make("leaky_large"); o = co.den_oracle(f, P, out, B, leaky, 1.0)
+    assert np.abs(o["deriv"].sum(1) - 1.0).max() <= 1e-4
+
+@pytest.mark.skipif(not co.available(), reason="oracle/_ref not built (needs /root/reference once)")
+def test_oracle_equals_the_reference_binary_on_random_cases():
+    rng = np.random.default_rng(11)
+    for it in range(5):
+        S, P = int(rng.choice([30, 200, 900])), int(rng.choice([20, 150, 700])); B, T = int(rng.integers(1, 7)), int(rng.integers(1, 25))
+        f = synth.make_den_fst(S, P, seed=int(rng.integers(0, 1 << 30)), mean_degree=float(rng.choice([3.0, 10.0])), hub_degree=int(min(S, 100)))
+        out = (rng.standard_normal((T * B, P)) * float(rng.choice([1.0, 3.0, 8.0]))).astype(np.float32); leaky = float(rng.choice([1e-5, 1e-2, 0.3])); dw = float(rng.choice([-1.0, 0.7]))
+        r = co.ref_den(f, P, out, B, leaky, dw); o = co.den_oracle(f, P, out, B, leaky, dw)
+        assert abs(o["objf"] - r["objf"]) <= 2e-6 * abs(r["objf"]) + 1e-5 and o["ok"] == r["ok"], (it, o["objf"], r["objf"])
+        assert np.abs(o["initial_probs"] - r["initial_probs"]).max() <= 1e-7 and np.abs(o["deriv"] - r["deriv"]).max() <= 2e-6, it
