@@ -356,3 +356,23 @@ def test_batched_wav_nnet3_cuda2_with_ivector_extraction(tmp_path):
     # without the extractor the model cannot run: the reference's message
     r = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf"] + common + [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/x.ark"], capture_output=True, text=True)
     assert r.returncode != 0 and "Neural net expects 'ivector' features with dimension 16 but you provided 0" in r.stderr
+
+
+def test_pipeline_class_with_callbacks_and_task_groups_equals_the_program(tmp_path):
+    """kaldi_amd/host/k3_pipeline.h: BatchedThreadedNnet3CudaPipeline2's class surface (DecodeWithCallback, CreateTaskGroup / WaitForGroup /
+    DestroyTaskGroup, WaitForAllTasks; cudadecoder/batched-threaded-nnet3-cuda-pipeline2.h:57-239) driven by a caller written like the
+    reference's program: the determinized lattices its callbacks receive equal the ones batched-wav-nnet3-cuda2 writes, text record for record"""
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001, 31000, 4100, 12000, 300]      # the last one is too short to decode
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5)
+    net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000"]
+    a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=4", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/prog.txt"], capture_output=True, text=True)
+    assert a.returncode == 0, a.stderr
+    b = subprocess.run([os.path.join(BIN, "k3-pipeline-example")] + common + ["--max-batch-size=3", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/cls.txt"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    assert "Decoded 7 utterances, 1 with errors." in b.stderr, b.stderr
+    assert open(f"{td}/prog.txt").read() == open(f"{td}/cls.txt").read() and open(f"{td}/cls.txt").read().count("utt") == 6
