@@ -213,18 +213,23 @@ __device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int
   K3_LS(6);
 }
 
-// The same for the usual frame (n <= kHoN tokens, labels < kHoM): label bitmap, leader offsets and bucket groups live in LDS (`arena`, kHoLds
-// bytes), a thread keeps its <= 4 tokens in registers across the phases, and global memory is touched three times -- the labels (one
-// stream), the bucket heads (hash_size is unbounded: min rank / count by atomics, then read back) and the result.
+// The same for the usual frame (n <= kHoN tokens, labels < kHoM), entirely in LDS: label bitmap, leader offsets and bucket groups in `arena`
+// (kHoLds bytes of the dynamic segment), and the buckets themselves -- hash_size is unbounded, a frame touches at most n of them -- in an
+// open-addressing table keyed by the bucket number in `tab` (the level-1 state table's 3 x kHL words, dead at both call sites): key, smallest
+// creation rank, member count.  A thread keeps its <= 4 tokens in registers across the phases; global memory is touched for the labels and
+// states (one stream in) and the result (one stream out).  (Per-bucket arrays in HBM cost two cache-line round trips per token and call: they
+// were half of the kernel's HBM traffic.)
 constexpr int kHoN = 2048, kHoM = 16384;
 constexpr size_t kHoLds = (size_t)(kHoM / 32) * 4 + (size_t)(kHoM / 32) * 2 + 2 * (size_t)kHoN * 2;
 __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins,
-                                                   char *arena, long long &lt_last__) {
-  static_assert(kHoN <= 4 * kBlock && kHoM / 32 <= kBlock, "one pass per phase");
+                                                   char *arena, int *tab, long long &lt_last__) {
+  static_assert(kHoN <= 4 * kBlock && kHoM / 32 <= kBlock && 2 * kHoN <= kHL, "one pass per phase; table at most half full");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
   const int W = (int)((M + 31u) >> 5);
   unsigned *s_bm = reinterpret_cast<unsigned *>(arena); unsigned short *s_wpre = reinterpret_cast<unsigned short *>(s_bm + kHoM / 32), *s_lead = s_wpre + kHoM / 32, *s_grp = s_lead + kHoN;
-  unsigned lab[4], bkt[4], lf[4], cnt[4]; int d[4];
+  unsigned *b_key = reinterpret_cast<unsigned *>(tab), *b_first = b_key + kHL, *b_cnt = b_first + kHL;
+  unsigned lab[4], bkt[4], lf[4], cnt[4]; int d[4], slot[4];
+  for (int i = tid; i < kHL; i += kBlock) { b_key[i] = 0xFFFFFFFFu; b_first[i] = 0xFFFFFFFFu; b_cnt[i] = 0u; }
   if (tid < W) s_bm[tid] = 0u;
 #pragma unroll
   for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { lab[k] = K3_ALD(&q.label[i]); bkt[k] = (unsigned)st[i] % hash_size; } }
@@ -248,7 +253,10 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
     const int i = tid + k * kBlock;
     if (i < n) {
       const unsigned l = lab[k]; d[k] = (int)s_wpre[l >> 5] + __popc(s_bm[l >> 5] & ((1u << (l & 31)) - 1u));
-      k3a_min(&q.bfirst[bkt[k]], (unsigned)d[k]); k3a_add(&q.bcnt[bkt[k]], 1u);
+      unsigned h = (bkt[k] * 2654435761u) >> 20;      // 12 bits: kHL = 4096 slots
+      for (;;) { const unsigned old = atomicCAS(&b_key[h], 0xFFFFFFFFu, bkt[k]); if (old == 0xFFFFFFFFu || old == bkt[k]) break; h = (h + 1) & (kHL - 1); }
+      slot[k] = (int)h;
+      atomicMin(&b_first[h], (unsigned)d[k]); atomicAdd(&b_cnt[h], 1u);
       if (write_by_ins) q.by_ins[d[k]] = i;
     }
   }
@@ -256,9 +264,7 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
   K3_LS(2);
   bool multi = false;
 #pragma unroll
-  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { lf[k] = K3_ALD(&q.bfirst[bkt[k]]); cnt[k] = K3_ALD(&q.bcnt[bkt[k]]); } }
-#pragma unroll
-  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { s_lead[d[k]] = lf[k] == (unsigned)d[k] ? (unsigned short)cnt[k] : (unsigned short)0; multi |= cnt[k] > 1u; } }
+  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { lf[k] = b_first[slot[k]]; cnt[k] = b_cnt[slot[k]]; s_lead[d[k]] = lf[k] == (unsigned)d[k] ? (unsigned short)cnt[k] : (unsigned short)0; multi |= cnt[k] > 1u; } }
   multi = __syncthreads_or(multi);
   {      // exclusive scan of the leaders' bucket sizes in creation order, in place (4 consecutive ranks per thread)
     const int b0 = tid * 4; int x[4], sum = 0;
@@ -274,9 +280,9 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
     __syncthreads();
   }
   K3_LS(3);
-  if (multi) {      // buckets with several tokens: their members' ranks, grouped behind the leader's offset
+  if (multi) {      // buckets with several tokens: their members' ranks, grouped behind the leader's offset (b_first now counts up from the leader's rank: a cursor)
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n && cnt[k] > 1u) { const unsigned s_ = k3a_add(&q.bfill[bkt[k]], 1u); s_grp[s_lead[lf[k]] + s_] = (unsigned short)d[k]; } }
+    for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n && cnt[k] > 1u) { const unsigned s_ = atomicAdd(&b_first[slot[k]], 1u) - lf[k]; s_grp[s_lead[lf[k]] + s_] = (unsigned short)d[k]; } }
     __syncthreads();
   }
   K3_LS(4);
@@ -287,7 +293,6 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
       const unsigned lp = s_lead[lf[k]]; unsigned rank = 0;
       if (cnt[k] > 1u) for (unsigned t = 0; t < cnt[k]; t++) rank += (int)s_grp[lp + t] < d[k];
       order_out[lp + rank] = i;
-      K3_AST(&q.bfirst[bkt[k]], kLabelNone); K3_AST(&q.bcnt[bkt[k]], 0u); if (cnt[k] > 1u) K3_AST(&q.bfill[bkt[k]], 0u);      // scratch back to its idle pattern
     }
   }
   __syncthreads();
@@ -741,11 +746,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
       for (int i = tid; i < n_e; i += kBlock) q.c0[i] = dec(tb.cost(tok_slot[i]));      // costs right after ProcessEmitting (the replay starts from them)
       __syncthreads();
     }   // f >= 0
-    // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens made so far
     K3_LT(4);
-    if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, lt_last__);
-    else lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
-    K3_LT(6);
     // ---- ProcessNonemitting: order-free fixpoint (costs, new tokens, eps links)
     finish_frame<false>(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
     if (block_err(sh)) break;
@@ -800,6 +801,13 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     __syncthreads();
     if (block_err(sh)) break;
     for (int i = tid; i < n; i += kBlock) { const int slot = tok_slot[i]; if (slot >= kHL) tb.clear(slot); }      // last use of the table in this frame
+    __syncthreads();
+    K3_LT(8);
+    // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made (their labels and states are
+    // untouched by the closure).  Computed here, where the level-1 table's LDS is free for the bucket table of the pass.
+    if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, s_tab, lt_last__);
+    else lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
+    K3_LT(6);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
     const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
                                        [&](int i, int4 ex) { q.grp[i] = ex.x; q.lead[i] = (unsigned)ex.y; }, n, reinterpret_cast<int4 *>(sh.hist));
@@ -902,11 +910,11 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
 #endif
     if (n_e + created_total != n) { if (tid == 0) sh.err = K3_ERR_HIP; }      // every token of the fixpoint must have been created by the replay
     if (block_err(sh)) break;
-    for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     __syncthreads();
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
-    if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, smem_raw, lt_last__);
+    if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, smem_raw, s_tab, lt_last__);
     else lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
+    for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     K3_LT(10);
     // ---- publish the frame: final costs into the pool, empty table, idle labels
     for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], kLabelNone);
