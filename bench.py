@@ -201,7 +201,7 @@ def main():
             line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_literal_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                 "traffic": None, "traffic_measured_in_run": False, "algorithmic_bytes_per_launch": ab,
                                 "note": "algorithmic bytes (SURVEY 8d: 32 B/emitting arc traversed + 28 B/eps arc traversed + 16 B/token) from device counters / HIP-event time of the kernel on its launch stream; "
-                                        "the kernel is bound by the per-frame dependent-latency chain (33 barriers + the serial replay of the eps queue per frame and lane), not by bandwidth"}
+                                        "the kernel moves ~10x these bytes through the memory system in 4-64 B requests (per-lane scratch that does not stay in L2; `traffic`) and is bound by that transaction rate (~2 TB/s) and the per-frame chain of dependent phases, not by peak bandwidth"}
             try:      # HBM traffic of the same kernel from the committed rocprofv3 PMC passes of this round (bench.py cannot collect counters itself)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_r02.json")))
                 if U == 512 and args.utt_seconds == 10.0: line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]; line["roofline"]["traffic_source"] = tj["source"]
