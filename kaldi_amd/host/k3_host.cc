@@ -523,6 +523,12 @@ void TableWriter::WriteMatrix(const std::string &key, const float *data, int32_t
   }
   if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on matrix " << key;
 }
+void TableWriter::WriteVector(const std::string &key, const float *data, int32_t dim) {
+  std::string o = key + " ";
+  if (binary_) { o.append("\0B", 2); o += "FV "; o.push_back(4); Put(&o, dim); o.append((const char *)data, 4 * (size_t)dim); }      // matrix/kaldi-vector.cc Vector::Write
+  else { o += " [ "; char buf[32]; for (int32_t i = 0; i < dim; i++) { snprintf(buf, sizeof buf, "%g ", (double)data[i]); o += buf; } o += "]\n"; }
+  if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on vector " << key;
+}
 
 
 // ------------------------------------------------------------------------------------------------ matrices ----

@@ -198,6 +198,7 @@ class TableWriter {        // "ark:wxfilename" | "ark,t:wxfilename" (other optio
   void WriteLattice(const std::string &key, const Lattice &lat);
   void WriteCompactLattice(const std::string &key, const CompactLattice &clat);
   void WriteMatrix(const std::string &key, const float *data, int32_t rows, int32_t cols, int64_t stride);
+  void WriteVector(const std::string &key, const float *data, int32_t dim);      // BaseFloatVectorWriter
   void WriteInt32Vector(const std::string &key, const std::vector<int32_t> &v);      // Int32VectorWriter (util/kaldi-holder-inl.h BasicVectorHolder)
   void Flush();
  private:

@@ -376,3 +376,39 @@ def test_pipeline_class_with_callbacks_and_task_groups_equals_the_program(tmp_pa
     assert b.returncode == 0, b.stderr
     assert "Decoded 7 utterances, 1 with errors." in b.stderr, b.stderr
     assert open(f"{td}/prog.txt").read() == open(f"{td}/cls.txt").read() and open(f"{td}/cls.txt").read().count("utt") == 6
+
+
+def test_compute_online_feats_batched_cuda_equals_the_offline_programs(tmp_path):
+    """cudafeatbin/compute-online-feats-batched-cuda.cc's contract: audio fed in chunks of --chunk-length samples over a few channels; the feature table
+    it writes must be bit-identical to compute-fbank-feats-cuda's (chunked == whole utterance), the i-vector table = the last i-vector
+    ivector-extract-online2 estimates for each utterance (text table parsed here: the vectors are written by BaseFloatVectorWriter)"""
+    from oracle import kaldi_io as kio
+    td = str(tmp_path); lens = [16000, 9000, 23001, 4000, 31007, 1234]; IV = os.path.join(ROOT, "tests", "golden", "ivector")
+    _wavs(td, lens); open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    r = subprocess.run([os.path.join(BIN, "compute-fbank-feats-cuda"), f"--config={td}/fbank.conf", f"scp:{td}/wav.scp", f"ark:{td}/f.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    feats = kio.read_ark(f"{td}/f.ark"); allf = np.concatenate(list(feats.values())).astype(np.float64); rng = np.random.default_rng(8)
+    tm = lambda path, m: open(path, "w").write(" [\n" + "\n".join("  " + " ".join(repr(float(x)) for x in row) for row in m) + " ]\n")
+    st = np.zeros((2, 41)); st[0, :40] = allf.sum(0); st[1, :40] = (allf ** 2).sum(0); st[0, 40] = allf.shape[0]; tm(f"{td}/global_cmvn.stats", st)
+    tm(f"{td}/final.mat", (rng.standard_normal((20, 7 * 40)) * 1.5 / np.sqrt(7 * 40)).astype(np.float32))
+    open(f"{td}/splice.conf", "w").write("--left-context=3\n--right-context=3\n"); open(f"{td}/cmvn.conf", "w").write("\n")
+    open(f"{td}/ivector.conf", "w").write(f"--lda-matrix={td}/final.mat\n--global-cmvn-stats={td}/global_cmvn.stats\n--cmvn-config={td}/cmvn.conf\n--splice-config={td}/splice.conf\n--diag-ubm={IV}/final.dubm\n"
+                                          f"--ivector-extractor={IV}/final.ie\n--num-gselect=5\n--min-post=0.025\n--posterior-scale=0.1\n--max-count=100\n--ivector-period=10\n")
+    exe = os.path.join(BIN, "compute-online-feats-batched-cuda")
+    for chunk, lanes, nch in ((4000, 2, 3), (777, 4, 4)):
+        r = subprocess.run([exe, "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", f"--ivector-extraction-config={td}/ivector.conf", f"--chunk-length={chunk}", f"--batch-size={lanes}", f"--num-channels={nch}",
+                            f"scp:{td}/wav.scp", f"ark,t:{td}/iv.txt", f"ark:{td}/of.ark"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Computed online features for 6 files" in r.stderr
+        of = kio.read_ark(f"{td}/of.ark")
+        assert sorted(of) == sorted(feats)
+        for k in feats: assert of[k].shape == feats[k].shape and np.array_equal(of[k], feats[k]), (chunk, k)
+        open(f"{td}/spk2utt", "w").write("".join(f"{k} {k}\n" for k in feats))
+        r2 = subprocess.run([os.path.join(BIN, "ivector-extract-online2"), f"--config={td}/ivector.conf", f"ark:{td}/spk2utt", f"ark:{td}/f.ark", f"ark:{td}/iv.ark"], capture_output=True, text=True); assert r2.returncode == 0, r2.stderr
+        ivm = kio.read_ark(f"{td}/iv.ark"); got = {}
+        for line in open(f"{td}/iv.txt"):
+            key, rest = line.split(None, 1); got[key] = np.array([float(x) for x in rest.replace("[", "").replace("]", "").split()], np.float32)
+        for k in feats: assert got[k].shape == (ivm[k].shape[1],) and np.abs(got[k] - ivm[k][-1]).max() <= 1e-5, (chunk, k)
+    # no i-vector extractor: empty vectors, like the reference's IvectorDim() == 0
+    r = subprocess.run([exe, "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", f"scp:{td}/wav.scp", f"ark,t:{td}/iv0.txt", f"ark:{td}/of0.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    assert all(line.split(None, 1)[1].strip() == "[ ]" for line in open(f"{td}/iv0.txt"))
+    assert subprocess.run([exe, "x"], capture_output=True).returncode == 1
