@@ -55,6 +55,25 @@ struct ArcRec { int next; float w; int pdf; int olabel; };            // 16 B gr
 // it, which is the term PruneForwardLinks needs (:339-341), so pruning never touches the graph; the arc id (labels, graph cost for
 // the lattice writer) lives in a parallel 4 B array that only the output kernel reads
 struct Link { unsigned src, dst; float tot; float ac; };
+// the link / token pools are written once per frame and read by the pruning kernel much later: streaming stores keep them from evicting the per-lane scratch out of L2
+#ifndef K3_DEC_NT
+#define K3_DEC_NT 1
+#endif
+__device__ __forceinline__ void store_link(Link *dst, const Link &v) {
+#if K3_DEC_NT
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(u32x4{v.src, v.dst, __float_as_uint(v.tot), __float_as_uint(v.ac)}, reinterpret_cast<u32x4 *>(dst));
+#else
+  *dst = v;
+#endif
+}
+template <typename T> __device__ __forceinline__ void store_stream(T *dst, T v) {
+#if K3_DEC_NT
+  __builtin_nontemporal_store(v, dst);
+#else
+  *dst = v;
+#endif
+}
 
 enum { kStOk = 0, kStNoTokens = 1 };
 
@@ -123,7 +142,7 @@ struct DecParams {
   float *lt_c0;                                          // [frame_tokens_cap] token costs right after ProcessEmitting
   int2 *lt_crng; int *lt_cdst; float *lt_cw;             // closure sub-graph in token space: per token (first, count), per eps arc (dst token | -1, weight)
   float *lt_rcost; int *lt_rflag, *lt_rown, *lt_stack, *lt_iq, *lt_c2t; int2 *lt_arcs2; int4 *lt_meta;   // replay state (global copies; small frames use LDS)
-  int *lt_par, *lt_rtmp; int2 *lt_rlist, *lt_rinfo; int4 *lt_cinfo, *lt_coffs, *lt_wrec;      // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of the tokens it created
+  int *lt_par, *lt_rtmp; int2 *lt_rlist, *lt_rinfo; int4 *lt_cinfo, *lt_coffs, *lt_wrec, *lt_vis;      // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of the tokens it created
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -481,7 +500,7 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         // are recognised as stale by their stamp (Link::ac of an eps link = the source cost it was created at)
         if (mk && !claimed) { idx = tb.wait_tok(slot2, &sh.err); if (idx < 0) { fail(K3_ERR_HIP); idx = 0; } }
         const long long lp = wave_append64(mk, &sh.n_link);
-        if (mk) { if (lp < p.lane_links_cap) { links[lp] = Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}; link_arc[lp] = arc; } else fail(K3_ERR_OVERFLOW); }
+        if (mk) { if (lp < p.lane_links_cap) { store_link(&links[lp], Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}); store_stream(&link_arc[lp], arc); } else fail(K3_ERR_OVERFLOW); }
       });
       K3_TW(14);
     }
@@ -752,7 +771,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       if (mk && !claimed) { idx = tb.wait_tok(slot, &sh.err); if (idx < 0) idx = 0; }
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
-        if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + c_s), (unsigned)(nb + idx), tot, c_c}; link_arc[pos] = c_a; }
+        if (pos < p.lane_links_cap) { store_link(&links[pos], Link{(unsigned)(cur_base + c_s), (unsigned)(nb + idx), tot, c_c}); store_stream(&link_arc[pos], c_a); }
         else sh.err = K3_ERR_OVERFLOW;
       }
     }
@@ -1440,7 +1459,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     auto place = [&](auto **ptr, size_t count) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(off); off += (count * sizeof(T) + 255) & ~(size_t)255; };
     place(&p.lt_order, 2 * cap); place(&p.lt_label, cap); place(&p.lt_c0, cap); place(&p.lt_rflag, cap); place(&p.lt_rown, cap); place(&p.lt_grp, cap); place(&p.lt_lead, cap + 1);
     place(&p.lt_crng, cap); place(&p.lt_c2t, cap); place(&p.lt_iq, cap); place(&p.lt_dense, cap); place(&p.lt_by_ins, cap); place(&p.lt_meta, cap); place(&p.lt_rcost, cap);
-    place(&p.lt_par, cap); place(&p.lt_rtmp, cap); place(&p.lt_rlist, cap); place(&p.lt_wrec, 2 * cap); place(&p.lt_cinfo, cap); place(&p.lt_coffs, cap); place(&p.lt_rinfo, cap);
+    place(&p.lt_par, cap); place(&p.lt_rtmp, cap); place(&p.lt_rlist, cap); place(&p.lt_wrec, 2 * cap); place(&p.lt_cinfo, cap); place(&p.lt_coffs, cap); place(&p.lt_rinfo, cap); place(&p.lt_vis, cap);
     place(&p.lt_cmin, 2 * nch); place(&p.lt_ccnt, 2 * nch); place(&p.lt_cdst, (size_t)p.eps_cap); place(&p.lt_cw, (size_t)p.eps_cap); place(&p.lt_arcs2, (size_t)p.eps_cap);
     place(&p.lt_stack, (size_t)p.stack_cap); place(&p.lt_bm, (size_t)p.seq_words_cap); place(&p.lt_wpre, (size_t)p.seq_words_cap);
     place(&p.lt_bfirst, (size_t)p.hash_cap); place(&p.lt_bcnt, (size_t)p.hash_cap); place(&p.lt_bfill, (size_t)p.hash_cap);
@@ -1450,7 +1469,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     auto rebase = [&](auto **ptr) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(arena + reinterpret_cast<size_t>(*ptr)); };
     rebase(&p.lt_order); rebase(&p.lt_label); rebase(&p.lt_c0); rebase(&p.lt_rflag); rebase(&p.lt_rown); rebase(&p.lt_grp); rebase(&p.lt_lead); rebase(&p.lt_crng); rebase(&p.lt_c2t); rebase(&p.lt_iq);
     rebase(&p.lt_dense); rebase(&p.lt_by_ins); rebase(&p.lt_meta); rebase(&p.lt_rcost); rebase(&p.lt_par); rebase(&p.lt_rtmp); rebase(&p.lt_rlist); rebase(&p.lt_wrec); rebase(&p.lt_cinfo); rebase(&p.lt_coffs);
-    rebase(&p.lt_rinfo); rebase(&p.lt_cmin); rebase(&p.lt_ccnt); rebase(&p.lt_cdst); rebase(&p.lt_cw); rebase(&p.lt_arcs2); rebase(&p.lt_stack); rebase(&p.lt_bm); rebase(&p.lt_wpre); rebase(&p.lt_bfirst);
+    rebase(&p.lt_rinfo); rebase(&p.lt_vis); rebase(&p.lt_cmin); rebase(&p.lt_ccnt); rebase(&p.lt_cdst); rebase(&p.lt_cw); rebase(&p.lt_arcs2); rebase(&p.lt_stack); rebase(&p.lt_bm); rebase(&p.lt_wpre); rebase(&p.lt_bfirst);
     rebase(&p.lt_bcnt); rebase(&p.lt_bfill);
     // idle patterns of the scratch: labels / bucket firsts all ones, bitmap / bucket counters zero
     K3_HIP_CHECK(hipMemset2D(p.lt_label, (size_t)p.lt_lane_bytes, 0xFF, cap * sizeof(unsigned), nl));

@@ -159,6 +159,7 @@ __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int 
 struct LitLane {      // this lane's slices of the literal_order scratch
   int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *bfirst, *bcnt, *bfill, *cmin; float *c0, *cw, *rcost; int2 *crng, *arcs2; int4 *meta; int *iq, *c2t;
   int *par, *rtmp; int2 *rlist, *rinfo; int4 *cinfo, *coffs, *wrec;      // component replay (below)
+  int4 *vis;      // per visit position of the frame being expanded: (token, cost, first emitting arc, emitting arcs)
   __device__ LitLane(const DecParams &p, int L) {
     const long long cap = p.frame_tokens_cap, nch = cap / 64 + 2; const long long lb = p.lt_lane_bytes * L;
     auto at = [lb](auto *base) { return reinterpret_cast<decltype(base)>(reinterpret_cast<char *>(base) + lb); };
@@ -168,7 +169,7 @@ struct LitLane {      // this lane's slices of the literal_order scratch
     cmin = at(p.lt_cmin); ccnt = at(p.lt_ccnt); c0 = at(p.lt_c0); crng = at(p.lt_crng); (void)nch;
     cdst = at(p.lt_cdst); cw = at(p.lt_cw); rcost = at(p.lt_rcost); rflag = at(p.lt_rflag); rown = at(p.lt_rown);
     stack = at(p.lt_stack); arcs2 = at(p.lt_arcs2); iq = at(p.lt_iq); meta = at(p.lt_meta); c2t = at(p.lt_c2t);
-    par = at(p.lt_par); rtmp = at(p.lt_rtmp); rlist = at(p.lt_rlist); wrec = at(p.lt_wrec); cinfo = at(p.lt_cinfo); coffs = at(p.lt_coffs); rinfo = at(p.lt_rinfo);
+    par = at(p.lt_par); rtmp = at(p.lt_rtmp); rlist = at(p.lt_rlist); wrec = at(p.lt_wrec); cinfo = at(p.lt_cinfo); coffs = at(p.lt_coffs); rinfo = at(p.lt_rinfo); vis = at(p.lt_vis);
   }
 };
 
@@ -659,6 +660,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
       };
       for (int c = wave; c < nchunks; c += nw) {
         int i, beg, deg; float cost; chunk_tokens(c, i, cost, beg, deg);
+        if (64 * c + lane < n_cur) q.vis[64 * c + lane] = make_int4(i, __float_as_int(cost), beg, deg);      // pass B reads this instead of walking order -> token -> state -> offsets again
         unsigned cm = kEncMax;
         const int total = wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int, int, int owner, const ArcRec &r) {
           const float oc = __shfl(cost, owner);
@@ -696,7 +698,8 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
       {
         const unsigned *cpre = q.cmin + (cap / 64 + 2); const int *cbase = q.ccnt + (cap / 64 + 2);
         for (int c = wave; c < nchunks; c += nw) {
-          int i, beg, deg; float cost; chunk_tokens(c, i, cost, beg, deg);
+          int i = 0, beg = 0, deg = 0; float cost = 0.0f;
+          if (64 * c + lane < n_cur) { const int4 v = q.vis[64 * c + lane]; i = v.x; cost = __int_as_float(v.y); beg = v.z; deg = v.w; }
           unsigned run = cpre[c]; const int jbase = cbase[c];
           wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int j, int arc, int owner, const ArcRec &r) {
             const float oc = __shfl(cost, owner); const int oi = __shfl(i, owner);
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
             if (mk) k3a_min(&q.label[idx], (unsigned)(jbase + j));
             const long long pos = wave_append64(mk, &sh.n_link);
             if (mk) {
-              if (pos < p.lane_links_cap) { links[pos] = Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}; link_arc[pos] = arc; }
+              if (pos < p.lane_links_cap) { store_link(&links[pos], Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}); store_stream(&link_arc[pos], arc); }
               else sh.err = K3_ERR_OVERFLOW;
             }
           });
