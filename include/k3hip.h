@@ -358,7 +358,7 @@ int k3_vec_f64(int32_t op, double alpha, const double *d_a, const double *d_b, d
  * minibatch (Forward()'s return value).  d_nnet_output_deriv (may be NULL: forward only) += deriv_weight * posterior of each pdf on each
  * frame (Backward()'s contract; chain training passes -supervision.weight); *h_ok (may be NULL) = Backward()'s return value: 0 when the
  * alpha-beta check of chain-denominator.cc:404-440 fails and the minibatch should be abandoned.  Synchronises the stream.
- * One launch for the whole minibatch, one workgroup per sequence; K3_ERR_UNSUPPORTED when 16 states + 8 pdfs bytes exceed 150 KB of LDS. */
+ * One launch for the whole minibatch, one workgroup per sequence; K3_ERR_UNSUPPORTED when 16 states + 12 pdfs bytes exceed 150 KB of LDS. */
 typedef struct k3_chain_den k3_chain_den;
 int k3_chain_den_create(int32_t num_states, int32_t start, int32_t num_pdfs, const int64_t *arc_offsets, const int32_t *ilabel, const int32_t *nextstate,
                         const float *weight, const float *final_cost, k3_chain_den **den);

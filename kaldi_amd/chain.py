@@ -26,7 +26,7 @@ class DenominatorGraph:
     def InitialProbs(self):
         p = np.zeros(self.num_states, np.float32); _l.check(_l.load().k3_chain_den_initial_probs(self._h, p.ctypes.data)); return p
     def __del__(self):
-        if getattr(self, "_h", None): _l.load().k3_chain_den_destroy(self._h); self._h = None
+        if getattr(self, "_h", None) and _l is not None: _l.load().k3_chain_den_destroy(self._h); self._h = None
 
 class DenominatorComputation:
     """nnet_output: [frames_per_sequence * num_sequences, num_pdfs] float32 on the GPU, row t * num_sequences + s."""

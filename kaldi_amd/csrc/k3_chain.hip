@@ -65,10 +65,10 @@ __global__ __launch_bounds__(kBlock) void k3_chain_den_kernel(DenParams p) {
   __shared__ double red[kWaves];
   const int S = p.S, P = p.P, E = p.E, s = blockIdx.x, tid = threadIdx.x;
   double *acc = reinterpret_cast<double *>(smem);                 // [S] per-state sums of the frame being built (double, like the reference's accumulators)
-  float *a_prev = reinterpret_cast<float *>(acc + S);             // [S + 1] alpha-dash of the previous frame (backward: beta of the next frame)
+  double *drow = acc + S;                                         // [P] backward: the frame's derivative row (double: ds_add_f64 runs at several times the rate of ds_add_f32 here, and the sums lose nothing)
+  float *a_prev = reinterpret_cast<float *>(drow + P);            // [S + 1] alpha-dash of the previous frame (backward: beta of the next frame)
   float *probs = a_prev + (S + 1);                                // [P] exp of the frame's output row
-  float *drow = probs + P;                                        // [P] backward: the frame's derivative row
-  float *occ = drow + P;                                          // [S + 1] backward: alpha-dash of this frame / its alpha-sum
+  float *occ = probs + P;                                         // [S + 1] backward: alpha-dash of this frame / its alpha-sum
   float *alpha = p.alpha + (long long)s * (p.T + 1) * (S + 1);
   const float leaky = p.leaky;
   auto load_probs = [&](int t) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k3_chain_den_kernel(DenParams p) {
   beta_from_dash();
   for (int t = p.T - 1; t >= 0; t--) {
     load_probs(t);
-    for (int k = tid; k < P; k += kBlock) drow[k] = 0.0f;
+    for (int k = tid; k < P; k += kBlock) drow[k] = 0.0;
     const float inv_scale = alpha[(long long)t * (S + 1) + S];
     for (int h = tid; h < S; h += kBlock) { acc[h] = 0.0; occ[h] = alpha[(long long)t * (S + 1) + h] / inv_scale; }      // occupation factor (:372)
     __syncthreads();
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k3_chain_den_kernel(DenParams p) {
       for (int k = tid; k < E; k += kBlock) {
         const int sr = e.src[k], pd = e.pdf[k];
         const float vf = e.p[k] * a_prev[e.dst[k]] * probs[pd];
-        atomicAdd(&acc[sr], (double)vf); atomicAdd(&drow[pd], vf * occ[sr]);
+        atomicAdd(&acc[sr], (double)vf); atomicAdd(&drow[pd], (double)(vf * occ[sr]));
       }
     }
     __syncthreads();
@@ -139,12 +139,12 @@ __global__ __launch_bounds__(kBlock) void k3_chain_den_kernel(DenParams p) {
     for (int h = tid; h < S; h += kBlock) { const float bd = (float)(acc[h] / (double)inv_scale); if (t == 0) ab += (double)(occ[h] * inv_scale * bd); bdash[h] = bd; }      // (occ is dead: each thread overwrites only the cells it read)
     if (t == 0) {      // BetaGeneralFrameDebug (:404-440): both sums are 1 per sequence when the computation is healthy
       double ds = 0.0;
-      for (int k = tid; k < P; k += kBlock) ds += (double)drow[k];
+      for (int k = tid; k < P; k += kBlock) ds += drow[k];
       ab = block_sum_f64(ab, red); ds = block_sum_f64(ds, red);
       if (tid == 0) { p.check[2 * s] = (float)ab; p.check[2 * s + 1] = (float)ds; }
     }
     float *drv = p.deriv + ((long long)t * p.B + s) * p.ld_deriv;
-    for (int k = tid; k < P; k += kBlock) drv[k] += p.deriv_weight * drow[k];      // nnet_output_deriv += deriv_weight * deriv (:318-330)
+    for (int k = tid; k < P; k += kBlock) drv[k] += p.deriv_weight * (float)drow[k];      // nnet_output_deriv += deriv_weight * deriv (:318-330)
     beta_from_dash();
   }
 }
@@ -220,7 +220,7 @@ extern "C" int k3_chain_den_forward_backward(k3_chain_den *d, const float *d_nne
   K3_REQUIRE(d && d_nnet_output && h_objf && num_sequences > 0 && frames_per_sequence > 0 && ld >= d->P, "k3_chain_den_forward_backward: bad argument");
   K3_REQUIRE(leaky_hmm_coefficient > 0.0f && leaky_hmm_coefficient < 1.0f, "k3_chain_den_forward_backward: leaky-hmm-coefficient must be in (0, 1) (chain-denominator.cc:58)");
   K3_REQUIRE(!d_nnet_output_deriv || ld_deriv >= d->P, "k3_chain_den_forward_backward: bad derivative stride");
-  const size_t lds = sizeof(double) * (size_t)d->S + sizeof(float) * (2 * (size_t)(d->S + 1) + 2 * (size_t)d->P);
+  const size_t lds = sizeof(double) * ((size_t)d->S + (size_t)d->P) + sizeof(float) * (2 * (size_t)(d->S + 1) + (size_t)d->P);
   if (lds > 150 * 1024) { k3::set_error("k3_chain_den_forward_backward: %d states x %d pdfs need %zu B of LDS per sequence (limit 150 KB)", d->S, d->P, lds); return K3_ERR_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   const size_t need = (size_t)num_sequences * (frames_per_sequence + 1) * (d->S + 1);
