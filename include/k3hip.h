@@ -368,6 +368,33 @@ int k3_chain_den_initial_probs(const k3_chain_den *den, float *h_probs /* [num_s
 int k3_chain_den_forward_backward(k3_chain_den *den, const float *d_nnet_output, int64_t ld, int32_t num_sequences, int32_t frames_per_sequence,
                                   float leaky_hmm_coefficient, float deriv_weight, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_objf, int32_t *h_ok, void *stream);
 
+/* The numerator and the objective (chain::NumeratorComputation chain/chain-numerator.{h,cc}; chain::ComputeChainObjfAndDeriv chain/chain-training.cc:242-337,
+ * the branch for ordinary -- not end-to-end -- supervisions).
+ * k3_chain_supervision_create: the supervision FSTs of the minibatch's num_sequences sequences, UNMERGED (what the examples hold before
+ * MergeSupervision concatenates them; sequence n's states are state_offsets[n] .. state_offsets[n+1] of one CSR numbering, arcs of global state s
+ * arc_offsets[s] .. arc_offsets[s+1], nextstate local to the sequence, ilabel = pdf-id + 1).  Each must have the properties the reference asserts
+ * (chain-supervision.cc:663-700): start state 0, epsilon-free, states sorted by path length, every path frames_per_sequence arcs long.  weight =
+ * Supervision::weight.  The reference walks the merged FST serially on the CPU; here every sequence is walked by its own wavefront.
+ * k3_chain_numerator = NumeratorComputation::Forward (+ Backward when d_nnet_output_deriv is not NULL: += weight * occupation probabilities).
+ * k3_chain_objf_and_deriv = ComputeChainObjfAndDeriv: derivative zeroed, denominator (deriv -= weight * den posteriors), out-of-range penalty
+ * (the reference applies it on a coin flip, RandInt(0, 1): here when opts->apply_out_of_range_penalty), numerator (into d_xent_output_deriv when
+ * given, then added), objf = numerator - denominator log-probs (weighted), weight = supervision weight * sequences * frames, the "-10 per frame"
+ * fall-back with zeroed derivatives when the objective is not finite or the denominator's check fails, l2 term.  Pointers to the two derivative
+ * matrices may be NULL (objective only).  Synchronises the stream. */
+typedef struct k3_chain_training_opts {      /* chain::ChainTrainingOptions (chain/chain-training.h:45-104) */
+  float l2_regularize;               /* 0.0 */
+  float out_of_range_regularize;     /* 0.01 */
+  float leaky_hmm_coefficient;       /* 1.0e-05 */
+  int32_t apply_out_of_range_penalty;
+} k3_chain_training_opts;
+typedef struct k3_chain_supervision k3_chain_supervision;
+int k3_chain_supervision_create(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
+                                const int32_t *ilabel, const int32_t *nextstate, const float *arc_weight, const float *final_cost, k3_chain_supervision **sup);
+void k3_chain_supervision_destroy(k3_chain_supervision *sup);
+int k3_chain_numerator(k3_chain_supervision *sup, const float *d_nnet_output, int64_t ld, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_logprob_weighted, void *stream);
+int k3_chain_objf_and_deriv(k3_chain_den *den, k3_chain_supervision *sup, const k3_chain_training_opts *opts, const float *d_nnet_output, int64_t ld,
+                            float *d_nnet_output_deriv, int64_t ld_deriv, float *d_xent_output_deriv, int64_t ld_xent, float *h_objf, float *h_l2_term, float *h_weight, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

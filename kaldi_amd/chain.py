@@ -8,9 +8,11 @@ import torch
 from . import lib as _l
 
 class ChainTrainingOptions:
-    """the fields of chain::ChainTrainingOptions (chain/chain-training.h:45-104) the denominator reads"""
-    def __init__(self, leaky_hmm_coefficient=1.0e-05):
-        self.leaky_hmm_coefficient = float(leaky_hmm_coefficient)
+    """chain::ChainTrainingOptions (chain/chain-training.h:45-104); apply_out_of_range_penalty replaces the reference's coin flip (chain-training.cc:273)"""
+    def __init__(self, leaky_hmm_coefficient=1.0e-05, l2_regularize=0.0, out_of_range_regularize=0.01, apply_out_of_range_penalty=False):
+        self.leaky_hmm_coefficient = float(leaky_hmm_coefficient); self.l2_regularize = float(l2_regularize); self.out_of_range_regularize = float(out_of_range_regularize)
+        self.apply_out_of_range_penalty = bool(apply_out_of_range_penalty)
+    def _c(self): return _l.ChainTrainingOpts(self.l2_regularize, self.out_of_range_regularize, self.leaky_hmm_coefficient, int(self.apply_out_of_range_penalty))
 
 class DenominatorGraph:
     def __init__(self, fst, num_pdfs):
@@ -49,3 +51,39 @@ class DenominatorComputation:
         (The forward pass is repeated inside the same launch: the kernel keeps no state between calls.)"""
         assert nnet_output_deriv.shape == self.out.shape and nnet_output_deriv.stride(1) == 1 and nnet_output_deriv.is_cuda
         self._objf, ok = self._run(deriv_weight, nnet_output_deriv); return ok
+
+
+class Supervision:
+    """chain::Supervision (chain/chain-supervision.h:226-330) for a minibatch, with the sequences' FSTs kept apart: fsts = one kaldi_amd.fst.Fst per
+    sequence (start state 0, labels pdf-id + 1, states sorted by path length, every path frames_per_sequence arcs long)."""
+    def __init__(self, fsts, frames_per_sequence, label_dim, weight=1.0):
+        L = _l.load(); self.num_sequences = len(fsts); self.frames_per_sequence = int(frames_per_sequence); self.label_dim = int(label_dim); self.weight = float(weight)
+        so = np.concatenate([[0], np.cumsum([f.num_states for f in fsts])]).astype(np.int32)
+        ao = np.concatenate([[0]] + [np.asarray(f.arc_offsets[1:], np.int64) + b for f, b in zip(fsts, np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in fsts])[:-1]]))]).astype(np.int64)
+        il = np.concatenate([f.ilabel for f in fsts]).astype(np.int32); nx = np.concatenate([f.nextstate for f in fsts]).astype(np.int32)
+        w = np.concatenate([f.weight for f in fsts]).astype(np.float32); fin = np.concatenate([f.final for f in fsts]).astype(np.float32)
+        h = ctypes.c_void_p()
+        _l.check(L.k3_chain_supervision_create(self.num_sequences, self.frames_per_sequence, self.label_dim, self.weight, so.ctypes.data, ao.ctypes.data, il.ctypes.data, nx.ctypes.data, w.ctypes.data, fin.ctypes.data, ctypes.byref(h)))
+        self._h = h
+    def __del__(self):
+        if getattr(self, "_h", None) and _l is not None: _l.load().k3_chain_supervision_destroy(self._h); self._h = None
+
+class NumeratorComputation:
+    """chain::NumeratorComputation (chain/chain-numerator.h:63-146): Forward() = weight * log-prob of the supervision; Backward(deriv) adds weight * occupation probabilities"""
+    def __init__(self, supervision, nnet_output):
+        assert nnet_output.shape == (supervision.num_sequences * supervision.frames_per_sequence, supervision.label_dim) and nnet_output.is_cuda and nnet_output.stride(1) == 1
+        self.sup, self.out = supervision, nnet_output
+    def _run(self, deriv):
+        v = ctypes.c_float(0.0)
+        _l.check(_l.load().k3_chain_numerator(self.sup._h, self.out.data_ptr(), self.out.stride(0), deriv.data_ptr() if deriv is not None else None, deriv.stride(0) if deriv is not None else 0, ctypes.byref(v), torch.cuda.current_stream().cuda_stream))
+        return v.value
+    def Forward(self): return self._run(None)
+    def Backward(self, nnet_output_deriv): self._run(nnet_output_deriv)
+
+def ComputeChainObjfAndDeriv(opts, den_graph, supervision, nnet_output, nnet_output_deriv=None, xent_output_deriv=None):
+    """chain::ComputeChainObjfAndDeriv (chain/chain-training.cc:242-337); returns (objf, l2_term, weight); the derivative matrices (optional) are overwritten"""
+    objf, l2, wt = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0); c = opts._c()
+    p = lambda m: (m.data_ptr(), m.stride(0)) if m is not None else (None, 0)
+    _l.check(_l.load().k3_chain_objf_and_deriv(den_graph._h, supervision._h, ctypes.byref(c), nnet_output.data_ptr(), nnet_output.stride(0), *p(nnet_output_deriv), *p(xent_output_deriv),
+                                               ctypes.byref(objf), ctypes.byref(l2), ctypes.byref(wt), torch.cuda.current_stream().cuda_stream))
+    return objf.value, l2.value, wt.value

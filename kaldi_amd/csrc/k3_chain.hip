@@ -250,3 +250,205 @@ extern "C" int k3_chain_den_forward_backward(k3_chain_den *d, const float *d_nne
   }
   return K3_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Numerator of the LF-MMI objective: forward-backward over the supervision FSTs (chain::NumeratorComputation, chain/chain-numerator.cc:115-213) and
+// the objective function that puts numerator, denominator and regularisers together (chain::ComputeChainObjfAndDeriv, chain/chain-training.cc:
+// 242-330, the non-e2e branch).
+// The reference runs the numerator on the CPU over ONE merged FST (the minibatch's supervisions concatenated: a chain of sequences x frames
+// levels walked serially in log space, in double).  The sequences of a minibatch are independent: here every sequence keeps its own FST and gets
+// its own wavefront, which walks its frames_per_sequence levels forward and backward with all arcs of a level in flight (the merged FST's
+// boundary states only differ by the final weights of the previous sequence, which factor out of the posteriors and add up in the total).
+// Per level the sums are taken in the linear domain against the level's largest term, accumulated in double by LDS atomics: terms more than
+// 700 nats below it vanish, as they do in the reference's LogAdd (which drops everything below -36.7 nats, base/kaldi-math.h:187-205).
+namespace {
+struct NumParams {
+  const int *state_off, *layer_off;      // [B + 1] first state of a sequence (global numbering); [B][T + 2] first state (local) of each time level, level T + 1 = number of states
+  const long long *arc_off;              // [total states + 1]
+  const int *arc_src, *arc_dst, *arc_pdf; const float *arc_w; const float *final_cost;      // arcs: local source / destination state, pdf-id, weight; per state final cost
+  int B, T; float weight;
+  const float *out; long long ld; float *deriv; long long ld_deriv; float *xent; long long ld_xent;
+  double *logprob;                       // [B]
+  int max_states;
+};
+
+__global__ __launch_bounds__(64) void k3_chain_num_kernel(NumParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *alpha = reinterpret_cast<double *>(smem), *beta = alpha + p.max_states, *acc = beta + p.max_states;      // log alpha, log beta, linear-domain accumulators
+  const int n = blockIdx.x, lane = threadIdx.x, T = p.T;
+  const int s0 = p.state_off[n], S = p.state_off[n + 1] - s0; const int *lo = p.layer_off + (long long)n * (T + 2);
+  const long long *aoff = p.arc_off + s0; const float *fin = p.final_cost + s0;
+  const double kNegInf = -__builtin_inf();
+  for (int i = lane; i < S; i += 64) { alpha[i] = i == 0 ? 0.0 : kNegInf; acc[i] = 0.0; }
+  __syncthreads();
+  auto wave_max = [](double v) { for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; } return v; };
+  auto loglike = [&](int t, int pdf) { return (double)p.out[((long long)t * p.B + n) * p.ld + pdf]; };
+  // ---- forward (:115-160): level t's arcs consume frame t
+  for (int t = 0; t < T; t++) {
+    const long long a0 = aoff[lo[t]], a1 = aoff[lo[t + 1]];
+    double m = kNegInf;
+    for (long long a = a0 + lane; a < a1; a += 64) { const double x = alpha[p.arc_src[a]] + loglike(t, p.arc_pdf[a]) - (double)p.arc_w[a]; m = x > m ? x : m; }
+    m = wave_max(m);
+    if (m != kNegInf) for (long long a = a0 + lane; a < a1; a += 64) { const double x = alpha[p.arc_src[a]] + loglike(t, p.arc_pdf[a]) - (double)p.arc_w[a]; atomicAdd(&acc[p.arc_dst[a]], exp(x - m)); }
+    __syncthreads();
+    for (int i = lo[t + 1] + lane; i < lo[t + 2]; i += 64) { alpha[i] = acc[i] > 0.0 ? m + log(acc[i]) : kNegInf; acc[i] = 0.0; }
+    __syncthreads();
+  }
+  // total log-prob over the final states (:150-156)
+  double m = kNegInf;
+  for (int i = lo[T] + lane; i < lo[T + 1]; i += 64) { const double x = alpha[i] - (double)fin[i]; m = x > m ? x : m; }
+  m = wave_max(m);
+  double sum = 0.0;
+  if (m != kNegInf) for (int i = lo[T] + lane; i < lo[T + 1]; i += 64) sum += exp(alpha[i] - (double)fin[i] - m);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const double tot = m != kNegInf ? m + log(sum) : kNegInf;
+  if (lane == 0) p.logprob[n] = tot;
+  if (!p.deriv && !p.xent) return;
+  // ---- backward (:163-213): log beta, occupation probabilities into the derivative rows
+  for (int i = lo[T] + lane; i < lo[T + 1]; i += 64) beta[i] = -(double)fin[i];
+  __syncthreads();
+  for (int t = T - 1; t >= 0; t--) {
+    const long long a0 = aoff[lo[t]], a1 = aoff[lo[t + 1]];
+    double mb = kNegInf;
+    for (long long a = a0 + lane; a < a1; a += 64) { const double y = loglike(t, p.arc_pdf[a]) - (double)p.arc_w[a] + beta[p.arc_dst[a]]; mb = y > mb ? y : mb; }
+    mb = wave_max(mb);
+    for (long long a = a0 + lane; a < a1; a += 64) {
+      const int src = p.arc_src[a], pdf = p.arc_pdf[a];
+      const double y = loglike(t, pdf) - (double)p.arc_w[a] + beta[p.arc_dst[a]];
+      if (mb != kNegInf) atomicAdd(&acc[src], exp(y - mb));
+      const float occ = (float)exp(alpha[src] + y - tot);      // occupation_logprob (:196-199)
+      if (occ != 0.0f) {
+        if (p.xent) atomicAdd(&p.xent[((long long)t * p.B + n) * p.ld_xent + pdf], p.weight * occ);
+        else atomicAdd(&p.deriv[((long long)t * p.B + n) * p.ld_deriv + pdf], p.weight * occ);
+      }
+    }
+    __syncthreads();
+    for (int i = lo[t] + lane; i < lo[t + 1]; i += 64) { beta[i] = acc[i] > 0.0 ? mb + log(acc[i]) : kNegInf; acc[i] = 0.0; }
+    __syncthreads();
+  }
+}
+
+// PenalizeOutOfRange (chain-training.cc:49-93) and the sum of squares of the l2 term
+__global__ void k3_chain_penalize_kernel(const float *in, long long ld, float *out, long long ld_out, int rows, int cols, float limit, float scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (long long)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols); const float v = in[r * ld + c];
+  if (v < -limit) out[r * ld_out + c] -= scale * (v + limit); else if (v > limit) out[r * ld_out + c] -= scale * (v - limit);
+}
+__global__ void k3_chain_sumsq_kernel(const float *in, long long ld, int rows, int cols, double *result) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)rows * cols; i += (long long)gridDim.x * blockDim.x) { const float v = in[(i / cols) * ld + (i % cols)]; acc += (double)v * v; }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(result, red[0] + red[1] + red[2] + red[3]);
+}
+}  // namespace
+
+struct k3_chain_supervision {
+  int B = 0, T = 0, P = 0, max_states = 0; float weight = 1.0f;
+  int *ints = nullptr; long long *arc_off = nullptr; float *floats = nullptr; double *logprob = nullptr; double *scratch = nullptr;
+  const int *state_off = nullptr, *layer_off = nullptr, *arc_src = nullptr, *arc_dst = nullptr, *arc_pdf = nullptr; const float *arc_w = nullptr, *final_cost = nullptr;
+};
+extern "C" void k3_chain_supervision_destroy(k3_chain_supervision *s) {
+  if (!s) return;
+  for (void *q : {(void *)s->ints, (void *)s->arc_off, (void *)s->floats, (void *)s->logprob, (void *)s->scratch}) if (q) (void)hipFree(q);
+  delete s;
+}
+extern "C" int k3_chain_supervision_create(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
+                                           const int32_t *ilabel, const int32_t *nextstate, const float *arc_weight, const float *final_cost, k3_chain_supervision **out) {
+  K3_REQUIRE(out && state_offsets && arc_offsets && ilabel && nextstate && arc_weight && final_cost && num_sequences > 0 && frames_per_sequence > 0 && label_dim > 0, "k3_chain_supervision_create: bad argument");
+  const int B = num_sequences, T = frames_per_sequence; const int NS = state_offsets[B]; const long long NA = arc_offsets[NS];
+  std::vector<int> layer((size_t)B * (T + 2)), src(NA), dst(NA), pdf(NA); int max_states = 0;
+  for (int n = 0; n < B; n++) {      // ComputeFstStateTimes (chain-supervision.cc:663-700): start state 0, every arc advances one frame, states sorted by time, all paths T arcs long
+    const int s0 = state_offsets[n], S = state_offsets[n + 1] - s0; K3_REQUIRE(S > 0, "k3_chain_supervision_create: empty supervision FST");
+    max_states = std::max(max_states, S);
+    std::vector<int> time(S, -1); time[0] = 0;
+    for (int st = 0; st < S; st++) {
+      K3_REQUIRE(time[st] >= 0 && (st == 0 || time[st] >= time[st - 1]), "k3_chain_supervision_create: the FST's states must be reachable and sorted by path length from state 0 (ComputeFstStateTimes)");
+      for (long long a = arc_offsets[s0 + st]; a < arc_offsets[s0 + st + 1]; a++) {
+        K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= label_dim && nextstate[a] >= 0 && nextstate[a] < S, "k3_chain_supervision_create: arc label must be pdf-id + 1 in [1, label_dim], next state in range");
+        K3_REQUIRE(time[nextstate[a]] == -1 || time[nextstate[a]] == time[st] + 1, "k3_chain_supervision_create: all paths to a state must have the same length");
+        time[nextstate[a]] = time[st] + 1; src[a] = st; dst[a] = nextstate[a]; pdf[a] = ilabel[a] - 1;
+      }
+      if (final_cost[s0 + st] != __builtin_inff()) K3_REQUIRE(time[st] == T, "k3_chain_supervision_create: final states must be frames_per_sequence arcs from the start state");
+      else K3_REQUIRE(time[st] < T, "k3_chain_supervision_create: a state at the last level must be final");
+    }
+    int *lo = &layer[(size_t)n * (T + 2)]; int st = 0;
+    for (int t = 0; t <= T; t++) { lo[t] = st; while (st < S && time[st] == t) st++; K3_REQUIRE(st > lo[t], "k3_chain_supervision_create: a time level has no states"); }
+    lo[T + 1] = S; K3_REQUIRE(st == S, "k3_chain_supervision_create: states beyond the last level");
+  }
+  auto s = new k3_chain_supervision; s->B = B; s->T = T; s->P = label_dim; s->weight = weight; s->max_states = max_states;
+  std::vector<int> ints; ints.insert(ints.end(), state_offsets, state_offsets + B + 1); ints.insert(ints.end(), layer.begin(), layer.end());
+  ints.insert(ints.end(), src.begin(), src.end()); ints.insert(ints.end(), dst.begin(), dst.end()); ints.insert(ints.end(), pdf.begin(), pdf.end());
+  std::vector<float> fl(arc_weight, arc_weight + NA); fl.insert(fl.end(), final_cost, final_cost + NS);
+  std::vector<long long> ao(arc_offsets, arc_offsets + NS + 1);
+#define K3_TRYS(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { k3_chain_supervision_destroy(s); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
+  K3_TRYS(hipMalloc(&s->ints, sizeof(int) * ints.size())); K3_TRYS(hipMalloc(&s->floats, sizeof(float) * std::max<size_t>(1, fl.size()))); K3_TRYS(hipMalloc(&s->arc_off, sizeof(long long) * ao.size()));
+  K3_TRYS(hipMalloc(&s->logprob, sizeof(double) * B)); K3_TRYS(hipMalloc(&s->scratch, sizeof(double)));
+  K3_TRYS(hipMemcpy(s->ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice)); K3_TRYS(hipMemcpy(s->floats, fl.data(), sizeof(float) * fl.size(), hipMemcpyHostToDevice));
+  K3_TRYS(hipMemcpy(s->arc_off, ao.data(), sizeof(long long) * ao.size(), hipMemcpyHostToDevice));
+#undef K3_TRYS
+  s->state_off = s->ints; s->layer_off = s->state_off + B + 1; s->arc_src = s->layer_off + (size_t)B * (T + 2); s->arc_dst = s->arc_src + NA; s->arc_pdf = s->arc_dst + NA;
+  s->arc_w = s->floats; s->final_cost = s->floats + NA;
+  *out = s;
+  return K3_OK;
+}
+
+// NumeratorComputation::Forward (+ Backward when a derivative matrix is given): *h_logprob_weighted = weight * total log-prob; deriv (or xent) += weight * occupation probabilities
+static int chain_numerator(k3_chain_supervision *s, const float *d_out, int64_t ld, float *d_deriv, int64_t ld_deriv, float *d_xent, int64_t ld_xent, float *h_logprob_weighted, hipStream_t st) {
+  const size_t lds = 3 * sizeof(double) * (size_t)s->max_states;
+  if (lds > 150 * 1024) { k3::set_error("k3_chain numerator: a supervision FST of %d states needs %zu B of LDS (limit 150 KB)", s->max_states, lds); return K3_ERR_UNSUPPORTED; }
+  NumParams p{}; p.state_off = s->state_off; p.layer_off = s->layer_off; p.arc_off = s->arc_off; p.arc_src = s->arc_src; p.arc_dst = s->arc_dst; p.arc_pdf = s->arc_pdf; p.arc_w = s->arc_w; p.final_cost = s->final_cost;
+  p.B = s->B; p.T = s->T; p.weight = s->weight; p.out = d_out; p.ld = ld; p.deriv = d_deriv; p.ld_deriv = ld_deriv; p.xent = d_xent; p.ld_xent = ld_xent; p.logprob = s->logprob; p.max_states = s->max_states;
+  K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_chain_num_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k3_chain_num_kernel, dim3(s->B), dim3(64), lds, st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  std::vector<double> lp(s->B);
+  K3_HIP_CHECK(hipMemcpyAsync(lp.data(), s->logprob, sizeof(double) * s->B, hipMemcpyDeviceToHost, st)); K3_HIP_CHECK(hipStreamSynchronize(st));
+  double tot = 0.0; for (double v : lp) tot += v;
+  *h_logprob_weighted = (float)(tot * (double)s->weight);
+  return K3_OK;
+}
+extern "C" int k3_chain_numerator(k3_chain_supervision *sup, const float *d_nnet_output, int64_t ld, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_logprob_weighted, void *stream) {
+  K3_REQUIRE(sup && d_nnet_output && h_logprob_weighted && ld >= sup->P && (!d_nnet_output_deriv || ld_deriv >= sup->P), "k3_chain_numerator: bad argument");
+  return chain_numerator(sup, d_nnet_output, ld, d_nnet_output_deriv, ld_deriv, nullptr, 0, h_logprob_weighted, (hipStream_t)stream);
+}
+
+extern "C" int k3_chain_objf_and_deriv(k3_chain_den *den, k3_chain_supervision *sup, const k3_chain_training_opts *opts, const float *d_nnet_output, int64_t ld,
+                                       float *d_nnet_output_deriv, int64_t ld_deriv, float *d_xent_output_deriv, int64_t ld_xent, float *h_objf, float *h_l2_term, float *h_weight, void *stream) {
+  K3_REQUIRE(den && sup && opts && d_nnet_output && h_objf && h_l2_term && h_weight && sup->P == den->P && ld >= den->P, "k3_chain_objf_and_deriv: bad argument");
+  K3_REQUIRE((!d_nnet_output_deriv || ld_deriv >= den->P) && (!d_xent_output_deriv || ld_xent >= den->P), "k3_chain_objf_and_deriv: bad derivative stride");
+  hipStream_t st = (hipStream_t)stream; const int rows = sup->B * sup->T, P = den->P; const float w = sup->weight;
+  auto zero = [&](float *m, int64_t l) -> int { K3_HIP_CHECK(hipMemset2DAsync(m, (size_t)l * 4, 0, (size_t)P * 4, (size_t)rows, st)); return K3_OK; };
+  if (d_nnet_output_deriv) { const int rc = zero(d_nnet_output_deriv, ld_deriv); if (rc) return rc; }                       // :258-259
+  float den_logprob = 0.0f; int32_t ok = 1;
+  { const int rc = k3_chain_den_forward_backward(den, d_nnet_output, ld, sup->B, sup->T, opts->leaky_hmm_coefficient, -w, d_nnet_output_deriv, ld_deriv, &den_logprob, &ok, stream); if (rc) return rc; }      // :261-271
+  const float den_logprob_weighted = w * den_logprob;
+  if (d_nnet_output_deriv && opts->apply_out_of_range_penalty && opts->out_of_range_regularize != 0.0f) {                      // :273-277 (the reference applies it on a coin flip; here the caller decides)
+    const long long n = (long long)rows * P;
+    hipLaunchKernelGGL(k3_chain_penalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_nnet_output, (long long)ld, d_nnet_output_deriv, (long long)ld_deriv, rows, P, 30.0f, 2.0f * opts->out_of_range_regularize);
+  }
+  if (d_xent_output_deriv) { const int rc = zero(d_xent_output_deriv, ld_xent); if (rc) return rc; }                       // :279-282
+  float num_logprob_weighted = 0.0f;
+  { const int rc = chain_numerator(sup, d_nnet_output, ld, d_xent_output_deriv ? nullptr : d_nnet_output_deriv, ld_deriv, d_xent_output_deriv, ld_xent, &num_logprob_weighted, st); if (rc) return rc; }      // :285-297
+  if (d_xent_output_deriv && d_nnet_output_deriv) { const int rc = k3_mat_add_mat(1.0f, d_xent_output_deriv, ld_xent, 0, d_nnet_output_deriv, ld_deriv, rows, P, stream); if (rc) return rc; }
+  *h_objf = num_logprob_weighted - den_logprob_weighted; *h_weight = w * sup->B * sup->T;                                    // :299-301
+  if (!(*h_objf - *h_objf == 0.0f) || !ok) {                                                                                // :302-314: abandon the minibatch
+    if (d_nnet_output_deriv) { const int rc = zero(d_nnet_output_deriv, ld_deriv); if (rc) return rc; }
+    if (d_xent_output_deriv) { const int rc = zero(d_xent_output_deriv, ld_xent); if (rc) return rc; }
+    *h_objf = -10.0f * *h_weight;
+  }
+  *h_l2_term = 0.0f;
+  if (opts->l2_regularize != 0.0f) {                                                                                        // :329-337
+    const float scale = w * opts->l2_regularize; double sumsq = 0.0;
+    K3_HIP_CHECK(hipMemsetAsync(sup->scratch, 0, sizeof(double), st));
+    hipLaunchKernelGGL(k3_chain_sumsq_kernel, dim3(512), dim3(256), 0, st, d_nnet_output, (long long)ld, rows, P, sup->scratch);
+    K3_HIP_CHECK(hipMemcpyAsync(&sumsq, sup->scratch, sizeof(double), hipMemcpyDeviceToHost, st)); K3_HIP_CHECK(hipStreamSynchronize(st));
+    *h_l2_term = (float)(-0.5 * (double)scale * sumsq);
+    if (d_nnet_output_deriv) { const int rc = k3_mat_add_mat(-scale, d_nnet_output, ld, 0, d_nnet_output_deriv, ld_deriv, rows, P, stream); if (rc) return rc; }
+  }
+  K3_HIP_CHECK(hipStreamSynchronize(st));
+  return K3_OK;
+}

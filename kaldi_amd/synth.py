@@ -308,3 +308,46 @@ def make_den_fst(num_states=3000, num_pdfs=4000, seed=77, mean_degree=12.0, hub_
     prob = raw / tot[src] * (1.0 - final_p[src])
     off = np.zeros(S + 1, np.int64); np.add.at(off, src + 1, 1); off = np.cumsum(off)
     return Fst(0, off, (pdf + 1).astype(np.int32), (pdf + 1).astype(np.int32), (-np.log(prob)).astype(np.float32), dst.astype(np.int32), (-np.log(final_p)).astype(np.float32))
+
+
+def make_supervision_fst(frames, num_pdfs, seed, width=3, branch=2.0, pdf_pool=None):
+    """One sequence's numerator FST in the shape chain-get-supervision gives it: an epsilon-free acceptor over pdf-id + 1, start
+    state 0, states sorted by time, `width` alternative states per frame on average (the alignment's tolerance window), ~`branch` arcs per state
+    to the next frame, small arc weights, final states (cost 0 or small) on the last level.  Every state is reachable and can reach a final state."""
+    from .fst import Fst
+    rng = np.random.default_rng(seed); T = int(frames)
+    nper = [1] + [int(rng.integers(1, 2 * width)) for _ in range(T)]
+    first = np.concatenate([[0], np.cumsum(nper)]); S = int(first[-1]); pool = np.arange(num_pdfs) if pdf_pool is None else np.asarray(pdf_pool)
+    src, dst, lab, w = [], [], [], []
+    for t in range(T):
+        a, b = np.arange(first[t], first[t + 1]), np.arange(first[t + 1], first[t + 2])
+        pdfs = rng.choice(pool, max(2, min(4, pool.size)), replace=False)      # a frame's alignment window allows a few pdfs
+        for s_ in a:                                                            # every state goes somewhere
+            for d in rng.choice(b, min(b.size, max(1, int(rng.poisson(branch)))), replace=False): src.append(s_); dst.append(d); lab.append(int(rng.choice(pdfs)) + 1); w.append(float(rng.choice([0.0, 0.0, rng.uniform(0, 2)])))
+        reached = set(dst[-1 - k] for k in range(0)) ; reached = set(d for s_, d in zip(src, dst) if first[t] <= s_ < first[t + 1])
+        for d in b:                                                             # every state is reached
+            if d not in reached: src.append(int(rng.choice(a))); dst.append(d); lab.append(int(rng.choice(pdfs)) + 1); w.append(0.0)
+    order = np.lexsort((np.arange(len(src)), np.array(src))); src, dst, lab, w = (np.asarray(x)[order] for x in (src, dst, lab, w))
+    off = np.zeros(S + 1, np.int64); np.add.at(off, src + 1, 1); off = np.cumsum(off)
+    fin = np.full(S, np.inf, np.float32); fin[first[T]:] = rng.choice([0.0, 0.5], S - first[T])
+    return Fst(0, off, lab.astype(np.int32), lab.astype(np.int32), w.astype(np.float32), dst.astype(np.int32), fin)
+
+def merge_supervision_fsts(fsts):
+    """The merged FST chain::MergeSupervision builds for a minibatch (fst::Concat of the sequences + RmEpsilon, chain-supervision.cc:744-800), restated
+    for the tests' reference run: the final states of sequence n take over copies of sequence n + 1's start arcs with their final cost added."""
+    from .fst import Fst
+    base = np.concatenate([[0], np.cumsum([f.num_states - 1 for f in fsts[1:]] and [fsts[0].num_states] + [f.num_states - 1 for f in fsts[1:]])])
+    arcs = []; S = int(base[-1]); fin = np.full(S, np.inf, np.float32)
+    gid = lambda n, s: int(s) if n == 0 else int(base[n] + s - 1)              # sequence n > 0 loses its start state
+    for n, f in enumerate(fsts):
+        for s in range(f.num_states):
+            if n > 0 and s == 0: continue
+            for a in range(int(f.arc_offsets[s]), int(f.arc_offsets[s + 1])): arcs.append((gid(n, s), int(f.ilabel[a]), float(f.weight[a]), gid(n, f.nextstate[a])))
+            if np.isfinite(f.final[s]):
+                if n + 1 < len(fsts):
+                    g = fsts[n + 1]
+                    for a in range(int(g.arc_offsets[0]), int(g.arc_offsets[1])): arcs.append((gid(n, s), int(g.ilabel[a]), float(np.float32(f.final[s]) + np.float32(g.weight[a])), gid(n + 1, g.nextstate[a])))
+                else: fin[gid(n, s)] = f.final[s]
+    arcs.sort(key=lambda x: x[0]); src = np.array([a[0] for a in arcs]); off = np.zeros(S + 1, np.int64); np.add.at(off, src + 1, 1); off = np.cumsum(off)
+    lab = np.array([a[1] for a in arcs], np.int32)
+    return Fst(0, off, lab, lab, np.array([a[2] for a in arcs], np.float32), np.array([a[3] for a in arcs], np.int32), fin)

@@ -103,9 +103,13 @@ link_iv ivector-extractor-copy      $R/ivectorbin/ivector-extractor-copy.cc
 # the reference's LF-MMI denominator (chain/chain-den-graph.cc + chain/chain-denominator.cc, CPU path) over the OpenFst stand-in.  Both files compile
 # UNMODIFIED; the graph-compilation half of chain-den-graph.cc (CreateDenominatorFst ...: real OpenFst algorithms) is never called and its callees are
 # declarations only (minifst/hmm/hmm-utils.h, minifst/fstext/{deterministic-fst,push-special}.h) -- the link line ignores unresolved symbols like the others.
+# chain/chain-numerator.cc and chain/chain-training.cc (ComputeChainObjfAndDeriv) compile unmodified too: ref-chain-objf is the oracle of the whole LF-MMI objective.
 mkdir -p $W/obj_chain
 g++ $MF -c $R/chain/chain-den-graph.cc -o $W/obj_chain/chain-den-graph.o
 g++ $MF -c $R/chain/chain-denominator.cc -o $W/obj_chain/chain-denominator.o
+g++ $MF -c $R/chain/chain-numerator.cc -o $W/obj_chain/chain-numerator.o
+g++ $MF -c $R/chain/chain-training.cc -o $W/obj_chain/chain-training.o
+g++ $MF $HERE/ref_tools/ref_chain_objf.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-chain-objf
 g++ $MF $HERE/ref_tools/ref_chain_den.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-chain-den
 for f in /opt/conda/lib/libmkl_{rt,core,intel_lp64,sequential,gnu_thread,intel_thread,avx2,avx512,def,mc3,vml_avx2,vml_avx512,vml_def}.so.1; do
   [ -e $f ] && ln -sf $f $W/mkl/ || true; done

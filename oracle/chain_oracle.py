@@ -80,3 +80,65 @@ def den_oracle(fst, num_pdfs, nnet_output, num_sequences, leaky_hmm_coefficient=
         beta = beta_of(bd)
     ok = bool(np.isfinite(objf) and abs(ab0 - B) <= 2.0 and abs(ds0 - B) <= 2.0)
     return dict(objf=objf, ok=ok, initial_probs=init, deriv=(f32(deriv_weight) * deriv).reshape(TB, P))
+
+# ---- numerator and the whole objective ------------------------------------------------------------------------------------------------------
+_BIN_OBJF = os.path.join(HERE, "_ref", "bin", "ref-chain-objf")
+def objf_available():
+    return os.path.exists(_BIN_OBJF)
+
+def _fst_bytes(f):
+    return (np.ascontiguousarray(f.arc_offsets, np.int64).tobytes() + np.ascontiguousarray(f.ilabel, np.int32).tobytes() + np.ascontiguousarray(f.nextstate, np.int32).tobytes() +
+            np.ascontiguousarray(f.weight, np.float32).tobytes() + np.ascontiguousarray(f.final, np.float32).tobytes())
+
+def ref_objf(den_fst, num_pdfs, merged_sup_fst, nnet_output, num_sequences, leaky_hmm_coefficient=1.0e-05, l2_regularize=0.0, weight=1.0):
+    """the reference's ComputeChainObjfAndDeriv (out-of-range penalty off) on a MERGED supervision FST: dict(objf, l2_term, weight, deriv, xent_deriv)"""
+    out = np.ascontiguousarray(nnet_output, np.float32); TB, P = out.shape
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(HERE, "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
+    with tempfile.TemporaryDirectory() as td:
+        with open(f"{td}/in.bin", "wb") as f:
+            f.write(struct.pack("<9i3f", 0x4b35, int(den_fst.num_states), int(den_fst.start), int(den_fst.arc_offsets[-1]), P, num_sequences, TB // num_sequences, int(merged_sup_fst.num_states), int(merged_sup_fst.arc_offsets[-1]),
+                                leaky_hmm_coefficient, l2_regularize, weight))
+            f.write(_fst_bytes(den_fst)); f.write(_fst_bytes(merged_sup_fst)); f.write(out.tobytes())
+        subprocess.check_call([_BIN_OBJF, f"{td}/in.bin", f"{td}/out.bin"], env=env, stderr=subprocess.DEVNULL)
+        raw = open(f"{td}/out.bin", "rb").read()
+    objf, l2, wt = struct.unpack("<3f", raw[:12]); d = np.frombuffer(raw, np.float32, TB * P, 12).reshape(TB, P); x = np.frombuffer(raw, np.float32, TB * P, 12 + 4 * TB * P).reshape(TB, P)
+    return dict(objf=float(objf), l2_term=float(l2), weight=float(wt), deriv=d.copy(), xent_deriv=x.copy())
+
+def num_oracle(fsts, num_pdfs, nnet_output, weight=1.0):
+    """NumeratorComputation (chain/chain-numerator.cc:115-213) sequence by sequence, log domain in double: returns (weight * total log-prob, weight * occupation
+    probabilities [T*B, P]).  fsts: the UNMERGED supervision FSTs (the merged FST's total factorises over the sequences)."""
+    out = np.asarray(nnet_output, np.float32).astype(np.float64); B = len(fsts); TB, P = out.shape; T = TB // B
+    post = np.zeros((TB, P), np.float64); tot = 0.0
+    for n, f in enumerate(fsts):
+        S = int(f.num_states); off = np.asarray(f.arc_offsets, np.int64); time = np.full(S, -1); time[0] = 0
+        for s in range(S):
+            for a in range(off[s], off[s + 1]): time[f.nextstate[a]] = time[s] + 1
+        la = np.full(S, -np.inf); la[0] = 0.0
+        for s in range(S):                                                    # states are sorted by time: one serial sweep, like the reference
+            for a in range(off[s], off[s + 1]):
+                x = la[s] + out[time[s] * B + n, f.ilabel[a] - 1] - float(f.weight[a]); la[f.nextstate[a]] = np.logaddexp(la[f.nextstate[a]], x)
+        fin = np.asarray(f.final, np.float64); lp = np.logaddexp.reduce([la[s] - fin[s] for s in range(S) if np.isfinite(fin[s])]); tot += lp
+        lb = np.full(S, -np.inf)
+        for s in range(S - 1, -1, -1):
+            b = -fin[s] if np.isfinite(fin[s]) else -np.inf
+            for a in range(off[s], off[s + 1]):
+                y = out[time[s] * B + n, f.ilabel[a] - 1] - float(f.weight[a]) + lb[f.nextstate[a]]; b = np.logaddexp(b, y)
+                post[time[s] * B + n, f.ilabel[a] - 1] += np.exp(la[s] + y - lp)
+            lb[s] = b
+    return float(weight) * tot, (float(weight) * post).astype(np.float32)
+
+def objf_oracle(den_fst, num_pdfs, fsts, nnet_output, leaky_hmm_coefficient=1.0e-05, l2_regularize=0.0, out_of_range_regularize=0.0, apply_out_of_range_penalty=False, weight=1.0):
+    """ComputeChainObjfAndDeriv (chain/chain-training.cc:242-337)"""
+    out = np.asarray(nnet_output, np.float32); B = len(fsts); TB, P = out.shape
+    den = den_oracle(den_fst, num_pdfs, out, B, leaky_hmm_coefficient, -weight)
+    deriv = den["deriv"].astype(np.float32).copy()
+    if apply_out_of_range_penalty and out_of_range_regularize != 0.0:
+        sc = np.float32(2.0 * out_of_range_regularize); deriv -= sc * (np.where(out < -30, out + 30, 0) + np.where(out > 30, out - 30, 0)).astype(np.float32)
+    num_lp, xent = num_oracle(fsts, num_pdfs, out, weight)
+    deriv = deriv + xent
+    objf = num_lp - weight * den["objf"]; wt = weight * TB
+    if not np.isfinite(objf) or not den["ok"]: deriv[:] = 0; xent = np.zeros_like(xent); objf = -10.0 * wt
+    l2 = 0.0
+    if l2_regularize != 0.0:
+        scale = weight * l2_regularize; l2 = -0.5 * scale * float((out.astype(np.float64) ** 2).sum()); deriv = deriv - np.float32(scale) * out
+    return dict(objf=float(objf), l2_term=float(l2), weight=float(wt), deriv=deriv.astype(np.float32), xent_deriv=xent)

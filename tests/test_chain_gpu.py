@@ -66,3 +66,56 @@ def test_graphs_beyond_the_lds_budget_are_refused_loudly():
     f = synth.make_den_fst(9000, 12000, mean_degree=3.0)
     g = chain.DenominatorGraph(f, 12000); o = torch.zeros((4, 12000), device="cuda")
     with pytest.raises(lib.K3Error): chain.DenominatorComputation(chain.ChainTrainingOptions(1e-5), g, 2, o).Forward()
+
+# ---- numerator + objective ------------------------------------------------------------------------------------------------------------------
+def _objf(den, P, fsts, out, leaky, l2, w, xent=True, oor=0.0, apply_oor=False, derivs=True):
+    from kaldi_amd import chain
+    g = chain.DenominatorGraph(den, P); T = out.shape[0] // len(fsts); sup = chain.Supervision(fsts, T, P, w); o = torch.from_numpy(out).cuda()
+    d = torch.full_like(o, 7.0) if derivs else None; x = torch.full_like(o, 7.0) if (xent and derivs) else None      # (both are overwritten)
+    objf, l2t, wt = chain.ComputeChainObjfAndDeriv(chain.ChainTrainingOptions(leaky, l2, oor, apply_oor), g, sup, o, d, x); torch.cuda.synchronize()
+    return dict(objf=objf, l2_term=l2t, weight=wt, deriv=d.cpu().numpy() if d is not None else None, xent_deriv=x.cpu().numpy() if x is not None else None)
+
+def _close_objf(h, r, tol_d=1e-5):
+    assert abs(h["objf"] - r["objf"]) <= 1e-4 * abs(r["objf"]) + 1e-4, (h["objf"], r["objf"])
+    assert abs(h["l2_term"] - r["l2_term"]) <= 1e-5 * abs(r["l2_term"]) + 1e-6 and abs(h["weight"] - r["weight"]) <= 1e-5 * r["weight"]
+    if h["deriv"] is not None: assert np.abs(h["deriv"] - r["deriv"]).max() <= tol_d, np.abs(h["deriv"] - r["deriv"]).max()
+    if h["xent_deriv"] is not None: assert np.abs(h["xent_deriv"] - r["xent_deriv"]).max() <= tol_d
+
+@pytest.mark.parametrize("name", sorted(mg.OBJF_CASES))
+def test_objective_and_derivatives_equal_the_reference_fixture(name):
+    den, P, fsts, out, leaky, l2, w = mg.make_objf(name); r = {k: GOLD[name + "." + k] for k in ("objf", "l2_term", "weight", "deriv", "xent_deriv")}
+    r = {k: (float(v) if v.ndim == 0 else v) for k, v in r.items()}
+    _close_objf(_objf(den, P, fsts, out, leaky, l2, w), r)
+    h = _objf(den, P, fsts, out, leaky, l2, w, xent=False); assert h["xent_deriv"] is None; _close_objf(h, r)           # numerator straight into the derivative
+    h = _objf(den, P, fsts, out, leaky, l2, w, derivs=False); assert abs(h["objf"] - r["objf"]) <= 1e-4 * abs(r["objf"]) + 1e-4      # objective only
+
+def test_numerator_class_and_out_of_range_penalty_against_the_oracle():
+    from kaldi_amd import chain
+    den, P, fsts, out, leaky, l2, w = mg.make_objf("objf_l2_weight"); out = out * 6.0                                 # some outputs beyond +-30
+    T = out.shape[0] // len(fsts); sup = chain.Supervision(fsts, T, P, w); o = torch.from_numpy(out).cuda(); d = torch.zeros_like(o)
+    num = chain.NumeratorComputation(sup, o); lp = num.Forward(); num.Backward(d); torch.cuda.synchronize()
+    olp, opost = co.num_oracle(fsts, P, out, w)
+    assert abs(lp - olp) <= 1e-5 * abs(olp) + 1e-4 and np.abs(d.cpu().numpy() - opost).max() <= 1e-5
+    r = co.objf_oracle(den, P, fsts, out, leaky, l2, out_of_range_regularize=0.01, apply_out_of_range_penalty=True, weight=w)
+    _close_objf(_objf(den, P, fsts, out, leaky, l2, w, oor=0.01, apply_oor=True), r, tol_d=2e-5)
+
+def test_objective_on_a_training_sized_minibatch():
+    """128 sequences x 50 frames, 3000-state denominator graph, 4000 pdfs: against the reference binary when oracle/_ref travels (merged supervision FST), else the oracle"""
+    P, B, T = 4000, 128, 50; den = synth.make_den_fst(3000, P); rng = np.random.default_rng(9)
+    fsts = [synth.make_supervision_fst(T, P, seed=1000 + i, width=4) for i in range(B)]
+    out = (rng.standard_normal((T * B, P)) * 2.0).astype(np.float32)
+    r = co.ref_objf(den, P, synth.merge_supervision_fsts(fsts), out, B, 1e-5, 5e-5, 1.0) if co.objf_available() else co.objf_oracle(den, P, fsts, out, 1e-5, 5e-5)
+    _close_objf(_objf(den, P, fsts, out, 1e-5, 5e-5, 1.0), r)
+    from kaldi_amd import chain
+    g = chain.DenominatorGraph(den, P); sup = chain.Supervision(fsts, T, P, 1.0); o = torch.from_numpy(out).cuda(); d = torch.zeros_like(o); x = torch.zeros_like(o); opts = chain.ChainTrainingOptions(1e-5, 5e-5)
+    chain.ComputeChainObjfAndDeriv(opts, g, sup, o, d, x); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): chain.ComputeChainObjfAndDeriv(opts, g, sup, o, d, x)
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
+    print(f"\nLF-MMI objective + derivatives (denominator, numerator, l2, xent derivative): {B} x {T} frames, {P} pdfs: {ms:.3f} ms per minibatch")
+
+def test_supervision_fsts_that_break_the_contract_are_refused():
+    from kaldi_amd import chain, lib
+    f = synth.make_supervision_fst(6, 20, seed=1)
+    with pytest.raises(lib.K3Error): chain.Supervision([f], 7, 20)                          # paths are 6 arcs long, not 7
+    g = synth.make_supervision_fst(6, 20, seed=1); g.ilabel[0] = 0
+    with pytest.raises(lib.K3Error): chain.Supervision([g], 6, 20)                          # epsilon label

@@ -40,3 +40,27 @@ def test_oracle_equals_the_reference_binary_on_random_cases():
         r = co.ref_den(f, P, out, B, leaky, dw); o = co.den_oracle(f, P, out, B, leaky, dw)
         assert abs(o["objf"] - r["objf"]) <= 2e-6 * abs(r["objf"]) + 1e-5 and o["ok"] == r["ok"], (it, o["objf"], r["objf"])
         assert np.abs(o["initial_probs"] - r["initial_probs"]).max() <= 1e-7 and np.abs(o["deriv"] - r["deriv"]).max() <= 2e-6, it
+
+# ---- numerator + objective ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(mg.OBJF_CASES))
+def test_objective_oracle_equals_the_reference_fixture(name):
+    """chain::ComputeChainObjfAndDeriv of the reference (merged supervision FST, numerator on its CPU path) vs the numpy restatement working sequence by sequence"""
+    den, P, fsts, out, leaky, l2, w = mg.make_objf(name); o = co.objf_oracle(den, P, fsts, out, leaky, l2, weight=w)
+    for k in ("objf", "l2_term", "weight"): assert abs(o[k] - float(GOLD[name + "." + k])) <= 2e-6 * abs(float(GOLD[name + "." + k])) + 1e-5, k
+    assert np.abs(o["deriv"] - GOLD[name + ".deriv"]).max() <= 2e-6 and np.abs(o["xent_deriv"] - GOLD[name + ".xent_deriv"]).max() <= 2e-6
+
+def test_numerator_posteriors_sum_to_the_weight_per_frame():
+    den, P, fsts, out, leaky, l2, w = mg.make_objf("objf_l2_weight"); lp, post = co.num_oracle(fsts, P, out, w)
+    assert np.abs(post.sum(1) - w).max() <= 1e-5 and np.isfinite(lp)
+
+@pytest.mark.skipif(not co.objf_available(), reason="oracle/_ref not built (needs /root/reference once)")
+def test_objective_oracle_equals_the_reference_binary_on_random_cases():
+    rng = np.random.default_rng(31)
+    for it in range(4):
+        S, P = int(rng.choice([40, 300])), int(rng.choice([25, 200])); B, T = int(rng.integers(1, 6)), int(rng.integers(2, 20)); w = float(rng.choice([1.0, 0.5])); l2 = float(rng.choice([0.0, 1e-3]))
+        den = synth.make_den_fst(S, P, seed=int(rng.integers(0, 1 << 30)), mean_degree=5.0, hub_degree=int(min(S, 60)))
+        fsts = [synth.make_supervision_fst(T, P, seed=int(rng.integers(0, 1 << 30)), width=int(rng.choice([1, 3, 5]))) for _ in range(B)]
+        out = (rng.standard_normal((T * B, P)) * float(rng.choice([1.0, 4.0]))).astype(np.float32)
+        r = co.ref_objf(den, P, synth.merge_supervision_fsts(fsts), out, B, 1e-5, l2, w); o = co.objf_oracle(den, P, fsts, out, 1e-5, l2, weight=w)
+        assert abs(o["objf"] - r["objf"]) <= 2e-6 * abs(r["objf"]) + 1e-5 and abs(o["l2_term"] - r["l2_term"]) <= 2e-6 * abs(r["l2_term"]) + 1e-6, it
+        assert np.abs(o["deriv"] - r["deriv"]).max() <= 2e-6 and np.abs(o["xent_deriv"] - r["xent_deriv"]).max() <= 2e-6, it
