@@ -31,7 +31,12 @@ int main(int argc, char **argv) {
       std::vector<std::string> keys; std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0);
       for (size_t i = b0; i < b1; i++) {
         Wave w;
-        try { w = ReadWave(scp[i].second); } catch (const FatalError &) { num_err++; continue; }
+        try {      // --channel like featbin/compute-fbank-feats.cc:140-160: -1 = expect mono (a multi-channel file: warn, take the left channel), else that channel or skip the file
+          int nch = 0; w = ReadWave(scp[i].second, 0, &nch);
+          if (channel == -1) { if (nch != 1) K3H_WARN << "Channel not specified but you have data with " << nch << " channels; defaulting to zero"; }
+          else if (channel >= nch) { K3H_WARN << "File with id " << scp[i].first << " has " << nch << " channels but you specified channel " << channel << ", producing no output."; num_err++; continue; }
+          else if (channel > 0) w = ReadWave(scp[i].second, channel);
+        } catch (const FatalError &) { num_err++; continue; }
         if (w.samp_freq != opts.samp_freq) { K3H_WARN << "Sample frequency mismatch for " << scp[i].first << ": " << w.samp_freq << " vs " << opts.samp_freq; num_err++; continue; }
         if (w.samples.size() / w.samp_freq < min_duration) { K3H_WARN << "File: " << scp[i].first << " is too short: producing no output."; num_err++; continue; }
         const int nf = k3_feat_num_frames(plan, (int64_t)w.samples.size());

@@ -165,7 +165,7 @@ std::vector<std::pair<std::string, std::string>> ReadScp(const std::string &rspe
 }
 
 // ------------------------------------------------------------------------------------------------ wave ----
-Wave ReadWave(const std::string &rxfilename) {      // feat/wave-reader.cc:113-330 (PCM, 16 bit; channel 0 is returned)
+Wave ReadWave(const std::string &rxfilename, int channel, int *num_channels) {      // feat/wave-reader.cc:113-330 (PCM, 16 bit, incl. WAVE_FORMAT_EXTENSIBLE with a PCM sub-format)
   const std::string b = ReadWholeInput(rxfilename);
   auto u32 = [&](size_t p) { uint32_t v; memcpy(&v, b.data() + p, 4); return v; };
   auto u16 = [&](size_t p) { uint16_t v; memcpy(&v, b.data() + p, 2); return v; };
@@ -174,15 +174,18 @@ Wave ReadWave(const std::string &rxfilename) {      // feat/wave-reader.cc:113-3
   while (pos + 8 <= b.size()) {
     const std::string id = b.substr(pos, 4); const uint32_t sz = u32(pos + 4);
     if (id == "fmt ") {
-      if (u16(pos + 8) != 1) K3H_ERR << "WaveData: can read only PCM data, audio_format is not 1 in " << rxfilename;
+      const unsigned fmt = u16(pos + 8);      // 1 = PCM; 0xFFFE = extensible: the sub-format GUID's first two bytes carry the real format (wave-reader.cc:176-205)
+      if (fmt != 1 && !(fmt == 0xFFFE && sz >= 26 && u16(pos + 8 + 24) == 1)) K3H_ERR << "WaveData: can read only PCM data, audio_format is not 1 in " << rxfilename;
       channels = u16(pos + 10); w.samp_freq = (float)u32(pos + 12); bits = u16(pos + 22);
       if (bits != 16 || channels < 1) K3H_ERR << "WaveData: unsupported bits_per_sample / channels = " << bits << " / " << channels;
     } else if (id == "data") {
       if (!channels) K3H_ERR << "WaveData: data chunk before fmt chunk in " << rxfilename;
       size_t n = std::min<size_t>(sz == 0xFFFFFFFFu || sz == 0 ? b.size() - pos - 8 : sz, b.size() - pos - 8) / (2 * channels);
+      if (num_channels) *num_channels = channels;
+      if (channel < 0 || channel >= channels) K3H_ERR << "WaveData: channel " << channel << " requested but the file has " << channels << " in " << rxfilename;
       w.samples.resize(n);
       const int16_t *s = reinterpret_cast<const int16_t *>(b.data() + pos + 8);
-      for (size_t i = 0; i < n; i++) { int16_t v; memcpy(&v, s + i * channels, 2); w.samples[i] = (float)v; }
+      for (size_t i = 0; i < n; i++) { int16_t v; memcpy(&v, s + i * channels + channel, 2); w.samples[i] = (float)v; }
       return w;
     }
     pos += 8 + sz + (sz & 1);

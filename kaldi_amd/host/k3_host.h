@@ -76,7 +76,7 @@ std::string ReadWholeInput(const std::string &rxfilename);
 std::vector<std::pair<std::string, std::string>> ReadScp(const std::string &rspecifier);
 
 struct Wave { float samp_freq = 0; std::vector<float> samples; };   // channel 0, values in int16 range like WaveData
-Wave ReadWave(const std::string &rxfilename);
+Wave ReadWave(const std::string &rxfilename, int channel = 0, int *num_channels = nullptr);      // one channel of the file (an out-of-range channel is an error)
 
 // .mdl (text or binary): parses the TransitionModel in front of the nnet; id2pdf[0] is unused
 // id2phone / self_loop / phone_start = TransitionIdToPhone, IsSelfLoop, TransitionIdIsStartOfPhone (hmm/transition-model.cc:790,925)

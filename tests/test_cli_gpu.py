@@ -412,3 +412,24 @@ def test_compute_online_feats_batched_cuda_equals_the_offline_programs(tmp_path)
     r = subprocess.run([exe, "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", f"scp:{td}/wav.scp", f"ark,t:{td}/iv0.txt", f"ark:{td}/of0.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
     assert all(line.split(None, 1)[1].strip() == "[ ]" for line in open(f"{td}/iv0.txt"))
     assert subprocess.run([exe, "x"], capture_output=True).returncode == 1
+
+
+def test_feature_program_channel_option_and_extensible_wav_header(tmp_path):
+    """--channel like featbin/compute-fbank-feats.cc:140-160 (a stereo file: channel 1 = the right channel; -1 warns and takes the left; an absent channel skips the
+    file) and WAVE_FORMAT_EXTENSIBLE headers with a PCM sub-format (feat/wave-reader.cc:176-205)"""
+    import struct
+    from oracle import kaldi_io as kio
+    td = str(tmp_path); rng = np.random.default_rng(3); L, R = (rng.standard_normal(8000) * 3000).astype(np.int16), (rng.standard_normal(8000) * 3000).astype(np.int16)
+    def wav(path, chans, extensible=False):
+        data = np.stack(chans, 1).astype("<i2").tobytes(); nch = len(chans)
+        fmt = struct.pack("<HHIIHH", 0xFFFE if extensible else 1, nch, 16000, 16000 * 2 * nch, 2 * nch, 16)
+        if extensible: fmt += struct.pack("<HHI", 22, 16, 3 if nch == 2 else 4) + struct.pack("<H", 1) + b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+        open(path, "wb").write(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(data)) + data)
+    wav(f"{td}/st.wav", [L, R]); wav(f"{td}/l.wav", [L]); wav(f"{td}/r.wav", [R]); wav(f"{td}/ext.wav", [L, R], extensible=True)
+    open(f"{td}/wav.scp", "w").write(f"st {td}/st.wav\nl {td}/l.wav\nr {td}/r.wav\next {td}/ext.wav\n")
+    exe = os.path.join(BIN, "compute-fbank-feats-cuda"); run = lambda *a: subprocess.run([exe, "--dither=0", "--num-mel-bins=40", *a, f"scp:{td}/wav.scp", f"ark:{td}/o.ark"], capture_output=True, text=True)
+    r = run("--channel=1"); assert r.returncode == 0, r.stderr
+    f = kio.read_ark(f"{td}/o.ark"); assert sorted(f) == ["ext", "st"] and "has 1 channels but you specified channel 1" in r.stderr
+    r0 = run("--channel=0"); f0 = kio.read_ark(f"{td}/o.ark"); assert sorted(f0) == ["ext", "l", "r", "st"]
+    assert np.array_equal(f["st"], f0["r"]) and np.array_equal(f["ext"], f0["r"]) and np.array_equal(f0["st"], f0["l"]) and np.array_equal(f0["ext"], f0["l"])
+    rm = run(); fm = kio.read_ark(f"{td}/o.ark"); assert "Channel not specified but you have data with 2 channels" in rm.stderr and np.array_equal(fm["st"], f0["l"])
