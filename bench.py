@@ -219,6 +219,19 @@ def main():
                                     "lattice_states": ls2[0], "lattice_arcs": ls2[1], "order_sensitive_upper_bound": int(d2.OrderSensitiveEvents().sum())}
         else:
             line["roofline"] = dict(line["roofline_gemm"], traffic=None)
+        if world == 1:      # the LF-MMI objective + derivatives of a training-sized minibatch, for the record (not part of `value`)
+            try:
+                from kaldi_amd import chain
+                cB, cT, cP = 128, 50, 4000; den = synth.make_den_fst(3000, cP); g_ = chain.DenominatorGraph(den, cP)
+                sup = chain.Supervision([synth.make_supervision_fst(cT, cP, seed=1000 + i, width=4) for i in range(cB)], cT, cP, 1.0)
+                o_ = torch.randn(cT * cB, cP, device=dev) * 2.0; d_ = torch.zeros_like(o_); x_ = torch.zeros_like(o_); copts = chain.ChainTrainingOptions(1e-5, 5e-5)
+                chain.ComputeChainObjfAndDeriv(copts, g_, sup, o_, d_, x_); torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(5): objf_ = chain.ComputeChainObjfAndDeriv(copts, g_, sup, o_, d_, x_)
+                torch.cuda.synchronize()
+                line["chain_objf"] = {"ms_per_minibatch": (time.perf_counter() - t0) / 5 * 1e3, "objf_per_frame": objf_[0] / objf_[2],
+                                      "config": f"k3_chain_objf_and_deriv (ComputeChainObjfAndDeriv: denominator + numerator + l2 + xent derivative): {cB} sequences x {cT} frames, 3000-state / {int(den.arc_offsets[-1])}-transition denominator graph, {cP} pdfs"}
+                del g_, sup, o_, d_, x_
+            except Exception as e: line["chain_objf"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if graph is None: graph = synth.make_hclg(args.graph_states, args.graph_arcs, num_pdfs)
