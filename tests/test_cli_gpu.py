@@ -433,3 +433,27 @@ def test_feature_program_channel_option_and_extensible_wav_header(tmp_path):
     r0 = run("--channel=0"); f0 = kio.read_ark(f"{td}/o.ark"); assert sorted(f0) == ["ext", "l", "r", "st"]
     assert np.array_equal(f["st"], f0["r"]) and np.array_equal(f["ext"], f0["r"]) and np.array_equal(f0["st"], f0["l"]) and np.array_equal(f0["ext"], f0["l"])
     rm = run(); fm = kio.read_ark(f"{td}/o.ark"); assert "Channel not specified but you have data with 2 channels" in rm.stderr and np.array_equal(fm["st"], f0["l"])
+
+
+def test_online_pipeline_class_with_correlation_ids_and_callbacks_equals_the_program(tmp_path):
+    """kaldi_amd/host/k3_online_pipeline.h: BatchedThreadedNnet3CudaOnlinePipeline's class surface (TryInitCorrID, DecodeBatch per chunk, SetLatticeCallback,
+    partial hypotheses / end-points, WaitForLatticeCallbacks; cudadecoder/batched-threaded-nnet3-cuda-online-pipeline.h:119-330) driven by a caller written like the
+    reference's streaming program: more streams than channels, chunk by chunk; the determinized lattices its callbacks receive equal the offline program's output"""
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001, 31000, 4100, 12000, 20011]
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5)
+    net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000"]
+    a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=4", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/prog.txt"], capture_output=True, text=True)
+    assert a.returncode == 0, a.stderr
+    for extra in (["--max-batch-size=3", "--num-channels=3", "--frames-per-chunk=51"], ["--max-batch-size=2", "--num-channels=4", "--frames-per-chunk=150", "--print-partial-hypotheses=true"]):
+        b = subprocess.run([os.path.join(BIN, "k3-online-pipeline-example")] + common + extra + ["--max-utterance-frames=400", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/cls.txt"], capture_output=True, text=True)
+        assert b.returncode == 0, b.stderr
+        assert "Decoded 7 utterances, 0 with errors." in b.stderr, b.stderr[-2000:]
+        assert open(f"{td}/prog.txt").read() == open(f"{td}/cls.txt").read()
+        if "--print-partial-hypotheses=true" in extra:
+            assert " partial: " in b.stderr and " final: " in b.stderr
+            n_partial = int(b.stderr.split("Non-empty partial hypotheses: ")[1].split(",")[0]); assert n_partial > 0
