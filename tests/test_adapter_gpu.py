@@ -53,3 +53,24 @@ def test_an_operation_outside_the_adapter_fails_loudly(tmp_path):
     fa = str(tmp_path / "f.ark"); kio.write_ark(fa, {"u": np.random.default_rng(0).standard_normal((20, 8)).astype(np.float32)})
     r = subprocess.run([EXE, "--use-gpu=no", raw, f"ark:{fa}", f"ark:{tmp_path}/o.ark"], capture_output=True, text=True)
     assert r.returncode != 0 and "not implemented on the MI355X path" in r.stderr and "LogSoftMaxPerRow" in r.stderr, r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("kind,flags,warp", [("fbank", ["--num-mel-bins=40", "--dither=0"], None), ("mfcc", ["--num-mel-bins=40", "--num-ceps=40", "--low-freq=20", "--high-freq=-400", "--dither=0"], None),
+                                             ("fbank", ["--num-mel-bins=23", "--dither=0", "--use-energy=true", "--window-type=hamming"], "1.1")])
+def test_cuda_spectral_features_class_equals_the_reference_binaries(kind, flags, warp, tmp_path):
+    """include/k3_cuda_features.h: kaldi::CudaSpectralFeatures with the reference's signatures (cudafeat/feature-spectral-cuda.h:70-107) in a caller that uses the reference's
+    own option classes, WaveData and table IO (tests/adapter/cuda_features_example.cc): its features against the reference's CPU compute-{fbank,mfcc}-feats binaries"""
+    from oracle import kaldi_io as kio
+    from kaldi_amd import synth
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "cuda-features-example"); ref = os.path.join(ROOT, "oracle", "_ref", "bin", f"compute-{kind}-feats")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/cuda-features-example is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    if not os.path.exists(ref): pytest.skip("oracle/_ref not built")
+    td = str(tmp_path); scp = []
+    for i, n in enumerate((16000, 5000, 23017)): kio.write_wav(f"{td}/u{i}.wav", synth.gaussian_pcm16(n, 70 + i)); scp.append(f"u{i} {td}/u{i}.wav")
+    open(f"{td}/wav.scp", "w").write("\n".join(scp) + "\n")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
+    r = subprocess.run([ref] + flags + ([f"--vtln-warp={warp}"] if warp else []) + [f"scp:{td}/wav.scp", f"ark:{td}/ref.ark"], capture_output=True, text=True, env=env); assert r.returncode == 0, r.stderr
+    g = subprocess.run([exe] + flags + [kind, f"scp:{td}/wav.scp", f"ark:{td}/got.ark"] + ([warp] if warp else []), capture_output=True, text=True, env=dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")); assert g.returncode == 0, g.stderr[-2000:]
+    a, b = kio.read_ark(f"{td}/ref.ark"), kio.read_ark(f"{td}/got.ark")
+    assert sorted(a) == sorted(b) == ["u0", "u1", "u2"]
+    for k in a: assert a[k].shape == b[k].shape and np.abs(a[k] - b[k]).max() <= (1e-4 if kind == "fbank" else 3e-4), (k, np.abs(a[k] - b[k]).max())
