@@ -247,7 +247,7 @@ typedef struct k3_decoder_config {
    * applies the frame's FINAL bound to every arc (order-independent, a sub-lattice with the same best path).  hash_ratio =
    * LatticeFasterDecoderConfig::hash_ratio (2.0): it decides the bucket count and with it the reference's visit order.
    * Needs frame_tokens_cap <= 65536 < frame_cands_cap. */
-  int32_t literal_order;      /* 0 */
+  int32_t literal_order;      /* 0; 1 = on; 2 = on, the closure's creation order by the one-wavefront replay (the fall-back path of 1, for A/B); 3 = 1 with the fall-back forced (tests) */
   float hash_ratio;           /* 2.0 */
 } k3_decoder_config;
 void k3_decoder_config_default(k3_decoder_config *cfg);

@@ -517,7 +517,7 @@ __device__ __forceinline__ int lit_replay_components(const DecParams &p, const L
   K3_LS(11);
   for (int w = tid; w < n_workers; w += kBlock) {
     const int4 w0 = q.wrec[2 * w], w1 = q.wrec[2 * w + 1];
-    if (!lit_replay_component(rcost, meta, AR, clist, q.rlist, q.rinfo, q.stack + w0.w, w1.x, w0.x, w0.y, w0.z, accept)) *s_flag = 1;
+    if (!lit_replay_component(rcost, meta, AR, clist, q.rlist, q.rinfo, q.stack + w0.w, p.literal == 3 ? 0 : w1.x, w0.x, w0.y, w0.z, accept)) *s_flag = 1;      // (literal_order = 3: no stack slices, a test hook for the fall-back)
   }
   __syncthreads();
   K3_LS(12);
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
         if (inv[u]) {
           const int cid = cid4[u], abeg = abeg4[u];
           q.c2t[cid] = i; rcost[cid] = c04[u]; int d0 = 0, w0 = 0;
-          if (p.literal == 1) { K3_AST(&par[cid], cid); int *ci = reinterpret_cast<int *>(&q.cinfo[cid]); K3_AST(&ci[0], 0); K3_AST(&ci[1], 0); K3_AST(&ci[2], 0); K3_AST(&ci[3], 0); }
+          if (p.literal & 1) { K3_AST(&par[cid], cid); int *ci = reinterpret_cast<int *>(&q.cinfo[cid]); K3_AST(&ci[0], 0); K3_AST(&ci[1], 0); K3_AST(&ci[2], 0); K3_AST(&ci[3], 0); }
           if (pc4[u] > 0) {
             int k = abeg;
             for (int a = rg4[u].x; a < rg4[u].x + rg4[u].y; a++) {
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     // the whole queue by one wavefront.
     // (separate instantiations so that mode 0 compiles to LDS instructions only: a flat access would wait for every outstanding global access)
     int created_total = -1;
-    if (p.literal == 1) {
+    if (p.literal & 1) {
       if (rmode == 0) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw),
                                                             reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, s_aux, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
       else if (rmode == 1) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab), (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(smem_raw), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);

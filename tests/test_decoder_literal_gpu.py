@@ -35,7 +35,7 @@ def _check_against_oracle(dec, u, lat, f, ll, t2p, kw):
     assert d == "", (u, d)
     return oi
 
-@pytest.mark.parametrize("replay", [1, 2])
+@pytest.mark.parametrize("replay", [1, 2, 3])      # 3: component replay whose stack slices are empty: every component that needs its stack falls back to the one-wavefront replay
 @pytest.mark.parametrize("name", sorted(dcases.CASES))
 def test_literal_order_equals_the_reference_decoder(name, replay):
     from kaldi_amd import decoder
@@ -53,7 +53,7 @@ def test_literal_order_equals_the_reference_decoder(name, replay):
     if rd.available():                                             # and live
         assert lsig.canonical_of_reference(rd.decode(f, ll, t2p, lo.Config(**kw))) == canon
 
-@pytest.mark.parametrize("replay", [1, 2])
+@pytest.mark.parametrize("replay", [1, 2, 3])
 def test_literal_order_random_configurations_and_lane_reuse(replay):
     """random graphs / lengths / spreads / every LatticeFasterDecoderConfig field incl. cost grids with exact ties; the same decoder object
     decodes every batch (scratch must return to its idle state), lanes hold different utterances"""
