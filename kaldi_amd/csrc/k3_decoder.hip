@@ -137,12 +137,11 @@ struct DecParams {
   unsigned *lt_label;     // [frame_tokens_cap] creation label of a token being built (all 0xFFFFFFFF between frames)
   int *lt_dense, *lt_grp; unsigned *lt_lead;            // [frame_tokens_cap (+1)]
   unsigned *lt_bm, *lt_wpre;                             // [seq_words_cap] label bitmap (all 0 between uses) / word prefix counts
-  unsigned *lt_bfirst, *lt_bcnt, *lt_bfill;              // [hash_cap] per bucket: first dense rank (0xFFFFFFFF), members, fill cursor (0)
   unsigned *lt_cmin; int *lt_ccnt;                       // [frame_tokens_cap / 64 + 2] per 64-token chunk: min (tot + adaptive_beam), emitting arcs
   float *lt_c0;                                          // [frame_tokens_cap] token costs right after ProcessEmitting
   int2 *lt_crng; int *lt_cdst; float *lt_cw;             // closure sub-graph in token space: per token (first, count), per eps arc (dst token | -1, weight)
   float *lt_rcost; int *lt_rflag, *lt_rown, *lt_stack, *lt_iq, *lt_c2t; int2 *lt_arcs2; int4 *lt_meta;   // replay state (global copies; small frames use LDS)
-  int *lt_par, *lt_rtmp; int2 *lt_rlist, *lt_rinfo; int4 *lt_cinfo, *lt_coffs, *lt_wrec, *lt_vis;      // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of the tokens it created
+  int *lt_par, *lt_rtmp; int2 *lt_rlist, *lt_rinfo; int4 *lt_cinfo, *lt_coffs, *lt_wrec, *lt_vis, *lt_btab;      // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of the tokens it created
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -1459,24 +1458,19 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     auto place = [&](auto **ptr, size_t count) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(off); off += (count * sizeof(T) + 255) & ~(size_t)255; };
     place(&p.lt_order, 2 * cap); place(&p.lt_label, cap); place(&p.lt_c0, cap); place(&p.lt_rflag, cap); place(&p.lt_rown, cap); place(&p.lt_grp, cap); place(&p.lt_lead, cap + 1);
     place(&p.lt_crng, cap); place(&p.lt_c2t, cap); place(&p.lt_iq, cap); place(&p.lt_dense, cap); place(&p.lt_by_ins, cap); place(&p.lt_meta, cap); place(&p.lt_rcost, cap);
-    place(&p.lt_par, cap); place(&p.lt_rtmp, cap); place(&p.lt_rlist, cap); place(&p.lt_wrec, 2 * cap); place(&p.lt_cinfo, cap); place(&p.lt_coffs, cap); place(&p.lt_rinfo, cap); place(&p.lt_vis, cap);
+    place(&p.lt_par, cap); place(&p.lt_rtmp, cap); place(&p.lt_rlist, cap); place(&p.lt_wrec, 2 * cap); place(&p.lt_cinfo, cap); place(&p.lt_coffs, cap); place(&p.lt_rinfo, cap); place(&p.lt_vis, cap); { size_t ts = 1024; while (ts < 2 * cap) ts <<= 1; place(&p.lt_btab, ts); }
     place(&p.lt_cmin, 2 * nch); place(&p.lt_ccnt, 2 * nch); place(&p.lt_cdst, (size_t)p.eps_cap); place(&p.lt_cw, (size_t)p.eps_cap); place(&p.lt_arcs2, (size_t)p.eps_cap);
     place(&p.lt_stack, (size_t)p.stack_cap); place(&p.lt_bm, (size_t)p.seq_words_cap); place(&p.lt_wpre, (size_t)p.seq_words_cap);
-    place(&p.lt_bfirst, (size_t)p.hash_cap); place(&p.lt_bcnt, (size_t)p.hash_cap); place(&p.lt_bfill, (size_t)p.hash_cap);
     p.lt_lane_bytes = (long long)((off + 4095) & ~(size_t)4095);
     char *arena = nullptr;
     if ((rc = dmalloc(&d->allocs, &arena, nl * (size_t)p.lt_lane_bytes))) return rc;
     auto rebase = [&](auto **ptr) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(arena + reinterpret_cast<size_t>(*ptr)); };
     rebase(&p.lt_order); rebase(&p.lt_label); rebase(&p.lt_c0); rebase(&p.lt_rflag); rebase(&p.lt_rown); rebase(&p.lt_grp); rebase(&p.lt_lead); rebase(&p.lt_crng); rebase(&p.lt_c2t); rebase(&p.lt_iq);
     rebase(&p.lt_dense); rebase(&p.lt_by_ins); rebase(&p.lt_meta); rebase(&p.lt_rcost); rebase(&p.lt_par); rebase(&p.lt_rtmp); rebase(&p.lt_rlist); rebase(&p.lt_wrec); rebase(&p.lt_cinfo); rebase(&p.lt_coffs);
-    rebase(&p.lt_rinfo); rebase(&p.lt_vis); rebase(&p.lt_cmin); rebase(&p.lt_ccnt); rebase(&p.lt_cdst); rebase(&p.lt_cw); rebase(&p.lt_arcs2); rebase(&p.lt_stack); rebase(&p.lt_bm); rebase(&p.lt_wpre); rebase(&p.lt_bfirst);
-    rebase(&p.lt_bcnt); rebase(&p.lt_bfill);
+    rebase(&p.lt_rinfo); rebase(&p.lt_vis); rebase(&p.lt_btab); rebase(&p.lt_cmin); rebase(&p.lt_ccnt); rebase(&p.lt_cdst); rebase(&p.lt_cw); rebase(&p.lt_arcs2); rebase(&p.lt_stack); rebase(&p.lt_bm); rebase(&p.lt_wpre);
     // idle patterns of the scratch: labels / bucket firsts all ones, bitmap / bucket counters zero
     K3_HIP_CHECK(hipMemset2D(p.lt_label, (size_t)p.lt_lane_bytes, 0xFF, cap * sizeof(unsigned), nl));
     K3_HIP_CHECK(hipMemset2D(p.lt_bm, (size_t)p.lt_lane_bytes, 0, (size_t)p.seq_words_cap * sizeof(unsigned), nl));
-    K3_HIP_CHECK(hipMemset2D(p.lt_bfirst, (size_t)p.lt_lane_bytes, 0xFF, (size_t)p.hash_cap * sizeof(unsigned), nl));
-    K3_HIP_CHECK(hipMemset2D(p.lt_bcnt, (size_t)p.lt_lane_bytes, 0, (size_t)p.hash_cap * sizeof(unsigned), nl));
-    K3_HIP_CHECK(hipMemset2D(p.lt_bfill, (size_t)p.lt_lane_bytes, 0, (size_t)p.hash_cap * sizeof(unsigned), nl));
     K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitDynLds));
   }
   // empty table: key = -1, cost = max, tok = -1, stamp = 0

@@ -157,26 +157,32 @@ __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int 
 }
 
 struct LitLane {      // this lane's slices of the literal_order scratch
-  int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *bfirst, *bcnt, *bfill, *cmin; float *c0, *cw, *rcost; int2 *crng, *arcs2; int4 *meta; int *iq, *c2t;
+  int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *cmin; float *c0, *cw, *rcost; int2 *crng, *arcs2; int4 *meta; int *iq, *c2t;
   int *par, *rtmp; int2 *rlist, *rinfo; int4 *cinfo, *coffs, *wrec;      // component replay (below)
+  int4 *btab;     // bucket table of the hash-order pass of large frames
   int4 *vis;      // per visit position of the frame being expanded: (token, cost, first emitting arc, emitting arcs)
   __device__ LitLane(const DecParams &p, int L) {
     const long long cap = p.frame_tokens_cap, nch = cap / 64 + 2; const long long lb = p.lt_lane_bytes * L;
     auto at = [lb](auto *base) { return reinterpret_cast<decltype(base)>(reinterpret_cast<char *>(base) + lb); };
     order[0] = at(p.lt_order); order[1] = order[0] + cap; by_ins = at(p.lt_by_ins); dense = at(p.lt_dense); grp = at(p.lt_grp);
     label = at(p.lt_label); lead = at(p.lt_lead); bm = at(p.lt_bm); wpre = at(p.lt_wpre);
-    bfirst = at(p.lt_bfirst); bcnt = at(p.lt_bcnt); bfill = at(p.lt_bfill);
     cmin = at(p.lt_cmin); ccnt = at(p.lt_ccnt); c0 = at(p.lt_c0); crng = at(p.lt_crng); (void)nch;
     cdst = at(p.lt_cdst); cw = at(p.lt_cw); rcost = at(p.lt_rcost); rflag = at(p.lt_rflag); rown = at(p.lt_rown);
     stack = at(p.lt_stack); arcs2 = at(p.lt_arcs2); iq = at(p.lt_iq); meta = at(p.lt_meta); c2t = at(p.lt_c2t);
-    par = at(p.lt_par); rtmp = at(p.lt_rtmp); rlist = at(p.lt_rlist); wrec = at(p.lt_wrec); cinfo = at(p.lt_cinfo); coffs = at(p.lt_coffs); rinfo = at(p.lt_rinfo); vis = at(p.lt_vis);
+    par = at(p.lt_par); rtmp = at(p.lt_rtmp); rlist = at(p.lt_rlist); wrec = at(p.lt_wrec); cinfo = at(p.lt_cinfo); coffs = at(p.lt_coffs); rinfo = at(p.lt_rinfo); vis = at(p.lt_vis); btab = at(p.lt_btab);
   }
 };
 
 // HashList order of n tokens with unique creation labels < M: order_out[position] = token.  by_ins[d] = token with creation rank d.
+// (The path of frames too large for lit_hash_order_lds.)  The buckets -- hash_size is unbounded, a frame touches at most n of them -- live in an
+// open-addressing table of 16 B records {bucket, smallest creation rank, members, fill cursor} sized to the frame (2n .. 4n slots): one
+// cache line per token and pass in a region that scales with the frame, where per-bucket arrays cost three lines spread over hash_size entries.
 __device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, long long &lt_last__) {
   const int tid = threadIdx.x;
   const int W = (int)((M + 31u) >> 5);
+  unsigned tsize = 1024; while (tsize < 2u * (unsigned)n) tsize <<= 1;      // <= 2 * next_pow2(cap) = the table's capacity
+  const unsigned tmask = tsize - 1; int4 *tab = q.btab; int *slot_of = q.rtmp;
+  for (unsigned s_ = tid; s_ < tsize; s_ += kBlock) tab[s_] = make_int4(-1, -1, 0, 0);
   for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); k3a_or(&q.bm[l >> 5], 1u << (l & 31)); }
   __syncthreads();
   K3_LS(0);
@@ -186,30 +192,30 @@ __device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int
     const unsigned l = K3_ALD(&q.label[i]); const unsigned wd = K3_ALD(&q.bm[l >> 5]);
     const int d = (int)(q.wpre[l >> 5] + (unsigned)__popc(wd & ((1u << (l & 31)) - 1u)));
     q.dense[i] = d; q.by_ins[d] = i;
-    const unsigned b = (unsigned)st[i] % hash_size; k3a_min(&q.bfirst[b], (unsigned)d); k3a_add(&q.bcnt[b], 1u);
+    const unsigned b = (unsigned)st[i] % hash_size; unsigned h = (b * 2654435761u) & tmask;
+    for (;;) { unsigned *key = reinterpret_cast<unsigned *>(&tab[h]); const unsigned old = k3a_cas(key, 0xFFFFFFFFu, b); if (old == 0xFFFFFFFFu || old == b) break; h = (h + 1) & tmask; }
+    slot_of[i] = (int)h;
+    unsigned *rec = reinterpret_cast<unsigned *>(&tab[h]); k3a_min(&rec[1], (unsigned)d); k3a_add(&rec[2], 1u);
   }
   __syncthreads();
   K3_LS(2);
-  block_excl_scan([&](int d) { const unsigned b = (unsigned)st[q.by_ins[d]] % hash_size; return K3_ALD(&q.bfirst[b]) == (unsigned)d ? K3_ALD(&q.bcnt[b]) : 0u; }, q.lead, n, sh.redi);
+  block_excl_scan([&](int d) { const unsigned *rec = reinterpret_cast<const unsigned *>(&tab[slot_of[q.by_ins[d]]]); return K3_ALD(&rec[1]) == (unsigned)d ? K3_ALD(&rec[2]) : 0u; }, q.lead, n, sh.redi);
   K3_LS(3);
   for (int i = tid; i < n; i += kBlock) {
-    const unsigned b = (unsigned)st[i] % hash_size;
-    if (K3_ALD(&q.bcnt[b]) > 1u) { const unsigned lp = q.lead[K3_ALD(&q.bfirst[b])]; const unsigned s = k3a_add(&q.bfill[b], 1u); q.grp[lp + s] = q.dense[i]; }
+    unsigned *rec = reinterpret_cast<unsigned *>(&tab[slot_of[i]]);
+    if (K3_ALD(&rec[2]) > 1u) { const unsigned lp = q.lead[K3_ALD(&rec[1])]; const unsigned s_ = k3a_add(&rec[3], 1u); q.grp[lp + s_] = q.dense[i]; }
   }
   __syncthreads();
   K3_LS(4);
   for (int i = tid; i < n; i += kBlock) {
-    const unsigned b = (unsigned)st[i] % hash_size; const unsigned cnt = K3_ALD(&q.bcnt[b]), lp = q.lead[K3_ALD(&q.bfirst[b])];
+    const unsigned *rec = reinterpret_cast<const unsigned *>(&tab[slot_of[i]]); const unsigned cnt = K3_ALD(&rec[2]), lp = q.lead[K3_ALD(&rec[1])];
     unsigned rank = 0;
     if (cnt > 1u) { const int d = q.dense[i]; for (unsigned k = 0; k < cnt; k++) rank += q.grp[lp + k] < d; }
     order_out[lp + rank] = i;
   }
   __syncthreads();
   K3_LS(5);
-  for (int i = tid; i < n; i += kBlock) {      // scratch back to its idle pattern
-    const unsigned l = K3_ALD(&q.label[i]); const unsigned b = (unsigned)st[i] % hash_size;
-    K3_AST(&q.bm[l >> 5], 0u); K3_AST(&q.bfirst[b], kLabelNone); K3_AST(&q.bcnt[b], 0u); K3_AST(&q.bfill[b], 0u);
-  }
+  for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); K3_AST(&q.bm[l >> 5], 0u); }      // the label bitmap back to its idle pattern
   __syncthreads();
   K3_LS(6);
 }
@@ -578,7 +584,6 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
       for (unsigned i = tid; i <= mask; i += kBlock) { Slot *s_ = &hash[i]; K3_AST(&s_->cost, kEncMax); K3_AST(&s_->stamp, 0); K3_AST(&s_->tok, -1); K3_AST(&s_->key, kEmpty); }
       for (int i = tid; i < cap; i += kBlock) K3_AST(&q.label[i], kLabelNone);
       for (int i = tid; i < p.seq_words_cap; i += kBlock) K3_AST(&q.bm[i], 0u);
-      for (int i = tid; i < p.hash_cap; i += kBlock) { K3_AST(&q.bfirst[i], kLabelNone); K3_AST(&q.bcnt[i], 0u); K3_AST(&q.bfill[i], 0u); }
       __threadfence(); __syncthreads();
     }
     if (tid == 0) {
