@@ -337,7 +337,15 @@ int k3_mat_add_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, 
 int k3_mat_copy_rows(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *stream); /* CopyRows, index -1 = zero row */
 int k3_mat_add_rows(float alpha, const float *d_src, int64_t lds, const int32_t *d_indexes, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream); /* AddRows, index -1 = skip */
 
-/* CuVectorBase: a vector is a [1 x dim] matrix for Set / Add / Scale / ApplyFloor / AddVec (k3_mat_add_vec_to_rows) / MulElements
+int k3_mat_mul_elements(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_A, int64_t lda, void *stream);   /* MulElements */
+int k3_mat_heaviside(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, void *stream);   /* Heaviside(src): 1 where src > 0, else 0 (ReLU backprop) */
+int k3_mat_add_mat_diag_vec(float alpha, const float *d_M, int64_t ldm, int32_t trans_m, const float *d_v, float beta, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream); /* AddMatDiagVec: C = beta C + alpha M diag(v) */
+int k3_mat_add_row_ranges(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, int32_t src_rows, const int32_t *d_ranges /* [rows][2] */, void *stream); /* AddRowRanges: C[r] += sum of src rows [first, second) */
+/* Reductions into a vector (CuVectorBase): op 0 AddRowSumMat: v[c] = beta v[c] + alpha sum_r M(r, c); 1 AddDiagMat2(M, kTrans): sum_r M(r, c)^2; 2 AddDiagMatMat(M, kTrans, N, kNoTrans):
+ * sum_r M(r, c) N(r, c); 3 AddDiagMat2(M, kNoTrans): v[r] = .. sum_c M(r, c)^2; 4 AddColSumMat: v[r] = .. sum_c M(r, c).  Sums in double. */
+int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *stream);
+
+/* CuVectorBase: a vector is a [1 x dim] matrix/* CuVectorBase: a vector is a [1 x dim] matrix for Set / Add / Scale / ApplyFloor / AddVec (k3_mat_add_vec_to_rows) / MulElements
  * (k3_mat_mul_cols_vec); the three operations below have no matrix counterpart (cudamatrix/cu-vector.h:79-103,147-160). */
 int k3_vec_convert(const void *d_src, int32_t src_is_f64, void *d_dst, int32_t dst_is_f64, int32_t n, void *stream);   /* CopyFromVec(const CuVectorBase<OtherReal>&) */
 int k3_vec_pow(const float *d_src, float *d_dst, int32_t n, float power, void *stream);                                /* Pow / ApplyPow */

@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
 }
 
 enum { kOpSet, kOpScale, kOpFloor, kOpCeil, kOpAddConst, kOpCopyRowsFromVec, kOpMulColsVec, kOpMulRowsVec, kOpAddVecToRows, kOpAddVecToCols, kOpCopy, kOpCopyT, kOpAddMat, kOpAddMatT,
-       kOpCopyRows, kOpAddRows };
-struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; };
+       kOpCopyRows, kOpAddRows, kOpMulElements, kOpHeaviside, kOpAddMatDiagVec, kOpAddMatDiagVecT, kOpAddRowRanges };
+struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; int src_rows; };
 
 __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -82,6 +82,11 @@ __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {
       case kOpAddMatT: x = *d + p.a * p.S[(long long)c * p.lds + r]; break;
       case kOpCopyRows: { const int s = p.idx[r]; x = s < 0 ? 0.0f : p.S[(long long)s * p.lds + c]; break; }          // index -1 = zero row
       case kOpAddRows: { const int s = p.idx[r]; x = s < 0 ? *d : *d + p.a * p.S[(long long)s * p.lds + c]; break; }
+      case kOpMulElements: x = *d * p.S[(long long)r * p.lds + c]; break;
+      case kOpHeaviside: x = p.S[(long long)r * p.lds + c] > 0.0f ? 1.0f : 0.0f; break;
+      case kOpAddMatDiagVec: x = p.b * *d + p.a * p.S[(long long)r * p.lds + c] * p.v[c]; break;               // this = beta this + alpha M diag(v)
+      case kOpAddMatDiagVecT: x = p.b * *d + p.a * p.S[(long long)c * p.lds + r] * p.v[c]; break;
+      case kOpAddRowRanges: { const int b0 = p.idx[2 * r], b1 = p.idx[2 * r + 1]; x = *d; for (int k = b0; k < b1; k++) x += p.S[(long long)k * p.lds + c]; break; }      // cu-kernels.cu _add_row_ranges
     }
     *d = x;
   }
@@ -102,6 +107,26 @@ __global__ void k3_vec64_kernel(int op, double alpha, const double *a, const dou
     case 2: d[i] = alpha * a[i] + beta * d[i]; break;                    // AddVec
     case 3: d[i] = alpha * a[i] * b[i] + beta * d[i]; break;             // AddVecVec
   }
+}
+
+
+// v[c] = beta v[c] + alpha sum_r f(r, c): AddRowSumMat (f = M), AddDiagMat2 with kTrans (f = M^2), AddDiagMatMat(M, kTrans, N, kNoTrans) (f = M N); op 3 / 4: the same
+// over the columns of a row (v[r]: AddDiagMat2 kNoTrans, AddColSumMat).  One wavefront-wide column strip per workgroup row block; partial sums in double.
+struct RedParams { int op, rows, cols; const float *M; long long ldm; const float *N; long long ldn; float *v; float alpha, beta; };
+__global__ __launch_bounds__(256) void k3_colred_kernel(RedParams p) {
+  __shared__ double part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (c < p.cols) for (int r = w; r < p.rows; r += 4) { const float m = p.M[(long long)r * p.ldm + c]; acc += p.op == 0 ? (double)m : p.op == 1 ? (double)m * m : (double)m * p.N[(long long)r * p.ldn + c]; }
+  part[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && c < p.cols) { const double s_ = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]; p.v[c] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[c]) + p.alpha * (float)s_; }
+}
+__global__ __launch_bounds__(64) void k3_rowred_kernel(RedParams p) {      // one wavefront per row
+  const int r = blockIdx.x, lane = threadIdx.x; double acc = 0.0;
+  for (int c = lane; c < p.cols; c += 64) { const float m = p.M[(long long)r * p.ldm + c]; acc += p.op == 3 ? (double)m * m : (double)m; }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) p.v[r] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[r]) + p.alpha * (float)acc;
 }
 
 int launch_ew(const EwParams &p, void *stream) {
@@ -142,6 +167,25 @@ extern "C" int k3_mat_copy_rows(float *C, int64_t ldc, int32_t rows, int32_t col
 extern "C" int k3_mat_add_rows(float alpha, const float *d_src, int64_t lds, const int32_t *d_indexes, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_indexes && lds >= cols, "k3_mat_add_rows: bad source"); EwParams p = mk(kOpAddRows, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_indexes; p.a = alpha; return launch_ew(p, st); }
 
 // ---- vectors (CuVectorBase): everything else a vector needs is the matrix entry points on a [1 x dim] matrix
+extern "C" int k3_mat_mul_elements(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_A, int64_t lda, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_A && lda >= cols, "k3_mat_mul_elements: bad source"); EwParams p = mk(kOpMulElements, C, ldc, rows, cols); p.S = d_A; p.lds = lda; return launch_ew(p, st); }
+extern "C" int k3_mat_heaviside(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && lds >= cols, "k3_mat_heaviside: bad source"); EwParams p = mk(kOpHeaviside, C, ldc, rows, cols); p.S = d_src; p.lds = lds; return launch_ew(p, st); }
+extern "C" int k3_mat_add_mat_diag_vec(float alpha, const float *d_M, int64_t ldm, int32_t trans_m, const float *d_v, float beta, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) {
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_M && d_v && ldm >= (trans_m ? rows : cols), "k3_mat_add_mat_diag_vec: bad source");
+  EwParams p = mk(trans_m ? kOpAddMatDiagVecT : kOpAddMatDiagVec, C, ldc, rows, cols); p.S = d_M; p.lds = ldm; p.v = d_v; p.a = alpha; p.b = beta; return launch_ew(p, st);
+}
+extern "C" int k3_mat_add_row_ranges(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, int32_t src_rows, const int32_t *d_ranges, void *st) {
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_ranges && lds >= cols && src_rows >= 0, "k3_mat_add_row_ranges: bad source");
+  EwParams p = mk(kOpAddRowRanges, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_ranges; p.src_rows = src_rows; return launch_ew(p, st);
+}
+extern "C" int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *st) {
+  K3_REQUIRE(d_M && d_v && rows >= 0 && cols >= 0 && ldm >= cols && op >= 0 && op <= 4 && (op != 2 || (d_N && ldn >= cols)), "k3_vec_col_reduce: bad argument");
+  RedParams p{op, rows, cols, d_M, ldm, d_N, ldn, d_v, alpha, beta};
+  if (op <= 2) { if (cols > 0) hipLaunchKernelGGL(k3_colred_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)st, p); }
+  else if (rows > 0) hipLaunchKernelGGL(k3_rowred_kernel, dim3(rows), dim3(64), 0, (hipStream_t)st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+
 extern "C" int k3_vec_convert(const void *d_src, int32_t src_is_f64, void *d_dst, int32_t dst_is_f64, int32_t n, void *st) {      // CuVectorBase<Real>::CopyFromVec(const CuVectorBase<OtherReal>&)
   if (n == 0) return K3_OK;
   K3_REQUIRE(d_src && d_dst && n > 0, "k3_vec_convert: bad argument");

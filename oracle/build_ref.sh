@@ -71,6 +71,9 @@ link nnet3-compute       $R/nnet3bin/nnet3-compute.cc
 link nnet3-copy          $R/nnet3bin/nnet3-copy.cc
 link nnet3-am-info       $R/nnet3bin/nnet3-am-info.cc
 link nnet3-am-copy       $R/nnet3bin/nnet3-am-copy.cc
+# the reference's training computation of one minibatch (forward in training mode + Backprop of every component, gradient nnet) on its CPU matrices: the oracle of
+# the same program linked against the MI355X CuMatrix adapter (kaldi_amd/adapter/_build/nnet3-train-grad); source shared with the adapter build
+link ref-nnet3-train-grad $HERE/../tests/adapter/nnet3_train_grad.cc
 link dump-tid2pdf        $HERE/ref_tools/dump_tid2pdf.cc
 link dump-tidinfo        $HERE/ref_tools/dump_tidinfo.cc
 # the reference's LatticeFasterDecoder over the OpenFst stand-in (include path: minifst first, so that fst/*.h, fstext/fstext-lib.h,

@@ -74,3 +74,40 @@ def test_cuda_spectral_features_class_equals_the_reference_binaries(kind, flags,
     a, b = kio.read_ark(f"{td}/ref.ark"), kio.read_ark(f"{td}/got.ark")
     assert sorted(a) == sorted(b) == ["u0", "u1", "u2"]
     for k in a: assert a[k].shape == b[k].shape and np.abs(a[k] - b[k]).max() <= (1e-4 if kind == "fbank" else 3e-4), (k, np.abs(a[k] - b[k]).max())
+
+
+def _kaldi_matrix(path, m):
+    import struct
+    m = np.ascontiguousarray(m, "<f4"); open(path, "wb").write(b"\0BFM " + b"\x04" + struct.pack("<i", m.shape[0]) + b"\x04" + struct.pack("<i", m.shape[1]) + m.tobytes())
+def _read_kaldi(path):
+    import struct
+    b = open(path, "rb").read(); assert b[:2] == b"\0B"
+    if b[2:5] == b"FM ": r, c = struct.unpack("<i", b[6:10])[0], struct.unpack("<i", b[11:15])[0]; return np.frombuffer(b, "<f4", r * c, 15).reshape(r, c)
+    assert b[2:5] == b"FV "; n = struct.unpack("<i", b[6:10])[0]; return np.frombuffer(b, "<f4", n, 10)
+
+@pytest.mark.parametrize("B,T,s", [(4, 10, 3), (16, 25, 3), (3, 7, 1)])
+def test_reference_training_computation_over_the_k3_cumatrix(B, T, s, tmp_path):
+    """The reference's OWN training computation of one minibatch -- request with need_model_derivative, CachingOptimizingCompiler, NnetComputer with a gradient nnet: forward in
+    TRAINING mode (BatchNorm on batch statistics), then Backprop of every component (tests/adapter/nnet3_train_grad.cc, the calls of nnet3/nnet-chain-training.cc:136-206) --
+    linked against kaldi_amd/adapter/cu-k3.cc: every matrix operation runs on the MI355X.  Output and the gradient of all parameters against the same program on the reference's
+    CPU matrices (oracle/_ref/bin/ref-nnet3-train-grad)."""
+    from kaldi_amd import synth
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-train-grad"); ref = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-nnet3-train-grad")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/nnet3-train-grad is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    if not os.path.exists(ref): pytest.skip("oracle/_ref not built")
+    td = str(tmp_path); N = 50
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/m.raw")
+    lc = rc = 8; Tin = (T - 1) * s + 1 + lc + rc; rng = np.random.default_rng(B * 100 + T)
+    _kaldi_matrix(f"{td}/in.mat", rng.standard_normal((Tin * B, 40)) * 1.2 + 16.5); _kaldi_matrix(f"{td}/od.mat", rng.standard_normal((T * B, N)) * 0.1)
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
+    r = subprocess.run([ref, f"{td}/m.raw", str(B), str(T), str(s), f"{td}/in.mat", f"{td}/od.mat", f"{td}/ro.mat", f"{td}/rg.vec"], capture_output=True, text=True, env=dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl")))
+    if r.returncode != 0 and "context" in r.stderr: pytest.skip(r.stderr[-300:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    g = subprocess.run([exe, f"{td}/m.raw", str(B), str(T), str(s), f"{td}/in.mat", f"{td}/od.mat", f"{td}/go.mat", f"{td}/gg.vec"], capture_output=True, text=True, env=env)
+    assert g.returncode == 0, g.stderr[-3000:]
+    ro, go, rg, gg = _read_kaldi(f"{td}/ro.mat"), _read_kaldi(f"{td}/go.mat"), _read_kaldi(f"{td}/rg.vec"), _read_kaldi(f"{td}/gg.vec")
+    assert ro.shape == go.shape and np.abs(ro - go).max() <= 2e-4 * max(1.0, np.abs(ro).max()), np.abs(ro - go).max()
+    assert rg.shape == gg.shape and np.linalg.norm(rg) > 0
+    assert np.linalg.norm(rg - gg) <= 1e-3 * np.linalg.norm(rg), (np.linalg.norm(rg - gg), np.linalg.norm(rg))
+    assert np.abs(rg - gg).max() <= 2e-3 * np.abs(rg).max(), (np.abs(rg - gg).max(), np.abs(rg).max())
