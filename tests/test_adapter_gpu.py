@@ -111,3 +111,37 @@ def test_reference_training_computation_over_the_k3_cumatrix(B, T, s, tmp_path):
     assert rg.shape == gg.shape and np.linalg.norm(rg) > 0
     assert np.linalg.norm(rg - gg) <= 1e-3 * np.linalg.norm(rg), (np.linalg.norm(rg - gg), np.linalg.norm(rg))
     assert np.abs(rg - gg).max() <= 2e-3 * np.abs(rg).max(), (np.abs(rg - gg).max(), np.abs(rg).max())
+
+
+@pytest.mark.parametrize("B,T", [(4, 10), (16, 25)])
+def test_lf_mmi_gradient_reference_nnet_computer_plus_native_objective(B, T, tmp_path):
+    """One minibatch of chain training as nnet3/nnet-chain-training.cc:136-300 runs it: NnetComputer forward (training mode) -> ComputeChainObjfAndDeriv -> NnetComputer backward into a
+    gradient nnet (tests/adapter/nnet3_chain_grad.cc).  MI355X build: the reference's unmodified NnetComputer over the CuMatrix adapter and the objective by k3_chain_objf_and_deriv on the
+    adapter's device pointers; oracle build: the reference's nnet3 + chain code on its CPU matrices with the merged supervision FST.  Objective, l2 term and the gradient of every parameter."""
+    import struct
+    from kaldi_amd import synth
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-chain-grad"); ref = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-nnet3-chain-grad")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/nnet3-chain-grad is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    if not os.path.exists(ref): pytest.skip("oracle/_ref not built")
+    td = str(tmp_path); P = 50; s = 3
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=P, calib_feats=calib, out_std=1.5).write(f"{td}/m.raw")
+    lc = rc = 8; Tin = (T - 1) * s + 1 + lc + rc; rng = np.random.default_rng(B * 100 + T)
+    _kaldi_matrix(f"{td}/in.mat", rng.standard_normal((Tin * B, 40)) * 1.2 + 16.5)
+    den = synth.make_den_fst(120, P, seed=5, mean_degree=6.0, hub_degree=60); fsts = [synth.make_supervision_fst(T, P, seed=200 + i) for i in range(B)]; merged = synth.merge_supervision_fsts(fsts)
+    fb = lambda f: (np.ascontiguousarray(f.arc_offsets, np.int64).tobytes() + np.ascontiguousarray(f.ilabel, np.int32).tobytes() + np.ascontiguousarray(f.nextstate, np.int32).tobytes() +
+                    np.ascontiguousarray(f.weight, np.float32).tobytes() + np.ascontiguousarray(f.final, np.float32).tobytes())
+    so = np.concatenate([[0], np.cumsum([f.num_states for f in fsts])]).astype(np.int32); ab = np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in fsts])])
+    with open(f"{td}/chain.spec", "wb") as fh:
+        fh.write(struct.pack("<11i3f", 0x4b36, den.num_states, den.start, int(den.arc_offsets[-1]), P, B, T, merged.num_states, int(merged.arc_offsets[-1]), int(so[-1]), int(ab[-1]), 1.0e-05, 5.0e-05, 1.0))
+        fh.write(fb(den)); fh.write(fb(merged)); fh.write(so.tobytes())
+        fh.write(np.concatenate([[0]] + [np.asarray(f.arc_offsets[1:], np.int64) + b for f, b in zip(fsts, ab[:-1])]).astype(np.int64).tobytes())
+        for k, dt in (("ilabel", np.int32), ("nextstate", np.int32), ("weight", np.float32), ("final", np.float32)): fh.write(np.concatenate([getattr(f, k) for f in fsts]).astype(dt).tobytes())
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
+    r = subprocess.run([ref, f"{td}/m.raw", str(s), f"{td}/in.mat", f"{td}/chain.spec", f"{td}/r.vec"], capture_output=True, text=True, env=dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"))); assert r.returncode == 0, r.stderr[-2000:]
+    g = subprocess.run([exe, f"{td}/m.raw", str(s), f"{td}/in.mat", f"{td}/chain.spec", f"{td}/g.vec"], capture_output=True, text=True, env=env); assert g.returncode == 0, g.stderr[-3000:]
+    rv, gv = _read_kaldi(f"{td}/r.vec"), _read_kaldi(f"{td}/g.vec")
+    assert rv.shape == gv.shape and rv[2] == gv[2] == B * T
+    assert abs(rv[0] - gv[0]) <= 2e-4 * abs(rv[0]) + 1e-3 and abs(rv[1] - gv[1]) <= 2e-4 * abs(rv[1]) + 1e-5, (rv[:3], gv[:3])
+    rg, gg = rv[3:], gv[3:]
+    assert np.linalg.norm(rg) > 0 and np.linalg.norm(rg - gg) <= 2e-3 * np.linalg.norm(rg), (np.linalg.norm(rg - gg), np.linalg.norm(rg))
