@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
 
   for (int f = fresh ? -1 : f0; f < f0 + T; f++) {
     if (block_err(sh)) break;
-    float accept = p.beam; long long nb = 0; unsigned m_e = 1; int n_e = 1;
+    float accept = p.beam; long long nb = 0, eps_l0 = sh.n_link; unsigned m_e = 1; int n_e = 1;      // (f == -1: InitDecoding, no links yet)
 #ifdef K3_LIT_PROF
     if (tid == 0) sh.prof_n = n_cur;
 #endif
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
       }
       if (block_err(sh)) break;
       K3_LT(4);
-      n_e = sh.n_next;
+      n_e = sh.n_next; eps_l0 = sh.n_link;      // the frame's eps links start here
       if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
       for (int i = tid; i < n_e; i += kBlock) q.c0[i] = dec(tb.cost(tok_slot[i]));      // costs right after ProcessEmitting (the replay starts from them)
       __syncthreads();
@@ -765,46 +765,15 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     // replay has seen so far (+inf = not created yet), meta = {first passing arc, number of passing arcs}; per passing arc, in FST order:
     // {destination id, weight}.
     if (tid == 0) { ls.n_created = 0; ls.n_csr = 0; }
-    for (int i = tid; i < n; i += kBlock) { K3_AST(&q.rflag[i], 0); K3_AST(&q.rown[i], 0); }
+    // step 1: final costs into the pool (the closure's "expanded at" marker is no longer needed).  The sub-graph is read off the eps links the
+    // fixpoint wrote: a link carries the source cost it was made at, a token is expanded once at every cost it takes, so the links made at a
+    // token's FINAL cost are exactly its arcs that pass there -- no second walk over offsets, arcs and the state table.
+    for (int i = tid; i < n; i += kBlock) { tok_cost[nb + i] = tb.cost(tok_slot[i]); K3_AST(&q.rflag[i], 0); K3_AST(&q.rown[i], 0); }
     __syncthreads();
-    // step 1 (wave-cooperative): every eps arc of every token below the cutoff -> slot {destination token | -1, weight} of an uncompacted
-    // CSR, passing arcs counted per source, destinations flagged.  (A thread's tokens of two 512-token blocks are fetched together.)
-    for (int ib = 0; ib < n; ib += 2 * kBlock) {
-      int slot4[2], st4[2]; unsigned cb4[2]; int2 oa4[2], ob4[2];
-#pragma unroll
-      for (int u = 0; u < 2; u++) { const int i = ib + u * kBlock + tid; if (i < n) { slot4[u] = tok_slot[i]; st4[u] = tok_state[nb + i]; } }
-#pragma unroll
-      for (int u = 0; u < 2; u++) { const int i = ib + u * kBlock + tid; if (i < n) { cb4[u] = tb.cost(slot4[u]); oa4[u] = p.offs[st4[u]]; ob4[u] = p.offs[st4[u] + 1]; } }
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int i0 = ib + u * kBlock;
-        if (i0 < n) {      // (block-uniform)
-          const int i = i0 + tid; int deg = 0, ebeg = 0; float c = 0.0f;
-          if (i < n) {
-            c = dec(cb4[u]);
-            tok_cost[nb + i] = cb4[u];                                 // the frame's final cost (the closure's "expanded at" marker is no longer needed)
-            ebeg = oa4[u].y; deg = (ob4[u].x > oa4[u].y && c < accept) ? ob4[u].x - oa4[u].y : 0;
-          }
-          const int incl = wave_incl_scan(deg);
-          int wbase = 0;
-          if (lane == 63) wbase = k3a_add(&ls.n_csr, incl);
-          wbase = __builtin_amdgcn_readlane(wbase, 63);
-          const int base = wbase + incl - deg;
-          if (i < n) q.crng[i] = make_int2(base, deg);
-          if (wbase + __builtin_amdgcn_readlane(incl, 63) > p.eps_cap) { sh.err = K3_ERR_OVERFLOW; deg = 0; }
-          wave_expand_seq(p.arcs, ebeg, deg, [&](bool valid, int, int arc, int owner, const ArcRec &r) {
-            const float oc = __shfl(c, owner); const int obase = __shfl(base, owner), obeg = __shfl(ebeg, owner), oi = i0 + (tid & ~63) + owner;
-            if (valid) {
-              int d = -1;
-              if (oc + r.w < accept) {
-                const int s2 = tb.find((int)((unsigned)r.next & ~kEpsFlag));
-                if (s2 >= 0) { d = tb.tok(s2); k3a_or(&q.rflag[d], 1); k3a_add(&q.rown[oi], 1); } else sh.err = K3_ERR_HIP;
-              }
-              q.cdst[obase + (arc - obeg)] = d; q.cw[obase + (arc - obeg)] = r.w;
-            }
-          });
-        }
-      }
+    const long long eps_l1 = sh.n_link;
+    for (long long l = eps_l0 + tid; l < eps_l1; l += kBlock) {
+      const Link k = links[l];
+      if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) { k3a_add(&q.rown[k.src - nb], 1); k3a_or(&q.rflag[k.dst - nb], 1); }      // passing arcs per source; destinations flagged
     }
     __syncthreads();
     if (block_err(sh)) break;
@@ -818,8 +787,17 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     K3_LT(6);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
     const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
-                                       [&](int i, int4 ex) { q.grp[i] = ex.x; q.lead[i] = (unsigned)ex.y; }, n, reinterpret_cast<int4 *>(sh.hist));
+                                       [&](int i, int4 ex) { q.grp[i] = ex.x; q.lead[i] = (unsigned)ex.y; K3_AST(&q.rtmp[i], 0); }, n, reinterpret_cast<int4 *>(sh.hist));
     const int n_cid = tot2.x, n_arc = tot2.y;
+    if (n_arc > p.eps_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
+    if (block_err(sh)) break;
+    // the live links again: (arc, destination token) into the source's slots (any order; step 2 sorts a source's few entries into FST order)
+    int *ent_arc = q.cdst, *ent_dst = reinterpret_cast<int *>(q.cw);
+    for (long long l = eps_l0 + tid; l < eps_l1; l += kBlock) {
+      const Link k = links[l];
+      if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) { const int sl = (int)(k.src - nb); const int pos = (int)q.lead[sl] + k3a_add(&q.rtmp[sl], 1); ent_arc[pos] = link_arc[l]; ent_dst[pos] = (int)(k.dst - nb); }
+    }
+    __syncthreads();
     // mode 0: costs, meta and arcs in LDS; mode 1: costs in LDS, meta / arcs (read-only during the replay) in HBM; mode 2: all in HBM
     // (mode 0: kRN x (16 B meta + 4 B cost + 4 B creation list) = the table's 12 B x kHL; mode 1: 3 kHL costs in the table, the list where mode 0 keeps its arcs)
     const int rmode = (n_cid <= kRN && n_arc <= kRA) ? 0 : ((n_cid <= 3 * kHL && n - n_e <= kRA * 2) ? 1 : 2);
@@ -834,30 +812,32 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     // FST order.  kSB tokens per thread in flight (the kernel has 128 registers per thread: more would spill).
     constexpr int kSB = 2;
     for (int ib = tid; ib < n; ib += kSB * kBlock) {
-      int pc4[kSB], fl4[kSB], cid4[kSB], abeg4[kSB], d1[kSB], g1[kSB]; int2 rg4[kSB]; float c04[kSB], w1[kSB]; bool inv[kSB];
+      int pc4[kSB], fl4[kSB], cid4[kSB], abeg4[kSB], a1[kSB], d1[kSB], g1[kSB]; float c04[kSB], w1[kSB]; bool inv[kSB];
 #pragma unroll
       for (int u = 0; u < kSB; u++) { const int i = ib + u * kBlock; pc4[u] = 0; fl4[u] = 0; if (i < n) { pc4[u] = K3_ALD(&q.rown[i]); fl4[u] = K3_ALD(&q.rflag[i]); } inv[u] = pc4[u] > 0 || fl4[u] != 0; }
 #pragma unroll
-      for (int u = 0; u < kSB; u++) { const int i = ib + u * kBlock; if (inv[u]) { cid4[u] = q.grp[i]; abeg4[u] = (int)q.lead[i]; c04[u] = i < n_e ? q.c0[i] : kInf; if (pc4[u] > 0) rg4[u] = q.crng[i]; } }
+      for (int u = 0; u < kSB; u++) { const int i = ib + u * kBlock; if (inv[u]) { cid4[u] = q.grp[i]; abeg4[u] = (int)q.lead[i]; c04[u] = i < n_e ? q.c0[i] : kInf; } }
 #pragma unroll
-      for (int u = 0; u < kSB; u++) { d1[u] = -1; if (inv[u] && pc4[u] > 0) { d1[u] = q.cdst[rg4[u].x]; w1[u] = q.cw[rg4[u].x]; } }
+      for (int u = 0; u < kSB; u++) { a1[u] = -1; if (inv[u] && pc4[u] == 1) { a1[u] = ent_arc[abeg4[u]]; d1[u] = ent_dst[abeg4[u]]; } }      // most sources have exactly one passing arc
 #pragma unroll
-      for (int u = 0; u < kSB; u++) if (d1[u] >= 0) g1[u] = q.grp[d1[u]];
+      for (int u = 0; u < kSB; u++) if (a1[u] >= 0) { g1[u] = q.grp[d1[u]]; w1[u] = p.arcs[a1[u]].w; }
 #pragma unroll
       for (int u = 0; u < kSB; u++) {
         const int i = ib + u * kBlock;
         if (inv[u]) {
-          const int cid = cid4[u], abeg = abeg4[u];
+          const int cid = cid4[u], abeg = abeg4[u], pc = pc4[u];
           q.c2t[cid] = i; rcost[cid] = c04[u]; int d0 = 0, w0 = 0;
           if (p.literal & 1) { K3_AST(&par[cid], cid); int *ci = reinterpret_cast<int *>(&q.cinfo[cid]); K3_AST(&ci[0], 0); K3_AST(&ci[1], 0); K3_AST(&ci[2], 0); K3_AST(&ci[3], 0); }
-          if (pc4[u] > 0) {
-            int k = abeg;
-            for (int a = rg4[u].x; a < rg4[u].x + rg4[u].y; a++) {
-              const int d = a == rg4[u].x ? d1[u] : q.cdst[a];
-              if (d >= 0) { const int2 ar = make_int2(a == rg4[u].x ? g1[u] : q.grp[d], __float_as_int(a == rg4[u].x ? w1[u] : q.cw[a])); if (k == abeg) { d0 = ar.x; w0 = ar.y; } AR[k++] = ar; }
+          if (pc == 1) { d0 = g1[u]; w0 = __float_as_int(w1[u]); AR[abeg] = make_int2(d0, w0); }
+          else if (pc > 1) {
+            for (int a = abeg + 1; a < abeg + pc; a++) {      // FST order = ascending arc index (a source's arcs are contiguous in the graph)
+              const int ka = ent_arc[a], kd = ent_dst[a]; int b_ = a - 1;
+              while (b_ >= abeg && ent_arc[b_] > ka) { ent_arc[b_ + 1] = ent_arc[b_]; ent_dst[b_ + 1] = ent_dst[b_]; b_--; }
+              ent_arc[b_ + 1] = ka; ent_dst[b_ + 1] = kd;
             }
+            for (int k = abeg; k < abeg + pc; k++) { const int2 ar = make_int2(q.grp[ent_dst[k]], __float_as_int(p.arcs[ent_arc[k]].w)); if (k == abeg) { d0 = ar.x; w0 = ar.y; } AR[k] = ar; }
           }
-          meta[cid] = make_int4(abeg, pc4[u], d0, w0);      // the first passing arc rides along: most sources have exactly one
+          meta[cid] = make_int4(abeg, pc, d0, w0);      // the first passing arc rides along
         }
       }
     }
