@@ -42,13 +42,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBM = 128, kBK = 32, kLdsLd = 36, kThreads = 256;
 constexpr int kMaxOffsets = 8, kMaxOps = 6;
 
-struct TileDesc {      // one per (utterance, 128-row slab) of a node's output
-  int out_row0, nrows; // rows [out_row0, out_row0 + nrows) of the output buffer
+struct TileDesc {      // one per 128-row slab of a node's output.  A slab is cut from ONE sequence (utterance / chunk), or -- when a sequence ends inside
+  // it -- continues with the first rows of the next one (rows [split, nrows)): sequences of 1030 or 340 rows would otherwise leave every ninth / third
+  // slab almost empty, and an empty row costs the same MFMA time as a full one.
+  int out_row0, nrows; // rows [out_row0, out_row0 + nrows) of the output buffer (consecutive across the two sequences)
+  int split;           // local rows >= split belong to the second sequence (== nrows: none)
   int in_base;         // input row of local index 0 with shift 0
   int in_lo, in_hi;    // clamp bounds (absolute input rows) -- edge-frame replication for the first layer
   int res_base;        // residual row of local index 0
   int bias_row;        // row of GemmParams::seq_bias this slab starts from instead of the bias (a node fed by the chunk's i-vector)
-  int pad1;
+  int in_base2, in_lo2, in_hi2, res_base2, bias_row2;      // the same for the second sequence; the bases are pre-shifted so that local row r maps to base2 + r * stride as well
+  int pad[3];
 };
 
 struct GemmParams {
@@ -95,9 +99,12 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
   const int ld_row = tid >> 3, ld_kv = (tid & 7) * 4;
 
   // per-thread row bookkeeping for the A loader (rows beyond nrows re-read the last valid row; never stored)
-  int a_row_local[A_LOADS];
+  int a_row_local[A_LOADS], a_lo[A_LOADS], a_hi[A_LOADS];
 #pragma unroll
-  for (int i = 0; i < A_LOADS; i++) a_row_local[i] = min(i * LR + ld_row, td.nrows - 1) * p.row_stride + td.in_base;
+  for (int i = 0; i < A_LOADS; i++) {
+    const int r = min(i * LR + ld_row, td.nrows - 1); const bool s2 = r >= td.split;
+    a_row_local[i] = r * p.row_stride + (s2 ? td.in_base2 : td.in_base); a_lo[i] = s2 ? td.in_lo2 : td.in_lo; a_hi[i] = s2 ? td.in_hi2 : td.in_hi;
+  }
 
   f32x4 ra[A_LOADS], rb[B_LOADS];
   // `oi_u` = time offset the k-tile lies in when offsets are tile aligned (tiles_per_off > 0): uniform over the block, so the
@@ -112,7 +119,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
 #pragma unroll
         for (int o = 1; o < kMaxOffsets; o++) sh = oi_u == o ? p.shifts[o] : sh;
 #pragma unroll
-        for (int i = 0; i < A_LOADS; i++) a_ptr[i] = p.A + (long long)clampi(a_row_local[i] + sh, td.in_lo, td.in_hi) * p.lda + ld_kv;
+        for (int i = 0; i < A_LOADS; i++) a_ptr[i] = p.A + (long long)clampi(a_row_local[i] + sh, a_lo[i], a_hi[i]) * p.lda + ld_kv;
       }
 #pragma unroll
       for (int i = 0; i < A_LOADS; i++) { ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i]); a_ptr[i] += kBK; }
@@ -123,7 +130,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
 #pragma unroll
       for (int i = 0; i < A_LOADS; i++) {
         if (kvalid) {
-          const int row = clampi(a_row_local[i] + shift, td.in_lo, td.in_hi);
+          const int row = clampi(a_row_local[i] + shift, a_lo[i], a_hi[i]);
           ra[i] = *reinterpret_cast<const f32x4 *>(p.A + (long long)row * p.lda + col);
         } else {
           ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -164,10 +171,18 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
     const int col = n0 + wn * WN + ni * 32 + (lane & 31);
     const float *bias = p.seq_bias ? p.seq_bias + (long long)td.bias_row * p.ld_seq_bias : p.bias;
     const float b0 = (bias && col < p.N) ? bias[col] : 0.0f;
+    if (p.seq_bias && td.split < td.nrows) {      // two sequences in the slab, each with its own "bias + W_iv . ivector" row (block-uniform branch)
+      const float b1 = col < p.N ? p.seq_bias[(long long)td.bias_row2 * p.ld_seq_bias + col] : 0.0f;
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++)
+      for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) { acc[mi][ni][r] = 0.0f; tot[mi][ni][r] = b0; }
+        for (int r = 0; r < 16; r++) { acc[mi][ni][r] = 0.0f; tot[mi][ni][r] = (wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) < td.split ? b0 : b1; }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[mi][ni][r] = 0.0f; tot[mi][ni][r] = b0; }
+    }
   }
 
   const int nk = (p.Ktot + kBK - 1) / kBK;
@@ -260,7 +275,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
     // bounds logic and walks its rows with one pointer increment per row piece
     const bool full = td.nrows == kBM && n0 + BN <= p.N;
     if ((EPI == kEpiAny || EPI == kEpiReluScaleRes) && res_kind >= 0 && !(K3_GDBG & 1)) {
-      if (full) {
+      if (full && td.split >= td.nrows) {
         const float *rp = R + (long long)(td.res_base + (wm * WM + row0c) * p.res_row_stride) * p.ldr + colc;
         const long long rstep = (long long)RPI * p.res_row_stride * p.ldr;
 #pragma unroll
@@ -269,7 +284,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
           const int lrow = min(wm * WM + it * RPI + row0, td.nrows - 1);
-          res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + colc);
+          res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)((lrow < td.split ? td.res_base : td.res_base2) + lrow * p.res_row_stride) * p.ldr + colc);
         }
       }
     }
@@ -340,7 +355,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
           const int kind = p.op_kind[o];
           if (kind == k3::kEpiRelu) x = fmaxf(x, 0.0f);
           else if (kind == k3::kEpiScaleOffset) x = x * p.op_scale[o][c] + p.op_offset[o][c];
-          else x = p.res_scale * R[(long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + c] + x;
+          else x = p.res_scale * R[(long long)((lrow < td.split ? td.res_base : td.res_base2) + lrow * p.res_row_stride) * p.ldr + c] + x;
         }
         C[(long long)(td.out_row0 + lrow) * p.ldc + c] = x;
       }
@@ -358,13 +373,14 @@ __global__ __launch_bounds__(256) void k3_elementwise_kernel(GemmParams p) {
   const TileDesc td = p.tiles[blockIdx.x];
   for (int idx = threadIdx.x; idx < td.nrows * p.N; idx += 256) {
     const int lrow = idx / p.N, col = idx - lrow * p.N;
-    const int row = clampi(td.in_base + lrow * p.row_stride + p.shifts[0], td.in_lo, td.in_hi);
+    const bool s2 = lrow >= td.split;
+    const int row = clampi((s2 ? td.in_base2 : td.in_base) + lrow * p.row_stride + p.shifts[0], s2 ? td.in_lo2 : td.in_lo, s2 ? td.in_hi2 : td.in_hi);
     float v = p.A[(long long)row * p.lda + col];
     for (int o = 0; o < p.nops; o++) {
       const int kind = p.op_kind[o];
       if (kind == k3::kEpiRelu) v = fmaxf(v, 0.0f);
       else if (kind == k3::kEpiScaleOffset) v = v * p.op_scale[o][col] + p.op_offset[o][col];
-      else v = p.res_scale * p.R[(long long)(td.res_base + lrow * p.res_row_stride) * p.ldr + col] + v;
+      else v = p.res_scale * p.R[(long long)((s2 ? td.res_base2 : td.res_base) + lrow * p.res_row_stride) * p.ldr + col] + v;
     }
     p.C[(long long)(td.out_row0 + lrow) * p.ldc + col] = v;
   }
@@ -653,22 +669,33 @@ static int batch_create_impl(k3_nnet *net, int32_t num_utts, const int32_t *h_nu
       p.R = res < 0 ? nullptr : slots[slot_of[res]].ptr; p.ldr = res < 0 ? 0 : ld[res];
       p.res_row_stride = G[i] / g_res;
     }
-    std::vector<TileDesc> tiles;
+    std::vector<TileDesc> tiles; TileDesc open; bool has_open = false;      // `open`: a slab whose sequence ended before row 128
+    auto segment = [&](int q, int r0, int *in_base, int *in_lo, int *in_hi, int *res_base) {      // rows r0.. of sequence q: input / residual row of its local row 0, clamp bounds
+      const int u = seqs[q].u, t0 = seqs[q].t0;
+      if (src < 0) { *in_base = (int)featoff[u] + t0 + r0 * p.row_stride; *in_lo = (int)featoff[u]; *in_hi = (int)featoff[u + 1] - 1; }
+      else { *in_base = (int)rowoff[src][q] + r0 * p.row_stride; *in_lo = (int)rowoff[src][q]; *in_hi = (int)rowoff[src][q + 1] - 1; }
+      *res_base = 0;
+      if (res >= -1) *res_base = (int)(res < 0 ? featoff[u] + t0 : rowoff[res][q]) + (A[i] - a_res) / g_res + r0 * p.res_row_stride;
+    };
     for (int q = 0; q < num_seqs; q++) {
-      const int rows = rows_of(i, q), u = seqs[q].u, t0 = seqs[q].t0;
-      for (int r0 = 0; r0 < rows; r0 += kBM) {
+      const int rows = rows_of(i, q); int r0 = 0;
+      if (has_open) {      // the previous sequence's last slab takes this sequence's first rows
+        const int take = std::min(kBM - open.nrows, rows);
+        segment(q, 0, &open.in_base2, &open.in_lo2, &open.in_hi2, &open.res_base2); open.bias_row2 = q;
+        open.split = open.nrows; open.nrows += take;
+        open.in_base2 -= open.split * p.row_stride; open.res_base2 -= open.split * p.res_row_stride;      // local row r -> base2 + r * stride
+        tiles.push_back(open); has_open = false; r0 = take;
+      }
+      for (; r0 < rows; r0 += kBM) {
         TileDesc t; memset(&t, 0, sizeof t);
-        t.out_row0 = (int)rowoff[i][q] + r0; t.nrows = std::min(kBM, rows - r0); t.bias_row = q;
-        if (src < 0) { t.in_base = (int)featoff[u] + t0 + r0 * p.row_stride; t.in_lo = (int)featoff[u]; t.in_hi = (int)featoff[u + 1] - 1; }
-        else { t.in_base = (int)rowoff[src][q] + r0 * p.row_stride; t.in_lo = (int)rowoff[src][q]; t.in_hi = (int)rowoff[src][q + 1] - 1; }
-        if (res >= -1) {
-          const int base = (A[i] - a_res) / g_res;
-          t.res_base = (int)(res < 0 ? featoff[u] + t0 : rowoff[res][q]) + base + r0 * p.res_row_stride;
-        }
-        tiles.push_back(t);
+        t.out_row0 = (int)rowoff[i][q] + r0; t.nrows = std::min(kBM, rows - r0); t.split = t.nrows; t.bias_row = q;
+        segment(q, r0, &t.in_base, &t.in_lo, &t.in_hi, &t.res_base);
+        t.in_base2 = t.in_base; t.in_lo2 = t.in_lo; t.in_hi2 = t.in_hi; t.res_base2 = t.res_base; t.bias_row2 = q;
+        if (t.nrows < kBM && q + 1 < num_seqs) { open = t; has_open = true; } else tiles.push_back(t);
       }
       if (f.has_gemm) b->flops += 2.0 * rows * (double)p.Ktot * f.out_dim;
     }
+    if (has_open) tiles.push_back(open);
     if (!f.W_iv.empty()) {                                       // this node starts from "bias + W_iv . ivector(sequence)" (k3_seq_bias_kernel, run by k3_nnet_forward_ivector)
       K3_REQUIRE(with_ivector, "k3_nnet_batch_create: the model has an i-vector input: use k3_nnet_batch_create_ivector");
       float *sb = nullptr; const int ldsb = (int)align_up(f.out_dim, 4);

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""GPU box: one TDNN-F forward at the bench size; run under `rocprofv3 --kernel-trace --output-format csv` and pass the trace csv as argv[2] of a
+second invocation (`prof_gemm.py parse <csv>`) to list every GEMM launch (grid, duration, TFLOP/s from the launch's tile count)."""
+import os, sys, csv, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+if len(sys.argv) > 2 and sys.argv[1] == "parse":
+    rows = list(csv.DictReader(open(sys.argv[2])))
+    rows = [r for r in rows if "gemm" in r["Kernel_Name"] or "tdnnf" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    n = len(rows) // int(sys.argv[3]) if len(sys.argv) > 3 else len(rows)
+    for r in rows[-n:]:
+        nm = r["Kernel_Name"]; nm = nm[nm.find("k3_"):nm.find("(", nm.find("k3_"))]
+        print("%-52s grid %7d wg %4d  %8.1f us" % (nm, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    sys.exit(0)
+import numpy as np, torch
+from kaldi_amd import feat, nnet3, synth
+U = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+dev = torch.device("cuda:0"); nsamp = 160000
+g = torch.Generator(device="cpu"); g.manual_seed(1234)
+waves = (torch.randn(U * nsamp, generator=g) * 3000).round().clamp(-32768, 32767).to(dev)
+sf = feat.SpectralFeatures(feat.fbank_options(dither=0.0, num_bins=40))
+wo, fo, total_frames, fo_h = sf.offsets([nsamp] * U, dev)
+calib = sf.ComputeFeatures(waves[:nsamp].contiguous(), *sf.offsets([nsamp], dev)[:3]).cpu().numpy()[:600]
+mp = os.path.join(tempfile.gettempdir(), "profgemm.raw"); synth.make_tdnnf(seed=1, calib_feats=calib).write(mp)
+net = nnet3.Nnet(mp); nb = nnet3.NnetBatch(net, [fo_h[i + 1] - fo_h[i] for i in range(U)], 3)
+feats = sf.ComputeFeatures(waves, wo, fo, total_frames)
+REP = int(os.environ.get("K3_REP", 3))
+for it in range(REP):
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); ll = nb.forward(feats); e1.record(); torch.cuda.synchronize()
+    print("forward ms %.3f  TFLOP/s %.1f" % (e0.elapsed_time(e1), nb.flops / e0.elapsed_time(e1) / 1e9))
