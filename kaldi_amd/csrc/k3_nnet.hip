@@ -201,24 +201,40 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
     const int w_cur = w_next, oi_cur = oi_next;        // index of tile kt inside its offset
     const bool more = kt + 1 < nk;
     if (++w_next == p.tiles_per_off) { w_next = 0; oi_next++; }
-    load_tiles(more ? kt + 1 : kt, more ? oi_next : oi_cur, more ? w_next : 1);
-    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMAs: the scheduler otherwise sinks the loads to the end of the tile, right in front of their use
     const float *a = As + buf * kBM * kLdsLd + (wm * WM + frag_row) * kLdsLd + frag_k;
     const float *b = Bs + buf * BN * kLdsLd + (wn * WN + frag_row) * kLdsLd + frag_k;
+    // fragments of step kk + 1 are requested before the MFMAs of step kk: a wavefront issues in order, so reads placed after the 16 MFMAs of a step
+    // reach the LDS only when the last of them has been accepted, and the pipe then idles for the LDS round trip (a lone workgroup ran at 72 %)
+    // The stretch between the last MFMA of one k-tile and the first of the next is what a workgroup cannot hide by itself, so only the barrier and one
+    // LDS read stay on it: the next tile's global loads are issued while the first fragments are on their way, and the tile is written to the other
+    // buffer before the LAST step's MFMAs (its loads were issued three steps earlier), not after them.
+    f32x4 fa[2][MI], fb[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) fa[0][mi] = *reinterpret_cast<const f32x4 *>(a + mi * 32 * kLdsLd);
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) fb[0][ni] = *reinterpret_cast<const f32x4 *>(b + ni * 32 * kLdsLd);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tiles(more ? kt + 1 : kt, more ? oi_next : oi_cur, more ? w_next : 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < kBK / 8; kk++) {
-      f32x4 fa[MI], fb[NI];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < kBK / 8) {
 #pragma unroll
-      for (int mi = 0; mi < MI; mi++) fa[mi] = *reinterpret_cast<const f32x4 *>(a + mi * 32 * kLdsLd + kk * 8);
+        for (int mi = 0; mi < MI; mi++) fa[nxt][mi] = *reinterpret_cast<const f32x4 *>(a + mi * 32 * kLdsLd + (kk + 1) * 8);
 #pragma unroll
-      for (int ni = 0; ni < NI; ni++) fb[ni] = *reinterpret_cast<const f32x4 *>(b + ni * 32 * kLdsLd + kk * 8);
+        for (int ni = 0; ni < NI; ni++) fb[nxt][ni] = *reinterpret_cast<const f32x4 *>(b + ni * 32 * kLdsLd + (kk + 1) * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // reads first, then this step's MFMAs (the scheduler otherwise sinks the reads to the end of the step)
+      if (kk == kBK / 8 - 1) { store_tiles(buf ^ 1); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int mi = 0; mi < MI; mi++)
 #pragma unroll
           for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][j], fb[cur][ni][j], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);      // (keeps the scheduler from sinking the next step's reads back below these MFMAs)
     }
     {   // end of an accumulation segment?
       bool flush = kt + 1 == nk;
@@ -232,7 +248,6 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
             for (int r = 0; r < 16; r++) { tot[mi][ni][r] += acc[mi][ni][r]; acc[mi][ni][r] = 0.0f; }
       }
     }
-    store_tiles(buf ^ 1);
     __syncthreads();
   }
 
@@ -806,8 +821,13 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
       else if (p.nops == 2 && p.op_kind[0] == k3::kEpiRelu && p.op_kind[1] == k3::kEpiScaleOffset) epi = kEpiReluScale;
       const bool al = p.tiles_per_off > 0, bn96 = b->net->dev[i].bn == 96;
       const size_t lds = 2 * (kBM + (bn96 ? 96 : 128)) * kLdsLd * sizeof(float);
+#ifdef K3_GEMM_PROF
+      static const size_t lds_pad = getenv("K3_GEMM_LDS_PAD") ? (size_t)atoi(getenv("K3_GEMM_LDS_PAD")) : 0;      // > 6 KB: one workgroup per CU
+#else
+      const size_t lds_pad = 0;
+#endif
       bool launched = false;
-#define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3((kBM / wm) * (bn / wn) * 64), lds, st, p); launched = true; }
+#define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3((kBM / wm) * (bn / wn) * 64), lds + lds_pad, st, p); launched = true; }
       K3_GEMM_VARIANTS(K3_LAUNCH)
       if (!launched) { epi = kEpiAny; K3_GEMM_VARIANTS(K3_LAUNCH) }      // no fixed-program instantiation for this shape: run-time dispatch
 #undef K3_LAUNCH
