@@ -111,7 +111,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
   // row shift is picked with scalar selects.  (Indexing the kernel-argument array with a per-lane value costs a dependent
   // global load at the top of every k-tile, and the waits the compiler puts around it serialise the whole tile prefetch.)
   const float *a_ptr[A_LOADS];      // kAligned: this thread's A addresses for the next tile; recomputed when the time offset changes
-  auto load_tiles = [&](int kt, int oi_u, int w_u) {
+  auto load_tiles = [&](int kt, int oi_u, int w_u, bool dummy = false) {      // dummy (block-uniform): the prefetch slot of the last k-tile -- nothing left to fetch
     const int kglob = kt * kBK + ld_kv;
     if constexpr (kAligned) {        // straight-line loads, nothing to wait for in between
       if (w_u == 0) {                // first tile of a time offset (block-uniform): row shift and clamped rows change
@@ -122,7 +122,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
         for (int i = 0; i < A_LOADS; i++) a_ptr[i] = p.A + (long long)clampi(a_row_local[i] + sh, a_lo[i], a_hi[i]) * p.lda + ld_kv;
       }
 #pragma unroll
-      for (int i = 0; i < A_LOADS; i++) { ra[i] = *reinterpret_cast<const f32x4 *>(a_ptr[i]); a_ptr[i] += kBK; }
+      for (int i = 0; i < A_LOADS; i++) { ra[i] = *reinterpret_cast<const f32x4 *>(dummy ? p.W : a_ptr[i]); a_ptr[i] += kBK; }      // (dummy: every lane the same 16 bytes -- one cache line per instruction, and no address past the last row)
     } else {
       const bool kvalid = kglob < p.Ktot;
       const int oi = kglob / p.in_dim, col = kglob - oi * p.in_dim;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; i++)   // W is zero-padded to [Npad x Kpad]: no bounds checks
-      rb[i] = *reinterpret_cast<const f32x4 *>(p.W + (long long)(n0 + i * LR + ld_row) * p.ldw + kglob);
+      rb[i] = *reinterpret_cast<const f32x4 *>(dummy ? p.W : p.W + (long long)(n0 + i * LR + ld_row) * p.ldw + kglob);
   };
   // LDS K layout: inside every group of 8 k-values position p holds k = 2 * (p & 3) + (p >> 2), so that the b128 fragment a
   // lane of half h = lane >> 5 reads (positions 4h .. 4h+3) is k = h, 2+h, 4+h, 6+h and MFMA j (A column k = lane >> 5)
@@ -196,7 +196,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
   const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
   for (int kt = 0; kt < ((K3_GDBG & 4) ? 1 : nk); kt++) {
     const int buf = kt & 1;
-    // prefetch tile kt + 1 (the last iteration fetches its own tile again: no branch in the loop body, so the compiler's
+    // prefetch tile kt + 1 (the last iteration issues dummy loads of one line: no branch in the loop body, so the compiler's
     // s_waitcnt placement stays exact -- with conditional prefetches it put vmcnt(0) between the loads of one tile)
     const int w_cur = w_next, oi_cur = oi_next;        // index of tile kt inside its offset
     const bool more = kt + 1 < nk;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) fb[0][ni] = *reinterpret_cast<const f32x4 *>(b + ni * 32 * kLdsLd);
     __builtin_amdgcn_sched_barrier(0);
-    load_tiles(more ? kt + 1 : kt, more ? oi_next : oi_cur, more ? w_next : 1);
+    load_tiles(more ? kt + 1 : kt, more ? oi_next : oi_cur, more ? w_next : 1, !more);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < kBK / 8; kk++) {
