@@ -31,3 +31,11 @@ for it in range(REP):
     e0.record(); ll = nb.forward(feats); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 print("forward ms", " ".join("%.2f" % t for t in ts), " best %.3f ms = %.1f TFLOP/s" % (min(ts), nb.flops / min(ts) / 1e9))
+if os.environ.get("K3_TRASH"):      # forwards separated by other work, as inside bench.py (cold L2 / MALL / TLB?): K3_TRASH=fill | sleep
+    big = torch.empty(1 << 30, dtype=torch.float32, device=dev); ts = []
+    for it in range(6):
+        if os.environ["K3_TRASH"] == "fill": big.fill_(float(it))
+        else: torch.cuda._sleep(200_000_000)
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); ll = nb.forward(feats); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    print("forward after", os.environ["K3_TRASH"], "ms", " ".join("%.2f" % t for t in ts))
