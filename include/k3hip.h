@@ -341,11 +341,19 @@ int k3_mat_mul_elements(float *d_C, int64_t ldc, int32_t rows, int32_t cols, con
 int k3_mat_heaviside(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, void *stream);   /* Heaviside(src): 1 where src > 0, else 0 (ReLU backprop) */
 int k3_mat_add_mat_diag_vec(float alpha, const float *d_M, int64_t ldm, int32_t trans_m, const float *d_v, float beta, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream); /* AddMatDiagVec: C = beta C + alpha M diag(v) */
 int k3_mat_add_row_ranges(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, int32_t src_rows, const int32_t *d_ranges /* [rows][2] */, void *stream); /* AddRowRanges: C[r] += sum of src rows [first, second) */
+int k3_mat_copy_lower_to_upper(float *d_C, int64_t ldc, int32_t n, void *stream);                                 /* CopyLowerToUpper (after SymAddMat2) */
+int k3_mat_add_to_diag(float *d_C, int64_t ldc, int32_t rows, int32_t cols, float value, void *stream);            /* AddToDiag */
+int k3_mat_add_vec_vec(float alpha, const float *d_x, const float *d_y, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream);   /* AddVecVec: C += alpha x y^T */
+int k3_mat_add_diag_vec_mat(float alpha, const float *d_v, const float *d_M, int64_t ldm, int32_t trans_m, float beta, float *d_C, int64_t ldc, int32_t rows, int32_t cols, void *stream); /* AddDiagVecMat: C = beta C + alpha diag(v) M */
+int k3_mat_div_elements(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_A, int64_t lda, void *stream);                    /* DivElements */
+/* Scalar reductions, result to the host (synchronises the stream): op 0 TraceMatMat(A, B, kTrans) = VecVec = sum A(i,j) B(i,j); 1 TraceMatMat(A, B, kNoTrans) = sum A(i,j) B(j,i)
+ * (B is cols x rows); 2 Trace(A) (square); 3 Sum; 4 Max; 5 Min.  Partial sums in double, folded in a fixed order (cudamatrix/cu-matrix.h:80-95,658-671, cu-vector.h:36-40). */
+int k3_mat_reduce_scalar(int32_t op, const float *d_A, int64_t lda, const float *d_B, int64_t ldb, int32_t rows, int32_t cols, double *h_result, void *stream);
 /* Reductions into a vector (CuVectorBase): op 0 AddRowSumMat: v[c] = beta v[c] + alpha sum_r M(r, c); 1 AddDiagMat2(M, kTrans): sum_r M(r, c)^2; 2 AddDiagMatMat(M, kTrans, N, kNoTrans):
  * sum_r M(r, c) N(r, c); 3 AddDiagMat2(M, kNoTrans): v[r] = .. sum_c M(r, c)^2; 4 AddColSumMat: v[r] = .. sum_c M(r, c).  Sums in double. */
 int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *stream);
 
-/* CuVectorBase: a vector is a [1 x dim] matrix/* CuVectorBase: a vector is a [1 x dim] matrix for Set / Add / Scale / ApplyFloor / AddVec (k3_mat_add_vec_to_rows) / MulElements
+/* CuVectorBase: a vector is a [1 x dim] matrix for Set / Add / Scale / ApplyFloor / AddVec (k3_mat_add_vec_to_rows) / MulElements
  * (k3_mat_mul_cols_vec); the three operations below have no matrix counterpart (cudamatrix/cu-vector.h:79-103,147-160). */
 int k3_vec_convert(const void *d_src, int32_t src_is_f64, void *d_dst, int32_t dst_is_f64, int32_t n, void *stream);   /* CopyFromVec(const CuVectorBase<OtherReal>&) */
 int k3_vec_pow(const float *d_src, float *d_dst, int32_t n, float power, void *stream);                                /* Pow / ApplyPow */

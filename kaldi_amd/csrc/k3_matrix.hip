@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
 }
 
 enum { kOpSet, kOpScale, kOpFloor, kOpCeil, kOpAddConst, kOpCopyRowsFromVec, kOpMulColsVec, kOpMulRowsVec, kOpAddVecToRows, kOpAddVecToCols, kOpCopy, kOpCopyT, kOpAddMat, kOpAddMatT,
-       kOpCopyRows, kOpAddRows, kOpMulElements, kOpHeaviside, kOpAddMatDiagVec, kOpAddMatDiagVecT, kOpAddRowRanges };
+       kOpCopyRows, kOpAddRows, kOpMulElements, kOpHeaviside, kOpAddMatDiagVec, kOpAddMatDiagVecT, kOpAddRowRanges, kOpCopyLowerToUpper, kOpAddToDiag, kOpAddVecVecOuter, kOpDivElements, kOpAddDiagVecMat, kOpAddDiagVecMatT };
 struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; int src_rows; };
 
 __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {
@@ -86,6 +86,12 @@ __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {
       case kOpHeaviside: x = p.S[(long long)r * p.lds + c] > 0.0f ? 1.0f : 0.0f; break;
       case kOpAddMatDiagVec: x = p.b * *d + p.a * p.S[(long long)r * p.lds + c] * p.v[c]; break;               // this = beta this + alpha M diag(v)
       case kOpAddMatDiagVecT: x = p.b * *d + p.a * p.S[(long long)c * p.lds + r] * p.v[c]; break;
+      case kOpCopyLowerToUpper: x = c > r ? p.C[(long long)c * p.ldc + r] : *d; break;                        // (reads only below the diagonal, writes only above it)
+      case kOpAddToDiag: x = r == c ? *d + p.a : *d; break;
+      case kOpAddVecVecOuter: x = *d + p.a * p.v[r] * p.S[c]; break;                                           // this += alpha x y^T
+      case kOpDivElements: x = *d / p.S[(long long)r * p.lds + c]; break;
+      case kOpAddDiagVecMat: x = p.b * *d + p.a * p.v[r] * p.S[(long long)r * p.lds + c]; break;                 // this = beta this + alpha diag(v) M
+      case kOpAddDiagVecMatT: x = p.b * *d + p.a * p.v[r] * p.S[(long long)c * p.lds + r]; break;
       case kOpAddRowRanges: { const int b0 = p.idx[2 * r], b1 = p.idx[2 * r + 1]; x = *d; for (int k = b0; k < b1; k++) x += p.S[(long long)k * p.lds + c]; break; }      // cu-kernels.cu _add_row_ranges
     }
     *d = x;
@@ -127,6 +133,30 @@ __global__ __launch_bounds__(64) void k3_rowred_kernel(RedParams p) {      // on
   for (int c = lane; c < p.cols; c += 64) { const float m = p.M[(long long)r * p.ldm + c]; acc += p.op == 3 ? (double)m * m : (double)m; }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) p.v[r] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[r]) + p.alpha * (float)acc;
+}
+
+
+// Scalar reductions (TraceMatMat, VecVec, Trace, Sum, Max, Min of cudamatrix/cu-matrix.h, cu-vector.h): per-workgroup partial results in double, folded on the host in
+// workgroup order (deterministic).  op 0: sum A(i,j) B(i,j); 1: sum A(i,j) B(j,i); 2: sum A(i,i); 3: sum A(i,j); 4: max; 5: min.
+struct ScalParams { int op, rows, cols; const float *A; long long lda; const float *B; long long ldb; double *part; };
+__global__ __launch_bounds__(256) void k3_scalar_reduce_kernel(ScalParams p) {
+  __shared__ double sh[256];
+  const long long n = p.op == 2 ? (long long)p.rows : (long long)p.rows * p.cols;
+  double acc = p.op == 4 ? -INFINITY : p.op == 5 ? INFINITY : 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int r = p.op == 2 ? (int)i : (int)(i / p.cols), c = p.op == 2 ? (int)i : (int)(i % p.cols);
+    const float a = p.A[(long long)r * p.lda + c];
+    switch (p.op) {
+      case 0: acc += (double)a * p.B[(long long)r * p.ldb + c]; break;
+      case 1: acc += (double)a * p.B[(long long)c * p.ldb + r]; break;
+      case 2: case 3: acc += a; break;
+      case 4: acc = fmax(acc, (double)a); break;
+      case 5: acc = fmin(acc, (double)a); break;
+    }
+  }
+  sh[threadIdx.x] = acc; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { const double x = sh[threadIdx.x], y = sh[threadIdx.x + o]; sh[threadIdx.x] = p.op == 4 ? fmax(x, y) : p.op == 5 ? fmin(x, y) : x + y; } __syncthreads(); }
+  if (threadIdx.x == 0) p.part[blockIdx.x] = sh[0];
 }
 
 int launch_ew(const EwParams &p, void *stream) {
@@ -176,6 +206,43 @@ extern "C" int k3_mat_add_mat_diag_vec(float alpha, const float *d_M, int64_t ld
 extern "C" int k3_mat_add_row_ranges(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, int32_t src_rows, const int32_t *d_ranges, void *st) {
   K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_ranges && lds >= cols && src_rows >= 0, "k3_mat_add_row_ranges: bad source");
   EwParams p = mk(kOpAddRowRanges, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_ranges; p.src_rows = src_rows; return launch_ew(p, st);
+}
+extern "C" int k3_mat_copy_lower_to_upper(float *C, int64_t ldc, int32_t n, void *st) {                                  // CuMatrixBase::CopyLowerToUpper
+  K3_MAT_REQUIRE(C, ldc, n, n); return launch_ew(mk(kOpCopyLowerToUpper, C, ldc, n, n), st);
+}
+extern "C" int k3_mat_add_to_diag(float *C, int64_t ldc, int32_t rows, int32_t cols, float value, void *st) {                // CuMatrixBase::AddToDiag
+  K3_MAT_REQUIRE(C, ldc, rows, cols); EwParams p = mk(kOpAddToDiag, C, ldc, rows, cols); p.a = value; return launch_ew(p, st);
+}
+extern "C" int k3_mat_add_vec_vec(float alpha, const float *d_x, const float *d_y, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) {      // CuMatrixBase::AddVecVec: this += alpha x y^T
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_x && d_y, "k3_mat_add_vec_vec: null vector");
+  EwParams p = mk(kOpAddVecVecOuter, C, ldc, rows, cols); p.a = alpha; p.v = d_x; p.S = d_y; return launch_ew(p, st);
+}
+extern "C" int k3_mat_div_elements(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_A, int64_t lda, void *st) {                       // CuMatrixBase::DivElements
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_A && lda >= cols, "k3_mat_div_elements: bad source"); EwParams p = mk(kOpDivElements, C, ldc, rows, cols); p.S = d_A; p.lds = lda; return launch_ew(p, st);
+}
+extern "C" int k3_mat_add_diag_vec_mat(float alpha, const float *d_v, const float *d_M, int64_t ldm, int32_t trans_m, float beta, float *C, int64_t ldc, int32_t rows, int32_t cols, void *st) {      // CuMatrixBase::AddDiagVecMat
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_v && d_M && ldm >= (trans_m ? rows : cols), "k3_mat_add_diag_vec_mat: bad source");
+  EwParams p = mk(trans_m ? kOpAddDiagVecMatT : kOpAddDiagVecMat, C, ldc, rows, cols); p.a = alpha; p.b = beta; p.v = d_v; p.S = d_M; p.lds = ldm; return launch_ew(p, st);
+}
+extern "C" int k3_mat_reduce_scalar(int32_t op, const float *d_A, int64_t lda, const float *d_B, int64_t ldb, int32_t rows, int32_t cols, double *h_result, void *st) {
+  K3_REQUIRE(h_result && op >= 0 && op <= 5 && rows >= 0 && cols >= 0, "k3_mat_reduce_scalar: bad argument");
+  *h_result = op == 4 ? -INFINITY : op == 5 ? INFINITY : 0.0;
+  if (rows == 0 || cols == 0) return K3_OK;
+  K3_REQUIRE(d_A && lda >= cols && (op > 1 || (d_B && ldb >= (op == 0 ? cols : rows))) && (op != 2 || rows == cols), "k3_mat_reduce_scalar: bad matrix");
+  constexpr int kMaxWgs = 1024;
+  static thread_local double *d_part = nullptr;      // per host thread: the call synchronises on its stream before returning
+  if (!d_part) K3_HIP_CHECK(hipMalloc((void **)&d_part, kMaxWgs * sizeof(double)));
+  const long long n = op == 2 ? (long long)rows : (long long)rows * cols;
+  const int wgs = (int)std::min<long long>(kMaxWgs, (n + 255) / 256);
+  ScalParams p{op, rows, cols, d_A, lda, d_B, ldb, d_part};
+  hipLaunchKernelGGL(k3_scalar_reduce_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  double h[kMaxWgs];
+  K3_HIP_CHECK(hipMemcpyAsync(h, d_part, wgs * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)st)); K3_HIP_CHECK(hipStreamSynchronize((hipStream_t)st));
+  double r = h[0];
+  for (int i = 1; i < wgs; i++) r = op == 4 ? std::max(r, h[i]) : op == 5 ? std::min(r, h[i]) : r + h[i];
+  *h_result = r;
+  return K3_OK;
 }
 extern "C" int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *st) {
   K3_REQUIRE(d_M && d_v && rows >= 0 && cols >= 0 && ldm >= cols && op >= 0 && op <= 4 && (op != 2 || (d_N && ldn >= cols)), "k3_vec_col_reduce: bad argument");

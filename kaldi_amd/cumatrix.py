@@ -33,3 +33,21 @@ class CuMatrix:
     def AddMat(self, alpha, A, transA=False): _l.check(self._L.k3_mat_add_mat(alpha, A.t.data_ptr(), A.Stride(), int(transA), *self._a(), _st()))
     def CopyRows(self, src, indexes): _l.check(self._L.k3_mat_copy_rows(*self._a(), src.t.data_ptr(), src.Stride(), indexes.data_ptr(), _st()))
     def AddRows(self, alpha, src, indexes): _l.check(self._L.k3_mat_add_rows(alpha, src.t.data_ptr(), src.Stride(), indexes.data_ptr(), *self._a(), _st()))
+    # ---- the parameter update's operations (natural gradient, max-change, orthonormal constraint)
+    def SymAddMat2(self, alpha, A, transA, beta): self.AddMatMat(alpha, A, transA, A, not transA, beta)      # both triangles
+    def CopyLowerToUpper(self): assert self.NumRows() == self.NumCols(); _l.check(self._L.k3_mat_copy_lower_to_upper(self.t.data_ptr(), self.Stride(), self.NumRows(), _st()))
+    def AddToDiag(self, v): _l.check(self._L.k3_mat_add_to_diag(*self._a(), v, _st()))
+    def AddVecVec(self, alpha, x, y): _l.check(self._L.k3_mat_add_vec_vec(alpha, x.data_ptr(), y.data_ptr(), *self._a(), _st()))
+    def DivElements(self, A): _l.check(self._L.k3_mat_div_elements(*self._a(), A.t.data_ptr(), A.Stride(), _st()))
+    def AddDiagVecMat(self, alpha, v, M, transM, beta):
+        _l.check(self._L.k3_mat_add_diag_vec_mat(alpha, v.data_ptr(), M.t.data_ptr(), M.Stride(), int(transM), beta, self.t.data_ptr(), self.Stride(), self.NumRows(), self.NumCols(), _st()))
+    def _reduce(self, op, B=None):
+        r = ctypes.c_double(0.0)
+        _l.check(self._L.k3_mat_reduce_scalar(op, self.t.data_ptr(), self.Stride(), B.t.data_ptr() if B is not None else None, B.Stride() if B is not None else 0, self.NumRows(), self.NumCols(), ctypes.byref(r), _st()))
+        return r.value
+    def Trace(self): return self._reduce(2)
+    def Sum(self): return self._reduce(3)
+    def Max(self): return self._reduce(4)
+    def Min(self): return self._reduce(5)
+
+def TraceMatMat(A, B, trans=False): return A._reduce(0 if trans else 1, B)

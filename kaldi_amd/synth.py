@@ -37,13 +37,15 @@ def _w_affine(f, c):   # NaturalGradientAffineComponent::Write nnet-simple-compo
 def _w_tdnn(f, c):     # TdnnComponent::Write nnet-tdnn-component.cc:382-408
     _tok(f, "<TdnnComponent>"); _tok(f, "<MaxChange>"); _f32(f, 0.75); _tok(f, "<LearningRate>"); _f32(f, 0.001)
     _tok(f, "<TimeOffsets>"); _ivec(f, c["offsets"]); _tok(f, "<LinearParams>"); _mat(f, c["W"]); _tok(f, "<BiasParams>"); _vec(f, c["b"])
-    _tok(f, "<OrthonormalConstraint>"); _f32(f, 0.0); _tok(f, "<UseNaturalGradient>"); _bool(f, True)
+    _tok(f, "<OrthonormalConstraint>"); _f32(f, c.get("orthonormal", 0.0)); _tok(f, "<UseNaturalGradient>"); _bool(f, True)
     _tok(f, "<NumSamplesHistory>"); _f32(f, 2000.0); _tok(f, "<AlphaInOut>"); _f32(f, 4.0); _f32(f, 4.0)
     _tok(f, "<RankInOut>"); _i32(f, 20); _i32(f, 80); _tok(f, "</TdnnComponent>")
 
 def _w_linear(f, c):   # LinearComponent::Write nnet-simple-component.cc:3174-3201
     _tok(f, "<LinearComponent>"); _tok(f, "<MaxChange>"); _f32(f, 0.75); _tok(f, "<LearningRate>"); _f32(f, 0.001)
-    _tok(f, "<Params>"); _mat(f, c["W"]); _tok(f, "<UseNaturalGradient>"); _bool(f, True)
+    _tok(f, "<Params>"); _mat(f, c["W"])
+    if c.get("orthonormal", 0.0) != 0.0: _tok(f, "<OrthonormalConstraint>"); _f32(f, c["orthonormal"])      # (optional on read: nnet-simple-component.cc:3074-3078)
+    _tok(f, "<UseNaturalGradient>"); _bool(f, True)
     _tok(f, "<RankInOut>"); _i32(f, 20); _i32(f, 80); _tok(f, "<Alpha>"); _f32(f, 4.0)
     _tok(f, "<NumSamplesHistory>"); _f32(f, 2000.0); _tok(f, "<UpdatePeriod>"); _i32(f, 4); _tok(f, "</LinearComponent>")
 
@@ -112,7 +114,7 @@ def _bn_apply(x, p, eps=1e-3):
     return (np.asarray(x, np.float64) - p["mean"].astype(np.float64)) * scale
 
 def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0) + (3,) * 12, prefinal_small=192,
-               num_pdfs=6024, bypass_scale=0.75, calib_frames=600, out_std=2.5, calib_feats=None, ivector_dim=0):
+               num_pdfs=6024, bypass_scale=0.75, calib_frames=600, out_std=2.5, calib_feats=None, ivector_dim=0, orthonormal_constraint=0.0):
     """The 17-layer LibriSpeech TDNN-F layout (egs/librispeech/s5/local/chain/tuning/run_tdnn_1d.sh:220-249 minus
     ivector/LDA/xent/dropout) at mini_librispeech widths (run_tdnn_1k.sh:185-202): '17L-768/96-6024', ~6.28 M params.
     Node/component names follow steps/libs/nnet3/xconfig (composite_layers.py:68-227)."""
@@ -143,7 +145,7 @@ def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0
         o1 = (-s, 0) if s else (0,); o2 = (0, s) if s else (0,)
         W1 = randn(bottleneck, len(o1) * dim, 1.0 / np.sqrt(len(o1) * dim))
         W2 = randn(dim, len(o2) * bottleneck, 1.0 / np.sqrt(len(o2) * bottleneck)); b2 = (rng.standard_normal(dim) * 0.1).astype(np.float32)
-        C.append((f"{n}.linear", "tdnn", dict(offsets=o1, W=W1, b=np.zeros(0, np.float32))))
+        C.append((f"{n}.linear", "tdnn", dict(offsets=o1, W=W1, b=np.zeros(0, np.float32), orthonormal=orthonormal_constraint)))      # tdnnf-layer: orthonormal-constraint=-1 in the recipes (training only)
         L.append(f"component-node name={n}.linear component={n}.linear input={prev}")
         C.append((f"{n}.affine", "tdnn", dict(offsets=o2, W=W2, b=b2)))
         L.append(f"component-node name={n}.affine component={n}.affine input={n}.linear")
@@ -156,7 +158,7 @@ def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0
         h = bypass_scale * h[s: h.shape[0] - s] + _bn_apply(y, bn)
         prev = f"{n}.noop"
     # prefinal-l (linear-component), prefinal-chain (prefinal-layer), output (output-layer include-log-softmax=false)
-    Wl = randn(prefinal_small, dim, 1.0 / np.sqrt(dim)); C.append(("prefinal-l", "linear", dict(W=Wl)))
+    Wl = randn(prefinal_small, dim, 1.0 / np.sqrt(dim)); C.append(("prefinal-l", "linear", dict(W=Wl, orthonormal=orthonormal_constraint)))
     L.append(f"component-node name=prefinal-l component=prefinal-l input={prev}")
     h = h @ Wl.T.astype(np.float64)
     Wa = randn(dim, prefinal_small, 1.0 / np.sqrt(prefinal_small)); ba = (rng.standard_normal(dim) * 0.1).astype(np.float32)
@@ -165,7 +167,7 @@ def make_tdnnf(seed=1, input_dim=40, dim=768, bottleneck=96, strides=(1, 1, 1, 0
     C.append(("prefinal-chain.relu", "relu", dict(dim=dim))); L.append("component-node name=prefinal-chain.relu component=prefinal-chain.relu input=prefinal-chain.affine")
     bn = _bn_from(h); C.append(("prefinal-chain.batchnorm1", "batchnorm", bn)); L.append("component-node name=prefinal-chain.batchnorm1 component=prefinal-chain.batchnorm1 input=prefinal-chain.relu")
     h = _bn_apply(h, bn)
-    Wp = randn(prefinal_small, dim, 1.0 / np.sqrt(dim)); C.append(("prefinal-chain.linear", "linear", dict(W=Wp)))
+    Wp = randn(prefinal_small, dim, 1.0 / np.sqrt(dim)); C.append(("prefinal-chain.linear", "linear", dict(W=Wp, orthonormal=orthonormal_constraint)))
     L.append("component-node name=prefinal-chain.linear component=prefinal-chain.linear input=prefinal-chain.batchnorm1")
     h = h @ Wp.T.astype(np.float64)
     bn = _bn_from(h); C.append(("prefinal-chain.batchnorm2", "batchnorm", bn)); L.append("component-node name=prefinal-chain.batchnorm2 component=prefinal-chain.batchnorm2 input=prefinal-chain.linear")

@@ -1,0 +1,115 @@
+// tests/adapter/nnet3_chain_train.cc -- N iterations of chain (LF-MMI) TRAINING on one minibatch, the sequence NnetChainTrainer::Train / TrainInternal runs
+// (nnet3/nnet-chain-training.cc:60-144): NnetComputer over (nnet, delta_nnet) with component statistics stored, forward in training mode, ComputeChainObjfAndDeriv,
+// backward (every updatable component's Update(): natural-gradient preconditioning (nnet3/natural-gradient-online.cc) times its learning rate into delta_nnet),
+// ApplyL2Regularization, UpdateNnetWithMaxChange (per-component and global max-change), ScaleBatchnormStats, ConstrainOrthonormal (the semi-orthogonal
+// constraint of the TDNN-F bottlenecks), momentum.  Everything but the objective is the reference's own unmodified code.
+// Linked twice from this one source.  Oracle (oracle/_ref/bin/ref-nnet3-chain-train): on the reference's CPU matrices, objective by chain::ComputeChainObjfAndDeriv.
+// MI355X (-DK3_ADAPTER, kaldi_amd/adapter/_build/nnet3-chain-train): the same objects over the CuMatrix adapter (every matrix operation of the forward pass, the
+// backprop, the preconditioner and the constraint is a k3_mat_* / k3_vec_* kernel), objective by k3_chain_objf_and_deriv on the adapter's device pointers.
+//   nnet3-chain-train <raw-nnet3-in> <frame-subsampling-factor> <input-matrix-in> <chain-spec-in> <num-iters> <learning-rate> <momentum> <raw-nnet3-out> <objf-vector-out>
+// chain-spec: as tests/adapter/nnet3_chain_grad.cc.  objf-vector: per iteration [objf, l2_term, weight], then the parameters of the trained model.
+#include "base/kaldi-common.h"
+#include "util/common-utils.h"
+#include "nnet3/nnet-nnet.h"
+#include "nnet3/nnet-utils.h"
+#include "nnet3/nnet-optimize.h"
+#include "nnet3/nnet-compute.h"
+#ifdef K3_ADAPTER
+#include "k3hip.h"
+#else
+#include "chain/chain-training.h"
+#include "chain/chain-denominator.h"
+namespace kaldi { namespace chain {
+int32 ComputeFstStateTimes(const fst::StdVectorFst &fst, std::vector<int32> *state_times) {      // restated: chain-supervision.cc:663-700 (that file needs real OpenFst as a whole)
+  const int32 n = fst.NumStates(); int32 total = -1; state_times->assign(n, -1); (*state_times)[0] = 0;
+  for (int32 s = 0; s < n; s++) {
+    const int32 nt = (*state_times)[s] + 1; if (nt <= 0) KALDI_ERR << "Input FST does not have required properties.";
+    for (fst::ArcIterator<fst::StdVectorFst> it(fst, s); !it.Done(); it.Next()) { int32 &r = (*state_times)[it.Value().nextstate]; if (r == -1) r = nt; else if (r != nt) KALDI_ERR << "Input FST does not have required properties."; }
+    if (fst.Final(s) != fst::TropicalWeight::Zero()) { if (total == -1) total = nt - 1; else if (total != nt - 1) KALDI_ERR << "Input FST does not have required properties."; }
+  }
+  return total;
+} } }
+#endif
+namespace {
+struct Reader { FILE *f; template <class T> void get(T *p, size_t n) { if (n && fread(p, sizeof(T), n, f) != n) { std::cerr << "nnet3-chain-train: short read\n"; exit(2); } } };
+struct Csr { std::vector<int64_t> off; std::vector<int32_t> il, nx; std::vector<float> w, fin; void read(Reader &r, int32_t S, int32_t A) { off.resize(S + 1); il.resize(A); nx.resize(A); w.resize(A); fin.resize(S); r.get(off.data(), S + 1); r.get(il.data(), A); r.get(nx.data(), A); r.get(w.data(), A); r.get(fin.data(), S); } };
+#ifndef K3_ADAPTER
+void ToFst(const Csr &c, int32_t start, fst::StdVectorFst *out) {
+  const int32_t S = (int32_t)c.fin.size(); for (int32_t s = 0; s < S; s++) out->AddState(); out->SetStart(start);
+  for (int32_t s = 0; s < S; s++) { if (c.fin[s] != std::numeric_limits<float>::infinity()) out->SetFinal(s, fst::TropicalWeight(c.fin[s])); for (int64_t a = c.off[s]; a < c.off[s + 1]; a++) out->AddArc(s, fst::StdArc(c.il[a], c.il[a], fst::TropicalWeight(c.w[a]), c.nx[a])); }
+}
+#endif
+}
+int main(int argc, char *argv[]) {
+  try {
+    using namespace kaldi; using namespace kaldi::nnet3;
+    ParseOptions po("nnet3-chain-train <raw-nnet3-in> <frame-subsampling-factor> <input-matrix-in> <chain-spec-in> <num-iters> <learning-rate> <momentum> <raw-nnet3-out> <objf-vector-out>");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 9) { po.PrintUsage(); return 1; }
+    Nnet nnet; ReadKaldiObject(po.GetArg(1), &nnet); int32 s; if (!ConvertStringToInteger(po.GetArg(2), &s)) KALDI_ERR << "bad subsampling factor";
+    Reader r{fopen(po.GetArg(4).c_str(), "rb")}; if (!r.f) KALDI_ERR << "cannot open " << po.GetArg(4);
+    int32_t h[11]; float fo[3]; r.get(h, 11); r.get(fo, 3); if (h[0] != 0x4b36) KALDI_ERR << "bad chain spec";
+    const int32 P = h[4], B = h[5], T = h[6];
+    Csr den, merged, sup; den.read(r, h[1], h[3]); merged.read(r, h[7], h[8]); std::vector<int32_t> state_off(B + 1); r.get(state_off.data(), B + 1); sup.read(r, h[9], h[10]); fclose(r.f);
+    int32 num_iters; double lrate, momentum;
+    if (!ConvertStringToInteger(po.GetArg(5), &num_iters) || !ConvertStringToReal(po.GetArg(6), &lrate) || !ConvertStringToReal(po.GetArg(7), &momentum)) KALDI_ERR << "bad iteration count / learning rate / momentum";
+    const BaseFloat max_param_change = 2.0, l2_regularize_factor = 1.0, batchnorm_stats_scale = 0.8;      // NnetTrainerOptions' defaults (nnet3/nnet-training.h:36-80)
+    SetBatchnormTestMode(false, &nnet); SetDropoutTestMode(false, &nnet); SetLearningRate(lrate, &nnet);
+    ZeroComponentStats(&nnet);                                                                            // NnetChainTrainer::NnetChainTrainer, nnet-chain-training.cc:36-41
+    Nnet *delta_nnet = nnet.Copy(); ScaleNnet(0.0, delta_nnet);
+    int32 left, right; ComputeSimpleNnetContext(nnet, &left, &right);
+    ComputationRequest request; request.need_model_derivative = true; request.store_component_stats = true;
+    IoSpecification in; in.name = "input"; in.has_deriv = false; for (int32 t = -left; t <= (T - 1) * s + right; t++) for (int32 n = 0; n < B; n++) in.indexes.push_back(Index(n, t));
+    IoSpecification out; out.name = "output"; out.has_deriv = true; for (int32 f = 0; f < T; f++) for (int32 n = 0; n < B; n++) out.indexes.push_back(Index(n, f * s));
+    request.inputs.push_back(in); request.outputs.push_back(out);
+    Matrix<BaseFloat> input; ReadKaldiObject(po.GetArg(3), &input);
+    if (input.NumRows() != (int32)in.indexes.size() || nnet.OutputDim("output") != P) KALDI_ERR << "input / model do not fit the chain spec";
+    NnetOptimizeOptions optimize_opts; CachingOptimizingCompilerOptions compiler_opts; CachingOptimizingCompiler compiler(nnet, optimize_opts, compiler_opts);
+    std::shared_ptr<const NnetComputation> computation = compiler.Compile(request);
+#ifdef K3_ADAPTER
+    k3_chain_den *kden = NULL; k3_chain_supervision *ksup = NULL;
+    if (k3_chain_den_create((int32_t)den.fin.size(), h[2], P, den.off.data(), den.il.data(), den.nx.data(), den.w.data(), den.fin.data(), &kden) != K3_OK) KALDI_ERR << k3_last_error();
+    if (k3_chain_supervision_create(B, T, P, fo[2], state_off.data(), sup.off.data(), sup.il.data(), sup.nx.data(), sup.w.data(), sup.fin.data(), &ksup) != K3_OK) KALDI_ERR << k3_last_error();
+#else
+    fst::StdVectorFst den_fst; ToFst(den, h[2], &den_fst); chain::DenominatorGraph den_graph(den_fst, P);
+    chain::Supervision supervision; ToFst(merged, 0, &supervision.fst); supervision.weight = fo[2]; supervision.num_sequences = B; supervision.frames_per_sequence = T; supervision.label_dim = P;
+#endif
+    MaxChangeStats max_change_stats(nnet);
+    Vector<BaseFloat> objfs(3 * num_iters + NumParameters(nnet));      // per iteration [objf, l2_term, weight], then every parameter of the trained model (VectorizeNnet)
+    CuMatrix<BaseFloat> cu_in_orig(input);
+    for (int32 iter = 0; iter < num_iters; iter++) {      // TrainInternal
+      // The reference draws from the host's rand() for its sampled decisions (which minibatches store statistics / repair gradients / get the orthonormal constraint) AND inside its CPU
+      // chain code's self-checks (chain-denominator.cc: RandInt(0, 10)), which k3_chain_objf_and_deriv does not have: reseeded at the same two points in both builds, every such decision is the same.
+      srand(2 * iter + 1);
+      NnetComputeOptions compute_opts; NnetComputer computer(compute_opts, *computation, &nnet, delta_nnet);
+      CuMatrix<BaseFloat> cu_in(cu_in_orig); computer.AcceptInput("input", &cu_in); computer.Run();
+      const CuMatrixBase<BaseFloat> &nnet_output = computer.GetOutput("output");
+      CuMatrix<BaseFloat> nnet_output_deriv(nnet_output.NumRows(), nnet_output.NumCols(), kUndefined);
+      BaseFloat objf = 0, l2_term = 0, weight = 0;
+#ifdef K3_ADAPTER
+      k3_chain_training_opts o = {fo[1], 0.0f, fo[0], 0};
+      if (k3_chain_objf_and_deriv(kden, ksup, &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv.Data(), nnet_output_deriv.Stride(), NULL, 0, &objf, &l2_term, &weight, NULL) != K3_OK) KALDI_ERR << k3_last_error();
+#else
+      chain::ChainTrainingOptions opts; opts.leaky_hmm_coefficient = fo[0]; opts.l2_regularize = fo[1]; opts.out_of_range_regularize = 0.0;
+      chain::ComputeChainObjfAndDeriv(opts, den_graph, supervision, nnet_output, &objf, &l2_term, &weight, &nnet_output_deriv, NULL);
+#endif
+      srand(2 * iter + 2);
+      computer.AcceptInput("output", &nnet_output_deriv); computer.Run();
+      ApplyL2Regularization(nnet, B * l2_regularize_factor, delta_nnet);      // GetNumNvalues(eg.inputs, false) = the number of sequences
+      const bool success = UpdateNnetWithMaxChange(*delta_nnet, max_param_change, 1.0, 1.0 - momentum, &nnet, &max_change_stats);
+      ScaleBatchnormStats(batchnorm_stats_scale, &nnet);
+      ConstrainOrthonormal(&nnet);
+      ScaleNnet(success ? momentum : 0.0, delta_nnet);
+      objfs(3 * iter) = objf; objfs(3 * iter + 1) = l2_term; objfs(3 * iter + 2) = weight;
+      KALDI_LOG << "iteration " << iter << ": LF-MMI objf per frame " << objf / weight << " (+ l2 " << l2_term / weight << ") over " << weight << " frames";
+    }
+    max_change_stats.Print(nnet);
+#ifdef K3_ADAPTER
+    k3_chain_supervision_destroy(ksup); k3_chain_den_destroy(kden);
+#endif
+    delete delta_nnet;
+    { SubVector<BaseFloat> pv(objfs, 3 * num_iters, objfs.Dim() - 3 * num_iters); VectorizeNnet(nnet, &pv); }
+    WriteKaldiObject(nnet, po.GetArg(8), true); WriteKaldiObject(objfs, po.GetArg(9), true);
+    return 0;
+  } catch (const std::exception &e) { std::cerr << e.what(); return -1; }
+}

@@ -145,3 +145,53 @@ def test_lf_mmi_gradient_reference_nnet_computer_plus_native_objective(B, T, tmp
     assert abs(rv[0] - gv[0]) <= 2e-4 * abs(rv[0]) + 1e-3 and abs(rv[1] - gv[1]) <= 2e-4 * abs(rv[1]) + 1e-5, (rv[:3], gv[:3])
     rg, gg = rv[3:], gv[3:]
     assert np.linalg.norm(rg) > 0 and np.linalg.norm(rg - gg) <= 2e-3 * np.linalg.norm(rg), (np.linalg.norm(rg - gg), np.linalg.norm(rg))
+
+
+@pytest.mark.parametrize("iters,momentum", [(1, 0.0), (2, 0.5), (3, 0.0)])
+def test_chain_training_iterations_equal_the_reference(iters, momentum, tmp_path):
+    """SURVEY 8f row 4: N iterations of LF-MMI TRAINING, the sequence NnetChainTrainer::TrainInternal runs (nnet3/nnet-chain-training.cc:100-144) -- forward in training mode with component
+    statistics, objective, backward with every component's natural-gradient update (OnlineNaturalGradient), L2, UpdateNnetWithMaxChange, batch-norm statistics decay, the semi-orthogonal
+    constraint of the TDNN-F bottlenecks, momentum (tests/adapter/nnet3_chain_train.cc).  MI355X build: the reference's unmodified nnet3 objects over the CuMatrix adapter + k3_chain_objf_and_deriv;
+    oracle build: the same source on the reference's CPU matrices and chain code.  Per-iteration objective and the trained parameters.
+    One iteration is compared strictly.  Over several iterations natural-gradient SGD amplifies float32 rounding discontinuously (the preconditioner's early eigen-decompositions): the
+    REFERENCE ITSELF ends 10-35 % of the training's own parameter change apart between MKL's AVX2 and AVX-512 code paths after two / three iterations on this case (measured),
+    so for N > 1 the MI355X result has to coincide with the reference under at least one of MKL's code paths (default, AVX2, AVX512, SSE4_2), to 1 % of the change."""
+    import struct
+    from kaldi_amd import synth
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-chain-train"); ref = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-nnet3-chain-train")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/nnet3-chain-train is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    if not os.path.exists(ref): pytest.skip("oracle/_ref not built")
+    td = str(tmp_path); B, T, P, s = 8, 12, 50, 3
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=P, calib_feats=calib, out_std=1.5, orthonormal_constraint=-1.0); net.write(f"{td}/m.raw")
+    lc = rc = 8; Tin = (T - 1) * s + 1 + lc + rc; rng = np.random.default_rng(B * 100 + T)
+    _kaldi_matrix(f"{td}/in.mat", rng.standard_normal((Tin * B, 40)) * 1.2 + 16.5)
+    den = synth.make_den_fst(120, P, seed=5, mean_degree=6.0, hub_degree=60); fsts = [synth.make_supervision_fst(T, P, seed=200 + i) for i in range(B)]; merged = synth.merge_supervision_fsts(fsts)
+    fb = lambda f: (np.ascontiguousarray(f.arc_offsets, np.int64).tobytes() + np.ascontiguousarray(f.ilabel, np.int32).tobytes() + np.ascontiguousarray(f.nextstate, np.int32).tobytes() +
+                    np.ascontiguousarray(f.weight, np.float32).tobytes() + np.ascontiguousarray(f.final, np.float32).tobytes())
+    so = np.concatenate([[0], np.cumsum([f.num_states for f in fsts])]).astype(np.int32); ab = np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in fsts])])
+    with open(f"{td}/chain.spec", "wb") as fh:
+        fh.write(struct.pack("<11i3f", 0x4b36, den.num_states, den.start, int(den.arc_offsets[-1]), P, B, T, merged.num_states, int(merged.arc_offsets[-1]), int(so[-1]), int(ab[-1]), 1.0e-05, 5.0e-05, 1.0))
+        fh.write(fb(den)); fh.write(fb(merged)); fh.write(so.tobytes())
+        fh.write(np.concatenate([[0]] + [np.asarray(f.arc_offsets[1:], np.int64) + b for f, b in zip(fsts, ab[:-1])]).astype(np.int64).tobytes())
+        for k, dt in (("ilabel", np.int32), ("nextstate", np.int32), ("weight", np.float32), ("final", np.float32)): fh.write(np.concatenate([getattr(f, k) for f in fsts]).astype(dt).tobytes())
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"); args = [f"{td}/m.raw", str(s), f"{td}/in.mat", f"{td}/chain.spec", str(iters), "0.002", str(momentum)]
+    g = subprocess.run([exe] + args + [f"{td}/g.raw", f"{td}/g.vec"], capture_output=True, text=True, env=env); assert g.returncode == 0, g.stderr[-3000:]
+    gv = _read_kaldi(f"{td}/g.vec"); go = gv[:3 * iters].reshape(iters, 3); gp = gv[3 * iters:]
+    p0 = np.concatenate([np.concatenate([c[2]["W"].ravel()] + ([c[2]["b"].ravel()] if "b" in c[2] and c[2]["b"].size else [])) for c in net.components if c[1] in ("affine", "tdnn", "linear")])
+    assert p0.shape == gp.shape
+    tried = []
+    for path in ([None] if iters == 1 else [None, "AVX512", "AVX2", "SSE4_2"]):
+        e = dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"))
+        if path: e["MKL_ENABLE_INSTRUCTIONS"] = path
+        r = subprocess.run([ref] + args + [f"{td}/r.raw", f"{td}/r.vec"], capture_output=True, text=True, env=e); assert r.returncode == 0, r.stderr[-2000:]
+        rv = _read_kaldi(f"{td}/r.vec"); assert rv.shape == gv.shape
+        ro = rv[:3 * iters].reshape(iters, 3); rp = rv[3 * iters:]
+        assert np.array_equal(ro[:, 2], go[:, 2]) and abs(ro[0, 0] - go[0, 0]) <= 2e-4 * abs(ro[0, 0]) + 1e-3      # the first objective does not depend on any update
+        assert np.linalg.norm(rp - p0) > 0.1 and (iters == 1 or abs(ro[-1, 0] - ro[0, 0]) > 10.0)                  # the training moved the model
+        rel = float(np.linalg.norm(rp - gp) / np.linalg.norm(rp - p0)); dobj = float(np.abs(ro[:, 0] - go[:, 0]).max() / np.abs(ro[:, 0]).max())
+        tried.append((path or "default", rel, dobj))
+        if rel <= (2e-3 if iters == 1 else 1e-2) and dobj <= (5e-4 if iters == 1 else 5e-3):
+            assert g.stderr.count("ConstrainOrthonormalInternal") == r.stderr.count("ConstrainOrthonormalInternal")
+            return
+    pytest.fail(f"MI355X training result matches none of the reference's runs: (MKL path, |params - ref| / |ref - initial|, max relative objective difference) = {tried}")

@@ -46,3 +46,41 @@ def test_add_mat_mat_matches_numpy(ta, tb):
         assert np.allclose(C.t.cpu().numpy(), want, rtol=2e-5, atol=2e-4), (M_, N_, K_)
         C.AddMatMat(1.0, A, ta, B, tb, 0.0); torch.cuda.synchronize()             # beta = 0 must not read C (it may hold NaN, cu-matrix.cc:1340)
         assert np.allclose(C.t.cpu().numpy(), a.astype(np.float64) @ b.astype(np.float64), rtol=2e-5, atol=2e-4)
+
+
+def test_update_step_operations_match_numpy():
+    """The operations the reference's parameter update adds to the forward / backward set (OnlineNaturalGradient::PreconditionDirections, UpdateNnetWithMaxChange,
+    ConstrainOrthonormalInternal): SymAddMat2, CopyLowerToUpper, AddToDiag, Trace, TraceMatMat (both transposes), Sum / Max / Min, AddVecVec, DivElements, AddDiagVecMat, and the
+    vector forms the adapter builds from matrix calls with leading dimension 1 (AddMatVec = AddMatMat with one column, CopyColFromMat)."""
+    import ctypes
+    from kaldi_amd import lib as _l
+    from kaldi_amd.cumatrix import CuMatrix, TraceMatMat
+    rng = np.random.default_rng(7); dev = torch.device("cuda:0")
+    def T(a): return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    for (m, n) in [(24, 96), (5, 7), (96, 24), (130, 257)]:
+        A = rng.standard_normal((m, n)).astype(np.float32); P0 = rng.standard_normal((m, m)).astype(np.float32)
+        P = CuMatrix(T(P0)); P.SymAddMat2(0.5, CuMatrix(T(A)), False, 0.25); want = 0.25 * P0 + 0.5 * (A.astype(np.float64) @ A.T.astype(np.float64))
+        assert np.abs(P.t.cpu().numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+        Q = CuMatrix(T(A.T.copy())); P2 = CuMatrix(T(np.zeros((m, m)))); P2.SymAddMat2(1.0, Q, True, 0.0)      # A^T given, transposed: the same product
+        assert np.abs(P2.t.cpu().numpy() - A.astype(np.float64) @ A.T.astype(np.float64)).max() <= 2e-5 * np.abs(want).max()
+        L = CuMatrix(T(P0)); L.CopyLowerToUpper(); w = np.tril(P0) + np.tril(P0, -1).T; assert np.array_equal(L.t.cpu().numpy(), w)
+        D = CuMatrix(T(A)); D.AddToDiag(1.5); w = A.copy(); w[np.arange(min(m, n)), np.arange(min(m, n))] += 1.5; assert np.array_equal(D.t.cpu().numpy(), w)
+        assert abs(CuMatrix(T(P0)).Trace() - np.trace(P0.astype(np.float64))) <= 1e-5 * m
+        B = rng.standard_normal((m, n)).astype(np.float32)
+        assert abs(TraceMatMat(CuMatrix(T(A)), CuMatrix(T(B)), True) - (A.astype(np.float64) * B).sum()) <= 1e-6 * m * n
+        assert abs(TraceMatMat(CuMatrix(T(A)), CuMatrix(T(B.T.copy())), False) - (A.astype(np.float64) * B).sum()) <= 1e-6 * m * n
+        a = CuMatrix(T(A)); assert abs(a.Sum() - A.astype(np.float64).sum()) <= 1e-6 * m * n and a.Max() == A.max() and a.Min() == A.min()
+        x = rng.standard_normal(m).astype(np.float32); y = rng.standard_normal(n).astype(np.float32)
+        V = CuMatrix(T(A)); V.AddVecVec(0.3, T(x), T(y)); assert np.abs(V.t.cpu().numpy() - (A + np.float32(0.3) * np.outer(x, y))).max() <= 1e-5
+        E = CuMatrix(T(A)); Bp = np.abs(B) + 0.5; E.DivElements(CuMatrix(T(Bp))); assert np.abs(E.t.cpu().numpy() - A / Bp).max() <= 1e-5
+        G = CuMatrix(T(A)); G.AddDiagVecMat(0.7, T(x), CuMatrix(T(B)), False, 0.2); assert np.abs(G.t.cpu().numpy() - (0.2 * A + 0.7 * x[:, None] * B)).max() <= 1e-5
+        G = CuMatrix(T(A)); G.AddDiagVecMat(0.7, T(x), CuMatrix(T(B.T.copy())), True, 0.2); assert np.abs(G.t.cpu().numpy() - (0.2 * A + 0.7 * x[:, None] * B)).max() <= 1e-5
+        # CuVectorBase::AddMatVec as the adapter issues it: out [m x 1] (ld 1) = beta out + alpha M v, v as a [n x 1] matrix of ld 1; and with M transposed
+        Lh = _l.load(); st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        out0 = rng.standard_normal(m).astype(np.float32); o = T(out0); Md = T(A); vd = T(y)
+        _l.check(Lh.k3_mat_add_mat_mat(0.5, Md.data_ptr(), n, 0, vd.data_ptr(), 1, 0, 0.25, o.data_ptr(), 1, m, 1, n, st))
+        assert np.abs(o.cpu().numpy() - (0.25 * out0 + 0.5 * (A.astype(np.float64) @ y))).max() <= 2e-5 * max(1.0, np.abs(A @ y).max())
+        out1 = rng.standard_normal(n).astype(np.float32); o = T(out1); xd = T(x)
+        _l.check(Lh.k3_mat_add_mat_mat(0.5, Md.data_ptr(), n, 1, xd.data_ptr(), 1, 0, 0.25, o.data_ptr(), 1, n, 1, m, st))
+        assert np.abs(o.cpu().numpy() - (0.25 * out1 + 0.5 * (A.T.astype(np.float64) @ x))).max() <= 2e-5 * max(1.0, np.abs(A.T @ x).max())
+        col = T(np.zeros(m)); _l.check(Lh.k3_mat_copy_from_mat(col.data_ptr(), 1, m, 1, Md.data_ptr() + 4 * (n // 2), n, 0, st)); assert np.array_equal(col.cpu().numpy(), A[:, n // 2])      # CopyColFromMat
