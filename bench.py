@@ -70,6 +70,7 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, utts_per_core=6, max_
                       "(decoder/lattice-faster-decoder.cc compiled unmodified; FST containers from oracle/ref_tools/minifst because OpenFst is not vendored)"}
 
 def main():
+    if os.environ.get("K3HIP_LIB"): raise SystemExit("bench.py measures the shipped kaldi_amd/lib/libk3hip.so only: unset K3HIP_LIB (developer override for profiling builds)")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=512); ap.add_argument("--utt-seconds", type=float, default=10.0)

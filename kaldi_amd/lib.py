@@ -2,7 +2,10 @@
 import ctypes, os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("K3HIP_LIB", os.path.join(HERE, "lib", "libk3hip.so"))   # K3HIP_LIB: developer override (kernel variants)
+LIB_PATH = os.path.join(HERE, "lib", "libk3hip.so")
+if os.environ.get("K3HIP_LIB"):      # developer override (profiling builds of the same sources, tools/prof_*.py): never silent, and bench.py refuses to run with it
+    import sys
+    LIB_PATH = os.environ["K3HIP_LIB"]; print(f"kaldi_amd: DEVELOPER OVERRIDE K3HIP_LIB -> {LIB_PATH}", file=sys.stderr)
 
 class K3Error(RuntimeError):
     """Raised for any non-zero k3_status (the C++ adapters raise KaldiFatalError instead)."""
