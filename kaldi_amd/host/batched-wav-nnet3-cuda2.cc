@@ -39,7 +39,11 @@ int main(int argc, char **argv) {
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
     po.Register("file-limit", &num_todo, "Limits the number of files that are processed by this driver.");
     po.Register("iterations", &iterations, "Number of times to decode the corpus. Output will be written only once.");
-    po.Register("segmentation", &segmentation, "Split audio files into segments (not supported)");
+    po.Register("segmentation", &segmentation, "Split audio files into segments");
+    // CudaPipelineSegmentationConfig (cudadecoder/cuda-pipeline-common.h:39-60)
+    double segment_length_s = 20, segment_overlap_s = 1, min_segment_length_s = 1;
+    po.Register("segment-length", &segment_length_s, "Segment length (s)"); po.Register("segment-overlap", &segment_overlap_s, "Overlap between segments (s)");
+    po.Register("min-segment-length", &min_segment_length_s, "Min segment length (s, >=1)");
     po.Register("lattice-postprocessor-rxfilename", &postproc, "(optional) Config file for lattice postprocessor (not supported)");
     po.Register("max-batch-size", &max_batch, "The maximum execution batch size (utterances decoded together)");
     po.Register("num-channels", &num_channels, "(accepted; whole-utterance batching needs no separate channel pool)");
@@ -78,8 +82,8 @@ int main(int argc, char **argv) {
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
-    if (segmentation || use_online || add_pitch || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
-      K3H_ERR << "an option that needs a component outside the accelerated path was given (segmentation / online features / pitch / PLP / CMVN / extra context)";
+    if (use_online || add_pitch || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
+      K3H_ERR << "an option that needs a component outside the accelerated path was given (online features / pitch / PLP / CMVN / extra context)";
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3); std::string out_wspec = po.GetArg(4);
     if (world_size < 1 || rank < 0 || rank >= world_size) K3H_ERR << "--rank=" << rank << " is not in [0, --world-size=" << world_size << ")";
     { int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev)); if (ndev < 1) K3H_ERR << "no HIP device";
@@ -147,6 +151,33 @@ int main(int argc, char **argv) {
     auto scp = ReadScp(wav_rspec);
     if (num_todo >= 0 && (size_t)num_todo < scp.size()) scp.resize(num_todo);
     if (world_size > 1) { decltype(scp) mine; for (size_t i = 0; i < scp.size(); i++) if ((int32_t)(i % (size_t)world_size) == rank) mine.push_back(scp[i]); scp.swap(mine); }      // static round-robin shard
+    // --segmentation (BatchedThreadedNnet3CudaPipeline2::SegmentedDecodeWithCallback, batched-threaded-nnet3-cuda-pipeline2.cc:265-337): every file is cut into segments of
+    // --segment-length seconds that overlap by --segment-overlap, a last piece shorter than --min-segment-length is dropped, every segment is decoded as an utterance of its own
+    // and written under the key [utt]-[offset in whole seconds] (WriteLattices with print_offsets, cuda-pipeline-common.cc:38-62).  One pass over the files for their lengths.
+    struct Segment { int64_t off = 0, len = -1; };
+    std::vector<Segment> segs(scp.size());
+    if (segmentation) {
+      if (min_segment_length_s < 0.5) K3H_ERR << "Min segment length must be at least 0.5 second";
+      if (segment_overlap_s > segment_length_s) K3H_ERR << "The segments overlap cannot be larger than segment length";
+      if (segment_length_s < min_segment_length_s) K3H_ERR << "Segment length cannot be smaller than min segment length";
+      if (segment_overlap_s >= segment_length_s) K3H_ERR << "The segments overlap must be smaller than the segment length";
+      const int seg_len = (int)(segment_length_s * fopts.samp_freq), seg_shift = (int)((segment_length_s - segment_overlap_s) * fopts.samp_freq), seg_min = (int)(min_segment_length_s * fopts.samp_freq);
+      decltype(scp) cut; std::vector<Segment> cut_segs;
+      for (size_t i = 0; i < scp.size(); i++) {
+        int64_t total = -1;
+        try { const Wave w = ReadWave(scp[i].second); if (w.samp_freq == fopts.samp_freq) total = (int64_t)w.samples.size(); } catch (const std::exception &) {}
+        if (total < 0) { cut.push_back(scp[i]); cut_segs.push_back(Segment()); continue; }      // unreadable / wrong rate: the batch loader reports it, once
+        for (int64_t offset = 0; total > 0; offset += seg_shift) {
+          const int64_t n = std::min<int64_t>(total - offset, seg_len);
+          if (n >= seg_min) {
+            std::ostringstream key; key << scp[i].first << "-" << (double)std::floor((float)offset / fopts.samp_freq);
+            cut.push_back({key.str(), scp[i].second}); Segment sg; sg.off = offset; sg.len = n; cut_segs.push_back(sg);
+          }
+          if (offset + n >= total) break;
+        }
+      }
+      scp.swap(cut); segs.swap(cut_segs);
+    }
     std::unique_ptr<TableWriter> writer; if (write_lattice) writer.reset(new TableWriter(out_wspec));
     // determinization runs on worker threads while the GPU works on the next batch; records come out in submission order
     std::unique_ptr<DeterminizeSequencer> det_pool;
@@ -172,7 +203,12 @@ int main(int argc, char **argv) {
         for (int t = 0; t < n_read_threads; t++) th.emplace_back([&, t] { for (size_t i = t; i < waves.size(); i += n_read_threads) fn(i); });
         for (auto &x : th) x.join();
       };
-      parallel([&](size_t i) { try { waves[i] = ReadWave(scp[b0 + i].second); } catch (const std::exception &) { bad[i] = 1; } });
+      parallel([&](size_t i) {
+        try {
+          waves[i] = ReadWave(scp[b0 + i].second); const Segment &sg = segs[b0 + i];
+          if (sg.len >= 0) { std::vector<float> piece(waves[i].samples.begin() + sg.off, waves[i].samples.begin() + sg.off + sg.len); waves[i].samples.swap(piece); }
+        } catch (const std::exception &) { bad[i] = 1; }
+      });
       std::vector<size_t> src;
       for (size_t i = 0; i < waves.size(); i++) {
         const Wave &w = waves[i];

@@ -5,6 +5,8 @@
 // Its output must equal batched-wav-nnet3-cuda2's for the same options (tests/test_cli_gpu.py).
 #include <cstring>
 #include <iostream>
+#include <mutex>
+#include <sstream>
 #include "k3_host.h"
 #include "../../include/k3hip.h"
 #include "k3_feat_options.h"
@@ -20,6 +22,7 @@ int main(int argc, char **argv) {
     po.Register("acoustic-scale", &cfg.acoustic_scale, "acoustic scale"); po.Register("frame-subsampling-factor", &cfg.frame_subsampling_factor, "output frame subsampling");
     po.Register("determinize-lattice", &cfg.determinize_lattice, "determinize before output"); po.Register("literal-order", &literal_order, "lattices identical to the CPU decoder's");
     po.Register("feature-type", &feature_type, "mfcc | fbank"); po.Register("mfcc-config", &mfcc_config, "MFCC config"); po.Register("fbank-config", &fbank_config, "fbank config");
+    bool segmentation = false; po.Register("segmentation", &segmentation, "Split audio files into segments (SegmentedDecodeWithCallback; keys [utt]-[offset])"); cfg.seg_opts.Register(&po);
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     const bool mfcc = feature_type == "mfcc"; FeatOptions fo(mfcc);
@@ -30,6 +33,27 @@ int main(int argc, char **argv) {
     TransitionInfo ti = ReadTransitionModel(po.GetArg(1)); k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(po.GetArg(1).c_str(), &nnet));
     HostFst hfst = ReadFstKaldiGeneric(po.GetArg(2));
     auto scp = ReadScp(po.GetArg(3)); TableWriter writer(po.GetArg(4));
+    if (segmentation) {      // the way cudadecoderbin/batched-wav-nnet3-cuda2.cc:196-232 drives it: one segmented callback per file, WriteLattices with print_offsets
+      std::mutex wm; int n_seg = 0;
+      {
+        cuda_decoder::BatchedThreadedNnet3CudaPipeline2 pipeline(cfg, hfst, nnet, ti);
+        for (size_t i = 0; i < scp.size(); i++) {
+          auto wave = std::make_shared<Wave>(ReadWave(scp[i].second)); const std::string key = scp[i].first;
+          pipeline.SegmentedDecodeWithCallback(wave, [&writer, &wm, &n_seg, key](cuda_decoder::SegmentedLatticeCallbackParams &params) {
+            std::lock_guard<std::mutex> lk(wm);
+            for (cuda_decoder::CudaPipelineResult &r : params.results) {
+              std::ostringstream k; k << key << "-" << (double)r.GetTimeOffsetSeconds();
+              if (!r.HasValidResult() || r.GetLatticeResult()->NumStates() == 0) { K3H_WARN << "Utterance " << key << ": segment with offset " << r.GetTimeOffsetSeconds() << " is not valid. Skipping"; continue; }
+              writer.WriteCompactLattice(k.str(), *r.GetLatticeResult()); n_seg++;
+            }
+          });
+        }
+        pipeline.WaitForAllTasks();
+      }
+      writer.Flush(); k3_nnet_destroy(nnet);
+      K3H_LOG << "Decoded " << scp.size() << " files in " << n_seg << " segments.";
+      return 0;
+    }
     std::vector<CompactLattice> results(scp.size()); std::vector<char> got(scp.size(), 0);
     {
       cuda_decoder::BatchedThreadedNnet3CudaPipeline2 pipeline(cfg, hfst, nnet, ti);

@@ -6,7 +6,9 @@
 // linked here; INTEGRATION.md shows the one-to-one mapping.  Behind it: a control thread that takes whatever is queued (up to max_batch_size
 // utterances, like AcquireTasks :349-380), runs waveforms -> k3_feat_compute_batch -> k3_nnet_forward -> k3_decoder_decode_batch -> raw
 // lattices, and a pool of worker threads that does Connect + (phone-)pruned determinization per utterance and calls the callback
-// (batched-threaded-nnet3-cuda-online-pipeline.cc:735-810).  SegmentedDecodeWithCallback / the lattice postprocessor (CTM output) are not provided.
+// (batched-threaded-nnet3-cuda-online-pipeline.cc:735-810).  SegmentedDecodeWithCallback (:265-337) cuts a waveform into overlapping segments, decodes each as
+// an utterance and hands all results to one callback (CudaPipelineResult, lattice results).  The lattice postprocessor (CTM results) is not provided:
+// asking for RESULT_TYPE_CTM is an error.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -20,6 +22,44 @@
 namespace k3host {
 namespace cuda_decoder {
 
+// cudadecoder/cuda-pipeline-common.h:36-60
+inline int NumberOfSegments(int nsamples, int seg_length, int seg_shift) {
+  if (seg_shift <= 0 || seg_length < seg_shift) K3H_ERR << "NumberOfSegments: bad segment length / shift";
+  if (nsamples <= seg_length) return 1;
+  return ((nsamples - (seg_length - seg_shift)) + seg_shift - 1) / seg_shift;
+}
+struct CudaPipelineSegmentationConfig {
+  double segment_length_s = 20, segment_overlap_s = 1, min_segment_length_s = 1;
+  void Register(ParseOptions *po) {
+    po->Register("segment-length", &segment_length_s, "Segment length (s)"); po->Register("segment-overlap", &segment_overlap_s, "Overlap between segments (s)");
+    po->Register("min-segment-length", &min_segment_length_s, "Min segment length (s, >=1)");
+  }
+  void Check() const {
+    if (min_segment_length_s < 0.5) K3H_ERR << "Min segment length must be at least 0.5 second";
+    if (segment_overlap_s > segment_length_s) K3H_ERR << "The segments overlap cannot be larger than segment length";
+    if (segment_length_s < min_segment_length_s) K3H_ERR << "Segment length cannot be smaller than min segment length";
+    if (segment_overlap_s >= segment_length_s) K3H_ERR << "The segments overlap must be smaller than the segment length";
+  }
+};
+// cudadecoder/cuda-pipeline-common.h:69-140 (the CTM half needs the lattice postprocessor, which is outside this scope)
+class CudaPipelineResult {
+  int result_type_ = 0; CompactLattice clat_; float offset_seconds_ = 0; int32_t segment_id_ = 0; bool is_last_segment_ = false;
+ public:
+  static constexpr int RESULT_TYPE_LATTICE = 1, RESULT_TYPE_CTM = 2;
+  int32_t GetResultType() const { return result_type_; }
+  bool HasValidResult() const { return result_type_ != 0; }
+  int32_t GetSegmentID() const { return segment_id_; }
+  bool IsLastSegment() const { return is_last_segment_; }
+  float GetTimeOffsetSeconds() const { return offset_seconds_; }
+  void SetLatticeResult(CompactLattice &&clat) { result_type_ |= RESULT_TYPE_LATTICE; clat_ = std::move(clat); }
+  CompactLattice *GetLatticeResult() { if (!(result_type_ & RESULT_TYPE_LATTICE)) K3H_ERR << "Lattice result was not requested"; return &clat_; }
+  void SetTimeOffsetSeconds(float offset_seconds) { if (offset_seconds < 0) K3H_ERR << "negative segment offset"; offset_seconds_ = offset_seconds; }
+  void SetSegmentID(int segment_id) { segment_id_ = segment_id; }
+  void SetAsLastSegment() { is_last_segment_ = true; }
+};
+struct SegmentedLatticeCallbackParams { std::vector<CudaPipelineResult> results; };
+typedef std::function<void(SegmentedLatticeCallbackParams &)> SegmentedResultsCallback;
+
 struct BatchedThreadedNnet3CudaPipeline2Config {      // the options of BatchedThreadedNnet3CudaOnlinePipelineConfig / CudaDecoderConfig this pipeline reads
   int32_t max_batch_size = 400, num_worker_threads = -1;      // --max-batch-size, --cuda-worker-threads (-1: hardware concurrency)
   bool determinize_lattice = true;                            // --determinize-lattice
@@ -27,6 +67,7 @@ struct BatchedThreadedNnet3CudaPipeline2Config {      // the options of BatchedT
   k3_feat_opts feature_opts;                                  // from --feature-type + its config (FeatOptions::Finish())
   k3_decoder_config decoder_opts;                             // beam, lattice-beam, max-active, capacities, literal_order
   float acoustic_scale = 0.1f; int32_t frame_subsampling_factor = 1;
+  CudaPipelineSegmentationConfig seg_opts;                    // --segment-length, --segment-overlap, --min-segment-length
   BatchedThreadedNnet3CudaPipeline2Config() { memset(&feature_opts, 0, sizeof feature_opts); k3_decoder_config_default(&decoder_opts); }
 };
 
@@ -67,6 +108,32 @@ class BatchedThreadedNnet3CudaPipeline2 {
   }
   void DecodeWithCallback(const std::shared_ptr<Wave> &wave_data, const LatticeCallback &callback, const std::string &group = std::string()) {
     DecodeWithCallback(wave_data->samples, wave_data->samp_freq, callback, group);
+  }
+  // Extracts segments from wave_data and decodes them; `segmented_callback` gets the results of all segments at once, in segment order, from the worker thread that
+  // finishes the last of them (:160-168, 265-337).  A waveform shorter than one segment is one segment; a last piece below min-segment-length is dropped.
+  void SegmentedDecodeWithCallback(const std::shared_ptr<Wave> &wave_data, const SegmentedResultsCallback &segmented_callback, const int result_type = CudaPipelineResult::RESULT_TYPE_LATTICE) {
+    if (!result_type) K3H_ERR << "You must define at least one result type";
+    if (result_type & CudaPipelineResult::RESULT_TYPE_CTM) K3H_ERR << "CTM results need the lattice postprocessor, which this pipeline does not provide";
+    if (wave_data->samp_freq != GetModelFrequency()) K3H_ERR << "SegmentedDecodeWithCallback: sample rate " << wave_data->samp_freq << " != model frequency " << GetModelFrequency();
+    config_.seg_opts.Check();
+    const float freq = GetModelFrequency();
+    const int seg_len = (int)(config_.seg_opts.segment_length_s * freq), seg_shift = (int)((config_.seg_opts.segment_length_s - config_.seg_opts.segment_overlap_s) * freq),
+              seg_min = (int)(config_.seg_opts.min_segment_length_s * freq), total = (int)wave_data->samples.size();
+    if (total == 0) { if (segmented_callback) { SegmentedLatticeCallbackParams params; params.results.resize(1); params.results[0].SetLatticeResult(CompactLattice()); params.results[0].SetAsLastSegment(); segmented_callback(params); } return; }
+    std::vector<std::pair<int, int>> pieces;      // (offset, samples)
+    for (int offset = 0;; offset += seg_shift) { const int n = std::min(total - offset, seg_len); if (n >= seg_min) pieces.push_back({offset, n}); if (offset + n >= total) break; }
+    if (pieces.empty()) { if (segmented_callback) { SegmentedLatticeCallbackParams params; segmented_callback(params); } return; }
+    auto results = std::make_shared<std::vector<CudaPipelineResult>>(pieces.size());
+    auto not_done = std::make_shared<std::atomic<int32_t>>((int32_t)pieces.size());
+    for (size_t i = 0; i < pieces.size(); i++) {
+      CudaPipelineResult &r = (*results)[i]; r.SetTimeOffsetSeconds(std::floor((float)pieces[i].first / freq)); r.SetSegmentID((int)i); if (i + 1 == pieces.size()) r.SetAsLastSegment();
+      LatticeCallback callback = [results, not_done, segmented_callback, i](CompactLattice &clat) {
+        (*results)[i].SetLatticeResult(std::move(clat));
+        if (not_done->fetch_sub(1) == 1 && segmented_callback) { SegmentedLatticeCallbackParams params; params.results = std::move(*results); segmented_callback(params); }
+      };
+      std::vector<float> piece(wave_data->samples.begin() + pieces[i].first, wave_data->samples.begin() + pieces[i].first + pieces[i].second);
+      DecodeWithCallback(piece, freq, callback);
+    }
   }
   void CreateTaskGroup(const std::string &group) {
     std::lock_guard<std::mutex> l(m_);

@@ -457,3 +457,51 @@ def test_online_pipeline_class_with_correlation_ids_and_callbacks_equals_the_pro
         if "--print-partial-hypotheses=true" in extra:
             assert " partial: " in b.stderr and " final: " in b.stderr
             n_partial = int(b.stderr.split("Non-empty partial hypotheses: ")[1].split(",")[0]); assert n_partial > 0
+
+
+def test_segmentation_program_and_class_equal_decoding_the_pieces(tmp_path):
+    """--segmentation (BatchedThreadedNnet3CudaPipeline2::SegmentedDecodeWithCallback, batched-threaded-nnet3-cuda-pipeline2.cc:265-337 + WriteLattices, cuda-pipeline-common.cc:38-62):
+    files cut into --segment-length pieces that overlap by --segment-overlap, a last piece below --min-segment-length dropped, keys [utt]-[offset in whole seconds].  The program and the class
+    (k3-pipeline-example --segmentation) must write, under those keys, exactly the lattices of the pieces decoded as files of their own."""
+    from oracle import kaldi_io as kio
+    td = str(tmp_path); N = 120; sr = 16000
+    # 7.6 s -> pieces at 0, 2.5, 5.0 (3 s long; the last 2.6 s); 3.0 s -> one piece; 5.6 s -> 0, 2.5 and a 0.6 s tail that is dropped (min 1 s); 0.4 s: one (short) piece, like the reference (< one segment = 1 segment, min applies)
+    lens = [int(7.6 * sr), int(3.0 * sr), int(5.6 * sr), int(1.2 * sr)]
+    pcm = [synth.gaussian_pcm16(n, 70 + i) for i, n in enumerate(lens)]
+    for i, p in enumerate(pcm): kio.write_wav(f"{td}/f{i}.wav", p)
+    open(f"{td}/wav.scp", "w").write("".join(f"file{i} {td}/f{i}.wav\n" for i in range(len(lens))))
+    seg_len, shift, seg_min = int(3.0 * sr), int(2.5 * sr), int(1.0 * sr); want = []
+    for i, p in enumerate(pcm):
+        off = 0
+        while True:
+            n = min(len(p) - off, seg_len)
+            if n >= seg_min:
+                key = f"file{i}-{int(np.floor(np.float32(off) / np.float32(sr)))}"; kio.write_wav(f"{td}/{key}.wav", p[off:off + n]); want.append(key)
+            if off + n >= len(p): break
+            off += shift
+    assert want == ["file0-0", "file0-2", "file0-5", "file1-0", "file2-0", "file2-2", "file3-0"], want
+    open(f"{td}/pieces.scp", "w").write("".join(f"{k} {td}/{k}.wav\n" for k in want))
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    synth.make_hclg(3000, 8000, N, seed=11, start_degree=50).write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000"]
+    seg = ["--segmentation=true", "--segment-length=3.0", "--segment-overlap=0.5", "--min-segment-length=1.0"]
+    ref = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=4", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/pieces.scp", f"ark,t:{td}/pieces.txt"], capture_output=True, text=True)
+    assert ref.returncode == 0, ref.stderr
+    a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + seg + ["--max-batch-size=3", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/prog.txt"], capture_output=True, text=True)
+    assert a.returncode == 0, a.stderr
+    assert open(f"{td}/prog.txt").read() == open(f"{td}/pieces.txt").read() and open(f"{td}/prog.txt").read().count("file") == len(want)
+    b = subprocess.run([os.path.join(BIN, "k3-pipeline-example")] + common + seg + ["--max-batch-size=3", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/cls.txt"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    assert f"Decoded 4 files in {len(want)} segments." in b.stderr, b.stderr
+    def records(path):      # the class hands results over per file in completion order: compare as a key -> record map
+        recs, cur = {}, []
+        for line in open(path).read().split("\n"):
+            if line.startswith("file"): key = line.split()[0]; cur = recs.setdefault(key, [line])
+            elif line.strip(): cur.append(line)
+        return recs
+    ra, rb = records(f"{td}/prog.txt"), records(f"{td}/cls.txt")
+    assert sorted(ra) == sorted(want) and ra == rb
+    e = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--segmentation=true", "--segment-length=3.0", "--segment-overlap=3.5", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/x.txt"], capture_output=True, text=True)
+    assert e.returncode != 0 and "overlap" in e.stderr
