@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--graph-states", type=int, default=2_000_000); ap.add_argument("--graph-arcs", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-two-pass", action="store_true", help="skip the second (order-independent decoder) measurement")
+    ap.add_argument("--no-pipeline", action="store_true", help="one stream: H2D, fbank, TDNN-F and decoder of a batch strictly after the previous batch (stage_ms then adds up to ms_per_step)")
     ap.add_argument("--det-threads", type=int, default=0, help="host threads of the determinization pool (0 = all cores / ranks)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -136,10 +137,35 @@ def main():
         return int(cs.sum()), int(ca.sum())
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    pipelined = not args.no_pipeline      # the next batch's front end (H2D + fbank + TDNN-F) on a second stream, queued behind the present batch's decoder
+    front = torch.cuda.Stream(device=dev); fev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(2)]; dec_done = [torch.cuda.Event() for _ in range(2)]
+    ll2 = [loglikes, torch.empty_like(loglikes) if pipelined else loglikes]
     def run(mode, steps, warmup):
         """W untimed + K timed steps of the whole path in one decoder mode; returns (wall seconds of the K steps, per-stage ms, last lattice sizes, determinized sizes)"""
-        dec = decs.get(mode); lat_sizes = [0, 0]; det_sizes = [0, 0]; pending = []
+        dec = decs.get(mode); lat_sizes = [0, 0]; det_sizes = [0, 0]; pending = []; nstep = [0]
+        for e in dec_done: e.record()
+        def front_end(k):      # batch k's H2D + fbank + TDNN-F on the front stream, into log-likelihood buffer k & 1 (last read by the decoder two batches ago)
+            with torch.cuda.stream(front):
+                front.wait_event(dec_done[k & 1])
+                fev[k & 1][0].record(); pcm_dev.copy_(pcm_host, non_blocking=True)
+                fev[k & 1][1].record(); sf.ComputeFeatures(pcm_dev, wo, fo, total_frames, out=feats)
+                fev[k & 1][2].record(); nb.forward(feats, out=ll2[k & 1])
+                fev[k & 1][3].record()
+        def step_pipelined(timed):
+            k = nstep[0]; nstep[0] += 1
+            if k == 0: front_end(0)
+            torch.cuda.current_stream().wait_event(fev[k & 1][3])
+            if timed: ev[3].record()
+            dec.DecodeBatch(ll2[k & 1], nb.out_offsets); dec_done[k & 1].record()
+            front_end(k + 1)       # queued behind the decoder: its workgroups take the CUs the decoder's lanes leave as they finish
+            if timed: ev[4].record()
+            while len(pending) >= 2: r = pending.pop(0).result(); det_sizes[0], det_sizes[1] = r
+            lats = dec.GetRawLattices()
+            lat_sizes[0] = int(lats.state_offsets[-1]); lat_sizes[1] = int(lats.arc_offsets[-1])
+            if timed: ev[5].record()
+            pending.append(pool.submit(postprocess, lats))
         def step(timed):
+            if pipelined and dec is not None: return step_pipelined(timed)
             if timed: ev[0].record()
             pcm_dev.copy_(pcm_host, non_blocking=True)                     # first waveform byte leaves host memory
             if timed: ev[1].record()
@@ -164,7 +190,10 @@ def main():
         for _ in range(steps):
             step(True)
             torch.cuda.current_stream().synchronize()
-            acc[0] += ev[0].elapsed_time(ev[1]); acc[1] += ev[1].elapsed_time(ev[2]); acc[2] += ev[2].elapsed_time(ev[3])
+            if pipelined and dec is not None:
+                fe = fev[(nstep[0] - 1) & 1]; acc[0] += fe[0].elapsed_time(fe[1]); acc[1] += fe[1].elapsed_time(fe[2]); acc[2] += fe[2].elapsed_time(fe[3])
+            else:
+                acc[0] += ev[0].elapsed_time(ev[1]); acc[1] += ev[1].elapsed_time(ev[2]); acc[2] += ev[2].elapsed_time(ev[3])
             if dec is not None:
                 acc[3] += ev[3].elapsed_time(ev[4]); acc[4] += ev[4].elapsed_time(ev[5])
                 k = dec.KernelTimes(); acc[5] += k[0]; acc[6] += k[1]
@@ -194,6 +223,7 @@ def main():
                            "utts_per_gpu": U, "frames_per_utt": fo_h[1], "output_rows": int(nb.total_out_rows), "params": int(net.info.num_params), "parallelism": f"utterance-shard x{world}"},
                 "value_kernels": U * args.utt_seconds * world / (kernels_ms * 1e-3),
                 "value_kernels_note": "audio / (fbank + TDNN-F + decode kernel time of a step): what the GPU stages alone sustain, H2D / D2H / host tail excluded",
+                "pipeline": ("batch k+1's PCM16 H2D + fbank + TDNN-F are issued on a second stream right behind batch k's decoder kernels (double-buffered log-likelihoods): the copy and the start of the network run while the decoder's last lanes finish; one of each per step inside the timed region; stage_ms are the stages' own durations and no longer add up to ms_per_step" if pipelined else "none (--no-pipeline): one stream, stage after stage"),
                 "stage_ms": {"pcm16_h2d": acc[0], "fbank": acc[1], "nnet3": acc[2], "decode": acc[3], "decode.token_passing_kernel": acc[5], "decode.lattice_prune_kernel": acc[6], "lattice_compact_and_d2h": acc[4]},
                 "roofline_gemm": {"bound": "mfma", "kernel": "k3_tdnn_gemm_kernel (all launches of one forward)", "achieved": gemm_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": gemm_tf / 157.3,
                                   "note": "exact sum(2MNK) of the launched GEMMs / HIP-event time of the forward on the launch stream; FP32 MFMA peak (the only MFMA class inside the 1e-4 bound)"}}
