@@ -248,41 +248,68 @@ int main(int argc, char **argv) {
     // the list of (iteration, first file, last file) batches
     std::vector<std::array<size_t, 3>> plan_batches;
     for (int iter = 0; iter < iterations; iter++) for (size_t b0 = 0; b0 < scp.size(); b0 += max_batch) plan_batches.push_back({(size_t)iter, b0, std::min(scp.size(), b0 + (size_t)max_batch)});
-    DevBuf<float> d_w, d_f, d_ll, d_iv; DevBuf<int64_t> d_wo, d_fo;
+    // GPU stage, two streams one batch apart: the FRONT END of batch k+1 (upload, features, i-vectors, network) is issued on its own stream right behind the decoder kernels of batch k
+    // (log-likelihoods double-buffered), so that the copy and the first network layers run while the decoder's last lanes finish -- as bench.py does.
+    DevBuf<float> d_w, d_f, d_ll[2], d_iv; DevBuf<int64_t> d_wo, d_fo;
     std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache;
     std::future<Batch> next; std::future<void> post;
+    hipStream_t s_front, s_dec; HIPCHK(hipStreamCreateWithFlags(&s_front, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&s_dec, hipStreamNonBlocking));
+    hipEvent_t ev_front[2]; for (auto &e : ev_front) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    struct Front { Batch b; std::vector<int64_t> ro; bool valid = false; double wait_ms = 0.0; } fr[2];
+    auto tick = [] { return std::chrono::steady_clock::now(); }; auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_start = std::chrono::steady_clock::now();
     if (!plan_batches.empty()) next = std::async(std::launch::async, load_batch, plan_batches[0][1], plan_batches[0][2], 0, (int)plan_batches[0][0]);
-    for (size_t k = 0; k < plan_batches.size(); k++) {
-      auto tick = [] { return std::chrono::steady_clock::now(); }; auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto front_end = [&](size_t k) {      // everything of batch k up to its log-likelihoods, on s_front; the shared device buffers and the network workspace are free: front end k-1 has completed (caller)
+      Front &f = fr[k & 1]; f.valid = false;
       const auto t_a = tick();
-      Batch b = next.get();
-      const auto t_b = tick();
+      f.b = next.get(); f.wait_ms = ms(t_a, tick());
       if (k + 1 < plan_batches.size()) next = std::async(std::launch::async, load_batch, plan_batches[k + 1][1], plan_batches[k + 1][2], (int)((k + 1) & 1), (int)plan_batches[k + 1][0]);
+      Batch &b = f.b;
       num_err += b.num_err; if (b.iter == 0) { total_audio += b.audio; num_task += (int)b.keys.size(); }      // per iteration, like the reference's counters
-      if (b.keys.empty()) continue;
+      if (b.keys.empty()) return;
       const int U = (int)b.keys.size(); const int64_t tot = b.foff.back(), nsamp = b.woff.back();
-      HIPCHK(hipMemcpyAsync(d_w.need((size_t)nsamp), pinned[b.slot].p, (size_t)nsamp * sizeof(float), hipMemcpyHostToDevice, nullptr));
+      HIPCHK(hipMemcpyAsync(d_w.need((size_t)nsamp), pinned[b.slot].p, (size_t)nsamp * sizeof(float), hipMemcpyHostToDevice, s_front));
       d_wo.upload(b.woff); d_fo.upload(b.foff);
-      K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w.p, d_wo.p, d_fo.p, U, tot, d_f.need((size_t)tot * fdim), fdim, nullptr));
+      K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w.p, d_wo.p, d_fo.p, U, tot, d_f.need((size_t)tot * fdim), fdim, s_front));
       // the network plan of a batch (row bookkeeping, tile tables, activation workspace in HBM) depends only on the utterances' frame counts: kept for
       // the batches that come back (--iterations, equal-length test sets) instead of being rebuilt per batch
-      k3_nnet_batch *nb = nullptr; std::vector<int64_t> ro(U + 1);
+      k3_nnet_batch *nb = nullptr; f.ro.assign(U + 1, 0);
       for (auto &c : plan_cache) if (c.first == b.nframes) { nb = c.second; break; }
       const bool cached = nb != nullptr;
+      DevBuf<float> &ll = d_ll[k & 1];
       if (!ivx) {
         if (!cached) K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
-        const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
-        K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
+        const int64_t rows = k3_nnet_batch_output_rows(nb, f.ro.data());
+        K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, s_front));
       } else {
         std::vector<int32_t> iv_rows(U); for (int u = 0; u < U; u++) iv_rows[u] = (b.nframes[u] + iv_period - 1) / iv_period;
         const int64_t n_iv = k3_ivector_num_rows(ivx, U, b.foff.data(), nullptr);
-        K3H_CHECK_K3(k3_ivector_extract_batch(ivx, d_f.p, fdim, b.foff.data(), U, d_iv.need((size_t)n_iv * ninfo.ivector_dim), ninfo.ivector_dim, nullptr));
+        K3H_CHECK_K3(k3_ivector_extract_batch(ivx, d_f.p, fdim, b.foff.data(), U, d_iv.need((size_t)n_iv * ninfo.ivector_dim), ninfo.ivector_dim, s_front));
         if (!cached) K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, frames_per_chunk, iv_period, iv_rows.data(), &nb));
-        const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
-        K3H_CHECK_K3(k3_nnet_forward_ivector(nb, d_f.p, fdim, d_iv.p, ninfo.ivector_dim, d_ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, nullptr));
+        const int64_t rows = k3_nnet_batch_output_rows(nb, f.ro.data());
+        K3H_CHECK_K3(k3_nnet_forward_ivector(nb, d_f.p, fdim, d_iv.p, ninfo.ivector_dim, ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, s_front));
       }
-      K3H_CHECK_K3(k3_decoder_decode_batch(dec, U, d_ll.p, ninfo.output_dim, ro.data(), nullptr));
+      if (!cached) {      // (an evicted plan's workspace is not in use: only this front end's network is in flight and it uses `nb`)
+        plan_cache.push_back({b.nframes, nb});
+        if (plan_cache.size() > 4) { HIPCHK(hipStreamSynchronize(s_front)); k3_nnet_batch_destroy(plan_cache.front().second); plan_cache.erase(plan_cache.begin()); }
+      }
+      HIPCHK(hipEventRecord(ev_front[k & 1], s_front)); f.valid = true;
+    };
+    if (!plan_batches.empty()) front_end(0);
+    for (size_t k = 0; k < plan_batches.size(); k++) {
+      const auto t_b = tick();
+      Front &f = fr[k & 1];
+      if (f.valid) {
+        HIPCHK(hipStreamWaitEvent(s_dec, ev_front[k & 1], 0));
+        K3H_CHECK_K3(k3_decoder_decode_batch(dec, (int)f.b.keys.size(), d_ll[k & 1].p, ninfo.output_dim, f.ro.data(), s_dec));
+        HIPCHK(hipEventSynchronize(ev_front[k & 1]));      // front end k is through: the staging / feature / network buffers are free for batch k+1
+      }
+      // batch k+1's front end is queued NOW, behind the decoder kernels of batch k; then this thread waits for batch k's decoder
+      const bool had = f.valid; Batch bk; const double waited = f.wait_ms;
+      if (had) bk = std::move(f.b);
+      if (k + 1 < plan_batches.size()) front_end(k + 1);
+      if (!had) continue;
+      Batch &b = bk; const int U = (int)b.keys.size();
       auto r = std::make_shared<Raw>(); r->info.resize(10 * (size_t)U);
       K3H_LATTICE_INFO(dec, r->info.data());
       const auto t_c = tick();
@@ -297,14 +324,15 @@ int main(int argc, char **argv) {
       } else {
         for (int u = 0; u < U; u++) if (r->info[10 * u + 2] != 0 || r->info[10 * u] == 0) { K3H_WARN << "Failed to decode utterance with id " << b.keys[u]; num_err++; }
       }
-      if (!cached) { plan_cache.push_back({b.nframes, nb}); if (plan_cache.size() > 4) { k3_nnet_batch_destroy(plan_cache.front().second); plan_cache.erase(plan_cache.begin()); } }
-      K3H_VLOG(1) << "batch " << k << ": waited " << ms(t_a, t_b) << " ms for the reader, " << ms(t_b, t_c) << " ms upload + features + network + decoder, " << ms(t_c, tick()) << " ms lattices to the host + hand-over";
+      K3H_VLOG(1) << "batch " << k << ": waited " << waited << " ms for the reader, " << ms(t_b, t_c) << " ms decoder of this batch (+ front end of the next one queued behind it), " << ms(t_c, tick()) << " ms lattices to the host + hand-over";
     }
     if (post.valid()) post.get();
     num_err += post_err;
     HIPCHK(hipDeviceSynchronize());
     for (auto &c : plan_cache) k3_nnet_batch_destroy(c.second);
-    if (det_pool) { det_pool->Wait(); det_pool.reset(); }
+    for (auto &e : ev_front) (void)hipEventDestroy(e); (void)hipStreamDestroy(s_front); (void)hipStreamDestroy(s_dec);
+    { const auto t_w = std::chrono::steady_clock::now(); if (det_pool) { det_pool->Wait(); det_pool.reset(); }
+      K3H_VLOG(1) << "waited " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_w).count() << " ms for the determinization pool after the last batch"; }
     if (writer) writer->Flush();
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
