@@ -1381,6 +1381,7 @@ struct k3_decoder {
   int last_utts = 0; std::vector<int> last_frames, fresh, lane_final;   // per lane: frames consumed, InitDecoding pending, FinalizeDecoding done
   std::vector<int> sel;                                                   // lanes of the latest finalize call (what the lattice getters return)
   hipStream_t last_stream = nullptr;
+  std::vector<int> lane_ids_uploaded;      // what d_lane_ids holds
   std::vector<LaneInfo> h_info; bool info_valid = false;
   void *out_buf = nullptr; size_t out_bytes = 0;
   bool started = false, finalized = false;
@@ -1596,8 +1597,12 @@ static int finalize_lanes(k3_decoder *d, const std::vector<int> &lanes, hipStrea
   K3_REQUIRE(d->started, "k3_decoder_finalize_decoding: nothing to finalize");
   for (int l : lanes) K3_REQUIRE(l >= 0 && l < d->last_utts && !d->fresh[l], "k3_decoder_finalize: lane out of range or never advanced");
   if (lanes.empty()) { d->sel.clear(); return K3_OK; }
-  K3_HIP_CHECK(hipStreamSynchronize(st));            // d_lane_ids may still be read by an earlier finalize
-  K3_HIP_CHECK(hipMemcpy(d->d_lane_ids, lanes.data(), sizeof(int) * lanes.size(), hipMemcpyHostToDevice));
+  if (lanes != d->lane_ids_uploaded) {      // (a whole-batch decode finalises lanes 0 .. n-1 every time: the list on the device is reused and the call stays asynchronous --
+                                            //  the caller can queue the next batch's front end behind the token-passing kernel instead of waiting for it here)
+    K3_HIP_CHECK(hipStreamSynchronize(st));            // d_lane_ids may still be read by an earlier finalize
+    K3_HIP_CHECK(hipMemcpy(d->d_lane_ids, lanes.data(), sizeof(int) * lanes.size(), hipMemcpyHostToDevice));
+    d->lane_ids_uploaded = lanes;
+  }
   d->p.lane_ids = d->d_lane_ids;
   hipLaunchKernelGGL(k3_decode_prune_kernel, dim3((unsigned)lanes.size()), dim3(kPBlock), 0, st, d->p);
   K3_HIP_CHECK(hipGetLastError());
