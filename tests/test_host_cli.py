@@ -55,7 +55,7 @@ def test_cli_exit_codes_follow_the_reference():
     exe = os.path.join(BIN, "batched-wav-nnet3-cuda2")
     r = _run(exe); assert r.returncode == 1 and "Usage: batched-wav-nnet3-cuda2" in r.stderr
     r = _run(exe, "--no-such-option=1", "a", "b", "c", "d"); assert r.returncode == 255 and "Invalid option" in r.stderr
-    r = _run(exe, "--segmentation=true", "a", "b", "c", "d"); assert r.returncode == 255 and "outside the accelerated path" in r.stderr
+    r = _run(exe, "--add-pitch=true", "a", "b", "c", "d"); assert r.returncode == 255 and "outside the accelerated path" in r.stderr
     r = _run(os.path.join(BIN, "compute-fbank-feats-cuda"), "only-one-arg"); assert r.returncode == 1
     r = _run(exe, "--help"); assert r.returncode == 0 and "--lattice-beam" in r.stderr and "--max-batch-size" in r.stderr
 
