@@ -258,7 +258,9 @@ int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg, int32_t n
 void k3_decoder_destroy(k3_decoder *dec);
 /* Decode num_utts utterances: utterance u owns rows h_row_offsets[u] .. h_row_offsets[u+1] of d_loglikes
  * (row-major, leading dimension ld; already scaled by the acoustic scale, as DecodableAmNnetSimple hands them
- * over).  Asynchronous on `stream`; results are fetched with the calls below (which synchronise). */
+ * over).  Asynchronous on `stream` (the call first waits for what is already queued on `stream`, never for its own kernels): the caller
+ * can queue the NEXT batch's features and network on a second stream right behind it -- their workgroups take the CUs this batch's lanes
+ * free as they finish (bench.py, batched-wav-nnet3-cuda2).  Results are fetched with the calls below (which synchronise). */
 int k3_decoder_decode_batch(k3_decoder *dec, int32_t num_utts, const float *d_loglikes, int64_t ld,
                             const int64_t *h_row_offsets, void *stream);
 /* The same in the pieces of CudaDecoder's online interface (cuda-decoder.h:248-262, lanes == channels here): InitDecoding for num_utts
