@@ -215,6 +215,14 @@ def main():
     if pipelined and decs:
         acc = run(mode0, 3, 1, pipelined=False)[1]
         if two is not None: two = (two[0], run("two_pass", 3, 1, pipelined=False)[1], two[2], two[3], two[1])
+    # the TDNN-F forward by itself, back to back (no decoder in between: no clock transient after 90 ms of a low-power kernel)
+    fwd_ms = None
+    if rank == 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3): nb.forward(feats, out=loglikes)
+        e0.record()
+        for _ in range(4): nb.forward(feats, out=loglikes)
+        e1.record(); torch.cuda.synchronize(); fwd_ms = e0.elapsed_time(e1) / 4
     if rank == 0:
         gemm_tf = nb.flops / (acc[2] * 1e-3) / 1e12
         kernels_ms = acc[1] + acc[2] + acc[3]
@@ -234,7 +242,8 @@ def main():
                 "stage_ms_note": ("stage and kernel durations of a serial pass (3 steps, one stream) run after the timed steps: each kernel has the GPU to itself, as in the committed rocprofv3 traces (tools/profile_round.sh uses --no-pipeline); stage_ms_in_pipeline are the event-to-event times of the same stages inside the timed, pipelined steps, where they share the GPU" if (pipelined and decs) else "stages of the timed steps (one stream)"),
                 "stage_ms_in_pipeline": ({"pcm16_h2d": acc_pipe[0], "fbank": acc_pipe[1], "nnet3": acc_pipe[2], "decode": acc_pipe[3], "decode.token_passing_kernel": acc_pipe[5], "decode.lattice_prune_kernel": acc_pipe[6], "lattice_compact_and_d2h": acc_pipe[4]} if (pipelined and decs) else None),
                 "roofline_gemm": {"bound": "mfma", "kernel": "k3_tdnn_gemm_kernel (all launches of one forward)", "achieved": gemm_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": gemm_tf / 157.3,
-                                  "note": "exact sum(2MNK) of the launched GEMMs / HIP-event time of the forward on the launch stream; FP32 MFMA peak (the only MFMA class inside the 1e-4 bound)"}}
+                                  "forward_back_to_back_ms": fwd_ms, "frac_back_to_back": nb.flops / (fwd_ms * 1e-3) / 1e12 / 157.3,
+                                  "note": "exact sum(2MNK) of the launched GEMMs / HIP-event time of the forward on the launch stream; FP32 MFMA peak (the only MFMA class inside the 1e-4 bound); achieved / frac: the forward as a stage of the serial pass (after the decoder); frac_back_to_back: four forwards in a row"}}
         if decs:
             dec = decs["literal"]; info = dec.LatticeInfo(); ab = dec.algorithmic_bytes(info); gbs = ab / (acc[5] * 1e-3) / 1e9
             line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_literal_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
