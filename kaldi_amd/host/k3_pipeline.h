@@ -179,38 +179,69 @@ class BatchedThreadedNnet3CudaPipeline2 {
       Finish(t);
     }
   }
+  // Batches one apart on two streams (as bench.py and batched-wav-nnet3-cuda2 do): while the decoder of batch k runs, whatever has been queued meanwhile (up to max_batch_size
+  // utterances) gets its upload, features and network issued behind it, on the front stream, into the other log-likelihood buffer.  Nothing waits for a next batch to fill: with an
+  // empty queue the present batch is simply finished.
+  struct InFlight { std::vector<std::shared_ptr<Task>> batch; std::vector<int> idx; std::vector<int64_t> ro; int U = 0, buf = 0; bool valid = false; };
+  std::vector<std::shared_ptr<Task>> TakeBatch(bool block) {
+    std::vector<std::shared_ptr<Task>> batch;
+    std::unique_lock<std::mutex> l(m_);
+    if (block) cv_.wait(l, [&] { return stop_ || !queue_.empty(); });
+    while (!queue_.empty() && (int)batch.size() < config_.max_batch_size) { batch.push_back(queue_.front()); queue_.pop_front(); }
+    return batch;
+  }
+  void Hand(std::vector<std::shared_ptr<Task>> &batch) { { std::lock_guard<std::mutex> l(m_); for (auto &t : batch) post_.push_back(t); } wcv_.notify_all(); }
   void ControlLoop() {
     K3O_HIP(hipSetDevice(device_));
+    K3O_HIP(hipStreamCreateWithFlags(&s_front_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_, hipStreamNonBlocking));
+    for (auto &e : ev_front_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    InFlight cur, nxt; int parity = 0;
+    auto start = [&](InFlight *f, std::vector<std::shared_ptr<Task>> &&batch) {
+      f->batch = std::move(batch); f->valid = false; f->buf = parity; parity ^= 1;
+      try { FrontEnd(f); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : f->batch) t->failed = true; f->valid = false; }
+    };
     for (;;) {
-      std::vector<std::shared_ptr<Task>> batch;
-      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return stop_ || !queue_.empty(); }); if (queue_.empty()) return;
-        while (!queue_.empty() && (int)batch.size() < config_.max_batch_size) { batch.push_back(queue_.front()); queue_.pop_front(); } }
-      try { ComputeBatch(batch); }
-      catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : batch) t->failed = true; }
-      { std::lock_guard<std::mutex> l(m_); for (auto &t : batch) post_.push_back(t); }
-      wcv_.notify_all();
+      if (cur.batch.empty()) { auto b = TakeBatch(true); if (b.empty()) break; start(&cur, std::move(b)); }
+      bool decoding = false;
+      try {
+        if (cur.valid) {
+          K3O_HIP(hipStreamWaitEvent(s_dec_, ev_front_[cur.buf], 0));
+          K3H_CHECK_K3(k3_decoder_decode_batch(dec_, cur.U, d_ll_[cur.buf].p, ninfo_.output_dim, cur.ro.data(), s_dec_)); decoding = true;
+          K3O_HIP(hipEventSynchronize(ev_front_[cur.buf]));      // the front end of `cur` is through: its staging, feature and network buffers are free
+        }
+      } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; decoding = false; }
+      nxt = InFlight(); { auto b = TakeBatch(false); if (!b.empty()) start(&nxt, std::move(b)); }
+      if (decoding) { try { Fetch(&cur); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; } }
+      Hand(cur.batch);
+      cur = std::move(nxt); nxt = InFlight();
     }
+    K3O_HIP(hipStreamSynchronize(s_front_)); K3O_HIP(hipStreamSynchronize(s_dec_));
+    for (auto &e : ev_front_) (void)hipEventDestroy(e); (void)hipStreamDestroy(s_front_); (void)hipStreamDestroy(s_dec_);
   }
-  void ComputeBatch(std::vector<std::shared_ptr<Task>> &batch) {
-    std::vector<int> idx; std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int32_t> nframes;
+  void FrontEnd(InFlight *f) {      // upload + features + network of f->batch on the front stream, log-likelihoods into buffer f->buf
+    std::vector<std::shared_ptr<Task>> &batch = f->batch;
+    std::vector<int> &idx = f->idx; idx.clear(); std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int32_t> nframes;
     for (size_t i = 0; i < batch.size(); i++) {
       const int nf = k3_feat_num_frames(plan_, (int64_t)batch[i]->samples.size());
       if (nf == 0) { batch[i]->failed = true; continue; }      // too short to decode
       idx.push_back((int)i); all.insert(all.end(), batch[i]->samples.begin(), batch[i]->samples.end()); woff.push_back((int64_t)all.size()); foff.push_back(foff.back() + nf); nframes.push_back(nf);
     }
-    const int U = (int)idx.size(); if (U == 0) return;
+    const int U = (int)idx.size(); f->U = U; if (U == 0) return;
     const int64_t tot = foff.back();
-    d_w_.upload(all); d_wo_.upload(woff); d_fo_.upload(foff);
-    K3H_CHECK_K3(k3_feat_compute_batch(plan_, d_w_.p, d_wo_.p, d_fo_.p, U, tot, d_f_.need((size_t)tot * fdim_), fdim_, nullptr));
+    d_w_.upload(all); d_wo_.upload(woff); d_fo_.upload(foff);      // (synchronous copies: the previous front end has completed, nothing reads these buffers)
+    K3H_CHECK_K3(k3_feat_compute_batch(plan_, d_w_.p, d_wo_.p, d_fo_.p, U, tot, d_f_.need((size_t)tot * fdim_), fdim_, s_front_));
     k3_nnet_batch *nb = nullptr;
     for (auto &c : plan_cache_) if (c.first == nframes) { nb = c.second; break; }
     if (!nb) {
       K3H_CHECK_K3(k3_nnet_batch_create(nnet_, U, nframes.data(), config_.frame_subsampling_factor, log_priors_.empty() ? nullptr : log_priors_.data(), config_.acoustic_scale, &nb));
       plan_cache_.push_back({nframes, nb}); if (plan_cache_.size() > 4) { k3_nnet_batch_destroy(plan_cache_.front().second); plan_cache_.erase(plan_cache_.begin()); }
     }
-    std::vector<int64_t> ro(U + 1); const int64_t rows = k3_nnet_batch_output_rows(nb, ro.data());
-    K3H_CHECK_K3(k3_nnet_forward(nb, d_f_.p, fdim_, d_ll_.need((size_t)rows * ninfo_.output_dim), ninfo_.output_dim, nullptr));
-    K3H_CHECK_K3(k3_decoder_decode_batch(dec_, U, d_ll_.p, ninfo_.output_dim, ro.data(), nullptr));
+    f->ro.assign(U + 1, 0); const int64_t rows = k3_nnet_batch_output_rows(nb, f->ro.data());
+    K3H_CHECK_K3(k3_nnet_forward(nb, d_f_.p, fdim_, d_ll_[f->buf].need((size_t)rows * ninfo_.output_dim), ninfo_.output_dim, s_front_));
+    K3O_HIP(hipEventRecord(ev_front_[f->buf], s_front_)); f->valid = true;
+  }
+  void Fetch(InFlight *f) {      // waits for the decoder of f->batch and turns its raw lattices into the tasks' Lattice objects
+    std::vector<std::shared_ptr<Task>> &batch = f->batch; const std::vector<int> &idx = f->idx; const int U = f->U;
     std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec_, info.data());
     int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
     std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
@@ -231,7 +262,8 @@ class BatchedThreadedNnet3CudaPipeline2 {
   const BatchedThreadedNnet3CudaPipeline2Config config_; k3_nnet *nnet_; const TransitionInfo &trans_;
   k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; k3_nnet_info ninfo_; int fdim_ = 0, device_ = 0; int32_t graph_start_ = 0; std::vector<float> log_priors_;
   std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache_;
-  DevBuf<float> d_w_, d_f_, d_ll_; DevBuf<int64_t> d_wo_, d_fo_;
+  DevBuf<float> d_w_, d_f_, d_ll_[2]; DevBuf<int64_t> d_wo_, d_fo_;
+  hipStream_t s_front_ = nullptr, s_dec_ = nullptr; hipEvent_t ev_front_[2] = {nullptr, nullptr};
   std::mutex m_; std::condition_variable cv_, wcv_, done_cv_; bool stop_ = false;
   std::deque<std::shared_ptr<Task>> queue_, post_; std::map<std::string, int> groups_; int n_tasks_not_done_ = 0;
   std::thread control_; std::vector<std::thread> workers_;
