@@ -39,3 +39,23 @@ def test_bench_two_ranks_on_one_device_with_gloo(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["decode_stats"]["graph_broadcast_s"] > 0 and line["decode_stats"]["lattice_arcs"] > 0
+
+
+def test_bench_pipelined_steps_give_the_single_stream_lattices():
+    """bench.py's default steps pipeline batches over two streams (batch k+1's upload, features and network queued behind batch k's decoder, double-buffered log-likelihoods;
+    k3_decoder_decode_batch does not wait for its own kernels).  The lattices and the determinized lattices of the last batch must be those of --no-pipeline, and the JSON line must
+    carry the serial pass's stage times next to the pipelined steps'."""
+    import json, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--utts", "24", "--utt-seconds", "3", "--graph-states", "30000", "--graph-arcs", "80000", "--no-cpu-baseline"]
+    lines = []
+    for extra in ([], ["--no-pipeline"]):
+        r = subprocess.run(common + extra, capture_output=True, text=True, timeout=600); assert r.returncode == 0, r.stderr[-3000:]
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    a, b = lines
+    for k in ("lattice_states", "lattice_arcs", "determinized_states", "determinized_arcs", "tokens", "emitting_arcs_traversed", "order_sensitive_events"):      # (eps_arcs_traversed counts the fixpoint's re-expansions, which depend on timing)
+        assert a["decode_stats"][k] == b["decode_stats"][k] and a["decode_stats"][k] > 0, k
+    assert a["two_pass"]["lattice_arcs"] == b["two_pass"]["lattice_arcs"]
+    assert a["pipeline"].startswith("batch k+1") and b["pipeline"].startswith("none") and a["stage_ms_in_pipeline"] is not None and b["stage_ms_in_pipeline"] is None
+    assert set(a["stage_ms"]) == set(b["stage_ms"]) and all(v > 0 for v in a["stage_ms"].values())
+    assert a["roofline"]["frac"] > 0 and a["roofline_gemm"]["frac_back_to_back"] > 0 and a["cpu_baseline"] is None if "cpu_baseline" in a else True
