@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <iostream>
+#include <thread>
 #include "k3_host.h"
 #include "k3_nnet_ivector_cli.h"
 #include "../../include/k3hip.h"
@@ -20,13 +21,13 @@ int main(int argc, char **argv) {
                         "Usage: nnet3-latgen-faster [options] <nnet-in> <fst-in> <features-rspecifier> <lattice-wspecifier> [ <words-wspecifier> [<alignments-wspecifier>] ]\n"
                         "See also: nnet3-latgen-faster-parallel, nnet3-latgen-faster-batch\n";
     ParseOptions po(usage);
-    bool allow_partial = false, determinize = true, debug_comp = false, literal_order = true, phone_det = true, word_det = true, minimize = false; std::string word_syms, use_gpu = "yes", ivector_rspecifier, online_ivector_rspecifier, utt2spk;
+    bool allow_partial = false, determinize = true, debug_comp = false, literal_order = true, phone_det = true, word_det = true, minimize = false; int32_t det_threads = 0; std::string word_syms, use_gpu = "yes", ivector_rspecifier, online_ivector_rspecifier, utt2spk;
     int32_t subsampling = 1, frames_per_chunk = 50, elc = 0, erc = 0, elci = -1, ercf = -1, online_ivector_period = 0, max_batch = 256, max_active = 2147483647, min_active = 200, prune_interval = 25, max_mem = 50000000, frame_tokens_cap = 65536, lane_tokens_cap = 4000000, lane_links_cap = 8000000;
     float beam = 16.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, hash_ratio = 2.0f, prune_scale = 0.1f, delta = 0.000976562f;
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)"); po.Register("allow-partial", &allow_partial, "If true, produce output even if end state was not reached.");
     po.Register("beam", &beam, "Decoding beam.  Larger->slower, more accurate."); po.Register("max-active", &max_active, "Decoder max active states.  Larger->slower; more accurate");
     po.Register("min-active", &min_active, "Decoder minimum #active states."); po.Register("lattice-beam", &lattice_beam, "Lattice generation beam.  Larger->slower, and deeper lattices");
-    po.Register("prune-interval", &prune_interval, "(accepted; pruning runs once after the last frame and gives the same lattice)"); po.Register("determinize-lattice", &determinize, "If true, determinize the lattice (lattice-determinization, keeping only best pdf-sequence for each word-sequence).");
+    po.Register("prune-interval", &prune_interval, "(accepted; pruning runs once after the last frame and gives the same lattice)"); po.Register("determinize-threads", &det_threads, "Host threads that determinize lattices while the GPU decodes the next batch (0: all cores; an addition -- the reference determinizes inline)"); po.Register("determinize-lattice", &determinize, "If true, determinize the lattice (lattice-determinization, keeping only best pdf-sequence for each word-sequence).");
     po.Register("beam-delta", &beam_delta, "Increment used in decoding-- this parameter is obscure and relates to a speedup in the way the max-active constraint is applied.");
     po.Register("hash-ratio", &hash_ratio, "Setting used in decoder to control hash behavior (it decides the token visit order, hence which tokens the running cutoff keeps; honoured with --literal-order)");
     po.Register("literal-order", &literal_order, "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's, bit for bit; false = the order-independent fast decoder"); po.Register("prune-scale", &prune_scale, "(accepted, unused)");
@@ -65,6 +66,13 @@ int main(int argc, char **argv) {
     dc.literal_order = literal_order ? 1 : 0; dc.hash_ratio = hash_ratio; if (literal_order) dc.frame_tokens_cap = std::min(dc.frame_tokens_cap, 65536);
     k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, max_batch, ni.output_dim, &dec));
     auto feats = ReadMatrixTable(po.GetArg(3)); TableWriter lat_writer(po.GetArg(4));
+    // determinization on a pool of host threads, records written in submission order (as batched-wav-nnet3-cuda2 does): inline it took longer per batch than the GPU by two orders of magnitude
+    std::unique_ptr<DeterminizeSequencer> det_pool;
+    if (determinize) {
+      DeterminizeSequencer::Config pc; pc.num_threads = det_threads > 0 ? det_threads : std::max(1, (int)std::thread::hardware_concurrency());
+      pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; pc.post_scale = acoustic_scale != 0.0f ? 1.0 / acoustic_scale : 1.0;
+      det_pool.reset(new DeterminizeSequencer(pc, &lat_writer));
+    }
     std::unique_ptr<TableWriter> words_writer, ali_writer;
     if (po.NumArgs() >= 5 && !po.GetArg(5).empty()) words_writer.reset(new TableWriter(po.GetArg(5)));
     if (po.NumArgs() >= 6 && !po.GetArg(6).empty()) ali_writer.reset(new TableWriter(po.GetArg(6)));
@@ -110,10 +118,7 @@ int main(int argc, char **argv) {
         if (ali_writer) ali_writer->WriteInt32Vector(utt, ali);
         Connect(&lat);
         if (determinize) {
-          CompactLattice clat;
-          if (!DeterminizeLatticePhonePruned(lat, ti, lattice_beam, &clat, det_opts)) K3H_WARN << "Determinization finished earlier than the beam for utterance " << utt;
-          if (acoustic_scale != 0.0f) ScaleAcoustic(&clat, 1.0 / acoustic_scale);
-          lat_writer.WriteCompactLattice(utt, clat);
+          det_pool->Run(utt, std::move(lat));
         } else {
           if (acoustic_scale != 0.0f) ScaleAcoustic(&lat, 1.0 / acoustic_scale);
           lat_writer.WriteLattice(utt, lat);
@@ -124,6 +129,7 @@ int main(int argc, char **argv) {
       }
       k3_nnet_batch_destroy(nb); HIPCHK(hipFree(d_o));
     }
+    if (det_pool) { det_pool->Wait(); det_pool.reset(); }
     lat_writer.Flush(); if (words_writer) words_writer->Flush(); if (ali_writer) ali_writer->Flush();
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     K3H_LOG << "Time taken " << elapsed << "s: real-time factor assuming 100 frames/sec is " << (elapsed * 100.0 / std::max<int64_t>(frame_count, 1));
