@@ -230,8 +230,9 @@ extern "C" int k3_mat_reduce_scalar(int32_t op, const float *d_A, int64_t lda, c
   if (rows == 0 || cols == 0) return K3_OK;
   K3_REQUIRE(d_A && lda >= cols && (op > 1 || (d_B && ldb >= (op == 0 ? cols : rows))) && (op != 2 || rows == cols), "k3_mat_reduce_scalar: bad matrix");
   constexpr int kMaxWgs = 1024;
-  static thread_local double *d_part = nullptr;      // per host thread: the call synchronises on its stream before returning
-  if (!d_part) K3_HIP_CHECK(hipMalloc((void **)&d_part, kMaxWgs * sizeof(double)));
+  static thread_local double *d_part = nullptr; static thread_local int d_part_dev = -1;      // per host thread (the call synchronises on its stream before returning) and per device
+  { int dev = 0; K3_HIP_CHECK(hipGetDevice(&dev));
+    if (!d_part || dev != d_part_dev) { K3_HIP_CHECK(hipMalloc((void **)&d_part, kMaxWgs * sizeof(double))); d_part_dev = dev; } }      // (a thread that moves to another device leaves 8 KB behind on the old one)
   const long long n = op == 2 ? (long long)rows : (long long)rows * cols;
   const int wgs = (int)std::min<long long>(kMaxWgs, (n + 255) / 256);
   ScalParams p{op, rows, cols, d_A, lda, d_B, ldb, d_part};
