@@ -34,9 +34,11 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
       for (int r = 0; r < 16; r++) { total[r] += alpha * acc[r]; acc[r] = 0.0f; }
     }
     for (int e = tid; e < 64 * 16; e += 256) {
-      const int r = e >> 4, k = e & 15, gm = m0 + r, gk = k0 + k;
+      // consecutive threads walk the operand's CONTIGUOUS dimension (k for A, n for B; the other one when the operand is transposed): the LDS strides 17 / 65 are odd, so
+      // either order is conflict-free there
+      const int r = ta ? (e & 63) : (e >> 4), k = ta ? (e >> 6) : (e & 15), gm = m0 + r, gk = k0 + k;
       As[r][k] = (gm < M && gk < K) ? (ta ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk]) : 0.0f;
-      const int kb = e >> 6, c = e & 63, gn = n0 + c, gk2 = k0 + kb;
+      const int kb = tb ? (e & 15) : (e >> 6), c = tb ? (e >> 4) : (e & 63), gn = n0 + c, gk2 = k0 + kb;
       Bs[kb][c] = (gn < N && gk2 < K) ? (tb ? B[(long long)gn * ldb + gk2] : B[(long long)gk2 * ldb + gn]) : 0.0f;
     }
     __syncthreads();
