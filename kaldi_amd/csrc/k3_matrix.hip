@@ -14,8 +14,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 64 x 64 x 16 tiles, 4 wavefronts of one 32x32 FP32-MFMA tile each; operands go through LDS element-wise so that any
 // transpose / stride / ragged edge is handled by the index function.  k is consumed in ascending order.
 __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int K, float alpha, const float *A, long long lda, int ta,
-                                                              const float *B, long long ldb, int tb, float beta, float *C, long long ldc) {
+                                                              const float *B, long long ldb, int tb, float beta, float *C, long long ldc, float *W, int Kc) {
   __shared__ float As[64][17], Bs[16][65];
+  // split-K (W != null; long-K products with few output tiles, e.g. a weight gradient): block z multiplies k in [z Kc, (z + 1) Kc) into its own M x N plane of W (alpha 1,
+  // beta 0; Kc is a multiple of the 384-wide accumulation blocks); k3_gemm_splitk_reduce_kernel adds the planes in ascending z
+  int kb_ = 0, ke_ = K;
+  if (W) { kb_ = (int)blockIdx.z * Kc; ke_ = min(K, kb_ + Kc); C = W + (long long)blockIdx.z * M * N; ldc = N; alpha = 1.0f; beta = 0.0f; }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   // The accumulation order is the contract: like the blocked CPU sgemm the reference calls, k runs in ascending order
@@ -28,8 +32,8 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
     const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (beta != 0.0f && row < M && col < N) total[r] = beta * C[(long long)row * ldc + col];
   }
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    if (k0 != 0 && k0 % 384 == 0) {
+  for (int k0 = kb_; k0 < ke_; k0 += 16) {
+    if (k0 != kb_ && k0 % 384 == 0) {
 #pragma unroll
       for (int r = 0; r < 16; r++) { total[r] += alpha * acc[r]; acc[r] = 0.0f; }
     }
@@ -37,9 +41,9 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
       // consecutive threads walk the operand's CONTIGUOUS dimension (k for A, n for B; the other one when the operand is transposed): the LDS strides 17 / 65 are odd, so
       // either order is conflict-free there
       const int r = ta ? (e & 63) : (e >> 4), k = ta ? (e >> 6) : (e & 15), gm = m0 + r, gk = k0 + k;
-      As[r][k] = (gm < M && gk < K) ? (ta ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk]) : 0.0f;
+      As[r][k] = (gm < M && gk < ke_) ? (ta ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk]) : 0.0f;
       const int kb = tb ? (e & 15) : (e >> 6), c = tb ? (e >> 4) : (e & 63), gn = n0 + c, gk2 = k0 + kb;
-      Bs[kb][c] = (gn < N && gk2 < K) ? (tb ? B[(long long)gn * ldb + gk2] : B[(long long)gk2 * ldb + gn]) : 0.0f;
+      Bs[kb][c] = (gn < N && gk2 < ke_) ? (tb ? B[(long long)gn * ldb + gk2] : B[(long long)gk2 * ldb + gn]) : 0.0f;
     }
     __syncthreads();
 #pragma unroll
@@ -56,6 +60,14 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
       if (row < M) C[(long long)row * ldc + col] = total[r] + alpha * acc[r];
     }
   }
+}
+
+__global__ void k3_gemm_splitk_reduce_kernel(const float *W, int S, long long MN, int N, float alpha, float beta, float *C, long long ldc) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x; if (i >= MN) return;
+  float acc = 0.0f;
+  for (int z = 0; z < S; z++) acc += W[(long long)z * MN + i];
+  float *c = C + (i / N) * ldc + (i % N);
+  *c = (beta != 0.0f ? beta * *c : 0.0f) + alpha * acc;
 }
 
 enum { kOpSet, kOpScale, kOpFloor, kOpCeil, kOpAddConst, kOpCopyRowsFromVec, kOpMulColsVec, kOpMulRowsVec, kOpAddVecToRows, kOpAddVecToCols, kOpCopy, kOpCopyT, kOpAddMat, kOpAddMatT,
@@ -179,7 +191,23 @@ extern "C" int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, in
   K3_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && ldc >= N, "k3_mat_add_mat_mat: bad argument");
   K3_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N), "k3_mat_add_mat_mat: leading dimension smaller than the row length");
   if (M == 0 || N == 0) return K3_OK;
-  hipLaunchKernelGGL(k3_gemm_generic_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, N, K, alpha, d_A, lda, trans_a, d_B, ldb, trans_b, beta, d_C, ldc);
+  const long long tiles = (long long)((N + 63) / 64) * ((M + 63) / 64);
+  if (tiles < 384 && K >= 3072) {      // few output tiles, long K (a layer's weight gradient over a minibatch): split K so that the chip is filled; planes reduced in a fixed order
+    int S = (int)std::min<long long>(16, std::max<long long>(2, 1024 / tiles)); int Kc = ((K + S - 1) / S + 383) / 384 * 384; S = (K + Kc - 1) / Kc;
+    static thread_local float *ws = nullptr; static thread_local size_t ws_cap = 0; static thread_local int ws_dev = -1;
+    int dev = 0; K3_HIP_CHECK(hipGetDevice(&dev));
+    const size_t need = (size_t)S * M * N;
+    if (need > ws_cap || dev != ws_dev) {
+      if (ws && dev == ws_dev) { K3_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(ws); }      // (the planes of an earlier call may still be read)
+      K3_HIP_CHECK(hipMalloc((void **)&ws, need * sizeof(float))); ws_cap = need; ws_dev = dev;
+    }
+    hipLaunchKernelGGL(k3_gemm_generic_kernel, dim3((N + 63) / 64, (M + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, M, N, K, alpha, d_A, lda, trans_a, d_B, ldb, trans_b, beta, d_C, ldc, ws, Kc);
+    const long long MN = (long long)M * N;
+    hipLaunchKernelGGL(k3_gemm_splitk_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, S, MN, N, alpha, beta, d_C, ldc);
+    K3_HIP_CHECK(hipGetLastError());
+    return K3_OK;
+  }
+  hipLaunchKernelGGL(k3_gemm_generic_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, N, K, alpha, d_A, lda, trans_a, d_B, ldb, trans_b, beta, d_C, ldc, (float *)nullptr, 0);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }
