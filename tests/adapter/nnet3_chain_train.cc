@@ -9,6 +9,7 @@
 //   nnet3-chain-train <raw-nnet3-in> <frame-subsampling-factor> <input-matrix-in> <chain-spec-in> <num-iters> <learning-rate> <momentum> <raw-nnet3-out> <objf-vector-out>
 // chain-spec: as tests/adapter/nnet3_chain_grad.cc.  objf-vector: per iteration [objf, l2_term, weight], then the parameters of the trained model.
 #include "base/kaldi-common.h"
+#include "base/timer.h"
 #include "util/common-utils.h"
 #include "nnet3/nnet-nnet.h"
 #include "nnet3/nnet-utils.h"
@@ -78,6 +79,7 @@ int main(int argc, char *argv[]) {
     Vector<BaseFloat> objfs(3 * num_iters + NumParameters(nnet));      // per iteration [objf, l2_term, weight], then every parameter of the trained model (VectorizeNnet)
     CuMatrix<BaseFloat> cu_in_orig(input);
     for (int32 iter = 0; iter < num_iters; iter++) {      // TrainInternal
+      Timer iter_timer;
       // The reference draws from the host's rand() for its sampled decisions (which minibatches store statistics / repair gradients / get the orthonormal constraint) AND inside its CPU
       // chain code's self-checks (chain-denominator.cc: RandInt(0, 10)), which k3_chain_objf_and_deriv does not have: reseeded at the same two points in both builds, every such decision is the same.
       srand(2 * iter + 1);
@@ -101,7 +103,7 @@ int main(int argc, char *argv[]) {
       ConstrainOrthonormal(&nnet);
       ScaleNnet(success ? momentum : 0.0, delta_nnet);
       objfs(3 * iter) = objf; objfs(3 * iter + 1) = l2_term; objfs(3 * iter + 2) = weight;
-      KALDI_LOG << "iteration " << iter << ": LF-MMI objf per frame " << objf / weight << " (+ l2 " << l2_term / weight << ") over " << weight << " frames";
+      KALDI_LOG << "iteration " << iter << ": LF-MMI objf per frame " << objf / weight << " (+ l2 " << l2_term / weight << ") over " << weight << " frames; " << iter_timer.Elapsed() * 1000.0 << " ms";
     }
     max_change_stats.Print(nnet);
 #ifdef K3_ADAPTER

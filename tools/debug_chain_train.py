@@ -7,14 +7,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from kaldi_amd import synth
 td = sys.argv[1]; iters = sys.argv[2] if len(sys.argv) > 2 else "3"; os.makedirs(td, exist_ok=True)
 B, T, P, s = 8, 12, 50, 3
+BIG = bool(os.environ.get("K3_TRAIN_BIG"))      # the benchmark model (17L-768/96-6024) and a training-sized minibatch
+if BIG: B, T, P = 64, 50, 6024
 def kaldi_matrix(path, m):
     m = np.ascontiguousarray(m, "<f4"); open(path, "wb").write(b"\0BFM " + b"\x04" + struct.pack("<i", m.shape[0]) + b"\x04" + struct.pack("<i", m.shape[1]) + m.tobytes())
 if not os.path.exists(f"{td}/chain.spec"):
     calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
-    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=P, calib_feats=calib, out_std=1.5, orthonormal_constraint=-1.0).write(f"{td}/m.raw")
-    lc = rc = 8; Tin = (T - 1) * s + 1 + lc + rc; rng = np.random.default_rng(B * 100 + T)
+    (synth.make_tdnnf(seed=1, calib_feats=calib, orthonormal_constraint=-1.0) if BIG else synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=P, calib_feats=calib, out_std=1.5, orthonormal_constraint=-1.0)).write(f"{td}/m.raw")
+    lc = rc = (40 if BIG else 8);      # 1 (tdnn1) + the sum of the TDNN-F time strides
+    Tin = (T - 1) * s + 1 + lc + rc; rng = np.random.default_rng(B * 100 + T)
     kaldi_matrix(f"{td}/in.mat", rng.standard_normal((Tin * B, 40)) * 1.2 + 16.5)
-    den = synth.make_den_fst(120, P, seed=5, mean_degree=6.0, hub_degree=60); fsts = [synth.make_supervision_fst(T, P, seed=200 + i) for i in range(B)]; merged = synth.merge_supervision_fsts(fsts)
+    den = synth.make_den_fst(3000, P) if BIG else synth.make_den_fst(120, P, seed=5, mean_degree=6.0, hub_degree=60); fsts = [synth.make_supervision_fst(T, P, seed=200 + i) for i in range(B)]; merged = synth.merge_supervision_fsts(fsts)
     fb = lambda f: (np.ascontiguousarray(f.arc_offsets, np.int64).tobytes() + np.ascontiguousarray(f.ilabel, np.int32).tobytes() + np.ascontiguousarray(f.nextstate, np.int32).tobytes() +
                     np.ascontiguousarray(f.weight, np.float32).tobytes() + np.ascontiguousarray(f.final, np.float32).tobytes())
     so = np.concatenate([[0], np.cumsum([f.num_states for f in fsts])]).astype(np.int32); ab = np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in fsts])])
