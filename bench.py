@@ -280,6 +280,31 @@ def main():
                                       "config": f"k3_chain_objf_and_deriv (ComputeChainObjfAndDeriv: denominator + numerator + l2 + xent derivative): {cB} sequences x {cT} frames, 3000-state / {int(den.arc_offsets[-1])}-transition denominator graph, {cP} pdfs"}
                 del g_, sup, o_, d_, x_
             except Exception as e: line["chain_objf"] = {"error": repr(e)}
+        exe_train = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-chain-train")
+        if world == 1 and os.path.exists(exe_train):      # SURVEY 8f row 4, for the record (not part of `value`): whole training iterations of THIS model -- the reference's unmodified nnet3 objects over the CuMatrix adapter
+            try:
+                import struct
+                td = tempfile.mkdtemp(prefix="k3_train_"); tB, tT, tP, ts = 64, 50, num_pdfs, 3; ctx = 40      # context of the 17-layer model: 1 + the sum of the TDNN-F strides
+                synth.make_tdnnf(seed=1, calib_feats=calib, orthonormal_constraint=-1.0).write(f"{td}/m.raw")
+                rng = np.random.default_rng(7); m = np.ascontiguousarray(rng.standard_normal((((tT - 1) * ts + 1 + 2 * ctx) * tB, 40)) * 1.2 + 16.5, "<f4")
+                open(f"{td}/in.mat", "wb").write(b"\0BFM " + b"\x04" + struct.pack("<i", m.shape[0]) + b"\x04" + struct.pack("<i", m.shape[1]) + m.tobytes())
+                den = synth.make_den_fst(3000, tP); fsts = [synth.make_supervision_fst(tT, tP, seed=300 + i) for i in range(tB)]; merged = synth.merge_supervision_fsts(fsts)
+                fb = lambda f: (np.ascontiguousarray(f.arc_offsets, np.int64).tobytes() + np.ascontiguousarray(f.ilabel, np.int32).tobytes() + np.ascontiguousarray(f.nextstate, np.int32).tobytes() +
+                                np.ascontiguousarray(f.weight, np.float32).tobytes() + np.ascontiguousarray(f.final, np.float32).tobytes())
+                so = np.concatenate([[0], np.cumsum([f.num_states for f in fsts])]).astype(np.int32); ab = np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in fsts])])
+                with open(f"{td}/chain.spec", "wb") as fh:
+                    fh.write(struct.pack("<11i3f", 0x4b36, den.num_states, den.start, int(den.arc_offsets[-1]), tP, tB, tT, merged.num_states, int(merged.arc_offsets[-1]), int(so[-1]), int(ab[-1]), 1.0e-05, 5.0e-05, 1.0))
+                    fh.write(fb(den)); fh.write(fb(merged)); fh.write(so.tobytes())
+                    fh.write(np.concatenate([[0]] + [np.asarray(f.arc_offsets[1:], np.int64) + b for f, b in zip(fsts, ab[:-1])]).astype(np.int64).tobytes())
+                    for k_, dt_ in (("ilabel", np.int32), ("nextstate", np.int32), ("weight", np.float32), ("final", np.float32)): fh.write(np.concatenate([getattr(f, k_) for f in fsts]).astype(dt_).tobytes())
+                r = subprocess.run([exe_train, f"{td}/m.raw", str(ts), f"{td}/in.mat", f"{td}/chain.spec", "6", "0.001", "0.0", f"{td}/out.raw", f"{td}/out.vec"], capture_output=True, text=True, timeout=300,
+                                   env=dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"))
+                its = [float(l.rsplit("; ", 1)[1].split()[0]) for l in r.stderr.splitlines() if "iteration" in l and l.rstrip().endswith("ms")]
+                line["chain_train"] = ({"ms_per_iteration": float(np.mean(its[2:])), "first_iteration_ms": its[0], "iterations": len(its),
+                                        "config": f"tests/adapter/nnet3_chain_train.cc over kaldi_amd/adapter (NnetChainTrainer::TrainInternal's sequence: forward, k3_chain_objf_and_deriv, backward with natural-gradient updates, max-change, orthonormal constraint): the benchmark model, {tB} sequences x {tT} output frames, 3000-state denominator graph"}
+                                       if r.returncode == 0 and len(its) >= 3 else {"error": (r.stderr or "")[-300:]})
+                import shutil; shutil.rmtree(td, ignore_errors=True)
+            except Exception as e: line["chain_train"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if graph is None: graph = synth.make_hclg(args.graph_states, args.graph_arcs, num_pdfs)
