@@ -153,9 +153,9 @@ def test_chain_training_iterations_equal_the_reference(iters, momentum, tmp_path
     statistics, objective, backward with every component's natural-gradient update (OnlineNaturalGradient), L2, UpdateNnetWithMaxChange, batch-norm statistics decay, the semi-orthogonal
     constraint of the TDNN-F bottlenecks, momentum (tests/adapter/nnet3_chain_train.cc).  MI355X build: the reference's unmodified nnet3 objects over the CuMatrix adapter + k3_chain_objf_and_deriv;
     oracle build: the same source on the reference's CPU matrices and chain code.  Per-iteration objective and the trained parameters.
-    One iteration is compared strictly.  Over several iterations natural-gradient SGD amplifies float32 rounding discontinuously (the preconditioner's early eigen-decompositions): the
+    Natural-gradient SGD amplifies float32 rounding discontinuously (the preconditioner's early eigen-decompositions): the
     REFERENCE ITSELF ends 10-35 % of the training's own parameter change apart between MKL's AVX2 and AVX-512 code paths after two / three iterations on this case (measured),
-    so for N > 1 the MI355X result has to coincide with the reference under at least one of MKL's code paths (default, AVX2, AVX512, SSE4_2), to 1 % of the change."""
+    so the MI355X result has to coincide with the reference under at least one of MKL's code paths (default, AVX2, AVX512, SSE4_2): to 2e-3 of the change after one iteration, 1 % after several."""
     import struct
     from kaldi_amd import synth
     exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-chain-train"); ref = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-nnet3-chain-train")
@@ -181,7 +181,7 @@ def test_chain_training_iterations_equal_the_reference(iters, momentum, tmp_path
     p0 = np.concatenate([np.concatenate([c[2]["W"].ravel()] + ([c[2]["b"].ravel()] if "b" in c[2] and c[2]["b"].size else [])) for c in net.components if c[1] in ("affine", "tdnn", "linear")])
     assert p0.shape == gp.shape
     tried = []
-    for path in ([None] if iters == 1 else [None, "AVX512", "AVX2", "SSE4_2"]):
+    for path in [None, "AVX512", "AVX2", "SSE4_2"]:      # (one iteration: the reference's own paths are 3.5e-3 apart, tests/test_oracle_chain.py; the MI355X result has to sit within 2e-3 of one of them)
         e = dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"))
         if path: e["MKL_ENABLE_INSTRUCTIONS"] = path
         r = subprocess.run([ref] + args + [f"{td}/r.raw", f"{td}/r.vec"], capture_output=True, text=True, env=e); assert r.returncode == 0, r.stderr[-2000:]
