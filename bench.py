@@ -28,17 +28,57 @@ sys.path.insert(0, ROOT)
 
 BEAM, LATTICE_BEAM, MAX_ACTIVE = 15.0, 8.0, 10000      # BASELINE.json configs[2]: beam 15; recipes' lattice-beam 8; CudaDecoderConfig max-active
 
+def _best_path(n, start, frame, final, src, dst, il, ol, cost):
+    """tropical shortest path of a raw lattice given as arrays (states ordered by nothing in particular; arcs go forward in `frame`, epsilon arcs stay
+    inside a frame): (ilabels without 0, olabels without 0, total cost), or None.  The same routine is applied to the reference's and to the GPU's
+    lattice (GetBestPath + GetLinearSymbolSequence, decoder/decoder-wrappers.cc:322-331)."""
+    if n == 0 or start < 0: return None
+    best = np.full(n, np.inf); best[start] = 0.0; back = np.full(n, -1, np.int64)
+    order = np.argsort(frame[src], kind="stable").tolist(); srcl, dstl, cl = src.tolist(), dst.tolist(), cost.tolist(); bl = best.tolist()
+    changed = True
+    while changed:
+        changed = False
+        for a in order:
+            v = bl[srcl[a]] + cl[a]
+            if v < bl[dstl[a]]: bl[dstl[a]] = v; back[dstl[a]] = a; changed = True
+    best = np.asarray(bl); fin = np.nonzero(np.isfinite(final))[0]
+    if fin.size == 0: return None
+    end = int(fin[np.argmin(best[fin] + final[fin])])
+    if not np.isfinite(best[end]): return None
+    ils, ols, s_ = [], [], end
+    while s_ != start:
+        a = int(back[s_]); ils.append(int(il[a])); ols.append(int(ol[a])); s_ = srcl[a]
+    return [i for i in ils[::-1] if i], [o for o in ols[::-1] if o], float(best[end] + final[end])
+
+def _compare_with_gpu(ref, ref_ll, glat, gpu_ll):
+    """one utterance of the end-to-end gate (SURVEY 8d gate 4): the reference chain's lattice (its own features and log-likelihoods) against the GPU chain's"""
+    r = {"max_abs_loglike_diff": float(np.abs(ref_ll - gpu_ll).max()) if ref_ll.shape == gpu_ll.shape else float("inf")}
+    rb = _best_path(ref["frame"].size, ref["start"], ref["frame"], ref["final_graph"].astype(np.float64) + ref["final_ac"], ref["src"], ref["dst"], ref["ilabel"], ref["olabel"],
+                    ref["graph"].astype(np.float64) + ref["ac"])
+    gb = _best_path(glat.num_states, glat.start_index(), glat.st_frame, glat.st_final.astype(np.float64), glat.arc_src, glat.arc_dst, glat.arc_ilabel, glat.arc_olabel,
+                    glat.arc_graph.astype(np.float64) + glat.arc_ac)
+    r["best_path_identical"] = bool(rb is not None and gb is not None and rb[0] == gb[0] and rb[1] == gb[1])
+    r["best_cost_diff"] = abs(rb[2] - gb[2]) if (rb and gb) else float("inf")
+    key = lambda fr, s_, d_, i_, o_: np.sort((fr[s_].astype(np.int64) << 44) | ((fr[d_] - fr[s_]).astype(np.int64) << 43) | (i_.astype(np.int64) << 21) | o_.astype(np.int64))
+    ka, kb = key(ref["frame"], ref["src"], ref["dst"], ref["ilabel"], ref["olabel"]), key(glat.st_frame, glat.arc_src, glat.arc_dst, glat.arc_ilabel, glat.arc_olabel)
+    r["lattice_identical"] = bool(ka.size == kb.size and np.array_equal(ka, kb) and np.array_equal(np.bincount(ref["frame"]), np.bincount(glat.st_frame)))
+    r["ref_arcs"] = int(ka.size); r["gpu_arcs"] = int(kb.size)
+    r["arcs_only_in_one"] = int(ka.size + kb.size - 2 * np.intersect1d(ka, kb).size) if not r["lattice_identical"] else 0
+    return r
+
 def _cpu_worker(job):
-    """one host core: reference compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder::Decode on its utterances; returns (audio_s, wall_s, stage seconds)"""
+    """one host core: reference compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder::Decode on its utterances; returns (audio_s, wall_s, stage seconds,
+    per-utterance comparisons with the GPU chain's results where the job carries them)"""
     from oracle import kaldi_io as kio, lattice_oracle as lo, ref_decoder as rd
     from kaldi_amd import synth
-    wid, seeds, utt_seconds, model_path, graph, num_pdfs = job
+    wid, utts, utt_seconds, model_path, graph, num_pdfs, gpu = job          # utts: [(name, int16 samples)]; gpu: None or (lattices, loglikes, out_offsets, U)
     bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+    cmp_ = []
     with tempfile.TemporaryDirectory() as td:
         scp = []
-        for s in seeds:
-            kio.write_wav(f"{td}/u{s}.wav", synth.gaussian_pcm16(int(16000 * utt_seconds), s)); scp.append(f"u{s} {td}/u{s}.wav")
+        for name, pcm in utts:
+            kio.write_wav(f"{td}/{name}.wav", pcm); scp.append(f"{name} {td}/{name}.wav")
         open(f"{td}/wav.scp", "w").write("\n".join(scp) + "\n")
         t0 = time.time()
         subprocess.check_call([f"{bindir}/compute-fbank-feats", "--dither=0", "--num-mel-bins=40", f"scp:{td}/wav.scp", f"ark:{td}/f.ark"], env=env, stderr=subprocess.DEVNULL)
@@ -46,28 +86,83 @@ def _cpu_worker(job):
         subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], env=env, stderr=subprocess.DEVNULL)
         t2 = time.time()
         lls = kio.read_ark(f"{td}/o.ark"); cfg = lo.Config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE); t2p = synth.tid2pdf(num_pdfs)
-        dec_s = sum(rd.decode(graph, lls[k], t2p, cfg)["decode_seconds"] for k in sorted(lls))      # time inside LatticeFasterDecoder::Decode, reported by the binary
-    return len(seeds) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s)
+        dec_s = 0.0
+        for name, _ in utts:
+            ref = rd.decode(graph, lls[name], t2p, cfg); dec_s += ref["decode_seconds"]      # time inside LatticeFasterDecoder::Decode, reported by the binary
+            u = int(name[1:])
+            if gpu is not None and u < gpu[3]:
+                c = _compare_with_gpu(ref, lls[name], gpu[0][u], gpu[1][gpu[2][u]:gpu[2][u + 1]]); c["utt"] = u; cmp_.append(c)
+    return len(utts) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s), cmp_
 
-def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, utts_per_core=6, max_procs=32):
+def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utts_per_core=12, max_procs=64):
     """The same workload on the host cores, bounded sample, the way decode.sh --nj splits it: P independent single-threaded workers, each running
-    the REFERENCE's own binaries (oracle/_ref, built from /root/reference by oracle/build_ref.sh) on its utterances."""
+    the REFERENCE's own binaries (oracle/_ref, built from /root/reference by oracle/build_ref.sh) on its utterances.  Utterance u of the sample is the
+    GPU batch's utterance u (same PCM16, `pcm_of(u)`); with `gpu` = (raw lattices, log-likelihoods, row offsets, U) of the GPU chain on that batch the
+    workers also compare the two chains' results utterance by utterance: the end-to-end parity gate of SURVEY 8d.  Returns (cpu_baseline, e2e_parity)."""
     from oracle import ref_decoder as rd
     bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
     if not (os.path.exists(os.path.join(bindir, "nnet3-compute")) and rd.available()):
-        return {"error": "oracle/_ref is not built (needs /root/reference once; it travels to the GPU box)"}
+        return {"error": "oracle/_ref is not built (needs /root/reference once; it travels to the GPU box)"}, None
     ncores = os.cpu_count() or 1; P = max(1, min(ncores, max_procs))
-    _cpu_worker((99, [99], 1.0, model_path, graph, num_pdfs))            # untimed warm-up: pages the binaries and MKL in
-    jobs = [(w, [1234 + w * utts_per_core + k for k in range(utts_per_core)], utt_seconds, model_path, graph, num_pdfs) for w in range(P)]
+    from kaldi_amd import synth
+    _cpu_worker((99, [("u99999", synth.gaussian_pcm16(16000, 99))], 1.0, model_path, graph, num_pdfs, None))            # untimed warm-up: pages the binaries and MKL in
+    # round-robin over the workers, so that the compared utterances 0 .. P * utts_per_core - 1 are spread evenly
+    jobs = [(w, [(f"u{u}", pcm_of(u)) for u in range(w, P * utts_per_core, P)], utt_seconds, model_path, graph, num_pdfs, gpu) for w in range(P)]
     t0 = time.time()
-    with ThreadPoolExecutor(P) as ex: res = list(ex.map(_cpu_worker, jobs))      # threads only launch and wait for the single-threaded reference processes
+    with ThreadPoolExecutor(P) as ex: res = list(ex.map(_cpu_worker, jobs))      # threads only launch and wait for the single-threaded reference processes (and compare lattices)
     wall = time.time() - t0
     audio = sum(r[0] for r in res); per_core = [r[0] / r[1] for r in res]; st = np.sum([r[2] for r in res], axis=0)
-    return {"value": audio / max(r[1] for r in res), "unit": "RTFx (audio-s/wall-s)", "cores": P, "kind": "reference", "host_cores_available": ncores,
-            "per_core_rtfx_mean": float(np.mean(per_core)), "wall_s_including_process_startup": wall,
-            "sample": f"{P} single-threaded workers x {utts_per_core} x {utt_seconds:g} s utts (like decode.sh --nj {P}); aggregate = audio / slowest worker; per stage over all workers: "
+    base = {"value": audio / max(r[1] for r in res), "unit": "RTFx (audio-s/wall-s)", "cores": P, "kind": "reference", "host_cores_available": ncores,
+            "per_core_rtfx_mean": float(np.mean(per_core)), "extrapolated_all_cores": float(np.mean(per_core)) * ncores,
+            "extrapolated_all_cores_note": f"per-core mean x {ncores} host cores (not measured: memory bandwidth and SMT are shared; an upper bound)",
+            "wall_s_including_process_startup": wall,
+            "sample": f"{P} single-threaded workers x {utts_per_core} x {utt_seconds:g} s utts (like decode.sh --nj {P}; utterance u = the GPU batch's utterance u, same PCM16); aggregate = audio / slowest worker (process "
+                      f"start-up and the comparison excluded: sum of the three binaries' own run times); per stage over all workers: "
                       f"reference compute-fbank-feats {audio / st[0]:.0f}x RT, reference nnet3-compute {audio / st[1]:.0f}x RT, reference LatticeFasterDecoder::Decode {audio / st[2]:.0f}x RT "
                       "(decoder/lattice-faster-decoder.cc compiled unmodified; FST containers from oracle/ref_tools/minifst because OpenFst is not vendored)"}
+    par = None
+    cmp_ = sorted((c for r in res for c in r[3]), key=lambda c: c["utt"])
+    if cmp_:
+        nb_ = sum(c["best_path_identical"] for c in cmp_); nl = sum(c["lattice_identical"] for c in cmp_)
+        bad = [c for c in cmp_ if not c["best_path_identical"]]
+        par = {"utterances": len(cmp_), "best_path_identical": nb_, "best_path_identical_frac": nb_ / len(cmp_), "raw_lattice_identical": nl,
+               "max_abs_loglike_diff": max(c["max_abs_loglike_diff"] for c in cmp_), "max_best_cost_diff": max(c["best_cost_diff"] for c in cmp_),
+               "raw_lattice_arcs_only_in_one_total": sum(c["arcs_only_in_one"] for c in cmp_), "raw_lattice_arcs_total": sum(c["ref_arcs"] for c in cmp_),
+               "best_path_mismatches": [{"utt": c["utt"], "best_cost_diff": c["best_cost_diff"], "max_abs_loglike_diff": c["max_abs_loglike_diff"]} for c in bad[:16]],
+               "note": "reference chain = compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder (oracle/_ref binaries built from /root/reference) on the SAME PCM16 as the GPU batch; GPU chain = the timed path "
+                       "(k3_feat -> k3_nnet_forward -> k3_decoder literal_order=1).  best_path_identical: (transition-ids, words) of the tropical best path of the two raw lattices equal "
+                       "(decoder-wrappers.cc:322-331).  raw_lattice_identical: same states per frame and the same multiset of arcs (source frame, emitting/epsilon, ilabel, olabel); the cost BITS cannot be "
+                       "equal because the two chains' log-likelihoods differ by max_abs_loglike_diff (<= 1e-4 is north_star's bound); on the GPU's own log-likelihoods the decoder is bit-identical to the "
+                       "reference's (tests/test_decoder_literal_gpu.py).  A best-path mismatch with best_cost_diff below frames x max_abs_loglike_diff is a tie broken by the log-likelihood difference."}
+    return base, par
+
+TRAFFIC_CMD = ("cd /tmp && TMPDIR=/tmp rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -d <dir> -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline "
+               "--no-two-pass --no-extras  (one pass per counter, no trace domains; Counter_Value of k3_decode_forward_literal_kernel summed over its dispatches / dispatches x 1024; "
+               "`bench.py --measure-traffic` runs exactly this and tools/profile_round.sh commits its raw csv)")
+
+def measure_traffic(args):
+    """HBM-side traffic of the token-passing kernel from the PMC counters, collected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: one rocprofv3 --pmc pass per counter,
+    no trace domains, over a one-step run of this script.  Returns {fetch,write,traffic}_bytes_per_launch or {"error": ...}."""
+    import csv, glob, shutil
+    if shutil.which("rocprofv3") is None: return {"error": "rocprofv3 not on PATH"}
+    out = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"k3_pmc_{c}_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pipeline",
+               "--no-two-pass", "--no-extras", "--utts", str(args.utts), "--utt-seconds", str(args.utt_seconds), "--graph-states", str(args.graph_states), "--graph-arcs", str(args.graph_arcs)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+            f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
+            if r.returncode != 0 or not f: return {"error": f"rocprofv3 --pmc {c} failed: rc {r.returncode} {r.stderr[-300:]}"}
+            disp = set(); tot = 0.0
+            for row in csv.DictReader(open(f[0])):
+                if row.get("Counter_Name") == c and "k3_decode_forward_literal_kernel" in row["Kernel_Name"]: disp.add(row["Dispatch_Id"]); tot += float(row["Counter_Value"])
+            if not disp: return {"error": f"no dispatch of the kernel in the {c} pass"}
+            out[c] = tot / len(disp) * 1024.0
+            keep = os.path.join(ROOT, "gpurun_out", "pmc_in_run"); os.makedirs(keep, exist_ok=True); shutil.copy(f[0], os.path.join(keep, f"{c}_counter_collection.csv"))
+        except Exception as e: return {"error": repr(e)}
+        finally: shutil.rmtree(d, ignore_errors=True)
+    return {"fetch_bytes_per_launch": out["FETCH_SIZE"], "write_bytes_per_launch": out["WRITE_SIZE"], "traffic_bytes_per_launch": out["FETCH_SIZE"] + out["WRITE_SIZE"]}
 
 def main():
     if os.environ.get("K3HIP_LIB"): raise SystemExit("bench.py measures the shipped kaldi_amd/lib/libk3hip.so only: unset K3HIP_LIB (developer override for profiling builds)")
@@ -78,6 +173,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-two-pass", action="store_true", help="skip the second (order-independent decoder) measurement")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: H2D, fbank, TDNN-F and decoder of a batch strictly after the previous batch (stage_ms then adds up to ms_per_step)")
+    ap.add_argument("--cpu-procs", type=int, default=64, help="cpu_baseline / e2e_parity: single-threaded reference workers (capped by the host's cores)")
+    ap.add_argument("--cpu-utts-per-core", type=int, default=8, help="cpu_baseline / e2e_parity: utterances per worker (utterance u = the GPU batch's utterance u while u < --utts)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the chain_objf / chain_train legs (for the record only; not part of `value`)")
+    ap.add_argument("--measure-traffic", action="store_true", help="roofline.traffic measured in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; no trace domains) of `bench.py --steps 1 --warmup 0` as child processes (adds ~2 min)")
+    ap.add_argument("--lattice-digest", action="store_true", help="decode_stats.lattice_digest: a hash of the canonical form of every raw lattice of the last timed batch")
     ap.add_argument("--det-threads", type=int, default=0, help="host threads of the determinization pool (0 = all cores / ranks)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -95,16 +195,20 @@ def main():
 
     U, nsamp = args.utts, int(16000 * args.utt_seconds)
     det_threads = args.det_threads or max(1, (os.cpu_count() or 1) // world)
-    # synthetic workload: Gaussian PCM16 sigma 3000, per-rank seed, in page-locked host memory; 17L-768/96-6024 TDNN-F, seed 1
-    g = torch.Generator(device="cpu"); g.manual_seed(1234 + rank)
-    pcm_host = (torch.randn(U * nsamp, generator=g) * 3000).round().clamp(-32768, 32767).to(torch.int16).pin_memory()
+    # synthetic workload: Gaussian PCM16 sigma 3000, utterance u of rank r = synth.gaussian_pcm16(nsamp, 1234 + 100000 r + u), in page-locked host memory
+    # (one spare utterance behind the batch: timed step k reads the batch from sample offset shift(k), so no two steps decode the same audio);
+    # 17L-768/96-6024 TDNN-F, seed 1
+    pcm_host = torch.empty((U + 1) * nsamp, dtype=torch.int16).pin_memory(); pcm_np = pcm_host.numpy()
+    def pcm_of(u, r=rank): return synth.gaussian_pcm16(nsamp, 1234 + 100000 * r + u)
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+        for u, w in enumerate(ex.map(pcm_of, range(U + 1))): pcm_np[u * nsamp:(u + 1) * nsamp] = w
+    shift_of = lambda k: (k * 40009) % nsamp            # batch k of a run starts here (k = 0: the utterances as generated)
     pcm_dev = torch.empty(U * nsamp, dtype=torch.int16, device=dev)
     sf = feat.SpectralFeatures(feat.fbank_options(dither=0.0, num_bins=40))
     wo, fo, total_frames, fo_h = sf.offsets([nsamp] * U, dev)
     model_path = os.path.join(tempfile.gettempdir(), f"k3_bench_tdnnf_{rank}.raw")
     # BatchNorm calibration on real fbank features of rank 0's first utterance (same model on every rank)
-    g0 = torch.Generator(device="cpu"); g0.manual_seed(1234)
-    w0 = (torch.randn(nsamp, generator=g0) * 3000).round().clamp(-32768, 32767).to(dev)
+    w0 = torch.from_numpy(pcm_of(0, 0).astype(np.float32)).to(dev)
     calib = sf.ComputeFeatures(w0, *sf.offsets([nsamp], dev)[:3]).cpu().numpy()[:600]
     net_spec = synth.make_tdnnf(seed=1, calib_feats=calib); net_spec.write(model_path)
     net = nnet3.Nnet(model_path); num_pdfs = net.info.output_dim
@@ -140,14 +244,15 @@ def main():
     pipelined = not args.no_pipeline      # the next batch's front end (H2D + fbank + TDNN-F) on a second stream, queued behind the present batch's decoder
     front = torch.cuda.Stream(device=dev); fev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(2)]; dec_done = [torch.cuda.Event() for _ in range(2)]
     ll2 = [loglikes, torch.empty_like(loglikes) if pipelined else loglikes]
-    def run(mode, steps, warmup, pipelined=pipelined):
+    def run(mode, steps, warmup, pipelined=pipelined, vary=True, keep=None):
         """W untimed + K timed steps of the whole path in one decoder mode; returns (wall seconds of the K steps, per-stage ms, last lattice sizes, determinized sizes)"""
-        dec = decs.get(mode); lat_sizes = [0, 0]; det_sizes = [0, 0]; pending = []; nstep = [0]
+        dec = decs.get(mode); lat_sizes = [0, 0, None]; det_sizes = [0, 0]; pending = []; nstep = [0]; nser = [0]; last = [None]
+        src = lambda k: pcm_host[shift_of(k) if vary else 0:][:U * nsamp]      # batch k's audio
         for e in dec_done: e.record()
         def front_end(k):      # batch k's H2D + fbank + TDNN-F on the front stream, into log-likelihood buffer k & 1 (last read by the decoder two batches ago)
             with torch.cuda.stream(front):
                 front.wait_event(dec_done[k & 1])
-                fev[k & 1][0].record(); pcm_dev.copy_(pcm_host, non_blocking=True)
+                fev[k & 1][0].record(); pcm_dev.copy_(src(k), non_blocking=True)
                 fev[k & 1][1].record(); sf.ComputeFeatures(pcm_dev, wo, fo, total_frames, out=feats)
                 fev[k & 1][2].record(); nb.forward(feats, out=ll2[k & 1])
                 fev[k & 1][3].record()
@@ -160,14 +265,14 @@ def main():
             front_end(k + 1)       # queued behind the decoder: its workgroups take the CUs the decoder's lanes leave as they finish
             if timed: ev[4].record()
             while len(pending) >= 2: r = pending.pop(0).result(); det_sizes[0], det_sizes[1] = r
-            lats = dec.GetRawLattices()
+            lats = dec.GetRawLattices(); last[0] = lats
             lat_sizes[0] = int(lats.state_offsets[-1]); lat_sizes[1] = int(lats.arc_offsets[-1])
             if timed: ev[5].record()
             pending.append(pool.submit(postprocess, lats))
         def step(timed):
             if pipelined and dec is not None: return step_pipelined(timed)
             if timed: ev[0].record()
-            pcm_dev.copy_(pcm_host, non_blocking=True)                     # first waveform byte leaves host memory
+            pcm_dev.copy_(src(nser[0]), non_blocking=True); nser[0] += 1     # first waveform byte leaves host memory
             if timed: ev[1].record()
             sf.ComputeFeatures(pcm_dev, wo, fo, total_frames, out=feats)
             if timed: ev[2].record()
@@ -177,7 +282,9 @@ def main():
                 dec.DecodeBatch(loglikes, nb.out_offsets)
                 if timed: ev[4].record()
                 while len(pending) >= 2: r = pending.pop(0).result(); det_sizes[0], det_sizes[1] = r      # the host buffers of batch k-2 are about to be reused
-                lats = dec.GetRawLattices()          # synchronises: compaction kernel + D2H of the pruned lattices
+                lats = dec.GetRawLattices(copy=keep is not None)          # synchronises: compaction kernel + D2H of the pruned lattices
+                if keep is not None: keep.append(lats)
+                last[0] = lats
                 lat_sizes[0] = int(lats.state_offsets[-1]); lat_sizes[1] = int(lats.arc_offsets[-1])
                 if timed: ev[5].record()
                 pending.append(pool.submit(postprocess, lats))
@@ -201,6 +308,12 @@ def main():
         torch.cuda.synchronize()
         if world > 1: dist.barrier()
         dt = time.perf_counter() - t0
+        if args.lattice_digest and last[0] is not None:      # identity of the last batch's raw lattices (canonical form: states by (frame, HCLG state), arcs sorted, cost bits included)
+            import hashlib
+            h = hashlib.blake2b(digest_size=16)
+            for lat in last[0]:
+                for a in lat.canonical(): h.update(np.ascontiguousarray(a).tobytes())
+            lat_sizes[2] = h.hexdigest()
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = t.item()
         return dt, acc / steps, lat_sizes, det_sizes
@@ -244,18 +357,29 @@ def main():
                 "roofline_gemm": {"bound": "mfma", "kernel": "k3_tdnn_gemm_kernel (all launches of one forward)", "achieved": gemm_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": gemm_tf / 157.3,
                                   "forward_back_to_back_ms": fwd_ms, "frac_back_to_back": nb.flops / (fwd_ms * 1e-3) / 1e12 / 157.3,
                                   "note": "exact sum(2MNK) of the launched GEMMs / HIP-event time of the forward on the launch stream; FP32 MFMA peak (the only MFMA class inside the 1e-4 bound); achieved / frac: the forward as a stage of the serial pass (after the decoder); frac_back_to_back: four forwards in a row"}}
+        fb_bytes = float(total_frames) * (160 * 2 + sf.dim * 4)      # the 160 new PCM16 samples a frame brings in + its output row
+        line["roofline_feat"] = {"bound": "hbm", "kernel": "k3_feat_kernel (k3_feat_compute_batch_pcm16: window, FFT, mel, log in one launch)", "achieved": fb_bytes / (acc[1] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": fb_bytes / (acc[1] * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": fb_bytes,
+                                 "note": "480 B per frame (160 new 16-bit samples in, 40 floats out) / HIP-event time of the stage in the serial pass; the kernel is ~15 kflop per frame of FFT + mel work through LDS, 1 ms of a step"}
         if decs:
             dec = decs["literal"]; info = dec.LatticeInfo(); ab = dec.algorithmic_bytes(info); gbs = ab / (acc[5] * 1e-3) / 1e9
             line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_literal_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                 "traffic": None, "traffic_measured_in_run": False, "algorithmic_bytes_per_launch": ab,
                                 "note": "algorithmic bytes (SURVEY 8d: 32 B/emitting arc traversed + 28 B/eps arc traversed + 16 B/token) from device counters / HIP-event time of the kernel on its launch stream; "
                                         "the kernel moves ~10x these bytes through the memory system in 4-64 B requests (per-lane scratch that does not stay in L2; `traffic`) and is bound by that transaction rate (~2 TB/s) and the per-frame chain of dependent phases, not by peak bandwidth"}
-            try:      # HBM traffic of the same kernel from the committed rocprofv3 PMC passes of this round (bench.py cannot collect counters itself)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_r02.json")))
-                if U == 512 and args.utt_seconds == 10.0: line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]; line["roofline"]["traffic_source"] = tj["source"]
-            except Exception: pass
+            line["roofline"]["traffic_command"] = TRAFFIC_CMD
+            tr = measure_traffic(args) if (args.measure_traffic and world == 1) else None
+            if tr and "traffic_bytes_per_launch" in tr:
+                line["roofline"].update(traffic=tr["traffic_bytes_per_launch"], traffic_measured_in_run=True, traffic_fetch=tr["fetch_bytes_per_launch"], traffic_write=tr["write_bytes_per_launch"],
+                                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (KB x 1024, per launch of the kernel)")
+            else:
+                if tr: line["roofline"]["traffic_error"] = tr.get("error")
+                try:      # the committed PMC passes of the round (the same command, run by tools/profile_round.sh)
+                    tj = json.load(open(sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "hbm_traffic_r*.json")))[-1]))
+                    if U == 512 and args.utt_seconds == 10.0: line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]; line["roofline"]["traffic_source"] = tj["source"]
+                except Exception: pass
             line["decode_stats"] = {"graph_broadcast_s": t_bcast if world > 1 else 0.0, "emitting_arcs_traversed": int(info[:, 7].sum()), "eps_arcs_traversed": int(info[:, 8].sum()), "tokens": int(info[:, 4].sum()),
-                                    "links": int(info[:, 5].sum()), "max_tokens_on_a_frame": int(info[:, 6].max()), "lattice_states": lat_sizes[0], "lattice_arcs": lat_sizes[1],
+                                    "links": int(info[:, 5].sum()), "max_tokens_on_a_frame": int(info[:, 6].max()), "lattice_states": lat_sizes[0], "lattice_arcs": lat_sizes[1], "lattice_digest": lat_sizes[2],
                                     "determinized_states": det_sizes[0], "determinized_arcs": det_sizes[1], "reached_final_frac": float(info[:, 3].mean()), "algorithmic_bytes": ab,
                                     "order_sensitive_events": int(dec.OrderSensitiveEvents().sum())}
             if two is not None:
@@ -264,10 +388,10 @@ def main():
                 line["two_pass"] = {"note": "same pipeline with the order-independent decoder (literal_order = 0): faster, lattices close to but NOT identical with the reference's at this configuration",
                                     "ms_per_step": 1000.0 * dt2 / args.steps, "stage_ms": {"pcm16_h2d": acc2[0], "fbank": acc2[1], "nnet3": acc2[2], "decode": acc2[3], "decode.token_passing_kernel": acc2[5], "decode.lattice_prune_kernel": acc2[6], "lattice_compact_and_d2h": acc2[4]},
                                     "roofline": {"bound": "hbm", "kernel": "k3_decode_forward_kernel", "achieved": ab2 / (acc2[5] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ab2 / (acc2[5] * 1e-3) / 1e9 / 8000.0},
-                                    "lattice_states": ls2[0], "lattice_arcs": ls2[1], "order_sensitive_upper_bound": int(d2.OrderSensitiveEvents().sum())}
+                                    "lattice_states": ls2[0], "lattice_arcs": ls2[1], "lattice_digest": ls2[2], "order_sensitive_upper_bound": int(d2.OrderSensitiveEvents().sum())}
         else:
             line["roofline"] = dict(line["roofline_gemm"], traffic=None)
-        if world == 1:      # the LF-MMI objective + derivatives of a training-sized minibatch, for the record (not part of `value`)
+        if world == 1 and not args.no_extras:      # the LF-MMI objective + derivatives of a training-sized minibatch, for the record (not part of `value`)
             try:
                 from kaldi_amd import chain
                 cB, cT, cP = 128, 50, 4000; den = synth.make_den_fst(3000, cP); g_ = chain.DenominatorGraph(den, cP)
@@ -281,7 +405,7 @@ def main():
                 del g_, sup, o_, d_, x_
             except Exception as e: line["chain_objf"] = {"error": repr(e)}
         exe_train = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-chain-train")
-        if world == 1 and os.path.exists(exe_train):      # SURVEY 8f row 4, for the record (not part of `value`): whole training iterations of THIS model -- the reference's unmodified nnet3 objects over the CuMatrix adapter
+        if world == 1 and not args.no_extras and os.path.exists(exe_train):      # SURVEY 8f row 4, for the record (not part of `value`): whole training iterations of THIS model -- the reference's unmodified nnet3 objects over the CuMatrix adapter
             try:
                 import struct
                 td = tempfile.mkdtemp(prefix="k3_train_"); tB, tT, tP, ts = 64, 50, num_pdfs, 3; ctx = 40      # context of the 17-layer model: 1 + the sum of the TDNN-F strides
@@ -308,7 +432,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if graph is None: graph = synth.make_hclg(args.graph_states, args.graph_arcs, num_pdfs)
-                line["cpu_baseline"] = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds)
+                gpu = None
+                if decs:      # the end-to-end gate: one more (serial) pass over the batch as generated (shift 0), its raw lattices and log-likelihoods kept for the comparison
+                    keep = []; run("literal", 1, 0, pipelined=False, vary=False, keep=keep)
+                    gpu = (keep[0], loglikes.cpu().numpy(), np.asarray(nb.out_offsets), U)
+                line["cpu_baseline"], par = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds, pcm_of, gpu, utts_per_core=args.cpu_utts_per_core, max_procs=args.cpu_procs)
+                if par is not None: line["e2e_parity"] = par
             except Exception as e: line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line))
     pool.shutdown()

@@ -6,7 +6,7 @@
 // every caller of these two classes (the batched pipelines, cudadecoderbin/*) compiling; what the classes do happens in the HIP kernels.
 // Differences from the reference, all of them in the direction of the CPU decoder:
 //   * results: with config.literal_order the raw lattice is LatticeFasterDecoder's own, bit for bit (the reference's GPU decoder is not);
-//   * a lane is a channel: the decoder keeps `nchannels` lanes resident (nlanes <= nchannels is accepted and ignored);
+//   * a lane is a channel: the decoder keeps `nchannels` lanes resident; nlanes (<= nchannels) bounds the batch of one AdvanceDecoding call only;
 //   * queue overflow is an error for that channel (CudaDecoderException, recoverable), never a silently narrowed beam (cuda-decoder.cc:944-976);
 //   * lattice-beam pruning and the raw-lattice build run on the GPU inside GetRawLattice / PrepareForGetRawLattice, so
 //     ConcurrentGetRawLatticeSingleChannel only unpacks host arrays (thread-safe per channel like the reference's).
@@ -50,6 +50,7 @@ struct CudaDecoderConfig {
   int32 min_active = 200;              // LatticeFasterDecoderConfig::min_active (the reference GPU decoder has no such knob; the CPU decoder does)
   BaseFloat beam_delta = 0.5, hash_ratio = 2.0;
   bool literal_order = true;           // raw lattices identical to LatticeFasterDecoder's (k3_decoder_config.literal_order)
+  int32 max_frames_per_channel = 3000; // frames a channel can hold before GetRawLattice (the reference keeps a channel's tokens in host memory and has no such bound; here they stay in HBM)
   void Check() const { KALDI_ASSERT(default_beam > 0.0 && max_active > 1 && lattice_beam > 0.0 && (aux_q_capacity == -1 || aux_q_capacity >= main_q_capacity)); }
   void ComputeConfig() { if (main_q_capacity == -1) main_q_capacity = 4 * max_active; if (aux_q_capacity == -1) aux_q_capacity = 3 * main_q_capacity; }
 };
@@ -76,36 +77,43 @@ class CudaFst {
     num_states_ = (int32)fin.size(); start_ = fst.Start(); num_arcs_ = (int64)il.size();
     std::vector<int32> tid2pdf(max_tid + 1, 0);
     for (int32 t = 1; t <= max_tid; t++) tid2pdf[t] = trans_model ? trans_model->TransitionIdToPdf(t) : t - 1;      // no model: ilabels are pdf-ids + 1 (cuda-fst.cc:166-175)
+    num_pdfs_ = 0;      // columns of a log-likelihood row the graph can ask for (the reference sizes its rows by max_ilabel_ the same way, cuda-fst.cc:139-141)
+    for (int32 l : il) if (l != 0) num_pdfs_ = std::max<int32>(num_pdfs_, tid2pdf[l] + 1);
     K3_CUDEC_CALL(k3_fst_create(num_states_, start_, off.data(), il.data(), ol.data(), w.data(), nx.data(), fin.data(), tid2pdf.data(), (int32)tid2pdf.size(), &fst_));
   }
   void Finalize() { if (fst_) k3_fst_destroy(fst_); fst_ = NULL; }
   ~CudaFst() { Finalize(); }
   inline uint32_t NumStates() const { return (uint32_t)num_states_; }
   inline int32 Start() const { return start_; }
+  inline int32 NumPdfs() const { return num_pdfs_; }      // 1 + the largest pdf-id on an arc
   const k3_fst *Handle() const { return fst_; }
  private:
   CudaFst(const CudaFst &); CudaFst &operator=(const CudaFst &);
-  k3_fst *fst_ = NULL; int32 num_states_ = 0, start_ = 0; int64 num_arcs_ = 0;
+  k3_fst *fst_ = NULL; int32 num_states_ = 0, start_ = 0, num_pdfs_ = 0; int64 num_arcs_ = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- CudaDecoder
 class CudaDecoder {
  public:
-  // cuda-decoder.h:224-232.  num_pdfs = columns of the log-likelihood rows handed to AdvanceDecoding.
-  CudaDecoder(const CudaFst &fst, const CudaDecoderConfig &config, int32 nlanes, int32 nchannels, int32 num_pdfs, int32 max_frames_per_channel = 3000)
-      : fst_(fst), nchannels_(nchannels), num_pdfs_(num_pdfs), raw_(nchannels), raw_lock_(nchannels) {
-    (void)nlanes;
+  // cuda-decoder.h:224-232, the reference's two constructors with the reference's argument lists.  nlanes = the largest batch AdvanceDecoding is
+  // called with (the reference's "lanes"); every channel keeps its own state resident, so nlanes only bounds the batch (checked there).  The
+  // width of a log-likelihood row is the graph's: CudaFst::NumPdfs().
+  CudaDecoder(const CudaFst &fst, const CudaDecoderConfig &config, int32 nlanes, int32 nchannels)
+      : fst_(fst), nlanes_(nlanes), nchannels_(nchannels), num_pdfs_(fst.NumPdfs()), raw_(nchannels), raw_lock_(nchannels) {
+    KALDI_ASSERT(nlanes > 0 && nchannels > 0 && nlanes <= nchannels);      // cuda-decoder.cc:66-68
     CudaDecoderConfig c = config; c.Check(); c.ComputeConfig();
     k3_decoder_config kc; k3_decoder_config_default(&kc);
     kc.beam = c.default_beam; kc.lattice_beam = c.lattice_beam; kc.max_active = c.max_active; kc.min_active = std::min(c.min_active, c.max_active - 1); kc.beam_delta = c.beam_delta;
     kc.frame_tokens_cap = std::min(65536, std::max(c.main_q_capacity, 4096)); kc.frame_cands_cap = std::max(c.aux_q_capacity, 2 * kc.frame_tokens_cap);
     kc.lane_tokens_cap = std::max<int64_t>(c.ntokens_pre_allocated, kc.frame_tokens_cap); kc.lane_links_cap = 2 * kc.lane_tokens_cap;
     kc.literal_order = c.literal_order ? 1 : 0; kc.hash_ratio = c.hash_ratio;
-    K3_CUDEC_CALL(k3_decoder_create(fst.Handle(), &kc, nchannels, num_pdfs, &dec_));
-    K3_CUDEC_CALL(k3_decoder_init_decoding(dec_, nchannels, max_frames_per_channel, NULL));
+    K3_CUDEC_CALL(k3_decoder_create(fst.Handle(), &kc, nchannels, num_pdfs_, &dec_));
+    K3_CUDEC_CALL(k3_decoder_init_decoding(dec_, nchannels, c.max_frames_per_channel, NULL));
     partial_.resize(nchannels); endpoint_.assign(nchannels, false);
   }
-  CudaDecoder(const CudaFst &fst, const CudaDecoderConfig &config, int32 nchannels, int32 num_pdfs) : CudaDecoder(fst, config, nchannels, nchannels, num_pdfs) {}
+  CudaDecoder(const CudaFst &fst, const CudaDecoderConfig &config, int32 nchannels) : CudaDecoder(fst, config, nchannels, nchannels) {}
+  // cuda-decoder.h:338-345: the reference hands the host-side lattice preparation to CPU workers; here that work runs on the GPU (pruning + compaction kernels), nothing to start
+  template <typename ThreadPoolT> void SetThreadPoolAndStartCPUWorkers(ThreadPoolT *, int32) {}
   virtual ~CudaDecoder() { if (dec_) k3_decoder_destroy(dec_); }
 
   // cuda-decoder.h:240: (re)start the listed channels
@@ -115,6 +123,7 @@ class CudaDecoder {
   }
   // cuda-decoder.h:262: one more frame for every listed channel; the second member of a pair is a DEVICE pointer to that frame's log-likelihoods
   void AdvanceDecoding(const std::vector<std::pair<ChannelId, const BaseFloat *>> &lanes_assignements) {
+    KALDI_ASSERT((int32)lanes_assignements.size() <= nlanes_);      // cuda-decoder.cc:1183
     std::vector<ChannelId> ch; std::vector<const float *> rows;
     for (const auto &p : lanes_assignements) { ch.push_back(p.first); rows.push_back(p.second); }
     K3_CUDEC_CALL(k3_decoder_advance_decoding_lanes(dec_, (int32)ch.size(), ch.data(), rows.data(), 1, num_pdfs_, NULL));
@@ -219,7 +228,7 @@ class CudaDecoder {
       }
     }
   }
-  const CudaFst &fst_; int32 nchannels_, num_pdfs_; k3_decoder *dec_ = NULL;
+  const CudaFst &fst_; int32 nlanes_, nchannels_, num_pdfs_; k3_decoder *dec_ = NULL;
   bool generate_partial_hypotheses_ = false, endpointing_ = false; BaseFloat frame_shift_seconds_ = FLT_MAX;
   std::vector<PartialHypothesis> partial_; std::vector<bool> endpoint_; std::vector<std::string> word_syms_; std::set<int32> silence_tids_; std::vector<EndpointRule> rules_;
   std::vector<Raw> raw_; std::vector<std::mutex> raw_lock_;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <cstdio>
 #include <iostream>
+#include <memory>
 #include <vector>
 #include "k3_cuda_decoder.h"
 using namespace kaldi; using namespace kaldi::cuda_decoder;
@@ -39,8 +40,16 @@ int main(int argc, char **argv) {
     CudaFst cuda_fst(graph, &trans);
     CudaDecoderConfig cfg; cfg.default_beam = c[0]; cfg.lattice_beam = c[1]; cfg.beam_delta = c[2]; cfg.hash_ratio = c[3]; cfg.max_active = h[7]; cfg.min_active = h[8];
     cfg.main_q_capacity = 65536; cfg.aux_q_capacity = 262144; cfg.ntokens_pre_allocated = 2500000;
-    const int32 nchannels = 2;
-    CudaDecoder decoder(cuda_fst, cfg, nchannels, nchannels, P, T + 8);
+    const int32 max_batch_size = 1, num_channels = 2;
+    cfg.max_frames_per_channel = T + 8;
+    // constructed the way the reference's online pipeline does (cudadecoder/batched-threaded-nnet3-cuda-online-pipeline.cc:125-136): (fst, config, nlanes, nchannels)
+    std::unique_ptr<CudaDecoder> cuda_decoder;
+    cuda_decoder.reset(new CudaDecoder(cuda_fst, cfg, max_batch_size, num_channels));
+    cuda_decoder->SetThreadPoolAndStartCPUWorkers((void *)NULL, 2);
+    cuda_decoder->SetOutputFrameShiftInSeconds(0.03f);
+    CudaDecoder &decoder = *cuda_decoder;
+    if (cuda_fst.NumPdfs() > P) { std::cerr << "graph needs " << cuda_fst.NumPdfs() << " pdfs, rows have " << P << "\n"; return 4; }
+    { CudaDecoder three_args(cuda_fst, cfg, num_channels); (void)three_args; }      // cuda-decoder.h:230-232
     decoder.AllowPartialHypotheses();
     float *d_ll = NULL;
     if (hipMalloc((void **)&d_ll, sizeof(float) * ll.size()) != hipSuccess || hipMemcpy(d_ll, ll.data(), sizeof(float) * ll.size(), hipMemcpyHostToDevice) != hipSuccess) { std::cerr << "hip alloc/copy failed\n"; return 3; }

@@ -47,7 +47,7 @@ def test_bench_pipelined_steps_give_the_single_stream_lattices():
     carry the serial pass's stage times next to the pipelined steps'."""
     import json, subprocess, sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--utts", "24", "--utt-seconds", "3", "--graph-states", "30000", "--graph-arcs", "80000", "--no-cpu-baseline"]
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--utts", "24", "--utt-seconds", "3", "--graph-states", "30000", "--graph-arcs", "80000", "--no-cpu-baseline", "--lattice-digest"]
     lines = []
     for extra in ([], ["--no-pipeline"]):
         r = subprocess.run(common + extra, capture_output=True, text=True, timeout=600); assert r.returncode == 0, r.stderr[-3000:]
@@ -55,7 +55,8 @@ def test_bench_pipelined_steps_give_the_single_stream_lattices():
     a, b = lines
     for k in ("lattice_states", "lattice_arcs", "determinized_states", "determinized_arcs", "tokens", "emitting_arcs_traversed", "order_sensitive_events"):      # (eps_arcs_traversed counts the fixpoint's re-expansions, which depend on timing)
         assert a["decode_stats"][k] == b["decode_stats"][k] and a["decode_stats"][k] > 0, k
-    assert a["two_pass"]["lattice_arcs"] == b["two_pass"]["lattice_arcs"]
+    assert a["decode_stats"]["lattice_digest"] == b["decode_stats"]["lattice_digest"] and len(a["decode_stats"]["lattice_digest"]) == 32      # the lattices themselves (canonical form, cost bits included)
+    assert a["two_pass"]["lattice_arcs"] == b["two_pass"]["lattice_arcs"] and a["two_pass"]["lattice_digest"] == b["two_pass"]["lattice_digest"]
     assert a["pipeline"].startswith("batch k+1") and b["pipeline"].startswith("none") and a["stage_ms_in_pipeline"] is not None and b["stage_ms_in_pipeline"] is None
     assert set(a["stage_ms"]) == set(b["stage_ms"]) and all(v > 0 for v in a["stage_ms"].values())
     assert a["roofline"]["frac"] > 0 and a["roofline_gemm"]["frac_back_to_back"] > 0 and a["cpu_baseline"] is None if "cpu_baseline" in a else True

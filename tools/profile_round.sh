@@ -6,10 +6,10 @@
 set -u
 TAG=${1:-rXX}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
-B="python $ROOT/bench.py --no-cpu-baseline --no-pipeline"      # one stream: every kernel has the GPU to itself (what bench.py's roofline objects are computed from, too)
+B="python $ROOT/bench.py --no-cpu-baseline --no-pipeline --no-extras"      # one stream: every kernel has the GPU to itself (what bench.py's roofline objects are computed from, too)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $B --steps 3 --warmup 1 > $OUT/bench_trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $B --steps 1 --warmup 0 > $OUT/bench_pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $B --no-two-pass --steps 1 --warmup 0 > $OUT/bench_pmc_$c.log 2>&1
 done
 cd $ROOT
 timeout 600 python bench.py --steps 5 --warmup 2 > $OUT/bench_line.json 2> $OUT/bench_line.err

@@ -43,5 +43,5 @@ if len(traffic) == 2:
     json.dump({"kernel": "k3_decode_forward_literal_kernel", "two_pass_kernel_traffic_bytes_per_launch": (traffic2.get("FETCH_SIZE", 0) + traffic2.get("WRITE_SIZE", 0)) or None, "source": f"profiles/{tag}_bench_full_pipeline_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 512 x 10 s utts)",
                "fetch_bytes_per_launch": traffic["FETCH_SIZE"], "write_bytes_per_launch": traffic["WRITE_SIZE"], "traffic_bytes_per_launch": traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"],
                "note": "FETCH_SIZE/WRITE_SIZE as reported (KB x 1024); the gfx950 x2 correction for wide coalesced loads does not apply to the decoder's narrow random accesses; uncalibrated for this pattern"},
-              open(os.path.join(dst, "hbm_traffic_r02.json"), "w"), indent=1)
+              open(os.path.join(dst, f"hbm_traffic_{tag[:3]}.json"), "w"), indent=1)
 print("summaries in", dst, os.listdir(dst))
