@@ -26,6 +26,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+ALT_BLAS = "SSE4_2"      # e2e_parity.reference_vs_itself: MKL_ENABLE_INSTRUCTIONS of the second reference run (libmkl_mc3 instead of the AVX2 / AVX-512 kernels)
 BEAM, LATTICE_BEAM, MAX_ACTIVE = 15.0, 8.0, 10000      # BASELINE.json configs[2]: beam 15; recipes' lattice-beam 8; CudaDecoderConfig max-active
 
 def _best_path(n, start, frame, final, src, dst, il, ol, cost):
@@ -50,18 +51,23 @@ def _best_path(n, start, frame, final, src, dst, il, ol, cost):
         a = int(back[s_]); ils.append(int(il[a])); ols.append(int(ol[a])); s_ = srcl[a]
     return [i for i in ils[::-1] if i], [o for o in ols[::-1] if o], float(best[end] + final[end])
 
-def _compare_with_gpu(ref, ref_ll, glat, gpu_ll):
-    """one utterance of the end-to-end gate (SURVEY 8d gate 4): the reference chain's lattice (its own features and log-likelihoods) against the GPU chain's"""
-    r = {"max_abs_loglike_diff": float(np.abs(ref_ll - gpu_ll).max()) if ref_ll.shape == gpu_ll.shape else float("inf")}
-    rb = _best_path(ref["frame"].size, ref["start"], ref["frame"], ref["final_graph"].astype(np.float64) + ref["final_ac"], ref["src"], ref["dst"], ref["ilabel"], ref["olabel"],
-                    ref["graph"].astype(np.float64) + ref["ac"])
-    gb = _best_path(glat.num_states, glat.start_index(), glat.st_frame, glat.st_final.astype(np.float64), glat.arc_src, glat.arc_dst, glat.arc_ilabel, glat.arc_olabel,
-                    glat.arc_graph.astype(np.float64) + glat.arc_ac)
-    r["best_path_identical"] = bool(rb is not None and gb is not None and rb[0] == gb[0] and rb[1] == gb[1])
-    r["best_cost_diff"] = abs(rb[2] - gb[2]) if (rb and gb) else float("inf")
-    key = lambda fr, s_, d_, i_, o_: np.sort((fr[s_].astype(np.int64) << 44) | ((fr[d_] - fr[s_]).astype(np.int64) << 43) | (i_.astype(np.int64) << 21) | o_.astype(np.int64))
-    ka, kb = key(ref["frame"], ref["src"], ref["dst"], ref["ilabel"], ref["olabel"]), key(glat.st_frame, glat.arc_src, glat.arc_dst, glat.arc_ilabel, glat.arc_olabel)
-    r["lattice_identical"] = bool(ka.size == kb.size and np.array_equal(ka, kb) and np.array_equal(np.bincount(ref["frame"]), np.bincount(glat.st_frame)))
+def _view_ref(r):      # oracle.ref_decoder.decode's dict -> the arrays _compare works on
+    return dict(n=r["frame"].size, start=r["start"], frame=r["frame"], final=r["final_graph"].astype(np.float64) + r["final_ac"], src=r["src"], dst=r["dst"], il=r["ilabel"], ol=r["olabel"],
+                cost=r["graph"].astype(np.float64) + r["ac"])
+def _view_raw(l):      # kaldi_amd.lattice.RawLattice (the C ABI's k3_decoder_get_raw_lattices output)
+    return dict(n=l.num_states, start=l.start_index(), frame=l.st_frame, final=l.st_final.astype(np.float64), src=l.arc_src, dst=l.arc_dst, il=l.arc_ilabel, ol=l.arc_olabel,
+                cost=l.arc_graph.astype(np.float64) + l.arc_ac)
+
+def _compare(a, a_ll, b, b_ll):
+    """one utterance of the end-to-end gate (SURVEY 8d gate 4): two chains' raw lattices (views above) and the log-likelihoods their decoders consumed"""
+    r = {"max_abs_loglike_diff": float(np.abs(a_ll - b_ll).max()) if a_ll.shape == b_ll.shape else float("inf")}
+    pa, pb = (_best_path(x["n"], x["start"], x["frame"], x["final"], x["src"], x["dst"], x["il"], x["ol"], x["cost"]) for x in (a, b))
+    r["best_path_identical"] = bool(pa is not None and pb is not None and pa[0] == pb[0] and pa[1] == pb[1])
+    r["words_identical"] = bool(pa is not None and pb is not None and pa[1] == pb[1])
+    r["best_cost_diff"] = abs(pa[2] - pb[2]) if (pa and pb) else float("inf")
+    key = lambda x: np.sort((x["frame"][x["src"]].astype(np.int64) << 44) | ((x["frame"][x["dst"]] - x["frame"][x["src"]]).astype(np.int64) << 43) | (x["il"].astype(np.int64) << 21) | x["ol"].astype(np.int64))
+    ka, kb = key(a), key(b)
+    r["lattice_identical"] = bool(ka.size == kb.size and np.array_equal(ka, kb) and np.array_equal(np.bincount(a["frame"]), np.bincount(b["frame"])))
     r["ref_arcs"] = int(ka.size); r["gpu_arcs"] = int(kb.size)
     r["arcs_only_in_one"] = int(ka.size + kb.size - 2 * np.intersect1d(ka, kb).size) if not r["lattice_identical"] else 0
     return r
@@ -71,10 +77,10 @@ def _cpu_worker(job):
     per-utterance comparisons with the GPU chain's results where the job carries them)"""
     from oracle import kaldi_io as kio, lattice_oracle as lo, ref_decoder as rd
     from kaldi_amd import synth
-    wid, utts, utt_seconds, model_path, graph, num_pdfs, gpu = job          # utts: [(name, int16 samples)]; gpu: None or (lattices, loglikes, out_offsets, U)
+    wid, utts, utt_seconds, model_path, graph, num_pdfs, gpu = job          # utts: [(name, int16 samples)]; gpu: None or (lattices, loglikes, out_offsets, U, features, frame offsets) of the GPU chain
     bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
-    cmp_ = []
+    cmp_ = []; cmp2 = []
     with tempfile.TemporaryDirectory() as td:
         scp = []
         for name, pcm in utts:
@@ -86,13 +92,24 @@ def _cpu_worker(job):
         subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/f.ark", f"ark:{td}/o.ark"], env=env, stderr=subprocess.DEVNULL)
         t2 = time.time()
         lls = kio.read_ark(f"{td}/o.ark"); cfg = lo.Config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE); t2p = synth.tid2pdf(num_pdfs)
-        dec_s = 0.0
+        dec_s = 0.0; refs = {}
         for name, _ in utts:
             ref = rd.decode(graph, lls[name], t2p, cfg); dec_s += ref["decode_seconds"]      # time inside LatticeFasterDecoder::Decode, reported by the binary
             u = int(name[1:])
             if gpu is not None and u < gpu[3]:
-                c = _compare_with_gpu(ref, lls[name], gpu[0][u], gpu[1][gpu[2][u]:gpu[2][u + 1]]); c["utt"] = u; cmp_.append(c)
-    return len(utts) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s), cmp_
+                refs[name] = ref
+                c = _compare(_view_ref(ref), lls[name], _view_raw(gpu[0][u]), gpu[1][gpu[2][u]:gpu[2][u + 1]]); c["utt"] = u; cmp_.append(c)
+        if refs:      # (untimed) the reference against ITSELF: the same features through nnet3-compute on another of MKL's code paths, the same decoder -- how far the reference's own results move
+            fr = kio.read_ark(f"{td}/f.ark")      # under a float32 rounding difference of the size that separates the two chains
+            for c in cmp_: c["max_abs_feature_diff"] = float(np.abs(fr["u%d" % c["utt"]] - gpu[4][gpu[5][c["utt"]]:gpu[5][c["utt"] + 1]]).max())
+            try:
+                subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/f.ark", f"ark:{td}/o2.ark"],
+                                      env=dict(env, MKL_ENABLE_INSTRUCTIONS=ALT_BLAS), stderr=subprocess.DEVNULL)
+                lls2 = kio.read_ark(f"{td}/o2.ark")
+                for name in refs:
+                    c = _compare(_view_ref(refs[name]), lls[name], _view_ref(rd.decode(graph, lls2[name], t2p, cfg)), lls2[name]); c["utt"] = int(name[1:]); cmp2.append(c)
+            except Exception as e: cmp2.append({"error": repr(e)})
+    return len(utts) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s), cmp_, cmp2
 
 def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utts_per_core=12, max_procs=64):
     """The same workload on the host cores, bounded sample, the way decode.sh --nj splits it: P independent single-threaded workers, each running
@@ -121,19 +138,26 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
                       f"reference compute-fbank-feats {audio / st[0]:.0f}x RT, reference nnet3-compute {audio / st[1]:.0f}x RT, reference LatticeFasterDecoder::Decode {audio / st[2]:.0f}x RT "
                       "(decoder/lattice-faster-decoder.cc compiled unmodified; FST containers from oracle/ref_tools/minifst because OpenFst is not vendored)"}
     par = None
-    cmp_ = sorted((c for r in res for c in r[3]), key=lambda c: c["utt"])
+    def summary(cs):
+        nb_ = sum(c["best_path_identical"] for c in cs); bad = [c for c in cs if not c["best_path_identical"]]
+        return {"utterances": len(cs), "best_path_identical": nb_, "best_path_identical_frac": nb_ / len(cs), "words_identical": sum(c["words_identical"] for c in cs),
+                "raw_lattice_identical": sum(c["lattice_identical"] for c in cs),
+                "max_abs_loglike_diff": max(c["max_abs_loglike_diff"] for c in cs), "mean_of_max_abs_loglike_diff": float(np.mean([c["max_abs_loglike_diff"] for c in cs])),
+                "max_best_cost_diff": max(c["best_cost_diff"] for c in cs),
+                "raw_lattice_arcs_only_in_one_total": sum(c["arcs_only_in_one"] for c in cs), "raw_lattice_arcs_total": sum(c["ref_arcs"] for c in cs),
+                "best_path_mismatches": [{"utt": c["utt"], "best_cost_diff": c["best_cost_diff"], "max_abs_loglike_diff": c["max_abs_loglike_diff"]} for c in bad[:16]]}
+    cmp_ = sorted((c for r in res for c in r[3]), key=lambda c: c["utt"]); cmp2 = [c for r in res for c in r[4]]
     if cmp_:
-        nb_ = sum(c["best_path_identical"] for c in cmp_); nl = sum(c["lattice_identical"] for c in cmp_)
-        bad = [c for c in cmp_ if not c["best_path_identical"]]
-        par = {"utterances": len(cmp_), "best_path_identical": nb_, "best_path_identical_frac": nb_ / len(cmp_), "raw_lattice_identical": nl,
-               "max_abs_loglike_diff": max(c["max_abs_loglike_diff"] for c in cmp_), "max_best_cost_diff": max(c["best_cost_diff"] for c in cmp_),
-               "raw_lattice_arcs_only_in_one_total": sum(c["arcs_only_in_one"] for c in cmp_), "raw_lattice_arcs_total": sum(c["ref_arcs"] for c in cmp_),
-               "best_path_mismatches": [{"utt": c["utt"], "best_cost_diff": c["best_cost_diff"], "max_abs_loglike_diff": c["max_abs_loglike_diff"]} for c in bad[:16]],
-               "note": "reference chain = compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder (oracle/_ref binaries built from /root/reference) on the SAME PCM16 as the GPU batch; GPU chain = the timed path "
+        par = summary(cmp_); par["max_abs_feature_diff"] = max(c.get("max_abs_feature_diff", 0.0) for c in cmp_)
+        err2 = [c for c in cmp2 if "error" in c]; ok2 = [c for c in cmp2 if "error" not in c]
+        par["reference_vs_itself"] = dict(summary(sorted(ok2, key=lambda c: c["utt"])), second_run=f"MKL_ENABLE_INSTRUCTIONS={ALT_BLAS} for nnet3-compute (same features, same decoder)") if ok2 else {"error": err2[:1]}
+        par["note"] = ("reference chain = compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder (oracle/_ref binaries built from /root/reference) on the SAME PCM16 as the GPU batch; GPU chain = the timed path "
                        "(k3_feat -> k3_nnet_forward -> k3_decoder literal_order=1).  best_path_identical: (transition-ids, words) of the tropical best path of the two raw lattices equal "
-                       "(decoder-wrappers.cc:322-331).  raw_lattice_identical: same states per frame and the same multiset of arcs (source frame, emitting/epsilon, ilabel, olabel); the cost BITS cannot be "
-                       "equal because the two chains' log-likelihoods differ by max_abs_loglike_diff (<= 1e-4 is north_star's bound); on the GPU's own log-likelihoods the decoder is bit-identical to the "
-                       "reference's (tests/test_decoder_literal_gpu.py).  A best-path mismatch with best_cost_diff below frames x max_abs_loglike_diff is a tie broken by the log-likelihood difference."}
+                       "(decoder-wrappers.cc:322-331).  raw_lattice_identical: same states per frame and the same multiset of arcs (source frame, emitting/epsilon, ilabel, olabel); cost BITS cannot be "
+                       "equal because the log-likelihoods the two decoders consume differ (max_abs_loglike_diff).  Stage by stage the GPU is inside north_star's bounds (features <= 1e-4: "
+                       "max_abs_feature_diff; log-likelihoods <= 1e-4 on the same features; lattices bit-identical on the same log-likelihoods: tests/), but this 17-layer model amplifies a 1e-5 feature "
+                       "difference to ~1e-3 in its output and max-active pruning on its flat posteriors is chaotic, so the chains can end on different paths.  reference_vs_itself measures the "
+                       "reference's own reproducibility under the same size of float32 difference (its nnet3-compute on another MKL code path): the GPU chain is at parity when its rates match these.")
     return base, par
 
 TRAFFIC_CMD = ("cd /tmp && TMPDIR=/tmp rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -d <dir> -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline "
@@ -435,7 +459,7 @@ def main():
                 gpu = None
                 if decs:      # the end-to-end gate: one more (serial) pass over the batch as generated (shift 0), its raw lattices and log-likelihoods kept for the comparison
                     keep = []; run("literal", 1, 0, pipelined=False, vary=False, keep=keep)
-                    gpu = (keep[0], loglikes.cpu().numpy(), np.asarray(nb.out_offsets), U)
+                    gpu = (keep[0], loglikes.cpu().numpy(), np.asarray(nb.out_offsets), U, feats.cpu().numpy(), np.asarray(fo_h))
                 line["cpu_baseline"], par = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds, pcm_of, gpu, utts_per_core=args.cpu_utts_per_core, max_procs=args.cpu_procs)
                 if par is not None: line["e2e_parity"] = par
             except Exception as e: line["cpu_baseline"] = {"error": repr(e)}
