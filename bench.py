@@ -26,7 +26,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALT_BLAS = "SSE4_2"      # e2e_parity.reference_vs_itself: MKL_ENABLE_INSTRUCTIONS of the second reference run (libmkl_mc3 instead of the AVX2 / AVX-512 kernels)
+ALT_BLAS = {"MKL_CBWR": "COMPATIBLE"}      # e2e_parity.reference_vs_itself: the second reference run takes MKL's "conditional numerical reproducibility" branch (tools/probe_mkl_paths.py: the setting that moves its sgemm rounding on Intel and AMD hosts alike)
 BEAM, LATTICE_BEAM, MAX_ACTIVE = 15.0, 8.0, 10000      # BASELINE.json configs[2]: beam 15; recipes' lattice-beam 8; CudaDecoderConfig max-active
 
 def _best_path(n, start, frame, final, src, dst, il, ol, cost):
@@ -80,7 +80,7 @@ def _cpu_worker(job):
     wid, utts, utt_seconds, model_path, graph, num_pdfs, gpu = job          # utts: [(name, int16 samples)]; gpu: None or (lattices, loglikes, out_offsets, U, features, frame offsets) of the GPU chain
     bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
-    cmp_ = []; cmp2 = []
+    cmp_ = []; cmp2 = []; keep_ = {}
     with tempfile.TemporaryDirectory() as td:
         scp = []
         for name, pcm in utts:
@@ -102,14 +102,15 @@ def _cpu_worker(job):
         if refs:      # (untimed) the reference against ITSELF: the same features through nnet3-compute on another of MKL's code paths, the same decoder -- how far the reference's own results move
             fr = kio.read_ark(f"{td}/f.ark")      # under a float32 rounding difference of the size that separates the two chains
             for c in cmp_: c["max_abs_feature_diff"] = float(np.abs(fr["u%d" % c["utt"]] - gpu[4][gpu[5][c["utt"]]:gpu[5][c["utt"] + 1]]).max())
+            for name in refs: keep_[int(name[1:])] = (fr[name], lls[name], refs[name])      # the reference's features, log-likelihoods and lattice: inputs / expected outputs of the stage gates
             try:
                 subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/f.ark", f"ark:{td}/o2.ark"],
-                                      env=dict(env, MKL_ENABLE_INSTRUCTIONS=ALT_BLAS), stderr=subprocess.DEVNULL)
+                                      env=dict(env, **ALT_BLAS), stderr=subprocess.DEVNULL)
                 lls2 = kio.read_ark(f"{td}/o2.ark")
                 for name in refs:
                     c = _compare(_view_ref(refs[name]), lls[name], _view_ref(rd.decode(graph, lls2[name], t2p, cfg)), lls2[name]); c["utt"] = int(name[1:]); cmp2.append(c)
             except Exception as e: cmp2.append({"error": repr(e)})
-    return len(utts) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s), cmp_, cmp2
+    return len(utts) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s), cmp_, cmp2, keep_
 
 def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utts_per_core=12, max_procs=64):
     """The same workload on the host cores, bounded sample, the way decode.sh --nj splits it: P independent single-threaded workers, each running
@@ -119,7 +120,7 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
     from oracle import ref_decoder as rd
     bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
     if not (os.path.exists(os.path.join(bindir, "nnet3-compute")) and rd.available()):
-        return {"error": "oracle/_ref is not built (needs /root/reference once; it travels to the GPU box)"}, None
+        return {"error": "oracle/_ref is not built (needs /root/reference once; it travels to the GPU box)"}, None, {}
     ncores = os.cpu_count() or 1; P = max(1, min(ncores, max_procs))
     from kaldi_amd import synth
     _cpu_worker((99, [("u99999", synth.gaussian_pcm16(16000, 99))], 1.0, model_path, graph, num_pdfs, None))            # untimed warm-up: pages the binaries and MKL in
@@ -147,10 +148,12 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
                 "raw_lattice_arcs_only_in_one_total": sum(c["arcs_only_in_one"] for c in cs), "raw_lattice_arcs_total": sum(c["ref_arcs"] for c in cs),
                 "best_path_mismatches": [{"utt": c["utt"], "best_cost_diff": c["best_cost_diff"], "max_abs_loglike_diff": c["max_abs_loglike_diff"]} for c in bad[:16]]}
     cmp_ = sorted((c for r in res for c in r[3]), key=lambda c: c["utt"]); cmp2 = [c for r in res for c in r[4]]
+    kept = {}
+    for r in res: kept.update(r[5])
     if cmp_:
         par = summary(cmp_); par["max_abs_feature_diff"] = max(c.get("max_abs_feature_diff", 0.0) for c in cmp_)
         err2 = [c for c in cmp2 if "error" in c]; ok2 = [c for c in cmp2 if "error" not in c]
-        par["reference_vs_itself"] = dict(summary(sorted(ok2, key=lambda c: c["utt"])), second_run=f"MKL_ENABLE_INSTRUCTIONS={ALT_BLAS} for nnet3-compute (same features, same decoder)") if ok2 else {"error": err2[:1]}
+        par["reference_vs_itself"] = dict(summary(sorted(ok2, key=lambda c: c["utt"])), second_run=f"{ALT_BLAS} for nnet3-compute (same features, same decoder)") if ok2 else {"error": err2[:1]}
         par["note"] = ("reference chain = compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder (oracle/_ref binaries built from /root/reference) on the SAME PCM16 as the GPU batch; GPU chain = the timed path "
                        "(k3_feat -> k3_nnet_forward -> k3_decoder literal_order=1).  best_path_identical: (transition-ids, words) of the tropical best path of the two raw lattices equal "
                        "(decoder-wrappers.cc:322-331).  raw_lattice_identical: same states per frame and the same multiset of arcs (source frame, emitting/epsilon, ilabel, olabel); cost BITS cannot be "
@@ -158,7 +161,7 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
                        "max_abs_feature_diff; log-likelihoods <= 1e-4 on the same features; lattices bit-identical on the same log-likelihoods: tests/), but this 17-layer model amplifies a 1e-5 feature "
                        "difference to ~1e-3 in its output and max-active pruning on its flat posteriors is chaotic, so the chains can end on different paths.  reference_vs_itself measures the "
                        "reference's own reproducibility under the same size of float32 difference (its nnet3-compute on another MKL code path): the GPU chain is at parity when its rates match these.")
-    return base, par
+    return base, par, kept
 
 TRAFFIC_CMD = ("cd /tmp && TMPDIR=/tmp rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -d <dir> -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline "
                "--no-two-pass --no-extras  (one pass per counter, no trace domains; Counter_Value of k3_decode_forward_literal_kernel summed over its dispatches / dispatches x 1024; "
@@ -460,8 +463,27 @@ def main():
                 if decs:      # the end-to-end gate: one more (serial) pass over the batch as generated (shift 0), its raw lattices and log-likelihoods kept for the comparison
                     keep = []; run("literal", 1, 0, pipelined=False, vary=False, keep=keep)
                     gpu = (keep[0], loglikes.cpu().numpy(), np.asarray(nb.out_offsets), U, feats.cpu().numpy(), np.asarray(fo_h))
-                line["cpu_baseline"], par = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds, pcm_of, gpu, utts_per_core=args.cpu_utts_per_core, max_procs=args.cpu_procs)
-                if par is not None: line["e2e_parity"] = par
+                line["cpu_baseline"], par, kept = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds, pcm_of, gpu, utts_per_core=args.cpu_utts_per_core, max_procs=args.cpu_procs)
+                if par is not None:
+                    line["e2e_parity"] = par
+                    # The stage gates at the bench's own scale, on the REFERENCE's intermediate results (so that each stage is judged on identical inputs):
+                    #   N: k3_nnet_forward on the reference's features vs the reference's nnet3-compute;  D: k3_decoder on the reference's log-likelihoods vs the reference's lattices
+                    us = sorted(kept); rf = np.zeros((total_frames, sf.dim), np.float32); rl = np.zeros((int(nb.total_out_rows), num_pdfs), np.float32); oo = np.asarray(nb.out_offsets)
+                    for u in us: rf[fo_h[u]:fo_h[u + 1]] = kept[u][0]; rl[oo[u]:oo[u + 1]] = kept[u][1]
+                    g_ll = nb.forward(torch.from_numpy(rf).to(dev)); torch.cuda.synchronize(); g_llh = g_ll.cpu().numpy()
+                    nd = max(float(np.abs(g_llh[oo[u]:oo[u + 1]] - kept[u][1]).max()) for u in us)
+                    dec = decs["literal"]; dec.DecodeBatch(torch.from_numpy(rl).to(dev), nb.out_offsets); glats = dec.GetRawLattices(copy=True)
+                    def same_lattice(u):      # every state (frame, final-cost bits) and every arc (source frame, emitting / epsilon, labels, graph- and acoustic-cost BITS), as multisets: identity up to the names of the states
+                        r, l = kept[u][2], glats[u]; bits = lambda x: (np.asarray(x, np.float32) + np.float32(0)).view(np.int32).astype(np.int64)
+                        ka = np.stack([r["frame"][r["src"]], r["frame"][r["dst"]], r["ilabel"], r["olabel"], bits(r["graph"]), bits(r["ac"])], 1); kb = np.stack([l.st_frame[l.arc_src], l.st_frame[l.arc_dst], l.arc_ilabel, l.arc_olabel, bits(l.arc_graph), bits(l.arc_ac)], 1)
+                        sa = np.stack([r["frame"], bits(r["final_graph"])], 1); sb = np.stack([l.st_frame, bits(l.st_final)], 1)
+                        srt = lambda m: m[np.lexsort(m.T[::-1])]
+                        return ka.shape == kb.shape and sa.shape == sb.shape and np.array_equal(srt(ka), srt(kb)) and np.array_equal(srt(sa), srt(sb))
+                    ident = sum(bool(same_lattice(u)) for u in us)
+                    par["stage_gates"] = {"utterances": len(us), "features_max_abs_diff": par["max_abs_feature_diff"], "nnet_on_reference_features_max_abs_loglike_diff": nd,
+                                          "decoder_on_reference_loglikes_lattices_identical": ident,
+                                          "note": "F: k3_feat vs compute-fbank-feats on the same PCM16; N: k3_nnet_forward vs nnet3-compute on the reference's features; D: k3_decoder (literal_order) vs "
+                                                  "LatticeFasterDecoder on the reference's log-likelihoods -- states and arcs with all cost bits, as multisets (the strict signature test is tests/test_decoder_literal_gpu.py)"}
             except Exception as e: line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line))
     pool.shutdown()
