@@ -101,7 +101,9 @@ def _cpu_worker(job):
                 c = _compare(_view_ref(ref), lls[name], _view_raw(gpu[0][u]), gpu[1][gpu[2][u]:gpu[2][u + 1]]); c["utt"] = u; cmp_.append(c)
         if refs:      # (untimed) the reference against ITSELF: the same features through nnet3-compute on another of MKL's code paths, the same decoder -- how far the reference's own results move
             fr = kio.read_ark(f"{td}/f.ark")      # under a float32 rounding difference of the size that separates the two chains
-            for c in cmp_: c["max_abs_feature_diff"] = float(np.abs(fr["u%d" % c["utt"]] - gpu[4][gpu[5][c["utt"]]:gpu[5][c["utt"] + 1]]).max())
+            for c in cmp_:
+                fd = np.abs(fr["u%d" % c["utt"]] - gpu[4][gpu[5][c["utt"]]:gpu[5][c["utt"] + 1]])
+                c["max_abs_feature_diff"] = float(fd.max()); c["feat_n"] = int(fd.size); c["feat_above"] = int((fd > 1e-4).sum()); c["feat_sum"] = float(fd.sum(dtype=np.float64))
             for name in refs: keep_[int(name[1:])] = (fr[name], lls[name], refs[name])      # the reference's features, log-likelihoods and lattice: inputs / expected outputs of the stage gates
             try:
                 subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path, f"ark:{td}/f.ark", f"ark:{td}/o2.ark"],
@@ -152,6 +154,7 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
     for r in res: kept.update(r[5])
     if cmp_:
         par = summary(cmp_); par["max_abs_feature_diff"] = max(c.get("max_abs_feature_diff", 0.0) for c in cmp_)
+        nfe = max(1, sum(c.get("feat_n", 0) for c in cmp_)); par["mean_abs_feature_diff"] = sum(c.get("feat_sum", 0.0) for c in cmp_) / nfe; par["feature_values_above_1e-4_frac"] = sum(c.get("feat_above", 0) for c in cmp_) / nfe
         err2 = [c for c in cmp2 if "error" in c]; ok2 = [c for c in cmp2 if "error" not in c]
         par["reference_vs_itself"] = dict(summary(sorted(ok2, key=lambda c: c["utt"])), second_run=f"{ALT_BLAS} for nnet3-compute (same features, same decoder)") if ok2 else {"error": err2[:1]}
         par["note"] = ("reference chain = compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder (oracle/_ref binaries built from /root/reference) on the SAME PCM16 as the GPU batch; GPU chain = the timed path "
@@ -480,9 +483,9 @@ def main():
                         srt = lambda m: m[np.lexsort(m.T[::-1])]
                         return ka.shape == kb.shape and sa.shape == sb.shape and np.array_equal(srt(ka), srt(kb)) and np.array_equal(srt(sa), srt(sb))
                     ident = sum(bool(same_lattice(u)) for u in us)
-                    par["stage_gates"] = {"utterances": len(us), "features_max_abs_diff": par["max_abs_feature_diff"], "nnet_on_reference_features_max_abs_loglike_diff": nd,
+                    par["stage_gates"] = {"utterances": len(us), "features_max_abs_diff": par["max_abs_feature_diff"], "features_mean_abs_diff": par["mean_abs_feature_diff"], "features_above_1e-4_frac": par["feature_values_above_1e-4_frac"], "nnet_on_reference_features_max_abs_loglike_diff": nd,
                                           "decoder_on_reference_loglikes_lattices_identical": ident,
-                                          "note": "F: k3_feat vs compute-fbank-feats on the same PCM16; N: k3_nnet_forward vs nnet3-compute on the reference's features; D: k3_decoder (literal_order) vs "
+                                          "note": "F: k3_feat vs compute-fbank-feats on the same PCM16 (the reference's own float32 binary is up to ~5e-5 from the float64 value of its formulas on 1e5 values and the two errors are independent: over the batch's 2e7 values the tail of the difference passes 1e-4; DESIGN.md); N: (the reference against itself on MKL's other branch: e2e_parity.reference_vs_itself.max_abs_loglike_diff); k3_nnet_forward vs nnet3-compute on the reference's features; D: k3_decoder (literal_order) vs "
                                                   "LatticeFasterDecoder on the reference's log-likelihoods -- states and arcs with all cost bits, as multisets (the strict signature test is tests/test_decoder_literal_gpu.py)"}
             except Exception as e: line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line))
