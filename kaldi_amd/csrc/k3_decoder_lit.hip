@@ -1,0 +1,23 @@
+// k3_decoder_lit.hip -- the literal_order token-passing kernel (k3_decoder_literal.h) as its own translation unit: it runs with its own number of
+// threads per lane (K3_LIT_BLOCK) while the two-pass kernel, the pruning and the output kernels of k3_decoder.hip keep theirs.  The two files share
+// k3_decoder_dev.h (DecParams, the state table, the epsilon closure, the block primitives), each compiled for its block size.
+#ifndef K3_LIT_BLOCK
+#define K3_LIT_BLOCK 512
+#endif
+#define K3_DEC_BLOCK K3_LIT_BLOCK
+#include "k3_decoder_dev.h"
+
+namespace {
+#define K3_LIT_FORWARD
+#include "k3_decoder_literal.h"
+}  // namespace
+
+extern "C" int k3_lit_forward_prepare() {
+  return hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitDynLds) == hipSuccess ? 0 : -1;
+}
+extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nlanes, hipStream_t stream) {
+  DecParams p; static_assert(sizeof(DecParams) % 8 == 0, "DecParams is copied between translation units");
+  if (params_bytes != sizeof(DecParams)) { fprintf(stderr, "k3_lit_forward_launch: DecParams size mismatch\n"); abort(); }
+  memcpy(&p, params, sizeof(p));
+  hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(nlanes), dim3(kBlock), kLitDynLds, stream, p);
+}

@@ -173,6 +173,7 @@ struct LitLane {      // this lane's slices of the literal_order scratch
   }
 };
 
+#ifdef K3_LIT_FORWARD      // the token-passing kernel and its helpers: compiled by k3_decoder_lit.hip (its own block size)
 // HashList order of n tokens with unique creation labels < M: order_out[position] = token.  by_ins[d] = token with creation rank d.
 // (The path of frames too large for lit_hash_order_lds.)  The buckets -- hash_size is unbounded, a frame touches at most n of them -- live in an
 // open-addressing table of 16 B records {bucket, smallest creation rank, members, fill cursor} sized to the frame (2n .. 4n slots): one
@@ -924,6 +925,9 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
   }
 }
 
+#endif  // K3_LIT_FORWARD
+
+#ifdef K3_LIT_FINAL      // the literal branch of the pruning kernel's last-frame stage: compiled by k3_decoder.hip
 // PruneForwardLinksFinal (:385-467) exactly: in-place sweeps over the last frame's tokens in list order (newest token first) until no extra
 // cost moves by more than 1e-5 relative (ApproxEqual, base/kaldi-math.h:265-275); a link is excised when it is found above the lattice beam.
 // n tokens tb.., eps links [l0, l1).  base / extra: per token; off: first link of a token (n + 1); ldst (bit 31 = keep), ldelta: per live link.
@@ -1068,3 +1072,4 @@ __device__ __forceinline__ void lit_final_frame(const DecParams &p, int L, long 
   if (use_lds) { for (int t = tid; t < n; t += kPBlock) extra[tb + t] = ex[t]; for (int j = tid; j < m; j += kPBlock) g_ldst[j] = ldst[j]; }
   __syncthreads();
 }
+#endif  // K3_LIT_FINAL

@@ -19,7 +19,7 @@ feats = sf.ComputeFeatures(waves, wo, fo, total_frames); ll = nb.forward(feats);
 print("loglikes", tuple(ll.shape), "mean", ll.mean().item(), "std", ll.std().item(), "max", ll.max().item(), "row-max mean", ll.max(dim=1).values.mean().item())
 t = time.time(); f = synth.make_hclg(); print("graph", f.stats(), "gen %.1fs" % (time.time() - t))
 t = time.time(); cf = decoder.CudaFst(f, synth.tid2pdf(net.info.output_dim)); print("upload %.2fs" % (time.time() - t))
-cfg = decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, min_active=int(os.environ.get("MINACT", 200)), frame_tokens_cap=65536, frame_cands_cap=131072,
+cfg = decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, min_active=int(os.environ.get("MINACT", 200)), literal_order=int(os.environ.get("LITERAL", 0)), frame_tokens_cap=65536, frame_cands_cap=131072,
                              lane_tokens_cap=int(os.environ.get("TOKCAP", 6_000_000)), lane_links_cap=int(os.environ.get("LINKCAP", 12_000_000)))
 dec = decoder.CudaDecoder(cf, cfg, U, net.info.output_dim); dec.SetProfiling(True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
