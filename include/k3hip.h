@@ -249,6 +249,9 @@ typedef struct k3_decoder_config {
    * Needs frame_tokens_cap <= 65536 < frame_cands_cap. */
   int32_t literal_order;      /* 0; 1 = on; 2 = on, the closure's creation order by the one-wavefront replay (the fall-back path of 1, for A/B); 3 = 1 with the fall-back forced (tests) */
   float hash_ratio;           /* 2.0 */
+  /* literal_order = 1 only: frames of at most this many tokens (before and after) are processed entirely in LDS (k3_decoder_fast.h), the others on the
+   * general path; same results either way.  -1 = the kernel's capacity (3072), 0 = general path only (A/B, tests), n = a smaller capacity (tests). */
+  int32_t fast_frame_tokens;  /* -1 */
 } k3_decoder_config;
 void k3_decoder_config_default(k3_decoder_config *cfg);
 typedef struct k3_decoder k3_decoder;

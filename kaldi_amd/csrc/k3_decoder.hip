@@ -769,6 +769,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // k3_decoder_lit.hip: the literal_order token-passing kernel (compiled with its own block size); `params` is this file's DecParams
 extern "C" int k3_lit_forward_prepare();
+extern "C" int k3_lit_fast_tokens();
 extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nlanes, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------ graph ----
@@ -889,7 +890,7 @@ extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
   if (!c) return;
   c->beam = 16.0f; c->max_active = std::numeric_limits<int32_t>::max(); c->min_active = 200; c->lattice_beam = 10.0f; c->beam_delta = 0.5f;
   c->frame_tokens_cap = 32768; c->frame_cands_cap = 65536; c->lane_tokens_cap = 2000000; c->lane_links_cap = 4000000;
-  c->literal_order = 0; c->hash_ratio = 2.0f;
+  c->literal_order = 0; c->hash_ratio = 2.0f; c->fast_frame_tokens = -1;
 }
 
 template <typename T> static int dmalloc(std::vector<void *> *allocs, T **ptr, size_t n) {
@@ -941,6 +942,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.live_link, nl * p.live_cap))) return rc;
   p.literal = (cfg->literal_order == 2 || cfg->literal_order == 3) ? cfg->literal_order : (cfg->literal_order ? 1 : 0); p.hash_ratio = cfg->hash_ratio;      // 2: the closure's creation order by the one-wavefront replay (the fall-back of 1); 3: 1 with zero-length component stacks (exercises the fall-back)
+  p.fast_cap = p.literal == 1 ? (cfg->fast_frame_tokens < 0 ? k3_lit_fast_tokens() : std::min(cfg->fast_frame_tokens, k3_lit_fast_tokens())) : 0;
   if (p.literal) {
     K3_REQUIRE(cfg->hash_ratio > 0.0f && cfg->hash_ratio <= 64.0f, "k3_decoder_create: literal_order needs 0 < hash_ratio <= 64 (LatticeFasterDecoderConfig::hash_ratio)");
     K3_REQUIRE(cfg->frame_tokens_cap <= 65536 && cfg->frame_cands_cap > cfg->frame_tokens_cap, "k3_decoder_create: literal_order needs frame_tokens_cap <= 65536 < frame_cands_cap");

@@ -5,6 +5,9 @@
 #define K3_LIT_BLOCK 512
 #endif
 #define K3_DEC_BLOCK K3_LIT_BLOCK
+#ifndef K3_LIT_WPE
+#define K3_LIT_WPE 4      // two 512-thread workgroups per CU (each within 80 KB of LDS): 4 waves per SIMD
+#endif
 #include "k3_decoder_dev.h"
 
 namespace {
@@ -12,12 +15,13 @@ namespace {
 #include "k3_decoder_literal.h"
 }  // namespace
 
+extern "C" int k3_lit_fast_tokens() { return kFT; }      // capacity of the LDS-resident frame path (tokens of a frame)
 extern "C" int k3_lit_forward_prepare() {
-  return hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitDynLds) == hipSuccess ? 0 : -1;
+  return hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitArena) == hipSuccess ? 0 : -1;
 }
 extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nlanes, hipStream_t stream) {
   DecParams p; static_assert(sizeof(DecParams) % 8 == 0, "DecParams is copied between translation units");
   if (params_bytes != sizeof(DecParams)) { fprintf(stderr, "k3_lit_forward_launch: DecParams size mismatch\n"); abort(); }
   memcpy(&p, params, sizeof(p));
-  hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(nlanes), dim3(kBlock), kLitDynLds, stream, p);
+  hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(nlanes), dim3(kBlock), kLitArena, stream, p);
 }

@@ -308,6 +308,10 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
 }
 
 static_assert(kHoLds <= kLitDynLds, "the hash-order arena lives in the replay's dynamic segment");
+constexpr size_t kLitTabBytes = (size_t)3 * kHL * 4, kLitMarkBytes = (size_t)3 * (kHL / 32) * 4, kLitAuxBytes = (size_t)2 * 1024 * 4;
+#include "k3_decoder_fast.h"
+constexpr size_t kLitGeneralLds = kLitTabBytes + kLitMarkBytes + kLitAuxBytes + kLitDynLds;
+constexpr size_t kLitArena = kLitGeneralLds > (size_t)kFastArena ? kLitGeneralLds : (size_t)kFastArena;
 struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 
 // The replay loop.  MODE 0: costs, meta, arcs, stack and the creation list in LDS; MODE 1: costs, stack and list in LDS, meta / arcs read-only
@@ -544,15 +548,19 @@ __device__ __forceinline__ int lit_replay_components(const DecParams &p, const L
   return created;
 }
 
-__global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(DecParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];       // replay arrays of a small frame
-  __shared__ Shared sh; __shared__ LitShared ls;
-  __shared__ __attribute__((aligned(16))) int s_tab[3 * kHL];      // level-1 table {key, cost, token}; between the closure and the end of a frame: the replay's records
+__global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_kernel(DecParams p) {
+  // One dynamic LDS arena (kLitArena bytes).  The general path below carves its level-1 state table, mark bits, work-lists / clash bins / union-find
+  // parents and the replay segment out of its first 77.5 KB; a frame of the LDS-resident path (k3_decoder_fast.h) uses all of it, so the two
+  // never run at the same time and the general path re-initialises its table after a fast frame.
+  extern __shared__ __attribute__((aligned(16))) char arena[];
+  __shared__ Shared sh; __shared__ LitShared ls; __shared__ FastShared fs;
+  int *const s_tab = reinterpret_cast<int *>(arena);      // level-1 table {key, cost, token}; between the closure and the end of a frame: the replay's records
   int *const s_lkey = s_tab; unsigned *const s_lcost = reinterpret_cast<unsigned *>(s_tab + kHL); int *const s_ltok = s_tab + 2 * kHL;
-  __shared__ unsigned s_lmark[3 * (kHL / 32)];
+  unsigned *const s_lmark = reinterpret_cast<unsigned *>(arena + kLitTabBytes);
   // 8 KB shared by three users with disjoint lifetimes: the eps rounds' work-lists (first half), the serial replay's clash bins (second half:
   // which lane of a batch targets a token; a false clash only takes the one-by-one path), the component replay's union-find parents (all of it)
-  __shared__ __attribute__((aligned(16))) int s_aux[2 * 1024];
+  int *const s_aux = reinterpret_cast<int *>(arena + kLitTabBytes + kLitMarkBytes);
+  char *const smem_raw = arena + kLitTabBytes + kLitMarkBytes + kLitAuxBytes;       // replay arrays of a small frame
   static_assert(2 * kWlLds * sizeof(unsigned short) <= 1024 * sizeof(int) && kHL / 2 <= 2 * 1024, "s_aux layout");
   unsigned short (*const s_lwl)[kWlLds] = reinterpret_cast<unsigned short (*)[kWlLds]>(s_aux); int *const s_own = s_aux + 1024;
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
@@ -565,7 +573,12 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
   int *st_ntoks = p.st_ntoks + L * p.fstride; float *st_cur = p.st_cur + L * p.fstride, *st_ab = p.st_ab + L * p.fstride, *st_next = p.st_next + L * p.fstride, *st_co = p.st_co + L * p.fstride;
   const unsigned mask = (unsigned)p.hash_mask; const float kInf = __builtin_inff(); const int cap = p.frame_tokens_cap;
   const LitLane q(p, L);
+  const LaneCtx lc{tok_state, tok_cost, links, link_arc, tok_off, loff_e, loff_n, st_ntoks, st_cur, st_ab, st_next, st_co};
+  long long cyc_fast = 0, cyc_general = 0, cyc_t0 = 0;
+  int n_fast = 0, n_gaveup = 0, n_general = 0; int why[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (thread 0: frames by path, reasons of the fast path's give-ups; k3_decoder_phase_cycles reads them)
+  bool v_valid = false, lds_dirty = false;      // the visit-order arrays of the fast path hold the current frame / the arena was used by a fast frame
   if (tid < 16) sh.prof[tid] = 0;
+  if (tid < 12) fs.prof[tid] = 0;
   if (tid == 0) { sh.n_next = 0; sh.n_cand = 0; sh.err = 0; sh.n_link = 0; sh.min_tot = kEncMax; sh.flag = 0; sh.n_eps = 0; sh.n_emit = 0; sh.n_os = 0; }
   for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; s_ltok[i] = -1; }
   for (int i = tid; i < 3 * (kHL / 32); i += kBlock) s_lmark[i] = 0;
@@ -615,6 +628,33 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
       const float *ll = p.lane_rows ? p.lane_rows[L] + (long long)(f - f0) * p.ld : p.loglikes + (r0 + (f - f0)) * p.ld;
       const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
       if (n_cur == 0) { status = kStNoTokens; break; }
+      // ---- the LDS-resident frame (k3_decoder_fast.h) when the frame fits; a frame it gives up on is redone below, from the same inputs
+      if (tid == 0) cyc_t0 = (long long)__builtin_readcyclecounter();
+      if (p.fast_cap > 0 && n_cur <= p.fast_cap) {
+        lds_dirty = true;
+        if (v_valid || fast_import(p, arena, lc, ord_cur, cur_base, n_cur, fs)) {
+          const long long link0 = sh.n_link;
+          const int n_new = lit_frame_fast(p, sh, fs, arena, q, lc, f, ll, cur_base, n_cur, hash_size, ord_nxt, p.fast_cap, cnt_emit, cnt_os, cnt_eps);
+          if (n_new >= 0) {
+            cur_base += n_cur; n_cur = n_new; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1; v_valid = true; n_fast++;
+            if (tid == 0) cyc_fast += (long long)__builtin_readcyclecounter() - cyc_t0;
+            continue;
+          }
+          __syncthreads();
+          if (tid == 0) { sh.n_link = link0; sh.n_next = 0; n_gaveup++; const int r_ = fs.reason; if (r_ >= 1 && r_ <= 12) why[r_ - 1]++; }
+#ifdef K3_LIT_DEBUG
+          if (tid == 0) printf("lane %d frame %d: fast path gave up (reason %d), n_cur %d\n", L, f, fs.reason, n_cur);
+#endif
+          __syncthreads();
+          if (block_err(sh)) break;
+        }
+      }
+      v_valid = false; n_general++;
+      if (lds_dirty) {      // the arena held a fast frame: the general path starts from an empty level-1 table
+        for (int i = tid; i < kHL; i += kBlock) { s_lkey[i] = kEmpty; s_lcost[i] = kEncMax; s_ltok[i] = -1; }
+        lds_dirty = false;
+        __syncthreads();
+      }
       // ---- GetCutoff (:653-720): the best token is the FIRST minimum-cost token of the list (strict <, :661-663)
       unsigned long long bm = ~0ull;
       for (int r = tid; r < n_cur; r += kBlock) { const unsigned long long v = ((unsigned long long)ccs[ord_cur[r]] << 32) | (unsigned)r; bm = v < bm ? v : bm; }
@@ -897,6 +937,14 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
 #ifdef K3_LIT_DEBUG
     if (n_e + created_total != n && tid == 0) printf("lane %d frame %d: n_e %d created %d n %d n_cid %d n_arc %d n_iq %d rmode %d\n", L, f, n_e, created_total, n, n_cid, n_arc, n_iq, rmode);
 #endif
+#ifdef K3_LIT_STATS      // size statistics of the frames a fast (LDS-resident) path could take: n_cur and n <= K3_LIT_STATS tokens
+    if (tid == 0 && f >= 0 && n_cur <= K3_LIT_STATS && n <= K3_LIT_STATS) {
+      const long long el = eps_l1 - eps_l0; long long *P = p.prof + blockIdx.x * 16;
+      auto mx = [&](int k, long long v) { if (v > P[k]) P[k] = v; };
+      mx(0, n_cid); mx(1, n_arc); mx(2, n_iq); mx(3, el); mx(4, (long long)m_e + created_total);
+      P[5] += 1; P[6] += n_cid > 1024; P[7] += n_cid > 1536; P[8] += n_iq > 1024; P[9] += el > 2048; P[10] += (long long)m_e + created_total > 32768; P[11] += n_cid; P[12] += n_arc; P[13] += n_iq; P[14] += el; P[15] += n_arc > 2048;
+    }
+#endif
     if (n_e + created_total != n) { if (tid == 0) sh.err = K3_ERR_HIP; }      // every token of the fixpoint must have been created by the replay
     if (block_err(sh)) break;
     __syncthreads();
@@ -910,12 +958,17 @@ __global__ __launch_bounds__(kBlock, 4) void k3_decode_forward_literal_kernel(De
     __syncthreads();
     K3_LT(11);
     cur_base = nb; n_cur = n; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1;
+    if (tid == 0 && f >= 0) cyc_general += (long long)__builtin_readcyclecounter() - cyc_t0;
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
   }
   { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { k3a_add(&sh.n_eps, a); k3a_add(&sh.n_emit, b); k3a_add(&sh.n_os, c); } }
   __syncthreads();
 #ifdef K3_LIT_PROF
   if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
+#elif defined(K3_FAST_PROF)
+  if (tid == 0) { long long *P = p.prof + blockIdx.x * 16; for (int k = 0; k < 12; k++) P[k] += fs.prof[k]; P[12] += n_fast; P[13] += n_gaveup; P[14] += n_general; P[15] += cyc_fast; }
+#elif !defined(K3_LIT_STATS)
+  if (tid == 0) { long long *P = p.prof + blockIdx.x * 16; for (int k = 0; k < 12; k++) P[k] += why[k]; P[12] += n_fast; P[13] += n_gaveup; P[14] += n_general; P[15] += cyc_fast; P[11] += cyc_general; }
 #endif
   if (tid == 0) {
     LaneInfo &li = p.info[L];

@@ -48,7 +48,7 @@ class DecoderConfig(ctypes.Structure):
     """k3_decoder_config (include/k3hip.h); decoding fields = LatticeFasterDecoderConfig (decoder/lattice-faster-decoder.h:37-107)."""
     _fields_ = [("beam", ctypes.c_float), ("max_active", ctypes.c_int32), ("min_active", ctypes.c_int32), ("lattice_beam", ctypes.c_float),
                 ("beam_delta", ctypes.c_float), ("frame_tokens_cap", ctypes.c_int32), ("frame_cands_cap", ctypes.c_int32),
-                ("lane_tokens_cap", ctypes.c_int64), ("lane_links_cap", ctypes.c_int64), ("literal_order", ctypes.c_int32), ("hash_ratio", ctypes.c_float)]
+                ("lane_tokens_cap", ctypes.c_int64), ("lane_links_cap", ctypes.c_int64), ("literal_order", ctypes.c_int32), ("hash_ratio", ctypes.c_float), ("fast_frame_tokens", ctypes.c_int32)]
 
 WINDOW_TYPES = {"hanning": 0, "sine": 1, "hamming": 2, "povey": 3, "rectangular": 4, "blackman": 5}
 

@@ -16,7 +16,7 @@ ll = nb.forward(sf.ComputeFeatures(waves, wo, fo, total_frames)); torch.cuda.syn
 f = synth.make_hclg(); cf = decoder.CudaFst(f, synth.tid2pdf(net.info.output_dim))
 CAP = int(os.environ.get("K3_PROF_CAP", 65536))
 for literal in (1, 0):
-    cfg = decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, frame_tokens_cap=CAP, frame_cands_cap=max(131072, CAP + 1) if CAP > 30000 else 65536, lane_tokens_cap=1_600_000, lane_links_cap=2_200_000, literal_order=literal)
+    cfg = decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, fast_frame_tokens=int(os.environ.get("K3_FAST", -1)), frame_tokens_cap=CAP, frame_cands_cap=max(131072, CAP + 1) if CAP > 30000 else 65536, lane_tokens_cap=1_600_000, lane_links_cap=2_200_000, literal_order=literal)
     dec = decoder.CudaDecoder(cf, cfg, U, net.info.output_dim); dec.SetProfiling(True)
     for it in range(2):
         dec.DecodeBatch(ll, nb.out_offsets); torch.cuda.synchronize(); kt = dec.KernelTimes()
@@ -26,6 +26,9 @@ for literal in (1, 0):
     if os.environ.get("K3_PRUNE_PROF"):      # library built with -DK3_PRUNE_PROF: cycles of the pruning kernel's stages, per lane
         cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
         print("prune kernel cycles/lane:", dict(zip(["last frame", "staging", "emitting links", "eps fixpoint", "offsets", "HBM-path frames"], (cyc[:6] // U).tolist())))
+    elif literal and not os.environ.get("K3HIP_LIB"):      # the shipped library: frames by path (LDS-resident / given up and redone / general) and why the fast path gave up
+        cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
+        print("cycles/lane: fast frames", cyc[15] // U, "general frames", cyc[11] // U, "| frames: fast", cyc[12], "gave up", cyc[13], "general (incl. redone)", cyc[14], "| give-up reasons", dict(zip(["tokens", "table", "hash", "labels", "worklist", "eps links", "degree", "closure", "queue", "stack", "mismatch", "pool"], cyc[:12].tolist())))
     elif literal:
         cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
         names = ["cutoff", "hash resize+prepass", "passA+chunk scan", "(non-LDS replay cycles)", "passB+c0", "(non-LDS replay pops)", "order1", "closure", "csr build", "replay", "order2", "publish"]
