@@ -216,6 +216,11 @@ int k3_fst_import_image(k3_fst *fst, const void *d_src);   /* the reverse, after
  * id_file, the others wait up to timeout_seconds for it).  RCCL is bound at run time (dlopen): single-GPU users never load it. */
 int k3_comm_create(const char *id_file, int32_t rank, int32_t world_size, int32_t timeout_seconds, void **comm);
 void k3_comm_destroy(void *comm);
+/* the rendezvous' file protocol by itself (no RCCL): rank 0 publishes the 128 bytes at id_in, the others receive them in id_out; files of other runs are
+ * refused (run identity: K3_COMM_NONCE / TORCHELASTIC_RUN_ID when set, otherwise nothing older than stale_seconds before the caller's start) */
+int k3_comm_exchange_id(const char *id_file, int32_t rank, int32_t timeout_seconds, int32_t stale_seconds, const void *id_in, void *id_out);
+/* in-place sum over the ranks of `comm` (ncclAllReduce): the gradient exchange of data-parallel chain training; asynchronous on `stream` */
+int k3_comm_allreduce_f32(void *comm, float *d_buf, int64_t count, void *stream);
 int k3_fst_bcast(k3_fst **fst, void *comm /* ncclComm_t */, int32_t root, int32_t rank, void *stream);
 
 /* ---------------------------------------------------------------- lattice decoder ------------

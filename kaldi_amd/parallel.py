@@ -51,3 +51,24 @@ def reduce_rtfx(audio_s, wall_s, device=None):
     a = torch.tensor([audio_s], dtype=torch.float64, device=device); w = torch.tensor([wall_s], dtype=torch.float64, device=device)
     dist.all_reduce(a, op=dist.ReduceOp.SUM); dist.all_reduce(w, op=dist.ReduceOp.MAX)
     return a.item() / w.item()
+
+def allreduce_gradients(grads, world=None, bucket_bytes=64 << 20):
+    """Synchronous data-parallel chain training: the ranks' gradients (a list of tensors, the same shapes on every rank, each
+    computed on that rank's share of the minibatch with the objective SUMMED over sequences) are summed in place over the process group --
+    RCCL over xGMI for CUDA tensors, gloo on CPU in the tests.  The tensors travel in flat buckets of ~bucket_bytes: xGMI is point-to-point
+    (ring collectives are per-link bound), so a few large all-reduces beat one per parameter matrix.  (C ABI: k3_comm_allreduce_f32.)"""
+    if world is None: world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1 or not grads: return grads
+    bucket, size = [], 0
+    def flush():
+        nonlocal bucket, size
+        if not bucket: return
+        flat = torch.cat([g.reshape(-1) for g in bucket]); dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        o = 0
+        for g in bucket: g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+        bucket, size = [], 0
+    for g in grads:
+        bucket.append(g); size += g.numel() * g.element_size()
+        if size >= bucket_bytes: flush()
+    flush()
+    return grads

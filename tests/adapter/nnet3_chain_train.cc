@@ -75,6 +75,15 @@ int main(int argc, char *argv[]) {
     fst::StdVectorFst den_fst; ToFst(den, h[2], &den_fst); chain::DenominatorGraph den_graph(den_fst, P);
     chain::Supervision supervision; ToFst(merged, 0, &supervision.fst); supervision.weight = fo[2]; supervision.num_sequences = B; supervision.frames_per_sequence = T; supervision.label_dim = P;
 #endif
+#ifdef K3_ADAPTER
+    // K3_TRAIN_ID_FILE [+ K3_TRAIN_RANK / K3_TRAIN_WORLD]: this process is one rank of a data-parallel job (k3_comm_create: RCCL communicator through a rendezvous file)
+    void *comm = NULL; int32 world = 1;
+    if (const char *idf = getenv("K3_TRAIN_ID_FILE")) {
+      const int32 rank = getenv("K3_TRAIN_RANK") ? atoi(getenv("K3_TRAIN_RANK")) : 0; world = getenv("K3_TRAIN_WORLD") ? atoi(getenv("K3_TRAIN_WORLD")) : 1;
+      if (k3_comm_create(idf, rank, world, 120, &comm) != K3_OK) KALDI_ERR << k3_last_error();
+      KALDI_LOG << "data-parallel rank " << rank << " of " << world << ": parameter changes all-reduced over RCCL every iteration";
+    }
+#endif
     MaxChangeStats max_change_stats(nnet);
     Vector<BaseFloat> objfs(3 * num_iters + NumParameters(nnet));      // per iteration [objf, l2_term, weight], then every parameter of the trained model (VectorizeNnet)
     CuMatrix<BaseFloat> cu_in_orig(input);
@@ -97,6 +106,15 @@ int main(int argc, char *argv[]) {
 #endif
       srand(2 * iter + 2);
       computer.AcceptInput("output", &nnet_output_deriv); computer.Run();
+#ifdef K3_ADAPTER
+      if (comm) {      // data-parallel ranks (one process per GPU, each with its share of the minibatch): the ranks' parameter changes are summed over RCCL / xGMI and averaged --
+        // what the reference's recipes do with the jobs' models after every iteration (egs/wsj/s5/steps/libs/nnet3/train/chain_objf/acoustic_model.py:121,238), here inside the iteration
+        Vector<BaseFloat> flat_host(NumParameters(*delta_nnet), kUndefined); VectorizeNnet(*delta_nnet, &flat_host);      // (nnet-utils.h:148 works on host vectors: one bucket for the whole model)
+        CuVector<BaseFloat> flat(flat_host);
+        if (k3_comm_allreduce_f32(comm, flat.Data(), flat.Dim(), NULL) != K3_OK) KALDI_ERR << k3_last_error();
+        flat.Scale(1.0 / world); flat.CopyToVec(&flat_host); UnVectorizeNnet(flat_host, delta_nnet);
+      }
+#endif
       ApplyL2Regularization(nnet, B * l2_regularize_factor, delta_nnet);      // GetNumNvalues(eg.inputs, false) = the number of sequences
       const bool success = UpdateNnetWithMaxChange(*delta_nnet, max_param_change, 1.0, 1.0 - momentum, &nnet, &max_change_stats);
       ScaleBatchnormStats(batchnorm_stats_scale, &nnet);
@@ -108,6 +126,7 @@ int main(int argc, char *argv[]) {
     max_change_stats.Print(nnet);
 #ifdef K3_ADAPTER
     k3_chain_supervision_destroy(ksup); k3_chain_den_destroy(kden);
+    if (comm) k3_comm_destroy(comm);
 #endif
     delete delta_nnet;
     { SubVector<BaseFloat> pv(objfs, 3 * num_iters, objfs.Dim() - 3 * num_iters); VectorizeNnet(nnet, &pv); }

@@ -178,6 +178,9 @@ def test_chain_training_iterations_equal_the_reference(iters, momentum, tmp_path
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"); args = [f"{td}/m.raw", str(s), f"{td}/in.mat", f"{td}/chain.spec", str(iters), "0.002", str(momentum)]
     g = subprocess.run([exe] + args + [f"{td}/g.raw", f"{td}/g.vec"], capture_output=True, text=True, env=env); assert g.returncode == 0, g.stderr[-3000:]
     gv = _read_kaldi(f"{td}/g.vec"); go = gv[:3 * iters].reshape(iters, 3); gp = gv[3 * iters:]
+    if iters == 1:      # the same iteration as rank 0 of a one-rank data-parallel job: the parameter changes go through k3_comm_create + k3_comm_allreduce_f32 (RCCL) and come back unchanged
+        g2 = subprocess.run([exe] + args + [f"{td}/g2.raw", f"{td}/g2.vec"], capture_output=True, text=True, env=dict(env, K3_TRAIN_ID_FILE=f"{td}/nccl.id", K3_TRAIN_RANK="0", K3_TRAIN_WORLD="1")); assert g2.returncode == 0, g2.stderr[-3000:]
+        assert "data-parallel rank 0 of 1" in g2.stderr and np.array_equal(_read_kaldi(f"{td}/g2.vec"), gv)
     p0 = np.concatenate([np.concatenate([c[2]["W"].ravel()] + ([c[2]["b"].ravel()] if "b" in c[2] and c[2]["b"].size else [])) for c in net.components if c[1] in ("affine", "tdnn", "linear")])
     assert p0.shape == gp.shape
     tried = []

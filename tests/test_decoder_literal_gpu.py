@@ -16,7 +16,7 @@ _CAPS = dict(frame_tokens_cap=65536, frame_cands_cap=262144, lane_tokens_cap=2_5
 
 def _decode(cf, N, lls, literal=True, **cfg):
     from kaldi_amd import decoder
-    kw = {k: v for k, v in cfg.items() if k in ("beam", "max_active", "min_active", "lattice_beam", "beam_delta", "hash_ratio")}
+    kw = {k: v for k, v in cfg.items() if k in ("beam", "max_active", "min_active", "lattice_beam", "beam_delta", "hash_ratio", "fast_frame_tokens")}
     c = decoder.decoder_config(literal_order=int(literal), **dict(_CAPS, **kw))      # 1: component replay, 2: one-wavefront replay (the fall-back of 1)
     dec = decoder.CudaDecoder(cf, c, len(lls), N)
     ro = np.concatenate([[0], np.cumsum([l.shape[0] for l in lls])])
@@ -35,14 +35,17 @@ def _check_against_oracle(dec, u, lat, f, ll, t2p, kw):
     assert d == "", (u, d)
     return oi
 
-@pytest.mark.parametrize("replay", [1, 2, 3])      # 3: component replay whose stack slices are empty: every component that needs its stack falls back to the one-wavefront replay
+# replay 1: frames of <= 1536 tokens on the LDS-resident path (k3_decoder_fast.h), the others on the general path; 2 / 3: general path with the one-wavefront replay / with component stacks of
+# length zero (every component that needs its stack falls back to the one-wavefront replay); (1, 0): general path only; (1, 96): an LDS path of 96 tokens -- most frames
+# give up half-way and are redone, the two paths alternate all the time
+@pytest.mark.parametrize("replay,fast", [(1, -1), (2, -1), (3, -1), (1, 0), (1, 96)])
 @pytest.mark.parametrize("name", sorted(dcases.CASES))
-def test_literal_order_equals_the_reference_decoder(name, replay):
+def test_literal_order_equals_the_reference_decoder(name, replay, fast):
     from kaldi_amd import decoder
     from oracle import ref_decoder as rd, lattice_oracle as lo
     f, t2p, ll, kw = dcases.make(name); N = ll.shape[1]
     cf = decoder.CudaFst(f, t2p)
-    lats, info, dec = _decode(cf, N, [ll, ll[: max(1, ll.shape[0] // 2)]], literal=replay, **kw)
+    lats, info, dec = _decode(cf, N, [ll, ll[: max(1, ll.shape[0] // 2)]], literal=replay, fast_frame_tokens=fast, **kw)
     assert (info[:, 2] == 0).all(), info[:, 2]
     oi = _check_against_oracle(dec, 0, lats[0], f, ll, t2p, kw)
     _check_against_oracle(dec, 1, lats[1], f, ll[: max(1, ll.shape[0] // 2)], t2p, kw)
@@ -53,8 +56,8 @@ def test_literal_order_equals_the_reference_decoder(name, replay):
     if rd.available():                                             # and live
         assert lsig.canonical_of_reference(rd.decode(f, ll, t2p, lo.Config(**kw))) == canon
 
-@pytest.mark.parametrize("replay", [1, 2, 3])
-def test_literal_order_random_configurations_and_lane_reuse(replay):
+@pytest.mark.parametrize("replay,fast", [(1, -1), (2, -1), (3, -1), (1, 0), (1, 200)])
+def test_literal_order_random_configurations_and_lane_reuse(replay, fast):
     """random graphs / lengths / spreads / every LatticeFasterDecoderConfig field incl. cost grids with exact ties; the same decoder object
     decodes every batch (scratch must return to its idle state), lanes hold different utterances"""
     from kaldi_amd import decoder
@@ -69,7 +72,7 @@ def test_literal_order_random_configurations_and_lane_reuse(replay):
         if rng.random() < 0.5: kw["min_active"] = int(rng.choice([0, 20, 500]))
         if "max_active" in kw and kw.get("min_active", 200) >= kw["max_active"]: kw["min_active"] = max(0, kw["max_active"] - 1)
         cf = decoder.CudaFst(f, t2p)
-        lats, info, dec = _decode(cf, N, lls, literal=replay, **kw)
+        lats, info, dec = _decode(cf, N, lls, literal=replay, fast_frame_tokens=fast, **kw)
         for u, ll in enumerate(lls):
             assert info[u, 2] in (0, 1), (it, u, info[u])
             if info[u, 2] == 0: _check_against_oracle(dec, u, lats[u], f, ll, t2p, kw)
@@ -85,8 +88,8 @@ def test_literal_order_chunked_advance_equals_whole_utterance():
     rng = np.random.default_rng(5)
     lls = [(rng.standard_normal((T, N)) * 2.5).astype(np.float32) for T in (120, 45, 77)]
     cfg = dict(beam=14.0, lattice_beam=7.0, max_active=3000)
-    whole, _, _ = _decode(cf, N, lls, **cfg)
-    dec = decoder.CudaDecoder(cf, decoder.decoder_config(literal_order=1, **dict(_CAPS, **cfg)), 3, N)
+    whole, _, _ = _decode(cf, N, lls, fast_frame_tokens=0, **cfg)      # (general path only; the chunked run below alternates between the paths)
+    dec = decoder.CudaDecoder(cf, decoder.decoder_config(literal_order=1, fast_frame_tokens=400, **dict(_CAPS, **cfg)), 3, N)
     dec.InitDecoding(3, 130); done = [0, 0, 0]
     for chunk in ([50, 45, 0], [17, 0, 30], [53, 0, 47]):
         parts = [lls[u][done[u]:done[u] + c] for u, c in enumerate(chunk)]

@@ -16,6 +16,11 @@ def test_graph_broadcast_through_the_c_abi_single_rank(tmp_path):
     h = ctypes.c_void_p(cf._h.value)
     lib.check(L.k3_fst_bcast(ctypes.byref(h), comm, 0, 0, None))
     assert h.value == cf._h.value                       # the root keeps its graph
+    # the gradient exchange of data-parallel training on the same communicator: in-place sum over the (one) rank
+    L.k3_comm_allreduce_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    g = torch.arange(100000, dtype=torch.float32, device="cuda") * 0.25; g0 = g.clone()
+    lib.check(L.k3_comm_allreduce_f32(comm, g.data_ptr(), g.numel(), None)); torch.cuda.synchronize()
+    assert torch.equal(g, g0)
     L.k3_comm_destroy(comm)
     rng = np.random.default_rng(0); ll = (rng.standard_normal((40, N)) * 2.5).astype(np.float32)
     dec = decoder.CudaDecoder(cf, decoder.decoder_config(beam=15.0, lattice_beam=8.0, literal_order=1), 1, N)
