@@ -471,11 +471,12 @@ def main():
                     line["e2e_parity"] = par
                     # The stage gates at the bench's own scale, on the REFERENCE's intermediate results (so that each stage is judged on identical inputs):
                     #   N: k3_nnet_forward on the reference's features vs the reference's nnet3-compute;  D: k3_decoder on the reference's log-likelihoods vs the reference's lattices
-                    us = sorted(kept); rf = np.zeros((total_frames, sf.dim), np.float32); rl = np.zeros((int(nb.total_out_rows), num_pdfs), np.float32); oo = np.asarray(nb.out_offsets)
-                    for u in us: rf[fo_h[u]:fo_h[u + 1]] = kept[u][0]; rl[oo[u]:oo[u + 1]] = kept[u][1]
+                    us = sorted(kept); rf = gpu[4].copy(); oo = np.asarray(nb.out_offsets)      # (utterances outside the sample keep the GPU's own features: the network is planned for the whole batch)
+                    for u in us: rf[fo_h[u]:fo_h[u + 1]] = kept[u][0]
                     g_ll = nb.forward(torch.from_numpy(rf).to(dev)); torch.cuda.synchronize(); g_llh = g_ll.cpu().numpy()
                     nd = max(float(np.abs(g_llh[oo[u]:oo[u + 1]] - kept[u][1]).max()) for u in us)
-                    dec = decs["literal"]; dec.DecodeBatch(torch.from_numpy(rl).to(dev), nb.out_offsets); glats = dec.GetRawLattices(copy=True)
+                    rl = np.concatenate([kept[u][1] for u in us]); ro_k = np.concatenate([[0], np.cumsum([kept[u][1].shape[0] for u in us])])      # the sample's utterances, lane k = utterance us[k]
+                    dec = decs["literal"]; dec.DecodeBatch(torch.from_numpy(rl).to(dev), ro_k); glats_k = dec.GetRawLattices(copy=True); glats = {u: glats_k[k] for k, u in enumerate(us)}
                     def same_lattice(u):      # every state (frame, final-cost bits) and every arc (source frame, emitting / epsilon, labels, graph- and acoustic-cost BITS), as multisets: identity up to the names of the states
                         r, l = kept[u][2], glats[u]; bits = lambda x: (np.asarray(x, np.float32) + np.float32(0)).view(np.int32).astype(np.int64)
                         ka = np.stack([r["frame"][r["src"]], r["frame"][r["dst"]], r["ilabel"], r["olabel"], bits(r["graph"]), bits(r["ac"])], 1); kb = np.stack([l.st_frame[l.arc_src], l.st_frame[l.arc_dst], l.arc_ilabel, l.arc_olabel, bits(l.arc_graph), bits(l.arc_ac)], 1)
