@@ -5,6 +5,10 @@
 // (cudamatrix/cu-matrix.cc, cu-kernels.cu); the fused path in k3_nnet.hip is the fast path for the same models.
 // All matrices are row-major float32 with a leading dimension (CuMatrixBase::Stride()), device pointers.
 #include "k3_common.h"
+#include <atomic>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -60,6 +64,111 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
       if (row < M) C[(long long)row * ldc + col] = total[r] + alpha * acc[r];
     }
   }
+}
+
+// The same product for operands that allow 16-byte loads (16-byte aligned base pointers, leading dimensions a multiple of 4 floats -- whole CuMatrix objects, not arbitrary column
+// ranges): 128 x 128 x 16 tiles, 4 wavefronts of 2 x 2 32x32 MFMA tiles, every operand fetched with dwordx4 loads along its CONTIGUOUS dimension (k when the operand is used as
+// stored for A / transposed for B, the m / n dimension otherwise), the next k-tile in registers while the present one is multiplied (one barrier per k-tile, two LDS buffers).
+// Same accumulation order as k3_gemm_generic_kernel: k ascending, 384-wide blocks added to a total that starts at beta C.  The training pass's GEMMs (activations x weights,
+// output derivative x weights, output derivative^T x activations over a minibatch) all qualify; the generic kernel stays the fall-back.
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void k3_gemm_tile128_kernel(int M, int N, int K, float alpha, const float *__restrict__ A, long long lda, const float *__restrict__ B, long long ldb, float beta,
+                                                              float *C, long long ldc, float *W, int Kc) {
+  __shared__ float As[2][128][17], Bs[2][16][132];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  int kb_ = 0, ke_ = K;
+  if (W) { kb_ = (int)blockIdx.z * Kc; ke_ = min(K, kb_ + Kc); C = W + (long long)blockIdx.z * M * N; ldc = N; alpha = 1.0f; beta = 0.0f; }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  f32x16 acc[2][2], total[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        acc[i][j][r] = 0.0f; total[i][j][r] = 0.0f;
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (beta != 0.0f && row < M && col < N) total[i][j][r] = beta * C[(long long)row * ldc + col];
+      }
+    }
+  f32x4 ra[2], rb[2];
+  // one k-tile of both operands into registers: two dwordx4 per thread and operand; elements outside the matrices / the k range are zero
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int f = tid + 256 * u;
+      {
+        const int r = TA ? (f & 31) * 4 : (f >> 2), k = TA ? (f >> 5) : (f & 3) * 4;      // TA: k-major rows of 128 m's; else m-major rows of 16 k's
+        const int gm = m0 + r, gk = k0 + k; f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (TA) {
+          if (gk < ke_) { const float *src = A + (long long)gk * lda + gm; if (gm + 3 < M) v = *reinterpret_cast<const f32x4 *>(src); else { for (int e = 0; e < 4; e++) if (gm + e < M) v[e] = src[e]; } }
+        } else {
+          if (gm < M) { const float *src = A + (long long)gm * lda + gk; if (gk + 3 < ke_) v = *reinterpret_cast<const f32x4 *>(src); else { for (int e = 0; e < 4; e++) if (gk + e < ke_) v[e] = src[e]; } }
+        }
+        ra[u] = v;
+      }
+      {
+        const int c = TB ? (f >> 2) : (f & 31) * 4, k = TB ? (f & 3) * 4 : (f >> 5);      // TB: n-major rows of 16 k's; else k-major rows of 128 n's
+        const int gn = n0 + c, gk = k0 + k; f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (TB) {
+          if (gn < N) { const float *src = B + (long long)gn * ldb + gk; if (gk + 3 < ke_) v = *reinterpret_cast<const f32x4 *>(src); else { for (int e = 0; e < 4; e++) if (gk + e < ke_) v[e] = src[e]; } }
+        } else {
+          if (gk < ke_) { const float *src = B + (long long)gk * ldb + gn; if (gn + 3 < N) v = *reinterpret_cast<const f32x4 *>(src); else { for (int e = 0; e < 4; e++) if (gn + e < N) v[e] = src[e]; } }
+        }
+        rb[u] = v;
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int f = tid + 256 * u;
+      if (TA) { const int r = (f & 31) * 4, k = f >> 5; for (int e = 0; e < 4; e++) As[buf][r + e][k] = ra[u][e]; }
+      else { const int r = f >> 2, k = (f & 3) * 4; for (int e = 0; e < 4; e++) As[buf][r][k + e] = ra[u][e]; }
+      if (TB) { const int c = f >> 2, k = (f & 3) * 4; for (int e = 0; e < 4; e++) Bs[buf][k + e][c] = rb[u][e]; }
+      else { const int c = (f & 31) * 4, k = f >> 5; for (int e = 0; e < 4; e++) Bs[buf][k][c + e] = rb[u][e]; }
+    }
+  };
+  fetch(kb_); stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb_; k0 < ke_; k0 += 16, buf ^= 1) {
+    if (k0 != kb_ && k0 % 384 == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) { total[i][j][r] += alpha * acc[i][j][r]; acc[i][j][r] = 0.0f; }
+    }
+    const bool more = k0 + 16 < ke_;
+    if (more) fetch(k0 + 16);      // in flight while this tile is multiplied
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      const int k = 2 * kk + (lane >> 5);
+      const float a0 = As[buf][wm * 64 + (lane & 31)][k], a1 = As[buf][wm * 64 + 32 + (lane & 31)][k];
+      const float b0 = Bs[buf][k][wn * 64 + (lane & 31)], b1 = Bs[buf][k][wn * 64 + 32 + (lane & 31)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0); acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0); acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) stage(buf ^ 1);      // (the other buffer was last read before the previous barrier)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M) C[(long long)row * ldc + col] = total[i][j][r] + alpha * acc[i][j][r];
+        }
+      }
+    }
 }
 
 __global__ void k3_gemm_splitk_reduce_kernel(const float *W, int S, long long MN, int N, float alpha, float beta, float *C, long long ldc) {
@@ -132,15 +241,26 @@ __global__ void k3_vec64_kernel(int op, double alpha, const double *a, const dou
 
 // v[c] = beta v[c] + alpha sum_r f(r, c): AddRowSumMat (f = M), AddDiagMat2 with kTrans (f = M^2), AddDiagMatMat(M, kTrans, N, kNoTrans) (f = M N); op 3 / 4: the same
 // over the columns of a row (v[r]: AddDiagMat2 kNoTrans, AddColSumMat).  One wavefront-wide column strip per workgroup row block; partial sums in double.
-struct RedParams { int op, rows, cols; const float *M; long long ldm; const float *N; long long ldn; float *v; float alpha, beta; };
-__global__ __launch_bounds__(256) void k3_colred_kernel(RedParams p) {
+struct RedParams { int op, rows, cols; const float *M; long long ldm; const float *N; long long ldn; float *v; float alpha, beta; double *part; int rows_per_chunk; };
+__global__ __launch_bounds__(256) void k3_colred_kernel(RedParams p) {      // blockIdx.y = row chunk: partial sums (double) to p.part[chunk][col], or the result itself when there is one chunk
   __shared__ double part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * p.rows_per_chunk, r1 = min(p.rows, r0 + p.rows_per_chunk);
   double acc = 0.0;
-  if (c < p.cols) for (int r = w; r < p.rows; r += 4) { const float m = p.M[(long long)r * p.ldm + c]; acc += p.op == 0 ? (double)m : p.op == 1 ? (double)m * m : (double)m * p.N[(long long)r * p.ldn + c]; }
+  if (c < p.cols) for (int r = r0 + w; r < r1; r += 4) { const float m = p.M[(long long)r * p.ldm + c]; acc += p.op == 0 ? (double)m : p.op == 1 ? (double)m * m : (double)m * p.N[(long long)r * p.ldn + c]; }
   part[w][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (w == 0 && c < p.cols) { const double s_ = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]; p.v[c] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[c]) + p.alpha * (float)s_; }
+  if (w == 0 && c < p.cols) {
+    const double s_ = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (p.part) p.part[(long long)blockIdx.y * p.cols + c] = s_;
+    else p.v[c] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[c]) + p.alpha * (float)s_;
+  }
+}
+__global__ void k3_colred_fold_kernel(RedParams p, int chunks) {      // chunks added in ascending order (deterministic)
+  const int c = blockIdx.x * 256 + threadIdx.x; if (c >= p.cols) return;
+  double s_ = 0.0;
+  for (int y = 0; y < chunks; y++) s_ += p.part[(long long)y * p.cols + c];
+  p.v[c] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[c]) + p.alpha * (float)s_;
 }
 __global__ __launch_bounds__(64) void k3_rowred_kernel(RedParams p) {      // one wavefront per row
   const int r = blockIdx.x, lane = threadIdx.x; double acc = 0.0;
@@ -186,28 +306,55 @@ EwParams mk(int op, float *C, long long ldc, int rows, int cols) { EwParams p{};
 
 #define K3_MAT_REQUIRE(C, ldc, rows, cols) K3_REQUIRE((C) && (rows) >= 0 && (cols) >= 0 && (ldc) >= (cols), "k3_mat: bad matrix argument")
 
+// scratch that a two-kernel operation hands from its first kernel to its second (split-K planes, column-reduction partials): one buffer per (device, stream), so that
+// operations queued on different streams never share one; it only grows (after a device synchronise: an earlier operation of the stream may still read the old one)
+namespace {
+int workspace(hipStream_t st, size_t bytes, void **out) {
+  struct Ws { void *p = nullptr; size_t cap = 0; };
+  static std::mutex mu; static std::map<std::pair<int, hipStream_t>, Ws> tab;
+  int dev = 0; K3_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(mu);
+  Ws &w = tab[{dev, st}];
+  if (bytes > w.cap) {
+    if (w.p) { K3_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(w.p); w.p = nullptr; w.cap = 0; }
+    const size_t cap = std::max(bytes + bytes / 2, (size_t)1 << 20);
+    K3_HIP_CHECK(hipMalloc(&w.p, cap)); w.cap = cap;
+  }
+  *out = w.p; return K3_OK;
+}
+std::atomic<long long> g_gemm_flops{0};
+void launch_gemm(int ta, int tb, bool fast, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const float *A, long long lda, const float *B, long long ldb, float beta, float *C, long long ldc, float *W, int Kc) {
+  if (!fast) { hipLaunchKernelGGL(k3_gemm_generic_kernel, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, ta, B, ldb, tb, beta, C, ldc, W, Kc); return; }
+  if (ta) { if (tb) hipLaunchKernelGGL((k3_gemm_tile128_kernel<1, 1>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc); else hipLaunchKernelGGL((k3_gemm_tile128_kernel<1, 0>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc); }
+  else { if (tb) hipLaunchKernelGGL((k3_gemm_tile128_kernel<0, 1>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc); else hipLaunchKernelGGL((k3_gemm_tile128_kernel<0, 0>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc); }
+}
+}  // namespace
+
+extern "C" int64_t k3_mat_gemm_flops(int32_t reset) { return reset ? g_gemm_flops.exchange(0) : g_gemm_flops.load(); }      // 2 M N K summed over the k3_mat_add_mat_mat calls of this process
+
 extern "C" int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta,
                                   float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream) {
   K3_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && ldc >= N, "k3_mat_add_mat_mat: bad argument");
   K3_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N), "k3_mat_add_mat_mat: leading dimension smaller than the row length");
   if (M == 0 || N == 0) return K3_OK;
-  const long long tiles = (long long)((N + 63) / 64) * ((M + 63) / 64);
-  if (tiles < 384 && K >= 3072) {      // few output tiles, long K (a layer's weight gradient over a minibatch): split K so that the chip is filled; planes reduced in a fixed order
-    int S = (int)std::min<long long>(16, std::max<long long>(2, 1024 / tiles)); int Kc = ((K + S - 1) / S + 383) / 384 * 384; S = (K + Kc - 1) / Kc;
-    static thread_local float *ws = nullptr; static thread_local size_t ws_cap = 0; static thread_local int ws_dev = -1;
-    int dev = 0; K3_HIP_CHECK(hipGetDevice(&dev));
-    const size_t need = (size_t)S * M * N;
-    if (need > ws_cap || dev != ws_dev) {
-      if (ws && dev == ws_dev) { K3_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(ws); }      // (the planes of an earlier call may still be read)
-      K3_HIP_CHECK(hipMalloc((void **)&ws, need * sizeof(float))); ws_cap = need; ws_dev = dev;
-    }
-    hipLaunchKernelGGL(k3_gemm_generic_kernel, dim3((N + 63) / 64, (M + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, M, N, K, alpha, d_A, lda, trans_a, d_B, ldb, trans_b, beta, d_C, ldc, ws, Kc);
+  g_gemm_flops += 2ll * M * N * K;
+  // the 128 x 128 tile kernel wants dwordx4 loads: aligned operands and enough output to fill a tile grid (small products stay on the 64 x 64 generic kernel)
+  const bool fast = ((reinterpret_cast<uintptr_t>(d_A) | reinterpret_cast<uintptr_t>(d_B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 && K >= 16 && ((long long)M * N >= 128 * 128 || K >= 1024) && !getenv("K3_GEMM_GENERIC");      // (small outputs with a long K -- the preconditioner's Gram products -- fill the chip through split-K)
+  const int T = fast ? 128 : 64, ta = trans_a ? 1 : 0, tb = trans_b ? 1 : 0;
+  if (!fast && getenv("K3_GEMM_TRACE")) fprintf(stderr, "k3 generic gemm M %d N %d K %d ta %d tb %d lda %lld ldb %lld A&15 %d B&15 %d\n", M, N, K, ta, tb, (long long)lda, (long long)ldb, (int)(reinterpret_cast<uintptr_t>(d_A) & 15), (int)(reinterpret_cast<uintptr_t>(d_B) & 15));      // developer aid: which products miss the tile kernel
+  const long long tiles = (long long)((N + T - 1) / T) * ((M + T - 1) / T);
+  hipStream_t st = (hipStream_t)stream;
+  if (tiles < (fast ? 192 : 384) && K >= (fast ? 1536 : 3072)) {      // few output tiles, long K (a layer's weight gradient over a minibatch): split K so that the chip is filled; planes reduced in a fixed order
+    int S = (int)std::min<long long>(fast ? 64 : 16, std::max<long long>(2, (fast ? 512 : 1024) / tiles)); int Kc = ((K + S - 1) / S + 383) / 384 * 384; S = (K + Kc - 1) / Kc;
+    void *wsv = nullptr; { const int rc = workspace(st, (size_t)S * M * N * sizeof(float), &wsv); if (rc) return rc; }
+    float *ws = static_cast<float *>(wsv);
+    launch_gemm(ta, tb, fast, dim3((N + T - 1) / T, (M + T - 1) / T, S), st, M, N, K, alpha, d_A, (long long)lda, d_B, (long long)ldb, beta, d_C, (long long)ldc, ws, Kc);
     const long long MN = (long long)M * N;
-    hipLaunchKernelGGL(k3_gemm_splitk_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, S, MN, N, alpha, beta, d_C, ldc);
+    hipLaunchKernelGGL(k3_gemm_splitk_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, ws, S, MN, N, alpha, beta, d_C, ldc);
     K3_HIP_CHECK(hipGetLastError());
     return K3_OK;
   }
-  hipLaunchKernelGGL(k3_gemm_generic_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, N, K, alpha, d_A, lda, trans_a, d_B, ldb, trans_b, beta, d_C, ldc, (float *)nullptr, 0);
+  launch_gemm(ta, tb, fast, dim3((N + T - 1) / T, (M + T - 1) / T), st, M, N, K, alpha, d_A, (long long)lda, d_B, (long long)ldb, beta, d_C, (long long)ldc, (float *)nullptr, 0);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }
@@ -277,8 +424,20 @@ extern "C" int k3_mat_reduce_scalar(int32_t op, const float *d_A, int64_t lda, c
 }
 extern "C" int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *st) {
   K3_REQUIRE(d_M && d_v && rows >= 0 && cols >= 0 && ldm >= cols && op >= 0 && op <= 4 && (op != 2 || (d_N && ldn >= cols)), "k3_vec_col_reduce: bad argument");
-  RedParams p{op, rows, cols, d_M, ldm, d_N, ldn, d_v, alpha, beta};
-  if (op <= 2) { if (cols > 0) hipLaunchKernelGGL(k3_colred_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)st, p); }
+  RedParams p{op, rows, cols, d_M, ldm, d_N, ldn, d_v, alpha, beta, nullptr, rows};
+  if (op <= 2) {
+    if (cols > 0) {
+      // rows split into chunks so that the launch fills the chip (a [9152 x 768] sum was 12 workgroups walking 9152 rows each); partials in double, folded in chunk order
+      const int xb = (cols + 63) / 64; int chunks = std::max(1, std::min(256, std::min((rows + 63) / 64, (1024 + xb - 1) / xb)));
+      if (chunks > 1) {
+        p.rows_per_chunk = (rows + chunks - 1) / chunks; chunks = (rows + p.rows_per_chunk - 1) / p.rows_per_chunk;
+        void *wsv = nullptr; { const int rc = workspace((hipStream_t)st, (size_t)chunks * cols * sizeof(double), &wsv); if (rc) return rc; }
+        p.part = static_cast<double *>(wsv);
+        hipLaunchKernelGGL(k3_colred_kernel, dim3(xb, chunks), dim3(256), 0, (hipStream_t)st, p);
+        hipLaunchKernelGGL(k3_colred_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)st, p, chunks);
+      } else hipLaunchKernelGGL(k3_colred_kernel, dim3(xb, 1), dim3(256), 0, (hipStream_t)st, p);
+    }
+  }
   else if (rows > 0) hipLaunchKernelGGL(k3_rowred_kernel, dim3(rows), dim3(64), 0, (hipStream_t)st, p);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;

@@ -121,6 +121,9 @@ int main(int argc, char *argv[]) {
       ConstrainOrthonormal(&nnet);
       ScaleNnet(success ? momentum : 0.0, delta_nnet);
       objfs(3 * iter) = objf; objfs(3 * iter + 1) = l2_term; objfs(3 * iter + 2) = weight;
+#ifdef K3_ADAPTER
+      KALDI_LOG << "iteration " << iter << ": " << (double)k3_mat_gemm_flops(1) * 1.0e-9 << " GFLOP in matrix products (2MNK over the AddMatMat calls of the forward, backward and update)";
+#endif
       KALDI_LOG << "iteration " << iter << ": LF-MMI objf per frame " << objf / weight << " (+ l2 " << l2_term / weight << ") over " << weight << " frames; " << iter_timer.Elapsed() * 1000.0 << " ms";
     }
     max_change_stats.Print(nnet);

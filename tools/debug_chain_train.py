@@ -36,3 +36,4 @@ try:
 except Exception: gpu = False
 if gpu:
     g = subprocess.run([exe] + args + [f"{td}/gpu.raw", f"{td}/gpu.objf"], capture_output=True, text=True, env=env); open(f"{td}/gpu.log", "w").write(g.stderr); print("gpu rc", g.returncode, g.stderr[-4000:])
+    import re; its = [float(x) for x in re.findall(r"frames; ([0-9.]+) ms", g.stderr)]; print("iteration ms:", its)
