@@ -330,6 +330,9 @@ int k3_decoder_frame_stats(k3_decoder *dec, int32_t utt, int32_t *h_ntoks, float
  * NnetComputer, so that a Kaldi build can keep its graph compiler/executor and swap only the device kernels:
  * each entry point is the body of the CuMatrixBase method of the same name (cudamatrix/cu-matrix.h:79-791; kernels
  * cudamatrix/cu-kernels.cu).  Row-major float32, leading dimension = CuMatrixBase::Stride(), device pointers. */
+/* CuMatrixBase::SoftMaxPerRow (op 0) / LogSoftMaxPerRow (1) (cudamatrix/cu-matrix.h:328,334): dst = f(a), row by row, in place allowed; DiffSoftmaxPerRow (2: a = value, b = diff) /
+ * DiffLogSoftmaxPerRow (3: a = out_value, b = out_deriv) (:403,:411) */
+int k3_mat_softmax_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_a, int64_t lda, const float *d_b, int64_t ldb, int32_t rows, int32_t cols, void *stream);
 int64_t k3_mat_gemm_flops(int32_t reset);      /* 2 M N K summed over this process's k3_mat_add_mat_mat calls (reset != 0: read and clear) -- the flop count of a training iteration for its roofline */
 int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta,
                        float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream);      /* AddMatMat: C = alpha op(A) op(B) + beta C, FP32 MFMA */

@@ -293,6 +293,29 @@ __global__ __launch_bounds__(256) void k3_scalar_reduce_kernel(ScalParams p) {
   if (threadIdx.x == 0) p.part[blockIdx.x] = sh[0];
 }
 
+// SoftMaxPerRow / LogSoftMaxPerRow and their derivatives (cu-matrix.h:328-334, :403-411): one wavefront per row.  op 0: dst = softmax(src); 1: dst = log-softmax(src);
+// 2 (DiffSoftmaxPerRow): dst = diff .* value - value * <diff, value>; 3 (DiffLogSoftmaxPerRow): dst = out_deriv - exp(out_value) * sum(out_deriv).  For op 2 / 3: A = value / out_value, B = diff / out_deriv.
+__global__ __launch_bounds__(256) void k3_row_softmax_kernel(int op, float *D, long long ldd, const float *A, long long lda, const float *B, long long ldb, int rows, int cols) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float *d = D + (long long)r * ldd; const float *a = A + (long long)r * lda; const float *b = B ? B + (long long)r * ldb : nullptr;
+  if (op <= 1) {
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, a[c]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+    for (int c = lane; c < cols; c += 64) sum += expf(a[c] - mx);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float lsum = logf(sum), inv = 1.0f / sum;
+    for (int c = lane; c < cols; c += 64) d[c] = op == 1 ? a[c] - mx - lsum : expf(a[c] - mx) * inv;
+  } else {
+    float sum = 0.0f;
+    for (int c = lane; c < cols; c += 64) sum += op == 2 ? a[c] * b[c] : b[c];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    for (int c = lane; c < cols; c += 64) d[c] = op == 2 ? b[c] * a[c] - a[c] * sum : b[c] - expf(a[c]) * sum;
+  }
+}
+
 int launch_ew(const EwParams &p, void *stream) {
   if (p.rows <= 0 || p.cols <= 0) return K3_OK;
   dim3 grid((p.cols + 63) / 64, (unsigned)std::min(65535, (p.rows + 3) / 4));
@@ -420,6 +443,13 @@ extern "C" int k3_mat_reduce_scalar(int32_t op, const float *d_A, int64_t lda, c
   double r = h[0];
   for (int i = 1; i < wgs; i++) r = op == 4 ? std::max(r, h[i]) : op == 5 ? std::min(r, h[i]) : r + h[i];
   *h_result = r;
+  return K3_OK;
+}
+extern "C" int k3_mat_softmax_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_a, int64_t lda, const float *d_b, int64_t ldb, int32_t rows, int32_t cols, void *st) {
+  K3_REQUIRE(d_dst && d_a && op >= 0 && op <= 3 && rows >= 0 && cols >= 0 && ldd >= cols && lda >= cols && (op <= 1 || (d_b && ldb >= cols)), "k3_mat_softmax_rows: bad argument");
+  if (rows == 0 || cols == 0) return K3_OK;
+  hipLaunchKernelGGL(k3_row_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)st, op, d_dst, (long long)ldd, d_a, (long long)lda, d_b, (long long)ldb, rows, cols);
+  K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }
 extern "C" int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *st) {

@@ -432,12 +432,37 @@ struct k3_nnet {
   ~k3_nnet() { for (void *p : allocs) (void)hipFree(p); }
 };
 
+namespace {
+// LogSoftmaxComponent / SoftmaxComponent::Propagate (nnet-simple-component.cc:3618-3625, :3494-3504; CuMatrixBase::LogSoftMaxPerRow / SoftMaxPerRow): one wavefront per row, in place:
+// max, sum of exp(x - max) (float, like the CPU's VectorBase::ApplyLogSoftMax / ApplySoftMax), then x - max - log(sum) or exp(x - max) / sum; optional y * scale[c] + offset[c] behind it
+// (the decodable's prior subtraction and acoustic scale on the output node).
+__global__ __launch_bounds__(256) void k3_row_softmax_kernel(float *C, long long ldc, int rows, int cols, int op, const float *scale, const float *offset) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float *x = C + (long long)r * ldc;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, x[c]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.0f;
+  for (int c = lane; c < cols; c += 64) sum += expf(x[c] - mx);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float lsum = logf(sum), inv = 1.0f / sum;
+  for (int c = lane; c < cols; c += 64) {
+    float y = op == 1 ? x[c] - mx - lsum : expf(x[c] - mx) * inv;
+    if (scale) y = y * scale[c] + offset[c];
+    x[c] = y;
+  }
+}
+
+}  // namespace
+
 struct k3_nnet_batch {
   k3_nnet *net = nullptr;
   int num_utts = 0, subsampling = 1;
   std::vector<int> num_frames;
   std::vector<long long> out_offsets;           // [U+1] rows of the output matrix
   long long total_in_rows = 0, total_out_rows = 0;
+  std::vector<long long> node_rows;      // output rows of every fused node (the row-wise softmax kernels run over them)
   double flops = 0.0;
   // per node
   std::vector<GemmParams> params;
@@ -617,6 +642,7 @@ static int batch_create_impl(k3_nnet *net, int32_t num_utts, const int32_t *h_nu
   for (int q = 0; q < num_seqs; q++) b->out_offsets[seqs[q].u + 1] += seqs[q].n_out;
   for (int u = 0; u < num_utts; u++) b->out_offsets[u + 1] += b->out_offsets[u];
   b->total_out_rows = b->out_offsets[num_utts];
+  b->node_rows.assign(nn, 0); for (int i = 0; i < nn; i++) if (used[i]) b->node_rows[i] = rowoff[i][num_seqs];
   for (int i = 0; i < nn; i++) K3_REQUIRE(rowoff[i][num_seqs] < (1ll << 31), "k3_nnet_batch_create: more than 2^31 rows in one batch");
 
   // ---- activation buffers with liveness-based reuse
@@ -674,7 +700,7 @@ static int batch_create_impl(k3_nnet *net, int32_t num_utts, const int32_t *h_nu
       p.op_kind[o] = f.ops[o].kind; p.op_scale[o] = d.op_scale[o]; p.op_offset[o] = d.op_offset[o];
       if (f.ops[o].kind == k3::kEpiResidual) { res = f.ops[o].res_node; p.res_scale = f.ops[o].res_scale; }
     }
-    if (i == fm.output_node && out_xform) {
+    if (i == fm.output_node && out_xform && f.row_op == 0) {      // (behind a softmax output layer the transform is applied by the row kernel: it follows the component)
       if (p.nops >= kMaxOps) { k3::set_error("k3_nnet_batch_create: too many epilogue ops on the output node"); return K3_ERR_UNSUPPORTED; }
       p.op_kind[p.nops] = k3::kEpiScaleOffset; p.op_scale[p.nops] = b->out_scale; p.op_offset[p.nops] = b->out_offset; p.nops++;
     }
@@ -831,6 +857,11 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
       K3_GEMM_VARIANTS(K3_LAUNCH)
       if (!launched) { epi = kEpiAny; K3_GEMM_VARIANTS(K3_LAUNCH) }      // no fixed-program instantiation for this shape: run-time dispatch
 #undef K3_LAUNCH
+    }
+    if (f.row_op) {      // LogSoftmaxComponent / SoftmaxComponent on the node's rows, in place; on the output node followed by (x - log prior) * acoustic scale
+      const bool outn = (int)i == fm.output_node;
+      hipLaunchKernelGGL(k3_row_softmax_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc, (int)b->node_rows[i], f.out_dim, f.row_op,
+                         outn ? b->out_scale : (const float *)nullptr, outn ? b->out_offset : (const float *)nullptr);
     }
     K3_HIP_CHECK(hipGetLastError());
   }

@@ -58,6 +58,7 @@ struct FusedNode {
   std::vector<float> bias;     // empty = none
   std::vector<float> W_iv;     // [out_dim x ivector_dim]: the columns that multiply ReplaceIndex(ivector, t, 0), the last part of the Append(); empty = none
   std::vector<EpiOp> ops;
+  int row_op = 0;              // applied to the node's output rows after `ops`: 1 = LogSoftmaxComponent, 2 = SoftmaxComponent (a reduction over the row: its own kernel)
 };
 struct FusedModel {
   int input_dim = 0, output_dim = 0, output_node = -1;

@@ -439,7 +439,8 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
     }
     // ---- element-wise component: fold into the producing node when it is that node's only consumer ----
     const bool is_relu = c.type == "RectifiedLinearComponent", is_bn = c.type == "BatchNormComponent", is_id = IsIdentityAtTest(c.type);
-    if (!is_relu && !is_bn && !is_id) {
+    const int row_op = c.type == "LogSoftmaxComponent" ? 1 : c.type == "SoftmaxComponent" ? 2 : 0;      // nnet-simple-component.cc:3618-3625 / :3494-3504 (the output layer of non-chain nnet3 models)
+    if (!is_relu && !is_bn && !is_id && !row_op) {
       *err = "component type " + c.type + " (" + c.name + ") is not supported by the MI355X TDNN/TDNN-F path"; return false;
     }
     // main input + optional residual term
@@ -468,7 +469,7 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
     } else { *err = "unsupported descriptor at element-wise node " + n.name; return false; }
     int main_idx; if (!lookup(main_name, &main_idx)) return false;
     int target;
-    if (main_idx >= 0 && consumers[main_name] == 1 && fm->nodes[main_idx].name == main_name) {
+    if (main_idx >= 0 && consumers[main_name] == 1 && fm->nodes[main_idx].name == main_name && fm->nodes[main_idx].row_op == 0) {
       target = main_idx;                                  // fold
       producer.erase(main_name);
     } else {                                              // stand-alone element-wise node
@@ -486,6 +487,7 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
     if (is_relu) { EpiOp op; op.kind = kEpiRelu; t.ops.push_back(std::move(op)); }
     if (is_bn) { EpiOp op; op.kind = kEpiScaleOffset; if (!BatchNormScaleOffset(c, &op.scale, &op.offset, err)) return false;
                  if ((int)op.scale.size() != t.out_dim) { *err = "BatchNorm dim mismatch at " + n.name; return false; } t.ops.push_back(std::move(op)); }
+    if (row_op) t.row_op = row_op;
     t.name = n.name; producer[n.name] = target; dims[n.name] = t.out_dim;
   }
   if (fm->output_node < 0) { *err = "model has no output-node name=output"; return false; }

@@ -40,19 +40,38 @@ def test_reference_nnet_computer_over_the_k3_cumatrix_benchmark_model(tmp_path):
     err = np.abs(got[:, ::8] - ref).max()
     assert err <= 1e-4, (err, float(g["max_abs"]))
 
-def test_an_operation_outside_the_adapter_fails_loudly(tmp_path):
-    """a model with a component the adapter does not cover (here: a log-softmax output) must stop with the member's name, not fall back"""
+def _init_model(tmp_path, tail):
     cfg = str(tmp_path / "n.config"); raw = str(tmp_path / "n.raw")
-    open(cfg, "w").write("input-node name=input dim=8\ncomponent name=a type=NaturalGradientAffineComponent input-dim=8 output-dim=6\ncomponent-node name=a component=a input=input\n"
-                         "component name=ls type=LogSoftmaxComponent dim=6\ncomponent-node name=ls component=ls input=a\noutput-node name=output input=ls\n")
+    open(cfg, "w").write("input-node name=input dim=8\ncomponent name=a type=NaturalGradientAffineComponent input-dim=8 output-dim=6\ncomponent-node name=a component=a input=input\n" + tail)
     init = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet3-init")
     if not os.path.exists(init): pytest.skip("oracle/_ref/bin/nnet3-init not built")
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"))
     assert subprocess.run([init, "--srand=1", cfg, raw], capture_output=True, env=env).returncode == 0
     from oracle import kaldi_io as kio
-    fa = str(tmp_path / "f.ark"); kio.write_ark(fa, {"u": np.random.default_rng(0).standard_normal((20, 8)).astype(np.float32)})
+    fa = str(tmp_path / "f.ark"); kio.write_ark(fa, {"u": np.random.default_rng(0).standard_normal((20, 8)).astype(np.float32) * 3.0})
+    return raw, fa, env
+
+def test_an_operation_outside_the_adapter_fails_loudly(tmp_path):
+    """a model with a component the adapter does not cover (here: a sigmoid) must stop with the member's name, not fall back"""
+    raw, fa, _ = _init_model(tmp_path, "component name=sg type=SigmoidComponent dim=6\ncomponent-node name=sg component=sg input=a\noutput-node name=output input=sg\n")
     r = subprocess.run([EXE, "--use-gpu=no", raw, f"ark:{fa}", f"ark:{tmp_path}/o.ark"], capture_output=True, text=True)
-    assert r.returncode != 0 and "not implemented on the MI355X path" in r.stderr and "LogSoftMaxPerRow" in r.stderr, r.stderr[-1500:]
+    assert r.returncode != 0 and "not implemented on the MI355X path" in r.stderr and "Sigmoid" in r.stderr, r.stderr[-1500:]
+
+@pytest.mark.parametrize("kind", ["LogSoftmaxComponent", "SoftmaxComponent"])
+def test_softmax_output_layers_equal_the_reference(kind, tmp_path):
+    """non-chain nnet3 models end in a (log-)softmax (nnet-simple-component.cc:3494-3504, :3618-3625): the reference's NnetComputer over the adapter (CuMatrixBase::SoftMaxPerRow /
+    LogSoftMaxPerRow, cu-matrix.h:328,334) and the fused path of k3_nnet_load (the drop-in nnet3-compute program) against the reference's own nnet3-compute on the CPU"""
+    from oracle import kaldi_io as kio
+    raw, fa, env = _init_model(tmp_path, f"component name=ls type={kind} dim=6\ncomponent-node name=ls component=ls input=a\noutput-node name=output input=ls\n")
+    ref = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet3-compute")
+    assert subprocess.run([ref, "--use-gpu=no", raw, f"ark:{fa}", f"ark:{tmp_path}/r.ark"], capture_output=True, env=env).returncode == 0
+    want = kio.read_ark(f"{tmp_path}/r.ark")["u"]
+    r = subprocess.run([EXE, "--use-gpu=no", raw, f"ark:{fa}", f"ark:{tmp_path}/a.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr[-1500:]
+    assert np.abs(kio.read_ark(f"{tmp_path}/a.ark")["u"] - want).max() <= 1e-5
+    prog = os.path.join(ROOT, "kaldi_amd", "bin", "nnet3-compute")
+    r = subprocess.run([prog, raw, f"ark:{fa}", f"ark:{tmp_path}/g.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr[-1500:]
+    got = kio.read_ark(f"{tmp_path}/g.ark")["u"]
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-5 and (kind != "SoftmaxComponent" or abs(float(got.sum(1).mean()) - 1.0) < 1e-5)
 
 
 @pytest.mark.parametrize("kind,flags,warp", [("fbank", ["--num-mel-bins=40", "--dither=0"], None), ("mfcc", ["--num-mel-bins=40", "--num-ceps=40", "--low-freq=20", "--high-freq=-400", "--dither=0"], None),
