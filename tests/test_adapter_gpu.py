@@ -45,7 +45,7 @@ def _init_model(tmp_path, tail):
     open(cfg, "w").write("input-node name=input dim=8\ncomponent name=a type=NaturalGradientAffineComponent input-dim=8 output-dim=6\ncomponent-node name=a component=a input=input\n" + tail)
     init = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet3-init")
     if not os.path.exists(init): pytest.skip("oracle/_ref/bin/nnet3-init not built")
-    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
     assert subprocess.run([init, "--srand=1", cfg, raw], capture_output=True, env=env).returncode == 0
     from oracle import kaldi_io as kio
     fa = str(tmp_path / "f.ark"); kio.write_ark(fa, {"u": np.random.default_rng(0).standard_normal((20, 8)).astype(np.float32) * 3.0})
