@@ -60,6 +60,10 @@ int k3h_clat_get(const k3h_clat *c, int32_t *start, uint8_t *is_final, float *fi
 int k3h_clat_scale_acoustic(k3h_clat *c, double scale);                 /* fst::ScaleLattice(fst::AcousticLatticeScale(scale), &clat) */
 int k3h_clat_write(const k3h_clat *c, const char *key, const char *wspecifier);   /* one record; "ark:file" or "ark,t:file" */
 void k3h_clat_free(k3h_clat *c);
+/* cuda_decoder::LatticePostprocessor::GetCTM (cudadecoder/lattice-postprocessor.cc:88-110) on every lattice of a table: scales and word insertion penalty of the post-processor's
+ * config file (lattice-postprocessor.h:35-76), word-level Minimum Bayes Risk decoding (lat/sausages.cc), times in seconds; CTM lines "<key> 0  <begin> <duration> <word> <conf>"
+ * (cuda-pipeline-common.cc:67-142) into `out`.  Returns the bytes written (without the terminating 0), -1 on error. */
+int64_t k3h_lattice_table_to_ctm(const char *lattice_rspecifier, const char *postprocessor_config_rxfilename, float decoder_frame_shift_seconds, char *out, int64_t out_cap);
 
 /* OnlineIvectorExtractionInfo(config) (online2/online-ivector-feature.cc:29-98): parse an --ivector-extraction-config file and read every file it
  * names (LDA matrix, global CMVN stats, cmvn / splice configs, diagonal UBM, i-vector extractor), with the reference's checks and messages.

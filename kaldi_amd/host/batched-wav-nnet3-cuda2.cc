@@ -10,6 +10,8 @@
 // CompactLattice, as the reference does; with --write-compact=false (an addition) it is written as a Lattice table, arc for arc.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <fstream>
+#include <sstream>
 #include <cmath>
 #include <cstring>
 #include <array>
@@ -26,8 +28,8 @@ int main(int argc, char **argv) {
   try {
     const char *usage =
         "Reads in wav file(s) and decodes them with neural nets\n(nnet3 setup).  Note: some configuration values and inputs are\n"
-        "set via config files whose filenames are passed as options\nOutput is a lattice wspecifier\n"
-        "Usage: batched-wav-nnet3-cuda2 [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
+        "set via config files whose filenames are passed as options\nOutput can either be a lattice wspecifier or a ctm filename\n"
+        "Usage: batched-wav-nnet3-cuda2 [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier|ctm-wxfilename>\n";
     ParseOptions po(usage);
     bool write_compact = true, write_lattice = true, segmentation = false, determinize = true, minimize = false, phone_det = true, word_det = true, gpu_feat = true, use_online = false, reset_on_endpoint = false, tensor_cores = false, tf32 = false, add_pitch = false, debug_comp = false, cache_mem = true;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, worker_threads = -1, copy_threads = 2, frames_per_chunk = 50, subsampling = 1;
@@ -36,7 +38,7 @@ int main(int argc, char **argv) {
     bool literal_order = true; float hash_ratio = 2.0f; int32_t rank = getenv("RANK") ? atoi(getenv("RANK")) : 0, world_size = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1, device = -1; std::string nccl_id_file;
     std::string word_syms, postproc, feature_type = "mfcc", mfcc_config, fbank_config, plp_config, pitch_config, cmvn_config, global_cmvn, ivector_config, use_gpu = "yes";
     po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
-    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
+    po.Register("word-symbol-table", &word_syms, "Symbol table for words [the words of the CTM output]");
     po.Register("file-limit", &num_todo, "Limits the number of files that are processed by this driver.");
     po.Register("iterations", &iterations, "Number of times to decode the corpus. Output will be written only once.");
     po.Register("segmentation", &segmentation, "Split audio files into segments");
@@ -44,7 +46,7 @@ int main(int argc, char **argv) {
     double segment_length_s = 20, segment_overlap_s = 1, min_segment_length_s = 1;
     po.Register("segment-length", &segment_length_s, "Segment length (s)"); po.Register("segment-overlap", &segment_overlap_s, "Overlap between segments (s)");
     po.Register("min-segment-length", &min_segment_length_s, "Min segment length (s, >=1)");
-    po.Register("lattice-postprocessor-rxfilename", &postproc, "(optional) Config file for lattice postprocessor (not supported)");
+    po.Register("lattice-postprocessor-rxfilename", &postproc, "(optional) Config file for lattice postprocessor (scales, word insertion penalty, MBR options; needed for CTM output)");
     po.Register("max-batch-size", &max_batch, "The maximum execution batch size (utterances decoded together)");
     po.Register("num-channels", &num_channels, "(accepted; whole-utterance batching needs no separate channel pool)");
     po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
@@ -82,7 +84,7 @@ int main(int argc, char **argv) {
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
-    if (use_online || add_pitch || !postproc.empty() || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
+    if (use_online || add_pitch || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty() || elc || erc)
       K3H_ERR << "an option that needs a component outside the accelerated path was given (online features / pitch / PLP / CMVN / extra context)";
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3); std::string out_wspec = po.GetArg(4);
     if (world_size < 1 || rank < 0 || rank >= world_size) K3H_ERR << "--rank=" << rank << " is not in [0, --world-size=" << world_size << ")";
@@ -178,12 +180,24 @@ int main(int argc, char **argv) {
       }
       scp.swap(cut); segs.swap(cut_segs);
     }
-    std::unique_ptr<TableWriter> writer; if (write_lattice) writer.reset(new TableWriter(out_wspec));
+    // OpenOutputHandles (cudadecoderbin/cuda-bin-tools.h:181-195): an output argument that is not a table wspecifier names a .ctm file
+    const bool ctm_mode = !(out_wspec.compare(0, 3, "ark") == 0 || out_wspec.compare(0, 3, "scp") == 0) || out_wspec.find(':') == std::string::npos;
+    std::shared_ptr<LatticePostprocessor> postprocessor; std::vector<std::string> syms;
+    if (postproc.empty()) { if (ctm_mode) K3H_ERR << "You must configure the lattice postprocessor with --lattice-postprocessor-rxfilename to use CTM output"; }
+    else { postprocessor = LoadLatticePostprocessor(postproc); postprocessor->SetDecoderFrameShift(fopts.frame_shift_ms * 1.0e-3f * subsampling); }
+    if (!word_syms.empty()) {      // fst::SymbolTable::ReadText: lines "symbol id"
+      std::istringstream in(ReadWholeInput(word_syms)); std::string sym; long id;
+      while (in >> sym >> id) { if (id >= 0) { if ((size_t)id >= syms.size()) syms.resize((size_t)id + 1); syms[(size_t)id] = sym; } }
+      if (syms.empty()) K3H_ERR << "Could not read symbol table from file " << word_syms;
+    }
+    std::unique_ptr<std::ofstream> ctm_file; if (ctm_mode) { ctm_file.reset(new std::ofstream(out_wspec)); if (!*ctm_file) K3H_ERR << "cannot open " << out_wspec; }
+    std::unique_ptr<TableWriter> writer; if (write_lattice && !ctm_mode) writer.reset(new TableWriter(out_wspec));
     // determinization runs on worker threads while the GPU works on the next batch; records come out in submission order
     std::unique_ptr<DeterminizeSequencer> det_pool;
-    if (writer && determinize) {
+    if ((writer && (determinize || postprocessor)) || ctm_mode) {
       DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
-      pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
+      pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; pc.determinize = determinize; pc.postprocessor = postprocessor; pc.ctm_out = ctm_file.get(); pc.word_syms = syms.empty() ? nullptr : &syms;
+      det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
     }
     int num_task = 0, num_err = 0; double total_audio = 0.0;
 

@@ -215,6 +215,9 @@ class DeterminizeSequencer {
   struct Config {
     int32_t num_threads = 1; double beam = 10.0, pre_scale = 1.0, post_scale = 1.0; bool topsort = false, minimize = false; DeterminizeLatticePrunedOptions det;
     const TransitionInfo *trans = nullptr; DeterminizeLatticePhonePrunedOptions phone_det;       // trans != nullptr: DeterminizeLatticePhonePruned with phone_det
+    // the CUDA pipeline's lattice post-processor (SetLatticePostprocessor, batched-threaded-nnet3-cuda-pipeline2.h:204): applied to the determinized lattice; with `ctm_out` the record written
+    // is the utterance's CTM lines (LatticePostprocessor::GetCTM + MergeSegmentsToCTMOutput) instead of the lattice -- `writer` may then be null
+    std::shared_ptr<class LatticePostprocessor> postprocessor; std::ostream *ctm_out = nullptr; const std::vector<std::string> *word_syms = nullptr; bool determinize = true;
   };
   DeterminizeSequencer(const Config &config, TableWriter *writer);
   ~DeterminizeSequencer();
@@ -225,5 +228,40 @@ class DeterminizeSequencer {
  private:
   struct Impl; std::unique_ptr<Impl> impl_;
 };
+
+
+// ---- word-level Minimum Bayes Risk decoding, the CUDA pipeline's lattice post-processor, CTM output (k3_mbr.cc) ----------------------------------------
+struct MinimumBayesRiskOptions { bool decode_mbr = true, print_silence = false; };      // lat/sausages.h:56-73
+class MinimumBayesRisk {      // lat/sausages.h:80-266; the lattice is not required to be determinized
+ public:
+  explicit MinimumBayesRisk(const CompactLattice &clat, MinimumBayesRiskOptions opts = MinimumBayesRiskOptions());
+  ~MinimumBayesRisk();
+  const std::vector<int32_t> &GetOneBest() const;                                       // the MBR word sequence
+  const std::vector<std::pair<float, float>> &GetOneBestTimes() const;                  // (begin, end) of every word of it, in frames
+  const std::vector<float> &GetOneBestConfidences() const;
+  const std::vector<std::vector<std::pair<int32_t, float>>> &GetSausageStats() const;   // per bin: (word or 0, posterior), most likely first
+  const std::vector<std::pair<float, float>> &GetSausageTimes() const;
+  double GetBayesRisk() const;                                                          // expected word errors
+ private:
+  struct Impl; std::unique_ptr<Impl> impl_;
+};
+struct CtmResult { std::vector<float> conf; std::vector<int32_t> words; std::vector<std::pair<float, float>> times_seconds; };      // cudadecoder/cuda-pipeline-common.h:53-57
+struct LatticePostprocessorConfig {      // cudadecoder/lattice-postprocessor.h:35-76
+  std::string word_boundary_rxfilename; MinimumBayesRiskOptions mbr_opts; int32_t silence_label = 0, partial_word_label = 0; bool reorder = true;
+  float max_expand = 0.0f, acoustic_scale = 1.0f, lm_scale = 1.0f, acoustic2lm_scale = 0.0f, lm2acoustic_scale = 0.0f, word_ins_penalty = 0.0f;
+  void Register(ParseOptions *po);
+};
+class LatticePostprocessor {      // cudadecoder/lattice-postprocessor.h:78-118
+ public:
+  explicit LatticePostprocessor(const LatticePostprocessorConfig &config);
+  bool GetCTM(CompactLattice &clat, CtmResult *ctm_result) const;
+  bool GetPostprocessedLattice(CompactLattice &clat, CompactLattice *out_clat) const;      // scales + word insertion penalty (clat is modified, like the reference's)
+  void SetDecoderFrameShift(float seconds) { decoder_frame_shift_ = seconds; }
+ private:
+  LatticePostprocessorConfig config_; bool use_lattice_scale_ = false; float decoder_frame_shift_ = 0.0f;
+};
+std::shared_ptr<LatticePostprocessor> LoadLatticePostprocessor(const std::string &config_rxfilename);      // LoadAndSetLatticePostprocessor's first half (:126-137)
+// the CTM lines of one (un-segmented) utterance: "<key> 0  <begin> <duration> <word> <confidence>", two decimals (cuda-pipeline-common.cc:67-142)
+void WriteCtm(const CtmResult &ctm, const std::string &key, std::ostream &os, const std::vector<std::string> *word_syms = nullptr);
 
 }  // namespace k3host

@@ -1,4 +1,6 @@
 // k3_host_abi.cc -- the C ABI of include/k3host.h over k3_lattice.cc / k3_host.cc (-> kaldi_amd/lib/libk3host.so).  No GPU code.
+#include <sstream>
+#include <cstring>
 #include <cmath>
 #include <cstring>
 #include <atomic>
@@ -53,6 +55,19 @@ int k3h_determinize_lattice(const k3h_transitions *trans, int32_t ns, int32_t st
 }
 int k3h_convert_lattice(int32_t ns, int32_t start, const float *fin, int64_t na, const int32_t *src, const int32_t *dst, const int32_t *il, const int32_t *ol, const float *g, const float *ac, k3h_clat **out) {
   return Guard([&] { const Lattice lat = FromArrays(ns, start, fin, na, src, dst, il, ol, g, ac); auto *c = new k3h_clat; try { ConvertLattice(lat, &c->c); } catch (...) { delete c; throw; } *out = c; });
+}
+// LatticePostprocessor::GetCTM on every lattice of a table: lattice -> CompactLattice (ConvertLattice) -> scales / word insertion penalty of the config file -> MBR -> CTM lines
+// (MergeSegmentsToCTMOutput's layout).  Returns the number of bytes written to `out` (0-terminated), or -1 (k3h_last_error).
+int64_t k3h_lattice_table_to_ctm(const char *lattice_rspecifier, const char *postprocessor_config_rxfilename, float decoder_frame_shift_seconds, char *out, int64_t out_cap) {
+  int64_t n = -1;
+  const int rc = Guard([&] {
+    auto pp = LoadLatticePostprocessor(postprocessor_config_rxfilename); pp->SetDecoderFrameShift(decoder_frame_shift_seconds);
+    std::ostringstream os;
+    for (auto &kv : ReadLatticeTable(lattice_rspecifier)) { Connect(&kv.second); CompactLattice clat; if (kv.second.NumStates() > 0) ConvertLattice(kv.second, &clat); CtmResult ctm; pp->GetCTM(clat, &ctm); WriteCtm(ctm, kv.first, os); }
+    const std::string s = os.str(); if ((int64_t)s.size() + 1 > out_cap) K3H_ERR << "k3h_lattice_table_to_ctm: output buffer too small (" << s.size() + 1 << " bytes needed)";
+    memcpy(out, s.c_str(), s.size() + 1); n = (int64_t)s.size();
+  });
+  return rc == 0 ? n : -1;
 }
 int k3h_clat_sizes(const k3h_clat *c, int32_t *ns, int64_t *na, int64_t *nl) {
   return Guard([&] { int64_t n = 0; for (const auto &s : c->c.fin_str) n += (int64_t)s.size(); for (const auto &s : c->c.arc_str) n += (int64_t)s.size(); *ns = c->c.NumStates(); *na = (int64_t)c->c.arc_src.size(); *nl = n; });

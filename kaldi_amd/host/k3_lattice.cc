@@ -16,6 +16,7 @@
 // lattice-determinize-phone-pruned call), with --minimize (PushCompactLatticeStrings / Weights + MinimizeCompactLattice).
 // --word-determinize=false gives the first pass's result (or, with both passes off, the lattice itself) re-packed by ConvertLattice.
 #include "k3_host.h"
+#include <sstream>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -985,7 +986,8 @@ struct DeterminizeSequencer::Impl {
   std::mutex m; std::condition_variable cv_work, cv_done;
   struct Job { int64_t seq; std::string key; Lattice lat; };
   std::deque<Job> queue;                                                   // submitted, not yet picked up
-  std::map<int64_t, std::pair<std::string, CompactLattice>> finished;      // determinized, waiting for their turn to be written
+  struct Done { std::string key; CompactLattice clat; std::string ctm; };
+  std::map<int64_t, Done> finished;      // determinized, waiting for their turn to be written
   int64_t submitted = 0, written = 0; int32_t num_warn = 0; bool stop = false; std::string error;
   std::vector<std::thread> threads;
 
@@ -993,24 +995,30 @@ struct DeterminizeSequencer::Impl {
     for (;;) {
       Job job;
       { std::unique_lock<std::mutex> lk(m); cv_work.wait(lk, [&] { return stop || !queue.empty(); }); if (queue.empty()) return; job = std::move(queue.front()); queue.pop_front(); }
-      CompactLattice clat; bool warn = false; std::string err;
+      CompactLattice clat; bool warn = false; std::string err, ctm_text;
       try {
         if (cfg.pre_scale != 1.0) ScaleAcoustic(&job.lat, cfg.pre_scale);
-        const bool ok = cfg.trans ? DeterminizeLatticePhonePruned(job.lat, *cfg.trans, cfg.beam, &clat, cfg.phone_det) : DeterminizeLatticePruned(job.lat, cfg.beam, &clat, cfg.det);
+        bool ok = true;
+        if (!cfg.determinize) ConvertLattice(job.lat, &clat);      // (--determinize-lattice=false with a post-processor: the lattice re-packed as it is)
+        else ok = cfg.trans ? DeterminizeLatticePhonePruned(job.lat, *cfg.trans, cfg.beam, &clat, cfg.phone_det) : DeterminizeLatticePruned(job.lat, cfg.beam, &clat, cfg.det);
         if (!ok) { K3H_WARN << "For key " << job.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; warn = true; }
         if (clat.NumStates() == 0) { K3H_WARN << "For key " << job.key << ", determinized and trimmed lattice was empty."; warn = true; }
         if (cfg.minimize && !cfg.trans) { PushCompactLatticeStrings(&clat); PushCompactLatticeWeights(&clat); MinimizeCompactLattice(&clat); }      // with cfg.trans: phone_det.minimize, inside
         if (cfg.topsort && !TopSortIfNeeded(&clat)) K3H_WARN << "Topological sorting of the determinized lattice failed for key " << job.key;
         if (cfg.post_scale != 1.0) ScaleAcoustic(&clat, cfg.post_scale);
+        if (cfg.postprocessor) {      // SetResultUsingLattice (cudadecoder/lattice-postprocessor.cc:112-137)
+          if (cfg.ctm_out) { CtmResult ctm; cfg.postprocessor->GetCTM(clat, &ctm); std::ostringstream os; WriteCtm(ctm, job.key, os, cfg.word_syms); ctm_text = os.str(); }
+          else { CompactLattice pp; cfg.postprocessor->GetPostprocessedLattice(clat, &pp); clat = std::move(pp); }
+        }
       } catch (const std::exception &e) { err = e.what(); }
       job.lat = Lattice();
       std::unique_lock<std::mutex> lk(m);
       if (!err.empty() && error.empty()) error = err;
       num_warn += warn;
-      finished.emplace(job.seq, std::make_pair(std::move(job.key), std::move(clat)));
+      finished.emplace(job.seq, Done{std::move(job.key), std::move(clat), std::move(ctm_text)});
       // whoever completes the next lattice in line writes it and everything behind it that is already there
       for (auto it = finished.find(written); it != finished.end(); it = finished.find(written)) {
-        if (error.empty()) { try { writer->WriteCompactLattice(it->second.first, it->second.second); } catch (const std::exception &e) { error = e.what(); } }
+        if (error.empty()) { try { if (cfg.ctm_out) { *cfg.ctm_out << it->second.ctm; cfg.ctm_out->flush(); } else writer->WriteCompactLattice(it->second.key, it->second.clat); } catch (const std::exception &e) { error = e.what(); } }
         finished.erase(it); written++;
       }
       cv_done.notify_all();

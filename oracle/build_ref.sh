@@ -87,6 +87,9 @@ for f in determinize-lattice-pruned push-lattice minimize-lattice; do g++ $MF -c
 g++ $MF $HERE/ref_tools/ref_lattice_determinize.cc $W/obj_minifst/determinize-lattice-pruned.o $W/obj_minifst/push-lattice.o $W/obj_minifst/minimize-lattice.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-lattice-determinize
 # ConvertLattice + Factor (fstext/lattice-utils-inl.h, fstext/factor-inl.h: header-only templates of the reference) over the stand-in
 g++ $MF $HERE/ref_tools/ref_convert_lattice.cc $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-convert-lattice
+# the reference's word-level MBR decoder (lat/sausages.cc, unmodified) over the same stand-in: pins kaldi_amd/host/k3_mbr.cc (the CTM output of the lattice post-processor)
+g++ $MF -c $R/lat/sausages.cc -o $W/obj_minifst/sausages.o
+g++ $MF $HERE/ref_tools/ref_mbr.cc $W/obj_minifst/sausages.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-mbr
 # i-vector extraction (the next row to build): the reference's gmm/, ivector/ and online2/online-ivector-feature.cc with
 # the programs that create a small extractor from features (gmm-global-init-from-feats -> gmm-global-to-fgmm -> ivector-extractor-init)
 # and the one that is the oracle for the GPU path to come (ivector-extract-online2 = OnlineIvectorFeature, what

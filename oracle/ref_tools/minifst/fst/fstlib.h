@@ -3,7 +3,7 @@
 // compiled UNMODIFIED into oracle/_ref without OpenFst (which /root/reference does not vendor); lat/determinize-lattice-pruned.cc
 // compiles against it as well.  Written from OpenFst's documented API (names, signatures, semantics); containers are plain
 // std::vector.  TopSort, ArcSort, Invert and Connect are implemented (depth-first topological order / std::sort / label swap / trim,
-// as documented); ShortestPath is declared and aborts when called.
+// as documented); ShortestPath (single best path, label-correcting) for the lattice tools.
 #ifndef K3_MINIFST_FSTLIB_H_
 #define K3_MINIFST_FSTLIB_H_
 #include <algorithm>
@@ -35,7 +35,7 @@ constexpr int kNoLabel = -1;
 constexpr float kDelta = 1.0F / 1024.0F;
 constexpr char kStringSeparator = '_';
 constexpr uint64 kLeftSemiring = 0x1, kRightSemiring = 0x2, kSemiring = 0x3, kCommutative = 0x4, kIdempotent = 0x8, kPath = 0x10;
-constexpr uint64 kExpanded = 0x1, kMutable = 0x2, kILabelSorted = 0x10000000ULL, kOLabelSorted = 0x40000000ULL, kTopSorted = 0x4000000000ULL;
+constexpr uint64 kExpanded = 0x1, kMutable = 0x2, kILabelSorted = 0x10000000ULL, kOLabelSorted = 0x40000000ULL, kTopSorted = 0x4000000000ULL, kFstProperties = 0x0000ffffffff0007ULL;
 inline std::string FST_FLAGS_fst_weight_separator = ",";
 enum DivideType { DIVIDE_LEFT, DIVIDE_RIGHT, DIVIDE_ANY };
 
@@ -251,7 +251,32 @@ template <class W1, class W2> class PairWeight {
 
 template <class A> struct ILabelCompare { bool operator()(const A &a, const A &b) const { return a.ilabel < b.ilabel; } };
 [[noreturn]] inline void NotInStandIn(const char *what) { std::cerr << what << " is not part of the OpenFst stand-in (oracle/ref_tools/minifst)\n"; std::abort(); }
-template <class A> void ShortestPath(const Fst<A> &, MutableFst<A> *) { NotInStandIn("ShortestPath"); }
+// single best path (fst/shortest-path.h with n = 1) for weights with a natural order (Plus(a, b) is a or b): label-correcting search from the start state,
+// result = a linear FST from its start state to one final state carrying the path's arcs and the final weight
+template <class A> void ShortestPath(const Fst<A> &fst, MutableFst<A> *out) {
+  using StateId = typename A::StateId; using W = typename A::Weight;
+  out->DeleteStates();
+  const auto *e = dynamic_cast<const ExpandedFst<A> *>(&fst); CHECK(e != nullptr);
+  const StateId n = e->NumStates(); if (n == 0 || fst.Start() == kNoStateId) return;
+  NaturalLess<W> less; std::vector<W> dist(n, W::Zero()); std::vector<StateId> prev(n, kNoStateId); std::vector<size_t> parc(n, 0); std::vector<char> inq(n, 0); std::vector<StateId> q;
+  dist[fst.Start()] = W::One(); q.push_back(fst.Start()); inq[fst.Start()] = 1;
+  for (size_t h = 0; h < q.size(); h++) {
+    const StateId s = q[h]; inq[s] = 0;
+    for (size_t k = 0; k < fst.NumArcs(s); k++) {
+      const A &a = fst.ArcsOf(s)[k]; const W w = Times(dist[s], a.weight);
+      if (less(w, dist[a.nextstate])) { dist[a.nextstate] = w; prev[a.nextstate] = s; parc[a.nextstate] = k; if (!inq[a.nextstate]) { inq[a.nextstate] = 1; q.push_back(a.nextstate); } }
+    }
+  }
+  StateId best = kNoStateId; W bw = W::Zero();
+  for (StateId s = 0; s < n; s++) if (fst.Final(s) != W::Zero() && dist[s] != W::Zero()) { const W w = Times(dist[s], fst.Final(s)); if (best == kNoStateId || less(w, bw)) { best = s; bw = w; } }
+  if (best == kNoStateId) return;
+  std::vector<StateId> path; for (StateId s = best; s != kNoStateId; s = prev[s]) path.push_back(s);
+  std::reverse(path.begin(), path.end());
+  for (size_t i = 0; i < path.size(); i++) out->AddState();
+  out->SetStart(0);
+  for (size_t i = 0; i + 1 < path.size(); i++) { A a = fst.ArcsOf(path[i])[parc[path[i + 1]]]; a.nextstate = (StateId)i + 1; out->AddArc((StateId)i, a); }
+  out->SetFinal((StateId)path.size() - 1, fst.Final(best));
+}
 template <class A> void Invert(MutableFst<A> *f) {
   for (typename A::StateId s = 0; s < f->NumStates(); s++) { A *a = f->MutableArcsOf(s); for (size_t k = 0; k < f->NumArcs(s); k++) std::swap(a[k].ilabel, a[k].olabel); f->ArcsChanged(s, false); }
 }

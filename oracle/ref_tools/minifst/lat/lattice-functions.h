@@ -7,7 +7,10 @@
 #include <limits>
 #include <vector>
 #include "lat/kaldi-lattice.h"
+#include "fstext/fstext-utils.h"
 namespace kaldi {
+using fst::ConvertLattice; using fst::RemoveAlignmentsFromCompactLattice; using fst::GetLinearSymbolSequence; using fst::CreateSuperFinal;
+int32 CompactLatticeStateTimes(const CompactLattice &clat, std::vector<int32> *times);      // lat/lattice-functions.cc:109 (defined by the tool that links lat/sausages.cc)
 template <class LatType> bool PruneLattice(BaseFloat beam, LatType *lat) {
   typedef typename LatType::Arc Arc; typedef typename Arc::Weight Weight;
   if (!lat->Properties(fst::kTopSorted, true) && !fst::TopSort(lat)) return false;

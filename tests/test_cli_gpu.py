@@ -505,3 +505,34 @@ def test_segmentation_program_and_class_equal_decoding_the_pieces(tmp_path):
     assert sorted(ra) == sorted(want) and ra == rb
     e = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--segmentation=true", "--segment-length=3.0", "--segment-overlap=3.5", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/x.txt"], capture_output=True, text=True)
     assert e.returncode != 0 and "overlap" in e.stderr
+
+
+def test_batched_wav_nnet3_cuda2_ctm_output(tmp_path):
+    """<lattice-wspecifier|ctm-wxfilename> (cudadecoderbin/batched-wav-nnet3-cuda2.cc:67-71,135-224): an output argument that is not a table wspecifier names a CTM file; the lines are
+    LatticePostprocessor::GetCTM (scales of --lattice-postprocessor-rxfilename, MBR) of every utterance's determinized lattice, in MergeSegmentsToCTMOutput's layout.  Checked against
+    lattice-mbr-decode (pinned to the reference's lat/sausages.cc in tests/test_lattice_det.py) run on the lattices the same program writes, with the same scales."""
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001]
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    synth.make_hclg(3000, 8000, N, seed=11, start_degree=50).write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n"); open(f"{td}/pp.conf", "w").write("--acoustic-scale=0.7\n--lm-scale=1.5\n")
+    base = [os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=6.0",
+            "--max-active=10000", "--max-batch-size=2", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp"]
+    r = subprocess.run(base + [f"{td}/out.ctm"], capture_output=True, text=True)
+    assert r.returncode != 0 and "You must configure the lattice postprocessor" in r.stderr
+    r = subprocess.run(base[:1] + [f"--lattice-postprocessor-rxfilename={td}/pp.conf"] + base[1:] + [f"{td}/out.ctm"], capture_output=True, text=True); assert r.returncode == 0, r.stderr[-2000:]
+    ctm = [l.split() for l in open(f"{td}/out.ctm")]
+    assert ctm and all(len(l) == 6 and l[1] == "0" for l in ctm) and [l[0] for l in ctm] == sorted(l[0] for l in ctm)
+    # the lattices of the same run, then MBR with the post-processor's scales
+    r = subprocess.run(base + [f"ark,t:{td}/det.txt"], capture_output=True, text=True); assert r.returncode == 0, r.stderr[-2000:]
+    g = subprocess.run([os.path.join(BIN, "lattice-mbr-decode"), "--acoustic-scale=0.7", "--lm-scale=1.5", "--one-best-times=true", f"ark,t:{td}/det.txt", f"ark,t:{td}/w.txt", "", "", f"ark,t:{td}/t.txt"], capture_output=True, text=True)
+    assert g.returncode == 0, g.stderr[-2000:]
+    words = {l.split()[0]: l.split()[1:] for l in open(f"{td}/w.txt")}
+    times = {l.split()[0]: [float(x) for x in l[len(l.split()[0]):].replace(";", " ").split()] for l in open(f"{td}/t.txt")}
+    for key in ("utt0", "utt1", "utt2"):
+        mine = [l for l in ctm if l[0] == key]
+        assert [l[4] for l in mine] == words[key], key
+        tb = times[key][0::2]; te = times[key][1::2]
+        for l, b, e in zip(mine, tb, te):      # frames -> seconds (0.03 s per decoder frame), two decimals
+            assert abs(float(l[2]) - b * 0.03) <= 0.006 and abs(float(l[3]) - (e - b) * 0.03) <= 0.011 and 0.0 <= float(l[5]) <= 1.0, (key, l, b, e)

