@@ -327,7 +327,7 @@ int main(int argc, char **argv) {
       auto r = std::make_shared<Raw>(); r->info.resize(10 * (size_t)U);
       K3H_LATTICE_INFO(dec, r->info.data());
       const auto t_c = tick();
-      if (b.iter == 0 && writer) {
+      if (b.iter == 0 && (writer || ctm_mode)) {
         int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += r->info[10 * u]; NA += r->info[10 * u + 1]; }
         r->sf.resize(NS + 1); r->ss.resize(NS + 1); r->sc.resize(NS + 1); r->sfin.resize(NS + 1);
         r->as.resize(NA + 1); r->ad.resize(NA + 1); r->ai.resize(NA + 1); r->ao.resize(NA + 1); r->ag.resize(NA + 1); r->aa.resize(NA + 1);
