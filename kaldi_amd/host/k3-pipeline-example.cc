@@ -3,6 +3,7 @@
 // lattice to the writer, two task groups waited for separately, then WaitForAllTasks.
 //   k3-pipeline-example [--max-batch-size=N] [--beam= --lattice-beam= --max-active= --acoustic-scale= --frame-subsampling-factor= --fbank-config=] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>
 // Its output must equal batched-wav-nnet3-cuda2's for the same options (tests/test_cli_gpu.py).
+#include <fstream>
 #include <cstring>
 #include <iostream>
 #include <mutex>
@@ -22,6 +23,7 @@ int main(int argc, char **argv) {
     po.Register("acoustic-scale", &cfg.acoustic_scale, "acoustic scale"); po.Register("frame-subsampling-factor", &cfg.frame_subsampling_factor, "output frame subsampling");
     po.Register("determinize-lattice", &cfg.determinize_lattice, "determinize before output"); po.Register("literal-order", &literal_order, "lattices identical to the CPU decoder's");
     po.Register("feature-type", &feature_type, "mfcc | fbank"); po.Register("mfcc-config", &mfcc_config, "MFCC config"); po.Register("fbank-config", &fbank_config, "fbank config");
+    std::string postproc, ctm_out; po.Register("lattice-postprocessor-rxfilename", &postproc, "Config file for the lattice postprocessor (SetLatticePostprocessor)"); po.Register("ctm-out", &ctm_out, "with --segmentation: also write the merged CTM of every file here (RESULT_TYPE_CTM)");
     bool segmentation = false; po.Register("segmentation", &segmentation, "Split audio files into segments (SegmentedDecodeWithCallback; keys [utt]-[offset])"); cfg.seg_opts.Register(&po);
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
@@ -34,19 +36,22 @@ int main(int argc, char **argv) {
     HostFst hfst = ReadFstKaldiGeneric(po.GetArg(2));
     auto scp = ReadScp(po.GetArg(3)); TableWriter writer(po.GetArg(4));
     if (segmentation) {      // the way cudadecoderbin/batched-wav-nnet3-cuda2.cc:196-232 drives it: one segmented callback per file, WriteLattices with print_offsets
-      std::mutex wm; int n_seg = 0;
+      std::mutex wm; int n_seg = 0; std::ofstream ctm; if (!ctm_out.empty()) { ctm.open(ctm_out); if (!ctm) K3H_ERR << "cannot open " << ctm_out; }
+      const int result_type = cuda_decoder::CudaPipelineResult::RESULT_TYPE_LATTICE | (ctm_out.empty() ? 0 : cuda_decoder::CudaPipelineResult::RESULT_TYPE_CTM);
       {
         cuda_decoder::BatchedThreadedNnet3CudaPipeline2 pipeline(cfg, hfst, nnet, ti);
+        if (!postproc.empty()) pipeline.SetLatticePostprocessor(LoadLatticePostprocessor(postproc));
         for (size_t i = 0; i < scp.size(); i++) {
           auto wave = std::make_shared<Wave>(ReadWave(scp[i].second)); const std::string key = scp[i].first;
-          pipeline.SegmentedDecodeWithCallback(wave, [&writer, &wm, &n_seg, key](cuda_decoder::SegmentedLatticeCallbackParams &params) {
+          pipeline.SegmentedDecodeWithCallback(wave, [&writer, &wm, &n_seg, &ctm, &ctm_out, key](cuda_decoder::SegmentedLatticeCallbackParams &params) {
             std::lock_guard<std::mutex> lk(wm);
+            if (!ctm_out.empty()) cuda_decoder::MergeSegmentsToCTMOutput(params.results, key, ctm);
             for (cuda_decoder::CudaPipelineResult &r : params.results) {
               std::ostringstream k; k << key << "-" << (double)r.GetTimeOffsetSeconds();
               if (!r.HasValidResult() || r.GetLatticeResult()->NumStates() == 0) { K3H_WARN << "Utterance " << key << ": segment with offset " << r.GetTimeOffsetSeconds() << " is not valid. Skipping"; continue; }
               writer.WriteCompactLattice(k.str(), *r.GetLatticeResult()); n_seg++;
             }
-          });
+          }, result_type);
         }
         pipeline.WaitForAllTasks();
       }

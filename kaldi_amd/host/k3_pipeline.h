@@ -10,6 +10,8 @@
 // an utterance and hands all results to one callback (CudaPipelineResult, lattice results).  The lattice postprocessor (CTM results) is not provided:
 // asking for RESULT_TYPE_CTM is an error.
 #pragma once
+#include <limits>
+#include <ostream>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -41,9 +43,9 @@ struct CudaPipelineSegmentationConfig {
     if (segment_overlap_s >= segment_length_s) K3H_ERR << "The segments overlap must be smaller than the segment length";
   }
 };
-// cudadecoder/cuda-pipeline-common.h:69-140 (the CTM half needs the lattice postprocessor, which is outside this scope)
+// cudadecoder/cuda-pipeline-common.h:69-140
 class CudaPipelineResult {
-  int result_type_ = 0; CompactLattice clat_; float offset_seconds_ = 0; int32_t segment_id_ = 0; bool is_last_segment_ = false;
+  int result_type_ = 0; CompactLattice clat_; CtmResult ctm_; float offset_seconds_ = 0; int32_t segment_id_ = 0; bool is_last_segment_ = false;
  public:
   static constexpr int RESULT_TYPE_LATTICE = 1, RESULT_TYPE_CTM = 2;
   int32_t GetResultType() const { return result_type_; }
@@ -53,11 +55,35 @@ class CudaPipelineResult {
   float GetTimeOffsetSeconds() const { return offset_seconds_; }
   void SetLatticeResult(CompactLattice &&clat) { result_type_ |= RESULT_TYPE_LATTICE; clat_ = std::move(clat); }
   CompactLattice *GetLatticeResult() { if (!(result_type_ & RESULT_TYPE_LATTICE)) K3H_ERR << "Lattice result was not requested"; return &clat_; }
+  void SetCTMResult(CtmResult &&ctm) { result_type_ |= RESULT_TYPE_CTM; ctm_ = std::move(ctm); }
+  CtmResult *GetCTMResult() { if (!(result_type_ & RESULT_TYPE_CTM)) K3H_ERR << "CTM result was not requested"; return &ctm_; }
   void SetTimeOffsetSeconds(float offset_seconds) { if (offset_seconds < 0) K3H_ERR << "negative segment offset"; offset_seconds_ = offset_seconds; }
   void SetSegmentID(int segment_id) { segment_id_ = segment_id; }
   void SetAsLastSegment() { is_last_segment_ = true; }
 };
 struct SegmentedLatticeCallbackParams { std::vector<CudaPipelineResult> results; };
+// cudadecoder/cuda-pipeline-common.cc:67-142: the CTM lines of one utterance from its segments' results -- of two overlapping segments the earlier one keeps the words that begin before the
+// later one starts, the later one the rest; times shifted by the segments' offsets
+inline void MergeSegmentsToCTMOutput(std::vector<CudaPipelineResult> &results, const std::string &key, std::ostream &os, const std::vector<std::string> *word_syms = nullptr, bool use_segment_offsets = true) {
+  if (results.empty()) { K3H_WARN << "Utterance " << key << " has no results. Skipping"; return; }
+  for (CudaPipelineResult &r : results) if (!r.HasValidResult()) { K3H_WARN << "Utterance " << key << " has at least one segment with an error. Skipping"; return; }
+  os << std::fixed; os.precision(2);
+  float previous_segment_word_end = 0;
+  for (size_t i = 0; i < results.size(); i++) {
+    bool first_word = true; const bool last = i + 1 == results.size(); const float next_offset = last ? std::numeric_limits<float>::max() : results[i + 1].GetTimeOffsetSeconds();
+    CudaPipelineResult &r = results[i]; const float offset = use_segment_offsets ? r.GetTimeOffsetSeconds() : 0; const CtmResult &ctm = *r.GetCTMResult();
+    for (size_t w = 0; w < ctm.times_seconds.size(); w++) {
+      const float from = offset + ctm.times_seconds[w].first, to = offset + ctm.times_seconds[w].second;
+      if (first_word) { if (from >= previous_segment_word_end) first_word = false; else continue; }
+      if (!last && from >= next_offset) break;
+      previous_segment_word_end = to;
+      os << key << " " << r.GetSegmentID() << "  " << from << ' ' << (to - from) << ' ';
+      const int32_t id = ctm.words[w];
+      if (word_syms && id >= 0 && (size_t)id < word_syms->size() && !(*word_syms)[id].empty()) os << (*word_syms)[id]; else os << id;
+      os << ' ' << ctm.conf[w] << '\n';
+    }
+  }
+}
 typedef std::function<void(SegmentedLatticeCallbackParams &)> SegmentedResultsCallback;
 
 struct BatchedThreadedNnet3CudaPipeline2Config {      // the options of BatchedThreadedNnet3CudaOnlinePipelineConfig / CudaDecoderConfig this pipeline reads
@@ -100,6 +126,11 @@ class BatchedThreadedNnet3CudaPipeline2 {
     k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
   }
   float GetModelFrequency() const { return config_.feature_opts.samp_freq; }
+  // batched-threaded-nnet3-cuda-pipeline2.h:204-208: scales / word insertion penalty / MBR applied to every lattice result; required for RESULT_TYPE_CTM
+  void SetLatticePostprocessor(const std::shared_ptr<LatticePostprocessor> &lattice_postprocessor) {
+    lattice_postprocessor_ = lattice_postprocessor;
+    lattice_postprocessor_->SetDecoderFrameShift(config_.feature_opts.frame_shift_ms * 1.0e-3f * config_.frame_subsampling_factor);
+  }
   // Enqueues one utterance; `callback` is called with its lattice from a worker thread ("will be called once the lattice is ready", :118-160).
   // An utterance that cannot be decoded (too short, decoder failure) still gets its callback, with an empty lattice (NumStates() == 0).
   void DecodeWithCallback(const std::vector<float> &wave_data, float sample_rate, const LatticeCallback &callback, const std::string &group = std::string()) {
@@ -113,7 +144,7 @@ class BatchedThreadedNnet3CudaPipeline2 {
   // finishes the last of them (:160-168, 265-337).  A waveform shorter than one segment is one segment; a last piece below min-segment-length is dropped.
   void SegmentedDecodeWithCallback(const std::shared_ptr<Wave> &wave_data, const SegmentedResultsCallback &segmented_callback, const int result_type = CudaPipelineResult::RESULT_TYPE_LATTICE) {
     if (!result_type) K3H_ERR << "You must define at least one result type";
-    if (result_type & CudaPipelineResult::RESULT_TYPE_CTM) K3H_ERR << "CTM results need the lattice postprocessor, which this pipeline does not provide";
+    if ((result_type & CudaPipelineResult::RESULT_TYPE_CTM) && !lattice_postprocessor_) K3H_ERR << "A lattice postprocessor must be set with SetLatticePostprocessor() to use RESULT_TYPE_CTM";
     if (wave_data->samp_freq != GetModelFrequency()) K3H_ERR << "SegmentedDecodeWithCallback: sample rate " << wave_data->samp_freq << " != model frequency " << GetModelFrequency();
     config_.seg_opts.Check();
     const float freq = GetModelFrequency();
@@ -127,8 +158,11 @@ class BatchedThreadedNnet3CudaPipeline2 {
     auto not_done = std::make_shared<std::atomic<int32_t>>((int32_t)pieces.size());
     for (size_t i = 0; i < pieces.size(); i++) {
       CudaPipelineResult &r = (*results)[i]; r.SetTimeOffsetSeconds(std::floor((float)pieces[i].first / freq)); r.SetSegmentID((int)i); if (i + 1 == pieces.size()) r.SetAsLastSegment();
-      LatticeCallback callback = [results, not_done, segmented_callback, i](CompactLattice &clat) {
-        (*results)[i].SetLatticeResult(std::move(clat));
+      auto pp = lattice_postprocessor_;
+      LatticeCallback callback = [results, not_done, segmented_callback, i, pp, result_type](CompactLattice &clat) {
+        // SetResultUsingLattice (cudadecoder/lattice-postprocessor.cc:112-137)
+        if (result_type & CudaPipelineResult::RESULT_TYPE_CTM) { CtmResult ctm; CompactLattice copy = clat; pp->GetCTM(copy, &ctm); (*results)[i].SetCTMResult(std::move(ctm)); }
+        if (result_type & CudaPipelineResult::RESULT_TYPE_LATTICE) { if (pp) { CompactLattice out; pp->GetPostprocessedLattice(clat, &out); (*results)[i].SetLatticeResult(std::move(out)); } else (*results)[i].SetLatticeResult(std::move(clat)); }
         if (not_done->fetch_sub(1) == 1 && segmented_callback) { SegmentedLatticeCallbackParams params; params.results = std::move(*results); segmented_callback(params); }
       };
       std::vector<float> piece(wave_data->samples.begin() + pieces[i].first, wave_data->samples.begin() + pieces[i].first + pieces[i].second);
@@ -259,6 +293,7 @@ class BatchedThreadedNnet3CudaPipeline2 {
       s0 += ns; a0 += na;
     }
   }
+  std::shared_ptr<LatticePostprocessor> lattice_postprocessor_;
   const BatchedThreadedNnet3CudaPipeline2Config config_; k3_nnet *nnet_; const TransitionInfo &trans_;
   k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; k3_nnet_info ninfo_; int fdim_ = 0, device_ = 0; int32_t graph_start_ = 0; std::vector<float> log_priors_;
   std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache_;

@@ -505,6 +505,20 @@ def test_segmentation_program_and_class_equal_decoding_the_pieces(tmp_path):
     assert sorted(ra) == sorted(want) and ra == rb
     e = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--segmentation=true", "--segment-length=3.0", "--segment-overlap=3.5", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/x.txt"], capture_output=True, text=True)
     assert e.returncode != 0 and "overlap" in e.stderr
+    # the class with a lattice post-processor and RESULT_TYPE_CTM (SetLatticePostprocessor, SetResultUsingLattice, MergeSegmentsToCTMOutput): one merged CTM per file -- of two overlapping
+    # segments the earlier one keeps the words that begin before the later one starts; times carry the segments' offsets; the lattices are the post-processed ones
+    open(f"{td}/pp.conf", "w").write("--acoustic-scale=0.8\n")
+    c = subprocess.run([os.path.join(BIN, "k3-pipeline-example")] + common + seg + ["--max-batch-size=3", f"--lattice-postprocessor-rxfilename={td}/pp.conf", f"--ctm-out={td}/cls.ctm", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/cls2.txt"],
+                       capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr
+    ctm = [l.split() for l in open(f"{td}/cls.ctm")]
+    assert ctm and all(len(l) == 6 for l in ctm) and {l[0] for l in ctm} == {"file0", "file1", "file2", "file3"}
+    for f, dur in zip(("file0", "file1", "file2", "file3"), (7.6, 3.0, 5.6, 1.2)):
+        mine = [l for l in ctm if l[0] == f]; starts = [float(l[2]) for l in mine]; segs = [int(l[1]) for l in mine]
+        assert starts == sorted(starts) and segs == sorted(segs) and float(mine[-1][2]) + float(mine[-1][3]) <= dur + 0.05 and all(0.0 <= float(l[5]) <= 1.0 for l in mine), (f, mine)
+    assert max(int(l[1]) for l in ctm if l[0] == "file0") == 2 and max(float(l[2]) for l in ctm if l[0] == "file0") > 5.0      # the third segment of file0 contributes words beyond its 5 s offset
+    d = subprocess.run([os.path.join(BIN, "k3-pipeline-example")] + common + seg + ["--max-batch-size=3", f"--ctm-out={td}/no.ctm", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/cls3.txt"], capture_output=True, text=True)
+    assert d.returncode != 0 and "SetLatticePostprocessor" in d.stderr
 
 
 def test_batched_wav_nnet3_cuda2_ctm_output(tmp_path):
