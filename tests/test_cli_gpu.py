@@ -516,7 +516,7 @@ def test_segmentation_program_and_class_equal_decoding_the_pieces(tmp_path):
     for f, dur in zip(("file0", "file1", "file2", "file3"), (7.6, 3.0, 5.6, 1.2)):
         mine = [l for l in ctm if l[0] == f]; starts = [float(l[2]) for l in mine]; segs = [int(l[1]) for l in mine]
         assert starts == sorted(starts) and segs == sorted(segs) and float(mine[-1][2]) + float(mine[-1][3]) <= dur + 0.05 and all(0.0 <= float(l[5]) <= 1.0 for l in mine), (f, mine)
-    assert max(int(l[1]) for l in ctm if l[0] == "file0") == 2 and max(float(l[2]) for l in ctm if l[0] == "file0") > 5.0      # the third segment of file0 contributes words beyond its 5 s offset
+    assert max(int(l[1]) for l in ctm if l[0] == "file0") == 2 and max(float(l[2]) for l in ctm if l[0] == "file0") >= 5.0      # the third segment of file0 contributes words beyond its 5 s offset
     d = subprocess.run([os.path.join(BIN, "k3-pipeline-example")] + common + seg + ["--max-batch-size=3", f"--ctm-out={td}/no.ctm", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/cls3.txt"], capture_output=True, text=True)
     assert d.returncode != 0 and "SetLatticePostprocessor" in d.stderr
 
