@@ -456,7 +456,7 @@ def main():
                 its = [float(l.rsplit("; ", 1)[1].split()[0]) for l in r.stderr.splitlines() if "iteration" in l and l.rstrip().endswith("ms")]
                 gf = [float(l.split(": ")[-1].split()[0]) for l in r.stderr.splitlines() if "GFLOP in matrix products" in l]
                 line["chain_train"] = ({"ms_per_iteration": float(np.mean(its[2:])), "first_iteration_ms": its[0], "iterations": len(its),
-                                        "config": f"tests/adapter/nnet3_chain_train.cc over kaldi_amd/adapter (NnetChainTrainer::TrainInternal's sequence: forward, k3_chain_objf_and_deriv, backward with natural-gradient updates, max-change, orthonormal constraint): the benchmark model, {tB} sequences x {tT} output frames, 3000-state denominator graph"}
+                                        "config": f"kaldi_amd/adapter/nnet3-chain-train.cc (NnetChainTrainer::TrainInternal's sequence: forward, k3_chain_objf_and_deriv, backward with natural-gradient updates, max-change, orthonormal constraint): the benchmark model, {tB} sequences x {tT} output frames, 3000-state denominator graph"}
                                        if r.returncode == 0 and len(its) >= 3 else {"error": (r.stderr or "")[-300:]})
                 if "error" not in line["chain_train"] and len(gf) >= 3:
                     tf = float(np.mean(gf[2:])) * 1e9 / (line["chain_train"]["ms_per_iteration"] * 1e-3) / 1e12

@@ -1,4 +1,4 @@
-// tests/adapter/nnet3_chain_train.cc -- N iterations of chain (LF-MMI) TRAINING on one minibatch, the sequence NnetChainTrainer::Train / TrainInternal runs
+// kaldi_amd/adapter/nnet3-chain-train.cc -- the drop-in for chainbin/nnet3-chain-train.cc:33-104 on the MI355X: N iterations of chain (LF-MMI) TRAINING over a list of minibatches, the sequence NnetChainTrainer::Train / TrainInternal runs
 // (nnet3/nnet-chain-training.cc:60-144): NnetComputer over (nnet, delta_nnet) with component statistics stored, forward in training mode, ComputeChainObjfAndDeriv,
 // backward (every updatable component's Update(): natural-gradient preconditioning (nnet3/natural-gradient-online.cc) times its learning rate into delta_nnet),
 // ApplyL2Regularization, UpdateNnetWithMaxChange (per-component and global max-change), ScaleBatchnormStats, ConstrainOrthonormal (the semi-orthogonal
@@ -6,8 +6,16 @@
 // Linked twice from this one source.  Oracle (oracle/_ref/bin/ref-nnet3-chain-train): on the reference's CPU matrices, objective by chain::ComputeChainObjfAndDeriv.
 // MI355X (-DK3_ADAPTER, kaldi_amd/adapter/_build/nnet3-chain-train): the same objects over the CuMatrix adapter (every matrix operation of the forward pass, the
 // backprop, the preconditioner and the constraint is a k3_mat_* / k3_vec_* kernel), objective by k3_chain_objf_and_deriv on the adapter's device pointers.
-//   nnet3-chain-train <raw-nnet3-in> <frame-subsampling-factor> <input-matrix-in> <chain-spec-in> <num-iters> <learning-rate> <momentum> <raw-nnet3-out> <objf-vector-out>
-// chain-spec: as tests/adapter/nnet3_chain_grad.cc.  objf-vector: per iteration [objf, l2_term, weight], then the parameters of the trained model.
+//   nnet3-chain-train <raw-nnet3-in> <frame-subsampling-factor> <input-matrix-in>[,...] <chain-spec-in>[,...] <num-iters> <learning-rate> <momentum> <raw-nnet3-out> <objf-vector-out>
+// The reference program reads NnetChainExample archives (nnet3/nnet-chain-example.cc), whose Supervision objects are OpenFst objects; /root/reference does not vendor OpenFst, so the
+// minibatches come as pairs of files instead (iteration i trains on pair i mod n; all pairs the same shape, like the minibatches merged from one egs archive):
+//   input-matrix  Kaldi binary Matrix<float> [(T-1)*s + 1 + left + right frames x num_sequences, sequence-minor rows (n, t) like a merged NnetChainExample's input, feature dim columns]
+//   chain-spec    int32[11] {0x4b36, den states, den start, den arcs, num pdfs P, num sequences B, frames per sequence T, merged-supervision states, arcs, per-sequence states, arcs}
+//                 float[3] {leaky-hmm-coefficient, l2-regularize, supervision weight}; the denominator FST, the merged supervision FST (chain::Supervision::fst after MergeSupervision),
+//                 int32[B+1] first state of every sequence's own FST, the B per-sequence FSTs concatenated; every FST as CSR: int64[S+1] arc offsets, int32[A] pdf-id + 1 labels,
+//                 int32[A] next states, float[A] weights, float[S] final costs.  (tools/debug_chain_train.py and bench.py write it.)
+// objf-vector: per iteration [objf, l2_term, weight], then the parameters of the trained model.
+// Data-parallel: K3_TRAIN_ID_FILE / K3_TRAIN_RANK / K3_TRAIN_WORLD make the process one rank of a job whose parameter changes are all-reduced over RCCL every iteration (k3_comm_allreduce_f32).
 #include "base/kaldi-common.h"
 #include "base/timer.h"
 #include "util/common-utils.h"
@@ -48,10 +56,19 @@ int main(int argc, char *argv[]) {
     po.Read(argc, argv);
     if (po.NumArgs() != 9) { po.PrintUsage(); return 1; }
     Nnet nnet; ReadKaldiObject(po.GetArg(1), &nnet); int32 s; if (!ConvertStringToInteger(po.GetArg(2), &s)) KALDI_ERR << "bad subsampling factor";
-    Reader r{fopen(po.GetArg(4).c_str(), "rb")}; if (!r.f) KALDI_ERR << "cannot open " << po.GetArg(4);
-    int32_t h[11]; float fo[3]; r.get(h, 11); r.get(fo, 3); if (h[0] != 0x4b36) KALDI_ERR << "bad chain spec";
+    std::vector<std::string> in_files, spec_files; SplitStringToVector(po.GetArg(3), ",", true, &in_files); SplitStringToVector(po.GetArg(4), ",", true, &spec_files);
+    if (in_files.empty() || in_files.size() != spec_files.size()) KALDI_ERR << "need as many input matrices as chain specs";
+    const size_t num_mb = spec_files.size();
+    struct Minibatch { int32_t h[11]; float fo[3]; Csr den, merged, sup; std::vector<int32_t> state_off; };
+    std::vector<Minibatch> mbs(num_mb);
+    for (size_t m = 0; m < num_mb; m++) {
+      Reader r{fopen(spec_files[m].c_str(), "rb")}; if (!r.f) KALDI_ERR << "cannot open " << spec_files[m];
+      Minibatch &mb = mbs[m]; r.get(mb.h, 11); r.get(mb.fo, 3); if (mb.h[0] != 0x4b36) KALDI_ERR << "bad chain spec " << spec_files[m];
+      mb.den.read(r, mb.h[1], mb.h[3]); mb.merged.read(r, mb.h[7], mb.h[8]); mb.state_off.resize(mb.h[5] + 1); r.get(mb.state_off.data(), mb.h[5] + 1); mb.sup.read(r, mb.h[9], mb.h[10]); fclose(r.f);
+      if (mb.h[4] != mbs[0].h[4] || mb.h[5] != mbs[0].h[5] || mb.h[6] != mbs[0].h[6] || mb.h[1] != mbs[0].h[1] || mb.h[3] != mbs[0].h[3]) KALDI_ERR << "the minibatches differ in shape or denominator graph";
+    }
+    const int32_t *h = mbs[0].h; const float *fo = mbs[0].fo; const Csr &den = mbs[0].den;
     const int32 P = h[4], B = h[5], T = h[6];
-    Csr den, merged, sup; den.read(r, h[1], h[3]); merged.read(r, h[7], h[8]); std::vector<int32_t> state_off(B + 1); r.get(state_off.data(), B + 1); sup.read(r, h[9], h[10]); fclose(r.f);
     int32 num_iters; double lrate, momentum;
     if (!ConvertStringToInteger(po.GetArg(5), &num_iters) || !ConvertStringToReal(po.GetArg(6), &lrate) || !ConvertStringToReal(po.GetArg(7), &momentum)) KALDI_ERR << "bad iteration count / learning rate / momentum";
     const BaseFloat max_param_change = 2.0, l2_regularize_factor = 1.0, batchnorm_stats_scale = 0.8;      // NnetTrainerOptions' defaults (nnet3/nnet-training.h:36-80)
@@ -63,17 +80,18 @@ int main(int argc, char *argv[]) {
     IoSpecification in; in.name = "input"; in.has_deriv = false; for (int32 t = -left; t <= (T - 1) * s + right; t++) for (int32 n = 0; n < B; n++) in.indexes.push_back(Index(n, t));
     IoSpecification out; out.name = "output"; out.has_deriv = true; for (int32 f = 0; f < T; f++) for (int32 n = 0; n < B; n++) out.indexes.push_back(Index(n, f * s));
     request.inputs.push_back(in); request.outputs.push_back(out);
-    Matrix<BaseFloat> input; ReadKaldiObject(po.GetArg(3), &input);
-    if (input.NumRows() != (int32)in.indexes.size() || nnet.OutputDim("output") != P) KALDI_ERR << "input / model do not fit the chain spec";
+    std::vector<Matrix<BaseFloat> > inputs(num_mb);
+    for (size_t m = 0; m < num_mb; m++) { ReadKaldiObject(in_files[m], &inputs[m]); if (inputs[m].NumRows() != (int32)in.indexes.size() || nnet.OutputDim("output") != P) KALDI_ERR << "input / model do not fit the chain spec"; }
     NnetOptimizeOptions optimize_opts; CachingOptimizingCompilerOptions compiler_opts; CachingOptimizingCompiler compiler(nnet, optimize_opts, compiler_opts);
     std::shared_ptr<const NnetComputation> computation = compiler.Compile(request);
 #ifdef K3_ADAPTER
-    k3_chain_den *kden = NULL; k3_chain_supervision *ksup = NULL;
+    k3_chain_den *kden = NULL; std::vector<k3_chain_supervision *> ksups(num_mb, NULL);
     if (k3_chain_den_create((int32_t)den.fin.size(), h[2], P, den.off.data(), den.il.data(), den.nx.data(), den.w.data(), den.fin.data(), &kden) != K3_OK) KALDI_ERR << k3_last_error();
-    if (k3_chain_supervision_create(B, T, P, fo[2], state_off.data(), sup.off.data(), sup.il.data(), sup.nx.data(), sup.w.data(), sup.fin.data(), &ksup) != K3_OK) KALDI_ERR << k3_last_error();
+    for (size_t m = 0; m < num_mb; m++) { const Minibatch &mb = mbs[m]; if (k3_chain_supervision_create(B, T, P, mb.fo[2], mb.state_off.data(), mb.sup.off.data(), mb.sup.il.data(), mb.sup.nx.data(), mb.sup.w.data(), mb.sup.fin.data(), &ksups[m]) != K3_OK) KALDI_ERR << k3_last_error(); }
 #else
     fst::StdVectorFst den_fst; ToFst(den, h[2], &den_fst); chain::DenominatorGraph den_graph(den_fst, P);
-    chain::Supervision supervision; ToFst(merged, 0, &supervision.fst); supervision.weight = fo[2]; supervision.num_sequences = B; supervision.frames_per_sequence = T; supervision.label_dim = P;
+    std::vector<chain::Supervision> supervisions(num_mb);
+    for (size_t m = 0; m < num_mb; m++) { chain::Supervision &sv = supervisions[m]; ToFst(mbs[m].merged, 0, &sv.fst); sv.weight = mbs[m].fo[2]; sv.num_sequences = B; sv.frames_per_sequence = T; sv.label_dim = P; }
 #endif
 #ifdef K3_ADAPTER
     // K3_TRAIN_ID_FILE [+ K3_TRAIN_RANK / K3_TRAIN_WORLD]: this process is one rank of a data-parallel job (k3_comm_create: RCCL communicator through a rendezvous file)
@@ -86,23 +104,24 @@ int main(int argc, char *argv[]) {
 #endif
     MaxChangeStats max_change_stats(nnet);
     Vector<BaseFloat> objfs(3 * num_iters + NumParameters(nnet));      // per iteration [objf, l2_term, weight], then every parameter of the trained model (VectorizeNnet)
-    CuMatrix<BaseFloat> cu_in_orig(input);
+    std::vector<CuMatrix<BaseFloat> > cu_in_orig(num_mb); for (size_t m = 0; m < num_mb; m++) cu_in_orig[m] = inputs[m];
     for (int32 iter = 0; iter < num_iters; iter++) {      // TrainInternal
       Timer iter_timer;
       // The reference draws from the host's rand() for its sampled decisions (which minibatches store statistics / repair gradients / get the orthonormal constraint) AND inside its CPU
       // chain code's self-checks (chain-denominator.cc: RandInt(0, 10)), which k3_chain_objf_and_deriv does not have: reseeded at the same two points in both builds, every such decision is the same.
       srand(2 * iter + 1);
       NnetComputeOptions compute_opts; NnetComputer computer(compute_opts, *computation, &nnet, delta_nnet);
-      CuMatrix<BaseFloat> cu_in(cu_in_orig); computer.AcceptInput("input", &cu_in); computer.Run();
+      const size_t mi = (size_t)iter % num_mb;      // the next minibatch of the list
+      CuMatrix<BaseFloat> cu_in(cu_in_orig[mi]); computer.AcceptInput("input", &cu_in); computer.Run();
       const CuMatrixBase<BaseFloat> &nnet_output = computer.GetOutput("output");
       CuMatrix<BaseFloat> nnet_output_deriv(nnet_output.NumRows(), nnet_output.NumCols(), kUndefined);
       BaseFloat objf = 0, l2_term = 0, weight = 0;
 #ifdef K3_ADAPTER
       k3_chain_training_opts o = {fo[1], 0.0f, fo[0], 0};
-      if (k3_chain_objf_and_deriv(kden, ksup, &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv.Data(), nnet_output_deriv.Stride(), NULL, 0, &objf, &l2_term, &weight, NULL) != K3_OK) KALDI_ERR << k3_last_error();
+      if (k3_chain_objf_and_deriv(kden, ksups[mi], &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv.Data(), nnet_output_deriv.Stride(), NULL, 0, &objf, &l2_term, &weight, NULL) != K3_OK) KALDI_ERR << k3_last_error();
 #else
       chain::ChainTrainingOptions opts; opts.leaky_hmm_coefficient = fo[0]; opts.l2_regularize = fo[1]; opts.out_of_range_regularize = 0.0;
-      chain::ComputeChainObjfAndDeriv(opts, den_graph, supervision, nnet_output, &objf, &l2_term, &weight, &nnet_output_deriv, NULL);
+      chain::ComputeChainObjfAndDeriv(opts, den_graph, supervisions[mi], nnet_output, &objf, &l2_term, &weight, &nnet_output_deriv, NULL);
 #endif
       srand(2 * iter + 2);
       computer.AcceptInput("output", &nnet_output_deriv); computer.Run();
@@ -128,7 +147,8 @@ int main(int argc, char *argv[]) {
     }
     max_change_stats.Print(nnet);
 #ifdef K3_ADAPTER
-    k3_chain_supervision_destroy(ksup); k3_chain_den_destroy(kden);
+    for (k3_chain_supervision *k : ksups) k3_chain_supervision_destroy(k);
+    k3_chain_den_destroy(kden);
     if (comm) k3_comm_destroy(comm);
 #endif
     delete delta_nnet;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes a small TDNN-F (orthonormal-constrained bottlenecks), a minibatch and a chain spec into a directory and runs both builds of tests/adapter/nnet3_chain_train.cc on it
+"""Writes a small TDNN-F (orthonormal-constrained bottlenecks), a minibatch and a chain spec into a directory and runs both builds of kaldi_amd/adapter/nnet3-chain-train.cc on it
 (oracle on the CPU where oracle/_ref exists; the adapter build on the GPU box).  With K3_ADAPTER_LIST_MISSING=1 the adapter build lists the CuMatrix members it reached without an
 implementation instead of stopping at the first.   tools/debug_chain_train.py <dir> [iters]"""
 import os, sys, struct, subprocess, numpy as np
