@@ -1,0 +1,307 @@
+// k3_pipeline.h -- the class surface of the reference's offline CUDA pipeline over the C ABI:
+//   kaldi::cuda_decoder::BatchedThreadedNnet3CudaPipeline2 (cudadecoder/batched-threaded-nnet3-cuda-pipeline2.h:57-239): the constructor taking
+//   (config, decoding graph, acoustic model, transition model), DecodeWithCallback (waveform in, CompactLattice handed to a callback on a worker
+//   thread), task groups (CreateTaskGroup / DestroyTaskGroup / WaitForGroup) and WaitForAllTasks, with the reference's names and semantics.
+// Types are this host layer's own (k3_host.h: HostFst, TransitionInfo, Wave, CompactLattice) because OpenFst and Kaldi's libraries cannot be
+// linked here; INTEGRATION.md shows the one-to-one mapping.  Behind it: a control thread that takes whatever is queued (up to max_batch_size
+// utterances, like AcquireTasks :349-380), runs waveforms -> k3_feat_compute_batch -> k3_nnet_forward -> k3_decoder_decode_batch -> raw
+// lattices, and a pool of worker threads that does Connect + (phone-)pruned determinization per utterance and calls the callback
+// (batched-threaded-nnet3-cuda-online-pipeline.cc:735-810).  SegmentedDecodeWithCallback (:265-337) cuts a waveform into overlapping segments, decodes each as
+// an utterance and hands all results to one callback (CudaPipelineResult, lattice results).  The lattice postprocessor (CTM results) is not provided:
+// asking for RESULT_TYPE_CTM is an error.
+#pragma once
+#include <limits>
+#include <ostream>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include "../kaldi_amd/host/k3_online.h"      // (the host layer of this repository: k3_host.h + the streaming helpers)
+namespace k3host {
+namespace cuda_decoder {
+
+// cudadecoder/cuda-pipeline-common.h:36-60
+inline int NumberOfSegments(int nsamples, int seg_length, int seg_shift) {
+  if (seg_shift <= 0 || seg_length < seg_shift) K3H_ERR << "NumberOfSegments: bad segment length / shift";
+  if (nsamples <= seg_length) return 1;
+  return ((nsamples - (seg_length - seg_shift)) + seg_shift - 1) / seg_shift;
+}
+struct CudaPipelineSegmentationConfig {
+  double segment_length_s = 20, segment_overlap_s = 1, min_segment_length_s = 1;
+  void Register(ParseOptions *po) {
+    po->Register("segment-length", &segment_length_s, "Segment length (s)"); po->Register("segment-overlap", &segment_overlap_s, "Overlap between segments (s)");
+    po->Register("min-segment-length", &min_segment_length_s, "Min segment length (s, >=1)");
+  }
+  void Check() const {
+    if (min_segment_length_s < 0.5) K3H_ERR << "Min segment length must be at least 0.5 second";
+    if (segment_overlap_s > segment_length_s) K3H_ERR << "The segments overlap cannot be larger than segment length";
+    if (segment_length_s < min_segment_length_s) K3H_ERR << "Segment length cannot be smaller than min segment length";
+    if (segment_overlap_s >= segment_length_s) K3H_ERR << "The segments overlap must be smaller than the segment length";
+  }
+};
+// cudadecoder/cuda-pipeline-common.h:69-140
+class CudaPipelineResult {
+  int result_type_ = 0; CompactLattice clat_; CtmResult ctm_; float offset_seconds_ = 0; int32_t segment_id_ = 0; bool is_last_segment_ = false;
+ public:
+  static constexpr int RESULT_TYPE_LATTICE = 1, RESULT_TYPE_CTM = 2;
+  int32_t GetResultType() const { return result_type_; }
+  bool HasValidResult() const { return result_type_ != 0; }
+  int32_t GetSegmentID() const { return segment_id_; }
+  bool IsLastSegment() const { return is_last_segment_; }
+  float GetTimeOffsetSeconds() const { return offset_seconds_; }
+  void SetLatticeResult(CompactLattice &&clat) { result_type_ |= RESULT_TYPE_LATTICE; clat_ = std::move(clat); }
+  CompactLattice *GetLatticeResult() { if (!(result_type_ & RESULT_TYPE_LATTICE)) K3H_ERR << "Lattice result was not requested"; return &clat_; }
+  void SetCTMResult(CtmResult &&ctm) { result_type_ |= RESULT_TYPE_CTM; ctm_ = std::move(ctm); }
+  CtmResult *GetCTMResult() { if (!(result_type_ & RESULT_TYPE_CTM)) K3H_ERR << "CTM result was not requested"; return &ctm_; }
+  void SetTimeOffsetSeconds(float offset_seconds) { if (offset_seconds < 0) K3H_ERR << "negative segment offset"; offset_seconds_ = offset_seconds; }
+  void SetSegmentID(int segment_id) { segment_id_ = segment_id; }
+  void SetAsLastSegment() { is_last_segment_ = true; }
+};
+struct SegmentedLatticeCallbackParams { std::vector<CudaPipelineResult> results; };
+// cudadecoder/cuda-pipeline-common.cc:67-142: the CTM lines of one utterance from its segments' results -- of two overlapping segments the earlier one keeps the words that begin before the
+// later one starts, the later one the rest; times shifted by the segments' offsets
+inline void MergeSegmentsToCTMOutput(std::vector<CudaPipelineResult> &results, const std::string &key, std::ostream &os, const std::vector<std::string> *word_syms = nullptr, bool use_segment_offsets = true) {
+  if (results.empty()) { K3H_WARN << "Utterance " << key << " has no results. Skipping"; return; }
+  for (CudaPipelineResult &r : results) if (!r.HasValidResult()) { K3H_WARN << "Utterance " << key << " has at least one segment with an error. Skipping"; return; }
+  os << std::fixed; os.precision(2);
+  float previous_segment_word_end = 0;
+  for (size_t i = 0; i < results.size(); i++) {
+    bool first_word = true; const bool last = i + 1 == results.size(); const float next_offset = last ? std::numeric_limits<float>::max() : results[i + 1].GetTimeOffsetSeconds();
+    CudaPipelineResult &r = results[i]; const float offset = use_segment_offsets ? r.GetTimeOffsetSeconds() : 0; const CtmResult &ctm = *r.GetCTMResult();
+    for (size_t w = 0; w < ctm.times_seconds.size(); w++) {
+      const float from = offset + ctm.times_seconds[w].first, to = offset + ctm.times_seconds[w].second;
+      if (first_word) { if (from >= previous_segment_word_end) first_word = false; else continue; }
+      if (!last && from >= next_offset) break;
+      previous_segment_word_end = to;
+      os << key << " " << r.GetSegmentID() << "  " << from << ' ' << (to - from) << ' ';
+      const int32_t id = ctm.words[w];
+      if (word_syms && id >= 0 && (size_t)id < word_syms->size() && !(*word_syms)[id].empty()) os << (*word_syms)[id]; else os << id;
+      os << ' ' << ctm.conf[w] << '\n';
+    }
+  }
+}
+typedef std::function<void(SegmentedLatticeCallbackParams &)> SegmentedResultsCallback;
+
+struct BatchedThreadedNnet3CudaPipeline2Config {      // the options of BatchedThreadedNnet3CudaOnlinePipelineConfig / CudaDecoderConfig this pipeline reads
+  int32_t max_batch_size = 400, num_worker_threads = -1;      // --max-batch-size, --cuda-worker-threads (-1: hardware concurrency)
+  bool determinize_lattice = true;                            // --determinize-lattice
+  DeterminizeLatticePhonePrunedOptions det_opts;
+  k3_feat_opts feature_opts;                                  // from --feature-type + its config (FeatOptions::Finish())
+  k3_decoder_config decoder_opts;                             // beam, lattice-beam, max-active, capacities, literal_order
+  float acoustic_scale = 0.1f; int32_t frame_subsampling_factor = 1;
+  CudaPipelineSegmentationConfig seg_opts;                    // --segment-length, --segment-overlap, --min-segment-length
+  BatchedThreadedNnet3CudaPipeline2Config() { memset(&feature_opts, 0, sizeof feature_opts); k3_decoder_config_default(&decoder_opts); }
+};
+
+class BatchedThreadedNnet3CudaPipeline2 {
+ public:
+  using LatticeCallback = std::function<void(CompactLattice &)>;
+  BatchedThreadedNnet3CudaPipeline2(const BatchedThreadedNnet3CudaPipeline2Config &config, const HostFst &decode_fst, k3_nnet *am_nnet, const TransitionInfo &trans_model)
+      : config_(config), nnet_(am_nnet), trans_(trans_model) {
+    K3H_CHECK_K3(k3_feat_plan_create(&config_.feature_opts, &plan_)); fdim_ = k3_feat_dim(plan_);
+    K3H_CHECK_K3(k3_nnet_get_info(nnet_, &ninfo_));
+    if (ninfo_.input_dim != fdim_) K3H_ERR << "Feature dimension " << fdim_ << " does not match the model's input dimension " << ninfo_.input_dim;
+    if (ninfo_.ivector_dim > 0) K3H_ERR << "this pipeline class does not extract i-vectors (the batched-wav-nnet3-cuda2 program does)";
+    if (ninfo_.output_dim != trans_.num_pdfs) K3H_ERR << "Model output dimension " << ninfo_.output_dim << " != number of pdfs in the transition model " << trans_.num_pdfs;
+    if (ninfo_.has_priors) { log_priors_.resize(ninfo_.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet_, log_priors_.data())); for (float &p : log_priors_) p = logf(p); }
+    K3H_CHECK_K3(k3_fst_create(decode_fst.NumStates(), decode_fst.start, decode_fst.arc_offsets.data(), decode_fst.ilabel.data(), decode_fst.olabel.data(), decode_fst.weight.data(),
+                               decode_fst.nextstate.data(), decode_fst.final_cost.data(), trans_.id2pdf.data(), (int32_t)trans_.id2pdf.size(), &fst_));
+    graph_start_ = k3_fst_start(fst_);
+    K3H_CHECK_K3(k3_decoder_create(fst_, &config_.decoder_opts, config_.max_batch_size, ninfo_.output_dim, &dec_));
+    K3O_HIP(hipGetDevice(&device_));
+    const int nw = config_.num_worker_threads > 0 ? config_.num_worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
+    for (int i = 0; i < nw; i++) workers_.emplace_back([this] { WorkerLoop(); });
+    control_ = std::thread([this] { ControlLoop(); });
+  }
+  virtual ~BatchedThreadedNnet3CudaPipeline2() {
+    WaitForAllTasks();
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all(); wcv_.notify_all();
+    control_.join(); for (auto &w : workers_) w.join();
+    for (auto &c : plan_cache_) k3_nnet_batch_destroy(c.second);
+    k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
+  }
+  float GetModelFrequency() const { return config_.feature_opts.samp_freq; }
+  // batched-threaded-nnet3-cuda-pipeline2.h:204-208: scales / word insertion penalty / MBR applied to every lattice result; required for RESULT_TYPE_CTM
+  void SetLatticePostprocessor(const std::shared_ptr<LatticePostprocessor> &lattice_postprocessor) {
+    lattice_postprocessor_ = lattice_postprocessor;
+    lattice_postprocessor_->SetDecoderFrameShift(config_.feature_opts.frame_shift_ms * 1.0e-3f * config_.frame_subsampling_factor);
+  }
+  // Enqueues one utterance; `callback` is called with its lattice from a worker thread ("will be called once the lattice is ready", :118-160).
+  // An utterance that cannot be decoded (too short, decoder failure) still gets its callback, with an empty lattice (NumStates() == 0).
+  void DecodeWithCallback(const std::vector<float> &wave_data, float sample_rate, const LatticeCallback &callback, const std::string &group = std::string()) {
+    if (sample_rate != GetModelFrequency()) K3H_ERR << "DecodeWithCallback: sample rate " << sample_rate << " != model frequency " << GetModelFrequency();
+    auto t = std::make_shared<Task>(); t->samples = wave_data; t->callback = callback; Enqueue(t, group);
+  }
+  void DecodeWithCallback(const std::shared_ptr<Wave> &wave_data, const LatticeCallback &callback, const std::string &group = std::string()) {
+    DecodeWithCallback(wave_data->samples, wave_data->samp_freq, callback, group);
+  }
+  // Extracts segments from wave_data and decodes them; `segmented_callback` gets the results of all segments at once, in segment order, from the worker thread that
+  // finishes the last of them (:160-168, 265-337).  A waveform shorter than one segment is one segment; a last piece below min-segment-length is dropped.
+  void SegmentedDecodeWithCallback(const std::shared_ptr<Wave> &wave_data, const SegmentedResultsCallback &segmented_callback, const int result_type = CudaPipelineResult::RESULT_TYPE_LATTICE) {
+    if (!result_type) K3H_ERR << "You must define at least one result type";
+    if ((result_type & CudaPipelineResult::RESULT_TYPE_CTM) && !lattice_postprocessor_) K3H_ERR << "A lattice postprocessor must be set with SetLatticePostprocessor() to use RESULT_TYPE_CTM";
+    if (wave_data->samp_freq != GetModelFrequency()) K3H_ERR << "SegmentedDecodeWithCallback: sample rate " << wave_data->samp_freq << " != model frequency " << GetModelFrequency();
+    config_.seg_opts.Check();
+    const float freq = GetModelFrequency();
+    const int seg_len = (int)(config_.seg_opts.segment_length_s * freq), seg_shift = (int)((config_.seg_opts.segment_length_s - config_.seg_opts.segment_overlap_s) * freq),
+              seg_min = (int)(config_.seg_opts.min_segment_length_s * freq), total = (int)wave_data->samples.size();
+    if (total == 0) { if (segmented_callback) { SegmentedLatticeCallbackParams params; params.results.resize(1); params.results[0].SetLatticeResult(CompactLattice()); params.results[0].SetAsLastSegment(); segmented_callback(params); } return; }
+    std::vector<std::pair<int, int>> pieces;      // (offset, samples)
+    for (int offset = 0;; offset += seg_shift) { const int n = std::min(total - offset, seg_len); if (n >= seg_min) pieces.push_back({offset, n}); if (offset + n >= total) break; }
+    if (pieces.empty()) { if (segmented_callback) { SegmentedLatticeCallbackParams params; segmented_callback(params); } return; }
+    auto results = std::make_shared<std::vector<CudaPipelineResult>>(pieces.size());
+    auto not_done = std::make_shared<std::atomic<int32_t>>((int32_t)pieces.size());
+    for (size_t i = 0; i < pieces.size(); i++) {
+      CudaPipelineResult &r = (*results)[i]; r.SetTimeOffsetSeconds(std::floor((float)pieces[i].first / freq)); r.SetSegmentID((int)i); if (i + 1 == pieces.size()) r.SetAsLastSegment();
+      auto pp = lattice_postprocessor_;
+      LatticeCallback callback = [results, not_done, segmented_callback, i, pp, result_type](CompactLattice &clat) {
+        // SetResultUsingLattice (cudadecoder/lattice-postprocessor.cc:112-137)
+        if (result_type & CudaPipelineResult::RESULT_TYPE_CTM) { CtmResult ctm; CompactLattice copy = clat; pp->GetCTM(copy, &ctm); (*results)[i].SetCTMResult(std::move(ctm)); }
+        if (result_type & CudaPipelineResult::RESULT_TYPE_LATTICE) { if (pp) { CompactLattice out; pp->GetPostprocessedLattice(clat, &out); (*results)[i].SetLatticeResult(std::move(out)); } else (*results)[i].SetLatticeResult(std::move(clat)); }
+        if (not_done->fetch_sub(1) == 1 && segmented_callback) { SegmentedLatticeCallbackParams params; params.results = std::move(*results); segmented_callback(params); }
+      };
+      std::vector<float> piece(wave_data->samples.begin() + pieces[i].first, wave_data->samples.begin() + pieces[i].first + pieces[i].second);
+      DecodeWithCallback(piece, freq, callback);
+    }
+  }
+  void CreateTaskGroup(const std::string &group) {
+    std::lock_guard<std::mutex> l(m_);
+    if (!groups_.emplace(group, 0).second) K3H_ERR << "Group is already in use: " << group;
+  }
+  void DestroyTaskGroup(const std::string &group) {
+    std::unique_lock<std::mutex> l(m_);
+    auto it = groups_.find(group); if (it == groups_.end()) K3H_ERR << "Group does not exist: " << group;
+    done_cv_.wait(l, [&] { return it->second == 0; }); groups_.erase(it);
+  }
+  void WaitForGroup(const std::string &group) {
+    std::unique_lock<std::mutex> l(m_);
+    auto it = groups_.find(group); if (it == groups_.end()) K3H_ERR << "Group does not exist: " << group;
+    done_cv_.wait(l, [&] { return it->second == 0; });
+  }
+  void WaitForAllTasks() { std::unique_lock<std::mutex> l(m_); done_cv_.wait(l, [&] { return n_tasks_not_done_ == 0; }); }
+
+ private:
+  struct Task { std::vector<float> samples; LatticeCallback callback; std::string group; bool has_group = false; Lattice raw; bool failed = false; };
+  void Enqueue(const std::shared_ptr<Task> &t, const std::string &group) {
+    std::lock_guard<std::mutex> l(m_);
+    if (!group.empty()) { auto it = groups_.find(group); if (it == groups_.end()) K3H_ERR << "Group does not exist: " << group; it->second++; t->group = group; t->has_group = true; }
+    n_tasks_not_done_++; queue_.push_back(t); cv_.notify_one();
+  }
+  void Finish(const std::shared_ptr<Task> &t) {
+    std::lock_guard<std::mutex> l(m_);
+    if (t->has_group) groups_[t->group]--;
+    n_tasks_not_done_--; done_cv_.notify_all();
+  }
+  void WorkerLoop() {      // Connect + determinization + callback, one utterance at a time
+    for (;;) {
+      std::shared_ptr<Task> t;
+      { std::unique_lock<std::mutex> l(m_); wcv_.wait(l, [&] { return stop_ || !post_.empty(); }); if (post_.empty()) return; t = post_.front(); post_.pop_front(); }
+      CompactLattice clat;
+      try {
+        if (!t->failed && t->raw.NumStates() > 0) {
+          Connect(&t->raw);
+          if (config_.determinize_lattice) DeterminizeLatticePhonePruned(t->raw, trans_, config_.decoder_opts.lattice_beam, &clat, config_.det_opts);
+          else ConvertLattice(t->raw, &clat);
+        }
+        t->callback(clat);
+      } catch (const std::exception &e) { K3H_WARN << "lattice post-processing / callback failed: " << e.what(); }
+      Finish(t);
+    }
+  }
+  // Batches one apart on two streams (as bench.py and batched-wav-nnet3-cuda2 do): while the decoder of batch k runs, whatever has been queued meanwhile (up to max_batch_size
+  // utterances) gets its upload, features and network issued behind it, on the front stream, into the other log-likelihood buffer.  Nothing waits for a next batch to fill: with an
+  // empty queue the present batch is simply finished.
+  struct InFlight { std::vector<std::shared_ptr<Task>> batch; std::vector<int> idx; std::vector<int64_t> ro; int U = 0, buf = 0; bool valid = false; };
+  std::vector<std::shared_ptr<Task>> TakeBatch(bool block) {
+    std::vector<std::shared_ptr<Task>> batch;
+    std::unique_lock<std::mutex> l(m_);
+    if (block) cv_.wait(l, [&] { return stop_ || !queue_.empty(); });
+    while (!queue_.empty() && (int)batch.size() < config_.max_batch_size) { batch.push_back(queue_.front()); queue_.pop_front(); }
+    return batch;
+  }
+  void Hand(std::vector<std::shared_ptr<Task>> &batch) { { std::lock_guard<std::mutex> l(m_); for (auto &t : batch) post_.push_back(t); } wcv_.notify_all(); }
+  void ControlLoop() {
+    K3O_HIP(hipSetDevice(device_));
+    K3O_HIP(hipStreamCreateWithFlags(&s_front_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_, hipStreamNonBlocking));
+    for (auto &e : ev_front_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    InFlight cur, nxt; int parity = 0;
+    auto start = [&](InFlight *f, std::vector<std::shared_ptr<Task>> &&batch) {
+      f->batch = std::move(batch); f->valid = false; f->buf = parity; parity ^= 1;
+      try { FrontEnd(f); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : f->batch) t->failed = true; f->valid = false; }
+    };
+    for (;;) {
+      if (cur.batch.empty()) { auto b = TakeBatch(true); if (b.empty()) break; start(&cur, std::move(b)); }
+      bool decoding = false;
+      try {
+        if (cur.valid) {
+          K3O_HIP(hipStreamWaitEvent(s_dec_, ev_front_[cur.buf], 0));
+          K3H_CHECK_K3(k3_decoder_decode_batch(dec_, cur.U, d_ll_[cur.buf].p, ninfo_.output_dim, cur.ro.data(), s_dec_)); decoding = true;
+          K3O_HIP(hipEventSynchronize(ev_front_[cur.buf]));      // the front end of `cur` is through: its staging, feature and network buffers are free
+        }
+      } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; decoding = false; }
+      nxt = InFlight(); { auto b = TakeBatch(false); if (!b.empty()) start(&nxt, std::move(b)); }
+      if (decoding) { try { Fetch(&cur); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; } }
+      Hand(cur.batch);
+      cur = std::move(nxt); nxt = InFlight();
+    }
+    K3O_HIP(hipStreamSynchronize(s_front_)); K3O_HIP(hipStreamSynchronize(s_dec_));
+    for (auto &e : ev_front_) (void)hipEventDestroy(e); (void)hipStreamDestroy(s_front_); (void)hipStreamDestroy(s_dec_);
+  }
+  void FrontEnd(InFlight *f) {      // upload + features + network of f->batch on the front stream, log-likelihoods into buffer f->buf
+    std::vector<std::shared_ptr<Task>> &batch = f->batch;
+    std::vector<int> &idx = f->idx; idx.clear(); std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int32_t> nframes;
+    for (size_t i = 0; i < batch.size(); i++) {
+      const int nf = k3_feat_num_frames(plan_, (int64_t)batch[i]->samples.size());
+      if (nf == 0) { batch[i]->failed = true; continue; }      // too short to decode
+      idx.push_back((int)i); all.insert(all.end(), batch[i]->samples.begin(), batch[i]->samples.end()); woff.push_back((int64_t)all.size()); foff.push_back(foff.back() + nf); nframes.push_back(nf);
+    }
+    const int U = (int)idx.size(); f->U = U; if (U == 0) return;
+    const int64_t tot = foff.back();
+    d_w_.upload(all); d_wo_.upload(woff); d_fo_.upload(foff);      // (synchronous copies: the previous front end has completed, nothing reads these buffers)
+    K3H_CHECK_K3(k3_feat_compute_batch(plan_, d_w_.p, d_wo_.p, d_fo_.p, U, tot, d_f_.need((size_t)tot * fdim_), fdim_, s_front_));
+    k3_nnet_batch *nb = nullptr;
+    for (auto &c : plan_cache_) if (c.first == nframes) { nb = c.second; break; }
+    if (!nb) {
+      K3H_CHECK_K3(k3_nnet_batch_create(nnet_, U, nframes.data(), config_.frame_subsampling_factor, log_priors_.empty() ? nullptr : log_priors_.data(), config_.acoustic_scale, &nb));
+      plan_cache_.push_back({nframes, nb}); if (plan_cache_.size() > 4) { k3_nnet_batch_destroy(plan_cache_.front().second); plan_cache_.erase(plan_cache_.begin()); }
+    }
+    f->ro.assign(U + 1, 0); const int64_t rows = k3_nnet_batch_output_rows(nb, f->ro.data());
+    K3H_CHECK_K3(k3_nnet_forward(nb, d_f_.p, fdim_, d_ll_[f->buf].need((size_t)rows * ninfo_.output_dim), ninfo_.output_dim, s_front_));
+    K3O_HIP(hipEventRecord(ev_front_[f->buf], s_front_)); f->valid = true;
+  }
+  void Fetch(InFlight *f) {      // waits for the decoder of f->batch and turns its raw lattices into the tasks' Lattice objects
+    std::vector<std::shared_ptr<Task>> &batch = f->batch; const std::vector<int> &idx = f->idx; const int U = f->U;
+    std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec_, info.data());
+    int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
+    std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
+    K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec_, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));
+    int64_t s0 = 0, a0 = 0;
+    for (int u = 0; u < U; u++) {
+      Task &t = *batch[idx[u]]; const int64_t ns = info[10 * u], na = info[10 * u + 1];
+      if (info[10 * u + 2] != 0 || ns == 0) t.failed = true;
+      else {
+        Lattice &lat = t.raw; lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns); lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
+        lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na); lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na); lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
+        lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
+        for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == graph_start_) lat.start = (int32_t)s;
+      }
+      s0 += ns; a0 += na;
+    }
+  }
+  std::shared_ptr<LatticePostprocessor> lattice_postprocessor_;
+  const BatchedThreadedNnet3CudaPipeline2Config config_; k3_nnet *nnet_; const TransitionInfo &trans_;
+  k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; k3_nnet_info ninfo_; int fdim_ = 0, device_ = 0; int32_t graph_start_ = 0; std::vector<float> log_priors_;
+  std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache_;
+  DevBuf<float> d_w_, d_f_, d_ll_[2]; DevBuf<int64_t> d_wo_, d_fo_;
+  hipStream_t s_front_ = nullptr, s_dec_ = nullptr; hipEvent_t ev_front_[2] = {nullptr, nullptr};
+  std::mutex m_; std::condition_variable cv_, wcv_, done_cv_; bool stop_ = false;
+  std::deque<std::shared_ptr<Task>> queue_, post_; std::map<std::string, int> groups_; int n_tasks_not_done_ = 0;
+  std::thread control_; std::vector<std::thread> workers_;
+};
+}  // namespace cuda_decoder
+}  // namespace k3host

@@ -34,3 +34,32 @@ def test_cuda_decoder_adapter_equals_the_reference_cpu_decoder(name, step, tmp_p
     else:
         lat, _ = lo.decode(f, ll, t2p, cfg, 0)
         assert lsig.canonical_of_reference(got) == lsig.canonical_of_raw(lat)
+
+
+def test_pipeline_class_with_the_references_constructor_types(tmp_path):
+    """include/k3_batched_pipeline.h: kaldi::cuda_decoder::BatchedThreadedNnet3CudaPipeline2(config, fst::Fst<fst::StdArc>, nnet3::AmNnetSimple, TransitionModel) and
+    DecodeWithCallback(std::shared_ptr<WaveData>, void(CompactLattice &)) -- the reference's signatures (batched-threaded-nnet3-cuda-pipeline2.h:153-200) -- in a caller that reads
+    final.mdl with the reference's own TransitionModel / AmNnetSimple readers (tests/adapter/cuda_pipeline_example.cc).  The lattices its callbacks receive must be the ones
+    the batched-wav-nnet3-cuda2 program writes for the same files."""
+    import struct
+    from kaldi_amd import synth
+    from oracle import kaldi_io as kio
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "cuda-pipeline-example")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/cuda-pipeline-example is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001, 12000]
+    for i, n in enumerate(lens): kio.write_wav(f"{td}/u{i}.wav", synth.gaussian_pcm16(n, 40 + i))
+    open(f"{td}/wav.scp", "w").write("".join(f"utt{i} {td}/u{i}.wav\n" for i in range(len(lens))))
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    g = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); g.write_openfst(f"{td}/HCLG.fst")
+    with open(f"{td}/graph.bin", "wb") as fh:
+        fh.write(struct.pack("<3i", g.num_states, g.start, int(g.ilabel.size)))
+        for x, dt in ((g.arc_offsets, np.int32), (g.ilabel, np.int32), (g.olabel, np.int32), (g.nextstate, np.int32), (g.weight, np.float32), (g.final, np.float32)): np.ascontiguousarray(x, dt).tofile(fh)
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
+    r = subprocess.run([exe, f"{td}/final.mdl", f"{td}/graph.bin", f"{td}/wav.scp", f"{td}/fbank.conf", f"ark,t:{td}/cls.txt"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "Decoded 4 utterances, 0 with errors." in r.stderr, r.stderr[-3000:]
+    p = subprocess.run([os.path.join(ROOT, "kaldi_amd", "bin", "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0",
+                        "--lattice-beam=8.0", "--max-active=10000", "--max-batch-size=2", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/prog.txt"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert open(f"{td}/cls.txt").read() == open(f"{td}/prog.txt").read() and open(f"{td}/cls.txt").read().count("utt") == 4
