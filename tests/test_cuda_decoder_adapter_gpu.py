@@ -62,4 +62,11 @@ def test_pipeline_class_with_the_references_constructor_types(tmp_path):
     p = subprocess.run([os.path.join(ROOT, "kaldi_amd", "bin", "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0",
                         "--lattice-beam=8.0", "--max-active=10000", "--max-batch-size=2", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/prog.txt"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
-    assert open(f"{td}/cls.txt").read() == open(f"{td}/prog.txt").read() and open(f"{td}/cls.txt").read().count("utt") == 4
+    # (the model went through the reference's reader and writer on its way into the class: the last digit of a cost may differ; everything else must be the same)
+    from tests import lattice_cases as lc
+    a, b = lc.parse_compact_text(open(f"{td}/cls.txt").read()), lc.parse_compact_text(open(f"{td}/prog.txt").read())
+    assert list(a) == list(b) == ["utt0", "utt1", "utt2", "utt3"]
+    for k in a:
+        assert len(a[k]["arcs"]) == len(b[k]["arcs"]) > 0 and sorted(a[k]["finals"]) == sorted(b[k]["finals"]), k
+        for x, y in zip(a[k]["arcs"], b[k]["arcs"]):
+            assert x[:3] == y[:3] and list(x[5]) == list(y[5]) and abs(x[3] - y[3]) <= 2e-3 and abs(x[4] - y[4]) <= 2e-3, (k, x, y)
