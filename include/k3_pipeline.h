@@ -243,7 +243,10 @@ class BatchedThreadedNnet3CudaPipeline2 {
           K3H_CHECK_K3(k3_decoder_decode_batch(dec_, cur.U, d_ll_[cur.buf].p, ninfo_.output_dim, cur.ro.data(), s_dec_)); decoding = true;
           K3O_HIP(hipEventSynchronize(ev_front_[cur.buf]));      // the front end of `cur` is through: its staging, feature and network buffers are free
         }
-      } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; decoding = false; }
+      } catch (const std::exception &e) {
+        K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; decoding = false;
+        (void)hipStreamSynchronize(s_front_);      // the wait for cur's front end was skipped: its shared staging / feature buffers must be quiescent before the next batch's front end reuses (or reallocates) them
+      }
       nxt = InFlight(); { auto b = TakeBatch(false); if (!b.empty()) start(&nxt, std::move(b)); }
       if (decoding) { try { Fetch(&cur); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; } }
       Hand(cur.batch);

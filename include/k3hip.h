@@ -136,6 +136,9 @@ int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, int64_t ld_fe
  * d_stats_out (nullable) receives the statistics after the utterance's last estimate (GetAdaptationState).  One record is k3_ivector_stats_size()
  * doubles: num_frames, the linear term [R], the quadratic term [R x R].  Utterances of one speaker go in consecutive calls. */
 int64_t k3_ivector_stats_size(const k3_ivector *iv);
+/* on: d_stats_out holds the statistics of EVERY frame of the utterance (the frames behind the last estimate included) -- what the reference's ivector-extract-online2 --repeat=true
+ * carries to the speaker's next utterance (it asks for the last frame's i-vector: ivector-extract-online2.cc:121-127); off (default): the statistics at the last estimate */
+void k3_ivector_set_accumulate_tail(k3_ivector *iv, int32_t on);
 int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
                                    float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in,
                                    double *d_stats_out, void *stream);

@@ -48,7 +48,7 @@ struct k3_ivector {
   float *gconsts = nullptr, *miv_t = nullptr, *iv_t = nullptr;   // [G], [D][G], [D][G]
   double *U = nullptr, *SM = nullptr;                            // [G][R][R], [G][D][R]
   bool quad_in_lds = true;
-  DevBuf frame_off, cmvn, xpost, xstats, post_g, post_w, post_n, quad, state;
+  DevBuf frame_off, cmvn, xpost, xstats, post_g, post_w, post_n, quad, state; int acc_tail = 0;
   ~k3_ivector() { for (void *p : {(void *)lda, (void *)global_stats, (void *)gconsts, (void *)miv_t, (void *)iv_t, (void *)U, (void *)SM}) if (p) (void)hipFree(p); }
 };
 
@@ -173,7 +173,7 @@ struct EstParams {
   const double *U, *SM; double *quad_g, *chol_g;              // per utterance [R][R] scratch (quad_g NULL = LDS)
   float *out; int64_t ld_out; const int64_t *out_off;
   int D, R, S, period, num_cg_iters, exact_solve; double prior, max_count;
-  const double *state_in; double *state_out;      // per utterance [1 + R + R*R]: num_frames, linear, quadratic (OnlineIvectorEstimationStats), nullable
+  int acc_tail; const double *state_in; double *state_out;      // per utterance [1 + R + R*R]: num_frames, linear, quadratic (OnlineIvectorEstimationStats), nullable
 };
 
 __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
@@ -191,8 +191,8 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
   if (tid < R) { s_lin[tid] = st_in ? st_in[1 + tid] : (tid == 0 ? p.prior : 0.0); s_x[tid] = tid == 0 ? p.prior : 0.0; }
   double nframes = st_in ? st_in[0] : 0.0;
   __syncthreads();
-  for (int k = 0; (int64_t)k * P < T; k++) {
-    const int t_lo = k == 0 ? 0 : (k - 1) * P + 1, t_hi = k * P;                     // frames not yet in the statistics, up to and including frame k*P
+  // OnlineIvectorFeature::UpdateStatsUntilFrame (online-ivector-feature.cc:248-277) for frames t_lo .. t_hi: every thread of the block calls it
+  auto accumulate = [&](int t_lo, int t_hi) {
     if (tid == 0) {                                                                   // entries in frame order, then in the order VectorToPosteriorEntry left them
       int n = 0;
       for (int t = t_lo; t <= t_hi; t++) { const int c = p.post_n[fb + t]; for (int j = 0; j < c; j++) { e_g[n] = p.post_g[(fb + t) * S + j]; e_w[n] = p.post_w[(fb + t) * S + j]; e_t[n] = t; n++; } }
@@ -228,6 +228,11 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
     }
     nframes += tot;
     __syncthreads();
+  };
+  int k_last = -1;
+  for (int k = 0; (int64_t)k * P < T; k++) {
+    const int t_lo = k == 0 ? 0 : (k - 1) * P + 1, t_hi = k * P;                     // frames not yet in the statistics, up to and including frame k*P
+    accumulate(t_lo, t_hi); k_last = k;
     if (nframes > 0.0) {
       if (tid == 0 && s_x[0] == 0.0) s_x[0] = p.prior;
       __syncthreads();
@@ -269,6 +274,9 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
     if (tid < R) p.out[(p.out_off[u] + k) * p.ld_out + tid] = tid == 0 ? (float)s_x[0] - (float)p.prior : (float)s_x[tid];
   }
   if (p.state_out) {                                                                  // GetAdaptationState: the statistics as they stand after the last estimate
+    // (accumulate_tail: the reference's --repeat=true asks for the i-vector of the LAST frame, so its statistics hold every frame of the utterance when the state is taken:
+    // ivector-extract-online2.cc:121-127 GetFrame(T - 1) -> UpdateStatsUntilFrame(T - 1))
+    if (p.acc_tail && k_last >= 0 && k_last * P + 1 <= T - 1) accumulate(k_last * P + 1, T - 1);
     double *so = p.state_out + (size_t)u * (1 + R + (size_t)R * R);
     __syncthreads();
     if (tid == 0) so[0] = nframes;
@@ -335,6 +343,7 @@ extern "C" int64_t k3_ivector_num_rows(const k3_ivector *iv, int32_t num_utts, c
   return n;
 }
 
+extern "C" void k3_ivector_set_accumulate_tail(k3_ivector *iv, int32_t on) { if (iv) iv->acc_tail = on ? 1 : 0; }
 extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
                                               const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream_);
 extern "C" int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
@@ -374,7 +383,7 @@ extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_fea
                      iv->o.posterior_scale, N, (int32_t *)iv->post_g.p, (float *)iv->post_w.p, (int32_t *)iv->post_n.p);
   EstParams p; p.xstats = (const float *)iv->xstats.p; p.frame_off = d_off; p.post_g = (const int32_t *)iv->post_g.p; p.post_w = (const float *)iv->post_w.p; p.post_n = (const int32_t *)iv->post_n.p;
   p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)iv->quad.p; p.chol_g = (double *)iv->state.p; p.out = d_ivectors; p.ld_out = ld_ivectors; p.out_off = d_row_off;
-  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out;
+  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out; p.acc_tail = iv->acc_tail;
   size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
   K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_extract_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));

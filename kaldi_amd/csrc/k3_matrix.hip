@@ -367,7 +367,7 @@ extern "C" int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, in
   if (!fast && getenv("K3_GEMM_TRACE")) fprintf(stderr, "k3 generic gemm M %d N %d K %d ta %d tb %d lda %lld ldb %lld A&15 %d B&15 %d\n", M, N, K, ta, tb, (long long)lda, (long long)ldb, (int)(reinterpret_cast<uintptr_t>(d_A) & 15), (int)(reinterpret_cast<uintptr_t>(d_B) & 15));      // developer aid: which products miss the tile kernel
   const long long tiles = (long long)((N + T - 1) / T) * ((M + T - 1) / T);
   hipStream_t st = (hipStream_t)stream;
-  if (tiles < (fast ? 192 : 384) && K >= (fast ? 1536 : 3072)) {      // few output tiles, long K (a layer's weight gradient over a minibatch): split K so that the chip is filled; planes reduced in a fixed order
+  if (tiles < (fast ? 192 : 384) && K >= (fast ? 768 : 3072)) {      // (planes are whole 384-wide accumulation blocks added in ascending order: the same sums as without the split)      // few output tiles, long K (a layer's weight gradient over a minibatch): split K so that the chip is filled; planes reduced in a fixed order
     int S = (int)std::min<long long>(fast ? 64 : 16, std::max<long long>(2, (fast ? 512 : 1024) / tiles)); int Kc = ((K + S - 1) / S + 383) / 384 * 384; S = (K + Kc - 1) / Kc;
     void *wsv = nullptr; { const int rc = workspace(st, (size_t)S * M * N * sizeof(float), &wsv); if (rc) return rc; }
     float *ws = static_cast<float *>(wsv);

@@ -42,6 +42,7 @@ int main(int argc, char **argv) {
     o.ivector_period = info.ivector_period; o.num_cg_iters = info.num_cg_iters; o.exact_solve = exact_solve; o.online_cmvn_iextractor = info.online_cmvn_iextractor;
     o.cmvn.cmn_window = info.cmn_window; o.cmvn.speaker_frames = info.speaker_frames; o.cmvn.global_frames = info.global_frames; o.cmvn.normalize_mean = info.normalize_mean; o.cmvn.normalize_variance = info.normalize_variance;
     k3_ivector *iv = nullptr; K3H_CHECK_K3(k3_ivector_create(&m, &o, &iv));
+    k3_ivector_set_accumulate_tail(iv, repeat ? 1 : 0);      // --repeat=true: the adaptation state handed to the speaker's next utterance holds every frame (GetFrame(T - 1), :121-127)
     const int32_t F = m.feat_dim, R = m.ivector_dim, P = info.ivector_period; const int64_t SS = k3_ivector_stats_size(iv);
     auto table = ReadMatrixTable(po.GetArg(2)); TableWriter writer(po.GetArg(3));
     std::map<std::string, size_t> index; for (size_t i = 0; i < table.size(); i++) index[table[i].first] = i;

@@ -79,9 +79,11 @@ class BatchedIvectorExtractor:
     def IvectorDim(self): return self.ivector_dim
     def NumGauss(self): return self.num_gauss
 
-    def GetIvectors(self, feats, frame_offsets, cmvn_speaker_stats=None, stats_in=None, return_stats=False):
+    def GetIvectors(self, feats, frame_offsets, cmvn_speaker_stats=None, stats_in=None, return_stats=False, accumulate_tail=False):
         """-> (ivectors, row_offsets[, stats]).  cmvn_speaker_stats [U, 2, feat_dim+1] / stats_in [U, StatsSize()] (float64, host or GPU): the adaptation state
-        the speaker's earlier utterances left (OnlineIvectorExtractorAdaptationState); return_stats: also the i-vector statistics after each utterance."""
+        the speaker's earlier utterances left (OnlineIvectorExtractorAdaptationState); return_stats: also the i-vector statistics after each utterance -- at its last estimate, or
+        with accumulate_tail over all of its frames (what ivector-extract-online2 --repeat=true hands on)."""
+        self._L.k3_ivector_set_accumulate_tail.restype = None; self._L.k3_ivector_set_accumulate_tail(self._h, ctypes.c_int32(1 if accumulate_tail else 0))
         assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and feats.stride(1) == 1
         fo = np.ascontiguousarray(np.asarray(frame_offsets, dtype=np.int64)); U = fo.size - 1
         ro = np.zeros(U + 1, np.int64)

@@ -14,5 +14,8 @@ with tempfile.TemporaryDirectory() as td:
     open(f"{td}/spk2utt", "w").write("spkA utt0 utt1\nspkB utt2 utt3\n")
     subprocess.check_call([EXE, "--config=ivector_extractor.conf", f"ark:{td}/spk2utt", f"ark:{td}/feats.ark", f"ark:{td}/iv.ark"], env=ENV, cwd=DIR, stderr=subprocess.DEVNULL)
     iv = kio.read_ark(f"{td}/iv.ark")
-np.savez_compressed(os.path.join(DIR, "ivector_adapt_golden.npz"), **{"iv_" + u: iv[u] for u in utts})
+    # --repeat=true: one row per frame, and the statistics handed on hold EVERY frame of the first utterance (GetFrame(T - 1), :121-127)
+    subprocess.check_call([EXE, "--config=ivector_extractor.conf", "--repeat=true", f"ark:{td}/spk2utt", f"ark:{td}/feats.ark", f"ark:{td}/ivr.ark"], env=ENV, cwd=DIR, stderr=subprocess.DEVNULL)
+    ivr = kio.read_ark(f"{td}/ivr.ark")
+np.savez_compressed(os.path.join(DIR, "ivector_adapt_golden.npz"), **{"iv_" + u: iv[u] for u in utts}, **{"ivrep_" + u: ivr[u][::10] for u in utts})      # (every 10th row = one per ivector period)
 print({u: (iv[u].shape, float(np.abs(iv[u] - g["iv_default_" + u]).max())) for u in utts})

@@ -124,3 +124,8 @@ def test_adaptation_state_carried_to_the_speakers_next_utterance(golden):
     for k, u in enumerate(("utt1", "utt3")): worst = max(worst, np.abs(iv2[ro2[k]:ro2[k + 1]] - ref["iv_" + u]).max())
     print("max |gpu - reference binary| with adaptation state =", worst)
     assert worst <= TOL, worst
+    # --repeat=true of the reference program: the state handed on holds EVERY frame of the first utterance (k3_ivector_set_accumulate_tail)
+    _, _, stats_all = ex.GetIvectors(x, fo, return_stats=True, accumulate_tail=True)
+    iv2r, _ = ex.GetIvectors(x2, fo2, cmvn_speaker_stats=cm, stats_in=stats_all); torch.cuda.synchronize(); iv2r = iv2r.cpu().numpy(); worst_r = 0.0
+    for k, u in enumerate(("utt1", "utt3")): worst_r = max(worst_r, np.abs(iv2r[ro2[k]:ro2[k + 1]] - ref["ivrep_" + u]).max())
+    assert worst_r <= TOL and np.abs(ref["ivrep_utt1"] - ref["iv_utt1"]).max() > 0.01, worst_r
