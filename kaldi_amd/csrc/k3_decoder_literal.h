@@ -310,7 +310,61 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
 static_assert(kHoLds <= kLitDynLds, "the hash-order arena lives in the replay's dynamic segment");
 constexpr size_t kLitTabBytes = (size_t)3 * kHL * 4, kLitMarkBytes = (size_t)3 * (kHL / 32) * 4, kLitAuxBytes = (size_t)2 * 1024 * 4;
 #include "k3_decoder_fast.h"
+// HashList order for the frames between the two LDS-only forms above and the HBM form (lit_hash_order): up to kHmN tokens, labels below kHmM, hash_size <= 65535 -- 95 % of
+// the frames the general path sees.  The structure of fast_hash_order (k3_decoder_fast.h: packed {bucket, smallest creation rank} table, members counted at the leader's
+// rank) with every per-token value in an LDS array instead of registers (the general path runs at 128 registers per thread); `arena` = the 77.5 KB of the general path, all of it
+// dead at both call sites.  Returns false when the frame does not fit (the caller takes lit_hash_order).
+constexpr int kHmN = 3072, kHmM = 32768, kHmB = 4096;
+constexpr size_t kHmLds = (size_t)kHmB * 4 + 7 * ((size_t)kHmN * 2 + 8) + (size_t)kHmM / 8 + (size_t)kHmM / 32 * 2;
+__device__ __forceinline__ bool lit_hash_order_mid(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins) {
+  if (n > kHmN || M > (unsigned)kHmM || hash_size > 65535u) return false;
+  const int tid = threadIdx.x; const int W = (int)((M + 31u) >> 5);
+  unsigned *btab = reinterpret_cast<unsigned *>(arena); char *a_ = arena + (size_t)kHmB * 4; constexpr size_t kCol = (size_t)kHmN * 2 + 8;
+  unsigned short *lab16 = reinterpret_cast<unsigned short *>(a_), *bkt16 = reinterpret_cast<unsigned short *>(a_ + kCol), *dense16 = reinterpret_cast<unsigned short *>(a_ + 2 * kCol),
+                 *lf16 = reinterpret_cast<unsigned short *>(a_ + 3 * kCol), *lead = reinterpret_cast<unsigned short *>(a_ + 4 * kCol), *grp = reinterpret_cast<unsigned short *>(a_ + 5 * kCol),
+                 *curs = reinterpret_cast<unsigned short *>(a_ + 6 * kCol);
+  unsigned *bm = reinterpret_cast<unsigned *>(a_ + 7 * kCol); unsigned short *wpre = reinterpret_cast<unsigned short *>(a_ + 7 * kCol + (size_t)kHmM / 8);
+  for (int i = tid; i < kHmB; i += kBlock) btab[i] = 0xFFFFFFFFu;
+  for (int i = tid; i < W; i += kBlock) bm[i] = 0u;
+  for (int i = tid; i < (n + 1) / 2 + 1; i += kBlock) { reinterpret_cast<unsigned *>(lead)[i] = 0u; reinterpret_cast<unsigned *>(curs)[i] = 0u; }
+  for (int i = tid; i < n; i += kBlock) { lab16[i] = (unsigned short)K3_ALD(&q.label[i]); bkt16[i] = (unsigned short)((unsigned)st[i] % hash_size); }
+  __syncthreads();
+  for (int i = tid; i < n; i += kBlock) { const unsigned l = lab16[i]; k3a_or(&bm[l >> 5], 1u << (l & 31)); }
+  __syncthreads();
+  block_excl_scan_f([&](int w) { return __popc(bm[w]); }, [&](int w, int ex) { wpre[w] = (unsigned short)ex; }, W, sh.redi);
+  for (int i = tid; i < n; i += kBlock) {
+    const unsigned l = lab16[i], b = bkt16[i]; const unsigned d = (unsigned)wpre[l >> 5] + (unsigned)__popc(bm[l >> 5] & ((1u << (l & 31)) - 1u));
+    dense16[i] = (unsigned short)d; if (write_by_ins) q.by_ins[d] = i;
+    const unsigned mine = (b << 16) | d; unsigned h = (b * 2654435761u) >> 20;      // 12 bits: kHmB = 4096
+    for (;;) {
+      unsigned w = lds_ld(&btab[h]);
+      if (w == 0xFFFFFFFFu) { const unsigned old = k3a_cas(&btab[h], 0xFFFFFFFFu, mine); if (old == 0xFFFFFFFFu) break; w = old; }
+      if ((w >> 16) == b) { k3a_min(&btab[h], mine); break; }
+      h = (h + 1) & (kHmB - 1);
+    }
+    lf16[i] = (unsigned short)h;      // (the slot for now; the leader's rank once every member has arrived)
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kBlock) { const unsigned lf = btab[lf16[i]] & 0xFFFFu; lf16[i] = (unsigned short)lf; add16(lead, (int)lf, 1u); }
+  __syncthreads();
+  bool multi = false;
+  for (int i = tid; i < n; i += kBlock) { const unsigned c = lead[lf16[i]]; bkt16[i] = (unsigned short)c; multi |= c > 1u; }      // (bkt16 is free now: the bucket's member count)
+  multi = __syncthreads_or(multi);
+  block_excl_scan_f([&](int r) { return (int)lead[r]; }, [&](int r, int ex) { lead[r] = (unsigned short)ex; }, n, sh.redi);
+  if (multi) {
+    for (int i = tid; i < n; i += kBlock) if (bkt16[i] > 1u) { const unsigned lf = lf16[i]; const unsigned s_ = add16(curs, (int)lf, 1u); grp[lead[lf] + s_] = dense16[i]; }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += kBlock) {
+    const unsigned lp = lead[lf16[i]], c = bkt16[i]; unsigned rank = 0;
+    if (c > 1u) { const unsigned d = dense16[i]; for (unsigned t = 0; t < c; t++) rank += grp[lp + t] < d; }
+    order_out[lp + rank] = i;
+  }
+  __syncthreads();
+  return true;
+}
 constexpr size_t kLitGeneralLds = kLitTabBytes + kLitMarkBytes + kLitAuxBytes + kLitDynLds;
+static_assert(kHmLds <= kLitTabBytes + kLitMarkBytes + kLitAuxBytes + kLitDynLds, "the mid-size hash order works in the general path's arena");
 constexpr size_t kLitArena = kLitGeneralLds > (size_t)kFastArena ? kLitGeneralLds : (size_t)kFastArena;
 struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 
@@ -824,7 +878,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made (their labels and states are
     // untouched by the closure).  Computed here, where the level-1 table's LDS is free for the bucket table of the pass.
     if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, s_tab, lt_last__);
-    else lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
+    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false)) lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
     K3_LT(6);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
     const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
@@ -950,7 +1004,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     __syncthreads();
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
     if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, smem_raw, s_tab, lt_last__);
-    else lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
+    else if (!lit_hash_order_mid(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true)) lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     K3_LT(10);
     // ---- publish the frame: final costs into the pool, empty table, idle labels
