@@ -349,7 +349,9 @@ def main():
         return dt, acc / steps, lat_sizes, det_sizes
 
     mode0 = "literal" if decs else None
+    if decs: decs["literal"].FramePathCounts()      # (reset)
     dt, acc, lat_sizes, det_sizes = run(mode0, args.steps, args.warmup)
+    paths = decs["literal"].FramePathCounts() if decs else None
     audio_s = U * args.utt_seconds * world * args.steps
     two = run("two_pass", args.steps, args.warmup) if "two_pass" in decs else None
     # Stage and kernel durations (stage_ms, roofline, roofline_gemm) come from a short SERIAL pass of the same objects: in the pipelined steps a kernel shares the GPU with the other
@@ -396,7 +398,7 @@ def main():
             line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_literal_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                 "traffic": None, "traffic_measured_in_run": False, "algorithmic_bytes_per_launch": ab,
                                 "note": "algorithmic bytes (SURVEY 8d: 32 B/emitting arc traversed + 28 B/eps arc traversed + 16 B/token) from device counters / HIP-event time of the kernel on its launch stream; "
-                                        "the kernel moves ~10x these bytes through the memory system in 4-64 B requests (per-lane scratch that does not stay in L2; `traffic`) and is bound by that transaction rate (~2 TB/s) and the per-frame chain of dependent phases, not by peak bandwidth"}
+                                        "bound by the per-frame chain of ~70 barrier-separated phases (each a few thousand cycles of dependent LDS / L2 accesses), not by bandwidth: frames of <= 1536 tokens run entirely in LDS (decode_stats.frames_by_path), the first frames of each utterance (the start state's thousands of arcs) run on the HBM-scratch path and move `traffic` (several x the algorithmic bytes, in 4-64 B requests); DESIGN.md section 5"}
             line["roofline"]["traffic_command"] = TRAFFIC_CMD
             tr = measure_traffic(args) if (args.measure_traffic and world == 1) else None
             if tr and "traffic_bytes_per_launch" in tr:
@@ -411,7 +413,8 @@ def main():
             line["decode_stats"] = {"graph_broadcast_s": t_bcast if world > 1 else 0.0, "emitting_arcs_traversed": int(info[:, 7].sum()), "eps_arcs_traversed": int(info[:, 8].sum()), "tokens": int(info[:, 4].sum()),
                                     "links": int(info[:, 5].sum()), "max_tokens_on_a_frame": int(info[:, 6].max()), "lattice_states": lat_sizes[0], "lattice_arcs": lat_sizes[1], "lattice_digest": lat_sizes[2],
                                     "determinized_states": det_sizes[0], "determinized_arcs": det_sizes[1], "reached_final_frac": float(info[:, 3].mean()), "algorithmic_bytes": ab,
-                                    "order_sensitive_events": int(dec.OrderSensitiveEvents().sum())}
+                                    "order_sensitive_events": int(dec.OrderSensitiveEvents().sum()),
+                                    "frames_by_path": dict(paths, note="frames of the warm-up + timed steps of this rank: lds_path = processed entirely in LDS (k3_decoder_fast.h: frames of <= 1536 tokens), given_up = started there, exceeded a capacity and redone, general_path = the HBM-scratch path (redone frames included)")}
             if two is not None:
                 dt2, acc2, ls2, ds2 = two[:4]; d2 = decs["two_pass"]; info2 = d2.LatticeInfo(); ab2 = d2.algorithmic_bytes(info2)
                 line["value_two_pass"] = audio_s / dt2

@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
 #elif defined(K3_FAST_PROF)
   if (tid == 0) { long long *P = p.prof + blockIdx.x * 16; for (int k = 0; k < 12; k++) P[k] += fs.prof[k]; P[12] += n_fast; P[13] += n_gaveup; P[14] += n_general; P[15] += cyc_fast; }
 #elif !defined(K3_LIT_STATS)
-  if (tid == 0) { long long *P = p.prof + blockIdx.x * 16; for (int k = 0; k < 12; k++) P[k] += why[k]; P[12] += n_fast; P[13] += n_gaveup; P[14] += n_general; P[15] += cyc_fast; P[11] += cyc_general; }
+  if (tid == 0) { long long *P = p.prof + blockIdx.x * 16; for (int k = 0; k < 11; k++) P[k] += why[k]; P[12] += n_fast; P[13] += n_gaveup; P[14] += n_general; P[15] += cyc_fast; P[11] += cyc_general; }
 #endif
   if (tid == 0) {
     LaneInfo &li = p.info[L];

@@ -171,6 +171,13 @@ class CudaDecoder:
                                                      ai[0].ctypes.data, ai[1].ctypes.data, ai[2].ctypes.data, ai[3].ctypes.data, af[0].ctypes.data, af[1].ctypes.data))
         return RawLatticeBatch(so, ao, si, sf, ai, af, self.fst.start)
 
+    def FramePathCounts(self):
+        """literal_order = 1: frames since the last call by path -- on the LDS-resident path (k3_decoder_fast.h), given up there and redone, on the general path (redone ones included) --
+        and why the LDS path gave frames up (k3_decoder_phase_cycles of the shipped library; reading resets the counters)"""
+        c = np.zeros(16, np.int64); _l.check(self._L.k3_decoder_phase_cycles(self._h, c.ctypes.data))
+        names = ("tokens", "table", "hash", "labels", "worklist", "eps_links", "degree", "closure", "queue", "stack", "mismatch")
+        return dict(lds_path=int(c[12]), given_up=int(c[13]), general_path=int(c[14]), give_up_reasons={n: int(v) for n, v in zip(names, c[:11]) if v})
+
     def SetProfiling(self, on=True):
         _l.check(self._L.k3_decoder_set_profiling(self._h, int(on)))
 
