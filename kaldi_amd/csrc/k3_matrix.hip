@@ -6,7 +6,9 @@
 // All matrices are row-major float32 with a leading dimension (CuMatrixBase::Stride()), device pointers.
 #include "k3_common.h"
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 
@@ -71,36 +73,55 @@ __global__ __launch_bounds__(256) void k3_gemm_generic_kernel(int M, int N, int 
 // stored for A / transposed for B, the m / n dimension otherwise), the next k-tile in registers while the present one is multiplied (one barrier per k-tile, two LDS buffers).
 // Same accumulation order as k3_gemm_generic_kernel: k ascending, 384-wide blocks added to a total that starts at beta C.  The training pass's GEMMs (activations x weights,
 // output derivative x weights, output derivative^T x activations over a minibatch) all qualify; the generic kernel stays the fall-back.
-template <int TA, int TB>
-__global__ __launch_bounds__(256) void k3_gemm_tile128_kernel(int M, int N, int K, float alpha, const float *__restrict__ A, long long lda, const float *__restrict__ B, long long ldb, float beta,
-                                                              float *C, long long ldc, float *W, int Kc) {
-  __shared__ float As[2][128][17], Bs[2][16][132];
+template <int T, int TA, int TB, int BK>
+__global__ __launch_bounds__(256) void k3_gemm_tile_kernel(int M, int N, int K, float alpha, const float *__restrict__ A, long long lda, const float *__restrict__ B, long long ldb, float beta,
+                                                           float *C, long long ldc, float *W, int Kc, int kblk) {
+  // a (64 T) x (64 T) output tile per workgroup, T = 1 or 2: four wavefronts as 2 x 2, each T x T MFMA 32x32 blocks; k-tiles of BK (16 / 32 / 64) double-buffered through LDS.
+  // The sum over k is formed in blocks of kblk (block sums added in ascending order), so a split of K at multiples of kblk gives the bits of the unsplit product.
+  constexpr int TS = 64 * T;
+  constexpr int U = T * BK / 16, Q = BK / 4;      // dwordx4 per thread and operand per k-tile; dwordx4 per row of BK k's
+  __shared__ float As[2][TS][BK + 1], Bs[2][BK][TS + 4];
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   int kb_ = 0, ke_ = K;
   if (W) { kb_ = (int)blockIdx.z * Kc; ke_ = min(K, kb_ + Kc); C = W + (long long)blockIdx.z * M * N; ldc = N; alpha = 1.0f; beta = 0.0f; }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-  f32x16 acc[2][2], total[2][2];
+  const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+  f32x16 acc[T][T], total[T][T], cin[T][T];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < T; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < T; j++) {
+      const int col = n0 + wn * 32 * T + j * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        acc[i][j][r] = 0.0f; total[i][j][r] = 0.0f;
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (beta != 0.0f && row < M && col < N) total[i][j][r] = beta * C[(long long)row * ldc + col];
-      }
+      for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.0f; total[i][j][r] = 0.0f; cin[i][j][r] = 0.0f; }
+      (void)col;
     }
-  f32x4 ra[2], rb[2];
-  // one k-tile of both operands into registers: two dwordx4 per thread and operand; elements outside the matrices / the k range are zero
+  // beta C is requested under the MFMAs of the last k-tile (at the top of the kernel the operand loads queued behind these 16 T^2 row pieces: +10 us on a [4736 x 768] product)
+  auto load_c = [&]() {
+#pragma unroll
+    for (int i = 0; i < T; i++)
+#pragma unroll
+      for (int j = 0; j < T; j++) {
+        const int col = n0 + wn * 32 * T + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * 32 * T + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M && col < N) cin[i][j][r] = C[(long long)row * ldc + col];
+        }
+      }
+  };
+  // the running sum starts from beta C (the reference-like order of DESIGN.md 2.1): with one accumulation block that is (beta C) + alpha acc whenever C arrives; with several,
+  // C is requested under the first k-tile's MFMAs and seeds `total` at the first block boundary
+  bool have_c = beta == 0.0f, seeded = false;
+  const bool several = (ke_ - 1) / kblk > kb_ / kblk;
+  f32x4 ra[U], rb[U];
+  // one k-tile of both operands into registers: T dwordx4 per thread and operand; elements outside the matrices / the k range are zero
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
       const int f = tid + 256 * u;
       {
-        const int r = TA ? (f & 31) * 4 : (f >> 2), k = TA ? (f >> 5) : (f & 3) * 4;      // TA: k-major rows of 128 m's; else m-major rows of 16 k's
+        const int r = TA ? (f & (16 * T - 1)) * 4 : f / Q, k = TA ? f / (16 * T) : (f % Q) * 4;      // TA: k-major rows of TS m's; else m-major rows of BK k's
         const int gm = m0 + r, gk = k0 + k; f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         if (TA) {
           if (gk < ke_) { const float *src = A + (long long)gk * lda + gm; if (gm + 3 < M) v = *reinterpret_cast<const f32x4 *>(src); else { for (int e = 0; e < 4; e++) if (gm + e < M) v[e] = src[e]; } }
@@ -110,7 +131,7 @@ __global__ __launch_bounds__(256) void k3_gemm_tile128_kernel(int M, int N, int 
         ra[u] = v;
       }
       {
-        const int c = TB ? (f >> 2) : (f & 31) * 4, k = TB ? (f & 3) * 4 : (f >> 5);      // TB: n-major rows of 16 k's; else k-major rows of 128 n's
+        const int c = TB ? f / Q : (f & (16 * T - 1)) * 4, k = TB ? (f % Q) * 4 : f / (16 * T);      // TB: n-major rows of BK k's; else k-major rows of TS n's
         const int gn = n0 + c, gk = k0 + k; f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         if (TB) {
           if (gn < N) { const float *src = B + (long long)gn * ldb + gk; if (gk + 3 < ke_) v = *reinterpret_cast<const f32x4 *>(src); else { for (int e = 0; e < 4; e++) if (gk + e < ke_) v[e] = src[e]; } }
@@ -123,49 +144,55 @@ __global__ __launch_bounds__(256) void k3_gemm_tile128_kernel(int M, int N, int 
   };
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
       const int f = tid + 256 * u;
-      if (TA) { const int r = (f & 31) * 4, k = f >> 5; for (int e = 0; e < 4; e++) As[buf][r + e][k] = ra[u][e]; }
-      else { const int r = f >> 2, k = (f & 3) * 4; for (int e = 0; e < 4; e++) As[buf][r][k + e] = ra[u][e]; }
-      if (TB) { const int c = f >> 2, k = (f & 3) * 4; for (int e = 0; e < 4; e++) Bs[buf][k + e][c] = rb[u][e]; }
-      else { const int c = (f & 31) * 4, k = f >> 5; for (int e = 0; e < 4; e++) Bs[buf][k][c + e] = rb[u][e]; }
+      if (TA) { const int r = (f & (16 * T - 1)) * 4, k = f / (16 * T); for (int e = 0; e < 4; e++) As[buf][r + e][k] = ra[u][e]; }
+      else { const int r = f / Q, k = (f % Q) * 4; for (int e = 0; e < 4; e++) As[buf][r][k + e] = ra[u][e]; }
+      if (TB) { const int c = f / Q, k = (f % Q) * 4; for (int e = 0; e < 4; e++) Bs[buf][k + e][c] = rb[u][e]; }
+      else { const int c = (f & (16 * T - 1)) * 4, k = f / (16 * T); for (int e = 0; e < 4; e++) Bs[buf][k][c + e] = rb[u][e]; }
     }
   };
   fetch(kb_); stage(0);
   __syncthreads();
   int buf = 0;
-  for (int k0 = kb_; k0 < ke_; k0 += 16, buf ^= 1) {
-    if (k0 != kb_ && k0 % 384 == 0) {
+  for (int k0 = kb_; k0 < ke_; k0 += BK, buf ^= 1) {
+    if (k0 != kb_ && k0 % kblk == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < T; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < T; j++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) { total[i][j][r] += alpha * acc[i][j][r]; acc[i][j][r] = 0.0f; }
+          for (int r = 0; r < 16; r++) { total[i][j][r] = (seeded ? total[i][j][r] : beta == 0.0f ? 0.0f : beta * cin[i][j][r]) + alpha * acc[i][j][r]; acc[i][j][r] = 0.0f; }
+      seeded = true;
     }
-    const bool more = k0 + 16 < ke_;
-    if (more) fetch(k0 + 16);      // in flight while this tile is multiplied
+    const bool more = k0 + BK < ke_;
+    if (more) fetch(k0 + BK);      // in flight while this tile is multiplied
+    if (!have_c && (several || !more)) { load_c(); have_c = true; }
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) {
+    for (int kk = 0; kk < BK / 2; kk++) {
       const int k = 2 * kk + (lane >> 5);
-      const float a0 = As[buf][wm * 64 + (lane & 31)][k], a1 = As[buf][wm * 64 + 32 + (lane & 31)][k];
-      const float b0 = Bs[buf][k][wn * 64 + (lane & 31)], b1 = Bs[buf][k][wn * 64 + 32 + (lane & 31)];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0); acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0); acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[T], b[T];
+#pragma unroll
+      for (int i = 0; i < T; i++) { a[i] = As[buf][wm * 32 * T + i * 32 + (lane & 31)][k]; b[i] = Bs[buf][k][wn * 32 * T + i * 32 + (lane & 31)]; }
+#pragma unroll
+      for (int i = 0; i < T; i++)
+#pragma unroll
+        for (int j = 0; j < T; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) stage(buf ^ 1);      // (the other buffer was last read before the previous barrier)
     __syncthreads();
   }
+  if (!have_c) load_c();      // (K = 0)
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < T; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < T; j++) {
+      const int col = n0 + wn * 32 * T + j * 32 + (lane & 31);
       if (col < N) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (row < M) C[(long long)row * ldc + col] = total[i][j][r] + alpha * acc[i][j][r];
+          const int row = m0 + wm * 32 * T + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M) C[(long long)row * ldc + col] = (seeded ? total[i][j][r] : beta == 0.0f ? 0.0f : beta * cin[i][j][r]) + alpha * acc[i][j][r];
         }
       }
     }
@@ -183,41 +210,49 @@ enum { kOpSet, kOpScale, kOpFloor, kOpCeil, kOpAddConst, kOpCopyRowsFromVec, kOp
        kOpCopyRows, kOpAddRows, kOpMulElements, kOpHeaviside, kOpAddMatDiagVec, kOpAddMatDiagVecT, kOpAddRowRanges, kOpCopyLowerToUpper, kOpAddToDiag, kOpAddVecVecOuter, kOpDivElements, kOpAddDiagVecMat, kOpAddDiagVecMatT };
 struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; int src_rows; };
 
-__global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  if (c >= p.cols) return;
-  for (int r = blockIdx.y * 4 + (threadIdx.x >> 6); r < p.rows; r += gridDim.y * 4) {
-    float *d = p.C + (long long)r * p.ldc + c; float x = 0.0f;
-    switch (p.op) {
+__device__ __forceinline__ float ew_elem(const EwParams &p, int r, int c, float dv) {      // the new value of element (r, c); dv = its old value (loaded only for the operations that read it)
+  float x = 0.0f;
+  switch (p.op) {
       case kOpSet: x = p.a; break;
-      case kOpScale: x = *d * p.a; break;
-      case kOpFloor: x = fmaxf(*d, p.a); break;
-      case kOpCeil: x = fminf(*d, p.a); break;
-      case kOpAddConst: x = *d + p.a; break;
+      case kOpScale: x = dv * p.a; break;
+      case kOpFloor: x = fmaxf(dv, p.a); break;
+      case kOpCeil: x = fminf(dv, p.a); break;
+      case kOpAddConst: x = dv + p.a; break;
       case kOpCopyRowsFromVec: x = p.v[c]; break;
-      case kOpMulColsVec: x = *d * p.v[c]; break;
-      case kOpMulRowsVec: x = *d * p.v[r]; break;
-      case kOpAddVecToRows: x = p.a * p.v[c] + p.b * *d; break;                   // cu-matrix.cc AddVecToRows: beta * this + alpha * row
-      case kOpAddVecToCols: x = p.a * p.v[r] + p.b * *d; break;
+      case kOpMulColsVec: x = dv * p.v[c]; break;
+      case kOpMulRowsVec: x = dv * p.v[r]; break;
+      case kOpAddVecToRows: x = p.a * p.v[c] + p.b * dv; break;                   // cu-matrix.cc AddVecToRows: beta * this + alpha * row
+      case kOpAddVecToCols: x = p.a * p.v[r] + p.b * dv; break;
       case kOpCopy: x = p.S[(long long)r * p.lds + c]; break;
       case kOpCopyT: x = p.S[(long long)c * p.lds + r]; break;
-      case kOpAddMat: x = *d + p.a * p.S[(long long)r * p.lds + c]; break;
-      case kOpAddMatT: x = *d + p.a * p.S[(long long)c * p.lds + r]; break;
+      case kOpAddMat: x = dv + p.a * p.S[(long long)r * p.lds + c]; break;
+      case kOpAddMatT: x = dv + p.a * p.S[(long long)c * p.lds + r]; break;
       case kOpCopyRows: { const int s = p.idx[r]; x = s < 0 ? 0.0f : p.S[(long long)s * p.lds + c]; break; }          // index -1 = zero row
-      case kOpAddRows: { const int s = p.idx[r]; x = s < 0 ? *d : *d + p.a * p.S[(long long)s * p.lds + c]; break; }
-      case kOpMulElements: x = *d * p.S[(long long)r * p.lds + c]; break;
+      case kOpAddRows: { const int s = p.idx[r]; x = s < 0 ? dv : dv + p.a * p.S[(long long)s * p.lds + c]; break; }
+      case kOpMulElements: x = dv * p.S[(long long)r * p.lds + c]; break;
       case kOpHeaviside: x = p.S[(long long)r * p.lds + c] > 0.0f ? 1.0f : 0.0f; break;
-      case kOpAddMatDiagVec: x = p.b * *d + p.a * p.S[(long long)r * p.lds + c] * p.v[c]; break;               // this = beta this + alpha M diag(v)
-      case kOpAddMatDiagVecT: x = p.b * *d + p.a * p.S[(long long)c * p.lds + r] * p.v[c]; break;
-      case kOpCopyLowerToUpper: x = c > r ? p.C[(long long)c * p.ldc + r] : *d; break;                        // (reads only below the diagonal, writes only above it)
-      case kOpAddToDiag: x = r == c ? *d + p.a : *d; break;
-      case kOpAddVecVecOuter: x = *d + p.a * p.v[r] * p.S[c]; break;                                           // this += alpha x y^T
-      case kOpDivElements: x = *d / p.S[(long long)r * p.lds + c]; break;
-      case kOpAddDiagVecMat: x = p.b * *d + p.a * p.v[r] * p.S[(long long)r * p.lds + c]; break;                 // this = beta this + alpha diag(v) M
-      case kOpAddDiagVecMatT: x = p.b * *d + p.a * p.v[r] * p.S[(long long)c * p.lds + r]; break;
-      case kOpAddRowRanges: { const int b0 = p.idx[2 * r], b1 = p.idx[2 * r + 1]; x = *d; for (int k = b0; k < b1; k++) x += p.S[(long long)k * p.lds + c]; break; }      // cu-kernels.cu _add_row_ranges
+      case kOpAddMatDiagVec: x = p.b * dv + p.a * p.S[(long long)r * p.lds + c] * p.v[c]; break;               // this = beta this + alpha M diag(v)
+      case kOpAddMatDiagVecT: x = p.b * dv + p.a * p.S[(long long)c * p.lds + r] * p.v[c]; break;
+      case kOpCopyLowerToUpper: x = c > r ? p.C[(long long)c * p.ldc + r] : dv; break;                        // (reads only below the diagonal, writes only above it)
+      case kOpAddToDiag: x = r == c ? dv + p.a : dv; break;
+      case kOpAddVecVecOuter: x = dv + p.a * p.v[r] * p.S[c]; break;                                           // this += alpha x y^T
+      case kOpDivElements: x = dv / p.S[(long long)r * p.lds + c]; break;
+      case kOpAddDiagVecMat: x = p.b * dv + p.a * p.v[r] * p.S[(long long)r * p.lds + c]; break;                 // this = beta this + alpha diag(v) M
+      case kOpAddDiagVecMatT: x = p.b * dv + p.a * p.v[r] * p.S[(long long)c * p.lds + r]; break;
+      case kOpAddRowRanges: { const int b0 = p.idx[2 * r], b1 = p.idx[2 * r + 1]; x = dv; for (int k = b0; k < b1; k++) x += p.S[(long long)k * p.lds + c]; break; }      // cu-kernels.cu _add_row_ranges
     }
-    *d = x;
+  return x;
+}
+__global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {      // 64 columns x 16 rows per workgroup and step: four rows per thread, their loads issued together
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c >= p.cols) return;
+  const bool reads_d = !(p.op == kOpSet || p.op == kOpCopyRowsFromVec || p.op == kOpCopy || p.op == kOpCopyT || p.op == kOpCopyRows || p.op == kOpHeaviside);
+  for (int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4; r0 < p.rows; r0 += gridDim.y * 16) {
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (r0 + e < p.rows) { const float dv = reads_d ? p.C[(long long)(r0 + e) * p.ldc + c] : 0.0f; x[e] = ew_elem(p, r0 + e, c, dv); }
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (r0 + e < p.rows) p.C[(long long)(r0 + e) * p.ldc + c] = x[e];
   }
 }
 
@@ -247,7 +282,7 @@ __global__ __launch_bounds__(256) void k3_colred_kernel(RedParams p) {      // b
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
   const int r0 = blockIdx.y * p.rows_per_chunk, r1 = min(p.rows, r0 + p.rows_per_chunk);
   double acc = 0.0;
-  if (c < p.cols) for (int r = r0 + w; r < r1; r += 4) { const float m = p.M[(long long)r * p.ldm + c]; acc += p.op == 0 ? (double)m : p.op == 1 ? (double)m * m : (double)m * p.N[(long long)r * p.ldn + c]; }
+  if (c < p.cols) for (int r = r0 + w; r < r1; r += 4) { const float m = p.M[(long long)r * p.ldm + c]; acc += p.op == 0 ? (double)m : p.op == 1 ? (double)m * m : p.op == 5 ? (double)m * p.N[(long long)r * p.ldn] : (double)m * p.N[(long long)r * p.ldn + c]; }      // (op 5: a weight per row -- A^T x)
   part[w][threadIdx.x & 63] = acc;
   __syncthreads();
   if (w == 0 && c < p.cols) {
@@ -256,11 +291,14 @@ __global__ __launch_bounds__(256) void k3_colred_kernel(RedParams p) {      // b
     else p.v[c] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[c]) + p.alpha * (float)s_;
   }
 }
-__global__ void k3_colred_fold_kernel(RedParams p, int chunks) {      // chunks added in ascending order (deterministic)
-  const int c = blockIdx.x * 256 + threadIdx.x; if (c >= p.cols) return;
+__global__ __launch_bounds__(256) void k3_colred_fold_kernel(RedParams p, int chunks) {      // 64 columns per workgroup; wavefront w adds chunks w, w + 4, ... in ascending order, the four sums in wavefront order (deterministic)
+  __shared__ double part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
   double s_ = 0.0;
-  for (int y = 0; y < chunks; y++) s_ += p.part[(long long)y * p.cols + c];
-  p.v[c] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[c]) + p.alpha * (float)s_;
+  if (c < p.cols) for (int y = w; y < chunks; y += 4) s_ += p.part[(long long)y * p.cols + c];
+  part[w][threadIdx.x & 63] = s_;
+  __syncthreads();
+  if (w == 0 && c < p.cols) { s_ = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]; p.v[c] = (p.beta == 0.0f ? 0.0f : p.beta * p.v[c]) + p.alpha * (float)s_; }
 }
 __global__ __launch_bounds__(64) void k3_rowred_kernel(RedParams p) {      // one wavefront per row
   const int r = blockIdx.x, lane = threadIdx.x; double acc = 0.0;
@@ -272,25 +310,58 @@ __global__ __launch_bounds__(64) void k3_rowred_kernel(RedParams p) {      // on
 
 // Scalar reductions (TraceMatMat, VecVec, Trace, Sum, Max, Min of cudamatrix/cu-matrix.h, cu-vector.h): per-workgroup partial results in double, folded on the host in
 // workgroup order (deterministic).  op 0: sum A(i,j) B(i,j); 1: sum A(i,j) B(j,i); 2: sum A(i,i); 3: sum A(i,j); 4: max; 5: min.
-struct ScalParams { int op, rows, cols; const float *A; long long lda; const float *B; long long ldb; double *part; };
+struct ScalParams { int op, rows, cols; const float *A; long long lda; const float *B; long long ldb; double *part; unsigned *ticket; double *h_out; unsigned long long *h_seq; unsigned long long seq; };
 __global__ __launch_bounds__(256) void k3_scalar_reduce_kernel(ScalParams p) {
   __shared__ double sh[256];
   const long long n = p.op == 2 ? (long long)p.rows : (long long)p.rows * p.cols;
   double acc = p.op == 4 ? -INFINITY : p.op == 5 ? INFINITY : 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const int r = p.op == 2 ? (int)i : (int)(i / p.cols), c = p.op == 2 ? (int)i : (int)(i % p.cols);
-    const float a = p.A[(long long)r * p.lda + c];
-    switch (p.op) {
-      case 0: acc += (double)a * p.B[(long long)r * p.ldb + c]; break;
-      case 1: acc += (double)a * p.B[(long long)c * p.ldb + r]; break;
-      case 2: case 3: acc += a; break;
-      case 4: acc = fmax(acc, (double)a); break;
-      case 5: acc = fmin(acc, (double)a); break;
+  if (p.op == 2) { for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += p.A[i * p.lda + i]; }
+  else {
+    // element i = (r, c) with r, c advanced incrementally (a 64-bit division per element was most of this kernel's time)
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    int r = (int)(i0 / p.cols), c = (int)(i0 % p.cols); const int dr = (int)(step / p.cols), dc = (int)(step % p.cols);
+    for (long long i = i0; i < n; i += step) {
+      const float a = p.A[(long long)r * p.lda + c];
+      switch (p.op) {
+        case 0: acc += (double)a * p.B[(long long)r * p.ldb + c]; break;
+        case 1: acc += (double)a * p.B[(long long)c * p.ldb + r]; break;
+        case 3: acc += a; break;
+        case 4: acc = fmax(acc, (double)a); break;
+        case 5: acc = fmin(acc, (double)a); break;
+      }
+      r += dr; c += dc; if (c >= p.cols) { c -= p.cols; r++; }
     }
   }
-  sh[threadIdx.x] = acc; __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { const double x = sh[threadIdx.x], y = sh[threadIdx.x + o]; sh[threadIdx.x] = p.op == 4 ? fmax(x, y) : p.op == 5 ? fmin(x, y) : x + y; } __syncthreads(); }
-  if (threadIdx.x == 0) p.part[blockIdx.x] = sh[0];
+  auto fold = [&](double v) {      // the workgroup's 256 values by a fixed tree (deterministic)
+    sh[threadIdx.x] = v; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { const double x = sh[threadIdx.x], y = sh[threadIdx.x + o]; sh[threadIdx.x] = p.op == 4 ? fmax(x, y) : p.op == 5 ? fmin(x, y) : x + y; } __syncthreads(); }
+    return sh[0];
+  };
+  const double mine = fold(acc);
+  // the last workgroup to finish folds the partial results (thread t: partials t, t + 256, ... in ascending order, then the same tree) and hands the scalar to the host through
+  // page-locked memory, followed by this call's sequence number: the host polls that word instead of waiting for the stream (an interrupt-driven wait costs ~20 us per reduction,
+  // and natural-gradient training makes ~230 of them per minibatch)
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    // No fences: an agent-scope release writes the XCD's L2 back (~20 us per call, measured).  The partial result goes out as a returning agent-scope atomic (complete when it
+    // returns), then the tickets -- two levels, groups of 32 workgroups, so that no word takes more than 32 serialised atomics.
+    (void)__hip_atomic_exchange(&p.part[blockIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned g = blockIdx.x >> 5, ng = (gridDim.x + 31) >> 5, gsize = min(32u, gridDim.x - g * 32u);
+    last = __hip_atomic_fetch_add(&p.ticket[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1 && __hip_atomic_fetch_add(&p.ticket[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  double v = p.op == 4 ? -INFINITY : p.op == 5 ? INFINITY : 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) { const double y = __hip_atomic_load(&p.part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = p.op == 4 ? fmax(v, y) : p.op == 5 ? fmin(v, y) : v + y; }
+  const double r = fold(v);
+  if (threadIdx.x == 0) {
+    for (int g = 0; g <= 32; g++) __hip_atomic_store(&p.ticket[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // result, check word (result bits ^ sequence number), sequence number: relaxed system-scope stores; the host accepts the result when all three agree
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(r);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p.h_out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p.h_seq + 1, bits ^ (p.seq * 0x9E3779B97F4A7C15ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p.h_seq, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // SoftMaxPerRow / LogSoftMaxPerRow and their derivatives (cu-matrix.h:328-334, :403-411): one wavefront per row.  op 0: dst = softmax(src); 1: dst = log-softmax(src);
@@ -318,7 +389,7 @@ __global__ __launch_bounds__(256) void k3_row_softmax_kernel(int op, float *D, l
 
 int launch_ew(const EwParams &p, void *stream) {
   if (p.rows <= 0 || p.cols <= 0) return K3_OK;
-  dim3 grid((p.cols + 63) / 64, (unsigned)std::min(65535, (p.rows + 3) / 4));
+  dim3 grid((p.cols + 63) / 64, (unsigned)std::min(65535, (p.rows + 15) / 16));
   hipLaunchKernelGGL(k3_ew_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
@@ -345,39 +416,86 @@ int workspace(hipStream_t st, size_t bytes, void **out) {
   }
   *out = w.p; return K3_OK;
 }
+int col_reduce(RedParams p, hipStream_t st) {      // ops 0 - 2 and 5 of k3_colred_kernel
+  if (p.cols <= 0) return K3_OK;
+  // rows split into chunks so that the launch fills the chip (a [9152 x 768] sum was 12 workgroups walking 9152 rows each); partials in double, folded in chunk order
+  const int xb = (p.cols + 63) / 64; int chunks = std::max(1, std::min(64, std::min((p.rows + 63) / 64, (1024 + xb - 1) / xb)));
+  if (chunks > 1) {
+    p.rows_per_chunk = (p.rows + chunks - 1) / chunks; chunks = (p.rows + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    void *wsv = nullptr; { const int rc = workspace(st, (size_t)chunks * p.cols * sizeof(double), &wsv); if (rc) return rc; }
+    p.part = static_cast<double *>(wsv);
+    hipLaunchKernelGGL(k3_colred_kernel, dim3(xb, chunks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k3_colred_fold_kernel, dim3(xb), dim3(256), 0, st, p, chunks);
+  } else { p.rows_per_chunk = p.rows; hipLaunchKernelGGL(k3_colred_kernel, dim3(xb, 1), dim3(256), 0, st, p); }
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
 std::atomic<long long> g_gemm_flops{0};
-void launch_gemm(int ta, int tb, bool fast, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const float *A, long long lda, const float *B, long long ldb, float beta, float *C, long long ldc, float *W, int Kc) {
-  if (!fast) { hipLaunchKernelGGL(k3_gemm_generic_kernel, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, ta, B, ldb, tb, beta, C, ldc, W, Kc); return; }
-  if (ta) { if (tb) hipLaunchKernelGGL((k3_gemm_tile128_kernel<1, 1>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc); else hipLaunchKernelGGL((k3_gemm_tile128_kernel<1, 0>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc); }
-  else { if (tb) hipLaunchKernelGGL((k3_gemm_tile128_kernel<0, 1>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc); else hipLaunchKernelGGL((k3_gemm_tile128_kernel<0, 0>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc); }
+template <int T, int BK> void launch_tile(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const float *A, long long lda, const float *B, long long ldb, float beta, float *C, long long ldc, float *W, int Kc, int kblk) {
+  if (ta) { if (tb) hipLaunchKernelGGL((k3_gemm_tile_kernel<T, 1, 1, BK>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc, kblk); else hipLaunchKernelGGL((k3_gemm_tile_kernel<T, 1, 0, BK>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc, kblk); }
+  else { if (tb) hipLaunchKernelGGL((k3_gemm_tile_kernel<T, 0, 1, BK>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc, kblk); else hipLaunchKernelGGL((k3_gemm_tile_kernel<T, 0, 0, BK>), grid, dim3(256), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc, kblk); }
+}
+// T: 0 = the generic kernel (any alignment), 1 / 2 = the 64 / 128 tile kernel
+void launch_gemm(int ta, int tb, int T, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const float *A, long long lda, const float *B, long long ldb, float beta, float *C, long long ldc, float *W, int Kc, int kblk) {
+  if (T == 0) { hipLaunchKernelGGL(k3_gemm_generic_kernel, grid, dim3(256), 0, st, M, N, K, alpha, A, lda, ta, B, ldb, tb, beta, C, ldc, W, Kc); return; }
+  static const int bk = [] { const char *e = getenv("K3_GEMM_BK"); return e ? atoi(e) : 32; }();      // (developer aid: the 64-tile kernel's k-tile)
+  if (T == 2) launch_tile<2, 16>(ta, tb, grid, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc, kblk);
+  else if (bk == 16) launch_tile<1, 16>(ta, tb, grid, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc, kblk);
+  else if (bk == 64) launch_tile<1, 64>(ta, tb, grid, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc, kblk);
+  else launch_tile<1, 32>(ta, tb, grid, st, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, W, Kc, kblk);
 }
 }  // namespace
 
 extern "C" int64_t k3_mat_gemm_flops(int32_t reset) { return reset ? g_gemm_flops.exchange(0) : g_gemm_flops.load(); }      // 2 M N K summed over the k3_mat_add_mat_mat calls of this process
 
+static int add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta, float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream);
 extern "C" int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta,
                                   float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream) {
+  static const int timed = [] { const char *e = getenv("K3_GEMM_TRACE"); return e && atoi(e) >= 2 ? 1 : 0; }();
+  if (!timed) return add_mat_mat(alpha, d_A, lda, trans_a, d_B, ldb, trans_b, beta, d_C, ldc, M, N, K, stream);
+  // developer aid (K3_GEMM_TRACE=2): every product alone on the device, its shape and its time
+  (void)hipDeviceSynchronize(); const auto t0 = std::chrono::steady_clock::now();
+  const int rc = add_mat_mat(alpha, d_A, lda, trans_a, d_B, ldb, trans_b, beta, d_C, ldc, M, N, K, stream);
+  (void)hipDeviceSynchronize(); const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  fprintf(stderr, "k3 gemm M %d N %d K %d ta %d tb %d lda %lld ldb %lld beta %g us %.1f\n", M, N, K, trans_a ? 1 : 0, trans_b ? 1 : 0, (long long)lda, (long long)ldb, (double)beta, us);
+  return rc;
+}
+static int add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta, float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream) {
   K3_REQUIRE(d_A && d_B && d_C && M >= 0 && N >= 0 && K >= 0 && ldc >= N, "k3_mat_add_mat_mat: bad argument");
   K3_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N), "k3_mat_add_mat_mat: leading dimension smaller than the row length");
   if (M == 0 || N == 0) return K3_OK;
   g_gemm_flops += 2ll * M * N * K;
-  // the 128 x 128 tile kernel wants dwordx4 loads: aligned operands and enough output to fill a tile grid (small products stay on the 64 x 64 generic kernel)
-  const bool fast = ((reinterpret_cast<uintptr_t>(d_A) | reinterpret_cast<uintptr_t>(d_B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 && K >= 16 && ((long long)M * N >= 128 * 128 || K >= 1024) && !getenv("K3_GEMM_GENERIC");      // (small outputs with a long K -- the preconditioner's Gram products -- fill the chip through split-K)
-  const int T = fast ? 128 : 64, ta = trans_a ? 1 : 0, tb = trans_b ? 1 : 0;
-  if (!fast && getenv("K3_GEMM_TRACE")) fprintf(stderr, "k3 generic gemm M %d N %d K %d ta %d tb %d lda %lld ldb %lld A&15 %d B&15 %d\n", M, N, K, ta, tb, (long long)lda, (long long)ldb, (int)(reinterpret_cast<uintptr_t>(d_A) & 15), (int)(reinterpret_cast<uintptr_t>(d_B) & 15));      // developer aid: which products miss the tile kernel
-  const long long tiles = (long long)((N + T - 1) / T) * ((M + T - 1) / T);
+  const int ta = trans_a ? 1 : 0, tb = trans_b ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
-  if (tiles < (fast ? 192 : 384) && K >= (fast ? 768 : 3072)) {      // (planes are whole 384-wide accumulation blocks added in ascending order: the same sums as without the split)      // few output tiles, long K (a layer's weight gradient over a minibatch): split K so that the chip is filled; planes reduced in a fixed order
-    int S = (int)std::min<long long>(fast ? 64 : 16, std::max<long long>(2, (fast ? 512 : 1024) / tiles)); int Kc = ((K + S - 1) / S + 383) / 384 * 384; S = (K + Kc - 1) / Kc;
+  // a product with one output column over a transposed A (the bias gradient y = A^T x of a minibatch) is a weighted column sum, not a tile problem
+  if (N == 1 && ta && ldc == 1 && M >= 64 && !getenv("K3_GEMM_GENERIC")) return col_reduce(RedParams{5, K, M, d_A, (long long)lda, d_B, tb ? 1ll : (long long)ldb, d_C, alpha, beta, nullptr, K}, st);
+  // the tile kernels want dwordx4 loads: aligned operands.  Everything else (and K < 16) stays on the generic kernel.
+  const bool aligned = ((reinterpret_cast<uintptr_t>(d_A) | reinterpret_cast<uintptr_t>(d_B)) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 && K >= 16 && !getenv("K3_GEMM_GENERIC");
+  const long long tiles128 = (long long)((N + 127) / 128) * ((M + 127) / 128), tiles64 = (long long)((N + 63) / 64) * ((M + 63) / 64);
+  // 128-tiles when they fill the chip by themselves (or with the coarse split of a long K: a layer's weight gradient), else 64-tiles: four times the workgroups, and K split
+  // in steps of 64 until there are two workgroups per CU (a minibatch of 64 sequences is 4 - 14 k rows: [4736 x 96 x 768] is 37 big tiles)
+  // Products that accumulate into C with A as it lies (beta != 0: every forward product and input derivative of the network) keep the reference-like order: blocks of 384,
+  // K split only there.  The others (beta == 0 or A transposed: weight gradients, the preconditioner's factors) split K in steps of 64 until the chip is full.
+  const bool fine = beta == 0.0f || ta;
+  const int T = !aligned ? 0 : (tiles128 >= 224 || (tiles128 >= 24 && K >= 3072)) ? 2 : 1, TS = T == 2 ? 128 : 64, kblk = (T == 1 && fine) ? 64 : 384;
+  if (T == 0 && getenv("K3_GEMM_TRACE")) fprintf(stderr, "k3 generic gemm M %d N %d K %d ta %d tb %d lda %lld ldb %lld A&15 %d B&15 %d\n", M, N, K, ta, tb, (long long)lda, (long long)ldb, (int)(reinterpret_cast<uintptr_t>(d_A) & 15), (int)(reinterpret_cast<uintptr_t>(d_B) & 15));      // developer aid: which products miss the tile kernels
+  const long long tiles = T == 2 ? tiles128 : tiles64;
+  const dim3 grid((N + TS - 1) / TS, (M + TS - 1) / TS);
+  int S = 1, Kc = 0;
+  if (T == 2) { if (tiles < 192 && K >= 768) { S = (int)std::min<long long>(64, std::max<long long>(2, 512 / tiles)); Kc = ((K + S - 1) / S + 383) / 384 * 384; } }
+  else if (T == 1) { if (tiles < 384 && K >= 2 * kblk) { S = (int)std::min<long long>(64, (512 + tiles - 1) / tiles); Kc = ((K + S - 1) / S + kblk - 1) / kblk * kblk; } }
+  else if (tiles < 384 && K >= (fine ? 512 : 3072)) { S = (int)std::min<long long>(16, std::max<long long>(2, 1024 / tiles)); Kc = fine ? ((K + S - 1) / S + 127) / 128 * 128 : ((K + S - 1) / S + 383) / 384 * 384; }
+  if (S > 1) S = (K + Kc - 1) / Kc;
+  if (S > 1) {      // planes are whole accumulation blocks, reduced in ascending order: deterministic, and for the tile kernels the same sums as without the split
     void *wsv = nullptr; { const int rc = workspace(st, (size_t)S * M * N * sizeof(float), &wsv); if (rc) return rc; }
     float *ws = static_cast<float *>(wsv);
-    launch_gemm(ta, tb, fast, dim3((N + T - 1) / T, (M + T - 1) / T, S), st, M, N, K, alpha, d_A, (long long)lda, d_B, (long long)ldb, beta, d_C, (long long)ldc, ws, Kc);
+    launch_gemm(ta, tb, T, dim3(grid.x, grid.y, S), st, M, N, K, alpha, d_A, (long long)lda, d_B, (long long)ldb, beta, d_C, (long long)ldc, ws, Kc, kblk);
     const long long MN = (long long)M * N;
     hipLaunchKernelGGL(k3_gemm_splitk_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, ws, S, MN, N, alpha, beta, d_C, ldc);
     K3_HIP_CHECK(hipGetLastError());
     return K3_OK;
   }
-  launch_gemm(ta, tb, fast, dim3((N + T - 1) / T, (M + T - 1) / T), st, M, N, K, alpha, d_A, (long long)lda, d_B, (long long)ldb, beta, d_C, (long long)ldc, (float *)nullptr, 0);
+  launch_gemm(ta, tb, T, grid, st, M, N, K, alpha, d_A, (long long)lda, d_B, (long long)ldb, beta, d_C, (long long)ldc, (float *)nullptr, 0, kblk);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }
@@ -430,19 +548,35 @@ extern "C" int k3_mat_reduce_scalar(int32_t op, const float *d_A, int64_t lda, c
   if (rows == 0 || cols == 0) return K3_OK;
   K3_REQUIRE(d_A && lda >= cols && (op > 1 || (d_B && ldb >= (op == 0 ? cols : rows))) && (op != 2 || rows == cols), "k3_mat_reduce_scalar: bad matrix");
   constexpr int kMaxWgs = 1024;
-  static thread_local double *d_part = nullptr; static thread_local int d_part_dev = -1;      // per host thread (the call synchronises on its stream before returning) and per device
+  // per host thread (the call does not return before its result is there): partial results + the ticket on the device, result + sequence word in page-locked host memory
+  struct Scratch { double *d_part = nullptr; unsigned *d_ticket = nullptr; double *h = nullptr; int dev = -1; unsigned long long seq = 0; };
+  static thread_local Scratch sc;
   { int dev = 0; K3_HIP_CHECK(hipGetDevice(&dev));
-    if (!d_part || dev != d_part_dev) { K3_HIP_CHECK(hipMalloc((void **)&d_part, kMaxWgs * sizeof(double))); d_part_dev = dev; } }      // (a thread that moves to another device leaves 8 KB behind on the old one)
+    if (sc.dev != dev) {      // (a thread that moves to another device leaves a few KB behind on the old one)
+      K3_HIP_CHECK(hipMalloc((void **)&sc.d_part, kMaxWgs * sizeof(double) + 256)); sc.d_ticket = reinterpret_cast<unsigned *>(sc.d_part + kMaxWgs); K3_HIP_CHECK(hipMemset(sc.d_ticket, 0, 256));
+      K3_HIP_CHECK(hipHostMalloc((void **)&sc.h, 128, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent)); memset(sc.h, 0, 128); sc.dev = dev; sc.seq = 0;
+    } }
   const long long n = op == 2 ? (long long)rows : (long long)rows * cols;
   const int wgs = (int)std::min<long long>(kMaxWgs, (n + 255) / 256);
-  ScalParams p{op, rows, cols, d_A, lda, d_B, ldb, d_part};
+  unsigned long long *h_seq = reinterpret_cast<unsigned long long *>(sc.h + 8); const unsigned long long seq = ++sc.seq;
+  ScalParams p{op, rows, cols, d_A, lda, d_B, ldb, sc.d_part, sc.d_ticket, sc.h, h_seq, seq};
   hipLaunchKernelGGL(k3_scalar_reduce_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)st, p);
   K3_HIP_CHECK(hipGetLastError());
-  double h[kMaxWgs];
-  K3_HIP_CHECK(hipMemcpyAsync(h, d_part, wgs * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)st)); K3_HIP_CHECK(hipStreamSynchronize((hipStream_t)st));
-  double r = h[0];
-  for (int i = 1; i < wgs; i++) r = op == 4 ? std::max(r, h[i]) : op == 5 ? std::min(r, h[i]) : r + h[i];
-  *h_result = r;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long long bits = 0;
+  auto arrived = [&]() {
+    if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) return false;
+    bits = __atomic_load_n(reinterpret_cast<unsigned long long *>(sc.h), __ATOMIC_ACQUIRE);
+    return __atomic_load_n(h_seq + 1, __ATOMIC_ACQUIRE) == (bits ^ (seq * 0x9E3779B97F4A7C15ull));
+  };
+  for (unsigned spins = 1; !arrived(); spins++) {
+    if ((spins & 4095) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {      // a long queue in front of the kernel: wait the ordinary way
+      K3_HIP_CHECK(hipStreamSynchronize((hipStream_t)st));
+      K3_REQUIRE(arrived(), "k3_mat_reduce_scalar: the reduction kernel finished without delivering its result");
+      break;
+    }
+  }
+  memcpy(h_result, &bits, sizeof(double));
   return K3_OK;
 }
 extern "C" int k3_mat_softmax_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_a, int64_t lda, const float *d_b, int64_t ldb, int32_t rows, int32_t cols, void *st) {
@@ -455,20 +589,8 @@ extern "C" int k3_mat_softmax_rows(int32_t op, float *d_dst, int64_t ldd, const 
 extern "C" int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *st) {
   K3_REQUIRE(d_M && d_v && rows >= 0 && cols >= 0 && ldm >= cols && op >= 0 && op <= 4 && (op != 2 || (d_N && ldn >= cols)), "k3_vec_col_reduce: bad argument");
   RedParams p{op, rows, cols, d_M, ldm, d_N, ldn, d_v, alpha, beta, nullptr, rows};
-  if (op <= 2) {
-    if (cols > 0) {
-      // rows split into chunks so that the launch fills the chip (a [9152 x 768] sum was 12 workgroups walking 9152 rows each); partials in double, folded in chunk order
-      const int xb = (cols + 63) / 64; int chunks = std::max(1, std::min(256, std::min((rows + 63) / 64, (1024 + xb - 1) / xb)));
-      if (chunks > 1) {
-        p.rows_per_chunk = (rows + chunks - 1) / chunks; chunks = (rows + p.rows_per_chunk - 1) / p.rows_per_chunk;
-        void *wsv = nullptr; { const int rc = workspace((hipStream_t)st, (size_t)chunks * cols * sizeof(double), &wsv); if (rc) return rc; }
-        p.part = static_cast<double *>(wsv);
-        hipLaunchKernelGGL(k3_colred_kernel, dim3(xb, chunks), dim3(256), 0, (hipStream_t)st, p);
-        hipLaunchKernelGGL(k3_colred_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)st, p, chunks);
-      } else hipLaunchKernelGGL(k3_colred_kernel, dim3(xb, 1), dim3(256), 0, (hipStream_t)st, p);
-    }
-  }
-  else if (rows > 0) hipLaunchKernelGGL(k3_rowred_kernel, dim3(rows), dim3(64), 0, (hipStream_t)st, p);
+  if (op <= 2) return col_reduce(p, (hipStream_t)st);
+  if (rows > 0) hipLaunchKernelGGL(k3_rowred_kernel, dim3(rows), dim3(64), 0, (hipStream_t)st, p);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }

@@ -38,7 +38,7 @@ def test_elementwise_and_row_ops_match_numpy():
 def test_add_mat_mat_matches_numpy(ta, tb):
     from kaldi_amd.cumatrix import CuMatrix
     rng = np.random.default_rng(1)
-    for M_, N_, K_ in [(1, 1, 1), (64, 64, 16), (65, 63, 17), (130, 96, 192), (300, 6024 // 8, 192), (96, 200, 5000), (33, 70, 3072)]:      # the last two: long K, few tiles -> the split-K path
+    for M_, N_, K_ in [(1, 1, 1), (64, 64, 16), (65, 63, 17), (130, 96, 192), (300, 6024 // 8, 192), (96, 200, 5000), (33, 70, 3072), (4736, 96, 768), (160, 80, 768), (1000, 1536, 20), (20, 196, 4700), (4700, 20, 196)]:      # long K and few tiles -> the split-K paths; the shapes of a training minibatch (64-tiles, K split in steps of 64)
         tol_a = 2e-4 * max(1.0, (K_ / 192.0) ** 0.5)
         A = CuMatrix(_mat(rng, *((K_, M_) if ta else (M_, K_)), 3)); B = CuMatrix(_mat(rng, *((N_, K_) if tb else (K_, N_)), 1)); C = CuMatrix(_mat(rng, M_, N_, 2))
         c0 = C.t.cpu().numpy().copy(); a = A.t.cpu().numpy().T if ta else A.t.cpu().numpy(); b = B.t.cpu().numpy().T if tb else B.t.cpu().numpy()
