@@ -243,6 +243,61 @@ __device__ __forceinline__ float ew_elem(const EwParams &p, int r, int c, float 
     }
   return x;
 }
+// The same operations four columns at a time (dwordx4) for the layouts the network's big matrices have: cols, strides and pointers multiples of 4 floats / 16 bytes, no transposed
+// source.  A minibatch's activations are 4 - 14 k rows x 768: ~475 of these per training iteration, each a 30 - 90 MB stream.
+__device__ __forceinline__ bool ew_vec4_op(int op) {
+  return op == kOpSet || op == kOpScale || op == kOpFloor || op == kOpCeil || op == kOpAddConst || op == kOpCopyRowsFromVec || op == kOpMulColsVec || op == kOpMulRowsVec || op == kOpAddVecToRows ||
+         op == kOpAddVecToCols || op == kOpCopy || op == kOpAddMat || op == kOpCopyRows || op == kOpAddRows || op == kOpMulElements || op == kOpHeaviside || op == kOpAddMatDiagVec || op == kOpDivElements ||
+         op == kOpAddDiagVecMat;
+}
+__device__ __forceinline__ float ew_f(int op, float d, float s_, float v, float a, float b) {      // element value from the old value d, the source element s_, the vector element v (column- or row-indexed by op)
+  switch (op) {
+    case kOpSet: return a;
+    case kOpScale: return d * a;
+    case kOpFloor: return fmaxf(d, a);
+    case kOpCeil: return fminf(d, a);
+    case kOpAddConst: return d + a;
+    case kOpCopyRowsFromVec: return v;
+    case kOpMulColsVec: case kOpMulRowsVec: return d * v;
+    case kOpAddVecToRows: case kOpAddVecToCols: return a * v + b * d;
+    case kOpCopy: case kOpCopyRows: return s_;
+    case kOpAddMat: case kOpAddRows: return d + a * s_;
+    case kOpMulElements: return d * s_;
+    case kOpHeaviside: return s_ > 0.0f ? 1.0f : 0.0f;
+    case kOpAddMatDiagVec: return b * d + a * s_ * v;
+    case kOpDivElements: return d / s_;
+    case kOpAddDiagVecMat: return b * d + a * v * s_;
+  }
+  return d;
+}
+__global__ __launch_bounds__(256) void k3_ew4_kernel(EwParams p) {      // 256 columns x 8 rows per workgroup and step; two rows per thread
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  if (c >= p.cols) return;
+  const int op = p.op;
+  const bool reads_d = !(op == kOpSet || op == kOpCopyRowsFromVec || op == kOpCopy || op == kOpCopyRows || op == kOpHeaviside);
+  const bool has_s = op == kOpCopy || op == kOpAddMat || op == kOpCopyRows || op == kOpAddRows || op == kOpMulElements || op == kOpHeaviside || op == kOpAddMatDiagVec || op == kOpDivElements || op == kOpAddDiagVecMat;
+  const bool col_v = op == kOpCopyRowsFromVec || op == kOpMulColsVec || op == kOpAddVecToRows || op == kOpAddMatDiagVec, row_v = op == kOpMulRowsVec || op == kOpAddVecToCols || op == kOpAddDiagVecMat;
+  const bool indexed = op == kOpCopyRows || op == kOpAddRows;
+  f32x4 vc = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (col_v) vc = *reinterpret_cast<const f32x4 *>(p.v + c);
+  for (int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2; r0 < p.rows; r0 += gridDim.y * 8) {
+    f32x4 x[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int r = r0 + e; if (r >= p.rows) break;
+      f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f}, sv = d;
+      if (reads_d) d = *reinterpret_cast<const f32x4 *>(p.C + (long long)r * p.ldc + c);
+      bool skip = false;
+      if (has_s) { const int sr = indexed ? p.idx[r] : r; if (sr >= 0) sv = *reinterpret_cast<const f32x4 *>(p.S + (long long)sr * p.lds + c); else skip = op == kOpAddRows; }
+      const float vr = row_v ? p.v[r] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[e][k] = skip ? d[k] : ew_f(op, d[k], sv[k], col_v ? vc[k] : vr, p.a, p.b);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) if (r0 + e < p.rows) *reinterpret_cast<f32x4 *>(p.C + (long long)(r0 + e) * p.ldc + c) = x[e];
+  }
+}
 __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {      // 64 columns x 16 rows per workgroup and step: four rows per thread, their loads issued together
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   if (c >= p.cols) return;
@@ -389,6 +444,18 @@ __global__ __launch_bounds__(256) void k3_row_softmax_kernel(int op, float *D, l
 
 int launch_ew(const EwParams &p, void *stream) {
   if (p.rows <= 0 || p.cols <= 0) return K3_OK;
+  static const int traced = [] { const char *e = getenv("K3_GEMM_TRACE"); return e && atoi(e) >= 2 ? 1 : 0; }();
+  if (traced) fprintf(stderr, "k3 ew op %d rows %d cols %d\n", p.op, p.rows, p.cols);      // developer aid
+  auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool has_s = p.op == kOpCopy || p.op == kOpAddMat || p.op == kOpCopyRows || p.op == kOpAddRows || p.op == kOpMulElements || p.op == kOpHeaviside || p.op == kOpAddMatDiagVec || p.op == kOpDivElements || p.op == kOpAddDiagVecMat;
+  const bool col_v = p.op == kOpCopyRowsFromVec || p.op == kOpMulColsVec || p.op == kOpAddVecToRows || p.op == kOpAddMatDiagVec;
+  const bool v4 = (p.op == kOpSet || p.op == kOpScale || p.op == kOpFloor || p.op == kOpCeil || p.op == kOpAddConst || p.op == kOpMulRowsVec || p.op == kOpAddVecToCols || has_s || col_v) &&
+                  p.cols % 4 == 0 && p.cols >= 64 && p.ldc % 4 == 0 && al16(p.C) && (!has_s || (p.lds % 4 == 0 && al16(p.S))) && (!col_v || al16(p.v)) && !getenv("K3_EW_SCALAR");
+  if (v4) {
+    hipLaunchKernelGGL(k3_ew4_kernel, dim3((p.cols + 255) / 256, (unsigned)std::min(65535, (p.rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, p);
+    K3_HIP_CHECK(hipGetLastError());
+    return K3_OK;
+  }
   dim3 grid((p.cols + 63) / 64, (unsigned)std::min(65535, (p.rows + 15) / 16));
   hipLaunchKernelGGL(k3_ew_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   K3_HIP_CHECK(hipGetLastError());

@@ -10,7 +10,7 @@ def _mat(rng, r, c, pad=0):
 def test_elementwise_and_row_ops_match_numpy():
     from kaldi_amd.cumatrix import CuMatrix
     rng = np.random.default_rng(0)
-    for r, c, pad in [(1, 1, 0), (7, 130, 3), (257, 65, 0), (33, 768, 8)]:
+    for r, c, pad in [(1, 1, 0), (7, 130, 3), (257, 65, 0), (33, 768, 8), (70, 256, 0), (19, 64, 4)]:
         t = _mat(rng, r, c, pad); M = CuMatrix(t); ref = t.cpu().numpy().copy()
         v = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).cuda(); w = torch.from_numpy(rng.standard_normal(r).astype(np.float32)).cuda()
         M.Scale(0.5); ref *= np.float32(0.5)
@@ -23,12 +23,14 @@ def test_elementwise_and_row_ops_match_numpy():
         M.Add(0.25); ref = ref + np.float32(0.25)
         A = CuMatrix(_mat(rng, r, c, 5)); M.AddMat(-1.5, A); ref = ref + np.float32(-1.5) * A.t.cpu().numpy()
         At = CuMatrix(_mat(rng, c, r, 2)); M.AddMat(0.3, At, True); ref = ref + np.float32(0.3) * At.t.cpu().numpy().T
+        A4 = CuMatrix(_mat(rng, r, c, 4)); M.AddMat(0.7, A4); ref = ref + np.float32(0.7) * A4.t.cpu().numpy()      # (a source whose stride keeps rows 16-byte aligned: the four-columns-at-a-time kernel)
+        M.DivElements(CuMatrix(A4.t.abs() + 1.0)); ref = ref / (np.abs(A4.t.cpu().numpy()) + np.float32(1.0))
         torch.cuda.synchronize()
         assert np.allclose(t.cpu().numpy(), ref, rtol=1e-5, atol=1e-5), (r, c)
         M.CopyRowsFromVec(v); assert np.array_equal(t.cpu().numpy(), np.tile(v.cpu().numpy(), (r, 1)))
         M.CopyFromMat(At, True); assert np.array_equal(t.cpu().numpy(), At.t.cpu().numpy().T)
         M.SetZero(); assert not t.cpu().numpy().any()
-        src = CuMatrix(_mat(rng, 19, c, 1)); idx = torch.from_numpy(rng.integers(-1, 19, r).astype(np.int32)).cuda(); ih = idx.cpu().numpy()
+        src = CuMatrix(_mat(rng, 19, c, 1 if r % 2 else 4)); idx = torch.from_numpy(rng.integers(-1, 19, r).astype(np.int32)).cuda(); ih = idx.cpu().numpy()
         M.CopyRows(src, idx); want = np.where(ih[:, None] >= 0, src.t.cpu().numpy()[np.maximum(ih, 0)], 0.0); assert np.array_equal(t.cpu().numpy(), want)
         M.AddRows(2.0, src, idx); want = want + np.where(ih[:, None] >= 0, np.float32(2.0) * src.t.cpu().numpy()[np.maximum(ih, 0)], 0.0)
         assert np.allclose(t.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
