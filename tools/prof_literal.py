@@ -39,6 +39,6 @@ for literal in (1, 0):
             fr = max(1, cyc[15]); print("sub-phase cycles/lane/frame:", {n: int(c / fr) for n, c in zip(sub, cyc[:14])})
         elif tot:
             print("phase share %:", {n: round(100.0 * c / tot, 1) for n, c in zip(names, cyc[:12])})
-            fr = max(1, cyc[15]); print("cycles/lane/frame", tot / fr, "replay pops/frame", cyc[12] / fr, "tokens/frame", cyc[13] / fr, "LDS-replay frames frac", cyc[14] / fr)
+            fr = max(1, cyc[15]); print("frames counted (two decodes)", int(cyc[15]), "Gcycles", tot / 1e9, "cycles/lane/frame", tot / fr, "replay pops/frame", cyc[12] / fr, "tokens/frame", cyc[13] / fr, "LDS-replay frames frac", cyc[14] / fr)
             print("replay: LDS mode cycles/pop", (cyc[9] - nl_cyc) / max(1, cyc[12] - nl_pops), "pops", (cyc[12] - nl_pops) / fr, "| other modes cycles/pop", nl_cyc / max(1, nl_pops), "pops/frame", nl_pops / fr, "share of replay", nl_cyc / max(1, cyc[9]))
     del dec

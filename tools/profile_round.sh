@@ -12,6 +12,13 @@ for c in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $B --no-two-pass --steps 1 --warmup 0 > $OUT/bench_pmc_$c.log 2>&1
 done
 cd $ROOT
-timeout 600 python bench.py --steps 5 --warmup 2 > $OUT/bench_line.json 2> $OUT/bench_line.err
+timeout 900 python bench.py --steps 5 --warmup 2 --measure-traffic > $OUT/bench_line.json 2> $OUT/bench_line.err
+# the decoder's frames by path (shipped library) and, when tools/build_variant.sh fp -DK3_FAST_PROF was run, the phases of the LDS-resident path
+python tools/prof_literal.py 512 > $OUT/literal_frames_by_path.txt 2>&1
+[ -f build/libk3hip_fp.so ] && K3HIP_LIB=build/libk3hip_fp.so python tools/prof_fast.py 512 >> $OUT/literal_frames_by_path.txt 2>&1
+# chain training over the adapter: kernel stats of 24 iterations on the benchmark model + the per-iteration times without the profiler
+export K3_TRAIN_BIG=1 RUN_REF=0
+python tools/debug_chain_train.py /tmp/ctb_prof 24 2>&1 | tail -1 > $OUT/chain_train_iterations.txt
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o train -- python $ROOT/tools/debug_chain_train.py /tmp/ctb_prof 24 > /dev/null 2>&1)
 python tools/profile_summary.py $TAG $OUT
 ls -la $OUT

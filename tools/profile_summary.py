@@ -44,4 +44,8 @@ if len(traffic) == 2:
                "fetch_bytes_per_launch": traffic["FETCH_SIZE"], "write_bytes_per_launch": traffic["WRITE_SIZE"], "traffic_bytes_per_launch": traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"],
                "note": "FETCH_SIZE/WRITE_SIZE as reported (KB x 1024); the gfx950 x2 correction for wide coalesced loads does not apply to the decoder's narrow random accesses; uncalibrated for this pattern"},
               open(os.path.join(dst, f"hbm_traffic_{tag[:3]}.json"), "w"), indent=1)
+ts = find("train", "*kernel_stats.csv")
+if ts: open(os.path.join(dst, f"{tag}_chain_train_kernel_stats.csv"), "w").write("# rocprofv3 --kernel-trace --stats of kaldi_amd/adapter/_build/nnet3-chain-train, 24 iterations, benchmark model, 64 sequences x 50 frames (tools/debug_chain_train.py, K3_TRAIN_BIG=1); iteration times without the profiler: " + (open(os.path.join(src, "chain_train_iterations.txt")).read().strip() if os.path.exists(os.path.join(src, "chain_train_iterations.txt")) else "") + "\n" + open(ts).read())
+fp = os.path.join(src, "literal_frames_by_path.txt")
+if os.path.exists(fp): open(os.path.join(dst, f"{tag}_literal_frames_by_path.txt"), "w").write("".join(l for l in open(fp) if "amdgpu.ids" not in l))
 print("summaries in", dst, os.listdir(dst))
