@@ -2,6 +2,8 @@
 // (cudadecoder/cuda-fst.h:62-149, cuda-decoder.h:224-345) and compiled against include/k3_cuda_decoder.h + the reference's lattice types.
 // Same file protocol as oracle/ref_tools/ref_lattice_decoder.cc (the reference's CPU LatticeFasterDecoder), so that the test can compare the
 // two outputs directly:   cuda-decoder-example <in.bin> <out.bin> [frames-per-call]
+#include <tuple>
+#include <algorithm>
 #include <hip/hip_runtime_api.h>
 #include <cstdio>
 #include <iostream>
@@ -54,12 +56,30 @@ int main(int argc, char **argv) {
     float *d_ll = NULL;
     if (hipMalloc((void **)&d_ll, sizeof(float) * ll.size()) != hipSuccess || hipMemcpy(d_ll, ll.data(), sizeof(float) * ll.size(), hipMemcpyHostToDevice) != hipSuccess) { std::cerr << "hip alloc/copy failed\n"; return 3; }
     const int32 step = argc > 3 ? atoi(argv[3]) : 1;
-    std::vector<ChannelId> channels = {1};                               // decode on channel 1; channel 0 stays idle
-    decoder.InitDecoding(channels);
+    std::vector<ChannelId> channels = {1};
+    // two channels share the ONE lane (nlanes = 1 < nchannels = 2, cuda-decoder.h:224-229): the same utterance is decoded on both, their AdvanceDecoding calls alternating --
+    // every call carries a single (channel, frame pointer) pair; a channel's state stays resident between its calls
+    decoder.InitDecoding(std::vector<ChannelId>{0, 1});
     for (int32 t = 0; t < T; t += step) {
       const int32 n = std::min(step, T - t);
-      std::vector<std::pair<ChannelId, const BaseFloat *>> lanes = {{1, d_ll + (size_t)t * P}};
-      if (n == 1) decoder.AdvanceDecoding(lanes); else decoder.AdvanceDecoding(lanes, n, P);
+      for (ChannelId ch : {1, 0}) {
+        std::vector<std::pair<ChannelId, const BaseFloat *>> lanes = {{ch, d_ll + (size_t)t * P}};
+        if (n == 1) decoder.AdvanceDecoding(lanes); else decoder.AdvanceDecoding(lanes, n, P);
+      }
+    }
+    {
+      Lattice l0, l1; std::vector<Lattice *> o0 = {&l0}, o1 = {&l1};
+      decoder.GetRawLattice(std::vector<ChannelId>{0}, o0, true); decoder.GetRawLattice(std::vector<ChannelId>{1}, o1, true);
+      // (state numbers and arc order follow the order tokens / links were allocated in, which without literal_order depends on timing: compare the arcs as a multiset of
+      //  (ilabel, olabel, graph cost, acoustic cost) and the final costs as a multiset; channel 1's lattice is held to the reference decoder's arc by arc by the calling test)
+      typedef std::tuple<int32, int32, float, float> ArcKey;
+      auto arcs_of = [](const Lattice &l) { std::vector<ArcKey> v; for (int32 st = 0; st < l.NumStates(); st++) for (fst::ArcIterator<Lattice> it(l, st); !it.Done(); it.Next()) { const LatticeArc &x = it.Value(); v.push_back(ArcKey(x.ilabel, x.olabel, x.weight.Value1(), x.weight.Value2())); } std::sort(v.begin(), v.end()); return v; };
+      auto finals_of = [](const Lattice &l) { std::vector<float> v; for (int32 st = 0; st < l.NumStates(); st++) v.push_back(l.Final(st).Value1()); std::sort(v.begin(), v.end()); return v; };
+      const bool same = l0.NumStates() == l1.NumStates() && decoder.NumFramesDecoded(0) == decoder.NumFramesDecoded(1) && arcs_of(l0) == arcs_of(l1) && finals_of(l0) == finals_of(l1);
+      if (!same) { int64_t a0 = 0, a1 = 0; for (int32 st = 0; st < l0.NumStates(); st++) a0 += l0.NumArcs(st); for (int32 st = 0; st < l1.NumStates(); st++) a1 += l1.NumArcs(st);
+        std::cerr << "channel 0: " << l0.NumStates() << " states " << a0 << " arcs " << decoder.NumFramesDecoded(0) << " frames; channel 1: " << l1.NumStates() << " states " << a1 << " arcs " << decoder.NumFramesDecoded(1) << " frames\n"; }
+      std::cerr << "two channels interleaved on one lane: lattices " << (same ? "identical" : "DIFFER") << "\n";
+      if (!same) return 5;
     }
     PartialHypothesis *ph; decoder.GetPartialHypothesis(1, &ph);
     Lattice best, lat; std::vector<Lattice *> outs = {&best};

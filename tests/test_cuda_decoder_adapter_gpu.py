@@ -23,6 +23,7 @@ def test_cuda_decoder_adapter_equals_the_reference_cpu_decoder(name, step, tmp_p
     r = subprocess.run([EXE, a, b, str(step)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert f"frames decoded {ll.shape[0]}" in r.stderr
+    assert "two channels interleaved on one lane: lattices identical" in r.stderr      # nlanes = 1 < nchannels = 2
     with open(b, "rb") as fh:
         ns, na, start, reached, nframes = np.fromfile(fh, np.int64, 5)
         frame = np.fromfile(fh, np.int32, ns); fg = np.fromfile(fh, np.float32, ns); fa = np.fromfile(fh, np.float32, ns)
