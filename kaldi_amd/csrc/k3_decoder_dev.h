@@ -152,25 +152,59 @@ struct Shared {
   int prof_n; long long prof[16];
 };
 
+// Cross-lane primitives on DPP row shifts / row broadcasts (gfx9: row_shr:n 0x11n, row_bcast:15 0x142, row_bcast:31 0x143, wave_shr:1 0x138): a few cycles per step, where
+// __shfl* compiles to ds_bpermute -- an LDS-crossbar round trip per step and word, on the critical path of every reduction and scan of a frame.  `idn` is what a lane
+// without a source keeps (the operation's identity).  All 64 lanes must be active.
+#define K3_DPP(idn, v, ctrl, rows) __builtin_amdgcn_update_dpp((int)(idn), (int)(v), ctrl, rows, 0xf, false)
+__device__ __forceinline__ int wave_incl_sum_i32(int v) {
+  v += K3_DPP(0, v, 0x111, 0xf); v += K3_DPP(0, v, 0x112, 0xf); v += K3_DPP(0, v, 0x114, 0xf); v += K3_DPP(0, v, 0x118, 0xf);
+  v += K3_DPP(0, v, 0x142, 0xa); v += K3_DPP(0, v, 0x143, 0xc);
+  return v;
+}
+__device__ __forceinline__ unsigned wave_incl_min_u32(unsigned v) {
+  unsigned t;
+  t = (unsigned)K3_DPP(~0u, v, 0x111, 0xf); v = t < v ? t : v; t = (unsigned)K3_DPP(~0u, v, 0x112, 0xf); v = t < v ? t : v;
+  t = (unsigned)K3_DPP(~0u, v, 0x114, 0xf); v = t < v ? t : v; t = (unsigned)K3_DPP(~0u, v, 0x118, 0xf); v = t < v ? t : v;
+  t = (unsigned)K3_DPP(~0u, v, 0x142, 0xa); v = t < v ? t : v; t = (unsigned)K3_DPP(~0u, v, 0x143, 0xc); v = t < v ? t : v;
+  return v;
+}
+__device__ __forceinline__ unsigned wave_shr1_u32(unsigned v, unsigned idn) { return (unsigned)K3_DPP(idn, v, 0x138, 0xf); }      // lane i gets lane i - 1's value, lane 0 gets idn
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; }
-  return v;
+  unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+#define K3_MIN64_STEP(ctrl, rows) { const unsigned th = (unsigned)K3_DPP(~0u, hi, ctrl, rows), tl = (unsigned)K3_DPP(~0u, lo, ctrl, rows); const bool take = th < hi || (th == hi && tl < lo); hi = take ? th : hi; lo = take ? tl : lo; }
+  K3_MIN64_STEP(0x111, 0xf) K3_MIN64_STEP(0x112, 0xf) K3_MIN64_STEP(0x114, 0xf) K3_MIN64_STEP(0x118, 0xf) K3_MIN64_STEP(0x142, 0xa) K3_MIN64_STEP(0x143, 0xc)
+#undef K3_MIN64_STEP
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
 }
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { unsigned t = __shfl_xor(v, o); v = t < v ? t : v; }
-  return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)wave_incl_min_u32(v), 63); }
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_incl_sum_i32(v), 63); }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+#define K3_SUM64_STEP(ctrl, rows) { const unsigned th = (unsigned)K3_DPP(0, (unsigned)(v >> 32), ctrl, rows), tl = (unsigned)K3_DPP(0, (unsigned)v, ctrl, rows); v += ((unsigned long long)th << 32) | tl; }
+  K3_SUM64_STEP(0x111, 0xf) K3_SUM64_STEP(0x112, 0xf) K3_SUM64_STEP(0x114, 0xf) K3_SUM64_STEP(0x118, 0xf) K3_SUM64_STEP(0x142, 0xa) K3_SUM64_STEP(0x143, 0xc)
+#undef K3_SUM64_STEP
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+}
+// Position j0 + lane of a wavefront's arc sequence (lane i owns positions [excl_i, excl_i + deg_i)) -> its owner lane.  The binary search over the scan it replaces was six
+// dependent ds_bpermute round trips per 64 arcs.  Here: the starts that fall into this chunk of 64 positions as a bit set (OR-reduced with DPP), the owner's rank among the
+// lanes with arcs = (owners that start before the chunk) + (starts at or before my position) - 1, and the rank-th set bit of the ballot of those lanes by a popcount descent.
+__device__ __forceinline__ int wave_owner_of(int j0, int deg, int excl, unsigned long long has_arcs) {
+  const int lane = threadIdx.x & 63, s_ = excl - j0; const bool pos = deg > 0;
+  const bool in_chunk = pos && s_ >= 0 && s_ < 64;
+  unsigned lo = in_chunk && s_ < 32 ? 1u << s_ : 0u, hi = in_chunk && s_ >= 32 ? 1u << (s_ - 32) : 0u;
+#define K3_OR_STEP(ctrl, rows) { lo |= (unsigned)K3_DPP(0, lo, ctrl, rows); hi |= (unsigned)K3_DPP(0, hi, ctrl, rows); }
+  K3_OR_STEP(0x111, 0xf) K3_OR_STEP(0x112, 0xf) K3_OR_STEP(0x114, 0xf) K3_OR_STEP(0x118, 0xf) K3_OR_STEP(0x142, 0xa) K3_OR_STEP(0x143, 0xc)
+#undef K3_OR_STEP
+  const unsigned long long starts = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+  const int before = __popcll(__ballot(pos && s_ < 0));
+  int r = before + __popcll(starts & ((2ull << lane) - 1ull)) - 1;      // rank of my owner among the lanes with arcs
+  unsigned w = (unsigned)has_arcs; int base = 0, c = __popc(w);
+  if (r >= c) { r -= c; w = (unsigned)(has_arcs >> 32); base = 32; }
+  c = __popc(w & 0xFFFFu); if (r >= c) { r -= c; w >>= 16; base += 16; }
+  c = __popc(w & 0xFFu); if (r >= c) { r -= c; w >>= 8; base += 8; }
+  c = __popc(w & 0xFu); if (r >= c) { r -= c; w >>= 4; base += 4; }
+  c = __popc(w & 0x3u); if (r >= c) { r -= c; w >>= 2; base += 2; }
+  c = (int)(w & 1u); if (r >= c) base += 1;
+  return base > 63 ? 63 : (base < 0 ? 0 : base);      // (positions beyond the total: any lane; the caller masks them)
 }
 __device__ unsigned long long block_min_u64(unsigned long long v, Shared &sh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -237,11 +271,9 @@ __device__ __forceinline__ void wave_expand(const ArcRec *arcs, int beg, int deg
   incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - deg;
+  const unsigned long long has_arcs = __ballot(deg > 0);
   auto locate = [&](int j, int &arc, int &owner) {
-    int lo = 0, hi = 63;
-#pragma unroll
-    for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; const int v = __shfl(incl, mid); if (v > j) hi = mid; else lo = mid + 1; }
-    lo = lo > 63 ? 63 : lo;
+    const int lo = wave_owner_of(j - lane, deg, excl, has_arcs);
     const int obeg = __shfl(beg, lo), oexcl = __shfl(excl, lo);
     arc = obeg + (j - oexcl); owner = lo;
   };
@@ -356,7 +388,7 @@ __device__ __forceinline__ unsigned block_select_kth(ForKeys &&for_keys, int k, 
       v = v && (key & mask) == prefix;
       const int d = (key >> shift) & 255;
       const unsigned long long mv = __ballot(v);
-      const int d0 = __shfl(d, mv ? __ffsll((long long)mv) - 1 : 0);
+      const int d0 = __builtin_amdgcn_readlane(d, mv ? __ffsll((long long)mv) - 1 : 0);      // (the index is wave-uniform)
       const unsigned long long diff = __ballot(v && d != d0);
       if (mv != 0) {
         if (diff == 0) { if (lane == __ffsll((long long)mv) - 1) k3a_add(&sh.hist[d0], __popcll(mv)); }
@@ -368,8 +400,7 @@ __device__ __forceinline__ unsigned block_select_kth(ForKeys &&for_keys, int k, 
       const int c0 = sh.hist[4 * lane], c1 = sh.hist[4 * lane + 1], c2 = sh.hist[4 * lane + 2], c3 = sh.hist[4 * lane + 3];
       int incl = c0 + c1 + c2 + c3;
       const int own = incl;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      incl = wave_incl_sum_i32(incl);
       const int excl = incl - own;
       const unsigned long long hit = __ballot(k >= excl && k < incl);
       const int owner = hit ? __ffsll((long long)hit) - 1 : 63;        // k beyond the total (cannot happen for k < n): last bin, like a serial scan would

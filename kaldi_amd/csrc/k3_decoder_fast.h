@@ -284,11 +284,10 @@ __device__ __forceinline__ int lit_frame_fast(const DecParams &p, Shared &sh, Fa
     const unsigned n0 = fs.next0; const float next0 = n0 == kEncMax ? kInf : dec(n0); const unsigned run0 = enc(next0);
     const unsigned m = lane < nchunks ? cmin[lane] : kEncMax; const int k = lane < nchunks ? ccnt[lane] : 0;
     unsigned em = m; int ik = k;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(em, o); const int tk = __shfl_up(ik, o); if (lane >= o) { em = t < em ? t : em; ik += tk; } }
-    unsigned exm = __shfl_up(em, 1); if (lane == 0) exm = kEncMax; exm = run0 < exm ? run0 : exm;
+    em = wave_incl_min_u32(em); ik = wave_incl_sum_i32(ik);
+    unsigned exm = wave_shr1_u32(em, kEncMax); exm = run0 < exm ? run0 : exm;
     cpre_l = exm; cbase_l = ik - k;
-    const unsigned wm = __shfl(em, 63); accept = dec(wm < run0 ? wm : run0); m_e = (unsigned)__shfl(ik, 63);
+    const unsigned wm = (unsigned)__builtin_amdgcn_readlane((int)em, 63); accept = dec(wm < run0 ? wm : run0); m_e = (unsigned)__builtin_amdgcn_readlane(ik, 63);
   }
   if (m_e + (unsigned)cap_tokens > (unsigned)kFM) return -1;      // (uniform; only LDS touched so far)
   // ---- pass B: accept against the bound in force at each arc; tokens, costs, creation labels, forward links
@@ -300,10 +299,9 @@ __device__ __forceinline__ int lit_frame_fast(const DecParams &p, Shared &sh, Fa
       float ac = 0.0f, tot = 0.0f; unsigned e = kEncMax;
       if (valid) { ac = co - ll[r.pdf]; tot = oc + ac + r.w; e = enc(tot + ab); }
       unsigned em = e;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(em, o); if (lane >= o) em = t < em ? t : em; }
-      unsigned exm = __shfl_up(em, 1); if (lane == 0) exm = kEncMax; exm = run < exm ? run : exm;
-      { const unsigned wm = __shfl(em, 63); run = wm < run ? wm : run; }
+      em = wave_incl_min_u32(em);
+      unsigned exm = wave_shr1_u32(em, kEncMax); exm = run < exm ? run : exm;
+      { const unsigned wm = (unsigned)__builtin_amdgcn_readlane((int)em, 63); run = wm < run ? wm : run; }
       const bool acc = valid && tot < dec(exm);
       cnt_os += acc && !(tot < accept);
       const int state = (int)((unsigned)r.next & ~kEpsFlag);

@@ -138,16 +138,13 @@ template <typename F>
 __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int deg, F &&f) {
   const int lane = threadIdx.x & 63;
   int incl = deg;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-  const int total = __shfl(incl, 63);
+  incl = wave_incl_sum_i32(incl);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - deg;
+  const unsigned long long has_arcs = __ballot(deg > 0);
   for (int j0 = 0; j0 < total; j0 += 64) {
     const int j = j0 + lane;
-    int lo = 0, hi = 63;
-#pragma unroll
-    for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; const int v = __shfl(incl, mid); if (v > j) hi = mid; else lo = mid + 1; }
-    lo = lo > 63 ? 63 : lo;
+    const int lo = wave_owner_of(j0, deg, excl, has_arcs);
     const int obeg = __shfl(beg, lo), oexcl = __shfl(excl, lo);
     const int a = obeg + (j - oexcl); ArcRec r{};
     if (j < total) r = arcs[a];
@@ -779,11 +776,10 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         for (int c0 = 0; c0 < nchunks; c0 += 64) {
           const int c = c0 + lane; const unsigned m = c < nchunks ? q.cmin[c] : kEncMax; const int k = c < nchunks ? q.ccnt[c] : 0;
           unsigned em = m; int ik = k;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(em, o); const int tk = __shfl_up(ik, o); if (lane >= o) { em = t < em ? t : em; ik += tk; } }
-          unsigned exm = __shfl_up(em, 1); if (lane == 0) exm = kEncMax; exm = run < exm ? run : exm;
+          em = wave_incl_min_u32(em); ik = wave_incl_sum_i32(ik);
+          unsigned exm = wave_shr1_u32(em, kEncMax); exm = run < exm ? run : exm;
           if (c < nchunks) { cpre[c] = exm; cbase[c] = base + ik - k; }
-          const unsigned wm = __shfl(em, 63); run = wm < run ? wm : run; base += __shfl(ik, 63);
+          const unsigned wm = (unsigned)__builtin_amdgcn_readlane((int)em, 63); run = wm < run ? wm : run; base += __builtin_amdgcn_readlane(ik, 63);
         }
         if (lane == 0) { ls.final_cut = run; ls.m_e = base; }
       }
@@ -806,10 +802,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
             float ac = 0.0f, tot = 0.0f; unsigned e = kEncMax;
             if (valid) { ac = co - ll[r.pdf]; tot = oc + ac + r.w; e = enc(tot + ab); }
             unsigned em = e;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(em, o); if (lane >= o) em = t < em ? t : em; }
-            unsigned exm = __shfl_up(em, 1); if (lane == 0) exm = kEncMax; exm = run < exm ? run : exm;
-            { const unsigned wm = __shfl(em, 63); run = wm < run ? wm : run; }
+            em = wave_incl_min_u32(em);
+            unsigned exm = wave_shr1_u32(em, kEncMax); exm = run < exm ? run : exm;
+            { const unsigned wm = (unsigned)__builtin_amdgcn_readlane((int)em, 63); run = wm < run ? wm : run; }
             const bool acc = valid && tot < dec(exm);
             cnt_os += acc && !(tot < accept);
             const int state = (int)((unsigned)r.next & ~kEpsFlag);
