@@ -65,6 +65,11 @@ int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_
 int k3_feat_compute_batch_pcm16(k3_feat_plan *plan, const int16_t *d_waves, const int64_t *d_wave_offsets,
                                 const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
                                 float *d_feats, int64_t ld, void *stream);
+/* ResampleWaveform (feat/resample.cc:363-372: LinearResample with cutoff 0.99 * 0.5 * min(rate), six zero crossings, flushed): what OfflineFeatureTpl::ComputeFeatures
+ * (feat/feature-common-inl.h:29-57) does to a waveform whose rate differs from --sample-frequency under --allow-downsample / --allow-upsample.  Utterance u's samples are
+ * d_in[h_in_offsets[u] .. h_in_offsets[u+1]) and come out as d_out[h_out_offsets[u] ..), k3_resample_num_samples(rate_in, rate_out, n) of them.  Synchronous. */
+int64_t k3_resample_num_samples(int32_t rate_in, int32_t rate_out, int64_t num_in);
+int k3_resample_batch(int32_t rate_in, int32_t rate_out, const float *d_in, const int64_t *h_in_offsets, int32_t num_utts, float *d_out, const int64_t *h_out_offsets, void *stream);
 /* Per-utterance CMVN in place: AccCmvnStats + ApplyCmvn (transform/cmvn.cc:30-115), what
  * `compute-cmvn-stats | apply-cmvn [--norm-vars]` do with one utterance per speaker.
  * fp64 accumulators like the reference.  d_stats (optional, may be NULL): [U x 2 x (dim+1)] doubles. */

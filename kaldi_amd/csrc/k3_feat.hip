@@ -773,3 +773,78 @@ extern "C" void k3_online_cmvn_opts_default(k3_online_cmvn_opts *o) {
   if (!o) return;
   o->cmn_window = 600; o->speaker_frames = 600; o->global_frames = 200; o->normalize_mean = 1; o->normalize_variance = 0;
 }
+
+// ---- ResampleWaveform (feat/resample.cc:363-372) = LinearResample (:33-230) with cutoff 0.99 * 0.5 * min(rates), six zero crossings, flush = true: what
+// OfflineFeatureTpl::ComputeFeatures does when a file's rate differs from --sample-frequency (feat/feature-common-inl.h:29-57, --allow-downsample / --allow-upsample).
+// The windowed-sinc weights of the out_rate / gcd phases are made on the host with the reference's float / double mix (FilterFunc takes and returns float, evaluates in double);
+// one thread per output sample forms its dot product in tap order.
+namespace {
+struct ResamplePlan { int in_unit, out_unit, max_taps; std::vector<int> first, ntaps; std::vector<float> w; };
+int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+ResamplePlan make_resample_plan(int rate_in, int rate_out) {
+  ResamplePlan r; const float min_freq = (float)std::min(rate_in, rate_out), cutoff = (float)(0.99 * 0.5 * min_freq); const int num_zeros = 6;
+  const int base = gcd_i(rate_in, rate_out); r.in_unit = rate_in / base; r.out_unit = rate_out / base;
+  const double window_width = num_zeros / (2.0 * cutoff);
+  auto filter_func = [&](float t) -> float {
+    float window, filter;
+    if (std::fabs(t) < num_zeros / (2.0 * cutoff)) window = (float)(0.5 * (1 + std::cos(6.283185307179586476925286766559005 * cutoff / num_zeros * t))); else window = 0.0f;
+    if (t != 0) filter = (float)(std::sin(6.283185307179586476925286766559005 * cutoff * t) / (M_PI * t)); else filter = 2 * cutoff;
+    return filter * window;
+  };
+  r.first.resize(r.out_unit); r.ntaps.resize(r.out_unit); r.max_taps = 0; std::vector<std::vector<float>> ws(r.out_unit);
+  for (int i = 0; i < r.out_unit; i++) {
+    const double output_t = i / (double)rate_out, min_t = output_t - window_width, max_t = output_t + window_width;
+    const int lo = (int)std::ceil(min_t * rate_in), hi = (int)std::floor(max_t * rate_in), n = hi - lo + 1;
+    r.first[i] = lo; r.ntaps[i] = n; r.max_taps = std::max(r.max_taps, n); ws[i].resize(n);
+    for (int j = 0; j < n; j++) { const double input_t = (lo + j) / (double)rate_in, delta_t = input_t - output_t; ws[i][j] = filter_func((float)delta_t) / rate_in; }
+  }
+  r.w.assign((size_t)r.out_unit * r.max_taps, 0.0f);
+  for (int i = 0; i < r.out_unit; i++) std::copy(ws[i].begin(), ws[i].end(), r.w.begin() + (size_t)i * r.max_taps);
+  return r;
+}
+long long resample_num_out(int rate_in, int rate_out, long long n_in) {      // GetNumOutputSamples(n, flush = true), :61-103
+  const long long tick = (long long)rate_in / gcd_i(rate_in, rate_out) * rate_out, per_in = tick / rate_in, per_out = tick / rate_out, interval = n_in * per_in;
+  if (interval <= 0) return 0;
+  long long last = interval / per_out; if (last * per_out == interval) last--;
+  return last + 1;
+}
+__global__ __launch_bounds__(256) void k3_resample_kernel(const float *in, const long long *in_off, float *out, const long long *out_off, int num_utts, int in_unit, int out_unit, int max_taps,
+                                                          const int *first, const int *ntaps, const float *w) {
+  const int u = blockIdx.y; const long long i0 = in_off[u], n_in = in_off[u + 1] - i0, o0 = out_off[u], n_out = out_off[u + 1] - o0;
+  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < n_out; s += (long long)gridDim.x * 256) {
+    const long long unit = s / out_unit; const int ph = (int)(s - unit * out_unit);
+    const long long f = first[ph] + unit * in_unit; const float *wp = w + (long long)ph * max_taps; const int n = ntaps[ph];
+    float acc = 0.0f;
+    for (int t = 0; t < n; t++) { const long long idx = f + t; if (idx >= 0 && idx < n_in) acc += wp[t] * in[i0 + idx]; }      // (samples before the start / beyond the end do not exist: flush = true, no remainder)
+    out[o0 + s] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int64_t k3_resample_num_samples(int32_t rate_in, int32_t rate_out, int64_t num_in) { return (rate_in > 0 && rate_out > 0 && num_in >= 0) ? resample_num_out(rate_in, rate_out, num_in) : -1; }
+extern "C" int k3_resample_batch(int32_t rate_in, int32_t rate_out, const float *d_in, const int64_t *h_in_offsets, int32_t num_utts, float *d_out, const int64_t *h_out_offsets, void *stream) {
+  K3_REQUIRE(rate_in > 0 && rate_out > 0 && rate_in != rate_out && d_in && d_out && h_in_offsets && h_out_offsets && num_utts >= 0, "k3_resample_batch: bad argument");
+  if (num_utts == 0) return K3_OK;
+  long long max_out = 0;
+  for (int u = 0; u < num_utts; u++) {
+    K3_REQUIRE(h_out_offsets[u + 1] - h_out_offsets[u] == resample_num_out(rate_in, rate_out, h_in_offsets[u + 1] - h_in_offsets[u]), "k3_resample_batch: output offsets do not match k3_resample_num_samples");
+    max_out = std::max<long long>(max_out, h_out_offsets[u + 1] - h_out_offsets[u]);
+  }
+  const ResamplePlan pl = make_resample_plan(rate_in, rate_out);
+  // one allocation for the tables and the offsets; the call is synchronous (a rate mismatch is the rare path of a feature program)
+  const size_t nb_w = pl.w.size() * 4, nb_i = (size_t)pl.out_unit * 4, nb_o = (size_t)(num_utts + 1) * 8; char *d = nullptr;
+  K3_HIP_CHECK(hipMalloc((void **)&d, nb_w + 2 * nb_i + 2 * nb_o + 64));
+  float *d_w = (float *)d; int *d_first = (int *)(d + nb_w), *d_nt = (int *)(d + nb_w + nb_i); long long *d_io = (long long *)(d + ((nb_w + 2 * nb_i + 15) & ~(size_t)15)), *d_oo = d_io + num_utts + 1;
+  hipStream_t st = (hipStream_t)stream; int rc = K3_OK;
+  if (hipMemcpyAsync(d_w, pl.w.data(), nb_w, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(d_first, pl.first.data(), nb_i, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_nt, pl.ntaps.data(), nb_i, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(d_io, h_in_offsets, nb_o, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_oo, h_out_offsets, nb_o, hipMemcpyHostToDevice, st) != hipSuccess) rc = K3_ERR_HIP;
+  if (rc == K3_OK && max_out > 0) {
+    hipLaunchKernelGGL(k3_resample_kernel, dim3((unsigned)std::min<long long>(1024, (max_out + 255) / 256), (unsigned)num_utts), dim3(256), 0, st, d_in, d_io, d_out, d_oo, num_utts, pl.in_unit, pl.out_unit, pl.max_taps, d_first, d_nt, d_w);
+    if (hipGetLastError() != hipSuccess) rc = K3_ERR_HIP;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) rc = K3_ERR_HIP;
+  (void)hipFree(d);
+  K3_REQUIRE(rc == K3_OK, "k3_resample_batch: HIP error");
+  return K3_OK;
+}

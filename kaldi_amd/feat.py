@@ -1,7 +1,7 @@
 """Python plumbing over the feature C ABI (k3_feat_*): what the C++ adapter
 kaldi::CudaSpectralFeatures / OnlineCudaFeaturePipeline (kaldi_amd/host) calls, exposed to tests and
 bench.py.  torch is used for device buffers and the current stream only."""
-import ctypes, torch
+import ctypes, numpy as np, torch
 from . import lib as _l
 
 def fbank_options(**kw):
@@ -61,6 +61,16 @@ class SpectralFeatures:
         _l.check(fn(self._h, waves.data_ptr(), wave_offsets.data_ptr(), frame_offsets.data_ptr(),
                                                wave_offsets.numel() - 1, int(total_frames), out.data_ptr(), out.stride(0), _stream()))
         return out
+
+def ResampleWaveform(waves, lengths, rate_in, rate_out):
+    """ResampleWaveform (feat/resample.cc:363-372) on a batch: `waves` = float32 CUDA tensor with the utterances back to back (lengths[u] samples each, at rate_in Hz).
+    Returns (resampled tensor, new lengths) -- what OfflineFeatureTpl::ComputeFeatures (feat/feature-common-inl.h:29-57) feeds its frame loop under --allow-downsample / --allow-upsample."""
+    L = _l.load(); assert waves.is_cuda and waves.dtype == torch.float32 and waves.is_contiguous()
+    io = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64); assert io[-1] == waves.numel()
+    nl = [int(L.k3_resample_num_samples(int(rate_in), int(rate_out), int(n))) for n in lengths]; oo = np.concatenate([[0], np.cumsum(nl)]).astype(np.int64)
+    out = torch.empty(int(oo[-1]), dtype=torch.float32, device=waves.device)
+    _l.check(L.k3_resample_batch(int(rate_in), int(rate_out), waves.data_ptr(), io.ctypes.data, len(lengths), out.data_ptr(), oo.ctypes.data, _stream()))
+    return out, nl
 
 def ApplyCmvnOffline(feats, frame_offsets, norm_vars=False, stats=None):
     """compute-cmvn-stats | apply-cmvn per utterance, in place (transform/cmvn.cc:30-115)."""

@@ -37,8 +37,8 @@ int main(int argc, char **argv) {
           else if (channel >= nch) { K3H_WARN << "File with id " << scp[i].first << " has " << nch << " channels but you specified channel " << channel << ", producing no output."; num_err++; continue; }
           else if (channel > 0) w = ReadWave(scp[i].second, channel);
         } catch (const FatalError &) { num_err++; continue; }
-        if (w.samp_freq != opts.samp_freq) { K3H_WARN << "Sample frequency mismatch for " << scp[i].first << ": " << w.samp_freq << " vs " << opts.samp_freq; num_err++; continue; }
         if (w.samples.size() / w.samp_freq < min_duration) { K3H_WARN << "File: " << scp[i].first << " is too short: producing no output."; num_err++; continue; }
+        if (!MatchSampleRate(&w, opts.samp_freq, fo.allow_downsample, fo.allow_upsample)) { K3H_WARN << "Waveform and config sample Frequency mismatch: " << w.samp_freq << " .vs " << opts.samp_freq << " (use --allow-downsample=true / --allow-upsample=true to resample); failed to compute features for utterance " << scp[i].first; num_err++; continue; }
         const int nf = k3_feat_num_frames(plan, (int64_t)w.samples.size());
         if (nf == 0) { K3H_WARN << "No frames fit in file " << scp[i].first << " (#samp = " << w.samples.size() << ")"; num_err++; continue; }
         keys.push_back(scp[i].first); all.insert(all.end(), w.samples.begin(), w.samples.end());

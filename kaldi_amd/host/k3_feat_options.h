@@ -3,7 +3,27 @@
 #pragma once
 #include "k3_host.h"
 #include "../../include/k3hip.h"
+#include <hip/hip_runtime.h>
 namespace k3host {
+// OfflineFeatureTpl::ComputeFeatures' rate check (feat/feature-common-inl.h:29-57): true = the wave is (now) at `want` Hz; false = mismatch without the flag that allows it (the
+// reference raises an error there, which the feature programs turn into a warning and a skipped file).  Resampling runs on the GPU (k3_resample_batch = ResampleWaveform).
+inline bool MatchSampleRate(Wave *w, float want, bool allow_downsample, bool allow_upsample) {
+  if (w->samp_freq == want) return true;
+  if ((want < w->samp_freq && !allow_downsample) || (want > w->samp_freq && !allow_upsample)) return false;
+  const int32_t ri = (int32_t)w->samp_freq, ro = (int32_t)want; const int64_t n_in = (int64_t)w->samples.size(), n_out = k3_resample_num_samples(ri, ro, n_in);
+  if (n_out < 0) return false;
+  std::vector<float> out((size_t)n_out);
+  if (n_out > 0 && n_in > 0) {
+    float *d_in = nullptr, *d_out = nullptr; const int64_t io[2] = {0, n_in}, oo[2] = {0, n_out};
+    if (hipMalloc((void **)&d_in, (size_t)n_in * 4) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n_out * 4) != hipSuccess || hipMemcpy(d_in, w->samples.data(), (size_t)n_in * 4, hipMemcpyHostToDevice) != hipSuccess)
+      K3H_ERR << "HIP error while resampling";
+    if (k3_resample_batch(ri, ro, d_in, io, 1, d_out, oo, nullptr) != 0) K3H_ERR << k3_last_error();
+    if (hipMemcpy(out.data(), d_out, (size_t)n_out * 4, hipMemcpyDeviceToHost) != hipSuccess) K3H_ERR << "HIP error while resampling";
+    (void)hipFree(d_in); (void)hipFree(d_out);
+  }
+  w->samples.swap(out); w->samp_freq = want;
+  return true;
+}
 struct FeatOptions {
   k3_feat_opts o; std::string window_type = "povey";
   bool remove_dc = true, round_pow2 = true, snip_edges = true, use_energy = false, raw_energy = true, htk_compat = false, use_log_fbank = true, use_power = true;
@@ -21,7 +41,7 @@ struct FeatOptions {
     po->Register("dither", &o.dither, "Dithering constant (0.0 means no dither)"); po->Register("window-type", &window_type, "Type of window (\"hamming\"|\"hanning\"|\"povey\"|\"rectangular\"|\"sine\"|\"blackman\")");
     po->Register("blackman-coeff", &o.blackman_coeff, "Constant coefficient for generalized Blackman window."); po->Register("round-to-power-of-two", &round_pow2, "If true, round window size to power of two by zero-padding input to FFT.");
     po->Register("snip-edges", &snip_edges, "If true, end effects will be handled by outputting only frames that completely fit in the file");
-    po->Register("allow-downsample", &allow_downsample, "(accepted, resampling is not implemented)"); po->Register("allow-upsample", &allow_upsample, "(accepted, resampling is not implemented)");
+    po->Register("allow-downsample", &allow_downsample, "If true, allow the input waveform to have a higher frequency than the specified --sample-frequency (and we'll downsample)."); po->Register("allow-upsample", &allow_upsample, "If true, allow the input waveform to have a lower frequency than the specified --sample-frequency (and we'll upsample).");
     po->Register("num-mel-bins", &o.num_bins, "Number of triangular mel-frequency bins"); po->Register("low-freq", &o.low_freq, "Low cutoff frequency for mel bins");
     po->Register("high-freq", &o.high_freq, "High cutoff frequency for mel bins (if <= 0, offset from Nyquist)"); po->Register("vtln-low", &o.vtln_low, "Low inflection point in piecewise linear VTLN warping function");
     po->Register("vtln-high", &o.vtln_high, "High inflection point in piecewise linear VTLN warping function (if negative, offset from high-mel-freq"); po->Register("debug-mel", &debug_mel, "(accepted, ignored)");

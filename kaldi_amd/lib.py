@@ -72,6 +72,7 @@ def load():
     L.k3_feat_dim.argtypes = [vp]; L.k3_feat_dim.restype = i32
     L.k3_feat_num_frames.argtypes = [vp, i64]; L.k3_feat_num_frames.restype = i32
     L.k3_feat_compute_batch.argtypes = [vp, vp, vp, vp, i32, i64, vp, i64, vp]; L.k3_feat_compute_batch_pcm16.argtypes = [vp, vp, vp, vp, i32, i64, vp, i64, vp]
+    L.k3_resample_num_samples.argtypes = [i32, i32, i64]; L.k3_resample_num_samples.restype = i64; L.k3_resample_batch.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp]
     L.k3_cmvn_offline_batch.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp]
     L.k3_online_cmvn_opts_default.argtypes = [ctypes.POINTER(OnlineCmvnOpts)]; L.k3_online_cmvn_opts_default.restype = None
     L.k3_cmvn_online_batch.argtypes = [vp, i64, vp, i64, i32, vp, i32, ctypes.POINTER(OnlineCmvnOpts), vp, vp, vp, i32, vp]

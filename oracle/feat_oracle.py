@@ -71,3 +71,36 @@ def cmvn_online(feats, global_stats, speaker_stats=None, cmn_window=600, speaker
                               g.ctypes.data, None if sp is None else sp.ctypes.data, sk.ctypes.data if len(sk) else None, len(sk))
     if r != 0: raise ValueError("online CMVN: the reference raises an error for these stats/options")
     return out
+
+
+def resample_waveform(wave, rate_in, rate_out):
+    """ResampleWaveform (feat/resample.cc:363-372) = LinearResample (:33-60 constructor, :61-103 GetNumOutputSamples, :105-128 SetIndexesAndWeights, :142-205 Resample with
+    flush = true, :232-246 FilterFunc): cutoff 0.99 * 0.5 * min(rates) as float32, six zero crossings; FilterFunc takes and returns float32 and evaluates in float64.
+    Test infrastructure (numpy); the dot products are summed in float32 in tap order."""
+    import math
+    wave = np.asarray(wave, np.float32); rate_in = int(rate_in); rate_out = int(rate_out); num_zeros = 6
+    cutoff = np.float32(0.99 * 0.5 * np.float32(min(rate_in, rate_out)))
+    base = math.gcd(rate_in, rate_out); in_unit = rate_in // base; out_unit = rate_out // base
+    window_width = num_zeros / (2.0 * float(cutoff))
+    def filter_func(t):                 # t: float32
+        t = float(np.float32(t))
+        window = np.float32(0.5 * (1 + math.cos(6.283185307179586476925286766559005 * float(cutoff) / num_zeros * t))) if abs(t) < num_zeros / (2.0 * float(cutoff)) else np.float32(0.0)
+        filt = np.float32(math.sin(6.283185307179586476925286766559005 * float(cutoff) * t) / (math.pi * t)) if t != 0 else np.float32(2) * cutoff
+        return np.float32(filt * window)
+    first, weights = [], []
+    for i in range(out_unit):
+        output_t = i / float(rate_out); lo = math.ceil((output_t - window_width) * rate_in); hi = math.floor((output_t + window_width) * rate_in)
+        first.append(lo); weights.append(np.array([filter_func(np.float32((lo + j) / float(rate_in) - output_t)) / np.float32(rate_in) for j in range(hi - lo + 1)], np.float32))
+    tick = rate_in // base * rate_out; interval = len(wave) * (tick // rate_in); per_out = tick // rate_out
+    if interval <= 0: return np.zeros(0, np.float32)
+    last = interval // per_out
+    if last * per_out == interval: last -= 1
+    out = np.zeros(last + 1, np.float32); n = len(wave)
+    for s in range(last + 1):
+        unit, ph = divmod(s, out_unit); f = first[ph] + unit * in_unit; w = weights[ph]
+        a = max(0, -f); b = min(len(w), n - f)
+        if b > a:
+            acc = np.float32(0.0)
+            for x in (w[a:b] * wave[f + a:f + b]): acc = np.float32(acc + x)
+            out[s] = acc
+    return out

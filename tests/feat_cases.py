@@ -41,3 +41,11 @@ FFTSIZE_CASES = {
     "fbank_16k_50ms": ("fbank", dict(dither=0.0, frame_length_ms=50.0, num_bins=40, use_energy=1), 16000, 20000, 45),
     "mfcc_16k_40ms_hires": ("mfcc", dict(dither=0.0, frame_length_ms=40.0, frame_shift_ms=15.0, num_bins=40, num_ceps=40, low_freq=20.0, high_freq=-400.0, use_energy=0), 16000, 24000, 46),
 }
+
+# files whose rate differs from --sample-frequency (OfflineFeatureTpl::ComputeFeatures' resampling branch, feat/feature-common-inl.h:29-57): (kind, options, file rate, samples, seed)
+RESAMPLE_CASES = {
+    "down_16k_to_8k": ("fbank", dict(dither=0.0, samp_freq=8000.0, num_bins=23), 16000, 20011, 51),
+    "up_8k_to_16k": ("fbank", dict(dither=0.0, samp_freq=16000.0, num_bins=40), 8000, 9001, 52),
+    "down_44k1_to_16k": ("mfcc", dict(dither=0.0, samp_freq=16000.0), 44100, 30000, 53),
+    "down_22k05_to_16k_nosnip": ("fbank", dict(dither=0.0, samp_freq=16000.0, num_bins=40, snip_edges=0), 22050, 15001, 54),
+}
