@@ -428,6 +428,12 @@ typedef struct k3_chain_training_opts {      /* chain::ChainTrainingOptions (cha
 typedef struct k3_chain_supervision k3_chain_supervision;
 int k3_chain_supervision_create(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
                                 const int32_t *ilabel, const int32_t *nextstate, const float *arc_weight, const float *final_cost, k3_chain_supervision **sup);
+/* End-to-end (flat-start) supervisions: chain::Supervision::e2e_fsts, one FST per sequence that may have self-loops and several final states (epsilon-free, ilabel = pdf-id + 1,
+ * start state 0; same array layout as above).  k3_chain_numerator / k3_chain_objf_and_deriv then run chain::GenericNumeratorComputation (chain/chain-generic-numerator.cc:30-463) and
+ * the end-to-end branch of ComputeChainObjfAndDeriv (chain-training.cc:86-215) -- including the reference's quirk that the numerator log-probability enters the objective without the
+ * supervision weight (:270) while its derivative carries it. */
+int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
+                                    const int32_t *ilabel, const int32_t *nextstate, const float *arc_weight, const float *final_cost, k3_chain_supervision **sup);
 void k3_chain_supervision_destroy(k3_chain_supervision *sup);
 int k3_chain_numerator(k3_chain_supervision *sup, const float *d_nnet_output, int64_t ld, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_logprob_weighted, void *stream);
 int k3_chain_objf_and_deriv(k3_chain_den *den, k3_chain_supervision *sup, const k3_chain_training_opts *opts, const float *d_nnet_output, int64_t ld,

@@ -56,14 +56,15 @@ class DenominatorComputation:
 class Supervision:
     """chain::Supervision (chain/chain-supervision.h:226-330) for a minibatch, with the sequences' FSTs kept apart: fsts = one kaldi_amd.fst.Fst per
     sequence (start state 0, labels pdf-id + 1, states sorted by path length, every path frames_per_sequence arcs long)."""
-    def __init__(self, fsts, frames_per_sequence, label_dim, weight=1.0):
-        L = _l.load(); self.num_sequences = len(fsts); self.frames_per_sequence = int(frames_per_sequence); self.label_dim = int(label_dim); self.weight = float(weight)
+    def __init__(self, fsts, frames_per_sequence, label_dim, weight=1.0, e2e=False):
+        """e2e: the FSTs are Supervision::e2e_fsts (end-to-end / flat-start training: self-loops, several final states; chain-supervision.h:255-282) -> GenericNumeratorComputation"""
+        L = _l.load(); self.e2e = bool(e2e); self.num_sequences = len(fsts); self.frames_per_sequence = int(frames_per_sequence); self.label_dim = int(label_dim); self.weight = float(weight)
         so = np.concatenate([[0], np.cumsum([f.num_states for f in fsts])]).astype(np.int32)
         ao = np.concatenate([[0]] + [np.asarray(f.arc_offsets[1:], np.int64) + b for f, b in zip(fsts, np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in fsts])[:-1]]))]).astype(np.int64)
         il = np.concatenate([f.ilabel for f in fsts]).astype(np.int32); nx = np.concatenate([f.nextstate for f in fsts]).astype(np.int32)
         w = np.concatenate([f.weight for f in fsts]).astype(np.float32); fin = np.concatenate([f.final for f in fsts]).astype(np.float32)
         h = ctypes.c_void_p()
-        _l.check(L.k3_chain_supervision_create(self.num_sequences, self.frames_per_sequence, self.label_dim, self.weight, so.ctypes.data, ao.ctypes.data, il.ctypes.data, nx.ctypes.data, w.ctypes.data, fin.ctypes.data, ctypes.byref(h)))
+        _l.check((L.k3_chain_supervision_create_e2e if self.e2e else L.k3_chain_supervision_create)(self.num_sequences, self.frames_per_sequence, self.label_dim, self.weight, so.ctypes.data, ao.ctypes.data, il.ctypes.data, nx.ctypes.data, w.ctypes.data, fin.ctypes.data, ctypes.byref(h)))
         self._h = h
     def __del__(self):
         if getattr(self, "_h", None) and _l is not None: _l.load().k3_chain_supervision_destroy(self._h); self._h = None

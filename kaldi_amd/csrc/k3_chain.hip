@@ -350,10 +350,13 @@ struct k3_chain_supervision {
   int B = 0, T = 0, P = 0, max_states = 0; float weight = 1.0f;
   int *ints = nullptr; long long *arc_off = nullptr; float *floats = nullptr; double *logprob = nullptr; double *scratch = nullptr;
   const int *state_off = nullptr, *layer_off = nullptr, *arc_src = nullptr, *arc_dst = nullptr, *arc_pdf = nullptr; const float *arc_w = nullptr, *final_cost = nullptr;
+  // end-to-end ("generic numerator") supervisions: transitions by destination and by pdf, the per-sequence offset of state 0's arcs, alpha rows
+  bool e2e = false; int max_pdfs = 0; float *alpha = nullptr;
+  const long long *in_off = nullptr, *pt_off = nullptr; const int *in_src = nullptr, *in_pdf = nullptr, *pdf_off = nullptr, *pdf_id = nullptr, *pt_src = nullptr, *pt_dst = nullptr; const float *in_tp = nullptr, *out_tp = nullptr, *pt_tp = nullptr, *seq_offset = nullptr;
 };
 extern "C" void k3_chain_supervision_destroy(k3_chain_supervision *s) {
   if (!s) return;
-  for (void *q : {(void *)s->ints, (void *)s->arc_off, (void *)s->floats, (void *)s->logprob, (void *)s->scratch}) if (q) (void)hipFree(q);
+  for (void *q : {(void *)s->ints, (void *)s->arc_off, (void *)s->floats, (void *)s->logprob, (void *)s->scratch, (void *)s->alpha}) if (q) (void)hipFree(q);
   delete s;
 }
 extern "C" int k3_chain_supervision_create(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
@@ -396,8 +399,181 @@ extern "C" int k3_chain_supervision_create(int32_t num_sequences, int32_t frames
   return K3_OK;
 }
 
+// ---- the end-to-end ("generic") numerator: chain::GenericNumeratorComputation (chain/chain-generic-numerator.cc:30-463), the forward-backward of flat-start chain training
+// over per-sequence FSTs that may have self-loops and several final states.  The reference runs it on the CPU, sequence by sequence in a few host threads, in the log domain
+// with LogAdd in float (base/kaldi-math.h:187-205) and a per-frame normaliser kept in an extra column of alpha.  Here one workgroup per sequence in one launch; the arithmetic
+// is the reference's, transition by transition in its order: alpha(t, h) = LogAdd over the in-transitions of h in (source state, arc) order (:196-207), minus the previous
+// frame's normaliser, normaliser = LogSumExp of the row (:208-216); beta(t, h) over the out-transitions (:330-350); the occupation log-probabilities of a pdf are LogAdd-ed
+// over the transitions that carry it in (state, arc) order -- a thread per pdf instead of the reference's serial sweep, same order.  exp / log1p are the device's, so results
+// agree to float rounding (tests: 1e-5), not bit for bit.  The offset of state 0's arcs (:84-93; only that state's, as the reference's loop scopes it) is kept.
+namespace {
+struct E2eParams {
+  const int *state_off; const long long *arc_off, *in_off, *pt_off; const int *arc_dst, *arc_pdf, *in_src, *in_pdf, *pdf_off, *pdf_id, *pt_src, *pt_dst;
+  const float *out_tp, *in_tp, *pt_tp, *final_cost, *seq_offset;
+  int B, T, max_states; float weight;
+  const float *out; long long ld; float *deriv; long long ld_deriv;
+  float *alpha;              // [B][T + 1][max_states + 1]
+  double *logprob;           // [B]
+};
+__device__ __forceinline__ float k3_logadd(float x, float y) {      // kaldi::LogAdd (float): the smaller term is dropped below log(FLT_EPSILON)
+  float diff; if (x < y) { diff = x - y; x = y; } else diff = y - x;
+  return diff >= -15.9423847198486328125f ? x + log1pf(expf(diff)) : x;
+}
+__global__ __launch_bounds__(256) void k3_chain_e2e_num_kernel(E2eParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *beta = reinterpret_cast<float *>(smem);      // [2][max_states]
+  __shared__ float redf[4]; __shared__ double redd[4];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = p.T, B = p.B;
+  const int s0 = p.state_off[n], S = p.state_off[n + 1] - s0, ld_a = p.max_states + 1;
+  float *A = p.alpha + (long long)n * (T + 1) * ld_a; const float *fin = p.final_cost + s0; const float kNegInf = -__builtin_inff();
+  auto probs = [&](int t, int pdf) { return p.out[((long long)t * B + n) * p.ld + pdf]; };
+  // MatrixBase::LogSumExp over a row of S floats (max, then exp(x - max) summed in double); every thread gets the result
+  auto row_logsumexp = [&](const float *row) -> float {
+    float m = kNegInf; for (int h = tid; h < S; h += 256) m = fmaxf(m, row[h]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) redf[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    double sum = 0.0; for (int h = tid; h < S; h += 256) sum += (double)expf(row[h] - m);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) redd[wave] = sum;
+    __syncthreads();
+    sum = redd[0] + redd[1] + redd[2] + redd[3];
+    __syncthreads();
+    return m + (float)log(sum);
+  };
+  // ---- forward (AlphaFirstFrame :122-131, AlphaRemainingFrames :163-236)
+  for (int h = tid; h <= S; h += 256) A[h] = (h == 0 || h == S) ? 0.0f : kNegInf;
+  __syncthreads();
+  double log_scale_product = 0.0;
+  for (int t = 1; t <= T; t++) {
+    const float *a_tm1 = A + (long long)(t - 1) * ld_a; float *a_t = A + (long long)t * ld_a; const float prev_norm = a_tm1[S];
+    for (int h = tid; h < S; h += 256) {
+      float a = kNegInf;
+      for (long long k = p.in_off[s0 + h]; k < p.in_off[s0 + h + 1]; k++) a = k3_logadd(a, a_tm1[p.in_src[k]] + p.in_tp[k] + probs(t - 1, p.in_pdf[k]));
+      a_t[h] = a + -prev_norm;
+    }
+    __syncthreads();
+    const float norm = row_logsumexp(a_t);
+    if (tid == 0) a_t[S] = norm;
+    log_scale_product += (double)norm;
+    __syncthreads();
+  }
+  float *a_T = A + (long long)T * ld_a;
+  log_scale_product -= (double)a_T[S];
+  __syncthreads();
+  for (int h = tid; h < S; h += 256) a_T[h] += fin[h] == __builtin_inff() ? kNegInf : -fin[h];      // last_alpha.AddVecToRows(final_probs)
+  __syncthreads();
+  const float tot = row_logsumexp(a_T);
+  if (tid == 0) { a_T[S] = tot; p.logprob[n] = ((double)tot - (double)p.seq_offset[n]) + log_scale_product; }
+  if (!p.deriv) return;
+  // ---- backward (BetaLastFrame :303-320, BetaRemainingFrames :322-363) with the derivative rows (AddSpecificPdfsIndirect :366-401: += weight * exp(log occupation))
+  for (int h = tid; h < S; h += 256) beta[(T & 1) * p.max_states + h] = -tot + (fin[h] == __builtin_inff() ? kNegInf : -fin[h]);
+  __syncthreads();
+  const int j0 = p.pdf_off[n], NP = p.pdf_off[n + 1] - j0;
+  for (int t = T - 1; t >= 0; t--) {
+    const float *a_t = A + (long long)t * ld_a, *b_tp1 = beta + ((t + 1) & 1) * p.max_states; float *b_t = beta + (t & 1) * p.max_states; const float inv = a_t[S];
+    for (int h = tid; h < S; h += 256) {
+      float totv = kNegInf;
+      for (long long k = p.arc_off[s0 + h]; k < p.arc_off[s0 + h + 1]; k++) totv = k3_logadd(totv, p.out_tp[k] + b_tp1[p.arc_dst[k]] + probs(t, p.arc_pdf[k]) - inv);
+      b_t[h] = totv;
+    }
+    for (int j = tid; j < NP; j += 256) {
+      const int pdf = p.pdf_id[j0 + j]; const float pr = probs(t, pdf); float ld_ = kNegInf;
+      for (long long k = p.pt_off[j0 + j]; k < p.pt_off[j0 + j + 1]; k++) ld_ = k3_logadd(ld_, (p.pt_tp[k] + b_tp1[p.pt_dst[k]] + pr - inv) + a_t[p.pt_src[k]]);
+      p.deriv[((long long)t * B + n) * p.ld_deriv + pdf] += p.weight * expf(ld_);
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
+                                               const int32_t *ilabel, const int32_t *nextstate, const float *arc_weight, const float *final_cost, k3_chain_supervision **out) {
+  K3_REQUIRE(out && state_offsets && arc_offsets && ilabel && nextstate && arc_weight && final_cost && num_sequences > 0 && frames_per_sequence > 0 && label_dim > 0, "k3_chain_supervision_create_e2e: bad argument");
+  const int B = num_sequences, T = frames_per_sequence; const int NS = state_offsets[B]; const long long NA = arc_offsets[NS];
+  std::vector<long long> in_off(NS + 1, 0), pt_off; std::vector<int> in_src(NA), in_pdf(NA), pdf_off(B + 1, 0), pdf_id, pt_src(NA), pt_dst(NA), dst(NA), pdf(NA); std::vector<float> in_tp(NA), out_tp(NA), pt_tp(NA), seq_offset(B, 0.0f);
+  int max_states = 0, max_pdfs = 0; bool any_final = true;
+  for (int n = 0; n < B; n++) {
+    const int s0 = state_offsets[n], S = state_offsets[n + 1] - s0; K3_REQUIRE(S > 0, "k3_chain_supervision_create_e2e: empty supervision FST");
+    max_states = std::max(max_states, S);
+    float offset = 0.0f; for (long long a = arc_offsets[s0]; a < arc_offsets[s0 + 1]; a++) if (arc_weight[a] > offset) offset = arc_weight[a];      // :84-93
+    seq_offset[n] = offset;
+    bool fin_any = false;
+    for (int st = 0; st < S; st++) {
+      if (final_cost[s0 + st] != __builtin_inff()) fin_any = true;
+      for (long long a = arc_offsets[s0 + st]; a < arc_offsets[s0 + st + 1]; a++) {
+        K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= label_dim && nextstate[a] >= 0 && nextstate[a] < S, "k3_chain_supervision_create_e2e: arc label must be pdf-id + 1 in [1, label_dim] (epsilon-free), next state in range");
+        dst[a] = nextstate[a]; pdf[a] = ilabel[a] - 1; out_tp[a] = -(arc_weight[a] - (st == 0 ? offset : 0.0f));
+        in_off[s0 + nextstate[a] + 1]++;
+      }
+    }
+    any_final = any_final && fin_any;
+  }
+  K3_REQUIRE(any_final, "k3_chain_supervision_create_e2e: a supervision FST without a final state");
+  for (int i = 0; i < NS; i++) in_off[i + 1] += in_off[i];
+  { std::vector<long long> cur(in_off.begin(), in_off.end() - 1);
+    for (int n = 0; n < B; n++) { const int s0 = state_offsets[n], S = state_offsets[n + 1] - s0;
+      for (int st = 0; st < S; st++) for (long long a = arc_offsets[s0 + st]; a < arc_offsets[s0 + st + 1]; a++) { const long long k = cur[s0 + dst[a]]++; in_src[k] = st; in_pdf[k] = pdf[a]; in_tp[k] = out_tp[a]; } } }
+  // transitions by pdf, per sequence (pdfs in order of first use like index_to_pdf_, transitions of a pdf in (state, arc) order)
+  pt_off.push_back(0);
+  for (int n = 0; n < B; n++) {
+    const int s0 = state_offsets[n], S = state_offsets[n + 1] - s0; std::vector<int> slot(label_dim, -1); std::vector<std::vector<long long>> lists;
+    for (int st = 0; st < S; st++) for (long long a = arc_offsets[s0 + st]; a < arc_offsets[s0 + st + 1]; a++) {
+      if (slot[pdf[a]] < 0) { slot[pdf[a]] = (int)lists.size(); lists.emplace_back(); pdf_id.push_back(pdf[a]); }
+      lists[slot[pdf[a]]].push_back(a);
+    }
+    for (size_t j = 0; j < lists.size(); j++) {
+      long long k = pt_off.back();
+      for (long long a : lists[j]) {
+        int st = (int)(std::upper_bound(arc_offsets + s0, arc_offsets + s0 + S + 1, (int64_t)a) - (arc_offsets + s0)) - 1;      // the arc's source state
+        pt_src[k] = st; pt_dst[k] = dst[a]; pt_tp[k] = out_tp[a]; k++;
+      }
+      pt_off.push_back(k);
+    }
+    pdf_off[n + 1] = (int)pdf_id.size(); max_pdfs = std::max(max_pdfs, (int)lists.size());
+  }
+  auto s = new k3_chain_supervision; s->B = B; s->T = T; s->P = label_dim; s->weight = weight; s->max_states = max_states; s->e2e = true; s->max_pdfs = max_pdfs;
+  std::vector<int> ints; auto put_i = [&](const std::vector<int> &v) { const size_t o = ints.size(); ints.insert(ints.end(), v.begin(), v.end()); return o; };
+  std::vector<int> so(state_offsets, state_offsets + B + 1);
+  const size_t o_so = put_i(so), o_dst = put_i(dst), o_pdf = put_i(pdf), o_isrc = put_i(in_src), o_ipdf = put_i(in_pdf), o_poff = put_i(pdf_off), o_pid = put_i(pdf_id), o_psrc = put_i(pt_src), o_pdst = put_i(pt_dst);
+  std::vector<float> fl; auto put_f = [&](const float *b, size_t n_) { const size_t o = fl.size(); fl.insert(fl.end(), b, b + n_); return o; };
+  const size_t o_otp = put_f(out_tp.data(), NA), o_itp = put_f(in_tp.data(), NA), o_ptp = put_f(pt_tp.data(), NA), o_fin = put_f(final_cost, NS), o_off = put_f(seq_offset.data(), B);
+  std::vector<long long> lls(arc_offsets, arc_offsets + NS + 1); const size_t o_in = lls.size(); lls.insert(lls.end(), in_off.begin(), in_off.end()); const size_t o_pt = lls.size(); lls.insert(lls.end(), pt_off.begin(), pt_off.end());
+#define K3_TRYS(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { k3_chain_supervision_destroy(s); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
+  K3_TRYS(hipMalloc(&s->ints, sizeof(int) * std::max<size_t>(1, ints.size()))); K3_TRYS(hipMalloc(&s->floats, sizeof(float) * std::max<size_t>(1, fl.size()))); K3_TRYS(hipMalloc(&s->arc_off, sizeof(long long) * lls.size()));
+  K3_TRYS(hipMalloc(&s->logprob, sizeof(double) * B)); K3_TRYS(hipMalloc(&s->scratch, sizeof(double))); K3_TRYS(hipMalloc(&s->alpha, sizeof(float) * (size_t)B * (T + 1) * (max_states + 1)));
+  K3_TRYS(hipMemcpy(s->ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice)); K3_TRYS(hipMemcpy(s->floats, fl.data(), sizeof(float) * fl.size(), hipMemcpyHostToDevice));
+  K3_TRYS(hipMemcpy(s->arc_off, lls.data(), sizeof(long long) * lls.size(), hipMemcpyHostToDevice));
+#undef K3_TRYS
+  s->state_off = s->ints + o_so; s->arc_dst = s->ints + o_dst; s->arc_pdf = s->ints + o_pdf; s->in_src = s->ints + o_isrc; s->in_pdf = s->ints + o_ipdf; s->pdf_off = s->ints + o_poff; s->pdf_id = s->ints + o_pid;
+  s->pt_src = s->ints + o_psrc; s->pt_dst = s->ints + o_pdst; s->out_tp = s->floats + o_otp; s->in_tp = s->floats + o_itp; s->pt_tp = s->floats + o_ptp; s->final_cost = s->floats + o_fin; s->seq_offset = s->floats + o_off;
+  s->in_off = s->arc_off + o_in; s->pt_off = s->arc_off + o_pt;
+  *out = s;
+  return K3_OK;
+}
+
+// GenericNumeratorComputation::ForwardBackward / ComputeObjf: *h_logprob = the total log-probability as the reference returns it (NOT multiplied by the supervision weight, whatever
+// the comment at chain-training.cc:147 says: :270 assigns the plain sum); the derivative gets weight * occupation probabilities
+static int chain_numerator_e2e(k3_chain_supervision *s, const float *d_out, int64_t ld, float *d_deriv, int64_t ld_deriv, float *h_logprob, hipStream_t st) {
+  const size_t lds = 2 * sizeof(float) * (size_t)s->max_states;
+  if (lds > 150 * 1024) { k3::set_error("k3_chain e2e numerator: a supervision FST of %d states needs %zu B of LDS (limit 150 KB)", s->max_states, lds); return K3_ERR_UNSUPPORTED; }
+  E2eParams p{}; p.state_off = s->state_off; p.arc_off = s->arc_off; p.in_off = s->in_off; p.pt_off = s->pt_off; p.arc_dst = s->arc_dst; p.arc_pdf = s->arc_pdf; p.in_src = s->in_src; p.in_pdf = s->in_pdf;
+  p.pdf_off = s->pdf_off; p.pdf_id = s->pdf_id; p.pt_src = s->pt_src; p.pt_dst = s->pt_dst; p.out_tp = s->out_tp; p.in_tp = s->in_tp; p.pt_tp = s->pt_tp; p.final_cost = s->final_cost; p.seq_offset = s->seq_offset;
+  p.B = s->B; p.T = s->T; p.max_states = s->max_states; p.weight = s->weight; p.out = d_out; p.ld = ld; p.deriv = d_deriv; p.ld_deriv = ld_deriv; p.alpha = s->alpha; p.logprob = s->logprob;
+  K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_chain_e2e_num_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 16)));
+  hipLaunchKernelGGL(k3_chain_e2e_num_kernel, dim3(s->B), dim3(256), std::max<size_t>(lds, 16), st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  std::vector<double> lp(s->B);
+  K3_HIP_CHECK(hipMemcpyAsync(lp.data(), s->logprob, sizeof(double) * s->B, hipMemcpyDeviceToHost, st)); K3_HIP_CHECK(hipStreamSynchronize(st));
+  float tot = 0.0f; for (double v : lp) tot += (float)v;      // (BaseFloat partial sums, :262-268)
+  *h_logprob = tot;
+  return K3_OK;
+}
+
 // NumeratorComputation::Forward (+ Backward when a derivative matrix is given): *h_logprob_weighted = weight * total log-prob; deriv (or xent) += weight * occupation probabilities
 static int chain_numerator(k3_chain_supervision *s, const float *d_out, int64_t ld, float *d_deriv, int64_t ld_deriv, float *d_xent, int64_t ld_xent, float *h_logprob_weighted, hipStream_t st) {
+  if (s->e2e) return d_xent ? chain_numerator_e2e(s, d_out, ld, d_xent, ld_xent, h_logprob_weighted, st) : chain_numerator_e2e(s, d_out, ld, d_deriv, ld_deriv, h_logprob_weighted, st);
   const size_t lds = 3 * sizeof(double) * (size_t)s->max_states;
   if (lds > 150 * 1024) { k3::set_error("k3_chain numerator: a supervision FST of %d states needs %zu B of LDS (limit 150 KB)", s->max_states, lds); return K3_ERR_UNSUPPORTED; }
   NumParams p{}; p.state_off = s->state_off; p.layer_off = s->layer_off; p.arc_off = s->arc_off; p.arc_src = s->arc_src; p.arc_dst = s->arc_dst; p.arc_pdf = s->arc_pdf; p.arc_w = s->arc_w; p.final_cost = s->final_cost;

@@ -135,7 +135,7 @@ def load():
     L.k3_chain_den_create.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]; L.k3_chain_den_destroy.argtypes = [vp]; L.k3_chain_den_destroy.restype = None
     L.k3_chain_den_num_states.argtypes = [vp]; L.k3_chain_den_initial_probs.argtypes = [vp, vp]
     L.k3_chain_den_forward_backward.argtypes = [vp, vp, i64, i32, i32, f32, f32, vp, i64, ctypes.POINTER(f32), ctypes.POINTER(i32), vp]
-    L.k3_chain_supervision_create.argtypes = [i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]; L.k3_chain_supervision_destroy.argtypes = [vp]; L.k3_chain_supervision_destroy.restype = None
+    L.k3_chain_supervision_create.argtypes = [i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]; L.k3_chain_supervision_create_e2e.argtypes = [i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]; L.k3_chain_supervision_destroy.argtypes = [vp]; L.k3_chain_supervision_destroy.restype = None
     L.k3_chain_numerator.argtypes = [vp, vp, i64, vp, i64, ctypes.POINTER(f32), vp]
     L.k3_chain_objf_and_deriv.argtypes = [vp, vp, ctypes.POINTER(ChainTrainingOpts), vp, i64, vp, i64, vp, i64, ctypes.POINTER(f32), ctypes.POINTER(f32), ctypes.POINTER(f32), vp]
     _lib = L

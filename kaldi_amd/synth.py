@@ -334,6 +334,32 @@ def make_supervision_fst(frames, num_pdfs, seed, width=3, branch=2.0, pdf_pool=N
     fin = np.full(S, np.inf, np.float32); fin[first[T]:] = rng.choice([0.0, 0.5], S - first[T])
     return Fst(0, off, lab.astype(np.int32), lab.astype(np.int32), w.astype(np.float32), dst.astype(np.int32), fin)
 
+def make_e2e_fst(frames, num_pdfs, seed, num_phones=None):
+    """One sequence's END-TO-END numerator FST (chain-generic-numerator.h:30-60: what TrainingGraphToSupervision makes of a training graph): an epsilon-free acceptor over pdf-id + 1
+    with self-loops and more than one final state -- a left-to-right chain of two-state phone HMMs (forward pdf, self-loop pdf per state; chain topology), an optional-silence
+    branch at the start, a skip here and there.  Paths of exactly `frames` arcs exist (2 * num_phones <= frames)."""
+    from .fst import Fst
+    rng = np.random.default_rng(seed); K = int(num_phones if num_phones is not None else max(1, frames // 5)); assert 2 * K <= frames
+    arcs = []      # (src, dst, pdf, weight)
+    st = 0
+    def hmm(s_in, s_out):      # two pdfs per phone: s_in -(fwd)-> mid [self-loop] -(.)-> s_out is how the chain topology expands; here mid has the self-loop and the exit
+        nonlocal nxt
+        f, l = int(rng.integers(0, num_pdfs)), int(rng.integers(0, num_pdfs)); mid = nxt; nxt += 1
+        arcs.append((s_in, mid, f, float(rng.choice([0.0, 0.1, 0.69])))); arcs.append((mid, mid, l, 0.69)); arcs.append((mid, s_out, l, 0.69))
+    nxt = 1; cur = 0
+    for k in range(K):
+        out = nxt; nxt += 1
+        hmm(cur, out)
+        if k == 0: hmm(cur, out)                                   # an alternative first phone (optional silence): two parallel branches
+        elif rng.random() < 0.2: arcs.append((cur, out, int(rng.integers(0, num_pdfs)), 1.2))      # a one-frame alternative pronunciation
+        cur = out
+    S = nxt; fin = np.full(S, np.inf, np.float32); fin[cur] = 0.0
+    arcs.append((cur, cur, int(rng.integers(0, num_pdfs)), 0.4))  # trailing silence self-loop on the final state
+    if S > 3: fin[cur - 1] = 0.5 if np.isinf(fin[cur - 1]) else fin[cur - 1]      # a second final state
+    arcs.sort(key=lambda a: a[0]); src = np.array([a[0] for a in arcs]); off = np.zeros(S + 1, np.int64); np.add.at(off, src + 1, 1); off = np.cumsum(off)
+    lab = np.array([a[2] + 1 for a in arcs], np.int32)
+    return Fst(0, off, lab, lab.copy(), np.array([a[3] for a in arcs], np.float32), np.array([a[1] for a in arcs], np.int32), fin)
+
 def merge_supervision_fsts(fsts):
     """The merged FST chain::MergeSupervision builds for a minibatch (fst::Concat of the sequences + RmEpsilon, chain-supervision.cc:744-800), restated
     for the tests' reference run: the final states of sequence n take over copies of sequence n + 1's start arcs with their final cost added."""

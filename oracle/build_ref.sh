@@ -115,7 +115,8 @@ g++ $MF -c $R/chain/chain-den-graph.cc -o $W/obj_chain/chain-den-graph.o
 g++ $MF -c $R/chain/chain-denominator.cc -o $W/obj_chain/chain-denominator.o
 g++ $MF -c $R/chain/chain-numerator.cc -o $W/obj_chain/chain-numerator.o
 g++ $MF -c $R/chain/chain-training.cc -o $W/obj_chain/chain-training.o
-g++ $MF $HERE/ref_tools/ref_chain_objf.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-chain-objf
+g++ $MF -c $R/chain/chain-generic-numerator.cc -o $W/obj_chain/chain-generic-numerator.o      # the end-to-end (flat-start) numerator: compiles unmodified too
+g++ $MF $HERE/ref_tools/ref_chain_objf.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-generic-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-chain-objf
 # the whole chain gradient on the reference's CPU code: NnetComputer forward (training mode) -> ComputeChainObjfAndDeriv -> backward (source shared with the adapter build)
 g++ $MF $HERE/../tests/adapter/nnet3_chain_grad.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-nnet3-chain-grad
 # N iterations of chain TRAINING (NnetChainTrainer::TrainInternal's sequence: natural-gradient update, max-change, batch-norm stats, orthonormal constraint) on the CPU (source shared with the adapter build)

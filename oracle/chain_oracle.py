@@ -104,6 +104,54 @@ def ref_objf(den_fst, num_pdfs, merged_sup_fst, nnet_output, num_sequences, leak
     objf, l2, wt = struct.unpack("<3f", raw[:12]); d = np.frombuffer(raw, np.float32, TB * P, 12).reshape(TB, P); x = np.frombuffer(raw, np.float32, TB * P, 12 + 4 * TB * P).reshape(TB, P)
     return dict(objf=float(objf), l2_term=float(l2), weight=float(wt), deriv=d.copy(), xent_deriv=x.copy())
 
+def ref_objf_e2e(den_fst, num_pdfs, e2e_fsts, nnet_output, leaky_hmm_coefficient=1.0e-05, l2_regularize=0.0, weight=1.0):
+    """the reference's ComputeChainObjfAndDeriv on END-TO-END supervisions (Supervision::e2e_fsts -> chain-training.cc:86-215 with GenericNumeratorComputation, compiled unmodified;
+    out-of-range penalty off): dict(objf, l2_term, weight, deriv, xent_deriv)"""
+    out = np.ascontiguousarray(nnet_output, np.float32); TB, P = out.shape; B = len(e2e_fsts)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(HERE, "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
+    so = np.concatenate([[0], np.cumsum([f.num_states for f in e2e_fsts])]).astype(np.int32); ab = np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in e2e_fsts])])
+    with tempfile.TemporaryDirectory() as td:
+        with open(f"{td}/in.bin", "wb") as f:
+            f.write(struct.pack("<9i3f", 0x4b37, int(den_fst.num_states), int(den_fst.start), int(den_fst.arc_offsets[-1]), P, B, TB // B, int(so[-1]), int(ab[-1]), leaky_hmm_coefficient, l2_regularize, weight))
+            f.write(_fst_bytes(den_fst)); f.write(so.tobytes())
+            f.write(np.concatenate([[0]] + [np.asarray(g.arc_offsets[1:], np.int64) + b for g, b in zip(e2e_fsts, ab[:-1])]).astype(np.int64).tobytes())
+            for k, dt in (("ilabel", np.int32), ("nextstate", np.int32), ("weight", np.float32), ("final", np.float32)): f.write(np.concatenate([getattr(g, k) for g in e2e_fsts]).astype(dt).tobytes())
+            f.write(out.tobytes())
+        subprocess.check_call([_BIN_OBJF, f"{td}/in.bin", f"{td}/out.bin"], env=env, stderr=subprocess.DEVNULL)
+        raw = open(f"{td}/out.bin", "rb").read()
+    objf, l2, wt = struct.unpack("<3f", raw[:12]); d = np.frombuffer(raw, np.float32, TB * P, 12).reshape(TB, P); x = np.frombuffer(raw, np.float32, TB * P, 12 + 4 * TB * P).reshape(TB, P)
+    return dict(objf=float(objf), l2_term=float(l2), weight=float(wt), deriv=d.copy(), xent_deriv=x.copy())
+
+def e2e_num_oracle(fsts, num_pdfs, nnet_output, weight=1.0):
+    """GenericNumeratorComputation::ForwardBackward (chain/chain-generic-numerator.cc:238-275 with AlphaRemainingFrames :163-236 and BetaRemainingFrames :322-363), sequence by
+    sequence in float64 log domain (the reference's per-frame normaliser and the offset of state 0's arcs cancel in exact arithmetic).  Returns (total log-prob -- NOT times the
+    weight, like the reference's return value --, weight * occupation probabilities [T*B, P])."""
+    out = np.asarray(nnet_output, np.float32).astype(np.float64); B = len(fsts); TB, P = out.shape; T = TB // B
+    post = np.zeros((TB, P), np.float64); tot = 0.0
+    for n, f in enumerate(fsts):
+        S = int(f.num_states); off = np.asarray(f.arc_offsets, np.int64); src = np.repeat(np.arange(S), np.diff(off)); dst = np.asarray(f.nextstate); pdf = np.asarray(f.ilabel) - 1; w = -np.asarray(f.weight, np.float64)
+        fin = np.where(np.isfinite(f.final), -np.asarray(f.final, np.float64), -np.inf)
+        alpha = np.full((T + 1, S), -np.inf); alpha[0, 0] = 0.0
+        for t in range(T):
+            x = alpha[t, src] + w + out[t * B + n, pdf]
+            for a in np.argsort(dst, kind="stable"): alpha[t + 1, dst[a]] = np.logaddexp(alpha[t + 1, dst[a]], x[a])
+        lp = np.logaddexp.reduce(alpha[T] + fin); tot += lp
+        beta = fin.copy()
+        for t in range(T - 1, -1, -1):
+            y = w + beta[dst] + out[t * B + n, pdf]; nb = np.full(S, -np.inf)
+            for a in range(len(src)): nb[src[a]] = np.logaddexp(nb[src[a]], y[a]); post[t * B + n, pdf[a]] += np.exp(alpha[t, src[a]] + y[a] - lp)
+            beta = nb
+    return float(tot), (float(weight) * post).astype(np.float32)
+
+def objf_oracle_e2e(den_fst, num_pdfs, fsts, nnet_output, leaky_hmm_coefficient=1.0e-05, l2_regularize=0.0, weight=1.0):
+    """ComputeChainObjfAndDerivE2e (chain/chain-training.cc:86-215), out-of-range penalty off"""
+    out = np.asarray(nnet_output, np.float32); B = len(fsts); TB, P = out.shape
+    den = den_oracle(den_fst, num_pdfs, out, B, leaky_hmm_coefficient, -weight)
+    num_lp, xent = e2e_num_oracle(fsts, num_pdfs, out, weight); deriv = den["deriv"].astype(np.float32) + xent
+    objf = num_lp - weight * den["objf"]; wt = weight * TB; l2 = 0.0
+    if l2_regularize != 0.0: scale = weight * l2_regularize; l2 = -0.5 * scale * float((out.astype(np.float64) ** 2).sum()); deriv = deriv - np.float32(scale) * out
+    return dict(objf=float(objf), l2_term=float(l2), weight=float(wt), deriv=deriv.astype(np.float32), xent_deriv=xent)
+
 def num_oracle(fsts, num_pdfs, nnet_output, weight=1.0):
     """NumeratorComputation (chain/chain-numerator.cc:115-213) sequence by sequence, log domain in double: returns (weight * total log-prob, weight * occupation
     probabilities [T*B, P]).  fsts: the UNMERGED supervision FSTs (the merged FST's total factorises over the sequences)."""

@@ -35,7 +35,7 @@ constexpr int kNoLabel = -1;
 constexpr float kDelta = 1.0F / 1024.0F;
 constexpr char kStringSeparator = '_';
 constexpr uint64 kLeftSemiring = 0x1, kRightSemiring = 0x2, kSemiring = 0x3, kCommutative = 0x4, kIdempotent = 0x8, kPath = 0x10;
-constexpr uint64 kExpanded = 0x1, kMutable = 0x2, kILabelSorted = 0x10000000ULL, kOLabelSorted = 0x40000000ULL, kTopSorted = 0x4000000000ULL, kFstProperties = 0x0000ffffffff0007ULL;
+constexpr uint64 kExpanded = 0x1, kMutable = 0x2, kILabelSorted = 0x10000000ULL, kOLabelSorted = 0x40000000ULL, kTopSorted = 0x4000000000ULL, kIEpsilons = 0x0000000001000000ULL, kFstProperties = 0x0000ffffffff0007ULL;
 inline std::string FST_FLAGS_fst_weight_separator = ",";
 enum DivideType { DIVIDE_LEFT, DIVIDE_RIGHT, DIVIDE_ANY };
 
@@ -153,12 +153,14 @@ template <class A> class VectorFst : public MutableFst<A> {
     uint64 p = kExpanded | kMutable;
     bool ils = ilabel_sorted_;
     if (test) {
-      bool top = true; ils = true;
+      bool top = true, ieps = false; ils = true;
       for (size_t s = 0; s < states_.size(); s++) for (size_t k = 0; k < states_[s].arcs.size(); k++) {
         if (states_[s].arcs[k].nextstate <= (StateId)s) top = false;
+        if (states_[s].arcs[k].ilabel == 0) ieps = true;
         if (k && states_[s].arcs[k].ilabel < states_[s].arcs[k - 1].ilabel) ils = false;
       }
       if (top) p |= kTopSorted;
+      if (ieps) p |= kIEpsilons;
     }
     if (ils) p |= kILabelSorted;
     return p & mask;

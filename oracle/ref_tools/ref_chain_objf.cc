@@ -5,6 +5,9 @@
 // One function of chain/chain-supervision.cc (which needs real OpenFst as a whole) is restated below because NumeratorComputation's constructor calls it:
 // ComputeFstStateTimes (:663-700).  --out-of-range-regularize is forced to 0: the reference applies that penalty on a coin flip (RandInt(0, 1), :273).
 //   ref-chain-objf <in.bin> <out.bin>
+// End-to-end supervisions (magic 0x4b37: the `sup` section is int32 state_offsets[B+1] followed by the B per-sequence FSTs concatenated in one CSR numbering, nextstate local to the
+// sequence, as in k3_chain_supervision_create): Supervision::e2e_fsts is filled instead of fst and ComputeChainObjfAndDeriv takes its end-to-end branch
+// (chain-training.cc:86-215) with chain::GenericNumeratorComputation (chain/chain-generic-numerator.cc, compiled unmodified).
 // in.bin : int32 {magic 0x4b35, den_states, den_start, den_arcs, num_pdfs, num_sequences, frames_per_sequence, sup_states, sup_arcs}; float {leaky, l2_regularize, supervision weight}
 //          den: int64 arc_offsets[S+1]; int32 ilabel[A], nextstate[A]; float weight[A], final_cost[S];   sup (merged): the same five arrays;   float nnet_output[T*B][P]
 // out.bin: float {objf, l2_term, weight}; float deriv[T*B][P]; float xent_deriv[T*B][P]
@@ -53,10 +56,25 @@ int main(int argc, char **argv) {
   if (argc != 3) { std::cerr << "usage: ref-chain-objf in.bin out.bin\n"; return 1; }
   FILE *fi = fopen(argv[1], "rb"); if (!fi) { std::cerr << "cannot open " << argv[1] << "\n"; return 1; }
   Reader r{fi}; int32_t h[9]; r.get(h, 9); float fo[3]; r.get(fo, 3);
-  if (h[0] != 0x4b35) { std::cerr << "bad magic\n"; return 1; }
+  if (h[0] != 0x4b35 && h[0] != 0x4b37) { std::cerr << "bad magic\n"; return 1; }
   const int32_t P = h[4], B = h[5], T = h[6];
   fst::StdVectorFst den; ReadFst(r, h[1], h[3], h[2], &den);
-  chain::Supervision sup; ReadFst(r, h[7], h[8], 0, &sup.fst);
+  chain::Supervision sup;
+  if (h[0] == 0x4b35) ReadFst(r, h[7], h[8], 0, &sup.fst);
+  else {
+    const int32_t S = h[7], A = h[8]; std::vector<int32_t> so(B + 1); r.get(so.data(), B + 1);
+    std::vector<int64_t> off(S + 1); r.get(off.data(), S + 1); std::vector<int32_t> il(A), nx(A); r.get(il.data(), A); r.get(nx.data(), A); std::vector<float> w(A), fin(S); r.get(w.data(), A); r.get(fin.data(), S);
+    sup.e2e_fsts.resize(B);
+    for (int32_t b = 0; b < B; b++) {
+      fst::StdVectorFst &f = sup.e2e_fsts[b];
+      for (int32_t s = so[b]; s < so[b + 1]; s++) f.AddState();
+      f.SetStart(0);
+      for (int32_t s = so[b]; s < so[b + 1]; s++) {
+        if (fin[s] != std::numeric_limits<float>::infinity()) f.SetFinal(s - so[b], fst::TropicalWeight(fin[s]));
+        for (int64_t a = off[s]; a < off[s + 1]; a++) f.AddArc(s - so[b], fst::StdArc(il[a], il[a], fst::TropicalWeight(w[a]), nx[a]));
+      }
+    }
+  }
   sup.weight = fo[2]; sup.num_sequences = B; sup.frames_per_sequence = T; sup.label_dim = P;
   Matrix<BaseFloat> out(T * B, P); for (int32_t i = 0; i < T * B; i++) r.get(out.RowData(i), P);
   fclose(fi);
