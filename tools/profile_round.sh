@@ -11,6 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 for c in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $B --no-two-pass --steps 1 --warmup 0 > $OUT/bench_pmc_$c.log 2>&1
 done
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_MFMA -o pmc -- $B --no-two-pass --steps 1 --warmup 0 > $OUT/bench_pmc_MFMA.log 2>&1
 cd $ROOT
 timeout 900 python bench.py --steps 5 --warmup 2 --measure-traffic > $OUT/bench_line.json 2> $OUT/bench_line.err
 # the decoder's frames by path (shipped library) and, when tools/build_variant.sh fp -DK3_FAST_PROF was run, the phases of the LDS-resident path

@@ -44,6 +44,17 @@ if len(traffic) == 2:
                "fetch_bytes_per_launch": traffic["FETCH_SIZE"], "write_bytes_per_launch": traffic["WRITE_SIZE"], "traffic_bytes_per_launch": traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"],
                "note": "FETCH_SIZE/WRITE_SIZE as reported (KB x 1024); the gfx950 x2 correction for wide coalesced loads does not apply to the decoder's narrow random accesses; uncalibrated for this pattern"},
               open(os.path.join(dst, f"hbm_traffic_{tag[:3]}.json"), "w"), indent=1)
+fm = find("pmc_MFMA", "*counter_collection.csv")
+if fm:      # MfmaUtil (gfx94x formula) per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs); rocprofv3 reports GRBM_GUI_ACTIVE summed over the XCDs
+    acc = {}
+    for r in csv.DictReader(open(fm)):
+        a = acc.setdefault(short(r["Kernel_Name"]), {"d": set(), "SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0}); a["d"].add(r["Dispatch_Id"])
+        if r["Counter_Name"] in a: a[r["Counter_Name"]] += float(r["Counter_Value"])
+    with open(os.path.join(dst, f"{tag}_bench_full_pipeline_pmc_mfma.csv"), "w") as f:
+        f.write(f"# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass, no trace domains) over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --no-extras --no-two-pass`, {tag}\n"
+                "# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs) -- the gfx94x MfmaUtil formula (GRBM_GUI_ACTIVE comes summed over the 8 XCDs)\nkernel,dispatches,SQ_VALU_MFMA_BUSY_CYCLES_per_dispatch,GRBM_GUI_ACTIVE_per_dispatch,mfma_util\n")
+        for k, a in sorted(acc.items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES"]):
+            if a["SQ_VALU_MFMA_BUSY_CYCLES"] > 0 and a["GRBM_GUI_ACTIVE"] > 0: f.write("%s,%d,%.0f,%.0f,%.3f\n" % (k, len(a["d"]), a["SQ_VALU_MFMA_BUSY_CYCLES"] / len(a["d"]), a["GRBM_GUI_ACTIVE"] / len(a["d"]), a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)))
 ts = find("train", "*kernel_stats.csv")
 if ts: open(os.path.join(dst, f"{tag}_chain_train_kernel_stats.csv"), "w").write("# rocprofv3 --kernel-trace --stats of kaldi_amd/adapter/_build/nnet3-chain-train, 24 iterations, benchmark model, 64 sequences x 50 frames (tools/debug_chain_train.py, K3_TRAIN_BIG=1); iteration times without the profiler: " + (open(os.path.join(src, "chain_train_iterations.txt")).read().strip() if os.path.exists(os.path.join(src, "chain_train_iterations.txt")) else "") + "\n" + open(ts).read())
 fp = os.path.join(src, "literal_frames_by_path.txt")
