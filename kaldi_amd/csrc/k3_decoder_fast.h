@@ -198,9 +198,12 @@ __device__ __forceinline__ bool fast_import(const DecParams &p, char *arena, con
   return ok;
 }
 
+#ifndef K3_FAST_INLINE
+#define K3_FAST_INLINE __forceinline__
+#endif
 // One frame.  Returns the number of tokens of the new frame, or -1 when the frame has to be redone on the general path (nothing the next frame reads
 // has been published; sh.n_link / sh.n_next are restored by the caller).
-__device__ __forceinline__ int lit_frame_fast(const DecParams &p, Shared &sh, FastShared &fs, char *arena, const LitLane &q, const LaneCtx &c, int f, const float *ll, long long cur_base, int n_cur,
+__device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, FastShared &fs, char *arena, const LitLane &q, const LaneCtx &c, int f, const float *ll, long long cur_base, int n_cur,
                                               unsigned &hash_size_io, int *ord_nxt, int cap_tokens, unsigned &cnt_emit_io, unsigned &cnt_os_io, unsigned &cnt_eps_io) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64; const float kInf = __builtin_inff();
   unsigned *N_cost = reinterpret_cast<unsigned *>(arena + oN_cost), *N_abeg = reinterpret_cast<unsigned *>(arena + oN_abeg), *X = reinterpret_cast<unsigned *>(arena + oX);

@@ -6,7 +6,7 @@
 #endif
 #define K3_DEC_BLOCK K3_LIT_BLOCK
 #ifndef K3_LIT_WPE
-#define K3_LIT_WPE 4      // two 512-thread workgroups per CU (each within 80 KB of LDS): 4 waves per SIMD
+#define K3_LIT_WPE 4      // two 512-thread workgroups per CU (each within 80 KB of LDS): 4 waves per SIMD = 128 VGPRs per lane (overridable for register-pressure experiments)
 #endif
 #include "k3_decoder_dev.h"
 
