@@ -28,6 +28,7 @@ struct BatchedThreadedNnet3CudaOnlinePipelineConfig {      // cudadecoder/batche
   float acoustic_scale = 0.1f; int32_t frame_subsampling_factor = 1, frames_per_chunk = 50, max_utterance_frames = 6000;
   // end-pointing (online2/online-endpoint.h rule 1-style: trailing silence is not known without a silence-phone list; the rule on the final relative cost is applied)
   float endpoint_max_relative_cost = 2.0f; int32_t endpoint_min_frames = 30;
+  std::string ivector_extraction_config;      // OnlineNnet2FeaturePipelineConfig::ivector_extraction_config (models with an i-vector input)
   BatchedThreadedNnet3CudaOnlinePipelineConfig() { memset(&feature_opts, 0, sizeof feature_opts); k3_decoder_config_default(&decoder_opts); }
 };
 
@@ -42,7 +43,9 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     K3H_CHECK_K3(k3_feat_plan_create(&config_.feature_opts, &plan_)); fdim_ = k3_feat_dim(plan_);
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(am_nnet, &ni)); N_ = ni.output_dim;
     if (ni.input_dim != fdim_) K3H_ERR << "Feature dimension " << fdim_ << " does not match the model's input dimension " << ni.input_dim;
-    if (ni.ivector_dim > 0) K3H_ERR << "this pipeline class does not extract i-vectors";
+    if (!config_.ivector_extraction_config.empty()) { iv_info_ = ReadIvectorExtractionConfig(config_.ivector_extraction_config); ivx_ = CreateIvectorExtractor(iv_info_, fdim_); }
+    if ((ni.ivector_dim > 0) != (ivx_ != nullptr) || (ivx_ && ni.ivector_dim != iv_info_.ie.ivector_dim))
+      K3H_ERR << "Neural net expects 'ivector' features with dimension " << ni.ivector_dim << " but you provided " << (ivx_ ? iv_info_.ie.ivector_dim : 0);
     if (N_ != trans_.num_pdfs) K3H_ERR << "Model output dimension " << N_ << " != number of pdfs in the transition model " << trans_.num_pdfs;
     std::vector<float> lp; if (ni.has_priors) { lp.resize(N_); K3H_CHECK_K3(k3_nnet_get_priors(am_nnet, lp.data())); for (float &p : lp) p = logf(p); }
     K3H_CHECK_K3(k3_fst_create(decode_fst.NumStates(), decode_fst.start, decode_fst.arc_offsets.data(), decode_fst.ilabel.data(), decode_fst.olabel.data(), decode_fst.weight.data(),
@@ -53,6 +56,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     const int s = config_.frame_subsampling_factor; C_ = std::max(s, config_.frames_per_chunk / s * s);
     features_.reset(new OnlineFeatures(plan_, config_.feature_opts, nch_));
     net_.reset(new StaticNnet3(am_nnet, nch_, nch_, C_, s, lp.empty() ? nullptr : lp.data(), config_.acoustic_scale));
+    if (ivx_) ivs_.reset(new OnlineIvectors(ivx_, iv_info_.right_context, nch_));
     samples_per_chunk_ = C_ * (int)(config_.feature_opts.samp_freq * 0.001 * config_.feature_opts.frame_shift_ms);
     pend_cap_ = (size_t)(2 * C_ + 8); pend_.resize(nch_); for (auto &p : pend_) p.need(pend_cap_ * fdim_); tmp_.need(pend_cap_ * fdim_);
     chan_.resize(nch_); for (int c = nch_ - 1; c >= 0; c--) free_.push_back(c);
@@ -63,6 +67,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     WaitForLatticeCallbacks();
     { std::lock_guard<std::mutex> l(m_); stop_ = true; } wcv_.notify_all();
     for (auto &w : workers_) w.join();
+    ivs_.reset(); if (ivx_) k3_ivector_destroy(ivx_);
     net_.reset(); features_.reset(); k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
   }
   int32_t GetNSampsPerChunk() const { return samples_per_chunk_; }
@@ -95,6 +100,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     { int64_t off = 0;
       for (size_t i = 0; i < n; i++) { Chan &c = chan_[chs[i]]; if ((size_t)(c.pend + nf[i]) > pend_cap_) K3H_ERR << "DecodeBatch: a chunk longer than GetNSampsPerChunk() samples";
         if (nf[i] > 0) K3O_HIP(hipMemcpy(pend_[chs[i]].p + (size_t)c.pend * fdim_, d_feats + off * fdim_, (size_t)nf[i] * fdim_ * 4, hipMemcpyDeviceToDevice));
+        if (ivs_) { if (first[i]) ivs_->Reset(chs[i]); ivs_->Accept(chs[i], d_feats + off * fdim_, nf[i], last[i]); }
         c.pend += nf[i]; c.frames += nf[i]; off += nf[i]; } }
     std::vector<char> is_last(nch_, 0), closed(nch_, 0); for (size_t i = 0; i < n; i++) is_last[chs[i]] = last[i];
     bool need_advance = !fresh.empty();
@@ -113,7 +119,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
         } }
       std::vector<int64_t> ro(nch_ + 1, 0); std::vector<int32_t> idx;
       if (!run.empty()) {
-        auto res = net_->Pass(run, new_.p, n_new, lasts);
+        auto res = net_->Pass(run, new_.p, n_new, lasts, ivs_ ? ivs_->Gather(run) : nullptr);
         std::vector<std::vector<std::pair<int, int>>> per(nch_); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
         for (int ch = 0; ch < nch_; ch++) { int64_t k = 0; for (auto &r : per[ch]) { for (int j = 0; j < r.second; j++) idx.push_back(r.first + j); k += r.second; } ro[ch + 1] = ro[ch] + k; }
       }
@@ -182,7 +188,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
   }
   const BatchedThreadedNnet3CudaOnlinePipelineConfig config_; const TransitionInfo &trans_;
   k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0; int32_t graph_start_ = 0; size_t pend_cap_ = 0;
-  std::unique_ptr<OnlineFeatures> features_; std::unique_ptr<StaticNnet3> net_;
+  std::unique_ptr<OnlineFeatures> features_; std::unique_ptr<StaticNnet3> net_; std::unique_ptr<OnlineIvectors> ivs_; k3_ivector *ivx_ = nullptr; IvectorExtractionInfo iv_info_;
   std::vector<Chan> chan_; std::vector<DevBuf<float>> pend_; DevBuf<float> tmp_, new_, ll_; DevBuf<int32_t> llidx_;
   std::mutex m_; std::condition_variable wcv_, done_cv_; bool stop_ = false; int n_callbacks_not_done_ = 0;
   std::map<CorrelationID, int> corr2chan_; std::vector<int> free_; std::map<CorrelationID, LatticeCallback> lat_cb_; std::map<CorrelationID, BestPathCallback> best_cb_;

@@ -29,7 +29,7 @@ int main(int argc, char **argv) {
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, frames_per_chunk = 51, subsampling = 1, num_streaming = 2000;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, max_frames = 6000;
     float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; int32_t det_max_mem = 50000000;
-    std::string feature_type = "mfcc", mfcc_config, fbank_config, word_syms, use_gpu = "yes";
+    std::string feature_type = "mfcc", mfcc_config, fbank_config, word_syms, use_gpu = "yes", ivector_config;
     po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
     po.Register("file-limit", &num_todo, "Limits the number of files that are processed by this driver.");
@@ -53,6 +53,8 @@ int main(int argc, char **argv) {
     po.Register("main-q-capacity", &main_q, "Max tokens alive on one frame of one utterance (-1 = 4 * max-active, capped)"); po.Register("aux-q-capacity", &aux_q, "Max arcs considered on one frame (-1 = 3 * main-q-capacity)");
     po.Register("ntokens-pre-allocated", &ntok_pre, "Tokens kept per utterance for all frames"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
     po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
+    po.Register("ivector-extraction-config", &ivector_config, "Configuration file for online iVector extraction, see class OnlineIvectorExtractionConfig in the code.  Every chunk the network evaluates gets the extractor's "
+                "latest i-vector for its stream (the estimate at the last multiple of --ivector-period among the frames seen so far), as in nnet3/decodable-online-looped.cc");
     po.Register("frames-per-chunk", &frames_per_chunk, "Number of feature frames evaluated per chunk and channel (a multiple of --frame-subsampling-factor)");
     po.Register("max-utterance-frames", &max_frames, "Upper bound on the decoded (subsampled) frames of one utterance: sizes the per-channel frame tables");
     po.Register("feature-type", &feature_type, "Base feature type [mfcc, fbank]"); po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc.conf)");
@@ -76,6 +78,10 @@ int main(int argc, char **argv) {
     k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(nnet3_rx.c_str(), &nnet));
     k3_nnet_info ninfo; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ninfo));
     if (ninfo.input_dim != fdim) K3H_ERR << "Feature dimension " << fdim << " does not match the model's input dimension " << ninfo.input_dim;
+    k3_ivector *ivx = nullptr; IvectorExtractionInfo iv_info;
+    if (!ivector_config.empty()) { iv_info = ReadIvectorExtractionConfig(ivector_config); ivx = CreateIvectorExtractor(iv_info, fdim); }
+    if ((ninfo.ivector_dim > 0) != (ivx != nullptr) || (ivx && ninfo.ivector_dim != iv_info.ie.ivector_dim))
+      K3H_ERR << "Neural net expects 'ivector' features with dimension " << ninfo.ivector_dim << " but you provided " << (ivx ? iv_info.ie.ivector_dim : 0);
     if (ninfo.output_dim != ti.num_pdfs) K3H_ERR << "Model output dimension " << ninfo.output_dim << " != number of pdfs in the transition model " << ti.num_pdfs;
     std::vector<float> log_priors;
     if (ninfo.has_priors) { log_priors.resize(ninfo.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet, log_priors.data())); for (float &p : log_priors) p = logf(p); }
@@ -93,6 +99,7 @@ int main(int argc, char **argv) {
     K3H_CHECK_K3(k3_decoder_init_decoding(dec, nch, max_frames, nullptr));
     OnlineFeatures features(plan, fopts, nch);
     StaticNnet3 net(nnet, nch, nch, C, subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale);
+    std::unique_ptr<OnlineIvectors> ivs; if (ivx) ivs.reset(new OnlineIvectors(ivx, iv_info.right_context, nch));
     const int shift = (int)(fopts.samp_freq * 0.001 * fopts.frame_shift_ms), chunk_samples = C * shift;
 
     auto scp = ReadScp(wav_rspec);
@@ -145,6 +152,7 @@ int main(int argc, char **argv) {
             Chan &c = chan[chs[i]];
             if ((size_t)(c.pend + nf[i]) > pend_cap) K3H_ERR << "internal: pending-frame buffer";
             if (nf[i] > 0) K3O_HIP(hipMemcpy(pend[chs[i]].p + (size_t)c.pend * fdim, d_feats + off * fdim, (size_t)nf[i] * fdim * 4, hipMemcpyDeviceToDevice));
+            if (ivs) { if (first[i]) ivs->Reset(chs[i]); ivs->Accept(chs[i], d_feats + off * fdim, nf[i], last[i]); }      // the extractor sees every frame as soon as it exists
             c.pend += nf[i]; off += nf[i];
           } }
         std::vector<char> is_last(nch, 0), closed(nch, 0); for (size_t i = 0; i < chs.size(); i++) is_last[chs[i]] = last[i];
@@ -168,7 +176,7 @@ int main(int argc, char **argv) {
             } }
           std::vector<int64_t> ro(nch + 1, 0); std::vector<int32_t> idx;
           if (!run.empty()) {
-            auto res = net.Pass(run, newbuf.p, n_new, lasts);
+            auto res = net.Pass(run, newbuf.p, n_new, lasts, ivs ? ivs->Gather(run) : nullptr);
             // end of stream: frames still waiting for right context may take more passes
             std::vector<std::vector<std::pair<int, int>>> per(nch); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
             for (int ch = 0; ch < nch; ch++) { int64_t n = 0; for (auto &r : per[ch]) { for (int k = 0; k < r.second; k++) idx.push_back(r.first + k); n += r.second; } ro[ch + 1] = ro[ch] + n; }
@@ -216,6 +224,7 @@ int main(int argc, char **argv) {
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
     K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio << " RealTimeX: " << total_audio / total_time;
+    ivs.reset(); if (ivx) k3_ivector_destroy(ivx);
     k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan);
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }

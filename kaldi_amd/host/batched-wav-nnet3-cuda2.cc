@@ -112,16 +112,7 @@ int main(int argc, char **argv) {
     k3_ivector *ivx = nullptr; IvectorExtractionInfo iv_info; int32_t iv_period = 0;
     if (!ivector_config.empty()) {
       iv_info = ReadIvectorExtractionConfig(ivector_config);
-      k3_ivector_model m; memset(&m, 0, sizeof m);
-      m.feat_dim = iv_info.global_cmvn_stats.cols - 1; m.lda_rows = iv_info.lda_rows; m.lda_cols = iv_info.lda_cols; m.num_gauss = iv_info.ubm.num_gauss; m.ivector_dim = iv_info.ie.ivector_dim;
-      m.lda = iv_info.lda.data(); m.global_cmvn_stats = iv_info.global_cmvn_stats.data.data(); m.gconsts = iv_info.ubm.gconsts.data(); m.means_invvars = iv_info.ubm.means_invvars.data(); m.inv_vars = iv_info.ubm.inv_vars.data();
-      m.M = iv_info.ie.M.data(); m.sigma_inv = iv_info.ie.sigma_inv.data(); m.prior_offset = iv_info.ie.prior_offset;
-      k3_ivector_opts o; k3_ivector_opts_default(&o);
-      o.left_context = iv_info.left_context; o.right_context = iv_info.right_context; o.num_gselect = iv_info.num_gselect; o.min_post = iv_info.min_post; o.posterior_scale = iv_info.posterior_scale; o.max_count = iv_info.max_count;
-      o.ivector_period = iv_info.ivector_period; o.num_cg_iters = iv_info.num_cg_iters; o.online_cmvn_iextractor = iv_info.online_cmvn_iextractor;
-      o.cmvn.cmn_window = iv_info.cmn_window; o.cmvn.speaker_frames = iv_info.speaker_frames; o.cmvn.global_frames = iv_info.global_frames; o.cmvn.normalize_mean = iv_info.normalize_mean; o.cmvn.normalize_variance = iv_info.normalize_variance;
-      if (m.feat_dim != fdim) K3H_ERR << "The i-vector extractor expects features of dimension " << m.feat_dim << " but the feature config gives " << fdim;
-      K3H_CHECK_K3(k3_ivector_create(&m, &o, &ivx)); iv_period = iv_info.ivector_period;
+      ivx = CreateIvectorExtractor(iv_info, fdim); iv_period = iv_info.ivector_period;
     }
     if ((ninfo.ivector_dim > 0) != (ivx != nullptr) || (ivx && ninfo.ivector_dim != iv_info.ie.ivector_dim))
       K3H_ERR << "Neural net expects 'ivector' features with dimension " << ninfo.ivector_dim << " but you provided " << (ivx ? iv_info.ie.ivector_dim : 0);

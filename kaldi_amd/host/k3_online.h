@@ -57,8 +57,10 @@ class StaticNnet3 {
     if (C_ <= 0 || C_ % s_) K3H_ERR << "--frames-per-chunk must be a positive multiple of --frame-subsampling-factor";
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
     dim_ = ni.input_dim; odim_ = ni.output_dim; Lc_ = (ni.left_context + s_ - 1) / s_ * s_; Rc_ = ni.right_context; P_ = Lc_ + C_ + Rc_; rps_ = (P_ + s_ - 1) / s_; S_ = Lc_ + Rc_ + C_ + 2 * s_;
-    std::vector<int32_t> nf(B_, P_);
-    K3H_CHECK_K3(k3_nnet_batch_create(nnet, B_, nf.data(), s_, log_priors, acoustic_scale, &batch_));
+    std::vector<int32_t> nf(B_, P_); ivdim_ = ni.ivector_dim;
+    // models with the recipes' i-vector input: every slot is an "utterance" with ONE i-vector (the --ivectors form of the planner), handed in per pass
+    if (ivdim_ > 0) { K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, B_, nf.data(), s_, log_priors, acoustic_scale, C_, 0, nullptr, &batch_)); iv_.need((size_t)B_ * ivdim_); }
+    else K3H_CHECK_K3(k3_nnet_batch_create(nnet, B_, nf.data(), s_, log_priors, acoustic_scale, &batch_));
     for (int k = 0; k < 2; k++) { stash_[k].need((size_t)nch_ * S_ * dim_); K3O_HIP(hipMemset(stash_[k].p, 0, (size_t)nch_ * S_ * dim_ * 4)); }
     inp_.need((size_t)B_ * P_ * dim_); out_.need((size_t)B_ * rps_ * odim_);
     t_next_.assign(nch_, 0); n_seen_.assign(nch_, 0); lo_.assign(nch_, 0);
@@ -69,7 +71,9 @@ class StaticNnet3 {
   void Reset(int ch) { t_next_[ch] = n_seen_[ch] = lo_[ch] = 0; }
   // One planned forward.  d_new: the new frames of the slots back to back (n_new[i] rows each, may be null when all are 0).  Returns per
   // slot (first row, count) of its valid output rows in Out().
-  std::vector<std::pair<int, int>> Pass(const std::vector<int> &channels, const float *d_new, const std::vector<int> &n_new, const std::vector<char> &last) {
+  // d_iv (models with an i-vector input): [channels.size() x IvectorDim()] on the device, the i-vector each slot's chunk is evaluated with (decodable-online-looped.cc:166-205: one per chunk)
+  std::vector<std::pair<int, int>> Pass(const std::vector<int> &channels, const float *d_new, const std::vector<int> &n_new, const std::vector<char> &last, const float *d_iv = nullptr) {
+    if ((ivdim_ > 0) != (d_iv != nullptr)) K3H_ERR << "StaticNnet3::Pass: the model " << (ivdim_ > 0 ? "has" : "has no") << " i-vector input";
     std::vector<int32_t> ist((size_t)B_ * P_, -1), inw((size_t)B_ * P_, -1), ust((size_t)nch_ * S_, -1), unw((size_t)nch_ * S_, -1);
     std::vector<char> touched(nch_, 0); for (int ch : channels) touched[ch] = 1;
     for (int ch = 0; ch < nch_; ch++) if (!touched[ch]) for (int64_t k = 0; k < n_seen_[ch] - lo_[ch]; k++) ust[(size_t)ch * S_ + k] = (int32_t)(ch * S_ + k);
@@ -95,15 +99,72 @@ class StaticNnet3 {
     K3H_CHECK_K3(k3_mat_copy_rows(Bn, dim_, nch_ * S_, dim_, A, dim_, i2_.p, nullptr));
     if (total_new > 0) K3H_CHECK_K3(k3_mat_add_rows(1.0f, d_new, dim_, i3_.p, Bn, dim_, nch_ * S_, dim_, nullptr));
     cur_ ^= 1;
-    K3H_CHECK_K3(k3_nnet_forward(batch_, inp_.p, dim_, out_.p, odim_, nullptr));
+    if (ivdim_ > 0) {
+      K3O_HIP(hipMemset(iv_.p, 0, (size_t)B_ * ivdim_ * 4)); K3O_HIP(hipMemcpy(iv_.p, d_iv, channels.size() * (size_t)ivdim_ * 4, hipMemcpyDeviceToDevice));
+      K3H_CHECK_K3(k3_nnet_forward_ivector(batch_, inp_.p, dim_, iv_.p, ivdim_, out_.p, odim_, nullptr));
+    } else K3H_CHECK_K3(k3_nnet_forward(batch_, inp_.p, dim_, out_.p, odim_, nullptr));
     return res;
   }
   const float *Out() const { return out_.p; }
   bool Pending(int ch) const { return t_next_[ch] < n_seen_[ch]; }
+  int IvectorDim() const { return ivdim_; }
  private:
+  int ivdim_ = 0; DevBuf<float> iv_;
   int B_, nch_, C_, s_, dim_ = 0, odim_ = 0, Lc_ = 0, Rc_ = 0, P_ = 0, rps_ = 0, S_ = 0, cur_ = 0;
   k3_nnet_batch *batch_ = nullptr;
   DevBuf<float> stash_[2], inp_, out_; DevBuf<int32_t> i0_, i1_, i2_, i3_;
   std::vector<int64_t> t_next_, n_seen_, lo_;
+};
+// The i-vector extractor of an --ivector-extraction-config (OnlineNnet2FeaturePipelineInfo's ivector_extractor_info, online2/online-nnet2-feature-pipeline.cc:70-80) on the GPU
+inline k3_ivector *CreateIvectorExtractor(const IvectorExtractionInfo &iv_info, int fdim) {
+  k3_ivector_model m; memset(&m, 0, sizeof m);
+  m.feat_dim = iv_info.global_cmvn_stats.cols - 1; m.lda_rows = iv_info.lda_rows; m.lda_cols = iv_info.lda_cols; m.num_gauss = iv_info.ubm.num_gauss; m.ivector_dim = iv_info.ie.ivector_dim;
+  m.lda = iv_info.lda.data(); m.global_cmvn_stats = iv_info.global_cmvn_stats.data.data(); m.gconsts = iv_info.ubm.gconsts.data(); m.means_invvars = iv_info.ubm.means_invvars.data(); m.inv_vars = iv_info.ubm.inv_vars.data();
+  m.M = iv_info.ie.M.data(); m.sigma_inv = iv_info.ie.sigma_inv.data(); m.prior_offset = iv_info.ie.prior_offset;
+  k3_ivector_opts o; k3_ivector_opts_default(&o);
+  o.left_context = iv_info.left_context; o.right_context = iv_info.right_context; o.num_gselect = iv_info.num_gselect; o.min_post = iv_info.min_post; o.posterior_scale = iv_info.posterior_scale; o.max_count = iv_info.max_count;
+  o.ivector_period = iv_info.ivector_period; o.num_cg_iters = iv_info.num_cg_iters; o.online_cmvn_iextractor = iv_info.online_cmvn_iextractor;
+  o.cmvn.cmn_window = iv_info.cmn_window; o.cmvn.speaker_frames = iv_info.speaker_frames; o.cmvn.global_frames = iv_info.global_frames; o.cmvn.normalize_mean = iv_info.normalize_mean; o.cmvn.normalize_variance = iv_info.normalize_variance;
+  if (m.feat_dim != fdim) K3H_ERR << "The i-vector extractor expects features of dimension " << m.feat_dim << " but the feature config gives " << fdim;
+  k3_ivector *ivx = nullptr; K3H_CHECK_K3(k3_ivector_create(&m, &o, &ivx));
+  return ivx;
+}
+
+// Per-channel i-vectors of a stream, the C++ twin of kaldi_amd/online.py: the extractor sees every feature frame as soon as it exists; Latest() is the i-vector the reference's online
+// decodable hands the network for a chunk (nnet3/decodable-online-looped.cc:182-197 over OnlineIvectorFeature with use_most_recent_ivector): the estimate made at the last multiple
+// of --ivector-period among the frames ready (all frames so far minus the LDA splice's right context while the stream goes on), zero before the first.  The estimates are rows of
+// the whole-utterance extraction (k3_ivector_extract_batch: row k = statistics of frames 0 .. k * period), obtained by re-extracting the stream's prefix.
+class OnlineIvectors {
+ public:
+  OnlineIvectors(k3_ivector *iv, int right_context, int nch) : iv_(iv), rc_(right_context), hist_(nch) {
+    k3_ivector_info i; K3H_CHECK_K3(k3_ivector_get_info(iv, &i)); F_ = i.feat_dim; R_ = i.ivector_dim; period_ = i.ivector_period; latest_.need((size_t)nch * R_); K3O_HIP(hipMemset(latest_.p, 0, (size_t)nch * R_ * 4));
+  }
+  int Dim() const { return R_; }
+  void Reset(int ch) { hist_[ch].n = 0; }
+  // n new feature rows of the channel (device, F_ wide, contiguous); finished: the stream's audio has ended.  Updates Row(ch).
+  void Accept(int ch, const float *d_rows, int n, bool finished) {
+    Hist &h = hist_[ch];
+    if (h.n + (size_t)n > h.cap) { const size_t cap = (h.n + n) * 2 + 256; float *q = nullptr; K3O_HIP(hipMalloc((void **)&q, cap * F_ * 4)); if (h.n) K3O_HIP(hipMemcpy(q, h.p, h.n * F_ * 4, hipMemcpyDeviceToDevice)); if (h.p) (void)hipFree(h.p); h.p = q; h.cap = cap; }
+    if (n > 0) K3O_HIP(hipMemcpy(h.p + h.n * F_, d_rows, (size_t)n * F_ * 4, hipMemcpyDeviceToDevice));
+    h.n += n;
+    const long long ready = (long long)h.n - (finished ? 0 : rc_);
+    float *dst = latest_.p + (size_t)ch * R_;
+    if (ready <= 0) { K3O_HIP(hipMemset(dst, 0, (size_t)R_ * 4)); return; }
+    const long long row = (ready - 1) / period_; const int64_t nn = std::min<long long>((long long)h.n, row * period_ + rc_ + 1), off[2] = {0, nn};
+    const int64_t rows = k3_ivector_num_rows(iv_, 1, off, nullptr);
+    K3H_CHECK_K3(k3_ivector_extract_batch(iv_, h.p, F_, off, 1, rows_.need((size_t)rows * R_), R_, nullptr));
+    K3O_HIP(hipMemcpy(dst, rows_.p + (size_t)row * R_, (size_t)R_ * 4, hipMemcpyDeviceToDevice));
+  }
+  const float *Row(int ch) const { return latest_.p + (size_t)ch * R_; }
+  // the rows of the listed channels back to back (what StaticNnet3::Pass takes)
+  const float *Gather(const std::vector<int> &channels) {
+    float *g = gather_.need(std::max<size_t>(channels.size(), 1) * R_);
+    for (size_t i = 0; i < channels.size(); i++) K3O_HIP(hipMemcpy(g + i * R_, Row(channels[i]), (size_t)R_ * 4, hipMemcpyDeviceToDevice));
+    return g;
+  }
+  ~OnlineIvectors() { for (auto &h : hist_) if (h.p) (void)hipFree(h.p); }
+ private:
+  struct Hist { float *p = nullptr; size_t cap = 0, n = 0; };
+  k3_ivector *iv_; int rc_, F_ = 0, R_ = 0, period_ = 1; std::vector<Hist> hist_; DevBuf<float> latest_, rows_, gather_;
 };
 }  // namespace k3host

@@ -48,6 +48,7 @@ class BatchedIvectorExtractor:
         self._L = _l.load(); self._h = ctypes.c_void_p(); self.info = info
         m = info.model(); o = info.opts(**overrides) if hasattr(info, "opts") else info._opts
         _l.check(self._L.k3_ivector_create(ctypes.byref(m), ctypes.byref(o), ctypes.byref(self._h)))
+        self.left_context, self.right_context = int(o.left_context), int(o.right_context)      # of the LDA splice: an i-vector for frame t needs the features up to t + right_context
         i = _l.IvectorInfo(); _l.check(self._L.k3_ivector_get_info(self._h, ctypes.byref(i)))
         self.feat_dim, self.lda_dim, self.num_gauss, self.ivector_dim, self.ivector_period = i.feat_dim, i.lda_dim, i.num_gauss, i.ivector_dim, i.ivector_period
 

@@ -86,7 +86,9 @@ class BatchedStaticNnet3:
         self.Lc = -(-nnet.info.left_context // s) * s; self.Rc = int(nnet.info.right_context)
         self.P = self.Lc + C + self.Rc; self.rows_per_slot = -(-self.P // s)
         self.dim = nnet.info.input_dim; self.dev = torch.device(device)
+        self.ivector_dim = int(nnet.info.ivector_dim)      # models with the recipes' i-vector input: one i-vector per slot and pass (RunBatch(..., ivectors=))
         self.batch = NnetBatch(nnet, [self.P] * self.B, s, log_priors, acoustic_scale)
+        self.iv = torch.zeros((self.B, max(1, self.ivector_dim)), dtype=torch.float32, device=self.dev) if self.ivector_dim else None
         self.S = self.Lc + self.Rc + C + 2 * s             # frames a channel can have waiting between calls (generous)
         self.stash = [torch.zeros((self.nch * self.S, self.dim), dtype=torch.float32, device=self.dev) for _ in range(2)]
         self.cur = 0
@@ -97,7 +99,7 @@ class BatchedStaticNnet3:
     def GetNOutputFramesPerChunk(self): return self.C // self.s
     def GetTotalNnet3RightContext(self): return self.Rc
 
-    def _pass(self, channels, new, n_new, last):
+    def _pass(self, channels, new, n_new, last, ivectors=None):
         """one planned forward over the slots: returns per-slot (row0, count) in self.out"""
         B, P, S, s = len(channels), self.P, self.S, self.s
         idx_st = np.full(self.B * P, -1, np.int32); idx_nw = np.full(self.B * P, -1, np.int32)
@@ -131,23 +133,29 @@ class BatchedStaticNnet3:
         M(Bn).CopyRows(M(A), d(upd_st))
         if new is not None and new.shape[0] > 0: M(Bn).AddRows(1.0, M(new), d(upd_nw))
         self.cur ^= 1
-        self.batch.forward(self.inp, out=self.out)
+        if self.ivector_dim:
+            if ivectors is None or ivectors.shape != (B, self.ivector_dim): raise ValueError("this model has an i-vector input: pass ivectors [len(channels), %d]" % self.ivector_dim)
+            self.iv.zero_(); self.iv[:B] = ivectors.to(self.dev, torch.float32)
+            self.batch.forward(self.inp, out=self.out, ivectors=self.iv)
+        else: self.batch.forward(self.inp, out=self.out)
         return res
 
-    def RunBatch(self, channels, chunks, is_first_chunk, is_last_chunk):
+    def RunBatch(self, channels, chunks, is_first_chunk, is_last_chunk, ivectors=None):
+        """ivectors (models with an i-vector input): [len(channels), ivector_dim], the i-vector every listed channel's chunk is evaluated with -- DecodableNnetLoopedOnlineBase::AdvanceChunk
+        (nnet3/decodable-online-looped.cc:166-205) hands the network ONE i-vector per chunk, the extractor's latest"""
         if len(channels) > self.B or len(set(channels)) != len(channels): raise ValueError("at most one chunk per channel and max_batch_size slots")
         n_new = [int(c.shape[0]) for c in chunks]
         if any(n > self.C for n in n_new): raise ValueError("a chunk has more than frames_per_chunk frames")
         for ch, first in zip(channels, is_first_chunk):
             if first: self.t_next[ch] = self.n_seen[ch] = self.stash_lo[ch] = 0
         new = torch.cat([c.to(self.dev, torch.float32) for c in chunks], 0) if chunks else None
-        res = self._pass(list(channels), new, n_new, list(is_last_chunk))
+        res = self._pass(list(channels), new, n_new, list(is_last_chunk), ivectors)
         outs = [[self.out[r0:r0 + n].clone()] if n else [] for r0, n in res]
         # end of stream: the frames that were waiting for right context may need more passes than one chunk's worth of output rows
         pending = [i for i, ch in enumerate(channels) if is_last_chunk[i] and self.t_next[ch] < self.n_seen[ch]]
         while pending:
             chs = [channels[i] for i in pending]
-            res2 = self._pass(chs, None, [0] * len(chs), [True] * len(chs))
+            res2 = self._pass(chs, None, [0] * len(chs), [True] * len(chs), None if ivectors is None else ivectors[pending])
             for i, (r0, n) in zip(pending, res2):
                 if n: outs[i].append(self.out[r0:r0 + n].clone())
             pending = [i for i in pending if self.t_next[channels[i]] < self.n_seen[channels[i]]]

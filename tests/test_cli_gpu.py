@@ -555,3 +555,53 @@ def test_batched_wav_nnet3_cuda2_ctm_output(tmp_path):
         assert np.allclose([float(l[5]) for l in mine], conf[key], atol=0.011), (key, mine, conf[key])
         starts = [float(l[2]) for l in mine]; ends = [float(l[2]) + float(l[3]) for l in mine]
         assert starts == sorted(starts) and all(e >= b for b, e in zip(starts, ends)) and ends[-1] <= lens[k] / 16000.0 + 0.05, (key, mine)
+
+
+def test_online_program_with_an_ivector_model_equals_the_python_pipeline(tmp_path):
+    """batched-wav-nnet3-cuda-online --ivector-extraction-config: every chunk the network evaluates gets the extractor's latest i-vector of its stream (the rule of
+    nnet3/decodable-online-looped.cc:182-197: the estimate at the last multiple of --ivector-period among the frames seen, minus the splice's right context while the stream goes on).
+    The C++ drivers (kaldi_amd/host/k3_online.h: OnlineIvectors, StaticNnet3 with an i-vector per slot) and the Python ones (kaldi_amd/online.py, whose choice of i-vector rows
+    tests/test_online_gpu.py holds to the whole-utterance extraction) are fed the same chunks and must write the same lattices."""
+    import torch
+    from oracle import kaldi_io as kio
+    from kaldi_amd import feat, nnet3, decoder, online, fst as kfst
+    from kaldi_amd.ivector import OnlineIvectorExtractionInfo, BatchedIvectorExtractor
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001]; IV = os.path.join(ROOT, "tests", "golden", "ivector")
+    _wavs(td, lens); open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    r = subprocess.run([os.path.join(BIN, "compute-fbank-feats-cuda"), f"--config={td}/fbank.conf", f"scp:{td}/wav.scp", f"ark:{td}/f.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr
+    feats = kio.read_ark(f"{td}/f.ark"); allf = np.concatenate(list(feats.values())).astype(np.float64); rng = np.random.default_rng(8)
+    tm = lambda path, m: open(path, "w").write(" [\n" + "\n".join("  " + " ".join(repr(float(x)) for x in row) for row in m) + " ]\n")
+    st = np.zeros((2, 41)); st[0, :40] = allf.sum(0); st[1, :40] = (allf ** 2).sum(0); st[0, 40] = allf.shape[0]; tm(f"{td}/global_cmvn.stats", st)
+    tm(f"{td}/final.mat", (rng.standard_normal((20, 7 * 40)) * 1.5 / np.sqrt(7 * 40)).astype(np.float32))
+    open(f"{td}/splice.conf", "w").write("--left-context=3\n--right-context=3\n"); open(f"{td}/cmvn.conf", "w").write("\n")
+    open(f"{td}/ivector.conf", "w").write(f"--lda-matrix={td}/final.mat\n--global-cmvn-stats={td}/global_cmvn.stats\n--cmvn-config={td}/cmvn.conf\n--splice-config={td}/splice.conf\n--diag-ubm={IV}/final.dubm\n"
+                                          f"--ivector-extractor={IV}/final.ie\n--num-gselect=5\n--min-post=0.025\n--posterior-scale=0.1\n--max-count=100\n--ivector-period=10\n")
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=feats["utt0"], out_std=1.5, ivector_dim=16)
+    net.write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N); net.write(f"{td}/final.raw")
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
+    C = 60
+    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--determinize-lattice=false", "--write-compact=false",
+              "--num-channels=3", f"--frames-per-chunk={C}", "--max-utterance-frames=400"]
+    tail = [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp"]
+    b = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + [f"--ivector-extraction-config={td}/ivector.conf"] + tail + [f"ark,t:{td}/on.txt"], capture_output=True, text=True)
+    assert b.returncode == 0 and "Decoded 3 utterances, 0 with errors." in b.stderr, b.stderr[-2000:]
+    on = _parse_text_lattices(f"{td}/on.txt")
+    # the same chunks through the Python pipeline (the program hands every busy channel frames_per_chunk * 160 samples per round)
+    dev = torch.device("cuda:0"); nn = nnet3.Nnet(f"{td}/final.raw"); cf = decoder.CudaFst(graph, synth.tid2pdf(N))
+    ex = BatchedIvectorExtractor(OnlineIvectorExtractionInfo(f"{td}/ivector.conf"))
+    cfg = decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, literal_order=1)
+    pipe = online.BatchedOnlinePipeline(feat.fbank_options(dither=0.0, num_bins=40), nn, cf, cfg, 3, 400, frames_per_chunk=C, ivector_extractor=ex)
+    waves = [torch.from_numpy(synth.gaussian_pcm16(n, 50 + i).astype(np.float32)).to(dev) for i, n in enumerate(lens)]; pos = [0, 0, 0]; lats = {}
+    while any(p < n for p, n in zip(pos, lens)):
+        chs = [u for u in range(3) if pos[u] < lens[u]]; chunks = [waves[u][pos[u]:pos[u] + C * 160] for u in chs]; first = [pos[u] == 0 for u in chs]
+        for u in chs: pos[u] = min(lens[u], pos[u] + C * 160)
+        for ch, lat in pipe.DecodeBatch(chs, chunks, first, [pos[u] >= lens[u] for u in chs]).items(): lats[f"utt{ch}"] = lat
+    assert sorted(lats) == sorted(on) == ["utt0", "utt1", "utt2"]
+    for k in on:
+        want = sorted((int(i), int(o), float(np.float32(g)), float(np.float32(a))) for i, o, g, a in zip(lats[k].arc_ilabel, lats[k].arc_olabel, lats[k].arc_graph, lats[k].arc_ac))
+        got = sorted((a[2], a[3], float(a[4]), float(a[5])) for a in on[k][0])
+        assert len(got) > 20 and len(got) == len(want), k      # (the text form carries the costs with the stream's default precision: labels equal, costs to that precision)
+        for x, y in zip(got, want): assert x[:2] == y[:2] and abs(x[2] - y[2]) <= 2e-5 * max(1.0, abs(y[2])) and abs(x[3] - y[3]) <= 2e-5 * max(1.0, abs(y[3])), (k, x, y)
+    # without the extractor: the reference's message
+    r = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + tail + [f"ark:{td}/x.ark"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Neural net expects 'ivector' features with dimension 16 but you provided 0" in r.stderr

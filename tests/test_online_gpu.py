@@ -99,3 +99,69 @@ def test_dynamic_batcher_threads_pushing_chunks_get_the_offline_lattices(tmp_pat
     assert sorted(got) == [1000 + u for u in range(6)]
     for u in range(6): d = got[1000 + u].diff(ref[u]); assert d == "", (u, d)
     assert max(batcher.batch_sizes) >= 2 and sum(batcher.batch_sizes) > len(batcher.batch_sizes), batcher.batch_sizes[:20]
+
+
+def _iv_setup(tmp_path, N=90):
+    """a TDNN-F with the recipes' i-vector input (dim 20) and a random i-vector extractor over the same 40-dim features"""
+    import importlib.util, os
+    from kaldi_amd import nnet3
+    from kaldi_amd.ivector import BatchedIvectorExtractor
+    spec = importlib.util.spec_from_file_location("tiv", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_ivector_gpu.py")); tiv = importlib.util.module_from_spec(spec); spec.loader.exec_module(tiv)
+    rng = np.random.default_rng(77); F, lc, rc, D, G, R = 40, 3, 3, 24, 32, 20
+    lda, st, ubm, ie = tiv._random_model(rng, F, lc, rc, D, G, R, False)
+    il = np.tril_indices(D); packed = np.stack([ie["sigma_inv"][g][il] for g in range(G)])
+    ex = BatchedIvectorExtractor.FromArrays(lda, st, ubm["gconsts"], ubm["means_invvars"], ubm["inv_vars"], ie["M"], packed, ie["prior_offset"], left_context=lc, right_context=rc, ivector_period=10)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net_w = synth.make_tdnnf(seed=21, dim=64, bottleneck=16, strides=(1, 3, 0, 3), prefinal_small=32, num_pdfs=N, calib_feats=calib, ivector_dim=R, out_std=1.5)
+    mp = str(tmp_path / "miv.raw"); net_w.write(mp)
+    return nnet3.Nnet(mp), ex
+
+def test_streaming_network_with_one_ivector_per_chunk(tmp_path):
+    """BatchedStaticNnet3 on a model with an i-vector input: with the SAME i-vector on every chunk the chunked log-likelihoods are, bit for bit, the whole-utterance forward with
+    that utterance-level i-vector (nnet3-compute --ivectors); with a different i-vector per chunk every chunk's rows are those of the whole-utterance forward with THAT i-vector"""
+    from kaldi_amd import nnet3
+    dev = torch.device("cuda:0"); nn, ex = _iv_setup(tmp_path); rng = np.random.default_rng(9); C = 60
+    T = [250, 77]; feats = [torch.from_numpy((rng.standard_normal((t, 40)) * 1.2 + 16.5).astype(np.float32)).to(dev) for t in T]
+    ivs = torch.from_numpy(rng.standard_normal((6, nn.info.ivector_dim)).astype(np.float32)).to(dev)
+    def offline(u, v):
+        b = nnet3.NnetBatch(nn, [T[u]], 3); return b.forward(feats[u], ivectors=v[None, :]).clone()
+    whole = [[offline(u, ivs[k]) for k in range(6)] for u in range(2)]
+    st = nnet3.BatchedStaticNnet3(nn, 2, 2, frames_per_chunk=C, frame_subsampling_factor=3)
+    for same in (True, False):
+        pos = [0, 0]; got = [[], []]; k = 0; rows = [0, 0]
+        while any(p < t for p, t in zip(pos, T)):
+            chs = [u for u in range(2) if pos[u] < T[u]]; chunks = [feats[u][pos[u]:pos[u] + C] for u in chs]
+            first = [pos[u] == 0 for u in chs]; last = [pos[u] + C >= T[u] for u in chs]
+            iv = torch.stack([ivs[0 if same else (k + u) % 6] for u in chs])
+            outs = st.RunBatch(chs, chunks, first, last, ivectors=iv)
+            for u, o in zip(chs, outs):
+                want = whole[u][0 if same else (k + u) % 6][rows[u]:rows[u] + o.shape[0]]
+                assert torch.equal(o, want), (same, u, k); rows[u] += o.shape[0]; pos[u] += C
+            k += 1
+        assert rows == [whole[0][0].shape[0], whole[1][0].shape[0]]
+    with pytest.raises(ValueError, match="i-vector input"): st.RunBatch([0], [feats[0][:C]], [True], [False])
+
+def test_streaming_pipeline_uses_the_extractors_latest_ivector(tmp_path):
+    """kaldi_amd/online.py with an i-vector extractor: the i-vector a chunk is evaluated with is the row of the WHOLE utterance's extraction that the reference's online decodable
+    would use (decodable-online-looped.cc:182-197: the estimate at the last multiple of the period among the frames ready = frames so far minus the splice's right context, zero before
+    the first) -- although the pipeline only ever saw the stream's prefix; and a model with an i-vector input decodes to the same lattice twice"""
+    from kaldi_amd import feat, decoder, online
+    dev = torch.device("cuda:0"); nn, ex = _iv_setup(tmp_path); N = nn.info.output_dim
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); cf = decoder.CudaFst(graph, synth.tid2pdf(N))
+    cfg = decoder.decoder_config(beam=13.0, lattice_beam=6.0, max_active=5000, literal_order=1); opts = feat.fbank_options(dither=0.0, num_bins=40)
+    pipe = online.BatchedOnlinePipeline(opts, nn, cf, cfg, 2, 400, frames_per_chunk=60, ivector_extractor=ex)
+    wave = torch.from_numpy(synth.gaussian_pcm16(30000, 5).astype(np.float32)).to(dev)
+    sf = feat.SpectralFeatures(opts); full = sf.ComputeFeatures(wave, *sf.offsets([30000], dev)[:3]); rows, _ = ex.GetIvectors(full, [0, full.shape[0]])
+    for n, fin in [(1, False), (3, False), (4, False), (13, False), (14, False), (57, False), (186, False), (186, True), (full.shape[0], True)]:
+        got = pipe._latest_ivector(full[:n].contiguous(), fin); ready = n - (0 if fin else ex.right_context)
+        want = rows[(ready - 1) // ex.ivector_period] if ready > 0 else torch.zeros_like(rows[0])
+        assert torch.equal(got, want), (n, fin)
+    def decode():
+        pos = 0; lat = None
+        while pos < wave.numel():
+            n = min(4321, wave.numel() - pos); r = pipe.DecodeBatch([1], [wave[pos:pos + n]], [pos == 0], [pos + n >= wave.numel()]); pos += n
+            if r: lat = r[1]
+        return lat
+    a = decode(); b = decode()
+    assert a is not None and a.num_arcs > 50 and a.diff(b) == ""
+    with pytest.raises(ValueError, match="needs an ivector_extractor"): online.BatchedOnlinePipeline(opts, nn, cf, cfg, 2, 400)
