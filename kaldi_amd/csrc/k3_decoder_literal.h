@@ -44,6 +44,9 @@ enum { kRfHasEps = 1, kRfExists = 2 };
 #define K3_LS(i) do { } while (0)
 #endif
 
+#ifndef K3_COLD_INLINE
+#define K3_COLD_INLINE __forceinline__      // (register-pressure experiments: -DK3_COLD_INLINE=__noinline__ makes the large-frame forms of the hash-order pass real calls)
+#endif
 // inclusive prefix sum over the wavefront with DPP row shifts / row broadcasts (no LDS-crossbar round trips)
 __device__ __forceinline__ int wave_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
@@ -175,7 +178,7 @@ struct LitLane {      // this lane's slices of the literal_order scratch
 // (The path of frames too large for lit_hash_order_lds.)  The buckets -- hash_size is unbounded, a frame touches at most n of them -- live in an
 // open-addressing table of 16 B records {bucket, smallest creation rank, members, fill cursor} sized to the frame (2n .. 4n slots): one
 // cache line per token and pass in a region that scales with the frame, where per-bucket arrays cost three lines spread over hash_size entries.
-__device__ __forceinline__ void lit_hash_order(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, long long &lt_last__) {
+__device__ K3_COLD_INLINE void lit_hash_order(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, long long &lt_last__) {
   const int tid = threadIdx.x;
   const int W = (int)((M + 31u) >> 5);
   unsigned tsize = 1024; while (tsize < 2u * (unsigned)n) tsize <<= 1;      // <= 2 * next_pow2(cap) = the table's capacity
@@ -313,7 +316,7 @@ constexpr size_t kLitTabBytes = (size_t)3 * kHL * 4, kLitMarkBytes = (size_t)3 *
 // dead at both call sites.  Returns false when the frame does not fit (the caller takes lit_hash_order).
 constexpr int kHmN = 3072, kHmM = 32768, kHmB = 4096;
 constexpr size_t kHmLds = (size_t)kHmB * 4 + 7 * ((size_t)kHmN * 2 + 8) + (size_t)kHmM / 8 + (size_t)kHmM / 32 * 2;
-__device__ __forceinline__ bool lit_hash_order_mid(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins) {
+__device__ K3_COLD_INLINE bool lit_hash_order_mid(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins) {
   if (n > kHmN || M > (unsigned)kHmM || hash_size > 65535u) return false;
   const int tid = threadIdx.x; const int W = (int)((M + 31u) >> 5);
   unsigned *btab = reinterpret_cast<unsigned *>(arena); char *a_ = arena + (size_t)kHmB * 4; constexpr size_t kCol = (size_t)kHmN * 2 + 8;
