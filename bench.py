@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-two-pass", action="store_true", help="skip the second (order-independent decoder) measurement")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: H2D, fbank, TDNN-F and decoder of a batch strictly after the previous batch (stage_ms then adds up to ms_per_step)")
+    ap.add_argument("--one-decoder", action="store_true", help="one decoder object instead of two alternating ones (the default keeps two sets of lane pools -- 2 x 41 GB of the 288 GB at the bench configuration -- so that a batch's token passing starts under the previous batch's pruning kernel and lattice fetch)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="cpu_baseline / e2e_parity: single-threaded reference workers (capped by the host's cores)")
     ap.add_argument("--cpu-utts-per-core", type=int, default=8, help="cpu_baseline / e2e_parity: utterances per worker (utterance u = the GPU batch's utterance u while u < --utts)")
     ap.add_argument("--no-extras", action="store_true", help="skip the chain_objf / chain_train legs (for the record only; not part of `value`)")
@@ -257,6 +258,8 @@ def main():
         for mode in (["literal"] if args.no_two_pass else ["literal", "two_pass"]):
             d = decoder.CudaDecoder(cfst, decoder.decoder_config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE, literal_order=1 if mode == "literal" else 0, **caps), U, num_pdfs)
             d.SetProfiling(True); decs[mode] = d
+        if not args.one_decoder and not args.no_pipeline:      # a second decoder object (another set of lane pools: 41 GB at the bench configuration; the GPU has 288): batch k + 1's token passing starts under batch k's pruning kernel and lattice fetch
+            decs["literal_b"] = decoder.CudaDecoder(cfst, decoder.decoder_config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE, literal_order=1, **caps), U, num_pdfs); decs["literal_b"].SetProfiling(True)
     hl = hostlib.load(); det_opts = hostlib.DetOpts(); hl.k3h_det_opts_default(ctypes.byref(det_opts))
     pool = ThreadPoolExecutor(1)                      # hands a batch of lattices to the native worker pool (k3h_postprocess_batch runs det_threads threads itself)
     def postprocess(lats):
@@ -299,7 +302,27 @@ def main():
             lat_sizes[0] = int(lats.state_offsets[-1]); lat_sizes[1] = int(lats.arc_offsets[-1])
             if timed: ev[5].record()
             pending.append(pool.submit(postprocess, lats))
+        two = "literal_b" in decs and mode == "literal" and pipelined; facc = [0.0, 0.0, 0.0, 0]; first_timed = [0]
+        if two: pair = (dec, decs["literal_b"]); dstr = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        def fetch(j):      # batch j's lattices (compaction kernel + D2H on its decoder's stream), handed to the determinization pool
+            while len(pending) >= 2: r = pending.pop(0).result(); det_sizes[0], det_sizes[1] = r
+            t_f = time.perf_counter(); lats = pair[j & 1].GetRawLattices(); last[0] = lats
+            lat_sizes[0] = int(lats.state_offsets[-1]); lat_sizes[1] = int(lats.arc_offsets[-1])
+            kt = pair[j & 1].KernelTimes(); facc[0] += kt[0]; facc[1] += kt[1]; facc[2] += (time.perf_counter() - t_f) * 1e3; facc[3] += 1
+            pending.append(pool.submit(postprocess, lats))
+        def step_two(timed):
+            k = nstep[0]; nstep[0] += 1
+            if k == 0: front_end(0)
+            with torch.cuda.stream(dstr[k & 1]):
+                dstr[k & 1].wait_event(fev[k & 1][3])
+                if timed: ev[3].record()
+                pair[k & 1].DecodeBatch(ll2[k & 1], nb.out_offsets); dec_done[k & 1].record()
+                if timed: ev[4].record()
+            front_end(k + 1)
+            if k > first_timed[0]: fetch(k - 1)
+            if timed: ev[5].record()
         def step(timed):
+            if two: return step_two(timed)
             if pipelined and dec is not None: return step_pipelined(timed)
             if timed: ev[0].record()
             pcm_dev.copy_(src(nser[0]), non_blocking=True); nser[0] += 1     # first waveform byte leaves host memory
@@ -319,6 +342,7 @@ def main():
                 if timed: ev[5].record()
                 pending.append(pool.submit(postprocess, lats))
         for _ in range(warmup): step(False)
+        if two and nstep[0] > 0: fetch(nstep[0] - 1); first_timed[0] = nstep[0]; torch.cuda.synchronize(); facc[:] = [0.0, 0.0, 0.0, 0]      # (the warm-up's last batch; batch nstep's front end is already queued, as in the one-decoder steps)
         while pending: pending.pop(0).result()
         torch.cuda.synchronize()
         if world > 1: dist.barrier()
@@ -326,14 +350,18 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step(True)
-            torch.cuda.current_stream().synchronize()
-            if pipelined and dec is not None:
+            if not two: torch.cuda.current_stream().synchronize()
+            if two: fe = fev[(nstep[0] - 1) & 1]; fe[3].synchronize(); acc[0] += fe[0].elapsed_time(fe[1]); acc[1] += fe[1].elapsed_time(fe[2]); acc[2] += fe[2].elapsed_time(fe[3])
+            elif pipelined and dec is not None:
                 fe = fev[(nstep[0] - 1) & 1]; acc[0] += fe[0].elapsed_time(fe[1]); acc[1] += fe[1].elapsed_time(fe[2]); acc[2] += fe[2].elapsed_time(fe[3])
             else:
                 acc[0] += ev[0].elapsed_time(ev[1]); acc[1] += ev[1].elapsed_time(ev[2]); acc[2] += ev[2].elapsed_time(ev[3])
-            if dec is not None:
+            if dec is not None and not two:
                 acc[3] += ev[3].elapsed_time(ev[4]); acc[4] += ev[4].elapsed_time(ev[5])
                 k = dec.KernelTimes(); acc[5] += k[0]; acc[6] += k[1]
+        if two and nstep[0] > 0:
+            fetch(nstep[0] - 1)      # the last batch's lattices belong to the timed region
+            if facc[3]: acc[5] = facc[0] / facc[3] * steps; acc[6] = facc[1] / facc[3] * steps; acc[4] = facc[2] / facc[3] * steps; acc[3] = acc[5] + acc[6]      # (per fetched batch: kernel times from the decoder objects' own events, the fetch as the host saw it)
         while pending: r = pending.pop(0).result(); det_sizes[0], det_sizes[1] = r      # last lattice handed to the writer
         torch.cuda.synchronize()
         if world > 1: dist.barrier()
@@ -349,9 +377,13 @@ def main():
         return dt, acc / steps, lat_sizes, det_sizes
 
     mode0 = "literal" if decs else None
-    if decs: decs["literal"].FramePathCounts()      # (reset)
+    if decs: [d_.FramePathCounts() for n_, d_ in decs.items() if n_.startswith("literal")]      # (reset)
     dt, acc, lat_sizes, det_sizes = run(mode0, args.steps, args.warmup)
     paths = decs["literal"].FramePathCounts() if decs else None
+    if decs and "literal_b" in decs:      # (two alternating decoder objects: their counts together)
+        pb = decs["literal_b"].FramePathCounts()
+        for k_ in ("lds_path", "given_up", "general_path"): paths[k_] += pb[k_]
+        for k_, v_ in pb["give_up_reasons"].items(): paths["give_up_reasons"][k_] = paths["give_up_reasons"].get(k_, 0) + v_
     audio_s = U * args.utt_seconds * world * args.steps
     two = run("two_pass", args.steps, args.warmup) if "two_pass" in decs else None
     # Stage and kernel durations (stage_ms, roofline, roofline_gemm) come from a short SERIAL pass of the same objects: in the pipelined steps a kernel shares the GPU with the other
@@ -382,7 +414,7 @@ def main():
                            "utts_per_gpu": U, "frames_per_utt": fo_h[1], "output_rows": int(nb.total_out_rows), "params": int(net.info.num_params), "parallelism": f"utterance-shard x{world}"},
                 "value_kernels": U * args.utt_seconds * world / (kernels_ms * 1e-3),
                 "value_kernels_note": "audio / (fbank + TDNN-F + decode kernel time of a step): what the GPU stages alone sustain, H2D / D2H / host tail excluded",
-                "pipeline": ("batch k+1's PCM16 H2D + fbank + TDNN-F are issued on a second stream right behind batch k's decoder kernels (double-buffered log-likelihoods): the copy and the start of the network run while the decoder's last lanes finish; one of each per step inside the timed region; stage_ms are the stages' own durations and no longer add up to ms_per_step" if pipelined else "none (--no-pipeline): one stream, stage after stage"),
+                "pipeline": ("batch k+1's PCM16 H2D + fbank + TDNN-F are issued on a second stream right behind batch k's decoder kernels (double-buffered log-likelihoods): the copy and the start of the network run while the decoder's last lanes finish; two decoder objects alternate (unless --one-decoder), so batch k+1's token passing starts under batch k's pruning kernel, compaction and lattice copy; one of each per step inside the timed region; stage_ms are the stages' own durations and no longer add up to ms_per_step" if pipelined else "none (--no-pipeline): one stream, stage after stage"),
                 "stage_ms": {"pcm16_h2d": acc[0], "fbank": acc[1], "nnet3": acc[2], "decode": acc[3], "decode.token_passing_kernel": acc[5], "decode.lattice_prune_kernel": acc[6], "lattice_compact_and_d2h": acc[4]},
                 "stage_ms_note": ("stage and kernel durations of a serial pass (3 steps, one stream) run after the timed steps: each kernel has the GPU to itself, as in the committed rocprofv3 traces (tools/profile_round.sh uses --no-pipeline); stage_ms_in_pipeline are the event-to-event times of the same stages inside the timed, pipelined steps, where they share the GPU" if (pipelined and decs) else "stages of the timed steps (one stream)"),
                 "stage_ms_in_pipeline": ({"pcm16_h2d": acc_pipe[0], "fbank": acc_pipe[1], "nnet3": acc_pipe[2], "decode": acc_pipe[3], "decode.token_passing_kernel": acc_pipe[5], "decode.lattice_prune_kernel": acc_pipe[6], "lattice_compact_and_d2h": acc_pipe[4]} if (pipelined and decs) else None),

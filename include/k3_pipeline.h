@@ -94,6 +94,7 @@ struct BatchedThreadedNnet3CudaPipeline2Config {      // the options of BatchedT
   k3_decoder_config decoder_opts;                             // beam, lattice-beam, max-active, capacities, literal_order
   float acoustic_scale = 0.1f; int32_t frame_subsampling_factor = 1;
   CudaPipelineSegmentationConfig seg_opts;                    // --segment-length, --segment-overlap, --min-segment-length
+  bool alternate_decoders = true;                             // two decoder objects (twice the lane pools) used in turn: a batch's token passing starts under the previous batch's pruning kernel and lattice copy
   BatchedThreadedNnet3CudaPipeline2Config() { memset(&feature_opts, 0, sizeof feature_opts); k3_decoder_config_default(&decoder_opts); }
 };
 
@@ -112,6 +113,7 @@ class BatchedThreadedNnet3CudaPipeline2 {
                                decode_fst.nextstate.data(), decode_fst.final_cost.data(), trans_.id2pdf.data(), (int32_t)trans_.id2pdf.size(), &fst_));
     graph_start_ = k3_fst_start(fst_);
     K3H_CHECK_K3(k3_decoder_create(fst_, &config_.decoder_opts, config_.max_batch_size, ninfo_.output_dim, &dec_));
+    if (config_.alternate_decoders) K3H_CHECK_K3(k3_decoder_create(fst_, &config_.decoder_opts, config_.max_batch_size, ninfo_.output_dim, &dec_b_));
     K3O_HIP(hipGetDevice(&device_));
     const int nw = config_.num_worker_threads > 0 ? config_.num_worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
     for (int i = 0; i < nw; i++) workers_.emplace_back([this] { WorkerLoop(); });
@@ -123,7 +125,7 @@ class BatchedThreadedNnet3CudaPipeline2 {
     cv_.notify_all(); wcv_.notify_all();
     control_.join(); for (auto &w : workers_) w.join();
     for (auto &c : plan_cache_) k3_nnet_batch_destroy(c.second);
-    k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
+    k3_decoder_destroy(dec_); if (dec_b_) k3_decoder_destroy(dec_b_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
   }
   float GetModelFrequency() const { return config_.feature_opts.samp_freq; }
   // batched-threaded-nnet3-cuda-pipeline2.h:204-208: scales / word insertion penalty / MBR applied to every lattice result; required for RESULT_TYPE_CTM
@@ -227,20 +229,32 @@ class BatchedThreadedNnet3CudaPipeline2 {
   void Hand(std::vector<std::shared_ptr<Task>> &batch) { { std::lock_guard<std::mutex> l(m_); for (auto &t : batch) post_.push_back(t); } wcv_.notify_all(); }
   void ControlLoop() {
     K3O_HIP(hipSetDevice(device_));
-    K3O_HIP(hipStreamCreateWithFlags(&s_front_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_, hipStreamNonBlocking));
+    K3O_HIP(hipStreamCreateWithFlags(&s_front_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_b_, hipStreamNonBlocking));
     for (auto &e : ev_front_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    InFlight cur, nxt; int parity = 0;
+    for (auto &e : ev_dec_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // Batches in flight: `prev` (decoded, lattices not fetched yet -- only with two decoder objects), `cur` (front end issued, decoder next), `nxt` (front end issued behind cur's decoder).
+    // With one decoder object a batch's lattices are fetched right after the next batch's front end has been queued; with two, one step later, so that the next batch's token passing is
+    // already queued on the other object's stream while this batch's pruning kernel, compaction and copy run.  Nothing waits for new work while a decoded batch is unfetched.
+    InFlight prev, cur, nxt; int parity = 0; bool prev_decoding = false;
     auto start = [&](InFlight *f, std::vector<std::shared_ptr<Task>> &&batch) {
       f->batch = std::move(batch); f->valid = false; f->buf = parity; parity ^= 1;
       try { FrontEnd(f); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : f->batch) t->failed = true; f->valid = false; }
     };
+    auto finish = [&](InFlight *f, bool decoding) {
+      if (decoding) { try { Fetch(f); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : f->batch) t->failed = true; } }
+      Hand(f->batch); *f = InFlight();
+    };
     for (;;) {
-      if (cur.batch.empty()) { auto b = TakeBatch(true); if (b.empty()) break; start(&cur, std::move(b)); }
+      if (cur.batch.empty()) {
+        if (!prev.batch.empty()) finish(&prev, prev_decoding);      // idle: hand the last decoded batch over before blocking for new work
+        auto b = TakeBatch(true); if (b.empty()) break; start(&cur, std::move(b));
+      }
       bool decoding = false;
       try {
         if (cur.valid) {
-          K3O_HIP(hipStreamWaitEvent(s_dec_, ev_front_[cur.buf], 0));
-          K3H_CHECK_K3(k3_decoder_decode_batch(dec_, cur.U, d_ll_[cur.buf].p, ninfo_.output_dim, cur.ro.data(), s_dec_)); decoding = true;
+          K3O_HIP(hipStreamWaitEvent(DecStream(cur.buf), ev_front_[cur.buf], 0));
+          K3H_CHECK_K3(k3_decoder_decode_batch(Dec(cur.buf), cur.U, d_ll_[cur.buf].p, ninfo_.output_dim, cur.ro.data(), DecStream(cur.buf))); decoding = true;
+          K3O_HIP(hipEventRecord(ev_dec_[cur.buf], DecStream(cur.buf)));
           K3O_HIP(hipEventSynchronize(ev_front_[cur.buf]));      // the front end of `cur` is through: its staging, feature and network buffers are free
         }
       } catch (const std::exception &e) {
@@ -248,12 +262,16 @@ class BatchedThreadedNnet3CudaPipeline2 {
         (void)hipStreamSynchronize(s_front_);      // the wait for cur's front end was skipped: its shared staging / feature buffers must be quiescent before the next batch's front end reuses (or reallocates) them
       }
       nxt = InFlight(); { auto b = TakeBatch(false); if (!b.empty()) start(&nxt, std::move(b)); }
-      if (decoding) { try { Fetch(&cur); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; } }
-      Hand(cur.batch);
+      if (dec_b_) {
+        if (!prev.batch.empty()) finish(&prev, prev_decoding);
+        prev = std::move(cur); prev_decoding = decoding;
+      } else finish(&cur, decoding);
       cur = std::move(nxt); nxt = InFlight();
     }
-    K3O_HIP(hipStreamSynchronize(s_front_)); K3O_HIP(hipStreamSynchronize(s_dec_));
-    for (auto &e : ev_front_) (void)hipEventDestroy(e); (void)hipStreamDestroy(s_front_); (void)hipStreamDestroy(s_dec_);
+    if (!prev.batch.empty()) finish(&prev, prev_decoding);
+    K3O_HIP(hipStreamSynchronize(s_front_)); K3O_HIP(hipStreamSynchronize(s_dec_)); K3O_HIP(hipStreamSynchronize(s_dec_b_));
+    for (auto &e : ev_front_) (void)hipEventDestroy(e); for (auto &e : ev_dec_) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(s_front_); (void)hipStreamDestroy(s_dec_); (void)hipStreamDestroy(s_dec_b_);
   }
   void FrontEnd(InFlight *f) {      // upload + features + network of f->batch on the front stream, log-likelihoods into buffer f->buf
     std::vector<std::shared_ptr<Task>> &batch = f->batch;
@@ -274,15 +292,18 @@ class BatchedThreadedNnet3CudaPipeline2 {
       plan_cache_.push_back({nframes, nb}); if (plan_cache_.size() > 4) { k3_nnet_batch_destroy(plan_cache_.front().second); plan_cache_.erase(plan_cache_.begin()); }
     }
     f->ro.assign(U + 1, 0); const int64_t rows = k3_nnet_batch_output_rows(nb, f->ro.data());
+    K3O_HIP(hipStreamWaitEvent(s_front_, ev_dec_[f->buf], 0));      // (two decoder objects: the batch before the last may still be decoding from this log-likelihood buffer)
+    if ((size_t)rows * ninfo_.output_dim > d_ll_[f->buf].cap) K3O_HIP(hipEventSynchronize(ev_dec_[f->buf]));      // (growing the buffer frees it: only once that decoder is through)
     K3H_CHECK_K3(k3_nnet_forward(nb, d_f_.p, fdim_, d_ll_[f->buf].need((size_t)rows * ninfo_.output_dim), ninfo_.output_dim, s_front_));
     K3O_HIP(hipEventRecord(ev_front_[f->buf], s_front_)); f->valid = true;
   }
   void Fetch(InFlight *f) {      // waits for the decoder of f->batch and turns its raw lattices into the tasks' Lattice objects
     std::vector<std::shared_ptr<Task>> &batch = f->batch; const std::vector<int> &idx = f->idx; const int U = f->U;
-    std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec_, info.data());
+    k3_decoder *dec = Dec(f->buf);
+    std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec, info.data());
     int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
     std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
-    K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec_, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));
+    K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));
     int64_t s0 = 0, a0 = 0;
     for (int u = 0; u < U; u++) {
       Task &t = *batch[idx[u]]; const int64_t ns = info[10 * u], na = info[10 * u + 1];
@@ -298,10 +319,12 @@ class BatchedThreadedNnet3CudaPipeline2 {
   }
   std::shared_ptr<LatticePostprocessor> lattice_postprocessor_;
   const BatchedThreadedNnet3CudaPipeline2Config config_; k3_nnet *nnet_; const TransitionInfo &trans_;
-  k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; k3_nnet_info ninfo_; int fdim_ = 0, device_ = 0; int32_t graph_start_ = 0; std::vector<float> log_priors_;
+  k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr, *dec_b_ = nullptr; k3_nnet_info ninfo_; int fdim_ = 0, device_ = 0; int32_t graph_start_ = 0; std::vector<float> log_priors_;
   std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache_;
   DevBuf<float> d_w_, d_f_, d_ll_[2]; DevBuf<int64_t> d_wo_, d_fo_;
-  hipStream_t s_front_ = nullptr, s_dec_ = nullptr; hipEvent_t ev_front_[2] = {nullptr, nullptr};
+  hipStream_t s_front_ = nullptr, s_dec_ = nullptr, s_dec_b_ = nullptr; hipEvent_t ev_front_[2] = {nullptr, nullptr}, ev_dec_[2] = {nullptr, nullptr};
+  k3_decoder *Dec(int buf) const { return (buf & 1) && dec_b_ ? dec_b_ : dec_; }
+  hipStream_t DecStream(int buf) const { return (buf & 1) && dec_b_ ? s_dec_b_ : s_dec_; }
   std::mutex m_; std::condition_variable cv_, wcv_, done_cv_; bool stop_ = false;
   std::deque<std::shared_ptr<Task>> queue_, post_; std::map<std::string, int> groups_; int n_tasks_not_done_ = 0;
   std::thread control_; std::vector<std::thread> workers_;

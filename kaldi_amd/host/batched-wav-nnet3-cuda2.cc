@@ -32,6 +32,7 @@ int main(int argc, char **argv) {
         "Usage: batched-wav-nnet3-cuda2 [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier|ctm-wxfilename>\n";
     ParseOptions po(usage);
     bool write_compact = true, write_lattice = true, segmentation = false, determinize = true, minimize = false, phone_det = true, word_det = true, gpu_feat = true, use_online = false, reset_on_endpoint = false, tensor_cores = false, tf32 = false, add_pitch = false, debug_comp = false, cache_mem = true;
+    bool alternate_decoders = true;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, worker_threads = -1, copy_threads = 2, frames_per_chunk = 50, subsampling = 1;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, elc = 0, erc = 0, elci = -1, ercf = -1;
     float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; double mem_prop = 0.5; int32_t det_max_mem = 50000000;
@@ -48,6 +49,7 @@ int main(int argc, char **argv) {
     po.Register("min-segment-length", &min_segment_length_s, "Min segment length (s, >=1)");
     po.Register("lattice-postprocessor-rxfilename", &postproc, "(optional) Config file for lattice postprocessor (scales, word insertion penalty, MBR options; needed for CTM output)");
     po.Register("max-batch-size", &max_batch, "The maximum execution batch size (utterances decoded together)");
+    po.Register("alternate-decoders", &alternate_decoders, "Keep two decoder objects (twice the lane pools in HBM) and alternate them batch by batch: a batch's token passing then starts while the previous batch's lattice pruning, compaction and copy to the host are still running");
     po.Register("num-channels", &num_channels, "(accepted; whole-utterance batching needs no separate channel pool)");
     po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
     po.Register("cuda-decoder-copy-threads", &copy_threads, "Number of worker threads that read the wave files and fill the pinned staging buffers.");
@@ -140,6 +142,8 @@ int main(int argc, char **argv) {
     dc.lane_tokens_cap = std::max<int64_t>(ntok_pre, dc.frame_tokens_cap); dc.lane_links_cap = 2 * dc.lane_tokens_cap;
     dc.literal_order = literal_order ? 1 : 0; dc.hash_ratio = hash_ratio; if (literal_order) { dc.frame_tokens_cap = std::min(dc.frame_tokens_cap, 65536); dc.frame_cands_cap = std::max(dc.frame_cands_cap, dc.frame_tokens_cap + 1); }
     k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, max_batch, ninfo.output_dim, &dec));
+    k3_decoder *dec_b = nullptr; if (alternate_decoders) K3H_CHECK_K3(k3_decoder_create(fst, &dc, max_batch, ninfo.output_dim, &dec_b));
+    k3_decoder *decs2[2] = {dec, alternate_decoders ? dec_b : dec};
 
     auto scp = ReadScp(wav_rspec);
     if (num_todo >= 0 && (size_t)num_todo < scp.size()) scp.resize(num_todo);
@@ -258,7 +262,9 @@ int main(int argc, char **argv) {
     DevBuf<float> d_w, d_f, d_ll[2], d_iv; DevBuf<int64_t> d_wo, d_fo;
     std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache;
     std::future<Batch> next; std::future<void> post;
-    hipStream_t s_front, s_dec; HIPCHK(hipStreamCreateWithFlags(&s_front, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&s_dec, hipStreamNonBlocking));
+    hipStream_t s_front, s_dec, s_dec_b; HIPCHK(hipStreamCreateWithFlags(&s_front, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&s_dec, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&s_dec_b, hipStreamNonBlocking));
+    hipStream_t s_decs[2] = {s_dec, alternate_decoders ? s_dec_b : s_dec};
+    hipEvent_t ev_dec[2]; for (auto &e : ev_dec) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));      // decoder of the batch that last read log-likelihood buffer k & 1 is through
     hipEvent_t ev_front[2]; for (auto &e : ev_front) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     struct Front { Batch b; std::vector<int64_t> ro; bool valid = false; double wait_ms = 0.0; } fr[2];
     auto tick = [] { return std::chrono::steady_clock::now(); }; auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -273,6 +279,7 @@ int main(int argc, char **argv) {
       num_err += b.num_err; if (b.iter == 0) { total_audio += b.audio; num_task += (int)b.keys.size(); }      // per iteration, like the reference's counters
       if (b.keys.empty()) return;
       const int U = (int)b.keys.size(); const int64_t tot = b.foff.back(), nsamp = b.woff.back();
+      HIPCHK(hipStreamWaitEvent(s_front, ev_dec[k & 1], 0));      // (alternating decoders: batch k - 2 may still be decoding from the log-likelihood buffer this front end writes)
       HIPCHK(hipMemcpyAsync(d_w.need((size_t)nsamp), pinned[b.slot].p, (size_t)nsamp * sizeof(float), hipMemcpyHostToDevice, s_front));
       d_wo.upload(b.woff); d_fo.upload(b.foff);
       K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w.p, d_wo.p, d_fo.p, U, tot, d_f.need((size_t)tot * fdim), fdim, s_front));
@@ -282,17 +289,18 @@ int main(int argc, char **argv) {
       for (auto &c : plan_cache) if (c.first == b.nframes) { nb = c.second; break; }
       const bool cached = nb != nullptr;
       DevBuf<float> &ll = d_ll[k & 1];
+      auto ll_need = [&](size_t n) { if (n > ll.cap) HIPCHK(hipEventSynchronize(ev_dec[k & 1])); return ll.need(n); };      // (growing the buffer frees it: only once the decoder that read it last is through)
       if (!ivx) {
         if (!cached) K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, &nb));
         const int64_t rows = k3_nnet_batch_output_rows(nb, f.ro.data());
-        K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, s_front));
+        K3H_CHECK_K3(k3_nnet_forward(nb, d_f.p, fdim, ll_need((size_t)rows * ninfo.output_dim), ninfo.output_dim, s_front));
       } else {
         std::vector<int32_t> iv_rows(U); for (int u = 0; u < U; u++) iv_rows[u] = (b.nframes[u] + iv_period - 1) / iv_period;
         const int64_t n_iv = k3_ivector_num_rows(ivx, U, b.foff.data(), nullptr);
         K3H_CHECK_K3(k3_ivector_extract_batch(ivx, d_f.p, fdim, b.foff.data(), U, d_iv.need((size_t)n_iv * ninfo.ivector_dim), ninfo.ivector_dim, s_front));
         if (!cached) K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, U, b.nframes.data(), subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, frames_per_chunk, iv_period, iv_rows.data(), &nb));
         const int64_t rows = k3_nnet_batch_output_rows(nb, f.ro.data());
-        K3H_CHECK_K3(k3_nnet_forward_ivector(nb, d_f.p, fdim, d_iv.p, ninfo.ivector_dim, ll.need((size_t)rows * ninfo.output_dim), ninfo.output_dim, s_front));
+        K3H_CHECK_K3(k3_nnet_forward_ivector(nb, d_f.p, fdim, d_iv.p, ninfo.ivector_dim, ll_need((size_t)rows * ninfo.output_dim), ninfo.output_dim, s_front));
       }
       if (!cached) {      // (an evicted plan's workspace is not in use: only this front end's network is in flight and it uses `nb`)
         plan_cache.push_back({b.nframes, nb});
@@ -301,28 +309,17 @@ int main(int argc, char **argv) {
       HIPCHK(hipEventRecord(ev_front[k & 1], s_front)); f.valid = true;
     };
     if (!plan_batches.empty()) front_end(0);
-    for (size_t k = 0; k < plan_batches.size(); k++) {
-      const auto t_b = tick();
-      Front &f = fr[k & 1];
-      if (f.valid) {
-        HIPCHK(hipStreamWaitEvent(s_dec, ev_front[k & 1], 0));
-        K3H_CHECK_K3(k3_decoder_decode_batch(dec, (int)f.b.keys.size(), d_ll[k & 1].p, ninfo.output_dim, f.ro.data(), s_dec));
-        HIPCHK(hipEventSynchronize(ev_front[k & 1]));      // front end k is through: the staging / feature / network buffers are free for batch k+1
-      }
-      // batch k+1's front end is queued NOW, behind the decoder kernels of batch k; then this thread waits for batch k's decoder
-      const bool had = f.valid; Batch bk; const double waited = f.wait_ms;
-      if (had) bk = std::move(f.b);
-      if (k + 1 < plan_batches.size()) front_end(k + 1);
-      if (!had) continue;
-      Batch &b = bk; const int U = (int)b.keys.size();
+    // lattices of a decoded batch: sizes, the ten arrays, hand-over to the post stage
+    auto fetch = [&](k3_decoder *d, Batch &b, size_t k, double waited, std::chrono::steady_clock::time_point t_b) {
+      const int U = (int)b.keys.size();
       auto r = std::make_shared<Raw>(); r->info.resize(10 * (size_t)U);
-      K3H_LATTICE_INFO(dec, r->info.data());
+      K3H_LATTICE_INFO(d, r->info.data());
       const auto t_c = tick();
       if (b.iter == 0 && (writer || ctm_mode)) {
         int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += r->info[10 * u]; NA += r->info[10 * u + 1]; }
         r->sf.resize(NS + 1); r->ss.resize(NS + 1); r->sc.resize(NS + 1); r->sfin.resize(NS + 1);
         r->as.resize(NA + 1); r->ad.resize(NA + 1); r->ai.resize(NA + 1); r->ao.resize(NA + 1); r->ag.resize(NA + 1); r->aa.resize(NA + 1);
-        K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, r->sf.data(), r->ss.data(), r->sc.data(), r->sfin.data(), r->as.data(), r->ad.data(), r->ai.data(), r->ao.data(), r->ag.data(), r->aa.data()));
+        K3H_CHECK_K3(k3_decoder_get_raw_lattices(d, r->sf.data(), r->ss.data(), r->sc.data(), r->sfin.data(), r->as.data(), r->ad.data(), r->ai.data(), r->ao.data(), r->ag.data(), r->aa.data()));
         r->keys = std::move(b.keys);
         if (post.valid()) post.get();          // keeps the records in order; an error in the previous batch's post stage surfaces here
         post = std::async(std::launch::async, post_process, r);
@@ -330,19 +327,40 @@ int main(int argc, char **argv) {
         for (int u = 0; u < U; u++) if (r->info[10 * u + 2] != 0 || r->info[10 * u] == 0) { K3H_WARN << "Failed to decode utterance with id " << b.keys[u]; num_err++; }
       }
       K3H_VLOG(1) << "batch " << k << ": waited " << waited << " ms for the reader, " << ms(t_b, t_c) << " ms decoder of this batch (+ front end of the next one queued behind it), " << ms(t_c, tick()) << " ms lattices to the host + hand-over";
+    };
+    struct Held { Batch b; bool valid = false; double waited = 0.0; std::chrono::steady_clock::time_point t_b; size_t k = 0; } held;      // alternating decoders: the batch whose lattices are fetched one step later
+    for (size_t k = 0; k < plan_batches.size(); k++) {
+      const auto t_b = tick();
+      Front &f = fr[k & 1];
+      if (f.valid) {
+        HIPCHK(hipStreamWaitEvent(s_decs[k & 1], ev_front[k & 1], 0));
+        K3H_CHECK_K3(k3_decoder_decode_batch(decs2[k & 1], (int)f.b.keys.size(), d_ll[k & 1].p, ninfo.output_dim, f.ro.data(), s_decs[k & 1]));
+        HIPCHK(hipEventRecord(ev_dec[k & 1], s_decs[k & 1]));
+        HIPCHK(hipEventSynchronize(ev_front[k & 1]));      // front end k is through: the staging / feature / network buffers are free for batch k+1
+      }
+      // batch k+1's front end is queued NOW, behind the decoder kernels of batch k; then this thread waits for a decoder: batch k's, or -- with two decoder objects -- batch k-1's,
+      // whose pruning kernel, compaction and copy run while batch k's token passing has already started on the other object's stream
+      const bool had = f.valid; Batch bk; const double waited = f.wait_ms;
+      if (had) bk = std::move(f.b);
+      if (k + 1 < plan_batches.size()) front_end(k + 1);
+      if (alternate_decoders) {
+        if (held.valid) { fetch(decs2[held.k & 1], held.b, held.k, held.waited, held.t_b); held.valid = false; }
+        if (had) { held.b = std::move(bk); held.valid = true; held.waited = waited; held.t_b = t_b; held.k = k; }
+      } else if (had) fetch(dec, bk, k, waited, t_b);
     }
+    if (held.valid) fetch(decs2[held.k & 1], held.b, held.k, held.waited, held.t_b);
     if (post.valid()) post.get();
     num_err += post_err;
     HIPCHK(hipDeviceSynchronize());
     for (auto &c : plan_cache) k3_nnet_batch_destroy(c.second);
-    for (auto &e : ev_front) (void)hipEventDestroy(e); (void)hipStreamDestroy(s_front); (void)hipStreamDestroy(s_dec);
+    for (auto &e : ev_front) (void)hipEventDestroy(e); for (auto &e : ev_dec) (void)hipEventDestroy(e); (void)hipStreamDestroy(s_front); (void)hipStreamDestroy(s_dec); (void)hipStreamDestroy(s_dec_b);
     { const auto t_w = std::chrono::steady_clock::now(); if (det_pool) { det_pool->Wait(); det_pool.reset(); }
       K3H_VLOG(1) << "waited " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_w).count() << " ms for the determinization pool after the last batch"; }
     if (writer) writer->Flush();
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
     K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio * iterations << " RealTimeX: " << total_audio * iterations / total_time;
-    k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan); if (ivx) k3_ivector_destroy(ivx);
+    k3_decoder_destroy(dec); if (dec_b) k3_decoder_destroy(dec_b); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan); if (ivx) k3_ivector_destroy(ivx);
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }
 }
