@@ -235,7 +235,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
     const unsigned ebc = enc(beam_cutoff);
     int c_lt = 0, c_le = 0;
     for (int i = tid; i < n_cur; i += kBlock) { const unsigned k = V_cost[i]; c_lt += k < ebc; c_le += k <= ebc; }
-    c_lt = block_sum_i32(c_lt, sh); c_le = block_sum_i32(c_le, sh);
+    { const int both = block_sum_i32((c_lt << 16) | c_le, sh); c_lt = both >> 16; c_le = both & 0xFFFF; }      // (n_cur <= kFT < 65536: one reduction for the two counts)
     int kth = -1;
     if (n_cur > p.max_active && c_lt > p.max_active) kth = p.max_active;
     else if (n_cur > p.min_active && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }
@@ -419,8 +419,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
       n = fs.n_wl[(round + 1) % 3];
     }
   }
-  if (block_err(sh)) return -1;
-  if (aborted()) return -1;
+  { __syncthreads(); const int bad = sh.err | fs.abort; __syncthreads(); if (bad) return -1; }      // (the lane's error flag and the give-up flag in one snapshot)
   const int n = sh.n_next; const int n_el = (int)(sh.n_link - eps_l0);
   K3_FP(4);
   // ---- the frame's final costs into the pool; buckets of the HashList (the table is dead afterwards)
