@@ -71,3 +71,37 @@ def test_pipeline_class_with_the_references_constructor_types(tmp_path):
         assert len(a[k]["arcs"]) == len(b[k]["arcs"]) > 0 and sorted(a[k]["finals"]) == sorted(b[k]["finals"]), k
         for x, y in zip(a[k]["arcs"], b[k]["arcs"]):
             assert x[:3] == y[:3] and list(x[5]) == list(y[5]) and abs(x[3] - y[3]) <= 2e-3 and abs(x[4] - y[4]) <= 2e-3, (k, x, y)
+
+
+def test_online_pipeline_class_with_the_references_constructor_types(tmp_path):
+    """include/k3_batched_online_pipeline.h: kaldi::cuda_decoder::BatchedThreadedNnet3CudaOnlinePipeline(config, fst::Fst<fst::StdArc>, nnet3::AmNnetSimple, TransitionModel),
+    TryInitCorrID / SetLatticeCallback(void(CompactLattice &)) / DecodeBatch(corr_ids, std::vector<SubVector<BaseFloat>>, is_first_chunk, is_last_chunk, partial hypotheses) -- the
+    reference's signatures (batched-threaded-nnet3-cuda-online-pipeline.h:119-330) -- in a caller that plays wave files as concurrent streams, more streams than channels
+    (tests/adapter/cuda_online_pipeline_example.cc).  The lattices its callbacks receive must be the ones the offline program writes for the same files (streaming == offline)."""
+    import struct
+    from kaldi_amd import synth
+    from oracle import kaldi_io as kio
+    from tests import lattice_cases as lc
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "cuda-online-pipeline-example")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/cuda-online-pipeline-example is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001, 12000, 5000]
+    for i, n in enumerate(lens): kio.write_wav(f"{td}/u{i}.wav", synth.gaussian_pcm16(n, 40 + i))
+    open(f"{td}/wav.scp", "w").write("".join(f"utt{i} {td}/u{i}.wav\n" for i in range(len(lens))))
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    g = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); g.write_openfst(f"{td}/HCLG.fst")
+    with open(f"{td}/graph.bin", "wb") as fh:
+        fh.write(struct.pack("<3i", g.num_states, g.start, int(g.ilabel.size)))
+        for x, dt in ((g.arc_offsets, np.int32), (g.ilabel, np.int32), (g.olabel, np.int32), (g.nextstate, np.int32), (g.weight, np.float32), (g.final, np.float32)): np.ascontiguousarray(x, dt).tofile(fh)
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    r = subprocess.run([exe, f"{td}/final.mdl", f"{td}/graph.bin", f"{td}/wav.scp", f"{td}/fbank.conf", f"ark,t:{td}/cls.txt"], capture_output=True, text=True, env=dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"))
+    assert r.returncode == 0 and "Decoded 5 utterances, 0 with errors" in r.stderr, r.stderr[-3000:]
+    assert int(r.stderr.split(" non-empty partial hypotheses")[0].split()[-1]) > 0
+    p = subprocess.run([os.path.join(ROOT, "kaldi_amd", "bin", "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0",
+                        "--lattice-beam=8.0", "--max-active=10000", "--max-batch-size=2", "--determinize-lattice=false", f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/prog.txt"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    a, b = lc.parse_compact_text(open(f"{td}/cls.txt").read()), lc.parse_compact_text(open(f"{td}/prog.txt").read())
+    assert sorted(a) == sorted(b) == [f"utt{i}" for i in range(5)]
+    for k in a:      # (raw lattices as CompactLattices: state numbers follow the order the GPU emitted the arcs in; the model went through the reference's reader and writer: last digit of a cost)
+        key = lambda x: (x[2], tuple(x[5]), round(float(x[3]), 2), round(float(x[4]), 2))
+        assert len(a[k]["arcs"]) == len(b[k]["arcs"]) > 0 and sorted(map(key, a[k]["arcs"])) == sorted(map(key, b[k]["arcs"])), k
