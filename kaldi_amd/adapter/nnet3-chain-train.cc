@@ -11,6 +11,7 @@
 // minibatches come as pairs of files instead (iteration i trains on pair i mod n; all pairs the same shape, like the minibatches merged from one egs archive):
 //   input-matrix  Kaldi binary Matrix<float> [(T-1)*s + 1 + left + right frames x num_sequences, sequence-minor rows (n, t) like a merged NnetChainExample's input, feature dim columns]
 //   chain-spec    int32[11] {0x4b36, den states, den start, den arcs, num pdfs P, num sequences B, frames per sequence T, merged-supervision states, arcs, per-sequence states, arcs}
+//                 (0x4b38 instead of 0x4b36: END-TO-END supervisions -- the per-sequence FSTs are Supervision::e2e_fsts, chain/chain-generic-numerator.cc; the merged FST is ignored)
 //                 float[3] {leaky-hmm-coefficient, l2-regularize, supervision weight}; the denominator FST, the merged supervision FST (chain::Supervision::fst after MergeSupervision),
 //                 int32[B+1] first state of every sequence's own FST, the B per-sequence FSTs concatenated; every FST as CSR: int64[S+1] arc offsets, int32[A] pdf-id + 1 labels,
 //                 int32[A] next states, float[A] weights, float[S] final costs.  (tools/debug_chain_train.py and bench.py write it.)
@@ -63,7 +64,8 @@ int main(int argc, char *argv[]) {
     std::vector<Minibatch> mbs(num_mb);
     for (size_t m = 0; m < num_mb; m++) {
       Reader r{fopen(spec_files[m].c_str(), "rb")}; if (!r.f) KALDI_ERR << "cannot open " << spec_files[m];
-      Minibatch &mb = mbs[m]; r.get(mb.h, 11); r.get(mb.fo, 3); if (mb.h[0] != 0x4b36) KALDI_ERR << "bad chain spec " << spec_files[m];
+      Minibatch &mb = mbs[m]; r.get(mb.h, 11); r.get(mb.fo, 3); if (mb.h[0] != 0x4b36 && mb.h[0] != 0x4b38) KALDI_ERR << "bad chain spec " << spec_files[m];
+      if (mb.h[0] != mbs[0].h[0]) KALDI_ERR << "ordinary and end-to-end minibatches cannot be mixed";
       mb.den.read(r, mb.h[1], mb.h[3]); mb.merged.read(r, mb.h[7], mb.h[8]); mb.state_off.resize(mb.h[5] + 1); r.get(mb.state_off.data(), mb.h[5] + 1); mb.sup.read(r, mb.h[9], mb.h[10]); fclose(r.f);
       if (mb.h[4] != mbs[0].h[4] || mb.h[5] != mbs[0].h[5] || mb.h[6] != mbs[0].h[6] || mb.h[1] != mbs[0].h[1] || mb.h[3] != mbs[0].h[3]) KALDI_ERR << "the minibatches differ in shape or denominator graph";
     }
@@ -87,11 +89,26 @@ int main(int argc, char *argv[]) {
 #ifdef K3_ADAPTER
     k3_chain_den *kden = NULL; std::vector<k3_chain_supervision *> ksups(num_mb, NULL);
     if (k3_chain_den_create((int32_t)den.fin.size(), h[2], P, den.off.data(), den.il.data(), den.nx.data(), den.w.data(), den.fin.data(), &kden) != K3_OK) KALDI_ERR << k3_last_error();
-    for (size_t m = 0; m < num_mb; m++) { const Minibatch &mb = mbs[m]; if (k3_chain_supervision_create(B, T, P, mb.fo[2], mb.state_off.data(), mb.sup.off.data(), mb.sup.il.data(), mb.sup.nx.data(), mb.sup.w.data(), mb.sup.fin.data(), &ksups[m]) != K3_OK) KALDI_ERR << k3_last_error(); }
+    const bool e2e = h[0] == 0x4b38;      // end-to-end (flat-start) supervisions: the per-sequence FSTs are Supervision::e2e_fsts (self-loops, several final states), the merged FST is unused
+    for (size_t m = 0; m < num_mb; m++) { const Minibatch &mb = mbs[m]; if ((e2e ? k3_chain_supervision_create_e2e : k3_chain_supervision_create)(B, T, P, mb.fo[2], mb.state_off.data(), mb.sup.off.data(), mb.sup.il.data(), mb.sup.nx.data(), mb.sup.w.data(), mb.sup.fin.data(), &ksups[m]) != K3_OK) KALDI_ERR << k3_last_error(); }
 #else
     fst::StdVectorFst den_fst; ToFst(den, h[2], &den_fst); chain::DenominatorGraph den_graph(den_fst, P);
     std::vector<chain::Supervision> supervisions(num_mb);
-    for (size_t m = 0; m < num_mb; m++) { chain::Supervision &sv = supervisions[m]; ToFst(mbs[m].merged, 0, &sv.fst); sv.weight = mbs[m].fo[2]; sv.num_sequences = B; sv.frames_per_sequence = T; sv.label_dim = P; }
+    const bool e2e = h[0] == 0x4b38;
+    for (size_t m = 0; m < num_mb; m++) {
+      chain::Supervision &sv = supervisions[m]; sv.weight = mbs[m].fo[2]; sv.num_sequences = B; sv.frames_per_sequence = T; sv.label_dim = P;
+      if (!e2e) { ToFst(mbs[m].merged, 0, &sv.fst); continue; }
+      const Minibatch &mb = mbs[m]; sv.e2e_fsts.resize(B);      // the per-sequence FSTs of the spec as Supervision::e2e_fsts
+      for (int32 b = 0; b < B; b++) {
+        fst::StdVectorFst &f = sv.e2e_fsts[b]; const int32 s0 = mb.state_off[b], S = mb.state_off[b + 1] - s0;
+        for (int32 st = 0; st < S; st++) f.AddState();
+        f.SetStart(0);
+        for (int32 st = 0; st < S; st++) {
+          if (mb.sup.fin[s0 + st] != std::numeric_limits<float>::infinity()) f.SetFinal(st, fst::TropicalWeight(mb.sup.fin[s0 + st]));
+          for (int64_t a = mb.sup.off[s0 + st]; a < mb.sup.off[s0 + st + 1]; a++) f.AddArc(st, fst::StdArc(mb.sup.il[a], mb.sup.il[a], fst::TropicalWeight(mb.sup.w[a]), mb.sup.nx[a]));
+        }
+      }
+    }
 #endif
 #ifdef K3_ADAPTER
     // K3_TRAIN_ID_FILE [+ K3_TRAIN_RANK / K3_TRAIN_WORLD]: this process is one rank of a data-parallel job (k3_comm_create: RCCL communicator through a rendezvous file)

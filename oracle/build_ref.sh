@@ -118,9 +118,9 @@ g++ $MF -c $R/chain/chain-training.cc -o $W/obj_chain/chain-training.o
 g++ $MF -c $R/chain/chain-generic-numerator.cc -o $W/obj_chain/chain-generic-numerator.o      # the end-to-end (flat-start) numerator: compiles unmodified too
 g++ $MF $HERE/ref_tools/ref_chain_objf.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-generic-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-chain-objf
 # the whole chain gradient on the reference's CPU code: NnetComputer forward (training mode) -> ComputeChainObjfAndDeriv -> backward (source shared with the adapter build)
-g++ $MF $HERE/../tests/adapter/nnet3_chain_grad.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-nnet3-chain-grad
+g++ $MF $HERE/../tests/adapter/nnet3_chain_grad.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-generic-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-nnet3-chain-grad
 # N iterations of chain TRAINING (NnetChainTrainer::TrainInternal's sequence: natural-gradient update, max-change, batch-norm stats, orthonormal constraint) on the CPU (source shared with the adapter build)
-g++ $MF $HERE/../kaldi_amd/adapter/nnet3-chain-train.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-nnet3-chain-train
+g++ $MF $HERE/../kaldi_amd/adapter/nnet3-chain-train.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/obj_chain/chain-numerator.o $W/obj_chain/chain-generic-numerator.o $W/obj_chain/chain-training.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-nnet3-chain-train
 g++ $MF $HERE/ref_tools/ref_chain_den.cc $W/obj_chain/chain-den-graph.o $W/obj_chain/chain-denominator.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-chain-den
 for f in /opt/conda/lib/libmkl_{rt,core,intel_lp64,sequential,gnu_thread,intel_thread,avx2,avx512,def,mc3,vml_avx2,vml_avx512,vml_def}.so.1; do
   [ -e $f ] && ln -sf $f $W/mkl/ || true; done

@@ -222,3 +222,40 @@ def test_chain_training_iterations_equal_the_reference(iters, momentum, nmb, tmp
             assert g.stderr.count("ConstrainOrthonormalInternal") == r.stderr.count("ConstrainOrthonormalInternal")
             return
     pytest.fail(f"MI355X training result matches none of the reference's runs: (MKL path, |params - ref| / |ref - initial|, max relative objective difference) = {tried}")
+
+
+def test_chain_training_iteration_with_end_to_end_supervisions(tmp_path):
+    """the training program on END-TO-END (flat-start) supervisions -- a chain spec with magic 0x4b38: the per-sequence FSTs (self-loops, several final states) are Supervision::e2e_fsts
+    in the oracle build (ComputeChainObjfAndDeriv's end-to-end branch with GenericNumeratorComputation, chain/chain-generic-numerator.cc compiled unmodified) and
+    k3_chain_supervision_create_e2e in the MI355X build: one training iteration ends at the reference's objective and parameters."""
+    import struct
+    from kaldi_amd import synth
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-chain-train"); ref = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-nnet3-chain-train")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/nnet3-chain-train is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    if not os.path.exists(ref): pytest.skip("oracle/_ref not built")
+    td = str(tmp_path); B, T, P, s = 6, 20, 50, 3
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net = synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=P, calib_feats=calib, out_std=1.5, orthonormal_constraint=-1.0); net.write(f"{td}/m.raw")
+    lc = rc = 8; Tin = (T - 1) * s + 1 + lc + rc; rng = np.random.default_rng(77)
+    _kaldi_matrix(f"{td}/in.mat", rng.standard_normal((Tin * B, 40)) * 1.2 + 16.5)
+    den = synth.make_den_fst(120, P, seed=5, mean_degree=6.0, hub_degree=60); fsts = [synth.make_e2e_fst(T, P, seed=900 + i, num_phones=int(rng.integers(2, 8))) for i in range(B)]
+    fb = lambda f: (np.ascontiguousarray(f.arc_offsets, np.int64).tobytes() + np.ascontiguousarray(f.ilabel, np.int32).tobytes() + np.ascontiguousarray(f.nextstate, np.int32).tobytes() +
+                    np.ascontiguousarray(f.weight, np.float32).tobytes() + np.ascontiguousarray(f.final, np.float32).tobytes())
+    so = np.concatenate([[0], np.cumsum([f.num_states for f in fsts])]).astype(np.int32); ab = np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in fsts])])
+    with open(f"{td}/chain.spec", "wb") as fh:      # (the merged-FST slot of the format holds a copy of the first sequence's FST: unused for end-to-end supervisions)
+        fh.write(struct.pack("<11i3f", 0x4b38, den.num_states, den.start, int(den.arc_offsets[-1]), P, B, T, fsts[0].num_states, int(fsts[0].arc_offsets[-1]), int(so[-1]), int(ab[-1]), 1.0e-05, 5.0e-05, 1.0))
+        fh.write(fb(den)); fh.write(fb(fsts[0])); fh.write(so.tobytes())
+        fh.write(np.concatenate([[0]] + [np.asarray(f.arc_offsets[1:], np.int64) + b for f, b in zip(fsts, ab[:-1])]).astype(np.int64).tobytes())
+        for k, dt in (("ilabel", np.int32), ("nextstate", np.int32), ("weight", np.float32), ("final", np.float32)): fh.write(np.concatenate([getattr(f, k) for f in fsts]).astype(dt).tobytes())
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"); args = [f"{td}/m.raw", str(s), f"{td}/in.mat", f"{td}/chain.spec", "1", "0.002", "0.0"]
+    g = subprocess.run([exe] + args + [f"{td}/g.raw", f"{td}/g.vec"], capture_output=True, text=True, env=env); assert g.returncode == 0, g.stderr[-3000:]
+    gv = _read_kaldi(f"{td}/g.vec"); p0 = np.concatenate([np.concatenate([c[2]["W"].ravel()] + ([c[2]["b"].ravel()] if "b" in c[2] and c[2]["b"].size else [])) for c in net.components if c[1] in ("affine", "tdnn", "linear")])
+    tried = []
+    for extra in ({}, {"MKL_CBWR": "COMPATIBLE"}):      # (the reference under MKL's two code paths on this host: natural-gradient SGD amplifies float32 rounding, DESIGN.md 4)
+        r = subprocess.run([ref] + args + [f"{td}/r.raw", f"{td}/r.vec"], capture_output=True, text=True, env=dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), **extra)); assert r.returncode == 0, r.stderr[-2000:]
+        rv = _read_kaldi(f"{td}/r.vec"); assert rv.shape == gv.shape and rv[2] == gv[2] == B * T
+        assert abs(rv[0] - gv[0]) <= 2e-4 * abs(rv[0]) + 1e-3 and abs(rv[1] - gv[1]) <= 2e-4 * abs(rv[1]) + 1e-5, (rv[:3], gv[:3])      # objective and l2 term of the iteration (no update involved yet)
+        rel = float(np.linalg.norm(rv[3:] - gv[3:]) / np.linalg.norm(rv[3:] - p0)); tried.append(rel)
+        assert np.linalg.norm(rv[3:] - p0) > 0.1
+        if rel <= 2e-3: return
+    pytest.fail(f"|params - ref| / |ref - initial| = {tried}")
