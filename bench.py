@@ -197,7 +197,7 @@ def measure_traffic(args):
 def main():
     if os.environ.get("K3HIP_LIB"): raise SystemExit("bench.py measures the shipped kaldi_amd/lib/libk3hip.so only: unset K3HIP_LIB (developer override for profiling builds)")
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=512); ap.add_argument("--utt-seconds", type=float, default=10.0)
     ap.add_argument("--graph-states", type=int, default=2_000_000); ap.add_argument("--graph-arcs", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-decode", action="store_true")
