@@ -13,7 +13,7 @@ for c in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES; do
 done
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_MFMA -o pmc -- $B --no-two-pass --steps 1 --warmup 0 > $OUT/bench_pmc_MFMA.log 2>&1
 cd $ROOT
-timeout 900 python bench.py --steps 5 --warmup 2 --measure-traffic > $OUT/bench_line.json 2> $OUT/bench_line.err
+timeout 900 python bench.py --steps 20 --warmup 3 --measure-traffic > $OUT/bench_line.json 2> $OUT/bench_line.err
 # the decoder's frames by path (shipped library) and, when tools/build_variant.sh fp -DK3_FAST_PROF was run, the phases of the LDS-resident path
 python tools/prof_literal.py 512 > $OUT/literal_frames_by_path.txt 2>&1
 [ -f build/libk3hip_fp.so ] && K3HIP_LIB=build/libk3hip_fp.so python tools/prof_fast.py 512 >> $OUT/literal_frames_by_path.txt 2>&1
