@@ -341,6 +341,16 @@ int k3_decoder_frame_stats(k3_decoder *dec, int32_t utt, int32_t *h_ntoks, float
 /* CuMatrixBase::SoftMaxPerRow (op 0) / LogSoftMaxPerRow (1) (cudamatrix/cu-matrix.h:328,334): dst = f(a), row by row, in place allowed; DiffSoftmaxPerRow (2: a = value, b = diff) /
  * DiffLogSoftmaxPerRow (3: a = out_value, b = out_deriv) (:403,:411) */
 int k3_mat_softmax_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_a, int64_t lda, const float *d_b, int64_t ldb, int32_t rows, int32_t cols, void *stream);
+/* cu::NormalizePerRow (op 0) / cu::DiffNormalizePerRow (op 1) (cudamatrix/cu-math.h:272-300, cu-math.cc:280-409; NormalizeComponent): op 0: dst [rows x cols (+1 with add_log_stddev)] from
+ * in [rows x cols]; op 1: dst = in_deriv, ADDED to (kBackpropAdds) unless it aliases out_deriv (the in-place backprop), out_deriv [rows x cols (+1)] */
+int k3_mat_normalize_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_in, int64_t ldi, const float *d_out_deriv, int64_t ldo, int32_t rows, int32_t cols, float target_rms, int32_t add_log_stddev, void *stream);
+/* CuMatrixBase::Sigmoid (op 0) / Tanh (1) / Log (2) / Pow (3: power a) / PowAbs (4: power a, flag = include_sign) / Max (5) (cudamatrix/cu-matrix.h:288-307,:386,:501): dst = f(src), in place allowed */
+int k3_mat_apply_map(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, float a, int32_t flag, void *stream);
+/* CuMatrixBase::DiffSigmoid (op 0) / DiffTanh (1) (cudamatrix/cu-matrix.h:390-396): dst = diff .* value .* (1 - value) | diff .* (1 - value^2) */
+int k3_mat_diff_activation(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_value, int64_t ldv, const float *d_diff, int64_t ldf, void *stream);
+int k3_mat_div_rows_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_div, void *stream);            /* DivRowsVec: row r divided by div[r] */
+int k3_mat_copy_cols_from_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_col, void *stream);      /* CopyColsFromVec with a vector of dimension rows: every column = v */
+int k3_mat_copy_cols(int32_t add, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *stream);   /* CopyCols (add 0) / AddCols (1): dst(r, c) (+)= src(r, indexes[c]), -1 = zero / skip */
 int64_t k3_mat_gemm_flops(int32_t reset);      /* 2 M N K summed over this process's k3_mat_add_mat_mat calls (reset != 0: read and clear) -- the flop count of a training iteration for its roofline */
 int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta,
                        float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream);      /* AddMatMat: C = alpha op(A) op(B) + beta C, FP32 MFMA */

@@ -207,8 +207,12 @@ __global__ void k3_gemm_splitk_reduce_kernel(const float *W, int S, long long MN
 }
 
 enum { kOpSet, kOpScale, kOpFloor, kOpCeil, kOpAddConst, kOpCopyRowsFromVec, kOpMulColsVec, kOpMulRowsVec, kOpAddVecToRows, kOpAddVecToCols, kOpCopy, kOpCopyT, kOpAddMat, kOpAddMatT,
-       kOpCopyRows, kOpAddRows, kOpMulElements, kOpHeaviside, kOpAddMatDiagVec, kOpAddMatDiagVecT, kOpAddRowRanges, kOpCopyLowerToUpper, kOpAddToDiag, kOpAddVecVecOuter, kOpDivElements, kOpAddDiagVecMat, kOpAddDiagVecMatT };
-struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; int src_rows; };
+       kOpCopyRows, kOpAddRows, kOpMulElements, kOpHeaviside, kOpAddMatDiagVec, kOpAddMatDiagVecT, kOpAddRowRanges, kOpCopyLowerToUpper, kOpAddToDiag, kOpAddVecVecOuter, kOpDivElements, kOpAddDiagVecMat, kOpAddDiagVecMatT,
+       kOpSigmoid, kOpTanh, kOpDiffSigmoid, kOpDiffTanh, kOpMax, kOpLog, kOpPow, kOpPowAbs, kOpDivRowsVec, kOpCopyCols, kOpAddCols, kOpCopyColsFromVec };
+struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; int src_rows; const float *S2; long long lds2; };
+// SigmoidComponent / TanhComponent (matrix/kaldi-vector.cc:900-960, the overflow-safe forms of the build without MKL's vector math)
+__device__ __forceinline__ float ew_sigmoid(float x) { if (x > 0.0f) return 1.0f / (1.0f + expf(-x)); const float e = expf(x); return e / (e + 1.0f); }
+__device__ __forceinline__ float ew_tanh(float x) { if (x > 0.0f) { const float e = expf(-x); return -1.0f + 2.0f / (1.0f + e * e); } const float e = expf(x); return 1.0f - 2.0f / (1.0f + e * e); }
 
 __device__ __forceinline__ float ew_elem(const EwParams &p, int r, int c, float dv) {      // the new value of element (r, c); dv = its old value (loaded only for the operations that read it)
   float x = 0.0f;
@@ -239,6 +243,18 @@ __device__ __forceinline__ float ew_elem(const EwParams &p, int r, int c, float 
       case kOpDivElements: x = dv / p.S[(long long)r * p.lds + c]; break;
       case kOpAddDiagVecMat: x = p.b * dv + p.a * p.v[r] * p.S[(long long)r * p.lds + c]; break;                 // this = beta this + alpha diag(v) M
       case kOpAddDiagVecMatT: x = p.b * dv + p.a * p.v[r] * p.S[(long long)c * p.lds + r]; break;
+      case kOpSigmoid: x = ew_sigmoid(p.S[(long long)r * p.lds + c]); break;
+      case kOpTanh: x = ew_tanh(p.S[(long long)r * p.lds + c]); break;
+      case kOpDiffSigmoid: { const float y = p.S[(long long)r * p.lds + c]; x = p.S2[(long long)r * p.lds2 + c] * y * (1.0f - y); break; }      // kaldi-matrix.cc:3004-3018: diff .* value .* (1 - value)
+      case kOpDiffTanh: { const float y = p.S[(long long)r * p.lds + c]; x = p.S2[(long long)r * p.lds2 + c] * (1.0f - y * y); break; }
+      case kOpMax: x = fmaxf(dv, p.S[(long long)r * p.lds + c]); break;
+      case kOpLog: x = logf(p.S[(long long)r * p.lds + c]); break;
+      case kOpPow: x = powf(p.S[(long long)r * p.lds + c], p.a); break;
+      case kOpPowAbs: { const float sv = p.S[(long long)r * p.lds + c], y = powf(fabsf(sv), p.a); x = (p.b != 0.0f && sv < 0.0f) ? -y : y; break; }      // kaldi-matrix.cc:2145-2160
+      case kOpDivRowsVec: x = dv / p.v[r]; break;
+      case kOpCopyCols: { const int s = p.idx[c]; x = s < 0 ? 0.0f : p.S[(long long)r * p.lds + s]; break; }                                         // kaldi-matrix.cc:2836-2858 (index -1 = zero column)
+      case kOpAddCols: { const int s = p.idx[c]; x = s < 0 ? dv : dv + p.S[(long long)r * p.lds + s]; break; }
+      case kOpCopyColsFromVec: x = p.v[r]; break;
       case kOpAddRowRanges: { const int b0 = p.idx[2 * r], b1 = p.idx[2 * r + 1]; x = dv; for (int k = b0; k < b1; k++) x += p.S[(long long)k * p.lds + c]; break; }      // cu-kernels.cu _add_row_ranges
     }
   return x;
@@ -248,9 +264,9 @@ __device__ __forceinline__ float ew_elem(const EwParams &p, int r, int c, float 
 __device__ __forceinline__ bool ew_vec4_op(int op) {
   return op == kOpSet || op == kOpScale || op == kOpFloor || op == kOpCeil || op == kOpAddConst || op == kOpCopyRowsFromVec || op == kOpMulColsVec || op == kOpMulRowsVec || op == kOpAddVecToRows ||
          op == kOpAddVecToCols || op == kOpCopy || op == kOpAddMat || op == kOpCopyRows || op == kOpAddRows || op == kOpMulElements || op == kOpHeaviside || op == kOpAddMatDiagVec || op == kOpDivElements ||
-         op == kOpAddDiagVecMat;
+         op == kOpAddDiagVecMat || op == kOpSigmoid || op == kOpTanh || op == kOpDiffSigmoid || op == kOpDiffTanh || op == kOpMax;
 }
-__device__ __forceinline__ float ew_f(int op, float d, float s_, float v, float a, float b) {      // element value from the old value d, the source element s_, the vector element v (column- or row-indexed by op)
+__device__ __forceinline__ float ew_f(int op, float d, float s_, float v, float a, float b, float s2 = 0.0f) {      // element value from the old value d, the source element s_, the vector element v (column- or row-indexed by op)
   switch (op) {
     case kOpSet: return a;
     case kOpScale: return d * a;
@@ -267,6 +283,11 @@ __device__ __forceinline__ float ew_f(int op, float d, float s_, float v, float 
     case kOpAddMatDiagVec: return b * d + a * s_ * v;
     case kOpDivElements: return d / s_;
     case kOpAddDiagVecMat: return b * d + a * v * s_;
+    case kOpSigmoid: return ew_sigmoid(s_);
+    case kOpTanh: return ew_tanh(s_);
+    case kOpDiffSigmoid: return s2 * s_ * (1.0f - s_);
+    case kOpDiffTanh: return s2 * (1.0f - s_ * s_);
+    case kOpMax: return fmaxf(d, s_);
   }
   return d;
 }
@@ -275,8 +296,9 @@ __global__ __launch_bounds__(256) void k3_ew4_kernel(EwParams p) {      // 256 c
   const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
   if (c >= p.cols) return;
   const int op = p.op;
-  const bool reads_d = !(op == kOpSet || op == kOpCopyRowsFromVec || op == kOpCopy || op == kOpCopyRows || op == kOpHeaviside);
-  const bool has_s = op == kOpCopy || op == kOpAddMat || op == kOpCopyRows || op == kOpAddRows || op == kOpMulElements || op == kOpHeaviside || op == kOpAddMatDiagVec || op == kOpDivElements || op == kOpAddDiagVecMat;
+  const bool unary = op == kOpSigmoid || op == kOpTanh, diff2 = op == kOpDiffSigmoid || op == kOpDiffTanh;
+  const bool reads_d = !(op == kOpSet || op == kOpCopyRowsFromVec || op == kOpCopy || op == kOpCopyRows || op == kOpHeaviside || unary || diff2);
+  const bool has_s = op == kOpCopy || op == kOpAddMat || op == kOpCopyRows || op == kOpAddRows || op == kOpMulElements || op == kOpHeaviside || op == kOpAddMatDiagVec || op == kOpDivElements || op == kOpAddDiagVecMat || unary || diff2 || op == kOpMax;
   const bool col_v = op == kOpCopyRowsFromVec || op == kOpMulColsVec || op == kOpAddVecToRows || op == kOpAddMatDiagVec, row_v = op == kOpMulRowsVec || op == kOpAddVecToCols || op == kOpAddDiagVecMat;
   const bool indexed = op == kOpCopyRows || op == kOpAddRows;
   f32x4 vc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -286,13 +308,14 @@ __global__ __launch_bounds__(256) void k3_ew4_kernel(EwParams p) {      // 256 c
 #pragma unroll
     for (int e = 0; e < 2; e++) {
       const int r = r0 + e; if (r >= p.rows) break;
-      f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f}, sv = d;
+      f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f}, sv = d, s2 = d;
+      if (diff2) s2 = *reinterpret_cast<const f32x4 *>(p.S2 + (long long)r * p.lds2 + c);
       if (reads_d) d = *reinterpret_cast<const f32x4 *>(p.C + (long long)r * p.ldc + c);
       bool skip = false;
       if (has_s) { const int sr = indexed ? p.idx[r] : r; if (sr >= 0) sv = *reinterpret_cast<const f32x4 *>(p.S + (long long)sr * p.lds + c); else skip = op == kOpAddRows; }
       const float vr = row_v ? p.v[r] : 0.0f;
 #pragma unroll
-      for (int k = 0; k < 4; k++) x[e][k] = skip ? d[k] : ew_f(op, d[k], sv[k], col_v ? vc[k] : vr, p.a, p.b);
+      for (int k = 0; k < 4; k++) x[e][k] = skip ? d[k] : ew_f(op, d[k], sv[k], col_v ? vc[k] : vr, p.a, p.b, s2[k]);
     }
 #pragma unroll
     for (int e = 0; e < 2; e++) if (r0 + e < p.rows) *reinterpret_cast<f32x4 *>(p.C + (long long)(r0 + e) * p.ldc + c) = x[e];
@@ -301,7 +324,8 @@ __global__ __launch_bounds__(256) void k3_ew4_kernel(EwParams p) {      // 256 c
 __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {      // 64 columns x 16 rows per workgroup and step: four rows per thread, their loads issued together
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   if (c >= p.cols) return;
-  const bool reads_d = !(p.op == kOpSet || p.op == kOpCopyRowsFromVec || p.op == kOpCopy || p.op == kOpCopyT || p.op == kOpCopyRows || p.op == kOpHeaviside);
+  const bool reads_d = !(p.op == kOpSet || p.op == kOpCopyRowsFromVec || p.op == kOpCopy || p.op == kOpCopyT || p.op == kOpCopyRows || p.op == kOpHeaviside || p.op == kOpSigmoid || p.op == kOpTanh ||
+                         p.op == kOpDiffSigmoid || p.op == kOpDiffTanh || p.op == kOpLog || p.op == kOpPow || p.op == kOpPowAbs || p.op == kOpCopyCols || p.op == kOpCopyColsFromVec);
   for (int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4; r0 < p.rows; r0 += gridDim.y * 16) {
     float x[4];
 #pragma unroll
@@ -442,15 +466,47 @@ __global__ __launch_bounds__(256) void k3_row_softmax_kernel(int op, float *D, l
   }
 }
 
+// cu::NormalizePerRow / cu::DiffNormalizePerRow (cudamatrix/cu-math.cc:280-318, :349-409; NormalizeComponent, nnet-normalize-component.cc): one wavefront per row.
+// forward: y = x * (max(|x|^2 / (D target_rms^2), 2^-66))^-1/2, and with add_log_stddev one more column log(target_rms) - log(that factor).
+// backward (the order of the CPU branch): in_deriv (+)= [log-stddev term] + f * out_deriv - (1 / (D target_rms^2)) * <out_deriv, x> * f^3 * x; f^3 := 0 where the floor applied;
+// in_deriv aliasing out_deriv (the component's in-place backprop) is overwritten instead of added to.
+__global__ __launch_bounds__(256) void k3_row_normalize_kernel(int op, float *D, long long ldd, const float *X, long long ldx, const float *G, long long ldg, int rows, int cols, float target_rms, int add_log) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float kFloor = 1.3552527156068805425e-20f;      // 2^-66
+  float *d = D + (long long)r * ldd; const float *x = X + (long long)r * ldx; const float *g = G ? G + (long long)r * ldg : nullptr;
+  const float d_scaled = (float)cols * target_rms * target_rms;
+  float ss = 0.0f, dot = 0.0f;
+  for (int c = lane; c < cols; c += 64) { const float v = x[c]; ss += v * v; if (op == 1) dot += g[c] * v; }
+  for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+  if (op == 0) {
+    const float f = 1.0f / sqrtf(fmaxf(ss * (1.0f / d_scaled), kFloor));
+    for (int c = lane; c < cols; c += 64) d[c] = x[c] * f;
+    if (add_log && lane == 0) d[cols] = -logf(f) + logf(target_rms);
+    return;
+  }
+  const float scaled = ss * (1.0f / d_scaled), f = 1.0f / sqrtf(fmaxf(scaled, kFloor)), f3 = scaled <= kFloor ? 0.0f : f * f * f;
+  const float lsd = add_log ? g[cols] / fmaxf(ss, (float)cols * kFloor) : 0.0f, w = (-1.0f / d_scaled) * (dot * f3);
+  const bool in_place = D == G;
+  for (int c = lane; c < cols; c += 64) {
+    float t;
+    if (in_place) t = g[c] * f;
+    else { t = d[c]; if (add_log) t += lsd * x[c]; t += f * g[c]; }
+    d[c] = t + w * x[c];
+  }
+}
+
 int launch_ew(const EwParams &p, void *stream) {
   if (p.rows <= 0 || p.cols <= 0) return K3_OK;
   static const int traced = [] { const char *e = getenv("K3_GEMM_TRACE"); return e && atoi(e) >= 2 ? 1 : 0; }();
   if (traced) fprintf(stderr, "k3 ew op %d rows %d cols %d\n", p.op, p.rows, p.cols);      // developer aid
   auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  const bool has_s = p.op == kOpCopy || p.op == kOpAddMat || p.op == kOpCopyRows || p.op == kOpAddRows || p.op == kOpMulElements || p.op == kOpHeaviside || p.op == kOpAddMatDiagVec || p.op == kOpDivElements || p.op == kOpAddDiagVecMat;
+  const bool has_s = p.op == kOpCopy || p.op == kOpAddMat || p.op == kOpCopyRows || p.op == kOpAddRows || p.op == kOpMulElements || p.op == kOpHeaviside || p.op == kOpAddMatDiagVec || p.op == kOpDivElements || p.op == kOpAddDiagVecMat ||
+                     p.op == kOpSigmoid || p.op == kOpTanh || p.op == kOpDiffSigmoid || p.op == kOpDiffTanh || p.op == kOpMax;
+  const bool has_s2 = p.op == kOpDiffSigmoid || p.op == kOpDiffTanh;
   const bool col_v = p.op == kOpCopyRowsFromVec || p.op == kOpMulColsVec || p.op == kOpAddVecToRows || p.op == kOpAddMatDiagVec;
   const bool v4 = (p.op == kOpSet || p.op == kOpScale || p.op == kOpFloor || p.op == kOpCeil || p.op == kOpAddConst || p.op == kOpMulRowsVec || p.op == kOpAddVecToCols || has_s || col_v) &&
-                  p.cols % 4 == 0 && p.cols >= 64 && p.ldc % 4 == 0 && al16(p.C) && (!has_s || (p.lds % 4 == 0 && al16(p.S))) && (!col_v || al16(p.v)) && !getenv("K3_EW_SCALAR");
+                  p.cols % 4 == 0 && p.cols >= 64 && p.ldc % 4 == 0 && al16(p.C) && (!has_s || (p.lds % 4 == 0 && al16(p.S))) && (!has_s2 || (p.lds2 % 4 == 0 && al16(p.S2))) && (!col_v || al16(p.v)) && !getenv("K3_EW_SCALAR");
   if (v4) {
     hipLaunchKernelGGL(k3_ew4_kernel, dim3((p.cols + 255) / 256, (unsigned)std::min(65535, (p.rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, p);
     K3_HIP_CHECK(hipGetLastError());
@@ -652,6 +708,33 @@ extern "C" int k3_mat_softmax_rows(int32_t op, float *d_dst, int64_t ldd, const 
   hipLaunchKernelGGL(k3_row_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)st, op, d_dst, (long long)ldd, d_a, (long long)lda, d_b, (long long)ldb, rows, cols);
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
+}
+extern "C" int k3_mat_normalize_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_in, int64_t ldi, const float *d_out_deriv, int64_t ldo, int32_t rows, int32_t cols, float target_rms, int32_t add_log_stddev, void *st) {
+  K3_REQUIRE(d_dst && d_in && (op == 0 || op == 1) && rows >= 0 && cols >= 0 && ldi >= cols && ldd >= cols + (op == 0 && add_log_stddev ? 1 : 0) && target_rms > 0.0f &&
+             (op == 0 || (d_out_deriv && ldo >= cols + (add_log_stddev ? 1 : 0))), "k3_mat_normalize_rows: bad argument");
+  if (rows == 0 || cols == 0) return K3_OK;
+  hipLaunchKernelGGL(k3_row_normalize_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)st, op, d_dst, (long long)ldd, d_in, (long long)ldi, d_out_deriv, (long long)ldo, rows, cols, target_rms, add_log_stddev ? 1 : 0);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+// element maps of the remaining nonlinearities (CuMatrixBase::Sigmoid / Tanh / Log / Pow / PowAbs / Max, cu-matrix.h): op 0 sigmoid(src), 1 tanh(src), 2 log(src), 3 pow(src, a),
+// 4 pow(|src|, a) (flag: with src's sign), 5 max(dst, src)
+extern "C" int k3_mat_apply_map(int32_t op, float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, float a, int32_t flag, void *st) {
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && lds >= cols && op >= 0 && op <= 5, "k3_mat_apply_map: bad argument");
+  static const int ops[6] = {kOpSigmoid, kOpTanh, kOpLog, kOpPow, kOpPowAbs, kOpMax};
+  EwParams p = mk(ops[op], C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.a = a; p.b = flag ? 1.0f : 0.0f; return launch_ew(p, st);
+}
+// CuMatrixBase::DiffSigmoid / DiffTanh (cu-matrix.h:390-396): dst = diff .* value .* (1 - value) (op 0) or diff .* (1 - value^2) (op 1); dst may be diff or value
+extern "C" int k3_mat_diff_activation(int32_t op, float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_value, int64_t ldv, const float *d_diff, int64_t ldf, void *st) {
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_value && d_diff && ldv >= cols && ldf >= cols && (op == 0 || op == 1), "k3_mat_diff_activation: bad argument");
+  EwParams p = mk(op == 0 ? kOpDiffSigmoid : kOpDiffTanh, C, ldc, rows, cols); p.S = d_value; p.lds = ldv; p.S2 = d_diff; p.lds2 = ldf; return launch_ew(p, st);
+}
+extern "C" int k3_mat_div_rows_vec(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_div, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_div, "k3_mat_div_rows_vec: null vector"); EwParams p = mk(kOpDivRowsVec, C, ldc, rows, cols); p.v = d_div; return launch_ew(p, st); }
+extern "C" int k3_mat_copy_cols_from_vec(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_col, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_col, "k3_mat_copy_cols_from_vec: null vector"); EwParams p = mk(kOpCopyColsFromVec, C, ldc, rows, cols); p.v = d_col; return launch_ew(p, st); }
+// CuMatrixBase::CopyCols / AddCols (cu-matrix.h:102-111): dst(r, c) (+)= src(r, indexes[c]); index -1 = zero / nothing added
+extern "C" int k3_mat_copy_cols(int32_t add, float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *st) {
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_indexes && lds > 0, "k3_mat_copy_cols: bad source");
+  EwParams p = mk(add ? kOpAddCols : kOpCopyCols, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_indexes; return launch_ew(p, st);
 }
 extern "C" int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *st) {
   K3_REQUIRE(d_M && d_v && rows >= 0 && cols >= 0 && ldm >= cols && op >= 0 && op <= 4 && (op != 2 || (d_N && ldn >= cols)), "k3_vec_col_reduce: bad argument");

@@ -75,6 +75,9 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // affine + ReLU + BatchNorm + bypass), 2: none (linear bottleneck), 3: ReLU, scale/offset.  The fixed programs are straight-line
 // code; the run-time dispatch costs a register shuffle per op when it merges the branches.
 enum { kEpiAny = 0, kEpiReluScaleRes = 1, kEpiNone = 2, kEpiReluScale = 3 };
+// SigmoidComponent / TanhComponent: the overflow-safe forms of matrix/kaldi-vector.cc:900-960
+__device__ __forceinline__ float epi_sigmoid(float x) { if (x > 0.0f) return 1.0f / (1.0f + expf(-x)); const float e = expf(x); return e / (e + 1.0f); }
+__device__ __forceinline__ float epi_tanh(float x) { if (x > 0.0f) { const float e = expf(-x); return -1.0f + 2.0f / (1.0f + e * e); } const float e = expf(x); return 1.0f - 2.0f / (1.0f + e * e); }
 template <int BN, int WM, int WN, bool kAligned, int EPI>
 __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN) == 8 ? 4 : 2) void k3_tdnn_gemm_kernel(GemmParams p) {
   constexpr int NT = (kBM / WM) * (BN / WN) * 64, LR = NT / 8;      // threads per workgroup (4 or 8 wavefronts); rows the loader covers per pass
@@ -327,6 +330,11 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
           } else if (kind == k3::kEpiScaleOffset) {
 #pragma unroll
             for (int it = 0; it < ITERS; it++) v[it] = v[it] * opS[o] + opO[o];
+          } else if (kind == k3::kEpiSigmoid || kind == k3::kEpiTanh) {
+#pragma unroll
+            for (int it = 0; it < ITERS; it++)
+#pragma unroll
+              for (int e = 0; e < 4; e++) v[it][e] = kind == k3::kEpiSigmoid ? epi_sigmoid(v[it][e]) : epi_tanh(v[it][e]);
           } else {
 #pragma unroll
             for (int it = 0; it < ITERS; it++) v[it] = p.res_scale * res[it] + v[it];
@@ -370,6 +378,8 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
           const int kind = p.op_kind[o];
           if (kind == k3::kEpiRelu) x = fmaxf(x, 0.0f);
           else if (kind == k3::kEpiScaleOffset) x = x * p.op_scale[o][c] + p.op_offset[o][c];
+          else if (kind == k3::kEpiSigmoid) x = epi_sigmoid(x);
+          else if (kind == k3::kEpiTanh) x = epi_tanh(x);
           else x = p.res_scale * R[(long long)((lrow < td.split ? td.res_base : td.res_base2) + lrow * p.res_row_stride) * p.ldr + c] + x;
         }
         C[(long long)(td.out_row0 + lrow) * p.ldc + c] = x;
@@ -395,6 +405,8 @@ __global__ __launch_bounds__(256) void k3_elementwise_kernel(GemmParams p) {
       const int kind = p.op_kind[o];
       if (kind == k3::kEpiRelu) v = fmaxf(v, 0.0f);
       else if (kind == k3::kEpiScaleOffset) v = v * p.op_scale[o][col] + p.op_offset[o][col];
+      else if (kind == k3::kEpiSigmoid) v = epi_sigmoid(v);
+      else if (kind == k3::kEpiTanh) v = epi_tanh(v);
       else v = p.res_scale * p.R[(long long)((s2 ? td.res_base2 : td.res_base) + lrow * p.res_row_stride) * p.ldr + col] + v;
     }
     p.C[(long long)(td.out_row0 + lrow) * p.ldc + col] = v;
@@ -452,6 +464,17 @@ __global__ __launch_bounds__(256) void k3_row_softmax_kernel(float *C, long long
     if (scale) y = y * scale[c] + offset[c];
     x[c] = y;
   }
+}
+// NormalizeComponent::Propagate (nnet-normalize-component.cc; cu::NormalizePerRow, cudamatrix/cu-math.cc:280-318) in place: x * (max(|x|^2 / (D target_rms^2), 2^-66))^-1/2
+__global__ __launch_bounds__(256) void k3_row_normalize_kernel(float *C, long long ldc, int rows, int cols, float target_rms, const float *scale, const float *offset) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float *x = C + (long long)r * ldc;
+  float ss = 0.0f;
+  for (int c = lane; c < cols; c += 64) ss += x[c] * x[c];
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float f = 1.0f / sqrtf(fmaxf(ss * (1.0f / ((float)cols * target_rms * target_rms)), 1.3552527156068805425e-20f));
+  for (int c = lane; c < cols; c += 64) { float y = x[c] * f; if (scale) y = y * scale[c] + offset[c]; x[c] = y; }
 }
 
 }  // namespace
@@ -860,7 +883,9 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
     }
     if (f.row_op) {      // LogSoftmaxComponent / SoftmaxComponent on the node's rows, in place; on the output node followed by (x - log prior) * acoustic scale
       const bool outn = (int)i == fm.output_node;
-      hipLaunchKernelGGL(k3_row_softmax_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc, (int)b->node_rows[i], f.out_dim, f.row_op,
+      if (f.row_op == 3) hipLaunchKernelGGL(k3_row_normalize_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc, (int)b->node_rows[i], f.out_dim, f.row_param,
+                                            outn ? b->out_scale : (const float *)nullptr, outn ? b->out_offset : (const float *)nullptr);
+      else hipLaunchKernelGGL(k3_row_softmax_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc, (int)b->node_rows[i], f.out_dim, f.row_op,
                          outn ? b->out_scale : (const float *)nullptr, outn ? b->out_offset : (const float *)nullptr);
     }
     K3_HIP_CHECK(hipGetLastError());

@@ -439,8 +439,17 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
     }
     // ---- element-wise component: fold into the producing node when it is that node's only consumer ----
     const bool is_relu = c.type == "RectifiedLinearComponent", is_bn = c.type == "BatchNormComponent", is_id = IsIdentityAtTest(c.type);
-    const int row_op = c.type == "LogSoftmaxComponent" ? 1 : c.type == "SoftmaxComponent" ? 2 : 0;      // nnet-simple-component.cc:3618-3625 / :3494-3504 (the output layer of non-chain nnet3 models)
-    if (!is_relu && !is_bn && !is_id && !row_op) {
+    const bool is_sig = c.type == "SigmoidComponent", is_tanh = c.type == "TanhComponent";
+    const int row_op = c.type == "LogSoftmaxComponent" ? 1 : c.type == "SoftmaxComponent" ? 2 : c.type == "NormalizeComponent" ? 3 : 0;      // nnet-simple-component.cc:3618-3625 / :3494-3504 (the output layer of non-chain nnet3 models); nnet-normalize-component.cc (relu-renorm layers)
+    float row_param = 0.0f;
+    if (row_op == 3) {      // NormalizeComponent::Read: <TargetRms> and <AddLogStddev> (absent in old models = 1.0 / false)
+      const Field *tr = c.get("<TargetRms>"), *als = c.get("<AddLogStddev>");
+      row_param = tr && !tr->scalars.empty() ? tr->scalars[0].as_float() : 1.0f;
+      if (c.get("<BlockDim>")) { *err = "NormalizeComponent " + c.name + " with block-dim != dim is not supported by the fused MI355X path"; return false; }
+      if (als && !als->scalars.empty() && als->scalars[0].num != 0.0) { *err = "NormalizeComponent " + c.name + " with add-log-stddev=true is not supported by the fused MI355X path (its output has one more column)"; return false; }
+      if (!(row_param > 0.0f)) { *err = "NormalizeComponent " + c.name + ": bad <TargetRms>"; return false; }
+    }
+    if (!is_relu && !is_bn && !is_id && !row_op && !is_sig && !is_tanh) {
       *err = "component type " + c.type + " (" + c.name + ") is not supported by the MI355X TDNN/TDNN-F path"; return false;
     }
     // main input + optional residual term
@@ -485,9 +494,10 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
       t.ops.push_back(std::move(op));
     }
     if (is_relu) { EpiOp op; op.kind = kEpiRelu; t.ops.push_back(std::move(op)); }
+    if (is_sig || is_tanh) { EpiOp op; op.kind = is_sig ? kEpiSigmoid : kEpiTanh; t.ops.push_back(std::move(op)); }
     if (is_bn) { EpiOp op; op.kind = kEpiScaleOffset; if (!BatchNormScaleOffset(c, &op.scale, &op.offset, err)) return false;
                  if ((int)op.scale.size() != t.out_dim) { *err = "BatchNorm dim mismatch at " + n.name; return false; } t.ops.push_back(std::move(op)); }
-    if (row_op) t.row_op = row_op;
+    if (row_op) { t.row_op = row_op; t.row_param = row_param; }
     t.name = n.name; producer[n.name] = target; dims[n.name] = t.out_dim;
   }
   if (fm->output_node < 0) { *err = "model has no output-node name=output"; return false; }

@@ -41,6 +41,23 @@ class CuMatrix:
     def DivElements(self, A): _l.check(self._L.k3_mat_div_elements(*self._a(), A.t.data_ptr(), A.Stride(), _st()))
     def AddDiagVecMat(self, alpha, v, M, transM, beta):
         _l.check(self._L.k3_mat_add_diag_vec_mat(alpha, v.data_ptr(), M.t.data_ptr(), M.Stride(), int(transM), beta, self.t.data_ptr(), self.Stride(), self.NumRows(), self.NumCols(), _st()))
+    # ---- the remaining nonlinearities of nnet3's simple components and their derivatives (cu-matrix.h:288-307,:386-396,:501-511; cu-math.h:272-300)
+    def _map(self, op, src, a=0.0, flag=0): _l.check(self._L.k3_mat_apply_map(op, *self._a(), src.t.data_ptr(), src.Stride(), a, flag, _st()))
+    def Sigmoid(self, src): self._map(0, src)
+    def Tanh(self, src): self._map(1, src)
+    def Log(self, src): self._map(2, src)
+    def Pow(self, src, power): self._map(3, src, power)
+    def PowAbs(self, src, power, include_sign=False): self._map(4, src, power, int(include_sign))
+    def MaxMat(self, A): self._map(5, A)      # CuMatrixBase::Max(const CuMatrixBase &A) (Max() without an argument is the scalar reduction)
+    def DiffSigmoid(self, value, diff): _l.check(self._L.k3_mat_diff_activation(0, *self._a(), value.t.data_ptr(), value.Stride(), diff.t.data_ptr(), diff.Stride(), _st()))
+    def DiffTanh(self, value, diff): _l.check(self._L.k3_mat_diff_activation(1, *self._a(), value.t.data_ptr(), value.Stride(), diff.t.data_ptr(), diff.Stride(), _st()))
+    def DivRowsVec(self, div): _l.check(self._L.k3_mat_div_rows_vec(*self._a(), div.data_ptr(), _st()))
+    def CopyColsFromVec(self, v):
+        if v.numel() == self.NumRows() * self.NumCols(): _l.check(self._L.k3_mat_copy_from_mat(*self._a(), v.data_ptr(), self.NumRows(), 1, _st()))      # the vector is the matrix column by column
+        else: assert v.numel() == self.NumRows(); _l.check(self._L.k3_mat_copy_cols_from_vec(*self._a(), v.data_ptr(), _st()))
+    def CopyColFromVec(self, v, col): assert v.numel() == self.NumRows(); _l.check(self._L.k3_mat_copy_from_mat(self.t.data_ptr() + 4 * col, self.Stride(), self.NumRows(), 1, v.data_ptr(), 1, 0, _st()))
+    def CopyCols(self, src, indexes): _l.check(self._L.k3_mat_copy_cols(0, *self._a(), src.t.data_ptr(), src.Stride(), indexes.data_ptr(), _st()))
+    def AddCols(self, src, indexes): _l.check(self._L.k3_mat_copy_cols(1, *self._a(), src.t.data_ptr(), src.Stride(), indexes.data_ptr(), _st()))
     def _reduce(self, op, B=None):
         r = ctypes.c_double(0.0)
         _l.check(self._L.k3_mat_reduce_scalar(op, self.t.data_ptr(), self.Stride(), B.t.data_ptr() if B is not None else None, B.Stride() if B is not None else 0, self.NumRows(), self.NumCols(), ctypes.byref(r), _st()))
@@ -51,3 +68,10 @@ class CuMatrix:
     def Min(self): return self._reduce(5)
 
 def TraceMatMat(A, B, trans=False): return A._reduce(0 if trans else 1, B)
+
+def NormalizePerRow(inp, target_rms, add_log_stddev, out):      # cu::NormalizePerRow (cudamatrix/cu-math.h:272)
+    assert out.NumRows() == inp.NumRows() and out.NumCols() == inp.NumCols() + int(add_log_stddev)
+    _l.check(out._L.k3_mat_normalize_rows(0, out.t.data_ptr(), out.Stride(), inp.t.data_ptr(), inp.Stride(), None, 0, inp.NumRows(), inp.NumCols(), target_rms, int(add_log_stddev), _st()))
+def DiffNormalizePerRow(in_value, out_deriv, target_rms, add_log_stddev, in_deriv):      # cu::DiffNormalizePerRow (cudamatrix/cu-math.h:296): ADDS to in_deriv unless it is out_deriv
+    assert out_deriv.NumCols() == in_value.NumCols() + int(add_log_stddev) and in_deriv.NumCols() == in_value.NumCols()
+    _l.check(in_deriv._L.k3_mat_normalize_rows(1, in_deriv.t.data_ptr(), in_deriv.Stride(), in_value.t.data_ptr(), in_value.Stride(), out_deriv.t.data_ptr(), out_deriv.Stride(), in_value.NumRows(), in_value.NumCols(), target_rms, int(add_log_stddev), _st()))

@@ -16,7 +16,9 @@ Component semantics restated (paths relative to /root/reference/src/nnet3):
   BatchNormComponent (test mode)                     nnet-normalize-component.cc:209-247 (ComputeDerived), :453-463
   NoOpComponent / (General)DropoutComponent in test mode: identity (nnet-simple-component.cc:440-445,
                                                      nnet-general-component.cc:1564-1576)
-  LogSoftmaxComponent                                nnet-simple-component.cc:3618-3625
+  LogSoftmaxComponent / SoftmaxComponent             nnet-simple-component.cc:3618-3625, :3494-3504
+  SigmoidComponent / TanhComponent                   nnet-simple-component.cc (Propagate = CuMatrixBase::Sigmoid / Tanh; matrix/kaldi-vector.cc:888-960)
+  NormalizeComponent                                 nnet-normalize-component.cc:132-151 (cu::NormalizePerRow, cudamatrix/cu-math.cc:280-318)
 Descriptors (nnet-descriptor.h): node | Offset(d, t) | Append(d...) | Sum(d, d) | Scale(a, d).
 
 Pinned by tests/test_oracle_nnet.py against outputs of the reference's own nnet3-compute binary
@@ -292,6 +294,23 @@ def _apply_component(c, seq):
     if t == "LogSoftmaxComponent":
         m = x.max(axis=1, keepdims=True)
         return _Seq(seq.t0, (x - m - np.log(np.exp(x - m).sum(axis=1, keepdims=True))).astype(_F()))
+    if t == "SoftmaxComponent":
+        m = x.max(axis=1, keepdims=True); e = np.exp(x - m)
+        return _Seq(seq.t0, (e / e.sum(axis=1, keepdims=True)).astype(_F()))
+    if t == "SigmoidComponent":      # matrix/kaldi-vector.cc:938-960 (the MKL build evaluates the same function as 0.5 (tanh(x / 2) + 1))
+        x64 = x.astype(np.float64); return _Seq(seq.t0, (1.0 / (1.0 + np.exp(-x64))).astype(_F()))
+    if t == "TanhComponent":         # matrix/kaldi-vector.cc:888-916
+        return _Seq(seq.t0, np.tanh(x.astype(np.float64)).astype(_F()))
+    if t == "NormalizeComponent":    # nnet-normalize-component.cc:132-151 -> cu::NormalizePerRow, cudamatrix/cu-math.cc:303-317 (CPU branch)
+        rms = _F()(float(f["<TargetRms>"][0])) if "<TargetRms>" in f else _F()(1.0)
+        D = x.shape[1]; block = int(f["<BlockDim>"][0]) if "<BlockDim>" in f else D
+        add_log = "<AddLogStddev>" in f and str(f["<AddLogStddev>"][0]) in ("T", "1", "1.0", "True")
+        xb = x.reshape(-1, block)
+        norm = (xb * xb).sum(axis=1, dtype=_F()) * _F()(1.0 / (block * float(rms) * float(rms)))
+        norm = np.maximum(norm, _F()(2.0 ** -66)) ** _F()(-0.5)
+        yb = (xb * norm[:, None]).astype(_F())
+        if add_log: yb = np.concatenate([yb, (-np.log(norm) + np.log(rms))[:, None].astype(_F())], axis=1)
+        return _Seq(seq.t0, yb.reshape(x.shape[0], -1))
     raise ValueError("oracle: unsupported component type " + t)
 
 def _eval_desc(d, vals):

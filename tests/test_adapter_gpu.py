@@ -52,10 +52,36 @@ def _init_model(tmp_path, tail):
     return raw, fa, env
 
 def test_an_operation_outside_the_adapter_fails_loudly(tmp_path):
-    """a model with a component the adapter does not cover (here: a sigmoid) must stop with the member's name, not fall back"""
-    raw, fa, _ = _init_model(tmp_path, "component name=sg type=SigmoidComponent dim=6\ncomponent-node name=sg component=sg input=a\noutput-node name=output input=sg\n")
+    """a model with a component the adapter does not cover (here: a p-norm, CuMatrixBase::GroupPnorm) must stop with the member's name, not fall back"""
+    raw, fa, _ = _init_model(tmp_path, "component name=pn type=PnormComponent input-dim=6 output-dim=3\ncomponent-node name=pn component=pn input=a\noutput-node name=output input=pn\n")
     r = subprocess.run([EXE, "--use-gpu=no", raw, f"ark:{fa}", f"ark:{tmp_path}/o.ark"], capture_output=True, text=True)
-    assert r.returncode != 0 and "not implemented on the MI355X path" in r.stderr and "Sigmoid" in r.stderr, r.stderr[-1500:]
+    assert r.returncode != 0 and "not implemented on the MI355X path" in r.stderr and "GroupPnorm" in r.stderr, r.stderr[-1500:]
+
+RENORM_TAILS = {
+    "sigmoid": "component name=x type=SigmoidComponent dim=6\ncomponent-node name=x component=x input=a\noutput-node name=output input=x\n",
+    "tanh": "component name=x type=TanhComponent dim=6\ncomponent-node name=x component=x input=a\noutput-node name=output input=x\n",
+    "renorm": "component name=x type=NormalizeComponent dim=6 target-rms=0.7\ncomponent-node name=x component=x input=a\noutput-node name=output input=x\n",
+    "renorm_log_stddev": "component name=x type=NormalizeComponent dim=6 add-log-stddev=true\ncomponent-node name=x component=x input=a\noutput-node name=output input=x\n",
+    "renorm_blocks": "component name=x type=NormalizeComponent dim=6 block-dim=3 target-rms=2.0\ncomponent-node name=x component=x input=a\noutput-node name=output input=x\n"}
+@pytest.mark.parametrize("kind", sorted(RENORM_TAILS))
+def test_sigmoid_tanh_renorm_layers_equal_the_reference(kind, tmp_path):
+    """SigmoidComponent / TanhComponent / NormalizeComponent (plain, with the log-stddev column, in blocks): the reference's NnetComputer over the adapter (CuMatrixBase::Sigmoid / Tanh,
+    cu-matrix.h:288,:386; cu::NormalizePerRow, cu-math.h:272) against the reference's own nnet3-compute on the CPU; the fused path of k3_nnet_load for the layouts it takes, a refusal by
+    name for the two it does not"""
+    from oracle import kaldi_io as kio
+    raw, fa, env = _init_model(tmp_path, RENORM_TAILS[kind])
+    ref = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet3-compute")
+    assert subprocess.run([ref, "--use-gpu=no", raw, f"ark:{fa}", f"ark:{tmp_path}/r.ark"], capture_output=True, env=env).returncode == 0
+    want = kio.read_ark(f"{tmp_path}/r.ark")["u"]
+    r = subprocess.run([EXE, "--use-gpu=no", raw, f"ark:{fa}", f"ark:{tmp_path}/a.ark"], capture_output=True, text=True); assert r.returncode == 0, r.stderr[-1500:]
+    got = kio.read_ark(f"{tmp_path}/a.ark")["u"]
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-5, np.abs(got - want).max()
+    prog = os.path.join(ROOT, "kaldi_amd", "bin", "nnet3-compute")
+    r = subprocess.run([prog, raw, f"ark:{fa}", f"ark:{tmp_path}/g.ark"], capture_output=True, text=True)
+    if kind in ("renorm_log_stddev", "renorm_blocks"): assert r.returncode != 0 and "NormalizeComponent" in r.stderr, r.stderr[-1500:]
+    else:
+        assert r.returncode == 0, r.stderr[-1500:]
+        got = kio.read_ark(f"{tmp_path}/g.ark")["u"]; assert got.shape == want.shape and np.abs(got - want).max() <= 1e-5, np.abs(got - want).max()
 
 @pytest.mark.parametrize("kind", ["LogSoftmaxComponent", "SoftmaxComponent"])
 def test_softmax_output_layers_equal_the_reference(kind, tmp_path):
@@ -130,6 +156,33 @@ def test_reference_training_computation_over_the_k3_cumatrix(B, T, s, tmp_path):
     assert rg.shape == gg.shape and np.linalg.norm(rg) > 0
     assert np.linalg.norm(rg - gg) <= 1e-3 * np.linalg.norm(rg), (np.linalg.norm(rg - gg), np.linalg.norm(rg))
     assert np.abs(rg - gg).max() <= 2e-3 * np.abs(rg).max(), (np.abs(rg - gg).max(), np.abs(rg).max())
+
+
+@pytest.mark.parametrize("variant", ["fixture", "log_stddev_and_blocks"])
+def test_reference_training_computation_with_sigmoid_tanh_renorm_layers(variant, tmp_path):
+    """forward in training mode + Backprop of SigmoidComponent / TanhComponent / NormalizeComponent (CuMatrixBase::DiffSigmoid / DiffTanh, cu-matrix.h:390-396; cu::DiffNormalizePerRow,
+    cu-math.h:296, added to the input derivative or in place as the compiled computation has it) through the reference's NnetComputer over the adapter, against the same program on the
+    reference's CPU matrices: tests/golden/nnet_renorm.raw, and a variant with the log-stddev column and a block dimension made by the reference's nnet3-init"""
+    import importlib.util
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-train-grad"); ref = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-nnet3-train-grad"); init = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet3-init")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/nnet3-train-grad is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    if not os.path.exists(ref) or not os.path.exists(init): pytest.skip("oracle/_ref not built")
+    td = str(tmp_path); env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"); renv = dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"))
+    model = os.path.join(GOLD, "nnet_renorm.raw"); out_dim = 16
+    if variant != "fixture":
+        spec = importlib.util.spec_from_file_location("mk", os.path.join(GOLD, "make_golden_nnet_renorm.py")); mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+        cfg = mk.CONFIG.replace("type=NormalizeComponent dim=32 target-rms=0.5", "type=NormalizeComponent dim=32 block-dim=8 target-rms=0.5 add-log-stddev=true").replace("input-dim=64 output-dim=24", "input-dim=72 output-dim=24")
+        cfg = cfg.replace("type=NormalizeComponent dim=24\n", "type=NormalizeComponent dim=24 add-log-stddev=true\n").replace("input-dim=24 output-dim=16", "input-dim=25 output-dim=16")
+        open(f"{td}/n.config", "w").write(cfg); model = f"{td}/n.raw"
+        r = subprocess.run([init, "--srand=5", f"{td}/n.config", model], capture_output=True, text=True, env=renv); assert r.returncode == 0, r.stderr[-1500:]
+    B, T, s, lc, rc = 6, 12, 3, 4, 4; Tin = (T - 1) * s + 1 + lc + rc; rng = np.random.default_rng(77)
+    x = rng.standard_normal((Tin * B, 20)) * 2.0; x[5] = 0.0; x[11] *= 40.0
+    _kaldi_matrix(f"{td}/in.mat", x); _kaldi_matrix(f"{td}/od.mat", rng.standard_normal((T * B, out_dim)) * 0.1)
+    r = subprocess.run([ref, model, str(B), str(T), str(s), f"{td}/in.mat", f"{td}/od.mat", f"{td}/ro.mat", f"{td}/rg.vec"], capture_output=True, text=True, env=renv); assert r.returncode == 0, r.stderr[-2000:]
+    g = subprocess.run([exe, model, str(B), str(T), str(s), f"{td}/in.mat", f"{td}/od.mat", f"{td}/go.mat", f"{td}/gg.vec"], capture_output=True, text=True, env=env); assert g.returncode == 0, g.stderr[-3000:]
+    ro, go, rg, gg = _read_kaldi(f"{td}/ro.mat"), _read_kaldi(f"{td}/go.mat"), _read_kaldi(f"{td}/rg.vec"), _read_kaldi(f"{td}/gg.vec")
+    assert ro.shape == go.shape and np.abs(ro - go).max() <= 1e-4, np.abs(ro - go).max()
+    assert rg.shape == gg.shape and np.linalg.norm(rg) > 0 and np.linalg.norm(rg - gg) <= 1e-4 * np.linalg.norm(rg), (np.linalg.norm(rg - gg), np.linalg.norm(rg))
 
 
 @pytest.mark.parametrize("B,T", [(4, 10), (16, 25)])

@@ -88,3 +88,46 @@ def test_update_step_operations_match_numpy():
         _l.check(Lh.k3_mat_add_mat_mat(0.5, Md.data_ptr(), n, 1, xd.data_ptr(), 1, 0, 0.25, o.data_ptr(), 1, n, 1, m, st))
         assert np.abs(o.cpu().numpy() - (0.25 * out1 + 0.5 * (A.T.astype(np.float64) @ x))).max() <= 2e-5 * max(1.0, np.abs(A.T @ x).max())
         col = T(np.zeros(m)); _l.check(Lh.k3_mat_copy_from_mat(col.data_ptr(), 1, m, 1, Md.data_ptr() + 4 * (n // 2), n, 0, st)); assert np.array_equal(col.cpu().numpy(), A[:, n // 2])      # CopyColFromMat
+
+
+def test_nonlinearity_maps_column_operations_and_row_normalisation_match_numpy():
+    """Sigmoid / Tanh / Log / Pow / PowAbs / Max / DiffSigmoid / DiffTanh / DivRowsVec / CopyCols / AddCols / CopyColsFromVec / CopyColFromVec (cu-matrix.h:102-111,:281-307,:386-396,:501-511) and
+    cu::NormalizePerRow / DiffNormalizePerRow (cu-math.cc:280-409, restated here in float64 from the CPU branch, incl. the log-stddev column, the floor and the in-place form)"""
+    from kaldi_amd import cumatrix as cm
+    from kaldi_amd.cumatrix import CuMatrix
+    rng = np.random.default_rng(5)
+    for r, c, pad in [(1, 1, 0), (7, 130, 3), (257, 65, 0), (33, 768, 8), (70, 256, 0), (19, 64, 4)]:
+        S = CuMatrix(_mat(rng, r, c, pad)); S.t.mul_(4.0); sh = S.t.cpu().numpy().astype(np.float64)
+        D = CuMatrix(_mat(rng, r, c, 4)); d0 = D.t.cpu().numpy().astype(np.float64)
+        chk = lambda want, tol=2e-6: (torch.cuda.synchronize(), np.testing.assert_allclose(D.t.cpu().numpy(), want, rtol=tol, atol=tol))
+        D.Sigmoid(S); chk(1.0 / (1.0 + np.exp(-sh)))
+        D.Tanh(S); chk(np.tanh(sh)); y = D.t.cpu().numpy().astype(np.float64)
+        G = CuMatrix(_mat(rng, r, c, 0)); gh = G.t.cpu().numpy().astype(np.float64)
+        E = CuMatrix(torch.empty_like(G.t)); E.DiffTanh(D, G); torch.cuda.synchronize(); np.testing.assert_allclose(E.t.cpu().numpy(), gh * (1.0 - y * y), rtol=1e-6, atol=1e-6)
+        G.DiffSigmoid(D, G); torch.cuda.synchronize(); np.testing.assert_allclose(G.t.cpu().numpy(), gh * y * (1.0 - y), rtol=1e-6, atol=1e-6)      # in place on diff
+        P = CuMatrix(S.t.abs() + 0.5); ph = P.t.cpu().numpy().astype(np.float64)
+        D.Log(P); chk(np.log(ph)); D.Pow(P, 1.7); chk(ph ** 1.7, 1e-5); D.PowAbs(S, 0.5, True); chk(np.sign(sh) * np.abs(sh) ** 0.5, 1e-5); D.PowAbs(S, 2.0); chk(sh * sh, 1e-5)
+        D.CopyFromMat(CuMatrix(torch.from_numpy(d0.astype(np.float32)).cuda())); D.MaxMat(S); chk(np.maximum(d0, sh))
+        w = torch.from_numpy((rng.random(r) + 0.5).astype(np.float32)).cuda(); D.DivRowsVec(w); chk(np.maximum(d0, sh) / w.cpu().numpy().astype(np.float64)[:, None])
+        src = CuMatrix(_mat(rng, r, 23, 1)); idx = torch.from_numpy(rng.integers(-1, 23, c).astype(np.int32)).cuda(); ih = idx.cpu().numpy(); sc = src.t.cpu().numpy()
+        D.CopyCols(src, idx); torch.cuda.synchronize(); want = np.where(ih[None, :] >= 0, sc[:, np.maximum(ih, 0)], 0.0).astype(np.float32); assert np.array_equal(D.t.cpu().numpy(), want)
+        D.AddCols(src, idx); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy(), want + want)
+        D.CopyColsFromVec(w); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy(), np.tile(w.cpu().numpy()[:, None], (1, c)))
+        full = torch.from_numpy(rng.standard_normal(r * c).astype(np.float32)).cuda(); D.CopyColsFromVec(full); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy(), full.cpu().numpy().reshape(c, r).T)
+        D.CopyColFromVec(w, c - 1); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy()[:, c - 1], w.cpu().numpy()) and (c == 1 or np.array_equal(D.t.cpu().numpy()[:, 0], full.cpu().numpy()[:r]))
+        # row normalisation
+        X = CuMatrix(_mat(rng, r, c, pad)); X.t[r // 2].zero_(); xh = X.t.cpu().numpy().astype(np.float64)
+        for rms, add_log in ((1.0, False), (0.5, True)):
+            ds = c * rms * rms; ss = (xh * xh).sum(1); f = np.maximum(ss / ds, 2.0 ** -66) ** -0.5
+            Y = CuMatrix(_mat(rng, r, c + int(add_log), 2)); cm.NormalizePerRow(X, rms, add_log, Y); torch.cuda.synchronize()
+            want = xh * f[:, None]
+            if add_log: want = np.concatenate([want, (np.log(rms) - np.log(f))[:, None]], 1)
+            np.testing.assert_allclose(Y.t.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+            OD = CuMatrix(_mat(rng, r, c + int(add_log), 0)); od = OD.t.cpu().numpy().astype(np.float64); ID = CuMatrix(_mat(rng, r, c, 4)); id0 = ID.t.cpu().numpy().astype(np.float64)
+            dot = (od[:, :c] * xh).sum(1); f3 = np.where(ss / ds <= 2.0 ** -66, 0.0, f ** 3)
+            core = f[:, None] * od[:, :c] - (dot * f3 / ds)[:, None] * xh
+            lsd = (od[:, c] / np.maximum(ss, c * 2.0 ** -66))[:, None] * xh if add_log else 0.0
+            cm.DiffNormalizePerRow(X, OD, rms, add_log, ID); torch.cuda.synchronize()
+            np.testing.assert_allclose(ID.t.cpu().numpy(), id0 + lsd + core, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(core).max()))
+            if not add_log:      # in place (kBackpropInPlace): overwritten, not added to
+                cm.DiffNormalizePerRow(X, OD, rms, False, OD); torch.cuda.synchronize(); np.testing.assert_allclose(OD.t.cpu().numpy(), core, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(core).max()))

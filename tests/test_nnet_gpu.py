@@ -41,6 +41,16 @@ def test_hip_vs_reference_nnet3_compute(fmt, s):
     assert got[0].shape == ref.shape
     assert np.abs(got[0] - ref).max() <= 1e-4, np.abs(got[0] - ref).max()
 
+@pytest.mark.parametrize("s", [1, 3])
+def test_hip_renorm_sigmoid_tanh_vs_reference_nnet3_compute(s):
+    """tests/golden/nnet_renorm*: NormalizeComponent / SigmoidComponent / TanhComponent / LogSoftmax layers (model by the reference's nnet3-init, outputs by its nnet3-compute): the fused
+    path folds ReLU / sigmoid / tanh into the producing GEMM's epilogue and runs the row normalisation behind it; the three utterances as one ragged batch and one by one"""
+    g = np.load(os.path.join(GOLD, "nnet_renorm_io.npz")); us = ("u0", "u1", "u2")
+    got, _ = _forward(os.path.join(GOLD, "nnet_renorm.raw"), [g["feats_" + u] for u in us], s)
+    for y, u in zip(got, us):
+        ref = g[f"ref_s{s}_{u}"]; assert y.shape == ref.shape and np.abs(y - ref).max() <= 1e-4, (u, np.abs(y - ref).max())
+        one, _ = _forward(os.path.join(GOLD, "nnet_renorm.raw"), [g["feats_" + u]], s); assert np.array_equal(one[0], y), u
+
 def test_hip_vs_reference_nnet3_compute_benchmark_model(tmp_path):
     """the 17L-768/96-6024 benchmark model (regenerated bit-identically, sha256 checked) vs the reference binary's output"""
     import importlib.util

@@ -42,10 +42,40 @@ def test_oracle_vs_reference_nnet3_compute():
 def test_unsupported_model_fails_loudly(tmp_path):
     import __graft_entry__ as ge; ge.build()
     from kaldi_amd import nnet3, lib
-    txt = open(os.path.join(GOLD, "nnet_small.txt")).read().replace("<RectifiedLinearComponent>", "<SigmoidComponent>").replace("</RectifiedLinearComponent>", "</SigmoidComponent>")
+    txt = open(os.path.join(GOLD, "nnet_small.txt")).read().replace("<RectifiedLinearComponent>", "<PnormComponent>").replace("</RectifiedLinearComponent>", "</PnormComponent>")
     p = tmp_path / "bad.txt"; p.write_text(txt)
-    with pytest.raises(lib.K3Error, match="SigmoidComponent"):
+    with pytest.raises(lib.K3Error, match="PnormComponent"):
         nnet3.Nnet(p)
+
+def test_oracle_renorm_sigmoid_tanh_vs_reference_nnet3_compute():
+    """NormalizeComponent (target-rms 0.5 and default), SigmoidComponent, TanhComponent, LogSoftmax output: the oracle against the REFERENCE's nnet3-compute on a model made by the
+    reference's nnet3-init (tests/golden/make_golden_nnet_renorm.py); inputs include saturating and all-zero utterances"""
+    from oracle import nnet3_oracle as no
+    g = np.load(os.path.join(GOLD, "nnet_renorm_io.npz")); net = no.read_nnet(os.path.join(GOLD, "nnet_renorm.raw"))
+    for s in (1, 3):
+        for u in ("u0", "u1", "u2"):
+            got = no.compute(net, g["feats_" + u], s); ref = g[f"ref_s{s}_{u}"]
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-5, (s, u, np.abs(got - ref).max())
+
+def test_reader_and_fuser_on_the_renorm_model(tmp_path):
+    """the fused model of the relu-renorm fixture: 4 GEMM nodes (ReLU, sigmoid, tanh folded into their producers; the two NormalizeComponents and the LogSoftmax as row operations
+    behind them); a NormalizeComponent with add-log-stddev or a block dimension is refused by name"""
+    import __graft_entry__ as ge; ge.build()
+    from kaldi_amd import nnet3, lib
+    i = nnet3.Nnet(os.path.join(GOLD, "nnet_renorm.raw")).info
+    assert (i.input_dim, i.output_dim, i.left_context, i.right_context, i.num_fused_nodes) == (20, 16, 4, 4, 4)
+    from oracle import nnet3_oracle as no
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet3-copy")
+    if not os.path.exists(exe): pytest.skip("oracle/_ref not built")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"))
+    assert subprocess.run([exe, "--binary=false", os.path.join(GOLD, "nnet_renorm.raw"), str(tmp_path / "m.txt")], capture_output=True, env=env).returncode == 0
+    txt = open(tmp_path / "m.txt").read()
+    assert nnet3.Nnet(tmp_path / "m.txt").info.num_fused_nodes == 4
+    (tmp_path / "als.txt").write_text(txt.replace("<AddLogStddev> F", "<AddLogStddev> T", 1))
+    with pytest.raises(lib.K3Error, match="add-log-stddev"): nnet3.Nnet(tmp_path / "als.txt")
+    (tmp_path / "blk.txt").write_text(txt.replace("<InputDim> 32 <TargetRms>", "<InputDim> 32 <BlockDim> 16 <TargetRms>", 1))
+    with pytest.raises(lib.K3Error, match="block-dim"): nnet3.Nnet(tmp_path / "blk.txt")
 
 
 def test_random_architectures_against_the_reference_nnet3_compute(tmp_path):
