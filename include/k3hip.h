@@ -348,9 +348,16 @@ int k3_mat_normalize_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_
 int k3_mat_apply_map(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, float a, int32_t flag, void *stream);
 /* CuMatrixBase::DiffSigmoid (op 0) / DiffTanh (1) (cudamatrix/cu-matrix.h:390-396): dst = diff .* value .* (1 - value) | diff .* (1 - value^2) */
 int k3_mat_diff_activation(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_value, int64_t ldv, const float *d_diff, int64_t ldf, void *stream);
+int k3_mat_mul_rows(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *stream);   /* MulRows (cudamatrix/cu-matrix.h:148): row r *= src row indexes[r]; -1 = unchanged (dropout masks per sequence) */
+/* CuMatrixBase::SetMatMatDivMat (op 0: dst = A .* (B ./ C3), = A where C3 is 0: DropoutComponent::Backprop) / AddMatMatElements (op 1: dst = beta dst + alpha A .* B) (cudamatrix/cu-matrix.h:580,:608) */
+int k3_mat_elements3(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, float alpha, const float *d_A, int64_t lda, const float *d_B, int64_t ldb, const float *d_C3, int64_t ldc3, float beta, void *stream);
 int k3_mat_div_rows_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_div, void *stream);            /* DivRowsVec: row r divided by div[r] */
 int k3_mat_copy_cols_from_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_col, void *stream);      /* CopyColsFromVec with a vector of dimension rows: every column = v */
 int k3_mat_copy_cols(int32_t add, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *stream);   /* CopyCols (add 0) / AddCols (1): dst(r, c) (+)= src(r, indexes[c]), -1 = zero / skip */
+/* CuRand<BaseFloat>::RandUniform (kind 0: [0, 1)) / RandGaussian (kind 1) (cudamatrix/cu-rand.h:50-56): Philox-4x32-10 keyed by `seed`, element i of the logical rows x cols matrix from
+ * counter offset + i / 4 -- reproducible for (seed, offset) independent of stride and launch shape; a fill consumes ceil(rows * cols / 4) counters.  (The reference's device stream is
+ * cuRAND's and its CPU stream is rand(): neither is reproduced; parity for this entry point is distributional.) */
+int k3_mat_set_rand(int32_t kind, float *d_C, int64_t ldc, int32_t rows, int32_t cols, uint64_t seed, uint64_t offset, void *stream);
 int64_t k3_mat_gemm_flops(int32_t reset);      /* 2 M N K summed over this process's k3_mat_add_mat_mat calls (reset != 0: read and clear) -- the flop count of a training iteration for its roofline */
 int k3_mat_add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans_a, const float *d_B, int64_t ldb, int32_t trans_b, float beta,
                        float *d_C, int64_t ldc, int32_t M, int32_t N, int32_t K, void *stream);      /* AddMatMat: C = alpha op(A) op(B) + beta C, FP32 MFMA */

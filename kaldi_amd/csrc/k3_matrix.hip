@@ -208,8 +208,8 @@ __global__ void k3_gemm_splitk_reduce_kernel(const float *W, int S, long long MN
 
 enum { kOpSet, kOpScale, kOpFloor, kOpCeil, kOpAddConst, kOpCopyRowsFromVec, kOpMulColsVec, kOpMulRowsVec, kOpAddVecToRows, kOpAddVecToCols, kOpCopy, kOpCopyT, kOpAddMat, kOpAddMatT,
        kOpCopyRows, kOpAddRows, kOpMulElements, kOpHeaviside, kOpAddMatDiagVec, kOpAddMatDiagVecT, kOpAddRowRanges, kOpCopyLowerToUpper, kOpAddToDiag, kOpAddVecVecOuter, kOpDivElements, kOpAddDiagVecMat, kOpAddDiagVecMatT,
-       kOpSigmoid, kOpTanh, kOpDiffSigmoid, kOpDiffTanh, kOpMax, kOpLog, kOpPow, kOpPowAbs, kOpDivRowsVec, kOpCopyCols, kOpAddCols, kOpCopyColsFromVec };
-struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; int src_rows; const float *S2; long long lds2; };
+       kOpSigmoid, kOpTanh, kOpDiffSigmoid, kOpDiffTanh, kOpMax, kOpLog, kOpPow, kOpPowAbs, kOpDivRowsVec, kOpCopyCols, kOpAddCols, kOpCopyColsFromVec, kOpMulRows, kOpSetMatMatDivMat, kOpAddMatMatElements };
+struct EwParams { int op, rows, cols; float *C; long long ldc; const float *S; long long lds; const float *v; const int *idx; float a, b; int src_rows; const float *S2; long long lds2; const float *S3; long long lds3; };
 // SigmoidComponent / TanhComponent (matrix/kaldi-vector.cc:900-960, the overflow-safe forms of the build without MKL's vector math)
 __device__ __forceinline__ float ew_sigmoid(float x) { if (x > 0.0f) return 1.0f / (1.0f + expf(-x)); const float e = expf(x); return e / (e + 1.0f); }
 __device__ __forceinline__ float ew_tanh(float x) { if (x > 0.0f) { const float e = expf(-x); return -1.0f + 2.0f / (1.0f + e * e); } const float e = expf(x); return 1.0f - 2.0f / (1.0f + e * e); }
@@ -255,6 +255,9 @@ __device__ __forceinline__ float ew_elem(const EwParams &p, int r, int c, float 
       case kOpCopyCols: { const int s = p.idx[c]; x = s < 0 ? 0.0f : p.S[(long long)r * p.lds + s]; break; }                                         // kaldi-matrix.cc:2836-2858 (index -1 = zero column)
       case kOpAddCols: { const int s = p.idx[c]; x = s < 0 ? dv : dv + p.S[(long long)r * p.lds + s]; break; }
       case kOpCopyColsFromVec: x = p.v[r]; break;
+      case kOpSetMatMatDivMat: { const float i = p.S3[(long long)r * p.lds3 + c], o = p.S2[(long long)r * p.lds2 + c], od = p.S[(long long)r * p.lds + c]; x = i != 0.0f ? od * (o / i) : od; break; }      // kaldi-matrix.cc:189-208
+      case kOpAddMatMatElements: x = p.b * dv + p.a * p.S[(long long)r * p.lds + c] * p.S2[(long long)r * p.lds2 + c]; break;                                                            // kaldi-matrix.cc:636-650
+      case kOpMulRows: { const int s = p.idx[r]; x = s < 0 ? dv : dv * p.S[(long long)s * p.lds + c]; break; }      // cu-matrix.cc:2813-2843 (a negative index leaves the row alone)
       case kOpAddRowRanges: { const int b0 = p.idx[2 * r], b1 = p.idx[2 * r + 1]; x = dv; for (int k = b0; k < b1; k++) x += p.S[(long long)k * p.lds + c]; break; }      // cu-kernels.cu _add_row_ranges
     }
   return x;
@@ -264,7 +267,7 @@ __device__ __forceinline__ float ew_elem(const EwParams &p, int r, int c, float 
 __device__ __forceinline__ bool ew_vec4_op(int op) {
   return op == kOpSet || op == kOpScale || op == kOpFloor || op == kOpCeil || op == kOpAddConst || op == kOpCopyRowsFromVec || op == kOpMulColsVec || op == kOpMulRowsVec || op == kOpAddVecToRows ||
          op == kOpAddVecToCols || op == kOpCopy || op == kOpAddMat || op == kOpCopyRows || op == kOpAddRows || op == kOpMulElements || op == kOpHeaviside || op == kOpAddMatDiagVec || op == kOpDivElements ||
-         op == kOpAddDiagVecMat || op == kOpSigmoid || op == kOpTanh || op == kOpDiffSigmoid || op == kOpDiffTanh || op == kOpMax;
+         op == kOpAddDiagVecMat || op == kOpSigmoid || op == kOpTanh || op == kOpDiffSigmoid || op == kOpDiffTanh || op == kOpMax || op == kOpMulRows;
 }
 __device__ __forceinline__ float ew_f(int op, float d, float s_, float v, float a, float b, float s2 = 0.0f) {      // element value from the old value d, the source element s_, the vector element v (column- or row-indexed by op)
   switch (op) {
@@ -288,6 +291,7 @@ __device__ __forceinline__ float ew_f(int op, float d, float s_, float v, float 
     case kOpDiffSigmoid: return s2 * s_ * (1.0f - s_);
     case kOpDiffTanh: return s2 * (1.0f - s_ * s_);
     case kOpMax: return fmaxf(d, s_);
+    case kOpMulRows: return d * s_;
   }
   return d;
 }
@@ -298,9 +302,9 @@ __global__ __launch_bounds__(256) void k3_ew4_kernel(EwParams p) {      // 256 c
   const int op = p.op;
   const bool unary = op == kOpSigmoid || op == kOpTanh, diff2 = op == kOpDiffSigmoid || op == kOpDiffTanh;
   const bool reads_d = !(op == kOpSet || op == kOpCopyRowsFromVec || op == kOpCopy || op == kOpCopyRows || op == kOpHeaviside || unary || diff2);
-  const bool has_s = op == kOpCopy || op == kOpAddMat || op == kOpCopyRows || op == kOpAddRows || op == kOpMulElements || op == kOpHeaviside || op == kOpAddMatDiagVec || op == kOpDivElements || op == kOpAddDiagVecMat || unary || diff2 || op == kOpMax;
+  const bool has_s = op == kOpCopy || op == kOpAddMat || op == kOpCopyRows || op == kOpAddRows || op == kOpMulElements || op == kOpHeaviside || op == kOpAddMatDiagVec || op == kOpDivElements || op == kOpAddDiagVecMat || unary || diff2 || op == kOpMax || op == kOpMulRows;
   const bool col_v = op == kOpCopyRowsFromVec || op == kOpMulColsVec || op == kOpAddVecToRows || op == kOpAddMatDiagVec, row_v = op == kOpMulRowsVec || op == kOpAddVecToCols || op == kOpAddDiagVecMat;
-  const bool indexed = op == kOpCopyRows || op == kOpAddRows;
+  const bool indexed = op == kOpCopyRows || op == kOpAddRows || op == kOpMulRows;
   f32x4 vc = {0.0f, 0.0f, 0.0f, 0.0f};
   if (col_v) vc = *reinterpret_cast<const f32x4 *>(p.v + c);
   for (int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2; r0 < p.rows; r0 += gridDim.y * 8) {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void k3_ew4_kernel(EwParams p) {      // 256 c
       if (diff2) s2 = *reinterpret_cast<const f32x4 *>(p.S2 + (long long)r * p.lds2 + c);
       if (reads_d) d = *reinterpret_cast<const f32x4 *>(p.C + (long long)r * p.ldc + c);
       bool skip = false;
-      if (has_s) { const int sr = indexed ? p.idx[r] : r; if (sr >= 0) sv = *reinterpret_cast<const f32x4 *>(p.S + (long long)sr * p.lds + c); else skip = op == kOpAddRows; }
+      if (has_s) { const int sr = indexed ? p.idx[r] : r; if (sr >= 0) sv = *reinterpret_cast<const f32x4 *>(p.S + (long long)sr * p.lds + c); else skip = op == kOpAddRows || op == kOpMulRows; }
       const float vr = row_v ? p.v[r] : 0.0f;
 #pragma unroll
       for (int k = 0; k < 4; k++) x[e][k] = skip ? d[k] : ew_f(op, d[k], sv[k], col_v ? vc[k] : vr, p.a, p.b, s2[k]);
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256) void k3_ew_kernel(EwParams p) {      // 64 col
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   if (c >= p.cols) return;
   const bool reads_d = !(p.op == kOpSet || p.op == kOpCopyRowsFromVec || p.op == kOpCopy || p.op == kOpCopyT || p.op == kOpCopyRows || p.op == kOpHeaviside || p.op == kOpSigmoid || p.op == kOpTanh ||
-                         p.op == kOpDiffSigmoid || p.op == kOpDiffTanh || p.op == kOpLog || p.op == kOpPow || p.op == kOpPowAbs || p.op == kOpCopyCols || p.op == kOpCopyColsFromVec);
+                         p.op == kOpDiffSigmoid || p.op == kOpDiffTanh || p.op == kOpLog || p.op == kOpPow || p.op == kOpPowAbs || p.op == kOpCopyCols || p.op == kOpCopyColsFromVec || p.op == kOpSetMatMatDivMat);
   for (int r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4; r0 < p.rows; r0 += gridDim.y * 16) {
     float x[4];
 #pragma unroll
@@ -496,13 +500,42 @@ __global__ __launch_bounds__(256) void k3_row_normalize_kernel(int op, float *D,
   }
 }
 
+// CuRand (cudamatrix/cu-rand.h:31-64): counter-based generator (Philox-4x32-10, Salmon et al. 2011: the published round constants and key schedule) -- element (r, c) of a call draws
+// from counter {offset + (r * cols + c) / 4, stream} under key = seed, so a fill is reproducible for a given (seed, offset) whatever the launch shape or stride, and calls with
+// disjoint offset ranges are independent.  kind 0: uniform in [0, 1) with 24 random bits (never 1.0); kind 1: standard normal (Box-Muller over two of the four words).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ __launch_bounds__(256) void k3_rand_kernel(int kind, float *C, long long ldc, int rows, int cols, unsigned long long seed, unsigned long long offset) {
+  const long long n = (long long)rows * cols, q = (long long)blockIdx.x * 256 + threadIdx.x;      // one counter = four consecutive elements (row-major over the logical matrix)
+  if (q * 4 >= n) return;
+  const unsigned long long ctr = offset + (unsigned long long)q;
+  unsigned w[4]; philox4x32_10((unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+  float v[4];
+  if (kind == 0) { for (int e = 0; e < 4; e++) v[e] = (float)(w[e] >> 8) * (1.0f / 16777216.0f); }
+  else {
+    for (int e = 0; e < 4; e += 2) {
+      const float u1 = ((float)(w[e] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(w[e + 1] >> 8) * (1.0f / 16777216.0f);      // u1 in (0, 1]
+      const float rad = sqrtf(-2.0f * logf(u1)), ang = 6.283185307179586f * u2;
+      v[e] = rad * cosf(ang); v[e + 1] = rad * sinf(ang);
+    }
+  }
+  for (int e = 0; e < 4; e++) { const long long i = q * 4 + e; if (i < n) C[(i / cols) * ldc + (i % cols)] = v[e]; }
+}
+
 int launch_ew(const EwParams &p, void *stream) {
   if (p.rows <= 0 || p.cols <= 0) return K3_OK;
   static const int traced = [] { const char *e = getenv("K3_GEMM_TRACE"); return e && atoi(e) >= 2 ? 1 : 0; }();
   if (traced) fprintf(stderr, "k3 ew op %d rows %d cols %d\n", p.op, p.rows, p.cols);      // developer aid
   auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool has_s = p.op == kOpCopy || p.op == kOpAddMat || p.op == kOpCopyRows || p.op == kOpAddRows || p.op == kOpMulElements || p.op == kOpHeaviside || p.op == kOpAddMatDiagVec || p.op == kOpDivElements || p.op == kOpAddDiagVecMat ||
-                     p.op == kOpSigmoid || p.op == kOpTanh || p.op == kOpDiffSigmoid || p.op == kOpDiffTanh || p.op == kOpMax;
+                     p.op == kOpSigmoid || p.op == kOpTanh || p.op == kOpDiffSigmoid || p.op == kOpDiffTanh || p.op == kOpMax || p.op == kOpMulRows;
   const bool has_s2 = p.op == kOpDiffSigmoid || p.op == kOpDiffTanh;
   const bool col_v = p.op == kOpCopyRowsFromVec || p.op == kOpMulColsVec || p.op == kOpAddVecToRows || p.op == kOpAddMatDiagVec;
   const bool v4 = (p.op == kOpSet || p.op == kOpScale || p.op == kOpFloor || p.op == kOpCeil || p.op == kOpAddConst || p.op == kOpMulRowsVec || p.op == kOpAddVecToCols || has_s || col_v) &&
@@ -729,12 +762,30 @@ extern "C" int k3_mat_diff_activation(int32_t op, float *C, int64_t ldc, int32_t
   K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_value && d_diff && ldv >= cols && ldf >= cols && (op == 0 || op == 1), "k3_mat_diff_activation: bad argument");
   EwParams p = mk(op == 0 ? kOpDiffSigmoid : kOpDiffTanh, C, ldc, rows, cols); p.S = d_value; p.lds = ldv; p.S2 = d_diff; p.lds2 = ldf; return launch_ew(p, st);
 }
+extern "C" int k3_mat_mul_rows(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *st) {      // CuMatrixBase::MulRows (cu-matrix.h: row r *= src row indexes[r]; -1 = unchanged)
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_indexes && lds >= cols, "k3_mat_mul_rows: bad source");
+  EwParams p = mk(kOpMulRows, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_indexes; return launch_ew(p, st);
+}
+// CuMatrixBase::SetMatMatDivMat (op 0: dst = A .* (B ./ C), A where C is 0 -- DropoutComponent::Backprop) / AddMatMatElements (op 1: dst = beta dst + alpha A .* B) (cu-matrix.h:580,:608)
+extern "C" int k3_mat_elements3(int32_t op, float *C, int64_t ldc, int32_t rows, int32_t cols, float alpha, const float *d_A, int64_t lda, const float *d_B, int64_t ldb, const float *d_C3, int64_t ldc3, float beta, void *st) {
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_A && d_B && lda >= cols && ldb >= cols && (op == 1 || (op == 0 && d_C3 && ldc3 >= cols)), "k3_mat_elements3: bad argument");
+  EwParams p = mk(op == 0 ? kOpSetMatMatDivMat : kOpAddMatMatElements, C, ldc, rows, cols); p.S = d_A; p.lds = lda; p.S2 = d_B; p.lds2 = ldb; p.S3 = d_C3; p.lds3 = ldc3; p.a = alpha; p.b = beta; return launch_ew(p, st);
+}
 extern "C" int k3_mat_div_rows_vec(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_div, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_div, "k3_mat_div_rows_vec: null vector"); EwParams p = mk(kOpDivRowsVec, C, ldc, rows, cols); p.v = d_div; return launch_ew(p, st); }
 extern "C" int k3_mat_copy_cols_from_vec(float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_col, void *st) { K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_col, "k3_mat_copy_cols_from_vec: null vector"); EwParams p = mk(kOpCopyColsFromVec, C, ldc, rows, cols); p.v = d_col; return launch_ew(p, st); }
 // CuMatrixBase::CopyCols / AddCols (cu-matrix.h:102-111): dst(r, c) (+)= src(r, indexes[c]); index -1 = zero / nothing added
 extern "C" int k3_mat_copy_cols(int32_t add, float *C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *st) {
   K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(d_src && d_indexes && lds > 0, "k3_mat_copy_cols: bad source");
   EwParams p = mk(add ? kOpAddCols : kOpCopyCols, C, ldc, rows, cols); p.S = d_src; p.lds = lds; p.idx = d_indexes; return launch_ew(p, st);
+}
+// CuRand<float>::RandUniform (kind 0) / RandGaussian (kind 1) (cudamatrix/cu-rand.h:50-56).  The caller owns the stream position: `offset` counts groups of four elements, a fill
+// of rows x cols consumes ceil(rows * cols / 4) of them.
+extern "C" int k3_mat_set_rand(int32_t kind, float *C, int64_t ldc, int32_t rows, int32_t cols, uint64_t seed, uint64_t offset, void *st) {
+  K3_MAT_REQUIRE(C, ldc, rows, cols); K3_REQUIRE(kind == 0 || kind == 1, "k3_mat_set_rand: kind must be 0 (uniform) or 1 (gaussian)");
+  const long long n = (long long)rows * cols; if (n == 0) return K3_OK;
+  hipLaunchKernelGGL(k3_rand_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)st, kind, C, (long long)ldc, rows, cols, (unsigned long long)seed, (unsigned long long)offset);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
 }
 extern "C" int k3_vec_col_reduce(int32_t op, float alpha, const float *d_M, int64_t ldm, const float *d_N, int64_t ldn, int32_t rows, int32_t cols, float beta, float *d_v, void *st) {
   K3_REQUIRE(d_M && d_v && rows >= 0 && cols >= 0 && ldm >= cols && op >= 0 && op <= 4 && (op != 2 || (d_N && ldn >= cols)), "k3_vec_col_reduce: bad argument");

@@ -57,6 +57,9 @@ class CuMatrix:
         else: assert v.numel() == self.NumRows(); _l.check(self._L.k3_mat_copy_cols_from_vec(*self._a(), v.data_ptr(), _st()))
     def CopyColFromVec(self, v, col): assert v.numel() == self.NumRows(); _l.check(self._L.k3_mat_copy_from_mat(self.t.data_ptr() + 4 * col, self.Stride(), self.NumRows(), 1, v.data_ptr(), 1, 0, _st()))
     def CopyCols(self, src, indexes): _l.check(self._L.k3_mat_copy_cols(0, *self._a(), src.t.data_ptr(), src.Stride(), indexes.data_ptr(), _st()))
+    def MulRows(self, src, indexes): _l.check(self._L.k3_mat_mul_rows(*self._a(), src.t.data_ptr(), src.Stride(), indexes.data_ptr(), _st()))
+    def SetMatMatDivMat(self, A, B, C): _l.check(self._L.k3_mat_elements3(0, *self._a(), 1.0, A.t.data_ptr(), A.Stride(), B.t.data_ptr(), B.Stride(), C.t.data_ptr(), C.Stride(), 0.0, _st()))
+    def AddMatMatElements(self, alpha, A, B, beta): _l.check(self._L.k3_mat_elements3(1, *self._a(), alpha, A.t.data_ptr(), A.Stride(), B.t.data_ptr(), B.Stride(), None, 0, beta, _st()))
     def AddCols(self, src, indexes): _l.check(self._L.k3_mat_copy_cols(1, *self._a(), src.t.data_ptr(), src.Stride(), indexes.data_ptr(), _st()))
     def _reduce(self, op, B=None):
         r = ctypes.c_double(0.0)
@@ -75,3 +78,11 @@ def NormalizePerRow(inp, target_rms, add_log_stddev, out):      # cu::NormalizeP
 def DiffNormalizePerRow(in_value, out_deriv, target_rms, add_log_stddev, in_deriv):      # cu::DiffNormalizePerRow (cudamatrix/cu-math.h:296): ADDS to in_deriv unless it is out_deriv
     assert out_deriv.NumCols() == in_value.NumCols() + int(add_log_stddev) and in_deriv.NumCols() == in_value.NumCols()
     _l.check(in_deriv._L.k3_mat_normalize_rows(1, in_deriv.t.data_ptr(), in_deriv.Stride(), in_value.t.data_ptr(), in_value.Stride(), out_deriv.t.data_ptr(), out_deriv.Stride(), in_value.NumRows(), in_value.NumCols(), target_rms, int(add_log_stddev), _st()))
+
+class CuRand:
+    """CuRand<BaseFloat> (cudamatrix/cu-rand.h:31-64) over k3_mat_set_rand: one seed per object, the counter position advances by what each fill consumes"""
+    def __init__(self, seed=0): self.seed, self.offset, self._L = int(seed), 0, _l.load()
+    def _fill(self, kind, M):
+        _l.check(self._L.k3_mat_set_rand(kind, M.t.data_ptr(), M.Stride(), M.NumRows(), M.NumCols(), self.seed, self.offset, _st())); self.offset += (M.NumRows() * M.NumCols() + 3) // 4
+    def RandUniform(self, M): self._fill(0, M)
+    def RandGaussian(self, M): self._fill(1, M)

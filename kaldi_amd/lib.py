@@ -132,6 +132,9 @@ def load():
     L.k3_mat_copy_lower_to_upper.argtypes = [vp, i64, i32, vp]; L.k3_mat_add_to_diag.argtypes = [vp, i64, i32, i32, f32, vp]; L.k3_mat_add_vec_vec.argtypes = [f32, vp, vp, vp, i64, i32, i32, vp]
     L.k3_mat_normalize_rows.argtypes = [i32, vp, i64, vp, i64, vp, i64, i32, i32, f32, i32, vp]; L.k3_mat_apply_map.argtypes = [i32, vp, i64, i32, i32, vp, i64, f32, i32, vp]
     L.k3_mat_diff_activation.argtypes = [i32, vp, i64, i32, i32, vp, i64, vp, i64, vp]; L.k3_mat_div_rows_vec.argtypes = [vp, i64, i32, i32, vp, vp]; L.k3_mat_copy_cols_from_vec.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.k3_mat_set_rand.argtypes = [i32, vp, i64, i32, i32, ctypes.c_uint64, ctypes.c_uint64, vp]
+    L.k3_mat_mul_rows.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp]
+    L.k3_mat_elements3.argtypes = [i32, vp, i64, i32, i32, f32, vp, i64, vp, i64, vp, i64, f32, vp]
     L.k3_mat_copy_cols.argtypes = [i32, vp, i64, i32, i32, vp, i64, vp, vp]
     L.k3_mat_add_diag_vec_mat.argtypes = [f32, vp, vp, i64, i32, f32, vp, i64, i32, i32, vp]; L.k3_mat_div_elements.argtypes = [vp, i64, i32, i32, vp, i64, vp]; L.k3_mat_reduce_scalar.argtypes = [i32, vp, i64, vp, i64, i32, i32, vp, vp]
     L.k3_vec_col_reduce.argtypes = [i32, f32, vp, i64, vp, i64, i32, i32, f32, vp, vp]

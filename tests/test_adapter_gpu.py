@@ -185,6 +185,45 @@ def test_reference_training_computation_with_sigmoid_tanh_renorm_layers(variant,
     assert rg.shape == gg.shape and np.linalg.norm(rg) > 0 and np.linalg.norm(rg - gg) <= 1e-4 * np.linalg.norm(rg), (np.linalg.norm(rg - gg), np.linalg.norm(rg))
 
 
+DROPOUTS = {"general_continuous": "type=GeneralDropoutComponent dim=32 dropout-proportion=0.3 continuous=true", "general_binary": "type=GeneralDropoutComponent dim=32 dropout-proportion=0.3",
+            "per_element": "type=DropoutComponent dim=32 dropout-proportion=0.3", "per_frame": "type=DropoutComponent dim=32 dropout-proportion=0.3 dropout-per-frame=true"}
+@pytest.mark.parametrize("kind", sorted(DROPOUTS))
+def test_dropout_in_training_mode_through_the_adapter(kind, tmp_path):
+    """The chain recipes train with a dropout schedule (GeneralDropoutComponent, dropout-per-dim-continuous): the masks come from CuRand<BaseFloat>::RandUniform (cu-rand.h:50), here the
+    device generator of k3_mat_set_rand.  The reference's stream (rand() on the CPU, cuRAND on its GPU) is not reproducible, so the gate is structural: the mask recovered from
+    output / (output of the same model without dropout) has the component's law (nnet-general-component.cc:1790-1806, nnet-simple-component.cc:139-176: continuous in [1 - 2p, 1 + 2p] per
+    (sequence, dim) and constant over time; binary {0, 1 / (1 - p)} per (sequence, dim); {0, 1} per element / per frame with P(0) = p), and the parameter gradient of the backward pass is the
+    one of exactly that mask (the memo of the forward pass)."""
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-train-grad"); init = os.path.join(ROOT, "oracle", "_ref", "bin", "nnet3-init")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/nnet3-train-grad is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    if not os.path.exists(init): pytest.skip("oracle/_ref not built")
+    td = str(tmp_path); env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"); renv = dict(env, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl")); p = 0.3
+    cfg = "input-node name=input dim=20\ncomponent name=a type=NaturalGradientAffineComponent input-dim=20 output-dim=32\ncomponent-node name=a component=a input=input\ncomponent name=d %s\ncomponent-node name=d component=d input=a\noutput-node name=output input=d\n"
+    for name, comp in (("drop", DROPOUTS[kind]), ("plain", "type=NoOpComponent dim=32")):
+        open(f"{td}/{name}.config", "w").write(cfg % comp)
+        r = subprocess.run([init, "--srand=4", f"{td}/{name}.config", f"{td}/{name}.raw"], capture_output=True, text=True, env=renv); assert r.returncode == 0, r.stderr[-1500:]
+    B, T = 48, 40; rng = np.random.default_rng(3); x = (rng.standard_normal((T * B, 20)) * 2.0).astype(np.float32); od = (rng.standard_normal((T * B, 32)) * 0.1).astype(np.float32)
+    _kaldi_matrix(f"{td}/in.mat", x); _kaldi_matrix(f"{td}/od.mat", od); outs = {}
+    for name in ("drop", "plain"):
+        g = subprocess.run([exe, f"{td}/{name}.raw", str(B), str(T), "1", f"{td}/in.mat", f"{td}/od.mat", f"{td}/{name}.o", f"{td}/{name}.g"], capture_output=True, text=True, env=env); assert g.returncode == 0, g.stderr[-3000:]
+        outs[name] = (_read_kaldi(f"{td}/{name}.o"), _read_kaldi(f"{td}/{name}.g"))
+    a = outs["plain"][0]; y = outs["drop"][0]; assert np.abs(a).min() > 1e-6
+    m = (y / a).reshape(T, B, 32)                      # rows are frame-major, sequence-minor
+    if kind.startswith("general"):
+        assert np.abs(m - m[0]).max() <= 1e-4          # one mask per (sequence, dim), shared by all frames
+        m0 = m[0]
+        if kind == "general_continuous": assert m0.min() >= 1 - 2 * p - 1e-4 and m0.max() <= 1 + 2 * p + 1e-4 and abs(m0.mean() - 1.0) < 0.05 and abs(m0.std() - 4 * p / np.sqrt(12)) < 0.03
+        else: assert np.all((np.abs(m0) < 1e-4) | (np.abs(m0 - 1 / (1 - p)) < 1e-4)) and abs((np.abs(m0) < 1e-4).mean() - p) < 0.05
+        assert len(np.unique(np.round(m0, 4), axis=0)) == B          # every sequence its own mask
+    else:
+        assert np.all((np.abs(m) < 1e-4) | (np.abs(m - 1) < 1e-4)) and abs((np.abs(m) < 1e-4).mean() - p) < (0.02 if kind == "per_element" else 0.04)
+        if kind == "per_frame": assert np.abs(m - m[:, :, :1]).max() <= 1e-4 and 0 < (np.abs(m[:, :, 0]) < 1e-4).sum() < T * B          # whole rows on / off
+        else: assert 0.2 < (np.abs(m[:, :, 0]) < 1e-4).mean() < 0.4 and np.abs(m - m[:, :, :1]).max() > 0.5
+    # backward: d/dW = (od .* mask)^T x, d/db = column sums of od .* mask (VectorizeNnet: the affine's linear rows, then its bias)
+    gm = (od * m.reshape(T * B, 32)).astype(np.float64); want = np.concatenate([(gm.T @ x.astype(np.float64)).ravel(), gm.sum(0)]); got = outs["drop"][1]
+    assert got.shape == want.shape and np.linalg.norm(got - want) <= 1e-4 * np.linalg.norm(want), (np.linalg.norm(got - want), np.linalg.norm(want))
+
+
 @pytest.mark.parametrize("B,T", [(4, 10), (16, 25)])
 def test_lf_mmi_gradient_reference_nnet_computer_plus_native_objective(B, T, tmp_path):
     """One minibatch of chain training as nnet3/nnet-chain-training.cc:136-300 runs it: NnetComputer forward (training mode) -> ComputeChainObjfAndDeriv -> NnetComputer backward into a

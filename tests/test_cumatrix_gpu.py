@@ -112,6 +112,11 @@ def test_nonlinearity_maps_column_operations_and_row_normalisation_match_numpy()
         src = CuMatrix(_mat(rng, r, 23, 1)); idx = torch.from_numpy(rng.integers(-1, 23, c).astype(np.int32)).cuda(); ih = idx.cpu().numpy(); sc = src.t.cpu().numpy()
         D.CopyCols(src, idx); torch.cuda.synchronize(); want = np.where(ih[None, :] >= 0, sc[:, np.maximum(ih, 0)], 0.0).astype(np.float32); assert np.array_equal(D.t.cpu().numpy(), want)
         D.AddCols(src, idx); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy(), want + want)
+        msk = CuMatrix(_mat(rng, 11, c, 4 if c % 4 == 0 else 1)); ridx = torch.from_numpy(rng.integers(-1, 11, r).astype(np.int32)).cuda(); rh = ridx.cpu().numpy(); before = D.t.cpu().numpy().copy()
+        D.MulRows(msk, ridx); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy(), np.where(rh[:, None] >= 0, before * msk.t.cpu().numpy()[np.maximum(rh, 0)], before))
+        A3 = CuMatrix(_mat(rng, r, c, 1)); B3 = CuMatrix(_mat(rng, r, c, 0)); C3 = CuMatrix(_mat(rng, r, c, 2)); C3.t[0, 0] = 0.0; ah, bh, ch = (q.t.cpu().numpy() for q in (A3, B3, C3)); before = D.t.cpu().numpy().copy()
+        D.AddMatMatElements(0.5, A3, B3, 2.0); torch.cuda.synchronize(); np.testing.assert_allclose(D.t.cpu().numpy(), np.float32(2.0) * before + np.float32(0.5) * ah * bh, rtol=1e-6, atol=1e-6)
+        D.SetMatMatDivMat(A3, B3, C3); torch.cuda.synchronize(); np.testing.assert_allclose(D.t.cpu().numpy(), np.where(ch != 0, ah * (bh / np.where(ch != 0, ch, 1)), ah), rtol=1e-6, atol=1e-6); assert D.t[0, 0].item() == A3.t[0, 0].item()
         D.CopyColsFromVec(w); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy(), np.tile(w.cpu().numpy()[:, None], (1, c)))
         full = torch.from_numpy(rng.standard_normal(r * c).astype(np.float32)).cuda(); D.CopyColsFromVec(full); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy(), full.cpu().numpy().reshape(c, r).T)
         D.CopyColFromVec(w, c - 1); torch.cuda.synchronize(); assert np.array_equal(D.t.cpu().numpy()[:, c - 1], w.cpu().numpy()) and (c == 1 or np.array_equal(D.t.cpu().numpy()[:, 0], full.cpu().numpy()[:r]))
@@ -131,3 +136,25 @@ def test_nonlinearity_maps_column_operations_and_row_normalisation_match_numpy()
             np.testing.assert_allclose(ID.t.cpu().numpy(), id0 + lsd + core, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(core).max()))
             if not add_log:      # in place (kBackpropInPlace): overwritten, not added to
                 cm.DiffNormalizePerRow(X, OD, rms, False, OD); torch.cuda.synchronize(); np.testing.assert_allclose(OD.t.cpu().numpy(), core, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(core).max()))
+
+
+def test_device_random_numbers_known_answers_reproducibility_and_distribution():
+    """k3_mat_set_rand (CuRand<BaseFloat>::RandUniform / RandGaussian, cu-rand.h:50-56): the Philox-4x32-10 known-answer vector of the Random123 distribution (counter 0, key 0 ->
+    6627e8d5 e169c58d bc57ac4c 9b00dbd8) through the uniform mapping, independence of stride and launch shape, stream continuity across fills, and the two laws (moments, a chi-square
+    over 64 bins, tails) in the manner of the reference's cu-rand-speed-test / cu-matrix-test moments checks"""
+    from kaldi_amd.cumatrix import CuMatrix, CuRand
+    t = torch.empty(1, 4, device="cuda"); CuRand(0).RandUniform(CuMatrix(t)); torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy()[0], (np.array([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], np.uint32) >> 8).astype(np.float32) / np.float32(2 ** 24))
+    # the same (seed, offset) gives the same logical matrix whatever the stride; consecutive fills continue the stream
+    a = torch.empty(37, 52, device="cuda"); b = torch.zeros(37, 60, device="cuda")[:, :52]; CuRand(7).RandUniform(CuMatrix(a)); CuRand(7).RandUniform(CuMatrix(b)); torch.cuda.synchronize()
+    assert torch.equal(a, b) and not b._base[:, 52:].any()
+    r = CuRand(7); c1 = torch.empty(10, 52, device="cuda"); c2 = torch.empty(27, 52, device="cuda"); r.RandUniform(CuMatrix(c1)); r.RandUniform(CuMatrix(c2)); torch.cuda.synchronize()
+    assert torch.equal(torch.cat([c1, c2]), a) and r.offset == 37 * 52 // 4
+    other = torch.empty(37, 52, device="cuda"); CuRand(8).RandUniform(CuMatrix(other)); assert not torch.equal(other, a)
+    n = 1 << 22; u = torch.empty(2048, n // 2048, device="cuda"); CuRand(123).RandUniform(CuMatrix(u)); g = torch.empty_like(u); CuRand(123).RandGaussian(CuMatrix(g)); torch.cuda.synchronize()
+    u = u.cpu().numpy().ravel().astype(np.float64); g = g.cpu().numpy().ravel().astype(np.float64)
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 6 * np.sqrt(1 / 12 / n) and abs(u.var() - 1 / 12) < 1e-3
+    h = np.bincount((u * 64).astype(int), minlength=64); chi2 = ((h - n / 64) ** 2 / (n / 64)).sum(); assert chi2 < 63 + 6 * np.sqrt(2 * 63), chi2
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 5 / np.sqrt(n)
+    assert abs(g.mean()) < 6 / np.sqrt(n) and abs(g.var() - 1) < 5e-3 and abs((g ** 3).mean()) < 0.01 and abs((g ** 4).mean() - 3) < 0.03 and np.isfinite(g).all()
+    assert abs((np.abs(g) > 3).mean() - 0.0026998) < 3e-4 and np.abs(g).max() < 6.5
