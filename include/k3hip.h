@@ -91,6 +91,13 @@ void k3_online_cmvn_opts_default(k3_online_cmvn_opts *opts);
 int k3_cmvn_online_batch(const float *d_in, int64_t ld_in, float *d_out, int64_t ld_out, int32_t dim, const int64_t *d_frame_offsets,
                          int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
                          const int32_t *skip_dims, int32_t num_skip_dims, void *stream);
+/* The same recursion continued over a stream (OnlineCmvn keeps its window statistics between GetFrame calls, feat/online-feature.cc:361-468): utterance u's rows
+ * [0, t_begin[u]) are the history the window still reads (at least min(cmn_window, frames so far) of them) -- not written --, d_carry [U x dim x 3] float64 holds each
+ * column's window (sum, sum of squares, count) after the last row of the previous call (read when t_begin[u] > 0) and receives it after the last row of this one: the
+ * rows written are bit-identical to those of the whole utterance in one call. */
+int k3_cmvn_online_batch_resume(const float *d_in, int64_t ld_in, float *d_out, int64_t ld_out, int32_t dim, const int64_t *d_frame_offsets,
+                                int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
+                                const int32_t *skip_dims, int32_t num_skip_dims, const int64_t *d_t_begin, double *d_carry, void *stream);
 
 /* ---------------------------------------------------------------- online i-vectors -----------
  * Replaces, for whole utterances: OnlineIvectorFeature (online2/online-ivector-feature.h:278-420) as ivector-extract-online2 drives it
@@ -144,6 +151,20 @@ int64_t k3_ivector_stats_size(const k3_ivector *iv);
 /* on: d_stats_out holds the statistics of EVERY frame of the utterance (the frames behind the last estimate included) -- what the reference's ivector-extract-online2 --repeat=true
  * carries to the speaker's next utterance (it asks for the last frame's i-vector: ivector-extract-online2.cc:121-127); off (default): the statistics at the last estimate */
 void k3_ivector_set_accumulate_tail(k3_ivector *iv, int32_t on);
+/* Streaming: one object per audio stream, fed with the feature frames as they come (OnlineIvectorFeature, online2/online-ivector-feature.h:233-330; per channel what
+ * BatchedIvectorExtractorCuda keeps, cudafeat/feature-online-batched-ivector-cuda.h:30-61).  accept(): `num_frames` new feature rows (device), `finished` != 0 with the
+ * stream's last frames (then the frames waiting for their splice context are processed with the last frame repeated).  Every estimate the frames ready allow is made
+ * -- frames ready = all frames so far minus the splice's right context while the stream goes on; estimate k when k * ivector_period < frames ready -- and the rows are,
+ * bit for bit, rows k of k3_ivector_extract_batch on the whole utterance; each frame is processed once (cost linear in the stream's length, memory bounded).
+ * d_new_rows (nullable) [max_new_rows x ld_rows] receives the rows made by this call, *h_num_new_rows their number; d_latest (nullable) [ivector_dim] the most recent
+ * estimate of the stream -- what the reference's online decodable hands the network (nnet3/decodable-online-looped.cc:182-197) --, zeros before the first. */
+typedef struct k3_ivector_stream k3_ivector_stream;
+int k3_ivector_stream_create(k3_ivector *iv, k3_ivector_stream **out);
+void k3_ivector_stream_destroy(k3_ivector_stream *s);
+int k3_ivector_stream_reset(k3_ivector_stream *s, void *stream);
+int64_t k3_ivector_stream_num_rows(const k3_ivector_stream *s);
+int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_feats, int64_t ld_feats, int32_t num_frames, int32_t finished, float *d_new_rows, int64_t ld_rows,
+                             int32_t max_new_rows, int32_t *h_num_new_rows, float *d_latest, void *stream);
 int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
                                    float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in,
                                    double *d_stats_out, void *stream);

@@ -454,6 +454,8 @@ struct OnlineCmvnParams {
   const double *global_stats, *speaker_stats;      // [2 x (dim+1)], [U x 2 x (dim+1)] or null
   unsigned long long skip[4];                      // bit d set: FakeStatsForSomeDims for column d
   int *err;                                        // set to 1 where the reference raises (count < 1, global count <= 0)
+  const long long *t_begin; double *carry;         // resume (streaming): rows [0, t_begin[u]) of utterance u are history -- read for the window, not written; carry [U][dim][3] = the
+                                                   // window's (sum, sum of squares, count) after the last row, read when t_begin[u] > 0 and written back.  Both null: whole utterances
 };
 
 __global__ __launch_bounds__(64) void k3_cmvn_online_kernel(OnlineCmvnParams p) {
@@ -468,8 +470,11 @@ __global__ __launch_bounds__(64) void k3_cmvn_online_kernel(OnlineCmvnParams p) 
   const double s_m = sp ? sp[d] : 0.0, s_v = sp ? sp[C + d] : 0.0, s_n = sp ? sp[p.dim] : 0.0;
   const bool skip = d < 256 && ((p.skip[d >> 6] >> (d & 63)) & 1ull);
   double sum = 0.0, sq = 0.0, n = 0.0;
+  const long long tb = p.t_begin ? p.t_begin[u] : 0;
+  double *cy = p.carry ? p.carry + ((long long)u * p.dim + d) * 3 : nullptr;
+  if (cy && tb > 0) { sum = cy[0]; sq = cy[1]; n = cy[2]; }
   constexpr int kAhead = 8;
-  for (long long t0 = 0; t0 < T; t0 += kAhead) {
+  for (long long t0 = tb; t0 < T; t0 += kAhead) {
     float xn[kAhead], xo[kAhead];
 #pragma unroll
     for (int k = 0; k < kAhead; k++) {
@@ -518,6 +523,7 @@ __global__ __launch_bounds__(64) void k3_cmvn_online_kernel(OnlineCmvnParams p) 
       y[t * p.ld_out] = z;
     }
   }
+  if (cy) { cy[0] = sum; cy[1] = sq; cy[2] = n; }
 }
 
 }  // namespace
@@ -740,6 +746,12 @@ extern "C" int k3_cmvn_offline_batch(float *d_feats, int64_t ld, int32_t dim, co
 extern "C" int k3_cmvn_online_batch(const float *d_in, int64_t ld_in, float *d_out, int64_t ld_out, int32_t dim, const int64_t *d_frame_offsets,
                                     int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
                                     const int32_t *skip_dims, int32_t num_skip_dims, void *stream) {
+  return k3_cmvn_online_batch_resume(d_in, ld_in, d_out, ld_out, dim, d_frame_offsets, num_utts, opts, d_global_stats, d_speaker_stats, skip_dims, num_skip_dims, nullptr, nullptr, stream);
+}
+extern "C" int k3_cmvn_online_batch_resume(const float *d_in, int64_t ld_in, float *d_out, int64_t ld_out, int32_t dim, const int64_t *d_frame_offsets,
+                                           int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
+                                           const int32_t *skip_dims, int32_t num_skip_dims, const int64_t *d_t_begin, double *d_carry, void *stream) {
+  K3_REQUIRE((d_t_begin == nullptr) == (d_carry == nullptr), "k3_cmvn_online_batch_resume: t_begin and carry go together");
   K3_REQUIRE(d_in && d_out && d_in != d_out && d_frame_offsets && opts && d_global_stats && dim > 0 && ld_in >= dim && ld_out >= dim && num_utts >= 0,
              "k3_cmvn_online_batch: bad argument (in-place operation is not possible: the window needs the raw frames)");
   // OnlineCmvnOptions::Check (feat/online-feature.h:226-229) and the assertion in OnlineCmvn::GetFrame (:465)
@@ -759,7 +771,7 @@ extern "C" int k3_cmvn_online_batch(const float *d_in, int64_t ld_in, float *d_o
   }
   static int *d_err = nullptr;
   if (!d_err) { K3_HIP_CHECK(hipMalloc(&d_err, sizeof(int))); K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); }
-  p.err = d_err;
+  p.err = d_err; p.t_begin = (const long long *)d_t_begin; p.carry = d_carry;
   hipLaunchKernelGGL(k3_cmvn_online_kernel, dim3((unsigned)num_utts, (unsigned)((dim + 63) / 64)), dim3(64), 0, (hipStream_t)stream, p);
   K3_HIP_CHECK(hipGetLastError());
   int h_err = 0;

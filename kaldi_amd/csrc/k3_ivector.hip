@@ -74,9 +74,9 @@ __global__ void ivec_u(const double *__restrict__ M, const double *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------------- splice + LDA
 // out[t][d] = offset[d] + sum_{o=-lc..rc} sum_f lda[d][(o+lc) F + f] in[clamp(t+o)][f]; one thread per (frame, output dim); rows of one utterance only
 __global__ void ivec_splice_lda_kernel(const float *__restrict__ in, int64_t ld_in, const int64_t *__restrict__ frame_off, int num_utts, const float *__restrict__ lda,
-                                       int lda_cols, int has_offset, int F, int D, int lc, int rc, float *__restrict__ out, int64_t total_frames) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= total_frames * D) return;
-  const int64_t row = i / D; const int d = (int)(i % D);
+                                       int lda_cols, int has_offset, int F, int D, int lc, int rc, float *__restrict__ out, int64_t total_frames, int64_t row0) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= total_frames * D) return;      // rows row0 .. row0 + total_frames - 1 of `in`, written to out rows 0 ..
+  const int64_t row = row0 + i / D; const int d = (int)(i % D);
   int lo = 0, hi = num_utts;                                  // utterance of this row: last u with frame_off[u] <= row
   while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (frame_off[m] <= row) lo = m; else hi = m; }
   const int64_t b = frame_off[lo], e = frame_off[lo + 1];
@@ -174,6 +174,9 @@ struct EstParams {
   float *out; int64_t ld_out; const int64_t *out_off;
   int D, R, S, period, num_cg_iters, exact_solve; double prior, max_count;
   int acc_tail; const double *state_in; double *state_out;      // per utterance [1 + R + R*R]: num_frames, linear, quadratic (OnlineIvectorEstimationStats), nullable
+  // streaming (k3_ivector_stream): the posterior-stage arrays start at frame t_base of the stream; estimates k_begin, k_begin + 1, ... while k * period < t_limit; x_io [R] = the
+  // conjugate-gradient start (the previous estimate) in, the last estimate out.  t_limit < 0: a whole utterance (all of the above off)
+  int64_t t_base, t_limit; int k_begin; double *x_io;
 };
 
 __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
@@ -185,10 +188,10 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
   double *A = p.quad_g ? p.quad_g + (size_t)u * R * R : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7);
   double *C = p.chol_g + (size_t)u * R * R;
   __shared__ int s_n; __shared__ double s_tot;
-  const int64_t fb = p.frame_off[u]; const int T = (int)(p.frame_off[u + 1] - fb);
+  const int64_t fb = p.frame_off[u] - (p.t_limit >= 0 ? p.t_base : 0); const int T = p.t_limit >= 0 ? (int)p.t_limit : (int)(p.frame_off[u + 1] - p.frame_off[u]);
   const double *st_in = p.state_in ? p.state_in + (size_t)u * (1 + R + (size_t)R * R) : nullptr;      // the speaker's statistics so far (SetAdaptationState)
   for (int i = tid; i < R * R; i += kBlock) A[i] = st_in ? st_in[1 + R + i] : ((i / R == i % R) ? 1.0 : 0.0);      // fresh: quadratic term of the prior I, linear term prior_offset e_0
-  if (tid < R) { s_lin[tid] = st_in ? st_in[1 + tid] : (tid == 0 ? p.prior : 0.0); s_x[tid] = tid == 0 ? p.prior : 0.0; }
+  if (tid < R) { s_lin[tid] = st_in ? st_in[1 + tid] : (tid == 0 ? p.prior : 0.0); s_x[tid] = p.x_io ? p.x_io[tid] : (tid == 0 ? p.prior : 0.0); }
   double nframes = st_in ? st_in[0] : 0.0;
   __syncthreads();
   // OnlineIvectorFeature::UpdateStatsUntilFrame (online-ivector-feature.cc:248-277) for frames t_lo .. t_hi: every thread of the block calls it
@@ -230,7 +233,8 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
     __syncthreads();
   };
   int k_last = -1;
-  for (int k = 0; (int64_t)k * P < T; k++) {
+  const int k0 = p.t_limit >= 0 ? p.k_begin : 0;
+  for (int k = k0; (int64_t)k * P < T; k++) {
     const int t_lo = k == 0 ? 0 : (k - 1) * P + 1, t_hi = k * P;                     // frames not yet in the statistics, up to and including frame k*P
     accumulate(t_lo, t_hi); k_last = k;
     if (nframes > 0.0) {
@@ -271,8 +275,9 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
       }
     } else if (tid < R) s_x[tid] = tid == 0 ? p.prior : 0.0;
     __syncthreads();
-    if (tid < R) p.out[(p.out_off[u] + k) * p.ld_out + tid] = tid == 0 ? (float)s_x[0] - (float)p.prior : (float)s_x[tid];
+    if (tid < R) p.out[(p.out_off[u] + k - k0) * p.ld_out + tid] = tid == 0 ? (float)s_x[0] - (float)p.prior : (float)s_x[tid];
   }
+  if (p.x_io) { __syncthreads(); if (tid < R) p.x_io[tid] = s_x[tid]; }
   if (p.state_out) {                                                                  // GetAdaptationState: the statistics as they stand after the last estimate
     // (accumulate_tail: the reference's --repeat=true asks for the i-vector of the LAST frame, so its statistics hold every frame of the utterance when the state is taken:
     // ivector-extract-online2.cc:121-127 GetFrame(T - 1) -> UpdateStatsUntilFrame(T - 1))
@@ -373,9 +378,9 @@ extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_fea
   rc = k3_cmvn_online_batch(d_feats, ld_feats, (float *)iv->cmvn.p, F, F, d_off, num_utts, &iv->o.cmvn, iv->global_stats, d_cmvn_speaker_stats, nullptr, 0, stream_); if (rc) return rc;
   const unsigned nb = (unsigned)((N * D + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)iv->cmvn.p, (int64_t)F, d_off, num_utts, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D,
-                     iv->o.left_context, iv->o.right_context, (float *)iv->xpost.p, N);
+                     iv->o.left_context, iv->o.right_context, (float *)iv->xpost.p, N, (int64_t)0);
   hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, iv->o.online_cmvn_iextractor ? (const float *)iv->cmvn.p : d_feats, iv->o.online_cmvn_iextractor ? (int64_t)F : ld_feats, d_off, num_utts, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D,
-                     iv->o.left_context, iv->o.right_context, (float *)iv->xstats.p, N);
+                     iv->o.left_context, iv->o.right_context, (float *)iv->xstats.p, N, (int64_t)0);
   const int nw = kBlock / kWave; const size_t lds_post = ((size_t)nw * G + (size_t)nw * 2 * S) * 4;
   K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_extract_batch: too many Gaussians for the posterior kernel's LDS tile");
   const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;       // GetMinPost caps it, online-ivector-feature.cc:188-199
@@ -383,11 +388,147 @@ extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_fea
                      iv->o.posterior_scale, N, (int32_t *)iv->post_g.p, (float *)iv->post_w.p, (int32_t *)iv->post_n.p);
   EstParams p; p.xstats = (const float *)iv->xstats.p; p.frame_off = d_off; p.post_g = (const int32_t *)iv->post_g.p; p.post_w = (const float *)iv->post_w.p; p.post_n = (const int32_t *)iv->post_n.p;
   p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)iv->quad.p; p.chol_g = (double *)iv->state.p; p.out = d_ivectors; p.ld_out = ld_ivectors; p.out_off = d_row_off;
-  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out; p.acc_tail = iv->acc_tail;
+  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out; p.acc_tail = iv->acc_tail; p.t_base = 0; p.t_limit = -1; p.k_begin = 0; p.x_io = nullptr;
   size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
   K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_extract_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
   hipLaunchKernelGGL(ivec_estimate_kernel, dim3((unsigned)num_utts), dim3(kBlock), lds_est, stream, p);
   K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- streaming
+// One stream's extractor state between chunks: what OnlineIvectorFeature keeps (online2/online-ivector-feature.h:233-330: the statistics ivector_stats_, the frames already in them,
+// the estimates made so far, and under it OnlineCmvn's window and OnlineSpliceFrames' context) and what BatchedIvectorExtractorCuda keeps per channel
+// (cudafeat/feature-online-batched-ivector-cuda.h:30-61).  Every frame passes each stage once -- CMVN recursion continued from its carried window sums, splice + LDA + posteriors
+// when the frame's right context exists (or the stream has ended), statistics and one estimate per period -- in the order and arithmetic of the whole-utterance kernels above, so the
+// rows are bit-identical to k3_ivector_extract_batch on the whole utterance (tests/test_ivector_gpu.py).  Device memory per stream: max(cmn_window, splice) raw frames, the splice
+// context of normalised frames, the posterior-stage output of at most one period (+ a chunk), and (3 F + 1 + 2 R + R^2) doubles.
+struct k3_ivector_stream {
+  k3_ivector *iv = nullptr;
+  DevBuf raw[2], cm[2], px[2], pg[2], pw[2], pn[2], xpost, rows, state, offs, latest, chol, quad;
+  int raw_i = 0, cm_i = 0, pend_i = 0;
+  int64_t n_abs = 0, raw_s0 = 0, cm_c0 = 0, n_post = 0, a0 = 0, k_next = 0;      // frames accepted; stream index of row 0 of raw / cm / the pending posterior arrays; frames with posteriors; estimates made
+  bool finished = false, fresh = false;
+};
+
+extern "C" int k3_ivector_stream_create(k3_ivector *iv, k3_ivector_stream **out) {
+  K3_REQUIRE(iv && out, "k3_ivector_stream_create: null argument");
+  k3_ivector_stream *s = new k3_ivector_stream(); s->iv = iv;
+  const int rc = k3_ivector_stream_reset(s, nullptr);
+  if (rc) { delete s; return rc; }
+  *out = s; return K3_OK;
+}
+extern "C" void k3_ivector_stream_destroy(k3_ivector_stream *s) { delete s; }
+extern "C" int64_t k3_ivector_stream_num_rows(const k3_ivector_stream *s) { return s ? s->k_next : -1; }
+
+extern "C" int k3_ivector_stream_reset(k3_ivector_stream *s, void *stream_) {
+  K3_REQUIRE(s, "k3_ivector_stream_reset: null stream");
+  const k3_ivector *iv = s->iv; const int F = iv->F, R = iv->R; hipStream_t stream = (hipStream_t)stream_;
+  // window sums 0; statistics of no frames: quadratic term I, linear term prior_offset e_0 (OnlineIvectorEstimationStats), estimate prior_offset e_0 (online-ivector-feature.cc:381-385)
+  std::vector<double> h((size_t)3 * F + 1 + R + (size_t)R * R + R, 0.0);
+  double *est = h.data() + 3 * F; est[1] = iv->prior_offset; for (int i = 0; i < R; i++) est[1 + R + (size_t)i * R + i] = 1.0; est[1 + R + (size_t)R * R] = iv->prior_offset;
+  int rc = s->state.reserve(h.size() * 8); if (rc) return rc;
+  if ((rc = s->latest.reserve((size_t)R * 4)) || (rc = s->chol.reserve((size_t)R * R * 8)) || (rc = s->offs.reserve(8 * 8))) return rc;
+  if (!iv->quad_in_lds && (rc = s->quad.reserve((size_t)R * R * 8))) return rc;
+  K3_HIP_CHECK(hipMemcpyAsync(s->state.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, stream));
+  K3_HIP_CHECK(hipMemsetAsync(s->latest.p, 0, (size_t)R * 4, stream));
+  K3_HIP_CHECK(hipStreamSynchronize(stream));                   // h is a local
+  s->n_abs = s->raw_s0 = s->cm_c0 = s->n_post = s->a0 = s->k_next = 0; s->finished = false; s->fresh = true;
+  return K3_OK;
+}
+
+namespace {
+// the other buffer of a pair becomes [rows keep_from .. keep_from + keep_rows of the current one | room up to total_rows]
+int carry_over(DevBuf (&b)[2], int *cur, size_t row_bytes, int64_t keep_from, int64_t keep_rows, int64_t total_rows, hipStream_t stream) {
+  DevBuf &dst = b[*cur ^ 1];
+  const size_t need = (size_t)std::max<int64_t>(total_rows, 1) * row_bytes;
+  if (need > dst.cap) { const int rc = dst.reserve(need + need / 2); if (rc) return rc; }
+  if (keep_rows > 0) K3_HIP_CHECK(hipMemcpyAsync(dst.p, (const char *)b[*cur].p + (size_t)keep_from * row_bytes, (size_t)keep_rows * row_bytes, hipMemcpyDeviceToDevice, stream));
+  *cur ^= 1; return K3_OK;
+}
+}  // namespace
+
+extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_feats, int64_t ld_feats, int32_t num_frames, int32_t finished, float *d_new_rows, int64_t ld_rows,
+                                        int32_t max_new_rows, int32_t *h_num_new_rows, float *d_latest, void *stream_) {
+  K3_REQUIRE(s && num_frames >= 0 && (num_frames == 0 || (d_feats && ld_feats >= s->iv->F)), "k3_ivector_stream_accept: bad argument");
+  K3_REQUIRE(!s->finished, "k3_ivector_stream_accept: the stream has ended (k3_ivector_stream_reset starts the next one)");
+  K3_REQUIRE(!d_new_rows || ld_rows >= s->iv->R, "k3_ivector_stream_accept: leading dimension of the rows smaller than the i-vector dimension");
+  k3_ivector *iv = s->iv; hipStream_t stream = (hipStream_t)stream_;
+  const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period, lc = iv->o.left_context, rc_ = iv->o.right_context, W = iv->o.cmvn.cmn_window;
+  const int64_t n_new = num_frames, keepN = std::max<int64_t>(W, (int64_t)lc + rc_ + 1);
+  int rc;
+  // ---- raw frames: [what the CMVN window and the splice still read | the new frames]
+  const int64_t new_s0 = std::max<int64_t>(0, s->n_abs - keepN), keep = s->n_abs - new_s0, raw_rows = keep + n_new;
+  if ((rc = carry_over(s->raw, &s->raw_i, (size_t)F * 4, new_s0 - s->raw_s0, keep, raw_rows, stream))) return rc;
+  s->raw_s0 = new_s0;
+  float *raw = (float *)s->raw[s->raw_i].p;
+  if (n_new > 0) K3_HIP_CHECK(hipMemcpy2DAsync(raw + keep * F, (size_t)F * 4, d_feats, (size_t)ld_feats * 4, (size_t)F * 4, (size_t)n_new, hipMemcpyDeviceToDevice, stream));
+  // ---- normalised frames: [the splice context of the frames without posteriors yet | the new frames]
+  const int64_t new_c0 = std::max<int64_t>(0, s->n_post - lc), cm_keep = s->n_abs - new_c0, cm_rows = cm_keep + n_new;
+  if ((rc = carry_over(s->cm, &s->cm_i, (size_t)F * 4, new_c0 - s->cm_c0, cm_keep, cm_rows, stream))) return rc;
+  s->cm_c0 = new_c0;
+  float *cm = (float *)s->cm[s->cm_i].p;
+  const int64_t h_offs[8] = {0, raw_rows, 0, cm_rows, keep, 0, 0, 0};
+  K3_HIP_CHECK(hipMemcpyAsync(s->offs.p, h_offs, sizeof h_offs, hipMemcpyHostToDevice, stream));
+  K3_HIP_CHECK(hipStreamSynchronize(stream));                   // h_offs is a local
+  const int64_t *d_offs = (const int64_t *)s->offs.p;
+  double *carry = (double *)s->state.p, *est = carry + 3 * F, *x_io = est + 1 + R + (size_t)R * R;
+  if (n_new > 0) {      // rows keep .. raw_rows - 1 of raw -> rows cm_keep .. of cm
+    rc = k3_cmvn_online_batch_resume(raw, F, cm + (cm_keep - keep) * F, F, F, d_offs, 1, &iv->o.cmvn, iv->global_stats, nullptr, nullptr, 0, d_offs + 4, carry, stream_); if (rc) return rc;
+  }
+  s->n_abs += n_new; s->finished = finished != 0;
+  // ---- splice + LDA + posteriors for the frames whose right context is there
+  const int64_t P0 = s->n_post, P1 = finished ? s->n_abs : std::max<int64_t>(P0, s->n_abs - rc_), nP = P1 - P0, pend_rows = P0 - s->a0;
+  if (nP > 0) {
+    if ((rc = s->xpost.reserve((size_t)nP * D * 4))) return rc;
+    int i0 = s->pend_i, i1 = s->pend_i, i2 = s->pend_i, i3 = s->pend_i;      // grow the pending arrays in step (they share pend_i)
+    if ((size_t)(pend_rows + nP) * D * 4 > s->px[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pg[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pw[s->pend_i].cap || (size_t)(pend_rows + nP) * 4 > s->pn[s->pend_i].cap) {
+      if ((rc = carry_over(s->px, &i0, (size_t)D * 4, 0, pend_rows, pend_rows + nP, stream)) || (rc = carry_over(s->pg, &i1, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) ||
+          (rc = carry_over(s->pw, &i2, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) || (rc = carry_over(s->pn, &i3, 4, 0, pend_rows, pend_rows + nP, stream))) return rc;
+      s->pend_i = i0;
+    }
+    float *px = (float *)s->px[s->pend_i].p + pend_rows * D; int32_t *pg = (int32_t *)s->pg[s->pend_i].p + pend_rows * S; float *pw = (float *)s->pw[s->pend_i].p + pend_rows * S; int32_t *pn = (int32_t *)s->pn[s->pend_i].p + pend_rows;
+    const unsigned nb = (unsigned)((nP * D + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)cm, (int64_t)F, d_offs + 2, 1, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_,
+                       (float *)s->xpost.p, nP, P0 - s->cm_c0);
+    if (iv->o.online_cmvn_iextractor)
+      hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)cm, (int64_t)F, d_offs + 2, 1, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, px, nP, P0 - s->cm_c0);
+    else
+      hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)raw, (int64_t)F, d_offs, 1, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, px, nP, P0 - s->raw_s0);
+    const int nw = kBlock / kWave; const size_t lds_post = ((size_t)nw * G + (size_t)nw * 2 * S) * 4;
+    K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_stream_accept: too many Gaussians for the posterior kernel's LDS tile");
+    const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;
+    hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((nP + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)s->xpost.p, D, G, iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
+                       iv->o.posterior_scale, nP, pg, pw, pn);
+    K3_HIP_CHECK(hipGetLastError());
+    s->n_post = P1;
+  }
+  // ---- one estimate per period among the frames with posteriors: k * period < n_post
+  const int64_t k_end = (s->n_post + P - 1) / P, nk = k_end - s->k_next;
+  if (h_num_new_rows) *h_num_new_rows = (int32_t)nk;
+  if (nk > 0) {
+    K3_REQUIRE(!d_new_rows || nk <= max_new_rows, "k3_ivector_stream_accept: more new rows than the caller's buffer holds ((num_frames + right_context) / ivector_period + 1 is enough)");
+    if ((rc = s->rows.reserve((size_t)nk * R * 4))) return rc;
+    EstParams p; p.xstats = (const float *)s->px[s->pend_i].p; p.frame_off = d_offs + 6; p.post_g = (const int32_t *)s->pg[s->pend_i].p; p.post_w = (const float *)s->pw[s->pend_i].p; p.post_n = (const int32_t *)s->pn[s->pend_i].p;
+    p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)s->quad.p; p.chol_g = (double *)s->chol.p; p.out = (float *)s->rows.p; p.ld_out = R; p.out_off = d_offs + 5;
+    p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count;
+    p.state_in = est; p.state_out = est; p.acc_tail = 0; p.t_base = s->a0; p.t_limit = s->n_post; p.k_begin = (int)s->k_next; p.x_io = x_io;
+    const size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
+    K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_stream_accept: ivector_period * num_gselect too large for the estimation kernel's LDS");
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
+    hipLaunchKernelGGL(ivec_estimate_kernel, dim3(1), dim3(kBlock), lds_est, stream, p);
+    K3_HIP_CHECK(hipGetLastError());
+    K3_HIP_CHECK(hipMemcpyAsync(s->latest.p, (const float *)s->rows.p + (nk - 1) * R, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
+    if (d_new_rows) K3_HIP_CHECK(hipMemcpy2DAsync(d_new_rows, (size_t)ld_rows * 4, s->rows.p, (size_t)R * 4, (size_t)R * 4, (size_t)nk, hipMemcpyDeviceToDevice, stream));
+    s->k_next = k_end;
+    // the statistics now hold the frames up to (k_next - 1) * period: the posterior-stage rows before that are done with
+    const int64_t new_a0 = (s->k_next - 1) * P + 1, left = s->n_post - new_a0;
+    int i0 = s->pend_i, i1 = s->pend_i, i2 = s->pend_i, i3 = s->pend_i;
+    if ((rc = carry_over(s->px, &i0, (size_t)D * 4, new_a0 - s->a0, left, left, stream)) || (rc = carry_over(s->pg, &i1, (size_t)S * 4, new_a0 - s->a0, left, left, stream)) ||
+        (rc = carry_over(s->pw, &i2, (size_t)S * 4, new_a0 - s->a0, left, left, stream)) || (rc = carry_over(s->pn, &i3, 4, new_a0 - s->a0, left, left, stream))) return rc;
+    s->pend_i = i0; s->a0 = new_a0;
+  }
+  if (d_latest) K3_HIP_CHECK(hipMemcpyAsync(d_latest, s->latest.p, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
   return K3_OK;
 }

@@ -132,28 +132,22 @@ inline k3_ivector *CreateIvectorExtractor(const IvectorExtractionInfo &iv_info, 
 
 // Per-channel i-vectors of a stream, the C++ twin of kaldi_amd/online.py: the extractor sees every feature frame as soon as it exists; Latest() is the i-vector the reference's online
 // decodable hands the network for a chunk (nnet3/decodable-online-looped.cc:182-197 over OnlineIvectorFeature with use_most_recent_ivector): the estimate made at the last multiple
-// of --ivector-period among the frames ready (all frames so far minus the LDA splice's right context while the stream goes on), zero before the first.  The estimates are rows of
-// the whole-utterance extraction (k3_ivector_extract_batch: row k = statistics of frames 0 .. k * period), obtained by re-extracting the stream's prefix.
+// of --ivector-period among the frames ready (all frames so far minus the LDA splice's right context while the stream goes on), zero before the first.  One k3_ivector_stream per
+// channel carries the CMVN window, the splice context, the statistics and the solver's start between chunks: the estimates are, bit for bit, rows of the whole-utterance extraction
+// (k3_ivector_extract_batch: row k = statistics of frames 0 .. k * period), every frame processed once.
 class OnlineIvectors {
  public:
-  OnlineIvectors(k3_ivector *iv, int right_context, int nch) : iv_(iv), rc_(right_context), hist_(nch) {
-    k3_ivector_info i; K3H_CHECK_K3(k3_ivector_get_info(iv, &i)); F_ = i.feat_dim; R_ = i.ivector_dim; period_ = i.ivector_period; latest_.need((size_t)nch * R_); K3O_HIP(hipMemset(latest_.p, 0, (size_t)nch * R_ * 4));
+  OnlineIvectors(k3_ivector *iv, int right_context, int nch) : iv_(iv), st_(nch, nullptr) {
+    (void)right_context;      // (the extractor's own option; kept in the signature for its callers)
+    k3_ivector_info i; K3H_CHECK_K3(k3_ivector_get_info(iv, &i)); F_ = i.feat_dim; R_ = i.ivector_dim; latest_.need((size_t)nch * R_); K3O_HIP(hipMemset(latest_.p, 0, (size_t)nch * R_ * 4));
+    for (auto &s : st_) K3H_CHECK_K3(k3_ivector_stream_create(iv_, &s));
   }
   int Dim() const { return R_; }
-  void Reset(int ch) { hist_[ch].n = 0; }
+  void Reset(int ch) { K3H_CHECK_K3(k3_ivector_stream_reset(st_[ch], nullptr)); K3O_HIP(hipMemset(latest_.p + (size_t)ch * R_, 0, (size_t)R_ * 4)); }
   // n new feature rows of the channel (device, F_ wide, contiguous); finished: the stream's audio has ended.  Updates Row(ch).
   void Accept(int ch, const float *d_rows, int n, bool finished) {
-    Hist &h = hist_[ch];
-    if (h.n + (size_t)n > h.cap) { const size_t cap = (h.n + n) * 2 + 256; float *q = nullptr; K3O_HIP(hipMalloc((void **)&q, cap * F_ * 4)); if (h.n) K3O_HIP(hipMemcpy(q, h.p, h.n * F_ * 4, hipMemcpyDeviceToDevice)); if (h.p) (void)hipFree(h.p); h.p = q; h.cap = cap; }
-    if (n > 0) K3O_HIP(hipMemcpy(h.p + h.n * F_, d_rows, (size_t)n * F_ * 4, hipMemcpyDeviceToDevice));
-    h.n += n;
-    const long long ready = (long long)h.n - (finished ? 0 : rc_);
-    float *dst = latest_.p + (size_t)ch * R_;
-    if (ready <= 0) { K3O_HIP(hipMemset(dst, 0, (size_t)R_ * 4)); return; }
-    const long long row = (ready - 1) / period_; const int64_t nn = std::min<long long>((long long)h.n, row * period_ + rc_ + 1), off[2] = {0, nn};
-    const int64_t rows = k3_ivector_num_rows(iv_, 1, off, nullptr);
-    K3H_CHECK_K3(k3_ivector_extract_batch(iv_, h.p, F_, off, 1, rows_.need((size_t)rows * R_), R_, nullptr));
-    K3O_HIP(hipMemcpy(dst, rows_.p + (size_t)row * R_, (size_t)R_ * 4, hipMemcpyDeviceToDevice));
+    K3H_CHECK_K3(k3_ivector_stream_accept(st_[ch], d_rows, F_, n, finished ? 1 : 0, nullptr, 0, 0, nullptr, latest_.p + (size_t)ch * R_, nullptr));
+    K3O_HIP(hipStreamSynchronize(nullptr));
   }
   const float *Row(int ch) const { return latest_.p + (size_t)ch * R_; }
   // the rows of the listed channels back to back (what StaticNnet3::Pass takes)
@@ -162,9 +156,8 @@ class OnlineIvectors {
     for (size_t i = 0; i < channels.size(); i++) K3O_HIP(hipMemcpy(g + i * R_, Row(channels[i]), (size_t)R_ * 4, hipMemcpyDeviceToDevice));
     return g;
   }
-  ~OnlineIvectors() { for (auto &h : hist_) if (h.p) (void)hipFree(h.p); }
+  ~OnlineIvectors() { for (auto *s : st_) if (s) k3_ivector_stream_destroy(s); }
  private:
-  struct Hist { float *p = nullptr; size_t cap = 0, n = 0; };
-  k3_ivector *iv_; int rc_, F_ = 0, R_ = 0, period_ = 1; std::vector<Hist> hist_; DevBuf<float> latest_, rows_, gather_;
+  k3_ivector *iv_; int F_ = 0, R_ = 0; std::vector<k3_ivector_stream *> st_; DevBuf<float> latest_, gather_;
 };
 }  // namespace k3host

@@ -100,3 +100,32 @@ class BatchedIvectorExtractor:
         return (out, ro, so) if return_stats else (out, ro)
 
     def StatsSize(self): return int(self._L.k3_ivector_stats_size(self._h))
+
+
+class IvectorStream:
+    """One audio stream's extractor state (k3_ivector_stream_*): AcceptFrames(feats, finished) takes the new feature rows and returns the i-vectors they complete -- rows of the whole
+    utterance's GetIvectors, bit for bit, every frame processed once -- Latest() the estimate the reference's online decodable would hand the network now (zeros before the first)."""
+    def __init__(self, extractor):
+        self.ex = extractor; self._L = extractor._L; self._h = ctypes.c_void_p()
+        _l.check(self._L.k3_ivector_stream_create(extractor._h, ctypes.byref(self._h)))
+        self.latest = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value: self._L.k3_ivector_stream_destroy(self._h); self._h.value = None
+        except Exception:
+            pass
+
+    def Reset(self): _l.check(self._L.k3_ivector_stream_reset(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))); self.latest = None
+    def NumRows(self): return int(self._L.k3_ivector_stream_num_rows(self._h))
+
+    def AcceptFrames(self, feats, finished):
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and (feats.shape[0] == 0 or feats.stride(1) == 1)
+        n = int(feats.shape[0]); cap = (n + self.ex.right_context) // self.ex.ivector_period + 2      # (the end of the stream releases the frames that waited for their right context)
+        rows = torch.empty((cap, self.ex.ivector_dim), dtype=torch.float32, device=feats.device); got = ctypes.c_int32(0)
+        if self.latest is None: self.latest = torch.zeros(self.ex.ivector_dim, dtype=torch.float32, device=feats.device)
+        _l.check(self._L.k3_ivector_stream_accept(self._h, feats.data_ptr() if n else None, feats.stride(0) if n else self.ex.feat_dim, n, int(bool(finished)), rows.data_ptr(), rows.stride(0), cap, ctypes.byref(got),
+                                                  self.latest.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return rows[:got.value]
+
+    def Latest(self): return self.latest

@@ -76,13 +76,16 @@ class BatchedOnlinePipeline:
         its channel, by the rule of the reference's online decodable (nnet3/decodable-online-looped.cc:182-197 over OnlineIvectorFeature, online2/online-ivector-feature.cc:
         use_most_recent_ivector): the estimate made at the last multiple of --ivector-period among the frames the extractor has seen -- all feature frames of the stream so far
         minus the LDA splice's right context while the stream goes on -- and zero before the first.  The estimates are rows of the whole-utterance extraction (k3_ivector_extract_batch:
-        row k = statistics of frames 0 .. k * period), taken from a re-extraction of the stream's prefix: exact, at the price of re-reading the prefix per chunk (carrying the CMVN
-        window, the splice context and the solver's warm start across calls would avoid that)."""
+        row k = statistics of frames 0 .. k * period), made by one kaldi_amd.ivector.IvectorStream per channel: the CMVN window, the splice context, the statistics and the solver's warm
+        start are carried across calls, every frame is processed once."""
         self.nch = num_channels; self.dev = torch.device(device)
         self.iv = ivector_extractor
         if (nnet.info.ivector_dim > 0) != (ivector_extractor is not None): raise ValueError("a model with an i-vector input needs an ivector_extractor (and only such a model)")
         if self.iv is not None and self.iv.ivector_dim != nnet.info.ivector_dim: raise ValueError("Ivector feature dimension mismatch: got %d but network expects %d" % (self.iv.ivector_dim, nnet.info.ivector_dim))
-        self.hist = [None] * num_channels      # per channel: all feature frames of the stream so far (i-vector models)
+        self.ivs = None
+        if self.iv is not None:
+            from .ivector import IvectorStream
+            self.ivs = [IvectorStream(self.iv) for _ in range(num_channels)]      # per channel: the extractor's state of the stream
         self.features = OnlineBatchedFeaturePipeline(feat_opts, num_channels, device)
         self.nnet = _nnet3.BatchedStaticNnet3(nnet, num_channels, num_channels, frames_per_chunk, frame_subsampling_factor, log_priors, acoustic_scale, device)
         self.C = frames_per_chunk
@@ -93,14 +96,6 @@ class BatchedOnlinePipeline:
         self.pending = [self._empty_feats for _ in range(num_channels)]
         self.started = np.zeros(num_channels, bool); self.frames_decoded = np.zeros(num_channels, np.int64)
         self.frame_shift_seconds = 0.001 * feat_opts.frame_shift_ms * frame_subsampling_factor      # SetOutputFrameShiftInSeconds
-
-    def _latest_ivector(self, hist, finished):
-        n_ready = hist.shape[0] - (0 if finished else self.iv.right_context)      # OnlineIvectorFeature::NumFramesReady = the spliced features' (online-feature.cc OnlineSpliceFrames)
-        if n_ready <= 0: return torch.zeros(self.iv.ivector_dim, dtype=torch.float32, device=self.dev)      # decodable-online-looped.cc:195-197
-        row = (n_ready - 1) // self.iv.ivector_period
-        n = min(hist.shape[0], row * self.iv.ivector_period + self.iv.right_context + 1)      # row `row` reads the features up to row * period + right_context, all of them real frames
-        rows, _ = self.iv.GetIvectors(hist[:n].contiguous(), [0, n])
-        return rows[row]
 
     def GetPartialHypothesis(self, channels):
         """CudaDecoder::GetPartialHypothesis (cuda-decoder.h:286): the words of the best path to the tokens each channel holds now (no final-probs)"""
@@ -123,14 +118,15 @@ class BatchedOnlinePipeline:
         fresh = [ch for ch, first in zip(channels, is_first_chunk) if first]
         if fresh:
             self.decoder.InitChannels(fresh)
-            for ch in fresh: self.pending[ch] = self._empty_feats; self.started[ch] = False; self.frames_decoded[ch] = 0; self.hist[ch] = None
+            for ch in fresh: self.pending[ch] = self._empty_feats; self.started[ch] = False; self.frames_decoded[ch] = 0
+            if self.ivs is not None:
+                for ch in fresh: self.ivs[ch].Reset()
         feats = self.features.ComputeFeaturesBatched(channels, wave_chunks, is_first_chunk, is_last_chunk)
         ivec = None
         if self.iv is not None:      # the extractor sees every feature frame as soon as it exists (OnlineIvectorFeature over the same base features)
             ivec = {}
             for ch, f, fin in zip(channels, feats, is_last_chunk):
-                self.hist[ch] = f if self.hist[ch] is None else torch.cat([self.hist[ch], f])
-                ivec[ch] = self._latest_ivector(self.hist[ch], bool(fin))
+                self.ivs[ch].AcceptFrames(f, bool(fin)); ivec[ch] = self.ivs[ch].Latest().clone()
         lls = {ch: [] for ch in channels}
         # feature frames go to the network at most frames_per_chunk at a time; what does not fill a chunk waits (unless the stream ends)
         todo = {ch: torch.cat([self.pending[ch], f]) for ch, f in zip(channels, feats)}

@@ -93,6 +93,39 @@ def test_against_the_oracle_on_random_models(case, exact, monkeypatch):
     assert worst <= TOL, worst
 
 
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("variant", ["default", "short_cmn_window", "cmvn_for_the_statistics"])
+def test_streaming_extraction_equals_the_whole_utterance_rows(case, variant):
+    """k3_ivector_stream_*: the stream's frames in chunks of random length (1 frame .. several periods, an empty chunk, the end announced with or without frames) through the stages that
+    carry state across calls -- CMVN window sums (with a window shorter than the stream: the subtraction branch), splice context, posterior-stage rows waiting for their period, statistics,
+    the solver's warm start -- give, bit for bit, the rows of k3_ivector_extract_batch on the whole utterance, and Latest() follows the rule of the reference's online decodable"""
+    from kaldi_amd.ivector import BatchedIvectorExtractor, IvectorStream
+    F, lc, rc, D, G, R, off, o, lens = CASES[case]; rng = np.random.default_rng(300 + case)
+    lda, st, ubm, ie = _random_model(rng, F, lc, rc, D, G, R, off)
+    opts = dict(num_gselect=5, min_post=0.025, posterior_scale=0.1, max_count=0.0, ivector_period=10, num_cg_iters=15); opts.update(o)
+    if variant == "short_cmn_window": opts.update(cmvn_cmn_window=17, cmvn_speaker_frames=17, cmvn_global_frames=9)
+    if variant == "cmvn_for_the_statistics": opts.update(online_cmvn_iextractor=1, cmvn_normalize_variance=1)
+    il = np.tril_indices(D); packed = np.stack([ie["sigma_inv"][g][il] for g in range(G)])
+    ex = BatchedIvectorExtractor.FromArrays(lda, st, ubm["gconsts"], ubm["means_invvars"], ubm["inv_vars"], ie["M"], packed, ie["prior_offset"], left_context=lc, right_context=rc, **opts)
+    dev = torch.device("cuda:0"); P = opts["ivector_period"]; stream = IvectorStream(ex)
+    for T in lens + [3 * max(lens) + 5]:
+        f = torch.from_numpy((rng.standard_normal((T, F)) * 2.0 + rng.standard_normal(F)).astype(np.float32)).to(dev)
+        whole, _ = ex.GetIvectors(f, [0, T])
+        for trial in range(3):
+            stream.Reset(); pos = 0; got = []; end_with_frames = bool(rng.integers(0, 2))
+            while pos < T:
+                m = min(int(rng.integers(0, 3 * P + 2)) if trial else 1 + int(rng.integers(0, 4)), T - pos); last = pos + m >= T
+                got.append(stream.AcceptFrames(f[pos:pos + m], last and end_with_frames).clone()); pos += m
+                ready = pos - (0 if (last and end_with_frames) else rc)
+                want = whole[(ready - 1) // P] if ready > 0 else torch.zeros_like(whole[0])
+                assert torch.equal(stream.Latest(), want), (T, trial, pos)
+            if not end_with_frames: got.append(stream.AcceptFrames(f[:0], True).clone())
+            got = torch.cat(got)
+            assert got.shape == whole.shape and torch.equal(got, whole), (T, trial, (got != whole).any(1).nonzero()[:3].tolist())
+            assert stream.NumRows() == whole.shape[0] and torch.equal(stream.Latest(), whole[-1])
+            with pytest.raises(Exception, match="has ended"): stream.AcceptFrames(f[:1], False)
+
+
 def test_argument_errors():
     from kaldi_amd.ivector import BatchedIvectorExtractor
     from kaldi_amd.lib import K3Error

@@ -144,7 +144,8 @@ def test_streaming_network_with_one_ivector_per_chunk(tmp_path):
 def test_streaming_pipeline_uses_the_extractors_latest_ivector(tmp_path):
     """kaldi_amd/online.py with an i-vector extractor: the i-vector a chunk is evaluated with is the row of the WHOLE utterance's extraction that the reference's online decodable
     would use (decodable-online-looped.cc:182-197: the estimate at the last multiple of the period among the frames ready = frames so far minus the splice's right context, zero before
-    the first) -- although the pipeline only ever saw the stream's prefix; and a model with an i-vector input decodes to the same lattice twice"""
+    the first) -- although the extractor only ever saw the stream's prefix, chunk by chunk (IvectorStream: every frame processed once); and a model with an i-vector input decodes to the
+    same lattice twice"""
     from kaldi_amd import feat, decoder, online
     dev = torch.device("cuda:0"); nn, ex = _iv_setup(tmp_path); N = nn.info.output_dim
     graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); cf = decoder.CudaFst(graph, synth.tid2pdf(N))
@@ -152,16 +153,23 @@ def test_streaming_pipeline_uses_the_extractors_latest_ivector(tmp_path):
     pipe = online.BatchedOnlinePipeline(opts, nn, cf, cfg, 2, 400, frames_per_chunk=60, ivector_extractor=ex)
     wave = torch.from_numpy(synth.gaussian_pcm16(30000, 5).astype(np.float32)).to(dev)
     sf = feat.SpectralFeatures(opts); full = sf.ComputeFeatures(wave, *sf.offsets([30000], dev)[:3]); rows, _ = ex.GetIvectors(full, [0, full.shape[0]])
+    from kaldi_amd.ivector import IvectorStream
+    st = IvectorStream(ex); rng = np.random.default_rng(4)
     for n, fin in [(1, False), (3, False), (4, False), (13, False), (14, False), (57, False), (186, False), (186, True), (full.shape[0], True)]:
-        got = pipe._latest_ivector(full[:n].contiguous(), fin); ready = n - (0 if fin else ex.right_context)
+        st.Reset(); pos = 0
+        while True:      # the prefix in chunks of random length; the last call carries `fin`
+            m = min(int(rng.integers(1, 40)), n - pos); last = pos + m >= n; st.AcceptFrames(full[pos:pos + m], fin and last); pos += m
+            if last: break
+        ready = n - (0 if fin else ex.right_context)
         want = rows[(ready - 1) // ex.ivector_period] if ready > 0 else torch.zeros_like(rows[0])
-        assert torch.equal(got, want), (n, fin)
+        assert torch.equal(st.Latest(), want) and st.NumRows() == (max(ready, 0) + ex.ivector_period - 1) // ex.ivector_period, (n, fin)
     def decode():
         pos = 0; lat = None
         while pos < wave.numel():
             n = min(4321, wave.numel() - pos); r = pipe.DecodeBatch([1], [wave[pos:pos + n]], [pos == 0], [pos + n >= wave.numel()]); pos += n
             if r: lat = r[1]
         return lat
-    a = decode(); b = decode()
+    a = decode(); assert pipe.ivs[1].NumRows() == rows.shape[0] and torch.equal(pipe.ivs[1].Latest(), rows[-1])      # the channel's extractor saw the whole stream, once
+    b = decode()
     assert a is not None and a.num_arcs > 50 and a.diff(b) == ""
     with pytest.raises(ValueError, match="needs an ivector_extractor"): online.BatchedOnlinePipeline(opts, nn, cf, cfg, 2, 400)
