@@ -12,6 +12,10 @@ inline int fail(int code, const char *what, const char *file, int line) {
   set_error("%s (%s:%d)", what, file, line);
   return code;
 }
+// k3_cmvn_online_batch_resume without the wait for its error flag (k3_feat.hip): the streaming i-vector extractor queues it between its own kernels.  The flag can only be
+// raised by global statistics without frames, which k3_ivector_create refuses
+int cmvn_online_resume_async(const float *d_in, long long ld_in, float *d_out, long long ld_out, int dim, const long long *d_frame_offsets, int num_utts, const void *opts,
+                             const double *d_global_stats, const long long *d_t_begin, double *d_carry, void *stream);
 }  // namespace k3
 
 #define K3_HIP_CHECK(expr)                                                              \

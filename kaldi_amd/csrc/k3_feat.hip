@@ -781,6 +781,22 @@ extern "C" int k3_cmvn_online_batch_resume(const float *d_in, int64_t ld_in, flo
   return K3_OK;
 }
 
+int k3::cmvn_online_resume_async(const float *d_in, long long ld_in, float *d_out, long long ld_out, int dim, const long long *d_frame_offsets, int num_utts, const void *opts_,
+                                 const double *d_global_stats, const long long *d_t_begin, double *d_carry, void *stream) {
+  const k3_online_cmvn_opts *opts = static_cast<const k3_online_cmvn_opts *>(opts_);
+  K3_REQUIRE(d_in && d_out && d_in != d_out && d_frame_offsets && opts && d_global_stats && d_t_begin && d_carry && dim > 0 && num_utts > 0, "cmvn_online_resume_async: bad argument");
+  OnlineCmvnParams p{};
+  p.in = d_in; p.out = d_out; p.ld_in = ld_in; p.ld_out = ld_out; p.dim = dim; p.frame_off = d_frame_offsets;
+  p.cmn_window = opts->cmn_window; p.speaker_frames = opts->speaker_frames; p.global_frames = opts->global_frames; p.norm_means = opts->normalize_mean; p.norm_vars = opts->normalize_variance;
+  p.global_stats = d_global_stats; p.speaker_stats = nullptr; p.t_begin = d_t_begin; p.carry = d_carry;
+  static int *d_err = nullptr;      // (never read here: see the header)
+  if (!d_err) { K3_HIP_CHECK(hipMalloc(&d_err, sizeof(int))); K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); }
+  p.err = d_err;
+  hipLaunchKernelGGL(k3_cmvn_online_kernel, dim3((unsigned)num_utts, (unsigned)((dim + 63) / 64)), dim3(64), 0, (hipStream_t)stream, p);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
+
 extern "C" void k3_online_cmvn_opts_default(k3_online_cmvn_opts *o) {
   if (!o) return;
   o->cmn_window = 600; o->speaker_frames = 600; o->global_frames = 200; o->normalize_mean = 1; o->normalize_variance = 0;

@@ -314,6 +314,7 @@ extern "C" int k3_ivector_create(const k3_ivector_model *m, const k3_ivector_opt
   iv->prior_offset = m->prior_offset;
   const int F = iv->F, D = iv->D, G = iv->G, R = iv->R;
   { std::vector<float> h(m->lda, m->lda + (size_t)D * m->lda_cols); const int rc = upload(&iv->lda, h); if (rc) return rc; }
+  K3_REQUIRE(m->global_cmvn_stats[F] > 0.0, "k3_ivector_create: the global CMVN statistics hold no frames (OnlineCmvn raises 'Global CMVN stats are required')");
   { std::vector<double> h(m->global_cmvn_stats, m->global_cmvn_stats + 2 * (size_t)(F + 1)); const int rc = upload(&iv->global_stats, h); if (rc) return rc; }
   { std::vector<float> gc(G), a((size_t)D * G), b((size_t)D * G);
     for (int g = 0; g < G; g++) { gc[g] = (float)m->gconsts[g]; for (int d = 0; d < D; d++) { a[(size_t)d * G + g] = (float)m->means_invvars[(size_t)g * D + d]; b[(size_t)d * G + g] = (float)m->inv_vars[(size_t)g * D + d]; } }
@@ -449,6 +450,10 @@ int carry_over(DevBuf (&b)[2], int *cur, size_t row_bytes, int64_t keep_from, in
 }
 }  // namespace
 
+namespace {
+__global__ void ivec_set_offsets_kernel(int64_t *o, int64_t raw_rows, int64_t cm_rows, int64_t keep) { o[0] = 0; o[1] = raw_rows; o[2] = 0; o[3] = cm_rows; o[4] = keep; o[5] = 0; o[6] = 0; o[7] = 0; }
+}  // namespace
+
 extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_feats, int64_t ld_feats, int32_t num_frames, int32_t finished, float *d_new_rows, int64_t ld_rows,
                                         int32_t max_new_rows, int32_t *h_num_new_rows, float *d_latest, void *stream_) {
   K3_REQUIRE(s && num_frames >= 0 && (num_frames == 0 || (d_feats && ld_feats >= s->iv->F)), "k3_ivector_stream_accept: bad argument");
@@ -469,13 +474,11 @@ extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_fea
   if ((rc = carry_over(s->cm, &s->cm_i, (size_t)F * 4, new_c0 - s->cm_c0, cm_keep, cm_rows, stream))) return rc;
   s->cm_c0 = new_c0;
   float *cm = (float *)s->cm[s->cm_i].p;
-  const int64_t h_offs[8] = {0, raw_rows, 0, cm_rows, keep, 0, 0, 0};
-  K3_HIP_CHECK(hipMemcpyAsync(s->offs.p, h_offs, sizeof h_offs, hipMemcpyHostToDevice, stream));
-  K3_HIP_CHECK(hipStreamSynchronize(stream));                   // h_offs is a local
+  hipLaunchKernelGGL(ivec_set_offsets_kernel, dim3(1), dim3(1), 0, stream, (int64_t *)s->offs.p, raw_rows, cm_rows, keep);      // (values travel as kernel arguments: nothing on the host to keep alive, no wait)
   const int64_t *d_offs = (const int64_t *)s->offs.p;
   double *carry = (double *)s->state.p, *est = carry + 3 * F, *x_io = est + 1 + R + (size_t)R * R;
   if (n_new > 0) {      // rows keep .. raw_rows - 1 of raw -> rows cm_keep .. of cm
-    rc = k3_cmvn_online_batch_resume(raw, F, cm + (cm_keep - keep) * F, F, F, d_offs, 1, &iv->o.cmvn, iv->global_stats, nullptr, nullptr, 0, d_offs + 4, carry, stream_); if (rc) return rc;
+    rc = k3::cmvn_online_resume_async(raw, F, cm + (cm_keep - keep) * F, F, F, (const long long *)d_offs, 1, &iv->o.cmvn, iv->global_stats, (const long long *)(d_offs + 4), carry, stream_); if (rc) return rc;
   }
   s->n_abs += n_new; s->finished = finished != 0;
   // ---- splice + LDA + posteriors for the frames whose right context is there

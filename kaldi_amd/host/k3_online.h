@@ -146,8 +146,7 @@ class OnlineIvectors {
   void Reset(int ch) { K3H_CHECK_K3(k3_ivector_stream_reset(st_[ch], nullptr)); K3O_HIP(hipMemset(latest_.p + (size_t)ch * R_, 0, (size_t)R_ * 4)); }
   // n new feature rows of the channel (device, F_ wide, contiguous); finished: the stream's audio has ended.  Updates Row(ch).
   void Accept(int ch, const float *d_rows, int n, bool finished) {
-    K3H_CHECK_K3(k3_ivector_stream_accept(st_[ch], d_rows, F_, n, finished ? 1 : 0, nullptr, 0, 0, nullptr, latest_.p + (size_t)ch * R_, nullptr));
-    K3O_HIP(hipStreamSynchronize(nullptr));
+    K3H_CHECK_K3(k3_ivector_stream_accept(st_[ch], d_rows, F_, n, finished ? 1 : 0, nullptr, 0, 0, nullptr, latest_.p + (size_t)ch * R_, nullptr));      // queued on the null stream, like its consumers
   }
   const float *Row(int ch) const { return latest_.p + (size_t)ch * R_; }
   // the rows of the listed channels back to back (what StaticNnet3::Pass takes)

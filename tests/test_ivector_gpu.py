@@ -134,6 +134,8 @@ def test_argument_errors():
     mk = lambda **kw: BatchedIvectorExtractor.FromArrays(lda, st, ubm["gconsts"], ubm["means_invvars"], ubm["inv_vars"], ie["M"], packed, 0.0, **kw)
     with pytest.raises(K3Error): mk(left_context=2, right_context=2)                       # LDA columns do not match the splice width
     with pytest.raises(K3Error): mk(left_context=1, right_context=1, ivector_period=0)
+    st0 = st.copy(); st0[0, 8] = 0.0
+    with pytest.raises(K3Error, match="hold no frames"): BatchedIvectorExtractor.FromArrays(lda, st0, ubm["gconsts"], ubm["means_invvars"], ubm["inv_vars"], ie["M"], packed, 0.0, left_context=1, right_context=1)      # OnlineCmvn: 'Global CMVN stats are required'
     ex = mk(left_context=1, right_context=1)
     x = torch.zeros((10, 8), device="cuda:0")
     with pytest.raises(K3Error): ex.GetIvectors(x, [0, 10, 10])                             # an utterance without frames
