@@ -74,7 +74,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // EPI: the epilogue program known at compile time -- 0: any (run-time dispatch per op), 1: ReLU, scale/offset, residual (a TDNN-F
 // affine + ReLU + BatchNorm + bypass), 2: none (linear bottleneck), 3: ReLU, scale/offset.  The fixed programs are straight-line
 // code; the run-time dispatch costs a register shuffle per op when it merges the branches.
-enum { kEpiAny = 0, kEpiReluScaleRes = 1, kEpiNone = 2, kEpiReluScale = 3 };
+enum { kEpiAny = 0, kEpiReluScaleRes = 1, kEpiNone = 2, kEpiReluScale = 3, kEpiAnyMap = 4 };      // kEpiAnyMap: kEpiAny + the sigmoid / tanh operations (their own instantiation: the exp code costs the generic one registers)
 // SigmoidComponent / TanhComponent: the overflow-safe forms of matrix/kaldi-vector.cc:900-960
 __device__ __forceinline__ float epi_sigmoid(float x) { if (x > 0.0f) return 1.0f / (1.0f + expf(-x)); const float e = expf(x); return e / (e + 1.0f); }
 __device__ __forceinline__ float epi_tanh(float x) { if (x > 0.0f) { const float e = expf(-x); return -1.0f + 2.0f / (1.0f + e * e); } const float e = expf(x); return 1.0f - 2.0f / (1.0f + e * e); }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
     // a full tile (all of the 128 rows and BN columns exist: every tile but the last of an utterance / of N) needs no per-row
     // bounds logic and walks its rows with one pointer increment per row piece
     const bool full = td.nrows == kBM && n0 + BN <= p.N;
-    if ((EPI == kEpiAny || EPI == kEpiReluScaleRes) && res_kind >= 0 && !(K3_GDBG & 1)) {
+    if ((EPI == kEpiAny || EPI == kEpiAnyMap || EPI == kEpiReluScaleRes) && res_kind >= 0 && !(K3_GDBG & 1)) {
       if (full && td.split >= td.nrows) {
         const float *rp = R + (long long)(td.res_base + (wm * WM + row0c) * p.res_row_stride) * p.ldr + colc;
         const long long rstep = (long long)RPI * p.res_row_stride * p.ldr;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
         }
       }
     }
-    if (EPI == kEpiAny) {
+    if (EPI == kEpiAny || EPI == kEpiAnyMap) {
 #pragma unroll
       for (int o = 0; o < kMaxOps; o++) {
         if (o < p.nops && p.op_kind[o] == k3::kEpiScaleOffset) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) v[it] = *reinterpret_cast<const f32x4 *>(stage + (it * RPI + row0c) * kStLd + c4 * 4);
-    if (EPI == kEpiAny) {
+    if (EPI == kEpiAny || EPI == kEpiAnyMap) {
 #pragma unroll
       for (int o = 0; o < kMaxOps; o++) {
         if (o < p.nops) {
@@ -330,7 +330,7 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
           } else if (kind == k3::kEpiScaleOffset) {
 #pragma unroll
             for (int it = 0; it < ITERS; it++) v[it] = v[it] * opS[o] + opO[o];
-          } else if (kind == k3::kEpiSigmoid || kind == k3::kEpiTanh) {
+          } else if (EPI == kEpiAnyMap && (kind == k3::kEpiSigmoid || kind == k3::kEpiTanh)) {
 #pragma unroll
             for (int it = 0; it < ITERS; it++)
 #pragma unroll
@@ -378,8 +378,8 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
           const int kind = p.op_kind[o];
           if (kind == k3::kEpiRelu) x = fmaxf(x, 0.0f);
           else if (kind == k3::kEpiScaleOffset) x = x * p.op_scale[o][c] + p.op_offset[o][c];
-          else if (kind == k3::kEpiSigmoid) x = epi_sigmoid(x);
-          else if (kind == k3::kEpiTanh) x = epi_tanh(x);
+          else if (EPI == kEpiAnyMap && kind == k3::kEpiSigmoid) x = epi_sigmoid(x);
+          else if (EPI == kEpiAnyMap && kind == k3::kEpiTanh) x = epi_tanh(x);
           else x = p.res_scale * R[(long long)((lrow < td.split ? td.res_base : td.res_base2) + lrow * p.res_row_stride) * p.ldr + c] + x;
         }
         C[(long long)(td.out_row0 + lrow) * p.ldc + c] = x;
@@ -830,7 +830,8 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
   static std::once_flag attr_once; int attr_rc = K3_OK;      // per-thread streams may call this concurrently (SURVEY 8b "Threading")
   std::call_once(attr_once, [&]() { attr_rc = [&]() -> int {
 #define K3_GEMM_VARIANTS(X) X(128, 64, 64, true, kEpiAny) X(128, 64, 64, false, kEpiAny) X(128, 64, 64, true, kEpiReluScaleRes) X(128, 64, 64, false, kEpiReluScale) \
-                            X(128, 64, 64, true, kEpiReluScale) X(96, 32, 96, true, kEpiAny) X(96, 32, 96, false, kEpiAny) X(96, 32, 96, true, kEpiNone)
+                            X(128, 64, 64, true, kEpiReluScale) X(96, 32, 96, true, kEpiAny) X(96, 32, 96, false, kEpiAny) X(96, 32, 96, true, kEpiNone) \
+                            X(128, 64, 64, true, kEpiAnyMap) X(128, 64, 64, false, kEpiAnyMap) X(96, 32, 96, true, kEpiAnyMap) X(96, 32, 96, false, kEpiAnyMap)
 #define K3_SET_ATTR(bn, wm, wn, al, ep) K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<bn, wm, wn, al, ep>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     K3_GEMM_VARIANTS(K3_SET_ATTR)
 #undef K3_SET_ATTR
@@ -864,7 +865,8 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
     } else {
       const int blocks = p.num_m_tiles * p.num_n_tiles;
       // the epilogue program, matched against the fixed ones
-      int epi = kEpiAny;
+      bool has_map = false; for (int o = 0; o < p.nops; o++) has_map = has_map || p.op_kind[o] == k3::kEpiSigmoid || p.op_kind[o] == k3::kEpiTanh;
+      int epi = has_map ? kEpiAnyMap : kEpiAny;
       if (p.nops == 0) epi = kEpiNone;
       else if (p.nops == 3 && p.op_kind[0] == k3::kEpiRelu && p.op_kind[1] == k3::kEpiScaleOffset && p.op_kind[2] == k3::kEpiResidual) epi = kEpiReluScaleRes;
       else if (p.nops == 2 && p.op_kind[0] == k3::kEpiRelu && p.op_kind[1] == k3::kEpiScaleOffset) epi = kEpiReluScale;
@@ -878,7 +880,7 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
       bool launched = false;
 #define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3((kBM / wm) * (bn / wn) * 64), lds + lds_pad, st, p); launched = true; }
       K3_GEMM_VARIANTS(K3_LAUNCH)
-      if (!launched) { epi = kEpiAny; K3_GEMM_VARIANTS(K3_LAUNCH) }      // no fixed-program instantiation for this shape: run-time dispatch
+      if (!launched) { epi = has_map ? kEpiAnyMap : kEpiAny; K3_GEMM_VARIANTS(K3_LAUNCH) }      // no fixed-program instantiation for this shape: run-time dispatch
 #undef K3_LAUNCH
     }
     if (f.row_op) {      // LogSoftmaxComponent / SoftmaxComponent on the node's rows, in place; on the output node followed by (x - log prior) * acoustic scale
