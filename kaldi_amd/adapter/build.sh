@@ -10,6 +10,12 @@ set -euo pipefail
 REF=${KALDI_REFERENCE:-/root/reference}; R=$REF/src
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd); B=$HERE/_build
 if [ ! -d "$R" ]; then echo "adapter/build.sh: $R absent (GPU box?) - using prebuilt files in $B"; exit 0; fi
+# nothing to do when every program is newer than everything it is made from (the sources of this adapter and of its callers, the headers of include/ and of the host layer, the
+# host layer's objects; the reference's sources are read-only): a no-op build is what the test suite calls a dozen times
+STAMP=$B/.built
+if [ -f $STAMP ] && [ -z "$(find $HERE/build.sh $HERE/*.cc $ROOT/tests/adapter/*.cc $ROOT/include/*.h $ROOT/kaldi_amd/host/*.h $ROOT/kaldi_amd/bin/k3_host.o $ROOT/kaldi_amd/bin/k3_lattice.o $ROOT/kaldi_amd/bin/k3_mbr.o \
+      $ROOT/oracle/ref_tools/minifst -newer $STAMP 2>/dev/null | head -1)" ]; then exit 0; fi
+rm -f $STAMP
 mkdir -p $B/obj $B/inc/base $B/stub/fst $B/mkl
 printf '#define KALDI_VERSION "5.5-k3"\n#define KALDI_GIT_HEAD "k3"\n' > $B/inc/base/version.h
 cat > $B/stub/fst/fst-decl.h <<'EOS'
@@ -92,3 +98,4 @@ echo "built $B/cuda-pipeline-example $B/cuda-online-pipeline-example"
 FLAGS="$FLAGS -I $ROOT/include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__"
 link_with_trampolines cuda-features-example $ROOT/tests/adapter/cuda_features_example.cc
 echo "built $B/cuda-features-example"
+touch $STAMP
