@@ -119,3 +119,37 @@ def test_oracle_with_ivector_input_vs_reference_nnet3_compute():
     # the chunking matters: the whole-utterance evaluation with one of the rows is NOT what the reference computes
     other = no.compute(net, g["feats"], 1, ivector=g["iv_s1_c50_p10"][0])
     assert np.abs(other - g["ref_s1_c50_p10"]).max() > 1e-2
+
+
+def test_random_relu_sigmoid_tanh_renorm_stacks_against_the_reference_nnet3_compute(tmp_path):
+    """fuzz (live only): random stacks of spliced affines with ReLU / sigmoid / tanh, NormalizeComponents (random target-rms, with and without the log-stddev column and a block
+    dimension) and a (log-)softmax or plain output, created by the reference's nnet3-init: the numpy oracle against the reference's nnet3-compute on the same file"""
+    import subprocess
+    from oracle import kaldi_io as kio, nnet3_oracle as no
+    binr = os.path.join(ROOT, "oracle", "_ref", "bin")
+    if not os.path.exists(os.path.join(binr, "nnet3-init")): pytest.skip("oracle/_ref not built (needs /root/reference)")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL")
+    rng = np.random.default_rng(31); td = str(tmp_path); worst = 0.0
+    for it in range(8):
+        dim = 12; prev = "input"; lines = [f"input-node name=input dim={dim}"]
+        for l in range(int(rng.integers(1, 4))):
+            offs = sorted(set(int(x) for x in rng.choice([-2, -1, 0, 1, 3], int(rng.integers(1, 4))))); out = int(rng.choice([8, 16, 24]))
+            app = ", ".join(prev if o == 0 else f"Offset({prev}, {o})" for o in offs)
+            lines += [f"component name=a{l} type=NaturalGradientAffineComponent input-dim={dim * len(offs)} output-dim={out}", f"component-node name=a{l} component=a{l} input=Append({app})"]
+            kind = str(rng.choice(["RectifiedLinearComponent", "SigmoidComponent", "TanhComponent"]))
+            lines += [f"component name=n{l} type={kind} dim={out}", f"component-node name=n{l} component=n{l} input=a{l}"]; prev, dim = f"n{l}", out
+            if rng.integers(0, 2):
+                als = bool(rng.integers(0, 2)); blk = int(rng.choice([out, out // 2])); rms = float(rng.choice([1.0, 0.5, 2.0]))
+                lines += [f"component name=r{l} type=NormalizeComponent dim={out} block-dim={blk} target-rms={rms} add-log-stddev={'true' if als else 'false'}", f"component-node name=r{l} component=r{l} input=n{l}"]
+                prev = f"r{l}"; dim = out + (out // blk if als else 0)
+        tail = str(rng.choice(["LogSoftmaxComponent", "SoftmaxComponent", ""]))
+        if tail: lines += [f"component name=o type={tail} dim={dim}", f"component-node name=o component=o input={prev}"]; prev = "o"
+        lines.append(f"output-node name=output input={prev}")
+        open(f"{td}/n.config", "w").write("\n".join(lines) + "\n")
+        r = subprocess.run([os.path.join(binr, "nnet3-init"), f"--srand={it}", f"{td}/n.config", f"{td}/n.raw"], capture_output=True, text=True, env=env); assert r.returncode == 0, r.stderr[-1500:]
+        feats = (rng.standard_normal((int(rng.integers(1, 40)), 12)) * float(rng.choice([0.5, 3.0, 20.0]))).astype(np.float32); kio.write_ark(f"{td}/f.ark", {"u": feats}); s_ = int(rng.choice([1, 3]))
+        r = subprocess.run([os.path.join(binr, "nnet3-compute"), "--use-gpu=no", f"--frame-subsampling-factor={s_}", f"{td}/n.raw", f"ark:{td}/f.ark", f"ark:{td}/o.ark"], capture_output=True, text=True, env=env); assert r.returncode == 0, r.stderr[-1500:]
+        ref = kio.read_ark(f"{td}/o.ark")["u"]; mine = no.compute(no.read_nnet(f"{td}/n.raw"), feats, s_)
+        assert mine.shape == ref.shape, (it, mine.shape, ref.shape)
+        worst = max(worst, float(np.abs(mine - ref).max())); assert np.abs(mine - ref).max() <= 2e-5, (it, np.abs(mine - ref).max(), lines)
+    print("worst |oracle - nnet3-compute| over the fuzz:", worst)
