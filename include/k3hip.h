@@ -165,6 +165,12 @@ int k3_ivector_stream_reset(k3_ivector_stream *s, void *stream);
 int64_t k3_ivector_stream_num_rows(const k3_ivector_stream *s);
 int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_feats, int64_t ld_feats, int32_t num_frames, int32_t finished, float *d_new_rows, int64_t ld_rows,
                              int32_t max_new_rows, int32_t *h_num_new_rows, float *d_latest, void *stream);
+/* The same for the streams of one batch, one kernel launch per stage (what BatchedIvectorExtractorCuda::GetIvectors is per chunk, cudafeat/feature-online-batched-ivector-cuda.h:30-61):
+ * stream i takes feature rows h_frame_offsets[i] .. h_frame_offsets[i + 1] of d_feats (offsets start at 0; a stream may get no rows), h_finished[i] != 0 ends it; d_latest (nullable)
+ * [num_streams x ld_latest] receives every stream's most recent estimate.  Results per stream are those of k3_ivector_stream_accept.  All streams belong to one extractor, each is
+ * listed once; one batched call at a time per extractor. */
+int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32_t num_streams, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, const int32_t *h_finished,
+                                   float *d_latest, int64_t ld_latest, void *stream);
 int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
                                    float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in,
                                    double *d_stats_out, void *stream);

@@ -14,6 +14,9 @@ inline int fail(int code, const char *what, const char *file, int line) {
 }
 // k3_cmvn_online_batch_resume without the wait for its error flag (k3_feat.hip): the streaming i-vector extractor queues it between its own kernels.  The flag can only be
 // raised by global statistics without frames, which k3_ivector_create refuses
+// one stream of a batched resume: rows [0, t_begin) of `in` are history, rows [t_begin, rows) are normalised into out[t] (both `dim` wide, dense), carry [dim][3]
+struct CmvnSeg { const float *in; float *out; long long rows, t_begin; double *carry; };
+int cmvn_online_resume_segs_async(const CmvnSeg *d_segs, int num_segs, int dim, const void *opts, const double *d_global_stats, void *stream);
 int cmvn_online_resume_async(const float *d_in, long long ld_in, float *d_out, long long ld_out, int dim, const long long *d_frame_offsets, int num_utts, const void *opts,
                              const double *d_global_stats, const long long *d_t_begin, double *d_carry, void *stream);
 }  // namespace k3

@@ -454,6 +454,7 @@ struct OnlineCmvnParams {
   const double *global_stats, *speaker_stats;      // [2 x (dim+1)], [U x 2 x (dim+1)] or null
   unsigned long long skip[4];                      // bit d set: FakeStatsForSomeDims for column d
   int *err;                                        // set to 1 where the reference raises (count < 1, global count <= 0)
+  const k3::CmvnSeg *segs;                         // (streaming, many streams in one launch) per utterance: its own buffers, length, first new row and carry; the fields above that they replace are unused
   const long long *t_begin; double *carry;         // resume (streaming): rows [0, t_begin[u]) of utterance u are history -- read for the window, not written; carry [U][dim][3] = the
                                                    // window's (sum, sum of squares, count) after the last row, read when t_begin[u] > 0 and written back.  Both null: whole utterances
 };
@@ -462,16 +463,16 @@ __global__ __launch_bounds__(64) void k3_cmvn_online_kernel(OnlineCmvnParams p) 
 #pragma clang fp contract(off)      // __fmul_rn & co are plain operators in this HIP: keep the compiler from fusing them into fma
   const int u = blockIdx.x, d = blockIdx.y * 64 + threadIdx.x;
   if (d >= p.dim) return;
-  const long long r0 = p.frame_off[u], T = p.frame_off[u + 1] - r0;
+  const long long r0 = p.segs ? 0 : p.frame_off[u], T = p.segs ? p.segs[u].rows : p.frame_off[u + 1] - r0;
   const int C = p.dim + 1, W = p.cmn_window;
-  const float *x = p.in + r0 * p.ld_in + d; float *y = p.out + r0 * p.ld_out + d;
+  const float *x = p.segs ? p.segs[u].in + d : p.in + r0 * p.ld_in + d; float *y = p.segs ? p.segs[u].out + d : p.out + r0 * p.ld_out + d;
   const double g_m = p.global_stats[d], g_v = p.global_stats[C + d], g_n = p.global_stats[p.dim];
   const double *sp = p.speaker_stats ? p.speaker_stats + (long long)u * 2 * C : nullptr;
   const double s_m = sp ? sp[d] : 0.0, s_v = sp ? sp[C + d] : 0.0, s_n = sp ? sp[p.dim] : 0.0;
   const bool skip = d < 256 && ((p.skip[d >> 6] >> (d & 63)) & 1ull);
   double sum = 0.0, sq = 0.0, n = 0.0;
-  const long long tb = p.t_begin ? p.t_begin[u] : 0;
-  double *cy = p.carry ? p.carry + ((long long)u * p.dim + d) * 3 : nullptr;
+  const long long tb = p.segs ? p.segs[u].t_begin : p.t_begin ? p.t_begin[u] : 0;
+  double *cy = p.segs ? p.segs[u].carry + (long long)d * 3 : p.carry ? p.carry + ((long long)u * p.dim + d) * 3 : nullptr;
   if (cy && tb > 0) { sum = cy[0]; sq = cy[1]; n = cy[2]; }
   constexpr int kAhead = 8;
   for (long long t0 = tb; t0 < T; t0 += kAhead) {
@@ -781,6 +782,20 @@ extern "C" int k3_cmvn_online_batch_resume(const float *d_in, int64_t ld_in, flo
   return K3_OK;
 }
 
+int k3::cmvn_online_resume_segs_async(const k3::CmvnSeg *d_segs, int num_segs, int dim, const void *opts_, const double *d_global_stats, void *stream) {
+  const k3_online_cmvn_opts *opts = static_cast<const k3_online_cmvn_opts *>(opts_);
+  K3_REQUIRE(d_segs && num_segs > 0 && opts && d_global_stats && dim > 0, "cmvn_online_resume_segs_async: bad argument");
+  OnlineCmvnParams p{};
+  p.segs = d_segs; p.ld_in = dim; p.ld_out = dim; p.dim = dim;
+  p.cmn_window = opts->cmn_window; p.speaker_frames = opts->speaker_frames; p.global_frames = opts->global_frames; p.norm_means = opts->normalize_mean; p.norm_vars = opts->normalize_variance;
+  p.global_stats = d_global_stats;
+  static int *d_err = nullptr;      // (never read here: see the header)
+  if (!d_err) { K3_HIP_CHECK(hipMalloc(&d_err, sizeof(int))); K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); }
+  p.err = d_err;
+  hipLaunchKernelGGL(k3_cmvn_online_kernel, dim3((unsigned)num_segs, (unsigned)((dim + 63) / 64)), dim3(64), 0, (hipStream_t)stream, p);
+  K3_HIP_CHECK(hipGetLastError());
+  return K3_OK;
+}
 int k3::cmvn_online_resume_async(const float *d_in, long long ld_in, float *d_out, long long ld_out, int dim, const long long *d_frame_offsets, int num_utts, const void *opts_,
                                  const double *d_global_stats, const long long *d_t_begin, double *d_carry, void *stream) {
   const k3_online_cmvn_opts *opts = static_cast<const k3_online_cmvn_opts *>(opts_);

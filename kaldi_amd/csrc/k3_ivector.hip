@@ -71,6 +71,21 @@ __global__ void ivec_u(const double *__restrict__ M, const double *__restrict__ 
   U[((size_t)g * R + r) * R + s] = a; U[((size_t)g * R + s) * R + r] = a;
 }
 
+// One stream of a batched streaming call (k3_ivector_stream_accept_batch): where each stage of this call reads and writes for that stream.  A device array of these is what the
+// batched kernels index by stream instead of the packed utterance layout of the whole-utterance path.
+struct BatchSeg {
+  const float *raw_old, *cm_old; float *raw, *cm;                        // the stream's raw / normalised frame buffers before and after this call
+  long long raw_from, keep, n_new, feat_off, cm_from, cm_keep;           // raw_old[raw_from .. + keep) -> raw[0 ..), the call's feature rows feat_off .. + n_new -> raw[keep ..); cm_old[cm_from .. + cm_keep) -> cm[0 ..)
+  long long nP, out_off, row0_cm, row0_raw, cm_rows, raw_rows;           // posterior stage: nP frames, rows out_off .. of the packed work arrays; first frame's row in cm / raw
+  float *px; int32_t *pg; float *pw; int32_t *pn;                        // where the new posterior-stage rows go (behind the rows still waiting for their period)
+  const float *e_px; const int32_t *e_pg; const float *e_pw; const int32_t *e_pn;      // the waiting rows from stream frame t_base on
+  double *est, *x_io, *chol, *quad; long long t_base, t_limit; int k_begin, nk; float *rows, *latest;
+  float *px_alt; int32_t *pg_alt; float *pw_alt; int32_t *pn_alt; long long shift_from, left;      // after the estimates: rows shift_from .. + left of the waiting arrays move to the other buffers
+};
+__device__ __forceinline__ int seg_of_row(const BatchSeg *segs, int n, long long row) {      // last stream whose out_off <= row (streams without rows share their successor's offset)
+  int lo = 0, hi = n; while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (segs[m].out_off <= row) lo = m; else hi = m; } return lo;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- splice + LDA
 // out[t][d] = offset[d] + sum_{o=-lc..rc} sum_f lda[d][(o+lc) F + f] in[clamp(t+o)][f]; one thread per (frame, output dim); rows of one utterance only
 __global__ void ivec_splice_lda_kernel(const float *__restrict__ in, int64_t ld_in, const int64_t *__restrict__ frame_off, int num_utts, const float *__restrict__ lda,
@@ -89,12 +104,31 @@ __global__ void ivec_splice_lda_kernel(const float *__restrict__ in, int64_t ld_
   out[i] = has_offset ? w[lda_cols - 1] + a : a;
 }
 
+// the same for the streams of a batched call: frame `local` of stream u is row row0 + local of its own buffer (clamped to that buffer: the first row is the stream's first frame
+// or has its left context in the buffer, the last row is only reached when the stream has ended); which = 0: normalised frames -> packed xpost, 1: the statistics' features -> px
+__global__ void ivec_splice_lda_multi_kernel(const BatchSeg *__restrict__ segs, int nseg, int which, int stats_from_cm, const float *__restrict__ lda, int lda_cols, int has_offset, int F, int D,
+                                             int lc, int rc, float *__restrict__ xpost, int64_t total_frames) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= total_frames * D) return;
+  const int64_t row = i / D; const int d = (int)(i % D);
+  const BatchSeg &g = segs[seg_of_row(segs, nseg, row)];
+  const int64_t local = row - g.out_off; const bool from_cm = which == 0 || stats_from_cm;
+  const float *in = from_cm ? g.cm : g.raw; const int64_t e = from_cm ? g.cm_rows : g.raw_rows, r0 = from_cm ? g.row0_cm : g.row0_raw;
+  const float *w = lda + (size_t)d * lda_cols; float a = 0.f;
+  for (int o = -lc; o <= rc; o++) {
+    int64_t t = r0 + local + o; t = t < 0 ? 0 : (t >= e ? e - 1 : t);
+    const float *x = in + t * F, *wo = w + (size_t)(o + lc) * F;
+    for (int f = 0; f < F; f++) a = fmaf(wo[f], x[f], a);
+  }
+  const float v = has_offset ? w[lda_cols - 1] + a : a;
+  if (which == 0) xpost[i] = v; else g.px[local * D + d] = v;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- posteriors
 // One wave per frame.  The log-likelihoods of the G Gaussians go to LDS; the num_gselect best that pass the min-post cut are taken one at a time
 // (a wave arg-max each), then pruned and renormalised by lane 0 exactly as VectorToPosteriorEntry does (float arithmetic, same order).
 __global__ void __launch_bounds__(kBlock) ivec_posterior_kernel(const float *__restrict__ x, int D, int G, const float *__restrict__ gconsts, const float *__restrict__ miv_t,
                                                                 const float *__restrict__ iv_t, int num_gselect, float min_post, float post_scale, int64_t total_frames,
-                                                                int32_t *__restrict__ post_g, float *__restrict__ post_w, int32_t *__restrict__ post_n) {
+                                                                int32_t *__restrict__ post_g, float *__restrict__ post_w, int32_t *__restrict__ post_n, const BatchSeg *__restrict__ segs = nullptr, int nseg = 0) {
   extern __shared__ float s_ll[];                             // [waves per block][G] log-likes, then [waves][2 * num_gselect] selections
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, nw = blockDim.x / kWave;
   const int64_t t = (int64_t)blockIdx.x * nw + wave;
@@ -127,8 +161,10 @@ __global__ void __launch_bounds__(kBlock) ivec_posterior_kernel(const float *__r
     const float cutoff = min_post * tot;
     while (n > 1 && sel_p[n - 1] < cutoff) { tot -= sel_p[n - 1]; n--; }
     const float inv = 1.0f / tot;
-    for (int k = 0; k < n; k++) { post_g[t * num_gselect + k] = sel_g[k]; post_w[t * num_gselect + k] = (sel_p[k] * inv) * post_scale; }
-    post_n[t] = n;
+    int64_t tt = t;
+    if (segs) { const BatchSeg &g = segs[seg_of_row(segs, nseg, t)]; tt = t - g.out_off; post_g = g.pg; post_w = g.pw; post_n = g.pn; }      // batched streaming: the stream's own arrays
+    for (int k = 0; k < n; k++) { post_g[tt * num_gselect + k] = sel_g[k]; post_w[tt * num_gselect + k] = (sel_p[k] * inv) * post_scale; }
+    post_n[tt] = n;
   }
 }
 
@@ -177,19 +213,27 @@ struct EstParams {
   // streaming (k3_ivector_stream): the posterior-stage arrays start at frame t_base of the stream; estimates k_begin, k_begin + 1, ... while k * period < t_limit; x_io [R] = the
   // conjugate-gradient start (the previous estimate) in, the last estimate out.  t_limit < 0: a whole utterance (all of the above off)
   int64_t t_base, t_limit; int k_begin; double *x_io;
+  const BatchSeg *segs;      // batched streaming: block u works on segs[u] (its arrays, state, scratch, range and output replace the fields above); null otherwise
 };
 
-__global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
+__global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p_in) {
   extern __shared__ double s_dyn[];
-  const int R = p.R, D = p.D, S = p.S, P = p.period, tid = threadIdx.x, u = blockIdx.x;
+  EstParams p = p_in; const int u = blockIdx.x; const BatchSeg *seg = p.segs ? p.segs + u : nullptr;
+  if (seg) {
+    if (seg->nk == 0) return;      // (the whole block: no barrier passed yet)
+    p.xstats = seg->e_px; p.post_g = seg->e_pg; p.post_w = seg->e_pw; p.post_n = seg->e_pn; p.state_in = seg->est; p.state_out = seg->est; p.x_io = seg->x_io;
+    p.t_base = seg->t_base; p.t_limit = seg->t_limit; p.k_begin = seg->k_begin; p.out = seg->rows; p.ld_out = p.R;
+  }
+  const int R = p.R, D = p.D, S = p.S, P = p.period, tid = threadIdx.x;
   double *s_x = s_dyn, *s_r = s_x + R, *s_p = s_r + R, *s_ap = s_p + R, *s_lin = s_ap + R, *s_xo = s_lin + R, *s_red = s_xo + R;    // 6R + 4 doubles
   const int max_ent = P * S;
   int *e_g = (int *)(s_red + kBlock / kWave); int *e_t = e_g + max_ent; float *e_w = (float *)(e_t + max_ent); float *e_gw = e_w + max_ent;   // gw > 0 marks a leader
-  double *A = p.quad_g ? p.quad_g + (size_t)u * R * R : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7);
-  double *C = p.chol_g + (size_t)u * R * R;
+  double *A = seg ? (seg->quad ? seg->quad : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7)) : p.quad_g ? p.quad_g + (size_t)u * R * R : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7);
+  double *C = seg ? seg->chol : p.chol_g + (size_t)u * R * R;
   __shared__ int s_n; __shared__ double s_tot;
-  const int64_t fb = p.frame_off[u] - (p.t_limit >= 0 ? p.t_base : 0); const int T = p.t_limit >= 0 ? (int)p.t_limit : (int)(p.frame_off[u + 1] - p.frame_off[u]);
-  const double *st_in = p.state_in ? p.state_in + (size_t)u * (1 + R + (size_t)R * R) : nullptr;      // the speaker's statistics so far (SetAdaptationState)
+  const int64_t fb = seg ? -p.t_base : p.frame_off[u] - (p.t_limit >= 0 ? p.t_base : 0); const int T = p.t_limit >= 0 ? (int)p.t_limit : (int)(p.frame_off[u + 1] - p.frame_off[u]);
+  const int64_t out_base = seg ? 0 : p.out_off[u]; const size_t st_stride = seg ? 0 : (1 + R + (size_t)R * R);
+  const double *st_in = p.state_in ? p.state_in + (size_t)u * st_stride : nullptr;      // the speaker's statistics so far (SetAdaptationState)
   for (int i = tid; i < R * R; i += kBlock) A[i] = st_in ? st_in[1 + R + i] : ((i / R == i % R) ? 1.0 : 0.0);      // fresh: quadratic term of the prior I, linear term prior_offset e_0
   if (tid < R) { s_lin[tid] = st_in ? st_in[1 + tid] : (tid == 0 ? p.prior : 0.0); s_x[tid] = p.x_io ? p.x_io[tid] : (tid == 0 ? p.prior : 0.0); }
   double nframes = st_in ? st_in[0] : 0.0;
@@ -275,14 +319,18 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p) {
       }
     } else if (tid < R) s_x[tid] = tid == 0 ? p.prior : 0.0;
     __syncthreads();
-    if (tid < R) p.out[(p.out_off[u] + k - k0) * p.ld_out + tid] = tid == 0 ? (float)s_x[0] - (float)p.prior : (float)s_x[tid];
+    if (tid < R) {
+      const float v = tid == 0 ? (float)s_x[0] - (float)p.prior : (float)s_x[tid];
+      p.out[(out_base + k - k0) * p.ld_out + tid] = v;
+      if (seg) seg->latest[tid] = v;      // (the last estimate of the call stays)
+    }
   }
   if (p.x_io) { __syncthreads(); if (tid < R) p.x_io[tid] = s_x[tid]; }
   if (p.state_out) {                                                                  // GetAdaptationState: the statistics as they stand after the last estimate
     // (accumulate_tail: the reference's --repeat=true asks for the i-vector of the LAST frame, so its statistics hold every frame of the utterance when the state is taken:
     // ivector-extract-online2.cc:121-127 GetFrame(T - 1) -> UpdateStatsUntilFrame(T - 1))
     if (p.acc_tail && k_last >= 0 && k_last * P + 1 <= T - 1) accumulate(k_last * P + 1, T - 1);
-    double *so = p.state_out + (size_t)u * (1 + R + (size_t)R * R);
+    double *so = p.state_out + (size_t)u * st_stride;
     __syncthreads();
     if (tid == 0) so[0] = nframes;
     if (tid < R) so[1 + tid] = s_lin[tid];
@@ -389,7 +437,7 @@ extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_fea
                      iv->o.posterior_scale, N, (int32_t *)iv->post_g.p, (float *)iv->post_w.p, (int32_t *)iv->post_n.p);
   EstParams p; p.xstats = (const float *)iv->xstats.p; p.frame_off = d_off; p.post_g = (const int32_t *)iv->post_g.p; p.post_w = (const float *)iv->post_w.p; p.post_n = (const int32_t *)iv->post_n.p;
   p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)iv->quad.p; p.chol_g = (double *)iv->state.p; p.out = d_ivectors; p.ld_out = ld_ivectors; p.out_off = d_row_off;
-  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out; p.acc_tail = iv->acc_tail; p.t_base = 0; p.t_limit = -1; p.k_begin = 0; p.x_io = nullptr;
+  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out; p.acc_tail = iv->acc_tail; p.t_base = 0; p.t_limit = -1; p.k_begin = 0; p.x_io = nullptr; p.segs = nullptr;
   size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
   K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_extract_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
@@ -516,7 +564,7 @@ extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_fea
     EstParams p; p.xstats = (const float *)s->px[s->pend_i].p; p.frame_off = d_offs + 6; p.post_g = (const int32_t *)s->pg[s->pend_i].p; p.post_w = (const float *)s->pw[s->pend_i].p; p.post_n = (const int32_t *)s->pn[s->pend_i].p;
     p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)s->quad.p; p.chol_g = (double *)s->chol.p; p.out = (float *)s->rows.p; p.ld_out = R; p.out_off = d_offs + 5;
     p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count;
-    p.state_in = est; p.state_out = est; p.acc_tail = 0; p.t_base = s->a0; p.t_limit = s->n_post; p.k_begin = (int)s->k_next; p.x_io = x_io;
+    p.state_in = est; p.state_out = est; p.acc_tail = 0; p.t_base = s->a0; p.t_limit = s->n_post; p.k_begin = (int)s->k_next; p.x_io = x_io; p.segs = nullptr;
     const size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
     K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_stream_accept: ivector_period * num_gselect too large for the estimation kernel's LDS");
     K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
@@ -533,5 +581,120 @@ extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_fea
     s->pend_i = i0; s->a0 = new_a0;
   }
   if (d_latest) K3_HIP_CHECK(hipMemcpyAsync(d_latest, s->latest.p, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
+  return K3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- streaming, many streams per call
+namespace {
+__global__ void __launch_bounds__(kBlock) ivec_batch_carry_kernel(const BatchSeg *__restrict__ segs, const float *__restrict__ feats, long long ld_feats, int F) {
+  const BatchSeg &g = segs[blockIdx.x];
+  for (long long i = threadIdx.x; i < g.keep * F; i += kBlock) g.raw[i] = g.raw_old[g.raw_from * F + i];
+  for (long long i = threadIdx.x; i < g.n_new * F; i += kBlock) g.raw[g.keep * F + i] = feats[(g.feat_off + i / F) * ld_feats + i % F];
+  for (long long i = threadIdx.x; i < g.cm_keep * F; i += kBlock) g.cm[i] = g.cm_old[g.cm_from * F + i];
+}
+__global__ void __launch_bounds__(kBlock) ivec_batch_shift_kernel(const BatchSeg *__restrict__ segs, int D, int S) {
+  const BatchSeg &g = segs[blockIdx.x]; if (g.nk == 0) return;
+  for (long long i = threadIdx.x; i < g.left * D; i += kBlock) g.px_alt[i] = g.e_px[g.shift_from * D + i];
+  for (long long i = threadIdx.x; i < g.left * S; i += kBlock) { g.pg_alt[i] = g.e_pg[g.shift_from * S + i]; g.pw_alt[i] = g.e_pw[g.shift_from * S + i]; }
+  for (long long i = threadIdx.x; i < g.left; i += kBlock) g.pn_alt[i] = g.e_pn[g.shift_from + i];
+}
+__global__ void ivec_batch_latest_kernel(const BatchSeg *__restrict__ segs, int R, float *__restrict__ out, long long ld_out) { if ((int)threadIdx.x < R) out[blockIdx.x * ld_out + threadIdx.x] = segs[blockIdx.x].latest[threadIdx.x]; }
+}  // namespace
+
+// k3_ivector_stream_accept for the streams of one batch in one launch per stage (BatchedIvectorExtractorCuda::GetIvectors per chunk, cudafeat/feature-online-batched-ivector-cuda.h:30-61):
+// stream i takes feature rows h_frame_offsets[i] .. [i + 1] of d_feats; d_latest [num_streams x ld_latest] receives every stream's most recent estimate.  The per-stream results are
+// those of k3_ivector_stream_accept (the same kernels' arithmetic; tests/test_ivector_gpu.py).  All streams must belong to one extractor; one batched call at a time per extractor.
+extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32_t num_streams, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, const int32_t *h_finished,
+                                              float *d_latest, int64_t ld_latest, void *stream_) {
+  K3_REQUIRE(streams && num_streams > 0 && h_frame_offsets && h_finished && h_frame_offsets[0] == 0, "k3_ivector_stream_accept_batch: bad argument");
+  k3_ivector *iv = streams[0]->iv; hipStream_t stream = (hipStream_t)stream_;
+  const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period, lc = iv->o.left_context, rc_ = iv->o.right_context, W = iv->o.cmvn.cmn_window;
+  const int64_t keepN = std::max<int64_t>(W, (int64_t)lc + rc_ + 1);
+  K3_REQUIRE(h_frame_offsets[num_streams] == 0 || (d_feats && ld_feats >= F), "k3_ivector_stream_accept_batch: features missing");
+  K3_REQUIRE(!d_latest || ld_latest >= R, "k3_ivector_stream_accept_batch: leading dimension of the output smaller than the i-vector dimension");
+  for (int i = 0; i < num_streams; i++) {
+    K3_REQUIRE(streams[i] && streams[i]->iv == iv && h_frame_offsets[i + 1] >= h_frame_offsets[i], "k3_ivector_stream_accept_batch: streams of different extractors, or descending offsets");
+    K3_REQUIRE(!streams[i]->finished, "k3_ivector_stream_accept_batch: a stream has ended (k3_ivector_stream_reset starts the next one)");
+    for (int j = 0; j < i; j++) K3_REQUIRE(streams[j] != streams[i], "k3_ivector_stream_accept_batch: a stream listed twice");
+  }
+  std::vector<BatchSeg> segs((size_t)num_streams); std::vector<k3::CmvnSeg> cs((size_t)num_streams);
+  int rc; int64_t total_nP = 0; bool any_new = false, any_est = false;
+  for (int i = 0; i < num_streams; i++) {
+    k3_ivector_stream *s = streams[i]; BatchSeg &g = segs[i]; g = BatchSeg{};
+    const int64_t n_new = h_frame_offsets[i + 1] - h_frame_offsets[i]; const bool fin = h_finished[i] != 0;
+    // raw and normalised frames: the other buffer of each pair becomes [what is still read | this call's rows] (ivec_batch_carry_kernel)
+    const int64_t new_s0 = std::max<int64_t>(0, s->n_abs - keepN), keep = s->n_abs - new_s0, raw_rows = keep + n_new;
+    const int64_t new_c0 = std::max<int64_t>(0, s->n_post - lc), cm_keep = s->n_abs - new_c0, cm_rows = cm_keep + n_new;
+    g.raw_old = (const float *)s->raw[s->raw_i].p; g.cm_old = (const float *)s->cm[s->cm_i].p; g.raw_from = new_s0 - s->raw_s0; g.cm_from = new_c0 - s->cm_c0;
+    if ((rc = carry_over(s->raw, &s->raw_i, (size_t)F * 4, 0, 0, raw_rows, stream)) || (rc = carry_over(s->cm, &s->cm_i, (size_t)F * 4, 0, 0, cm_rows, stream))) return rc;      // (capacity + switch; the kernel copies)
+    g.raw = (float *)s->raw[s->raw_i].p; g.cm = (float *)s->cm[s->cm_i].p; g.keep = keep; g.n_new = n_new; g.feat_off = h_frame_offsets[i]; g.cm_keep = cm_keep; g.raw_rows = raw_rows; g.cm_rows = cm_rows;
+    s->raw_s0 = new_s0; s->cm_c0 = new_c0;
+    double *carry = (double *)s->state.p, *est = carry + 3 * F; g.est = est; g.x_io = est + 1 + R + (size_t)R * R; g.chol = (double *)s->chol.p; g.quad = iv->quad_in_lds ? nullptr : (double *)s->quad.p;
+    cs[i].in = g.raw; cs[i].out = g.cm + (cm_keep - keep) * F; cs[i].rows = raw_rows; cs[i].t_begin = keep; cs[i].carry = carry;
+    any_new = any_new || n_new > 0;
+    s->n_abs += n_new; s->finished = fin;
+    // posterior stage
+    const int64_t P0 = s->n_post, P1 = fin ? s->n_abs : std::max<int64_t>(P0, s->n_abs - rc_), nP = P1 - P0, pend_rows = P0 - s->a0;
+    g.nP = nP; g.out_off = total_nP; g.row0_cm = P0 - s->cm_c0; g.row0_raw = P0 - s->raw_s0; total_nP += nP;
+    if (nP > 0 && ((size_t)(pend_rows + nP) * D * 4 > s->px[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pg[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pw[s->pend_i].cap ||
+                   (size_t)(pend_rows + nP) * 4 > s->pn[s->pend_i].cap)) {
+      int i0 = s->pend_i, i1 = s->pend_i, i2 = s->pend_i, i3 = s->pend_i;
+      if ((rc = carry_over(s->px, &i0, (size_t)D * 4, 0, pend_rows, pend_rows + nP, stream)) || (rc = carry_over(s->pg, &i1, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) ||
+          (rc = carry_over(s->pw, &i2, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) || (rc = carry_over(s->pn, &i3, 4, 0, pend_rows, pend_rows + nP, stream))) return rc;
+      s->pend_i = i0;
+    }
+    g.e_px = (const float *)s->px[s->pend_i].p; g.e_pg = (const int32_t *)s->pg[s->pend_i].p; g.e_pw = (const float *)s->pw[s->pend_i].p; g.e_pn = (const int32_t *)s->pn[s->pend_i].p;
+    g.px = (float *)s->px[s->pend_i].p + pend_rows * D; g.pg = (int32_t *)s->pg[s->pend_i].p + pend_rows * S; g.pw = (float *)s->pw[s->pend_i].p + pend_rows * S; g.pn = (int32_t *)s->pn[s->pend_i].p + pend_rows;
+    s->n_post = P1;
+    // estimates
+    const int64_t k_end = (s->n_post + P - 1) / P, nk = k_end - s->k_next;
+    g.t_base = s->a0; g.t_limit = s->n_post; g.k_begin = (int)s->k_next; g.nk = (int)nk; g.latest = (float *)s->latest.p;
+    if (nk > 0) {
+      any_est = true;
+      if ((rc = s->rows.reserve((size_t)nk * R * 4))) return rc;
+      g.rows = (float *)s->rows.p; s->k_next = k_end;
+      const int64_t new_a0 = (s->k_next - 1) * P + 1, left = s->n_post - new_a0;
+      g.shift_from = new_a0 - s->a0; g.left = left;
+      int i0 = s->pend_i, i1 = s->pend_i, i2 = s->pend_i, i3 = s->pend_i;      // (capacity + switch; ivec_batch_shift_kernel copies)
+      if ((rc = carry_over(s->px, &i0, (size_t)D * 4, 0, 0, left, stream)) || (rc = carry_over(s->pg, &i1, (size_t)S * 4, 0, 0, left, stream)) ||
+          (rc = carry_over(s->pw, &i2, (size_t)S * 4, 0, 0, left, stream)) || (rc = carry_over(s->pn, &i3, 4, 0, 0, left, stream))) return rc;
+      s->pend_i = i0; s->a0 = new_a0;
+      g.px_alt = (float *)s->px[s->pend_i].p; g.pg_alt = (int32_t *)s->pg[s->pend_i].p; g.pw_alt = (float *)s->pw[s->pend_i].p; g.pn_alt = (int32_t *)s->pn[s->pend_i].p;
+    }
+  }
+  // the tables go up in one copy
+  const size_t seg_bytes = segs.size() * sizeof(BatchSeg), cs_bytes = cs.size() * sizeof(k3::CmvnSeg);
+  if ((rc = iv->frame_off.reserve(seg_bytes + cs_bytes))) return rc;
+  if (total_nP > 0 && (rc = iv->xpost.reserve((size_t)total_nP * D * 4))) return rc;
+  K3_HIP_CHECK(hipMemcpyAsync(iv->frame_off.p, segs.data(), seg_bytes, hipMemcpyHostToDevice, stream));
+  K3_HIP_CHECK(hipMemcpyAsync((char *)iv->frame_off.p + seg_bytes, cs.data(), cs_bytes, hipMemcpyHostToDevice, stream));
+  K3_HIP_CHECK(hipStreamSynchronize(stream));                   // the tables are locals
+  const BatchSeg *d_segs = (const BatchSeg *)iv->frame_off.p; const k3::CmvnSeg *d_cs = (const k3::CmvnSeg *)((const char *)iv->frame_off.p + seg_bytes);
+  hipLaunchKernelGGL(ivec_batch_carry_kernel, dim3((unsigned)num_streams), dim3(kBlock), 0, stream, d_segs, d_feats, (long long)ld_feats, F);
+  if (any_new && (rc = k3::cmvn_online_resume_segs_async(d_cs, num_streams, F, &iv->o.cmvn, iv->global_stats, stream_))) return rc;
+  if (total_nP > 0) {
+    const unsigned nb = (unsigned)((total_nP * D + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(ivec_splice_lda_multi_kernel, dim3(nb), dim3(kBlock), 0, stream, d_segs, num_streams, 0, 0, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, (float *)iv->xpost.p, total_nP);
+    hipLaunchKernelGGL(ivec_splice_lda_multi_kernel, dim3(nb), dim3(kBlock), 0, stream, d_segs, num_streams, 1, iv->o.online_cmvn_iextractor ? 1 : 0, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_,
+                       (float *)iv->xpost.p, total_nP);
+    const int nw = kBlock / kWave; const size_t lds_post = ((size_t)nw * G + (size_t)nw * 2 * S) * 4;
+    K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_stream_accept_batch: too many Gaussians for the posterior kernel's LDS tile");
+    const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;
+    hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((total_nP + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)iv->xpost.p, D, G, iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
+                       iv->o.posterior_scale, total_nP, (int32_t *)nullptr, (float *)nullptr, (int32_t *)nullptr, d_segs, num_streams);
+  }
+  if (any_est) {
+    EstParams p{};
+    p.U = iv->U; p.SM = iv->SM; p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count;
+    p.acc_tail = 0; p.t_limit = 0; p.segs = d_segs;
+    const size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
+    K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_stream_accept_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
+    K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
+    hipLaunchKernelGGL(ivec_estimate_kernel, dim3((unsigned)num_streams), dim3(kBlock), lds_est, stream, p);
+    hipLaunchKernelGGL(ivec_batch_shift_kernel, dim3((unsigned)num_streams), dim3(kBlock), 0, stream, d_segs, D, S);
+  }
+  if (d_latest) hipLaunchKernelGGL(ivec_batch_latest_kernel, dim3((unsigned)num_streams), dim3(256), 0, stream, d_segs, R, d_latest, (long long)ld_latest);
+  K3_HIP_CHECK(hipGetLastError());
+  K3_HIP_CHECK(hipStreamSynchronize(stream));                   // the tables in iv->frame_off are reused by the next call
   return K3_OK;
 }

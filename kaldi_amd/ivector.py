@@ -129,3 +129,15 @@ class IvectorStream:
         return rows[:got.value]
 
     def Latest(self): return self.latest
+
+
+def AcceptFramesBatch(streams, feats, frame_offsets, finished):
+    """k3_ivector_stream_accept_batch: stream i takes rows frame_offsets[i] .. [i + 1] of feats (GPU, float32); -> [len(streams), ivector_dim], every stream's latest estimate.  One launch
+    per stage for the whole batch; per stream the same results as IvectorStream.AcceptFrames."""
+    ex = streams[0].ex; n = len(streams); fo = np.ascontiguousarray(np.asarray(frame_offsets, dtype=np.int64)); fin = np.ascontiguousarray(np.asarray(finished, dtype=np.int32))
+    assert fo.size == n + 1 and fin.size == n and feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and (feats.shape[0] == 0 or feats.stride(1) == 1)
+    hs = (ctypes.c_void_p * n)(*[s._h.value for s in streams]); out = torch.empty((n, ex.ivector_dim), dtype=torch.float32, device=feats.device)
+    _l.check(ex._L.k3_ivector_stream_accept_batch(hs, n, feats.data_ptr() if feats.shape[0] else None, feats.stride(0) if feats.shape[0] else ex.feat_dim, fo.ctypes.data, fin.ctypes.data, out.data_ptr(), out.stride(0),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for i, s in enumerate(streams): s.latest = out[i]
+    return out

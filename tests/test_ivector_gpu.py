@@ -126,6 +126,41 @@ def test_streaming_extraction_equals_the_whole_utterance_rows(case, variant):
             with pytest.raises(Exception, match="has ended"): stream.AcceptFrames(f[:1], False)
 
 
+@pytest.mark.parametrize("case", [0, 2, 3])
+def test_batched_streaming_equals_the_per_stream_calls(case):
+    """k3_ivector_stream_accept_batch: five streams of different lengths advancing together in chunks of random length (some empty, ends at different calls, one stream re-used for a
+    second utterance after a reset) -- one launch per stage for the batch -- against the same chunks through k3_ivector_stream_accept stream by stream: the latest estimate after every
+    call, the number of rows, and at the end the last row of the whole-utterance extraction"""
+    from kaldi_amd.ivector import BatchedIvectorExtractor, IvectorStream, AcceptFramesBatch
+    F, lc, rc, D, G, R, off, o, lens = CASES[case]; rng = np.random.default_rng(500 + case)
+    lda, st, ubm, ie = _random_model(rng, F, lc, rc, D, G, R, off)
+    opts = dict(num_gselect=5, min_post=0.025, posterior_scale=0.1, max_count=0.0, ivector_period=10, num_cg_iters=15); opts.update(o); opts.update(cmvn_cmn_window=23, cmvn_speaker_frames=23, cmvn_global_frames=11)
+    il = np.tril_indices(D); packed = np.stack([ie["sigma_inv"][g][il] for g in range(G)])
+    ex = BatchedIvectorExtractor.FromArrays(lda, st, ubm["gconsts"], ubm["means_invvars"], ubm["inv_vars"], ie["M"], packed, ie["prior_offset"], left_context=lc, right_context=rc, **opts)
+    dev = torch.device("cuda:0"); P = opts["ivector_period"]; N = 5
+    T = [int(x) for x in rng.integers(1, 120, N)]; T[1] = 1
+    feats = [torch.from_numpy((rng.standard_normal((t, F)) * 2.0 + rng.standard_normal(F)).astype(np.float32)).to(dev) for t in T]
+    batch = [IvectorStream(ex) for _ in range(N)]; single = [IvectorStream(ex) for _ in range(N)]; pos = [0] * N; done = [False] * N; second = False
+    for call in range(400):
+        live = [u for u in range(N) if not done[u]]
+        if not live:
+            if second: break
+            second = True; u = 0; batch[u].Reset(); single[u].Reset(); pos[u] = 0; done[u] = False; live = [u]      # the stream object of utterance 0 takes a second utterance (the same frames)
+        chunks, fins = [], []
+        for u in live:
+            m = min(int(rng.integers(0, 2 * P + 3)), T[u] - pos[u]); fin = pos[u] + m >= T[u] and bool(rng.integers(0, 2) or m == 0)
+            chunks.append(feats[u][pos[u]:pos[u] + m]); fins.append(fin); pos[u] += m
+        fo = np.concatenate([[0], np.cumsum([c.shape[0] for c in chunks])])
+        got = AcceptFramesBatch([batch[u] for u in live], torch.cat(chunks) if fo[-1] else feats[0][:0], fo, fins)
+        for i, u in enumerate(live):
+            single[u].AcceptFrames(chunks[i], fins[i])
+            assert torch.equal(got[i], single[u].Latest()) and batch[u].NumRows() == single[u].NumRows(), (call, u, pos[u], T[u])
+            if fins[i]:
+                done[u] = True; whole, _ = ex.GetIvectors(feats[u], [0, T[u]])
+                assert batch[u].NumRows() == whole.shape[0] and torch.equal(got[i], whole[-1]), (call, u)
+    assert second and all(done)
+
+
 def test_argument_errors():
     from kaldi_amd.ivector import BatchedIvectorExtractor
     from kaldi_amd.lib import K3Error
