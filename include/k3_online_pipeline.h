@@ -100,8 +100,8 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     { int64_t off = 0;
       for (size_t i = 0; i < n; i++) { Chan &c = chan_[chs[i]]; if ((size_t)(c.pend + nf[i]) > pend_cap_) K3H_ERR << "DecodeBatch: a chunk longer than GetNSampsPerChunk() samples";
         if (nf[i] > 0) K3O_HIP(hipMemcpy(pend_[chs[i]].p + (size_t)c.pend * fdim_, d_feats + off * fdim_, (size_t)nf[i] * fdim_ * 4, hipMemcpyDeviceToDevice));
-        if (ivs_) { if (first[i]) ivs_->Reset(chs[i]); ivs_->Accept(chs[i], d_feats + off * fdim_, nf[i], last[i]); }
         c.pend += nf[i]; c.frames += nf[i]; off += nf[i]; } }
+    if (ivs_) ivs_->AcceptBatch(chs, d_feats, nf, first, last);      // the extractor sees every frame as soon as it exists: all channels of the batch in one launch per stage
     std::vector<char> is_last(nch_, 0), closed(nch_, 0); for (size_t i = 0; i < n; i++) is_last[chs[i]] = last[i];
     bool need_advance = !fresh.empty();
     while (true) {      // network passes of frames_per_chunk frames per channel until every stream of the batch is drained to less than a chunk (or flushed, at its end)

@@ -152,9 +152,9 @@ int main(int argc, char **argv) {
             Chan &c = chan[chs[i]];
             if ((size_t)(c.pend + nf[i]) > pend_cap) K3H_ERR << "internal: pending-frame buffer";
             if (nf[i] > 0) K3O_HIP(hipMemcpy(pend[chs[i]].p + (size_t)c.pend * fdim, d_feats + off * fdim, (size_t)nf[i] * fdim * 4, hipMemcpyDeviceToDevice));
-            if (ivs) { if (first[i]) ivs->Reset(chs[i]); ivs->Accept(chs[i], d_feats + off * fdim, nf[i], last[i]); }      // the extractor sees every frame as soon as it exists
             c.pend += nf[i]; off += nf[i];
           } }
+        if (ivs) ivs->AcceptBatch(chs, d_feats, nf, first, last);      // the extractor sees every frame as soon as it exists: all channels of the batch in one launch per stage
         std::vector<char> is_last(nch, 0), closed(nch, 0); for (size_t i = 0; i < chs.size(); i++) is_last[chs[i]] = last[i];
         bool need_advance = !fresh.empty();
         while (true) {

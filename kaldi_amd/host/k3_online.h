@@ -148,6 +148,16 @@ class OnlineIvectors {
   void Accept(int ch, const float *d_rows, int n, bool finished) {
     K3H_CHECK_K3(k3_ivector_stream_accept(st_[ch], d_rows, F_, n, finished ? 1 : 0, nullptr, 0, 0, nullptr, latest_.p + (size_t)ch * R_, nullptr));      // queued on the null stream, like its consumers
   }
+  // the same for the channels of one batch, one launch per stage (k3_ivector_stream_accept_batch): channel channels[i] takes nf[i] rows of d_rows (back to back, F_ wide); first[i]: a
+  // new stream takes the channel
+  template <class B1, class B2> void AcceptBatch(const std::vector<int> &channels, const float *d_rows, const std::vector<int> &nf, const B1 &first, const B2 &last) {
+    const size_t n = channels.size(); if (n == 0) return;
+    std::vector<k3_ivector_stream *> st(n); std::vector<int64_t> off(n + 1, 0); std::vector<int32_t> fin(n);
+    for (size_t i = 0; i < n; i++) { if (first[i]) Reset(channels[i]); st[i] = st_[channels[i]]; off[i + 1] = off[i] + nf[i]; fin[i] = last[i] ? 1 : 0; }
+    float *tmp = batch_.need(n * R_);
+    K3H_CHECK_K3(k3_ivector_stream_accept_batch(st.data(), (int32_t)n, d_rows, F_, off.data(), fin.data(), tmp, R_, nullptr));
+    for (size_t i = 0; i < n; i++) K3O_HIP(hipMemcpyAsync(latest_.p + (size_t)channels[i] * R_, tmp + i * R_, (size_t)R_ * 4, hipMemcpyDeviceToDevice, nullptr));
+  }
   const float *Row(int ch) const { return latest_.p + (size_t)ch * R_; }
   // the rows of the listed channels back to back (what StaticNnet3::Pass takes)
   const float *Gather(const std::vector<int> &channels) {
@@ -157,6 +167,6 @@ class OnlineIvectors {
   }
   ~OnlineIvectors() { for (auto *s : st_) if (s) k3_ivector_stream_destroy(s); }
  private:
-  k3_ivector *iv_; int F_ = 0, R_ = 0; std::vector<k3_ivector_stream *> st_; DevBuf<float> latest_, gather_;
+  k3_ivector *iv_; int F_ = 0, R_ = 0; std::vector<k3_ivector_stream *> st_; DevBuf<float> latest_, gather_, batch_;
 };
 }  // namespace k3host

@@ -124,9 +124,10 @@ class BatchedOnlinePipeline:
         feats = self.features.ComputeFeaturesBatched(channels, wave_chunks, is_first_chunk, is_last_chunk)
         ivec = None
         if self.iv is not None:      # the extractor sees every feature frame as soon as it exists (OnlineIvectorFeature over the same base features)
-            ivec = {}
-            for ch, f, fin in zip(channels, feats, is_last_chunk):
-                self.ivs[ch].AcceptFrames(f, bool(fin)); ivec[ch] = self.ivs[ch].Latest().clone()
+            from .ivector import AcceptFramesBatch
+            fo = np.concatenate([[0], np.cumsum([int(f.shape[0]) for f in feats])]).astype(np.int64)
+            rows = AcceptFramesBatch([self.ivs[ch] for ch in channels], torch.cat(list(feats)) if fo[-1] else self._empty_feats, fo, [bool(x) for x in is_last_chunk])      # one launch per stage for the batch
+            ivec = {ch: rows[i].clone() for i, ch in enumerate(channels)}
         lls = {ch: [] for ch in channels}
         # feature frames go to the network at most frames_per_chunk at a time; what does not fill a chunk waits (unless the stream ends)
         todo = {ch: torch.cat([self.pending[ch], f]) for ch, f in zip(channels, feats)}
