@@ -32,12 +32,19 @@ namespace {
 
 // The kernel is instantiated for padded window sizes N = 32 R, R = 8 / 16 / 32 (256, 512, 1024 samples: 8 kHz, 16 kHz and 32..44.1 kHz speech at
 // 25 ms): the complex FFT of length NC = 16 R is a Cooley-Tukey R x 16 (a lane holds R points, 16 lanes hold a frame).
+//
+// Arithmetic (round 4): the data path from the samples to the logarithm is FLOAT64; the tables (window, mel weights, DCT, lifter, pre-emphasis
+// coefficient) are the reference's own float32 values, made on the host the way its code makes them.  Why: on the benchmark audio the reference's
+// float32 binary is up to 1.07e-4 away from the exact value of its own formulas (low mel bins: pre-emphasis leaves ~1e-3 of the mean power there and
+// every float32 butterfly adds noise relative to the frame's rms), and so was the float32 version of this kernel, with independent errors: the two
+// differed by up to 1.35e-4.  In float64 this kernel sits ~1e-6 (the output's own float32 rounding) from the exact value, so |kernel - reference| is
+// the reference's own rounding error and nothing else (tests/test_feat_gpu.py, bench.py e2e_parity: truth64 gates).  The stage is ~8 GFLOP per
+// 512 x 10 s batch: float64 costs nothing measurable against the 2.6 TFLOP network behind it.
 constexpr int kFramesPerIter = 16;    // 4 waves x 4 frames
 constexpr int kThreads = 256;
-constexpr int kTpad = 17;             // transpose tile row stride (float2 units)
-__host__ __device__ constexpr int frame_buf_bytes(int R) { return R * kTpad * 8; }                       // R = 16: 2176 B per frame: transpose tile / X / (P | logmel)
-__host__ __device__ constexpr int logmel_off(int R) { return ((16 * R + 1) * 4 + 15) / 16 * 16; }        // byte offset of the log-mel vector inside the frame buffer (R = 16: 1040)
-__host__ __device__ constexpr int lds_fixed_bytes(int R) { return 16 * R * 8 + ((8 * R + 1) * 8 + 15) / 16 * 16 + 32 * R * 4; }   // twiddles NC, twiddles N (N/4 + 1), window (R = 16: 5136)
+constexpr int kTpad = 17;             // transpose tile row stride (doubles)
+__host__ __device__ constexpr int frame_buf_bytes(int R) { return R * kTpad * 8; }                       // R = 16: 2176 B per frame: transpose tile (real parts, then imaginary parts) / P
+__host__ __device__ constexpr int lds_fixed_bytes(int R) { return 16 * R * 16 + ((8 * R + 1) * 16) + 32 * R * 4; }   // twiddles NC (double2), twiddles N (N/4 + 1, double2), window (float)
 
 struct FeatParams {
   int win_len, win_shift, snip_edges, remove_dc, use_energy, raw_energy, htk_compat, use_log, use_power,
@@ -45,42 +52,44 @@ struct FeatParams {
   float preemph, log_energy_floor;
   float dither; unsigned dither_seed;   // Dither (feat/feature-window.cc:90-98): x[i] += RandGauss() * dither, independently per frame
   const float *window;      // [win_len]
-  const float2 *tw256;      // [NC] exp(-2 pi i m / NC)
-  const float2 *tw512;      // [N/4 + 1] exp(-2 pi i k / N), k = 0..N/4, built by the reference's recurrence
+  const double2 *tw256;     // [NC] exp(-2 pi i m / NC)
+  const double2 *tw512;     // [N/4 + 1] exp(-2 pi i k / N), k = 0..N/4
   const int *bin_meta;      // [3 * num_bins]: first fft bin, length, offset into bin_w
   const float *bin_w;       // [total_w]
   const float *dct;         // [num_ceps x num_bins] (mfcc)
   const float *lifter;      // [num_ceps] (mfcc)
 };
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+typedef double2 cd;
+__device__ __forceinline__ cd mk(double x, double y) { cd r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ cd cadd(cd a, cd b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cd csub(cd a, cd b) { return mk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cd cmul(cd a, cd b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // forward 4-point DFT in place: (a,b,c,d) -> (X0,X1,X2,X3)
-__device__ __forceinline__ void fft4(float2 &a, float2 &b, float2 &c, float2 &d) {
-  float2 s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+__device__ __forceinline__ void fft4(cd &a, cd &b, cd &c, cd &d) {
+  cd s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
   a = cadd(s0, s2);
   c = csub(s0, s2);
-  b = make_float2(s1.x + s3.y, s1.y - s3.x);   // s1 - i s3
-  d = make_float2(s1.x - s3.y, s1.y + s3.x);   // s1 + i s3
+  b = mk(s1.x + s3.y, s1.y - s3.x);   // s1 - i s3
+  d = mk(s1.x - s3.y, s1.y + s3.x);   // s1 + i s3
 }
 
 // forward 16-point DFT in registers; on return X[k] sits at v[4*(k&3) + (k>>2)]
-__device__ __forceinline__ void fft16(float2 (&v)[16]) {
-  constexpr float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f, r2 = 0.70710678118654752440f;
+__device__ __forceinline__ void fft16(cd (&v)[16]) {
+  constexpr double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, r2 = 0.70710678118654752440;
 #pragma unroll
   for (int n2 = 0; n2 < 4; n2++) fft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
   // v[4*k1 + n2] *= exp(-2 pi i n2 k1 / 16)
-  v[5] = cmul(v[5], make_float2(c1, -s1));      // m = 1
-  v[6] = cmul(v[6], make_float2(r2, -r2));      // m = 2
-  v[7] = cmul(v[7], make_float2(s1, -c1));      // m = 3
-  v[9] = cmul(v[9], make_float2(r2, -r2));      // m = 2
-  v[10] = make_float2(v[10].y, -v[10].x);       // m = 4: * (-i)
-  v[11] = cmul(v[11], make_float2(-r2, -r2));   // m = 6
-  v[13] = cmul(v[13], make_float2(s1, -c1));    // m = 3
-  v[14] = cmul(v[14], make_float2(-r2, -r2));   // m = 6
-  v[15] = cmul(v[15], make_float2(-c1, s1));    // m = 9
+  v[5] = cmul(v[5], mk(c1, -s1));      // m = 1
+  v[6] = cmul(v[6], mk(r2, -r2));      // m = 2
+  v[7] = cmul(v[7], mk(s1, -c1));      // m = 3
+  v[9] = cmul(v[9], mk(r2, -r2));      // m = 2
+  v[10] = mk(v[10].y, -v[10].x);       // m = 4: * (-i)
+  v[11] = cmul(v[11], mk(-r2, -r2));   // m = 6
+  v[13] = cmul(v[13], mk(s1, -c1));    // m = 3
+  v[14] = cmul(v[14], mk(-r2, -r2));   // m = 6
+  v[15] = cmul(v[15], mk(-c1, s1));    // m = 9
 #pragma unroll
   for (int k1 = 0; k1 < 4; k1++) fft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
@@ -89,44 +98,55 @@ __host__ __device__ constexpr int fft16_slot(int k) { return 4 * (k & 3) + (k >>
 // forward R-point DFT in registers, R = 8 / 16 / 32; X[k] sits at v[FftR<R>::slot(k)]
 template <int R> struct FftR;
 template <> struct FftR<16> {
-  static __device__ __forceinline__ void run(float2 (&v)[16]) { fft16(v); }
+  static __device__ __forceinline__ void run(cd (&v)[16]) { fft16(v); }
   static __host__ __device__ constexpr int slot(int k) { return fft16_slot(k); }
 };
 template <> struct FftR<8> {      // two 4-point DFTs (even / odd samples) + one radix-2 stage
-  static __device__ __forceinline__ void run(float2 (&v)[8]) {
-    constexpr float r2 = 0.70710678118654752440f;
+  static __device__ __forceinline__ void run(cd (&v)[8]) {
+    constexpr double r2 = 0.70710678118654752440;
     fft4(v[0], v[2], v[4], v[6]); fft4(v[1], v[3], v[5], v[7]);
-    const float2 o1 = cmul(v[3], make_float2(r2, -r2)), o2 = make_float2(v[5].y, -v[5].x), o3 = cmul(v[7], make_float2(-r2, -r2)), o0 = v[1];
-    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    const cd o1 = cmul(v[3], mk(r2, -r2)), o2 = mk(v[5].y, -v[5].x), o3 = cmul(v[7], mk(-r2, -r2)), o0 = v[1];
+    const cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
     v[0] = cadd(e0, o0); v[4] = csub(e0, o0); v[1] = cadd(e1, o1); v[5] = csub(e1, o1); v[2] = cadd(e2, o2); v[6] = csub(e2, o2); v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
   }
   static __host__ __device__ constexpr int slot(int k) { return k; }
 };
 template <> struct FftR<32> {     // two 16-point DFTs (even / odd samples) + one radix-2 stage
-  static __device__ __forceinline__ void run(float2 (&v)[32]) {
-    constexpr float c[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128673848f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508978178f,
-                             0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508978178f, -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
-                             -0.92387953251128673848f, -0.98078528040323044913f};
-    constexpr float sn[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508978178f, 0.55557023301960222474f, 0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128673848f,
-                              0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128673848f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
-                              0.38268343236508978178f, 0.19509032201612826785f};
-    float2 e[16], o[16];
+  static __device__ __forceinline__ void run(cd (&v)[32]) {
+    constexpr double c[16] = {1.0, 0.98078528040323044913, 0.92387953251128673848, 0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474, 0.38268343236508978178,
+                              0.19509032201612826785, 0.0, -0.19509032201612826785, -0.38268343236508978178, -0.55557023301960222474, -0.70710678118654752440, -0.83146961230254523708,
+                              -0.92387953251128673848, -0.98078528040323044913};
+    constexpr double sn[16] = {0.0, 0.19509032201612826785, 0.38268343236508978178, 0.55557023301960222474, 0.70710678118654752440, 0.83146961230254523708, 0.92387953251128673848,
+                               0.98078528040323044913, 1.0, 0.98078528040323044913, 0.92387953251128673848, 0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474,
+                               0.38268343236508978178, 0.19509032201612826785};
+    cd e[16], o[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
     fft16(e); fft16(o);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const float2 ek = e[fft16_slot(k)], ok = k == 0 ? o[fft16_slot(0)] : cmul(o[fft16_slot(k)], make_float2(c[k], -sn[k]));
+      const cd ek = e[fft16_slot(k)], ok = k == 0 ? o[fft16_slot(0)] : cmul(o[fft16_slot(k)], mk(c[k], -sn[k]));
       v[k] = cadd(ek, ok); v[k + 16] = csub(ek, ok);
     }
   }
   static __host__ __device__ constexpr int slot(int k) { return k; }
 };
 
-__device__ __forceinline__ float group_sum16(float x) {
-  x += __shfl_xor(x, 8, 16); x += __shfl_xor(x, 4, 16); x += __shfl_xor(x, 2, 16); x += __shfl_xor(x, 1, 16);
+// A frame belongs to the 16 lanes of one DPP row: cross-lane traffic inside a frame is DPP row rotations (VALU, no LDS crossbar trip).
+// row_ror:n -- lane l of a row receives lane (l - n) mod 16.
+template <int N> __device__ __forceinline__ double row_ror(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double group_sum16(double x) {      // every lane of the row gets the row's sum (the four partial orders differ by lane: callers use lane 0's, or exact sums)
+  x += row_ror<8>(x); x += row_ror<4>(x); x += row_ror<2>(x); x += row_ror<1>(x);
   return x;
 }
+// The 4 frames of a wavefront own their LDS buffers: the phases of a frame are ordered by the wave's own program order (LDS instructions of a
+// wave execute in order); only the compiler has to be told not to move LDS accesses across the phase boundary.  No workgroup barrier in the frame loop.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 // TS = float (CuVector<BaseFloat> waves, the reference's interface) or int16_t (PCM16 as it sits in a wav file: 2 of the 480 B / frame of SURVEY 8d)
 template <typename TS, int R>
@@ -135,13 +155,13 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
                                                           const int64_t *__restrict__ frame_off, int num_utts,
                                                           int64_t total_frames, float *__restrict__ feats, int64_t ld,
                                                           int frames_per_block) {
-  constexpr int kNc = 16 * R, kNfft = 32 * R, kFrameBufBytes = frame_buf_bytes(R), kLogMelOff = logmel_off(R), kTwN = ((8 * R + 1) * 8 + 15) / 16 * 16, kFixed = lds_fixed_bytes(R);
+  constexpr int kNc = 16 * R, kNfft = 32 * R, kFrameBufBytes = frame_buf_bytes(R), kTwN = (8 * R + 1) * 16, kFixed = lds_fixed_bytes(R);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS carve (all offsets multiples of 16)
-  float2 *s_tw256 = reinterpret_cast<float2 *>(smem);                 // NC * 8 B (R = 16: 2048)
-  float2 *s_tw512 = reinterpret_cast<float2 *>(smem + kNc * 8);       // (N/4 + 1) * 8 -> 16-aligned (1040)
-  float *s_window = reinterpret_cast<float *>(smem + kNc * 8 + kTwN); // N * 4 B (2048)
-  int *s_meta = reinterpret_cast<int *>(smem + kFixed);               // 3*num_bins ints, padded to 16
+  cd *s_tw256 = reinterpret_cast<cd *>(smem);                         // NC * 16 B (R = 16: 4096)
+  cd *s_tw512 = reinterpret_cast<cd *>(smem + kNc * 16);              // (N/4 + 1) * 16 (2064)
+  float *s_window = reinterpret_cast<float *>(smem + kNc * 16 + kTwN); // N * 4 B (2048)
+  int *s_meta = reinterpret_cast<int *>(smem + kFixed);                // 3*num_bins ints, padded to 16
   const int meta_bytes = ((3 * p.num_bins * 4 + 15) / 16) * 16;
   float *s_binw = reinterpret_cast<float *>(smem + kFixed + meta_bytes);
   const int binw_bytes = ((p.total_w * 4 + 15) / 16) * 16;
@@ -153,22 +173,19 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
   for (int i = tid; i < kNfft; i += kThreads) s_window[i] = (i < p.win_len) ? p.window[i] : 0.0f;
   for (int i = tid; i < 3 * p.num_bins; i += kThreads) s_meta[i] = p.bin_meta[i];
   for (int i = tid; i < p.total_w; i += kThreads) s_binw[i] = p.bin_w[i];
-  __syncthreads();
+  __syncthreads();      // the only workgroup barrier: the tables
 
   const int lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l = lane & 15;
   const int fslot = wave * 4 + grp;
-  char *fb = s_frames + fslot * kFrameBufBytes;
-  float2 *T = reinterpret_cast<float2 *>(fb);
-  float *P = reinterpret_cast<float *>(fb);
-  float *M = reinterpret_cast<float *>(fb + kLogMelOff);
+  double *T = reinterpret_cast<double *>(s_frames + fslot * kFrameBufBytes);      // R x 17 transpose tile / X / P
   const int L = p.win_len;
-  const float eps = FLT_EPSILON;
+  const double eps = (double)FLT_EPSILON;
 
   const int64_t block_first = (int64_t)blockIdx.x * frames_per_block;
   for (int it = 0; it < frames_per_block; it += kFramesPerIter) {
     const int64_t g = block_first + it + fslot;
     const bool valid = g < total_frames;
-    float x0[R], x1[R];
+    double x0[R], x1[R];
     int64_t n = 0, start = 0;
     const TS *base = waves;
     if (valid) {
@@ -185,15 +202,15 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
 #pragma unroll
     for (int j = 0; j < R; j++) {
       const int s = 2 * (l + 16 * j);
-      float a = 0.0f, b = 0.0f;
+      TS a = 0, b = 0;
       if (interior) {
-        if (s < L) a = (float)base[start + s];
-        if (s + 1 < L) b = (float)base[start + s + 1];
+        if (s < L) a = base[start + s];
+        if (s + 1 < L) b = base[start + s + 1];
       } else if (valid) {
-        if (s < L) { int64_t si = start + s; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; a = (float)base[si]; }
-        if (s + 1 < L) { int64_t si = start + s + 1; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; b = (float)base[si]; }
+        if (s < L) { int64_t si = start + s; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; a = base[si]; }
+        if (s + 1 < L) { int64_t si = start + s + 1; while (si < 0 || si >= n) si = (si < 0) ? -si - 1 : 2 * n - 1 - si; b = base[si]; }
       }
-      x0[j] = a; x1[j] = b;
+      x0[j] = (double)a; x1[j] = (double)b;
     }
     // ---- ProcessWindow ----
     if (p.dither != 0.0f && valid) {     // counter-based generator (frame, sample pair, seed) -> Box-Muller pair; not the reference's rand() stream
@@ -204,16 +221,16 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
         z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;          // splitmix64 finaliser
         const float u1 = ((unsigned)(z >> 40) + 1.0f) * (1.0f / 16777217.0f), u2 = (unsigned)((z >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
         const float r = sqrtf(-2.0f * logf(u1)), th = 6.283185307179586f * u2;
-        if (s < L) x0[j] += p.dither * r * cosf(th);
-        if (s + 1 < L) x1[j] += p.dither * r * sinf(th);
+        if (s < L) x0[j] += (double)(p.dither * r * cosf(th));
+        if (s + 1 < L) x1[j] += (double)(p.dither * r * sinf(th));
       }
     }
     if (p.remove_dc) {
-      float sum = 0.0f;
+      double sum = 0.0;
 #pragma unroll
       for (int j = 0; j < R; j++) sum += x0[j] + x1[j];
       sum = group_sum16(sum);
-      const float m = -sum / (float)L;
+      const double m = -sum / (double)L;
 #pragma unroll
       for (int j = 0; j < R; j++) {
         const int s = 2 * (l + 16 * j);
@@ -221,164 +238,163 @@ __global__ __launch_bounds__(kThreads) void k3_feat_kernel(FeatParams p, const T
         if (s + 1 < L) x1[j] += m;
       }
     }
-    float log_energy = 0.0f;
+    double log_energy = 0.0;
     if (p.use_energy && p.raw_energy) {
-      float e = 0.0f;
+      double e = 0.0;
 #pragma unroll
       for (int j = 0; j < R; j++) e += x0[j] * x0[j] + x1[j] * x1[j];
       e = group_sum16(e);
-      log_energy = logf(fmaxf(e, eps));
+      log_energy = log(fmax(e, eps));
     }
-    float2 v[R];
+    cd v[R];
     {
-      const float c = p.preemph;
-      float prev_hi = 0.0f;  // lane 15's x1[j-1]
+      const double c = (double)p.preemph;      // the reference's float32 coefficient
+      double prev_wrap = 0.0;     // lane 15's x1[j-1], as rotated into lane 0
 #pragma unroll
       for (int j = 0; j < R; j++) {
         const int s = 2 * (l + 16 * j);
-        float up = __shfl_up(x1[j], 1, 16);
-        float prev0 = (l > 0) ? up : ((j > 0) ? prev_hi : x0[0]);
-        prev_hi = __shfl(x1[j], 15, 16);
-        float y0 = x0[j], y1 = x1[j];
-        if (c != 0.0f) {
-          // __fmul_rn/__fsub_rn keep the reference's two roundings (no fma contraction)
-          if (s < L) y0 = __fsub_rn(x0[j], __fmul_rn(c, prev0));
-          if (s + 1 < L) y1 = __fsub_rn(x1[j], __fmul_rn(c, x0[j]));
+        const double rot = row_ror<1>(x1[j]);       // lane l: x1[j] of lane l - 1; lane 0: lane 15's
+        const double prev0 = (l > 0) ? rot : ((j > 0) ? prev_wrap : x0[0]);      // sample s - 1 (Preemphasize: the first sample is its own predecessor)
+        prev_wrap = rot;
+        double y0 = x0[j], y1 = x1[j];
+        if (c != 0.0) {
+          if (s < L) y0 = x0[j] - c * prev0;
+          if (s + 1 < L) y1 = x1[j] - c * x0[j];
         }
         const float2 w = *reinterpret_cast<const float2 *>(&s_window[s]);
-        v[j] = make_float2(y0 * w.x, y1 * w.y);
+        v[j] = mk(y0 * (double)w.x, y1 * (double)w.y);
       }
     }
     if (p.use_energy && !p.raw_energy) {
-      float e = 0.0f;
+      double e = 0.0;
 #pragma unroll
       for (int j = 0; j < R; j++) e += v[j].x * v[j].x + v[j].y * v[j].y;
       e = group_sum16(e);
-      log_energy = logf(fmaxf(e, eps));
+      log_energy = log(fmax(e, eps));
     }
     // ---- NC-point complex FFT, NC = R x 16.  Pass 1: a lane's R points (n = l + 16 j) -> Y[l][k2]; twiddle W_NC^(l k2); transpose;
-    //      pass 2: for every k2 a 16-point DFT over l -> X[k2 + R k1] ----
+    //      pass 2: for every k2 a 16-point DFT over l -> X[k2 + R k1].  The tile holds doubles: real parts go through it first, then the imaginary parts ----
     FftR<R>::run(v);
 #pragma unroll
-    for (int k2 = 0; k2 < R; k2++) {
-      float2 y = v[FftR<R>::slot(k2)];
-      if (k2 > 0) y = cmul(y, s_tw256[(l * k2) & (kNc - 1)]);
-      T[k2 * kTpad + l] = y;
-    }
-    __syncthreads();
+    for (int k2 = 1; k2 < R; k2++) v[FftR<R>::slot(k2)] = cmul(v[FftR<R>::slot(k2)], s_tw256[(l * k2) & (kNc - 1)]);
     constexpr int kPer = (R + 15) / 16;          // k2 values a lane transforms in pass 2 (R = 8: lanes 8..15 idle)
-    float2 u[kPer][16];
+    cd u[kPer][16];
 #pragma unroll
-    for (int q = 0; q < kPer; q++) {
-      const int k2 = l + 16 * q;
-      if (k2 < R) {
+    for (int k2 = 0; k2 < R; k2++) T[k2 * kTpad + l] = v[FftR<R>::slot(k2)].x;
+    wave_sync();
 #pragma unroll
-        for (int i = 0; i < 16; i++) u[q][i] = T[k2 * kTpad + i];
-        fft16(u[q]);   // now X[k2 + R*k1] = u[q][slot(k1)]
-      }
-    }
-    __syncthreads();
+    for (int q = 0; q < kPer; q++) { const int k2 = l + 16 * q; if (k2 < R) {
 #pragma unroll
-    for (int q = 0; q < kPer; q++) {
-      const int k2 = l + 16 * q;
-      if (k2 < R) {
+      for (int i = 0; i < 16; i++) u[q][i].x = T[k2 * kTpad + i]; } }
+    wave_sync();
 #pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) T[k2 + R * k1] = u[q][fft16_slot(k1)];
-      }
-    }
-    __syncthreads();
-    // ---- real-FFT unpacking (srfft.cc:372-405) + power spectrum ----
-    float2 Bk[R / 2], Bm[R / 2];
+    for (int k2 = 0; k2 < R; k2++) T[k2 * kTpad + l] = v[FftR<R>::slot(k2)].y;
+    wave_sync();
 #pragma unroll
-    for (int i = 0; i < R / 2; i++) {
-      const int k = l + 16 * i;
-      Bk[i] = T[k];
-      Bm[i] = T[(kNc - k) & (kNc - 1)];
-    }
-    const float2 B128 = T[kNc / 2];
-    __syncthreads();
+    for (int q = 0; q < kPer; q++) { const int k2 = l + 16 * q; if (k2 < R) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) u[q][i].y = T[k2 * kTpad + i];
+      fft16(u[q]); } }   // now X[k2 + R*k1] = u[q][slot(k1)]
+    wave_sync();
+    // ---- X in natural order through the tile (real parts, then imaginary parts); real-FFT unpacking (srfft.cc:372-405) + power spectrum ----
+    cd Bk[R / 2], Bm[R / 2], B128;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) { const int k2 = l + 16 * q; if (k2 < R) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) T[k2 + R * k1] = u[q][fft16_slot(k1)].x; } }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < R / 2; i++) { const int k = l + 16 * i; Bk[i].x = T[k]; Bm[i].x = T[(kNc - k) & (kNc - 1)]; }
+    B128.x = T[kNc / 2];
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < kPer; q++) { const int k2 = l + 16 * q; if (k2 < R) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; k1++) T[k2 + R * k1] = u[q][fft16_slot(k1)].y; } }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < R / 2; i++) { const int k = l + 16 * i; Bk[i].y = T[k]; Bm[i].y = T[(kNc - k) & (kNc - 1)]; }
+    B128.y = T[kNc / 2];
+    wave_sync();
+    double *P = T;
 #pragma unroll
     for (int i = 0; i < R / 2; i++) {
       const int k = l + 16 * i;
       if (k == 0) {
-        const float a0 = Bk[0].x + Bk[0].y, an = Bk[0].x - Bk[0].y;
-        float p0 = a0 * a0, pn = an * an;
-        if (!p.use_power) { p0 = sqrtf(p0); pn = sqrtf(pn); }
+        const double a0 = Bk[0].x + Bk[0].y, an = Bk[0].x - Bk[0].y;
+        double p0 = a0 * a0, pn = an * an;
+        if (!p.use_power) { p0 = sqrt(p0); pn = sqrt(pn); }
         P[0] = p0; P[kNc] = pn;
       } else {
-        const float2 w = s_tw512[k];
-        const float Cr = 0.5f * (Bk[i].x + Bm[i].x), Ci = 0.5f * (Bk[i].y - Bm[i].y);
-        const float Dr = 0.5f * (Bk[i].y + Bm[i].y), Di = -0.5f * (Bk[i].x - Bm[i].x);
-        const float Ar = Cr + (Dr * w.x - Di * w.y), Ai = Ci + (Dr * w.y + Di * w.x);
-        const float Er = Cr + (Dr * (-w.x) + Di * w.y), Ei = -Ci + (Dr * w.y + Di * w.x);
-        float pk = Ar * Ar + Ai * Ai, pm = Er * Er + Ei * Ei;
-        if (!p.use_power) { pk = sqrtf(pk); pm = sqrtf(pm); }
+        const cd w = s_tw512[k];
+        const double Cr = 0.5 * (Bk[i].x + Bm[i].x), Ci = 0.5 * (Bk[i].y - Bm[i].y);
+        const double Dr = 0.5 * (Bk[i].y + Bm[i].y), Di = -0.5 * (Bk[i].x - Bm[i].x);
+        const double Ar = Cr + (Dr * w.x - Di * w.y), Ai = Ci + (Dr * w.y + Di * w.x);
+        const double Er = Cr + (Dr * (-w.x) + Di * w.y), Ei = -Ci + (Dr * w.y + Di * w.x);
+        double pk = Ar * Ar + Ai * Ai, pm = Er * Er + Ei * Ei;
+        if (!p.use_power) { pk = sqrt(pk); pm = sqrt(pm); }
         P[k] = pk; P[kNc - k] = pm;
       }
     }
     if (l == 0) {  // k = N/4 (kdash == k)
-      const float2 w = s_tw512[kNc / 2];
-      const float Cr = B128.x, Ci = 0.0f, Dr = B128.y, Di = 0.0f;
-      const float Ar = Cr + (Dr * w.x - Di * w.y), Ai = Ci + (Dr * w.y + Di * w.x);
-      float pk = Ar * Ar + Ai * Ai;
-      if (!p.use_power) pk = sqrtf(pk);
+      const cd w = s_tw512[kNc / 2];
+      const double Ar = B128.x + B128.y * w.x, Ai = B128.y * w.y;
+      double pk = Ar * Ar + Ai * Ai;
+      if (!p.use_power) pk = sqrt(pk);
       P[kNc / 2] = pk;
     }
-    __syncthreads();
+    wave_sync();
     // ---- mel filterbank: MelBanks::Compute ----
     float *row = feats + g * ld;
     const int mel_off = (p.feature_type == 0 && p.use_energy && !p.htk_compat) ? 1 : 0;
-    float logmel[8];
+    double logmel[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
       const int b = l + 16 * r;
-      float e = 0.0f;
+      double e = 0.0;
       if (r * 16 < p.num_bins && b < p.num_bins) {
         const int first = s_meta[3 * b], len = s_meta[3 * b + 1], wo = s_meta[3 * b + 2];
-        for (int i = 0; i < len; i++) e += s_binw[wo + i] * P[first + i];
-        if (p.htk_mode && e < 1.0f) e = 1.0f;
-        if (p.feature_type == 1 || p.use_log) e = logf(fmaxf(e, eps));
+        for (int i = 0; i < len; i++) e += (double)s_binw[wo + i] * P[first + i];
+        if (p.htk_mode && e < 1.0) e = 1.0;
+        if (p.feature_type == 1 || p.use_log) e = log(fmax(e, eps));
       }
       logmel[r] = e;
     }
     if (p.feature_type == 0) {
       if (valid) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const int b = l + 16 * r; if (b < p.num_bins) row[mel_off + b] = logmel[r]; }
+        for (int r = 0; r < 8; r++) { const int b = l + 16 * r; if (b < p.num_bins) row[mel_off + b] = (float)logmel[r]; }
         if (p.use_energy && l == 0) {
-          float e = log_energy;
+          float e = (float)log_energy;
           if (p.has_energy_floor && e < p.log_energy_floor) e = p.log_energy_floor;
           row[p.htk_compat ? p.num_bins : 0] = e;
         }
       }
-      __syncthreads();   // P is overwritten by the next iteration's transpose tile
     } else {
-      __syncthreads();   // all P reads done before M (aliases the tile tail) is written
+      // DCT (MfccComputer::Compute feature-mfcc.cc:61-80): a lane holds the log-mel values of its bins; one row sum per cepstrum
+      for (int c = 0; c < p.num_ceps; c++) {
+        const float *drow = p.dct + c * p.num_bins;
+        double acc = 0.0;
 #pragma unroll
-      for (int r = 0; r < 8; r++) { const int b = l + 16 * r; if (b < p.num_bins) M[b] = logmel[r]; }
-      __syncthreads();
-      for (int r = 0; r * 16 < p.num_ceps; r++) {
-        const int c = l + 16 * r;
-        if (c < p.num_ceps && valid) {
-          const float *drow = p.dct + c * p.num_bins;
-          float acc = 0.0f;
-          for (int b = 0; b < p.num_bins; b++) acc += drow[b] * M[b];
-          if (p.has_lifter) acc *= p.lifter[c];
+        for (int r = 0; r < 8; r++) { const int b = l + 16 * r; if (b < p.num_bins) acc += (double)drow[b] * logmel[r]; }
+        acc = group_sum16(acc);
+        if (valid && l == (c & 15)) {
+          if (p.has_lifter) acc *= (double)p.lifter[c];
+          float out = (float)acc;
           if (c == 0 && p.use_energy) {
-            float e = log_energy;
-            if (p.has_energy_floor && e < p.log_energy_floor) e = p.log_energy_floor;
-            acc = e;
+            out = (float)log_energy;
+            if (p.has_energy_floor && out < p.log_energy_floor) out = p.log_energy_floor;
           }
           int oc = c;
           if (p.htk_compat) {
-            if (c == 0) { oc = p.num_ceps - 1; if (!p.use_energy) acc *= 1.41421356237309504880f; }
+            if (c == 0) { oc = p.num_ceps - 1; if (!p.use_energy) out = (float)(acc * 1.41421356237309504880); }
             else oc = c - 1;
           }
-          row[oc] = acc;
+          row[oc] = out;
         }
       }
-      __syncthreads();
     }
+    wave_sync();   // P is overwritten by the next iteration's transpose tile
   }
 }
 
@@ -626,16 +642,10 @@ extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out)
     for (int i = first; i <= last; i++) binw.push_back(w[i]);
     if (o.htk_mode && bin == 0 && mlow != 0.0f) binw[meta[2]] = 0.0f;
   }
-  // twiddles
-  std::vector<float> tw256(2 * (size_t)NC), tw512(2 * ((size_t)NC / 2 + 1));
+  // twiddles: exact to float64 (the data path is float64; the reference builds exp(-2 pi i k / N) by a float32 recurrence, srfft.cc:370-376, which is part of ITS rounding error)
+  std::vector<double> tw256(2 * (size_t)NC), tw512(2 * ((size_t)NC / 2 + 1));
   for (int m = 0; m < NC; m++) { const double ang = -6.283185307179586476925286766559005 * m / (double)NC; tw256[2 * m] = cos(ang); tw256[2 * m + 1] = sin(ang); }
-  {  // srfft.cc:370-376: kN built by repeated float complex multiplication by exp(-2 pi i / N)
-    const float ang = (float)(6.283185307179586476925286766559005 / padded * -1);
-    const float rr = cosf(ang), ri = sinf(ang);
-    float kr = 1.0f, ki = 0.0f;
-    tw512[0] = 1.0f; tw512[1] = 0.0f;
-    for (int k = 1; k <= NC / 2; k++) { const float t = kr * rr - ki * ri; ki = kr * ri + ki * rr; kr = t; tw512[2 * k] = kr; tw512[2 * k + 1] = ki; }
-  }
+  for (int k = 0; k <= NC / 2; k++) { const double ang = -6.283185307179586476925286766559005 * k / (double)padded; tw512[2 * k] = cos(ang); tw512[2 * k + 1] = sin(ang); }
   // MFCC tables
   std::vector<float> dct, lifter;
   if (o.feature_type == 1) {
@@ -649,13 +659,13 @@ extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out)
   }
   // one device blob
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  size_t off_win = 0, off_tw256 = al(off_win + window.size() * 4), off_tw512 = al(off_tw256 + tw256.size() * 4),
-         off_meta = al(off_tw512 + tw512.size() * 4), off_binw = al(off_meta + meta.size() * 4),
+  size_t off_win = 0, off_tw256 = al(off_win + window.size() * 4), off_tw512 = al(off_tw256 + tw256.size() * 8),
+         off_meta = al(off_tw512 + tw512.size() * 8), off_binw = al(off_meta + meta.size() * 4),
          off_dct = al(off_binw + binw.size() * 4), off_lift = al(off_dct + dct.size() * 4), total = al(off_lift + lifter.size() * 4 + 4);
   std::vector<char> host(total, 0);
   memcpy(&host[off_win], window.data(), window.size() * 4);
-  memcpy(&host[off_tw256], tw256.data(), tw256.size() * 4);
-  memcpy(&host[off_tw512], tw512.data(), tw512.size() * 4);
+  memcpy(&host[off_tw256], tw256.data(), tw256.size() * 8);
+  memcpy(&host[off_tw512], tw512.data(), tw512.size() * 8);
   memcpy(&host[off_meta], meta.data(), meta.size() * 4);
   memcpy(&host[off_binw], binw.data(), binw.size() * 4);
   if (!dct.empty()) { memcpy(&host[off_dct], dct.data(), dct.size() * 4); memcpy(&host[off_lift], lifter.data(), lifter.size() * 4); }
@@ -676,12 +686,11 @@ extern "C" int k3_feat_plan_create(const k3_feat_opts *opts, k3_feat_plan **out)
   p.has_lifter = (o.feature_type == 1 && o.cepstral_lifter != 0.0f);
   p.total_w = (int)binw.size(); p.preemph = o.preemph_coeff;
   char *b = (char *)blob;
-  p.window = (const float *)(b + off_win); p.tw256 = (const float2 *)(b + off_tw256); p.tw512 = (const float2 *)(b + off_tw512);
+  p.window = (const float *)(b + off_win); p.tw256 = (const double2 *)(b + off_tw256); p.tw512 = (const double2 *)(b + off_tw512);
   p.bin_meta = (const int *)(b + off_meta); p.bin_w = (const float *)(b + off_binw);
   p.dct = (const float *)(b + off_dct); p.lifter = (const float *)(b + off_lift);
   const size_t meta_bytes = ((3 * nb * 4 + 15) / 16) * 16, binw_bytes = ((binw.size() * 4 + 15) / 16) * 16;
   pl->lds_bytes = lds_fixed_bytes(R) + meta_bytes + binw_bytes + (size_t)kFramesPerIter * frame_buf_bytes(R);
-  if ((size_t)logmel_off(R) + nb * 4 > (size_t)frame_buf_bytes(R)) { delete pl; hipFree(blob); return k3::fail(K3_ERR_UNSUPPORTED, "num_bins too large for the LDS frame buffer", __FILE__, __LINE__); }
   *out = pl;
   return K3_OK;
 }

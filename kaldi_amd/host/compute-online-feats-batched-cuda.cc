@@ -9,6 +9,10 @@
 // estimate is made once, after the utterance's last chunk, by the whole-utterance extractor (k3_ivector_extract_batch: the statistics of all
 // periods up to the last one that starts inside the utterance, OnlineIvectorFeature's schedule) -- the i-vector ivector-extract-online2 ends on.
 // Without --ivector-extraction-config the i-vector table is written with empty vectors like the reference (IvectorDim() == 0).
+// Under the name compute-online-feats-cuda (no "batched" in argv[0]) the program is the drop-in for cudafeatbin/compute-online-feats-cuda.cc:30-125:
+//   compute-online-feats-cuda [options] <wave-rspecifier> <ivector-wspecifier> <feats-wspecifier>
+// OnlineCudaFeaturePipeline::ComputeFeatures (cudafeat/online-cuda-feature-pipeline.h:33-51) on one whole utterance after the other: the same options
+// (OnlineNnet2FeaturePipelineConfig), every file one chunk, one file per GPU call, a file that fails is counted and skipped, exit code 1 when nothing succeeded.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <deque>
@@ -20,7 +24,11 @@ using namespace k3host;
 
 int main(int argc, char **argv) {
   try {
-    const char *usage = "Compute online features and ivector features.\n\nThis binary processes the audio in chunks of samples. In addition, the computation is batched and done on the GPU.\n\n"
+    const bool whole = strstr(argv[0], "batched") == nullptr;      // compute-online-feats-cuda: one whole utterance per call
+    const char *usage = whole ? "Extract features and ivectors for utterances using the online\nfeature pipeline on the GPU. This class models the online feature pipeline.\n\n"
+                                "Usage:  compute-online-feats-cuda [options] <wave-rspecifier> <ivector-wspecifier> <feats-wspecifier>\ne.g.: \n"
+                                "  ./compute-online-feats-cuda --config=feature_config wav.scp ark,scp:ivector.ark,ivector.scp ark,scp:feat.ark,feat.scp\n" :
+                        "Compute online features and ivector features.\n\nThis binary processes the audio in chunks of samples. In addition, the computation is batched and done on the GPU.\n\n"
                         "Usage: ./compute-online-feats-batched-cuda --batch-size=100 <wave-rspecifier> <ivector-wspecifier> <feature-wspecifier> \n";
     ParseOptions po(usage);
     int32_t num_channels = 50, num_lanes = 10, chunk_len = 10000; std::string feature_type = "mfcc", mfcc_config, fbank_config, plp_config, ivector_config, cmvn_config, global_cmvn, pitch_config, use_gpu = "yes"; bool add_pitch = false;
@@ -34,6 +42,7 @@ int main(int argc, char **argv) {
     po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) { po.PrintUsage(); return 1; }
+    if (whole) { num_lanes = 1; num_channels = 1; chunk_len = 0x7FFFFFFF; }
     if (add_pitch || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty()) K3H_ERR << "an option that needs a component outside the accelerated path was given (pitch / PLP / CMVN)";
     if (num_channels < num_lanes) K3H_ERR << "--num-channels must be at least --batch-size";
     const bool mfcc = feature_type == "mfcc";
@@ -61,7 +70,7 @@ int main(int argc, char **argv) {
     struct Utt { std::string key; Wave wave; size_t pos = 0; std::vector<float> feats; int channel = -1; bool started = false; };
     std::deque<Utt> active; size_t next = 0; std::vector<int> free_channels; for (int c = num_channels - 1; c >= 0; c--) free_channels.push_back(c);
     OnlineFeatures online(plan, fopts, num_channels);
-    int num_done = 0; int64_t tot_t = 0;
+    int num_done = 0, num_fail = 0; int64_t tot_t = 0;
     auto finish = [&](Utt &u) {
       const int nf = (int)(u.feats.size() / dim);
       std::vector<float> ivec(iv_dim, 0.0f);
@@ -78,8 +87,16 @@ int main(int argc, char **argv) {
     };
     for (;;) {
       while (next < scp.size() && !free_channels.empty() && (int)active.size() < num_channels) {      // fill the free channels (cudafeatbin/...:262-290)
-        Utt u; u.key = scp[next].first; u.wave = ReadWave(scp[next].second); next++;
+        Utt u; u.key = scp[next].first;
+        if (whole) {      // (:83-113: "Processing Utterance", a failure is a warning and the next file)
+          K3H_LOG << "Processing Utterance " << u.key;
+          try { u.wave = ReadWave(scp[next].second); if (u.wave.samp_freq != fopts.samp_freq) K3H_ERR << "Sample frequency mismatch"; }
+          catch (const std::exception &) { K3H_WARN << "Failed to compute features for utterance " << u.key; num_fail++; next++; continue; }
+          next++;
+        } else {
+        u.wave = ReadWave(scp[next].second); next++;
         if (u.wave.samp_freq != fopts.samp_freq) K3H_ERR << "Sample frequency mismatch for " << u.key << ": " << u.wave.samp_freq << " vs " << fopts.samp_freq;
+        }
         u.channel = free_channels.back(); free_channels.pop_back(); active.push_back(std::move(u));
       }
       if (active.empty()) break;
@@ -100,6 +117,7 @@ int main(int argc, char **argv) {
       active.swap(keep);
     }
     feature_writer.Flush(); ivector_writer.Flush(); k3_feat_plan_destroy(plan); if (ivx) k3_ivector_destroy(ivx);
+    if (whole) { K3H_LOG << "Processed " << num_done + num_fail << " utterances with " << num_fail << " failures."; return num_done != 0 ? 0 : 1; }
     K3H_LOG << "Computed online features for " << num_done << " files, and " << tot_t << " total feature frames.";
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }

@@ -4,10 +4,12 @@ import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 TARGETS = [
-    ("libk3oracle_feat.so", ["feat_oracle.c"], "gcc", ["-O2", "-std=gnu11"]),
+    ("libk3oracle_feat.so", ["feat_oracle.c"], "gcc", ["-O2", "-std=gnu11"]),      # includes feat_oracle_path.inc twice (float32 / float64 data path), see DEPS
     ("libk3oracle_nnet.so", ["nnet_oracle.c"], "gcc", ["-O3", "-std=gnu11", "-march=native"]),
     ("libk3oracle_dec.so", ["lattice_faster_oracle.cc"], "g++", ["-O2", "-std=c++17", "-ffp-contract=off", "-Wall"]),
 ]
+
+DEPS = {"libk3oracle_feat.so": ["feat_oracle_path.inc"]}      # included files: rebuild when they change
 
 def _stale(out, srcs):
     if not os.path.exists(out):
@@ -21,7 +23,7 @@ def build(verbose=False, with_ref=True):
         if not all(os.path.exists(s) for s in srcs_abs):
             continue
         out_abs = os.path.join(HERE, out)
-        if _stale(out_abs, srcs_abs):
+        if _stale(out_abs, srcs_abs + [os.path.join(HERE, d) for d in DEPS.get(out, [])]):
             cmd = [cc] + flags + ["-shared", "-fPIC", "-o", out_abs] + srcs_abs + ["-lm"]
             if verbose:
                 print(" ".join(cmd))

@@ -156,126 +156,34 @@ static melbin *make_mel_banks(const k3o_feat_opts *o) {
   return b;
 }
 
-/* complex FFT of length n (power of two), interleaved re/im, forward (exp(-i...)).  See header. */
-static void complex_fft(float *d, int32_t n, const float *tw /* n/2 (cos,-sin) pairs */) {
-  for (int32_t i = 1, j = 0; i < n; i++) {
-    int32_t bit = n >> 1;
-    for (; j & bit; bit >>= 1) j ^= bit;
-    j ^= bit;
-    if (i < j) { float tr = d[2*i], ti = d[2*i+1]; d[2*i] = d[2*j]; d[2*i+1] = d[2*j+1]; d[2*j] = tr; d[2*j+1] = ti; }
-  }
-  for (int32_t len = 2; len <= n; len <<= 1) {
-    int32_t half = len >> 1, step = n / len;
-    for (int32_t i = 0; i < n; i += len)
-      for (int32_t k = 0; k < half; k++) {
-        float wr = tw[2*(k*step)], wi = tw[2*(k*step)+1];
-        float *a = d + 2*(i+k), *b = d + 2*(i+k+half);
-        float xr = b[0]*wr - b[1]*wi, xi = b[0]*wi + b[1]*wr;
-        b[0] = a[0] - xr; b[1] = a[1] - xi; a[0] += xr; a[1] += xi;
-      }
-  }
-}
-
-/* matrix/srfft.cc:356-432, forward branch: in-place real FFT of N floats; output packed
- * [re0, re(N/2), re1, im1, re2, im2, ...]. */
-static void real_fft(float *data, int32_t N, const float *tw) {
-  int32_t N2 = N / 2;
-  complex_fft(data, N2, tw);
-  float rootN_re = (float)cos(-M_2PI / N), rootN_im = (float)sin(-M_2PI / N);
-  /* ComplexImExp(static_cast<Real>(M_2PI/N * forward_sign)) evaluates cos/sin of a float arg */
-  { float ang = (float)(M_2PI / N * -1); rootN_re = cosf(ang); rootN_im = sinf(ang); }
-  float kN_re = 1.0f, kN_im = 0.0f;
-  for (int32_t k = 1; 2 * k <= N2; k++) {
-    { float t = kN_re * rootN_re - kN_im * rootN_im; kN_im = kN_re * rootN_im + kN_im * rootN_re; kN_re = t; }
-    float Ck_re = 0.5f * (data[2*k] + data[N - 2*k]);
-    float Ck_im = 0.5f * (data[2*k+1] - data[N - 2*k + 1]);
-    float Dk_re = 0.5f * (data[2*k+1] + data[N - 2*k + 1]);
-    float Dk_im = -0.5f * (data[2*k] - data[N - 2*k]);
-    data[2*k] = Ck_re + (Dk_re * kN_re - Dk_im * kN_im);
-    data[2*k+1] = Ck_im + (Dk_re * kN_im + Dk_im * kN_re);
-    int32_t kd = N2 - k;
-    if (kd != k) {
-      /* D_k' = conj(D_k), twiddle = (-kN_re, kN_im) */
-      data[2*kd] = Ck_re + (Dk_re * -kN_re - (-Dk_im) * kN_im);
-      data[2*kd+1] = -Ck_im + (Dk_re * kN_im + (-Dk_im) * -kN_re);
-    }
-  }
-  float z = data[0] + data[1], n2 = data[0] - data[1];
-  data[0] = z; data[1] = n2;
-}
-
-static float dotf(const float *a, const float *b, int32_t n) { float s = 0.0f; for (int32_t i = 0; i < n; i++) s += a[i] * b[i]; return s; }
-
-/*
- * Whole-utterance feature extraction: feat/feature-common-inl.h:59-83 (frame loop) calling
- * ExtractWindow (feature-window.cc:166-224), ProcessWindow (:137-160) and FbankComputer::Compute
- * (feature-fbank.cc:72-123) / MfccComputer::Compute (feature-mfcc.cc:28-80).  dither must be 0
- * (RandGauss is unreproducible).  out: [num_frames x dim] row-major.  Returns frames.
- */
-int32_t k3o_compute_features(const k3o_feat_opts *o, const float *wave, int64_t nsamp, float *out) {
-  int32_t L = window_size(o), N = padded_window_size(o), T = k3o_num_frames(nsamp, o);
-  int32_t nb = o->num_bins, dim = k3o_feat_dim(o);
-  if (T <= 0) return 0;
-  if (N & (N - 1)) return -1; /* oracle covers the srfft (power of two) branch only */
-  float *win = (float *)malloc(sizeof(float) * L); make_window(o, win);
-  melbin *banks = make_mel_banks(o);
-  float *tw = (float *)malloc(sizeof(float) * N);
-  for (int32_t k = 0; k < N / 4; k++) { double a = -M_2PI * k / (N / 2); tw[2*k] = (float)cos(a); tw[2*k+1] = (float)sin(a); }
-  float *frame = (float *)malloc(sizeof(float) * N);
-  float *mel = (float *)malloc(sizeof(float) * nb);
-  /* MFCC tables: matrix/matrix-functions.cc:592-608, mel-computations.cc:253-259 */
-  float *dct = NULL, *lifter = NULL;
-  if (o->feature_type == 1) {
-    dct = (float *)malloc(sizeof(float) * o->num_ceps * nb);
-    float norm0 = sqrtf(1.0f / (float)nb), norm = sqrtf(2.0f / (float)nb);
-    for (int32_t j = 0; j < nb; j++) dct[j] = norm0;
-    for (int32_t k = 1; k < o->num_ceps; k++)
-      for (int32_t n = 0; n < nb; n++) dct[k * nb + n] = (float)(norm * cos((double)M_PI / nb * (n + 0.5) * k));
-    lifter = (float *)malloc(sizeof(float) * o->num_ceps);
-    for (int32_t i = 0; i < o->num_ceps; i++) lifter[i] = (float)(1.0 + 0.5 * o->cepstral_lifter * sin(M_PI * i / o->cepstral_lifter));
-  }
-  float log_energy_floor = (o->energy_floor > 0.0f) ? logf(o->energy_floor) : 0.0f;
-  for (int32_t f = 0; f < T; f++) {
-    int64_t start = first_sample_of_frame(f, o);
-    /* ExtractWindow: copy or reflect (feature-window.cc:195-214) */
-    for (int32_t s = 0; s < L; s++) {
-      int64_t si = s + start;
-      while (si < 0 || si >= nsamp) { if (si < 0) si = -si - 1; else si = 2 * nsamp - 1 - si; }
-      frame[s] = wave[si];
-    }
-    for (int32_t s = L; s < N; s++) frame[s] = 0.0f;
-    /* ProcessWindow */
-    if (o->remove_dc_offset) { float sum = 0.0f; for (int32_t s = 0; s < L; s++) sum += frame[s]; float m = -sum / L; for (int32_t s = 0; s < L; s++) frame[s] += m; }
-    float raw_log_energy = 0.0f;
-    if (o->use_energy && o->raw_energy) { float e = dotf(frame, frame, L); if (e < FLT_EPSILON) e = FLT_EPSILON; raw_log_energy = logf(e); }
-    if (o->preemph_coeff != 0.0f) { for (int32_t i = L - 1; i > 0; i--) frame[i] -= o->preemph_coeff * frame[i-1]; frame[0] -= o->preemph_coeff * frame[0]; }
-    for (int32_t s = 0; s < L; s++) frame[s] *= win[s];
-    if (o->use_energy && !o->raw_energy) { float e = dotf(frame, frame, N); if (e < FLT_EPSILON) e = FLT_EPSILON; raw_log_energy = logf(e); }
-    real_fft(frame, N, tw);
-    /* ComputePowerSpectrum feat/feature-functions.cc:30-52 */
-    { int32_t h = N / 2; float fe = frame[0] * frame[0], le = frame[1] * frame[1];
-      for (int32_t i = 1; i < h; i++) { float re = frame[2*i], im = frame[2*i+1]; frame[i] = re*re + im*im; }
-      frame[0] = fe; frame[h] = le; }
-    if (o->feature_type == 0 && !o->use_power) for (int32_t i = 0; i <= N / 2; i++) frame[i] = powf(frame[i], 0.5f);
-    /* MelBanks::Compute mel-computations.cc:226-251 */
-    for (int32_t b = 0; b < nb; b++) { float e = dotf(banks[b].w, frame + banks[b].offset, banks[b].len); if (o->htk_mode && e < 1.0f) e = 1.0f; mel[b] = e; }
-    float *row = out + (int64_t)f * dim;
-    if (o->feature_type == 0) {
-      int32_t off = (o->use_energy && !o->htk_compat) ? 1 : 0;
-      for (int32_t b = 0; b < nb; b++) { float e = mel[b]; if (o->use_log_fbank) { if (e < FLT_EPSILON) e = FLT_EPSILON; e = logf(e); } row[off + b] = e; }
-      if (o->use_energy) { if (o->energy_floor > 0.0f && raw_log_energy < log_energy_floor) raw_log_energy = log_energy_floor; row[o->htk_compat ? nb : 0] = raw_log_energy; }
-    } else {
-      for (int32_t b = 0; b < nb; b++) { float e = mel[b]; if (e < FLT_EPSILON) e = FLT_EPSILON; mel[b] = logf(e); }
-      for (int32_t c = 0; c < o->num_ceps; c++) row[c] = dotf(dct + c * nb, mel, nb);
-      if (o->cepstral_lifter != 0.0f) for (int32_t c = 0; c < o->num_ceps; c++) row[c] *= lifter[c];
-      if (o->use_energy) { if (o->energy_floor > 0.0f && raw_log_energy < log_energy_floor) raw_log_energy = log_energy_floor; row[0] = raw_log_energy; }
-      if (o->htk_compat) { float e = row[0]; for (int32_t i = 0; i < o->num_ceps - 1; i++) row[i] = row[i+1]; if (!o->use_energy) e *= (float)M_SQRT2; row[o->num_ceps - 1] = e; }
-    }
-  }
-  for (int32_t b = 0; b < nb; b++) free(banks[b].w);
-  free(banks); free(win); free(tw); free(frame); free(mel); free(dct); free(lifter);
-  return T;
-}
+/* The data path (FFT, ProcessWindow, power spectrum, mel, log, DCT) lives in feat_oracle_path.inc and is compiled twice: float32 (the restatement proper) and
+ * float64 over the same float32 tables (k3o_compute_features_f64path: the exact value of the reference's formulas, the yardstick of the truth-distance gates). */
+#define REAL float
+#define FN(x) x
+#define RCOS cosf
+#define RSIN sinf
+#define RLOG logf
+#define RPOW powf
+#include "feat_oracle_path.inc"
+#undef REAL
+#undef FN
+#undef RCOS
+#undef RSIN
+#undef RLOG
+#undef RPOW
+#define REAL double
+#define FN(x) x##_f64path
+#define RCOS cos
+#define RSIN sin
+#define RLOG log
+#define RPOW pow
+#include "feat_oracle_path.inc"
+#undef REAL
+#undef FN
+#undef RCOS
+#undef RSIN
+#undef RLOG
+#undef RPOW
 
 /* transform/cmvn.cc:30-62 AccCmvnStats (double accumulators) then :64-115 ApplyCmvn, per utterance
  * (what `compute-cmvn-stats | apply-cmvn` do for a one-utterance speaker).  In place. */

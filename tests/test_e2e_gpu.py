@@ -21,14 +21,23 @@ def test_bench_line_carries_the_end_to_end_parity_gate():
     assert "error" not in line["cpu_baseline"], line["cpu_baseline"]
     par = line["e2e_parity"]; os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True); json.dump(par, open(os.path.join(ROOT, "gpurun_out", "e2e_parity_test.json"), "w"), indent=1)
     assert par["utterances"] == procs * 4
-    assert par["max_abs_feature_diff"] <= 2e-4 and par["feature_values_above_1e-4_frac"] <= 1e-5 and par["mean_abs_feature_diff"] <= 5e-6, par      # stage gate F on the bench's own audio (tail: two independent float32 errors)
+    # stage gate F on the bench's own audio: the kernel's data path is float64, so it must BE the exact value of the reference's formulas (rounded once to float32), and its
+    # distance to compute-fbank-feats must be that binary's own float32 rounding error (<= ~1.1e-4 on a few low-mel-bin values out of 2e7, measured on 512 utterances) and nothing more
+    ft = par["feature_truth"]
+    assert ft["gpu_vs_exact_max_abs"] <= 2e-6, ft
+    assert par["max_abs_feature_diff"] <= ft["reference_vs_exact_max_abs"] + 2e-6 and ft["reference_vs_exact_max_abs"] <= 1.5e-4, (par["max_abs_feature_diff"], ft)
+    assert par["feature_values_above_1e-4"] <= ft["reference_values_above_1e-4_from_exact"] + 2 and par["feature_values_above_1e-4_frac"] <= 1e-6 and par["mean_abs_feature_diff"] <= 5e-6, par
     sg = par["stage_gates"]
     assert sg["decoder_on_reference_loglikes_lattices_identical"] == sg["utterances"] == par["utterances"], sg      # gate D at the bench configuration, on the reference's own log-likelihoods
-    assert sg["nnet_on_reference_features_max_abs_loglike_diff"] <= max(1e-4, 0.5 * par["reference_vs_itself"]["max_abs_loglike_diff"]), sg      # gate N: inside the reference's own BLAS-path spread
+    # gate N at the bench's scale: two float32 evaluations of a 17-layer network cannot be asked to agree to 1e-4 (the reference's own binary moves by 8.9e-4 between two MKL code paths and is
+    # ~7e-4 from the float64 value); asserted instead: k3_nnet_forward is no further from the float64 evaluation of the network than nnet3-compute is, in the maximum and in the mean
+    nt = sg["nnet_truth"]
+    assert nt["gpu_vs_exact_max_abs"] <= nt["reference_vs_exact_max_abs"] + 5e-5 and nt["gpu_vs_exact_mean_abs"] <= 1.05 * nt["reference_vs_exact_mean_abs"], nt
+    assert sg["nnet_on_reference_features_max_abs_loglike_diff"] <= max(1e-4, 0.5 * par["reference_vs_itself"]["max_abs_loglike_diff"]), sg      # ... and inside the reference's own BLAS-path spread
     slf = par["reference_vs_itself"]; assert "error" not in slf, slf
-    # The two chains' log-likelihoods differ by what a <= 1e-4 feature difference becomes behind 17 layers (~1e-3), so the bar is the reference's own
+    # The two chains' log-likelihoods differ by what the reference's own feature rounding error becomes behind 17 layers (~1e-3), so the bar is the reference's own
     # reproducibility under a float32 difference of that size (its nnet3-compute on another MKL code path, same features, same decoder):
     assert slf["max_abs_loglike_diff"] > 0, "the second reference run did not take another code path: no yardstick"
     assert par["mean_of_max_abs_loglike_diff"] <= 3.0 * slf["mean_of_max_abs_loglike_diff"] + 1e-4, (par["mean_of_max_abs_loglike_diff"], slf["mean_of_max_abs_loglike_diff"])
-    assert par["best_path_identical_frac"] >= min(0.999, slf["best_path_identical_frac"] - 0.04), (par["best_path_identical_frac"], slf["best_path_identical_frac"])
+    assert par["best_path_identical_frac"] >= min(0.999, slf["best_path_identical_frac"] - 0.01 - 1.0 / par["utterances"]), (par["best_path_identical_frac"], slf["best_path_identical_frac"])      # (one utterance of the sample = the rate's quantum)
     assert line["roofline_feat"]["frac"] > 0 and line["cpu_baseline"]["extrapolated_all_cores"] > line["cpu_baseline"]["value"] * 0.5

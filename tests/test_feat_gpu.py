@@ -1,7 +1,11 @@
 """GPU parity: HIP fbank/MFCC/CMVN (through the C ABI) vs the oracle, the reference-binary fixtures
-and the HTK golden vectors.  Tolerances: |delta| <= 1e-4 on log-mel (north_star / SURVEY 8d parity
-gate), 3e-4 on MFCC (values up to ~150, float32 ulp 1.5e-5, 40-term sums), HTK goldens at the
-reference tests' own tolerances."""
+and the HTK golden vectors.
+
+Round 4: the kernel's data path is float64 over the reference's float32 tables, so it is held to the EXACT value of the reference's formulas
+(oracle.feat_oracle.compute_features_f64path: same tables, float64 data path) at one float32 ulp of the output -- TRUTH_TOL below -- and its distance
+to the reference BINARY is asserted to be the binary's own float32 rounding error and nothing more: |gpu - ref| <= |ref - exact| + TRUTH_TOL.  (The
+reference's binary is itself up to 1.04e-4 (log-mel, one value of the fixtures) / 3.7e-4 (lifted cepstra) from the exact value of what it computes, so a
+plain "within 1e-4 of the binary" can only be met by sharing its rounding errors, not by being right.)  HTK goldens at the reference tests' own tolerances."""
 import os, numpy as np, pytest, torch
 from tests import feat_cases as fc
 
@@ -22,21 +26,24 @@ def _opts(kind, kw):
     from kaldi_amd import feat
     return feat.mfcc_options(**kw) if kind == "mfcc" else feat.fbank_options(**kw)
 
+TRUTH_TOL = {"fbank": 2e-6, "mfcc": 1.6e-5}      # one float32 ulp of the largest outputs (log-mel < 32: 1.9e-6; lifted cepstra < 256: 1.5e-5): the kernel rounds a float64 result once
+
+def _exact(wave, kind, kw):
+    """the exact value of the reference's formulas on the reference's float32 tables (test infrastructure: oracle/feat_oracle_path.inc, REAL = double)"""
+    from oracle import feat_oracle as fo
+    return fo.compute_features_f64path(np.asarray(wave, np.float32), fo.mfcc_opts(**kw) if kind == "mfcc" else fo.fbank_opts(**kw))
+
 @pytest.mark.parametrize("name", sorted(fc.REF_CASES))
 def test_hip_vs_reference_binary(feat_golden, name):
     kind, kw, wkey = fc.REF_CASES[name]
     got = _gpu_feats([feat_golden[wkey].astype(np.float32)], _opts(kind, kw))[0]
     ref = feat_golden["ref_" + name]
     assert got.shape == ref.shape
-    # log-mel: the 1e-4 of SURVEY 8d.  Lifted cepstra (values up to 150, cepstral lifter x12 on top of a 40-term DCT): the REFERENCE's own float32
-    # binary is 1.2e-4 .. 3.7e-4 away from the float64 evaluation of its own formulas (tests/golden/feat_truth64.npz, generator committed), so two
-    # float32 implementations cannot be asked to agree to 1e-4 there.  What is asserted instead: within 3e-4 of the reference binary AND no further
-    # from the float64 truth than the reference itself is (+ 5e-5): the difference to the reference is the reference's float32 rounding, not ours.
-    tol = 1e-4 if kind == "fbank" else 3e-4
-    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
-    truth = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feat_truth64.npz"))["truth64_" + name]
-    err_ref, err_gpu = np.abs(ref - truth).max(), np.abs(got - truth).max()
-    assert err_gpu <= err_ref + 5e-5, (name, err_gpu, err_ref)
+    exact = _exact(feat_golden[wkey], kind, kw)
+    err_ref, err_gpu, d = np.abs(ref - exact).max(), np.abs(got - exact).max(), np.abs(got - ref).max()
+    assert err_gpu <= TRUTH_TOL[kind], (name, err_gpu)                      # the kernel IS the exact value, rounded once
+    assert d <= err_ref + TRUTH_TOL[kind], (name, d, err_ref)               # what separates it from the reference binary is the binary's own float32 rounding
+    assert d <= (1.1e-4 if kind == "fbank" else 4e-4), (name, d)            # ... which is <= 1.04e-4 on log-mel (one value of fbank_energy_nosnip above 1e-4) and <= 3.7e-4 on lifted cepstra in these fixtures
 
 @pytest.mark.parametrize("idx", [1, 2, 3, 4])
 def test_hip_fbank_vs_htk(feat_golden, idx):
@@ -65,7 +72,8 @@ def test_hip_ragged_batch_vs_oracle():
             ref = fo.compute_features(w, oo)
             assert g.shape == ref.shape
             if ref.size:
-                assert np.abs(g - ref).max() <= (1e-4 if kind == "fbank" else 3e-4)
+                assert np.abs(g - _exact(w, kind, kw)).max() <= TRUTH_TOL[kind]
+                assert np.abs(g - ref).max() <= (1.5e-4 if kind == "fbank" else 4e-4)      # the float32 restatement (its own rounding errors: up to 1.3e-4 on noise like this)
 
 def test_hip_cmvn(feat_golden):
     from kaldi_amd import feat
@@ -173,12 +181,12 @@ def test_hip_on_256_and_1024_point_windows_vs_reference_binary(name):
     wav = g["wav_" + name].astype(np.float32)
     got = _gpu_feats([wav, wav[: len(wav) // 2]], _opts(kind, kw)); ref = g["ref_" + name]
     assert got[0].shape == ref.shape
-    tol = 1e-4 if kind == "fbank" else 3e-4
-    assert np.abs(got[0] - ref).max() <= tol, np.abs(got[0] - ref).max()
-    # against the oracle on the second, shorter utterance of the batch
-    from oracle import feat_oracle as fo
-    want = fo.compute_features(wav[: len(wav) // 2], fo.mfcc_opts(**kw) if kind == "mfcc" else fo.fbank_opts(**kw))
-    assert got[1].shape == want.shape and np.abs(got[1] - want).max() <= tol
+    exact = _exact(wav, kind, kw); err_ref = np.abs(ref - exact).max()
+    assert np.abs(got[0] - exact).max() <= TRUTH_TOL[kind], np.abs(got[0] - exact).max()
+    assert np.abs(got[0] - ref).max() <= err_ref + TRUTH_TOL[kind] and err_ref <= (1.2e-4 if kind == "fbank" else 4e-4), (np.abs(got[0] - ref).max(), err_ref)
+    # against the exact value on the second, shorter utterance of the batch
+    want = _exact(wav[: len(wav) // 2], kind, kw)
+    assert got[1].shape == want.shape and np.abs(got[1] - want).max() <= TRUTH_TOL[kind]
 
 
 def test_unsupported_window_size_is_refused():
