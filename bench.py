@@ -144,7 +144,7 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
             "sample": f"{P} single-threaded workers x {utts_per_core} x {utt_seconds:g} s utts (like decode.sh --nj {P}; utterance u = the GPU batch's utterance u, same PCM16); aggregate = audio / slowest worker (process "
                       f"start-up and the comparison excluded: sum of the three binaries' own run times); per stage over all workers: "
                       f"reference compute-fbank-feats {audio / st[0]:.0f}x RT, reference nnet3-compute {audio / st[1]:.0f}x RT, reference LatticeFasterDecoder::Decode {audio / st[2]:.0f}x RT "
-                      "(decoder/lattice-faster-decoder.cc compiled unmodified; FST containers from oracle/ref_tools/minifst because OpenFst is not vendored)"}
+                      "(decoder/lattice-faster-decoder.cc compiled unmodified; FST containers from third_party/minifst because OpenFst is not vendored)"}
     par = None
     def summary(cs):
         nb_ = sum(c["best_path_identical"] for c in cs); bad = [c for c in cs if not c["best_path_identical"]]

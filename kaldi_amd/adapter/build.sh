@@ -14,7 +14,7 @@ if [ ! -d "$R" ]; then echo "adapter/build.sh: $R absent (GPU box?) - using preb
 # host layer's objects; the reference's sources are read-only): a no-op build is what the test suite calls a dozen times
 STAMP=$B/.built
 if [ -f $STAMP ] && [ -z "$(find $HERE/build.sh $HERE/*.cc $ROOT/tests/adapter/*.cc $ROOT/include/*.h $ROOT/kaldi_amd/host/*.h $ROOT/kaldi_amd/bin/k3_host.o $ROOT/kaldi_amd/bin/k3_lattice.o $ROOT/kaldi_amd/bin/k3_mbr.o \
-      $ROOT/oracle/ref_tools/minifst -newer $STAMP 2>/dev/null | head -1)" ]; then exit 0; fi
+      $ROOT/third_party/minifst -newer $STAMP 2>/dev/null | head -1)" ]; then exit 0; fi
 rm -f $STAMP
 mkdir -p $B/obj $B/inc/base $B/stub/fst $B/mkl
 printf '#define KALDI_VERSION "5.5-k3"\n#define KALDI_GIT_HEAD "k3"\n' > $B/inc/base/version.h
@@ -82,8 +82,8 @@ FLAGS="$FLAGS_SAVE"
 echo "built $B/nnet3-chain-grad $B/nnet3-chain-train"
 # The CudaFst / CudaDecoder adapter header (include/k3_cuda_decoder.h) compiled into a caller written against the reference's signatures.  The lattice
 # types are the reference's own (fstext/lattice-weight.h, lat/kaldi-lattice.h names); OpenFst, which /root/reference does not vendor, is stood in for
-# by the small container header of the test infrastructure (oracle/ref_tools/minifst) -- include path only, nothing of the oracle is linked.
-MF="-std=c++17 -O2 -DNDEBUG -w -I $ROOT/oracle/ref_tools/minifst -I $B/inc -I $R -I $REF/tools/CLAPACK -DHAVE_CLAPACK -DOPENFST_VER=10804 -DHAVE_EXECINFO_H=1 -DHAVE_CXXABI_H -DHAVE_CUDA=0 -pthread"
+# by the small OpenFst stand-in headers of third_party/minifst (include path only; no object code).
+MF="-std=c++17 -O2 -DNDEBUG -w -I $ROOT/third_party/minifst -I $B/inc -I $R -I $REF/tools/CLAPACK -DHAVE_CLAPACK -DOPENFST_VER=10804 -DHAVE_EXECINFO_H=1 -DHAVE_CXXABI_H -DHAVE_CUDA=0 -pthread"
 g++ $MF -I $ROOT/include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ $ROOT/tests/adapter/cuda_decoder_example.cc $B/obj/base_*.o $ROOT/kaldi_amd/lib/libk3hip.so -L/opt/rocm/lib -lamdhip64 -ldl -lm \
     -Wl,-rpath,\$ORIGIN/../../lib -Wl,-rpath,/opt/rocm/lib -o $B/cuda-decoder-example
 echo "built $B/cuda-decoder-example"

@@ -26,11 +26,21 @@ using namespace k3host;
 
 int main(int argc, char **argv) {
   try {
-    const char *usage =
+    const char *slash = strrchr(argv[0], '/'); const std::string prog = slash ? slash + 1 : argv[0];
+    const bool v1 = prog.size() >= 22 && prog.compare(prog.size() - 22, 22, "batched-wav-nnet3-cuda") == 0;      // the first-generation driver's name (no trailing 2)
+    const char *usage = v1 ?
+        "Reads in wav file(s) and simulates online decoding with neural nets\n(nnet3 setup), with optional iVector-based speaker adaptation and\noptional endpointing.  Note: some configuration values and inputs are\n"
+        "set via config files whose filenames are passed as options\n\nUsage: batched-wav-nnet3-cuda [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n" :
         "Reads in wav file(s) and decodes them with neural nets\n(nnet3 setup).  Note: some configuration values and inputs are\n"
         "set via config files whose filenames are passed as options\nOutput can either be a lattice wspecifier or a ctm filename\n"
         "Usage: batched-wav-nnet3-cuda2 [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier|ctm-wxfilename>\n";
     ParseOptions po(usage);
+    int32_t v1_drain = 10, v1_control = 2, v1_pending = 4000;
+    if (v1) {      // BatchedThreadedNnet3CudaPipelineConfig::Register (batched-threaded-nnet3-cuda-pipeline.h:65-110): the knobs of the v1 class's task queue
+      po.Register("batch-drain-size", &v1_drain, "How far to drain the batch before refilling work. (accepted: batches here are whole --max-batch-size groups of utterances)");
+      po.Register("cuda-control-threads", &v1_control, "The number of pipeline control threads for the CUDA work. (accepted: one control thread drives the front-end and decoder streams here)");
+      po.Register("max-outstanding-queue-length", &v1_pending, "Number of files to allow to be outstanding at a time. (accepted: two batches are in flight)");
+    }
     bool write_compact = true, write_lattice = true, segmentation = false, determinize = true, minimize = false, phone_det = true, word_det = true, gpu_feat = true, use_online = false, reset_on_endpoint = false, tensor_cores = false, tf32 = false, add_pitch = false, debug_comp = false, cache_mem = true;
     bool alternate_decoders = true;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, worker_threads = -1, copy_threads = 2, frames_per_chunk = 50, subsampling = 1;
@@ -236,7 +246,7 @@ int main(int argc, char **argv) {
       return b;
     };
     struct Raw { std::vector<std::string> keys; std::vector<int64_t> info; std::vector<int32_t> sf, ss, as, ad, ai, ao; std::vector<float> sc, sfin, ag, aa; };
-    int post_err = 0;
+    int post_err = 0; double tot_like = 0.0; int64_t like_frames = 0;      // (v1) GetDiagnosticsAndPrintOutput: likelihood of the best path, per frame
     auto post_process = [&](std::shared_ptr<Raw> r) {
       int64_t s0 = 0, a0 = 0; const int U = (int)r->keys.size();
       for (int u = 0; u < U; u++) {
@@ -248,6 +258,7 @@ int main(int argc, char **argv) {
         lat.arc_olabel.assign(r->ao.begin() + a0, r->ao.begin() + a0 + na); lat.arc_graph.assign(r->ag.begin() + a0, r->ag.begin() + a0 + na); lat.arc_ac.assign(r->aa.begin() + a0, r->aa.begin() + a0 + na);
         for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == graph_start) lat.start = (int32_t)s;
         Connect(&lat);
+        if (v1) { std::vector<int32_t> ali, words; double gc = 0.0, ac = 0.0; if (BestPath(lat, &ali, &words, &gc, &ac)) { tot_like += -(gc + ac); like_frames += (int64_t)ali.size(); } else K3H_WARN << "Empty lattice."; }
         if (det_pool) det_pool->Run(key, std::move(lat));
         else if (write_compact) { CompactLattice clat; ConvertLattice(lat, &clat); writer->WriteCompactLattice(key, clat); }
         else writer->WriteLattice(key, lat);
@@ -315,16 +326,21 @@ int main(int argc, char **argv) {
       auto r = std::make_shared<Raw>(); r->info.resize(10 * (size_t)U);
       K3H_LATTICE_INFO(d, r->info.data());
       const auto t_c = tick();
-      if (b.iter == 0 && (writer || ctm_mode)) {
+      if ((b.iter == 0 || v1) && (writer || ctm_mode)) {
         int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += r->info[10 * u]; NA += r->info[10 * u + 1]; }
         r->sf.resize(NS + 1); r->ss.resize(NS + 1); r->sc.resize(NS + 1); r->sfin.resize(NS + 1);
         r->as.resize(NA + 1); r->ad.resize(NA + 1); r->ai.resize(NA + 1); r->ao.resize(NA + 1); r->ag.resize(NA + 1); r->aa.resize(NA + 1);
         K3H_CHECK_K3(k3_decoder_get_raw_lattices(d, r->sf.data(), r->ss.data(), r->sc.data(), r->sfin.data(), r->as.data(), r->ad.data(), r->ai.data(), r->ao.data(), r->ag.data(), r->aa.data()));
         r->keys = std::move(b.keys);
+        if (v1 && b.iter > 0) for (auto &key : r->keys) key = std::to_string(b.iter) + "-" + key;      // "make key unique for each iteration" (batched-wav-nnet3-cuda.cc:211-214)
         if (post.valid()) post.get();          // keeps the records in order; an error in the previous batch's post stage surfaces here
         post = std::async(std::launch::async, post_process, r);
       } else {
         for (int u = 0; u < U; u++) if (r->info[10 * u + 2] != 0 || r->info[10 * u] == 0) { K3H_WARN << "Failed to decode utterance with id " << b.keys[u]; num_err++; }
+      }
+      if (v1 && (k + 1 == plan_batches.size() || plan_batches[k + 1][0] != plan_batches[k][0])) {      // the iteration's last batch: its group is complete (:292-299)
+        const double tt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); const int it = (int)plan_batches[k][0];
+        K3H_LOG << "~Group " << it << " completed Aggregate Total Time: " << tt << " Audio: " << total_audio * (it + 1) << " RealTimeX: " << total_audio * (it + 1) / tt;
       }
       K3H_VLOG(1) << "batch " << k << ": waited " << waited << " ms for the reader, " << ms(t_b, t_c) << " ms decoder of this batch (+ front end of the next one queued behind it), " << ms(t_c, tick()) << " ms lattices to the host + hand-over";
     };
@@ -359,6 +375,7 @@ int main(int argc, char **argv) {
     if (writer) writer->Flush();
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
+    if (v1) K3H_LOG << "Overall likelihood per frame was " << (like_frames ? tot_like / like_frames : 0.0) << " per frame over " << like_frames << " frames.";
     K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio * iterations << " RealTimeX: " << total_audio * iterations / total_time;
     k3_decoder_destroy(dec); if (dec_b) k3_decoder_destroy(dec_b); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan); if (ivx) k3_ivector_destroy(ivx);
     return 0;

@@ -4,7 +4,7 @@
 // This restates the algorithm of the reference's lat/determinize-lattice-pruned.cc (LatticeDeterminizerPruned, cited per function)
 // in this library's own data structures: a CSR input automaton, a string trie addressed by int32 ids instead of Entry pointers,
 // std containers for the subset hashes.  PINNED to the reference's own source: OpenFst is not vendored in /root/reference, but
-// lat/determinize-lattice-pruned.cc compiles unmodified against a stand-in for the part of OpenFst it touches (oracle/ref_tools/minifst
+// lat/determinize-lattice-pruned.cc compiles unmodified against a stand-in for the part of OpenFst it touches (third_party/minifst
 // -> oracle/_ref/bin/ref-lattice-determinize), and the programs built on this file print the same CompactLattices as that binary,
 // character for character, on random lattices, exact cost ties, decoder lattices and the --max-mem prune-and-retry path, for the
 // word-level and the phone+word entry points (tests/test_lattice_det.py; digests of the reference output in tests/golden/).

@@ -13,7 +13,7 @@
 #   fst/fst-decl.h   (OpenFst forward declarations only; hmm/transition-model.h:26 includes it)
 # OpenFst 1.8.4 is not vendored, so the reference's own build of src/decoder, src/lat, src/fstext is impossible here.  But
 # decoder/lattice-faster-decoder.{h,cc} only touch a small part of OpenFst's public interface (a graph's read interface, a vector
-# FST to fill, arc iterators, a memory pool): oracle/ref_tools/minifst/ is a stand-in for exactly that part, and with it the
+# FST to fill, arc iterators, a memory pool): third_party/minifst/ is a stand-in for exactly that part, and with it the
 # reference's decoder source compiles UNMODIFIED into oracle/_ref/bin/ref-lattice-decoder (driver: ref_tools/ref_lattice_decoder.cc).
 # That binary pins the restated decoder oracle (oracle/lattice_faster_oracle.cc, tests/test_oracle_decoder.py).  With TopSort / ArcSort /
 # Invert / Connect added to the stand-in, lat/determinize-lattice-pruned.cc compiles unmodified too: oracle/_ref/bin/
@@ -78,7 +78,7 @@ link dump-tid2pdf        $HERE/ref_tools/dump_tid2pdf.cc
 link dump-tidinfo        $HERE/ref_tools/dump_tidinfo.cc
 # the reference's LatticeFasterDecoder over the OpenFst stand-in (include path: minifst first, so that fst/*.h, fstext/fstext-lib.h,
 # lat/*.h and decoder/grammar-fst.h resolve to the stand-in; every other header, and the .cc itself, is the reference's)
-MF="-std=c++17 -O2 -DNDEBUG -w -I $HERE/ref_tools/minifst -I $W/inc -I $R -I $REF/tools/CLAPACK -DHAVE_CLAPACK -DOPENFST_VER=10804 -DHAVE_EXECINFO_H=1 -DHAVE_CXXABI_H -DHAVE_CUDA=0 -pthread"
+MF="-std=c++17 -O2 -DNDEBUG -w -I $HERE/../third_party/minifst -I $W/inc -I $R -I $REF/tools/CLAPACK -DHAVE_CLAPACK -DOPENFST_VER=10804 -DHAVE_EXECINFO_H=1 -DHAVE_CXXABI_H -DHAVE_CUDA=0 -pthread"
 mkdir -p $W/obj_minifst
 g++ $MF -c $R/decoder/lattice-faster-decoder.cc -o $W/obj_minifst/lattice-faster-decoder.o
 g++ $MF $HERE/ref_tools/ref_lattice_decoder.cc $W/obj_minifst/lattice-faster-decoder.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-lattice-decoder

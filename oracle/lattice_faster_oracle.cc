@@ -7,7 +7,7 @@
  * PINNED against the reference's own source: the reference holds no golden vectors or tests for its decoders
  * (decoder/Makefile:6 and cudadecoder/Makefile:16 have empty TESTFILES) and OpenFst 1.8.4 is neither installed nor
  * vendored (tools/Makefile:10), but decoder/lattice-faster-decoder.{h,cc} compile UNMODIFIED against a stand-in for the
- * small part of OpenFst they touch (oracle/ref_tools/minifst, recipe in oracle/build_ref.sh -> oracle/_ref/bin/
+ * small part of OpenFst they touch (third_party/minifst, recipe in oracle/build_ref.sh -> oracle/_ref/bin/
  * ref-lattice-decoder).  Mode 0 of this file reproduces that binary's GetRawLattice output exactly -- states per
  * frame, arcs, labels, float bits, sharing of states, up to state renaming -- on every case of tests/decoder_cases.py
  * (active-state limits, beams, prune intervals, hash sizes; tests/test_oracle_decoder.py, live where oracle/_ref is

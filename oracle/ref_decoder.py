@@ -1,6 +1,6 @@
 """oracle/ref_decoder.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 Front-end of oracle/_ref/bin/ref-lattice-decoder: the REFERENCE's own decoder/lattice-faster-decoder.cc, compiled unmodified
-against the OpenFst stand-in of oracle/ref_tools/minifst (build: oracle/build_ref.sh).  Used only to pin the restated decoder
+against the OpenFst stand-in of third_party/minifst (build: oracle/build_ref.sh).  Used only to pin the restated decoder
 oracle (oracle/lattice_faster_oracle.cc) in tests/test_oracle_decoder.py."""
 import os, subprocess, tempfile
 import numpy as np

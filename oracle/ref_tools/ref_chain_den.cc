@@ -1,6 +1,6 @@
 // oracle/ref_tools/ref_chain_den.cc -- TEST INFRASTRUCTURE.  Runs the REFERENCE's LF-MMI denominator -- chain/chain-den-graph.cc (the
 // DenominatorGraph constructor) and chain/chain-denominator.cc (DenominatorComputation::Forward / Backward, CPU path), both compiled
-// unmodified from /root/reference against the OpenFst stand-in in oracle/ref_tools/minifst -- on a denominator FST and a network
+// unmodified from /root/reference against the OpenFst stand-in in third_party/minifst -- on a denominator FST and a network
 // output read from one binary file, and writes the objective, Backward()'s verdict, the graph's initial probabilities and the
 // derivative to another.  oracle/chain_oracle.py (the numpy restatement) and the HIP kernel (kaldi_amd/csrc/k3_chain.hip) are pinned to it.
 //   ref-chain-den <in.bin> <out.bin>

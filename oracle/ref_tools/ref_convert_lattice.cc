@@ -1,6 +1,6 @@
 // oracle/ref_tools/ref_convert_lattice.cc -- TEST INFRASTRUCTURE.  Runs the REFERENCE's ConvertLattice(Lattice -> CompactLattice)
 // (fstext/lattice-utils-inl.h:33-86 with Factor, fstext/factor-inl.h, both compiled unmodified from /root/reference against the
-// OpenFst stand-in in oracle/ref_tools/minifst) and prints the CompactLattices in Kaldi's text layout; kaldi_amd/host/k3_lattice.cc's
+// OpenFst stand-in in third_party/minifst) and prints the CompactLattices in Kaldi's text layout; kaldi_amd/host/k3_lattice.cc's
 // ConvertLattice is pinned to this output in tests/test_lattice_det.py.
 //   ref-convert-lattice <lattices.txt> <out.txt>
 #include <cstdlib>

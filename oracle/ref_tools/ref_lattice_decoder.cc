@@ -1,5 +1,5 @@
 // oracle/ref_tools/ref_lattice_decoder.cc -- TEST INFRASTRUCTURE.  Runs the REFERENCE's LatticeFasterDecoder -- decoder/
-// lattice-faster-decoder.cc compiled unmodified from /root/reference against the OpenFst stand-in in oracle/ref_tools/minifst --
+// lattice-faster-decoder.cc compiled unmodified from /root/reference against the OpenFst stand-in in third_party/minifst --
 // on a graph, a log-likelihood matrix and a transition-id -> pdf map read from one binary file, and writes the raw lattice
 // (GetRawLattice, before fst::Connect) to another.  oracle/lattice_faster_oracle.cc (the restatement every GPU test is checked
 // against) is pinned to this program's output in tests/test_oracle_decoder.py.

@@ -1,5 +1,5 @@
 // oracle/ref_tools/ref_lattice_determinize.cc -- TEST INFRASTRUCTURE.  Runs the REFERENCE's lattice determinization --
-// lat/determinize-lattice-pruned.cc compiled unmodified from /root/reference against the OpenFst stand-in in oracle/ref_tools/minifst --
+// lat/determinize-lattice-pruned.cc compiled unmodified from /root/reference against the OpenFst stand-in in third_party/minifst --
 // the way the reference's programs call it, and prints the CompactLattices in Kaldi's text layout.  kaldi_amd/host/k3_lattice.cc (the
 // restated determinizer behind the drop-in programs) is pinned to this program's output in tests/test_lattice_det.py.
 //   ref-lattice-determinize word  <beam> <acoustic-scale> <lattices.txt> <out.txt>            = latbin/lattice-determinize-pruned.cc:96-140

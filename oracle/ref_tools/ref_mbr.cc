@@ -1,5 +1,5 @@
 // oracle/ref_tools/ref_mbr.cc -- TEST INFRASTRUCTURE.  Runs the REFERENCE's MinimumBayesRisk (lat/sausages.cc, compiled unmodified from /root/reference against
-// the OpenFst stand-in in oracle/ref_tools/minifst) on CompactLattices made from raw lattices by the reference's ConvertLattice; kaldi_amd/host/k3_mbr.cc is pinned to this
+// the OpenFst stand-in in third_party/minifst) on CompactLattices made from raw lattices by the reference's ConvertLattice; kaldi_amd/host/k3_mbr.cc is pinned to this
 // output in tests/test_lattice_det.py.      ref-mbr <lattices.txt> <out.txt> [decode-mbr(1|0) [print-silence(0|1)]]
 // Output per lattice: "key", "words w...", "times b e ...", "conf c ...", "risk r", "bins n" and per bin "bin b e word:post ...".
 #include <cstdlib>

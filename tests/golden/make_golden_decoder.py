@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Records tests/golden/decoder_ref_golden.json: for every case of tests/decoder_cases.py the size and the canonical digest
 (tests/lattice_sig.py) of the raw lattice produced by the REFERENCE's own LatticeFasterDecoder (oracle/_ref/bin/ref-lattice-decoder =
-/root/reference/src/decoder/lattice-faster-decoder.cc compiled unmodified against oracle/ref_tools/minifst).  Needs /root/reference
+/root/reference/src/decoder/lattice-faster-decoder.cc compiled unmodified against third_party/minifst).  Needs /root/reference
 (run oracle/build_ref.sh first); the JSON travels to machines that have neither."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)

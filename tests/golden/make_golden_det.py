@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Records tests/golden/det_ref_golden.json: the text output of the REFERENCE's lattice determinization (oracle/_ref/bin/
-ref-lattice-determinize = /root/reference/src/lat/determinize-lattice-pruned.cc compiled unmodified against oracle/ref_tools/minifst,
+ref-lattice-determinize = /root/reference/src/lat/determinize-lattice-pruned.cc compiled unmodified against third_party/minifst,
 called the way lattice-determinize-pruned / lattice-determinize-phone-pruned call it) on the lattices of tests/test_lattice_det.py's
 REF_CASES.  Needs /root/reference (run oracle/build_ref.sh first); the JSON travels to machines that have neither."""
 import json, os, subprocess, sys, tempfile

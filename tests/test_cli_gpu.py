@@ -605,3 +605,101 @@ def test_online_program_with_an_ivector_model_equals_the_python_pipeline(tmp_pat
     # without the extractor: the reference's message
     r = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + tail + [f"ark:{td}/x.ark"], capture_output=True, text=True)
     assert r.returncode != 0 and "Neural net expects 'ivector' features with dimension 16 but you provided 0" in r.stderr
+
+
+# ---- round 4: the rest of the cudafeatbin family and the first-generation decoder driver
+@pytest.mark.parametrize("kind,flags", [("fbank", ["--dither=0", "--num-mel-bins=40"]), ("mfcc", ["--dither=0", "--num-mel-bins=40", "--num-ceps=40", "--low-freq=20", "--high-freq=-400"])])
+def test_online_batched_feature_programs_match_the_whole_utterance_programs_and_the_reference(tmp_path, kind, flags):
+    """compute-{fbank,mfcc}-online-batched-cuda (cudafeatbin/compute-fbank-online-batched-cuda.cc:64): audio in chunks of samples over a few channels -> the rows of the
+    whole-utterance program bit for bit, and the reference's CPU binary within its own rounding error"""
+    from oracle import kaldi_io as kio
+    td = str(tmp_path); lens = [16000, 4001, 23001, 399 + 160 * 3, 30011, 12345, 8000]; _wavs(td, lens)
+    w = subprocess.run([os.path.join(BIN, f"compute-{kind}-feats-cuda")] + flags + [f"scp:{td}/wav.scp", f"ark:{td}/whole.ark"], capture_output=True, text=True); assert w.returncode == 0, w.stderr
+    whole = kio.read_ark(f"{td}/whole.ark")
+    for chunk, lanes, ch in ((10000, 3, 4), (777, 2, 2), (100000, 7, 7)):
+        g = subprocess.run([os.path.join(BIN, f"compute-{kind}-online-batched-cuda")] + flags + [f"--chunk-length={chunk}", f"--batch-size={lanes}", f"--num-channels={ch}", f"scp:{td}/wav.scp", f"ark:{td}/on.ark"], capture_output=True, text=True)
+        assert g.returncode == 0, g.stderr
+        assert f"Computed Online Features for  {len(lens)} files" in g.stderr and "RTFX:" in g.stderr
+        on = kio.read_ark(f"{td}/on.ark")
+        assert list(on) == list(whole)
+        for k in whole: assert on[k].shape == whole[k].shape and np.array_equal(on[k], whole[k]), (chunk, k)
+    if os.path.exists(os.path.join(REF, f"compute-{kind}-feats")):
+        r = subprocess.run([os.path.join(REF, f"compute-{kind}-feats")] + flags + [f"scp:{td}/wav.scp", f"ark:{td}/ref.ark"], env=ENV, capture_output=True, text=True); assert r.returncode == 0, r.stderr
+        ref = kio.read_ark(f"{td}/ref.ark")
+        for k in ref: assert np.abs(ref[k] - whole[k]).max() <= (1e-4 if kind == "fbank" else 3e-4), k
+    exe = os.path.join(BIN, f"compute-{kind}-online-batched-cuda")
+    assert subprocess.run([exe, f"scp:{td}/wav.scp"], capture_output=True).returncode == 1                                                        # usage
+    b = subprocess.run([exe] + flags + ["--num-channels=2", "--batch-size=3", f"scp:{td}/wav.scp", f"ark:{td}/x.ark"], capture_output=True, text=True); assert b.returncode == 255 and "num-channels" in b.stderr
+    b = subprocess.run([exe] + flags + ["--sample-frequency=8000", f"scp:{td}/wav.scp", f"ark:{td}/x.ark"], capture_output=True, text=True); assert b.returncode == 255 and "mismatched sampling rate" in b.stderr
+
+
+def test_compute_online_feats_cuda_whole_utterance_driver(tmp_path):
+    """compute-online-feats-cuda (cudafeatbin/compute-online-feats-cuda.cc:30): the whole-utterance form of the online feature pipeline; features = compute-fbank-feats-cuda's,
+    an empty i-vector per utterance without an extractor, a broken file is a counted failure"""
+    from oracle import kaldi_io as kio
+    td = str(tmp_path); lens = [16000, 4001, 23001]; _wavs(td, lens); open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    open(f"{td}/wav.scp", "a").write(f"broken {td}/nonexistent.wav\n")
+    w = subprocess.run([os.path.join(BIN, "compute-fbank-feats-cuda"), f"--config={td}/fbank.conf", f"scp:{td}/wav.scp", f"ark:{td}/whole.ark"], capture_output=True, text=True); assert w.returncode == 0, w.stderr
+    g = subprocess.run([os.path.join(BIN, "compute-online-feats-cuda"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", f"scp:{td}/wav.scp", f"ark:{td}/iv.ark", f"ark:{td}/f.ark"], capture_output=True, text=True)
+    assert g.returncode == 0, g.stderr
+    assert "Processing Utterance utt0" in g.stderr and "Failed to compute features for utterance broken" in g.stderr and "Processed 4 utterances with 1 failures." in g.stderr
+    whole, got, iv = kio.read_ark(f"{td}/whole.ark"), kio.read_ark(f"{td}/f.ark"), kio.read_ark(f"{td}/iv.ark")
+    assert list(got) == list(whole) == ["utt0", "utt1", "utt2"] and list(iv) == list(got)
+    for k in whole: assert np.array_equal(got[k], whole[k]) and iv[k].size == 0
+    assert subprocess.run([os.path.join(BIN, "compute-online-feats-cuda"), f"scp:{td}/wav.scp"], capture_output=True).returncode == 1
+
+
+@pytest.mark.parametrize("flags", [[], ["--cmn-window=100", "--speaker-frames=100", "--global-frames=10", "--norm-vars=true", "--skip-dims=0:5"]])
+def test_apply_batched_cmvn_online_cuda_matches_the_reference_binary(tmp_path, cmvn_online_golden, flags):
+    """apply-batched-cmvn-online-cuda (cudafeatbin/apply-batched-cmvn-online-cuda.cc:49): online CMVN in chunks of frames over a few channels = the rows of the
+    reference's online2bin/apply-cmvn-online on the whole utterances, bit for bit, for any chunking (window statistics and raw-frame history carried per channel)"""
+    from oracle import kaldi_io as kio
+    g = cmvn_online_golden; td = str(tmp_path); rng = np.random.default_rng(11)
+    feats = {"utt_a": g["feats_a"], "utt_b": g["feats_b"], "utt_c": (rng.normal(0, 3, (1303, g["feats_a"].shape[1])) + 1.0).astype(np.float32), "utt_d": g["feats_a"][:1]}
+    kio.write_ark(f"{td}/in.ark", feats)
+    with open(f"{td}/g.txt", "w") as f: f.write(" [\n" + "\n".join("  " + " ".join(repr(float(x)) for x in row) for row in g["global"]) + " ]\n")
+    a = subprocess.run([os.path.join(BIN, "apply-cmvn-online-cuda")] + flags + [f"{td}/g.txt", f"ark:{td}/in.ark", f"ark:{td}/whole.ark"], capture_output=True, text=True); assert a.returncode == 0, a.stderr
+    whole = kio.read_ark(f"{td}/whole.ark")
+    if os.path.exists(os.path.join(REF, "apply-cmvn-online")):
+        q = subprocess.run([os.path.join(REF, "apply-cmvn-online")] + flags + [f"{td}/g.txt", f"ark:{td}/in.ark", f"ark:{td}/ref.ark"], env=ENV, capture_output=True, text=True); assert q.returncode == 0, q.stderr
+        ref = kio.read_ark(f"{td}/ref.ark")
+        for k in ref: assert np.array_equal(ref[k], whole[k]), k
+    for chunk, lanes, ch in ((10000, 100, 200), (64, 2, 3), (150, 3, 3), (1, 5, 5)):
+        if chunk == 1: feats_run = {k: v[:40] for k, v in feats.items()}; kio.write_ark(f"{td}/in1.ark", feats_run); src = f"ark:{td}/in1.ark"      # (one frame per call: short streams)
+        else: feats_run = feats; src = f"ark:{td}/in.ark"
+        b = subprocess.run([os.path.join(BIN, "apply-batched-cmvn-online-cuda")] + flags + [f"--chunk-length={chunk}", f"--batch-size={lanes}", f"--num-channels={ch}", "--stats-coarsening-factor=1", f"{td}/g.txt", src, f"ark:{td}/b.ark"],
+                           capture_output=True, text=True)
+        assert b.returncode == 0, b.stderr
+        assert f"Applied online CMVN to {len(feats)} files, or {sum(v.shape[0] for v in feats_run.values())} frames." in b.stderr
+        got = kio.read_ark(f"{td}/b.ark"); assert list(got) == list(feats)
+        for k in got: assert got[k].shape == feats_run[k].shape and np.array_equal(got[k], whole[k][:feats_run[k].shape[0]]), (chunk, k)
+    exe = os.path.join(BIN, "apply-batched-cmvn-online-cuda")
+    assert subprocess.run([exe, f"{td}/g.txt"], capture_output=True).returncode == 1
+    b = subprocess.run([exe, "--num-channels=2", "--batch-size=3", f"{td}/g.txt", f"ark:{td}/in.ark", f"ark:{td}/x.ark"], capture_output=True, text=True); assert b.returncode == 255 and "num-channels" in b.stderr
+
+
+def test_batched_wav_nnet3_cuda_first_generation_driver(tmp_path):
+    """batched-wav-nnet3-cuda (cudadecoderbin/batched-wav-nnet3-cuda.cc:114): the v1 driver's command line over the same pipeline -- same lattices as batched-wav-nnet3-cuda2,
+    every iteration written under "<iteration>-<utt>", "~Group" lines, the likelihood-per-frame line, the v1-only options accepted"""
+    td = str(tmp_path); N = 120; lens = [16000, 9000, 23001, 12000, 8000]
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    synth.make_hclg(3000, 8000, N, seed=11, start_degree=50).write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-batch-size=3"]
+    tail = [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp"]
+    a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + tail + [f"ark,t:{td}/v2.txt"], capture_output=True, text=True); assert a.returncode == 0, a.stderr
+    b = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda")] + common + ["--iterations=2", "--batch-drain-size=2", "--cuda-control-threads=1", "--max-outstanding-queue-length=100", "--cuda-worker-threads=4"] + tail + [f"ark,t:{td}/v1.txt"],
+                       capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    assert "~Group 0 completed Aggregate Total Time:" in b.stderr and "~Group 1 completed" in b.stderr and "Decoded 5 utterances, 0 with errors." in b.stderr
+    assert "Overall likelihood per frame was" in b.stderr and "Overall:  Aggregate Total Time:" in b.stderr
+    rec = lambda path: {blk.split("\n", 1)[0].strip(): blk.split("\n", 1)[1] for blk in open(path).read().strip().split("\n\n")}
+    r2, r1 = rec(f"{td}/v2.txt"), rec(f"{td}/v1.txt")
+    assert sorted(r1) == sorted(list(r2) + ["1-" + k for k in r2]), sorted(r1)
+    for k in r2: assert r1[k] == r2[k] and r1["1-" + k] == r2[k], k      # determinized CompactLattices, character for character
+    assert float(b.stderr.split("per frame over ")[1].split(" frames")[0]) > 0
+    # cuda2-only behaviour stays with cuda2: a CTM file name as output is refused without a postprocessor by both; the v1-only options are unknown to cuda2
+    u = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--batch-drain-size=2"] + common + tail + [f"ark,t:{td}/x.txt"], capture_output=True, text=True); assert u.returncode != 0
+    assert subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda"), "x"], capture_output=True).returncode == 1

@@ -1,6 +1,6 @@
 """Host-side word-level lattice determinization (kaldi_amd/host/k3_lattice.cc, the lattice-determinize-pruned program): CPU only.
 Two kinds of checks: (1) at the end of the file, character-for-character equality with the REFERENCE's own determinizer source
-(compiled unmodified against the OpenFst stand-in of oracle/ref_tools/minifst); (2) the defining properties the reference's own
+(compiled unmodified against the OpenFst stand-in of third_party/minifst); (2) the defining properties the reference's own
 determinize-lattice-pruned-test.cc checks through RandEquivalent, verified by exhaustive path enumeration on small random lattices:
   * the output is deterministic on word labels and has no epsilon arcs,
   * every word sequence whose best raw path is within the beam is present,
@@ -353,7 +353,7 @@ def test_convert_lattice_folds_chains_and_keeps_every_path():
 
 # ---- the restated determinizer against the REFERENCE's own source ----------------------------------------------------------------
 # oracle/_ref/bin/ref-lattice-determinize is /root/reference/src/lat/determinize-lattice-pruned.cc compiled unmodified against a
-# stand-in for the part of OpenFst it touches (oracle/ref_tools/minifst, oracle/build_ref.sh), driven like the reference's
+# stand-in for the part of OpenFst it touches (third_party/minifst, oracle/build_ref.sh), driven like the reference's
 # lattice-determinize-pruned / lattice-determinize-phone-pruned.  The programs here must print the same CompactLattices character for
 # character: same states in the same order, same arcs, same weights to the 6 digits of the text format, same transition-id strings.
 REF_EXE = os.path.join(ROOT, "oracle", "_ref", "bin", "ref-lattice-determinize")

@@ -132,7 +132,7 @@ def test_max_active_and_min_active_cutoffs():
 
 # ---- the restated decoder against the REFERENCE's own decoder source ------------------------------------------------------------
 # oracle/_ref/bin/ref-lattice-decoder is /root/reference/src/decoder/lattice-faster-decoder.cc compiled unmodified against a stand-in
-# for the part of OpenFst it touches (oracle/ref_tools/minifst, oracle/build_ref.sh).  The oracle's literal mode (mode 0) must
+# for the part of OpenFst it touches (third_party/minifst, oracle/build_ref.sh).  The oracle's literal mode (mode 0) must
 # reproduce its GetRawLattice output exactly: same states per frame, same arcs, same labels, same float bits, same sharing of states
 # -- compared up to state renaming (tests/lattice_sig.py), for all limits / beams / prune intervals / hash sizes of decoder_cases.
 import json, os
