@@ -139,7 +139,8 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
     audio = sum(r[0] for r in res); per_core = [r[0] / r[1] for r in res]; st = np.sum([r[2] for r in res], axis=0)
     base = {"value": audio / max(r[1] for r in res), "unit": "RTFx (audio-s/wall-s)", "cores": P, "kind": "reference", "host_cores_available": ncores,
             "per_core_rtfx_mean": float(np.mean(per_core)), "extrapolated_all_cores": float(np.mean(per_core)) * ncores,
-            "extrapolated_all_cores_note": f"per-core mean x {ncores} host cores (not measured: memory bandwidth and SMT are shared; an upper bound)",
+            "extrapolated_all_cores_note": (f"per-core mean x {ncores} host cores (not measured: memory bandwidth and SMT are shared; an upper bound)" if P < ncores else
+                                            f"all {ncores} host cores were used: `value` is the measured whole-host figure, this is its per-core mean x cores (no extrapolation)"),
             "wall_s_including_process_startup": wall,
             "sample": f"{P} single-threaded workers x {utts_per_core} x {utt_seconds:g} s utts (like decode.sh --nj {P}; utterance u = the GPU batch's utterance u, same PCM16); aggregate = audio / slowest worker (process "
                       f"start-up and the comparison excluded: sum of the three binaries' own run times); per stage over all workers: "
@@ -215,12 +216,14 @@ def main():
     ap.add_argument("--no-two-pass", action="store_true", help="skip the second (order-independent decoder) measurement")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: H2D, fbank, TDNN-F and decoder of a batch strictly after the previous batch (stage_ms then adds up to ms_per_step)")
     ap.add_argument("--one-decoder", action="store_true", help="one decoder object instead of two alternating ones (the default keeps two sets of lane pools -- 2 x 41 GB of the 288 GB at the bench configuration -- so that a batch's token passing starts under the previous batch's pruning kernel and lattice fetch)")
-    ap.add_argument("--cpu-procs", type=int, default=64, help="cpu_baseline / e2e_parity: single-threaded reference workers (capped by the host's cores)")
-    ap.add_argument("--cpu-utts-per-core", type=int, default=8, help="cpu_baseline / e2e_parity: utterances per worker (utterance u = the GPU batch's utterance u while u < --utts)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="cpu_baseline / e2e_parity: single-threaded reference workers (0 = one per host core: the baseline is then MEASURED on the whole host, no extrapolation)")
+    ap.add_argument("--cpu-utts-per-core", type=int, default=0, help="cpu_baseline / e2e_parity: utterances per worker (0 = the batch spread over the workers, at least 2 each; utterance u = the GPU batch's utterance u while u < --utts)")
     ap.add_argument("--no-extras", action="store_true", help="skip the chain_objf / chain_train legs (for the record only; not part of `value`)")
     ap.add_argument("--measure-traffic", action="store_true", help="roofline.traffic measured in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; no trace domains) of `bench.py --steps 1 --warmup 0` as child processes (adds ~2 min)")
     ap.add_argument("--lattice-digest", action="store_true", help="decode_stats.lattice_digest: a hash of the canonical form of every raw lattice of the last timed batch")
     ap.add_argument("--truth-utts", type=int, default=64, help="e2e_parity.stage_gates.nnet_truth: utterances whose log-likelihoods are also evaluated in float64 on the host (1.8 s each)")
+    ap.add_argument("--host-load-replicas", type=int, default=1, help="rehearsal of an N-GPU node's HOST load on one GPU: every batch's host tail (Connect + determinization) runs this many times concurrently, each copy on --det-threads threads "
+                                                                         "(default: cores / replicas), i.e. what the box's cores see when this many ranks hand over lattices at the same rate; `value` then says whether the host keeps up")
     ap.add_argument("--det-threads", type=int, default=0, help="host threads of the determinization pool (0 = all cores / ranks)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -237,7 +240,7 @@ def main():
     from kaldi_amd import feat, nnet3, synth, decoder, parallel, hostlib
 
     U, nsamp = args.utts, int(16000 * args.utt_seconds)
-    det_threads = args.det_threads or max(1, (os.cpu_count() or 1) // world)
+    det_threads = args.det_threads or max(1, (os.cpu_count() or 1) // (world * max(1, args.host_load_replicas)))
     # synthetic workload: Gaussian PCM16 sigma 3000, utterance u of rank r = synth.gaussian_pcm16(nsamp, 1234 + 100000 r + u), in page-locked host memory
     # (one spare utterance behind the batch: timed step k reads the batch from sample offset shift(k), so no two steps decode the same audio);
     # 17L-768/96-6024 TDNN-F, seed 1
@@ -264,7 +267,21 @@ def main():
     if not args.no_decode:
         graph = synth.make_hclg(args.graph_states, args.graph_arcs, num_pdfs) if rank == 0 else None
         t0 = time.perf_counter()
-        cfst = parallel.broadcast_graph(graph, synth.tid2pdf(num_pdfs), rank, world, dev)
+        # N > 1 over RCCL: the graph travels through the PRODUCT's own C ABI (k3_comm_create + k3_fst_bcast: parallel.broadcast_graph_abi), in a worker thread with a deadline, and
+        # the ranks agree (one all-reduce) on whether every one of them got it; otherwise -- and in the gloo rehearsal on one device, where RCCL cannot put two ranks on a GPU --
+        # the same image goes through torch.distributed (parallel.broadcast_graph).  Either way before the timed region, once.
+        cfst = None; rccl_ranks = 0; bcast_via = "none (one rank)" if world == 1 else "torch.distributed broadcast of the k3_fst image"
+        if world > 1 and dist.get_backend() == "nccl" and os.environ.get("K3_BENCH_ABI_BCAST", "1") == "1":
+            import threading
+            box = {}; id_file = os.path.join(tempfile.gettempdir(), "k3_bench_rccl_%s_%s.id" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run")))
+            def _abi():
+                try: torch.cuda.set_device(local); box["r"] = parallel.broadcast_graph_abi(graph, synth.tid2pdf(num_pdfs), rank, world, id_file, timeout_s=90)
+                except Exception as e: box["e"] = repr(e)
+            th = threading.Thread(target=_abi, daemon=True); th.start(); th.join(150)
+            ok = torch.tensor([1 if "r" in box else 0], device=dev); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1: cfst, rccl_ranks = box["r"]; bcast_via = "k3_comm_create + k3_fst_bcast (RCCL through the C ABI)"
+            else: bcast_via += " (k3_fst_bcast did not complete on every rank: %s)" % (box.get("e") or ("timeout" if th.is_alive() else "another rank failed"))
+        if cfst is None: cfst = parallel.broadcast_graph(graph, synth.tid2pdf(num_pdfs), rank, world, dev)
         t_bcast = time.perf_counter() - t0
         caps = dict(frame_tokens_cap=65536, frame_cands_cap=131072, lane_tokens_cap=int(4500 * args.utt_seconds * 33.4) + 65536, lane_links_cap=int(6000 * args.utt_seconds * 33.4) + 131072)
         for mode in (["literal"] if args.no_two_pass else ["literal", "two_pass"]):
@@ -273,17 +290,24 @@ def main():
         if not args.one_decoder and not args.no_pipeline:      # a second decoder object (another set of lane pools: 41 GB at the bench configuration; the GPU has 288): batch k + 1's token passing starts under batch k's pruning kernel and lattice fetch
             decs["literal_b"] = decoder.CudaDecoder(cfst, decoder.decoder_config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE, literal_order=1, **caps), U, num_pdfs); decs["literal_b"].SetProfiling(True)
     hl = hostlib.load(); det_opts = hostlib.DetOpts(); hl.k3h_det_opts_default(ctypes.byref(det_opts))
+    extra_pool = ThreadPoolExecutor(max(1, args.host_load_replicas - 1)) if args.host_load_replicas > 1 else None
     pool = ThreadPoolExecutor(1)                      # hands a batch of lattices to the native worker pool (k3h_postprocess_batch runs det_threads threads itself)
     def postprocess(lats):
         """Connect + DeterminizeLatticePruned (word level, beam = lattice-beam: what the CUDA pipeline does with --determinize-lattice=true and no
         phone pass) of every lattice of the batch; returns (determinized states, arcs)"""
-        n = len(lats); cs = np.zeros(n, np.int32); ca = np.zeros(n, np.int64); ok = np.zeros(n, np.int32)
+        n = len(lats)
         so = np.ascontiguousarray(lats.state_offsets, np.int64); ao = np.ascontiguousarray(lats.arc_offsets, np.int64)
         si, sf_, ai, af = lats._si, lats._sf, lats._ai, lats._af
-        hostlib.check(hl.k3h_postprocess_batch(None, n, so.ctypes.data, ao.ctypes.data, int(cfst.start), si[0].ctypes.data, si[1].ctypes.data, sf_[1].ctypes.data, ai[0].ctypes.data, ai[1].ctypes.data,
-                                               ai[2].ctypes.data, ai[3].ctypes.data, af[0].ctypes.data, af[1].ctypes.data, float(LATTICE_BEAM), ctypes.byref(det_opts), det_threads, None,
-                                               cs.ctypes.data, ca.ctypes.data, ok.ctypes.data))
-        return int(cs.sum()), int(ca.sum())
+        def one():
+            cs = np.zeros(n, np.int32); ca = np.zeros(n, np.int64); ok = np.zeros(n, np.int32)
+            hostlib.check(hl.k3h_postprocess_batch(None, n, so.ctypes.data, ao.ctypes.data, int(cfst.start), si[0].ctypes.data, si[1].ctypes.data, sf_[1].ctypes.data, ai[0].ctypes.data, ai[1].ctypes.data,
+                                                   ai[2].ctypes.data, ai[3].ctypes.data, af[0].ctypes.data, af[1].ctypes.data, float(LATTICE_BEAM), ctypes.byref(det_opts), det_threads, None,
+                                                   cs.ctypes.data, ca.ctypes.data, ok.ctypes.data))
+            return int(cs.sum()), int(ca.sum())
+        others = [extra_pool.submit(one) for _ in range(args.host_load_replicas - 1)] if extra_pool else []      # (--host-load-replicas: the other ranks' host tails, same lattices, results dropped)
+        r = one()
+        for o in others: o.result()
+        return r
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     pipelined = not args.no_pipeline      # the next batch's front end (H2D + fbank + TDNN-F) on a second stream, queued behind the present batch's decoder
@@ -423,7 +447,7 @@ def main():
                                         f"{args.graph_states} states / {args.graph_arcs} arcs) -> raw lattices to the host -> Connect + determinization on {det_threads} host threads, {U} x {args.utt_seconds:g} s utts per GPU") if decs else
                                        f"configs[1]: PCM16 H2D -> fbank(40) + 17-layer TDNN-F forward, {U} x {args.utt_seconds:g} s utts per GPU",
                            "decoder_mode": "literal_order=1: raw lattices identical to the reference's LatticeFasterDecoder" if decs else None,
-                           "utts_per_gpu": U, "frames_per_utt": fo_h[1], "output_rows": int(nb.total_out_rows), "params": int(net.info.num_params), "parallelism": f"utterance-shard x{world}"},
+                           "host_load_replicas": args.host_load_replicas, "det_threads": det_threads, "utts_per_gpu": U, "frames_per_utt": fo_h[1], "output_rows": int(nb.total_out_rows), "params": int(net.info.num_params), "parallelism": f"utterance-shard x{world}"},
                 "value_kernels": U * args.utt_seconds * world / (kernels_ms * 1e-3),
                 "value_kernels_note": "audio / (fbank + TDNN-F + decode kernel time of a step): what the GPU stages alone sustain, H2D / D2H / host tail excluded",
                 "pipeline": ("batch k+1's PCM16 H2D + fbank + TDNN-F are issued on a second stream right behind batch k's decoder kernels (double-buffered log-likelihoods): the copy and the start of the network run while the decoder's last lanes finish; two decoder objects alternate (unless --one-decoder), so batch k+1's token passing starts under batch k's pruning kernel, compaction and lattice copy; one of each per step inside the timed region; stage_ms are the stages' own durations and no longer add up to ms_per_step" if pipelined else "none (--no-pipeline): one stream, stage after stage"),
@@ -454,7 +478,7 @@ def main():
                     tj = json.load(open(sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "hbm_traffic_r*.json")))[-1]))
                     if U == 512 and args.utt_seconds == 10.0: line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]; line["roofline"]["traffic_source"] = tj["source"]
                 except Exception: pass
-            line["decode_stats"] = {"graph_broadcast_s": t_bcast if world > 1 else 0.0, "emitting_arcs_traversed": int(info[:, 7].sum()), "eps_arcs_traversed": int(info[:, 8].sum()), "tokens": int(info[:, 4].sum()),
+            line["decode_stats"] = {"graph_broadcast_s": t_bcast if world > 1 else 0.0, "graph_broadcast_via": bcast_via, "rccl_ranks": rccl_ranks, "emitting_arcs_traversed": int(info[:, 7].sum()), "eps_arcs_traversed": int(info[:, 8].sum()), "tokens": int(info[:, 4].sum()),
                                     "links": int(info[:, 5].sum()), "max_tokens_on_a_frame": int(info[:, 6].max()), "lattice_states": lat_sizes[0], "lattice_arcs": lat_sizes[1], "lattice_digest": lat_sizes[2],
                                     "determinized_states": det_sizes[0], "determinized_arcs": det_sizes[1], "reached_final_frac": float(info[:, 3].mean()), "algorithmic_bytes": ab,
                                     "order_sensitive_events": int(dec.OrderSensitiveEvents().sum()),
@@ -528,7 +552,8 @@ def main():
                 if decs:      # the end-to-end gate: one more (serial) pass over the batch as generated (shift 0), its raw lattices and log-likelihoods kept for the comparison
                     keep = []; run("literal", 1, 0, pipelined=False, vary=False, keep=keep)
                     gpu = (keep[0], loglikes.cpu().numpy(), np.asarray(nb.out_offsets), U, feats.cpu().numpy(), np.asarray(fo_h))
-                line["cpu_baseline"], par, kept = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds, pcm_of, gpu, utts_per_core=args.cpu_utts_per_core, max_procs=args.cpu_procs)
+                P_ = args.cpu_procs or (os.cpu_count() or 1); upc_ = args.cpu_utts_per_core or max(2, -(-U // min(P_, os.cpu_count() or 1)))
+                line["cpu_baseline"], par, kept = cpu_baseline(model_path, graph, num_pdfs, args.utt_seconds, pcm_of, gpu, utts_per_core=upc_, max_procs=P_)
                 if par is not None:
                     line["e2e_parity"] = par
                     # The stage gates at the bench's own scale, on the REFERENCE's intermediate results (so that each stage is judged on identical inputs):

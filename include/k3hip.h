@@ -274,12 +274,14 @@ typedef struct k3_decoder_config {
   int32_t min_active;      /* 200 */
   float lattice_beam;      /* 10.0 (recipes: 8.0) */
   float beam_delta;        /* 0.5 */
-  /* capacities (tokens/links are kept for every frame until FinalizeDecoding; exceeding one is K3_ERR_OVERFLOW,
-   * never a silent beam change -- contrast cuda-decoder.cc:944-976) */
+  /* capacities.  The per-FRAME ones are hard limits (exceeding one is K3_ERR_OVERFLOW for that utterance, never a silent beam change -- contrast
+   * cuda-decoder.cc:944-976).  The per-LANE ones (tokens / links kept for every frame until FinalizeDecoding) are a RESERVATION, like the reference's
+   * ntokens_pre_allocated (cuda-decoder.cc:232-238: reserve(), the per-channel vectors grow): a lane that outgrows them moves, inside the token-passing
+   * kernel, to pools of at least twice the size carved off the decoder's spare arena (spare_pool_bytes below); K3_ERR_OVERFLOW only when that arena is exhausted. */
   int32_t frame_tokens_cap;   /* max tokens alive on one frame of one lane (hash table = 2x next pow2) */
   int32_t frame_cands_cap;    /* max emitting arcs that pass the pre-pass bound on one frame */
-  int64_t lane_tokens_cap;    /* tokens of all frames of one lane */
-  int64_t lane_links_cap;     /* forward links of all frames of one lane */
+  int64_t lane_tokens_cap;    /* tokens of all frames of one lane: the reservation */
+  int64_t lane_links_cap;     /* forward links of all frames of one lane: the reservation */
   /* literal_order = 1: reproduce the reference's SERIAL algorithm bit for bit -- next_cutoff tightened while the previous frame's tokens are
    * visited in HashList order (lattice-faster-decoder.cc:779-797, util/hash-list-inl.h:125-165), the first minimum-cost token of that list as
    * the best token, PruneForwardLinksFinal's in-place sweeps with its 1e-5 stop rule (:385-467).  The raw lattice then equals
@@ -292,6 +294,9 @@ typedef struct k3_decoder_config {
   /* literal_order = 1 only: frames of at most this many tokens (before and after) are processed entirely in LDS (k3_decoder_fast.h), the others on the
    * general path; same results either way.  -1 = the kernel's capacity (3072), 0 = general path only (A/B, tests), n = a smaller capacity (tests). */
   int32_t fast_frame_tokens;  /* -1 */
+  /* HBM set aside for lanes that outgrow lane_tokens_cap / lane_links_cap (16 B per token + 20 B per link of the new pools; a lane's old pools are not reused):
+   * -1 = a quarter of the lanes' reservation, at least 1 GiB and 14 x one lane's reservation (a lane growing 2x, 4x, 8x); 0 = none (the reservation is then a hard limit). */
+  int64_t spare_pool_bytes;   /* -1 */
 } k3_decoder_config;
 void k3_decoder_config_default(k3_decoder_config *cfg);
 typedef struct k3_decoder k3_decoder;
@@ -341,6 +346,8 @@ int k3_decoder_get_best_path(k3_decoder *dec, const int32_t *channels, int32_t n
  * only because next_cutoff was still loose when their arc was examined (tot >= the frame's final next_cutoff); default mode: emitting arcs below
  * the pre-pass bound but not below the final bound (an upper bound on the arcs the serial and the two-pass rule can disagree on). */
 int k3_decoder_order_sensitive_events(k3_decoder *dec, int64_t *h_events);
+/* h_growths[u]: how often the lane of finalised utterance u has moved to bigger token / link pools since the decoder was created (0 while the reservation holds) */
+int k3_decoder_pool_growths(k3_decoder *dec, int32_t *h_growths);
 /* GetRawLattice for every utterance of the last batch, concatenated in utterance order (utterance u owns
  * states h_state_offsets[u]..[u+1] and arcs h_arc_offsets[u]..[u+1]; arc endpoints are indices local to the
  * utterance).  All output pointers are HOST buffers sized from k3_decoder_lattice_info.

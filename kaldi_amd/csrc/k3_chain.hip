@@ -617,7 +617,10 @@ extern "C" int k3_chain_objf_and_deriv(k3_chain_den *den, k3_chain_supervision *
     *h_objf = -10.0f * *h_weight;
   }
   *h_l2_term = 0.0f;
-  if (opts->l2_regularize != 0.0f) {                                                                                        // :329-337
+  // end-to-end supervisions (ComputeChainObjfAndDerivE2e): the l2 term and its derivative only when the numerator computation was fine (`if (opts.l2_regularize != 0.0 &&
+  // numerator_ok)`, chain-training.cc:203) -- an abandoned minibatch keeps its zero derivatives; the regular branch (:329-337) applies it unconditionally
+  const bool numerator_ok = num_logprob_weighted - num_logprob_weighted == 0.0f;
+  if (opts->l2_regularize != 0.0f && (!sup->e2e || numerator_ok)) {                                                         // :329-337
     const float scale = w * opts->l2_regularize; double sumsq = 0.0;
     K3_HIP_CHECK(hipMemsetAsync(sup->scratch, 0, sizeof(double), st));
     hipLaunchKernelGGL(k3_chain_sumsq_kernel, dim3(512), dim3(256), 0, st, d_nnet_output, (long long)ld, rows, P, sup->scratch);

@@ -51,9 +51,11 @@ uint64_t run_nonce() {      // a launcher-supplied run identity (K3_COMM_NONCE, 
 
 // The file protocol of the rendezvous by itself (no RCCL: tests/test_parallel_cpu.py runs it with several processes).  Rank 0 removes whatever a
 // previous run left at `id_file`, then publishes {id, magic, nonce} atomically (rename); the other ranks poll for a file that (a) carries the magic and
-// this run's nonce when the launcher supplied one (K3_COMM_NONCE / TORCHELASTIC_RUN_ID), or (b) without a nonce, is not older than `stale_seconds`
-// before their own start (a file a crashed run left behind hours ago is never taken for the new one).  k3_comm_create removes the file again once
-// every rank has joined (ncclCommInitRank is collective), so a recipe directory can be reused run after run.
+// this run's nonce (K3_COMM_NONCE / TORCHELASTIC_RUN_ID; 0 when the launcher supplied none) AND (b) is not older than `stale_seconds` before their own
+// start -- also with a nonce: torchrun's static rendezvous hands every run the same id ("none"), so the nonce alone does not tell two runs apart.  A file a
+// crashed or one-rank run left behind is therefore only ever mistaken for the new one inside that window and before rank 0 has replaced it; launchers that
+// restart within the window should set K3_COMM_NONCE per run.  k3_comm_create removes the file again once every rank has joined (ncclCommInitRank is
+// collective), so a recipe directory can be reused run after run.
 extern "C" int k3_comm_exchange_id(const char *id_file, int32_t rank, int32_t timeout_seconds, int32_t stale_seconds, const void *id_in, void *id_out) {
   K3_REQUIRE(id_file && id_out && rank >= 0 && (rank != 0 || id_in), "k3_comm_exchange_id: bad argument");
   const uint64_t nonce = run_nonce(); const time_t t_start = time(nullptr);
@@ -68,7 +70,7 @@ extern "C" int k3_comm_exchange_id(const char *id_file, int32_t rank, int32_t ti
     FILE *f = fopen(id_file, "rb");
     if (f) {
       IdFile rec; struct stat st; const bool got = fread(&rec, sizeof rec, 1, f) == 1 && fstat(fileno(f), &st) == 0; fclose(f);
-      if (got && rec.magic == kIdMagic && rec.nonce == nonce && (nonce != 0 || st.st_mtime + stale_seconds >= t_start)) { memcpy(id_out, rec.id, sizeof rec.id); return K3_OK; }
+      if (got && rec.magic == kIdMagic && rec.nonce == nonce && st.st_mtime + stale_seconds >= t_start) { memcpy(id_out, rec.id, sizeof rec.id); return K3_OK; }
     }
     usleep(50000);
   }
@@ -82,7 +84,7 @@ extern "C" int k3_comm_create(const char *id_file, int32_t rank, int32_t world_s
   Rccl *R; { const int rc = rccl(&R); if (rc) return rc; }
   UniqueId id, mine; memset(&id, 0, sizeof id); memset(&mine, 0, sizeof mine);
   if (rank == 0) K3_RCCL(R, R->GetUniqueId(&mine));
-  { const int rc = k3_comm_exchange_id(id_file, rank, timeout_seconds, 600, &mine, &id); if (rc) return rc; }
+  { const int rc = k3_comm_exchange_id(id_file, rank, timeout_seconds, 120, &mine, &id); if (rc) return rc; }
   void *c = nullptr;
   K3_RCCL(R, R->CommInitRank(&c, world_size, id, rank));
   if (rank == 0 && world_size > 1) (void)unlink(id_file);      // every rank has joined: nothing of this run stays behind (a one-rank communicator keeps it: nobody else reads it, tests look at it)

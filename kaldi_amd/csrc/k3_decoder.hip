@@ -43,8 +43,9 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
   float *s_ll = reinterpret_cast<float *>(smem_raw);
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
-  int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
-  Link *links = p.links + (long long)L * p.lane_links_cap; int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
+  __shared__ LanePool s_pool;
+  LanePool lp = k3_uniform_pool(p.pools[L]);
+  int *tok_state = lp.tok_state; unsigned *tok_cost = lp.tok_cost; Link *links = lp.links; int *link_arc = lp.link_arc;
   Slot *hash = p.hash + (long long)L * (p.hash_mask + 1);
   int *tok_slot = p.tok_slot + (long long)L * p.frame_tokens_cap, *wl = p.wl + 2ll * L * p.frame_tokens_cap;
   float *c_tot = p.c_tot + (long long)L * p.frame_cands_cap, *c_ac = p.c_ac + (long long)L * p.frame_cands_cap;
@@ -106,6 +107,13 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
 #endif
     float accept = p.beam; long long nb = 0;
     if (f >= 0) {
+    // room for a whole frame behind what the lane holds (a frame makes at most frame_tokens_cap tokens, frame_cands_cap forward links and -- a bound the closure's
+    // overflow check enforces -- as many epsilon links): a lane that has outgrown its reservation moves to bigger pools here, where nothing of the new frame exists yet
+    { const long long nl_ = sh.n_link;
+      if (lp.tcap - (cur_base + n_cur) < p.frame_tokens_cap || lp.lcap - nl_ < 2ll * p.frame_cands_cap) {
+        if (!grow_lane_pools(p, L, lp, cur_base + n_cur, nl_, p.frame_tokens_cap, 2ll * p.frame_cands_cap, &s_pool)) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; __syncthreads(); break; }
+        tok_state = lp.tok_state; tok_cost = lp.tok_cost; links = lp.links; link_arc = lp.link_arc;
+      } }
     // stage the log-likelihood row of this frame in LDS (coalesced), overlapped with the cutoff passes
     K3_T(0);
     const float *row = p.lane_rows ? p.lane_rows[L] + (long long)(f - f0) * p.ld : p.loglikes + (r0 + (f - f0)) * p.ld;
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       }
       int idx = wave_append(claimed, &sh.n_next);
       if (claimed) {
-        if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot; tok_state[nb + idx] = state; K3_AST(&tok_cost[nb + idx], kEncMax); }
+        if (idx < p.frame_tokens_cap && nb + idx < lp.tcap) { tok_slot[idx] = slot; tok_state[nb + idx] = state; K3_AST(&tok_cost[nb + idx], kEncMax); }
         else { sh.err = K3_ERR_OVERFLOW; idx = 0; }
         tb.set_tok(slot, idx);
       }
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
       if (mk && !claimed) { idx = tb.wait_tok(slot, &sh.err); if (idx < 0) idx = 0; }
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
-        if (pos < p.lane_links_cap) { store_link(&links[pos], Link{(unsigned)(cur_base + c_s), (unsigned)(nb + idx), tot, c_c}); store_stream(&link_arc[pos], c_a); }
+        if (pos < lp.lcap) { store_link(&links[pos], Link{(unsigned)(cur_base + c_s), (unsigned)(nb + idx), tot, c_c}); store_stream(&link_arc[pos], c_a); }
         else sh.err = K3_ERR_OVERFLOW;
       }
     }
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
     }   // f >= 0
     // ---- ProcessNonemitting(next_cutoff) + eps links + publish the frame
-    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
+    finish_frame(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, lp.tcap, lp.lcap, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
     if (block_err(sh)) break;
     cur_base = nb; n_cur = sh.n_next; max_frame = n_cur > max_frame ? n_cur : max_frame; in_regs = n_cur <= kCurRegs * kBlock;
     __syncthreads();
@@ -326,9 +334,10 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
   LaneInfo &li = p.info[L];
   if (li.status != kStOk) return;
   const int T = li.num_frames;
-  const int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; const unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
-  float *extra = p.tok_extra + (long long)L * p.lane_tokens_cap;
-  const Link *links = p.links + (long long)L * p.lane_links_cap;
+  const LanePool lp = k3_uniform_pool(p.pools[L]);
+  const int *tok_state = lp.tok_state; const unsigned *tok_cost = lp.tok_cost;
+  float *extra = lp.tok_extra;
+  const Link *links = lp.links;
   const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
   const float kInf = __builtin_inff(); const float lb = p.lattice_beam;
 
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
   long long pt_last__ = (long long)__builtin_readcyclecounter();
 #endif
   int *live_tok = p.live_tok + (long long)L * p.live_cap; long long *live_link = p.live_link + (long long)L * p.live_cap;
-  int *newidx = p.newidx + (long long)L * p.lane_tokens_cap;
+  int *newidx = lp.newidx;
   auto keep_tok = [&](long long t) { const int pos = k3a_add(&s_nt, 1); if (pos < p.live_cap) live_tok[pos] = (int)t; newidx[t] = pos; };
   auto keep_link = [&](long long l) { const int pos = k3a_add(&s_nl, 1); if (pos < p.live_cap) live_link[pos] = l; };
   // ---- last frame: ComputeFinalCosts (:545-586) + PruneForwardLinksFinal (:385-467), in HBM (one frame only)
@@ -623,12 +632,13 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_output_kernel(DecParams p, 
   const LaneInfo &li = p.info[L];
   if (li.status != kStOk) return;
   const int T = li.num_frames;
-  const int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; const unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
-  const float *extra = p.tok_extra + (long long)L * p.lane_tokens_cap;
-  const Link *links = p.links + (long long)L * p.lane_links_cap; const int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
+  const LanePool lp = k3_uniform_pool(p.pools[L]);
+  const int *tok_state = lp.tok_state; const unsigned *tok_cost = lp.tok_cost;
+  const float *extra = lp.tok_extra;
+  const Link *links = lp.links; const int *link_arc = lp.link_arc;
   const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
   const float *st_co = p.st_co + L * p.fstride;
-  int *newidx = p.newidx + (long long)L * p.lane_tokens_cap;
+  int *newidx = lp.newidx;
   const float kInf = __builtin_inff(); const float lb = p.lattice_beam;
   const long long so = o.st_off[blockIdx.x], ao = o.arc_off[blockIdx.x];      // offsets are per finalised lane, in launch order
   if (!li.live_overflow) {       // survivors were listed by the pruning pass: touch only them
@@ -713,8 +723,9 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_best_path_kernel(DecParams 
   if (tid == 0) { o.path_len[blockIdx.x] = 0; o.final_cost[blockIdx.x] = 0.0f; o.relative_cost[blockIdx.x] = __builtin_inff(); o.reached_final[blockIdx.x] = 0; }
   if (li.status != kStOk) return;
   const int T = li.num_frames;
-  const int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; const unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
-  const Link *links = p.links + (long long)L * p.lane_links_cap; const int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
+  const LanePool lp = k3_uniform_pool(p.pools[L]);
+  const int *tok_state = lp.tok_state; const unsigned *tok_cost = lp.tok_cost;
+  const Link *links = lp.links; const int *link_arc = lp.link_arc;
   const long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
   const float *st_co = p.st_co + L * p.fstride; const float kInf = __builtin_inff();
   // best token of the newest frame: min (cost + final) if a final state was reached and final-probs are asked for, else min cost
@@ -890,7 +901,7 @@ extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
   if (!c) return;
   c->beam = 16.0f; c->max_active = std::numeric_limits<int32_t>::max(); c->min_active = 200; c->lattice_beam = 10.0f; c->beam_delta = 0.5f;
   c->frame_tokens_cap = 32768; c->frame_cands_cap = 65536; c->lane_tokens_cap = 2000000; c->lane_links_cap = 4000000;
-  c->literal_order = 0; c->hash_ratio = 2.0f; c->fast_frame_tokens = -1;
+  c->literal_order = 0; c->hash_ratio = 2.0f; c->fast_frame_tokens = -1; c->spare_pool_bytes = -1;
 }
 
 template <typename T> static int dmalloc(std::vector<void *> *allocs, T **ptr, size_t n) {
@@ -911,17 +922,34 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   DecParams &p = d->p;
   p.offs = fst->offs; p.arcs = fst->arcs; p.final_cost = fst->final_cost; p.arc_ilabel = fst->arc_ilabel; p.start = fst->start;
   p.beam = cfg->beam; p.lattice_beam = cfg->lattice_beam; p.beam_delta = cfg->beam_delta; p.max_active = cfg->max_active; p.min_active = cfg->min_active;
-  p.frame_tokens_cap = cfg->frame_tokens_cap; p.frame_cands_cap = cfg->frame_cands_cap; p.lane_tokens_cap = cfg->lane_tokens_cap; p.lane_links_cap = cfg->lane_links_cap;
+  p.frame_tokens_cap = cfg->frame_tokens_cap; p.frame_cands_cap = cfg->frame_cands_cap;
   int hs = 1; while (hs < 2 * cfg->frame_tokens_cap) hs <<= 1;
   p.hash_mask = hs - 1; p.num_pdfs = num_pdfs;
   p.use_lds_row = (K3_DEC_LDSROW && (size_t)num_pdfs * sizeof(float) <= 25 * 1024) ? 1 : 0;   // keeps a lane under 80 KB of LDS: two lanes per CU
   const size_t nl = (size_t)nlanes;
   int rc;
-  if ((rc = dmalloc(&d->allocs, &p.tok_state, nl * cfg->lane_tokens_cap))) return rc;
-  if ((rc = dmalloc(&d->allocs, &p.tok_cost, nl * cfg->lane_tokens_cap))) return rc;
-  if ((rc = dmalloc(&d->allocs, &p.tok_extra, nl * cfg->lane_tokens_cap))) return rc;
-  if ((rc = dmalloc(&d->allocs, &p.links, nl * cfg->lane_links_cap))) return rc;
-  if ((rc = dmalloc(&d->allocs, &p.link_arc, nl * cfg->lane_links_cap))) return rc;
+  {      // the lanes' token / link pools: lane l starts on slice l of one allocation per array (the reservation); pools[l] says where it lives now
+    int *tok_state, *link_arc, *newidx; unsigned *tok_cost; float *tok_extra; Link *links;
+    if ((rc = dmalloc(&d->allocs, &tok_state, nl * cfg->lane_tokens_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &tok_cost, nl * cfg->lane_tokens_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &tok_extra, nl * cfg->lane_tokens_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &newidx, nl * cfg->lane_tokens_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &links, nl * cfg->lane_links_cap))) return rc;
+    if ((rc = dmalloc(&d->allocs, &link_arc, nl * cfg->lane_links_cap))) return rc;
+    std::vector<LanePool> pools(nl);
+    for (size_t l = 0; l < nl; l++) pools[l] = LanePool{tok_state + l * cfg->lane_tokens_cap, tok_cost + l * cfg->lane_tokens_cap, tok_extra + l * cfg->lane_tokens_cap, newidx + l * cfg->lane_tokens_cap,
+                                                        links + l * cfg->lane_links_cap, link_arc + l * cfg->lane_links_cap, (long long)cfg->lane_tokens_cap, (long long)cfg->lane_links_cap};
+    if ((rc = dmalloc(&d->allocs, &p.pools, nl))) return rc;
+    K3_HIP_CHECK(hipMemcpy(p.pools, pools.data(), nl * sizeof(LanePool), hipMemcpyHostToDevice));
+    // spare arena for the lanes that outgrow the reservation (grow_lane_pools): -1 = a quarter of the reservation, but at least 1 GiB and 14 times a lane's reservation
+    // (one lane growing 2x, 4x, 8x: an utterance eight times as long as the reservation was sized for -- the reference's host vectors grow without a limit; HBM is 288 GB)
+    const long long lane_bytes = 16ll * cfg->lane_tokens_cap + 20ll * cfg->lane_links_cap + 6 * 256;
+    p.spare_bytes = cfg->spare_pool_bytes >= 0 ? cfg->spare_pool_bytes : std::max<long long>({(long long)nl * lane_bytes / 4, 14 * lane_bytes, 1ll << 30});
+    p.spare = nullptr;
+    if (p.spare_bytes > 0 && (rc = dmalloc(&d->allocs, &p.spare, (size_t)p.spare_bytes))) return rc;
+    if ((rc = dmalloc(&d->allocs, &p.spare_used, 1))) return rc;
+    K3_HIP_CHECK(hipMemset(p.spare_used, 0, sizeof(unsigned long long)));
+  }
   if ((rc = dmalloc(&d->allocs, &p.hash, nl * hs))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.tok_slot, nl * cfg->frame_tokens_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.wl, 2 * nl * cfg->frame_tokens_cap))) return rc;
@@ -937,7 +965,6 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
   if ((rc = dmalloc(&d->allocs, &d->d_fresh, nl))) return rc;
   if ((rc = dmalloc(&d->allocs, &d->d_lane_ids, nl))) return rc;
-  if ((rc = dmalloc(&d->allocs, &p.newidx, nl * cfg->lane_tokens_cap))) return rc;
   p.live_cap = (int)std::min<long long>(cfg->lane_tokens_cap, 1 << 18);
   if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.live_link, nl * p.live_cap))) return rc;
@@ -1163,6 +1190,13 @@ extern "C" int k3_decoder_lattice_info(k3_decoder *d, int64_t *h_info) {
                                                           u, li.status, li.status == K3_ERR_OVERFLOW ? "capacity overflow" : "internal error", li.n_tokens, li.n_links, li.max_frame_tokens); }
   }
   return worst;
+}
+
+extern "C" int k3_decoder_pool_growths(k3_decoder *d, int32_t *h_growths) {
+  K3_REQUIRE(d && h_growths, "k3_decoder_pool_growths: null argument");
+  { const int rc = fetch_info(d); if (rc) return rc; }
+  for (size_t k = 0; k < d->sel.size(); k++) h_growths[k] = d->h_info[d->sel[k]].pool_grows;
+  return K3_OK;
 }
 
 extern "C" int k3_decoder_order_sensitive_events(k3_decoder *d, int64_t *h_events) {

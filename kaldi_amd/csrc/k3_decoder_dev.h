@@ -53,6 +53,12 @@ template <typename T> __device__ __forceinline__ void store_stream(T *dst, T v) 
 }
 
 enum { kStOk = 0, kStNoTokens = 1 };
+constexpr int kErrPool = -1000;      // internal to the forward kernels: a lane's token / link pool is full -- grow it and go on (never leaves the kernel; K3_ERR_OVERFLOW when the spare arena is exhausted)
+
+// A lane's token / link pools.  The configured capacities (k3_decoder_config::lane_tokens_cap / lane_links_cap = the reference's ntokens_pre_allocated) are a RESERVATION like the
+// reference's (cuda-decoder.cc:232-238 reserves, the per-channel vectors grow): a lane that outgrows them moves, inside the token-passing kernel and without the host, to a block of
+// at least twice the size carved off the decoder's spare arena (grow_lane_pools below); every kernel reads a lane's pointers and capacities from this record.
+struct LanePool { int *tok_state; unsigned *tok_cost; float *tok_extra; int *newidx; Link *links; int *link_arc; long long tcap, lcap; };
 
 struct LaneInfo {            // per lane, written by the kernels, read by the host
   long long n_tokens, n_links, n_cands, n_eps;   // created / emitting arcs examined / eps arcs examined
@@ -66,6 +72,7 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
   // pre-pass bound but not below the final bound, an upper bound on the arcs the two rules can disagree on.
   long long n_order_sensitive;
   int hash_size, order_sel;               // literal_order: HashList bucket count (PossiblyResizeHash) and which half of lt_order holds the newest frame, carried across AdvanceDecoding calls
+  int pool_grows;                         // how often this lane moved to bigger pools (since the decoder was created)
 };
 
 #ifdef K3_DEC_PROF
@@ -92,15 +99,15 @@ struct DecParams {
   const int2 *offs; const ArcRec *arcs; const float *final_cost; const int *arc_ilabel; int start;
   // config
   float beam, lattice_beam, beam_delta; int max_active, min_active;
-  int frame_tokens_cap, frame_cands_cap, hash_mask; long long lane_tokens_cap, lane_links_cap;
+  int frame_tokens_cap, frame_cands_cap, hash_mask;
   // input
   const float *loglikes; long long ld; const long long *row_off; int num_pdfs; int use_lds_row;
   const float *const *lane_rows;          // non-null: lane l's next frames start at lane_rows[l] (rows ld apart) instead of row row_off[l] of `loglikes`
   const int *fresh;                       // [nlanes] 1: InitDecoding first (start token + eps closure), frames start at 0; 0: continue after LaneInfo::num_frames frames (AdvanceDecoding)
   const int *lane_ids;                    // prune / output kernels: the lanes being finalised (workgroup b works on lane lane_ids[b]); null = lane b
-  // per-lane pools (lane l at base + l * stride)
-  int *tok_state; unsigned *tok_cost; float *tok_extra; Link *links; int *link_arc;
-  int *live_tok; long long *live_link; int *newidx; int live_cap;   // survivors of the pruning pass (pool indices), per lane
+  // per-lane pools: pools[l] (initially lane l's slice of one allocation per array; after a growth a block of the spare arena)
+  LanePool *pools; char *spare; unsigned long long *spare_used; long long spare_bytes;      // spare arena: bump-allocated by the lanes that outgrow their pools, never freed before the decoder is destroyed
+  int *live_tok; long long *live_link; int live_cap;   // survivors of the pruning pass (pool indices), per lane
   Slot *hash; int *tok_slot; int *wl;            // wl: 2 x frame_tokens_cap
   float *c_tot, *c_ac; int *c_dst, *c_arc, *c_src;
   // per-lane per-frame arrays, stride fstride = max_frames + 2
@@ -417,12 +424,65 @@ __device__ __forceinline__ unsigned block_select_kth(ForKeys &&for_keys, int k, 
   return prefix;
 }
 
+// A lane's pool record is the same for every thread of its workgroup: pin it to scalar registers (read through LDS or a vector load it would sit in 16 vector registers per thread,
+// in kernels that have none to spare, and every pool access would form its address on the vector unit)
+template <typename T> __device__ __forceinline__ T *k3_uniform_ptr(T *q) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long k3_uniform_i64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ LanePool k3_uniform_pool(const LanePool &a) {
+  return LanePool{k3_uniform_ptr(a.tok_state), k3_uniform_ptr(a.tok_cost), k3_uniform_ptr(a.tok_extra), k3_uniform_ptr(a.newidx), k3_uniform_ptr(a.links), k3_uniform_ptr(a.link_arc), k3_uniform_i64(a.tcap), k3_uniform_i64(a.lcap)};
+}
+
+// Move lane L to pools in which at least need_t tokens and need_l links fit behind the n_tok tokens / n_link links it holds: a block of the spare arena with both capacities at
+// least doubled (bump allocation, one device-scope atomic), the lane's contents copied by its own workgroup, the lane's record updated for the kernels that follow.  Called by all
+// threads of the workgroup at a point where nothing of the frame being built is in the pools yet.  false: the arena is exhausted (the caller reports K3_ERR_OVERFLOW).
+__device__ __forceinline__ bool grow_lane_pools(const DecParams &p, int L, LanePool &lp, long long n_tok, long long n_link, long long need_t, long long need_l, LanePool *s_new) {
+  const int tid = threadIdx.x, nthr = (int)blockDim.x;
+  __syncthreads();
+  if (tid == 0) {
+    LanePool np = lp; long long nt = 2 * lp.tcap, nl = 2 * lp.lcap;
+    while (nt - n_tok < need_t) nt *= 2;
+    while (nl - n_link < need_l) nl *= 2;
+    const unsigned long long bt = ((unsigned long long)nt * 4 + 255) & ~255ull, bl4 = ((unsigned long long)nl * 4 + 255) & ~255ull, bl16 = ((unsigned long long)nl * 16 + 255) & ~255ull;
+    const unsigned long long bytes = 4 * bt + bl4 + bl16;
+    np.tcap = -1;
+    if (p.spare && nt < (1ll << 31)) {
+      const unsigned long long off = __hip_atomic_fetch_add(p.spare_used, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (off + bytes <= (unsigned long long)p.spare_bytes) {
+        char *b = p.spare + off;
+        np.links = reinterpret_cast<Link *>(b); b += bl16; np.tok_state = reinterpret_cast<int *>(b); b += bt; np.tok_cost = reinterpret_cast<unsigned *>(b); b += bt;
+        np.tok_extra = reinterpret_cast<float *>(b); b += bt; np.newidx = reinterpret_cast<int *>(b); b += bt; np.link_arc = reinterpret_cast<int *>(b);
+        np.tcap = nt; np.lcap = nl;
+      }
+    }
+    *s_new = np;
+  }
+  __syncthreads();
+  const LanePool np = k3_uniform_pool(*s_new);
+  if (np.tcap < 0) return false;
+  for (long long i = tid; i < n_tok; i += nthr) { np.tok_state[i] = lp.tok_state[i]; np.tok_cost[i] = K3_ALD(&lp.tok_cost[i]); }
+  { const int4 *src = reinterpret_cast<const int4 *>(lp.links); int4 *dst = reinterpret_cast<int4 *>(np.links); for (long long i = tid; i < n_link; i += nthr) dst[i] = src[i]; }
+  for (long long i = tid; i < n_link; i += nthr) np.link_arc[i] = lp.link_arc[i];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) { p.pools[L] = np; p.info[L].pool_grows += 1; }
+  lp = np;
+  __syncthreads();
+  return true;
+}
+
 // ---- epsilon closure + eps links + frame finalisation for the frame being built (tokens [nb, nb + n_next)) ----
 // ProcessNonemitting (lattice-faster-decoder.cc:830-897): relax eps arcs until no cost changes, with tot < cutoff;
 // the links a token ends up with are exactly its eps arcs with cur + graph < cutoff at its final cost.
 template <bool kPublish = true>
 __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, const Table &tb, float cutoff, long long nb, int *tok_state, unsigned *tok_cost,
-                                             Link *links, int *link_arc, int *tok_slot, int *wl, unsigned short (*lwl)[kWlLds], unsigned (&creg)[kCurRegs], int (&sreg)[kCurRegs],
+                                             Link *links, int *link_arc, long long tcap, long long lcap, int *tok_slot, int *wl, unsigned short (*lwl)[kWlLds], unsigned (&creg)[kCurRegs], int (&sreg)[kCurRegs],
                                              long long &t_last__, unsigned &cnt_eps) {
   const int tid = threadIdx.x, lane = tid & 63;
   // One barrier per round.  Work-list counters n_wl[3], error flags err_r[4] and LDS mark bits [3] rotate: round r reads list r,
@@ -494,8 +554,8 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         }
         int idx = wave_append(claimed, &sh.n_next);
         if (claimed) {
-          if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; K3_AST(&tok_cost[nb + idx], kEncMax); }
-          else { fail(K3_ERR_OVERFLOW); idx = 0; }
+          if (idx < p.frame_tokens_cap && nb + idx < tcap) { tok_slot[idx] = slot2; tok_state[nb + idx] = nxt; K3_AST(&tok_cost[nb + idx], kEncMax); }
+          else { fail(K3_ERR_OVERFLOW); idx = 0; }      // (the callers make room for a whole frame before it starts: the pool cannot be what is full)
           tb.set_tok(slot2, idx);
         }
         const int pos = wave_append(push, n_nxt);
@@ -507,7 +567,7 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         // are recognised as stale by their stamp (Link::ac of an eps link = the source cost it was created at)
         if (mk && !claimed) { idx = tb.wait_tok(slot2, &sh.err); if (idx < 0) { fail(K3_ERR_HIP); idx = 0; } }
         const long long lp = wave_append64(mk, &sh.n_link);
-        if (mk) { if (lp < p.lane_links_cap) { store_link(&links[lp], Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}); store_stream(&link_arc[lp], arc); } else fail(K3_ERR_OVERFLOW); }
+        if (mk) { if (lp < lcap) { store_link(&links[lp], Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}); store_stream(&link_arc[lp], arc); } else fail(K3_ERR_OVERFLOW); }
       });
       K3_TW(14);
     }

@@ -53,6 +53,7 @@ static_assert(oE_w + 4 * kFE <= oV_end && oSub_end <= oChunk && oRcost + 4 * kFC
 
 struct LaneCtx {      // this lane's slices of the pools and per-frame arrays
   int *tok_state; unsigned *tok_cost; Link *links; int *link_arc; long long *tok_off, *loff_e, *loff_n; int *st_ntoks; float *st_cur, *st_ab, *st_next, *st_co;
+  long long tcap, lcap;      // capacities of the lane's token / link pools (the caller has made room for a whole LDS-resident frame: the checks below cannot fire, they guard the memory)
 };
 struct FastShared { int abort, abort_r[4], n_wl[3], n_el; unsigned next0; int reason; long long prof[12]; };
 #ifdef K3_FAST_PROF
@@ -322,7 +323,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
       int idx = wave_append(claimed, &sh.n_next);
       int2 oa = make_int2(0, 0), ob = make_int2(0, 0);
       if (claimed) {
-        if (idx >= cap_tokens || nb + idx >= p.lane_tokens_cap) { abort_now(kFaTokens); idx = 0; }
+        if (idx >= cap_tokens || nb + idx >= c.tcap) { abort_now(kFaTokens); idx = 0; }
         else { c.tok_state[nb + idx] = state; oa = p.offs[state]; ob = p.offs[state + 1]; }
         __hip_atomic_store(&T_tix[slot], (unsigned short)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -335,7 +336,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
       if (mk) { k3a_min(&N_cost[idx], enc(tot)); k3a_min(&X[idx], (unsigned)(jbase + j)); }
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
-        if (pos < p.lane_links_cap) { store_link(&c.links[pos], Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}); store_stream(&c.link_arc[pos], arc); }
+        if (pos < c.lcap) { store_link(&c.links[pos], Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}); store_stream(&c.link_arc[pos], arc); }
         else abort_now(kFaPool);
       }
       if (claimed) {      // the new token's arc ranges (requested above, arrived by now): neither the next frame nor an epsilon round starts with an offsets look-up
@@ -386,7 +387,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
           int idx = wave_append(claimed, &sh.n_next);
           int2 oa = make_int2(0, 0), ob = make_int2(0, 0);
           if (claimed) {
-            if (idx >= cap_tokens || nb + idx >= p.lane_tokens_cap) { fail(kFaTokens); idx = 0; }
+            if (idx >= cap_tokens || nb + idx >= c.tcap) { fail(kFaTokens); idx = 0; }
             else { c.tok_state[nb + idx] = nxt; oa = p.offs[nxt]; ob = p.offs[nxt + 1]; }
             __hip_atomic_store(&T_tix[slot], (unsigned short)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
@@ -400,10 +401,10 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
           const long long lp = wave_append64(mk, &sh.n_link);
           if (mk) {
             const long long el = lp - eps_l0;
-            if (lp < p.lane_links_cap && el < kFE) {
+            if (lp < c.lcap && el < kFE) {
               store_link(&c.links[lp], Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}); store_stream(&c.link_arc[lp], arc);
               E_src[el] = (unsigned short)oti; E_dst[el] = (unsigned short)idx; E_arc[el] = (unsigned)arc; E_stamp[el] = ocb; E_w[el] = r.w;
-            } else fail(lp < p.lane_links_cap ? kFaLinks : kFaPool);
+            } else fail(lp < c.lcap ? kFaLinks : kFaPool);
           }
           if (claimed) {
             const int ne = oa.y - oa.x, nn = ob.x - oa.y;

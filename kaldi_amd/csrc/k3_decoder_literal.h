@@ -619,15 +619,25 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
   unsigned short (*const s_lwl)[kWlLds] = reinterpret_cast<unsigned short (*)[kWlLds]>(s_aux); int *const s_own = s_aux + 1024;
   const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
   const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
-  int *tok_state = p.tok_state + (long long)L * p.lane_tokens_cap; unsigned *tok_cost = p.tok_cost + (long long)L * p.lane_tokens_cap;
-  Link *links = p.links + (long long)L * p.lane_links_cap; int *link_arc = p.link_arc + (long long)L * p.lane_links_cap;
+  __shared__ LanePool s_pool;
+  LanePool lp = k3_uniform_pool(p.pools[L]);      // this lane's token / link pools (grow_lane_pools moves them when the lane outgrows its reservation)
+  int *tok_state = lp.tok_state; unsigned *tok_cost = lp.tok_cost; Link *links = lp.links; int *link_arc = lp.link_arc;
   Slot *hash = p.hash + (long long)L * (p.hash_mask + 1);
   int *tok_slot = p.tok_slot + (long long)L * p.frame_tokens_cap, *wl = p.wl + 2ll * L * p.frame_tokens_cap;
   long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
   int *st_ntoks = p.st_ntoks + L * p.fstride; float *st_cur = p.st_cur + L * p.fstride, *st_ab = p.st_ab + L * p.fstride, *st_next = p.st_next + L * p.fstride, *st_co = p.st_co + L * p.fstride;
   const unsigned mask = (unsigned)p.hash_mask; const float kInf = __builtin_inff(); const int cap = p.frame_tokens_cap;
   const LitLane q(p, L);
-  const LaneCtx lc{tok_state, tok_cost, links, link_arc, tok_off, loff_e, loff_n, st_ntoks, st_cur, st_ab, st_next, st_co};
+  LaneCtx lc{tok_state, tok_cost, links, link_arc, tok_off, loff_e, loff_n, st_ntoks, st_cur, st_ab, st_next, st_co, lp.tcap, lp.lcap};
+  // room behind what the lane holds for `need_l` more links and a whole frame of tokens; all threads call it where nothing of the frame being built is in the pools yet
+  auto make_room = [&](long long n_tok, long long need_l) -> bool {
+    const long long nl_ = sh.n_link;
+    if (lp.tcap - n_tok >= p.frame_tokens_cap && lp.lcap - nl_ >= need_l) return true;
+    if (!grow_lane_pools(p, L, lp, n_tok, nl_, p.frame_tokens_cap, need_l, &s_pool)) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; __syncthreads(); return false; }
+    tok_state = lp.tok_state; tok_cost = lp.tok_cost; links = lp.links; link_arc = lp.link_arc;
+    lc.tok_state = tok_state; lc.tok_cost = tok_cost; lc.links = links; lc.link_arc = link_arc; lc.tcap = lp.tcap; lc.lcap = lp.lcap;
+    return true;
+  };
   long long cyc_fast = 0, cyc_general = 0, cyc_t0 = 0;
   int n_fast = 0, n_gaveup = 0, n_general = 0; int why[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (thread 0: frames by path, reasons of the fast path's give-ups; k3_decoder_phase_cycles reads them)
   bool v_valid = false, lds_dirty = false;      // the visit-order arrays of the fast path hold the current frame / the arena was used by a fast frame
@@ -680,8 +690,11 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     const int *ord_cur = q.order[sel]; int *ord_nxt = q.order[sel ^ 1];
     if (f >= 0) {
       const float *ll = p.lane_rows ? p.lane_rows[L] + (long long)(f - f0) * p.ld : p.loglikes + (r0 + (f - f0)) * p.ld;
-      const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
       if (n_cur == 0) { status = kStNoTokens; break; }
+      // the pools hold a whole frame of tokens and the links of an LDS-resident frame (<= kFM emitting + kFE epsilon) behind what the lane has; the general path
+      // asks again once it knows how many emitting arcs the frame examines (after pass A)
+      if (!make_room(cur_base + n_cur, (long long)kFM + kFE)) break;
+      const int *cst = tok_state + cur_base; const unsigned *ccs = tok_cost + cur_base;
       // ---- the LDS-resident frame (k3_decoder_fast.h) when the frame fits; a frame it gives up on is redone below, from the same inputs
       if (tid == 0) cyc_t0 = (long long)__builtin_readcyclecounter();
       if (p.fast_cap > 0 && n_cur <= p.fast_cap) {
@@ -792,6 +805,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       if ((long long)m_e + cap > 32ll * p.seq_words_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
       if (block_err(sh)) break;
       nb = cur_base + n_cur;
+      // every emitting arc examined makes at most one forward link, the closure at most eps_cap more (its own check): make room before anything of the frame is written
+      if (!make_room(nb, (long long)m_e + p.eps_cap)) break;
+      cst = tok_state + cur_base; ccs = tok_cost + cur_base;
       K3_LT(2);
       // ---- pass B: accept against the bound in force at each arc; min cost / min sequence number per destination state; forward links
       {
@@ -818,7 +834,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
             }
             int idx = wave_append(claimed, &sh.n_next);
             if (claimed) {
-              if (idx < p.frame_tokens_cap && nb + idx < p.lane_tokens_cap) { tok_slot[idx] = slot; tok_state[nb + idx] = state; K3_AST(&tok_cost[nb + idx], kEncMax); }
+              if (idx < p.frame_tokens_cap && nb + idx < lp.tcap) { tok_slot[idx] = slot; tok_state[nb + idx] = state; K3_AST(&tok_cost[nb + idx], kEncMax); }
               else { sh.err = K3_ERR_OVERFLOW; idx = 0; }
               tb.set_tok(slot, idx);
             }
@@ -834,7 +850,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
             if (mk) k3a_min(&q.label[idx], (unsigned)(jbase + j));
             const long long pos = wave_append64(mk, &sh.n_link);
             if (mk) {
-              if (pos < p.lane_links_cap) { store_link(&links[pos], Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}); store_stream(&link_arc[pos], arc); }
+              if (pos < lp.lcap) { store_link(&links[pos], Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}); store_stream(&link_arc[pos], arc); }
               else sh.err = K3_ERR_OVERFLOW;
             }
           });
@@ -849,7 +865,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     }   // f >= 0
     K3_LT(4);
     // ---- ProcessNonemitting: order-free fixpoint (costs, new tokens, eps links)
-    finish_frame<false>(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
+    finish_frame<false>(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, lp.tcap, lp.lcap, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
     if (block_err(sh)) break;
     const int n = sh.n_next;
     K3_LT(7);

@@ -459,6 +459,7 @@ struct k3_ivector_stream {
   int raw_i = 0, cm_i = 0, pend_i = 0;
   int64_t n_abs = 0, raw_s0 = 0, cm_c0 = 0, n_post = 0, a0 = 0, k_next = 0;      // frames accepted; stream index of row 0 of raw / cm / the pending posterior arrays; frames with posteriors; estimates made
   bool finished = false, fresh = false;
+  bool poisoned = false;      // a batched call failed after it had begun to move this stream's state (buffer switches, counters): the host state and the device buffers may be out of step -- k3_ivector_stream_reset
 };
 
 extern "C" int k3_ivector_stream_create(k3_ivector *iv, k3_ivector_stream **out) {
@@ -483,7 +484,7 @@ extern "C" int k3_ivector_stream_reset(k3_ivector_stream *s, void *stream_) {
   K3_HIP_CHECK(hipMemcpyAsync(s->state.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, stream));
   K3_HIP_CHECK(hipMemsetAsync(s->latest.p, 0, (size_t)R * 4, stream));
   K3_HIP_CHECK(hipStreamSynchronize(stream));                   // h is a local
-  s->n_abs = s->raw_s0 = s->cm_c0 = s->n_post = s->a0 = s->k_next = 0; s->finished = false; s->fresh = true;
+  s->n_abs = s->raw_s0 = s->cm_c0 = s->n_post = s->a0 = s->k_next = 0; s->finished = false; s->fresh = true; s->poisoned = false;
   return K3_OK;
 }
 
@@ -506,6 +507,7 @@ extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_fea
                                         int32_t max_new_rows, int32_t *h_num_new_rows, float *d_latest, void *stream_) {
   K3_REQUIRE(s && num_frames >= 0 && (num_frames == 0 || (d_feats && ld_feats >= s->iv->F)), "k3_ivector_stream_accept: bad argument");
   K3_REQUIRE(!s->finished, "k3_ivector_stream_accept: the stream has ended (k3_ivector_stream_reset starts the next one)");
+  K3_REQUIRE(!s->poisoned, "k3_ivector_stream_accept: an earlier batched call on this stream failed half-way, its state is lost (k3_ivector_stream_reset starts over)");
   K3_REQUIRE(!d_new_rows || ld_rows >= s->iv->R, "k3_ivector_stream_accept: leading dimension of the rows smaller than the i-vector dimension");
   k3_ivector *iv = s->iv; hipStream_t stream = (hipStream_t)stream_;
   const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period, lc = iv->o.left_context, rc_ = iv->o.right_context, W = iv->o.cmvn.cmn_window;
@@ -606,7 +608,7 @@ __global__ void ivec_batch_latest_kernel(const BatchSeg *__restrict__ segs, int 
 // those of k3_ivector_stream_accept (the same kernels' arithmetic; tests/test_ivector_gpu.py).  All streams must belong to one extractor; one batched call at a time per extractor.
 extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32_t num_streams, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, const int32_t *h_finished,
                                               float *d_latest, int64_t ld_latest, void *stream_) {
-  K3_REQUIRE(streams && num_streams > 0 && h_frame_offsets && h_finished && h_frame_offsets[0] == 0, "k3_ivector_stream_accept_batch: bad argument");
+  K3_REQUIRE(streams && num_streams > 0 && streams[0] && h_frame_offsets && h_finished && h_frame_offsets[0] == 0, "k3_ivector_stream_accept_batch: bad argument");
   k3_ivector *iv = streams[0]->iv; hipStream_t stream = (hipStream_t)stream_;
   const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period, lc = iv->o.left_context, rc_ = iv->o.right_context, W = iv->o.cmvn.cmn_window;
   const int64_t keepN = std::max<int64_t>(W, (int64_t)lc + rc_ + 1);
@@ -615,8 +617,17 @@ extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32
   for (int i = 0; i < num_streams; i++) {
     K3_REQUIRE(streams[i] && streams[i]->iv == iv && h_frame_offsets[i + 1] >= h_frame_offsets[i], "k3_ivector_stream_accept_batch: streams of different extractors, or descending offsets");
     K3_REQUIRE(!streams[i]->finished, "k3_ivector_stream_accept_batch: a stream has ended (k3_ivector_stream_reset starts the next one)");
+    K3_REQUIRE(!streams[i]->poisoned, "k3_ivector_stream_accept_batch: an earlier batched call on a stream failed half-way, its state is lost (k3_ivector_stream_reset starts over)");
     for (int j = 0; j < i; j++) K3_REQUIRE(streams[j] != streams[i], "k3_ivector_stream_accept_batch: a stream listed twice");
   }
+  // everything that can be refused is refused BEFORE a stream's state moves: the kernels' LDS limits depend on the extractor only
+  const size_t lds_post = ((size_t)(kBlock / kWave) * G + (size_t)(kBlock / kWave) * 2 * S) * 4, lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
+  K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_stream_accept_batch: too many Gaussians for the posterior kernel's LDS tile");
+  K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_stream_accept_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
+  // The planning loop below switches buffers and advances counters stream by stream while it sizes the launches; an error after it has begun (an allocation that fails for a
+  // later stream, a HIP error) would leave the streams visited so far out of step with their device buffers.  They are then marked: the next call on them says so instead of
+  // producing wrong i-vectors, and k3_ivector_stream_reset starts them over.
+  struct Poison { k3_ivector_stream **s; int n; bool ok = false; ~Poison() { if (!ok) for (int i = 0; i < n; i++) s[i]->poisoned = true; } } poison{streams, num_streams};
   std::vector<BatchSeg> segs((size_t)num_streams); std::vector<k3::CmvnSeg> cs((size_t)num_streams);
   int rc; int64_t total_nP = 0; bool any_new = false, any_est = false;
   for (int i = 0; i < num_streams; i++) {
@@ -677,8 +688,7 @@ extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32
     hipLaunchKernelGGL(ivec_splice_lda_multi_kernel, dim3(nb), dim3(kBlock), 0, stream, d_segs, num_streams, 0, 0, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, (float *)iv->xpost.p, total_nP);
     hipLaunchKernelGGL(ivec_splice_lda_multi_kernel, dim3(nb), dim3(kBlock), 0, stream, d_segs, num_streams, 1, iv->o.online_cmvn_iextractor ? 1 : 0, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_,
                        (float *)iv->xpost.p, total_nP);
-    const int nw = kBlock / kWave; const size_t lds_post = ((size_t)nw * G + (size_t)nw * 2 * S) * 4;
-    K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_stream_accept_batch: too many Gaussians for the posterior kernel's LDS tile");
+    const int nw = kBlock / kWave;
     const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;
     hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((total_nP + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)iv->xpost.p, D, G, iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
                        iv->o.posterior_scale, total_nP, (int32_t *)nullptr, (float *)nullptr, (int32_t *)nullptr, d_segs, num_streams);
@@ -687,8 +697,6 @@ extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32
     EstParams p{};
     p.U = iv->U; p.SM = iv->SM; p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count;
     p.acc_tail = 0; p.t_limit = 0; p.segs = d_segs;
-    const size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
-    K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_stream_accept_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
     K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
     hipLaunchKernelGGL(ivec_estimate_kernel, dim3((unsigned)num_streams), dim3(kBlock), lds_est, stream, p);
     hipLaunchKernelGGL(ivec_batch_shift_kernel, dim3((unsigned)num_streams), dim3(kBlock), 0, stream, d_segs, D, S);
@@ -696,5 +704,6 @@ extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32
   if (d_latest) hipLaunchKernelGGL(ivec_batch_latest_kernel, dim3((unsigned)num_streams), dim3(256), 0, stream, d_segs, R, d_latest, (long long)ld_latest);
   K3_HIP_CHECK(hipGetLastError());
   K3_HIP_CHECK(hipStreamSynchronize(stream));                   // the tables in iv->frame_off are reused by the next call
+  poison.ok = true;
   return K3_OK;
 }

@@ -557,13 +557,15 @@ EwParams mk(int op, float *C, long long ldc, int rows, int cols) { EwParams p{};
 #define K3_MAT_REQUIRE(C, ldc, rows, cols) K3_REQUIRE((C) && (rows) >= 0 && (cols) >= 0 && (ldc) >= (cols), "k3_mat: bad matrix argument")
 
 // scratch that a two-kernel operation hands from its first kernel to its second (split-K planes, column-reduction partials): one buffer per (device, stream), so that
-// operations queued on different streams never share one; it only grows (after a device synchronise: an earlier operation of the stream may still read the old one)
+// operations queued on different streams never share one; it only grows (after a device synchronise: an earlier operation of the stream may still read the old one).
+// `hold` keeps the table's lock until the caller has queued BOTH kernels of its operation: two host threads that issue such operations on the same stream (the null stream, say)
+// must not interleave as producer A, producer B, consumer A -- consumer A would read B's planes -- and the buffer must not be regrown under a queued-but-unlaunched pair.
 namespace {
-int workspace(hipStream_t st, size_t bytes, void **out) {
+int workspace(hipStream_t st, size_t bytes, void **out, std::unique_lock<std::mutex> &hold) {
   struct Ws { void *p = nullptr; size_t cap = 0; };
   static std::mutex mu; static std::map<std::pair<int, hipStream_t>, Ws> tab;
   int dev = 0; K3_HIP_CHECK(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> g(mu);
+  hold = std::unique_lock<std::mutex>(mu);
   Ws &w = tab[{dev, st}];
   if (bytes > w.cap) {
     if (w.p) { K3_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(w.p); w.p = nullptr; w.cap = 0; }
@@ -578,7 +580,7 @@ int col_reduce(RedParams p, hipStream_t st) {      // ops 0 - 2 and 5 of k3_colr
   const int xb = (p.cols + 63) / 64; int chunks = std::max(1, std::min(64, std::min((p.rows + 63) / 64, (1024 + xb - 1) / xb)));
   if (chunks > 1) {
     p.rows_per_chunk = (p.rows + chunks - 1) / chunks; chunks = (p.rows + p.rows_per_chunk - 1) / p.rows_per_chunk;
-    void *wsv = nullptr; { const int rc = workspace(st, (size_t)chunks * p.cols * sizeof(double), &wsv); if (rc) return rc; }
+    std::unique_lock<std::mutex> hold; void *wsv = nullptr; { const int rc = workspace(st, (size_t)chunks * p.cols * sizeof(double), &wsv, hold); if (rc) return rc; }      // (held until both kernels are queued)
     p.part = static_cast<double *>(wsv);
     hipLaunchKernelGGL(k3_colred_kernel, dim3(xb, chunks), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k3_colred_fold_kernel, dim3(xb), dim3(256), 0, st, p, chunks);
@@ -643,7 +645,7 @@ static int add_mat_mat(float alpha, const float *d_A, int64_t lda, int32_t trans
   else if (tiles < 384 && K >= (fine ? 512 : 3072)) { S = (int)std::min<long long>(16, std::max<long long>(2, 1024 / tiles)); Kc = fine ? ((K + S - 1) / S + 127) / 128 * 128 : ((K + S - 1) / S + 383) / 384 * 384; }
   if (S > 1) S = (K + Kc - 1) / Kc;
   if (S > 1) {      // planes are whole accumulation blocks, reduced in ascending order: deterministic, and for the tile kernels the same sums as without the split
-    void *wsv = nullptr; { const int rc = workspace(st, (size_t)S * M * N * sizeof(float), &wsv); if (rc) return rc; }
+    std::unique_lock<std::mutex> hold; void *wsv = nullptr; { const int rc = workspace(st, (size_t)S * M * N * sizeof(float), &wsv, hold); if (rc) return rc; }      // (held until both kernels are queued)
     float *ws = static_cast<float *>(wsv);
     launch_gemm(ta, tb, T, dim3(grid.x, grid.y, S), st, M, N, K, alpha, d_A, (long long)lda, d_B, (long long)ldb, beta, d_C, (long long)ldc, ws, Kc, kblk);
     const long long MN = (long long)M * N;
@@ -745,6 +747,10 @@ extern "C" int k3_mat_softmax_rows(int32_t op, float *d_dst, int64_t ldd, const 
 extern "C" int k3_mat_normalize_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_in, int64_t ldi, const float *d_out_deriv, int64_t ldo, int32_t rows, int32_t cols, float target_rms, int32_t add_log_stddev, void *st) {
   K3_REQUIRE(d_dst && d_in && (op == 0 || op == 1) && rows >= 0 && cols >= 0 && ldi >= cols && ldd >= cols + (op == 0 && add_log_stddev ? 1 : 0) && target_rms > 0.0f &&
              (op == 0 || (d_out_deriv && ldo >= cols + (add_log_stddev ? 1 : 0))), "k3_mat_normalize_rows: bad argument");
+  // in-place backward (in_deriv aliasing out_deriv) exists for the plain form only: NormalizeComponent advertises kBackpropInPlace only without add_log_stddev
+  // (nnet3/nnet-normalize-component.h Properties()), and the reference's CPU branch for the combination (cu-math.cc DiffNormalizePerRow: the log-stddev term is added
+  // into the aliased matrix BEFORE the products that read it) is not what the kernel's in-place branch computes
+  K3_REQUIRE(!(op == 1 && add_log_stddev && d_dst == d_out_deriv), "k3_mat_normalize_rows: the in-place backward pass is not defined with add_log_stddev");
   if (rows == 0 || cols == 0) return K3_OK;
   hipLaunchKernelGGL(k3_row_normalize_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)st, op, d_dst, (long long)ldd, d_in, (long long)ldi, d_out_deriv, (long long)ldo, rows, cols, target_rms, add_log_stddev ? 1 : 0);
   K3_HIP_CHECK(hipGetLastError());

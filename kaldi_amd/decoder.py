@@ -30,6 +30,13 @@ class CudaFst:
         _l.check(self._L.k3_fst_create_empty(num_states, num_arcs, start, ctypes.byref(self._h)))
         return self
 
+    @classmethod
+    def adopt(cls, handle):
+        """wrap a k3_fst* the C ABI handed out (the receiving side of k3_fst_bcast); this object owns it"""
+        self = cls.__new__(cls); self._L = _l.load(); self._h = ctypes.c_void_p(handle)
+        self.start = int(self._L.k3_fst_start(self._h)); self.num_states = int(self._L.k3_fst_num_states(self._h)); self.num_arcs = int(self._L.k3_fst_num_arcs(self._h))
+        return self
+
     def export_image(self, tensor):
         """copy the graph image into a uint8 CUDA tensor (the collective's buffer)"""
         assert tensor.is_cuda and tensor.dtype == torch.uint8 and tensor.numel() >= self.image()[1]
@@ -147,6 +154,12 @@ class CudaDecoder:
         their arc was examined; default mode -> emitting arcs below the pre-pass bound but not below the final bound (an upper bound)"""
         ev = np.zeros(getattr(self, "_n_sel", None) or self._n, np.int64)
         _l.check(self._L.k3_decoder_order_sensitive_events(self._h, ev.ctypes.data)); return ev
+
+    def PoolGrowths(self):
+        """int32 per finalised utterance: how often its lane has moved to bigger token / link pools (lane_tokens_cap / lane_links_cap are a reservation, like the
+        reference's ntokens_pre_allocated; the growth happens inside the token-passing kernel, from the decoder's spare arena)"""
+        g = np.zeros(getattr(self, "_n_sel", None) or self._n, np.int32)
+        _l.check(self._L.k3_decoder_pool_growths(self._h, g.ctypes.data)); return g
 
     def GetRawLattices(self, copy=False):
         """sequence of RawLattice, one per utterance of the last batch (GetRawLattice, not yet Connect()-ed).  All lattices arrive in

@@ -74,7 +74,7 @@ int main(int argc, char **argv) {
     po.Register("max-active", &max_active, "Decoder max active states. Larger->slower; more accurate"); po.Register("min-active", &min_active, "Decoder min active states (LatticeFasterDecoderConfig)");
     po.Register("beam-delta", &beam_delta, "Increment used when the active-state limits move the beam (LatticeFasterDecoderConfig)");
     po.Register("main-q-capacity", &main_q, "Max tokens alive on one frame of one utterance (-1 = 4 * max-active, capped)"); po.Register("aux-q-capacity", &aux_q, "Max arcs considered on one frame (-1 = 3 * main-q-capacity)");
-    po.Register("ntokens-pre-allocated", &ntok_pre, "Tokens kept per utterance for all frames"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
+    po.Register("ntokens-pre-allocated", &ntok_pre, "Advanced - Number of tokens pre-allocated in host buffers to store lattices. If this size is exceeded the buffer will reallocate (here: an utterance that outgrows it moves to bigger token / link pools inside the decoder kernel)"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
     po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
     po.Register("frames-per-chunk", &frames_per_chunk, "Number of frames in each chunk that is separately evaluated by the neural net (matters with i-vectors: one i-vector per chunk; without them chunking does not change the outputs of a feed-forward model and utterances are evaluated whole)");
     po.Register("extra-left-context", &elc, "(accepted; only 0 is supported)"); po.Register("extra-right-context", &erc, "(accepted; only 0 is supported)");

@@ -48,7 +48,8 @@ class DecoderConfig(ctypes.Structure):
     """k3_decoder_config (include/k3hip.h); decoding fields = LatticeFasterDecoderConfig (decoder/lattice-faster-decoder.h:37-107)."""
     _fields_ = [("beam", ctypes.c_float), ("max_active", ctypes.c_int32), ("min_active", ctypes.c_int32), ("lattice_beam", ctypes.c_float),
                 ("beam_delta", ctypes.c_float), ("frame_tokens_cap", ctypes.c_int32), ("frame_cands_cap", ctypes.c_int32),
-                ("lane_tokens_cap", ctypes.c_int64), ("lane_links_cap", ctypes.c_int64), ("literal_order", ctypes.c_int32), ("hash_ratio", ctypes.c_float), ("fast_frame_tokens", ctypes.c_int32)]
+                ("lane_tokens_cap", ctypes.c_int64), ("lane_links_cap", ctypes.c_int64), ("literal_order", ctypes.c_int32), ("hash_ratio", ctypes.c_float), ("fast_frame_tokens", ctypes.c_int32),
+                ("spare_pool_bytes", ctypes.c_int64)]
 
 WINDOW_TYPES = {"hanning": 0, "sine": 1, "hamming": 2, "povey": 3, "rectangular": 4, "blackman": 5}
 
@@ -104,6 +105,7 @@ def load():
     L.k3_fst_destroy.argtypes = [vp]; L.k3_fst_destroy.restype = None
     L.k3_fst_num_arcs.argtypes = [vp]; L.k3_fst_num_arcs.restype = i64
     L.k3_fst_num_states.argtypes = [vp]; L.k3_fst_num_states.restype = i32
+    L.k3_fst_start.argtypes = [vp]; L.k3_fst_start.restype = i32
     L.k3_fst_image.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     L.k3_comm_create.argtypes = [ctypes.c_char_p, i32, i32, i32, ctypes.POINTER(vp)]; L.k3_comm_destroy.argtypes = [vp]; L.k3_comm_destroy.restype = None
     L.k3_fst_bcast.argtypes = [ctypes.POINTER(vp), vp, i32, i32, vp]
@@ -115,7 +117,7 @@ def load():
     L.k3_decoder_advance_decoding_lanes.argtypes = [vp, i32, vp, vp, i32, i64, vp]
     L.k3_decoder_init_channels.argtypes = [vp, vp, i32, vp]; L.k3_decoder_finalize_channels.argtypes = [vp, vp, i32, vp]
     L.k3_decoder_finalize_decoding.argtypes = [vp, vp]; L.k3_decoder_num_frames_decoded.argtypes = [vp, i32]; L.k3_decoder_num_frames_decoded.restype = i32
-    L.k3_decoder_lattice_info.argtypes = [vp, vp]; L.k3_decoder_order_sensitive_events.argtypes = [vp, vp]
+    L.k3_decoder_lattice_info.argtypes = [vp, vp]; L.k3_decoder_order_sensitive_events.argtypes = [vp, vp]; L.k3_decoder_pool_growths.argtypes = [vp, vp]
     L.k3_decoder_get_raw_lattices.argtypes = [vp] + [vp] * 10
     L.k3_decoder_get_best_path.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]
     L.k3_fst_export_image.argtypes = [vp, vp]; L.k3_fst_import_image.argtypes = [vp, vp]

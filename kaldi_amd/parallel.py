@@ -45,6 +45,27 @@ def broadcast_graph(fst, tid2pdf, rank, world, device, src=0):
     torch.cuda.synchronize(device)
     return cf
 
+def broadcast_graph_abi(fst, tid2pdf, rank, world, id_file, src=0, timeout_s=120):
+    """The same broadcast through the PRODUCT's C ABI (what batched-wav-nnet3-cuda2 --nccl-id-file does): k3_comm_create (an RCCL communicator of the library's own, the 128-byte
+    ncclUniqueId through `id_file`) + k3_fst_bcast (shape, then the packed device image, one ncclBroadcast each) + k3_comm_destroy.  Returns (CudaFst, ranks of the communicator).
+    The caller sets the device first (one process per GPU)."""
+    import ctypes
+    from . import decoder, lib
+    L = lib.load()
+    if world == 1: return decoder.CudaFst(fst, tid2pdf), 1
+    assert src == 0, "k3_comm_create: rank 0 publishes the id"
+    cf = decoder.CudaFst(fst, tid2pdf) if rank == src else None
+    comm = ctypes.c_void_p()
+    lib.check(L.k3_comm_create(str(id_file).encode(), rank, world, int(timeout_s), ctypes.byref(comm)))
+    try:
+        h = ctypes.c_void_p(cf._h.value if cf is not None else None)
+        lib.check(L.k3_fst_bcast(ctypes.byref(h), comm, src, rank, None))
+        torch.cuda.synchronize()
+        if cf is None: cf = decoder.CudaFst.adopt(h.value)
+    finally:
+        L.k3_comm_destroy(comm)
+    return cf, world
+
 def reduce_rtfx(audio_s, wall_s, device=None):
     """whole-job RTFx = sum(audio) / max(wall) over ranks"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1: return audio_s / wall_s

@@ -703,3 +703,42 @@ def test_batched_wav_nnet3_cuda_first_generation_driver(tmp_path):
     # cuda2-only behaviour stays with cuda2: a CTM file name as output is refused without a postprocessor by both; the v1-only options are unknown to cuda2
     u = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--batch-drain-size=2"] + common + tail + [f"ark,t:{td}/x.txt"], capture_output=True, text=True); assert u.returncode != 0
     assert subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda"), "x"], capture_output=True).returncode == 1
+
+
+def test_ntokens_pre_allocated_is_a_reservation_60s_utterance_equals_the_reference_decoder(tmp_path):
+    """--ntokens-pre-allocated only reserves (cudadecoder/cuda-decoder.cc:232-238): a 60 s utterance that needs many times --ntokens-pre-allocated=200000 is decoded without
+    error -- its lane moves to bigger pools inside the token-passing kernel -- and its raw lattice is the reference LatticeFasterDecoder's (oracle/_ref, the reference's own
+    decoder source) on the same log-likelihoods: every arc, label and cost bit; the same file next to short ones, and with a roomy reservation, gives the same record."""
+    from kaldi_amd import feat, nnet3
+    from oracle import kaldi_io as kio, ref_decoder as rd, lattice_oracle as lo
+    from tests import lattice_sig as lsig
+    td = str(tmp_path); N = 120; lens = [960000, 16000, 9000]
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst"); t2p = synth.tid2pdf(N)
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n")
+    base = [os.path.join(BIN, "batched-wav-nnet3-cuda2"), "--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000",
+            "--max-batch-size=3", "--determinize-lattice=false", "--write-compact=false"]
+    tail = [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp"]
+    a = subprocess.run(base + ["--ntokens-pre-allocated=200000"] + tail + [f"ark,t:{td}/small.txt"], capture_output=True, text=True); assert a.returncode == 0, a.stderr
+    assert "Decoded 3 utterances, 0 with errors." in a.stderr, a.stderr[-600:]
+    b = subprocess.run(base + ["--ntokens-pre-allocated=12000000"] + tail + [f"ark,t:{td}/big.txt"], capture_output=True, text=True); assert b.returncode == 0, b.stderr
+    ls_, lb_ = _parse_text_lattices(f"{td}/small.txt"), _parse_text_lattices(f"{td}/big.txt")
+    canon = lambda lat: (sorted((x[2], x[3], float(x[4]), float(x[5])) for x in lat[0]), sorted(float(v) for v in lat[1].values()))      # (state numbers depend on the order the GPU happened to emit the arcs in)
+    assert sorted(ls_) == sorted(lb_) == ["utt0", "utt1", "utt2"]
+    for k in ls_: assert canon(ls_[k]) == canon(lb_[k]) and len(ls_[k][0]) > 0, k      # the same lattices whatever the reservation
+    # the reference decoder on the log-likelihoods the program's network stage makes of the long file
+    dev = torch.device("cuda:0"); sf = feat.SpectralFeatures(feat.fbank_options(dither=0.0, num_bins=40))
+    w = kio.read_wav(f"{td}/u0.wav")[0].astype(np.float32); wo, fo, total, fo_h = sf.offsets([len(w)], dev)
+    nn = nnet3.Nnet(f"{td}/final.mdl"); nb = nnet3.NnetBatch(nn, [total], 3); ll = nb.forward(sf.ComputeFeatures(torch.from_numpy(w).to(dev), wo, fo, total)).cpu().numpy()
+    from kaldi_amd import decoder
+    dec = decoder.CudaDecoder(decoder.CudaFst(graph, t2p), decoder.decoder_config(beam=15.0, lattice_beam=8.0, max_active=10000, literal_order=1, lane_tokens_cap=200000, lane_links_cap=400000), 1, N)
+    dec.DecodeBatch(torch.from_numpy(ll).to(dev), np.array([0, ll.shape[0]])); info = dec.LatticeInfo(); lat = dec.GetRawLattices(copy=True)[0]
+    assert info[0, 2] == 0 and info[0, 4] > 2 * 200000 and dec.PoolGrowths()[0] >= 2, (info[0], dec.PoolGrowths())
+    if rd.available():
+        assert lsig.canonical_of_reference(rd.decode(graph, ll, t2p, lo.Config(beam=15.0, lattice_beam=8.0, max_active=10000))) == lsig.canonical_of_raw(lat)
+    # ... and it is the record the program wrote (Connect()-ed): same arcs
+    t = subprocess.run(base + ["--ntokens-pre-allocated=200000", "--file-limit=1"] + tail + [f"ark,t:{td}/one.txt"], capture_output=True, text=True); assert t.returncode == 0, t.stderr
+    arcs, fins = _parse_text_lattices(f"{td}/one.txt")["utt0"]; ref = lat.connect()
+    assert len(arcs) == ref.num_arcs and sorted((x[2], x[3]) for x in arcs) == sorted(zip(ref.arc_ilabel.tolist(), ref.arc_olabel.tolist()))

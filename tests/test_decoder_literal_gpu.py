@@ -152,3 +152,44 @@ def test_bench_configuration_against_the_reference_decoder(tmp_path):
     report["max_symmetric_difference_frac"] = max(p["symmetric_difference"] / max(1, p["ref_arcs"]) for p in report["per_utt"])
     os.makedirs("gpurun_out", exist_ok=True); json.dump(report, open("gpurun_out/decoder_parity_bench_config.json", "w"), indent=1)
     assert report["literal_identical"] == U, report
+
+
+@pytest.mark.parametrize("literal", [1, 0])
+def test_lane_pools_are_a_reservation_and_grow_inside_the_kernel(literal):
+    """k3_decoder_config::lane_tokens_cap / lane_links_cap (the reference's ntokens_pre_allocated) only RESERVE (cuda-decoder.cc:232-238): lanes that outgrow them move to
+    bigger pools from the spare arena inside the token-passing kernel -- several times over a long utterance -- and the lattices are those of a decoder whose pools were big
+    enough from the start, bit for bit (literal_order: also the reference decoder's); without a spare arena the reservation is the hard limit it used to be.  Whole-utterance
+    and chunked (AdvanceDecoding) calls, lanes reused for a second batch."""
+    from kaldi_amd import decoder
+    N = 80; f = synth.make_hclg(3000, 8000, N, seed=9, start_degree=60); t2p = synth.tid2pdf(N); cf = decoder.CudaFst(f, t2p)
+    rng = np.random.default_rng(17)
+    lls = [(rng.standard_normal((T, N)) * 2.5).astype(np.float32) for T in (700, 60, 333)]      # ~20 s, 2 s and 10 s at 3x subsampling
+    cfg = dict(beam=14.0, lattice_beam=7.0, max_active=3000)
+    big, info_big, dec_big = _decode(cf, N, lls, literal=literal, **cfg)
+    assert (info_big[:, 2] == 0).all() and (dec_big.PoolGrowths() == 0).all()
+    small = dict(_CAPS, frame_tokens_cap=8192, frame_cands_cap=32768, lane_tokens_cap=8192, lane_links_cap=40000, **cfg)      # the smallest legal reservation: one frame's worth
+    need_t = int(info_big[:, 4].max()); assert need_t > 8 * small["lane_tokens_cap"], need_t      # the long utterance needs many times the reservation
+    ro = np.concatenate([[0], np.cumsum([l.shape[0] for l in lls])]); x = torch.from_numpy(np.concatenate(lls)).cuda()
+    dec = decoder.CudaDecoder(cf, decoder.decoder_config(literal_order=literal, **small), len(lls), N)
+    for rep in range(2):      # (the second batch starts on the pools the first one grew into)
+        dec.DecodeBatch(x, ro); info = dec.LatticeInfo(); lats = dec.GetRawLattices(copy=True); g = dec.PoolGrowths()
+        assert (info[:, 2] == 0).all(), info[:, 2]
+        assert g[0] >= 3 and g[2] >= 2, g
+        for u in range(len(lls)): assert lats[u].diff(big[u]) == "", (rep, u)
+        if literal and rep == 0: _check_against_oracle(dec, 2, lats[2], f, lls[2], t2p, cfg)
+    # chunked
+    dec2 = decoder.CudaDecoder(cf, decoder.decoder_config(literal_order=literal, **small), 2, N)
+    dec2.InitDecoding(2, 720); done = [0, 0]
+    for chunk in ([300, 100], [1, 233], [399, 0]):
+        parts = [lls[u][done[k]:done[k] + c] for k, (u, c) in enumerate(zip((0, 2), chunk))]
+        dec2.AdvanceDecoding(torch.from_numpy(np.concatenate(parts)).cuda(), np.concatenate([[0], np.cumsum(chunk)])); done = [d + c for d, c in zip(done, chunk)]
+    dec2.FinalizeDecoding(); l2 = dec2.GetRawLattices()
+    assert l2[0].diff(big[0]) == "" and l2[1].diff(big[2]) == "" and (dec2.PoolGrowths() >= 2).all()
+    # no spare arena: the reservation is a hard limit, reported per utterance
+    dec3 = decoder.CudaDecoder(cf, decoder.decoder_config(literal_order=literal, spare_pool_bytes=0, **small), len(lls), N)
+    dec3.DecodeBatch(x, ro); i3 = dec3.LatticeInfo(check=False)
+    assert i3[0, 2] == -4 and i3[2, 2] == -4, i3[:, 2]      # K3_ERR_OVERFLOW
+    # an arena that holds two growths of one lane: not enough for the long utterance
+    dec4 = decoder.CudaDecoder(cf, decoder.decoder_config(literal_order=literal, spare_pool_bytes=(16 * 8192 + 20 * 40000) * 7, **small), 1, N)
+    dec4.DecodeBatch(x[:700].contiguous(), np.array([0, 700])); i4 = dec4.LatticeInfo(check=False)
+    assert i4[0, 2] == -4, i4[:, 2]

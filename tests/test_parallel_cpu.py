@@ -76,3 +76,6 @@ def test_comm_rendezvous_refuses_files_of_other_runs(tmp_path, monkeypatch):
     run(b"\x07" * 128 + struct.pack("<QQ", magic, 0), None, 3600)          # no run identity: an hour-old file of a crashed run
     run(b"\x09" * 128 + struct.pack("<QQ", magic, 12345), "run-2", 0)      # a fresh file of ANOTHER run (different nonce), same path reused
     run(b"\x01" * 128, "run-3", 0)                                         # a file in the old format (no magic)
+    h = 1469598103934665603
+    for ch in b"none": h = ((h ^ ch) * 1099511628211) % (1 << 64)
+    run(b"\x05" * 128 + struct.pack("<QQ", magic, h), "none", 3600)        # the SAME run identity (torchrun's static rendezvous calls every run "none") on an hour-old file: age decides

@@ -65,3 +65,21 @@ def test_bench_pipelined_steps_give_the_single_stream_lattices():
     assert a["pipeline"].startswith("batch k+1") and b["pipeline"].startswith("none") and a["stage_ms_in_pipeline"] is not None and b["stage_ms_in_pipeline"] is None
     assert set(a["stage_ms"]) == set(b["stage_ms"]) and all(v > 0 for v in a["stage_ms"].values())
     assert a["roofline"]["frac"] > 0 and a["roofline_gemm"]["frac_back_to_back"] > 0 and a["cpu_baseline"] is None if "cpu_baseline" in a else True
+
+
+def test_c_abi_rccl_collectives_on_two_devices(tmp_path):
+    """N > 1 through the product's C ABI, the moment two devices are visible (skipped on the one-GPU test box; the driver's multi-GPU node runs it): k3_comm_create with a real
+    2-rank RCCL communicator, k3_fst_bcast from rank 0 (the only rank that built the graph) -- identical image bytes on both ranks, identical lattices decoded from them --
+    and k3_comm_allreduce_f32 summing rank-dependent buffers."""
+    import json, subprocess, sys
+    if torch.cuda.device_count() < 2: pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, K3_COMM_NONCE="test-%d" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank_worker.py"), str(r), "2", str(tmp_path / "nccl.id"), str(tmp_path / f"r{r}.json")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    a, b = (json.load(open(tmp_path / f"r{r}.json")) for r in range(2))
+    assert a["ranks"] == b["ranks"] == 2 and (a["states"], a["arcs"], a["start"]) == (b["states"], b["arcs"], b["start"]) == (2000, a["arcs"], a["start"])
+    assert a["image_sha"] == b["image_sha"] and a["lattice_sha"] == b["lattice_sha"] and a["lattice_arcs"] > 0
+    assert a["allreduce_ok"] and b["allreduce_ok"]
