@@ -418,7 +418,7 @@ def main():
     paths = decs["literal"].FramePathCounts() if decs else None
     if decs and "literal_b" in decs:      # (two alternating decoder objects: their counts together)
         pb = decs["literal_b"].FramePathCounts()
-        for k_ in ("lds_path", "given_up", "general_path"): paths[k_] += pb[k_]
+        for k_ in ("lds_path", "given_up", "general_path", "cycles_lds_path", "cycles_general_path"): paths[k_] += pb[k_]
         for k_, v_ in pb["give_up_reasons"].items(): paths["give_up_reasons"][k_] = paths["give_up_reasons"].get(k_, 0) + v_
     audio_s = U * args.utt_seconds * world * args.steps
     two = run("two_pass", args.steps, args.warmup) if "two_pass" in decs else None
@@ -466,7 +466,20 @@ def main():
             line["roofline"] = {"bound": "hbm", "kernel": "k3_decode_forward_literal_kernel (one launch = all frames of all lanes)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                                 "traffic": None, "traffic_measured_in_run": False, "algorithmic_bytes_per_launch": ab,
                                 "note": "algorithmic bytes (SURVEY 8d: 32 B/emitting arc traversed + 28 B/eps arc traversed + 16 B/token) from device counters / HIP-event time of the kernel on its launch stream; "
-                                        "bound by the per-frame chain of ~70 barrier-separated phases (each a few thousand cycles of dependent LDS / L2 accesses), not by bandwidth: frames of <= 1536 tokens run entirely in LDS (decode_stats.frames_by_path), the first frames of each utterance (the start state's thousands of arcs) run on the HBM-scratch path and move `traffic` (several x the algorithmic bytes, in 4-64 B requests); DESIGN.md section 5"}
+                                        "bound by the per-frame chain of ~70 barrier-separated phases (each a few thousand cycles of dependent LDS / L2 accesses), not by bandwidth (roofline_latency is the bound that applies): frames of <= 1536 tokens run entirely in LDS (decode_stats.frames_by_path), the first frames of each utterance (the start state's thousands of arcs) run on the HBM-scratch path and move `traffic`; `traffic` is FETCH_SIZE + WRITE_SIZE as reported, and the calibration of profiles/hbm_counter_calibration_r04.json says how to read it for this pattern: a random 4 - 16 B read counts 64 B, a random 4 - 16 B write or atomic 32 B -- the counters tally REQUESTS (60.7 GB of reads = 0.95 G requests, 42.1 GB of writes = 1.3 G requests per launch), so traffic / algorithmic bytes ~ 7 is the request granularity of narrow accesses, not re-reading; DESIGN.md section 4"}
+            # The HBM roofline above is the wrong yardstick for this kernel: a lane is a DEPENDENT CHAIN -- frame after frame, and inside a frame the ~70 barrier-separated
+            # phases of the reference's serial algorithm unrolled (cutoff, bound pass, accept pass, eps rounds, closure sub-graph, two hash-order passes, queue order, component replay,
+            # creation labels).  The cheapest such a phase gets on this hardware -- LDS read -> DPP scan -> LDS atomic -> workgroup barrier over 8 wavefronts -- is what the LDS-resident
+            # frames of <= 512 tokens cost per phase: 141 k cycles / 70 (profiles/r04_literal_frames_by_size.txt).  floor = frames x phases x that / clock; all lanes run in parallel.
+            n_frames = int(info[:, 9].max()); ph, cpp, ghz = 70, 2014.0, 2.1
+            floor_ms = n_frames * ph * cpp / (ghz * 1e6)
+            lane_launches = max(1, (paths["lds_path"] + paths["general_path"]) // max(1, n_frames))      # (a frame is counted once: on the LDS path, or -- given up there or not -- on the general path)
+            mean_lane_ms = (paths["cycles_lds_path"] + paths["cycles_general_path"]) / lane_launches / (ghz * 1e6)
+            line["roofline_latency"] = {"bound": "latency: the per-lane chain of frames x barrier-separated phases", "kernel": "k3_decode_forward_literal_kernel", "frames_per_lane": n_frames, "phases_per_frame": ph,
+                                        "cycles_per_phase_floor": cpp, "shader_clock_ghz": ghz, "floor_ms": floor_ms, "achieved_ms": acc[5], "frac": floor_ms / acc[5], "mean_lane_ms": mean_lane_ms, "frac_mean_lane": floor_ms / mean_lane_ms,
+                                        "note": "floor = every frame at the cost of an LDS-resident frame of <= 512 tokens (70 phases x 2.0 k cycles, measured); achieved_ms = the kernel (its slowest lane, 512 lanes two to a CU), "
+                                                "mean_lane_ms = shader cycles per lane from the kernel's own counters / 2.1 GHz.  What separates them from the floor: frames above 512 tokens (cost grows ~0.28 k cycles per token), the "
+                                                "frames beyond the LDS path's 1536 tokens on HBM scratch (46 % of the cycles), the first ~12 frames of every utterance (3 - 25 k tokens: 35 % of the cycles) -- profiles/r04_literal_frames_by_size.txt, r04_literal_phase_profile_by_size.txt"}
             line["roofline"]["traffic_command"] = TRAFFIC_CMD
             tr = measure_traffic(args) if (args.measure_traffic and world == 1) else None
             if tr and "traffic_bytes_per_launch" in tr:

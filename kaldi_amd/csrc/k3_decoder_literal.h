@@ -705,6 +705,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
           if (n_new >= 0) {
             cur_base += n_cur; n_cur = n_new; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1; v_valid = true; n_fast++;
             if (tid == 0) cyc_fast += (long long)__builtin_readcyclecounter() - cyc_t0;
+#ifdef K3_LIT_FRAMECYC      // profiling builds only (tools/prof_frames.py): FrameStats' adaptive_beam column = cycles of the frame, > 0: LDS-resident path
+            if (tid == 0) st_ab[f] = (float)((long long)__builtin_readcyclecounter() - cyc_t0);
+#endif
             continue;
           }
           __syncthreads();
@@ -1027,6 +1030,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     K3_LT(11);
     cur_base = nb; n_cur = n; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1;
     if (tid == 0 && f >= 0) cyc_general += (long long)__builtin_readcyclecounter() - cyc_t0;
+#ifdef K3_LIT_FRAMECYC      // (< 0: general path, a given-up attempt on the LDS path included; cur_cutoff column = 1 when there was one)
+    if (tid == 0 && f >= 0) { st_ab[f] = -(float)((long long)__builtin_readcyclecounter() - cyc_t0); }
+#endif
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
   }
   { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { k3a_add(&sh.n_eps, a); k3a_add(&sh.n_emit, b); k3a_add(&sh.n_os, c); } }

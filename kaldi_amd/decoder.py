@@ -189,7 +189,8 @@ class CudaDecoder:
         and why the LDS path gave frames up (k3_decoder_phase_cycles of the shipped library; reading resets the counters)"""
         c = np.zeros(16, np.int64); _l.check(self._L.k3_decoder_phase_cycles(self._h, c.ctypes.data))
         names = ("tokens", "table", "hash", "labels", "worklist", "eps_links", "degree", "closure", "queue", "stack", "mismatch")
-        return dict(lds_path=int(c[12]), given_up=int(c[13]), general_path=int(c[14]), give_up_reasons={n: int(v) for n, v in zip(names, c[:11]) if v})
+        return dict(lds_path=int(c[12]), given_up=int(c[13]), general_path=int(c[14]), give_up_reasons={n: int(v) for n, v in zip(names, c[:11]) if v},
+                    cycles_lds_path=int(c[15]), cycles_general_path=int(c[11]))      # shader cycles summed over the lanes (general: a given-up attempt on the LDS path included)
 
     def SetProfiling(self, on=True):
         _l.check(self._L.k3_decoder_set_profiling(self._h, int(on)))
