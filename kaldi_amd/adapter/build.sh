@@ -53,7 +53,7 @@ names = [l.rstrip("\n") for l in open(sys.argv[1]) if l.strip()]
 # the linker prints demangled names; get the mangled ones back from the objects' symbol tables
 import glob, os
 B = os.path.dirname(sys.argv[1])
-und = subprocess.run("nm -u " + " ".join(glob.glob(B + "/obj/*.o") + [B + "/cu-k3.o"]) + " | awk '{print $2}' | sort -u", shell=True, capture_output=True, text=True).stdout.split()
+und = subprocess.run("nm -u " + " ".join(glob.glob(B + "/obj/*.o") + glob.glob(B + "/obj_chain/*.o") + [B + "/cu-k3.o"]) + " | awk '{print $2}' | sort -u", shell=True, capture_output=True, text=True).stdout.split()
 dem = subprocess.run(["c++filt"], input="\n".join(und), capture_output=True, text=True).stdout.split("\n")
 want = set(names); out = []
 for m, d in zip(und, dem):
@@ -94,6 +94,21 @@ link_with_trampolines cuda-pipeline-example "$ROOT/tests/adapter/cuda_pipeline_e
 link_with_trampolines cuda-online-pipeline-example "$ROOT/tests/adapter/cuda_online_pipeline_example.cc $ROOT/kaldi_amd/bin/k3_host.o $ROOT/kaldi_amd/bin/k3_lattice.o $ROOT/kaldi_amd/bin/k3_mbr.o"
 FLAGS="$FLAGS_SAVE2"
 echo "built $B/cuda-pipeline-example $B/cuda-online-pipeline-example"
+# nnet3-chain-train with the REFERENCE's command line and example archives: chainbin/nnet3-chain-train.cc, nnet3/nnet-chain-training.cc (NnetChainTrainer), nnet3/nnet-chain-example.cc,
+# nnet3/nnet-example.cc and nnet3/nnet-example-utils.cc compiled UNMODIFIED over the adapter; chain-k3.cc stands behind chain::ComputeChainObjfAndDeriv, chain::DenominatorGraph,
+# chain::Supervision::Read and fst::ReadFstKaldi (k3_chain_* kernels, the host layer's FST reader); the chain library's other members resolve to loud trampolines
+mkdir -p $B/obj_chain
+MFA="$MF -DK3_ADAPTER -I $ROOT/include -I $ROOT/kaldi_amd/host -I /opt/rocm/include -D__HIP_PLATFORM_AMD__"
+for f in nnet3/nnet-chain-training nnet3/nnet-chain-example nnet3/nnet-example nnet3/nnet-example-utils; do
+  o=$B/obj_chain/$(basename $f).o; if [ ! -f $o ] || [ $R/$f.cc -nt $o ]; then g++ $MFA -c $R/$f.cc -o $o || { echo "FAILED $f"; exit 1; }; fi
+done
+g++ $MFA -c $HERE/chain-k3.cc -o $B/obj_chain/chain-k3.o
+FLAGS_SAVE3="$FLAGS"; FLAGS="$MFA"
+link_with_trampolines nnet3-chain-train-egs "$R/chainbin/nnet3-chain-train.cc $B/obj_chain/chain-k3.o $B/obj_chain/nnet-chain-training.o $B/obj_chain/nnet-chain-example.o $B/obj_chain/nnet-example.o $B/obj_chain/nnet-example-utils.o $ROOT/kaldi_amd/bin/k3_host.o $ROOT/kaldi_amd/bin/k3_lattice.o $ROOT/kaldi_amd/bin/k3_mbr.o"
+# ... and the reference's chainbin/nnet3-chain-copy-egs.cc over the same objects: text <-> binary example archives (Supervision::Write of chain-k3.cc on the way out)
+link_with_trampolines nnet3-chain-copy-egs "$R/chainbin/nnet3-chain-copy-egs.cc $B/obj_chain/chain-k3.o $B/obj_chain/nnet-chain-training.o $B/obj_chain/nnet-chain-example.o $B/obj_chain/nnet-example.o $B/obj_chain/nnet-example-utils.o $ROOT/kaldi_amd/bin/k3_host.o $ROOT/kaldi_amd/bin/k3_lattice.o $ROOT/kaldi_amd/bin/k3_mbr.o"
+FLAGS="$FLAGS_SAVE3"
+echo "built $B/nnet3-chain-train-egs $B/nnet3-chain-copy-egs"
 # kaldi::CudaSpectralFeatures with the reference's signatures (include/k3_cuda_features.h) in a caller that uses the reference's own WaveData / table IO / option classes
 FLAGS="$FLAGS -I $ROOT/include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__"
 link_with_trampolines cuda-features-example $ROOT/tests/adapter/cuda_features_example.cc

@@ -351,3 +351,68 @@ def test_chain_training_iteration_with_end_to_end_supervisions(tmp_path):
         assert np.linalg.norm(rv[3:] - p0) > 0.1
         if rel <= 2e-3: return
     pytest.fail(f"|params - ref| / |ref - initial| = {tried}")
+
+
+def test_nnet3_chain_train_with_the_reference_command_line_and_example_archives(tmp_path):
+    """chainbin/nnet3-chain-train.cc ITSELF over the adapter (kaldi_amd/adapter/_build/nnet3-chain-train-egs: the reference's main, NnetChainTrainer, NnetChainExample readers and
+    computation-request code unmodified; chain-k3.cc behind ComputeChainObjfAndDeriv / DenominatorGraph / Supervision::Read / ReadFstKaldi): the reference's command line
+      nnet3-chain-train [options] <raw-nnet-in> <denominator-fst-in> <chain-training-examples-in> <raw-nnet-out>
+    on merged example archives (text as tests/chain_egs.py writes them, and binary as the reference's nnet3-chain-copy-egs -- same objects -- rewrites them).  Checked: the objective
+    of the first minibatch is the one the spec-driven program (nnet3-chain-train, itself held to the CPU reference above) gets on the same minibatch -- i.e. the merged supervision
+    FST read from the archive, cut back into sequences, gives the per-sequence numerator exactly --; text and binary archives train to the same model bit for bit; several minibatches,
+    xent regularisation, deriv weights and an end-to-end supervision run through; the parsed log-prob line is there."""
+    import re, struct
+    from kaldi_amd import synth
+    from tests import chain_egs as ce
+    B_ = os.path.join(ROOT, "kaldi_amd", "adapter", "_build"); exe = os.path.join(B_, "nnet3-chain-train-egs"); cp = os.path.join(B_, "nnet3-chain-copy-egs"); spec_exe = os.path.join(B_, "nnet3-chain-train")
+    for e in (exe, cp, spec_exe):
+        if not os.path.exists(e): pytest.fail(f"{e} is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    td = str(tmp_path); B, T, P, s = 8, 12, 50, 3; lc = rc = 8; Tin = (T - 1) * s + 1 + lc + rc
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=P, calib_feats=calib, out_std=1.5, orthonormal_constraint=-1.0).write(f"{td}/m.raw")
+    den = synth.make_den_fst(120, P, seed=5, mean_degree=6.0, hub_degree=60); den.write_openfst(f"{td}/den.fst")
+    fb = lambda f: (np.ascontiguousarray(f.arc_offsets, np.int64).tobytes() + np.ascontiguousarray(f.ilabel, np.int32).tobytes() + np.ascontiguousarray(f.nextstate, np.int32).tobytes() +
+                    np.ascontiguousarray(f.weight, np.float32).tobytes() + np.ascontiguousarray(f.final, np.float32).tobytes())
+    egs = []; nmb = 3
+    for m in range(nmb):
+        rng = np.random.default_rng(B * 100 + T + 7 * m); x = (rng.standard_normal((Tin * B, 40)) * 1.2 + 16.5).astype(np.float32)
+        fsts = [synth.make_supervision_fst(T, P, seed=200 + i + 50 * m) for i in range(B)]; merged = synth.merge_supervision_fsts(fsts)
+        egs.append(ce.minibatch(f"mb{m}", x, B, T, s, lc, rc, P, merged_fst=merged))
+        if m == 0:      # the same minibatch for the spec-driven program
+            _kaldi_matrix(f"{td}/in0.mat", x)
+            so = np.concatenate([[0], np.cumsum([f.num_states for f in fsts])]).astype(np.int32); ab = np.concatenate([[0], np.cumsum([int(f.arc_offsets[-1]) for f in fsts])])
+            with open(f"{td}/chain0.spec", "wb") as fh:
+                fh.write(struct.pack("<11i3f", 0x4b36, den.num_states, den.start, int(den.arc_offsets[-1]), P, B, T, merged.num_states, int(merged.arc_offsets[-1]), int(so[-1]), int(ab[-1]), 1.0e-05, 5.0e-05, 1.0))
+                fh.write(fb(den)); fh.write(fb(merged)); fh.write(so.tobytes())
+                fh.write(np.concatenate([[0]] + [np.asarray(f.arc_offsets[1:], np.int64) + b for f, b in zip(fsts, ab[:-1])]).astype(np.int64).tobytes())
+                for k, dt in (("ilabel", np.int32), ("nextstate", np.int32), ("weight", np.float32), ("final", np.float32)): fh.write(np.concatenate([getattr(f, k) for f in fsts]).astype(dt).tobytes())
+    ce.write_chain_egs_text(f"{td}/one.txt", egs[:1]); ce.write_chain_egs_text(f"{td}/all.txt", egs)
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"); opts = ["--print-interval=1", "--leaky-hmm-coefficient=1.0e-05", "--l2-regularize=5.0e-05", "--out-of-range-regularize=0.0", "--srand=3"]
+    def objf(stderr, which="Overall average objective function for 'output' is "):
+        m_ = re.search(re.escape(which) + r"(-?[0-9.e+-]+)", stderr); assert m_, stderr[-1500:]; return float(m_.group(1))
+    # (1) first minibatch: the objective against the spec-driven program's iteration 0
+    g = subprocess.run([exe] + opts + [f"{td}/m.raw", f"{td}/den.fst", f"ark,t:{td}/one.txt", f"{td}/o1.raw"], capture_output=True, text=True, env=env); assert g.returncode == 0, g.stderr[-3000:]
+    assert "[this line is to be parsed by a script:] log-prob-per-frame=" in g.stderr and "Wrote raw model to" in g.stderr
+    q = subprocess.run([spec_exe, f"{td}/m.raw", str(s), f"{td}/in0.mat", f"{td}/chain0.spec", "1", "0.002", "0.0", f"{td}/q.raw", f"{td}/q.vec"], capture_output=True, text=True, env=env); assert q.returncode == 0, q.stderr[-3000:]
+    qv = _read_kaldi(f"{td}/q.vec"); want = float(qv[0] / qv[2])
+    assert abs(objf(g.stderr) - want) <= 2e-5 * max(1.0, abs(want)), (objf(g.stderr), want)
+    # (2) text and binary archives: the same trained model, bit for bit; the binary one is what the reference's copy tool writes (Supervision::Write of the adapter)
+    c = subprocess.run([cp, f"ark,t:{td}/all.txt", f"ark:{td}/all.egs"], capture_output=True, text=True, env=env); assert c.returncode == 0 and "wrote 3" in c.stderr, c.stderr[-1500:]
+    c = subprocess.run([cp, f"ark:{td}/all.egs", f"ark,t:{td}/all2.txt"], capture_output=True, text=True, env=env); assert c.returncode == 0, c.stderr[-1500:]
+    outs = []
+    for spec_ in (f"ark,t:{td}/all2.txt", f"ark:{td}/all.egs"):      # (all2.txt holds the values the binary archive holds: six significant digits of all.txt were not lost twice)
+        c = subprocess.run([cp, spec_, f"ark:{td}/norm.egs"], capture_output=True, text=True, env=env); assert c.returncode == 0, c.stderr[-1500:]
+        t_ = subprocess.run([exe] + opts + [f"{td}/m.raw", f"{td}/den.fst", f"ark:{td}/norm.egs", f"{td}/o.raw"], capture_output=True, text=True, env=env); assert t_.returncode == 0, t_.stderr[-3000:]
+        assert "for minibatches 2-2 is" in t_.stderr
+        outs.append((open(f"{td}/o.raw", "rb").read(), objf(t_.stderr)))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and np.isfinite(outs[0][1])
+    assert outs[0][0] != open(f"{td}/m.raw", "rb").read()      # the model moved
+    # (3) xent regularisation needs an output-xent node: refused by the reference's own check, loudly
+    x_ = subprocess.run([exe] + opts + ["--xent-regularize=0.1", f"{td}/m.raw", f"{td}/den.fst", f"ark:{td}/all.egs", f"{td}/x.raw"], capture_output=True, text=True, env=env)
+    assert x_.returncode != 0 and "xent" in x_.stderr
+    # (4) deriv weights of zero on every frame: objective reported, model (but for the batch-norm statistics and l2) unchanged by the gradient; usage / bad den FST errors
+    z = [(k, i, [(n_, idx, sup, np.zeros(B * T, np.float32)) for n_, idx, sup, dw in o]) for k, i, o in egs[:1]]; ce.write_chain_egs_text(f"{td}/z.txt", z)
+    zr = subprocess.run([exe] + opts + [f"{td}/m.raw", f"{td}/den.fst", f"ark,t:{td}/z.txt", f"{td}/z.raw"], capture_output=True, text=True, env=env); assert zr.returncode == 0, zr.stderr[-2000:]
+    assert abs(objf(zr.stderr) - want) <= 2e-5 * max(1.0, abs(want))
+    assert subprocess.run([exe, f"{td}/m.raw"], capture_output=True).returncode == 1
+    bad = subprocess.run([exe] + opts + [f"{td}/m.raw", f"{td}/m.raw", f"ark:{td}/all.egs", f"{td}/b.raw"], capture_output=True, text=True, env=env); assert bad.returncode != 0
