@@ -174,6 +174,12 @@ int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32_t num_stre
 int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
                                    float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in,
                                    double *d_stats_out, void *stream);
+/* The same with per-frame weights on the statistics (silence weighting: OnlineIvectorFeature::UpdateFrameWeights with the whole utterance's weights known at the start, what
+ * ivector-extract-online2 --frame-weights-rspecifier does, online2bin/ivector-extract-online2.cc:130-153): d_frame_weights [total frames] (NULL: every frame weighs 1) -- a frame of
+ * weight 0 contributes nothing, otherwise its posteriors are pruned at GetMinPost(weight) = min(0.99, min_post / |weight|) and scaled by posterior_scale * weight
+ * (online2/online-ivector-feature.cc:188-199, :226-236). */
+int k3_ivector_extract_batch_weighted(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, const float *d_frame_weights,
+                                      float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream);
 
 /* ---------------------------------------------------------------- nnet3 forward -------------
  * Replaces, for "simple" feed-forward TDNN / TDNN-F models: nnet3::NnetComputer::Run over the compiled

@@ -128,12 +128,20 @@ __global__ void ivec_splice_lda_multi_kernel(const BatchSeg *__restrict__ segs, 
 // (a wave arg-max each), then pruned and renormalised by lane 0 exactly as VectorToPosteriorEntry does (float arithmetic, same order).
 __global__ void __launch_bounds__(kBlock) ivec_posterior_kernel(const float *__restrict__ x, int D, int G, const float *__restrict__ gconsts, const float *__restrict__ miv_t,
                                                                 const float *__restrict__ iv_t, int num_gselect, float min_post, float post_scale, int64_t total_frames,
-                                                                int32_t *__restrict__ post_g, float *__restrict__ post_w, int32_t *__restrict__ post_n, const BatchSeg *__restrict__ segs = nullptr, int nseg = 0) {
+                                                                int32_t *__restrict__ post_g, float *__restrict__ post_w, int32_t *__restrict__ post_n, const BatchSeg *__restrict__ segs = nullptr, int nseg = 0,
+                                                                const float *__restrict__ frame_w = nullptr) {
   extern __shared__ float s_ll[];                             // [waves per block][G] log-likes, then [waves][2 * num_gselect] selections
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, nw = blockDim.x / kWave;
   const int64_t t = (int64_t)blockIdx.x * nw + wave;
   float *ll = s_ll + (size_t)wave * G; float *sel_p = s_ll + (size_t)nw * G + (size_t)wave * 2 * num_gselect; int *sel_g = (int *)(sel_p + num_gselect);
   if (t >= total_frames) return;                              // whole waves leave together; no block barrier below
+  // frame weights (OnlineIvectorFeature::UpdateStatsForFrames, online-ivector-feature.cc:226-236): a frame of weight 0 has no posteriors; otherwise the pruning threshold is
+  // GetMinPost(weight) = min(0.99, min_post / |weight|) (:188-199) and the posteriors are scaled by posterior_scale * weight
+  if (frame_w) {
+    const float w = frame_w[t];
+    if (w == 0.0f) { if (lane == 0) post_n[t] = 0; return; }
+    min_post = fminf(min_post / fabsf(w), 0.99f); post_scale *= w;
+  }
   const float *xt = x + t * D;
   float mx = -INFINITY;
   for (int g = lane; g < G; g += kWave) {
@@ -227,7 +235,7 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p_in) {
   const int R = p.R, D = p.D, S = p.S, P = p.period, tid = threadIdx.x;
   double *s_x = s_dyn, *s_r = s_x + R, *s_p = s_r + R, *s_ap = s_p + R, *s_lin = s_ap + R, *s_xo = s_lin + R, *s_red = s_xo + R;    // 6R + 4 doubles
   const int max_ent = P * S;
-  int *e_g = (int *)(s_red + kBlock / kWave); int *e_t = e_g + max_ent; float *e_w = (float *)(e_t + max_ent); float *e_gw = e_w + max_ent;   // gw > 0 marks a leader
+  int *e_g = (int *)(s_red + kBlock / kWave); int *e_t = e_g + max_ent; float *e_w = (float *)(e_t + max_ent); float *e_gw = e_w + max_ent;   // gw != 0 marks a leader (weights may be negative)
   double *A = seg ? (seg->quad ? seg->quad : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7)) : p.quad_g ? p.quad_g + (size_t)u * R * R : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7);
   double *C = seg ? seg->chol : p.chol_g + (size_t)u * R * R;
   __shared__ int s_n; __shared__ double s_tot;
@@ -264,7 +272,7 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p_in) {
       s_lin[tid] += a;
     }
     for (int i = tid; i < R * R; i += kBlock) {                                       // quad += sum_g gw_g U_g
-      double a = 0; for (int e = 0; e < n; e++) if (e_gw[e] > 0.f) a += (double)e_gw[e] * p.U[(size_t)e_g[e] * R * R + i];
+      double a = 0; for (int e = 0; e < n; e++) if (e_gw[e] != 0.f) a += (double)e_gw[e] * p.U[(size_t)e_g[e] * R * R + i];
       A[i] += a;
     }
     __syncthreads();
@@ -407,6 +415,10 @@ extern "C" int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, in
 extern "C" int64_t k3_ivector_stats_size(const k3_ivector *iv) { return iv ? 1 + iv->R + (int64_t)iv->R * iv->R : -1; }
 extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
                                               const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream_) {
+  return k3_ivector_extract_batch_weighted(iv, d_feats, ld_feats, h_frame_offsets, num_utts, nullptr, d_ivectors, ld_ivectors, d_cmvn_speaker_stats, d_stats_in, d_stats_out, stream_);
+}
+extern "C" int k3_ivector_extract_batch_weighted(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, const float *d_frame_weights,
+                                                 float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream_) {
   K3_REQUIRE(iv && d_feats && h_frame_offsets && d_ivectors && num_utts > 0, "k3_ivector_extract_batch: null or empty argument");
   K3_REQUIRE(ld_feats >= iv->F && ld_ivectors >= iv->R, "k3_ivector_extract_batch: leading dimension smaller than the row length");
   hipStream_t stream = (hipStream_t)stream_;
@@ -434,7 +446,7 @@ extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_fea
   K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_extract_batch: too many Gaussians for the posterior kernel's LDS tile");
   const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;       // GetMinPost caps it, online-ivector-feature.cc:188-199
   hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((N + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)iv->xpost.p, D, G, iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
-                     iv->o.posterior_scale, N, (int32_t *)iv->post_g.p, (float *)iv->post_w.p, (int32_t *)iv->post_n.p);
+                     iv->o.posterior_scale, N, (int32_t *)iv->post_g.p, (float *)iv->post_w.p, (int32_t *)iv->post_n.p, (const BatchSeg *)nullptr, 0, d_frame_weights);
   EstParams p; p.xstats = (const float *)iv->xstats.p; p.frame_off = d_off; p.post_g = (const int32_t *)iv->post_g.p; p.post_w = (const float *)iv->post_w.p; p.post_n = (const int32_t *)iv->post_n.p;
   p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)iv->quad.p; p.chol_g = (double *)iv->state.p; p.out = d_ivectors; p.ld_out = ld_ivectors; p.out_off = d_row_off;
   p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out; p.acc_tail = iv->acc_tail; p.t_base = 0; p.t_limit = -1; p.k_begin = 0; p.x_io = nullptr; p.segs = nullptr;

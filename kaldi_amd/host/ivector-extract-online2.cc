@@ -26,11 +26,11 @@ int main(int argc, char **argv) {
     IvectorExtractionInfo info; info.Register(&po);
     int32_t length_tolerance = 0, max_batch = 512; bool repeat = false, exact_solve = false; std::string frame_weights;
     po.Register("repeat", &repeat, "If true, output the same number of iVectors as input frames (including repeated data).");
-    po.Register("frame-weights-rspecifier", &frame_weights, "(not supported)"); po.Register("length-tolerance", &length_tolerance, "(accepted; only used with frame weights)");
+    po.Register("frame-weights-rspecifier", &frame_weights, "Archive of frame weights to scale stats");
+    po.Register("length-tolerance", &length_tolerance, "Tolerance on the difference in number of frames for feats and weights");
     po.Register("max-batch-size", &max_batch, "Utterances per GPU batch"); po.Register("exact-solve", &exact_solve, "Solve for the iVector directly (Cholesky) instead of by conjugate gradient, like the GPU reference");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) { po.PrintUsage(); return 1; }
-    if (!frame_weights.empty()) K3H_ERR << "--frame-weights-rspecifier is not supported by this program";
     info.use_most_recent_ivector = false;
     info.Init();
     k3_ivector_model m; memset(&m, 0, sizeof m);
@@ -46,6 +46,8 @@ int main(int argc, char **argv) {
     const int32_t F = m.feat_dim, R = m.ivector_dim, P = info.ivector_period; const int64_t SS = k3_ivector_stats_size(iv);
     auto table = ReadMatrixTable(po.GetArg(2)); TableWriter writer(po.GetArg(3));
     std::map<std::string, size_t> index; for (size_t i = 0; i < table.size(); i++) index[table[i].first] = i;
+    std::map<std::string, std::vector<float>> weights_of;      // --frame-weights-rspecifier: a vector per utterance (:130-153)
+    if (!frame_weights.empty()) for (auto &kv : ReadMatrixTable(frame_weights)) weights_of[kv.first] = std::move(kv.second.data);
     // speakers -> the utterances that exist, in spk2utt order
     struct Spk { std::vector<size_t> utts; std::vector<double> cmvn, stats; bool has_stats = false; };
     std::vector<Spk> spks; int32_t num_done = 0, num_err = 0; bool warned_dim = false; size_t rounds = 0;
@@ -59,12 +61,18 @@ int main(int argc, char **argv) {
       std::vector<size_t> who; for (size_t k = 0; k < spks.size(); k++) if (r < spks[k].utts.size()) who.push_back(k);
       for (size_t b0 = 0; b0 < who.size(); b0 += max_batch) {
         const size_t U = std::min(who.size() - b0, (size_t)max_batch);
-        std::vector<int64_t> fo(1, 0); std::vector<float> all; std::vector<double> cm, st; bool any_state = false; std::vector<size_t> keep;
+        std::vector<int64_t> fo(1, 0); std::vector<float> all, fw; std::vector<double> cm, st; bool any_state = false; std::vector<size_t> keep;
         for (size_t k = 0; k < U; k++) {
           Spk &s = spks[who[b0 + k]]; const Matrix &f = table[s.utts[r]].second; int32_t dim = f.cols;
           if (dim == F + 3) { if (!warned_dim) { K3H_WARN << "Feature dimension is too large by 3, assuming there are pitch features and removing the last 3 dims."; warned_dim = true; } dim -= 3; }
           if (dim != F) K3H_ERR << "Feature dimension " << f.cols << " does not match the extractor's " << F << " for utterance " << table[s.utts[r]].first;
           if (f.rows == 0) { K3H_WARN << "Empty feature matrix for utterance " << table[s.utts[r]].first; num_err++; continue; }
+          if (!frame_weights.empty()) {      // frames past the end of the weights weigh 0; a length off by more than --length-tolerance is an error (:137-149)
+            auto w = weights_of.find(table[s.utts[r]].first);
+            if (w == weights_of.end()) { K3H_WARN << "Did not find weights for utterance " << table[s.utts[r]].first; num_err++; continue; }
+            if (std::abs((int32_t)w->second.size() - f.rows) > length_tolerance) { num_err++; continue; }
+            for (int32_t t = 0; t < f.rows; t++) fw.push_back(t < (int32_t)w->second.size() ? w->second[t] : 0.0f);
+          }
           for (int32_t t = 0; t < f.rows; t++) all.insert(all.end(), f.data.begin() + (size_t)t * f.cols, f.data.begin() + (size_t)t * f.cols + F);
           fo.push_back(fo.back() + f.rows); cm.insert(cm.end(), s.cmvn.begin(), s.cmvn.end()); any_state = any_state || s.has_stats; keep.push_back(who[b0 + k]);
         }
@@ -75,11 +83,12 @@ int main(int argc, char **argv) {
           else { std::vector<double> fresh(SS, 0.0); fresh[1] = m.prior_offset; for (int32_t i = 0; i < R; i++) fresh[1 + R + (size_t)i * R + i] = 1.0; st.insert(st.end(), fresh.begin(), fresh.end()); }
         }
         std::vector<int64_t> ro(n + 1); const int64_t rows = k3_ivector_num_rows(iv, (int32_t)n, fo.data(), ro.data());
-        float *d_f, *d_iv; double *d_cm, *d_si = nullptr, *d_so;
+        float *d_f, *d_iv, *d_fw = nullptr; double *d_cm, *d_si = nullptr, *d_so;
         HIPCHK(hipMalloc((void **)&d_f, all.size() * 4)); HIPCHK(hipMalloc((void **)&d_iv, (size_t)rows * R * 4)); HIPCHK(hipMalloc((void **)&d_cm, cm.size() * 8)); HIPCHK(hipMalloc((void **)&d_so, n * SS * 8));
         HIPCHK(hipMemcpy(d_f, all.data(), all.size() * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_cm, cm.data(), cm.size() * 8, hipMemcpyHostToDevice));
         if (any_state) { HIPCHK(hipMalloc((void **)&d_si, st.size() * 8)); HIPCHK(hipMemcpy(d_si, st.data(), st.size() * 8, hipMemcpyHostToDevice)); }
-        K3H_CHECK_K3(k3_ivector_extract_batch_adapt(iv, d_f, F, fo.data(), (int32_t)n, d_iv, R, d_cm, d_si, d_so, nullptr));
+        if (!frame_weights.empty()) { HIPCHK(hipMalloc((void **)&d_fw, fw.size() * 4)); HIPCHK(hipMemcpy(d_fw, fw.data(), fw.size() * 4, hipMemcpyHostToDevice)); }
+        K3H_CHECK_K3(k3_ivector_extract_batch_weighted(iv, d_f, F, fo.data(), (int32_t)n, d_fw, d_iv, R, d_cm, d_si, d_so, nullptr));
         std::vector<float> h((size_t)rows * R); std::vector<double> so(n * SS);
         HIPCHK(hipMemcpy(h.data(), d_iv, h.size() * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(so.data(), d_so, so.size() * 8, hipMemcpyDeviceToHost));
         for (size_t k = 0; k < n; k++) {
@@ -95,7 +104,7 @@ int main(int argc, char **argv) {
           for (int32_t t = 0; t < f.rows; t++) { for (int32_t d = 0; d < F; d++) { const double x = f.data[(size_t)t * f.cols + d]; s.cmvn[d] += x; s.cmvn[F + 1 + d] += x * x; } s.cmvn[F] += 1.0; }
           num_done++;
         }
-        HIPCHK(hipFree(d_f)); HIPCHK(hipFree(d_iv)); HIPCHK(hipFree(d_cm)); HIPCHK(hipFree(d_so)); if (d_si) HIPCHK(hipFree(d_si));
+        HIPCHK(hipFree(d_f)); HIPCHK(hipFree(d_iv)); HIPCHK(hipFree(d_cm)); HIPCHK(hipFree(d_so)); if (d_si) HIPCHK(hipFree(d_si)); if (d_fw) HIPCHK(hipFree(d_fw));
       }
     }
     writer.Flush();

@@ -80,10 +80,11 @@ class BatchedIvectorExtractor:
     def IvectorDim(self): return self.ivector_dim
     def NumGauss(self): return self.num_gauss
 
-    def GetIvectors(self, feats, frame_offsets, cmvn_speaker_stats=None, stats_in=None, return_stats=False, accumulate_tail=False):
+    def GetIvectors(self, feats, frame_offsets, cmvn_speaker_stats=None, stats_in=None, return_stats=False, accumulate_tail=False, frame_weights=None):
         """-> (ivectors, row_offsets[, stats]).  cmvn_speaker_stats [U, 2, feat_dim+1] / stats_in [U, StatsSize()] (float64, host or GPU): the adaptation state
         the speaker's earlier utterances left (OnlineIvectorExtractorAdaptationState); return_stats: also the i-vector statistics after each utterance -- at its last estimate, or
-        with accumulate_tail over all of its frames (what ivector-extract-online2 --repeat=true hands on)."""
+        with accumulate_tail over all of its frames (what ivector-extract-online2 --repeat=true hands on).  frame_weights [total frames] (float32, host or GPU): the weight of
+        each frame in the statistics (silence weighting, ivector-extract-online2 --frame-weights-rspecifier): 0 drops the frame, w scales its posteriors and prunes them at min(0.99, min_post/|w|)."""
         self._L.k3_ivector_set_accumulate_tail.restype = None; self._L.k3_ivector_set_accumulate_tail(self._h, ctypes.c_int32(1 if accumulate_tail else 0))
         assert feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and feats.stride(1) == 1
         fo = np.ascontiguousarray(np.asarray(frame_offsets, dtype=np.int64)); U = fo.size - 1
@@ -95,8 +96,10 @@ class BatchedIvectorExtractor:
         cm, si = dev(cmvn_speaker_stats), dev(stats_in)
         so = torch.empty((U, self.StatsSize()), dtype=torch.float64, device=feats.device) if return_stats else None
         ptr = lambda t: None if t is None else t.data_ptr()
-        _l.check(self._L.k3_ivector_extract_batch_adapt(self._h, feats.data_ptr(), feats.stride(0), fo.ctypes.data, U, out.data_ptr(), out.stride(0), ptr(cm), ptr(si), ptr(so),
-                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        fw = None if frame_weights is None else torch.as_tensor(frame_weights, dtype=torch.float32).to(feats.device).contiguous()
+        if fw is not None and fw.numel() != int(fo[-1]): raise ValueError("frame_weights: one weight per frame")
+        _l.check(self._L.k3_ivector_extract_batch_weighted(self._h, feats.data_ptr(), feats.stride(0), fo.ctypes.data, U, ptr(fw), out.data_ptr(), out.stride(0), ptr(cm), ptr(si), ptr(so),
+                                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return (out, ro, so) if return_stats else (out, ro)
 
     def StatsSize(self): return int(self._L.k3_ivector_stats_size(self._h))

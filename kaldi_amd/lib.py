@@ -87,7 +87,7 @@ def load():
     L.k3_ivector_stream_num_rows.argtypes = [vp]; L.k3_ivector_stream_num_rows.restype = i64; L.k3_ivector_stream_accept.argtypes = [vp, vp, i64, i32, i32, vp, i64, i32, ctypes.POINTER(i32), vp, vp]
     L.k3_ivector_stream_accept_batch.argtypes = [vp, i32, vp, i64, vp, vp, vp, i64, vp]
     L.k3_cmvn_online_batch_resume.argtypes = [vp, i64, vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp]
-    L.k3_ivector_extract_batch_adapt.argtypes = [vp, vp, i64, vp, i32, vp, i64, vp, vp, vp, vp]; L.k3_ivector_stats_size.argtypes = [vp]; L.k3_ivector_stats_size.restype = i64
+    L.k3_ivector_extract_batch_adapt.argtypes = [vp, vp, i64, vp, i32, vp, i64, vp, vp, vp, vp]; L.k3_ivector_extract_batch_weighted.argtypes = [vp, vp, i64, vp, i32, vp, vp, i64, vp, vp, vp, vp]; L.k3_ivector_stats_size.argtypes = [vp]; L.k3_ivector_stats_size.restype = i64
     L.k3_nnet_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.k3_nnet_destroy.argtypes = [vp]; L.k3_nnet_destroy.restype = None
     L.k3_nnet_get_info.argtypes = [vp, ctypes.POINTER(NnetInfo)]

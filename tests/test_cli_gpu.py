@@ -298,6 +298,23 @@ def test_ivector_extract_online2_and_nnet3_compute_with_ivectors(tmp_path):
     r = subprocess.run([exe, "--config=ivector_extractor.conf", "--repeat=true", "--max-batch-size=3", f"ark:{td}/spk2utt1", f"ark:{td}/feats.ark", f"ark:{td}/ivr.ark"], capture_output=True, text=True, cwd=IV); assert r.returncode == 0, r.stderr
     ivr = kio.read_ark(f"{td}/ivr.ark")
     for u in utts: assert ivr[u].shape == g["iv_repeat_" + u].shape and np.abs(ivr[u] - g["iv_repeat_" + u]).max() <= 2e-5
+    # ---- silence weighting: --frame-weights-rspecifier / --length-tolerance against the reference binary (tests/golden/make_golden_ivector_weighted.py)
+    wg = np.load(os.path.join(IV, "ivector_weighted_golden.npz"))
+    open(f"{td}/w.txt", "w").write("".join(u + "  [ " + " ".join(repr(float(x)) for x in wg["w_" + u]) + " ]\n" for u in utts))
+    open(f"{td}/spk2utt2", "w").write("spkA utt0 utt1\nspkB utt2 utt3\n")
+    for tag, extra in (("iv", []), ("ivrep", ["--repeat=true"])):
+        r = subprocess.run([exe, "--config=ivector_extractor.conf", "--length-tolerance=2", f"--frame-weights-rspecifier=ark,t:{td}/w.txt"] + extra + [f"ark:{td}/spk2utt2", f"ark:{td}/feats.ark", f"ark:{td}/ivw.ark"],
+                           capture_output=True, text=True, cwd=IV); assert r.returncode == 0, r.stderr
+        ivw = kio.read_ark(f"{td}/ivw.ark")
+        for u in utts:
+            got = ivw[u] if tag == "iv" else ivw[u][::10]
+            assert got.shape == wg[f"{tag}_{u}"].shape and np.abs(got - wg[f"{tag}_{u}"]).max() <= 2e-5, (tag, u, np.abs(got - wg[f"{tag}_{u}"]).max())
+    r = subprocess.run([exe, "--config=ivector_extractor.conf", f"--frame-weights-rspecifier=ark,t:{td}/w.txt", f"ark:{td}/spk2utt2", f"ark:{td}/feats.ark", f"ark:{td}/ivw0.ark"], capture_output=True, text=True, cwd=IV)
+    assert r.returncode == 0 and "Estimated iVectors for 3 files, 1 with errors." in r.stderr, r.stderr      # utt2's weights are 2 frames short: an error at the default tolerance 0
+    ivw0 = kio.read_ark(f"{td}/ivw0.ark"); assert sorted(ivw0) == ["utt0", "utt1", "utt3"] and np.abs(ivw0["utt3"] - wg["tol0_utt3"]).max() <= 2e-5
+    open(f"{td}/w1.txt", "w").write("utt0  [ " + " ".join("1" for _ in wg["w_utt0"]) + " ]\n")
+    r = subprocess.run([exe, "--config=ivector_extractor.conf", f"--frame-weights-rspecifier=ark,t:{td}/w1.txt", f"ark:{td}/spk2utt1", f"ark:{td}/feats.ark", f"ark:{td}/ivw1.ark"], capture_output=True, text=True, cwd=IV)
+    assert r.returncode == 0 and "Did not find weights for utterance utt1" in r.stderr and "Estimated iVectors for 1 files, 3 with errors." in r.stderr, r.stderr
     bad = subprocess.run([exe, "--config=ivector_extractor.conf", "--diag-ubm=nonexistent.dubm", f"ark:{td}/spk2utt1", f"ark:{td}/feats.ark", f"ark:{td}/x.ark"], capture_output=True, text=True, cwd=IV)
     assert bad.returncode != 0 and "nonexistent.dubm" in bad.stderr
     # ---- the network side

@@ -199,3 +199,30 @@ def test_adaptation_state_carried_to_the_speakers_next_utterance(golden):
     iv2r, _ = ex.GetIvectors(x2, fo2, cmvn_speaker_stats=cm, stats_in=stats_all); torch.cuda.synchronize(); iv2r = iv2r.cpu().numpy(); worst_r = 0.0
     for k, u in enumerate(("utt1", "utt3")): worst_r = max(worst_r, np.abs(iv2r[ro2[k]:ro2[k + 1]] - ref["ivrep_" + u]).max())
     assert worst_r <= TOL and np.abs(ref["ivrep_utt1"] - ref["iv_utt1"]).max() > 0.01, worst_r
+
+
+def test_frame_weights_on_the_statistics_equal_the_reference_binary(golden):
+    """silence weighting: ivector-extract-online2 --frame-weights-rspecifier of the REFERENCE (tests/golden/make_golden_ivector_weighted.py: runs of 0/1, fractional weights incl.
+    ones below min_post/0.99 and negative ones, a weight vector two frames short) -> GetIvectors(frame_weights=); all-ones weights are the unweighted call, bit for bit"""
+    from kaldi_amd.ivector import OnlineIvectorExtractionInfo, BatchedIvectorExtractor
+    ref = np.load(os.path.join(DIR, "ivector_weighted_golden.npz")); plain = np.load(os.path.join(DIR, "ivector_adapt_golden.npz"))
+    ex = BatchedIvectorExtractor(OnlineIvectorExtractionInfo("ivector_extractor.conf")); dev = torch.device("cuda:0")
+    first = [golden["feat_utt0"], golden["feat_utt2"]]; second = [golden["feat_utt1"], golden["feat_utt3"]]
+    pad = lambda w, f: np.concatenate([w, np.zeros(f.shape[0] - w.size, np.float32)])
+    w1 = np.concatenate([pad(ref["w_utt0"], first[0]), pad(ref["w_utt2"], first[1])]); w2 = np.concatenate([pad(ref["w_utt1"], second[0]), pad(ref["w_utt3"], second[1])])
+    x = torch.from_numpy(np.concatenate(first)).to(dev); fo = np.concatenate([[0], np.cumsum([f.shape[0] for f in first])])
+    x2 = torch.from_numpy(np.concatenate(second)).to(dev); fo2 = np.concatenate([[0], np.cumsum([f.shape[0] for f in second])])
+    cm = np.zeros((2, 2, 14))
+    for k, f in enumerate(first): cm[k, 0, :13] = f.astype(np.float64).sum(0); cm[k, 0, 13] = f.shape[0]; cm[k, 1, :13] = (f.astype(np.float64) ** 2).sum(0)
+    for tag, tail in (("iv", False), ("ivrep", True)):
+        iv1, ro1, stats = ex.GetIvectors(x, fo, return_stats=True, frame_weights=w1, accumulate_tail=tail)
+        iv2, ro2 = ex.GetIvectors(x2, fo2, cmvn_speaker_stats=cm, stats_in=stats, frame_weights=torch.from_numpy(w2).to(dev)); torch.cuda.synchronize()
+        a, b = iv1.cpu().numpy(), iv2.cpu().numpy(); worst = 0.0
+        if tag == "iv":
+            for k, u in enumerate(("utt0", "utt2")): worst = max(worst, np.abs(a[ro1[k]:ro1[k + 1]] - ref["iv_" + u]).max())
+        for k, u in enumerate(("utt1", "utt3")): worst = max(worst, np.abs(b[ro2[k]:ro2[k + 1]] - ref[f"{tag}_" + u]).max())
+        print(tag, "max |gpu - reference binary| with frame weights =", worst); assert worst <= TOL, (tag, worst)
+    assert np.abs(ref["iv_utt0"] - plain["iv_utt0"]).max() > 0.1                                    # (the weights matter)
+    ones, _ = ex.GetIvectors(x, fo, frame_weights=np.ones(int(fo[-1]), np.float32)); none, _ = ex.GetIvectors(x, fo); assert torch.equal(ones, none)
+    with pytest.raises(ValueError): ex.GetIvectors(x, fo, frame_weights=np.ones(3, np.float32))
+
