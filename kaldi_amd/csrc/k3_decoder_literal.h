@@ -366,7 +366,141 @@ __device__ K3_COLD_INLINE bool lit_hash_order_mid(const LitLane &q, Shared &sh, 
 constexpr size_t kLitGeneralLds = kLitTabBytes + kLitMarkBytes + kLitAuxBytes + kLitDynLds;
 static_assert(kHmLds <= kLitTabBytes + kLitMarkBytes + kLitAuxBytes + kLitDynLds, "the mid-size hash order works in the general path's arena");
 constexpr size_t kLitArena = kLitGeneralLds > (size_t)kFastArena ? kLitGeneralLds : (size_t)kFastArena;
-struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
+struct LitShared { int n_csr, use_lds, n_created, m_e, ho_fail; unsigned final_cut; };
+
+// HashList order for the frames above lit_hash_order_mid (the head of an utterance: 3 k .. 25 k tokens on every lane at the same time) WITHOUT global atomics.  The HBM form
+// (lit_hash_order) spends ~6 read-modify-write operations per token at the L2, and with all lanes in their large frames together the chip's atomic rate -- not latency --
+// is what those frames wait for (tools/prof_frames.py: the same frame takes half the cycles with 128 lanes resident instead of 512).  Here every atomic is an LDS atomic:
+//   * creation ranks: the label bitmap of a RANGE of kHbW x 32 labels in LDS (one range covers the usual frame), prefix counts over its words, ranks to q.dense;
+//   * buckets: the tokens are taken in P = 2^k PARTITIONS by the top bits of the bucket's hash (<= ~1536 tokens each); a partition's buckets {key, smallest rank,
+//     members | cursor} live in an LDS table of kHbT slots, its multi-member buckets' ranks in an LDS member list; three sweeps over the tokens (coalesced reads of bucket and
+//     rank, the partition's tokens filtered) fill the table, hand out member slots, and count the members ahead of each token;
+//   * global memory sees streams (labels, states, ranks, the leader-size scan) plus per token one scattered store of the leader's bucket size, one scattered load of the
+//     leader's offset and the result.
+// Returns false when a partition does not fit its table (the caller takes lit_hash_order): the result is then untouched.
+constexpr int kHbT = 4096, kHbW = 8192, kHbPart = 1536;
+constexpr size_t kHbLdsA = (size_t)kHbW * 4 + (size_t)kHbW * 2, kHbLdsB = (size_t)kHbT * 12 + (size_t)kHbT * 2 + (size_t)kHbT * 2;
+static_assert(kHbLdsA <= kLitGeneralLds && kHbLdsB <= kLitGeneralLds, "the large-frame hash order works in the general path's arena");
+__device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, char *arena, int *s_fail, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins,
+                                                  long long &lt_last__) {
+  const int tid = threadIdx.x;
+  int *dense = q.dense, *bkt = q.grp, *lr = q.rtmp; unsigned *lead = q.lead;
+  if (tid == 0) *s_fail = 0;
+  {      // ---- creation ranks (label ranges of kHbW words)
+    unsigned *bm = reinterpret_cast<unsigned *>(arena); unsigned short *wpre = reinterpret_cast<unsigned short *>(bm + kHbW);
+    int base = 0;
+    for (unsigned l0 = 0; l0 < M; l0 += (unsigned)kHbW * 32u) {
+      const unsigned span = M - l0 < (unsigned)kHbW * 32u ? M - l0 : (unsigned)kHbW * 32u; const int W = (int)((span + 31u) >> 5);
+      for (int i = tid; i < W; i += kBlock) bm[i] = 0u;
+      __syncthreads();
+      for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {
+        unsigned l[4]; int s_[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; l[k] = 0xFFFFFFFFu; s_[k] = 0; if (i < n) { l[k] = K3_ALD(&q.label[i]) - l0; if (l0 == 0u) s_[k] = st[i]; } }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = i0 + k * kBlock;
+          if (i < n) {
+            if (l[k] < span) k3a_or(&bm[l[k] >> 5], 1u << (l[k] & 31));
+            if (l0 == 0u) { bkt[i] = (int)((unsigned)s_[k] % hash_size); lead[i] = 0u; }      // (first range: the token's bucket, and the leader sizes start at zero)
+          }
+        }
+      }
+      __syncthreads();
+      const int tot = block_excl_scan_f([&](int w) { return __popc(bm[w]); }, [&](int w, int ex) { wpre[w] = (unsigned short)ex; }, W, sh.redi);
+      for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {
+        unsigned l[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; l[k] = i < n ? K3_ALD(&q.label[i]) - l0 : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = i0 + k * kBlock;
+          if (l[k] < span) { const int d = base + (int)wpre[l[k] >> 5] + __popc(bm[l[k] >> 5] & ((1u << (l[k] & 31)) - 1u)); dense[i] = d; if (write_by_ins) q.by_ins[d] = i; }
+        }
+      }
+      base += tot;
+      __syncthreads();
+    }
+  }
+  K3_LS(0);
+  // ---- buckets, partition by partition
+  int lgp = 0; while ((n >> lgp) > kHbPart) lgp++;
+  unsigned *key = reinterpret_cast<unsigned *>(arena), *mind = key + kHbT, *cnt = mind + kHbT; unsigned short *moff = reinterpret_cast<unsigned short *>(cnt + kHbT), *mem = moff + kHbT;
+  auto part_of = [&](unsigned h) { return lgp ? (int)(h >> (32 - lgp)) : 0; };
+  auto start_of = [&](unsigned h) { return (h >> (20 - lgp)) & (unsigned)(kHbT - 1); };
+  for (int pt = 0; pt < (1 << lgp); pt++) {
+    for (int i = tid; i < kHbT; i += kBlock) { key[i] = 0xFFFFFFFFu; mind[i] = 0xFFFFFFFFu; cnt[i] = 0u; }
+    __syncthreads();
+    for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {      // sweep 1: buckets of the partition -> {key, smallest creation rank, members}
+      unsigned b[4]; int d[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0u; d[k] = -1; if (i < n) { b[k] = (unsigned)bkt[i]; d[k] = dense[i]; } }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned h = b[k] * 2654435761u;
+        if (d[k] >= 0 && part_of(h) == pt) {
+          unsigned s_ = start_of(h); int tries = 0;
+          for (;;) { const unsigned old = k3a_cas(&key[s_], 0xFFFFFFFFu, b[k]); if (old == 0xFFFFFFFFu || old == b[k]) break; s_ = (s_ + 1) & (unsigned)(kHbT - 1); if (++tries >= kHbT) { *s_fail = 1; break; } }
+          if (tries < kHbT) { k3a_min(&mind[s_], (unsigned)d[k]); k3a_add(&cnt[s_], 1u); }
+        }
+      }
+    }
+    __syncthreads();
+    if (*s_fail) return false;
+    const int tm = block_excl_scan_f([&](int s_) { const unsigned c = cnt[s_]; return c > 1u ? (int)c : 0; }, [&](int s_, int ex) { moff[s_] = (unsigned short)ex; }, kHbT, sh.redi);
+    if (tm > kHbT) { __syncthreads(); return false; }
+    for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {      // sweep 2: the leader publishes its bucket's size; members of shared buckets line up behind their bucket's offset
+      unsigned b[4]; int d[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0u; d[k] = -1; if (i < n) { b[k] = (unsigned)bkt[i]; d[k] = dense[i]; } }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = i0 + k * kBlock; const unsigned h = b[k] * 2654435761u;
+        if (d[k] >= 0 && part_of(h) == pt) {
+          unsigned s_ = start_of(h); while (key[s_] != b[k]) s_ = (s_ + 1) & (unsigned)(kHbT - 1);
+          const unsigned c = lds_ld(&cnt[s_]) & 0xFFFFu, lf = mind[s_];
+          if (lf == (unsigned)d[k]) lead[lf] = c;
+          if (c > 1u) { const unsigned pos = k3a_add(&cnt[s_], 0x10000u) >> 16; mem[moff[s_] + pos] = (unsigned short)d[k]; }
+          else lr[i] = (int)(lf << 16);
+        }
+      }
+    }
+    __syncthreads();
+    if (tm > 0) {
+      for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {      // sweep 3: position inside a shared bucket = members created earlier
+        unsigned b[4]; int d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0u; d[k] = -1; if (i < n) { b[k] = (unsigned)bkt[i]; d[k] = dense[i]; } }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = i0 + k * kBlock; const unsigned h = b[k] * 2654435761u;
+          if (d[k] >= 0 && part_of(h) == pt) {
+            unsigned s_ = start_of(h); while (key[s_] != b[k]) s_ = (s_ + 1) & (unsigned)(kHbT - 1);
+            const unsigned c = cnt[s_] & 0xFFFFu;
+            if (c > 1u) { const unsigned short *m_ = mem + moff[s_]; unsigned rank = 0; for (unsigned t = 0; t < c; t++) rank += (unsigned)m_[t] < (unsigned)d[k]; lr[i] = (int)((mind[s_] << 16) | rank); }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  K3_LS(2);
+  // ---- leaders' bucket sizes in creation order -> offsets; position = leader's offset + own place in the bucket
+  block_excl_scan([&](int r) { return lead[r]; }, lead, n, sh.redi);
+  K3_LS(3);
+  for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {
+    int v[4]; unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; v[k] = i < n ? lr[i] : 0; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; o[k] = i < n ? lead[(unsigned)v[k] >> 16] : 0u; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; if (i < n) order_out[o[k] + ((unsigned)v[k] & 0xFFFFu)] = i; }
+  }
+  __syncthreads();
+  K3_LS(5);
+  return true;
+}
 
 // The replay loop.  MODE 0: costs, meta, arcs, stack and the creation list in LDS; MODE 1: costs, stack and list in LDS, meta / arcs read-only
 // in HBM; MODE 2: everything in HBM.  rcost[id] = the cost the serial code has seen for the token so far (+inf: not created yet);
@@ -895,7 +1029,8 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made (their labels and states are
     // untouched by the closure).  Computed here, where the level-1 table's LDS is free for the bucket table of the pass.
     if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, s_tab, lt_last__);
-    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false)) lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
+    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) && !lit_hash_order_big(q, sh, arena, &ls.ho_fail, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__))
+      lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
     K3_LT(6);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
     const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
@@ -1021,7 +1156,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     __syncthreads();
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
     if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, smem_raw, s_tab, lt_last__);
-    else if (!lit_hash_order_mid(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true)) lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
+    else if (!lit_hash_order_mid(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true) &&
+             !lit_hash_order_big(q, sh, arena, &ls.ho_fail, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, lt_last__))
+      lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     K3_LT(10);
     // ---- publish the frame: final costs into the pool, empty table, idle labels

@@ -37,6 +37,10 @@ first = np.concatenate([np.arange(333) for _ in range(U)])[:nt.size] if nt.size 
 if first is not None:
     head = first < 12
     print("first 12 frames of every utterance: %.2f%% of the frames, %.2f%% of the cycles, mean tokens %.0f" % (100 * head.mean(), 100 * cyc[head].sum() / tot, nt[head].mean()))
+if first is not None:
+    print("by frame index: frame, mean tokens in, mean cycles (k), share of the lane's cycles %, on LDS path")
+    for fi in list(range(16)) + [20, 30, 50, 100, 200, 332]:
+        m = first == fi; print("  %3d %8.0f %10.0f %6.2f %6.3f" % (fi, nt[m].mean(), cyc[m].mean() / 1e3, 100 * cyc[m].sum() / tot, fast[m].mean()))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"token_passing_ms": kt[0], "lanes": U, "cycles_per_lane": tot / U, "rows": rows, "head12_cycles_share": float(cyc[head].sum() / tot) if first is not None else None},
           open(os.path.join(ROOT, "gpurun_out", "literal_frames_by_size.json"), "w"), indent=1)
