@@ -366,27 +366,35 @@ __device__ K3_COLD_INLINE bool lit_hash_order_mid(const LitLane &q, Shared &sh, 
 constexpr size_t kLitGeneralLds = kLitTabBytes + kLitMarkBytes + kLitAuxBytes + kLitDynLds;
 static_assert(kHmLds <= kLitTabBytes + kLitMarkBytes + kLitAuxBytes + kLitDynLds, "the mid-size hash order works in the general path's arena");
 constexpr size_t kLitArena = kLitGeneralLds > (size_t)kFastArena ? kLitGeneralLds : (size_t)kFastArena;
-struct LitShared { int n_csr, use_lds, n_created, m_e, ho_fail; unsigned final_cut; };
+struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 
 // HashList order for the frames above lit_hash_order_mid (the head of an utterance: 3 k .. 25 k tokens on every lane at the same time) WITHOUT global atomics.  The HBM form
 // (lit_hash_order) spends ~6 read-modify-write operations per token at the L2, and with all lanes in their large frames together the chip's atomic rate -- not latency --
 // is what those frames wait for (tools/prof_frames.py: the same frame takes half the cycles with 128 lanes resident instead of 512).  Here every atomic is an LDS atomic:
 //   * creation ranks: the label bitmap of a RANGE of kHbW x 32 labels in LDS (one range covers the usual frame), prefix counts over its words, ranks to q.dense;
-//   * buckets: the tokens are taken in P = 2^k PARTITIONS by the top bits of the bucket's hash (<= ~1536 tokens each); a partition's buckets {key, smallest rank,
-//     members | cursor} live in an LDS table of kHbT slots, its multi-member buckets' ranks in an LDS member list; three sweeps over the tokens (coalesced reads of bucket and
-//     rank, the partition's tokens filtered) fill the table, hand out member slots, and count the members ahead of each token;
-//   * global memory sees streams (labels, states, ranks, the leader-size scan) plus per token one scattered store of the leader's bucket size, one scattered load of the
-//     leader's offset and the result.
-// Returns false when a partition does not fit its table (the caller takes lit_hash_order): the result is then untouched.
-constexpr int kHbT = 4096, kHbW = 8192, kHbPart = 1536;
-constexpr size_t kHbLdsA = (size_t)kHbW * 4 + (size_t)kHbW * 2, kHbLdsB = (size_t)kHbT * 12 + (size_t)kHbT * 2 + (size_t)kHbT * 2;
-static_assert(kHbLdsA <= kLitGeneralLds && kHbLdsB <= kLitGeneralLds, "the large-frame hash order works in the general path's arena");
-__device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, char *arena, int *s_fail, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins,
+//   * the tokens' records {bucket, rank | token} are grouped into P = 2^k PARTITIONS by the top bits of the bucket's hash (<= 2048 tokens each, ~1000 on average): a histogram and
+//     per-partition cursors in LDS, one 8-byte store per token;
+//   * a partition at a time: its records in registers (<= 4 per thread), its buckets {key, smallest rank, members | cursor} in an LDS table of kHbT slots, the ranks of the
+//     members of shared buckets in an LDS list; the leader publishes the bucket's size at its rank, every token gets {leader's rank, members created before it};
+//   * a scan over the leaders' sizes in creation order gives the buckets' offsets; position = offset of the leader + place inside the bucket.
+// Global memory sees streams plus, per token, the record store, the leader's size (one store per bucket), one load of the leader's offset and the result.
+// Returns false when a partition does not fit (the caller takes lit_hash_order): the result is then untouched.
+constexpr int kHbT = 4096, kHbW = 8192, kHbPart = 1536, kHbMaxPart = 2048, kHbMaxP = 64;
+constexpr size_t kHbLdsA = (size_t)kHbW * 4 + (size_t)kHbW * 2, kHbLdsB = (size_t)kHbT * 12 + (size_t)kHbT * 2 + (size_t)kHbMaxPart * 2, kHbLdsP = kHbLdsB > kHbLdsA ? kHbLdsB : kHbLdsA;
+static_assert(kHbLdsP + 2 * kHbMaxP * 4 <= kLitGeneralLds, "the large-frame hash order works in the general path's arena");
+static_assert(kHbMaxPart <= 4 * kBlock, "a partition's records fit the registers of one pass");
+__device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins,
                                                   long long &lt_last__) {
   const int tid = threadIdx.x;
-  int *dense = q.dense, *bkt = q.grp, *lr = q.rtmp; unsigned *lead = q.lead;
-  if (tid == 0) *s_fail = 0;
-  {      // ---- creation ranks (label ranges of kHbW words)
+  int *dense = q.dense, *bkt = q.grp, *lr = q.rtmp; unsigned *lead = q.lead; int2 *rec = q.rlist;
+  int *pcnt = reinterpret_cast<int *>(arena + kHbLdsP), *pbase = pcnt + kHbMaxP;      // partition sizes -> cursors; first record of each partition
+  int lgp = 0; while ((n >> lgp) > kHbPart) lgp++;
+  if (lgp > 6) return false;
+  const int P = 1 << lgp;
+  auto part_of = [&](unsigned h) { return lgp ? (int)(h >> (32 - lgp)) : 0; };
+  auto start_of = [&](unsigned h) { return (h >> (20 - lgp)) & (unsigned)(kHbT - 1); };
+  if (tid < kHbMaxP) pcnt[tid] = 0;
+  {      // ---- creation ranks (label ranges of kHbW words); the first range's sweep also computes the buckets and counts the partitions
     unsigned *bm = reinterpret_cast<unsigned *>(arena); unsigned short *wpre = reinterpret_cast<unsigned short *>(bm + kHbW);
     int base = 0;
     for (unsigned l0 = 0; l0 < M; l0 += (unsigned)kHbW * 32u) {
@@ -402,7 +410,7 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
           const int i = i0 + k * kBlock;
           if (i < n) {
             if (l[k] < span) k3a_or(&bm[l[k] >> 5], 1u << (l[k] & 31));
-            if (l0 == 0u) { bkt[i] = (int)((unsigned)s_[k] % hash_size); lead[i] = 0u; }      // (first range: the token's bucket, and the leader sizes start at zero)
+            if (l0 == 0u) { const unsigned b = (unsigned)s_[k] % hash_size; bkt[i] = (int)b; lead[i] = 0u; k3a_add(&pcnt[part_of(b * 2654435761u)], 1); }
           }
         }
       }
@@ -423,62 +431,58 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
     }
   }
   K3_LS(0);
+  // ---- records grouped by partition
+  if (tid < 64) {      // (one wavefront: exclusive scan of the <= 64 partition sizes; a partition beyond the register budget of a pass -> the HBM form)
+    const int c = tid < P ? pcnt[tid] : 0; const int incl = wave_incl_scan(c);
+    pbase[tid] = incl - c; pcnt[tid] = incl - c;      // (pcnt becomes the cursor)
+    if (c > kHbMaxPart) sh.flag = 1;
+  }
+  __syncthreads();
+  if (sh.flag) { __syncthreads(); if (tid == 0) sh.flag = 0; __syncthreads(); return false; }
+  for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {
+    int b[4], d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0; d[k] = 0; if (i < n) { b[k] = bkt[i]; d[k] = dense[i]; } }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; if (i < n) { const int pos = k3a_add(&pcnt[part_of((unsigned)b[k] * 2654435761u)], 1); rec[pos] = make_int2(b[k], (d[k] << 16) | i); } }
+  }
+  __syncthreads();
+  K3_LS(1);
   // ---- buckets, partition by partition
-  int lgp = 0; while ((n >> lgp) > kHbPart) lgp++;
   unsigned *key = reinterpret_cast<unsigned *>(arena), *mind = key + kHbT, *cnt = mind + kHbT; unsigned short *moff = reinterpret_cast<unsigned short *>(cnt + kHbT), *mem = moff + kHbT;
-  auto part_of = [&](unsigned h) { return lgp ? (int)(h >> (32 - lgp)) : 0; };
-  auto start_of = [&](unsigned h) { return (h >> (20 - lgp)) & (unsigned)(kHbT - 1); };
-  for (int pt = 0; pt < (1 << lgp); pt++) {
+  for (int pt = 0; pt < P; pt++) {
+    const int pb = pbase[pt], np_ = (pt + 1 < P ? pbase[pt + 1] : n) - pb;
+    int2 r_[4]; unsigned slot[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int j = tid + k * kBlock; r_[k] = make_int2(0, 0); if (j < np_) r_[k] = rec[pb + j]; }
     for (int i = tid; i < kHbT; i += kBlock) { key[i] = 0xFFFFFFFFu; mind[i] = 0xFFFFFFFFu; cnt[i] = 0u; }
     __syncthreads();
-    for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {      // sweep 1: buckets of the partition -> {key, smallest creation rank, members}
-      unsigned b[4]; int d[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0u; d[k] = -1; if (i < n) { b[k] = (unsigned)bkt[i]; d[k] = dense[i]; } }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned h = b[k] * 2654435761u;
-        if (d[k] >= 0 && part_of(h) == pt) {
-          unsigned s_ = start_of(h); int tries = 0;
-          for (;;) { const unsigned old = k3a_cas(&key[s_], 0xFFFFFFFFu, b[k]); if (old == 0xFFFFFFFFu || old == b[k]) break; s_ = (s_ + 1) & (unsigned)(kHbT - 1); if (++tries >= kHbT) { *s_fail = 1; break; } }
-          if (tries < kHbT) { k3a_min(&mind[s_], (unsigned)d[k]); k3a_add(&cnt[s_], 1u); }
-        }
+    for (int k = 0; k < 4; k++) {      // the partition's buckets: {key, smallest creation rank, members}
+      if (tid + k * kBlock < np_) {
+        const unsigned b = (unsigned)r_[k].x; unsigned s_ = start_of(b * 2654435761u);
+        for (;;) { const unsigned old = k3a_cas(&key[s_], 0xFFFFFFFFu, b); if (old == 0xFFFFFFFFu || old == b) break; s_ = (s_ + 1) & (unsigned)(kHbT - 1); }      // (<= 2048 keys in 4096 slots: always ends)
+        slot[k] = s_; k3a_min(&mind[s_], (unsigned)r_[k].y >> 16); k3a_add(&cnt[s_], 1u);
       }
     }
     __syncthreads();
-    if (*s_fail) return false;
     const int tm = block_excl_scan_f([&](int s_) { const unsigned c = cnt[s_]; return c > 1u ? (int)c : 0; }, [&](int s_, int ex) { moff[s_] = (unsigned short)ex; }, kHbT, sh.redi);
-    if (tm > kHbT) { __syncthreads(); return false; }
-    for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {      // sweep 2: the leader publishes its bucket's size; members of shared buckets line up behind their bucket's offset
-      unsigned b[4]; int d[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0u; d[k] = -1; if (i < n) { b[k] = (unsigned)bkt[i]; d[k] = dense[i]; } }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int i = i0 + k * kBlock; const unsigned h = b[k] * 2654435761u;
-        if (d[k] >= 0 && part_of(h) == pt) {
-          unsigned s_ = start_of(h); while (key[s_] != b[k]) s_ = (s_ + 1) & (unsigned)(kHbT - 1);
-          const unsigned c = lds_ld(&cnt[s_]) & 0xFFFFu, lf = mind[s_];
-          if (lf == (unsigned)d[k]) lead[lf] = c;
-          if (c > 1u) { const unsigned pos = k3a_add(&cnt[s_], 0x10000u) >> 16; mem[moff[s_] + pos] = (unsigned short)d[k]; }
-          else lr[i] = (int)(lf << 16);
-        }
+    for (int k = 0; k < 4; k++) {      // the leader publishes its bucket's size; members of shared buckets line up behind their bucket's offset
+      if (tid + k * kBlock < np_) {
+        const unsigned s_ = slot[k], d = (unsigned)r_[k].y >> 16; const unsigned c = lds_ld(&cnt[s_]) & 0xFFFFu, lf = mind[s_];
+        if (lf == d) lead[lf] = c;
+        if (c > 1u) { const unsigned pos = k3a_add(&cnt[s_], 0x10000u) >> 16; mem[moff[s_] + pos] = (unsigned short)d; }
+        else lr[pb + tid + k * kBlock] = (int)(lf << 16);
       }
     }
     __syncthreads();
     if (tm > 0) {
-      for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {      // sweep 3: position inside a shared bucket = members created earlier
-        unsigned b[4]; int d[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0u; d[k] = -1; if (i < n) { b[k] = (unsigned)bkt[i]; d[k] = dense[i]; } }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int i = i0 + k * kBlock; const unsigned h = b[k] * 2654435761u;
-          if (d[k] >= 0 && part_of(h) == pt) {
-            unsigned s_ = start_of(h); while (key[s_] != b[k]) s_ = (s_ + 1) & (unsigned)(kHbT - 1);
-            const unsigned c = cnt[s_] & 0xFFFFu;
-            if (c > 1u) { const unsigned short *m_ = mem + moff[s_]; unsigned rank = 0; for (unsigned t = 0; t < c; t++) rank += (unsigned)m_[t] < (unsigned)d[k]; lr[i] = (int)((mind[s_] << 16) | rank); }
-          }
+      for (int k = 0; k < 4; k++) {      // position inside a shared bucket = members created earlier
+        if (tid + k * kBlock < np_) {
+          const unsigned s_ = slot[k], d = (unsigned)r_[k].y >> 16, c = cnt[s_] & 0xFFFFu;
+          if (c > 1u) { const unsigned short *m_ = mem + moff[s_]; unsigned rank = 0; for (unsigned t = 0; t < c; t++) rank += (unsigned)m_[t] < d; lr[pb + tid + k * kBlock] = (int)((mind[s_] << 16) | rank); }
         }
       }
     }
@@ -488,14 +492,14 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
   // ---- leaders' bucket sizes in creation order -> offsets; position = leader's offset + own place in the bucket
   block_excl_scan([&](int r) { return lead[r]; }, lead, n, sh.redi);
   K3_LS(3);
-  for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {
-    int v[4]; unsigned o[4];
+  for (int j0 = tid; j0 < n; j0 += 4 * kBlock) {
+    int v[4], t_[4]; unsigned o[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; v[k] = i < n ? lr[i] : 0; }
+    for (int k = 0; k < 4; k++) { const int j = j0 + k * kBlock; v[k] = 0; t_[k] = 0; if (j < n) { v[k] = lr[j]; t_[k] = rec[j].y & 0xFFFF; } }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; o[k] = i < n ? lead[(unsigned)v[k] >> 16] : 0u; }
+    for (int k = 0; k < 4; k++) { const int j = j0 + k * kBlock; o[k] = j < n ? lead[(unsigned)v[k] >> 16] : 0u; }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; if (i < n) order_out[o[k] + ((unsigned)v[k] & 0xFFFFu)] = i; }
+    for (int k = 0; k < 4; k++) { const int j = j0 + k * kBlock; if (j < n) order_out[o[k] + ((unsigned)v[k] & 0xFFFFu)] = t_[k]; }
   }
   __syncthreads();
   K3_LS(5);
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made (their labels and states are
     // untouched by the closure).  Computed here, where the level-1 table's LDS is free for the bucket table of the pass.
     if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, s_tab, lt_last__);
-    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) && !lit_hash_order_big(q, sh, arena, &ls.ho_fail, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__))
+    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) && !lit_hash_order_big(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__))
       lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
     K3_LT(6);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
@@ -1157,7 +1161,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
     if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, smem_raw, s_tab, lt_last__);
     else if (!lit_hash_order_mid(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true) &&
-             !lit_hash_order_big(q, sh, arena, &ls.ho_fail, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, lt_last__))
+             !lit_hash_order_big(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, lt_last__))
       lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     K3_LT(10);

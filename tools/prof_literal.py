@@ -32,7 +32,8 @@ for literal in (1, 0):
     elif literal:
         cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
         names = ["cutoff", "hash resize+prepass", "passA+chunk scan", "(non-LDS replay cycles)", "passB+c0", "(non-LDS replay pops)", "order1", "closure", "csr build", "replay", "order2", "publish"]
-        nl_cyc, nl_pops = cyc[3], cyc[5]; cyc[3] = 0; cyc[5] = 0
+        nl_cyc, nl_pops = cyc[3], cyc[5]
+        if not os.environ.get("K3_LIT_PROF_FINE"): cyc[3] = 0; cyc[5] = 0
         tot = cyc[:12].sum()
         if os.environ.get("K3_LIT_PROF_FINE"):      # library built with -DK3_LIT_PROF=2: sub-phases of the hash-order passes and of the component replay
             sub = ["ho:bitmap", "ho:word scan", "ho:dense+buckets", "ho:leader scan", "ho:group fill", "ho:order", "ho:reset", "cr:init", "cr:union", "cr:count", "cr:scan4", "cr:group roots", "cr:workers", "cr:labels"]
