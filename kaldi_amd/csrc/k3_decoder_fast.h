@@ -250,6 +250,13 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   if (hash_size > 65535u || hash_size > (unsigned)p.hash_cap) return -1;      // (uniform; nothing touched yet)
   const float co = -best;
   const long long nb = cur_base + n_cur; const long long link0 = sh.n_link;
+  {      // the number of emitting arcs pass A would count (m_e below) from the per-token degrees: a frame whose labels cannot fit (the first frame of an utterance: a hundred
+    // tokens with tens of thousands of arcs, walked by two wavefronts) leaves before that walk
+    int deg_sum = 0;
+    for (int r = tid; r < n_cur; r += kBlock) if (dec(V_cost[r]) <= cur_cutoff) deg_sum += (int)V_ne[r];
+    deg_sum = block_sum_i32(deg_sum, sh);
+    if ((unsigned)deg_sum + (unsigned)cap_tokens > (unsigned)kFM) return -1;      // (uniform; nothing touched yet)
+  }
   K3_FP(0);
   // ---- the frame's structures
   if (tid == 0) { fs.abort = 0; fs.reason = 0; fs.next0 = kEncMax; fs.n_wl[0] = 0; fs.n_wl[1] = 0; fs.n_wl[2] = 0; fs.abort_r[0] = fs.abort_r[1] = fs.abort_r[2] = fs.abort_r[3] = 0; sh.n_next = 0; c.loff_e[f] = link0; }

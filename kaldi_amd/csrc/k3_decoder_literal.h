@@ -1018,14 +1018,24 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // step 1: final costs into the pool (the closure's "expanded at" marker is no longer needed).  The sub-graph is read off the eps links the
     // fixpoint wrote: a link carries the source cost it was made at, a token is expanded once at every cost it takes, so the links made at a
     // token's FINAL cost are exactly its arcs that pass there -- no second walk over offsets, arcs and the state table.
-    for (int i = tid; i < n; i += kBlock) { tok_cost[nb + i] = tb.cost(tok_slot[i]); K3_AST(&q.rflag[i], 0); K3_AST(&q.rown[i], 0); }
+    // Frames of <= kCsrN tokens count in LDS (the level-1 table is dead once the costs are out; read-modify-write operations at the L2 are what the large frames of all lanes
+    // queue for) and stream the counts out before the hash-order pass takes the arena.
+    constexpr int kCsrN = 16384; static_assert((size_t)kCsrN * 4 + kCsrN / 8 <= kLitGeneralLds, "per-token counters of the closure sub-graph fit the arena");
+    const bool csr_lds = n <= kCsrN;
+    int *l_cnt = reinterpret_cast<int *>(arena); unsigned *l_flag = reinterpret_cast<unsigned *>(arena + (size_t)kCsrN * 4);
+    for (int i = tid; i < n; i += kBlock) { tok_cost[nb + i] = tb.cost(tok_slot[i]); if (!csr_lds) { K3_AST(&q.rflag[i], 0); K3_AST(&q.rown[i], 0); } }
     __syncthreads();
+    if (csr_lds) { for (int i = tid; i < n; i += kBlock) l_cnt[i] = 0; for (int i = tid; i < (n + 31) / 32; i += kBlock) l_flag[i] = 0u; __syncthreads(); }
     const long long eps_l1 = sh.n_link;
     for (long long l = eps_l0 + tid; l < eps_l1; l += kBlock) {
       const Link k = links[l];
-      if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) { k3a_add(&q.rown[k.src - nb], 1); k3a_or(&q.rflag[k.dst - nb], 1); }      // passing arcs per source; destinations flagged
+      if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) {      // passing arcs per source; destinations flagged
+        const int s_ = (int)(k.src - nb), d_ = (int)(k.dst - nb);
+        if (csr_lds) { k3a_add(&l_cnt[s_], 1); k3a_or(&l_flag[d_ >> 5], 1u << (d_ & 31)); } else { k3a_add(&q.rown[s_], 1); k3a_or(&q.rflag[d_], 1); }
+      }
     }
     __syncthreads();
+    if (csr_lds) { for (int i = tid; i < n; i += kBlock) { q.rown[i] = l_cnt[i]; q.rflag[i] = (int)(l_flag[i >> 5] >> (i & 31) & 1u); } }
     if (block_err(sh)) break;
     for (int i = tid; i < n; i += kBlock) { const int slot = tok_slot[i]; if (slot >= kHL) tb.clear(slot); }      // last use of the table in this frame
     __syncthreads();
@@ -1038,7 +1048,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     K3_LT(6);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
     const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
-                                       [&](int i, int4 ex) { q.grp[i] = ex.x; q.lead[i] = (unsigned)ex.y; K3_AST(&q.rtmp[i], 0); }, n, reinterpret_cast<int4 *>(sh.hist));
+                                       [&](int i, int4 ex) { q.grp[i] = ex.x; q.lead[i] = (unsigned)ex.y; if (csr_lds) l_cnt[i] = ex.y; else K3_AST(&q.rtmp[i], 0); }, n, reinterpret_cast<int4 *>(sh.hist));      // (LDS: the source's fill cursor starts at its first slot)
     const int n_cid = tot2.x, n_arc = tot2.y;
     if (n_arc > p.eps_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
     if (block_err(sh)) break;
@@ -1046,7 +1056,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     int *ent_arc = q.cdst, *ent_dst = reinterpret_cast<int *>(q.cw);
     for (long long l = eps_l0 + tid; l < eps_l1; l += kBlock) {
       const Link k = links[l];
-      if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) { const int sl = (int)(k.src - nb); const int pos = (int)q.lead[sl] + k3a_add(&q.rtmp[sl], 1); ent_arc[pos] = link_arc[l]; ent_dst[pos] = (int)(k.dst - nb); }
+      if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) { const int sl = (int)(k.src - nb); const int pos = csr_lds ? k3a_add(&l_cnt[sl], 1) : (int)q.lead[sl] + k3a_add(&q.rtmp[sl], 1); ent_arc[pos] = link_arc[l]; ent_dst[pos] = (int)(k.dst - nb); }
     }
     __syncthreads();
     // mode 0: costs, meta and arcs in LDS; mode 1: costs in LDS, meta / arcs (read-only during the replay) in HBM; mode 2: all in HBM

@@ -41,6 +41,12 @@ if first is not None:
     print("by frame index: frame, mean tokens in, mean cycles (k), share of the lane's cycles %, on LDS path")
     for fi in list(range(16)) + [20, 30, 50, 100, 200, 332]:
         m = first == fi; print("  %3d %8.0f %10.0f %6.2f %6.3f" % (fi, nt[m].mean(), cyc[m].mean() / 1e3, 100 * cyc[m].sum() / tot, fast[m].mean()))
+if first is not None:
+    per_lane = cyc.reshape(U, 333).sum(1); tok_lane = nt.reshape(U, 333).sum(1)
+    q = np.percentile(per_lane, [0, 10, 50, 90, 100]) / 1e6
+    print("cycles per lane (M): min %.1f p10 %.1f median %.1f p90 %.1f max %.1f | corr with the lane's token count %.3f" % (*q, np.corrcoef(per_lane, tok_lane)[0, 1]))
+    print("mean cycles per lane (M) by lane %% 8:", np.round([per_lane[k::8].mean() / 1e6 for k in range(8)], 1).tolist(), "| first / second half of the lanes:", round(per_lane[:U // 2].mean() / 1e6, 1), round(per_lane[U // 2:].mean() / 1e6, 1))
+    print("cycles per token of the lane: min %.0f median %.0f max %.0f" % tuple(np.percentile(per_lane / tok_lane, [0, 50, 100])))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"token_passing_ms": kt[0], "lanes": U, "cycles_per_lane": tot / U, "rows": rows, "head12_cycles_share": float(cyc[head].sum() / tot) if first is not None else None},
           open(os.path.join(ROOT, "gpurun_out", "literal_frames_by_size.json"), "w"), indent=1)
