@@ -479,7 +479,9 @@ def main():
                                         "cycles_per_phase_floor": cpp, "shader_clock_ghz": ghz, "floor_ms": floor_ms, "achieved_ms": acc[5], "frac": floor_ms / acc[5], "mean_lane_ms": mean_lane_ms, "frac_mean_lane": floor_ms / mean_lane_ms,
                                         "note": "floor = every frame at the cost of an LDS-resident frame of <= 512 tokens (70 phases x 2.0 k cycles, measured); achieved_ms = the kernel (its slowest lane, 512 lanes two to a CU), "
                                                 "mean_lane_ms = shader cycles per lane from the kernel's own counters / 2.1 GHz.  What separates them from the floor: frames above 512 tokens (cost grows ~0.28 k cycles per token), the "
-                                                "frames beyond the LDS path's 1536 tokens on HBM scratch (46 % of the cycles), the first ~12 frames of every utterance (3 - 25 k tokens: 35 % of the cycles) -- profiles/r04_literal_frames_by_size.txt, r04_literal_phase_profile_by_size.txt"}
+                                                "frames beyond the LDS path's 1536 tokens on HBM scratch (general_path_cycles_share of the cycles), the first ~12 frames of every utterance (3 - 25 k tokens on every lane at once: 27 % of the cycles, bound by the chip's "
+                                                "rate of scattered read-modify-write accesses rather than by latency) -- profiles/r04_literal_frames_by_size.txt, r04_literal_phase_profile_by_size.txt",
+                                        "general_path_cycles_share": paths["cycles_general_path"] / max(1, paths["cycles_lds_path"] + paths["cycles_general_path"])}
             line["roofline"]["traffic_command"] = TRAFFIC_CMD
             tr = measure_traffic(args) if (args.measure_traffic and world == 1) else None
             if tr and "traffic_bytes_per_launch" in tr:

@@ -32,7 +32,7 @@ with open(os.path.join(dst, f"{tag}_bench_full_pipeline_pmc_hbm.csv"), "w") as f
     f.write(f"# rocprofv3 --pmc <counter> (separate passes, no trace domains) over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline` (512 x 10 s utts), {tag}\n"
             "# Counter_Value summed over the dispatches of each kernel; FETCH_SIZE / WRITE_SIZE are in KB (rocprof definition).\n"
             "# gfx950 caveat (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced loads (x2 correction); narrow random\n"
-            "# 4-16 B accesses (the decoder's pattern) and WRITE_SIZE are uncalibrated -> read these as relative over-fetch indicators, not absolute HBM bytes.\n"
+            "# calibration (profiles/hbm_counter_calibration_r04.json, tools/pmc_calib.sh): a random 4 - 16 B read counts one 64 B line, a random 4 - 16 B write or atomic 32 B, streaming 16 B reads count 0.5x.\n"
             "kernel,counter,dispatches,sum_KB,per_dispatch_KB\n")
     for r in rows: f.write("%s,%s,%d,%.1f,%.1f\n" % r)
 bl = os.path.join(src, "bench_line.json")
@@ -42,7 +42,7 @@ if os.path.exists(bl):
 if len(traffic) == 2:
     json.dump({"kernel": "k3_decode_forward_literal_kernel", "two_pass_kernel_traffic_bytes_per_launch": (traffic2.get("FETCH_SIZE", 0) + traffic2.get("WRITE_SIZE", 0)) or None, "source": f"profiles/{tag}_bench_full_pipeline_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 512 x 10 s utts)",
                "fetch_bytes_per_launch": traffic["FETCH_SIZE"], "write_bytes_per_launch": traffic["WRITE_SIZE"], "traffic_bytes_per_launch": traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"],
-               "note": "FETCH_SIZE/WRITE_SIZE as reported (KB x 1024); the gfx950 x2 correction for wide coalesced loads does not apply to the decoder's narrow random accesses; uncalibrated for this pattern"},
+               "note": "FETCH_SIZE/WRITE_SIZE as reported (KB x 1024).  Calibrated with tools/microbench/hbm_random_access.hip (profiles/hbm_counter_calibration_r04.json): a random 4 - 16 B read counts one 64 B line (16x / 4x the requested bytes), a random 4 - 16 B write or atomic counts 32 B (8x / 2x), streaming 16 B reads count 0.5x, streaming writes 1.0x -- so for the decoder's access mix (narrow random accesses) the counters are memory-side bytes at line granularity, not requested bytes: traffic / algorithmic bytes = 5.5 is mostly the 64 B / 32 B granule around 4 - 16 B items"},
               open(os.path.join(dst, f"hbm_traffic_{tag[:3]}.json"), "w"), indent=1)
 fm = find("pmc_MFMA", "*counter_collection.csv")
 if fm:      # MfmaUtil (gfx94x formula) per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs); rocprofv3 reports GRBM_GUI_ACTIVE summed over the XCDs
