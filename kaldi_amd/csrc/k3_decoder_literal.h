@@ -33,7 +33,11 @@ enum { kRfHasEps = 1, kRfExists = 2 };
 #define K3_LIT_PROF_MAXTOK 0x7FFFFFFF
 #endif
 #define K3_LP_ON (sh.prof_n >= K3_LIT_PROF_MINTOK && sh.prof_n <= K3_LIT_PROF_MAXTOK)
-#if defined(K3_LIT_PROF) && K3_LIT_PROF == 2
+#if defined(K3_LIT_PROF) && K3_LIT_PROF == 3      // =3: a finer split of the frame's phases (K3_LQ) instead of K3_LT's; a general frame's first phase also holds the LDS-path frames before it
+#define K3_LT(i) do { } while (0)
+#define K3_LS(i) do { } while (0)
+#define K3_LQ(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); if (K3_LP_ON) sh.prof[i] += now__ - lt_last__; lt_last__ = now__; } } while (0)
+#elif defined(K3_LIT_PROF) && K3_LIT_PROF == 2
 #define K3_LT(i) do { if (threadIdx.x == 0) lt_last__ = (long long)__builtin_readcyclecounter(); } while (0)
 #define K3_LS(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); if (K3_LP_ON) sh.prof[i] += now__ - lt_last__; lt_last__ = now__; } } while (0)
 #elif defined(K3_LIT_PROF)
@@ -42,6 +46,9 @@ enum { kRfHasEps = 1, kRfExists = 2 };
 #else
 #define K3_LT(i) do { } while (0)
 #define K3_LS(i) do { } while (0)
+#endif
+#ifndef K3_LQ
+#define K3_LQ(i) do { } while (0)
 #endif
 
 #ifndef K3_COLD_INLINE
@@ -885,7 +892,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         else { ab = kInf - best + p.beam_delta; cur_cutoff = kInf; }
         if (kth >= 0) { const float sel_ = dec(block_select_kth(for_keys, kth, sh)); ab = sel_ - best + p.beam_delta; cur_cutoff = sel_; }
       }
-      K3_LT(0);
+      K3_LT(0); K3_LQ(0);
       { const unsigned want = (unsigned)((float)n_cur * p.hash_ratio); if (want > hash_size) hash_size = want; }      // PossiblyResizeHash (:227-233)
       if (hash_size > (unsigned)p.hash_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
       const float co = -best;
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       for (int i = tid; i < 3 * (kHL / 32); i += kBlock) s_lmark[i] = 0;
       __syncthreads();
       if (block_err(sh)) break;
-      K3_LT(1);
+      K3_LT(1); K3_LQ(1);
       // ---- pass A: per 64-token chunk of the visit order, the number of emitting arcs and min (tot + adaptive_beam)
       const int nchunks = (n_cur + 63) >> 6;
       auto chunk_tokens = [&](int c, int &i, float &cost, int &beg, int &deg) {
@@ -925,7 +932,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         if (lane == 0) { q.cmin[c] = cm; q.ccnt[c] = total; }
       }
       __syncthreads();
-      K3_LT(2);
+      K3_LT(2); K3_LQ(2);
       // exclusive scans over the chunks: bound in force at a chunk's first arc, sequence number of its first arc
       if (wave == 0) {
         unsigned run = enc(next0); int base = 0;
@@ -949,7 +956,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       // every emitting arc examined makes at most one forward link, the closure at most eps_cap more (its own check): make room before anything of the frame is written
       if (!make_room(nb, (long long)m_e + p.eps_cap)) break;
       cst = tok_state + cur_base; ccs = tok_cost + cur_base;
-      K3_LT(2);
+      K3_LT(2); K3_LQ(3);
       // ---- pass B: accept against the bound in force at each arc; min cost / min sequence number per destination state; forward links
       {
         const unsigned *cpre = q.cmin + (cap / 64 + 2); const int *cbase = q.ccnt + (cap / 64 + 2);
@@ -998,18 +1005,18 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         }
       }
       if (block_err(sh)) break;
-      K3_LT(4);
+      K3_LT(4); K3_LQ(4);
       n_e = sh.n_next; eps_l0 = sh.n_link;      // the frame's eps links start here
       if (tid == 0) { loff_n[f + 1] = sh.n_link; st_ntoks[f] = n_cur; st_cur[f] = cur_cutoff; st_ab[f] = ab; st_next[f] = accept; st_co[f] = co; }
       for (int i = tid; i < n_e; i += kBlock) q.c0[i] = dec(tb.cost(tok_slot[i]));      // costs right after ProcessEmitting (the replay starts from them)
       __syncthreads();
     }   // f >= 0
-    K3_LT(4);
+    K3_LT(4); K3_LQ(5);
     // ---- ProcessNonemitting: order-free fixpoint (costs, new tokens, eps links)
     finish_frame<false>(p, sh, tb, accept, nb, tok_state, tok_cost, links, link_arc, lp.tcap, lp.lcap, tok_slot, wl, s_lwl, creg, sreg, t_last__, cnt_eps);
     if (block_err(sh)) break;
     const int n = sh.n_next;
-    K3_LT(7);
+    K3_LT(7); K3_LQ(6);
     // ---- closure sub-graph in "closure id" space.  Only tokens that take part in it get an id: sources (>= 1 eps arc that passes at the
     // token's FINAL cost -- an arc that fails there fails at every earlier, higher cost too) and their destinations.  Per id: the cost the
     // replay has seen so far (+inf = not created yet), meta = {first passing arc, number of passing arcs}; per passing arc, in FST order:
@@ -1039,13 +1046,13 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     if (block_err(sh)) break;
     for (int i = tid; i < n; i += kBlock) { const int slot = tok_slot[i]; if (slot >= kHL) tb.clear(slot); }      // last use of the table in this frame
     __syncthreads();
-    K3_LT(8);
+    K3_LT(8); K3_LQ(7);
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made (their labels and states are
     // untouched by the closure).  Computed here, where the level-1 table's LDS is free for the bucket table of the pass.
     if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, s_tab, lt_last__);
     else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) && !lit_hash_order_big(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__))
       lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
-    K3_LT(6);
+    K3_LT(6); K3_LQ(8);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
     const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
                                        [&](int i, int4 ex) { q.grp[i] = ex.x; q.lead[i] = (unsigned)ex.y; if (csr_lds) l_cnt[i] = ex.y; else K3_AST(&q.rtmp[i], 0); }, n, reinterpret_cast<int4 *>(sh.hist));      // (LDS: the source's fill cursor starts at its first slot)
@@ -1059,6 +1066,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) { const int sl = (int)(k.src - nb); const int pos = csr_lds ? k3a_add(&l_cnt[sl], 1) : (int)q.lead[sl] + k3a_add(&q.rtmp[sl], 1); ent_arc[pos] = link_arc[l]; ent_dst[pos] = (int)(k.dst - nb); }
     }
     __syncthreads();
+    K3_LQ(9);
     // mode 0: costs, meta and arcs in LDS; mode 1: costs in LDS, meta / arcs (read-only during the replay) in HBM; mode 2: all in HBM
     // (mode 0: kRN x (16 B meta + 4 B cost + 4 B creation list) = the table's 12 B x kHL; mode 1: 3 kHL costs in the table, the list where mode 0 keeps its arcs)
     const int rmode = (n_cid <= kRN && n_arc <= kRA) ? 0 : ((n_cid <= 3 * kHL && n - n_e <= kRA * 2) ? 1 : 2);
@@ -1104,10 +1112,11 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     }
     // the initial queue (:845-850): the tokens ProcessEmitting made, in HashList order, that can expand (a token without a passing arc at its
     // final cost pops as a no-op); it is consumed from its back
+    K3_LQ(10);
     const int n_iq = block_excl_scan([&](int r) { return K3_ALD(&q.rown[ord_nxt[r]]) > 0 ? 1u : 0u; }, reinterpret_cast<unsigned *>(q.dense), n_e, sh.redi);
     for (int r = tid; r < n_e; r += kBlock) { const int i = ord_nxt[r]; if (K3_ALD(&q.rown[i]) > 0) q.iq[q.dense[r]] = q.grp[i]; }
     __syncthreads();
-    K3_LT(8);
+    K3_LT(8); K3_LQ(11);
 #ifdef K3_LIT_PROF
     if (tid == 0 && K3_LP_ON) { if (K3_LIT_PROF == 1) { sh.prof[13] += n; sh.prof[14] += rmode == 0 ? 1 : 0; } sh.prof[15] += 1; }
     const long long rp_t0 = (long long)__builtin_readcyclecounter(); (void)rp_t0;
@@ -1153,7 +1162,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       created_total = ls.n_created;
       for (int k = tid; k < created_total; k += kBlock) K3_AST(&q.label[q.c2t[clist[k]]], m_e + (unsigned)k);      // creation labels of the closure's tokens
     }
-    K3_LT(9);
+    K3_LT(9); K3_LQ(12);
 #ifdef K3_LIT_DEBUG
     if (n_e + created_total != n && tid == 0) printf("lane %d frame %d: n_e %d created %d n %d n_cid %d n_arc %d n_iq %d rmode %d\n", L, f, n_e, created_total, n, n_cid, n_arc, n_iq, rmode);
 #endif
@@ -1174,11 +1183,11 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
              !lit_hash_order_big(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, lt_last__))
       lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
-    K3_LT(10);
+    K3_LT(10); K3_LQ(13);
     // ---- publish the frame: final costs into the pool, empty table, idle labels
     for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], kLabelNone);
     __syncthreads();
-    K3_LT(11);
+    K3_LT(11); K3_LQ(14);
     cur_base = nb; n_cur = n; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1;
     if (tid == 0 && f >= 0) cyc_general += (long long)__builtin_readcyclecounter() - cyc_t0;
 #ifdef K3_LIT_FRAMECYC      // (< 0: general path, a given-up attempt on the LDS path included; cur_cutoff column = 1 when there was one)

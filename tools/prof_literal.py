@@ -35,7 +35,12 @@ for literal in (1, 0):
         nl_cyc, nl_pops = cyc[3], cyc[5]
         if not os.environ.get("K3_LIT_PROF_FINE"): cyc[3] = 0; cyc[5] = 0
         tot = cyc[:12].sum()
-        if os.environ.get("K3_LIT_PROF_FINE"):      # library built with -DK3_LIT_PROF=2: sub-phases of the hash-order passes and of the component replay
+        if os.environ.get("K3_LIT_PROF_Q"):      # library built with -DK3_LIT_PROF=3: the frame's phases split further
+            qn = ["cutoff (+LDS-path attempt)", "pre-pass", "pass A", "chunk scan", "pass B", "c0", "closure fixpoint", "final costs + passing-arc counts + table clear", "order1", "ids scan + arc slots", "records (step 2)", "initial queue",
+                  "replay", "order2", "publish"]
+            fr = max(1, cyc[15]); tq = cyc[:15].sum()
+            print("frames", int(fr), "cycles/lane/frame", int(tq / fr)); print("phase: cycles per frame (share %):", {n: "%d (%.1f)" % (c / fr, 100.0 * c / tq) for n, c in zip(qn, cyc[:15])})
+        elif os.environ.get("K3_LIT_PROF_FINE"):      # library built with -DK3_LIT_PROF=2: sub-phases of the hash-order passes and of the component replay
             sub = ["ho:bitmap", "ho:word scan", "ho:dense+buckets", "ho:leader scan", "ho:group fill", "ho:order", "ho:reset", "cr:init", "cr:union", "cr:count", "cr:scan4", "cr:group roots", "cr:workers", "cr:labels"]
             fr = max(1, cyc[15]); print("sub-phase cycles/lane/frame:", {n: int(c / fr) for n, c in zip(sub, cyc[:14])})
         elif tot:
