@@ -295,7 +295,7 @@ typedef struct k3_decoder_config {
    * applies the frame's FINAL bound to every arc (order-independent, a sub-lattice with the same best path).  hash_ratio =
    * LatticeFasterDecoderConfig::hash_ratio (2.0): it decides the bucket count and with it the reference's visit order.
    * Needs frame_tokens_cap <= 65536 < frame_cands_cap. */
-  int32_t literal_order;      /* 0; 1 = on; 2 = on, the closure's creation order by the one-wavefront replay (the fall-back path of 1, for A/B); 3 = 1 with the fall-back forced (tests) */
+  int32_t literal_order;      /* 0; 1 = on; 2 = on, the closure's creation order by the one-wavefront replay (the fall-back path of 1, for A/B); 3 = 1 with the fall-back forced (tests); 4 = 1 with the hash-order passes of frames above 3072 tokens on their HBM fall-back form instead of the LDS-partition form (tests) */
   float hash_ratio;           /* 2.0 */
   /* literal_order = 1 only: frames of at most this many tokens (before and after) are processed entirely in LDS (k3_decoder_fast.h), the others on the
    * general path; same results either way.  -1 = the kernel's capacity (3072), 0 = general path only (A/B, tests), n = a smaller capacity (tests). */

@@ -968,7 +968,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   p.live_cap = (int)std::min<long long>(cfg->lane_tokens_cap, 1 << 18);
   if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.live_link, nl * p.live_cap))) return rc;
-  p.literal = (cfg->literal_order == 2 || cfg->literal_order == 3) ? cfg->literal_order : (cfg->literal_order ? 1 : 0); p.hash_ratio = cfg->hash_ratio;      // 2: the closure's creation order by the one-wavefront replay (the fall-back of 1); 3: 1 with zero-length component stacks (exercises the fall-back)
+  p.literal = (cfg->literal_order == 2 || cfg->literal_order == 3) ? cfg->literal_order : (cfg->literal_order ? 1 : 0); p.lit_force_hbm_order = cfg->literal_order == 4; p.hash_ratio = cfg->hash_ratio;      // 2: the closure's creation order by the one-wavefront replay (the fall-back of 1); 3: 1 with zero-length component stacks (exercises the fall-back)
   p.fast_cap = p.literal == 1 ? (cfg->fast_frame_tokens < 0 ? k3_lit_fast_tokens() : std::min(cfg->fast_frame_tokens, k3_lit_fast_tokens())) : 0;
   if (p.literal) {
     K3_REQUIRE(cfg->hash_ratio > 0.0f && cfg->hash_ratio <= 64.0f, "k3_decoder_create: literal_order needs 0 < hash_ratio <= 64 (LatticeFasterDecoderConfig::hash_ratio)");

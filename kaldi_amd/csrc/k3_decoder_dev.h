@@ -115,7 +115,7 @@ struct DecParams {
   int *st_ntoks; float *st_cur, *st_ab, *st_next, *st_co;
   LaneInfo *info;
   // literal_order scratch (k3_decoder_literal.h), per lane
-  int literal, fast_cap; float hash_ratio; int hash_cap, seq_words_cap, eps_cap, stack_cap; long long lt_lane_bytes;      // the lt_* pointers below are lane 0's; lane l's arrays start lt_lane_bytes * l further on
+  int literal, fast_cap, lit_force_hbm_order; float hash_ratio; int hash_cap, seq_words_cap, eps_cap, stack_cap; long long lt_lane_bytes;      // the lt_* pointers below are lane 0's; lane l's arrays start lt_lane_bytes * l further on
   int *lt_order;          // [2 x frame_tokens_cap] HashList order of the current / the next frame (local token indices)
   int *lt_by_ins;         // [frame_tokens_cap] tokens of the newest frame in creation order (the final-frame sweeps walk it backwards)
   unsigned *lt_label;     // [frame_tokens_cap] creation label of a token being built (all 0xFFFFFFFF between frames)

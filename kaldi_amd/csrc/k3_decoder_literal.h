@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made (their labels and states are
     // untouched by the closure).  Computed here, where the level-1 table's LDS is free for the bucket table of the pass.
     if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, s_tab, lt_last__);
-    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) && !lit_hash_order_big(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__))
+    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) && (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__)))
       lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
     K3_LT(6); K3_LQ(8);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
     if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, smem_raw, s_tab, lt_last__);
     else if (!lit_hash_order_mid(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true) &&
-             !lit_hash_order_big(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, lt_last__))
+             (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, lt_last__)))
       lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     K3_LT(10); K3_LQ(13);

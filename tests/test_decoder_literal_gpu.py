@@ -37,8 +37,8 @@ def _check_against_oracle(dec, u, lat, f, ll, t2p, kw):
 
 # replay 1: frames of <= 1536 tokens on the LDS-resident path (k3_decoder_fast.h), the others on the general path; 2 / 3: general path with the one-wavefront replay / with component stacks of
 # length zero (every component that needs its stack falls back to the one-wavefront replay); (1, 0): general path only; (1, 96): an LDS path of 96 tokens -- most frames
-# give up half-way and are redone, the two paths alternate all the time
-@pytest.mark.parametrize("replay,fast", [(1, -1), (2, -1), (3, -1), (1, 0), (1, 96)])
+# give up half-way and are redone, the two paths alternate all the time; (4, 0): general path with the large frames' hash-order passes on their HBM fall-back form
+@pytest.mark.parametrize("replay,fast", [(1, -1), (2, -1), (3, -1), (1, 0), (1, 96), (4, 0)])
 @pytest.mark.parametrize("name", sorted(dcases.CASES))
 def test_literal_order_equals_the_reference_decoder(name, replay, fast):
     from kaldi_amd import decoder
