@@ -378,7 +378,8 @@ struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 // HashList order for the frames above lit_hash_order_mid (the head of an utterance: 3 k .. 25 k tokens on every lane at the same time) WITHOUT global atomics.  The HBM form
 // (lit_hash_order) spends ~6 read-modify-write operations per token at the L2, and with all lanes in their large frames together the chip's atomic rate -- not latency --
 // is what those frames wait for (tools/prof_frames.py: the same frame takes half the cycles with 128 lanes resident instead of 512).  Here every atomic is an LDS atomic:
-//   * creation ranks: the label bitmap of a RANGE of kHbW x 32 labels in LDS (one range covers the usual frame), prefix counts over its words, ranks to q.dense;
+//   * creation ranks: the label bitmap of a RANGE of kHbW x 32 = 32 768 labels in LDS, prefix counts over its words, ranks to q.dense (the head frames of an utterance take two to
+//     four ranges, so the range loop is exercised by every decode of the bench configuration; a range costs two coalesced sweeps over the labels);
 //   * the tokens' records {bucket, rank | token} are grouped into P = 2^k PARTITIONS by the top bits of the bucket's hash (<= 2048 tokens each, ~1000 on average): a histogram and
 //     per-partition cursors in LDS, one 8-byte store per token;
 //   * a partition at a time: its records in registers (<= 4 per thread), its buckets {key, smallest rank, members | cursor} in an LDS table of kHbT slots, the ranks of the
@@ -386,7 +387,7 @@ struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 //   * a scan over the leaders' sizes in creation order gives the buckets' offsets; position = offset of the leader + place inside the bucket.
 // Global memory sees streams plus, per token, the record store, the leader's size (one store per bucket), one load of the leader's offset and the result.
 // Returns false when a partition does not fit (the caller takes lit_hash_order): the result is then untouched.
-constexpr int kHbT = 4096, kHbW = 8192, kHbPart = 1536, kHbMaxPart = 2048, kHbMaxP = 64;
+constexpr int kHbT = 4096, kHbW = 1024, kHbPart = 1536, kHbMaxPart = 2048, kHbMaxP = 64;
 constexpr size_t kHbLdsA = (size_t)kHbW * 4 + (size_t)kHbW * 2, kHbLdsB = (size_t)kHbT * 12 + (size_t)kHbT * 2 + (size_t)kHbMaxPart * 2, kHbLdsP = kHbLdsB > kHbLdsA ? kHbLdsB : kHbLdsA;
 static_assert(kHbLdsP + 2 * kHbMaxP * 4 <= kLitGeneralLds, "the large-frame hash order works in the general path's arena");
 static_assert(kHbMaxPart <= 4 * kBlock, "a partition's records fit the registers of one pass");
