@@ -82,6 +82,22 @@ def test_literal_order_random_configurations_and_lane_reuse(replay, fast):
         for u in range(len(lls)):
             if info2[u, 2] == 0: assert lats2[u].diff(lats[(u + 1) % len(lls)]) == "", (it, u)
 
+@pytest.mark.parametrize("hash_ratio,replay", [(2.0, 1), (0.25, 1), (1.0, 4), (7.3, 1), (64.0, 1)])
+def test_literal_order_large_frames_over_hash_ratios(hash_ratio, replay):
+    """frames of 4 k - 20 k tokens (wide beam, no active-state limit, a graph whose start state fans out) with the reference's hash_ratio from a quarter (many tokens per bucket:
+    the large-frame hash-order pass ranks long member lists) to 64 (bucket numbers far above 65535); replay 4 = the same frames through the HBM fall-back form of that pass"""
+    from kaldi_amd import decoder
+    N = 120; f = synth.make_hclg(60000, 200000, N, seed=77, start_degree=1500); t2p = synth.tid2pdf(N); cf = decoder.CudaFst(f, t2p)
+    rng = np.random.default_rng(11)
+    lls = [(rng.standard_normal((T, N)) * 1.2).astype(np.float32) for T in (14, 9)]
+    kw = dict(beam=17.0, lattice_beam=6.0, hash_ratio=hash_ratio)
+    lats, info, dec = _decode(cf, N, lls, literal=replay, **kw)
+    assert (info[:, 2] == 0).all(), info
+    big = 0
+    for u, ll in enumerate(lls):
+        oi = _check_against_oracle(dec, u, lats[u], f, ll, t2p, kw); big = max(big, int(oi["ntoks"].max()))
+    assert big > 4096, big      # (the case must reach the large-frame forms)
+
 def test_literal_order_chunked_advance_equals_whole_utterance():
     from kaldi_amd import decoder
     N = 80; f = synth.make_hclg(3000, 8000, N, seed=9, start_degree=60); t2p = synth.tid2pdf(N); cf = decoder.CudaFst(f, t2p)
