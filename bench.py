@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--graph-states", type=int, default=2_000_000); ap.add_argument("--graph-arcs", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-two-pass", action="store_true", help="skip the second (order-independent decoder) measurement")
+    ap.add_argument("--wait-whole-decoder", action="store_true", help="A/B: the next front end waits for the whole decoder call of two batches ago (token passing + pruning) instead of its token-passing launch")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: H2D, fbank, TDNN-F and decoder of a batch strictly after the previous batch (stage_ms then adds up to ms_per_step)")
     ap.add_argument("--one-decoder", action="store_true", help="one decoder object instead of two alternating ones (the default keeps two sets of lane pools -- 2 x 41 GB of the 288 GB at the bench configuration -- so that a batch's token passing starts under the previous batch's pruning kernel and lattice fetch)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="cpu_baseline / e2e_parity: single-threaded reference workers (0 = one per host core: the baseline is then MEASURED on the whole host, no extrapolation)")
@@ -318,9 +319,13 @@ def main():
         dec = decs.get(mode); lat_sizes = [0, 0, None]; det_sizes = [0, 0]; pending = []; nstep = [0]; nser = [0]; last = [None]
         src = lambda k: pcm_host[shift_of(k) if vary else 0:][:U * nsamp]      # batch k's audio
         for e in dec_done: e.record()
+        reader = [None, None]      # the decoder object that read log-likelihood buffer 0 / 1 last
         def front_end(k):      # batch k's H2D + fbank + TDNN-F on the front stream, into log-likelihood buffer k & 1 (last read by the decoder two batches ago)
             with torch.cuda.stream(front):
-                front.wait_event(dec_done[k & 1])
+                # the buffer's last reader is the token-passing launch of batch k - 2, not the pruning / output kernels behind it: those cannot run beside the resident launch of batch k - 1
+                # (LDS) and finish ~50 ms into it, which is when this front end used to start (profiles/r04c_pipeline_overlap.txt)
+                if reader[k & 1] is not None and not args.wait_whole_decoder: reader[k & 1].StreamWaitTokenPassing(front)
+                else: front.wait_event(dec_done[k & 1])
                 fev[k & 1][0].record(); pcm_dev.copy_(src(k), non_blocking=True)
                 fev[k & 1][1].record(); sf.ComputeFeatures(pcm_dev, wo, fo, total_frames, out=feats)
                 fev[k & 1][2].record(); nb.forward(feats, out=ll2[k & 1])
@@ -330,7 +335,7 @@ def main():
             if k == 0: front_end(0)
             torch.cuda.current_stream().wait_event(fev[k & 1][3])
             if timed: ev[3].record()
-            dec.DecodeBatch(ll2[k & 1], nb.out_offsets); dec_done[k & 1].record()
+            dec.DecodeBatch(ll2[k & 1], nb.out_offsets); dec_done[k & 1].record()      # (one decoder object: its latest token-passing launch is batch k's, not the buffer's last reader)
             front_end(k + 1)       # queued behind the decoder: its workgroups take the CUs the decoder's lanes leave as they finish
             if timed: ev[4].record()
             while len(pending) >= 2: r = pending.pop(0).result(); det_sizes[0], det_sizes[1] = r
@@ -352,7 +357,7 @@ def main():
             with torch.cuda.stream(dstr[k & 1]):
                 dstr[k & 1].wait_event(fev[k & 1][3])
                 if timed: ev[3].record()
-                pair[k & 1].DecodeBatch(ll2[k & 1], nb.out_offsets); dec_done[k & 1].record()
+                pair[k & 1].DecodeBatch(ll2[k & 1], nb.out_offsets); dec_done[k & 1].record(); reader[k & 1] = pair[k & 1]
                 if timed: ev[4].record()
             front_end(k + 1)
             if k > first_timed[0]: fetch(k - 1)

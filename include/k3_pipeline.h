@@ -292,7 +292,10 @@ class BatchedThreadedNnet3CudaPipeline2 {
       plan_cache_.push_back({nframes, nb}); if (plan_cache_.size() > 4) { k3_nnet_batch_destroy(plan_cache_.front().second); plan_cache_.erase(plan_cache_.begin()); }
     }
     f->ro.assign(U + 1, 0); const int64_t rows = k3_nnet_batch_output_rows(nb, f->ro.data());
-    K3O_HIP(hipStreamWaitEvent(s_front_, ev_dec_[f->buf], 0));      // (two decoder objects: the batch before the last may still be decoding from this log-likelihood buffer)
+    // (two decoder objects: the batch before the last may still be decoding from this log-likelihood buffer.  Its last reader is that decoder's token-passing launch; the pruning and
+    // output kernels behind it cannot run beside the other decoder's resident launch and would hold this front end back by tens of milliseconds)
+    if (Dec(0) != Dec(1)) K3H_CHECK_K3(k3_decoder_stream_wait_token_passing(Dec(f->buf), s_front_));
+    else K3O_HIP(hipStreamWaitEvent(s_front_, ev_dec_[f->buf], 0));
     if ((size_t)rows * ninfo_.output_dim > d_ll_[f->buf].cap) K3O_HIP(hipEventSynchronize(ev_dec_[f->buf]));      // (growing the buffer frees it: only once that decoder is through)
     K3H_CHECK_K3(k3_nnet_forward(nb, d_f_.p, fdim_, d_ll_[f->buf].need((size_t)rows * ninfo_.output_dim), ninfo_.output_dim, s_front_));
     K3O_HIP(hipEventRecord(ev_front_[f->buf], s_front_)); f->valid = true;

@@ -365,6 +365,9 @@ int k3_decoder_get_raw_lattices(k3_decoder *dec, int32_t *h_st_frame, int32_t *h
 /* HIP-event timing of the two decode kernels of the last batch on their launch stream: h_ms[0] = token passing
  * (k3_decode_forward_kernel), h_ms[1] = lattice-beam pruning (k3_decode_prune_kernel). */
 int k3_decoder_set_profiling(k3_decoder *dec, int32_t on);
+/* `stream` waits (on the device) for the decoder's latest token-passing launch: the last reader of the log-likelihoods handed to k3_decoder_decode_batch / k3_decoder_advance_decoding*.
+ * What a pipelined caller puts in front of the kernels that refill that buffer, instead of waiting for the pruning / output kernels as well.  No-op before the first launch. */
+int k3_decoder_stream_wait_token_passing(k3_decoder *dec, void *stream);
 int k3_decoder_kernel_times(k3_decoder *dec, float *h_ms);
 /* developer aid: per-phase shader-clock totals of the token-passing kernel (all zero unless the library was built with -DK3_DEC_PROF) */
 int k3_decoder_phase_cycles(k3_decoder *dec, int64_t *h_cycles /* [16] */);

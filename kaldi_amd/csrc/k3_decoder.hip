@@ -893,8 +893,9 @@ struct k3_decoder {
   void *out_buf = nullptr; size_t out_bytes = 0;
   bool started = false, finalized = false;
   bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_tp = nullptr; bool ev_tp_recorded = false;      // recorded behind every token-passing launch: the last reader of the caller's log-likelihoods (k3_decoder_stream_wait_token_passing)
 
-  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); if (out_buf) (void)hipFree(out_buf); }
+  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); if (ev_tp) (void)hipEventDestroy(ev_tp); if (out_buf) (void)hipFree(out_buf); }
 };
 
 extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
@@ -1082,6 +1083,8 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
+  if (!d->ev_tp) K3_HIP_CHECK(hipEventCreateWithFlags(&d->ev_tp, hipEventDisableTiming));
+  K3_HIP_CHECK(hipEventRecord(d->ev_tp, st)); d->ev_tp_recorded = true;
   d->started = true; d->last_stream = st; d->info_valid = false;
   return K3_OK;
 }
@@ -1112,6 +1115,8 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
+  if (!d->ev_tp) K3_HIP_CHECK(hipEventCreateWithFlags(&d->ev_tp, hipEventDisableTiming));
+  K3_HIP_CHECK(hipEventRecord(d->ev_tp, st)); d->ev_tp_recorded = true;
   d->started = true; d->last_stream = st; d->info_valid = false;
   return K3_OK;
 }
@@ -1165,6 +1170,15 @@ extern "C" int k3_decoder_decode_batch(k3_decoder *d, int32_t num_utts, const fl
   if ((rc = k3_decoder_init_decoding(d, num_utts, maxT, stream))) return rc;
   if ((rc = k3_decoder_advance_decoding(d, num_utts, d_loglikes, ld, h_row_off, stream))) return rc;
   return k3_decoder_finalize_decoding(d, stream);
+}
+
+// Make `stream` wait for the decoder's latest token-passing launch -- the last kernel that reads the caller's log-likelihood buffer (the pruning and output kernels behind it work on
+// the lane's own pools).  A pipeline that refills that buffer for a later batch waits for THIS, not for the whole of k3_decoder_decode_batch: the pruning kernel cannot run beside a
+// resident token-passing launch of another decoder object (LDS), so behind it the next front end would start tens of milliseconds later than it has to.
+extern "C" int k3_decoder_stream_wait_token_passing(k3_decoder *d, void *stream) {
+  K3_REQUIRE(d, "k3_decoder_stream_wait_token_passing: null decoder");
+  if (d->ev_tp_recorded) K3_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, d->ev_tp, 0));
+  return K3_OK;
 }
 
 static int fetch_info(k3_decoder *d) {

@@ -51,6 +51,9 @@ enum { kRfHasEps = 1, kRfExists = 2 };
 #define K3_LQ(i) do { } while (0)
 #endif
 
+#ifndef K3_LIT_BASE_PRIO
+#define K3_LIT_BASE_PRIO 2      // wave priority of the token-passing kernel (0 .. 3); A/B with -DK3_LIT_BASE_PRIO=0
+#endif
 #ifndef K3_COLD_INLINE
 #define K3_COLD_INLINE __forceinline__      // (register-pressure experiments: -DK3_COLD_INLINE=__noinline__ makes the large-frame forms of the hash-order pass real calls)
 #endif
@@ -754,6 +757,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
   // never run at the same time and the general path re-initialises its table after a fast frame.
   extern __shared__ __attribute__((aligned(16))) char arena[];
   __shared__ Shared sh; __shared__ LitShared ls; __shared__ FastShared fs;
+  // A lane is a latency chain that issues in a sixth of its cycles; the workgroups that share its CU in the tail of a batch are the next batch's GEMMs, which would issue every cycle.
+  // Raised priority lets the lane's few instructions go first (the GEMM loses nothing it could use: its MFMA work is fixed).
+  __builtin_amdgcn_s_setprio(K3_LIT_BASE_PRIO);
   int *const s_tab = reinterpret_cast<int *>(arena);      // level-1 table {key, cost, token}; between the closure and the end of a frame: the replay's records
   int *const s_lkey = s_tab; unsigned *const s_lcost = reinterpret_cast<unsigned *>(s_tab + kHL); int *const s_ltok = s_tab + 2 * kHL;
   unsigned *const s_lmark = reinterpret_cast<unsigned *>(arena + kLitTabBytes);
@@ -1149,7 +1155,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         else if (rmode == 1) lit_replay<1>(reinterpret_cast<float *>(s_tab), q.meta, q.arcs2, reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
                                            reinterpret_cast<unsigned *>(smem_raw), q.iq, n_iq, accept, s_own, &created, &err, &pops);
         else lit_replay<2>(q.rcost, q.meta, q.arcs2, q.stack, p.stack_cap, reinterpret_cast<unsigned *>(q.rflag), q.iq, n_iq, accept, s_own, &created, &err, &pops);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(K3_LIT_BASE_PRIO);
 #if defined(K3_LIT_PROF) && K3_LIT_PROF == 1
         if (lane == 0) { sh.prof[12] += pops; if (rmode != 0) sh.prof[3] += (long long)__builtin_readcyclecounter() - rp_t0; }
 #endif

@@ -195,6 +195,11 @@ class CudaDecoder:
     def SetProfiling(self, on=True):
         _l.check(self._L.k3_decoder_set_profiling(self._h, int(on)))
 
+    def StreamWaitTokenPassing(self, stream):
+        """`stream` (torch.cuda.Stream) waits on the device for this decoder's latest token-passing launch -- the last reader of the log-likelihoods it was given; what a pipelined
+        caller puts in front of the kernels that refill that buffer (the pruning kernel behind the launch works on the lane pools only)"""
+        _l.check(self._L.k3_decoder_stream_wait_token_passing(self._h, ctypes.c_void_p(stream.cuda_stream)))
+
     def KernelTimes(self):
         """(token-passing kernel ms, lattice-pruning kernel ms) of the last batch, HIP events on the launch stream"""
         ms = np.zeros(2, np.float32); _l.check(self._L.k3_decoder_kernel_times(self._h, ms.ctypes.data)); return float(ms[0]), float(ms[1])

@@ -121,7 +121,7 @@ def load():
     L.k3_decoder_get_raw_lattices.argtypes = [vp] + [vp] * 10
     L.k3_decoder_get_best_path.argtypes = [vp, vp, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp]
     L.k3_fst_export_image.argtypes = [vp, vp]; L.k3_fst_import_image.argtypes = [vp, vp]
-    L.k3_decoder_set_profiling.argtypes = [vp, i32]; L.k3_decoder_kernel_times.argtypes = [vp, vp]
+    L.k3_decoder_set_profiling.argtypes = [vp, i32]; L.k3_decoder_kernel_times.argtypes = [vp, vp]; L.k3_decoder_stream_wait_token_passing.argtypes = [vp, vp]
     L.k3_decoder_phase_cycles.argtypes = [vp, vp]
     L.k3_decoder_frame_stats.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     f32 = ctypes.c_float

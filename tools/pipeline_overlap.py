@@ -18,3 +18,14 @@ for i, d in enumerate(dec):
     inside = [f for f in fe if d[0] < f[0] < d[1]]
     done = (max(f[1] for f in inside) - d[1]) / 1e6 if inside else float("nan")
     print("%2d %-34s %10.2f %9.2f | %5d   %+10.2f ms   %s" % (i, d[2], (d[0] - t00) / 1e6, (d[1] - d[0]) / 1e6, len(inside), done, "%8.2f ms" % ((nxt - d[0]) / 1e6) if nxt else "       -"))
+# ---- per launch: where the next batch's front end sits relative to it, and when the next token-passing launch starts relative to the end of that front end
+prn = [e for e in ev if e[2].startswith("k3_decode_prune")]
+print("# launch   dur_ms | next batch's front end: first kernel starts at, last ends at (ms after this launch's start), sum of its kernels' durations | next launch starts (ms after this one's start; after that front end's end) | pruning kernel of this launch: start, dur")
+for i, d in enumerate(dec):
+    nxt = dec[i + 1][0] if i + 1 < len(dec) else None
+    inside = [f for f in fe if d[0] < f[0] < (nxt if nxt else d[1])]
+    if not inside or nxt is None: continue
+    f0 = min(f[0] for f in inside); f1 = max(f[1] for f in inside); busy = sum(f[1] - f[0] for f in inside)
+    pr = [q for q in prn if q[0] >= d[1] - 1000 and q[0] < d[1] + 30e6][:1]
+    print("%2d %9.2f | %7.2f %7.2f %7.2f | %7.2f %+7.2f | %s" % (i, (d[1] - d[0]) / 1e6, (f0 - d[0]) / 1e6, (f1 - d[0]) / 1e6, busy / 1e6, (nxt - d[0]) / 1e6, (nxt - f1) / 1e6,
+                                                        "%7.2f %6.2f" % ((pr[0][0] - d[0]) / 1e6, (pr[0][1] - pr[0][0]) / 1e6) if pr else "-"))
