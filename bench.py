@@ -476,14 +476,14 @@ def main():
             # phases of the reference's serial algorithm unrolled (cutoff, bound pass, accept pass, eps rounds, closure sub-graph, two hash-order passes, queue order, component replay,
             # creation labels).  The cheapest such a phase gets on this hardware -- LDS read -> DPP scan -> LDS atomic -> workgroup barrier over 8 wavefronts -- is what the LDS-resident
             # frames of <= 512 tokens cost per phase: 141 k cycles / 70 (profiles/r04_literal_frames_by_size.txt).  floor = frames x phases x that / clock; all lanes run in parallel.
-            n_frames = int(info[:, 9].max()); ph, cpp, ghz = 70, 2014.0, 2.1
+            n_frames = int(info[:, 9].max()); ph, cpp, ghz = 70, 2014.0, 2.4      # (this kernel runs at the chip's 2.4 GHz engine clock: the slowest lane's frame cycles / the kernel time = 2.38, tools/prof_frames.py; the GEMMs, power-bound, at 2.06)
             floor_ms = n_frames * ph * cpp / (ghz * 1e6)
             lane_launches = max(1, (paths["lds_path"] + paths["general_path"]) // max(1, n_frames))      # (a frame is counted once: on the LDS path, or -- given up there or not -- on the general path)
             mean_lane_ms = (paths["cycles_lds_path"] + paths["cycles_general_path"]) / lane_launches / (ghz * 1e6)
             line["roofline_latency"] = {"bound": "latency: the per-lane chain of frames x barrier-separated phases", "kernel": "k3_decode_forward_literal_kernel", "frames_per_lane": n_frames, "phases_per_frame": ph,
                                         "cycles_per_phase_floor": cpp, "shader_clock_ghz": ghz, "floor_ms": floor_ms, "achieved_ms": acc[5], "frac": floor_ms / acc[5], "mean_lane_ms": mean_lane_ms, "frac_mean_lane": floor_ms / mean_lane_ms,
                                         "note": "floor = every frame at the cost of an LDS-resident frame of <= 512 tokens (70 phases x 2.0 k cycles, measured); achieved_ms = the kernel (its slowest lane, 512 lanes two to a CU), "
-                                                "mean_lane_ms = shader cycles per lane from the kernel's own counters / 2.1 GHz.  What separates them from the floor: frames above 512 tokens (cost grows ~0.28 k cycles per token), the "
+                                                "mean_lane_ms = shader cycles per lane from the kernel's own counters / 2.4 GHz.  What separates them from the floor: frames above 512 tokens (cost grows ~0.28 k cycles per token), the "
                                                 "frames beyond the LDS path's 1536 tokens on HBM scratch (general_path_cycles_share of the cycles), the first ~12 frames of every utterance (3 - 25 k tokens on every lane at once: 27 % of the cycles, bound by the chip's "
                                                 "rate of scattered read-modify-write accesses rather than by latency) -- profiles/r04_literal_frames_by_size.txt, r04_literal_phase_profile_by_size.txt",
                                         "general_path_cycles_share": paths["cycles_general_path"] / max(1, paths["cycles_lds_path"] + paths["cycles_general_path"])}

@@ -47,6 +47,7 @@ if first is not None:
     print("cycles per lane (M): min %.1f p10 %.1f median %.1f p90 %.1f max %.1f | corr with the lane's token count %.3f" % (*q, np.corrcoef(per_lane, tok_lane)[0, 1]))
     print("mean cycles per lane (M) by lane %% 8:", np.round([per_lane[k::8].mean() / 1e6 for k in range(8)], 1).tolist(), "| first / second half of the lanes:", round(per_lane[:U // 2].mean() / 1e6, 1), round(per_lane[U // 2:].mean() / 1e6, 1))
     print("cycles per token of the lane: min %.0f median %.0f max %.0f" % tuple(np.percentile(per_lane / tok_lane, [0, 50, 100])))
+    print("shader clock implied by the slowest lane: %.1f M cycles of frames / %.2f ms of kernel = %.2f GHz (a lower bound: the lane's prologue and InitDecoding are not in its frame cycles)" % (per_lane.max() / 1e6, kt[0], per_lane.max() / kt[0] / 1e6))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"token_passing_ms": kt[0], "lanes": U, "cycles_per_lane": tot / U, "rows": rows, "head12_cycles_share": float(cyc[head].sum() / tot) if first is not None else None},
           open(os.path.join(ROOT, "gpurun_out", "literal_frames_by_size.json"), "w"), indent=1)
