@@ -331,6 +331,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
   __shared__ float s_cost[2][kPCap], s_extra[2][kPCap];   // token costs / extra costs of frames f+1 (buffer nb) and f (buffer nb ^ 1)
   __shared__ unsigned s_xb[kPCap];
   const int L = p.lane_ids ? p.lane_ids[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
+  __builtin_amdgcn_s_setprio(2);      // (a latency chain like the token-passing kernel: its few instructions go ahead of the GEMM workgroups it shares CUs with in a pipeline)
   LaneInfo &li = p.info[L];
   if (li.status != kStOk) return;
   const int T = li.num_frames;
