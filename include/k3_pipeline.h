@@ -19,6 +19,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <future>
 #include <thread>
 #include "../kaldi_amd/host/k3_online.h"      // (the host layer of this repository: k3_host.h + the streaming helpers)
 namespace k3host {
@@ -232,6 +233,7 @@ class BatchedThreadedNnet3CudaPipeline2 {
     K3O_HIP(hipStreamCreateWithFlags(&s_front_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_b_, hipStreamNonBlocking));
     for (auto &e : ev_front_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ev_dec_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : ev_h2d_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // Batches in flight: `prev` (decoded, lattices not fetched yet -- only with two decoder objects), `cur` (front end issued, decoder next), `nxt` (front end issued behind cur's decoder).
     // With one decoder object a batch's lattices are fetched right after the next batch's front end has been queued; with two, one step later, so that the next batch's token passing is
     // already queued on the other object's stream while this batch's pruning kernel, compaction and copy run.  Nothing waits for new work while a decoded batch is unfetched.
@@ -244,52 +246,80 @@ class BatchedThreadedNnet3CudaPipeline2 {
       if (decoding) { try { Fetch(f); } catch (const std::exception &e) { K3H_WARN << "batch failed: " << e.what(); for (auto &t : f->batch) t->failed = true; } }
       Hand(f->batch); *f = InFlight();
     };
+    // Two decoder objects: a decoded batch's lattices are fetched (Fetch blocks until that batch's pruning / output kernels and the copy are through) on a helper thread, so that
+    // this loop goes on to QUEUE the next front end at once; it only waits for the fetch of the batch that used the same decoder object two batches ago, right before it launches on that
+    // object again.  (Fetched on this thread, every other batch's front end reached the stream 30 ms late: the pruning kernel cannot start beside the other object's resident launch and the
+    // loop sat in Fetch while the CUs that launch freed stayed idle -- tools/pipeline_overlap.py on the program's kernel trace.)
+    std::future<void> fetching[2];
+    auto finish_async = [&](InFlight &&f, bool decoding) {
+      const int b = f.buf & 1; auto sp = std::make_shared<InFlight>(std::move(f));
+      fetching[b] = std::async(std::launch::async, [this, sp, decoding, &finish]() { (void)hipSetDevice(device_); finish(sp.get(), decoding); });
+    };
+    auto fetched = [&](int b) { if (fetching[b & 1].valid()) fetching[b & 1].get(); };
     for (;;) {
       if (cur.batch.empty()) {
-        if (!prev.batch.empty()) finish(&prev, prev_decoding);      // idle: hand the last decoded batch over before blocking for new work
+        if (!prev.batch.empty()) { fetched(prev.buf ^ 1); finish(&prev, prev_decoding); }      // idle: hand the last decoded batch over (after the one before it) before blocking for new work
         auto b = TakeBatch(true); if (b.empty()) break; start(&cur, std::move(b));
       }
+      // the next batch's front end first: nothing it needs waits for this batch's decoder launch (its log-likelihood buffer is guarded on the device, its staging is its own)
+      nxt = InFlight(); { auto b = TakeBatch(false); if (!b.empty()) start(&nxt, std::move(b)); }
       bool decoding = false;
       try {
         if (cur.valid) {
+          fetched(cur.buf);      // this decoder object's previous batch: its lattices must be out before the object is launched again
           K3O_HIP(hipStreamWaitEvent(DecStream(cur.buf), ev_front_[cur.buf], 0));
           K3H_CHECK_K3(k3_decoder_decode_batch(Dec(cur.buf), cur.U, d_ll_[cur.buf].p, ninfo_.output_dim, cur.ro.data(), DecStream(cur.buf))); decoding = true;
           K3O_HIP(hipEventRecord(ev_dec_[cur.buf], DecStream(cur.buf)));
-          K3O_HIP(hipEventSynchronize(ev_front_[cur.buf]));      // the front end of `cur` is through: its staging, feature and network buffers are free
         }
       } catch (const std::exception &e) {
         K3H_WARN << "batch failed: " << e.what(); for (auto &t : cur.batch) t->failed = true; decoding = false;
-        (void)hipStreamSynchronize(s_front_);      // the wait for cur's front end was skipped: its shared staging / feature buffers must be quiescent before the next batch's front end reuses (or reallocates) them
       }
-      nxt = InFlight(); { auto b = TakeBatch(false); if (!b.empty()) start(&nxt, std::move(b)); }
+      if (nxt.batch.empty()) { auto b = TakeBatch(false); if (!b.empty()) start(&nxt, std::move(b)); }      // (it may have arrived while this thread waited)
       if (dec_b_) {
-        if (!prev.batch.empty()) finish(&prev, prev_decoding);
+        if (!prev.batch.empty()) finish_async(std::move(prev), prev_decoding);
         prev = std::move(cur); prev_decoding = decoding;
       } else finish(&cur, decoding);
       cur = std::move(nxt); nxt = InFlight();
     }
+    fetched(0); fetched(1);
     if (!prev.batch.empty()) finish(&prev, prev_decoding);
     K3O_HIP(hipStreamSynchronize(s_front_)); K3O_HIP(hipStreamSynchronize(s_dec_)); K3O_HIP(hipStreamSynchronize(s_dec_b_));
-    for (auto &e : ev_front_) (void)hipEventDestroy(e); for (auto &e : ev_dec_) (void)hipEventDestroy(e);
+    for (auto &e : ev_front_) (void)hipEventDestroy(e); for (auto &e : ev_dec_) (void)hipEventDestroy(e); for (auto &e : ev_h2d_) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(s_front_); (void)hipStreamDestroy(s_dec_); (void)hipStreamDestroy(s_dec_b_);
   }
   void FrontEnd(InFlight *f) {      // upload + features + network of f->batch on the front stream, log-likelihoods into buffer f->buf
     std::vector<std::shared_ptr<Task>> &batch = f->batch;
-    std::vector<int> &idx = f->idx; idx.clear(); std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int32_t> nframes;
+    std::vector<int> &idx = f->idx; idx.clear(); std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int32_t> nframes;
     for (size_t i = 0; i < batch.size(); i++) {
       const int nf = k3_feat_num_frames(plan_, (int64_t)batch[i]->samples.size());
       if (nf == 0) { batch[i]->failed = true; continue; }      // too short to decode
-      idx.push_back((int)i); all.insert(all.end(), batch[i]->samples.begin(), batch[i]->samples.end()); woff.push_back((int64_t)all.size()); foff.push_back(foff.back() + nf); nframes.push_back(nf);
+      idx.push_back((int)i); woff.push_back(woff.back() + (int64_t)batch[i]->samples.size()); foff.push_back(foff.back() + nf); nframes.push_back(nf);
     }
     const int U = (int)idx.size(); f->U = U; if (U == 0) return;
     const int64_t tot = foff.back();
-    d_w_.upload(all); d_wo_.upload(woff); d_fo_.upload(foff);      // (synchronous copies: the previous front end has completed, nothing reads these buffers)
-    K3H_CHECK_K3(k3_feat_compute_batch(plan_, d_w_.p, d_wo_.p, d_fo_.p, U, tot, d_f_.need((size_t)tot * fdim_), fdim_, s_front_));
+    // The batch's samples are gathered into a page-locked staging buffer by a few threads and copied asynchronously on the front stream.  Staging, waveform and offset buffers are
+    // double-buffered by f->buf, so this front end is QUEUED while the previous one may not even have started (its kernels wait for CUs the decoder's lanes free): the only host wait
+    // is for the copy out of this staging buffer two batches ago.  (A pageable synchronous copy of a 512 x 10 s batch, 328 MB, behind a host wait for the previous front end put this
+    // batch's kernels on the stream 30 - 60 ms after the decoder launch they hide behind: tools/pipeline_overlap.py on the program's trace.)
+    const int B = f->buf & 1;
+    if (h2d_recorded_[B]) K3O_HIP(hipEventSynchronize(ev_h2d_[B]));
+    {
+      float *stage = h_w_[B].need((size_t)std::max<int64_t>(woff.back(), 1));
+      const int nthr = (int)std::min<size_t>(4, (size_t)U); std::vector<std::thread> th;
+      auto gather = [&](int t) { for (int k = t; k < U; k += nthr) { const auto &s_ = batch[idx[k]]->samples; if (!s_.empty()) memcpy(stage + woff[k], s_.data(), s_.size() * sizeof(float)); } };
+      for (int t = 1; t < nthr; t++) th.emplace_back(gather, t);
+      gather(0); for (auto &t : th) t.join();
+      K3O_HIP(hipMemcpyAsync(d_w_[B].need((size_t)std::max<int64_t>(woff.back(), 1)), stage, (size_t)woff.back() * sizeof(float), hipMemcpyHostToDevice, s_front_));
+      K3O_HIP(hipEventRecord(ev_h2d_[B], s_front_)); h2d_recorded_[B] = true;
+    }
+    d_wo_[B].upload(woff); d_fo_[B].upload(foff);      // (small synchronous copies into this batch's own offset buffers)
+    K3H_CHECK_K3(k3_feat_compute_batch(plan_, d_w_[B].p, d_wo_[B].p, d_fo_[B].p, U, tot, d_f_.need((size_t)tot * fdim_), fdim_, s_front_));      // (d_f_ and the network's buffers: one set, ordered by the stream)
     k3_nnet_batch *nb = nullptr;
     for (auto &c : plan_cache_) if (c.first == nframes) { nb = c.second; break; }
     if (!nb) {
       K3H_CHECK_K3(k3_nnet_batch_create(nnet_, U, nframes.data(), config_.frame_subsampling_factor, log_priors_.empty() ? nullptr : log_priors_.data(), config_.acoustic_scale, &nb));
-      plan_cache_.push_back({nframes, nb}); if (plan_cache_.size() > 4) { k3_nnet_batch_destroy(plan_cache_.front().second); plan_cache_.erase(plan_cache_.begin()); }
+      plan_cache_.push_back({nframes, nb});
+      if (plan_cache_.size() > 4) { K3O_HIP(hipStreamSynchronize(s_front_)); k3_nnet_batch_destroy(plan_cache_.front().second); plan_cache_.erase(plan_cache_.begin()); }      // (a queued front end may still use the plan)
     }
     f->ro.assign(U + 1, 0); const int64_t rows = k3_nnet_batch_output_rows(nb, f->ro.data());
     // (two decoder objects: the batch before the last may still be decoding from this log-likelihood buffer.  Its last reader is that decoder's token-passing launch; the pruning and
@@ -324,7 +354,7 @@ class BatchedThreadedNnet3CudaPipeline2 {
   const BatchedThreadedNnet3CudaPipeline2Config config_; k3_nnet *nnet_; const TransitionInfo &trans_;
   k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr, *dec_b_ = nullptr; k3_nnet_info ninfo_; int fdim_ = 0, device_ = 0; int32_t graph_start_ = 0; std::vector<float> log_priors_;
   std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache_;
-  DevBuf<float> d_w_, d_f_, d_ll_[2]; DevBuf<int64_t> d_wo_, d_fo_;
+  DevBuf<float> d_w_[2], d_f_, d_ll_[2]; DevBuf<int64_t> d_wo_[2], d_fo_[2]; PinnedBuf<float> h_w_[2]; hipEvent_t ev_h2d_[2] = {nullptr, nullptr}; bool h2d_recorded_[2] = {false, false};
   hipStream_t s_front_ = nullptr, s_dec_ = nullptr, s_dec_b_ = nullptr; hipEvent_t ev_front_[2] = {nullptr, nullptr}, ev_dec_[2] = {nullptr, nullptr};
   k3_decoder *Dec(int buf) const { return (buf & 1) && dec_b_ ? dec_b_ : dec_; }
   hipStream_t DecStream(int buf) const { return (buf & 1) && dec_b_ ? s_dec_b_ : s_dec_; }

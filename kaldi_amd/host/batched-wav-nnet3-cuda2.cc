@@ -270,13 +270,14 @@ int main(int argc, char **argv) {
     for (int iter = 0; iter < iterations; iter++) for (size_t b0 = 0; b0 < scp.size(); b0 += max_batch) plan_batches.push_back({(size_t)iter, b0, std::min(scp.size(), b0 + (size_t)max_batch)});
     // GPU stage, two streams one batch apart: the FRONT END of batch k+1 (upload, features, i-vectors, network) is issued on its own stream right behind the decoder kernels of batch k
     // (log-likelihoods double-buffered), so that the copy and the first network layers run while the decoder's last lanes finish -- as bench.py does.
-    DevBuf<float> d_w, d_f, d_ll[2], d_iv; DevBuf<int64_t> d_wo, d_fo;
+    DevBuf<float> d_w, d_f, d_ll[2], d_iv; DevBuf<int64_t> d_wo, d_fo; PinnedBuf<int64_t> h_off[2];
     std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache;
     std::future<Batch> next; std::future<void> post;
     hipStream_t s_front, s_dec, s_dec_b; HIPCHK(hipStreamCreateWithFlags(&s_front, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&s_dec, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&s_dec_b, hipStreamNonBlocking));
     hipStream_t s_decs[2] = {s_dec, alternate_decoders ? s_dec_b : s_dec};
     hipEvent_t ev_dec[2]; for (auto &e : ev_dec) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));      // decoder of the batch that last read log-likelihood buffer k & 1 is through
     hipEvent_t ev_front[2]; for (auto &e : ev_front) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t ev_h2d[2]; for (auto &e : ev_h2d) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); bool h2d_recorded[2] = {false, false};      // the copy out of staging slot 0 / 1 is through
     struct Front { Batch b; std::vector<int64_t> ro; bool valid = false; double wait_ms = 0.0; } fr[2];
     auto tick = [] { return std::chrono::steady_clock::now(); }; auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_start = std::chrono::steady_clock::now();
@@ -285,14 +286,26 @@ int main(int argc, char **argv) {
       Front &f = fr[k & 1]; f.valid = false;
       const auto t_a = tick();
       f.b = next.get(); f.wait_ms = ms(t_a, tick());
-      if (k + 1 < plan_batches.size()) next = std::async(std::launch::async, load_batch, plan_batches[k + 1][1], plan_batches[k + 1][2], (int)((k + 1) & 1), (int)plan_batches[k + 1][0]);
+      if (k + 1 < plan_batches.size()) {
+        if (h2d_recorded[(k + 1) & 1]) HIPCHK(hipEventSynchronize(ev_h2d[(k + 1) & 1]));      // the reader fills the staging slot batch k - 1 was copied from: that copy must be through
+        next = std::async(std::launch::async, load_batch, plan_batches[k + 1][1], plan_batches[k + 1][2], (int)((k + 1) & 1), (int)plan_batches[k + 1][0]);
+      }
       Batch &b = f.b;
       num_err += b.num_err; if (b.iter == 0) { total_audio += b.audio; num_task += (int)b.keys.size(); }      // per iteration, like the reference's counters
       if (b.keys.empty()) return;
       const int U = (int)b.keys.size(); const int64_t tot = b.foff.back(), nsamp = b.woff.back();
-      HIPCHK(hipStreamWaitEvent(s_front, ev_dec[k & 1], 0));      // (alternating decoders: batch k - 2 may still be decoding from the log-likelihood buffer this front end writes)
+      // (alternating decoders: batch k - 2 may still be decoding from the log-likelihood buffer this front end writes.  The buffer's last reader is that decoder object's token-passing
+      // launch; the pruning / output kernels behind it cannot start beside the other object's resident launch and end tens of milliseconds into it)
+      if (alternate_decoders) K3H_CHECK_K3(k3_decoder_stream_wait_token_passing(decs2[k & 1], s_front)); else HIPCHK(hipStreamWaitEvent(s_front, ev_dec[k & 1], 0));
       HIPCHK(hipMemcpyAsync(d_w.need((size_t)nsamp), pinned[b.slot].p, (size_t)nsamp * sizeof(float), hipMemcpyHostToDevice, s_front));
-      d_wo.upload(b.woff); d_fo.upload(b.foff);
+      // the offsets go through the stream as well (a synchronous copy on the null stream would overtake a previous front end that is still queued: this one is issued without waiting for it)
+      {      // (from page-locked memory: an asynchronous copy out of pageable memory may wait for the stream's earlier work on the host)
+        int64_t *ho = h_off[b.slot & 1].need(b.woff.size() + b.foff.size());      // (this slot's previous copy is through: ev_h2d was waited for before the reader refilled the slot)
+        memcpy(ho, b.woff.data(), b.woff.size() * sizeof(int64_t)); memcpy(ho + b.woff.size(), b.foff.data(), b.foff.size() * sizeof(int64_t));
+        HIPCHK(hipMemcpyAsync(d_wo.need(b.woff.size()), ho, b.woff.size() * sizeof(int64_t), hipMemcpyHostToDevice, s_front));
+        HIPCHK(hipMemcpyAsync(d_fo.need(b.foff.size()), ho + b.woff.size(), b.foff.size() * sizeof(int64_t), hipMemcpyHostToDevice, s_front));
+      }
+      HIPCHK(hipEventRecord(ev_h2d[b.slot & 1], s_front)); h2d_recorded[b.slot & 1] = true;
       K3H_CHECK_K3(k3_feat_compute_batch(plan, d_w.p, d_wo.p, d_fo.p, U, tot, d_f.need((size_t)tot * fdim), fdim, s_front));
       // the network plan of a batch (row bookkeeping, tile tables, activation workspace in HBM) depends only on the utterances' frame counts: kept for
       // the batches that come back (--iterations, equal-length test sets) instead of being rebuilt per batch
@@ -352,7 +365,9 @@ int main(int argc, char **argv) {
         HIPCHK(hipStreamWaitEvent(s_decs[k & 1], ev_front[k & 1], 0));
         K3H_CHECK_K3(k3_decoder_decode_batch(decs2[k & 1], (int)f.b.keys.size(), d_ll[k & 1].p, ninfo.output_dim, f.ro.data(), s_decs[k & 1]));
         HIPCHK(hipEventRecord(ev_dec[k & 1], s_decs[k & 1]));
-        HIPCHK(hipEventSynchronize(ev_front[k & 1]));      // front end k is through: the staging / feature / network buffers are free for batch k+1
+        // (no host wait for front end k here: batch k+1's front end is queued behind it on the same stream, its staging slot is guarded by ev_h2d; with an i-vector extractor the
+        // extraction call reads host-side offsets of the batch, so that configuration keeps the wait)
+        if (ivx) HIPCHK(hipEventSynchronize(ev_front[k & 1]));
       }
       // batch k+1's front end is queued NOW, behind the decoder kernels of batch k; then this thread waits for a decoder: batch k's, or -- with two decoder objects -- batch k-1's,
       // whose pruning kernel, compaction and copy run while batch k's token passing has already started on the other object's stream
@@ -369,7 +384,7 @@ int main(int argc, char **argv) {
     num_err += post_err;
     HIPCHK(hipDeviceSynchronize());
     for (auto &c : plan_cache) k3_nnet_batch_destroy(c.second);
-    for (auto &e : ev_front) (void)hipEventDestroy(e); for (auto &e : ev_dec) (void)hipEventDestroy(e); (void)hipStreamDestroy(s_front); (void)hipStreamDestroy(s_dec); (void)hipStreamDestroy(s_dec_b);
+    for (auto &e : ev_front) (void)hipEventDestroy(e); for (auto &e : ev_dec) (void)hipEventDestroy(e); for (auto &e : ev_h2d) (void)hipEventDestroy(e); (void)hipStreamDestroy(s_front); (void)hipStreamDestroy(s_dec); (void)hipStreamDestroy(s_dec_b);
     { const auto t_w = std::chrono::steady_clock::now(); if (det_pool) { det_pool->Wait(); det_pool.reset(); }
       K3H_VLOG(1) << "waited " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_w).count() << " ms for the determinization pool after the last batch"; }
     if (writer) writer->Flush();

@@ -19,6 +19,12 @@ template <class T> struct DevBuf {          // grow-only device array
   void upload(const std::vector<T> &h) { need(std::max<size_t>(h.size(), 1)); if (!h.empty()) K3O_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
 };
 
+template <class T> struct PinnedBuf {       // grow-only page-locked host array (staging for asynchronous copies)
+  T *p = nullptr; size_t cap = 0;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  T *need(size_t n) { if (n > cap) { if (p) (void)hipHostFree(p); cap = n + n / 2 + 64; K3O_HIP(hipHostMalloc((void **)&p, cap * sizeof(T), hipHostMallocDefault)); } return p; }
+};
+
 class OnlineFeatures {
  public:
   OnlineFeatures(k3_feat_plan *plan, const k3_feat_opts &o, int num_channels) : plan_(plan), dim_(k3_feat_dim(plan)), stash_(num_channels) {

@@ -43,7 +43,7 @@ for name, extra, out in (("no lattice output", ["--write-lattice=false"], "ark:/
 if os.environ.get("K3CLI_PROFILE"):      # kernel trace of one more run of the default configuration -> gpurun_out/prof_cli (rocprofv3 --kernel-trace --stats)
     out = os.path.join(ROOT, "gpurun_out", "prof_cli"); os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", out, "--"] + [exe] + common + [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/det2.ark"], capture_output=True, text=True, cwd="/tmp", env=env)
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "-o", "t", "--"] + [exe] + common + [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/det2.ark"], capture_output=True, text=True, cwd="/tmp", env=env)
     print("profiled run rc=%d | %s" % (r.returncode, " | ".join(l.split(") ", 1)[-1] for l in r.stderr.splitlines() if "RealTimeX" in l)), flush=True)
 for f in ("raw.ark", "det.ark"):
     if os.path.exists(f"{td}/{f}"): print(f, "%.1f MB" % (os.path.getsize(f"{td}/{f}") / 1e6))
