@@ -40,6 +40,16 @@ for name, extra, out in (("no lattice output", ["--write-lattice=false"], "ark:/
     if r.returncode != 0: print(r.stderr[-2000:])
     for l in r.stderr.splitlines():
         if l.startswith("VLOG"): print("   ", l.split(") ", 1)[-1])
+if os.environ.get("K3CLI_ONLINE"):      # the streaming program on the same files: every file played as an audio stream in chunks of --frames-per-chunk frames over --num-channels channels
+    exe_o = os.path.join(ROOT, "kaldi_amd", "bin", "batched-wav-nnet3-cuda-online")
+    for fpc in (51, 150):
+        args = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", f"--max-batch-size={U}", f"--num-channels={U}",
+                f"--frames-per-chunk={fpc}", f"--iterations={max(1, iters // 4)}", "--main-q-capacity=65536", "--aux-q-capacity=131072"]
+        t0 = time.time()
+        r = subprocess.run([exe_o] + args + [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/online.ark"], capture_output=True, text=True)
+        last = [l for l in r.stderr.splitlines() if "RealTimeX" in l or "Decoded" in l]
+        print("online, %3d frames per chunk rc=%d wall %.1f s | %s" % (fpc, r.returncode, time.time() - t0, " | ".join(l.split(") ", 1)[-1] for l in last)), flush=True)
+        if r.returncode != 0: print(r.stderr[-1500:])
 if os.environ.get("K3CLI_PROFILE"):      # kernel trace of one more run of the default configuration -> gpurun_out/prof_cli (rocprofv3 --kernel-trace --stats)
     out = os.path.join(ROOT, "gpurun_out", "prof_cli"); os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
