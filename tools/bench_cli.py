@@ -50,6 +50,12 @@ if os.environ.get("K3CLI_ONLINE"):      # the streaming program on the same file
         last = [l for l in r.stderr.splitlines() if "RealTimeX" in l or "Decoded" in l]
         print("online, %3d frames per chunk rc=%d wall %.1f s | %s" % (fpc, r.returncode, time.time() - t0, " | ".join(l.split(") ", 1)[-1] for l in last)), flush=True)
         if r.returncode != 0: print(r.stderr[-1500:])
+    if os.environ.get("K3CLI_ONLINE") == "profile":      # kernel trace + stats of the 51-frame run -> gpurun_out/prof_online
+        out = os.path.join(ROOT, "gpurun_out", "prof_online"); os.makedirs(out, exist_ok=True)
+        args[9] = "--frames-per-chunk=51"; args[10] = "--iterations=1"
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "-o", "t", "--"] + [exe_o] + args + [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/online2.ark"],
+                           capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        print("profiled online run rc=%d | %s" % (r.returncode, " | ".join(l.split(") ", 1)[-1] for l in r.stderr.splitlines() if "RealTimeX" in l)), flush=True)
 if os.environ.get("K3CLI_PROFILE"):      # kernel trace of one more run of the default configuration -> gpurun_out/prof_cli (rocprofv3 --kernel-trace --stats)
     out = os.path.join(ROOT, "gpurun_out", "prof_cli"); os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
