@@ -58,7 +58,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     net_.reset(new StaticNnet3(am_nnet, nch_, nch_, C_, s, lp.empty() ? nullptr : lp.data(), config_.acoustic_scale));
     if (ivx_) ivs_.reset(new OnlineIvectors(ivx_, iv_info_.right_context, nch_));
     samples_per_chunk_ = C_ * (int)(config_.feature_opts.samp_freq * 0.001 * config_.feature_opts.frame_shift_ms);
-    pend_cap_ = (size_t)(2 * C_ + 8); pend_.resize(nch_); for (auto &p : pend_) p.need(pend_cap_ * fdim_); tmp_.need(pend_cap_ * fdim_);
+    pend_cap_ = (size_t)(2 * C_ + 8); for (auto &h : held_) h.need((size_t)nch_ * (pend_cap_ + (size_t)C_ + 16) * fdim_);      // (pending feature rows of all channels, compact; see DecodeBatch)
     chan_.resize(nch_); for (int c = nch_ - 1; c >= 0; c--) free_.push_back(c);
     const int nw = config_.num_worker_threads > 0 ? config_.num_worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
     for (int i = 0; i < nw; i++) workers_.emplace_back([this] { WorkerLoop(); });
@@ -97,10 +97,15 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     std::vector<int32_t> fresh; for (size_t i = 0; i < n; i++) if (first[i]) { fresh.push_back(chs[i]); net_->Reset(chs[i]); chan_[chs[i]] = Chan(); }
     if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec_, fresh.data(), (int32_t)fresh.size(), nullptr));
     float *d_feats = nullptr; const std::vector<int> nf = features_->ComputeFeaturesBatched(chs, wave_samples, first, &d_feats);
-    { int64_t off = 0;
+    // Feature rows a channel has computed but not yet fed to the network live compactly in one device buffer, channel after channel, (offset, count) on the host, at most two segments
+    // per channel (leftover + this call's rows).  A pass takes its rows with one row gather and the leftovers of all channels move to the other buffer with one more, once per call:
+    // per-channel buffers cost ~4 synchronous device copies per channel and call (40 k copies in a 512-channel run of 10 s files, half of its GPU time).
+    { int64_t off = 0, tot = 0; for (int k : nf) tot += k;
+      if ((size_t)(held_rows_ + tot) * fdim_ > held_[held_cur_].cap) K3H_ERR << "DecodeBatch: pending-frame buffer exceeded";
+      if (tot > 0) K3O_HIP(hipMemcpyAsync(held_[held_cur_].p + (size_t)held_rows_ * fdim_, d_feats, (size_t)tot * fdim_ * 4, hipMemcpyDeviceToDevice, nullptr));
       for (size_t i = 0; i < n; i++) { Chan &c = chan_[chs[i]]; if ((size_t)(c.pend + nf[i]) > pend_cap_) K3H_ERR << "DecodeBatch: a chunk longer than GetNSampsPerChunk() samples";
-        if (nf[i] > 0) K3O_HIP(hipMemcpy(pend_[chs[i]].p + (size_t)c.pend * fdim_, d_feats + off * fdim_, (size_t)nf[i] * fdim_ * 4, hipMemcpyDeviceToDevice));
-        c.pend += nf[i]; c.frames += nf[i]; off += nf[i]; } }
+        if (c.seg_cnt[1] != 0) K3H_ERR << "DecodeBatch: internal: pending rows not compacted";
+        c.seg_off[1] = held_rows_ + off; c.seg_cnt[1] = nf[i]; c.pend += nf[i]; c.frames += nf[i]; off += nf[i]; } }
     if (ivs_) ivs_->AcceptBatch(chs, d_feats, nf, first, last);      // the extractor sees every frame as soon as it exists: all channels of the batch in one launch per stage
     std::vector<char> is_last(nch_, 0), closed(nch_, 0); for (size_t i = 0; i < n; i++) is_last[chs[i]] = last[i];
     bool need_advance = !fresh.empty();
@@ -110,13 +115,13 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
       if (run.empty() && !need_advance) break;
       int64_t tot_new = 0; for (int ch : run) { const int k = std::min(C_, chan_[ch].pend); n_new.push_back(k); tot_new += k; }
       new_.need((size_t)std::max<int64_t>(tot_new, 1) * fdim_);
-      { int64_t off = 0;
+      { std::vector<int32_t> take; take.reserve((size_t)tot_new);
         for (size_t i = 0; i < run.size(); i++) {
-          Chan &c = chan_[run[i]]; const int k = n_new[i], rest = c.pend - k;
-          if (k > 0) K3O_HIP(hipMemcpy(new_.p + off * fdim_, pend_[run[i]].p, (size_t)k * fdim_ * 4, hipMemcpyDeviceToDevice));
-          if (rest > 0) { K3O_HIP(hipMemcpy(tmp_.p, pend_[run[i]].p + (size_t)k * fdim_, (size_t)rest * fdim_ * 4, hipMemcpyDeviceToDevice)); K3O_HIP(hipMemcpy(pend_[run[i]].p, tmp_.p, (size_t)rest * fdim_ * 4, hipMemcpyDeviceToDevice)); }
-          c.pend = rest; off += k; const bool end = is_last[run[i]] && rest == 0; lasts.push_back(end); if (end) closed[run[i]] = 1;
-        } }
+          Chan &c = chan_[run[i]]; int k = n_new[i];
+          for (int sgm = 0; sgm < 2 && k > 0; sgm++) { const int m = std::min(k, c.seg_cnt[sgm]); for (int j = 0; j < m; j++) take.push_back((int32_t)(c.seg_off[sgm] + j)); c.seg_off[sgm] += m; c.seg_cnt[sgm] -= m; k -= m; c.pend -= m; }
+          const bool end = is_last[run[i]] && c.pend == 0; lasts.push_back(end); if (end) closed[run[i]] = 1;
+        }
+        if (!take.empty()) { gidx_.upload(take); K3H_CHECK_K3(k3_mat_copy_rows(new_.p, fdim_, (int32_t)take.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, nullptr)); } }
       std::vector<int64_t> ro(nch_ + 1, 0); std::vector<int32_t> idx;
       if (!run.empty()) {
         auto res = net_->Pass(run, new_.p, n_new, lasts, ivs_ ? ivs_->Gather(run) : nullptr);
@@ -128,6 +133,16 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
       K3H_CHECK_K3(k3_decoder_advance_decoding(dec_, nch_, ll_.p, N_, ro.data(), nullptr));
       need_advance = false;
       for (int ch : run) if (closed[ch] && net_->Pending(ch)) closed[ch] = 0;
+    }
+    {      // the rows still waiting, of ALL channels (also those that were not in this batch), into the other buffer; every channel is back to one segment
+      std::vector<int32_t> keep; int64_t at = 0;
+      for (int ch = 0; ch < nch_; ch++) {
+        Chan &c = chan_[ch]; const int k = c.seg_cnt[0] + c.seg_cnt[1];
+        for (int sgm = 0; sgm < 2; sgm++) for (int j = 0; j < c.seg_cnt[sgm]; j++) keep.push_back((int32_t)(c.seg_off[sgm] + j));
+        c.seg_off[0] = at; c.seg_cnt[0] = k; c.seg_off[1] = 0; c.seg_cnt[1] = 0; at += k;
+      }
+      if (!keep.empty()) { gidx_.upload(keep); K3H_CHECK_K3(k3_mat_copy_rows(held_[held_cur_ ^ 1].p, fdim_, (int32_t)keep.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, nullptr)); }
+      held_cur_ ^= 1; held_rows_ = at;
     }
     // partial hypotheses / end-pointing / best-path callbacks (cuda-decoder.cc:1864-2003) from the tokens the channels hold now
     bool want_best = partial_hypotheses || end_point; { std::lock_guard<std::mutex> l(m_); for (size_t i = 0; i < n && !want_best; i++) want_best = best_cb_.count(corr_ids[i]) > 0; }
@@ -172,7 +187,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
   void WaitForLatticeCallbacks() noexcept { std::unique_lock<std::mutex> l(m_); done_cv_.wait(l, [&] { return n_callbacks_not_done_ == 0; }); }
 
  private:
-  struct Chan { int pend = 0; int64_t frames = 0; };
+  struct Chan { int pend = 0; int64_t frames = 0; int64_t seg_off[2] = {0, 0}; int seg_cnt[2] = {0, 0}; };      // seg: where the channel's pending rows lie in held_[held_cur_]
   struct Task { Lattice raw; LatticeCallback callback; };
   void WorkerLoop() {
     for (;;) {
@@ -189,7 +204,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
   const BatchedThreadedNnet3CudaOnlinePipelineConfig config_; const TransitionInfo &trans_;
   k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0; int32_t graph_start_ = 0; size_t pend_cap_ = 0;
   std::unique_ptr<OnlineFeatures> features_; std::unique_ptr<StaticNnet3> net_; std::unique_ptr<OnlineIvectors> ivs_; k3_ivector *ivx_ = nullptr; IvectorExtractionInfo iv_info_;
-  std::vector<Chan> chan_; std::vector<DevBuf<float>> pend_; DevBuf<float> tmp_, new_, ll_; DevBuf<int32_t> llidx_;
+  std::vector<Chan> chan_; DevBuf<float> held_[2], new_, ll_; DevBuf<int32_t> llidx_, gidx_; int held_cur_ = 0; int64_t held_rows_ = 0;
   std::mutex m_; std::condition_variable wcv_, done_cv_; bool stop_ = false; int n_callbacks_not_done_ = 0;
   std::map<CorrelationID, int> corr2chan_; std::vector<int> free_; std::map<CorrelationID, LatticeCallback> lat_cb_; std::map<CorrelationID, BestPathCallback> best_cb_;
   std::deque<std::shared_ptr<Task>> post_; std::vector<std::thread> workers_;
