@@ -274,7 +274,9 @@ def main():
         cfst = None; rccl_ranks = 0; bcast_via = "none (one rank)" if world == 1 else "torch.distributed broadcast of the k3_fst image"
         if world > 1 and dist.get_backend() == "nccl" and os.environ.get("K3_BENCH_ABI_BCAST", "1") == "1":
             import threading
-            box = {}; id_file = os.path.join(tempfile.gettempdir(), "k3_bench_rccl_%s_%s.id" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run")))
+            # a nonce of this run, agreed over the process group that already exists: the id file of an earlier run (same port, same launcher run id) cannot be mistaken for this one's
+            nonce = [os.urandom(8).hex() if rank == 0 else None]; dist.broadcast_object_list(nonce, src=0); os.environ["K3_COMM_NONCE"] = nonce[0]
+            box = {}; id_file = os.path.join(tempfile.gettempdir(), "k3_bench_rccl_%s_%s.id" % (os.environ.get("MASTER_PORT", "0"), nonce[0]))
             def _abi():
                 try: torch.cuda.set_device(local); box["r"] = parallel.broadcast_graph_abi(graph, synth.tid2pdf(num_pdfs), rank, world, id_file, timeout_s=90)
                 except Exception as e: box["e"] = repr(e)
