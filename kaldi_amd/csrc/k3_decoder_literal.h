@@ -455,7 +455,7 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0; d[k] = 0; if (i < n) { b[k] = bkt[i]; d[k] = dense[i]; } }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; if (i < n) { const int pos = k3a_add(&pcnt[part_of((unsigned)b[k] * 2654435761u)], 1); rec[pos] = make_int2(b[k], (d[k] << 16) | i); } }
+    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; if (i < n) { const int pos = k3a_add(&pcnt[part_of((unsigned)b[k] * 2654435761u)], 1); rec[pos] = make_int2(b[k], (int)(((unsigned)d[k] << 16) | (unsigned)i)); } }
   }
   __syncthreads();
   K3_LS(1);
