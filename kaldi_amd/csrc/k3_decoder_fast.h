@@ -97,7 +97,7 @@ __device__ __forceinline__ int block_excl_scan_f(In &&in, Out &&out, int n, int 
 template <typename Emit>
 __device__ __forceinline__ void fast_hash_order(Shared &sh, int n, unsigned M, const unsigned short *label16, const unsigned short *bkt16, unsigned *btab, unsigned *bm, unsigned short *wpre,
                                                 unsigned short *lead, unsigned short *grp, unsigned short *curs, Emit &&emit) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64; constexpr int kPer = (kFT + kBlock - 1) / kBlock;
+  const int tid = threadIdx.x; constexpr int kPer = (kFT + kBlock - 1) / kBlock;
   const int W = (int)((M + 31u) >> 5);
   unsigned lab[kPer], bkt[kPer], lf[kPer], cnt[kPer]; int d[kPer], slot[kPer];
   for (int i = tid; i < kFB; i += kBlock) btab[i] = 0xFFFFFFFFu;

@@ -1323,7 +1323,7 @@ __device__ __forceinline__ bool lit_final_sweeps_parallel(const float *base, flo
 __device__ __forceinline__ void lit_final_frame(const DecParams &p, int L, long long tb, long long te, long long l0, long long l1, float final_best, bool final_empty,
                                                const int *tok_state, const unsigned *tok_cost, float *extra, const Link *links, int *err,
                                                float *l_base, float *l_extra, unsigned *l_off, int *l_ldst, float *l_ldelta, int *redi, int *s_m) {
-  const int tid = threadIdx.x; const int n = (int)(te - tb); const float kInf = __builtin_inff(), lb = p.lattice_beam;
+  const int tid = threadIdx.x; const int n = (int)(te - tb); const float lb = p.lattice_beam;
   const long long fc = p.frame_cands_cap;
   unsigned *g_off = reinterpret_cast<unsigned *>(p.c_dst + L * fc); unsigned *cursor = reinterpret_cast<unsigned *>(p.c_src + L * fc); int *lid = p.c_arc + L * fc;
   float *g_base = p.c_tot + L * fc, *g_delta = p.c_ac + L * fc; int *g_ldst = p.wl + 2ll * L * p.frame_tokens_cap;

@@ -39,7 +39,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 128, kBK = 32, kLdsLd = 36, kThreads = 256;
+constexpr int kBM = 128, kBK = 32, kLdsLd = 36;
 constexpr int kMaxOffsets = 8, kMaxOps = 6;
 
 struct TileDesc {      // one per 128-row slab of a node's output.  A slab is cut from ONE sequence (utterance / chunk), or -- when a sequence ends inside
@@ -149,7 +149,6 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
   // consumes k = 2j, 2j+1: the accumulation runs over k in ASCENDING order, the order a CPU sgemm kernel sums in -- with a
   // different order every partial sum rounds differently and the result drifts ~5x further from the reference.
   // A thread holding k..k+3 therefore writes (k, k+2) and (k+1, k+3) as two 8-byte pieces.
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int st_col = (ld_kv & ~7) + ((ld_kv >> 2) & 1) * 2;
   auto store_tiles = [&](int buf) {
     float *a = As + buf * kBM * kLdsLd, *b = Bs + buf * BN * kLdsLd;
