@@ -77,7 +77,10 @@ def test_c_abi_rccl_collectives_on_two_devices(tmp_path):
     env = dict(os.environ, K3_COMM_NONCE="test-%d" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank_worker.py"), str(r), "2", str(tmp_path / "nccl.id"), str(tmp_path / f"r{r}.json")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    try: outs = [p.communicate(timeout=240)[0] for p in procs]
+    except subprocess.TimeoutExpired:
+        for p in procs: p.kill()      # (the two workers this test started, by handle)
+        pytest.fail("the two RCCL ranks did not finish within 240 s: " + " | ".join((p.communicate()[0] or b"").decode(errors="replace")[-800:] for p in procs))
     assert all(p.returncode == 0 for p in procs), outs
     a, b = (json.load(open(tmp_path / f"r{r}.json")) for r in range(2))
     assert a["ranks"] == b["ranks"] == 2 and (a["states"], a["arcs"], a["start"]) == (b["states"], b["arcs"], b["start"]) == (2000, a["arcs"], a["start"])
