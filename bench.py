@@ -278,9 +278,9 @@ def main():
             nonce = [os.urandom(8).hex() if rank == 0 else None]; dist.broadcast_object_list(nonce, src=0); os.environ["K3_COMM_NONCE"] = nonce[0]
             box = {}; id_file = os.path.join(tempfile.gettempdir(), "k3_bench_rccl_%s_%s.id" % (os.environ.get("MASTER_PORT", "0"), nonce[0]))
             def _abi():
-                try: torch.cuda.set_device(local); box["r"] = parallel.broadcast_graph_abi(graph, synth.tid2pdf(num_pdfs), rank, world, id_file, timeout_s=90)
+                try: torch.cuda.set_device(local); box["r"] = parallel.broadcast_graph_abi(graph, synth.tid2pdf(num_pdfs), rank, world, id_file, timeout_s=45)
                 except Exception as e: box["e"] = repr(e)
-            th = threading.Thread(target=_abi, daemon=True); th.start(); th.join(150)
+            th = threading.Thread(target=_abi, daemon=True); th.start(); th.join(75)
             ok = torch.tensor([1 if "r" in box else 0], device=dev); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1: cfst, rccl_ranks = box["r"]; bcast_via = "k3_comm_create + k3_fst_bcast (RCCL through the C ABI)"
             else: bcast_via += " (k3_fst_bcast did not complete on every rank: %s)" % (box.get("e") or ("timeout" if th.is_alive() else "another rank failed"))
