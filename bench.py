@@ -267,6 +267,7 @@ def main():
     graph = None; decs = {}
     if not args.no_decode:
         graph = synth.make_hclg(args.graph_states, args.graph_arcs, num_pdfs) if rank == 0 else None
+        if world > 1: dist.barrier()      # (the ranks enter the graph exchange together: its deadlines do not run while rank 0 builds the graph)
         t0 = time.perf_counter()
         # N > 1 over RCCL: the graph travels through the PRODUCT's own C ABI (k3_comm_create + k3_fst_bcast: parallel.broadcast_graph_abi), in a worker thread with a deadline, and
         # the ranks agree (one all-reduce) on whether every one of them got it; otherwise -- and in the gloo rehearsal on one device, where RCCL cannot put two ranks on a GPU --
