@@ -321,6 +321,7 @@ struct Decoder {
   Frame2 cf; size_t hash_size2 = 1000;  // lattice-faster-decoder.cc:41 toks_.SetSize(1000)
   uint64_t rng_state = 0x9E3779B97F4A7C15ull;
   int64_t n_replay_pops = 0, n_replay_pushes = 0, n_replay_crit = 0, n_replay_comps = 0, n_replay_frames = 0;
+  int64_t n_replay_pops_once = 0, n_replay_crit_once = 0, n_replay_big_pops = 0, n_replay_big_once = 0;      // K3O_COMP_STATS: pops in components where no existing token is improved (a forest walked once)
   uint32_t Rand() { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng_state >> 33); }
   template <class T> void MaybeShuffle(std::vector<T> &v) { if (mode < 3) return; for (size_t i = v.size(); i > 1; i--) std::swap(v[i - 1], v[Rand() % i]); }
   std::vector<int32_t> Iota(size_t n) { std::vector<int32_t> v(n); for (size_t i = 0; i < n; i++) v[i] = (int32_t)i; MaybeShuffle(v); return v; }
@@ -417,9 +418,9 @@ struct Decoder {
       std::vector<float> rc(n, kInf); std::vector<char> ex(n, 0);
       for (size_t i = 0; i < n_e; i++) { rc[i] = c0[i]; ex[i] = 1; }
       std::vector<std::vector<int32_t>> created(roots.size());
-      int64_t crit = 0;
+      int64_t crit = 0; bool crit_once = false;
       for (int32_t c : comps) {                           // PAR over components
-        std::vector<int32_t> stack; const int64_t pops0 = n_replay_pops;
+        std::vector<int32_t> stack; const int64_t pops0 = n_replay_pops; int64_t improved = 0;
         for (int32_t r : comp_roots[c]) {                 // SER: this component's roots in queue order
           stack.push_back(roots[r]);
           while (!stack.empty()) {
@@ -432,14 +433,17 @@ struct Decoder {
               if (!(tot < cutoff)) continue;
               bool changed = false;
               if (!ex[d]) { ex[d] = 1; rc[d] = tot; created[r].push_back(d); changed = true; }
-              else if (rc[d] > tot) { rc[d] = tot; changed = true; }
+              else if (rc[d] > tot) { rc[d] = tot; changed = true; improved++; }
               if (changed && fst.num_ieps[state[d]] != 0) { stack.push_back(d); n_replay_pushes++; }
             }
           }
         }
+        { const int64_t cp = n_replay_pops - pops0; if (improved == 0) n_replay_pops_once += cp; if (cp >= 64) { n_replay_big_pops += cp; if (improved == 0) n_replay_big_once += cp; }
+          if (cp > crit) crit_once = improved == 0; }
         crit = std::max(crit, n_replay_pops - pops0);
       }
-      n_replay_crit += crit; n_replay_comps += (int64_t)comps.size(); n_replay_frames++;
+      if (getenv("K3O_COMP_STATS") && atoi(getenv("K3O_COMP_STATS")) >= 2 && n_replay_frames < 12) fprintf(stderr, "  closure %lld: tokens %zu (emitting %zu) roots %zu components %zu critical-path pops %lld%s\n", (long long)n_replay_frames, n, (size_t)n_e, roots.size(), comps.size(), (long long)crit, crit_once ? " (no improvement)" : "");
+      n_replay_crit += crit; if (crit_once) n_replay_crit_once += crit; n_replay_comps += (int64_t)comps.size(); n_replay_frames++;
       for (size_t r = 0; r < roots.size(); r++) for (int32_t d : created[r]) label[d] = n_labels++;      // exclusive scan over the roots' counts on the GPU
       for (size_t i = 0; i < n; i++) if (!ex[i] || rc[i] != cost[i]) abort();
     } else
@@ -724,7 +728,9 @@ void *k3o_lfd_decode(const k3o_fst *f, const float *loglikes, int32_t num_frames
   for (int32_t s = 0; s < fst.num_states; s++) for (int32_t a = fst.off[s]; a < fst.off[s + 1]; a++) if (fst.ilabel[a] == 0) fst.num_ieps[s]++;
   Config cfg{c->beam, c->max_active, c->min_active, c->lattice_beam, c->prune_interval, c->beam_delta, c->hash_ratio, c->prune_scale};
   Decoder d(fst, cfg, mode);
-  struct StatPrinter { Decoder &d; ~StatPrinter() { if (getenv("K3O_COMP_STATS") && d.n_replay_frames) fprintf(stderr, "replay: frames %lld pops/frame %.1f comps/frame %.1f critical-path pops/frame %.1f\n", (long long)d.n_replay_frames, (double)d.n_replay_pops / d.n_replay_frames, (double)d.n_replay_comps / d.n_replay_frames, (double)d.n_replay_crit / d.n_replay_frames); } } stat_printer{d};
+  struct StatPrinter { Decoder &d; ~StatPrinter() { if (getenv("K3O_COMP_STATS") && d.n_replay_frames) fprintf(stderr, "replay: frames %lld pops/frame %.1f comps/frame %.1f critical-path pops/frame %.1f\n", (long long)d.n_replay_frames, (double)d.n_replay_pops / d.n_replay_frames, (double)d.n_replay_comps / d.n_replay_frames, (double)d.n_replay_crit / d.n_replay_frames);
+    if (getenv("K3O_COMP_STATS") && d.n_replay_pops) fprintf(stderr, "replay: pops in components without an improvement of an existing token %.3f of all; of the critical-path pops %.3f; components of >= 64 pops hold %.3f of the pops, %.3f of those without improvement\n",
+        (double)d.n_replay_pops_once / d.n_replay_pops, d.n_replay_crit ? (double)d.n_replay_crit_once / d.n_replay_crit : 0.0, (double)d.n_replay_big_pops / d.n_replay_pops, d.n_replay_big_pops ? (double)d.n_replay_big_once / d.n_replay_big_pops : 0.0); } } stat_printer{d};
   d.loglikes = loglikes; d.ld = ld; d.tid2pdf = tid2pdf; d.num_frames_ready = num_frames;
   if (mode >= 2) d.Init2(); else d.Init();
   d.Advance(); d.Finalize();
