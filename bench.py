@@ -281,8 +281,9 @@ def measure_traffic(args):
             "traffic_bytes_per_launch": out["FETCH_SIZE"] + out["WRITE_SIZE"]}
 
 def main():
-    if os.environ.get("K3HIP_LIB"):
-        raise SystemExit("bench.py measures the shipped kaldi_amd/lib/libk3hip.so only: unset K3HIP_LIB (developer override for profiling builds)")
+    if os.environ.get("K3HIP_LIB") and "--allow-dev-lib" not in sys.argv:
+        raise SystemExit("bench.py measures the shipped kaldi_amd/lib/libk3hip.so only: unset K3HIP_LIB (developer override for profiling builds), "
+                         "or pass --allow-dev-lib (the line then carries \"dev_lib\": the path, and is not a result)")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -321,6 +322,11 @@ def main():
          "(default: cores / replicas), i.e. what the box's cores see when this many ranks hand over lattices at the same rate; "
         "`value` then says whether the host keeps up")
     ap.add_argument("--det-threads", type=int, default=0, help="host threads of the determinization pool (0 = all cores / ranks)")
+    ap.add_argument("--allow-dev-lib", action="store_true", help="accept a K3HIP_LIB developer build (A/B experiments); the line is marked \"dev_lib\"")
+    ap.add_argument("--no-strict-rccl", action="store_true",
+                    help="N > 1 over RCCL: if the graph broadcast through the product's C ABI (k3_comm_create + k3_fst_bcast) fails on any rank, fall back to "
+                         "torch.distributed and only mark the line (\"rccl_abi_failed\": true).  Default (strict): mark the line, print it, and exit with status 3")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin this rank's host threads to its share of the cores (cores / ranks, by LOCAL_RANK)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -339,7 +345,21 @@ def main():
     from kaldi_amd import feat, nnet3, synth, decoder, parallel, hostlib
 
     U, nsamp = args.utts, int(16000 * args.utt_seconds)
-    det_threads = args.det_threads or max(1, (os.cpu_count() or 1) // (world * max(1, args.host_load_replicas)))
+    # host budget of a rank on an N-GPU node: cores / N threads for its lattice tail, and -- unless --no-pin -- those threads on the rank's OWN contiguous share of
+    # the cores (by LOCAL_RANK; the affinity mask is inherited by every thread created from here on: the determinization pool, the lattice fetch helpers), so that
+    # eight ranks' pools do not migrate over each other's cores.  One rank: the whole host, no pinning.
+    ncpu = os.cpu_count() or 1
+    det_threads = args.det_threads or max(1, ncpu // (world * max(1, args.host_load_replicas)))
+    pinned_cores = None
+    if world > 1 and not args.no_pin and hasattr(os, "sched_setaffinity"):
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        share = max(1, ncpu // max(1, lw))
+        first = (int(os.environ.get("LOCAL_RANK", "0")) % max(1, lw)) * share
+        try:
+            os.sched_setaffinity(0, range(first, min(ncpu, first + share)))
+            pinned_cores = [first, min(ncpu, first + share) - 1]
+        except OSError:
+            pinned_cores = None
     # synthetic workload: Gaussian PCM16 sigma 3000, utterance u of rank r = synth.gaussian_pcm16(nsamp, 1234 + 100000 r + u), in page-locked host
     # memory
     # (one spare utterance behind the batch: timed step k reads the batch from sample offset shift(k), so no two steps decode the same audio);
@@ -379,6 +399,8 @@ def main():
         # the same image goes through torch.distributed (parallel.broadcast_graph).  Either way before the timed region, once.
         cfst = None
         rccl_ranks = 0
+        rccl_abi_failed = False
+        rccl_abi_error = None
         bcast_via = "none (one rank)" if world == 1 else "torch.distributed broadcast of the k3_fst image"
         if world > 1 and dist.get_backend() == "nccl" and os.environ.get("K3_BENCH_ABI_BCAST", "1") == "1":
             import threading
@@ -402,7 +424,22 @@ def main():
             if int(ok.item()) == 1:
                 cfst, rccl_ranks = box["r"]
                 bcast_via = "k3_comm_create + k3_fst_bcast (RCCL through the C ABI)"
-            else: bcast_via += " (k3_fst_bcast did not complete on every rank: %s)" % (box.get("e") or ("timeout" if th.is_alive() else "another rank failed"))
+            else:
+                # NOT silent: every rank's reason is collected, the line carries "rccl_abi_failed": true + the reasons, and unless
+                # --no-strict-rccl the run ends with exit status 3 (after printing the line, measured over the torch.distributed fall-back, when the ABI call
+                # returned an error; at once when it is still blocked inside RCCL -- nothing on this device can be trusted to make progress then)
+                mine = box.get("e") or ("still blocked in k3_comm_create / k3_fst_bcast after 75 s" if th.is_alive() else None)
+                reasons = [None] * world
+                dist.all_gather_object(reasons, mine)
+                rccl_abi_failed = True
+                rccl_abi_error = {"rank %d" % r: e for r, e in enumerate(reasons) if e}
+                bcast_via += " (k3_fst_bcast did not complete on every rank)"
+                if not args.no_strict_rccl and any(e and e.startswith("still blocked") for e in reasons):
+                    if rank == 0:
+                        print(json.dumps({"metric": "RTFx (audio-s/wall-s) batched fbank -> TDNN-F -> HCLG lattice decode", "value": None, "n_gpus": world,
+                                          "rccl_abi_failed": True, "rccl_abi_error": rccl_abi_error,
+                                          "error": "graph broadcast through the C ABI (RCCL) timed out; --no-strict-rccl falls back to torch.distributed"}), flush=True)
+                    os._exit(3)
         if cfst is None: cfst = parallel.broadcast_graph(graph, synth.tid2pdf(num_pdfs), rank, world, dev)
         t_bcast = time.perf_counter() - t0
         caps = dict(frame_tokens_cap=65536, frame_cands_cap=131072, lane_tokens_cap=int(4500 * args.utt_seconds * 33.4) + 65536,
@@ -702,9 +739,9 @@ def main():
                 "LDS (decode_stats.frames_by_path), the first frames of each utterance (the start state's thousands of arcs) run on "
                 "the HBM-scratch path and move `traffic`; `traffic` is FETCH_SIZE + WRITE_SIZE as reported, and the calibration of "
                 "profiles/hbm_counter_calibration_r04.json says how to read it for this pattern: a random 4 - 16 B read counts 64 "
-                "B, a random 4 - 16 B write or atomic 32 B -- the counters tally REQUESTS (60.7 GB of reads = 0.95 G requests, 42.1 "
-                "GB of writes = 1.3 G requests per launch), so traffic / algorithmic bytes ~ 7 is the request granularity of narrow "
-                "accesses, not re-reading; DESIGN.md section 4"}
+                "B, a random 4 - 16 B write or atomic 32 B -- the counters tally REQUESTS at line granularity (traffic_fetch / 64 and "
+                "traffic_write / 32 are the request counts), so traffic_over_algorithmic is the granule around narrow scattered accesses, "
+                "not re-reading; DESIGN.md section 4"}
             # The HBM roofline above is the wrong yardstick for this kernel: a lane is a DEPENDENT CHAIN -- frame after frame, and inside a frame
             # the ~70 barrier-separated
             # phases of the reference's serial algorithm unrolled (cutoff, bound pass, accept pass, eps rounds, closure sub-graph, two hash-order passes, queue
@@ -747,8 +784,13 @@ def main():
                     if U == 512 and args.utt_seconds == 10.0:
                         line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
                         line["roofline"]["traffic_source"] = tj["source"]
+                        for k_ in ("fetch_bytes_per_launch", "write_bytes_per_launch"):
+                            if k_ in tj: line["roofline"]["traffic_" + k_.split("_")[0]] = tj[k_]
                 except Exception: pass
+            if line["roofline"].get("traffic"):
+                line["roofline"]["traffic_over_algorithmic"] = line["roofline"]["traffic"] / ab
             line["decode_stats"] = {"graph_broadcast_s": t_bcast if world > 1 else 0.0, "graph_broadcast_via": bcast_via, "rccl_ranks": rccl_ranks,
+                "rccl_abi_failed": rccl_abi_failed, "rccl_abi_error": rccl_abi_error, "pinned_cores_rank0": pinned_cores,
                  "emitting_arcs_traversed": int(info[:, 7].sum()), "eps_arcs_traversed": int(info[:, 8].sum()), "tokens": int(info[:, 4].sum()),
                     "links": int(info[:, 5].sum()), "max_tokens_on_a_frame": int(info[:, 6].max()), "lattice_states": lat_sizes[0],
                 "lattice_arcs": lat_sizes[1], "lattice_digest": lat_sizes[2], "determinized_states": det_sizes[0], "determinized_arcs": det_sizes[1],
@@ -896,6 +938,13 @@ def main():
                     tu = us[:args.truth_utts]
                     with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
                         tr64 = list(ex.map(lambda u: no.compute(onet, kept[u][0], 3, dtype=np.float64), tu))
+                    # |k3_nnet_forward - nnet3-compute| over ALL log-likelihoods of the sample as a distribution, not only its maximum
+                    ad = np.concatenate([np.abs(g_llh[oo[u]:oo[u + 1]] - kept[u][1]).ravel() for u in us])
+                    nn_dist = {"values": int(ad.size), "max": float(ad.max()), "mean": float(ad.mean()),
+                               "above_1e-4_frac": float((ad > 1e-4).mean()), "above_1e-4": int((ad > 1e-4).sum()),
+                               "above_2e-4_frac": float((ad > 2e-4).mean()), "above_2e-4": int((ad > 2e-4).sum()),
+                               "p99": float(np.quantile(ad, 0.99)), "p99.9": float(np.quantile(ad, 0.999)), "p99.999": float(np.quantile(ad, 0.99999))}
+                    del ad
                     n_eg = max(float(np.abs(g_llh[oo[u]:oo[u + 1]] - t).max()) for u, t in zip(tu, tr64))
                     n_er = max(float(np.abs(kept[u][1] - t).max()) for u, t in zip(tu, tr64))
                     n_mg = float(np.mean([np.abs(g_llh[oo[u]:oo[u + 1]] - t).mean() for u, t in zip(tu, tr64)]))
@@ -925,7 +974,7 @@ def main():
                     ident = sum(bool(same_lattice(u)) for u in us)
                     par["stage_gates"] = {"utterances": len(us), "features_max_abs_diff": par["max_abs_feature_diff"],
                             "features_mean_abs_diff": par["mean_abs_feature_diff"], "features_above_1e-4_frac": par["feature_values_above_1e-4_frac"],
-                         "nnet_on_reference_features_max_abs_loglike_diff": nd, "nnet_truth": {"utterances": len(tu), "gpu_vs_exact_max_abs": n_eg,
+                         "nnet_on_reference_features_max_abs_loglike_diff": nd, "nnet_on_reference_features_loglike_diff_distribution": nn_dist, "nnet_truth": {"utterances": len(tu), "gpu_vs_exact_max_abs": n_eg,
                              "reference_vs_exact_max_abs": n_er, "gpu_vs_exact_mean_abs": n_mg, "reference_vs_exact_mean_abs": n_mr,
                              "largest_difference_to_reference": worst,
                             "note": "exact = the same network in float64 (numpy) on the reference's features; k3_nnet_forward and nnet3-compute "
@@ -943,9 +992,13 @@ def main():
                          "LatticeFasterDecoder on the reference's log-likelihoods -- states and arcs with all cost bits, as "
                         "multisets (the strict signature test is tests/test_decoder_literal_gpu.py)"}
             except Exception as e: line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line))
+        if os.environ.get("K3HIP_LIB"): line["dev_lib"] = os.environ["K3HIP_LIB"]
+        if decs and rccl_abi_failed: line["rccl_abi_failed"] = True      # (top level too: a reader of `value` cannot miss it)
+        print(json.dumps(line), flush=True)
     pool.shutdown()
     if world > 1: dist.destroy_process_group()
+    if decs and rccl_abi_failed and not args.no_strict_rccl:
+        sys.exit(3)      # the product's RCCL path failed: the number above was measured over the torch.distributed fall-back and says so
 
 if __name__ == "__main__":
     main()

@@ -254,12 +254,17 @@ int k3_fst_import_image(k3_fst *fst, const void *d_src);   /* the reverse, after
  * other ranks' HBM, once; nothing else is shared (utterances are independent, every rank writes its own lattices: lat.JOB of decode.sh:123).
  * k3_fst_bcast: on `root` *fst is the graph; on the other ranks *fst is NULL on entry and owns a graph with root's image on return.  `comm` is an
  * ncclComm_t -- the application's own, or k3_comm_create's: the 128-byte ncclUniqueId travels through a file every rank can see (rank 0 writes
- * id_file, the others wait up to timeout_seconds for it).  RCCL is bound at run time (dlopen): single-GPU users never load it. */
+ * id_file, the others wait up to timeout_seconds for it; k3_comm_rendezvous below).  RCCL is bound at run time (dlopen): single-GPU users never load it. */
 int k3_comm_create(const char *id_file, int32_t rank, int32_t world_size, int32_t timeout_seconds, void **comm);
 void k3_comm_destroy(void *comm);
 /* the rendezvous' file protocol by itself (no RCCL): rank 0 publishes the 128 bytes at id_in, the others receive them in id_out; files of other runs are
  * refused (run identity: K3_COMM_NONCE / TORCHELASTIC_RUN_ID when set, otherwise nothing older than stale_seconds before the caller's start) */
 int k3_comm_exchange_id(const char *id_file, int32_t rank, int32_t timeout_seconds, int32_t stale_seconds, const void *id_in, void *id_out);
+/* what k3_comm_create does in front of ncclCommInitRank (which has no deadline of its own): the id exchange above plus an arrival handshake -- rank r announces itself in
+ * <id_file>.arrived.<r>, rank 0 writes <id_file>.go once it has seen all world_size - 1 announcements of the id it published -- so that no rank enters the collective
+ * unless every rank is there; a rank that never arrives makes every other rank return an error that names it within timeout_seconds instead of blocking for ever
+ * (tests/test_parallel_cpu.py: fault injection with real processes, no RCCL needed) */
+int k3_comm_rendezvous(const char *id_file, int32_t rank, int32_t world_size, int32_t timeout_seconds, int32_t stale_seconds, const void *id_in, void *id_out);
 /* in-place sum over the ranks of `comm` (ncclAllReduce): the gradient exchange of data-parallel chain training; asynchronous on `stream` */
 int k3_comm_allreduce_f32(void *comm, float *d_buf, int64_t count, void *stream);
 int k3_fst_bcast(k3_fst **fst, void *comm /* ncclComm_t */, int32_t root, int32_t rank, void *stream);

@@ -40,41 +40,101 @@ int rccl(Rccl **out) {
 #define K3_RCCL(R, e) do { const int rc__ = (e); if (rc__ != 0) { k3::set_error("RCCL error %d (%s) in %s", rc__, (R)->GetErrorString ? (R)->GetErrorString(rc__) : "?", #e); return K3_ERR_HIP; } } while (0)
 constexpr int kNcclUint8 = 1, kNcclInt64 = 4, kNcclFloat32 = 7, kNcclSum = 0;      // ncclDataType_t / ncclRedOp_t (rccl.h:459-467, :441)
 struct IdFile { char id[128]; uint64_t magic, nonce; };      // what rank 0 writes
+struct Note { uint64_t magic, nonce, id_hash; };               // <id_file>.arrived.<rank> (a rank has read the id) and <id_file>.go (rank 0 has seen every rank)
 constexpr uint64_t kIdMagic = 0x4b33636f6d6d3031ull;      // "K3comm01"
-uint64_t run_nonce() {      // a launcher-supplied run identity (K3_COMM_NONCE, else torchrun's run id): ranks of different runs never accept each other's file
-  const char *e = getenv("K3_COMM_NONCE"); if (!e || !*e) e = getenv("TORCHELASTIC_RUN_ID");
+uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull) { const unsigned char *c = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; } return h; }
+// A launcher-supplied run identity (K3_COMM_NONCE, else torchrun's run id): ranks of different runs never accept each other's files.  *unique = the identity is
+// K3_COMM_NONCE, which the caller makes up per run; torchrun's static rendezvous hands EVERY run the id "none", so that one alone does not tell two runs apart.
+uint64_t run_nonce(bool *unique = nullptr) {
+  const char *e = getenv("K3_COMM_NONCE"); if (unique) *unique = e && *e;
+  if (!e || !*e) e = getenv("TORCHELASTIC_RUN_ID");
   if (!e || !*e) return 0;
-  uint64_t h = 1469598103934665603ull; for (; *e; e++) { h ^= (unsigned char)*e; h *= 1099511628211ull; }
+  const uint64_t h = fnv(e, strlen(e));
   return h ? h : 1;
 }
+bool write_atomically(const std::string &path, const void *rec, size_t n) {
+  const std::string tmp = path + ".tmp";
+  FILE *f = fopen(tmp.c_str(), "wb"); if (!f) return false;
+  const bool ok = fwrite(rec, n, 1, f) == 1; return (fclose(f) == 0) && ok && rename(tmp.c_str(), path.c_str()) == 0;
+}
+// a file of exactly the record's size whose age passes: with a per-run K3_COMM_NONCE the nonce decides alone (a rank that enters late must not reject a valid
+// file for its age); otherwise nothing older than max(stale_seconds, timeout_seconds) before the caller's start is taken for this run's
+template <typename Rec> bool read_fresh(const std::string &path, Rec *rec, time_t t_start, int window, bool nonce_is_unique) {
+  FILE *f = fopen(path.c_str(), "rb"); if (!f) return false;
+  struct stat st; char extra; const bool got = fread(rec, sizeof *rec, 1, f) == 1 && fread(&extra, 1, 1, f) == 0 && fstat(fileno(f), &st) == 0; fclose(f);      // (a truncated or over-long file is not a record)
+  return got && (nonce_is_unique || st.st_mtime + window >= t_start);
+}
+std::string note_path(const char *id_file, const char *what, int rank = -1) { std::string p = std::string(id_file) + "." + what; if (rank >= 0) p += "." + std::to_string(rank); return p; }
 }  // namespace
 
 // The file protocol of the rendezvous by itself (no RCCL: tests/test_parallel_cpu.py runs it with several processes).  Rank 0 removes whatever a
 // previous run left at `id_file`, then publishes {id, magic, nonce} atomically (rename); the other ranks poll for a file that (a) carries the magic and
-// this run's nonce (K3_COMM_NONCE / TORCHELASTIC_RUN_ID; 0 when the launcher supplied none) AND (b) is not older than `stale_seconds` before their own
-// start -- also with a nonce: torchrun's static rendezvous hands every run the same id ("none"), so the nonce alone does not tell two runs apart.  A file a
-// crashed or one-rank run left behind is therefore only ever mistaken for the new one inside that window and before rank 0 has replaced it; launchers that
-// restart within the window should set K3_COMM_NONCE per run.  k3_comm_create removes the file again once every rank has joined (ncclCommInitRank is
-// collective), so a recipe directory can be reused run after run.
+// this run's nonce (K3_COMM_NONCE / TORCHELASTIC_RUN_ID; 0 when the launcher supplied none) AND (b) unless the nonce is a per-run K3_COMM_NONCE, is not older
+// than max(stale_seconds, timeout_seconds) before their own start: torchrun's static rendezvous hands every run the same id ("none"), so that nonce alone does
+// not tell two runs apart.  A file a crashed run left behind is therefore only ever mistaken for the new one inside that window and before rank 0 has replaced
+// it -- and k3_comm_rendezvous below does not act on an id before rank 0 has confirmed it.
 extern "C" int k3_comm_exchange_id(const char *id_file, int32_t rank, int32_t timeout_seconds, int32_t stale_seconds, const void *id_in, void *id_out) {
   K3_REQUIRE(id_file && id_out && rank >= 0 && (rank != 0 || id_in), "k3_comm_exchange_id: bad argument");
-  const uint64_t nonce = run_nonce(); const time_t t_start = time(nullptr);
+  bool unique = false; const uint64_t nonce = run_nonce(&unique); const time_t t_start = time(nullptr); const int window = std::max(stale_seconds, timeout_seconds);
   if (rank == 0) {
     (void)unlink(id_file);
     IdFile rec; memcpy(rec.id, id_in, sizeof rec.id); rec.magic = kIdMagic; rec.nonce = nonce;
-    const std::string tmp = std::string(id_file) + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "wb"); K3_REQUIRE(f && fwrite(&rec, sizeof rec, 1, f) == 1 && fclose(f) == 0 && rename(tmp.c_str(), id_file) == 0, "k3_comm_exchange_id: cannot write the id file");
+    K3_REQUIRE(write_atomically(id_file, &rec, sizeof rec), "k3_comm_exchange_id: cannot write the id file");
     memcpy(id_out, id_in, sizeof rec.id); return K3_OK;
   }
   for (int i = 0; i < 20 * std::max(1, timeout_seconds); i++) {
-    FILE *f = fopen(id_file, "rb");
-    if (f) {
-      IdFile rec; struct stat st; const bool got = fread(&rec, sizeof rec, 1, f) == 1 && fstat(fileno(f), &st) == 0; fclose(f);
-      if (got && rec.magic == kIdMagic && rec.nonce == nonce && st.st_mtime + stale_seconds >= t_start) { memcpy(id_out, rec.id, sizeof rec.id); return K3_OK; }
-    }
+    IdFile rec;
+    if (read_fresh(id_file, &rec, t_start, window, unique) && rec.magic == kIdMagic && rec.nonce == nonce) { memcpy(id_out, rec.id, sizeof rec.id); return K3_OK; }
     usleep(50000);
   }
   k3::set_error("k3_comm_exchange_id: timed out waiting for rank 0's id file %s (a file of another run is not accepted)", id_file); return K3_ERR_ARG;
+}
+
+// The whole rendezvous in front of ncclCommInitRank, which has no deadline of its own (a rank that never arrives would leave the others blocked in its bootstrap
+// for ever): nobody enters the collective before EVERY rank has been seen.  Rank r > 0 reads the id, announces itself in <id_file>.arrived.<r> (naming the id it
+// read; it re-reads and re-announces if rank 0 replaces a stale file under it) and waits for <id_file>.go; rank 0 publishes the id, waits for all world_size - 1
+// announcements of THAT id and then writes .go.  Every wait ends after timeout_seconds with an error that names what was missing (the ranks that never arrived /
+// rank 0's confirmation); on failure rank 0 withdraws its files, so late ranks time out too instead of joining a dead run.
+extern "C" int k3_comm_rendezvous(const char *id_file, int32_t rank, int32_t world_size, int32_t timeout_seconds, int32_t stale_seconds, const void *id_in, void *id_out) {
+  K3_REQUIRE(id_file && id_out && world_size >= 1 && rank >= 0 && rank < world_size && (rank != 0 || id_in), "k3_comm_rendezvous: bad argument");
+  bool unique = false; const uint64_t nonce = run_nonce(&unique); const time_t t_start = time(nullptr); const int window = std::max(stale_seconds, timeout_seconds);
+  const int polls = 20 * std::max(1, timeout_seconds); const std::string go = note_path(id_file, "go");
+  if (world_size == 1) return k3_comm_exchange_id(id_file, 0, timeout_seconds, stale_seconds, id_in, id_out);      // (nobody to wait for)
+  if (rank == 0) {
+    (void)unlink(go.c_str()); for (int r = 1; r < world_size; r++) (void)unlink(note_path(id_file, "arrived", r).c_str());
+    { const int rc = k3_comm_exchange_id(id_file, 0, timeout_seconds, stale_seconds, id_in, id_out); if (rc) return rc; }
+    const Note want{kIdMagic, nonce, fnv(id_in, 128)}; std::vector<char> seen(world_size, 0); int missing = world_size - 1;
+    for (int i = 0; i < polls && missing > 0; i++) {
+      for (int r = 1; r < world_size; r++) {
+        Note n; if (!seen[r] && read_fresh(note_path(id_file, "arrived", r), &n, t_start, window, true) && n.magic == want.magic && n.nonce == want.nonce && n.id_hash == want.id_hash) { seen[r] = 1; missing--; }
+      }
+      if (missing > 0) usleep(50000);
+    }
+    if (missing > 0) {
+      std::string who; for (int r = 1; r < world_size; r++) if (!seen[r]) who += (who.empty() ? "" : ", ") + std::to_string(r);
+      (void)unlink(id_file); for (int r = 1; r < world_size; r++) (void)unlink(note_path(id_file, "arrived", r).c_str());
+      k3::set_error("k3_comm_rendezvous: %d of %d ranks never arrived within %d s (missing: %s); id file %s withdrawn", missing, world_size, timeout_seconds, who.c_str(), id_file); return K3_ERR_ARG;
+    }
+    K3_REQUIRE(write_atomically(go, &want, sizeof want), "k3_comm_rendezvous: cannot write the confirmation file");
+    return K3_OK;
+  }
+  uint64_t announced = 0; bool have = false; IdFile rec;
+  for (int i = 0; i < polls; i++) {
+    IdFile cur;
+    if (read_fresh(id_file, &cur, t_start, window, unique) && cur.magic == kIdMagic && cur.nonce == nonce) {
+      const uint64_t h = fnv(cur.id, sizeof cur.id);
+      if (!have || h != announced) {
+        const Note n{kIdMagic, nonce, h}; K3_REQUIRE(write_atomically(note_path(id_file, "arrived", rank), &n, sizeof n), "k3_comm_rendezvous: cannot write the arrival file");
+        rec = cur; announced = h; have = true;
+      }
+      Note g; if (read_fresh(go, &g, t_start, window, unique) && g.magic == kIdMagic && g.nonce == nonce && g.id_hash == announced) { memcpy(id_out, rec.id, sizeof rec.id); return K3_OK; }
+    }
+    usleep(50000);
+  }
+  (void)unlink(note_path(id_file, "arrived", rank).c_str());
+  k3::set_error(have ? "k3_comm_rendezvous: rank %d read the id but rank 0 never confirmed that all %d ranks arrived within %d s (%s)" : "k3_comm_rendezvous: rank %d of %d timed out after %d s waiting for rank 0's id file %s (a file of another run is not accepted)",
+                rank, world_size, timeout_seconds, id_file);
+  return K3_ERR_ARG;
 }
 
 // One communicator per process (one process per GPU, hipSetDevice done by the caller).  The 128-byte ncclUniqueId travels through a file on a
@@ -84,10 +144,12 @@ extern "C" int k3_comm_create(const char *id_file, int32_t rank, int32_t world_s
   Rccl *R; { const int rc = rccl(&R); if (rc) return rc; }
   UniqueId id, mine; memset(&id, 0, sizeof id); memset(&mine, 0, sizeof mine);
   if (rank == 0) K3_RCCL(R, R->GetUniqueId(&mine));
-  { const int rc = k3_comm_exchange_id(id_file, rank, timeout_seconds, 120, &mine, &id); if (rc) return rc; }
+  { const int rc = k3_comm_rendezvous(id_file, rank, world_size, timeout_seconds, 120, &mine, &id); if (rc) return rc; }      // (returns once EVERY rank has been seen, or with an error inside the timeout)
   void *c = nullptr;
   K3_RCCL(R, R->CommInitRank(&c, world_size, id, rank));
-  if (rank == 0 && world_size > 1) (void)unlink(id_file);      // every rank has joined: nothing of this run stays behind (a one-rank communicator keeps it: nobody else reads it, tests look at it)
+  if (rank == 0 && world_size > 1) {      // every rank has joined: nothing of this run stays behind (a one-rank communicator keeps the id file: nobody else reads it, tests look at it)
+    (void)unlink(id_file); (void)unlink(note_path(id_file, "go").c_str()); for (int r = 1; r < world_size; r++) (void)unlink(note_path(id_file, "arrived", r).c_str());
+  }
   *comm = c; return K3_OK;
 }
 extern "C" void k3_comm_destroy(void *comm) { Rccl *R; if (comm && rccl(&R) == K3_OK && R->CommDestroy) (void)R->CommDestroy(comm); }

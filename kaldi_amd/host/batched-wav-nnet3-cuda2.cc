@@ -9,6 +9,7 @@
 // decoders' wrappers undo it).  --determinize-lattice=false writes the trimmed state-level lattice re-packed by ConvertLattice as a
 // CompactLattice, as the reference does; with --write-compact=false (an addition) it is written as a Lattice table, arc for arc.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <chrono>
 #include <fstream>
 #include <sstream>
@@ -46,7 +47,7 @@ int main(int argc, char **argv) {
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, worker_threads = -1, copy_threads = 2, frames_per_chunk = 50, subsampling = 1;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, elc = 0, erc = 0, elci = -1, ercf = -1;
     float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; double mem_prop = 0.5; int32_t det_max_mem = 50000000;
-    bool literal_order = true; float hash_ratio = 2.0f; int32_t rank = getenv("RANK") ? atoi(getenv("RANK")) : 0, world_size = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1, device = -1; std::string nccl_id_file;
+    bool literal_order = true; float hash_ratio = 2.0f; bool pin_cores = true; int32_t rank = getenv("RANK") ? atoi(getenv("RANK")) : 0, world_size = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1, device = -1; std::string nccl_id_file;
     std::string word_syms, postproc, feature_type = "mfcc", mfcc_config, fbank_config, plp_config, pitch_config, cmvn_config, global_cmvn, ivector_config, use_gpu = "yes";
     po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
     po.Register("word-symbol-table", &word_syms, "Symbol table for words [the words of the CTM output]");
@@ -88,6 +89,8 @@ int main(int argc, char **argv) {
     po.Register("literal-order", &literal_order, "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's, bit for bit (serial cutoff tightening in hash-list order reproduced on the GPU); false = the order-independent fast decoder");
     po.Register("hash-ratio", &hash_ratio, "LatticeFasterDecoderConfig::hash_ratio (it decides the reference's token visit order; used with --literal-order)");
     po.Register("rank", &rank, "(not in the reference) this process's rank in a multi-GPU job: it takes the utterances i with i % world-size == rank, uses GPU <rank> of the node unless LOCAL_RANK / --device says otherwise, and writes the lattice wspecifier with JOB replaced by rank + 1 (lat.JOB.gz of decode.sh).  Default: $RANK or 0");
+    po.Register("pin-cores", &pin_cores, "(not in the reference) with world-size > 1: this rank's threads run on its own contiguous share of the host's cores (cores / world-size, by LOCAL_RANK), "
+                "and --cuda-worker-threads defaults to that share instead of every core -- eight ranks' determinizers do not oversubscribe a 256-core host");
     po.Register("world-size", &world_size, "(not in the reference) number of ranks (one process per GPU).  Default: $WORLD_SIZE or 1");
     po.Register("device", &device, "(not in the reference) HIP device of this process (-1: $LOCAL_RANK, else rank modulo the number of devices)");
     po.Register("nccl-id-file", &nccl_id_file, "(not in the reference) with world-size > 1: rank 0 reads the graph and broadcasts it once over RCCL/xGMI to the other ranks; the communicator's id travels through this file (shared directory).  Empty: every rank reads the graph itself");
@@ -100,6 +103,14 @@ int main(int argc, char **argv) {
       K3H_ERR << "an option that needs a component outside the accelerated path was given (online features / pitch / PLP / CMVN / extra context)";
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3); std::string out_wspec = po.GetArg(4);
     if (world_size < 1 || rank < 0 || rank >= world_size) K3H_ERR << "--rank=" << rank << " is not in [0, --world-size=" << world_size << ")";
+    int cores_of_rank = std::max(1, (int)std::thread::hardware_concurrency());
+    if (world_size > 1 && pin_cores) {      // before any worker thread exists: they inherit the mask
+      const int ncpu = cores_of_rank, lr = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank, lw = getenv("LOCAL_WORLD_SIZE") ? std::max(1, atoi(getenv("LOCAL_WORLD_SIZE"))) : world_size;
+      const int share = std::max(1, ncpu / lw), first = (lr % lw) * share;
+      cpu_set_t set; CPU_ZERO(&set); for (int c = first; c < first + share && c < ncpu; c++) CPU_SET(c, &set);
+      if (sched_setaffinity(0, sizeof set, &set) == 0) { cores_of_rank = share; K3H_LOG << "rank " << rank << ": host threads on cores " << first << " .. " << first + share - 1; }
+      else K3H_WARN << "sched_setaffinity failed; the rank's threads stay on all cores";
+    }
     { int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev)); if (ndev < 1) K3H_ERR << "no HIP device";
       if (device < 0) device = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) % ndev : rank % ndev;
       if (device >= ndev) K3H_ERR << "--device=" << device << " but the node has " << ndev << " devices";
@@ -200,7 +211,7 @@ int main(int argc, char **argv) {
     // determinization runs on worker threads while the GPU works on the next batch; records come out in submission order
     std::unique_ptr<DeterminizeSequencer> det_pool;
     if ((writer && (determinize || postprocessor)) || ctm_mode) {
-      DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
+      DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : cores_of_rank;
       pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; pc.determinize = determinize; pc.postprocessor = postprocessor; pc.ctm_out = ctm_file.get(); pc.word_syms = syms.empty() ? nullptr : &syms;
       det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
     }
