@@ -310,9 +310,15 @@ class BatchedThreadedNnet3CudaPipeline2 {
       for (int t = 1; t < nthr; t++) th.emplace_back(gather, t);
       gather(0); for (auto &t : th) t.join();
       K3O_HIP(hipMemcpyAsync(d_w_[B].need((size_t)std::max<int64_t>(woff.back(), 1)), stage, (size_t)woff.back() * sizeof(float), hipMemcpyHostToDevice, s_front_));
+      // The offsets travel on the FRONT stream from this slot's page-locked buffer, behind the previous front end that read d_wo_[B] / d_fo_[B] (a synchronous copy
+      // on the null stream does not wait for the non-blocking front stream and could overwrite them while batch k - 2's feature kernel is still queued).  ev_h2d_[B], recorded
+      // behind all three copies, is what guards the reuse of both staging buffers.
+      int64_t *ho = h_off_[B].need(woff.size() + foff.size());
+      memcpy(ho, woff.data(), woff.size() * sizeof(int64_t)); memcpy(ho + woff.size(), foff.data(), foff.size() * sizeof(int64_t));
+      K3O_HIP(hipMemcpyAsync(d_wo_[B].need(woff.size()), ho, woff.size() * sizeof(int64_t), hipMemcpyHostToDevice, s_front_));
+      K3O_HIP(hipMemcpyAsync(d_fo_[B].need(foff.size()), ho + woff.size(), foff.size() * sizeof(int64_t), hipMemcpyHostToDevice, s_front_));
       K3O_HIP(hipEventRecord(ev_h2d_[B], s_front_)); h2d_recorded_[B] = true;
     }
-    d_wo_[B].upload(woff); d_fo_[B].upload(foff);      // (small synchronous copies into this batch's own offset buffers)
     K3H_CHECK_K3(k3_feat_compute_batch(plan_, d_w_[B].p, d_wo_[B].p, d_fo_[B].p, U, tot, d_f_.need((size_t)tot * fdim_), fdim_, s_front_));      // (d_f_ and the network's buffers: one set, ordered by the stream)
     k3_nnet_batch *nb = nullptr;
     for (auto &c : plan_cache_) if (c.first == nframes) { nb = c.second; break; }
@@ -354,7 +360,7 @@ class BatchedThreadedNnet3CudaPipeline2 {
   const BatchedThreadedNnet3CudaPipeline2Config config_; k3_nnet *nnet_; const TransitionInfo &trans_;
   k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr, *dec_b_ = nullptr; k3_nnet_info ninfo_; int fdim_ = 0, device_ = 0; int32_t graph_start_ = 0; std::vector<float> log_priors_;
   std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache_;
-  DevBuf<float> d_w_[2], d_f_, d_ll_[2]; DevBuf<int64_t> d_wo_[2], d_fo_[2]; PinnedBuf<float> h_w_[2]; hipEvent_t ev_h2d_[2] = {nullptr, nullptr}; bool h2d_recorded_[2] = {false, false};
+  DevBuf<float> d_w_[2], d_f_, d_ll_[2]; DevBuf<int64_t> d_wo_[2], d_fo_[2]; PinnedBuf<float> h_w_[2]; PinnedBuf<int64_t> h_off_[2]; hipEvent_t ev_h2d_[2] = {nullptr, nullptr}; bool h2d_recorded_[2] = {false, false};
   hipStream_t s_front_ = nullptr, s_dec_ = nullptr, s_dec_b_ = nullptr; hipEvent_t ev_front_[2] = {nullptr, nullptr}, ev_dec_[2] = {nullptr, nullptr};
   k3_decoder *Dec(int buf) const { return (buf & 1) && dec_b_ ? dec_b_ : dec_; }
   hipStream_t DecStream(int buf) const { return (buf & 1) && dec_b_ ? s_dec_b_ : s_dec_; }

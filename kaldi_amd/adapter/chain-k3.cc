@@ -250,7 +250,10 @@ void SplitMergedSupervision(const Supervision &sup, std::vector<int32_t> *state_
       c->off.push_back((int64_t)c->il.size());      // a final state of this sequence: its arcs belong to the next one
       if (!have_ref) { c->fin.push_back(f.Final(s).Value()); continue; }
       float cost = inf;
-      for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) if (it.Value().ilabel == ref_arc.ilabel && it.Value().nextstate == ref_arc.nextstate) { cost = it.Value().weight.Value() - ref_arc.weight.Value(); break; }
+      // the corresponding arc: by POSITION first (the boundary states carry copies of the same arc list, so arc 0 of b is arc 0 of b0 -- unambiguous also when two parallel arcs
+      // share label and destination), by (label, destination) only if the lists are ordered differently
+      { fst::ArcIterator<fst::StdVectorFst> it(f, s); if (!it.Done() && it.Value().ilabel == ref_arc.ilabel && it.Value().nextstate == ref_arc.nextstate) cost = it.Value().weight.Value() - ref_arc.weight.Value(); }
+      if (cost == inf) for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) if (it.Value().ilabel == ref_arc.ilabel && it.Value().nextstate == ref_arc.nextstate) { cost = it.Value().weight.Value() - ref_arc.weight.Value(); break; }
       if (cost == inf) KALDI_ERR << "Supervision FST: the states of a sequence boundary do not share their arcs (not the output of MergeSupervision?)";
       c->fin.push_back(cost);
     }
@@ -285,7 +288,12 @@ void ComputeChainObjfAndDeriv(const ChainTrainingOptions &opts, const Denominato
   if ((e2e ? k3_chain_supervision_create_e2e : k3_chain_supervision_create)(B, T, P, supervision.weight, so.data(), c.off.data(), c.il.data(), c.nx.data(), c.w.data(), c.fin.data(), &ks) != K3_OK) KALDI_ERR << k3_last_error();
   if (xent_output_deriv) xent_output_deriv->Resize(nnet_output.NumRows(), nnet_output.NumCols(), kUndefined);      // (zeroed by the kernel side)
   // the reference applies the out-of-range penalty on every other minibatch, by a coin flip on the host's rand() (chain-training.cc:273-277)
-  k3_chain_training_opts o = {opts.l2_regularize, opts.out_of_range_regularize, opts.leaky_hmm_coefficient, (opts.out_of_range_regularize != 0.0 && RandInt(0, 1) == 0) ? 1 : 0};
+  // -- RandInt(0, 1) is drawn if and only if a derivative is asked for (:107, :249), whatever the penalty's scale: the host's rand() stream then stays in step with the reference's.
+  // The end-to-end branch scales the denominator derivative by 1 + opts.lwf_den_scale (:124-128); k3_chain_objf_and_deriv has no such factor: refuse instead of ignoring it.
+  // (GenericNumeratorComputation::ForwardBackward's own `ok` only ever turns false under --verbose >= 1 (CheckValues, chain-generic-numerator.cc:281); at the default level the
+  // reference's numerator_ok is the finiteness test the kernel side applies.)
+  if (e2e && opts.lwf_den_scale != 0.0) KALDI_ERR << "--lwf-den-scale=" << opts.lwf_den_scale << " (end-to-end supervision) is not supported by the MI355X objective";
+  k3_chain_training_opts o = {opts.l2_regularize, opts.out_of_range_regularize, opts.leaky_hmm_coefficient, (nnet_output_deriv != NULL && RandInt(0, 1) == 0) ? 1 : 0};
   float fo = 0, fl = 0, fw = 0;
   const int rc = k3_chain_objf_and_deriv(den, ks, &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv ? nnet_output_deriv->Data() : NULL, nnet_output_deriv ? nnet_output_deriv->Stride() : 0,
                                          xent_output_deriv ? xent_output_deriv->Data() : NULL, xent_output_deriv ? xent_output_deriv->Stride() : 0, &fo, &fl, &fw, NULL);

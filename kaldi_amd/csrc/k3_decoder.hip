@@ -948,7 +948,12 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     const long long lane_bytes = 16ll * cfg->lane_tokens_cap + 20ll * cfg->lane_links_cap + 6 * 256;
     p.spare_bytes = cfg->spare_pool_bytes >= 0 ? cfg->spare_pool_bytes : std::max<long long>({(long long)nl * lane_bytes / 4, 14 * lane_bytes, 1ll << 30});
     p.spare = nullptr;
-    if (p.spare_bytes > 0 && (rc = dmalloc(&d->allocs, &p.spare, (size_t)p.spare_bytes))) return rc;
+    // (a DEFAULT-sized arena that does not fit beside the reservation is halved until it does -- on a smaller part, or with several decoder objects, the decoder still
+    // comes up and only utterances that outgrow their reservation by more than what is left see K3_ERR_OVERFLOW; an arena the caller asked for explicitly must fit)
+    while (p.spare_bytes > 0 && (rc = dmalloc(&d->allocs, &p.spare, (size_t)p.spare_bytes))) {
+      if (cfg->spare_pool_bytes >= 0) return rc;
+      (void)hipGetLastError(); p.spare = nullptr; p.spare_bytes = p.spare_bytes >= (64ll << 20) ? p.spare_bytes / 2 : 0;
+    }
     if ((rc = dmalloc(&d->allocs, &p.spare_used, 1))) return rc;
     K3_HIP_CHECK(hipMemset(p.spare_used, 0, sizeof(unsigned long long)));
   }

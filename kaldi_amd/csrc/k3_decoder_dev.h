@@ -453,8 +453,13 @@ __device__ __forceinline__ bool grow_lane_pools(const DecParams &p, int L, LaneP
     const unsigned long long bytes = 4 * bt + bl4 + bl16;
     np.tcap = -1;
     if (p.spare && nt < (1ll << 31)) {
-      const unsigned long long off = __hip_atomic_fetch_add(p.spare_used, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (off + bytes <= (unsigned long long)p.spare_bytes) {
+      // reserve with a compare-and-swap: a request that does not fit leaves the cursor where it was, so a later, smaller growth of another lane still succeeds
+      // (a fetch-add before the capacity check pushed the cursor past the arena for good)
+      unsigned long long off = __hip_atomic_load(p.spare_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bool got = false;
+      while (off + bytes <= (unsigned long long)p.spare_bytes) {
+        if (__hip_atomic_compare_exchange_strong(p.spare_used, &off, off + bytes, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = true; break; }
+      }
+      if (got) {
         char *b = p.spare + off;
         np.links = reinterpret_cast<Link *>(b); b += bl16; np.tok_state = reinterpret_cast<int *>(b); b += bt; np.tok_cost = reinterpret_cast<unsigned *>(b); b += bt;
         np.tok_extra = reinterpret_cast<float *>(b); b += bt; np.newidx = reinterpret_cast<int *>(b); b += bt; np.link_arc = reinterpret_cast<int *>(b);

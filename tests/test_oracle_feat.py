@@ -1,6 +1,6 @@
 """Pins oracle/feat_oracle.c (the CPU restatement) against (a) the reference's HTK golden vectors and
 (b) outputs of the reference's own binaries (tests/golden/feat_golden.npz).  CPU only."""
-import numpy as np, pytest
+import os, numpy as np, pytest
 from oracle import feat_oracle as fo
 from tests import feat_cases as fc
 
@@ -117,3 +117,20 @@ def test_oracle_vs_reference_binary_on_256_and_1024_point_windows(name):
     assert got.shape == ref.shape
     tol = 5e-5 if kind == "fbank" else 2e-4
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+
+@pytest.mark.parametrize("name", sorted(fc.REF_CASES))
+def test_f64path_yardstick_is_pinned_three_ways(feat_golden, name):
+    """the GPU kernel's primary gate is its distance to oracle.feat_oracle.compute_features_f64path ("the exact value of the reference's formulas"), so
+    that yardstick must not be self-referential.  It is (a) the SAME source as the float32 restatement (oracle/feat_oracle_path.inc compiled with REAL = double),
+    whose float32 instantiation is pinned to the HTK vectors and to the reference binaries above; here additionally (b) within table rounding of the committed
+    all-float64 evaluation tests/golden/feat_truth64.npz (tables in double as well: another code path of the restatement) and (c) no further from the reference
+    BINARY's committed output than the float32 rounding noise measured when the fixture was made (fbank <= 1.1e-4, lifted cepstra <= 4e-4)."""
+    kind, kw, wkey = fc.REF_CASES[name]
+    o = fo.mfcc_opts(**kw) if kind == "mfcc" else fo.fbank_opts(**kw)
+    w = feat_golden[wkey].astype(np.float32)
+    exact = fo.compute_features_f64path(w, o)
+    t64 = np.load(os.path.join(os.path.dirname(__file__), "golden", "feat_truth64.npz"))["truth64_" + name]
+    assert exact.shape == t64.shape == feat_golden["ref_" + name].shape
+    assert np.abs(exact - t64).max() <= (3e-5 if kind == "fbank" else 2e-4), np.abs(exact - t64).max()      # float32 vs float64 TABLES only
+    assert np.abs(exact - feat_golden["ref_" + name]).max() <= (1.1e-4 if kind == "fbank" else 4e-4)
+    assert np.abs(exact - fo.compute_features(w, o)).max() <= (1.1e-4 if kind == "fbank" else 4.5e-4)
