@@ -54,9 +54,11 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     K3H_CHECK_K3(k3_decoder_create(fst_, &config_.decoder_opts, nch_, N_, &dec_));
     K3H_CHECK_K3(k3_decoder_init_decoding(dec_, nch_, config_.max_utterance_frames, nullptr));
     const int s = config_.frame_subsampling_factor; C_ = std::max(s, config_.frames_per_chunk / s * s);
-    features_.reset(new OnlineFeatures(plan_, config_.feature_opts, nch_));
-    net_.reset(new StaticNnet3(am_nnet, nch_, nch_, C_, s, lp.empty() ? nullptr : lp.data(), config_.acoustic_scale));
-    if (ivx_) ivs_.reset(new OnlineIvectors(ivx_, iv_info_.right_context, nch_));
+    // one work stream for everything DecodeBatch queues, fed from page-locked staging rings: the host does not wait for the device inside a call (k3_online.h: DevBuf::upload_async)
+    K3O_HIP(hipStreamCreate(&ws_));
+    features_.reset(new OnlineFeatures(plan_, config_.feature_opts, nch_, ws_));
+    net_.reset(new StaticNnet3(am_nnet, nch_, nch_, C_, s, lp.empty() ? nullptr : lp.data(), config_.acoustic_scale, ws_));
+    if (ivx_) ivs_.reset(new OnlineIvectors(ivx_, iv_info_.right_context, nch_, ws_));
     samples_per_chunk_ = C_ * (int)(config_.feature_opts.samp_freq * 0.001 * config_.feature_opts.frame_shift_ms);
     pend_cap_ = (size_t)(2 * C_ + 8); for (auto &h : held_) h.need((size_t)nch_ * (pend_cap_ + (size_t)C_ + 16) * fdim_);      // (pending feature rows of all channels, compact; see DecodeBatch)
     chan_.resize(nch_); for (int c = nch_ - 1; c >= 0; c--) free_.push_back(c);
@@ -68,7 +70,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     { std::lock_guard<std::mutex> l(m_); stop_ = true; } wcv_.notify_all();
     for (auto &w : workers_) w.join();
     ivs_.reset(); if (ivx_) k3_ivector_destroy(ivx_);
-    net_.reset(); features_.reset(); k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
+    net_.reset(); features_.reset(); if (ws_) { (void)hipStreamSynchronize(ws_); (void)hipStreamDestroy(ws_); } k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
   }
   int32_t GetNSampsPerChunk() const { return samples_per_chunk_; }
   int32_t GetNInputFramesPerChunk() const { return C_; }
@@ -95,14 +97,14 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
       chs[i] = it->second; first[i] = is_first_chunk[i]; last[i] = is_last_chunk[i];
     }
     std::vector<int32_t> fresh; for (size_t i = 0; i < n; i++) if (first[i]) { fresh.push_back(chs[i]); net_->Reset(chs[i]); chan_[chs[i]] = Chan(); }
-    if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec_, fresh.data(), (int32_t)fresh.size(), nullptr));
+    if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec_, fresh.data(), (int32_t)fresh.size(), ws_));
     float *d_feats = nullptr; const std::vector<int> nf = features_->ComputeFeaturesBatched(chs, wave_samples, first, &d_feats);
     // Feature rows a channel has computed but not yet fed to the network live compactly in one device buffer, channel after channel, (offset, count) on the host, at most two segments
     // per channel (leftover + this call's rows).  A pass takes its rows with one row gather and the leftovers of all channels move to the other buffer with one more, once per call:
     // per-channel buffers cost ~4 synchronous device copies per channel and call (40 k copies in a 512-channel run of 10 s files, half of its GPU time).
     { int64_t off = 0, tot = 0; for (int k : nf) tot += k;
       if ((size_t)(held_rows_ + tot) * fdim_ > held_[held_cur_].cap) K3H_ERR << "DecodeBatch: pending-frame buffer exceeded";
-      if (tot > 0) K3O_HIP(hipMemcpyAsync(held_[held_cur_].p + (size_t)held_rows_ * fdim_, d_feats, (size_t)tot * fdim_ * 4, hipMemcpyDeviceToDevice, nullptr));
+      if (tot > 0) K3O_HIP(hipMemcpyAsync(held_[held_cur_].p + (size_t)held_rows_ * fdim_, d_feats, (size_t)tot * fdim_ * 4, hipMemcpyDeviceToDevice, ws_));
       for (size_t i = 0; i < n; i++) { Chan &c = chan_[chs[i]]; if ((size_t)(c.pend + nf[i]) > pend_cap_) K3H_ERR << "DecodeBatch: a chunk longer than GetNSampsPerChunk() samples";
         if (c.seg_cnt[1] != 0) K3H_ERR << "DecodeBatch: internal: pending rows not compacted";
         c.seg_off[1] = held_rows_ + off; c.seg_cnt[1] = nf[i]; c.pend += nf[i]; c.frames += nf[i]; off += nf[i]; } }
@@ -121,7 +123,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
           for (int sgm = 0; sgm < 2 && k > 0; sgm++) { const int m = std::min(k, c.seg_cnt[sgm]); for (int j = 0; j < m; j++) take.push_back((int32_t)(c.seg_off[sgm] + j)); c.seg_off[sgm] += m; c.seg_cnt[sgm] -= m; k -= m; c.pend -= m; }
           const bool end = is_last[run[i]] && c.pend == 0; lasts.push_back(end); if (end) closed[run[i]] = 1;
         }
-        if (!take.empty()) { gidx_.upload(take); K3H_CHECK_K3(k3_mat_copy_rows(new_.p, fdim_, (int32_t)take.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, nullptr)); } }
+        if (!take.empty()) { gidx_.upload_async(take, ws_); K3H_CHECK_K3(k3_mat_copy_rows(new_.p, fdim_, (int32_t)take.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, ws_)); } }
       std::vector<int64_t> ro(nch_ + 1, 0); std::vector<int32_t> idx;
       if (!run.empty()) {
         auto res = net_->Pass(run, new_.p, n_new, lasts, ivs_ ? ivs_->Gather(run) : nullptr);
@@ -129,8 +131,8 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
         for (int ch = 0; ch < nch_; ch++) { int64_t k = 0; for (auto &r : per[ch]) { for (int j = 0; j < r.second; j++) idx.push_back(r.first + j); k += r.second; } ro[ch + 1] = ro[ch] + k; }
       }
       ll_.need(std::max<size_t>(idx.size(), 1) * N_);
-      if (!idx.empty()) { llidx_.upload(idx); K3H_CHECK_K3(k3_mat_copy_rows(ll_.p, N_, (int32_t)idx.size(), N_, net_->Out(), N_, llidx_.p, nullptr)); }
-      K3H_CHECK_K3(k3_decoder_advance_decoding(dec_, nch_, ll_.p, N_, ro.data(), nullptr));
+      if (!idx.empty()) { llidx_.upload_async(idx, ws_); K3H_CHECK_K3(k3_mat_copy_rows(ll_.p, N_, (int32_t)idx.size(), N_, net_->Out(), N_, llidx_.p, ws_)); }
+      K3H_CHECK_K3(k3_decoder_advance_decoding(dec_, nch_, ll_.p, N_, ro.data(), ws_));
       need_advance = false;
       for (int ch : run) if (closed[ch] && net_->Pending(ch)) closed[ch] = 0;
     }
@@ -141,7 +143,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
         for (int sgm = 0; sgm < 2; sgm++) for (int j = 0; j < c.seg_cnt[sgm]; j++) keep.push_back((int32_t)(c.seg_off[sgm] + j));
         c.seg_off[0] = at; c.seg_cnt[0] = k; c.seg_off[1] = 0; c.seg_cnt[1] = 0; at += k;
       }
-      if (!keep.empty()) { gidx_.upload(keep); K3H_CHECK_K3(k3_mat_copy_rows(held_[held_cur_ ^ 1].p, fdim_, (int32_t)keep.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, nullptr)); }
+      if (!keep.empty()) { gidx_.upload_async(keep, ws_); K3H_CHECK_K3(k3_mat_copy_rows(held_[held_cur_ ^ 1].p, fdim_, (int32_t)keep.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, ws_)); }
       held_cur_ ^= 1; held_rows_ = at;
     }
     // partial hypotheses / end-pointing / best-path callbacks (cuda-decoder.cc:1864-2003) from the tokens the channels hold now
@@ -162,7 +164,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     // streams that ended: finalise their channels, hand the raw lattices to the workers, free the channels (:560-640)
     std::vector<int32_t> ended; std::vector<CorrelationID> ended_ids; for (size_t i = 0; i < n; i++) if (last[i]) { ended.push_back(chs[i]); ended_ids.push_back(corr_ids[i]); }
     if (ended.empty()) return;
-    K3H_CHECK_K3(k3_decoder_finalize_channels(dec_, ended.data(), (int32_t)ended.size(), nullptr));
+    K3H_CHECK_K3(k3_decoder_finalize_channels(dec_, ended.data(), (int32_t)ended.size(), ws_));
     const int U = (int)ended.size(); std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec_, info.data());
     int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
     std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
@@ -202,7 +204,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     }
   }
   const BatchedThreadedNnet3CudaOnlinePipelineConfig config_; const TransitionInfo &trans_;
-  k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0; int32_t graph_start_ = 0; size_t pend_cap_ = 0;
+  hipStream_t ws_ = nullptr; k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0; int32_t graph_start_ = 0; size_t pend_cap_ = 0;
   std::unique_ptr<OnlineFeatures> features_; std::unique_ptr<StaticNnet3> net_; std::unique_ptr<OnlineIvectors> ivs_; k3_ivector *ivx_ = nullptr; IvectorExtractionInfo iv_info_;
   std::vector<Chan> chan_; DevBuf<float> held_[2], new_, ll_; DevBuf<int32_t> llidx_, gidx_; int held_cur_ = 0; int64_t held_rows_ = 0;
   std::mutex m_; std::condition_variable wcv_, done_cv_; bool stop_ = false; int n_callbacks_not_done_ = 0;

@@ -895,8 +895,15 @@ struct k3_decoder {
   bool started = false, finalized = false;
   bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_tp = nullptr; bool ev_tp_recorded = false;      // recorded behind every token-passing launch: the last reader of the caller's log-likelihoods (k3_decoder_stream_wait_token_passing)
+  // Per-call arguments of AdvanceDecoding (row offsets, per-lane frame pointers, "fresh" flags): a ring of slots, each a page-locked host block + its device copy + an event recorded
+  // behind the launch that reads it.  The call fills a slot, copies it asynchronously on the caller's stream and returns: no hipStreamSynchronize + synchronous hipMemcpy per chunk
+  // (round 4: a streaming round of 17 frames paid a stream drain and three blocking copies).  A slot is reused kArgSlots calls later, after its event.
+  static constexpr int kArgSlots = 4;
+  struct ArgSlot { char *h = nullptr, *d = nullptr; hipEvent_t ev = nullptr; bool used = false; };
+  ArgSlot arg[kArgSlots]; unsigned arg_seq = 0; size_t arg_off_rows = 0, arg_off_fresh = 0, arg_bytes = 0;
 
-  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); if (ev_tp) (void)hipEventDestroy(ev_tp); if (out_buf) (void)hipFree(out_buf); }
+  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); if (ev_tp) (void)hipEventDestroy(ev_tp); if (out_buf) (void)hipFree(out_buf);
+                 for (ArgSlot &a : arg) { if (a.h) (void)hipHostFree(a.h); if (a.d) (void)hipFree(a.d); if (a.ev) (void)hipEventDestroy(a.ev); } }
 };
 
 extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
@@ -971,6 +978,11 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   K3_HIP_CHECK(hipMemset(p.prof, 0, nl * 16 * sizeof(long long)));
   if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
   if ((rc = dmalloc(&d->allocs, &d->d_fresh, nl))) return rc;
+  d->arg_off_rows = align_up(sizeof(long long) * (nl + 1), 16); d->arg_off_fresh = d->arg_off_rows + align_up(sizeof(float *) * nl, 16); d->arg_bytes = d->arg_off_fresh + align_up(sizeof(int) * nl, 16);
+  for (k3_decoder::ArgSlot &a : d->arg) {
+    K3_HIP_CHECK(hipHostMalloc((void **)&a.h, d->arg_bytes, hipHostMallocDefault)); K3_HIP_CHECK(hipMalloc((void **)&a.d, d->arg_bytes));
+    K3_HIP_CHECK(hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
+  }
   if ((rc = dmalloc(&d->allocs, &d->d_lane_ids, nl))) return rc;
   p.live_cap = (int)std::min<long long>(cfg->lane_tokens_cap, 1 << 18);
   if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
@@ -1078,11 +1090,12 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
     K3_REQUIRE(T == 0 || !d->lane_final[u], "k3_decoder_advance_decoding: frames for a finalised lane (k3_decoder_init_channels restarts it)");
   }
   for (int u = 0; u < num_utts; u++) d->last_frames[u] += (int)(h_row_off[u + 1] - h_row_off[u]);      // state changes only after every check passed
-  K3_HIP_CHECK(hipStreamSynchronize(st));            // d_row_off may still be read by the previous chunk's kernel
-  K3_HIP_CHECK(hipMemcpy(d->d_row_off, h_row_off, sizeof(long long) * (num_utts + 1), hipMemcpyHostToDevice));
-  K3_HIP_CHECK(hipMemcpy(d->d_fresh, d->fresh.data(), sizeof(int) * num_utts, hipMemcpyHostToDevice));
+  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq++ % k3_decoder::kArgSlots];
+  if (slot.used) K3_HIP_CHECK(hipEventSynchronize(slot.ev));      // (the launch of kArgSlots calls ago: long finished)
+  memcpy(slot.h, h_row_off, sizeof(long long) * (num_utts + 1)); memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * num_utts);
+  K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
   std::fill(d->fresh.begin(), d->fresh.end(), 0);
-  p.loglikes = d_loglikes; p.ld = ld; p.row_off = d->d_row_off; p.fresh = d->d_fresh; p.lane_ids = nullptr; p.lane_rows = nullptr;
+  p.loglikes = d_loglikes; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr; p.lane_rows = nullptr;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   if (p.literal) k3_lit_forward_launch(&p, sizeof(p), num_utts, st);
@@ -1091,6 +1104,7 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
   if (!d->ev_tp) K3_HIP_CHECK(hipEventCreateWithFlags(&d->ev_tp, hipEventDisableTiming));
   K3_HIP_CHECK(hipEventRecord(d->ev_tp, st)); d->ev_tp_recorded = true;
+  K3_HIP_CHECK(hipEventRecord(slot.ev, st)); slot.used = true;
   d->started = true; d->last_stream = st; d->info_valid = false;
   return K3_OK;
 }
@@ -1108,13 +1122,13 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
     T[c] = num_frames; rows[c] = h_lane_frames[i];
   }
   for (int u = 0; u < U; u++) { ro[u + 1] = ro[u] + T[u]; d->last_frames[u] += T[u]; }
-  K3_HIP_CHECK(hipStreamSynchronize(st));
-  if (!d->d_lane_rows) { int rc = dmalloc(&d->allocs, &d->d_lane_rows, (size_t)d->nlanes); if (rc) return rc; }
-  K3_HIP_CHECK(hipMemcpy(d->d_row_off, ro.data(), sizeof(long long) * (U + 1), hipMemcpyHostToDevice));
-  K3_HIP_CHECK(hipMemcpy(d->d_lane_rows, rows.data(), sizeof(float *) * U, hipMemcpyHostToDevice));
-  K3_HIP_CHECK(hipMemcpy(d->d_fresh, d->fresh.data(), sizeof(int) * U, hipMemcpyHostToDevice));
+  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq++ % k3_decoder::kArgSlots];
+  if (slot.used) K3_HIP_CHECK(hipEventSynchronize(slot.ev));
+  memcpy(slot.h, ro.data(), sizeof(long long) * (U + 1)); memcpy(slot.h + d->arg_off_rows, rows.data(), sizeof(float *) * U); memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * U);
+  K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
   std::fill(d->fresh.begin(), d->fresh.end(), 0);
-  p.loglikes = nullptr; p.ld = ld; p.row_off = d->d_row_off; p.fresh = d->d_fresh; p.lane_ids = nullptr; p.lane_rows = d->d_lane_rows;
+  p.loglikes = nullptr; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr;
+  p.lane_rows = reinterpret_cast<const float **>(slot.d + d->arg_off_rows);
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   if (p.literal) k3_lit_forward_launch(&p, sizeof(p), U, st);
@@ -1123,6 +1137,7 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
   if (!d->ev_tp) K3_HIP_CHECK(hipEventCreateWithFlags(&d->ev_tp, hipEventDisableTiming));
   K3_HIP_CHECK(hipEventRecord(d->ev_tp, st)); d->ev_tp_recorded = true;
+  K3_HIP_CHECK(hipEventRecord(slot.ev, st)); slot.used = true;
   d->started = true; d->last_stream = st; d->info_valid = false;
   return K3_OK;
 }

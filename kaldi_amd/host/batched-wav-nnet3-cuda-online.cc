@@ -97,9 +97,13 @@ int main(int argc, char **argv) {
     const int nch = num_channels, N = ninfo.output_dim, C = frames_per_chunk / subsampling * subsampling > 0 ? frames_per_chunk / subsampling * subsampling : subsampling;
     k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, nch, N, &dec));
     K3H_CHECK_K3(k3_decoder_init_decoding(dec, nch, max_frames, nullptr));
-    OnlineFeatures features(plan, fopts, nch);
-    StaticNnet3 net(nnet, nch, nch, C, subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale);
-    std::unique_ptr<OnlineIvectors> ivs; if (ivx) ivs.reset(new OnlineIvectors(ivx, iv_info.right_context, nch));
+    // ONE work stream for everything a round queues -- sample copy, features, row gathers, network, token passing -- fed from page-locked staging rings (DevBuf::upload_async,
+    // k3_decoder_advance_decoding's argument ring): the host never waits for the device inside a round, so it prepares round k + 1 while the GPU runs round k; it only
+    // synchronises where a stream ends and its lattice is fetched.  (A blocking stream: ordered with the few null-stream calls the C ABI still makes when lattices are fetched.)
+    hipStream_t ws = nullptr; K3O_HIP(hipStreamCreate(&ws));
+    OnlineFeatures features(plan, fopts, nch, ws);
+    StaticNnet3 net(nnet, nch, nch, C, subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, ws);
+    std::unique_ptr<OnlineIvectors> ivs; if (ivx) ivs.reset(new OnlineIvectors(ivx, iv_info.right_context, nch, ws));
     const int shift = (int)(fopts.samp_freq * 0.001 * fopts.frame_shift_ms), chunk_samples = C * shift;
 
     auto scp = ReadScp(wav_rspec);
@@ -142,20 +146,20 @@ int main(int argc, char **argv) {
         }
         if (busy == 0) break;
         // one chunk of audio per busy channel
-        std::vector<int> chs; std::vector<std::vector<float>> chunks; std::vector<char> first, last;
+        std::vector<int> chs; std::vector<const float *> chunk_ptr; std::vector<size_t> chunk_len; std::vector<char> first, last;
         for (int ch = 0; ch < nch; ch++) {
           Chan &c = chan[ch]; if (c.utt < 0) continue;
           const size_t n = std::min<size_t>(chunk_samples, c.wav.samples.size() - c.pos);
-          chs.push_back(ch); chunks.emplace_back(c.wav.samples.begin() + c.pos, c.wav.samples.begin() + c.pos + n);
+          chs.push_back(ch); chunk_ptr.push_back(c.wav.samples.data() + c.pos); chunk_len.push_back(n);      // (the chunk is read where it lies: no copy out of the waveform)
           first.push_back(c.pos == 0); c.pos += n; last.push_back(c.pos == c.wav.samples.size());
         }
         std::vector<int32_t> fresh; for (size_t i = 0; i < chs.size(); i++) if (first[i]) { fresh.push_back(chs[i]); net.Reset(chs[i]); }
-        if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec, fresh.data(), (int32_t)fresh.size(), nullptr));
+        if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec, fresh.data(), (int32_t)fresh.size(), ws));
         float *d_feats = nullptr;
-        const std::vector<int> nf = features.ComputeFeaturesBatched(chs, chunks, first, &d_feats);
+        const std::vector<int> nf = features.ComputeFeaturesBatched(chs, chunk_ptr.data(), chunk_len.data(), first, &d_feats);
         { int64_t off = 0, tot = 0; for (int n : nf) tot += n;
           if ((size_t)(held_rows + tot) * fdim > held[held_cur].cap) K3H_ERR << "internal: pending-frame buffer";
-          if (tot > 0) K3O_HIP(hipMemcpyAsync(held[held_cur].p + (size_t)held_rows * fdim, d_feats, (size_t)tot * fdim * 4, hipMemcpyDeviceToDevice, nullptr));      // the round's new rows behind the leftovers
+          if (tot > 0) K3O_HIP(hipMemcpyAsync(held[held_cur].p + (size_t)held_rows * fdim, d_feats, (size_t)tot * fdim * 4, hipMemcpyDeviceToDevice, ws));      // the round's new rows behind the leftovers
           for (size_t i = 0; i < chs.size(); i++) {
             Chan &c = chan[chs[i]];
             if ((size_t)(c.pend + nf[i]) > pend_cap) K3H_ERR << "internal: pending-frame buffer";
@@ -179,7 +183,7 @@ int main(int argc, char **argv) {
               const bool end = is_last[run[i]] && c.pend == 0; lasts.push_back(end); if (end) closed[run[i]] = 1;
               c.started = true;
             }
-            if (!take.empty()) { gidx.upload(take); K3H_CHECK_K3(k3_mat_copy_rows(newbuf.p, fdim, (int32_t)take.size(), fdim, held[held_cur].p, fdim, gidx.p, nullptr)); } }
+            if (!take.empty()) { gidx.upload_async(take, ws); K3H_CHECK_K3(k3_mat_copy_rows(newbuf.p, fdim, (int32_t)take.size(), fdim, held[held_cur].p, fdim, gidx.p, ws)); } }
           std::vector<int64_t> ro(nch + 1, 0); std::vector<int32_t> idx;
           if (!run.empty()) {
             auto res = net.Pass(run, newbuf.p, n_new, lasts, ivs ? ivs->Gather(run) : nullptr);
@@ -188,8 +192,8 @@ int main(int argc, char **argv) {
             for (int ch = 0; ch < nch; ch++) { int64_t n = 0; for (auto &r : per[ch]) { for (int k = 0; k < r.second; k++) idx.push_back(r.first + k); n += r.second; } ro[ch + 1] = ro[ch] + n; }
           }
           ll.need((size_t)std::max<size_t>(idx.size(), 1) * N);
-          if (!idx.empty()) { llidx.upload(idx); K3H_CHECK_K3(k3_mat_copy_rows(ll.p, N, (int32_t)idx.size(), N, net.Out(), N, llidx.p, nullptr)); }
-          K3H_CHECK_K3(k3_decoder_advance_decoding(dec, nch, ll.p, N, ro.data(), nullptr));
+          if (!idx.empty()) { llidx.upload_async(idx, ws); K3H_CHECK_K3(k3_mat_copy_rows(ll.p, N, (int32_t)idx.size(), N, net.Out(), N, llidx.p, ws)); }
+          K3H_CHECK_K3(k3_decoder_advance_decoding(dec, nch, ll.p, N, ro.data(), ws));
           need_advance = false;
           // flush passes for closed channels whose last outputs did not fit one pass
           for (int ch : run) if (closed[ch] && net.Pending(ch)) { closed[ch] = 0; }      // stays in `run` candidates: is_last and pend == 0 -> another (empty-input) pass
@@ -201,13 +205,13 @@ int main(int argc, char **argv) {
             const int n = c.pend; for (int sgm = 0; sgm < 2; sgm++) for (int j = 0; j < c.seg_cnt[sgm]; j++) keep.push_back((int32_t)(c.seg_off[sgm] + j));
             c.seg_off[0] = at; c.seg_cnt[0] = n; c.seg_off[1] = 0; c.seg_cnt[1] = 0; at += n;
           }
-          if (!keep.empty()) { gidx.upload(keep); K3H_CHECK_K3(k3_mat_copy_rows(held[held_cur ^ 1].p, fdim, (int32_t)keep.size(), fdim, held[held_cur].p, fdim, gidx.p, nullptr)); }
+          if (!keep.empty()) { gidx.upload_async(keep, ws); K3H_CHECK_K3(k3_mat_copy_rows(held[held_cur ^ 1].p, fdim, (int32_t)keep.size(), fdim, held[held_cur].p, fdim, gidx.p, ws)); }
           held_cur ^= 1; held_rows = at;
         }
         // finalise the channels whose stream ended, write their lattices, free the channels
         std::vector<int32_t> ended; for (size_t i = 0; i < chs.size(); i++) if (last[i]) ended.push_back(chs[i]);
         if (!ended.empty()) {
-          K3H_CHECK_K3(k3_decoder_finalize_channels(dec, ended.data(), (int32_t)ended.size(), nullptr));
+          K3H_CHECK_K3(k3_decoder_finalize_channels(dec, ended.data(), (int32_t)ended.size(), ws));
           const int U = (int)ended.size();
           std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec, info.data());
           int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
@@ -241,6 +245,7 @@ int main(int argc, char **argv) {
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
     K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio << " RealTimeX: " << total_audio / total_time;
     ivs.reset(); if (ivx) k3_ivector_destroy(ivx);
+    (void)hipStreamDestroy(ws);
     k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan);
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }

@@ -14,9 +14,30 @@ namespace k3host {
 
 template <class T> struct DevBuf {          // grow-only device array
   T *p = nullptr; size_t cap = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  T *need(size_t n) { if (n > cap) { if (p) (void)hipFree(p); cap = n + n / 2 + 64; K3O_HIP(hipMalloc((void **)&p, cap * sizeof(T))); } return p; }
+  ~DevBuf() { if (p) (void)hipFree(p); for (Stage &g : stage_) { if (g.p) (void)hipHostFree(g.p); if (g.ev) (void)hipEventDestroy(g.ev); } }
+  T *need(size_t n) { if (n > cap) { if (p) (void)hipFree(p); cap = n + n / 2 + 64; K3O_HIP(hipMalloc((void **)&p, cap * sizeof(T))); } return p; }      // (hipFree waits for the device: no kernel still reads the old block)
   void upload(const std::vector<T> &h) { need(std::max<size_t>(h.size(), 1)); if (!h.empty()) K3O_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+  // The streaming path's form: the host never waits for the device.  begin_upload(n) hands out a page-locked staging block to fill (a ring of kStages blocks, each guarded by an
+  // event recorded behind its copy, so a block is only waited for when the host is kStages uploads ahead of the device); end_upload queues the copy on `st`, behind whatever on that
+  // stream still reads the device block (every chunk round of the streaming programs paid ~10 blocking pageable copies on the null stream).
+  T *begin_upload(size_t n) {
+    Stage &g = stage_[seq_ % kStages];
+    if (g.used) K3O_HIP(hipEventSynchronize(g.ev));
+    if (n > g.cap) { if (g.p) (void)hipHostFree(g.p); g.cap = n + n / 2 + 64; K3O_HIP(hipHostMalloc((void **)&g.p, g.cap * sizeof(T), hipHostMallocDefault)); }
+    return g.p;
+  }
+  void end_upload(size_t n, hipStream_t st) {
+    Stage &g = stage_[seq_++ % kStages]; need(std::max<size_t>(n, 1));
+    if (n == 0) return;
+    K3O_HIP(hipMemcpyAsync(p, g.p, n * sizeof(T), hipMemcpyHostToDevice, st));
+    if (!g.ev) K3O_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+    K3O_HIP(hipEventRecord(g.ev, st)); g.used = true;
+  }
+  void upload_async(const std::vector<T> &h, hipStream_t st) { T *dst = begin_upload(h.size()); if (!h.empty()) memcpy(dst, h.data(), h.size() * sizeof(T)); end_upload(h.size(), st); }
+ private:
+  static constexpr int kStages = 4;
+  struct Stage { T *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+  Stage stage_[kStages]; unsigned seq_ = 0;
 };
 
 template <class T> struct PinnedBuf {       // grow-only page-locked host array (staging for asynchronous copies)
@@ -27,39 +48,52 @@ template <class T> struct PinnedBuf {       // grow-only page-locked host array 
 
 class OnlineFeatures {
  public:
-  OnlineFeatures(k3_feat_plan *plan, const k3_feat_opts &o, int num_channels) : plan_(plan), dim_(k3_feat_dim(plan)), stash_(num_channels) {
+  OnlineFeatures(k3_feat_plan *plan, const k3_feat_opts &o, int num_channels, hipStream_t stream = nullptr) : plan_(plan), dim_(k3_feat_dim(plan)), stash_(num_channels), stream_(stream) {
     if (!o.snip_edges) K3H_ERR << "streaming features need --snip-edges=true";
     shift_ = (int)(o.samp_freq * 0.001 * o.frame_shift_ms);
   }
   int Dim() const { return dim_; }
   // chunks[i]: new samples of channels[i]; returns the number of new frames per slot, rows back to back in d_feats (device, dim wide)
   std::vector<int> ComputeFeaturesBatched(const std::vector<int> &channels, const std::vector<std::vector<float>> &chunks, const std::vector<char> &first, float **d_feats) {
-    std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int> nf(channels.size());
+    std::vector<const float *> ptr(chunks.size()); std::vector<size_t> len(chunks.size());
+    for (size_t i = 0; i < chunks.size(); i++) { ptr[i] = chunks[i].data(); len[i] = chunks[i].size(); }
+    return ComputeFeaturesBatched(channels, ptr.data(), len.data(), first, d_feats);
+  }
+  // the same over (pointer, length) pairs: a caller that holds the whole waveform does not copy its chunks out first.  The samples of a slot -- what the channel stashed for the
+  // frame overlap, then the chunk -- go straight into the page-locked staging block of the waveform buffer and travel asynchronously on the work stream.
+  std::vector<int> ComputeFeaturesBatched(const std::vector<int> &channels, const float *const *chunk, const size_t *chunk_len, const std::vector<char> &first, float **d_feats) {
+    std::vector<int64_t> woff(1, 0), foff(1, 0); std::vector<int> nf(channels.size());
     for (size_t i = 0; i < channels.size(); i++) {
-      std::vector<float> &st = stash_[channels[i]];
-      if (first[i]) st.clear();
-      st.insert(st.end(), chunks[i].begin(), chunks[i].end());
-      nf[i] = k3_feat_num_frames(plan_, (int64_t)st.size());
-      all.insert(all.end(), st.begin(), st.end()); woff.push_back((int64_t)all.size()); foff.push_back(foff.back() + nf[i]);
+      std::vector<float> &st = stash_[channels[i]]; if (first[i]) st.clear();
+      const int64_t n = (int64_t)(st.size() + chunk_len[i]); nf[i] = k3_feat_num_frames(plan_, n);
+      woff.push_back(woff.back() + n); foff.push_back(foff.back() + nf[i]);
     }
     const int64_t tot = foff.back();
     *d_feats = feats_.need((size_t)std::max<int64_t>(tot, 1) * dim_);
-    if (tot > 0) {
-      waves_.upload(all); woff_.upload(woff); foff_.upload(foff);
-      K3H_CHECK_K3(k3_feat_compute_batch(plan_, waves_.p, woff_.p, foff_.p, (int32_t)channels.size(), tot, feats_.p, dim_, nullptr));
+    float *all = waves_.begin_upload((size_t)woff.back());
+    for (size_t i = 0; i < channels.size(); i++) {
+      std::vector<float> &st = stash_[channels[i]]; float *dst = all + woff[i];
+      if (!st.empty()) memcpy(dst, st.data(), st.size() * sizeof(float));
+      if (chunk_len[i]) memcpy(dst + st.size(), chunk[i], chunk_len[i] * sizeof(float));
+      // what the next call still needs: the samples behind the last frame's shift
+      const size_t n = st.size() + chunk_len[i], used = std::min<size_t>(n, (size_t)nf[i] * shift_);
+      std::vector<float> rest(dst + used, dst + n); st.swap(rest);
     }
-    for (size_t i = 0; i < channels.size(); i++) { std::vector<float> &st = stash_[channels[i]]; st.erase(st.begin(), st.begin() + std::min<size_t>(st.size(), (size_t)nf[i] * shift_)); }
+    if (tot > 0) {
+      waves_.end_upload((size_t)woff.back(), stream_); woff_.upload_async(woff, stream_); foff_.upload_async(foff, stream_);
+      K3H_CHECK_K3(k3_feat_compute_batch(plan_, waves_.p, woff_.p, foff_.p, (int32_t)channels.size(), tot, feats_.p, dim_, stream_));
+    } else waves_.end_upload(0, stream_);
     return nf;
   }
  private:
-  k3_feat_plan *plan_; int dim_, shift_; std::vector<std::vector<float>> stash_;
+  k3_feat_plan *plan_; int dim_, shift_; std::vector<std::vector<float>> stash_; hipStream_t stream_ = nullptr;
   DevBuf<float> waves_, feats_; DevBuf<int64_t> woff_, foff_;
 };
 
 class StaticNnet3 {
  public:
-  StaticNnet3(k3_nnet *nnet, int max_batch, int nchannels, int frames_per_chunk, int subsampling, const float *log_priors, float acoustic_scale)
-      : B_(max_batch), nch_(nchannels), C_(frames_per_chunk), s_(subsampling) {
+  StaticNnet3(k3_nnet *nnet, int max_batch, int nchannels, int frames_per_chunk, int subsampling, const float *log_priors, float acoustic_scale, hipStream_t stream = nullptr)
+      : stream_(stream), B_(max_batch), nch_(nchannels), C_(frames_per_chunk), s_(subsampling) {
     if (C_ <= 0 || C_ % s_) K3H_ERR << "--frames-per-chunk must be a positive multiple of --frame-subsampling-factor";
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
     dim_ = ni.input_dim; odim_ = ni.output_dim; Lc_ = (ni.left_context + s_ - 1) / s_ * s_; Rc_ = ni.right_context; P_ = Lc_ + C_ + Rc_; rps_ = (P_ + s_ - 1) / s_; S_ = Lc_ + Rc_ + C_ + 2 * s_;
@@ -67,7 +101,7 @@ class StaticNnet3 {
     // models with the recipes' i-vector input: every slot is an "utterance" with ONE i-vector (the --ivectors form of the planner), handed in per pass
     if (ivdim_ > 0) { K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, B_, nf.data(), s_, log_priors, acoustic_scale, C_, 0, nullptr, &batch_)); iv_.need((size_t)B_ * ivdim_); }
     else K3H_CHECK_K3(k3_nnet_batch_create(nnet, B_, nf.data(), s_, log_priors, acoustic_scale, &batch_));
-    for (int k = 0; k < 2; k++) { stash_[k].need((size_t)nch_ * S_ * dim_); K3O_HIP(hipMemset(stash_[k].p, 0, (size_t)nch_ * S_ * dim_ * 4)); }
+    for (int k = 0; k < 2; k++) { stash_[k].need((size_t)nch_ * S_ * dim_); K3O_HIP(hipMemsetAsync(stash_[k].p, 0, (size_t)nch_ * S_ * dim_ * 4, stream_)); }
     inp_.need((size_t)B_ * P_ * dim_); out_.need((size_t)B_ * rps_ * odim_);
     t_next_.assign(nch_, 0); n_seen_.assign(nch_, 0); lo_.assign(nch_, 0);
   }
@@ -99,23 +133,23 @@ class StaticNnet3 {
       t_next_[ch] = tn2; n_seen_[ch] = avail; lo_[ch] = lo2; noff += n_new[i];
     }
     float *A = stash_[cur_].p, *Bn = stash_[cur_ ^ 1].p;
-    i0_.upload(ist); i1_.upload(inw); i2_.upload(ust); i3_.upload(unw);
-    K3H_CHECK_K3(k3_mat_copy_rows(inp_.p, dim_, B_ * P_, dim_, A, dim_, i0_.p, nullptr));
-    if (total_new > 0) K3H_CHECK_K3(k3_mat_add_rows(1.0f, d_new, dim_, i1_.p, inp_.p, dim_, B_ * P_, dim_, nullptr));
-    K3H_CHECK_K3(k3_mat_copy_rows(Bn, dim_, nch_ * S_, dim_, A, dim_, i2_.p, nullptr));
-    if (total_new > 0) K3H_CHECK_K3(k3_mat_add_rows(1.0f, d_new, dim_, i3_.p, Bn, dim_, nch_ * S_, dim_, nullptr));
+    i0_.upload_async(ist, stream_); i1_.upload_async(inw, stream_); i2_.upload_async(ust, stream_); i3_.upload_async(unw, stream_);      // (page-locked rings: the host does not wait)
+    K3H_CHECK_K3(k3_mat_copy_rows(inp_.p, dim_, B_ * P_, dim_, A, dim_, i0_.p, stream_));
+    if (total_new > 0) K3H_CHECK_K3(k3_mat_add_rows(1.0f, d_new, dim_, i1_.p, inp_.p, dim_, B_ * P_, dim_, stream_));
+    K3H_CHECK_K3(k3_mat_copy_rows(Bn, dim_, nch_ * S_, dim_, A, dim_, i2_.p, stream_));
+    if (total_new > 0) K3H_CHECK_K3(k3_mat_add_rows(1.0f, d_new, dim_, i3_.p, Bn, dim_, nch_ * S_, dim_, stream_));
     cur_ ^= 1;
     if (ivdim_ > 0) {
-      K3O_HIP(hipMemset(iv_.p, 0, (size_t)B_ * ivdim_ * 4)); K3O_HIP(hipMemcpy(iv_.p, d_iv, channels.size() * (size_t)ivdim_ * 4, hipMemcpyDeviceToDevice));
-      K3H_CHECK_K3(k3_nnet_forward_ivector(batch_, inp_.p, dim_, iv_.p, ivdim_, out_.p, odim_, nullptr));
-    } else K3H_CHECK_K3(k3_nnet_forward(batch_, inp_.p, dim_, out_.p, odim_, nullptr));
+      K3O_HIP(hipMemsetAsync(iv_.p, 0, (size_t)B_ * ivdim_ * 4, stream_)); K3O_HIP(hipMemcpyAsync(iv_.p, d_iv, channels.size() * (size_t)ivdim_ * 4, hipMemcpyDeviceToDevice, stream_));
+      K3H_CHECK_K3(k3_nnet_forward_ivector(batch_, inp_.p, dim_, iv_.p, ivdim_, out_.p, odim_, stream_));
+    } else K3H_CHECK_K3(k3_nnet_forward(batch_, inp_.p, dim_, out_.p, odim_, stream_));
     return res;
   }
   const float *Out() const { return out_.p; }
   bool Pending(int ch) const { return t_next_[ch] < n_seen_[ch]; }
   int IvectorDim() const { return ivdim_; }
  private:
-  int ivdim_ = 0; DevBuf<float> iv_;
+  hipStream_t stream_ = nullptr; int ivdim_ = 0; DevBuf<float> iv_;
   int B_, nch_, C_, s_, dim_ = 0, odim_ = 0, Lc_ = 0, Rc_ = 0, P_ = 0, rps_ = 0, S_ = 0, cur_ = 0;
   k3_nnet_batch *batch_ = nullptr;
   DevBuf<float> stash_[2], inp_, out_; DevBuf<int32_t> i0_, i1_, i2_, i3_;
@@ -143,16 +177,16 @@ inline k3_ivector *CreateIvectorExtractor(const IvectorExtractionInfo &iv_info, 
 // (k3_ivector_extract_batch: row k = statistics of frames 0 .. k * period), every frame processed once.
 class OnlineIvectors {
  public:
-  OnlineIvectors(k3_ivector *iv, int right_context, int nch) : iv_(iv), st_(nch, nullptr) {
+  OnlineIvectors(k3_ivector *iv, int right_context, int nch, hipStream_t stream = nullptr) : iv_(iv), st_(nch, nullptr), stream_(stream) {
     (void)right_context;      // (the extractor's own option; kept in the signature for its callers)
-    k3_ivector_info i; K3H_CHECK_K3(k3_ivector_get_info(iv, &i)); F_ = i.feat_dim; R_ = i.ivector_dim; latest_.need((size_t)nch * R_); K3O_HIP(hipMemset(latest_.p, 0, (size_t)nch * R_ * 4));
+    k3_ivector_info i; K3H_CHECK_K3(k3_ivector_get_info(iv, &i)); F_ = i.feat_dim; R_ = i.ivector_dim; latest_.need((size_t)nch * R_); K3O_HIP(hipMemsetAsync(latest_.p, 0, (size_t)nch * R_ * 4, stream_));
     for (auto &s : st_) K3H_CHECK_K3(k3_ivector_stream_create(iv_, &s));
   }
   int Dim() const { return R_; }
-  void Reset(int ch) { K3H_CHECK_K3(k3_ivector_stream_reset(st_[ch], nullptr)); K3O_HIP(hipMemset(latest_.p + (size_t)ch * R_, 0, (size_t)R_ * 4)); }
+  void Reset(int ch) { K3H_CHECK_K3(k3_ivector_stream_reset(st_[ch], stream_)); K3O_HIP(hipMemsetAsync(latest_.p + (size_t)ch * R_, 0, (size_t)R_ * 4, stream_)); }
   // n new feature rows of the channel (device, F_ wide, contiguous); finished: the stream's audio has ended.  Updates Row(ch).
   void Accept(int ch, const float *d_rows, int n, bool finished) {
-    K3H_CHECK_K3(k3_ivector_stream_accept(st_[ch], d_rows, F_, n, finished ? 1 : 0, nullptr, 0, 0, nullptr, latest_.p + (size_t)ch * R_, nullptr));      // queued on the null stream, like its consumers
+    K3H_CHECK_K3(k3_ivector_stream_accept(st_[ch], d_rows, F_, n, finished ? 1 : 0, nullptr, 0, 0, nullptr, latest_.p + (size_t)ch * R_, stream_));      // queued on the work stream, like its consumers
   }
   // the same for the channels of one batch, one launch per stage (k3_ivector_stream_accept_batch): channel channels[i] takes nf[i] rows of d_rows (back to back, F_ wide); first[i]: a
   // new stream takes the channel
@@ -161,18 +195,18 @@ class OnlineIvectors {
     std::vector<k3_ivector_stream *> st(n); std::vector<int64_t> off(n + 1, 0); std::vector<int32_t> fin(n);
     for (size_t i = 0; i < n; i++) { if (first[i]) Reset(channels[i]); st[i] = st_[channels[i]]; off[i + 1] = off[i] + nf[i]; fin[i] = last[i] ? 1 : 0; }
     float *tmp = batch_.need(n * R_);
-    K3H_CHECK_K3(k3_ivector_stream_accept_batch(st.data(), (int32_t)n, d_rows, F_, off.data(), fin.data(), tmp, R_, nullptr));
-    for (size_t i = 0; i < n; i++) K3O_HIP(hipMemcpyAsync(latest_.p + (size_t)channels[i] * R_, tmp + i * R_, (size_t)R_ * 4, hipMemcpyDeviceToDevice, nullptr));
+    K3H_CHECK_K3(k3_ivector_stream_accept_batch(st.data(), (int32_t)n, d_rows, F_, off.data(), fin.data(), tmp, R_, stream_));
+    for (size_t i = 0; i < n; i++) K3O_HIP(hipMemcpyAsync(latest_.p + (size_t)channels[i] * R_, tmp + i * R_, (size_t)R_ * 4, hipMemcpyDeviceToDevice, stream_));
   }
   const float *Row(int ch) const { return latest_.p + (size_t)ch * R_; }
   // the rows of the listed channels back to back (what StaticNnet3::Pass takes)
   const float *Gather(const std::vector<int> &channels) {
     float *g = gather_.need(std::max<size_t>(channels.size(), 1) * R_);
-    for (size_t i = 0; i < channels.size(); i++) K3O_HIP(hipMemcpy(g + i * R_, Row(channels[i]), (size_t)R_ * 4, hipMemcpyDeviceToDevice));
+    for (size_t i = 0; i < channels.size(); i++) K3O_HIP(hipMemcpyAsync(g + i * R_, Row(channels[i]), (size_t)R_ * 4, hipMemcpyDeviceToDevice, stream_));
     return g;
   }
   ~OnlineIvectors() { for (auto *s : st_) if (s) k3_ivector_stream_destroy(s); }
  private:
-  k3_ivector *iv_; int F_ = 0, R_ = 0; std::vector<k3_ivector_stream *> st_; DevBuf<float> latest_, gather_, batch_;
+  k3_ivector *iv_; int F_ = 0, R_ = 0; std::vector<k3_ivector_stream *> st_; hipStream_t stream_ = nullptr; DevBuf<float> latest_, gather_, batch_;
 };
 }  // namespace k3host
