@@ -56,6 +56,10 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     const int s = config_.frame_subsampling_factor; C_ = std::max(s, config_.frames_per_chunk / s * s);
     // one work stream for everything DecodeBatch queues, fed from page-locked staging rings: the host does not wait for the device inside a call (k3_online.h: DevBuf::upload_async)
     K3O_HIP(hipStreamCreate(&ws_));
+    // token passing on its own stream: a chunk's launch lasts as long as its slowest lane, the next pass's features / network run beside it; the two streams share only the
+    // gathered log-likelihood block (two of them, events ev_ll_: filled / ev_tp_: consumed)
+    K3O_HIP(hipStreamCreate(&ds_));
+    for (int k = 0; k < 2; k++) { K3O_HIP(hipEventCreateWithFlags(&ev_ll_[k], hipEventDisableTiming)); K3O_HIP(hipEventCreateWithFlags(&ev_tp_[k], hipEventDisableTiming)); }
     features_.reset(new OnlineFeatures(plan_, config_.feature_opts, nch_, ws_));
     net_.reset(new StaticNnet3(am_nnet, nch_, nch_, C_, s, lp.empty() ? nullptr : lp.data(), config_.acoustic_scale, ws_));
     if (ivx_) ivs_.reset(new OnlineIvectors(ivx_, iv_info_.right_context, nch_, ws_));
@@ -70,7 +74,8 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     { std::lock_guard<std::mutex> l(m_); stop_ = true; } wcv_.notify_all();
     for (auto &w : workers_) w.join();
     ivs_.reset(); if (ivx_) k3_ivector_destroy(ivx_);
-    net_.reset(); features_.reset(); if (ws_) { (void)hipStreamSynchronize(ws_); (void)hipStreamDestroy(ws_); } k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
+    net_.reset(); features_.reset(); if (ws_) { (void)hipStreamSynchronize(ws_); (void)hipStreamDestroy(ws_); } if (ds_) { (void)hipStreamSynchronize(ds_); (void)hipStreamDestroy(ds_); }
+    for (int k = 0; k < 2; k++) { if (ev_ll_[k]) (void)hipEventDestroy(ev_ll_[k]); if (ev_tp_[k]) (void)hipEventDestroy(ev_tp_[k]); } k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
   }
   int32_t GetNSampsPerChunk() const { return samples_per_chunk_; }
   int32_t GetNInputFramesPerChunk() const { return C_; }
@@ -97,7 +102,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
       chs[i] = it->second; first[i] = is_first_chunk[i]; last[i] = is_last_chunk[i];
     }
     std::vector<int32_t> fresh; for (size_t i = 0; i < n; i++) if (first[i]) { fresh.push_back(chs[i]); net_->Reset(chs[i]); chan_[chs[i]] = Chan(); }
-    if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec_, fresh.data(), (int32_t)fresh.size(), ws_));
+    if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec_, fresh.data(), (int32_t)fresh.size(), ds_));
     float *d_feats = nullptr; const std::vector<int> nf = features_->ComputeFeaturesBatched(chs, wave_samples, first, &d_feats);
     // Feature rows a channel has computed but not yet fed to the network live compactly in one device buffer, channel after channel, (offset, count) on the host, at most two segments
     // per channel (leftover + this call's rows).  A pass takes its rows with one row gather and the leftovers of all channels move to the other buffer with one more, once per call:
@@ -130,9 +135,13 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
         std::vector<std::vector<std::pair<int, int>>> per(nch_); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
         for (int ch = 0; ch < nch_; ch++) { int64_t k = 0; for (auto &r : per[ch]) { for (int j = 0; j < r.second; j++) idx.push_back(r.first + j); k += r.second; } ro[ch + 1] = ro[ch] + k; }
       }
-      ll_.need(std::max<size_t>(idx.size(), 1) * N_);
-      if (!idx.empty()) { llidx_.upload_async(idx, ws_); K3H_CHECK_K3(k3_mat_copy_rows(ll_.p, N_, (int32_t)idx.size(), N_, net_->Out(), N_, llidx_.p, ws_)); }
-      K3H_CHECK_K3(k3_decoder_advance_decoding(dec_, nch_, ll_.p, N_, ro.data(), ws_));
+      const int lb = (int)(pass_no_++ & 1); DevBuf<float> &llb = ll_[lb];
+      if (tp_used_[lb]) K3O_HIP(hipStreamWaitEvent(ws_, ev_tp_[lb], 0));      // the launch that read this block two passes ago
+      llb.need(std::max<size_t>(idx.size(), 1) * N_);
+      if (!idx.empty()) { llidx_.upload_async(idx, ws_); K3H_CHECK_K3(k3_mat_copy_rows(llb.p, N_, (int32_t)idx.size(), N_, net_->Out(), N_, llidx_.p, ws_)); }
+      K3O_HIP(hipEventRecord(ev_ll_[lb], ws_)); K3O_HIP(hipStreamWaitEvent(ds_, ev_ll_[lb], 0));
+      K3H_CHECK_K3(k3_decoder_advance_decoding(dec_, nch_, llb.p, N_, ro.data(), ds_));
+      K3O_HIP(hipEventRecord(ev_tp_[lb], ds_)); tp_used_[lb] = true;
       need_advance = false;
       for (int ch : run) if (closed[ch] && net_->Pending(ch)) closed[ch] = 0;
     }
@@ -164,7 +173,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     // streams that ended: finalise their channels, hand the raw lattices to the workers, free the channels (:560-640)
     std::vector<int32_t> ended; std::vector<CorrelationID> ended_ids; for (size_t i = 0; i < n; i++) if (last[i]) { ended.push_back(chs[i]); ended_ids.push_back(corr_ids[i]); }
     if (ended.empty()) return;
-    K3H_CHECK_K3(k3_decoder_finalize_channels(dec_, ended.data(), (int32_t)ended.size(), ws_));
+    K3H_CHECK_K3(k3_decoder_finalize_channels(dec_, ended.data(), (int32_t)ended.size(), ds_));
     const int U = (int)ended.size(); std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec_, info.data());
     int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
     std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
@@ -204,9 +213,9 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     }
   }
   const BatchedThreadedNnet3CudaOnlinePipelineConfig config_; const TransitionInfo &trans_;
-  hipStream_t ws_ = nullptr; k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0; int32_t graph_start_ = 0; size_t pend_cap_ = 0;
+  hipStream_t ws_ = nullptr, ds_ = nullptr; hipEvent_t ev_ll_[2] = {nullptr, nullptr}, ev_tp_[2] = {nullptr, nullptr}; bool tp_used_[2] = {false, false}; unsigned pass_no_ = 0; k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0; int32_t graph_start_ = 0; size_t pend_cap_ = 0;
   std::unique_ptr<OnlineFeatures> features_; std::unique_ptr<StaticNnet3> net_; std::unique_ptr<OnlineIvectors> ivs_; k3_ivector *ivx_ = nullptr; IvectorExtractionInfo iv_info_;
-  std::vector<Chan> chan_; DevBuf<float> held_[2], new_, ll_; DevBuf<int32_t> llidx_, gidx_; int held_cur_ = 0; int64_t held_rows_ = 0;
+  std::vector<Chan> chan_; DevBuf<float> held_[2], new_, ll_[2]; DevBuf<int32_t> llidx_, gidx_; int held_cur_ = 0; int64_t held_rows_ = 0;
   std::mutex m_; std::condition_variable wcv_, done_cv_; bool stop_ = false; int n_callbacks_not_done_ = 0;
   std::map<CorrelationID, int> corr2chan_; std::vector<int> free_; std::map<CorrelationID, LatticeCallback> lat_cb_; std::map<CorrelationID, BestPathCallback> best_cb_;
   std::deque<std::shared_ptr<Task>> post_; std::vector<std::thread> workers_;

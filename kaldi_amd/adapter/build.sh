@@ -74,6 +74,9 @@ echo "built $B/nnet3-compute"
 # the reference's training computation of one minibatch (NnetComputer forward in training mode + Backprop of every component into a gradient nnet) over the adapter
 link_with_trampolines nnet3-train-grad $ROOT/tests/adapter/nnet3_train_grad.cc
 echo "built $B/nnet3-train-grad"
+# the same training computation on several host threads at once (per-thread streams, thread-aware memory pool, shared index cache): tests/adapter/nnet3_two_threads.cc
+link_with_trampolines nnet3-two-threads $ROOT/tests/adapter/nnet3_two_threads.cc
+echo "built $B/nnet3-two-threads"
 # the gradient of the LF-MMI objective: the reference's NnetComputer over the adapter + k3_chain_objf_and_deriv on the adapter's device pointers
 FLAGS_SAVE="$FLAGS"; FLAGS="$FLAGS -DK3_ADAPTER -I $ROOT/include"
 link_with_trampolines nnet3-chain-grad $ROOT/tests/adapter/nnet3_chain_grad.cc

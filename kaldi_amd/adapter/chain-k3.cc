@@ -24,6 +24,7 @@
 #include "chain/chain-supervision.h"
 #include "cudamatrix/cu-allocator.h"
 #include "k3hip.h"
+extern "C" void *k3_adapter_stream();      // kaldi_amd/adapter/cu-k3.cc: the calling thread's stream (every CuMatrix operation of this thread is queued on it)
 #include "k3_host.h"
 
 namespace kaldi { CuAllocatorOptions g_allocator_options; }      // cudamatrix/cu-allocator.cc:49 (RegisterCuAllocatorOptions registers its fields; the allocator itself is the adapter's)
@@ -296,7 +297,7 @@ void ComputeChainObjfAndDeriv(const ChainTrainingOptions &opts, const Denominato
   k3_chain_training_opts o = {opts.l2_regularize, opts.out_of_range_regularize, opts.leaky_hmm_coefficient, (nnet_output_deriv != NULL && RandInt(0, 1) == 0) ? 1 : 0};
   float fo = 0, fl = 0, fw = 0;
   const int rc = k3_chain_objf_and_deriv(den, ks, &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv ? nnet_output_deriv->Data() : NULL, nnet_output_deriv ? nnet_output_deriv->Stride() : 0,
-                                         xent_output_deriv ? xent_output_deriv->Data() : NULL, xent_output_deriv ? xent_output_deriv->Stride() : 0, &fo, &fl, &fw, NULL);
+                                         xent_output_deriv ? xent_output_deriv->Data() : NULL, xent_output_deriv ? xent_output_deriv->Stride() : 0, &fo, &fl, &fw, k3_adapter_stream());
   k3_chain_supervision_destroy(ks);
   if (rc != K3_OK) KALDI_ERR << k3_last_error();
   *objf = fo; *l2_term = fl; *weight = fw;

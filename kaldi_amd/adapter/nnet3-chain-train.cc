@@ -26,6 +26,7 @@
 #include "nnet3/nnet-compute.h"
 #ifdef K3_ADAPTER
 #include "k3hip.h"
+extern "C" void *k3_adapter_stream();      // kaldi_amd/adapter/cu-k3.cc: the calling thread's stream (every CuMatrix operation of this thread is queued on it)
 #else
 #include "chain/chain-training.h"
 #include "chain/chain-denominator.h"
@@ -135,7 +136,7 @@ int main(int argc, char *argv[]) {
       BaseFloat objf = 0, l2_term = 0, weight = 0;
 #ifdef K3_ADAPTER
       k3_chain_training_opts o = {fo[1], 0.0f, fo[0], 0};
-      if (k3_chain_objf_and_deriv(kden, ksups[mi], &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv.Data(), nnet_output_deriv.Stride(), NULL, 0, &objf, &l2_term, &weight, NULL) != K3_OK) KALDI_ERR << k3_last_error();
+      if (k3_chain_objf_and_deriv(kden, ksups[mi], &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv.Data(), nnet_output_deriv.Stride(), NULL, 0, &objf, &l2_term, &weight, k3_adapter_stream()) != K3_OK) KALDI_ERR << k3_last_error();
 #else
       chain::ChainTrainingOptions opts; opts.leaky_hmm_coefficient = fo[0]; opts.l2_regularize = fo[1]; opts.out_of_range_regularize = 0.0;
       chain::ComputeChainObjfAndDeriv(opts, den_graph, supervisions[mi], nnet_output, &objf, &l2_term, &weight, &nnet_output_deriv, NULL);
@@ -147,7 +148,7 @@ int main(int argc, char *argv[]) {
         // what the reference's recipes do with the jobs' models after every iteration (egs/wsj/s5/steps/libs/nnet3/train/chain_objf/acoustic_model.py:121,238), here inside the iteration
         Vector<BaseFloat> flat_host(NumParameters(*delta_nnet), kUndefined); VectorizeNnet(*delta_nnet, &flat_host);      // (nnet-utils.h:148 works on host vectors: one bucket for the whole model)
         CuVector<BaseFloat> flat(flat_host);
-        if (k3_comm_allreduce_f32(comm, flat.Data(), flat.Dim(), NULL) != K3_OK) KALDI_ERR << k3_last_error();
+        if (k3_comm_allreduce_f32(comm, flat.Data(), flat.Dim(), k3_adapter_stream()) != K3_OK) KALDI_ERR << k3_last_error();
         flat.Scale(1.0 / world); flat.CopyToVec(&flat_host); UnVectorizeNnet(flat_host, delta_nnet);
       }
 #endif

@@ -101,6 +101,12 @@ int main(int argc, char **argv) {
     // k3_decoder_advance_decoding's argument ring): the host never waits for the device inside a round, so it prepares round k + 1 while the GPU runs round k; it only
     // synchronises where a stream ends and its lattice is fetched.  (A blocking stream: ordered with the few null-stream calls the C ABI still makes when lattices are fetched.)
     hipStream_t ws = nullptr; K3O_HIP(hipStreamCreate(&ws));
+    // ... and a second stream for token passing.  A chunk's token-passing launch lasts as long as its SLOWEST lane (5 - 9 ms for 17 frames of 512 lanes whose mean is ~2 ms:
+    // most CUs idle in its tail), so the next pass's features / gathers / network run beside it on `ws`, the way the offline pipeline hides its front end behind the decoder.
+    // The only buffer the two streams share is the gathered log-likelihood block: two of them, guarded by events (ev_ll: filled, ev_tp: consumed).
+    hipStream_t ds = nullptr; K3O_HIP(hipStreamCreate(&ds));
+    hipEvent_t ev_ll[2], ev_tp[2]; for (int k = 0; k < 2; k++) { K3O_HIP(hipEventCreateWithFlags(&ev_ll[k], hipEventDisableTiming)); K3O_HIP(hipEventCreateWithFlags(&ev_tp[k], hipEventDisableTiming)); }
+    bool tp_used[2] = {false, false}; unsigned pass_no = 0;
     OnlineFeatures features(plan, fopts, nch, ws);
     StaticNnet3 net(nnet, nch, nch, C, subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, ws);
     std::unique_ptr<OnlineIvectors> ivs; if (ivx) ivs.reset(new OnlineIvectors(ivx, iv_info.right_context, nch, ws));
@@ -122,7 +128,7 @@ int main(int argc, char **argv) {
     // synchronous device copies per round (40 k copyBuffer calls = 46 % of the GPU time of a 512-channel run, 27 ms per round of 512 chunks).
     struct Chan { int utt = -1; Wave wav; size_t pos = 0; int pend = 0; bool started = false; int64_t seg_off[2] = {0, 0}; int seg_cnt[2] = {0, 0}; };
     std::vector<Chan> chan(nch);
-    DevBuf<float> held[2], newbuf, ll; DevBuf<int32_t> llidx, gidx; int held_cur = 0; int64_t held_rows = 0;
+    DevBuf<float> held[2], newbuf, ll[2]; DevBuf<int32_t> llidx, gidx; int held_cur = 0; int64_t held_rows = 0;
     const size_t pend_cap = (size_t)(2 * C + 8);
     for (auto &h : held) h.need((size_t)nch * (pend_cap + (size_t)C + 16) * fdim);
     auto take_rows = [](Chan &c, int n, std::vector<int32_t> *idx) {      // the first n pending rows of the channel, in order
@@ -154,7 +160,7 @@ int main(int argc, char **argv) {
           first.push_back(c.pos == 0); c.pos += n; last.push_back(c.pos == c.wav.samples.size());
         }
         std::vector<int32_t> fresh; for (size_t i = 0; i < chs.size(); i++) if (first[i]) { fresh.push_back(chs[i]); net.Reset(chs[i]); }
-        if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec, fresh.data(), (int32_t)fresh.size(), ws));
+        if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec, fresh.data(), (int32_t)fresh.size(), ds));
         float *d_feats = nullptr;
         const std::vector<int> nf = features.ComputeFeaturesBatched(chs, chunk_ptr.data(), chunk_len.data(), first, &d_feats);
         { int64_t off = 0, tot = 0; for (int n : nf) tot += n;
@@ -191,9 +197,13 @@ int main(int argc, char **argv) {
             std::vector<std::vector<std::pair<int, int>>> per(nch); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
             for (int ch = 0; ch < nch; ch++) { int64_t n = 0; for (auto &r : per[ch]) { for (int k = 0; k < r.second; k++) idx.push_back(r.first + k); n += r.second; } ro[ch + 1] = ro[ch] + n; }
           }
-          ll.need((size_t)std::max<size_t>(idx.size(), 1) * N);
-          if (!idx.empty()) { llidx.upload_async(idx, ws); K3H_CHECK_K3(k3_mat_copy_rows(ll.p, N, (int32_t)idx.size(), N, net.Out(), N, llidx.p, ws)); }
-          K3H_CHECK_K3(k3_decoder_advance_decoding(dec, nch, ll.p, N, ro.data(), ws));
+          const int lb = (int)(pass_no++ & 1); DevBuf<float> &llb = ll[lb];
+          if (tp_used[lb]) K3O_HIP(hipStreamWaitEvent(ws, ev_tp[lb], 0));      // the launch that read this block two passes ago (growing the block frees it: hipFree waits for the device)
+          llb.need((size_t)std::max<size_t>(idx.size(), 1) * N);
+          if (!idx.empty()) { llidx.upload_async(idx, ws); K3H_CHECK_K3(k3_mat_copy_rows(llb.p, N, (int32_t)idx.size(), N, net.Out(), N, llidx.p, ws)); }
+          K3O_HIP(hipEventRecord(ev_ll[lb], ws)); K3O_HIP(hipStreamWaitEvent(ds, ev_ll[lb], 0));
+          K3H_CHECK_K3(k3_decoder_advance_decoding(dec, nch, llb.p, N, ro.data(), ds));
+          K3O_HIP(hipEventRecord(ev_tp[lb], ds)); tp_used[lb] = true;
           need_advance = false;
           // flush passes for closed channels whose last outputs did not fit one pass
           for (int ch : run) if (closed[ch] && net.Pending(ch)) { closed[ch] = 0; }      // stays in `run` candidates: is_last and pend == 0 -> another (empty-input) pass
@@ -211,7 +221,7 @@ int main(int argc, char **argv) {
         // finalise the channels whose stream ended, write their lattices, free the channels
         std::vector<int32_t> ended; for (size_t i = 0; i < chs.size(); i++) if (last[i]) ended.push_back(chs[i]);
         if (!ended.empty()) {
-          K3H_CHECK_K3(k3_decoder_finalize_channels(dec, ended.data(), (int32_t)ended.size(), ws));
+          K3H_CHECK_K3(k3_decoder_finalize_channels(dec, ended.data(), (int32_t)ended.size(), ds));
           const int U = (int)ended.size();
           std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec, info.data());
           int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
@@ -245,7 +255,7 @@ int main(int argc, char **argv) {
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
     K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio << " RealTimeX: " << total_audio / total_time;
     ivs.reset(); if (ivx) k3_ivector_destroy(ivx);
-    (void)hipStreamDestroy(ws);
+    (void)hipStreamDestroy(ws); (void)hipStreamDestroy(ds); for (int k = 0; k < 2; k++) { (void)hipEventDestroy(ev_ll[k]); (void)hipEventDestroy(ev_tp[k]); }
     k3_decoder_destroy(dec); k3_fst_destroy(fst); k3_nnet_destroy(nnet); k3_feat_plan_destroy(plan);
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }

@@ -111,7 +111,7 @@ EdgeFst InvertedEdges(const Lattice &lat) {
 }
 
 // TopSort + ArcSort(ILabelCompare) (lattice-determinize-pruned.cc:106-112): states reachable from the start state in depth-first
-// topological order, the arcs of a state sorted on the word label (std::sort like OpenFst's ArcSort; sort_arcs = false: TopSort only)
+// topological order, the arcs of a state sorted on (word label, transition-id) (std::sort with OpenFst's ILabelCompare; sort_arcs = false: TopSort only)
 InputFst SortedInput(const EdgeFst &e, bool sort_arcs = true) {
   InputFst f; const int32_t n = (int32_t)e.fin.size(); const size_t na = e.src.size();
   if (n == 0 || e.start < 0) return f;
@@ -128,7 +128,8 @@ InputFst SortedInput(const EdgeFst &e, bool sort_arcs = true) {
     const int32_t s = order[i];
     f.fin[i] = e.fin[s];
     std::vector<int32_t> arcs(idx.begin() + off[s], idx.begin() + off[s + 1]);
-    if (sort_arcs) std::sort(arcs.begin(), arcs.end(), [&](int32_t x, int32_t y) { return e.word[x] < e.word[y]; });
+    // (OpenFst's ILabelCompare orders on the pair (input label, output label): arcs with the same word are ordered by their transition-id)
+    if (sort_arcs) std::sort(arcs.begin(), arcs.end(), [&](int32_t x, int32_t y) { return e.word[x] != e.word[y] ? e.word[x] < e.word[y] : e.tid[x] < e.tid[y]; });
     for (int32_t a : arcs) { f.word.push_back(e.word[a]); f.tid.push_back(e.tid[a]); f.next.push_back(newid[e.dst[a]]); f.w.push_back(e.w[a]); }
     f.off[i + 1] = (int32_t)f.word.size();
   }

@@ -424,3 +424,18 @@ def test_nnet3_chain_train_with_the_reference_command_line_and_example_archives(
     assert abs(objf(zr.stderr) - want) <= 2e-5 * max(1.0, abs(want))
     assert subprocess.run([exe, f"{td}/m.raw"], capture_output=True).returncode == 1
     bad = subprocess.run([exe] + opts + [f"{td}/m.raw", f"{td}/m.raw", f"ark:{td}/all.egs", f"{td}/b.raw"], capture_output=True, text=True, env=env); assert bad.returncode != 0
+
+
+@pytest.mark.parametrize("threads,iters", [(2, 6), (4, 3)])
+def test_adapter_on_several_host_threads_reproduces_the_single_threaded_results(threads, iters, tmp_path):
+    """SURVEY 8b "threading" (cudamatrix/cu-device.cc:112-124: every host thread gets cudaStreamPerThread): the reference's training computation -- NnetComputer forward in training
+    mode + Backprop, tests/adapter/nnet3_two_threads.cc -- run by several host threads AT ONCE over the adapter (one stream per thread, a memory pool that synchronises only when a
+    block changes threads, index arrays cached on the device) must reproduce every thread's single-threaded output and gradient bit for bit: any difference is a race."""
+    from kaldi_amd import synth
+    exe = os.path.join(ROOT, "kaldi_amd", "adapter", "_build", "nnet3-two-threads")
+    if not os.path.exists(exe): pytest.fail("kaldi_amd/adapter/_build/nnet3-two-threads is missing: run kaldi_amd/adapter/build.sh where /root/reference exists")
+    td = str(tmp_path)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=5, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=60, calib_feats=calib, out_std=1.5).write(f"{td}/m.raw")
+    g = subprocess.run([exe, f"{td}/m.raw", str(threads), str(iters), "8", "12", "3"], capture_output=True, text=True, env=dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL"), timeout=600)
+    assert g.returncode == 0 and "two-threads ok" in g.stdout, (g.stdout[-500:], g.stderr[-3000:])
