@@ -132,8 +132,8 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
       std::vector<int64_t> ro(nch_ + 1, 0); std::vector<int32_t> idx;
       if (!run.empty()) {
         auto res = net_->Pass(run, new_.p, n_new, lasts, ivs_ ? ivs_->Gather(run) : nullptr);
-        std::vector<std::vector<std::pair<int, int>>> per(nch_); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
-        for (int ch = 0; ch < nch_; ch++) { int64_t k = 0; for (auto &r : per[ch]) { for (int j = 0; j < r.second; j++) idx.push_back(r.first + j); k += r.second; } ro[ch + 1] = ro[ch] + k; }
+        std::vector<std::vector<StaticNnet3::Rows>> per(nch_); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
+        for (int ch = 0; ch < nch_; ch++) { int64_t k = 0; for (auto &r : per[ch]) { for (int j = 0; j < r.count; j++) idx.push_back(r.first + j * r.stride); k += r.count; } ro[ch + 1] = ro[ch] + k; }
       }
       const int lb = (int)(pass_no_++ & 1); DevBuf<float> &llb = ll_[lb];
       if (tp_used_[lb]) K3O_HIP(hipStreamWaitEvent(ws_, ev_tp_[lb], 0));      // the launch that read this block two passes ago

@@ -213,6 +213,27 @@ void k3_nnet_batch_destroy(k3_nnet_batch *batch);
 int64_t k3_nnet_batch_output_rows(const k3_nnet_batch *batch, int64_t *h_out_offsets);
 double k3_nnet_batch_flops(const k3_nnet_batch *batch);   /* exact sum of 2*M*N*K over the launched GEMMs */
 int k3_nnet_forward(k3_nnet_batch *batch, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream);
+/* Stateful streaming forward (round 5): what BatchedStaticNnet3::RunBatch (cudadecoder/batched-static-nnet3.cc:139-233) is for the online pipeline -- one network pass per
+ * chunk of every active channel -- WITHOUT re-evaluating the chunk's left and right context: every node keeps, per channel, the last few rows it produced, a pass consumes
+ * frames_per_chunk new input frames per channel and produces frames_per_chunk / subsampling output rows, every row of every node is computed once per stream.  Outputs are
+ * bit-identical to k3_nnet_forward over the whole utterance (edge frames: a restarted channel's histories are its response to frame 0 replicated, the end of a stream
+ * replicates its last frame; nnet-am-decodable-simple.cc:154-163).  K3_ERR_UNSUPPORTED for models it cannot run (i-vector input, row operations inside the network,
+ * frames_per_chunk shorter than a node's history): callers fall back to planning chunk + context with k3_nnet_batch_create.
+ * Channel c's output row k of a pass lies at d_out row k * num_channels + c and belongs to time first_output_time + P * frames_per_chunk + k * subsampling, P = the passes
+ * channel c took part in since its last reset (rows at negative times, or beyond the stream's last frame, are to be ignored). */
+typedef struct k3_nnet_stream k3_nnet_stream;
+typedef struct k3_nnet_stream_info {
+  int32_t num_channels, frames_per_chunk, subsampling, output_rows_per_pass, first_output_time, right_context, input_history;
+  double flops_per_pass;
+} k3_nnet_stream_info;
+int k3_nnet_stream_create(k3_nnet *nnet, int32_t num_channels, int32_t frames_per_chunk, int32_t frame_subsampling_factor, const float *h_log_priors, float acoustic_scale, k3_nnet_stream **out);
+void k3_nnet_stream_destroy(k3_nnet_stream *s);
+int k3_nnet_stream_get_info(const k3_nnet_stream *s, k3_nnet_stream_info *info);
+/* the listed channels start new streams; d_first_frames row i = the first feature frame of channel h_channels[i]'s stream */
+int k3_nnet_stream_reset(k3_nnet_stream *s, const int32_t *h_channels, int32_t n, const float *d_first_frames, int64_t ld, void *stream);
+/* one pass: channel c with h_row_count[c] >= 0 consumes rows h_row_start[c] .. + h_row_count[c] of d_new (frames_per_chunk of them; fewer or none only once its audio has
+ * ended: the missing frames replicate the last one); h_row_count[c] < 0: the channel sits the pass out */
+int k3_nnet_stream_forward(k3_nnet_stream *s, const float *d_new, int64_t ld_new, const int64_t *h_row_start, const int32_t *h_row_count, float *d_out, int64_t ld_out, void *stream);
 /* Models with the recipes' i-vector input ("input-node name=ivector", tdnn1 fed by Append(.., ReplaceIndex(ivector, t, 0)); k3_nnet_info.ivector_dim > 0).
  * online_ivector_period > 0: nnet3-compute / nnet3-latgen-faster --online-ivectors=.. --online-ivector-period=P --frames-per-chunk=C: the network is
  * evaluated chunk by chunk (chunks of C frames rounded up to a multiple of the subsampling factor), chunk c with the row GetCurrentIvector picks for it

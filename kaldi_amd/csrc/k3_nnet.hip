@@ -893,3 +893,260 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
   }
   return K3_OK;
 }
+
+// ================================================================================================ stateful streaming forward (round 5)
+// BatchedStaticNnet3::RunBatch (cudadecoder/batched-static-nnet3.cc:139-233) evaluates every chunk of a stream together with its whole left and right context:
+// frames_per_chunk + ~80 input frames for 17 output rows at the benchmark model, and this repository's StaticNnet3 (kaldi_amd/host/k3_online.h) did the same.  The engine
+// below evaluates every row of every node exactly ONCE per stream: each node keeps, per channel, the last H_i rows it produced (what its consumers' time offsets still reach
+// back to), a pass consumes frames_per_chunk new input frames per channel and produces frames_per_chunk / G_i new rows per node.
+//
+// Time bookkeeping (channel-local time, t = 0 the stream's first frame).  With R_in = the model's right context and R_i the right extension of node i (the backward sweep of
+// the whole-utterance planner), after p passes node i can hold exactly the rows t <= hi_i(p) = C p - 1 - (R_in - R_i) of its grid A_i + k G_i: the new rows of a pass are the
+// C / G_i grid points in (hi_i(p - 1), hi_i(p)].  Rows t <= hi_i(0) depend only on input frames at t < 0, which the reference replicates from frame 0 (edge-frame
+// replication, nnet-am-decodable-simple.cc:154-163): they all equal the node's response to a constant input, c_i(frame 0).  So a stream starts with its histories SEEDED
+// with c_i -- one extra tiny forward over one row per channel whose loads all hit that row -- and its first pass is a pass like any other; the end of a stream is more passes
+// whose missing input frames replicate the last one.  Every row is the same arithmetic on the same operands as in the whole-utterance forward (same kernel, same K order; the
+// rows of a tile are independent), so the outputs are bit-identical to k3_nnet_forward over the whole utterance (tests/test_nnet_gpu.py).
+//
+// Layout: node buffers are TIME-major, channel-minor -- row (h, c) = h * num_channels + c, h = 0 .. H_i - 1 the history, then the C / G_i new time steps -- so that a 128-row
+// slab of the GEMM is 128 channels of one time step (full slabs whatever C / G_i is: 17 rows per channel and pass would fill 13 % of a per-channel slab), a time offset o is a
+// constant row shift (o / G_src) * num_channels, and moving the history is one strided copy per node.  Channels that sit a pass out keep their histories (the move is masked).
+struct k3_nnet_stream {
+  k3_nnet *net = nullptr; int nch = 0, C = 0, s = 1, in_dim = 0, out_dim = 0, H_in = 0, N_out = 0, first_out = 0, R_in = 0;
+  std::unique_ptr<k3_nnet_batch> pass, seed;      // the per-pass plan and the constant-response plan (one row per channel and node), both run by forward_impl
+  float *in_buf = nullptr, *const_in = nullptr; long long ld_in = 0;
+  struct NodeBuf { float *buf = nullptr, *cst = nullptr; int ld = 0, dim = 0, H = 0, N = 0; };
+  std::vector<NodeBuf> nb; NodeBuf *d_nb = nullptr; int n_nb = 0;      // device copy of the nodes that keep a history (incl. the input as entry 0)
+  // per-call host arrays (row offsets, active flags, reset lists): page-locked ring + device copies
+  static constexpr int kSlots = 4;
+  struct Slot { char *h = nullptr, *d = nullptr; hipEvent_t ev = nullptr; bool used = false; } slot[kSlots]; unsigned seq = 0; size_t slot_bytes = 0;
+  std::vector<void *> allocs;
+  ~k3_nnet_stream() { for (void *p : allocs) (void)hipFree(p); for (Slot &g : slot) { if (g.h) (void)hipHostFree(g.h); if (g.d) (void)hipFree(g.d); if (g.ev) (void)hipEventDestroy(g.ev); } }
+};
+
+namespace {
+// new input rows of a pass into the time-major input buffer: channel c's rows [off[c], off[c + 1]) of `src` (at most C; fewer = the stream's audio has ended: the missing frames
+// replicate the last real one -- this pass's, or the newest history row when the channel has none left); inactive channels are skipped
+__global__ __launch_bounds__(256) void k3_stream_prep_kernel(const float *src, long long lds, const long long *start, const int *count, float *in_buf, long long ld, int nch, int C, int H, int dim4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x; const long long per_t = (long long)nch * dim4;
+  if (i >= (long long)C * per_t) return;
+  const int t = (int)(i / per_t), c = (int)((i % per_t) / dim4), q = (int)(i % dim4);
+  const int n = count[c]; if (n < 0) return;      // (the channel sits this pass out)
+  const long long r0 = start[c];
+  const float4 *from = n > 0 ? reinterpret_cast<const float4 *>(src + (r0 + (t < n ? t : n - 1)) * lds) : reinterpret_cast<const float4 *>(in_buf + ((long long)(H - 1) * nch + c) * ld);
+  reinterpret_cast<float4 *>(in_buf + ((long long)(H + t) * nch + c) * ld)[q] = from[q];
+}
+// behind a pass: every node's newest H rows become its history (active channels only).  One launch for all nodes: blockIdx.y = node, x over (h, channel, float4 column)
+__global__ __launch_bounds__(256) void k3_stream_shift_kernel(const k3_nnet_stream::NodeBuf *nodes, const int *count, int nch) {
+  const k3_nnet_stream::NodeBuf nb = nodes[blockIdx.y]; const int d4 = nb.dim / 4;
+  const long long n = (long long)nb.H * nch * d4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int h = (int)(i / ((long long)nch * d4)), c = (int)((i / d4) % nch), q = (int)(i % d4);
+    if (count[c] < 0) continue;
+    reinterpret_cast<float4 *>(nb.buf + ((long long)h * nch + c) * nb.ld)[q] = reinterpret_cast<const float4 *>(nb.buf + ((long long)(nb.N + h) * nch + c) * nb.ld)[q];      // (H <= N: source and destination never overlap)
+  }
+}
+// a restarted channel's histories: H copies of the node's constant response (entry 0: the input itself, i.e. frame 0 replicated)
+__global__ __launch_bounds__(256) void k3_stream_seed_kernel(const k3_nnet_stream::NodeBuf *nodes, const int *channels, int n_ch, int nch) {
+  const k3_nnet_stream::NodeBuf nb = nodes[blockIdx.y]; const int d4 = nb.dim / 4;
+  const long long n = (long long)nb.H * n_ch * d4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int h = (int)(i / ((long long)n_ch * d4)), c = channels[(i / d4) % n_ch], q = (int)(i % d4);
+    reinterpret_cast<float4 *>(nb.buf + ((long long)h * nch + c) * nb.ld)[q] = reinterpret_cast<const float4 *>(nb.cst + (long long)c * nb.ld)[q];
+  }
+}
+// frame 0 of the restarted channels into their rows of the constant-input matrix
+__global__ __launch_bounds__(256) void k3_stream_const_in_kernel(const float *first, long long ld, const int *channels, int n_ch, float *const_in, long long ld_in, int dim4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x; if (i >= (long long)n_ch * dim4) return;
+  const int k = (int)(i / dim4), q = (int)(i % dim4);
+  reinterpret_cast<float4 *>(const_in + (long long)channels[k] * ld_in)[q] = reinterpret_cast<const float4 *>(first + (long long)k * ld)[q];
+}
+int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+}  // namespace
+
+extern "C" void k3_nnet_stream_destroy(k3_nnet_stream *s) { delete s; }
+
+extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t frames_per_chunk, int32_t subsampling, const float *h_log_priors, float acoustic_scale, k3_nnet_stream **out) {
+  K3_REQUIRE(net && out && num_channels > 0 && frames_per_chunk > 0 && subsampling >= 1 && frames_per_chunk % subsampling == 0, "k3_nnet_stream_create: bad argument (frames_per_chunk must be a positive multiple of the subsampling factor)");
+  K3_REQUIRE(net->fm.input_dim % 4 == 0, "k3_nnet_stream_create: the input dimension must be a multiple of 4 (vector loads)");
+  { const int rc = ensure_uploaded(net); if (rc) return rc; }
+  const k3::FusedModel &fm = net->fm; const int nn = (int)fm.nodes.size(), C = frames_per_chunk, NCH = num_channels;
+  if (fm.ivector_dim > 0) { k3::set_error("k3_nnet_stream_create: models with an i-vector input are evaluated chunk by chunk with their context (k3_nnet_batch_create_ivector)"); return K3_ERR_UNSUPPORTED; }
+  // ---- time grids: the whole-utterance planner's backward sweep (A = first time, R = right extension, G = step)
+  std::vector<int> A(nn, 0), R(nn, 0), G(nn, 0); std::vector<char> used(nn, 0); int R_in = -(1 << 30), A_in = 1 << 30;
+  A[fm.output_node] = 0; R[fm.output_node] = 0; G[fm.output_node] = subsampling; used[fm.output_node] = 1;
+  {
+    std::vector<std::vector<std::pair<int, int>>> anchors(nn); std::vector<int> rmax(nn, -(1 << 30));
+    for (int i = nn - 1; i >= 0; i--) {
+      if (i != fm.output_node) {
+        if (anchors[i].empty()) continue;
+        int a = 1 << 30, g = 0;
+        for (auto &an : anchors[i]) a = std::min(a, an.first);
+        for (auto &an : anchors[i]) { g = gcd_i(g, an.second); g = gcd_i(g, an.first - a); }
+        A[i] = a; G[i] = g; R[i] = rmax[i]; used[i] = 1;
+      }
+      const k3::FusedNode &f = fm.nodes[i];
+      auto contribute = [&](int src, int off) { if (src < 0) { R_in = std::max(R_in, R[i] + off); A_in = std::min(A_in, A[i] + off); return; } anchors[src].push_back({A[i] + off, G[i]}); rmax[src] = std::max(rmax[src], R[i] + off); };
+      for (int o : f.offsets) contribute(f.input, o);
+      for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual) contribute(op.res_node, 0);
+    }
+  }
+  K3_REQUIRE(R_in > -(1 << 30), "k3_nnet_stream_create: no node reads the network input");
+  // node -1 (the input) as index nn in the tables below
+  auto Gx = [&](int i) { return i < 0 ? 1 : G[i]; };
+  std::vector<int> first(nn + 1, 0), Nn(nn + 1, 0), H(nn + 1, 0);
+  auto idx = [&](int i) { return i < 0 ? nn : i; };
+  for (int i = -1; i < nn; i++) {
+    if (i >= 0 && !used[i]) continue;
+    const int g = Gx(i), a = i < 0 ? 0 : A[i], r = i < 0 ? R_in : R[i];
+    if (C % g != 0) { k3::set_error("k3_nnet_stream_create: frames_per_chunk %d is not a multiple of node %s's time step %d", C, i < 0 ? "input" : fm.nodes[i].name.c_str(), g); return K3_ERR_UNSUPPORTED; }
+    const int lo = -1 - (R_in - r);                                   // hi_i(0): the newest row before the first pass
+    first[idx(i)] = a + (floor_div(lo - a, g) + 1) * g;               // smallest grid point > lo
+    Nn[idx(i)] = C / g;
+  }
+  for (int i = 0; i < nn; i++) {
+    if (!used[i]) continue;
+    const k3::FusedNode &f = fm.nodes[i];
+    if (f.row_op && i != fm.output_node) { k3::set_error("k3_nnet_stream_create: node %s applies a row operation in place (NormalizeComponent / softmax inside the network): not supported by the stateful engine", f.name.c_str()); return K3_ERR_UNSUPPORTED; }
+    auto need = [&](int src, int o_min, int o_max) {
+      const int gs = Gx(src), fs = first[idx(src)], fi = first[i];
+      if ((fi + o_min - fs) % gs != 0 || G[i] % gs != 0) return false;
+      { const int d = fs - (fi + o_min); H[idx(src)] = std::max(H[idx(src)], d > 0 ? d / gs : 0); }      // grid points of the source in [fi + o_min, fs): rows of its history this node still reads
+      return fi + (Nn[i] - 1) * G[i] + o_max <= fs + (Nn[idx(src)] - 1) * gs;      // the newest row it reads exists
+    };
+    bool ok = true;
+    { int lo = 1 << 30, hi = -(1 << 30); for (int o : f.offsets) { lo = std::min(lo, o); hi = std::max(hi, o); if ((first[i] + o - first[idx(f.input)]) % Gx(f.input) != 0) ok = false; } ok = ok && need(f.input, lo, hi); }
+    for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual) ok = ok && need(op.res_node, 0, 0) && Gx(op.res_node) == G[i];
+    if (!ok) { k3::set_error("k3_nnet_stream_create: the time grids of node %s do not line up for incremental evaluation", f.name.c_str()); return K3_ERR_UNSUPPORTED; }
+  }
+  H[nn] = std::max(H[nn], 1);      // (the input keeps at least its newest frame: what the end of a stream replicates)
+  for (int i = -1; i < nn; i++) if ((i < 0 || used[i]) && H[idx(i)] > Nn[idx(i)]) { k3::set_error("k3_nnet_stream_create: frames_per_chunk %d is shorter than the history a node keeps (%d rows)", C, H[idx(i)]); return K3_ERR_UNSUPPORTED; }
+
+  std::unique_ptr<k3_nnet_stream> S(new k3_nnet_stream());
+  S->net = net; S->nch = NCH; S->C = C; S->s = subsampling; S->in_dim = fm.input_dim; S->out_dim = fm.output_dim; S->H_in = H[nn]; S->N_out = Nn[fm.output_node]; S->first_out = first[fm.output_node]; S->R_in = R_in;
+  auto dalloc = [&](size_t bytes, float **p) -> int { K3_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(bytes, 256))); S->allocs.push_back(*p); K3_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(bytes, 256))); return K3_OK; };
+  S->nb.assign(nn + 1, k3_nnet_stream::NodeBuf());
+  S->ld_in = (long long)align_up(fm.input_dim, 4);
+  { int rc = dalloc((size_t)(H[nn] + C) * NCH * S->ld_in * 4, &S->in_buf); if (rc) return rc; rc = dalloc((size_t)NCH * S->ld_in * 4, &S->const_in); if (rc) return rc; }
+  S->nb[nn] = {S->in_buf, S->const_in, (int)S->ld_in, (int)S->ld_in, H[nn], C};
+  for (int i = 0; i < nn; i++) {
+    if (!used[i] || i == fm.output_node) continue;
+    k3_nnet_stream::NodeBuf &b = S->nb[i]; b.ld = (int)align_up(fm.nodes[i].out_dim, 4); b.dim = b.ld; b.H = H[i]; b.N = Nn[i];
+    int rc = dalloc((size_t)(H[i] + Nn[i]) * NCH * b.ld * 4, &b.buf); if (rc) return rc;
+    rc = dalloc((size_t)NCH * b.ld * 4, &b.cst); if (rc) return rc;
+  }
+  { std::vector<k3_nnet_stream::NodeBuf> keep; keep.push_back(S->nb[nn]); for (int i = 0; i < nn; i++) if (S->nb[i].buf && S->nb[i].H > 0) keep.push_back(S->nb[i]);
+    S->n_nb = (int)keep.size(); K3_HIP_CHECK(hipMalloc((void **)&S->d_nb, keep.size() * sizeof(keep[0]))); S->allocs.push_back(S->d_nb);
+    K3_HIP_CHECK(hipMemcpy(S->d_nb, keep.data(), keep.size() * sizeof(keep[0]), hipMemcpyHostToDevice)); }
+  S->slot_bytes = align_up(sizeof(long long) * (NCH + 1), 16) + align_up(sizeof(int) * NCH, 16) * 2;
+  for (auto &g : S->slot) { K3_HIP_CHECK(hipHostMalloc((void **)&g.h, S->slot_bytes, hipHostMallocDefault)); K3_HIP_CHECK(hipMalloc((void **)&g.d, S->slot_bytes)); K3_HIP_CHECK(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming)); }
+
+  // ---- the two plans, as k3_nnet_batch objects that forward_impl runs: `pass` (C / G_i time steps of num_channels rows per node) and `seed` (one row per channel and node,
+  // every time offset reading that row)
+  float *out_scale = nullptr, *out_offset = nullptr;
+  const bool out_xform = (h_log_priors != nullptr) || acoustic_scale != 1.0f;
+  const int blocks_per_t = (NCH + kBM - 1) / kBM;
+  for (int which = 0; which < 2; which++) {
+    std::unique_ptr<k3_nnet_batch> b(new k3_nnet_batch());
+    b->net = net; b->num_utts = NCH; b->subsampling = subsampling; b->params.resize(nn); b->seq_bias.assign(nn, nullptr); b->seq_bias_ld.assign(nn, 0); b->node_rows.assign(nn, 0);
+    if (which == 0 && out_xform) {
+      std::vector<float> sc(fm.output_dim, acoustic_scale), of(fm.output_dim, 0.0f);
+      if (h_log_priors) for (int i = 0; i < fm.output_dim; i++) of[i] = -h_log_priors[i] * acoustic_scale;
+      int rc = upload(&b->allocs, sc, &out_scale); if (rc) return rc; rc = upload(&b->allocs, of, &out_offset); if (rc) return rc;
+      b->out_scale = out_scale; b->out_offset = out_offset;
+    }
+    for (int i = 0; i < nn; i++) {
+      GemmParams &p = b->params[i]; memset(&p, 0, sizeof(p));
+      if (!used[i] || (which == 1 && i == fm.output_node)) { p.num_m_tiles = 0; continue; }      // (the output node keeps no history: nothing to seed)
+      const k3::FusedNode &f = fm.nodes[i]; const DeviceNode &d = net->dev[i]; const int src = f.input;
+      const k3_nnet_stream::NodeBuf &sb = S->nb[idx(src)];
+      p.in_dim = f.in_dim; p.noff = (int)f.offsets.size(); p.row_stride = 1;
+      for (int o = 0; o < p.noff; o++) p.shifts[o] = which == 1 ? 0 : ((first[i] + f.offsets[o] - first[idx(src)]) / Gx(src)) * NCH;
+      p.tiles_per_off = (f.in_dim % kBK == 0) ? f.in_dim / kBK : 0; p.tiles_per_seg = 384 / kBK;
+      p.A = src < 0 ? nullptr : (which == 1 ? sb.cst : sb.buf); p.lda = src < 0 ? 0 : sb.ld;      // (the network input is patched in by forward_impl)
+      p.W = d.W; p.ldw = d.ldw; p.Ktot = p.noff * f.in_dim; p.N = f.out_dim; p.bias = d.bias;
+      p.C = i == fm.output_node ? nullptr : (which == 1 ? S->nb[i].cst : S->nb[i].buf); p.ldc = i == fm.output_node ? 0 : S->nb[i].ld;
+      p.nops = (int)f.ops.size(); int res = -2;
+      for (int o = 0; o < p.nops; o++) { p.op_kind[o] = f.ops[o].kind; p.op_scale[o] = d.op_scale[o]; p.op_offset[o] = d.op_offset[o]; if (f.ops[o].kind == k3::kEpiResidual) { res = f.ops[o].res_node; p.res_scale = f.ops[o].res_scale; } }
+      if (i == fm.output_node && out_xform && f.row_op == 0) {
+        if (p.nops >= kMaxOps) { k3::set_error("k3_nnet_stream_create: too many epilogue ops on the output node"); return K3_ERR_UNSUPPORTED; }
+        p.op_kind[p.nops] = k3::kEpiScaleOffset; p.op_scale[p.nops] = out_scale; p.op_offset[p.nops] = out_offset; p.nops++;
+      }
+      const k3_nnet_stream::NodeBuf *rb = res >= -1 ? &S->nb[idx(res)] : nullptr;
+      if (rb) { p.R = res < 0 ? nullptr : (which == 1 ? rb->cst : rb->buf); p.ldr = res < 0 ? 0 : rb->ld; p.res_row_stride = 1; }
+      const int steps = which == 1 ? 1 : Nn[i], Hi = i == fm.output_node ? 0 : H[i];
+      const long long in_rows = which == 1 ? NCH : (long long)(sb.H + sb.N) * NCH;
+      std::vector<TileDesc> tiles;
+      for (int k = 0; k < steps; k++) for (int bl = 0; bl < blocks_per_t; bl++) {
+        TileDesc t; memset(&t, 0, sizeof t);
+        t.nrows = std::min(kBM, NCH - bl * kBM); t.split = t.nrows; t.bias_row = 0;
+        t.out_row0 = which == 1 ? bl * kBM : (Hi + k) * NCH + bl * kBM;
+        t.in_base = which == 1 ? bl * kBM : (sb.H + k * (G[i] / Gx(src))) * NCH + bl * kBM; t.in_lo = 0; t.in_hi = (int)in_rows - 1;
+        if (rb) t.res_base = which == 1 ? bl * kBM : (rb->H + (first[i] + k * G[i] - first[idx(res)]) / Gx(res)) * NCH + bl * kBM;
+        t.in_base2 = t.in_base; t.in_lo2 = t.in_lo; t.in_hi2 = t.in_hi; t.res_base2 = t.res_base; t.bias_row2 = 0;
+        tiles.push_back(t);
+      }
+      if (f.has_gemm) b->flops += 2.0 * steps * NCH * (double)p.Ktot * f.out_dim;
+      b->node_rows[i] = (long long)steps * NCH;
+      TileDesc *dt = nullptr; int rc = upload(&b->allocs, tiles, &dt); if (rc) return rc;
+      p.tiles = dt; p.num_m_tiles = (int)tiles.size(); p.num_n_tiles = f.has_gemm ? d.npad / d.bn : 1;
+    }
+    (which == 0 ? S->pass : S->seed) = std::move(b);
+  }
+  *out = S.release();
+  return K3_OK;
+}
+
+extern "C" int k3_nnet_stream_get_info(const k3_nnet_stream *s, k3_nnet_stream_info *info) {
+  K3_REQUIRE(s && info, "k3_nnet_stream_get_info: null argument");
+  info->num_channels = s->nch; info->frames_per_chunk = s->C; info->subsampling = s->s; info->output_rows_per_pass = s->N_out; info->first_output_time = s->first_out; info->right_context = s->R_in;
+  info->input_history = s->H_in; info->flops_per_pass = s->pass->flops;
+  return K3_OK;
+}
+
+namespace {
+int stream_slot(k3_nnet_stream *s, k3_nnet_stream::Slot **out) { k3_nnet_stream::Slot &g = s->slot[s->seq++ % k3_nnet_stream::kSlots]; if (g.used) K3_HIP_CHECK(hipEventSynchronize(g.ev)); *out = &g; return K3_OK; }
+}
+
+// The listed channels start new streams: their histories become the response to a constant input -- d_first_frames row i = frame 0 of channel h_channels[i]'s stream (what the
+// reference replicates to the left of the utterance).  Queued on `stream`; the next k3_nnet_stream_forward on that stream sees the new state.
+extern "C" int k3_nnet_stream_reset(k3_nnet_stream *s, const int32_t *h_channels, int32_t n, const float *d_first_frames, int64_t ld, void *stream) {
+  K3_REQUIRE(s && (n == 0 || (h_channels && d_first_frames)) && n >= 0 && n <= s->nch && ld >= s->in_dim, "k3_nnet_stream_reset: bad argument");
+  if (n == 0) return K3_OK;
+  for (int i = 0; i < n; i++) K3_REQUIRE(h_channels[i] >= 0 && h_channels[i] < s->nch, "k3_nnet_stream_reset: channel out of range");
+  hipStream_t st = (hipStream_t)stream; k3_nnet_stream::Slot *g; { const int rc = stream_slot(s, &g); if (rc) return rc; }
+  int *hc = reinterpret_cast<int *>(g->h); memcpy(hc, h_channels, sizeof(int) * n);
+  K3_HIP_CHECK(hipMemcpyAsync(g->d, g->h, sizeof(int) * n, hipMemcpyHostToDevice, st));
+  const int *dc = reinterpret_cast<const int *>(g->d);
+  // frame 0 of the restarted channels into their rows of the constant-input matrix (rows of the other channels keep whatever they hold: their results are not used)
+  K3_REQUIRE(ld % 4 == 0 && ((uintptr_t)d_first_frames & 15) == 0, "k3_nnet_stream_reset: d_first_frames must be 16-byte aligned with ld % 4 == 0");
+  { const int dim4 = s->in_dim / 4; const long long m = (long long)n * dim4; hipLaunchKernelGGL(k3_stream_const_in_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_first_frames, (long long)ld, dc, n, s->const_in, s->ld_in, dim4); }
+  { const int rc = forward_impl(s->seed.get(), s->const_in, s->ld_in, s->const_in /* unused: the output node is not part of the seed plan */, s->out_dim > 0 ? (int64_t)align_up(s->out_dim, 4) : 4, stream); if (rc) return rc; }
+  hipLaunchKernelGGL(k3_stream_seed_kernel, dim3(64, (unsigned)s->n_nb), dim3(256), 0, st, s->d_nb, dc, n, s->nch);
+  K3_HIP_CHECK(hipGetLastError());
+  K3_HIP_CHECK(hipEventRecord(g->ev, st)); g->used = true;
+  return K3_OK;
+}
+
+// One pass.  Channel c with h_row_count[c] >= 0 takes part and consumes rows h_row_start[c] .. + h_row_count[c] of d_new as its next frames: exactly frames_per_chunk of them while
+// its stream goes on, fewer (or none) once its audio has ended -- the missing frames replicate the last real one; h_row_count[c] < 0: the channel sits the pass out and keeps its
+// state.  d_out [output_rows_per_pass * num_channels x ld_out], time-major: row k * num_channels + c is channel c's output at time first_output_time + (passes of c before this
+// one) * frames_per_chunk + k * subsampling; rows of channels that sat out are undefined.
+extern "C" int k3_nnet_stream_forward(k3_nnet_stream *s, const float *d_new, int64_t ld_new, const int64_t *h_row_start, const int32_t *h_row_count, float *d_out, int64_t ld_out, void *stream) {
+  K3_REQUIRE(s && h_row_start && h_row_count && d_out && ld_out >= s->out_dim && ld_new >= s->in_dim && ld_new % 4 == 0, "k3_nnet_stream_forward: bad argument");
+  long long total = 0;
+  for (int c = 0; c < s->nch; c++) { K3_REQUIRE(h_row_count[c] <= s->C && (h_row_count[c] <= 0 || h_row_start[c] >= 0), "k3_nnet_stream_forward: a channel takes at most frames_per_chunk rows per pass"); total += std::max(0, h_row_count[c]); }
+  K3_REQUIRE(total == 0 || (d_new && ((uintptr_t)d_new & 15) == 0), "k3_nnet_stream_forward: d_new must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream; k3_nnet_stream::Slot *g; { const int rc = stream_slot(s, &g); if (rc) return rc; }
+  const size_t o_cnt = align_up(sizeof(long long) * (s->nch + 1), 16);
+  memcpy(g->h, h_row_start, sizeof(long long) * s->nch); memcpy(g->h + o_cnt, h_row_count, sizeof(int) * s->nch);
+  K3_HIP_CHECK(hipMemcpyAsync(g->d, g->h, s->slot_bytes, hipMemcpyHostToDevice, st));
+  const long long *d_start = reinterpret_cast<const long long *>(g->d); const int *d_cnt = reinterpret_cast<const int *>(g->d + o_cnt);
+  const int dim4 = s->in_dim / 4; const long long n = (long long)s->C * s->nch * dim4;
+  hipLaunchKernelGGL(k3_stream_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_new ? d_new : s->in_buf, (long long)ld_new, d_start, d_cnt, s->in_buf, s->ld_in, s->nch, s->C, s->H_in, dim4);
+  { const int rc = forward_impl(s->pass.get(), s->in_buf, s->ld_in, d_out, ld_out, stream); if (rc) return rc; }
+  hipLaunchKernelGGL(k3_stream_shift_kernel, dim3(128, (unsigned)s->n_nb), dim3(256), 0, st, s->d_nb, d_cnt, s->nch);
+  K3_HIP_CHECK(hipGetLastError());
+  K3_HIP_CHECK(hipEventRecord(g->ev, st)); g->used = true;
+  return K3_OK;
+}

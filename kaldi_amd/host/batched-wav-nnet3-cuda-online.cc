@@ -10,12 +10,52 @@
 #include <chrono>
 #include <cstring>
 #include <cmath>
+#include <atomic>
+#include <condition_variable>
 #include <deque>
 #include <iostream>
+#include <mutex>
 #include <thread>
 #include "k3_feat_options.h"
 #include "k3_online.h"
 using namespace k3host;
+
+// The simulation's audio source: the wav files are read and parsed by a few background threads, a bounded number of files ahead of the channel that will play them, in the order
+// the main loop admits them (iteration-major).  Reading 512 files of 10 s between two iterations was ~60 ms on the main thread with the GPU idle -- a fifth of an iteration.
+namespace {
+struct WavePrefetcher {
+  struct Item { k3host::Wave wave; bool ok = false, ready = false; };
+  WavePrefetcher(const std::vector<std::pair<std::string, std::string>> &scp, int iterations, size_t window, int threads) : scp_(scp), total_((size_t)iterations * scp.size()), window_(std::max<size_t>(window, 1)), items_(window_) {
+    for (int t = 0; t < std::max(1, threads); t++) th_.emplace_back([this] { Loop(); });
+  }
+  ~WavePrefetcher() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); for (auto &t : th_) t.join(); }
+  // the k-th file of the run (k = iteration * files + index): false when it could not be read
+  bool Get(size_t k, k3host::Wave *out) {
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [&] { return items_[k % window_].ready && tag_[k % window_] == k; });
+    Item &it = items_[k % window_]; const bool ok = it.ok; if (ok) *out = std::move(it.wave);
+    it = Item(); consumed_ = k + 1; l.unlock(); cv_.notify_all();
+    return ok;
+  }
+ private:
+  void Loop() {
+    for (;;) {
+      size_t k;
+      { std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return stop_ || (next_ < total_ && next_ < consumed_ + window_); });
+        if (stop_ || next_ >= total_) return;
+        k = next_++; }
+      Item it;
+      try { it.wave = k3host::ReadWave(scp_[k % scp_.size()].second); it.ok = true; } catch (const k3host::FatalError &) { it.ok = false; }
+      it.ready = true;
+      { std::lock_guard<std::mutex> l(m_); items_[k % window_] = std::move(it); tag_[k % window_] = k; }
+      cv_.notify_all();
+    }
+  }
+  const std::vector<std::pair<std::string, std::string>> &scp_; size_t total_, window_; std::vector<Item> items_; std::map<size_t, size_t> tag_;
+  std::mutex m_; std::condition_variable cv_; size_t next_ = 0, consumed_ = 0; bool stop_ = false; std::vector<std::thread> th_;
+};
+}  // namespace
 
 int main(int argc, char **argv) {
   try {
@@ -134,6 +174,7 @@ int main(int argc, char **argv) {
     auto take_rows = [](Chan &c, int n, std::vector<int32_t> *idx) {      // the first n pending rows of the channel, in order
       for (int sgm = 0; sgm < 2 && n > 0; sgm++) { const int k = std::min(n, c.seg_cnt[sgm]); for (int j = 0; j < k; j++) idx->push_back((int32_t)(c.seg_off[sgm] + j)); c.seg_off[sgm] += k; c.seg_cnt[sgm] -= k; n -= k; c.pend -= k; }
     };
+    WavePrefetcher prefetch(scp, iterations, (size_t)2 * nch + 8, 8);
     const auto t_start = std::chrono::steady_clock::now();
     for (int iter = 0; iter < iterations; iter++) {
       std::deque<int> queue; for (size_t i = 0; i < scp.size(); i++) queue.push_back((int)i);
@@ -144,7 +185,7 @@ int main(int argc, char **argv) {
           if (chan[ch].utt >= 0) continue;
           const int u = queue.front(); queue.pop_front();
           Wave w;
-          try { w = ReadWave(scp[u].second); } catch (const FatalError &) { num_err++; ch--; continue; }
+          if (!prefetch.Get((size_t)iter * scp.size() + (size_t)u, &w)) { num_err++; ch--; continue; }
           if (w.samp_freq != fopts.samp_freq) { K3H_WARN << "Sample frequency mismatch for " << scp[u].first; num_err++; ch--; continue; }
           if (k3_feat_num_frames(plan, (int64_t)w.samples.size()) == 0) { K3H_WARN << "Utterance " << scp[u].first << " is too short to decode"; num_err++; ch--; continue; }
           total_audio += w.samples.size() / (double)w.samp_freq; num_task++;
@@ -194,8 +235,8 @@ int main(int argc, char **argv) {
           if (!run.empty()) {
             auto res = net.Pass(run, newbuf.p, n_new, lasts, ivs ? ivs->Gather(run) : nullptr);
             // end of stream: frames still waiting for right context may take more passes
-            std::vector<std::vector<std::pair<int, int>>> per(nch); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
-            for (int ch = 0; ch < nch; ch++) { int64_t n = 0; for (auto &r : per[ch]) { for (int k = 0; k < r.second; k++) idx.push_back(r.first + k); n += r.second; } ro[ch + 1] = ro[ch] + n; }
+            std::vector<std::vector<StaticNnet3::Rows>> per(nch); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
+            for (int ch = 0; ch < nch; ch++) { int64_t n = 0; for (auto &r : per[ch]) { for (int k = 0; k < r.count; k++) idx.push_back(r.first + k * r.stride); n += r.count; } ro[ch + 1] = ro[ch] + n; }
           }
           const int lb = (int)(pass_no++ & 1); DevBuf<float> &llb = ll[lb];
           if (tp_used[lb]) K3O_HIP(hipStreamWaitEvent(ws, ev_tp[lb], 0));      // the launch that read this block two passes ago (growing the block frees it: hipFree waits for the device)

@@ -90,12 +90,23 @@ class OnlineFeatures {
   DevBuf<float> waves_, feats_; DevBuf<int64_t> woff_, foff_;
 };
 
+// Two engines behind one interface.  (i) The stateful engine of the C ABI (k3_nnet_stream_*, round 5): every node keeps its last rows per channel and a pass evaluates the
+// frames_per_chunk NEW frames of every listed channel, nothing else -- used whenever the model allows it.  (ii) The reference's scheme (BatchedStaticNnet3::RunBatch): the network
+// planned once for max_batch slots of left context + chunk + right context, the context frames stashed per channel and re-evaluated with every chunk -- for models with an
+// i-vector input or row operations inside the network.  Either way the rows are those of the whole-utterance forward, bit for bit.
 class StaticNnet3 {
  public:
+  struct Rows { int first, count, stride; };      // a slot's valid output rows in Out(): first, first + stride, ...
   StaticNnet3(k3_nnet *nnet, int max_batch, int nchannels, int frames_per_chunk, int subsampling, const float *log_priors, float acoustic_scale, hipStream_t stream = nullptr)
       : stream_(stream), B_(max_batch), nch_(nchannels), C_(frames_per_chunk), s_(subsampling) {
     if (C_ <= 0 || C_ % s_) K3H_ERR << "--frames-per-chunk must be a positive multiple of --frame-subsampling-factor";
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
+    if (ni.ivector_dim == 0 && !getenv("K3_ONLINE_RECOMPUTE_CONTEXT") && k3_nnet_stream_create(nnet, nch_, C_, s_, log_priors, acoustic_scale, &inc_) == K3_OK) {
+      k3_nnet_stream_info si; K3H_CHECK_K3(k3_nnet_stream_get_info(inc_, &si)); dim_ = ni.input_dim; odim_ = ni.output_dim; Rc_ = si.right_context; n_out_ = si.output_rows_per_pass; first_out_ = si.first_output_time;
+      out_.need((size_t)n_out_ * nch_ * odim_); passes_.assign(nch_, 0); total_.assign(nch_, 0); ended_.assign(nch_, 0);
+      return;
+    }
+    inc_ = nullptr;      // (K3_ERR_UNSUPPORTED: the model needs the chunk + context scheme)
     dim_ = ni.input_dim; odim_ = ni.output_dim; Lc_ = (ni.left_context + s_ - 1) / s_ * s_; Rc_ = ni.right_context; P_ = Lc_ + C_ + Rc_; rps_ = (P_ + s_ - 1) / s_; S_ = Lc_ + Rc_ + C_ + 2 * s_;
     std::vector<int32_t> nf(B_, P_); ivdim_ = ni.ivector_dim;
     // models with the recipes' i-vector input: every slot is an "utterance" with ONE i-vector (the --ivectors form of the planner), handed in per pass
@@ -105,19 +116,21 @@ class StaticNnet3 {
     inp_.need((size_t)B_ * P_ * dim_); out_.need((size_t)B_ * rps_ * odim_);
     t_next_.assign(nch_, 0); n_seen_.assign(nch_, 0); lo_.assign(nch_, 0);
   }
-  ~StaticNnet3() { if (batch_) k3_nnet_batch_destroy(batch_); }
+  ~StaticNnet3() { if (batch_) k3_nnet_batch_destroy(batch_); if (inc_) k3_nnet_stream_destroy(inc_); }
+  bool Stateful() const { return inc_ != nullptr; }
   int OutputDim() const { return odim_; }
   int FramesPerChunk() const { return C_; }
-  void Reset(int ch) { t_next_[ch] = n_seen_[ch] = lo_[ch] = 0; }
+  void Reset(int ch) { if (inc_) { passes_[ch] = 0; total_[ch] = 0; ended_[ch] = 0; return; } t_next_[ch] = n_seen_[ch] = lo_[ch] = 0; }
   // One planned forward.  d_new: the new frames of the slots back to back (n_new[i] rows each, may be null when all are 0).  Returns per
   // slot (first row, count) of its valid output rows in Out().
   // d_iv (models with an i-vector input): [channels.size() x IvectorDim()] on the device, the i-vector each slot's chunk is evaluated with (decodable-online-looped.cc:166-205: one per chunk)
-  std::vector<std::pair<int, int>> Pass(const std::vector<int> &channels, const float *d_new, const std::vector<int> &n_new, const std::vector<char> &last, const float *d_iv = nullptr) {
+  std::vector<Rows> Pass(const std::vector<int> &channels, const float *d_new, const std::vector<int> &n_new, const std::vector<char> &last, const float *d_iv = nullptr) {
     if ((ivdim_ > 0) != (d_iv != nullptr)) K3H_ERR << "StaticNnet3::Pass: the model " << (ivdim_ > 0 ? "has" : "has no") << " i-vector input";
+    if (inc_) return PassStateful(channels, d_new, n_new, last);
     std::vector<int32_t> ist((size_t)B_ * P_, -1), inw((size_t)B_ * P_, -1), ust((size_t)nch_ * S_, -1), unw((size_t)nch_ * S_, -1);
     std::vector<char> touched(nch_, 0); for (int ch : channels) touched[ch] = 1;
     for (int ch = 0; ch < nch_; ch++) if (!touched[ch]) for (int64_t k = 0; k < n_seen_[ch] - lo_[ch]; k++) ust[(size_t)ch * S_ + k] = (int32_t)(ch * S_ + k);
-    std::vector<std::pair<int, int>> res; int64_t noff = 0, total_new = 0; for (int n : n_new) total_new += n;
+    std::vector<Rows> res; int64_t noff = 0, total_new = 0; for (int n : n_new) total_new += n;
     for (size_t i = 0; i < channels.size(); i++) {
       const int ch = channels[i]; const int64_t avail = n_seen_[ch] + n_new[i], tn = t_next_[ch];
       int64_t count = 0;
@@ -126,7 +139,7 @@ class StaticNnet3 {
       count = std::min<int64_t>(count, C_ / s_);
       auto source = [&](int64_t tau, int32_t *st, int32_t *nw) { if (tau >= n_seen_[ch]) *nw = (int32_t)(noff + tau - n_seen_[ch]); else *st = (int32_t)(ch * S_ + tau - lo_[ch]); };
       if (avail > 0) for (int k = 0; k < P_; k++) { const int64_t tau = std::min<int64_t>(std::max<int64_t>(tn - Lc_ + k, 0), avail - 1); source(tau, &ist[i * P_ + k], &inw[i * P_ + k]); }
-      res.push_back({(int)(i * rps_ + Lc_ / s_), (int)count});
+      res.push_back({(int)(i * rps_ + Lc_ / s_), (int)count, 1});
       const int64_t tn2 = tn + count * s_, lo2 = std::max<int64_t>(0, tn2 - Lc_);
       if (avail - lo2 > S_) K3H_ERR << "internal: context stash capacity";
       for (int64_t tau = lo2; tau < avail; tau++) source(tau, &ust[(size_t)ch * S_ + (tau - lo2)], &unw[(size_t)ch * S_ + (tau - lo2)]);
@@ -146,9 +159,44 @@ class StaticNnet3 {
     return res;
   }
   const float *Out() const { return out_.p; }
-  bool Pending(int ch) const { return t_next_[ch] < n_seen_[ch]; }
+  bool Pending(int ch) const {
+    if (!inc_) return t_next_[ch] < n_seen_[ch];
+    // stateful engine: an ended stream needs more passes (its last frame replicated) until the newest output row reaches its last output time
+    return ended_[ch] && total_[ch] > 0 && passes_[ch] * (int64_t)C_ - 1 - Rc_ < (total_[ch] - 1) / s_ * s_;
+  }
   int IvectorDim() const { return ivdim_; }
  private:
+  // One pass of the stateful engine: slot i's channel consumes its n_new[i] rows of d_new (frames_per_chunk of them, fewer / none only with last[i]: the end of its stream).
+  // A channel's FIRST pass seeds its histories with the response to its first frame replicated (k3_nnet_stream_reset).  Output row k of the pass belongs to channel-local time
+  // first_out_ + passes * C + k * s: the valid ones -- t >= 0, and below the stream's length once that is known -- are what the caller hands to the decoder.
+  std::vector<Rows> PassStateful(const std::vector<int> &channels, const float *d_new, const std::vector<int> &n_new, const std::vector<char> &last) {
+    std::vector<int64_t> start(nch_, 0); std::vector<int32_t> count(nch_, -1), fresh, fresh_row; int64_t noff = 0;
+    for (size_t i = 0; i < channels.size(); i++) {
+      const int ch = channels[i];
+      if (n_new[i] != C_ && !last[i]) K3H_ERR << "StaticNnet3::Pass: the stateful engine takes whole chunks of " << C_ << " frames (got " << n_new[i] << " before the end of the stream)";
+      if (ended_[ch] && n_new[i] > 0) K3H_ERR << "StaticNnet3::Pass: frames for a stream that has ended";
+      if (passes_[ch] == 0 && total_[ch] == 0) { if (n_new[i] == 0) { count[ch] = -1; continue; } fresh.push_back(ch); fresh_row.push_back((int32_t)noff); }      // (an empty stream: nothing to evaluate)
+      start[ch] = noff; count[ch] = n_new[i]; noff += n_new[i];
+    }
+    if (!fresh.empty()) {
+      float *f0 = first_.need(fresh.size() * (size_t)dim_); fidx_.upload_async(fresh_row, stream_);
+      K3H_CHECK_K3(k3_mat_copy_rows(f0, dim_, (int32_t)fresh.size(), dim_, d_new, dim_, fidx_.p, stream_));
+      K3H_CHECK_K3(k3_nnet_stream_reset(inc_, fresh.data(), (int32_t)fresh.size(), f0, dim_, stream_));
+    }
+    K3H_CHECK_K3(k3_nnet_stream_forward(inc_, d_new, dim_, start.data(), count.data(), out_.p, odim_, stream_));
+    std::vector<Rows> res;
+    for (size_t i = 0; i < channels.size(); i++) {
+      const int ch = channels[i];
+      if (count[ch] < 0) { res.push_back({0, 0, nch_}); if (last[i]) ended_[ch] = 1; continue; }
+      total_[ch] += n_new[i]; if (last[i]) ended_[ch] = 1;
+      const int64_t t0 = first_out_ + passes_[ch] * (int64_t)C_; passes_[ch]++;
+      int k0 = 0; while (k0 < n_out_ && t0 + (int64_t)k0 * s_ < 0) k0++;
+      int k1 = n_out_; if (ended_[ch]) while (k1 > k0 && t0 + (int64_t)(k1 - 1) * s_ >= total_[ch]) k1--;
+      res.push_back({k0 * nch_ + ch, k1 - k0, nch_});
+    }
+    return res;
+  }
+  k3_nnet_stream *inc_ = nullptr; int n_out_ = 0, first_out_ = 0; std::vector<int64_t> passes_, total_; std::vector<char> ended_; DevBuf<float> first_; DevBuf<int32_t> fidx_;
   hipStream_t stream_ = nullptr; int ivdim_ = 0; DevBuf<float> iv_;
   int B_, nch_, C_, s_, dim_ = 0, odim_ = 0, Lc_ = 0, Rc_ = 0, P_ = 0, rps_ = 0, S_ = 0, cur_ = 0;
   k3_nnet_batch *batch_ = nullptr;

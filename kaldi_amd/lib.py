@@ -44,6 +44,11 @@ class NnetInfo(ctypes.Structure):
                 ("num_components", ctypes.c_int32), ("num_fused_nodes", ctypes.c_int32), ("has_priors", ctypes.c_int32), ("num_params", ctypes.c_int64),
                 ("ivector_dim", ctypes.c_int32)]
 
+class NnetStreamInfo(ctypes.Structure):
+    """k3_nnet_stream_info (include/k3hip.h)"""
+    _fields_ = [("num_channels", ctypes.c_int32), ("frames_per_chunk", ctypes.c_int32), ("subsampling", ctypes.c_int32), ("output_rows_per_pass", ctypes.c_int32),
+                ("first_output_time", ctypes.c_int32), ("right_context", ctypes.c_int32), ("input_history", ctypes.c_int32), ("flops_per_pass", ctypes.c_double)]
+
 class DecoderConfig(ctypes.Structure):
     """k3_decoder_config (include/k3hip.h); decoding fields = LatticeFasterDecoderConfig (decoder/lattice-faster-decoder.h:37-107)."""
     _fields_ = [("beam", ctypes.c_float), ("max_active", ctypes.c_int32), ("min_active", ctypes.c_int32), ("lattice_beam", ctypes.c_float),
@@ -97,6 +102,11 @@ def load():
     L.k3_nnet_batch_output_rows.argtypes = [vp, vp]; L.k3_nnet_batch_output_rows.restype = i64
     L.k3_nnet_batch_flops.argtypes = [vp]; L.k3_nnet_batch_flops.restype = ctypes.c_double
     L.k3_nnet_forward.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.k3_nnet_stream_create.argtypes = [vp, i32, i32, i32, vp, ctypes.c_float, ctypes.POINTER(vp)]
+    L.k3_nnet_stream_destroy.argtypes = [vp]; L.k3_nnet_stream_destroy.restype = None
+    L.k3_nnet_stream_get_info.argtypes = [vp, ctypes.POINTER(NnetStreamInfo)]
+    L.k3_nnet_stream_reset.argtypes = [vp, vp, i32, vp, i64, vp]
+    L.k3_nnet_stream_forward.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp]
     L.k3_nnet_batch_create_ivector.argtypes = [vp, i32, vp, i32, vp, ctypes.c_float, i32, i32, vp, ctypes.POINTER(vp)]
     L.k3_nnet_batch_ivector_rows.argtypes = [vp]; L.k3_nnet_batch_ivector_rows.restype = i64
     L.k3_nnet_forward_ivector.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp]

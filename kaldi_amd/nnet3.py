@@ -161,3 +161,70 @@ class BatchedStaticNnet3:
             pending = [i for i in pending if self.t_next[channels[i]] < self.n_seen[channels[i]]]
         od = self.nnet.info.output_dim
         return [torch.cat(o, 0) if o else torch.empty((0, od), dtype=torch.float32, device=self.dev) for o in outs]
+
+
+class StreamNnet3:
+    """Stateful streaming forward (k3_nnet_stream_*, round 5): the role of BatchedStaticNnet3 WITHOUT re-evaluating a chunk's context -- every node keeps its last rows per
+    channel, a pass consumes frames_per_chunk new frames per channel, every row of every node is computed once per stream; outputs bit-identical to NnetBatch.forward over the
+    whole utterance.  RunBatch has BatchedStaticNnet3's signature; frames are buffered per channel until a whole chunk (or the end of the stream) is there, so a call returns
+    the output rows that became computable (possibly none), in time order."""
+    def __init__(self, nnet, nchannels, frames_per_chunk=51, frame_subsampling_factor=3, log_priors=None, acoustic_scale=1.0, device="cuda:0"):
+        self._L = _l.load(); self.nnet = nnet; self.nch = int(nchannels); self.C = int(frames_per_chunk); self.s = int(frame_subsampling_factor); self.dev = torch.device(device)
+        lp = None if log_priors is None else np.ascontiguousarray(log_priors, np.float32)
+        h = ctypes.c_void_p()
+        _l.check(self._L.k3_nnet_stream_create(nnet._h, self.nch, self.C, self.s, None if lp is None else lp.ctypes.data, float(acoustic_scale), ctypes.byref(h)))
+        self._h = h; info = _l.NnetStreamInfo(); _l.check(self._L.k3_nnet_stream_get_info(self._h, ctypes.byref(info))); self.info = info
+        self.N_out = info.output_rows_per_pass; self.first_out = info.first_output_time; self.dim = nnet.info.input_dim; self.odim = nnet.info.output_dim
+        self.out = torch.empty((self.N_out * self.nch, self.odim), dtype=torch.float32, device=self.dev)
+        self.passes = np.zeros(self.nch, np.int64); self.n_total = np.zeros(self.nch, np.int64); self.ended = np.zeros(self.nch, bool)
+        self.pend = [torch.empty((0, self.dim), dtype=torch.float32, device=self.dev) for _ in range(self.nch)]; self.needs_seed = np.zeros(self.nch, bool)
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None): self._L.k3_nnet_stream_destroy(self._h); self._h = None
+        except Exception: pass
+    def GetNOutputFramesPerChunk(self): return self.C // self.s
+    def _wants_pass(self, ch):
+        if self.pend[ch].shape[0] >= self.C: return True
+        if not self.ended[ch]: return False
+        if self.pend[ch].shape[0] > 0: return True
+        last_out = (int(self.n_total[ch]) - 1) // self.s * self.s      # outputs exist for t = 0, s, 2s, ... < number of frames
+        hi_out = int(self.passes[ch]) * self.C - 1 - self.info.right_context
+        return self.n_total[ch] > 0 and hi_out < last_out
+    def _pass(self, chs):
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        start = np.zeros(self.nch, np.int64); cnt = np.full(self.nch, -1, np.int32); parts = []; at = 0
+        for ch in chs:      # (any order: a channel's rows are addressed by (start, count))
+            n = min(self.C, int(self.pend[ch].shape[0])); start[ch] = at; cnt[ch] = n
+            if n: parts.append(self.pend[ch][:n]); self.pend[ch] = self.pend[ch][n:]; at += n
+        new = torch.cat(parts, 0).contiguous() if parts else None
+        _l.check(self._L.k3_nnet_stream_forward(self._h, None if new is None else new.data_ptr(), self.dim if new is None else new.stride(0), start.ctypes.data, cnt.ctypes.data, self.out.data_ptr(), self.out.stride(0), st))
+        res = {}
+        for ch in chs:
+            t = self.first_out + int(self.passes[ch]) * self.C + np.arange(self.N_out) * self.s
+            ok = t >= 0
+            if self.ended[ch]: ok &= t < self.n_total[ch]
+            k = np.nonzero(ok)[0]
+            res[ch] = self.out[torch.from_numpy(k * self.nch + ch).to(self.dev)] if len(k) else None
+            self.passes[ch] += 1
+        return res
+    def RunBatch(self, channels, chunks, is_first_chunk, is_last_chunk, ivectors=None):
+        if ivectors is not None: raise ValueError("StreamNnet3: models with an i-vector input use BatchedStaticNnet3")
+        if len(set(channels)) != len(channels): raise ValueError("at most one chunk per channel")
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        for ch, f in zip(channels, is_first_chunk):
+            if f: self.passes[ch] = 0; self.n_total[ch] = 0; self.ended[ch] = False; self.pend[ch] = self.pend[ch][:0]; self.needs_seed[ch] = True
+        for ch, c, last in zip(channels, chunks, is_last_chunk):
+            if self.ended[ch]: raise ValueError("StreamNnet3: frames for a stream that has ended")
+            self.pend[ch] = torch.cat([self.pend[ch], c.to(self.dev, torch.float32)], 0); self.n_total[ch] += int(c.shape[0]); self.ended[ch] = bool(last)
+        fresh = [ch for ch in channels if self.needs_seed[ch] and self.pend[ch].shape[0] > 0]      # a stream is seeded with its first frame as soon as that exists
+        if fresh:
+            ids = np.ascontiguousarray(fresh, np.int32); f0 = torch.stack([self.pend[ch][0] for ch in fresh], 0).contiguous()
+            _l.check(self._L.k3_nnet_stream_reset(self._h, ids.ctypes.data, len(ids), f0.data_ptr(), f0.stride(0), st))
+            for ch in fresh: self.needs_seed[ch] = False
+        outs = {ch: [] for ch in channels}
+        while True:
+            run = [ch for ch in channels if self._wants_pass(ch)]
+            if not run: break
+            for ch, o in self._pass(run).items():
+                if o is not None: outs[ch].append(o)
+        return [torch.cat(outs[ch], 0) if outs[ch] else torch.empty((0, self.odim), dtype=torch.float32, device=self.dev) for ch in channels]

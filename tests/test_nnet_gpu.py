@@ -148,6 +148,50 @@ def test_batched_static_nnet3_streaming_equals_whole_utterance(tmp_path):
             assert torch.equal(g, ref_u[u]), (C, u, (g - ref_u[u]).abs().max().item())
 
 
+def test_stateful_streaming_forward_equals_whole_utterance(tmp_path):
+    """k3_nnet_stream_* (round 5): every node keeps its last rows per channel, a pass evaluates frames_per_chunk NEW frames per channel and nothing else -- no re-evaluation of a
+    chunk's left / right context as in BatchedStaticNnet3::RunBatch.  Streams of every length (1 frame .. 12 chunks), random chunk sizes (frames are buffered to whole chunks),
+    channels reused by later streams, channels that sit passes out, the end of a stream flushed with its last frame replicated: the rows must be those of the whole-utterance
+    forward BIT FOR BIT, and every output row must come out exactly once."""
+    import torch
+    from kaldi_amd import nnet3, synth
+    rng = np.random.default_rng(12); dev = torch.device("cuda:0")
+    calib = (rng.standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    net_w = synth.make_tdnnf(seed=5, dim=96, bottleneck=24, strides=(1, 1, 0, 3, 3), prefinal_small=48, num_pdfs=120, calib_feats=calib, out_std=1.5)
+    mp = str(tmp_path / "m.raw"); net_w.write(mp)
+    net = nnet3.Nnet(mp); s = 3
+    lens = [1, 2, 47, 150, 151, 333, 610, 29, 51, 52, 102, 3]
+    utts = [torch.from_numpy((rng.standard_normal((T, 40)) * 1.2 + 16.5).astype(np.float32)).to(dev) for T in lens]
+    whole = nnet3.NnetBatch(net, lens, s); ref = whole.forward(torch.cat(utts, 0)); torch.cuda.synchronize()
+    ref_u = [ref[whole.out_offsets[u]:whole.out_offsets[u + 1]] for u in range(len(lens))]
+    lp = rng.uniform(-6, -1, 120).astype(np.float32)
+    whole2 = nnet3.NnetBatch(net, lens, s, lp, 0.7); ref2 = whole2.forward(torch.cat(utts, 0)); torch.cuda.synchronize()
+    for C, nch, B, priors in ((51, 5, 3, False), (30, 4, 4, False), (150, 6, 2, True)):
+        drv = nnet3.StreamNnet3(net, nch, frames_per_chunk=C, frame_subsampling_factor=s, log_priors=lp if priors else None, acoustic_scale=0.7 if priors else 1.0)
+        assert drv.GetNOutputFramesPerChunk() == C // s and drv.info.right_context == net.info.right_context
+        got = [[] for _ in lens]; pos = [0] * len(lens); todo = list(range(len(lens))); chan_of = {}; free = list(range(nch))
+        while todo or chan_of:
+            while todo and free: chan_of[todo.pop(0)] = free.pop(0)
+            slots = [kv for kv in chan_of.items() if rng.uniform() < 0.8][:B] or list(chan_of.items())[:1]      # some channels sit this call out
+            chans, chunks, first, last = [], [], [], []
+            for u, ch in slots:
+                n = int(rng.integers(0, C + 1)) if lens[u] - pos[u] > 3 else lens[u] - pos[u]
+                n = min(n, lens[u] - pos[u])
+                chans.append(ch); chunks.append(utts[u][pos[u]:pos[u] + n]); first.append(pos[u] == 0); pos[u] += n; last.append(pos[u] == lens[u])
+            outs = drv.RunBatch(chans, chunks, first, last)
+            for (u, ch), o, l in zip(slots, outs, last):
+                got[u].append(o)
+                if l: free.append(chan_of.pop(u))
+        want = [ref2[whole2.out_offsets[u]:whole2.out_offsets[u + 1]] for u in range(len(lens))] if priors else ref_u
+        for u in range(len(lens)):
+            g = torch.cat(got[u], 0)
+            assert g.shape == want[u].shape, (C, u, lens[u], g.shape, want[u].shape)
+            assert torch.equal(g, want[u]), (C, u, lens[u], (g - want[u]).abs().max().item())
+    # a model the stateful engine cannot run says so (the callers fall back to chunk + context)
+    from kaldi_amd import lib
+    with pytest.raises(lib.K3Error): nnet3.StreamNnet3(net, 2, frames_per_chunk=3, frame_subsampling_factor=3)      # a chunk shorter than a node's history
+
+
 # ---------------------------------------------------------------------------------------------- models with an i-vector input
 IV_CASES = {"s1_c50_p10": (1, 50, 10, False), "s3_c50_p10": (3, 50, 10, False), "s3_c21_p7": (3, 21, 7, False), "s1_c20_p10_short": (1, 20, 10, False), "s3_utt": (3, 50, 0, True), "s1_utt": (1, 50, 0, True)}
 
