@@ -969,7 +969,6 @@ extern "C" void k3_nnet_stream_destroy(k3_nnet_stream *s) { delete s; }
 extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t frames_per_chunk, int32_t subsampling, const float *h_log_priors, float acoustic_scale, k3_nnet_stream **out) {
   K3_REQUIRE(net && out && num_channels > 0 && frames_per_chunk > 0 && subsampling >= 1 && frames_per_chunk % subsampling == 0, "k3_nnet_stream_create: bad argument (frames_per_chunk must be a positive multiple of the subsampling factor)");
   K3_REQUIRE(net->fm.input_dim % 4 == 0, "k3_nnet_stream_create: the input dimension must be a multiple of 4 (vector loads)");
-  { const int rc = ensure_uploaded(net); if (rc) return rc; }
   const k3::FusedModel &fm = net->fm; const int nn = (int)fm.nodes.size(), C = frames_per_chunk, NCH = num_channels;
   if (fm.ivector_dim > 0) { k3::set_error("k3_nnet_stream_create: models with an i-vector input are evaluated chunk by chunk with their context (k3_nnet_batch_create_ivector)"); return K3_ERR_UNSUPPORTED; }
   // ---- time grids: the whole-utterance planner's backward sweep (A = first time, R = right extension, G = step)
@@ -1016,12 +1015,15 @@ extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t
     };
     bool ok = true;
     { int lo = 1 << 30, hi = -(1 << 30); for (int o : f.offsets) { lo = std::min(lo, o); hi = std::max(hi, o); if ((first[i] + o - first[idx(f.input)]) % Gx(f.input) != 0) ok = false; } ok = ok && need(f.input, lo, hi); }
-    for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual) ok = ok && need(op.res_node, 0, 0) && Gx(op.res_node) == G[i];
-    if (!ok) { k3::set_error("k3_nnet_stream_create: the time grids of node %s do not line up for incremental evaluation", f.name.c_str()); return K3_ERR_UNSUPPORTED; }
+    for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual) ok = ok && need(op.res_node, 0, 0);      // (the bypass may come from a finer grid: G_i % G_res == 0 is all it takes)
+    if (!ok) { k3::set_error("k3_nnet_stream_create: the time grids of node %s (first %d, step %d) and its inputs do not line up for incremental evaluation", f.name.c_str(), first[i], G[i]); return K3_ERR_UNSUPPORTED; }
   }
   H[nn] = std::max(H[nn], 1);      // (the input keeps at least its newest frame: what the end of a stream replicates)
   for (int i = -1; i < nn; i++) if ((i < 0 || used[i]) && H[idx(i)] > Nn[idx(i)]) { k3::set_error("k3_nnet_stream_create: frames_per_chunk %d is shorter than the history a node keeps (%d rows)", C, H[idx(i)]); return K3_ERR_UNSUPPORTED; }
 
+  if (getenv("K3_NNET_STREAM_PLAN")) for (int i = -1; i < nn; i++) if (i < 0 || used[i])      // development aid: the plan, before anything is allocated
+    fprintf(stderr, "k3_nnet_stream plan: node %-22s A %4d R %3d G %d first %4d new %3d history %d\n", i < 0 ? "input" : fm.nodes[i].name.c_str(), i < 0 ? A_in : A[i], i < 0 ? R_in : R[i], Gx(i), first[idx(i)], Nn[idx(i)], H[idx(i)]);
+  { const int rc = ensure_uploaded(net); if (rc) return rc; }      // (everything above is host arithmetic: a model the engine cannot run is refused without touching the device)
   std::unique_ptr<k3_nnet_stream> S(new k3_nnet_stream());
   S->net = net; S->nch = NCH; S->C = C; S->s = subsampling; S->in_dim = fm.input_dim; S->out_dim = fm.output_dim; S->H_in = H[nn]; S->N_out = Nn[fm.output_node]; S->first_out = first[fm.output_node]; S->R_in = R_in;
   auto dalloc = [&](size_t bytes, float **p) -> int { K3_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(bytes, 256))); S->allocs.push_back(*p); K3_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(bytes, 256))); return K3_OK; };

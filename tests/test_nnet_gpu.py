@@ -187,9 +187,9 @@ def test_stateful_streaming_forward_equals_whole_utterance(tmp_path):
             g = torch.cat(got[u], 0)
             assert g.shape == want[u].shape, (C, u, lens[u], g.shape, want[u].shape)
             assert torch.equal(g, want[u]), (C, u, lens[u], (g - want[u]).abs().max().item())
-    # a model the stateful engine cannot run says so (the callers fall back to chunk + context)
+    # a configuration the stateful engine cannot run says so (the callers fall back to chunk + context)
     from kaldi_amd import lib
-    with pytest.raises(lib.K3Error): nnet3.StreamNnet3(net, 2, frames_per_chunk=3, frame_subsampling_factor=3)      # a chunk shorter than a node's history
+    with pytest.raises(lib.K3Error): nnet3.StreamNnet3(net, 2, frames_per_chunk=4, frame_subsampling_factor=3)      # a chunk that is not a whole number of output frames
 
 
 # ---------------------------------------------------------------------------------------------- models with an i-vector input
