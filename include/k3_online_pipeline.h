@@ -129,18 +129,18 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
           const bool end = is_last[run[i]] && c.pend == 0; lasts.push_back(end); if (end) closed[run[i]] = 1;
         }
         if (!take.empty()) { gidx_.upload_async(take, ws_); K3H_CHECK_K3(k3_mat_copy_rows(new_.p, fdim_, (int32_t)take.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, ws_)); } }
-      std::vector<int64_t> ro(nch_ + 1, 0); std::vector<int32_t> idx;
+      // the pass's log-likelihoods are decoded where the network left them (k3_decoder_advance_decoding_strided): two network output buffers in turn, pass k + 1 queued behind the
+      // token-passing launch that read its buffer two passes ago (ev_tp_), the launch behind the pass that fills it (ev_ll_)
+      const int lb = (int)(pass_no_++ & 1);
+      std::vector<const float *> lane_first(nch_, nullptr); std::vector<int32_t> lane_frames(nch_, 0); int64_t ld_rows = N_;
       if (!run.empty()) {
+        if (tp_used_[lb]) K3O_HIP(hipStreamWaitEvent(ws_, ev_tp_[lb], 0));
+        net_->SelectOut(lb);
         auto res = net_->Pass(run, new_.p, n_new, lasts, ivs_ ? ivs_->Gather(run) : nullptr);
-        std::vector<std::vector<StaticNnet3::Rows>> per(nch_); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
-        for (int ch = 0; ch < nch_; ch++) { int64_t k = 0; for (auto &r : per[ch]) { for (int j = 0; j < r.count; j++) idx.push_back(r.first + j * r.stride); k += r.count; } ro[ch + 1] = ro[ch] + k; }
+        for (size_t i = 0; i < run.size(); i++) if (res[i].count > 0) { lane_first[run[i]] = net_->Out() + (size_t)res[i].first * N_; lane_frames[run[i]] = res[i].count; ld_rows = (int64_t)res[i].stride * N_; }
       }
-      const int lb = (int)(pass_no_++ & 1); DevBuf<float> &llb = ll_[lb];
-      if (tp_used_[lb]) K3O_HIP(hipStreamWaitEvent(ws_, ev_tp_[lb], 0));      // the launch that read this block two passes ago
-      llb.need(std::max<size_t>(idx.size(), 1) * N_);
-      if (!idx.empty()) { llidx_.upload_async(idx, ws_); K3H_CHECK_K3(k3_mat_copy_rows(llb.p, N_, (int32_t)idx.size(), N_, net_->Out(), N_, llidx_.p, ws_)); }
       K3O_HIP(hipEventRecord(ev_ll_[lb], ws_)); K3O_HIP(hipStreamWaitEvent(ds_, ev_ll_[lb], 0));
-      K3H_CHECK_K3(k3_decoder_advance_decoding(dec_, nch_, llb.p, N_, ro.data(), ds_));
+      K3H_CHECK_K3(k3_decoder_advance_decoding_strided(dec_, nch_, lane_first.data(), lane_frames.data(), ld_rows, ds_));
       K3O_HIP(hipEventRecord(ev_tp_[lb], ds_)); tp_used_[lb] = true;
       need_advance = false;
       for (int ch : run) if (closed[ch] && net_->Pending(ch)) closed[ch] = 0;
@@ -215,7 +215,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
   const BatchedThreadedNnet3CudaOnlinePipelineConfig config_; const TransitionInfo &trans_;
   hipStream_t ws_ = nullptr, ds_ = nullptr; hipEvent_t ev_ll_[2] = {nullptr, nullptr}, ev_tp_[2] = {nullptr, nullptr}; bool tp_used_[2] = {false, false}; unsigned pass_no_ = 0; k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0; int32_t graph_start_ = 0; size_t pend_cap_ = 0;
   std::unique_ptr<OnlineFeatures> features_; std::unique_ptr<StaticNnet3> net_; std::unique_ptr<OnlineIvectors> ivs_; k3_ivector *ivx_ = nullptr; IvectorExtractionInfo iv_info_;
-  std::vector<Chan> chan_; DevBuf<float> held_[2], new_, ll_[2]; DevBuf<int32_t> llidx_, gidx_; int held_cur_ = 0; int64_t held_rows_ = 0;
+  std::vector<Chan> chan_; DevBuf<float> held_[2], new_; DevBuf<int32_t> gidx_; int held_cur_ = 0; int64_t held_rows_ = 0;
   std::mutex m_; std::condition_variable wcv_, done_cv_; bool stop_ = false; int n_callbacks_not_done_ = 0;
   std::map<CorrelationID, int> corr2chan_; std::vector<int> free_; std::map<CorrelationID, LatticeCallback> lat_cb_; std::map<CorrelationID, BestPathCallback> best_cb_;
   std::deque<std::shared_ptr<Task>> post_; std::vector<std::thread> workers_;

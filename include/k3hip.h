@@ -352,6 +352,9 @@ int k3_decoder_advance_decoding(k3_decoder *dec, int32_t num_utts, const float *
 /* The reference's own form of the call, CudaDecoder::AdvanceDecoding(lanes_assignements) (cuda-decoder.h:262): each listed channel gets a DEVICE
  * pointer to the log-likelihoods of its next num_frames frames (rows ld floats apart), wherever they live; the other channels of the group idle. */
 int k3_decoder_advance_decoding_lanes(k3_decoder *dec, int32_t num_channels, const int32_t *channels, const float *const *h_lane_frames, int32_t num_frames, int64_t ld, void *stream);
+/* ... with a frame count per channel and the rows of a channel `ld` floats apart: log-likelihoods decoded where a producer left them, e.g. the time-major output of
+ * k3_nnet_stream_forward (channel c's row k at k * num_channels + c: ld = num_channels * its row length).  h_lane_first[u] null or h_num_frames[u] = 0: channel u idles. */
+int k3_decoder_advance_decoding_strided(k3_decoder *dec, int32_t num_utts, const float *const *h_lane_first, const int32_t *h_num_frames, int64_t ld, void *stream);
 int k3_decoder_finalize_decoding(k3_decoder *dec, void *stream);
 /* Channels with independent lifetimes inside one lane group (CudaDecoder::InitDecoding(channels) cuda-decoder.h:248 / the per-channel
  * end of an utterance in the online pipeline): k3_decoder_init_channels restarts the listed lanes (start token + eps closure at their

@@ -1142,6 +1142,41 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
   return K3_OK;
 }
 
+// The same with a frame count per channel and the rows of a channel `ld` floats apart, wherever they lie: what the stateful network engine produces (k3_nnet_stream_forward:
+// channel c's output row k at row k * num_channels + c, i.e. ld = num_channels * row length) is decoded where it is -- no gather of a pass's log-likelihoods into one block
+// (round 5: that copy was 210 MB per pass of 512 channels, a sixth of the GPU work of a streaming round).  h_lane_first[u] = channel u's first row (null or h_num_frames[u] = 0:
+// the channel idles in this call).
+extern "C" int k3_decoder_advance_decoding_strided(k3_decoder *d, int32_t num_utts, const float *const *h_lane_first, const int32_t *h_num_frames, int64_t ld, void *stream) {
+  K3_REQUIRE(d && h_lane_first && h_num_frames && num_utts == d->last_utts && ld >= d->num_pdfs, "k3_decoder_advance_decoding_strided: bad argument (call k3_decoder_init_decoding for this many lanes first)");
+  hipStream_t st = (hipStream_t)stream; DecParams &p = d->p; const int U = d->last_utts;
+  for (int u = 0; u < U; u++) {
+    const int T = h_lane_first[u] ? h_num_frames[u] : 0;
+    K3_REQUIRE(T >= 0 && d->last_frames[u] + T + 2 <= d->fstride, "k3_decoder_advance_decoding_strided: more frames than max_total_frames of k3_decoder_init_decoding");
+    K3_REQUIRE(T == 0 || !d->lane_final[u], "k3_decoder_advance_decoding_strided: frames for a finalised lane (k3_decoder_init_channels restarts it)");
+  }
+  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq++ % k3_decoder::kArgSlots];
+  if (slot.used) K3_HIP_CHECK(hipEventSynchronize(slot.ev));
+  long long *ro = reinterpret_cast<long long *>(slot.h); const float **rows = reinterpret_cast<const float **>(slot.h + d->arg_off_rows);
+  ro[0] = 0;
+  for (int u = 0; u < U; u++) { const int T = h_lane_first[u] ? h_num_frames[u] : 0; ro[u + 1] = ro[u] + T; rows[u] = h_lane_first[u]; d->last_frames[u] += T; }
+  memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * U);
+  K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
+  std::fill(d->fresh.begin(), d->fresh.end(), 0);
+  p.loglikes = nullptr; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr;
+  p.lane_rows = reinterpret_cast<const float **>(slot.d + d->arg_off_rows);
+  const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
+  if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
+  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), U, st);
+  else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
+  K3_HIP_CHECK(hipGetLastError());
+  if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
+  if (!d->ev_tp) K3_HIP_CHECK(hipEventCreateWithFlags(&d->ev_tp, hipEventDisableTiming));
+  K3_HIP_CHECK(hipEventRecord(d->ev_tp, st)); d->ev_tp_recorded = true;
+  K3_HIP_CHECK(hipEventRecord(slot.ev, st)); slot.used = true;
+  d->started = true; d->last_stream = st; d->info_valid = false;
+  return K3_OK;
+}
+
 // FinalizeDecoding (lattice-faster-decoder.cc:634-649) on the GPU: lattice-beam pruning with final-probs; lattices can be fetched afterwards.
 static int finalize_lanes(k3_decoder *d, const std::vector<int> &lanes, hipStream_t st) {
   K3_REQUIRE(d->started, "k3_decoder_finalize_decoding: nothing to finalize");

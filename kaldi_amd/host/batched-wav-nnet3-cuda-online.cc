@@ -168,7 +168,7 @@ int main(int argc, char **argv) {
     // synchronous device copies per round (40 k copyBuffer calls = 46 % of the GPU time of a 512-channel run, 27 ms per round of 512 chunks).
     struct Chan { int utt = -1; Wave wav; size_t pos = 0; int pend = 0; bool started = false; int64_t seg_off[2] = {0, 0}; int seg_cnt[2] = {0, 0}; };
     std::vector<Chan> chan(nch);
-    DevBuf<float> held[2], newbuf, ll[2]; DevBuf<int32_t> llidx, gidx; int held_cur = 0; int64_t held_rows = 0;
+    DevBuf<float> held[2], newbuf; DevBuf<int32_t> gidx; int held_cur = 0; int64_t held_rows = 0;
     const size_t pend_cap = (size_t)(2 * C + 8);
     for (auto &h : held) h.need((size_t)nch * (pend_cap + (size_t)C + 16) * fdim);
     auto take_rows = [](Chan &c, int n, std::vector<int32_t> *idx) {      // the first n pending rows of the channel, in order
@@ -231,19 +231,20 @@ int main(int argc, char **argv) {
               c.started = true;
             }
             if (!take.empty()) { gidx.upload_async(take, ws); K3H_CHECK_K3(k3_mat_copy_rows(newbuf.p, fdim, (int32_t)take.size(), fdim, held[held_cur].p, fdim, gidx.p, ws)); } }
-          std::vector<int64_t> ro(nch + 1, 0); std::vector<int32_t> idx;
+          // The pass's log-likelihoods are decoded WHERE THE NETWORK LEFT THEM (k3_decoder_advance_decoding_strided: a first row, a count and a row distance per channel) -- no
+          // gather into one block (210 MB per pass of 512 channels).  The network writes two output buffers in turn: pass k + 1 is queued behind the token-passing launch
+          // that read the buffer two passes ago (ev_tp), the launch behind the pass that fills its buffer (ev_ll).
+          const int lb = (int)(pass_no++ & 1);
+          std::vector<const float *> lane_first(nch, nullptr); std::vector<int32_t> lane_frames(nch, 0); int64_t ld_rows = N;
           if (!run.empty()) {
+            if (tp_used[lb]) K3O_HIP(hipStreamWaitEvent(ws, ev_tp[lb], 0));
+            net.SelectOut(lb);
             auto res = net.Pass(run, newbuf.p, n_new, lasts, ivs ? ivs->Gather(run) : nullptr);
             // end of stream: frames still waiting for right context may take more passes
-            std::vector<std::vector<StaticNnet3::Rows>> per(nch); for (size_t i = 0; i < run.size(); i++) per[run[i]].push_back(res[i]);
-            for (int ch = 0; ch < nch; ch++) { int64_t n = 0; for (auto &r : per[ch]) { for (int k = 0; k < r.count; k++) idx.push_back(r.first + k * r.stride); n += r.count; } ro[ch + 1] = ro[ch] + n; }
+            for (size_t i = 0; i < run.size(); i++) if (res[i].count > 0) { lane_first[run[i]] = net.Out() + (size_t)res[i].first * N; lane_frames[run[i]] = res[i].count; ld_rows = (int64_t)res[i].stride * N; }
           }
-          const int lb = (int)(pass_no++ & 1); DevBuf<float> &llb = ll[lb];
-          if (tp_used[lb]) K3O_HIP(hipStreamWaitEvent(ws, ev_tp[lb], 0));      // the launch that read this block two passes ago (growing the block frees it: hipFree waits for the device)
-          llb.need((size_t)std::max<size_t>(idx.size(), 1) * N);
-          if (!idx.empty()) { llidx.upload_async(idx, ws); K3H_CHECK_K3(k3_mat_copy_rows(llb.p, N, (int32_t)idx.size(), N, net.Out(), N, llidx.p, ws)); }
           K3O_HIP(hipEventRecord(ev_ll[lb], ws)); K3O_HIP(hipStreamWaitEvent(ds, ev_ll[lb], 0));
-          K3H_CHECK_K3(k3_decoder_advance_decoding(dec, nch, llb.p, N, ro.data(), ds));
+          K3H_CHECK_K3(k3_decoder_advance_decoding_strided(dec, nch, lane_first.data(), lane_frames.data(), ld_rows, ds));
           K3O_HIP(hipEventRecord(ev_tp[lb], ds)); tp_used[lb] = true;
           need_advance = false;
           // flush passes for closed channels whose last outputs did not fit one pass

@@ -103,7 +103,7 @@ class StaticNnet3 {
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
     if (ni.ivector_dim == 0 && !getenv("K3_ONLINE_RECOMPUTE_CONTEXT") && k3_nnet_stream_create(nnet, nch_, C_, s_, log_priors, acoustic_scale, &inc_) == K3_OK) {
       k3_nnet_stream_info si; K3H_CHECK_K3(k3_nnet_stream_get_info(inc_, &si)); dim_ = ni.input_dim; odim_ = ni.output_dim; Rc_ = si.right_context; n_out_ = si.output_rows_per_pass; first_out_ = si.first_output_time;
-      out_.need((size_t)n_out_ * nch_ * odim_); passes_.assign(nch_, 0); total_.assign(nch_, 0); ended_.assign(nch_, 0);
+      out_.need((size_t)n_out_ * nch_ * odim_); out2_.need((size_t)n_out_ * nch_ * odim_); passes_.assign(nch_, 0); total_.assign(nch_, 0); ended_.assign(nch_, 0);
       return;
     }
     inc_ = nullptr;      // (K3_ERR_UNSUPPORTED: the model needs the chunk + context scheme)
@@ -113,7 +113,7 @@ class StaticNnet3 {
     if (ivdim_ > 0) { K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, B_, nf.data(), s_, log_priors, acoustic_scale, C_, 0, nullptr, &batch_)); iv_.need((size_t)B_ * ivdim_); }
     else K3H_CHECK_K3(k3_nnet_batch_create(nnet, B_, nf.data(), s_, log_priors, acoustic_scale, &batch_));
     for (int k = 0; k < 2; k++) { stash_[k].need((size_t)nch_ * S_ * dim_); K3O_HIP(hipMemsetAsync(stash_[k].p, 0, (size_t)nch_ * S_ * dim_ * 4, stream_)); }
-    inp_.need((size_t)B_ * P_ * dim_); out_.need((size_t)B_ * rps_ * odim_);
+    inp_.need((size_t)B_ * P_ * dim_); out_.need((size_t)B_ * rps_ * odim_); out2_.need((size_t)B_ * rps_ * odim_);
     t_next_.assign(nch_, 0); n_seen_.assign(nch_, 0); lo_.assign(nch_, 0);
   }
   ~StaticNnet3() { if (batch_) k3_nnet_batch_destroy(batch_); if (inc_) k3_nnet_stream_destroy(inc_); }
@@ -154,11 +154,15 @@ class StaticNnet3 {
     cur_ ^= 1;
     if (ivdim_ > 0) {
       K3O_HIP(hipMemsetAsync(iv_.p, 0, (size_t)B_ * ivdim_ * 4, stream_)); K3O_HIP(hipMemcpyAsync(iv_.p, d_iv, channels.size() * (size_t)ivdim_ * 4, hipMemcpyDeviceToDevice, stream_));
-      K3H_CHECK_K3(k3_nnet_forward_ivector(batch_, inp_.p, dim_, iv_.p, ivdim_, out_.p, odim_, stream_));
-    } else K3H_CHECK_K3(k3_nnet_forward(batch_, inp_.p, dim_, out_.p, odim_, stream_));
+      K3H_CHECK_K3(k3_nnet_forward_ivector(batch_, inp_.p, dim_, iv_.p, ivdim_, (which_ ? out2_ : out_).p, odim_, stream_));
+    } else K3H_CHECK_K3(k3_nnet_forward(batch_, inp_.p, dim_, (which_ ? out2_ : out_).p, odim_, stream_));
     return res;
   }
-  const float *Out() const { return out_.p; }
+  // the rows of the latest pass.  Two buffers alternate (SelectOut before a pass): a consumer on another stream -- token passing -- may still read pass k - 1's rows while pass k is
+  // evaluated; the caller orders pass k + 1 behind the consumer of pass k - 1 (an event), as it did for its own copy of the rows
+  const float *Out() const { return (which_ ? out2_ : out_).p; }
+  void SelectOut(int which) { which_ = which & 1; }
+  int OutputStride() const { return odim_; }
   bool Pending(int ch) const {
     if (!inc_) return t_next_[ch] < n_seen_[ch];
     // stateful engine: an ended stream needs more passes (its last frame replicated) until the newest output row reaches its last output time
@@ -183,7 +187,7 @@ class StaticNnet3 {
       K3H_CHECK_K3(k3_mat_copy_rows(f0, dim_, (int32_t)fresh.size(), dim_, d_new, dim_, fidx_.p, stream_));
       K3H_CHECK_K3(k3_nnet_stream_reset(inc_, fresh.data(), (int32_t)fresh.size(), f0, dim_, stream_));
     }
-    K3H_CHECK_K3(k3_nnet_stream_forward(inc_, d_new, dim_, start.data(), count.data(), out_.p, odim_, stream_));
+    K3H_CHECK_K3(k3_nnet_stream_forward(inc_, d_new, dim_, start.data(), count.data(), (which_ ? out2_ : out_).p, odim_, stream_));
     std::vector<Rows> res;
     for (size_t i = 0; i < channels.size(); i++) {
       const int ch = channels[i];
@@ -200,7 +204,7 @@ class StaticNnet3 {
   hipStream_t stream_ = nullptr; int ivdim_ = 0; DevBuf<float> iv_;
   int B_, nch_, C_, s_, dim_ = 0, odim_ = 0, Lc_ = 0, Rc_ = 0, P_ = 0, rps_ = 0, S_ = 0, cur_ = 0;
   k3_nnet_batch *batch_ = nullptr;
-  DevBuf<float> stash_[2], inp_, out_; DevBuf<int32_t> i0_, i1_, i2_, i3_;
+  DevBuf<float> stash_[2], inp_, out_, out2_; int which_ = 0; DevBuf<int32_t> i0_, i1_, i2_, i3_;
   std::vector<int64_t> t_next_, n_seen_, lo_;
 };
 // The i-vector extractor of an --ivector-extraction-config (OnlineNnet2FeaturePipelineInfo's ivector_extractor_info, online2/online-nnet2-feature-pipeline.cc:70-80) on the GPU

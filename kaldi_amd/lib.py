@@ -125,6 +125,7 @@ def load():
     L.k3_decoder_decode_batch.argtypes = [vp, i32, vp, i64, vp, vp]
     L.k3_decoder_init_decoding.argtypes = [vp, i32, i32, vp]; L.k3_decoder_advance_decoding.argtypes = [vp, i32, vp, i64, vp, vp]
     L.k3_decoder_advance_decoding_lanes.argtypes = [vp, i32, vp, vp, i32, i64, vp]
+    L.k3_decoder_advance_decoding_strided.argtypes = [vp, i32, vp, vp, i64, vp]
     L.k3_decoder_init_channels.argtypes = [vp, vp, i32, vp]; L.k3_decoder_finalize_channels.argtypes = [vp, vp, i32, vp]
     L.k3_decoder_finalize_decoding.argtypes = [vp, vp]; L.k3_decoder_num_frames_decoded.argtypes = [vp, i32]; L.k3_decoder_num_frames_decoded.restype = i32
     L.k3_decoder_lattice_info.argtypes = [vp, vp]; L.k3_decoder_order_sensitive_events.argtypes = [vp, vp]; L.k3_decoder_pool_growths.argtypes = [vp, vp]
