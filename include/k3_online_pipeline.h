@@ -58,7 +58,7 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     K3O_HIP(hipStreamCreate(&ws_));
     // token passing on its own stream: a chunk's launch lasts as long as its slowest lane, the next pass's features / network run beside it; the two streams share only the
     // gathered log-likelihood block (two of them, events ev_ll_: filled / ev_tp_: consumed)
-    K3O_HIP(hipStreamCreate(&ds_));
+    { int lo = 0, hi = 0; K3O_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); if (lo == hi) K3O_HIP(hipStreamCreate(&ds_)); else K3O_HIP(hipStreamCreateWithPriority(&ds_, hipStreamDefault, hi)); }      // (the critical path of a round)
     for (int k = 0; k < 2; k++) { K3O_HIP(hipEventCreateWithFlags(&ev_ll_[k], hipEventDisableTiming)); K3O_HIP(hipEventCreateWithFlags(&ev_tp_[k], hipEventDisableTiming)); }
     features_.reset(new OnlineFeatures(plan_, config_.feature_opts, nch_, ws_));
     net_.reset(new StaticNnet3(am_nnet, nch_, nch_, C_, s, lp.empty() ? nullptr : lp.data(), config_.acoustic_scale, ws_));

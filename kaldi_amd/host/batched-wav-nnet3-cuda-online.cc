@@ -144,7 +144,11 @@ int main(int argc, char **argv) {
     // ... and a second stream for token passing.  A chunk's token-passing launch lasts as long as its SLOWEST lane (5 - 9 ms for 17 frames of 512 lanes whose mean is ~2 ms:
     // most CUs idle in its tail), so the next pass's features / gathers / network run beside it on `ws`, the way the offline pipeline hides its front end behind the decoder.
     // The only buffer the two streams share is the gathered log-likelihood block: two of them, guarded by events (ev_ll: filled, ev_tp: consumed).
-    hipStream_t ds = nullptr; K3O_HIP(hipStreamCreate(&ds));
+    // (the decoder's stream at the highest priority the device offers: a chunk's launches are the critical path of a round -- consecutive launches of the same lanes --, the
+    // network's GEMMs beside them are throughput work; K3_ONLINE_FLAT_PRIORITY=1: both streams at the default priority, for A/B)
+    hipStream_t ds = nullptr;
+    { int lo = 0, hi = 0; K3O_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      if (getenv("K3_ONLINE_FLAT_PRIORITY") || lo == hi) K3O_HIP(hipStreamCreate(&ds)); else K3O_HIP(hipStreamCreateWithPriority(&ds, hipStreamDefault, hi)); }
     hipEvent_t ev_ll[2], ev_tp[2]; for (int k = 0; k < 2; k++) { K3O_HIP(hipEventCreateWithFlags(&ev_ll[k], hipEventDisableTiming)); K3O_HIP(hipEventCreateWithFlags(&ev_tp[k], hipEventDisableTiming)); }
     bool tp_used[2] = {false, false}; unsigned pass_no = 0;
     OnlineFeatures features(plan, fopts, nch, ws);
