@@ -133,6 +133,7 @@ class BatchedThreadedNnet3CudaPipeline2 {
   void SetLatticePostprocessor(const std::shared_ptr<LatticePostprocessor> &lattice_postprocessor) {
     lattice_postprocessor_ = lattice_postprocessor;
     lattice_postprocessor_->SetDecoderFrameShift(config_.feature_opts.frame_shift_ms * 1.0e-3f * config_.frame_subsampling_factor);
+    lattice_postprocessor_->SetTransitionInformation(&trans_);      // (batched-threaded-nnet3-cuda-pipeline2.h:206: SetTransitionModel)
   }
   // Enqueues one utterance; `callback` is called with its lattice from a worker thread ("will be called once the lattice is ready", :118-160).
   // An utterance that cannot be decoded (too short, decoder failure) still gets its callback, with an empty lattice (NumStates() == 0).

@@ -200,7 +200,7 @@ int main(int argc, char **argv) {
     const bool ctm_mode = !(out_wspec.compare(0, 3, "ark") == 0 || out_wspec.compare(0, 3, "scp") == 0) || out_wspec.find(':') == std::string::npos;
     std::shared_ptr<LatticePostprocessor> postprocessor; std::vector<std::string> syms;
     if (postproc.empty()) { if (ctm_mode) K3H_ERR << "You must configure the lattice postprocessor with --lattice-postprocessor-rxfilename to use CTM output"; }
-    else { postprocessor = LoadLatticePostprocessor(postproc); postprocessor->SetDecoderFrameShift(fopts.frame_shift_ms * 1.0e-3f * subsampling); }
+    else { postprocessor = LoadLatticePostprocessor(postproc); postprocessor->SetDecoderFrameShift(fopts.frame_shift_ms * 1.0e-3f * subsampling); postprocessor->SetTransitionInformation(&ti); }      // (the model: --word-boundary-rxfilename aligns the lattice on word boundaries first)
     if (!word_syms.empty()) {      // fst::SymbolTable::ReadText: lines "symbol id"
       std::istringstream in(ReadWholeInput(word_syms)); std::string sym; long id;
       while (in >> sym >> id) { if (id >= 0) { if ((size_t)id >= syms.size()) syms.resize((size_t)id + 1); syms[(size_t)id] = sym; } }

@@ -7,6 +7,7 @@
 //   k3-host-tool parse-options [options] [args]   the option values ParseOptions::Read ends up with (config files vs command line)
 //   k3-host-tool convert-lattice <lattice-rspecifier> <lattice-wspecifier>   state-level lattices re-packed as CompactLattices
 #include <iostream>
+#include <fstream>
 #include "k3_host.h"
 using namespace k3host;
 int main(int argc, char **argv) {
@@ -53,6 +54,37 @@ int main(int argc, char **argv) {
       po.Register("beam", &beam, "beam"); po.Register("max-active", &max_active, "max active"); po.Register("flag", &flag, "flag"); po.Register("name", &name, "name");
       po.Read(argc - 1, argv + 1);
       std::cout << "beam=" << beam << " max-active=" << max_active << " flag=" << (flag ? "true" : "false") << " name=" << name << " nargs=" << po.NumArgs() << "\n"; return 0;
+    }
+    if (cmd == "word-align" && argc >= 6) {      // WordAlignLattice + MBR on every lattice of a table, in the format of oracle/ref_tools/ref_word_align.cc:
+      // k3-host-tool word-align <mdl> <word_boundary.int> <lattice-rspecifier> <out.txt> [reorder [silence-label [partial-word-label [max-expand]]]]
+      const TransitionInfo ti = ReadTransitionModel(argv[2]);
+      const WordBoundaryInfo info = ReadWordBoundaryInfo(argv[3], argc > 6 ? atoi(argv[6]) != 0 : true, argc > 7 ? atoi(argv[7]) : 0, argc > 8 ? atoi(argv[8]) : 0);
+      const float max_expand = argc > 9 ? (float)atof(argv[9]) : 0.0f;
+      std::ofstream out(argv[5]); out.precision(9);
+      for (auto &kv : ReadLatticeTable(argv[4])) {
+        Connect(&kv.second); CompactLattice c; if (kv.second.NumStates() > 0) ConvertLattice(kv.second, &c);
+        const int32_t max_states = max_expand > 0 ? (int32_t)(1000 + max_expand * c.NumStates()) : 0;
+        CompactLattice al; const bool ok = c.NumStates() == 0 ? true : WordAlignLattice(c, ti, info, max_states, &al);
+        out << kv.first << "\nok " << (ok ? 1 : 0) << "\nstates " << al.NumStates() << " start " << (al.NumStates() ? al.start : -1) << "\n";
+        size_t k = 0;
+        for (int32_t s = 0; s < al.NumStates(); s++) {
+          for (; k < al.arc_src.size() && al.arc_src[k] == s; k++) {
+            out << "a " << s << " " << al.arc_dst[k] << " " << al.arc_label[k] << " " << al.arc_graph[k] << " " << al.arc_ac[k] << " ";
+            for (size_t j = 0; j < al.arc_str[k].size(); j++) out << (j ? "_" : "") << al.arc_str[k][j];
+            out << "\n";
+          }
+          if (al.is_final[s]) out << "f " << s << " " << al.fin_graph[s] << " " << al.fin_ac[s] << "\n";
+        }
+        if (al.NumStates() > 0) {
+          MinimumBayesRisk mbr(al, MinimumBayesRiskOptions());
+          out << "words"; for (int32_t w : mbr.GetOneBest()) out << " " << w;
+          out << "\ntimes"; for (const auto &t : mbr.GetOneBestTimes()) out << " " << t.first << " " << t.second;
+          out << "\nconf"; for (float x : mbr.GetOneBestConfidences()) out << " " << x;
+          out << "\n";
+        }
+        out << "end\n";
+      }
+      return 0;
     }
     if (cmd == "copy-fst" && argc == 4) { WriteFstVector(ReadFstKaldiGeneric(argv[2]), argv[3]); return 0; }
     std::cerr << "usage: k3-host-tool tid2pdf <mdl> | tidinfo <mdl> | fstinfo <fst> | copy-fst <in> <out> | convert-lattice <rspecifier> <wspecifier>\n"; return 1;

@@ -307,7 +307,7 @@ TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename) {
   const std::string tok = in.Token();                                    // transition-model.cc:229-243
   if (tok != "<Triples>" && tok != "<Tuples>") K3H_ERR << "TransitionModel: expected <Triples> or <Tuples>, got " << tok;
   const int32_t n = in.Basic<int32_t>();
-  TransitionInfo ti; ti.id2pdf.assign(1, 0); ti.id2phone.assign(1, 0); ti.self_loop.assign(1, 0); ti.phone_start.assign(1, 0);
+  TransitionInfo ti; ti.id2pdf.assign(1, 0); ti.id2phone.assign(1, 0); ti.self_loop.assign(1, 0); ti.phone_start.assign(1, 0); ti.is_final.assign(1, 0);
   for (int32_t i = 0; i < n; i++) {                                       // ComputeDerived (:90-124): transition-ids in tuple order
     const int32_t phone = in.Basic<int32_t>(), hs = in.Basic<int32_t>(), fpdf = in.Basic<int32_t>();
     const int32_t spdf = tok == "<Tuples>" ? in.Basic<int32_t>() : fpdf;
@@ -316,7 +316,7 @@ TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename) {
     if (hs < 0 || hs >= (int32_t)entry.size()) K3H_ERR << "TransitionModel: bad hmm-state " << hs;
     for (const auto &tr : entry[hs].trans) {
       ti.id2pdf.push_back(tr.first == hs ? spdf : fpdf);     // IsSelfLoop
-      ti.id2phone.push_back(phone); ti.self_loop.push_back(tr.first == hs); ti.phone_start.push_back(hs == 0);
+      ti.id2phone.push_back(phone); ti.self_loop.push_back(tr.first == hs); ti.phone_start.push_back(hs == 0); ti.is_final.push_back(tr.first + 1 == (int32_t)entry.size());      // IsFinal (transition-model.cc:511-518)
     }
     ti.num_pdfs = std::max(ti.num_pdfs, 1 + std::max(fpdf, spdf));
   }

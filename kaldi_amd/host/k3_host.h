@@ -80,7 +80,7 @@ Wave ReadWave(const std::string &rxfilename, int channel = 0, int *num_channels 
 
 // .mdl (text or binary): parses the TransitionModel in front of the nnet; id2pdf[0] is unused
 // id2phone / self_loop / phone_start = TransitionIdToPhone, IsSelfLoop, TransitionIdIsStartOfPhone (hmm/transition-model.cc:790,925)
-struct TransitionInfo { int32_t num_pdfs = 0; std::vector<int32_t> id2pdf, id2phone; std::vector<char> self_loop, phone_start; };
+struct TransitionInfo { int32_t num_pdfs = 0; std::vector<int32_t> id2pdf, id2phone; std::vector<char> self_loop, phone_start, is_final; };      // is_final: TransitionModel::IsFinal (the transition enters the topology's last, non-emitting state)
 TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename);
 
 // model files of the online i-vector extractor (binary files only), values widened to double, matrices row-major:
@@ -251,14 +251,28 @@ struct LatticePostprocessorConfig {      // cudadecoder/lattice-postprocessor.h:
   float max_expand = 0.0f, acoustic_scale = 1.0f, lm_scale = 1.0f, acoustic2lm_scale = 0.0f, lm2acoustic_scale = 0.0f, word_ins_penalty = 0.0f;
   void Register(ParseOptions *po);
 };
+// ---- word alignment of a CompactLattice (lat/word-align-lattice.{h,cc}), k3_mbr.cc: every arc of the output is one word (or one silence, or a partial word at the end of a
+// forced-out utterance) with exactly that word's transition-ids, so that state times are word boundaries.  The lexicon must use word-position-dependent phones; which phone is what
+// comes from phones/word_boundary.int ("<phone-id> nonword|begin|end|internal|singleton").
+struct WordBoundaryInfo {      // lat/word-align-lattice.h:119-170 (the WordBoundaryInfoNewOpts form)
+  enum PhoneType { kNoPhone = 0, kWordBeginPhone, kWordEndPhone, kWordBeginAndEndPhone, kWordInternalPhone, kNonWordPhone };
+  std::vector<PhoneType> phone_to_type; int32_t silence_label = 0, partial_word_label = 0; bool reorder = true;
+  PhoneType TypeOfPhone(int32_t p) const;      // throws for a phone the file does not list
+};
+WordBoundaryInfo ReadWordBoundaryInfo(const std::string &word_boundary_rxfilename, bool reorder = true, int32_t silence_label = 0, int32_t partial_word_label = 0);
+// WordAlignLattice (:724-731): false when the lattice could not be aligned cleanly (a broken / forced-out lattice, a mismatched model or --reorder option, max_states > 0 exceeded);
+// lat_out then holds what could be made of it, as in the reference
+bool WordAlignLattice(const CompactLattice &lat, const TransitionInfo &tmodel, const WordBoundaryInfo &info, int32_t max_states, CompactLattice *lat_out);
+
 class LatticePostprocessor {      // cudadecoder/lattice-postprocessor.h:78-118
  public:
   explicit LatticePostprocessor(const LatticePostprocessorConfig &config);
   bool GetCTM(CompactLattice &clat, CtmResult *ctm_result) const;
   bool GetPostprocessedLattice(CompactLattice &clat, CompactLattice *out_clat) const;      // scales + word insertion penalty (clat is modified, like the reference's)
   void SetDecoderFrameShift(float seconds) { decoder_frame_shift_ = seconds; }
+  void SetTransitionInformation(const TransitionInfo *tmodel) { tmodel_ = tmodel; }      // (:93-95; needed with --word-boundary-rxfilename)
  private:
-  LatticePostprocessorConfig config_; bool use_lattice_scale_ = false; float decoder_frame_shift_ = 0.0f;
+  LatticePostprocessorConfig config_; bool use_lattice_scale_ = false; float decoder_frame_shift_ = 0.0f; const TransitionInfo *tmodel_ = nullptr; std::shared_ptr<WordBoundaryInfo> word_info_;
 };
 std::shared_ptr<LatticePostprocessor> LoadLatticePostprocessor(const std::string &config_rxfilename);      // LoadAndSetLatticePostprocessor's first half (:126-137)
 // the CTM lines of one (un-segmented) utterance: "<key> 0  <begin> <duration> <word> <confidence>", two decimals (cuda-pipeline-common.cc:67-142)

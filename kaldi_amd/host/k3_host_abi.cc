@@ -69,6 +69,20 @@ int64_t k3h_lattice_table_to_ctm(const char *lattice_rspecifier, const char *pos
   });
   return rc == 0 ? n : -1;
 }
+// ... with the model (final.mdl) the post-processor needs when its config names a --word-boundary-rxfilename: the lattice is word-aligned (WordAlignLattice) before MBR, so that the
+// CTM times are word boundaries (cudadecoder/lattice-postprocessor.cc:66-85)
+int64_t k3h_lattice_table_to_ctm_model(const char *lattice_rspecifier, const char *postprocessor_config_rxfilename, float decoder_frame_shift_seconds, const char *model_rxfilename, char *out, int64_t out_cap) {
+  int64_t n = -1;
+  const int rc = Guard([&] {
+    auto pp = LoadLatticePostprocessor(postprocessor_config_rxfilename); pp->SetDecoderFrameShift(decoder_frame_shift_seconds);
+    TransitionInfo ti; if (model_rxfilename && *model_rxfilename) { ti = ReadTransitionModel(model_rxfilename); pp->SetTransitionInformation(&ti); }
+    std::ostringstream os;
+    for (auto &kv : ReadLatticeTable(lattice_rspecifier)) { Connect(&kv.second); CompactLattice clat; if (kv.second.NumStates() > 0) ConvertLattice(kv.second, &clat); CtmResult ctm; pp->GetCTM(clat, &ctm); WriteCtm(ctm, kv.first, os); }
+    const std::string s = os.str(); if ((int64_t)s.size() + 1 > out_cap) K3H_ERR << "k3h_lattice_table_to_ctm_model: output buffer too small (" << s.size() + 1 << " bytes needed)";
+    memcpy(out, s.c_str(), s.size() + 1); n = (int64_t)s.size();
+  });
+  return rc == 0 ? n : -1;
+}
 int k3h_clat_sizes(const k3h_clat *c, int32_t *ns, int64_t *na, int64_t *nl) {
   return Guard([&] { int64_t n = 0; for (const auto &s : c->c.fin_str) n += (int64_t)s.size(); for (const auto &s : c->c.arc_str) n += (int64_t)s.size(); *ns = c->c.NumStates(); *na = (int64_t)c->c.arc_src.size(); *nl = n; });
 }

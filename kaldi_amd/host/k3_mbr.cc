@@ -4,6 +4,8 @@
 //                         distance"): Figures 4-6 of the paper as the reference codes them -- EditDistance :130-166, AccStats :169-318, MbrDecode :28-108,
 //                         PrepareLatticeAndInitStats :320-363 (CreateSuperFinal fstext/pre-determinize-inl.h:689-724, CompactLatticeStateTimes
 //                         lat/lattice-functions.cc:109-147), first hypothesis = the lattice's best path (:377-395)
+//   WordAlignLattice      lat/word-align-lattice.{h,cc} (round 5): the lattice re-cut so that every arc is one word / silence with exactly its transition-ids -- what the post-processor
+//                         does in front of MBR when its config names --word-boundary-rxfilename; pinned to the reference's own source (oracle/_ref/bin/ref-word-align, tests/test_word_align.py)
 //   LatticePostprocessor  cudadecoder/lattice-postprocessor.{h,cc}: ScaleLattice (fstext/lattice-utils-inl.h:197-219), AddWordInsPenToCompactLattice
 //                         (lat/lattice-functions.cc:1342-1363), MBR -> CTMResult {words, (begin, end) in seconds, confidences}
 //   WriteCtm              MergeSegmentsToCTMOutput of one un-segmented utterance (cudadecoder/cuda-pipeline-common.cc:67-142)
@@ -15,6 +17,7 @@
 #include <limits>
 #include <map>
 #include <sstream>
+#include <unordered_map>
 
 namespace k3host {
 namespace {
@@ -222,6 +225,316 @@ const std::vector<std::vector<std::pair<int32_t, float>>> &MinimumBayesRisk::Get
 const std::vector<std::pair<float, float>> &MinimumBayesRisk::GetSausageTimes() const { return impl_->sausage_times; }
 double MinimumBayesRisk::GetBayesRisk() const { return impl_->L; }
 
+// ---- WordAlignLattice (lat/word-align-lattice.cc) -------------------------------------------------------------------------------
+// The reference builds a new lattice whose states are (input state, computation state) pairs -- the computation state holds the transition-ids and word labels seen but not yet
+// put on an output arc, and the weight that goes with them -- expands them from a LIFO queue (:204-248), lets a computation state emit an arc as soon as it holds a complete word /
+// silence (OutputNormalWordArc / OutputSilenceArc / OutputOnePhoneWordArc, :349-533) before any more input is read, forces out what is left at the final state (:591-667), and
+// then removes the epsilon arcs that carried the input (fst::RmEpsilon + Connect) and, when the silence / partial-word labels were asked to be 0, maps the stand-in labels back
+// (RemoveSomeInputSymbols + Project, :292-306).  Restated over plain vectors; the order in which states and arcs are created is the reference's (the pin compares whole lattices).
+namespace {
+struct LW { float g = 0.0f, a = 0.0f; };      // LatticeWeight: (graph, acoustic)
+const float kInfF = std::numeric_limits<float>::infinity();
+inline bool IsZero(const LW &w) { return w.g == kInfF && w.a == kInfF; }
+inline LW TimesLW(const LW &x, const LW &y) { return LW{x.g + y.g, x.a + y.a}; }
+inline int CompareLW(const LW &x, const LW &y) {      // fstext/lattice-weight.h:299-315: > 0 when x is better (lower cost)
+  const float f1 = x.g + x.a, f2 = y.g + y.a;
+  if (f1 < f2) return 1;
+  if (f1 > f2) return -1;
+  if (x.g < y.g) return 1;
+  if (x.g > y.g) return -1;
+  return 0;
+}
+struct CW { LW w; std::vector<int32_t> str; };      // CompactLatticeWeight
+inline CW ZeroCW() { return CW{LW{kInfF, kInfF}, {}}; }
+inline int CompareCW(const CW &x, const CW &y) {      // :674-698: weight first, then the SHORTER string is better, then lexicographic
+  const int c = CompareLW(x.w, y.w); if (c != 0) return c;
+  const size_t l1 = x.str.size(), l2 = y.str.size();
+  if (l1 > l2) return -1;
+  if (l1 < l2) return 1;
+  for (size_t i = 0; i < l1; i++) {
+    if (x.str[i] < y.str[i]) return -1;
+    if (x.str[i] > y.str[i]) return 1;
+  }
+  return 0;
+}
+inline CW PlusCW(const CW &x, const CW &y) { return CompareCW(x, y) >= 0 ? x : y; }
+inline CW TimesCW(const CW &x, const CW &y) {      // :740-764 (Zero absorbs)
+  if (IsZero(x.w) || IsZero(y.w)) return ZeroCW();
+  CW r; r.w = TimesLW(x.w, y.w); r.str = x.str; r.str.insert(r.str.end(), y.str.begin(), y.str.end()); return r;
+}
+struct WArc { int32_t label, next; CW w; };
+struct WFst { int32_t start = -1; std::vector<std::vector<WArc>> arcs; std::vector<CW> fin;
+  int32_t AddState() { arcs.emplace_back(); fin.push_back(ZeroCW()); return (int32_t)fin.size() - 1; } int32_t NumStates() const { return (int32_t)fin.size(); } };
+
+struct CompState {      // LatticeWordAligner::ComputationState (:30-128)
+  std::vector<int32_t> tids, words; LW weight;
+  bool operator==(const CompState &o) const { return tids == o.tids && words == o.words && weight.g == o.weight.g && weight.a == o.weight.a; }
+  bool IsEmpty() const { return tids.empty() && words.empty(); }
+};
+struct AlignCtx { const TransitionInfo &tm; const WordBoundaryInfo &info; bool *error;
+  int32_t Phone(int32_t tid) const { if (tid <= 0 || (size_t)tid >= tm.id2phone.size()) K3H_ERR << "WordAlignLattice: transition-id " << tid << " is not in the model"; return tm.id2phone[tid]; }
+  bool Final(int32_t tid) const { return tm.is_final[tid] != 0; } bool SelfLoop(int32_t tid) const { return tm.self_loop[tid] != 0; } };
+
+bool OutputSilenceArc(CompState &c, const AlignCtx &x, WArc *out) {      // :349-393
+  if (c.tids.empty()) return false;
+  const int32_t phone = x.Phone(c.tids[0]);
+  if (x.info.TypeOfPhone(phone) != WordBoundaryInfo::kNonWordPhone) return false;
+  const size_t len = c.tids.size(); size_t i;
+  for (i = 0; i < len; i++) {
+    const int32_t tid = c.tids[i];
+    if (x.Phone(tid) != phone && !*x.error) { *x.error = true; K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]"; }
+    if (x.Final(tid)) break;
+  }
+  if (i == len) return false;
+  i++;
+  if (x.info.reorder) while (i < len && x.SelfLoop(c.tids[i])) i++;
+  if (i == len) return false;
+  if (x.Phone(c.tids[i - 1]) != phone && !*x.error) K3H_WARN << "Phone changed unexpectedly in lattice [broken lattice or mismatched model?]";
+  *out = WArc{x.info.silence_label, -1, CW{c.weight, std::vector<int32_t>(c.tids.begin(), c.tids.begin() + i)}};
+  c.tids.erase(c.tids.begin(), c.tids.begin() + i); c.weight = LW();
+  return true;
+}
+bool OutputOnePhoneWordArc(CompState &c, const AlignCtx &x, WArc *out) {      // :396-446
+  if (c.tids.empty() || c.words.empty()) return false;
+  const int32_t phone = x.Phone(c.tids[0]);
+  if (x.info.TypeOfPhone(phone) != WordBoundaryInfo::kWordBeginAndEndPhone) return false;
+  const size_t len = c.tids.size(); size_t i;
+  for (i = 0; i < len; i++) {
+    const int32_t tid = c.tids[i];
+    if (x.Phone(tid) != phone && !*x.error) K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]";
+    if (x.Final(tid)) break;
+  }
+  if (i == len) return false;
+  i++;
+  if (x.info.reorder) while (i < len && x.SelfLoop(c.tids[i])) i++;
+  if (i == len) return false;
+  if (x.Phone(c.tids[i - 1]) != phone && !*x.error) { K3H_WARN << "Phone changed unexpectedly in lattice [broken lattice or mismatched model?]"; *x.error = true; }
+  const int32_t word = c.words[0];
+  *out = WArc{word, -1, CW{c.weight, std::vector<int32_t>(c.tids.begin(), c.tids.begin() + i)}};
+  c.tids.erase(c.tids.begin(), c.tids.begin() + i); c.words.erase(c.words.begin()); c.weight = LW();
+  return true;
+}
+bool OutputNormalWordArc(CompState &c, const AlignCtx &x, WArc *out) {      // :451-545: a word of at least two phones
+  if (c.tids.empty() || c.words.empty()) return false;
+  const int32_t begin_phone = x.Phone(c.tids[0]);
+  if (x.info.TypeOfPhone(begin_phone) != WordBoundaryInfo::kWordBeginPhone) return false;
+  const size_t len = c.tids.size(); size_t i;
+  for (i = 0; i < len && !x.Final(c.tids[i]); i++);
+  if (i == len) return false;
+  i++;
+  if (x.info.reorder) for (; i < len && x.SelfLoop(c.tids[i]); i++);
+  if (i == len) return false;
+  if (x.Phone(c.tids[i - 1]) != begin_phone && !*x.error) { K3H_WARN << "Phone changed unexpectedly in lattice [broken lattice or mismatched model?]"; *x.error = true; }
+  for (; i < len; i++) {
+    const int32_t this_phone = x.Phone(c.tids[i]);
+    if (x.info.TypeOfPhone(this_phone) == WordBoundaryInfo::kWordEndPhone) break;
+    if (x.info.TypeOfPhone(this_phone) != WordBoundaryInfo::kWordInternalPhone && !*x.error) { K3H_WARN << "Unexpected phone " << this_phone << " found inside a word."; *x.error = true; }
+  }
+  if (i == len) return false;
+  const int32_t final_phone = x.Phone(c.tids[i]);
+  for (; i < len; i++) {
+    if (x.Phone(c.tids[i]) != final_phone && !*x.error) { *x.error = true; K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]"; }
+    if (x.Final(c.tids[i])) break;
+  }
+  if (i == len) return false;
+  i++;
+  if (x.info.reorder) while (i < len && x.SelfLoop(c.tids[i])) i++;
+  if (i == len) return false;
+  if (x.Phone(c.tids[i - 1]) != final_phone && !*x.error) { *x.error = true; K3H_WARN << "Phone changed while following final self-loop [broken lattice or mismatched model or wrong --reorder option?]"; }
+  const int32_t word = c.words[0];
+  *out = WArc{word, -1, CW{c.weight, std::vector<int32_t>(c.tids.begin(), c.tids.begin() + i)}};
+  c.tids.erase(c.tids.begin(), c.tids.begin() + i); c.words.erase(c.words.begin()); c.weight = LW();
+  return true;
+}
+bool IsPlausibleWord(const AlignCtx &x, const std::vector<int32_t> &tids) {      // :549-569
+  if (tids.empty()) return false;
+  const int32_t first_phone = x.Phone(tids.front()), last_phone = x.Phone(tids.back());
+  if ((x.info.TypeOfPhone(first_phone) == WordBoundaryInfo::kWordBeginAndEndPhone && first_phone == last_phone) ||
+      (x.info.TypeOfPhone(first_phone) == WordBoundaryInfo::kWordBeginPhone && x.info.TypeOfPhone(last_phone) == WordBoundaryInfo::kWordEndPhone)) {
+    if (!x.info.reorder) return x.Final(tids.back());
+    int32_t i = (int32_t)tids.size() - 1; while (i > 0 && x.SelfLoop(tids[i])) i--;
+    return x.Final(tids[i]);
+  }
+  return false;
+}
+void OutputArcForce(CompState &c, const AlignCtx &x, WArc *out) {      // :572-667
+  if (!c.words.empty() && !c.tids.empty()) {
+    const int32_t word = c.words[0];
+    if (!*x.error && !IsPlausibleWord(x, c.tids)) { *x.error = true; K3H_WARN << "Invalid word at end of lattice [partial lattice, forced out?]"; }
+    *out = WArc{word, -1, CW{c.weight, c.tids}}; c.weight = LW(); c.tids.clear(); c.words.erase(c.words.begin());
+  } else if (!c.words.empty() && c.tids.empty()) {
+    if (!*x.error) { *x.error = true; K3H_WARN << "Discarding word-ids at the end of a sentence, that don't have alignments."; }
+    *out = WArc{0, -1, CW{c.weight, c.tids}}; c.weight = LW(); c.words.clear();
+  } else if (!c.tids.empty() && c.words.empty()) {
+    const int32_t first_phone = x.Phone(c.tids[0]);
+    if (x.info.TypeOfPhone(first_phone) == WordBoundaryInfo::kNonWordPhone) {
+      if (first_phone != x.Phone(c.tids.back()) && !*x.error) { *x.error = true; K3H_ERR << "Broken silence arc at end of utterance (the phone changed); code error"; }
+      if (!*x.error) {
+        int32_t i = (int32_t)c.tids.size() - 1;
+        if (x.info.reorder) while (x.SelfLoop(c.tids[i]) && i > 0) i--;
+        if (!x.Final(c.tids[i])) { *x.error = true; K3H_WARN << "Broken silence arc at end of utterance (does not reach end of silence)"; }
+      }
+      *out = WArc{x.info.silence_label, -1, CW{c.weight, c.tids}};
+    } else {
+      if (!*x.error) { *x.error = true; K3H_WARN << "Partial word detected at end of utterance"; }
+      *out = WArc{x.info.partial_word_label, -1, CW{c.weight, c.tids}};
+    }
+    c.tids.clear(); c.weight = LW();
+  } else K3H_ERR << "Code error, word-aligning lattice";
+}
+
+// fst::RmEpsilon(fst, connect = true) over the compact-lattice semiring, for the aligner's output (its epsilon arcs -- label 0 -- form no cycle): see third_party/minifst/fst/fstlib.h
+// for the algorithm's statement; states that only epsilon arcs reach are dropped, every other state gets the non-epsilon arcs of its epsilon closure
+void RmEpsilonAndConnect(WFst *f) {
+  const int32_t n = f->NumStates(); if (f->start < 0) return;
+  std::vector<char> noneps_in(n, 0); noneps_in[f->start] = 1;
+  for (int32_t s = 0; s < n; s++) for (const WArc &a : f->arcs[s]) if (a.label != 0) noneps_in[a.next] = 1;
+  std::vector<int32_t> order; bool top = true;
+  for (int32_t s = 0; s < n && top; s++) for (const WArc &a : f->arcs[s]) if (a.next <= s) { top = false; break; }
+  if (top) for (int32_t s = 0; s < n; s++) order.push_back(s);
+  else {
+    std::vector<char> color(n, 0); std::vector<size_t> pos(n, 0); std::vector<int32_t> stack, finish;
+    auto visit = [&](int32_t root) { stack.push_back(root); color[root] = 1; while (!stack.empty()) { const int32_t s = stack.back(); if (pos[s] < f->arcs[s].size()) { const int32_t d = f->arcs[s][pos[s]++].next; if (color[d] == 1) K3H_ERR << "WordAlignLattice: cycle in the aligned lattice"; if (color[d] == 0) { color[d] = 1; stack.push_back(d); } } else { color[s] = 2; finish.push_back(s); stack.pop_back(); } } };
+    visit(f->start); for (int32_t s = 0; s < n; s++) if (color[s] == 0) visit(s);
+    order.assign(finish.rbegin(), finish.rend());
+  }
+  std::vector<CW> dist(n); std::vector<char> has(n, 0), visited(n, 0);
+  while (!order.empty()) {
+    const int32_t source = order.back(); order.pop_back();
+    if (!noneps_in[source]) continue;
+    std::vector<int32_t> q; std::vector<int32_t> touched;
+    dist[source] = CW(); has[source] = 1; q.push_back(source); touched.push_back(source);
+    for (size_t h = 0; h < q.size(); h++) {      // shortest distances over epsilon arcs (label-correcting: exact for a path semiring)
+      const int32_t s = q[h];
+      for (const WArc &a : f->arcs[s]) {
+        if (a.label != 0) continue;
+        CW w = TimesCW(dist[s], a.w);
+        if (!has[a.next] || CompareCW(w, dist[a.next]) > 0) { if (!has[a.next]) touched.push_back(a.next); dist[a.next] = std::move(w); has[a.next] = 1; q.push_back(a.next); }
+      }
+    }
+    std::vector<WArc> arcs; CW final_weight = ZeroCW(); std::vector<int32_t> eps_stack, seen; eps_stack.push_back(source);
+    while (!eps_stack.empty()) {
+      const int32_t s = eps_stack.back(); eps_stack.pop_back();
+      if (visited[s]) continue;
+      visited[s] = 1; seen.push_back(s);
+      for (const WArc &a0 : f->arcs[s]) {
+        if (a0.label == 0) { if (!visited[a0.next]) eps_stack.push_back(a0.next); continue; }
+        WArc arc{a0.label, a0.next, TimesCW(dist[s], a0.w)}; bool merged = false;
+        for (WArc &b : arcs) if (b.label == arc.label && b.next == arc.next) { b.w = PlusCW(b.w, arc.w); merged = true; break; }
+        if (!merged) arcs.push_back(std::move(arc));
+      }
+      final_weight = PlusCW(final_weight, TimesCW(dist[s], f->fin[s]));
+    }
+    for (int32_t s : touched) has[s] = 0;
+    for (int32_t s : seen) visited[s] = 0;
+    f->fin[source] = final_weight; f->arcs[source].clear();
+    while (!arcs.empty()) { f->arcs[source].push_back(std::move(arcs.back())); arcs.pop_back(); }
+  }
+  for (int32_t s = 0; s < n; s++) if (!noneps_in[s]) f->arcs[s].clear();
+  // fst::Connect: accessible and co-accessible states, in their old relative order
+  std::vector<char> acc(n, 0), co(n, 0); std::vector<int32_t> st; std::vector<std::vector<int32_t>> rev(n);
+  for (int32_t s = 0; s < n; s++) for (const WArc &a : f->arcs[s]) rev[a.next].push_back(s);
+  acc[f->start] = 1; st.push_back(f->start);
+  while (!st.empty()) { const int32_t s = st.back(); st.pop_back(); for (const WArc &a : f->arcs[s]) if (!acc[a.next]) { acc[a.next] = 1; st.push_back(a.next); } }
+  for (int32_t s = 0; s < n; s++) if (!IsZero(f->fin[s].w)) { co[s] = 1; st.push_back(s); }
+  while (!st.empty()) { const int32_t s = st.back(); st.pop_back(); for (int32_t p_ : rev[s]) if (!co[p_]) { co[p_] = 1; st.push_back(p_); } }
+  std::vector<int32_t> newid(n, -1); int32_t m = 0; for (int32_t s = 0; s < n; s++) if (acc[s] && co[s]) newid[s] = m++;
+  if (m == n) return;
+  WFst g; if (m == 0 || newid[f->start] < 0) { *f = g; return; }
+  g.arcs.resize(m); g.fin.resize(m); g.start = newid[f->start];
+  for (int32_t s = 0; s < n; s++) if (newid[s] >= 0) { g.fin[newid[s]] = f->fin[s]; for (WArc &a : f->arcs[s]) if (newid[a.next] >= 0) { a.next = newid[a.next]; g.arcs[newid[s]].push_back(std::move(a)); } }
+  *f = std::move(g);
+}
+}  // namespace
+
+WordBoundaryInfo::PhoneType WordBoundaryInfo::TypeOfPhone(int32_t p) const {
+  if (p < 0 || (size_t)p >= phone_to_type.size()) K3H_ERR << "Phone " << p << " was not specified in word-boundary file (or options)";
+  return phone_to_type[p];
+}
+WordBoundaryInfo ReadWordBoundaryInfo(const std::string &rxfilename, bool reorder, int32_t silence_label, int32_t partial_word_label) {      // WordBoundaryInfo::Init (:696-722)
+  WordBoundaryInfo info; info.reorder = reorder; info.silence_label = silence_label; info.partial_word_label = partial_word_label;
+  std::istringstream is(ReadWholeInput(rxfilename)); std::string line;
+  while (std::getline(is, line)) {
+    std::istringstream ls(line); std::vector<std::string> f; std::string t; while (ls >> t) f.push_back(t);
+    char *end = nullptr; const long p = f.size() == 2 ? strtol(f[0].c_str(), &end, 10) : 0;
+    if (f.size() != 2 || *end != '\0' || f[0].empty()) K3H_ERR << "Invalid line in word-boundary file: " << line;
+    if (p <= 0) K3H_ERR << "Invalid line in word-boundary file (phone ids are positive): " << line;
+    if (info.phone_to_type.size() <= (size_t)p) info.phone_to_type.resize(p + 1, WordBoundaryInfo::kNoPhone);
+    if (f[1] == "nonword") info.phone_to_type[p] = WordBoundaryInfo::kNonWordPhone; else if (f[1] == "begin") info.phone_to_type[p] = WordBoundaryInfo::kWordBeginPhone;
+    else if (f[1] == "singleton") info.phone_to_type[p] = WordBoundaryInfo::kWordBeginAndEndPhone; else if (f[1] == "end") info.phone_to_type[p] = WordBoundaryInfo::kWordEndPhone;
+    else if (f[1] == "internal") info.phone_to_type[p] = WordBoundaryInfo::kWordInternalPhone; else K3H_ERR << "Invalid line in word-boundary file: " << line;
+  }
+  if (info.phone_to_type.empty()) K3H_ERR << "Empty word-boundary file";
+  return info;
+}
+
+bool WordAlignLattice(const CompactLattice &lat, const TransitionInfo &tmodel, const WordBoundaryInfo &info_in, int32_t max_states, CompactLattice *lat_out) {
+  *lat_out = CompactLattice();
+  // ---- the input as per-state arc lists + CreateSuperFinal (fstext/pre-determinize-inl.h:689-724): one final state, weight One, reached by epsilon arcs with the old final weights
+  WFst in; in.start = lat.start; const int32_t n0 = lat.NumStates();
+  for (int32_t s = 0; s < n0; s++) { in.AddState(); if (lat.is_final[s]) in.fin[s] = CW{LW{lat.fin_graph[s], lat.fin_ac[s]}, lat.fin_str[s]}; }
+  int32_t highest_label = 0;
+  for (size_t k = 0; k < lat.arc_src.size(); k++) { in.arcs[lat.arc_src[k]].push_back(WArc{lat.arc_label[k], lat.arc_dst[k], CW{LW{lat.arc_graph[k], lat.arc_ac[k]}, lat.arc_str[k]}}); highest_label = std::max(highest_label, lat.arc_label[k]); }
+  {
+    bool idet = true, ieps = false;
+    for (int32_t s = 0; s < n0; s++) { std::vector<int32_t> l; for (const WArc &a : in.arcs[s]) { l.push_back(a.label); if (a.label == 0) ieps = true; } std::sort(l.begin(), l.end()); if (std::adjacent_find(l.begin(), l.end()) != l.end()) idet = false; }
+    if (!idet || ieps) K3H_WARN << "[Lattice has input epsilons and/or is not input-deterministic (in Mohri sense)]-- i.e. lattice is not deterministic.  Word-alignment may be slow and-or blow up in memory.";
+  }
+  {
+    std::vector<int32_t> finals; for (int32_t s = 0; s < n0; s++) if (!IsZero(in.fin[s].w)) finals.push_back(s);
+    const bool single = finals.size() == 1 && in.fin[finals[0]].w.g == 0.0f && in.fin[finals[0]].w.a == 0.0f && in.fin[finals[0]].str.empty() && in.arcs[finals[0]].empty();
+    if (!single) { const int32_t fs = in.AddState(); in.fin[fs] = CW(); for (int32_t s : finals) { in.arcs[s].push_back(WArc{0, fs, in.fin[s]}); in.fin[s] = ZeroCW(); } }
+  }
+  WordBoundaryInfo info = info_in;      // zero silence / partial-word labels are replaced by unused ones while the epsilons are removed (:268-283)
+  if (info.partial_word_label == 0 || info.silence_label == 0) {
+    int32_t unused = 1 + highest_label;
+    if (info.partial_word_label >= unused) unused = info.partial_word_label + 1;
+    if (info.silence_label >= unused) unused = info.silence_label + 1;
+    if (info.partial_word_label == 0) info.partial_word_label = unused++;
+    if (info.silence_label == 0) info.silence_label = unused;
+  }
+  bool error = false; const AlignCtx ctx{tmodel, info, &error};
+  WFst out;
+  struct Tuple { int32_t state; CompState c; };
+  struct TupleHash { size_t operator()(const Tuple &t) const { size_t h = (size_t)t.state; for (int32_t v : t.c.tids) h = h * 7853 + (size_t)v; for (int32_t v : t.c.words) h = h * 90647 + (size_t)v; return h; } };
+  struct TupleEq { bool operator()(const Tuple &x, const Tuple &y) const { return x.state == y.state && x.c == y.c; } };
+  std::unordered_map<Tuple, int32_t, TupleHash, TupleEq> map; std::vector<std::pair<Tuple, int32_t>> queue;
+  auto state_for = [&](const Tuple &t) { auto it = map.find(t); if (it != map.end()) return it->second; const int32_t o = out.AddState(); map.emplace(t, o); queue.push_back({t, o}); return o; };      // GetStateForTuple(.., true)
+  bool ok = true;
+  if (in.start < 0) { K3H_WARN << "Trying to word-align empty lattice."; return false; }
+  out.start = state_for(Tuple{in.start, CompState()});
+  while (!queue.empty()) {
+    if (max_states > 0 && out.NumStates() > max_states) { K3H_WARN << "Number of states in lattice exceeded max-states of " << max_states << ", original lattice had " << in.NumStates() << " states.  Returning what we have."; ok = false; break; }
+    Tuple tuple = std::move(queue.back().first); const int32_t ostate = queue.back().second; queue.pop_back();      // ProcessQueueElement (:204-248)
+    WArc arc;
+    if (OutputNormalWordArc(tuple.c, ctx, &arc) || OutputSilenceArc(tuple.c, ctx, &arc) || OutputOnePhoneWordArc(tuple.c, ctx, &arc)) {      // something complete is pending: emit it before reading on
+      arc.next = state_for(tuple); out.arcs[ostate].push_back(std::move(arc));
+      continue;
+    }
+    if (!IsZero(in.fin[tuple.state].w)) {      // ProcessFinal (:169-201): the super-final state (weight One, no arcs)
+      if (tuple.c.IsEmpty()) out.fin[ostate] = PlusCW(out.fin[ostate], CW{tuple.c.weight, {}});
+      else { Tuple t2 = tuple; OutputArcForce(t2.c, ctx, &arc); arc.next = state_for(t2); out.arcs[ostate].push_back(std::move(arc)); }
+    }
+    for (const WArc &a : in.arcs[tuple.state]) {      // read one input arc: its labels join the computation state, its weight goes out on an epsilon arc (Advance, :38-47)
+      Tuple nt = tuple; nt.c.tids.insert(nt.c.tids.end(), a.w.str.begin(), a.w.str.end()); if (a.label != 0) nt.c.words.push_back(a.label);
+      const LW w = TimesLW(nt.c.weight, a.w.w); nt.c.weight = LW(); nt.state = a.next;
+      const int32_t no = state_for(nt);
+      out.arcs[ostate].push_back(WArc{0, no, CW{w, {}}});
+    }
+  }
+  RmEpsilonAndConnect(&out);
+  for (int32_t s = 0; s < out.NumStates(); s++) for (WArc &a : out.arcs[s]) {      // RemoveSomeInputSymbols + Project (:292-306)
+    if (info_in.partial_word_label == 0 && a.label == info.partial_word_label) a.label = 0;
+    if (info_in.silence_label == 0 && a.label == info.silence_label) a.label = 0;
+  }
+  lat_out->start = out.start;
+  for (int32_t s = 0; s < out.NumStates(); s++) { lat_out->AddState(); if (!IsZero(out.fin[s].w)) { lat_out->is_final[s] = 1; lat_out->fin_graph[s] = out.fin[s].w.g; lat_out->fin_ac[s] = out.fin[s].w.a; lat_out->fin_str[s] = out.fin[s].str; } }
+  for (int32_t s = 0; s < out.NumStates(); s++) for (WArc &a : out.arcs[s]) {
+    lat_out->arc_src.push_back(s); lat_out->arc_dst.push_back(a.next); lat_out->arc_label.push_back(a.label); lat_out->arc_graph.push_back(a.w.w.g); lat_out->arc_ac.push_back(a.w.w.a); lat_out->arc_str.push_back(std::move(a.w.str));
+  }
+  return ok && !error;
+}
+
 // ---- LatticePostprocessor -----------------------------------------------------------------------------------------------------
 void LatticePostprocessorConfig::Register(ParseOptions *po) {
   po->Register("max-expand", &max_expand, "If >0, the maximum amount by which this program will expand lattices before refusing to continue.");
@@ -236,9 +549,8 @@ void LatticePostprocessorConfig::Register(ParseOptions *po) {
 }
 LatticePostprocessor::LatticePostprocessor(const LatticePostprocessorConfig &config) : config_(config) {
   use_lattice_scale_ = config_.lm_scale != 1.0f || config_.acoustic2lm_scale != 0.0f || config_.lm2acoustic_scale != 0.0f || config_.acoustic_scale != 1.0f;
-  if (!config_.word_boundary_rxfilename.empty())
-    K3H_ERR << "LatticePostprocessor: --word-boundary-rxfilename (WordAlignLattice, lat/word-align-lattice.cc) is not part of this build; without it the words' times come from the "
-               "MBR statistics over the lattice as it is (what the reference does when no word-boundary file is configured)";
+  if (!config_.word_boundary_rxfilename.empty())      // LoadWordBoundaryInfo (lattice-postprocessor.h:100-103)
+    word_info_ = std::make_shared<WordBoundaryInfo>(ReadWordBoundaryInfo(config_.word_boundary_rxfilename, config_.reorder, config_.silence_label, config_.partial_word_label));
 }
 bool LatticePostprocessor::GetPostprocessedLattice(CompactLattice &clat, CompactLattice *out) const {
   if (clat.NumStates() == 0) return true;
@@ -250,7 +562,12 @@ bool LatticePostprocessor::GetPostprocessedLattice(CompactLattice &clat, Compact
   }
   if (config_.word_ins_penalty > 0.0f) for (size_t k = 0; k < clat.arc_src.size(); k++) if (clat.arc_label[k] != 0) clat.arc_graph[k] += config_.word_ins_penalty;
   if (decoder_frame_shift_ == 0.0f) K3H_ERR << "SetDecoderFrameShift() must be called (typically by pipeline)";
-  *out = clat; return true;
+  if (word_info_) {      // :66-85: the return value is ignored as in the reference (a warning has been printed; it happens with end-pointing)
+    if (!tmodel_) K3H_ERR << "SetTransitionInformation() must be called (typically by pipeline)";
+    const int32_t max_states = config_.max_expand > 0 ? (int32_t)(1000 + config_.max_expand * clat.NumStates()) : 0;
+    WordAlignLattice(clat, *tmodel_, *word_info_, max_states, out);
+  } else *out = clat;
+  return true;
 }
 bool LatticePostprocessor::GetCTM(CompactLattice &clat, CtmResult *ctm) const {
   if (clat.NumStates() == 0) return true;

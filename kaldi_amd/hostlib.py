@@ -31,6 +31,7 @@ def load():
         L.k3h_clat_get.argtypes = [P, ctypes.POINTER(ctypes.c_int32)] + [P] * 11
         L.k3h_clat_scale_acoustic.argtypes = [P, ctypes.c_double]
         L.k3h_clat_write.argtypes = [P, ctypes.c_char_p, ctypes.c_char_p]
+        L.k3h_lattice_table_to_ctm_model.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_float, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64]; L.k3h_lattice_table_to_ctm_model.restype = ctypes.c_int64
         L.k3h_lattice_table_to_ctm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_float, ctypes.c_char_p, ctypes.c_int64]; L.k3h_lattice_table_to_ctm.restype = ctypes.c_int64
         L.k3h_ivector_config_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]; L.k3h_ivector_config_free.argtypes = [P]; L.k3h_ivector_config_free.restype = None
         L.k3h_ivector_config_get.argtypes = [P, P, P] + [ctypes.POINTER(P)] * 7

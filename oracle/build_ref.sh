@@ -90,6 +90,10 @@ g++ $MF $HERE/ref_tools/ref_convert_lattice.cc $W/libref.a $MKL -ldl -lm -Wl,--u
 # the reference's word-level MBR decoder (lat/sausages.cc, unmodified) over the same stand-in: pins kaldi_amd/host/k3_mbr.cc (the CTM output of the lattice post-processor)
 g++ $MF -c $R/lat/sausages.cc -o $W/obj_minifst/sausages.o
 g++ $MF $HERE/ref_tools/ref_mbr.cc $W/obj_minifst/sausages.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-mbr
+# the reference's word aligner (lat/word-align-lattice.cc, unmodified) over the same stand-in, followed by its MBR decoder -- the two steps of LatticePostprocessor::GetCTM
+# with --word-boundary-rxfilename: pins the restatement in kaldi_amd/host/k3_mbr.cc (tests/test_word_align.py)
+g++ $MF -c $R/lat/word-align-lattice.cc -o $W/obj_minifst/word-align-lattice.o
+g++ $MF $HERE/ref_tools/ref_word_align.cc $W/obj_minifst/word-align-lattice.o $W/obj_minifst/sausages.o $W/libref.a $MKL -ldl -lm -Wl,--unresolved-symbols=ignore-all -Wl,-rpath,$W/mkl -o $W/bin/ref-word-align
 # i-vector extraction (the next row to build): the reference's gmm/, ivector/ and online2/online-ivector-feature.cc with
 # the programs that create a small extractor from features (gmm-global-init-from-feats -> gmm-global-to-fgmm -> ivector-extractor-init)
 # and the one that is the oracle for the GPU path to come (ivector-extract-online2 = OnlineIvectorFeature, what
