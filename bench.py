@@ -467,7 +467,13 @@ def main():
         so = np.ascontiguousarray(lats.state_offsets, np.int64)
         ao = np.ascontiguousarray(lats.arc_offsets, np.int64)
         si, sf_, ai, af = lats._si, lats._sf, lats._ai, lats._af
-        def one():
+        def one(replica=0):
+            # --host-load-replicas R (the host side of an R-GPU node rehearsed on one GPU): replica r's worker threads run on ITS share of the cores, cores / R wide, like
+            # rank r's would (the affinity of this calling thread is inherited by the threads k3h_postprocess_batch starts)
+            if args.host_load_replicas > 1 and not args.no_pin and hasattr(os, "sched_setaffinity"):
+                share = max(1, ncpu // args.host_load_replicas)
+                try: os.sched_setaffinity(0, range(replica * share, min(ncpu, (replica + 1) * share)))
+                except OSError: pass
             cs = np.zeros(n, np.int32)
             ca = np.zeros(n, np.int64)
             ok = np.zeros(n, np.int32)
@@ -476,8 +482,8 @@ def main():
                         float(LATTICE_BEAM), ctypes.byref(det_opts), det_threads, None, cs.ctypes.data, ca.ctypes.data, ok.ctypes.data))
             return int(cs.sum()), int(ca.sum())
         # (--host-load-replicas: the other ranks' host tails, same lattices, results dropped)
-        others = [extra_pool.submit(one) for _ in range(args.host_load_replicas - 1)] if extra_pool else []
-        r = one()
+        others = [extra_pool.submit(one, k + 1) for k in range(args.host_load_replicas - 1)] if extra_pool else []
+        r = one(0)
         for o in others: o.result()
         return r
 

@@ -392,6 +392,263 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
   }
 }
 
+// ---- the same product on the bf16 matrix core, operands split three ways (exploratory; never the default) ----------------------------------------------------
+// x = x_hi + x_mid + x_lo with every part a bf16 (the top, middle and bottom 8 bits of the float's 24-bit significand, by truncation: the split is EXACT), and
+//   x * w ~= hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid            (the three dropped terms are below 2^-24 of the product)
+// six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block instead of eight v_mfma_f32_32x32x2_f32: 0.375 of the FP32 matrix-core time at gfx950's 16 : 1 rate, every bf16 x bf16
+// product exact in the fp32 accumulator.  The weights are split once on the host (three planes), the activations when a tile is staged (and / sub / and / sub per element + one
+// v_perm per pair and plane).  What it is NOT: the reference's ascending-k fp32 summation order -- it is as accurate as an fp32 GEMM but rounds differently, so it is held to the
+// float64 forward (no further from it than nnet3-compute is), not to the 1e-4 fixture gates of the FP32 kernel above ("split-bf16").
+// One LDS buffer of three planes per operand (rows of 32 bf16 padded to 80 bytes: b128 fragment reads and b64 / b128 stage writes conflict-free), two workgroups per CU; the next
+// tile's global loads are in flight under the current tile's MFMAs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, 2) void k3_tdnn_gemm_x6_kernel(GemmParams p, const unsigned short *__restrict__ Wp, long long plane_stride) {
+  constexpr int NT = 256, LR = NT / 8, MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN, A_LOADS = kBM * kBK / 4 / NT;
+  constexpr int kRow = 80, B_CH = BN * 4 * 3, B_LOADS = (B_CH + NT - 1) / NT;      // bytes per LDS row of a plane; 16-byte chunks of the weight tile (3 planes x BN rows x 4)
+  static_assert((kBM / WM) * (BN / WN) == 4 && kBK == 32, "four wavefronts, k-tiles of 32");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *As = smem, *Bs = smem + 3 * kBM * kRow;      // [3][kBM][kRow], [3][BN][kRow]
+  const int nblocks = p.num_m_tiles * p.num_n_tiles;
+  int bid = blockIdx.x;
+  { const int per = nblocks / 8; if (bid < per * 8) bid = (bid % 8) * per + bid / 8; }
+  const int m_tile = bid / p.num_n_tiles, n_tile = bid % p.num_n_tiles;
+  const TileDesc td = p.tiles[m_tile];
+  const int n0 = n_tile * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int ld_row = tid >> 3, ld_kv = (tid & 7) * 4;
+  int a_row_local[A_LOADS], a_lo[A_LOADS], a_hi[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; i++) {
+    const int r = min(i * LR + ld_row, td.nrows - 1); const bool s2 = r >= td.split;
+    a_row_local[i] = r * p.row_stride + (s2 ? td.in_base2 : td.in_base); a_lo[i] = s2 ? td.in_lo2 : td.in_lo; a_hi[i] = s2 ? td.in_hi2 : td.in_hi;
+  }
+  f32x4 ra[A_LOADS]; uint4 rb[B_LOADS];
+  const float *a_ptr[A_LOADS];
+  auto load_tiles = [&](int kt, int oi_u, int w_u, bool dummy = false) {
+    if (w_u == 0) {
+      int sh = p.shifts[0];
+#pragma unroll
+      for (int o = 1; o < kMaxOffsets; o++) sh = oi_u == o ? p.shifts[o] : sh;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; i++) a_ptr[i] = p.A + (long long)clampi(a_row_local[i] + sh, a_lo[i], a_hi[i]) * p.lda + ld_kv;
+    }
+#pragma unroll
+    for (int i = 0; i < A_LOADS; i++) { ra[i] = *reinterpret_cast<const f32x4 *>(dummy ? p.W : a_ptr[i]); a_ptr[i] += kBK; }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; i++) {
+      const int c = i * NT + tid;
+      if (B_CH % NT == 0 || c < B_CH) {
+        const int pl = c / (BN * 4), r = (c % (BN * 4)) >> 2, kc = c & 3;
+        rb[i] = *reinterpret_cast<const uint4 *>(dummy ? Wp : Wp + pl * plane_stride + (long long)(n0 + r) * p.ldw + kt * kBK + kc * 8);
+      }
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; i++) {      // split the four floats: hi = top 16 bits, mid = top 16 bits of (x - hi), lo = x - hi - mid (8 significant bits left: exact as bf16)
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float x = ra[i][e]; const unsigned xb = __float_as_uint(x);
+        const float r1 = x - __uint_as_float(xb & 0xFFFF0000u); const unsigned r1b = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(r1b & 0xFFFF0000u);
+        h[e] = xb; m[e] = r1b; l[e] = __float_as_uint(r2);
+      }
+      char *q = As + (i * LR + ld_row) * kRow + ld_kv * 2;
+      // (v_perm_b32 selector 0x07060302: the upper halves of the two operands, the second operand's in the low half)
+      *reinterpret_cast<uint2 *>(q) = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+      *reinterpret_cast<uint2 *>(q + kBM * kRow) = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+      *reinterpret_cast<uint2 *>(q + 2 * kBM * kRow) = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; i++) {
+      const int c = i * NT + tid;
+      if (B_CH % NT == 0 || c < B_CH) { const int pl = c / (BN * 4), r = (c % (BN * 4)) >> 2, kc = c & 3; *reinterpret_cast<uint4 *>(Bs + (pl * BN + r) * kRow + kc * 16) = rb[i]; }
+    }
+  };
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ni++) {
+    const int col = n0 + wn * WN + ni * 32 + (lane & 31);
+    const float *bias = p.seq_bias ? p.seq_bias + (long long)td.bias_row * p.ld_seq_bias : p.bias;
+    const float b0 = (bias && col < p.N) ? bias[col] : 0.0f;
+    const float b1 = (p.seq_bias && td.split < td.nrows && col < p.N) ? p.seq_bias[(long long)td.bias_row2 * p.ld_seq_bias + col] : b0;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mi][ni][r] = (wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) < td.split ? b0 : b1;
+  }
+  const int nk = (p.Ktot + kBK - 1) / kBK;
+  int oi_next = 0, w_next = 0;
+  load_tiles(0, 0, 0);
+  const int frag_row = lane & 31, frag_b = (lane >> 5) * 16;      // a lane's row of the 32 x 32 block and its 16-byte half of a 16-wide k step
+  for (int kt = 0; kt < nk; kt++) {
+    __syncthreads();      // (every wavefront is through with the previous tile's fragments)
+    store_tiles();
+    __syncthreads();
+    const int oi_cur = oi_next; const bool more = kt + 1 < nk;
+    if (++w_next == p.tiles_per_off) { w_next = 0; oi_next++; }
+    load_tiles(more ? kt + 1 : kt, more ? oi_next : oi_cur, more ? w_next : 1, !more);      // in flight under this tile's MFMAs
+    const char *a = As + (wm * WM + frag_row) * kRow + frag_b, *b = Bs + (wn * WN + frag_row) * kRow + frag_b;
+#pragma unroll
+    for (int s_ = 0; s_ < kBK / 16; s_++) {
+      bf16x8 fa[3][MI], fb[3][NI];
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) fa[pl][mi] = *reinterpret_cast<const bf16x8 *>(a + (pl * kBM + mi * 32) * kRow + s_ * 32);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) fb[pl][ni] = *reinterpret_cast<const bf16x8 *>(b + (pl * BN + ni * 32) * kRow + s_ * 32);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {      // the small terms first
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][mi], fb[1][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mi], fb[2][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mi], fb[1][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+  }
+  __syncthreads();
+  // ---- epilogue.  The MFMA C/D layout gives a lane 4 consecutive ROWS of one column (col = lane & 31,
+  // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)), i.e. dword stores of 128-byte row pieces: 64 store and 64 residual-load
+  // instructions per lane, which is what the affine layers (K = 192 only) spent 60 % of their time on.  Instead each wavefront
+  // transposes its WM x WN accumulator tile through LDS (the tile buffers are dead by now) and then works on float4 row
+  // pieces: 4x fewer, 4x wider memory instructions, 256-byte runs per row.
+  constexpr int kStLd = WN + 4, C4 = WN / 4, RPI = 64 / C4, ITERS = WM / RPI;      // RPI rows per iteration; lanes >= RPI * C4 idle (WN = 96: 48 of 64 busy)
+  float *stage = reinterpret_cast<float *>(smem) + wave * (WM * kStLd);
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        stage[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * kStLd + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+  int res_kind = -1;
+#pragma unroll
+  for (int o = 0; o < kMaxOps; o++) if (o < p.nops && p.op_kind[o] == k3::kEpiResidual) res_kind = o;
+  const float *__restrict__ R = p.R; float *__restrict__ C = p.C;
+  const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                      (res_kind < 0 || ((p.ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0)));
+  // Everything the per-element program needs is fetched up front, all loads in flight together: the residual row pieces of the
+  // tile and, per epilogue op, this lane's four columns of its scale / offset vectors (a lane keeps the same columns over all
+  // its rows).  The op program is then applied op by op over the whole register tile: six block-uniform dispatches per tile
+  // instead of per row piece, and no scalar / vector loads between the arithmetic.  (Fetching kinds, pointers and vectors
+  // inside the row loop cost 42 k of the 48 k epilogue cycles of a K = 192 layer.)
+  const int c4 = lane % C4, row0 = lane / C4;                 // row = it * RPI + row0, column group c4
+  static_assert(WM % RPI == 0, "rows per iteration must divide the wave tile");
+  const bool lane_on = lane < RPI * C4;
+  const int col = lane_on ? n0 + wn * WN + c4 * 4 : p.N;      // idle lanes look like out-of-range columns
+  if (vec_ok) {
+    f32x4 res[ITERS], opS[kMaxOps], opO[kMaxOps], v[ITERS];
+    const bool col_ok = col < p.N;
+    const int colc = min(col, p.N - 4);
+    const int row0c = lane_on ? row0 : 0;
+    // a full tile (all of the 128 rows and BN columns exist: every tile but the last of an utterance / of N) needs no per-row
+    // bounds logic and walks its rows with one pointer increment per row piece
+    const bool full = td.nrows == kBM && n0 + BN <= p.N;
+    if ((EPI == kEpiAny || EPI == kEpiAnyMap || EPI == kEpiReluScaleRes) && res_kind >= 0 && !(0 & 1)) {
+      if (full && td.split >= td.nrows) {
+        const float *rp = R + (long long)(td.res_base + (wm * WM + row0c) * p.res_row_stride) * p.ldr + colc;
+        const long long rstep = (long long)RPI * p.res_row_stride * p.ldr;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) res[it] = *reinterpret_cast<const f32x4 *>(rp + it * rstep);
+      } else {
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+          const int lrow = min(wm * WM + it * RPI + row0, td.nrows - 1);
+          res[it] = *reinterpret_cast<const f32x4 *>(R + (long long)((lrow < td.split ? td.res_base : td.res_base2) + lrow * p.res_row_stride) * p.ldr + colc);
+        }
+      }
+    }
+    if (EPI == kEpiAny || EPI == kEpiAnyMap) {
+#pragma unroll
+      for (int o = 0; o < kMaxOps; o++) {
+        if (o < p.nops && p.op_kind[o] == k3::kEpiScaleOffset) {
+          opS[o] = *reinterpret_cast<const f32x4 *>(p.op_scale[o] + colc); opO[o] = *reinterpret_cast<const f32x4 *>(p.op_offset[o] + colc);
+        }
+      }
+    } else if (EPI == kEpiReluScaleRes || EPI == kEpiReluScale) {
+      opS[1] = *reinterpret_cast<const f32x4 *>(p.op_scale[1] + colc); opO[1] = *reinterpret_cast<const f32x4 *>(p.op_offset[1] + colc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) v[it] = *reinterpret_cast<const f32x4 *>(stage + (it * RPI + row0c) * kStLd + c4 * 4);
+    if (EPI == kEpiAny || EPI == kEpiAnyMap) {
+#pragma unroll
+      for (int o = 0; o < kMaxOps; o++) {
+        if (o < p.nops) {
+          const int kind = p.op_kind[o];
+          if (kind == k3::kEpiRelu) {
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) { v[it][0] = fmaxf(v[it][0], 0.0f); v[it][1] = fmaxf(v[it][1], 0.0f); v[it][2] = fmaxf(v[it][2], 0.0f); v[it][3] = fmaxf(v[it][3], 0.0f); }
+          } else if (kind == k3::kEpiScaleOffset) {
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) v[it] = v[it] * opS[o] + opO[o];
+          } else if (EPI == kEpiAnyMap && (kind == k3::kEpiSigmoid || kind == k3::kEpiTanh)) {
+#pragma unroll
+            for (int it = 0; it < ITERS; it++)
+#pragma unroll
+              for (int e = 0; e < 4; e++) v[it][e] = kind == k3::kEpiSigmoid ? epi_sigmoid(v[it][e]) : epi_tanh(v[it][e]);
+          } else {
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) v[it] = p.res_scale * res[it] + v[it];
+          }
+        }
+      }
+    } else if (EPI == kEpiReluScaleRes || EPI == kEpiReluScale) {
+#pragma unroll
+      for (int it = 0; it < ITERS; it++) {
+        v[it][0] = fmaxf(v[it][0], 0.0f); v[it][1] = fmaxf(v[it][1], 0.0f); v[it][2] = fmaxf(v[it][2], 0.0f); v[it][3] = fmaxf(v[it][3], 0.0f);
+        v[it] = v[it] * opS[1] + opO[1];
+        if (EPI == kEpiReluScaleRes) v[it] = p.res_scale * res[it] + v[it];
+      }
+    }
+    if (full && !(0 & 2)) {
+      if (lane_on) {
+        float *cp = C + (long long)(td.out_row0 + wm * WM + row0) * p.ldc + col;
+        const long long cstep = (long long)RPI * p.ldc;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) *reinterpret_cast<f32x4 *>(cp + it * cstep) = v[it];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < ITERS; it++) {
+        const int lrow = wm * WM + it * RPI + row0;
+        if (col_ok && lrow < td.nrows && (!(0 & 2) || v[it][0] == 12345.678f)) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v[it];
+      }
+    }
+  } else {                                             // unaligned / odd-width output: element-wise tail path
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) {
+      const int row = it * RPI + row0, lrow = wm * WM + row;
+      if (col >= p.N || lrow >= td.nrows) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * kStLd + c4 * 4);
+      for (int e = 0; e < 4; e++) {
+        const int c = col + e;
+        if (c >= p.N) break;
+        float x = v[e];
+        for (int o = 0; o < p.nops; o++) {
+          const int kind = p.op_kind[o];
+          if (kind == k3::kEpiRelu) x = fmaxf(x, 0.0f);
+          else if (kind == k3::kEpiScaleOffset) x = x * p.op_scale[o][c] + p.op_offset[o][c];
+          else if (EPI == kEpiAnyMap && kind == k3::kEpiSigmoid) x = epi_sigmoid(x);
+          else if (EPI == kEpiAnyMap && kind == k3::kEpiTanh) x = epi_tanh(x);
+          else x = p.res_scale * R[(long long)((lrow < td.split ? td.res_base : td.res_base2) + lrow * p.res_row_stride) * p.ldr + c] + x;
+        }
+        C[(long long)(td.out_row0 + lrow) * p.ldc + c] = x;
+      }
+    }
+  }
+}
+
 // element-wise fused node without a GEMM (rare: a ReLU/BatchNorm/NoOp whose input has several consumers)
 __global__ __launch_bounds__(256) void k3_elementwise_kernel(GemmParams p) {
   const TileDesc td = p.tiles[blockIdx.x];
@@ -417,6 +674,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct DeviceNode {     // model-level (batch independent) device data of one fused node
   float *W = nullptr; int ldw = 0, npad = 0, bn = 128;
+  unsigned short *Wp = nullptr; long long plane_stride = 0;      // the weights split into three bf16 planes [3][npad][ldw] (k3_nnet_batch_set_precision(.., 1) makes them)
   float *bias = nullptr;
   float *W_iv = nullptr;                      // [N x ivector_dim] (nodes fed by ReplaceIndex(ivector, t, 0))
   std::vector<float *> op_scale, op_offset;   // per op (null when not scale/offset)
@@ -480,7 +738,7 @@ __global__ __launch_bounds__(256) void k3_row_normalize_kernel(float *C, long lo
 
 struct k3_nnet_batch {
   k3_nnet *net = nullptr;
-  int num_utts = 0, subsampling = 1;
+  int num_utts = 0, subsampling = 1, precision = 0;      // precision: 0 = FP32 matrix core (the parity path), 1 = split-bf16 (exploratory)
   std::vector<int> num_frames;
   std::vector<long long> out_offsets;           // [U+1] rows of the output matrix
   long long total_in_rows = 0, total_out_rows = 0;
@@ -804,6 +1062,32 @@ extern "C" int64_t k3_nnet_batch_output_rows(const k3_nnet_batch *b, int64_t *h_
 
 extern "C" double k3_nnet_batch_flops(const k3_nnet_batch *b) { return b ? b->flops : -1.0; }
 
+// k3_nnet_batch_set_precision(batch, 1): the affine products of this batch run as six bf16 matrix-core products over three-way split operands (k3_tdnn_gemm_x6_kernel) wherever a
+// node's time offsets are tile aligned (every layer of a TDNN-F but the first); 0 = back to the FP32 matrix core.  The first call splits the model's weights (host, once).
+extern "C" int k3_nnet_batch_set_precision(k3_nnet_batch *b, int32_t mode) {
+  K3_REQUIRE(b && (mode == 0 || mode == 1), "k3_nnet_batch_set_precision: mode is 0 (FP32 matrix core) or 1 (split-bf16)");
+  if (mode == 1) {
+    k3_nnet *net = b->net; static std::mutex mu; std::lock_guard<std::mutex> g(mu);
+    for (size_t i = 0; i < net->fm.nodes.size(); i++) {
+      const k3::FusedNode &f = net->fm.nodes[i]; DeviceNode &d = net->dev[i];
+      if (!f.has_gemm || d.Wp || f.in_dim % kBK != 0) continue;
+      const int K = (int)f.offsets.size() * f.in_dim, N = f.out_dim; const size_t plane = (size_t)d.npad * d.ldw;
+      std::vector<unsigned short> wp(3 * plane, 0);
+      for (int n = 0; n < N; n++) for (int k = 0; k < K; k++) {
+        const float x = f.W[(size_t)n * K + k]; unsigned xb; memcpy(&xb, &x, 4);
+        unsigned hb = xb & 0xFFFF0000u; float hf; memcpy(&hf, &hb, 4); const float r1 = x - hf; unsigned r1b; memcpy(&r1b, &r1, 4);
+        unsigned mb = r1b & 0xFFFF0000u; float mf; memcpy(&mf, &mb, 4); const float r2 = r1 - mf; unsigned r2b; memcpy(&r2b, &r2, 4);
+        const size_t at = (size_t)n * d.ldw + k;
+        wp[at] = (unsigned short)(xb >> 16); wp[plane + at] = (unsigned short)(r1b >> 16); wp[2 * plane + at] = (unsigned short)(r2b >> 16);
+      }
+      const int rc = upload(&net->allocs, wp, &d.Wp); if (rc) return rc;
+      d.plane_stride = (long long)plane;
+    }
+  }
+  b->precision = mode;
+  return K3_OK;
+}
+
 static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream);
 extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream) {
   K3_REQUIRE(b && b->net->fm.ivector_dim == 0, "k3_nnet_forward: null batch, or the model has an i-vector input (use k3_nnet_forward_ivector)");
@@ -834,6 +1118,10 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
 #define K3_SET_ATTR(bn, wm, wn, al, ep) K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_kernel<bn, wm, wn, al, ep>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     K3_GEMM_VARIANTS(K3_SET_ATTR)
 #undef K3_SET_ATTR
+#define K3_X6_VARIANTS(X) X(128, 64, 64, kEpiAny) X(128, 64, 64, kEpiReluScaleRes) X(128, 64, 64, kEpiReluScale) X(96, 32, 96, kEpiAny) X(96, 32, 96, kEpiNone)
+#define K3_SET_ATTR6(bn, wm, wn, ep) K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_x6_kernel<bn, wm, wn, ep>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    K3_X6_VARIANTS(K3_SET_ATTR6)
+#undef K3_SET_ATTR6
     return K3_OK; }(); });
   if (attr_rc) return attr_rc;
   hipStream_t st = (hipStream_t)stream;
@@ -877,6 +1165,14 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
       const size_t lds_pad = 0;
 #endif
       bool launched = false;
+      if (b->precision == 1 && al && b->net->dev[i].Wp && !has_map) {      // split-bf16: three planes of 80-byte rows per operand, or the epilogue's staging tile, whichever is larger
+        const int bn_ = bn96 ? 96 : 128, wm_ = bn96 ? 32 : 64, wn_ = bn96 ? 96 : 64;
+        const size_t lds6 = std::max<size_t>((size_t)3 * (kBM + bn_) * 80, (size_t)4 * wm_ * (wn_ + 4) * sizeof(float));
+        const int epi6 = (epi == kEpiNone && !bn96) ? (int)kEpiAny : ((epi == kEpiReluScaleRes || epi == kEpiReluScale) && bn96 ? (int)kEpiAny : epi);
+#define K3_LAUNCH6(bn, wm, wn, ep) if (!launched && bn96 == (bn == 96) && epi6 == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_x6_kernel<bn, wm, wn, ep>), dim3(blocks), dim3(256), lds6, st, p, b->net->dev[i].Wp, b->net->dev[i].plane_stride); launched = true; }
+        K3_X6_VARIANTS(K3_LAUNCH6)
+#undef K3_LAUNCH6
+      }
 #define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3((kBM / wm) * (bn / wn) * 64), lds + lds_pad, st, p); launched = true; }
       K3_GEMM_VARIANTS(K3_LAUNCH)
       if (!launched) { epi = has_map ? kEpiAnyMap : kEpiAny; K3_GEMM_VARIANTS(K3_LAUNCH) }      // no fixed-program instantiation for this shape: run-time dispatch

@@ -102,6 +102,7 @@ def load():
     L.k3_nnet_batch_output_rows.argtypes = [vp, vp]; L.k3_nnet_batch_output_rows.restype = i64
     L.k3_nnet_batch_flops.argtypes = [vp]; L.k3_nnet_batch_flops.restype = ctypes.c_double
     L.k3_nnet_forward.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.k3_nnet_batch_set_precision.argtypes = [vp, i32]
     L.k3_nnet_stream_create.argtypes = [vp, i32, i32, i32, vp, ctypes.c_float, ctypes.POINTER(vp)]
     L.k3_nnet_stream_destroy.argtypes = [vp]; L.k3_nnet_stream_destroy.restype = None
     L.k3_nnet_stream_get_info.argtypes = [vp, ctypes.POINTER(NnetStreamInfo)]

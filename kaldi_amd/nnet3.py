@@ -49,6 +49,9 @@ class NnetBatch:
         except Exception:      # interpreter shutdown
             pass
 
+    def set_precision(self, mode):
+        """0 = the FP32 matrix core with the reference's summation order (default, the parity path); 1 = split-bf16 (exploratory: six bf16 matrix-core products per product)"""
+        _l.check(self._L.k3_nnet_batch_set_precision(self._h, int(mode)))
     def forward(self, feats, out=None, ivectors=None):
         """feats: float32 [sum T_u, >= input_dim] on the GPU -> float32 [total_out_rows, output_dim]; ivectors (models with an i-vector input):
         float32 [total_ivector_rows, ivector_dim] on the GPU, the utterances' rows back to back."""
