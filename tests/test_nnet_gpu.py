@@ -192,6 +192,30 @@ def test_stateful_streaming_forward_equals_whole_utterance(tmp_path):
     with pytest.raises(lib.K3Error): nnet3.StreamNnet3(net, 2, frames_per_chunk=4, frame_subsampling_factor=3)      # a chunk that is not a whole number of output frames
 
 
+def test_split_bf16_products_are_as_accurate_as_the_fp32_matrix_core(tmp_path):
+    """EXPLORATORY path (k3_nnet_batch_set_precision(.., 1), never the default): every affine product as six bf16 matrix-core products over three-way split operands.  The split
+    is exact and the dropped cross terms are below 2^-24, so the forward must sit as close to the float64 forward (oracle, the checker) as the FP32 matrix-core forward does --
+    what it may NOT be asked is the reference's rounding (it sums in another order): only a loose bound on its distance to the FP32 path."""
+    import torch
+    from kaldi_amd import nnet3, synth
+    from oracle import nnet3_oracle as no
+    rng = np.random.default_rng(21); dev = torch.device("cuda:0")
+    calib = (rng.standard_normal((300, 40)) * 1.2 + 16.5).astype(np.float32)
+    mp = str(tmp_path / "m.raw"); synth.make_tdnnf(seed=9, dim=256, bottleneck=64, strides=(1, 1, 0, 3, 3, 3), prefinal_small=64, num_pdfs=500, calib_feats=calib, out_std=2.0).write(mp)
+    net = nnet3.Nnet(mp); lens = [333, 200, 97]
+    utts = [(rng.standard_normal((T, 40)) * 1.2 + 16.5).astype(np.float32) for T in lens]
+    nb = nnet3.NnetBatch(net, lens, 3); x = torch.from_numpy(np.concatenate(utts)).to(dev)
+    y32 = nb.forward(x).clone(); nb.set_precision(1); y6 = nb.forward(x).clone(); nb.set_precision(0); y32b = nb.forward(x).clone(); torch.cuda.synchronize()
+    assert torch.equal(y32, y32b)                      # switching back restores the parity path bit for bit
+    onet = no.read_nnet(mp); e32 = e6 = 0.0
+    for u, f in enumerate(utts):
+        t = no.compute(onet, f, 3, dtype=np.float64); sl = slice(nb.out_offsets[u], nb.out_offsets[u + 1])
+        e32 = max(e32, float(np.abs(y32[sl].cpu().numpy() - t).max())); e6 = max(e6, float(np.abs(y6[sl].cpu().numpy() - t).max()))
+    assert not torch.equal(y6, y32), "the split-bf16 kernel did not run"
+    assert e6 <= 1.5 * e32 + 2e-5, (e6, e32)
+    assert float((y6 - y32).abs().max()) <= 4.0 * e32 + 1e-4
+
+
 # ---------------------------------------------------------------------------------------------- models with an i-vector input
 IV_CASES = {"s1_c50_p10": (1, 50, 10, False), "s3_c50_p10": (3, 50, 10, False), "s3_c21_p7": (3, 21, 7, False), "s1_c20_p10_short": (1, 20, 10, False), "s3_utt": (3, 50, 0, True), "s1_utt": (1, 50, 0, True)}
 
