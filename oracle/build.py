@@ -29,7 +29,7 @@ def build(verbose=False, with_ref=True):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
     if with_ref and os.path.isdir(os.environ.get("KALDI_REFERENCE", "/root/reference") + "/src"):
-        if not os.path.exists(os.path.join(HERE, "_ref", "bin", "ivector-extractor-copy")):      # the newest of the reference tools
+        if not os.path.exists(os.path.join(HERE, "_ref", "bin", "ref-word-align")):      # the newest of the reference tools
             subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")])
 
 if __name__ == "__main__":
