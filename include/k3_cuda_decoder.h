@@ -37,7 +37,8 @@ typedef int32 LaneId;
 
 class CudaDecoderException : public std::exception {      // cuda-decoder-common.h:100-127
  public:
-  CudaDecoderException(const char *str_, const char *file_, int line_, bool recoverable_) : str(str_), file(file_), line(line_), recoverable(recoverable_), buffer(std::string(file_) + ":" + std::to_string(line_) + " :" + str_) {}
+  CudaDecoderException(const char *str_, const char *file_, int line_, bool recoverable_) : str(str_), file(file_), line(line_), recoverable(recoverable_),
+      buffer(std::string(file_) + ":" + std::to_string(line_) + " :" + str_) {}
   const char *what() const throw() { return buffer.c_str(); }
   const char *str; const char *file; const int line; const bool recoverable; const std::string buffer;
 };
@@ -50,7 +51,8 @@ struct CudaDecoderConfig {
   int32 min_active = 200;              // LatticeFasterDecoderConfig::min_active (the reference GPU decoder has no such knob; the CPU decoder does)
   BaseFloat beam_delta = 0.5, hash_ratio = 2.0;
   bool literal_order = true;           // raw lattices identical to LatticeFasterDecoder's (k3_decoder_config.literal_order)
-  int32 max_frames_per_channel = 3000; // frames a channel can hold before GetRawLattice (the reference keeps a channel's tokens in host memory and has no such bound; here they stay in HBM)
+  // frames a channel can hold before GetRawLattice (the reference keeps a channel's tokens in host memory and has no such bound; here they stay in HBM)
+  int32 max_frames_per_channel = 3000;
   void Check() const { KALDI_ASSERT(default_beam > 0.0 && max_active > 1 && lattice_beam > 0.0 && (aux_q_capacity == -1 || aux_q_capacity >= main_q_capacity)); }
   void ComputeConfig() { if (main_q_capacity == -1) main_q_capacity = 4 * max_active; if (aux_q_capacity == -1) aux_q_capacity = 3 * main_q_capacity; }
 };
@@ -103,7 +105,11 @@ class CudaDecoder {
     KALDI_ASSERT(nlanes > 0 && nchannels > 0 && nlanes <= nchannels);      // cuda-decoder.cc:66-68
     CudaDecoderConfig c = config; c.Check(); c.ComputeConfig();
     k3_decoder_config kc; k3_decoder_config_default(&kc);
-    kc.beam = c.default_beam; kc.lattice_beam = c.lattice_beam; kc.max_active = c.max_active; kc.min_active = std::min(c.min_active, c.max_active - 1); kc.beam_delta = c.beam_delta;
+    kc.beam = c.default_beam;
+    kc.lattice_beam = c.lattice_beam;
+    kc.max_active = c.max_active;
+    kc.min_active = std::min(c.min_active, c.max_active - 1);
+    kc.beam_delta = c.beam_delta;
     kc.frame_tokens_cap = std::min(65536, std::max(c.main_q_capacity, 4096)); kc.frame_cands_cap = std::max(c.aux_q_capacity, 2 * kc.frame_tokens_cap);
     kc.lane_tokens_cap = std::max<int64_t>(c.ntokens_pre_allocated, kc.frame_tokens_cap); kc.lane_links_cap = 2 * kc.lane_tokens_cap;
     kc.literal_order = c.literal_order ? 1 : 0; kc.hash_ratio = c.hash_ratio;
@@ -139,7 +145,8 @@ class CudaDecoder {
   void AllowPartialHypotheses() { generate_partial_hypotheses_ = true; }
   void AllowEndpointing() { if (frame_shift_seconds_ == FLT_MAX) KALDI_ERR << "You must call SetOutputFrameShiftInSeconds() to use endpointing"; endpointing_ = true; }
   void SetOutputFrameShiftInSeconds(BaseFloat f) { frame_shift_seconds_ = f; }
-  // the silence transition-ids and the five rules of kaldi::EndpointDetected (online2/online-endpoint.cc:26-72): {must_contain_nonsilence, min_trailing_silence, max_relative_cost, min_utterance_length}
+  // the silence transition-ids and the five rules of kaldi::EndpointDetected (online2/online-endpoint.cc:26-72): {must_contain_nonsilence,
+  // min_trailing_silence, max_relative_cost, min_utterance_length}
   struct EndpointRule { bool must_contain_nonsilence; BaseFloat min_trailing_silence, max_relative_cost, min_utterance_length; };
   void SetEndpointing(const std::set<int32> &silence_transition_ids, const std::vector<EndpointRule> &rules) { silence_tids_ = silence_transition_ids; rules_ = rules; }
   void GetPartialHypothesis(ChannelId ichannel, PartialHypothesis **out) { KALDI_ASSERT(generate_partial_hypotheses_); *out = &partial_[ichannel]; }
@@ -175,7 +182,10 @@ class CudaDecoder {
       const int64_t ns = info[10 * u], na = info[10 * u + 1]; std::lock_guard<std::mutex> lk(raw_lock_[channels[u]]);
       Raw &r = raw_[channels[u]]; r.failed = info[10 * u + 2] < 0;
       r.frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); r.state.assign(ss.begin() + s0, ss.begin() + s0 + ns); r.fin.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
-      r.src.assign(as.begin() + a0, as.begin() + a0 + na); r.dst.assign(ad.begin() + a0, ad.begin() + a0 + na); r.il.assign(ai.begin() + a0, ai.begin() + a0 + na); r.ol.assign(ao.begin() + a0, ao.begin() + a0 + na);
+      r.src.assign(as.begin() + a0, as.begin() + a0 + na);
+      r.dst.assign(ad.begin() + a0, ad.begin() + a0 + na);
+      r.il.assign(ai.begin() + a0, ai.begin() + a0 + na);
+      r.ol.assign(ao.begin() + a0, ao.begin() + a0 + na);
       r.g.assign(ag.begin() + a0, ag.begin() + a0 + na); r.ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
       s0 += ns; a0 += na;
     }
@@ -202,11 +212,20 @@ class CudaDecoder {
  private:
   CudaDecoder(const CudaDecoder &); CudaDecoder &operator=(const CudaDecoder &);
   struct Raw { bool failed = false; std::vector<int32> frame, state, src, dst, il, ol; std::vector<float> fin, g, ac; };
-  void BestPaths(const std::vector<ChannelId> &channels, bool use_final, std::vector<int64_t> *off, std::vector<int32> *il, std::vector<int32> *ol, std::vector<float> *g, std::vector<float> *ac,
+  void BestPaths(const std::vector<ChannelId> &channels, bool use_final, std::vector<int64_t> *off, std::vector<int32> *il, std::vector<int32> *ol,
+      std::vector<float> *g, std::vector<float> *ac,
                  std::vector<float> *fc, std::vector<float> *rel) {
     const int32 n = (int32)channels.size(); int64_t cap = 0; for (ChannelId c : channels) cap += 4 * std::max(1, NumFramesDecoded(c)) + 64;
-    off->assign(n + 1, 0); il->assign(cap, 0); ol->assign(cap, 0); g->assign(cap, 0.0f); ac->assign(cap, 0.0f); fc->assign(n, 0.0f); std::vector<float> r(n); std::vector<int32> rf(n);
-    K3_CUDEC_CALL(k3_decoder_get_best_path(dec_, channels.data(), n, use_final ? 1 : 0, off->data(), cap, il->data(), ol->data(), g->data(), ac->data(), fc->data(), r.data(), rf.data()));
+    off->assign(n + 1, 0);
+    il->assign(cap, 0);
+    ol->assign(cap, 0);
+    g->assign(cap, 0.0f);
+    ac->assign(cap, 0.0f);
+    fc->assign(n, 0.0f);
+    std::vector<float> r(n);
+    std::vector<int32> rf(n);
+    K3_CUDEC_CALL(k3_decoder_get_best_path(dec_, channels.data(), n, use_final ? 1 : 0, off->data(), cap, il->data(), ol->data(), g->data(), ac->data(),
+        fc->data(), r.data(), rf.data()));
     if (rel) *rel = r;
   }
   void UpdatePartial(const std::vector<ChannelId> &channels) {      // GeneratePartialPath + EndpointDetected + BuildPartialHypothesisOutput (cuda-decoder.cc:1864-2003)
@@ -216,14 +235,19 @@ class CudaDecoder {
       const ChannelId c = channels[u];
       if (generate_partial_hypotheses_) {
         PartialHypothesis &ph = partial_[c]; ph.clear();
-        for (int64_t k = off[u]; k < off[u + 1]; k++) if (ol[k] != 0) { ph.words.push_back(ol[k]); if (!ph.out_str.empty()) ph.out_str += " "; ph.out_str += (size_t)ol[k] < word_syms_.size() ? word_syms_[ol[k]] : std::to_string(ol[k]); }
+        for (int64_t k = off[u]; k < off[u + 1]; k++) if (ol[k] != 0) {
+          ph.words.push_back(ol[k]);
+          if (!ph.out_str.empty()) ph.out_str += " ";
+          ph.out_str += (size_t)ol[k] < word_syms_.size() ? word_syms_[ol[k]] : std::to_string(ol[k]);
+        }
       }
       if (endpointing_) {
         int32 sil = 0, frames = 0;
         for (int64_t k = off[u + 1] - 1; k >= off[u]; k--) { if (il[k] == 0) continue; if (!silence_tids_.count(il[k])) break; sil++; }
         for (int64_t k = off[u]; k < off[u + 1]; k++) frames += il[k] != 0;
         const BaseFloat len = frames * frame_shift_seconds_, ts = sil * frame_shift_seconds_; bool ans = false;
-        for (const EndpointRule &r : rules_) ans = ans || (((len > ts) || !r.must_contain_nonsilence) && ts >= r.min_trailing_silence && rel[u] <= r.max_relative_cost && len >= r.min_utterance_length);
+        for (const EndpointRule &r : rules_) ans = ans ||
+            (((len > ts) || !r.must_contain_nonsilence) && ts >= r.min_trailing_silence && rel[u] <= r.max_relative_cost && len >= r.min_utterance_length);
         endpoint_[c] = ans;
       }
     }

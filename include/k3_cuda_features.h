@@ -38,7 +38,8 @@ class CudaSpectralFeatures {
   const FrameExtractionOptions &GetFrameOptions() const { return cumfcc_opts_.mfcc_opts.frame_opts; }
   /* cudafeat/feature-spectral-cuda.cu:525-567 */
   void ComputeFeatures(const CuVectorBase<BaseFloat> &cu_wave, BaseFloat sample_freq, BaseFloat vtln_warp, CuMatrix<BaseFloat> *cu_features) {
-    if (sample_freq != cumfcc_opts_.mfcc_opts.frame_opts.samp_freq) KALDI_ERR << "Waveform and config sample Frequency mismatch: " << sample_freq << " .vs " << cumfcc_opts_.mfcc_opts.frame_opts.samp_freq;
+    if (sample_freq != cumfcc_opts_.mfcc_opts.frame_opts.samp_freq) KALDI_ERR << "Waveform and config sample Frequency mismatch: " << sample_freq << " .vs " <<
+        cumfcc_opts_.mfcc_opts.frame_opts.samp_freq;
     k3_feat_plan *plan = Plan(vtln_warp);
     const int64_t nsamp = cu_wave.Dim(), nframes = k3_feat_num_frames(plan, nsamp);
     cu_features->Resize((int32)nframes, k3_feat_dim(plan), kUndefined);
@@ -46,7 +47,8 @@ class CudaSpectralFeatures {
     if (!d_off_ && hipMalloc((void **)&d_off_, 4 * sizeof(int64_t)) != hipSuccess) KALDI_ERR << "hipMalloc failed";
     const int64_t h[4] = {0, nsamp, 0, nframes};
     if (hipMemcpy(d_off_, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) KALDI_ERR << "hipMemcpy failed";
-    if (k3_feat_compute_batch(plan, cu_wave.Data(), d_off_, d_off_ + 2, 1, nframes, cu_features->Data(), cu_features->Stride(), NULL) != K3_OK) KALDI_ERR << "k3_feat_compute_batch: " << k3_last_error();
+    if (k3_feat_compute_batch(plan, cu_wave.Data(), d_off_, d_off_ + 2, 1, nframes, cu_features->Data(), cu_features->Stride(), NULL) != K3_OK) KALDI_ERR <<
+        "k3_feat_compute_batch: " << k3_last_error();
     if (hipDeviceSynchronize() != hipSuccess) KALDI_ERR << "feature kernel failed";
   }
  private:
@@ -54,13 +56,23 @@ class CudaSpectralFeatures {
     auto it = plans_.find(vtln_warp); if (it != plans_.end()) return it->second;
     const MfccOptions &m = cumfcc_opts_.mfcc_opts; const FrameExtractionOptions &f = m.frame_opts; const MelBanksOptions &b = m.mel_opts;
     k3_feat_opts o; memset(&o, 0, sizeof o);
-    o.samp_freq = f.samp_freq; o.frame_shift_ms = f.frame_shift_ms; o.frame_length_ms = f.frame_length_ms; o.dither = f.dither; o.preemph_coeff = f.preemph_coeff; o.blackman_coeff = f.blackman_coeff;
+    o.samp_freq = f.samp_freq;
+    o.frame_shift_ms = f.frame_shift_ms;
+    o.frame_length_ms = f.frame_length_ms;
+    o.dither = f.dither;
+    o.preemph_coeff = f.preemph_coeff;
+    o.blackman_coeff = f.blackman_coeff;
     o.remove_dc_offset = f.remove_dc_offset; o.round_to_power_of_two = f.round_to_power_of_two; o.snip_edges = f.snip_edges;
     const char *names[] = {"hanning", "sine", "hamming", "povey", "rectangular", "blackman"}; o.window_type = -1;
     for (int i = 0; i < 6; i++) if (f.window_type == names[i]) o.window_type = i;
     if (o.window_type < 0) KALDI_ERR << "Invalid window type " << f.window_type;
     o.num_bins = b.num_bins; o.low_freq = b.low_freq; o.high_freq = b.high_freq; o.vtln_low = b.vtln_low; o.vtln_high = b.vtln_high; o.htk_mode = b.htk_mode;
-    o.use_energy = m.use_energy; o.energy_floor = m.energy_floor; o.raw_energy = m.raw_energy; o.htk_compat = m.htk_compat; o.use_log_fbank = cumfcc_opts_.use_log_fbank; o.use_power = cumfcc_opts_.use_power;
+    o.use_energy = m.use_energy;
+    o.energy_floor = m.energy_floor;
+    o.raw_energy = m.raw_energy;
+    o.htk_compat = m.htk_compat;
+    o.use_log_fbank = cumfcc_opts_.use_log_fbank;
+    o.use_power = cumfcc_opts_.use_power;
     o.num_ceps = m.num_ceps; o.cepstral_lifter = m.cepstral_lifter; o.feature_type = cumfcc_opts_.feature_type == MFCC ? 1 : 0; o.vtln_warp = vtln_warp;
     k3_feat_plan *p = NULL;
     if (k3_feat_plan_create(&o, &p) != K3_OK) KALDI_ERR << "k3_feat_plan_create: " << k3_last_error();

@@ -48,23 +48,33 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
       K3H_ERR << "Neural net expects 'ivector' features with dimension " << ni.ivector_dim << " but you provided " << (ivx_ ? iv_info_.ie.ivector_dim : 0);
     if (N_ != trans_.num_pdfs) K3H_ERR << "Model output dimension " << N_ << " != number of pdfs in the transition model " << trans_.num_pdfs;
     std::vector<float> lp; if (ni.has_priors) { lp.resize(N_); K3H_CHECK_K3(k3_nnet_get_priors(am_nnet, lp.data())); for (float &p : lp) p = logf(p); }
-    K3H_CHECK_K3(k3_fst_create(decode_fst.NumStates(), decode_fst.start, decode_fst.arc_offsets.data(), decode_fst.ilabel.data(), decode_fst.olabel.data(), decode_fst.weight.data(),
+    K3H_CHECK_K3(k3_fst_create(decode_fst.NumStates(), decode_fst.start, decode_fst.arc_offsets.data(), decode_fst.ilabel.data(), decode_fst.olabel.data(),
+        decode_fst.weight.data(),
                                decode_fst.nextstate.data(), decode_fst.final_cost.data(), trans_.id2pdf.data(), (int32_t)trans_.id2pdf.size(), &fst_));
     graph_start_ = k3_fst_start(fst_);
     K3H_CHECK_K3(k3_decoder_create(fst_, &config_.decoder_opts, nch_, N_, &dec_));
     K3H_CHECK_K3(k3_decoder_init_decoding(dec_, nch_, config_.max_utterance_frames, nullptr));
     const int s = config_.frame_subsampling_factor; C_ = std::max(s, config_.frames_per_chunk / s * s);
-    // one work stream for everything DecodeBatch queues, fed from page-locked staging rings: the host does not wait for the device inside a call (k3_online.h: DevBuf::upload_async)
+    // one work stream for everything DecodeBatch queues, fed from page-locked staging rings: the host does not wait for the device inside a call (k3_online.h:
+    // DevBuf::upload_async)
     K3O_HIP(hipStreamCreate(&ws_));
     // token passing on its own stream: a chunk's launch lasts as long as its slowest lane, the next pass's features / network run beside it; the two streams share only the
     // gathered log-likelihood block (two of them, events ev_ll_: filled / ev_tp_: consumed)
-    { int lo = 0, hi = 0; K3O_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); if (lo == hi) K3O_HIP(hipStreamCreate(&ds_)); else K3O_HIP(hipStreamCreateWithPriority(&ds_, hipStreamDefault, hi)); }      // (the critical path of a round)
+    // (the critical path of a round)
+    {
+      int lo = 0, hi = 0;
+      K3O_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      if (lo == hi) K3O_HIP(hipStreamCreate(&ds_));
+      else K3O_HIP(hipStreamCreateWithPriority(&ds_, hipStreamDefault, hi));
+    }
     for (int k = 0; k < 2; k++) { K3O_HIP(hipEventCreateWithFlags(&ev_ll_[k], hipEventDisableTiming)); K3O_HIP(hipEventCreateWithFlags(&ev_tp_[k], hipEventDisableTiming)); }
     features_.reset(new OnlineFeatures(plan_, config_.feature_opts, nch_, ws_));
     net_.reset(new StaticNnet3(am_nnet, nch_, nch_, C_, s, lp.empty() ? nullptr : lp.data(), config_.acoustic_scale, ws_));
     if (ivx_) ivs_.reset(new OnlineIvectors(ivx_, iv_info_.right_context, nch_, ws_));
     samples_per_chunk_ = C_ * (int)(config_.feature_opts.samp_freq * 0.001 * config_.feature_opts.frame_shift_ms);
-    pend_cap_ = (size_t)(2 * C_ + 8); for (auto &h : held_) h.need((size_t)nch_ * (pend_cap_ + (size_t)C_ + 16) * fdim_);      // (pending feature rows of all channels, compact; see DecodeBatch)
+    // (pending feature rows of all channels, compact; see DecodeBatch)
+    pend_cap_ = (size_t)(2 * C_ + 8);
+    for (auto &h : held_) h.need((size_t)nch_ * (pend_cap_ + (size_t)C_ + 16) * fdim_);
     chan_.resize(nch_); for (int c = nch_ - 1; c >= 0; c--) free_.push_back(c);
     const int nw = config_.num_worker_threads > 0 ? config_.num_worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
     for (int i = 0; i < nw; i++) workers_.emplace_back([this] { WorkerLoop(); });
@@ -74,8 +84,23 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     { std::lock_guard<std::mutex> l(m_); stop_ = true; } wcv_.notify_all();
     for (auto &w : workers_) w.join();
     ivs_.reset(); if (ivx_) k3_ivector_destroy(ivx_);
-    net_.reset(); features_.reset(); if (ws_) { (void)hipStreamSynchronize(ws_); (void)hipStreamDestroy(ws_); } if (ds_) { (void)hipStreamSynchronize(ds_); (void)hipStreamDestroy(ds_); }
-    for (int k = 0; k < 2; k++) { if (ev_ll_[k]) (void)hipEventDestroy(ev_ll_[k]); if (ev_tp_[k]) (void)hipEventDestroy(ev_tp_[k]); } k3_decoder_destroy(dec_); k3_fst_destroy(fst_); k3_feat_plan_destroy(plan_);
+    net_.reset();
+    features_.reset();
+    if (ws_) {
+      (void)hipStreamSynchronize(ws_);
+      (void)hipStreamDestroy(ws_);
+    }
+    if (ds_) {
+      (void)hipStreamSynchronize(ds_);
+      (void)hipStreamDestroy(ds_);
+    }
+    for (int k = 0; k < 2; k++) {
+      if (ev_ll_[k]) (void)hipEventDestroy(ev_ll_[k]);
+      if (ev_tp_[k]) (void)hipEventDestroy(ev_tp_[k]);
+    }
+    k3_decoder_destroy(dec_);
+    k3_fst_destroy(fst_);
+    k3_feat_plan_destroy(plan_);
   }
   int32_t GetNSampsPerChunk() const { return samples_per_chunk_; }
   int32_t GetNInputFramesPerChunk() const { return C_; }
@@ -91,7 +116,8 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
   void SetBestPathCallback(CorrelationID corr_id, const BestPathCallback &cb) { std::lock_guard<std::mutex> l(m_); best_cb_[corr_id] = cb; }
   // One chunk of audio for each listed stream (at most max_batch_size of them, each at most GetNSampsPerChunk() samples unless it is the stream's last chunk).
   // partial_hypotheses / end_point (optional): the current best path's word ids and the end-point verdict of every stream of the batch.
-  void DecodeBatch(const std::vector<CorrelationID> &corr_ids, const std::vector<std::vector<float>> &wave_samples, const std::vector<bool> &is_first_chunk, const std::vector<bool> &is_last_chunk,
+  void DecodeBatch(const std::vector<CorrelationID> &corr_ids, const std::vector<std::vector<float>> &wave_samples, const std::vector<bool> &is_first_chunk,
+      const std::vector<bool> &is_last_chunk,
                    std::vector<std::string> *partial_hypotheses = nullptr, std::vector<bool> *end_point = nullptr) {
     const size_t n = corr_ids.size();
     if (n > (size_t)config_.max_batch_size || wave_samples.size() != n || is_first_chunk.size() != n || is_last_chunk.size() != n) K3H_ERR << "DecodeBatch: bad batch";
@@ -104,7 +130,8 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     std::vector<int32_t> fresh; for (size_t i = 0; i < n; i++) if (first[i]) { fresh.push_back(chs[i]); net_->Reset(chs[i]); chan_[chs[i]] = Chan(); }
     if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec_, fresh.data(), (int32_t)fresh.size(), ds_));
     float *d_feats = nullptr; const std::vector<int> nf = features_->ComputeFeaturesBatched(chs, wave_samples, first, &d_feats);
-    // Feature rows a channel has computed but not yet fed to the network live compactly in one device buffer, channel after channel, (offset, count) on the host, at most two segments
+    // Feature rows a channel has computed but not yet fed to the network live compactly in one device buffer, channel after channel, (offset, count) on the
+    // host, at most two segments
     // per channel (leftover + this call's rows).  A pass takes its rows with one row gather and the leftovers of all channels move to the other buffer with one more, once per call:
     // per-channel buffers cost ~4 synchronous device copies per channel and call (40 k copies in a 512-channel run of 10 s files, half of its GPU time).
     { int64_t off = 0, tot = 0; for (int k : nf) tot += k;
@@ -125,7 +152,14 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
       { std::vector<int32_t> take; take.reserve((size_t)tot_new);
         for (size_t i = 0; i < run.size(); i++) {
           Chan &c = chan_[run[i]]; int k = n_new[i];
-          for (int sgm = 0; sgm < 2 && k > 0; sgm++) { const int m = std::min(k, c.seg_cnt[sgm]); for (int j = 0; j < m; j++) take.push_back((int32_t)(c.seg_off[sgm] + j)); c.seg_off[sgm] += m; c.seg_cnt[sgm] -= m; k -= m; c.pend -= m; }
+          for (int sgm = 0; sgm < 2 && k > 0; sgm++) {
+            const int m = std::min(k, c.seg_cnt[sgm]);
+            for (int j = 0; j < m; j++) take.push_back((int32_t)(c.seg_off[sgm] + j));
+            c.seg_off[sgm] += m;
+            c.seg_cnt[sgm] -= m;
+            k -= m;
+            c.pend -= m;
+          }
           const bool end = is_last[run[i]] && c.pend == 0; lasts.push_back(end); if (end) closed[run[i]] = 1;
         }
         if (!take.empty()) { gidx_.upload_async(take, ws_); K3H_CHECK_K3(k3_mat_copy_rows(new_.p, fdim_, (int32_t)take.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, ws_)); } }
@@ -137,7 +171,11 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
         if (tp_used_[lb]) K3O_HIP(hipStreamWaitEvent(ws_, ev_tp_[lb], 0));
         net_->SelectOut(lb);
         auto res = net_->Pass(run, new_.p, n_new, lasts, ivs_ ? ivs_->Gather(run) : nullptr);
-        for (size_t i = 0; i < run.size(); i++) if (res[i].count > 0) { lane_first[run[i]] = net_->Out() + (size_t)res[i].first * N_; lane_frames[run[i]] = res[i].count; ld_rows = (int64_t)res[i].stride * N_; }
+        for (size_t i = 0; i < run.size(); i++) if (res[i].count > 0) {
+          lane_first[run[i]] = net_->Out() + (size_t)res[i].first * N_;
+          lane_frames[run[i]] = res[i].count;
+          ld_rows = (int64_t)res[i].stride * N_;
+        }
       }
       K3O_HIP(hipEventRecord(ev_ll_[lb], ws_)); K3O_HIP(hipStreamWaitEvent(ds_, ev_ll_[lb], 0));
       K3H_CHECK_K3(k3_decoder_advance_decoding_strided(dec_, nch_, lane_first.data(), lane_frames.data(), ld_rows, ds_));
@@ -152,11 +190,18 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
         for (int sgm = 0; sgm < 2; sgm++) for (int j = 0; j < c.seg_cnt[sgm]; j++) keep.push_back((int32_t)(c.seg_off[sgm] + j));
         c.seg_off[0] = at; c.seg_cnt[0] = k; c.seg_off[1] = 0; c.seg_cnt[1] = 0; at += k;
       }
-      if (!keep.empty()) { gidx_.upload_async(keep, ws_); K3H_CHECK_K3(k3_mat_copy_rows(held_[held_cur_ ^ 1].p, fdim_, (int32_t)keep.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, ws_)); }
+      if (!keep.empty()) {
+        gidx_.upload_async(keep, ws_);
+        K3H_CHECK_K3(k3_mat_copy_rows(held_[held_cur_ ^ 1].p, fdim_, (int32_t)keep.size(), fdim_, held_[held_cur_].p, fdim_, gidx_.p, ws_));
+      }
       held_cur_ ^= 1; held_rows_ = at;
     }
     // partial hypotheses / end-pointing / best-path callbacks (cuda-decoder.cc:1864-2003) from the tokens the channels hold now
-    bool want_best = partial_hypotheses || end_point; { std::lock_guard<std::mutex> l(m_); for (size_t i = 0; i < n && !want_best; i++) want_best = best_cb_.count(corr_ids[i]) > 0; }
+    bool want_best = partial_hypotheses || end_point;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      for (size_t i = 0; i < n && !want_best; i++) want_best = best_cb_.count(corr_ids[i]) > 0;
+    }
     if (want_best && n > 0) {
       std::vector<int32_t> c32(chs.begin(), chs.end()); std::vector<int64_t> off(n + 1); const int64_t cap = (int64_t)n * (config_.max_utterance_frames + 16);
       std::vector<int32_t> il(cap), ol(cap); std::vector<float> g(cap), a(cap), fc(n), rc(n); std::vector<int32_t> rf(n);
@@ -182,9 +227,16 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
     for (int u = 0; u < U; u++) {
       const int64_t ns = info[10 * u], na = info[10 * u + 1]; auto t = std::make_shared<Task>();
       if (info[10 * u + 2] == 0 && ns > 0) {
-        Lattice &lat = t->raw; lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns); lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
-        lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na); lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na); lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
-        lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
+        Lattice &lat = t->raw;
+        lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns);
+        lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns);
+        lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
+        lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na);
+        lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na);
+        lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
+        lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na);
+        lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na);
+        lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
         for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == graph_start_) lat.start = (int32_t)s;
       }
       s0 += ns; a0 += na;
@@ -206,14 +258,27 @@ class BatchedThreadedNnet3CudaOnlinePipeline {
       { std::unique_lock<std::mutex> l(m_); wcv_.wait(l, [&] { return stop_ || !post_.empty(); }); if (post_.empty()) return; t = post_.front(); post_.pop_front(); }
       CompactLattice clat;
       try {
-        if (t->raw.NumStates() > 0) { Connect(&t->raw); if (config_.determinize_lattice) DeterminizeLatticePhonePruned(t->raw, trans_, config_.decoder_opts.lattice_beam, &clat, config_.det_opts); else ConvertLattice(t->raw, &clat); }
+        if (t->raw.NumStates() > 0) {
+          Connect(&t->raw);
+          if (config_.determinize_lattice) DeterminizeLatticePhonePruned(t->raw, trans_, config_.decoder_opts.lattice_beam, &clat, config_.det_opts);
+          else ConvertLattice(t->raw, &clat);
+        }
         t->callback(clat);
       } catch (const std::exception &e) { K3H_WARN << "lattice post-processing / callback failed: " << e.what(); }
       { std::lock_guard<std::mutex> l(m_); n_callbacks_not_done_--; } done_cv_.notify_all();
     }
   }
   const BatchedThreadedNnet3CudaOnlinePipelineConfig config_; const TransitionInfo &trans_;
-  hipStream_t ws_ = nullptr, ds_ = nullptr; hipEvent_t ev_ll_[2] = {nullptr, nullptr}, ev_tp_[2] = {nullptr, nullptr}; bool tp_used_[2] = {false, false}; unsigned pass_no_ = 0; k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr; int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0; int32_t graph_start_ = 0; size_t pend_cap_ = 0;
+  hipStream_t ws_ = nullptr, ds_ = nullptr;
+  hipEvent_t ev_ll_[2] = {nullptr, nullptr}, ev_tp_[2] = {nullptr, nullptr};
+  bool tp_used_[2] = {false, false};
+  unsigned pass_no_ = 0;
+  k3_feat_plan *plan_ = nullptr;
+  k3_fst *fst_ = nullptr;
+  k3_decoder *dec_ = nullptr;
+  int nch_ = 0, fdim_ = 0, N_ = 0, C_ = 0, samples_per_chunk_ = 0;
+  int32_t graph_start_ = 0;
+  size_t pend_cap_ = 0;
   std::unique_ptr<OnlineFeatures> features_; std::unique_ptr<StaticNnet3> net_; std::unique_ptr<OnlineIvectors> ivs_; k3_ivector *ivx_ = nullptr; IvectorExtractionInfo iv_info_;
   std::vector<Chan> chan_; DevBuf<float> held_[2], new_; DevBuf<int32_t> gidx_; int held_cur_ = 0; int64_t held_rows_ = 0;
   std::mutex m_; std::condition_variable wcv_, done_cv_; bool stop_ = false; int n_callbacks_not_done_ = 0;

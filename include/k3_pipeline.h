@@ -63,9 +63,11 @@ class CudaPipelineResult {
   void SetAsLastSegment() { is_last_segment_ = true; }
 };
 struct SegmentedLatticeCallbackParams { std::vector<CudaPipelineResult> results; };
-// cudadecoder/cuda-pipeline-common.cc:67-142: the CTM lines of one utterance from its segments' results -- of two overlapping segments the earlier one keeps the words that begin before the
+// cudadecoder/cuda-pipeline-common.cc:67-142: the CTM lines of one utterance from its segments' results -- of two overlapping segments the earlier one keeps
+// the words that begin before the
 // later one starts, the later one the rest; times shifted by the segments' offsets
-inline void MergeSegmentsToCTMOutput(std::vector<CudaPipelineResult> &results, const std::string &key, std::ostream &os, const std::vector<std::string> *word_syms = nullptr, bool use_segment_offsets = true) {
+inline void MergeSegmentsToCTMOutput(std::vector<CudaPipelineResult> &results, const std::string &key, std::ostream &os,
+    const std::vector<std::string> *word_syms = nullptr, bool use_segment_offsets = true) {
   if (results.empty()) { K3H_WARN << "Utterance " << key << " has no results. Skipping"; return; }
   for (CudaPipelineResult &r : results) if (!r.HasValidResult()) { K3H_WARN << "Utterance " << key << " has at least one segment with an error. Skipping"; return; }
   os << std::fixed; os.precision(2);
@@ -95,7 +97,8 @@ struct BatchedThreadedNnet3CudaPipeline2Config {      // the options of BatchedT
   k3_decoder_config decoder_opts;                             // beam, lattice-beam, max-active, capacities, literal_order
   float acoustic_scale = 0.1f; int32_t frame_subsampling_factor = 1;
   CudaPipelineSegmentationConfig seg_opts;                    // --segment-length, --segment-overlap, --min-segment-length
-  bool alternate_decoders = true;                             // two decoder objects (twice the lane pools) used in turn: a batch's token passing starts under the previous batch's pruning kernel and lattice copy
+  // two decoder objects (twice the lane pools) used in turn: a batch's token passing starts under the previous batch's pruning kernel and lattice copy
+  bool alternate_decoders = true;
   BatchedThreadedNnet3CudaPipeline2Config() { memset(&feature_opts, 0, sizeof feature_opts); k3_decoder_config_default(&decoder_opts); }
 };
 
@@ -110,7 +113,8 @@ class BatchedThreadedNnet3CudaPipeline2 {
     if (ninfo_.ivector_dim > 0) K3H_ERR << "this pipeline class does not extract i-vectors (the batched-wav-nnet3-cuda2 program does)";
     if (ninfo_.output_dim != trans_.num_pdfs) K3H_ERR << "Model output dimension " << ninfo_.output_dim << " != number of pdfs in the transition model " << trans_.num_pdfs;
     if (ninfo_.has_priors) { log_priors_.resize(ninfo_.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet_, log_priors_.data())); for (float &p : log_priors_) p = logf(p); }
-    K3H_CHECK_K3(k3_fst_create(decode_fst.NumStates(), decode_fst.start, decode_fst.arc_offsets.data(), decode_fst.ilabel.data(), decode_fst.olabel.data(), decode_fst.weight.data(),
+    K3H_CHECK_K3(k3_fst_create(decode_fst.NumStates(), decode_fst.start, decode_fst.arc_offsets.data(), decode_fst.ilabel.data(), decode_fst.olabel.data(),
+        decode_fst.weight.data(),
                                decode_fst.nextstate.data(), decode_fst.final_cost.data(), trans_.id2pdf.data(), (int32_t)trans_.id2pdf.size(), &fst_));
     graph_start_ = k3_fst_start(fst_);
     K3H_CHECK_K3(k3_decoder_create(fst_, &config_.decoder_opts, config_.max_batch_size, ninfo_.output_dim, &dec_));
@@ -146,27 +150,48 @@ class BatchedThreadedNnet3CudaPipeline2 {
   }
   // Extracts segments from wave_data and decodes them; `segmented_callback` gets the results of all segments at once, in segment order, from the worker thread that
   // finishes the last of them (:160-168, 265-337).  A waveform shorter than one segment is one segment; a last piece below min-segment-length is dropped.
-  void SegmentedDecodeWithCallback(const std::shared_ptr<Wave> &wave_data, const SegmentedResultsCallback &segmented_callback, const int result_type = CudaPipelineResult::RESULT_TYPE_LATTICE) {
+  void SegmentedDecodeWithCallback(const std::shared_ptr<Wave> &wave_data, const SegmentedResultsCallback &segmented_callback,
+      const int result_type = CudaPipelineResult::RESULT_TYPE_LATTICE) {
     if (!result_type) K3H_ERR << "You must define at least one result type";
-    if ((result_type & CudaPipelineResult::RESULT_TYPE_CTM) && !lattice_postprocessor_) K3H_ERR << "A lattice postprocessor must be set with SetLatticePostprocessor() to use RESULT_TYPE_CTM";
-    if (wave_data->samp_freq != GetModelFrequency()) K3H_ERR << "SegmentedDecodeWithCallback: sample rate " << wave_data->samp_freq << " != model frequency " << GetModelFrequency();
+    if ((result_type & CudaPipelineResult::RESULT_TYPE_CTM) && !lattice_postprocessor_) K3H_ERR <<
+        "A lattice postprocessor must be set with SetLatticePostprocessor() to use RESULT_TYPE_CTM";
+    if (wave_data->samp_freq != GetModelFrequency()) K3H_ERR << "SegmentedDecodeWithCallback: sample rate " << wave_data->samp_freq << " != model frequency "
+        << GetModelFrequency();
     config_.seg_opts.Check();
     const float freq = GetModelFrequency();
     const int seg_len = (int)(config_.seg_opts.segment_length_s * freq), seg_shift = (int)((config_.seg_opts.segment_length_s - config_.seg_opts.segment_overlap_s) * freq),
               seg_min = (int)(config_.seg_opts.min_segment_length_s * freq), total = (int)wave_data->samples.size();
-    if (total == 0) { if (segmented_callback) { SegmentedLatticeCallbackParams params; params.results.resize(1); params.results[0].SetLatticeResult(CompactLattice()); params.results[0].SetAsLastSegment(); segmented_callback(params); } return; }
+    if (total == 0) {
+      if (segmented_callback) {
+        SegmentedLatticeCallbackParams params;
+        params.results.resize(1);
+        params.results[0].SetLatticeResult(CompactLattice());
+        params.results[0].SetAsLastSegment();
+        segmented_callback(params);
+      }
+      return;
+    }
     std::vector<std::pair<int, int>> pieces;      // (offset, samples)
     for (int offset = 0;; offset += seg_shift) { const int n = std::min(total - offset, seg_len); if (n >= seg_min) pieces.push_back({offset, n}); if (offset + n >= total) break; }
     if (pieces.empty()) { if (segmented_callback) { SegmentedLatticeCallbackParams params; segmented_callback(params); } return; }
     auto results = std::make_shared<std::vector<CudaPipelineResult>>(pieces.size());
     auto not_done = std::make_shared<std::atomic<int32_t>>((int32_t)pieces.size());
     for (size_t i = 0; i < pieces.size(); i++) {
-      CudaPipelineResult &r = (*results)[i]; r.SetTimeOffsetSeconds(std::floor((float)pieces[i].first / freq)); r.SetSegmentID((int)i); if (i + 1 == pieces.size()) r.SetAsLastSegment();
+      CudaPipelineResult &r = (*results)[i];
+      r.SetTimeOffsetSeconds(std::floor((float)pieces[i].first / freq));
+      r.SetSegmentID((int)i);
+      if (i + 1 == pieces.size()) r.SetAsLastSegment();
       auto pp = lattice_postprocessor_;
       LatticeCallback callback = [results, not_done, segmented_callback, i, pp, result_type](CompactLattice &clat) {
         // SetResultUsingLattice (cudadecoder/lattice-postprocessor.cc:112-137)
         if (result_type & CudaPipelineResult::RESULT_TYPE_CTM) { CtmResult ctm; CompactLattice copy = clat; pp->GetCTM(copy, &ctm); (*results)[i].SetCTMResult(std::move(ctm)); }
-        if (result_type & CudaPipelineResult::RESULT_TYPE_LATTICE) { if (pp) { CompactLattice out; pp->GetPostprocessedLattice(clat, &out); (*results)[i].SetLatticeResult(std::move(out)); } else (*results)[i].SetLatticeResult(std::move(clat)); }
+        if (result_type & CudaPipelineResult::RESULT_TYPE_LATTICE) {
+          if (pp) {
+            CompactLattice out;
+            pp->GetPostprocessedLattice(clat, &out);
+            (*results)[i].SetLatticeResult(std::move(out));
+          } else (*results)[i].SetLatticeResult(std::move(clat));
+        }
         if (not_done->fetch_sub(1) == 1 && segmented_callback) { SegmentedLatticeCallbackParams params; params.results = std::move(*results); segmented_callback(params); }
       };
       std::vector<float> piece(wave_data->samples.begin() + pieces[i].first, wave_data->samples.begin() + pieces[i].first + pieces[i].second);
@@ -193,7 +218,13 @@ class BatchedThreadedNnet3CudaPipeline2 {
   struct Task { std::vector<float> samples; LatticeCallback callback; std::string group; bool has_group = false; Lattice raw; bool failed = false; };
   void Enqueue(const std::shared_ptr<Task> &t, const std::string &group) {
     std::lock_guard<std::mutex> l(m_);
-    if (!group.empty()) { auto it = groups_.find(group); if (it == groups_.end()) K3H_ERR << "Group does not exist: " << group; it->second++; t->group = group; t->has_group = true; }
+    if (!group.empty()) {
+      auto it = groups_.find(group);
+      if (it == groups_.end()) K3H_ERR << "Group does not exist: " << group;
+      it->second++;
+      t->group = group;
+      t->has_group = true;
+    }
     n_tasks_not_done_++; queue_.push_back(t); cv_.notify_one();
   }
   void Finish(const std::shared_ptr<Task> &t) {
@@ -231,12 +262,16 @@ class BatchedThreadedNnet3CudaPipeline2 {
   void Hand(std::vector<std::shared_ptr<Task>> &batch) { { std::lock_guard<std::mutex> l(m_); for (auto &t : batch) post_.push_back(t); } wcv_.notify_all(); }
   void ControlLoop() {
     K3O_HIP(hipSetDevice(device_));
-    K3O_HIP(hipStreamCreateWithFlags(&s_front_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_, hipStreamNonBlocking)); K3O_HIP(hipStreamCreateWithFlags(&s_dec_b_, hipStreamNonBlocking));
+    K3O_HIP(hipStreamCreateWithFlags(&s_front_, hipStreamNonBlocking));
+    K3O_HIP(hipStreamCreateWithFlags(&s_dec_, hipStreamNonBlocking));
+    K3O_HIP(hipStreamCreateWithFlags(&s_dec_b_, hipStreamNonBlocking));
     for (auto &e : ev_front_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ev_dec_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ev_h2d_) K3O_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    // Batches in flight: `prev` (decoded, lattices not fetched yet -- only with two decoder objects), `cur` (front end issued, decoder next), `nxt` (front end issued behind cur's decoder).
-    // With one decoder object a batch's lattices are fetched right after the next batch's front end has been queued; with two, one step later, so that the next batch's token passing is
+    // Batches in flight: `prev` (decoded, lattices not fetched yet -- only with two decoder objects), `cur` (front end issued, decoder next), `nxt` (front end
+    // issued behind cur's decoder).
+    // With one decoder object a batch's lattices are fetched right after the next batch's front end has been queued; with two, one step later, so that the next
+    // batch's token passing is
     // already queued on the other object's stream while this batch's pruning kernel, compaction and copy run.  Nothing waits for new work while a decoded batch is unfetched.
     InFlight prev, cur, nxt; int parity = 0; bool prev_decoding = false;
     auto start = [&](InFlight *f, std::vector<std::shared_ptr<Task>> &&batch) {
@@ -248,7 +283,8 @@ class BatchedThreadedNnet3CudaPipeline2 {
       Hand(f->batch); *f = InFlight();
     };
     // Two decoder objects: a decoded batch's lattices are fetched (Fetch blocks until that batch's pruning / output kernels and the copy are through) on a helper thread, so that
-    // this loop goes on to QUEUE the next front end at once; it only waits for the fetch of the batch that used the same decoder object two batches ago, right before it launches on that
+    // this loop goes on to QUEUE the next front end at once; it only waits for the fetch of the batch that used the same decoder object two batches ago, right
+    // before it launches on that
     // object again.  (Fetched on this thread, every other batch's front end reached the stream 30 ms late: the pruning kernel cannot start beside the other object's resident launch and the
     // loop sat in Fetch while the CUs that launch freed stayed idle -- tools/pipeline_overlap.py on the program's kernel trace.)
     std::future<void> fetching[2];
@@ -259,7 +295,11 @@ class BatchedThreadedNnet3CudaPipeline2 {
     auto fetched = [&](int b) { if (fetching[b & 1].valid()) fetching[b & 1].get(); };
     for (;;) {
       if (cur.batch.empty()) {
-        if (!prev.batch.empty()) { fetched(prev.buf ^ 1); finish(&prev, prev_decoding); }      // idle: hand the last decoded batch over (after the one before it) before blocking for new work
+        // idle: hand the last decoded batch over (after the one before it) before blocking for new work
+        if (!prev.batch.empty()) {
+          fetched(prev.buf ^ 1);
+          finish(&prev, prev_decoding);
+        }
         auto b = TakeBatch(true); if (b.empty()) break; start(&cur, std::move(b));
       }
       // the next batch's front end first: nothing it needs waits for this batch's decoder launch (its log-likelihood buffer is guarded on the device, its staging is its own)
@@ -299,7 +339,8 @@ class BatchedThreadedNnet3CudaPipeline2 {
     const int U = (int)idx.size(); f->U = U; if (U == 0) return;
     const int64_t tot = foff.back();
     // The batch's samples are gathered into a page-locked staging buffer by a few threads and copied asynchronously on the front stream.  Staging, waveform and offset buffers are
-    // double-buffered by f->buf, so this front end is QUEUED while the previous one may not even have started (its kernels wait for CUs the decoder's lanes free): the only host wait
+    // double-buffered by f->buf, so this front end is QUEUED while the previous one may not even have started (its kernels wait for CUs the decoder's lanes
+    // free): the only host wait
     // is for the copy out of this staging buffer two batches ago.  (A pageable synchronous copy of a 512 x 10 s batch, 328 MB, behind a host wait for the previous front end put this
     // batch's kernels on the stream 30 - 60 ms after the decoder launch they hide behind: tools/pipeline_overlap.py on the program's trace.)
     const int B = f->buf & 1;
@@ -307,7 +348,12 @@ class BatchedThreadedNnet3CudaPipeline2 {
     {
       float *stage = h_w_[B].need((size_t)std::max<int64_t>(woff.back(), 1));
       const int nthr = (int)std::min<size_t>(4, (size_t)U); std::vector<std::thread> th;
-      auto gather = [&](int t) { for (int k = t; k < U; k += nthr) { const auto &s_ = batch[idx[k]]->samples; if (!s_.empty()) memcpy(stage + woff[k], s_.data(), s_.size() * sizeof(float)); } };
+      auto gather = [&](int t) {
+        for (int k = t; k < U; k += nthr) {
+          const auto &s_ = batch[idx[k]]->samples;
+          if (!s_.empty()) memcpy(stage + woff[k], s_.data(), s_.size() * sizeof(float));
+        }
+      };
       for (int t = 1; t < nthr; t++) th.emplace_back(gather, t);
       gather(0); for (auto &t : th) t.join();
       K3O_HIP(hipMemcpyAsync(d_w_[B].need((size_t)std::max<int64_t>(woff.back(), 1)), stage, (size_t)woff.back() * sizeof(float), hipMemcpyHostToDevice, s_front_));
@@ -320,20 +366,28 @@ class BatchedThreadedNnet3CudaPipeline2 {
       K3O_HIP(hipMemcpyAsync(d_fo_[B].need(foff.size()), ho + woff.size(), foff.size() * sizeof(int64_t), hipMemcpyHostToDevice, s_front_));
       K3O_HIP(hipEventRecord(ev_h2d_[B], s_front_)); h2d_recorded_[B] = true;
     }
-    K3H_CHECK_K3(k3_feat_compute_batch(plan_, d_w_[B].p, d_wo_[B].p, d_fo_[B].p, U, tot, d_f_.need((size_t)tot * fdim_), fdim_, s_front_));      // (d_f_ and the network's buffers: one set, ordered by the stream)
+    // (d_f_ and the network's buffers: one set, ordered by the stream)
+    K3H_CHECK_K3(k3_feat_compute_batch(plan_, d_w_[B].p, d_wo_[B].p, d_fo_[B].p, U, tot, d_f_.need((size_t)tot * fdim_), fdim_, s_front_));
     k3_nnet_batch *nb = nullptr;
     for (auto &c : plan_cache_) if (c.first == nframes) { nb = c.second; break; }
     if (!nb) {
-      K3H_CHECK_K3(k3_nnet_batch_create(nnet_, U, nframes.data(), config_.frame_subsampling_factor, log_priors_.empty() ? nullptr : log_priors_.data(), config_.acoustic_scale, &nb));
+      K3H_CHECK_K3(k3_nnet_batch_create(nnet_, U, nframes.data(), config_.frame_subsampling_factor, log_priors_.empty() ? nullptr : log_priors_.data(),
+          config_.acoustic_scale, &nb));
       plan_cache_.push_back({nframes, nb});
-      if (plan_cache_.size() > 4) { K3O_HIP(hipStreamSynchronize(s_front_)); k3_nnet_batch_destroy(plan_cache_.front().second); plan_cache_.erase(plan_cache_.begin()); }      // (a queued front end may still use the plan)
+      // (a queued front end may still use the plan)
+      if (plan_cache_.size() > 4) {
+        K3O_HIP(hipStreamSynchronize(s_front_));
+        k3_nnet_batch_destroy(plan_cache_.front().second);
+        plan_cache_.erase(plan_cache_.begin());
+      }
     }
     f->ro.assign(U + 1, 0); const int64_t rows = k3_nnet_batch_output_rows(nb, f->ro.data());
     // (two decoder objects: the batch before the last may still be decoding from this log-likelihood buffer.  Its last reader is that decoder's token-passing launch; the pruning and
     // output kernels behind it cannot run beside the other decoder's resident launch and would hold this front end back by tens of milliseconds)
     if (Dec(0) != Dec(1)) K3H_CHECK_K3(k3_decoder_stream_wait_token_passing(Dec(f->buf), s_front_));
     else K3O_HIP(hipStreamWaitEvent(s_front_, ev_dec_[f->buf], 0));
-    if ((size_t)rows * ninfo_.output_dim > d_ll_[f->buf].cap) K3O_HIP(hipEventSynchronize(ev_dec_[f->buf]));      // (growing the buffer frees it: only once that decoder is through)
+    // (growing the buffer frees it: only once that decoder is through)
+    if ((size_t)rows * ninfo_.output_dim > d_ll_[f->buf].cap) K3O_HIP(hipEventSynchronize(ev_dec_[f->buf]));
     K3H_CHECK_K3(k3_nnet_forward(nb, d_f_.p, fdim_, d_ll_[f->buf].need((size_t)rows * ninfo_.output_dim), ninfo_.output_dim, s_front_));
     K3O_HIP(hipEventRecord(ev_front_[f->buf], s_front_)); f->valid = true;
   }
@@ -349,9 +403,16 @@ class BatchedThreadedNnet3CudaPipeline2 {
       Task &t = *batch[idx[u]]; const int64_t ns = info[10 * u], na = info[10 * u + 1];
       if (info[10 * u + 2] != 0 || ns == 0) t.failed = true;
       else {
-        Lattice &lat = t.raw; lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns); lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
-        lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na); lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na); lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
-        lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
+        Lattice &lat = t.raw;
+        lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns);
+        lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns);
+        lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
+        lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na);
+        lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na);
+        lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
+        lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na);
+        lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na);
+        lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
         for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == graph_start_) lat.start = (int32_t)s;
       }
       s0 += ns; a0 += na;
@@ -359,9 +420,20 @@ class BatchedThreadedNnet3CudaPipeline2 {
   }
   std::shared_ptr<LatticePostprocessor> lattice_postprocessor_;
   const BatchedThreadedNnet3CudaPipeline2Config config_; k3_nnet *nnet_; const TransitionInfo &trans_;
-  k3_feat_plan *plan_ = nullptr; k3_fst *fst_ = nullptr; k3_decoder *dec_ = nullptr, *dec_b_ = nullptr; k3_nnet_info ninfo_; int fdim_ = 0, device_ = 0; int32_t graph_start_ = 0; std::vector<float> log_priors_;
+  k3_feat_plan *plan_ = nullptr;
+  k3_fst *fst_ = nullptr;
+  k3_decoder *dec_ = nullptr, *dec_b_ = nullptr;
+  k3_nnet_info ninfo_;
+  int fdim_ = 0, device_ = 0;
+  int32_t graph_start_ = 0;
+  std::vector<float> log_priors_;
   std::vector<std::pair<std::vector<int32_t>, k3_nnet_batch *>> plan_cache_;
-  DevBuf<float> d_w_[2], d_f_, d_ll_[2]; DevBuf<int64_t> d_wo_[2], d_fo_[2]; PinnedBuf<float> h_w_[2]; PinnedBuf<int64_t> h_off_[2]; hipEvent_t ev_h2d_[2] = {nullptr, nullptr}; bool h2d_recorded_[2] = {false, false};
+  DevBuf<float> d_w_[2], d_f_, d_ll_[2];
+  DevBuf<int64_t> d_wo_[2], d_fo_[2];
+  PinnedBuf<float> h_w_[2];
+  PinnedBuf<int64_t> h_off_[2];
+  hipEvent_t ev_h2d_[2] = {nullptr, nullptr};
+  bool h2d_recorded_[2] = {false, false};
   hipStream_t s_front_ = nullptr, s_dec_ = nullptr, s_dec_b_ = nullptr; hipEvent_t ev_front_[2] = {nullptr, nullptr}, ev_dec_[2] = {nullptr, nullptr};
   k3_decoder *Dec(int buf) const { return (buf & 1) && dec_b_ ? dec_b_ : dec_; }
   hipStream_t DecStream(int buf) const { return (buf & 1) && dec_b_ ? s_dec_b_ : s_dec_; }

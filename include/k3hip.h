@@ -69,7 +69,8 @@ int k3_feat_compute_batch_pcm16(k3_feat_plan *plan, const int16_t *d_waves, cons
  * (feat/feature-common-inl.h:29-57) does to a waveform whose rate differs from --sample-frequency under --allow-downsample / --allow-upsample.  Utterance u's samples are
  * d_in[h_in_offsets[u] .. h_in_offsets[u+1]) and come out as d_out[h_out_offsets[u] ..), k3_resample_num_samples(rate_in, rate_out, n) of them.  Synchronous. */
 int64_t k3_resample_num_samples(int32_t rate_in, int32_t rate_out, int64_t num_in);
-int k3_resample_batch(int32_t rate_in, int32_t rate_out, const float *d_in, const int64_t *h_in_offsets, int32_t num_utts, float *d_out, const int64_t *h_out_offsets, void *stream);
+int k3_resample_batch(int32_t rate_in, int32_t rate_out, const float *d_in, const int64_t *h_in_offsets, int32_t num_utts, float *d_out,
+    const int64_t *h_out_offsets, void *stream);
 /* Per-utterance CMVN in place: AccCmvnStats + ApplyCmvn (transform/cmvn.cc:30-115), what
  * `compute-cmvn-stats | apply-cmvn [--norm-vars]` do with one utterance per speaker.
  * fp64 accumulators like the reference.  d_stats (optional, may be NULL): [U x 2 x (dim+1)] doubles. */
@@ -166,16 +167,20 @@ int64_t k3_ivector_stream_num_rows(const k3_ivector_stream *s);
 int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_feats, int64_t ld_feats, int32_t num_frames, int32_t finished, float *d_new_rows, int64_t ld_rows,
                              int32_t max_new_rows, int32_t *h_num_new_rows, float *d_latest, void *stream);
 /* The same for the streams of one batch, one kernel launch per stage (what BatchedIvectorExtractorCuda::GetIvectors is per chunk, cudafeat/feature-online-batched-ivector-cuda.h:30-61):
- * stream i takes feature rows h_frame_offsets[i] .. h_frame_offsets[i + 1] of d_feats (offsets start at 0; a stream may get no rows), h_finished[i] != 0 ends it; d_latest (nullable)
+ * stream i takes feature rows h_frame_offsets[i] .. h_frame_offsets[i + 1] of d_feats (offsets start at 0; a stream may get no rows),
+     h_finished[i] != 0 ends it;
+ d_latest (nullable)
  * [num_streams x ld_latest] receives every stream's most recent estimate.  Results per stream are those of k3_ivector_stream_accept.  All streams belong to one extractor, each is
  * listed once; one batched call at a time per extractor. */
-int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32_t num_streams, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, const int32_t *h_finished,
+int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32_t num_streams, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets,
+    const int32_t *h_finished,
                                    float *d_latest, int64_t ld_latest, void *stream);
 int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
                                    float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in,
                                    double *d_stats_out, void *stream);
 /* The same with per-frame weights on the statistics (silence weighting: OnlineIvectorFeature::UpdateFrameWeights with the whole utterance's weights known at the start, what
- * ivector-extract-online2 --frame-weights-rspecifier does, online2bin/ivector-extract-online2.cc:130-153): d_frame_weights [total frames] (NULL: every frame weighs 1) -- a frame of
+ * ivector-extract-online2 --frame-weights-rspecifier does,
+     online2bin/ivector-extract-online2.cc:130-153): d_frame_weights [total frames] (NULL: every frame weighs 1) -- a frame of
  * weight 0 contributes nothing, otherwise its posteriors are pruned at GetMinPost(weight) = min(0.99, min_post / |weight|) and scaled by posterior_scale * weight
  * (online2/online-ivector-feature.cc:188-199, :226-236). */
 int k3_ivector_extract_batch_weighted(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, const float *d_frame_weights,
@@ -231,14 +236,16 @@ typedef struct k3_nnet_stream_info {
   int32_t num_channels, frames_per_chunk, subsampling, output_rows_per_pass, first_output_time, right_context, input_history;
   double flops_per_pass;
 } k3_nnet_stream_info;
-int k3_nnet_stream_create(k3_nnet *nnet, int32_t num_channels, int32_t frames_per_chunk, int32_t frame_subsampling_factor, const float *h_log_priors, float acoustic_scale, k3_nnet_stream **out);
+int k3_nnet_stream_create(k3_nnet *nnet, int32_t num_channels, int32_t frames_per_chunk, int32_t frame_subsampling_factor, const float *h_log_priors,
+    float acoustic_scale, k3_nnet_stream **out);
 void k3_nnet_stream_destroy(k3_nnet_stream *s);
 int k3_nnet_stream_get_info(const k3_nnet_stream *s, k3_nnet_stream_info *info);
 /* the listed channels start new streams; d_first_frames row i = the first feature frame of channel h_channels[i]'s stream */
 int k3_nnet_stream_reset(k3_nnet_stream *s, const int32_t *h_channels, int32_t n, const float *d_first_frames, int64_t ld, void *stream);
 /* one pass: channel c with h_row_count[c] >= 0 consumes rows h_row_start[c] .. + h_row_count[c] of d_new (frames_per_chunk of them; fewer or none only once its audio has
  * ended: the missing frames replicate the last one); h_row_count[c] < 0: the channel sits the pass out */
-int k3_nnet_stream_forward(k3_nnet_stream *s, const float *d_new, int64_t ld_new, const int64_t *h_row_start, const int32_t *h_row_count, float *d_out, int64_t ld_out, void *stream);
+int k3_nnet_stream_forward(k3_nnet_stream *s, const float *d_new, int64_t ld_new, const int64_t *h_row_start, const int32_t *h_row_count, float *d_out,
+    int64_t ld_out, void *stream);
 /* Models with the recipes' i-vector input ("input-node name=ivector", tdnn1 fed by Append(.., ReplaceIndex(ivector, t, 0)); k3_nnet_info.ivector_dim > 0).
  * online_ivector_period > 0: nnet3-compute / nnet3-latgen-faster --online-ivectors=.. --online-ivector-period=P --frames-per-chunk=C: the network is
  * evaluated chunk by chunk (chunks of C frames rounded up to a multiple of the subsampling factor), chunk c with the row GetCurrentIvector picks for it
@@ -356,7 +363,8 @@ int k3_decoder_init_decoding(k3_decoder *dec, int32_t num_utts, int32_t max_tota
 int k3_decoder_advance_decoding(k3_decoder *dec, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_offsets, void *stream);
 /* The reference's own form of the call, CudaDecoder::AdvanceDecoding(lanes_assignements) (cuda-decoder.h:262): each listed channel gets a DEVICE
  * pointer to the log-likelihoods of its next num_frames frames (rows ld floats apart), wherever they live; the other channels of the group idle. */
-int k3_decoder_advance_decoding_lanes(k3_decoder *dec, int32_t num_channels, const int32_t *channels, const float *const *h_lane_frames, int32_t num_frames, int64_t ld, void *stream);
+int k3_decoder_advance_decoding_lanes(k3_decoder *dec, int32_t num_channels, const int32_t *channels, const float *const *h_lane_frames, int32_t num_frames,
+    int64_t ld, void *stream);
 /* ... with a frame count per channel and the rows of a channel `ld` floats apart: log-likelihoods decoded where a producer left them, e.g. the time-major output of
  * k3_nnet_stream_forward (channel c's row k at k * num_channels + c: ld = num_channels * its row length).  h_lane_first[u] null or h_num_frames[u] = 0: channel u idles. */
 int k3_decoder_advance_decoding_strided(k3_decoder *dec, int32_t num_utts, const float *const *h_lane_first, const int32_t *h_num_frames, int64_t ld, void *stream);
@@ -420,19 +428,22 @@ int k3_decoder_frame_stats(k3_decoder *dec, int32_t utt, int32_t *h_ntoks, float
 int k3_mat_softmax_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_a, int64_t lda, const float *d_b, int64_t ldb, int32_t rows, int32_t cols, void *stream);
 /* cu::NormalizePerRow (op 0) / cu::DiffNormalizePerRow (op 1) (cudamatrix/cu-math.h:272-300, cu-math.cc:280-409; NormalizeComponent): op 0: dst [rows x cols (+1 with add_log_stddev)] from
  * in [rows x cols]; op 1: dst = in_deriv, ADDED to (kBackpropAdds) unless it aliases out_deriv (the in-place backprop), out_deriv [rows x cols (+1)] */
-int k3_mat_normalize_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_in, int64_t ldi, const float *d_out_deriv, int64_t ldo, int32_t rows, int32_t cols, float target_rms, int32_t add_log_stddev, void *stream);
+int k3_mat_normalize_rows(int32_t op, float *d_dst, int64_t ldd, const float *d_in, int64_t ldi, const float *d_out_deriv, int64_t ldo, int32_t rows,
+    int32_t cols, float target_rms, int32_t add_log_stddev, void *stream);
 /* CuMatrixBase::Sigmoid (op 0) / Tanh (1) / Log (2) / Pow (3: power a) / PowAbs (4: power a, flag = include_sign) / Max (5) (cudamatrix/cu-matrix.h:288-307,:386,:501): dst = f(src), in place allowed */
 int k3_mat_apply_map(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, float a, int32_t flag, void *stream);
 /* CuMatrixBase::DiffSigmoid (op 0) / DiffTanh (1) (cudamatrix/cu-matrix.h:390-396): dst = diff .* value .* (1 - value) | diff .* (1 - value^2) */
 int k3_mat_diff_activation(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_value, int64_t ldv, const float *d_diff, int64_t ldf, void *stream);
 int k3_mat_mul_rows(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *stream);   /* MulRows (cudamatrix/cu-matrix.h:148): row r *= src row indexes[r]; -1 = unchanged (dropout masks per sequence) */
 /* CuMatrixBase::SetMatMatDivMat (op 0: dst = A .* (B ./ C3), = A where C3 is 0: DropoutComponent::Backprop) / AddMatMatElements (op 1: dst = beta dst + alpha A .* B) (cudamatrix/cu-matrix.h:580,:608) */
-int k3_mat_elements3(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, float alpha, const float *d_A, int64_t lda, const float *d_B, int64_t ldb, const float *d_C3, int64_t ldc3, float beta, void *stream);
+int k3_mat_elements3(int32_t op, float *d_C, int64_t ldc, int32_t rows, int32_t cols, float alpha, const float *d_A, int64_t lda, const float *d_B,
+    int64_t ldb, const float *d_C3, int64_t ldc3, float beta, void *stream);
 int k3_mat_div_rows_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_div, void *stream);            /* DivRowsVec: row r divided by div[r] */
 int k3_mat_copy_cols_from_vec(float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_col, void *stream);      /* CopyColsFromVec with a vector of dimension rows: every column = v */
 int k3_mat_copy_cols(int32_t add, float *d_C, int64_t ldc, int32_t rows, int32_t cols, const float *d_src, int64_t lds, const int32_t *d_indexes, void *stream);   /* CopyCols (add 0) / AddCols (1): dst(r, c) (+)= src(r, indexes[c]), -1 = zero / skip */
 /* CuRand<BaseFloat>::RandUniform (kind 0: [0, 1)) / RandGaussian (kind 1) (cudamatrix/cu-rand.h:50-56): Philox-4x32-10 keyed by `seed`, element i of the logical rows x cols matrix from
- * counter offset + i / 4 -- reproducible for (seed, offset) independent of stride and launch shape; a fill consumes ceil(rows * cols / 4) counters.  (The reference's device stream is
+ * counter offset + i / 4 -- reproducible for (seed, offset) independent of stride and launch shape;
+ a fill consumes ceil(rows * cols / 4) counters.  (The reference's device stream is
  * cuRAND's and its CPU stream is rand(): neither is reproduced; parity for this entry point is distributional.) */
 int k3_mat_set_rand(int32_t kind, float *d_C, int64_t ldc, int32_t rows, int32_t cols, uint64_t seed, uint64_t offset, void *stream);
 int64_t k3_mat_gemm_flops(int32_t reset);      /* 2 M N K summed over this process's k3_mat_add_mat_mat calls (reset != 0: read and clear) -- the flop count of a training iteration for its roofline */
@@ -523,7 +534,8 @@ typedef struct k3_chain_supervision k3_chain_supervision;
 int k3_chain_supervision_create(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
                                 const int32_t *ilabel, const int32_t *nextstate, const float *arc_weight, const float *final_cost, k3_chain_supervision **sup);
 /* End-to-end (flat-start) supervisions: chain::Supervision::e2e_fsts, one FST per sequence that may have self-loops and several final states (epsilon-free, ilabel = pdf-id + 1,
- * start state 0; same array layout as above).  k3_chain_numerator / k3_chain_objf_and_deriv then run chain::GenericNumeratorComputation (chain/chain-generic-numerator.cc:30-463) and
+ * start state 0;
+ same array layout as above).  k3_chain_numerator / k3_chain_objf_and_deriv then run chain::GenericNumeratorComputation (chain/chain-generic-numerator.cc:30-463) and
  * the end-to-end branch of ComputeChainObjfAndDeriv (chain-training.cc:86-215) -- including the reference's quirk that the numerator log-probability enters the objective without the
  * supervision weight (:270) while its derivative carries it. */
 int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
@@ -531,7 +543,8 @@ int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t frames_per_se
 void k3_chain_supervision_destroy(k3_chain_supervision *sup);
 int k3_chain_numerator(k3_chain_supervision *sup, const float *d_nnet_output, int64_t ld, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_logprob_weighted, void *stream);
 int k3_chain_objf_and_deriv(k3_chain_den *den, k3_chain_supervision *sup, const k3_chain_training_opts *opts, const float *d_nnet_output, int64_t ld,
-                            float *d_nnet_output_deriv, int64_t ld_deriv, float *d_xent_output_deriv, int64_t ld_xent, float *h_objf, float *h_l2_term, float *h_weight, void *stream);
+                            float *d_nnet_output_deriv, int64_t ld_deriv, float *d_xent_output_deriv, int64_t ld_xent, float *h_objf, float *h_l2_term,
+                                float *h_weight, void *stream);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,8 @@ void k3h_clat_free(k3h_clat *c);
 int64_t k3h_lattice_table_to_ctm(const char *lattice_rspecifier, const char *postprocessor_config_rxfilename, float decoder_frame_shift_seconds, char *out, int64_t out_cap);
 /* the same with the acoustic model's file (final.mdl): needed when the config names --word-boundary-rxfilename (LatticePostprocessor::SetTransitionModel, lattice-postprocessor.h:93-95):
  * the lattice is word-aligned (lat/word-align-lattice.cc) in front of MBR, so that the CTM's times are word boundaries */
-int64_t k3h_lattice_table_to_ctm_model(const char *lattice_rspecifier, const char *postprocessor_config_rxfilename, float decoder_frame_shift_seconds, const char *model_rxfilename, char *out, int64_t out_cap);
+int64_t k3h_lattice_table_to_ctm_model(const char *lattice_rspecifier, const char *postprocessor_config_rxfilename, float decoder_frame_shift_seconds,
+    const char *model_rxfilename, char *out, int64_t out_cap);
 
 /* OnlineIvectorExtractionInfo(config) (online2/online-ivector-feature.cc:29-98): parse an --ivector-extraction-config file and read every file it
  * names (LDA matrix, global CMVN stats, cmvn / splice configs, diagonal UBM, i-vector extractor), with the reference's checks and messages.

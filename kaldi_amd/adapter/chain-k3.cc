@@ -14,7 +14,8 @@
 // back into its sequences here, because the numerator kernel walks every sequence with its own wavefront (k3_chain_supervision_create takes UNMERGED FSTs): SplitMergedSupervision.
 //
 // PARITY NOTE (binary egs): Supervision::Read's binary branch reads an OpenFst StdCompactAcceptorFst (fst::CompactFst with the acceptor compactor).  OpenFst 1.8.4 is not in
-// /root/reference (tools/Makefile downloads it), so that file layout is restated from OpenFst's published format (FstHeader; Unsigned states[nstates + 1]; {label, weight, nextstate}
+// /root/reference (tools/Makefile downloads it), so that file layout is restated from OpenFst's published format (FstHeader; Unsigned states[nstates + 1];
+// {label, weight, nextstate}
 // compacts[], a final weight being an element with label kNoLabel) and checked only against files written by tests/adapter/write_chain_egs.py from the same description: UNPINNED.
 // The text form (nnet3-chain-copy-egs ark,t:) uses the OpenFst text format Kaldi's own fstext/kaldi-fst-io-inl.h:76-166 parses; that parser is restated from the reference.
 #include <map>
@@ -27,14 +28,22 @@
 extern "C" void *k3_adapter_stream();      // kaldi_amd/adapter/cu-k3.cc: the calling thread's stream (every CuMatrix operation of this thread is queued on it)
 #include "k3_host.h"
 
-namespace kaldi { CuAllocatorOptions g_allocator_options; }      // cudamatrix/cu-allocator.cc:49 (RegisterCuAllocatorOptions registers its fields; the allocator itself is the adapter's)
+// cudamatrix/cu-allocator.cc:49 (RegisterCuAllocatorOptions registers its fields; the allocator itself is the adapter's)
+namespace kaldi {
+  CuAllocatorOptions g_allocator_options;
+}
 
 namespace {
 struct Csr { std::vector<int64_t> off; std::vector<int32_t> il, nx; std::vector<float> w, fin; };
 void ToCsr(const fst::StdVectorFst &f, Csr *c) {
   const int32_t S = f.NumStates(); c->off.assign(1, 0); c->il.clear(); c->nx.clear(); c->w.clear(); c->fin.resize(S);
   for (int32_t s = 0; s < S; s++) {
-    for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) { const fst::StdArc &a = it.Value(); c->il.push_back(a.ilabel); c->nx.push_back(a.nextstate); c->w.push_back(a.weight.Value()); }
+    for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) {
+      const fst::StdArc &a = it.Value();
+      c->il.push_back(a.ilabel);
+      c->nx.push_back(a.nextstate);
+      c->w.push_back(a.weight.Value());
+    }
     c->off.push_back((int64_t)c->il.size()); c->fin[s] = f.Final(s).Value();
   }
 }
@@ -73,10 +82,14 @@ int32 DenominatorGraph::NumStates() const { return initial_probs_.Dim(); }
 const CuVector<BaseFloat> &DenominatorGraph::InitialProbs() const { return initial_probs_; }
 
 // ---- Supervision (chain-supervision.cc:708-713, :596-609 Swap, :611-661 Read)
-Supervision::Supervision(const Supervision &other): weight(other.weight), num_sequences(other.num_sequences), frames_per_sequence(other.frames_per_sequence), label_dim(other.label_dim), fst(other.fst),
+Supervision::Supervision(const Supervision &other): weight(other.weight), num_sequences(other.num_sequences), frames_per_sequence(other.frames_per_sequence),
+    label_dim(other.label_dim), fst(other.fst),
                                                     e2e_fsts(other.e2e_fsts), alignment_pdfs(other.alignment_pdfs) { }
 void Supervision::Swap(Supervision *other) {
-  std::swap(weight, other->weight); std::swap(num_sequences, other->num_sequences); std::swap(frames_per_sequence, other->frames_per_sequence); std::swap(label_dim, other->label_dim);
+  std::swap(weight, other->weight);
+  std::swap(num_sequences, other->num_sequences);
+  std::swap(frames_per_sequence, other->frames_per_sequence);
+  std::swap(label_dim, other->label_dim);
   std::swap(fst, other->fst); std::swap(e2e_fsts, other->e2e_fsts); std::swap(alignment_pdfs, other->alignment_pdfs);
 }
 namespace {
@@ -106,13 +119,23 @@ void ReadFstText(std::istream &is, fst::StdVectorFst *ofst) {
     if (!ok) KALDI_ERR << "Bad line in FST: " << line;
   }
 }
-// OpenFst binary StdCompactAcceptorFst (see the parity note at the top): FstHeader {int32 magic 2125659606; string fsttype "compact_acceptor"; string arctype "standard"; int32 version;
-// int32 flags; uint64 properties; int64 start, numstates, numarcs}, [symbol tables when flagged], then the compact store: uint32 states[numstates + 1] (element offsets; read when the
-// compactor has variable out-degree, as the acceptor compactor has), element {int32 label, float weight, int32 nextstate} x states[numstates]; an element with label -1 is the state's
+// OpenFst binary StdCompactAcceptorFst (see the parity note at the top): FstHeader {int32 magic 2125659606; string fsttype "compact_acceptor"; string arctype
+// "standard"; int32 version;
+// int32 flags; uint64 properties; int64 start, numstates, numarcs}, [symbol tables when flagged], then the compact store: uint32 states[numstates + 1] (element
+// offsets; read when the
+// compactor has variable out-degree, as the acceptor compactor has), element {int32 label, float weight, int32 nextstate} x states[numstates]; an element with
+// label -1 is the state's
 // final weight.  In an aligned file (flag bit 2) both arrays start at a multiple of 16 bytes of the stream.
 void ReadCompactAcceptor(std::istream &is, fst::StdVectorFst *ofst) {
   auto rd = [&](void *p, size_t n) { is.read(reinterpret_cast<char *>(p), n); if (!is) KALDI_ERR << "Error reading compact FST from disk"; };
-  auto rstr = [&]() { int32 n = 0; rd(&n, 4); if (n < 0 || n > 1024) KALDI_ERR << "Error reading compact FST from disk (header)"; std::string s(n, '\0'); if (n) rd(&s[0], n); return s; };
+  auto rstr = [&]() {
+    int32 n = 0;
+    rd(&n, 4);
+    if (n < 0 || n > 1024) KALDI_ERR << "Error reading compact FST from disk (header)";
+    std::string s(n, '\0');
+    if (n) rd(&s[0], n);
+    return s;
+  };
   const std::streampos p0 = is.tellg();
   int32 magic = 0; rd(&magic, 4); if (magic != 2125659606) KALDI_ERR << "Error reading compact FST from disk (bad magic number " << magic << ")";
   const std::string fsttype = rstr(), arctype = rstr();
@@ -156,10 +179,17 @@ void Supervision::Read(std::istream &is, bool binary) {
 // chain-supervision.cc:549-609 (Write) and operator==
 namespace {
 void WriteSupFst(std::ostream &os, bool binary, const fst::StdVectorFst &f) {
-  if (!binary) {      // WriteFstKaldi(os, false, fst): a newline, "src dst ilabel olabel [weight]" lines in state order with the start state first, finals, an empty line (fstext/kaldi-fst-io-inl.h:34-72)
+  // WriteFstKaldi(os, false, fst): a newline, "src dst ilabel olabel [weight]" lines in state order with the start state first, finals, an empty line
+  // (fstext/kaldi-fst-io-inl.h:34-72)
+  if (!binary) {
     os << '\n';
     auto state = [&](int32 s) {
-      for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) { const fst::StdArc &a = it.Value(); os << s << '\t' << a.nextstate << '\t' << a.ilabel << '\t' << a.olabel; if (a.weight != fst::TropicalWeight::One()) os << '\t' << a.weight.Value(); os << '\n'; }
+      for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) {
+        const fst::StdArc &a = it.Value();
+        os << s << '\t' << a.nextstate << '\t' << a.ilabel << '\t' << a.olabel;
+        if (a.weight != fst::TropicalWeight::One()) os << '\t' << a.weight.Value();
+        os << '\n';
+      }
       if (f.Final(s) != fst::TropicalWeight::Zero()) { os << s; if (f.Final(s) != fst::TropicalWeight::One()) os << '\t' << f.Final(s).Value(); os << '\n'; }
     };
     if (f.Start() != fst::kNoStateId) { state(f.Start()); for (int32 s = 0; s < f.NumStates(); s++) if (s != f.Start()) state(s); }
@@ -185,23 +215,34 @@ bool SameFst(const fst::StdVectorFst &a, const fst::StdVectorFst &b) {
   for (int32 s = 0; s < a.NumStates(); s++) {
     if (a.Final(s) != b.Final(s) || a.NumArcs(s) != b.NumArcs(s)) return false;
     fst::ArcIterator<fst::StdVectorFst> i(a, s), j(b, s);
-    for (; !i.Done(); i.Next(), j.Next()) if (i.Value().ilabel != j.Value().ilabel || i.Value().olabel != j.Value().olabel || i.Value().nextstate != j.Value().nextstate || i.Value().weight != j.Value().weight) return false;
+    for (; !i.Done(); i.Next(), j.Next()) if (i.Value().ilabel != j.Value().ilabel || i.Value().olabel != j.Value().olabel ||
+        i.Value().nextstate != j.Value().nextstate || i.Value().weight != j.Value().weight) return false;
   }
   return true;
 }
 }  // namespace
 void Supervision::Write(std::ostream &os, bool binary) const {
-  WriteToken(os, binary, "<Supervision>"); WriteToken(os, binary, "<Weight>"); WriteBasicType(os, binary, weight); WriteToken(os, binary, "<NumSequences>"); WriteBasicType(os, binary, num_sequences);
+  WriteToken(os, binary, "<Supervision>");
+  WriteToken(os, binary, "<Weight>");
+  WriteBasicType(os, binary, weight);
+  WriteToken(os, binary, "<NumSequences>");
+  WriteBasicType(os, binary, num_sequences);
   WriteToken(os, binary, "<FramesPerSeq>"); WriteBasicType(os, binary, frames_per_sequence); WriteToken(os, binary, "<LabelDim>"); WriteBasicType(os, binary, label_dim);
   KALDI_ASSERT(frames_per_sequence > 0 && label_dim > 0 && num_sequences > 0);
   const bool e2e = !e2e_fsts.empty(); WriteToken(os, binary, "<End2End>"); WriteBasicType(os, binary, e2e);
   if (!e2e) WriteSupFst(os, binary, fst);
-  else { KALDI_ASSERT((int32)e2e_fsts.size() == num_sequences); WriteToken(os, binary, "<Fsts>"); for (int32 i = 0; i < num_sequences; i++) WriteSupFst(os, binary, e2e_fsts[i]); WriteToken(os, binary, "</Fsts>"); }
+  else {
+    KALDI_ASSERT((int32)e2e_fsts.size() == num_sequences);
+    WriteToken(os, binary, "<Fsts>");
+    for (int32 i = 0; i < num_sequences; i++) WriteSupFst(os, binary, e2e_fsts[i]);
+    WriteToken(os, binary, "</Fsts>");
+  }
   if (!alignment_pdfs.empty()) { WriteToken(os, binary, "<AlignmentPdfs>"); WriteIntegerVector(os, binary, alignment_pdfs); }
   WriteToken(os, binary, "</Supervision>");
 }
 bool Supervision::operator == (const Supervision &other) const {
-  if (!(weight == other.weight && num_sequences == other.num_sequences && frames_per_sequence == other.frames_per_sequence && label_dim == other.label_dim && SameFst(fst, other.fst))) return false;
+  if (!(weight == other.weight && num_sequences == other.num_sequences && frames_per_sequence == other.frames_per_sequence && label_dim == other.label_dim &&
+      SameFst(fst, other.fst))) return false;
   if (e2e_fsts.size() != other.e2e_fsts.size() || alignment_pdfs != other.alignment_pdfs) return false;
   for (size_t i = 0; i < e2e_fsts.size(); i++) if (!SameFst(e2e_fsts[i], other.e2e_fsts[i])) return false;
   return true;
@@ -215,7 +256,11 @@ int32 StateTimes(const fst::StdVectorFst &f, std::vector<int32> *t) {
   const int32 n = f.NumStates(); int32 total = -1; t->assign(n, -1); (*t)[0] = 0;
   for (int32 s = 0; s < n; s++) {
     const int32 nt = (*t)[s] + 1; if (nt <= 0) KALDI_ERR << "Input FST does not have required properties.";
-    for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) { int32 &r = (*t)[it.Value().nextstate]; if (r == -1) r = nt; else if (r != nt) KALDI_ERR << "Input FST does not have required properties."; }
+    for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) {
+      int32 &r = (*t)[it.Value().nextstate];
+      if (r == -1) r = nt;
+      else if (r != nt) KALDI_ERR << "Input FST does not have required properties.";
+    }
     if (f.Final(s) != fst::TropicalWeight::Zero()) { if (total == -1) total = nt - 1; else if (total != nt - 1) KALDI_ERR << "Input FST does not have required properties."; }
   }
   if (total < 0) KALDI_ERR << "Input FST does not have required properties.";
@@ -240,12 +285,20 @@ void SplitMergedSupervision(const Supervision &sup, std::vector<int32_t> *state_
     // local numbering: 0 = the start; merged states of times (qT, (q + 1) T] follow in their order
     const int32 b0 = first_at[q * T], lo = first_at[q * T + 1], hi = q + 1 < B ? first_at[(q + 1) * T + 1] : n, fin_lo = first_at[(q + 1) * T];
     auto local = [&](int32 s) { return s - lo + 1; };
-    auto emit_arcs = [&](int32 s) { for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) { const fst::StdArc &a = it.Value(); if (a.nextstate < lo || a.nextstate >= hi) KALDI_ERR << "Supervision FST: an arc leaves its sequence";
+    auto emit_arcs = [&](int32 s) {
+      for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) {
+        const fst::StdArc &a = it.Value();
+        if (a.nextstate < lo || a.nextstate >= hi) KALDI_ERR << "Supervision FST: an arc leaves its sequence";
                                     c->il.push_back(a.ilabel); c->nx.push_back(local(a.nextstate)); c->w.push_back(a.weight.Value()); } c->off.push_back((int64_t)c->il.size()); };
     emit_arcs(b0); c->fin.push_back(inf);
     // the next sequence's reference state and one of its arcs, to read the final costs off
     const int32 nb0 = fin_lo; fst::StdArc ref_arc; bool have_ref = false;
-    if (q + 1 < B) { fst::ArcIterator<fst::StdVectorFst> it(f, nb0); if (it.Done()) KALDI_ERR << "Supervision FST: a sequence boundary without arcs"; ref_arc = it.Value(); have_ref = true; }
+    if (q + 1 < B) {
+      fst::ArcIterator<fst::StdVectorFst> it(f, nb0);
+      if (it.Done()) KALDI_ERR << "Supervision FST: a sequence boundary without arcs";
+      ref_arc = it.Value();
+      have_ref = true;
+    }
     for (int32 s = lo; s < hi; s++) {
       if (s < fin_lo) { emit_arcs(s); c->fin.push_back(inf); continue; }
       c->off.push_back((int64_t)c->il.size());      // a final state of this sequence: its arcs belong to the next one
@@ -253,8 +306,16 @@ void SplitMergedSupervision(const Supervision &sup, std::vector<int32_t> *state_
       float cost = inf;
       // the corresponding arc: by POSITION first (the boundary states carry copies of the same arc list, so arc 0 of b is arc 0 of b0 -- unambiguous also when two parallel arcs
       // share label and destination), by (label, destination) only if the lists are ordered differently
-      { fst::ArcIterator<fst::StdVectorFst> it(f, s); if (!it.Done() && it.Value().ilabel == ref_arc.ilabel && it.Value().nextstate == ref_arc.nextstate) cost = it.Value().weight.Value() - ref_arc.weight.Value(); }
-      if (cost == inf) for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) if (it.Value().ilabel == ref_arc.ilabel && it.Value().nextstate == ref_arc.nextstate) { cost = it.Value().weight.Value() - ref_arc.weight.Value(); break; }
+      {
+        fst::ArcIterator<fst::StdVectorFst> it(f, s);
+        if (!it.Done() && it.Value().ilabel == ref_arc.ilabel && it.Value().nextstate == ref_arc.nextstate) cost =
+            it.Value().weight.Value() - ref_arc.weight.Value();
+      }
+      if (cost == inf) for (fst::ArcIterator<fst::StdVectorFst> it(f, s); !it.Done(); it.Next()) if (it.Value().ilabel == ref_arc.ilabel &&
+          it.Value().nextstate == ref_arc.nextstate) {
+        cost = it.Value().weight.Value() - ref_arc.weight.Value();
+        break;
+      }
       if (cost == inf) KALDI_ERR << "Supervision FST: the states of a sequence boundary do not share their arcs (not the output of MergeSupervision?)";
       c->fin.push_back(cost);
     }
@@ -270,8 +331,10 @@ void ComputeChainObjfAndDeriv(const ChainTrainingOptions &opts, const Denominato
   { std::lock_guard<std::mutex> g(g_mu); auto it = g_den.find(&den_graph); if (it != g_den.end()) den = it->second; }
   if (!den) KALDI_ERR << "ComputeChainObjfAndDeriv: a DenominatorGraph that was not made by its (FST, num-pdfs) constructor";
   const int32 B = supervision.num_sequences, T = supervision.frames_per_sequence, P = supervision.label_dim;
-  if (nnet_output.NumRows() != B * T || nnet_output.NumCols() != P) KALDI_ERR << "Network output is " << nnet_output.NumRows() << " x " << nnet_output.NumCols() << ", the supervision wants " << B * T << " x " << P;
-  if (nnet_output_deriv && (nnet_output_deriv->NumRows() != nnet_output.NumRows() || nnet_output_deriv->NumCols() != nnet_output.NumCols())) KALDI_ERR << "Derivative matrix of the wrong size";
+  if (nnet_output.NumRows() != B * T || nnet_output.NumCols() != P) KALDI_ERR << "Network output is " << nnet_output.NumRows() << " x " <<
+      nnet_output.NumCols() << ", the supervision wants " << B * T << " x " << P;
+  if (nnet_output_deriv && (nnet_output_deriv->NumRows() != nnet_output.NumRows() || nnet_output_deriv->NumCols() != nnet_output.NumCols())) KALDI_ERR <<
+      "Derivative matrix of the wrong size";
   k3_chain_supervision *ks = NULL; std::vector<int32_t> so; Csr c;
   const bool e2e = !supervision.e2e_fsts.empty();
   if (!e2e) SplitMergedSupervision(supervision, &so, &c);
@@ -282,22 +345,29 @@ void ComputeChainObjfAndDeriv(const ChainTrainingOptions &opts, const Denominato
       if (f.Start() != 0) KALDI_ERR << "Expecting input FST start state to be zero";
       Csr one; ToCsr(f, &one); const int64_t a0 = c.off.back();
       for (size_t s = 1; s < one.off.size(); s++) c.off.push_back(a0 + one.off[s]);
-      c.il.insert(c.il.end(), one.il.begin(), one.il.end()); c.nx.insert(c.nx.end(), one.nx.begin(), one.nx.end()); c.w.insert(c.w.end(), one.w.begin(), one.w.end()); c.fin.insert(c.fin.end(), one.fin.begin(), one.fin.end());
+      c.il.insert(c.il.end(), one.il.begin(), one.il.end());
+      c.nx.insert(c.nx.end(), one.nx.begin(), one.nx.end());
+      c.w.insert(c.w.end(), one.w.begin(), one.w.end());
+      c.fin.insert(c.fin.end(), one.fin.begin(), one.fin.end());
       so.push_back((int32_t)c.fin.size());
     }
   }
-  if ((e2e ? k3_chain_supervision_create_e2e : k3_chain_supervision_create)(B, T, P, supervision.weight, so.data(), c.off.data(), c.il.data(), c.nx.data(), c.w.data(), c.fin.data(), &ks) != K3_OK) KALDI_ERR << k3_last_error();
+  if ((e2e ? k3_chain_supervision_create_e2e : k3_chain_supervision_create)(B, T, P, supervision.weight, so.data(), c.off.data(), c.il.data(), c.nx.data(),
+      c.w.data(), c.fin.data(), &ks) != K3_OK) KALDI_ERR << k3_last_error();
   if (xent_output_deriv) xent_output_deriv->Resize(nnet_output.NumRows(), nnet_output.NumCols(), kUndefined);      // (zeroed by the kernel side)
   // the reference applies the out-of-range penalty on every other minibatch, by a coin flip on the host's rand() (chain-training.cc:273-277)
-  // -- RandInt(0, 1) is drawn if and only if a derivative is asked for (:107, :249), whatever the penalty's scale: the host's rand() stream then stays in step with the reference's.
+  // -- RandInt(0, 1) is drawn if and only if a derivative is asked for (:107, :249), whatever the penalty's scale: the host's rand() stream then stays in step
+  // with the reference's.
   // The end-to-end branch scales the denominator derivative by 1 + opts.lwf_den_scale (:124-128); k3_chain_objf_and_deriv has no such factor: refuse instead of ignoring it.
   // (GenericNumeratorComputation::ForwardBackward's own `ok` only ever turns false under --verbose >= 1 (CheckValues, chain-generic-numerator.cc:281); at the default level the
   // reference's numerator_ok is the finiteness test the kernel side applies.)
   if (e2e && opts.lwf_den_scale != 0.0) KALDI_ERR << "--lwf-den-scale=" << opts.lwf_den_scale << " (end-to-end supervision) is not supported by the MI355X objective";
   k3_chain_training_opts o = {opts.l2_regularize, opts.out_of_range_regularize, opts.leaky_hmm_coefficient, (nnet_output_deriv != NULL && RandInt(0, 1) == 0) ? 1 : 0};
   float fo = 0, fl = 0, fw = 0;
-  const int rc = k3_chain_objf_and_deriv(den, ks, &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv ? nnet_output_deriv->Data() : NULL, nnet_output_deriv ? nnet_output_deriv->Stride() : 0,
-                                         xent_output_deriv ? xent_output_deriv->Data() : NULL, xent_output_deriv ? xent_output_deriv->Stride() : 0, &fo, &fl, &fw, k3_adapter_stream());
+  const int rc = k3_chain_objf_and_deriv(den, ks, &o, nnet_output.Data(), nnet_output.Stride(), nnet_output_deriv ? nnet_output_deriv->Data() : NULL,
+      nnet_output_deriv ? nnet_output_deriv->Stride() : 0,
+                                         xent_output_deriv ? xent_output_deriv->Data() : NULL, xent_output_deriv ? xent_output_deriv->Stride() : 0, &fo, &fl,
+                                             &fw, k3_adapter_stream());
   k3_chain_supervision_destroy(ks);
   if (rc != K3_OK) KALDI_ERR << k3_last_error();
   *objf = fo; *l2_term = fl; *weight = fw;

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kBlock) void k3_chain_den_kernel(DenParams p) {
   __shared__ double red[kWaves];
   const int S = p.S, P = p.P, E = p.E, s = blockIdx.x, tid = threadIdx.x;
   double *acc = reinterpret_cast<double *>(smem);                 // [S] per-state sums of the frame being built (double, like the reference's accumulators)
-  double *drow = acc + S;                                         // [P] backward: the frame's derivative row (double: ds_add_f64 runs at several times the rate of ds_add_f32 here, and the sums lose nothing)
+  // [P] backward: the frame's derivative row (double: ds_add_f64 runs at several times the rate of ds_add_f32 here, and the sums lose nothing)
+  double *drow = acc + S;
   float *a_prev = reinterpret_cast<float *>(drow + P);            // [S + 1] alpha-dash of the previous frame (backward: beta of the next frame)
   float *probs = a_prev + (S + 1);                                // [P] exp of the frame's output row
   float *occ = probs + P;                                         // [S + 1] backward: alpha-dash of this frame / its alpha-sum
@@ -136,7 +137,12 @@ __global__ __launch_bounds__(kBlock) void k3_chain_den_kernel(DenParams p) {
     }
     __syncthreads();
     double ab = 0.0;
-    for (int h = tid; h < S; h += kBlock) { const float bd = (float)(acc[h] / (double)inv_scale); if (t == 0) ab += (double)(occ[h] * inv_scale * bd); bdash[h] = bd; }      // (occ is dead: each thread overwrites only the cells it read)
+    // (occ is dead: each thread overwrites only the cells it read)
+    for (int h = tid; h < S; h += kBlock) {
+      const float bd = (float)(acc[h] / (double)inv_scale);
+      if (t == 0) ab += (double)(occ[h] * inv_scale * bd);
+      bdash[h] = bd;
+    }
     if (t == 0) {      // BetaGeneralFrameDebug (:404-440): both sums are 1 per sequence when the computation is healthy
       double ds = 0.0;
       for (int k = tid; k < P; k += kBlock) ds += drow[k];
@@ -152,7 +158,10 @@ __global__ __launch_bounds__(kBlock) void k3_chain_den_kernel(DenParams p) {
 
 struct k3_chain_den {
   int S = 0, P = 0; int E = 0;
-  float *ep = nullptr; int *ei = nullptr; float *init = nullptr;      // ep: [2][E] probabilities, ei: [2][3][E] pdf / src / dst, first half ordered by source, second by destination
+  // ep: [2][E] probabilities, ei: [2][3][E] pdf / src / dst, first half ordered by source, second by destination
+  float *ep = nullptr;
+  int *ei = nullptr;
+  float *init = nullptr;
   std::vector<float> h_init;
   float *alpha = nullptr; size_t alpha_cap = 0; double *logprob = nullptr; float *check = nullptr; int b_cap = 0;
 };
@@ -165,7 +174,8 @@ extern "C" void k3_chain_den_destroy(k3_chain_den *d) {
 
 extern "C" int k3_chain_den_create(int32_t num_states, int32_t start, int32_t num_pdfs, const int64_t *arc_offsets, const int32_t *ilabel, const int32_t *nextstate,
                                    const float *weight, const float *final_cost, k3_chain_den **out) {
-  K3_REQUIRE(out && arc_offsets && ilabel && nextstate && weight && final_cost && num_states > 0 && num_pdfs > 0 && start >= 0 && start < num_states, "k3_chain_den_create: bad argument");
+  K3_REQUIRE(out && arc_offsets && ilabel && nextstate && weight && final_cost && num_states > 0 && num_pdfs > 0 && start >= 0 && start < num_states,
+      "k3_chain_den_create: bad argument");
   const int S = num_states; const long long A = arc_offsets[S];
   K3_REQUIRE(A >= 0 && A < (1ll << 30), "k3_chain_den_create: bad arc count");
   // SetTransitions (chain-den-graph.cc:52-95): a transition = (probability exp(-weight), pdf-id = label - 1, the state at its other end); the reference keeps
@@ -175,7 +185,8 @@ extern "C" int k3_chain_den_create(int32_t num_states, int32_t start, int32_t nu
   int *pdf0 = ei.data(), *src0 = pdf0 + A, *dst0 = src0 + A, *pdf1 = dst0 + A, *src1 = pdf1 + A, *dst1 = src1 + A;
   for (int st = 0; st < S; st++)
     for (long long a = arc_offsets[st]; a < arc_offsets[st + 1]; a++) {
-      K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= num_pdfs && nextstate[a] >= 0 && nextstate[a] < S, "k3_chain_den_create: arc label must be pdf-id + 1 in [1, num_pdfs], next state in range");
+      K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= num_pdfs && nextstate[a] >= 0 && nextstate[a] < S,
+          "k3_chain_den_create: arc label must be pdf-id + 1 in [1, num_pdfs], next state in range");
       const float pr = expf(-weight[a]);
       ep[a] = pr; pdf0[a] = ilabel[a] - 1; src0[a] = st; dst0[a] = nextstate[a];
       ins[nextstate[a]].push_back(Tr{pr, ilabel[a] - 1, st});
@@ -192,7 +203,10 @@ extern "C" int k3_chain_den_create(int32_t num_states, int32_t start, int32_t nu
   cur[start] = 1.0;
   for (int it = 0; it < 100; it++) {
     for (int st = 0; st < S; st++) avg[st] += (1.0 / 100) * cur[st];
-    for (int st = 0; st < S; st++) { const double pr = cur[st] * norm[st]; for (long long a = arc_offsets[st]; a < arc_offsets[st + 1]; a++) nxt[nextstate[a]] += pr * std::exp(-(double)weight[a]); }
+    for (int st = 0; st < S; st++) {
+      const double pr = cur[st] * norm[st];
+      for (long long a = arc_offsets[st]; a < arc_offsets[st + 1]; a++) nxt[nextstate[a]] += pr * std::exp(-(double)weight[a]);
+    }
     cur.swap(nxt); std::fill(nxt.begin(), nxt.end(), 0.0);
     double sum = 0.0; for (double v : cur) sum += v;
     for (double &v : cur) v *= 1.0 / sum;
@@ -200,7 +214,9 @@ extern "C" int k3_chain_den_create(int32_t num_states, int32_t start, int32_t nu
   auto d = new k3_chain_den; d->S = S; d->P = num_pdfs; d->E = (int)A;
   d->h_init.resize(S); for (int st = 0; st < S; st++) d->h_init[st] = (float)avg[st];
 #define K3_TRYC(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { k3_chain_den_destroy(d); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
-  K3_TRYC(hipMalloc(&d->ep, sizeof(float) * std::max<size_t>(1, ep.size()))); K3_TRYC(hipMalloc(&d->ei, sizeof(int) * std::max<size_t>(1, ei.size()))); K3_TRYC(hipMalloc(&d->init, sizeof(float) * S));
+  K3_TRYC(hipMalloc(&d->ep, sizeof(float) * std::max<size_t>(1, ep.size())));
+  K3_TRYC(hipMalloc(&d->ei, sizeof(int) * std::max<size_t>(1, ei.size())));
+  K3_TRYC(hipMalloc(&d->init, sizeof(float) * S));
   K3_TRYC(hipMemcpy(d->ep, ep.data(), sizeof(float) * ep.size(), hipMemcpyHostToDevice)); K3_TRYC(hipMemcpy(d->ei, ei.data(), sizeof(int) * ei.size(), hipMemcpyHostToDevice));
   K3_TRYC(hipMemcpy(d->init, d->h_init.data(), sizeof(float) * S, hipMemcpyHostToDevice));
 #undef K3_TRYC
@@ -215,16 +231,26 @@ extern "C" int k3_chain_den_initial_probs(const k3_chain_den *d, float *h_probs)
   return K3_OK;
 }
 
-extern "C" int k3_chain_den_forward_backward(k3_chain_den *d, const float *d_nnet_output, int64_t ld, int32_t num_sequences, int32_t frames_per_sequence, float leaky_hmm_coefficient,
+extern "C" int k3_chain_den_forward_backward(k3_chain_den *d, const float *d_nnet_output, int64_t ld, int32_t num_sequences, int32_t frames_per_sequence,
+    float leaky_hmm_coefficient,
                                              float deriv_weight, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_objf, int32_t *h_ok, void *stream) {
   K3_REQUIRE(d && d_nnet_output && h_objf && num_sequences > 0 && frames_per_sequence > 0 && ld >= d->P, "k3_chain_den_forward_backward: bad argument");
   K3_REQUIRE(leaky_hmm_coefficient > 0.0f && leaky_hmm_coefficient < 1.0f, "k3_chain_den_forward_backward: leaky-hmm-coefficient must be in (0, 1) (chain-denominator.cc:58)");
   K3_REQUIRE(!d_nnet_output_deriv || ld_deriv >= d->P, "k3_chain_den_forward_backward: bad derivative stride");
   const size_t lds = sizeof(double) * ((size_t)d->S + (size_t)d->P) + sizeof(float) * (2 * (size_t)(d->S + 1) + (size_t)d->P);
-  if (lds > 150 * 1024) { k3::set_error("k3_chain_den_forward_backward: %d states x %d pdfs need %zu B of LDS per sequence (limit 150 KB)", d->S, d->P, lds); return K3_ERR_UNSUPPORTED; }
+  if (lds > 150 * 1024) {
+    k3::set_error("k3_chain_den_forward_backward: %d states x %d pdfs need %zu B of LDS per sequence (limit 150 KB)", d->S, d->P, lds);
+    return K3_ERR_UNSUPPORTED;
+  }
   hipStream_t st = (hipStream_t)stream;
   const size_t need = (size_t)num_sequences * (frames_per_sequence + 1) * (d->S + 1);
-  if (need > d->alpha_cap) { if (d->alpha) (void)hipFree(d->alpha); d->alpha = nullptr; d->alpha_cap = 0; K3_HIP_CHECK(hipMalloc(&d->alpha, need * sizeof(float))); d->alpha_cap = need; }
+  if (need > d->alpha_cap) {
+    if (d->alpha) (void)hipFree(d->alpha);
+    d->alpha = nullptr;
+    d->alpha_cap = 0;
+    K3_HIP_CHECK(hipMalloc(&d->alpha, need * sizeof(float)));
+    d->alpha_cap = need;
+  }
   if (num_sequences > d->b_cap) {
     if (d->logprob) (void)hipFree(d->logprob); if (d->check) (void)hipFree(d->check); d->logprob = nullptr; d->check = nullptr; d->b_cap = 0;
     K3_HIP_CHECK(hipMalloc(&d->logprob, sizeof(double) * num_sequences)); K3_HIP_CHECK(hipMalloc(&d->check, sizeof(float) * 2 * num_sequences)); d->b_cap = num_sequences;
@@ -290,7 +316,10 @@ __global__ __launch_bounds__(64) void k3_chain_num_kernel(NumParams p) {
     double m = kNegInf;
     for (long long a = a0 + lane; a < a1; a += 64) { const double x = alpha[p.arc_src[a]] + loglike(t, p.arc_pdf[a]) - (double)p.arc_w[a]; m = x > m ? x : m; }
     m = wave_max(m);
-    if (m != kNegInf) for (long long a = a0 + lane; a < a1; a += 64) { const double x = alpha[p.arc_src[a]] + loglike(t, p.arc_pdf[a]) - (double)p.arc_w[a]; atomicAdd(&acc[p.arc_dst[a]], exp(x - m)); }
+    if (m != kNegInf) for (long long a = a0 + lane; a < a1; a += 64) {
+      const double x = alpha[p.arc_src[a]] + loglike(t, p.arc_pdf[a]) - (double)p.arc_w[a];
+      atomicAdd(&acc[p.arc_dst[a]], exp(x - m));
+    }
     __syncthreads();
     for (int i = lo[t + 1] + lane; i < lo[t + 2]; i += 64) { alpha[i] = acc[i] > 0.0 ? m + log(acc[i]) : kNegInf; acc[i] = 0.0; }
     __syncthreads();
@@ -338,7 +367,10 @@ __global__ void k3_chain_penalize_kernel(const float *in, long long ld, float *o
 __global__ void k3_chain_sumsq_kernel(const float *in, long long ld, int rows, int cols, double *result) {
   __shared__ double red[4];
   double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)rows * cols; i += (long long)gridDim.x * blockDim.x) { const float v = in[(i / cols) * ld + (i % cols)]; acc += (double)v * v; }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)rows * cols; i += (long long)gridDim.x * blockDim.x) {
+    const float v = in[(i / cols) * ld + (i % cols)];
+    acc += (double)v * v;
+  }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -352,26 +384,33 @@ struct k3_chain_supervision {
   const int *state_off = nullptr, *layer_off = nullptr, *arc_src = nullptr, *arc_dst = nullptr, *arc_pdf = nullptr; const float *arc_w = nullptr, *final_cost = nullptr;
   // end-to-end ("generic numerator") supervisions: transitions by destination and by pdf, the per-sequence offset of state 0's arcs, alpha rows
   bool e2e = false; int max_pdfs = 0; float *alpha = nullptr;
-  const long long *in_off = nullptr, *pt_off = nullptr; const int *in_src = nullptr, *in_pdf = nullptr, *pdf_off = nullptr, *pdf_id = nullptr, *pt_src = nullptr, *pt_dst = nullptr; const float *in_tp = nullptr, *out_tp = nullptr, *pt_tp = nullptr, *seq_offset = nullptr;
+  const long long *in_off = nullptr, *pt_off = nullptr;
+  const int *in_src = nullptr, *in_pdf = nullptr, *pdf_off = nullptr, *pdf_id = nullptr, *pt_src = nullptr, *pt_dst = nullptr;
+  const float *in_tp = nullptr, *out_tp = nullptr, *pt_tp = nullptr, *seq_offset = nullptr;
 };
 extern "C" void k3_chain_supervision_destroy(k3_chain_supervision *s) {
   if (!s) return;
   for (void *q : {(void *)s->ints, (void *)s->arc_off, (void *)s->floats, (void *)s->logprob, (void *)s->scratch, (void *)s->alpha}) if (q) (void)hipFree(q);
   delete s;
 }
-extern "C" int k3_chain_supervision_create(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
+extern "C" int k3_chain_supervision_create(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets,
+    const int64_t *arc_offsets,
                                            const int32_t *ilabel, const int32_t *nextstate, const float *arc_weight, const float *final_cost, k3_chain_supervision **out) {
-  K3_REQUIRE(out && state_offsets && arc_offsets && ilabel && nextstate && arc_weight && final_cost && num_sequences > 0 && frames_per_sequence > 0 && label_dim > 0, "k3_chain_supervision_create: bad argument");
+  K3_REQUIRE(out && state_offsets && arc_offsets && ilabel && nextstate && arc_weight && final_cost && num_sequences > 0 && frames_per_sequence > 0 &&
+      label_dim > 0, "k3_chain_supervision_create: bad argument");
   const int B = num_sequences, T = frames_per_sequence; const int NS = state_offsets[B]; const long long NA = arc_offsets[NS];
   std::vector<int> layer((size_t)B * (T + 2)), src(NA), dst(NA), pdf(NA); int max_states = 0;
-  for (int n = 0; n < B; n++) {      // ComputeFstStateTimes (chain-supervision.cc:663-700): start state 0, every arc advances one frame, states sorted by time, all paths T arcs long
+  // ComputeFstStateTimes (chain-supervision.cc:663-700): start state 0, every arc advances one frame, states sorted by time, all paths T arcs long
+  for (int n = 0; n < B; n++) {
     const int s0 = state_offsets[n], S = state_offsets[n + 1] - s0; K3_REQUIRE(S > 0, "k3_chain_supervision_create: empty supervision FST");
     max_states = std::max(max_states, S);
     std::vector<int> time(S, -1); time[0] = 0;
     for (int st = 0; st < S; st++) {
-      K3_REQUIRE(time[st] >= 0 && (st == 0 || time[st] >= time[st - 1]), "k3_chain_supervision_create: the FST's states must be reachable and sorted by path length from state 0 (ComputeFstStateTimes)");
+      K3_REQUIRE(time[st] >= 0 && (st == 0 || time[st] >= time[st - 1]),
+          "k3_chain_supervision_create: the FST's states must be reachable and sorted by path length from state 0 (ComputeFstStateTimes)");
       for (long long a = arc_offsets[s0 + st]; a < arc_offsets[s0 + st + 1]; a++) {
-        K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= label_dim && nextstate[a] >= 0 && nextstate[a] < S, "k3_chain_supervision_create: arc label must be pdf-id + 1 in [1, label_dim], next state in range");
+        K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= label_dim && nextstate[a] >= 0 && nextstate[a] < S,
+            "k3_chain_supervision_create: arc label must be pdf-id + 1 in [1, label_dim], next state in range");
         K3_REQUIRE(time[nextstate[a]] == -1 || time[nextstate[a]] == time[st] + 1, "k3_chain_supervision_create: all paths to a state must have the same length");
         time[nextstate[a]] = time[st] + 1; src[a] = st; dst[a] = nextstate[a]; pdf[a] = ilabel[a] - 1;
       }
@@ -388,9 +427,12 @@ extern "C" int k3_chain_supervision_create(int32_t num_sequences, int32_t frames
   std::vector<float> fl(arc_weight, arc_weight + NA); fl.insert(fl.end(), final_cost, final_cost + NS);
   std::vector<long long> ao(arc_offsets, arc_offsets + NS + 1);
 #define K3_TRYS(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { k3_chain_supervision_destroy(s); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
-  K3_TRYS(hipMalloc(&s->ints, sizeof(int) * ints.size())); K3_TRYS(hipMalloc(&s->floats, sizeof(float) * std::max<size_t>(1, fl.size()))); K3_TRYS(hipMalloc(&s->arc_off, sizeof(long long) * ao.size()));
+  K3_TRYS(hipMalloc(&s->ints, sizeof(int) * ints.size()));
+  K3_TRYS(hipMalloc(&s->floats, sizeof(float) * std::max<size_t>(1, fl.size())));
+  K3_TRYS(hipMalloc(&s->arc_off, sizeof(long long) * ao.size()));
   K3_TRYS(hipMalloc(&s->logprob, sizeof(double) * B)); K3_TRYS(hipMalloc(&s->scratch, sizeof(double)));
-  K3_TRYS(hipMemcpy(s->ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice)); K3_TRYS(hipMemcpy(s->floats, fl.data(), sizeof(float) * fl.size(), hipMemcpyHostToDevice));
+  K3_TRYS(hipMemcpy(s->ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice));
+  K3_TRYS(hipMemcpy(s->floats, fl.data(), sizeof(float) * fl.size(), hipMemcpyHostToDevice));
   K3_TRYS(hipMemcpy(s->arc_off, ao.data(), sizeof(long long) * ao.size(), hipMemcpyHostToDevice));
 #undef K3_TRYS
   s->state_off = s->ints; s->layer_off = s->state_off + B + 1; s->arc_src = s->layer_off + (size_t)B * (T + 2); s->arc_dst = s->arc_src + NA; s->arc_pdf = s->arc_dst + NA;
@@ -488,11 +530,15 @@ __global__ __launch_bounds__(256) void k3_chain_e2e_num_kernel(E2eParams p) {
 }
 }  // namespace
 
-extern "C" int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight, const int32_t *state_offsets, const int64_t *arc_offsets,
+extern "C" int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t frames_per_sequence, int32_t label_dim, float weight,
+    const int32_t *state_offsets, const int64_t *arc_offsets,
                                                const int32_t *ilabel, const int32_t *nextstate, const float *arc_weight, const float *final_cost, k3_chain_supervision **out) {
-  K3_REQUIRE(out && state_offsets && arc_offsets && ilabel && nextstate && arc_weight && final_cost && num_sequences > 0 && frames_per_sequence > 0 && label_dim > 0, "k3_chain_supervision_create_e2e: bad argument");
+  K3_REQUIRE(out && state_offsets && arc_offsets && ilabel && nextstate && arc_weight && final_cost && num_sequences > 0 && frames_per_sequence > 0 &&
+      label_dim > 0, "k3_chain_supervision_create_e2e: bad argument");
   const int B = num_sequences, T = frames_per_sequence; const int NS = state_offsets[B]; const long long NA = arc_offsets[NS];
-  std::vector<long long> in_off(NS + 1, 0), pt_off; std::vector<int> in_src(NA), in_pdf(NA), pdf_off(B + 1, 0), pdf_id, pt_src(NA), pt_dst(NA), dst(NA), pdf(NA); std::vector<float> in_tp(NA), out_tp(NA), pt_tp(NA), seq_offset(B, 0.0f);
+  std::vector<long long> in_off(NS + 1, 0), pt_off;
+  std::vector<int> in_src(NA), in_pdf(NA), pdf_off(B + 1, 0), pdf_id, pt_src(NA), pt_dst(NA), dst(NA), pdf(NA);
+  std::vector<float> in_tp(NA), out_tp(NA), pt_tp(NA), seq_offset(B, 0.0f);
   int max_states = 0, max_pdfs = 0; bool any_final = true;
   for (int n = 0; n < B; n++) {
     const int s0 = state_offsets[n], S = state_offsets[n + 1] - s0; K3_REQUIRE(S > 0, "k3_chain_supervision_create_e2e: empty supervision FST");
@@ -503,7 +549,8 @@ extern "C" int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t fr
     for (int st = 0; st < S; st++) {
       if (final_cost[s0 + st] != __builtin_inff()) fin_any = true;
       for (long long a = arc_offsets[s0 + st]; a < arc_offsets[s0 + st + 1]; a++) {
-        K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= label_dim && nextstate[a] >= 0 && nextstate[a] < S, "k3_chain_supervision_create_e2e: arc label must be pdf-id + 1 in [1, label_dim] (epsilon-free), next state in range");
+        K3_REQUIRE(ilabel[a] >= 1 && ilabel[a] <= label_dim && nextstate[a] >= 0 && nextstate[a] < S,
+            "k3_chain_supervision_create_e2e: arc label must be pdf-id + 1 in [1, label_dim] (epsilon-free), next state in range");
         dst[a] = nextstate[a]; pdf[a] = ilabel[a] - 1; out_tp[a] = -(arc_weight[a] - (st == 0 ? offset : 0.0f));
         in_off[s0 + nextstate[a] + 1]++;
       }
@@ -514,7 +561,14 @@ extern "C" int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t fr
   for (int i = 0; i < NS; i++) in_off[i + 1] += in_off[i];
   { std::vector<long long> cur(in_off.begin(), in_off.end() - 1);
     for (int n = 0; n < B; n++) { const int s0 = state_offsets[n], S = state_offsets[n + 1] - s0;
-      for (int st = 0; st < S; st++) for (long long a = arc_offsets[s0 + st]; a < arc_offsets[s0 + st + 1]; a++) { const long long k = cur[s0 + dst[a]]++; in_src[k] = st; in_pdf[k] = pdf[a]; in_tp[k] = out_tp[a]; } } }
+      for (int st = 0; st < S; st++) for (long long a = arc_offsets[s0 + st]; a < arc_offsets[s0 + st + 1]; a++) {
+        const long long k = cur[s0 + dst[a]]++;
+        in_src[k] = st;
+        in_pdf[k] = pdf[a];
+        in_tp[k] = out_tp[a];
+      }
+      }
+      }
   // transitions by pdf, per sequence (pdfs in order of first use like index_to_pdf_, transitions of a pdf in (state, arc) order)
   pt_off.push_back(0);
   for (int n = 0; n < B; n++) {
@@ -536,31 +590,83 @@ extern "C" int k3_chain_supervision_create_e2e(int32_t num_sequences, int32_t fr
   auto s = new k3_chain_supervision; s->B = B; s->T = T; s->P = label_dim; s->weight = weight; s->max_states = max_states; s->e2e = true; s->max_pdfs = max_pdfs;
   std::vector<int> ints; auto put_i = [&](const std::vector<int> &v) { const size_t o = ints.size(); ints.insert(ints.end(), v.begin(), v.end()); return o; };
   std::vector<int> so(state_offsets, state_offsets + B + 1);
-  const size_t o_so = put_i(so), o_dst = put_i(dst), o_pdf = put_i(pdf), o_isrc = put_i(in_src), o_ipdf = put_i(in_pdf), o_poff = put_i(pdf_off), o_pid = put_i(pdf_id), o_psrc = put_i(pt_src), o_pdst = put_i(pt_dst);
+  const size_t o_so = put_i(so), o_dst = put_i(dst), o_pdf = put_i(pdf), o_isrc = put_i(in_src), o_ipdf = put_i(in_pdf), o_poff = put_i(pdf_off),
+      o_pid = put_i(pdf_id), o_psrc = put_i(pt_src), o_pdst = put_i(pt_dst);
   std::vector<float> fl; auto put_f = [&](const float *b, size_t n_) { const size_t o = fl.size(); fl.insert(fl.end(), b, b + n_); return o; };
-  const size_t o_otp = put_f(out_tp.data(), NA), o_itp = put_f(in_tp.data(), NA), o_ptp = put_f(pt_tp.data(), NA), o_fin = put_f(final_cost, NS), o_off = put_f(seq_offset.data(), B);
-  std::vector<long long> lls(arc_offsets, arc_offsets + NS + 1); const size_t o_in = lls.size(); lls.insert(lls.end(), in_off.begin(), in_off.end()); const size_t o_pt = lls.size(); lls.insert(lls.end(), pt_off.begin(), pt_off.end());
+  const size_t o_otp = put_f(out_tp.data(), NA), o_itp = put_f(in_tp.data(), NA), o_ptp = put_f(pt_tp.data(), NA), o_fin = put_f(final_cost, NS),
+      o_off = put_f(seq_offset.data(), B);
+  std::vector<long long> lls(arc_offsets, arc_offsets + NS + 1);
+  const size_t o_in = lls.size();
+  lls.insert(lls.end(), in_off.begin(), in_off.end());
+  const size_t o_pt = lls.size();
+  lls.insert(lls.end(), pt_off.begin(), pt_off.end());
 #define K3_TRYS(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { k3_chain_supervision_destroy(s); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
-  K3_TRYS(hipMalloc(&s->ints, sizeof(int) * std::max<size_t>(1, ints.size()))); K3_TRYS(hipMalloc(&s->floats, sizeof(float) * std::max<size_t>(1, fl.size()))); K3_TRYS(hipMalloc(&s->arc_off, sizeof(long long) * lls.size()));
-  K3_TRYS(hipMalloc(&s->logprob, sizeof(double) * B)); K3_TRYS(hipMalloc(&s->scratch, sizeof(double))); K3_TRYS(hipMalloc(&s->alpha, sizeof(float) * (size_t)B * (T + 1) * (max_states + 1)));
-  K3_TRYS(hipMemcpy(s->ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice)); K3_TRYS(hipMemcpy(s->floats, fl.data(), sizeof(float) * fl.size(), hipMemcpyHostToDevice));
+  K3_TRYS(hipMalloc(&s->ints, sizeof(int) * std::max<size_t>(1, ints.size())));
+  K3_TRYS(hipMalloc(&s->floats, sizeof(float) * std::max<size_t>(1, fl.size())));
+  K3_TRYS(hipMalloc(&s->arc_off, sizeof(long long) * lls.size()));
+  K3_TRYS(hipMalloc(&s->logprob, sizeof(double) * B));
+  K3_TRYS(hipMalloc(&s->scratch, sizeof(double)));
+  K3_TRYS(hipMalloc(&s->alpha, sizeof(float) * (size_t)B * (T + 1) * (max_states + 1)));
+  K3_TRYS(hipMemcpy(s->ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice));
+  K3_TRYS(hipMemcpy(s->floats, fl.data(), sizeof(float) * fl.size(), hipMemcpyHostToDevice));
   K3_TRYS(hipMemcpy(s->arc_off, lls.data(), sizeof(long long) * lls.size(), hipMemcpyHostToDevice));
 #undef K3_TRYS
-  s->state_off = s->ints + o_so; s->arc_dst = s->ints + o_dst; s->arc_pdf = s->ints + o_pdf; s->in_src = s->ints + o_isrc; s->in_pdf = s->ints + o_ipdf; s->pdf_off = s->ints + o_poff; s->pdf_id = s->ints + o_pid;
-  s->pt_src = s->ints + o_psrc; s->pt_dst = s->ints + o_pdst; s->out_tp = s->floats + o_otp; s->in_tp = s->floats + o_itp; s->pt_tp = s->floats + o_ptp; s->final_cost = s->floats + o_fin; s->seq_offset = s->floats + o_off;
+  s->state_off = s->ints + o_so;
+  s->arc_dst = s->ints + o_dst;
+  s->arc_pdf = s->ints + o_pdf;
+  s->in_src = s->ints + o_isrc;
+  s->in_pdf = s->ints + o_ipdf;
+  s->pdf_off = s->ints + o_poff;
+  s->pdf_id = s->ints + o_pid;
+  s->pt_src = s->ints + o_psrc;
+  s->pt_dst = s->ints + o_pdst;
+  s->out_tp = s->floats + o_otp;
+  s->in_tp = s->floats + o_itp;
+  s->pt_tp = s->floats + o_ptp;
+  s->final_cost = s->floats + o_fin;
+  s->seq_offset = s->floats + o_off;
   s->in_off = s->arc_off + o_in; s->pt_off = s->arc_off + o_pt;
   *out = s;
   return K3_OK;
 }
 
-// GenericNumeratorComputation::ForwardBackward / ComputeObjf: *h_logprob = the total log-probability as the reference returns it (NOT multiplied by the supervision weight, whatever
+// GenericNumeratorComputation::ForwardBackward / ComputeObjf: *h_logprob = the total log-probability as the reference returns it (NOT multiplied by the
+// supervision weight, whatever
 // the comment at chain-training.cc:147 says: :270 assigns the plain sum); the derivative gets weight * occupation probabilities
 static int chain_numerator_e2e(k3_chain_supervision *s, const float *d_out, int64_t ld, float *d_deriv, int64_t ld_deriv, float *h_logprob, hipStream_t st) {
   const size_t lds = 2 * sizeof(float) * (size_t)s->max_states;
-  if (lds > 150 * 1024) { k3::set_error("k3_chain e2e numerator: a supervision FST of %d states needs %zu B of LDS (limit 150 KB)", s->max_states, lds); return K3_ERR_UNSUPPORTED; }
-  E2eParams p{}; p.state_off = s->state_off; p.arc_off = s->arc_off; p.in_off = s->in_off; p.pt_off = s->pt_off; p.arc_dst = s->arc_dst; p.arc_pdf = s->arc_pdf; p.in_src = s->in_src; p.in_pdf = s->in_pdf;
-  p.pdf_off = s->pdf_off; p.pdf_id = s->pdf_id; p.pt_src = s->pt_src; p.pt_dst = s->pt_dst; p.out_tp = s->out_tp; p.in_tp = s->in_tp; p.pt_tp = s->pt_tp; p.final_cost = s->final_cost; p.seq_offset = s->seq_offset;
-  p.B = s->B; p.T = s->T; p.max_states = s->max_states; p.weight = s->weight; p.out = d_out; p.ld = ld; p.deriv = d_deriv; p.ld_deriv = ld_deriv; p.alpha = s->alpha; p.logprob = s->logprob;
+  if (lds > 150 * 1024) {
+    k3::set_error("k3_chain e2e numerator: a supervision FST of %d states needs %zu B of LDS (limit 150 KB)", s->max_states, lds);
+    return K3_ERR_UNSUPPORTED;
+  }
+  E2eParams p{};
+  p.state_off = s->state_off;
+  p.arc_off = s->arc_off;
+  p.in_off = s->in_off;
+  p.pt_off = s->pt_off;
+  p.arc_dst = s->arc_dst;
+  p.arc_pdf = s->arc_pdf;
+  p.in_src = s->in_src;
+  p.in_pdf = s->in_pdf;
+  p.pdf_off = s->pdf_off;
+  p.pdf_id = s->pdf_id;
+  p.pt_src = s->pt_src;
+  p.pt_dst = s->pt_dst;
+  p.out_tp = s->out_tp;
+  p.in_tp = s->in_tp;
+  p.pt_tp = s->pt_tp;
+  p.final_cost = s->final_cost;
+  p.seq_offset = s->seq_offset;
+  p.B = s->B;
+  p.T = s->T;
+  p.max_states = s->max_states;
+  p.weight = s->weight;
+  p.out = d_out;
+  p.ld = ld;
+  p.deriv = d_deriv;
+  p.ld_deriv = ld_deriv;
+  p.alpha = s->alpha;
+  p.logprob = s->logprob;
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_chain_e2e_num_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 16)));
   hipLaunchKernelGGL(k3_chain_e2e_num_kernel, dim3(s->B), dim3(256), std::max<size_t>(lds, 16), st, p);
   K3_HIP_CHECK(hipGetLastError());
@@ -572,12 +678,32 @@ static int chain_numerator_e2e(k3_chain_supervision *s, const float *d_out, int6
 }
 
 // NumeratorComputation::Forward (+ Backward when a derivative matrix is given): *h_logprob_weighted = weight * total log-prob; deriv (or xent) += weight * occupation probabilities
-static int chain_numerator(k3_chain_supervision *s, const float *d_out, int64_t ld, float *d_deriv, int64_t ld_deriv, float *d_xent, int64_t ld_xent, float *h_logprob_weighted, hipStream_t st) {
-  if (s->e2e) return d_xent ? chain_numerator_e2e(s, d_out, ld, d_xent, ld_xent, h_logprob_weighted, st) : chain_numerator_e2e(s, d_out, ld, d_deriv, ld_deriv, h_logprob_weighted, st);
+static int chain_numerator(k3_chain_supervision *s, const float *d_out, int64_t ld, float *d_deriv, int64_t ld_deriv, float *d_xent, int64_t ld_xent,
+    float *h_logprob_weighted, hipStream_t st) {
+  if (s->e2e) return d_xent ? chain_numerator_e2e(s, d_out, ld, d_xent, ld_xent, h_logprob_weighted, st) :
+      chain_numerator_e2e(s, d_out, ld, d_deriv, ld_deriv, h_logprob_weighted, st);
   const size_t lds = 3 * sizeof(double) * (size_t)s->max_states;
   if (lds > 150 * 1024) { k3::set_error("k3_chain numerator: a supervision FST of %d states needs %zu B of LDS (limit 150 KB)", s->max_states, lds); return K3_ERR_UNSUPPORTED; }
-  NumParams p{}; p.state_off = s->state_off; p.layer_off = s->layer_off; p.arc_off = s->arc_off; p.arc_src = s->arc_src; p.arc_dst = s->arc_dst; p.arc_pdf = s->arc_pdf; p.arc_w = s->arc_w; p.final_cost = s->final_cost;
-  p.B = s->B; p.T = s->T; p.weight = s->weight; p.out = d_out; p.ld = ld; p.deriv = d_deriv; p.ld_deriv = ld_deriv; p.xent = d_xent; p.ld_xent = ld_xent; p.logprob = s->logprob; p.max_states = s->max_states;
+  NumParams p{};
+  p.state_off = s->state_off;
+  p.layer_off = s->layer_off;
+  p.arc_off = s->arc_off;
+  p.arc_src = s->arc_src;
+  p.arc_dst = s->arc_dst;
+  p.arc_pdf = s->arc_pdf;
+  p.arc_w = s->arc_w;
+  p.final_cost = s->final_cost;
+  p.B = s->B;
+  p.T = s->T;
+  p.weight = s->weight;
+  p.out = d_out;
+  p.ld = ld;
+  p.deriv = d_deriv;
+  p.ld_deriv = ld_deriv;
+  p.xent = d_xent;
+  p.ld_xent = ld_xent;
+  p.logprob = s->logprob;
+  p.max_states = s->max_states;
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_chain_num_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k3_chain_num_kernel, dim3(s->B), dim3(64), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
@@ -587,29 +713,46 @@ static int chain_numerator(k3_chain_supervision *s, const float *d_out, int64_t 
   *h_logprob_weighted = (float)(tot * (double)s->weight);
   return K3_OK;
 }
-extern "C" int k3_chain_numerator(k3_chain_supervision *sup, const float *d_nnet_output, int64_t ld, float *d_nnet_output_deriv, int64_t ld_deriv, float *h_logprob_weighted, void *stream) {
+extern "C" int k3_chain_numerator(k3_chain_supervision *sup, const float *d_nnet_output, int64_t ld, float *d_nnet_output_deriv, int64_t ld_deriv,
+    float *h_logprob_weighted, void *stream) {
   K3_REQUIRE(sup && d_nnet_output && h_logprob_weighted && ld >= sup->P && (!d_nnet_output_deriv || ld_deriv >= sup->P), "k3_chain_numerator: bad argument");
   return chain_numerator(sup, d_nnet_output, ld, d_nnet_output_deriv, ld_deriv, nullptr, 0, h_logprob_weighted, (hipStream_t)stream);
 }
 
 extern "C" int k3_chain_objf_and_deriv(k3_chain_den *den, k3_chain_supervision *sup, const k3_chain_training_opts *opts, const float *d_nnet_output, int64_t ld,
-                                       float *d_nnet_output_deriv, int64_t ld_deriv, float *d_xent_output_deriv, int64_t ld_xent, float *h_objf, float *h_l2_term, float *h_weight, void *stream) {
+                                       float *d_nnet_output_deriv, int64_t ld_deriv, float *d_xent_output_deriv, int64_t ld_xent, float *h_objf,
+                                           float *h_l2_term, float *h_weight, void *stream) {
   K3_REQUIRE(den && sup && opts && d_nnet_output && h_objf && h_l2_term && h_weight && sup->P == den->P && ld >= den->P, "k3_chain_objf_and_deriv: bad argument");
   K3_REQUIRE((!d_nnet_output_deriv || ld_deriv >= den->P) && (!d_xent_output_deriv || ld_xent >= den->P), "k3_chain_objf_and_deriv: bad derivative stride");
   hipStream_t st = (hipStream_t)stream; const int rows = sup->B * sup->T, P = den->P; const float w = sup->weight;
   auto zero = [&](float *m, int64_t l) -> int { K3_HIP_CHECK(hipMemset2DAsync(m, (size_t)l * 4, 0, (size_t)P * 4, (size_t)rows, st)); return K3_OK; };
   if (d_nnet_output_deriv) { const int rc = zero(d_nnet_output_deriv, ld_deriv); if (rc) return rc; }                       // :258-259
   float den_logprob = 0.0f; int32_t ok = 1;
-  { const int rc = k3_chain_den_forward_backward(den, d_nnet_output, ld, sup->B, sup->T, opts->leaky_hmm_coefficient, -w, d_nnet_output_deriv, ld_deriv, &den_logprob, &ok, stream); if (rc) return rc; }      // :261-271
+  // :261-271
+  {
+    const int rc = k3_chain_den_forward_backward(den, d_nnet_output, ld, sup->B, sup->T, opts->leaky_hmm_coefficient, -w, d_nnet_output_deriv, ld_deriv,
+        &den_logprob, &ok, stream);
+    if (rc) return rc;
+  }
   const float den_logprob_weighted = w * den_logprob;
-  if (d_nnet_output_deriv && opts->apply_out_of_range_penalty && opts->out_of_range_regularize != 0.0f) {                      // :273-277 (the reference applies it on a coin flip; here the caller decides)
+  // :273-277 (the reference applies it on a coin flip; here the caller decides)
+  if (d_nnet_output_deriv && opts->apply_out_of_range_penalty && opts->out_of_range_regularize != 0.0f) {
     const long long n = (long long)rows * P;
-    hipLaunchKernelGGL(k3_chain_penalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_nnet_output, (long long)ld, d_nnet_output_deriv, (long long)ld_deriv, rows, P, 30.0f, 2.0f * opts->out_of_range_regularize);
+    hipLaunchKernelGGL(k3_chain_penalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_nnet_output, (long long)ld, d_nnet_output_deriv,
+        (long long)ld_deriv, rows, P, 30.0f, 2.0f * opts->out_of_range_regularize);
   }
   if (d_xent_output_deriv) { const int rc = zero(d_xent_output_deriv, ld_xent); if (rc) return rc; }                       // :279-282
   float num_logprob_weighted = 0.0f;
-  { const int rc = chain_numerator(sup, d_nnet_output, ld, d_xent_output_deriv ? nullptr : d_nnet_output_deriv, ld_deriv, d_xent_output_deriv, ld_xent, &num_logprob_weighted, st); if (rc) return rc; }      // :285-297
-  if (d_xent_output_deriv && d_nnet_output_deriv) { const int rc = k3_mat_add_mat(1.0f, d_xent_output_deriv, ld_xent, 0, d_nnet_output_deriv, ld_deriv, rows, P, stream); if (rc) return rc; }
+  // :285-297
+  {
+    const int rc = chain_numerator(sup, d_nnet_output, ld, d_xent_output_deriv ? nullptr : d_nnet_output_deriv, ld_deriv, d_xent_output_deriv, ld_xent,
+        &num_logprob_weighted, st);
+    if (rc) return rc;
+  }
+  if (d_xent_output_deriv && d_nnet_output_deriv) {
+    const int rc = k3_mat_add_mat(1.0f, d_xent_output_deriv, ld_xent, 0, d_nnet_output_deriv, ld_deriv, rows, P, stream);
+    if (rc) return rc;
+  }
   *h_objf = num_logprob_weighted - den_logprob_weighted; *h_weight = w * sup->B * sup->T;                                    // :299-301
   if (!(*h_objf - *h_objf == 0.0f) || !ok) {                                                                                // :302-314: abandon the minibatch
     if (d_nnet_output_deriv) { const int rc = zero(d_nnet_output_deriv, ld_deriv); if (rc) return rc; }

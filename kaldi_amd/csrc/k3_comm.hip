@@ -34,7 +34,10 @@ int rccl(Rccl **out) {
     r.GetErrorString = (const char *(*)(int))dlsym(r.h, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.Broadcast || !r.AllReduce) r.why = "symbols missing";
   });
-  if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.Broadcast || !r.AllReduce) { k3::set_error("RCCL (librccl.so.1) is not available: %s", r.why.c_str()); return K3_ERR_UNSUPPORTED; }
+  if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.Broadcast || !r.AllReduce) {
+    k3::set_error("RCCL (librccl.so.1) is not available: %s", r.why.c_str());
+    return K3_ERR_UNSUPPORTED;
+  }
   *out = &r; return K3_OK;
 }
 #define K3_RCCL(R, e) do { const int rc__ = (e); if (rc__ != 0) { k3::set_error("RCCL error %d (%s) in %s", rc__, (R)->GetErrorString ? (R)->GetErrorString(rc__) : "?", #e); return K3_ERR_HIP; } } while (0)
@@ -42,7 +45,14 @@ constexpr int kNcclUint8 = 1, kNcclInt64 = 4, kNcclFloat32 = 7, kNcclSum = 0;   
 struct IdFile { char id[128]; uint64_t magic, nonce; };      // what rank 0 writes
 struct Note { uint64_t magic, nonce, id_hash; };               // <id_file>.arrived.<rank> (a rank has read the id) and <id_file>.go (rank 0 has seen every rank)
 constexpr uint64_t kIdMagic = 0x4b33636f6d6d3031ull;      // "K3comm01"
-uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull) { const unsigned char *c = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; } return h; }
+uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char *c = (const unsigned char *)p;
+  for (size_t i = 0; i < n; i++) {
+    h ^= c[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
 // A launcher-supplied run identity (K3_COMM_NONCE, else torchrun's run id): ranks of different runs never accept each other's files.  *unique = the identity is
 // K3_COMM_NONCE, which the caller makes up per run; torchrun's static rendezvous hands EVERY run the id "none", so that one alone does not tell two runs apart.
 uint64_t run_nonce(bool *unique = nullptr) {
@@ -61,10 +71,18 @@ bool write_atomically(const std::string &path, const void *rec, size_t n) {
 // file for its age); otherwise nothing older than max(stale_seconds, timeout_seconds) before the caller's start is taken for this run's
 template <typename Rec> bool read_fresh(const std::string &path, Rec *rec, time_t t_start, int window, bool nonce_is_unique) {
   FILE *f = fopen(path.c_str(), "rb"); if (!f) return false;
-  struct stat st; char extra; const bool got = fread(rec, sizeof *rec, 1, f) == 1 && fread(&extra, 1, 1, f) == 0 && fstat(fileno(f), &st) == 0; fclose(f);      // (a truncated or over-long file is not a record)
+  // (a truncated or over-long file is not a record)
+  struct stat st;
+  char extra;
+  const bool got = fread(rec, sizeof *rec, 1, f) == 1 && fread(&extra, 1, 1, f) == 0 && fstat(fileno(f), &st) == 0;
+  fclose(f);
   return got && (nonce_is_unique || st.st_mtime + window >= t_start);
 }
-std::string note_path(const char *id_file, const char *what, int rank = -1) { std::string p = std::string(id_file) + "." + what; if (rank >= 0) p += "." + std::to_string(rank); return p; }
+std::string note_path(const char *id_file, const char *what, int rank = -1) {
+  std::string p = std::string(id_file) + "." + what;
+  if (rank >= 0) p += "." + std::to_string(rank);
+  return p;
+}
 }  // namespace
 
 // The file protocol of the rendezvous by itself (no RCCL: tests/test_parallel_cpu.py runs it with several processes).  Rank 0 removes whatever a
@@ -106,14 +124,21 @@ extern "C" int k3_comm_rendezvous(const char *id_file, int32_t rank, int32_t wor
     const Note want{kIdMagic, nonce, fnv(id_in, 128)}; std::vector<char> seen(world_size, 0); int missing = world_size - 1;
     for (int i = 0; i < polls && missing > 0; i++) {
       for (int r = 1; r < world_size; r++) {
-        Note n; if (!seen[r] && read_fresh(note_path(id_file, "arrived", r), &n, t_start, window, true) && n.magic == want.magic && n.nonce == want.nonce && n.id_hash == want.id_hash) { seen[r] = 1; missing--; }
+        Note n;
+        if (!seen[r] && read_fresh(note_path(id_file, "arrived", r), &n, t_start, window, true) && n.magic == want.magic && n.nonce == want.nonce &&
+            n.id_hash == want.id_hash) {
+          seen[r] = 1;
+          missing--;
+        }
       }
       if (missing > 0) usleep(50000);
     }
     if (missing > 0) {
       std::string who; for (int r = 1; r < world_size; r++) if (!seen[r]) who += (who.empty() ? "" : ", ") + std::to_string(r);
       (void)unlink(id_file); for (int r = 1; r < world_size; r++) (void)unlink(note_path(id_file, "arrived", r).c_str());
-      k3::set_error("k3_comm_rendezvous: %d of %d ranks never arrived within %d s (missing: %s); id file %s withdrawn", missing, world_size, timeout_seconds, who.c_str(), id_file); return K3_ERR_ARG;
+      k3::set_error("k3_comm_rendezvous: %d of %d ranks never arrived within %d s (missing: %s); id file %s withdrawn", missing, world_size, timeout_seconds,
+          who.c_str(), id_file);
+      return K3_ERR_ARG;
     }
     K3_REQUIRE(write_atomically(go, &want, sizeof want), "k3_comm_rendezvous: cannot write the confirmation file");
     return K3_OK;
@@ -127,12 +152,17 @@ extern "C" int k3_comm_rendezvous(const char *id_file, int32_t rank, int32_t wor
         const Note n{kIdMagic, nonce, h}; K3_REQUIRE(write_atomically(note_path(id_file, "arrived", rank), &n, sizeof n), "k3_comm_rendezvous: cannot write the arrival file");
         rec = cur; announced = h; have = true;
       }
-      Note g; if (read_fresh(go, &g, t_start, window, unique) && g.magic == kIdMagic && g.nonce == nonce && g.id_hash == announced) { memcpy(id_out, rec.id, sizeof rec.id); return K3_OK; }
+      Note g;
+      if (read_fresh(go, &g, t_start, window, unique) && g.magic == kIdMagic && g.nonce == nonce && g.id_hash == announced) {
+        memcpy(id_out, rec.id, sizeof rec.id);
+        return K3_OK;
+      }
     }
     usleep(50000);
   }
   (void)unlink(note_path(id_file, "arrived", rank).c_str());
-  k3::set_error(have ? "k3_comm_rendezvous: rank %d read the id but rank 0 never confirmed that all %d ranks arrived within %d s (%s)" : "k3_comm_rendezvous: rank %d of %d timed out after %d s waiting for rank 0's id file %s (a file of another run is not accepted)",
+  k3::set_error(have ? "k3_comm_rendezvous: rank %d read the id but rank 0 never confirmed that all %d ranks arrived within %d s (%s)" :
+      "k3_comm_rendezvous: rank %d of %d timed out after %d s waiting for rank 0's id file %s (a file of another run is not accepted)",
                 rank, world_size, timeout_seconds, id_file);
   return K3_ERR_ARG;
 }
@@ -144,10 +174,15 @@ extern "C" int k3_comm_create(const char *id_file, int32_t rank, int32_t world_s
   Rccl *R; { const int rc = rccl(&R); if (rc) return rc; }
   UniqueId id, mine; memset(&id, 0, sizeof id); memset(&mine, 0, sizeof mine);
   if (rank == 0) K3_RCCL(R, R->GetUniqueId(&mine));
-  { const int rc = k3_comm_rendezvous(id_file, rank, world_size, timeout_seconds, 120, &mine, &id); if (rc) return rc; }      // (returns once EVERY rank has been seen, or with an error inside the timeout)
+  // (returns once EVERY rank has been seen, or with an error inside the timeout)
+  {
+    const int rc = k3_comm_rendezvous(id_file, rank, world_size, timeout_seconds, 120, &mine, &id);
+    if (rc) return rc;
+  }
   void *c = nullptr;
   K3_RCCL(R, R->CommInitRank(&c, world_size, id, rank));
-  if (rank == 0 && world_size > 1) {      // every rank has joined: nothing of this run stays behind (a one-rank communicator keeps the id file: nobody else reads it, tests look at it)
+  // every rank has joined: nothing of this run stays behind (a one-rank communicator keeps the id file: nobody else reads it, tests look at it)
+  if (rank == 0 && world_size > 1) {
     (void)unlink(id_file); (void)unlink(note_path(id_file, "go").c_str()); for (int r = 1; r < world_size; r++) (void)unlink(note_path(id_file, "arrived", r).c_str());
   }
   *comm = c; return K3_OK;
@@ -179,7 +214,13 @@ extern "C" int k3_fst_bcast(k3_fst **fst, void *comm, int32_t root, int32_t rank
   K3_RCCL(R, R->Broadcast(d_shape, d_shape, 5, kNcclInt64, root, comm, st));
   K3_HIP_CHECK(hipStreamSynchronize(st));
   K3_HIP_CHECK(hipMemcpy(shape, d_shape, sizeof shape, hipMemcpyDeviceToHost));
-  if (rank != root) { const int rc = k3_fst_create_shaped(shape, fst); if (rc) return rc; int64_t s2[5]; const int rc2 = k3_fst_shape_and_image(*fst, s2, &image); if (rc2) return rc2; }
+  if (rank != root) {
+    const int rc = k3_fst_create_shaped(shape, fst);
+    if (rc) return rc;
+    int64_t s2[5];
+    const int rc2 = k3_fst_shape_and_image(*fst, s2, &image);
+    if (rc2) return rc2;
+  }
   K3_RCCL(R, R->Broadcast(image, image, (size_t)shape[3], kNcclUint8, root, comm, st));
   K3_HIP_CHECK(hipStreamSynchronize(st));
   return K3_OK;

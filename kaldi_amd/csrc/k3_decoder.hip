@@ -80,7 +80,13 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     // ---- InitDecoding (:63-81): start token, eps closure with cutoff = beam
     if (tid == 0) {
       bool cl; const int slot = tb.claim(p.start, &cl);
-      tb.cost_min(slot, enc(0.0f)); tb.set_tok(slot, 0); tok_slot[0] = slot; tok_state[0] = p.start; K3_AST(&tok_cost[0], kEncMax); sh.n_next = 1;      // marker stores are agent-scope atomics: the expander's atomicExch (at L2) must not overtake them
+      // marker stores are agent-scope atomics: the expander's atomicExch (at L2) must not overtake them
+      tb.cost_min(slot, enc(0.0f));
+      tb.set_tok(slot, 0);
+      tok_slot[0] = slot;
+      tok_state[0] = p.start;
+      K3_AST(&tok_cost[0], kEncMax);
+      sh.n_next = 1;
       sh.n_wl[0] = 0; sh.n_wl[2] = 0; sh.n_wl[1] = 1; for (int i = 0; i < 4; i++) sh.err_r[i] = 0;      // round-1 list = the start token
       if (slot < kHL) s_lwl[1][0] = (unsigned short)slot; else { s_lwl[1][0] = 0xFFFF; wl[p.frame_tokens_cap] = slot; }
       tok_off[0] = 0; loff_n[0] = 0;
@@ -91,7 +97,12 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     const LaneInfo &li = p.info[L];
     if (li.status != kStOk) return;
     f0 = li.num_frames; cur_base = li.cur_base; n_cur = li.n_cur; max_frame = li.max_frame_tokens;
-    if (tid == 0) { sh.n_link = li.n_links; sh.n_eps = (unsigned long long)li.n_eps; sh.n_emit = (unsigned long long)li.n_cands; sh.n_os = (unsigned long long)li.n_order_sensitive; }
+    if (tid == 0) {
+      sh.n_link = li.n_links;
+      sh.n_eps = (unsigned long long)li.n_eps;
+      sh.n_emit = (unsigned long long)li.n_cands;
+      sh.n_os = (unsigned long long)li.n_order_sensitive;
+    }
     __syncthreads();
   }
 
@@ -111,7 +122,11 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     // overflow check enforces -- as many epsilon links): a lane that has outgrown its reservation moves to bigger pools here, where nothing of the new frame exists yet
     { const long long nl_ = sh.n_link;
       if (lp.tcap - (cur_base + n_cur) < p.frame_tokens_cap || lp.lcap - nl_ < 2ll * p.frame_cands_cap) {
-        if (!grow_lane_pools(p, L, lp, cur_base + n_cur, nl_, p.frame_tokens_cap, 2ll * p.frame_cands_cap, &s_pool)) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; __syncthreads(); break; }
+        if (!grow_lane_pools(p, L, lp, cur_base + n_cur, nl_, p.frame_tokens_cap, 2ll * p.frame_cands_cap, &s_pool)) {
+          if (tid == 0) sh.err = K3_ERR_OVERFLOW;
+          __syncthreads();
+          break;
+        }
         tok_state = lp.tok_state; tok_cost = lp.tok_cost; links = lp.links; link_arc = lp.link_arc;
       } }
     // stage the log-likelihood row of this frame in LDS (coalesced), overlapped with the cutoff passes
@@ -289,10 +304,22 @@ __global__ __launch_bounds__(kBlock, K3_DEC_WPE) void k3_decode_forward_kernel(D
     __syncthreads();
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
 #ifdef K3_DEC_PROF
-    if (tid == 0 && f >= 0) { const long long now__ = (long long)__builtin_readcyclecounter(); st_ab[f] = (float)(now__ - t_frame__); t_frame__ = now__; }   // profiling builds only: FrameStats' adaptive_beam column = cycles of the frame
+    // profiling builds only: FrameStats' adaptive_beam column = cycles of the frame
+    if (tid == 0 && f >= 0) {
+      const long long now__ = (long long)__builtin_readcyclecounter();
+      st_ab[f] = (float)(now__ - t_frame__);
+      t_frame__ = now__;
+    }
 #endif
   }
-  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { k3a_add(&sh.n_eps, a); k3a_add(&sh.n_emit, b); k3a_add(&sh.n_os, c); } }
+  {
+    const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os);
+    if (lane == 0) {
+      k3a_add(&sh.n_eps, a);
+      k3a_add(&sh.n_emit, b);
+      k3a_add(&sh.n_os, c);
+    }
+  }
   __syncthreads();
 #ifdef K3_DEC_PROF
   if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
@@ -438,7 +465,15 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
   };
   auto load_off = [&](int f) {
     FrameOff o{0, 0, 0, 0, 0, 0, 0};
-    if (f >= 0) { o.b0 = uni(tok_off[f]); o.b1 = uni(tok_off[f + 1]); o.b2 = uni(tok_off[f + 2]); o.e0 = uni(loff_e[f]); o.e1 = uni(loff_n[f + 1]); o.n0 = uni(loff_n[f]); o.n1 = o.e0; }
+    if (f >= 0) {
+      o.b0 = uni(tok_off[f]);
+      o.b1 = uni(tok_off[f + 1]);
+      o.b2 = uni(tok_off[f + 2]);
+      o.e0 = uni(loff_e[f]);
+      o.e1 = uni(loff_n[f + 1]);
+      o.n0 = uni(loff_n[f]);
+      o.n1 = o.e0;
+    }
     return o;
   };
   // frame f - 1's offsets share all but three values with frame f's: those are fetched a frame early and made scalar late
@@ -531,7 +566,10 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
           const int i = tid + k * kPBlock;
           if ((elive >> k & 1) && !(link_extra_cost(cextra[er[k].dst - b0], er[k].tot, ccost[er[k].dst - b0]) > lb)) keep_link(n0 + i);
         }
-        for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) { const Link k = links[l]; if (eps_link_live(k, enc(ccost[k.src - b0])) && !(link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]) > lb)) keep_link(l); }
+        for (long long l = n0 + kEpsRegs * kPBlock + tid; l < n1; l += kPBlock) {
+          const Link k = links[l];
+          if (eps_link_live(k, enc(ccost[k.src - b0])) && !(link_extra_cost(cextra[k.dst - b0], k.tot, ccost[k.dst - b0]) > lb)) keep_link(l);
+        }
       }
       K3_PT(3);    // eps fixpoint + write-back
       pre_valid = pre_next;
@@ -576,7 +614,14 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
 #pragma unroll
           for (int j = 0; j < kE; j++) { const long long l = l0 + j * kPBlock; if (l < n1) k[j] = links[l]; }
 #pragma unroll
-          for (int j = 0; j < kE; j++) { const long long l = l0 + j * kPBlock; if (l < n1) { sc[j] = tok_cost[k[j].src]; xd[j] = K3_ALD(&x[k[j].dst - b0]); dc[j] = dec(tok_cost[k[j].dst]); } }
+          for (int j = 0; j < kE; j++) {
+            const long long l = l0 + j * kPBlock;
+            if (l < n1) {
+              sc[j] = tok_cost[k[j].src];
+              xd[j] = K3_ALD(&x[k[j].dst - b0]);
+              dc[j] = dec(tok_cost[k[j].dst]);
+            }
+          }
 #pragma unroll
           for (int j = 0; j < kE; j++) {
             const long long l = l0 + j * kPBlock;
@@ -602,7 +647,15 @@ __global__ __launch_bounds__(kPBlock, 4) void k3_decode_prune_kernel(DecParams p
 #pragma unroll
       for (int j = 0; j < kE; j++) { const long long l = l0 + j * kPBlock; if (l < n1) k[j] = links[l]; }
 #pragma unroll
-      for (int j = 0; j < kE; j++) { const long long l = l0 + j * kPBlock; if (l < n1) { sc[j] = tok_cost[k[j].src]; xd[j] = x[k[j].dst - b0]; xs[j] = x[k[j].src - b0]; dc[j] = dec(tok_cost[k[j].dst]); } }
+      for (int j = 0; j < kE; j++) {
+        const long long l = l0 + j * kPBlock;
+        if (l < n1) {
+          sc[j] = tok_cost[k[j].src];
+          xd[j] = x[k[j].dst - b0];
+          xs[j] = x[k[j].src - b0];
+          dc[j] = dec(tok_cost[k[j].dst]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < kE; j++) {
         const long long l = l0 + j * kPBlock;
@@ -743,7 +796,11 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_best_path_kernel(DecParams 
   __syncthreads();
   if (te == tb) return;
   long long cur = tb + (long long)(s_best & 0xFFFFFFFFull);
-  if (tid == 0) { o.reached_final[blockIdx.x] = any_final; o.final_cost[blockIdx.x] = with_final ? p.final_cost[tok_state[cur]] : 0.0f; o.relative_cost[blockIdx.x] = any_final ? dec(s_minf) - dec(s_min) : kInf; }
+  if (tid == 0) {
+    o.reached_final[blockIdx.x] = any_final;
+    o.final_cost[blockIdx.x] = with_final ? p.final_cost[tok_state[cur]] : 0.0f;
+    o.relative_cost[blockIdx.x] = any_final ? dec(s_minf) - dec(s_min) : kInf;
+  }
   int len = 0, f = T;
   for (int guard = 0; guard < 4 * (T + 1) + 64; guard++) {
     const unsigned cc = tok_cost[cur];
@@ -753,7 +810,8 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_best_path_kernel(DecParams 
     // an eps link of frame f into cur (source in the same frame), stamped with its source's final cost (live), whose tot is cur's cost
     for (long long l = loff_n[f] + tid; l < loff_e[f]; l += kPBlock) {
       const Link k = links[l];
-      if (k.dst == (unsigned)cur && __float_as_uint(k.tot) == __float_as_uint(dec(cc)) && eps_link_live(k, tok_cost[k.src])) k3a_min((unsigned long long *)&s_link, (unsigned long long)l);
+      if (k.dst == (unsigned)cur && __float_as_uint(k.tot) == __float_as_uint(dec(cc)) &&
+          eps_link_live(k, tok_cost[k.src])) k3a_min((unsigned long long *)&s_link, (unsigned long long)l);
     }
     __syncthreads();
     long long best = s_link; bool emitting = false;
@@ -769,7 +827,14 @@ __global__ __launch_bounds__(kPBlock) void k3_decode_best_path_kernel(DecParams 
     if (best == 0x7FFFFFFFFFFFFFFFll) break;      // the start token (or a token nothing points to: cannot happen for a token with finite cost)
     const Link k = links[best];
     if (len >= o.cap) { if (tid == 0) o.path_len[blockIdx.x] = -1; return; }
-    if (tid == 0) { const int a = link_arc[best]; const ArcRec r = p.arcs[a]; o.path_il[po + len] = p.arc_ilabel[a]; o.path_ol[po + len] = r.olabel; o.path_g[po + len] = r.w; o.path_ac[po + len] = emitting ? k.ac - st_co[f - 1] : 0.0f; }
+    if (tid == 0) {
+      const int a = link_arc[best];
+      const ArcRec r = p.arcs[a];
+      o.path_il[po + len] = p.arc_ilabel[a];
+      o.path_ol[po + len] = r.olabel;
+      o.path_g[po + len] = r.w;
+      o.path_ac[po + len] = emitting ? k.ac - st_co[f - 1] : 0.0f;
+    }
     len++; cur = k.src; if (emitting) f--;
   }
   if (tid == 0) o.path_len[blockIdx.x] = len;
@@ -786,7 +851,10 @@ extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, i
 
 // ------------------------------------------------------------------------------------------------ graph ----
 struct k3_fst {
-  int32_t num_states = 0, start = 0; int64_t num_arcs = 0; int32_t max_pdf = -1;      // max_pdf: largest column of the log-likelihood matrix an arc reads (-1: unknown, image imported)
+  // max_pdf: largest column of the log-likelihood matrix an arc reads (-1: unknown, image imported)
+  int32_t num_states = 0, start = 0;
+  int64_t num_arcs = 0;
+  int32_t max_pdf = -1;
   void *image = nullptr; size_t bytes = 0;
   int2 *offs = nullptr; ArcRec *arcs = nullptr; float *final_cost = nullptr; int *arc_ilabel = nullptr;
   ~k3_fst() { if (image) (void)hipFree(image); }
@@ -894,15 +962,23 @@ struct k3_decoder {
   void *out_buf = nullptr; size_t out_bytes = 0;
   bool started = false, finalized = false;
   bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_tp = nullptr; bool ev_tp_recorded = false;      // recorded behind every token-passing launch: the last reader of the caller's log-likelihoods (k3_decoder_stream_wait_token_passing)
-  // Per-call arguments of AdvanceDecoding (row offsets, per-lane frame pointers, "fresh" flags): a ring of slots, each a page-locked host block + its device copy + an event recorded
+  // recorded behind every token-passing launch: the last reader of the caller's log-likelihoods (k3_decoder_stream_wait_token_passing)
+  hipEvent_t ev_tp = nullptr;
+  bool ev_tp_recorded = false;
+  // Per-call arguments of AdvanceDecoding (row offsets, per-lane frame pointers, "fresh" flags): a ring of slots, each a page-locked host block + its device
+  // copy + an event recorded
   // behind the launch that reads it.  The call fills a slot, copies it asynchronously on the caller's stream and returns: no hipStreamSynchronize + synchronous hipMemcpy per chunk
   // (round 4: a streaming round of 17 frames paid a stream drain and three blocking copies).  A slot is reused kArgSlots calls later, after its event.
   static constexpr int kArgSlots = 4;
   struct ArgSlot { char *h = nullptr, *d = nullptr; hipEvent_t ev = nullptr; bool used = false; };
   ArgSlot arg[kArgSlots]; unsigned arg_seq = 0; size_t arg_off_rows = 0, arg_off_fresh = 0, arg_bytes = 0;
 
-  ~k3_decoder() { for (void *q : allocs) (void)hipFree(q); for (void *q : frame_allocs) (void)hipFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); if (ev_tp) (void)hipEventDestroy(ev_tp); if (out_buf) (void)hipFree(out_buf);
+  ~k3_decoder() {
+    for (void *q : allocs) (void)hipFree(q);
+    for (void *q : frame_allocs) (void)hipFree(q);
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_tp) (void)hipEventDestroy(ev_tp);
+    if (out_buf) (void)hipFree(out_buf);
                  for (ArgSlot &a : arg) { if (a.h) (void)hipHostFree(a.h); if (a.d) (void)hipFree(a.d); if (a.ev) (void)hipEventDestroy(a.ev); } }
 };
 
@@ -922,10 +998,15 @@ template <typename T> static int dmalloc(std::vector<void *> *allocs, T **ptr, s
 
 extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg, int32_t nlanes, int32_t num_pdfs, k3_decoder **out) {
   K3_REQUIRE(fst && cfg && out && nlanes > 0 && num_pdfs > 0, "k3_decoder_create: bad argument");
-  if (fst->max_pdf >= num_pdfs) { k3::set_error("k3_decoder_create: the graph reads pdf %d but the log-likelihood matrix has %d columns (graph / model mismatch)", fst->max_pdf, num_pdfs); return K3_ERR_ARG; }
-  K3_REQUIRE(cfg->beam > 0 && cfg->lattice_beam > 0 && cfg->max_active > 1 && cfg->min_active >= 0 && cfg->min_active < cfg->max_active, "k3_decoder_create: bad beam / active limits");
+  if (fst->max_pdf >= num_pdfs) {
+    k3::set_error("k3_decoder_create: the graph reads pdf %d but the log-likelihood matrix has %d columns (graph / model mismatch)", fst->max_pdf, num_pdfs);
+    return K3_ERR_ARG;
+  }
+  K3_REQUIRE(cfg->beam > 0 && cfg->lattice_beam > 0 && cfg->max_active > 1 && cfg->min_active >= 0 && cfg->min_active < cfg->max_active,
+      "k3_decoder_create: bad beam / active limits");
   K3_REQUIRE(cfg->frame_tokens_cap >= 64 && cfg->frame_cands_cap >= cfg->frame_tokens_cap && cfg->lane_tokens_cap >= cfg->frame_tokens_cap && cfg->lane_links_cap > 0 &&
-             cfg->lane_tokens_cap < (1ll << 31) && cfg->lane_links_cap < (1ll << 40), "k3_decoder_create: bad capacities (need frame_cands_cap >= frame_tokens_cap, lane_tokens_cap < 2^31)");
+             cfg->lane_tokens_cap < (1ll << 31) && cfg->lane_links_cap < (1ll << 40),
+                 "k3_decoder_create: bad capacities (need frame_cands_cap >= frame_tokens_cap, lane_tokens_cap < 2^31)");
   std::unique_ptr<k3_decoder> d(new k3_decoder());
   d->fst = fst; d->cfg = *cfg; d->nlanes = nlanes; d->num_pdfs = num_pdfs;
   DecParams &p = d->p;
@@ -946,8 +1027,11 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     if ((rc = dmalloc(&d->allocs, &links, nl * cfg->lane_links_cap))) return rc;
     if ((rc = dmalloc(&d->allocs, &link_arc, nl * cfg->lane_links_cap))) return rc;
     std::vector<LanePool> pools(nl);
-    for (size_t l = 0; l < nl; l++) pools[l] = LanePool{tok_state + l * cfg->lane_tokens_cap, tok_cost + l * cfg->lane_tokens_cap, tok_extra + l * cfg->lane_tokens_cap, newidx + l * cfg->lane_tokens_cap,
-                                                        links + l * cfg->lane_links_cap, link_arc + l * cfg->lane_links_cap, (long long)cfg->lane_tokens_cap, (long long)cfg->lane_links_cap};
+    for (size_t l = 0; l < nl; l++) pools[l] = LanePool{
+      tok_state + l * cfg->lane_tokens_cap, tok_cost + l * cfg->lane_tokens_cap, tok_extra + l * cfg->lane_tokens_cap, newidx + l * cfg->lane_tokens_cap,
+                                                        links + l * cfg->lane_links_cap, link_arc + l * cfg->lane_links_cap, (long long)cfg->lane_tokens_cap,
+                                                            (long long)cfg->lane_links_cap
+                                                        };
     if ((rc = dmalloc(&d->allocs, &p.pools, nl))) return rc;
     K3_HIP_CHECK(hipMemcpy(p.pools, pools.data(), nl * sizeof(LanePool), hipMemcpyHostToDevice));
     // spare arena for the lanes that outgrow the reservation (grow_lane_pools): -1 = a quarter of the reservation, but at least 1 GiB and 14 times a lane's reservation
@@ -978,7 +1062,9 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   K3_HIP_CHECK(hipMemset(p.prof, 0, nl * 16 * sizeof(long long)));
   if ((rc = dmalloc(&d->allocs, &d->d_row_off, nl + 1))) return rc;
   if ((rc = dmalloc(&d->allocs, &d->d_fresh, nl))) return rc;
-  d->arg_off_rows = align_up(sizeof(long long) * (nl + 1), 16); d->arg_off_fresh = d->arg_off_rows + align_up(sizeof(float *) * nl, 16); d->arg_bytes = d->arg_off_fresh + align_up(sizeof(int) * nl, 16);
+  d->arg_off_rows = align_up(sizeof(long long) * (nl + 1), 16);
+  d->arg_off_fresh = d->arg_off_rows + align_up(sizeof(float *) * nl, 16);
+  d->arg_bytes = d->arg_off_fresh + align_up(sizeof(int) * nl, 16);
   for (k3_decoder::ArgSlot &a : d->arg) {
     K3_HIP_CHECK(hipHostMalloc((void **)&a.h, d->arg_bytes, hipHostMallocDefault)); K3_HIP_CHECK(hipMalloc((void **)&a.d, d->arg_bytes));
     K3_HIP_CHECK(hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
@@ -987,11 +1073,15 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   p.live_cap = (int)std::min<long long>(cfg->lane_tokens_cap, 1 << 18);
   if ((rc = dmalloc(&d->allocs, &p.live_tok, nl * p.live_cap))) return rc;
   if ((rc = dmalloc(&d->allocs, &p.live_link, nl * p.live_cap))) return rc;
-  p.literal = (cfg->literal_order == 2 || cfg->literal_order == 3) ? cfg->literal_order : (cfg->literal_order ? 1 : 0); p.lit_force_hbm_order = cfg->literal_order == 4; p.hash_ratio = cfg->hash_ratio;      // 2: the closure's creation order by the one-wavefront replay (the fall-back of 1); 3: 1 with zero-length component stacks (exercises the fall-back)
+  // 2: the closure's creation order by the one-wavefront replay (the fall-back of 1); 3: 1 with zero-length component stacks (exercises the fall-back)
+  p.literal = (cfg->literal_order == 2 || cfg->literal_order == 3) ? cfg->literal_order : (cfg->literal_order ? 1 : 0);
+  p.lit_force_hbm_order = cfg->literal_order == 4;
+  p.hash_ratio = cfg->hash_ratio;
   p.fast_cap = p.literal == 1 ? (cfg->fast_frame_tokens < 0 ? k3_lit_fast_tokens() : std::min(cfg->fast_frame_tokens, k3_lit_fast_tokens())) : 0;
   if (p.literal) {
     K3_REQUIRE(cfg->hash_ratio > 0.0f && cfg->hash_ratio <= 64.0f, "k3_decoder_create: literal_order needs 0 < hash_ratio <= 64 (LatticeFasterDecoderConfig::hash_ratio)");
-    K3_REQUIRE(cfg->frame_tokens_cap <= 65536 && cfg->frame_cands_cap > cfg->frame_tokens_cap, "k3_decoder_create: literal_order needs frame_tokens_cap <= 65536 < frame_cands_cap");
+    K3_REQUIRE(cfg->frame_tokens_cap <= 65536 && cfg->frame_cands_cap > cfg->frame_tokens_cap,
+        "k3_decoder_create: literal_order needs frame_tokens_cap <= 65536 < frame_cands_cap");
     const size_t cap = (size_t)cfg->frame_tokens_cap, nch = cap / 64 + 2;
     p.hash_cap = (int)std::max<double>(1000.0, std::ceil((double)cap * cfg->hash_ratio) + 1.0);
     p.seq_words_cap = (int)((8 * (size_t)cfg->frame_cands_cap + cap) / 32 + 64);      // labels: emitting arcs expanded on a frame + tokens its closure creates
@@ -999,19 +1089,63 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     // one arena, LANE-major: a lane's scratch arrays are neighbours in memory (a workgroup touches the first few KB of every one of them on
     // every frame; as separate allocations that was ~45 distant pages per lane, and the address translation dominated the memory latency)
     size_t off = 0;
-    auto place = [&](auto **ptr, size_t count) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(off); off += (count * sizeof(T) + 255) & ~(size_t)255; };
+    auto place = [&](auto **ptr, size_t count) {
+      using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>;
+      *ptr = reinterpret_cast<T *>(off);
+      off += (count * sizeof(T) + 255) & ~(size_t)255;
+    };
     place(&p.lt_order, 2 * cap); place(&p.lt_label, cap); place(&p.lt_c0, cap); place(&p.lt_rflag, cap); place(&p.lt_rown, cap); place(&p.lt_grp, cap); place(&p.lt_lead, cap + 1);
     place(&p.lt_crng, cap); place(&p.lt_c2t, cap); place(&p.lt_iq, cap); place(&p.lt_dense, cap); place(&p.lt_by_ins, cap); place(&p.lt_meta, cap); place(&p.lt_rcost, cap);
-    place(&p.lt_par, cap); place(&p.lt_rtmp, cap); place(&p.lt_rlist, cap); place(&p.lt_wrec, 2 * cap); place(&p.lt_cinfo, cap); place(&p.lt_coffs, cap); place(&p.lt_rinfo, cap); place(&p.lt_vis, cap); { size_t ts = 1024; while (ts < 2 * cap) ts <<= 1; place(&p.lt_btab, ts); }
+    place(&p.lt_par, cap);
+    place(&p.lt_rtmp, cap);
+    place(&p.lt_rlist, cap);
+    place(&p.lt_wrec, 2 * cap);
+    place(&p.lt_cinfo, cap);
+    place(&p.lt_coffs, cap);
+    place(&p.lt_rinfo, cap);
+    place(&p.lt_vis, cap);
+    {
+      size_t ts = 1024;
+      while (ts < 2 * cap) ts <<= 1;
+      place(&p.lt_btab, ts);
+    }
     place(&p.lt_cmin, 2 * nch); place(&p.lt_ccnt, 2 * nch); place(&p.lt_cdst, (size_t)p.eps_cap); place(&p.lt_cw, (size_t)p.eps_cap); place(&p.lt_arcs2, (size_t)p.eps_cap);
     place(&p.lt_stack, (size_t)p.stack_cap); place(&p.lt_bm, (size_t)p.seq_words_cap); place(&p.lt_wpre, (size_t)p.seq_words_cap);
     p.lt_lane_bytes = (long long)((off + 4095) & ~(size_t)4095);
     char *arena = nullptr;
     if ((rc = dmalloc(&d->allocs, &arena, nl * (size_t)p.lt_lane_bytes))) return rc;
     auto rebase = [&](auto **ptr) { using T = std::remove_pointer_t<std::remove_pointer_t<decltype(ptr)>>; *ptr = reinterpret_cast<T *>(arena + reinterpret_cast<size_t>(*ptr)); };
-    rebase(&p.lt_order); rebase(&p.lt_label); rebase(&p.lt_c0); rebase(&p.lt_rflag); rebase(&p.lt_rown); rebase(&p.lt_grp); rebase(&p.lt_lead); rebase(&p.lt_crng); rebase(&p.lt_c2t); rebase(&p.lt_iq);
-    rebase(&p.lt_dense); rebase(&p.lt_by_ins); rebase(&p.lt_meta); rebase(&p.lt_rcost); rebase(&p.lt_par); rebase(&p.lt_rtmp); rebase(&p.lt_rlist); rebase(&p.lt_wrec); rebase(&p.lt_cinfo); rebase(&p.lt_coffs);
-    rebase(&p.lt_rinfo); rebase(&p.lt_vis); rebase(&p.lt_btab); rebase(&p.lt_cmin); rebase(&p.lt_ccnt); rebase(&p.lt_cdst); rebase(&p.lt_cw); rebase(&p.lt_arcs2); rebase(&p.lt_stack); rebase(&p.lt_bm); rebase(&p.lt_wpre);
+    rebase(&p.lt_order);
+    rebase(&p.lt_label);
+    rebase(&p.lt_c0);
+    rebase(&p.lt_rflag);
+    rebase(&p.lt_rown);
+    rebase(&p.lt_grp);
+    rebase(&p.lt_lead);
+    rebase(&p.lt_crng);
+    rebase(&p.lt_c2t);
+    rebase(&p.lt_iq);
+    rebase(&p.lt_dense);
+    rebase(&p.lt_by_ins);
+    rebase(&p.lt_meta);
+    rebase(&p.lt_rcost);
+    rebase(&p.lt_par);
+    rebase(&p.lt_rtmp);
+    rebase(&p.lt_rlist);
+    rebase(&p.lt_wrec);
+    rebase(&p.lt_cinfo);
+    rebase(&p.lt_coffs);
+    rebase(&p.lt_rinfo);
+    rebase(&p.lt_vis);
+    rebase(&p.lt_btab);
+    rebase(&p.lt_cmin);
+    rebase(&p.lt_ccnt);
+    rebase(&p.lt_cdst);
+    rebase(&p.lt_cw);
+    rebase(&p.lt_arcs2);
+    rebase(&p.lt_stack);
+    rebase(&p.lt_bm);
+    rebase(&p.lt_wpre);
     // idle patterns of the scratch: labels / bucket firsts all ones, bitmap / bucket counters zero
     K3_HIP_CHECK(hipMemset2D(p.lt_label, (size_t)p.lt_lane_bytes, 0xFF, cap * sizeof(unsigned), nl));
     K3_HIP_CHECK(hipMemset2D(p.lt_bm, (size_t)p.lt_lane_bytes, 0, (size_t)p.seq_words_cap * sizeof(unsigned), nl));
@@ -1082,7 +1216,8 @@ extern "C" int k3_decoder_init_channels(k3_decoder *d, const int32_t *channels, 
 // AdvanceDecoding (cuda-decoder.h:262: AdvanceDecoding(lanes, loglikes)): lane u consumes rows h_row_offsets[u] .. [u+1] of d_loglikes as
 // its NEXT frames (zero rows = the lane idles in this call).  Chunked calls give bit-identical results to one call with all frames.
 extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream) {
-  K3_REQUIRE(d && d_loglikes && h_row_off && num_utts == d->last_utts && ld >= d->num_pdfs, "k3_decoder_advance_decoding: bad argument (call k3_decoder_init_decoding for this many lanes first)");
+  K3_REQUIRE(d && d_loglikes && h_row_off && num_utts == d->last_utts && ld >= d->num_pdfs,
+      "k3_decoder_advance_decoding: bad argument (call k3_decoder_init_decoding for this many lanes first)");
   hipStream_t st = (hipStream_t)stream; DecParams &p = d->p;
   for (int u = 0; u < num_utts; u++) {
     const long long T = h_row_off[u + 1] - h_row_off[u];
@@ -1095,7 +1230,12 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   memcpy(slot.h, h_row_off, sizeof(long long) * (num_utts + 1)); memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * num_utts);
   K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
   std::fill(d->fresh.begin(), d->fresh.end(), 0);
-  p.loglikes = d_loglikes; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr; p.lane_rows = nullptr;
+  p.loglikes = d_loglikes;
+  p.ld = ld;
+  p.row_off = reinterpret_cast<long long *>(slot.d);
+  p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh);
+  p.lane_ids = nullptr;
+  p.lane_rows = nullptr;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   if (p.literal) k3_lit_forward_launch(&p, sizeof(p), num_utts, st);
@@ -1111,20 +1251,25 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
 
 // AdvanceDecoding(lanes_assignements) of the reference (cuda-decoder.h:262): every listed channel gets a device pointer to the log-likelihoods of
 // its next frame(s) -- num_frames rows, ld floats apart -- wherever they live; the other channels of the group idle.
-extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const int32_t *channels, const float *const *h_lane_frames, int32_t num_frames, int64_t ld, void *stream) {
-  K3_REQUIRE(d && channels && h_lane_frames && n >= 0 && num_frames > 0 && ld >= d->num_pdfs && d->last_utts > 0, "k3_decoder_advance_decoding_lanes: bad argument (call k3_decoder_init_decoding first)");
+extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const int32_t *channels, const float *const *h_lane_frames, int32_t num_frames,
+    int64_t ld, void *stream) {
+  K3_REQUIRE(d && channels && h_lane_frames && n >= 0 && num_frames > 0 && ld >= d->num_pdfs && d->last_utts > 0,
+      "k3_decoder_advance_decoding_lanes: bad argument (call k3_decoder_init_decoding first)");
   hipStream_t st = (hipStream_t)stream; DecParams &p = d->p; const int U = d->last_utts;
   std::vector<long long> ro(U + 1, 0); std::vector<const float *> rows(U, nullptr); std::vector<int> T(U, 0);
   for (int i = 0; i < n; i++) {
     const int c = channels[i];
     K3_REQUIRE(c >= 0 && c < U && h_lane_frames[i] && T[c] == 0, "k3_decoder_advance_decoding_lanes: channel out of range / listed twice / null frame pointer");
-    K3_REQUIRE(d->last_frames[c] + num_frames + 2 <= d->fstride && !d->lane_final[c], "k3_decoder_advance_decoding_lanes: more frames than max_total_frames, or a finalised channel");
+    K3_REQUIRE(d->last_frames[c] + num_frames + 2 <= d->fstride && !d->lane_final[c],
+        "k3_decoder_advance_decoding_lanes: more frames than max_total_frames, or a finalised channel");
     T[c] = num_frames; rows[c] = h_lane_frames[i];
   }
   for (int u = 0; u < U; u++) { ro[u + 1] = ro[u] + T[u]; d->last_frames[u] += T[u]; }
   k3_decoder::ArgSlot &slot = d->arg[d->arg_seq++ % k3_decoder::kArgSlots];
   if (slot.used) K3_HIP_CHECK(hipEventSynchronize(slot.ev));
-  memcpy(slot.h, ro.data(), sizeof(long long) * (U + 1)); memcpy(slot.h + d->arg_off_rows, rows.data(), sizeof(float *) * U); memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * U);
+  memcpy(slot.h, ro.data(), sizeof(long long) * (U + 1));
+  memcpy(slot.h + d->arg_off_rows, rows.data(), sizeof(float *) * U);
+  memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * U);
   K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
   std::fill(d->fresh.begin(), d->fresh.end(), 0);
   p.loglikes = nullptr; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr;
@@ -1147,7 +1292,8 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
 // (round 5: that copy was 210 MB per pass of 512 channels, a sixth of the GPU work of a streaming round).  h_lane_first[u] = channel u's first row (null or h_num_frames[u] = 0:
 // the channel idles in this call).
 extern "C" int k3_decoder_advance_decoding_strided(k3_decoder *d, int32_t num_utts, const float *const *h_lane_first, const int32_t *h_num_frames, int64_t ld, void *stream) {
-  K3_REQUIRE(d && h_lane_first && h_num_frames && num_utts == d->last_utts && ld >= d->num_pdfs, "k3_decoder_advance_decoding_strided: bad argument (call k3_decoder_init_decoding for this many lanes first)");
+  K3_REQUIRE(d && h_lane_first && h_num_frames && num_utts == d->last_utts && ld >= d->num_pdfs,
+      "k3_decoder_advance_decoding_strided: bad argument (call k3_decoder_init_decoding for this many lanes first)");
   hipStream_t st = (hipStream_t)stream; DecParams &p = d->p; const int U = d->last_utts;
   for (int u = 0; u < U; u++) {
     const int T = h_lane_first[u] ? h_num_frames[u] : 0;
@@ -1228,7 +1374,8 @@ extern "C" int k3_decoder_decode_batch(k3_decoder *d, int32_t num_utts, const fl
   return k3_decoder_finalize_decoding(d, stream);
 }
 
-// Make `stream` wait for the decoder's latest token-passing launch -- the last kernel that reads the caller's log-likelihood buffer (the pruning and output kernels behind it work on
+// Make `stream` wait for the decoder's latest token-passing launch -- the last kernel that reads the caller's log-likelihood buffer (the pruning and output
+// kernels behind it work on
 // the lane's own pools).  A pipeline that refills that buffer for a later batch waits for THIS, not for the whole of k3_decoder_decode_batch: the pruning kernel cannot run beside a
 // resident token-passing launch of another decoder object (LDS), so behind it the next front end would start tens of milliseconds later than it has to.
 extern "C" int k3_decoder_stream_wait_token_passing(k3_decoder *d, void *stream) {
@@ -1256,8 +1403,11 @@ extern "C" int k3_decoder_lattice_info(k3_decoder *d, int64_t *h_info) {
     const LaneInfo &li = d->h_info[u]; int64_t *o = h_info + 10 * k;
     o[0] = li.status == kStOk ? li.out_states : 0; o[1] = li.status == kStOk ? li.out_arcs : 0; o[2] = li.status; o[3] = li.reached_final;
     o[4] = li.n_tokens; o[5] = li.n_links; o[6] = li.max_frame_tokens; o[7] = li.n_cands; o[8] = li.n_eps; o[9] = li.num_frames;
-    if (li.status < 0) { worst = li.status; k3::set_error("k3_decoder: utterance %d failed with status %d (%s); tokens %lld links %lld max tokens/frame %d -- raise the k3_decoder_config capacities",
-                                                          u, li.status, li.status == K3_ERR_OVERFLOW ? "capacity overflow" : "internal error", li.n_tokens, li.n_links, li.max_frame_tokens); }
+    if (li.status < 0) {
+      worst = li.status;
+      k3::set_error("k3_decoder: utterance %d failed with status %d (%s); tokens %lld links %lld max tokens/frame %d -- raise the k3_decoder_config capacities",
+                                                          u, li.status, li.status == K3_ERR_OVERFLOW ? "capacity overflow" : "internal error", li.n_tokens,
+                                                              li.n_links, li.max_frame_tokens); }
   }
   return worst;
 }
@@ -1283,7 +1433,12 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
   const int U = (int)d->sel.size();
   K3_REQUIRE(U > 0, "k3_decoder_get_raw_lattices: no finalised lanes");
   std::vector<long long> so(U + 1, 0), ao(U + 1, 0);
-  for (int u = 0; u < U; u++) { const LaneInfo &li = d->h_info[d->sel[u]]; const bool ok = li.status == kStOk; so[u + 1] = so[u] + (ok ? li.out_states : 0); ao[u + 1] = ao[u] + (ok ? li.out_arcs : 0); }
+  for (int u = 0; u < U; u++) {
+    const LaneInfo &li = d->h_info[d->sel[u]];
+    const bool ok = li.status == kStOk;
+    so[u + 1] = so[u] + (ok ? li.out_states : 0);
+    ao[u + 1] = ao[u] + (ok ? li.out_arcs : 0);
+  }
   const size_t NS = (size_t)so[U], NA = (size_t)ao[U];
   // one grow-only device staging area: [offsets | 4 state arrays | 6 arc arrays]
   const size_t need = sizeof(long long) * 2 * (U + 1) + 4 * (4 * NS + 6 * NA) + 256;
@@ -1338,16 +1493,20 @@ extern "C" int k3_decoder_get_raw_lattices(k3_decoder *d, int32_t *st_frame, int
 // - min(cost) over the newest frame (+inf: no final state active) -- what kaldi::EndpointDetected takes; cap_arcs = capacity of the arc arrays.
 extern "C" int k3_decoder_get_best_path(k3_decoder *d, const int32_t *channels, int32_t n, int32_t use_final_probs, int64_t *h_offsets, int64_t cap_arcs,
                                         int32_t *h_ilabel, int32_t *h_olabel, float *h_graph, float *h_ac, float *h_final_cost, float *h_relative_cost, int32_t *h_reached_final) {
-  K3_REQUIRE(d && channels && n > 0 && n <= d->nlanes && h_offsets && h_ilabel && h_olabel && h_graph && h_ac && d->started, "k3_decoder_get_best_path: bad argument or nothing decoded");
-  for (int i = 0; i < n; i++) K3_REQUIRE(channels[i] >= 0 && channels[i] < d->last_utts && !d->fresh[channels[i]], "k3_decoder_get_best_path: channel out of range or never advanced");
+  K3_REQUIRE(d && channels && n > 0 && n <= d->nlanes && h_offsets && h_ilabel && h_olabel && h_graph && h_ac && d->started,
+      "k3_decoder_get_best_path: bad argument or nothing decoded");
+  for (int i = 0; i < n; i++) K3_REQUIRE(channels[i] >= 0 && channels[i] < d->last_utts && !d->fresh[channels[i]],
+      "k3_decoder_get_best_path: channel out of range or never advanced");
   hipStream_t st = d->last_stream; K3_HIP_CHECK(hipStreamSynchronize(st));
   int maxT = 0; for (int i = 0; i < n; i++) maxT = std::max(maxT, d->last_frames[channels[i]]);
   const int cap = 4 * maxT + 64;
   int *d_ids = nullptr, *d_il = nullptr, *d_ol = nullptr, *d_len = nullptr, *d_rf = nullptr; float *d_g = nullptr, *d_ac = nullptr, *d_fc = nullptr, *d_rc = nullptr;
   std::vector<void *> tmp; auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
   int rc; const size_t nc = (size_t)n * cap;
-  if ((rc = dmalloc(&tmp, &d_ids, (size_t)n)) || (rc = dmalloc(&tmp, &d_il, nc)) || (rc = dmalloc(&tmp, &d_ol, nc)) || (rc = dmalloc(&tmp, &d_g, nc)) || (rc = dmalloc(&tmp, &d_ac, nc)) ||
-      (rc = dmalloc(&tmp, &d_len, (size_t)n)) || (rc = dmalloc(&tmp, &d_fc, (size_t)n)) || (rc = dmalloc(&tmp, &d_rc, (size_t)n)) || (rc = dmalloc(&tmp, &d_rf, (size_t)n))) { cleanup(); return rc; }
+  if ((rc = dmalloc(&tmp, &d_ids, (size_t)n)) || (rc = dmalloc(&tmp, &d_il, nc)) || (rc = dmalloc(&tmp, &d_ol, nc)) || (rc = dmalloc(&tmp, &d_g, nc)) ||
+      (rc = dmalloc(&tmp, &d_ac, nc)) ||
+      (rc = dmalloc(&tmp, &d_len, (size_t)n)) || (rc = dmalloc(&tmp, &d_fc, (size_t)n)) || (rc = dmalloc(&tmp, &d_rc, (size_t)n)) ||
+          (rc = dmalloc(&tmp, &d_rf, (size_t)n))) { cleanup(); return rc; }
 #define K3_TRY(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { cleanup(); k3::set_error("HIP error %s: %s", hipGetErrorName(e__), #e); return K3_ERR_HIP; } } while (0)
   K3_TRY(hipMemcpy(d_ids, channels, sizeof(int) * n, hipMemcpyHostToDevice));
   DecParams p = d->p; p.lane_ids = d_ids;
@@ -1362,7 +1521,15 @@ extern "C" int k3_decoder_get_best_path(k3_decoder *d, const int32_t *channels, 
   K3_TRY(hipStreamSynchronize(st));
 #undef K3_TRY
   int64_t total = 0; h_offsets[0] = 0;
-  for (int u = 0; u < n; u++) { if (len[u] < 0) { cleanup(); k3::set_error("k3_decoder_get_best_path: path of channel %d longer than %d arcs", channels[u], cap); return K3_ERR_OVERFLOW; } total += len[u]; h_offsets[u + 1] = total; }
+  for (int u = 0; u < n; u++) {
+    if (len[u] < 0) {
+      cleanup();
+      k3::set_error("k3_decoder_get_best_path: path of channel %d longer than %d arcs", channels[u], cap);
+      return K3_ERR_OVERFLOW;
+    }
+    total += len[u];
+    h_offsets[u + 1] = total;
+  }
   if (total > cap_arcs) { cleanup(); k3::set_error("k3_decoder_get_best_path: %lld arcs but room for %lld", (long long)total, (long long)cap_arcs); return K3_ERR_OVERFLOW; }
   for (int u = 0; u < n; u++)
     for (int k = 0; k < len[u]; k++) {      // the kernel wrote the last arc first
@@ -1379,7 +1546,10 @@ extern "C" int k3_decoder_phase_cycles(k3_decoder *d, int64_t *h_cycles /* [16] 
   std::vector<long long> h((size_t)d->nlanes * 16);
   K3_HIP_CHECK(hipMemcpy(h.data(), d->p.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
   const bool mx = getenv("K3_PROF_MAX") != nullptr;      // profiling builds: the slowest lane instead of the sum
-  for (int i = 0; i < 16; i++) { h_cycles[i] = 0; for (int l = 0; l < d->nlanes; l++) h_cycles[i] = mx ? std::max<int64_t>(h_cycles[i], h[(size_t)l * 16 + i]) : h_cycles[i] + h[(size_t)l * 16 + i]; }
+  for (int i = 0; i < 16; i++) {
+    h_cycles[i] = 0;
+    for (int l = 0; l < d->nlanes; l++) h_cycles[i] = mx ? std::max<int64_t>(h_cycles[i], h[(size_t)l * 16 + i]) : h_cycles[i] + h[(size_t)l * 16 + i];
+  }
   K3_HIP_CHECK(hipMemset(d->p.prof, 0, h.size() * sizeof(long long)));
   return K3_OK;
 }

@@ -53,10 +53,13 @@ template <typename T> __device__ __forceinline__ void store_stream(T *dst, T v) 
 }
 
 enum { kStOk = 0, kStNoTokens = 1 };
-constexpr int kErrPool = -1000;      // internal to the forward kernels: a lane's token / link pool is full -- grow it and go on (never leaves the kernel; K3_ERR_OVERFLOW when the spare arena is exhausted)
+// internal to the forward kernels: a lane's token / link pool is full -- grow it and go on (never leaves the kernel; K3_ERR_OVERFLOW when the spare arena is
+// exhausted)
+constexpr int kErrPool = -1000;
 
 // A lane's token / link pools.  The configured capacities (k3_decoder_config::lane_tokens_cap / lane_links_cap = the reference's ntokens_pre_allocated) are a RESERVATION like the
-// reference's (cuda-decoder.cc:232-238 reserves, the per-channel vectors grow): a lane that outgrows them moves, inside the token-passing kernel and without the host, to a block of
+// reference's (cuda-decoder.cc:232-238 reserves, the per-channel vectors grow): a lane that outgrows them moves, inside the token-passing kernel and without
+// the host, to a block of
 // at least twice the size carved off the decoder's spare arena (grow_lane_pools below); every kernel reads a lane's pointers and capacities from this record.
 struct LanePool { int *tok_state; unsigned *tok_cost; float *tok_extra; int *newidx; Link *links; int *link_arc; long long tcap, lcap; };
 
@@ -71,7 +74,8 @@ struct LaneInfo {            // per lane, written by the kernels, read by the ho
   // their arc was examined (tot >= the frame's final next_cutoff) -- the oracle's extra_links.  Default (two-pass) mode: emitting arcs below the
   // pre-pass bound but not below the final bound, an upper bound on the arcs the two rules can disagree on.
   long long n_order_sensitive;
-  int hash_size, order_sel;               // literal_order: HashList bucket count (PossiblyResizeHash) and which half of lt_order holds the newest frame, carried across AdvanceDecoding calls
+  // literal_order: HashList bucket count (PossiblyResizeHash) and which half of lt_order holds the newest frame, carried across AdvanceDecoding calls
+  int hash_size, order_sel;
   int pool_grows;                         // how often this lane moved to bigger pools (since the decoder was created)
 };
 
@@ -103,10 +107,15 @@ struct DecParams {
   // input
   const float *loglikes; long long ld; const long long *row_off; int num_pdfs; int use_lds_row;
   const float *const *lane_rows;          // non-null: lane l's next frames start at lane_rows[l] (rows ld apart) instead of row row_off[l] of `loglikes`
-  const int *fresh;                       // [nlanes] 1: InitDecoding first (start token + eps closure), frames start at 0; 0: continue after LaneInfo::num_frames frames (AdvanceDecoding)
+  // [nlanes] 1: InitDecoding first (start token + eps closure), frames start at 0; 0: continue after LaneInfo::num_frames frames (AdvanceDecoding)
+  const int *fresh;
   const int *lane_ids;                    // prune / output kernels: the lanes being finalised (workgroup b works on lane lane_ids[b]); null = lane b
   // per-lane pools: pools[l] (initially lane l's slice of one allocation per array; after a growth a block of the spare arena)
-  LanePool *pools; char *spare; unsigned long long *spare_used; long long spare_bytes;      // spare arena: bump-allocated by the lanes that outgrow their pools, never freed before the decoder is destroyed
+  // spare arena: bump-allocated by the lanes that outgrow their pools, never freed before the decoder is destroyed
+  LanePool *pools;
+  char *spare;
+  unsigned long long *spare_used;
+  long long spare_bytes;
   int *live_tok; long long *live_link; int live_cap;   // survivors of the pruning pass (pool indices), per lane
   Slot *hash; int *tok_slot; int *wl;            // wl: 2 x frame_tokens_cap
   float *c_tot, *c_ac; int *c_dst, *c_arc, *c_src;
@@ -115,7 +124,11 @@ struct DecParams {
   int *st_ntoks; float *st_cur, *st_ab, *st_next, *st_co;
   LaneInfo *info;
   // literal_order scratch (k3_decoder_literal.h), per lane
-  int literal, fast_cap, lit_force_hbm_order; float hash_ratio; int hash_cap, seq_words_cap, eps_cap, stack_cap; long long lt_lane_bytes;      // the lt_* pointers below are lane 0's; lane l's arrays start lt_lane_bytes * l further on
+  // the lt_* pointers below are lane 0's; lane l's arrays start lt_lane_bytes * l further on
+  int literal, fast_cap, lit_force_hbm_order;
+  float hash_ratio;
+  int hash_cap, seq_words_cap, eps_cap, stack_cap;
+  long long lt_lane_bytes;
   int *lt_order;          // [2 x frame_tokens_cap] HashList order of the current / the next frame (local token indices)
   int *lt_by_ins;         // [frame_tokens_cap] tokens of the newest frame in creation order (the final-frame sweeps walk it backwards)
   unsigned *lt_label;     // [frame_tokens_cap] creation label of a token being built (all 0xFFFFFFFF between frames)
@@ -125,7 +138,11 @@ struct DecParams {
   float *lt_c0;                                          // [frame_tokens_cap] token costs right after ProcessEmitting
   int2 *lt_crng; int *lt_cdst; float *lt_cw;             // closure sub-graph in token space: per token (first, count), per eps arc (dst token | -1, weight)
   float *lt_rcost; int *lt_rflag, *lt_rown, *lt_stack, *lt_iq, *lt_c2t; int2 *lt_arcs2; int4 *lt_meta;   // replay state (global copies; small frames use LDS)
-  int *lt_par, *lt_rtmp; int2 *lt_rlist, *lt_rinfo; int4 *lt_cinfo, *lt_coffs, *lt_wrec, *lt_vis, *lt_btab;      // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of the tokens it created
+  // [frame_tokens_cap] component replay: union-find parents, roots grouped by component, workers, per-component counts / offsets, per-root (first, count) of
+  // the tokens it created
+  int *lt_par, *lt_rtmp;
+  int2 *lt_rlist, *lt_rinfo;
+  int4 *lt_cinfo, *lt_coffs, *lt_wrec, *lt_vis, *lt_btab;
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -358,7 +375,10 @@ struct Table {
   __device__ __forceinline__ unsigned cost(int id) const { return id < kHL ? K3_LLD(&lcost[id]) : K3_ALD(&g[id - kHL].cost); }
   __device__ __forceinline__ int key(int id) const { return id < kHL ? K3_LLD(&lkey[id]) : K3_ALD(&g[id - kHL].key); }
   __device__ __forceinline__ int tok(int id) const { return id < kHL ? K3_LLD(&ltok[id]) : K3_ALD(&g[id - kHL].tok); }
-  __device__ __forceinline__ void set_tok(int id, int t) const { if (id < kHL) __hip_atomic_store(&ltok[id], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else K3_AST(&g[id - kHL].tok, t); }
+  __device__ __forceinline__ void set_tok(int id, int t) const {
+    if (id < kHL) __hip_atomic_store(&ltok[id], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else K3_AST(&g[id - kHL].tok, t);
+  }
   // token index of a slot some other thread claimed a moment ago: the claimer publishes it right after its claim (same
   // program point for every lane of a wave, so lanes of one wave never wait on each other); bounded in case of a bug
   __device__ __forceinline__ int wait_tok(int id, int *err) const {
@@ -432,11 +452,13 @@ template <typename T> __device__ __forceinline__ T *k3_uniform_ptr(T *q) {
   return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ long long k3_uniform_i64(long long v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v),
+      hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ LanePool k3_uniform_pool(const LanePool &a) {
-  return LanePool{k3_uniform_ptr(a.tok_state), k3_uniform_ptr(a.tok_cost), k3_uniform_ptr(a.tok_extra), k3_uniform_ptr(a.newidx), k3_uniform_ptr(a.links), k3_uniform_ptr(a.link_arc), k3_uniform_i64(a.tcap), k3_uniform_i64(a.lcap)};
+  return LanePool{k3_uniform_ptr(a.tok_state), k3_uniform_ptr(a.tok_cost), k3_uniform_ptr(a.tok_extra), k3_uniform_ptr(a.newidx), k3_uniform_ptr(a.links),
+      k3_uniform_ptr(a.link_arc), k3_uniform_i64(a.tcap), k3_uniform_i64(a.lcap)};
 }
 
 // Move lane L to pools in which at least need_t tokens and need_l links fit behind the n_tok tokens / n_link links it holds: a block of the spare arena with both capacities at
@@ -449,7 +471,8 @@ __device__ __forceinline__ bool grow_lane_pools(const DecParams &p, int L, LaneP
     LanePool np = lp; long long nt = 2 * lp.tcap, nl = 2 * lp.lcap;
     while (nt - n_tok < need_t) nt *= 2;
     while (nl - n_link < need_l) nl *= 2;
-    const unsigned long long bt = ((unsigned long long)nt * 4 + 255) & ~255ull, bl4 = ((unsigned long long)nl * 4 + 255) & ~255ull, bl16 = ((unsigned long long)nl * 16 + 255) & ~255ull;
+    const unsigned long long bt = ((unsigned long long)nt * 4 + 255) & ~255ull, bl4 = ((unsigned long long)nl * 4 + 255) & ~255ull,
+        bl16 = ((unsigned long long)nl * 16 + 255) & ~255ull;
     const unsigned long long bytes = 4 * bt + bl4 + bl16;
     np.tcap = -1;
     if (p.spare && nt < (1ll << 31)) {
@@ -487,7 +510,8 @@ __device__ __forceinline__ bool grow_lane_pools(const DecParams &p, int L, LaneP
 // the links a token ends up with are exactly its eps arcs with cur + graph < cutoff at its final cost.
 template <bool kPublish = true>
 __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, const Table &tb, float cutoff, long long nb, int *tok_state, unsigned *tok_cost,
-                                             Link *links, int *link_arc, long long tcap, long long lcap, int *tok_slot, int *wl, unsigned short (*lwl)[kWlLds], unsigned (&creg)[kCurRegs], int (&sreg)[kCurRegs],
+                                             Link *links, int *link_arc, long long tcap, long long lcap, int *tok_slot, int *wl, unsigned short (*lwl)[kWlLds],
+                                                 unsigned (&creg)[kCurRegs], int (&sreg)[kCurRegs],
                                              long long &t_last__, unsigned &cnt_eps) {
   const int tid = threadIdx.x, lane = tid & 63;
   // One barrier per round.  Work-list counters n_wl[3], error flags err_r[4] and LDS mark bits [3] rotate: round r reads list r,
@@ -572,7 +596,12 @@ __device__ __forceinline__ void finish_frame(const DecParams &p, Shared &sh, con
         // are recognised as stale by their stamp (Link::ac of an eps link = the source cost it was created at)
         if (mk && !claimed) { idx = tb.wait_tok(slot2, &sh.err); if (idx < 0) { fail(K3_ERR_HIP); idx = 0; } }
         const long long lp = wave_append64(mk, &sh.n_link);
-        if (mk) { if (lp < lcap) { store_link(&links[lp], Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)}); store_stream(&link_arc[lp], arc); } else fail(K3_ERR_OVERFLOW); }
+        if (mk) {
+          if (lp < lcap) {
+            store_link(&links[lp], Link{(unsigned)(nb + oti), (unsigned)(nb + idx), tot, __uint_as_float(ocb)});
+            store_stream(&link_arc[lp], arc);
+          } else fail(K3_ERR_OVERFLOW);
+        }
       });
       K3_TW(14);
     }

@@ -35,25 +35,31 @@ constexpr int oT_key = oV_end, oT_tix = oT_key + 4 * kFH, oT_end = oT_tix + 2 * 
 // (4) work-lists, mark bits, chunk records, the 16-bit columns of the epsilon links
 constexpr int oWl = oT_end, oMarks = oWl + 2 * 2 * kFW, oChunk = oMarks + 3 * (kFT / 32) * 4, oE_src = oChunk + 512, oE_dst = oE_src + 2 * kFE, kFastArena = oE_dst + 2 * kFE;
 // closure sub-graph (over the table and the work-lists)
-constexpr int oRown = oT_key, oCid = oRown + 4 * kFT, oLead = oCid + 2 * kFT, oAR_arc = oLead + 2 * kFT, oAR_dst = oAR_arc + 4 * kFA, oAR_w = oAR_dst + 2 * kFA, oM_abeg = oAR_w + 4 * kFA, oM_pc = oM_abeg + 2 * kFC,
+constexpr int oRown = oT_key, oCid = oRown + 4 * kFT, oLead = oCid + 2 * kFT, oAR_arc = oLead + 2 * kFT, oAR_dst = oAR_arc + 4 * kFA,
+    oAR_w = oAR_dst + 2 * kFA, oM_abeg = oAR_w + 4 * kFA, oM_pc = oM_abeg + 2 * kFC,
               oC2t = oM_pc + 2 * kFC, oRflag = oC2t + 2 * kFC, oSrcbit = oRflag + kFT / 8, oSub_end = oSrcbit + kFT / 8;
 constexpr int oRcost = oE_arc;      // (over E_arc, dead after the second pass over the links)
 // order pass 1 (emitting tokens, between the sub-graph and the replay): in the holes the links and the build scratch left
 constexpr int oO1_btab = oE_stamp, oO1_bm = oRown, oO1_wpre = oO1_bm + kFM / 8, oO1_lead = oO1_wpre + kFM / 32 * 2, oO1_grp = oLead, oO1_curs = oAR_arc, oOrd1 = oX + 2 * kFT;
 // order pass 2 (all tokens, last phase): everything but (1) is dead; the result goes straight to (2)
-constexpr int oO2_btab = oT_key, oO2_bm = oO2_btab + 4 * kFB, oO2_wpre = oO2_bm + kFM / 8, oO2_lead = oO2_wpre + kFM / 32 * 2, oO2_grp = oO2_lead + 2 * kFT + 8, oO2_curs = oO2_grp + 2 * kFT + 8, oO2_end = oO2_curs + 2 * kFT + 8;
+constexpr int oO2_btab = oT_key, oO2_bm = oO2_btab + 4 * kFB, oO2_wpre = oO2_bm + kFM / 8, oO2_lead = oO2_wpre + kFM / 32 * 2,
+    oO2_grp = oO2_lead + 2 * kFT + 8, oO2_curs = oO2_grp + 2 * kFT + 8, oO2_end = oO2_curs + 2 * kFT + 8;
 // replay (after order pass 1)
-constexpr int oIq = oE_stamp, oPar = oIq + 2 * kFQ, oCroots = oPar + 4 * kFC, oCcreated = oCroots + 2 * kFC + 8, oCarcs = oCcreated + 2 * kFC + 8, oCcurs = oCarcs + 2 * kFC + 8, oOx = oCcurs + 2 * kFC + 8, oOy = oOx + 2 * kFC, oOz = oOy + 2 * kFC,
+constexpr int oIq = oE_stamp, oPar = oIq + 2 * kFQ, oCroots = oPar + 4 * kFC, oCcreated = oCroots + 2 * kFC + 8, oCarcs = oCcreated + 2 * kFC + 8,
+    oCcurs = oCarcs + 2 * kFC + 8, oOx = oCcurs + 2 * kFC + 8, oOy = oOx + 2 * kFC, oOz = oOy + 2 * kFC,
               oOw = oOz + 2 * kFC, oRlist = oOw + 2 * kFC, oStack = oRlist + 4 * kFQ, oRep_end = oStack + 2 * kFA;
 constexpr int oRinfo = oOrd1 /* consumed by then */, oRtmp = oN_nn, oDense = oRtmp + 2 * kFQ, oWrec = oC0 /* consumed by then */, oClist = oE_src;
 static_assert(kFastArena <= 79360, "two workgroups per CU: the frame lives in the 77.5 KB of the general path");
-static_assert(oE_w + 4 * kFE <= oV_end && oSub_end <= oChunk && oRcost + 4 * kFC <= oE_stamp && oO1_btab + 4 * kFB <= oV_end + 0 * kFB && oO1_lead + 2 * kFT + 8 <= oCid && oO1_grp + 2 * kFT <= oAR_arc &&
-              oO1_curs + 2 * kFT + 8 <= oAR_dst && oOrd1 + 2 * kFT <= oN_nn && oRep_end <= oAR_dst && oRinfo + 4 * kFQ <= oN_nn && oDense + 2 * kFQ <= oV_cost && oWrec + 10 * kFQ <= oRcost &&
+static_assert(oE_w + 4 * kFE <= oV_end && oSub_end <= oChunk && oRcost + 4 * kFC <= oE_stamp && oO1_btab + 4 * kFB <= oV_end + 0 * kFB &&
+    oO1_lead + 2 * kFT + 8 <= oCid && oO1_grp + 2 * kFT <= oAR_arc &&
+              oO1_curs + 2 * kFT + 8 <= oAR_dst && oOrd1 + 2 * kFT <= oN_nn && oRep_end <= oAR_dst && oRinfo + 4 * kFQ <= oN_nn && oDense + 2 * kFQ <= oV_cost
+                  && oWrec + 10 * kFQ <= oRcost &&
               oClist + 2 * kFT <= kFastArena && oO2_end <= kFastArena && 2 * kFT <= 4 * kFT / 2 + 2 * kFT, "LDS map");
 
 struct LaneCtx {      // this lane's slices of the pools and per-frame arrays
   int *tok_state; unsigned *tok_cost; Link *links; int *link_arc; long long *tok_off, *loff_e, *loff_n; int *st_ntoks; float *st_cur, *st_ab, *st_next, *st_co;
-  long long tcap, lcap;      // capacities of the lane's token / link pools (the caller has made room for a whole LDS-resident frame: the checks below cannot fire, they guard the memory)
+  // capacities of the lane's token / link pools (the caller has made room for a whole LDS-resident frame: the checks below cannot fire, they guard the memory)
+  long long tcap, lcap;
 };
 struct FastShared { int abort, abort_r[4], n_wl[3], n_el; unsigned next0; int reason; long long prof[12]; };
 #ifdef K3_FAST_PROF
@@ -95,7 +101,8 @@ __device__ __forceinline__ int block_excl_scan_f(In &&in, Out &&out, int n, int 
 // The phase structure of lit_hash_order_lds; the bucket table packs {bucket, smallest creation rank} into one word (equal buckets -> equal upper
 // halves, so the minimum over the word is the minimum over the ranks) and the members of a bucket are counted at its leader's rank.
 template <typename Emit>
-__device__ __forceinline__ void fast_hash_order(Shared &sh, int n, unsigned M, const unsigned short *label16, const unsigned short *bkt16, unsigned *btab, unsigned *bm, unsigned short *wpre,
+__device__ __forceinline__ void fast_hash_order(Shared &sh, int n, unsigned M, const unsigned short *label16, const unsigned short *bkt16, unsigned *btab,
+    unsigned *bm, unsigned short *wpre,
                                                 unsigned short *lead, unsigned short *grp, unsigned short *curs, Emit &&emit) {
   const int tid = threadIdx.x; constexpr int kPer = (kFT + kBlock - 1) / kBlock;
   const int W = (int)((M + 31u) >> 5);
@@ -134,10 +141,17 @@ __device__ __forceinline__ void fast_hash_order(Shared &sh, int n, unsigned M, c
 #pragma unroll
   for (int k = 0; k < kPer; k++) { const int i = tid + k * kBlock; cnt[k] = 1; if (i < n) { cnt[k] = lead[lf[k]]; multi |= cnt[k] > 1u; } }
   multi = __syncthreads_or(multi);
-  block_excl_scan_f([&](int r) { return (int)lead[r]; }, [&](int r, int ex) { lead[r] = (unsigned short)ex; }, n, sh.redi);      // (reads precede the writes: every thread scans its own consecutive ranks)
+  // (reads precede the writes: every thread scans its own consecutive ranks)
+  block_excl_scan_f([&](int r) { return (int)lead[r]; }, [&](int r, int ex) { lead[r] = (unsigned short)ex; }, n, sh.redi);
   if (multi) {
 #pragma unroll
-    for (int k = 0; k < kPer; k++) { const int i = tid + k * kBlock; if (i < n && cnt[k] > 1u) { const unsigned s_ = add16(curs, (int)lf[k], 1u); grp[lead[lf[k]] + s_] = (unsigned short)d[k]; } }
+    for (int k = 0; k < kPer; k++) {
+      const int i = tid + k * kBlock;
+      if (i < n && cnt[k] > 1u) {
+        const unsigned s_ = add16(curs, (int)lf[k], 1u);
+        grp[lead[lf[k]] + s_] = (unsigned short)d[k];
+      }
+    }
     __syncthreads();
   }
 #pragma unroll
@@ -153,7 +167,8 @@ __device__ __forceinline__ void fast_hash_order(Shared &sh, int n, unsigned M, c
 }
 
 // One component of the replay on one thread (lit_replay_component with 16-bit LDS records)
-__device__ __forceinline__ bool fast_replay_component(float *rcost, const unsigned short *m_abeg, const unsigned short *m_pc, const unsigned short *ar_dst, const float *ar_w, unsigned short *clist,
+__device__ __forceinline__ bool fast_replay_component(float *rcost, const unsigned short *m_abeg, const unsigned short *m_pc, const unsigned short *ar_dst,
+    const float *ar_w, unsigned short *clist,
                                                       const unsigned short *rlist, unsigned short *rinfo, unsigned short *stk, int scap, int r0, int rcnt, int cpos, float accept) {
   const float kInf = __builtin_inff();
   for (int j = 0; j < rcnt; j++) {
@@ -204,11 +219,13 @@ __device__ __forceinline__ bool fast_import(const DecParams &p, char *arena, con
 #endif
 // One frame.  Returns the number of tokens of the new frame, or -1 when the frame has to be redone on the general path (nothing the next frame reads
 // has been published; sh.n_link / sh.n_next are restored by the caller).
-__device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, FastShared &fs, char *arena, const LitLane &q, const LaneCtx &c, int f, const float *ll, long long cur_base, int n_cur,
+__device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, FastShared &fs, char *arena, const LitLane &q, const LaneCtx &c, int f,
+    const float *ll, long long cur_base, int n_cur,
                                               unsigned &hash_size_io, int *ord_nxt, int cap_tokens, unsigned &cnt_emit_io, unsigned &cnt_os_io, unsigned &cnt_eps_io) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64; const float kInf = __builtin_inff();
   unsigned *N_cost = reinterpret_cast<unsigned *>(arena + oN_cost), *N_abeg = reinterpret_cast<unsigned *>(arena + oN_abeg), *X = reinterpret_cast<unsigned *>(arena + oX);
-  unsigned short *N_ne = reinterpret_cast<unsigned short *>(arena + oN_ne), *N_nn = reinterpret_cast<unsigned short *>(arena + oN_nn), *lab16 = reinterpret_cast<unsigned short *>(arena + oLab16);
+  unsigned short *N_ne = reinterpret_cast<unsigned short *>(arena + oN_ne), *N_nn = reinterpret_cast<unsigned short *>(arena + oN_nn),
+      *lab16 = reinterpret_cast<unsigned short *>(arena + oLab16);
   unsigned short *B16 = reinterpret_cast<unsigned short *>(arena + oX);
   unsigned *V_cost = reinterpret_cast<unsigned *>(arena + oV_cost), *V_abeg = reinterpret_cast<unsigned *>(arena + oV_abeg);
   unsigned short *V_ne = reinterpret_cast<unsigned short *>(arena + oV_ne), *V_tok = reinterpret_cast<unsigned short *>(arena + oV_tok);
@@ -259,7 +276,17 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   }
   K3_FP(0);
   // ---- the frame's structures
-  if (tid == 0) { fs.abort = 0; fs.reason = 0; fs.next0 = kEncMax; fs.n_wl[0] = 0; fs.n_wl[1] = 0; fs.n_wl[2] = 0; fs.abort_r[0] = fs.abort_r[1] = fs.abort_r[2] = fs.abort_r[3] = 0; sh.n_next = 0; c.loff_e[f] = link0; }
+  if (tid == 0) {
+    fs.abort = 0;
+    fs.reason = 0;
+    fs.next0 = kEncMax;
+    fs.n_wl[0] = 0;
+    fs.n_wl[1] = 0;
+    fs.n_wl[2] = 0;
+    fs.abort_r[0] = fs.abort_r[1] = fs.abort_r[2] = fs.abort_r[3] = 0;
+    sh.n_next = 0;
+    c.loff_e[f] = link0;
+  }
   for (int i = tid; i < cap_tokens; i += kBlock) { N_cost[i] = kEncMax; X[i] = kLabelNone; }
   for (int i = tid; i < kFH; i += kBlock) T_key[i] = kEmpty;
   for (int i = tid; i < kFH / 2; i += kBlock) reinterpret_cast<unsigned *>(T_tix)[i] = 0xFFFFFFFFu;
@@ -339,7 +366,21 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
         const int pos1 = wave_append(q1, &fs.n_wl[1]);
         if (q1) { if (pos1 < kFW) wl[kFW + pos1] = (unsigned short)idx; else abort_now(kFaWl); }
       }
-      if (mk && !claimed) { for (int spin = 0;; spin++) { const unsigned short t = lds_ld16(&T_tix[slot]); if (t != 0xFFFFu) { idx = t; break; } if (spin > (1 << 22)) { sh.err = K3_ERR_HIP; idx = 0; break; } __builtin_amdgcn_s_sleep(1); } }
+      if (mk && !claimed) {
+        for (int spin = 0;; spin++) {
+          const unsigned short t = lds_ld16(&T_tix[slot]);
+          if (t != 0xFFFFu) {
+            idx = t;
+            break;
+          }
+          if (spin > (1 << 22)) {
+            sh.err = K3_ERR_HIP;
+            idx = 0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
       if (mk) { k3a_min(&N_cost[idx], enc(tot)); k3a_min(&X[idx], (unsigned)(jbase + j)); }
       const long long pos = wave_append64(mk, &sh.n_link);
       if (mk) {
@@ -357,7 +398,14 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   const int n_e = sh.n_next; const long long eps_l0 = sh.n_link;
   K3_FP(2);
   if (tid == 0) { c.loff_n[f + 1] = eps_l0; c.st_ntoks[f] = n_cur; c.st_cur[f] = cur_cutoff; c.st_ab[f] = ab; c.st_next[f] = accept; c.st_co[f] = co; }
-  for (int i = tid; i < cap_tokens; i += kBlock) { if (i < n_e) { c0[i] = dec(N_cost[i]); lab16[i] = (unsigned short)X[i]; } X[i] = kEncMax; }      // X: creation labels -> "expanded at" costs
+  // X: creation labels -> "expanded at" costs
+  for (int i = tid; i < cap_tokens; i += kBlock) {
+    if (i < n_e) {
+      c0[i] = dec(N_cost[i]);
+      lab16[i] = (unsigned short)X[i];
+    }
+    X[i] = kEncMax;
+  }
   __syncthreads();
   K3_FP(3);
   // ---- ProcessNonemitting (:830-897): the order-free fixpoint of finish_frame on token indices; every epsilon link also stays in LDS
@@ -372,7 +420,14 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
         const int i = i0 + tid; int ti = 0, beg = 0, deg = 0; unsigned cb = 0u;
         if (i < n) {
           ti = wl_cur[i]; cb = lds_ld(&N_cost[ti]);
-          if (dec(cb) < cutoff) { const unsigned prev = k3a_exch(&X[ti], cb); if (prev != cb) { beg = (int)(N_abeg[ti] + N_ne[ti]); deg = (int)N_nn[ti]; } }      // a token is expanded once per cost value
+          // a token is expanded once per cost value
+          if (dec(cb) < cutoff) {
+            const unsigned prev = k3a_exch(&X[ti], cb);
+            if (prev != cb) {
+              beg = (int)(N_abeg[ti] + N_ne[ti]);
+              deg = (int)N_nn[ti];
+            }
+          }
         }
         wave_expand(p.arcs, beg, deg, [&](bool valid, int arc, int owner, const ArcRec &r) {
           const unsigned ocb = __shfl(cb, owner); const int oti = __shfl(ti, owner); const float oc = dec(ocb);
@@ -398,10 +453,28 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
             else { c.tok_state[nb + idx] = nxt; oa = p.offs[nxt]; ob = p.offs[nxt + 1]; }
             __hip_atomic_store(&T_tix[slot], (unsigned short)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
-          if (mk && !claimed) { for (int spin = 0;; spin++) { const unsigned short t = lds_ld16(&T_tix[slot]); if (t != 0xFFFFu) { idx = t; break; } if (spin > (1 << 22)) { sh.err = K3_ERR_HIP; idx = 0; break; } __builtin_amdgcn_s_sleep(1); } }
+          if (mk && !claimed) {
+            for (int spin = 0;; spin++) {
+              const unsigned short t = lds_ld16(&T_tix[slot]);
+              if (t != 0xFFFFu) {
+                idx = t;
+                break;
+              }
+              if (spin > (1 << 22)) {
+                sh.err = K3_ERR_HIP;
+                idx = 0;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
           if (mk) {
             const unsigned e = enc(tot); const unsigned old = k3a_min(&N_cost[idx], e);
-            if (e < old && r.next < 0) { const unsigned bit = 1u << (idx & 31); push = (k3a_or(&marks[((round + 1) % 3) * (kFT / 32) + (idx >> 5)], bit) & bit) == 0; }      // only tokens whose state has eps arcs are queued, once per round
+            // only tokens whose state has eps arcs are queued, once per round
+            if (e < old && r.next < 0) {
+              const unsigned bit = 1u << (idx & 31);
+              push = (k3a_or(&marks[((round + 1) % 3) * (kFT / 32) + (idx >> 5)], bit) & bit) == 0;
+            }
           }
           const int pos = wave_append(push, n_nxt);
           if (push) { if (pos < kFW) wl_nxt[pos] = (unsigned short)idx; else fail(kFaWl); }
@@ -437,8 +510,11 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   // ---- closure sub-graph from the live links (made at their source's FINAL cost), in closure-id space
   unsigned *rown = reinterpret_cast<unsigned *>(arena + oRown), *rflag = reinterpret_cast<unsigned *>(arena + oRflag), *srcbit = reinterpret_cast<unsigned *>(arena + oSrcbit);
   unsigned short *cid = reinterpret_cast<unsigned short *>(arena + oCid), *lead = reinterpret_cast<unsigned short *>(arena + oLead);
-  unsigned *AR_arc = reinterpret_cast<unsigned *>(arena + oAR_arc); unsigned short *AR_dst = reinterpret_cast<unsigned short *>(arena + oAR_dst); float *AR_w = reinterpret_cast<float *>(arena + oAR_w);
-  unsigned short *m_abeg = reinterpret_cast<unsigned short *>(arena + oM_abeg), *m_pc = reinterpret_cast<unsigned short *>(arena + oM_pc), *c2t = reinterpret_cast<unsigned short *>(arena + oC2t);
+  unsigned *AR_arc = reinterpret_cast<unsigned *>(arena + oAR_arc);
+  unsigned short *AR_dst = reinterpret_cast<unsigned short *>(arena + oAR_dst);
+  float *AR_w = reinterpret_cast<float *>(arena + oAR_w);
+  unsigned short *m_abeg = reinterpret_cast<unsigned short *>(arena + oM_abeg), *m_pc = reinterpret_cast<unsigned short *>(arena + oM_pc),
+      *c2t = reinterpret_cast<unsigned short *>(arena + oC2t);
   float *rcost = reinterpret_cast<float *>(arena + oRcost);
   for (int i = tid; i < n; i += kBlock) rown[i] = 0u;
   for (int i = tid; i < kFT / 32; i += kBlock) { rflag[i] = 0u; srcbit[i] = 0u; }
@@ -453,18 +529,28 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
                                      [&](int i, int4 ex) {
                                        const int pc = (int)rown[i];
                                        cid[i] = (unsigned short)ex.x; lead[i] = (unsigned short)ex.y;
-                                       if ((pc > 0 || (rflag[i >> 5] >> (i & 31) & 1u)) && ex.x < kFC) { m_abeg[ex.x] = (unsigned short)ex.y; m_pc[ex.x] = (unsigned short)pc; c2t[ex.x] = (unsigned short)i; }
+                                       if ((pc > 0 || (rflag[i >> 5] >> (i & 31) & 1u)) && ex.x < kFC) {
+                                         m_abeg[ex.x] = (unsigned short)ex.y;
+                                         m_pc[ex.x] = (unsigned short)pc;
+                                         c2t[ex.x] = (unsigned short)i;
+                                       }
                                        if (pc > 0) k3a_or(&srcbit[i >> 5], 1u << (i & 31));
                                      }, n, red4);
   const int n_cid = tot2.x, n_arc = tot2.y;
   if (n_cid > kFC || n_arc > kFA) { if (tid == 0) fs.reason = kFaClosure; return -1; }      // (uniform)
   for (int l = tid; l < n_el; l += kBlock) {
     const int s_ = E_src[l];
-    if (E_stamp[l] == N_cost[s_]) { const int pos = (int)lead[s_] + (int)k3a_add(&rown[s_], 0xFFFFFFFFu) - 1; AR_arc[pos] = E_arc[l]; AR_dst[pos] = cid[E_dst[l]]; AR_w[pos] = E_w[l]; }
+    if (E_stamp[l] == N_cost[s_]) {
+      const int pos = (int)lead[s_] + (int)k3a_add(&rown[s_], 0xFFFFFFFFu) - 1;
+      AR_arc[pos] = E_arc[l];
+      AR_dst[pos] = cid[E_dst[l]];
+      AR_w[pos] = E_w[l];
+    }
   }
   __syncthreads();
   unsigned *par = reinterpret_cast<unsigned *>(arena + oPar);
-  unsigned short *croots = reinterpret_cast<unsigned short *>(arena + oCroots), *ccreated = reinterpret_cast<unsigned short *>(arena + oCcreated), *carcs = reinterpret_cast<unsigned short *>(arena + oCarcs),
+  unsigned short *croots = reinterpret_cast<unsigned short *>(arena + oCroots), *ccreated = reinterpret_cast<unsigned short *>(arena + oCcreated),
+      *carcs = reinterpret_cast<unsigned short *>(arena + oCarcs),
                  *ccurs = reinterpret_cast<unsigned short *>(arena + oCcurs);
   // a source's passing arcs in FST order (ascending arc index); the replay's starting costs (the costs right after ProcessEmitting; +inf: not created yet)
   for (int cc = tid; cc < n_cid; cc += kBlock) {
@@ -480,7 +566,8 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   K3_FP(5);
   // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made
   unsigned short *ord1 = reinterpret_cast<unsigned short *>(arena + oOrd1);
-  fast_hash_order(sh, n_e, m_e, lab16, B16, reinterpret_cast<unsigned *>(arena + oO1_btab), reinterpret_cast<unsigned *>(arena + oO1_bm), reinterpret_cast<unsigned short *>(arena + oO1_wpre),
+  fast_hash_order(sh, n_e, m_e, lab16, B16, reinterpret_cast<unsigned *>(arena + oO1_btab), reinterpret_cast<unsigned *>(arena + oO1_bm),
+      reinterpret_cast<unsigned short *>(arena + oO1_wpre),
                   reinterpret_cast<unsigned short *>(arena + oO1_lead), reinterpret_cast<unsigned short *>(arena + oO1_grp), reinterpret_cast<unsigned short *>(arena + oO1_curs),
                   [&](int r, int i, int) { ord1[r] = (unsigned short)i; });
   K3_FP(6);
@@ -490,11 +577,19 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
                                      [&](int r, int ex) { const int i = ord1[r]; if ((srcbit[i >> 5] >> (i & 31) & 1u) && ex < kFQ) iq[ex] = cid[i]; }, n_e, sh.redi);
   if (n_iq > kFQ) { if (tid == 0) fs.reason = kFaQueue; return -1; }
   // ---- replay of the LIFO queue by connected components (oracle mode 4; lit_replay_components with 16-bit LDS records)
-  unsigned short *ox = reinterpret_cast<unsigned short *>(arena + oOx), *oy = reinterpret_cast<unsigned short *>(arena + oOy), *oz = reinterpret_cast<unsigned short *>(arena + oOz), *ow = reinterpret_cast<unsigned short *>(arena + oOw);
-  unsigned short *rlist = reinterpret_cast<unsigned short *>(arena + oRlist), *rinfo = reinterpret_cast<unsigned short *>(arena + oRinfo), *rtmp = reinterpret_cast<unsigned short *>(arena + oRtmp);
-  unsigned short *wrec = reinterpret_cast<unsigned short *>(arena + oWrec), *stack = reinterpret_cast<unsigned short *>(arena + oStack), *clist = reinterpret_cast<unsigned short *>(arena + oClist);
+  unsigned short *ox = reinterpret_cast<unsigned short *>(arena + oOx), *oy = reinterpret_cast<unsigned short *>(arena + oOy),
+      *oz = reinterpret_cast<unsigned short *>(arena + oOz), *ow = reinterpret_cast<unsigned short *>(arena + oOw);
+  unsigned short *rlist = reinterpret_cast<unsigned short *>(arena + oRlist), *rinfo = reinterpret_cast<unsigned short *>(arena + oRinfo),
+      *rtmp = reinterpret_cast<unsigned short *>(arena + oRtmp);
+  unsigned short *wrec = reinterpret_cast<unsigned short *>(arena + oWrec), *stack = reinterpret_cast<unsigned short *>(arena + oStack),
+      *clist = reinterpret_cast<unsigned short *>(arena + oClist);
   for (int cc = tid; cc < n_cid; cc += kBlock) par[cc] = (unsigned)cc;
-  for (int i = tid; i < n_cid / 2 + 1; i += kBlock) { reinterpret_cast<unsigned *>(croots)[i] = 0u; reinterpret_cast<unsigned *>(ccreated)[i] = 0u; reinterpret_cast<unsigned *>(carcs)[i] = 0u; reinterpret_cast<unsigned *>(ccurs)[i] = 0u; }
+  for (int i = tid; i < n_cid / 2 + 1; i += kBlock) {
+    reinterpret_cast<unsigned *>(croots)[i] = 0u;
+    reinterpret_cast<unsigned *>(ccreated)[i] = 0u;
+    reinterpret_cast<unsigned *>(carcs)[i] = 0u;
+    reinterpret_cast<unsigned *>(ccurs)[i] = 0u;
+  }
   __syncthreads();
   auto find = [&](int x) { for (;;) { const int q_ = (int)lds_ld(&par[x]); if (q_ == x) return x; x = q_; } };
   for (int cc = tid; cc < n_cid; cc += kBlock) {
@@ -513,12 +608,27 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   for (int k = tid; k < n_iq; k += kBlock) add16(croots, find(iq[k]), 1u);
   __syncthreads();
   const int4 tot = block_excl_scan4([&](int cc) { const int rr = croots[cc]; return make_int4(rr, (int)ccreated[cc], (int)carcs[cc], rr > 0 ? 1 : 0); },
-                                    [&](int cc, int4 ex) { ox[cc] = (unsigned short)ex.x; oy[cc] = (unsigned short)ex.y; oz[cc] = (unsigned short)ex.z; ow[cc] = (unsigned short)ex.w; }, n_cid, red4);
+                                    [&](int cc, int4 ex) {
+                                      ox[cc] = (unsigned short)ex.x;
+                                      oy[cc] = (unsigned short)ex.y;
+                                      oz[cc] = (unsigned short)ex.z;
+                                      ow[cc] = (unsigned short)ex.w;
+                                    },
+                                    n_cid, red4);
   const int n_workers = tot.w;
   bool multi = false;
   for (int k = tid; k < n_iq; k += kBlock) {      // a component's roots in queue order (the queue is consumed from its back: descending k)
     const int e = iq[k]; const int r = (int)par[e]; const int nr = croots[r];
-    if (nr == 1) { rlist[2 * ox[r]] = (unsigned short)k; rlist[2 * ox[r] + 1] = (unsigned short)e; unsigned short *w = wrec + 5 * ow[r]; w[0] = ox[r]; w[1] = 1; w[2] = oy[r]; w[3] = oz[r]; w[4] = carcs[r]; }
+    if (nr == 1) {
+      rlist[2 * ox[r]] = (unsigned short)k;
+      rlist[2 * ox[r] + 1] = (unsigned short)e;
+      unsigned short *w = wrec + 5 * ow[r];
+      w[0] = ox[r];
+      w[1] = 1;
+      w[2] = oy[r];
+      w[3] = oz[r];
+      w[4] = carcs[r];
+    }
     else { multi = true; const unsigned pos = add16(ccurs, r, 1u); rtmp[ox[r] + pos] = (unsigned short)k; }
   }
   multi = __syncthreads_or(multi);
@@ -542,7 +652,11 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   K3_FP(7);
   // creation labels: roots in queue order (j-th root processed = position n_iq - 1 - j), tokens of a root in the order it created them
   const int created = block_excl_scan_f([&](int j) { return (int)rinfo[2 * (n_iq - 1 - j) + 1]; }, [&](int j, int ex) { dense[j] = (unsigned short)ex; }, n_iq, sh.redi);
-  if (n_e + created != n) { if (tid == 0) fs.reason = kFaMismatch; return -1; }      // every token of the fixpoint must have been created by the replay (the general path re-checks)
+  // every token of the fixpoint must have been created by the replay (the general path re-checks)
+  if (n_e + created != n) {
+    if (tid == 0) fs.reason = kFaMismatch;
+    return -1;
+  }
   for (int j = tid; j < n_iq; j += kBlock) {
     const int seg0 = rinfo[2 * (n_iq - 1 - j)], cnt = rinfo[2 * (n_iq - 1 - j) + 1]; const unsigned base = m_e + (unsigned)dense[j];
     for (int t = 0; t < cnt; t++) lab16[c2t[clist[seg0 + t]]] = (unsigned short)(base + (unsigned)t);
@@ -550,7 +664,8 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   __syncthreads();
   K3_FP(8);
   // ---- the frame's final HashList order = the next frame's visit order, written where the next frame reads it; creation order for the final-frame sweeps
-  fast_hash_order(sh, n, m_e + (unsigned)created, lab16, B16, reinterpret_cast<unsigned *>(arena + oO2_btab), reinterpret_cast<unsigned *>(arena + oO2_bm), reinterpret_cast<unsigned short *>(arena + oO2_wpre),
+  fast_hash_order(sh, n, m_e + (unsigned)created, lab16, B16, reinterpret_cast<unsigned *>(arena + oO2_btab), reinterpret_cast<unsigned *>(arena + oO2_bm),
+      reinterpret_cast<unsigned short *>(arena + oO2_wpre),
                   reinterpret_cast<unsigned short *>(arena + oO2_lead), reinterpret_cast<unsigned short *>(arena + oO2_grp), reinterpret_cast<unsigned short *>(arena + oO2_curs),
                   [&](int r, int i, int d) { V_cost[r] = N_cost[i]; V_abeg[r] = N_abeg[i]; V_ne[r] = N_ne[i]; V_tok[r] = (unsigned short)i; ord_nxt[r] = i; q.by_ins[d] = i; });
   K3_FP(9);

@@ -20,7 +20,9 @@
 // Capacities: frame_tokens_cap <= 65536; arcs expanded + tokens created on one frame <= 32 * seq_words_cap.
 
 constexpr int kRN = kHL / 2, kRA = 2048, kRS = 1024;      // replay fully in LDS: closure ids (cost + meta alias the level-1 table: kHL x 12 B) / passing arcs / stack entries
-constexpr size_t kLitDynLds = (size_t)kRA * 8 + (size_t)kRS * 4;      // (the hash-order passes use the same segment between replays: kHoLds below)      // replay in LDS: tokens / closure arcs / stack entries of a frame (larger frames: HBM scratch)
+// (the hash-order passes use the same segment between replays: kHoLds below)      // replay in LDS: tokens / closure arcs / stack entries of a frame (larger
+// frames: HBM scratch)
+constexpr size_t kLitDynLds = (size_t)kRA * 8 + (size_t)kRS * 4;
 constexpr unsigned kLabelNone = 0xFFFFFFFFu;
 enum { kRfHasEps = 1, kRfExists = 2 };
 
@@ -167,7 +169,12 @@ __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int 
 }
 
 struct LitLane {      // this lane's slices of the literal_order scratch
-  int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack; unsigned *label, *lead, *bm, *wpre, *cmin; float *c0, *cw, *rcost; int2 *crng, *arcs2; int4 *meta; int *iq, *c2t;
+  int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack;
+  unsigned *label, *lead, *bm, *wpre, *cmin;
+  float *c0, *cw, *rcost;
+  int2 *crng, *arcs2;
+  int4 *meta;
+  int *iq, *c2t;
   int *par, *rtmp; int2 *rlist, *rinfo; int4 *cinfo, *coffs, *wrec;      // component replay (below)
   int4 *btab;     // bucket table of the hash-order pass of large frames
   int4 *vis;      // per visit position of the frame being expanded: (token, cost, first emitting arc, emitting arcs)
@@ -179,7 +186,15 @@ struct LitLane {      // this lane's slices of the literal_order scratch
     cmin = at(p.lt_cmin); ccnt = at(p.lt_ccnt); c0 = at(p.lt_c0); crng = at(p.lt_crng); (void)nch;
     cdst = at(p.lt_cdst); cw = at(p.lt_cw); rcost = at(p.lt_rcost); rflag = at(p.lt_rflag); rown = at(p.lt_rown);
     stack = at(p.lt_stack); arcs2 = at(p.lt_arcs2); iq = at(p.lt_iq); meta = at(p.lt_meta); c2t = at(p.lt_c2t);
-    par = at(p.lt_par); rtmp = at(p.lt_rtmp); rlist = at(p.lt_rlist); wrec = at(p.lt_wrec); cinfo = at(p.lt_cinfo); coffs = at(p.lt_coffs); rinfo = at(p.lt_rinfo); vis = at(p.lt_vis); btab = at(p.lt_btab);
+    par = at(p.lt_par);
+    rtmp = at(p.lt_rtmp);
+    rlist = at(p.lt_rlist);
+    wrec = at(p.lt_wrec);
+    cinfo = at(p.lt_cinfo);
+    coffs = at(p.lt_coffs);
+    rinfo = at(p.lt_rinfo);
+    vis = at(p.lt_vis);
+    btab = at(p.lt_btab);
   }
 };
 
@@ -204,13 +219,19 @@ __device__ K3_COLD_INLINE void lit_hash_order(const LitLane &q, Shared &sh, int 
     const int d = (int)(q.wpre[l >> 5] + (unsigned)__popc(wd & ((1u << (l & 31)) - 1u)));
     q.dense[i] = d; q.by_ins[d] = i;
     const unsigned b = (unsigned)st[i] % hash_size; unsigned h = (b * 2654435761u) & tmask;
-    for (;;) { unsigned *key = reinterpret_cast<unsigned *>(&tab[h]); const unsigned old = k3a_cas(key, 0xFFFFFFFFu, b); if (old == 0xFFFFFFFFu || old == b) break; h = (h + 1) & tmask; }
+    for (;;) {
+      unsigned *key = reinterpret_cast<unsigned *>(&tab[h]);
+      const unsigned old = k3a_cas(key, 0xFFFFFFFFu, b);
+      if (old == 0xFFFFFFFFu || old == b) break;
+      h = (h + 1) & tmask;
+    }
     slot_of[i] = (int)h;
     unsigned *rec = reinterpret_cast<unsigned *>(&tab[h]); k3a_min(&rec[1], (unsigned)d); k3a_add(&rec[2], 1u);
   }
   __syncthreads();
   K3_LS(2);
-  block_excl_scan([&](int d) { const unsigned *rec = reinterpret_cast<const unsigned *>(&tab[slot_of[q.by_ins[d]]]); return K3_ALD(&rec[1]) == (unsigned)d ? K3_ALD(&rec[2]) : 0u; }, q.lead, n, sh.redi);
+  block_excl_scan([&](int d) { const unsigned *rec = reinterpret_cast<const unsigned *>(&tab[slot_of[q.by_ins[d]]]); return K3_ALD(&rec[1]) == (unsigned)d ?
+      K3_ALD(&rec[2]) : 0u; }, q.lead, n, sh.redi);
   K3_LS(3);
   for (int i = tid; i < n; i += kBlock) {
     unsigned *rec = reinterpret_cast<unsigned *>(&tab[slot_of[i]]);
@@ -244,7 +265,8 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
   static_assert(kHoN <= 4 * kBlock && kHoM / 32 <= kBlock && 2 * kHoN <= kHL, "one pass per phase; table at most half full");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
   const int W = (int)((M + 31u) >> 5);
-  unsigned *s_bm = reinterpret_cast<unsigned *>(arena); unsigned short *s_wpre = reinterpret_cast<unsigned short *>(s_bm + kHoM / 32), *s_lead = s_wpre + kHoM / 32, *s_grp = s_lead + kHoN;
+  unsigned *s_bm = reinterpret_cast<unsigned *>(arena);
+  unsigned short *s_wpre = reinterpret_cast<unsigned short *>(s_bm + kHoM / 32), *s_lead = s_wpre + kHoM / 32, *s_grp = s_lead + kHoN;
   unsigned *b_key = reinterpret_cast<unsigned *>(tab), *b_first = b_key + kHL, *b_cnt = b_first + kHL;
   unsigned lab[4], bkt[4], lf[4], cnt[4]; int d[4], slot[4];
   for (int i = tid; i < kHL; i += kBlock) { b_key[i] = 0xFFFFFFFFu; b_first[i] = 0xFFFFFFFFu; b_cnt[i] = 0u; }
@@ -282,7 +304,15 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
   K3_LS(2);
   bool multi = false;
 #pragma unroll
-  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { lf[k] = b_first[slot[k]]; cnt[k] = b_cnt[slot[k]]; s_lead[d[k]] = lf[k] == (unsigned)d[k] ? (unsigned short)cnt[k] : (unsigned short)0; multi |= cnt[k] > 1u; } }
+  for (int k = 0; k < 4; k++) {
+    const int i = tid + k * kBlock;
+    if (i < n) {
+      lf[k] = b_first[slot[k]];
+      cnt[k] = b_cnt[slot[k]];
+      s_lead[d[k]] = lf[k] == (unsigned)d[k] ? (unsigned short)cnt[k] : (unsigned short)0;
+      multi |= cnt[k] > 1u;
+    }
+  }
   multi = __syncthreads_or(multi);
   {      // exclusive scan of the leaders' bucket sizes in creation order, in place (4 consecutive ranks per thread)
     const int b0 = tid * 4; int x[4], sum = 0;
@@ -300,7 +330,13 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
   K3_LS(3);
   if (multi) {      // buckets with several tokens: their members' ranks, grouped behind the leader's offset (b_first now counts up from the leader's rank: a cursor)
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n && cnt[k] > 1u) { const unsigned s_ = atomicAdd(&b_first[slot[k]], 1u) - lf[k]; s_grp[s_lead[lf[k]] + s_] = (unsigned short)d[k]; } }
+    for (int k = 0; k < 4; k++) {
+      const int i = tid + k * kBlock;
+      if (i < n && cnt[k] > 1u) {
+        const unsigned s_ = atomicAdd(&b_first[slot[k]], 1u) - lf[k];
+        s_grp[s_lead[lf[k]] + s_] = (unsigned short)d[k];
+      }
+    }
     __syncthreads();
   }
   K3_LS(4);
@@ -326,12 +362,15 @@ constexpr size_t kLitTabBytes = (size_t)3 * kHL * 4, kLitMarkBytes = (size_t)3 *
 // dead at both call sites.  Returns false when the frame does not fit (the caller takes lit_hash_order).
 constexpr int kHmN = 3072, kHmM = 32768, kHmB = 4096;
 constexpr size_t kHmLds = (size_t)kHmB * 4 + 7 * ((size_t)kHmN * 2 + 8) + (size_t)kHmM / 8 + (size_t)kHmM / 32 * 2;
-__device__ K3_COLD_INLINE bool lit_hash_order_mid(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins) {
+__device__ K3_COLD_INLINE bool lit_hash_order_mid(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size,
+    int *order_out, bool write_by_ins) {
   if (n > kHmN || M > (unsigned)kHmM || hash_size > 65535u) return false;
   const int tid = threadIdx.x; const int W = (int)((M + 31u) >> 5);
   unsigned *btab = reinterpret_cast<unsigned *>(arena); char *a_ = arena + (size_t)kHmB * 4; constexpr size_t kCol = (size_t)kHmN * 2 + 8;
-  unsigned short *lab16 = reinterpret_cast<unsigned short *>(a_), *bkt16 = reinterpret_cast<unsigned short *>(a_ + kCol), *dense16 = reinterpret_cast<unsigned short *>(a_ + 2 * kCol),
-                 *lf16 = reinterpret_cast<unsigned short *>(a_ + 3 * kCol), *lead = reinterpret_cast<unsigned short *>(a_ + 4 * kCol), *grp = reinterpret_cast<unsigned short *>(a_ + 5 * kCol),
+  unsigned short *lab16 = reinterpret_cast<unsigned short *>(a_), *bkt16 = reinterpret_cast<unsigned short *>(a_ + kCol),
+      *dense16 = reinterpret_cast<unsigned short *>(a_ + 2 * kCol),
+                 *lf16 = reinterpret_cast<unsigned short *>(a_ + 3 * kCol), *lead = reinterpret_cast<unsigned short *>(a_ + 4 * kCol),
+                     *grp = reinterpret_cast<unsigned short *>(a_ + 5 * kCol),
                  *curs = reinterpret_cast<unsigned short *>(a_ + 6 * kCol);
   unsigned *bm = reinterpret_cast<unsigned *>(a_ + 7 * kCol); unsigned short *wpre = reinterpret_cast<unsigned short *>(a_ + 7 * kCol + (size_t)kHmM / 8);
   for (int i = tid; i < kHmB; i += kBlock) btab[i] = 0xFFFFFFFFu;
@@ -391,10 +430,12 @@ struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 // Global memory sees streams plus, per token, the record store, the leader's size (one store per bucket), one load of the leader's offset and the result.
 // Returns false when a partition does not fit (the caller takes lit_hash_order): the result is then untouched.
 constexpr int kHbT = 4096, kHbW = 1024, kHbPart = 1536, kHbMaxPart = 2048, kHbMaxP = 64;
-constexpr size_t kHbLdsA = (size_t)kHbW * 4 + (size_t)kHbW * 2, kHbLdsB = (size_t)kHbT * 12 + (size_t)kHbT * 2 + (size_t)kHbMaxPart * 2, kHbLdsP = kHbLdsB > kHbLdsA ? kHbLdsB : kHbLdsA;
+constexpr size_t kHbLdsA = (size_t)kHbW * 4 + (size_t)kHbW * 2, kHbLdsB = (size_t)kHbT * 12 + (size_t)kHbT * 2 + (size_t)kHbMaxPart * 2,
+    kHbLdsP = kHbLdsB > kHbLdsA ? kHbLdsB : kHbLdsA;
 static_assert(kHbLdsP + 2 * kHbMaxP * 4 <= kLitGeneralLds, "the large-frame hash order works in the general path's arena");
 static_assert(kHbMaxPart <= 4 * kBlock, "a partition's records fit the registers of one pass");
-__device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins,
+__device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size,
+    int *order_out, bool write_by_ins,
                                                   long long &lt_last__) {
   const int tid = threadIdx.x;
   int *dense = q.dense, *bkt = q.grp, *lr = q.rtmp; unsigned *lead = q.lead; int2 *rec = q.rlist;
@@ -455,12 +496,19 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; b[k] = 0; d[k] = 0; if (i < n) { b[k] = bkt[i]; d[k] = dense[i]; } }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; if (i < n) { const int pos = k3a_add(&pcnt[part_of((unsigned)b[k] * 2654435761u)], 1); rec[pos] = make_int2(b[k], (int)(((unsigned)d[k] << 16) | (unsigned)i)); } }
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + k * kBlock;
+      if (i < n) {
+        const int pos = k3a_add(&pcnt[part_of((unsigned)b[k] * 2654435761u)], 1);
+        rec[pos] = make_int2(b[k], (int)(((unsigned)d[k] << 16) | (unsigned)i));
+      }
+    }
   }
   __syncthreads();
   K3_LS(1);
   // ---- buckets, partition by partition
-  unsigned *key = reinterpret_cast<unsigned *>(arena), *mind = key + kHbT, *cnt = mind + kHbT; unsigned short *moff = reinterpret_cast<unsigned short *>(cnt + kHbT), *mem = moff + kHbT;
+  unsigned *key = reinterpret_cast<unsigned *>(arena), *mind = key + kHbT, *cnt = mind + kHbT;
+  unsigned short *moff = reinterpret_cast<unsigned short *>(cnt + kHbT), *mem = moff + kHbT;
   for (int pt = 0; pt < P; pt++) {
     const int pb = pbase[pt], np_ = (pt + 1 < P ? pbase[pt + 1] : n) - pb;
     int2 r_[4]; unsigned slot[4];
@@ -472,12 +520,18 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
     for (int k = 0; k < 4; k++) {      // the partition's buckets: {key, smallest creation rank, members}
       if (tid + k * kBlock < np_) {
         const unsigned b = (unsigned)r_[k].x; unsigned s_ = start_of(b * 2654435761u);
-        for (;;) { const unsigned old = k3a_cas(&key[s_], 0xFFFFFFFFu, b); if (old == 0xFFFFFFFFu || old == b) break; s_ = (s_ + 1) & (unsigned)(kHbT - 1); }      // (<= 2048 keys in 4096 slots: always ends)
+        // (<= 2048 keys in 4096 slots: always ends)
+        for (;;) {
+          const unsigned old = k3a_cas(&key[s_], 0xFFFFFFFFu, b);
+          if (old == 0xFFFFFFFFu || old == b) break;
+          s_ = (s_ + 1) & (unsigned)(kHbT - 1);
+        }
         slot[k] = s_; k3a_min(&mind[s_], (unsigned)r_[k].y >> 16); k3a_add(&cnt[s_], 1u);
       }
     }
     __syncthreads();
-    const int tm = block_excl_scan_f([&](int s_) { const unsigned c = cnt[s_]; return c > 1u ? (int)c : 0; }, [&](int s_, int ex) { moff[s_] = (unsigned short)ex; }, kHbT, sh.redi);
+    const int tm = block_excl_scan_f([&](int s_) { const unsigned c = cnt[s_]; return c > 1u ? (int)c : 0; },
+        [&](int s_, int ex) { moff[s_] = (unsigned short)ex; }, kHbT, sh.redi);
 #pragma unroll
     for (int k = 0; k < 4; k++) {      // the leader publishes its bucket's size; members of shared buckets line up behind their bucket's offset
       if (tid + k * kBlock < np_) {
@@ -493,7 +547,12 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
       for (int k = 0; k < 4; k++) {      // position inside a shared bucket = members created earlier
         if (tid + k * kBlock < np_) {
           const unsigned s_ = slot[k], d = (unsigned)r_[k].y >> 16, c = cnt[s_] & 0xFFFFu;
-          if (c > 1u) { const unsigned short *m_ = mem + moff[s_]; unsigned rank = 0; for (unsigned t = 0; t < c; t++) rank += (unsigned)m_[t] < d; lr[pb + tid + k * kBlock] = (int)((mind[s_] << 16) | rank); }
+          if (c > 1u) {
+            const unsigned short *m_ = mem + moff[s_];
+            unsigned rank = 0;
+            for (unsigned t = 0; t < c; t++) rank += (unsigned)m_[t] < d;
+            lr[pb + tid + k * kBlock] = (int)((mind[s_] << 16) | rank);
+          }
         }
       }
     }
@@ -586,7 +645,9 @@ __device__ __forceinline__ void lit_replay(float *rcost, const int4 *meta, const
         }
       } else {
         for (unsigned long long rest = okm; rest; rest &= rest - 1) {
-          const int jl = __ffsll((long long)rest) - 1; const int dj = __builtin_amdgcn_readlane(d, jl); const float tj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), jl));
+          const int jl = __ffsll((long long)rest) - 1;
+          const int dj = __builtin_amdgcn_readlane(d, jl);
+          const float tj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), jl));
           const float old = k3_uf(rcost[dj]);
           const bool isnew = old == kInf, changed = old > tj;
           if (isnew) { if (lane == 0) clist[created] = (unsigned)dj; created++; }
@@ -608,7 +669,11 @@ __device__ __forceinline__ void lit_replay(float *rcost, const int4 *meta, const
 // reads and writes only the costs of tokens it can reach, so cascades in different components commute.  Every component replays its own
 // roots in queue order on ONE THREAD with a stack of its own (hundreds of components per frame, the longest chain a dozen pops), and the
 // creation labels are handed out afterwards root by root in queue order by a prefix sum over the roots' creation counts.
-__device__ __forceinline__ int4 k3_ald4(const int4 *p_) { const int *w = reinterpret_cast<const int *>(p_); return make_int4(K3_ALD(&w[0]), K3_ALD(&w[1]), K3_ALD(&w[2]), K3_ALD(&w[3])); }      // words updated by atomics (at L2): not through the L1
+// words updated by atomics (at L2): not through the L1
+__device__ __forceinline__ int4 k3_ald4(const int4 *p_) {
+  const int *w = reinterpret_cast<const int *>(p_);
+  return make_int4(K3_ALD(&w[0]), K3_ALD(&w[1]), K3_ALD(&w[2]), K3_ALD(&w[3]));
+}
 template <typename P> __device__ __forceinline__ int uf_find(P par, int x) { for (;;) { const int q_ = K3_ALD(&par[x]); if (q_ == x) return x; x = q_; } }
 // lock-free union: the larger root hooks under the smaller one (parents only ever decrease: no cycles)
 template <typename P> __device__ __forceinline__ void uf_union(P par, int a, int b) {
@@ -731,7 +796,8 @@ __device__ __forceinline__ int lit_replay_components(const DecParams &p, const L
   K3_LS(11);
   for (int w = tid; w < n_workers; w += kBlock) {
     const int4 w0 = q.wrec[2 * w], w1 = q.wrec[2 * w + 1];
-    if (!lit_replay_component(rcost, meta, AR, clist, q.rlist, q.rinfo, q.stack + w0.w, p.literal == 3 ? 0 : w1.x, w0.x, w0.y, w0.z, accept)) *s_flag = 1;      // (literal_order = 3: no stack slices, a test hook for the fall-back)
+    // (literal_order = 3: no stack slices, a test hook for the fall-back)
+    if (!lit_replay_component(rcost, meta, AR, clist, q.rlist, q.rinfo, q.stack + w0.w, p.literal == 3 ? 0 : w1.x, w0.x, w0.y, w0.z, accept)) *s_flag = 1;
   }
   __syncthreads();
   K3_LS(12);
@@ -757,7 +823,8 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
   // never run at the same time and the general path re-initialises its table after a fast frame.
   extern __shared__ __attribute__((aligned(16))) char arena[];
   __shared__ Shared sh; __shared__ LitShared ls; __shared__ FastShared fs;
-  // A lane is a latency chain that issues in a sixth of its cycles; the workgroups that share its CU in the tail of a batch are the next batch's GEMMs, which would issue every cycle.
+  // A lane is a latency chain that issues in a sixth of its cycles; the workgroups that share its CU in the tail of a batch are the next batch's GEMMs, which
+  // would issue every cycle.
   // Raised priority lets the lane's few instructions go first (the GEMM loses nothing it could use: its MFMA work is fixed).
   __builtin_amdgcn_s_setprio(K3_LIT_BASE_PRIO);
   int *const s_tab = reinterpret_cast<int *>(arena);      // level-1 table {key, cost, token}; between the closure and the end of a frame: the replay's records
@@ -777,7 +844,8 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
   Slot *hash = p.hash + (long long)L * (p.hash_mask + 1);
   int *tok_slot = p.tok_slot + (long long)L * p.frame_tokens_cap, *wl = p.wl + 2ll * L * p.frame_tokens_cap;
   long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
-  int *st_ntoks = p.st_ntoks + L * p.fstride; float *st_cur = p.st_cur + L * p.fstride, *st_ab = p.st_ab + L * p.fstride, *st_next = p.st_next + L * p.fstride, *st_co = p.st_co + L * p.fstride;
+  int *st_ntoks = p.st_ntoks + L * p.fstride;
+  float *st_cur = p.st_cur + L * p.fstride, *st_ab = p.st_ab + L * p.fstride, *st_next = p.st_next + L * p.fstride, *st_co = p.st_co + L * p.fstride;
   const unsigned mask = (unsigned)p.hash_mask; const float kInf = __builtin_inff(); const int cap = p.frame_tokens_cap;
   const LitLane q(p, L);
   LaneCtx lc{tok_state, tok_cost, links, link_arc, tok_off, loff_e, loff_n, st_ntoks, st_cur, st_ab, st_next, st_co, lp.tcap, lp.lcap};
@@ -791,7 +859,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     return true;
   };
   long long cyc_fast = 0, cyc_general = 0, cyc_t0 = 0;
-  int n_fast = 0, n_gaveup = 0, n_general = 0; int why[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (thread 0: frames by path, reasons of the fast path's give-ups; k3_decoder_phase_cycles reads them)
+  // (thread 0: frames by path, reasons of the fast path's give-ups; k3_decoder_phase_cycles reads them)
+  int n_fast = 0, n_gaveup = 0, n_general = 0;
+  int why[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool v_valid = false, lds_dirty = false;      // the visit-order arrays of the fast path hold the current frame / the arena was used by a fast frame
   if (tid < 16) sh.prof[tid] = 0;
   if (tid < 12) fs.prof[tid] = 0;
@@ -829,7 +899,12 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     const LaneInfo &li = p.info[L];
     if (li.status != kStOk) return;
     f0 = li.num_frames; cur_base = li.cur_base; n_cur = li.n_cur; max_frame = li.max_frame_tokens; sel = li.order_sel; hash_size = (unsigned)li.hash_size;
-    if (tid == 0) { sh.n_link = li.n_links; sh.n_eps = (unsigned long long)li.n_eps; sh.n_emit = (unsigned long long)li.n_cands; sh.n_os = (unsigned long long)li.n_order_sensitive; }
+    if (tid == 0) {
+      sh.n_link = li.n_links;
+      sh.n_eps = (unsigned long long)li.n_eps;
+      sh.n_emit = (unsigned long long)li.n_cands;
+      sh.n_os = (unsigned long long)li.n_order_sensitive;
+    }
     __syncthreads();
   }
 
@@ -908,7 +983,12 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       unsigned n0 = kEncMax;
       {
         const int2 a = p.offs[best_state];
-        for (int arc = a.x + tid; arc < a.y; arc += kBlock) { const ArcRec r = p.arcs[arc]; const float nw_ = r.w + co - ll[r.pdf] + best; const unsigned e = enc(nw_ + ab); n0 = e < n0 ? e : n0; }
+        for (int arc = a.x + tid; arc < a.y; arc += kBlock) {
+          const ArcRec r = p.arcs[arc];
+          const float nw_ = r.w + co - ll[r.pdf] + best;
+          const unsigned e = enc(nw_ + ab);
+          n0 = e < n0 ? e : n0;
+        }
       }
       n0 = (unsigned)(block_min_u64((unsigned long long)n0, sh) & 0xFFFFFFFFull);
       const float next0 = n0 == kEncMax ? kInf : dec(n0);
@@ -928,7 +1008,8 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       };
       for (int c = wave; c < nchunks; c += nw) {
         int i, beg, deg; float cost; chunk_tokens(c, i, cost, beg, deg);
-        if (64 * c + lane < n_cur) q.vis[64 * c + lane] = make_int4(i, __float_as_int(cost), beg, deg);      // pass B reads this instead of walking order -> token -> state -> offsets again
+        // pass B reads this instead of walking order -> token -> state -> offsets again
+        if (64 * c + lane < n_cur) q.vis[64 * c + lane] = make_int4(i, __float_as_int(cost), beg, deg);
         unsigned cm = kEncMax;
         const int total = wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int, int, int owner, const ArcRec &r) {
           const float oc = __shfl(cost, owner);
@@ -1057,12 +1138,20 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made (their labels and states are
     // untouched by the closure).  Computed here, where the level-1 table's LDS is free for the bucket table of the pass.
     if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, s_tab, lt_last__);
-    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) && (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__)))
+    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) &&
+        (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__)))
       lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
     K3_LT(6); K3_LQ(8);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
     const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
-                                       [&](int i, int4 ex) { q.grp[i] = ex.x; q.lead[i] = (unsigned)ex.y; if (csr_lds) l_cnt[i] = ex.y; else K3_AST(&q.rtmp[i], 0); }, n, reinterpret_cast<int4 *>(sh.hist));      // (LDS: the source's fill cursor starts at its first slot)
+                                       // (LDS: the source's fill cursor starts at its first slot)
+                                       [&](int i, int4 ex) {
+                                         q.grp[i] = ex.x;
+                                         q.lead[i] = (unsigned)ex.y;
+                                         if (csr_lds) l_cnt[i] = ex.y;
+                                         else K3_AST(&q.rtmp[i], 0);
+                                       },
+                                       n, reinterpret_cast<int4 *>(sh.hist));
     const int n_cid = tot2.x, n_arc = tot2.y;
     if (n_arc > p.eps_cap) { if (tid == 0) sh.err = K3_ERR_OVERFLOW; }
     if (block_err(sh)) break;
@@ -1070,7 +1159,12 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     int *ent_arc = q.cdst, *ent_dst = reinterpret_cast<int *>(q.cw);
     for (long long l = eps_l0 + tid; l < eps_l1; l += kBlock) {
       const Link k = links[l];
-      if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) { const int sl = (int)(k.src - nb); const int pos = csr_lds ? k3a_add(&l_cnt[sl], 1) : (int)q.lead[sl] + k3a_add(&q.rtmp[sl], 1); ent_arc[pos] = link_arc[l]; ent_dst[pos] = (int)(k.dst - nb); }
+      if (__float_as_uint(k.ac) == K3_ALD(&tok_cost[k.src])) {
+        const int sl = (int)(k.src - nb);
+        const int pos = csr_lds ? k3a_add(&l_cnt[sl], 1) : (int)q.lead[sl] + k3a_add(&q.rtmp[sl], 1);
+        ent_arc[pos] = link_arc[l];
+        ent_dst[pos] = (int)(k.dst - nb);
+      }
     }
     __syncthreads();
     K3_LQ(9);
@@ -1082,7 +1176,8 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     int4 *meta = rmode == 0 ? reinterpret_cast<int4 *>(s_tab) : q.meta;
     int2 *AR = rmode == 0 ? reinterpret_cast<int2 *>(smem_raw) : q.arcs2;
     int *par = rmode == 0 ? s_aux : q.par;
-    const unsigned *clist = rmode == 0 ? reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN : rmode == 1 ? reinterpret_cast<unsigned *>(smem_raw) : reinterpret_cast<unsigned *>(q.rflag);
+    const unsigned *clist = rmode == 0 ? reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN : rmode == 1 ? reinterpret_cast<unsigned *>(smem_raw) :
+        reinterpret_cast<unsigned *>(q.rflag);
     if (tid == 0) ls.use_lds = 0;      // (the component replay's "take the serial replay" flag)
     // step 2: per involved token its record (and its component-replay cells: own parent, zero counters), per source its passing arcs compacted in
     // FST order.  kSB tokens per thread in flight (the kernel has 128 registers per thread: more would spill).
@@ -1090,11 +1185,27 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     for (int ib = tid; ib < n; ib += kSB * kBlock) {
       int pc4[kSB], fl4[kSB], cid4[kSB], abeg4[kSB], a1[kSB], d1[kSB], g1[kSB]; float c04[kSB], w1[kSB]; bool inv[kSB];
 #pragma unroll
-      for (int u = 0; u < kSB; u++) { const int i = ib + u * kBlock; pc4[u] = 0; fl4[u] = 0; if (i < n) { pc4[u] = K3_ALD(&q.rown[i]); fl4[u] = K3_ALD(&q.rflag[i]); } inv[u] = pc4[u] > 0 || fl4[u] != 0; }
+      for (int u = 0; u < kSB; u++) {
+        const int i = ib + u * kBlock;
+        pc4[u] = 0;
+        fl4[u] = 0;
+        if (i < n) {
+          pc4[u] = K3_ALD(&q.rown[i]);
+          fl4[u] = K3_ALD(&q.rflag[i]);
+        }
+        inv[u] = pc4[u] > 0 || fl4[u] != 0;
+      }
 #pragma unroll
       for (int u = 0; u < kSB; u++) { const int i = ib + u * kBlock; if (inv[u]) { cid4[u] = q.grp[i]; abeg4[u] = (int)q.lead[i]; c04[u] = i < n_e ? q.c0[i] : kInf; } }
 #pragma unroll
-      for (int u = 0; u < kSB; u++) { a1[u] = -1; if (inv[u] && pc4[u] == 1) { a1[u] = ent_arc[abeg4[u]]; d1[u] = ent_dst[abeg4[u]]; } }      // most sources have exactly one passing arc
+      // most sources have exactly one passing arc
+      for (int u = 0; u < kSB; u++) {
+        a1[u] = -1;
+        if (inv[u] && pc4[u] == 1) {
+          a1[u] = ent_arc[abeg4[u]];
+          d1[u] = ent_dst[abeg4[u]];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < kSB; u++) if (a1[u] >= 0) { g1[u] = q.grp[d1[u]]; w1[u] = p.arcs[a1[u]].w; }
 #pragma unroll
@@ -1103,7 +1214,14 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         if (inv[u]) {
           const int cid = cid4[u], abeg = abeg4[u], pc = pc4[u];
           q.c2t[cid] = i; rcost[cid] = c04[u]; int d0 = 0, w0 = 0;
-          if (p.literal & 1) { K3_AST(&par[cid], cid); int *ci = reinterpret_cast<int *>(&q.cinfo[cid]); K3_AST(&ci[0], 0); K3_AST(&ci[1], 0); K3_AST(&ci[2], 0); K3_AST(&ci[3], 0); }
+          if (p.literal & 1) {
+            K3_AST(&par[cid], cid);
+            int *ci = reinterpret_cast<int *>(&q.cinfo[cid]);
+            K3_AST(&ci[0], 0);
+            K3_AST(&ci[1], 0);
+            K3_AST(&ci[2], 0);
+            K3_AST(&ci[3], 0);
+          }
           if (pc == 1) { d0 = g1[u]; w0 = __float_as_int(w1[u]); AR[abeg] = make_int2(d0, w0); }
           else if (pc > 1) {
             for (int a = abeg + 1; a < abeg + pc; a++) {      // FST order = ascending arc index (a source's arcs are contiguous in the graph)
@@ -1111,7 +1229,14 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
               while (b_ >= abeg && ent_arc[b_] > ka) { ent_arc[b_ + 1] = ent_arc[b_]; ent_dst[b_ + 1] = ent_dst[b_]; b_--; }
               ent_arc[b_ + 1] = ka; ent_dst[b_ + 1] = kd;
             }
-            for (int k = abeg; k < abeg + pc; k++) { const int2 ar = make_int2(q.grp[ent_dst[k]], __float_as_int(p.arcs[ent_arc[k]].w)); if (k == abeg) { d0 = ar.x; w0 = ar.y; } AR[k] = ar; }
+            for (int k = abeg; k < abeg + pc; k++) {
+              const int2 ar = make_int2(q.grp[ent_dst[k]], __float_as_int(p.arcs[ent_arc[k]].w));
+              if (k == abeg) {
+                d0 = ar.x;
+                w0 = ar.y;
+              }
+              AR[k] = ar;
+            }
           }
           meta[cid] = make_int4(abeg, pc, d0, w0);      // the first passing arc rides along
         }
@@ -1134,10 +1259,13 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     // (separate instantiations so that mode 0 compiles to LDS instructions only: a flat access would wait for every outstanding global access)
     int created_total = -1;
     if (p.literal & 1) {
-      if (rmode == 0) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw),
+      if (rmode == 0) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab) + 2 * kHL,
+          reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw),
                                                             reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, s_aux, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
-      else if (rmode == 1) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab), (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(smem_raw), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
-      else created_total = lit_replay_components(p, q, sh, &ls.use_lds, q.rcost, (const int4 *)q.meta, (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(q.rflag), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
+      else if (rmode == 1) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab), (const int4 *)q.meta,
+          (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(smem_raw), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
+      else created_total = lit_replay_components(p, q, sh, &ls.use_lds, q.rcost, (const int4 *)q.meta, (const int2 *)q.arcs2,
+          reinterpret_cast<unsigned *>(q.rflag), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
 #if defined(K3_LIT_PROF) && K3_LIT_PROF == 1
       if (tid == 0 && created_total < 0) sh.prof[5] += 1;
 #endif
@@ -1150,7 +1278,8 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);      // one wavefront on a dependent chain: let it issue ahead of the other workgroup's parallel phases
         int created = 0, err = 0, pops = 0;
-        if (rmode == 0) lit_replay<0>(reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw), reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
+        if (rmode == 0) lit_replay<0>(reinterpret_cast<float *>(s_tab) + 2 * kHL, reinterpret_cast<const int4 *>(s_tab),
+            reinterpret_cast<const int2 *>(smem_raw), reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
                                       reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, q.iq, n_iq, accept, s_own, &created, &err, &pops);
         else if (rmode == 1) lit_replay<1>(reinterpret_cast<float *>(s_tab), q.meta, q.arcs2, reinterpret_cast<int *>(smem_raw + (size_t)kRA * 8), kRS,
                                            reinterpret_cast<unsigned *>(smem_raw), q.iq, n_iq, accept, s_own, &created, &err, &pops);
@@ -1171,21 +1300,33 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     }
     K3_LT(9); K3_LQ(12);
 #ifdef K3_LIT_DEBUG
-    if (n_e + created_total != n && tid == 0) printf("lane %d frame %d: n_e %d created %d n %d n_cid %d n_arc %d n_iq %d rmode %d\n", L, f, n_e, created_total, n, n_cid, n_arc, n_iq, rmode);
+    if (n_e + created_total != n && tid == 0) printf("lane %d frame %d: n_e %d created %d n %d n_cid %d n_arc %d n_iq %d rmode %d\n", L, f, n_e, created_total,
+        n, n_cid, n_arc, n_iq, rmode);
 #endif
 #ifdef K3_LIT_STATS      // size statistics of the frames a fast (LDS-resident) path could take: n_cur and n <= K3_LIT_STATS tokens
     if (tid == 0 && f >= 0 && n_cur <= K3_LIT_STATS && n <= K3_LIT_STATS) {
       const long long el = eps_l1 - eps_l0; long long *P = p.prof + blockIdx.x * 16;
       auto mx = [&](int k, long long v) { if (v > P[k]) P[k] = v; };
       mx(0, n_cid); mx(1, n_arc); mx(2, n_iq); mx(3, el); mx(4, (long long)m_e + created_total);
-      P[5] += 1; P[6] += n_cid > 1024; P[7] += n_cid > 1536; P[8] += n_iq > 1024; P[9] += el > 2048; P[10] += (long long)m_e + created_total > 32768; P[11] += n_cid; P[12] += n_arc; P[13] += n_iq; P[14] += el; P[15] += n_arc > 2048;
+      P[5] += 1;
+      P[6] += n_cid > 1024;
+      P[7] += n_cid > 1536;
+      P[8] += n_iq > 1024;
+      P[9] += el > 2048;
+      P[10] += (long long)m_e + created_total > 32768;
+      P[11] += n_cid;
+      P[12] += n_arc;
+      P[13] += n_iq;
+      P[14] += el;
+      P[15] += n_arc > 2048;
     }
 #endif
     if (n_e + created_total != n) { if (tid == 0) sh.err = K3_ERR_HIP; }      // every token of the fixpoint must have been created by the replay
     if (block_err(sh)) break;
     __syncthreads();
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
-    if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, smem_raw, s_tab, lt_last__);
+    if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size,
+        ord_nxt, true, smem_raw, s_tab, lt_last__);
     else if (!lit_hash_order_mid(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true) &&
              (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, lt_last__)))
       lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
@@ -1202,14 +1343,36 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
 #endif
     if (tid == 0) { tok_off[f + 2] = cur_base + n_cur; loff_e[f + 1] = sh.n_link; }
   }
-  { const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os); if (lane == 0) { k3a_add(&sh.n_eps, a); k3a_add(&sh.n_emit, b); k3a_add(&sh.n_os, c); } }
+  {
+    const unsigned long long a = wave_sum_u64(cnt_eps), b = wave_sum_u64(cnt_emit), c = wave_sum_u64(cnt_os);
+    if (lane == 0) {
+      k3a_add(&sh.n_eps, a);
+      k3a_add(&sh.n_emit, b);
+      k3a_add(&sh.n_os, c);
+    }
+  }
   __syncthreads();
 #ifdef K3_LIT_PROF
   if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
 #elif defined(K3_FAST_PROF)
-  if (tid == 0) { long long *P = p.prof + blockIdx.x * 16; for (int k = 0; k < 12; k++) P[k] += fs.prof[k]; P[12] += n_fast; P[13] += n_gaveup; P[14] += n_general; P[15] += cyc_fast; }
+  if (tid == 0) {
+    long long *P = p.prof + blockIdx.x * 16;
+    for (int k = 0; k < 12; k++) P[k] += fs.prof[k];
+    P[12] += n_fast;
+    P[13] += n_gaveup;
+    P[14] += n_general;
+    P[15] += cyc_fast;
+  }
 #elif !defined(K3_LIT_STATS)
-  if (tid == 0) { long long *P = p.prof + blockIdx.x * 16; for (int k = 0; k < 11; k++) P[k] += why[k]; P[12] += n_fast; P[13] += n_gaveup; P[14] += n_general; P[15] += cyc_fast; P[11] += cyc_general; }
+  if (tid == 0) {
+    long long *P = p.prof + blockIdx.x * 16;
+    for (int k = 0; k < 11; k++) P[k] += why[k];
+    P[12] += n_fast;
+    P[13] += n_gaveup;
+    P[14] += n_general;
+    P[15] += cyc_fast;
+    P[11] += cyc_general;
+  }
 #endif
   if (tid == 0) {
     LaneInfo &li = p.info[L];
@@ -1346,7 +1509,9 @@ __device__ __forceinline__ void lit_final_frame(const DecParams &p, int L, long 
   for (int t = tid; t < n; t += kPBlock) { const float fcost = final_empty ? 0.0f : p.final_cost[tok_state[tb + t]]; g_base[t] = dec(tok_cost[tb + t]) + fcost - final_best; }
   __syncthreads();
   const bool use_lds = n + 1 <= kPCap && m <= kPCap;
-  float *base = use_lds ? l_base : g_base, *ex = use_lds ? l_extra : extra + tb, *ldelta = use_lds ? l_ldelta : g_delta; unsigned *off = use_lds ? l_off : g_off; int *ldst = use_lds ? l_ldst : g_ldst;
+  float *base = use_lds ? l_base : g_base, *ex = use_lds ? l_extra : extra + tb, *ldelta = use_lds ? l_ldelta : g_delta;
+  unsigned *off = use_lds ? l_off : g_off;
+  int *ldst = use_lds ? l_ldst : g_ldst;
   if (use_lds) {      // (offsets < 65536 here: the creation list rides in the upper halves, off[d] >> 16 = the token with creation rank d)
     for (int t = tid; t <= n; t += kPBlock) { off[t] = g_off[t] | (t < n ? (unsigned)by_ins[t] << 16 : 0u); if (t < n) base[t] = g_base[t]; }
     for (int j = tid; j < m; j += kPBlock) { ldst[j] = g_ldst[j]; ldelta[j] = g_delta[j]; }
@@ -1358,7 +1523,8 @@ __device__ __forceinline__ void lit_final_frame(const DecParams &p, int L, long 
   if (use_lds) { if (tid == 0) lit_final_sweeps<true>(l_base, l_extra, l_off, l_ldst, l_ldelta, by_ins, n, lb); }
   else {
     const LitLane q(p, L);      // (forward-pass scratch, idle here)
-    if (!lit_final_sweeps_parallel(g_base, extra + tb, g_off, g_ldst, g_delta, by_ins, n, lb, p.tok_slot + (long long)L * p.frame_tokens_cap, reinterpret_cast<int *>(cursor), q.c0, q.dense)) {
+    if (!lit_final_sweeps_parallel(g_base, extra + tb, g_off, g_ldst, g_delta, by_ins, n, lb, p.tok_slot + (long long)L * p.frame_tokens_cap,
+        reinterpret_cast<int *>(cursor), q.c0, q.dense)) {
       if (tid == 0) lit_final_sweeps<false>(g_base, extra + tb, g_off, g_ldst, g_delta, by_ins, n, lb);
     }
   }

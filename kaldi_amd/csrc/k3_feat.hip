@@ -43,8 +43,14 @@ namespace {
 constexpr int kFramesPerIter = 16;    // 4 waves x 4 frames
 constexpr int kThreads = 256;
 constexpr int kTpad = 17;             // transpose tile row stride (doubles)
-__host__ __device__ constexpr int frame_buf_bytes(int R) { return R * kTpad * 8; }                       // R = 16: 2176 B per frame: transpose tile (real parts, then imaginary parts) / P
-__host__ __device__ constexpr int lds_fixed_bytes(int R) { return 16 * R * 16 + ((8 * R + 1) * 16) + 32 * R * 4; }   // twiddles NC (double2), twiddles N (N/4 + 1, double2), window (float)
+// R = 16: 2176 B per frame: transpose tile (real parts, then imaginary parts) / P
+__host__ __device__ constexpr int frame_buf_bytes(int R) {
+  return R * kTpad * 8;
+}
+// twiddles NC (double2), twiddles N (N/4 + 1, double2), window (float)
+__host__ __device__ constexpr int lds_fixed_bytes(int R) {
+  return 16 * R * 16 + ((8 * R + 1) * 16) + 32 * R * 4;
+}
 
 struct FeatParams {
   int win_len, win_shift, snip_edges, remove_dc, use_energy, raw_energy, htk_compat, use_log, use_power,
@@ -114,7 +120,8 @@ template <> struct FftR<8> {      // two 4-point DFTs (even / odd samples) + one
 template <> struct FftR<32> {     // two 16-point DFTs (even / odd samples) + one radix-2 stage
   static __device__ __forceinline__ void run(cd (&v)[32]) {
     constexpr double c[16] = {1.0, 0.98078528040323044913, 0.92387953251128673848, 0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474, 0.38268343236508978178,
-                              0.19509032201612826785, 0.0, -0.19509032201612826785, -0.38268343236508978178, -0.55557023301960222474, -0.70710678118654752440, -0.83146961230254523708,
+                              0.19509032201612826785, 0.0, -0.19509032201612826785, -0.38268343236508978178, -0.55557023301960222474, -0.70710678118654752440,
+                                  -0.83146961230254523708,
                               -0.92387953251128673848, -0.98078528040323044913};
     constexpr double sn[16] = {0.0, 0.19509032201612826785, 0.38268343236508978178, 0.55557023301960222474, 0.70710678118654752440, 0.83146961230254523708, 0.92387953251128673848,
                                0.98078528040323044913, 1.0, 0.98078528040323044913, 0.92387953251128673848, 0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474,
@@ -140,13 +147,18 @@ template <int N> __device__ __forceinline__ double row_ror(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double group_sum16(double x) {      // every lane of the row gets the row's sum (the four partial orders differ by lane: callers use lane 0's, or exact sums)
+// every lane of the row gets the row's sum (the four partial orders differ by lane: callers use lane 0's, or exact sums)
+__device__ __forceinline__ double group_sum16(double x) {
   x += row_ror<8>(x); x += row_ror<4>(x); x += row_ror<2>(x); x += row_ror<1>(x);
   return x;
 }
 // The 4 frames of a wavefront own their LDS buffers: the phases of a frame are ordered by the wave's own program order (LDS instructions of a
 // wave execute in order); only the compiler has to be told not to move LDS accesses across the phase boundary.  No workgroup barrier in the frame loop.
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // TS = float (CuVector<BaseFloat> waves, the reference's interface) or int16_t (PCM16 as it sits in a wav file: 2 of the 480 B / frame of SURVEY 8d)
 template <typename TS, int R>
@@ -470,8 +482,11 @@ struct OnlineCmvnParams {
   const double *global_stats, *speaker_stats;      // [2 x (dim+1)], [U x 2 x (dim+1)] or null
   unsigned long long skip[4];                      // bit d set: FakeStatsForSomeDims for column d
   int *err;                                        // set to 1 where the reference raises (count < 1, global count <= 0)
-  const k3::CmvnSeg *segs;                         // (streaming, many streams in one launch) per utterance: its own buffers, length, first new row and carry; the fields above that they replace are unused
-  const long long *t_begin; double *carry;         // resume (streaming): rows [0, t_begin[u]) of utterance u are history -- read for the window, not written; carry [U][dim][3] = the
+  // (streaming, many streams in one launch) per utterance: its own buffers, length, first new row and carry; the fields above that they replace are unused
+  const k3::CmvnSeg *segs;
+  // resume (streaming): rows [0, t_begin[u]) of utterance u are history -- read for the window, not written; carry [U][dim][3] = the
+  const long long *t_begin;
+  double *carry;
                                                    // window's (sum, sum of squares, count) after the last row, read when t_begin[u] > 0 and written back.  Both null: whole utterances
 };
 
@@ -512,13 +527,23 @@ __global__ __launch_bounds__(64) void k3_cmvn_online_kernel(OnlineCmvnParams p) 
           double from_spk = (double)W - cnt;
           if (from_spk > (double)p.speaker_frames) from_spk = (double)p.speaker_frames;
           if (from_spk > s_n) from_spk = s_n;
-          if (from_spk > 0.0) { const double a = __ddiv_rn(from_spk, s_n); m = __dadd_rn(m, rounded(a * s_m)); v = __dadd_rn(v, rounded(a * s_v)); cnt = __dadd_rn(cnt, rounded(a * s_n)); }
+          if (from_spk > 0.0) {
+            const double a = __ddiv_rn(from_spk, s_n);
+            m = __dadd_rn(m, rounded(a * s_m));
+            v = __dadd_rn(v, rounded(a * s_v));
+            cnt = __dadd_rn(cnt, rounded(a * s_n));
+          }
         }
         if (cnt < (double)W) {
           double from_glob = (double)W - cnt;
           if (!(g_n > 0.0)) { *p.err = 1; return; }
           if (from_glob > (double)p.global_frames) from_glob = (double)p.global_frames;
-          if (from_glob > 0.0) { const double a = __ddiv_rn(from_glob, g_n); m = __dadd_rn(m, rounded(a * g_m)); v = __dadd_rn(v, rounded(a * g_v)); cnt = __dadd_rn(cnt, rounded(a * g_n)); }
+          if (from_glob > 0.0) {
+            const double a = __ddiv_rn(from_glob, g_n);
+            m = __dadd_rn(m, rounded(a * g_m));
+            v = __dadd_rn(v, rounded(a * g_v));
+            cnt = __dadd_rn(cnt, rounded(a * g_n));
+          }
         }
       }
       if (skip) { m = 0.0; v = cnt; }
@@ -727,18 +752,26 @@ static int feat_launch(k3_feat_plan *plan, const TS *d_waves, const int64_t *d_w
   if (rc) return rc;
   const dim3 grid((unsigned)blocks), block(kThreads); hipStream_t st = (hipStream_t)stream;
   switch (plan->padded) {      // one instantiation per padded window size
-    case 256: hipLaunchKernelGGL((k3_feat_kernel<TS, 8>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block); break;
-    case 512: hipLaunchKernelGGL((k3_feat_kernel<TS, 16>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block); break;
-    default: hipLaunchKernelGGL((k3_feat_kernel<TS, 32>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts, total_frames, d_feats, ld, frames_per_block); break;
+    case 256: hipLaunchKernelGGL((k3_feat_kernel<TS, 8>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts,
+        total_frames, d_feats, ld, frames_per_block);
+    break;
+    case 512: hipLaunchKernelGGL((k3_feat_kernel<TS, 16>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets,
+        (int)num_utts, total_frames, d_feats, ld, frames_per_block);
+    break;
+    default: hipLaunchKernelGGL((k3_feat_kernel<TS, 32>), grid, block, plan->lds_bytes, st, plan->prm, d_waves, d_wave_offsets, d_frame_offsets, (int)num_utts,
+        total_frames, d_feats, ld, frames_per_block);
+    break;
   }
   K3_HIP_CHECK(hipGetLastError());
   return K3_OK;
 }
-extern "C" int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_t *d_wave_offsets, const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
+extern "C" int k3_feat_compute_batch(k3_feat_plan *plan, const float *d_waves, const int64_t *d_wave_offsets, const int64_t *d_frame_offsets, int32_t num_utts,
+    int64_t total_frames,
                                      float *d_feats, int64_t ld, void *stream) {
   return feat_launch(plan, d_waves, d_wave_offsets, d_frame_offsets, num_utts, total_frames, d_feats, ld, stream);
 }
-extern "C" int k3_feat_compute_batch_pcm16(k3_feat_plan *plan, const int16_t *d_waves, const int64_t *d_wave_offsets, const int64_t *d_frame_offsets, int32_t num_utts, int64_t total_frames,
+extern "C" int k3_feat_compute_batch_pcm16(k3_feat_plan *plan, const int16_t *d_waves, const int64_t *d_wave_offsets, const int64_t *d_frame_offsets,
+    int32_t num_utts, int64_t total_frames,
                                            float *d_feats, int64_t ld, void *stream) {
   return feat_launch(plan, d_waves, d_wave_offsets, d_frame_offsets, num_utts, total_frames, d_feats, ld, stream);
 }
@@ -756,7 +789,8 @@ extern "C" int k3_cmvn_offline_batch(float *d_feats, int64_t ld, int32_t dim, co
 extern "C" int k3_cmvn_online_batch(const float *d_in, int64_t ld_in, float *d_out, int64_t ld_out, int32_t dim, const int64_t *d_frame_offsets,
                                     int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
                                     const int32_t *skip_dims, int32_t num_skip_dims, void *stream) {
-  return k3_cmvn_online_batch_resume(d_in, ld_in, d_out, ld_out, dim, d_frame_offsets, num_utts, opts, d_global_stats, d_speaker_stats, skip_dims, num_skip_dims, nullptr, nullptr, stream);
+  return k3_cmvn_online_batch_resume(d_in, ld_in, d_out, ld_out, dim, d_frame_offsets, num_utts, opts, d_global_stats, d_speaker_stats, skip_dims,
+      num_skip_dims, nullptr, nullptr, stream);
 }
 extern "C" int k3_cmvn_online_batch_resume(const float *d_in, int64_t ld_in, float *d_out, int64_t ld_out, int32_t dim, const int64_t *d_frame_offsets,
                                            int32_t num_utts, const k3_online_cmvn_opts *opts, const double *d_global_stats, const double *d_speaker_stats,
@@ -787,7 +821,10 @@ extern "C" int k3_cmvn_online_batch_resume(const float *d_in, int64_t ld_in, flo
   int h_err = 0;
   K3_HIP_CHECK(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   K3_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-  if (h_err) { K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); K3_REQUIRE(false, "k3_cmvn_online_batch: insufficient stats (count < 1 or empty global stats), the reference raises an error here"); }
+  if (h_err) {
+    K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int)));
+    K3_REQUIRE(false, "k3_cmvn_online_batch: insufficient stats (count < 1 or empty global stats), the reference raises an error here");
+  }
   return K3_OK;
 }
 
@@ -796,7 +833,11 @@ int k3::cmvn_online_resume_segs_async(const k3::CmvnSeg *d_segs, int num_segs, i
   K3_REQUIRE(d_segs && num_segs > 0 && opts && d_global_stats && dim > 0, "cmvn_online_resume_segs_async: bad argument");
   OnlineCmvnParams p{};
   p.segs = d_segs; p.ld_in = dim; p.ld_out = dim; p.dim = dim;
-  p.cmn_window = opts->cmn_window; p.speaker_frames = opts->speaker_frames; p.global_frames = opts->global_frames; p.norm_means = opts->normalize_mean; p.norm_vars = opts->normalize_variance;
+  p.cmn_window = opts->cmn_window;
+  p.speaker_frames = opts->speaker_frames;
+  p.global_frames = opts->global_frames;
+  p.norm_means = opts->normalize_mean;
+  p.norm_vars = opts->normalize_variance;
   p.global_stats = d_global_stats;
   static int *d_err = nullptr;      // (never read here: see the header)
   if (!d_err) { K3_HIP_CHECK(hipMalloc(&d_err, sizeof(int))); K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); }
@@ -808,10 +849,15 @@ int k3::cmvn_online_resume_segs_async(const k3::CmvnSeg *d_segs, int num_segs, i
 int k3::cmvn_online_resume_async(const float *d_in, long long ld_in, float *d_out, long long ld_out, int dim, const long long *d_frame_offsets, int num_utts, const void *opts_,
                                  const double *d_global_stats, const long long *d_t_begin, double *d_carry, void *stream) {
   const k3_online_cmvn_opts *opts = static_cast<const k3_online_cmvn_opts *>(opts_);
-  K3_REQUIRE(d_in && d_out && d_in != d_out && d_frame_offsets && opts && d_global_stats && d_t_begin && d_carry && dim > 0 && num_utts > 0, "cmvn_online_resume_async: bad argument");
+  K3_REQUIRE(d_in && d_out && d_in != d_out && d_frame_offsets && opts && d_global_stats && d_t_begin && d_carry && dim > 0 && num_utts > 0,
+      "cmvn_online_resume_async: bad argument");
   OnlineCmvnParams p{};
   p.in = d_in; p.out = d_out; p.ld_in = ld_in; p.ld_out = ld_out; p.dim = dim; p.frame_off = d_frame_offsets;
-  p.cmn_window = opts->cmn_window; p.speaker_frames = opts->speaker_frames; p.global_frames = opts->global_frames; p.norm_means = opts->normalize_mean; p.norm_vars = opts->normalize_variance;
+  p.cmn_window = opts->cmn_window;
+  p.speaker_frames = opts->speaker_frames;
+  p.global_frames = opts->global_frames;
+  p.norm_means = opts->normalize_mean;
+  p.norm_vars = opts->normalize_variance;
   p.global_stats = d_global_stats; p.speaker_stats = nullptr; p.t_begin = d_t_begin; p.carry = d_carry;
   static int *d_err = nullptr;      // (never read here: see the header)
   if (!d_err) { K3_HIP_CHECK(hipMalloc(&d_err, sizeof(int))); K3_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); }
@@ -860,39 +906,51 @@ long long resample_num_out(int rate_in, int rate_out, long long n_in) {      // 
   long long last = interval / per_out; if (last * per_out == interval) last--;
   return last + 1;
 }
-__global__ __launch_bounds__(256) void k3_resample_kernel(const float *in, const long long *in_off, float *out, const long long *out_off, int num_utts, int in_unit, int out_unit, int max_taps,
+__global__ __launch_bounds__(256) void k3_resample_kernel(const float *in, const long long *in_off, float *out, const long long *out_off, int num_utts,
+    int in_unit, int out_unit, int max_taps,
                                                           const int *first, const int *ntaps, const float *w) {
   const int u = blockIdx.y; const long long i0 = in_off[u], n_in = in_off[u + 1] - i0, o0 = out_off[u], n_out = out_off[u + 1] - o0;
   for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < n_out; s += (long long)gridDim.x * 256) {
     const long long unit = s / out_unit; const int ph = (int)(s - unit * out_unit);
     const long long f = first[ph] + unit * in_unit; const float *wp = w + (long long)ph * max_taps; const int n = ntaps[ph];
     float acc = 0.0f;
-    for (int t = 0; t < n; t++) { const long long idx = f + t; if (idx >= 0 && idx < n_in) acc += wp[t] * in[i0 + idx]; }      // (samples before the start / beyond the end do not exist: flush = true, no remainder)
+    // (samples before the start / beyond the end do not exist: flush = true, no remainder)
+    for (int t = 0; t < n; t++) {
+      const long long idx = f + t;
+      if (idx >= 0 && idx < n_in) acc += wp[t] * in[i0 + idx];
+    }
     out[o0 + s] = acc;
   }
 }
 }  // namespace
 
-extern "C" int64_t k3_resample_num_samples(int32_t rate_in, int32_t rate_out, int64_t num_in) { return (rate_in > 0 && rate_out > 0 && num_in >= 0) ? resample_num_out(rate_in, rate_out, num_in) : -1; }
-extern "C" int k3_resample_batch(int32_t rate_in, int32_t rate_out, const float *d_in, const int64_t *h_in_offsets, int32_t num_utts, float *d_out, const int64_t *h_out_offsets, void *stream) {
+extern "C" int64_t k3_resample_num_samples(int32_t rate_in, int32_t rate_out, int64_t num_in) {
+  return (rate_in > 0 && rate_out > 0 && num_in >= 0) ? resample_num_out(rate_in, rate_out, num_in) : -1;
+}
+extern "C" int k3_resample_batch(int32_t rate_in, int32_t rate_out, const float *d_in, const int64_t *h_in_offsets, int32_t num_utts, float *d_out,
+    const int64_t *h_out_offsets, void *stream) {
   K3_REQUIRE(rate_in > 0 && rate_out > 0 && rate_in != rate_out && d_in && d_out && h_in_offsets && h_out_offsets && num_utts >= 0, "k3_resample_batch: bad argument");
   if (num_utts == 0) return K3_OK;
   long long max_out = 0;
   for (int u = 0; u < num_utts; u++) {
-    K3_REQUIRE(h_out_offsets[u + 1] - h_out_offsets[u] == resample_num_out(rate_in, rate_out, h_in_offsets[u + 1] - h_in_offsets[u]), "k3_resample_batch: output offsets do not match k3_resample_num_samples");
+    K3_REQUIRE(h_out_offsets[u + 1] - h_out_offsets[u] == resample_num_out(rate_in, rate_out, h_in_offsets[u + 1] - h_in_offsets[u]),
+        "k3_resample_batch: output offsets do not match k3_resample_num_samples");
     max_out = std::max<long long>(max_out, h_out_offsets[u + 1] - h_out_offsets[u]);
   }
   const ResamplePlan pl = make_resample_plan(rate_in, rate_out);
   // one allocation for the tables and the offsets; the call is synchronous (a rate mismatch is the rare path of a feature program)
   const size_t nb_w = pl.w.size() * 4, nb_i = (size_t)pl.out_unit * 4, nb_o = (size_t)(num_utts + 1) * 8; char *d = nullptr;
   K3_HIP_CHECK(hipMalloc((void **)&d, nb_w + 2 * nb_i + 2 * nb_o + 64));
-  float *d_w = (float *)d; int *d_first = (int *)(d + nb_w), *d_nt = (int *)(d + nb_w + nb_i); long long *d_io = (long long *)(d + ((nb_w + 2 * nb_i + 15) & ~(size_t)15)), *d_oo = d_io + num_utts + 1;
+  float *d_w = (float *)d;
+  int *d_first = (int *)(d + nb_w), *d_nt = (int *)(d + nb_w + nb_i);
+  long long *d_io = (long long *)(d + ((nb_w + 2 * nb_i + 15) & ~(size_t)15)), *d_oo = d_io + num_utts + 1;
   hipStream_t st = (hipStream_t)stream; int rc = K3_OK;
   if (hipMemcpyAsync(d_w, pl.w.data(), nb_w, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(d_first, pl.first.data(), nb_i, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(d_nt, pl.ntaps.data(), nb_i, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(d_io, h_in_offsets, nb_o, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(d_oo, h_out_offsets, nb_o, hipMemcpyHostToDevice, st) != hipSuccess) rc = K3_ERR_HIP;
   if (rc == K3_OK && max_out > 0) {
-    hipLaunchKernelGGL(k3_resample_kernel, dim3((unsigned)std::min<long long>(1024, (max_out + 255) / 256), (unsigned)num_utts), dim3(256), 0, st, d_in, d_io, d_out, d_oo, num_utts, pl.in_unit, pl.out_unit, pl.max_taps, d_first, d_nt, d_w);
+    hipLaunchKernelGGL(k3_resample_kernel, dim3((unsigned)std::min<long long>(1024, (max_out + 255) / 256), (unsigned)num_utts), dim3(256), 0, st, d_in, d_io,
+        d_out, d_oo, num_utts, pl.in_unit, pl.out_unit, pl.max_taps, d_first, d_nt, d_w);
     if (hipGetLastError() != hipSuccess) rc = K3_ERR_HIP;
   }
   if (hipStreamSynchronize(st) != hipSuccess) rc = K3_ERR_HIP;

@@ -75,14 +75,21 @@ __global__ void ivec_u(const double *__restrict__ M, const double *__restrict__ 
 // batched kernels index by stream instead of the packed utterance layout of the whole-utterance path.
 struct BatchSeg {
   const float *raw_old, *cm_old; float *raw, *cm;                        // the stream's raw / normalised frame buffers before and after this call
-  long long raw_from, keep, n_new, feat_off, cm_from, cm_keep;           // raw_old[raw_from .. + keep) -> raw[0 ..), the call's feature rows feat_off .. + n_new -> raw[keep ..); cm_old[cm_from .. + cm_keep) -> cm[0 ..)
+  // raw_old[raw_from .. + keep) -> raw[0 ..), the call's feature rows feat_off .. + n_new -> raw[keep ..); cm_old[cm_from .. + cm_keep) -> cm[0 ..)
+  long long raw_from, keep, n_new, feat_off, cm_from, cm_keep;
   long long nP, out_off, row0_cm, row0_raw, cm_rows, raw_rows;           // posterior stage: nP frames, rows out_off .. of the packed work arrays; first frame's row in cm / raw
   float *px; int32_t *pg; float *pw; int32_t *pn;                        // where the new posterior-stage rows go (behind the rows still waiting for their period)
   const float *e_px; const int32_t *e_pg; const float *e_pw; const int32_t *e_pn;      // the waiting rows from stream frame t_base on
   double *est, *x_io, *chol, *quad; long long t_base, t_limit; int k_begin, nk; float *rows, *latest;
-  float *px_alt; int32_t *pg_alt; float *pw_alt; int32_t *pn_alt; long long shift_from, left;      // after the estimates: rows shift_from .. + left of the waiting arrays move to the other buffers
+  // after the estimates: rows shift_from .. + left of the waiting arrays move to the other buffers
+  float *px_alt;
+  int32_t *pg_alt;
+  float *pw_alt;
+  int32_t *pn_alt;
+  long long shift_from, left;
 };
-__device__ __forceinline__ int seg_of_row(const BatchSeg *segs, int n, long long row) {      // last stream whose out_off <= row (streams without rows share their successor's offset)
+// last stream whose out_off <= row (streams without rows share their successor's offset)
+__device__ __forceinline__ int seg_of_row(const BatchSeg *segs, int n, long long row) {
   int lo = 0, hi = n; while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (segs[m].out_off <= row) lo = m; else hi = m; } return lo;
 }
 
@@ -106,7 +113,8 @@ __global__ void ivec_splice_lda_kernel(const float *__restrict__ in, int64_t ld_
 
 // the same for the streams of a batched call: frame `local` of stream u is row row0 + local of its own buffer (clamped to that buffer: the first row is the stream's first frame
 // or has its left context in the buffer, the last row is only reached when the stream has ended); which = 0: normalised frames -> packed xpost, 1: the statistics' features -> px
-__global__ void ivec_splice_lda_multi_kernel(const BatchSeg *__restrict__ segs, int nseg, int which, int stats_from_cm, const float *__restrict__ lda, int lda_cols, int has_offset, int F, int D,
+__global__ void ivec_splice_lda_multi_kernel(const BatchSeg *__restrict__ segs, int nseg, int which, int stats_from_cm, const float *__restrict__ lda,
+    int lda_cols, int has_offset, int F, int D,
                                              int lc, int rc, float *__restrict__ xpost, int64_t total_frames) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i >= total_frames * D) return;
   const int64_t row = i / D; const int d = (int)(i % D);
@@ -128,7 +136,8 @@ __global__ void ivec_splice_lda_multi_kernel(const BatchSeg *__restrict__ segs, 
 // (a wave arg-max each), then pruned and renormalised by lane 0 exactly as VectorToPosteriorEntry does (float arithmetic, same order).
 __global__ void __launch_bounds__(kBlock) ivec_posterior_kernel(const float *__restrict__ x, int D, int G, const float *__restrict__ gconsts, const float *__restrict__ miv_t,
                                                                 const float *__restrict__ iv_t, int num_gselect, float min_post, float post_scale, int64_t total_frames,
-                                                                int32_t *__restrict__ post_g, float *__restrict__ post_w, int32_t *__restrict__ post_n, const BatchSeg *__restrict__ segs = nullptr, int nseg = 0,
+                                                                int32_t *__restrict__ post_g, float *__restrict__ post_w, int32_t *__restrict__ post_n,
+                                                                    const BatchSeg *__restrict__ segs = nullptr, int nseg = 0,
                                                                 const float *__restrict__ frame_w = nullptr) {
   extern __shared__ float s_ll[];                             // [waves per block][G] log-likes, then [waves][2 * num_gselect] selections
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, nw = blockDim.x / kWave;
@@ -170,7 +179,14 @@ __global__ void __launch_bounds__(kBlock) ivec_posterior_kernel(const float *__r
     while (n > 1 && sel_p[n - 1] < cutoff) { tot -= sel_p[n - 1]; n--; }
     const float inv = 1.0f / tot;
     int64_t tt = t;
-    if (segs) { const BatchSeg &g = segs[seg_of_row(segs, nseg, t)]; tt = t - g.out_off; post_g = g.pg; post_w = g.pw; post_n = g.pn; }      // batched streaming: the stream's own arrays
+    // batched streaming: the stream's own arrays
+    if (segs) {
+      const BatchSeg &g = segs[seg_of_row(segs, nseg, t)];
+      tt = t - g.out_off;
+      post_g = g.pg;
+      post_w = g.pw;
+      post_n = g.pn;
+    }
     for (int k = 0; k < n; k++) { post_g[tt * num_gselect + k] = sel_g[k]; post_w[tt * num_gselect + k] = (sel_p[k] * inv) * post_scale; }
     post_n[tt] = n;
   }
@@ -202,7 +218,10 @@ __device__ void chol_solve(double *C, const double *b, double *x, double *y, int
     for (int i = k + 1 + threadIdx.x; i < R; i += kBlock) C[(size_t)i * R + k] /= dkk;
     __syncthreads();
     const int m = R - k - 1;                                    // trailing update of the lower triangle
-    for (int e = threadIdx.x; e < m * m; e += kBlock) { const int i = k + 1 + e / m, j = k + 1 + e % m; if (j <= i) C[(size_t)i * R + j] -= C[(size_t)i * R + k] * C[(size_t)j * R + k]; }
+    for (int e = threadIdx.x; e < m * m; e += kBlock) {
+      const int i = k + 1 + e / m, j = k + 1 + e % m;
+      if (j <= i) C[(size_t)i * R + j] -= C[(size_t)i * R + k] * C[(size_t)j * R + k];
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {                                       // R <= a few hundred: two serial triangular solves
@@ -235,14 +254,20 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p_in) {
   const int R = p.R, D = p.D, S = p.S, P = p.period, tid = threadIdx.x;
   double *s_x = s_dyn, *s_r = s_x + R, *s_p = s_r + R, *s_ap = s_p + R, *s_lin = s_ap + R, *s_xo = s_lin + R, *s_red = s_xo + R;    // 6R + 4 doubles
   const int max_ent = P * S;
-  int *e_g = (int *)(s_red + kBlock / kWave); int *e_t = e_g + max_ent; float *e_w = (float *)(e_t + max_ent); float *e_gw = e_w + max_ent;   // gw != 0 marks a leader (weights may be negative)
-  double *A = seg ? (seg->quad ? seg->quad : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7)) : p.quad_g ? p.quad_g + (size_t)u * R * R : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7);
+  // gw != 0 marks a leader (weights may be negative)
+  int *e_g = (int *)(s_red + kBlock / kWave);
+  int *e_t = e_g + max_ent;
+  float *e_w = (float *)(e_t + max_ent);
+  float *e_gw = e_w + max_ent;
+  double *A = seg ? (seg->quad ? seg->quad : (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7)) : p.quad_g ? p.quad_g + (size_t)u * R * R :
+      (double *)(((uintptr_t)(e_gw + max_ent) + 7) & ~(uintptr_t)7);
   double *C = seg ? seg->chol : p.chol_g + (size_t)u * R * R;
   __shared__ int s_n; __shared__ double s_tot;
   const int64_t fb = seg ? -p.t_base : p.frame_off[u] - (p.t_limit >= 0 ? p.t_base : 0); const int T = p.t_limit >= 0 ? (int)p.t_limit : (int)(p.frame_off[u + 1] - p.frame_off[u]);
   const int64_t out_base = seg ? 0 : p.out_off[u]; const size_t st_stride = seg ? 0 : (1 + R + (size_t)R * R);
   const double *st_in = p.state_in ? p.state_in + (size_t)u * st_stride : nullptr;      // the speaker's statistics so far (SetAdaptationState)
-  for (int i = tid; i < R * R; i += kBlock) A[i] = st_in ? st_in[1 + R + i] : ((i / R == i % R) ? 1.0 : 0.0);      // fresh: quadratic term of the prior I, linear term prior_offset e_0
+  // fresh: quadratic term of the prior I, linear term prior_offset e_0
+  for (int i = tid; i < R * R; i += kBlock) A[i] = st_in ? st_in[1 + R + i] : ((i / R == i % R) ? 1.0 : 0.0);
   if (tid < R) { s_lin[tid] = st_in ? st_in[1 + tid] : (tid == 0 ? p.prior : 0.0); s_x[tid] = p.x_io ? p.x_io[tid] : (tid == 0 ? p.prior : 0.0); }
   double nframes = st_in ? st_in[0] : 0.0;
   __syncthreads();
@@ -250,7 +275,15 @@ __global__ void __launch_bounds__(kBlock) ivec_estimate_kernel(EstParams p_in) {
   auto accumulate = [&](int t_lo, int t_hi) {
     if (tid == 0) {                                                                   // entries in frame order, then in the order VectorToPosteriorEntry left them
       int n = 0;
-      for (int t = t_lo; t <= t_hi; t++) { const int c = p.post_n[fb + t]; for (int j = 0; j < c; j++) { e_g[n] = p.post_g[(fb + t) * S + j]; e_w[n] = p.post_w[(fb + t) * S + j]; e_t[n] = t; n++; } }
+      for (int t = t_lo; t <= t_hi; t++) {
+        const int c = p.post_n[fb + t];
+        for (int j = 0; j < c; j++) {
+          e_g[n] = p.post_g[(fb + t) * S + j];
+          e_w[n] = p.post_w[(fb + t) * S + j];
+          e_t[n] = t;
+          n++;
+        }
+      }
       s_n = n;
     }
     __syncthreads();
@@ -353,17 +386,25 @@ extern "C" void k3_ivector_opts_default(k3_ivector_opts *o) {
   o->ivector_period = 10; o->num_cg_iters = 15; o->exact_solve = 0; o->online_cmvn_iextractor = 0; k3_online_cmvn_opts_default(&o->cmvn);
 }
 
-template <typename T> static int upload(T **dst, const std::vector<T> &h) { K3_HIP_CHECK(hipMalloc((void **)dst, h.size() * sizeof(T))); K3_HIP_CHECK(hipMemcpy(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return K3_OK; }
+template <typename T> static int upload(T **dst, const std::vector<T> &h) {
+  K3_HIP_CHECK(hipMalloc((void **)dst, h.size() * sizeof(T)));
+  K3_HIP_CHECK(hipMemcpy(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return K3_OK;
+}
 
 extern "C" int k3_ivector_create(const k3_ivector_model *m, const k3_ivector_opts *opts, k3_ivector **out) {
   K3_REQUIRE(m && opts && out, "k3_ivector_create: null argument");
-  K3_REQUIRE(m->feat_dim > 0 && m->lda && m->lda_rows > 0 && m->global_cmvn_stats && m->num_gauss > 0 && m->gconsts && m->means_invvars && m->inv_vars && m->ivector_dim > 0 && m->M && m->sigma_inv,
+  K3_REQUIRE(m->feat_dim > 0 && m->lda && m->lda_rows > 0 && m->global_cmvn_stats && m->num_gauss > 0 && m->gconsts && m->means_invvars && m->inv_vars &&
+      m->ivector_dim > 0 && m->M && m->sigma_inv,
              "k3_ivector_create: incomplete model");
   K3_REQUIRE(m->ivector_dim <= kBlock, "k3_ivector_create: i-vector dimension above 256");
   const int spl = opts->left_context + opts->right_context + 1;
   K3_REQUIRE(opts->left_context >= 0 && opts->right_context >= 0, "k3_ivector_create: negative splice context");
-  K3_REQUIRE(m->lda_cols == m->feat_dim * spl || m->lda_cols == m->feat_dim * spl + 1, "k3_ivector_create: the LDA matrix does not match the spliced feature dimension");   // OnlineTransform, feat/online-feature.cc:520-535
-  K3_REQUIRE(opts->num_gselect > 0 && opts->ivector_period > 0 && opts->min_post >= 0.f && opts->min_post < 1.f, "k3_ivector_create: bad option value");                    // OnlineIvectorExtractionInfo::Check :100-121
+  // OnlineTransform, feat/online-feature.cc:520-535
+  K3_REQUIRE(m->lda_cols == m->feat_dim * spl || m->lda_cols == m->feat_dim * spl + 1,
+      "k3_ivector_create: the LDA matrix does not match the spliced feature dimension");
+  // OnlineIvectorExtractionInfo::Check :100-121
+  K3_REQUIRE(opts->num_gselect > 0 && opts->ivector_period > 0 && opts->min_post >= 0.f && opts->min_post < 1.f, "k3_ivector_create: bad option value");
   K3_REQUIRE(opts->posterior_scale > 0.f && opts->posterior_scale <= 1.f && opts->max_count >= 0.f, "k3_ivector_create: bad posterior-scale / max-count");
   std::unique_ptr<k3_ivector> iv(new k3_ivector);
   iv->o = *opts; iv->F = m->feat_dim; iv->D = m->lda_rows; iv->G = m->num_gauss; iv->R = m->ivector_dim; iv->splice = spl; iv->has_offset = m->lda_cols == m->feat_dim * spl + 1;
@@ -373,7 +414,13 @@ extern "C" int k3_ivector_create(const k3_ivector_model *m, const k3_ivector_opt
   K3_REQUIRE(m->global_cmvn_stats[F] > 0.0, "k3_ivector_create: the global CMVN statistics hold no frames (OnlineCmvn raises 'Global CMVN stats are required')");
   { std::vector<double> h(m->global_cmvn_stats, m->global_cmvn_stats + 2 * (size_t)(F + 1)); const int rc = upload(&iv->global_stats, h); if (rc) return rc; }
   { std::vector<float> gc(G), a((size_t)D * G), b((size_t)D * G);
-    for (int g = 0; g < G; g++) { gc[g] = (float)m->gconsts[g]; for (int d = 0; d < D; d++) { a[(size_t)d * G + g] = (float)m->means_invvars[(size_t)g * D + d]; b[(size_t)d * G + g] = (float)m->inv_vars[(size_t)g * D + d]; } }
+    for (int g = 0; g < G; g++) {
+      gc[g] = (float)m->gconsts[g];
+      for (int d = 0; d < D; d++) {
+        a[(size_t)d * G + g] = (float)m->means_invvars[(size_t)g * D + d];
+        b[(size_t)d * G + g] = (float)m->inv_vars[(size_t)g * D + d];
+      }
+    }
     int rc = upload(&iv->gconsts, gc); if (!rc) rc = upload(&iv->miv_t, a); if (!rc) rc = upload(&iv->iv_t, b); if (rc) return rc; }
   { double *dM = nullptr, *dS = nullptr;
     std::vector<double> hM(m->M, m->M + (size_t)G * D * R), hS(m->sigma_inv, m->sigma_inv + (size_t)G * (D * (D + 1) / 2));
@@ -406,50 +453,89 @@ extern "C" int64_t k3_ivector_num_rows(const k3_ivector *iv, int32_t num_utts, c
 }
 
 extern "C" void k3_ivector_set_accumulate_tail(k3_ivector *iv, int32_t on) { if (iv) iv->acc_tail = on ? 1 : 0; }
-extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
+extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
+    float *d_ivectors, int64_t ld_ivectors,
                                               const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream_);
-extern "C" int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
+extern "C" int k3_ivector_extract_batch(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
+    float *d_ivectors, int64_t ld_ivectors,
                                         void *stream_) {
   return k3_ivector_extract_batch_adapt(iv, d_feats, ld_feats, h_frame_offsets, num_utts, d_ivectors, ld_ivectors, nullptr, nullptr, nullptr, stream_);
 }
 extern "C" int64_t k3_ivector_stats_size(const k3_ivector *iv) { return iv ? 1 + iv->R + (int64_t)iv->R * iv->R : -1; }
-extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, float *d_ivectors, int64_t ld_ivectors,
+extern "C" int k3_ivector_extract_batch_adapt(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
+    float *d_ivectors, int64_t ld_ivectors,
                                               const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream_) {
-  return k3_ivector_extract_batch_weighted(iv, d_feats, ld_feats, h_frame_offsets, num_utts, nullptr, d_ivectors, ld_ivectors, d_cmvn_speaker_stats, d_stats_in, d_stats_out, stream_);
+  return k3_ivector_extract_batch_weighted(iv, d_feats, ld_feats, h_frame_offsets, num_utts, nullptr, d_ivectors, ld_ivectors, d_cmvn_speaker_stats,
+      d_stats_in, d_stats_out, stream_);
 }
-extern "C" int k3_ivector_extract_batch_weighted(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts, const float *d_frame_weights,
-                                                 float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in, double *d_stats_out, void *stream_) {
+extern "C" int k3_ivector_extract_batch_weighted(k3_ivector *iv, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, int32_t num_utts,
+    const float *d_frame_weights,
+                                                 float *d_ivectors, int64_t ld_ivectors, const double *d_cmvn_speaker_stats, const double *d_stats_in,
+                                                     double *d_stats_out, void *stream_) {
   K3_REQUIRE(iv && d_feats && h_frame_offsets && d_ivectors && num_utts > 0, "k3_ivector_extract_batch: null or empty argument");
   K3_REQUIRE(ld_feats >= iv->F && ld_ivectors >= iv->R, "k3_ivector_extract_batch: leading dimension smaller than the row length");
   hipStream_t stream = (hipStream_t)stream_;
   const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period; const int64_t N = h_frame_offsets[num_utts] - h_frame_offsets[0];
   K3_REQUIRE(h_frame_offsets[0] == 0, "k3_ivector_extract_batch: frame offsets must start at 0");
-  for (int u = 0; u < num_utts; u++) K3_REQUIRE(h_frame_offsets[u + 1] > h_frame_offsets[u], "k3_ivector_extract_batch: an utterance without frames");   // the reference writes no i-vector for an empty utterance
+  // the reference writes no i-vector for an empty utterance
+  for (int u = 0; u < num_utts; u++) K3_REQUIRE(h_frame_offsets[u + 1] > h_frame_offsets[u], "k3_ivector_extract_batch: an utterance without frames");
   std::vector<int64_t> offs(2 * (size_t)(num_utts + 1));
   for (int u = 0; u <= num_utts; u++) offs[u] = h_frame_offsets[u];
   k3_ivector_num_rows(iv, num_utts, h_frame_offsets, offs.data() + num_utts + 1);
   int rc = iv->frame_off.reserve(offs.size() * 8); if (rc) return rc;
-  if ((rc = iv->cmvn.reserve((size_t)N * F * 4)) || (rc = iv->xpost.reserve((size_t)N * D * 4)) || (rc = iv->xstats.reserve((size_t)N * D * 4)) || (rc = iv->post_g.reserve((size_t)N * S * 4)) ||
+  if ((rc = iv->cmvn.reserve((size_t)N * F * 4)) || (rc = iv->xpost.reserve((size_t)N * D * 4)) || (rc = iv->xstats.reserve((size_t)N * D * 4)) ||
+      (rc = iv->post_g.reserve((size_t)N * S * 4)) ||
       (rc = iv->post_w.reserve((size_t)N * S * 4)) || (rc = iv->post_n.reserve((size_t)N * 4)) || (rc = iv->state.reserve((size_t)num_utts * R * R * 8)))
     return rc;
   if (!iv->quad_in_lds && (rc = iv->quad.reserve((size_t)num_utts * R * R * 8))) return rc;
   K3_HIP_CHECK(hipMemcpyAsync(iv->frame_off.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, stream));
   K3_HIP_CHECK(hipStreamSynchronize(stream));                   // offs is a local
   const int64_t *d_off = (const int64_t *)iv->frame_off.p, *d_row_off = d_off + num_utts + 1;
-  rc = k3_cmvn_online_batch(d_feats, ld_feats, (float *)iv->cmvn.p, F, F, d_off, num_utts, &iv->o.cmvn, iv->global_stats, d_cmvn_speaker_stats, nullptr, 0, stream_); if (rc) return rc;
+  rc = k3_cmvn_online_batch(d_feats, ld_feats, (float *)iv->cmvn.p, F, F, d_off, num_utts, &iv->o.cmvn, iv->global_stats, d_cmvn_speaker_stats, nullptr, 0,
+      stream_);
+  if (rc) return rc;
   const unsigned nb = (unsigned)((N * D + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)iv->cmvn.p, (int64_t)F, d_off, num_utts, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D,
+  hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)iv->cmvn.p, (int64_t)F, d_off, num_utts, iv->lda,
+      F * iv->splice + iv->has_offset, iv->has_offset, F, D,
                      iv->o.left_context, iv->o.right_context, (float *)iv->xpost.p, N, (int64_t)0);
-  hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, iv->o.online_cmvn_iextractor ? (const float *)iv->cmvn.p : d_feats, iv->o.online_cmvn_iextractor ? (int64_t)F : ld_feats, d_off, num_utts, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D,
+  hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, iv->o.online_cmvn_iextractor ? (const float *)iv->cmvn.p : d_feats,
+      iv->o.online_cmvn_iextractor ? (int64_t)F : ld_feats, d_off, num_utts, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D,
                      iv->o.left_context, iv->o.right_context, (float *)iv->xstats.p, N, (int64_t)0);
   const int nw = kBlock / kWave; const size_t lds_post = ((size_t)nw * G + (size_t)nw * 2 * S) * 4;
   K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_extract_batch: too many Gaussians for the posterior kernel's LDS tile");
   const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;       // GetMinPost caps it, online-ivector-feature.cc:188-199
-  hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((N + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)iv->xpost.p, D, G, iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
+  hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((N + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)iv->xpost.p, D, G, iv->gconsts,
+      iv->miv_t, iv->iv_t, S, min_post,
                      iv->o.posterior_scale, N, (int32_t *)iv->post_g.p, (float *)iv->post_w.p, (int32_t *)iv->post_n.p, (const BatchSeg *)nullptr, 0, d_frame_weights);
-  EstParams p; p.xstats = (const float *)iv->xstats.p; p.frame_off = d_off; p.post_g = (const int32_t *)iv->post_g.p; p.post_w = (const float *)iv->post_w.p; p.post_n = (const int32_t *)iv->post_n.p;
-  p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)iv->quad.p; p.chol_g = (double *)iv->state.p; p.out = d_ivectors; p.ld_out = ld_ivectors; p.out_off = d_row_off;
-  p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count; p.state_in = d_stats_in; p.state_out = d_stats_out; p.acc_tail = iv->acc_tail; p.t_base = 0; p.t_limit = -1; p.k_begin = 0; p.x_io = nullptr; p.segs = nullptr;
+  EstParams p;
+  p.xstats = (const float *)iv->xstats.p;
+  p.frame_off = d_off;
+  p.post_g = (const int32_t *)iv->post_g.p;
+  p.post_w = (const float *)iv->post_w.p;
+  p.post_n = (const int32_t *)iv->post_n.p;
+  p.U = iv->U;
+  p.SM = iv->SM;
+  p.quad_g = iv->quad_in_lds ? nullptr : (double *)iv->quad.p;
+  p.chol_g = (double *)iv->state.p;
+  p.out = d_ivectors;
+  p.ld_out = ld_ivectors;
+  p.out_off = d_row_off;
+  p.D = D;
+  p.R = R;
+  p.S = S;
+  p.period = P;
+  p.num_cg_iters = iv->o.num_cg_iters;
+  p.exact_solve = iv->o.exact_solve;
+  p.prior = iv->prior_offset;
+  p.max_count = iv->o.max_count;
+  p.state_in = d_stats_in;
+  p.state_out = d_stats_out;
+  p.acc_tail = iv->acc_tail;
+  p.t_base = 0;
+  p.t_limit = -1;
+  p.k_begin = 0;
+  p.x_io = nullptr;
+  p.segs = nullptr;
   size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
   K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_extract_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
@@ -459,19 +545,24 @@ extern "C" int k3_ivector_extract_batch_weighted(k3_ivector *iv, const float *d_
 }
 
 // ---------------------------------------------------------------------------------------------------------------- streaming
-// One stream's extractor state between chunks: what OnlineIvectorFeature keeps (online2/online-ivector-feature.h:233-330: the statistics ivector_stats_, the frames already in them,
+// One stream's extractor state between chunks: what OnlineIvectorFeature keeps (online2/online-ivector-feature.h:233-330: the statistics ivector_stats_, the
+// frames already in them,
 // the estimates made so far, and under it OnlineCmvn's window and OnlineSpliceFrames' context) and what BatchedIvectorExtractorCuda keeps per channel
 // (cudafeat/feature-online-batched-ivector-cuda.h:30-61).  Every frame passes each stage once -- CMVN recursion continued from its carried window sums, splice + LDA + posteriors
-// when the frame's right context exists (or the stream has ended), statistics and one estimate per period -- in the order and arithmetic of the whole-utterance kernels above, so the
+// when the frame's right context exists (or the stream has ended), statistics and one estimate per period -- in the order and arithmetic of the whole-utterance
+// kernels above, so the
 // rows are bit-identical to k3_ivector_extract_batch on the whole utterance (tests/test_ivector_gpu.py).  Device memory per stream: max(cmn_window, splice) raw frames, the splice
 // context of normalised frames, the posterior-stage output of at most one period (+ a chunk), and (3 F + 1 + 2 R + R^2) doubles.
 struct k3_ivector_stream {
   k3_ivector *iv = nullptr;
   DevBuf raw[2], cm[2], px[2], pg[2], pw[2], pn[2], xpost, rows, state, offs, latest, chol, quad;
   int raw_i = 0, cm_i = 0, pend_i = 0;
-  int64_t n_abs = 0, raw_s0 = 0, cm_c0 = 0, n_post = 0, a0 = 0, k_next = 0;      // frames accepted; stream index of row 0 of raw / cm / the pending posterior arrays; frames with posteriors; estimates made
+  // frames accepted; stream index of row 0 of raw / cm / the pending posterior arrays; frames with posteriors; estimates made
+  int64_t n_abs = 0, raw_s0 = 0, cm_c0 = 0, n_post = 0, a0 = 0, k_next = 0;
   bool finished = false, fresh = false;
-  bool poisoned = false;      // a batched call failed after it had begun to move this stream's state (buffer switches, counters): the host state and the device buffers may be out of step -- k3_ivector_stream_reset
+  // a batched call failed after it had begun to move this stream's state (buffer switches, counters): the host state and the device buffers may be out of step
+  // -- k3_ivector_stream_reset
+  bool poisoned = false;
 };
 
 extern "C" int k3_ivector_stream_create(k3_ivector *iv, k3_ivector_stream **out) {
@@ -487,7 +578,8 @@ extern "C" int64_t k3_ivector_stream_num_rows(const k3_ivector_stream *s) { retu
 extern "C" int k3_ivector_stream_reset(k3_ivector_stream *s, void *stream_) {
   K3_REQUIRE(s, "k3_ivector_stream_reset: null stream");
   const k3_ivector *iv = s->iv; const int F = iv->F, R = iv->R; hipStream_t stream = (hipStream_t)stream_;
-  // window sums 0; statistics of no frames: quadratic term I, linear term prior_offset e_0 (OnlineIvectorEstimationStats), estimate prior_offset e_0 (online-ivector-feature.cc:381-385)
+  // window sums 0; statistics of no frames: quadratic term I, linear term prior_offset e_0 (OnlineIvectorEstimationStats), estimate prior_offset e_0
+  // (online-ivector-feature.cc:381-385)
   std::vector<double> h((size_t)3 * F + 1 + R + (size_t)R * R + R, 0.0);
   double *est = h.data() + 3 * F; est[1] = iv->prior_offset; for (int i = 0; i < R; i++) est[1 + R + (size_t)i * R + i] = 1.0; est[1 + R + (size_t)R * R] = iv->prior_offset;
   int rc = s->state.reserve(h.size() * 8); if (rc) return rc;
@@ -512,7 +604,16 @@ int carry_over(DevBuf (&b)[2], int *cur, size_t row_bytes, int64_t keep_from, in
 }  // namespace
 
 namespace {
-__global__ void ivec_set_offsets_kernel(int64_t *o, int64_t raw_rows, int64_t cm_rows, int64_t keep) { o[0] = 0; o[1] = raw_rows; o[2] = 0; o[3] = cm_rows; o[4] = keep; o[5] = 0; o[6] = 0; o[7] = 0; }
+__global__ void ivec_set_offsets_kernel(int64_t *o, int64_t raw_rows, int64_t cm_rows, int64_t keep) {
+  o[0] = 0;
+  o[1] = raw_rows;
+  o[2] = 0;
+  o[3] = cm_rows;
+  o[4] = keep;
+  o[5] = 0;
+  o[6] = 0;
+  o[7] = 0;
+}
 }  // namespace
 
 extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_feats, int64_t ld_feats, int32_t num_frames, int32_t finished, float *d_new_rows, int64_t ld_rows,
@@ -522,7 +623,8 @@ extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_fea
   K3_REQUIRE(!s->poisoned, "k3_ivector_stream_accept: an earlier batched call on this stream failed half-way, its state is lost (k3_ivector_stream_reset starts over)");
   K3_REQUIRE(!d_new_rows || ld_rows >= s->iv->R, "k3_ivector_stream_accept: leading dimension of the rows smaller than the i-vector dimension");
   k3_ivector *iv = s->iv; hipStream_t stream = (hipStream_t)stream_;
-  const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period, lc = iv->o.left_context, rc_ = iv->o.right_context, W = iv->o.cmvn.cmn_window;
+  const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period, lc = iv->o.left_context, rc_ = iv->o.right_context,
+      W = iv->o.cmvn.cmn_window;
   const int64_t n_new = num_frames, keepN = std::max<int64_t>(W, (int64_t)lc + rc_ + 1);
   int rc;
   // ---- raw frames: [what the CMVN window and the splice still read | the new frames]
@@ -536,11 +638,14 @@ extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_fea
   if ((rc = carry_over(s->cm, &s->cm_i, (size_t)F * 4, new_c0 - s->cm_c0, cm_keep, cm_rows, stream))) return rc;
   s->cm_c0 = new_c0;
   float *cm = (float *)s->cm[s->cm_i].p;
-  hipLaunchKernelGGL(ivec_set_offsets_kernel, dim3(1), dim3(1), 0, stream, (int64_t *)s->offs.p, raw_rows, cm_rows, keep);      // (values travel as kernel arguments: nothing on the host to keep alive, no wait)
+  // (values travel as kernel arguments: nothing on the host to keep alive, no wait)
+  hipLaunchKernelGGL(ivec_set_offsets_kernel, dim3(1), dim3(1), 0, stream, (int64_t *)s->offs.p, raw_rows, cm_rows, keep);
   const int64_t *d_offs = (const int64_t *)s->offs.p;
   double *carry = (double *)s->state.p, *est = carry + 3 * F, *x_io = est + 1 + R + (size_t)R * R;
   if (n_new > 0) {      // rows keep .. raw_rows - 1 of raw -> rows cm_keep .. of cm
-    rc = k3::cmvn_online_resume_async(raw, F, cm + (cm_keep - keep) * F, F, F, (const long long *)d_offs, 1, &iv->o.cmvn, iv->global_stats, (const long long *)(d_offs + 4), carry, stream_); if (rc) return rc;
+    rc = k3::cmvn_online_resume_async(raw, F, cm + (cm_keep - keep) * F, F, F, (const long long *)d_offs, 1, &iv->o.cmvn, iv->global_stats,
+        (const long long *)(d_offs + 4), carry, stream_);
+    if (rc) return rc;
   }
   s->n_abs += n_new; s->finished = finished != 0;
   // ---- splice + LDA + posteriors for the frames whose right context is there
@@ -548,23 +653,32 @@ extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_fea
   if (nP > 0) {
     if ((rc = s->xpost.reserve((size_t)nP * D * 4))) return rc;
     int i0 = s->pend_i, i1 = s->pend_i, i2 = s->pend_i, i3 = s->pend_i;      // grow the pending arrays in step (they share pend_i)
-    if ((size_t)(pend_rows + nP) * D * 4 > s->px[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pg[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pw[s->pend_i].cap || (size_t)(pend_rows + nP) * 4 > s->pn[s->pend_i].cap) {
-      if ((rc = carry_over(s->px, &i0, (size_t)D * 4, 0, pend_rows, pend_rows + nP, stream)) || (rc = carry_over(s->pg, &i1, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) ||
+    if ((size_t)(pend_rows + nP) * D * 4 > s->px[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pg[s->pend_i].cap ||
+        (size_t)(pend_rows + nP) * S * 4 > s->pw[s->pend_i].cap || (size_t)(pend_rows + nP) * 4 > s->pn[s->pend_i].cap) {
+      if ((rc = carry_over(s->px, &i0, (size_t)D * 4, 0, pend_rows, pend_rows + nP, stream)) ||
+          (rc = carry_over(s->pg, &i1, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) ||
           (rc = carry_over(s->pw, &i2, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) || (rc = carry_over(s->pn, &i3, 4, 0, pend_rows, pend_rows + nP, stream))) return rc;
       s->pend_i = i0;
     }
-    float *px = (float *)s->px[s->pend_i].p + pend_rows * D; int32_t *pg = (int32_t *)s->pg[s->pend_i].p + pend_rows * S; float *pw = (float *)s->pw[s->pend_i].p + pend_rows * S; int32_t *pn = (int32_t *)s->pn[s->pend_i].p + pend_rows;
+    float *px = (float *)s->px[s->pend_i].p + pend_rows * D;
+    int32_t *pg = (int32_t *)s->pg[s->pend_i].p + pend_rows * S;
+    float *pw = (float *)s->pw[s->pend_i].p + pend_rows * S;
+    int32_t *pn = (int32_t *)s->pn[s->pend_i].p + pend_rows;
     const unsigned nb = (unsigned)((nP * D + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)cm, (int64_t)F, d_offs + 2, 1, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_,
+    hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)cm, (int64_t)F, d_offs + 2, 1, iv->lda,
+        F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_,
                        (float *)s->xpost.p, nP, P0 - s->cm_c0);
     if (iv->o.online_cmvn_iextractor)
-      hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)cm, (int64_t)F, d_offs + 2, 1, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, px, nP, P0 - s->cm_c0);
+      hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)cm, (int64_t)F, d_offs + 2, 1, iv->lda,
+          F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, px, nP, P0 - s->cm_c0);
     else
-      hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)raw, (int64_t)F, d_offs, 1, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, px, nP, P0 - s->raw_s0);
+      hipLaunchKernelGGL(ivec_splice_lda_kernel, dim3(nb), dim3(kBlock), 0, stream, (const float *)raw, (int64_t)F, d_offs, 1, iv->lda,
+          F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, px, nP, P0 - s->raw_s0);
     const int nw = kBlock / kWave; const size_t lds_post = ((size_t)nw * G + (size_t)nw * 2 * S) * 4;
     K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_stream_accept: too many Gaussians for the posterior kernel's LDS tile");
     const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;
-    hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((nP + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)s->xpost.p, D, G, iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
+    hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((nP + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)s->xpost.p, D, G,
+        iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
                        iv->o.posterior_scale, nP, pg, pw, pn);
     K3_HIP_CHECK(hipGetLastError());
     s->n_post = P1;
@@ -573,10 +687,22 @@ extern "C" int k3_ivector_stream_accept(k3_ivector_stream *s, const float *d_fea
   const int64_t k_end = (s->n_post + P - 1) / P, nk = k_end - s->k_next;
   if (h_num_new_rows) *h_num_new_rows = (int32_t)nk;
   if (nk > 0) {
-    K3_REQUIRE(!d_new_rows || nk <= max_new_rows, "k3_ivector_stream_accept: more new rows than the caller's buffer holds ((num_frames + right_context) / ivector_period + 1 is enough)");
+    K3_REQUIRE(!d_new_rows || nk <= max_new_rows,
+        "k3_ivector_stream_accept: more new rows than the caller's buffer holds ((num_frames + right_context) / ivector_period + 1 is enough)");
     if ((rc = s->rows.reserve((size_t)nk * R * 4))) return rc;
-    EstParams p; p.xstats = (const float *)s->px[s->pend_i].p; p.frame_off = d_offs + 6; p.post_g = (const int32_t *)s->pg[s->pend_i].p; p.post_w = (const float *)s->pw[s->pend_i].p; p.post_n = (const int32_t *)s->pn[s->pend_i].p;
-    p.U = iv->U; p.SM = iv->SM; p.quad_g = iv->quad_in_lds ? nullptr : (double *)s->quad.p; p.chol_g = (double *)s->chol.p; p.out = (float *)s->rows.p; p.ld_out = R; p.out_off = d_offs + 5;
+    EstParams p;
+    p.xstats = (const float *)s->px[s->pend_i].p;
+    p.frame_off = d_offs + 6;
+    p.post_g = (const int32_t *)s->pg[s->pend_i].p;
+    p.post_w = (const float *)s->pw[s->pend_i].p;
+    p.post_n = (const int32_t *)s->pn[s->pend_i].p;
+    p.U = iv->U;
+    p.SM = iv->SM;
+    p.quad_g = iv->quad_in_lds ? nullptr : (double *)s->quad.p;
+    p.chol_g = (double *)s->chol.p;
+    p.out = (float *)s->rows.p;
+    p.ld_out = R;
+    p.out_off = d_offs + 5;
     p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count;
     p.state_in = est; p.state_out = est; p.acc_tail = 0; p.t_base = s->a0; p.t_limit = s->n_post; p.k_begin = (int)s->k_next; p.x_io = x_io; p.segs = nullptr;
     const size_t lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
@@ -612,28 +738,36 @@ __global__ void __launch_bounds__(kBlock) ivec_batch_shift_kernel(const BatchSeg
   for (long long i = threadIdx.x; i < g.left * S; i += kBlock) { g.pg_alt[i] = g.e_pg[g.shift_from * S + i]; g.pw_alt[i] = g.e_pw[g.shift_from * S + i]; }
   for (long long i = threadIdx.x; i < g.left; i += kBlock) g.pn_alt[i] = g.e_pn[g.shift_from + i];
 }
-__global__ void ivec_batch_latest_kernel(const BatchSeg *__restrict__ segs, int R, float *__restrict__ out, long long ld_out) { if ((int)threadIdx.x < R) out[blockIdx.x * ld_out + threadIdx.x] = segs[blockIdx.x].latest[threadIdx.x]; }
+__global__ void ivec_batch_latest_kernel(const BatchSeg *__restrict__ segs, int R, float *__restrict__ out, long long ld_out) {
+  if ((int)threadIdx.x < R) out[blockIdx.x * ld_out + threadIdx.x] = segs[blockIdx.x].latest[threadIdx.x];
+}
 }  // namespace
 
-// k3_ivector_stream_accept for the streams of one batch in one launch per stage (BatchedIvectorExtractorCuda::GetIvectors per chunk, cudafeat/feature-online-batched-ivector-cuda.h:30-61):
+// k3_ivector_stream_accept for the streams of one batch in one launch per stage (BatchedIvectorExtractorCuda::GetIvectors per chunk,
+// cudafeat/feature-online-batched-ivector-cuda.h:30-61):
 // stream i takes feature rows h_frame_offsets[i] .. [i + 1] of d_feats; d_latest [num_streams x ld_latest] receives every stream's most recent estimate.  The per-stream results are
 // those of k3_ivector_stream_accept (the same kernels' arithmetic; tests/test_ivector_gpu.py).  All streams must belong to one extractor; one batched call at a time per extractor.
-extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32_t num_streams, const float *d_feats, int64_t ld_feats, const int64_t *h_frame_offsets, const int32_t *h_finished,
+extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32_t num_streams, const float *d_feats, int64_t ld_feats,
+    const int64_t *h_frame_offsets, const int32_t *h_finished,
                                               float *d_latest, int64_t ld_latest, void *stream_) {
   K3_REQUIRE(streams && num_streams > 0 && streams[0] && h_frame_offsets && h_finished && h_frame_offsets[0] == 0, "k3_ivector_stream_accept_batch: bad argument");
   k3_ivector *iv = streams[0]->iv; hipStream_t stream = (hipStream_t)stream_;
-  const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period, lc = iv->o.left_context, rc_ = iv->o.right_context, W = iv->o.cmvn.cmn_window;
+  const int F = iv->F, D = iv->D, G = iv->G, R = iv->R, S = iv->o.num_gselect, P = iv->o.ivector_period, lc = iv->o.left_context, rc_ = iv->o.right_context,
+      W = iv->o.cmvn.cmn_window;
   const int64_t keepN = std::max<int64_t>(W, (int64_t)lc + rc_ + 1);
   K3_REQUIRE(h_frame_offsets[num_streams] == 0 || (d_feats && ld_feats >= F), "k3_ivector_stream_accept_batch: features missing");
   K3_REQUIRE(!d_latest || ld_latest >= R, "k3_ivector_stream_accept_batch: leading dimension of the output smaller than the i-vector dimension");
   for (int i = 0; i < num_streams; i++) {
-    K3_REQUIRE(streams[i] && streams[i]->iv == iv && h_frame_offsets[i + 1] >= h_frame_offsets[i], "k3_ivector_stream_accept_batch: streams of different extractors, or descending offsets");
+    K3_REQUIRE(streams[i] && streams[i]->iv == iv && h_frame_offsets[i + 1] >= h_frame_offsets[i],
+        "k3_ivector_stream_accept_batch: streams of different extractors, or descending offsets");
     K3_REQUIRE(!streams[i]->finished, "k3_ivector_stream_accept_batch: a stream has ended (k3_ivector_stream_reset starts the next one)");
-    K3_REQUIRE(!streams[i]->poisoned, "k3_ivector_stream_accept_batch: an earlier batched call on a stream failed half-way, its state is lost (k3_ivector_stream_reset starts over)");
+    K3_REQUIRE(!streams[i]->poisoned,
+        "k3_ivector_stream_accept_batch: an earlier batched call on a stream failed half-way, its state is lost (k3_ivector_stream_reset starts over)");
     for (int j = 0; j < i; j++) K3_REQUIRE(streams[j] != streams[i], "k3_ivector_stream_accept_batch: a stream listed twice");
   }
   // everything that can be refused is refused BEFORE a stream's state moves: the kernels' LDS limits depend on the extractor only
-  const size_t lds_post = ((size_t)(kBlock / kWave) * G + (size_t)(kBlock / kWave) * 2 * S) * 4, lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
+  const size_t lds_post = ((size_t)(kBlock / kWave) * G + (size_t)(kBlock / kWave) * 2 * S) * 4,
+      lds_est = (size_t)(6 * R + kBlock / kWave) * 8 + (size_t)P * S * 16 + 8 + (iv->quad_in_lds ? (size_t)R * R * 8 : 0);
   K3_REQUIRE(lds_post <= 64 * 1024, "k3_ivector_stream_accept_batch: too many Gaussians for the posterior kernel's LDS tile");
   K3_REQUIRE(lds_est <= 156 * 1024, "k3_ivector_stream_accept_batch: ivector_period * num_gselect too large for the estimation kernel's LDS");
   // The planning loop below switches buffers and advances counters stream by stream while it sizes the launches; an error after it has begun (an allocation that fails for a
@@ -649,25 +783,46 @@ extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32
     const int64_t new_s0 = std::max<int64_t>(0, s->n_abs - keepN), keep = s->n_abs - new_s0, raw_rows = keep + n_new;
     const int64_t new_c0 = std::max<int64_t>(0, s->n_post - lc), cm_keep = s->n_abs - new_c0, cm_rows = cm_keep + n_new;
     g.raw_old = (const float *)s->raw[s->raw_i].p; g.cm_old = (const float *)s->cm[s->cm_i].p; g.raw_from = new_s0 - s->raw_s0; g.cm_from = new_c0 - s->cm_c0;
-    if ((rc = carry_over(s->raw, &s->raw_i, (size_t)F * 4, 0, 0, raw_rows, stream)) || (rc = carry_over(s->cm, &s->cm_i, (size_t)F * 4, 0, 0, cm_rows, stream))) return rc;      // (capacity + switch; the kernel copies)
-    g.raw = (float *)s->raw[s->raw_i].p; g.cm = (float *)s->cm[s->cm_i].p; g.keep = keep; g.n_new = n_new; g.feat_off = h_frame_offsets[i]; g.cm_keep = cm_keep; g.raw_rows = raw_rows; g.cm_rows = cm_rows;
+    // (capacity + switch; the kernel copies)
+    if ((rc = carry_over(s->raw, &s->raw_i, (size_t)F * 4, 0, 0, raw_rows, stream)) ||
+        (rc = carry_over(s->cm, &s->cm_i, (size_t)F * 4, 0, 0, cm_rows, stream))) return rc;
+    g.raw = (float *)s->raw[s->raw_i].p;
+    g.cm = (float *)s->cm[s->cm_i].p;
+    g.keep = keep;
+    g.n_new = n_new;
+    g.feat_off = h_frame_offsets[i];
+    g.cm_keep = cm_keep;
+    g.raw_rows = raw_rows;
+    g.cm_rows = cm_rows;
     s->raw_s0 = new_s0; s->cm_c0 = new_c0;
-    double *carry = (double *)s->state.p, *est = carry + 3 * F; g.est = est; g.x_io = est + 1 + R + (size_t)R * R; g.chol = (double *)s->chol.p; g.quad = iv->quad_in_lds ? nullptr : (double *)s->quad.p;
+    double *carry = (double *)s->state.p, *est = carry + 3 * F;
+    g.est = est;
+    g.x_io = est + 1 + R + (size_t)R * R;
+    g.chol = (double *)s->chol.p;
+    g.quad = iv->quad_in_lds ? nullptr : (double *)s->quad.p;
     cs[i].in = g.raw; cs[i].out = g.cm + (cm_keep - keep) * F; cs[i].rows = raw_rows; cs[i].t_begin = keep; cs[i].carry = carry;
     any_new = any_new || n_new > 0;
     s->n_abs += n_new; s->finished = fin;
     // posterior stage
     const int64_t P0 = s->n_post, P1 = fin ? s->n_abs : std::max<int64_t>(P0, s->n_abs - rc_), nP = P1 - P0, pend_rows = P0 - s->a0;
     g.nP = nP; g.out_off = total_nP; g.row0_cm = P0 - s->cm_c0; g.row0_raw = P0 - s->raw_s0; total_nP += nP;
-    if (nP > 0 && ((size_t)(pend_rows + nP) * D * 4 > s->px[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pg[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pw[s->pend_i].cap ||
+    if (nP > 0 && ((size_t)(pend_rows + nP) * D * 4 > s->px[s->pend_i].cap || (size_t)(pend_rows + nP) * S * 4 > s->pg[s->pend_i].cap ||
+        (size_t)(pend_rows + nP) * S * 4 > s->pw[s->pend_i].cap ||
                    (size_t)(pend_rows + nP) * 4 > s->pn[s->pend_i].cap)) {
       int i0 = s->pend_i, i1 = s->pend_i, i2 = s->pend_i, i3 = s->pend_i;
-      if ((rc = carry_over(s->px, &i0, (size_t)D * 4, 0, pend_rows, pend_rows + nP, stream)) || (rc = carry_over(s->pg, &i1, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) ||
+      if ((rc = carry_over(s->px, &i0, (size_t)D * 4, 0, pend_rows, pend_rows + nP, stream)) ||
+          (rc = carry_over(s->pg, &i1, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) ||
           (rc = carry_over(s->pw, &i2, (size_t)S * 4, 0, pend_rows, pend_rows + nP, stream)) || (rc = carry_over(s->pn, &i3, 4, 0, pend_rows, pend_rows + nP, stream))) return rc;
       s->pend_i = i0;
     }
-    g.e_px = (const float *)s->px[s->pend_i].p; g.e_pg = (const int32_t *)s->pg[s->pend_i].p; g.e_pw = (const float *)s->pw[s->pend_i].p; g.e_pn = (const int32_t *)s->pn[s->pend_i].p;
-    g.px = (float *)s->px[s->pend_i].p + pend_rows * D; g.pg = (int32_t *)s->pg[s->pend_i].p + pend_rows * S; g.pw = (float *)s->pw[s->pend_i].p + pend_rows * S; g.pn = (int32_t *)s->pn[s->pend_i].p + pend_rows;
+    g.e_px = (const float *)s->px[s->pend_i].p;
+    g.e_pg = (const int32_t *)s->pg[s->pend_i].p;
+    g.e_pw = (const float *)s->pw[s->pend_i].p;
+    g.e_pn = (const int32_t *)s->pn[s->pend_i].p;
+    g.px = (float *)s->px[s->pend_i].p + pend_rows * D;
+    g.pg = (int32_t *)s->pg[s->pend_i].p + pend_rows * S;
+    g.pw = (float *)s->pw[s->pend_i].p + pend_rows * S;
+    g.pn = (int32_t *)s->pn[s->pend_i].p + pend_rows;
     s->n_post = P1;
     // estimates
     const int64_t k_end = (s->n_post + P - 1) / P, nk = k_end - s->k_next;
@@ -697,17 +852,29 @@ extern "C" int k3_ivector_stream_accept_batch(k3_ivector_stream **streams, int32
   if (any_new && (rc = k3::cmvn_online_resume_segs_async(d_cs, num_streams, F, &iv->o.cmvn, iv->global_stats, stream_))) return rc;
   if (total_nP > 0) {
     const unsigned nb = (unsigned)((total_nP * D + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(ivec_splice_lda_multi_kernel, dim3(nb), dim3(kBlock), 0, stream, d_segs, num_streams, 0, 0, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_, (float *)iv->xpost.p, total_nP);
-    hipLaunchKernelGGL(ivec_splice_lda_multi_kernel, dim3(nb), dim3(kBlock), 0, stream, d_segs, num_streams, 1, iv->o.online_cmvn_iextractor ? 1 : 0, iv->lda, F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_,
+    hipLaunchKernelGGL(ivec_splice_lda_multi_kernel, dim3(nb), dim3(kBlock), 0, stream, d_segs, num_streams, 0, 0, iv->lda, F * iv->splice + iv->has_offset,
+        iv->has_offset, F, D, lc, rc_, (float *)iv->xpost.p, total_nP);
+    hipLaunchKernelGGL(ivec_splice_lda_multi_kernel, dim3(nb), dim3(kBlock), 0, stream, d_segs, num_streams, 1, iv->o.online_cmvn_iextractor ? 1 : 0, iv->lda,
+        F * iv->splice + iv->has_offset, iv->has_offset, F, D, lc, rc_,
                        (float *)iv->xpost.p, total_nP);
     const int nw = kBlock / kWave;
     const float min_post = iv->o.min_post < 0.99f ? iv->o.min_post : 0.99f;
-    hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((total_nP + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)iv->xpost.p, D, G, iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
+    hipLaunchKernelGGL(ivec_posterior_kernel, dim3((unsigned)((total_nP + nw - 1) / nw)), dim3(kBlock), lds_post, stream, (const float *)iv->xpost.p, D, G,
+        iv->gconsts, iv->miv_t, iv->iv_t, S, min_post,
                        iv->o.posterior_scale, total_nP, (int32_t *)nullptr, (float *)nullptr, (int32_t *)nullptr, d_segs, num_streams);
   }
   if (any_est) {
     EstParams p{};
-    p.U = iv->U; p.SM = iv->SM; p.D = D; p.R = R; p.S = S; p.period = P; p.num_cg_iters = iv->o.num_cg_iters; p.exact_solve = iv->o.exact_solve; p.prior = iv->prior_offset; p.max_count = iv->o.max_count;
+    p.U = iv->U;
+    p.SM = iv->SM;
+    p.D = D;
+    p.R = R;
+    p.S = S;
+    p.period = P;
+    p.num_cg_iters = iv->o.num_cg_iters;
+    p.exact_solve = iv->o.exact_solve;
+    p.prior = iv->prior_offset;
+    p.max_count = iv->o.max_count;
     p.acc_tail = 0; p.t_limit = 0; p.segs = d_segs;
     K3_HIP_CHECK(hipFuncSetAttribute((const void *)ivec_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_est));
     hipLaunchKernelGGL(ivec_estimate_kernel, dim3((unsigned)num_streams), dim3(kBlock), lds_est, stream, p);

@@ -74,10 +74,18 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // EPI: the epilogue program known at compile time -- 0: any (run-time dispatch per op), 1: ReLU, scale/offset, residual (a TDNN-F
 // affine + ReLU + BatchNorm + bypass), 2: none (linear bottleneck), 3: ReLU, scale/offset.  The fixed programs are straight-line
 // code; the run-time dispatch costs a register shuffle per op when it merges the branches.
-enum { kEpiAny = 0, kEpiReluScaleRes = 1, kEpiNone = 2, kEpiReluScale = 3, kEpiAnyMap = 4 };      // kEpiAnyMap: kEpiAny + the sigmoid / tanh operations (their own instantiation: the exp code costs the generic one registers)
+// kEpiAnyMap: kEpiAny + the sigmoid / tanh operations (their own instantiation: the exp code costs the generic one registers)
+enum { kEpiAny = 0, kEpiReluScaleRes = 1, kEpiNone = 2, kEpiReluScale = 3, kEpiAnyMap = 4 };
 // SigmoidComponent / TanhComponent: the overflow-safe forms of matrix/kaldi-vector.cc:900-960
 __device__ __forceinline__ float epi_sigmoid(float x) { if (x > 0.0f) return 1.0f / (1.0f + expf(-x)); const float e = expf(x); return e / (e + 1.0f); }
-__device__ __forceinline__ float epi_tanh(float x) { if (x > 0.0f) { const float e = expf(-x); return -1.0f + 2.0f / (1.0f + e * e); } const float e = expf(x); return 1.0f - 2.0f / (1.0f + e * e); }
+__device__ __forceinline__ float epi_tanh(float x) {
+  if (x > 0.0f) {
+    const float e = expf(-x);
+    return -1.0f + 2.0f / (1.0f + e * e);
+  }
+  const float e = expf(x);
+  return 1.0f - 2.0f / (1.0f + e * e);
+}
 template <int BN, int WM, int WN, bool kAligned, int EPI>
 __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN) == 8 ? 4 : 2) void k3_tdnn_gemm_kernel(GemmParams p) {
   constexpr int NT = (kBM / WM) * (BN / WN) * 64, LR = NT / 8;      // threads per workgroup (4 or 8 wavefronts); rows the loader covers per pass
@@ -125,7 +133,11 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
         for (int i = 0; i < A_LOADS; i++) a_ptr[i] = p.A + (long long)clampi(a_row_local[i] + sh, a_lo[i], a_hi[i]) * p.lda + ld_kv;
       }
 #pragma unroll
-      for (int i = 0; i < A_LOADS; i++) { ra[i] = *reinterpret_cast<const f32x4 *>(dummy ? p.W : a_ptr[i]); a_ptr[i] += kBK; }      // (dummy: every lane the same 16 bytes -- one cache line per instruction, and no address past the last row)
+      // (dummy: every lane the same 16 bytes -- one cache line per instruction, and no address past the last row)
+      for (int i = 0; i < A_LOADS; i++) {
+        ra[i] = *reinterpret_cast<const f32x4 *>(dummy ? p.W : a_ptr[i]);
+        a_ptr[i] += kBK;
+      }
     } else {
       const bool kvalid = kglob < p.Ktot;
       const int oi = kglob / p.in_dim, col = kglob - oi * p.in_dim;
@@ -325,7 +337,12 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
           const int kind = p.op_kind[o];
           if (kind == k3::kEpiRelu) {
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) { v[it][0] = fmaxf(v[it][0], 0.0f); v[it][1] = fmaxf(v[it][1], 0.0f); v[it][2] = fmaxf(v[it][2], 0.0f); v[it][3] = fmaxf(v[it][3], 0.0f); }
+            for (int it = 0; it < ITERS; it++) {
+              v[it][0] = fmaxf(v[it][0], 0.0f);
+              v[it][1] = fmaxf(v[it][1], 0.0f);
+              v[it][2] = fmaxf(v[it][2], 0.0f);
+              v[it][3] = fmaxf(v[it][3], 0.0f);
+            }
           } else if (kind == k3::kEpiScaleOffset) {
 #pragma unroll
             for (int it = 0; it < ITERS; it++) v[it] = v[it] * opS[o] + opO[o];
@@ -587,7 +604,12 @@ __global__ __launch_bounds__(256, 2) void k3_tdnn_gemm_x6_kernel(GemmParams p, c
           const int kind = p.op_kind[o];
           if (kind == k3::kEpiRelu) {
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) { v[it][0] = fmaxf(v[it][0], 0.0f); v[it][1] = fmaxf(v[it][1], 0.0f); v[it][2] = fmaxf(v[it][2], 0.0f); v[it][3] = fmaxf(v[it][3], 0.0f); }
+            for (int it = 0; it < ITERS; it++) {
+              v[it][0] = fmaxf(v[it][0], 0.0f);
+              v[it][1] = fmaxf(v[it][1], 0.0f);
+              v[it][2] = fmaxf(v[it][2], 0.0f);
+              v[it][3] = fmaxf(v[it][3], 0.0f);
+            }
           } else if (kind == k3::kEpiScaleOffset) {
 #pragma unroll
             for (int it = 0; it < ITERS; it++) v[it] = v[it] * opS[o] + opO[o];
@@ -702,8 +724,10 @@ struct k3_nnet {
 };
 
 namespace {
-// LogSoftmaxComponent / SoftmaxComponent::Propagate (nnet-simple-component.cc:3618-3625, :3494-3504; CuMatrixBase::LogSoftMaxPerRow / SoftMaxPerRow): one wavefront per row, in place:
-// max, sum of exp(x - max) (float, like the CPU's VectorBase::ApplyLogSoftMax / ApplySoftMax), then x - max - log(sum) or exp(x - max) / sum; optional y * scale[c] + offset[c] behind it
+// LogSoftmaxComponent / SoftmaxComponent::Propagate (nnet-simple-component.cc:3618-3625, :3494-3504; CuMatrixBase::LogSoftMaxPerRow / SoftMaxPerRow): one
+// wavefront per row, in place:
+// max, sum of exp(x - max) (float, like the CPU's VectorBase::ApplyLogSoftMax / ApplySoftMax), then x - max - log(sum) or exp(x - max) / sum; optional y *
+// scale[c] + offset[c] behind it
 // (the decodable's prior subtraction and acoustic scale on the output node).
 __global__ __launch_bounds__(256) void k3_row_softmax_kernel(float *C, long long ldc, int rows, int cols, int op, const float *scale, const float *offset) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -867,13 +891,18 @@ static int batch_create_impl(k3_nnet *net, int32_t num_utts, const int32_t *h_nu
     for (int u = 0; u < num_utts; u++) {
       const int n_sub = (h_num_frames[u] + subsampling - 1) / subsampling;
       if (!with_ivector || online_ivector_period <= 0) { seqs.push_back({u, 0, n_sub, with_ivector ? (int)iv_base : -1}); if (with_ivector) iv_base += 1; continue; }
-      const int per = (frames_per_chunk + subsampling - 1) / subsampling, rows = h_num_ivector_rows[u];      // the chunk rounded up to a multiple of s (CheckAndFixConfigs, nnet-am-decodable-simple.h:120-134)
+      // the chunk rounded up to a multiple of s (CheckAndFixConfigs, nnet-am-decodable-simple.h:120-134)
+      const int per = (frames_per_chunk + subsampling - 1) / subsampling, rows = h_num_ivector_rows[u];
       K3_REQUIRE(rows > 0, "k3_nnet_batch_create_ivector: utterance without i-vector rows");
       for (int c0 = 0; c0 < n_sub; c0 += per) {
         const int n = std::min(per, n_sub - c0), first = c0 * subsampling, last = (c0 + n - 1) * subsampling;
         int f = (first + (last - first) / 2) / online_ivector_period;                                        // GetCurrentIvector :178-213
         if (f >= rows) {
-          if ((long long)(f - (rows - 1)) * online_ivector_period > 50) { k3::set_error("Could not get iVector for frame %d, only available till frame %d * ivector-period=%d (mismatched --online-ivector-period?)", first + (last - first) / 2, rows, online_ivector_period); return K3_ERR_ARG; }
+          if ((long long)(f - (rows - 1)) * online_ivector_period > 50) {
+            k3::set_error("Could not get iVector for frame %d, only available till frame %d * ivector-period=%d (mismatched --online-ivector-period?)",
+                first + (last - first) / 2, rows, online_ivector_period);
+            return K3_ERR_ARG;
+          }
           f = rows - 1;
         }
         seqs.push_back({u, first, n, (int)(iv_base + f)});
@@ -1047,8 +1076,10 @@ extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_
 extern "C" int k3_nnet_batch_create_ivector(k3_nnet *net, int32_t num_utts, const int32_t *h_num_frames, int32_t subsampling, const float *h_log_priors, float acoustic_scale,
                                             int32_t frames_per_chunk, int32_t online_ivector_period, const int32_t *h_num_ivector_rows, k3_nnet_batch **out) {
   K3_REQUIRE(net, "k3_nnet_batch_create_ivector: bad argument");
-  K3_REQUIRE(net->fm.ivector_dim > 0, "k3_nnet_batch_create_ivector: the model has no i-vector input");      // "Neural net expects 'ivector' features with dimension 0 but you provided N" (:105-107)
-  K3_REQUIRE(online_ivector_period == 0 || (online_ivector_period > 0 && frames_per_chunk > 0 && h_num_ivector_rows), "k3_nnet_batch_create_ivector: online i-vectors need a period, a chunk size and the row counts");
+  // "Neural net expects 'ivector' features with dimension 0 but you provided N" (:105-107)
+  K3_REQUIRE(net->fm.ivector_dim > 0, "k3_nnet_batch_create_ivector: the model has no i-vector input");
+  K3_REQUIRE(online_ivector_period == 0 || (online_ivector_period > 0 && frames_per_chunk > 0 && h_num_ivector_rows),
+      "k3_nnet_batch_create_ivector: online i-vectors need a period, a chunk size and the row counts");
   return batch_create_impl(net, num_utts, h_num_frames, subsampling, h_log_priors, acoustic_scale, true, frames_per_chunk, online_ivector_period, h_num_ivector_rows, out);
 }
 
@@ -1093,14 +1124,16 @@ extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t l
   K3_REQUIRE(b && b->net->fm.ivector_dim == 0, "k3_nnet_forward: null batch, or the model has an i-vector input (use k3_nnet_forward_ivector)");
   return forward_impl(b, d_feats, ld_feats, d_out, ld_out, stream);
 }
-extern "C" int k3_nnet_forward_ivector(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, const float *d_ivectors, int64_t ld_ivectors, float *d_out, int64_t ld_out, void *stream) {
+extern "C" int k3_nnet_forward_ivector(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, const float *d_ivectors, int64_t ld_ivectors, float *d_out,
+    int64_t ld_out, void *stream) {
   K3_REQUIRE(b && d_ivectors && b->d_seq_iv_row, "k3_nnet_forward_ivector: null argument, or the batch was not made by k3_nnet_batch_create_ivector");
   const k3::FusedModel &fm = b->net->fm;
   K3_REQUIRE(ld_ivectors >= fm.ivector_dim, "k3_nnet_forward_ivector: ld_ivectors < i-vector dim");
   for (size_t i = 0; i < fm.nodes.size(); i++) {
     if (!b->seq_bias[i]) continue;
     const long long n = (long long)b->num_seqs * fm.nodes[i].out_dim;
-    hipLaunchKernelGGL(k3_seq_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_ivectors, (long long)ld_ivectors, b->d_seq_iv_row, b->num_seqs, b->net->dev[i].W_iv,
+    hipLaunchKernelGGL(k3_seq_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_ivectors, (long long)ld_ivectors,
+        b->d_seq_iv_row, b->num_seqs, b->net->dev[i].W_iv,
                        fm.ivector_dim, b->net->dev[i].bias, fm.nodes[i].out_dim, b->seq_bias[i], (long long)b->seq_bias_ld[i]);
   }
   return forward_impl(b, d_feats, ld_feats, d_out, ld_out, stream);
@@ -1136,7 +1169,8 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
         p.dbg_buf = dbuf + 4 * (i % 64);
         if (i + 1 == fm.nodes.size()) {    // dump after the last node was launched (previous forward's numbers + this one's so far)
           long long h[64 * 4]; (void)hipDeviceSynchronize(); (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
-          for (size_t n = 0; n < fm.nodes.size() && n < 64; n++) if (h[4 * n + 3]) fprintf(stderr, "node %zu %-24s blocks %lld  prologue %.0f  mainloop %.0f  epilogue %.0f cycles/block\n", n, fm.nodes[n].name.c_str(), h[4 * n + 3],
+          for (size_t n = 0; n < fm.nodes.size() && n < 64; n++) if (h[4 * n + 3]) fprintf(stderr,
+              "node %zu %-24s blocks %lld  prologue %.0f  mainloop %.0f  epilogue %.0f cycles/block\n", n, fm.nodes[n].name.c_str(), h[4 * n + 3],
                   (double)h[4 * n] / h[4 * n + 3], (double)h[4 * n + 1] / h[4 * n + 3], (double)h[4 * n + 2] / h[4 * n + 3]);
           (void)hipMemset(dbuf, 0, sizeof(h));
         }
@@ -1165,7 +1199,8 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
       const size_t lds_pad = 0;
 #endif
       bool launched = false;
-      if (b->precision == 1 && al && b->net->dev[i].Wp && !has_map) {      // split-bf16: three planes of 80-byte rows per operand, or the epilogue's staging tile, whichever is larger
+      // split-bf16: three planes of 80-byte rows per operand, or the epilogue's staging tile, whichever is larger
+      if (b->precision == 1 && al && b->net->dev[i].Wp && !has_map) {
         const int bn_ = bn96 ? 96 : 128, wm_ = bn96 ? 32 : 64, wn_ = bn96 ? 96 : 64;
         const size_t lds6 = std::max<size_t>((size_t)3 * (kBM + bn_) * 80, (size_t)4 * wm_ * (wn_ + 4) * sizeof(float));
         const int epi6 = (epi == kEpiNone && !bn96) ? (int)kEpiAny : ((epi == kEpiReluScaleRes || epi == kEpiReluScale) && bn96 ? (int)kEpiAny : epi);
@@ -1180,9 +1215,11 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
     }
     if (f.row_op) {      // LogSoftmaxComponent / SoftmaxComponent on the node's rows, in place; on the output node followed by (x - log prior) * acoustic scale
       const bool outn = (int)i == fm.output_node;
-      if (f.row_op == 3) hipLaunchKernelGGL(k3_row_normalize_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc, (int)b->node_rows[i], f.out_dim, f.row_param,
+      if (f.row_op == 3) hipLaunchKernelGGL(k3_row_normalize_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc,
+          (int)b->node_rows[i], f.out_dim, f.row_param,
                                             outn ? b->out_scale : (const float *)nullptr, outn ? b->out_offset : (const float *)nullptr);
-      else hipLaunchKernelGGL(k3_row_softmax_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc, (int)b->node_rows[i], f.out_dim, f.row_op,
+      else hipLaunchKernelGGL(k3_row_softmax_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc,
+          (int)b->node_rows[i], f.out_dim, f.row_op,
                          outn ? b->out_scale : (const float *)nullptr, outn ? b->out_offset : (const float *)nullptr);
     }
     K3_HIP_CHECK(hipGetLastError());
@@ -1217,19 +1254,28 @@ struct k3_nnet_stream {
   static constexpr int kSlots = 4;
   struct Slot { char *h = nullptr, *d = nullptr; hipEvent_t ev = nullptr; bool used = false; } slot[kSlots]; unsigned seq = 0; size_t slot_bytes = 0;
   std::vector<void *> allocs;
-  ~k3_nnet_stream() { for (void *p : allocs) (void)hipFree(p); for (Slot &g : slot) { if (g.h) (void)hipHostFree(g.h); if (g.d) (void)hipFree(g.d); if (g.ev) (void)hipEventDestroy(g.ev); } }
+  ~k3_nnet_stream() {
+    for (void *p : allocs) (void)hipFree(p);
+    for (Slot &g : slot) {
+      if (g.h) (void)hipHostFree(g.h);
+      if (g.d) (void)hipFree(g.d);
+      if (g.ev) (void)hipEventDestroy(g.ev);
+    }
+  }
 };
 
 namespace {
 // new input rows of a pass into the time-major input buffer: channel c's rows [off[c], off[c + 1]) of `src` (at most C; fewer = the stream's audio has ended: the missing frames
 // replicate the last real one -- this pass's, or the newest history row when the channel has none left); inactive channels are skipped
-__global__ __launch_bounds__(256) void k3_stream_prep_kernel(const float *src, long long lds, const long long *start, const int *count, float *in_buf, long long ld, int nch, int C, int H, int dim4) {
+__global__ __launch_bounds__(256) void k3_stream_prep_kernel(const float *src, long long lds, const long long *start, const int *count, float *in_buf,
+    long long ld, int nch, int C, int H, int dim4) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x; const long long per_t = (long long)nch * dim4;
   if (i >= (long long)C * per_t) return;
   const int t = (int)(i / per_t), c = (int)((i % per_t) / dim4), q = (int)(i % dim4);
   const int n = count[c]; if (n < 0) return;      // (the channel sits this pass out)
   const long long r0 = start[c];
-  const float4 *from = n > 0 ? reinterpret_cast<const float4 *>(src + (r0 + (t < n ? t : n - 1)) * lds) : reinterpret_cast<const float4 *>(in_buf + ((long long)(H - 1) * nch + c) * ld);
+  const float4 *from = n > 0 ? reinterpret_cast<const float4 *>(src + (r0 + (t < n ? t : n - 1)) * lds) :
+      reinterpret_cast<const float4 *>(in_buf + ((long long)(H - 1) * nch + c) * ld);
   reinterpret_cast<float4 *>(in_buf + ((long long)(H + t) * nch + c) * ld)[q] = from[q];
 }
 // behind a pass: every node's newest H rows become its history (active channels only).  One launch for all nodes: blockIdx.y = node, x over (h, channel, float4 column)
@@ -1239,7 +1285,9 @@ __global__ __launch_bounds__(256) void k3_stream_shift_kernel(const k3_nnet_stre
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const int h = (int)(i / ((long long)nch * d4)), c = (int)((i / d4) % nch), q = (int)(i % d4);
     if (count[c] < 0) continue;
-    reinterpret_cast<float4 *>(nb.buf + ((long long)h * nch + c) * nb.ld)[q] = reinterpret_cast<const float4 *>(nb.buf + ((long long)(nb.N + h) * nch + c) * nb.ld)[q];      // (H <= N: source and destination never overlap)
+    // (H <= N: source and destination never overlap)
+    reinterpret_cast<float4 *>(nb.buf + ((long long)h * nch + c) * nb.ld)[q] =
+        reinterpret_cast<const float4 *>(nb.buf + ((long long)(nb.N + h) * nch + c) * nb.ld)[q];
   }
 }
 // a restarted channel's histories: H copies of the node's constant response (entry 0: the input itself, i.e. frame 0 replicated)
@@ -1262,11 +1310,16 @@ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 extern "C" void k3_nnet_stream_destroy(k3_nnet_stream *s) { delete s; }
 
-extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t frames_per_chunk, int32_t subsampling, const float *h_log_priors, float acoustic_scale, k3_nnet_stream **out) {
-  K3_REQUIRE(net && out && num_channels > 0 && frames_per_chunk > 0 && subsampling >= 1 && frames_per_chunk % subsampling == 0, "k3_nnet_stream_create: bad argument (frames_per_chunk must be a positive multiple of the subsampling factor)");
+extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t frames_per_chunk, int32_t subsampling, const float *h_log_priors,
+    float acoustic_scale, k3_nnet_stream **out) {
+  K3_REQUIRE(net && out && num_channels > 0 && frames_per_chunk > 0 && subsampling >= 1 && frames_per_chunk % subsampling == 0,
+      "k3_nnet_stream_create: bad argument (frames_per_chunk must be a positive multiple of the subsampling factor)");
   K3_REQUIRE(net->fm.input_dim % 4 == 0, "k3_nnet_stream_create: the input dimension must be a multiple of 4 (vector loads)");
   const k3::FusedModel &fm = net->fm; const int nn = (int)fm.nodes.size(), C = frames_per_chunk, NCH = num_channels;
-  if (fm.ivector_dim > 0) { k3::set_error("k3_nnet_stream_create: models with an i-vector input are evaluated chunk by chunk with their context (k3_nnet_batch_create_ivector)"); return K3_ERR_UNSUPPORTED; }
+  if (fm.ivector_dim > 0) {
+    k3::set_error("k3_nnet_stream_create: models with an i-vector input are evaluated chunk by chunk with their context (k3_nnet_batch_create_ivector)");
+    return K3_ERR_UNSUPPORTED;
+  }
   // ---- time grids: the whole-utterance planner's backward sweep (A = first time, R = right extension, G = step)
   std::vector<int> A(nn, 0), R(nn, 0), G(nn, 0); std::vector<char> used(nn, 0); int R_in = -(1 << 30), A_in = 1 << 30;
   A[fm.output_node] = 0; R[fm.output_node] = 0; G[fm.output_node] = subsampling; used[fm.output_node] = 1;
@@ -1281,7 +1334,15 @@ extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t
         A[i] = a; G[i] = g; R[i] = rmax[i]; used[i] = 1;
       }
       const k3::FusedNode &f = fm.nodes[i];
-      auto contribute = [&](int src, int off) { if (src < 0) { R_in = std::max(R_in, R[i] + off); A_in = std::min(A_in, A[i] + off); return; } anchors[src].push_back({A[i] + off, G[i]}); rmax[src] = std::max(rmax[src], R[i] + off); };
+      auto contribute = [&](int src, int off) {
+        if (src < 0) {
+          R_in = std::max(R_in, R[i] + off);
+          A_in = std::min(A_in, A[i] + off);
+          return;
+        }
+        anchors[src].push_back({A[i] + off, G[i]});
+        rmax[src] = std::max(rmax[src], R[i] + off);
+      };
       for (int o : f.offsets) contribute(f.input, o);
       for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual) contribute(op.res_node, 0);
     }
@@ -1294,7 +1355,10 @@ extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t
   for (int i = -1; i < nn; i++) {
     if (i >= 0 && !used[i]) continue;
     const int g = Gx(i), a = i < 0 ? 0 : A[i], r = i < 0 ? R_in : R[i];
-    if (C % g != 0) { k3::set_error("k3_nnet_stream_create: frames_per_chunk %d is not a multiple of node %s's time step %d", C, i < 0 ? "input" : fm.nodes[i].name.c_str(), g); return K3_ERR_UNSUPPORTED; }
+    if (C % g != 0) {
+      k3::set_error("k3_nnet_stream_create: frames_per_chunk %d is not a multiple of node %s's time step %d", C, i < 0 ? "input" : fm.nodes[i].name.c_str(), g);
+      return K3_ERR_UNSUPPORTED;
+    }
     const int lo = -1 - (R_in - r);                                   // hi_i(0): the newest row before the first pass
     first[idx(i)] = a + (floor_div(lo - a, g) + 1) * g;               // smallest grid point > lo
     Nn[idx(i)] = C / g;
@@ -1302,27 +1366,65 @@ extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t
   for (int i = 0; i < nn; i++) {
     if (!used[i]) continue;
     const k3::FusedNode &f = fm.nodes[i];
-    if (f.row_op && i != fm.output_node) { k3::set_error("k3_nnet_stream_create: node %s applies a row operation in place (NormalizeComponent / softmax inside the network): not supported by the stateful engine", f.name.c_str()); return K3_ERR_UNSUPPORTED; }
+    if (f.row_op && i != fm.output_node) {
+      k3::set_error("k3_nnet_stream_create: node %s applies a row operation in place (NormalizeComponent / softmax inside the network): not supported by the stateful engine", f.name.c_str());
+      return K3_ERR_UNSUPPORTED;
+    }
     auto need = [&](int src, int o_min, int o_max) {
       const int gs = Gx(src), fs = first[idx(src)], fi = first[i];
       if ((fi + o_min - fs) % gs != 0 || G[i] % gs != 0) return false;
-      { const int d = fs - (fi + o_min); H[idx(src)] = std::max(H[idx(src)], d > 0 ? d / gs : 0); }      // grid points of the source in [fi + o_min, fs): rows of its history this node still reads
+      // grid points of the source in [fi + o_min, fs): rows of its history this node still reads
+      {
+        const int d = fs - (fi + o_min);
+        H[idx(src)] = std::max(H[idx(src)], d > 0 ? d / gs : 0);
+      }
       return fi + (Nn[i] - 1) * G[i] + o_max <= fs + (Nn[idx(src)] - 1) * gs;      // the newest row it reads exists
     };
     bool ok = true;
-    { int lo = 1 << 30, hi = -(1 << 30); for (int o : f.offsets) { lo = std::min(lo, o); hi = std::max(hi, o); if ((first[i] + o - first[idx(f.input)]) % Gx(f.input) != 0) ok = false; } ok = ok && need(f.input, lo, hi); }
-    for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual) ok = ok && need(op.res_node, 0, 0);      // (the bypass may come from a finer grid: G_i % G_res == 0 is all it takes)
-    if (!ok) { k3::set_error("k3_nnet_stream_create: the time grids of node %s (first %d, step %d) and its inputs do not line up for incremental evaluation", f.name.c_str(), first[i], G[i]); return K3_ERR_UNSUPPORTED; }
+    {
+      int lo = 1 << 30, hi = -(1 << 30);
+      for (int o : f.offsets) {
+        lo = std::min(lo, o);
+        hi = std::max(hi, o);
+        if ((first[i] + o - first[idx(f.input)]) % Gx(f.input) != 0) ok = false;
+      }
+      ok = ok && need(f.input, lo, hi);
+    }
+    // (the bypass may come from a finer grid: G_i % G_res == 0 is all it takes)
+    for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual) ok = ok && need(op.res_node, 0, 0);
+    if (!ok) {
+      k3::set_error("k3_nnet_stream_create: the time grids of node %s (first %d, step %d) and its inputs do not line up for incremental evaluation",
+          f.name.c_str(), first[i], G[i]);
+      return K3_ERR_UNSUPPORTED;
+    }
   }
   H[nn] = std::max(H[nn], 1);      // (the input keeps at least its newest frame: what the end of a stream replicates)
-  for (int i = -1; i < nn; i++) if ((i < 0 || used[i]) && H[idx(i)] > Nn[idx(i)]) { k3::set_error("k3_nnet_stream_create: frames_per_chunk %d is shorter than the history a node keeps (%d rows)", C, H[idx(i)]); return K3_ERR_UNSUPPORTED; }
+  for (int i = -1; i < nn; i++) if ((i < 0 || used[i]) && H[idx(i)] > Nn[idx(i)]) {
+    k3::set_error("k3_nnet_stream_create: frames_per_chunk %d is shorter than the history a node keeps (%d rows)", C, H[idx(i)]);
+    return K3_ERR_UNSUPPORTED;
+  }
 
   if (getenv("K3_NNET_STREAM_PLAN")) for (int i = -1; i < nn; i++) if (i < 0 || used[i])      // development aid: the plan, before anything is allocated
-    fprintf(stderr, "k3_nnet_stream plan: node %-22s A %4d R %3d G %d first %4d new %3d history %d\n", i < 0 ? "input" : fm.nodes[i].name.c_str(), i < 0 ? A_in : A[i], i < 0 ? R_in : R[i], Gx(i), first[idx(i)], Nn[idx(i)], H[idx(i)]);
+    fprintf(stderr, "k3_nnet_stream plan: node %-22s A %4d R %3d G %d first %4d new %3d history %d\n", i < 0 ? "input" : fm.nodes[i].name.c_str(),
+        i < 0 ? A_in : A[i], i < 0 ? R_in : R[i], Gx(i), first[idx(i)], Nn[idx(i)], H[idx(i)]);
   { const int rc = ensure_uploaded(net); if (rc) return rc; }      // (everything above is host arithmetic: a model the engine cannot run is refused without touching the device)
   std::unique_ptr<k3_nnet_stream> S(new k3_nnet_stream());
-  S->net = net; S->nch = NCH; S->C = C; S->s = subsampling; S->in_dim = fm.input_dim; S->out_dim = fm.output_dim; S->H_in = H[nn]; S->N_out = Nn[fm.output_node]; S->first_out = first[fm.output_node]; S->R_in = R_in;
-  auto dalloc = [&](size_t bytes, float **p) -> int { K3_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(bytes, 256))); S->allocs.push_back(*p); K3_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(bytes, 256))); return K3_OK; };
+  S->net = net;
+  S->nch = NCH;
+  S->C = C;
+  S->s = subsampling;
+  S->in_dim = fm.input_dim;
+  S->out_dim = fm.output_dim;
+  S->H_in = H[nn];
+  S->N_out = Nn[fm.output_node];
+  S->first_out = first[fm.output_node];
+  S->R_in = R_in;
+  auto dalloc = [&](size_t bytes, float **p) -> int {
+    K3_HIP_CHECK(hipMalloc((void **)p, std::max<size_t>(bytes, 256)));
+    S->allocs.push_back(*p);
+    K3_HIP_CHECK(hipMemset(*p, 0, std::max<size_t>(bytes, 256)));
+    return K3_OK;
+  };
   S->nb.assign(nn + 1, k3_nnet_stream::NodeBuf());
   S->ld_in = (long long)align_up(fm.input_dim, 4);
   { int rc = dalloc((size_t)(H[nn] + C) * NCH * S->ld_in * 4, &S->in_buf); if (rc) return rc; rc = dalloc((size_t)NCH * S->ld_in * 4, &S->const_in); if (rc) return rc; }
@@ -1337,7 +1439,11 @@ extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t
     S->n_nb = (int)keep.size(); K3_HIP_CHECK(hipMalloc((void **)&S->d_nb, keep.size() * sizeof(keep[0]))); S->allocs.push_back(S->d_nb);
     K3_HIP_CHECK(hipMemcpy(S->d_nb, keep.data(), keep.size() * sizeof(keep[0]), hipMemcpyHostToDevice)); }
   S->slot_bytes = align_up(sizeof(long long) * (NCH + 1), 16) + align_up(sizeof(int) * NCH, 16) * 2;
-  for (auto &g : S->slot) { K3_HIP_CHECK(hipHostMalloc((void **)&g.h, S->slot_bytes, hipHostMallocDefault)); K3_HIP_CHECK(hipMalloc((void **)&g.d, S->slot_bytes)); K3_HIP_CHECK(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming)); }
+  for (auto &g : S->slot) {
+    K3_HIP_CHECK(hipHostMalloc((void **)&g.h, S->slot_bytes, hipHostMallocDefault));
+    K3_HIP_CHECK(hipMalloc((void **)&g.d, S->slot_bytes));
+    K3_HIP_CHECK(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+  }
 
   // ---- the two plans, as k3_nnet_batch objects that forward_impl runs: `pass` (C / G_i time steps of num_channels rows per node) and `seed` (one row per channel and node,
   // every time offset reading that row)
@@ -1365,7 +1471,15 @@ extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t
       p.W = d.W; p.ldw = d.ldw; p.Ktot = p.noff * f.in_dim; p.N = f.out_dim; p.bias = d.bias;
       p.C = i == fm.output_node ? nullptr : (which == 1 ? S->nb[i].cst : S->nb[i].buf); p.ldc = i == fm.output_node ? 0 : S->nb[i].ld;
       p.nops = (int)f.ops.size(); int res = -2;
-      for (int o = 0; o < p.nops; o++) { p.op_kind[o] = f.ops[o].kind; p.op_scale[o] = d.op_scale[o]; p.op_offset[o] = d.op_offset[o]; if (f.ops[o].kind == k3::kEpiResidual) { res = f.ops[o].res_node; p.res_scale = f.ops[o].res_scale; } }
+      for (int o = 0; o < p.nops; o++) {
+        p.op_kind[o] = f.ops[o].kind;
+        p.op_scale[o] = d.op_scale[o];
+        p.op_offset[o] = d.op_offset[o];
+        if (f.ops[o].kind == k3::kEpiResidual) {
+          res = f.ops[o].res_node;
+          p.res_scale = f.ops[o].res_scale;
+        }
+      }
       if (i == fm.output_node && out_xform && f.row_op == 0) {
         if (p.nops >= kMaxOps) { k3::set_error("k3_nnet_stream_create: too many epilogue ops on the output node"); return K3_ERR_UNSUPPORTED; }
         p.op_kind[p.nops] = k3::kEpiScaleOffset; p.op_scale[p.nops] = out_scale; p.op_offset[p.nops] = out_offset; p.nops++;
@@ -1397,13 +1511,23 @@ extern "C" int k3_nnet_stream_create(k3_nnet *net, int32_t num_channels, int32_t
 
 extern "C" int k3_nnet_stream_get_info(const k3_nnet_stream *s, k3_nnet_stream_info *info) {
   K3_REQUIRE(s && info, "k3_nnet_stream_get_info: null argument");
-  info->num_channels = s->nch; info->frames_per_chunk = s->C; info->subsampling = s->s; info->output_rows_per_pass = s->N_out; info->first_output_time = s->first_out; info->right_context = s->R_in;
+  info->num_channels = s->nch;
+  info->frames_per_chunk = s->C;
+  info->subsampling = s->s;
+  info->output_rows_per_pass = s->N_out;
+  info->first_output_time = s->first_out;
+  info->right_context = s->R_in;
   info->input_history = s->H_in; info->flops_per_pass = s->pass->flops;
   return K3_OK;
 }
 
 namespace {
-int stream_slot(k3_nnet_stream *s, k3_nnet_stream::Slot **out) { k3_nnet_stream::Slot &g = s->slot[s->seq++ % k3_nnet_stream::kSlots]; if (g.used) K3_HIP_CHECK(hipEventSynchronize(g.ev)); *out = &g; return K3_OK; }
+int stream_slot(k3_nnet_stream *s, k3_nnet_stream::Slot **out) {
+  k3_nnet_stream::Slot &g = s->slot[s->seq++ % k3_nnet_stream::kSlots];
+  if (g.used) K3_HIP_CHECK(hipEventSynchronize(g.ev));
+  *out = &g;
+  return K3_OK;
+}
 }
 
 // The listed channels start new streams: their histories become the response to a constant input -- d_first_frames row i = frame 0 of channel h_channels[i]'s stream (what the
@@ -1418,7 +1542,12 @@ extern "C" int k3_nnet_stream_reset(k3_nnet_stream *s, const int32_t *h_channels
   const int *dc = reinterpret_cast<const int *>(g->d);
   // frame 0 of the restarted channels into their rows of the constant-input matrix (rows of the other channels keep whatever they hold: their results are not used)
   K3_REQUIRE(ld % 4 == 0 && ((uintptr_t)d_first_frames & 15) == 0, "k3_nnet_stream_reset: d_first_frames must be 16-byte aligned with ld % 4 == 0");
-  { const int dim4 = s->in_dim / 4; const long long m = (long long)n * dim4; hipLaunchKernelGGL(k3_stream_const_in_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_first_frames, (long long)ld, dc, n, s->const_in, s->ld_in, dim4); }
+  {
+    const int dim4 = s->in_dim / 4;
+    const long long m = (long long)n * dim4;
+    hipLaunchKernelGGL(k3_stream_const_in_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_first_frames, (long long)ld, dc, n, s->const_in,
+        s->ld_in, dim4);
+  }
   { const int rc = forward_impl(s->seed.get(), s->const_in, s->ld_in, s->const_in /* unused: the output node is not part of the seed plan */, s->out_dim > 0 ? (int64_t)align_up(s->out_dim, 4) : 4, stream); if (rc) return rc; }
   hipLaunchKernelGGL(k3_stream_seed_kernel, dim3(64, (unsigned)s->n_nb), dim3(256), 0, st, s->d_nb, dc, n, s->nch);
   K3_HIP_CHECK(hipGetLastError());
@@ -1430,10 +1559,15 @@ extern "C" int k3_nnet_stream_reset(k3_nnet_stream *s, const int32_t *h_channels
 // its stream goes on, fewer (or none) once its audio has ended -- the missing frames replicate the last real one; h_row_count[c] < 0: the channel sits the pass out and keeps its
 // state.  d_out [output_rows_per_pass * num_channels x ld_out], time-major: row k * num_channels + c is channel c's output at time first_output_time + (passes of c before this
 // one) * frames_per_chunk + k * subsampling; rows of channels that sat out are undefined.
-extern "C" int k3_nnet_stream_forward(k3_nnet_stream *s, const float *d_new, int64_t ld_new, const int64_t *h_row_start, const int32_t *h_row_count, float *d_out, int64_t ld_out, void *stream) {
+extern "C" int k3_nnet_stream_forward(k3_nnet_stream *s, const float *d_new, int64_t ld_new, const int64_t *h_row_start, const int32_t *h_row_count,
+    float *d_out, int64_t ld_out, void *stream) {
   K3_REQUIRE(s && h_row_start && h_row_count && d_out && ld_out >= s->out_dim && ld_new >= s->in_dim && ld_new % 4 == 0, "k3_nnet_stream_forward: bad argument");
   long long total = 0;
-  for (int c = 0; c < s->nch; c++) { K3_REQUIRE(h_row_count[c] <= s->C && (h_row_count[c] <= 0 || h_row_start[c] >= 0), "k3_nnet_stream_forward: a channel takes at most frames_per_chunk rows per pass"); total += std::max(0, h_row_count[c]); }
+  for (int c = 0; c < s->nch; c++) {
+    K3_REQUIRE(h_row_count[c] <= s->C && (h_row_count[c] <= 0 || h_row_start[c] >= 0),
+        "k3_nnet_stream_forward: a channel takes at most frames_per_chunk rows per pass");
+    total += std::max(0, h_row_count[c]);
+  }
   K3_REQUIRE(total == 0 || (d_new && ((uintptr_t)d_new & 15) == 0), "k3_nnet_stream_forward: d_new must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream; k3_nnet_stream::Slot *g; { const int rc = stream_slot(s, &g); if (rc) return rc; }
   const size_t o_cnt = align_up(sizeof(long long) * (s->nch + 1), 16);
@@ -1441,7 +1575,8 @@ extern "C" int k3_nnet_stream_forward(k3_nnet_stream *s, const float *d_new, int
   K3_HIP_CHECK(hipMemcpyAsync(g->d, g->h, s->slot_bytes, hipMemcpyHostToDevice, st));
   const long long *d_start = reinterpret_cast<const long long *>(g->d); const int *d_cnt = reinterpret_cast<const int *>(g->d + o_cnt);
   const int dim4 = s->in_dim / 4; const long long n = (long long)s->C * s->nch * dim4;
-  hipLaunchKernelGGL(k3_stream_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_new ? d_new : s->in_buf, (long long)ld_new, d_start, d_cnt, s->in_buf, s->ld_in, s->nch, s->C, s->H_in, dim4);
+  hipLaunchKernelGGL(k3_stream_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_new ? d_new : s->in_buf, (long long)ld_new, d_start, d_cnt,
+      s->in_buf, s->ld_in, s->nch, s->C, s->H_in, dim4);
   { const int rc = forward_impl(s->pass.get(), s->in_buf, s->ld_in, d_out, ld_out, stream); if (rc) return rc; }
   hipLaunchKernelGGL(k3_stream_shift_kernel, dim3(128, (unsigned)s->n_nb), dim3(256), 0, st, s->d_nb, d_cnt, s->nch);
   K3_HIP_CHECK(hipGetLastError());

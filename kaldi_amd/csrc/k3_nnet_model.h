@@ -41,7 +41,8 @@ struct RawModel {
   std::vector<float> priors;
 };
 
-enum EpiKind { kEpiRelu = 0, kEpiScaleOffset = 1, kEpiResidual = 2, kEpiSigmoid = 3, kEpiTanh = 4 };      // (SigmoidComponent / TanhComponent: nnet-simple-component.cc Propagate = CuMatrixBase::Sigmoid / Tanh)
+// (SigmoidComponent / TanhComponent: nnet-simple-component.cc Propagate = CuMatrixBase::Sigmoid / Tanh)
+enum EpiKind { kEpiRelu = 0, kEpiScaleOffset = 1, kEpiResidual = 2, kEpiSigmoid = 3, kEpiTanh = 4 };
 struct EpiOp {
   int kind;
   std::vector<float> scale, offset;  // kEpiScaleOffset
@@ -58,7 +59,9 @@ struct FusedNode {
   std::vector<float> bias;     // empty = none
   std::vector<float> W_iv;     // [out_dim x ivector_dim]: the columns that multiply ReplaceIndex(ivector, t, 0), the last part of the Append(); empty = none
   std::vector<EpiOp> ops;
-  int row_op = 0;              // applied to the node's output rows after `ops`: 1 = LogSoftmaxComponent, 2 = SoftmaxComponent, 3 = NormalizeComponent (a reduction over the row: its own kernel)
+  // applied to the node's output rows after `ops`: 1 = LogSoftmaxComponent, 2 = SoftmaxComponent, 3 = NormalizeComponent (a reduction over the row: its own
+  // kernel)
+  int row_op = 0;
   float row_param = 0.0f;      // row_op 3: target_rms
 };
 struct FusedModel {

@@ -254,7 +254,10 @@ struct DescParser {
       d->kind = Desc::kIvector; Desc inner; int zero = -1;
       if (!parse(&inner) || !expect(',')) return false;
       ws(); const bool is_t = i < s.size() && s[i] == 't'; if (is_t) i++;
-      if (!is_t || !expect(',') || !integer(&zero) || zero != 0 || inner.kind != Desc::kNode || inner.node != "ivector") { err = "only ReplaceIndex(ivector, t, 0) is supported, got '" + s + "'"; return false; }
+      if (!is_t || !expect(',') || !integer(&zero) || zero != 0 || inner.kind != Desc::kNode || inner.node != "ivector") {
+        err = "only ReplaceIndex(ivector, t, 0) is supported, got '" + s + "'";
+        return false;
+      }
       d->node = "ivector";
     } else {
       err = "descriptor function " + word + "() is unsupported (IfDefined/Failover/Round/Const need recurrent or multi-input models)";
@@ -263,7 +266,18 @@ struct DescParser {
     return expect(')');
   }
   bool expect(char ch) { ws(); if (i < s.size() && s[i] == ch) { i++; return true; } err = std::string("expected '") + ch + "' in descriptor '" + s + "'"; return false; }
-  bool integer(int *v) { ws(); char *e; long x = strtol(s.c_str() + i, &e, 10); if (e == s.c_str() + i) { err = "bad integer in descriptor '" + s + "'"; return false; } i = e - s.c_str(); *v = (int)x; return true; }
+  bool integer(int *v) {
+    ws();
+    char *e;
+    long x = strtol(s.c_str() + i, &e, 10);
+    if (e == s.c_str() + i) {
+      err = "bad integer in descriptor '" + s + "'";
+      return false;
+    }
+    i = e - s.c_str();
+    *v = (int)x;
+    return true;
+  }
 };
 
 void CollectNodes(const Desc &d, std::vector<std::string> *out) {
@@ -385,7 +399,10 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
     for (const Desc *p : parts) {
       int o = 0; const Desc *q = p;
       while (q->kind == Desc::kOffset) { o += q->offset; q = &q->args[0]; }
-      if (q->kind != Desc::kNode) { *err = "unsupported input descriptor for an affine component (need Append(Offset(x,t)..., [ReplaceIndex(ivector, t, 0)]) of one node, the i-vector last)"; return false; }
+      if (q->kind != Desc::kNode) {
+        *err = "unsupported input descriptor for an affine component (need Append(Offset(x,t)..., [ReplaceIndex(ivector, t, 0)]) of one node, the i-vector last)";
+        return false;
+      }
       if (!src->empty() && *src != q->node) { *err = "Append() of different nodes (" + *src + ", " + q->node + ") is unsupported (no ivector/multi-stream models)"; return false; }
       *src = q->node; offs->push_back(o);
     }
@@ -422,15 +439,23 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
       for (int co : comp_offs) for (int dofs : desc_offs) f.offsets.push_back(co + dofs);
       f.out_dim = w->rows;
       const int iv_cols = with_iv ? fm->ivector_dim : 0;
-      if (with_iv && comp_offs.size() != 1) { *err = "TdnnComponent " + c.name + " with several time offsets over an Append() that holds the i-vector is unsupported"; return false; }
+      if (with_iv && comp_offs.size() != 1) {
+        *err = "TdnnComponent " + c.name + " with several time offsets over an Append() that holds the i-vector is unsupported";
+        return false;
+      }
       if ((int64_t)w->cols != (int64_t)f.offsets.size() * f.in_dim + iv_cols) {
-        char m[256]; snprintf(m, sizeof m, "%s %s: weight is %d x %d but input is %zu x %d + %d", c.type.c_str(), c.name.c_str(), w->rows, w->cols, f.offsets.size(), f.in_dim, iv_cols);
+        char m[256];
+        snprintf(m, sizeof m, "%s %s: weight is %d x %d but input is %zu x %d + %d", c.type.c_str(), c.name.c_str(), w->rows, w->cols, f.offsets.size(),
+            f.in_dim, iv_cols);
         *err = m; return false;
       }
       if (!with_iv) f.W = w->data;
       else {                                              // split the columns: [ spliced | i-vector ]
         const int ks = w->cols - iv_cols; f.W.resize((size_t)w->rows * ks); f.W_iv.resize((size_t)w->rows * iv_cols);
-        for (int r = 0; r < w->rows; r++) { memcpy(&f.W[(size_t)r * ks], &w->data[(size_t)r * w->cols], sizeof(float) * ks); memcpy(&f.W_iv[(size_t)r * iv_cols], &w->data[(size_t)r * w->cols + ks], sizeof(float) * iv_cols); }
+        for (int r = 0; r < w->rows; r++) {
+          memcpy(&f.W[(size_t)r * ks], &w->data[(size_t)r * w->cols], sizeof(float) * ks);
+          memcpy(&f.W_iv[(size_t)r * iv_cols], &w->data[(size_t)r * w->cols + ks], sizeof(float) * iv_cols);
+        }
       }
       if (b && !b->data.empty()) { if ((int)b->data.size() != f.out_dim) { *err = c.name + ": bias dim mismatch"; return false; } f.bias = b->data; }
       fm->nodes.push_back(std::move(f));
@@ -440,13 +465,17 @@ bool FuseModel(const RawModel &raw, FusedModel *fm, std::string *err) {
     // ---- element-wise component: fold into the producing node when it is that node's only consumer ----
     const bool is_relu = c.type == "RectifiedLinearComponent", is_bn = c.type == "BatchNormComponent", is_id = IsIdentityAtTest(c.type);
     const bool is_sig = c.type == "SigmoidComponent", is_tanh = c.type == "TanhComponent";
-    const int row_op = c.type == "LogSoftmaxComponent" ? 1 : c.type == "SoftmaxComponent" ? 2 : c.type == "NormalizeComponent" ? 3 : 0;      // nnet-simple-component.cc:3618-3625 / :3494-3504 (the output layer of non-chain nnet3 models); nnet-normalize-component.cc (relu-renorm layers)
+    // nnet-simple-component.cc:3618-3625 / :3494-3504 (the output layer of non-chain nnet3 models); nnet-normalize-component.cc (relu-renorm layers)
+    const int row_op = c.type == "LogSoftmaxComponent" ? 1 : c.type == "SoftmaxComponent" ? 2 : c.type == "NormalizeComponent" ? 3 : 0;
     float row_param = 0.0f;
     if (row_op == 3) {      // NormalizeComponent::Read: <TargetRms> and <AddLogStddev> (absent in old models = 1.0 / false)
       const Field *tr = c.get("<TargetRms>"), *als = c.get("<AddLogStddev>");
       row_param = tr && !tr->scalars.empty() ? tr->scalars[0].as_float() : 1.0f;
       if (c.get("<BlockDim>")) { *err = "NormalizeComponent " + c.name + " with block-dim != dim is not supported by the fused MI355X path"; return false; }
-      if (als && !als->scalars.empty() && als->scalars[0].num != 0.0) { *err = "NormalizeComponent " + c.name + " with add-log-stddev=true is not supported by the fused MI355X path (its output has one more column)"; return false; }
+      if (als && !als->scalars.empty() && als->scalars[0].num != 0.0) {
+        *err = "NormalizeComponent " + c.name + " with add-log-stddev=true is not supported by the fused MI355X path (its output has one more column)";
+        return false;
+      }
       if (!(row_param > 0.0f)) { *err = "NormalizeComponent " + c.name + ": bad <TargetRms>"; return false; }
     }
     if (!is_relu && !is_bn && !is_id && !row_op && !is_sig && !is_tanh) {

@@ -24,7 +24,8 @@ int main(int argc, char **argv) {
         "e.g. apply-batched-cmvn-online-cuda 'matrix-sum scp:data/train/cmvn.scp -|' data/train/split8/1/feats.scp ark:-\n";
     ParseOptions po(usage);
     int32_t num_channels = 200, batch_size = 100, chunk_length = 10000, coarsening = 1;
-    po.Register("num-channels", &num_channels, "The number of channels used for compute"); po.Register("batch-size", &batch_size, "The number of chunks from audio cuts processed in a single batch");
+    po.Register("num-channels", &num_channels, "The number of channels used for compute");
+    po.Register("batch-size", &batch_size, "The number of chunks from audio cuts processed in a single batch");
     po.Register("chunk-length", &chunk_length, "The length of a chunk of audio in frames that is processed at one time");
     po.Register("stats-coarsening-factor", &coarsening, " Coarsen CMVN stats by this factor.  (accepted; the statistics here are exact, i.e. the behaviour of factor 1)");
     k3_online_cmvn_opts o; k3_online_cmvn_opts_default(&o);
@@ -63,7 +64,13 @@ int main(int argc, char **argv) {
     std::deque<size_t> lanes; size_t not_done = 0; int32_t free_channels = num_channels;
     for (;;) {
       // fill the batch with new work (:177-197); an empty utterance is done at once
-      while ((int)lanes.size() < batch_size && not_done < utts.size() && free_channels > 0) { if (table[not_done].second.rows > 0) { lanes.push_back(not_done); free_channels--; } not_done++; }
+      while ((int)lanes.size() < batch_size && not_done < utts.size() && free_channels > 0) {
+        if (table[not_done].second.rows > 0) {
+          lanes.push_back(not_done);
+          free_channels--;
+        }
+        not_done++;
+      }
       if (lanes.empty()) break;
       const int n = (int)lanes.size(); const int64_t W = o.cmn_window;
       // a lane's rows of this call: the history the window still reads, then the chunk
@@ -76,7 +83,9 @@ int main(int argc, char **argv) {
       }
       d_in.upload(in); d_fo.upload(fo); d_tb.upload(tb); d_carry.upload(carry); d_out.need(in.size());
       K3H_CHECK_K3(k3_cmvn_online_batch_resume(d_in.p, dim, d_out.p, dim, dim, d_fo.p, n, &o, d_g.p, nullptr, skip.data(), (int32_t)skip.size(), d_tb.p, d_carry.p, nullptr));
-      std::vector<float> out(in.size()); HIPCHK(hipMemcpy(out.data(), d_out.p, out.size() * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(carry.data(), d_carry.p, carry.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<float> out(in.size());
+      HIPCHK(hipMemcpy(out.data(), d_out.p, out.size() * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(carry.data(), d_carry.p, carry.size() * 8, hipMemcpyDeviceToHost));
       std::deque<size_t> keep;
       for (int i = 0; i < n; i++) {
         Utt &u = utts[lanes[i]]; const Matrix &m = table[u.idx].second;
@@ -88,7 +97,13 @@ int main(int argc, char **argv) {
       lanes.swap(keep);
     }
     int32_t num_done = 0; int64_t tot_t = 0;
-    for (auto &u : utts) { const Matrix &m = table[u.idx].second; writer.WriteMatrix(table[u.idx].first, u.out.data(), m.rows, dim, dim); num_done++; tot_t += m.rows; }      // "output all utterances" (:281-292)
+    // "output all utterances" (:281-292)
+    for (auto &u : utts) {
+      const Matrix &m = table[u.idx].second;
+      writer.WriteMatrix(table[u.idx].first, u.out.data(), m.rows, dim, dim);
+      num_done++;
+      tot_t += m.rows;
+    }
     writer.Flush();
     K3H_LOG << "Applied online CMVN to " << num_done << " files, or " << tot_t << " frames.";
     return num_done != 0 ? 0 : 1;

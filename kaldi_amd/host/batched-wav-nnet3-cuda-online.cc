@@ -25,7 +25,8 @@ using namespace k3host;
 namespace {
 struct WavePrefetcher {
   struct Item { k3host::Wave wave; bool ok = false, ready = false; };
-  WavePrefetcher(const std::vector<std::pair<std::string, std::string>> &scp, int iterations, size_t window, int threads) : scp_(scp), total_((size_t)iterations * scp.size()), window_(std::max<size_t>(window, 1)), items_(window_) {
+  WavePrefetcher(const std::vector<std::pair<std::string, std::string>> &scp, int iterations, size_t window, int threads) : scp_(scp),
+      total_((size_t)iterations * scp.size()), window_(std::max<size_t>(window, 1)), items_(window_) {
     for (int t = 0; t < std::max(1, threads); t++) th_.emplace_back([this] { Loop(); });
   }
   ~WavePrefetcher() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); for (auto &t : th_) t.join(); }
@@ -64,7 +65,8 @@ int main(int argc, char **argv) {
         "Usage: batched-wav-nnet3-cuda-online [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
     ParseOptions po(usage);
     bool literal_order = true; float hash_ratio = 2.0f;
-    bool write_compact = true, write_lattice = true, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
+    bool write_compact = true, write_lattice = true, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false,
+        print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
     int32_t worker_threads = -1;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, frames_per_chunk = 51, subsampling = 1, num_streaming = 2000;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, max_frames = 6000;
@@ -78,31 +80,48 @@ int main(int argc, char **argv) {
     po.Register("num-channels", &num_channels, "The number of parallel audio channels (-1 = max-batch-size)");
     po.Register("num-parallel-streaming-channels", &num_streaming, "(accepted; the streams are fed round-robin over --num-channels)");
     po.Register("determinize-lattice", &determinize, "Determinize the lattice before output.");
-    po.Register("write-compact", &write_compact, "(not in the reference) with --determinize-lattice=false: true = the state-level lattice re-packed as a CompactLattice like the reference (ConvertLattice), false = written as a Lattice table");
-    po.Register("cuda-worker-threads", &worker_threads, "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
-    po.Register("delta", &det_delta, "Tolerance used in determinization"); po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
-    po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)"); po.Register("word-determinize", &word_det, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
+    po.Register("write-compact", &write_compact,
+        "(not in the reference) with --determinize-lattice=false: true = the state-level lattice re-packed as a CompactLattice like the reference (ConvertLattice), false = written as a Lattice table");
+    po.Register("cuda-worker-threads", &worker_threads,
+        "The total number of CPU threads launched to process CPU tasks (here: lattice determinization). -1 = use std::hardware_concurrency().");
+    po.Register("delta", &det_delta, "Tolerance used in determinization");
+    po.Register("max-mem", &det_max_mem, "Maximum approximate memory usage in determinization (real usage might be many times this).");
+    po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)");
+    po.Register("word-determinize", &word_det, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization.");
     po.Register("print-partial-hypotheses", &print_partial, "(not supported)"); po.Register("print-endpoints", &print_endpoints, "(not supported)");
     po.Register("simulate-realtime-writing", &simulate_rt, "(accepted, unused: chunks are submitted as fast as the GPU takes them)");
     po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused)");
-    po.Register("literal-order", &literal_order, "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's; false = the order-independent fast decoder"); po.Register("hash-ratio", &hash_ratio, "LatticeFasterDecoderConfig::hash_ratio (used with --literal-order)");
+    po.Register("literal-order", &literal_order,
+        "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's; false = the order-independent fast decoder");
+    po.Register("hash-ratio", &hash_ratio, "LatticeFasterDecoderConfig::hash_ratio (used with --literal-order)");
     po.Register("beam", &beam, "Decoding beam. Larger->slower, more accurate."); po.Register("lattice-beam", &lattice_beam, "The width of the lattice beam");
     po.Register("max-active", &max_active, "Decoder max active states. Larger->slower; more accurate"); po.Register("min-active", &min_active, "Decoder min active states");
     po.Register("beam-delta", &beam_delta, "Increment used when the active-state limits move the beam");
-    po.Register("main-q-capacity", &main_q, "Max tokens alive on one frame of one utterance (-1 = 4 * max-active, capped)"); po.Register("aux-q-capacity", &aux_q, "Max arcs considered on one frame (-1 = 3 * main-q-capacity)");
-    po.Register("ntokens-pre-allocated", &ntok_pre, "Advanced - Number of tokens pre-allocated in host buffers to store lattices. If this size is exceeded the buffer will reallocate (here: an utterance that outgrows it moves to bigger token / link pools inside the decoder kernel)"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
-    po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
-    po.Register("ivector-extraction-config", &ivector_config, "Configuration file for online iVector extraction, see class OnlineIvectorExtractionConfig in the code.  Every chunk the network evaluates gets the extractor's "
+    po.Register("main-q-capacity", &main_q, "Max tokens alive on one frame of one utterance (-1 = 4 * max-active, capped)");
+    po.Register("aux-q-capacity", &aux_q, "Max arcs considered on one frame (-1 = 3 * main-q-capacity)");
+    po.Register("ntokens-pre-allocated", &ntok_pre,
+        "Advanced - Number of tokens pre-allocated in host buffers to store lattices. If this size is exceeded the buffer will reallocate (here: an utterance that outgrows it moves to bigger token / link pools inside the decoder kernel)");
+    po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
+    po.Register("frame-subsampling-factor", &subsampling,
+        "Required if the frame-rate of the output (e.g. in 'chain' models) is less than the frame-rate of the original alignment.");
+    po.Register("ivector-extraction-config", &ivector_config,
+        "Configuration file for online iVector extraction, see class OnlineIvectorExtractionConfig in the code.  Every chunk the network evaluates gets the extractor's "
                 "latest i-vector for its stream (the estimate at the last multiple of --ivector-period among the frames seen so far), as in nnet3/decodable-online-looped.cc");
     po.Register("frames-per-chunk", &frames_per_chunk, "Number of feature frames evaluated per chunk and channel (a multiple of --frame-subsampling-factor)");
     po.Register("max-utterance-frames", &max_frames, "Upper bound on the decoded (subsampled) frames of one utterance: sizes the per-channel frame tables");
-    po.Register("feature-type", &feature_type, "Base feature type [mfcc, fbank]"); po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc.conf)");
+    po.Register("feature-type", &feature_type, "Base feature type [mfcc, fbank]");
+    po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc.conf)");
     po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)"); po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)");
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     if (print_partial || print_endpoints) K3H_ERR << "--print-partial-hypotheses / --print-endpoints are not supported";
-    DeterminizeLatticePhonePrunedOptions det_opts; det_opts.delta = det_delta; det_opts.max_mem = det_max_mem; det_opts.phone_determinize = phone_det; det_opts.word_determinize = word_det; det_opts.minimize = minimize;
+    DeterminizeLatticePhonePrunedOptions det_opts;
+    det_opts.delta = det_delta;
+    det_opts.max_mem = det_max_mem;
+    det_opts.phone_determinize = phone_det;
+    det_opts.word_determinize = word_det;
+    det_opts.minimize = minimize;
     if (num_channels < 0) num_channels = max_batch;
     if (num_channels > max_batch) max_batch = num_channels;      // one slot per channel and round
     const std::string nnet3_rx = po.GetArg(1), fst_rx = po.GetArg(2), wav_rspec = po.GetArg(3), out_wspec = po.GetArg(4);
@@ -131,9 +150,15 @@ int main(int argc, char **argv) {
                                hfst.final_cost.data(), ti.id2pdf.data(), (int32_t)ti.id2pdf.size(), &fst));
     k3_decoder_config dc; k3_decoder_config_default(&dc);
     dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(min_active, max_active - 1); dc.beam_delta = beam_delta;
-    dc.frame_tokens_cap = main_q > 0 ? main_q : std::min(65536, std::max(4 * max_active, 4096)); dc.frame_cands_cap = aux_q > 0 ? std::max(aux_q, dc.frame_tokens_cap) : 3 * dc.frame_tokens_cap;
+    dc.frame_tokens_cap = main_q > 0 ? main_q : std::min(65536, std::max(4 * max_active, 4096));
+    dc.frame_cands_cap = aux_q > 0 ? std::max(aux_q, dc.frame_tokens_cap) : 3 * dc.frame_tokens_cap;
     dc.lane_tokens_cap = std::max<int64_t>(ntok_pre, dc.frame_tokens_cap); dc.lane_links_cap = 2 * dc.lane_tokens_cap;
-    dc.literal_order = literal_order ? 1 : 0; dc.hash_ratio = hash_ratio; if (literal_order) { dc.frame_tokens_cap = std::min(dc.frame_tokens_cap, 65536); dc.frame_cands_cap = std::max(dc.frame_cands_cap, dc.frame_tokens_cap + 1); }
+    dc.literal_order = literal_order ? 1 : 0;
+    dc.hash_ratio = hash_ratio;
+    if (literal_order) {
+      dc.frame_tokens_cap = std::min(dc.frame_tokens_cap, 65536);
+      dc.frame_cands_cap = std::max(dc.frame_cands_cap, dc.frame_tokens_cap + 1);
+    }
     const int nch = num_channels, N = ninfo.output_dim, C = frames_per_chunk / subsampling * subsampling > 0 ? frames_per_chunk / subsampling * subsampling : subsampling;
     k3_decoder *dec = nullptr; K3H_CHECK_K3(k3_decoder_create(fst, &dc, nch, N, &dec));
     K3H_CHECK_K3(k3_decoder_init_decoding(dec, nch, max_frames, nullptr));
@@ -149,7 +174,11 @@ int main(int argc, char **argv) {
     hipStream_t ds = nullptr;
     { int lo = 0, hi = 0; K3O_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
       if (getenv("K3_ONLINE_FLAT_PRIORITY") || lo == hi) K3O_HIP(hipStreamCreate(&ds)); else K3O_HIP(hipStreamCreateWithPriority(&ds, hipStreamDefault, hi)); }
-    hipEvent_t ev_ll[2], ev_tp[2]; for (int k = 0; k < 2; k++) { K3O_HIP(hipEventCreateWithFlags(&ev_ll[k], hipEventDisableTiming)); K3O_HIP(hipEventCreateWithFlags(&ev_tp[k], hipEventDisableTiming)); }
+    hipEvent_t ev_ll[2], ev_tp[2];
+    for (int k = 0; k < 2; k++) {
+      K3O_HIP(hipEventCreateWithFlags(&ev_ll[k], hipEventDisableTiming));
+      K3O_HIP(hipEventCreateWithFlags(&ev_tp[k], hipEventDisableTiming));
+    }
     bool tp_used[2] = {false, false}; unsigned pass_no = 0;
     OnlineFeatures features(plan, fopts, nch, ws);
     StaticNnet3 net(nnet, nch, nch, C, subsampling, log_priors.empty() ? nullptr : log_priors.data(), acoustic_scale, ws);
@@ -166,7 +195,8 @@ int main(int argc, char **argv) {
     }
     int num_task = 0, num_err = 0; double total_audio = 0.0;
     // per-channel state of the simulation
-    // Feature rows a channel has computed but not yet fed to the network (less than a chunk, or waiting behind one) live COMPACTLY in one device buffer, channel after channel, with
+    // Feature rows a channel has computed but not yet fed to the network (less than a chunk, or waiting behind one) live COMPACTLY in one device buffer,
+    // channel after channel, with
     // their (offset, count) on the host -- up to two segments per channel: what was left over + this round's new rows.  A pass takes its rows out with ONE row gather
     // (k3_mat_copy_rows) and the leftovers of all channels are gathered into the other buffer once per round: three launches per round where per-channel buffers cost ~2000
     // synchronous device copies per round (40 k copyBuffer calls = 46 % of the GPU time of a 512-channel run, 27 ms per round of 512 chunks).
@@ -176,7 +206,14 @@ int main(int argc, char **argv) {
     const size_t pend_cap = (size_t)(2 * C + 8);
     for (auto &h : held) h.need((size_t)nch * (pend_cap + (size_t)C + 16) * fdim);
     auto take_rows = [](Chan &c, int n, std::vector<int32_t> *idx) {      // the first n pending rows of the channel, in order
-      for (int sgm = 0; sgm < 2 && n > 0; sgm++) { const int k = std::min(n, c.seg_cnt[sgm]); for (int j = 0; j < k; j++) idx->push_back((int32_t)(c.seg_off[sgm] + j)); c.seg_off[sgm] += k; c.seg_cnt[sgm] -= k; n -= k; c.pend -= k; }
+      for (int sgm = 0; sgm < 2 && n > 0; sgm++) {
+        const int k = std::min(n, c.seg_cnt[sgm]);
+        for (int j = 0; j < k; j++) idx->push_back((int32_t)(c.seg_off[sgm] + j));
+        c.seg_off[sgm] += k;
+        c.seg_cnt[sgm] -= k;
+        n -= k;
+        c.pend -= k;
+      }
     };
     WavePrefetcher prefetch(scp, iterations, (size_t)2 * nch + 8, 8);
     const auto t_start = std::chrono::steady_clock::now();
@@ -210,7 +247,8 @@ int main(int argc, char **argv) {
         const std::vector<int> nf = features.ComputeFeaturesBatched(chs, chunk_ptr.data(), chunk_len.data(), first, &d_feats);
         { int64_t off = 0, tot = 0; for (int n : nf) tot += n;
           if ((size_t)(held_rows + tot) * fdim > held[held_cur].cap) K3H_ERR << "internal: pending-frame buffer";
-          if (tot > 0) K3O_HIP(hipMemcpyAsync(held[held_cur].p + (size_t)held_rows * fdim, d_feats, (size_t)tot * fdim * 4, hipMemcpyDeviceToDevice, ws));      // the round's new rows behind the leftovers
+          // the round's new rows behind the leftovers
+          if (tot > 0) K3O_HIP(hipMemcpyAsync(held[held_cur].p + (size_t)held_rows * fdim, d_feats, (size_t)tot * fdim * 4, hipMemcpyDeviceToDevice, ws));
           for (size_t i = 0; i < chs.size(); i++) {
             Chan &c = chan[chs[i]];
             if ((size_t)(c.pend + nf[i]) > pend_cap) K3H_ERR << "internal: pending-frame buffer";
@@ -245,7 +283,11 @@ int main(int argc, char **argv) {
             net.SelectOut(lb);
             auto res = net.Pass(run, newbuf.p, n_new, lasts, ivs ? ivs->Gather(run) : nullptr);
             // end of stream: frames still waiting for right context may take more passes
-            for (size_t i = 0; i < run.size(); i++) if (res[i].count > 0) { lane_first[run[i]] = net.Out() + (size_t)res[i].first * N; lane_frames[run[i]] = res[i].count; ld_rows = (int64_t)res[i].stride * N; }
+            for (size_t i = 0; i < run.size(); i++) if (res[i].count > 0) {
+              lane_first[run[i]] = net.Out() + (size_t)res[i].first * N;
+              lane_frames[run[i]] = res[i].count;
+              ld_rows = (int64_t)res[i].stride * N;
+            }
           }
           K3O_HIP(hipEventRecord(ev_ll[lb], ws)); K3O_HIP(hipStreamWaitEvent(ds, ev_ll[lb], 0));
           K3H_CHECK_K3(k3_decoder_advance_decoding_strided(dec, nch, lane_first.data(), lane_frames.data(), ld_rows, ds));
@@ -261,7 +303,10 @@ int main(int argc, char **argv) {
             const int n = c.pend; for (int sgm = 0; sgm < 2; sgm++) for (int j = 0; j < c.seg_cnt[sgm]; j++) keep.push_back((int32_t)(c.seg_off[sgm] + j));
             c.seg_off[0] = at; c.seg_cnt[0] = n; c.seg_off[1] = 0; c.seg_cnt[1] = 0; at += n;
           }
-          if (!keep.empty()) { gidx.upload_async(keep, ws); K3H_CHECK_K3(k3_mat_copy_rows(held[held_cur ^ 1].p, fdim, (int32_t)keep.size(), fdim, held[held_cur].p, fdim, gidx.p, ws)); }
+          if (!keep.empty()) {
+            gidx.upload_async(keep, ws);
+            K3H_CHECK_K3(k3_mat_copy_rows(held[held_cur ^ 1].p, fdim, (int32_t)keep.size(), fdim, held[held_cur].p, fdim, gidx.p, ws));
+          }
           held_cur ^= 1; held_rows = at;
         }
         // finalise the channels whose stream ended, write their lattices, free the channels
@@ -272,16 +317,24 @@ int main(int argc, char **argv) {
           std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec, info.data());
           int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
           std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
-          if (NS > 0) K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(), ag.data(), aa.data()));
+          if (NS > 0) K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(),
+              ag.data(), aa.data()));
           int64_t s0 = 0, a0 = 0;
           for (int u = 0; u < U; u++) {
             const int64_t ns = info[10 * u], na = info[10 * u + 1]; const std::string &key = scp[chan[ended[u]].utt].first;
             if (info[10 * u + 2] != 0 || ns == 0) { K3H_WARN << "Failed to decode utterance with id " << key; num_err++; }
             else if (iter == 0 && writer) {
               if (!info[10 * u + 3]) K3H_WARN << "Outputting partial output for utterance " << key << " since no final-state reached";
-              Lattice lat; lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns); lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns); lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
-              lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na); lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na); lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
-              lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na); lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na); lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
+              Lattice lat;
+              lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns);
+              lat.st_state.assign(ss.begin() + s0, ss.begin() + s0 + ns);
+              lat.st_final.assign(sfin.begin() + s0, sfin.begin() + s0 + ns);
+              lat.arc_src.assign(as.begin() + a0, as.begin() + a0 + na);
+              lat.arc_dst.assign(ad.begin() + a0, ad.begin() + a0 + na);
+              lat.arc_ilabel.assign(ai.begin() + a0, ai.begin() + a0 + na);
+              lat.arc_olabel.assign(ao.begin() + a0, ao.begin() + a0 + na);
+              lat.arc_graph.assign(ag.begin() + a0, ag.begin() + a0 + na);
+              lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
               for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
               Connect(&lat);
               if (det_pool) det_pool->Run(key, std::move(lat));

@@ -18,7 +18,8 @@ int main(int argc, char **argv) {
     FeatOptions fo(mfcc); fo.Register(&po);
     int32_t max_batch = 512, channel = -1; float min_duration = 0.0f; std::string use_gpu = "yes";
     po.Register("max-batch-size", &max_batch, "Utterances per GPU batch"); po.Register("channel", &channel, "Channel to extract (-1 -> expect mono, 0 -> left)");
-    po.Register("min-duration", &min_duration, "Minimum duration of segments to process (in seconds)."); po.Register("use-gpu", &use_gpu, "(accepted; this program always uses the GPU)");
+    po.Register("min-duration", &min_duration, "Minimum duration of segments to process (in seconds).");
+    po.Register("use-gpu", &use_gpu, "(accepted; this program always uses the GPU)");
     po.Read(argc, argv);
     if (po.NumArgs() != 2) { po.PrintUsage(); return 1; }
     const k3_feat_opts &opts = fo.Finish();
@@ -31,14 +32,25 @@ int main(int argc, char **argv) {
       std::vector<std::string> keys; std::vector<float> all; std::vector<int64_t> woff(1, 0), foff(1, 0);
       for (size_t i = b0; i < b1; i++) {
         Wave w;
-        try {      // --channel like featbin/compute-fbank-feats.cc:140-160: -1 = expect mono (a multi-channel file: warn, take the left channel), else that channel or skip the file
+        // --channel like featbin/compute-fbank-feats.cc:140-160: -1 = expect mono (a multi-channel file: warn, take the left channel), else that channel or
+        // skip the file
+        try {
           int nch = 0; w = ReadWave(scp[i].second, 0, &nch);
           if (channel == -1) { if (nch != 1) K3H_WARN << "Channel not specified but you have data with " << nch << " channels; defaulting to zero"; }
-          else if (channel >= nch) { K3H_WARN << "File with id " << scp[i].first << " has " << nch << " channels but you specified channel " << channel << ", producing no output."; num_err++; continue; }
+          else if (channel >= nch) {
+            K3H_WARN << "File with id " << scp[i].first << " has " << nch << " channels but you specified channel " << channel << ", producing no output.";
+            num_err++;
+            continue;
+          }
           else if (channel > 0) w = ReadWave(scp[i].second, channel);
         } catch (const FatalError &) { num_err++; continue; }
         if (w.samples.size() / w.samp_freq < min_duration) { K3H_WARN << "File: " << scp[i].first << " is too short: producing no output."; num_err++; continue; }
-        if (!MatchSampleRate(&w, opts.samp_freq, fo.allow_downsample, fo.allow_upsample)) { K3H_WARN << "Waveform and config sample Frequency mismatch: " << w.samp_freq << " .vs " << opts.samp_freq << " (use --allow-downsample=true / --allow-upsample=true to resample); failed to compute features for utterance " << scp[i].first; num_err++; continue; }
+        if (!MatchSampleRate(&w, opts.samp_freq, fo.allow_downsample, fo.allow_upsample)) {
+          K3H_WARN << "Waveform and config sample Frequency mismatch: " << w.samp_freq << " .vs " << opts.samp_freq <<
+              " (use --allow-downsample=true / --allow-upsample=true to resample); failed to compute features for utterance " << scp[i].first;
+          num_err++;
+          continue;
+        }
         const int nf = k3_feat_num_frames(plan, (int64_t)w.samples.size());
         if (nf == 0) { K3H_WARN << "No frames fit in file " << scp[i].first << " (#samp = " << w.samples.size() << ")"; num_err++; continue; }
         keys.push_back(scp[i].first); all.insert(all.end(), w.samples.begin(), w.samples.end());

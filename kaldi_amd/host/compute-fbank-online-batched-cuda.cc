@@ -21,13 +21,17 @@ using namespace k3host;
 int main(int argc, char **argv) {
   try {
     const bool mfcc = strstr(argv[0], "mfcc") != nullptr;
-    const std::string usage = std::string("Compute online ") + (mfcc ? "mfcc" : "fbank") + " features.\n\nThis binary processes the audio in chunks of samples. In addition, the computation is batched and done on the GPU. "
+    const std::string usage = std::string("Compute online ") + (mfcc ? "mfcc" : "fbank") +
+        " features.\n\nThis binary processes the audio in chunks of samples. In addition, the computation is batched and done on the GPU. "
                               "This binary is not intended to demonstrate how to achieve maximum performance.  Instead it is intended to demonstrate how to use the batched online feature class and provide "
-                              "a mechanism to test this class independently.\n\nUsage: ./" + (mfcc ? "compute-mfcc-online-batched-cuda" : "compute-fbank-online-batched-cuda") + " --batch-size=50 <wave-rspecifier> <feature-wspecifier> \n";
+                              "a mechanism to test this class independently.\n\nUsage: ./" +
+                                  (mfcc ? "compute-mfcc-online-batched-cuda" : "compute-fbank-online-batched-cuda") +
+                                  " --batch-size=50 <wave-rspecifier> <feature-wspecifier> \n";
     ParseOptions po(usage.c_str());
     FeatOptions fo(mfcc); fo.Register(&po);
     int32_t num_channels = 50, num_lanes = 10, chunk_len = 10000; std::string use_gpu = "yes";
-    po.Register("num-channels", &num_channels, "The number of channels used for compute"); po.Register("batch-size", &num_lanes, "The number of chunks from audio cuts processed in a single batch");
+    po.Register("num-channels", &num_channels, "The number of channels used for compute");
+    po.Register("batch-size", &num_lanes, "The number of chunks from audio cuts processed in a single batch");
     po.Register("chunk-length", &chunk_len, "The length of a chunk of audio in terms of samples."); po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)");
     po.Read(argc, argv);
     if (po.NumArgs() != 2) { po.PrintUsage(); return 1; }
@@ -41,7 +45,8 @@ int main(int argc, char **argv) {
     std::vector<Utt> utts; double duration = 0.0;
     for (auto &e : ReadScp(po.GetArg(1))) {
       Utt u; u.key = e.first; u.wave = ReadWave(e.second);
-      if (u.wave.samp_freq != fopts.samp_freq) K3H_ERR << "File: " << u.key << " has an mismatched sampling rate (config= " << fopts.samp_freq << " vs file=" << u.wave.samp_freq << ".";
+      if (u.wave.samp_freq != fopts.samp_freq) K3H_ERR << "File: " << u.key << " has an mismatched sampling rate (config= " << fopts.samp_freq << " vs file="
+          << u.wave.samp_freq << ".";
       duration += u.wave.samples.size() / (double)u.wave.samp_freq; utts.push_back(std::move(u));
     }
     TableWriter feature_writer(po.GetArg(2));
@@ -50,7 +55,12 @@ int main(int argc, char **argv) {
     std::deque<size_t> lanes; size_t not_done = 0; int num_done = 0; int64_t tot_t = 0;
     const auto t0 = std::chrono::steady_clock::now();      // "Timing just compute, we don't want to include disc I/O in this timer."
     for (;;) {
-      while ((int)lanes.size() < num_lanes && not_done < utts.size()) { utts[not_done].channel = free_channels.back(); free_channels.pop_back(); lanes.push_back(not_done++); }      // fill the batch (:212-236)
+      // fill the batch (:212-236)
+      while ((int)lanes.size() < num_lanes && not_done < utts.size()) {
+        utts[not_done].channel = free_channels.back();
+        free_channels.pop_back();
+        lanes.push_back(not_done++);
+      }
       if (lanes.empty()) break;
       const int n = (int)lanes.size();
       std::vector<int> channels(n); std::vector<std::vector<float>> chunks(n); std::vector<char> first(n);
@@ -69,7 +79,12 @@ int main(int argc, char **argv) {
       lanes.swap(keep);
     }
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (auto &u : utts) { const int nf = (int)(u.feats.size() / dim); tot_t += nf; feature_writer.WriteMatrix(u.key, u.feats.data(), nf, dim, dim); }      // "output all utterances" (:361-366)
+    // "output all utterances" (:361-366)
+    for (auto &u : utts) {
+      const int nf = (int)(u.feats.size() / dim);
+      tot_t += nf;
+      feature_writer.WriteMatrix(u.key, u.feats.data(), nf, dim, dim);
+    }
     feature_writer.Flush(); k3_feat_plan_destroy(plan);
     K3H_LOG << "Computed Online Features for  " << num_done << " files, and " << tot_t << " frames.";
     K3H_LOG << "Total Audio: " << duration << " seconds, Total Time: " << total_time << " seconds, RTFX: " << duration / total_time;

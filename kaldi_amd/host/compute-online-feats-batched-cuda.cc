@@ -31,19 +31,26 @@ int main(int argc, char **argv) {
                         "Compute online features and ivector features.\n\nThis binary processes the audio in chunks of samples. In addition, the computation is batched and done on the GPU.\n\n"
                         "Usage: ./compute-online-feats-batched-cuda --batch-size=100 <wave-rspecifier> <ivector-wspecifier> <feature-wspecifier> \n";
     ParseOptions po(usage);
-    int32_t num_channels = 50, num_lanes = 10, chunk_len = 10000; std::string feature_type = "mfcc", mfcc_config, fbank_config, plp_config, ivector_config, cmvn_config, global_cmvn, pitch_config, use_gpu = "yes"; bool add_pitch = false;
-    po.Register("num-channels", &num_channels, "The number of channels used for compute"); po.Register("batch-size", &num_lanes, "The number of chunks from audio cuts processed in a single batch");
+    int32_t num_channels = 50, num_lanes = 10, chunk_len = 10000;
+    std::string feature_type = "mfcc", mfcc_config, fbank_config, plp_config, ivector_config, cmvn_config, global_cmvn, pitch_config, use_gpu = "yes";
+    bool add_pitch = false;
+    po.Register("num-channels", &num_channels, "The number of channels used for compute");
+    po.Register("batch-size", &num_lanes, "The number of chunks from audio cuts processed in a single batch");
     po.Register("chunk-length", &chunk_len, "The length of a chunk of audio in terms of samples.");
-    po.Register("feature-type", &feature_type, "Base feature type [mfcc, plp, fbank]"); po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc.conf)");
-    po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)"); po.Register("plp-config", &plp_config, "(PLP features are not supported)");
+    po.Register("feature-type", &feature_type, "Base feature type [mfcc, plp, fbank]");
+    po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc.conf)");
+    po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)");
+    po.Register("plp-config", &plp_config, "(PLP features are not supported)");
     po.Register("add-pitch", &add_pitch, "(pitch features are not supported)"); po.Register("online-pitch-config", &pitch_config, "(not supported)");
-    po.Register("cmvn-config", &cmvn_config, "(online CMVN of the network features is not supported here; see apply-cmvn-online-cuda)"); po.Register("global-cmvn-stats", &global_cmvn, "(not supported)");
+    po.Register("cmvn-config", &cmvn_config, "(online CMVN of the network features is not supported here; see apply-cmvn-online-cuda)");
+    po.Register("global-cmvn-stats", &global_cmvn, "(not supported)");
     po.Register("ivector-extraction-config", &ivector_config, "Configuration file for online iVector extraction, see class OnlineIvectorExtractionConfig in the code");
     po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) { po.PrintUsage(); return 1; }
     if (whole) { num_lanes = 1; num_channels = 1; chunk_len = 0x7FFFFFFF; }
-    if (add_pitch || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty()) K3H_ERR << "an option that needs a component outside the accelerated path was given (pitch / PLP / CMVN)";
+    if (add_pitch || !plp_config.empty() || !cmvn_config.empty() || !global_cmvn.empty()) K3H_ERR <<
+        "an option that needs a component outside the accelerated path was given (pitch / PLP / CMVN)";
     if (num_channels < num_lanes) K3H_ERR << "--num-channels must be at least --batch-size";
     const bool mfcc = feature_type == "mfcc";
     if (!mfcc && feature_type != "fbank") K3H_ERR << "Invalid feature type: " << feature_type << " (supported: mfcc, fbank)";
@@ -56,13 +63,30 @@ int main(int argc, char **argv) {
     if (!ivector_config.empty()) {
       iv_info = ReadIvectorExtractionConfig(ivector_config);
       k3_ivector_model m; memset(&m, 0, sizeof m);
-      m.feat_dim = iv_info.global_cmvn_stats.cols - 1; m.lda_rows = iv_info.lda_rows; m.lda_cols = iv_info.lda_cols; m.num_gauss = iv_info.ubm.num_gauss; m.ivector_dim = iv_info.ie.ivector_dim;
-      m.lda = iv_info.lda.data(); m.global_cmvn_stats = iv_info.global_cmvn_stats.data.data(); m.gconsts = iv_info.ubm.gconsts.data(); m.means_invvars = iv_info.ubm.means_invvars.data(); m.inv_vars = iv_info.ubm.inv_vars.data();
+      m.feat_dim = iv_info.global_cmvn_stats.cols - 1;
+      m.lda_rows = iv_info.lda_rows;
+      m.lda_cols = iv_info.lda_cols;
+      m.num_gauss = iv_info.ubm.num_gauss;
+      m.ivector_dim = iv_info.ie.ivector_dim;
+      m.lda = iv_info.lda.data();
+      m.global_cmvn_stats = iv_info.global_cmvn_stats.data.data();
+      m.gconsts = iv_info.ubm.gconsts.data();
+      m.means_invvars = iv_info.ubm.means_invvars.data();
+      m.inv_vars = iv_info.ubm.inv_vars.data();
       m.M = iv_info.ie.M.data(); m.sigma_inv = iv_info.ie.sigma_inv.data(); m.prior_offset = iv_info.ie.prior_offset;
       k3_ivector_opts o; k3_ivector_opts_default(&o);
-      o.left_context = iv_info.left_context; o.right_context = iv_info.right_context; o.num_gselect = iv_info.num_gselect; o.min_post = iv_info.min_post; o.posterior_scale = iv_info.posterior_scale; o.max_count = iv_info.max_count;
+      o.left_context = iv_info.left_context;
+      o.right_context = iv_info.right_context;
+      o.num_gselect = iv_info.num_gselect;
+      o.min_post = iv_info.min_post;
+      o.posterior_scale = iv_info.posterior_scale;
+      o.max_count = iv_info.max_count;
       o.ivector_period = iv_info.ivector_period; o.num_cg_iters = iv_info.num_cg_iters; o.online_cmvn_iextractor = iv_info.online_cmvn_iextractor;
-      o.cmvn.cmn_window = iv_info.cmn_window; o.cmvn.speaker_frames = iv_info.speaker_frames; o.cmvn.global_frames = iv_info.global_frames; o.cmvn.normalize_mean = iv_info.normalize_mean; o.cmvn.normalize_variance = iv_info.normalize_variance;
+      o.cmvn.cmn_window = iv_info.cmn_window;
+      o.cmvn.speaker_frames = iv_info.speaker_frames;
+      o.cmvn.global_frames = iv_info.global_frames;
+      o.cmvn.normalize_mean = iv_info.normalize_mean;
+      o.cmvn.normalize_variance = iv_info.normalize_variance;
       if (m.feat_dim != dim) K3H_ERR << "The i-vector extractor expects features of dimension " << m.feat_dim << " but the feature config gives " << dim;
       K3H_CHECK_K3(k3_ivector_create(&m, &o, &ivx)); iv_dim = iv_info.ie.ivector_dim;
     }

@@ -33,13 +33,21 @@ int main(int argc, char **argv) {
     }
     if (cmd == "ie-dump" && argc == 3) {
       const IvectorExtractorModel m = ReadIvectorExtractor(argv[2]); std::cout.precision(12);
-      std::cout << "num_gauss " << m.num_gauss << " feat_dim " << m.feat_dim << " ivector_dim " << m.ivector_dim << " w " << m.w_rows << "x" << m.w_cols << " prior_offset " << m.prior_offset << "\n";
+      std::cout << "num_gauss " << m.num_gauss << " feat_dim " << m.feat_dim << " ivector_dim " << m.ivector_dim << " w " << m.w_rows << "x" << m.w_cols <<
+          " prior_offset " << m.prior_offset << "\n";
       auto dump = [&](const char *name, const std::vector<double> &v) { std::cout << name; for (double x : v) std::cout << " " << x; std::cout << "\n"; };
       dump("w", m.w); dump("w_vec", m.w_vec); dump("M", m.M); dump("sigma_inv", m.sigma_inv); return 0;
     }
     if (cmd == "fstinfo" && argc == 3) {
       HostFst f = ReadFstKaldiGeneric(argv[2]);
-      uint64_t h = 1469598103934665603ull; auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+      uint64_t h = 1469598103934665603ull;
+      auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; i++) {
+          h ^= b[i];
+          h *= 1099511628211ull;
+        }
+      };
       mix(f.arc_offsets.data(), 4 * f.arc_offsets.size()); mix(f.ilabel.data(), 4 * f.ilabel.size()); mix(f.olabel.data(), 4 * f.olabel.size());
       mix(f.weight.data(), 4 * f.weight.size()); mix(f.nextstate.data(), 4 * f.nextstate.size()); mix(f.final_cost.data(), 4 * f.final_cost.size());
       std::cout << f.NumStates() << " " << f.ilabel.size() << " " << f.start << " " << h << "\n"; return 0;

@@ -1,7 +1,8 @@
 // k3-pipeline-example -- a caller written against the BatchedThreadedNnet3CudaPipeline2 class surface (k3_pipeline.h), the way
 // cudadecoderbin/batched-wav-nnet3-cuda2.cc:170-245 drives the reference's class: one DecodeWithCallback per utterance, callbacks that hand the
 // lattice to the writer, two task groups waited for separately, then WaitForAllTasks.
-//   k3-pipeline-example [--max-batch-size=N] [--beam= --lattice-beam= --max-active= --acoustic-scale= --frame-subsampling-factor= --fbank-config=] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>
+// k3-pipeline-example [--max-batch-size=N] [--beam= --lattice-beam= --max-active= --acoustic-scale= --frame-subsampling-factor= --fbank-config=] <nnet3-in>
+// <fst-in> <wav-rspecifier> <lattice-wspecifier>
 // Its output must equal batched-wav-nnet3-cuda2's for the same options (tests/test_cli_gpu.py).
 #include <fstream>
 #include <cstring>
@@ -21,17 +22,26 @@ int main(int argc, char **argv) {
     po.Register("max-batch-size", &cfg.max_batch_size, "utterances decoded together"); po.Register("cuda-worker-threads", &worker_threads, "post-processing threads");
     po.Register("beam", &beam, "decoding beam"); po.Register("lattice-beam", &lattice_beam, "lattice beam"); po.Register("max-active", &max_active, "max active states");
     po.Register("acoustic-scale", &cfg.acoustic_scale, "acoustic scale"); po.Register("frame-subsampling-factor", &cfg.frame_subsampling_factor, "output frame subsampling");
-    po.Register("determinize-lattice", &cfg.determinize_lattice, "determinize before output"); po.Register("literal-order", &literal_order, "lattices identical to the CPU decoder's");
+    po.Register("determinize-lattice", &cfg.determinize_lattice, "determinize before output");
+    po.Register("literal-order", &literal_order, "lattices identical to the CPU decoder's");
     po.Register("feature-type", &feature_type, "mfcc | fbank"); po.Register("mfcc-config", &mfcc_config, "MFCC config"); po.Register("fbank-config", &fbank_config, "fbank config");
-    std::string postproc, ctm_out; po.Register("lattice-postprocessor-rxfilename", &postproc, "Config file for the lattice postprocessor (SetLatticePostprocessor)"); po.Register("ctm-out", &ctm_out, "with --segmentation: also write the merged CTM of every file here (RESULT_TYPE_CTM)");
-    bool segmentation = false; po.Register("segmentation", &segmentation, "Split audio files into segments (SegmentedDecodeWithCallback; keys [utt]-[offset])"); cfg.seg_opts.Register(&po);
+    std::string postproc, ctm_out;
+    po.Register("lattice-postprocessor-rxfilename", &postproc, "Config file for the lattice postprocessor (SetLatticePostprocessor)");
+    po.Register("ctm-out", &ctm_out, "with --segmentation: also write the merged CTM of every file here (RESULT_TYPE_CTM)");
+    bool segmentation = false;
+    po.Register("segmentation", &segmentation, "Split audio files into segments (SegmentedDecodeWithCallback; keys [utt]-[offset])");
+    cfg.seg_opts.Register(&po);
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     const bool mfcc = feature_type == "mfcc"; FeatOptions fo(mfcc);
     { ParseOptions fpo(""); fo.Register(&fpo); const std::string &c = mfcc ? mfcc_config : fbank_config; if (!c.empty()) fpo.ReadConfigFile(c); }
     cfg.feature_opts = fo.Finish(); cfg.num_worker_threads = worker_threads;
     k3_decoder_config &dc = cfg.decoder_opts; dc.beam = beam; dc.lattice_beam = lattice_beam; dc.max_active = max_active; dc.min_active = std::min(200, max_active - 1);
-    dc.frame_tokens_cap = std::min(65536, std::max(4 * max_active, 4096)); dc.frame_cands_cap = 3 * dc.frame_tokens_cap; dc.lane_tokens_cap = 1000000; dc.lane_links_cap = 2000000; dc.literal_order = literal_order ? 1 : 0;
+    dc.frame_tokens_cap = std::min(65536, std::max(4 * max_active, 4096));
+    dc.frame_cands_cap = 3 * dc.frame_tokens_cap;
+    dc.lane_tokens_cap = 1000000;
+    dc.lane_links_cap = 2000000;
+    dc.literal_order = literal_order ? 1 : 0;
     TransitionInfo ti = ReadTransitionModel(po.GetArg(1)); k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(po.GetArg(1).c_str(), &nnet));
     HostFst hfst = ReadFstKaldiGeneric(po.GetArg(2));
     auto scp = ReadScp(po.GetArg(3)); TableWriter writer(po.GetArg(4));
@@ -48,7 +58,10 @@ int main(int argc, char **argv) {
             if (!ctm_out.empty()) cuda_decoder::MergeSegmentsToCTMOutput(params.results, key, ctm);
             for (cuda_decoder::CudaPipelineResult &r : params.results) {
               std::ostringstream k; k << key << "-" << (double)r.GetTimeOffsetSeconds();
-              if (!r.HasValidResult() || r.GetLatticeResult()->NumStates() == 0) { K3H_WARN << "Utterance " << key << ": segment with offset " << r.GetTimeOffsetSeconds() << " is not valid. Skipping"; continue; }
+              if (!r.HasValidResult() || r.GetLatticeResult()->NumStates() == 0) {
+                K3H_WARN << "Utterance " << key << ": segment with offset " << r.GetTimeOffsetSeconds() << " is not valid. Skipping";
+                continue;
+              }
               writer.WriteCompactLattice(k.str(), *r.GetLatticeResult()); n_seg++;
             }
           }, result_type);
@@ -73,7 +86,14 @@ int main(int argc, char **argv) {
       pipeline.DestroyTaskGroup("even"); pipeline.DestroyTaskGroup("odd");
     }
     int n_err = 0;
-    for (size_t i = 0; i < scp.size(); i++) { if (!got[i] || results[i].NumStates() == 0) { K3H_WARN << "Failed to decode utterance with id " << scp[i].first; n_err++; continue; } writer.WriteCompactLattice(scp[i].first, results[i]); }
+    for (size_t i = 0; i < scp.size(); i++) {
+      if (!got[i] || results[i].NumStates() == 0) {
+        K3H_WARN << "Failed to decode utterance with id " << scp[i].first;
+        n_err++;
+        continue;
+      }
+      writer.WriteCompactLattice(scp[i].first, results[i]);
+    }
     writer.Flush(); k3_nnet_destroy(nnet);
     K3H_LOG << "Decoded " << scp.size() << " utterances, " << n_err << " with errors.";
     return 0;

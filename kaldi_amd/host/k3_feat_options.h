@@ -15,7 +15,8 @@ inline bool MatchSampleRate(Wave *w, float want, bool allow_downsample, bool all
   std::vector<float> out((size_t)n_out);
   if (n_out > 0 && n_in > 0) {
     float *d_in = nullptr, *d_out = nullptr; const int64_t io[2] = {0, n_in}, oo[2] = {0, n_out};
-    if (hipMalloc((void **)&d_in, (size_t)n_in * 4) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n_out * 4) != hipSuccess || hipMemcpy(d_in, w->samples.data(), (size_t)n_in * 4, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMalloc((void **)&d_in, (size_t)n_in * 4) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n_out * 4) != hipSuccess ||
+        hipMemcpy(d_in, w->samples.data(), (size_t)n_in * 4, hipMemcpyHostToDevice) != hipSuccess)
       K3H_ERR << "HIP error while resampling";
     if (k3_resample_batch(ri, ro, d_in, io, 1, d_out, oo, nullptr) != 0) K3H_ERR << k3_last_error();
     if (hipMemcpy(out.data(), d_out, (size_t)n_out * 4, hipMemcpyDeviceToHost) != hipSuccess) K3H_ERR << "HIP error while resampling";
@@ -37,18 +38,30 @@ struct FeatOptions {
   void Register(ParseOptions *po) {
     po->Register("sample-frequency", &o.samp_freq, "Waveform data sample frequency (must match the waveform file, if specified there)");
     po->Register("frame-length", &o.frame_length_ms, "Frame length in milliseconds"); po->Register("frame-shift", &o.frame_shift_ms, "Frame shift in milliseconds");
-    po->Register("preemphasis-coefficient", &o.preemph_coeff, "Coefficient for use in signal preemphasis"); po->Register("remove-dc-offset", &remove_dc, "Subtract mean from waveform on each frame");
-    po->Register("dither", &o.dither, "Dithering constant (0.0 means no dither)"); po->Register("window-type", &window_type, "Type of window (\"hamming\"|\"hanning\"|\"povey\"|\"rectangular\"|\"sine\"|\"blackman\")");
-    po->Register("blackman-coeff", &o.blackman_coeff, "Constant coefficient for generalized Blackman window."); po->Register("round-to-power-of-two", &round_pow2, "If true, round window size to power of two by zero-padding input to FFT.");
+    po->Register("preemphasis-coefficient", &o.preemph_coeff, "Coefficient for use in signal preemphasis");
+    po->Register("remove-dc-offset", &remove_dc, "Subtract mean from waveform on each frame");
+    po->Register("dither", &o.dither, "Dithering constant (0.0 means no dither)");
+    po->Register("window-type", &window_type, "Type of window (\"hamming\"|\"hanning\"|\"povey\"|\"rectangular\"|\"sine\"|\"blackman\")");
+    po->Register("blackman-coeff", &o.blackman_coeff, "Constant coefficient for generalized Blackman window.");
+    po->Register("round-to-power-of-two", &round_pow2, "If true, round window size to power of two by zero-padding input to FFT.");
     po->Register("snip-edges", &snip_edges, "If true, end effects will be handled by outputting only frames that completely fit in the file");
-    po->Register("allow-downsample", &allow_downsample, "If true, allow the input waveform to have a higher frequency than the specified --sample-frequency (and we'll downsample)."); po->Register("allow-upsample", &allow_upsample, "If true, allow the input waveform to have a lower frequency than the specified --sample-frequency (and we'll upsample).");
+    po->Register("allow-downsample", &allow_downsample,
+        "If true, allow the input waveform to have a higher frequency than the specified --sample-frequency (and we'll downsample).");
+    po->Register("allow-upsample", &allow_upsample,
+        "If true, allow the input waveform to have a lower frequency than the specified --sample-frequency (and we'll upsample).");
     po->Register("num-mel-bins", &o.num_bins, "Number of triangular mel-frequency bins"); po->Register("low-freq", &o.low_freq, "Low cutoff frequency for mel bins");
-    po->Register("high-freq", &o.high_freq, "High cutoff frequency for mel bins (if <= 0, offset from Nyquist)"); po->Register("vtln-low", &o.vtln_low, "Low inflection point in piecewise linear VTLN warping function");
-    po->Register("vtln-high", &o.vtln_high, "High inflection point in piecewise linear VTLN warping function (if negative, offset from high-mel-freq"); po->Register("debug-mel", &debug_mel, "(accepted, ignored)");
-    po->Register("use-energy", &use_energy, "Add an extra dimension with energy / use energy (not C0)"); po->Register("energy-floor", &o.energy_floor, "Floor on energy (absolute, not relative)");
-    po->Register("raw-energy", &raw_energy, "If true, compute energy before preemphasis and windowing"); po->Register("htk-compat", &htk_compat, "If true, put energy/C0 last and (mfcc) use a factor of sqrt(2) on C0");
-    po->Register("use-log-fbank", &use_log_fbank, "If true, produce log-filterbank, else produce linear."); po->Register("use-power", &use_power, "If true, use power, else use magnitude.");
-    po->Register("num-ceps", &o.num_ceps, "Number of cepstra in MFCC computation (including C0)"); po->Register("cepstral-lifter", &o.cepstral_lifter, "Constant that controls scaling of MFCCs");
+    po->Register("high-freq", &o.high_freq, "High cutoff frequency for mel bins (if <= 0, offset from Nyquist)");
+    po->Register("vtln-low", &o.vtln_low, "Low inflection point in piecewise linear VTLN warping function");
+    po->Register("vtln-high", &o.vtln_high, "High inflection point in piecewise linear VTLN warping function (if negative, offset from high-mel-freq");
+    po->Register("debug-mel", &debug_mel, "(accepted, ignored)");
+    po->Register("use-energy", &use_energy, "Add an extra dimension with energy / use energy (not C0)");
+    po->Register("energy-floor", &o.energy_floor, "Floor on energy (absolute, not relative)");
+    po->Register("raw-energy", &raw_energy, "If true, compute energy before preemphasis and windowing");
+    po->Register("htk-compat", &htk_compat, "If true, put energy/C0 last and (mfcc) use a factor of sqrt(2) on C0");
+    po->Register("use-log-fbank", &use_log_fbank, "If true, produce log-filterbank, else produce linear.");
+    po->Register("use-power", &use_power, "If true, use power, else use magnitude.");
+    po->Register("num-ceps", &o.num_ceps, "Number of cepstra in MFCC computation (including C0)");
+    po->Register("cepstral-lifter", &o.cepstral_lifter, "Constant that controls scaling of MFCCs");
     po->Register("vtln-warp", &o.vtln_warp, "Vtln warp factor (only applicable if vtln-map not specified)");
   }
   const k3_feat_opts &Finish() {

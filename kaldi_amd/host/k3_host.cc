@@ -49,9 +49,24 @@ bool ParseOptions::SetOption(const std::string &key_in, const std::string &value
       else K3H_ERR << "Invalid format for boolean argument [expected true or false]: --" << key << "=" << value;
       break;
     }
-    case kInt: { long v = strtol(value.c_str(), &end, 10); if (!has_value || value.empty() || *end || errno) K3H_ERR << "Invalid integer option \"" << value << "\" for --" << key; *(int32_t *)o.ptr = (int32_t)v; break; }
-    case kFloat: { double v = strtod(value.c_str(), &end); if (!has_value || value.empty() || *end) K3H_ERR << "Invalid floating-point option \"" << value << "\" for --" << key; *(float *)o.ptr = (float)v; break; }
-    case kDouble: { double v = strtod(value.c_str(), &end); if (!has_value || value.empty() || *end) K3H_ERR << "Invalid floating-point option \"" << value << "\" for --" << key; *(double *)o.ptr = v; break; }
+    case kInt: {
+      long v = strtol(value.c_str(), &end, 10);
+      if (!has_value || value.empty() || *end || errno) K3H_ERR << "Invalid integer option \"" << value << "\" for --" << key;
+      *(int32_t *)o.ptr = (int32_t)v;
+      break;
+    }
+    case kFloat: {
+      double v = strtod(value.c_str(), &end);
+      if (!has_value || value.empty() || *end) K3H_ERR << "Invalid floating-point option \"" << value << "\" for --" << key;
+      *(float *)o.ptr = (float)v;
+      break;
+    }
+    case kDouble: {
+      double v = strtod(value.c_str(), &end);
+      if (!has_value || value.empty() || *end) K3H_ERR << "Invalid floating-point option \"" << value << "\" for --" << key;
+      *(double *)o.ptr = v;
+      break;
+    }
     case kString: *(std::string *)o.ptr = value; break;
   }
   set_[key] = 1;
@@ -66,7 +81,8 @@ void ParseOptions::ReadConfigFile(const std::string &path) {          // util/pa
     const size_t h = line.find('#'); if (h != std::string::npos) line.erase(h);
     const size_t b = line.find_first_not_of(" \t\r"); if (b == std::string::npos) continue;
     line = line.substr(b, line.find_last_not_of(" \t\r") - b + 1);
-    if (line.compare(0, 2, "--") != 0) K3H_ERR << "Reading config file " << path << ": line " << ln << " does not look like a line from a Kaldi command-line program's config file: should be of the form --x=y.";
+    if (line.compare(0, 2, "--") != 0) K3H_ERR << "Reading config file " << path << ": line " << ln <<
+        " does not look like a line from a Kaldi command-line program's config file: should be of the form --x=y.";
     const size_t eq = line.find('=');
     const std::string key = line.substr(2, eq == std::string::npos ? std::string::npos : eq - 2), val = eq == std::string::npos ? "" : line.substr(eq + 1);
     if (!SetOption(key, val, eq != std::string::npos)) K3H_ERR << "Invalid option " << line << " in config file " << path;
@@ -117,7 +133,11 @@ void ParseOptions::PrintUsage(bool print_command_line) const {
 }
 
 // ------------------------------------------------------------------------------------------------ streams ----
-static std::string Trim(const std::string &s) { const size_t b = s.find_first_not_of(" \t\r\n"); if (b == std::string::npos) return ""; return s.substr(b, s.find_last_not_of(" \t\r\n") - b + 1); }
+static std::string Trim(const std::string &s) {
+  const size_t b = s.find_first_not_of(" \t\r\n");
+  if (b == std::string::npos) return "";
+  return s.substr(b, s.find_last_not_of(" \t\r\n") - b + 1);
+}
 std::shared_ptr<FILE> OpenInput(const std::string &rx_in) {
   const std::string rx = Trim(rx_in);
   if (rx.empty()) K3H_ERR << "empty rxfilename";
@@ -316,7 +336,11 @@ TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename) {
     if (hs < 0 || hs >= (int32_t)entry.size()) K3H_ERR << "TransitionModel: bad hmm-state " << hs;
     for (const auto &tr : entry[hs].trans) {
       ti.id2pdf.push_back(tr.first == hs ? spdf : fpdf);     // IsSelfLoop
-      ti.id2phone.push_back(phone); ti.self_loop.push_back(tr.first == hs); ti.phone_start.push_back(hs == 0); ti.is_final.push_back(tr.first + 1 == (int32_t)entry.size());      // IsFinal (transition-model.cc:511-518)
+      // IsFinal (transition-model.cc:511-518)
+      ti.id2phone.push_back(phone);
+      ti.self_loop.push_back(tr.first == hs);
+      ti.phone_start.push_back(hs == 0);
+      ti.is_final.push_back(tr.first + 1 == (int32_t)entry.size());
     }
     ti.num_pdfs = std::max(ti.num_pdfs, 1 + std::max(fpdf, spdf));
   }
@@ -399,20 +423,36 @@ HostFst ReadFstKaldiGeneric(const std::string &rxfilename) {
     for (int64_t s = 0; s < ns; s++) {
       f.final_cost.push_back(in.Get<float>());
       const int64_t n = in.Get<int64_t>();
-      for (int64_t a = 0; a < n; a++) { f.ilabel.push_back(in.Get<int32_t>()); f.olabel.push_back(in.Get<int32_t>()); f.weight.push_back(in.Get<float>()); f.nextstate.push_back(in.Get<int32_t>()); }
+      for (int64_t a = 0; a < n; a++) {
+        f.ilabel.push_back(in.Get<int32_t>());
+        f.olabel.push_back(in.Get<int32_t>());
+        f.weight.push_back(in.Get<float>());
+        f.nextstate.push_back(in.Get<int32_t>());
+      }
       f.arc_offsets.push_back((int32_t)f.ilabel.size());
     }
   } else if (ftype == "const") {                     // ConstFst<StdArc, uint32>: states {final, pos, narcs, niepsilons, noepsilons} then arcs
     const bool aligned = (flags & 4) != 0 || version == 1;
     if (aligned) in.Align(16);
     std::vector<uint32_t> pos(ns), cnt(ns);
-    for (int64_t s = 0; s < ns; s++) { f.final_cost.push_back(in.Get<float>()); pos[s] = in.Get<uint32_t>(); cnt[s] = in.Get<uint32_t>(); (void)in.Get<uint32_t>(); (void)in.Get<uint32_t>(); }
+    for (int64_t s = 0; s < ns; s++) {
+      f.final_cost.push_back(in.Get<float>());
+      pos[s] = in.Get<uint32_t>();
+      cnt[s] = in.Get<uint32_t>();
+      (void)in.Get<uint32_t>();
+      (void)in.Get<uint32_t>();
+    }
     if (aligned) in.Align(16);
     const size_t arcs0 = in.p;
     f.arc_offsets.push_back(0);
     for (int64_t s = 0; s < ns; s++) {
       in.p = arcs0 + 16 * (size_t)pos[s];
-      for (uint32_t a = 0; a < cnt[s]; a++) { f.ilabel.push_back(in.Get<int32_t>()); f.olabel.push_back(in.Get<int32_t>()); f.weight.push_back(in.Get<float>()); f.nextstate.push_back(in.Get<int32_t>()); }
+      for (uint32_t a = 0; a < cnt[s]; a++) {
+        f.ilabel.push_back(in.Get<int32_t>());
+        f.olabel.push_back(in.Get<int32_t>());
+        f.weight.push_back(in.Get<float>());
+        f.nextstate.push_back(in.Get<int32_t>());
+      }
       f.arc_offsets.push_back((int32_t)f.ilabel.size());
     }
   } else K3H_ERR << "Reading FST: unsupported FST type: " << ftype;
@@ -442,7 +482,14 @@ void Connect(Lattice *lat) {
   for (size_t a = 0; a < na; a++) { fadj[fp[lat->arc_src[a]]++] = lat->arc_dst[a]; radj[rp[lat->arc_dst[a]]++] = lat->arc_src[a]; }
   std::vector<char> acc(n, 0), co(n, 0); std::vector<int32_t> st;
   if (lat->start >= 0) { acc[lat->start] = 1; st.push_back(lat->start); }
-  while (!st.empty()) { const int32_t s = st.back(); st.pop_back(); for (int32_t k = foff[s]; k < foff[s + 1]; k++) if (!acc[fadj[k]]) { acc[fadj[k]] = 1; st.push_back(fadj[k]); } }
+  while (!st.empty()) {
+    const int32_t s = st.back();
+    st.pop_back();
+    for (int32_t k = foff[s]; k < foff[s + 1]; k++) if (!acc[fadj[k]]) {
+      acc[fadj[k]] = 1;
+      st.push_back(fadj[k]);
+    }
+  }
   for (int32_t s = 0; s < n; s++) if (std::isfinite(lat->st_final[s])) { co[s] = 1; st.push_back(s); }
   while (!st.empty()) { const int32_t s = st.back(); st.pop_back(); for (int32_t k = roff[s]; k < roff[s + 1]; k++) if (!co[radj[k]]) { co[radj[k]] = 1; st.push_back(radj[k]); } }
   std::vector<int32_t> newid(n, -1); int32_t m = 0;
@@ -475,7 +522,12 @@ TableWriter::TableWriter(const std::string &wspecifier) {
 void TableWriter::Flush() { fflush(f_.get()); }
 
 static void PrintWeight(std::string *o, float g, float a) {     // operator<< of LatticeWeightTpl: "graph,acoustic"
-  char buf[64]; auto num = [&](float v) { if (std::isinf(v)) return std::string(v > 0 ? "Infinity" : "-Infinity"); snprintf(buf, sizeof buf, "%g", (double)v); return std::string(buf); };
+  char buf[64];
+  auto num = [&](float v) {
+    if (std::isinf(v)) return std::string(v > 0 ? "Infinity" : "-Infinity");
+    snprintf(buf, sizeof buf, "%g", (double)v);
+    return std::string(buf);
+  };
   *o += num(g); *o += ","; *o += num(a);
 }
 void TableWriter::WriteLattice(const std::string &key, const Lattice &lat) {
@@ -495,7 +547,15 @@ void TableWriter::WriteLattice(const std::string &key, const Lattice &lat) {
         if (!(lat.arc_graph[a] == 0.0f && lat.arc_ac[a] == 0.0f)) { o += "\t"; PrintWeight(&o, lat.arc_graph[a], lat.arc_ac[a]); }
         o += "\n";
       }
-      if (std::isfinite(lat.st_final[s])) { const float fa = lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]; o += std::to_string(s); if (lat.st_final[s] != 0.0f || fa != 0.0f) { o += "\t"; PrintWeight(&o, lat.st_final[s], fa); } o += "\n"; }
+      if (std::isfinite(lat.st_final[s])) {
+        const float fa = lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s];
+        o += std::to_string(s);
+        if (lat.st_final[s] != 0.0f || fa != 0.0f) {
+          o += "\t";
+          PrintWeight(&o, lat.st_final[s], fa);
+        }
+        o += "\n";
+      }
     };
     if (lat.start >= 0) print_state(lat.start);
     for (int32_t s = 0; s < n; s++) if (s != lat.start) print_state(s);
@@ -507,7 +567,14 @@ void TableWriter::WriteLattice(const std::string &key, const Lattice &lat) {
     for (int32_t s = 0; s < n; s++) {
       const bool fin = std::isfinite(lat.st_final[s]);
       Put<float>(&o, fin ? lat.st_final[s] : inf); Put<float>(&o, fin ? (lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]) : inf); Put<int64_t>(&o, off[s + 1] - off[s]);
-      for (int32_t k = off[s]; k < off[s + 1]; k++) { const int32_t a = order[k]; Put(&o, lat.arc_ilabel[a]); Put(&o, lat.arc_olabel[a]); Put(&o, lat.arc_graph[a]); Put(&o, lat.arc_ac[a]); Put(&o, lat.arc_dst[a]); }
+      for (int32_t k = off[s]; k < off[s + 1]; k++) {
+        const int32_t a = order[k];
+        Put(&o, lat.arc_ilabel[a]);
+        Put(&o, lat.arc_olabel[a]);
+        Put(&o, lat.arc_graph[a]);
+        Put(&o, lat.arc_ac[a]);
+        Put(&o, lat.arc_dst[a]);
+      }
     }
   }
   if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on lattice " << key;
@@ -551,17 +618,27 @@ size_t ReadOneMatrix(const std::string &b, size_t p, Matrix *m, const std::strin
       if (tok == "FV") { need(4 * n); memcpy(m->data.data(), b.data() + p, 4 * n); p += 4 * n; }
       else { need(8 * n); for (size_t i = 0; i < n; i++) { double d; memcpy(&d, b.data() + p + 8 * i, 8); m->data[i] = (float)d; } p += 8 * n; }
     } else if (tok == "CM" || tok == "CM2" || tok == "CM3") {
-      need(16); float mn, range; int32_t nr, nc; memcpy(&mn, b.data() + p, 4); memcpy(&range, b.data() + p + 4, 4); memcpy(&nr, b.data() + p + 8, 4); memcpy(&nc, b.data() + p + 12, 4); p += 16;
+      need(16);
+      float mn, range;
+      int32_t nr, nc;
+      memcpy(&mn, b.data() + p, 4);
+      memcpy(&range, b.data() + p + 4, 4);
+      memcpy(&nr, b.data() + p + 8, 4);
+      memcpy(&nc, b.data() + p + 12, 4);
+      p += 16;
       m->rows = nr; m->cols = nc; m->data.resize((size_t)nr * nc);
       if (tok == "CM") {                 // per-column percentile headers + column-major bytes (compressed-matrix.cc:626-648)
         need((size_t)nc * 8 + (size_t)nc * nr);
         const uint16_t *ch = reinterpret_cast<const uint16_t *>(b.data() + p); const uint8_t *bytes = reinterpret_cast<const uint8_t *>(b.data() + p + (size_t)nc * 8);
         for (int32_t c = 0; c < nc; c++) {
           uint16_t h[4]; memcpy(h, ch + 4 * c, 8);
-          const float p0 = mn + range * 1.52590218966964e-05F * h[0], p25 = mn + range * 1.52590218966964e-05F * h[1], p75 = mn + range * 1.52590218966964e-05F * h[2], p100 = mn + range * 1.52590218966964e-05F * h[3];
+          const float p0 = mn + range * 1.52590218966964e-05F * h[0], p25 = mn + range * 1.52590218966964e-05F * h[1],
+              p75 = mn + range * 1.52590218966964e-05F * h[2], p100 = mn + range * 1.52590218966964e-05F * h[3];
           for (int32_t r = 0; r < nr; r++) {
             const uint8_t v = bytes[(size_t)c * nr + r]; float f;
-            if (v <= 64) f = p0 + (p25 - p0) * v * (1 / 64.0); else if (v <= 192) f = p25 + (p75 - p25) * (v - 64) * (1 / 128.0); else f = p75 + (p100 - p75) * (v - 192) * (1 / 63.0);
+            if (v <= 64) f = p0 + (p25 - p0) * v * (1 / 64.0);
+            else if (v <= 192) f = p25 + (p75 - p25) * (v - 64) * (1 / 128.0);
+            else f = p75 + (p100 - p75) * (v - 192) * (1 / 63.0);
             m->data[(size_t)r * nc + c] = f;
           }
         }
@@ -586,7 +663,13 @@ size_t ReadOneMatrix(const std::string &b, size_t p, Matrix *m, const std::strin
     while (p < b.size() && (b[p] == ' ' || b[p] == '\t' || b[p] == '\r')) p++;
     if (p >= b.size()) break;
     if (b[p] == '\n' || b[p] == ']') {
-      if (!row.empty()) { if (m->cols && (int32_t)row.size() != m->cols) K3H_ERR << "Inconsistent row lengths in text matrix " << what; m->cols = (int32_t)row.size(); m->data.insert(m->data.end(), row.begin(), row.end()); m->rows++; row.clear(); }
+      if (!row.empty()) {
+        if (m->cols && (int32_t)row.size() != m->cols) K3H_ERR << "Inconsistent row lengths in text matrix " << what;
+        m->cols = (int32_t)row.size();
+        m->data.insert(m->data.end(), row.begin(), row.end());
+        m->rows++;
+        row.clear();
+      }
       if (b[p++] == ']') { while (p < b.size() && b[p] != '\n') p++; if (p < b.size()) p++; return p; }
       continue;
     }
@@ -619,7 +702,13 @@ MatrixD ReadDoubleMatrix(const std::string &rxfilename) {
     while (p < b.size() && (b[p] == ' ' || b[p] == '\t' || b[p] == '\r')) p++;
     if (p >= b.size()) break;
     if (b[p] == '\n' || b[p] == ']') {
-      if (!row.empty()) { if (m.cols && (int32_t)row.size() != m.cols) K3H_ERR << "Inconsistent row lengths in text matrix " << rxfilename; m.cols = (int32_t)row.size(); m.data.insert(m.data.end(), row.begin(), row.end()); m.rows++; row.clear(); }
+      if (!row.empty()) {
+        if (m.cols && (int32_t)row.size() != m.cols) K3H_ERR << "Inconsistent row lengths in text matrix " << rxfilename;
+        m.cols = (int32_t)row.size();
+        m.data.insert(m.data.end(), row.begin(), row.end());
+        m.rows++;
+        row.clear();
+      }
       if (b[p++] == ']') return m;
       continue;
     }
@@ -663,7 +752,10 @@ std::vector<std::pair<std::string, Matrix>> ReadMatrixTable(const std::string &r
     for (auto &kv : ReadScp(rspecifier)) {
       std::string path = kv.second; size_t off = 0;
       const size_t c = path.rfind(':');
-      if (c != std::string::npos && c + 1 < path.size() && path.find_first_not_of("0123456789", c + 1) == std::string::npos) { off = strtoull(path.c_str() + c + 1, nullptr, 10); path = path.substr(0, c); }
+      if (c != std::string::npos && c + 1 < path.size() && path.find_first_not_of("0123456789", c + 1) == std::string::npos) {
+        off = strtoull(path.c_str() + c + 1, nullptr, 10);
+        path = path.substr(0, c);
+      }
       if (!cache.count(path)) { if (cache.size() > 4) cache.clear(); cache[path] = ReadWholeInput(path); }
       Matrix m; ReadOneMatrix(cache[path], off, &m, kv.first); out.push_back({kv.first, std::move(m)});
     }
@@ -680,14 +772,28 @@ bool BestPath(const Lattice &lat, std::vector<int32_t> *ali, std::vector<int32_t
   std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return lat.st_frame[lat.arc_src[x]] < lat.st_frame[lat.arc_src[y]]; });
   for (bool changed = true; changed;) {       // arcs in frame order; epsilon chains inside a frame may need another sweep
     changed = false;
-    for (int32_t a : order) { const double c = best[lat.arc_src[a]] + (double)lat.arc_graph[a] + (double)lat.arc_ac[a]; if (c < best[lat.arc_dst[a]]) { best[lat.arc_dst[a]] = c; back[lat.arc_dst[a]] = a; changed = true; } }
+    for (int32_t a : order) {
+      const double c = best[lat.arc_src[a]] + (double)lat.arc_graph[a] + (double)lat.arc_ac[a];
+      if (c < best[lat.arc_dst[a]]) {
+        best[lat.arc_dst[a]] = c;
+        back[lat.arc_dst[a]] = a;
+        changed = true;
+      }
+    }
   }
   int32_t end = -1; double bc = std::numeric_limits<double>::infinity();
   auto final_ac = [&](int32_t s) { return lat.st_final_ac.empty() ? 0.0 : (double)lat.st_final_ac[s]; };      // zero for the decoder's lattices
   for (int32_t s = 0; s < n; s++) if (std::isfinite(lat.st_final[s]) && best[s] + lat.st_final[s] + final_ac(s) < bc) { bc = best[s] + lat.st_final[s] + final_ac(s); end = s; }
   if (end < 0) return false;
   ali->clear(); words->clear(); *gcost = lat.st_final[end]; *acost = final_ac(end);
-  for (int32_t s = end; s != lat.start;) { const int64_t a = back[s]; if (lat.arc_ilabel[a]) ali->push_back(lat.arc_ilabel[a]); if (lat.arc_olabel[a]) words->push_back(lat.arc_olabel[a]); *gcost += lat.arc_graph[a]; *acost += lat.arc_ac[a]; s = lat.arc_src[a]; }
+  for (int32_t s = end; s != lat.start;) {
+    const int64_t a = back[s];
+    if (lat.arc_ilabel[a]) ali->push_back(lat.arc_ilabel[a]);
+    if (lat.arc_olabel[a]) words->push_back(lat.arc_olabel[a]);
+    *gcost += lat.arc_graph[a];
+    *acost += lat.arc_ac[a];
+    s = lat.arc_src[a];
+  }
   std::reverse(ali->begin(), ali->end()); std::reverse(words->begin(), words->end());
   return true;
 }
@@ -702,7 +808,8 @@ void TableWriter::WriteInt32Vector(const std::string &key, const std::vector<int
 // ---------------------------------------------------------------------------------------------------------------- i-vector extraction config
 void IvectorExtractionInfo::Register(ParseOptions *po) {       // option names and meanings of OnlineIvectorExtractionConfig::Register (online2/online-ivector-feature.h:113-160)
   po->Register("lda-matrix", &lda_mat_rxfilename, "Filename of LDA matrix, e.g. final.mat; used for iVector extraction.");
-  po->Register("global-cmvn-stats", &global_cmvn_stats_rxfilename, "(Extended) filename for global CMVN stats, used in iVector extraction, obtained for example from 'matrix-sum scp:data/train/cmvn.scp -'");
+  po->Register("global-cmvn-stats", &global_cmvn_stats_rxfilename,
+      "(Extended) filename for global CMVN stats, used in iVector extraction, obtained for example from 'matrix-sum scp:data/train/cmvn.scp -'");
   po->Register("cmvn-config", &cmvn_config_rxfilename, "Configuration file for online CMVN features (e.g. conf/online_cmvn.conf), only used for iVector extraction.");
   po->Register("online-cmvn-iextractor", &online_cmvn_iextractor, "add online-cmvn to feature pipeline of ivector extractor (the statistics side).");
   po->Register("splice-config", &splice_config_rxfilename, "Configuration file for frame splicing (--left-context and --right-context options); used for iVector extraction.");

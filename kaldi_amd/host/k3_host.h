@@ -80,7 +80,12 @@ Wave ReadWave(const std::string &rxfilename, int channel = 0, int *num_channels 
 
 // .mdl (text or binary): parses the TransitionModel in front of the nnet; id2pdf[0] is unused
 // id2phone / self_loop / phone_start = TransitionIdToPhone, IsSelfLoop, TransitionIdIsStartOfPhone (hmm/transition-model.cc:790,925)
-struct TransitionInfo { int32_t num_pdfs = 0; std::vector<int32_t> id2pdf, id2phone; std::vector<char> self_loop, phone_start, is_final; };      // is_final: TransitionModel::IsFinal (the transition enters the topology's last, non-emitting state)
+// is_final: TransitionModel::IsFinal (the transition enters the topology's last, non-emitting state)
+struct TransitionInfo {
+  int32_t num_pdfs = 0;
+  std::vector<int32_t> id2pdf, id2phone;
+  std::vector<char> self_loop, phone_start, is_final;
+};
 TransitionInfo ReadTransitionModel(const std::string &mdl_rxfilename);
 
 // model files of the online i-vector extractor (binary files only), values widened to double, matrices row-major:
@@ -215,7 +220,8 @@ class DeterminizeSequencer {
   struct Config {
     int32_t num_threads = 1; double beam = 10.0, pre_scale = 1.0, post_scale = 1.0; bool topsort = false, minimize = false; DeterminizeLatticePrunedOptions det;
     const TransitionInfo *trans = nullptr; DeterminizeLatticePhonePrunedOptions phone_det;       // trans != nullptr: DeterminizeLatticePhonePruned with phone_det
-    // the CUDA pipeline's lattice post-processor (SetLatticePostprocessor, batched-threaded-nnet3-cuda-pipeline2.h:204): applied to the determinized lattice; with `ctm_out` the record written
+    // the CUDA pipeline's lattice post-processor (SetLatticePostprocessor, batched-threaded-nnet3-cuda-pipeline2.h:204): applied to the determinized lattice;
+    // with `ctm_out` the record written
     // is the utterance's CTM lines (LatticePostprocessor::GetCTM + MergeSegmentsToCTMOutput) instead of the lattice -- `writer` may then be null
     std::shared_ptr<class LatticePostprocessor> postprocessor; std::ostream *ctm_out = nullptr; const std::vector<std::string> *word_syms = nullptr; bool determinize = true;
   };
@@ -260,7 +266,8 @@ struct WordBoundaryInfo {      // lat/word-align-lattice.h:119-170 (the WordBoun
   PhoneType TypeOfPhone(int32_t p) const;      // throws for a phone the file does not list
 };
 WordBoundaryInfo ReadWordBoundaryInfo(const std::string &word_boundary_rxfilename, bool reorder = true, int32_t silence_label = 0, int32_t partial_word_label = 0);
-// WordAlignLattice (:724-731): false when the lattice could not be aligned cleanly (a broken / forced-out lattice, a mismatched model or --reorder option, max_states > 0 exceeded);
+// WordAlignLattice (:724-731): false when the lattice could not be aligned cleanly (a broken / forced-out lattice, a mismatched model or --reorder option,
+// max_states > 0 exceeded);
 // lat_out then holds what could be made of it, as in the reference
 bool WordAlignLattice(const CompactLattice &lat, const TransitionInfo &tmodel, const WordBoundaryInfo &info, int32_t max_states, CompactLattice *lat_out);
 
@@ -272,7 +279,11 @@ class LatticePostprocessor {      // cudadecoder/lattice-postprocessor.h:78-118
   void SetDecoderFrameShift(float seconds) { decoder_frame_shift_ = seconds; }
   void SetTransitionInformation(const TransitionInfo *tmodel) { tmodel_ = tmodel; }      // (:93-95; needed with --word-boundary-rxfilename)
  private:
-  LatticePostprocessorConfig config_; bool use_lattice_scale_ = false; float decoder_frame_shift_ = 0.0f; const TransitionInfo *tmodel_ = nullptr; std::shared_ptr<WordBoundaryInfo> word_info_;
+  LatticePostprocessorConfig config_;
+  bool use_lattice_scale_ = false;
+  float decoder_frame_shift_ = 0.0f;
+  const TransitionInfo *tmodel_ = nullptr;
+  std::shared_ptr<WordBoundaryInfo> word_info_;
 };
 std::shared_ptr<LatticePostprocessor> LoadLatticePostprocessor(const std::string &config_rxfilename);      // LoadAndSetLatticePostprocessor's first half (:126-137)
 // the CTM lines of one (un-segmented) utterance: "<key> 0  <begin> <duration> <word> <confidence>", two decimals (cuda-pipeline-common.cc:67-142)

@@ -105,7 +105,8 @@ struct EdgeFst {
 // they determinize (decoder-wrappers.cc:353), and so do the programs here.
 EdgeFst InvertedEdges(const Lattice &lat) {
   EdgeFst e; e.start = lat.NumStates() ? lat.start : -1;
-  for (int32_t s = 0; s < lat.NumStates(); s++) e.fin.push_back(std::isfinite(lat.st_final[s]) ? LatW{lat.st_final[s], lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]} : Zero());
+  for (int32_t s = 0; s < lat.NumStates(); s++) e.fin.push_back(std::isfinite(lat.st_final[s]) ?
+      LatW{lat.st_final[s], lat.st_final_ac.empty() ? 0.0f : lat.st_final_ac[s]} : Zero());
   for (size_t a = 0; a < lat.arc_src.size(); a++) e.AddArc(lat.arc_src[a], lat.arc_dst[a], lat.arc_olabel[a], lat.arc_ilabel[a], {lat.arc_graph[a], lat.arc_ac[a]});
   return e;
 }
@@ -160,13 +161,21 @@ bool PruneInput(double beam, InputFst *f) {
   // trim: accessible through kept arcs and co-accessible to a final weight that is still there
   std::vector<char> acc(n, 0), co(n, 0); acc[f->start] = 1;
   for (int32_t s = 0; s < n; s++) if (acc[s]) for (int32_t k = f->off[s]; k < f->off[s + 1]; k++) if (keep_arc[k]) acc[f->next[k]] = 1;
-  for (int32_t s = n - 1; s >= 0; s--) { if (f->fin[s] != Zero()) co[s] = 1; for (int32_t k = f->off[s]; k < f->off[s + 1] && !co[s]; k++) if (keep_arc[k] && co[f->next[k]]) co[s] = 1; }
+  for (int32_t s = n - 1; s >= 0; s--) {
+    if (f->fin[s] != Zero()) co[s] = 1;
+    for (int32_t k = f->off[s]; k < f->off[s + 1] && !co[s]; k++) if (keep_arc[k] && co[f->next[k]]) co[s] = 1;
+  }
   std::vector<int32_t> newid(n, -1); int32_t m = 0; for (int32_t s = 0; s < n; s++) if (acc[s] && co[s]) newid[s] = m++;
   InputFst o; o.start = newid[f->start]; o.fin.resize(m); o.off.assign(m + 1, 0);
   for (int32_t s = 0; s < n; s++) {
     if (newid[s] < 0) continue;
     o.fin[newid[s]] = f->fin[s];
-    for (int32_t k = f->off[s]; k < f->off[s + 1]; k++) if (keep_arc[k] && newid[f->next[k]] >= 0) { o.word.push_back(f->word[k]); o.tid.push_back(f->tid[k]); o.next.push_back(newid[f->next[k]]); o.w.push_back(f->w[k]); }
+    for (int32_t k = f->off[s]; k < f->off[s + 1]; k++) if (keep_arc[k] && newid[f->next[k]] >= 0) {
+      o.word.push_back(f->word[k]);
+      o.tid.push_back(f->tid[k]);
+      o.next.push_back(newid[f->next[k]]);
+      o.w.push_back(f->w[k]);
+    }
     o.off[newid[s] + 1] = (int32_t)o.word.size();
   }
   if (o.start < 0) o = InputFst();
@@ -212,7 +221,14 @@ class StringTrie {
   void KeepOnly(const std::vector<char> &needed) { num_held_ = 0; for (size_t i = 1; i < held_.size(); i++) { held_[i] = needed[i]; num_held_ += needed[i]; } removed_.Clear(); }
   void ToVector(int32_t s, std::vector<int32_t> *v) const { v->resize(depth_[s]); for (int32_t i = depth_[s] - 1; i >= 0; i--, s = parent_[s]) (*v)[i] = label_[s]; }
   int32_t FromVector(const std::vector<int32_t> &v, size_t from = 0) { int32_t s = 0; for (size_t i = from; i < v.size(); i++) s = Successor(s, v[i]); return s; }
-  int32_t Concatenate(int32_t a, int32_t b) { if (b == 0) return a; if (a == 0) return b; std::vector<int32_t> v; ToVector(b, &v); for (int32_t l : v) a = Successor(a, l); return a; }
+  int32_t Concatenate(int32_t a, int32_t b) {
+    if (b == 0) return a;
+    if (a == 0) return b;
+    std::vector<int32_t> v;
+    ToVector(b, &v);
+    for (int32_t l : v) a = Successor(a, l);
+    return a;
+  }
   void ReduceToCommonPrefix(int32_t s, std::vector<int32_t> *prefix) const {
     while (depth_[s] > (int32_t)prefix->size()) s = parent_[s];
     prefix->resize(depth_[s]);
@@ -248,13 +264,15 @@ class StringTrie {
 // ---- LatticeDeterminizerPruned (lat/determinize-lattice-pruned.cc:47-1190) -------------------------------------------------------
 class Determinizer {
  public:
-  Determinizer(const InputFst &f, double beam, const DeterminizeLatticePrunedOptions &opts) : f_(f), beam_(beam), opts_(opts), minimal_hash_(16, SubsetHash(), SubsetEqual{opts.delta}), initial_hash_(16, SubsetHash(), SubsetEqual{opts.delta}) {}
+  Determinizer(const InputFst &f, double beam, const DeterminizeLatticePrunedOptions &opts) : f_(f), beam_(beam), opts_(opts),
+      minimal_hash_(16, SubsetHash(), SubsetEqual{opts.delta}), initial_hash_(16, SubsetHash(), SubsetEqual{opts.delta}) {}
 
   bool Determinize(double *effective_beam) {                 // :329-375
     Initialize();
     while (!queue_.empty()) {
       const size_t num_states = out_.size();
-      if ((opts_.max_states > 0 && (int64_t)num_states > opts_.max_states) || (opts_.max_arcs > 0 && num_arcs_ > opts_.max_arcs) || (num_states % 10 == 0 && !CheckMemoryUsage())) break;
+      if ((opts_.max_states > 0 && (int64_t)num_states > opts_.max_states) || (opts_.max_arcs > 0 && num_arcs_ > opts_.max_arcs) ||
+          (num_states % 10 == 0 && !CheckMemoryUsage())) break;
       Task *task = queue_.top(); queue_.pop();
       ProcessTransition(task->state, task->label, &task->subset);
       delete task;
@@ -297,7 +315,14 @@ class Determinizer {
       for (const TempArc &t : out_[s].arcs) {
         trie_.ToVector(t.string, &str);
         if (t.next < 0) { o->is_final[s] = 1; o->fin_graph[s] = t.w.g; o->fin_ac[s] = t.w.a; o->fin_str[s] = str; }
-        else { o->arc_src.push_back((int32_t)s); o->arc_dst.push_back(t.next); o->arc_label.push_back(t.label); o->arc_graph.push_back(t.w.g); o->arc_ac.push_back(t.w.a); o->arc_str.push_back(str); }
+        else {
+          o->arc_src.push_back((int32_t)s);
+          o->arc_dst.push_back(t.next);
+          o->arc_label.push_back(t.label);
+          o->arc_graph.push_back(t.w.g);
+          o->arc_ac.push_back(t.w.a);
+          o->arc_str.push_back(str);
+        }
       }
   }
 
@@ -311,7 +336,15 @@ class Determinizer {
   struct Task { int32_t state, label; std::vector<Element> subset; double priority_cost; };
   struct TaskCompare { bool operator()(const Task *a, const Task *b) const { return a->priority_cost > b->priority_cost; } };     // :1156-1162: cheapest first
   struct SubsetHash {                                        // :432-443: state and string only, not the weight
-    size_t operator()(const std::vector<Element> *v) const { size_t h = 0, factor = 1; for (const Element &e : *v) { h *= factor; h += (size_t)e.state + 103333u * (size_t)e.string; factor *= 23531; } return h; }
+    size_t operator()(const std::vector<Element> *v) const {
+      size_t h = 0, factor = 1;
+      for (const Element &e : *v) {
+        h *= factor;
+        h += (size_t)e.state + 103333u * (size_t)e.string;
+        factor *= 23531;
+      }
+      return h;
+    }
   };
   struct SubsetEqual {                                       // :447-463: exact on state and string, within delta on the weight
     float delta;
@@ -359,7 +392,8 @@ class Determinizer {
     while (!queue.empty()) {
       const Element elem = queue.top(); queue.pop();
       if (replaced && *find(elem.state) != elem) continue;     // a stale copy of an element that was improved later
-      if (opts_.max_loop > 0 && counter++ > opts_.max_loop) K3H_ERR << "Lattice determinization aborted since looped more than " << opts_.max_loop << " times during epsilon closure.";
+      if (opts_.max_loop > 0 && counter++ > opts_.max_loop) K3H_ERR << "Lattice determinization aborted since looped more than " << opts_.max_loop <<
+          " times during epsilon closure.";
       for (int32_t k = f_.off[elem.state]; k < f_.off[elem.state + 1] && f_.word[k] == 0; k++) {
         if (f_.w[k] == Zero()) continue;
         Element nx; nx.state = f_.next[k]; nx.w = Times(elem.w, f_.w[k]); nx.string = -1;
@@ -412,7 +446,8 @@ class Determinizer {
   int32_t MinimalToStateId(const std::vector<Element> &subset, double forward_cost) {   // :520-547
     auto it = minimal_hash_.find(&subset);
     if (it != minimal_hash_.end()) {
-      if (forward_cost < out_[it->second].forward_cost - 0.1) K3H_WARN << "New cost is less (check the difference is small) " << forward_cost << ", " << out_[it->second].forward_cost;
+      if (forward_cost < out_[it->second].forward_cost - 0.1) K3H_WARN << "New cost is less (check the difference is small) " << forward_cost << ", " <<
+          out_[it->second].forward_cost;
       return it->second;
     }
     const int32_t id = (int32_t)out_.size();
@@ -461,7 +496,8 @@ class Determinizer {
         if (f_.word[k] == 0 || f_.w[k] == Zero()) continue;
         all.push_back({f_.word[k], Element{f_.next[k], f_.tid[k] == 0 ? e.string : trie_.Successor(e.string, f_.tid[k]), Times(e.w, f_.w[k])}});
       }
-    std::sort(all.begin(), all.end(), [](const std::pair<int32_t, Element> &a, const std::pair<int32_t, Element> &b) { return a.first != b.first ? a.first < b.first : a.second.state < b.second.state; });
+    std::sort(all.begin(), all.end(), [](const std::pair<int32_t, Element> &a, const std::pair<int32_t,
+        Element> &b) { return a.first != b.first ? a.first < b.first : a.second.state < b.second.state; });
     const double forward_cost = out_[id].forward_cost;
     for (size_t i = 0; i < all.size();) {
       Task *task = new Task; task->state = id; task->label = all[i].first; task->priority_cost = kInfD;
@@ -512,12 +548,23 @@ class Determinizer {
     auto mark = [&](int32_t s) { for (; s > 0 && !live[s]; s = trie_.Parent(s)) live[s] = 1; };
     for (const OutputState &st : out_) { for (const Element &e : st.minimal_subset) mark(e.string); for (const TempArc &t : st.arcs) mark(t.string); }
     for (const auto &kv : initial_hash_) { for (const Element &e : *kv.first) mark(e.string); mark(kv.second.string); }
-    { std::vector<Task *> tasks; while (!queue_.empty()) { tasks.push_back(queue_.top()); queue_.pop(); } for (Task *t : tasks) { for (const Element &e : t->subset) mark(e.string); queue_.push(t); } }
+    {
+      std::vector<Task *> tasks;
+      while (!queue_.empty()) {
+        tasks.push_back(queue_.top());
+        queue_.pop();
+      }
+      for (Task *t : tasks) {
+        for (const Element &e : t->subset) mark(e.string);
+        queue_.push(t);
+      }
+    }
     trie_.KeepOnly(live);
     const int64_t new_repo = (int64_t)trie_.NumHeld() * 32;
     if (new_repo + arcs + elems > (int64_t)(opts_.max_mem * 0.8)) {
       double eff = beam_; if (!queue_.empty()) eff = queue_.top()->priority_cost - backward_[f_.start];
-      K3H_WARN << "Did not reach requested beam in determinize-lattice: size exceeds maximum " << opts_.max_mem << " bytes; (repo,arcs,elems) = (" << repo << "," << arcs << "," << elems
+      K3H_WARN << "Did not reach requested beam in determinize-lattice: size exceeds maximum " << opts_.max_mem << " bytes; (repo,arcs,elems) = (" << repo <<
+          "," << arcs << "," << elems
                << "), after rebuilding, repo size was " << new_repo << ", effective beam was " << eff << " vs. requested beam " << beam_;
       return false;
     }
@@ -646,7 +693,13 @@ bool PruneLattice(double beam, Lattice *lat) {
   auto fin = [&](int32_t s) { return std::isfinite(lat->st_final[s]) ? (double)lat->st_final[s] + (lat->st_final_ac.empty() ? 0.0 : (double)lat->st_final_ac[s]) : kInfD; };
   auto cost = [&](int32_t a) { return (double)lat->arc_graph[a] + (double)lat->arc_ac[a]; };
   std::vector<double> fwd(n, kInfD), bwd(n, kInfD); fwd[lat->start] = 0.0; double best = kInfD;
-  for (int32_t s : order) { for (int32_t k = off[s]; k < off[s + 1]; k++) { const double c = fwd[s] + cost(idx[k]); if (c < fwd[nx[k]]) fwd[nx[k]] = c; } best = std::min(best, fwd[s] + fin(s)); }
+  for (int32_t s : order) {
+    for (int32_t k = off[s]; k < off[s + 1]; k++) {
+      const double c = fwd[s] + cost(idx[k]);
+      if (c < fwd[nx[k]]) fwd[nx[k]] = c;
+    }
+    best = std::min(best, fwd[s] + fin(s));
+  }
   const double cutoff = best + beam;
   std::vector<char> drop(na, 0);
   for (auto it = order.rbegin(); it != order.rend(); ++it) {
@@ -657,7 +710,13 @@ bool PruneLattice(double beam, Lattice *lat) {
   }
   size_t o = 0;
   for (size_t a = 0; a < na; a++) if (!drop[a]) {
-    lat->arc_src[o] = lat->arc_src[a]; lat->arc_dst[o] = lat->arc_dst[a]; lat->arc_ilabel[o] = lat->arc_ilabel[a]; lat->arc_olabel[o] = lat->arc_olabel[a]; lat->arc_graph[o] = lat->arc_graph[a]; lat->arc_ac[o] = lat->arc_ac[a]; o++;
+    lat->arc_src[o] = lat->arc_src[a];
+    lat->arc_dst[o] = lat->arc_dst[a];
+    lat->arc_ilabel[o] = lat->arc_ilabel[a];
+    lat->arc_olabel[o] = lat->arc_olabel[a];
+    lat->arc_graph[o] = lat->arc_graph[a];
+    lat->arc_ac[o] = lat->arc_ac[a];
+    o++;
   }
   for (auto *v : {&lat->arc_src, &lat->arc_dst, &lat->arc_ilabel, &lat->arc_olabel}) v->resize(o);
   lat->arc_graph.resize(o); lat->arc_ac.resize(o);
@@ -670,11 +729,24 @@ namespace {
 void Renumber(CompactLattice *c, const std::vector<int32_t> &newid, int32_t m) {     // newid[s] < 0: state removed
   CompactLattice o; for (int32_t i = 0; i < m; i++) o.AddState();
   o.start = c->start >= 0 ? newid[c->start] : -1;
-  for (int32_t s = 0; s < c->NumStates(); s++) if (newid[s] >= 0) { const int32_t t = newid[s]; o.is_final[t] = c->is_final[s]; o.fin_graph[t] = c->fin_graph[s]; o.fin_ac[t] = c->fin_ac[s]; o.fin_str[t] = std::move(c->fin_str[s]); }
+  for (int32_t s = 0; s < c->NumStates(); s++) if (newid[s] >= 0) {
+    const int32_t t = newid[s];
+    o.is_final[t] = c->is_final[s];
+    o.fin_graph[t] = c->fin_graph[s];
+    o.fin_ac[t] = c->fin_ac[s];
+    o.fin_str[t] = std::move(c->fin_str[s]);
+  }
   // arcs stay grouped by (new) source state, in their old relative order
   std::vector<int32_t> keep; for (size_t a = 0; a < c->arc_src.size(); a++) if (newid[c->arc_src[a]] >= 0 && newid[c->arc_dst[a]] >= 0) keep.push_back((int32_t)a);
   std::stable_sort(keep.begin(), keep.end(), [&](int32_t x, int32_t y) { return newid[c->arc_src[x]] < newid[c->arc_src[y]]; });
-  for (int32_t a : keep) { o.arc_src.push_back(newid[c->arc_src[a]]); o.arc_dst.push_back(newid[c->arc_dst[a]]); o.arc_label.push_back(c->arc_label[a]); o.arc_graph.push_back(c->arc_graph[a]); o.arc_ac.push_back(c->arc_ac[a]); o.arc_str.push_back(std::move(c->arc_str[a])); }
+  for (int32_t a : keep) {
+    o.arc_src.push_back(newid[c->arc_src[a]]);
+    o.arc_dst.push_back(newid[c->arc_dst[a]]);
+    o.arc_label.push_back(c->arc_label[a]);
+    o.arc_graph.push_back(c->arc_graph[a]);
+    o.arc_ac.push_back(c->arc_ac[a]);
+    o.arc_str.push_back(std::move(c->arc_str[a]));
+  }
   if (o.start < 0) o = CompactLattice();
   *c = std::move(o);
 }
@@ -762,7 +834,12 @@ void ConvertLattice(const Lattice &lat, CompactLattice *out) {
     for (int32_t k = foff[x]; k < foff[x + 1]; k++) {
       const int32_t a = fidx[k];
       if (newid[f.dst[a]] < 0) continue;
-      out->arc_src.push_back(t); out->arc_dst.push_back(newid[f.dst[a]]); out->arc_label.push_back(f.word[a]); out->arc_graph.push_back(f.w[a].g); out->arc_ac.push_back(f.w[a].a); out->arc_str.push_back(std::move(strings[f.tid[a]]));
+      out->arc_src.push_back(t);
+      out->arc_dst.push_back(newid[f.dst[a]]);
+      out->arc_label.push_back(f.word[a]);
+      out->arc_graph.push_back(f.w[a].g);
+      out->arc_ac.push_back(f.w[a].a);
+      out->arc_str.push_back(std::move(strings[f.tid[a]]));
     }
   }
 }
@@ -771,7 +848,14 @@ void ConvertLattice(const CompactLattice &c, Lattice *out) {
   Lattice l; const int32_t n = c.NumStates();
   l.start = c.start; l.st_final.assign(n, kInfF); l.st_final_ac.assign(n, 0.0f);
   auto add_state = [&]() { l.st_final.push_back(kInfF); l.st_final_ac.push_back(0.0f); return (int32_t)l.st_final.size() - 1; };
-  auto add_arc = [&](int32_t s, int32_t d, int32_t tid, int32_t word, float g, float a) { l.arc_src.push_back(s); l.arc_dst.push_back(d); l.arc_ilabel.push_back(tid); l.arc_olabel.push_back(word); l.arc_graph.push_back(g); l.arc_ac.push_back(a); };
+  auto add_arc = [&](int32_t s, int32_t d, int32_t tid, int32_t word, float g, float a) {
+    l.arc_src.push_back(s);
+    l.arc_dst.push_back(d);
+    l.arc_ilabel.push_back(tid);
+    l.arc_olabel.push_back(word);
+    l.arc_graph.push_back(g);
+    l.arc_ac.push_back(a);
+  };
   std::vector<int32_t> off(n + 1, 0), idx(c.arc_src.size());
   for (int32_t s : c.arc_src) off[s + 1]++;
   for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
@@ -779,12 +863,20 @@ void ConvertLattice(const CompactLattice &c, Lattice *out) {
   for (int32_t s = 0; s < n; s++) {
     if (c.is_final[s]) {
       int32_t cur = s; const std::vector<int32_t> &str = c.fin_str[s];
-      for (size_t k = 0; k < str.size(); k++) { const int32_t nx = add_state(); add_arc(cur, nx, str[k], 0, k == 0 ? c.fin_graph[s] : 0.0f, k == 0 ? c.fin_ac[s] : 0.0f); cur = nx; }
+      for (size_t k = 0; k < str.size(); k++) {
+        const int32_t nx = add_state();
+        add_arc(cur, nx, str[k], 0, k == 0 ? c.fin_graph[s] : 0.0f, k == 0 ? c.fin_ac[s] : 0.0f);
+        cur = nx;
+      }
       l.st_final[cur] = str.empty() ? c.fin_graph[s] : 0.0f; l.st_final_ac[cur] = str.empty() ? c.fin_ac[s] : 0.0f;
     }
     for (int32_t k = off[s]; k < off[s + 1]; k++) {
       const int32_t a = idx[k]; const std::vector<int32_t> &str = c.arc_str[a]; int32_t cur = s;
-      for (size_t i = 0; i + 1 < str.size(); i++) { const int32_t nx = add_state(); add_arc(cur, nx, str[i], i == 0 ? c.arc_label[a] : 0, i == 0 ? c.arc_graph[a] : 0.0f, i == 0 ? c.arc_ac[a] : 0.0f); cur = nx; }
+      for (size_t i = 0; i + 1 < str.size(); i++) {
+        const int32_t nx = add_state();
+        add_arc(cur, nx, str[i], i == 0 ? c.arc_label[a] : 0, i == 0 ? c.arc_graph[a] : 0.0f, i == 0 ? c.arc_ac[a] : 0.0f);
+        cur = nx;
+      }
       const bool single = str.size() <= 1;
       add_arc(cur, c.arc_dst[a], str.empty() ? 0 : str.back(), single ? c.arc_label[a] : 0, single ? c.arc_graph[a] : 0.0f, single ? c.arc_ac[a] : 0.0f);
     }
@@ -793,7 +885,10 @@ void ConvertLattice(const CompactLattice &c, Lattice *out) {
   *out = std::move(l);
 }
 
-void ScaleAcoustic(CompactLattice *c, double scale) { for (float &a : c->arc_ac) a = (float)(a * scale); for (int32_t s = 0; s < c->NumStates(); s++) if (c->is_final[s]) c->fin_ac[s] = (float)(c->fin_ac[s] * scale); }
+void ScaleAcoustic(CompactLattice *c, double scale) {
+  for (float &a : c->arc_ac) a = (float)(a * scale);
+  for (int32_t s = 0; s < c->NumStates(); s++) if (c->is_final[s]) c->fin_ac[s] = (float)(c->fin_ac[s] * scale);
+}
 
 bool TopSortIfNeeded(CompactLattice *c) {
   bool sorted = true;
@@ -835,7 +930,10 @@ void GetString(const CompactLattice &c, const ArcsByState &by, int32_t state, in
 }  // namespace
 
 bool PushCompactLatticeStrings(CompactLattice *c) {      // push-lattice.cc:30-227
-  if (!TopSortIfNeeded(c)) { K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)"; return false; }
+  if (!TopSortIfNeeded(c)) {
+    K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)";
+    return false;
+  }
   const int32_t n = c->NumStates(); const ArcsByState by(*c);
   std::vector<int32_t> shift(n, 0);
   for (int32_t s = n - 1; s > c->start; s--) {           // ComputeShifts :134-164; the start state keeps shift 0
@@ -872,7 +970,10 @@ bool PushCompactLatticeStrings(CompactLattice *c) {      // push-lattice.cc:30-2
 }
 
 bool PushCompactLatticeWeights(CompactLattice *c) {      // push-lattice.cc:236-289
-  if (!TopSortIfNeeded(c)) { K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)"; return false; }
+  if (!TopSortIfNeeded(c)) {
+    K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)";
+    return false;
+  }
   const int32_t n = c->NumStates();
   if (n == 0) { K3H_WARN << "Pushing weights of empty compact lattice"; return true; }
   const ArcsByState by(*c);
@@ -897,9 +998,20 @@ bool PushCompactLatticeWeights(CompactLattice *c) {      // push-lattice.cc:236-
 }
 
 bool MinimizeCompactLattice(CompactLattice *c, float delta) {      // minimize-lattice.cc:37-275
-  if (!TopSortIfNeeded(c)) { K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)"; return false; }
+  if (!TopSortIfNeeded(c)) {
+    K3H_WARN << "Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles; this  is a bad idea.)";
+    return false;
+  }
   const int32_t n = c->NumStates(); const ArcsByState by(*c);
-  auto string_hash = [](const std::vector<int32_t> &v) { size_t h = 0; for (int32_t x : v) { h *= 7853; h += (size_t)x; } return h == 0 ? (size_t)53281 : h; };    // VectorHasher, never 0
+  // VectorHasher, never 0
+  auto string_hash = [](const std::vector<int32_t> &v) {
+    size_t h = 0;
+    for (int32_t x : v) {
+      h *= 7853;
+      h += (size_t)x;
+    }
+    return h == 0 ? (size_t)53281 : h;
+  };
   std::vector<size_t> hash(n);
   for (int32_t s = n - 1; s >= 0; s--) {                 // ComputeStateHashValues :98-123: order-insensitive over the arcs
     size_t h = c->is_final[s] ? (size_t)607 * string_hash(c->fin_str[s]) : (size_t)33317;
@@ -914,7 +1026,11 @@ bool MinimizeCompactLattice(CompactLattice *c, float delta) {      // minimize-l
   std::vector<int32_t> map(n); for (int32_t s = 0; s < n; s++) map[s] = s;
   struct A { int32_t label, next; LatW w; const std::vector<int32_t> *str; };
   auto arcs_of = [&](int32_t s) {
-    std::vector<A> v; for (int32_t k = 0; k < by.Num(s); k++) { const int32_t a = by.Arc(s, k); v.push_back({c->arc_label[a], map[c->arc_dst[a]], LatW{c->arc_graph[a], c->arc_ac[a]}, &c->arc_str[a]}); }
+    std::vector<A> v;
+    for (int32_t k = 0; k < by.Num(s); k++) {
+      const int32_t a = by.Arc(s, k);
+      v.push_back({c->arc_label[a], map[c->arc_dst[a]], LatW{c->arc_graph[a], c->arc_ac[a]}, &c->arc_str[a]});
+    }
     std::sort(v.begin(), v.end(), [](const A &x, const A &y) { return x.label != y.label ? x.label < y.label : x.next < y.next; });
     return v;
   };
@@ -923,7 +1039,8 @@ bool MinimizeCompactLattice(CompactLattice *c, float delta) {      // minimize-l
     if (c->is_final[s] && !(ApproxEqual(LatW{c->fin_graph[s], c->fin_ac[s]}, LatW{c->fin_graph[t], c->fin_ac[t]}, delta) && c->fin_str[s] == c->fin_str[t])) return false;
     if (by.Num(s) != by.Num(t)) return false;
     const std::vector<A> x = arcs_of(s), y = arcs_of(t);
-    for (size_t i = 0; i < x.size(); i++) if (x[i].next != y[i].next || x[i].label != y[i].label || !(ApproxEqual(x[i].w, y[i].w, 1.0f / 1024.0f) && *x[i].str == *y[i].str)) return false;
+    for (size_t i = 0; i < x.size(); i++) if (x[i].next != y[i].next || x[i].label != y[i].label ||
+        !(ApproxEqual(x[i].w, y[i].w, 1.0f / 1024.0f) && *x[i].str == *y[i].str)) return false;
     return true;
   };
   for (int32_t s = n - 1; s >= 0; s--)                   // ComputeStateMap :188-229
@@ -962,7 +1079,14 @@ void TableWriter::WriteCompactLattice(const std::string &key, const CompactLatti
         if (!(c.arc_graph[a] == 0.0f && c.arc_ac[a] == 0.0f && c.arc_str[a].empty())) { o += "\t"; PrintCompactWeight(&o, c.arc_graph[a], c.arc_ac[a], c.arc_str[a]); }
         o += "\n";
       }
-      if (c.is_final[s]) { o += std::to_string(s); if (!(c.fin_graph[s] == 0.0f && c.fin_ac[s] == 0.0f && c.fin_str[s].empty())) { o += "\t"; PrintCompactWeight(&o, c.fin_graph[s], c.fin_ac[s], c.fin_str[s]); } o += "\n"; }
+      if (c.is_final[s]) {
+        o += std::to_string(s);
+        if (!(c.fin_graph[s] == 0.0f && c.fin_ac[s] == 0.0f && c.fin_str[s].empty())) {
+          o += "\t";
+          PrintCompactWeight(&o, c.fin_graph[s], c.fin_ac[s], c.fin_str[s]);
+        }
+        o += "\n";
+      }
     };
     if (c.start >= 0) print_state(c.start);
     for (int32_t s = 0; s < n; s++) if (s != c.start) print_state(s);
@@ -975,7 +1099,13 @@ void TableWriter::WriteCompactLattice(const std::string &key, const CompactLatti
     for (int32_t s = 0; s < n; s++) {
       if (c.is_final[s]) put_w(c.fin_graph[s], c.fin_ac[s], c.fin_str[s]); else put_w(kInfF, kInfF, kEmpty);
       Put<int64_t>(&o, off[s + 1] - off[s]);
-      for (int32_t k = off[s]; k < off[s + 1]; k++) { const int32_t a = order[k]; Put(&o, c.arc_label[a]); Put(&o, c.arc_label[a]); put_w(c.arc_graph[a], c.arc_ac[a], c.arc_str[a]); Put(&o, c.arc_dst[a]); }
+      for (int32_t k = off[s]; k < off[s + 1]; k++) {
+        const int32_t a = order[k];
+        Put(&o, c.arc_label[a]);
+        Put(&o, c.arc_label[a]);
+        put_w(c.arc_graph[a], c.arc_ac[a], c.arc_str[a]);
+        Put(&o, c.arc_dst[a]);
+      }
     }
   }
   if (fwrite(o.data(), 1, o.size(), f_.get()) != o.size()) K3H_ERR << "Write failure on compact lattice " << key;
@@ -995,7 +1125,13 @@ struct DeterminizeSequencer::Impl {
   void Work() {
     for (;;) {
       Job job;
-      { std::unique_lock<std::mutex> lk(m); cv_work.wait(lk, [&] { return stop || !queue.empty(); }); if (queue.empty()) return; job = std::move(queue.front()); queue.pop_front(); }
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+        if (queue.empty()) return;
+        job = std::move(queue.front());
+        queue.pop_front();
+      }
       CompactLattice clat; bool warn = false; std::string err, ctm_text;
       try {
         if (cfg.pre_scale != 1.0) ScaleAcoustic(&job.lat, cfg.pre_scale);
@@ -1004,7 +1140,12 @@ struct DeterminizeSequencer::Impl {
         else ok = cfg.trans ? DeterminizeLatticePhonePruned(job.lat, *cfg.trans, cfg.beam, &clat, cfg.phone_det) : DeterminizeLatticePruned(job.lat, cfg.beam, &clat, cfg.det);
         if (!ok) { K3H_WARN << "For key " << job.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; warn = true; }
         if (clat.NumStates() == 0) { K3H_WARN << "For key " << job.key << ", determinized and trimmed lattice was empty."; warn = true; }
-        if (cfg.minimize && !cfg.trans) { PushCompactLatticeStrings(&clat); PushCompactLatticeWeights(&clat); MinimizeCompactLattice(&clat); }      // with cfg.trans: phone_det.minimize, inside
+        // with cfg.trans: phone_det.minimize, inside
+        if (cfg.minimize && !cfg.trans) {
+          PushCompactLatticeStrings(&clat);
+          PushCompactLatticeWeights(&clat);
+          MinimizeCompactLattice(&clat);
+        }
         if (cfg.topsort && !TopSortIfNeeded(&clat)) K3H_WARN << "Topological sorting of the determinized lattice failed for key " << job.key;
         if (cfg.post_scale != 1.0) ScaleAcoustic(&clat, cfg.post_scale);
         if (cfg.postprocessor) {      // SetResultUsingLattice (cudadecoder/lattice-postprocessor.cc:112-137)
@@ -1019,7 +1160,16 @@ struct DeterminizeSequencer::Impl {
       finished.emplace(job.seq, Done{std::move(job.key), std::move(clat), std::move(ctm_text)});
       // whoever completes the next lattice in line writes it and everything behind it that is already there
       for (auto it = finished.find(written); it != finished.end(); it = finished.find(written)) {
-        if (error.empty()) { try { if (cfg.ctm_out) { *cfg.ctm_out << it->second.ctm; cfg.ctm_out->flush(); } else writer->WriteCompactLattice(it->second.key, it->second.clat); } catch (const std::exception &e) { error = e.what(); } }
+        if (error.empty()) {
+          try {
+            if (cfg.ctm_out) {
+              *cfg.ctm_out << it->second.ctm;
+              cfg.ctm_out->flush();
+            } else writer->WriteCompactLattice(it->second.key, it->second.clat);
+          } catch (const std::exception &e) {
+            error = e.what();
+          }
+        }
         finished.erase(it); written++;
       }
       cv_done.notify_all();
@@ -1056,11 +1206,19 @@ int32_t DeterminizeSequencer::NumWarn() const { std::unique_lock<std::mutex> lk(
 // ------------------------------------------------------------------------------------------------ lattice table reader ----
 std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string &rspecifier) {
   const size_t colon = rspecifier.find(':');
-  if (colon == std::string::npos || rspecifier.compare(0, 3, "ark") != 0) K3H_ERR << "Invalid lattice rspecifier " << rspecifier << " (supported: ark:<rxfilename>, ark,t:<rxfilename>)";
+  if (colon == std::string::npos || rspecifier.compare(0, 3, "ark") != 0) K3H_ERR << "Invalid lattice rspecifier " << rspecifier <<
+      " (supported: ark:<rxfilename>, ark,t:<rxfilename>)";
   const std::string b = ReadWholeInput(rspecifier.substr(colon + 1));
   std::vector<std::pair<std::string, Lattice>> out;
   size_t p = 0;
-  auto parse_float = [&](const std::string &t) { if (t == "Infinity") return kInfF; if (t == "-Infinity") return -kInfF; char *e; const float v = strtof(t.c_str(), &e); if (*e || t.empty()) K3H_ERR << "Bad number \"" << t << "\" in lattice"; return v; };
+  auto parse_float = [&](const std::string &t) {
+    if (t == "Infinity") return kInfF;
+    if (t == "-Infinity") return -kInfF;
+    char *e;
+    const float v = strtof(t.c_str(), &e);
+    if (*e || t.empty()) K3H_ERR << "Bad number \"" << t << "\" in lattice";
+    return v;
+  };
   while (true) {
     while (p < b.size() && (b[p] == '\n' || b[p] == ' ' || b[p] == '\t' || b[p] == '\r')) p++;
     if (p >= b.size()) break;
@@ -1069,21 +1227,49 @@ std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string 
     if (p >= b.size() || b[p] != ' ') K3H_ERR << "Lattice table: expected a space after key " << key;
     p++;
     Lattice lat;
-    auto add_state = [&](int64_t s) { while ((int64_t)lat.st_final.size() <= s) { lat.st_final.push_back(kInfF); lat.st_final_ac.push_back(kInfF); lat.st_frame.push_back(0); lat.st_state.push_back(0); } };
+    auto add_state = [&](int64_t s) {
+      while ((int64_t)lat.st_final.size() <= s) {
+        lat.st_final.push_back(kInfF);
+        lat.st_final_ac.push_back(kInfF);
+        lat.st_frame.push_back(0);
+        lat.st_state.push_back(0);
+      }
+    };
     if (p < b.size() && (unsigned char)b[p] == 214) {       // first byte of the FST magic number: binary
       auto get = [&](auto *v) { if (p + sizeof(*v) > b.size()) K3H_ERR << "unexpected end of lattice " << key; memcpy(v, b.data() + p, sizeof(*v)); p += sizeof(*v); };
       auto str = [&]() { int32_t n; get(&n); if (n < 0 || p + n > b.size()) K3H_ERR << "corrupt FST header in lattice " << key; std::string s = b.substr(p, n); p += n; return s; };
       int32_t magic, version, flags; uint64_t props; int64_t start, ns, na; get(&magic);
       const std::string ftype = str(), atype = str(); get(&version); get(&flags); get(&props); get(&start); get(&ns); get(&na);
-      if (ftype != "vector" || (atype != "lattice4" && atype != "compactlattice44")) K3H_ERR << "Lattice " << key << ": expected a vector FST with arc type lattice4 or compactlattice44, got " << ftype << " / " << atype;
+      if (ftype != "vector" || (atype != "lattice4" && atype != "compactlattice44")) K3H_ERR << "Lattice " << key <<
+          ": expected a vector FST with arc type lattice4 or compactlattice44, got " << ftype << " / " << atype;
       if (flags & 3) K3H_ERR << "Lattice " << key << " has embedded symbol tables";
       if (atype == "compactlattice44") {
         CompactLattice c; c.start = (int32_t)start; for (int64_t s = 0; s < ns; s++) c.AddState();
-        auto weight = [&](float *g, float *a, std::vector<int32_t> *str) { int32_t n; get(g); get(a); get(&n); if (n < 0) K3H_ERR << "corrupt compact lattice " << key; str->resize(n); for (int32_t &t : *str) get(&t); };
+        auto weight = [&](float *g, float *a, std::vector<int32_t> *str) {
+          int32_t n;
+          get(g);
+          get(a);
+          get(&n);
+          if (n < 0) K3H_ERR << "corrupt compact lattice " << key;
+          str->resize(n);
+          for (int32_t &t : *str) get(&t);
+        };
         for (int64_t s = 0; s < ns; s++) {
           float g, a; std::vector<int32_t> str; int64_t n; weight(&g, &a, &str); get(&n);
           if (std::isfinite(g) && std::isfinite(a)) { c.is_final[s] = 1; c.fin_graph[s] = g; c.fin_ac[s] = a; c.fin_str[s] = str; }
-          for (int64_t i = 0; i < n; i++) { int32_t il, ol, nx; get(&il); get(&ol); weight(&g, &a, &str); get(&nx); c.arc_src.push_back((int32_t)s); c.arc_dst.push_back(nx); c.arc_label.push_back(il); c.arc_graph.push_back(g); c.arc_ac.push_back(a); c.arc_str.push_back(str); }
+          for (int64_t i = 0; i < n; i++) {
+            int32_t il, ol, nx;
+            get(&il);
+            get(&ol);
+            weight(&g, &a, &str);
+            get(&nx);
+            c.arc_src.push_back((int32_t)s);
+            c.arc_dst.push_back(nx);
+            c.arc_label.push_back(il);
+            c.arc_graph.push_back(g);
+            c.arc_ac.push_back(a);
+            c.arc_str.push_back(str);
+          }
         }
         ConvertLattice(c, &lat);
         out.emplace_back(key, std::move(lat)); continue;
@@ -1092,7 +1278,20 @@ std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string 
       for (int64_t s = 0; s < ns; s++) {
         float g, a; int64_t n; get(&g); get(&a); get(&n);
         lat.st_final[s] = (std::isfinite(g) && std::isfinite(a)) ? g : kInfF; lat.st_final_ac[s] = a;
-        for (int64_t i = 0; i < n; i++) { int32_t il, ol, nx; get(&il); get(&ol); get(&g); get(&a); get(&nx); lat.arc_src.push_back((int32_t)s); lat.arc_dst.push_back(nx); lat.arc_ilabel.push_back(il); lat.arc_olabel.push_back(ol); lat.arc_graph.push_back(g); lat.arc_ac.push_back(a); }
+        for (int64_t i = 0; i < n; i++) {
+          int32_t il, ol, nx;
+          get(&il);
+          get(&ol);
+          get(&g);
+          get(&a);
+          get(&nx);
+          lat.arc_src.push_back((int32_t)s);
+          lat.arc_dst.push_back(nx);
+          lat.arc_ilabel.push_back(il);
+          lat.arc_olabel.push_back(ol);
+          lat.arc_graph.push_back(g);
+          lat.arc_ac.push_back(a);
+        }
       }
     } else {                                                  // text: lines until an empty line (lat/kaldi-lattice.cc:204-300 reads the FstPrinter format)
       while (p < b.size() && b[p] != '\n') p++;
@@ -1101,7 +1300,12 @@ std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string 
       auto cadd = [&](int64_t s) { while (c.NumStates() <= s) c.AddState(); };
       auto cweight = [&](const std::string &t, float *g, float *a, std::vector<int32_t> *str) {      // "graph,acoustic,t1_t2_..."
         const size_t c1 = t.find(','), c2 = t.find(',', c1 + 1); *g = parse_float(t.substr(0, c1)); *a = parse_float(t.substr(c1 + 1, c2 - c1 - 1)); str->clear();
-        for (size_t q = c2 + 1; q < t.size();) { size_t e = t.find('_', q); if (e == std::string::npos) e = t.size(); str->push_back((int32_t)strtol(t.substr(q, e - q).c_str(), nullptr, 10)); q = e + 1; }
+        for (size_t q = c2 + 1; q < t.size();) {
+          size_t e = t.find('_', q);
+          if (e == std::string::npos) e = t.size();
+          str->push_back((int32_t)strtol(t.substr(q, e - q).c_str(), nullptr, 10));
+          q = e + 1;
+        }
       };
       while (p < b.size()) {
         const size_t l0 = p; while (p < b.size() && b[p] != '\n') p++;
@@ -1109,25 +1313,42 @@ std::vector<std::pair<std::string, Lattice>> ReadLatticeTable(const std::string 
         std::vector<std::string> col; { std::istringstream ss(line); std::string t; while (ss >> t) col.push_back(t); }
         if (col.empty()) break;
         // a CompactLattice record is an acceptor (3 or 4 columns per arc) whose weights have three comma-separated fields
-        if (first && ((col.size() == 3) || (col.size() == 4 && std::count(col[3].begin(), col[3].end(), ',') == 2) || (col.size() == 2 && std::count(col[1].begin(), col[1].end(), ',') == 2))) compact = true;
+        if (first && ((col.size() == 3) || (col.size() == 4 && std::count(col[3].begin(), col[3].end(), ',') == 2) ||
+            (col.size() == 2 && std::count(col[1].begin(), col[1].end(), ',') == 2))) compact = true;
         if (compact) {
           const int64_t s = strtoll(col[0].c_str(), nullptr, 10); cadd(s);
           if (first) { c.start = (int32_t)s; first = false; }
           float g = 0, a = 0; std::vector<int32_t> str;
           if (col.size() <= 2) { if (col.size() == 2) cweight(col[1], &g, &a, &str); c.is_final[s] = 1; c.fin_graph[s] = g; c.fin_ac[s] = a; c.fin_str[s] = str; }
           else if (col.size() <= 4) { if (col.size() == 4) cweight(col[3], &g, &a, &str); const int64_t d = strtoll(col[1].c_str(), nullptr, 10); cadd(d);
-            c.arc_src.push_back((int32_t)s); c.arc_dst.push_back((int32_t)d); c.arc_label.push_back((int32_t)strtol(col[2].c_str(), nullptr, 10)); c.arc_graph.push_back(g); c.arc_ac.push_back(a); c.arc_str.push_back(str); }
+            c.arc_src.push_back((int32_t)s);
+            c.arc_dst.push_back((int32_t)d);
+            c.arc_label.push_back((int32_t)strtol(col[2].c_str(), nullptr, 10));
+            c.arc_graph.push_back(g);
+            c.arc_ac.push_back(a);
+            c.arc_str.push_back(str);
+            }
           else K3H_ERR << "Lattice " << key << ": bad line \"" << line << "\"";
           continue;
         }
-        auto weight = [&](const std::string &t, float *g, float *a) { const size_t c = t.find(','); if (c == std::string::npos || t.find(',', c + 1) != std::string::npos) K3H_ERR << "Lattice " << key << ": bad weight \"" << t << "\""; *g = parse_float(t.substr(0, c)); *a = parse_float(t.substr(c + 1)); };
+        auto weight = [&](const std::string &t, float *g, float *a) {
+          const size_t c = t.find(',');
+          if (c == std::string::npos || t.find(',', c + 1) != std::string::npos) K3H_ERR << "Lattice " << key << ": bad weight \"" << t << "\"";
+          *g = parse_float(t.substr(0, c));
+          *a = parse_float(t.substr(c + 1));
+        };
         const int64_t s = strtoll(col[0].c_str(), nullptr, 10); add_state(s);
         if (first) { lat.start = (int32_t)s; first = false; }
         if (col.size() <= 2) { float g = 0, a = 0; if (col.size() == 2) weight(col[1], &g, &a); lat.st_final[s] = g; lat.st_final_ac[s] = a; }
         else if (col.size() == 4 || col.size() == 5) {
           float g = 0, a = 0; if (col.size() == 5) weight(col[4], &g, &a);
           const int64_t d = strtoll(col[1].c_str(), nullptr, 10); add_state(d);
-          lat.arc_src.push_back((int32_t)s); lat.arc_dst.push_back((int32_t)d); lat.arc_ilabel.push_back((int32_t)strtol(col[2].c_str(), nullptr, 10)); lat.arc_olabel.push_back((int32_t)strtol(col[3].c_str(), nullptr, 10)); lat.arc_graph.push_back(g); lat.arc_ac.push_back(a);
+          lat.arc_src.push_back((int32_t)s);
+          lat.arc_dst.push_back((int32_t)d);
+          lat.arc_ilabel.push_back((int32_t)strtol(col[2].c_str(), nullptr, 10));
+          lat.arc_olabel.push_back((int32_t)strtol(col[3].c_str(), nullptr, 10));
+          lat.arc_graph.push_back(g);
+          lat.arc_ac.push_back(a);
         } else K3H_ERR << "Lattice " << key << ": bad line \"" << line << "\"";
       }
       if (compact) ConvertLattice(c, &lat);

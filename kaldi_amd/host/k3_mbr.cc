@@ -5,7 +5,8 @@
 //                         PrepareLatticeAndInitStats :320-363 (CreateSuperFinal fstext/pre-determinize-inl.h:689-724, CompactLatticeStateTimes
 //                         lat/lattice-functions.cc:109-147), first hypothesis = the lattice's best path (:377-395)
 //   WordAlignLattice      lat/word-align-lattice.{h,cc} (round 5): the lattice re-cut so that every arc is one word / silence with exactly its transition-ids -- what the post-processor
-//                         does in front of MBR when its config names --word-boundary-rxfilename; pinned to the reference's own source (oracle/_ref/bin/ref-word-align, tests/test_word_align.py)
+// does in front of MBR when its config names --word-boundary-rxfilename; pinned to the reference's own source (oracle/_ref/bin/ref-word-align,
+// tests/test_word_align.py)
 //   LatticePostprocessor  cudadecoder/lattice-postprocessor.{h,cc}: ScaleLattice (fstext/lattice-utils-inl.h:197-219), AddWordInsPenToCompactLattice
 //                         (lat/lattice-functions.cc:1342-1363), MBR -> CTMResult {words, (begin, end) in seconds, confidences}
 //   WriteCtm              MergeSegmentsToCTMOutput of one un-segmented utterance (cudadecoder/cuda-pipeline-common.cc:67-142)
@@ -29,13 +30,21 @@ inline double LogAdd(double x, double y) {      // base/kaldi-math.h:177-193
   return x;
 }
 inline void AddToMap(int32_t i, double d, std::map<int32_t, double> *m) { if (d == 0) return; auto r = m->insert({i, d}); if (!r.second) r.first->second += d; }
-struct Dense { int32_t cols = 0; std::vector<double> v; Dense(int32_t r, int32_t c) : cols(c), v((size_t)r * c, 0.0) {} double &operator()(int32_t r, int32_t c) { return v[(size_t)r * cols + c]; } };
+struct Dense {
+  int32_t cols = 0;
+  std::vector<double> v;
+  Dense(int32_t r, int32_t c) : cols(c), v((size_t)r * c, 0.0) {} double &operator()(int32_t r, int32_t c) {
+    return v[(size_t)r * cols + c];
+  }
+};
 }  // namespace
 
 struct MinimumBayesRisk::Impl {
   struct Arc { int32_t word, start_node, end_node; float loglike; };
   MinimumBayesRiskOptions opts; std::vector<Arc> arcs; std::vector<std::vector<int32_t>> pre; std::vector<int32_t> state_times; std::vector<int32_t> R; double L = 0.0;
-  std::vector<std::vector<std::pair<int32_t, float>>> gamma; std::vector<std::vector<std::pair<float, float>>> times; std::vector<std::pair<float, float>> sausage_times, one_best_times;
+  std::vector<std::vector<std::pair<int32_t, float>>> gamma;
+  std::vector<std::vector<std::pair<float, float>>> times;
+  std::vector<std::pair<float, float>> sausage_times, one_best_times;
   std::vector<float> one_best_conf;
   static double delta() { return 1.0e-05f; }      // (BaseFloat in the reference)
   static double l(int32_t a, int32_t b, bool penalize = false) { return a == b ? 0.0 : (penalize ? 1.0 + delta() : 1.0); }
@@ -89,9 +98,17 @@ struct MinimumBayesRisk::Impl {
         for (int32_t q = Q; q >= 1; q--) {
           beta_dash_arc[q] += w * beta_dash(n, q);
           switch (b_arc[q]) {
-            case 1: beta_dash(s_a, q - 1) += beta_dash_arc[q]; AddToMap(w_a, beta_dash_arc[q], &gam[q]); AddToMap(w_a, state_times[s_a] * beta_dash_arc[q], &tau_b[q]); AddToMap(w_a, state_times[n] * beta_dash_arc[q], &tau_e[q]); break;
+            case 1: beta_dash(s_a, q - 1) += beta_dash_arc[q];
+            AddToMap(w_a, beta_dash_arc[q], &gam[q]);
+            AddToMap(w_a, state_times[s_a] * beta_dash_arc[q], &tau_b[q]);
+            AddToMap(w_a, state_times[n] * beta_dash_arc[q], &tau_e[q]);
+            break;
             case 2: beta_dash(s_a, q) += beta_dash_arc[q]; break;
-            default: beta_dash_arc[q - 1] += beta_dash_arc[q]; AddToMap(0, beta_dash_arc[q], &gam[q]); AddToMap(0, state_times[n] * beta_dash_arc[q], &tau_b[q]); AddToMap(0, state_times[n] * beta_dash_arc[q], &tau_e[q]); break;
+            default: beta_dash_arc[q - 1] += beta_dash_arc[q];
+            AddToMap(0, beta_dash_arc[q], &gam[q]);
+            AddToMap(0, state_times[n] * beta_dash_arc[q], &tau_b[q]);
+            AddToMap(0, state_times[n] * beta_dash_arc[q], &tau_e[q]);
+            break;
           }
         }
         beta_dash_arc[0] += w * beta_dash(n, 0);
@@ -106,14 +123,17 @@ struct MinimumBayesRisk::Impl {
     gamma.assign(Q, {}); times.assign(Q, {}); sausage_times.assign(Q, {0.0f, 0.0f});
     for (int32_t q = 1; q <= Q; q++) {
       for (const auto &kv : gam[q]) gamma[q - 1].push_back({kv.first, (float)kv.second});
-      std::sort(gamma[q - 1].begin(), gamma[q - 1].end(), [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) { return a.second > b.second || (a.second == b.second && a.first > b.first); });
+      std::sort(gamma[q - 1].begin(), gamma[q - 1].end(),
+          [](const std::pair<int32_t, float> &a, const std::pair<int32_t,
+          float> &b) { return a.second > b.second || (a.second == b.second && a.first > b.first); });
       double t_b = 0.0, t_e = 0.0;
       for (const auto &g : gamma[q - 1]) {
         const double w_b = tau_b[q][g.first], w_e = tau_e[q][g.first];
         times[q - 1].push_back({(float)(w_b / g.second), (float)(w_e / g.second)}); t_b += w_b; t_e += w_e;
       }
       sausage_times[q - 1] = {(float)t_b, (float)t_e};
-      if (q > 1 && sausage_times[q - 2].second > sausage_times[q - 1].first) sausage_times[q - 2].second = sausage_times[q - 1].first = 0.5f * (sausage_times[q - 2].second + sausage_times[q - 1].first);
+      if (q > 1 && sausage_times[q - 2].second > sausage_times[q - 1].first) sausage_times[q - 2].second = sausage_times[q - 1].first =
+          0.5f * (sausage_times[q - 2].second + sausage_times[q - 1].first);
     }
   }
   void MbrDecode() {
@@ -133,7 +153,8 @@ struct MinimumBayesRisk::Impl {
           const size_t i = one_best_times.size();
           if (i > 1 && one_best_times[i - 2].second > one_best_times[i - 1].first) {      // overlapping words: the available interval is shared out
             const float prev_right = i > 2 ? one_best_times[i - 3].second : 0.0f;
-            const float left = std::max(prev_right, std::min(one_best_times[i - 2].first, one_best_times[i - 1].first)), right = std::max(one_best_times[i - 2].second, one_best_times[i - 1].second);
+            const float left = std::max(prev_right, std::min(one_best_times[i - 2].first, one_best_times[i - 1].first)),
+                right = std::max(one_best_times[i - 2].second, one_best_times[i - 1].second);
             const float first_dur = one_best_times[i - 2].second - one_best_times[i - 2].first, second_dur = one_best_times[i - 1].second - one_best_times[i - 1].first;
             const float mid = first_dur > 0 ? left + (right - left) * first_dur / (first_dur + second_dur) : left;
             one_best_times[i - 2].first = left; one_best_times[i - 2].second = one_best_times[i - 1].first = mid; one_best_times[i - 1].second = right;
@@ -164,12 +185,19 @@ MinimumBayesRisk::MinimumBayesRisk(const CompactLattice &clat_in, MinimumBayesRi
     if (!done) {
       const int32_t fs = clat.AddState(); clat.is_final[fs] = 1;
       for (int32_t s : finals) {
-        clat.arc_src.push_back(s); clat.arc_dst.push_back(fs); clat.arc_label.push_back(0); clat.arc_graph.push_back(clat.fin_graph[s]); clat.arc_ac.push_back(clat.fin_ac[s]); clat.arc_str.push_back(clat.fin_str[s]);
+        clat.arc_src.push_back(s);
+        clat.arc_dst.push_back(fs);
+        clat.arc_label.push_back(0);
+        clat.arc_graph.push_back(clat.fin_graph[s]);
+        clat.arc_ac.push_back(clat.fin_ac[s]);
+        clat.arc_str.push_back(clat.fin_str[s]);
         clat.is_final[s] = 0; clat.fin_graph[s] = 0; clat.fin_ac[s] = 0; clat.fin_str[s].clear();
       }
     }
   }
-  {      // fst::TopSort when the lattice is not known to be sorted (fst/topsort.h: depth-first from the start state, then from every state not reached yet; new numbers = reverse finishing order)
+  // fst::TopSort when the lattice is not known to be sorted (fst/topsort.h: depth-first from the start state, then from every state not reached yet; new
+  // numbers = reverse finishing order)
+  {
     bool sorted = clat.start == 0;
     for (size_t a = 0; a < clat.arc_src.size() && sorted; a++) sorted = clat.arc_dst[a] > clat.arc_src[a];
     if (!sorted) {
@@ -179,7 +207,14 @@ MinimumBayesRisk::MinimumBayesRisk(const CompactLattice &clat_in, MinimumBayesRi
         stack.push_back(root); color[root] = 1;
         while (!stack.empty()) {
           const int32_t u = stack.back();
-          if (pos[u] < nx[u].size()) { const int32_t d = nx[u][pos[u]++]; if (color[d] == 1) K3H_ERR << "Cycles detected in lattice."; if (color[d] == 0) { color[d] = 1; stack.push_back(d); } }
+          if (pos[u] < nx[u].size()) {
+            const int32_t d = nx[u][pos[u]++];
+            if (color[d] == 1) K3H_ERR << "Cycles detected in lattice.";
+            if (color[d] == 0) {
+              color[d] = 1;
+              stack.push_back(d);
+            }
+          }
           else { color[u] = 2; finish.push_back(u); stack.pop_back(); }
         }
       };
@@ -187,10 +222,23 @@ MinimumBayesRisk::MinimumBayesRisk(const CompactLattice &clat_in, MinimumBayesRi
       for (int32_t u = 0; u < n; u++) if (color[u] == 0) visit(u);
       std::vector<int32_t> newid(n); for (int32_t i = 0; i < n; i++) newid[finish[n - 1 - i]] = i;
       CompactLattice o; o.start = newid[clat.start]; o.is_final.assign(n, 0); o.fin_graph.assign(n, 0); o.fin_ac.assign(n, 0); o.fin_str.assign(n, {});
-      for (int32_t u = 0; u < n; u++) { const int32_t v = newid[u]; o.is_final[v] = clat.is_final[u]; o.fin_graph[v] = clat.fin_graph[u]; o.fin_ac[v] = clat.fin_ac[u]; o.fin_str[v] = clat.fin_str[u]; }
+      for (int32_t u = 0; u < n; u++) {
+        const int32_t v = newid[u];
+        o.is_final[v] = clat.is_final[u];
+        o.fin_graph[v] = clat.fin_graph[u];
+        o.fin_ac[v] = clat.fin_ac[u];
+        o.fin_str[v] = clat.fin_str[u];
+      }
       // arcs keep their order inside a state; states in new order
       std::vector<std::vector<int32_t>> by(n); for (size_t a = 0; a < clat.arc_src.size(); a++) by[newid[clat.arc_src[a]]].push_back((int32_t)a);
-      for (int32_t v = 0; v < n; v++) for (int32_t a : by[v]) { o.arc_src.push_back(v); o.arc_dst.push_back(newid[clat.arc_dst[a]]); o.arc_label.push_back(clat.arc_label[a]); o.arc_graph.push_back(clat.arc_graph[a]); o.arc_ac.push_back(clat.arc_ac[a]); o.arc_str.push_back(clat.arc_str[a]); }
+      for (int32_t v = 0; v < n; v++) for (int32_t a : by[v]) {
+        o.arc_src.push_back(v);
+        o.arc_dst.push_back(newid[clat.arc_dst[a]]);
+        o.arc_label.push_back(clat.arc_label[a]);
+        o.arc_graph.push_back(clat.arc_graph[a]);
+        o.arc_ac.push_back(clat.arc_ac[a]);
+        o.arc_str.push_back(clat.arc_str[a]);
+      }
       clat = std::move(o);
     }
   }
@@ -199,7 +247,11 @@ MinimumBayesRisk::MinimumBayesRisk(const CompactLattice &clat_in, MinimumBayesRi
   // arcs grouped by source state in stored order; CompactLatticeStateTimes
   std::vector<std::vector<int32_t>> out(N); for (size_t a = 0; a < clat.arc_src.size(); a++) out[clat.arc_src[a]].push_back((int32_t)a);
   std::vector<int32_t> t(N, -1); t[0] = 0;
-  for (int32_t s = 0; s < N; s++) for (int32_t a : out[s]) { const int32_t d = clat.arc_dst[a], len = (int32_t)clat.arc_str[a].size(); if (t[d] == -1) t[d] = t[s] + len; else if (t[d] != t[s] + len) K3H_ERR << "MinimumBayesRisk: inconsistent state times in the lattice"; }
+  for (int32_t s = 0; s < N; s++) for (int32_t a : out[s]) {
+    const int32_t d = clat.arc_dst[a], len = (int32_t)clat.arc_str[a].size();
+    if (t[d] == -1) t[d] = t[s] + len;
+    else if (t[d] != t[s] + len) K3H_ERR << "MinimumBayesRisk: inconsistent state times in the lattice";
+  }
   m.state_times.assign(N + 1, 0); for (int32_t s = 0; s < N; s++) m.state_times[s + 1] = t[s];
   m.pre.assign(N + 1, {});
   for (int32_t n = 1; n <= N; n++) for (int32_t a : out[n - 1]) {
@@ -209,7 +261,14 @@ MinimumBayesRisk::MinimumBayesRisk(const CompactLattice &clat_in, MinimumBayesRi
   // first hypothesis: the words of the best path (ShortestPath over the lattice as a tropical FST, weights graph + acoustic in float)
   {
     std::vector<float> best(N, std::numeric_limits<float>::infinity()); std::vector<int32_t> back(N, -1); best[0] = 0.0f;
-    for (int32_t s = 0; s < N; s++) if (best[s] < std::numeric_limits<float>::infinity()) for (int32_t a : out[s]) { const float c = best[s] + (clat.arc_graph[a] + clat.arc_ac[a]); const int32_t d = clat.arc_dst[a]; if (c < best[d]) { best[d] = c; back[d] = a; } }
+    for (int32_t s = 0; s < N; s++) if (best[s] < std::numeric_limits<float>::infinity()) for (int32_t a : out[s]) {
+      const float c = best[s] + (clat.arc_graph[a] + clat.arc_ac[a]);
+      const int32_t d = clat.arc_dst[a];
+      if (c < best[d]) {
+        best[d] = c;
+        back[d] = a;
+      }
+    }
     std::vector<int32_t> words; int32_t s = N - 1;      // the super-final state is the last one of the sorted lattice
     for (int32_t f = 0; f < N; f++) if (clat.is_final[f]) s = f;
     while (s != 0 && back[s] >= 0) { const int32_t a = back[s]; if (clat.arc_label[a] != 0) words.push_back(clat.arc_label[a]); s = clat.arc_src[a]; }
@@ -272,7 +331,10 @@ struct CompState {      // LatticeWordAligner::ComputationState (:30-128)
   bool IsEmpty() const { return tids.empty() && words.empty(); }
 };
 struct AlignCtx { const TransitionInfo &tm; const WordBoundaryInfo &info; bool *error;
-  int32_t Phone(int32_t tid) const { if (tid <= 0 || (size_t)tid >= tm.id2phone.size()) K3H_ERR << "WordAlignLattice: transition-id " << tid << " is not in the model"; return tm.id2phone[tid]; }
+  int32_t Phone(int32_t tid) const {
+    if (tid <= 0 || (size_t)tid >= tm.id2phone.size()) K3H_ERR << "WordAlignLattice: transition-id " << tid << " is not in the model";
+    return tm.id2phone[tid];
+  }
   bool Final(int32_t tid) const { return tm.is_final[tid] != 0; } bool SelfLoop(int32_t tid) const { return tm.self_loop[tid] != 0; } };
 
 bool OutputSilenceArc(CompState &c, const AlignCtx &x, WArc *out) {      // :349-393
@@ -282,7 +344,10 @@ bool OutputSilenceArc(CompState &c, const AlignCtx &x, WArc *out) {      // :349
   const size_t len = c.tids.size(); size_t i;
   for (i = 0; i < len; i++) {
     const int32_t tid = c.tids[i];
-    if (x.Phone(tid) != phone && !*x.error) { *x.error = true; K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]"; }
+    if (x.Phone(tid) != phone && !*x.error) {
+      *x.error = true;
+      K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]";
+    }
     if (x.Final(tid)) break;
   }
   if (i == len) return false;
@@ -328,19 +393,28 @@ bool OutputNormalWordArc(CompState &c, const AlignCtx &x, WArc *out) {      // :
   for (; i < len; i++) {
     const int32_t this_phone = x.Phone(c.tids[i]);
     if (x.info.TypeOfPhone(this_phone) == WordBoundaryInfo::kWordEndPhone) break;
-    if (x.info.TypeOfPhone(this_phone) != WordBoundaryInfo::kWordInternalPhone && !*x.error) { K3H_WARN << "Unexpected phone " << this_phone << " found inside a word."; *x.error = true; }
+    if (x.info.TypeOfPhone(this_phone) != WordBoundaryInfo::kWordInternalPhone && !*x.error) {
+      K3H_WARN << "Unexpected phone " << this_phone << " found inside a word.";
+      *x.error = true;
+    }
   }
   if (i == len) return false;
   const int32_t final_phone = x.Phone(c.tids[i]);
   for (; i < len; i++) {
-    if (x.Phone(c.tids[i]) != final_phone && !*x.error) { *x.error = true; K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]"; }
+    if (x.Phone(c.tids[i]) != final_phone && !*x.error) {
+      *x.error = true;
+      K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]";
+    }
     if (x.Final(c.tids[i])) break;
   }
   if (i == len) return false;
   i++;
   if (x.info.reorder) while (i < len && x.SelfLoop(c.tids[i])) i++;
   if (i == len) return false;
-  if (x.Phone(c.tids[i - 1]) != final_phone && !*x.error) { *x.error = true; K3H_WARN << "Phone changed while following final self-loop [broken lattice or mismatched model or wrong --reorder option?]"; }
+  if (x.Phone(c.tids[i - 1]) != final_phone && !*x.error) {
+    *x.error = true;
+    K3H_WARN << "Phone changed while following final self-loop [broken lattice or mismatched model or wrong --reorder option?]";
+  }
   const int32_t word = c.words[0];
   *out = WArc{word, -1, CW{c.weight, std::vector<int32_t>(c.tids.begin(), c.tids.begin() + i)}};
   c.tids.erase(c.tids.begin(), c.tids.begin() + i); c.words.erase(c.words.begin()); c.weight = LW();
@@ -383,7 +457,8 @@ void OutputArcForce(CompState &c, const AlignCtx &x, WArc *out) {      // :572-6
   } else K3H_ERR << "Code error, word-aligning lattice";
 }
 
-// fst::RmEpsilon(fst, connect = true) over the compact-lattice semiring, for the aligner's output (its epsilon arcs -- label 0 -- form no cycle): see third_party/minifst/fst/fstlib.h
+// fst::RmEpsilon(fst, connect = true) over the compact-lattice semiring, for the aligner's output (its epsilon arcs -- label 0 -- form no cycle): see
+// third_party/minifst/fst/fstlib.h
 // for the algorithm's statement; states that only epsilon arcs reach are dropped, every other state gets the non-epsilon arcs of its epsilon closure
 void RmEpsilonAndConnect(WFst *f) {
   const int32_t n = f->NumStates(); if (f->start < 0) return;
@@ -394,7 +469,25 @@ void RmEpsilonAndConnect(WFst *f) {
   if (top) for (int32_t s = 0; s < n; s++) order.push_back(s);
   else {
     std::vector<char> color(n, 0); std::vector<size_t> pos(n, 0); std::vector<int32_t> stack, finish;
-    auto visit = [&](int32_t root) { stack.push_back(root); color[root] = 1; while (!stack.empty()) { const int32_t s = stack.back(); if (pos[s] < f->arcs[s].size()) { const int32_t d = f->arcs[s][pos[s]++].next; if (color[d] == 1) K3H_ERR << "WordAlignLattice: cycle in the aligned lattice"; if (color[d] == 0) { color[d] = 1; stack.push_back(d); } } else { color[s] = 2; finish.push_back(s); stack.pop_back(); } } };
+    auto visit = [&](int32_t root) {
+      stack.push_back(root);
+      color[root] = 1;
+      while (!stack.empty()) {
+        const int32_t s = stack.back();
+        if (pos[s] < f->arcs[s].size()) {
+          const int32_t d = f->arcs[s][pos[s]++].next;
+          if (color[d] == 1) K3H_ERR << "WordAlignLattice: cycle in the aligned lattice";
+          if (color[d] == 0) {
+            color[d] = 1;
+            stack.push_back(d);
+          }
+        } else {
+          color[s] = 2;
+          finish.push_back(s);
+          stack.pop_back();
+        }
+      }
+    };
     visit(f->start); for (int32_t s = 0; s < n; s++) if (color[s] == 0) visit(s);
     order.assign(finish.rbegin(), finish.rend());
   }
@@ -442,7 +535,13 @@ void RmEpsilonAndConnect(WFst *f) {
   if (m == n) return;
   WFst g; if (m == 0 || newid[f->start] < 0) { *f = g; return; }
   g.arcs.resize(m); g.fin.resize(m); g.start = newid[f->start];
-  for (int32_t s = 0; s < n; s++) if (newid[s] >= 0) { g.fin[newid[s]] = f->fin[s]; for (WArc &a : f->arcs[s]) if (newid[a.next] >= 0) { a.next = newid[a.next]; g.arcs[newid[s]].push_back(std::move(a)); } }
+  for (int32_t s = 0; s < n; s++) if (newid[s] >= 0) {
+    g.fin[newid[s]] = f->fin[s];
+    for (WArc &a : f->arcs[s]) if (newid[a.next] >= 0) {
+      a.next = newid[a.next];
+      g.arcs[newid[s]].push_back(std::move(a));
+    }
+  }
   *f = std::move(g);
 }
 }  // namespace
@@ -470,15 +569,28 @@ WordBoundaryInfo ReadWordBoundaryInfo(const std::string &rxfilename, bool reorde
 
 bool WordAlignLattice(const CompactLattice &lat, const TransitionInfo &tmodel, const WordBoundaryInfo &info_in, int32_t max_states, CompactLattice *lat_out) {
   *lat_out = CompactLattice();
-  // ---- the input as per-state arc lists + CreateSuperFinal (fstext/pre-determinize-inl.h:689-724): one final state, weight One, reached by epsilon arcs with the old final weights
+  // ---- the input as per-state arc lists + CreateSuperFinal (fstext/pre-determinize-inl.h:689-724): one final state, weight One, reached by epsilon arcs with
+  // the old final weights
   WFst in; in.start = lat.start; const int32_t n0 = lat.NumStates();
   for (int32_t s = 0; s < n0; s++) { in.AddState(); if (lat.is_final[s]) in.fin[s] = CW{LW{lat.fin_graph[s], lat.fin_ac[s]}, lat.fin_str[s]}; }
   int32_t highest_label = 0;
-  for (size_t k = 0; k < lat.arc_src.size(); k++) { in.arcs[lat.arc_src[k]].push_back(WArc{lat.arc_label[k], lat.arc_dst[k], CW{LW{lat.arc_graph[k], lat.arc_ac[k]}, lat.arc_str[k]}}); highest_label = std::max(highest_label, lat.arc_label[k]); }
+  for (size_t k = 0; k < lat.arc_src.size(); k++) {
+    in.arcs[lat.arc_src[k]].push_back(WArc{lat.arc_label[k], lat.arc_dst[k], CW{LW{lat.arc_graph[k], lat.arc_ac[k]}, lat.arc_str[k]}});
+    highest_label = std::max(highest_label, lat.arc_label[k]);
+  }
   {
     bool idet = true, ieps = false;
-    for (int32_t s = 0; s < n0; s++) { std::vector<int32_t> l; for (const WArc &a : in.arcs[s]) { l.push_back(a.label); if (a.label == 0) ieps = true; } std::sort(l.begin(), l.end()); if (std::adjacent_find(l.begin(), l.end()) != l.end()) idet = false; }
-    if (!idet || ieps) K3H_WARN << "[Lattice has input epsilons and/or is not input-deterministic (in Mohri sense)]-- i.e. lattice is not deterministic.  Word-alignment may be slow and-or blow up in memory.";
+    for (int32_t s = 0; s < n0; s++) {
+      std::vector<int32_t> l;
+      for (const WArc &a : in.arcs[s]) {
+        l.push_back(a.label);
+        if (a.label == 0) ieps = true;
+      }
+      std::sort(l.begin(), l.end());
+      if (std::adjacent_find(l.begin(), l.end()) != l.end()) idet = false;
+    }
+    if (!idet || ieps) K3H_WARN <<
+        "[Lattice has input epsilons and/or is not input-deterministic (in Mohri sense)]-- i.e. lattice is not deterministic.  Word-alignment may be slow and-or blow up in memory.";
   }
   {
     std::vector<int32_t> finals; for (int32_t s = 0; s < n0; s++) if (!IsZero(in.fin[s].w)) finals.push_back(s);
@@ -496,18 +608,39 @@ bool WordAlignLattice(const CompactLattice &lat, const TransitionInfo &tmodel, c
   bool error = false; const AlignCtx ctx{tmodel, info, &error};
   WFst out;
   struct Tuple { int32_t state; CompState c; };
-  struct TupleHash { size_t operator()(const Tuple &t) const { size_t h = (size_t)t.state; for (int32_t v : t.c.tids) h = h * 7853 + (size_t)v; for (int32_t v : t.c.words) h = h * 90647 + (size_t)v; return h; } };
+  struct TupleHash {
+    size_t operator()(const Tuple &t) const {
+      size_t h = (size_t)t.state;
+      for (int32_t v : t.c.tids) h = h * 7853 + (size_t)v;
+      for (int32_t v : t.c.words) h = h * 90647 + (size_t)v;
+      return h;
+    }
+  };
   struct TupleEq { bool operator()(const Tuple &x, const Tuple &y) const { return x.state == y.state && x.c == y.c; } };
   std::unordered_map<Tuple, int32_t, TupleHash, TupleEq> map; std::vector<std::pair<Tuple, int32_t>> queue;
-  auto state_for = [&](const Tuple &t) { auto it = map.find(t); if (it != map.end()) return it->second; const int32_t o = out.AddState(); map.emplace(t, o); queue.push_back({t, o}); return o; };      // GetStateForTuple(.., true)
+  // GetStateForTuple(.., true)
+  auto state_for = [&](const Tuple &t) {
+    auto it = map.find(t);
+    if (it != map.end()) return it->second;
+    const int32_t o = out.AddState();
+    map.emplace(t, o);
+    queue.push_back({t, o});
+    return o;
+  };
   bool ok = true;
   if (in.start < 0) { K3H_WARN << "Trying to word-align empty lattice."; return false; }
   out.start = state_for(Tuple{in.start, CompState()});
   while (!queue.empty()) {
-    if (max_states > 0 && out.NumStates() > max_states) { K3H_WARN << "Number of states in lattice exceeded max-states of " << max_states << ", original lattice had " << in.NumStates() << " states.  Returning what we have."; ok = false; break; }
+    if (max_states > 0 && out.NumStates() > max_states) {
+      K3H_WARN << "Number of states in lattice exceeded max-states of " << max_states << ", original lattice had " << in.NumStates() <<
+          " states.  Returning what we have.";
+      ok = false;
+      break;
+    }
     Tuple tuple = std::move(queue.back().first); const int32_t ostate = queue.back().second; queue.pop_back();      // ProcessQueueElement (:204-248)
     WArc arc;
-    if (OutputNormalWordArc(tuple.c, ctx, &arc) || OutputSilenceArc(tuple.c, ctx, &arc) || OutputOnePhoneWordArc(tuple.c, ctx, &arc)) {      // something complete is pending: emit it before reading on
+    // something complete is pending: emit it before reading on
+    if (OutputNormalWordArc(tuple.c, ctx, &arc) || OutputSilenceArc(tuple.c, ctx, &arc) || OutputOnePhoneWordArc(tuple.c, ctx, &arc)) {
       arc.next = state_for(tuple); out.arcs[ostate].push_back(std::move(arc));
       continue;
     }
@@ -528,9 +661,22 @@ bool WordAlignLattice(const CompactLattice &lat, const TransitionInfo &tmodel, c
     if (info_in.silence_label == 0 && a.label == info.silence_label) a.label = 0;
   }
   lat_out->start = out.start;
-  for (int32_t s = 0; s < out.NumStates(); s++) { lat_out->AddState(); if (!IsZero(out.fin[s].w)) { lat_out->is_final[s] = 1; lat_out->fin_graph[s] = out.fin[s].w.g; lat_out->fin_ac[s] = out.fin[s].w.a; lat_out->fin_str[s] = out.fin[s].str; } }
+  for (int32_t s = 0; s < out.NumStates(); s++) {
+    lat_out->AddState();
+    if (!IsZero(out.fin[s].w)) {
+      lat_out->is_final[s] = 1;
+      lat_out->fin_graph[s] = out.fin[s].w.g;
+      lat_out->fin_ac[s] = out.fin[s].w.a;
+      lat_out->fin_str[s] = out.fin[s].str;
+    }
+  }
   for (int32_t s = 0; s < out.NumStates(); s++) for (WArc &a : out.arcs[s]) {
-    lat_out->arc_src.push_back(s); lat_out->arc_dst.push_back(a.next); lat_out->arc_label.push_back(a.label); lat_out->arc_graph.push_back(a.w.w.g); lat_out->arc_ac.push_back(a.w.w.a); lat_out->arc_str.push_back(std::move(a.w.str));
+    lat_out->arc_src.push_back(s);
+    lat_out->arc_dst.push_back(a.next);
+    lat_out->arc_label.push_back(a.label);
+    lat_out->arc_graph.push_back(a.w.w.g);
+    lat_out->arc_ac.push_back(a.w.w.a);
+    lat_out->arc_str.push_back(std::move(a.w.str));
   }
   return ok && !error;
 }
@@ -539,12 +685,14 @@ bool WordAlignLattice(const CompactLattice &lat, const TransitionInfo &tmodel, c
 void LatticePostprocessorConfig::Register(ParseOptions *po) {
   po->Register("max-expand", &max_expand, "If >0, the maximum amount by which this program will expand lattices before refusing to continue.");
   po->Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic likelihoods"); po->Register("lm-scale", &lm_scale, "Scaling factor for graph/lm costs");
-  po->Register("acoustic2lm-scale", &acoustic2lm_scale, "Add this times original acoustic costs to LM costs"); po->Register("lm2acoustic-scale", &lm2acoustic_scale, "Add this times original LM costs to acoustic costs");
+  po->Register("acoustic2lm-scale", &acoustic2lm_scale, "Add this times original acoustic costs to LM costs");
+  po->Register("lm2acoustic-scale", &lm2acoustic_scale, "Add this times original LM costs to acoustic costs");
   po->Register("word-ins-penalty", &word_ins_penalty, "Word insertion penalty."); po->Register("word-boundary-rxfilename", &word_boundary_rxfilename, "Word boundary file");
   po->Register("decode-mbr", &mbr_opts.decode_mbr, "If true, do Minimum Bayes Risk decoding (else, Maximum a Posteriori)");
   po->Register("print-silence", &mbr_opts.print_silence, "Keep the inter-word '<eps>' bins in the 1-best output (ctm, <eps> can be a 'silence' or a 'deleted' word)");
   po->Register("silence-label", &silence_label, "Numeric id of word symbol that is to be used for silence arcs in the word-aligned lattice (zero is OK)");
-  po->Register("partial-word-label", &partial_word_label, "Numeric id of word symbol that is to be used for arcs in the word-aligned lattice corresponding to partial words at the end of forced-out utterances (zero is OK)");
+  po->Register("partial-word-label", &partial_word_label,
+      "Numeric id of word symbol that is to be used for arcs in the word-aligned lattice corresponding to partial words at the end of forced-out utterances (zero is OK)");
   po->Register("reorder", &reorder, "True if the lattices were generated from graphs that had the --reorder option true");
 }
 LatticePostprocessor::LatticePostprocessor(const LatticePostprocessorConfig &config) : config_(config) {

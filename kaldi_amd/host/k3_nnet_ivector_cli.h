@@ -44,7 +44,8 @@ inline void RunNnetBatch(k3_nnet *nnet, const k3_nnet_info &ni, const std::vecto
       if (iv.per_utt && m.rows != 1) K3H_ERR << "--ivectors must be a table of vectors";
       iv_rows.push_back(m.rows); ivs.insert(ivs.end(), m.data.begin(), m.data.end());
     }
-    K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, U, nf.data(), subsampling, lp, acoustic_scale, frames_per_chunk, iv.online ? iv.period : 0, iv.online ? iv_rows.data() : nullptr, nb));
+    K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, U, nf.data(), subsampling, lp, acoustic_scale, frames_per_chunk, iv.online ? iv.period : 0,
+        iv.online ? iv_rows.data() : nullptr, nb));
   } else {
     if (iv.Any()) K3H_ERR << "Neural net expects 'ivector' features with dimension 0 but you provided " << (utt_iv.empty() || !utt_iv[0] ? 0 : utt_iv[0]->cols);
     K3H_CHECK_K3(k3_nnet_batch_create(nnet, U, nf.data(), subsampling, lp, acoustic_scale, nb));

@@ -15,10 +15,19 @@ namespace k3host {
 template <class T> struct DevBuf {          // grow-only device array
   T *p = nullptr; size_t cap = 0;
   ~DevBuf() { if (p) (void)hipFree(p); for (Stage &g : stage_) { if (g.p) (void)hipHostFree(g.p); if (g.ev) (void)hipEventDestroy(g.ev); } }
-  T *need(size_t n) { if (n > cap) { if (p) (void)hipFree(p); cap = n + n / 2 + 64; K3O_HIP(hipMalloc((void **)&p, cap * sizeof(T))); } return p; }      // (hipFree waits for the device: no kernel still reads the old block)
+  // (hipFree waits for the device: no kernel still reads the old block)
+  T *need(size_t n) {
+    if (n > cap) {
+      if (p) (void)hipFree(p);
+      cap = n + n / 2 + 64;
+      K3O_HIP(hipMalloc((void **)&p, cap * sizeof(T)));
+    }
+    return p;
+  }
   void upload(const std::vector<T> &h) { need(std::max<size_t>(h.size(), 1)); if (!h.empty()) K3O_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
   // The streaming path's form: the host never waits for the device.  begin_upload(n) hands out a page-locked staging block to fill (a ring of kStages blocks, each guarded by an
-  // event recorded behind its copy, so a block is only waited for when the host is kStages uploads ahead of the device); end_upload queues the copy on `st`, behind whatever on that
+  // event recorded behind its copy, so a block is only waited for when the host is kStages uploads ahead of the device); end_upload queues the copy on `st`,
+  // behind whatever on that
   // stream still reads the device block (every chunk round of the streaming programs paid ~10 blocking pageable copies on the null stream).
   T *begin_upload(size_t n) {
     Stage &g = stage_[seq_ % kStages];
@@ -33,7 +42,11 @@ template <class T> struct DevBuf {          // grow-only device array
     if (!g.ev) K3O_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
     K3O_HIP(hipEventRecord(g.ev, st)); g.used = true;
   }
-  void upload_async(const std::vector<T> &h, hipStream_t st) { T *dst = begin_upload(h.size()); if (!h.empty()) memcpy(dst, h.data(), h.size() * sizeof(T)); end_upload(h.size(), st); }
+  void upload_async(const std::vector<T> &h, hipStream_t st) {
+    T *dst = begin_upload(h.size());
+    if (!h.empty()) memcpy(dst, h.data(), h.size() * sizeof(T));
+    end_upload(h.size(), st);
+  }
  private:
   static constexpr int kStages = 4;
   struct Stage { T *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
@@ -48,7 +61,8 @@ template <class T> struct PinnedBuf {       // grow-only page-locked host array 
 
 class OnlineFeatures {
  public:
-  OnlineFeatures(k3_feat_plan *plan, const k3_feat_opts &o, int num_channels, hipStream_t stream = nullptr) : plan_(plan), dim_(k3_feat_dim(plan)), stash_(num_channels), stream_(stream) {
+  OnlineFeatures(k3_feat_plan *plan, const k3_feat_opts &o, int num_channels, hipStream_t stream = nullptr) : plan_(plan), dim_(k3_feat_dim(plan)),
+      stash_(num_channels), stream_(stream) {
     if (!o.snip_edges) K3H_ERR << "streaming features need --snip-edges=true";
     shift_ = (int)(o.samp_freq * 0.001 * o.frame_shift_ms);
   }
@@ -102,12 +116,24 @@ class StaticNnet3 {
     if (C_ <= 0 || C_ % s_) K3H_ERR << "--frames-per-chunk must be a positive multiple of --frame-subsampling-factor";
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
     if (ni.ivector_dim == 0 && !getenv("K3_ONLINE_RECOMPUTE_CONTEXT") && k3_nnet_stream_create(nnet, nch_, C_, s_, log_priors, acoustic_scale, &inc_) == K3_OK) {
-      k3_nnet_stream_info si; K3H_CHECK_K3(k3_nnet_stream_get_info(inc_, &si)); dim_ = ni.input_dim; odim_ = ni.output_dim; Rc_ = si.right_context; n_out_ = si.output_rows_per_pass; first_out_ = si.first_output_time;
+      k3_nnet_stream_info si;
+      K3H_CHECK_K3(k3_nnet_stream_get_info(inc_, &si));
+      dim_ = ni.input_dim;
+      odim_ = ni.output_dim;
+      Rc_ = si.right_context;
+      n_out_ = si.output_rows_per_pass;
+      first_out_ = si.first_output_time;
       out_.need((size_t)n_out_ * nch_ * odim_); out2_.need((size_t)n_out_ * nch_ * odim_); passes_.assign(nch_, 0); total_.assign(nch_, 0); ended_.assign(nch_, 0);
       return;
     }
     inc_ = nullptr;      // (K3_ERR_UNSUPPORTED: the model needs the chunk + context scheme)
-    dim_ = ni.input_dim; odim_ = ni.output_dim; Lc_ = (ni.left_context + s_ - 1) / s_ * s_; Rc_ = ni.right_context; P_ = Lc_ + C_ + Rc_; rps_ = (P_ + s_ - 1) / s_; S_ = Lc_ + Rc_ + C_ + 2 * s_;
+    dim_ = ni.input_dim;
+    odim_ = ni.output_dim;
+    Lc_ = (ni.left_context + s_ - 1) / s_ * s_;
+    Rc_ = ni.right_context;
+    P_ = Lc_ + C_ + Rc_;
+    rps_ = (P_ + s_ - 1) / s_;
+    S_ = Lc_ + Rc_ + C_ + 2 * s_;
     std::vector<int32_t> nf(B_, P_); ivdim_ = ni.ivector_dim;
     // models with the recipes' i-vector input: every slot is an "utterance" with ONE i-vector (the --ivectors form of the planner), handed in per pass
     if (ivdim_ > 0) { K3H_CHECK_K3(k3_nnet_batch_create_ivector(nnet, B_, nf.data(), s_, log_priors, acoustic_scale, C_, 0, nullptr, &batch_)); iv_.need((size_t)B_ * ivdim_); }
@@ -123,7 +149,8 @@ class StaticNnet3 {
   void Reset(int ch) { if (inc_) { passes_[ch] = 0; total_[ch] = 0; ended_[ch] = 0; return; } t_next_[ch] = n_seen_[ch] = lo_[ch] = 0; }
   // One planned forward.  d_new: the new frames of the slots back to back (n_new[i] rows each, may be null when all are 0).  Returns per
   // slot (first row, count) of its valid output rows in Out().
-  // d_iv (models with an i-vector input): [channels.size() x IvectorDim()] on the device, the i-vector each slot's chunk is evaluated with (decodable-online-looped.cc:166-205: one per chunk)
+  // d_iv (models with an i-vector input): [channels.size() x IvectorDim()] on the device, the i-vector each slot's chunk is evaluated with
+  // (decodable-online-looped.cc:166-205: one per chunk)
   std::vector<Rows> Pass(const std::vector<int> &channels, const float *d_new, const std::vector<int> &n_new, const std::vector<char> &last, const float *d_iv = nullptr) {
     if ((ivdim_ > 0) != (d_iv != nullptr)) K3H_ERR << "StaticNnet3::Pass: the model " << (ivdim_ > 0 ? "has" : "has no") << " i-vector input";
     if (inc_) return PassStateful(channels, d_new, n_new, last);
@@ -137,8 +164,14 @@ class StaticNnet3 {
       if (last[i]) count = avail > tn ? (avail - tn + s_ - 1) / s_ : 0;
       else if (avail - 1 - Rc_ - tn >= 0) count = (avail - 1 - Rc_ - tn) / s_ + 1;
       count = std::min<int64_t>(count, C_ / s_);
-      auto source = [&](int64_t tau, int32_t *st, int32_t *nw) { if (tau >= n_seen_[ch]) *nw = (int32_t)(noff + tau - n_seen_[ch]); else *st = (int32_t)(ch * S_ + tau - lo_[ch]); };
-      if (avail > 0) for (int k = 0; k < P_; k++) { const int64_t tau = std::min<int64_t>(std::max<int64_t>(tn - Lc_ + k, 0), avail - 1); source(tau, &ist[i * P_ + k], &inw[i * P_ + k]); }
+      auto source = [&](int64_t tau, int32_t *st, int32_t *nw) {
+        if (tau >= n_seen_[ch]) *nw = (int32_t)(noff + tau - n_seen_[ch]);
+        else *st = (int32_t)(ch * S_ + tau - lo_[ch]);
+      };
+      if (avail > 0) for (int k = 0; k < P_; k++) {
+        const int64_t tau = std::min<int64_t>(std::max<int64_t>(tn - Lc_ + k, 0), avail - 1);
+        source(tau, &ist[i * P_ + k], &inw[i * P_ + k]);
+      }
       res.push_back({(int)(i * rps_ + Lc_ / s_), (int)count, 1});
       const int64_t tn2 = tn + count * s_, lo2 = std::max<int64_t>(0, tn2 - Lc_);
       if (avail - lo2 > S_) K3H_ERR << "internal: context stash capacity";
@@ -146,14 +179,19 @@ class StaticNnet3 {
       t_next_[ch] = tn2; n_seen_[ch] = avail; lo_[ch] = lo2; noff += n_new[i];
     }
     float *A = stash_[cur_].p, *Bn = stash_[cur_ ^ 1].p;
-    i0_.upload_async(ist, stream_); i1_.upload_async(inw, stream_); i2_.upload_async(ust, stream_); i3_.upload_async(unw, stream_);      // (page-locked rings: the host does not wait)
+    // (page-locked rings: the host does not wait)
+    i0_.upload_async(ist, stream_);
+    i1_.upload_async(inw, stream_);
+    i2_.upload_async(ust, stream_);
+    i3_.upload_async(unw, stream_);
     K3H_CHECK_K3(k3_mat_copy_rows(inp_.p, dim_, B_ * P_, dim_, A, dim_, i0_.p, stream_));
     if (total_new > 0) K3H_CHECK_K3(k3_mat_add_rows(1.0f, d_new, dim_, i1_.p, inp_.p, dim_, B_ * P_, dim_, stream_));
     K3H_CHECK_K3(k3_mat_copy_rows(Bn, dim_, nch_ * S_, dim_, A, dim_, i2_.p, stream_));
     if (total_new > 0) K3H_CHECK_K3(k3_mat_add_rows(1.0f, d_new, dim_, i3_.p, Bn, dim_, nch_ * S_, dim_, stream_));
     cur_ ^= 1;
     if (ivdim_ > 0) {
-      K3O_HIP(hipMemsetAsync(iv_.p, 0, (size_t)B_ * ivdim_ * 4, stream_)); K3O_HIP(hipMemcpyAsync(iv_.p, d_iv, channels.size() * (size_t)ivdim_ * 4, hipMemcpyDeviceToDevice, stream_));
+      K3O_HIP(hipMemsetAsync(iv_.p, 0, (size_t)B_ * ivdim_ * 4, stream_));
+      K3O_HIP(hipMemcpyAsync(iv_.p, d_iv, channels.size() * (size_t)ivdim_ * 4, hipMemcpyDeviceToDevice, stream_));
       K3H_CHECK_K3(k3_nnet_forward_ivector(batch_, inp_.p, dim_, iv_.p, ivdim_, (which_ ? out2_ : out_).p, odim_, stream_));
     } else K3H_CHECK_K3(k3_nnet_forward(batch_, inp_.p, dim_, (which_ ? out2_ : out_).p, odim_, stream_));
     return res;
@@ -177,9 +215,18 @@ class StaticNnet3 {
     std::vector<int64_t> start(nch_, 0); std::vector<int32_t> count(nch_, -1), fresh, fresh_row; int64_t noff = 0;
     for (size_t i = 0; i < channels.size(); i++) {
       const int ch = channels[i];
-      if (n_new[i] != C_ && !last[i]) K3H_ERR << "StaticNnet3::Pass: the stateful engine takes whole chunks of " << C_ << " frames (got " << n_new[i] << " before the end of the stream)";
+      if (n_new[i] != C_ && !last[i]) K3H_ERR << "StaticNnet3::Pass: the stateful engine takes whole chunks of " << C_ << " frames (got " << n_new[i] <<
+          " before the end of the stream)";
       if (ended_[ch] && n_new[i] > 0) K3H_ERR << "StaticNnet3::Pass: frames for a stream that has ended";
-      if (passes_[ch] == 0 && total_[ch] == 0) { if (n_new[i] == 0) { count[ch] = -1; continue; } fresh.push_back(ch); fresh_row.push_back((int32_t)noff); }      // (an empty stream: nothing to evaluate)
+      // (an empty stream: nothing to evaluate)
+      if (passes_[ch] == 0 && total_[ch] == 0) {
+        if (n_new[i] == 0) {
+          count[ch] = -1;
+          continue;
+        }
+        fresh.push_back(ch);
+        fresh_row.push_back((int32_t)noff);
+      }
       start[ch] = noff; count[ch] = n_new[i]; noff += n_new[i];
     }
     if (!fresh.empty()) {
@@ -210,19 +257,37 @@ class StaticNnet3 {
 // The i-vector extractor of an --ivector-extraction-config (OnlineNnet2FeaturePipelineInfo's ivector_extractor_info, online2/online-nnet2-feature-pipeline.cc:70-80) on the GPU
 inline k3_ivector *CreateIvectorExtractor(const IvectorExtractionInfo &iv_info, int fdim) {
   k3_ivector_model m; memset(&m, 0, sizeof m);
-  m.feat_dim = iv_info.global_cmvn_stats.cols - 1; m.lda_rows = iv_info.lda_rows; m.lda_cols = iv_info.lda_cols; m.num_gauss = iv_info.ubm.num_gauss; m.ivector_dim = iv_info.ie.ivector_dim;
-  m.lda = iv_info.lda.data(); m.global_cmvn_stats = iv_info.global_cmvn_stats.data.data(); m.gconsts = iv_info.ubm.gconsts.data(); m.means_invvars = iv_info.ubm.means_invvars.data(); m.inv_vars = iv_info.ubm.inv_vars.data();
+  m.feat_dim = iv_info.global_cmvn_stats.cols - 1;
+  m.lda_rows = iv_info.lda_rows;
+  m.lda_cols = iv_info.lda_cols;
+  m.num_gauss = iv_info.ubm.num_gauss;
+  m.ivector_dim = iv_info.ie.ivector_dim;
+  m.lda = iv_info.lda.data();
+  m.global_cmvn_stats = iv_info.global_cmvn_stats.data.data();
+  m.gconsts = iv_info.ubm.gconsts.data();
+  m.means_invvars = iv_info.ubm.means_invvars.data();
+  m.inv_vars = iv_info.ubm.inv_vars.data();
   m.M = iv_info.ie.M.data(); m.sigma_inv = iv_info.ie.sigma_inv.data(); m.prior_offset = iv_info.ie.prior_offset;
   k3_ivector_opts o; k3_ivector_opts_default(&o);
-  o.left_context = iv_info.left_context; o.right_context = iv_info.right_context; o.num_gselect = iv_info.num_gselect; o.min_post = iv_info.min_post; o.posterior_scale = iv_info.posterior_scale; o.max_count = iv_info.max_count;
+  o.left_context = iv_info.left_context;
+  o.right_context = iv_info.right_context;
+  o.num_gselect = iv_info.num_gselect;
+  o.min_post = iv_info.min_post;
+  o.posterior_scale = iv_info.posterior_scale;
+  o.max_count = iv_info.max_count;
   o.ivector_period = iv_info.ivector_period; o.num_cg_iters = iv_info.num_cg_iters; o.online_cmvn_iextractor = iv_info.online_cmvn_iextractor;
-  o.cmvn.cmn_window = iv_info.cmn_window; o.cmvn.speaker_frames = iv_info.speaker_frames; o.cmvn.global_frames = iv_info.global_frames; o.cmvn.normalize_mean = iv_info.normalize_mean; o.cmvn.normalize_variance = iv_info.normalize_variance;
+  o.cmvn.cmn_window = iv_info.cmn_window;
+  o.cmvn.speaker_frames = iv_info.speaker_frames;
+  o.cmvn.global_frames = iv_info.global_frames;
+  o.cmvn.normalize_mean = iv_info.normalize_mean;
+  o.cmvn.normalize_variance = iv_info.normalize_variance;
   if (m.feat_dim != fdim) K3H_ERR << "The i-vector extractor expects features of dimension " << m.feat_dim << " but the feature config gives " << fdim;
   k3_ivector *ivx = nullptr; K3H_CHECK_K3(k3_ivector_create(&m, &o, &ivx));
   return ivx;
 }
 
-// Per-channel i-vectors of a stream, the C++ twin of kaldi_amd/online.py: the extractor sees every feature frame as soon as it exists; Latest() is the i-vector the reference's online
+// Per-channel i-vectors of a stream, the C++ twin of kaldi_amd/online.py: the extractor sees every feature frame as soon as it exists; Latest() is the i-vector
+// the reference's online
 // decodable hands the network for a chunk (nnet3/decodable-online-looped.cc:182-197 over OnlineIvectorFeature with use_most_recent_ivector): the estimate made at the last multiple
 // of --ivector-period among the frames ready (all frames so far minus the LDA splice's right context while the stream goes on), zero before the first.  One k3_ivector_stream per
 // channel carries the CMVN window, the splice context, the statistics and the solver's start between chunks: the estimates are, bit for bit, rows of the whole-utterance extraction
@@ -231,16 +296,23 @@ class OnlineIvectors {
  public:
   OnlineIvectors(k3_ivector *iv, int right_context, int nch, hipStream_t stream = nullptr) : iv_(iv), st_(nch, nullptr), stream_(stream) {
     (void)right_context;      // (the extractor's own option; kept in the signature for its callers)
-    k3_ivector_info i; K3H_CHECK_K3(k3_ivector_get_info(iv, &i)); F_ = i.feat_dim; R_ = i.ivector_dim; latest_.need((size_t)nch * R_); K3O_HIP(hipMemsetAsync(latest_.p, 0, (size_t)nch * R_ * 4, stream_));
+    k3_ivector_info i;
+    K3H_CHECK_K3(k3_ivector_get_info(iv, &i));
+    F_ = i.feat_dim;
+    R_ = i.ivector_dim;
+    latest_.need((size_t)nch * R_);
+    K3O_HIP(hipMemsetAsync(latest_.p, 0, (size_t)nch * R_ * 4, stream_));
     for (auto &s : st_) K3H_CHECK_K3(k3_ivector_stream_create(iv_, &s));
   }
   int Dim() const { return R_; }
   void Reset(int ch) { K3H_CHECK_K3(k3_ivector_stream_reset(st_[ch], stream_)); K3O_HIP(hipMemsetAsync(latest_.p + (size_t)ch * R_, 0, (size_t)R_ * 4, stream_)); }
   // n new feature rows of the channel (device, F_ wide, contiguous); finished: the stream's audio has ended.  Updates Row(ch).
   void Accept(int ch, const float *d_rows, int n, bool finished) {
-    K3H_CHECK_K3(k3_ivector_stream_accept(st_[ch], d_rows, F_, n, finished ? 1 : 0, nullptr, 0, 0, nullptr, latest_.p + (size_t)ch * R_, stream_));      // queued on the work stream, like its consumers
+    // queued on the work stream, like its consumers
+    K3H_CHECK_K3(k3_ivector_stream_accept(st_[ch], d_rows, F_, n, finished ? 1 : 0, nullptr, 0, 0, nullptr, latest_.p + (size_t)ch * R_, stream_));
   }
-  // the same for the channels of one batch, one launch per stage (k3_ivector_stream_accept_batch): channel channels[i] takes nf[i] rows of d_rows (back to back, F_ wide); first[i]: a
+  // the same for the channels of one batch, one launch per stage (k3_ivector_stream_accept_batch): channel channels[i] takes nf[i] rows of d_rows (back to
+  // back, F_ wide); first[i]: a
   // new stream takes the channel
   template <class B1, class B2> void AcceptBatch(const std::vector<int> &channels, const float *d_rows, const std::vector<int> &nf, const B1 &first, const B2 &last) {
     const size_t n = channels.size(); if (n == 0) return;

@@ -48,7 +48,8 @@ int main(int argc, char **argv) {
     }
     if (words_writer) words_writer->Flush();
     if (ali_writer) ali_writer->Flush();
-    K3H_LOG << "Overall cost per frame is " << ((tot_graph + tot_ac) / n_frame) << " = " << (tot_graph / n_frame) << " [graph] + " << (tot_ac / n_frame) << " [acoustic] over " << n_frame << " frames.";
+    K3H_LOG << "Overall cost per frame is " << ((tot_graph + tot_ac) / n_frame) << " = " << (tot_graph / n_frame) << " [graph] + " << (tot_ac / n_frame) <<
+        " [acoustic] over " << n_frame << " frames.";
     K3H_LOG << "Done " << n_done << " lattices, failed for " << n_fail;
     return n_done != 0 ? 0 : 1;
   } catch (const std::exception &e) { std::cerr << e.what() << "\n"; return -1; }

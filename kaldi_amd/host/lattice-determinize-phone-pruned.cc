@@ -44,7 +44,10 @@ int main(int argc, char **argv) {
       Lattice &lat = kv.second;
       ScaleAcoustic(&lat, acoustic_scale);
       CompactLattice clat;
-      if (!DeterminizeLatticePhonePruned(lat, trans, beam, &clat, opts)) { K3H_WARN << "For key " << kv.first << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; n_warn++; }
+      if (!DeterminizeLatticePhonePruned(lat, trans, beam, &clat, opts)) {
+        K3H_WARN << "For key " << kv.first << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)";
+        n_warn++;
+      }
       if (!TopSortIfNeeded(&clat)) K3H_WARN << "Topological sorting of the determinized lattice failed for key " << kv.first;
       ScaleAcoustic(&clat, 1.0 / acoustic_scale);
       writer.WriteCompactLattice(kv.first, clat);

@@ -26,7 +26,8 @@ int main(int argc, char **argv) {
     po.Register("max-arcs", &opts.max_arcs, "Maximum number of arcs in output FST (total, not per state");
     po.Register("max-states", &opts.max_states, "Maximum number of arcs in output FST (total, not per state");
     po.Register("max-loop", &opts.max_loop, "Option used to detect a particular type of determinization failure, typically due to invalid input (e.g., negative-cost loops)");
-    po.Register("retry-cutoff", &opts.retry_cutoff, "Controls pruning un-determinized lattice and retrying determinization: if effective-beam < retry-cutoff * beam, we prune the raw lattice and retry.");
+    po.Register("retry-cutoff", &opts.retry_cutoff,
+        "Controls pruning un-determinized lattice and retrying determinization: if effective-beam < retry-cutoff * beam, we prune the raw lattice and retry.");
     po.Register("num-threads", &num_threads, "Number of actively processing threads to run in parallel");
     po.Register("num-threads-total", &num_threads_total, "(accepted; the number of lattices in flight is num-threads + 20)");
     po.Read(argc, argv);
@@ -37,7 +38,13 @@ int main(int argc, char **argv) {
     TableWriter writer(po.GetArg(2));
     int32_t n_done = 0, n_warn = 0;
     {
-      DeterminizeSequencer::Config cfg; cfg.num_threads = num_threads; cfg.beam = beam; cfg.pre_scale = acoustic_scale; cfg.post_scale = 1.0 / acoustic_scale; cfg.det = opts; cfg.minimize = minimize;
+      DeterminizeSequencer::Config cfg;
+      cfg.num_threads = num_threads;
+      cfg.beam = beam;
+      cfg.pre_scale = acoustic_scale;
+      cfg.post_scale = 1.0 / acoustic_scale;
+      cfg.det = opts;
+      cfg.minimize = minimize;
       DeterminizeSequencer seq(cfg, &writer);
       for (auto &kv : lats) seq.Run(kv.first, std::move(kv.second));
       seq.Wait(); n_done = seq.NumDone(); n_warn = seq.NumWarn();

@@ -27,7 +27,8 @@ int main(int argc, char **argv) {
     po.Register("max-arcs", &opts.max_arcs, "Maximum number of arcs in output FST (total, not per state");
     po.Register("max-states", &opts.max_states, "Maximum number of arcs in output FST (total, not per state");
     po.Register("max-loop", &opts.max_loop, "Option used to detect a particular type of determinization failure, typically due to invalid input (e.g., negative-cost loops)");
-    po.Register("retry-cutoff", &opts.retry_cutoff, "Controls pruning un-determinized lattice and retrying determinization: if effective-beam < retry-cutoff * beam, we prune the raw lattice and retry.");
+    po.Register("retry-cutoff", &opts.retry_cutoff,
+        "Controls pruning un-determinized lattice and retrying determinization: if effective-beam < retry-cutoff * beam, we prune the raw lattice and retry.");
     po.Read(argc, argv);
     if (po.NumArgs() != 2) { po.PrintUsage(); return 1; }
     if (!write_compact) K3H_ERR << "--write-compact=false is not supported";
@@ -39,7 +40,10 @@ int main(int argc, char **argv) {
       Lattice &lat = kv.second;
       ScaleAcoustic(&lat, acoustic_scale);
       CompactLattice clat;
-      if (!DeterminizeLatticePruned(lat, beam, &clat, opts)) { K3H_WARN << "For key " << kv.first << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)"; n_warn++; }
+      if (!DeterminizeLatticePruned(lat, beam, &clat, opts)) {
+        K3H_WARN << "For key " << kv.first << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)";
+        n_warn++;
+      }
       if (clat.NumStates() == 0) { K3H_WARN << "For key " << kv.first << ", determinized and trimmed lattice was empty."; n_warn++; }
       if (minimize) { PushCompactLatticeStrings(&clat); PushCompactLatticeWeights(&clat); MinimizeCompactLattice(&clat); }
       if (!TopSortIfNeeded(&clat)) K3H_WARN << "Topological sorting of the determinized lattice failed for key " << kv.first;

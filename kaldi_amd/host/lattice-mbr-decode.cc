@@ -15,8 +15,10 @@ int main(int argc, char **argv) {
         " e.g.: lattice-mbr-decode --acoustic-scale=0.1 ark:1.lats 'ark,t:text.int' ark:/dev/null ark,t:1.sau\n";
     ParseOptions po(usage);
     float acoustic_scale = 1.0f, lm_scale = 1.0f; bool one_best_times = false; std::string word_syms; MinimumBayesRiskOptions mbr_opts;
-    po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic likelihoods"); po.Register("lm-scale", &lm_scale, "Scaling factor for language model probabilities");
-    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output]"); po.Register("one-best-times", &one_best_times, "If true, output times corresponding to one-best, not whole sausage.");
+    po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic likelihoods");
+    po.Register("lm-scale", &lm_scale, "Scaling factor for language model probabilities");
+    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output]");
+    po.Register("one-best-times", &one_best_times, "If true, output times corresponding to one-best, not whole sausage.");
     po.Register("decode-mbr", &mbr_opts.decode_mbr, "(lattice-to-ctm-conf's option) If true, do Minimum Bayes Risk decoding (else, Maximum a Posteriori)");
     po.Register("print-silence", &mbr_opts.print_silence, "(lattice-to-ctm-conf's option) Keep the inter-word '<eps>' bins in the 1-best output");
     po.Read(argc, argv);
@@ -41,8 +43,21 @@ int main(int argc, char **argv) {
       MinimumBayesRisk mbr(clat, mbr_opts);
       if (trans) trans->WriteInt32Vector(kv.first, mbr.GetOneBest());
       if (risk_out) *risk_out << kv.first << " " << mbr.GetBayesRisk() << "\n";
-      if (saus_out) { *saus_out << kv.first; for (const auto &bin : mbr.GetSausageStats()) { *saus_out << " ["; for (const auto &e : bin) *saus_out << " " << e.first << " " << e.second; *saus_out << " ]"; } *saus_out << "\n"; }
-      if (times_out) { *times_out << kv.first; const auto &t = one_best_times ? mbr.GetOneBestTimes() : mbr.GetSausageTimes(); for (size_t i = 0; i < t.size(); i++) *times_out << " " << t[i].first << " " << t[i].second << (i + 1 < t.size() ? " ;" : ""); *times_out << "\n"; }
+      if (saus_out) {
+        *saus_out << kv.first;
+        for (const auto &bin : mbr.GetSausageStats()) {
+          *saus_out << " [";
+          for (const auto &e : bin) *saus_out << " " << e.first << " " << e.second;
+          *saus_out << " ]";
+        }
+        *saus_out << "\n";
+      }
+      if (times_out) {
+        *times_out << kv.first;
+        const auto &t = one_best_times ? mbr.GetOneBestTimes() : mbr.GetSausageTimes();
+        for (size_t i = 0; i < t.size(); i++) *times_out << " " << t[i].first << " " << t[i].second << (i + 1 < t.size() ? " ;" : "");
+        *times_out << "\n";
+      }
       n_done++; n_words += (int64_t)mbr.GetOneBest().size(); tot_risk += mbr.GetBayesRisk();
     }
     if (trans) trans->Flush();

@@ -18,14 +18,25 @@ int main(int argc, char **argv) {
     ParseOptions po(usage);
     bool apply_exp = false, use_priors = false, debug_comp = false; std::string use_gpu = "yes", ivector_rspecifier, online_ivector_rspecifier, utt2spk;
     int32_t subsampling = 1, frames_per_chunk = 50, elc = 0, erc = 0, elci = -1, ercf = -1, online_ivector_period = 0, max_batch = 512; float acoustic_scale = 1.0f;
-    po.Register("apply-exp", &apply_exp, "If true, apply exp function to output"); po.Register("use-priors", &use_priors, "If true, subtract the logs of the priors stored with the model (in this case, a .mdl file is expected as input).");
-    po.Register("use-gpu", &use_gpu, "yes|no|optional|wait (this build always uses the GPU)"); po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output is less than the frame-rate of the input");
-    po.Register("frames-per-chunk", &frames_per_chunk, "Number of frames in each chunk that is separately evaluated by the neural net (matters with --online-ivectors: one i-vector per chunk; without i-vectors the result does not depend on it and utterances are evaluated whole)"); po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
-    po.Register("extra-left-context", &elc, "(only 0 is supported)"); po.Register("extra-right-context", &erc, "(only 0 is supported)"); po.Register("extra-left-context-initial", &elci, "(accepted)"); po.Register("extra-right-context-final", &ercf, "(accepted)");
-    po.Register("ivectors", &ivector_rspecifier, "Rspecifier for iVectors as vectors (i.e. not estimated online); per utterance by default, or per speaker if you provide the --utt2spk option.");
-    po.Register("online-ivectors", &online_ivector_rspecifier, "Rspecifier for iVectors estimated online, as matrices.  If you supply this, you must set the --online-ivector-period option.");
+    po.Register("apply-exp", &apply_exp, "If true, apply exp function to output");
+    po.Register("use-priors", &use_priors, "If true, subtract the logs of the priors stored with the model (in this case, a .mdl file is expected as input).");
+    po.Register("use-gpu", &use_gpu, "yes|no|optional|wait (this build always uses the GPU)");
+    po.Register("frame-subsampling-factor", &subsampling, "Required if the frame-rate of the output is less than the frame-rate of the input");
+    po.Register("frames-per-chunk", &frames_per_chunk,
+        "Number of frames in each chunk that is separately evaluated by the neural net (matters with --online-ivectors: one i-vector per chunk; without i-vectors the result does not depend on it and utterances are evaluated whole)");
+    po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
+    po.Register("extra-left-context", &elc, "(only 0 is supported)");
+    po.Register("extra-right-context", &erc, "(only 0 is supported)");
+    po.Register("extra-left-context-initial", &elci, "(accepted)");
+    po.Register("extra-right-context-final", &ercf, "(accepted)");
+    po.Register("ivectors", &ivector_rspecifier,
+        "Rspecifier for iVectors as vectors (i.e. not estimated online); per utterance by default, or per speaker if you provide the --utt2spk option.");
+    po.Register("online-ivectors", &online_ivector_rspecifier,
+        "Rspecifier for iVectors estimated online, as matrices.  If you supply this, you must set the --online-ivector-period option.");
     po.Register("online-ivector-period", &online_ivector_period, "Number of frames between iVectors in matrices supplied to the --online-ivectors option");
-    po.Register("utt2spk", &utt2spk, "Rspecifier for utt2spk option used to get ivectors per speaker"); po.Register("debug-computation", &debug_comp, "(accepted, unused)"); po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
+    po.Register("utt2spk", &utt2spk, "Rspecifier for utt2spk option used to get ivectors per speaker");
+    po.Register("debug-computation", &debug_comp, "(accepted, unused)");
+    po.Register("max-batch-size", &max_batch, "Utterances per GPU batch");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) { po.PrintUsage(); return 1; }
     if (elc || erc) K3H_ERR << "extra context is not supported by this program (feed-forward TDNN / TDNN-F models do not use it)";
@@ -33,7 +44,12 @@ int main(int argc, char **argv) {
     k3_nnet *nnet = nullptr; K3H_CHECK_K3(k3_nnet_load(po.GetArg(1).c_str(), &nnet));
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
     std::vector<float> log_priors;
-    if (use_priors) { if (!ni.has_priors) K3H_ERR << "Priors vector is empty (a .mdl with priors is expected with --use-priors)"; log_priors.resize(ni.output_dim); K3H_CHECK_K3(k3_nnet_get_priors(nnet, log_priors.data())); for (float &p : log_priors) p = logf(p); }
+    if (use_priors) {
+      if (!ni.has_priors) K3H_ERR << "Priors vector is empty (a .mdl with priors is expected with --use-priors)";
+      log_priors.resize(ni.output_dim);
+      K3H_CHECK_K3(k3_nnet_get_priors(nnet, log_priors.data()));
+      for (float &p : log_priors) p = logf(p);
+    }
     auto feats = ReadMatrixTable(po.GetArg(2)); TableWriter writer(po.GetArg(3));
     int num_success = 0, num_fail = 0; int64_t frame_count = 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -54,7 +70,11 @@ int main(int argc, char **argv) {
       const int64_t rows = ro.back();
       std::vector<float> h((size_t)rows * ni.output_dim); HIPCHK(hipMemcpy(h.data(), d_o, h.size() * 4, hipMemcpyDeviceToHost));
       if (apply_exp) for (float &v : h) v = expf(v);
-      for (size_t u = 0; u < idx.size(); u++) { writer.WriteMatrix(feats[idx[u]].first, h.data() + ro[u] * ni.output_dim, (int32_t)(ro[u + 1] - ro[u]), ni.output_dim, ni.output_dim); frame_count += nf[u]; num_success++; }
+      for (size_t u = 0; u < idx.size(); u++) {
+        writer.WriteMatrix(feats[idx[u]].first, h.data() + ro[u] * ni.output_dim, (int32_t)(ro[u + 1] - ro[u]), ni.output_dim, ni.output_dim);
+        frame_count += nf[u];
+        num_success++;
+      }
       k3_nnet_batch_destroy(nb); HIPCHK(hipFree(d_o));
     }
     writer.Flush();
