@@ -979,7 +979,12 @@ struct k3_decoder {
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_tp) (void)hipEventDestroy(ev_tp);
     if (out_buf) (void)hipFree(out_buf);
-                 for (ArgSlot &a : arg) { if (a.h) (void)hipHostFree(a.h); if (a.d) (void)hipFree(a.d); if (a.ev) (void)hipEventDestroy(a.ev); } }
+    for (ArgSlot &a : arg) {
+      if (a.h) (void)hipHostFree(a.h);
+      if (a.d) (void)hipFree(a.d);
+      if (a.ev) (void)hipEventDestroy(a.ev);
+    }
+  }
 };
 
 extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
