@@ -26,7 +26,7 @@ for literal in (1, 0):
     if os.environ.get("K3_PRUNE_PROF"):      # library built with -DK3_PRUNE_PROF: cycles of the pruning kernel's stages, per lane
         cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
         print("prune kernel cycles/lane:", dict(zip(["last frame", "staging", "emitting links", "eps fixpoint", "offsets", "HBM-path frames"], (cyc[:6] // U).tolist())))
-    elif literal and not os.environ.get("K3HIP_LIB"):      # the shipped library: frames by path (LDS-resident / given up and redone / general) and why the fast path gave up
+    elif literal and (not os.environ.get("K3HIP_LIB") or os.environ.get("K3_PROF_PATHS")):      # the shipped library: frames by path (LDS-resident / given up and redone / general) and why the fast path gave up
         cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
         print("cycles/lane (two decodes): fast frames", cyc[15] // U, "general frames", cyc[11] // U, "| frames: fast", cyc[12], "gave up", cyc[13], "general (incl. redone)", cyc[14], "| give-up reasons", dict(zip(["tokens", "table", "hash", "labels", "worklist", "eps links", "degree", "closure", "queue", "stack", "mismatch"], cyc[:11].tolist())))
     elif literal:
