@@ -326,6 +326,8 @@ def main():
     ap.add_argument("--no-strict-rccl", action="store_true",
                     help="N > 1 over RCCL: if the graph broadcast through the product's C ABI (k3_comm_create + k3_fst_bcast) fails on any rank, fall back to "
                          "torch.distributed and only mark the line (\"rccl_abi_failed\": true).  Default (strict): mark the line, print it, and exit with status 3")
+    ap.add_argument("--decoder-stream-priority", type=int, default=0,
+                    help="queue priority of the two decoder streams (0 = default, -1 = high): whose workgroups take a slot that frees up, a waiting lane's or the next front end's")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin this rank's host threads to its share of the cores (cores / ranks, by LOCAL_RANK)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -544,7 +546,7 @@ def main():
         first_timed = [0]
         if two:
             pair = (dec, decs["literal_b"])
-            dstr = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            dstr = (torch.cuda.Stream(device=dev, priority=args.decoder_stream_priority), torch.cuda.Stream(device=dev, priority=args.decoder_stream_priority))
         def fetch(j):      # batch j's lattices (compaction kernel + D2H on its decoder's stream), handed to the determinization pool
             while len(pending) >= 2:
                 r = pending.pop(0).result()

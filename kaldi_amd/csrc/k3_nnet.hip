@@ -777,7 +777,18 @@ struct k3_nnet_batch {
   int num_seqs = 0; int *d_seq_iv_row = nullptr; long long total_iv_rows = 0;
   std::vector<float *> seq_bias;                // per node (null = none) [num_seqs x ld]
   std::vector<int> seq_bias_ld;
-  ~k3_nnet_batch() { for (void *p : allocs) (void)hipFree(p); }
+  // K3_NNET_SPLIT=1 (opt-in, see k3_nnet_batch_create): the batch is planned as TWO halves of its utterances (each a batch of its own: tiles, activation buffers), run on two
+  // streams: a launch's last, partly filled round of tiles and the ramps at both ends of the forward's ~36 launches then run under the other half's tiles (512 x 10 s: 27.0 ->
+  // 26.3 ms per forward back to back; the same tiles and the same arithmetic, so the output is bit-identical).  This object then only holds the totals.
+  std::unique_ptr<k3_nnet_batch> half[2];
+  long long half_in_rows0 = 0, half_out_rows0 = 0;      // rows of the first half in the feature / output matrices
+  hipStream_t side = nullptr; int side_prio = 0; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  ~k3_nnet_batch() {
+    for (void *p : allocs) (void)hipFree(p);
+    if (side) (void)hipStreamDestroy(side);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+  }
 };
 
 namespace {
@@ -1070,7 +1081,32 @@ extern "C" int k3_nnet_batch_create(k3_nnet *net, int32_t num_utts, const int32_
                                     const float *h_log_priors, float acoustic_scale, k3_nnet_batch **out) {
   K3_REQUIRE(net, "k3_nnet_batch_create: bad argument");
   K3_REQUIRE(net->fm.ivector_dim == 0, "k3_nnet_batch_create: the model has an i-vector input (input-node name=ivector): use k3_nnet_batch_create_ivector");
-  return batch_create_impl(net, num_utts, h_num_frames, subsampling, h_log_priors, acoustic_scale, false, 0, 0, nullptr, out);
+  K3_REQUIRE(h_num_frames && out && num_utts > 0, "k3_nnet_batch_create: bad argument");
+  // two halves on two streams: OPT-IN (K3_NNET_SPLIT=1).  Measured (tools/bench_nnet_streams.py, bench.py --decoder-stream-priority): forwards back to back 27.0 -> 26.3 ms, but
+  // nothing in the pipelined step -- there the gaps of one forward's launches are already filled by the decoder's lanes and the other batch's kernels (80.0 against 80.1 ms with
+  // the decoder streams at high queue priority; 89 ms without: two queues of GEMM workgroups then take the freed slots the next decoder launch is waiting for).
+  long long frames = 0; for (int u = 0; u < num_utts; u++) frames += h_num_frames[u] > 0 ? h_num_frames[u] : 0;
+  const int force = getenv("K3_NNET_SPLIT") ? atoi(getenv("K3_NNET_SPLIT")) : -1;      // (read per call: tests/test_nnet_gpu.py builds both forms in one process)
+  const bool split = num_utts >= 2 && force == 1;
+  if (!split) return batch_create_impl(net, num_utts, h_num_frames, subsampling, h_log_priors, acoustic_scale, false, 0, 0, nullptr, out);
+  std::unique_ptr<k3_nnet_batch> b(new k3_nnet_batch());
+  b->net = net; b->num_utts = num_utts; b->subsampling = subsampling; b->num_frames.assign(h_num_frames, h_num_frames + num_utts);
+  int u0 = 1; { long long acc = 0; for (int u = 0; u < num_utts; u++) { acc += h_num_frames[u]; if (2 * acc >= frames) { u0 = std::min(std::max(u + 1, 1), num_utts - 1); break; } } }      // first half: about half of the frames
+  for (int h = 0; h < 2; h++) {
+    k3_nnet_batch *hb = nullptr;
+    const int rc = batch_create_impl(net, h == 0 ? u0 : num_utts - u0, h_num_frames + (h == 0 ? 0 : u0), subsampling, h_log_priors, acoustic_scale, false, 0, 0, nullptr, &hb);
+    if (rc) return rc;
+    b->half[h].reset(hb);
+  }
+  const k3_nnet_batch &h0 = *b->half[0], &h1 = *b->half[1];
+  b->half_in_rows0 = h0.total_in_rows; b->half_out_rows0 = h0.total_out_rows;
+  b->total_in_rows = h0.total_in_rows + h1.total_in_rows; b->total_out_rows = h0.total_out_rows + h1.total_out_rows; b->flops = h0.flops + h1.flops;
+  b->out_offsets = h0.out_offsets; for (size_t i = 1; i < h1.out_offsets.size(); i++) b->out_offsets.push_back(h0.total_out_rows + h1.out_offsets[i]);
+  b->node_rows = h0.node_rows; for (size_t i = 0; i < h1.node_rows.size(); i++) b->node_rows[i] += h1.node_rows[i];
+  b->node_a = h0.node_a; b->node_r = h0.node_r; b->node_g = h0.node_g; b->num_seqs = h0.num_seqs + h1.num_seqs;
+  K3_HIP_CHECK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming)); K3_HIP_CHECK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  *out = b.release();
+  return K3_OK;
 }
 
 extern "C" int k3_nnet_batch_create_ivector(k3_nnet *net, int32_t num_utts, const int32_t *h_num_frames, int32_t subsampling, const float *h_log_priors, float acoustic_scale,
@@ -1116,13 +1152,27 @@ extern "C" int k3_nnet_batch_set_precision(k3_nnet_batch *b, int32_t mode) {
     }
   }
   b->precision = mode;
+  for (int h = 0; h < 2; h++) if (b->half[h]) b->half[h]->precision = mode;
   return K3_OK;
 }
 
 static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream);
 extern "C" int k3_nnet_forward(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, float *d_out, int64_t ld_out, void *stream) {
   K3_REQUIRE(b && b->net->fm.ivector_dim == 0, "k3_nnet_forward: null batch, or the model has an i-vector input (use k3_nnet_forward_ivector)");
-  return forward_impl(b, d_feats, ld_feats, d_out, ld_out, stream);
+  if (!b->half[0]) return forward_impl(b, d_feats, ld_feats, d_out, ld_out, stream);
+  K3_REQUIRE(d_feats && d_out, "k3_nnet_forward: null argument");
+  // the second half on a side stream of the caller's priority, forked from and joined to the caller's stream by events (also what a stream capture needs)
+  hipStream_t st = (hipStream_t)stream; int prio = 0;
+  if (st) (void)hipStreamGetPriority(st, &prio);
+  if (!b->side || b->side_prio != prio) {
+    if (b->side) { K3_HIP_CHECK(hipStreamSynchronize(b->side)); K3_HIP_CHECK(hipStreamDestroy(b->side)); b->side = nullptr; }
+    K3_HIP_CHECK(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, prio)); b->side_prio = prio;
+  }
+  K3_HIP_CHECK(hipEventRecord(b->ev_fork, st)); K3_HIP_CHECK(hipStreamWaitEvent(b->side, b->ev_fork, 0));
+  { const int rc = forward_impl(b->half[0].get(), d_feats, ld_feats, d_out, ld_out, stream); if (rc) return rc; }
+  { const int rc = forward_impl(b->half[1].get(), d_feats + b->half_in_rows0 * ld_feats, ld_feats, d_out + b->half_out_rows0 * ld_out, ld_out, b->side); if (rc) return rc; }
+  K3_HIP_CHECK(hipEventRecord(b->ev_join, b->side)); K3_HIP_CHECK(hipStreamWaitEvent(st, b->ev_join, 0));
+  return K3_OK;
 }
 extern "C" int k3_nnet_forward_ivector(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats, const float *d_ivectors, int64_t ld_ivectors, float *d_out,
     int64_t ld_out, void *stream) {

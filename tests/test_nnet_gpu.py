@@ -96,6 +96,31 @@ def test_hip_vs_oracle_tdnn_config1_priors_acwt(tmp_path):
     for f, g in zip(feats, got):
         _check(no, onet, f, g, 1, lp, 0.1)
 
+def test_two_halves_on_two_streams_equal_one_plan(tmp_path, monkeypatch):
+    """K3_NNET_SPLIT=1 plans a batch as two halves of its utterances run on two streams (k3_nnet_batch_create; opt-in): the same tiles, the same
+    arithmetic -- every value bit-identical to the single plan, ragged lengths (incl. a 1-frame utterance at the cut), priors and scale, on the caller's own stream,
+    call after call (the fork / join events are reused)"""
+    from kaldi_amd import nnet3
+    net = synth.make_tdnnf(seed=3, dim=128, bottleneck=32, prefinal_small=64, num_pdfs=300, calib_frames=400, out_std=1.5)
+    p = str(tmp_path / "m.raw"); net.write(p); n = nnet3.Nnet(p); dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11); lens = [257, 3, 998, 1, 1, 131, 640, 17, 100]; lp = np.log(rng.dirichlet(np.ones(300)).astype(np.float32) + 1e-8)
+    xs = [torch.from_numpy(np.concatenate([_feats(rng, T) for T in lens])).to(dev) for _ in range(3)]
+    for s_, kw in ((3, {}), (1, dict(log_priors=lp, acoustic_scale=0.3))):
+        monkeypatch.setenv("K3_NNET_SPLIT", "0"); one = nnet3.NnetBatch(n, lens, s_, **kw)
+        monkeypatch.setenv("K3_NNET_SPLIT", "1"); two = nnet3.NnetBatch(n, lens, s_, **kw)
+        assert (one.out_offsets == two.out_offsets).all() and one.total_out_rows == two.total_out_rows and one.flops == two.flops
+        st = torch.cuda.Stream(priority=-1)
+        for k, x in enumerate(xs):
+            ref = one.forward(x).clone()
+            if k == 1:
+                with torch.cuda.stream(st): got = two.forward(x)
+                st.synchronize()
+            else: got = two.forward(x)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (s_, k)
+    monkeypatch.setenv("K3_NNET_SPLIT", "1"); single = nnet3.NnetBatch(n, [50], 3)      # one utterance: nothing to split
+    assert single.forward(xs[0][:50]).shape[0] == single.total_out_rows
+
 def test_hip_full_model_spot_check(tmp_path):
     """The benchmark model (17L-768/96-6024) on a 64-utterance batch: every utterance is the same signal, so all
     outputs must be identical across the batch (row-mapping / tile-boundary check at full width) and utterance 0
