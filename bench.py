@@ -328,6 +328,11 @@ def main():
                          "torch.distributed and only mark the line (\"rccl_abi_failed\": true).  Default (strict): mark the line, print it, and exit with status 3")
     ap.add_argument("--decoder-stream-priority", type=int, default=0,
                     help="queue priority of the two decoder streams (0 = default, -1 = high): whose workgroups take a slot that frees up, a waiting lane's or the next front end's")
+    ap.add_argument("--ragged", action="store_true",
+        help="SURVEY 8d's second set instead of the equal-length one: --utts utterances of length U(2 s, 20 s), seed 1235 (same model, graph and decoder); prints "
+        "its own line (metric ... ragged), no cpu_baseline / extras.  The default run spawns this as a child at its end and reports the child's value as `value_ragged`")
+    ap.add_argument("--no-ragged", action="store_true", help="default run: do not measure the ragged set (value_ragged) at the end")
+    ap.add_argument("--ragged-sort", action="store_true", help="--ragged: the batch's utterances sorted by length, longest first (lane u = the u-th longest)")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin this rank's host threads to its share of the cores (cores / ranks, by LOCAL_RANK)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -344,9 +349,25 @@ def main():
     import __graft_entry__ as ge
     if rank == 0: ge.build()
     if world > 1: dist.barrier()
-    from kaldi_amd import feat, nnet3, synth, decoder, parallel, hostlib
+    from kaldi_amd import feat, nnet3, synth, decoder, parallel, hostlib, lib as k3lib
+    # provenance: the library this run maps was built from the sources next to it (its build id ends with their digest); a developer build (--allow-dev-lib) is only reported
+    build_id, src_digest = k3lib.build_id(), k3lib.source_digest()
+    if not build_id.endswith("+" + src_digest) and not args.allow_dev_lib:
+        raise SystemExit(f"bench.py: kaldi_amd/lib/libk3hip.so ({build_id}) was not built from the sources in this tree (digest {src_digest}): run make -C kaldi_amd/csrc")
 
     U, nsamp = args.utts, int(16000 * args.utt_seconds)
+    if args.ragged:      # lengths U(2 s, 20 s), seed 1235; the same lengths on every step (the audio under them moves with the step, as in the equal-length set)
+        args.no_cpu_baseline = True
+        args.no_extras = True
+        args.no_two_pass = True
+        lens = (np.random.default_rng(1235).uniform(2.0, 20.0, U) * 16000).astype(np.int64)
+        if args.ragged_sort: lens = np.sort(lens)[::-1].copy()
+    else:
+        lens = np.full(U, nsamp, np.int64)
+    lens = [int(x) for x in lens]
+    samp_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tot_samp = int(samp_off[-1])
+    max_seconds = max(lens) / 16000.0
     # host budget of a rank on an N-GPU node: cores / N threads for its lattice tail, and -- unless --no-pin -- those threads on the rank's OWN contiguous share of
     # the cores (by LOCAL_RANK; the affinity mask is inherited by every thread created from here on: the determinization pool, the lattice fetch helpers), so that
     # eight ranks' pools do not migrate over each other's cores.  One rank: the whole host, no pinning.
@@ -366,15 +387,15 @@ def main():
     # memory
     # (one spare utterance behind the batch: timed step k reads the batch from sample offset shift(k), so no two steps decode the same audio);
     # 17L-768/96-6024 TDNN-F, seed 1
-    pcm_host = torch.empty((U + 1) * nsamp, dtype=torch.int16).pin_memory()
+    pcm_host = torch.empty(tot_samp + nsamp, dtype=torch.int16).pin_memory()
     pcm_np = pcm_host.numpy()
-    def pcm_of(u, r=rank): return synth.gaussian_pcm16(nsamp, 1234 + 100000 * r + u)
+    def pcm_of(u, r=rank): return synth.gaussian_pcm16(lens[u] if u < U else nsamp, 1234 + 100000 * r + u)
     with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
-        for u, w in enumerate(ex.map(pcm_of, range(U + 1))): pcm_np[u * nsamp:(u + 1) * nsamp] = w
+        for u, w in enumerate(ex.map(pcm_of, range(U + 1))): pcm_np[samp_off[u] if u < U else tot_samp:][:w.size] = w
     shift_of = lambda k: (k * 40009) % nsamp            # batch k of a run starts here (k = 0: the utterances as generated)
-    pcm_dev = torch.empty(U * nsamp, dtype=torch.int16, device=dev)
+    pcm_dev = torch.empty(tot_samp, dtype=torch.int16, device=dev)
     sf = feat.SpectralFeatures(feat.fbank_options(dither=0.0, num_bins=40))
-    wo, fo, total_frames, fo_h = sf.offsets([nsamp] * U, dev)
+    wo, fo, total_frames, fo_h = sf.offsets(lens, dev)
     model_path = os.path.join(tempfile.gettempdir(), f"k3_bench_tdnnf_{rank}.raw")
     # BatchNorm calibration on real fbank features of rank 0's first utterance (same model on every rank)
     w0 = torch.from_numpy(pcm_of(0, 0).astype(np.float32)).to(dev)
@@ -444,8 +465,8 @@ def main():
                     os._exit(3)
         if cfst is None: cfst = parallel.broadcast_graph(graph, synth.tid2pdf(num_pdfs), rank, world, dev)
         t_bcast = time.perf_counter() - t0
-        caps = dict(frame_tokens_cap=65536, frame_cands_cap=131072, lane_tokens_cap=int(4500 * args.utt_seconds * 33.4) + 65536,
-                lane_links_cap=int(6000 * args.utt_seconds * 33.4) + 131072)
+        caps = dict(frame_tokens_cap=65536, frame_cands_cap=131072, lane_tokens_cap=int(4500 * max_seconds * 33.4) + 65536,
+                lane_links_cap=int(6000 * max_seconds * 33.4) + 131072)
         for mode in (["literal"] if args.no_two_pass else ["literal", "two_pass"]):
             d = decoder.CudaDecoder(cfst, decoder.decoder_config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE,
                     literal_order=1 if mode == "literal" else 0, **caps), U, num_pdfs)
@@ -505,7 +526,7 @@ def main():
         nstep = [0]
         nser = [0]
         last = [None]
-        src = lambda k: pcm_host[shift_of(k) if vary else 0:][:U * nsamp]      # batch k's audio
+        src = lambda k: pcm_host[shift_of(k) if vary else 0:][:tot_samp]      # batch k's audio
         for e in dec_done: e.record()
         reader = [None, None]      # the decoder object that read log-likelihood buffer 0 / 1 last
         def front_end(k):      # batch k's H2D + fbank + TDNN-F on the front stream, into log-likelihood buffer k & 1 (last read by the decoder two batches ago)
@@ -669,7 +690,7 @@ def main():
         pb = decs["literal_b"].FramePathCounts()
         for k_ in ("lds_path", "given_up", "general_path", "cycles_lds_path", "cycles_general_path"): paths[k_] += pb[k_]
         for k_, v_ in pb["give_up_reasons"].items(): paths["give_up_reasons"][k_] = paths["give_up_reasons"].get(k_, 0) + v_
-    audio_s = U * args.utt_seconds * world * args.steps
+    audio_s = tot_samp / 16000.0 * world * args.steps
     two = run("two_pass", args.steps, args.warmup) if "two_pass" in decs else None
     # Stage and kernel durations (stage_ms, roofline, roofline_gemm) come from a short SERIAL pass of the same objects: in the pipelined steps a kernel shares
     # the GPU with the other
@@ -707,7 +728,7 @@ def main():
                 "decoder_mode": "literal_order=1: raw lattices identical to the reference's LatticeFasterDecoder" if decs else None,
                 "host_load_replicas": args.host_load_replicas, "det_threads": det_threads, "utts_per_gpu": U, "frames_per_utt": fo_h[1],
                     "output_rows": int(nb.total_out_rows), "params": int(net.info.num_params), "parallelism": f"utterance-shard x{world}"},
-            "value_kernels": U * args.utt_seconds * world / (kernels_ms * 1e-3),
+            "value_kernels": tot_samp / 16000.0 * world / (kernels_ms * 1e-3),
             "value_kernels_note": "audio / (fbank + TDNN-F + decode kernel time of a step): what the GPU stages alone sustain, H2D / D2H / host tail excluded",
              "pipeline": ("batch k+1's PCM16 H2D + fbank + TDNN-F are issued on a second stream right behind batch k's decoder kernels "
                 "(double-buffered log-likelihoods): the copy and the start of the network run while the decoder's last lanes finish; "
@@ -789,7 +810,7 @@ def main():
                 if tr: line["roofline"]["traffic_error"] = tr.get("error")
                 try:      # the committed PMC passes of the round (the same command, run by tools/profile_round.sh)
                     tj = json.load(open(sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "hbm_traffic_r*.json")))[-1]))
-                    if U == 512 and args.utt_seconds == 10.0:
+                    if U == 512 and args.utt_seconds == 10.0 and not args.ragged:
                         line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
                         line["roofline"]["traffic_source"] = tj["source"]
                         for k_ in ("fetch_bytes_per_launch", "write_bytes_per_launch"):
@@ -1000,6 +1021,37 @@ def main():
                          "LatticeFasterDecoder on the reference's log-likelihoods -- states and arcs with all cost bits, as "
                         "multisets (the strict signature test is tests/test_decoder_literal_gpu.py)"}
             except Exception as e: line["cpu_baseline"] = {"error": repr(e)}
+        if args.ragged:
+            fr = np.diff(np.asarray(nb.out_offsets))
+            line["metric"] += " -- RAGGED set (SURVEY 8d: utterance lengths U(2 s, 20 s), seed 1235)"
+            line["config"]["workload"] = line["config"]["workload"].replace(f"{U} x {args.utt_seconds:g} s utts per GPU",
+                f"{U} utts of U(2 s, 20 s) (seed 1235{', sorted longest first' if args.ragged_sort else ', in generation order'}) per GPU = {tot_samp / 16000.0:.0f} s of audio")
+            line["ragged"] = {"utt_seconds": {"min": min(lens) / 16000.0, "mean": tot_samp / 16000.0 / U, "max": max(lens) / 16000.0},
+                              "decoder_frames_per_lane": {"min": int(fr.min()), "mean": float(fr.mean()), "max": int(fr.max())},
+                              "token_passing_kernel_ms_serial": line["stage_ms"]["decode.token_passing_kernel"],
+                              "mean_lane_ms": line.get("roofline_latency", {}).get("mean_lane_ms"),
+                              "note": "one persistent workgroup per utterance: a launch lasts as long as its longest lane (token_passing_kernel_ms_serial vs mean_lane_ms); in the "
+                                      "pipelined steps the CUs the short lanes free are taken by the next batch's front end and, through the second decoder object, by the next "
+                                      "batch's lanes"}
+        # SURVEY 8d's second set, measured by a child process of the same program once this process's decoders are gone (two sets of lane pools sized for 20 s utterances
+        # do not fit beside the three this run holds): `value_ragged`
+        if decs and world == 1 and not args.ragged and not args.no_ragged:
+            try:
+                import gc
+                decs.clear()
+                dec = d = d2 = d_ = None
+                gc.collect()
+                torch.cuda.empty_cache()
+                cmd = [sys.executable, os.path.abspath(__file__), "--ragged", "--steps", str(min(args.steps, 10)), "--warmup", str(min(args.warmup, 2)), "--utts", str(U),
+                       "--graph-states", str(args.graph_states), "--graph-arcs", str(args.graph_arcs)] + (["--allow-dev-lib"] if args.allow_dev_lib else [])
+                rr = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                cl = json.loads([l for l in rr.stdout.splitlines() if l.startswith("{")][-1])
+                line["value_ragged"] = cl["value"]
+                line["ragged"] = dict(cl.get("ragged", {}), ms_per_step=cl["ms_per_step"], steps=cl["steps"], value_over_equal_length_value=cl["value"] / line["value"],
+                                      command=" ".join(cmd[1:]))
+            except Exception as e: line["ragged"] = {"error": repr(e)}
+        line["provenance"] = {"libk3hip_build_id": build_id, "source_digest": src_digest, "match": build_id.endswith("+" + src_digest),
+                              "note": "k3_build_id() of the mapped library vs the SHA-256 prefix of kaldi_amd/csrc/*.hip, *.h + include/k3hip.h as shipped (kaldi_amd/lib.py)"}
         if os.environ.get("K3HIP_LIB"): line["dev_lib"] = os.environ["K3HIP_LIB"]
         if decs and rccl_abi_failed: line["rccl_abi_failed"] = True      # (top level too: a reader of `value` cannot miss it)
         print(json.dumps(line), flush=True)

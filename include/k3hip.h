@@ -21,6 +21,9 @@ extern "C" {
 typedef enum { K3_OK = 0, K3_ERR_ARG = -1, K3_ERR_HIP = -2, K3_ERR_UNSUPPORTED = -3, K3_ERR_OVERFLOW = -4 } k3_status;
 const char *k3_last_error(void);
 int k3_version(void);
+/* "k3hip-<abi revision>+<digest>": digest = first 16 hex digits of the SHA-256 over the sources the library was built from (kaldi_amd/csrc/ *.hip and *.h in byte order
+ * of their names, then this header) -- a caller that has the sources can tell whether the shared object it mapped was built from them (kaldi_amd/lib.py source_digest()). */
+const char *k3_build_id(void);
 
 /* ---------------------------------------------------------------- features ------------------
  * Replaces: feat::OfflineFeatureTpl<FbankComputer|MfccComputer>::Compute (feat/feature-common-inl.h:59-83)
@@ -341,6 +344,13 @@ typedef struct k3_decoder_config {
   /* HBM set aside for lanes that outgrow lane_tokens_cap / lane_links_cap (16 B per token + 20 B per link of the new pools; a lane's old pools are not reused):
    * -1 = a quarter of the lanes' reservation, at least 1 GiB and 14 x one lane's reservation (a lane growing 2x, 4x, 8x); 0 = none (the reservation is then a hard limit). */
   int64_t spare_pool_bytes;   /* -1 */
+  /* literal_order only -- the token-passing launch's shape.  resident_lanes = 0: one workgroup per utterance, all in flight at once.  n > 0 (and fewer than the call's
+   * utterances): n workgroups take the utterances from a work-queue, longest first (the reference reschedules lanes per chunk: cuda-online-pipeline-dynamic-batcher.cc;
+   * batched-threaded-nnet3-cuda-online-pipeline.cc:316-413), so a batch of unequal lengths keeps every slot busy and a launch does not last as long as its longest lane
+   * x the lanes per slot.  resident_exclusive = 1: a workgroup asks for more than half of a CU's LDS -- one lane per CU, the other half of the CU (registers, LDS, issue
+   * slots) is left to whatever else is queued on the device, i.e. the next batch's features and network.  Same lattices in every shape. */
+  int32_t resident_lanes;     /* 0 */
+  int32_t resident_exclusive; /* 0 */
 } k3_decoder_config;
 void k3_decoder_config_default(k3_decoder_config *cfg);
 typedef struct k3_decoder k3_decoder;

@@ -847,7 +847,8 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // k3_decoder_lit.hip: the literal_order token-passing kernel (compiled with its own block size); `params` is this file's DecParams
 extern "C" int k3_lit_forward_prepare();
 extern "C" int k3_lit_fast_tokens();
-extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nlanes, hipStream_t stream);
+extern "C" int k3_lit_has_queue();      // 0: this build's kernel decodes one lane per workgroup only (resident_lanes is then ignored)
+extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nworkgroups, int exclusive, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------ graph ----
 struct k3_fst {
@@ -857,8 +858,33 @@ struct k3_fst {
   int32_t max_pdf = -1;
   void *image = nullptr; size_t bytes = 0;
   int2 *offs = nullptr; ArcRec *arcs = nullptr; float *final_cost = nullptr; int *arc_ilabel = nullptr;
-  ~k3_fst() { if (image) (void)hipFree(image); }
+  // derived from the image when a decoder first asks for it (not part of the image: a graph that arrived through k3_fst_bcast / k3_fst_import_image derives its own;
+  // dropped when the image is handed out for writing): per arc {first arc of the destination state, its emitting arcs | eps arcs << 16}
+  mutable int2 *dinfo = nullptr;
+  void drop_derived() const { if (dinfo) { (void)hipFree(dinfo); dinfo = nullptr; } }
+  ~k3_fst() { drop_derived(); if (image) (void)hipFree(image); }
 };
+
+namespace {
+__global__ __launch_bounds__(256) void k3_fst_dinfo_kernel(const int2 *offs, const ArcRec *arcs, long long num_arcs, int2 *dinfo) {
+  const long long a = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (a >= num_arcs) return;
+  const int nxt = (int)((unsigned)arcs[a].next & ~kEpsFlag);
+  const int2 o = offs[nxt]; const int e1 = offs[nxt + 1].x;
+  const int ne = o.y - o.x, nn = e1 - o.y;
+  dinfo[a] = make_int2(o.x, (ne < 65535 ? ne : 65535) | ((nn < 65535 ? nn : 65535) << 16));
+}
+}  // namespace
+static int fst_dinfo(const k3_fst *f, const int2 **out) {
+  if (!f->dinfo && f->num_arcs > 0) {
+    K3_HIP_CHECK(hipMalloc((void **)&f->dinfo, sizeof(int2) * (size_t)f->num_arcs));
+    hipLaunchKernelGGL(k3_fst_dinfo_kernel, dim3((unsigned)((f->num_arcs + 255) / 256)), dim3(256), 0, nullptr, f->offs, f->arcs, (long long)f->num_arcs, f->dinfo);
+    K3_HIP_CHECK(hipGetLastError());
+    K3_HIP_CHECK(hipDeviceSynchronize());
+  }
+  *out = f->dinfo;
+  return K3_OK;
+}
 
 static int fst_alloc(k3_fst *f) {
   const size_t o0 = 0, o1 = align_up(o0 + sizeof(int2) * (size_t)(f->num_states + 1), 256), o2 = align_up(o1 + sizeof(ArcRec) * (size_t)f->num_arcs, 256),
@@ -926,11 +952,13 @@ extern "C" int k3_fst_export_image(const k3_fst *f, void *d_dst) {
 }
 extern "C" int k3_fst_import_image(k3_fst *f, const void *d_src) {
   K3_REQUIRE(f && d_src, "k3_fst_import_image: null argument");
+  f->drop_derived();
   K3_HIP_CHECK(hipMemcpy(f->image, d_src, f->bytes, hipMemcpyDeviceToDevice));
   return K3_OK;
 }
 extern "C" int k3_fst_shape_and_image(const k3_fst *f, int64_t *shape, void **d_image) {      // (k3_comm.hip)
   K3_REQUIRE(f && shape && d_image, "k3_fst_shape_and_image: null argument");
+  f->drop_derived();      // (the caller may write the image: k3_fst_bcast on a receiving rank)
   shape[0] = f->num_states; shape[1] = f->num_arcs; shape[2] = f->start; shape[3] = (int64_t)f->bytes; shape[4] = f->max_pdf; *d_image = f->image; return K3_OK;
 }
 extern "C" int k3_fst_create_shaped(const int64_t *shape, k3_fst **out) {
@@ -944,6 +972,7 @@ extern "C" int32_t k3_fst_num_states(const k3_fst *f) { return f ? f->num_states
 extern "C" int32_t k3_fst_start(const k3_fst *f) { return f ? f->start : -1; }
 extern "C" int k3_fst_image(const k3_fst *f, void **d_image, int64_t *bytes) {
   K3_REQUIRE(f && d_image && bytes, "k3_fst_image: null argument");
+  f->drop_derived();
   *d_image = f->image; *bytes = (int64_t)f->bytes; return K3_OK;
 }
 
@@ -971,7 +1000,10 @@ struct k3_decoder {
   // (round 4: a streaming round of 17 frames paid a stream drain and three blocking copies).  A slot is reused kArgSlots calls later, after its event.
   static constexpr int kArgSlots = 4;
   struct ArgSlot { char *h = nullptr, *d = nullptr; hipEvent_t ev = nullptr; bool used = false; };
-  ArgSlot arg[kArgSlots]; unsigned arg_seq = 0; size_t arg_off_rows = 0, arg_off_fresh = 0, arg_bytes = 0;
+  ArgSlot arg[kArgSlots]; unsigned arg_seq = 0; size_t arg_off_rows = 0, arg_off_fresh = 0, arg_off_queue = 0, arg_bytes = 0;
+  // literal_order launch shape: > 0 = that many workgroups take the call's lanes from a work-queue (longest first) instead of one workgroup per lane; exclusive: a workgroup
+  // asks for more than half of a CU's LDS, so that it shares its CU with other kernels' workgroups (the next batch's front end) instead of a second lane
+  int lit_resident = 0; bool lit_exclusive = false;
 
   ~k3_decoder() {
     for (void *q : allocs) (void)hipFree(q);
@@ -991,7 +1023,7 @@ extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
   if (!c) return;
   c->beam = 16.0f; c->max_active = std::numeric_limits<int32_t>::max(); c->min_active = 200; c->lattice_beam = 10.0f; c->beam_delta = 0.5f;
   c->frame_tokens_cap = 32768; c->frame_cands_cap = 65536; c->lane_tokens_cap = 2000000; c->lane_links_cap = 4000000;
-  c->literal_order = 0; c->hash_ratio = 2.0f; c->fast_frame_tokens = -1; c->spare_pool_bytes = -1;
+  c->literal_order = 0; c->hash_ratio = 2.0f; c->fast_frame_tokens = -1; c->spare_pool_bytes = -1; c->resident_lanes = 0; c->resident_exclusive = 0;
 }
 
 template <typename T> static int dmalloc(std::vector<void *> *allocs, T **ptr, size_t n) {
@@ -1016,6 +1048,8 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   d->fst = fst; d->cfg = *cfg; d->nlanes = nlanes; d->num_pdfs = num_pdfs;
   DecParams &p = d->p;
   p.offs = fst->offs; p.arcs = fst->arcs; p.final_cost = fst->final_cost; p.arc_ilabel = fst->arc_ilabel; p.start = fst->start;
+  p.dinfo = nullptr;
+  if (cfg->literal_order) { const int rc_ = fst_dinfo(fst, &p.dinfo); if (rc_) return rc_; }
   p.beam = cfg->beam; p.lattice_beam = cfg->lattice_beam; p.beam_delta = cfg->beam_delta; p.max_active = cfg->max_active; p.min_active = cfg->min_active;
   p.frame_tokens_cap = cfg->frame_tokens_cap; p.frame_cands_cap = cfg->frame_cands_cap;
   int hs = 1; while (hs < 2 * cfg->frame_tokens_cap) hs <<= 1;
@@ -1069,7 +1103,11 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   if ((rc = dmalloc(&d->allocs, &d->d_fresh, nl))) return rc;
   d->arg_off_rows = align_up(sizeof(long long) * (nl + 1), 16);
   d->arg_off_fresh = d->arg_off_rows + align_up(sizeof(float *) * nl, 16);
-  d->arg_bytes = d->arg_off_fresh + align_up(sizeof(int) * nl, 16);
+  d->arg_off_queue = d->arg_off_fresh + align_up(sizeof(int) * nl, 16);      // {head counter, pad x 3, lanes[nl]}
+  d->arg_bytes = d->arg_off_queue + 16 + align_up(sizeof(int) * nl, 16);
+  d->lit_resident = cfg->resident_lanes > 0 ? cfg->resident_lanes : 0; d->lit_exclusive = cfg->resident_exclusive != 0;
+  if (const char *e = getenv("K3_LIT_RESIDENT")) d->lit_resident = atoi(e);      // (developer override for A/B runs)
+  if (const char *e = getenv("K3_LIT_EXCLUSIVE")) d->lit_exclusive = atoi(e) != 0;
   for (k3_decoder::ArgSlot &a : d->arg) {
     K3_HIP_CHECK(hipHostMalloc((void **)&a.h, d->arg_bytes, hipHostMallocDefault)); K3_HIP_CHECK(hipMalloc((void **)&a.d, d->arg_bytes));
     K3_HIP_CHECK(hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
@@ -1218,6 +1256,28 @@ extern "C" int k3_decoder_init_channels(k3_decoder *d, const int32_t *channels, 
   return K3_OK;
 }
 
+// The literal_order kernel's lane list for this call (slot.h already holds the call's row offsets): the lanes with frames (or a fresh start), longest first.  Workgroup b of the
+// launch decodes entry b: a CU's two workgroups (b, b + 256 of a 512-lane launch) then hold a long and a short utterance, and a batch of unequal lengths no longer pairs two long
+// ones on a CU while another CU idles (the reference reschedules lanes per chunk for the same reason: cuda-online-pipeline-dynamic-batcher.cc).  With a work-queue build
+// (k3_lit_has_queue) and resident_lanes < lanes, fewer workgroups take the entries through the head counter.  Returns the number of workgroups to launch.
+static int fill_lane_queue(k3_decoder *d, k3_decoder::ArgSlot &slot, int U) {
+  DecParams &p = d->p;
+  p.q_head = nullptr; p.q_lanes = nullptr; p.q_n = 0;
+  if (!p.literal) return U;
+  const long long *ro = reinterpret_cast<const long long *>(slot.h); const int *fresh = reinterpret_cast<const int *>(slot.h + d->arg_off_fresh);
+  int *head = reinterpret_cast<int *>(slot.h + d->arg_off_queue), *lanes = head + 4; int n = 0;
+  bool sorted = true;
+  for (int u = 0; u < U; u++) if (ro[u + 1] > ro[u] || fresh[u]) { if (n && ro[u + 1] - ro[u] > ro[lanes[n - 1] + 1] - ro[lanes[n - 1]]) sorted = false; lanes[n++] = u; }
+  if (n == 0) return U;      // (nothing to do: every workgroup of the plain launch returns at once)
+  if (!sorted) std::stable_sort(lanes, lanes + n, [ro](int a, int b) { return ro[a + 1] - ro[a] > ro[b + 1] - ro[b]; });
+  head[0] = 0;
+  if (getenv("K3_DEBUG_QUEUE")) fprintf(stderr, "k3 lane list: %d of %d lanes, sorted on entry %d, first %d (%lld frames) last %d (%lld frames)\n", n, U, (int)sorted, lanes[0],
+      (long long)(ro[lanes[0] + 1] - ro[lanes[0]]), lanes[n - 1], (long long)(ro[lanes[n - 1] + 1] - ro[lanes[n - 1]]));
+  p.q_lanes = reinterpret_cast<int *>(slot.d + d->arg_off_queue) + 4; p.q_n = n;
+  if (k3_lit_has_queue() && d->lit_resident > 0 && d->lit_resident < n) { p.q_head = reinterpret_cast<int *>(slot.d + d->arg_off_queue); return d->lit_resident; }
+  return n;
+}
+
 // AdvanceDecoding (cuda-decoder.h:262: AdvanceDecoding(lanes, loglikes)): lane u consumes rows h_row_offsets[u] .. [u+1] of d_loglikes as
 // its NEXT frames (zero rows = the lane idles in this call).  Chunked calls give bit-identical results to one call with all frames.
 extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream) {
@@ -1233,6 +1293,7 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   k3_decoder::ArgSlot &slot = d->arg[d->arg_seq++ % k3_decoder::kArgSlots];
   if (slot.used) K3_HIP_CHECK(hipEventSynchronize(slot.ev));      // (the launch of kArgSlots calls ago: long finished)
   memcpy(slot.h, h_row_off, sizeof(long long) * (num_utts + 1)); memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * num_utts);
+  const int lit_grid = fill_lane_queue(d, slot, num_utts);
   K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
   std::fill(d->fresh.begin(), d->fresh.end(), 0);
   p.loglikes = d_loglikes;
@@ -1243,7 +1304,7 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   p.lane_rows = nullptr;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
-  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), num_utts, st);
+  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
@@ -1275,13 +1336,14 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
   memcpy(slot.h, ro.data(), sizeof(long long) * (U + 1));
   memcpy(slot.h + d->arg_off_rows, rows.data(), sizeof(float *) * U);
   memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * U);
+  const int lit_grid = fill_lane_queue(d, slot, U);
   K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
   std::fill(d->fresh.begin(), d->fresh.end(), 0);
   p.loglikes = nullptr; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr;
   p.lane_rows = reinterpret_cast<const float **>(slot.d + d->arg_off_rows);
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
-  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), U, st);
+  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
@@ -1311,13 +1373,14 @@ extern "C" int k3_decoder_advance_decoding_strided(k3_decoder *d, int32_t num_ut
   ro[0] = 0;
   for (int u = 0; u < U; u++) { const int T = h_lane_first[u] ? h_num_frames[u] : 0; ro[u + 1] = ro[u] + T; rows[u] = h_lane_first[u]; d->last_frames[u] += T; }
   memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * U);
+  const int lit_grid = fill_lane_queue(d, slot, U);
   K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
   std::fill(d->fresh.begin(), d->fresh.end(), 0);
   p.loglikes = nullptr; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr;
   p.lane_rows = reinterpret_cast<const float **>(slot.d + d->arg_off_rows);
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
-  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), U, st);
+  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));

@@ -101,6 +101,9 @@ struct DecParams {
   long long *prof;   // [nlanes x 16] cycle counters per phase (only with -DK3_DEC_PROF)
   // graph
   const int2 *offs; const ArcRec *arcs; const float *final_cost; const int *arc_ilabel; int start;
+  // per arc, what a token created through it needs to know about its state: {first arc of the destination, emitting arcs | eps arcs << 16 (65535 = more: look the
+  // state up)} -- derived from offs / arcs when the decoder is created, loaded NEXT TO the arc instead of behind it (literal_order's LDS-resident frames)
+  const int2 *dinfo;
   // config
   float beam, lattice_beam, beam_delta; int max_active, min_active;
   int frame_tokens_cap, frame_cands_cap, hash_mask;
@@ -143,6 +146,9 @@ struct DecParams {
   int *lt_par, *lt_rtmp;
   int2 *lt_rlist, *lt_rinfo;
   int4 *lt_cinfo, *lt_coffs, *lt_wrec, *lt_vis, *lt_btab;
+  // literal_order kernel: q_lanes = the call's lanes (those with frames or a fresh start), longest first, q_n of them: workgroup b decodes lane q_lanes[b] (null: lane b).
+  // q_head (work-queue builds, fewer workgroups than lanes): the cursor through which a workgroup takes its next entry.
+  int *q_head; const int *q_lanes; long long q_n;
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -296,16 +302,32 @@ __device__ __forceinline__ void wave_expand(const ArcRec *arcs, int beg, int deg
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - deg;
   const unsigned long long has_arcs = __ballot(deg > 0);
+  const int rel = beg - excl;      // (arc of position j of owner o = beg_o + (j - excl_o): one cross-lane read per arc instead of two)
   auto locate = [&](int j, int &arc, int &owner) {
     const int lo = wave_owner_of(j - lane, deg, excl, has_arcs);
-    const int obeg = __shfl(beg, lo), oexcl = __shfl(excl, lo);
-    arc = obeg + (j - oexcl); owner = lo;
+    arc = __shfl(rel, lo) + j; owner = lo;
   };
   for (int j0 = 0; j0 < total; j0 += 64) {
     int a, o; ArcRec r{};
     locate(j0 + lane, a, o);
     if (j0 + lane < total) r = arcs[a];
     f(j0 + lane < total, a, o, r);
+  }
+}
+
+// wave_expand with the destination record of every arc (DecParams::dinfo) loaded together with the arc
+template <typename F>
+__device__ __forceinline__ void wave_expand_d(const ArcRec *arcs, const int2 *dinfo, int beg, int deg, F &&f) {
+  const int lane = threadIdx.x & 63;
+  const int incl = wave_incl_sum_i32(deg);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int excl = incl - deg;
+  const unsigned long long has_arcs = __ballot(deg > 0);
+  for (int j0 = 0; j0 < total; j0 += 64) {
+    const int lo = wave_owner_of(j0, deg, excl, has_arcs);
+    const int a = __shfl(beg - excl, lo) + j0 + lane; ArcRec r{}; int2 di = make_int2(0, 0);
+    if (j0 + lane < total) { r = arcs[a]; di = dinfo[a]; }
+    f(j0 + lane < total, a, lo, r, di);
   }
 }
 

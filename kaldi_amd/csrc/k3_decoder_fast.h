@@ -100,12 +100,14 @@ __device__ __forceinline__ int block_excl_scan_f(In &&in, Out &&out, int n, int 
 // HashList order of n <= kFT tokens (label16[i] < M <= kFM unique creation labels, bkt16[i] = state % hash_size): emit(position, token, creation rank).
 // The phase structure of lit_hash_order_lds; the bucket table packs {bucket, smallest creation rank} into one word (equal buckets -> equal upper
 // halves, so the minimum over the word is the minimum over the ranks) and the members of a bucket are counted at its leader's rank.
-template <typename Emit>
+// kDense: the labels already ARE dense creation ranks (0 .. n-1, the frame's second pass: the first pass left the emitting tokens' ranks in label16 and the closure numbers its
+// tokens behind them), so the label bitmap, its prefix counts and their four barriers are skipped.
+template <bool kDense, typename Emit>
 __device__ __forceinline__ void fast_hash_order(Shared &sh, int n, unsigned M, const unsigned short *label16, const unsigned short *bkt16, unsigned *btab,
     unsigned *bm, unsigned short *wpre,
                                                 unsigned short *lead, unsigned short *grp, unsigned short *curs, Emit &&emit) {
   const int tid = threadIdx.x; constexpr int kPer = (kFT + kBlock - 1) / kBlock;
-  const int W = (int)((M + 31u) >> 5);
+  const int W = kDense ? 0 : (int)((M + 31u) >> 5);
   unsigned lab[kPer], bkt[kPer], lf[kPer], cnt[kPer]; int d[kPer], slot[kPer];
   for (int i = tid; i < kFB; i += kBlock) btab[i] = 0xFFFFFFFFu;
   for (int i = tid; i < W; i += kBlock) bm[i] = 0u;
@@ -113,15 +115,17 @@ __device__ __forceinline__ void fast_hash_order(Shared &sh, int n, unsigned M, c
 #pragma unroll
   for (int k = 0; k < kPer; k++) { const int i = tid + k * kBlock; lab[k] = 0; bkt[k] = 0; if (i < n) { lab[k] = label16[i]; bkt[k] = bkt16[i]; } }
   __syncthreads();
+  if (!kDense) {
 #pragma unroll
-  for (int k = 0; k < kPer; k++) { const int i = tid + k * kBlock; if (i < n) k3a_or(&bm[lab[k] >> 5], 1u << (lab[k] & 31)); }
-  __syncthreads();
-  block_excl_scan_f([&](int w) { return __popc(bm[w]); }, [&](int w, int ex) { wpre[w] = (unsigned short)ex; }, W, sh.redi);
+    for (int k = 0; k < kPer; k++) { const int i = tid + k * kBlock; if (i < n) k3a_or(&bm[lab[k] >> 5], 1u << (lab[k] & 31)); }
+    __syncthreads();
+    block_excl_scan_f([&](int w) { return __popc(bm[w]); }, [&](int w, int ex) { wpre[w] = (unsigned short)ex; }, W, sh.redi);
+  }
 #pragma unroll
   for (int k = 0; k < kPer; k++) {
     const int i = tid + k * kBlock;
     if (i < n) {
-      const unsigned l = lab[k]; d[k] = (int)wpre[l >> 5] + __popc(bm[l >> 5] & ((1u << (l & 31)) - 1u));
+      const unsigned l = lab[k]; d[k] = kDense ? (int)l : (int)wpre[l >> 5] + __popc(bm[l >> 5] & ((1u << (l & 31)) - 1u));
       const unsigned mine = (bkt[k] << 16) | (unsigned)d[k];
       unsigned h = (bkt[k] * 2654435761u) >> 21;      // 11 bits: kFB = 2048
       for (;;) {
@@ -248,12 +252,21 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   auto for_keys = [&](auto fn) { for (int i0 = 0; i0 < n_cur; i0 += kBlock) { const int i = i0 + tid; fn(i < n_cur, i < n_cur ? V_cost[i] : 0u); } };
   float cur_cutoff, ab;
   const float beam_cutoff = best + p.beam;
+  int deg_beam = -1;      // emitting arcs of the tokens within beam_cutoff (what pass A will count when the cutoff is the beam's, the usual case): summed in the counting pass
   if (p.max_active == 0x7FFFFFFF && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }
   else {
     const unsigned ebc = enc(beam_cutoff);
-    int c_lt = 0, c_le = 0;
-    for (int i = tid; i < n_cur; i += kBlock) { const unsigned k = V_cost[i]; c_lt += k < ebc; c_le += k <= ebc; }
-    { const int both = block_sum_i32((c_lt << 16) | c_le, sh); c_lt = both >> 16; c_le = both & 0xFFFF; }      // (n_cur <= kFT < 65536: one reduction for the two counts)
+    int c_lt = 0, c_le = 0, dsum = 0;
+    for (int i = tid; i < n_cur; i += kBlock) { const unsigned k = V_cost[i]; c_lt += k < ebc; c_le += k <= ebc; if (k <= ebc) dsum += (int)V_ne[i]; }
+    {      // (n_cur <= kFT < 65536: the two counts share a word; one barrier pair for both sums)
+      int both = wave_sum_i32((c_lt << 16) | c_le); dsum = wave_sum_i32(dsum);
+      __syncthreads();
+      if (lane == 0) { sh.redi[wave] = both; sh.hist[wave] = dsum; }
+      __syncthreads();
+      both = 0; dsum = 0;
+      for (int w = 0; w < nw; w++) { both += sh.redi[w]; dsum += sh.hist[w]; }
+      c_lt = both >> 16; c_le = both & 0xFFFF; deg_beam = dsum;
+    }
     int kth = -1;
     if (n_cur > p.max_active && c_lt > p.max_active) kth = p.max_active;
     else if (n_cur > p.min_active && p.min_active == 0) { ab = p.beam; cur_cutoff = beam_cutoff; }
@@ -269,9 +282,12 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   const long long nb = cur_base + n_cur; const long long link0 = sh.n_link;
   {      // the number of emitting arcs pass A would count (m_e below) from the per-token degrees: a frame whose labels cannot fit (the first frame of an utterance: a hundred
     // tokens with tens of thousands of arcs, walked by two wavefronts) leaves before that walk
-    int deg_sum = 0;
-    for (int r = tid; r < n_cur; r += kBlock) if (dec(V_cost[r]) <= cur_cutoff) deg_sum += (int)V_ne[r];
-    deg_sum = block_sum_i32(deg_sum, sh);
+    int deg_sum = deg_beam;
+    if (deg_beam < 0 || cur_cutoff != beam_cutoff) {
+      deg_sum = 0;
+      for (int r = tid; r < n_cur; r += kBlock) if (dec(V_cost[r]) <= cur_cutoff) deg_sum += (int)V_ne[r];
+      deg_sum = block_sum_i32(deg_sum, sh);
+    }
     if ((unsigned)deg_sum + (unsigned)cap_tokens > (unsigned)kFM) return -1;      // (uniform; nothing touched yet)
   }
   K3_FP(0);
@@ -388,6 +404,8 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
         else abort_now(kFaPool);
       }
       if (claimed) {      // the new token's arc ranges (requested above, arrived by now): neither the next frame nor an epsilon round starts with an offsets look-up
+        // (a per-arc destination record loaded beside every arc instead -- DecParams::dinfo, as the epsilon rounds do -- costs this pass 2 k cycles: a scattered 8-byte load per
+        // arc examined against two per token created)
         const int ne = oa.y - oa.x, nn = ob.x - oa.y;
         if (ne > 65535 || nn > 65535) abort_now(kFaDegree);
         N_abeg[idx] = (unsigned)oa.x; N_ne[idx] = (unsigned short)ne; N_nn[idx] = (unsigned short)nn;
@@ -429,7 +447,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
             }
           }
         }
-        wave_expand(p.arcs, beg, deg, [&](bool valid, int arc, int owner, const ArcRec &r) {
+        wave_expand_d(p.arcs, p.dinfo, beg, deg, [&](bool valid, int arc, int owner, const ArcRec &r, const int2 &di) {
           const unsigned ocb = __shfl(cb, owner); const int oti = __shfl(ti, owner); const float oc = dec(ocb);
           bool claimed = false, push = false, mk = false; int slot = -1, nxt = 0; float tot = 0.0f;
           cnt_eps += valid;
@@ -447,10 +465,9 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
             }
           }
           int idx = wave_append(claimed, &sh.n_next);
-          int2 oa = make_int2(0, 0), ob = make_int2(0, 0);
           if (claimed) {
             if (idx >= cap_tokens || nb + idx >= c.tcap) { fail(kFaTokens); idx = 0; }
-            else { c.tok_state[nb + idx] = nxt; oa = p.offs[nxt]; ob = p.offs[nxt + 1]; }
+            else c.tok_state[nb + idx] = nxt;
             __hip_atomic_store(&T_tix[slot], (unsigned short)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           if (mk && !claimed) {
@@ -487,9 +504,9 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
             } else fail(lp < c.lcap ? kFaLinks : kFaPool);
           }
           if (claimed) {
-            const int ne = oa.y - oa.x, nn = ob.x - oa.y;
-            if (ne > 65535 || nn > 65535) fail(kFaDegree);
-            N_abeg[idx] = (unsigned)oa.x; N_ne[idx] = (unsigned short)ne; N_nn[idx] = (unsigned short)nn;
+            const unsigned ne = (unsigned)di.y & 0xFFFFu, nn = (unsigned)di.y >> 16;
+            if (ne == 0xFFFFu || nn == 0xFFFFu) fail(kFaDegree);
+            N_abeg[idx] = (unsigned)di.x; N_ne[idx] = (unsigned short)ne; N_nn[idx] = (unsigned short)nn;
           }
         });
       }
@@ -566,10 +583,12 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   K3_FP(5);
   // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made
   unsigned short *ord1 = reinterpret_cast<unsigned short *>(arena + oOrd1);
-  fast_hash_order(sh, n_e, m_e, lab16, B16, reinterpret_cast<unsigned *>(arena + oO1_btab), reinterpret_cast<unsigned *>(arena + oO1_bm),
+  // (the emitting tokens' labels -- arc sequence numbers -- become their dense creation ranks 0 .. n_e-1: the pass has every label in registers by now, and
+  // the frame's second pass then needs no ranking of its own)
+  fast_hash_order<false>(sh, n_e, m_e, lab16, B16, reinterpret_cast<unsigned *>(arena + oO1_btab), reinterpret_cast<unsigned *>(arena + oO1_bm),
       reinterpret_cast<unsigned short *>(arena + oO1_wpre),
                   reinterpret_cast<unsigned short *>(arena + oO1_lead), reinterpret_cast<unsigned short *>(arena + oO1_grp), reinterpret_cast<unsigned short *>(arena + oO1_curs),
-                  [&](int r, int i, int) { ord1[r] = (unsigned short)i; });
+                  [&](int r, int i, int d) { ord1[r] = (unsigned short)i; lab16[i] = (unsigned short)d; });
   K3_FP(6);
   // the initial queue: the tokens of that list that can expand (closure ids), consumed from its back
   unsigned short *iq = reinterpret_cast<unsigned short *>(arena + oIq), *dense = reinterpret_cast<unsigned short *>(arena + oDense);
@@ -658,13 +677,13 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
     return -1;
   }
   for (int j = tid; j < n_iq; j += kBlock) {
-    const int seg0 = rinfo[2 * (n_iq - 1 - j)], cnt = rinfo[2 * (n_iq - 1 - j) + 1]; const unsigned base = m_e + (unsigned)dense[j];
+    const int seg0 = rinfo[2 * (n_iq - 1 - j)], cnt = rinfo[2 * (n_iq - 1 - j) + 1]; const unsigned base = (unsigned)n_e + (unsigned)dense[j];      // (dense ranks: behind the emitting tokens')
     for (int t = 0; t < cnt; t++) lab16[c2t[clist[seg0 + t]]] = (unsigned short)(base + (unsigned)t);
   }
   __syncthreads();
   K3_FP(8);
   // ---- the frame's final HashList order = the next frame's visit order, written where the next frame reads it; creation order for the final-frame sweeps
-  fast_hash_order(sh, n, m_e + (unsigned)created, lab16, B16, reinterpret_cast<unsigned *>(arena + oO2_btab), reinterpret_cast<unsigned *>(arena + oO2_bm),
+  fast_hash_order<true>(sh, n, (unsigned)n, lab16, B16, reinterpret_cast<unsigned *>(arena + oO2_btab), reinterpret_cast<unsigned *>(arena + oO2_bm),
       reinterpret_cast<unsigned short *>(arena + oO2_wpre),
                   reinterpret_cast<unsigned short *>(arena + oO2_lead), reinterpret_cast<unsigned short *>(arena + oO2_grp), reinterpret_cast<unsigned short *>(arena + oO2_curs),
                   [&](int r, int i, int d) { V_cost[r] = N_cost[i]; V_abeg[r] = N_abeg[i]; V_ne[r] = N_ne[i]; V_tok[r] = (unsigned short)i; ord_nxt[r] = i; q.by_ins[d] = i; });

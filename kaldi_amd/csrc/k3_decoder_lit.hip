@@ -8,6 +8,9 @@
 #ifndef K3_LIT_WPE
 #define K3_LIT_WPE 4      // two 512-thread workgroups per CU (each within 80 KB of LDS): 4 waves per SIMD = 128 VGPRs per lane (overridable for register-pressure experiments)
 #endif
+#ifndef K3_LIT_QUEUE
+#define K3_LIT_QUEUE 0     // 1: a workgroup decodes lane after lane from the call's work-queue (k3_decoder_config.resident_lanes); see k3_decode_forward_literal_kernel
+#endif
 #include "k3_decoder_dev.h"
 
 namespace {
@@ -15,13 +18,16 @@ namespace {
 #include "k3_decoder_literal.h"
 }  // namespace
 
-extern "C" int k3_lit_fast_tokens() { return kFT; }      // capacity of the LDS-resident frame path (tokens of a frame)
+extern "C" int k3_lit_fast_tokens() { return kFT; }
+extern "C" int k3_lit_has_queue() { return K3_LIT_QUEUE; }      // capacity of the LDS-resident frame path (tokens of a frame)
+// (exclusive launches ask for a little more than half of a CU's 160 KB: no second lane fits beside the workgroup, another kernel's workgroups do)
+constexpr size_t kLitExclusiveLds = 82 * 1024;
 extern "C" int k3_lit_forward_prepare() {
-  return hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitArena) == hipSuccess ? 0 : -1;
+  return hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLitArena > kLitExclusiveLds ? kLitArena : kLitExclusiveLds)) == hipSuccess ? 0 : -1;
 }
-extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nlanes, hipStream_t stream) {
+extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nworkgroups, int exclusive, hipStream_t stream) {
   DecParams p; static_assert(sizeof(DecParams) % 8 == 0, "DecParams is copied between translation units");
   if (params_bytes != sizeof(DecParams)) { fprintf(stderr, "k3_lit_forward_launch: DecParams size mismatch\n"); abort(); }
   memcpy(&p, params, sizeof(p));
-  hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(nlanes), dim3(kBlock), kLitArena, stream, p);
+  hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(nworkgroups), dim3(kBlock), exclusive && kLitExclusiveLds > kLitArena ? kLitExclusiveLds : kLitArena, stream, p);
 }

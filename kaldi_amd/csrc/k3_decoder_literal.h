@@ -160,8 +160,7 @@ __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int 
   for (int j0 = 0; j0 < total; j0 += 64) {
     const int j = j0 + lane;
     const int lo = wave_owner_of(j0, deg, excl, has_arcs);
-    const int obeg = __shfl(beg, lo), oexcl = __shfl(excl, lo);
-    const int a = obeg + (j - oexcl); ArcRec r{};
+    const int a = __shfl(beg - excl, lo) + j; ArcRec r{};
     if (j < total) r = arcs[a];
     f(j < total, j, a, lo, r);
   }
@@ -203,20 +202,23 @@ struct LitLane {      // this lane's slices of the literal_order scratch
 // (The path of frames too large for lit_hash_order_lds.)  The buckets -- hash_size is unbounded, a frame touches at most n of them -- live in an
 // open-addressing table of 16 B records {bucket, smallest creation rank, members, fill cursor} sized to the frame (2n .. 4n slots): one
 // cache line per token and pass in a region that scales with the frame, where per-bucket arrays cost three lines spread over hash_size entries.
-__device__ K3_COLD_INLINE void lit_hash_order(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, long long &lt_last__) {
+// dense_in (every form below): the labels already are dense creation ranks 0 .. n-1 (the frame's second pass), no ranking needed; relabel (the first pass): leave the
+// tokens' dense ranks in q.label for that second pass.
+__device__ K3_COLD_INLINE void lit_hash_order(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool dense_in, bool relabel,
+                                              long long &lt_last__) {
   const int tid = threadIdx.x;
-  const int W = (int)((M + 31u) >> 5);
+  const int W = dense_in ? 0 : (int)((M + 31u) >> 5);
   unsigned tsize = 1024; while (tsize < 2u * (unsigned)n) tsize <<= 1;      // <= 2 * next_pow2(cap) = the table's capacity
   const unsigned tmask = tsize - 1; int4 *tab = q.btab; int *slot_of = q.rtmp;
   for (unsigned s_ = tid; s_ < tsize; s_ += kBlock) tab[s_] = make_int4(-1, -1, 0, 0);
-  for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); k3a_or(&q.bm[l >> 5], 1u << (l & 31)); }
+  if (!dense_in) for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); k3a_or(&q.bm[l >> 5], 1u << (l & 31)); }
   __syncthreads();
   K3_LS(0);
-  block_excl_scan([&](int w) { return __popc(K3_ALD(&q.bm[w])); }, q.wpre, W, sh.redi);
+  if (!dense_in) block_excl_scan([&](int w) { return __popc(K3_ALD(&q.bm[w])); }, q.wpre, W, sh.redi);
   K3_LS(1);
   for (int i = tid; i < n; i += kBlock) {
-    const unsigned l = K3_ALD(&q.label[i]); const unsigned wd = K3_ALD(&q.bm[l >> 5]);
-    const int d = (int)(q.wpre[l >> 5] + (unsigned)__popc(wd & ((1u << (l & 31)) - 1u)));
+    const unsigned l = K3_ALD(&q.label[i]); int d = (int)l;
+    if (!dense_in) { const unsigned wd = K3_ALD(&q.bm[l >> 5]); d = (int)(q.wpre[l >> 5] + (unsigned)__popc(wd & ((1u << (l & 31)) - 1u))); }
     q.dense[i] = d; q.by_ins[d] = i;
     const unsigned b = (unsigned)st[i] % hash_size; unsigned h = (b * 2654435761u) & tmask;
     for (;;) {
@@ -247,8 +249,9 @@ __device__ K3_COLD_INLINE void lit_hash_order(const LitLane &q, Shared &sh, int 
   }
   __syncthreads();
   K3_LS(5);
-  for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); K3_AST(&q.bm[l >> 5], 0u); }      // the label bitmap back to its idle pattern
+  if (!dense_in) for (int i = tid; i < n; i += kBlock) { const unsigned l = K3_ALD(&q.label[i]); K3_AST(&q.bm[l >> 5], 0u); }      // the label bitmap back to its idle pattern
   __syncthreads();
+  if (relabel) { for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], (unsigned)q.dense[i]); __syncthreads(); }
   K3_LS(6);
 }
 
@@ -261,10 +264,10 @@ __device__ K3_COLD_INLINE void lit_hash_order(const LitLane &q, Shared &sh, int 
 constexpr int kHoN = 2048, kHoM = 16384;
 constexpr size_t kHoLds = (size_t)(kHoM / 32) * 4 + (size_t)(kHoM / 32) * 2 + 2 * (size_t)kHoN * 2;
 __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins,
-                                                   char *arena, int *tab, long long &lt_last__) {
+                                                   bool dense_in, bool relabel, char *arena, int *tab, long long &lt_last__) {
   static_assert(kHoN <= 4 * kBlock && kHoM / 32 <= kBlock && 2 * kHoN <= kHL, "one pass per phase; table at most half full");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
-  const int W = (int)((M + 31u) >> 5);
+  const int W = dense_in ? 0 : (int)((M + 31u) >> 5);
   unsigned *s_bm = reinterpret_cast<unsigned *>(arena);
   unsigned short *s_wpre = reinterpret_cast<unsigned short *>(s_bm + kHoM / 32), *s_lead = s_wpre + kHoM / 32, *s_grp = s_lead + kHoN;
   unsigned *b_key = reinterpret_cast<unsigned *>(tab), *b_first = b_key + kHL, *b_cnt = b_first + kHL;
@@ -274,25 +277,28 @@ __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh,
 #pragma unroll
   for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) { lab[k] = K3_ALD(&q.label[i]); bkt[k] = (unsigned)st[i] % hash_size; } }
   __syncthreads();
+  if (!dense_in) {
 #pragma unroll
-  for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) atomicOr(&s_bm[lab[k] >> 5], 1u << (lab[k] & 31)); }
-  __syncthreads();
-  K3_LS(0);
-  {      // exclusive prefix count over the bitmap words (W <= kBlock: one word per thread)
-    const int x = tid < W ? __popc(s_bm[tid]) : 0; const int incl = wave_incl_scan(x);
-    if (lane == 63) sh.redi[wave] = incl;
+    for (int k = 0; k < 4; k++) { const int i = tid + k * kBlock; if (i < n) atomicOr(&s_bm[lab[k] >> 5], 1u << (lab[k] & 31)); }
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < nw; w++) if (w < wave) woff += sh.redi[w];
-    if (tid < W) s_wpre[tid] = (unsigned short)(woff + incl - x);
-    __syncthreads();
+    K3_LS(0);
+    {      // exclusive prefix count over the bitmap words (W <= kBlock: one word per thread)
+      const int x = tid < W ? __popc(s_bm[tid]) : 0; const int incl = wave_incl_scan(x);
+      if (lane == 63) sh.redi[wave] = incl;
+      __syncthreads();
+      int woff = 0;
+      for (int w = 0; w < nw; w++) if (w < wave) woff += sh.redi[w];
+      if (tid < W) s_wpre[tid] = (unsigned short)(woff + incl - x);
+      __syncthreads();
+    }
   }
   K3_LS(1);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int i = tid + k * kBlock;
     if (i < n) {
-      const unsigned l = lab[k]; d[k] = (int)s_wpre[l >> 5] + __popc(s_bm[l >> 5] & ((1u << (l & 31)) - 1u));
+      const unsigned l = lab[k]; d[k] = dense_in ? (int)l : (int)s_wpre[l >> 5] + __popc(s_bm[l >> 5] & ((1u << (l & 31)) - 1u));
+      if (relabel) K3_AST(&q.label[i], (unsigned)d[k]);
       unsigned h = (bkt[k] * 2654435761u) >> 20;      // 12 bits: kHL = 4096 slots
       for (;;) { const unsigned old = atomicCAS(&b_key[h], 0xFFFFFFFFu, bkt[k]); if (old == 0xFFFFFFFFu || old == bkt[k]) break; h = (h + 1) & (kHL - 1); }
       slot[k] = (int)h;
@@ -363,9 +369,9 @@ constexpr size_t kLitTabBytes = (size_t)3 * kHL * 4, kLitMarkBytes = (size_t)3 *
 constexpr int kHmN = 3072, kHmM = 32768, kHmB = 4096;
 constexpr size_t kHmLds = (size_t)kHmB * 4 + 7 * ((size_t)kHmN * 2 + 8) + (size_t)kHmM / 8 + (size_t)kHmM / 32 * 2;
 __device__ K3_COLD_INLINE bool lit_hash_order_mid(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size,
-    int *order_out, bool write_by_ins) {
+    int *order_out, bool write_by_ins, bool dense_in, bool relabel) {
   if (n > kHmN || M > (unsigned)kHmM || hash_size > 65535u) return false;
-  const int tid = threadIdx.x; const int W = (int)((M + 31u) >> 5);
+  const int tid = threadIdx.x; const int W = dense_in ? 0 : (int)((M + 31u) >> 5);
   unsigned *btab = reinterpret_cast<unsigned *>(arena); char *a_ = arena + (size_t)kHmB * 4; constexpr size_t kCol = (size_t)kHmN * 2 + 8;
   unsigned short *lab16 = reinterpret_cast<unsigned short *>(a_), *bkt16 = reinterpret_cast<unsigned short *>(a_ + kCol),
       *dense16 = reinterpret_cast<unsigned short *>(a_ + 2 * kCol),
@@ -378,12 +384,15 @@ __device__ K3_COLD_INLINE bool lit_hash_order_mid(const LitLane &q, Shared &sh, 
   for (int i = tid; i < (n + 1) / 2 + 1; i += kBlock) { reinterpret_cast<unsigned *>(lead)[i] = 0u; reinterpret_cast<unsigned *>(curs)[i] = 0u; }
   for (int i = tid; i < n; i += kBlock) { lab16[i] = (unsigned short)K3_ALD(&q.label[i]); bkt16[i] = (unsigned short)((unsigned)st[i] % hash_size); }
   __syncthreads();
-  for (int i = tid; i < n; i += kBlock) { const unsigned l = lab16[i]; k3a_or(&bm[l >> 5], 1u << (l & 31)); }
-  __syncthreads();
-  block_excl_scan_f([&](int w) { return __popc(bm[w]); }, [&](int w, int ex) { wpre[w] = (unsigned short)ex; }, W, sh.redi);
+  if (!dense_in) {
+    for (int i = tid; i < n; i += kBlock) { const unsigned l = lab16[i]; k3a_or(&bm[l >> 5], 1u << (l & 31)); }
+    __syncthreads();
+    block_excl_scan_f([&](int w) { return __popc(bm[w]); }, [&](int w, int ex) { wpre[w] = (unsigned short)ex; }, W, sh.redi);
+  }
   for (int i = tid; i < n; i += kBlock) {
-    const unsigned l = lab16[i], b = bkt16[i]; const unsigned d = (unsigned)wpre[l >> 5] + (unsigned)__popc(bm[l >> 5] & ((1u << (l & 31)) - 1u));
+    const unsigned l = lab16[i], b = bkt16[i]; const unsigned d = dense_in ? l : (unsigned)wpre[l >> 5] + (unsigned)__popc(bm[l >> 5] & ((1u << (l & 31)) - 1u));
     dense16[i] = (unsigned short)d; if (write_by_ins) q.by_ins[d] = i;
+    if (relabel) K3_AST(&q.label[i], d);
     const unsigned mine = (b << 16) | d; unsigned h = (b * 2654435761u) >> 20;      // 12 bits: kHmB = 4096
     for (;;) {
       unsigned w = lds_ld(&btab[h]);
@@ -435,7 +444,7 @@ constexpr size_t kHbLdsA = (size_t)kHbW * 4 + (size_t)kHbW * 2, kHbLdsB = (size_
 static_assert(kHbLdsP + 2 * kHbMaxP * 4 <= kLitGeneralLds, "the large-frame hash order works in the general path's arena");
 static_assert(kHbMaxPart <= 4 * kBlock, "a partition's records fit the registers of one pass");
 __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, char *arena, int n, unsigned M, const int *st, unsigned hash_size,
-    int *order_out, bool write_by_ins,
+    int *order_out, bool write_by_ins, bool dense_in, bool relabel,
                                                   long long &lt_last__) {
   const int tid = threadIdx.x;
   int *dense = q.dense, *bkt = q.grp, *lr = q.rtmp; unsigned *lead = q.lead; int2 *rec = q.rlist;
@@ -446,7 +455,23 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
   auto part_of = [&](unsigned h) { return lgp ? (int)(h >> (32 - lgp)) : 0; };
   auto start_of = [&](unsigned h) { return (h >> (20 - lgp)) & (unsigned)(kHbT - 1); };
   if (tid < kHbMaxP) pcnt[tid] = 0;
-  {      // ---- creation ranks (label ranges of kHbW words); the first range's sweep also computes the buckets and counts the partitions
+  if (dense_in) {      // ---- the labels are the creation ranks: one sweep for the ranks, the buckets and the partition counts
+    __syncthreads();
+    for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {
+      unsigned l[4]; int s_[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int i = i0 + k * kBlock; l[k] = 0u; s_[k] = 0; if (i < n) { l[k] = K3_ALD(&q.label[i]); s_[k] = st[i]; } }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = i0 + k * kBlock;
+        if (i < n) {
+          dense[i] = (int)l[k]; if (write_by_ins) q.by_ins[l[k]] = i;
+          const unsigned b = (unsigned)s_[k] % hash_size; bkt[i] = (int)b; lead[i] = 0u; k3a_add(&pcnt[part_of(b * 2654435761u)], 1);
+        }
+      }
+    }
+    __syncthreads();
+  } else {      // ---- creation ranks (label ranges of kHbW words); the first range's sweep also computes the buckets and counts the partitions
     unsigned *bm = reinterpret_cast<unsigned *>(arena); unsigned short *wpre = reinterpret_cast<unsigned short *>(bm + kHbW);
     int base = 0;
     for (unsigned l0 = 0; l0 < M; l0 += (unsigned)kHbW * 32u) {
@@ -572,6 +597,7 @@ __device__ K3_COLD_INLINE bool lit_hash_order_big(const LitLane &q, Shared &sh, 
     for (int k = 0; k < 4; k++) { const int j = j0 + k * kBlock; if (j < n) order_out[o[k] + ((unsigned)v[k] & 0xFFFFu)] = t_[k]; }
   }
   __syncthreads();
+  if (relabel) { for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], (unsigned)dense[i]); __syncthreads(); }
   K3_LS(5);
   return true;
 }
@@ -836,9 +862,30 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
   char *const smem_raw = arena + kLitTabBytes + kLitMarkBytes + kLitAuxBytes;       // replay arrays of a small frame
   static_assert(2 * kWlLds * sizeof(unsigned short) <= 1024 * sizeof(int) && kHL / 2 <= 2 * 1024, "s_aux layout");
   unsigned short (*const s_lwl)[kWlLds] = reinterpret_cast<unsigned short (*)[kWlLds]>(s_aux); int *const s_own = s_aux + 1024;
-  const int L = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nw = kBlock / 64;
+  __shared__ LanePool s_pool; __shared__ int s_qi;
+  // Which lane this workgroup decodes: entry blockIdx.x of the call's lane list -- the lanes sorted by their number of frames, longest first, so that the two workgroups of a
+  // CU (b and b + 256 of a 512-lane launch) are a long and a short utterance and the long one has the CU to itself once the short one is done (a ragged batch in
+  // generation order: 144 ms per launch, sorted: 83 ms) -- or, builds with -DK3_LIT_QUEUE=1 and fewer workgroups than lanes (k3_decoder_config.resident_lanes), entry after
+  // entry of that list through an atomic cursor until it is exhausted.  (The loop costs the kernel 165 spilled vector registers, +14 % time: measured, not shipped.)
+#if K3_LIT_QUEUE
+#define K3_LANE_DONE continue
+  for (int q_it = 0;; q_it++) {
+  int L;
+  if (p.q_head) {
+    __syncthreads();      // (the previous lane's last readers of sh / s_qi are done)
+    if (tid == 0) s_qi = __hip_atomic_fetch_add(p.q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int k_ = s_qi;
+    if (k_ >= (int)p.q_n) break;
+    L = __builtin_amdgcn_readfirstlane(p.q_lanes[k_]);
+  } else { if (q_it) break; L = p.q_lanes ? __builtin_amdgcn_readfirstlane(p.q_lanes[blockIdx.x]) : (int)blockIdx.x; }
+#else
+#define K3_LANE_DONE return
+  {
+  const int L = p.q_lanes ? __builtin_amdgcn_readfirstlane(p.q_lanes[blockIdx.x]) : (int)blockIdx.x; (void)s_qi;
+#endif
   const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
-  __shared__ LanePool s_pool;
   LanePool lp = k3_uniform_pool(p.pools[L]);      // this lane's token / link pools (grow_lane_pools moves them when the lane outgrows its reservation)
   int *tok_state = lp.tok_state; unsigned *tok_cost = lp.tok_cost; Link *links = lp.links; int *link_arc = lp.link_arc;
   Slot *hash = p.hash + (long long)L * (p.hash_mask + 1);
@@ -878,7 +925,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
 #pragma unroll
   for (int k = 0; k < kCurRegs; k++) { creg[k] = kEncMax; sreg[k] = 0; }
   const bool fresh = p.fresh[L] != 0;
-  if (!fresh && T == 0) return;
+  if (!fresh && T == 0) K3_LANE_DONE;
   if (fresh) {
     if (p.info[L].status < 0) {      // a failed utterance left the scratch in an unknown state: back to the idle patterns
       for (unsigned i = tid; i <= mask; i += kBlock) { Slot *s_ = &hash[i]; K3_AST(&s_->cost, kEncMax); K3_AST(&s_->stamp, 0); K3_AST(&s_->tok, -1); K3_AST(&s_->key, kEmpty); }
@@ -897,7 +944,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     __syncthreads();
   } else {
     const LaneInfo &li = p.info[L];
-    if (li.status != kStOk) return;
+    if (li.status != kStOk) K3_LANE_DONE;
     f0 = li.num_frames; cur_base = li.cur_base; n_cur = li.n_cur; max_frame = li.max_frame_tokens; sel = li.order_sel; hash_size = (unsigned)li.hash_size;
     if (tid == 0) {
       sh.n_link = li.n_links;
@@ -1137,10 +1184,12 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     K3_LT(8); K3_LQ(7);
     // ---- the list ProcessNonemitting fills its queue from (:845-850): HashList order of the tokens ProcessEmitting made (their labels and states are
     // untouched by the closure).  Computed here, where the level-1 table's LDS is free for the bucket table of the pass.
-    if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, smem_raw, s_tab, lt_last__);
-    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false) &&
-        (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, lt_last__)))
-      lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, lt_last__);
+    // (it leaves the emitting tokens' DENSE creation ranks 0 .. n_e-1 in q.label; the closure numbers its tokens n_e .. n-1 behind them, so the frame's second pass has
+    // every rank at hand)
+    if (n_e <= kHoN && m_e <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, false, true, smem_raw, s_tab, lt_last__);
+    else if (!lit_hash_order_mid(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, false, true) &&
+        (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, false, true, lt_last__)))
+      lit_hash_order(q, sh, n_e, m_e, tok_state + nb, hash_size, ord_nxt, false, true, lt_last__);
     K3_LT(6); K3_LQ(8);
     // closure ids of the involved tokens and first arc slots of the sources: one pass
     const int4 tot2 = block_excl_scan4([&](int i) { const int pc = K3_ALD(&q.rown[i]); return make_int4((pc > 0 || K3_ALD(&q.rflag[i]) != 0) ? 1 : 0, pc, 0, 0); },
@@ -1261,11 +1310,11 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     if (p.literal & 1) {
       if (rmode == 0) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab) + 2 * kHL,
           reinterpret_cast<const int4 *>(s_tab), reinterpret_cast<const int2 *>(smem_raw),
-                                                            reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, s_aux, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
+                                                            reinterpret_cast<unsigned *>(s_tab) + 2 * kHL + kRN, s_aux, n_cid, n_arc, n_iq, (unsigned)n_e, accept, lt_last__);
       else if (rmode == 1) created_total = lit_replay_components(p, q, sh, &ls.use_lds, reinterpret_cast<float *>(s_tab), (const int4 *)q.meta,
-          (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(smem_raw), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
+          (const int2 *)q.arcs2, reinterpret_cast<unsigned *>(smem_raw), q.par, n_cid, n_arc, n_iq, (unsigned)n_e, accept, lt_last__);
       else created_total = lit_replay_components(p, q, sh, &ls.use_lds, q.rcost, (const int4 *)q.meta, (const int2 *)q.arcs2,
-          reinterpret_cast<unsigned *>(q.rflag), q.par, n_cid, n_arc, n_iq, m_e, accept, lt_last__);
+          reinterpret_cast<unsigned *>(q.rflag), q.par, n_cid, n_arc, n_iq, (unsigned)n_e, accept, lt_last__);
 #if defined(K3_LIT_PROF) && K3_LIT_PROF == 1
       if (tid == 0 && created_total < 0) sh.prof[5] += 1;
 #endif
@@ -1296,7 +1345,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       __syncthreads();
       if (block_err(sh)) break;
       created_total = ls.n_created;
-      for (int k = tid; k < created_total; k += kBlock) K3_AST(&q.label[q.c2t[clist[k]]], m_e + (unsigned)k);      // creation labels of the closure's tokens
+      for (int k = tid; k < created_total; k += kBlock) K3_AST(&q.label[q.c2t[clist[k]]], (unsigned)n_e + (unsigned)k);      // creation ranks of the closure's tokens
     }
     K3_LT(9); K3_LQ(12);
 #ifdef K3_LIT_DEBUG
@@ -1305,7 +1354,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
 #endif
 #ifdef K3_LIT_STATS      // size statistics of the frames a fast (LDS-resident) path could take: n_cur and n <= K3_LIT_STATS tokens
     if (tid == 0 && f >= 0 && n_cur <= K3_LIT_STATS && n <= K3_LIT_STATS) {
-      const long long el = eps_l1 - eps_l0; long long *P = p.prof + blockIdx.x * 16;
+      const long long el = eps_l1 - eps_l0; long long *P = p.prof + L * 16;
       auto mx = [&](int k, long long v) { if (v > P[k]) P[k] = v; };
       mx(0, n_cid); mx(1, n_arc); mx(2, n_iq); mx(3, el); mx(4, (long long)m_e + created_total);
       P[5] += 1;
@@ -1325,11 +1374,10 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     if (block_err(sh)) break;
     __syncthreads();
     // ---- the frame's final HashList order (next frame's visit order; creation order for the final-frame sweeps)
-    if (n <= kHoN && m_e + (unsigned)created_total <= (unsigned)kHoM) lit_hash_order_lds(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size,
-        ord_nxt, true, smem_raw, s_tab, lt_last__);
-    else if (!lit_hash_order_mid(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true) &&
-             (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, true, lt_last__)))
-      lit_hash_order(q, sh, n, m_e + (unsigned)created_total, tok_state + nb, hash_size, ord_nxt, lt_last__);
+    if (n <= kHoN) lit_hash_order_lds(q, sh, n, (unsigned)n, tok_state + nb, hash_size, ord_nxt, true, true, false, smem_raw, s_tab, lt_last__);
+    else if (!lit_hash_order_mid(q, sh, arena, n, (unsigned)n, tok_state + nb, hash_size, ord_nxt, true, true, false) &&
+             (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n, (unsigned)n, tok_state + nb, hash_size, ord_nxt, true, true, false, lt_last__)))
+      lit_hash_order(q, sh, n, (unsigned)n, tok_state + nb, hash_size, ord_nxt, true, false, lt_last__);
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     K3_LT(10); K3_LQ(13);
     // ---- publish the frame: final costs into the pool, empty table, idle labels
@@ -1353,10 +1401,10 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
   }
   __syncthreads();
 #ifdef K3_LIT_PROF
-  if (tid < 16) p.prof[blockIdx.x * 16 + tid] += sh.prof[tid];
+  if (tid < 16) p.prof[L * 16 + tid] += sh.prof[tid];
 #elif defined(K3_FAST_PROF)
   if (tid == 0) {
-    long long *P = p.prof + blockIdx.x * 16;
+    long long *P = p.prof + L * 16;
     for (int k = 0; k < 12; k++) P[k] += fs.prof[k];
     P[12] += n_fast;
     P[13] += n_gaveup;
@@ -1365,7 +1413,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
   }
 #elif !defined(K3_LIT_STATS)
   if (tid == 0) {
-    long long *P = p.prof + blockIdx.x * 16;
+    long long *P = p.prof + L * 16;
     for (int k = 0; k < 11; k++) P[k] += why[k];
     P[12] += n_fast;
     P[13] += n_gaveup;
@@ -1380,6 +1428,8 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     li.status = sh.err ? sh.err : status; li.num_frames = f0 + T; li.reached_final = 0; li.out_states = 0; li.out_arcs = 0;
     li.cur_base = cur_base; li.n_cur = n_cur; li.n_order_sensitive = (long long)sh.n_os; li.hash_size = (int)hash_size; li.order_sel = sel;
   }
+  }      // (next lane of the work-queue)
+#undef K3_LANE_DONE
 }
 
 #endif  // K3_LIT_FORWARD

@@ -54,7 +54,7 @@ class DecoderConfig(ctypes.Structure):
     _fields_ = [("beam", ctypes.c_float), ("max_active", ctypes.c_int32), ("min_active", ctypes.c_int32), ("lattice_beam", ctypes.c_float),
                 ("beam_delta", ctypes.c_float), ("frame_tokens_cap", ctypes.c_int32), ("frame_cands_cap", ctypes.c_int32),
                 ("lane_tokens_cap", ctypes.c_int64), ("lane_links_cap", ctypes.c_int64), ("literal_order", ctypes.c_int32), ("hash_ratio", ctypes.c_float), ("fast_frame_tokens", ctypes.c_int32),
-                ("spare_pool_bytes", ctypes.c_int64)]
+                ("spare_pool_bytes", ctypes.c_int64), ("resident_lanes", ctypes.c_int32), ("resident_exclusive", ctypes.c_int32)]
 
 WINDOW_TYPES = {"hanning": 0, "sine": 1, "hamming": 2, "povey": 3, "rectangular": 4, "blackman": 5}
 
@@ -73,6 +73,7 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     L.k3_last_error.restype = ctypes.c_char_p
+    L.k3_build_id.restype = ctypes.c_char_p
     L.k3_feat_plan_create.argtypes = [ctypes.POINTER(FeatOpts), ctypes.POINTER(vp)]
     L.k3_feat_plan_destroy.argtypes = [vp]; L.k3_feat_plan_destroy.restype = None
     L.k3_feat_dim.argtypes = [vp]; L.k3_feat_dim.restype = i32
@@ -168,6 +169,28 @@ def load():
 class ChainTrainingOpts(ctypes.Structure):
     """k3_chain_training_opts (include/k3hip.h) = chain::ChainTrainingOptions"""
     _fields_ = [("l2_regularize", ctypes.c_float), ("out_of_range_regularize", ctypes.c_float), ("leaky_hmm_coefficient", ctypes.c_float), ("apply_out_of_range_penalty", ctypes.c_int32)]
+
+def source_digest():
+    """The digest k3_build_id() carries, recomputed from the sources next to this file (kaldi_amd/csrc/Makefile: every *.hip / *.h of csrc in byte order of their
+    names, then include/k3hip.h; first 16 hex digits of the SHA-256 of the concatenation)."""
+    import glob, hashlib
+    d = os.path.join(HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")), key=lambda f: os.path.basename(f).encode())
+    files.append(os.path.join(os.path.dirname(HERE), "include", "k3hip.h"))
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh: h.update(fh.read())
+    return h.hexdigest()[:16]
+
+def build_id():
+    return load().k3_build_id().decode()
+
+def check_provenance():
+    """(build id of the mapped library, digest of the shipped sources); raises K3Error when the library was not built from these sources."""
+    bid, dig = build_id(), source_digest()
+    if not bid.endswith("+" + dig):
+        raise K3Error(f"{LIB_PATH} was built from other sources: its build id is {bid}, the sources here digest to {dig} (run make -C kaldi_amd/csrc)")
+    return bid, dig
 
 def check(status):
     if status != 0:
