@@ -159,6 +159,47 @@ def _cpu_worker(job):
             except Exception as e: cmp2.append({"error": repr(e)})
     return len(utts) * utt_seconds, (t2 - t0) + dec_s, (t1 - t0, t2 - t1, dec_s), cmp_, cmp2, keep_
 
+def e2e_gate(flips_gpu, flips_self, utterances, alpha=0.01):
+    """The end-to-end parity gate as a stated two-sample test (SURVEY 8d gate 4, "at WER parity"; what DecodeUtteranceLatticeFaster's best path is compared on,
+    decoder/decoder-wrappers.cc:322-373).  Both chains are compared with the SAME reference run on the SAME utterances, so the samples are paired: flips_gpu = utterances
+    whose best path differs between the GPU chain and the reference chain, flips_self = utterances whose best path differs between the reference chain and the reference
+    chain run a second time (nnet3-compute on another MKL code path).  Exact one-sided McNemar test on the discordant pairs: b = flipped by the GPU chain only, c = flipped
+    by the second reference run only; under H0 "the GPU chain flips no more often than the reference does against itself" b ~ Binomial(b + c, 1/2); p = P(X >= b).
+    The gate passes when p >= alpha: no evidence at level alpha that the GPU chain is further from the reference than the reference is from itself.  Independent of the
+    sample size (128 or 512 utterances give the same verdict for the same rates), unlike a threshold of "self rate - 1 / utterances"."""
+    from math import comb
+    g, s_ = set(flips_gpu), set(flips_self)
+    b, c = len(g - s_), len(s_ - g)
+    n = b + c
+    p = 1.0 if n == 0 else sum(comb(n, k) for k in range(b, n + 1)) / float(2 ** n)
+    # what the test could have seen: the smallest b that would have failed at this c
+    b_fail = next((bb for bb in range(0, 10 * (c + 8)) if sum(comb(bb + c, k) for k in range(bb, bb + c + 1)) / float(2 ** (bb + c)) < alpha), None)
+    return {"test": "exact one-sided McNemar test on paired per-utterance best-path flips (GPU chain vs reference) against (reference vs itself)", "alpha": alpha,
+            "utterances": int(utterances), "flips_gpu": len(g), "flips_self": len(s_), "flipped_by_both": len(g & s_), "gpu_only_b": b, "self_only_c": c, "p_value": p,
+            "pass": bool(p >= alpha), "gpu_only_flips_that_would_fail": b_fail,
+            "note": "pass = p_value >= alpha; H0: the GPU chain's best path differs from the reference's no more often than the reference's own second run does"}
+
+def _ctrl_worker(job):
+    """control (ii) of the end-to-end gate: the GPU chain's FEATURES through the reference's nnet3-compute and LatticeFasterDecoder; returns the utterances whose best
+    path differs from the all-reference chain's"""
+    from oracle import kaldi_io as kio, lattice_oracle as lo, ref_decoder as rd
+    from kaldi_amd import synth
+    items, model_path, graph, num_pdfs = job      # items: [(utt, GPU features, (reference features, log-likelihoods, lattice))]
+    bindir = os.path.join(ROOT, "oracle", "_ref", "bin")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mkl"), MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+    flips = []
+    with tempfile.TemporaryDirectory() as td:
+        kio.write_ark(f"{td}/f.ark", {f"u{u}": f for u, f, _ in items})
+        subprocess.check_call([f"{bindir}/nnet3-compute", "--use-gpu=no", "--frame-subsampling-factor=3", "--frames-per-chunk=150", model_path,
+                 f"ark:{td}/f.ark", f"ark:{td}/o.ark"], env=env, stderr=subprocess.DEVNULL)
+        lls = kio.read_ark(f"{td}/o.ark")
+        cfg = lo.Config(beam=BEAM, lattice_beam=LATTICE_BEAM, max_active=MAX_ACTIVE)
+        t2p = synth.tid2pdf(num_pdfs)
+        for u, _, kept_u in items:
+            c = _compare(_view_ref(kept_u[2]), kept_u[1], _view_ref(rd.decode(graph, lls[f"u{u}"], t2p, cfg)), lls[f"u{u}"])
+            if not c["best_path_identical"]: flips.append(u)
+    return flips
+
 def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utts_per_core=12, max_procs=64):
     """The same workload on the host cores, bounded sample, the way decode.sh --nj splits it: P independent single-threaded workers, each running
     the REFERENCE's own binaries (oracle/_ref, built from /root/reference by oracle/build_ref.sh) on its utterances.  Utterance u of the sample is the
@@ -197,7 +238,7 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
     def summary(cs):
         nb_ = sum(c["best_path_identical"] for c in cs)
         bad = [c for c in cs if not c["best_path_identical"]]
-        return {"utterances": len(cs), "best_path_identical": nb_, "best_path_identical_frac": nb_ / len(cs),
+        return {"utterances": len(cs), "best_path_identical": nb_, "best_path_identical_frac": nb_ / len(cs), "flip_utts": [c["utt"] for c in bad],
                 "words_identical": sum(c["words_identical"] for c in cs), "raw_lattice_identical": sum(c["lattice_identical"] for c in cs),
              "max_abs_loglike_diff": max(c["max_abs_loglike_diff"] for c in cs),
                     "mean_of_max_abs_loglike_diff": float(np.mean([c["max_abs_loglike_diff"] for c in cs])),
@@ -228,6 +269,10 @@ def cpu_baseline(model_path, graph, num_pdfs, utt_seconds, pcm_of, gpu=None, utt
         ok2 = [c for c in cmp2 if "error" not in c]
         par["reference_vs_itself"] = dict(summary(sorted(ok2, key=lambda c: c["utt"])),
             second_run=f"{ALT_BLAS} for nnet3-compute (same features, same decoder)") if ok2 else {"error": err2[:1]}
+        if ok2:
+            par["gate"] = e2e_gate(par["flip_utts"], par["reference_vs_itself"]["flip_utts"], par["utterances"])
+            par["gate_pass"] = par["gate"]["pass"]
+        else: par["gate_pass"] = False
         par["note"] = ("reference chain = compute-fbank-feats -> nnet3-compute -> LatticeFasterDecoder (oracle/_ref binaries built from "
             "/root/reference) on the SAME PCM16 as the GPU batch; GPU chain = the timed path "
              "(k3_feat -> k3_nnet_forward -> k3_decoder literal_order=1).  best_path_identical: (transition-ids, words) of the "
@@ -398,7 +443,8 @@ def main():
     wo, fo, total_frames, fo_h = sf.offsets(lens, dev)
     model_path = os.path.join(tempfile.gettempdir(), f"k3_bench_tdnnf_{rank}.raw")
     # BatchNorm calibration on real fbank features of rank 0's first utterance (same model on every rank)
-    w0 = torch.from_numpy(pcm_of(0, 0).astype(np.float32)).to(dev)
+    # (always --utt-seconds of it, also for the ragged set: the SAME model in both sets)
+    w0 = torch.from_numpy(synth.gaussian_pcm16(nsamp, 1234).astype(np.float32)).to(dev)
     calib = sf.ComputeFeatures(w0, *sf.offsets([nsamp], dev)[:3]).cpu().numpy()[:600]
     net_spec = synth.make_tdnnf(seed=1, calib_feats=calib)
     net_spec.write(model_path)
@@ -1001,6 +1047,29 @@ def main():
                         srt = lambda m: m[np.lexsort(m.T[::-1])]
                         return ka.shape == kb.shape and sa.shape == sb.shape and np.array_equal(srt(ka), srt(kb)) and np.array_equal(srt(sa), srt(sb))
                     ident = sum(bool(same_lattice(u)) for u in us)
+                    # The controls that separate the causes of the end-to-end flips:
+                    # (i) the reference's FEATURES through the GPU network and decoder -- what remains when the feature difference is taken away;
+                    # (ii) the GPU's FEATURES through the reference's network and decoder -- what the feature difference alone does to the reference chain
+                    ctrl = {}
+                    try:
+                        rl2 = np.concatenate([g_llh[oo[u]:oo[u + 1]] for u in us])
+                        dec.DecodeBatch(torch.from_numpy(rl2).to(dev), ro_k)
+                        gl2 = dec.GetRawLattices(copy=True)
+                        f_i = [u for k, u in enumerate(us)
+                               if not _compare(_view_ref(kept[u][2]), kept[u][1], _view_raw(gl2[k]), g_llh[oo[u]:oo[u + 1]])["best_path_identical"]]
+                        Pc = min(len(us), args.cpu_procs or (os.cpu_count() or 1))
+                        jobs_c = [([(u, gpu[4][fo_h[u]:fo_h[u + 1]], kept[u]) for u in us[w::Pc]], model_path, graph, num_pdfs) for w in range(Pc)]
+                        with ThreadPoolExecutor(Pc) as ex: f_ii = sorted(u for r_ in ex.map(_ctrl_worker, jobs_c) for u in r_)
+                        slf_f = par["reference_vs_itself"].get("flip_utts", [])
+                        ctrl = {"utterances": len(us), "end_to_end_flips": par["flip_utts"], "reference_vs_itself_flips": slf_f,
+                                "reference_features_gpu_net_gpu_decoder": {"flips": f_i, "gate": e2e_gate(f_i, slf_f, len(us))},
+                                "gpu_features_reference_net_reference_decoder": {"flips": f_ii, "gate": e2e_gate(f_ii, slf_f, len(us))},
+                                "note": "flips = utterances whose best path (transition-ids and words) differs from the all-reference chain's.  (i) isolates the network "
+                                        "+ decoder (the decoder is bit-identical on identical log-likelihoods: decoder_on_reference_loglikes_lattices_identical), (ii) "
+                                        "isolates the features: the float64 feature path is the exact value, compute-fbank-feats is up to 1.1e-4 from it, and the 17 "
+                                        "layers amplify that ~20x -- the reference's own chain moves by that much when fed the exact features"}
+                    except Exception as e: ctrl = {"error": repr(e)}
+                    par["controls"] = ctrl
                     par["stage_gates"] = {"utterances": len(us), "features_max_abs_diff": par["max_abs_feature_diff"],
                             "features_mean_abs_diff": par["mean_abs_feature_diff"], "features_above_1e-4_frac": par["feature_values_above_1e-4_frac"],
                          "nnet_on_reference_features_max_abs_loglike_diff": nd, "nnet_on_reference_features_loglike_diff_distribution": nn_dist, "nnet_truth": {"utterances": len(tu), "gpu_vs_exact_max_abs": n_eg,

@@ -26,6 +26,7 @@
 #include <utility>
 #include <vector>
 #include "k3hip.h"
+#include "itf/decodable-itf.h"               // kaldi::DecodableInterface (the deprecated AdvanceDecoding overload)
 #include "itf/transition-information.h"      // kaldi::TransitionInformation
 #include "lat/kaldi-lattice.h"               // kaldi::Lattice, LatticeArc, LatticeWeight (pulls in the Fst interface)
 
@@ -34,6 +35,12 @@ namespace cuda_decoder {
 
 typedef int32 ChannelId;
 typedef int32 LaneId;
+
+// cudadecoder/cuda-decodable-itf.h:30-33: a decodable whose log-likelihood rows live in DEVICE memory
+class CudaDecodableInterface : public DecodableInterface {
+ public:
+  virtual BaseFloat *GetLogLikelihoodsCudaPointer(int32 subsampled_frame) = 0;
+};
 
 class CudaDecoderException : public std::exception {      // cuda-decoder-common.h:100-127
  public:
@@ -134,6 +141,26 @@ class CudaDecoder {
     for (const auto &p : lanes_assignements) { ch.push_back(p.first); rows.push_back(p.second); }
     K3_CUDEC_CALL(k3_decoder_advance_decoding_lanes(dec_, (int32)ch.size(), ch.data(), rows.data(), 1, num_pdfs_, NULL));
     if (generate_partial_hypotheses_ || endpointing_) UpdatePartial(ch);
+  }
+  // cuda-decoder.h:267-270 / cuda-decoder.cc:798-830, "Version with deprecated API - will be removed at some point": as many frames as EVERY listed channel's decodable has
+  // ready beyond what the channel has decoded (at most max_num_frames when that is >= 0), frame by frame through the call above
+  void AdvanceDecoding(const std::vector<ChannelId> &channels, std::vector<CudaDecodableInterface *> &decodables, int32 max_num_frames = -1) {
+    KALDI_ASSERT(channels.size() == decodables.size());
+    int32 nframes_to_decode = std::numeric_limits<int32>::max();
+    for (size_t ilane = 0; ilane < channels.size(); ++ilane) {
+      const int32 num_frames_decoded = NumFramesDecoded(channels[ilane]), num_frames_ready = decodables[ilane]->NumFramesReady();
+      KALDI_ASSERT(num_frames_decoded >= 0 && "You must call InitDecoding() before AdvanceDecoding()");
+      KALDI_ASSERT(num_frames_ready >= num_frames_decoded);      // (the decodable object must not change between calls)
+      nframes_to_decode = std::min(nframes_to_decode, num_frames_ready - num_frames_decoded);
+    }
+    if (max_num_frames >= 0) nframes_to_decode = std::min(nframes_to_decode, max_num_frames);
+    std::vector<std::pair<ChannelId, const BaseFloat *>> lanes_assignments;
+    for (int32 f = 0; f < nframes_to_decode; ++f) {
+      lanes_assignments.clear();
+      for (size_t ilane = 0; ilane < channels.size(); ++ilane)
+        lanes_assignments.push_back({channels[ilane], decodables[ilane]->GetLogLikelihoodsCudaPointer(NumFramesDecoded(channels[ilane]))});
+      AdvanceDecoding(lanes_assignments);
+    }
   }
   // several frames at once (rows ld floats apart): what BatchedThreadedNnet3CudaPipeline2 does frame by frame, in one launch
   void AdvanceDecoding(const std::vector<std::pair<ChannelId, const BaseFloat *>> &lanes_assignements, int32 num_frames, int64 ld) {

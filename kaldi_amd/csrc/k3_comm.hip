@@ -69,15 +69,17 @@ bool write_atomically(const std::string &path, const void *rec, size_t n) {
 }
 // a file of exactly the record's size whose age passes: with a per-run K3_COMM_NONCE the nonce decides alone (a rank that enters late must not reject a valid
 // file for its age); otherwise nothing older than max(stale_seconds, timeout_seconds) before the caller's start is taken for this run's
-template <typename Rec> bool read_fresh(const std::string &path, Rec *rec, time_t t_start, int window, bool nonce_is_unique) {
+template <typename Rec> bool read_fresh(const std::string &path, Rec *rec, time_t t_start, int window, bool nonce_is_unique, struct timespec *mtime = nullptr) {
   FILE *f = fopen(path.c_str(), "rb"); if (!f) return false;
   // (a truncated or over-long file is not a record)
   struct stat st;
   char extra;
   const bool got = fread(rec, sizeof *rec, 1, f) == 1 && fread(&extra, 1, 1, f) == 0 && fstat(fileno(f), &st) == 0;
   fclose(f);
+  if (got && mtime) *mtime = st.st_mtim;
   return got && (nonce_is_unique || st.st_mtime + window >= t_start);
 }
+bool not_older(const struct timespec &a, const struct timespec &b) { return a.tv_sec > b.tv_sec || (a.tv_sec == b.tv_sec && a.tv_nsec >= b.tv_nsec); }
 std::string note_path(const char *id_file, const char *what, int rank = -1) {
   std::string p = std::string(id_file) + "." + what;
   if (rank >= 0) p += "." + std::to_string(rank);
@@ -111,8 +113,10 @@ extern "C" int k3_comm_exchange_id(const char *id_file, int32_t rank, int32_t ti
 // The whole rendezvous in front of ncclCommInitRank, which has no deadline of its own (a rank that never arrives would leave the others blocked in its bootstrap
 // for ever): nobody enters the collective before EVERY rank has been seen.  Rank r > 0 reads the id, announces itself in <id_file>.arrived.<r> (naming the id it
 // read; it re-reads and re-announces if rank 0 replaces a stale file under it) and waits for <id_file>.go; rank 0 publishes the id, waits for all world_size - 1
-// announcements of THAT id and then writes .go.  Every wait ends after timeout_seconds with an error that names what was missing (the ranks that never arrived /
-// rank 0's confirmation); on failure rank 0 withdraws its files, so late ranks time out too instead of joining a dead run.
+// announcements of THAT id and then writes .go.  A rank takes a .go only if it was written AFTER its own announcement (file times of the shared file system, to the
+// nanosecond): the .go a crashed run left next to its id file -- same launcher id, inside the age window -- is older than any announcement of this run, so a rank that
+// starts before rank 0 has cleaned up cannot walk into ncclCommInitRank with the dead run's id.  Every wait ends after timeout_seconds with an error that
+// names what was missing (the ranks that never arrived / rank 0's confirmation); on failure rank 0 withdraws its files, so late ranks time out too instead of joining a dead run.
 extern "C" int k3_comm_rendezvous(const char *id_file, int32_t rank, int32_t world_size, int32_t timeout_seconds, int32_t stale_seconds, const void *id_in, void *id_out) {
   K3_REQUIRE(id_file && id_out && world_size >= 1 && rank >= 0 && rank < world_size && (rank != 0 || id_in), "k3_comm_rendezvous: bad argument");
   bool unique = false; const uint64_t nonce = run_nonce(&unique); const time_t t_start = time(nullptr); const int window = std::max(stale_seconds, timeout_seconds);
@@ -143,17 +147,18 @@ extern "C" int k3_comm_rendezvous(const char *id_file, int32_t rank, int32_t wor
     K3_REQUIRE(write_atomically(go, &want, sizeof want), "k3_comm_rendezvous: cannot write the confirmation file");
     return K3_OK;
   }
-  uint64_t announced = 0; bool have = false; IdFile rec;
+  uint64_t announced = 0; bool have = false; IdFile rec; struct timespec announced_at = {0, 0};
   for (int i = 0; i < polls; i++) {
     IdFile cur;
     if (read_fresh(id_file, &cur, t_start, window, unique) && cur.magic == kIdMagic && cur.nonce == nonce) {
       const uint64_t h = fnv(cur.id, sizeof cur.id);
       if (!have || h != announced) {
         const Note n{kIdMagic, nonce, h}; K3_REQUIRE(write_atomically(note_path(id_file, "arrived", rank), &n, sizeof n), "k3_comm_rendezvous: cannot write the arrival file");
+        { struct stat st; K3_REQUIRE(stat(note_path(id_file, "arrived", rank).c_str(), &st) == 0, "k3_comm_rendezvous: cannot stat the arrival file"); announced_at = st.st_mtim; }
         rec = cur; announced = h; have = true;
       }
-      Note g;
-      if (read_fresh(go, &g, t_start, window, unique) && g.magic == kIdMagic && g.nonce == nonce && g.id_hash == announced) {
+      Note g; struct timespec go_at = {0, 0};
+      if (read_fresh(go, &g, t_start, window, unique, &go_at) && g.magic == kIdMagic && g.nonce == nonce && g.id_hash == announced && not_older(go_at, announced_at)) {
         memcpy(id_out, rec.id, sizeof rec.id);
         return K3_OK;
       }

@@ -1019,6 +1019,9 @@ struct k3_decoder {
   }
 };
 
+extern "C" int k3_decoder_init_decoding(k3_decoder *d, int32_t num_utts, int32_t max_total_frames, void *stream);
+extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, const float *d_loglikes, int64_t ld, const int64_t *h_row_off, void *stream);
+
 extern "C" void k3_decoder_config_default(k3_decoder_config *c) {
   if (!c) return;
   c->beam = 16.0f; c->max_active = std::numeric_limits<int32_t>::max(); c->min_active = 200; c->lattice_beam = 10.0f; c->beam_delta = 0.5f;
@@ -1030,6 +1033,42 @@ template <typename T> static int dmalloc(std::vector<void *> *allocs, T **ptr, s
   *ptr = nullptr;
   K3_HIP_CHECK(hipMalloc((void **)ptr, std::max<size_t>(n, 1) * sizeof(T)));
   allocs->push_back(*ptr);
+  return K3_OK;
+}
+
+// InitDecoding's result is the same for every utterance of a decoder: decode "no frames" on lane 0 once (the literal_order kernel's own f == -1 pass), keep what it left as
+// the template DecParams::tpl_* describes, and give the lane back.  A start closure beyond the template's bounds (or one that fails) simply leaves the decoder without one.
+static int build_init_template(k3_decoder *d) {
+  DecParams &p = d->p; int rc;
+  if ((rc = k3_decoder_init_decoding(d, 1, 1, nullptr))) return rc;
+  const int64_t ro[2] = {0, 0};
+  if ((rc = k3_decoder_advance_decoding(d, 1, reinterpret_cast<const float *>(p.prof), d->num_pdfs, ro, nullptr))) return rc;
+  K3_HIP_CHECK(hipDeviceSynchronize());
+  LaneInfo li; LanePool pool0;
+  K3_HIP_CHECK(hipMemcpy(&li, p.info, sizeof(li), hipMemcpyDeviceToHost));
+  K3_HIP_CHECK(hipMemcpy(&pool0, p.pools, sizeof(pool0), hipMemcpyDeviceToHost));
+  const long long n = li.n_tokens, nl = li.n_links;
+  if (li.status == kStOk && li.cur_base == 0 && li.n_cur == n && n > 0 && n <= 8192 && nl <= 32768) {
+    int *t_state = nullptr, *t_arc = nullptr, *t_order = nullptr, *t_by_ins = nullptr; unsigned *t_cost = nullptr; Link *t_links = nullptr;
+    if ((rc = dmalloc(&d->allocs, &t_state, (size_t)n)) || (rc = dmalloc(&d->allocs, &t_cost, (size_t)n)) || (rc = dmalloc(&d->allocs, &t_order, (size_t)n)) ||
+        (rc = dmalloc(&d->allocs, &t_by_ins, (size_t)n)) || (rc = dmalloc(&d->allocs, &t_links, (size_t)std::max<long long>(nl, 1))) ||
+        (rc = dmalloc(&d->allocs, &t_arc, (size_t)std::max<long long>(nl, 1)))) return rc;
+    K3_HIP_CHECK(hipMemcpy(t_state, pool0.tok_state, sizeof(int) * n, hipMemcpyDeviceToDevice));
+    K3_HIP_CHECK(hipMemcpy(t_cost, pool0.tok_cost, sizeof(unsigned) * n, hipMemcpyDeviceToDevice));
+    K3_HIP_CHECK(hipMemcpy(t_order, p.lt_order + (size_t)li.order_sel * p.frame_tokens_cap, sizeof(int) * n, hipMemcpyDeviceToDevice));
+    K3_HIP_CHECK(hipMemcpy(t_by_ins, p.lt_by_ins, sizeof(int) * n, hipMemcpyDeviceToDevice));
+    if (nl > 0) {
+      K3_HIP_CHECK(hipMemcpy(t_links, pool0.links, sizeof(Link) * nl, hipMemcpyDeviceToDevice));
+      K3_HIP_CHECK(hipMemcpy(t_arc, pool0.link_arc, sizeof(int) * nl, hipMemcpyDeviceToDevice));
+    }
+    p.tpl_state = t_state; p.tpl_cost = t_cost; p.tpl_links = t_links; p.tpl_arc = t_arc; p.tpl_order = t_order; p.tpl_by_ins = t_by_ins;
+    p.tpl_n = (int)n; p.tpl_nl = (int)nl; p.tpl_eps = li.n_eps;
+  }
+  if (getenv("K3_DEBUG_QUEUE")) fprintf(stderr, "k3 InitDecoding template: status %d, %lld tokens, %lld links, cur_base %lld n_cur %d -> %s\n", li.status, n, nl, li.cur_base, li.n_cur,
+      p.tpl_n > 0 ? "kept" : "none");
+  // the lane as it was: no utterance yet
+  K3_HIP_CHECK(hipMemset(p.info, 0, sizeof(LaneInfo)));
+  d->last_utts = 0; d->last_frames.clear(); d->fresh.clear(); d->lane_final.clear(); d->sel.clear(); d->started = false; d->finalized = false; d->info_valid = false;
   return K3_OK;
 }
 
@@ -1198,6 +1237,7 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
   std::vector<Slot> init((size_t)hs, Slot{kEmpty, kEncMax, -1, 0});
   for (int l = 0; l < nlanes; l++) K3_HIP_CHECK(hipMemcpy(p.hash + (size_t)l * hs, init.data(), sizeof(Slot) * hs, hipMemcpyHostToDevice));
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_decode_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+  if (p.literal && !getenv("K3_LIT_NO_INIT_TEMPLATE")) { const int rc_ = build_init_template(d.get()); if (rc_) return rc_; }
   *out = d.release();
   return K3_OK;
 }
@@ -1289,13 +1329,13 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
     K3_REQUIRE(T >= 0 && d->last_frames[u] + T + 2 <= d->fstride, "k3_decoder_advance_decoding: more frames than max_total_frames of k3_decoder_init_decoding");
     K3_REQUIRE(T == 0 || !d->lane_final[u], "k3_decoder_advance_decoding: frames for a finalised lane (k3_decoder_init_channels restarts it)");
   }
-  for (int u = 0; u < num_utts; u++) d->last_frames[u] += (int)(h_row_off[u + 1] - h_row_off[u]);      // state changes only after every check passed
-  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq++ % k3_decoder::kArgSlots];
+  // (the decoder's host state -- frames consumed, pending InitDecoding flags, the argument ring's cursor -- changes only once the launch is queued: a HIP failure on the way
+  // leaves it as it was, so the call can be repeated)
+  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq % k3_decoder::kArgSlots];
   if (slot.used) K3_HIP_CHECK(hipEventSynchronize(slot.ev));      // (the launch of kArgSlots calls ago: long finished)
   memcpy(slot.h, h_row_off, sizeof(long long) * (num_utts + 1)); memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * num_utts);
   const int lit_grid = fill_lane_queue(d, slot, num_utts);
   K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
-  std::fill(d->fresh.begin(), d->fresh.end(), 0);
   p.loglikes = d_loglikes;
   p.ld = ld;
   p.row_off = reinterpret_cast<long long *>(slot.d);
@@ -1311,6 +1351,8 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   if (!d->ev_tp) K3_HIP_CHECK(hipEventCreateWithFlags(&d->ev_tp, hipEventDisableTiming));
   K3_HIP_CHECK(hipEventRecord(d->ev_tp, st)); d->ev_tp_recorded = true;
   K3_HIP_CHECK(hipEventRecord(slot.ev, st)); slot.used = true;
+  for (int u = 0; u < num_utts; u++) d->last_frames[u] += (int)(h_row_off[u + 1] - h_row_off[u]);
+  std::fill(d->fresh.begin(), d->fresh.end(), 0); d->arg_seq++;
   d->started = true; d->last_stream = st; d->info_valid = false;
   return K3_OK;
 }
@@ -1330,15 +1372,14 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
         "k3_decoder_advance_decoding_lanes: more frames than max_total_frames, or a finalised channel");
     T[c] = num_frames; rows[c] = h_lane_frames[i];
   }
-  for (int u = 0; u < U; u++) { ro[u + 1] = ro[u] + T[u]; d->last_frames[u] += T[u]; }
-  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq++ % k3_decoder::kArgSlots];
+  for (int u = 0; u < U; u++) ro[u + 1] = ro[u] + T[u];
+  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq % k3_decoder::kArgSlots];
   if (slot.used) K3_HIP_CHECK(hipEventSynchronize(slot.ev));
   memcpy(slot.h, ro.data(), sizeof(long long) * (U + 1));
   memcpy(slot.h + d->arg_off_rows, rows.data(), sizeof(float *) * U);
   memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * U);
   const int lit_grid = fill_lane_queue(d, slot, U);
   K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
-  std::fill(d->fresh.begin(), d->fresh.end(), 0);
   p.loglikes = nullptr; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr;
   p.lane_rows = reinterpret_cast<const float **>(slot.d + d->arg_off_rows);
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
@@ -1350,6 +1391,8 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
   if (!d->ev_tp) K3_HIP_CHECK(hipEventCreateWithFlags(&d->ev_tp, hipEventDisableTiming));
   K3_HIP_CHECK(hipEventRecord(d->ev_tp, st)); d->ev_tp_recorded = true;
   K3_HIP_CHECK(hipEventRecord(slot.ev, st)); slot.used = true;
+  for (int u = 0; u < U; u++) d->last_frames[u] += T[u];
+  std::fill(d->fresh.begin(), d->fresh.end(), 0); d->arg_seq++;
   d->started = true; d->last_stream = st; d->info_valid = false;
   return K3_OK;
 }
@@ -1367,15 +1410,14 @@ extern "C" int k3_decoder_advance_decoding_strided(k3_decoder *d, int32_t num_ut
     K3_REQUIRE(T >= 0 && d->last_frames[u] + T + 2 <= d->fstride, "k3_decoder_advance_decoding_strided: more frames than max_total_frames of k3_decoder_init_decoding");
     K3_REQUIRE(T == 0 || !d->lane_final[u], "k3_decoder_advance_decoding_strided: frames for a finalised lane (k3_decoder_init_channels restarts it)");
   }
-  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq++ % k3_decoder::kArgSlots];
+  k3_decoder::ArgSlot &slot = d->arg[d->arg_seq % k3_decoder::kArgSlots];
   if (slot.used) K3_HIP_CHECK(hipEventSynchronize(slot.ev));
   long long *ro = reinterpret_cast<long long *>(slot.h); const float **rows = reinterpret_cast<const float **>(slot.h + d->arg_off_rows);
   ro[0] = 0;
-  for (int u = 0; u < U; u++) { const int T = h_lane_first[u] ? h_num_frames[u] : 0; ro[u + 1] = ro[u] + T; rows[u] = h_lane_first[u]; d->last_frames[u] += T; }
+  for (int u = 0; u < U; u++) { const int T = h_lane_first[u] ? h_num_frames[u] : 0; ro[u + 1] = ro[u] + T; rows[u] = h_lane_first[u]; }
   memcpy(slot.h + d->arg_off_fresh, d->fresh.data(), sizeof(int) * U);
   const int lit_grid = fill_lane_queue(d, slot, U);
   K3_HIP_CHECK(hipMemcpyAsync(slot.d, slot.h, d->arg_bytes, hipMemcpyHostToDevice, st));
-  std::fill(d->fresh.begin(), d->fresh.end(), 0);
   p.loglikes = nullptr; p.ld = ld; p.row_off = reinterpret_cast<long long *>(slot.d); p.fresh = reinterpret_cast<int *>(slot.d + d->arg_off_fresh); p.lane_ids = nullptr;
   p.lane_rows = reinterpret_cast<const float **>(slot.d + d->arg_off_rows);
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
@@ -1387,6 +1429,8 @@ extern "C" int k3_decoder_advance_decoding_strided(k3_decoder *d, int32_t num_ut
   if (!d->ev_tp) K3_HIP_CHECK(hipEventCreateWithFlags(&d->ev_tp, hipEventDisableTiming));
   K3_HIP_CHECK(hipEventRecord(d->ev_tp, st)); d->ev_tp_recorded = true;
   K3_HIP_CHECK(hipEventRecord(slot.ev, st)); slot.used = true;
+  for (int u = 0; u < U; u++) d->last_frames[u] += (int)(ro[u + 1] - ro[u]);
+  std::fill(d->fresh.begin(), d->fresh.end(), 0); d->arg_seq++;
   d->started = true; d->last_stream = st; d->info_valid = false;
   return K3_OK;
 }

@@ -149,6 +149,11 @@ struct DecParams {
   // literal_order kernel: q_lanes = the call's lanes (those with frames or a fresh start), longest first, q_n of them: workgroup b decodes lane q_lanes[b] (null: lane b).
   // q_head (work-queue builds, fewer workgroups than lanes): the cursor through which a workgroup takes its next entry.
   int *q_head; const int *q_lanes; long long q_n;
+  // literal_order kernel: what InitDecoding (the start token and its epsilon closure, lattice-faster-decoder.cc:63-81) leaves in a lane -- the same for every utterance of a
+  // decoder (graph, beam and hash ratio decide it), computed once when the decoder is created (one lane, no frames) and copied into a fresh lane instead of being worked out
+  // again (0.9 M cycles of a lane's ~98 M): tokens (state, cost) in creation order, the closure's forward links, the HashList visit order and the creation order.  tpl_n = 0: none.
+  const int *tpl_state; const unsigned *tpl_cost; const Link *tpl_links; const int *tpl_arc; const int *tpl_order, *tpl_by_ins;
+  int tpl_n, tpl_nl; long long tpl_eps;
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }

@@ -61,9 +61,25 @@ struct LaneCtx {      // this lane's slices of the pools and per-frame arrays
   // capacities of the lane's token / link pools (the caller has made room for a whole LDS-resident frame: the checks below cannot fire, they guard the memory)
   long long tcap, lcap;
 };
-struct FastShared { int abort, abort_r[4], n_wl[3], n_el; unsigned next0; int reason; long long prof[12]; };
+// cnt: the frame's three running counts in one word -- tokens created [0, 16), first work-list entries [16, 32), forward links made [32, 64) -- so that a wavefront step
+// reserves its token indices, work-list slots and link slots with ONE LDS atomic (three dependent round trips before)
+struct FastShared { unsigned long long cnt; int abort, abort_r[4], n_wl[3], n_el; unsigned next0; int reason; long long prof[12]; };
+__device__ __forceinline__ void wave_append3(bool a, bool b, bool c, unsigned long long *counter, int &ia, int &ib, long long &ic) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long ma = __ballot(a), mb = __ballot(b), mc = __ballot(c), any = ma | mb | mc;
+  ia = 0; ib = 0; ic = 0;
+  if (any == 0) return;
+  const int leader = __ffsll((long long)any) - 1;
+  unsigned long long base = 0;
+  if (lane == leader) base = k3a_add(counter, (unsigned long long)__popcll(ma) | ((unsigned long long)__popcll(mb) << 16) | ((unsigned long long)__popcll(mc) << 32));
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)base, leader), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(base >> 32), leader);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  ia = (int)(lo & 0xFFFFu) + __popcll(ma & lt); ib = (int)(lo >> 16) + __popcll(mb & lt); ic = (long long)hi + __popcll(mc & lt);
+}
 #ifdef K3_FAST_PROF
 #define K3_FP(i) do { if (threadIdx.x == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); fs.prof[i] += now__ - fp_last__; fp_last__ = now__; } } while (0)
+#elif defined(K3_FAST_MARK)      // -S builds: a comment in the ISA at every phase boundary (tools/count_fast_isa.py counts the instructions between them)
+#define K3_FP(i) asm volatile("; K3MARK " #i)
 #else
 #define K3_FP(i) do { } while (0)
 #endif
@@ -300,7 +316,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
     fs.n_wl[1] = 0;
     fs.n_wl[2] = 0;
     fs.abort_r[0] = fs.abort_r[1] = fs.abort_r[2] = fs.abort_r[3] = 0;
-    sh.n_next = 0;
+    fs.cnt = 0ull;
     c.loff_e[f] = link0;
   }
   for (int i = tid; i < cap_tokens; i += kBlock) { N_cost[i] = kEncMax; X[i] = kLabelNone; }
@@ -310,9 +326,14 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   __syncthreads();
   // ---- pass A (:779-797 first half): per 64-token chunk of the visit order the number of emitting arcs and min (tot + adaptive_beam); the pre-pass
   // (:753-768) rides along: the best token's arcs are among them
-  const int nchunks = (n_cur + 63) >> 6;
+  // A chunk = the 2^csh consecutive tokens of the visit order a wavefront expands together (their arcs one per lane).  64 tokens for the large frames; fewer for a frame
+  // that would otherwise give the eight wavefronts less than two chunks each (600 tokens = 10 chunks of ~80 arcs: two wavefronts walk four 64-arc steps while six walk two;
+  // 19 chunks of ~40 arcs: three steps at most), down to 8 tokens.  At most 64 chunks: the scan below is one chunk per lane.
+  int csh = 6;
+  while (K3_LIT_CSH && csh > 3 && ((n_cur + (1 << csh) - 1) >> csh) < 2 * nw && ((n_cur + (1 << (csh - 1)) - 1) >> (csh - 1)) <= 64) csh--;
+  const int nchunks = (n_cur + (1 << csh) - 1) >> csh;
   auto chunk_tokens = [&](int ch, float &cost, int &beg, int &deg, int &vtok) {
-    const int r = 64 * ch + lane; const bool v = r < n_cur;
+    const int r = (ch << csh) + lane; const bool v = lane < (1 << csh) && r < n_cur;
     cost = v ? dec(V_cost[r]) : 0.0f; beg = 0; deg = 0; vtok = v ? (int)V_tok[r] : 0;
     if (v && cost <= cur_cutoff) { beg = (int)V_abeg[r]; deg = (int)V_ne[r]; }
   };
@@ -323,7 +344,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
       const float oc = __shfl(cost, owner);
       if (valid) {
         const float llv = ll[r.pdf]; const float ac = co - llv; const float tot = oc + ac + r.w; const unsigned e = enc(tot + ab); cm = e < cm ? e : cm;
-        if (64 * ch + owner == best_r) { const float nw_ = r.w + co - llv + best; const unsigned e0 = enc(nw_ + ab); pm = e0 < pm ? e0 : pm; }
+        if ((ch << csh) + owner == best_r) { const float nw_ = r.w + co - llv + best; const unsigned e0 = enc(nw_ + ab); pm = e0 < pm ? e0 : pm; }
       }
       cnt_emit += valid;
     });
@@ -370,18 +391,16 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
         }
         if (slot < 0) abort_now(kFaTable); else mk = true;
       }
-      int idx = wave_append(claimed, &sh.n_next);
+      const bool q1 = claimed && r.next < 0;
+      int idx, pos1; long long lpos;
+      wave_append3(claimed, q1, mk, &fs.cnt, idx, pos1, lpos);      // token index / work-list slot / link slot of this arc, where it needs them
       int2 oa = make_int2(0, 0), ob = make_int2(0, 0);
       if (claimed) {
         if (idx >= cap_tokens || nb + idx >= c.tcap) { abort_now(kFaTokens); idx = 0; }
         else { c.tok_state[nb + idx] = state; oa = p.offs[state]; ob = p.offs[state + 1]; }
         __hip_atomic_store(&T_tix[slot], (unsigned short)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      {
-        const bool q1 = claimed && r.next < 0;
-        const int pos1 = wave_append(q1, &fs.n_wl[1]);
-        if (q1) { if (pos1 < kFW) wl[kFW + pos1] = (unsigned short)idx; else abort_now(kFaWl); }
-      }
+      if (q1) { if (pos1 < kFW) wl[kFW + pos1] = (unsigned short)idx; else abort_now(kFaWl); }
       if (mk && !claimed) {
         for (int spin = 0;; spin++) {
           const unsigned short t = lds_ld16(&T_tix[slot]);
@@ -398,7 +417,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
         }
       }
       if (mk) { k3a_min(&N_cost[idx], enc(tot)); k3a_min(&X[idx], (unsigned)(jbase + j)); }
-      const long long pos = wave_append64(mk, &sh.n_link);
+      const long long pos = link0 + lpos;
       if (mk) {
         if (pos < c.lcap) { store_link(&c.links[pos], Link{(unsigned)(cur_base + oi), (unsigned)(nb + idx), tot, ac}); store_stream(&c.link_arc[pos], arc); }
         else abort_now(kFaPool);
@@ -413,7 +432,8 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
     });
   }
   if (aborted()) return -1;
-  const int n_e = sh.n_next; const long long eps_l0 = sh.n_link;
+  const unsigned long long cnt_e = fs.cnt;      // (uniform: read between the barriers of aborted() and the next phase's; the rounds below add to it only after another barrier)
+  const int n_e = (int)(cnt_e & 0xFFFFull); const long long eps_l0 = link0 + (long long)(cnt_e >> 32);
   K3_FP(2);
   if (tid == 0) { c.loff_n[f + 1] = eps_l0; c.st_ntoks[f] = n_cur; c.st_cur[f] = cur_cutoff; c.st_ab[f] = ab; c.st_next[f] = accept; c.st_co[f] = co; }
   // X: creation labels -> "expanded at" costs
@@ -429,7 +449,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   // ---- ProcessNonemitting (:830-897): the order-free fixpoint of finish_frame on token indices; every epsilon link also stays in LDS
   const float cutoff = accept;
   {
-    int n = fs.n_wl[1];
+    int n = (int)((cnt_e >> 16) & 0xFFFFull);
     for (int round = 1; n > 0; round++) {
       if (round > 100000) { sh.err = K3_ERR_HIP; break; }
       const int cur = round & 1; const unsigned short *wl_cur = wl + cur * kFW; unsigned short *wl_nxt = wl + (cur ^ 1) * kFW; int *n_nxt = &fs.n_wl[(round + 1) % 3];
@@ -464,7 +484,8 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
               if (slot < 0) fail(kFaTable); else mk = true;
             }
           }
-          int idx = wave_append(claimed, &sh.n_next);
+          int idx, unused_; long long lrel;
+          wave_append3(claimed, false, mk, &fs.cnt, idx, unused_, lrel);
           if (claimed) {
             if (idx >= cap_tokens || nb + idx >= c.tcap) { fail(kFaTokens); idx = 0; }
             else c.tok_state[nb + idx] = nxt;
@@ -495,7 +516,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
           }
           const int pos = wave_append(push, n_nxt);
           if (push) { if (pos < kFW) wl_nxt[pos] = (unsigned short)idx; else fail(kFaWl); }
-          const long long lp = wave_append64(mk, &sh.n_link);
+          const long long lp = link0 + lrel;
           if (mk) {
             const long long el = lp - eps_l0;
             if (lp < c.lcap && el < kFE) {
@@ -518,7 +539,8 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
     }
   }
   { __syncthreads(); const int bad = sh.err | fs.abort; __syncthreads(); if (bad) return -1; }      // (the lane's error flag and the give-up flag in one snapshot)
-  const int n = sh.n_next; const int n_el = (int)(sh.n_link - eps_l0);
+  const unsigned long long cnt_n = fs.cnt;      // (uniform: nothing adds to it any more)
+  const int n = (int)(cnt_n & 0xFFFFull); const long long n_link_end = link0 + (long long)(cnt_n >> 32); const int n_el = (int)(n_link_end - eps_l0);
   K3_FP(4);
   // ---- the frame's final costs into the pool; buckets of the HashList (the table is dead afterwards)
   for (int i = tid; i < n; i += kBlock) c.tok_cost[nb + i] = N_cost[i];
@@ -592,6 +614,14 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   K3_FP(6);
   // the initial queue: the tokens of that list that can expand (closure ids), consumed from its back
   unsigned short *iq = reinterpret_cast<unsigned short *>(arena + oIq), *dense = reinterpret_cast<unsigned short *>(arena + oDense);
+  // (the component replay's cells -- own parent, zero counters -- are set here: the scan's barriers put them in front of the union phase, no barrier of their own)
+  for (int cc = tid; cc < n_cid; cc += kBlock) par[cc] = (unsigned)cc;
+  for (int i = tid; i < n_cid / 2 + 1; i += kBlock) {
+    reinterpret_cast<unsigned *>(croots)[i] = 0u;
+    reinterpret_cast<unsigned *>(ccreated)[i] = 0u;
+    reinterpret_cast<unsigned *>(carcs)[i] = 0u;
+    reinterpret_cast<unsigned *>(ccurs)[i] = 0u;
+  }
   const int n_iq = block_excl_scan_f([&](int r) { const int i = ord1[r]; return (int)(srcbit[i >> 5] >> (i & 31) & 1u); },
                                      [&](int r, int ex) { const int i = ord1[r]; if ((srcbit[i >> 5] >> (i & 31) & 1u) && ex < kFQ) iq[ex] = cid[i]; }, n_e, sh.redi);
   if (n_iq > kFQ) { if (tid == 0) fs.reason = kFaQueue; return -1; }
@@ -602,14 +632,6 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
       *rtmp = reinterpret_cast<unsigned short *>(arena + oRtmp);
   unsigned short *wrec = reinterpret_cast<unsigned short *>(arena + oWrec), *stack = reinterpret_cast<unsigned short *>(arena + oStack),
       *clist = reinterpret_cast<unsigned short *>(arena + oClist);
-  for (int cc = tid; cc < n_cid; cc += kBlock) par[cc] = (unsigned)cc;
-  for (int i = tid; i < n_cid / 2 + 1; i += kBlock) {
-    reinterpret_cast<unsigned *>(croots)[i] = 0u;
-    reinterpret_cast<unsigned *>(ccreated)[i] = 0u;
-    reinterpret_cast<unsigned *>(carcs)[i] = 0u;
-    reinterpret_cast<unsigned *>(ccurs)[i] = 0u;
-  }
-  __syncthreads();
   auto find = [&](int x) { for (;;) { const int q_ = (int)lds_ld(&par[x]); if (q_ == x) return x; x = q_; } };
   for (int cc = tid; cc < n_cid; cc += kBlock) {
     const int abeg = m_abeg[cc], pc = m_pc[cc];
@@ -619,6 +641,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
     }
   }
   __syncthreads();
+  K3_FP(10);
   for (int cc = tid; cc < n_cid; cc += kBlock) {
     const int r = find(cc); if (r != cc) __hip_atomic_store(&par[cc], (unsigned)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (rcost[cc] == kInf) add16(ccreated, r, 1u);
@@ -663,6 +686,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
     }
     __syncthreads();
   }
+  K3_FP(11);
   for (int w_ = tid; w_ < n_workers; w_ += kBlock) {
     const unsigned short *w = wrec + 5 * w_;
     if (!fast_replay_component(rcost, m_abeg, m_pc, AR_dst, AR_w, clist, rlist, rinfo, stack + w[3], (int)w[4], (int)w[0], (int)w[1], (int)w[2], accept)) abort_now(kFaStack);
@@ -688,7 +712,7 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
                   reinterpret_cast<unsigned short *>(arena + oO2_lead), reinterpret_cast<unsigned short *>(arena + oO2_grp), reinterpret_cast<unsigned short *>(arena + oO2_curs),
                   [&](int r, int i, int d) { V_cost[r] = N_cost[i]; V_abeg[r] = N_abeg[i]; V_ne[r] = N_ne[i]; V_tok[r] = (unsigned short)i; ord_nxt[r] = i; q.by_ins[d] = i; });
   K3_FP(9);
-  if (tid == 0) { c.tok_off[f + 2] = nb + n; c.loff_e[f + 1] = sh.n_link; }
+  if (tid == 0) { c.tok_off[f + 2] = nb + n; c.loff_e[f + 1] = n_link_end; sh.n_link = n_link_end; sh.n_next = n; }
   hash_size_io = hash_size; cnt_emit_io += cnt_emit; cnt_os_io += cnt_os; cnt_eps_io += cnt_eps;
   return n;
 }

@@ -11,6 +11,9 @@
 #ifndef K3_LIT_QUEUE
 #define K3_LIT_QUEUE 0     // 1: a workgroup decodes lane after lane from the call's work-queue (k3_decoder_config.resident_lanes); see k3_decode_forward_literal_kernel
 #endif
+#ifndef K3_LIT_CSH
+#define K3_LIT_CSH 0     // 1: passes A / B cut a frame of few tokens into chunks of fewer than 64 tokens (more, shorter chunks per wavefront); measured: see DESIGN.md 4
+#endif
 #include "k3_decoder_dev.h"
 
 namespace {
@@ -29,5 +32,6 @@ extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, i
   DecParams p; static_assert(sizeof(DecParams) % 8 == 0, "DecParams is copied between translation units");
   if (params_bytes != sizeof(DecParams)) { fprintf(stderr, "k3_lit_forward_launch: DecParams size mismatch\n"); abort(); }
   memcpy(&p, params, sizeof(p));
+  if (p.tpl_n > 0) hipLaunchKernelGGL(k3_decode_init_from_template_kernel, dim3(p.q_lanes ? (unsigned)p.q_n : (unsigned)nworkgroups), dim3(256), 0, stream, p, const_cast<int *>(p.fresh));
   hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(nworkgroups), dim3(kBlock), exclusive && kLitExclusiveLds > kLitArena ? kLitExclusiveLds : kLitArena, stream, p);
 }

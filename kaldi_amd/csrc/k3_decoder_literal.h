@@ -261,7 +261,7 @@ __device__ K3_COLD_INLINE void lit_hash_order(const LitLane &q, Shared &sh, int 
 // creation rank, member count.  A thread keeps its <= 4 tokens in registers across the phases; global memory is touched for the labels and
 // states (one stream in) and the result (one stream out).  (Per-bucket arrays in HBM cost two cache-line round trips per token and call: they
 // were half of the kernel's HBM traffic.)
-constexpr int kHoN = 2048, kHoM = 16384;
+constexpr int kHoN = 4 * kBlock < 2048 ? 4 * kBlock : 2048, kHoM = 32 * kBlock < 16384 ? 32 * kBlock : 16384;      // (four tokens per thread in registers, one bitmap word per thread)
 constexpr size_t kHoLds = (size_t)(kHoM / 32) * 4 + (size_t)(kHoM / 32) * 2 + 2 * (size_t)kHoN * 2;
 __device__ __forceinline__ void lit_hash_order_lds(const LitLane &q, Shared &sh, int n, unsigned M, const int *st, unsigned hash_size, int *order_out, bool write_by_ins,
                                                    bool dense_in, bool relabel, char *arena, int *tab, long long &lt_last__) {
@@ -438,7 +438,7 @@ struct LitShared { int n_csr, use_lds, n_created, m_e; unsigned final_cut; };
 //   * a scan over the leaders' sizes in creation order gives the buckets' offsets; position = offset of the leader + place inside the bucket.
 // Global memory sees streams plus, per token, the record store, the leader's size (one store per bucket), one load of the leader's offset and the result.
 // Returns false when a partition does not fit (the caller takes lit_hash_order): the result is then untouched.
-constexpr int kHbT = 4096, kHbW = 1024, kHbPart = 1536, kHbMaxPart = 2048, kHbMaxP = 64;
+constexpr int kHbT = 4096, kHbW = 1024, kHbMaxPart = 4 * kBlock < 2048 ? 4 * kBlock : 2048, kHbPart = kHbMaxPart * 3 / 4, kHbMaxP = 64;
 constexpr size_t kHbLdsA = (size_t)kHbW * 4 + (size_t)kHbW * 2, kHbLdsB = (size_t)kHbT * 12 + (size_t)kHbT * 2 + (size_t)kHbMaxPart * 2,
     kHbLdsP = kHbLdsB > kHbLdsA ? kHbLdsB : kHbLdsA;
 static_assert(kHbLdsP + 2 * kHbMaxP * 4 <= kLitGeneralLds, "the large-frame hash order works in the general path's arena");
@@ -843,6 +843,32 @@ __device__ __forceinline__ int lit_replay_components(const DecParams &p, const L
   return created;
 }
 
+// InitDecoding from the decoder's template (DecParams::tpl_*), launched in front of the token-passing kernel: a fresh lane (one workgroup each) gets exactly what that
+// kernel's f == -1 pass would leave -- tokens, links, visit order (in the half of lt_order that pass writes), creation order, offsets, counters -- as the state of a lane that
+// continues after zero frames, and its `fresh` flag is cleared, so the token-passing kernel resumes it like any chunked AdvanceDecoding call.  A lane whose previous utterance
+// failed (its scratch needs the token-passing kernel's clean-up) or whose pools are smaller than the template stays fresh.  (A kernel of its own, not a branch of the
+// token-passing kernel: that kernel lives at 128 registers with ~50 spilled, and the branch cost its frames 1.7 %.)
+__global__ __launch_bounds__(256) void k3_decode_init_from_template_kernel(DecParams p, int *fresh) {
+  const int L = p.q_lanes ? p.q_lanes[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
+  if (!fresh[L] || p.tpl_n <= 0) return;
+  LaneInfo &li = p.info[L];
+  const LanePool lp = p.pools[L];
+  if (li.status < 0 || lp.tcap < p.tpl_n || lp.lcap < p.tpl_nl) return;      // (uniform over the workgroup)
+  const LitLane q(p, L);
+  const int n_t = p.tpl_n, n_l = p.tpl_nl; int *ord_t = q.order[1];      // (a fresh lane starts with order_sel = 0 and its InitDecoding pass writes the other half)
+  for (int i = tid; i < n_t; i += 256) { lp.tok_state[i] = p.tpl_state[i]; lp.tok_cost[i] = p.tpl_cost[i]; ord_t[i] = p.tpl_order[i]; q.by_ins[i] = p.tpl_by_ins[i]; }
+  for (int l = tid; l < n_l; l += 256) { lp.links[l] = p.tpl_links[l]; lp.link_arc[l] = p.tpl_arc[l]; }
+  __syncthreads();
+  if (tid == 0) {
+    long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
+    tok_off[0] = 0; tok_off[1] = n_t; loff_n[0] = 0; loff_e[0] = n_l;
+    li.n_tokens = n_t; li.n_links = n_l; li.n_cands = 0; li.n_eps = p.tpl_eps; li.max_frame_tokens = n_t; li.status = kStOk; li.num_frames = 0; li.reached_final = 0;
+    li.out_states = 0; li.out_arcs = 0; li.cur_base = 0; li.n_cur = n_t; li.n_order_sensitive = 0; li.hash_size = 1000; li.order_sel = 1;
+    __threadfence();
+    fresh[L] = 0;
+  }
+}
+
 __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_kernel(DecParams p) {
   // One dynamic LDS arena (kLitArena bytes).  The general path below carves its level-1 state table, mark bits, work-lists / clash bins / union-find
   // parents and the replay segment out of its first 77.5 KB; a frame of the LDS-resident path (k3_decoder_fast.h) uses all of it, so the two
@@ -1047,16 +1073,20 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
       if (block_err(sh)) break;
       K3_LT(1); K3_LQ(1);
       // ---- pass A: per 64-token chunk of the visit order, the number of emitting arcs and min (tot + adaptive_beam)
-      const int nchunks = (n_cur + 63) >> 6;
+      // (chunks of 2^csh tokens: 64 for the large frames, fewer when the frame would give the wavefronts less than two chunks each -- the first frame of an utterance is
+      // a hundred tokens with tens of thousands of arcs, two 64-token chunks walked by two wavefronts --, within the chunk arrays' cap / 64 + 2 entries)
+      int csh = 6;
+      while (K3_LIT_CSH && csh > 3 && ((n_cur + (1 << csh) - 1) >> csh) < 2 * nw && ((n_cur + (1 << (csh - 1)) - 1) >> (csh - 1)) <= cap / 64) csh--;
+      const int nchunks = (n_cur + (1 << csh) - 1) >> csh;
       auto chunk_tokens = [&](int c, int &i, float &cost, int &beg, int &deg) {
-        const int r = 64 * c + lane; const bool v = r < n_cur;
+        const int r = (c << csh) + lane; const bool v = lane < (1 << csh) && r < n_cur;
         i = v ? ord_cur[r] : 0; const unsigned cb = v ? ccs[i] : kEncMax; const int st = v ? cst[i] : 0; cost = dec(cb); beg = 0; deg = 0;
         if (v && cost <= cur_cutoff) { const int2 a = p.offs[st]; beg = a.x; deg = a.y - a.x; }
       };
       for (int c = wave; c < nchunks; c += nw) {
         int i, beg, deg; float cost; chunk_tokens(c, i, cost, beg, deg);
         // pass B reads this instead of walking order -> token -> state -> offsets again
-        if (64 * c + lane < n_cur) q.vis[64 * c + lane] = make_int4(i, __float_as_int(cost), beg, deg);
+        if (lane < (1 << csh) && (c << csh) + lane < n_cur) q.vis[(c << csh) + lane] = make_int4(i, __float_as_int(cost), beg, deg);
         unsigned cm = kEncMax;
         const int total = wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int, int, int owner, const ArcRec &r) {
           const float oc = __shfl(cost, owner);
@@ -1097,7 +1127,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         const unsigned *cpre = q.cmin + (cap / 64 + 2); const int *cbase = q.ccnt + (cap / 64 + 2);
         for (int c = wave; c < nchunks; c += nw) {
           int i = 0, beg = 0, deg = 0; float cost = 0.0f;
-          if (64 * c + lane < n_cur) { const int4 v = q.vis[64 * c + lane]; i = v.x; cost = __int_as_float(v.y); beg = v.z; deg = v.w; }
+          if (lane < (1 << csh) && (c << csh) + lane < n_cur) { const int4 v = q.vis[(c << csh) + lane]; i = v.x; cost = __int_as_float(v.y); beg = v.z; deg = v.w; }
           unsigned run = cpre[c]; const int jbase = cbase[c];
           wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int j, int arc, int owner, const ArcRec &r) {
             const float oc = __shfl(cost, owner); const int oi = __shfl(i, owner);

@@ -4,9 +4,12 @@
 // --frames-per-chunk frames' worth of samples; the chunks go through the streaming drivers of k3_online.h (sample stash ->
 // k3_feat_compute_batch, input-context stash -> k3_nnet_forward planned once, k3_decoder_advance_decoding); a channel whose stream
 // ended is finalised (k3_decoder_finalize_channels), its lattice determinized on the host (default; see batched-wav-nnet3-cuda2.cc) and
-// written, and the channel given to the next file.  Lattices are bit-identical to batched-wav-nnet3-cuda2's.  Not implemented from the
-// reference program: the dynamic batcher's wall-clock pacing (--simulate-realtime-writing), latency statistics, partial hypotheses /
-// endpointing, CTM output.
+// written, and the channel given to the next file.  Lattices are bit-identical to batched-wav-nnet3-cuda2's.
+// The reference program's outputs (cudadecoderbin/cuda-bin-tools.h:33-104, batched-wav-nnet3-cuda-online.cc:150-320): --print-hypotheses / --print-partial-hypotheses /
+// --print-endpoints lines "corr_id #N ...", --write-lattice (default false, like the reference) / --generate-lattice, --lattice-postprocessor-rxfilename with CTM output when
+// the fourth argument is not a table wspecifier, and the latency statistics of PrintLatencyStats.  One deliberate difference: the reference ALWAYS plays its streams in real
+// time (a stream's chunk is submitted when it would have been spoken); here that is --simulate-realtime-writing=true and the default submits chunks as fast as the GPU takes
+// them (a throughput run; the latency of an utterance is then counted from the submission of its last chunk).
 #include <chrono>
 #include <cstring>
 #include <cmath>
@@ -15,6 +18,10 @@
 #include <deque>
 #include <iostream>
 #include <mutex>
+#include <random>
+#include <set>
+#include <sstream>
+#include <fstream>
 #include <thread>
 #include "k3_feat_options.h"
 #include "k3_online.h"
@@ -65,15 +72,33 @@ int main(int argc, char **argv) {
         "Usage: batched-wav-nnet3-cuda-online [options] <nnet3-in> <fst-in> <wav-rspecifier> <lattice-wspecifier>\n";
     ParseOptions po(usage);
     bool literal_order = true; float hash_ratio = 2.0f;
-    bool write_compact = true, write_lattice = true, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false,
-        print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
+    bool write_compact = true, write_lattice = false, generate_lattice = false, determinize = true, minimize = false, phone_det = true, word_det = true, print_partial = false,
+        print_hyp = false, print_endpoints = false, simulate_rt = false, reset_on_endpoint = false;
+    // OnlineEndpointConfig (online2/online-endpoint.h:122-170): {must_contain_nonsilence, min_trailing_silence, max_relative_cost, min_utterance_length} x 5
+    struct Rule { bool nonsil; float sil, rel, len; };
+    const float kInfF = std::numeric_limits<float>::infinity();
+    Rule rules[5] = {{false, 5.0f, kInfF, 0.0f}, {true, 0.5f, 2.0f, 0.0f}, {true, 1.0f, 8.0f, 0.0f}, {true, 2.0f, kInfF, 0.0f}, {false, 0.0f, kInfF, 20.0f}};
+    std::string silence_phones, postproc;
     int32_t worker_threads = -1;
     int32_t num_todo = -1, iterations = 1, max_batch = 400, num_channels = -1, frames_per_chunk = 51, subsampling = 1, num_streaming = 2000;
     int32_t max_active = 10000, min_active = 200, main_q = -1, aux_q = -1, ntok_pre = 1000000, max_frames = 6000;
     float beam = 15.0f, lattice_beam = 10.0f, acoustic_scale = 0.1f, beam_delta = 0.5f, det_delta = 1.0f / 1024.0f; int32_t det_max_mem = 50000000;
     std::string feature_type = "mfcc", mfcc_config, fbank_config, word_syms, use_gpu = "yes", ivector_config;
-    po.Register("write-lattice", &write_lattice, "Output lattice to a file. Setting to false is useful when benchmarking");
-    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output] (accepted, unused)");
+    po.Register("print-hypotheses", &print_hyp, "Prints the final hypotheses");
+    po.Register("print-partial-hypotheses", &print_partial, "Prints the partial hypotheses");
+    po.Register("print-endpoints", &print_endpoints, "Prints the detected endpoints");
+    po.Register("generate-lattice", &generate_lattice, "Generate full lattices");
+    po.Register("write-lattice", &write_lattice, "Output lattice to a file");
+    po.Register("lattice-postprocessor-rxfilename", &postproc, "(optional) Config file for lattice postprocessor");
+    po.Register("word-symbol-table", &word_syms, "Symbol table for words [for debug output]");
+    po.Register("endpoint.silence-phones", &silence_phones, "List of phones that are considered to be silence phones by the endpointing code.");
+    for (int r = 0; r < 5; r++) {
+      const std::string pre = "endpoint.rule" + std::to_string(r + 1) + ".";
+      po.Register(pre + "must-contain-nonsilence", &rules[r].nonsil, "If true, for this endpointing rule to apply there must be nonsilence in the best-path traceback.");
+      po.Register(pre + "min-trailing-silence", &rules[r].sil, "This endpointing rule requires duration of trailing silence (in seconds) to be >= this value.");
+      po.Register(pre + "max-relative-cost", &rules[r].rel, "This endpointing rule requires relative-cost of final-states to be <= this value (describes how good the probability of final-states is).");
+      po.Register(pre + "min-utterance-length", &rules[r].len, "This endpointing rule requires utterance-length (in seconds) to be >= this value.");
+    }
     po.Register("file-limit", &num_todo, "Limits the number of files that are processed by this driver.");
     po.Register("iterations", &iterations, "Number of times to decode the corpus. Output will be written only once.");
     po.Register("max-batch-size", &max_batch, "The maximum execution batch size (chunks evaluated together)");
@@ -89,9 +114,10 @@ int main(int argc, char **argv) {
     po.Register("phone-determinize", &phone_det, "If true, do an initial pass of determinization on both phones and words (see also --word-determinize)");
     po.Register("word-determinize", &word_det, "If true, do a second pass of determinization on words only (see also --phone-determinize)");
     po.Register("minimize", &minimize, "If true, push and minimize after determinization.");
-    po.Register("print-partial-hypotheses", &print_partial, "(not supported)"); po.Register("print-endpoints", &print_endpoints, "(not supported)");
-    po.Register("simulate-realtime-writing", &simulate_rt, "(accepted, unused: chunks are submitted as fast as the GPU takes them)");
-    po.Register("reset-on-endpoint", &reset_on_endpoint, "(accepted, unused)");
+    po.Register("simulate-realtime-writing", &simulate_rt,
+        "(not in the reference, whose streams are always paced) true = a stream's chunk is submitted when it would have been spoken: streams start at a random point of the first "
+        "second, latency = result time - end of speech; false = chunks are submitted as fast as the GPU takes them");
+    po.Register("reset-on-endpoint", &reset_on_endpoint, "Reset a decoder channel when endpoint detected. Do not close stream (accepted; streams are decoded as one segment)");
     po.Register("literal-order", &literal_order,
         "(not in the reference) true = raw lattices identical to the CPU LatticeFasterDecoder's; false = the order-independent fast decoder");
     po.Register("hash-ratio", &hash_ratio, "LatticeFasterDecoderConfig::hash_ratio (used with --literal-order)");
@@ -115,7 +141,7 @@ int main(int argc, char **argv) {
     po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)"); po.Register("use-gpu", &use_gpu, "(accepted; always the GPU)");
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
-    if (print_partial || print_endpoints) K3H_ERR << "--print-partial-hypotheses / --print-endpoints are not supported";
+    if (write_lattice) generate_lattice = true;
     DeterminizeLatticePhonePrunedOptions det_opts;
     det_opts.delta = det_delta;
     det_opts.max_mem = det_max_mem;
@@ -187,20 +213,72 @@ int main(int argc, char **argv) {
 
     auto scp = ReadScp(wav_rspec);
     if (num_todo >= 0 && (size_t)num_todo < scp.size()) scp.resize(num_todo);
-    std::unique_ptr<TableWriter> writer; if (write_lattice) writer.reset(new TableWriter(out_wspec));
-    std::unique_ptr<DeterminizeSequencer> det_pool;          // lattices are determinized on worker threads while the streams go on
-    if (writer && determinize) {
-      DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
-      pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
+    // OpenOutputHandles (cudadecoderbin/cuda-bin-tools.h:181-195): an output argument that is not a table wspecifier names a .ctm file
+    const bool ctm_mode = !(out_wspec.compare(0, 3, "ark") == 0 || out_wspec.compare(0, 3, "scp") == 0) || out_wspec.find(':') == std::string::npos;
+    if (!write_lattice && !ctm_mode) K3H_LOG << "If you want to write lattices to disk, please set --write-lattice=true";
+    std::shared_ptr<LatticePostprocessor> postprocessor; std::vector<std::string> syms;
+    if (postproc.empty()) { if (ctm_mode) K3H_ERR << "You must configure the lattice postprocessor with --lattice-postprocessor-rxfilename to use CTM output"; }
+    else {
+      postprocessor = LoadLatticePostprocessor(postproc);
+      postprocessor->SetDecoderFrameShift(fopts.frame_shift_ms * 1.0e-3f * subsampling);
+      postprocessor->SetTransitionInformation(&ti);
     }
-    int num_task = 0, num_err = 0; double total_audio = 0.0;
+    if (!word_syms.empty()) {      // fst::SymbolTable::ReadText: lines "symbol id"
+      std::istringstream in(ReadWholeInput(word_syms)); std::string sym; long id;
+      while (in >> sym >> id) { if (id >= 0) { if ((size_t)id >= syms.size()) syms.resize((size_t)id + 1); syms[(size_t)id] = sym; } }
+      if (syms.empty()) K3H_ERR << "Could not read symbol table from file " << word_syms;
+    }
+    std::unique_ptr<std::ofstream> ctm_file; if (ctm_mode) { ctm_file.reset(new std::ofstream(out_wspec)); if (!*ctm_file) K3H_ERR << "cannot open " << out_wspec; }
+    std::unique_ptr<TableWriter> writer; if (write_lattice && !ctm_mode) writer.reset(new TableWriter(out_wspec));
+    const bool want_lattice = writer || ctm_mode;      // result_type != 0 of the reference: a lattice (or the CTM made from it) is what the stream's latency waits for
+    // latency of stream k: its result's time - the time its speaker stopped (paced streams) / its last chunk was submitted (unpaced); the reference's PrintLatencyStats
+    std::vector<double> latencies; std::mutex lat_m; std::map<std::string, std::pair<size_t, double>> lat_pending;      // key -> (stream, stop time): closed by the determinization pool
+    const auto t_clock0 = std::chrono::steady_clock::now();
+    auto now_s = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_clock0).count(); };
+    std::unique_ptr<DeterminizeSequencer> det_pool;          // lattices are determinized on worker threads while the streams go on
+    if ((writer && (determinize || postprocessor)) || ctm_mode) {
+      DeterminizeSequencer::Config pc; pc.num_threads = worker_threads > 0 ? worker_threads : std::max(1, (int)std::thread::hardware_concurrency());
+      pc.beam = lattice_beam; pc.trans = &ti; pc.phone_det = det_opts; pc.determinize = determinize; pc.postprocessor = postprocessor; pc.ctm_out = ctm_file.get();
+      pc.word_syms = syms.empty() ? nullptr : &syms;
+      pc.on_done = [&](const std::string &key) {      // (a worker thread: the lattice / CTM of `key` exists now)
+        std::lock_guard<std::mutex> l(lat_m); auto it = lat_pending.find(key);
+        if (it != lat_pending.end()) { latencies[it->second.first] = now_s() - it->second.second; lat_pending.erase(it); }
+      };
+      det_pool.reset(new DeterminizeSequencer(pc, writer.get()));
+    }
+    // end-pointing (kaldi::EndpointDetected, online2/online-endpoint.cc:26-72) on the partial best path of a channel
+    std::set<int32_t> sil_phones; { std::string tok; std::istringstream in(silence_phones); while (std::getline(in, tok, ':')) if (!tok.empty()) sil_phones.insert(std::stoi(tok)); }
+    const float out_shift_s = fopts.frame_shift_ms * 1.0e-3f * subsampling;
+    auto words_of = [&](const int32_t *ol, int64_t n) {
+      std::string str;
+      for (int64_t k = 0; k < n; k++) {
+        if (ol[k] == 0) continue;
+        if (!str.empty()) str += " ";
+        str += ((size_t)ol[k] < syms.size() && !syms[ol[k]].empty()) ? syms[ol[k]] : std::to_string(ol[k]);
+      }
+      return str;
+    };
+    struct Paths { std::vector<int64_t> off; std::vector<int32_t> il, ol, rf; std::vector<float> g, ac, fc, rel; };
+    auto best_paths = [&](const std::vector<int32_t> &channels, bool use_final, Paths *bp) {      // (synchronises with the decoder's stream)
+      const int32_t n = (int32_t)channels.size(); bp->off.assign(n + 1, 0); bp->fc.assign(n, 0.f); bp->rel.assign(n, 0.f); bp->rf.assign(n, 0);
+      int64_t cap = 0; for (int32_t c : channels) cap += 2 * (int64_t)k3_decoder_num_frames_decoded(dec, c) + 64;
+      for (;;) {
+        bp->il.resize(cap); bp->ol.resize(cap); bp->g.resize(cap); bp->ac.resize(cap);
+        const int rc = k3_decoder_get_best_path(dec, channels.data(), n, use_final ? 1 : 0, bp->off.data(), cap, bp->il.data(), bp->ol.data(), bp->g.data(), bp->ac.data(),
+            bp->fc.data(), bp->rel.data(), bp->rf.data());
+        if (rc == K3_ERR_OVERFLOW) { cap *= 2; continue; }
+        K3H_CHECK_K3(rc); break;
+      }
+    };
+    int num_task = 0, num_err = 0; double total_audio = 0.0; size_t corr_cnt = 0;
     // per-channel state of the simulation
     // Feature rows a channel has computed but not yet fed to the network (less than a chunk, or waiting behind one) live COMPACTLY in one device buffer,
     // channel after channel, with
     // their (offset, count) on the host -- up to two segments per channel: what was left over + this round's new rows.  A pass takes its rows out with ONE row gather
     // (k3_mat_copy_rows) and the leftovers of all channels are gathered into the other buffer once per round: three launches per round where per-channel buffers cost ~2000
     // synchronous device copies per round (40 k copyBuffer calls = 46 % of the GPU time of a 512-channel run, 27 ms per round of 512 chunks).
-    struct Chan { int utt = -1; Wave wav; size_t pos = 0; int pend = 0; bool started = false; int64_t seg_off[2] = {0, 0}; int seg_cnt[2] = {0, 0}; };
+    struct Chan { int utt = -1; Wave wav; size_t pos = 0; int pend = 0; bool started = false; int64_t seg_off[2] = {0, 0}; int seg_cnt[2] = {0, 0};
+                  size_t corr_id = 0; double next_at = 0.0, stop_at = 0.0; };      // stream id (admission order); when its next chunk is spoken / its speaker stops (paced runs)
     std::vector<Chan> chan(nch);
     DevBuf<float> held[2], newbuf; DevBuf<int32_t> gidx; int held_cur = 0; int64_t held_rows = 0;
     const size_t pend_cap = (size_t)(2 * C + 8);
@@ -216,6 +294,7 @@ int main(int argc, char **argv) {
       }
     };
     WavePrefetcher prefetch(scp, iterations, (size_t)2 * nch + 8, 8);
+    std::mt19937 rng(std::random_device{}()); std::uniform_real_distribution<double> start_jitter(0.0, 1.0); bool add_random_offset = simulate_rt;
     const auto t_start = std::chrono::steady_clock::now();
     for (int iter = 0; iter < iterations; iter++) {
       std::deque<int> queue; for (size_t i = 0; i < scp.size(); i++) queue.push_back((int)i);
@@ -231,16 +310,31 @@ int main(int argc, char **argv) {
           if (k3_feat_num_frames(plan, (int64_t)w.samples.size()) == 0) { K3H_WARN << "Utterance " << scp[u].first << " is too short to decode"; num_err++; ch--; continue; }
           total_audio += w.samples.size() / (double)w.samp_freq; num_task++;
           chan[ch] = Chan(); chan[ch].utt = u; chan[ch].wav = std::move(w); busy++;
+          chan[ch].corr_id = corr_cnt++; latencies.push_back(0.0);
+          {      // the stream starts now (the first ones: somewhere in the first second, batched-wav-nnet3-cuda-online.cc:150-177); its first chunk exists once it has been spoken
+            const double dur = chan[ch].wav.samples.size() / (double)chan[ch].wav.samp_freq, start = now_s() + (add_random_offset ? start_jitter(rng) : 0.0);
+            chan[ch].next_at = start + std::min(dur, chunk_samples / (double)fopts.samp_freq); chan[ch].stop_at = start + dur;
+          }
         }
+        add_random_offset = false;
         if (busy == 0) break;
+        if (simulate_rt) {      // nothing to submit before the earliest chunk has been spoken
+          double first = 1e300; for (int ch = 0; ch < nch; ch++) if (chan[ch].utt >= 0) first = std::min(first, chan[ch].next_at);
+          const double wait = first - now_s(); if (wait > 0) std::this_thread::sleep_for(std::chrono::duration<double>(wait));
+        }
+        const double t_round = now_s();
         // one chunk of audio per busy channel
         std::vector<int> chs; std::vector<const float *> chunk_ptr; std::vector<size_t> chunk_len; std::vector<char> first, last;
         for (int ch = 0; ch < nch; ch++) {
           Chan &c = chan[ch]; if (c.utt < 0) continue;
+          if (simulate_rt && c.next_at > t_round) continue;      // (its next chunk has not been spoken yet)
           const size_t n = std::min<size_t>(chunk_samples, c.wav.samples.size() - c.pos);
           chs.push_back(ch); chunk_ptr.push_back(c.wav.samples.data() + c.pos); chunk_len.push_back(n);      // (the chunk is read where it lies: no copy out of the waveform)
           first.push_back(c.pos == 0); c.pos += n; last.push_back(c.pos == c.wav.samples.size());
+          c.next_at += std::min<size_t>(chunk_samples, c.wav.samples.size() - c.pos) / (double)fopts.samp_freq;
+          if (!simulate_rt && last.back()) c.stop_at = t_round;
         }
+        if (chs.empty()) continue;
         std::vector<int32_t> fresh; for (size_t i = 0; i < chs.size(); i++) if (first[i]) { fresh.push_back(chs[i]); net.Reset(chs[i]); }
         if (!fresh.empty()) K3H_CHECK_K3(k3_decoder_init_channels(dec, fresh.data(), (int32_t)fresh.size(), ds));
         float *d_feats = nullptr;
@@ -309,21 +403,53 @@ int main(int argc, char **argv) {
           }
           held_cur ^= 1; held_rows = at;
         }
+        // the BestPathCallback of the reference (batched-threaded-nnet3-cuda-online-pipeline.cc:455-475), for the streams that go on: partial hypothesis and end-point
+        if (print_partial || print_endpoints) {
+          std::vector<int32_t> cont; for (size_t i = 0; i < chs.size(); i++) if (!last[i] && k3_decoder_num_frames_decoded(dec, chs[i]) > 0) cont.push_back(chs[i]);
+          if (!cont.empty()) {
+            Paths bp; best_paths(cont, false, &bp);
+            for (size_t u = 0; u < cont.size(); u++) {
+              const Chan &c = chan[cont[u]];
+              if (print_partial) K3H_LOG << "corr_id #" << c.corr_id << " [partial] : " << words_of(bp.ol.data() + bp.off[u], bp.off[u + 1] - bp.off[u]);
+              if (print_endpoints) {
+                int32_t sil = 0, frames = 0;
+                for (int64_t k = bp.off[u + 1] - 1; k >= bp.off[u]; k--) {
+                  const int32_t t = bp.il[k]; if (t == 0) continue;
+                  if (!((size_t)t < ti.id2phone.size() && sil_phones.count(ti.id2phone[t]))) break;
+                  sil++;
+                }
+                for (int64_t k = bp.off[u]; k < bp.off[u + 1]; k++) frames += bp.il[k] != 0;
+                const float len = frames * out_shift_s, ts = sil * out_shift_s; bool ep = false;
+                for (const Rule &r : rules) ep = ep || (((len > ts) || !r.nonsil) && ts >= r.sil && bp.rel[u] <= r.rel && len >= r.len);
+                if (ep) K3H_LOG << "corr_id #" << c.corr_id << " [endpoint detected]";
+              }
+            }
+          }
+        }
         // finalise the channels whose stream ended, write their lattices, free the channels
         std::vector<int32_t> ended; for (size_t i = 0; i < chs.size(); i++) if (last[i]) ended.push_back(chs[i]);
         if (!ended.empty()) {
           K3H_CHECK_K3(k3_decoder_finalize_channels(dec, ended.data(), (int32_t)ended.size(), ds));
+          if (print_hyp || !want_lattice) {      // the final best path (with final-probs): the result a stream without a lattice callback waits for
+            Paths bp; best_paths(ended, true, &bp); const double t_res = now_s();
+            for (size_t u = 0; u < ended.size(); u++) {
+              const Chan &c = chan[ended[u]];
+              if (!want_lattice) latencies[c.corr_id] = t_res - c.stop_at;
+              if (print_hyp) K3H_LOG << "corr_id #" << c.corr_id << " : " << words_of(bp.ol.data() + bp.off[u], bp.off[u + 1] - bp.off[u]);
+            }
+          }
           const int U = (int)ended.size();
           std::vector<int64_t> info(10 * (size_t)U); K3H_LATTICE_INFO(dec, info.data());
           int64_t NS = 0, NA = 0; for (int u = 0; u < U; u++) { NS += info[10 * u]; NA += info[10 * u + 1]; }
           std::vector<int32_t> sf(NS + 1), ss(NS + 1), as(NA + 1), ad(NA + 1), ai(NA + 1), ao(NA + 1); std::vector<float> sc(NS + 1), sfin(NS + 1), ag(NA + 1), aa(NA + 1);
-          if (NS > 0) K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(),
+          if (NS > 0 && want_lattice) K3H_CHECK_K3(k3_decoder_get_raw_lattices(dec, sf.data(), ss.data(), sc.data(), sfin.data(), as.data(), ad.data(), ai.data(), ao.data(),
               ag.data(), aa.data()));
           int64_t s0 = 0, a0 = 0;
           for (int u = 0; u < U; u++) {
             const int64_t ns = info[10 * u], na = info[10 * u + 1]; const std::string &key = scp[chan[ended[u]].utt].first;
             if (info[10 * u + 2] != 0 || ns == 0) { K3H_WARN << "Failed to decode utterance with id " << key; num_err++; }
-            else if (iter == 0 && writer) {
+            else if (want_lattice && !(iter == 0) ) { latencies[chan[ended[u]].corr_id] = now_s() - chan[ended[u]].stop_at; }      // (later iterations: decoded, not written)
+            else if (iter == 0 && want_lattice) {
               if (!info[10 * u + 3]) K3H_WARN << "Outputting partial output for utterance " << key << " since no final-state reached";
               Lattice lat;
               lat.st_frame.assign(sf.begin() + s0, sf.begin() + s0 + ns);
@@ -337,9 +463,12 @@ int main(int argc, char **argv) {
               lat.arc_ac.assign(aa.begin() + a0, aa.begin() + a0 + na);
               for (int64_t s = 0; s < ns; s++) if (lat.st_frame[s] == 0 && lat.st_state[s] == hfst.start) lat.start = (int32_t)s;
               Connect(&lat);
-              if (det_pool) det_pool->Run(key, std::move(lat));
-        else if (write_compact) { CompactLattice clat; ConvertLattice(lat, &clat); writer->WriteCompactLattice(key, clat); }
-        else writer->WriteLattice(key, lat);
+              if (det_pool) { { std::lock_guard<std::mutex> l(lat_m); lat_pending[key] = std::make_pair(chan[ended[u]].corr_id, chan[ended[u]].stop_at); } det_pool->Run(key, std::move(lat)); }
+              else {
+                if (write_compact) { CompactLattice clat; ConvertLattice(lat, &clat); writer->WriteCompactLattice(key, clat); }
+                else writer->WriteLattice(key, lat);
+                latencies[chan[ended[u]].corr_id] = now_s() - chan[ended[u]].stop_at;
+              }
             }
             s0 += ns; a0 += na;
             chan[ended[u]] = Chan(); busy--;
@@ -351,6 +480,18 @@ int main(int argc, char **argv) {
     if (det_pool) { det_pool->Wait(); det_pool.reset(); }
     if (writer) writer->Flush();
     const double total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    {      // PrintLatencyStats (cudadecoderbin/cuda-bin-tools.h:33-55)
+      K3H_LOG << "Latency stats:";
+      std::vector<double> lat; { std::lock_guard<std::mutex> l(lat_m); lat = latencies; }
+      if (!lat.empty()) {
+        double total = 0.0; for (double x : lat) total += x;
+        std::sort(lat.begin(), lat.end()); const double n = (double)lat.size();
+        const double l90 = lat[(size_t)std::floor(90. * n / 100.)], l95 = lat[(size_t)std::floor(95. * n / 100.)], l99 = lat[(size_t)std::floor(99. * n / 100.)];
+        K3H_LOG << "Latencies (s):\tAvg\t\t90%\t\t95%\t\t99%";
+        std::ostringstream os; os << std::fixed; os.precision(3); os << "\t\t\t" << total / n << "\t\t" << l90 << "\t\t" << l95 << "\t\t" << l99;
+        K3H_LOG << os.str();
+      }
+    }
     K3H_LOG << "Decoded " << num_task << " utterances, " << num_err << " with errors.";
     K3H_LOG << "Overall: " << " Aggregate Total Time: " << total_time << " Total Audio: " << total_audio << " RealTimeX: " << total_audio / total_time;
     ivs.reset(); if (ivx) k3_ivector_destroy(ivx);

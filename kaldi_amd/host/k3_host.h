@@ -16,6 +16,7 @@
 #include <memory>
 #include <sstream>
 #include <stdexcept>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -224,6 +225,8 @@ class DeterminizeSequencer {
     // with `ctm_out` the record written
     // is the utterance's CTM lines (LatticePostprocessor::GetCTM + MergeSegmentsToCTMOutput) instead of the lattice -- `writer` may then be null
     std::shared_ptr<class LatticePostprocessor> postprocessor; std::ostream *ctm_out = nullptr; const std::vector<std::string> *word_syms = nullptr; bool determinize = true;
+    // called by a worker thread when `key`'s result exists (before it is written in its turn): the moment a streaming caller's latency clock stops
+    std::function<void(const std::string &key)> on_done;
   };
   DeterminizeSequencer(const Config &config, TableWriter *writer);
   ~DeterminizeSequencer();

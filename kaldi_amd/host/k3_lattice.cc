@@ -1154,6 +1154,7 @@ struct DeterminizeSequencer::Impl {
         }
       } catch (const std::exception &e) { err = e.what(); }
       job.lat = Lattice();
+      if (cfg.on_done) cfg.on_done(job.key);
       std::unique_lock<std::mutex> lk(m);
       if (!err.empty() && error.empty()) error = err;
       num_warn += warn;

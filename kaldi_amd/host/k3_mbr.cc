@@ -287,7 +287,7 @@ double MinimumBayesRisk::GetBayesRisk() const { return impl_->L; }
 // ---- WordAlignLattice (lat/word-align-lattice.cc) -------------------------------------------------------------------------------
 // The reference builds a new lattice whose states are (input state, computation state) pairs -- the computation state holds the transition-ids and word labels seen but not yet
 // put on an output arc, and the weight that goes with them -- expands them from a LIFO queue (:204-248), lets a computation state emit an arc as soon as it holds a complete word /
-// silence (OutputNormalWordArc / OutputSilenceArc / OutputOnePhoneWordArc, :349-533) before any more input is read, forces out what is left at the final state (:591-667), and
+// silence (OutputNormalWordArc / OutputSilenceArc / OutputOnePhoneWordArc, :349-533; here: OutputCompleteUnit) before any more input is read, forces out what is left at the final state (:591-667), and
 // then removes the epsilon arcs that carried the input (fst::RmEpsilon + Connect) and, when the silence / partial-word labels were asked to be 0, maps the stand-in labels back
 // (RemoveSomeInputSymbols + Project, :292-306).  Restated over plain vectors; the order in which states and arcs are created is the reference's (the pin compares whole lattices).
 namespace {
@@ -335,89 +335,58 @@ struct AlignCtx { const TransitionInfo &tm; const WordBoundaryInfo &info; bool *
     if (tid <= 0 || (size_t)tid >= tm.id2phone.size()) K3H_ERR << "WordAlignLattice: transition-id " << tid << " is not in the model";
     return tm.id2phone[tid];
   }
-  bool Final(int32_t tid) const { return tm.is_final[tid] != 0; } bool SelfLoop(int32_t tid) const { return tm.self_loop[tid] != 0; } };
+  // (every id goes through Phone()'s range check first: the unit walkers ask Final() before they ask Phone())
+  bool Final(int32_t tid) const { Phone(tid); return tm.is_final[tid] != 0; } bool SelfLoop(int32_t tid) const { Phone(tid); return tm.self_loop[tid] != 0; } };
 
-bool OutputSilenceArc(CompState &c, const AlignCtx &x, WArc *out) {      // :349-393
-  if (c.tids.empty()) return false;
-  const int32_t phone = x.Phone(c.tids[0]);
-  if (x.info.TypeOfPhone(phone) != WordBoundaryInfo::kNonWordPhone) return false;
-  const size_t len = c.tids.size(); size_t i;
-  for (i = 0; i < len; i++) {
-    const int32_t tid = c.tids[i];
-    if (x.Phone(tid) != phone && !*x.error) {
-      *x.error = true;
-      K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]";
-    }
-    if (x.Final(tid)) break;
-  }
-  if (i == len) return false;
-  i++;
-  if (x.info.reorder) while (i < len && x.SelfLoop(c.tids[i])) i++;
-  if (i == len) return false;
-  if (x.Phone(c.tids[i - 1]) != phone && !*x.error) K3H_WARN << "Phone changed unexpectedly in lattice [broken lattice or mismatched model?]";
-  *out = WArc{x.info.silence_label, -1, CW{c.weight, std::vector<int32_t>(c.tids.begin(), c.tids.begin() + i)}};
-  c.tids.erase(c.tids.begin(), c.tids.begin() + i); c.weight = LW();
-  return true;
-}
-bool OutputOnePhoneWordArc(CompState &c, const AlignCtx &x, WArc *out) {      // :396-446
-  if (c.tids.empty() || c.words.empty()) return false;
-  const int32_t phone = x.Phone(c.tids[0]);
-  if (x.info.TypeOfPhone(phone) != WordBoundaryInfo::kWordBeginAndEndPhone) return false;
-  const size_t len = c.tids.size(); size_t i;
-  for (i = 0; i < len; i++) {
-    const int32_t tid = c.tids[i];
-    if (x.Phone(tid) != phone && !*x.error) K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]";
-    if (x.Final(tid)) break;
-  }
-  if (i == len) return false;
-  i++;
-  if (x.info.reorder) while (i < len && x.SelfLoop(c.tids[i])) i++;
-  if (i == len) return false;
-  if (x.Phone(c.tids[i - 1]) != phone && !*x.error) { K3H_WARN << "Phone changed unexpectedly in lattice [broken lattice or mismatched model?]"; *x.error = true; }
-  const int32_t word = c.words[0];
-  *out = WArc{word, -1, CW{c.weight, std::vector<int32_t>(c.tids.begin(), c.tids.begin() + i)}};
-  c.tids.erase(c.tids.begin(), c.tids.begin() + i); c.words.erase(c.words.begin()); c.weight = LW();
-  return true;
-}
-bool OutputNormalWordArc(CompState &c, const AlignCtx &x, WArc *out) {      // :451-545: a word of at least two phones
-  if (c.tids.empty() || c.words.empty()) return false;
-  const int32_t begin_phone = x.Phone(c.tids[0]);
-  if (x.info.TypeOfPhone(begin_phone) != WordBoundaryInfo::kWordBeginPhone) return false;
-  const size_t len = c.tids.size(); size_t i;
-  for (i = 0; i < len && !x.Final(c.tids[i]); i++);
-  if (i == len) return false;
-  i++;
-  if (x.info.reorder) for (; i < len && x.SelfLoop(c.tids[i]); i++);
-  if (i == len) return false;
-  if (x.Phone(c.tids[i - 1]) != begin_phone && !*x.error) { K3H_WARN << "Phone changed unexpectedly in lattice [broken lattice or mismatched model?]"; *x.error = true; }
+// What a computation state can emit before more input is read (:349-545) is ONE complete unit at the front of its transition-ids: a silence, a one-phone word or a word of
+// several phones.  The class of the first phone says which (the three are exclusive), and a unit is a run of PHONE SPANS -- a span = the transition-ids of one phone up to and
+// including its final transition-id and, with --reorder, the self-loops behind it -- so one routine walks them from a table instead of one function per unit.  What differs
+// between the units is in the table: whether a word label goes with it, and, because the lattices this runs on may be broken, which of the reference's consistency checks
+// warn and which of them also raise the aligner's error flag (the flag silences every later warning and decides WordAlignLattice's return value, so the pin needs it exact).
+struct SpanRule { bool check_phone, raise_on_change;        // while looking for the final transition-id: compare every id's phone with the span's / also raise the flag
+                  bool raise_after; const char *after_msg; };      // behind the self-loops: the last id's phone is compared; flag; the warning's text
+struct UnitRule { WordBoundaryInfo::PhoneType opens; bool takes_word, has_inner_phones; SpanRule first, last; };
+const char *const kMsgChanged = "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]";
+const char *const kMsgUnexpected = "Phone changed unexpectedly in lattice [broken lattice or mismatched model?]";
+const UnitRule kUnitRules[3] = {
+    {WordBoundaryInfo::kNonWordPhone, false, false, {true, true, false, kMsgUnexpected}, {}},                  // silence (:349-393)
+    {WordBoundaryInfo::kWordBeginAndEndPhone, true, false, {true, false, true, kMsgUnexpected}, {}},         // one-phone word (:396-446)
+    {WordBoundaryInfo::kWordBeginPhone, true, true, {false, false, true, kMsgUnexpected},                     // word of at least two phones (:451-545): begin phone ...
+     {true, true, true, "Phone changed while following final self-loop [broken lattice or mismatched model or wrong --reorder option?]"}}};      // ... and end phone
+// one span starting at *pos; false when the ids run out before the span is known to be over (the unit cannot be emitted yet)
+bool WalkSpan(const CompState &c, const AlignCtx &x, const SpanRule &r, int32_t phone, size_t *pos) {
+  const size_t len = c.tids.size(); size_t i = *pos;
   for (; i < len; i++) {
-    const int32_t this_phone = x.Phone(c.tids[i]);
-    if (x.info.TypeOfPhone(this_phone) == WordBoundaryInfo::kWordEndPhone) break;
-    if (x.info.TypeOfPhone(this_phone) != WordBoundaryInfo::kWordInternalPhone && !*x.error) {
-      K3H_WARN << "Unexpected phone " << this_phone << " found inside a word.";
-      *x.error = true;
-    }
-  }
-  if (i == len) return false;
-  const int32_t final_phone = x.Phone(c.tids[i]);
-  for (; i < len; i++) {
-    if (x.Phone(c.tids[i]) != final_phone && !*x.error) {
-      *x.error = true;
-      K3H_WARN << "Phone changed before final transition-id found [broken lattice or mismatched model or wrong --reorder option?]";
-    }
+    if (r.check_phone && x.Phone(c.tids[i]) != phone && !*x.error) { if (r.raise_on_change) *x.error = true; K3H_WARN << kMsgChanged; }
     if (x.Final(c.tids[i])) break;
   }
   if (i == len) return false;
   i++;
   if (x.info.reorder) while (i < len && x.SelfLoop(c.tids[i])) i++;
   if (i == len) return false;
-  if (x.Phone(c.tids[i - 1]) != final_phone && !*x.error) {
-    *x.error = true;
-    K3H_WARN << "Phone changed while following final self-loop [broken lattice or mismatched model or wrong --reorder option?]";
+  if (x.Phone(c.tids[i - 1]) != phone && !*x.error) { if (r.raise_after) *x.error = true; K3H_WARN << r.after_msg; }
+  *pos = i;
+  return true;
+}
+bool OutputCompleteUnit(CompState &c, const AlignCtx &x, WArc *out) {
+  if (c.tids.empty()) return false;
+  const int32_t phone0 = x.Phone(c.tids[0]); const WordBoundaryInfo::PhoneType type0 = x.info.TypeOfPhone(phone0);
+  const UnitRule *u = nullptr; for (const UnitRule &r : kUnitRules) if (r.opens == type0) u = &r;
+  if (!u || (u->takes_word && c.words.empty())) return false;
+  size_t i = 0;
+  if (!WalkSpan(c, x, u->first, phone0, &i)) return false;
+  if (u->has_inner_phones) {
+    const size_t len = c.tids.size();
+    for (; i < len; i++) {      // the word-internal phones, up to the first id of a word-end phone
+      const int32_t ph = x.Phone(c.tids[i]); const WordBoundaryInfo::PhoneType t = x.info.TypeOfPhone(ph);
+      if (t == WordBoundaryInfo::kWordEndPhone) break;
+      if (t != WordBoundaryInfo::kWordInternalPhone && !*x.error) { K3H_WARN << "Unexpected phone " << ph << " found inside a word."; *x.error = true; }
+    }
+    if (i == len) return false;
+    if (!WalkSpan(c, x, u->last, x.Phone(c.tids[i]), &i)) return false;
   }
-  const int32_t word = c.words[0];
-  *out = WArc{word, -1, CW{c.weight, std::vector<int32_t>(c.tids.begin(), c.tids.begin() + i)}};
-  c.tids.erase(c.tids.begin(), c.tids.begin() + i); c.words.erase(c.words.begin()); c.weight = LW();
+  *out = WArc{u->takes_word ? c.words[0] : x.info.silence_label, -1, CW{c.weight, std::vector<int32_t>(c.tids.begin(), c.tids.begin() + i)}};
+  c.tids.erase(c.tids.begin(), c.tids.begin() + i); if (u->takes_word) c.words.erase(c.words.begin()); c.weight = LW();
   return true;
 }
 bool IsPlausibleWord(const AlignCtx &x, const std::vector<int32_t> &tids) {      // :549-569
@@ -640,7 +609,7 @@ bool WordAlignLattice(const CompactLattice &lat, const TransitionInfo &tmodel, c
     Tuple tuple = std::move(queue.back().first); const int32_t ostate = queue.back().second; queue.pop_back();      // ProcessQueueElement (:204-248)
     WArc arc;
     // something complete is pending: emit it before reading on
-    if (OutputNormalWordArc(tuple.c, ctx, &arc) || OutputSilenceArc(tuple.c, ctx, &arc) || OutputOnePhoneWordArc(tuple.c, ctx, &arc)) {
+    if (OutputCompleteUnit(tuple.c, ctx, &arc)) {
       arc.next = state_for(tuple); out.arcs[ostate].push_back(std::move(arc));
       continue;
     }

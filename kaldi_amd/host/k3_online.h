@@ -115,7 +115,15 @@ class StaticNnet3 {
       : stream_(stream), B_(max_batch), nch_(nchannels), C_(frames_per_chunk), s_(subsampling) {
     if (C_ <= 0 || C_ % s_) K3H_ERR << "--frames-per-chunk must be a positive multiple of --frame-subsampling-factor";
     k3_nnet_info ni; K3H_CHECK_K3(k3_nnet_get_info(nnet, &ni));
-    if (ni.ivector_dim == 0 && !getenv("K3_ONLINE_RECOMPUTE_CONTEXT") && k3_nnet_stream_create(nnet, nch_, C_, s_, log_priors, acoustic_scale, &inc_) == K3_OK) {
+    // (only K3_ERR_UNSUPPORTED -- a model the stateful engine cannot run -- selects the chunk + context scheme, and says so once; a device or allocation failure is an error,
+    // not a silent change to the several-times slower engine: ADVICE r5)
+    int rc_stream = K3_ERR_UNSUPPORTED;
+    if (ni.ivector_dim == 0 && !getenv("K3_ONLINE_RECOMPUTE_CONTEXT")) {
+      rc_stream = k3_nnet_stream_create(nnet, nch_, C_, s_, log_priors, acoustic_scale, &inc_);
+      if (rc_stream == K3_ERR_UNSUPPORTED) K3H_LOG << "StaticNnet3: the stateful streaming engine does not take this model (" << k3_last_error() << "); chunks are evaluated with their context";
+      else if (rc_stream != K3_OK) K3H_CHECK_K3(rc_stream);
+    }
+    if (rc_stream == K3_OK) {
       k3_nnet_stream_info si;
       K3H_CHECK_K3(k3_nnet_stream_get_info(inc_, &si));
       dim_ = ni.input_dim;

@@ -60,9 +60,20 @@ int main(int argc, char **argv) {
     // two channels share the ONE lane (nlanes = 1 < nchannels = 2, cuda-decoder.h:224-229): the same utterance is decoded on both, their AdvanceDecoding calls alternating --
     // every call carries a single (channel, frame pointer) pair; a channel's state stays resident between its calls
     decoder.InitDecoding(std::vector<ChannelId>{0, 1});
+    // channel 0 goes through the DEPRECATED overload (cuda-decoder.h:267-270): a CudaDecodableInterface that hands out device pointers frame by frame, at most n frames a call
+    struct RowsDecodable : public CudaDecodableInterface {
+      float *rows; int32 T, P;
+      RowsDecodable(float *rows, int32 T, int32 P) : rows(rows), T(T), P(P) {}
+      BaseFloat LogLikelihood(int32, int32) override { return 0.0f; }
+      bool IsLastFrame(int32 frame) const override { return frame == T - 1; }
+      int32 NumFramesReady() const override { return T; }
+      int32 NumIndices() const override { return P; }
+      BaseFloat *GetLogLikelihoodsCudaPointer(int32 subsampled_frame) override { return rows + (size_t)subsampled_frame * P; }
+    } decodable0(d_ll, T, P);
     for (int32 t = 0; t < T; t += step) {
       const int32 n = std::min(step, T - t);
       for (ChannelId ch : {1, 0}) {
+        if (ch == 0) { std::vector<ChannelId> c0 = {0}; std::vector<CudaDecodableInterface *> d0 = {&decodable0}; decoder.AdvanceDecoding(c0, d0, n); continue; }
         std::vector<std::pair<ChannelId, const BaseFloat *>> lanes = {{ch, d_ll + (size_t)t * P}};
         if (n == 1) decoder.AdvanceDecoding(lanes); else decoder.AdvanceDecoding(lanes, n, P);
       }

@@ -244,7 +244,7 @@ def test_batched_wav_nnet3_cuda_online_equals_offline_program(tmp_path):
     off = _parse_text_lattices(f"{td}/off.txt")
     for fpc, nch in ((150, 2), (30, 3)):
         import time; t0 = time.time()
-        b = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + [f"--num-channels={nch}", f"--frames-per-chunk={fpc}", "--max-utterance-frames=400",
+        b = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + ["--write-lattice=true", f"--num-channels={nch}", f"--frames-per-chunk={fpc}", "--max-utterance-frames=400",
                                                                                             f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark,t:{td}/on.txt"], capture_output=True, text=True)
         assert b.returncode == 0, b.stderr
         print("online program", fpc, nch, "%.1f s" % (time.time() - t0), b.stderr.strip().splitlines()[-1])
@@ -598,7 +598,7 @@ def test_online_program_with_an_ivector_model_equals_the_python_pipeline(tmp_pat
     graph = synth.make_hclg(3000, 8000, N, seed=11, start_degree=50); graph.write_openfst(f"{td}/HCLG.fst")
     C = 60
     common = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", "--determinize-lattice=false", "--write-compact=false",
-              "--num-channels=3", f"--frames-per-chunk={C}", "--max-utterance-frames=400"]
+              "--num-channels=3", f"--frames-per-chunk={C}", "--max-utterance-frames=400", "--write-lattice=true"]
     tail = [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp"]
     b = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + [f"--ivector-extraction-config={td}/ivector.conf"] + tail + [f"ark,t:{td}/on.txt"], capture_output=True, text=True)
     assert b.returncode == 0 and "Decoded 3 utterances, 0 with errors." in b.stderr, b.stderr[-2000:]
@@ -759,3 +759,101 @@ def test_ntokens_pre_allocated_is_a_reservation_60s_utterance_equals_the_referen
     t = subprocess.run(base + ["--ntokens-pre-allocated=200000", "--file-limit=1"] + tail + [f"ark,t:{td}/one.txt"], capture_output=True, text=True); assert t.returncode == 0, t.stderr
     arcs, fins = _parse_text_lattices(f"{td}/one.txt")["utt0"]; ref = lat.connect()
     assert len(arcs) == ref.num_arcs and sorted((x[2], x[3]) for x in arcs) == sorted(zip(ref.arc_ilabel.tolist(), ref.arc_olabel.tolist()))
+
+
+def _online_setup(td, lens, N=120):
+    _wavs(td, lens)
+    calib = (np.random.default_rng(1).standard_normal((200, 40)) * 1.2 + 16.5).astype(np.float32)
+    synth.make_tdnnf(seed=3, dim=96, bottleneck=24, strides=(1, 0, 3, 3), prefinal_small=48, num_pdfs=N, calib_feats=calib, out_std=1.5).write(f"{td}/final.mdl", as_mdl=True, num_pdfs=N)
+    synth.make_hclg(3000, 8000, N, seed=11, start_degree=50).write_openfst(f"{td}/HCLG.fst")
+    open(f"{td}/fbank.conf", "w").write("--num-mel-bins=40\n--dither=0\n"); open(f"{td}/pp.conf", "w").write("--acoustic-scale=0.7\n--lm-scale=1.5\n")
+    return ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=6.0", "--max-active=10000"]
+
+def _corr_lines(stderr, tag):
+    """'corr_id #N<tag>...' log lines -> {N: [texts]} (cudadecoderbin/batched-wav-nnet3-cuda-online.cc:180-215)"""
+    import re
+    out = {}
+    for l in stderr.splitlines():
+        m = re.search(r"corr_id #(\d+)" + re.escape(tag) + r"(.*)$", l)
+        if m: out.setdefault(int(m.group(1)), []).append(m.group(2).strip())
+    return out
+
+def test_online_program_print_hypotheses_equal_the_offline_lattices_best_path(tmp_path):
+    """--print-hypotheses (cuda-bin-tools.h:83-85, batched-wav-nnet3-cuda-online.cc:207-210): the words of the final best path of every stream, 'corr_id #N : words'; with
+    --word-symbol-table the symbols.  Equal to the cheapest path of the lattice batched-wav-nnet3-cuda2 writes for the same file.  No lattice is written without --write-lattice=true
+    (the reference's default) and the program says so."""
+    td = str(tmp_path); lens = [16000, 9000, 23001]; common = _online_setup(td, lens)
+    tail = [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp"]
+    a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=3"] + tail + [f"ark,t:{td}/det.txt"], capture_output=True, text=True); assert a.returncode == 0, a.stderr[-2000:]
+    from tests.lattice_cases import parse_compact_text
+    want = {k: _compact_best_words(c) for k, c in parse_compact_text(open(f"{td}/det.txt").read()).items()}
+    b = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + ["--num-channels=3", "--frames-per-chunk=60", "--max-utterance-frames=400", "--print-hypotheses=true"] + tail + [f"ark:{td}/none.ark"],
+                       capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-2000:]
+    assert "please set --write-lattice=true" in b.stderr and not os.path.exists(f"{td}/none.ark")
+    hyp = _corr_lines(b.stderr, " :")
+    assert sorted(hyp) == [0, 1, 2] and all(len(v) == 1 for v in hyp.values())
+    for u in range(3): assert [int(w) for w in hyp[u][0].split()] == want[f"utt{u}"] and len(want[f"utt{u}"]) > 0, u      # (stream N = the N-th file admitted)
+    assert "Latency stats:" in b.stderr and "Latencies (s):" in b.stderr      # PrintLatencyStats (cuda-bin-tools.h:33-55)
+    # the symbols of --word-symbol-table
+    ids = sorted({w for v in want.values() for w in v}); open(f"{td}/words.txt", "w").write("<eps> 0\n" + "".join(f"W{w} {w}\n" for w in ids))
+    c = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + ["--num-channels=3", "--frames-per-chunk=60", "--max-utterance-frames=400", "--print-hypotheses=true", f"--word-symbol-table={td}/words.txt"]
+                       + tail + [f"ark:{td}/none.ark"], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    for u, v in _corr_lines(c.stderr, " :").items(): assert v[0].split() == [f"W{w}" for w in want[f"utt{u}"]], u
+
+def test_online_program_partial_hypotheses_and_endpoints(tmp_path):
+    """--print-partial-hypotheses / --print-endpoints (batched-wav-nnet3-cuda-online.cc:194-205): after every chunk of a stream that goes on, the words of its best path so far
+    (no final-probs) and whether kaldi::EndpointDetected fires on it (online2/online-endpoint.cc:26-72; the rules' options as OnlineEndpointConfig registers them).  The
+    partial hypotheses of a stream are the k3_decoder_get_best_path results the library's own test pins to the lattice's best path; here: one line per chunk but the last, and the
+    end-point lines follow the rules -- rule 5 alone (utterance >= 0.9 s) fires from the chunk that brings a stream to 0.9 s on, with every rule out of reach never."""
+    td = str(tmp_path); lens = [32000, 9000, 23001]; common = _online_setup(td, lens)
+    tail = [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/none.ark"]
+    C = 30; off = ["--endpoint.rule%d.min-trailing-silence=1000" % r for r in (1, 2, 3, 4)]
+    run = lambda extra: subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + ["--num-channels=3", f"--frames-per-chunk={C}", "--max-utterance-frames=400", "--print-partial-hypotheses=true",
+                                                                                                     "--print-endpoints=true", "--print-hypotheses=true"] + extra + tail, capture_output=True, text=True)
+    b = run(off + ["--endpoint.rule5.min-utterance-length=0.9"]); assert b.returncode == 0, b.stderr[-2000:]
+    part, ep, fin = _corr_lines(b.stderr, " [partial] :"), _corr_lines(b.stderr, " [endpoint detected]"), _corr_lines(b.stderr, " :")
+    chunk = C * 160
+    for u, n in enumerate(lens):
+        nchunks = -(-n // chunk)
+        # every chunk of the stream but its last (whose result is the final hypothesis) -- once the stream has decoded frames: the network's right context keeps the first chunk or two back
+        assert max(0, nchunks - 3) <= len(part.get(u, [])) <= nchunks - 1, (u, part.get(u))
+        # a chunk's frames are decoded once the network has its right context, so the decoded length lags the audio: rule 5 fires on the later chunks of the long streams only
+        assert len(ep.get(u, [])) <= nchunks - 1
+        assert len(fin[u]) == 1
+        if part.get(u): assert len(part[u][-1].split()) <= len(fin[u][0].split()) + 3      # (a prefix-like partial result: never much longer than the final one)
+    assert 1 <= len(ep.get(0, [])) <= len(part[0]) - 1 and len(ep.get(1, [])) == 0      # 2 s stream: 0.9 s of decoded frames before its end, not from its first chunks on; 0.56 s stream: never
+    d = run(off + ["--endpoint.rule5.min-utterance-length=0.25"]); assert d.returncode == 0, d.stderr[-2000:]      # one chunk of decoded frames is enough: (almost) every partial result is an end-point
+    ep2 = _corr_lines(d.stderr, " [endpoint detected]")
+    assert len(part[0]) - 1 <= len(ep2.get(0, [])) <= len(part[0]) and len(ep2.get(0, [])) > len(ep.get(0, []))
+    c = run(off + ["--endpoint.rule5.min-utterance-length=1000"]); assert c.returncode == 0, c.stderr[-2000:]
+    assert not _corr_lines(c.stderr, " [endpoint detected]") and _corr_lines(c.stderr, " [partial] :") == part      # no rule in reach: no end-points; the hypotheses do not depend on them
+
+def test_online_program_generate_lattice_postprocessor_and_ctm(tmp_path):
+    """--lattice-postprocessor-rxfilename + a fourth argument that is not a table wspecifier -> CTM output (cuda-bin-tools.h:181-195, batched-wav-nnet3-cuda-online.cc:92-118,
+    228-262); --write-lattice=true with the post-processor -> its scaled lattices.  Both equal to what batched-wav-nnet3-cuda2 produces from the same files; the real-time
+    simulation (--simulate-realtime-writing=true: the reference's pacing) gives the same CTM and sane latencies."""
+    td = str(tmp_path); lens = [16000, 9000, 23001]; common = _online_setup(td, lens)
+    tail = [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp"]; pp = [f"--lattice-postprocessor-rxfilename={td}/pp.conf"]
+    on = [os.path.join(BIN, "batched-wav-nnet3-cuda-online")] + common + ["--num-channels=3", "--frames-per-chunk=60", "--max-utterance-frames=400"]
+    r = subprocess.run(on + tail + [f"{td}/on.ctm"], capture_output=True, text=True)
+    assert r.returncode != 0 and "You must configure the lattice postprocessor" in r.stderr
+    a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=3"] + pp + tail + [f"{td}/off.ctm"], capture_output=True, text=True); assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run(on + pp + tail + [f"{td}/on.ctm"], capture_output=True, text=True); assert b.returncode == 0, b.stderr[-2000:]
+    ctm = lambda f: sorted(tuple(l.split()) for l in open(f))
+    assert ctm(f"{td}/on.ctm") == ctm(f"{td}/off.ctm") and len(ctm(f"{td}/on.ctm")) >= 3 and {l[0] for l in ctm(f"{td}/on.ctm")} == {"utt0", "utt1", "utt2"}
+    # the post-processed lattices
+    a = subprocess.run([os.path.join(BIN, "batched-wav-nnet3-cuda2")] + common + ["--max-batch-size=3"] + pp + tail + [f"ark,t:{td}/off.txt"], capture_output=True, text=True); assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run(on + pp + ["--write-lattice=true"] + tail + [f"ark,t:{td}/on.txt"], capture_output=True, text=True); assert b.returncode == 0, b.stderr[-2000:]
+    from tests.lattice_cases import parse_compact_text
+    la, lb = parse_compact_text(open(f"{td}/off.txt").read()), parse_compact_text(open(f"{td}/on.txt").read())
+    assert sorted(la) == sorted(lb) == ["utt0", "utt1", "utt2"]
+    for k in la: assert _compact_best_words(la[k]) == _compact_best_words(lb[k]) and len(la[k]["arcs"]) == len(lb[k]["arcs"]), k
+    # the reference's pacing: every stream played in real time (2 s of wall clock for these files)
+    import re, time
+    t0 = time.time()
+    c = subprocess.run(on + pp + ["--simulate-realtime-writing=true"] + tail + [f"{td}/rt.ctm"], capture_output=True, text=True); assert c.returncode == 0, c.stderr[-2000:]
+    assert time.time() - t0 >= max(lens) / 16000.0 and ctm(f"{td}/rt.ctm") == ctm(f"{td}/off.ctm")
+    m = re.search(r"Latencies \(s\):.*\n.*?([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", c.stderr, re.M); assert m, c.stderr[-1500:]
+    assert 0.0 <= float(m.group(1)) <= float(m.group(4)) + 1e-9 and float(m.group(4)) < 30.0      # (result time - end of speech; the first run of a process includes its warm-up)

@@ -39,7 +39,15 @@ def test_bench_line_carries_the_end_to_end_parity_gate():
     # reproducibility under a float32 difference of that size (its nnet3-compute on another MKL code path, same features, same decoder):
     assert slf["max_abs_loglike_diff"] > 0, "the second reference run did not take another code path: no yardstick"
     assert par["mean_of_max_abs_loglike_diff"] <= 3.0 * slf["mean_of_max_abs_loglike_diff"] + 1e-4, (par["mean_of_max_abs_loglike_diff"], slf["mean_of_max_abs_loglike_diff"])
-    assert par["best_path_identical_frac"] >= min(0.999, slf["best_path_identical_frac"] - 1.0 / par["utterances"]), (par["best_path_identical_frac"], slf["best_path_identical_frac"])      # (one utterance of the sample = the rate's quantum; round 5: the extra 0.01 is gone)
+    # the gate itself: bench.e2e_gate -- an exact one-sided McNemar test on the paired per-utterance best-path flips (GPU chain vs reference) against (reference vs itself),
+    # alpha = 0.01; the same function gives the same verdict on this 128-utterance sample and on the driver's 512 (round 5's threshold `self - 1 / utterances` did not)
+    sys.path.insert(0, ROOT)
+    import bench
+    gate = bench.e2e_gate(par["flip_utts"], slf["flip_utts"], par["utterances"])
+    assert par["gate"] == gate and par["gate_pass"] is True and gate["pass"], (par.get("gate"), gate)
+    assert len(par["flip_utts"]) == par["utterances"] - par["best_path_identical"]
+    ctrl = par["controls"]; assert "error" not in ctrl, ctrl      # the two controls that separate the causes ran and carry their own gate
+    assert ctrl["reference_features_gpu_net_gpu_decoder"]["gate"]["pass"], ctrl      # without the feature difference the GPU net + decoder is inside the reference's own spread
     dd = sg["nnet_on_reference_features_loglike_diff_distribution"]      # the whole distribution of |k3_nnet_forward - nnet3-compute| on the reference's features, not only its maximum
     assert dd["values"] >= 1e8 and dd["above_2e-4_frac"] <= 1e-6 and dd["above_1e-4_frac"] <= 1e-3 and dd["p99.9"] <= 1.5e-4 and dd["mean"] <= 5e-5, dd
     assert line["roofline_feat"]["frac"] > 0 and line["cpu_baseline"]["extrapolated_all_cores"] > line["cpu_baseline"]["value"] * 0.5

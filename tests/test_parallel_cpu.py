@@ -98,7 +98,9 @@ def test_comm_rendezvous_late_rank_with_a_per_run_nonce_is_not_rejected_for_the_
 
 def _rendezvous_rank(path, rank, world, timeout, nonce, delay, q):
     import ctypes, time
-    os.environ.pop("TORCHELASTIC_RUN_ID", None); os.environ["K3_COMM_NONCE"] = nonce
+    os.environ.pop("TORCHELASTIC_RUN_ID", None)
+    if nonce is None: os.environ.pop("K3_COMM_NONCE", None)      # (a launcher that supplies no run identity: only the files' ages and the handshake tell two runs apart)
+    else: os.environ["K3_COMM_NONCE"] = nonce
     from kaldi_amd import lib
     L = lib.load()
     L.k3_comm_rendezvous.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
@@ -145,3 +147,18 @@ def test_comm_rendezvous_ignores_a_confirmation_left_by_another_run(tmp_path):
     open(path, "wb").write(b"\x11" * 128 + struct.pack("<QQ", magic, 999)); open(path + ".go", "wb").write(struct.pack("<QQQ", magic, 999, 42))
     res = _run_rendezvous(path, [0, 1], 2, 20, delays={0: 1.0})
     assert all(r[1] == 0 and r[2] for r in res.values()), res
+
+
+def test_comm_rendezvous_ignores_a_fresh_confirmation_of_a_crashed_run_with_the_same_identity(tmp_path):
+    """no per-run nonce (torchrun's static rendezvous), and a run that crashed seconds ago left BOTH its id file and the matching .go -- same identity, inside
+    the age window, hashes that agree.  Rank 1 of the new run starts before rank 0 has cleaned up: it must not leave with the dead run's id (it would block in
+    ncclCommInitRank for ever); the .go is older than rank 1's own announcement, so it waits for this run's rank 0 and both end with the new id."""
+    import struct
+    def fnv(b, h=1469598103934665603):
+        for c in b: h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    path = str(tmp_path / "rv.id"); magic = 0x4b33636f6d6d3031; dead = b"\x11" * 128
+    open(path, "wb").write(dead + struct.pack("<QQ", magic, 0)); open(path + ".go", "wb").write(struct.pack("<QQQ", magic, 0, fnv(dead)))
+    res = _run_rendezvous(path, [0, 1], 2, 20, nonce=None, delays={0: 1.5})
+    assert all(r[1] == 0 and r[2] for r in res.values()), res      # r[2]: the id a rank left with is this run's rank-0 id
+    assert res[1][3] >= 1.0, res                                       # rank 1 really waited for rank 0

@@ -44,7 +44,7 @@ if os.environ.get("K3CLI_ONLINE"):      # the streaming program on the same file
     exe_o = os.path.join(ROOT, "kaldi_amd", "bin", "batched-wav-nnet3-cuda-online")
     for fpc in (51, 150):
         args = ["--feature-type=fbank", f"--fbank-config={td}/fbank.conf", "--frame-subsampling-factor=3", "--acoustic-scale=1.0", "--beam=15.0", "--lattice-beam=8.0", "--max-active=10000", f"--max-batch-size={U}", f"--num-channels={U}",
-                f"--frames-per-chunk={fpc}", f"--iterations={iters}", "--main-q-capacity=65536", "--aux-q-capacity=131072"]
+                f"--frames-per-chunk={fpc}", f"--iterations={iters}", "--main-q-capacity=65536", "--aux-q-capacity=131072", "--write-lattice=true"]
         t0 = time.time()
         r = subprocess.run([exe_o] + args + [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/online.ark"], capture_output=True, text=True)
         last = [l for l in r.stderr.splitlines() if "RealTimeX" in l or "Decoded" in l]

@@ -17,6 +17,7 @@ for it in range(2): dec.DecodeBatch(ll, nb.out_offsets); torch.cuda.synchronize(
 print("token passing ms %.2f prune ms %.2f" % dec.KernelTimes())
 cyc = np.zeros(16, np.int64); _l.load().k3_decoder_phase_cycles(dec._h, cyc.ctypes.data)
 names = ["cutoff", "init+passA", "scan+passB", "c0/labels", "closure", "buckets+subgraph", "order1", "queue+replay", "labels", "order2+publish"]
-fr = max(1, cyc[12]); tot = cyc[:10].sum()
+names += ["queue+union (of queue+replay)", "count+offsets+roots (of queue+replay)"]      # fs.prof[10], [11]; "queue+replay" is then the workers alone
+fr = max(1, cyc[12]); tot = cyc[:12].sum()
 print("fast frames", cyc[12], "gave up", cyc[13], "general", cyc[14], "| cycles per fast frame", tot / fr, "(whole call incl. import: %.0f)" % (cyc[15] / fr))
-print({n: "%.0f (%.0f%%)" % (c / fr, 100.0 * c / tot) for n, c in zip(names, cyc[:10])})
+print({n: "%.0f (%.0f%%)" % (c / fr, 100.0 * c / tot) for n, c in zip(names, cyc[:12])})
