@@ -583,6 +583,9 @@ def main():
                 if reader[k & 1] is not None and not args.wait_whole_decoder: reader[k & 1].StreamWaitTokenPassing(front)
                 else: front.wait_event(dec_done[k & 1])
                 fev[k & 1][0].record()
+                # (the waveform copy stays on this stream, in front of the features: issued on a copy stream of its own into a second device buffer, so that it runs under
+                # the previous batch's decoder, the step got SLOWER -- 85 - 87 ms against 79 --: the DMA traffic beside the token-passing kernel costs that kernel more than
+                # the 2.9 ms the copy takes; measured in rounds 2 and 6)
                 pcm_dev.copy_(src(k), non_blocking=True)
                 fev[k & 1][1].record()
                 sf.ComputeFeatures(pcm_dev, wo, fo, total_frames, out=feats)
@@ -831,7 +834,8 @@ def main():
             ph, cpp, ghz = 70, 2014.0, 2.4
             floor_ms = n_frames * ph * cpp / (ghz * 1e6)
             # (a frame is counted once: on the LDS path, or -- given up there or not -- on the general path)
-            lane_launches = max(1, (paths["lds_path"] + paths["general_path"]) // max(1, n_frames))
+            # (lane launches = frames counted / mean frames per lane: the same for equal lengths, right for the ragged set)
+            lane_launches = max(1.0, (paths["lds_path"] + paths["general_path"]) / max(1.0, float(info[:, 9].mean())))
             mean_lane_ms = (paths["cycles_lds_path"] + paths["cycles_general_path"]) / lane_launches / (ghz * 1e6)
             line["roofline_latency"] = {"bound": "latency: the per-lane chain of frames x barrier-separated phases",
                 "kernel": "k3_decode_forward_literal_kernel", "frames_per_lane": n_frames, "phases_per_frame": ph, "cycles_per_phase_floor": cpp,

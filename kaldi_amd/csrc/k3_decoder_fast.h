@@ -256,10 +256,20 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   unsigned *E_arc = reinterpret_cast<unsigned *>(arena + oE_arc), *E_stamp = reinterpret_cast<unsigned *>(arena + oE_stamp); float *E_w = reinterpret_cast<float *>(arena + oE_w);
   unsigned short *E_src = reinterpret_cast<unsigned short *>(arena + oE_src), *E_dst = reinterpret_cast<unsigned short *>(arena + oE_dst);
   unsigned cnt_emit = 0, cnt_os = 0, cnt_eps = 0;
+#if K3_LIT_PREFETCH_ARCS
+  int arc_pf = 0;
+#endif
   auto abort_now = [&](int why) { fs.abort = 1; fs.reason = why; };
   auto aborted = [&]() { __syncthreads(); const int a = fs.abort; __syncthreads(); return a != 0; };      // uniform snapshot between two barriers
 
   long long fp_last__ = (long long)__builtin_readcyclecounter(); (void)fp_last__;
+#if K3_LIT_PREFETCH_ROW
+  // The frame's log-likelihood row (24 KB for 6024 pdfs), requested now, coalesced: the ~2000 scattered 4-byte reads of passes A / B then find their lines in the L2 instead of
+  // missing to HBM one by one (a miss is on the critical path of every 64-arc step).  The values are summed into a register that is looked at once, behind the cutoff phase
+  // (which touches LDS only: nothing waits for these loads before that).
+  float row_pf = 0.0f;
+  for (int i = tid * 4; i + 3 < p.num_pdfs; i += kBlock * 4) { const float4 v = *reinterpret_cast<const float4 *>(ll + i); row_pf += v.x + v.y + v.z + v.w; }
+#endif
   // ---- GetCutoff (:653-720) on the visit-ordered costs
   unsigned long long bm = ~0ull;
   for (int r = tid; r < n_cur; r += kBlock) { const unsigned long long v = ((unsigned long long)V_cost[r] << 32) | (unsigned)r; bm = v < bm ? v : bm; }
@@ -307,6 +317,9 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
     if ((unsigned)deg_sum + (unsigned)cap_tokens > (unsigned)kFM) return -1;      // (uniform; nothing touched yet)
   }
   K3_FP(0);
+#if K3_LIT_PREFETCH_ROW
+  if (row_pf == 1.2345678e33f) fs.reason = -7;      // (never true: keeps the row's loads alive)
+#endif
   // ---- the frame's structures
   if (tid == 0) {
     fs.abort = 0;
@@ -710,7 +723,15 @@ __device__ K3_FAST_INLINE int lit_frame_fast(const DecParams &p, Shared &sh, Fas
   fast_hash_order<true>(sh, n, (unsigned)n, lab16, B16, reinterpret_cast<unsigned *>(arena + oO2_btab), reinterpret_cast<unsigned *>(arena + oO2_bm),
       reinterpret_cast<unsigned short *>(arena + oO2_wpre),
                   reinterpret_cast<unsigned short *>(arena + oO2_lead), reinterpret_cast<unsigned short *>(arena + oO2_grp), reinterpret_cast<unsigned short *>(arena + oO2_curs),
-                  [&](int r, int i, int d) { V_cost[r] = N_cost[i]; V_abeg[r] = N_abeg[i]; V_ne[r] = N_ne[i]; V_tok[r] = (unsigned short)i; ord_nxt[r] = i; q.by_ins[d] = i; });
+                  [&](int r, int i, int d) {
+                    V_cost[r] = N_cost[i]; V_abeg[r] = N_abeg[i]; V_ne[r] = N_ne[i]; V_tok[r] = (unsigned short)i; ord_nxt[r] = i; q.by_ins[d] = i;
+#if K3_LIT_PREFETCH_ARCS
+                    if (N_ne[i] > 0) arc_pf += p.arcs[N_abeg[i]].pdf;      // (the next frame's pass A finds the token's first arcs in the L2)
+#endif
+                  });
+#if K3_LIT_PREFETCH_ARCS
+  if (arc_pf == 0x7FFFFFF1) fs.reason = -8;      // (never true: keeps the loads alive; looked at behind the phase's barrier)
+#endif
   K3_FP(9);
   if (tid == 0) { c.tok_off[f + 2] = nb + n; c.loff_e[f + 1] = n_link_end; sh.n_link = n_link_end; sh.n_next = n; }
   hash_size_io = hash_size; cnt_emit_io += cnt_emit; cnt_os_io += cnt_os; cnt_eps_io += cnt_eps;

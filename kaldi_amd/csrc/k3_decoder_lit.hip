@@ -11,6 +11,12 @@
 #ifndef K3_LIT_QUEUE
 #define K3_LIT_QUEUE 0     // 1: a workgroup decodes lane after lane from the call's work-queue (k3_decoder_config.resident_lanes); see k3_decode_forward_literal_kernel
 #endif
+#ifndef K3_LIT_PREFETCH_ROW
+#define K3_LIT_PREFETCH_ROW 0     // 1: LDS-resident frames request their whole log-likelihood row at the start of the frame (see lit_frame_fast)
+#endif
+#ifndef K3_LIT_PREFETCH_ARCS
+#define K3_LIT_PREFETCH_ARCS 0     // 1: the last phase of an LDS-resident frame requests the first emitting arc of every token of the frame it hands over
+#endif
 #ifndef K3_LIT_CSH
 #define K3_LIT_CSH 0     // 1: passes A / B cut a frame of few tokens into chunks of fewer than 64 tokens (more, shorter chunks per wavefront); measured: see DESIGN.md 4
 #endif
