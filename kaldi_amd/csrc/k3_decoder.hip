@@ -847,6 +847,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // k3_decoder_lit.hip: the literal_order token-passing kernel (compiled with its own block size); `params` is this file's DecParams
 extern "C" int k3_lit_forward_prepare();
 extern "C" int k3_lit_fast_tokens();
+extern "C" int k3_lit_capture_launch(const void *params, size_t params_bytes, int nworkgroups, hipStream_t stream);      // k3_decoder_lit_cap.hip
 extern "C" int k3_lit_has_queue();      // 0: this build's kernel decodes one lane per workgroup only (resident_lanes is then ignored)
 extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nworkgroups, int exclusive, hipStream_t stream);
 
@@ -1004,6 +1005,7 @@ struct k3_decoder {
   // literal_order launch shape: > 0 = that many workgroups take the call's lanes from a work-queue (longest first) instead of one workgroup per lane; exclusive: a workgroup
   // asks for more than half of a CU's LDS, so that it shares its CU with other kernels' workgroups (the next batch's front end) instead of a second lane
   int lit_resident = 0; bool lit_exclusive = false;
+  bool capture_launch = false;      // (k3_decoder_create only: the next token-passing launch is the capture build's, see build_frame0_template)
 
   ~k3_decoder() {
     for (void *q : allocs) (void)hipFree(q);
@@ -1067,6 +1069,98 @@ static int build_init_template(k3_decoder *d) {
   if (getenv("K3_DEBUG_QUEUE")) fprintf(stderr, "k3 InitDecoding template: status %d, %lld tokens, %lld links, cur_base %lld n_cur %d -> %s\n", li.status, n, nl, li.cur_base, li.n_cur,
       p.tpl_n > 0 ? "kept" : "none");
   // the lane as it was: no utterance yet
+  K3_HIP_CHECK(hipMemset(p.info, 0, sizeof(LaneInfo)));
+  d->last_utts = 0; d->last_frames.clear(); d->fresh.clear(); d->lane_final.clear(); d->sel.clear(); d->started = false; d->finalized = false; d->info_valid = false;
+  return K3_OK;
+}
+
+// The FIRST FRAME's structure (DecParams::t0_*): lane 0 decodes one frame of all-zero log-likelihoods from the InitDecoding template with the capture build of the
+// token-passing kernel, which leaves the replay's records in the lane's scratch; they, the frame's tokens and its links (as source / destination / arc) become the template.
+// Only when frame 0 is structurally the same for every utterance: the tokens after InitDecoding do not exceed min_active (adaptive beam +inf).
+static int build_frame0_template(k3_decoder *d) {
+  DecParams &p = d->p; int rc;
+  if (p.tpl_n <= 0 || p.literal != 1 || p.tpl_n > p.min_active || p.tpl_n > p.max_active) return K3_OK;
+  long long *cap = nullptr; float *zero_row = nullptr;
+  if ((rc = dmalloc(&d->allocs, &cap, 16)) || (rc = dmalloc(&d->allocs, &zero_row, (size_t)d->num_pdfs))) return rc;
+  K3_HIP_CHECK(hipMemset(cap, 0, 16 * sizeof(long long))); K3_HIP_CHECK(hipMemset(zero_row, 0, sizeof(float) * d->num_pdfs));
+  p.cap = cap; d->capture_launch = true;
+  const int64_t ro[2] = {0, 1};
+  rc = k3_decoder_init_decoding(d, 1, 2, nullptr);
+  if (!rc) rc = k3_decoder_advance_decoding(d, 1, zero_row, d->num_pdfs, ro, nullptr);
+  d->capture_launch = false; p.cap = nullptr;
+  if (rc) return rc;
+  K3_HIP_CHECK(hipDeviceSynchronize());
+  long long hc[16]; LaneInfo li; LanePool pool0;
+  K3_HIP_CHECK(hipMemcpy(hc, cap, sizeof hc, hipMemcpyDeviceToHost));
+  K3_HIP_CHECK(hipMemcpy(&li, p.info, sizeof(li), hipMemcpyDeviceToHost));
+  K3_HIP_CHECK(hipMemcpy(&pool0, p.pools, sizeof(pool0), hipMemcpyDeviceToHost));
+  const long long n_e = hc[0], n = hc[1], m_e = hc[2], ncid = hc[3], narc = hc[4], niq = hc[5], nwork = hc[6], created = hc[7], nb = p.tpl_n, l0 = p.tpl_nl;
+  const size_t cap_tok = (size_t)p.frame_tokens_cap;
+  bool ok = li.status == kStOk && li.num_frames == 1 && li.cur_base == nb && li.n_cur == n && n > 0 && n <= 65535 && p.tpl_n <= 8191 && n_e + created == n && ncid > 0 && nwork > 0 && niq > 0;
+  std::vector<long long> off(3, 0), le(2, 0), ln(2, 0);
+  if (ok) {
+    K3_HIP_CHECK(hipMemcpy(off.data(), p.tok_off, sizeof(long long) * 3, hipMemcpyDeviceToHost));
+    K3_HIP_CHECK(hipMemcpy(le.data(), p.link_off_e, sizeof(long long) * 2, hipMemcpyDeviceToHost));
+    K3_HIP_CHECK(hipMemcpy(ln.data(), p.link_off_n, sizeof(long long) * 2, hipMemcpyDeviceToHost));
+    ok = off[1] == nb && off[2] == nb + n && le[0] == l0 && ln[1] >= l0 && le[1] == li.n_links && le[1] >= ln[1];
+  }
+  if (ok) {
+    const long long nle = ln[1] - l0, nx_all = le[1] - ln[1];
+    std::vector<Link> hl((size_t)(nle + nx_all)); std::vector<int> ha((size_t)(nle + nx_all)); std::vector<unsigned> hcst((size_t)(nb + n)); std::vector<int> hst((size_t)n), hrank((size_t)n);
+    K3_HIP_CHECK(hipMemcpy(hl.data(), pool0.links + l0, sizeof(Link) * hl.size(), hipMemcpyDeviceToHost));
+    K3_HIP_CHECK(hipMemcpy(ha.data(), pool0.link_arc + l0, sizeof(int) * ha.size(), hipMemcpyDeviceToHost));
+    K3_HIP_CHECK(hipMemcpy(hcst.data(), pool0.tok_cost, sizeof(unsigned) * hcst.size(), hipMemcpyDeviceToHost));
+    K3_HIP_CHECK(hipMemcpy(hst.data(), pool0.tok_state + nb, sizeof(int) * n, hipMemcpyDeviceToHost));
+    K3_HIP_CHECK(hipMemcpy(hrank.data(), p.lt_label, sizeof(int) * n, hipMemcpyDeviceToHost));      // (left in place by the capture build: dense creation ranks)
+    std::vector<ArcRec> harcs((size_t)d->fst->num_arcs);
+    K3_HIP_CHECK(hipMemcpy(harcs.data(), d->fst->arcs, sizeof(ArcRec) * harcs.size(), hipMemcpyDeviceToHost));
+    std::vector<int4> el, xl;
+    for (long long l = 0; l < nle && ok; l++) {
+      const Link &k = hl[(size_t)l]; const int a = ha[(size_t)l];
+      if (k.src >= (unsigned)nb || k.dst < (unsigned)nb || k.dst >= (unsigned)(nb + n) || a < 0 || a >= d->fst->num_arcs) { ok = false; break; }
+      el.push_back(make_int4((int)((k.src << 16) | (k.dst - (unsigned)nb)), a, harcs[(size_t)a].pdf, __builtin_bit_cast(int, harcs[(size_t)a].w)));
+    }
+    for (long long l = nle; l < nle + nx_all && ok; l++) {      // the closure's links that are live at their source's final cost
+      const Link &k = hl[(size_t)l]; const int a = ha[(size_t)l];
+      if (k.src < (unsigned)nb || k.src >= (unsigned)(nb + n) || k.dst < (unsigned)nb || k.dst >= (unsigned)(nb + n) || a < 0 || a >= d->fst->num_arcs) { ok = false; break; }
+      if (__builtin_bit_cast(unsigned, k.ac) != hcst[k.src]) continue;
+      xl.push_back(make_int4((int)(((k.src - (unsigned)nb) << 16) | (k.dst - (unsigned)nb)), a, 0, __builtin_bit_cast(int, harcs[(size_t)a].w)));
+    }
+    ok = ok && (long long)el.size() == m_e && (long long)xl.size() == narc;      // every emitting arc examined is accepted; the live closure links ARE the sub-graph's arcs
+    float best = std::numeric_limits<float>::infinity();
+    for (long long i = 0; i < nb; i++) { const unsigned c = hcst[(size_t)i]; const float v = __builtin_bit_cast(float, (c & 0x80000000u) ? (c ^ 0x80000000u) : ~c); best = v < best ? v : best; }
+    if (ok) {
+      int4 *t_el = nullptr, *t_xl = nullptr, *t_meta = nullptr, *t_wrec = nullptr; int2 *t_ar = nullptr, *t_rlist = nullptr; int *t_state = nullptr, *t_rank = nullptr, *t_c2t = nullptr;
+      if ((rc = dmalloc(&d->allocs, &t_el, el.size())) || (rc = dmalloc(&d->allocs, &t_xl, std::max<size_t>(xl.size(), 1))) || (rc = dmalloc(&d->allocs, &t_meta, (size_t)ncid)) ||
+          (rc = dmalloc(&d->allocs, &t_wrec, (size_t)(2 * nwork))) || (rc = dmalloc(&d->allocs, &t_ar, (size_t)std::max<long long>(narc, 1))) || (rc = dmalloc(&d->allocs, &t_rlist, (size_t)niq)) ||
+          (rc = dmalloc(&d->allocs, &t_state, (size_t)n)) || (rc = dmalloc(&d->allocs, &t_rank, (size_t)n)) || (rc = dmalloc(&d->allocs, &t_c2t, (size_t)ncid))) return rc;
+      K3_HIP_CHECK(hipMemcpy(t_el, el.data(), sizeof(int4) * el.size(), hipMemcpyHostToDevice));
+      if (!xl.empty()) K3_HIP_CHECK(hipMemcpy(t_xl, xl.data(), sizeof(int4) * xl.size(), hipMemcpyHostToDevice));
+      K3_HIP_CHECK(hipMemcpy(t_state, hst.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+      K3_HIP_CHECK(hipMemcpy(t_rank, hrank.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+      K3_HIP_CHECK(hipMemcpy(t_c2t, p.lt_c2t, sizeof(int) * ncid, hipMemcpyDeviceToDevice));
+      K3_HIP_CHECK(hipMemcpy(t_meta, p.lt_meta, sizeof(int4) * ncid, hipMemcpyDeviceToDevice));
+      if (narc > 0) K3_HIP_CHECK(hipMemcpy(t_ar, p.lt_arcs2, sizeof(int2) * narc, hipMemcpyDeviceToDevice));
+      K3_HIP_CHECK(hipMemcpy(t_rlist, p.lt_coffs, sizeof(int2) * niq, hipMemcpyDeviceToDevice));      // (the capture build's copy of q.rlist: the frame's last pass reuses q.rlist)
+      K3_HIP_CHECK(hipMemcpy(t_wrec, p.lt_wrec, sizeof(int4) * 2 * nwork, hipMemcpyDeviceToDevice));
+      p.t0_elinks = t_el; p.t0_xlinks = t_xl; p.t0_state = t_state; p.t0_rank1 = t_rank; p.t0_c2t = t_c2t; p.t0_meta = t_meta; p.t0_ar = t_ar; p.t0_rlist = t_rlist; p.t0_wrec = t_wrec;
+      p.t0_n_e = (int)n_e; p.t0_m_e = (int)m_e; p.t0_nle = (int)el.size(); p.t0_nlx = (int)xl.size(); p.t0_ncid = (int)ncid; p.t0_narc = (int)narc; p.t0_niq = (int)niq;
+      p.t0_nworkers = (int)nwork; p.t0_hash_size = (unsigned)hc[8]; p.t0_best = best; p.t0_eps = li.n_eps - p.tpl_eps;
+      if (const char *e = getenv("K3_T0_STAGE")) p.t0_pad = atoi(e);      // (developer: the first-frame kernel stops behind stage N; results are then garbage)
+      p.t0_n = (int)n;      // (last: the template is in use from here on)
+    }
+    (void)cap_tok;
+  }
+  if (getenv("K3_DEBUG_QUEUE") && p.t0_n > 0) {
+    std::vector<int2> a(8), b(8); std::vector<int4> w(8);
+    (void)hipMemcpy(a.data(), p.lt_coffs, sizeof(int2) * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), p.lt_rlist, sizeof(int2) * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(w.data(), p.lt_wrec, sizeof(int4) * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 8; i++) fprintf(stderr, "  rlist(coffs)[%d] = (%d, %d)   q.rlist[%d] = (%d, %d)   wrec[%d] = (%d %d %d %d)\n", i, a[i].x, a[i].y, i, b[i].x, b[i].y, i, w[i].x, w[i].y, w[i].z, w[i].w);
+  }
+  if (getenv("K3_DEBUG_QUEUE")) fprintf(stderr, "k3 first-frame template: %s (%lld emitting + %lld closure tokens, %lld emitting arcs, closure %lld ids / %lld arcs / %lld roots / %lld components)\n",
+      p.t0_n > 0 ? "kept" : "none", n_e, n - n_e, m_e, ncid, narc, niq, nwork);
+  // the lane as it was: idle creation labels (the capture build left the frame's in place), no utterance
+  K3_HIP_CHECK(hipMemset(p.lt_label, 0xFF, cap_tok * sizeof(unsigned)));
   K3_HIP_CHECK(hipMemset(p.info, 0, sizeof(LaneInfo)));
   d->last_utts = 0; d->last_frames.clear(); d->fresh.clear(); d->lane_final.clear(); d->sel.clear(); d->started = false; d->finalized = false; d->info_valid = false;
   return K3_OK;
@@ -1232,12 +1326,15 @@ extern "C" int k3_decoder_create(const k3_fst *fst, const k3_decoder_config *cfg
     K3_HIP_CHECK(hipMemset2D(p.lt_label, (size_t)p.lt_lane_bytes, 0xFF, cap * sizeof(unsigned), nl));
     K3_HIP_CHECK(hipMemset2D(p.lt_bm, (size_t)p.lt_lane_bytes, 0, (size_t)p.seq_words_cap * sizeof(unsigned), nl));
     K3_REQUIRE(k3_lit_forward_prepare() == 0, "k3_decoder_create: the literal_order kernel could not be configured");
+    if ((rc = dmalloc(&d->allocs, &p.row_skip, nl))) return rc;
+    K3_HIP_CHECK(hipMemset(p.row_skip, 0, nl * sizeof(int)));
   }
   // empty table: key = -1, cost = max, tok = -1, stamp = 0
   std::vector<Slot> init((size_t)hs, Slot{kEmpty, kEncMax, -1, 0});
   for (int l = 0; l < nlanes; l++) K3_HIP_CHECK(hipMemcpy(p.hash + (size_t)l * hs, init.data(), sizeof(Slot) * hs, hipMemcpyHostToDevice));
   K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_decode_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   if (p.literal && !getenv("K3_LIT_NO_INIT_TEMPLATE")) { const int rc_ = build_init_template(d.get()); if (rc_) return rc_; }
+  if (p.literal && !getenv("K3_LIT_NO_INIT_TEMPLATE") && !getenv("K3_LIT_NO_FRAME0_TEMPLATE")) { const int rc_ = build_frame0_template(d.get()); if (rc_) return rc_; }
   *out = d.release();
   return K3_OK;
 }
@@ -1344,7 +1441,8 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   p.lane_rows = nullptr;
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
-  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
+  if (p.literal && d->capture_launch) { K3_REQUIRE(k3_lit_capture_launch(&p, sizeof(p), lit_grid, st) == 0, "k3_decoder: the capture launch failed"); }
+  else if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
@@ -1384,7 +1482,8 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
   p.lane_rows = reinterpret_cast<const float **>(slot.d + d->arg_off_rows);
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
-  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
+  if (p.literal && d->capture_launch) { K3_REQUIRE(k3_lit_capture_launch(&p, sizeof(p), lit_grid, st) == 0, "k3_decoder: the capture launch failed"); }
+  else if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
@@ -1422,7 +1521,8 @@ extern "C" int k3_decoder_advance_decoding_strided(k3_decoder *d, int32_t num_ut
   p.lane_rows = reinterpret_cast<const float **>(slot.d + d->arg_off_rows);
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
-  if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
+  if (p.literal && d->capture_launch) { K3_REQUIRE(k3_lit_capture_launch(&p, sizeof(p), lit_grid, st) == 0, "k3_decoder: the capture launch failed"); }
+  else if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));

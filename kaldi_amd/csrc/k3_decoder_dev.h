@@ -154,6 +154,16 @@ struct DecParams {
   // again (0.9 M cycles of a lane's ~98 M): tokens (state, cost) in creation order, the closure's forward links, the HashList visit order and the creation order.  tpl_n = 0: none.
   const int *tpl_state; const unsigned *tpl_cost; const Link *tpl_links; const int *tpl_arc; const int *tpl_order, *tpl_by_ins;
   int tpl_n, tpl_nl; long long tpl_eps;
+  // ... and the FIRST FRAME's structure (k3_decode_frame0_from_template_kernel).  With n_cur <= min_active tokens after InitDecoding the adaptive beam of frame 0 is +inf
+  // (lattice-faster-decoder.cc:700-716): every emitting arc of those tokens is accepted and every epsilon arc of the closure passes, whatever the utterance -- so the tokens
+  // of frame 1, the forward links (as source / destination / arc), the emitting tokens' creation ranks, the closure sub-graph with its components, root lists and worker
+  // records are the same for every utterance of a decoder; only costs (hence the ORDER the closure creates its tokens in) depend on the log-likelihoods.  Captured once when
+  // the decoder is created (one lane, one frame, the capture build of the token-passing kernel).  t0_n = 0: none.
+  const int4 *t0_elinks, *t0_xlinks;      // emitting links {src << 16 | dst, arc, pdf, weight bits}; epsilon links {src << 16 | dst, arc, 0, weight bits}; token indices frame-local
+  const int *t0_state, *t0_rank1, *t0_c2t; const int4 *t0_meta; const int2 *t0_ar, *t0_rlist; const int4 *t0_wrec;
+  int t0_n_e, t0_n, t0_m_e, t0_nle, t0_nlx, t0_ncid, t0_narc, t0_niq, t0_nworkers; unsigned t0_hash_size; float t0_best; int t0_pad; long long t0_eps;
+  int *row_skip;        // [nlanes] rows of this call's log-likelihoods a lane has already consumed in front of the token-passing kernel (0 or 1: frame 0 from the template)
+  long long *cap;       // capture build only: [16] scalars of the frame just decoded by lane 0
 };
 
 __device__ __forceinline__ unsigned enc(float x) { unsigned b = __float_as_uint(x); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }

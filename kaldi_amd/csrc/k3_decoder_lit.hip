@@ -17,6 +17,9 @@
 #ifndef K3_LIT_PREFETCH_ARCS
 #define K3_LIT_PREFETCH_ARCS 0     // 1: the last phase of an LDS-resident frame requests the first emitting arc of every token of the frame it hands over
 #endif
+#ifndef K3_LIT_CAPTURE
+#define K3_LIT_CAPTURE 0     // 1 (k3_decoder_lit_cap.hip only): the build that decodes the one frame the first-frame template is captured from
+#endif
 #ifndef K3_LIT_CSH
 #define K3_LIT_CSH 0     // 1: passes A / B cut a frame of few tokens into chunks of fewer than 64 tokens (more, shorter chunks per wavefront); measured: see DESIGN.md 4
 #endif
@@ -32,12 +35,15 @@ extern "C" int k3_lit_has_queue() { return K3_LIT_QUEUE; }      // capacity of t
 // (exclusive launches ask for a little more than half of a CU's 160 KB: no second lane fits beside the workgroup, another kernel's workgroups do)
 constexpr size_t kLitExclusiveLds = 82 * 1024;
 extern "C" int k3_lit_forward_prepare() {
+  if (hipFuncSetAttribute((const void *)k3_decode_frame0_from_template_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitArena) != hipSuccess) return -1;
   return hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLitArena > kLitExclusiveLds ? kLitArena : kLitExclusiveLds)) == hipSuccess ? 0 : -1;
 }
 extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nworkgroups, int exclusive, hipStream_t stream) {
   DecParams p; static_assert(sizeof(DecParams) % 8 == 0, "DecParams is copied between translation units");
   if (params_bytes != sizeof(DecParams)) { fprintf(stderr, "k3_lit_forward_launch: DecParams size mismatch\n"); abort(); }
   memcpy(&p, params, sizeof(p));
-  if (p.tpl_n > 0) hipLaunchKernelGGL(k3_decode_init_from_template_kernel, dim3(p.q_lanes ? (unsigned)p.q_n : (unsigned)nworkgroups), dim3(256), 0, stream, p, const_cast<int *>(p.fresh));
+  const unsigned nl_ = p.q_lanes ? (unsigned)p.q_n : (unsigned)nworkgroups;
+  if (p.tpl_n > 0) hipLaunchKernelGGL(k3_decode_init_from_template_kernel, dim3(nl_), dim3(256), 0, stream, p, const_cast<int *>(p.fresh));
+  if (p.tpl_n > 0 && p.t0_n > 0) hipLaunchKernelGGL(k3_decode_frame0_from_template_kernel, dim3(nl_), dim3(kBlock), kLitArena, stream, p);
   hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(nworkgroups), dim3(kBlock), exclusive && kLitExclusiveLds > kLitArena ? kLitExclusiveLds : kLitArena, stream, p);
 }

@@ -782,6 +782,9 @@ __device__ __forceinline__ int lit_replay_components(const DecParams &p, const L
   const int4 tot = block_excl_scan4([&](int c) { const int4 ci = k3_ald4(&q.cinfo[c]); return make_int4(ci.x, ci.y, ci.z, ci.x > 0 ? 1 : 0); },
                                     [&](int c, int4 ex) { q.coffs[c] = ex; }, n_cid, red4);
   const int n_workers = tot.w;
+#if K3_LIT_CAPTURE
+  if (p.cap && tid == 0) p.cap[6] = n_workers;
+#endif
   K3_LS(10);
   // a component's roots in queue order (the queue is consumed from its back: descending k).  A component with one root (the usual case) is done
   // in one step; the others collect their roots, then rank them.
@@ -869,6 +872,111 @@ __global__ __launch_bounds__(256) void k3_decode_init_from_template_kernel(DecPa
   }
 }
 
+// Frame 0 from the decoder's template (DecParams::t0_*), launched between the InitDecoding kernel above and the token-passing kernel: a lane that stands right behind
+// InitDecoding (no frame decoded, the template's tokens) and has at least one frame in this call gets its first frame WITHOUT the passes that only depend on the graph --
+// candidate walk, state table, the closure's link bookkeeping, the closure sub-graph, union-find, root lists -- which are the same for every utterance when the adaptive beam
+// of frame 0 is +inf (see DecParams).  What is left is what the log-likelihoods decide:
+//   costs of the emitting links and tokens (the reference's own arithmetic: (cost + (offset - loglike)) + graph, :779-797), the closure's costs as the least fixpoint over the
+//   template's epsilon links (:830-897 relaxes the same arcs until nothing changes: the same minimum), the links at their final costs, the REPLAY of the LIFO queue on the
+//   template's components (lit_replay_component: the order the closure creates tokens in depends on which cost improves when), the creation ranks and the frame's HashList order.
+// The token-passing kernel then resumes the lane at frame 1 (row_skip = 1).  Bit-identical to that kernel's own frame 0 (tests/test_decoder_literal_gpu.py).
+__global__ __launch_bounds__(kBlock) void k3_decode_frame0_from_template_kernel(DecParams p) {
+  extern __shared__ __attribute__((aligned(16))) char arena[];
+  __shared__ Shared sh; __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  const int L = p.q_lanes ? __builtin_amdgcn_readfirstlane(p.q_lanes[blockIdx.x]) : (int)blockIdx.x;
+  const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
+  LaneInfo &li = p.info[L];
+  if (tid == 0) p.row_skip[L] = 0;
+  if (p.fresh[L] || T < 1 || p.t0_n <= 0 || li.status != kStOk || li.num_frames != 0 || li.cur_base != 0 || li.n_cur != p.tpl_n || li.n_links != p.tpl_nl || li.order_sel != 1) return;
+  const LanePool lp = k3_uniform_pool(p.pools[L]);
+  const int n = p.t0_n, n_e = p.t0_n_e, nle = p.t0_nle, nlx = p.t0_nlx, ncid = p.t0_ncid, niq = p.t0_niq; const long long nb = p.tpl_n, l0 = p.tpl_nl;
+  if (lp.tcap < nb + n || lp.lcap < l0 + nle + nlx) return;      // (the token-passing kernel grows the pools and decodes the frame itself)
+  const LitLane q(p, L);
+  const float *ll = p.lane_rows ? p.lane_rows[L] : p.loglikes + r0 * p.ld;
+  const float kInf = __builtin_inff(), co = -p.t0_best;
+  int *tok_state = lp.tok_state; unsigned *tok_cost = lp.tok_cost; Link *links = lp.links; int *link_arc = lp.link_arc;
+  if (tid == 0) { sh.err = 0; sh.flag = 0; s_bad = 0; }
+  // ---- the frame's tokens; the emitting links: cost of a link = (source cost + (offset - loglike)) + graph cost, cost of a token = the minimum over its links
+  for (int i = tid; i < n; i += kBlock) { tok_state[nb + i] = p.t0_state[i]; K3_AST(&tok_cost[nb + i], kEncMax); }
+  __syncthreads();
+  for (int l = tid; l < nle; l += kBlock) {
+    const int4 e = p.t0_elinks[l]; const int s_ = (int)((unsigned)e.x >> 16), d_ = e.x & 0xFFFF;
+    const float oc = dec(K3_ALD(&tok_cost[s_])), ac = co - ll[e.z]; const float tot = oc + ac + __int_as_float(e.w);
+    k3a_min(&tok_cost[nb + d_], enc(tot));
+    store_link(&links[l0 + l], Link{(unsigned)s_, (unsigned)(nb + d_), tot, ac}); store_stream(&link_arc[l0 + l], e.y);
+  }
+  __syncthreads();
+  if (p.t0_pad == 1) return;
+  // ---- the replay's starting costs (the tokens right after ProcessEmitting; +inf: not created yet) and the emitting tokens' creation ranks
+  unsigned *clist = reinterpret_cast<unsigned *>(q.rflag);
+  for (int c = tid; c < ncid; c += kBlock) { const int i = p.t0_c2t[c]; q.rcost[c] = i < n_e ? dec(K3_ALD(&tok_cost[nb + i])) : kInf; }
+  for (int i = tid; i < n_e; i += kBlock) K3_AST(&q.label[i], (unsigned)p.t0_rank1[i]);
+  // ---- ProcessNonemitting's costs: relax the template's epsilon links until nothing moves (every one of them passes: the cutoff is +inf)
+  for (int round = 0; round < 100000; round++) {
+    int changed = 0;
+    for (int l = tid; l < nlx; l += kBlock) {
+      const int4 x = p.t0_xlinks[l]; const int s_ = (int)((unsigned)x.x >> 16), d_ = x.x & 0xFFFF;
+      const unsigned cs = K3_ALD(&tok_cost[nb + s_]);
+      if (cs != kEncMax) { const unsigned e = enc(dec(cs) + __int_as_float(x.w)); if (e < k3a_min(&tok_cost[nb + d_], e)) changed = 1; }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+  // ---- the closure's forward links at their sources' final costs (Link::ac of an epsilon link = the source cost it was made at: the live-link stamp)
+  for (int l = tid; l < nlx; l += kBlock) {
+    const int4 x = p.t0_xlinks[l]; const int s_ = (int)((unsigned)x.x >> 16), d_ = x.x & 0xFFFF;
+    const unsigned cs = K3_ALD(&tok_cost[nb + s_]);
+    store_link(&links[l0 + nle + l], Link{(unsigned)(nb + s_), (unsigned)(nb + d_), dec(cs) + __int_as_float(x.w), __uint_as_float(cs)}); store_stream(&link_arc[l0 + nle + l], x.y);
+  }
+  __syncthreads();
+  if (p.t0_pad == 2) return;
+  // ---- replay of the LIFO queue, one thread per component of the template (lit_replay_components' worker phase and label phase)
+  for (int w = tid; w < p.t0_nworkers; w += kBlock) {
+    const int4 w0 = p.t0_wrec[2 * w], w1 = p.t0_wrec[2 * w + 1];
+    if (!lit_replay_component(q.rcost, p.t0_meta, p.t0_ar, clist, p.t0_rlist, q.rinfo, q.stack + w0.w, w1.x, w0.x, w0.y, w0.z, kInf)) {
+      if (p.t0_pad == 9 && atomicAdd(&s_bad, 1) < 3) { const int2 r_ = p.t0_rlist[w0.x]; const int4 m_ = p.t0_meta[r_.y];
+        printf("frame0 lane %d worker %d: w0 %d %d %d %d scap %d | first root k %d cid %d meta %d %d %d %d rcost %g\n", L, w, w0.x, w0.y, w0.z, w0.w, w1.x, r_.x, r_.y, m_.x, m_.y, m_.z, m_.w, (double)q.rcost[r_.y]); }
+      s_bad = 1;
+    }
+  }
+  __syncthreads();
+  if (p.t0_pad == 3) return;
+  const int created = block_excl_scan([&](int j) { return (unsigned)q.rinfo[niq - 1 - j].y; }, reinterpret_cast<unsigned *>(q.dense), niq, sh.redi);
+  if (s_bad) {      // a component's stack slice overflowed (the token-passing kernel falls back to its one-wavefront replay then): the frame is left to that kernel -- nothing
+    // it reads has been changed but the creation labels, which go back to their idle pattern
+    for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], kLabelNone);
+    if (tid == 0 && p.t0_pad == 9) printf("frame0 lane %d: a component stack overflowed, frame left to the token-passing kernel\n", L);
+    return;
+  }
+  if (n_e + created != n) { if (tid == 0) li.status = K3_ERR_HIP; return; }      // (cannot happen: every token of the template is reachable and the cutoff is +inf)
+  for (int j = tid; j < niq; j += kBlock) {
+    const int2 ri = q.rinfo[niq - 1 - j]; const unsigned base = (unsigned)n_e + (unsigned)q.dense[j];
+    for (int t = 0; t < ri.y; t++) K3_AST(&q.label[p.t0_c2t[clist[ri.x + t]]], base + (unsigned)t);
+  }
+  __syncthreads();
+  if (p.t0_pad == 4) return;
+  // ---- the frame's HashList order (the next frame's visit order) and creation order
+  const unsigned hash_size = p.t0_hash_size; int *ord_nxt = q.order[0]; long long lt_last__ = 0; (void)lt_last__;
+  int *const s_tab = reinterpret_cast<int *>(arena); char *const smem_raw = arena + kLitTabBytes + kLitMarkBytes + kLitAuxBytes;
+  if (n <= kHoN) lit_hash_order_lds(q, sh, n, (unsigned)n, tok_state + nb, hash_size, ord_nxt, true, true, false, smem_raw, s_tab, lt_last__);
+  else if (!lit_hash_order_mid(q, sh, arena, n, (unsigned)n, tok_state + nb, hash_size, ord_nxt, true, true, false) &&
+           (p.lit_force_hbm_order || !lit_hash_order_big(q, sh, arena, n, (unsigned)n, tok_state + nb, hash_size, ord_nxt, true, true, false, lt_last__)))
+    lit_hash_order(q, sh, n, (unsigned)n, tok_state + nb, hash_size, ord_nxt, true, false, lt_last__);
+  for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], kLabelNone);
+  __syncthreads();
+  if (p.t0_pad == 5) return;
+  if (tid == 0) {
+    long long *tok_off = p.tok_off + L * p.fstride, *loff_e = p.link_off_e + L * p.fstride, *loff_n = p.link_off_n + L * p.fstride;
+    tok_off[2] = nb + n; loff_e[0] = l0; loff_n[1] = l0 + nle; loff_e[1] = l0 + nle + nlx;
+    (p.st_ntoks + L * p.fstride)[0] = (int)nb; (p.st_cur + L * p.fstride)[0] = kInf; (p.st_ab + L * p.fstride)[0] = kInf; (p.st_next + L * p.fstride)[0] = kInf;
+    (p.st_co + L * p.fstride)[0] = co;
+    li.n_tokens = nb + n; li.n_links = l0 + nle + nlx; li.n_cands += p.t0_m_e; li.n_eps += p.t0_eps; li.max_frame_tokens = n > (int)nb ? n : (int)nb; li.num_frames = 1;
+    li.cur_base = nb; li.n_cur = n; li.hash_size = (int)hash_size; li.order_sel = 0;
+    __threadfence();
+    p.row_skip[L] = 1;
+  }
+}
+
 __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_kernel(DecParams p) {
   // One dynamic LDS arena (kLitArena bytes).  The general path below carves its level-1 state table, mark bits, work-lists / clash bins / union-find
   // parents and the replay segment out of its first 77.5 KB; a frame of the LDS-resident path (k3_decoder_fast.h) uses all of it, so the two
@@ -911,7 +1019,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
   {
   const int L = p.q_lanes ? __builtin_amdgcn_readfirstlane(p.q_lanes[blockIdx.x]) : (int)blockIdx.x; (void)s_qi;
 #endif
-  const long long r0 = p.row_off[L]; const int T = (int)(p.row_off[L + 1] - r0);
+  // (row_skip: the frames of this call that k3_decode_frame0_from_template_kernel has already decoded for the lane -- 0 or 1)
+  const int skip = p.row_skip ? __builtin_amdgcn_readfirstlane(p.row_skip[L]) : 0;
+  const long long r0 = p.row_off[L] + skip; const int T = (int)(p.row_off[L + 1] - r0);
   LanePool lp = k3_uniform_pool(p.pools[L]);      // this lane's token / link pools (grow_lane_pools moves them when the lane outgrows its reservation)
   int *tok_state = lp.tok_state; unsigned *tok_cost = lp.tok_cost; Link *links = lp.links; int *link_arc = lp.link_arc;
   Slot *hash = p.hash + (long long)L * (p.hash_mask + 1);
@@ -989,7 +1099,7 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
 #endif
     const int *ord_cur = q.order[sel]; int *ord_nxt = q.order[sel ^ 1];
     if (f >= 0) {
-      const float *ll = p.lane_rows ? p.lane_rows[L] + (long long)(f - f0) * p.ld : p.loglikes + (r0 + (f - f0)) * p.ld;
+      const float *ll = p.lane_rows ? p.lane_rows[L] + (long long)(f - f0 + skip) * p.ld : p.loglikes + (r0 + (f - f0)) * p.ld;
       if (n_cur == 0) { status = kStNoTokens; break; }
       // the pools hold a whole frame of tokens and the links of an LDS-resident frame (<= kFM emitting + kFE epsilon) behind what the lane has; the general path
       // asks again once it knows how many emitting arcs the frame examines (after pass A)
@@ -1249,7 +1359,11 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     K3_LQ(9);
     // mode 0: costs, meta and arcs in LDS; mode 1: costs in LDS, meta / arcs (read-only during the replay) in HBM; mode 2: all in HBM
     // (mode 0: kRN x (16 B meta + 4 B cost + 4 B creation list) = the table's 12 B x kHL; mode 1: 3 kHL costs in the table, the list where mode 0 keeps its arcs)
+#if K3_LIT_CAPTURE      // (the capture build keeps every record of the replay in the lane's HBM scratch, where the host finds it after the launch)
+    const int rmode = 2;
+#else
     const int rmode = (n_cid <= kRN && n_arc <= kRA) ? 0 : ((n_cid <= 3 * kHL && n - n_e <= kRA * 2) ? 1 : 2);
+#endif
     // LDS arena of the replay: the level-1 table's memory (dead from here until the end of the frame) + the dynamic segment
     float *rcost = rmode == 2 ? q.rcost : reinterpret_cast<float *>(s_tab) + (rmode == 0 ? 2 * kHL : 0);
     int4 *meta = rmode == 0 ? reinterpret_cast<int4 *>(s_tab) : q.meta;
@@ -1353,6 +1467,9 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         __syncthreads();
       }
     }
+#if K3_LIT_CAPTURE      // (the frame's second hash-order pass uses q.rlist as scratch: the roots, grouped by component in queue order, are kept in q.coffs -- dead by now -- for the host)
+    if (p.cap) { int2 *keep = reinterpret_cast<int2 *>(q.coffs); for (int k = tid; k < n_iq; k += kBlock) keep[k] = q.rlist[k]; __syncthreads(); }
+#endif
     if (created_total < 0) {
       if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);      // one wavefront on a dependent chain: let it issue ahead of the other workgroup's parallel phases
@@ -1411,7 +1528,11 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
     for (int i = tid; i < kHL; i += kBlock) { tb.lkey[i] = kEmpty; tb.lcost[i] = kEncMax; tb.ltok[i] = -1; }      // the arena becomes the (empty) table again
     K3_LT(10); K3_LQ(13);
     // ---- publish the frame: final costs into the pool, empty table, idle labels
+#if K3_LIT_CAPTURE      // (the host reads the frame's creation ranks out of q.label, then restores the idle pattern itself)
+    if (p.cap && tid == 0 && f >= 0) { p.cap[0] = n_e; p.cap[1] = n; p.cap[2] = (long long)m_e; p.cap[3] = n_cid; p.cap[4] = n_arc; p.cap[5] = n_iq; p.cap[7] = created_total; p.cap[8] = (long long)hash_size; }
+#else
     for (int i = tid; i < n; i += kBlock) K3_AST(&q.label[i], kLabelNone);
+#endif
     __syncthreads();
     K3_LT(11); K3_LQ(14);
     cur_base = nb; n_cur = n; max_frame = n_cur > max_frame ? n_cur : max_frame; sel ^= 1;

@@ -210,27 +210,41 @@ def test_lane_pools_are_a_reservation_and_grow_inside_the_kernel(literal):
     dec4.DecodeBatch(x[:700].contiguous(), np.array([0, 700])); i4 = dec4.LatticeInfo(check=False)
     assert i4[0, 2] == -4, i4[:, 2]
 
-def test_init_decoding_template_and_longest_first_launch_change_nothing(monkeypatch):
-    """The decoder works InitDecoding out once (k3_decoder_create: one lane, no frames) and copies the result into every fresh lane with a small kernel in front of the
-    token-passing launch, and it launches the lanes longest first (workgroup b decodes the b-th longest lane).  Neither may change a bit: the same ragged batch decoded by a decoder created with the
-    template and by one created without (K3_LIT_NO_INIT_TEMPLATE, a developer switch) gives identical lattices and per-frame numbers, equal to the oracle's."""
+def test_init_decoding_and_first_frame_templates_and_longest_first_launch_change_nothing(monkeypatch):
+    """The decoder works out once, when it is created, what InitDecoding leaves in a lane and -- when the tokens after InitDecoding do not exceed min_active, so that frame 0's
+    adaptive beam is +inf -- the whole STRUCTURE of an utterance's first frame (tokens, links, closure sub-graph, components); two small kernels in front of the token-passing
+    launch apply them (k3_decode_init_from_template_kernel, k3_decode_frame0_from_template_kernel) and the token-passing kernel resumes the lane at frame 1.  It also launches
+    the lanes longest first.  None of this may change a bit: the same ragged batch (one-frame utterances included) decoded by decoders created with both templates, with the
+    InitDecoding template only, and with neither (K3_LIT_NO_FRAME0_TEMPLATE / K3_LIT_NO_INIT_TEMPLATE: developer switches read by k3_decoder_create) gives identical lattices,
+    per-frame token counts and cutoff bits, equal to the oracle's; so does a lane's second utterance, chunked AdvanceDecoding, and a configuration the first-frame
+    template does not apply to (min_active below the start closure)."""
     from kaldi_amd import decoder
     rng = np.random.default_rng(99); N = 40
     f = synth.make_hclg(4000, 11000, N, seed=5, start_degree=60); t2p = synth.tid2pdf(N); cf = decoder.CudaFst(f, t2p)
     lls = [(rng.standard_normal((T, N)) * 2.0).astype(np.float32) for T in (7, 61, 1, 33, 90, 18)]
-    kw = dict(beam=13.0, lattice_beam=6.0, max_active=400, min_active=30)
-    res = []
-    for no_tpl in (False, True):
-        if no_tpl: monkeypatch.setenv("K3_LIT_NO_INIT_TEMPLATE", "1")
-        lats, info, dec = _decode(cf, N, lls, **kw)
-        assert (info[:, 2] == 0).all(), info[:, 2]
-        res.append((lats, [dec.FrameStats(u) for u in range(len(lls))]))
-        if not no_tpl:
-            for u, ll in enumerate(lls): _check_against_oracle(dec, u, lats[u], f, ll, t2p, kw)
-            # the same decoder again, lanes rotated (a lane's second utterance starts from the template as well)
-            ro = np.concatenate([[0], np.cumsum([l.shape[0] for l in lls[2:] + lls[:2]])])
-            dec.DecodeBatch(torch.from_numpy(np.concatenate(lls[2:] + lls[:2])).cuda(), ro); l2 = dec.GetRawLattices(copy=True)
-            for u in range(len(lls)): assert l2[u].diff(lats[(u + 2) % len(lls)]) == "", u
-    for u in range(len(lls)):
-        assert res[0][0][u].diff(res[1][0][u]) == "", u
-        for k in ("ntoks", "cur_cutoff", "adaptive_beam", "next_cutoff", "cost_offset"): assert np.array_equal(np.asarray(res[0][1][u][k]).view(np.int32), np.asarray(res[1][1][u][k]).view(np.int32)), (u, k)
+    for kw in (dict(beam=13.0, lattice_beam=6.0, max_active=400, min_active=150), dict(beam=13.0, lattice_beam=6.0, max_active=400, min_active=3)):
+        res = []
+        for env in ((), ("K3_LIT_NO_FRAME0_TEMPLATE",), ("K3_LIT_NO_INIT_TEMPLATE",)):
+            for k in ("K3_LIT_NO_FRAME0_TEMPLATE", "K3_LIT_NO_INIT_TEMPLATE"): monkeypatch.delenv(k, raising=False)
+            for k in env: monkeypatch.setenv(k, "1")
+            lats, info, dec = _decode(cf, N, lls, **kw)
+            assert (info[:, 2] == 0).all(), info[:, 2]
+            res.append((lats, [dec.FrameStats(u) for u in range(len(lls))]))
+            if not env:
+                for u, ll in enumerate(lls): _check_against_oracle(dec, u, lats[u], f, ll, t2p, kw)
+                # the same decoder again, lanes rotated (a lane's second utterance starts from the templates as well)
+                ro = np.concatenate([[0], np.cumsum([l.shape[0] for l in lls[2:] + lls[:2]])])
+                dec.DecodeBatch(torch.from_numpy(np.concatenate(lls[2:] + lls[:2])).cuda(), ro); l2 = dec.GetRawLattices(copy=True)
+                for u in range(len(lls)): assert l2[u].diff(lats[(u + 2) % len(lls)]) == "", u
+                # chunked: InitDecoding alone (no frames), then one frame, then the rest
+                T = [l.shape[0] for l in lls]; dec.InitDecoding(len(lls), max(T))
+                for lo, hi in ((0, 0), (0, 1), (1, None)):
+                    part = [l[lo:hi] for l in lls]
+                    dec.AdvanceDecoding(torch.from_numpy(np.concatenate(part + [np.zeros((1, N), np.float32)])).cuda(), np.concatenate([[0], np.cumsum([x.shape[0] for x in part])]))
+                dec.FinalizeDecoding(); l3 = dec.GetRawLattices(copy=True)
+                for u in range(len(lls)): assert l3[u].diff(lats[u]) == "", u
+        for v in (1, 2):
+            for u in range(len(lls)):
+                assert res[0][0][u].diff(res[v][0][u]) == "", (v, u)
+                for k in ("ntoks", "cur_cutoff", "adaptive_beam", "next_cutoff", "cost_offset"):
+                    assert np.array_equal(np.asarray(res[0][1][u][k]).view(np.int32), np.asarray(res[v][1][u][k]).view(np.int32)), (v, u, k)
