@@ -63,7 +63,8 @@ def test_streaming_and_cmvn_programs_usage_and_option_errors():
     """the newer programs follow the same contract: usage -> 1, bad option / unsupported feature -> message on stderr and -1, --help -> 0"""
     on = os.path.join(BIN, "batched-wav-nnet3-cuda-online")
     r = _run(on); assert r.returncode == 1 and "Usage: batched-wav-nnet3-cuda-online" in r.stderr
-    r = _run(on, "--print-endpoints=true", "a", "b", "c", "d"); assert r.returncode == 255 and "not supported" in r.stderr
+    r = _run(on, "--feature-type=plp", "--print-endpoints=true", "a", "b", "c", "d"); assert r.returncode == 255 and "Invalid feature type" in r.stderr      # (--print-endpoints itself is an option of the program since round 6)
+    r = _run(on, "--help"); assert "--print-hypotheses" in r.stderr and "--endpoint.rule2.min-trailing-silence" in r.stderr and "--lattice-postprocessor-rxfilename" in r.stderr and "not supported" not in r.stderr
     r = _run(on, "--help"); assert r.returncode == 0 and "--frames-per-chunk" in r.stderr and "--num-channels" in r.stderr
     cm = os.path.join(BIN, "apply-cmvn-online-cuda")
     r = _run(cm, "a"); assert r.returncode == 1 and "Usage: apply-cmvn-online-cuda" in r.stderr
