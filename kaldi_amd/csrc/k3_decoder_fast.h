@@ -200,11 +200,11 @@ __device__ __forceinline__ bool fast_replay_component(float *rcost, const unsign
         for (int a = 0; a < pc; a++) {
           const int d = ar_dst[abeg + a]; const float tot = cc + ar_w[abeg + a];
           if (tot < accept) {
-            const float old = rcost[d];
+            const float old = rcost[d]; const int dpc = m_pc[d];      // (both behind `d`, requested together: the chain is one LDS round trip shorter per arc)
             if (old > tot) {
               if (old == kInf) clist[cpos++] = (unsigned short)d;
               rcost[d] = tot;
-              if (m_pc[d] > 0) { if (nxt >= 0) { if (sp >= scap) return false; stk[sp++] = (unsigned short)nxt; } nxt = d; }
+              if (dpc > 0) { if (nxt >= 0) { if (sp >= scap) return false; stk[sp++] = (unsigned short)nxt; } nxt = d; }
             }
           }
         }

@@ -730,11 +730,11 @@ __device__ __forceinline__ bool lit_replay_component(RC rcost, MT meta, AT AR, C
           if (a > 0) { const int2 ar = AR[mt.x + a]; d = ar.x; wb = ar.y; }
           const float tot = cc + __int_as_float(wb);
           if (tot < accept) {
-            const float old = rcost[d];
+            const float old = rcost[d]; const int dpc = meta[d].y;      // (both behind `d`, requested together)
             if (old > tot) {
               if (old == kInf) clist[cpos++] = (unsigned)d;
               rcost[d] = tot;
-              if (meta[d].y > 0) { if (nxt >= 0) { if (sp >= scap) return false; stk[sp++] = nxt; } nxt = d; }
+              if (dpc > 0) { if (nxt >= 0) { if (sp >= scap) return false; stk[sp++] = nxt; } nxt = d; }
             }
           }
         }

@@ -2,7 +2,7 @@
 // on stdin and prints the result, so that tests/test_minifst_independent.py can hold them to an INDEPENDENT implementation (scipy.sparse.csgraph for
 // reachability / acyclicity, numpy.lexsort for arc order): the decoder / determinizer oracles are the reference's sources compiled over these containers,
 // and nothing else checks the containers' algorithms.
-//   minifst_check <connect|topsort|arcsort|invert|shortestpath>  < fst.txt  > result.txt
+//   minifst_check <connect|topsort|arcsort|invert|shortestpath|rmepsilon|rmepsilon_noconnect|project_input|project_output|map_ilabel_plus1>  < fst.txt  > result.txt
 // text form, both ways:  "n <states> <start>" / "a <src> <dst> <ilabel> <olabel> <weight>" (arcs of a state in stored order) / "f <state> <weight>";
 // topsort prints "cyclic" instead when TopSort returns false.
 #include <fst/fstlib.h>
@@ -26,6 +26,11 @@ int main(int argc, char **argv) {
   else if (op == "arcsort") ArcSort(&f, ILabelCompare<StdArc>());
   else if (op == "invert") Invert(&f);
   else if (op == "shortestpath") { StdVectorFst o; ShortestPath(f, &o); f = o; }
+  else if (op == "rmepsilon") RmEpsilon(&f);
+  else if (op == "rmepsilon_noconnect") RmEpsilon(&f, false);
+  else if (op == "project_input") Project(&f, PROJECT_INPUT);
+  else if (op == "project_output") Project(&f, PROJECT_OUTPUT);
+  else if (op == "map_ilabel_plus1") Map(&f, [](const StdArc &a) { return StdArc(a.ilabel + 1, a.olabel, a.weight, a.nextstate); });
   else { std::cerr << "unknown op " << op << "\n"; return 2; }
   std::printf("n %d %d\n", (int)f.NumStates(), (int)f.Start());
   for (StateIterator<StdVectorFst> si(f); !si.Done(); si.Next()) {

@@ -127,6 +127,48 @@ def test_shortest_path_has_the_cost_of_an_independent_shortest_distance(exe, see
     have = {(int(s), int(d), int(i), int(o), float(np.float32(w))) for s, d, i, o, w in zip(f["src"], f["dst"], f["il"], f["ol"], f["w"])}
     assert all(any(abs(w - hw) < 1e-6 and (i, o) == (hi, ho) for _, _, hi, ho, hw in have) for _, _, i, o, w in got_arcs)      # made of arcs of the input
 
+def path_set(n, start, arcs, final, drop_eps_pairs=True):
+    """{(input label sequence without 0s, output label sequence without 0s): least total weight} over ALL successful paths of an acyclic transducer, by exhaustive walk (no
+    shortest-distance algorithm, no closure: nothing in common with RmEpsilon).  Weights are multiples of 1/8: sums are exact."""
+    out_arcs = {}
+    for s, d, i, o, w in arcs: out_arcs.setdefault(s, []).append((d, i, o, w))
+    best = {}
+    def walk(s, iseq, oseq, w):
+        if s in final:
+            k = (iseq, oseq); t = w + final[s]
+            if k not in best or t < best[k]: best[k] = t
+        for d, i, o, aw in out_arcs.get(s, ()): walk(d, iseq + ((i,) if i else ()), oseq + ((o,) if o else ()), w + aw)
+    if n and start >= 0: walk(start, (), (), 0.0)
+    return best
+
+@pytest.mark.parametrize("seed", range(24))
+def test_rmepsilon_keeps_the_weighted_path_set_and_leaves_no_epsilon_arc(exe, seed):
+    """RmEpsilon (used by the reference's word-align code compiled over minifst, which pins k3_mbr.cc) against an exhaustive enumeration of the paths before and
+    after: same {(input string, output string): least weight}, no arc with both labels 0 left, and -- with connect -- every remaining state on a successful path."""
+    rng = np.random.default_rng(900 + seed); n = int(rng.integers(2, 11)); f = random_fst(rng, n, int(rng.integers(n, 3 * n)), acyclic=True, labels=3)
+    eps = rng.random(len(f["src"])) < 0.45; f["il"] = np.where(eps, 0, f["il"]); f["ol"] = np.where(eps, 0, f["ol"])      # real epsilon arcs (0:0) next to 0:x, x:0 and x:y arcs
+    finals = sorted(rng.choice(n, size=int(rng.integers(1, max(2, n // 2) + 1)), replace=False).tolist()); f["final"] = {s: float(rng.integers(0, 17)) / 8.0 for s in finals}
+    arcs_in = [(int(s), int(d), int(i), int(o), float(w)) for s, d, i, o, w in zip(f["src"], f["dst"], f["il"], f["ol"], f["w"])]
+    want = path_set(n, f["start"], arcs_in, f["final"])
+    for op in ("rmepsilon", "rmepsilon_noconnect"):
+        got_n, got_start, got_arcs, got_final = from_text(run(exe, op, f))
+        assert not any(i == 0 and o == 0 for _, _, i, o, _ in got_arcs), op
+        assert path_set(got_n, got_start if got_n else -1, got_arcs, got_final) == want, op
+        if op == "rmepsilon" and got_n:
+            src = np.array([a[0] for a in got_arcs], int); dst = np.array([a[1] for a in got_arcs], int)
+            assert reach(got_n, src, dst, [got_start]).all() and reach(got_n, dst, src, sorted(got_final)).all()      # trim
+        if op == "rmepsilon_noconnect": assert got_n == n and got_start == f["start"]      # states keep their numbers
+        # no two arcs of a state with the same labels and destination (OpenFst's RmEpsilon combines them with Plus)
+        assert len({(s, d, i, o) for s, d, i, o, _ in got_arcs}) == len(got_arcs), op
+
+def test_project_and_map_touch_the_labels_only(exe):
+    rng = np.random.default_rng(11); f = random_fst(rng, 9, 30)
+    base = [(int(s), int(d), int(i), int(o), float(w)) for s, d, i, o, w in zip(f["src"], f["dst"], f["il"], f["ol"], f["w"])]
+    for op, fn in (("project_input", lambda i, o: (i, i)), ("project_output", lambda i, o: (o, o)), ("map_ilabel_plus1", lambda i, o: (i + 1, o))):
+        _, start, got_arcs, got_final = from_text(run(exe, op, f))
+        assert start == f["start"] and got_final == f["final"]
+        assert got_arcs == [(s, d) + fn(i, o) + (w,) for s, d, i, o, w in base], op
+
 # ------------------------------------------------------------------------------------------------------------------------------------------------------
 # Binary containers, bytes by hand.  FstHeader (fst/fst.h, FstHeader::Write): int32 magic 2125659606; fst type and arc type as (int32 length, bytes);
 # int32 version; int32 flags (1 = has input symbols, 2 = has output symbols, 4 = aligned); uint64 properties; int64 start; int64 num states; int64 num arcs.

@@ -72,7 +72,9 @@ def test_c_abi_rccl_collectives_on_two_devices(tmp_path):
     2-rank RCCL communicator, k3_fst_bcast from rank 0 (the only rank that built the graph) -- identical image bytes on both ranks, identical lattices decoded from them --
     and k3_comm_allreduce_f32 summing rank-dependent buffers."""
     import json, subprocess, sys
-    if torch.cuda.device_count() < 2: pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    ndev = torch.cuda.device_count()
+    if ndev < 2: pytest.skip("torch.cuda.device_count() == %d: needs two GPUs (RCCL refuses two ranks on one device); with >= 2 visible devices this test runs, there is no other skip" % ndev)
+    assert ndev >= 2      # (the only way past the skip above; nothing below may skip)
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, K3_COMM_NONCE="test-%d" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank_worker.py"), str(r), "2", str(tmp_path / "nccl.id"), str(tmp_path / f"r{r}.json")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
