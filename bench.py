@@ -374,6 +374,7 @@ def main():
                          "torch.distributed and only mark the line (\"rccl_abi_failed\": true).  Default (strict): mark the line, print it, and exit with status 3")
     ap.add_argument("--decoder-stream-priority", type=int, default=0,
                     help="queue priority of the two decoder streams (0 = default, -1 = high): whose workgroups take a slot that frees up, a waiting lane's or the next front end's")
+    ap.add_argument("--no-split-bf16", action="store_true", help="skip the split-bf16 record (value_split_bf16: the same steps with the TDNN-F products on the bf16 matrix core)")
     ap.add_argument("--ragged", action="store_true",
         help="SURVEY 8d's second set instead of the equal-length one: --utts utterances of length U(2 s, 20 s), seed 1235 (same model, graph and decoder); prints "
         "its own line (metric ... ragged), no cpu_baseline / extras.  The default run spawns this as a child at its end and reports the child's value as `value_ragged`")
@@ -742,6 +743,29 @@ def main():
         for k_, v_ in pb["give_up_reasons"].items(): paths["give_up_reasons"][k_] = paths["give_up_reasons"].get(k_, 0) + v_
     audio_s = tot_samp / 16000.0 * world * args.steps
     two = run("two_pass", args.steps, args.warmup) if "two_pass" in decs else None
+    # VERDICT r5 item 2, for the record only (`value` and `dtype` stay the FP32 matrix core's): the same pipelined steps with the TDNN-F products as six bf16 matrix-core products over
+    # exactly split operands, the activations' planes written by the producing epilogue (k3_nnet_batch_set_precision(.., 2)); forwards of both split forms back to back
+    sb = None
+    if decs and not args.no_split_bf16 and not args.no_extras:
+        sb_steps = max(3, min(args.steps, 6))
+        try:
+            nb.set_precision(2)
+            sb_dt = run(mode0, sb_steps, 2)[0]
+            sb = {"ms_per_step": 1000.0 * sb_dt / sb_steps, "steps": sb_steps}
+            ll_ref = None
+            for mode_, key_ in ((0, "forward_back_to_back_ms_fp32_mfma"), (1, "forward_back_to_back_ms_split_in_loader"), (2, "forward_back_to_back_ms_producer_planes")):
+                nb.set_precision(mode_)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(2): nb.forward(feats, out=loglikes)
+                e0.record()
+                for _ in range(3): nb.forward(feats, out=loglikes)
+                e1.record(); torch.cuda.synchronize()
+                sb[key_] = e0.elapsed_time(e1) / 3
+                if mode_ == 0: ll_ref = loglikes.clone()
+                elif mode_ == 2: sb["loglike_max_abs_diff_vs_fp32_mfma"] = float((loglikes - ll_ref).abs().max())
+            del ll_ref
+        finally:
+            nb.set_precision(0)
     # Stage and kernel durations (stage_ms, roofline, roofline_gemm) come from a short SERIAL pass of the same objects: in the pipelined steps a kernel shares
     # the GPU with the other
     # batch's kernels and its event-to-event time is not its own duration (token passing 86 -> 105 ms, fbank 1 -> 64 ms).  `value` / `ms_per_step` are the
@@ -892,6 +916,12 @@ def main():
                             "achieved": ab2 / (acc2[5] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ab2 / (acc2[5] * 1e-3) / 1e9 / 8000.0},
                      "lattice_states": ls2[0], "lattice_arcs": ls2[1], "lattice_digest": ls2[2],
                         "order_sensitive_upper_bound": int(d2.OrderSensitiveEvents().sum())}
+            if sb is not None:
+                line["value_split_bf16"] = tot_samp / 16000.0 * world / (sb["ms_per_step"] * 1e-3)
+                line["split_bf16"] = dict(sb, note="NOT the headline (dtype stays f32): the pipelined steps with every tile-aligned TDNN-F product as six v_mfma_f32_32x32x16_bf16 "
+                    "over exactly three-way split operands, the activations' three bf16 planes written by the producing epilogue (6 B per element next to the fp32 copy) so that the "
+                    "loader only loads; as accurate as the FP32 matrix core against the float64 forward (tests/test_nnet_gpu.py), rounds differently from the reference.  Slower than "
+                    "the FP32 matrix core here: the planes make the K = 192 layers' output traffic 10 B per element instead of 4 (DESIGN.md 4.2, Appendix A.2)")
         else:
             line["roofline"] = dict(line["roofline_gemm"], traffic=None)
         # the LF-MMI objective + derivatives of a training-sized minibatch, for the record (not part of `value`)

@@ -224,7 +224,9 @@ int k3_nnet_forward(k3_nnet_batch *batch, const float *d_feats, int64_t ld_feats
 /* EXPLORATORY (round 5), never the default and never behind bench.py's `value`: mode 1 runs this batch's affine products on the bf16 matrix core with both
  * operands split three ways (hi + mid + lo bf16 parts, exact; six of the nine cross products: as accurate as an fp32 GEMM, 0.375 of the FP32 matrix-core time) wherever a
  * node's time offsets are k-tile aligned; mode 0 = the FP32 matrix core with the reference's summation order (the parity path).  Outputs of mode 1 are NOT held to the 1e-4
- * fixture gates -- they round differently from the reference -- but to the float64 forward: no further from it than nnet3-compute is (bench.py split_bf16). */
+ * fixture gates -- they round differently from the reference -- but to the float64 forward: no further from it than nnet3-compute is (bench.py split_bf16).
+ * mode 2 = the same six products with the ACTIVATIONS' planes written by the producing kernel's epilogue (three bf16 planes next to the fp32 copy, 6 more bytes per element of HBM),
+ * so that the consumer's loader only loads; bit-identical to mode 1's output. */
 int k3_nnet_batch_set_precision(k3_nnet_batch *batch, int32_t mode);
 /* Stateful streaming forward (round 5): what BatchedStaticNnet3::RunBatch (cudadecoder/batched-static-nnet3.cc:139-233) is for the online pipeline -- one network pass per
  * chunk of every active channel -- WITHOUT re-evaluating the chunk's left and right context: every node keeps, per channel, the last few rows it produced, a pass consumes

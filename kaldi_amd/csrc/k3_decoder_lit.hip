@@ -17,6 +17,9 @@
 #ifndef K3_LIT_PREFETCH_ARCS
 #define K3_LIT_PREFETCH_ARCS 0     // 1: the last phase of an LDS-resident frame requests the first emitting arc of every token of the frame it hands over
 #endif
+#ifndef K3_LIT_PF_SEQ
+#define K3_LIT_PF_SEQ 0     // 1: passes A / B of the general path request arc records two groups and log-likelihoods one group ahead (wave_expand_seq_pf)
+#endif
 #ifndef K3_LIT_CAPTURE
 #define K3_LIT_CAPTURE 0     // 1 (k3_decoder_lit_cap.hip only): the build that decodes the one frame the first-frame template is captured from
 #endif

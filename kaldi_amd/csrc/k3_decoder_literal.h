@@ -167,6 +167,31 @@ __device__ __forceinline__ int wave_expand_seq(const ArcRec *arcs, int beg, int 
   return total;
 }
 
+// wave_expand_seq for the frames that live in HBM (general path), software-pipelined: the arc records are requested TWO groups of 64 ahead and the log-likelihood of an arc's pdf ONE
+// group ahead, so that a group's body (a chain of table round trips) starts with both in registers instead of behind two more dependent round trips.  f gets ll[r.pdf] as `llv`.
+template <typename F>
+__device__ __forceinline__ int wave_expand_seq_pf(const ArcRec *arcs, const float *ll, int beg, int deg, F &&f) {
+  const int lane = threadIdx.x & 63;
+  int incl = deg;
+  incl = wave_incl_sum_i32(incl);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int excl = incl - deg, rel = beg - excl;
+  const unsigned long long has_arcs = __ballot(deg > 0);
+  auto locate = [&](int j0, int &a, int &lo) { lo = j0 < total ? wave_owner_of(j0, deg, excl, has_arcs) : 0; a = __shfl(rel, lo) + j0 + lane; };
+  int a0, lo0, a1, lo1; ArcRec r0{}, r1{};
+  locate(0, a0, lo0); if (lane < total) r0 = arcs[a0];
+  locate(64, a1, lo1); if (64 + lane < total) r1 = arcs[a1];
+  float l0 = lane < total ? ll[r0.pdf] : 0.0f;
+  for (int j0 = 0; j0 < total; j0 += 64) {
+    int a2, lo2; ArcRec r2{};
+    locate(j0 + 128, a2, lo2); if (j0 + 128 + lane < total) r2 = arcs[a2];
+    const float l1 = j0 + 64 + lane < total ? ll[r1.pdf] : 0.0f;
+    f(j0 + lane < total, j0 + lane, a0, lo0, r0, l0);
+    r0 = r1; a0 = a1; lo0 = lo1; l0 = l1; r1 = r2; a1 = a2; lo1 = lo2;
+  }
+  return total;
+}
+
 struct LitLane {      // this lane's slices of the literal_order scratch
   int *order[2], *by_ins, *dense, *grp, *ccnt, *cdst, *rflag, *rown, *stack;
   unsigned *label, *lead, *bm, *wpre, *cmin;
@@ -1198,11 +1223,19 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
         // pass B reads this instead of walking order -> token -> state -> offsets again
         if (lane < (1 << csh) && (c << csh) + lane < n_cur) q.vis[(c << csh) + lane] = make_int4(i, __float_as_int(cost), beg, deg);
         unsigned cm = kEncMax;
+#if K3_LIT_PF_SEQ
+        const int total = wave_expand_seq_pf(p.arcs, ll, beg, deg, [&](bool valid, int, int, int owner, const ArcRec &r, float llv) {
+          const float oc = __shfl(cost, owner);
+          if (valid) { const float ac = co - llv; const float tot = oc + ac + r.w; const unsigned e = enc(tot + ab); cm = e < cm ? e : cm; }
+          cnt_emit += valid;
+        });
+#else
         const int total = wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int, int, int owner, const ArcRec &r) {
           const float oc = __shfl(cost, owner);
           if (valid) { const float ac = co - ll[r.pdf]; const float tot = oc + ac + r.w; const unsigned e = enc(tot + ab); cm = e < cm ? e : cm; }
           cnt_emit += valid;
         });
+#endif
         cm = wave_min_u32(cm);
         if (lane == 0) { q.cmin[c] = cm; q.ccnt[c] = total; }
       }
@@ -1239,10 +1272,15 @@ __global__ __launch_bounds__(kBlock, K3_LIT_WPE) void k3_decode_forward_literal_
           int i = 0, beg = 0, deg = 0; float cost = 0.0f;
           if (lane < (1 << csh) && (c << csh) + lane < n_cur) { const int4 v = q.vis[(c << csh) + lane]; i = v.x; cost = __int_as_float(v.y); beg = v.z; deg = v.w; }
           unsigned run = cpre[c]; const int jbase = cbase[c];
+#if K3_LIT_PF_SEQ
+          wave_expand_seq_pf(p.arcs, ll, beg, deg, [&](bool valid, int j, int arc, int owner, const ArcRec &r, float llv) {
+#else
           wave_expand_seq(p.arcs, beg, deg, [&](bool valid, int j, int arc, int owner, const ArcRec &r) {
+            const float llv = valid ? ll[r.pdf] : 0.0f;
+#endif
             const float oc = __shfl(cost, owner); const int oi = __shfl(i, owner);
             float ac = 0.0f, tot = 0.0f; unsigned e = kEncMax;
-            if (valid) { ac = co - ll[r.pdf]; tot = oc + ac + r.w; e = enc(tot + ab); }
+            if (valid) { ac = co - llv; tot = oc + ac + r.w; e = enc(tot + ab); }
             unsigned em = e;
             em = wave_incl_min_u32(em);
             unsigned exm = wave_shr1_u32(em, kEncMax); exm = run < exm ? run : exm;

@@ -65,6 +65,9 @@ struct GemmParams {
   int nops; int op_kind[kMaxOps]; const float *op_scale[kMaxOps]; const float *op_offset[kMaxOps];
   const float *R; long long ldr; int res_row_stride; float res_scale;
   const TileDesc *tiles; int num_m_tiles, num_n_tiles; int dbg; long long *dbg_buf;
+  // split-bf16 with producer-side planes (k3_nnet_batch_set_precision(.., 2)): the three bf16 planes [3][rows][ld] of the input (same rows and ld as A; null: the loader splits A)
+  // and of the output (same rows and ld as C; null: not wanted), plane strides in elements
+  const unsigned short *Ap; long long ap_stride; unsigned short *Cp; long long cp_stride;
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -419,9 +422,34 @@ __global__ __launch_bounds__((kBM / WM) * (BN / WN) * 64, (kBM / WM) * (BN / WN)
 // One LDS buffer of three planes per operand (rows of 32 bf16 padded to 80 bytes: b128 fragment reads and b64 / b128 stage writes conflict-free), two workgroups per CU; the next
 // tile's global loads are in flight under the current tile's MFMAs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <int BN, int WM, int WN, int EPI>
+// the exact three-way split of a float into bf16 bit patterns (upper halves of h, m, l): hi = top 16 bits, mid = top 16 bits of (x - hi), lo = x - hi - mid (8 significant bits left)
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l) {
+  const unsigned xb = __float_as_uint(x);
+  const float r1 = x - __uint_as_float(xb & 0xFFFF0000u); const unsigned r1b = __float_as_uint(r1);
+  const float r2 = r1 - __uint_as_float(r1b & 0xFFFF0000u);
+  h = xb; m = r1b; l = __float_as_uint(r2);
+}
+// four consecutive floats of a row -> their three planes (8 bytes each) at element offset `at` of plane 0
+__device__ __forceinline__ void store_planes4(unsigned short *Cp, long long cp_stride, long long at, const f32x4 &v) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) split3(v[e], h[e], m[e], l[e]);
+  // (v_perm_b32 selector 0x07060302: the upper halves of the two operands, the second operand's in the low half)
+  *reinterpret_cast<uint2 *>(Cp + at) = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+  *reinterpret_cast<uint2 *>(Cp + cp_stride + at) = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+  *reinterpret_cast<uint2 *>(Cp + 2 * cp_stride + at) = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+// an activation matrix produced by something else than the x6 kernel (the first layer, element-wise nodes), split after the fact: one thread per four columns
+__global__ __launch_bounds__(256) void k3_split_planes_kernel(const float *__restrict__ C, long long ldc, long long rows, int cols4, unsigned short *Cp, long long cp_stride) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x; if (i >= rows * cols4) return;
+  const long long r = i / cols4; const int c = (int)(i - r * cols4) * 4;
+  store_planes4(Cp, cp_stride, r * ldc + c, *reinterpret_cast<const f32x4 *>(C + r * ldc + c));
+}
+// PA: the input comes as three bf16 planes (GemmParams::Ap, written by the producing epilogue): the loader only loads -- 6 bytes per element instead of 4 and no arithmetic
+template <int BN, int WM, int WN, int EPI, bool PA>
 __global__ __launch_bounds__(256, 2) void k3_tdnn_gemm_x6_kernel(GemmParams p, const unsigned short *__restrict__ Wp, long long plane_stride) {
-  constexpr int NT = 256, LR = NT / 8, MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN, A_LOADS = kBM * kBK / 4 / NT;
+  constexpr int NT = 256, LR = NT / 8, MI = WM / 32, NI = WN / 32, WAVES_N = BN / WN, A_LOADS = PA ? 1 : kBM * kBK / 4 / NT;
+  constexpr int AP_LOADS = PA ? kBM * 4 * 3 / NT : 1;      // 16-byte chunks of the input tile: 3 planes x kBM rows x 4
   constexpr int kRow = 80, B_CH = BN * 4 * 3, B_LOADS = (B_CH + NT - 1) / NT;      // bytes per LDS row of a plane; 16-byte chunks of the weight tile (3 planes x BN rows x 4)
   static_assert((kBM / WM) * (BN / WN) == 4 && kBK == 32, "four wavefronts, k-tiles of 32");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -435,24 +463,37 @@ __global__ __launch_bounds__(256, 2) void k3_tdnn_gemm_x6_kernel(GemmParams p, c
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int ld_row = tid >> 3, ld_kv = (tid & 7) * 4;
-  int a_row_local[A_LOADS], a_lo[A_LOADS], a_hi[A_LOADS];
+  constexpr int A_ROWS = PA ? 2 : A_LOADS;      // PA: a thread's chunks lie in two rows of the tile (tid >> 2 and 64 + (tid >> 2)), each in all three planes
+  int a_row_local[A_ROWS], a_lo[A_ROWS], a_hi[A_ROWS];
 #pragma unroll
-  for (int i = 0; i < A_LOADS; i++) {
-    const int r = min(i * LR + ld_row, td.nrows - 1); const bool s2 = r >= td.split;
+  for (int i = 0; i < A_ROWS; i++) {
+    const int r = min(PA ? i * 64 + (tid >> 2) : i * LR + ld_row, td.nrows - 1); const bool s2 = r >= td.split;
     a_row_local[i] = r * p.row_stride + (s2 ? td.in_base2 : td.in_base); a_lo[i] = s2 ? td.in_lo2 : td.in_lo; a_hi[i] = s2 ? td.in_hi2 : td.in_hi;
   }
-  f32x4 ra[A_LOADS]; uint4 rb[B_LOADS];
-  const float *a_ptr[A_LOADS];
+  f32x4 ra[A_LOADS]; uint4 rb[B_LOADS]; uint4 rap[AP_LOADS];
+  const float *a_ptr[A_LOADS]; const unsigned short *ap_ptr[A_ROWS];
   auto load_tiles = [&](int kt, int oi_u, int w_u, bool dummy = false) {
     if (w_u == 0) {
       int sh = p.shifts[0];
 #pragma unroll
       for (int o = 1; o < kMaxOffsets; o++) sh = oi_u == o ? p.shifts[o] : sh;
+      if (PA) {
 #pragma unroll
-      for (int i = 0; i < A_LOADS; i++) a_ptr[i] = p.A + (long long)clampi(a_row_local[i] + sh, a_lo[i], a_hi[i]) * p.lda + ld_kv;
+        for (int i = 0; i < A_ROWS; i++) ap_ptr[i] = p.Ap + (long long)clampi(a_row_local[i] + sh, a_lo[i], a_hi[i]) * p.lda + (tid & 3) * 8;
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; i++) a_ptr[i] = p.A + (long long)clampi(a_row_local[i] + sh, a_lo[i], a_hi[i]) * p.lda + ld_kv;
+      }
     }
+    if (PA) {
 #pragma unroll
-    for (int i = 0; i < A_LOADS; i++) { ra[i] = *reinterpret_cast<const f32x4 *>(dummy ? p.W : a_ptr[i]); a_ptr[i] += kBK; }
+      for (int i = 0; i < AP_LOADS; i++) rap[i] = *reinterpret_cast<const uint4 *>(dummy ? Wp : ap_ptr[i & 1] + (i >> 1) * p.ap_stride);      // chunk i * NT + tid: plane i / 2, row (i & 1) * 64 + tid / 4
+#pragma unroll
+      for (int i = 0; i < A_ROWS; i++) ap_ptr[i] += kBK;
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; i++) { ra[i] = *reinterpret_cast<const f32x4 *>(dummy ? p.W : a_ptr[i]); a_ptr[i] += kBK; }
+    }
 #pragma unroll
     for (int i = 0; i < B_LOADS; i++) {
       const int c = i * NT + tid;
@@ -463,16 +504,15 @@ __global__ __launch_bounds__(256, 2) void k3_tdnn_gemm_x6_kernel(GemmParams p, c
     }
   };
   auto store_tiles = [&]() {
+    if (PA) {
+#pragma unroll
+      for (int i = 0; i < AP_LOADS; i++) *reinterpret_cast<uint4 *>(As + ((i >> 1) * kBM + (i & 1) * 64 + (tid >> 2)) * kRow + (tid & 3) * 16) = rap[i];
+    } else
 #pragma unroll
     for (int i = 0; i < A_LOADS; i++) {      // split the four floats: hi = top 16 bits, mid = top 16 bits of (x - hi), lo = x - hi - mid (8 significant bits left: exact as bf16)
       unsigned h[4], m[4], l[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const float x = ra[i][e]; const unsigned xb = __float_as_uint(x);
-        const float r1 = x - __uint_as_float(xb & 0xFFFF0000u); const unsigned r1b = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(r1b & 0xFFFF0000u);
-        h[e] = xb; m[e] = r1b; l[e] = __float_as_uint(r2);
-      }
+      for (int e = 0; e < 4; e++) split3(ra[i][e], h[e], m[e], l[e]);
       char *q = As + (i * LR + ld_row) * kRow + ld_kv * 2;
       // (v_perm_b32 selector 0x07060302: the upper halves of the two operands, the second operand's in the low half)
       *reinterpret_cast<uint2 *>(q) = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
@@ -638,12 +678,20 @@ __global__ __launch_bounds__(256, 2) void k3_tdnn_gemm_x6_kernel(GemmParams p, c
         const long long cstep = (long long)RPI * p.ldc;
 #pragma unroll
         for (int it = 0; it < ITERS; it++) *reinterpret_cast<f32x4 *>(cp + it * cstep) = v[it];
+        if (p.Cp) {      // the consumer's operand planes, written where the values are produced (block-uniform branch)
+          const long long at0 = (long long)(td.out_row0 + wm * WM + row0) * p.ldc + col;
+#pragma unroll
+          for (int it = 0; it < ITERS; it++) store_planes4(p.Cp, p.cp_stride, at0 + it * cstep, v[it]);
+        }
       }
     } else {
 #pragma unroll
       for (int it = 0; it < ITERS; it++) {
         const int lrow = wm * WM + it * RPI + row0;
-        if (col_ok && lrow < td.nrows && (!(0 & 2) || v[it][0] == 12345.678f)) *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v[it];
+        if (col_ok && lrow < td.nrows && (!(0 & 2) || v[it][0] == 12345.678f)) {
+          *reinterpret_cast<f32x4 *>(C + (long long)(td.out_row0 + lrow) * p.ldc + col) = v[it];
+          if (p.Cp) store_planes4(p.Cp, p.cp_stride, (long long)(td.out_row0 + lrow) * p.ldc + col, v[it]);
+        }
       }
     }
   } else {                                             // unaligned / odd-width output: element-wise tail path
@@ -666,6 +714,7 @@ __global__ __launch_bounds__(256, 2) void k3_tdnn_gemm_x6_kernel(GemmParams p, c
           else x = p.res_scale * R[(long long)((lrow < td.split ? td.res_base : td.res_base2) + lrow * p.res_row_stride) * p.ldr + c] + x;
         }
         C[(long long)(td.out_row0 + lrow) * p.ldc + c] = x;
+        if (p.Cp) { unsigned h_, m_, l_; split3(x, h_, m_, l_); const long long at = (long long)(td.out_row0 + lrow) * p.ldc + c; p.Cp[at] = (unsigned short)(h_ >> 16); p.Cp[p.cp_stride + at] = (unsigned short)(m_ >> 16); p.Cp[2 * p.cp_stride + at] = (unsigned short)(l_ >> 16); }
       }
     }
   }
@@ -762,7 +811,10 @@ __global__ __launch_bounds__(256) void k3_row_normalize_kernel(float *C, long lo
 
 struct k3_nnet_batch {
   k3_nnet *net = nullptr;
-  int num_utts = 0, subsampling = 1, precision = 0;      // precision: 0 = FP32 matrix core (the parity path), 1 = split-bf16 (exploratory)
+  int num_utts = 0, subsampling = 1, precision = 0;      // precision: 0 = FP32 matrix core (the parity path), 1 = split-bf16, operands split by the loader, 2 = split-bf16, the activations' planes written by the producing epilogue (both exploratory)
+  // mode 2: per node the three bf16 planes of its output (null: none; same rows / ld as the fp32 buffer, which shares its slot with other nodes -- so do the planes) and whether a
+  // consumer wants them
+  std::vector<int> act_slot; std::vector<size_t> slot_bytes; std::vector<unsigned short *> slot_planes; std::vector<char> wants_planes;
   std::vector<int> num_frames;
   std::vector<long long> out_offsets;           // [U+1] rows of the output matrix
   long long total_in_rows = 0, total_out_rows = 0;
@@ -985,6 +1037,12 @@ static int batch_create_impl(k3_nnet *net, int32_t num_utts, const int32_t *h_nu
     slot_of[i] = best;
   }
   for (Slot &s : slots) { K3_HIP_CHECK(hipMalloc((void **)&s.ptr, std::max<size_t>(s.bytes, 256))); b->allocs.push_back(s.ptr); }
+  b->act_slot = slot_of; b->slot_bytes.clear(); for (const Slot &s : slots) b->slot_bytes.push_back(std::max<size_t>(s.bytes, 256));
+  b->slot_planes.assign(slots.size(), nullptr); b->wants_planes.assign(nn, 0);
+  for (int i = 0; i < nn; i++) {      // a node's planes are wanted when a consumer can run on the bf16 matrix core from planes (tile-aligned offsets, 16-byte aligned plane rows)
+    const int src = used[i] ? fm.nodes[i].input : -1;
+    if (src >= 0 && fm.nodes[i].has_gemm && fm.nodes[i].in_dim % kBK == 0 && ld[src] % 8 == 0 && slot_of[src] >= 0) b->wants_planes[src] = 1;
+  }
 
   // ---- output transform: (x - log_prior) * acwt as one more scale/offset op (nnet-am-decodable-simple.cc:268-271)
   const bool out_xform = (h_log_priors != nullptr) || acoustic_scale != 1.0f;
@@ -1132,8 +1190,8 @@ extern "C" double k3_nnet_batch_flops(const k3_nnet_batch *b) { return b ? b->fl
 // k3_nnet_batch_set_precision(batch, 1): the affine products of this batch run as six bf16 matrix-core products over three-way split operands (k3_tdnn_gemm_x6_kernel) wherever a
 // node's time offsets are tile aligned (every layer of a TDNN-F but the first); 0 = back to the FP32 matrix core.  The first call splits the model's weights (host, once).
 extern "C" int k3_nnet_batch_set_precision(k3_nnet_batch *b, int32_t mode) {
-  K3_REQUIRE(b && (mode == 0 || mode == 1), "k3_nnet_batch_set_precision: mode is 0 (FP32 matrix core) or 1 (split-bf16)");
-  if (mode == 1) {
+  K3_REQUIRE(b && (mode == 0 || mode == 1 || mode == 2), "k3_nnet_batch_set_precision: mode is 0 (FP32 matrix core), 1 (split-bf16, split in the loader) or 2 (split-bf16, planes from the producer)");
+  if (mode >= 1) {
     k3_nnet *net = b->net; static std::mutex mu; std::lock_guard<std::mutex> g(mu);
     for (size_t i = 0; i < net->fm.nodes.size(); i++) {
       const k3::FusedNode &f = net->fm.nodes[i]; DeviceNode &d = net->dev[i];
@@ -1150,6 +1208,18 @@ extern "C" int k3_nnet_batch_set_precision(k3_nnet_batch *b, int32_t mode) {
       const int rc = upload(&net->allocs, wp, &d.Wp); if (rc) return rc;
       d.plane_stride = (long long)plane;
     }
+  }
+  auto planes = [](k3_nnet_batch *x) -> int {      // mode 2: three planes per activation slot that a consumer reads from planes (6 bytes per element next to the 4 of the fp32 copy)
+    for (size_t i = 0; i < x->act_slot.size(); i++) {
+      const int sl = x->act_slot[i];
+      if (sl < 0 || !x->wants_planes[i] || x->slot_planes[sl]) continue;
+      K3_HIP_CHECK(hipMalloc((void **)&x->slot_planes[sl], 3 * (x->slot_bytes[sl] / 4) * sizeof(unsigned short) + 256)); x->allocs.push_back(x->slot_planes[sl]);
+    }
+    return K3_OK;
+  };
+  if (mode == 2) {
+    if (b->half[0]) { for (int h = 0; h < 2; h++) { const int rc = planes(b->half[h].get()); if (rc) return rc; } }
+    else { const int rc = planes(b); if (rc) return rc; }
   }
   b->precision = mode;
   for (int h = 0; h < 2; h++) if (b->half[h]) b->half[h]->precision = mode;
@@ -1202,7 +1272,8 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
     K3_GEMM_VARIANTS(K3_SET_ATTR)
 #undef K3_SET_ATTR
 #define K3_X6_VARIANTS(X) X(128, 64, 64, kEpiAny) X(128, 64, 64, kEpiReluScaleRes) X(128, 64, 64, kEpiReluScale) X(96, 32, 96, kEpiAny) X(96, 32, 96, kEpiNone)
-#define K3_SET_ATTR6(bn, wm, wn, ep) K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_x6_kernel<bn, wm, wn, ep>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define K3_SET_ATTR6(bn, wm, wn, ep) K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_x6_kernel<bn, wm, wn, ep, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                                     K3_HIP_CHECK(hipFuncSetAttribute((const void *)k3_tdnn_gemm_x6_kernel<bn, wm, wn, ep, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     K3_X6_VARIANTS(K3_SET_ATTR6)
 #undef K3_SET_ATTR6
     return K3_OK; }(); });
@@ -1231,6 +1302,11 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
     if (f.input < 0) { p.A = d_feats; p.lda = ld_feats; }
     for (const k3::EpiOp &op : f.ops) if (op.kind == k3::kEpiResidual && op.res_node < 0) { p.R = d_feats; p.ldr = ld_feats; }
     if ((int)i == fm.output_node) { p.C = d_out; p.ldc = ld_out; }
+    auto planes_of = [&](int node, long long *stride) -> unsigned short * {
+      if (b->precision != 2 || node < 0 || node >= (int)b->act_slot.size() || b->act_slot[node] < 0 || !b->wants_planes[node]) return nullptr;
+      *stride = (long long)(b->slot_bytes[b->act_slot[node]] / 4); return b->slot_planes[b->act_slot[node]];
+    };
+    if ((int)i != fm.output_node) p.Cp = planes_of((int)i, &p.cp_stride);
     if (!f.has_gemm) {
       hipLaunchKernelGGL(k3_elementwise_kernel, dim3(p.num_m_tiles), dim3(256), 0, st, p);
     } else {
@@ -1250,13 +1326,19 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
 #endif
       bool launched = false;
       // split-bf16: three planes of 80-byte rows per operand, or the epilogue's staging tile, whichever is larger
-      if (b->precision == 1 && al && b->net->dev[i].Wp && !has_map) {
+      if (b->precision >= 1 && al && b->net->dev[i].Wp && !has_map) {
         const int bn_ = bn96 ? 96 : 128, wm_ = bn96 ? 32 : 64, wn_ = bn96 ? 96 : 64;
         const size_t lds6 = std::max<size_t>((size_t)3 * (kBM + bn_) * 80, (size_t)4 * wm_ * (wn_ + 4) * sizeof(float));
         const int epi6 = (epi == kEpiNone && !bn96) ? (int)kEpiAny : ((epi == kEpiReluScaleRes || epi == kEpiReluScale) && bn96 ? (int)kEpiAny : epi);
-#define K3_LAUNCH6(bn, wm, wn, ep) if (!launched && bn96 == (bn == 96) && epi6 == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_x6_kernel<bn, wm, wn, ep>), dim3(blocks), dim3(256), lds6, st, p, b->net->dev[i].Wp, b->net->dev[i].plane_stride); launched = true; }
+        p.Ap = planes_of(f.input, &p.ap_stride);
+        const bool pa = p.Ap != nullptr;
+#define K3_LAUNCH6(bn, wm, wn, ep) if (!launched && bn96 == (bn == 96) && epi6 == ep) { \
+          if (pa) hipLaunchKernelGGL((k3_tdnn_gemm_x6_kernel<bn, wm, wn, ep, true>), dim3(blocks), dim3(256), lds6, st, p, b->net->dev[i].Wp, b->net->dev[i].plane_stride); \
+          else hipLaunchKernelGGL((k3_tdnn_gemm_x6_kernel<bn, wm, wn, ep, false>), dim3(blocks), dim3(256), lds6, st, p, b->net->dev[i].Wp, b->net->dev[i].plane_stride); \
+          launched = true; }
         K3_X6_VARIANTS(K3_LAUNCH6)
 #undef K3_LAUNCH6
+        if (launched) p.Cp = nullptr;      // (written by the epilogue)
       }
 #define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3((kBM / wm) * (bn / wn) * 64), lds + lds_pad, st, p); launched = true; }
       K3_GEMM_VARIANTS(K3_LAUNCH)
@@ -1271,6 +1353,10 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
       else hipLaunchKernelGGL(k3_row_softmax_kernel, dim3((unsigned)((b->node_rows[i] + 3) / 4)), dim3(256), 0, st, p.C, (long long)p.ldc,
           (int)b->node_rows[i], f.out_dim, f.row_op,
                          outn ? b->out_scale : (const float *)nullptr, outn ? b->out_offset : (const float *)nullptr);
+    }
+    if (p.Cp && b->precision == 2) {      // a producer that is not the x6 kernel (first layer, element-wise node, row operation): its planes by a pass of their own
+      const long long rows = b->node_rows[i]; const int cols4 = (int)(p.ldc / 4);
+      hipLaunchKernelGGL(k3_split_planes_kernel, dim3((unsigned)((rows * cols4 + 255) / 256)), dim3(256), 0, st, p.C, (long long)p.ldc, rows, cols4, p.Cp, p.cp_stride);
     }
     K3_HIP_CHECK(hipGetLastError());
   }

@@ -50,7 +50,8 @@ class NnetBatch:
             pass
 
     def set_precision(self, mode):
-        """0 = the FP32 matrix core with the reference's summation order (default, the parity path); 1 = split-bf16 (exploratory: six bf16 matrix-core products per product)"""
+        """0 = the FP32 matrix core with the reference's summation order (default, the parity path); 1 = split-bf16 (exploratory: six bf16 matrix-core products per product, operands split by the loader); 2 = the same with the
+        activations' three bf16 planes written by the producing epilogue (bit-identical to 1)"""
         _l.check(self._L.k3_nnet_batch_set_precision(self._h, int(mode)))
     def forward(self, feats, out=None, ivectors=None):
         """feats: float32 [sum T_u, >= input_dim] on the GPU -> float32 [total_out_rows, output_dim]; ivectors (models with an i-vector input):

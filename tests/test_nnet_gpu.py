@@ -230,8 +230,12 @@ def test_split_bf16_products_are_as_accurate_as_the_fp32_matrix_core(tmp_path):
     net = nnet3.Nnet(mp); lens = [333, 200, 97]
     utts = [(rng.standard_normal((T, 40)) * 1.2 + 16.5).astype(np.float32) for T in lens]
     nb = nnet3.NnetBatch(net, lens, 3); x = torch.from_numpy(np.concatenate(utts)).to(dev)
-    y32 = nb.forward(x).clone(); nb.set_precision(1); y6 = nb.forward(x).clone(); nb.set_precision(0); y32b = nb.forward(x).clone(); torch.cuda.synchronize()
+    y32 = nb.forward(x).clone(); nb.set_precision(1); y6 = nb.forward(x).clone()
+    # mode 2: the same six products from operand planes written by the PRODUCING epilogue (the loader only loads): the split is exact either way, so bit for bit mode 1's output
+    nb.set_precision(2); y6p = nb.forward(x).clone(); y6p2 = nb.forward(x).clone()
+    nb.set_precision(0); y32b = nb.forward(x).clone(); torch.cuda.synchronize()
     assert torch.equal(y32, y32b)                      # switching back restores the parity path bit for bit
+    assert torch.equal(y6p, y6) and torch.equal(y6p2, y6)
     onet = no.read_nnet(mp); e32 = e6 = 0.0
     for u, f in enumerate(utts):
         t = no.compute(onet, f, 3, dtype=np.float64); sl = slice(nb.out_offsets[u], nb.out_offsets[u + 1])

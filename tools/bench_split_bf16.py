@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """EXPLORATORY: the TDNN-F forward of the benchmark model with its affine products on the bf16 matrix core, operands split three ways
-(k3_nnet_batch_set_precision(batch, 1): six bf16 MFMA products per product), next to the FP32 matrix-core forward: time of a forward at the bench size, and the
+(k3_nnet_batch_set_precision(batch, 1): six bf16 MFMA products per product, operands split by the loader; (batch, 2): the activations' planes written by the producing
+epilogue, the loader only loads), next to the FP32 matrix-core forward: time of a forward at the bench size, and the
 distance of both to the float64 forward of the same network (oracle/nnet3_oracle.py, the checker) on a few utterances.
   python tools/bench_split_bf16.py [utts=512] [truth_utts=8]"""
 import os, sys, time, json, tempfile, numpy as np, torch
@@ -37,8 +38,10 @@ def timed(mode):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
     for _ in range(5): nbt.forward(xt, out=out)
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / 5
-t32 = timed(0); t6 = timed(1); t32b = timed(0)
-print(json.dumps({"utts": U, "frames_per_utt": int(T), "forward_ms_fp32_mfma": t32, "forward_ms_fp32_mfma_again": t32b, "forward_ms_split_bf16": t6, "speedup": t32 / t6,
+t32 = timed(0); t6 = timed(1); t6p = timed(2); t32b = timed(0)
+nb.set_precision(2); y6p = nb.forward(x).clone(); torch.cuda.synchronize(); nb.set_precision(0)
+print(json.dumps({"utts": U, "frames_per_utt": int(T), "forward_ms_fp32_mfma": t32, "forward_ms_fp32_mfma_again": t32b, "forward_ms_split_bf16": t6, "speedup": t32 / t6, "forward_ms_split_bf16_producer_planes": t6p, "speedup_producer_planes": t32 / t6p, "tflops_fp32_equiv_producer_planes": nbt.flops / (t6p * 1e-3) / 1e12,
+                  "producer_planes_output_equals_loader_split_bitwise": bool(torch.equal(y6p, y6)),
                   "tflops_fp32_equiv_split_bf16": nbt.flops / (t6 * 1e-3) / 1e12, "tflops_fp32_mfma": nbt.flops / (t32 * 1e-3) / 1e12,
                   "truth_utts": TU, "fp32_vs_f64_max_abs": float(max(e[0] for e in e32)), "fp32_vs_f64_mean_abs": float(np.mean([e[1] for e in e32])),
                   "split_bf16_vs_f64_max_abs": float(max(e[0] for e in e6)), "split_bf16_vs_f64_mean_abs": float(np.mean([e[1] for e in e6])), "split_bf16_vs_fp32_max_abs": float(max(d))}))

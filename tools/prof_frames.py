@@ -20,7 +20,9 @@ kt = dec.KernelTimes(); info = dec.LatticeInfo(check=False)
 nt, cyc = [], []
 for u in range(U):
     st = dec.FrameStats(u); nt.append(st["ntoks"]); cyc.append(st["adaptive_beam"])
-nt = np.concatenate(nt).astype(np.int64); cyc = np.concatenate(cyc).astype(np.float64); fast = cyc > 0; cyc = np.abs(cyc)
+nt = np.concatenate(nt).astype(np.int64); cyc = np.concatenate(cyc).astype(np.float64)
+cyc[~np.isfinite(cyc)] = 0.0      # (frame 0 is made by the template kernel: its slot holds the adaptive beam, +inf, not a cycle count)
+fast = cyc > 0; cyc = np.abs(cyc)
 edges = [0, 256, 512, 768, 1024, 1280, 1536, 1792, 2048, 2560, 3072, 4096, 6144, 8192, 16384, 65536]
 tot = cyc.sum(); rows = []
 print("token passing ms %.2f | frames %d | cycles per lane %.1f M | tokens/frame mean %.0f median %.0f" % (kt[0], nt.size, tot / U / 1e6, nt.mean(), np.median(nt)))
