@@ -734,15 +734,7 @@ def main():
         return dt, acc / steps, lat_sizes, det_sizes
 
     mode0 = "literal" if decs else None
-    if decs: [d_.FramePathCounts() for n_, d_ in decs.items() if n_.startswith("literal")]      # (reset)
-    dt, acc, lat_sizes, det_sizes = run(mode0, args.steps, args.warmup)
-    paths = decs["literal"].FramePathCounts() if decs else None
-    if decs and "literal_b" in decs:      # (two alternating decoder objects: their counts together)
-        pb = decs["literal_b"].FramePathCounts()
-        for k_ in ("lds_path", "given_up", "general_path", "cycles_lds_path", "cycles_general_path"): paths[k_] += pb[k_]
-        for k_, v_ in pb["give_up_reasons"].items(): paths["give_up_reasons"][k_] = paths["give_up_reasons"].get(k_, 0) + v_
-    audio_s = tot_samp / 16000.0 * world * args.steps
-    two = run("two_pass", args.steps, args.warmup) if "two_pass" in decs else None
+    # (run BEFORE the measured steps: the decoders' statistics and the last lattices the line reports are then the FP32 path's)
     # VERDICT r5 item 2, for the record only (`value` and `dtype` stay the FP32 matrix core's): the same pipelined steps with the TDNN-F products as six bf16 matrix-core products over
     # exactly split operands, the activations' planes written by the producing epilogue (k3_nnet_batch_set_precision(.., 2)); forwards of both split forms back to back
     sb = None
@@ -766,6 +758,15 @@ def main():
             del ll_ref
         finally:
             nb.set_precision(0)
+    if decs: [d_.FramePathCounts() for n_, d_ in decs.items() if n_.startswith("literal")]      # (reset)
+    dt, acc, lat_sizes, det_sizes = run(mode0, args.steps, args.warmup)
+    paths = decs["literal"].FramePathCounts() if decs else None
+    if decs and "literal_b" in decs:      # (two alternating decoder objects: their counts together)
+        pb = decs["literal_b"].FramePathCounts()
+        for k_ in ("lds_path", "given_up", "general_path", "cycles_lds_path", "cycles_general_path"): paths[k_] += pb[k_]
+        for k_, v_ in pb["give_up_reasons"].items(): paths["give_up_reasons"][k_] = paths["give_up_reasons"].get(k_, 0) + v_
+    audio_s = tot_samp / 16000.0 * world * args.steps
+    two = run("two_pass", args.steps, args.warmup) if "two_pass" in decs else None
     # Stage and kernel durations (stage_ms, roofline, roofline_gemm) come from a short SERIAL pass of the same objects: in the pipelined steps a kernel shares
     # the GPU with the other
     # batch's kernels and its event-to-event time is not its own duration (token passing 86 -> 105 ms, fbank 1 -> 64 ms).  `value` / `ms_per_step` are the
@@ -921,7 +922,8 @@ def main():
                 line["split_bf16"] = dict(sb, note="NOT the headline (dtype stays f32): the pipelined steps with every tile-aligned TDNN-F product as six v_mfma_f32_32x32x16_bf16 "
                     "over exactly three-way split operands, the activations' three bf16 planes written by the producing epilogue (6 B per element next to the fp32 copy) so that the "
                     "loader only loads; as accurate as the FP32 matrix core against the float64 forward (tests/test_nnet_gpu.py), rounds differently from the reference.  Slower than "
-                    "the FP32 matrix core here: the planes make the K = 192 layers' output traffic 10 B per element instead of 4 (DESIGN.md 4.2, Appendix A.2)")
+                    "the FP32 matrix core here, and slower than splitting in the loader: both layer kinds lose the same 2.1 x, i.e. on the operand side -- 6 B per input element in "
+                    "64-byte row pieces per plane instead of 4 B in 128-byte pieces (DESIGN.md Appendix A.2)")
         else:
             line["roofline"] = dict(line["roofline_gemm"], traffic=None)
         # the LF-MMI objective + derivatives of a training-sized minibatch, for the record (not part of `value`)
