@@ -72,8 +72,39 @@ int main(int argc, char *argv[]) {
     std::vector<std::thread> th; for (int32 k = 0; k < NT; k++) th.emplace_back(worker, k);
     for (auto &t : th) t.join();
     if (bad.load()) { for (auto &m : msg) if (!m.empty()) std::cerr << "two-threads MISMATCH: " << m << "\n"; return 1; }
+    // ---- the index cache under churn: every thread keeps making NEW index arrays -- freed and reallocated, so host addresses come back with other content (the
+    // cache must replace the copy without pulling it from under another thread's queued kernel), 8 MB each and more of them than the cache's cap (least-recently-used copies are
+    // retired while other threads hold theirs) -- and checks every CopyRows against the host.
+    {
+      const int32 R = 1 << 21, SRC = 4099, ROUNDS = 24;      // 2 M row indexes per array (8 MB), 24 arrays per thread: 4 threads x 192 MB > the 256 MB cap
+      Matrix<BaseFloat> src_h(SRC, 2); for (int32 r = 0; r < SRC; r++) { src_h(r, 0) = (BaseFloat)r; src_h(r, 1) = (BaseFloat)(-r); }
+      CuMatrix<BaseFloat> src(src_h);
+      std::atomic<int> bad2(0); std::vector<std::string> msg2(NT);
+      auto churn = [&](int32 k) {
+        try {
+          uint64_t x = 0xD1B54A32D192ED03ull * (uint64_t)(k + 7);
+          for (int32 it = 0; it < ROUNDS && bad2.load() == 0; it++) {
+            std::vector<int32> idx(R);
+            for (int32 i = 0; i < R; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; idx[i] = (x >> 40) % 17 == 0 ? -1 : (int32)((x >> 20) % SRC); }
+            CuArray<int32> cu_idx(idx);
+            CuMatrix<BaseFloat> dst(R, 2, kUndefined); dst.CopyRows(src, cu_idx);
+            Matrix<BaseFloat> got(dst);
+            for (int32 i = 0; i < R; i += 997) {
+              const BaseFloat w0 = idx[i] < 0 ? 0.0f : (BaseFloat)idx[i], w1 = idx[i] < 0 ? 0.0f : (BaseFloat)(-idx[i]);
+              if (got(i, 0) != w0 || got(i, 1) != w1) {
+                std::ostringstream os; os << "thread " << k << " array " << it << " row " << i << ": CopyRows gave (" << got(i, 0) << ", " << got(i, 1) << ") for index " << idx[i];
+                msg2[k] = os.str(); bad2.fetch_add(1); return;
+              }
+            }
+          }
+        } catch (const std::exception &e) { msg2[k] = std::string("thread ") + std::to_string(k) + ": " + e.what(); bad2.fetch_add(1); }
+      };
+      std::vector<std::thread> th2; for (int32 k = 0; k < NT; k++) th2.emplace_back(churn, k);
+      for (auto &t : th2) t.join();
+      if (bad2.load()) { for (auto &m : msg2) if (!m.empty()) std::cerr << "two-threads INDEX CACHE MISMATCH: " << m << "\n"; return 1; }
+    }
     std::cout << "two-threads ok: " << NT << " threads x " << IT << " iterations of forward + backward (" << B << " sequences x " << T << " output frames, " << want_grad[0].Dim()
-              << " parameters) reproduce the single-threaded outputs and gradients bit for bit\n";
+              << " parameters) reproduce the single-threaded outputs and gradients bit for bit; index cache churn ok\n";
     return 0;
   } catch (const std::exception &e) { std::cerr << e.what(); return -1; }
 }

@@ -1,4 +1,1 @@
-for rep in 1 2 3; do
-for v in base oz o2; do
-echo -n "$v "; K3HIP_LIB=build/libk3hip_$v.so K3_PROF_PATHS=1 python tools/prof_literal.py 512 2>&1 | grep "^literal" | sed 's/status.*//'
-done; done
+python -m pytest tests/test_adapter_gpu.py -x -q -m gpu 2>&1 | tail -5 | cut -c1-600
