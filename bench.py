@@ -374,6 +374,7 @@ def main():
                          "torch.distributed and only mark the line (\"rccl_abi_failed\": true).  Default (strict): mark the line, print it, and exit with status 3")
     ap.add_argument("--decoder-stream-priority", type=int, default=0,
                     help="queue priority of the two decoder streams (0 = default, -1 = high): whose workgroups take a slot that frees up, a waiting lane's or the next front end's")
+    ap.add_argument("--fe-ahead", type=int, default=1, help="pipelined steps: how many batches the front end (H2D + fbank + TDNN-F) runs ahead of the decoder (1 or 2; 2 = three log-likelihood buffers)")
     ap.add_argument("--no-split-bf16", action="store_true", help="skip the split-bf16 record (value_split_bf16: the same steps with the TDNN-F products on the bf16 matrix core)")
     ap.add_argument("--ragged", action="store_true",
         help="SURVEY 8d's second set instead of the equal-length one: --utts utterances of length U(2 s, 20 s), seed 1235 (same model, graph and decoder); prints "
@@ -561,9 +562,13 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     pipelined = not args.no_pipeline      # the next batch's front end (H2D + fbank + TDNN-F) on a second stream, queued behind the present batch's decoder
     front = torch.cuda.Stream(device=dev)
-    fev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(2)]
-    dec_done = [torch.cuda.Event() for _ in range(2)]
-    ll2 = [loglikes, torch.empty_like(loglikes) if pipelined else loglikes]
+    # log-likelihood buffers: batch j's front end writes buffer j % NB; NB = 2 (the front end runs ONE batch ahead of the decoder) or 3 (--fe-ahead 2: two batches ahead, so that
+    # decoder lanes and GEMM workgroups are both queued at every moment of a step)
+    NB = 1 + max(1, min(2, args.fe_ahead)) if pipelined else 1
+    fev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(max(2, NB))]
+    dec_done = [torch.cuda.Event() for _ in range(max(2, NB))]
+    ll2 = [loglikes] + [torch.empty_like(loglikes) for _ in range(NB - 1)] if pipelined else [loglikes, loglikes]
+    NBI = NB if pipelined else 2
     def run(mode, steps, warmup, pipelined=pipelined, vary=True, keep=None):
         """W untimed + K timed steps of the whole path in one decoder mode.
         Returns (wall seconds of the K steps, per-stage ms, last lattice sizes, determinized sizes)."""
@@ -576,32 +581,32 @@ def main():
         last = [None]
         src = lambda k: pcm_host[shift_of(k) if vary else 0:][:tot_samp]      # batch k's audio
         for e in dec_done: e.record()
-        reader = [None, None]      # the decoder object that read log-likelihood buffer 0 / 1 last
+        reader = [None] * max(2, NB)      # the decoder object that read log-likelihood buffer b last
         def front_end(k):      # batch k's H2D + fbank + TDNN-F on the front stream, into log-likelihood buffer k & 1 (last read by the decoder two batches ago)
             with torch.cuda.stream(front):
                 # the buffer's last reader is the token-passing launch of batch k - 2, not the pruning / output kernels behind it: those cannot run beside the
                 # resident launch of batch k - 1
                 # (LDS) and finish ~50 ms into it, which is when this front end used to start (profiles/r04c_pipeline_overlap.txt)
-                if reader[k & 1] is not None and not args.wait_whole_decoder: reader[k & 1].StreamWaitTokenPassing(front)
-                else: front.wait_event(dec_done[k & 1])
-                fev[k & 1][0].record()
+                if reader[k % NBI] is not None and not args.wait_whole_decoder: reader[k % NBI].StreamWaitTokenPassing(front)
+                else: front.wait_event(dec_done[k % NBI])
+                fev[k % NBI][0].record()
                 # (the waveform copy stays on this stream, in front of the features: issued on a copy stream of its own into a second device buffer, so that it runs under
                 # the previous batch's decoder, the step got SLOWER -- 85 - 87 ms against 79 --: the DMA traffic beside the token-passing kernel costs that kernel more than
                 # the 2.9 ms the copy takes; measured in rounds 2 and 6)
                 pcm_dev.copy_(src(k), non_blocking=True)
-                fev[k & 1][1].record()
+                fev[k % NBI][1].record()
                 sf.ComputeFeatures(pcm_dev, wo, fo, total_frames, out=feats)
-                fev[k & 1][2].record()
-                nb.forward(feats, out=ll2[k & 1])
-                fev[k & 1][3].record()
+                fev[k % NBI][2].record()
+                nb.forward(feats, out=ll2[k % NBI])
+                fev[k % NBI][3].record()
         def step_pipelined(timed):
             k = nstep[0]
             nstep[0] += 1
             if k == 0: front_end(0)
-            torch.cuda.current_stream().wait_event(fev[k & 1][3])
+            torch.cuda.current_stream().wait_event(fev[k % NBI][3])
             if timed: ev[3].record()
-            dec.DecodeBatch(ll2[k & 1], nb.out_offsets)      # (one decoder object: its latest token-passing launch is batch k's, not the buffer's last reader)
-            dec_done[k & 1].record()
+            dec.DecodeBatch(ll2[k % NBI], nb.out_offsets)      # (one decoder object: its latest token-passing launch is batch k's, not the buffer's last reader)
+            dec_done[k % NBI].record()
             front_end(k + 1)       # queued behind the decoder: its workgroups take the CUs the decoder's lanes leave as they finish
             if timed: ev[4].record()
             while len(pending) >= 2:
@@ -637,15 +642,16 @@ def main():
         def step_two(timed):
             k = nstep[0]
             nstep[0] += 1
-            if k == 0: front_end(0)
+            if k == 0:
+                for j in range(NB - 1): front_end(j)
             with torch.cuda.stream(dstr[k & 1]):
-                dstr[k & 1].wait_event(fev[k & 1][3])
+                dstr[k & 1].wait_event(fev[k % NB][3])
                 if timed: ev[3].record()
-                pair[k & 1].DecodeBatch(ll2[k & 1], nb.out_offsets)
-                dec_done[k & 1].record()
-                reader[k & 1] = pair[k & 1]
+                pair[k & 1].DecodeBatch(ll2[k % NB], nb.out_offsets)
+                dec_done[k % NB].record()
+                reader[k % NB] = pair[k & 1]
                 if timed: ev[4].record()
-            front_end(k + 1)
+            front_end(k + NB - 1)      # (buffer (k + NB - 1) % NB: last read by batch k - 1's token passing)
             if k > first_timed[0]: fetch(k - 1)
             if timed: ev[5].record()
         def step(timed):
@@ -687,13 +693,13 @@ def main():
             step(True)
             if not two: torch.cuda.current_stream().synchronize()
             if two:
-                fe = fev[(nstep[0] - 1) & 1]
+                fe = fev[(nstep[0] - 1) % NBI]
                 fe[3].synchronize()
                 acc[0] += fe[0].elapsed_time(fe[1])
                 acc[1] += fe[1].elapsed_time(fe[2])
                 acc[2] += fe[2].elapsed_time(fe[3])
             elif pipelined and dec is not None:
-                fe = fev[(nstep[0] - 1) & 1]
+                fe = fev[(nstep[0] - 1) % NBI]
                 acc[0] += fe[0].elapsed_time(fe[1])
                 acc[1] += fe[1].elapsed_time(fe[2])
                 acc[2] += fe[2].elapsed_time(fe[3])

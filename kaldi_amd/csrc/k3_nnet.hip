@@ -1340,7 +1340,11 @@ static int forward_impl(k3_nnet_batch *b, const float *d_feats, int64_t ld_feats
 #undef K3_LAUNCH6
         if (launched) p.Cp = nullptr;      // (written by the epilogue)
       }
-#define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3((kBM / wm) * (bn / wn) * 64), lds + lds_pad, st, p); launched = true; }
+      // K3_NNET_LDS_FLOOR=<bytes> (environment, experiment of round 6): every GEMM workgroup asks for at least this much LDS.  With 82432 two GEMM workgroups no longer fit on a CU
+      // but one fits beside a token-passing lane (81216 B) and two lanes still fit: while GEMM work is queued next to a decoder launch every CU runs one of each.
+      static const size_t lds_floor = getenv("K3_NNET_LDS_FLOOR") ? (size_t)atoll(getenv("K3_NNET_LDS_FLOOR")) : 0;
+      const size_t lds_launch = std::max(lds + lds_pad, lds_floor);
+#define K3_LAUNCH(bn, wm, wn, al_, ep) if (!launched && bn96 == (bn == 96) && al == al_ && epi == ep) { hipLaunchKernelGGL((k3_tdnn_gemm_kernel<bn, wm, wn, al_, ep>), dim3(blocks), dim3((kBM / wm) * (bn / wn) * 64), lds_launch, st, p); launched = true; }
       K3_GEMM_VARIANTS(K3_LAUNCH)
       if (!launched) { epi = has_map ? kEpiAnyMap : kEpiAny; K3_GEMM_VARIANTS(K3_LAUNCH) }      // no fixed-program instantiation for this shape: run-time dispatch
 #undef K3_LAUNCH
