@@ -849,7 +849,7 @@ extern "C" int k3_lit_forward_prepare();
 extern "C" int k3_lit_fast_tokens();
 extern "C" int k3_lit_capture_launch(const void *params, size_t params_bytes, int nworkgroups, hipStream_t stream);      // k3_decoder_lit_cap.hip
 extern "C" int k3_lit_has_queue();      // 0: this build's kernel decodes one lane per workgroup only (resident_lanes is then ignored)
-extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nworkgroups, int exclusive, hipStream_t stream);
+extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nworkgroups, int flags, hipStream_t stream);      // flags: 1 exclusive LDS, 2 no template kernels
 
 // ------------------------------------------------------------------------------------------------ graph ----
 struct k3_fst {
@@ -1005,6 +1005,7 @@ struct k3_decoder {
   // literal_order launch shape: > 0 = that many workgroups take the call's lanes from a work-queue (longest first) instead of one workgroup per lane; exclusive: a workgroup
   // asks for more than half of a CU's LDS, so that it shares its CU with other kernels' workgroups (the next batch's front end) instead of a second lane
   int lit_resident = 0; bool lit_exclusive = false;
+  bool row_skip_dirty = false;      // DecParams::row_skip may hold a 1 from an earlier call (launch_literal)
   bool capture_launch = false;      // (k3_decoder_create only: the next token-passing launch is the capture build's, see build_frame0_template)
 
   ~k3_decoder() {
@@ -1397,6 +1398,22 @@ extern "C" int k3_decoder_init_channels(k3_decoder *d, const int32_t *channels, 
 // launch decodes entry b: a CU's two workgroups (b, b + 256 of a 512-lane launch) then hold a long and a short utterance, and a batch of unequal lengths no longer pairs two long
 // ones on a CU while another CU idles (the reference reschedules lanes per chunk for the same reason: cuda-online-pipeline-dynamic-batcher.cc).  With a work-queue build
 // (k3_lit_has_queue) and resident_lanes < lanes, fewer workgroups take the entries through the head counter.  Returns the number of workgroups to launch.
+// The literal_order launch of a call (slot.h holds the call's row offsets and pending-InitDecoding flags).  The two template kernels in front of the token-passing kernel have
+// something to do only for a lane that starts in this call or that holds just its InitDecoding tokens and gets its first frame now; in every other call -- all but one of the ~20
+// chunk calls of a streamed utterance -- they are not launched: each is one more launch that has to find 79 KB of LDS per workgroup on CUs other streams are using, and the two of
+// them cost the online program 8 - 10 % (24.2 -> 26.2 k x RT at 51-frame chunks).  row_skip, which the first-frame kernel resets per call, is then cleared by a fill if it may hold
+// a 1 from an earlier call.
+static int launch_literal(k3_decoder *d, const k3_decoder::ArgSlot &slot, int lit_grid, hipStream_t st) {
+  DecParams &p = d->p; const int U = d->last_utts;
+  const long long *ro = reinterpret_cast<const long long *>(slot.h); const int *fresh = reinterpret_cast<const int *>(slot.h + d->arg_off_fresh);
+  bool need = false;
+  for (int u = 0; u < U && !need; u++) need = fresh[u] != 0 || (ro[u + 1] > ro[u] && d->last_frames[u] == 0);
+  if (need) d->row_skip_dirty = true;
+  else if (d->row_skip_dirty && p.row_skip) { K3_HIP_CHECK(hipMemsetAsync(p.row_skip, 0, sizeof(int) * (size_t)d->nlanes, st)); d->row_skip_dirty = false; }
+  k3_lit_forward_launch(&p, sizeof(p), lit_grid, (d->lit_exclusive ? 1 : 0) | (need ? 0 : 2), st);
+  return K3_OK;
+}
+
 static int fill_lane_queue(k3_decoder *d, k3_decoder::ArgSlot &slot, int U) {
   DecParams &p = d->p;
   p.q_head = nullptr; p.q_lanes = nullptr; p.q_n = 0;
@@ -1442,7 +1459,7 @@ extern "C" int k3_decoder_advance_decoding(k3_decoder *d, int32_t num_utts, cons
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   if (p.literal && d->capture_launch) { K3_REQUIRE(k3_lit_capture_launch(&p, sizeof(p), lit_grid, st) == 0, "k3_decoder: the capture launch failed"); }
-  else if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
+  else if (p.literal) { const int rc_ = launch_literal(d, slot, lit_grid, st); if (rc_) return rc_; }
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(num_utts), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
@@ -1483,7 +1500,7 @@ extern "C" int k3_decoder_advance_decoding_lanes(k3_decoder *d, int32_t n, const
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   if (p.literal && d->capture_launch) { K3_REQUIRE(k3_lit_capture_launch(&p, sizeof(p), lit_grid, st) == 0, "k3_decoder: the capture launch failed"); }
-  else if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
+  else if (p.literal) { const int rc_ = launch_literal(d, slot, lit_grid, st); if (rc_) return rc_; }
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));
@@ -1522,7 +1539,7 @@ extern "C" int k3_decoder_advance_decoding_strided(k3_decoder *d, int32_t num_ut
   const size_t lds = p.use_lds_row ? align_up((size_t)d->num_pdfs * sizeof(float), 16) : 16;
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[0], st));
   if (p.literal && d->capture_launch) { K3_REQUIRE(k3_lit_capture_launch(&p, sizeof(p), lit_grid, st) == 0, "k3_decoder: the capture launch failed"); }
-  else if (p.literal) k3_lit_forward_launch(&p, sizeof(p), lit_grid, d->lit_exclusive ? 1 : 0, st);
+  else if (p.literal) { const int rc_ = launch_literal(d, slot, lit_grid, st); if (rc_) return rc_; }
   else hipLaunchKernelGGL(k3_decode_forward_kernel, dim3(U), dim3(kBlock), lds, st, p);
   K3_HIP_CHECK(hipGetLastError());
   if (d->profiling) K3_HIP_CHECK(hipEventRecord(d->ev[1], st));

@@ -41,12 +41,13 @@ extern "C" int k3_lit_forward_prepare() {
   if (hipFuncSetAttribute((const void *)k3_decode_frame0_from_template_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLitArena) != hipSuccess) return -1;
   return hipFuncSetAttribute((const void *)k3_decode_forward_literal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLitArena > kLitExclusiveLds ? kLitArena : kLitExclusiveLds)) == hipSuccess ? 0 : -1;
 }
-extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nworkgroups, int exclusive, hipStream_t stream) {
+extern "C" void k3_lit_forward_launch(const void *params, size_t params_bytes, int nworkgroups, int flags, hipStream_t stream) {      // flags: 1 = exclusive LDS, 2 = no lane of this call can use the template kernels
+  const int exclusive = flags & 1; const bool templates = (flags & 2) == 0;
   DecParams p; static_assert(sizeof(DecParams) % 8 == 0, "DecParams is copied between translation units");
   if (params_bytes != sizeof(DecParams)) { fprintf(stderr, "k3_lit_forward_launch: DecParams size mismatch\n"); abort(); }
   memcpy(&p, params, sizeof(p));
   const unsigned nl_ = p.q_lanes ? (unsigned)p.q_n : (unsigned)nworkgroups;
-  if (p.tpl_n > 0) hipLaunchKernelGGL(k3_decode_init_from_template_kernel, dim3(nl_), dim3(256), 0, stream, p, const_cast<int *>(p.fresh));
-  if (p.tpl_n > 0 && p.t0_n > 0) hipLaunchKernelGGL(k3_decode_frame0_from_template_kernel, dim3(nl_), dim3(kBlock), kLitArena, stream, p);
+  if (templates && p.tpl_n > 0) hipLaunchKernelGGL(k3_decode_init_from_template_kernel, dim3(nl_), dim3(256), 0, stream, p, const_cast<int *>(p.fresh));
+  if (templates && p.tpl_n > 0 && p.t0_n > 0) hipLaunchKernelGGL(k3_decode_frame0_from_template_kernel, dim3(nl_), dim3(kBlock), kLitArena, stream, p);
   hipLaunchKernelGGL(k3_decode_forward_literal_kernel, dim3(nworkgroups), dim3(kBlock), exclusive && kLitExclusiveLds > kLitArena ? kLitExclusiveLds : kLitArena, stream, p);
 }
