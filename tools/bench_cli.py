@@ -52,7 +52,7 @@ if os.environ.get("K3CLI_ONLINE"):      # the streaming program on the same file
         if r.returncode != 0: print(r.stderr[-1500:])
     if os.environ.get("K3CLI_ONLINE") == "profile":      # kernel trace + stats of the 51-frame run -> gpurun_out/prof_online
         out = os.path.join(ROOT, "gpurun_out", "prof_online"); os.makedirs(out, exist_ok=True)
-        args[9] = "--frames-per-chunk=51"; args[10] = "--iterations=1"
+        args[9] = "--frames-per-chunk=51"; args[10] = "--iterations=%s" % os.environ.get("K3CLI_PROFILE_ITERS", "1")
         r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "-o", "t", "--"] + [exe_o] + args + [f"{td}/final.mdl", f"{td}/HCLG.fst", f"scp:{td}/wav.scp", f"ark:{td}/online2.ark"],
                            capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
         print("profiled online run rc=%d | %s" % (r.returncode, " | ".join(l.split(") ", 1)[-1] for l in r.stderr.splitlines() if "RealTimeX" in l)), flush=True)
